@@ -1,0 +1,194 @@
+/*
+ * gigl_hip.h — C ABI of libgigl_hip.so: the MI355X (gfx950) k-hop subgraph sampler +
+ * GNN aggregation hot path of GiGL.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own for
+ * this path (it is Scala-on-Spark + PyTorch-Geometric); the closest operator interface is the
+ * Scala trait `KHopSamplerService` and the Python collate / conv calls.  Each entry point
+ * below names the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *  - every function returns int32 status: 0 = OK, <0 = error (GIGL_E_*); the message for the
+ *    last error on a ctx is `gigl_last_error(ctx)` (owned by the ctx, valid until next call).
+ *  - a ctx is bound to ONE device and ONE HIP stream and is single-threaded — this mirrors
+ *    "one sampler service per Spark partition" (setup()/teardown() per partition:
+ *    scala_spark35/subgraph_sampler/src/main/scala/libs/task/graphdb/
+ *    GraphDBNodeAnchorBasedLinkPredictionTask.scala:62-78).  Different ctxs are independent.
+ *  - pointers tagged DEVICE are HBM addresses on the ctx's device; HOST are host addresses.
+ *    Per-batch calls take DEVICE pointers only and never synchronise with the host, so a whole
+ *    step can be captured into a hipGraph.
+ *  - node ids are uint32 (proto/snapchat/research/gbml/graph_schema.proto:7,20-21), edge
+ *    offsets int64, batch-local ids int32.
+ *  - GIGL_INVALID (0xFFFFFFFF) marks an empty slot in the tree layout.
+ */
+#ifndef GIGL_HIP_H
+#define GIGL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GIGL_OK 0
+#define GIGL_E_INVALID_ARG (-1)
+#define GIGL_E_HIP (-2)
+#define GIGL_E_OOM (-3)
+#define GIGL_E_UNSUPPORTED (-4)
+#define GIGL_E_NO_DEVICE (-5)
+
+#define GIGL_INVALID 0xFFFFFFFFu
+#define GIGL_MAX_HOPS 4
+#define GIGL_MAX_FANOUT 64 /* wave-resident top-f selection: one candidate per lane */
+
+#define GIGL_LOC_HOST 0
+#define GIGL_LOC_DEVICE 1
+
+#define GIGL_DTYPE_F32 0
+#define GIGL_DTYPE_F16 1
+
+/* sampling modes */
+#define GIGL_MODE_SPARK_HASH 0 /* parity: xxhash64-keyed permutation, SamplingStrategy.scala:16-82 */
+#define GIGL_MODE_FAST 1       /* NOT parity: counter-based RNG positions; labelled as such everywhere */
+
+typedef struct gigl_ctx gigl_ctx;
+typedef struct gigl_graph gigl_graph;
+typedef struct gigl_feat gigl_feat;
+
+/* ---- lifecycle: KHopSamplerService.setup()/teardown()
+ *      (scala_spark35/common/src/main/scala/graphdb/KHopSamplerService.scala:10-33) ---- */
+int32_t gigl_version(void);
+int32_t gigl_ctx_create(int32_t device, gigl_ctx** out);
+int32_t gigl_ctx_destroy(gigl_ctx* ctx);
+const char* gigl_last_error(gigl_ctx* ctx);
+/* bind the ctx to a caller-owned hipStream_t (NULL = the ctx's own stream) */
+int32_t gigl_ctx_set_stream(gigl_ctx* ctx, void* hip_stream);
+int32_t gigl_ctx_synchronize(gigl_ctx* ctx);
+/* pre-size the ctx scratch arena (bytes); grows on demand otherwise (grow = hipMalloc, so
+ * warm up once before capturing a hipGraph) */
+int32_t gigl_ctx_reserve(gigl_ctx* ctx, int64_t bytes);
+
+/* ---- graph ingest: replaces loadEdgeDataframeIntoSparkSql + enforceBidirectionalization
+ *      (scala/subgraph_sampler/src/main/scala/libs/task/pureSpark/SGSPureSparkV1Task.scala:120-286)
+ * CSC by destination: rowptr[n+1] (int64), col[e] (uint32 in-neighbour ids), each row sorted
+ * ascending and duplicate-free (== array_sort(collect_list(_src_node)) per _dst_node on a simple
+ * graph, SGSPureSparkV1Task.scala:338-345). `loc` says where rowptr/col live; data is copied. */
+int32_t gigl_graph_load_csc(gigl_ctx* ctx, int64_t n, int64_t e, const int64_t* rowptr,
+                            const uint32_t* col, int32_t loc, gigl_graph** out);
+/* COO edge list (src -> dst).  is_directed == 0 applies the reference's bidirectionalisation:
+ * canonicalise (min,max), drop duplicates, union with the reversed copy (:218-258).  Always
+ * sorts rows ascending and drops duplicate (src,dst) pairs.  Runs on the device. */
+int32_t gigl_graph_build_from_coo(gigl_ctx* ctx, int64_t n, int64_t e, const uint32_t* src,
+                                  const uint32_t* dst, int32_t loc, int32_t is_directed,
+                                  gigl_graph** out);
+int32_t gigl_graph_info(gigl_graph* g, int64_t* n, int64_t* e);
+/* DEVICE pointers to the resident CSC (borrowed; valid until gigl_graph_destroy) */
+int32_t gigl_graph_device_ptrs(gigl_graph* g, const int64_t** rowptr, const uint32_t** col);
+int32_t gigl_graph_destroy(gigl_graph* g);
+
+/* ---- node features: replaces loadNodeDataframeIntoSparkSql (SGSPureSparkV1Task.scala:52-118):
+ * dense row-major [n][d], row index == node id. */
+int32_t gigl_features_load(gigl_ctx* ctx, int64_t n, int32_t d, int32_t dtype, const void* rows,
+                           int32_t loc, gigl_feat** out);
+int32_t gigl_features_device_ptr(gigl_feat* f, const void** rows, int64_t* n, int32_t* d,
+                                 int32_t* dtype);
+int32_t gigl_features_destroy(gigl_feat* f);
+
+/* ---- k-hop rooted sampling: replaces sampleOnehopSrcNodesUniformly / sampleTwohopSrcNodesUniformly
+ *      (SGSPureSparkV1Task.scala:313-388, :390-494), SamplingStrategy.hashBasedUniformPermutation
+ *      (scala/subgraph_sampler/src/main/scala/libs/task/SamplingStrategy.scala:16-82) and, for
+ *      per-hop fanouts, KHopSamplerService.getKHopSubgraphForRootNodes / GraphDBSampler
+ *      (scala_spark35/subgraph_sampler/src/main/scala/libs/sampler/GraphDBSampler.scala:40-148).
+ *
+ * Tree layout.  slots[0] = b*fanouts[0]; slots[k] = slots[k-1]*fanouts[k].
+ *   nbr[k][p*fanouts[k] + j]  = j-th sampled in-neighbour of the node in parent slot p
+ *                               (parent of hop 0 = root p), GIGL_INVALID past cnt.
+ *   cnt[k][p]                 = number of valid entries under parent slot p (0 if the parent slot
+ *                               is itself invalid or has no in-edges).
+ * Within a parent the sampled ids are written in ascending id order: the reference's output is a
+ * set (collect_list order after its joins is undefined), ascending is this library's canonical form.
+ * Parity mode selects, for a parent with sorted in-neighbours A[1..n] and n > f, the f indices i
+ * with the smallest (xxhash64_int32(i + K + seed*(k+1), 42) as signed int64, i), where K is the
+ * int32 wrapping sum of the ids on the path root..parent — K={_dst_node} at hop 1, {_0_hop,_1_hop}
+ * at hop 2; `seed*(k+1)` is samplingSeed*_counter with _counter = 1,2 (SamplingStrategy.scala:14,36).
+ * All pointers DEVICE, caller-allocated. */
+typedef struct gigl_tree {
+  int32_t hops;
+  int32_t b;
+  int32_t fanouts[GIGL_MAX_HOPS];
+  uint32_t* nbr[GIGL_MAX_HOPS]; /* [slots[k]] */
+  int32_t* cnt[GIGL_MAX_HOPS];  /* [k==0 ? b : slots[k-1]] */
+} gigl_tree;
+
+int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, int32_t b,
+                         const int32_t* fanouts, int32_t hops, int32_t sampling_seed,
+                         int32_t mode, gigl_tree* out);
+
+/* positives for node-anchor link prediction: `f` OUT-neighbours of each root, counter = 3
+ * (sampleDstNodesUniformly, NodeAnchorBasedLinkPredictionBaseTask.scala:19-104).  `g_out` is the
+ * CSR-by-source graph loaded through gigl_graph_load_csc with the roles of src/dst swapped. */
+int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* roots, int32_t b,
+                              int32_t f, int32_t sampling_seed, int32_t mode, uint32_t* pos,
+                              int32_t* cnt);
+
+/* ---- batch union graph ("collate"): replaces GraphBuilder.add_graph_data/add_edge dedup
+ *      (python/gigl/src/common/graph_builder/abstract_graph_builder.py:49-150), the collate
+ *      functions (python/gigl/src/training/v1/lib/data_loaders/
+ *      rooted_node_neighborhood_data_loader.py:78-158) and coalesce().
+ * Merges the b rooted trees into ONE deduplicated graph: unique nodes, unique (src,dst) edges.
+ * Local numbering is level-ordered: level 0 = roots, level l = nodes first reached as a source of
+ * an in-edge of a level l-1 node in the UNION graph; within a level: first occurrence in the
+ * canonical stream (roots, then hop-1 slots, then hop-2 slots ...).  So the rows a layer must
+ * compute are always a prefix (layer-wise trimmed schedule, exact for root outputs).
+ * Outputs (DEVICE, caller-allocated, capacities from gigl_union_capacity):
+ *   meta[0]=n_nodes, meta[1]=n_edges, meta[2+l]=cumulative node count through level l
+ *           (meta[2]=#distinct roots), l=0..hops; meta[GIGL_META_AGG_EDGES]… see below
+ *   nodes[n_nodes]    global id of local node i
+ *   rowptr[n_nodes+1] CSR by destination over local ids (int32)
+ *   col[n_edges]      local source ids, ascending within a row
+ *   root_local[b]     local id of roots[i] (duplicates in `roots` map to the same local id) */
+#define GIGL_META_N_NODES 0
+#define GIGL_META_N_EDGES 1
+#define GIGL_META_LEVEL0 2 /* meta[2+l], l = 0..hops */
+#define GIGL_META_LEN 16
+
+typedef struct gigl_union {
+  int32_t* meta;       /* [GIGL_META_LEN] */
+  uint32_t* nodes;     /* [cap_nodes] */
+  int32_t* rowptr;     /* [cap_nodes+1] */
+  int32_t* col;        /* [cap_edges] */
+  int32_t* root_local; /* [b] */
+  int64_t cap_nodes;
+  int64_t cap_edges;
+} gigl_union;
+
+int32_t gigl_union_capacity(int32_t b, const int32_t* fanouts, int32_t hops, int64_t* cap_nodes,
+                            int64_t* cap_edges);
+int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree,
+                         gigl_union* out);
+
+/* ---- message passing over the union graph: replaces PyG SAGEConv / GATConv / GCNConv as used by
+ *      python/gigl/src/common/models/pyg/homogeneous.py:107-153,171-202,300-343,488-546.
+ *
+ * gigl_gather_mean: the segmented gather + mean reduce, fused with feature hydration.
+ *   rows i in [0, n_rows):  out[i][0:d]  = mean_{e in row i} src[ idx(col[e]) ][0:d]   (0 if empty)
+ *                           out[i][d:2d] = src[ idx(i) ][0:d]
+ *   idx(j) = gather_ids ? gather_ids[j] : j   (gather_ids = union.nodes reads the global feature
+ *   table directly: hydrateNodes, SGSPureSparkV1Task.scala:496-547, without materialising x).
+ *   n_rows is read on the device from *n_rows_dev (a union.meta entry); rows_cap bounds the grid.
+ *   out is f32 [rows_cap][2d] — the A operand of the SAGE projection [mean | self]·[W_l ; W_r]^T. */
+int32_t gigl_gather_mean(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
+                         const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* col,
+                         const int32_t* n_rows_dev, int64_t rows_cap, float* out);
+
+/* dense projection  y[i][0:n] = act( a[i][0:k] · w[0:n][0:k]^T + bias )  — fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32, exact f32).  w is row-major [n][k] (torch Linear layout; for SAGE
+ * w = cat(lin_l.weight, lin_r.weight, dim=1)).  act: 0 none, 1 relu.  m read from *m_dev. */
+int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* bias,
+                    const int32_t* m_dev, int64_t m_cap, int32_t k, int32_t n, int32_t act,
+                    float* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIGL_HIP_H */
