@@ -1,0 +1,115 @@
+"""ctypes binding of libgigl_hip.so (C ABI: include/gigl_hip.h).
+
+There is deliberately NO fallback: if the library is missing, cannot be loaded, or there is no GPU,
+every compute entry point raises — a silent CPU path would void the parity claims.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+GIGL_INVALID = 0xFFFFFFFF
+GIGL_MAX_HOPS = 4
+GIGL_MAX_FANOUT = 64
+GIGL_META_LEN = 16
+GIGL_META_N_NODES, GIGL_META_N_EDGES, GIGL_META_LEVEL0 = 0, 1, 2
+LOC_HOST, LOC_DEVICE = 0, 1
+DTYPE_F32, DTYPE_F16 = 0, 1
+MODE_SPARK_HASH, MODE_FAST = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgigl_hip.so")
+
+# every symbol include/gigl_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
+SYMBOLS = [
+    "gigl_version", "gigl_ctx_create", "gigl_ctx_destroy", "gigl_last_error", "gigl_ctx_set_stream",
+    "gigl_ctx_synchronize", "gigl_ctx_reserve", "gigl_memcpy", "gigl_graph_load_csc", "gigl_graph_build_from_coo",
+    "gigl_graph_info", "gigl_graph_device_ptrs", "gigl_graph_destroy", "gigl_features_load",
+    "gigl_features_device_ptr", "gigl_features_destroy", "gigl_sample_khop", "gigl_sample_positives",
+    "gigl_union_capacity", "gigl_union_build", "gigl_gather_mean", "gigl_linear",
+]
+
+
+class GiglTree(C.Structure):
+    _fields_ = [
+        ("hops", C.c_int32),
+        ("b", C.c_int32),
+        ("fanouts", C.c_int32 * GIGL_MAX_HOPS),
+        ("nbr", C.c_void_p * GIGL_MAX_HOPS),
+        ("cnt", C.c_void_p * GIGL_MAX_HOPS),
+    ]
+
+
+class GiglUnion(C.Structure):
+    _fields_ = [
+        ("meta", C.c_void_p),
+        ("nodes", C.c_void_p),
+        ("rowptr", C.c_void_p),
+        ("col", C.c_void_p),
+        ("root_local", C.c_void_p),
+        ("cap_nodes", C.c_int64),
+        ("cap_edges", C.c_int64),
+    ]
+
+
+class GiglError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libgigl_hip error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C gigl_amd/csrc`. gigl_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    P = C.POINTER
+    lib.gigl_version.restype = i32
+    lib.gigl_last_error.restype = C.c_char_p
+    lib.gigl_last_error.argtypes = [vp]
+    sig = {
+        "gigl_ctx_create": [i32, P(vp)],
+        "gigl_ctx_destroy": [vp],
+        "gigl_ctx_set_stream": [vp, vp],
+        "gigl_ctx_synchronize": [vp],
+        "gigl_ctx_reserve": [vp, i64],
+        "gigl_memcpy": [vp, vp, i32, vp, i32, i64],
+        "gigl_graph_load_csc": [vp, i64, i64, vp, vp, i32, P(vp)],
+        "gigl_graph_build_from_coo": [vp, i64, i64, vp, vp, i32, i32, P(vp)],
+        "gigl_graph_info": [vp, P(i64), P(i64)],
+        "gigl_graph_device_ptrs": [vp, P(vp), P(vp)],
+        "gigl_graph_destroy": [vp],
+        "gigl_features_load": [vp, i64, i32, i32, vp, i32, P(vp)],
+        "gigl_features_device_ptr": [vp, P(vp), P(i64), P(i32), P(i32)],
+        "gigl_features_destroy": [vp],
+        "gigl_sample_khop": [vp, vp, vp, i32, P(i32), i32, i32, i32, P(GiglTree)],
+        "gigl_sample_positives": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+        "gigl_union_capacity": [i32, P(i32), i32, P(i64), P(i64)],
+        "gigl_union_build": [vp, vp, P(GiglTree), P(GiglUnion)],
+        "gigl_gather_mean": [vp, vp, i32, i32, vp, vp, vp, vp, i64, vp],
+        "gigl_linear": [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = i32
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, ctx=None) -> None:
+    if rc != 0:
+        msg = ""
+        if ctx:
+            raw = load().gigl_last_error(ctx)
+            msg = raw.decode("utf-8", "replace") if raw else ""
+        raise GiglError(rc, msg or {-5: "no HIP device visible", -1: "invalid argument"}.get(rc, "failed"))

@@ -1,0 +1,62 @@
+// common.h — internal definitions shared by the HIP translation units of libgigl_hip.so.
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts are assumed everywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/gigl_hip.h"
+
+#define GIGL_WAVE 64
+
+struct gigl_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  // scratch arena: one device allocation, bump-allocated per call, grown (hipMalloc) on demand
+  char* arena = nullptr;
+  int64_t arena_bytes = 0;
+  int64_t arena_off = 0;
+};
+
+struct gigl_graph {
+  gigl_ctx* ctx = nullptr;
+  int64_t n = 0, e = 0;
+  int64_t* rowptr = nullptr;  // device [n+1]
+  uint32_t* col = nullptr;    // device [e]
+};
+
+struct gigl_feat {
+  gigl_ctx* ctx = nullptr;
+  int64_t n = 0;
+  int32_t d = 0;
+  int32_t dtype = 0;
+  void* rows = nullptr;  // device [n][d]
+};
+
+int32_t gigl_fail(gigl_ctx* ctx, int32_t code, const char* fmt, ...);
+
+#define GIGL_HIP_CHECK(ctx, expr)                                                          \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess)                                                                  \
+      return gigl_fail((ctx), _e == hipErrorOutOfMemory ? GIGL_E_OOM : GIGL_E_HIP,         \
+                       "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                       __LINE__);                                                          \
+  } while (0)
+
+#define GIGL_REQUIRE(ctx, cond, ...)                                  \
+  do {                                                                \
+    if (!(cond)) return gigl_fail((ctx), GIGL_E_INVALID_ARG, __VA_ARGS__); \
+  } while (0)
+
+// arena: reset at the start of every public per-batch call, then bump-allocate (256 B aligned)
+int32_t gigl_arena_reset(gigl_ctx* ctx, int64_t need_bytes);
+void* gigl_arena_alloc(gigl_ctx* ctx, int64_t bytes);
+
+static inline int64_t gigl_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

@@ -1,0 +1,169 @@
+// graph_build.hip — edge-list ingest: COO (src -> dst) to the resident CSC-by-destination.
+//
+// Replaces loadEdgeDataframeIntoSparkSql + enforceBidirectionalization
+//   scala/subgraph_sampler/src/main/scala/libs/task/pureSpark/SGSPureSparkV1Task.scala:120-286 (:218-258)
+// and the per-destination `array_sort(collect_list(_src_node))` of :338-345.
+//   undirected: {(min,max)} distinct, UNION (distinct) with the reversed copy == sort+unique of both
+//   orientations of every input edge.  Rows come out ascending and duplicate-free.
+// Not on the per-batch path (runs once per graph): keys are radix-sorted with rocPRIM.
+#include "common.h"
+
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+__global__ void coo_keys_kernel(const uint32_t* src, const uint32_t* dst, int64_t e, int64_t n,
+                                int directed, uint64_t* keys, int32_t* bad) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= e) return;
+  uint32_t s = src[i], d = dst[i];
+  if ((int64_t)s >= n || (int64_t)d >= n) {
+    atomicAdd(bad, 1);
+    s = d = 0;
+  }
+  if (directed) {
+    keys[i] = ((uint64_t)d << 32) | s;
+  } else {
+    keys[2 * i] = ((uint64_t)d << 32) | s;
+    keys[2 * i + 1] = ((uint64_t)s << 32) | d;
+  }
+}
+
+__global__ void uniq_flag_kernel(const uint64_t* sorted, int64_t m, int32_t* flags) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  flags[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
+}
+
+__global__ void uniq_write_kernel(const uint64_t* sorted, const int32_t* flags, const int32_t* scan,
+                                  int64_t m, uint64_t* ukeys, int64_t* count) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  if (flags[i]) ukeys[scan[i]] = sorted[i];
+  if (i == m - 1) *count = (int64_t)scan[i] + flags[i];
+}
+
+__global__ void csc_col_kernel(const uint64_t* ukeys, int64_t u, uint32_t* col) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < u) col[i] = (uint32_t)(ukeys[i] & 0xFFFFFFFFu);
+}
+
+__global__ void csc_rowptr_kernel(const uint64_t* ukeys, int64_t u, int64_t n, int64_t* rowptr) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v > n) return;
+  uint64_t target = (uint64_t)v << 32;
+  int64_t lo = 0, hi = u;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (ukeys[mid] < target) lo = mid + 1;
+    else hi = mid;
+  }
+  rowptr[v] = lo;
+}
+
+}  // namespace
+
+extern "C" int32_t gigl_graph_build_from_coo(gigl_ctx* ctx, int64_t n, int64_t e, const uint32_t* src,
+                                             const uint32_t* dst, int32_t loc, int32_t is_directed,
+                                             gigl_graph** out) {
+  if (!ctx || !out) return GIGL_E_INVALID_ARG;
+  *out = nullptr;
+  GIGL_REQUIRE(ctx, n >= 0 && e >= 0 && (e == 0 || (src && dst)), "bad COO arguments");
+  GIGL_REQUIRE(ctx, n < (int64_t)GIGL_INVALID, "node ids must fit uint32");
+  GIGL_REQUIRE(ctx, loc == GIGL_LOC_HOST || loc == GIGL_LOC_DEVICE, "bad loc %d", loc);
+  const int64_t m = is_directed ? e : 2 * e;
+  if (m >= ((int64_t)1 << 31))
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "more than 2^31 directed edge records in one shard");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+
+  gigl_graph* g = new (std::nothrow) gigl_graph();
+  if (!g) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
+  g->ctx = ctx;
+  g->n = n;
+  struct Tmp {
+    void* p[8] = {nullptr};
+    int k = 0;
+    ~Tmp() { for (int i = 0; i < k; ++i) if (p[i]) hipFree(p[i]); }
+    hipError_t alloc(void** q, size_t bytes) {
+      hipError_t r = hipMalloc(q, bytes ? bytes : 16);
+      if (r == hipSuccess) p[k++] = *q;
+      return r;
+    }
+  } tmp;
+#define BUILD_CHECK(expr)                                                                  \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      gigl_graph_destroy(g);                                                               \
+      return gigl_fail(ctx, _e == hipErrorOutOfMemory ? GIGL_E_OOM : GIGL_E_HIP,           \
+                       "%s failed: %s", #expr, hipGetErrorString(_e));                     \
+    }                                                                                      \
+  } while (0)
+
+  BUILD_CHECK(hipMalloc((void**)&g->rowptr, (size_t)(n + 1) * sizeof(int64_t)));
+  if (m == 0) {
+    BUILD_CHECK(hipMalloc((void**)&g->col, 16));
+    BUILD_CHECK(hipMemsetAsync(g->rowptr, 0, (size_t)(n + 1) * sizeof(int64_t), st));
+    BUILD_CHECK(hipStreamSynchronize(st));
+    g->e = 0;
+    *out = g;
+    return GIGL_OK;
+  }
+  const uint32_t *dsrc = src, *ddst = dst;
+  if (loc == GIGL_LOC_HOST) {
+    uint32_t *a, *b;
+    BUILD_CHECK(tmp.alloc((void**)&a, (size_t)e * 4));
+    BUILD_CHECK(tmp.alloc((void**)&b, (size_t)e * 4));
+    BUILD_CHECK(hipMemcpyAsync(a, src, (size_t)e * 4, hipMemcpyHostToDevice, st));
+    BUILD_CHECK(hipMemcpyAsync(b, dst, (size_t)e * 4, hipMemcpyHostToDevice, st));
+    dsrc = a;
+    ddst = b;
+  }
+  uint64_t *keys, *sorted;
+  int32_t *flags, *scan, *bad;
+  int64_t* count;
+  BUILD_CHECK(tmp.alloc((void**)&keys, (size_t)m * 8));
+  BUILD_CHECK(tmp.alloc((void**)&sorted, (size_t)m * 8));
+  BUILD_CHECK(tmp.alloc((void**)&flags, (size_t)m * 4));
+  BUILD_CHECK(tmp.alloc((void**)&scan, (size_t)m * 4));
+  BUILD_CHECK(tmp.alloc((void**)&bad, 256));
+  count = (int64_t*)((char*)bad + 64);
+  BUILD_CHECK(hipMemsetAsync(bad, 0, 256, st));
+  const int TB = 256;
+  auto grid = [&](int64_t c) { return dim3((unsigned)((c + TB - 1) / TB)); };
+  hipLaunchKernelGGL(coo_keys_kernel, grid(e), dim3(TB), 0, st, dsrc, ddst, e, n, is_directed ? 1 : 0,
+                     keys, bad);
+  int key_bits = 33;
+  while (key_bits < 64 && (1LL << (key_bits - 32)) < n) ++key_bits;
+  size_t t1 = 0, t2 = 0;
+  hipcub::DeviceRadixSort::SortKeys((void*)nullptr, t1, keys, sorted, (int)m, 0, key_bits, st);
+  hipcub::DeviceScan::ExclusiveSum((void*)nullptr, t2, flags, scan, (int)m, st);
+  size_t tb = t1 > t2 ? t1 : t2;
+  void* work;
+  BUILD_CHECK(tmp.alloc(&work, tb));
+  BUILD_CHECK(hipcub::DeviceRadixSort::SortKeys(work, tb, keys, sorted, (int)m, 0, key_bits, st));
+  hipLaunchKernelGGL(uniq_flag_kernel, grid(m), dim3(TB), 0, st, sorted, m, flags);
+  BUILD_CHECK(hipcub::DeviceScan::ExclusiveSum(work, tb, flags, scan, (int)m, st));
+  // unique keys overwrite `keys`
+  hipLaunchKernelGGL(uniq_write_kernel, grid(m), dim3(TB), 0, st, sorted, flags, scan, m, keys, count);
+  int64_t h_count = 0;
+  int32_t h_bad = 0;
+  BUILD_CHECK(hipMemcpyAsync(&h_count, count, 8, hipMemcpyDeviceToHost, st));
+  BUILD_CHECK(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, st));
+  BUILD_CHECK(hipStreamSynchronize(st));
+  if (h_bad) {
+    gigl_graph_destroy(g);
+    return gigl_fail(ctx, GIGL_E_INVALID_ARG, "%d edges reference node ids >= n=%lld", h_bad,
+                     (long long)n);
+  }
+  g->e = h_count;
+  BUILD_CHECK(hipMalloc((void**)&g->col, (size_t)(h_count > 0 ? h_count : 1) * 4));
+  hipLaunchKernelGGL(csc_col_kernel, grid(h_count), dim3(TB), 0, st, keys, h_count, g->col);
+  hipLaunchKernelGGL(csc_rowptr_kernel, grid(n + 1), dim3(TB), 0, st, keys, h_count, n, g->rowptr);
+  BUILD_CHECK(hipGetLastError());
+  BUILD_CHECK(hipStreamSynchronize(st));
+#undef BUILD_CHECK
+  *out = g;
+  return GIGL_OK;
+}

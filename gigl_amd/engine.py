@@ -1,0 +1,287 @@
+"""HipEngine — thin host-side owner of one libgigl_hip ctx (one device, one stream).
+
+torch is used only for device memory and streams (`torch.empty(..., device=...)`, `.data_ptr()`,
+the current stream handle); all compute happens in the HIP library.  Lifecycle mirrors the
+reference's per-partition `KHopSamplerService.setup()/teardown()`
+(scala_spark35/common/src/main/scala/graphdb/KHopSamplerService.scala:10-33).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (DTYPE_F16, DTYPE_F32, GIGL_INVALID, GIGL_META_LEN, GiglTree, GiglUnion, LOC_DEVICE,
+                   LOC_HOST, MODE_FAST, MODE_SPARK_HASH, check)
+
+
+@dataclass
+class Tree:
+    """device-resident tree-layout sample (include/gigl_hip.h `gigl_tree`)"""
+    roots: torch.Tensor            # int32 storage of uint32 ids, [b]
+    fanouts: List[int]
+    nbr: List[torch.Tensor]        # int32 storage of uint32 ids, [slots_k]; -1 == GIGL_INVALID
+    cnt: List[torch.Tensor]        # int32 [parents_k]
+    c_struct: GiglTree
+
+    @property
+    def b(self) -> int:
+        return int(self.roots.numel())
+
+    def sampled_edges(self) -> int:
+        return int(sum(int(c.sum().item()) for c in self.cnt))
+
+
+@dataclass
+class UnionGraph:
+    """device-resident batch union graph (include/gigl_hip.h `gigl_union`)"""
+    meta: torch.Tensor        # int32 [16]
+    nodes: torch.Tensor       # int32 storage of uint32 global ids [cap_nodes]
+    rowptr: torch.Tensor      # int32 [cap_nodes+1]
+    col: torch.Tensor         # int32 [cap_edges]
+    root_local: torch.Tensor  # int32 [b]
+    hops: int
+    c_struct: GiglUnion
+
+    def counts(self):
+        m = self.meta.cpu().tolist()
+        return dict(n_nodes=m[0], n_edges=m[1], levels=m[2:2 + self.hops + 1])
+
+
+class HipEngine:
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load()  # raises if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("gigl_amd.HipEngine needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        ctx = C.c_void_p()
+        check(self._lib.gigl_ctx_create(device, C.byref(ctx)))
+        self._ctx = ctx
+        self._graph = None
+        self._graph_out = None
+        self._feat = None
+        self.n_nodes = 0
+        self.n_edges = 0
+        self.feat_dim = 0
+        self.feat_dtype = DTYPE_F32
+        self.bind_stream()
+
+    # ---- lifecycle -------------------------------------------------------------------------
+    def bind_stream(self, stream: Optional[torch.cuda.Stream] = None) -> None:
+        """run library kernels on `stream` (default: torch's current stream on this device)"""
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._stream = s
+        check(self._lib.gigl_ctx_set_stream(self._ctx, C.c_void_p(s.cuda_stream)), self._ctx)
+
+    def synchronize(self) -> None:
+        check(self._lib.gigl_ctx_synchronize(self._ctx), self._ctx)
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None):
+            for h, fn in ((self._graph, self._lib.gigl_graph_destroy), (self._graph_out, self._lib.gigl_graph_destroy),
+                          (self._feat, self._lib.gigl_features_destroy)):
+                if h:
+                    fn(h)
+            self._graph = self._graph_out = self._feat = None
+            self._lib.gigl_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    teardown = close
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- resident data ---------------------------------------------------------------------
+    @staticmethod
+    def _ptr_loc(x):
+        if isinstance(x, torch.Tensor):
+            x = x.contiguous()
+            return x, C.c_void_p(x.data_ptr()), (LOC_DEVICE if x.is_cuda else LOC_HOST)
+        x = np.ascontiguousarray(x)
+        return x, C.c_void_p(x.ctypes.data), LOC_HOST
+
+    def load_csc(self, rowptr, col, *, out_graph: bool = False) -> None:
+        """rowptr int64[n+1], col uint32/int32[e] (numpy or torch, host or device)."""
+        rp, rp_p, loc1 = self._ptr_loc(rowptr if isinstance(rowptr, torch.Tensor) else np.asarray(rowptr, dtype=np.int64))
+        if isinstance(col, torch.Tensor):
+            assert col.dtype in (torch.int32, torch.uint32)
+        else:
+            col = np.asarray(col).astype(np.uint32, copy=False)
+        cl, cl_p, loc2 = self._ptr_loc(col)
+        assert loc1 == loc2, "rowptr and col must live on the same side"
+        if isinstance(rp, torch.Tensor):
+            assert rp.dtype == torch.int64
+        n = int(rp.shape[0]) - 1
+        e = int(cl.shape[0])
+        g = C.c_void_p()
+        check(self._lib.gigl_graph_load_csc(self._ctx, n, e, rp_p, cl_p, loc1, C.byref(g)), self._ctx)
+        self._set_graph(g, n, e, out_graph)
+
+    def build_from_coo(self, n: int, src, dst, is_directed: bool, *, out_graph: bool = False) -> None:
+        s, s_p, loc1 = self._ptr_loc(src if isinstance(src, torch.Tensor) else np.asarray(src).astype(np.uint32))
+        d, d_p, loc2 = self._ptr_loc(dst if isinstance(dst, torch.Tensor) else np.asarray(dst).astype(np.uint32))
+        assert loc1 == loc2
+        g = C.c_void_p()
+        check(self._lib.gigl_graph_build_from_coo(self._ctx, n, int(s.shape[0]), s_p, d_p, loc1,
+                                                  1 if is_directed else 0, C.byref(g)), self._ctx)
+        nn, ee = C.c_int64(), C.c_int64()
+        check(self._lib.gigl_graph_info(g, C.byref(nn), C.byref(ee)), self._ctx)
+        self._set_graph(g, nn.value, ee.value, out_graph)
+
+    def _set_graph(self, g, n, e, out_graph):
+        attr = "_graph_out" if out_graph else "_graph"
+        old = getattr(self, attr)
+        if old:
+            self._lib.gigl_graph_destroy(old)
+        setattr(self, attr, g)
+        if not out_graph:
+            self.n_nodes, self.n_edges = n, e
+
+    def graph_to_host(self, out_graph: bool = False):
+        g = self._graph_out if out_graph else self._graph
+        n, e = C.c_int64(), C.c_int64()
+        check(self._lib.gigl_graph_info(g, C.byref(n), C.byref(e)), self._ctx)
+        rp, cl = C.c_void_p(), C.c_void_p()
+        check(self._lib.gigl_graph_device_ptrs(g, C.byref(rp), C.byref(cl)), self._ctx)
+        rowptr = np.empty(n.value + 1, dtype=np.int64)
+        col = np.empty(max(e.value, 1), dtype=np.uint32)
+        check(self._lib.gigl_memcpy(self._ctx, C.c_void_p(rowptr.ctypes.data), LOC_HOST, rp, LOC_DEVICE,
+                                    rowptr.nbytes), self._ctx)
+        if e.value:
+            check(self._lib.gigl_memcpy(self._ctx, C.c_void_p(col.ctypes.data), LOC_HOST, cl, LOC_DEVICE,
+                                        e.value * 4), self._ctx)
+        return rowptr, col[: e.value]
+
+    def load_features(self, x) -> None:
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        assert x.dim() == 2 and x.dtype in (torch.float32, torch.float16)
+        x = x.contiguous()
+        dt = DTYPE_F32 if x.dtype == torch.float32 else DTYPE_F16
+        f = C.c_void_p()
+        check(self._lib.gigl_features_load(self._ctx, x.shape[0], x.shape[1], dt, C.c_void_p(x.data_ptr()),
+                                           LOC_DEVICE if x.is_cuda else LOC_HOST, C.byref(f)), self._ctx)
+        if self._feat:
+            self._lib.gigl_features_destroy(self._feat)
+        self._feat = f
+        self.feat_dim, self.feat_dtype = int(x.shape[1]), dt
+        rows = C.c_void_p()
+        check(self._lib.gigl_features_device_ptr(f, C.byref(rows), None, None, None), self._ctx)
+        self._feat_ptr = rows
+
+    # ---- per-batch ops (device pointers only, no host sync) --------------------------------
+    def _roots_tensor(self, roots) -> torch.Tensor:
+        if isinstance(roots, torch.Tensor):
+            r = roots.to(device=self.device)
+            if r.dtype != torch.int32:
+                r = r.to(torch.int64).to(torch.int32) if r.dtype != torch.int64 else r.to(torch.int32)
+            return r.contiguous()
+        a = np.asarray(roots, dtype=np.int64).astype(np.uint32).view(np.int32)
+        return torch.from_numpy(a).to(self.device)
+
+    def alloc_tree(self, b: int, fanouts: Sequence[int]) -> Tree:
+        t = GiglTree()
+        nbr, cnt, parents = [], [], b
+        for k, f in enumerate(fanouts):
+            cnt.append(torch.empty(max(parents, 1), dtype=torch.int32, device=self.device))
+            parents *= int(f)
+            nbr.append(torch.empty(max(parents, 1), dtype=torch.int32, device=self.device))
+            t.nbr[k] = nbr[-1].data_ptr()
+            t.cnt[k] = cnt[-1].data_ptr()
+        return Tree(roots=None, fanouts=[int(f) for f in fanouts], nbr=nbr, cnt=cnt, c_struct=t)
+
+    def sample_khop(self, roots, fanouts: Sequence[int], sampling_seed: int = 42,
+                    mode: int = MODE_SPARK_HASH, out: Optional[Tree] = None) -> Tree:
+        assert self._graph is not None, "load a graph first"
+        r = self._roots_tensor(roots)
+        b = int(r.numel())
+        tree = out if out is not None else self.alloc_tree(b, fanouts)
+        tree.roots = r
+        fo = (C.c_int32 * len(fanouts))(*[int(f) for f in fanouts])
+        check(self._lib.gigl_sample_khop(self._ctx, self._graph, C.c_void_p(r.data_ptr()), b, fo, len(fanouts),
+                                         sampling_seed, mode, C.byref(tree.c_struct)), self._ctx)
+        if b:  # trim the >=1 padding used for empty allocations
+            parents = b
+            for k, f in enumerate(tree.fanouts):
+                tree.cnt[k] = tree.cnt[k][:parents]
+                parents *= f
+                tree.nbr[k] = tree.nbr[k][:parents]
+        return tree
+
+    def sample_positives(self, roots, num_positives: int, sampling_seed: int = 42):
+        assert self._graph_out is not None, "load the out-edge graph first (out_graph=True)"
+        r = self._roots_tensor(roots)
+        b = int(r.numel())
+        pos = torch.empty(max(b * num_positives, 1), dtype=torch.int32, device=self.device)
+        cnt = torch.empty(max(b, 1), dtype=torch.int32, device=self.device)
+        check(self._lib.gigl_sample_positives(self._ctx, self._graph_out, C.c_void_p(r.data_ptr()), b, num_positives,
+                                              sampling_seed, MODE_SPARK_HASH, C.c_void_p(pos.data_ptr()),
+                                              C.c_void_p(cnt.data_ptr())), self._ctx)
+        return pos[: b * num_positives], cnt[:b]
+
+    def union_capacity(self, b: int, fanouts: Sequence[int]):
+        fo = (C.c_int32 * len(fanouts))(*[int(f) for f in fanouts])
+        cn, ce = C.c_int64(), C.c_int64()
+        check(self._lib.gigl_union_capacity(b, fo, len(fanouts), C.byref(cn), C.byref(ce)))
+        return cn.value, ce.value
+
+    def alloc_union(self, b: int, fanouts: Sequence[int]) -> UnionGraph:
+        cn, ce = self.union_capacity(b, fanouts)
+        dev = self.device
+        u = GiglUnion()
+        meta = torch.zeros(GIGL_META_LEN, dtype=torch.int32, device=dev)
+        nodes = torch.empty(max(cn, 1), dtype=torch.int32, device=dev)
+        rowptr = torch.zeros(cn + 2, dtype=torch.int32, device=dev)
+        col = torch.empty(max(ce, 1), dtype=torch.int32, device=dev)
+        root_local = torch.empty(max(b, 1), dtype=torch.int32, device=dev)
+        u.meta, u.nodes, u.rowptr, u.col, u.root_local = (meta.data_ptr(), nodes.data_ptr(), rowptr.data_ptr(),
+                                                           col.data_ptr(), root_local.data_ptr())
+        u.cap_nodes, u.cap_edges = cn, ce
+        return UnionGraph(meta=meta, nodes=nodes, rowptr=rowptr, col=col, root_local=root_local,
+                          hops=len(fanouts), c_struct=u)
+
+    def union_build(self, tree: Tree, out: Optional[UnionGraph] = None) -> UnionGraph:
+        u = out if out is not None else self.alloc_union(tree.b, tree.fanouts)
+        check(self._lib.gigl_union_build(self._ctx, C.c_void_p(tree.roots.data_ptr()), C.byref(tree.c_struct),
+                                         C.byref(u.c_struct)), self._ctx)
+        return u
+
+    def gather_mean(self, src: Optional[torch.Tensor], d: int, gather_ids: Optional[torch.Tensor],
+                    rowptr: torch.Tensor, col: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """src None -> the resident feature table."""
+        if src is None:
+            src_ptr, dt = self._feat_ptr, self.feat_dtype
+        else:
+            assert src.is_cuda and src.is_contiguous()
+            src_ptr = C.c_void_p(src.data_ptr())
+            dt = DTYPE_F32 if src.dtype == torch.float32 else DTYPE_F16
+        if out is None:
+            out = torch.empty((rows_cap, 2 * d), dtype=torch.float32, device=self.device)
+        gid = C.c_void_p(gather_ids.data_ptr()) if gather_ids is not None else None
+        check(self._lib.gigl_gather_mean(self._ctx, src_ptr, dt, d, gid, C.c_void_p(rowptr.data_ptr()),
+                                         C.c_void_p(col.data_ptr()), C.c_void_p(n_rows_dev.data_ptr()), rows_cap,
+                                         C.c_void_p(out.data_ptr())), self._ctx)
+        return out
+
+    def linear(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m_dev: torch.Tensor,
+               m_cap: int, act: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert a.is_cuda and w.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32
+        assert a.is_contiguous() and w.is_contiguous()
+        n, k = int(w.shape[0]), int(w.shape[1])
+        assert a.shape[1] == k
+        if out is None:
+            out = torch.empty((m_cap, n), dtype=torch.float32, device=self.device)
+        check(self._lib.gigl_linear(self._ctx, C.c_void_p(a.data_ptr()), C.c_void_p(w.data_ptr()),
+                                    C.c_void_p(bias.data_ptr()) if bias is not None else None,
+                                    C.c_void_p(m_dev.data_ptr()), m_cap, k, n, act, C.c_void_p(out.data_ptr())),
+              self._ctx)
+        return out

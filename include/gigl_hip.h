@@ -67,6 +67,10 @@ int32_t gigl_ctx_synchronize(gigl_ctx* ctx);
 /* pre-size the ctx scratch arena (bytes); grows on demand otherwise (grow = hipMalloc, so
  * warm up once before capturing a hipGraph) */
 int32_t gigl_ctx_reserve(gigl_ctx* ctx, int64_t bytes);
+/* synchronous copy between host/device buffers on the ctx stream (`*_loc` = GIGL_LOC_*): the
+ * "block_to_host" of the boundary — results leave HBM only through this or the caller's own copies */
+int32_t gigl_memcpy(gigl_ctx* ctx, void* dst, int32_t dst_loc, const void* src, int32_t src_loc,
+                    int64_t bytes);
 
 /* ---- graph ingest: replaces loadEdgeDataframeIntoSparkSql + enforceBidirectionalization
  *      (scala/subgraph_sampler/src/main/scala/libs/task/pureSpark/SGSPureSparkV1Task.scala:120-286)

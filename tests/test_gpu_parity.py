@@ -1,0 +1,205 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle, bit-exact for all
+integer / index work, 1e-5 for fp32 aggregation (tolerance from BASELINE.json's north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle.oracle import canonicalise
+from helpers import INVALID, load_fixture_graph, rmat_edges
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from gigl_amd.engine import HipEngine
+    e = HipEngine(0)
+    yield e
+    e.close()
+
+
+def _u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def _check_tree(eng, rowptr, col, roots, fanouts):
+    tree = eng.sample_khop(roots, fanouts)
+    nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots, fanouts)
+    nbr_o = canonicalise(nbr_o, fanouts)
+    for k in range(len(fanouts)):
+        assert np.array_equal(tree.cnt[k].cpu().numpy(), cnt_o[k]), f"cnt hop {k}"
+        assert np.array_equal(_u32(tree.nbr[k]), nbr_o[k]), f"nbr hop {k}"
+    return tree, nbr_o
+
+
+def test_sampler_fixture_graph(eng, golden_dir):
+    n, src, dst, _ = load_fixture_graph(golden_dir)
+    rowptr, col = oracle.build_csc(n, src, dst, is_directed=False)
+    eng.load_csc(rowptr, col)
+    roots = np.arange(n, dtype=np.uint32)
+    for f in ([3, 3], [1, 1], [2, 5], [64, 64]):
+        _check_tree(eng, rowptr, col, roots, f)
+
+
+def test_graph_build_from_coo_matches_oracle(eng, golden_dir):
+    n, src, dst, _ = load_fixture_graph(golden_dir)
+    for directed in (False, True):
+        rp_o, col_o = oracle.build_csc(n, src, dst, is_directed=directed)
+        eng.build_from_coo(n, src, dst, is_directed=directed)
+        rp, cl = eng.graph_to_host()
+        assert np.array_equal(rp, rp_o) and np.array_equal(cl, col_o)
+    s, d = rmat_edges(12, 60000, seed=11)
+    rp_o, col_o = oracle.build_csc(4096, s, d, is_directed=False)
+    eng.build_from_coo(4096, s, d, is_directed=False)
+    rp, cl = eng.graph_to_host()
+    assert np.array_equal(rp, rp_o) and np.array_equal(cl, col_o)
+    with pytest.raises(RuntimeError):
+        eng.build_from_coo(10, np.array([1, 50], np.uint32), np.array([2, 3], np.uint32), True)
+
+
+@pytest.mark.parametrize("fanouts", [[10, 5], [25, 10], [15, 10, 5], [7]])
+def test_sampler_rmat_parity(eng, fanouts):
+    s, d = rmat_edges(13, 200000, seed=7)
+    n = 1 << 13
+    rowptr, col = oracle.build_csc(n, s, d, is_directed=False)
+    eng.load_csc(rowptr, col)
+    rng = np.random.default_rng(1)
+    roots = rng.integers(0, n, size=257).astype(np.uint32)  # with repeats, odd size
+    _check_tree(eng, rowptr, col, roots, fanouts)
+
+
+def test_sampler_heavy_rows_and_edge_cases(eng):
+    # a star: node 0 has 20000 in-neighbours (> HEAVY_DEG, workgroup path), plus medium rows
+    n = 20100
+    src = np.concatenate([np.arange(1, 20001), np.arange(1, 300), np.arange(1, 70), np.array([5])]).astype(np.uint32)
+    dst = np.concatenate([np.zeros(20000), np.full(299, 1), np.full(69, 2), np.array([3])]).astype(np.uint32)
+    rowptr, col = oracle.build_csc(n, src, dst, is_directed=True)
+    eng.load_csc(rowptr, col)
+    roots = np.array([0, 1, 2, 3, 4, 0, 20099], dtype=np.uint32)  # 4 and 20099: no in-edges
+    for f in ([25, 10], [64, 2], [1, 1]):
+        _check_tree(eng, rowptr, col, roots, f)
+    # empty batch
+    t = eng.sample_khop(np.zeros(0, np.uint32), [5, 5])
+    assert t.b == 0
+    with pytest.raises(RuntimeError):
+        eng.sample_khop(roots, [65, 2])  # GIGL_E_UNSUPPORTED: fanout > 64
+
+
+def test_int32_wraparound_of_key_sum(eng):
+    """the int32 adds of `i + K + seed*counter` wrap exactly like Spark's IntegerType (exercised through
+    extreme sampling seeds; ids near 2^31 would need a >16 GB rowptr)"""
+    s, d = rmat_edges(10, 20000, seed=3)
+    rowptr, col = oracle.build_csc(1024, s, d, is_directed=False)
+    eng.load_csc(rowptr, col)
+    roots = np.arange(0, 1024, 7, dtype=np.uint32)
+    for seed in (2**31 - 1, -(2**31), 1234567891):
+        tree = eng.sample_khop(roots, [4, 3], sampling_seed=seed)
+        nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots, [4, 3], sampling_seed=seed)
+        nbr_o = canonicalise(nbr_o, [4, 3])
+        for k in range(2):
+            assert np.array_equal(_u32(tree.nbr[k]), nbr_o[k])
+
+
+def test_positives_counter_three(eng):
+    s, d = rmat_edges(11, 30000, seed=9)
+    n = 2048
+    # out-edge graph: CSR by source == CSC of the reversed edges
+    rowptr, col = oracle.build_csc(n, d, s, is_directed=True)
+    eng.load_csc(rowptr, col, out_graph=True)
+    roots = np.arange(0, n, 3, dtype=np.uint32)
+    pos, cnt = eng.sample_positives(roots, 2)
+    nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots, [2], first_counter=3)
+    assert np.array_equal(cnt.cpu().numpy(), cnt_o[0])
+    assert np.array_equal(_u32(pos), canonicalise(nbr_o, [2])[0])
+
+
+@pytest.mark.parametrize("fanouts,b", [([10, 5], 64), ([25, 10], 300), ([4, 3, 2], 50), ([6], 33)])
+def test_union_build_bit_exact(eng, fanouts, b):
+    s, d = rmat_edges(12, 80000, seed=21)
+    n = 1 << 12
+    rowptr, col = oracle.build_csc(n, s, d, is_directed=False)
+    eng.load_csc(rowptr, col)
+    rng = np.random.default_rng(5)
+    roots = rng.integers(0, n, size=b).astype(np.uint32)  # duplicates allowed
+    tree, nbr_o = _check_tree(eng, rowptr, col, roots, fanouts)
+    u = eng.union_build(tree)
+    o = oracle.union_build(roots, fanouts, nbr_o)
+    meta = u.meta.cpu().numpy()
+    hops = len(fanouts)
+    assert np.array_equal(meta[: 3 + hops], o["meta"][: 3 + hops]), (meta, o["meta"])
+    nn, ne = int(meta[0]), int(meta[1])
+    assert np.array_equal(_u32(u.nodes)[:nn], o["nodes"])
+    assert np.array_equal(u.rowptr.cpu().numpy()[: nn + 1], o["rowptr"])
+    assert np.array_equal(u.col.cpu().numpy()[:ne], o["col"])
+    assert np.array_equal(u.root_local.cpu().numpy()[:b], o["root_local"])
+
+
+def test_union_isolated_roots_only(eng):
+    rowptr = np.zeros(11, dtype=np.int64)
+    eng.load_csc(rowptr, np.zeros(0, np.uint32))
+    roots = np.array([3, 3, 9], dtype=np.uint32)
+    tree = eng.sample_khop(roots, [3, 2])
+    assert tree.sampled_edges() == 0
+    u = eng.union_build(tree)
+    c = u.counts()
+    assert c["n_nodes"] == 2 and c["n_edges"] == 0 and c["levels"] == [2, 2, 2]
+    assert _u32(u.nodes)[:2].tolist() == [3, 9]
+    assert u.root_local.cpu().tolist()[:3] == [0, 0, 1]
+    assert u.rowptr.cpu().tolist()[:3] == [0, 0, 0]
+
+
+def _ref_gather_mean(x, ids, rowptr, col, n_rows):
+    d = x.shape[1]
+    out = np.zeros((n_rows, 2 * d), dtype=np.float32)
+    for i in range(n_rows):
+        js = col[rowptr[i]:rowptr[i + 1]]
+        if js.size:
+            out[i, :d] = x[ids[js]].astype(np.float32).sum(axis=0, dtype=np.float32) / np.float32(js.size)
+        out[i, d:] = x[ids[i]]
+    return out
+
+
+@pytest.mark.parametrize("d,dtype", [(100, torch.float32), (16, torch.float32), (256, torch.float32),
+                                     (768, torch.float16), (1433, torch.float32), (2, torch.float32)])
+def test_gather_mean_against_fp32_reference(eng, d, dtype):
+    rng = np.random.default_rng(d)
+    n_tab, n_loc = 5000, 700
+    x = torch.from_numpy(rng.standard_normal((n_tab, d)).astype(np.float32)).to(dtype)
+    ids = rng.choice(n_tab, size=n_loc, replace=False).astype(np.int32)
+    deg = rng.integers(0, 40, size=n_loc)
+    deg[:5] = [0, 1, 2, 3, 130]
+    rowptr = np.zeros(n_loc + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, n_loc, size=int(rowptr[-1])).astype(np.int32)
+    n_rows = 650  # a prefix
+    dev = eng.device
+    out = eng.gather_mean(x.to(dev), d, torch.from_numpy(ids).to(dev), torch.from_numpy(rowptr).to(dev),
+                          torch.from_numpy(col).to(dev), torch.tensor([n_rows], dtype=torch.int32, device=dev), n_loc)
+    got = out.cpu().numpy()[:n_rows]
+    want = _ref_gather_mean(x.float().numpy(), ids, rowptr, col, n_rows)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    # identity gather (layer >= 2: sources are a dense local matrix)
+    h = x[:n_loc].float().contiguous()
+    out2 = eng.gather_mean(h.to(dev), d, None, torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev),
+                           torch.tensor([n_rows], dtype=torch.int32, device=dev), n_loc)
+    want2 = _ref_gather_mean(h.numpy(), np.arange(n_loc), rowptr, col, n_rows)
+    np.testing.assert_allclose(out2.cpu().numpy()[:n_rows], want2, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("m,k,n,act", [(1000, 200, 256, 1), (1024, 512, 47, 0), (33, 8, 7, 0), (70, 2866, 16, 1),
+                                       (5, 30, 33, 1), (257, 4, 64, 0)])
+def test_linear_against_fp32_reference(eng, m, k, n, act):
+    g = torch.Generator().manual_seed(m * 31 + k)
+    a = torch.randn(m + 9, k, generator=g)
+    w = torch.randn(n, k, generator=g) / (k ** 0.5)
+    bias = torch.randn(n, generator=g)
+    dev = eng.device
+    y = eng.linear(a.to(dev), w.to(dev), bias.to(dev), torch.tensor([m], dtype=torch.int32, device=dev), m + 9, act)
+    want = a[:m].double() @ w.double().T + bias.double()
+    if act:
+        want = want.clamp_min(0)
+    np.testing.assert_allclose(y.cpu().numpy()[:m], want.float().numpy(), rtol=1e-5, atol=1e-5)
+    # no bias
+    y2 = eng.linear(a.to(dev), w.to(dev), None, torch.tensor([m], dtype=torch.int32, device=dev), m + 9, 0)
+    np.testing.assert_allclose(y2.cpu().numpy()[:m], (a[:m].double() @ w.double().T).float().numpy(), rtol=1e-5, atol=2e-5)
