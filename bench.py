@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""bench.py — sampled+aggregated edges/s of the HIP hot path (BASELINE.json metric).
+
+A "step" = one batch of B roots through the whole path, inputs already resident in HBM:
+    k-hop sample (parity mode, Spark-hash permutation)  ->  batch union graph (dedup + CSR)
+    ->  GraphSAGE forward (gather-mean + fp32 MFMA projection per layer, trimmed schedule)
+Workload at N=1 = BASELINE.json configs[1]: ogbn-products-SHAPED synthetic graph (N=2,449,029,
+RMAT(.57,.19,.19) power-law, ~61.9M undirected pairs bidirectionalised, D=100 fp32), fanout
+[25,10], B=1024, GraphSAGE 100->256->47.  MAG240M (the config the metric is
+quoted on) does not fit one GPU (375 GB of features), so per the contract the N=1 line is the
+largest single-GPU configuration.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--small]
+
+N>1: one process per GPU (torch.distributed, RCCL); every rank holds a replica of the graph and takes
+its own root batches — the path shards by roots with no data-path collective ("weak" scaling);
+time = max over ranks, value = total edges of all ranks / that time.
+
+Counting: sampled edge = one (src->dst) pair emitted by a hop expansion before batch
+dedup; aggregated edge = one edge actually consumed by one layer's segmented reduce (sum_l |E_l|,
+trimmed schedule — never the inflated L*|E_union|, which is reported in config for context).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def rmat_edges_gpu(scale: int, n_edges: int, seed: int, device, a=0.57, b=0.19, c=0.19):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    src = torch.zeros(n_edges, dtype=torch.int64, device=device)
+    dst = torch.zeros(n_edges, dtype=torch.int64, device=device)
+    for _ in range(scale):
+        r = torch.rand(n_edges, generator=g, device=device)
+        src = src * 2 + (r >= a + b).to(torch.int64)
+        dst = dst * 2 + (((r >= a) & (r < a + b)) | (r >= a + b + c)).to(torch.int64)
+    return src, dst
+
+
+def build_workload(eng, args, rank):
+    dev = eng.device
+    if args.small:
+        n, scale, pairs, d = 200_000, 18, 3_000_000, 100
+    else:
+        n, scale, pairs, d = 2_449_029, 22, 61_859_140, 100
+    src, dst = rmat_edges_gpu(scale, pairs, seed=2, device=dev)
+    # fold the 2^scale id space onto [0, n) and scatter ids so hubs are not the low ids
+    perm_mul = 0x9E3779B1
+    src = ((src * perm_mul) % n).to(torch.int32)
+    dst = ((dst * perm_mul) % n).to(torch.int32)
+    eng.build_from_coo(n, src, dst, is_directed=False)
+    del src, dst
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    x = torch.randn((n, d), generator=g, device=dev, dtype=torch.float32)
+    eng.load_features(x)
+    del x
+    torch.cuda.empty_cache()
+    return n, d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--fanouts", type=str, default="25,10")
+    ap.add_argument("--small", action="store_true", help="200k-node graph (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", type=str, default="parity", choices=["parity", "fast"])
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == max(args.gpus, 1) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+
+    from gigl_amd._lib import MODE_FAST, MODE_SPARK_HASH
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE, HipBatch
+
+    torch.cuda.set_device(local_rank)
+    eng = HipEngine(local_rank)
+    dev = eng.device
+    fanouts = [int(v) for v in args.fanouts.split(",")]
+    B, K, W = args.batch, args.steps, args.warmup
+    mode = MODE_SPARK_HASH if args.mode == "parity" else MODE_FAST
+
+    t0 = time.time()
+    n, d = build_workload(eng, args, rank)
+    hid, out_dim = 256, 47
+    torch.manual_seed(0)
+    model = GraphSAGE(d, hid, out_dim, num_layers=len(fanouts)).to(dev)
+    # roots: seeded permutation of node ids (seed 42); rank r takes batches r, r+world, ...
+    gp = torch.Generator(device="cpu")
+    gp.manual_seed(42)
+    total_batches = (W + K) * world
+    perm = torch.randperm(n, generator=gp)[: total_batches * B]
+    if perm.numel() < total_batches * B:
+        perm = perm.repeat((total_batches * B + perm.numel() - 1) // perm.numel())[: total_batches * B]
+    my = perm.view(total_batches, B)[rank::world].to(torch.int32).to(dev).contiguous()
+    setup_s = time.time() - t0
+
+    tree = eng.alloc_tree(B, fanouts)
+    union = eng.alloc_union(B, fanouts)
+
+    def step(i):
+        t = eng.sample_khop(my[i], fanouts, 42, mode, out=tree)
+        u = eng.union_build(t, out=union)
+        return model(HipBatch(eng, t, u))
+
+    # ---- untimed: warm-up + find the dominant kernel with all event timers on
+    for i in range(min(W, 3)):
+        step(i)
+    torch.cuda.synchronize()
+    from gigl_amd._lib import KERNEL_IDS
+    names = list(KERNEL_IDS)
+    eng.profile_enable(names, capacity=64 * 16)
+    for i in range(min(W, 5)):
+        step(i)
+    prof = {k: eng.profile_read(k) for k in names}
+    dominant = max(prof, key=lambda k: prof[k][0])
+    eng.profile_enable([dominant], capacity=(K + 8) * 8)
+    for i in range(W):
+        step(i)
+    eng.profile_reset()
+
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t1
+    dom_ms, dom_launches = eng.profile_read(dominant)
+    eng.profile_enable([], 0)
+
+    # ---- untimed: exact edge counts and algorithmic bytes of the same K batches (sampling is deterministic)
+    sampled = 0
+    aggregated = 0
+    ref_equiv = 0
+    union_edges = 0
+    alg_bytes = {k: 0.0 for k in names}
+    rowptr_g, col_g = None, None
+    import ctypes as C
+    rp, cl = C.c_void_p(), C.c_void_p()
+    eng._lib.gigl_graph_device_ptrs(eng._graph, C.byref(rp), C.byref(cl))
+    count_steps = range(W, W + K)
+    L = len(fanouts)
+    for i in count_steps:
+        t = eng.sample_khop(my[i], fanouts, 42, mode, out=tree)
+        u = eng.union_build(t, out=union)
+        torch.cuda.synchronize()
+        cnts = [int(c.sum().item()) for c in t.cnt]
+        s_edges = sum(cnts)
+        sampled += s_edges
+        meta = u.meta.cpu().tolist()
+        nn, ne = meta[0], meta[1]
+        rowp = u.rowptr[: nn + 1]
+        agg_l = [int(rowp[meta[2 + (L - 1 - l)]].item()) for l in range(L)]
+        aggregated += sum(agg_l)
+        ref_equiv += L * ne
+        union_edges += ne
+        # algorithmic bytes:
+        #  gather layer l: E_l*(4 + D_l*s) + N_dst*(8 + D_l*s_out) [+ self row D_l*s for the fused hydration copy]
+        dims = [d] + [hid] * (L - 1)
+        for l in range(L):
+            n_dst = meta[2 + (L - 1 - l)]
+            alg_bytes["gather_mean"] += agg_l[l] * (4 + dims[l] * 4) + n_dst * (8 + 2 * dims[l] * 4)
+        #  union: 16 B per sampled edge + 4 B per unique node
+        for k in ("union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr"):
+            alg_bytes[k] += (16 * s_edges + 4 * nn) / 5.0
+    # sampler bytes need frontier degrees: 16 + 4*deg + 8*min(deg,f) per frontier node (parity mode)
+    if dominant in ("expand", "expand_heavy", "find_heavy"):
+        eng_rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        eng._lib.gigl_memcpy(eng._ctx, C.c_void_p(eng_rowptr.data_ptr()), 1, rp, 1, (n + 1) * 8)
+        deg_all = (eng_rowptr[1:] - eng_rowptr[:-1])
+        heavy_thr = 4096
+        for i in count_steps:
+            t = eng.sample_khop(my[i], fanouts, 42, mode, out=tree)
+            torch.cuda.synchronize()
+            parents = [my[i]] + [t.nbr[k] for k in range(L - 1)]
+            for k in range(L):
+                p = parents[k].long()
+                valid = p >= 0
+                dg = deg_all[p.clamp(min=0)] * valid
+                f = fanouts[k]
+                per = 16 * valid + 4 * dg + 8 * torch.clamp(dg, max=f)
+                is_heavy = (dg > heavy_thr)
+                alg_bytes["expand_heavy"] += float((per * is_heavy).sum().item())
+                alg_bytes["expand"] += float((per * (~is_heavy)).sum().item())
+
+    # ---- reduce over ranks
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        cc = torch.tensor([sampled, aggregated, ref_equiv], dtype=torch.float64, device=dev)
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        sampled_all, aggregated_all, ref_equiv_all = [float(v) for v in cc.tolist()]
+    else:
+        sampled_all, aggregated_all, ref_equiv_all = float(sampled), float(aggregated), float(ref_equiv)
+
+    value = (sampled_all + aggregated_all) / elapsed
+    launches_per_step = {"expand": L, "expand_heavy": L, "find_heavy": L, "gather_mean": L, "linear": L}.get(dominant, 1)
+    avg_launch_ms = dom_ms / max(dom_launches, 1)
+    bytes_per_launch = alg_bytes[dominant] / max(K * launches_per_step, 1)
+    achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_us": round(avg_launch_ms * 1e3, 2), "alg_bytes_per_launch": round(bytes_per_launch),
+                "launches": int(dom_launches),
+                "kernel_ms_untimed_probe": {k: round(v[0] / max(min(W, 5), 1), 4) for k, v in prof.items()}}
+
+    cpu_baseline = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(eng, model, my, fanouts, W, n, d)
+
+    if rank == 0:
+        line = {
+            "metric": "sampled+aggregated edges/s", "value": value, "unit": "edges/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("products-shaped-small" if args.small else "ogbn-products-shaped RMAT") +
+                       f" N={n} E={eng.n_edges} D={d} fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}"
+                       " inference step (sample+union+forward), sampler mode=" + args.mode,
+                       "graph": "replica per GPU, roots sharded across ranks",
+                       "sampled_edges_per_step": sampled_all / (K * world),
+                       "aggregated_edges_per_step": aggregated_all / (K * world),
+                       "reference_equivalent_aggregated_per_step": ref_equiv_all / (K * world),
+                       "sampled_edges_per_s": sampled_all / elapsed, "aggregated_edges_per_s": aggregated_all / elapsed,
+                       "setup_s": round(setup_s, 1)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+def run_cpu_baseline(eng, model, my, fanouts, W, n, d):
+    """oracle (C port of the reference sampler + collate) + fp32 torch CPU forward over the WHOLE union graph
+    (reference semantics), single thread for the sampler, on a bounded sample of the same workload."""
+    import oracle
+    from oracle import gnn_ref
+    from oracle.oracle import tree_edges
+
+    rowptr, col = eng.graph_to_host()
+    import ctypes as C
+    x = np.empty((n, d), dtype=np.float32)
+    eng._lib.gigl_memcpy(eng._ctx, C.c_void_p(x.ctypes.data), 0, eng._feat_ptr, 1, x.nbytes)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    L = len(fanouts)
+    budget_s, t_used, edges, batches = 20.0, 0.0, 0, 0
+    sub = 128  # roots per CPU batch (bounded sample: the full B=1024 batch costs minutes on one core)
+    torch.set_num_threads(1)
+    i = W
+    while t_used < budget_s and batches < 64:
+        roots = my[i % my.shape[0]].cpu().numpy().view(np.uint32)[:sub]
+        t0 = time.perf_counter()
+        nbr, cnt = oracle.sample_khop(rowptr, col, roots, fanouts, canonical=True)
+        u = oracle.union_build(roots, fanouts, nbr)
+        ei = gnn_ref.union_edge_index(u["rowptr"], u["col"])
+        xs = torch.from_numpy(x[u["nodes"]])
+        out = gnn_ref.graphsage_forward(xs, ei, sd, L)
+        _ = out[u["root_local"]]
+        t_used += time.perf_counter() - t0
+        edges += int(sum(int(c.sum()) for c in cnt)) + L * int(u["meta"][1])
+        batches += 1
+        i += 1
+    return {"value": edges / t_used, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"{batches} batches of {sub} roots of the same graph/fanout, {t_used:.1f} s; sampler+collate = "
+                      "oracle/gigl_oracle.c (1 thread), forward = fp32 torch CPU (1 thread) over the whole union graph "
+                      "(L*|E_union| aggregated edges, the reference's execution order)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,13 @@ SYMBOLS = [
     "gigl_graph_info", "gigl_graph_device_ptrs", "gigl_graph_destroy", "gigl_features_load",
     "gigl_features_device_ptr", "gigl_features_destroy", "gigl_sample_khop", "gigl_sample_positives",
     "gigl_union_capacity", "gigl_union_build", "gigl_gather_mean", "gigl_linear",
+    "gigl_profile_enable", "gigl_profile_read", "gigl_profile_reset",
 ]
+
+KERNEL_IDS = {
+    "expand": 0, "expand_heavy": 1, "find_heavy": 2, "union_insert": 3, "union_relax": 4, "union_nodes": 5,
+    "union_edge_sort": 6, "union_csr": 7, "gather_mean": 8, "linear": 9,
+}
 
 
 class GiglTree(C.Structure):
@@ -70,6 +76,10 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C gigl_amd/csrc`. gigl_amd has no CPU fallback.")
+    # torch first: the library must share the HIP runtime (libamdhip64) torch already mapped, or the
+    # two would each own a runtime and device pointers could not be exchanged
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     P = C.POINTER
@@ -97,6 +107,9 @@ def load() -> C.CDLL:
         "gigl_union_build": [vp, vp, P(GiglTree), P(GiglUnion)],
         "gigl_gather_mean": [vp, vp, i32, i32, vp, vp, vp, vp, i64, vp],
         "gigl_linear": [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp],
+        "gigl_profile_enable": [vp, C.c_uint32, i32],
+        "gigl_profile_read": [vp, i32, P(C.c_double), P(i64)],
+        "gigl_profile_reset": [vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

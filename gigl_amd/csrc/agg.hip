@@ -295,6 +295,7 @@ int32_t gigl_gather_mean(gigl_ctx* ctx, const void* src, int32_t src_dtype, int3
   GIGL_REQUIRE(ctx, d > 0 && rows_cap >= 0, "bad sizes");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   if (src_dtype == GIGL_DTYPE_F32)
     return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, col, n_rows_dev,
                                 rows_cap, out);
@@ -314,6 +315,7 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (m_cap == 0) return GIGL_OK;
   hipStream_t st = ctx->stream;
+  gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
   if (n > 32) {
     constexpr int MT = 1, NT = 2;
     int64_t tiles = ((m_cap + 32 * MT - 1) / (32 * MT)) * ((n + 32 * NT - 1) / (32 * NT));

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "../../include/gigl_hip.h"
 
@@ -22,6 +23,21 @@ struct gigl_ctx {
   char* arena = nullptr;
   int64_t arena_bytes = 0;
   int64_t arena_off = 0;
+  // optional per-kernel HIP-event timing (gigl_profile_*): events are recorded on ctx->stream
+  // around the launches whose id bit is set in prof_mask
+  uint32_t prof_mask = 0;
+  std::vector<hipEvent_t> prof_ev;   // 2 per recorded launch
+  std::vector<int32_t> prof_id;      // kernel id per recorded launch
+  size_t prof_used = 0;              // launches recorded so far
+};
+
+// RAII bracket: records start/stop events around a launch when profiling of `id` is on
+struct gigl_prof_scope {
+  gigl_ctx* ctx;
+  bool on;
+  size_t slot;
+  gigl_prof_scope(gigl_ctx* c, int id);
+  ~gigl_prof_scope();
 };
 
 struct gigl_graph {

@@ -36,9 +36,61 @@ void* gigl_arena_alloc(gigl_ctx* ctx, int64_t bytes) {
   return ctx->arena + off;
 }
 
+gigl_prof_scope::gigl_prof_scope(gigl_ctx* c, int id) : ctx(c), on(false), slot(0) {
+  if (!(c->prof_mask & (1u << id)) || c->prof_used * 2 + 2 > c->prof_ev.size()) return;
+  slot = c->prof_used++;
+  c->prof_id[slot] = id;
+  on = hipEventRecord(c->prof_ev[2 * slot], c->stream) == hipSuccess;
+}
+
+gigl_prof_scope::~gigl_prof_scope() {
+  if (on) hipEventRecord(ctx->prof_ev[2 * slot + 1], ctx->stream);
+}
+
 extern "C" {
 
 int32_t gigl_version(void) { return 100; }
+
+int32_t gigl_profile_enable(gigl_ctx* ctx, uint32_t mask, int32_t capacity) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, capacity >= 0 && capacity <= (1 << 20), "bad profile capacity");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->prof_mask = mask;
+  ctx->prof_used = 0;
+  while (ctx->prof_ev.size() < (size_t)capacity * 2) {
+    hipEvent_t e;
+    GIGL_HIP_CHECK(ctx, hipEventCreate(&e));
+    ctx->prof_ev.push_back(e);
+  }
+  ctx->prof_id.assign(ctx->prof_ev.size() / 2, -1);
+  return GIGL_OK;
+}
+
+int32_t gigl_profile_reset(gigl_ctx* ctx) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->prof_used = 0;
+  return GIGL_OK;
+}
+
+int32_t gigl_profile_read(gigl_ctx* ctx, int32_t kernel_id, double* total_ms, int64_t* launches) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, kernel_id >= 0 && kernel_id < GIGL_K_COUNT, "bad kernel id");
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0.0;
+  int64_t n = 0;
+  for (size_t s = 0; s < ctx->prof_used; ++s) {
+    if (ctx->prof_id[s] != kernel_id) continue;
+    float ms = 0.f;
+    GIGL_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[2 * s], ctx->prof_ev[2 * s + 1]));
+    tot += ms;
+    ++n;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = n;
+  return GIGL_OK;
+}
 
 int32_t gigl_ctx_create(int32_t device, gigl_ctx** out) {
   if (!out) return GIGL_E_INVALID_ARG;
@@ -64,6 +116,7 @@ int32_t gigl_ctx_destroy(gigl_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   if (ctx->arena) hipFree(ctx->arena);
+  for (hipEvent_t e : ctx->prof_ev) hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return GIGL_OK;
@@ -73,15 +126,11 @@ const char* gigl_last_error(gigl_ctx* ctx) { return ctx ? ctx->err.c_str() : "nu
 
 int32_t gigl_ctx_set_stream(gigl_ctx* ctx, void* hip_stream) {
   if (!ctx) return GIGL_E_INVALID_ARG;
-  if (ctx->stream) hipStreamSynchronize(ctx->stream);
-  if (hip_stream) {
-    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
-    ctx->stream = (hipStream_t)hip_stream;
-    ctx->own_stream = false;
-  } else if (!ctx->own_stream) {
-    GIGL_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    ctx->own_stream = true;
-  }
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+  ctx->stream = (hipStream_t)hip_stream;  // NULL is a valid handle: the legacy default stream
+  ctx->own_stream = false;
   return GIGL_OK;
 }
 

@@ -313,7 +313,7 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
                          const int32_t* fanouts, int32_t hops, int32_t sampling_seed, int32_t mode,
                          gigl_tree* out) {
   if (!ctx) return GIGL_E_INVALID_ARG;
-  GIGL_REQUIRE(ctx, g && roots && fanouts && out, "null argument");
+  GIGL_REQUIRE(ctx, g && (roots || b == 0) && fanouts && out, "null argument");
   GIGL_REQUIRE(ctx, hops >= 1 && hops <= GIGL_MAX_HOPS, "hops must be in [1,%d]", GIGL_MAX_HOPS);
   GIGL_REQUIRE(ctx, b >= 0, "negative batch");
   GIGL_REQUIRE(ctx, mode == GIGL_MODE_SPARK_HASH || mode == GIGL_MODE_FAST, "bad mode %d", mode);
@@ -366,13 +366,22 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
     if (mode == GIGL_MODE_FAST) {
       hipLaunchKernelGGL(expand_fast_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
     } else {
-      GIGL_HIP_CHECK(ctx, hipMemsetAsync(heavy_count, 0, 4, ctx->stream));
-      hipLaunchKernelGGL(find_heavy_kernel, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0,
-                         ctx->stream, a, heavy_list, heavy_count);
-      hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
-      int64_t hb = parents < 2048 ? parents : 2048;
-      hipLaunchKernelGGL(expand_heavy_kernel, dim3((unsigned)hb), dim3(256), 0, ctx->stream, a,
-                         heavy_list, heavy_count);
+      {
+        gigl_prof_scope ps(ctx, GIGL_K_FIND_HEAVY);
+        GIGL_HIP_CHECK(ctx, hipMemsetAsync(heavy_count, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(find_heavy_kernel, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0,
+                           ctx->stream, a, heavy_list, heavy_count);
+      }
+      {
+        gigl_prof_scope ps(ctx, GIGL_K_EXPAND);
+        hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+      }
+      {
+        gigl_prof_scope ps(ctx, GIGL_K_EXPAND_HEAVY);
+        int64_t hb = parents < 2048 ? parents : 2048;
+        hipLaunchKernelGGL(expand_heavy_kernel, dim3((unsigned)hb), dim3(256), 0, ctx->stream, a,
+                           heavy_list, heavy_count);
+      }
     }
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     a.anc[k] = out->nbr[k];

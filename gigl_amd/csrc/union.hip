@@ -244,7 +244,7 @@ int32_t gigl_union_capacity(int32_t b, const int32_t* fanouts, int32_t hops, int
 int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree,
                          gigl_union* out) {
   if (!ctx) return GIGL_E_INVALID_ARG;
-  GIGL_REQUIRE(ctx, roots && tree && out, "null argument");
+  GIGL_REQUIRE(ctx, tree && out && (roots || tree->b == 0), "null argument");
   GIGL_REQUIRE(ctx, out->meta && out->nodes && out->rowptr && out->col && out->root_local,
                "union output buffers are null");
   const int hops = tree->hops, b = tree->b;
@@ -321,31 +321,46 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
   void* tmp = gigl_arena_alloc(ctx, (int64_t)tmp_bytes);
   if (!tmp || !escan) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
 
-  GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.keys, 0xFF, cap * 4, st));
-  GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.firstpos, 0xFF, cap * 4, st));
-  // LVL_INF = 0x00100000: bytes are not uniform, so fill via 0x7F (0x7F7F7F7F > any real level)
-  GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.level, 0x7F, cap * 4, st));
-
   const int TB = 256;
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
-  hipLaunchKernelGGL(insert_kernel, grid(T), dim3(TB), 0, st, a);
-  for (int r = 0; r < hops; ++r) hipLaunchKernelGGL(relax_kernel, grid(E), dim3(TB), 0, st, a);
-  hipLaunchKernelGGL(flag_kernel, grid(T), dim3(TB), 0, st, a, flags);
-  GIGL_HIP_CHECK(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, scan, (int)T, st));
-  hipLaunchKernelGGL(meta_kernel, dim3(1), dim3(64), 0, st, a, flags, scan, out->meta, level_base);
-  hipLaunchKernelGGL(assign_kernel, grid(T), dim3(TB), 0, st, a, flags, scan, level_base, out->nodes);
-  hipLaunchKernelGGL(root_local_kernel, grid(b), dim3(TB), 0, st, a, out->root_local);
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_INSERT);
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.keys, 0xFF, cap * 4, st));
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.firstpos, 0xFF, cap * 4, st));
+    // LVL_INF = 0x00100000: bytes are not uniform, so fill via 0x7F (0x7F7F7F7F > any real level)
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.level, 0x7F, cap * 4, st));
+    hipLaunchKernelGGL(insert_kernel, grid(T), dim3(TB), 0, st, a);
+  }
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_RELAX);
+    for (int r = 0; r < hops; ++r) hipLaunchKernelGGL(relax_kernel, grid(E), dim3(TB), 0, st, a);
+  }
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_NODES);
+    hipLaunchKernelGGL(flag_kernel, grid(T), dim3(TB), 0, st, a, flags);
+    GIGL_HIP_CHECK(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, scan, (int)T, st));
+    hipLaunchKernelGGL(meta_kernel, dim3(1), dim3(64), 0, st, a, flags, scan, out->meta, level_base);
+    hipLaunchKernelGGL(assign_kernel, grid(T), dim3(TB), 0, st, a, flags, scan, level_base, out->nodes);
+    hipLaunchKernelGGL(root_local_kernel, grid(b), dim3(TB), 0, st, a, out->root_local);
+  }
   if (E > 0) {
-    hipLaunchKernelGGL(edge_key_kernel, grid(E), dim3(TB), 0, st, a, ekeys);
-    GIGL_HIP_CHECK(ctx, hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, ekeys, sorted, (int)E, 0,
-                                                          key_bits, st));
+    {
+      gigl_prof_scope ps(ctx, GIGL_K_UNION_EDGE_SORT);
+      hipLaunchKernelGGL(edge_key_kernel, grid(E), dim3(TB), 0, st, a, ekeys);
+      GIGL_HIP_CHECK(ctx, hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, ekeys, sorted, (int)E, 0,
+                                                            key_bits, st));
+    }
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_CSR);
     hipLaunchKernelGGL(edge_flag_kernel, grid(E), dim3(TB), 0, st, sorted, E, eflags);
     GIGL_HIP_CHECK(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, eflags, escan, (int)E, st));
     hipLaunchKernelGGL(edge_write_kernel, grid(E), dim3(TB), 0, st, sorted, eflags, escan, E, out->col,
                        ukeys, out->meta);
+    hipLaunchKernelGGL(rowptr_kernel, grid(cap_nodes + 1), dim3(TB), 0, st, ukeys, out->meta,
+                       out->rowptr, out->cap_nodes);
+  } else {
+    hipLaunchKernelGGL(rowptr_kernel, grid(cap_nodes + 1), dim3(TB), 0, st, ukeys, out->meta,
+                       out->rowptr, out->cap_nodes);
   }
-  hipLaunchKernelGGL(rowptr_kernel, grid(cap_nodes + 1), dim3(TB), 0, st, ukeys, out->meta,
-                     out->rowptr, out->cap_nodes);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -81,6 +81,22 @@ class HipEngine:
     def synchronize(self) -> None:
         check(self._lib.gigl_ctx_synchronize(self._ctx), self._ctx)
 
+    def profile_enable(self, kernels: Sequence[str] = (), capacity: int = 0) -> None:
+        """HIP-event timing of the named kernels (see _lib.KERNEL_IDS); empty = off"""
+        mask = 0
+        for k in kernels:
+            mask |= 1 << _lib.KERNEL_IDS[k]
+        check(self._lib.gigl_profile_enable(self._ctx, mask, capacity), self._ctx)
+
+    def profile_read(self, kernel: str):
+        """-> (total_ms, launches) since the last enable/reset (synchronises the stream)"""
+        ms, n = C.c_double(), C.c_int64()
+        check(self._lib.gigl_profile_read(self._ctx, _lib.KERNEL_IDS[kernel], C.byref(ms), C.byref(n)), self._ctx)
+        return ms.value, n.value
+
+    def profile_reset(self) -> None:
+        check(self._lib.gigl_profile_reset(self._ctx), self._ctx)
+
     def close(self) -> None:
         if getattr(self, "_ctx", None):
             for h, fn in ((self._graph, self._lib.gigl_graph_destroy), (self._graph_out, self._lib.gigl_graph_destroy),

@@ -1,0 +1,103 @@
+"""GNN encoders over the device-resident batch union graph.
+
+Mirror of the reference's homogeneous PyG models for this path:
+  GraphSAGE  python/gigl/src/common/models/pyg/homogeneous.py:157-202 (BasicHomogeneousGNN.forward :107-153)
+Parameter names follow PyG 2.5.3's SAGEConv (`conv_layers.{i}.lin_l.{weight,bias}`,
+`conv_layers.{i}.lin_r.weight`) so state_dicts interchange with the reference model
+(names come from the un-vendored PyG: "parity unpinned").
+
+Forward = layer-wise trimmed schedule on the level-ordered union graph (include/gigl_hip.h):
+layer l of L only computes the rows that can still reach a root, always a prefix
+[0, meta[LEVEL0 + L-1-l]).  For the roots this is exactly the reference's result, which runs every
+layer over the whole union graph (SURVEY.md §0 fact 4, §7 "Batch-union semantics").
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from ._lib import GIGL_META_LEVEL0
+from .engine import HipEngine, Tree, UnionGraph
+
+
+@dataclass
+class HipBatch:
+    """what the HIP path hands to a model: the sampled trees and their union graph, all in HBM"""
+    engine: HipEngine
+    tree: Tree
+    union: UnionGraph
+    x: Optional[torch.Tensor] = None  # None: hydrate from the engine's resident feature table
+
+    @property
+    def root_local(self) -> torch.Tensor:
+        return self.union.root_local[: self.tree.b]
+
+
+class SAGEConv(nn.Module):
+    """parameter holder with PyG SAGEConv's layout: out = lin_l(mean_j x_j) + lin_r(x_i)"""
+
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True, root_weight: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=bias)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False) if root_weight else None
+
+    def fused_weight(self) -> torch.Tensor:
+        """[out, 2*in] = [W_l | W_r]: one projection of the [mean | self] operand"""
+        wr = self.lin_r.weight if self.lin_r is not None else torch.zeros_like(self.lin_l.weight)
+        return torch.cat([self.lin_l.weight, wr], dim=1).contiguous()
+
+
+class GraphSAGE(nn.Module):
+    def __init__(self, in_dim: int, hid_dim: int, out_dim: int, num_layers: int = 2,
+                 activation_after_last_conv: bool = False, should_l2_normalize_embedding_layer_output: bool = False,
+                 **conv_kwargs):
+        super().__init__()
+        self.in_dim, self.hid_dim, self.out_dim, self.num_layers = in_dim, hid_dim, out_dim, num_layers
+        self.activation_after_last_conv = activation_after_last_conv
+        self.should_l2_normalize_embedding_layer_output = should_l2_normalize_embedding_layer_output
+        bias = bool(conv_kwargs.get("bias", True))
+        root_weight = bool(conv_kwargs.get("root_weight", True))
+        self.conv_layers = nn.ModuleList([
+            SAGEConv(in_dim if i == 0 else hid_dim, hid_dim if i < num_layers - 1 else out_dim, bias=bias,
+                     root_weight=root_weight) for i in range(num_layers)])
+        self._ws = None  # workspace cache
+
+    @torch.no_grad()
+    def forward(self, batch: HipBatch) -> torch.Tensor:
+        """returns [cap, out_dim]; rows [0, n_level0) are the distinct roots' outputs
+        (index with batch.root_local for per-root rows in batch order)"""
+        eng, u = batch.engine, batch.union
+        L = self.num_layers
+        assert u.hops == L, "one hop per layer"
+        cap = int(u.nodes.numel())
+        h = None
+        for l, conv in enumerate(self.conv_layers):
+            n_rows = u.meta[GIGL_META_LEVEL0 + (L - 1 - l): GIGL_META_LEVEL0 + (L - l)]
+            d = conv.in_channels
+            if l == 0 and batch.x is None:
+                a = eng.gather_mean(None, d, u.nodes, u.rowptr, u.col, n_rows, cap, out=self._buf("a", l, cap, 2 * d))
+            elif l == 0:
+                a = eng.gather_mean(batch.x, d, None, u.rowptr, u.col, n_rows, cap, out=self._buf("a", l, cap, 2 * d))
+            else:
+                a = eng.gather_mean(h, d, None, u.rowptr, u.col, n_rows, cap, out=self._buf("a", l, cap, 2 * d))
+            act = 1 if (l < L - 1 or self.activation_after_last_conv) else 0
+            bias = conv.lin_l.bias
+            h = eng.linear(a, conv.fused_weight(), bias, n_rows, cap, act, out=self._buf("h", l, cap, conv.out_channels))
+        if self.should_l2_normalize_embedding_layer_output:
+            h = torch.nn.functional.normalize(h, p=2, dim=1)
+        return h
+
+    def _buf(self, kind: str, layer: int, rows: int, cols: int) -> torch.Tensor:
+        if self._ws is None:
+            self._ws = {}
+        key = (kind, layer)
+        t = self._ws.get(key)
+        dev = self.conv_layers[0].lin_l.weight.device
+        if t is None or t.shape[0] < rows or t.shape[1] != cols or t.device != dev:
+            t = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+            self._ws[key] = t
+        return t[:rows]

@@ -61,7 +61,8 @@ int32_t gigl_version(void);
 int32_t gigl_ctx_create(int32_t device, gigl_ctx** out);
 int32_t gigl_ctx_destroy(gigl_ctx* ctx);
 const char* gigl_last_error(gigl_ctx* ctx);
-/* bind the ctx to a caller-owned hipStream_t (NULL = the ctx's own stream) */
+/* bind the ctx to a caller-owned hipStream_t; NULL is the legacy default stream.  Until this is
+ * called the ctx runs on a private non-blocking stream created by gigl_ctx_create. */
 int32_t gigl_ctx_set_stream(gigl_ctx* ctx, void* hip_stream);
 int32_t gigl_ctx_synchronize(gigl_ctx* ctx);
 /* pre-size the ctx scratch arena (bytes); grows on demand otherwise (grow = hipMalloc, so
@@ -71,6 +72,25 @@ int32_t gigl_ctx_reserve(gigl_ctx* ctx, int64_t bytes);
  * "block_to_host" of the boundary — results leave HBM only through this or the caller's own copies */
 int32_t gigl_memcpy(gigl_ctx* ctx, void* dst, int32_t dst_loc, const void* src, int32_t src_loc,
                     int64_t bytes);
+
+/* ---- per-kernel timing with HIP events recorded on the ctx stream (the reference's analogue is the
+ *      @profileit wall timer, python/gigl/common/metrics/decorators.py:68-111).  `mask` selects
+ *      kernel ids (bit i = GIGL_K_*); capacity = max launches kept.  gigl_profile_read synchronises
+ *      the stream and returns the summed duration and launch count of one kernel id. */
+#define GIGL_K_EXPAND 0        /* frontier-expand, wave-per-parent (all hops) */
+#define GIGL_K_EXPAND_HEAVY 1  /* frontier-expand, workgroup-per-parent rows */
+#define GIGL_K_FIND_HEAVY 2
+#define GIGL_K_UNION_INSERT 3
+#define GIGL_K_UNION_RELAX 4
+#define GIGL_K_UNION_NODES 5   /* flag + scan + assign */
+#define GIGL_K_UNION_EDGE_SORT 6
+#define GIGL_K_UNION_CSR 7     /* unique + scan + col/rowptr */
+#define GIGL_K_GATHER_MEAN 8
+#define GIGL_K_LINEAR 9
+#define GIGL_K_COUNT 10
+int32_t gigl_profile_enable(gigl_ctx* ctx, uint32_t mask, int32_t capacity);
+int32_t gigl_profile_read(gigl_ctx* ctx, int32_t kernel_id, double* total_ms, int64_t* launches);
+int32_t gigl_profile_reset(gigl_ctx* ctx);
 
 /* ---- graph ingest: replaces loadEdgeDataframeIntoSparkSql + enforceBidirectionalization
  *      (scala/subgraph_sampler/src/main/scala/libs/task/pureSpark/SGSPureSparkV1Task.scala:120-286)

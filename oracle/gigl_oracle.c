@@ -106,14 +106,16 @@ int gigl_oracle_hash_permutation(const uint32_t* sorted_arr, int64_t n, int32_t 
  *          permute(K={_0_hop,_1_hop}, counter 2) -> slice(1, f)
  *   hop k>2: same rule continued along the path (the reference hard-wires 2 hops; per-hop fanouts
  *          come from SamplingOp DAGs, GraphDBSampler.scala:40-148).
- * rowptr/col: CSC by destination, rows ascending.  Output in PERMUTATION order (slice order);
- * tests canonicalise to ascending before comparing with the HIP path (the reference output is a set).
+ * rowptr/col: CSC by destination, rows ascending.  canonical_order == 0: each parent's samples in
+ * PERMUTATION order (the reference's slice order); == 1: the same SET written ascending (the HIP
+ * path's canonical form; the reference output is a set).  The tree positions of deeper hops follow
+ * the order chosen here; the sampled sets do not depend on it (K is a sum over the path).
  * first_counter = value of the process-global _counter at the first hop (1 for a fresh JVM).
  * ---------------------------------------------------------------------------------------- */
 int gigl_oracle_sample_khop(int64_t n_nodes, const int64_t* rowptr, const uint32_t* col,
                             const uint32_t* roots, int32_t b, const int32_t* fanouts, int32_t hops,
-                            int32_t sampling_seed, int32_t first_counter, uint32_t** nbr,
-                            int32_t** cnt) {
+                            int32_t sampling_seed, int32_t first_counter, int32_t canonical_order,
+                            uint32_t** nbr, int32_t** cnt) {
   if (hops < 1 || hops > 4) return -1;
   int64_t parents = b;
   const uint32_t* parent_ids = roots;
@@ -144,6 +146,17 @@ int gigl_oracle_sample_khop(int64_t n_nodes, const int64_t* rowptr, const uint32
                                        first_counter + k, perm);
           c = (int32_t)(deg < f ? deg : f);
           for (int32_t j = 0; j < c; ++j) o[j] = perm[j];
+          if (canonical_order) { /* the sampled SET in ascending id order (insertion sort, c <= f) */
+            for (int32_t j = 1; j < c; ++j) {
+              uint32_t x = o[j];
+              int32_t q = j - 1;
+              while (q >= 0 && o[q] > x) {
+                o[q + 1] = o[q];
+                --q;
+              }
+              o[q + 1] = x;
+            }
+          }
         }
       }
       for (int32_t j = c; j < f; ++j) o[j] = GIGL_INVALID;

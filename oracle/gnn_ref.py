@@ -1,0 +1,98 @@
+"""fp32 CPU restatement of the reference's GNN forward for this path (TEST INFRASTRUCTURE ONLY).
+
+The arithmetic lives in torch-geometric==2.5.3 (python/pyproject.toml:53), which is NOT under
+/root/reference and not installable here, and no reference test pins conv outputs -> "parity
+unpinned" (SURVEY.md §8(c)).  These functions restate PyG 2.5.3's documented formulas with plain
+torch ops, in the reference's execution order: EVERY layer over the WHOLE batch union graph
+(python/gigl/src/common/models/pyg/homogeneous.py:107-153).
+
+  SAGEConv (aggr=mean, root_weight=True, bias=True):  out_i = W_l·mean_{j->i} x_j + b_l + W_r·x_i
+  GCNConv  (add_self_loops, sym. norm):               out = D^-1/2 (A+I) D^-1/2 X W^T + b
+  GATConv  (heads H, concat, negative_slope 0.2, add_self_loops): see gat_conv below
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+
+def scatter_mean(src_rows: torch.Tensor, index: torch.Tensor, n: int) -> torch.Tensor:
+    out = torch.zeros((n, src_rows.shape[1]), dtype=src_rows.dtype)
+    out.index_add_(0, index, src_rows)
+    cnt = torch.bincount(index, minlength=n).clamp(min=1).to(src_rows.dtype)
+    return out / cnt[:, None]
+
+
+def sage_conv(x: torch.Tensor, edge_index: torch.Tensor, w_l: torch.Tensor, b_l: Optional[torch.Tensor],
+              w_r: Optional[torch.Tensor]) -> torch.Tensor:
+    src, dst = edge_index[0], edge_index[1]
+    mean = scatter_mean(x[src], dst, x.shape[0])
+    out = mean @ w_l.T
+    if b_l is not None:
+        out = out + b_l
+    if w_r is not None:
+        out = out + x @ w_r.T
+    return out
+
+
+def graphsage_forward(x: torch.Tensor, edge_index: torch.Tensor, state_dict, num_layers: int,
+                      activation_after_last_conv: bool = False) -> torch.Tensor:
+    """BasicHomogeneousGNN.forward with GraphSAGE convs, relu, no batchnorm/dropout (eval)"""
+    h = x
+    for i in range(num_layers):
+        p = f"conv_layers.{i}."
+        h = sage_conv(h, edge_index, state_dict[p + "lin_l.weight"], state_dict.get(p + "lin_l.bias"),
+                      state_dict.get(p + "lin_r.weight"))
+        if i < num_layers - 1 or activation_after_last_conv:
+            h = torch.relu(h)
+    return h
+
+
+def gcn_conv(x: torch.Tensor, edge_index: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    n = x.shape[0]
+    loops = torch.arange(n, dtype=edge_index.dtype)
+    keep = edge_index[0] != edge_index[1]  # add_remaining_self_loops keeps one loop per node
+    src = torch.cat([edge_index[0][keep], loops])
+    dst = torch.cat([edge_index[1][keep], loops])
+    deg = torch.zeros(n, dtype=x.dtype).index_add_(0, dst, torch.ones(dst.numel(), dtype=x.dtype))
+    dinv = deg.pow(-0.5)
+    dinv[torch.isinf(dinv)] = 0
+    norm = dinv[src] * dinv[dst]
+    xw = x @ w.T
+    out = torch.zeros_like(xw).index_add_(0, dst, xw[src] * norm[:, None])
+    return out + b if b is not None else out
+
+
+def gat_conv(x: torch.Tensor, edge_index: torch.Tensor, w: torch.Tensor, att_src: torch.Tensor,
+             att_dst: torch.Tensor, bias: Optional[torch.Tensor], heads: int, concat: bool = True,
+             negative_slope: float = 0.2) -> torch.Tensor:
+    """PyG GATConv: h = xW viewed [N,H,C]; e_ij = leaky_relu(a_src·h_j + a_dst·h_i); softmax over the
+    in-edges of i (self loops removed then added); out_i = sum_j alpha_ij h_j; concat or mean heads."""
+    n = x.shape[0]
+    c = w.shape[0] // heads
+    h = (x @ w.T).view(n, heads, c)
+    loops = torch.arange(n, dtype=edge_index.dtype)
+    keep = edge_index[0] != edge_index[1]
+    src = torch.cat([edge_index[0][keep], loops])
+    dst = torch.cat([edge_index[1][keep], loops])
+    a_s = (h * att_src.view(1, heads, c)).sum(-1)
+    a_d = (h * att_dst.view(1, heads, c)).sum(-1)
+    e = torch.nn.functional.leaky_relu(a_s[src] + a_d[dst], negative_slope)
+    emax = torch.full((n, heads), float("-inf"), dtype=x.dtype).scatter_reduce(0, dst[:, None].expand(-1, heads), e,
+                                                                              reduce="amax", include_self=True)
+    ex = torch.exp(e - emax[dst])
+    den = torch.zeros((n, heads), dtype=x.dtype).index_add_(0, dst, ex)
+    alpha = ex / (den[dst] + 1e-16)
+    out = torch.zeros((n, heads, c), dtype=x.dtype).index_add_(0, dst, h[src] * alpha[:, :, None])
+    out = out.reshape(n, heads * c) if concat else out.mean(1)
+    return out + bias if bias is not None else out
+
+
+def union_edge_index(rowptr, col) -> torch.Tensor:
+    """CSR-by-destination (int arrays) -> PyG edge_index [2, E] (row 0 = src, row 1 = dst)"""
+    rowptr = torch.as_tensor(rowptr, dtype=torch.int64)
+    col = torch.as_tensor(col, dtype=torch.int64)
+    deg = rowptr[1:] - rowptr[:-1]
+    dst = torch.repeat_interleave(torch.arange(deg.numel(), dtype=torch.int64), deg)
+    return torch.stack([col, dst])

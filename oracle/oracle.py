@@ -57,8 +57,9 @@ def hash_permutation(sorted_arr, internal_seed: int, sampling_seed: int = 42, co
 
 
 def sample_khop(rowptr, col, roots, fanouts: Sequence[int], sampling_seed: int = 42,
-                first_counter: int = 1) -> Tuple[List[np.ndarray], List[np.ndarray]]:
-    """Tree-layout k-hop sample in PERMUTATION order; returns (nbr[k], cnt[k]) lists."""
+                first_counter: int = 1, canonical: bool = False) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """Tree-layout k-hop sample; per-parent order = permutation order (reference slice order) or, with
+    canonical=True, ascending ids (the HIP path's form).  Returns (nbr[k], cnt[k]) lists."""
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
     col = np.ascontiguousarray(col, dtype=np.uint32)
     roots = np.ascontiguousarray(roots, dtype=np.uint32)
@@ -74,14 +75,26 @@ def sample_khop(rowptr, col, roots, fanouts: Sequence[int], sampling_seed: int =
     rc = _L().gigl_oracle_sample_khop(
         C.c_int64(rowptr.size - 1), _p(rowptr, C.c_int64), _p(col, C.c_uint32),
         _p(roots, C.c_uint32), C.c_int32(b), _p(f, C.c_int32), C.c_int32(hops),
-        C.c_int32(sampling_seed), C.c_int32(first_counter), nbr_p, cnt_p)
+        C.c_int32(sampling_seed), C.c_int32(first_counter), C.c_int32(1 if canonical else 0), nbr_p, cnt_p)
     assert rc == 0, rc
     return nbr, cnt
 
 
-def canonicalise(nbr: Sequence[np.ndarray], fanouts: Sequence[int]) -> List[np.ndarray]:
-    """ascending order within every parent (INVALID = 0xFFFFFFFF sorts last) — the HIP path's form"""
-    return [np.sort(a.reshape(-1, int(f)), axis=1).reshape(-1) for a, f in zip(nbr, fanouts)]
+def tree_edges(roots, fanouts: Sequence[int], nbr: Sequence[np.ndarray]):
+    """per-root set of (src, dst) global-id edges of a tree-layout sample (order-independent view)"""
+    roots = np.asarray(roots, dtype=np.uint32)
+    out = [set() for _ in range(roots.size)]
+    per_root = 1
+    parent = None
+    for k, f in enumerate(fanouts):
+        per_root *= int(f)
+        a = nbr[k]
+        for j in np.nonzero(a != INVALID)[0]:
+            p = j // int(f)
+            dst = roots[p] if k == 0 else parent[p]
+            out[j // per_root].add((int(a[j]), int(dst)))
+        parent = a
+    return out
 
 
 def collate_reference(node_lists: Sequence[np.ndarray], edge_lists: Sequence[Tuple[np.ndarray, np.ndarray]],

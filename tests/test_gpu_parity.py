@@ -5,7 +5,6 @@ import pytest
 import torch
 
 import oracle
-from oracle.oracle import canonicalise
 from helpers import INVALID, load_fixture_graph, rmat_edges
 
 pytestmark = pytest.mark.gpu
@@ -25,8 +24,7 @@ def _u32(t):
 
 def _check_tree(eng, rowptr, col, roots, fanouts):
     tree = eng.sample_khop(roots, fanouts)
-    nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots, fanouts)
-    nbr_o = canonicalise(nbr_o, fanouts)
+    nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots, fanouts, canonical=True)
     for k in range(len(fanouts)):
         assert np.array_equal(tree.cnt[k].cpu().numpy(), cnt_o[k]), f"cnt hop {k}"
         assert np.array_equal(_u32(tree.nbr[k]), nbr_o[k]), f"nbr hop {k}"
@@ -95,8 +93,7 @@ def test_int32_wraparound_of_key_sum(eng):
     roots = np.arange(0, 1024, 7, dtype=np.uint32)
     for seed in (2**31 - 1, -(2**31), 1234567891):
         tree = eng.sample_khop(roots, [4, 3], sampling_seed=seed)
-        nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots, [4, 3], sampling_seed=seed)
-        nbr_o = canonicalise(nbr_o, [4, 3])
+        nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots, [4, 3], sampling_seed=seed, canonical=True)
         for k in range(2):
             assert np.array_equal(_u32(tree.nbr[k]), nbr_o[k])
 
@@ -109,9 +106,9 @@ def test_positives_counter_three(eng):
     eng.load_csc(rowptr, col, out_graph=True)
     roots = np.arange(0, n, 3, dtype=np.uint32)
     pos, cnt = eng.sample_positives(roots, 2)
-    nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots, [2], first_counter=3)
+    nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots, [2], first_counter=3, canonical=True)
     assert np.array_equal(cnt.cpu().numpy(), cnt_o[0])
-    assert np.array_equal(_u32(pos), canonicalise(nbr_o, [2])[0])
+    assert np.array_equal(_u32(pos), nbr_o[0])
 
 
 @pytest.mark.parametrize("fanouts,b", [([10, 5], 64), ([25, 10], 300), ([4, 3, 2], 50), ([6], 33)])
@@ -203,3 +200,54 @@ def test_linear_against_fp32_reference(eng, m, k, n, act):
     # no bias
     y2 = eng.linear(a.to(dev), w.to(dev), None, torch.tensor([m], dtype=torch.int32, device=dev), m + 9, 0)
     np.testing.assert_allclose(y2.cpu().numpy()[:m], (a[:m].double() @ w.double().T).float().numpy(), rtol=1e-5, atol=2e-5)
+
+
+def _ref_collate_from_tree(roots, fanouts, nbr):
+    """per-root RootedNodeNeighborhood node/edge lists in the reference's construction order
+    (hop-1 ++ hop-2 nodes, distinct, root appended: SGSPureSparkV1Task.scala:721-735,782-815)"""
+    from oracle.oracle import tree_edges
+    per_root = tree_edges(roots, fanouts, nbr)
+    node_lists, edge_lists = [], []
+    for r, es in zip(roots.tolist(), per_root):
+        es = sorted(es)
+        nodes = []
+        for s, d in es:
+            for v in (s, d):
+                if v not in nodes:
+                    nodes.append(v)
+        if r not in nodes:
+            nodes.append(r)
+        node_lists.append(np.array(nodes, dtype=np.uint32))
+        edge_lists.append((np.array([e[0] for e in es], dtype=np.uint32), np.array([e[1] for e in es], dtype=np.uint32)))
+    return node_lists, edge_lists
+
+
+@pytest.mark.parametrize("d,hid,out,fanouts,b", [(100, 256, 47, [25, 10], 200), (1433, 16, 7, [10, 5], 16),
+                                                 (32, 64, 32, [5, 5, 5], 40)])
+def test_graphsage_forward_matches_reference_semantics(eng, d, hid, out, fanouts, b):
+    """HIP trimmed-schedule root embeddings == fp32 CPU forward of EVERY layer over the WHOLE union graph in
+    the reference's own (first-seen) numbering; tolerance 1e-5 (BASELINE.json north_star)."""
+    from gigl_amd.models import GraphSAGE, HipBatch
+    from oracle import gnn_ref
+    s, dd = rmat_edges(12, 60000, seed=33)
+    n = 1 << 12
+    rowptr, col = oracle.build_csc(n, s, dd, is_directed=False)
+    rng = np.random.default_rng(d)
+    x = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    eng.load_csc(rowptr, col)
+    eng.load_features(x)
+    roots = rng.integers(0, n, size=b).astype(np.uint32)
+    torch.manual_seed(0)
+    model = GraphSAGE(d, hid, out, num_layers=len(fanouts)).to(eng.device)
+    tree = eng.sample_khop(roots, fanouts)
+    u = eng.union_build(tree)
+    emb = model(HipBatch(eng, tree, u))[u.root_local[:b].long()].cpu().numpy()
+    # reference path on the CPU
+    nbr_o, _ = oracle.sample_khop(rowptr, col, roots, fanouts)  # permutation order, like the reference
+    node_lists, edge_lists = _ref_collate_from_tree(roots, fanouts, nbr_o)
+    nodes, ls, ld = oracle.collate_reference(node_lists, edge_lists)
+    g2l = {int(g): i for i, g in enumerate(nodes)}
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = gnn_ref.graphsage_forward(torch.from_numpy(x[nodes]), torch.from_numpy(np.stack([ls, ld])), sd, len(fanouts))
+    want = ref[[g2l[int(r)] for r in roots]].numpy()
+    np.testing.assert_allclose(emb, want, rtol=1e-5, atol=1e-5)

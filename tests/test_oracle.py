@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from oracle.oracle import canonicalise
+from oracle.oracle import tree_edges
 from gigl_amd import wire
 from helpers import A, INVALID, check_rnn_validity, load_fixture_graph, rmat_edges
 
@@ -199,8 +199,10 @@ def test_union_build_same_graph_as_reference_collate():
     rng = np.random.default_rng(0)
     roots = rng.choice(512, size=24, replace=False).astype(np.uint32)
     f = [5, 3]
-    nbr, cnt = oracle.sample_khop(rowptr, col, roots, f)
-    nbr = canonicalise(nbr, f)
+    nbr, cnt = oracle.sample_khop(rowptr, col, roots, f, canonical=True)
+    # canonical (ascending) and permutation order hold the same per-root edge sets
+    nbr_p, _ = oracle.sample_khop(rowptr, col, roots, f)
+    assert tree_edges(roots, f, nbr) == tree_edges(roots, f, nbr_p)
     u = oracle.union_build(roots, f, nbr)
     node_lists, edge_lists = [], []
     for bi, r in enumerate(roots.tolist()):
