@@ -178,8 +178,10 @@ def main():
         sampled += s_edges
         meta = u.meta.cpu().tolist()
         nn, ne = meta[0], meta[1]
-        rowp = u.rowptr[: nn + 1]
-        agg_l = [int(rowp[meta[2 + (L - 1 - l)]].item()) for l in range(L)]
+        if meta[8]:
+            raise RuntimeError("union dedup overflow (meta[GIGL_META_OVERFLOW])")
+        rowlen = (u.rowend[:nn] - u.rowptr[:nn]).to(torch.int64)
+        agg_l = [int(rowlen[: meta[2 + (L - 1 - l)]].sum().item()) for l in range(L)]
         aggregated += sum(agg_l)
         ref_equiv += L * ne
         union_edges += ne

@@ -12,7 +12,7 @@ GIGL_INVALID = 0xFFFFFFFF
 GIGL_MAX_HOPS = 4
 GIGL_MAX_FANOUT = 64
 GIGL_META_LEN = 16
-GIGL_META_N_NODES, GIGL_META_N_EDGES, GIGL_META_LEVEL0 = 0, 1, 2
+GIGL_META_N_NODES, GIGL_META_N_EDGES, GIGL_META_LEVEL0, GIGL_META_OVERFLOW = 0, 1, 2, 8
 LOC_HOST, LOC_DEVICE = 0, 1
 DTYPE_F32, DTYPE_F16 = 0, 1
 MODE_SPARK_HASH, MODE_FAST = 0, 1
@@ -51,6 +51,7 @@ class GiglUnion(C.Structure):
         ("meta", C.c_void_p),
         ("nodes", C.c_void_p),
         ("rowptr", C.c_void_p),
+        ("rowend", C.c_void_p),
         ("col", C.c_void_p),
         ("root_local", C.c_void_p),
         ("cap_nodes", C.c_int64),
@@ -105,7 +106,7 @@ def load() -> C.CDLL:
         "gigl_sample_positives": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
         "gigl_union_capacity": [i32, P(i32), i32, P(i64), P(i64)],
         "gigl_union_build": [vp, vp, P(GiglTree), P(GiglUnion)],
-        "gigl_gather_mean": [vp, vp, i32, i32, vp, vp, vp, vp, i64, vp],
+        "gigl_gather_mean": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, vp],
         "gigl_linear": [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp],
         "gigl_profile_enable": [vp, C.c_uint32, i32],
         "gigl_profile_read": [vp, i32, P(C.c_double), P(i64)],

@@ -8,13 +8,17 @@
 //       root_weight=True, bias in lin_l only, normalize=False)
 //   hydrateNodes (feature join)  scala/.../pureSpark/SGSPureSparkV1Task.scala:496-547
 //
-// gather_mean  HBM-bound: per aggregated edge 4 B (col) + d*s B (source row); one lane group of
-//              LPR lanes streams a whole source row with 16-byte loads, G = 64/LPR rows in flight per
-//              wave, 4 edges unrolled per group for memory-level parallelism; fp32 accumulate.
-// linear       exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): every wave owns a 32*MT x 32*NT output tile
-//              and streams A / W rows straight from global (L2-resident W) as float4 — K is consumed
-//              8 at a time: lane (r, h) loads k0+4h..k0+4h+3 and the t-th MFMA of the group multiplies
-//              the k-pairs {k0+t, k0+4+t} of A and W, so no LDS staging or transposes are needed.
+// gather_mean  HBM-bound: per aggregated edge 4 B (col) + d*s B (source row).  One wave per
+//              destination row.  The row's source indices are fetched ONCE, 64 at a time, one per
+//              lane (col -> gather_ids: two dependent loads for the whole row instead of per edge);
+//              then LPR lanes stream each source row with 16-byte loads, G = 64/LPR source rows per
+//              wave-instruction and 4 instructions in flight; fp32 accumulate; the destination's own
+//              row is copied alongside, producing the [mean | self] operand of the projection.
+// linear       exact-fp32 MFMA (v_mfma_f32_32x32x2_f32): every wave owns a 32 x 32*NT output tile and
+//              streams A / W rows straight from global (L2-resident W) as float4, register
+//              double-buffered one K-step (8) ahead.  K is consumed 8 at a time: lane (r, h) loads
+//              k0+4h..k0+4h+3 and the t-th MFMA of the group multiplies the k-pairs {k0+t, k0+4+t} of A
+//              and W, so no LDS staging or transposes are needed.
 #include "common.h"
 
 #include <hip/hip_fp16.h>
@@ -29,7 +33,6 @@ struct RowLoader;
 
 template <>
 struct RowLoader<float> {
-  // 4 consecutive features starting at element e (row base pointer p)
   static __device__ __forceinline__ float4_t load4(const float* p, int e) {
     return *reinterpret_cast<const float4_t*>(p + e);
   }
@@ -45,56 +48,56 @@ struct RowLoader<__half> {
   }
 };
 
-// LPR lanes cooperate on one row; VPL float4 vectors per lane cover d (d % 4 == 0, d <= LPR*VPL*4)
+// LPR lanes cooperate on one source row; VPL float4 vectors per lane cover d (d % 4 == 0,
+// d <= LPR*VPL*4)
 template <typename T, int LPR, int VPL>
 __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ src, int d,
                                                           const uint32_t* __restrict__ gather_ids,
                                                           const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ rowend,
                                                           const int32_t* __restrict__ col,
                                                           const int32_t* __restrict__ n_rows_dev,
                                                           float* __restrict__ out) {
-  constexpr int G = 64 / LPR;  // row groups per wave
+  constexpr int G = 64 / LPR;  // source rows per wave-instruction
   const int lane = threadIdx.x & 63;
-  const int sub = lane / LPR;   // which group of the wave
-  const int sl = lane % LPR;    // lane within group
+  const int sub = lane / LPR;  // which source row of the instruction
+  const int sl = lane % LPR;   // lane within the row
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_rows = *n_rows_dev;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
   for (int i = wave; i < n_rows; i += waves_total) {
-    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    const int self = gather_ids ? (int)gather_ids[i] : i;
     float4_t acc[VPL];
 #pragma unroll
-    for (int v = 0; v < VPL; ++v) acc[v] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    // group `sub` takes edges e0+sub, e0+sub+G, ...; 4 in flight
-    int e = e0 + sub;
-    for (; e + 3 * G < e1; e += 4 * G) {
-      int j0 = col[e], j1 = col[e + G], j2 = col[e + 2 * G], j3 = col[e + 3 * G];
-      if (gather_ids) {
-        j0 = (int)gather_ids[j0]; j1 = (int)gather_ids[j1];
-        j2 = (int)gather_ids[j2]; j3 = (int)gather_ids[j3];
+    for (int v = 0; v < VPL; ++v) acc[v] = zero4;
+    for (int c0 = 0; c0 < m; c0 += 64) {
+      const int mm = min(64, m - c0);
+      int my = 0;
+      if (lane < mm) {
+        my = col[e0 + c0 + lane];
+        if (gather_ids) my = (int)gather_ids[my];
       }
-      const T* p0 = src + (int64_t)j0 * d;
-      const T* p1 = src + (int64_t)j1 * d;
-      const T* p2 = src + (int64_t)j2 * d;
-      const T* p3 = src + (int64_t)j3 * d;
+      for (int e = 0; e < mm; e += 4 * G) {  // wave-uniform trip count (shuffles need every lane)
+        const int ea = e + sub, eb = ea + G, ec = ea + 2 * G, ed = ea + 3 * G;
+        const int ja = __shfl(my, ea & 63, 64), jb = __shfl(my, eb & 63, 64), jc = __shfl(my, ec & 63, 64),
+                  jd = __shfl(my, ed & 63, 64);
+        const T* pa = src + (int64_t)ja * d;
+        const T* pb = src + (int64_t)jb * d;
+        const T* pc = src + (int64_t)jc * d;
+        const T* pd = src + (int64_t)jd * d;
 #pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        int el = (v * LPR + sl) * 4;
-        if (el < d) {
-          float4_t a0 = RowLoader<T>::load4(p0, el), a1 = RowLoader<T>::load4(p1, el);
-          float4_t a2 = RowLoader<T>::load4(p2, el), a3 = RowLoader<T>::load4(p3, el);
-          acc[v] += (a0 + a1) + (a2 + a3);
+        for (int v = 0; v < VPL; ++v) {
+          const int el = (v * LPR + sl) * 4;
+          if (el < d) {
+            float4_t a = ea < mm ? RowLoader<T>::load4(pa, el) : zero4;
+            float4_t b = eb < mm ? RowLoader<T>::load4(pb, el) : zero4;
+            float4_t c = ec < mm ? RowLoader<T>::load4(pc, el) : zero4;
+            float4_t dd = ed < mm ? RowLoader<T>::load4(pd, el) : zero4;
+            acc[v] += (a + b) + (c + dd);
+          }
         }
-      }
-    }
-    for (; e < e1; e += G) {
-      int j0 = col[e];
-      if (gather_ids) j0 = (int)gather_ids[j0];
-      const T* p0 = src + (int64_t)j0 * d;
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        int el = (v * LPR + sl) * 4;
-        if (el < d) acc[v] += RowLoader<T>::load4(p0, el);
       }
     }
     // combine the G partial sums (lanes sl, sl+LPR, ...)
@@ -108,20 +111,18 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
         acc[v].w += __shfl_xor(acc[v].w, off, 64);
       }
     }
-    const int deg = e1 - e0;
     float* o = out + (int64_t)i * 2 * d;
-    const int self = gather_ids ? (int)gather_ids[i] : i;
     const T* ps = src + (int64_t)self * d;
     if (sub == 0) {
       // mean = sum / deg (a true division, like torch's scatter-mean), 0 for an empty row
-      const float dv = deg > 0 ? (float)deg : 1.f;
+      const float dv = m > 0 ? (float)m : 1.f;
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
-        int el = (v * LPR + sl) * 4;
+        const int el = (v * LPR + sl) * 4;
         if (el < d) *reinterpret_cast<float4_t*>(o + el) = acc[v] / dv;
       }
     }
-    // self row copy: spread over all lanes of the wave
+    // self row copy, spread over all lanes of the wave
     for (int el = lane * 4; el < d; el += 64 * 4)
       *reinterpret_cast<float4_t*>(o + d + el) = RowLoader<T>::load4(ps, el);
   }
@@ -132,6 +133,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gather_mean_generic_kernel(const T* __restrict__ src, int d,
                                                                   const uint32_t* __restrict__ gather_ids,
                                                                   const int32_t* __restrict__ rowptr,
+                                                                  const int32_t* __restrict__ rowend,
                                                                   const int32_t* __restrict__ col,
                                                                   const int32_t* __restrict__ n_rows_dev,
                                                                   float* __restrict__ out) {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void gather_mean_generic_kernel(const T* __res
   const int n_rows = *n_rows_dev;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
   for (int i = wave; i < n_rows; i += waves_total) {
-    const int e0 = rowptr[i], e1 = rowptr[i + 1];
+    const int e0 = rowptr[i], e1 = rowend[i];
     const int deg = e1 - e0;
     float* o = out + (int64_t)i * 2 * d;
     const int self = gather_ids ? (int)gather_ids[i] : i;
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void gather_mean_generic_kernel(const T* __res
 // ------------------------------------------------------------------------------------------
 // y[m][n] = act(sum_k a[m][k] * w[n][k] + bias[n])       a: [M][K], w: [N][K] row-major, fp32
 // ------------------------------------------------------------------------------------------
-template <int MT, int NT>
+template <int NT>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ a,
                                                           const float* __restrict__ w,
                                                           const float* __restrict__ bias,
@@ -170,66 +172,63 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
   const int lane = threadIdx.x & 63;
   const int r = lane & 31, h = lane >> 5;
   const int tiles_n = (N + 32 * NT - 1) / (32 * NT);
-  const int tiles_m = (M + 32 * MT - 1) / (32 * MT);
+  const int tiles_m = (M + 31) / 32;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (wave >= tiles_m * tiles_n) return;
   // consecutive waves share the A row-panel (tn fastest) so it stays in L1/L2
   const int tm = wave / tiles_n, tn = wave % tiles_n;
-  const int m0 = tm * 32 * MT, n0 = tn * 32 * NT;
+  const int m0 = tm * 32, n0 = tn * 32 * NT;
 
-  float16_t acc[MT][NT];
+  float16_t acc[NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
 
-  const float* ap[MT];
+  const bool aok = m0 + r < M;
+  const float* ap = a + (int64_t)(aok ? m0 + r : 0) * K;
   const float* wp[NT];
-  bool aok[MT], wok[NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    int row = m0 + i * 32 + r;
-    aok[i] = row < M;
-    ap[i] = a + (int64_t)(aok[i] ? row : 0) * K;
-  }
+  bool wok[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    int row = n0 + j * 32 + r;
+    const int row = n0 + j * 32 + r;
     wok[j] = row < N;
     wp[j] = w + (int64_t)(wok[j] ? row : 0) * K;
   }
   const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
   const bool vec_ok = (K & 3) == 0;
-  for (int k0 = 0; k0 < K; k0 += 8) {
+
+  auto load_step = [&](int k0, float4_t& av, float4_t (&wv)[NT]) {
     const int kk = k0 + 4 * h;
-    float4_t av[MT], wv[NT];
     if (vec_ok) {
       const bool kin = kk < K;  // K % 4 == 0 -> whole float4 in range
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        av[i] = (aok[i] && kin) ? *reinterpret_cast<const float4_t*>(ap[i] + kk) : zero4;
+      av = (aok && kin) ? *reinterpret_cast<const float4_t*>(ap + kk) : zero4;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         wv[j] = (wok[j] && kin) ? *reinterpret_cast<const float4_t*>(wp[j] + kk) : zero4;
     } else {
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) av[i][t] = (aok[i] && kk + t < K) ? ap[i][kk + t] : 0.f;
+      for (int t = 0; t < 4; ++t) av[t] = (aok && kk + t < K) ? ap[kk + t] : 0.f;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int t = 0; t < 4; ++t) wv[j][t] = (wok[j] && kk + t < K) ? wp[j][kk + t] : 0.f;
     }
+  };
+
+  float4_t av_n, wv_n[NT];
+  load_step(0, av_n, wv_n);
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    const float4_t av = av_n;
+    float4_t wv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wv[j] = wv_n[j];
+    if (k0 + 8 < K) load_step(k0 + 8, av_n, wv_n);  // prefetch the next K-step under this step's MFMAs
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][t], wv[j][t], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wv[j][t], acc[j], 0, 0, 0);
   }
   // D layout (32x32, 16 regs): reg v -> row 8*(v/4) + 4*h + (v%4), col r
 #pragma unroll
@@ -238,25 +237,22 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
     if (coln >= N) continue;
     const float bv = bias ? bias[coln] : 0.f;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        int row = m0 + i * 32 + 8 * (v >> 2) + 4 * h + (v & 3);
-        if (row < M) {
-          float val = acc[i][j][v] + bv;
-          if (act == 1) val = val > 0.f ? val : 0.f;
-          y[(int64_t)row * N + coln] = val;
-        }
+    for (int v = 0; v < 16; ++v) {
+      const int row = m0 + 8 * (v >> 2) + 4 * h + (v & 3);
+      if (row < M) {
+        float val = acc[j][v] + bv;
+        if (act == 1) val = val > 0.f ? val : 0.f;
+        y[(int64_t)row * N + coln] = val;
       }
+    }
   }
 }
 
 template <typename T>
 int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather_ids,
-                      const int32_t* rowptr, const int32_t* col, const int32_t* n_rows_dev,
-                      int64_t rows_cap, float* out) {
-  int64_t waves = rows_cap;
-  int64_t blocks = (waves + 3) / 4;
+                      const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                      const int32_t* n_rows_dev, int64_t rows_cap, float* out) {
+  int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
   dim3 g((unsigned)blocks), b(256);
@@ -264,20 +260,17 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
   const int vecs = d / 4;
 #define GL(LPR, VPL)                                                                             \
   hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL>), g, b, 0, st, src, d, gather_ids, rowptr, \
-                     col, n_rows_dev, out)
-  if ((d & 3) != 0) {
-    hipLaunchKernelGGL((gather_mean_generic_kernel<T>), g, b, 0, st, src, d, gather_ids, rowptr, col,
-                       n_rows_dev, out);
+                     rowend, col, n_rows_dev, out)
+  if ((d & 3) != 0 || vecs > 512) {
+    hipLaunchKernelGGL((gather_mean_generic_kernel<T>), g, b, 0, st, src, d, gather_ids, rowptr, rowend,
+                       col, n_rows_dev, out);
   } else if (vecs <= 8) GL(8, 1);
   else if (vecs <= 16) GL(16, 1);
   else if (vecs <= 32) GL(32, 1);
   else if (vecs <= 64) GL(64, 1);
   else if (vecs <= 128) GL(64, 2);
   else if (vecs <= 256) GL(64, 4);
-  else if (vecs <= 512) GL(64, 8);
-  else
-    hipLaunchKernelGGL((gather_mean_generic_kernel<T>), g, b, 0, st, src, d, gather_ids, rowptr, col,
-                       n_rows_dev, out);
+  else GL(64, 8);
 #undef GL
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
@@ -288,19 +281,19 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
 extern "C" {
 
 int32_t gigl_gather_mean(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
-                         const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* col,
-                         const int32_t* n_rows_dev, int64_t rows_cap, float* out) {
+                         const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* rowend,
+                         const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, float* out) {
   if (!ctx) return GIGL_E_INVALID_ARG;
-  GIGL_REQUIRE(ctx, src && rowptr && col && n_rows_dev && out, "null argument");
+  GIGL_REQUIRE(ctx, src && rowptr && rowend && col && n_rows_dev && out, "null argument");
   GIGL_REQUIRE(ctx, d > 0 && rows_cap >= 0, "bad sizes");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   if (src_dtype == GIGL_DTYPE_F32)
-    return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, col, n_rows_dev,
+    return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev,
                                 rows_cap, out);
   if (src_dtype == GIGL_DTYPE_F16)
-    return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, col, n_rows_dev,
+    return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev,
                                  rows_cap, out);
   return gigl_fail(ctx, GIGL_E_INVALID_ARG, "bad dtype %d", src_dtype);
 }
@@ -316,16 +309,17 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
   if (m_cap == 0) return GIGL_OK;
   hipStream_t st = ctx->stream;
   gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
+  const int64_t tiles_m = (m_cap + 31) / 32;
   if (n > 32) {
-    constexpr int MT = 1, NT = 2;
-    int64_t tiles = ((m_cap + 32 * MT - 1) / (32 * MT)) * ((n + 32 * NT - 1) / (32 * NT));
-    hipLaunchKernelGGL((linear_mfma_kernel<MT, NT>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0,
-                       st, a, w, bias, m_dev, k, n, act, y);
+    constexpr int NT = 2;
+    int64_t tiles = tiles_m * ((n + 32 * NT - 1) / (32 * NT));
+    hipLaunchKernelGGL((linear_mfma_kernel<NT>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a, w,
+                       bias, m_dev, k, n, act, y);
   } else {
-    constexpr int MT = 1, NT = 1;
-    int64_t tiles = ((m_cap + 31) / 32) * ((n + 31) / 32);
-    hipLaunchKernelGGL((linear_mfma_kernel<MT, NT>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0,
-                       st, a, w, bias, m_dev, k, n, act, y);
+    constexpr int NT = 1;
+    int64_t tiles = tiles_m * ((n + 31) / 32);
+    hipLaunchKernelGGL((linear_mfma_kernel<NT>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a, w,
+                       bias, m_dev, k, n, act, y);
   }
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;

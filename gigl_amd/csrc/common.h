@@ -29,7 +29,11 @@ struct gigl_ctx {
   std::vector<hipEvent_t> prof_ev;   // 2 per recorded launch
   std::vector<int32_t> prof_id;      // kernel id per recorded launch
   size_t prof_used = 0;              // launches recorded so far
+  // sampler: range-top-K table over the xxhash sequence (sample.hip), built lazily
+  void* sampler_table = nullptr;
 };
+
+void gigl_sampler_table_free(gigl_ctx* ctx);
 
 // RAII bracket: records start/stop events around a launch when profiling of `id` is on
 struct gigl_prof_scope {
@@ -43,6 +47,7 @@ struct gigl_prof_scope {
 struct gigl_graph {
   gigl_ctx* ctx = nullptr;
   int64_t n = 0, e = 0;
+  int64_t maxdeg = 0;         // largest in-degree (bounds the sampler's hash windows)
   int64_t* rowptr = nullptr;  // device [n+1]
   uint32_t* col = nullptr;    // device [e]
 };
@@ -74,5 +79,8 @@ int32_t gigl_fail(gigl_ctx* ctx, int32_t code, const char* fmt, ...);
 // arena: reset at the start of every public per-batch call, then bump-allocate (256 B aligned)
 int32_t gigl_arena_reset(gigl_ctx* ctx, int64_t need_bytes);
 void* gigl_arena_alloc(gigl_ctx* ctx, int64_t bytes);
+
+// fills g->maxdeg from the resident rowptr (synchronises the ctx stream)
+int32_t gigl_graph_compute_maxdeg(gigl_ctx* ctx, gigl_graph* g);
 
 static inline int64_t gigl_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

@@ -116,6 +116,7 @@ int32_t gigl_ctx_destroy(gigl_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->stream) hipStreamSynchronize(ctx->stream);
   if (ctx->arena) hipFree(ctx->arena);
+  gigl_sampler_table_free(ctx);
   for (hipEvent_t e : ctx->prof_ev) hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -194,6 +195,7 @@ int32_t gigl_graph_load_csc(gigl_ctx* ctx, int64_t n, int64_t e, const int64_t* 
   }
   int32_t rc = copy_in(ctx, g->rowptr, rowptr, (size_t)(n + 1) * sizeof(int64_t), loc);
   if (rc == GIGL_OK) rc = copy_in(ctx, g->col, col, (size_t)e * sizeof(uint32_t), loc);
+  if (rc == GIGL_OK) rc = gigl_graph_compute_maxdeg(ctx, g);
   if (rc != GIGL_OK) {
     gigl_graph_destroy(g);
     return rc;

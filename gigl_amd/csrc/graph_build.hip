@@ -61,7 +61,34 @@ __global__ void csc_rowptr_kernel(const uint64_t* ukeys, int64_t u, int64_t n, i
   rowptr[v] = lo;
 }
 
+__global__ void maxdeg_kernel(const int64_t* rowptr, int64_t n, unsigned long long* out) {
+  int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long d = v < n ? (unsigned long long)(rowptr[v + 1] - rowptr[v]) : 0ull;
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long o = __shfl_xor(d, off, 64);
+    d = o > d ? o : d;
+  }
+  if ((threadIdx.x & 63) == 0 && d) atomicMax(out, d);
+}
+
 }  // namespace
+
+int32_t gigl_graph_compute_maxdeg(gigl_ctx* ctx, gigl_graph* g) {
+  g->maxdeg = 0;
+  if (g->n == 0) return GIGL_OK;
+  unsigned long long* d_out = nullptr;
+  GIGL_HIP_CHECK(ctx, hipMalloc((void**)&d_out, 8));
+  hipMemsetAsync(d_out, 0, 8, ctx->stream);
+  hipLaunchKernelGGL(maxdeg_kernel, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, ctx->stream, g->rowptr,
+                     g->n, d_out);
+  unsigned long long h = 0;
+  hipError_t e = hipMemcpyAsync(&h, d_out, 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d_out);
+  if (e != hipSuccess) return gigl_fail(ctx, GIGL_E_HIP, "maxdeg reduction failed: %s", hipGetErrorString(e));
+  g->maxdeg = (int64_t)h;
+  return GIGL_OK;
+}
 
 extern "C" int32_t gigl_graph_build_from_coo(gigl_ctx* ctx, int64_t n, int64_t e, const uint32_t* src,
                                              const uint32_t* dst, int32_t loc, int32_t is_directed,
@@ -164,6 +191,13 @@ extern "C" int32_t gigl_graph_build_from_coo(gigl_ctx* ctx, int64_t n, int64_t e
   BUILD_CHECK(hipGetLastError());
   BUILD_CHECK(hipStreamSynchronize(st));
 #undef BUILD_CHECK
+  {
+    int32_t rc = gigl_graph_compute_maxdeg(ctx, g);
+    if (rc != GIGL_OK) {
+      gigl_graph_destroy(g);
+      return rc;
+    }
+  }
   *out = g;
   return GIGL_OK;
 }

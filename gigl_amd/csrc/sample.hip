@@ -11,13 +11,12 @@
 // (xxhash64_int32(i + K + seed*counter) as signed int64, i); K = int32-wrapping sum of the ids on the
 // path root..parent, counter = hop number (1-based).  n <= f copies the row through.
 //
-// Kernel shape (gfx950): one 64-lane wavefront per parent slot.  Adjacency is read coalesced, 64
-// ids per wave-instruction; each lane hashes its own index.  Top-f selection never leaves the
-// wave: the first 64 candidates are bitonic-sorted across lanes (shuffles), later chunks are
-// filtered against the current f-th key with one ballot and the (rare) survivors are inserted by
-// a one-step lane shift.  The selected indices are re-sorted ascending so that output is the
-// canonical (ascending id) form of the set.  Rows with n > HEAVY_DEG are handled by a whole
-// workgroup (4 waves striding the row, merge through LDS).
+// Kernel shape (gfx950): one 64-lane wavefront per parent slot.  Top-f selection never leaves the
+// wave: the first 64 candidates are bitonic-sorted across lanes (shuffles), later candidates are
+// filtered against the running f-th key with one ballot and the (rare) survivors are inserted by a
+// one-step lane shift.  Long rows do not hash their whole adjacency: see "Range-top-K table" below.
+// The selected indices are re-sorted ascending so the output is the canonical (ascending id) form
+// of the sampled set.
 #include "common.h"
 
 namespace {
@@ -46,53 +45,80 @@ __device__ __forceinline__ bool less96(uint64_t k1, uint32_t i1, uint64_t k2, ui
   return k1 < k2 || (k1 == k2 && i1 < i2);
 }
 
-// ascending bitonic sort of one (key, idx) per lane across the 64-lane wave
-__device__ __forceinline__ void wave_sort96(uint64_t& key, uint32_t& idx, int lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      uint64_t ok = __shfl_xor(key, j, 64);
-      uint32_t oi = __shfl_xor(idx, j, 64);
-      bool up = (lane & k) == 0;
-      bool lower = (lane & j) == 0;
-      bool mine_less = less96(key, idx, ok, oi);
-      bool keep_mine = (lower == up) ? mine_less : !mine_less;
-      key = keep_mine ? key : ok;
-      idx = keep_mine ? idx : oi;
-    }
-  }
+// ---- wave-level primitives.  Everything below is VALU/SALU only (DPP lane shifts and
+// v_readlane broadcasts): no LDS crossbar (ds_bpermute) round trips on the insertion path.
+__device__ __forceinline__ uint32_t dpp_shr1(uint32_t x) {  // lane i <- lane i-1 (whole wave), lane 0 <- 0
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
 }
-
-__device__ __forceinline__ void wave_sort32(uint32_t& v, int lane) {
-#pragma unroll
-  for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      uint32_t o = __shfl_xor(v, j, 64);
-      bool up = (lane & k) == 0;
-      bool lower = (lane & j) == 0;
-      uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
-      v = (lower == up) ? mn : mx;
-    }
-  }
+__device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
+  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)x, l);
+  uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ uint32_t readlane32(uint32_t x, int l) { return __builtin_amdgcn_readlane(x, l); }
 
 // insert wave-uniform candidate (ck, ci) into the ascending per-lane list (key, idx); the last
 // lane's element falls off
-__device__ __forceinline__ void wave_insert96(uint64_t& key, uint32_t& idx, uint64_t ck, uint32_t ci,
-                                              int lane) {
-  bool gt = less96(ck, ci, key, idx);  // my element is greater than the candidate
-  uint64_t uk = __shfl_up(key, 1, 64);
-  uint32_t ui = __shfl_up(idx, 1, 64);
-  int gtu = __shfl_up((int)gt, 1, 64);
-  if (lane == 0) gtu = 0;
+__device__ __forceinline__ void wave_insert96(uint64_t& key, uint32_t& idx, uint64_t ck, uint32_t ci) {
+  const bool gt = less96(ck, ci, key, idx);  // my element is greater than the candidate
+  const uint32_t ulo = dpp_shr1((uint32_t)key), uhi = dpp_shr1((uint32_t)(key >> 32));
+  const uint32_t ui = dpp_shr1(idx);
+  const uint32_t gtu = dpp_shr1(gt ? 1u : 0u);  // lane 0 receives 0
   if (gtu) {
-    key = uk;
+    key = ((uint64_t)uhi << 32) | ulo;
     idx = ui;
   } else if (gt) {
     key = ck;
     idx = ci;
+  }
+}
+
+// merge one candidate per lane into the wave's ascending best list; (tk, ti) = current f-th element
+__device__ __forceinline__ void merge_candidates(uint64_t& key, uint32_t& idx, uint64_t ck, uint32_t ci,
+                                                 bool valid, uint64_t& tk, uint32_t& ti, int f, int lane) {
+  bool pass = valid && less96(ck, ci, tk, ti);
+  unsigned long long m = __ballot(pass);
+  while (m) {
+    const int src = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const uint64_t sk = readlane64(ck, src);
+    const uint32_t si = readlane32(ci, src);
+    if (less96(sk, si, tk, ti)) {  // threshold may have tightened since the ballot
+      wave_insert96(key, idx, sk, si);
+      tk = readlane64(key, f - 1);
+      ti = readlane32(idx, f - 1);
+    }
+  }
+}
+
+// lanes [0, f) hold distinct 1-based positions: write row[pos-1] in ascending position order
+__device__ __forceinline__ void emit_sorted(const uint32_t* row, uint32_t idx, int f, int lane, uint32_t* out) {
+  int rank = 0;
+  for (int l = 0; l < f; ++l) rank += readlane32(idx, l) < idx ? 1 : 0;
+  if (lane < f) out[rank] = row[idx - 1];
+}
+
+// direct hashing of positions i in [i_lo, i_hi] (1-based, inclusive); chunks c0, c0+cstride, ...
+// Four chunks are hashed before their merges so the multiply chains overlap.
+__device__ __forceinline__ void scan_direct(uint64_t& key, uint32_t& idx, uint64_t& tk, uint32_t& ti,
+                                            int64_t i_lo, int64_t i_hi, int64_t c0, int64_t cstride,
+                                            uint32_t base, int f, int lane) {
+  const int64_t n = i_hi - i_lo + 1;
+  const int64_t nchunks = (n + 63) >> 6;
+  int64_t c = c0;
+  for (; c + 3 * cstride < nchunks; c += 4 * cstride) {
+    const int64_t ia = i_lo + c * 64 + lane, ib = ia + cstride * 64, ic = ib + cstride * 64,
+                  id = ic + cstride * 64;
+    const uint64_t ka = xxh64_i32_ordered((uint32_t)ia + base), kb = xxh64_i32_ordered((uint32_t)ib + base),
+                   kc = xxh64_i32_ordered((uint32_t)ic + base), kd = xxh64_i32_ordered((uint32_t)id + base);
+    merge_candidates(key, idx, ka, (uint32_t)ia, ia <= i_hi, tk, ti, f, lane);
+    merge_candidates(key, idx, kb, (uint32_t)ib, ib <= i_hi, tk, ti, f, lane);
+    merge_candidates(key, idx, kc, (uint32_t)ic, ic <= i_hi, tk, ti, f, lane);
+    merge_candidates(key, idx, kd, (uint32_t)id, id <= i_hi, tk, ti, f, lane);
+  }
+  for (; c < nchunks; c += cstride) {
+    const int64_t i = i_lo + c * 64 + lane;
+    merge_candidates(key, idx, xxh64_i32_ordered((uint32_t)i + base), (uint32_t)i, i <= i_hi, tk, ti, f, lane);
   }
 }
 
@@ -132,35 +158,59 @@ __device__ __forceinline__ void parent_of(const ExpandArgs& a, int64_t p, uint32
 
 constexpr int64_t HEAVY_DEG = 4096;
 
-// Scan indices [first, deg) in steps of `stride` chunks of 64 starting at chunk c0, maintaining the
-// wave's ascending best list (key, idx) whose f-th element is the running threshold.
-__device__ __forceinline__ void scan_chunks(uint64_t& key, uint32_t& idx, int64_t deg, int64_t c0,
-                                            int64_t cstride, uint32_t base, int f, int lane) {
-  uint64_t tk = __shfl(key, f - 1, 64);
-  uint32_t ti = __shfl(idx, f - 1, 64);
-  int64_t nchunks = (deg + 63) >> 6;
-  for (int64_t c = c0; c < nchunks; c += cstride) {
-    int64_t i0 = c * 64 + lane;  // 0-based position
-    uint32_t i1 = (uint32_t)(i0 + 1);
-    bool valid = i0 < deg;
-    uint64_t ck = xxh64_i32_ordered(i1 + base);
-    bool pass = valid && less96(ck, i1, tk, ti);
-    unsigned long long m = __ballot(pass);
-    while (m) {
-      int src = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      uint64_t sk = __shfl(ck, src, 64);
-      uint32_t si = __shfl(i1, src, 64);
-      if (less96(sk, si, tk, ti)) {  // threshold may have tightened since the ballot
-        wave_insert96(key, idx, sk, si, lane);
-        tk = __shfl(key, f - 1, 64);
-        ti = __shfl(idx, f - 1, 64);
-      }
+// ------------------------------------------------------------------------------------------
+// Range-top-K table over the hash sequence.
+//
+// Every parity-mode query is "the f smallest (g(j), j) for j in [base+1, base+deg]" where
+// g(j) = xxhash64_int32(j) is ONE fixed function of the integer j = i + K + seed*counter — the graph,
+// the roots and the sampling seed only move the window.  So the top-64 of g over aligned blocks of
+// the j axis is computed once per ctx and shared by all queries: a hub row of degree 10^5 then costs
+// two partial blocks of direct hashing (< 2*256 hashes) plus a handful of list-merge rounds instead
+// of 10^5 hashes.  Results are bit-identical to the direct evaluation: a block's top-64 by (g, j)
+// contains every element of that block that can be in the window's top-f (f <= 64), and j order ==
+// i order inside a non-wrapping window.
+//   level 0 block = 256 consecutive j; level l block = 16 level-(l-1) blocks.
+//   memory: 64/256 * 12 B = 3 B per covered j (+1/16 per extra level).
+// A window decomposes into <= 15 blocks per level and side.  The lists are merged by ROUNDS: lane q
+// owns list q and offers its next entry each round (one parallel load for all lists); a list stays
+// in play only while its offer still beats the running threshold, so the serial chain per row is
+// the largest number of winners coming from one block, not the number of blocks.
+// Windows that leave the covered domain or wrap around 2^32 fall back to direct hashing.
+// ------------------------------------------------------------------------------------------
+constexpr int TBL_S0_SHIFT = 8;   // 256 j per level-0 block
+constexpr int TBL_FAN_SHIFT = 4;  // 16 children per block
+constexpr int TBL_MAX_LEVELS = 7;
+constexpr int TBL_TOPK = 64;
+
+struct RangeTable {
+  int levels;
+  uint64_t dom;          // covered j domain [0, dom), multiple of 256
+  const uint64_t* keys;  // entry e of block blk at level l: [(lvl_off[l] + blk) * 64 + e]
+  const uint32_t* js;
+  int64_t lvl_off[TBL_MAX_LEVELS];
+  int64_t nblocks[TBL_MAX_LEVELS];
+};
+
+// merge the lists owned by the lanes (my_ent = first entry index of the lane's list, or -1) by rounds
+__device__ __forceinline__ void merge_lists(const RangeTable& tb, int64_t my_ent, uint32_t base, uint64_t& key,
+                                            uint32_t& idx, uint64_t& tk, uint32_t& ti, int f, int lane) {
+  bool active = my_ent >= 0;
+  int cur = 0;
+  while (__ballot(active)) {
+    uint64_t ck = ~0ULL;
+    uint32_t ci = 0xFFFFFFFFu;
+    if (active) {
+      ck = tb.keys[my_ent + cur];
+      ci = tb.js[my_ent + cur] - base;  // position i = j - base
     }
+    merge_candidates(key, idx, ck, ci, active, tk, ti, f, lane);
+    ++cur;
+    // my list can still contribute only if this offer made it into the best f (offer <= threshold)
+    active = active && cur < TBL_TOPK && !less96(tk, ti, ck, ci);
   }
 }
 
-__global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) {
+__global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a, RangeTable tb) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int64_t waves_total = (int64_t)gridDim.x * 4;
@@ -182,25 +232,121 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a) {
       if (lane == 0) a.out_cnt[p] = (int32_t)deg;
       continue;
     }
-    if (deg > HEAVY_DEG) {  // left to expand_heavy_kernel (whole workgroup per parent)
-      continue;
-    }
     const uint32_t base = ksum + (uint32_t)a.hash_add;  // int32 wrap == uint32 wrap
-    // chunk 0: one candidate per lane, full sort
-    uint32_t idx = lane < deg ? (uint32_t)(lane + 1) : 0xFFFFFFFFu;
-    uint64_t key = lane < deg ? xxh64_i32_ordered(idx + base) : ~0ULL;
-    wave_sort96(key, idx, lane);
-    if (deg > 64) scan_chunks(key, idx, deg, 1, 1, base, f, lane);
-    // lanes [0,f) hold the selected 1-based indices; emit ascending
-    uint32_t sel = lane < f ? idx : 0xFFFFFFFFu;
-    wave_sort32(sel, lane);
-    if (lane < f) out[lane] = row[sel - 1];
+    const uint64_t j_lo = (uint64_t)base + 1, j_hi = (uint64_t)base + (uint64_t)deg;  // inclusive window
+    const bool in_table = j_hi < tb.dom;  // also excludes 2^32 wrap-around
+    if (!in_table && deg > HEAVY_DEG) continue;  // left to expand_heavy_kernel (workgroup per parent)
+    // best list: ascending (key, position) per lane, +inf padded; (tk, ti) = f-th element
+    uint64_t key = ~0ULL;
+    uint32_t idx = 0xFFFFFFFFu;
+    uint64_t tk = ~0ULL;
+    uint32_t ti = 0xFFFFFFFFu;
+    // aligned level-0 blocks fully inside the window come from the table
+    const uint64_t b_first = (j_lo + ((1u << TBL_S0_SHIFT) - 1)) >> TBL_S0_SHIFT;
+    const uint64_t b_last = (j_hi + 1) >> TBL_S0_SHIFT;  // one past the last full block
+    if (!in_table || b_first >= b_last) {
+      scan_direct(key, idx, tk, ti, 1, deg, 0, 1, base, f, lane);
+    } else {
+      // pass A of the greedy aligned decomposition of [b_first, b_last): find the largest block.  Its
+      // sorted top-64 list becomes the initial best list, so the threshold is tight before anything
+      // is inserted (the block usually covers most of the window).
+      int best_l = -1;
+      uint64_t best_b = 0;
+      for (uint64_t b = b_first; b < b_last;) {
+        int l = 0;
+        while (l + 1 < tb.levels) {
+          const int sh = TBL_FAN_SHIFT * (l + 1);
+          if ((b & ((1ull << sh) - 1)) != 0 || b + (1ull << sh) > b_last ||
+              (int64_t)(b >> sh) >= tb.nblocks[l + 1])
+            break;
+          ++l;
+        }
+        if (l > best_l) {
+          best_l = l;
+          best_b = b;
+        }
+        b += 1ull << (TBL_FAN_SHIFT * l);
+      }
+      {
+        const int64_t ent = (tb.lvl_off[best_l] + (int64_t)(best_b >> (TBL_FAN_SHIFT * best_l))) * TBL_TOPK;
+        key = tb.keys[ent + lane];
+        idx = tb.js[ent + lane] - base;  // position i = j - base
+        tk = readlane64(key, f - 1);
+        ti = readlane32(idx, f - 1);
+      }
+      // pass B: the other lists, 64 per batch, list q of a batch owned by lane q, merged by rounds
+      uint64_t b = b_first;
+      int q = 0;
+      int64_t my_ent = -1;
+      while (b < b_last) {
+        int l = 0;
+        while (l + 1 < tb.levels) {
+          const int sh = TBL_FAN_SHIFT * (l + 1);
+          if ((b & ((1ull << sh) - 1)) != 0 || b + (1ull << sh) > b_last ||
+              (int64_t)(b >> sh) >= tb.nblocks[l + 1])
+            break;
+          ++l;
+        }
+        if (b != best_b) {
+          const int64_t ent = (tb.lvl_off[l] + (int64_t)(b >> (TBL_FAN_SHIFT * l))) * TBL_TOPK;
+          if (lane == q) my_ent = ent;
+          ++q;
+        }
+        b += 1ull << (TBL_FAN_SHIFT * l);
+        if (q == 64 || (b >= b_last && q > 0)) {
+          merge_lists(tb, my_ent, base, key, idx, tk, ti, f, lane);
+          q = 0;
+          my_ent = -1;
+        }
+      }
+      // head: positions before the first block boundary; tail: after the last full block
+      const int64_t head_hi = (int64_t)((b_first << TBL_S0_SHIFT) - 1 - base);  // position of the last head j
+      if (head_hi >= 1) scan_direct(key, idx, tk, ti, 1, head_hi, 0, 1, base, f, lane);
+      const int64_t tail_lo = (int64_t)((b_last << TBL_S0_SHIFT) - base);
+      if (tail_lo <= deg) scan_direct(key, idx, tk, ti, tail_lo, deg, 0, 1, base, f, lane);
+    }
+    emit_sorted(row, idx, f, lane, out);
     if (lane == 0) a.out_cnt[p] = f;
   }
 }
 
-// heavy rows: one workgroup (4 waves) per parent; wave w scans chunks w, w+4, ...; the four best
-// lists are merged by wave 0 through LDS.
+// table construction, level 0: one wave per block of 256 consecutive j
+__global__ __launch_bounds__(256) void table_l0_kernel(uint64_t* keys, uint32_t* js, int64_t nblocks) {
+  const int lane = threadIdx.x & 63;
+  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= nblocks) return;
+  const uint32_t j0 = (uint32_t)(blk << TBL_S0_SHIFT);
+  uint32_t idx = 0xFFFFFFFFu;
+  uint64_t key = ~0ULL, tk = ~0ULL;
+  uint32_t ti = 0xFFFFFFFFu;
+  for (int c = 0; c < (1 << TBL_S0_SHIFT) / 64; ++c) {
+    uint32_t j = j0 + c * 64 + lane;
+    merge_candidates(key, idx, xxh64_i32_ordered(j), j, true, tk, ti, 64, lane);
+  }
+  keys[blk * TBL_TOPK + lane] = key;
+  js[blk * TBL_TOPK + lane] = idx;
+}
+
+// level l+1 from level l: one wave per parent block, merging its 16 children's lists
+__global__ __launch_bounds__(256) void table_up_kernel(const uint64_t* ckeys, const uint32_t* cjs,
+                                                       uint64_t* keys, uint32_t* js, int64_t nblocks) {
+  const int lane = threadIdx.x & 63;
+  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= nblocks) return;
+  const int64_t c0 = blk << TBL_FAN_SHIFT;
+  uint64_t key = ckeys[c0 * TBL_TOPK + lane];
+  uint32_t idx = cjs[c0 * TBL_TOPK + lane];  // child lists are ascending already
+  uint64_t tk = readlane64(key, 63);
+  uint32_t ti = readlane32(idx, 63);
+  for (int c = 1; c < (1 << TBL_FAN_SHIFT); ++c)
+    merge_candidates(key, idx, ckeys[(c0 + c) * TBL_TOPK + lane], cjs[(c0 + c) * TBL_TOPK + lane], true, tk,
+                     ti, 64, lane);
+  keys[blk * TBL_TOPK + lane] = key;
+  js[blk * TBL_TOPK + lane] = idx;
+}
+
+// fallback for rows with deg > HEAVY_DEG whose window is outside the table: one workgroup (4 waves)
+// per parent; wave w scans chunks w, w+4, ...; the four best lists are merged by wave 0 through LDS.
 __global__ __launch_bounds__(256) void expand_heavy_kernel(ExpandArgs a, const int64_t* heavy_list,
                                                            const int32_t* heavy_count) {
   __shared__ uint64_t s_key[4][64];
@@ -217,51 +363,145 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(ExpandArgs a, const i
     const int64_t deg = a.rowptr[v + 1] - s;
     const uint32_t* row = a.col + s;
     const uint32_t base = ksum + (uint32_t)a.hash_add;
-    // first chunk of this wave: chunk index w (deg > HEAVY_DEG >= 256 so it is full)
-    uint32_t idx = (uint32_t)(w * 64 + lane + 1);
-    uint64_t key = xxh64_i32_ordered(idx + base);
-    wave_sort96(key, idx, lane);
-    scan_chunks(key, idx, deg, w + 4, 4, base, f, lane);
+    uint32_t idx = 0xFFFFFFFFu;
+    uint64_t key = ~0ULL;
+    {
+      uint64_t tk0 = ~0ULL;
+      uint32_t ti0 = 0xFFFFFFFFu;
+      scan_direct(key, idx, tk0, ti0, 1, deg, w, 4, base, f, lane);
+    }
     s_key[w][lane] = key;
     s_idx[w][lane] = idx;
     __syncthreads();
     if (w == 0) {
-      uint64_t tk = __shfl(key, f - 1, 64);
-      uint32_t ti = __shfl(idx, f - 1, 64);
-      for (int ow = 1; ow < 4; ++ow) {
-        for (int j = 0; j < f; ++j) {  // other waves' lists are ascending: stop at first non-improving
-          uint64_t ck = s_key[ow][j];
-          uint32_t ci = s_idx[ow][j];
-          if (!less96(ck, ci, tk, ti)) break;
-          wave_insert96(key, idx, ck, ci, lane);
-          tk = __shfl(key, f - 1, 64);
-          ti = __shfl(idx, f - 1, 64);
-        }
-      }
-      uint32_t sel = lane < f ? idx : 0xFFFFFFFFu;
-      wave_sort32(sel, lane);
-      if (lane < f) a.out_nbr[p * f + lane] = row[sel - 1];
+      uint64_t tk = readlane64(key, f - 1);
+      uint32_t ti = readlane32(idx, f - 1);
+      for (int ow = 1; ow < 4; ++ow)
+        merge_candidates(key, idx, s_key[ow][lane], s_idx[ow][lane], true, tk, ti, f, lane);
+      emit_sorted(row, idx, f, lane, a.out_nbr + p * f);
       if (lane == 0) a.out_cnt[p] = f;
     }
     __syncthreads();
   }
 }
 
-// compacts the parent slots whose degree exceeds HEAVY_DEG
-__global__ void find_heavy_kernel(ExpandArgs a, int64_t* heavy_list, int32_t* heavy_count) {
+// compacts the parent slots with degree > HEAVY_DEG whose hash window is NOT covered by the table
+// (only launched when the host cannot prove that every window is covered)
+__global__ void find_heavy_kernel(ExpandArgs a, uint64_t dom, int64_t* heavy_list, int32_t* heavy_count) {
   int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= a.n_parents) return;
-  uint32_t v = a.hop == 0 ? a.roots[p] : a.anc[a.hop - 1][p];
+  uint32_t v, ksum;
+  parent_of(a, p, v, ksum);
   if (v == GIGL_INVALID || (int64_t)v >= a.n_nodes) return;
   int64_t deg = a.rowptr[v + 1] - a.rowptr[v];
-  if (deg > HEAVY_DEG && deg > a.f) {
+  const uint32_t base = ksum + (uint32_t)a.hash_add;
+  const bool in_table = (uint64_t)base + (uint64_t)deg < dom;
+  if (deg > HEAVY_DEG && deg > a.f && !in_table) {
     int32_t at = atomicAdd(heavy_count, 1);
     heavy_list[at] = p;
   }
 }
 
-// ---- fast (non-parity) mode: f distinct positions by a counter-based RNG (Floyd's algorithm per
-// lane-0 loop would serialise; instead: stratified offsets).  Labelled NOT parity everywhere.
+struct TableOwner {
+  RangeTable t{};
+  void* mem = nullptr;
+};
+
+// (re)build the ctx's range table so that it covers [0, want_dom)
+int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
+  constexpr uint64_t S0 = 1ull << TBL_S0_SHIFT;
+  constexpr uint64_t DOM_CAP = 1ull << 32;  // j is a uint32
+  if (want_dom > DOM_CAP) want_dom = DOM_CAP;
+  want_dom = (want_dom + S0 - 1) / S0 * S0;
+  TableOwner* own = (TableOwner*)ctx->sampler_table;
+  if (own && own->t.dom >= want_dom) return GIGL_OK;
+  if (own) {
+    GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (own->mem) hipFree(own->mem);
+    own->mem = nullptr;
+    own->t = RangeTable{};
+  } else {
+    own = new TableOwner();
+    ctx->sampler_table = own;
+  }
+  // grow geometrically so that slightly larger requests do not rebuild
+  uint64_t dom = want_dom + want_dom / 4;
+  if (dom > DOM_CAP) dom = DOM_CAP;
+  dom = dom / S0 * S0;
+  RangeTable t{};
+  t.dom = dom;
+  int64_t nb = (int64_t)(dom >> TBL_S0_SHIFT), total_blocks = 0;
+  int L = 0;
+  while (nb >= 1 && L < TBL_MAX_LEVELS) {
+    t.nblocks[L] = nb;
+    t.lvl_off[L] = total_blocks;
+    total_blocks += nb;
+    ++L;
+    nb >>= TBL_FAN_SHIFT;
+  }
+  t.levels = L;
+  const size_t key_bytes = (size_t)total_blocks * TBL_TOPK * 8;
+  const size_t total = key_bytes + (size_t)total_blocks * TBL_TOPK * 4;
+  if (hipMalloc(&own->mem, total ? total : 256) != hipSuccess) {
+    own->mem = nullptr;
+    return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the %zu-byte hash range table failed", total);
+  }
+  uint64_t* keys = (uint64_t*)own->mem;
+  uint32_t* js = (uint32_t*)((char*)own->mem + key_bytes);
+  t.keys = keys;
+  t.js = js;
+  hipLaunchKernelGGL(table_l0_kernel, dim3((unsigned)((t.nblocks[0] + 3) / 4)), dim3(256), 0, ctx->stream,
+                     keys, js, t.nblocks[0]);
+  for (int l = 1; l < L; ++l)
+    hipLaunchKernelGGL(table_up_kernel, dim3((unsigned)((t.nblocks[l] + 3) / 4)), dim3(256), 0, ctx->stream,
+                       keys + t.lvl_off[l - 1] * TBL_TOPK, js + t.lvl_off[l - 1] * TBL_TOPK,
+                       keys + t.lvl_off[l] * TBL_TOPK, js + t.lvl_off[l] * TBL_TOPK, t.nblocks[l]);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  own->t = t;
+  return GIGL_OK;
+}
+
+// one hop of parity-mode expansion.  `covered` = the host proved every window lies inside the table.
+int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a, const RangeTable& tb, bool covered,
+                   int64_t* heavy_list, int32_t* heavy_count) {
+  int64_t blocks = (a.n_parents + 3) / 4;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  if (!covered) {
+    gigl_prof_scope ps(ctx, GIGL_K_FIND_HEAVY);
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(heavy_count, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(find_heavy_kernel, dim3((unsigned)((a.n_parents + 255) / 256)), dim3(256), 0,
+                       ctx->stream, a, tb.dom, heavy_list, heavy_count);
+  }
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_EXPAND);
+    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a, tb);
+  }
+  if (!covered) {
+    gigl_prof_scope ps(ctx, GIGL_K_EXPAND_HEAVY);
+    int64_t hb = a.n_parents < 2048 ? a.n_parents : 2048;
+    hipLaunchKernelGGL(expand_heavy_kernel, dim3((unsigned)hb), dim3(256), 0, ctx->stream, a, heavy_list,
+                       heavy_count);
+  }
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+// largest j any window of this call can reach, or UINT64_MAX if windows may wrap / go negative
+uint64_t window_bound(const gigl_graph* g, int32_t hops, int32_t first_counter, int32_t sampling_seed) {
+  uint64_t worst = 0;
+  for (int k = 0; k < hops; ++k) {
+    int64_t add = (int64_t)sampling_seed * (int64_t)(first_counter + k);
+    if (add < 0 || add > (int64_t)0x7FFFFFFF) return ~0ULL;
+    // K <= (k+1) ids each < n ; window end = K + add + deg
+    uint64_t hi = (uint64_t)(k + 1) * (uint64_t)(g->n > 0 ? g->n - 1 : 0) + (uint64_t)add + (uint64_t)g->maxdeg;
+    if (hi > worst) worst = hi;
+  }
+  return worst;
+}
+
+// ---- fast (non-parity) mode: stratified positions from a counter-based RNG: reads f ids instead of
+// deg.  Labelled NOT parity everywhere.
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16;
   x *= 0x7feb352dU;
@@ -293,8 +533,7 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(ExpandArgs a) {
       if (lane == 0) a.out_cnt[p] = (int32_t)deg;
       continue;
     }
-    // stratified: stratum j covers [j*deg/f, (j+1)*deg/f); one uniform draw inside each -> f distinct,
-    // ascending positions; reads f ids instead of deg.
+    // stratum j covers [j*deg/f, (j+1)*deg/f); one uniform draw inside each -> f distinct ascending positions
     if (lane < f) {
       int64_t lo = (int64_t)lane * deg / f, hi = (int64_t)(lane + 1) * deg / f;
       uint32_t r = mix32(mix32(ksum + (uint32_t)a.hash_add) ^ (uint32_t)(lane * 0x9E3779B9u));
@@ -306,6 +545,14 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(ExpandArgs a) {
 }
 
 }  // namespace
+
+void gigl_sampler_table_free(gigl_ctx* ctx) {
+  TableOwner* own = (TableOwner*)ctx->sampler_table;
+  if (!own) return;
+  if (own->mem) hipFree(own->mem);
+  delete own;
+  ctx->sampler_table = nullptr;
+}
 
 extern "C" {
 
@@ -332,20 +579,34 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
   for (int k = 0; k < hops; ++k) out->fanouts[k] = fanouts[k];
   if (b == 0) return GIGL_OK;
 
-  // scratch: heavy list per hop (worst case every parent) + counter
-  int64_t max_parents = b;
-  {
-    int64_t q = b;
+  RangeTable tb{};
+  bool covered = false;
+  int32_t rc = GIGL_OK;
+  if (mode == GIGL_MODE_SPARK_HASH) {
+    // size the hash range table for this graph/seed (built once, reused by every later call)
+    const uint64_t bound = window_bound(g, hops, 1, sampling_seed);
+    const uint64_t cap = 1ull << 31;  // 6 GiB of table at most; windows beyond fall back to direct hashing
+    rc = ensure_table(ctx, bound == ~0ULL ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));
+    if (rc != GIGL_OK) return rc;
+    tb = ((TableOwner*)ctx->sampler_table)->t;
+    covered = bound != ~0ULL && bound < tb.dom;
+  }
+
+  // scratch (only needed when some window may fall outside the table): heavy list + counter
+  int64_t* heavy_list = nullptr;
+  int32_t* heavy_count = nullptr;
+  if (mode == GIGL_MODE_SPARK_HASH && !covered) {
+    int64_t max_parents = b, q = b;
     for (int k = 0; k + 1 < hops; ++k) {
       q *= fanouts[k];
       if (q > max_parents) max_parents = q;
     }
+    rc = gigl_arena_reset(ctx, max_parents * 8 + 256 * 4);
+    if (rc != GIGL_OK) return rc;
+    heavy_list = (int64_t*)gigl_arena_alloc(ctx, max_parents * 8);
+    heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
+    if (!heavy_list || !heavy_count) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   }
-  int32_t rc = gigl_arena_reset(ctx, max_parents * 8 + 256 * 4);
-  if (rc != GIGL_OK) return rc;
-  int64_t* heavy_list = (int64_t*)gigl_arena_alloc(ctx, max_parents * 8);
-  int32_t* heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
-  if (!heavy_list || !heavy_count) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
 
   ExpandArgs a{};
   a.rowptr = g->rowptr;
@@ -361,29 +622,16 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
     a.hash_add = (int32_t)((uint32_t)sampling_seed * (uint32_t)(k + 1));
     a.out_nbr = out->nbr[k];
     a.out_cnt = out->cnt[k];
-    int64_t blocks = (parents + 3) / 4;
-    if (blocks > 256 * 32) blocks = 256 * 32;
     if (mode == GIGL_MODE_FAST) {
+      int64_t blocks = (parents + 3) / 4;
+      if (blocks > 256 * 32) blocks = 256 * 32;
+      gigl_prof_scope ps(ctx, GIGL_K_EXPAND);
       hipLaunchKernelGGL(expand_fast_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+      GIGL_HIP_CHECK(ctx, hipGetLastError());
     } else {
-      {
-        gigl_prof_scope ps(ctx, GIGL_K_FIND_HEAVY);
-        GIGL_HIP_CHECK(ctx, hipMemsetAsync(heavy_count, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(find_heavy_kernel, dim3((unsigned)((parents + 255) / 256)), dim3(256), 0,
-                           ctx->stream, a, heavy_list, heavy_count);
-      }
-      {
-        gigl_prof_scope ps(ctx, GIGL_K_EXPAND);
-        hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
-      }
-      {
-        gigl_prof_scope ps(ctx, GIGL_K_EXPAND_HEAVY);
-        int64_t hb = parents < 2048 ? parents : 2048;
-        hipLaunchKernelGGL(expand_heavy_kernel, dim3((unsigned)hb), dim3(256), 0, ctx->stream, a,
-                           heavy_list, heavy_count);
-      }
+      rc = run_expand(ctx, a, tb, covered, heavy_list, heavy_count);
+      if (rc != GIGL_OK) return rc;
     }
-    GIGL_HIP_CHECK(ctx, hipGetLastError());
     a.anc[k] = out->nbr[k];
     parents *= fanouts[k];
   }
@@ -394,7 +642,7 @@ int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* 
                               int32_t f, int32_t sampling_seed, int32_t mode, uint32_t* pos,
                               int32_t* cnt) {
   if (!ctx) return GIGL_E_INVALID_ARG;
-  GIGL_REQUIRE(ctx, g_out && roots && pos && cnt, "null argument");
+  GIGL_REQUIRE(ctx, g_out && (roots || b == 0) && pos && cnt, "null argument");
   GIGL_REQUIRE(ctx, mode == GIGL_MODE_SPARK_HASH, "positives are parity-mode only");
   if (f < 1 || f > GIGL_MAX_FANOUT)
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "num positives %d outside [1,%d]", f, GIGL_MAX_FANOUT);
@@ -404,6 +652,7 @@ int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* 
   if (rc != GIGL_OK) return rc;
   int64_t* heavy_list = (int64_t*)gigl_arena_alloc(ctx, (int64_t)b * 8);
   int32_t* heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
+  if (!heavy_list || !heavy_count) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   ExpandArgs a{};
   a.rowptr = g_out->rowptr;
   a.col = g_out->col;
@@ -418,15 +667,12 @@ int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* 
   a.hash_add = (int32_t)((uint32_t)sampling_seed * 3u);
   a.out_nbr = pos;
   a.out_cnt = cnt;
-  GIGL_HIP_CHECK(ctx, hipMemsetAsync(heavy_count, 0, 4, ctx->stream));
-  hipLaunchKernelGGL(find_heavy_kernel, dim3((unsigned)((b + 255) / 256)), dim3(256), 0, ctx->stream,
-                     a, heavy_list, heavy_count);
-  int64_t blocks = (b + 3) / 4;
-  hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
-  hipLaunchKernelGGL(expand_heavy_kernel, dim3((unsigned)(b < 2048 ? b : 2048)), dim3(256), 0,
-                     ctx->stream, a, heavy_list, heavy_count);
-  GIGL_HIP_CHECK(ctx, hipGetLastError());
-  return GIGL_OK;
+  const uint64_t bound = window_bound(g_out, 1, 3, sampling_seed);
+  const uint64_t cap = 1ull << 31;
+  rc = ensure_table(ctx, bound == ~0ULL ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));
+  if (rc != GIGL_OK) return rc;
+  const RangeTable tb = ((TableOwner*)ctx->sampler_table)->t;
+  return run_expand(ctx, a, tb, bound != ~0ULL && bound < tb.dom, heavy_list, heavy_count);
 }
 
 }  // extern "C"

@@ -9,37 +9,30 @@
 //   SupervisedNodeClassificationBatch.collate_pyg_node_classification_minibatch
 //       python/gigl/src/training/v1/lib/data_loaders/supervised_node_classification_data_loader.py:74-117
 //
-// Pipeline (T = b + sum slots[k] stream positions; roots first, then hop slots in order):
-//   1 insert      open-addressing hash table keyed by node id (atomicCAS), atomicMin of the first
-//                 stream position; roots get level 0
-//   2 relax xhops level(src) = min(level(src), level(dst)+1) over every sampled edge occurrence
-//   3 flag        first occurrences -> per-level one-hot counters; exclusive scan (rocPRIM)
-//   4 assign      local id = level base + rank within level; write nodes[], root_local[]
-//   5 edges       (dst_local << 32 | src_local) keys; radix sort (rocPRIM) ; unique flags ; scan
-//   6 csr         col[] from unique keys; rowptr[] by binary search over the unique keys
+// Pipeline (T = b + sum slots[k] stream positions; roots first, then hop slots in order), 9 launches,
+// no library sort/scan:
+//   1 insert_roots   open-addressing table keyed by node id (atomicCAS); first stream position by
+//                    atomicMin; level 0
+//   2 insert_slots   same for every sampled slot.  hops <= 2: the level is final here (a hop-1 slot
+//                    is level 1; a hop-2 slot is level 1 iff its parent is a root, which step 1 made
+//                    visible).  hops > 2: levels are relaxed by `hops` extra rounds.
+//   3 count          per 1024-position tile: number of first occurrences per level
+//   4 assign         local id = level base + tile prefix + rank inside the tile (ballot/popcount);
+//                    deterministic: (level, first stream position) order
+//   5 edge_count     rowcnt[dst_local]++ for every sampled edge occurrence (duplicates included)
+//   6 row_scan       exclusive scan of rowcnt -> rowptr (one workgroup; only rows that can have edges)
+//   7 edge_fill      col[rowptr[dst] + cursor++] = src_local
+//   8 row_sort       every row sorted ascending + deduplicated IN PLACE: one wave per row (<= 64
+//                    entries, rank-by-counting with v_readlane), rows > 64 queued for
+//   9 row_sort_big   one workgroup per queued row, bitonic sort in LDS (<= 16384 entries)
+// Rows keep their pre-dedup capacity: row i is col[rowptr[i] .. rowend[i]).
 #include "common.h"
-
-#include <hipcub/hipcub.hpp>
 
 namespace {
 
 constexpr int MAXL = GIGL_MAX_HOPS + 1;
-constexpr int32_t LVL_INF = 1 << 20;
-
-struct LevelCount {
-  int32_t c[MAXL];
-  LevelCount() = default;
-  __host__ __device__ LevelCount(int v) {
-#pragma unroll
-    for (int i = 0; i < MAXL; ++i) c[i] = v;
-  }
-  __host__ __device__ LevelCount operator+(const LevelCount& o) const {
-    LevelCount r;
-#pragma unroll
-    for (int i = 0; i < MAXL; ++i) r.c[i] = c[i] + o.c[i];
-    return r;
-  }
-};
+constexpr int TILE = 1024;          // stream positions per count/assign workgroup
+constexpr int BIG_ROW_CAP = 16384;  // LDS bitonic capacity (64 KiB of int32)
 
 struct UnionArgs {
   const uint32_t* roots;
@@ -90,8 +83,42 @@ __device__ __forceinline__ int64_t parent_pos(const UnionArgs& a, int k, int64_t
   return k == 0 ? p : a.off[k - 1] + p;
 }
 
-__global__ void insert_kernel(UnionArgs a) {
+__device__ __forceinline__ uint32_t table_insert(const UnionArgs& a, uint32_t id) {
+  uint32_t s = hash_u32(id) & a.mask;
+  while (true) {
+    uint32_t prev = atomicCAS(&a.keys[s], GIGL_INVALID, id);
+    if (prev == GIGL_INVALID || prev == id) return s;
+    s = (s + 1) & a.mask;
+  }
+}
+
+// slot of `id` or -1 (read-only probe; keys written by an EARLIER kernel are always found)
+__device__ __forceinline__ int32_t table_find(const UnionArgs& a, uint32_t id) {
+  uint32_t s = hash_u32(id) & a.mask;
+  while (true) {
+    uint32_t k = __hip_atomic_load(&a.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == id) return (int32_t)s;
+    if (k == GIGL_INVALID) return -1;
+    s = (s + 1) & a.mask;
+  }
+}
+
+__global__ void insert_roots_kernel(UnionArgs a) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.b) return;
+  uint32_t id = a.roots[t];
+  if (id == GIGL_INVALID) {
+    a.slot_of[t] = -1;
+    return;
+  }
+  uint32_t s = table_insert(a, id);
+  atomicMin(&a.firstpos[s], (uint32_t)t);
+  a.level[s] = 0;
+  a.slot_of[t] = (int32_t)s;
+}
+
+__global__ void insert_slots_kernel(UnionArgs a) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + a.b;
   if (t >= a.T) return;
   int k;
   int64_t j;
@@ -100,17 +127,24 @@ __global__ void insert_kernel(UnionArgs a) {
     a.slot_of[t] = -1;
     return;
   }
-  uint32_t s = hash_u32(id) & a.mask;
-  while (true) {
-    uint32_t prev = atomicCAS(&a.keys[s], GIGL_INVALID, id);
-    if (prev == GIGL_INVALID || prev == id) break;
-    s = (s + 1) & a.mask;
-  }
+  uint32_t s = table_insert(a, id);
   atomicMin(&a.firstpos[s], (uint32_t)t);
-  if (k < 0) atomicMin(&a.level[s], 0);
+  int32_t lvl;
+  if (k == 0) {
+    lvl = 1;
+  } else if (k == 1) {
+    // parent = hop-0 slot node: level 0 iff it is a root (roots were inserted by the previous kernel)
+    uint32_t pid = a.nbr[0][j / a.fan[1]];
+    int32_t ps = table_find(a, pid);
+    lvl = (ps >= 0 && __hip_atomic_load(&a.level[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) ? 1 : 2;
+  } else {
+    lvl = k + 1;  // upper bound; relaxed below
+  }
+  atomicMin(&a.level[s], lvl);
   a.slot_of[t] = (int32_t)s;
 }
 
+// hops > 2 only: level(src) = min(level(src), level(dst)+1)
 __global__ void relax_kernel(UnionArgs a) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + a.b;
   if (t >= a.T) return;
@@ -120,108 +154,314 @@ __global__ void relax_kernel(UnionArgs a) {
   int64_t j;
   stream_at(a, t, k, j);
   int32_t ds = a.slot_of[parent_pos(a, k, j)];
-  // level[] is only ever lowered; a stale read only delays convergence (hops rounds suffice)
   int32_t dl = __hip_atomic_load(&a.level[ds], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (dl + 1 < LVL_INF) atomicMin(&a.level[s], dl + 1);
+  atomicMin(&a.level[s], dl + 1);
 }
 
-__global__ void flag_kernel(UnionArgs a, LevelCount* flags) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.T) return;
-  LevelCount f;
+// first-occurrence level of stream position t, or -1
+__device__ __forceinline__ int first_level(const UnionArgs& a, int64_t t) {
+  if (t >= a.T) return -1;
+  int32_t s = a.slot_of[t];
+  if (s < 0 || a.firstpos[s] != (uint32_t)t) return -1;
+  return a.level[s];
+}
+
+// tile_counts[tile][l] = number of first occurrences of level l in the tile
+__global__ __launch_bounds__(256) void count_kernel(UnionArgs a, int32_t* tile_counts) {
+  __shared__ int32_t s_cnt[MAXL];
+  if (threadIdx.x < MAXL) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+  int32_t c[MAXL];
 #pragma unroll
-  for (int i = 0; i < MAXL; ++i) f.c[i] = 0;
-  int32_t s = a.slot_of[t];
-  if (s >= 0 && a.firstpos[s] == (uint32_t)t) {
-    int32_t l = a.level[s];
-    if (l >= 0 && l < MAXL) f.c[l] = 1;
+  for (int l = 0; l < MAXL; ++l) c[l] = 0;
+#pragma unroll
+  for (int r = 0; r < TILE / 256; ++r) {
+    int lv = first_level(a, base + r * 256 + threadIdx.x);
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) c[l] += (lv == l);
   }
-  flags[t] = f;
-}
-
-// meta from the scan tail: totals per level -> cumulative
-__global__ void meta_kernel(UnionArgs a, const LevelCount* flags, const LevelCount* scan,
-                            int32_t* meta, int32_t* level_base) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  LevelCount tot = scan[a.T - 1] + flags[a.T - 1];
-  int32_t cum = 0;
+#pragma unroll
   for (int l = 0; l < MAXL; ++l) {
-    level_base[l] = cum;
-    cum += tot.c[l];
-    if (l <= a.hops) meta[GIGL_META_LEVEL0 + l] = cum;
+    int v = c[l];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cnt[l], v);
   }
-  meta[GIGL_META_N_NODES] = cum;
+  __syncthreads();
+  if (threadIdx.x < MAXL) tile_counts[blockIdx.x * MAXL + threadIdx.x] = s_cnt[threadIdx.x];
 }
 
-__global__ void assign_kernel(UnionArgs a, const LevelCount* flags, const LevelCount* scan,
-                              const int32_t* level_base, uint32_t* nodes) {
+// local id = base[level] + (first occurrences of that level at smaller stream positions)
+__global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t* tile_counts, int32_t n_tiles,
+                                                     uint32_t* nodes, int32_t* meta) {
+  __shared__ int32_t s_before[MAXL];  // this level's firsts in earlier tiles
+  __shared__ int32_t s_total[MAXL];   // totals per level
+  __shared__ int32_t s_wave[TILE / 64][MAXL];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  {
+    int32_t bef[MAXL], tot[MAXL];
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) bef[l] = tot[l] = 0;
+    for (int i = tid; i < n_tiles; i += 256) {
+#pragma unroll
+      for (int l = 0; l < MAXL; ++l) {
+        int32_t v = tile_counts[i * MAXL + l];
+        tot[l] += v;
+        if (i < (int)blockIdx.x) bef[l] += v;
+      }
+    }
+    if (tid < MAXL) s_before[tid] = s_total[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+      int vb = bef[l], vt = tot[l];
+      for (int off = 32; off > 0; off >>= 1) {
+        vb += __shfl_xor(vb, off, 64);
+        vt += __shfl_xor(vt, off, 64);
+      }
+      if (lane == 0) {
+        if (vb) atomicAdd(&s_before[l], vb);
+        if (vt) atomicAdd(&s_total[l], vt);
+      }
+    }
+    __syncthreads();
+  }
+  // ranks inside the tile: sub-tile r = 256 consecutive positions = 4 waves
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+  int lv[TILE / 256];
+  int rank_in_wave[TILE / 256];
+#pragma unroll
+  for (int r = 0; r < TILE / 256; ++r) {
+    lv[r] = first_level(a, base + r * 256 + tid);
+    rank_in_wave[r] = 0;
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) {
+      unsigned long long m = __ballot(lv[r] == l);
+      if (lv[r] == l) rank_in_wave[r] = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wave[r * 4 + w][l] = __popcll(m);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < TILE / 256; ++r) {
+    if (lv[r] < 0) continue;
+    const int l = lv[r];
+    int32_t id = s_before[l] + rank_in_wave[r];
+    for (int q = 0; q < r * 4 + w; ++q) id += s_wave[q][l];
+    for (int ll = 0; ll < l; ++ll) id += s_total[ll];
+    const int32_t s = a.slot_of[base + r * 256 + tid];
+    a.lid[s] = id;
+    nodes[id] = a.keys[s];
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    int32_t cum = 0;
+    for (int l = 0; l < MAXL; ++l) {
+      cum += s_total[l];
+      if (l <= a.hops) meta[GIGL_META_LEVEL0 + l] = cum;
+    }
+    meta[GIGL_META_N_NODES] = cum;
+  }
+}
+
+// edge dedup: the first occurrence to claim (dst_local, src_local) in the edge hash set is the edge's
+// "winner"; winners are counted per destination row.  Which occurrence wins is irrelevant (rows are
+// sorted afterwards).  Threads t < b also publish root_local.
+__global__ void edge_dedup_count_kernel(UnionArgs a, unsigned long long* ekeys, uint32_t emask,
+                                        uint8_t* winner, int32_t* rowcnt, int32_t* root_local) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.T) return;
   int32_t s = a.slot_of[t];
-  if (s < 0 || a.firstpos[s] != (uint32_t)t) return;
-  int32_t l = a.level[s];
-  int32_t id = level_base[l] + scan[t].c[l];
-  a.lid[s] = id;
-  nodes[id] = a.keys[s];
-}
-
-__global__ void root_local_kernel(UnionArgs a, int32_t* root_local) {
-  int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.b) return;
-  int32_t s = a.slot_of[i];
-  root_local[i] = s >= 0 ? a.lid[s] : -1;
-}
-
-__global__ void edge_key_kernel(UnionArgs a, uint64_t* ekeys) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t t = e + a.b;
-  if (t >= a.T) return;
-  int32_t s = a.slot_of[t];
-  uint64_t key = ~0ULL;
+  if (t < a.b) {
+    root_local[t] = s >= 0 ? a.lid[s] : -1;
+    return;
+  }
+  bool win = false;
   if (s >= 0) {
     int k;
     int64_t j;
     stream_at(a, t, k, j);
-    int32_t ds = a.slot_of[parent_pos(a, k, j)];
-    key = ((uint64_t)(uint32_t)a.lid[ds] << 32) | (uint32_t)a.lid[s];
+    const int32_t dl = a.lid[a.slot_of[parent_pos(a, k, j)]];
+    const int32_t sl = a.lid[s];
+    const unsigned long long key = ((unsigned long long)(uint32_t)dl << 32) | (uint32_t)sl;
+    uint32_t h = hash_u32((uint32_t)sl * 0x9E3779B1u ^ (uint32_t)dl) & emask;
+    while (true) {
+      unsigned long long prev = atomicCAS(&ekeys[h], ~0ULL, key);
+      if (prev == ~0ULL) {
+        win = true;
+        break;
+      }
+      if (prev == key) break;
+      h = (h + 1) & emask;
+    }
+    if (win) atomicAdd(&rowcnt[dl], 1);
   }
-  ekeys[e] = key;
+  winner[t - a.b] = win ? 1 : 0;
 }
 
-__global__ void edge_flag_kernel(const uint64_t* sorted, int64_t n, int32_t* flags) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  uint64_t k = sorted[e];
-  flags[e] = (k != ~0ULL && (e == 0 || sorted[e - 1] != k)) ? 1 : 0;
+// exclusive scan of rowcnt[0..n) -> rowptr[0..n], rowend[i] = rowptr[i] (fill cursor); rows >= n get
+// rowptr = rowend = total.  n = nodes that can have in-edges (levels < hops).  One workgroup.
+__global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* rowcnt, int32_t* meta, int hops,
+                                                        int64_t cap_nodes, int32_t* rowptr, int32_t* rowend) {
+  __shared__ int32_t s_w[16];
+  __shared__ int32_t s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int32_t n = meta[GIGL_META_LEVEL0 + hops - 1];
+  const int32_t n_nodes = meta[GIGL_META_N_NODES];
+  if (tid == 0) s_carry = 0;
+  __syncthreads();
+  for (int32_t base = 0; base < n; base += 1024) {
+    const int32_t i = base + tid;
+    int32_t v = i < n ? rowcnt[i] : 0;
+    int32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      int32_t o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int32_t wave_off = 0;
+    for (int q = 0; q < w; ++q) wave_off += s_w[q];
+    const int32_t carry = s_carry;
+    if (i < n) {
+      const int32_t ex = carry + wave_off + incl - v;
+      rowptr[i] = ex;
+      rowend[i] = ex;
+    }
+    __syncthreads();
+    if (tid == 1023) s_carry = carry + wave_off + incl;
+    __syncthreads();
+  }
+  const int32_t total = s_carry;
+  for (int64_t i = (int64_t)n + tid; i <= n_nodes && i <= cap_nodes; i += 1024) {
+    rowptr[i] = total;
+    rowend[i] = total;
+  }
+  if (tid == 0) meta[GIGL_META_N_EDGES] = total;  // winners only: the unique edge count
 }
 
-__global__ void edge_write_kernel(const uint64_t* sorted, const int32_t* flags, const int32_t* scan,
-                                  int64_t n, int32_t* col, uint64_t* ukeys, int32_t* meta) {
-  int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  if (flags[e]) {
-    int32_t r = scan[e];
-    col[r] = (int32_t)(sorted[e] & 0xFFFFFFFFu);
-    ukeys[r] = sorted[e];
-  }
-  if (e == n - 1) meta[GIGL_META_N_EDGES] = scan[e] + flags[e];
+__global__ void edge_fill_kernel(UnionArgs a, const uint8_t* winner, int32_t* rowend, int32_t* col) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + a.b;
+  if (t >= a.T) return;
+  if (!winner[t - a.b]) return;
+  int32_t s = a.slot_of[t];
+  int k;
+  int64_t j;
+  stream_at(a, t, k, j);
+  int32_t ds = a.slot_of[parent_pos(a, k, j)];
+  int32_t pos = atomicAdd(&rowend[a.lid[ds]], 1);
+  col[pos] = a.lid[s];
 }
 
-// rowptr[i] = number of unique edges with dst < i  (lower_bound of i<<32 in the unique sorted keys)
-__global__ void rowptr_kernel(const uint64_t* ukeys, const int32_t* meta, int32_t* rowptr,
-                              int64_t cap_nodes) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int32_t nn = meta[GIGL_META_N_NODES];
-  if (i > nn || i > cap_nodes) return;
-  int32_t ne = meta[GIGL_META_N_EDGES];
-  uint64_t target = (uint64_t)i << 32;
-  int32_t lo = 0, hi = ne;
-  while (lo < hi) {
-    int32_t mid = (lo + hi) >> 1;
-    if (ukeys[mid] < target) lo = mid + 1;
-    else hi = mid;
+// one wave per row: sort ascending in place (rows <= 64, values are unique); longer rows are queued
+__global__ __launch_bounds__(256) void row_sort_kernel(const int32_t* meta, int hops, const int32_t* rowptr,
+                                                       const int32_t* rowend, int32_t* col, int32_t* big_rows,
+                                                       int32_t* big_count) {
+  const int lane = threadIdx.x & 63;
+  const int32_t n = meta[GIGL_META_LEVEL0 + hops - 1];
+  const int32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int32_t waves_total = (gridDim.x * blockDim.x) >> 6;
+  for (int32_t i = wave; i < n; i += waves_total) {
+    const int32_t s = rowptr[i], m = rowend[i] - s;
+    if (m <= 1) continue;
+    if (m > 64) {
+      if (lane == 0) big_rows[atomicAdd(big_count, 1)] = i;
+      continue;
+    }
+    const int32_t v = lane < m ? col[s + lane] : 0x7FFFFFFF;
+    int32_t pos = 0;
+    for (int j = 0; j < m; ++j) pos += __builtin_amdgcn_readlane(v, j) < v ? 1 : 0;
+    if (lane < m) col[s + pos] = v;
   }
-  rowptr[i] = lo;
+}
+
+// one 1024-thread workgroup per queued row (65 .. BIG_ROW_CAP unique values): bucket sort in LDS.
+// Values are unique local ids, so 1024 range buckets over [min, max] hold a handful each; a bucket is
+// sorted by one wave (rank-by-counting in registers when <= 64, from LDS otherwise).
+constexpr int NBUCKET = 1024;
+__global__ __launch_bounds__(1024) void row_sort_big_kernel(const int32_t* rowptr, const int32_t* rowend,
+                                                            int32_t* col, const int32_t* big_rows,
+                                                            const int32_t* big_count, int32_t* overflow) {
+  extern __shared__ int32_t lds[];  // A = lds[0..CAP), B = lds[CAP..2CAP)
+  int32_t* A = lds;
+  int32_t* B = lds + BIG_ROW_CAP;
+  __shared__ int32_t s_cnt[NBUCKET];
+  __shared__ int32_t s_off[NBUCKET + 1];
+  __shared__ int32_t s_w[16];
+  __shared__ int32_t s_min, s_max;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int32_t nb = *big_count;
+  for (int32_t r = blockIdx.x; r < nb; r += gridDim.x) {
+    const int32_t i = big_rows[r];
+    const int32_t s = rowptr[i], m = rowend[i] - s;
+    if (m > BIG_ROW_CAP) {  // does not fit the LDS sort: left unsorted, reported through meta
+      if (tid == 0) atomicAdd(overflow, 1);
+      continue;
+    }
+    if (tid == 0) {
+      s_min = 0x7FFFFFFF;
+      s_max = 0;
+    }
+    s_cnt[tid] = 0;
+    __syncthreads();
+    int32_t mn = 0x7FFFFFFF, mx = 0;
+    for (int q = tid; q < m; q += 1024) {
+      const int32_t v = col[s + q];
+      A[q] = v;
+      mn = min(mn, v);
+      mx = max(mx, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = min(mn, __shfl_xor(mn, off, 64));
+      mx = max(mx, __shfl_xor(mx, off, 64));
+    }
+    if (lane == 0) {
+      atomicMin(&s_min, mn);
+      atomicMax(&s_max, mx);
+    }
+    __syncthreads();
+    const int64_t vmin = s_min, span = (int64_t)s_max - s_min + 1;
+    for (int q = tid; q < m; q += 1024) atomicAdd(&s_cnt[(int)(((int64_t)(A[q] - vmin) * NBUCKET) / span)], 1);
+    __syncthreads();
+    {  // exclusive scan of the 1024 bucket counts (one per thread)
+      const int32_t v = s_cnt[tid];
+      int32_t incl = v;
+      for (int off = 1; off < 64; off <<= 1) {
+        int32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) s_w[w] = incl;
+      __syncthreads();
+      int32_t wave_off = 0;
+      for (int q = 0; q < w; ++q) wave_off += s_w[q];
+      s_off[tid] = wave_off + incl - v;
+      if (tid == 1023) s_off[NBUCKET] = wave_off + incl;
+      s_cnt[tid] = wave_off + incl - v;  // reuse as the scatter cursor
+    }
+    __syncthreads();
+    for (int q = tid; q < m; q += 1024) {
+      const int32_t v = A[q];
+      B[atomicAdd(&s_cnt[(int)(((int64_t)(v - vmin) * NBUCKET) / span)], 1)] = v;
+    }
+    __syncthreads();
+    for (int bk = w; bk < NBUCKET; bk += 16) {
+      const int32_t lo = s_off[bk], sz = s_off[bk + 1] - lo;
+      if (sz == 0) continue;
+      if (sz <= 64) {
+        const int32_t v = lane < sz ? B[lo + lane] : 0x7FFFFFFF;
+        int32_t pos = 0;
+        for (int j = 0; j < sz; ++j) pos += __builtin_amdgcn_readlane(v, j) < v ? 1 : 0;
+        if (lane < sz) col[s + lo + pos] = v;
+      } else {  // crowded bucket: rank against the whole bucket from LDS
+        for (int q = lane; q < sz; q += 64) {
+          const int32_t v = B[lo + q];
+          int32_t pos = 0;
+          for (int j = 0; j < sz; ++j) pos += B[lo + j] < v ? 1 : 0;
+          col[s + lo + pos] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
 }
 
 }  // namespace
@@ -245,7 +485,7 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
                          gigl_union* out) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   GIGL_REQUIRE(ctx, tree && out && (roots || tree->b == 0), "null argument");
-  GIGL_REQUIRE(ctx, out->meta && out->nodes && out->rowptr && out->col && out->root_local,
+  GIGL_REQUIRE(ctx, out->meta && out->nodes && out->rowptr && out->rowend && out->col && out->root_local,
                "union output buffers are null");
   const int hops = tree->hops, b = tree->b;
   GIGL_REQUIRE(ctx, hops >= 1 && hops <= GIGL_MAX_HOPS && b >= 0, "bad tree");
@@ -259,6 +499,7 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
   GIGL_HIP_CHECK(ctx, hipMemsetAsync(out->meta, 0, GIGL_META_LEN * sizeof(int32_t), st));
   if (b == 0) {
     GIGL_HIP_CHECK(ctx, hipMemsetAsync(out->rowptr, 0, sizeof(int32_t), st));
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(out->rowend, 0, sizeof(int32_t), st));
     return GIGL_OK;
   }
 
@@ -276,90 +517,90 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
   }
   a.off[hops] = T;
   a.T = T;
-  const int64_t E = T - b;  // edge occurrences
+  const int64_t E = T - b;              // edge occurrences
+  const int64_t max_rows = a.off[hops - 1];  // nodes that are the parent of some slot
   uint64_t cap = 1024;
   while (cap < (uint64_t)T * 2) cap <<= 1;
   a.mask = (uint32_t)(cap - 1);
+  const int32_t n_tiles = (int32_t)((T + TILE - 1) / TILE);
+  uint64_t ecap = 1024;
+  while (ecap < (uint64_t)E * 2) ecap <<= 1;
 
-  // temp storage sizes for rocPRIM calls
-  size_t tmp_scan_lc = 0, tmp_scan_i = 0, tmp_sort = 0;
-  hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_scan_lc, (LevelCount*)nullptr,
-                                   (LevelCount*)nullptr, (int)T, st);
-  hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_scan_i, (int32_t*)nullptr, (int32_t*)nullptr,
-                                   (int)(E > 0 ? E : 1), st);
-  int key_bits = 32;
-  while ((1LL << (key_bits - 32)) < T + 1) ++key_bits;  // dst_local < T
-  hipcub::DeviceRadixSort::SortKeys((void*)nullptr, tmp_sort, (uint64_t*)nullptr, (uint64_t*)nullptr,
-                                    (int)(E > 0 ? E : 1), 0, key_bits, st);
-  size_t tmp_bytes = tmp_scan_lc > tmp_scan_i ? tmp_scan_lc : tmp_scan_i;
-  if (tmp_sort > tmp_bytes) tmp_bytes = tmp_sort;
-
+  // scratch: [keys | firstpos | level] are memset together; everything else is written before read
   int64_t need = 0;
   auto add = [&](int64_t bytes) { need += gigl_align_up(bytes, 256); };
-  add(cap * 4); add(cap * 4); add(cap * 4); add(cap * 4);      // table
-  add(T * 4);                                                  // slot_of
-  add(T * sizeof(LevelCount)); add(T * sizeof(LevelCount));    // flags, scan
-  add(256);                                                    // level_base
-  add(E * 8); add(E * 8); add(E * 8);                          // ekeys, sorted, ukeys
-  add(E * 4); add(E * 4);                                      // eflags, escan
-  add((int64_t)tmp_bytes);
+  add((int64_t)cap * 4 * 3);         // keys, firstpos, level (contiguous)
+  add((int64_t)cap * 4);             // lid
+  add(T * 4);                        // slot_of
+  add((int64_t)n_tiles * MAXL * 4);  // tile counts
+  add((cap_nodes + 1) * 4);          // rowcnt
+  add(cap_nodes * 4 + 256);          // big-row queue + counter
+  add((int64_t)ecap * 8);            // edge hash set
+  add(E + 256);                      // winner flags
   int32_t rc = gigl_arena_reset(ctx, need + 4096);
   if (rc != GIGL_OK) return rc;
-  a.keys = (uint32_t*)gigl_arena_alloc(ctx, cap * 4);
-  a.firstpos = (uint32_t*)gigl_arena_alloc(ctx, cap * 4);
-  a.level = (int32_t*)gigl_arena_alloc(ctx, cap * 4);
-  a.lid = (int32_t*)gigl_arena_alloc(ctx, cap * 4);
+  uint32_t* tbl = (uint32_t*)gigl_arena_alloc(ctx, (int64_t)cap * 4 * 3);
+  a.lid = (int32_t*)gigl_arena_alloc(ctx, (int64_t)cap * 4);
   a.slot_of = (int32_t*)gigl_arena_alloc(ctx, T * 4);
-  LevelCount* flags = (LevelCount*)gigl_arena_alloc(ctx, T * sizeof(LevelCount));
-  LevelCount* scan = (LevelCount*)gigl_arena_alloc(ctx, T * sizeof(LevelCount));
-  int32_t* level_base = (int32_t*)gigl_arena_alloc(ctx, 256);
-  uint64_t* ekeys = (uint64_t*)gigl_arena_alloc(ctx, E * 8);
-  uint64_t* sorted = (uint64_t*)gigl_arena_alloc(ctx, E * 8);
-  uint64_t* ukeys = (uint64_t*)gigl_arena_alloc(ctx, E * 8);
-  int32_t* eflags = (int32_t*)gigl_arena_alloc(ctx, E * 4);
-  int32_t* escan = (int32_t*)gigl_arena_alloc(ctx, E * 4);
-  void* tmp = gigl_arena_alloc(ctx, (int64_t)tmp_bytes);
-  if (!tmp || !escan) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  int32_t* tile_counts = (int32_t*)gigl_arena_alloc(ctx, (int64_t)n_tiles * MAXL * 4);
+  int32_t* rowcnt = (int32_t*)gigl_arena_alloc(ctx, (cap_nodes + 1) * 4);
+  int32_t* big = (int32_t*)gigl_arena_alloc(ctx, cap_nodes * 4 + 256);
+  unsigned long long* ekeys = (unsigned long long*)gigl_arena_alloc(ctx, (int64_t)ecap * 8);
+  uint8_t* winner = (uint8_t*)gigl_arena_alloc(ctx, E + 256);
+  if (!tbl || !big || !rowcnt || !ekeys || !winner) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  a.keys = tbl;
+  a.firstpos = tbl + cap;
+  a.level = (int32_t*)(tbl + 2 * cap);
+  int32_t* big_count = big;  // [0] = number of queued rows
+  int32_t* big_rows = big + 64;
 
   const int TB = 256;
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_INSERT);
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.keys, 0xFF, cap * 4, st));
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.firstpos, 0xFF, cap * 4, st));
-    // LVL_INF = 0x00100000: bytes are not uniform, so fill via 0x7F (0x7F7F7F7F > any real level)
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.level, 0x7F, cap * 4, st));
-    hipLaunchKernelGGL(insert_kernel, grid(T), dim3(TB), 0, st, a);
+    // keys / firstpos = 0xFFFFFFFF, level = 0x7F7F7F7F (+inf)
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.keys, 0xFF, (size_t)cap * 4 * 2, st));
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.level, 0x7F, (size_t)cap * 4, st));
+    hipLaunchKernelGGL(insert_roots_kernel, grid(b), dim3(TB), 0, st, a);
+    if (E > 0) hipLaunchKernelGGL(insert_slots_kernel, grid(E), dim3(TB), 0, st, a);
   }
-  {
+  if (hops > 2 && E > 0) {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_RELAX);
     for (int r = 0; r < hops; ++r) hipLaunchKernelGGL(relax_kernel, grid(E), dim3(TB), 0, st, a);
   }
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_NODES);
-    hipLaunchKernelGGL(flag_kernel, grid(T), dim3(TB), 0, st, a, flags);
-    GIGL_HIP_CHECK(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flags, scan, (int)T, st));
-    hipLaunchKernelGGL(meta_kernel, dim3(1), dim3(64), 0, st, a, flags, scan, out->meta, level_base);
-    hipLaunchKernelGGL(assign_kernel, grid(T), dim3(TB), 0, st, a, flags, scan, level_base, out->nodes);
-    hipLaunchKernelGGL(root_local_kernel, grid(b), dim3(TB), 0, st, a, out->root_local);
+    hipLaunchKernelGGL(count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, a, tile_counts);
+    hipLaunchKernelGGL(assign_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, a, tile_counts, n_tiles,
+                       out->nodes, out->meta);
+  }
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_EDGE_SORT);
+    // every node of level < hops may be a row (also leaf-only ones reached under a root parent)
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(rowcnt, 0, (size_t)(cap_nodes + 1) * 4, st));
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(big_count, 0, 256, st));
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(ekeys, 0xFF, (size_t)ecap * 8, st));
+    hipLaunchKernelGGL(edge_dedup_count_kernel, grid(T), dim3(TB), 0, st, a, ekeys, (uint32_t)(ecap - 1), winner,
+                       rowcnt, out->root_local);
+    hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, st, rowcnt, out->meta, hops, out->cap_nodes,
+                       out->rowptr, out->rowend);
+    if (E > 0) hipLaunchKernelGGL(edge_fill_kernel, grid(E), dim3(TB), 0, st, a, winner, out->rowend, out->col);
   }
   if (E > 0) {
-    {
-      gigl_prof_scope ps(ctx, GIGL_K_UNION_EDGE_SORT);
-      hipLaunchKernelGGL(edge_key_kernel, grid(E), dim3(TB), 0, st, a, ekeys);
-      GIGL_HIP_CHECK(ctx, hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, ekeys, sorted, (int)E, 0,
-                                                            key_bits, st));
-    }
     gigl_prof_scope ps(ctx, GIGL_K_UNION_CSR);
-    hipLaunchKernelGGL(edge_flag_kernel, grid(E), dim3(TB), 0, st, sorted, E, eflags);
-    GIGL_HIP_CHECK(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, eflags, escan, (int)E, st));
-    hipLaunchKernelGGL(edge_write_kernel, grid(E), dim3(TB), 0, st, sorted, eflags, escan, E, out->col,
-                       ukeys, out->meta);
-    hipLaunchKernelGGL(rowptr_kernel, grid(cap_nodes + 1), dim3(TB), 0, st, ukeys, out->meta,
-                       out->rowptr, out->cap_nodes);
-  } else {
-    hipLaunchKernelGGL(rowptr_kernel, grid(cap_nodes + 1), dim3(TB), 0, st, ukeys, out->meta,
-                       out->rowptr, out->cap_nodes);
+    int64_t blocks = (max_rows + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(row_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out->meta, hops, out->rowptr,
+                       out->rowend, out->col, big_rows, big_count);
+    static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs the opt-in once per process
+    if (!lds_attr_set) {
+      GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)row_sort_big_kernel,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
+      lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(row_sort_big_kernel, dim3(256), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st,
+                       out->rowptr, out->rowend, out->col, big_rows, big_count, out->meta + GIGL_META_OVERFLOW);
   }
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;

@@ -41,7 +41,8 @@ class UnionGraph:
     """device-resident batch union graph (include/gigl_hip.h `gigl_union`)"""
     meta: torch.Tensor        # int32 [16]
     nodes: torch.Tensor       # int32 storage of uint32 global ids [cap_nodes]
-    rowptr: torch.Tensor      # int32 [cap_nodes+1]
+    rowptr: torch.Tensor      # int32 [cap_nodes+1]  row i = col[rowptr[i]:rowend[i]]
+    rowend: torch.Tensor      # int32 [cap_nodes+1]
     col: torch.Tensor         # int32 [cap_edges]
     root_local: torch.Tensor  # int32 [b]
     hops: int
@@ -49,7 +50,22 @@ class UnionGraph:
 
     def counts(self):
         m = self.meta.cpu().tolist()
+        if m[8]:
+            raise RuntimeError(f"{m[8]} union rows exceeded the in-LDS dedup capacity (meta[GIGL_META_OVERFLOW])")
         return dict(n_nodes=m[0], n_edges=m[1], levels=m[2:2 + self.hops + 1])
+
+    def to_csr(self):
+        """host copy as a packed CSR: (nodes uint32[n], rowptr int64[n+1], col int32[e])"""
+        m = self.counts()
+        n = m["n_nodes"]
+        rp = self.rowptr[: n + 1].cpu().numpy().astype(np.int64)
+        re = self.rowend[: n + 1].cpu().numpy().astype(np.int64)
+        col = self.col.cpu().numpy()
+        lens = re[:n] - rp[:n]
+        out_rp = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=out_rp[1:])
+        idx = np.repeat(rp[:n] - out_rp[:n], lens) + np.arange(int(out_rp[-1]))
+        return self.nodes[:n].cpu().numpy().view(np.uint32), out_rp, col[idx]
 
 
 class HipEngine:
@@ -256,12 +272,14 @@ class HipEngine:
         meta = torch.zeros(GIGL_META_LEN, dtype=torch.int32, device=dev)
         nodes = torch.empty(max(cn, 1), dtype=torch.int32, device=dev)
         rowptr = torch.zeros(cn + 2, dtype=torch.int32, device=dev)
+        rowend = torch.zeros(cn + 2, dtype=torch.int32, device=dev)
         col = torch.empty(max(ce, 1), dtype=torch.int32, device=dev)
         root_local = torch.empty(max(b, 1), dtype=torch.int32, device=dev)
-        u.meta, u.nodes, u.rowptr, u.col, u.root_local = (meta.data_ptr(), nodes.data_ptr(), rowptr.data_ptr(),
-                                                           col.data_ptr(), root_local.data_ptr())
+        u.meta, u.nodes, u.rowptr, u.rowend, u.col, u.root_local = (
+            meta.data_ptr(), nodes.data_ptr(), rowptr.data_ptr(), rowend.data_ptr(), col.data_ptr(),
+            root_local.data_ptr())
         u.cap_nodes, u.cap_edges = cn, ce
-        return UnionGraph(meta=meta, nodes=nodes, rowptr=rowptr, col=col, root_local=root_local,
+        return UnionGraph(meta=meta, nodes=nodes, rowptr=rowptr, rowend=rowend, col=col, root_local=root_local,
                           hops=len(fanouts), c_struct=u)
 
     def union_build(self, tree: Tree, out: Optional[UnionGraph] = None) -> UnionGraph:
@@ -271,9 +289,11 @@ class HipEngine:
         return u
 
     def gather_mean(self, src: Optional[torch.Tensor], d: int, gather_ids: Optional[torch.Tensor],
-                    rowptr: torch.Tensor, col: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """src None -> the resident feature table."""
+                    rowptr: torch.Tensor, rowend: Optional[torch.Tensor], col: torch.Tensor,
+                    n_rows_dev: torch.Tensor, rows_cap: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """src None -> the resident feature table; rowend None -> packed CSR (rowend = rowptr[1:])."""
+        if rowend is None:
+            rowend = rowptr[1:]
         if src is None:
             src_ptr, dt = self._feat_ptr, self.feat_dtype
         else:
@@ -284,7 +304,7 @@ class HipEngine:
             out = torch.empty((rows_cap, 2 * d), dtype=torch.float32, device=self.device)
         gid = C.c_void_p(gather_ids.data_ptr()) if gather_ids is not None else None
         check(self._lib.gigl_gather_mean(self._ctx, src_ptr, dt, d, gid, C.c_void_p(rowptr.data_ptr()),
-                                         C.c_void_p(col.data_ptr()), C.c_void_p(n_rows_dev.data_ptr()), rows_cap,
+                                         C.c_void_p(rowend.data_ptr()), C.c_void_p(col.data_ptr()), C.c_void_p(n_rows_dev.data_ptr()), rows_cap,
                                          C.c_void_p(out.data_ptr())), self._ctx)
         return out
 

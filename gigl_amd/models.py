@@ -78,12 +78,13 @@ class GraphSAGE(nn.Module):
         for l, conv in enumerate(self.conv_layers):
             n_rows = u.meta[GIGL_META_LEVEL0 + (L - 1 - l): GIGL_META_LEVEL0 + (L - l)]
             d = conv.in_channels
+            abuf = self._buf("a", l, cap, 2 * d)
             if l == 0 and batch.x is None:
-                a = eng.gather_mean(None, d, u.nodes, u.rowptr, u.col, n_rows, cap, out=self._buf("a", l, cap, 2 * d))
+                a = eng.gather_mean(None, d, u.nodes, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf)
             elif l == 0:
-                a = eng.gather_mean(batch.x, d, None, u.rowptr, u.col, n_rows, cap, out=self._buf("a", l, cap, 2 * d))
+                a = eng.gather_mean(batch.x, d, None, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf)
             else:
-                a = eng.gather_mean(h, d, None, u.rowptr, u.col, n_rows, cap, out=self._buf("a", l, cap, 2 * d))
+                a = eng.gather_mean(h, d, None, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf)
             act = 1 if (l < L - 1 or self.activation_after_last_conv) else 0
             bias = conv.lin_l.bias
             h = eng.linear(a, conv.fused_weight(), bias, n_rows, cap, act, out=self._buf("h", l, cap, conv.out_channels))

@@ -165,21 +165,27 @@ int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* 
  * canonical stream (roots, then hop-1 slots, then hop-2 slots ...).  So the rows a layer must
  * compute are always a prefix (layer-wise trimmed schedule, exact for root outputs).
  * Outputs (DEVICE, caller-allocated, capacities from gigl_union_capacity):
- *   meta[0]=n_nodes, meta[1]=n_edges, meta[2+l]=cumulative node count through level l
- *           (meta[2]=#distinct roots), l=0..hops; meta[GIGL_META_AGG_EDGES]… see below
+ *   meta[0]=n_nodes, meta[1]=n_edges (unique), meta[2+l]=cumulative node count through level l
+ *           (meta[2]=#distinct roots), l=0..hops; meta[GIGL_META_OVERFLOW] != 0 reports rows that
+ *           exceeded the in-LDS dedup capacity (16384 sampled in-edges of ONE node in ONE batch):
+ *           such a row keeps its duplicates — treat the batch as failed
  *   nodes[n_nodes]    global id of local node i
- *   rowptr[n_nodes+1] CSR by destination over local ids (int32)
- *   col[n_edges]      local source ids, ascending within a row
+ *   rowptr[i], rowend[i]  row i = col[rowptr[i] .. rowend[i]) — CSR by destination over local ids
+ *                     whose rows keep their pre-dedup capacity (rowptr is monotone, rowend[i] <=
+ *                     rowptr[i+1]); only nodes of level < hops have in-edges
+ *   col[...]          local source ids, ascending and duplicate-free within a row
  *   root_local[b]     local id of roots[i] (duplicates in `roots` map to the same local id) */
 #define GIGL_META_N_NODES 0
 #define GIGL_META_N_EDGES 1
 #define GIGL_META_LEVEL0 2 /* meta[2+l], l = 0..hops */
+#define GIGL_META_OVERFLOW 8
 #define GIGL_META_LEN 16
 
 typedef struct gigl_union {
   int32_t* meta;       /* [GIGL_META_LEN] */
   uint32_t* nodes;     /* [cap_nodes] */
   int32_t* rowptr;     /* [cap_nodes+1] */
+  int32_t* rowend;     /* [cap_nodes+1] */
   int32_t* col;        /* [cap_edges] */
   int32_t* root_local; /* [b] */
   int64_t cap_nodes;
@@ -195,15 +201,16 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
  *      python/gigl/src/common/models/pyg/homogeneous.py:107-153,171-202,300-343,488-546.
  *
  * gigl_gather_mean: the segmented gather + mean reduce, fused with feature hydration.
- *   rows i in [0, n_rows):  out[i][0:d]  = mean_{e in row i} src[ idx(col[e]) ][0:d]   (0 if empty)
+ *   rows i in [0, n_rows), row i = col[rowptr[i] .. rowend[i]) (rowend == rowptr + 1 for a packed CSR):
+ *                           out[i][0:d]  = mean_{e in row i} src[ idx(col[e]) ][0:d]   (0 if empty)
  *                           out[i][d:2d] = src[ idx(i) ][0:d]
  *   idx(j) = gather_ids ? gather_ids[j] : j   (gather_ids = union.nodes reads the global feature
  *   table directly: hydrateNodes, SGSPureSparkV1Task.scala:496-547, without materialising x).
  *   n_rows is read on the device from *n_rows_dev (a union.meta entry); rows_cap bounds the grid.
  *   out is f32 [rows_cap][2d] — the A operand of the SAGE projection [mean | self]·[W_l ; W_r]^T. */
 int32_t gigl_gather_mean(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
-                         const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* col,
-                         const int32_t* n_rows_dev, int64_t rows_cap, float* out);
+                         const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* rowend,
+                         const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, float* out);
 
 /* dense projection  y[i][0:n] = act( a[i][0:k] · w[0:n][0:k]^T + bias )  — fp32 MFMA
  * (v_mfma_f32_32x32x2_f32, exact f32).  w is row-major [n][k] (torch Linear layout; for SAGE

@@ -127,9 +127,14 @@ def test_union_build_bit_exact(eng, fanouts, b):
     assert np.array_equal(meta[: 3 + hops], o["meta"][: 3 + hops]), (meta, o["meta"])
     nn, ne = int(meta[0]), int(meta[1])
     assert np.array_equal(_u32(u.nodes)[:nn], o["nodes"])
-    assert np.array_equal(u.rowptr.cpu().numpy()[: nn + 1], o["rowptr"])
-    assert np.array_equal(u.col.cpu().numpy()[:ne], o["col"])
+    nodes_h, rp_h, col_h = u.to_csr()  # rows keep their pre-dedup capacity on the device; packed here
+    assert rp_h[-1] == ne
+    assert np.array_equal(rp_h, o["rowptr"])
+    assert np.array_equal(col_h, o["col"])
     assert np.array_equal(u.root_local.cpu().numpy()[:b], o["root_local"])
+    # device layout invariants: monotone starts, rowend within capacity
+    rp_d, re_d = u.rowptr.cpu().numpy()[: nn + 1], u.rowend.cpu().numpy()[: nn + 1]
+    assert np.all(np.diff(rp_d) >= 0) and np.all(re_d[:nn] <= rp_d[1:]) and np.all(re_d >= rp_d)
 
 
 def test_union_isolated_roots_only(eng):
@@ -171,14 +176,14 @@ def test_gather_mean_against_fp32_reference(eng, d, dtype):
     col = rng.integers(0, n_loc, size=int(rowptr[-1])).astype(np.int32)
     n_rows = 650  # a prefix
     dev = eng.device
-    out = eng.gather_mean(x.to(dev), d, torch.from_numpy(ids).to(dev), torch.from_numpy(rowptr).to(dev),
+    out = eng.gather_mean(x.to(dev), d, torch.from_numpy(ids).to(dev), torch.from_numpy(rowptr).to(dev), None,
                           torch.from_numpy(col).to(dev), torch.tensor([n_rows], dtype=torch.int32, device=dev), n_loc)
     got = out.cpu().numpy()[:n_rows]
     want = _ref_gather_mean(x.float().numpy(), ids, rowptr, col, n_rows)
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
     # identity gather (layer >= 2: sources are a dense local matrix)
     h = x[:n_loc].float().contiguous()
-    out2 = eng.gather_mean(h.to(dev), d, None, torch.from_numpy(rowptr).to(dev), torch.from_numpy(col).to(dev),
+    out2 = eng.gather_mean(h.to(dev), d, None, torch.from_numpy(rowptr).to(dev), None, torch.from_numpy(col).to(dev),
                            torch.tensor([n_rows], dtype=torch.int32, device=dev), n_loc)
     want2 = _ref_gather_mean(h.numpy(), np.arange(n_loc), rowptr, col, n_rows)
     np.testing.assert_allclose(out2.cpu().numpy()[:n_rows], want2, rtol=1e-5, atol=1e-5)
