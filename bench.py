@@ -4,14 +4,18 @@
 A "step" = one batch of B roots through the whole path, inputs already resident in HBM:
     k-hop sample (parity mode, Spark-hash permutation)  ->  batch union graph (dedup + CSR)
     ->  GraphSAGE forward (gather-mean + fp32 MFMA projection per layer, trimmed schedule)
-Workload at N=1 = BASELINE.json configs[1]: ogbn-products-SHAPED synthetic graph (N=2,449,029,
-RMAT(.57,.19,.19) power-law, ~61.9M undirected pairs bidirectionalised, D=100 fp32), fanout
-[25,10], B=1024, GraphSAGE 100->256->47.  MAG240M (the config the metric is
-quoted on) does not fit one GPU (375 GB of features), so per the contract the N=1 line is the
-largest single-GPU configuration.
+    ->  one embedding row per root
+enqueued by ONE library call (gigl_sage_plan_run).  Workload at N=1 = BASELINE.json configs[1]:
+ogbn-products-SHAPED synthetic graph (N=2,449,029, RMAT(.57,.19,.19) power-law, ~61.9M undirected
+pairs bidirectionalised, D=100 fp32), fanout [25,10], B=1024, GraphSAGE 100->256->47 (SURVEY.md
+§8(d) C2).  MAG240M (the config the metric is quoted on) does not fit one GPU (375 GB of features),
+so per the contract the N=1 line is the largest single-GPU configuration.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--small]
 
+Steps are independent batches, so they are pipelined over S HIP streams (one library ctx + one host
+thread per stream, all sharing the HBM-resident graph): while one batch is in its MFMA projection
+another is sampling.  Exactly K steps are timed in total.
 N>1: one process per GPU (torch.distributed, RCCL); every rank holds a replica of the graph and takes
 its own root batches — the path shards by roots with no data-path collective ("weak" scaling);
 time = max over ranks, value = total edges of all ranks / that time.
@@ -23,9 +27,11 @@ trimmed schedule — never the inflated L*|E_union|, which is reported in config
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -50,7 +56,7 @@ def rmat_edges_gpu(scale: int, n_edges: int, seed: int, device, a=0.57, b=0.19, 
     return src, dst
 
 
-def build_workload(eng, args, rank):
+def build_workload(eng, args):
     dev = eng.device
     if args.small:
         n, scale, pairs, d = 200_000, 18, 3_000_000, 100
@@ -75,10 +81,11 @@ def build_workload(eng, args, rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--fanouts", type=str, default="25,10")
+    ap.add_argument("--streams", type=int, default=8)
     ap.add_argument("--small", action="store_true", help="200k-node graph (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", type=str, default="parity", choices=["parity", "fast"])
@@ -93,126 +100,137 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert world == max(args.gpus, 1) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
-    from gigl_amd._lib import MODE_FAST, MODE_SPARK_HASH
+    from gigl_amd._lib import KERNEL_IDS, MODE_FAST, MODE_SPARK_HASH
     from gigl_amd.engine import HipEngine
-    from gigl_amd.models import GraphSAGE, HipBatch
+    from gigl_amd.models import GraphSAGE
 
     torch.cuda.set_device(local_rank)
-    eng = HipEngine(local_rank)
-    dev = eng.device
+    eng0 = HipEngine(local_rank)
+    dev = eng0.device
     fanouts = [int(v) for v in args.fanouts.split(",")]
-    B, K, W = args.batch, args.steps, args.warmup
+    B, K, W, S = args.batch, args.steps, args.warmup, max(1, args.streams)
+    L = len(fanouts)
     mode = MODE_SPARK_HASH if args.mode == "parity" else MODE_FAST
 
     t0 = time.time()
-    n, d = build_workload(eng, args, rank)
+    n, d = build_workload(eng0, args)
     hid, out_dim = 256, 47
     torch.manual_seed(0)
-    model = GraphSAGE(d, hid, out_dim, num_layers=len(fanouts)).to(dev)
+    model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
     # roots: seeded permutation of node ids (seed 42); rank r takes batches r, r+world, ...
     gp = torch.Generator(device="cpu")
     gp.manual_seed(42)
     total_batches = (W + K) * world
-    perm = torch.randperm(n, generator=gp)[: total_batches * B]
+    perm = torch.randperm(n, generator=gp)
     if perm.numel() < total_batches * B:
-        perm = perm.repeat((total_batches * B + perm.numel() - 1) // perm.numel())[: total_batches * B]
-    my = perm.view(total_batches, B)[rank::world].to(torch.int32).to(dev).contiguous()
+        perm = perm.repeat((total_batches * B + perm.numel() - 1) // perm.numel())
+    my = perm[: total_batches * B].view(total_batches, B)[rank::world].to(torch.int32).to(dev).contiguous()
+    torch.cuda.synchronize()
     setup_s = time.time() - t0
 
-    tree = eng.alloc_tree(B, fanouts)
-    union = eng.alloc_union(B, fanouts)
+    # S pipelines: ctx + stream + plan + host thread each, all sampling the same resident graph
+    engines, streams, plans, outs = [eng0], [], [], []
+    for s in range(1, S):
+        e = HipEngine(local_rank)
+        e.share_resident(eng0)
+        engines.append(e)
+    for s in range(S):
+        st = torch.cuda.Stream(device=dev)
+        engines[s].bind_stream(st)
+        streams.append(st)
+        plans.append(model.make_plan(engines[s], B, fanouts))
+        outs.append(torch.empty((B, out_dim), dtype=torch.float32, device=dev))
 
-    def step(i):
-        t = eng.sample_khop(my[i], fanouts, 42, mode, out=tree)
-        u = eng.union_build(t, out=union)
-        return model(HipBatch(eng, t, u))
+    def run_range(lo, hi):
+        """steps lo..hi-1, step i on pipeline i % S, one host thread per pipeline"""
+        def worker(s):
+            for i in range(lo + ((s - lo) % S), hi, S):
+                plans[s].run(my[i], out=outs[s], mode=mode)
+        ths = [threading.Thread(target=worker, args=(s,)) for s in range(S)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
 
-    # ---- untimed: warm-up + find the dominant kernel with all event timers on
-    for i in range(min(W, 3)):
-        step(i)
-    torch.cuda.synchronize()
-    from gigl_amd._lib import KERNEL_IDS
     names = list(KERNEL_IDS)
-    eng.profile_enable(names, capacity=64 * 16)
-    for i in range(min(W, 5)):
-        step(i)
-    prof = {k: eng.profile_read(k) for k in names}
+    # ---- untimed: warm-up, then find the dominant kernel with all event timers on
+    run_range(0, min(W, 2 * S))
+    torch.cuda.synchronize()
+    for e in engines:
+        e.profile_enable(names, capacity=64 * 16)
+    run_range(0, min(W, 2 * S))
+    prof = {k: [sum(x) for x in zip(*[e.profile_read(k) for e in engines])] for k in names}
     dominant = max(prof, key=lambda k: prof[k][0])
-    eng.profile_enable([dominant], capacity=(K + 8) * 8)
-    for i in range(W):
-        step(i)
-    eng.profile_reset()
+    for e in engines:
+        e.profile_enable([dominant], capacity=(K // S + 8) * 8)
+    run_range(0, W)
+    for e in engines:
+        e.profile_reset()
 
     # ---- timed region: exactly K steps, barrier + synchronize on both sides
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
+    run_range(W, W + K)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t1
-    dom_ms, dom_launches = eng.profile_read(dominant)
-    eng.profile_enable([], 0)
+    dom_ms, dom_launches = [sum(x) for x in zip(*[e.profile_read(dominant) for e in engines])]
+    for e in engines:
+        e.profile_enable([], 0)
 
     # ---- untimed: exact edge counts and algorithmic bytes of the same K batches (sampling is deterministic)
-    sampled = 0
-    aggregated = 0
-    ref_equiv = 0
-    union_edges = 0
+    g_rowptr, _ = (None, None)
+    rp_host = np.empty(n + 1, dtype=np.int64)
+    rp_dev, _cl = C.c_void_p(), C.c_void_p()
+    eng0._lib.gigl_graph_device_ptrs(eng0._graph, C.byref(rp_dev), C.byref(_cl))
+    eng0._lib.gigl_memcpy(eng0._ctx, C.c_void_p(rp_host.ctypes.data), 0, rp_dev, 1, rp_host.nbytes)
+    deg_all = np.diff(rp_host)
+    sampled = aggregated = ref_equiv = 0
     alg_bytes = {k: 0.0 for k in names}
-    rowptr_g, col_g = None, None
-    import ctypes as C
-    rp, cl = C.c_void_p(), C.c_void_p()
-    eng._lib.gigl_graph_device_ptrs(eng._graph, C.byref(rp), C.byref(cl))
-    count_steps = range(W, W + K)
-    L = len(fanouts)
+    dims = [d] + [hid] * (L - 1)
+    heavy_thr = 4096
+    count_steps = range(W, W + K)  # every timed batch, exactly
     for i in count_steps:
-        t = eng.sample_khop(my[i], fanouts, 42, mode, out=tree)
-        u = eng.union_build(t, out=union)
-        torch.cuda.synchronize()
-        cnts = [int(c.sum().item()) for c in t.cnt]
-        s_edges = sum(cnts)
-        sampled += s_edges
-        meta = u.meta.cpu().tolist()
-        nn, ne = meta[0], meta[1]
+        plans[0].run(my[i], out=outs[0], mode=mode)
+        hb = plans[0].last_batch_to_host()
+        meta = hb["meta"]
         if meta[8]:
             raise RuntimeError("union dedup overflow (meta[GIGL_META_OVERFLOW])")
-        rowlen = (u.rowend[:nn] - u.rowptr[:nn]).to(torch.int64)
-        agg_l = [int(rowlen[: meta[2 + (L - 1 - l)]].sum().item()) for l in range(L)]
+        s_edges = int(sum(int(c.sum()) for c in hb["cnt"]))
+        sampled += s_edges
+        nn, ne = int(meta[0]), int(meta[1])
+        rowlen = (hb["rowend"][:nn] - hb["rowptr"][:nn]).astype(np.int64)
+        agg_l = [int(rowlen[: int(meta[2 + (L - 1 - l)])].sum()) for l in range(L)]
         aggregated += sum(agg_l)
         ref_equiv += L * ne
-        union_edges += ne
         # algorithmic bytes (SURVEY.md §8(d)):
-        #  gather layer l: E_l*(4 + D_l*s) + N_dst*(8 + D_l*s_out) [+ self row D_l*s for the fused hydration copy]
-        dims = [d] + [hid] * (L - 1)
+        #  gather layer l: E_l*(4 + D_l*s) + N_dst*(8 + D_l*s_out) (+ the fused self-row copy D_l*s read + write)
         for l in range(L):
-            n_dst = meta[2 + (L - 1 - l)]
-            alg_bytes["gather_mean"] += agg_l[l] * (4 + dims[l] * 4) + n_dst * (8 + 2 * dims[l] * 4)
-        #  union: 16 B per sampled edge + 4 B per unique node
+            n_dst = int(meta[2 + (L - 1 - l)])
+            alg_bytes["gather_mean"] += agg_l[l] * (4 + dims[l] * 4) + n_dst * (8 + 3 * dims[l] * 4)
+        #  union: 16 B per sampled edge + 4 B per unique node, attributed evenly to its phases
         for k in ("union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr"):
-            alg_bytes[k] += (16 * s_edges + 4 * nn) / 5.0
-    # sampler bytes need frontier degrees: 16 + 4*deg + 8*min(deg,f) per frontier node (parity mode)
-    if dominant in ("expand", "expand_heavy", "find_heavy"):
-        eng_rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
-        eng._lib.gigl_memcpy(eng._ctx, C.c_void_p(eng_rowptr.data_ptr()), 1, rp, 1, (n + 1) * 8)
-        deg_all = (eng_rowptr[1:] - eng_rowptr[:-1])
-        heavy_thr = 4096
-        for i in count_steps:
-            t = eng.sample_khop(my[i], fanouts, 42, mode, out=tree)
-            torch.cuda.synchronize()
-            parents = [my[i]] + [t.nbr[k] for k in range(L - 1)]
-            for k in range(L):
-                p = parents[k].long()
-                valid = p >= 0
-                dg = deg_all[p.clamp(min=0)] * valid
-                f = fanouts[k]
-                per = 16 * valid + 4 * dg + 8 * torch.clamp(dg, max=f)
-                is_heavy = (dg > heavy_thr)
-                alg_bytes["expand_heavy"] += float((per * is_heavy).sum().item())
-                alg_bytes["expand"] += float((per * (~is_heavy)).sum().item())
+            alg_bytes[k] += (16 * s_edges + 4 * nn) / 4.0
+        #  sampler (parity mode): 16 + 4*deg + 8*min(deg, f) per frontier node
+        roots_h = my[i].cpu().numpy().view(np.uint32)
+        parents = [roots_h] + [hb["nbr"][k] for k in range(L - 1)]
+        for k in range(L):
+            p = parents[k]
+            valid = p != 0xFFFFFFFF
+            dg = deg_all[np.where(valid, p, 0)] * valid
+            per = 16 * valid + 4 * dg + 8 * np.minimum(dg, fanouts[k])
+            alg_bytes["expand"] += float(per.sum())
+        #  dense projections are FLOP-bound; bytes = operands once
+        for l in range(L):
+            n_dst = int(meta[2 + (L - 1 - l)])
+            dout = hid if l < L - 1 else out_dim
+            alg_bytes["linear"] += n_dst * (2 * dims[l] + dout) * 4 + dout * 2 * dims[l] * 4
+    scale = K / len(count_steps)
+    sampled, aggregated, ref_equiv = sampled * scale, aggregated * scale, ref_equiv * scale
+    alg_bytes = {k: v * scale for k, v in alg_bytes.items()}
 
     # ---- reduce over ranks
     if world > 1:
@@ -226,19 +244,19 @@ def main():
         sampled_all, aggregated_all, ref_equiv_all = float(sampled), float(aggregated), float(ref_equiv)
 
     value = (sampled_all + aggregated_all) / elapsed
-    launches_per_step = {"expand": L, "expand_heavy": L, "find_heavy": L, "gather_mean": L, "linear": L}.get(dominant, 1)
     avg_launch_ms = dom_ms / max(dom_launches, 1)
-    bytes_per_launch = alg_bytes[dominant] / max(K * launches_per_step, 1)
+    bytes_per_launch = alg_bytes[dominant] / max(dom_launches, 1)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    probe_steps = max(min(W, 2 * S), 1)
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                 "avg_launch_us": round(avg_launch_ms * 1e3, 2), "alg_bytes_per_launch": round(bytes_per_launch),
                 "launches": int(dom_launches),
-                "kernel_ms_untimed_probe": {k: round(v[0] / max(min(W, 5), 1), 4) for k, v in prof.items()}}
+                "kernel_ms_per_step_untimed_probe": {k: round(v[0] / probe_steps, 4) for k, v in prof.items()}}
 
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(eng, model, my, fanouts, W, n, d)
+        cpu_baseline = run_cpu_baseline(eng0, model, my, fanouts, W, n, d)
 
     if rank == 0:
         line = {
@@ -246,13 +264,15 @@ def main():
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("products-shaped-small" if args.small else "ogbn-products-shaped RMAT") +
-                       f" N={n} E={eng.n_edges} D={d} fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}"
+                       f" N={n} E={eng0.n_edges} D={d} fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}"
                        " inference step (sample+union+forward), sampler mode=" + args.mode,
                        "graph": "replica per GPU, roots sharded across ranks",
+                       "streams": S,
                        "sampled_edges_per_step": sampled_all / (K * world),
                        "aggregated_edges_per_step": aggregated_all / (K * world),
                        "reference_equivalent_aggregated_per_step": ref_equiv_all / (K * world),
                        "sampled_edges_per_s": sampled_all / elapsed, "aggregated_edges_per_s": aggregated_all / elapsed,
+                       "edge_counts_from": "all timed batches re-run untimed (sampling is deterministic)",
                        "setup_s": round(setup_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
@@ -260,7 +280,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    for e in reversed(engines):
+        e.close()
 
 
 def run_cpu_baseline(eng, model, my, fanouts, W, n, d):
@@ -268,10 +289,8 @@ def run_cpu_baseline(eng, model, my, fanouts, W, n, d):
     (reference semantics), single thread for the sampler, on a bounded sample of the same workload."""
     import oracle
     from oracle import gnn_ref
-    from oracle.oracle import tree_edges
 
     rowptr, col = eng.graph_to_host()
-    import ctypes as C
     x = np.empty((n, d), dtype=np.float32)
     eng._lib.gigl_memcpy(eng._ctx, C.c_void_p(x.ctypes.data), 0, eng._feat_ptr, 1, x.nbytes)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}

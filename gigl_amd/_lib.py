@@ -28,6 +28,8 @@ SYMBOLS = [
     "gigl_features_device_ptr", "gigl_features_destroy", "gigl_sample_khop", "gigl_sample_positives",
     "gigl_union_capacity", "gigl_union_build", "gigl_gather_mean", "gigl_linear",
     "gigl_profile_enable", "gigl_profile_read", "gigl_profile_reset",
+    "gigl_sage_plan_create", "gigl_sage_plan_set_weights", "gigl_sage_plan_buffers", "gigl_sage_plan_run",
+    "gigl_sage_plan_destroy",
 ]
 
 KERNEL_IDS = {
@@ -111,6 +113,11 @@ def load() -> C.CDLL:
         "gigl_profile_enable": [vp, C.c_uint32, i32],
         "gigl_profile_read": [vp, i32, P(C.c_double), P(i64)],
         "gigl_profile_reset": [vp],
+        "gigl_sage_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), P(vp), P(vp), i32, P(vp)],
+        "gigl_sage_plan_set_weights": [vp, P(vp), P(vp)],
+        "gigl_sage_plan_buffers": [vp, P(GiglTree), P(GiglUnion)],
+        "gigl_sage_plan_run": [vp, vp, i32, i32, vp],
+        "gigl_sage_plan_destroy": [vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

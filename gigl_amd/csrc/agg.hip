@@ -216,21 +216,119 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
     }
   };
 
-  float4_t av_n, wv_n[NT];
-  load_step(0, av_n, wv_n);
-  for (int k0 = 0; k0 < K; k0 += 8) {
-    const float4_t av = av_n;
-    float4_t wv[NT];
+  // PF K-steps of operands are kept in flight in a register ring (global -> L2/MALL latency is
+  // ~1.5k cycles here, one K-step of MFMAs only 256*NT)
+  constexpr int PF = 4;
+  float4_t av_s[PF], wv_s[PF][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wv[j] = wv_n[j];
-    if (k0 + 8 < K) load_step(k0 + 8, av_n, wv_n);  // prefetch the next K-step under this step's MFMAs
+  for (int s = 0; s < PF; ++s) load_step(8 * s, av_s[s], wv_s[s]);
+  for (int k0 = 0; k0 < K; k0 += 8 * PF) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int s = 0; s < PF; ++s) {
+      if (k0 + 8 * s >= K) break;
+      const float4_t av = av_s[s];
+      float4_t wv[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wv[j][t], acc[j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) wv[j] = wv_s[s][j];
+      if (k0 + 8 * (s + PF) < K) load_step(k0 + 8 * (s + PF), av_s[s], wv_s[s]);  // refill this stage
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wv[j][t], acc[j], 0, 0, 0);
+    }
   }
   // D layout (32x32, 16 regs): reg v -> row 8*(v/4) + 4*h + (v%4), col r
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int coln = n0 + j * 32 + r;
+    if (coln >= N) continue;
+    const float bv = bias ? bias[coln] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = m0 + 8 * (v >> 2) + 4 * h + (v & 3);
+      if (row < M) {
+        float val = acc[j][v] + bv;
+        if (act == 1) val = val > 0.f ? val : 0.f;
+        y[(int64_t)row * N + coln] = val;
+      }
+    }
+  }
+}
+
+// LDS-staged variant (K % 4 == 0): a workgroup of 4 waves computes a 128 x 32*NT tile, wave w the rows
+// [32w, 32w+32).  Per K-chunk of 32 every wave fetches its own 32x32 A sub-tile and a quarter of the
+// shared 32*NT x 32 W tile with fully coalesced 128-byte row segments (8 lanes x 16 B), parks them in
+// LDS (row stride 36 floats: conflict-free ds_read_b128 for the MFMA operand layout) and reads them
+// back in operand order.  Next chunk's global loads are issued before this chunk's MFMAs.
+template <int NT>
+__global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict__ a,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         const int32_t* __restrict__ m_dev, int K, int N,
+                                                         int act, float* __restrict__ y) {
+  constexpr int BK = 32, LDK = BK + 4;
+  __shared__ float s_a[4][32 * LDK];
+  __shared__ float s_w[32 * NT * LDK];
+  const int M = *m_dev;
+  const int tiles_n = (N + 32 * NT - 1) / (32 * NT);
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0b = tm * 128;
+  if (m0b >= M) return;  // whole workgroup
+  const int tid = threadIdx.x, lane = tid & 63, wv_id = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = m0b + wv_id * 32, n0 = tn * 32 * NT;
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  float16_t acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+
+  // loader mapping: lane -> (row lr + 8*i, k segment lc*4 .. lc*4+3), i = 0..3
+  const int lr = lane >> 3, lc = lane & 7;
+  // W loader: thread tid -> rows (tid>>3) + 32*i, i < NT
+  const int wr = tid >> 3, wc = tid & 7;
+
+  float4_t ga[4], gw[NT];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + lr + 8 * i, kk = k0 + lc * 4;
+      ga[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(a + (int64_t)row * K + kk) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int row = n0 + wr + 32 * i, kk = k0 + wc * 4;
+      gw[i] = (row < N && kk < K) ? *reinterpret_cast<const float4_t*>(w + (int64_t)row * K + kk) : zero4;
+    }
+  };
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();  // previous chunk's LDS reads are done
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4_t*>(&s_a[wv_id][(lr + 8 * i) * LDK + lc * 4]) = ga[i];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) *reinterpret_cast<float4_t*>(&s_w[(wr + 32 * i) * LDK + wc * 4]) = gw[i];
+    __syncthreads();
+    if (k0 + BK < K) gload(k0 + BK);  // in flight under the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 8) {
+      if (k0 + ks >= K) break;
+      const float4_t av = *reinterpret_cast<const float4_t*>(&s_a[wv_id][r * LDK + ks + 4 * h]);
+      float4_t wv[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        wv[j] = *reinterpret_cast<const float4_t*>(&s_w[(j * 32 + r) * LDK + ks + 4 * h]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wv[j][t], acc[j], 0, 0, 0);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int coln = n0 + j * 32 + r;
@@ -310,7 +408,16 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
   hipStream_t st = ctx->stream;
   gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
   const int64_t tiles_m = (m_cap + 31) / 32;
-  if (n > 32) {
+  if ((k & 3) == 0) {  // LDS-staged, coalesced operand fetch
+    const int64_t bm = (m_cap + 127) / 128;
+    if (n > 32) {
+      hipLaunchKernelGGL((linear_lds_kernel<2>), dim3((unsigned)(bm * ((n + 63) / 64))), dim3(256), 0, st, a, w,
+                         bias, m_dev, k, n, act, y);
+    } else {
+      hipLaunchKernelGGL((linear_lds_kernel<1>), dim3((unsigned)(bm * ((n + 31) / 32))), dim3(256), 0, st, a, w,
+                         bias, m_dev, k, n, act, y);
+    }
+  } else if (n > 32) {
     constexpr int NT = 2;
     int64_t tiles = tiles_m * ((n + 32 * NT - 1) / (32 * NT));
     hipLaunchKernelGGL((linear_mfma_kernel<NT>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a, w,

@@ -113,12 +113,26 @@ class HipEngine:
     def profile_reset(self) -> None:
         check(self._lib.gigl_profile_reset(self._ctx), self._ctx)
 
+    def share_resident(self, other: "HipEngine") -> None:
+        """borrow `other`'s HBM-resident graph / feature table (same device).  Lets several ctxs — one per
+        stream / host thread — sample the same graph concurrently; `other` must outlive this engine."""
+        assert other.device == self.device
+        self._graph, self._graph_out, self._feat = other._graph, other._graph_out, other._feat
+        self._feat_ptr = getattr(other, "_feat_ptr", None)
+        self.n_nodes, self.n_edges = other.n_nodes, other.n_edges
+        self.feat_dim, self.feat_dtype = other.feat_dim, other.feat_dtype
+        self._borrowed = True
+
     def close(self) -> None:
         if getattr(self, "_ctx", None):
-            for h, fn in ((self._graph, self._lib.gigl_graph_destroy), (self._graph_out, self._lib.gigl_graph_destroy),
-                          (self._feat, self._lib.gigl_features_destroy)):
-                if h:
-                    fn(h)
+            for p in list(getattr(self, "_plans", [])):
+                p.close()
+            if not getattr(self, "_borrowed", False):
+                for h, fn in ((self._graph, self._lib.gigl_graph_destroy),
+                              (self._graph_out, self._lib.gigl_graph_destroy),
+                              (self._feat, self._lib.gigl_features_destroy)):
+                    if h:
+                        fn(h)
             self._graph = self._graph_out = self._feat = None
             self._lib.gigl_ctx_destroy(self._ctx)
             self._ctx = None
@@ -321,3 +335,86 @@ class HipEngine:
                                     C.c_void_p(m_dev.data_ptr()), m_cap, k, n, act, C.c_void_p(out.data_ptr())),
               self._ctx)
         return out
+
+    # ---- one-call batch pipeline -----------------------------------------------------------
+    def make_sage_plan(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], b: int,
+                       fanouts: Sequence[int], act_last: bool = False) -> "SagePlan":
+        """weights[l]: fused fp32 [out_l, 2*in_l] = cat(lin_l.weight, lin_r.weight, dim=1) on this device"""
+        return SagePlan(self, weights, biases, b, fanouts, act_last)
+
+
+class SagePlan:
+    """sample -> union -> GraphSAGE forward -> one row per root, enqueued by ONE library call
+    (include/gigl_hip.h `gigl_sage_plan_*`)."""
+
+    def __init__(self, eng: HipEngine, weights, biases, b: int, fanouts, act_last: bool):
+        assert eng._graph is not None and eng._feat is not None, "load the graph and the features first"
+        L = len(fanouts)
+        assert len(weights) == L
+        self.eng, self.b, self.fanouts = eng, int(b), [int(f) for f in fanouts]
+        self._lib = eng._lib
+        self.dims = [int(weights[0].shape[1]) // 2] + [int(w.shape[0]) for w in weights]
+        self._keep = None
+        self._plan = C.c_void_p()
+        w_arr, b_arr = self._ptr_arrays(weights, biases)
+        fo = (C.c_int32 * L)(*self.fanouts)
+        dims = (C.c_int32 * (L + 1))(*self.dims)
+        check(self._lib.gigl_sage_plan_create(eng._ctx, eng._graph, eng._feat, self.b, fo, L, dims, w_arr, b_arr,
+                                              1 if act_last else 0, C.byref(self._plan)), eng._ctx)
+        if not hasattr(eng, "_plans"):
+            eng._plans = []
+        eng._plans.append(self)
+
+    def _ptr_arrays(self, weights, biases):
+        L = len(weights)
+        ws = [w.detach().to(device=self.eng.device, dtype=torch.float32).contiguous() for w in weights]
+        bs = [None if x is None else x.detach().to(device=self.eng.device, dtype=torch.float32).contiguous()
+              for x in biases]
+        self._keep = (ws, bs)  # the plan borrows these device buffers
+        w_arr = (C.c_void_p * L)(*[w.data_ptr() for w in ws])
+        b_arr = (C.c_void_p * L)(*[(x.data_ptr() if x is not None else None) for x in bs])
+        return w_arr, b_arr
+
+    def set_weights(self, weights, biases) -> None:
+        w_arr, b_arr = self._ptr_arrays(weights, biases)
+        check(self._lib.gigl_sage_plan_set_weights(self._plan, w_arr, b_arr), self.eng._ctx)
+
+    def run(self, roots: torch.Tensor, out: Optional[torch.Tensor] = None, sampling_seed: int = 42,
+            mode: int = MODE_SPARK_HASH) -> torch.Tensor:
+        """roots: int32 device tensor [b] (uint32 ids); returns [b, out_dim] (row i <-> roots[i])"""
+        assert roots.is_cuda and roots.dtype == torch.int32 and roots.numel() == self.b and roots.is_contiguous()
+        if out is None:
+            out = torch.empty((self.b, self.dims[-1]), dtype=torch.float32, device=self.eng.device)
+        check(self._lib.gigl_sage_plan_run(self._plan, C.c_void_p(roots.data_ptr()), sampling_seed, mode,
+                                           C.c_void_p(out.data_ptr())), self.eng._ctx)
+        return out
+
+    def _d2h(self, ptr, n, dtype):
+        a = np.empty(n, dtype=dtype)
+        if n:
+            check(self._lib.gigl_memcpy(self.eng._ctx, C.c_void_p(a.ctypes.data), LOC_HOST, C.c_void_p(ptr), LOC_DEVICE,
+                                        a.nbytes), self.eng._ctx)
+        return a
+
+    def last_batch_to_host(self):
+        """host copies of the last batch's tree and union graph:
+        dict(nbr=[...], cnt=[...], meta, nodes, rowptr, rowend, col, root_local)"""
+        t, u = GiglTree(), GiglUnion()
+        check(self._lib.gigl_sage_plan_buffers(self._plan, C.byref(t), C.byref(u)), self.eng._ctx)
+        nbr, cnt, parents = [], [], self.b
+        for k, f in enumerate(self.fanouts):
+            cnt.append(self._d2h(t.cnt[k], parents, np.int32))
+            parents *= f
+            nbr.append(self._d2h(t.nbr[k], parents, np.uint32))
+        meta = self._d2h(u.meta, GIGL_META_LEN, np.int32)
+        nn = int(meta[0])
+        return dict(nbr=nbr, cnt=cnt, meta=meta, nodes=self._d2h(u.nodes, nn, np.uint32),
+                    rowptr=self._d2h(u.rowptr, nn + 1, np.int32), rowend=self._d2h(u.rowend, nn + 1, np.int32),
+                    col=self._d2h(u.col, int(u.cap_edges), np.int32), root_local=self._d2h(u.root_local, self.b, np.int32))
+
+    def close(self) -> None:
+        if getattr(self, "_plan", None):
+            self._lib.gigl_sage_plan_destroy(self._plan)
+            self._plan = None
+            if self in getattr(self.eng, "_plans", []):
+                self.eng._plans.remove(self)

@@ -92,6 +92,17 @@ class GraphSAGE(nn.Module):
             h = torch.nn.functional.normalize(h, p=2, dim=1)
         return h
 
+    def make_plan(self, eng: HipEngine, b: int, fanouts: Sequence[int]):
+        """one-call pipeline (sample -> union -> this model's forward -> one row per root) for batches of
+        `b` roots on `eng`; weights are snapshotted — call plan.set_weights(*model.fused_params()) after updates"""
+        assert len(fanouts) == self.num_layers, "one hop per layer"
+        w, bs = self.fused_params()
+        return eng.make_sage_plan(w, bs, b, fanouts, act_last=self.activation_after_last_conv)
+
+    def fused_params(self):
+        return ([c.fused_weight().detach() for c in self.conv_layers],
+                [None if c.lin_l.bias is None else c.lin_l.bias.detach() for c in self.conv_layers])
+
     def _buf(self, kind: str, layer: int, rows: int, cols: int) -> torch.Tensor:
         if self._ws is None:
             self._ws = {}

@@ -219,6 +219,30 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
                     const int32_t* m_dev, int64_t m_cap, int32_t k, int32_t n, int32_t act,
                     float* y);
 
+/* ---- one-call batch pipeline: sample -> union -> GraphSAGE forward -> one output row per root.
+ *      Replaces `infer_batch` of the reference's task specs for a RootedNodeNeighborhood batch
+ *      (python/gigl/src/common/modeling_task_specs/node_anchor_based_link_prediction_modeling_task_spec.py:626-655,
+ *      node_classification_modeling_task_spec.py:176-187: `model(data)[root_node_indices]`) together with
+ *      the sampler + collate that feed it.  The plan owns the per-batch workspace (tree, union graph,
+ *      activations) sized for batch `b`; graph / feature table / weights are borrowed and may belong
+ *      to another ctx on the same device.
+ *        dims[0..hops]: dims[0] = feature dim, dims[l+1] = out dim of layer l
+ *        w[l]:   DEVICE fp32 [dims[l+1]][2*dims[l]] = cat(lin_l.weight, lin_r.weight, dim=1)
+ *        bias[l]: DEVICE fp32 [dims[l+1]] or NULL;  relu between layers (and after the last if act_last)
+ *      gigl_sage_plan_run enqueues the whole batch on the ctx stream with no host synchronisation and
+ *      writes out[b][dims[hops]] (row i = embedding of roots[i]). */
+typedef struct gigl_sage_plan gigl_sage_plan;
+int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b,
+                              const int32_t* fanouts, int32_t hops, const int32_t* dims,
+                              const float* const* w, const float* const* bias, int32_t act_last,
+                              gigl_sage_plan** out);
+int32_t gigl_sage_plan_set_weights(gigl_sage_plan* plan, const float* const* w, const float* const* bias);
+/* borrow the plan's device buffers (valid until the next run overwrites them / destroy) */
+int32_t gigl_sage_plan_buffers(gigl_sage_plan* plan, gigl_tree* tree, gigl_union* un);
+int32_t gigl_sage_plan_run(gigl_sage_plan* plan, const uint32_t* roots, int32_t sampling_seed,
+                           int32_t mode, float* out);
+int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);
+
 #ifdef __cplusplus
 }
 #endif

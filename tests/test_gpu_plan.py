@@ -1,0 +1,102 @@
+"""gigl_sage_plan_* (one-call pipeline) == the step-by-step path == the reference semantics on the CPU."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import rmat_edges
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from gigl_amd.engine import HipEngine
+    s, d = rmat_edges(13, 150000, seed=8)
+    n = 1 << 13
+    rowptr, col = oracle.build_csc(n, s, d, is_directed=False)
+    x = (np.random.default_rng(0).standard_normal((n, 100)) / 10).astype(np.float32)
+    eng = HipEngine(0)
+    eng.load_csc(rowptr, col)
+    eng.load_features(x)
+    yield eng, rowptr, col, x, n
+    eng.close()
+
+
+def test_plan_matches_stepwise_and_oracle(setup):
+    from gigl_amd.models import GraphSAGE, HipBatch
+    from oracle import gnn_ref
+    eng, rowptr, col, x, n = setup
+    torch.manual_seed(1)
+    model = GraphSAGE(100, 64, 47, num_layers=2).to(eng.device)
+    b, fan = 300, [25, 10]
+    plan = model.make_plan(eng, b, fan)
+    rng = np.random.default_rng(2)
+    for it in range(3):
+        roots = rng.integers(0, n, size=b).astype(np.uint32)
+        r_dev = torch.from_numpy(roots.view(np.int32)).to(eng.device)
+        out = plan.run(r_dev).cpu().numpy()
+        # step by step through the separate entry points
+        tree = eng.sample_khop(roots, fan)
+        u = eng.union_build(tree)
+        ref_steps = model(HipBatch(eng, tree, u))[u.root_local[:b].long()].cpu().numpy()
+        assert np.array_equal(out, ref_steps)  # same kernels, same order: bitwise
+        # integer side of the plan's last batch == oracle
+        hb = plan.last_batch_to_host()
+        nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots, fan, canonical=True)
+        for k in range(2):
+            assert np.array_equal(hb["nbr"][k], nbr_o[k]) and np.array_equal(hb["cnt"][k], cnt_o[k])
+        o = oracle.union_build(roots, fan, nbr_o)
+        assert np.array_equal(hb["meta"][:5], o["meta"][:5]) and np.array_equal(hb["nodes"], o["nodes"])
+        assert np.array_equal(hb["root_local"], o["root_local"])
+        # fp32 CPU forward over the whole union graph (reference execution order)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        ei = gnn_ref.union_edge_index(o["rowptr"], o["col"])
+        want = gnn_ref.graphsage_forward(torch.from_numpy(x[o["nodes"]]), ei, sd, 2)[o["root_local"]].numpy()
+        np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-5)
+    plan.close()
+
+
+def test_plans_on_several_streams_and_threads(setup):
+    """S ctxs sharing one resident graph, each on its own stream and host thread: same results as serial"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE
+    eng, rowptr, col, x, n = setup
+    torch.manual_seed(3)
+    model = GraphSAGE(100, 32, 16, num_layers=2).to(eng.device)
+    b, fan, S, iters = 128, [10, 5], 3, 6
+    rng = np.random.default_rng(5)
+    all_roots = torch.from_numpy(rng.integers(0, n, size=(S * iters, b)).astype(np.int32)).to(eng.device)
+    serial_plan = model.make_plan(eng, b, fan)
+    want = [serial_plan.run(all_roots[i]).clone() for i in range(S * iters)]
+    torch.cuda.synchronize()
+    engines, plans, streams = [], [], []
+    for s in range(S):
+        e = HipEngine(0)
+        e.share_resident(eng)
+        st = torch.cuda.Stream(device=eng.device)
+        e.bind_stream(st)
+        engines.append(e)
+        streams.append(st)
+        plans.append(model.make_plan(e, b, fan))
+    got = [None] * (S * iters)
+
+    def worker(s):
+        with torch.cuda.stream(streams[s]):
+            for i in range(s, S * iters, S):
+                got[i] = plans[s].run(all_roots[i], out=torch.empty((b, 16), device=eng.device))
+        streams[s].synchronize()
+
+    ths = [threading.Thread(target=worker, args=(s,)) for s in range(S)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    for i in range(S * iters):
+        assert torch.equal(got[i], want[i]), i
+    for e in engines:
+        e.close()
+    serial_plan.close()
