@@ -128,6 +128,32 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
   }
 }
 
+// backward of gather_mean w.r.t. a dense local source matrix (layers >= 2; raw input features need no
+// gradient):  dsrc[i] += dout[i][d:2d];  dsrc[col[e]] += dout[i][0:d] / deg_i for every edge e of row i.
+// One wave per destination row; fp32 atomics (several rows can share a source).
+__global__ __launch_bounds__(256) void gather_mean_backward_kernel(const float* __restrict__ dout, int d,
+                                                                   const int32_t* __restrict__ rowptr,
+                                                                   const int32_t* __restrict__ rowend,
+                                                                   const int32_t* __restrict__ col,
+                                                                   const int32_t* __restrict__ n_rows_dev,
+                                                                   float* __restrict__ dsrc) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_rows = *n_rows_dev;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    const float* g = dout + (int64_t)i * 2 * d;
+    for (int el = lane; el < d; el += 64) atomicAdd(&dsrc[(int64_t)i * d + el], g[d + el]);
+    if (m == 0) continue;
+    const float inv = 1.0f / (float)m;
+    for (int e = 0; e < m; ++e) {
+      const int j = col[e0 + e];
+      for (int el = lane; el < d; el += 64) atomicAdd(&dsrc[(int64_t)j * d + el], g[el] * inv);
+    }
+  }
+}
+
 // generic fallback (any d): one wave per row, scalar elements
 template <typename T>
 __global__ __launch_bounds__(256) void gather_mean_generic_kernel(const T* __restrict__ src, int d,
@@ -394,6 +420,22 @@ int32_t gigl_gather_mean(gigl_ctx* ctx, const void* src, int32_t src_dtype, int3
     return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev,
                                  rows_cap, out);
   return gigl_fail(ctx, GIGL_E_INVALID_ARG, "bad dtype %d", src_dtype);
+}
+
+int32_t gigl_gather_mean_backward(gigl_ctx* ctx, const float* dout, int32_t d, const int32_t* rowptr,
+                                  const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
+                                  int64_t rows_cap, float* dsrc) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, dout && rowptr && rowend && col && n_rows_dev && dsrc, "null argument");
+  GIGL_REQUIRE(ctx, d > 0 && rows_cap >= 0, "bad sizes");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(gather_mean_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dout, d,
+                     rowptr, rowend, col, n_rows_dev, dsrc);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
 }
 
 int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* bias,

@@ -322,6 +322,17 @@ class HipEngine:
                                          C.c_void_p(out.data_ptr())), self._ctx)
         return out
 
+    def gather_mean_backward(self, dout: torch.Tensor, d: int, rowptr: torch.Tensor, rowend: Optional[torch.Tensor],
+                             col: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int, dsrc: torch.Tensor) -> None:
+        """dsrc (zero-filled, [n_src, d] fp32) += the gradient of gather_mean w.r.t. its dense local source"""
+        if rowend is None:
+            rowend = rowptr[1:]
+        assert dout.is_cuda and dout.is_contiguous() and dsrc.is_contiguous() and dout.dtype == torch.float32
+        check(self._lib.gigl_gather_mean_backward(self._ctx, C.c_void_p(dout.data_ptr()), d,
+                                                  C.c_void_p(rowptr.data_ptr()), C.c_void_p(rowend.data_ptr()),
+                                                  C.c_void_p(col.data_ptr()), C.c_void_p(n_rows_dev.data_ptr()),
+                                                  rows_cap, C.c_void_p(dsrc.data_ptr())), self._ctx)
+
     def linear(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m_dev: torch.Tensor,
                m_cap: int, act: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert a.is_cuda and w.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32

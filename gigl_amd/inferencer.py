@@ -1,0 +1,103 @@
+"""Inferencer — drop-in for the reference component
+
+    python -m gigl.src.inference.inferencer --job_name --task_config_uri --resource_config_uri
+    Inferencer().run(applied_task_identifier, task_config_uri, resource_config_uri, custom_worker_image_uri=None,
+                     cpu_docker_uri=None, cuda_docker_uri=None)          (python/gigl/src/inference/inferencer.py:25-33)
+
+Reference body (python/gigl/src/inference/v1/gnn_inferencer.py:113-140,234-340; v1/lib/utils.py:78-228;
+v1/lib/base_inference_blueprint.py:52-103): build the plugin, load the trained state_dict, read the
+RootedNodeNeighborhood (or SupervisedNodeClassificationSample) TFRecords, batch `inference_batch_size`
+(default 3000) samples, `infer_batch`, and emit ONE row per ROOT in batch order — {"node_id", "emb": [...]}
+and/or {"node_id", "pred"} — as JSON lines (the Beam/Dataflow + BigQuery load is cloud plumbing, out of scope:
+rows are written to the local paths named in inferenceMetadata).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+from typing import Dict, Optional
+
+import torch
+
+from .base import BaseInferencer, import_obj
+from .batches import RootedNodeNeighborhoodBatch, SupervisedNodeClassificationBatch, iterate_tfrecord_batches
+from .config import GbmlConfigPbWrapper, _get, resolve_uri, tfrecord_files
+from . import wire
+
+
+def generate_inferencer_instance(cfg: GbmlConfigPbWrapper) -> BaseInferencer:
+    cls_path = cfg.inferencer_cls_path
+    if not cls_path:
+        raise ValueError("inferencerConfig.inferencerClsPath is not set")
+    inferencer = import_obj(cls_path)(**cfg.inferencer_args)
+    assert isinstance(inferencer, BaseInferencer)
+    state_dict = torch.load(cfg.trained_model_uri, map_location="cpu")
+    inferencer.init_model(gbml_config_pb_wrapper=cfg, state_dict=state_dict)
+    return inferencer
+
+
+class Inferencer:
+    def run(self, applied_task_identifier: str, task_config_uri: str, resource_config_uri: Optional[str] = None,
+            custom_worker_image_uri: Optional[str] = None, cpu_docker_uri: Optional[str] = None,
+            cuda_docker_uri: Optional[str] = None, *, uri_base: Optional[str] = None, device: int = 0) -> Dict[str, str]:
+        if not torch.cuda.is_available():
+            raise RuntimeError("gigl_amd.Inferencer needs a HIP device; there is no CPU fallback")
+        cfg = GbmlConfigPbWrapper.from_uri(task_config_uri, uri_base=uri_base)
+        dev = torch.device("cuda", device)
+        inferencer = generate_inferencer_instance(cfg)
+        inferencer.model = inferencer.model.to(dev)
+        if cfg.task_kind == "node_classification":
+            files = tfrecord_files(cfg.unlabeled_tfrecord_uri_prefix)
+        else:
+            files = [f for p in cfg.random_negative_tfrecord_uri_prefixes.values() for f in tfrecord_files(p)]
+        info = (_get(cfg.doc, "sharedConfig.inferenceMetadata.nodeTypeToInferencerOutputInfoMap", {}) or {})
+        out_files: Dict[str, str] = {}
+        emb_fh = pred_fh = None
+        for _, v in info.items():
+            if v.get("embeddingsPath"):
+                out_files["embeddings"] = resolve_uri(v["embeddingsPath"], cfg.uri_base)
+            if v.get("predictionsPath"):
+                out_files["predictions"] = resolve_uri(v["predictionsPath"], cfg.uri_base)
+        for p in out_files.values():
+            os.makedirs(os.path.dirname(p) or ".", exist_ok=True)
+        if "embeddings" in out_files:
+            emb_fh = open(out_files["embeddings"], "w")
+        if "predictions" in out_files:
+            pred_fh = open(out_files["predictions"], "w")
+        n_rows = 0
+        try:
+            for raw in iterate_tfrecord_batches(files, cfg.inference_batch_size):
+                rnn = RootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(raw, cfg.node_types[0])
+                batch = SupervisedNodeClassificationBatch(
+                    graph=rnn.graph, root_node_indices=rnn.condensed_node_type_to_root_node_indices_map[0],
+                    root_nodes=rnn.root_nodes, root_node_labels=None)
+                res = inferencer.infer_batch(batch=batch, device=dev)
+                emb = res.embeddings.cpu() if res.embeddings is not None else None
+                pred = res.predictions.cpu() if res.predictions is not None else None
+                for i, root in enumerate(batch.root_nodes):  # one row per root, in batch order
+                    if emb_fh is not None and emb is not None:
+                        emb_fh.write(json.dumps({"node_id": root.id, "emb": emb[i].tolist()}) + "\n")
+                    if pred_fh is not None and pred is not None:
+                        pred_fh.write(json.dumps({"node_id": root.id, "pred": int(pred[i])}) + "\n")
+                    n_rows += 1
+        finally:
+            for fh in (emb_fh, pred_fh):
+                if fh is not None:
+                    fh.close()
+        self.rows_written = n_rows
+        return out_files
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="MI355X inferencer (drop-in for gigl.src.inference.inferencer)")
+    ap.add_argument("--job_name", required=True)
+    ap.add_argument("--task_config_uri", required=True)
+    ap.add_argument("--resource_config_uri", default=None)
+    ap.add_argument("--uri_base", default=None)
+    a = ap.parse_args(argv)
+    print(Inferencer().run(a.job_name, a.task_config_uri, a.resource_config_uri, uri_base=a.uri_base))
+
+
+if __name__ == "__main__":
+    main()

@@ -66,10 +66,29 @@ class GraphSAGE(nn.Module):
                      root_weight=root_weight) for i in range(num_layers)])
         self._ws = None  # workspace cache
 
-    @torch.no_grad()
-    def forward(self, batch: HipBatch) -> torch.Tensor:
-        """returns [cap, out_dim]; rows [0, n_level0) are the distinct roots' outputs
-        (index with batch.root_local for per-root rows in batch order)"""
+    def forward(self, batch, engine: Optional[HipEngine] = None) -> torch.Tensor:
+        """HipBatch  -> inference over the level-ordered union graph (trimmed schedule, no autograd): returns
+                        [cap, out_dim]; rows [0, n_level0) are the distinct roots' outputs (index with
+                        batch.root_local for per-root rows in batch order)
+        GraphData -> every layer over the whole batch graph with autograd (the reference's execution order,
+                        homogeneous.py:107-153): returns [n, out_dim]"""
+        from .nn import GraphData, sage_conv
+        if isinstance(batch, GraphData):
+            eng = engine or getattr(self, "engine", None)
+            if eng is None:
+                raise RuntimeError("GraphSAGE.forward(GraphData) needs the HipEngine (model.engine = eng)")
+            h = batch.x
+            for l, conv in enumerate(self.conv_layers):
+                act = l < self.num_layers - 1 or self.activation_after_last_conv
+                w_r = conv.lin_r.weight if conv.lin_r is not None else torch.zeros_like(conv.lin_l.weight)
+                h = sage_conv(h, conv.lin_l.weight, conv.lin_l.bias, w_r, eng, batch, act)
+            if self.should_l2_normalize_embedding_layer_output:
+                h = torch.nn.functional.normalize(h, p=2, dim=1)
+            return h
+        with torch.no_grad():
+            return self._forward_union(batch)
+
+    def _forward_union(self, batch: HipBatch) -> torch.Tensor:
         eng, u = batch.engine, batch.union
         L = self.num_layers
         assert u.hops == L, "one hop per layer"

@@ -1,0 +1,101 @@
+"""Trainable message passing on HIP kernels: autograd wrappers + the batch graph container.
+
+Mirror of what the reference gets from PyG for this path:
+  torch_geometric.data.Data{x, edge_index}  (built by PygGraphBuilder.build, python/gigl/src/common/
+      graph_builder/pyg_graph_builder.py:20-69, cast at data_loaders/utils.py:59-146)  -> GraphData
+  SAGEConv forward/backward (PyG 2.5.3 MessagePassing.propagate + scatter-mean + Linear)       -> sage_conv
+The forward kernels are gigl_gather_mean + gigl_linear; the backward is gigl_linear (two more GEMMs on
+transposed operands) + gigl_gather_mean_backward.  torch supplies memory, autograd bookkeeping, the loss
+and the optimiser — exactly the parts the reference also takes from torch.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .engine import HipEngine
+
+
+@dataclass
+class GraphData:
+    """homogeneous batch graph: `x` [n, D] fp32, `edge_index` [2, E] int64 (row 0 = src, row 1 = dst) — the
+    fields the reference's models read from a PyG Data — plus the CSR-by-destination the kernels use"""
+    x: torch.Tensor
+    edge_index: torch.Tensor
+    rowptr: Optional[torch.Tensor] = None  # int32 [n+1]
+    col: Optional[torch.Tensor] = None     # int32 [E], sources, rows ascending
+    n_dev: Optional[torch.Tensor] = None   # int32 [1] = n (device-side row count for the kernels)
+
+    @property
+    def num_nodes(self) -> int:
+        return int(self.x.shape[0])
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.edge_index.shape[1])
+
+    def to(self, device) -> "GraphData":
+        device = torch.device(device)
+        x = self.x.to(device=device, dtype=torch.float32).contiguous()
+        ei = self.edge_index.to(device)
+        g = GraphData(x=x, edge_index=ei)
+        if device.type == "cuda":
+            g._build_csr()
+        return g
+
+    def _build_csr(self) -> None:
+        n, dev = self.num_nodes, self.x.device
+        src, dst = self.edge_index[0], self.edge_index[1]
+        order = torch.argsort(dst * max(n, 1) + src)  # by destination, sources ascending
+        self.col = src[order].to(torch.int32).contiguous()
+        deg = torch.bincount(dst, minlength=n)
+        rp = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        rp[1:] = torch.cumsum(deg, 0)
+        self.rowptr = rp.to(torch.int32).contiguous()
+        if self.col.numel() == 0:
+            self.col = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+
+
+class _SageConvFn(torch.autograd.Function):
+    """y = act([mean_{j->i} h_j | h_i] @ [W_l | W_r]^T + b) over ALL rows of the graph"""
+
+    @staticmethod
+    def forward(ctx, h, w_l, b_l, w_r, eng: HipEngine, g: GraphData, act: int):
+        n, d = int(h.shape[0]), int(h.shape[1])
+        h = h.contiguous()
+        a = eng.gather_mean(h, d, None, g.rowptr, None, g.col, g.n_dev, n)
+        wcat = torch.cat([w_l, w_r], dim=1).contiguous()
+        y = eng.linear(a, wcat, b_l, g.n_dev, n, act)
+        ctx.eng, ctx.g, ctx.act, ctx.d = eng, g, act, d
+        ctx.has_bias = b_l is not None
+        ctx.save_for_backward(a, wcat, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, wcat, y = ctx.saved_tensors
+        eng, g, d = ctx.eng, ctx.g, ctx.d
+        n = int(a.shape[0])
+        dy = dy.contiguous()
+        if ctx.act == 1:
+            dy = dy * (y > 0).to(dy.dtype)
+        dev = dy.device
+        # dW[N, 2d] = dy^T[N, n] @ a[n, 2d]  ->  linear(a = dy^T, w = a^T)
+        n_out = torch.tensor([dy.shape[1]], dtype=torch.int32, device=dev)
+        dw = eng.linear(dy.t().contiguous(), a.t().contiguous(), None, n_out, int(dy.shape[1]), 0)
+        # da[n, 2d] = dy[n, N] @ wcat[N, 2d]  ->  linear(a = dy, w = wcat^T)
+        da = eng.linear(dy, wcat.t().contiguous(), None, g.n_dev, n, 0)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.zeros((n, d), dtype=torch.float32, device=dev)
+            eng.gather_mean_backward(da, d, g.rowptr, None, g.col, g.n_dev, n, dh)
+        db = dy.sum(0) if ctx.has_bias else None
+        return dh, dw[:, :d].contiguous(), db, dw[:, d:].contiguous(), None, None, None
+
+
+def sage_conv(h: torch.Tensor, w_l: torch.Tensor, b_l: Optional[torch.Tensor], w_r: torch.Tensor, eng: HipEngine,
+              g: GraphData, act: bool) -> torch.Tensor:
+    return _SageConvFn.apply(h, w_l, b_l, w_r, eng, g, 1 if act else 0)

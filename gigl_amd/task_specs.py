@@ -1,0 +1,166 @@
+"""Task-spec plugin classes (BaseTrainer + BaseInferencer) that run on the HIP path.
+
+HipGraphSageNodeClassificationSpec — the node-classification loop of the reference
+  NodeClassificationModelingTaskSpec (python/gigl/src/common/modeling_task_specs/
+  node_classification_modeling_task_spec.py:48-299): same constructor kwargs (string-valued
+  `trainer_args` / `inferencer_args`: optim_lr 0.01, optim_weight_decay 5e-4, num_epochs 5, out_dim 7,
+  main_sample_batch_size 16), same `_train` / `score` / `train` / `eval` / `infer_batch` bodies, with
+  `GraphSAGE` wired in place of the stock `TwoLayerGCN` (BASELINE config 1 is
+  GraphSAGE node classification; the plugin API allows exactly this substitution).
+Data: the labeled SupervisedNodeClassificationSample TFRecords written by the sampler.  The reference
+reads the Split Generator's train/val/test re-filing of those samples (out of scope);
+here the split is a deterministic function of the root id (id % 10: 0-7 train, 8 val, 9 test), falling
+back to "all samples in every split" for tiny fixtures.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .base import (BaseInferencer, BaseTrainer, EvalMetric, EvalMetricsCollection, EvalMetricType, InferBatchResults,
+                   no_grad_eval)
+from .batches import SupervisedNodeClassificationBatch, iterate_tfrecord_batches
+from .config import GbmlConfigPbWrapper, tfrecord_files
+from .models import GraphSAGE
+from . import wire
+
+
+def _rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
+    def __init__(self, is_training: bool = True, **kwargs) -> None:
+        self._optim_lr = float(kwargs.get("optim_lr", 0.01))
+        self._optim_weight_decay = float(kwargs.get("optim_weight_decay", 5e-4))
+        self._num_epochs = int(kwargs.get("num_epochs", 5))
+        self._out_dim = int(kwargs.get("out_dim", 7))
+        self._hid_dim = int(kwargs.get("hid_dim", 16))
+        self._num_layers = int(kwargs.get("num_layers", 2))
+        self._batch_size = int(kwargs.get("main_sample_batch_size", 16))
+        self._is_training = is_training
+        self._model: Optional[torch.nn.Module] = None
+        self._engine = None
+        self._cfg: Optional[GbmlConfigPbWrapper] = None
+
+    # ---- BaseModelOperationsProtocol
+    @property
+    def model(self) -> torch.nn.Module:
+        return self._model
+
+    @model.setter
+    def model(self, model: torch.nn.Module) -> None:
+        self._model = model
+
+    @property
+    def supports_distributed_training(self) -> bool:
+        return True
+
+    def init_model(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, state_dict=None) -> torch.nn.Module:
+        self._cfg = gbml_config_pb_wrapper
+        in_dim = gbml_config_pb_wrapper.preprocessed_metadata.nodes[0].feature_dim
+        model = GraphSAGE(in_dim=max(in_dim, 1), hid_dim=self._hid_dim, out_dim=self._out_dim,
+                          num_layers=self._num_layers)
+        if state_dict is not None:
+            model.load_state_dict(state_dict)
+        self.model = model
+        return model
+
+    def _ensure_engine(self, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("the HIP path needs a GPU device; there is no CPU fallback")
+        if self._engine is None:
+            from .engine import HipEngine
+            self._engine = HipEngine(device.index or 0)
+        inner = self.model.module if hasattr(self.model, "module") else self.model
+        inner.engine = self._engine
+        return self._engine
+
+    def setup_for_training(self):
+        self._optimizer = torch.optim.Adam(self.model.parameters(), lr=self._optim_lr,
+                                           weight_decay=self._optim_weight_decay)
+        self._train_loss_fn = lambda input, target: F.cross_entropy(input=input, target=target)
+        self.model.train()
+
+    # ---- data
+    def _split_batches(self, cfg: GbmlConfigPbWrapper, split: str):
+        rank, world = _rank_world()
+        files = tfrecord_files(cfg.labeled_tfrecord_uri_prefix)
+        want = {"train": range(0, 8), "val": (8,), "test": (9,)}[split]
+        for raw in iterate_tfrecord_batches(files, 10 ** 9, rank=rank, world_size=world):
+            samples = [wire.SupervisedNodeClassificationSample.FromString(b) for b in raw]
+            part = [s for s in samples if s.root_node.node_id % 10 in want]
+            if len(samples) < 100:  # tiny fixture: every split sees everything
+                part = samples
+            for i in range(0, len(part), self._batch_size):
+                yield SupervisedNodeClassificationBatch.collate_pyg_node_classification_minibatch(
+                    part[i:i + self._batch_size], node_type=cfg.node_types[0])
+
+    # ---- loops (reference :134-173, :190-227)
+    def _train(self, batches, device: torch.device) -> Optional[torch.Tensor]:
+        self.model.train()
+        loss = None
+        for batch in batches:
+            self._optimizer.zero_grad()
+            inputs = batch.graph.to(device=device)
+            root_node_indices = batch.root_node_indices.to(device=device)
+            assert batch.root_node_labels is not None, "Labels required for training."
+            root_node_labels = batch.root_node_labels.to(device=device)
+            out = self.model(inputs)
+            loss = self._train_loss_fn(input=out[root_node_indices], target=root_node_labels)
+            loss.backward()
+            self._optimizer.step()
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+        return loss
+
+    @no_grad_eval
+    def infer_batch(self, batch: SupervisedNodeClassificationBatch, device: torch.device = torch.device("cpu")
+                    ) -> InferBatchResults:
+        self._ensure_engine(device)
+        inputs = batch.graph.to(device)
+        root_node_indices = batch.root_node_indices.to(device)
+        out = self.model(inputs)
+        embed = out[root_node_indices]
+        pred = embed.argmax(dim=1)
+        return InferBatchResults(embeddings=embed, predictions=pred)
+
+    @no_grad_eval
+    def score(self, batches, device: torch.device) -> float:
+        num_correct = num_evaluated = 0
+        for batch in batches:
+            assert batch.root_node_labels is not None, "Labels required for scoring."
+            results = self.infer_batch(batch=batch, device=device)
+            num_correct += int((results.predictions == batch.root_node_labels.to(device)).sum())
+            num_evaluated += len(batch.root_node_labels)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+            t = torch.tensor([float(num_correct), float(num_evaluated)], device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            num_correct, num_evaluated = int(t[0].item()), int(t[1].item())
+        return num_correct / max(num_evaluated, 1)
+
+    def train(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, device: torch.device, profiler=None) -> None:
+        self._ensure_engine(device)
+        best_val_acc = 0.0
+        self.history: List[Dict[str, float]] = []
+        for epoch in range(self._num_epochs):
+            train_loss = self._train(self._split_batches(gbml_config_pb_wrapper, "train"), device)
+            val_acc = self.score(self._split_batches(gbml_config_pb_wrapper, "val"), device)
+            best_val_acc = max(best_val_acc, val_acc)
+            self.history.append({"epoch": epoch, "loss": float(train_loss) if train_loss is not None else float("nan"),
+                                 "val_acc": val_acc})
+            if profiler is not None:
+                profiler.step()
+
+    def eval(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, device: torch.device) -> EvalMetricsCollection:
+        self._ensure_engine(device)
+        test_acc = self.score(self._split_batches(gbml_config_pb_wrapper, "test"), device)
+        return EvalMetricsCollection(metrics=[EvalMetric.from_eval_metric_type(EvalMetricType.acc, test_acc)])

@@ -212,6 +212,13 @@ int32_t gigl_gather_mean(gigl_ctx* ctx, const void* src, int32_t src_dtype, int3
                          const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* rowend,
                          const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, float* out);
 
+/* backward of gigl_gather_mean w.r.t. a dense local fp32 source (gather_ids == NULL; layers >= 2):
+ *   dsrc[i][0:d] += dout[i][d:2d];  dsrc[col[e]][0:d] += dout[i][0:d] / deg_i  for e in row i, i < n_rows.
+ * dsrc must be zero-filled by the caller.  (PyG's autograd of MessagePassing.propagate + scatter-mean.) */
+int32_t gigl_gather_mean_backward(gigl_ctx* ctx, const float* dout, int32_t d, const int32_t* rowptr,
+                                  const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
+                                  int64_t rows_cap, float* dsrc);
+
 /* dense projection  y[i][0:n] = act( a[i][0:k] · w[0:n][0:k]^T + bias )  — fp32 MFMA
  * (v_mfma_f32_32x32x2_f32, exact f32).  w is row-major [n][k] (torch Linear layout; for SAGE
  * w = cat(lin_l.weight, lin_r.weight, dim=1)).  act: 0 none, 1 relu.  m read from *m_dev. */
