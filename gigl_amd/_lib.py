@@ -29,7 +29,7 @@ SYMBOLS = [
     "gigl_union_capacity", "gigl_union_build", "gigl_gather_mean", "gigl_linear",
     "gigl_profile_enable", "gigl_profile_read", "gigl_profile_reset",
     "gigl_sage_plan_create", "gigl_sage_plan_set_weights", "gigl_sage_plan_buffers", "gigl_sage_plan_run",
-    "gigl_sage_plan_destroy", "gigl_gather_mean_backward",
+    "gigl_sage_plan_destroy", "gigl_gather_mean_backward", "gigl_expand_frontier",
 ]
 
 KERNEL_IDS = {
@@ -119,6 +119,7 @@ def load() -> C.CDLL:
         "gigl_sage_plan_run": [vp, vp, i32, i32, vp],
         "gigl_sage_plan_destroy": [vp],
         "gigl_gather_mean_backward": [vp, vp, i32, vp, vp, vp, vp, i64, vp],
+        "gigl_expand_frontier": [vp, vp, vp, vp, i64, i32, i32, i32, i64, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -135,10 +135,21 @@ struct ExpandArgs {
   int32_t hash_add;  // sampling_seed * (hop+1), int32 wrap
   uint32_t* out_nbr;
   int32_t* out_cnt;
+  // explicit frontier (hash-partitioned graphs): node ids + their K sums arrive from other ranks; the
+  // resident CSC holds only the rows of the nodes this rank owns, row = id / row_div
+  const uint32_t* ex_nodes;
+  const uint32_t* ex_ksum;
+  uint32_t row_div;
 };
 
-// parent node id and K (wrapping int32 sum of the path ids) for parent slot p — wave-uniform
+// CSC row of the parent in slot p and K (wrapping int32 sum of the path ids) — wave-uniform
 __device__ __forceinline__ void parent_of(const ExpandArgs& a, int64_t p, uint32_t& v, uint32_t& ksum) {
+  if (a.ex_nodes) {
+    v = a.ex_nodes[p];
+    ksum = a.ex_ksum[p];
+    if (v != GIGL_INVALID) v /= a.row_div;
+    return;
+  }
   if (a.hop == 0) {
     v = a.roots[p];
     ksum = v;
@@ -636,6 +647,49 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
     parents *= fanouts[k];
   }
   return GIGL_OK;
+}
+
+int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* nodes, const uint32_t* ksums,
+                             int64_t m, int32_t f, int32_t hash_add, int32_t world, int64_t max_window_end,
+                             uint32_t* out_nbr, int32_t* out_cnt) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, shard && (m == 0 || (nodes && ksums && out_nbr && out_cnt)), "null argument");
+  GIGL_REQUIRE(ctx, world >= 1 && m >= 0 && m < ((int64_t)1 << 31), "bad sizes");
+  if (f < 1 || f > GIGL_MAX_FANOUT)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "fanout %d outside [1,%d]", f, GIGL_MAX_FANOUT);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (m == 0) return GIGL_OK;
+  const uint64_t cap = 1ull << 31;
+  const bool bounded = max_window_end >= 0;
+  const uint64_t bound = bounded ? (uint64_t)max_window_end : ~0ULL;
+  int32_t rc = ensure_table(ctx, !bounded ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));
+  if (rc != GIGL_OK) return rc;
+  const RangeTable tb = ((TableOwner*)ctx->sampler_table)->t;
+  const bool covered = bounded && bound < tb.dom;
+  int64_t* heavy_list = nullptr;
+  int32_t* heavy_count = nullptr;
+  if (!covered) {
+    rc = gigl_arena_reset(ctx, m * 8 + 256 * 4);
+    if (rc != GIGL_OK) return rc;
+    heavy_list = (int64_t*)gigl_arena_alloc(ctx, m * 8);
+    heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
+    if (!heavy_list || !heavy_count) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  }
+  ExpandArgs a{};
+  a.rowptr = shard->rowptr;
+  a.col = shard->col;
+  a.n_nodes = shard->n;  // local rows
+  a.hop = 0;
+  a.n_parents = m;
+  a.f = f;
+  a.fan[0] = f;
+  a.hash_add = hash_add;
+  a.out_nbr = out_nbr;
+  a.out_cnt = out_cnt;
+  a.ex_nodes = nodes;
+  a.ex_ksum = ksums;
+  a.row_div = (uint32_t)world;
+  return run_expand(ctx, a, tb, covered, heavy_list, heavy_count);
 }
 
 int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* roots, int32_t b,

@@ -262,6 +262,20 @@ class HipEngine:
                 tree.nbr[k] = tree.nbr[k][:parents]
         return tree
 
+    def expand_frontier(self, nodes: torch.Tensor, ksums: torch.Tensor, f: int, hash_add: int, world: int,
+                        max_window_end: int = -1):
+        """one hop over an explicit frontier on this rank's shard (resident graph = rows of owned nodes);
+        nodes/ksums: int32 device tensors (uint32 payload).  -> (nbr [m*f] int32, cnt [m] int32)"""
+        assert self._graph is not None
+        m = int(nodes.numel())
+        nbr = torch.empty(max(m * f, 1), dtype=torch.int32, device=self.device)
+        cnt = torch.empty(max(m, 1), dtype=torch.int32, device=self.device)
+        hash_add = ((int(hash_add) + 2**31) % 2**32) - 2**31
+        check(self._lib.gigl_expand_frontier(self._ctx, self._graph, C.c_void_p(nodes.data_ptr()),
+                                             C.c_void_p(ksums.data_ptr()), m, f, hash_add, world, max_window_end,
+                                             C.c_void_p(nbr.data_ptr()), C.c_void_p(cnt.data_ptr())), self._ctx)
+        return nbr[: m * f], cnt[:m]
+
     def sample_positives(self, roots, num_positives: int, sampling_seed: int = 42):
         assert self._graph_out is not None, "load the out-edge graph first (out_graph=True)"
         r = self._roots_tensor(roots)

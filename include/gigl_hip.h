@@ -148,6 +148,17 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
                          const int32_t* fanouts, int32_t hops, int32_t sampling_seed,
                          int32_t mode, gigl_tree* out);
 
+/* one hop over an EXPLICIT frontier on a hash-partitioned graph (owner(v) = v % world,
+ * python/gigl/distributed/dist_link_prediction_data_partitioner.py:692-695): `shard` holds only the CSC rows of
+ * the nodes this rank owns (row v / world, ids inside rows stay global); nodes[i] (all owned by this rank, or
+ * GIGL_INVALID) and ksums[i] (K of the path root..nodes[i], computed by the requesting rank) arrive through the
+ * frontier all-to-all.  Same selection rule as gigl_sample_khop with hash_add = seed * counter; output
+ * out_nbr[i*f + j], out_cnt[i].  max_window_end >= 0 bounds ksum + hash_add + degree over all requests (lets
+ * every window use the hash range table); -1 = unknown. */
+int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* nodes, const uint32_t* ksums,
+                             int64_t m, int32_t f, int32_t hash_add, int32_t world, int64_t max_window_end,
+                             uint32_t* out_nbr, int32_t* out_cnt);
+
 /* positives for node-anchor link prediction: `f` OUT-neighbours of each root, counter = 3
  * (sampleDstNodesUniformly, NodeAnchorBasedLinkPredictionBaseTask.scala:19-104).  `g_out` is the
  * CSR-by-source graph loaded through gigl_graph_load_csc with the roles of src/dst swapped. */
