@@ -29,7 +29,8 @@ SYMBOLS = [
     "gigl_union_capacity", "gigl_union_build", "gigl_gather_mean", "gigl_linear",
     "gigl_profile_enable", "gigl_profile_read", "gigl_profile_reset",
     "gigl_sage_plan_create", "gigl_sage_plan_set_weights", "gigl_sage_plan_buffers", "gigl_sage_plan_run",
-    "gigl_sage_plan_destroy", "gigl_gather_mean_backward", "gigl_expand_frontier",
+    "gigl_sage_plan_destroy", "gigl_gather_mean_backward", "gigl_expand_frontier", "gigl_gcn_aggregate",
+    "gigl_gat_aggregate", "gigl_gather_rows",
 ]
 
 KERNEL_IDS = {
@@ -120,6 +121,9 @@ def load() -> C.CDLL:
         "gigl_sage_plan_destroy": [vp],
         "gigl_gather_mean_backward": [vp, vp, i32, vp, vp, vp, vp, i64, vp],
         "gigl_expand_frontier": [vp, vp, vp, vp, i64, i32, i32, i32, i64, vp, vp],
+        "gigl_gather_rows": [vp, vp, i32, i32, vp, vp, i64, vp],
+        "gigl_gcn_aggregate": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, vp],
+        "gigl_gat_aggregate": [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -372,6 +372,165 @@ __global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// GCNConv / GATConv aggregation (PyG 2.5.3 semantics as used by homogeneous.py:300-343,488-546)
+// ------------------------------------------------------------------------------------------
+
+// hydration only: out[i][0:d] = (float) src[ids[i]][0:d] for i < *n_dev   (one wave per row)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, int d,
+                                                          const uint32_t* __restrict__ ids,
+                                                          const int32_t* __restrict__ n_dev, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n = *n_dev;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wave; i < n; i += waves_total) {
+    const T* p = src + (int64_t)ids[i] * d;
+    for (int el = lane; el < d; el += 64) out[(int64_t)i * d + el] = (float)p[el];
+  }
+}
+
+// dinv[i] = 1/sqrt(1 + #in-edges of i that are not self loops)   (add_remaining_self_loops + sym. norm)
+__global__ __launch_bounds__(256) void gcn_dinv_kernel(const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ rowend,
+                                                       const int32_t* __restrict__ col,
+                                                       const int32_t* __restrict__ n_nodes_dev, float* __restrict__ dinv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= *n_nodes_dev) return;
+  const int e0 = rowptr[i], e1 = rowend[i];
+  int deg = 1;
+  for (int e = e0; e < e1; ++e) deg += col[e] != i;
+  dinv[i] = 1.0f / sqrtf((float)deg);
+}
+
+// out[i] = act( dinv_i * ( dinv_i * h[idx(i)] + sum_{j in row i, j != i} dinv_j * h[idx(j)] ) + bias )
+// one wave per destination row; h rows are fp32 [*, d] gathered through gather_ids (or identity)
+template <typename T>
+__global__ __launch_bounds__(256) void gcn_gather_kernel(const T* __restrict__ h, int d,
+                                                         const uint32_t* __restrict__ gather_ids,
+                                                         const float* __restrict__ dinv,
+                                                         const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ rowend,
+                                                         const int32_t* __restrict__ col,
+                                                         const int32_t* __restrict__ n_rows_dev,
+                                                         const float* __restrict__ bias, int act,
+                                                         float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_rows = *n_rows_dev;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    const float di = dinv[i];
+    const int64_t self = gather_ids ? (int64_t)gather_ids[i] : i;
+    for (int el = lane; el < d; el += 64) {
+      float acc = di * (float)h[self * d + el];
+      for (int e = 0; e < m; ++e) {
+        const int j = col[e0 + e];
+        if (j == i) continue;
+        const int64_t gj = gather_ids ? (int64_t)gather_ids[j] : j;
+        acc += dinv[j] * (float)h[gj * d + el];
+      }
+      float v = di * acc + (bias ? bias[el] : 0.f);
+      if (act == 1) v = v > 0.f ? v : 0.f;
+      out[(int64_t)i * d + el] = v;
+    }
+  }
+}
+
+// alpha[i][hd] = sum_c h[i][hd*C + c] * att[hd*C + c]      (one thread per (node, head))
+__global__ void gat_alpha_kernel(const float* __restrict__ h, const float* __restrict__ att_src,
+                                 const float* __restrict__ att_dst, const int32_t* __restrict__ n_dev, int heads,
+                                 int C, float* __restrict__ a_src, float* __restrict__ a_dst) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = *n_dev;
+  if (t >= n * heads) return;
+  const int64_t i = t / heads;
+  const int hd = (int)(t % heads);
+  const float* row = h + i * heads * C + hd * C;
+  float s = 0.f, dd = 0.f;
+  for (int c = 0; c < C; ++c) {
+    s += row[c] * att_src[hd * C + c];
+    dd += row[c] * att_dst[hd * C + c];
+  }
+  a_src[t] = s;
+  a_dst[t] = dd;
+}
+
+// GAT attention + weighted sum for one destination row per wave, all heads:
+//   e_ij = leaky_relu(a_src[j] + a_dst[i]) over the in-edges of i (self loops removed) plus ONE self loop,
+//   alpha = softmax_j(e_ij), out[i][hd*C + c] = sum_j alpha_ij h[j][hd*C + c]  (+ bias, optional relu);
+//   concat == 0: mean over heads -> out[i][c].
+__global__ __launch_bounds__(256) void gat_gather_kernel(const float* __restrict__ h, const float* __restrict__ a_src,
+                                                         const float* __restrict__ a_dst,
+                                                         const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ rowend,
+                                                         const int32_t* __restrict__ col,
+                                                         const int32_t* __restrict__ n_rows_dev, int heads, int C,
+                                                         float slope, int concat, const float* __restrict__ bias,
+                                                         int act, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_rows = *n_rows_dev;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int HC = heads * C;
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    for (int hd = 0; hd < heads; ++hd) {
+      const float ad = a_dst[(int64_t)i * heads + hd];
+      // pass 1: max logit (self loop included)
+      float self_e = a_src[(int64_t)i * heads + hd] + ad;
+      self_e = self_e > 0.f ? self_e : slope * self_e;
+      float mx = self_e;
+      for (int e = lane; e < m; e += 64) {
+        const int j = col[e0 + e];
+        if (j == i) continue;
+        float x = a_src[(int64_t)j * heads + hd] + ad;
+        x = x > 0.f ? x : slope * x;
+        mx = fmaxf(mx, x);
+      }
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      // pass 2: denominator
+      float den = lane == 0 ? expf(self_e - mx) : 0.f;
+      for (int e = lane; e < m; e += 64) {
+        const int j = col[e0 + e];
+        if (j == i) continue;
+        float x = a_src[(int64_t)j * heads + hd] + ad;
+        x = x > 0.f ? x : slope * x;
+        den += expf(x - mx);
+      }
+      for (int off = 32; off > 0; off >>= 1) den += __shfl_xor(den, off, 64);
+      const float inv = 1.0f / (den + 1e-16f);
+      // pass 3: weighted sum; lanes over channels
+      for (int c = lane; c < C; c += 64) {
+        float acc = expf(self_e - mx) * inv * h[(int64_t)i * HC + hd * C + c];
+        for (int e = 0; e < m; ++e) {
+          const int j = col[e0 + e];
+          if (j == i) continue;
+          float x = a_src[(int64_t)j * heads + hd] + ad;
+          x = x > 0.f ? x : slope * x;
+          acc += expf(x - mx) * inv * h[(int64_t)j * HC + hd * C + c];
+        }
+        if (concat) {
+          float v = acc + (bias ? bias[hd * C + c] : 0.f);
+          if (act == 1) v = v > 0.f ? v : 0.f;
+          out[(int64_t)i * HC + hd * C + c] = v;
+        } else {
+          // mean over heads: accumulate in place (heads are processed sequentially by this wave)
+          float prev = hd == 0 ? 0.f : out[(int64_t)i * C + c];
+          float v = prev + acc / (float)heads;
+          if (hd == heads - 1) {
+            v += bias ? bias[c] : 0.f;
+            if (act == 1) v = v > 0.f ? v : 0.f;
+          }
+          out[(int64_t)i * C + c] = v;
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather_ids,
                       const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
@@ -420,6 +579,74 @@ int32_t gigl_gather_mean(gigl_ctx* ctx, const void* src, int32_t src_dtype, int3
     return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev,
                                  rows_cap, out);
   return gigl_fail(ctx, GIGL_E_INVALID_ARG, "bad dtype %d", src_dtype);
+}
+
+int32_t gigl_gather_rows(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* ids,
+                         const int32_t* n_dev, int64_t cap, float* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, src && ids && n_dev && out && d > 0 && cap >= 0, "bad arguments");
+  GIGL_REQUIRE(ctx, src_dtype == GIGL_DTYPE_F32 || src_dtype == GIGL_DTYPE_F16, "bad dtype %d", src_dtype);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (cap == 0) return GIGL_OK;
+  int64_t blocks = (cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (src_dtype == GIGL_DTYPE_F32)
+    hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)src,
+                       d, ids, n_dev, out);
+  else
+    hipLaunchKernelGGL((gather_rows_kernel<__half>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       (const __half*)src, d, ids, n_dev, out);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_gcn_aggregate(gigl_ctx* ctx, const void* h, int32_t h_dtype, int32_t d, const uint32_t* gather_ids,
+                           const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                           const int32_t* n_nodes_dev, int64_t nodes_cap, const int32_t* n_rows_dev,
+                           int64_t rows_cap, const float* bias, int32_t act, float* dinv_scratch, float* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, h && rowptr && rowend && col && n_nodes_dev && n_rows_dev && dinv_scratch && out, "null argument");
+  GIGL_REQUIRE(ctx, d > 0 && rows_cap >= 0 && nodes_cap >= rows_cap, "bad sizes");
+  GIGL_REQUIRE(ctx, h_dtype == GIGL_DTYPE_F32 || h_dtype == GIGL_DTYPE_F16, "bad dtype %d", h_dtype);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  hipLaunchKernelGGL(gcn_dinv_kernel, dim3((unsigned)((nodes_cap + 255) / 256)), dim3(256), 0, ctx->stream, rowptr,
+                     rowend, col, n_nodes_dev, dinv_scratch);
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (h_dtype == GIGL_DTYPE_F32)
+    hipLaunchKernelGGL((gcn_gather_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)h,
+                       d, gather_ids, dinv_scratch, rowptr, rowend, col, n_rows_dev, bias, act, out);
+  else
+    hipLaunchKernelGGL((gcn_gather_kernel<__half>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                       (const __half*)h, d, gather_ids, dinv_scratch, rowptr, rowend, col, n_rows_dev, bias, act, out);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_gat_aggregate(gigl_ctx* ctx, const float* h, const float* att_src, const float* att_dst, int32_t heads,
+                           int32_t channels, float negative_slope, int32_t concat, const int32_t* rowptr,
+                           const int32_t* rowend, const int32_t* col, const int32_t* n_nodes_dev, int64_t nodes_cap,
+                           const int32_t* n_rows_dev, int64_t rows_cap, const float* bias, int32_t act,
+                           float* alpha_scratch, float* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, h && att_src && att_dst && rowptr && rowend && col && n_nodes_dev && n_rows_dev &&
+                        alpha_scratch && out, "null argument");
+  GIGL_REQUIRE(ctx, heads > 0 && channels > 0 && rows_cap >= 0 && nodes_cap >= rows_cap, "bad sizes");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  float* a_src = alpha_scratch;
+  float* a_dst = alpha_scratch + nodes_cap * heads;
+  hipLaunchKernelGGL(gat_alpha_kernel, dim3((unsigned)((nodes_cap * heads + 255) / 256)), dim3(256), 0, ctx->stream,
+                     h, att_src, att_dst, n_nodes_dev, heads, channels, a_src, a_dst);
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(gat_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, h, a_src, a_dst, rowptr,
+                     rowend, col, n_rows_dev, heads, channels, negative_slope, concat, bias, act, out);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
 }
 
 int32_t gigl_gather_mean_backward(gigl_ctx* ctx, const float* dout, int32_t d, const int32_t* rowptr,

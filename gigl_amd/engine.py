@@ -336,6 +336,54 @@ class HipEngine:
                                          C.c_void_p(out.data_ptr())), self._ctx)
         return out
 
+    def gather_rows(self, ids: torch.Tensor, n_dev: torch.Tensor, cap: int,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """fp32 rows of the resident feature table for the first *n_dev ids"""
+        if out is None:
+            out = torch.empty((cap, self.feat_dim), dtype=torch.float32, device=self.device)
+        check(self._lib.gigl_gather_rows(self._ctx, self._feat_ptr, self.feat_dtype, self.feat_dim,
+                                         C.c_void_p(ids.data_ptr()), C.c_void_p(n_dev.data_ptr()), cap,
+                                         C.c_void_p(out.data_ptr())), self._ctx)
+        return out
+
+    def gcn_aggregate(self, h: Optional[torch.Tensor], d: int, gather_ids: Optional[torch.Tensor], u: "UnionGraph",
+                      n_rows_dev: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """GCN-normalised aggregation over the union graph `u` (h None -> resident feature table)"""
+        cap = int(u.nodes.numel())
+        if h is None:
+            h_ptr, dt = self._feat_ptr, self.feat_dtype
+        else:
+            assert h.is_cuda and h.is_contiguous()
+            h_ptr, dt = C.c_void_p(h.data_ptr()), (DTYPE_F32 if h.dtype == torch.float32 else DTYPE_F16)
+        if out is None:
+            out = torch.empty((cap, d), dtype=torch.float32, device=self.device)
+        dinv = torch.empty(cap, dtype=torch.float32, device=self.device)
+        gid = C.c_void_p(gather_ids.data_ptr()) if gather_ids is not None else None
+        check(self._lib.gigl_gcn_aggregate(self._ctx, h_ptr, dt, d, gid, C.c_void_p(u.rowptr.data_ptr()),
+                                           C.c_void_p(u.rowend.data_ptr()), C.c_void_p(u.col.data_ptr()),
+                                           C.c_void_p(u.meta.data_ptr()), cap, C.c_void_p(n_rows_dev.data_ptr()), cap,
+                                           C.c_void_p(bias.data_ptr()) if bias is not None else None, act,
+                                           C.c_void_p(dinv.data_ptr()), C.c_void_p(out.data_ptr())), self._ctx)
+        return out
+
+    def gat_aggregate(self, h: torch.Tensor, att_src: torch.Tensor, att_dst: torch.Tensor, heads: int, channels: int,
+                      u: "UnionGraph", n_rows_dev: torch.Tensor, bias: Optional[torch.Tensor], concat: bool = True,
+                      negative_slope: float = 0.2, act: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        cap = int(u.nodes.numel())
+        assert h.is_cuda and h.is_contiguous() and h.dtype == torch.float32 and h.shape[1] == heads * channels
+        if out is None:
+            out = torch.empty((cap, heads * channels if concat else channels), dtype=torch.float32, device=self.device)
+        scratch = torch.empty(2 * cap * heads, dtype=torch.float32, device=self.device)
+        check(self._lib.gigl_gat_aggregate(self._ctx, C.c_void_p(h.data_ptr()), C.c_void_p(att_src.data_ptr()),
+                                           C.c_void_p(att_dst.data_ptr()), heads, channels, negative_slope,
+                                           1 if concat else 0, C.c_void_p(u.rowptr.data_ptr()),
+                                           C.c_void_p(u.rowend.data_ptr()), C.c_void_p(u.col.data_ptr()),
+                                           C.c_void_p(u.meta.data_ptr()), cap, C.c_void_p(n_rows_dev.data_ptr()), cap,
+                                           C.c_void_p(bias.data_ptr()) if bias is not None else None, act,
+                                           C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr())), self._ctx)
+        return out
+
     def gather_mean_backward(self, dout: torch.Tensor, d: int, rowptr: torch.Tensor, rowend: Optional[torch.Tensor],
                              col: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int, dsrc: torch.Tensor) -> None:
         """dsrc (zero-filled, [n_src, d] fp32) += the gradient of gather_mean w.r.t. its dense local source"""

@@ -1,0 +1,108 @@
+"""GCN / GAT encoders on the HIP aggregation kernels (inference over the level-ordered union graph).
+
+Mirror of (paths relative to the reference root):
+  TwoLayerGCN  python/gigl/src/common/models/pyg/homogeneous.py:488-546   conv1 -> relu -> dropout -> conv2
+               [-> L2 normalise]; PyG GCNConv params `conv{1,2}.lin.weight`, `conv{1,2}.bias`.
+               The reference applies F.dropout(training=self.is_training) with the CONSTRUCTOR flag (default True)
+               even in infer_batch; parity is defined for is_training=False, which is
+               what this inference path computes (no dropout).
+  GAT          :300-343 + BasicHomogeneousGNN.forward :107-153: GATConv(in, hid, heads=H) ... last layer heads=1,
+               relu between layers; PyG 2.5.3 GATConv params `lin.weight`, `att_src`, `att_dst`, `bias`.
+Parameter names come from the un-vendored PyG 2.5.3 ("parity unpinned"); the arithmetic is
+checked against oracle/gnn_ref.py (tests/test_gpu_attn.py).
+Trimmed schedule as in models.GraphSAGE: layer l computes only the prefix of rows that can still reach a root.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ._lib import GIGL_META_LEVEL0
+from .models import HipBatch
+
+
+class GCNConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, bias: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        nn.init.xavier_uniform_(self.lin.weight)  # PyG: glorot weight, zero bias
+
+
+class TwoLayerGCN(nn.Module):
+    def __init__(self, in_dim: int, out_dim: int, hid_dim: int = 16, is_training: bool = True,
+                 should_l2_normalize_output: bool = False, **kwargs):
+        super().__init__()
+        self.is_training = is_training
+        self.should_normalize = should_l2_normalize_output
+        self.conv1 = GCNConv(in_dim, hid_dim, bias=bool(kwargs.get("bias", True)))
+        self.conv2 = GCNConv(hid_dim, out_dim, bias=bool(kwargs.get("bias", True)))
+
+    @torch.no_grad()
+    def forward(self, batch: HipBatch) -> torch.Tensor:
+        """[cap, out_dim]; rows [0, n_level0) = distinct roots (index with batch.root_local)"""
+        eng, u = batch.engine, batch.union
+        assert u.hops == 2, "TwoLayerGCN needs 2-hop samples"
+        cap = int(u.nodes.numel())
+        n1 = u.meta[GIGL_META_LEVEL0 + 1: GIGL_META_LEVEL0 + 2]
+        n0 = u.meta[GIGL_META_LEVEL0: GIGL_META_LEVEL0 + 1]
+        # (A_hat X) W == A_hat (X W): aggregate first so that the projection only touches the needed rows
+        a1 = eng.gcn_aggregate(None, self.conv1.in_channels, u.nodes, u, n1, None, 0)
+        h1 = eng.linear(a1, self.conv1.lin.weight.contiguous(), self.conv1.bias, n1, cap, act=1)
+        a2 = eng.gcn_aggregate(h1, self.conv2.in_channels, None, u, n0, None, 0)
+        out = eng.linear(a2, self.conv2.lin.weight.contiguous(), self.conv2.bias, n0, cap, act=0)
+        if self.should_normalize:
+            out = torch.nn.functional.normalize(out, p=2, dim=1)
+        return out
+
+
+class GATConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
+                 negative_slope: float = 0.2, bias: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.concat, self.negative_slope = concat, negative_slope
+        self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels if concat else out_channels)) if bias else None
+        nn.init.xavier_uniform_(self.lin.weight)
+        nn.init.xavier_uniform_(self.att_src)
+        nn.init.xavier_uniform_(self.att_dst)
+
+
+class GAT(nn.Module):
+    def __init__(self, in_dim: int, hid_dim: int, out_dim: int, num_layers: int = 2, heads: int = 1,
+                 activation_after_last_conv: bool = False, should_l2_normalize_embedding_layer_output: bool = False,
+                 **conv_kwargs):
+        super().__init__()
+        self.num_layers = num_layers
+        self.activation_after_last_conv = activation_after_last_conv
+        self.should_l2_normalize_embedding_layer_output = should_l2_normalize_embedding_layer_output
+        self.conv_layers = nn.ModuleList([
+            GATConv(in_dim if i == 0 else hid_dim * heads, hid_dim if i < num_layers - 1 else out_dim,
+                    heads=heads if i < num_layers - 1 else 1, concat=bool(conv_kwargs.get("concat", True)),
+                    negative_slope=float(conv_kwargs.get("negative_slope", 0.2)), bias=bool(conv_kwargs.get("bias", True)))
+            for i in range(num_layers)])
+
+    @torch.no_grad()
+    def forward(self, batch: HipBatch) -> torch.Tensor:
+        eng, u = batch.engine, batch.union
+        L = self.num_layers
+        assert u.hops == L, "one hop per layer"
+        cap = int(u.nodes.numel())
+        h = None
+        for l, conv in enumerate(self.conv_layers):
+            # sources of layer l are the rows computed by layer l-1 (all union nodes for the first layer)
+            n_src = u.meta[GIGL_META_LEVEL0 + (L - l): GIGL_META_LEVEL0 + (L - l) + 1]
+            n_dst = u.meta[GIGL_META_LEVEL0 + (L - 1 - l): GIGL_META_LEVEL0 + (L - l)]
+            x = eng.gather_rows(u.nodes, n_src, cap) if l == 0 else h
+            hw = eng.linear(x, conv.lin.weight.contiguous(), None, n_src, cap, act=0)
+            act = 1 if (l < L - 1 or self.activation_after_last_conv) else 0
+            h = eng.gat_aggregate(hw, conv.att_src.reshape(-1).contiguous(), conv.att_dst.reshape(-1).contiguous(),
+                                  conv.heads, conv.out_channels, u, n_dst, conv.bias, concat=conv.concat,
+                                  negative_slope=conv.negative_slope, act=act)
+        if self.should_l2_normalize_embedding_layer_output:
+            h = torch.nn.functional.normalize(h, p=2, dim=1)
+        return h

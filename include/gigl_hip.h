@@ -223,6 +223,34 @@ int32_t gigl_gather_mean(gigl_ctx* ctx, const void* src, int32_t src_dtype, int3
                          const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* rowend,
                          const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, float* out);
 
+/* feature hydration alone (hydrateNodes, SGSPureSparkV1Task.scala:496-547): out[i][0:d] = src[ids[i]][0:d] as fp32
+ * for i < *n_dev.  Needed when a layer projects before it aggregates (GAT). */
+int32_t gigl_gather_rows(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* ids,
+                         const int32_t* n_dev, int64_t cap, float* out);
+
+/* GCNConv aggregation (PyG 2.5.3 GCNConv as used by TwoLayerGCN, python/gigl/src/common/models/pyg/homogeneous.py:
+ * 488-546): symmetric normalisation with one self loop per node,
+ *   out[i] = act( sum_{j in N(i) u {i}} h[idx(j)] / sqrt(deg_i deg_j) + bias ),  deg = 1 + #non-self in-edges,
+ * for rows i < *n_rows_dev; degrees are taken over the first *n_nodes_dev nodes of the union graph.
+ * h: [*, d] fp32/fp16 rows (gather_ids = union.nodes reads the resident feature table; NULL = local matrix).
+ * dinv_scratch: DEVICE fp32 [nodes_cap].  (A X) W == A (X W): apply gigl_linear before or after. */
+int32_t gigl_gcn_aggregate(gigl_ctx* ctx, const void* h, int32_t h_dtype, int32_t d, const uint32_t* gather_ids,
+                           const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                           const int32_t* n_nodes_dev, int64_t nodes_cap, const int32_t* n_rows_dev,
+                           int64_t rows_cap, const float* bias, int32_t act, float* dinv_scratch, float* out);
+
+/* GATConv attention + aggregation (PyG 2.5.3 GATConv as configured by GAT.init_conv_layers, homogeneous.py:300-343):
+ *   h: fp32 [nodes][heads*channels] = x W (gigl_linear), att_src/att_dst: [heads*channels];
+ *   e_ij = leaky_relu(<h_j, att_src> + <h_i, att_dst>, negative_slope) over the in-edges of i (self loops removed)
+ *   plus one self loop; alpha = softmax_j e_ij; out[i] = sum_j alpha_ij h_j, heads concatenated (concat=1,
+ *   [rows][heads*channels]) or averaged (concat=0, [rows][channels]); + bias; optional relu.
+ * alpha_scratch: DEVICE fp32 [2*nodes_cap*heads]. */
+int32_t gigl_gat_aggregate(gigl_ctx* ctx, const float* h, const float* att_src, const float* att_dst, int32_t heads,
+                           int32_t channels, float negative_slope, int32_t concat, const int32_t* rowptr,
+                           const int32_t* rowend, const int32_t* col, const int32_t* n_nodes_dev, int64_t nodes_cap,
+                           const int32_t* n_rows_dev, int64_t rows_cap, const float* bias, int32_t act,
+                           float* alpha_scratch, float* out);
+
 /* backward of gigl_gather_mean w.r.t. a dense local fp32 source (gather_ids == NULL; layers >= 2):
  *   dsrc[i][0:d] += dout[i][d:2d];  dsrc[col[e]][0:d] += dout[i][0:d] / deg_i  for e in row i, i < n_rows.
  * dsrc must be zero-filled by the caller.  (PyG's autograd of MessagePassing.propagate + scatter-mean.) */

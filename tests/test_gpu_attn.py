@@ -1,0 +1,104 @@
+"""GCN / GAT root embeddings of the HIP trimmed schedule == fp32 CPU forward of every layer over the WHOLE batch
+union graph (reference execution order, PyG 2.5.3 formulas restated in oracle/gnn_ref.py); tolerance 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import rmat_edges
+from oracle import gnn_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from gigl_amd.engine import HipEngine
+    s, d = rmat_edges(12, 70000, seed=44)
+    n = 1 << 12
+    # add a few self loops to exercise add_remaining_self_loops / remove_self_loops
+    s = np.concatenate([s, np.arange(0, 200, dtype=np.uint32)])
+    d = np.concatenate([d, np.arange(0, 200, dtype=np.uint32)])
+    rowptr, col = oracle.build_csc(n, s, d, is_directed=True)
+    x = (np.random.default_rng(0).standard_normal((n, 48)) / 4).astype(np.float32)
+    eng = HipEngine(0)
+    eng.load_csc(rowptr, col)
+    eng.load_features(x)
+    yield eng, rowptr, col, x, n
+    eng.close()
+
+
+def _union(eng, rowptr, col, roots, fan):
+    from gigl_amd.models import HipBatch
+    tree = eng.sample_khop(roots, fan)
+    u = eng.union_build(tree)
+    nbr_o, _ = oracle.sample_khop(rowptr, col, roots, fan, canonical=True)
+    o = oracle.union_build(roots, fan, nbr_o)
+    return HipBatch(eng, tree, u), u, o
+
+
+@pytest.mark.parametrize("hid,out,norm", [(16, 7, False), (64, 32, True)])
+def test_two_layer_gcn(setup, hid, out, norm):
+    from gigl_amd.models_attn import TwoLayerGCN
+    eng, rowptr, col, x, n = setup
+    torch.manual_seed(hid)
+    model = TwoLayerGCN(48, out, hid_dim=hid, is_training=False, should_l2_normalize_output=norm).to(eng.device)
+    with torch.no_grad():
+        model.conv1.bias.normal_(0, 0.1)
+        model.conv2.bias.normal_(0, 0.1)
+    roots = np.random.default_rng(1).integers(0, n, size=150).astype(np.uint32)
+    batch, u, o = _union(eng, rowptr, col, roots, [8, 5])
+    got = model(batch)[u.root_local[:150].long()].cpu().numpy()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ei = gnn_ref.union_edge_index(o["rowptr"], o["col"])
+    xs = torch.from_numpy(x[o["nodes"]])
+    h = torch.relu(gnn_ref.gcn_conv(xs, ei, sd["conv1.lin.weight"], sd["conv1.bias"]))
+    ref = gnn_ref.gcn_conv(h, ei, sd["conv2.lin.weight"], sd["conv2.bias"])
+    if norm:
+        ref = torch.nn.functional.normalize(ref, p=2, dim=1)
+    np.testing.assert_allclose(got, ref[o["root_local"]].numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("heads,hid,out,fan", [(1, 32, 16, [8, 5]), (2, 16, 24, [10, 4]), (4, 8, 8, [5, 3, 2])])
+def test_gat(setup, heads, hid, out, fan):
+    from gigl_amd.models_attn import GAT
+    eng, rowptr, col, x, n = setup
+    torch.manual_seed(heads)
+    L = len(fan)
+    model = GAT(48, hid, out, num_layers=L, heads=heads).to(eng.device)
+    with torch.no_grad():
+        for c in model.conv_layers:
+            c.bias.normal_(0, 0.1)
+    roots = np.random.default_rng(2).integers(0, n, size=120).astype(np.uint32)
+    batch, u, o = _union(eng, rowptr, col, roots, fan)
+    got = model(batch)[u.root_local[:120].long()].cpu().numpy()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ei = gnn_ref.union_edge_index(o["rowptr"], o["col"])
+    h = torch.from_numpy(x[o["nodes"]])
+    for l in range(L):
+        p = f"conv_layers.{l}."
+        hd = heads if l < L - 1 else 1
+        h = gnn_ref.gat_conv(h, ei, sd[p + "lin.weight"], sd[p + "att_src"], sd[p + "att_dst"], sd[p + "bias"], hd)
+        if l < L - 1:
+            h = torch.relu(h)
+    np.testing.assert_allclose(got, h[o["root_local"]].numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_gnn_ref_identities():
+    """algebraic pins of the restated formulas: GCN == dense D^-1/2 (A+I) D^-1/2 X W; GAT rows are convex
+    combinations (softmax sums to 1) -> with W = I, att = 0 the output is the plain mean over N(i) u {i}"""
+    torch.manual_seed(0)
+    n, e = 40, 160
+    ei = torch.randint(0, n, (2, e))
+    ei = torch.unique(ei[:, ei[0] != ei[1]], dim=1)
+    x = torch.randn(n, 6)
+    w = torch.randn(5, 6)
+    a = torch.zeros(n, n)
+    a[ei[1], ei[0]] = 1.0
+    a = a + torch.eye(n)
+    dinv = a.sum(1).pow(-0.5)
+    dense = (dinv[:, None] * a * dinv[None, :]) @ x @ w.T
+    assert torch.allclose(gnn_ref.gcn_conv(x, ei, w, None), dense, atol=1e-5)
+    out = gnn_ref.gat_conv(x, ei, torch.eye(6), torch.zeros(1, 1, 6), torch.zeros(1, 1, 6), None, heads=1)
+    mean = (a @ x) / a.sum(1, keepdim=True)
+    assert torch.allclose(out, mean, atol=1e-5)
