@@ -1,0 +1,103 @@
+"""Link-prediction head against the reference's known answers
+(python/tests/unit/src/common/models/layers/loss_test.py:61-166, decoder_test.py:44-86)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gigl_amd.link_prediction import DecoderType, LinkPredictionDecoder, RetrievalLoss
+
+Q = F.normalize(torch.tensor([[1.0, 1.0, 0.0, 0.0], [1.0, 1.0, 0.0, 0.0], [0.0, 0.0, 0.9, 1.1], [0.0, 0.0, 0.9, 1.1]]), p=2, dim=1)
+POS = F.normalize(torch.tensor([[1.0, 0.2, 0.0, 0.0], [0.3, 1.0, 0.2, 0.0], [0.0, 0.0, 1.0, 0.4], [0.0, 0.0, 0.4, 0.9]]), p=2, dim=1)
+NEG = F.normalize(torch.tensor([[0.21, 0.22, 0.23, 0.24], [0.24, 0.23, 0.22, 0.21]]), p=2, dim=1)
+CAND = torch.concat([POS, NEG], dim=0)
+CAND_IDS = torch.tensor([1, 2, 3, 4, 1, 5], dtype=torch.int64)  # one random negative collides with a positive
+QUERY_IDS = torch.tensor([11, 11, 12, 12], dtype=torch.int64)   # each anchor has two positives
+LABELS = torch.eye(4, 6)
+MINF = torch.finfo(torch.float).min
+
+
+def test_mask_by_query_ids():
+    got = RetrievalLoss()._mask_by_query_ids(QUERY_IDS, 4, 6, torch.float32)
+    want = torch.tensor([[1., 1, 0, 0, 0, 0], [1, 1, 0, 0, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 1, 1, 0, 0]])
+    assert torch.allclose(got, want)
+
+
+def test_mask_by_candidate_ids():
+    got = RetrievalLoss()._mask_by_candidate_ids(CAND_IDS, 4, torch.float32)
+    want = torch.tensor([[1., 0, 0, 0, 1, 0], [0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0]])
+    assert torch.allclose(got, want)
+
+
+def test_loss_values():
+    scores = torch.mm(Q, CAND.T)
+    e1 = torch.tensor([[0.8321, 0.8647, 0.0, 0.0, 0.6748, 0.7376], [0.8321, 0.8647, 0.0, 0.0, 0.6748, 0.7376],
+                       [0.0, 0.1191, 0.8754, 0.9644, 0.7355, 0.6699], [0.0, 0.1191, 0.8754, 0.9644, 0.7355, 0.6699]])
+    a1 = RetrievalLoss(remove_accidental_hits=False).calculate_batch_retrieval_loss(scores)
+    assert torch.isclose(F.cross_entropy(e1, LABELS, reduction="sum"), a1, atol=1e-3)
+    loss = RetrievalLoss(remove_accidental_hits=True)
+    e2 = e1.clone()
+    e2[0, 4] = MINF
+    a2 = loss.calculate_batch_retrieval_loss(scores, candidate_ids=CAND_IDS)
+    assert torch.isclose(F.cross_entropy(e2, LABELS, reduction="sum"), a2, atol=1e-3)
+    e3 = e2.clone()
+    e3[0, 1] = e3[1, 0] = e3[2, 3] = e3[3, 2] = MINF
+    a3 = loss.calculate_batch_retrieval_loss(scores, candidate_ids=CAND_IDS, query_ids=QUERY_IDS)
+    assert torch.isclose(F.cross_entropy(e3, LABELS, reduction="sum"), a3, atol=1e-3)
+    assert a3 < a2 < a1 + 1e-6  # masking other positives / accidental hits can only lower the loss
+    with pytest.raises(ValueError):
+        loss.calculate_batch_retrieval_loss(scores)  # accidental-hit removal needs candidate ids
+    with pytest.raises(ValueError):
+        RetrievalLoss(temperature=1e-13)
+    t = RetrievalLoss(temperature=0.07).calculate_batch_retrieval_loss(scores)
+    assert torch.isclose(t, F.cross_entropy(scores / 0.07, LABELS, reduction="sum"))
+
+
+def test_decoder_construction_errors():
+    with pytest.raises(AttributeError):
+        LinkPredictionDecoder(decoder_type="outer_product", decoder_channel_list=None)
+    with pytest.raises(ValueError):
+        LinkPredictionDecoder(decoder_type=DecoderType.hadamard_MLP, decoder_channel_list=None)
+    with pytest.raises(ValueError):
+        LinkPredictionDecoder(decoder_type=DecoderType.hadamard_MLP, decoder_channel_list=[1])
+    with pytest.raises(ValueError):
+        LinkPredictionDecoder(decoder_type=DecoderType.hadamard_MLP, decoder_channel_list=[2, 2])
+    dec = LinkPredictionDecoder(decoder_type=DecoderType.inner_product, decoder_channel_list=[4, 2, 1])
+    with pytest.raises(RuntimeError):  # no CPU fallback for the GEMM
+        dec(Q, CAND)
+
+
+@pytest.mark.gpu
+def test_inner_product_decoder_known_answer_and_grads():
+    from gigl_amd.engine import HipEngine
+    eng = HipEngine(0)
+    dev = eng.device
+    q = F.normalize(torch.tensor([[1.0, 1.0, 0.0, 0.0], [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.9, 1.1], [0.0, 0.0, 0.9, 1.1],
+                                  [0.0, 0.0, 0.1, 1.1]]), p=2, dim=1)
+    c = torch.tensor([[0.9806, 0.1961, 0.0, 0.0], [0.2822, 0.9407, 0.1881, 0.0], [0.0, 0.0, 0.9285, 0.3714],
+                      [0.0, 0.0, 0.4061, 0.9138], [0.4661, 0.4883, 0.5105, 0.5327], [0.5327, 0.5105, 0.4883, 0.4661]])
+    want = torch.tensor([[0.8321, 0.8647, 0.0, 0.0, 0.6749, 0.7377], [0.9806, 0.2822, 0.0, 0.0, 0.4661, 0.5327],
+                         [0.0, 0.1191, 0.8754, 0.9644, 0.7356, 0.6700], [0.0, 0.1191, 0.8754, 0.9644, 0.7356, 0.6700],
+                         [0.0, 0.0170, 0.4539, 0.9468, 0.5767, 0.5084]])
+    dec = LinkPredictionDecoder(decoder_type=DecoderType.inner_product, decoder_channel_list=[4, 2, 1])
+    dec.engine = eng
+    got = dec(q.to(dev), c.to(dev))
+    assert got.shape.numel() == 5 * 6
+    assert torch.allclose(got.cpu(), want, atol=1e-4)  # decoder_test.py:44-62
+    # gradients == torch.mm autograd
+    g = torch.Generator().manual_seed(0)
+    qq, cc = torch.randn(37, 24, generator=g), torch.randn(53, 24, generator=g)
+    q1, c1 = qq.clone().requires_grad_(True), cc.clone().requires_grad_(True)
+    q2, c2 = qq.to(dev).requires_grad_(True), cc.to(dev).requires_grad_(True)
+    wgt = torch.randn(37, 53, generator=g)
+    (torch.mm(q1, c1.T) * wgt).sum().backward()
+    (dec(q2, c2) * wgt.to(dev)).sum().backward()
+    np.testing.assert_allclose(q2.grad.cpu().numpy(), q1.grad.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c2.grad.cpu().numpy(), c1.grad.numpy(), rtol=1e-5, atol=1e-5)
+    # end to end: decoder + retrieval loss on the device
+    loss = RetrievalLoss(temperature=0.07, remove_accidental_hits=True)
+    s = dec(Q.to(dev), CAND.to(dev))
+    got_l = loss.calculate_batch_retrieval_loss(s, query_ids=QUERY_IDS.to(dev), candidate_ids=CAND_IDS.to(dev), device=dev)
+    ref_l = loss.calculate_batch_retrieval_loss(torch.mm(Q, CAND.T), query_ids=QUERY_IDS, candidate_ids=CAND_IDS)
+    assert abs(float(got_l) - float(ref_l)) < 1e-4
+    eng.close()
