@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--streams", type=int, default=8)
     ap.add_argument("--small", action="store_true", help="200k-node graph (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--mode", type=str, default="parity", choices=["parity", "fast"])
     args = ap.parse_args()
 
@@ -139,6 +140,8 @@ def main():
         engines[s].bind_stream(st)
         streams.append(st)
         plans.append(model.make_plan(engines[s], B, fanouts))
+        if not args.no_graph:
+            plans[s].use_graph(True)  # the batch's ~28 launches replayed as one hipGraph launch
         outs.append(torch.empty((B, out_dim), dtype=torch.float32, device=dev))
 
     def run_range(lo, hi):
@@ -159,6 +162,9 @@ def main():
     for e in engines:
         e.profile_enable(names, capacity=64 * 16)
     run_range(0, min(W, 2 * S))
+    run_range(0, min(W, 2 * S))  # (graph mode: the first call after a mask change re-captures)
+    for p in plans:
+        p.flush_profile()
     prof = {k: [sum(x) for x in zip(*[e.profile_read(k) for e in engines])] for k in names}
     dominant = max(prof, key=lambda k: prof[k][0])
     for e in engines:
@@ -177,6 +183,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t1
+    for p in plans:
+        p.flush_profile()
     dom_ms, dom_launches = [sum(x) for x in zip(*[e.profile_read(dominant) for e in engines])]
     for e in engines:
         e.profile_enable([], 0)

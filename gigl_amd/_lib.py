@@ -30,7 +30,7 @@ SYMBOLS = [
     "gigl_profile_enable", "gigl_profile_read", "gigl_profile_reset",
     "gigl_sage_plan_create", "gigl_sage_plan_set_weights", "gigl_sage_plan_buffers", "gigl_sage_plan_run",
     "gigl_sage_plan_destroy", "gigl_gather_mean_backward", "gigl_expand_frontier", "gigl_gcn_aggregate",
-    "gigl_gat_aggregate", "gigl_gather_rows",
+    "gigl_gat_aggregate", "gigl_gather_rows", "gigl_sage_plan_use_graph", "gigl_sage_plan_flush_profile",
 ]
 
 KERNEL_IDS = {
@@ -119,6 +119,8 @@ def load() -> C.CDLL:
         "gigl_sage_plan_buffers": [vp, P(GiglTree), P(GiglUnion)],
         "gigl_sage_plan_run": [vp, vp, i32, i32, vp],
         "gigl_sage_plan_destroy": [vp],
+        "gigl_sage_plan_use_graph": [vp, i32],
+        "gigl_sage_plan_flush_profile": [vp],
         "gigl_gather_mean_backward": [vp, vp, i32, vp, vp, vp, vp, i64, vp],
         "gigl_expand_frontier": [vp, vp, vp, vp, i64, i32, i32, i32, i64, vp, vp],
         "gigl_gather_rows": [vp, vp, i32, i32, vp, vp, i64, vp],

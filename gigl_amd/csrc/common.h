@@ -29,6 +29,9 @@ struct gigl_ctx {
   std::vector<hipEvent_t> prof_ev;   // 2 per recorded launch
   std::vector<int32_t> prof_id;      // kernel id per recorded launch
   size_t prof_used = 0;              // launches recorded so far
+  bool capturing = false;            // stream capture in progress: events become EXTERNAL event-record nodes
+  double prof_acc_ms[16] = {0};      // + durations harvested from hipGraph replays (pipeline.hip)
+  int64_t prof_acc_n[16] = {0};
   // sampler: range-top-K table over the xxhash sequence (sample.hip), built lazily
   void* sampler_table = nullptr;
 };

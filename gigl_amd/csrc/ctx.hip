@@ -40,6 +40,7 @@ gigl_prof_scope::gigl_prof_scope(gigl_ctx* c, int id) : ctx(c), on(false), slot(
   if (!(c->prof_mask & (1u << id)) || c->prof_used * 2 + 2 > c->prof_ev.size()) return;
   slot = c->prof_used++;
   c->prof_id[slot] = id;
+  // inside a stream capture this becomes an event-record node of the graph (re-recorded by every replay)
   on = hipEventRecord(c->prof_ev[2 * slot], c->stream) == hipSuccess;
 }
 
@@ -58,6 +59,10 @@ int32_t gigl_profile_enable(gigl_ctx* ctx, uint32_t mask, int32_t capacity) {
   GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->prof_mask = mask;
   ctx->prof_used = 0;
+  for (int i = 0; i < 16; ++i) {
+    ctx->prof_acc_ms[i] = 0.0;
+    ctx->prof_acc_n[i] = 0;
+  }
   while (ctx->prof_ev.size() < (size_t)capacity * 2) {
     hipEvent_t e;
     GIGL_HIP_CHECK(ctx, hipEventCreate(&e));
@@ -71,6 +76,10 @@ int32_t gigl_profile_reset(gigl_ctx* ctx) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->prof_used = 0;
+  for (int i = 0; i < 16; ++i) {
+    ctx->prof_acc_ms[i] = 0.0;
+    ctx->prof_acc_n[i] = 0;
+  }
   return GIGL_OK;
 }
 
@@ -78,8 +87,8 @@ int32_t gigl_profile_read(gigl_ctx* ctx, int32_t kernel_id, double* total_ms, in
   if (!ctx) return GIGL_E_INVALID_ARG;
   GIGL_REQUIRE(ctx, kernel_id >= 0 && kernel_id < GIGL_K_COUNT, "bad kernel id");
   GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-  double tot = 0.0;
-  int64_t n = 0;
+  double tot = ctx->prof_acc_ms[kernel_id];
+  int64_t n = ctx->prof_acc_n[kernel_id];
   for (size_t s = 0; s < ctx->prof_used; ++s) {
     if (ctx->prof_id[s] != kernel_id) continue;
     float ms = 0.f;

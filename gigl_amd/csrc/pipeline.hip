@@ -1,6 +1,7 @@
 // pipeline.hip — one-call batch pipeline: k-hop sample -> batch union graph -> GraphSAGE forward ->
 // per-root rows.  Everything a batch needs is enqueued by ONE host call on the ctx stream (the host
-// side of the hop loop / layer loop lives here, in C++, like the reference's compiled sampler).
+// side of the hop loop / layer loop lives here, in C++, like the reference's compiled sampler), and
+// optionally replayed from hipGraphs so that the ~28 launches of a batch cost one or two host calls.
 //
 // Replaces, for a RootedNodeNeighborhood batch (paths relative to the reference root):
 //   NodeAnchorBasedLinkPredictionModelingTaskSpec.infer_batch
@@ -12,6 +13,18 @@
 
 #include <new>
 #include <vector>
+
+namespace {
+
+// a maximal run of consecutive stages: either replayed from a captured graph or launched eagerly
+// (stages that contain launches selected for HIP-event timing stay eager: events recorded inside a
+// captured graph cannot be timed on this runtime)
+struct Segment {
+  int s0 = 0, s1 = 0;  // stages [s0, s1)
+  hipGraphExec_t exec = nullptr;
+};
+
+}  // namespace
 
 struct gigl_sage_plan {
   gigl_ctx* ctx = nullptr;
@@ -28,6 +41,14 @@ struct gigl_sage_plan {
   float* abuf = nullptr;  // [cap_nodes][2*max_in]
   float* hbuf[2] = {nullptr, nullptr};  // ping-pong [cap_nodes][max_out]
   std::vector<void*> owned;
+  // hipGraph replay
+  bool use_graph = false;
+  uint32_t* roots_buf = nullptr;  // static input of the captured graphs
+  float* out_buf = nullptr;       // static output of the captured graphs
+  std::vector<Segment> segs;
+  int32_t cap_seed = 0, cap_mode = -1;
+  uint32_t cap_prof_mask = 0;
+  bool captured = false;
 };
 
 namespace {
@@ -41,6 +62,101 @@ __global__ void take_rows_kernel(const float* __restrict__ h, const int32_t* __r
   out[i] = l >= 0 ? h[(int64_t)l * d + c] : 0.f;
 }
 
+// stages of one batch: 0 sample, 1 union, 2+2l gather l, 3+2l linear l, 2+2L take_rows
+int n_stages(const gigl_sage_plan* p) { return 3 + 2 * p->hops; }
+
+uint32_t stage_kernel_mask(const gigl_sage_plan* p, int s) {
+  if (s == 0) return (1u << GIGL_K_EXPAND) | (1u << GIGL_K_EXPAND_HEAVY) | (1u << GIGL_K_FIND_HEAVY);
+  if (s == 1)
+    return (1u << GIGL_K_UNION_INSERT) | (1u << GIGL_K_UNION_RELAX) | (1u << GIGL_K_UNION_NODES) |
+           (1u << GIGL_K_UNION_EDGE_SORT) | (1u << GIGL_K_UNION_CSR);
+  if (s == n_stages(p) - 1) return 0;
+  return ((s - 2) & 1) ? (1u << GIGL_K_LINEAR) : (1u << GIGL_K_GATHER_MEAN);
+}
+
+int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t sampling_seed, int32_t mode,
+                      float* out) {
+  gigl_ctx* ctx = p->ctx;
+  const int L = p->hops;
+  if (s == 0)
+    return gigl_sample_khop(ctx, p->graph, roots, p->b, p->fanouts, p->hops, sampling_seed, mode, &p->tree);
+  if (s == 1) return gigl_union_build(ctx, roots, &p->tree, &p->un);
+  if (s == n_stages(p) - 1) {
+    const int dout = p->dims[L];
+    const int64_t total = (int64_t)p->b * dout;
+    hipLaunchKernelGGL(take_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       p->hbuf[(L - 1) & 1], p->un.root_local, p->b, dout, out);
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    return GIGL_OK;
+  }
+  const int l = (s - 2) >> 1;
+  const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
+  const int d = p->dims[l];
+  if (((s - 2) & 1) == 0) {
+    if (l == 0)
+      return gigl_gather_mean(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend,
+                              p->un.col, n_rows, p->un.cap_nodes, p->abuf);
+    return gigl_gather_mean(ctx, p->hbuf[(l - 1) & 1], GIGL_DTYPE_F32, d, nullptr, p->un.rowptr, p->un.rowend,
+                            p->un.col, n_rows, p->un.cap_nodes, p->abuf);
+  }
+  const int act = (l < L - 1 || p->act_last) ? 1 : 0;
+  return gigl_linear(ctx, p->abuf, p->w[l], p->bias[l], n_rows, p->un.cap_nodes, 2 * d, p->dims[l + 1], act,
+                     p->hbuf[l & 1]);
+}
+
+int32_t enqueue_range(gigl_sage_plan* p, int s0, int s1, const uint32_t* roots, int32_t sampling_seed, int32_t mode,
+                      float* out) {
+  for (int s = s0; s < s1; ++s) {
+    int32_t rc = enqueue_stage(p, s, roots, sampling_seed, mode, out);
+    if (rc != GIGL_OK) return rc;
+  }
+  return GIGL_OK;
+}
+
+void drop_graphs(gigl_sage_plan* p) {
+  for (Segment& sg : p->segs)
+    if (sg.exec) hipGraphExecDestroy(sg.exec);
+  p->segs.clear();
+  p->captured = false;
+}
+
+// split the stages into timed (eager) and untimed (captured) segments and capture the latter
+int32_t capture_segments(gigl_sage_plan* p, int32_t sampling_seed, int32_t mode) {
+  gigl_ctx* ctx = p->ctx;
+  const int n = n_stages(p);
+  const uint32_t mask = ctx->prof_mask;
+  int s = 0;
+  while (s < n) {
+    Segment sg;
+    sg.s0 = s;
+    const bool timed = (stage_kernel_mask(p, s) & mask) != 0;
+    int e = s + 1;
+    while (e < n && ((stage_kernel_mask(p, e) & mask) != 0) == timed) ++e;
+    sg.s1 = e;
+    if (!timed) {
+      hipGraph_t graph = nullptr;
+      hipError_t err = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+      int32_t rc = GIGL_OK;
+      if (err == hipSuccess) {
+        rc = enqueue_range(p, sg.s0, sg.s1, p->roots_buf, sampling_seed, mode, p->out_buf);
+        hipError_t e2 = hipStreamEndCapture(ctx->stream, &graph);
+        if (rc == GIGL_OK && e2 != hipSuccess) err = e2;
+      }
+      if (rc == GIGL_OK && err == hipSuccess) err = hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0);
+      if (graph) hipGraphDestroy(graph);
+      if (rc != GIGL_OK) return rc;
+      if (err != hipSuccess) {
+        sg.exec = nullptr;
+        return gigl_fail(ctx, GIGL_E_HIP, "capturing stages [%d,%d) of the batch pipeline failed: %s", sg.s0, sg.s1,
+                         hipGetErrorString(err));
+      }
+    }
+    p->segs.push_back(sg);
+    s = e;
+  }
+  return GIGL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -51,6 +167,7 @@ int32_t gigl_sage_plan_destroy(gigl_sage_plan* p) {
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
   }
+  drop_graphs(p);
   for (void* q : p->owned) hipFree(q);
   delete p;
   return GIGL_OK;
@@ -123,8 +240,10 @@ int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat,
   p->abuf = (float*)alloc((size_t)cap_nodes * 2 * max_in * 4);
   p->hbuf[0] = (float*)alloc((size_t)cap_nodes * max_out * 4);
   p->hbuf[1] = hops > 1 ? (float*)alloc((size_t)cap_nodes * max_out * 4) : p->hbuf[0];
+  p->roots_buf = (uint32_t*)alloc((size_t)b * 4);
+  p->out_buf = (float*)alloc((size_t)b * dims[hops] * 4);
   ok = ok && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col && p->un.root_local &&
-       p->abuf && p->hbuf[0] && p->hbuf[1];
+       p->abuf && p->hbuf[0] && p->hbuf[1] && p->roots_buf && p->out_buf;
   if (!ok) {
     gigl_sage_plan_destroy(p);
     return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the batch workspace failed (cap_nodes=%lld)",
@@ -141,6 +260,10 @@ int32_t gigl_sage_plan_set_weights(gigl_sage_plan* p, const float* const* w, con
     p->w[k] = w[k];
     p->bias[k] = bias ? bias[k] : nullptr;
   }
+  if (p->captured) {  // weight pointers are baked into the captured kernels
+    hipStreamSynchronize(p->ctx->stream);
+    drop_graphs(p);
+  }
   return GIGL_OK;
 }
 
@@ -151,38 +274,67 @@ int32_t gigl_sage_plan_buffers(gigl_sage_plan* p, gigl_tree* tree, gigl_union* u
   return GIGL_OK;
 }
 
+int32_t gigl_sage_plan_use_graph(gigl_sage_plan* p, int32_t on) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  if (on && ctx->stream == nullptr)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED,
+                     "hipGraph replay needs a non-default stream (the legacy default stream cannot be captured): "
+                     "bind the ctx to a created stream first (gigl_ctx_set_stream)");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  drop_graphs(p);
+  p->use_graph = on != 0;
+  return GIGL_OK;
+}
+
+int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* p) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  GIGL_HIP_CHECK(p->ctx, hipStreamSynchronize(p->ctx->stream));
+  return GIGL_OK;
+}
+
 int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sampling_seed, int32_t mode,
                            float* out) {
   if (!p) return GIGL_E_INVALID_ARG;
   gigl_ctx* ctx = p->ctx;
   GIGL_REQUIRE(ctx, roots && out, "null argument");
-  int32_t rc = gigl_sample_khop(ctx, p->graph, roots, p->b, p->fanouts, p->hops, sampling_seed, mode, &p->tree);
-  if (rc != GIGL_OK) return rc;
-  rc = gigl_union_build(ctx, roots, &p->tree, &p->un);
-  if (rc != GIGL_OK) return rc;
-  const int L = p->hops;
-  const float* h = nullptr;
-  for (int l = 0; l < L; ++l) {
-    const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
-    const int d = p->dims[l];
-    if (l == 0)
-      rc = gigl_gather_mean(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend,
-                            p->un.col, n_rows, p->un.cap_nodes, p->abuf);
-    else
-      rc = gigl_gather_mean(ctx, h, GIGL_DTYPE_F32, d, nullptr, p->un.rowptr, p->un.rowend, p->un.col, n_rows,
-                            p->un.cap_nodes, p->abuf);
+  if (!p->use_graph) return enqueue_range(p, 0, n_stages(p), roots, sampling_seed, mode, out);
+
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!p->captured || p->cap_mode != mode || p->cap_seed != sampling_seed || p->cap_prof_mask != ctx->prof_mask) {
+    GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    drop_graphs(p);
+    // one eager run first: sizes the arena, builds the hash range table, sets kernel attributes — none of
+    // which may happen inside a capture.  (This batch is produced by that run.)
+    const uint32_t keep_mask = ctx->prof_mask;
+    ctx->prof_mask = 0;
+    int32_t rc = enqueue_range(p, 0, n_stages(p), roots, sampling_seed, mode, out);
+    ctx->prof_mask = keep_mask;
     if (rc != GIGL_OK) return rc;
-    float* y = p->hbuf[l & 1];
-    const int act = (l < L - 1 || p->act_last) ? 1 : 0;
-    rc = gigl_linear(ctx, p->abuf, p->w[l], p->bias[l], n_rows, p->un.cap_nodes, 2 * d, p->dims[l + 1], act, y);
-    if (rc != GIGL_OK) return rc;
-    h = y;
+    GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    rc = capture_segments(p, sampling_seed, mode);
+    if (rc != GIGL_OK) {
+      drop_graphs(p);
+      return rc;
+    }
+    p->captured = true;
+    p->cap_mode = mode;
+    p->cap_seed = sampling_seed;
+    p->cap_prof_mask = ctx->prof_mask;
+    return GIGL_OK;
   }
-  const int dout = p->dims[L];
-  const int64_t total = (int64_t)p->b * dout;
-  hipLaunchKernelGGL(take_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, h,
-                     p->un.root_local, p->b, dout, out);
-  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(p->roots_buf, roots, (size_t)p->b * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  for (const Segment& sg : p->segs) {
+    if (sg.exec) {
+      GIGL_HIP_CHECK(ctx, hipGraphLaunch(sg.exec, ctx->stream));
+    } else {
+      int32_t rc = enqueue_range(p, sg.s0, sg.s1, p->roots_buf, sampling_seed, mode, p->out_buf);
+      if (rc != GIGL_OK) return rc;
+    }
+  }
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(out, p->out_buf, (size_t)p->b * p->dims[p->hops] * 4,
+                                     hipMemcpyDeviceToDevice, ctx->stream));
   return GIGL_OK;
 }
 

@@ -19,6 +19,9 @@
 // of the sampled set.
 #include "common.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace {
 
 constexpr uint64_t P1 = 0x9E3779B185EBCA87ULL;
@@ -140,6 +143,7 @@ struct ExpandArgs {
   const uint32_t* ex_nodes;
   const uint32_t* ex_ksum;
   uint32_t row_div;
+  int32_t proxy_drop;  // test knob (env GIGL_SAMPLER_PROXY_BITS): 32 - bits kept by the fast path's proxy keys
 };
 
 // CSC row of the parent in slot p and K (wrapping int32 sum of the path ids) — wave-uniform
@@ -202,24 +206,203 @@ struct RangeTable {
   int64_t nblocks[TBL_MAX_LEVELS];
 };
 
-// merge the lists owned by the lanes (my_ent = first entry index of the lane's list, or -1) by rounds
-__device__ __forceinline__ void merge_lists(const RangeTable& tb, int64_t my_ent, uint32_t base, uint64_t& key,
-                                            uint32_t& idx, uint64_t& tk, uint32_t& ti, int f, int lane) {
-  bool active = my_ent >= 0;
-  int cur = 0;
-  while (__ballot(active)) {
-    uint64_t ck = ~0ULL;
-    uint32_t ci = 0xFFFFFFFFu;
-    if (active) {
-      ck = tb.keys[my_ent + cur];
-      ci = tb.js[my_ent + cur] - base;  // position i = j - base
-    }
-    merge_candidates(key, idx, ck, ci, active, tk, ti, f, lane);
-    ++cur;
-    // my list can still contribute only if this offer made it into the best f (offer <= threshold)
-    active = active && cur < TBL_TOPK && !less96(tk, ti, ck, ci);
+// ------------------------------------------------------------------------------------------
+// Per-row selection, in two precisions.
+//   FAST  keys are the top 32 bits of the ordered hash ("proxy").  Orders exactly like the 64-bit key
+//         whenever two proxies differ; any proxy EQUALITY that could matter (candidate vs. threshold,
+//         candidate vs. a list element) raises `tie` and the row is redone by the exact path.  An insert
+//         costs about half the instructions of the exact one (1 compare instead of 5, 3 DPP moves
+//         instead of 4, 2 broadcasts instead of 3).
+//   exact 64-bit key + position tie-break: SamplingStrategy.scala:63 verbatim.
+// ------------------------------------------------------------------------------------------
+template <bool FAST>
+struct Sel {
+  using key_t = typename std::conditional<FAST, uint32_t, uint64_t>::type;
+  key_t key, tk;      // per-lane best key (ascending over lanes), threshold = f-th key
+  uint32_t idx, ti;   // per-lane best position, threshold position
+  bool tie;           // FAST only: a proxy equality was seen -> result not trustworthy
+  int f, lane;
+
+  static __device__ __forceinline__ key_t inf() { return (key_t)~(key_t)0; }
+  int drop;           // FAST only: low proxy bits discarded (0 in production; tests raise it to force ties)
+  __device__ __forceinline__ key_t mk(uint64_t ordered) const {
+    if constexpr (FAST) return ((uint32_t)(ordered >> 32) >> drop) << drop;
+    else return ordered;
   }
-}
+  __device__ __forceinline__ void init(int f_, int lane_, int drop_ = 0) {
+    drop = drop_;
+    key = tk = inf();
+    idx = ti = 0xFFFFFFFFu;
+    tie = false;
+    f = f_;
+    lane = lane_;
+  }
+  __device__ __forceinline__ bool lt(key_t k1, uint32_t i1, key_t k2, uint32_t i2) const {
+    if constexpr (FAST) return k1 < k2;
+    else return less96(k1, i1, k2, i2);
+  }
+  __device__ __forceinline__ key_t bcast(key_t x, int l) const {
+    if constexpr (FAST) return readlane32(x, l);
+    else return readlane64(x, l);
+  }
+  __device__ __forceinline__ void refresh_threshold() {
+    tk = bcast(key, f - 1);
+    ti = readlane32(idx, f - 1);
+  }
+  // insert the wave-uniform candidate; the last lane's element falls off
+  __device__ __forceinline__ void insert(key_t ck, uint32_t ci) {
+    const bool gt = lt(ck, ci, key, idx);  // my element is greater than the candidate
+    if constexpr (FAST) {
+      if (__ballot(key == ck && idx != 0xFFFFFFFFu)) tie = true;
+      const uint32_t uk = dpp_shr1(key), ui = dpp_shr1(idx), gtu = dpp_shr1(gt ? 1u : 0u);
+      if (gtu) {
+        key = uk;
+        idx = ui;
+      } else if (gt) {
+        key = ck;
+        idx = ci;
+      }
+    } else {
+      const uint32_t ulo = dpp_shr1((uint32_t)key), uhi = dpp_shr1((uint32_t)(key >> 32));
+      const uint32_t ui = dpp_shr1(idx), gtu = dpp_shr1(gt ? 1u : 0u);
+      if (gtu) {
+        key = ((uint64_t)uhi << 32) | ulo;
+        idx = ui;
+      } else if (gt) {
+        key = ck;
+        idx = ci;
+      }
+    }
+  }
+  // merge one candidate per lane
+  __device__ __forceinline__ void merge(key_t ck, uint32_t ci, bool valid) {
+    if constexpr (FAST) {
+      if (__ballot(valid && ck == tk && tk != inf())) tie = true;
+    }
+    unsigned long long m = __ballot(valid && lt(ck, ci, tk, ti));
+    while (m) {
+      const int src = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const key_t sk = bcast(ck, src);
+      const uint32_t si = readlane32(ci, src);
+      if constexpr (FAST) {
+        if (sk == tk) tie = true;
+      }
+      if (lt(sk, si, tk, ti)) {  // threshold may have tightened since the ballot
+        insert(sk, si);
+        refresh_threshold();
+      }
+    }
+  }
+  // direct hashing of positions [i_lo, i_hi] (1-based, inclusive); 4 chunks hashed ahead of their merges
+  __device__ __forceinline__ void scan_direct(int64_t i_lo, int64_t i_hi, uint32_t base) {
+    const int64_t nchunks = (i_hi - i_lo + 1 + 63) >> 6;
+    int64_t c = 0;
+    for (; c + 3 < nchunks; c += 4) {
+      const int64_t ia = i_lo + c * 64 + lane, ib = ia + 64, ic = ib + 64, id = ic + 64;
+      const key_t ka = mk(xxh64_i32_ordered((uint32_t)ia + base)), kb = mk(xxh64_i32_ordered((uint32_t)ib + base)),
+                  kc = mk(xxh64_i32_ordered((uint32_t)ic + base)), kd = mk(xxh64_i32_ordered((uint32_t)id + base));
+      merge(ka, (uint32_t)ia, ia <= i_hi);
+      merge(kb, (uint32_t)ib, ib <= i_hi);
+      merge(kc, (uint32_t)ic, ic <= i_hi);
+      merge(kd, (uint32_t)id, id <= i_hi);
+    }
+    for (; c < nchunks; ++c) {
+      const int64_t i = i_lo + c * 64 + lane;
+      merge(mk(xxh64_i32_ordered((uint32_t)i + base)), (uint32_t)i, i <= i_hi);
+    }
+  }
+  __device__ __forceinline__ key_t table_key(const RangeTable& tb, int64_t e) const {
+    if constexpr (FAST)  // high word (little endian)
+      return (reinterpret_cast<const uint32_t*>(tb.keys)[2 * e + 1] >> drop) << drop;
+    else return tb.keys[e];
+  }
+  // merge the lists owned by the lanes (my_ent = first entry of the lane's list, or -1) by rounds
+  __device__ __forceinline__ void merge_lists(const RangeTable& tb, int64_t my_ent, uint32_t base) {
+    bool active = my_ent >= 0;
+    int cur = 0;
+    while (__ballot(active)) {
+      key_t ck = inf();
+      uint32_t ci = 0xFFFFFFFFu;
+      if (active) {
+        ck = table_key(tb, my_ent + cur);
+        ci = tb.js[my_ent + cur] - base;  // position i = j - base
+      }
+      merge(ck, ci, active);
+      ++cur;
+      // my list can still contribute only if this offer made it into the best f (offer <= threshold)
+      active = active && cur < TBL_TOPK && !lt(tk, ti, ck, ci);
+    }
+  }
+  // the whole row: window of positions [1, deg] with hash offset `base`
+  __device__ __forceinline__ void select(const RangeTable& tb, int64_t deg, uint32_t base, bool in_table) {
+    const uint64_t j_lo = (uint64_t)base + 1, j_hi = (uint64_t)base + (uint64_t)deg;  // inclusive window
+    // aligned level-0 blocks fully inside the window come from the table
+    const uint64_t b_first = (j_lo + ((1u << TBL_S0_SHIFT) - 1)) >> TBL_S0_SHIFT;
+    const uint64_t b_last = (j_hi + 1) >> TBL_S0_SHIFT;  // one past the last full block
+    if (!in_table || b_first >= b_last) {
+      scan_direct(1, deg, base);
+      return;
+    }
+    // pass A of the greedy aligned decomposition of [b_first, b_last): find the largest block.  Its sorted
+    // top-64 list becomes the initial best list, so the threshold is tight before anything is inserted.
+    int best_l = -1;
+    uint64_t best_b = 0;
+    for (uint64_t b = b_first; b < b_last;) {
+      int l = 0;
+      while (l + 1 < tb.levels) {
+        const int sh = TBL_FAN_SHIFT * (l + 1);
+        if ((b & ((1ull << sh) - 1)) != 0 || b + (1ull << sh) > b_last || (int64_t)(b >> sh) >= tb.nblocks[l + 1])
+          break;
+        ++l;
+      }
+      if (l > best_l) {
+        best_l = l;
+        best_b = b;
+      }
+      b += 1ull << (TBL_FAN_SHIFT * l);
+    }
+    {
+      const int64_t ent = (tb.lvl_off[best_l] + (int64_t)(best_b >> (TBL_FAN_SHIFT * best_l))) * TBL_TOPK;
+      key = table_key(tb, ent + lane);
+      idx = tb.js[ent + lane] - base;  // position i = j - base
+      if constexpr (FAST) {  // equal proxies inside the seed list (adjacent: it is sorted by the full key)
+        const uint32_t up = dpp_shr1(key);
+        if (__ballot(lane > 0 && lane <= f && up == key)) tie = true;
+      }
+      refresh_threshold();
+    }
+    // pass B: the other lists, 64 per batch, list q of a batch owned by lane q, merged by rounds
+    uint64_t b = b_first;
+    int q = 0;
+    int64_t my_ent = -1;
+    while (b < b_last) {
+      int l = 0;
+      while (l + 1 < tb.levels) {
+        const int sh = TBL_FAN_SHIFT * (l + 1);
+        if ((b & ((1ull << sh) - 1)) != 0 || b + (1ull << sh) > b_last || (int64_t)(b >> sh) >= tb.nblocks[l + 1])
+          break;
+        ++l;
+      }
+      if (b != best_b) {
+        const int64_t ent = (tb.lvl_off[l] + (int64_t)(b >> (TBL_FAN_SHIFT * l))) * TBL_TOPK;
+        if (lane == q) my_ent = ent;
+        ++q;
+      }
+      b += 1ull << (TBL_FAN_SHIFT * l);
+      if (q == 64 || (b >= b_last && q > 0)) {
+        merge_lists(tb, my_ent, base);
+        q = 0;
+        my_ent = -1;
+      }
+    }
+    // head: positions before the first block boundary; tail: after the last full block
+    const int64_t head_hi = (int64_t)((b_first << TBL_S0_SHIFT) - 1 - base);  // position of the last head j
+    if (head_hi >= 1) scan_direct(1, head_hi, base);
+    const int64_t tail_lo = (int64_t)((b_last << TBL_S0_SHIFT) - base);
+    if (tail_lo <= deg) scan_direct(tail_lo, deg, base);
+  }
+};
 
 __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a, RangeTable tb) {
   const int lane = threadIdx.x & 63;
@@ -244,79 +427,22 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a, RangeTable tb
       continue;
     }
     const uint32_t base = ksum + (uint32_t)a.hash_add;  // int32 wrap == uint32 wrap
-    const uint64_t j_lo = (uint64_t)base + 1, j_hi = (uint64_t)base + (uint64_t)deg;  // inclusive window
-    const bool in_table = j_hi < tb.dom;  // also excludes 2^32 wrap-around
+    const bool in_table = (uint64_t)base + (uint64_t)deg < tb.dom;  // also excludes 2^32 wrap-around
     if (!in_table && deg > HEAVY_DEG) continue;  // left to expand_heavy_kernel (workgroup per parent)
-    // best list: ascending (key, position) per lane, +inf padded; (tk, ti) = f-th element
-    uint64_t key = ~0ULL;
-    uint32_t idx = 0xFFFFFFFFu;
-    uint64_t tk = ~0ULL;
-    uint32_t ti = 0xFFFFFFFFu;
-    // aligned level-0 blocks fully inside the window come from the table
-    const uint64_t b_first = (j_lo + ((1u << TBL_S0_SHIFT) - 1)) >> TBL_S0_SHIFT;
-    const uint64_t b_last = (j_hi + 1) >> TBL_S0_SHIFT;  // one past the last full block
-    if (!in_table || b_first >= b_last) {
-      scan_direct(key, idx, tk, ti, 1, deg, 0, 1, base, f, lane);
-    } else {
-      // pass A of the greedy aligned decomposition of [b_first, b_last): find the largest block.  Its
-      // sorted top-64 list becomes the initial best list, so the threshold is tight before anything
-      // is inserted (the block usually covers most of the window).
-      int best_l = -1;
-      uint64_t best_b = 0;
-      for (uint64_t b = b_first; b < b_last;) {
-        int l = 0;
-        while (l + 1 < tb.levels) {
-          const int sh = TBL_FAN_SHIFT * (l + 1);
-          if ((b & ((1ull << sh) - 1)) != 0 || b + (1ull << sh) > b_last ||
-              (int64_t)(b >> sh) >= tb.nblocks[l + 1])
-            break;
-          ++l;
-        }
-        if (l > best_l) {
-          best_l = l;
-          best_b = b;
-        }
-        b += 1ull << (TBL_FAN_SHIFT * l);
+    uint32_t sel_idx;
+    {
+      Sel<true> fast;
+      fast.init(f, lane, a.proxy_drop);
+      fast.select(tb, deg, base, in_table);
+      sel_idx = fast.idx;
+      if (fast.tie) {  // a 32-bit proxy tie touched the result (about once per 10^7 rows): redo exactly
+        Sel<false> exact;
+        exact.init(f, lane);
+        exact.select(tb, deg, base, in_table);
+        sel_idx = exact.idx;
       }
-      {
-        const int64_t ent = (tb.lvl_off[best_l] + (int64_t)(best_b >> (TBL_FAN_SHIFT * best_l))) * TBL_TOPK;
-        key = tb.keys[ent + lane];
-        idx = tb.js[ent + lane] - base;  // position i = j - base
-        tk = readlane64(key, f - 1);
-        ti = readlane32(idx, f - 1);
-      }
-      // pass B: the other lists, 64 per batch, list q of a batch owned by lane q, merged by rounds
-      uint64_t b = b_first;
-      int q = 0;
-      int64_t my_ent = -1;
-      while (b < b_last) {
-        int l = 0;
-        while (l + 1 < tb.levels) {
-          const int sh = TBL_FAN_SHIFT * (l + 1);
-          if ((b & ((1ull << sh) - 1)) != 0 || b + (1ull << sh) > b_last ||
-              (int64_t)(b >> sh) >= tb.nblocks[l + 1])
-            break;
-          ++l;
-        }
-        if (b != best_b) {
-          const int64_t ent = (tb.lvl_off[l] + (int64_t)(b >> (TBL_FAN_SHIFT * l))) * TBL_TOPK;
-          if (lane == q) my_ent = ent;
-          ++q;
-        }
-        b += 1ull << (TBL_FAN_SHIFT * l);
-        if (q == 64 || (b >= b_last && q > 0)) {
-          merge_lists(tb, my_ent, base, key, idx, tk, ti, f, lane);
-          q = 0;
-          my_ent = -1;
-        }
-      }
-      // head: positions before the first block boundary; tail: after the last full block
-      const int64_t head_hi = (int64_t)((b_first << TBL_S0_SHIFT) - 1 - base);  // position of the last head j
-      if (head_hi >= 1) scan_direct(key, idx, tk, ti, 1, head_hi, 0, 1, base, f, lane);
-      const int64_t tail_lo = (int64_t)((b_last << TBL_S0_SHIFT) - base);
-      if (tail_lo <= deg) scan_direct(key, idx, tk, ti, tail_lo, deg, 0, 1, base, f, lane);
     }
-    emit_sorted(row, idx, f, lane, out);
+    emit_sorted(row, sel_idx, f, lane, out);
     if (lane == 0) a.out_cnt[p] = f;
   }
 }
@@ -474,8 +600,14 @@ int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
 }
 
 // one hop of parity-mode expansion.  `covered` = the host proved every window lies inside the table.
-int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a, const RangeTable& tb, bool covered,
+int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a_in, const RangeTable& tb, bool covered,
                    int64_t* heavy_list, int32_t* heavy_count) {
+  ExpandArgs a = a_in;
+  a.proxy_drop = 0;
+  if (const char* e = getenv("GIGL_SAMPLER_PROXY_BITS")) {  // test knob: fewer proxy bits -> forced ties
+    int bits = atoi(e);
+    if (bits >= 1 && bits <= 32) a.proxy_drop = 32 - bits;
+  }
   int64_t blocks = (a.n_parents + 3) / 4;
   if (blocks > 256 * 32) blocks = 256 * 32;
   if (!covered) {

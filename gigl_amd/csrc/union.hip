@@ -103,6 +103,19 @@ __device__ __forceinline__ int32_t table_find(const UnionArgs& a, uint32_t id) {
   }
 }
 
+// all per-batch table initialisation in one dispatch: 0xFF.. words, +inf levels, zeros, meta
+__global__ __launch_bounds__(256) void init_scratch_kernel(uint4* ff, int64_t ff_vec, uint4* lvl, int64_t lvl_vec,
+                                                           int32_t* zeros, int64_t zero_words, int32_t* meta) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint4 f4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  const uint4 l4 = make_uint4(0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
+  for (int64_t i = t0; i < ff_vec; i += stride) ff[i] = f4;
+  for (int64_t i = t0; i < lvl_vec; i += stride) lvl[i] = l4;
+  for (int64_t i = t0; i < zero_words; i += stride) zeros[i] = 0;
+  if (t0 < GIGL_META_LEN) meta[t0] = 0;
+}
+
 __global__ void insert_roots_kernel(UnionArgs a) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.b) return;
@@ -496,8 +509,8 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
                (long long)cap_edges);
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  GIGL_HIP_CHECK(ctx, hipMemsetAsync(out->meta, 0, GIGL_META_LEN * sizeof(int32_t), st));
   if (b == 0) {
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(out->meta, 0, GIGL_META_LEN * sizeof(int32_t), st));
     GIGL_HIP_CHECK(ctx, hipMemsetAsync(out->rowptr, 0, sizeof(int32_t), st));
     GIGL_HIP_CHECK(ctx, hipMemsetAsync(out->rowend, 0, sizeof(int32_t), st));
     return GIGL_OK;
@@ -519,48 +532,52 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
   a.T = T;
   const int64_t E = T - b;              // edge occurrences
   const int64_t max_rows = a.off[hops - 1];  // nodes that are the parent of some slot
+  // open-addressing tables at load factor <= 2/3
   uint64_t cap = 1024;
-  while (cap < (uint64_t)T * 2) cap <<= 1;
+  while (cap * 2 < (uint64_t)T * 3) cap <<= 1;
   a.mask = (uint32_t)(cap - 1);
   const int32_t n_tiles = (int32_t)((T + TILE - 1) / TILE);
   uint64_t ecap = 1024;
-  while (ecap < (uint64_t)E * 2) ecap <<= 1;
+  while (ecap * 2 < (uint64_t)E * 3) ecap <<= 1;
 
-  // scratch: [keys | firstpos | level] are memset together; everything else is written before read
+  // scratch.  Everything that needs an initial pattern is laid out contiguously per pattern so ONE kernel
+  // initialises it: [ekeys | keys | firstpos] = 0xFF.., [level] = +inf, [rowcnt | big_count] = 0
   int64_t need = 0;
   auto add = [&](int64_t bytes) { need += gigl_align_up(bytes, 256); };
-  add((int64_t)cap * 4 * 3);         // keys, firstpos, level (contiguous)
+  const int64_t ff_words = (int64_t)ecap * 2 + (int64_t)cap * 2;  // 32-bit words
+  const int64_t zero_words = cap_nodes + 1 + 64;
+  add(ff_words * 4);
+  add((int64_t)cap * 4);             // level
+  add(zero_words * 4);               // rowcnt + big-row counter
   add((int64_t)cap * 4);             // lid
   add(T * 4);                        // slot_of
   add((int64_t)n_tiles * MAXL * 4);  // tile counts
-  add((cap_nodes + 1) * 4);          // rowcnt
-  add(cap_nodes * 4 + 256);          // big-row queue + counter
-  add((int64_t)ecap * 8);            // edge hash set
+  add(cap_nodes * 4);                // big-row queue
   add(E + 256);                      // winner flags
   int32_t rc = gigl_arena_reset(ctx, need + 4096);
   if (rc != GIGL_OK) return rc;
-  uint32_t* tbl = (uint32_t*)gigl_arena_alloc(ctx, (int64_t)cap * 4 * 3);
+  uint32_t* ff = (uint32_t*)gigl_arena_alloc(ctx, ff_words * 4);
+  a.level = (int32_t*)gigl_arena_alloc(ctx, (int64_t)cap * 4);
+  int32_t* zeros = (int32_t*)gigl_arena_alloc(ctx, zero_words * 4);
   a.lid = (int32_t*)gigl_arena_alloc(ctx, (int64_t)cap * 4);
   a.slot_of = (int32_t*)gigl_arena_alloc(ctx, T * 4);
   int32_t* tile_counts = (int32_t*)gigl_arena_alloc(ctx, (int64_t)n_tiles * MAXL * 4);
-  int32_t* rowcnt = (int32_t*)gigl_arena_alloc(ctx, (cap_nodes + 1) * 4);
-  int32_t* big = (int32_t*)gigl_arena_alloc(ctx, cap_nodes * 4 + 256);
-  unsigned long long* ekeys = (unsigned long long*)gigl_arena_alloc(ctx, (int64_t)ecap * 8);
+  int32_t* big_rows = (int32_t*)gigl_arena_alloc(ctx, cap_nodes * 4);
   uint8_t* winner = (uint8_t*)gigl_arena_alloc(ctx, E + 256);
-  if (!tbl || !big || !rowcnt || !ekeys || !winner) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
-  a.keys = tbl;
-  a.firstpos = tbl + cap;
-  a.level = (int32_t*)(tbl + 2 * cap);
-  int32_t* big_count = big;  // [0] = number of queued rows
-  int32_t* big_rows = big + 64;
+  if (!ff || !zeros || !big_rows || !winner || !a.slot_of) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  unsigned long long* ekeys = (unsigned long long*)ff;  // 8-byte aligned (arena blocks are 256-byte aligned)
+  a.keys = ff + ecap * 2;
+  a.firstpos = a.keys + cap;
+  int32_t* rowcnt = zeros;
+  int32_t* big_count = zeros + cap_nodes + 1;  // [0] = number of queued rows
 
   const int TB = 256;
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_INSERT);
-    // keys / firstpos = 0xFFFFFFFF, level = 0x7F7F7F7F (+inf)
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.keys, 0xFF, (size_t)cap * 4 * 2, st));
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(a.level, 0x7F, (size_t)cap * 4, st));
+    // one launch initialises every table of this batch (instead of six memset dispatches)
+    hipLaunchKernelGGL(init_scratch_kernel, dim3(1024), dim3(256), 0, st, (uint4*)ff, ff_words / 4,
+                       (uint4*)a.level, (int64_t)cap / 4, zeros, zero_words, out->meta);
     hipLaunchKernelGGL(insert_roots_kernel, grid(b), dim3(TB), 0, st, a);
     if (E > 0) hipLaunchKernelGGL(insert_slots_kernel, grid(E), dim3(TB), 0, st, a);
   }
@@ -577,9 +594,6 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_EDGE_SORT);
     // every node of level < hops may be a row (also leaf-only ones reached under a root parent)
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(rowcnt, 0, (size_t)(cap_nodes + 1) * 4, st));
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(big_count, 0, 256, st));
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(ekeys, 0xFF, (size_t)ecap * 8, st));
     hipLaunchKernelGGL(edge_dedup_count_kernel, grid(T), dim3(TB), 0, st, a, ekeys, (uint32_t)(ecap - 1), winner,
                        rowcnt, out->root_local);
     hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, st, rowcnt, out->meta, hops, out->cap_nodes,

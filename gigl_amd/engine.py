@@ -452,6 +452,13 @@ class SagePlan:
         w_arr, b_arr = self._ptr_arrays(weights, biases)
         check(self._lib.gigl_sage_plan_set_weights(self._plan, w_arr, b_arr), self.eng._ctx)
 
+    def use_graph(self, on: bool = True) -> None:
+        """replay the batch as one hipGraph launch (captured on the next run)"""
+        check(self._lib.gigl_sage_plan_use_graph(self._plan, 1 if on else 0), self.eng._ctx)
+
+    def flush_profile(self) -> None:
+        check(self._lib.gigl_sage_plan_flush_profile(self._plan), self.eng._ctx)
+
     def run(self, roots: torch.Tensor, out: Optional[torch.Tensor] = None, sampling_seed: int = 42,
             mode: int = MODE_SPARK_HASH) -> torch.Tensor:
         """roots: int32 device tensor [b] (uint32 ids); returns [b, out_dim] (row i <-> roots[i])"""

@@ -287,6 +287,13 @@ int32_t gigl_sage_plan_set_weights(gigl_sage_plan* plan, const float* const* w, 
 int32_t gigl_sage_plan_buffers(gigl_sage_plan* plan, gigl_tree* tree, gigl_union* un);
 int32_t gigl_sage_plan_run(gigl_sage_plan* plan, const uint32_t* roots, int32_t sampling_seed,
                            int32_t mode, float* out);
+/* hipGraph replay: on != 0 captures the plan's launches once (per seed/mode/profile mask) and replays them
+ * with one graph launch per batch plus the D2D copies of the root ids in and the rows out.  Weights and the
+ * graph/feature tables are baked into the captured kernels: call again (or set_weights + use_graph) after
+ * changing them.  gigl_sage_plan_flush_profile folds the timing events of in-flight replays into
+ * gigl_profile_read (synchronises). */
+int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
+int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);
 
 #ifdef __cplusplus
