@@ -124,6 +124,52 @@ class SupervisedNodeClassificationBatch:
             [wire.SupervisedNodeClassificationSample.FromString(b) for b in batch], node_type=node_type)
 
 
+@dataclass
+class BatchSupervisionEdgeData:
+    """node_anchor_based_link_prediction_data_loader.py:39-47 (nested class there)"""
+    root_node_to_target_node_id: Dict[int, torch.Tensor]
+    label_edge_features: Optional[Dict[int, torch.Tensor]] = None
+
+
+@dataclass
+class NodeAnchorBasedLinkPredictionBatch:
+    """node_anchor_based_link_prediction_data_loader.py:38-58; collate :61-224.  Homogeneous: one condensed
+    edge type (0) and one condensed node type (0); supervision edges carry no label features (the sampler
+    writes none — NodeAnchorBasedLinkPredictionTask.scala:146-312)."""
+    BatchSupervisionEdgeData = BatchSupervisionEdgeData
+    graph: GraphData
+    root_node_indices: torch.Tensor
+    pos_supervision_edge_data: Dict[int, BatchSupervisionEdgeData]
+    hard_neg_supervision_edge_data: Dict[int, BatchSupervisionEdgeData]
+    condensed_node_type_to_subgraph_id_to_global_node_id: Dict[int, Dict[int, int]]
+
+    @staticmethod
+    def collate_pyg_node_anchor_based_link_prediction_minibatch(
+            samples: Sequence[wire.NodeAnchorBasedLinkPredictionSample]) -> "NodeAnchorBasedLinkPredictionBatch":
+        x, ei, g2l, order = build_batch_graph([(s.neighborhood.nodes, s.neighborhood.edges) for s in samples])
+        pos = BatchSupervisionEdgeData(root_node_to_target_node_id={})
+        neg = BatchSupervisionEdgeData(root_node_to_target_node_id={})
+        roots: List[int] = []
+        for s in samples:
+            r = g2l[s.root_node.node_id]
+            roots.append(r)
+            # a positive / hard negative that is not in the neighbourhood is a KeyError, like node_mapping[...] (:186,:199)
+            pos.root_node_to_target_node_id[r] = torch.tensor([g2l[e.dst_node_id] for e in s.pos_edges],
+                                                              dtype=torch.int64)
+            neg.root_node_to_target_node_id[r] = torch.tensor([g2l[e.dst_node_id] for e in s.hard_neg_edges],
+                                                              dtype=torch.int64)
+        return NodeAnchorBasedLinkPredictionBatch(
+            graph=GraphData(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei)),
+            root_node_indices=torch.tensor(roots, dtype=torch.int64),
+            pos_supervision_edge_data={0: pos}, hard_neg_supervision_edge_data={0: neg},
+            condensed_node_type_to_subgraph_id_to_global_node_id={0: {l: g for l, g in enumerate(order)}})
+
+    @staticmethod
+    def process_raw_pyg_samples_and_collate_fn(batch: Sequence[bytes]):
+        return NodeAnchorBasedLinkPredictionBatch.collate_pyg_node_anchor_based_link_prediction_minibatch(
+            [wire.NodeAnchorBasedLinkPredictionSample.FromString(b) for b in batch])
+
+
 def iterate_tfrecord_batches(files: Sequence[str], batch_size: int, rank: int = 0, world_size: int = 1,
                              seed: int = 42, loop: bool = False):
     """TfRecordsIterableDataset (tf_records_iterable_dataset.py:49-82) + get_data_split_for_current_worker

@@ -69,9 +69,12 @@ class Inferencer:
         try:
             for raw in iterate_tfrecord_batches(files, cfg.inference_batch_size):
                 rnn = RootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(raw, cfg.node_types[0])
-                batch = SupervisedNodeClassificationBatch(
-                    graph=rnn.graph, root_node_indices=rnn.condensed_node_type_to_root_node_indices_map[0],
-                    root_nodes=rnn.root_nodes, root_node_labels=None)
+                if cfg.task_kind == "node_classification":
+                    batch = SupervisedNodeClassificationBatch(
+                        graph=rnn.graph, root_node_indices=rnn.condensed_node_type_to_root_node_indices_map[0],
+                        root_nodes=rnn.root_nodes, root_node_labels=None)
+                else:  # link prediction plugins take the RootedNodeNeighborhoodBatch (utils.py:78-228)
+                    batch = rnn
                 res = inferencer.infer_batch(batch=batch, device=dev)
                 emb = res.embeddings.cpu() if res.embeddings is not None else None
                 pred = res.predictions.cpu() if res.predictions is not None else None

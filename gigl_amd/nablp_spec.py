@@ -1,0 +1,435 @@
+"""Node-anchor-based link prediction task spec (trainer + inferencer plugin) on the HIP path.
+
+Mirror of (paths relative to the reference root):
+  NodeAnchorBasedLinkPredictionModelingTaskSpec
+        python/gigl/src/common/modeling_task_specs/node_anchor_based_link_prediction_modeling_task_spec.py:66-660
+        (kwargs :69-209, init_model :229-316, setup_for_training :319-332, train :334-451, validate :454-571,
+         eval :573-624, infer_batch :626-655)
+  infer_task_inputs      python/gigl/src/common/modeling_task_specs/utils/infer.py:103-456
+  Retrieval task         python/gigl/src/common/models/layers/task.py:108-214
+  NodeAnchorBasedLinkPredictionTasks.calculate_losses   task.py:699-758
+  EarlyStopper           python/gigl/src/common/modeling_task_specs/utils/early_stop.py:12-59
+  KS_FOR_EVAL            python/gigl/src/training/v1/lib/eval_metrics.py
+What runs where: the encoder (GraphSAGE over the coalesced batch graph: gather-mean + fp32 MFMA GEMM, with
+autograd through gigl_gather_mean_backward) and the inner-product decoder (gigl_linear) are HIP kernels; the
+loss/metric algebra on the [queries x candidates] score matrix is the reference's own small torch code.
+Scope: homogeneous graphs (one condensed node type 0 and edge type 0), the Retrieval task, no candidate
+sampling correction (count-min sketch) — other tasks (Margin, Softmax, GRACE, ...) are out of scope.
+Data: main samples are the NodeAnchorBasedLinkPredictionSample TFRecords and random negatives the
+RootedNodeNeighborhood TFRecords the sampler wrote.  The Split Generator that re-files them into
+train/val/test is out of scope: the split is root id % 10 (0-7 train, 8 val, 9 test),
+and tiny fixtures (< 100 samples) use every sample in every split.
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+from dataclasses import dataclass, field
+from itertools import cycle
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import wire
+from .base import (BaseInferencer, BaseTrainer, EvalMetric, EvalMetricsCollection, EvalMetricType, InferBatchResults,
+                   hit_rate_at_k, import_obj, mean_reciprocal_rank, no_grad_eval)
+from .batches import NodeAnchorBasedLinkPredictionBatch, RootedNodeNeighborhoodBatch, iterate_tfrecord_batches
+from .config import GbmlConfigPbWrapper, tfrecord_files
+from .link_prediction import LinkPredictionDecoder, LinkPredictionGNN, RetrievalLoss
+from .models import GraphSAGE
+from .task_specs import _rank_world
+
+KS_FOR_EVAL = [1, 5, 10, 50, 100, 500]
+
+
+def _strtobool(v) -> bool:
+    if isinstance(v, bool):
+        return v
+    s = str(v).strip().lower()
+    if s in ("y", "yes", "t", "true", "on", "1"):
+        return True
+    if s in ("n", "no", "f", "false", "off", "0"):
+        return False
+    raise ValueError(f"invalid truth value {v!r}")
+
+
+# ---- task inputs (python/gigl/src/common/types/task_inputs.py) -------------------------------------
+@dataclass
+class BatchScores:
+    pos_scores: torch.Tensor
+    hard_neg_scores: torch.Tensor
+    random_neg_scores: torch.Tensor
+
+
+@dataclass
+class BatchCombinedScores:
+    repeated_candidate_scores: torch.Tensor
+    positive_ids: torch.Tensor
+    hard_neg_ids: torch.Tensor
+    random_neg_ids: torch.Tensor
+    repeated_query_ids: Optional[torch.Tensor]
+    num_unique_query_ids: Optional[int]
+
+
+@dataclass
+class BatchEmbeddings:
+    query_embeddings: torch.Tensor
+    repeated_query_embeddings: Dict[int, torch.Tensor]
+    pos_embeddings: Dict[int, torch.Tensor]
+    hard_neg_embeddings: Dict[int, torch.Tensor]
+    random_neg_embeddings: Dict[int, torch.Tensor]
+
+
+@dataclass
+class NodeAnchorBasedLinkPredictionTaskInputs:
+    main_batch: NodeAnchorBasedLinkPredictionBatch
+    random_neg_batch: RootedNodeNeighborhoodBatch
+    batch_embeddings: Optional[BatchEmbeddings]
+    batch_scores: List[Dict[int, BatchScores]] = field(default_factory=list)
+    batch_combined_scores: Dict[int, BatchCombinedScores] = field(default_factory=dict)
+
+
+def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrapper,
+                      main_batch: NodeAnchorBasedLinkPredictionBatch, random_neg_batch: RootedNodeNeighborhoodBatch,
+                      should_eval: bool, device: torch.device) -> NodeAnchorBasedLinkPredictionTaskInputs:
+    """infer.py:103-456 for one condensed edge type: encode both batch graphs, then per root gather the
+    positive / hard-negative rows, and build the [sum(num_pos) x (pos | hard_neg | random_neg)] score matrix"""
+    inner = model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
+    decoder = inner.decode
+    cet = 0
+    main_emb = model(main_batch.graph.to(device))
+    rn_emb = model(random_neg_batch.graph.to(device))
+    root_idx = main_batch.root_node_indices.to(device)
+    query = main_emb[root_idx]
+    rn_root_idx = random_neg_batch.condensed_node_type_to_root_node_indices_map[0].to(device)
+    empty = torch.zeros((0,), dtype=torch.float32, device=device)
+    rn_root_emb = rn_emb[rn_root_idx] if rn_root_idx.numel() else empty
+    rn_scores = decoder(query, rn_root_emb) if (should_eval and rn_root_emb.numel()) else empty
+
+    pos_map = main_batch.pos_supervision_edge_data[cet].root_node_to_target_node_id
+    neg_map = main_batch.hard_neg_supervision_edge_data[cet].root_node_to_target_node_id
+    pos_e, neg_e, pos_ids, neg_ids, rep = [], [], [], [], []
+    batch_scores: List[Dict[int, BatchScores]] = []
+    for i, r in enumerate(main_batch.root_node_indices.tolist()):
+        p, h = pos_map[r], neg_map[r]
+        rep.append(p.numel())
+        if p.numel():
+            pos_e.append(main_emb[p.to(device)])
+            pos_ids.append(p)
+        if h.numel():
+            neg_e.append(main_emb[h.to(device)])
+            neg_ids.append(h)
+        if should_eval:
+            q1 = main_emb[root_idx[i:i + 1]]
+            batch_scores.append({cet: BatchScores(
+                pos_scores=decoder(q1, main_emb[p.to(device)]) if p.numel() else empty,
+                hard_neg_scores=decoder(q1, main_emb[h.to(device)]) if h.numel() else empty,
+                random_neg_scores=rn_scores[[i], :] if rn_scores.numel() else empty)})
+    d = query.shape[1]
+    pos_emb = torch.cat(pos_e) if pos_e else torch.zeros((0, d), device=device)
+    neg_emb = torch.cat(neg_e) if neg_e else torch.zeros((0, d), device=device)
+    rep_t = torch.tensor(rep, device=device)
+    rep_query = query.repeat_interleave(rep_t, dim=0)
+    cand = torch.cat((pos_emb, neg_emb, rn_root_emb.reshape(-1, d)))
+    g_main = main_batch.condensed_node_type_to_subgraph_id_to_global_node_id[0]
+    g_rn = random_neg_batch.condensed_node_type_to_subgraph_id_to_global_node_id[0]
+    rep_sub_q = main_batch.root_node_indices.repeat_interleave(torch.tensor(rep))
+
+    def to_global(ids, mapping):
+        return torch.tensor([mapping[int(v)] for v in ids], dtype=torch.int64, device=device)
+
+    combined = BatchCombinedScores(
+        repeated_candidate_scores=decoder(rep_query, cand) if rep_query.numel() else empty,
+        positive_ids=to_global(torch.cat(pos_ids) if pos_ids else [], g_main),
+        hard_neg_ids=to_global(torch.cat(neg_ids) if neg_ids else [], g_main),
+        random_neg_ids=to_global(random_neg_batch.condensed_node_type_to_root_node_indices_map[0], g_rn),
+        repeated_query_ids=to_global(rep_sub_q, g_main),
+        num_unique_query_ids=int(root_idx.shape[0]))
+    return NodeAnchorBasedLinkPredictionTaskInputs(
+        main_batch=main_batch, random_neg_batch=random_neg_batch,
+        batch_embeddings=BatchEmbeddings(query_embeddings=query, repeated_query_embeddings={cet: rep_query},
+                                         pos_embeddings={cet: pos_emb}, hard_neg_embeddings={cet: neg_emb},
+                                         random_neg_embeddings={0: rn_root_emb}),
+        batch_scores=batch_scores, batch_combined_scores={cet: combined})
+
+
+class Retrieval(nn.Module):
+    """task.py:108-214 without candidate-sampling correction; forward -> (summed loss, number of query rows)"""
+    task_name = "Retrieval"
+
+    def __init__(self, loss: Optional[nn.Module] = None, temperature: float = 0.07,
+                 remove_accidental_hits: bool = True, should_enable_candidate_sampling_correction: bool = False):
+        super().__init__()
+        if should_enable_candidate_sampling_correction:
+            raise NotImplementedError("candidate sampling correction (count-min sketch) is out of scope")
+        self.loss = RetrievalLoss(loss=loss, temperature=temperature, remove_accidental_hits=remove_accidental_hits)
+
+    def forward(self, task_input: NodeAnchorBasedLinkPredictionTaskInputs, gbml_config_pb_wrapper=None,
+                should_eval: bool = False, device: torch.device = torch.device("cpu")):
+        assert len(task_input.batch_combined_scores) > 0
+        assert task_input.batch_embeddings is not None
+        running_loss = torch.tensor(0.0, device=device)
+        running_batch_size = 0
+        for cet, bcs in task_input.batch_combined_scores.items():
+            rq = task_input.batch_embeddings.repeated_query_embeddings[cet]
+            if rq.numel():  # loss.py:333-359
+                cand_ids = torch.cat((bcs.positive_ids, bcs.hard_neg_ids, bcs.random_neg_ids)).to(device)
+                loss = self.loss.calculate_batch_retrieval_loss(
+                    scores=bcs.repeated_candidate_scores, candidate_sampling_probability=None,
+                    query_ids=bcs.repeated_query_ids, candidate_ids=cand_ids, device=device)
+                n = int(rq.shape[0])
+            else:
+                loss, n = torch.tensor(0.0, device=device), 1
+            running_loss = running_loss + loss
+            running_batch_size += n
+        return running_loss, running_batch_size
+
+
+class NodeAnchorBasedLinkPredictionTasks:
+    """task.py:699-758: weighted sum of per-sample task losses"""
+
+    def __init__(self) -> None:
+        self._task_to_fn_map = nn.ModuleDict()
+        self._task_to_weights_map: Dict[str, float] = {}
+
+    def add_task(self, task: nn.Module, weight: float) -> None:
+        self._task_to_fn_map[task.task_name] = task
+        self._task_to_weights_map[task.task_name] = weight
+
+    def calculate_losses(self, batch_results, gbml_config_pb_wrapper, should_eval: bool, device: torch.device):
+        total = torch.tensor(0.0, device=device)
+        breakdown: Dict[str, float] = {}
+        for name, weight in self._task_to_weights_map.items():
+            loss_val, bs = self._task_to_fn_map[name](task_input=batch_results,
+                                                      gbml_config_pb_wrapper=gbml_config_pb_wrapper,
+                                                      should_eval=should_eval, device=device)
+            total = total + weight * loss_val / bs
+            breakdown[name] = float("{:.3f}".format(float(weight * loss_val.detach()) / bs))
+        return total, breakdown
+
+
+class EarlyStopper:
+    """early_stop.py:12-59"""
+
+    def __init__(self, early_stop_criterion: EvalMetricType, early_stop_patience: int):
+        supported = [m for m in EvalMetricType.get_all_criteria() if m != "hits"]
+        if early_stop_criterion.name not in supported:
+            raise NotImplementedError(f"Found invalid early stop criterion {early_stop_criterion.name}. Please make "
+                                      f"sure to supply one of {supported}.")
+        self.criterion = early_stop_criterion
+        self._should_maximize = self.criterion != EvalMetricType.loss
+        self.prev_best = float("-inf") if self._should_maximize else float("inf")
+        self.early_stop_counter = 0
+        self.early_stop_patience = early_stop_patience
+        self.best_val_model: Dict[str, Any] = {}
+
+    def has_improved(self, value: float) -> bool:
+        return (self._should_maximize and value > self.prev_best) or (
+            not self._should_maximize and value < self.prev_best)
+
+    def should_early_stop(self, metrics: Dict[EvalMetricType, Any], model: nn.Module) -> bool:
+        value = metrics[self.criterion]
+        if self.has_improved(value):
+            self.early_stop_counter = 0
+            self.prev_best = value
+            self.best_val_model = deepcopy(model.state_dict())
+        else:
+            self.early_stop_counter += 1
+        return self.early_stop_counter >= self.early_stop_patience
+
+
+class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
+    def __init__(self, **kwargs) -> None:
+        gnn_path = str(kwargs.get("gnn_model_class_path", "gigl_amd.models.GraphSAGE"))
+        self.gnn_model = import_obj(gnn_path)
+        self.hidden_dim = int(kwargs.get("hidden_dim", 16))
+        self.num_layers = int(kwargs.get("num_layers", 2))
+        self.out_channels = int(kwargs.get("out_channels", 16))
+        self.should_l2_normalize_embedding_layer_output = bool(
+            kwargs.get("should_l2_normalize_embedding_layer_output", True))
+        self.validate_every_n_batches = int(kwargs.get("val_every_num_batches", 20))
+        self.num_val_batches = int(kwargs.get("num_val_batches", 10))
+        self.num_test_batches = int(kwargs.get("num_test_batches", 100))
+        self._optim_cls = import_obj(str(kwargs.get("optim_class_path", "torch.optim.Adam")))
+        self._optim_kwargs = {"lr": float(kwargs.get("optim_lr", 5e-3)),
+                              "weight_decay": float(kwargs.get("optim_weight_decay", 1e-6))}
+        self.clip_grad_norm = float(kwargs.get("clip_grad_norm", 0.0))
+        self._lr_scheduler_cls = import_obj(str(kwargs.get("lr_scheduler_name", "torch.optim.lr_scheduler.ConstantLR")))
+        self._lr_scheduler_kwargs = {"factor": float(kwargs.get("factor", 1.0)),
+                                     "total_iters": int(kwargs.get("total_iters", 10))}
+        self.main_sample_batch_size = int(kwargs.get("main_sample_batch_size", 2048))
+        self.random_negative_sample_batch_size = int(kwargs.get("random_negative_sample_batch_size", 512))
+        self.random_negative_sample_batch_size_for_evaluation = int(
+            kwargs.get("random_negative_sample_batch_size_for_evaluation", 512))
+        self.early_stopper = EarlyStopper(EvalMetricType[kwargs.get("early_stop_criterion", "loss")],
+                                          int(kwargs.get("early_stop_patience", 3)))
+        self.tasks = NodeAnchorBasedLinkPredictionTasks()
+        task_cls = import_obj(str(kwargs.get("task_path", "gigl_amd.nablp_spec.Retrieval")))
+        self.tasks.add_task(task_cls(temperature=float(kwargs.get("softmax_temp", 0.07)),
+                                     remove_accidental_hits=_strtobool(
+                                         kwargs.get("should_remove_accidental_hits", "True"))), weight=1.0)
+        self._model: Optional[nn.Module] = None
+        self._engine = None
+        self._cfg: Optional[GbmlConfigPbWrapper] = None
+        self.history: List[Dict[str, Any]] = []
+
+    @property
+    def gbml_config_pb_wrapper(self) -> GbmlConfigPbWrapper:
+        if self._cfg is None:
+            raise ValueError("gbml_config_pb_wrapper is not initialized before use, run init_model to set.")
+        return self._cfg
+
+    @property
+    def model(self) -> nn.Module:
+        return self._model
+
+    @model.setter
+    def model(self, model: nn.Module) -> None:
+        self._model = model
+
+    @property
+    def supports_distributed_training(self) -> bool:
+        return True
+
+    def init_model(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, state_dict=None) -> nn.Module:
+        self._cfg = gbml_config_pb_wrapper
+        in_dim = gbml_config_pb_wrapper.preprocessed_metadata.nodes[0].feature_dim
+        encoder = self.gnn_model(
+            in_dim=max(in_dim, 1), hid_dim=self.hidden_dim, out_dim=self.out_channels, num_layers=self.num_layers,
+            should_l2_normalize_embedding_layer_output=self.should_l2_normalize_embedding_layer_output)
+        model = LinkPredictionGNN(encoder=encoder, decoder=LinkPredictionDecoder())
+        if state_dict is not None:
+            model.load_state_dict(state_dict)
+        self.model = model
+        return model
+
+    def _ensure_engine(self, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("the HIP path needs a GPU device; there is no CPU fallback")
+        if self._engine is None:
+            from .engine import HipEngine
+            self._engine = HipEngine(device.index or 0)
+        inner = self.model.module if hasattr(self.model, "module") else self.model
+        inner.encoder.engine = self._engine
+        inner.decoder.engine = self._engine
+        return self._engine
+
+    def setup_for_training(self):
+        self._optimizer = self._optim_cls(params=self.model.parameters(), **self._optim_kwargs)
+        self._lr_scheduler = self._lr_scheduler_cls(self._optimizer, **self._lr_scheduler_kwargs)
+        self.model.train()
+
+    # ---- data (dataset/dataloader roles of NodeAnchorBasedLinkPredictionDatasetDataloaders)
+    def _main_batches(self, cfg: GbmlConfigPbWrapper, split: str, loop: bool):
+        rank, world = _rank_world()
+        files = tfrecord_files(cfg.nablp_tfrecord_uri_prefix)
+        want = {"train": range(0, 8), "val": (8,), "test": (9,)}[split]
+        raw = [b for chunk in iterate_tfrecord_batches(files, 10 ** 9, rank=rank, world_size=world) for b in chunk]
+        samples = [wire.NodeAnchorBasedLinkPredictionSample.FromString(b) for b in raw]
+        part = samples if len(samples) < 100 else [s for s in samples if s.root_node.node_id % 10 in want]
+        bs = self.main_sample_batch_size
+        chunks = [part[i:i + bs] for i in range(0, len(part), bs)]
+        for chunk in (cycle(chunks) if (loop and chunks) else chunks):
+            yield NodeAnchorBasedLinkPredictionBatch.collate_pyg_node_anchor_based_link_prediction_minibatch(chunk)
+
+    def _random_negative_batches(self, cfg: GbmlConfigPbWrapper, batch_size: int):
+        """always looped, like the reference's LoopyIterableDataset for random negatives"""
+        rank, world = _rank_world()
+        prefix = next(iter(cfg.random_negative_tfrecord_uri_prefixes.values()))
+        for raw in iterate_tfrecord_batches(tfrecord_files(prefix), batch_size, rank=rank, world_size=world, loop=True):
+            yield RootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(raw, node_type=cfg.node_types[0])
+
+    # ---- loops
+    def train(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, device: torch.device, profiler=None) -> None:
+        self._ensure_engine(device)
+        cfg = gbml_config_pb_wrapper
+        _, world = _rank_world()
+        main = self._main_batches(cfg, "train", loop=False)
+        rn = self._random_negative_batches(cfg, self.random_negative_sample_batch_size)
+        val_main = self._main_batches(cfg, "val", loop=True)
+        val_rn = self._random_negative_batches(cfg, self.random_negative_sample_batch_size_for_evaluation)
+        self.model.train()
+        every = max(self.validate_every_n_batches // world, 1)
+        for batch_index, (main_batch, rn_batch) in enumerate(zip(main, rn), start=1):
+            self._optimizer.zero_grad()
+            task_inputs = infer_task_inputs(self.model, cfg, main_batch, rn_batch, should_eval=False, device=device)
+            loss, _ = self.tasks.calculate_losses(task_inputs, cfg, should_eval=False, device=device)
+            loss.backward()
+            if self.clip_grad_norm > 0:
+                nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad_norm)
+            self._optimizer.step()
+            self._lr_scheduler.step()
+            self.history.append({"batch": batch_index, "loss": float(loss)})
+            if batch_index % every == 0:
+                if torch.distributed.is_available() and torch.distributed.is_initialized():
+                    torch.distributed.barrier()
+                metrics = self.validate(val_main, val_rn, cfg, device, self.num_val_batches)
+                self.history[-1]["val"] = metrics
+                if self.early_stopper.should_early_stop(metrics, self.model):
+                    break
+            if profiler is not None:
+                profiler.step()
+        if not self.early_stopper.best_val_model:  # fewer train batches than val_every_num_batches: validate once
+            metrics = self.validate(val_main, val_rn, cfg, device, self.num_val_batches)
+            self.early_stopper.should_early_stop(metrics, self.model)
+        assert len(self.early_stopper.best_val_model) > 0
+        self.model.load_state_dict(self.early_stopper.best_val_model)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.barrier()
+
+    @no_grad_eval
+    def validate(self, main_data_loader, random_negative_data_loader, gbml_config_pb_wrapper: GbmlConfigPbWrapper,
+                 device: torch.device, num_batches: int) -> Dict[EvalMetricType, Any]:
+        ks = torch.tensor(KS_FOR_EVAL, dtype=torch.int64, device=device)
+        n_rank_nodes = 0
+        metrics = {EvalMetricType.mrr: torch.zeros(1, device=device), EvalMetricType.loss: torch.zeros(1, device=device),
+                   EvalMetricType.hits: torch.zeros(len(KS_FOR_EVAL), device=device)}
+        _, world = _rank_world()
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        per_rank = num_batches // world if distributed else num_batches
+        seen = 0
+        for batch_idx, (main_batch, rn_batch) in enumerate(zip(main_data_loader, random_negative_data_loader)):
+            if batch_idx >= per_rank:
+                break
+            seen += 1
+            ti = infer_task_inputs(self.model, gbml_config_pb_wrapper, main_batch, rn_batch, should_eval=True,
+                                   device=device)
+            loss, _ = self.tasks.calculate_losses(ti, gbml_config_pb_wrapper, should_eval=True, device=device)
+            metrics[EvalMetricType.loss] += loss
+            for result in ti.batch_scores:
+                for _, bs in result.items():
+                    if bs.pos_scores.numel():
+                        n_rank_nodes += 1
+                        metrics[EvalMetricType.hits] += hit_rate_at_k(bs.pos_scores, bs.random_neg_scores, ks)
+                        metrics[EvalMetricType.mrr] += mean_reciprocal_rank(bs.pos_scores, bs.random_neg_scores)
+        metrics[EvalMetricType.hits] /= max(n_rank_nodes, 1)
+        metrics[EvalMetricType.mrr] /= max(n_rank_nodes, 1)
+        metrics[EvalMetricType.loss] /= max(min(per_rank, seen), 1)
+        if distributed:
+            torch.distributed.barrier()
+            for k in metrics:
+                torch.distributed.all_reduce(metrics[k], op=torch.distributed.ReduceOp.SUM)
+                metrics[k] = metrics[k] / world
+        return {k: (v.tolist() if v.shape[0] > 1 else v.item()) for k, v in metrics.items()}
+
+    def eval(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, device: torch.device) -> EvalMetricsCollection:
+        self._ensure_engine(device)
+        m = self.validate(self._main_batches(gbml_config_pb_wrapper, "test", loop=False),
+                          self._random_negative_batches(gbml_config_pb_wrapper,
+                                                        self.random_negative_sample_batch_size_for_evaluation),
+                          gbml_config_pb_wrapper, device, self.num_test_batches)
+        hits = [EvalMetric(name=f"HitRate_at_{k}", value=rate) for k, rate in zip(KS_FOR_EVAL, m[EvalMetricType.hits])]
+        return EvalMetricsCollection(metrics=[
+            EvalMetric.from_eval_metric_type(EvalMetricType.mrr, m[EvalMetricType.mrr]),
+            EvalMetric.from_eval_metric_type(EvalMetricType.loss, m[EvalMetricType.loss]), *hits])
+
+    @no_grad_eval
+    def infer_batch(self, batch: RootedNodeNeighborhoodBatch, device: torch.device = torch.device("cpu")
+                    ) -> InferBatchResults:
+        self._ensure_engine(device)
+        keys = list(batch.condensed_node_type_to_root_node_indices_map.keys())
+        assert len(keys) == 1, ("RootedNodeNeighborhoodBatch for inference must have only one root node type. "
+                                f"Found root node types: {keys}")
+        idx = batch.condensed_node_type_to_root_node_indices_map[keys[0]].to(device)
+        out = self.model(batch.graph.to(device))
+        return InferBatchResults(embeddings=out[idx], predictions=None)

@@ -89,6 +89,32 @@ def gat_conv(x: torch.Tensor, edge_index: torch.Tensor, w: torch.Tensor, att_src
     return out + bias if bias is not None else out
 
 
+def retrieval_loss_rows(scores: torch.Tensor, query_ids: Sequence[int], candidate_ids: Sequence[int],
+                        temperature: float = 0.07, remove_accidental_hits: bool = True) -> torch.Tensor:
+    """Row-by-row restatement of RetrievalLoss (python/gigl/src/common/models/layers/loss.py:209-331) — pinned by
+    the reference's known-answer tests (python/tests/unit/src/common/models/layers/loss_test.py:61-166, restated in
+    tests/test_link_prediction.py).  Row i's target is column i.  Column j != i is masked out (logit = finfo.min)
+    when it is another row of the same query (j < Q and query_ids[j] == query_ids[i]) or, with accidental-hit
+    removal, when it holds the same candidate as the positive (candidate_ids[j] == candidate_ids[i]).
+    Returns the SUM over rows of the softmax cross-entropy (CrossEntropyLoss(reduction="sum") against eye)."""
+    q, c = scores.shape
+    lo = torch.finfo(scores.dtype).min
+    total = scores.new_zeros(())
+    for i in range(q):
+        row = scores[i] / temperature
+        mask = torch.zeros(c, dtype=torch.bool)
+        for j in range(c):
+            if j == i:
+                continue
+            if j < q and query_ids[j] == query_ids[i]:
+                mask[j] = True
+            if remove_accidental_hits and candidate_ids[j] == candidate_ids[i]:
+                mask[j] = True
+        row = torch.where(mask, row + lo, row)
+        total = total - torch.log_softmax(row, dim=0)[i]
+    return total
+
+
 def union_edge_index(rowptr, col) -> torch.Tensor:
     """CSR-by-destination (int arrays) -> PyG edge_index [2, E] (row 0 = src, row 1 = dst)"""
     rowptr = torch.as_tensor(rowptr, dtype=torch.int64)

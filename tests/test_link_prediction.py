@@ -51,6 +51,15 @@ def test_loss_values():
         RetrievalLoss(temperature=1e-13)
     t = RetrievalLoss(temperature=0.07).calculate_batch_retrieval_loss(scores)
     assert torch.isclose(t, F.cross_entropy(scores / 0.07, LABELS, reduction="sum"))
+    # the oracle's row-by-row restatement is pinned on the same known answers
+    from oracle import gnn_ref
+    o2 = gnn_ref.retrieval_loss_rows(scores, list(range(4)), CAND_IDS.tolist(), temperature=1.0)
+    assert torch.isclose(F.cross_entropy(e2, LABELS, reduction="sum"), o2, atol=1e-3)
+    o3 = gnn_ref.retrieval_loss_rows(scores, QUERY_IDS.tolist(), CAND_IDS.tolist(), temperature=1.0)
+    assert torch.isclose(F.cross_entropy(e3, LABELS, reduction="sum"), o3, atol=1e-3) and torch.isclose(o3, a3)
+    o1 = gnn_ref.retrieval_loss_rows(scores, list(range(4)), CAND_IDS.tolist(), temperature=1.0,
+                                     remove_accidental_hits=False)
+    assert torch.isclose(o1, a1)
 
 
 def test_decoder_construction_errors():
