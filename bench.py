@@ -43,6 +43,38 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
+# library timer id -> the device functions it brackets (names as rocprofv3 prints them, see scripts/pmc_summary.py)
+PMC_KERNELS = {
+    "expand": ["expand_kernel"],
+    "gather_mean": ["gather_mean_kernel<float, 32, 1>", "gather_mean_kernel<float, 64, 1>"],
+    "linear": ["linear_lds_kernel<2>"],
+    "union_insert": ["init_scratch_kernel", "insert_roots_kernel", "insert_slots_kernel"],
+    "union_nodes": ["count_kernel", "assign_kernel"],
+    "union_edge_sort": ["edge_dedup_count_kernel", "row_scan_kernel", "edge_fill_kernel"],
+    "union_csr": ["row_sort_kernel", "row_sort_big_kernel"],
+}
+
+
+def pmc_traffic(kernel_id: str):
+    """HBM bytes per launch of `kernel_id` from the newest committed rocprofv3 PMC summary (profiles/*_pmc.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes by scripts/gpu_pmc.sh on the same workload, corrected
+    with the factors calibrated there).  bench.py cannot collect PMC counters on itself, so this is a measured
+    constant of the committed build, refreshed whenever the profile is; None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files or kernel_id not in PMC_KERNELS:
+        return None, None
+    doc = json.load(open(files[-1]))
+    tot_bytes = tot_calls = 0.0
+    for name in PMC_KERNELS[kernel_id]:
+        e = doc["kernels"].get(name)
+        if e is None:
+            return None, None
+        calls = e.get("FETCH_SIZE_calls", 0)
+        tot_bytes += e["hbm_bytes_per_launch"] * calls
+        tot_calls = max(tot_calls, calls) if kernel_id.startswith("union") else tot_calls + calls
+    return (tot_bytes / tot_calls if tot_calls else None), os.path.basename(files[-1])
+
 
 def rmat_edges_gpu(scale: int, n_edges: int, seed: int, device, a=0.57, b=0.19, c=0.19):
     g = torch.Generator(device=device)
@@ -86,6 +118,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--fanouts", type=str, default="25,10")
     ap.add_argument("--streams", type=int, default=8)
+    ap.add_argument("--group", type=int, default=4,
+                    help="batches per library call: G independent batches of B roots share one set of launches "
+                         "(each keeps its own union graph; results are bit-identical to G single-batch calls)")
     ap.add_argument("--small", action="store_true", help="200k-node graph (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -110,6 +145,7 @@ def main():
     dev = eng0.device
     fanouts = [int(v) for v in args.fanouts.split(",")]
     B, K, W, S = args.batch, args.steps, args.warmup, max(1, args.streams)
+    G = max(1, args.group)
     L = len(fanouts)
     mode = MODE_SPARK_HASH if args.mode == "parity" else MODE_FAST
 
@@ -139,16 +175,26 @@ def main():
         st = torch.cuda.Stream(device=dev)
         engines[s].bind_stream(st)
         streams.append(st)
-        plans.append(model.make_plan(engines[s], B, fanouts))
+        plans.append(model.make_plan(engines[s], B, fanouts, groups=G))
         if not args.no_graph:
-            plans[s].use_graph(True)  # the batch's ~28 launches replayed as one hipGraph launch
-        outs.append(torch.empty((B, out_dim), dtype=torch.float32, device=dev))
+            plans[s].use_graph(True)  # the call's ~28 launches replayed as one hipGraph launch
+        outs.append(torch.empty((G * B, out_dim), dtype=torch.float32, device=dev))
+    # single-batch plan: the tail of a step range that is not a multiple of G, and the untimed counting pass
+    plan1 = model.make_plan(engines[0], B, fanouts) if G > 1 else plans[0]
+    out1 = torch.empty((B, out_dim), dtype=torch.float32, device=dev)
 
     def run_range(lo, hi):
-        """steps lo..hi-1, step i on pipeline i % S, one host thread per pipeline"""
+        """steps (= batches of B roots) lo..hi-1: call c takes the G consecutive batches lo+c*G.. on pipeline
+        c % S (one host thread per pipeline); a remainder of < G steps runs batch by batch on pipeline 0"""
+        n_calls = (hi - lo) // G
+
         def worker(s):
-            for i in range(lo + ((s - lo) % S), hi, S):
-                plans[s].run(my[i], out=outs[s], mode=mode)
+            for c in range(s, n_calls, S):
+                i = lo + c * G
+                plans[s].run(my[i:i + G].view(-1), out=outs[s], mode=mode)
+            if s == 0:
+                for i in range(lo + n_calls * G, hi):
+                    plan1.run(my[i], out=out1, mode=mode)
         ths = [threading.Thread(target=worker, args=(s,)) for s in range(S)]
         for t in ths:
             t.start()
@@ -157,12 +203,13 @@ def main():
 
     names = list(KERNEL_IDS)
     # ---- untimed: warm-up, then find the dominant kernel with all event timers on
-    run_range(0, min(W, 2 * S))
+    P = min(max(G, (min(W, 2 * S * G) // G) * G), W + K)  # probe steps: whole calls, about two per pipeline
+    run_range(0, P)
     torch.cuda.synchronize()
     for e in engines:
         e.profile_enable(names, capacity=64 * 16)
-    run_range(0, min(W, 2 * S))
-    run_range(0, min(W, 2 * S))  # (graph mode: the first call after a mask change re-captures)
+    run_range(0, P)
+    run_range(0, P)  # (graph mode: the first call after a mask change re-captures)
     for p in plans:
         p.flush_profile()
     prof = {k: [sum(x) for x in zip(*[e.profile_read(k) for e in engines])] for k in names}
@@ -202,8 +249,8 @@ def main():
     heavy_thr = 4096
     count_steps = range(W, W + K)  # every timed batch, exactly
     for i in count_steps:
-        plans[0].run(my[i], out=outs[0], mode=mode)
-        hb = plans[0].last_batch_to_host()
+        plan1.run(my[i], out=out1, mode=mode)
+        hb = plan1.last_batch_to_host()
         meta = hb["meta"]
         if meta[8]:
             raise RuntimeError("union dedup overflow (meta[GIGL_META_OVERFLOW])")
@@ -255,9 +302,11 @@ def main():
     avg_launch_ms = dom_ms / max(dom_launches, 1)
     bytes_per_launch = alg_bytes[dominant] / max(dom_launches, 1)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    probe_steps = max(min(W, 2 * S), 1)
+    probe_steps = max(P, 1)
+    traffic, traffic_src = pmc_traffic(dominant)
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
                 "avg_launch_us": round(avg_launch_ms * 1e3, 2), "alg_bytes_per_launch": round(bytes_per_launch),
                 "launches": int(dom_launches),
                 "kernel_ms_per_step_untimed_probe": {k: round(v[0] / probe_steps, 4) for k, v in prof.items()}}
@@ -275,7 +324,7 @@ def main():
                        f" N={n} E={eng0.n_edges} D={d} fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}"
                        " inference step (sample+union+forward), sampler mode=" + args.mode,
                        "graph": "replica per GPU, roots sharded across ranks",
-                       "streams": S,
+                       "streams": S, "batches_per_call": G,
                        "sampled_edges_per_step": sampled_all / (K * world),
                        "aggregated_edges_per_step": aggregated_all / (K * world),
                        "reference_equivalent_aggregated_per_step": ref_equiv_all / (K * world),

@@ -31,6 +31,7 @@ SYMBOLS = [
     "gigl_sage_plan_create", "gigl_sage_plan_set_weights", "gigl_sage_plan_buffers", "gigl_sage_plan_run",
     "gigl_sage_plan_destroy", "gigl_gather_mean_backward", "gigl_expand_frontier", "gigl_gcn_aggregate",
     "gigl_gat_aggregate", "gigl_gather_rows", "gigl_sage_plan_use_graph", "gigl_sage_plan_flush_profile",
+    "gigl_union_build_groups", "gigl_sage_plan_set_groups",
 ]
 
 KERNEL_IDS = {
@@ -109,6 +110,8 @@ def load() -> C.CDLL:
         "gigl_sample_positives": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
         "gigl_union_capacity": [i32, P(i32), i32, P(i64), P(i64)],
         "gigl_union_build": [vp, vp, P(GiglTree), P(GiglUnion)],
+        "gigl_union_build_groups": [vp, vp, P(GiglTree), i32, P(GiglUnion)],
+        "gigl_sage_plan_set_groups": [vp, i32],
         "gigl_gather_mean": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, vp],
         "gigl_linear": [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp],
         "gigl_profile_enable": [vp, C.c_uint32, i32],

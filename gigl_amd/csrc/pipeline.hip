@@ -31,6 +31,7 @@ struct gigl_sage_plan {
   gigl_graph* graph = nullptr;
   gigl_feat* feat = nullptr;
   int32_t b = 0, hops = 0;
+  int32_t group_roots = 0;  // roots per independent batch (== b: one batch)
   int32_t fanouts[GIGL_MAX_HOPS] = {0};
   int32_t dims[GIGL_MAX_HOPS + 1] = {0};  // dims[0] = input dim, dims[l+1] = output dim of layer l
   const float* w[GIGL_MAX_HOPS] = {nullptr};     // fused [dims[l+1]][2*dims[l]] (= [W_l | W_r]), device, borrowed
@@ -38,8 +39,8 @@ struct gigl_sage_plan {
   int32_t act_last = 0;
   gigl_tree tree{};
   gigl_union un{};
-  float* abuf = nullptr;  // [cap_nodes][2*max_in]
-  float* hbuf[2] = {nullptr, nullptr};  // ping-pong [cap_nodes][max_out]
+  float* abuf = nullptr;  // [act_rows][2*max_in], act_rows = b*(1 + f0 + f0*f1 + ...) over hops-1 terms
+  float* hbuf[2] = {nullptr, nullptr};  // ping-pong [act_rows][max_out]
   std::vector<void*> owned;
   // hipGraph replay
   bool use_graph = false;
@@ -80,7 +81,7 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
   const int L = p->hops;
   if (s == 0)
     return gigl_sample_khop(ctx, p->graph, roots, p->b, p->fanouts, p->hops, sampling_seed, mode, &p->tree);
-  if (s == 1) return gigl_union_build(ctx, roots, &p->tree, &p->un);
+  if (s == 1) return gigl_union_build_groups(ctx, roots, &p->tree, p->group_roots, &p->un);
   if (s == n_stages(p) - 1) {
     const int dout = p->dims[L];
     const int64_t total = (int64_t)p->b * dout;
@@ -92,15 +93,22 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
   const int l = (s - 2) >> 1;
   const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
   const int d = p->dims[l];
+  // layer l computes the nodes of level <= L-1-l: at most b*(1 + f0 + f0*f1 + ...) of them — the launch is
+  // sized for that bound, not for the whole union (the exact count is read on the device)
+  int64_t rows_cap = 0, width = p->b;
+  for (int i = 0; i <= L - 1 - l; ++i) {
+    rows_cap += width;
+    width *= p->fanouts[i];
+  }
   if (((s - 2) & 1) == 0) {
     if (l == 0)
       return gigl_gather_mean(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend,
-                              p->un.col, n_rows, p->un.cap_nodes, p->abuf);
+                              p->un.col, n_rows, rows_cap, p->abuf);
     return gigl_gather_mean(ctx, p->hbuf[(l - 1) & 1], GIGL_DTYPE_F32, d, nullptr, p->un.rowptr, p->un.rowend,
-                            p->un.col, n_rows, p->un.cap_nodes, p->abuf);
+                            p->un.col, n_rows, rows_cap, p->abuf);
   }
   const int act = (l < L - 1 || p->act_last) ? 1 : 0;
-  return gigl_linear(ctx, p->abuf, p->w[l], p->bias[l], n_rows, p->un.cap_nodes, 2 * d, p->dims[l + 1], act,
+  return gigl_linear(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
                      p->hbuf[l & 1]);
 }
 
@@ -189,6 +197,7 @@ int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat,
   p->graph = graph;
   p->feat = feat;
   p->b = b;
+  p->group_roots = b;
   p->hops = hops;
   p->act_last = act_last;
   int64_t cap_nodes = 0, cap_edges = 0;
@@ -237,9 +246,15 @@ int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat,
   p->un.root_local = (int32_t*)alloc((size_t)b * 4);
   p->un.cap_nodes = cap_nodes;
   p->un.cap_edges = cap_edges;
-  p->abuf = (float*)alloc((size_t)cap_nodes * 2 * max_in * 4);
-  p->hbuf[0] = (float*)alloc((size_t)cap_nodes * max_out * 4);
-  p->hbuf[1] = hops > 1 ? (float*)alloc((size_t)cap_nodes * max_out * 4) : p->hbuf[0];
+  // activations exist only for nodes of level < hops (leaves are read straight from the feature table)
+  int64_t act_rows = 0, width = b;
+  for (int k = 0; k < hops; ++k) {
+    act_rows += width;
+    width *= fanouts[k];
+  }
+  p->abuf = (float*)alloc((size_t)act_rows * 2 * max_in * 4);
+  p->hbuf[0] = (float*)alloc((size_t)act_rows * max_out * 4);
+  p->hbuf[1] = hops > 1 ? (float*)alloc((size_t)act_rows * max_out * 4) : p->hbuf[0];
   p->roots_buf = (uint32_t*)alloc((size_t)b * 4);
   p->out_buf = (float*)alloc((size_t)b * dims[hops] * 4);
   ok = ok && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col && p->un.root_local &&
@@ -264,6 +279,19 @@ int32_t gigl_sage_plan_set_weights(gigl_sage_plan* p, const float* const* w, con
     hipStreamSynchronize(p->ctx->stream);
     drop_graphs(p);
   }
+  return GIGL_OK;
+}
+
+int32_t gigl_sage_plan_set_groups(gigl_sage_plan* p, int32_t group_roots) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, group_roots >= 1 && p->b % group_roots == 0, "group_roots=%d does not divide the plan's b=%d",
+               group_roots, p->b);
+  if (p->captured) {  // the group split is baked into the captured kernels
+    hipStreamSynchronize(ctx->stream);
+    drop_graphs(p);
+  }
+  p->group_roots = group_roots;
   return GIGL_OK;
 }
 

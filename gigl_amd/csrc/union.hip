@@ -34,6 +34,15 @@ constexpr int MAXL = GIGL_MAX_HOPS + 1;
 constexpr int TILE = 1024;          // stream positions per count/assign workgroup
 constexpr int BIG_ROW_CAP = 16384;  // LDS bitonic capacity (64 KiB of int32)
 
+// one open-addressing slot: everything the passes need about a node sits in ONE 16-byte entry, so a probe
+// costs one random memory access instead of one per attribute array
+struct __attribute__((aligned(16))) Slot {
+  uint32_t key;       // node id, GIGL_INVALID = empty
+  int32_t lid;        // local id (assign)
+  uint32_t firstpos;  // smallest stream position holding the node   } read together (8-byte aligned pair)
+  int32_t level;      // BFS level in the batch's union graph        }
+};
+
 struct UnionArgs {
   const uint32_t* roots;
   int32_t b;
@@ -42,14 +51,15 @@ struct UnionArgs {
   int32_t fan[GIGL_MAX_HOPS];
   int64_t off[GIGL_MAX_HOPS + 1];  // stream offset of hop k slots; off[hops] = T
   int64_t T;
-  // hash table
-  uint32_t* keys;
-  uint32_t* firstpos;
-  int32_t* level;
-  int32_t* lid;
+  // node hash table: one sub-table of (mask+1) slots per batch, sub-table g at slots[g * (mask+1)]
+  Slot* slots;
   uint32_t mask;
   // per stream position
-  int32_t* slot_of;  // table slot or -1
+  int32_t* slot_of;  // table slot (global index) or -1
+  // independent batches in one build (gigl_union_build_groups)
+  int32_t grouped;
+  uint32_t group_roots;
+  uint32_t gdiv[GIGL_MAX_HOPS];  // stream slots of ONE batch at hop k
 };
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
@@ -61,12 +71,12 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   return x;
 }
 
-// stream position -> (node id, hop k or -1 for roots, slot index j within the hop)
-__device__ __forceinline__ uint32_t stream_at(const UnionArgs& a, int64_t t, int& k, int64_t& j) {
+// stream position -> (hop k or -1 for roots, slot index j within the hop)
+__device__ __forceinline__ void locate(const UnionArgs& a, int64_t t, int& k, int64_t& j) {
   if (t < a.b) {
     k = -1;
     j = t;
-    return a.roots[t];
+    return;
   }
   int kk = 0;
 #pragma unroll
@@ -74,7 +84,19 @@ __device__ __forceinline__ uint32_t stream_at(const UnionArgs& a, int64_t t, int
     if (i < a.hops && t >= a.off[i]) kk = i;
   k = kk;
   j = t - a.off[kk];
-  return a.nbr[kk][j];
+}
+
+// stream position -> (node id, hop k or -1 for roots, slot index j within the hop)
+__device__ __forceinline__ uint32_t stream_at(const UnionArgs& a, int64_t t, int& k, int64_t& j) {
+  locate(a, t, k, j);
+  return k < 0 ? a.roots[j] : a.nbr[k][j];
+}
+
+// first slot of the sub-table of the batch that stream slot (k, j) belongs to (0 when there is one batch)
+__device__ __forceinline__ uint32_t group_base(const UnionArgs& a, int k, int64_t j) {
+  if (!a.grouped) return 0u;
+  const uint32_t g = k < 0 ? (uint32_t)j / a.group_roots : (uint32_t)j / a.gdiv[k];
+  return g * (a.mask + 1u);
 }
 
 // stream position of the destination (parent) of the occurrence at hop k, slot j
@@ -83,35 +105,37 @@ __device__ __forceinline__ int64_t parent_pos(const UnionArgs& a, int k, int64_t
   return k == 0 ? p : a.off[k - 1] + p;
 }
 
-__device__ __forceinline__ uint32_t table_insert(const UnionArgs& a, uint32_t id) {
+// claim / find the slot of `id` in the sub-table starting at `base`; returns the global slot index
+__device__ __forceinline__ uint32_t table_insert(const UnionArgs& a, uint32_t base, uint32_t id) {
   uint32_t s = hash_u32(id) & a.mask;
   while (true) {
-    uint32_t prev = atomicCAS(&a.keys[s], GIGL_INVALID, id);
-    if (prev == GIGL_INVALID || prev == id) return s;
+    uint32_t prev = atomicCAS(&a.slots[base + s].key, GIGL_INVALID, id);
+    if (prev == GIGL_INVALID || prev == id) return base + s;
     s = (s + 1) & a.mask;
   }
 }
 
 // slot of `id` or -1 (read-only probe; keys written by an EARLIER kernel are always found)
-__device__ __forceinline__ int32_t table_find(const UnionArgs& a, uint32_t id) {
+__device__ __forceinline__ int32_t table_find(const UnionArgs& a, uint32_t base, uint32_t id) {
   uint32_t s = hash_u32(id) & a.mask;
   while (true) {
-    uint32_t k = __hip_atomic_load(&a.keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == id) return (int32_t)s;
+    uint32_t k = __hip_atomic_load(&a.slots[base + s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == id) return (int32_t)(base + s);
     if (k == GIGL_INVALID) return -1;
     s = (s + 1) & a.mask;
   }
 }
 
-// all per-batch table initialisation in one dispatch: 0xFF.. words, +inf levels, zeros, meta
-__global__ __launch_bounds__(256) void init_scratch_kernel(uint4* ff, int64_t ff_vec, uint4* lvl, int64_t lvl_vec,
+// all per-batch table initialisation in one dispatch: empty edge keys (0xFF..), empty node slots
+// {INVALID, +inf position, +inf level, -}, zeros, meta
+__global__ __launch_bounds__(256) void init_scratch_kernel(uint4* ff, int64_t ff_vec, uint4* slots, int64_t n_slots,
                                                            int32_t* zeros, int64_t zero_words, int32_t* meta) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint4 f4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-  const uint4 l4 = make_uint4(0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu, 0x7F7F7F7Fu);
+  const uint4 s4 = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0x7F7F7F7Fu);  // {key, lid, firstpos, level}
   for (int64_t i = t0; i < ff_vec; i += stride) ff[i] = f4;
-  for (int64_t i = t0; i < lvl_vec; i += stride) lvl[i] = l4;
+  for (int64_t i = t0; i < n_slots; i += stride) slots[i] = s4;
   for (int64_t i = t0; i < zero_words; i += stride) zeros[i] = 0;
   if (t0 < GIGL_META_LEN) meta[t0] = 0;
 }
@@ -124,9 +148,9 @@ __global__ void insert_roots_kernel(UnionArgs a) {
     a.slot_of[t] = -1;
     return;
   }
-  uint32_t s = table_insert(a, id);
-  atomicMin(&a.firstpos[s], (uint32_t)t);
-  a.level[s] = 0;
+  uint32_t s = table_insert(a, group_base(a, -1, t), id);
+  atomicMin(&a.slots[s].firstpos, (uint32_t)t);
+  a.slots[s].level = 0;
   a.slot_of[t] = (int32_t)s;
 }
 
@@ -140,20 +164,21 @@ __global__ void insert_slots_kernel(UnionArgs a) {
     a.slot_of[t] = -1;
     return;
   }
-  uint32_t s = table_insert(a, id);
-  atomicMin(&a.firstpos[s], (uint32_t)t);
+  const uint32_t base = group_base(a, k, j);
+  uint32_t s = table_insert(a, base, id);
+  atomicMin(&a.slots[s].firstpos, (uint32_t)t);
   int32_t lvl;
   if (k == 0) {
     lvl = 1;
   } else if (k == 1) {
     // parent = hop-0 slot node: level 0 iff it is a root (roots were inserted by the previous kernel)
     uint32_t pid = a.nbr[0][j / a.fan[1]];
-    int32_t ps = table_find(a, pid);
-    lvl = (ps >= 0 && __hip_atomic_load(&a.level[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) ? 1 : 2;
+    int32_t ps = table_find(a, base, pid);
+    lvl = (ps >= 0 && __hip_atomic_load(&a.slots[ps].level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) ? 1 : 2;
   } else {
     lvl = k + 1;  // upper bound; relaxed below
   }
-  atomicMin(&a.level[s], lvl);
+  atomicMin(&a.slots[s].level, lvl);
   a.slot_of[t] = (int32_t)s;
 }
 
@@ -165,18 +190,19 @@ __global__ void relax_kernel(UnionArgs a) {
   if (s < 0) return;
   int k;
   int64_t j;
-  stream_at(a, t, k, j);
+  locate(a, t, k, j);
   int32_t ds = a.slot_of[parent_pos(a, k, j)];
-  int32_t dl = __hip_atomic_load(&a.level[ds], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  atomicMin(&a.level[s], dl + 1);
+  int32_t dl = __hip_atomic_load(&a.slots[ds].level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  atomicMin(&a.slots[s].level, dl + 1);
 }
 
-// first-occurrence level of stream position t, or -1
+// first-occurrence level of stream position t, or -1 (one 8-byte read of the slot)
 __device__ __forceinline__ int first_level(const UnionArgs& a, int64_t t) {
   if (t >= a.T) return -1;
   int32_t s = a.slot_of[t];
-  if (s < 0 || a.firstpos[s] != (uint32_t)t) return -1;
-  return a.level[s];
+  if (s < 0) return -1;
+  const uint2 fl = *reinterpret_cast<const uint2*>(&a.slots[s].firstpos);  // {firstpos, level}
+  return fl.x == (uint32_t)t ? (int)fl.y : -1;
 }
 
 // tile_counts[tile][l] = number of first occurrences of level l in the tile
@@ -263,8 +289,8 @@ __global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t*
     for (int q = 0; q < r * 4 + w; ++q) id += s_wave[q][l];
     for (int ll = 0; ll < l; ++ll) id += s_total[ll];
     const int32_t s = a.slot_of[base + r * 256 + tid];
-    a.lid[s] = id;
-    nodes[id] = a.keys[s];
+    a.slots[s].lid = id;
+    nodes[id] = a.slots[s].key;
   }
   if (blockIdx.x == 0 && tid == 0) {
     int32_t cum = 0;
@@ -278,27 +304,30 @@ __global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t*
 
 // edge dedup: the first occurrence to claim (dst_local, src_local) in the edge hash set is the edge's
 // "winner"; winners are counted per destination row.  Which occurrence wins is irrelevant (rows are
-// sorted afterwards).  Threads t < b also publish root_local.
+// sorted afterwards).  A winner leaves its (dst_local, src_local) pair for edge_fill.  Threads t < b also
+// publish root_local.  The edge set has one sub-table of (emask+1) keys per batch, like the node table.
 __global__ void edge_dedup_count_kernel(UnionArgs a, unsigned long long* ekeys, uint32_t emask,
-                                        uint8_t* winner, int32_t* rowcnt, int32_t* root_local) {
+                                        uint8_t* winner, int2* pairs, int32_t* rowcnt, int32_t* root_local) {
   int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.T) return;
   int32_t s = a.slot_of[t];
   if (t < a.b) {
-    root_local[t] = s >= 0 ? a.lid[s] : -1;
+    root_local[t] = s >= 0 ? a.slots[s].lid : -1;
     return;
   }
   bool win = false;
   if (s >= 0) {
     int k;
     int64_t j;
-    stream_at(a, t, k, j);
-    const int32_t dl = a.lid[a.slot_of[parent_pos(a, k, j)]];
-    const int32_t sl = a.lid[s];
+    locate(a, t, k, j);
+    const int32_t dl = a.slots[a.slot_of[parent_pos(a, k, j)]].lid;
+    const int32_t sl = a.slots[s].lid;
     const unsigned long long key = ((unsigned long long)(uint32_t)dl << 32) | (uint32_t)sl;
+    unsigned long long* sub = ekeys;
+    if (a.grouped) sub += (uint64_t)((uint32_t)j / a.gdiv[k]) * (emask + 1u);
     uint32_t h = hash_u32((uint32_t)sl * 0x9E3779B1u ^ (uint32_t)dl) & emask;
     while (true) {
-      unsigned long long prev = atomicCAS(&ekeys[h], ~0ULL, key);
+      unsigned long long prev = atomicCAS(&sub[h], ~0ULL, key);
       if (prev == ~0ULL) {
         win = true;
         break;
@@ -306,7 +335,10 @@ __global__ void edge_dedup_count_kernel(UnionArgs a, unsigned long long* ekeys, 
       if (prev == key) break;
       h = (h + 1) & emask;
     }
-    if (win) atomicAdd(&rowcnt[dl], 1);
+    if (win) {
+      atomicAdd(&rowcnt[dl], 1);
+      pairs[t - a.b] = make_int2(dl, sl);
+    }
   }
   winner[t - a.b] = win ? 1 : 0;
 }
@@ -314,7 +346,8 @@ __global__ void edge_dedup_count_kernel(UnionArgs a, unsigned long long* ekeys, 
 // exclusive scan of rowcnt[0..n) -> rowptr[0..n], rowend[i] = rowptr[i] (fill cursor); rows >= n get
 // rowptr = rowend = total.  n = nodes that can have in-edges (levels < hops).  One workgroup.
 __global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* rowcnt, int32_t* meta, int hops,
-                                                        int64_t cap_nodes, int32_t* rowptr, int32_t* rowend) {
+                                                        int64_t cap_nodes, int32_t* rowptr, int32_t* rowend,
+                                                        int tail_here) {
   __shared__ int32_t s_w[16];
   __shared__ int32_t s_carry;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -322,9 +355,15 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* rowcnt, i
   const int32_t n_nodes = meta[GIGL_META_N_NODES];
   if (tid == 0) s_carry = 0;
   __syncthreads();
-  for (int32_t base = 0; base < n; base += 1024) {
-    const int32_t i = base + tid;
-    int32_t v = i < n ? rowcnt[i] : 0;
+  constexpr int PER = 8;  // consecutive rows per thread: 8192 rows per pass of the workgroup
+  for (int32_t base = 0; base < n; base += 1024 * PER) {
+    const int32_t i0 = base + tid * PER;
+    int32_t c[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) c[q] = (i0 + q) < n ? rowcnt[i0 + q] : 0;
+    int32_t v = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) v += c[q];
     int32_t incl = v;
     for (int off = 1; off < 64; off <<= 1) {
       int32_t o = __shfl_up(incl, off, 64);
@@ -335,34 +374,45 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* rowcnt, i
     int32_t wave_off = 0;
     for (int q = 0; q < w; ++q) wave_off += s_w[q];
     const int32_t carry = s_carry;
-    if (i < n) {
-      const int32_t ex = carry + wave_off + incl - v;
-      rowptr[i] = ex;
-      rowend[i] = ex;
+    int32_t ex = carry + wave_off + incl - v;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      if (i0 + q < n) {
+        rowptr[i0 + q] = ex;
+        rowend[i0 + q] = ex;
+      }
+      ex += c[q];
     }
     __syncthreads();
     if (tid == 1023) s_carry = carry + wave_off + incl;
     __syncthreads();
   }
   const int32_t total = s_carry;
-  for (int64_t i = (int64_t)n + tid; i <= n_nodes && i <= cap_nodes; i += 1024) {
-    rowptr[i] = total;
-    rowend[i] = total;
-  }
+  if (tail_here)  // no edge_fill launch follows (a batch without slots): close the row arrays here
+    for (int64_t i = (int64_t)n + tid; i <= n_nodes && i <= cap_nodes; i += 1024) {
+      rowptr[i] = total;
+      rowend[i] = total;
+    }
   if (tid == 0) meta[GIGL_META_N_EDGES] = total;  // winners only: the unique edge count
 }
 
-__global__ void edge_fill_kernel(UnionArgs a, const uint8_t* winner, int32_t* rowend, int32_t* col) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + a.b;
+// scatter the winners into their rows; the same wide launch also closes the row arrays of the nodes
+// that have no in-edges (rows n .. n_nodes get rowptr = rowend = n_edges): n_nodes - n <= E always
+__global__ void edge_fill_kernel(UnionArgs a, const uint8_t* winner, const int2* pairs, const int32_t* meta,
+                                 int32_t* rowptr, int32_t* rowend, int32_t* col) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t t = e + a.b;
   if (t >= a.T) return;
-  if (!winner[t - a.b]) return;
-  int32_t s = a.slot_of[t];
-  int k;
-  int64_t j;
-  stream_at(a, t, k, j);
-  int32_t ds = a.slot_of[parent_pos(a, k, j)];
-  int32_t pos = atomicAdd(&rowend[a.lid[ds]], 1);
-  col[pos] = a.lid[s];
+  {
+    const int32_t n = meta[GIGL_META_LEVEL0 + a.hops - 1], n_nodes = meta[GIGL_META_N_NODES];
+    const int32_t total = meta[GIGL_META_N_EDGES];
+    const int64_t i = (int64_t)n + e;
+    if (i < n_nodes) rowptr[i] = rowend[i] = total;
+    if (e == 0) rowptr[n_nodes] = rowend[n_nodes] = total;
+  }
+  if (!winner[e]) return;
+  const int2 p = pairs[e];  // (dst_local, src_local) left by edge_dedup_count
+  col[atomicAdd(&rowend[p.x], 1)] = p.y;
 }
 
 // one wave per row: sort ascending in place (rows <= 64, values are unique); longer rows are queued
@@ -391,6 +441,14 @@ __global__ __launch_bounds__(256) void row_sort_kernel(const int32_t* meta, int 
 // Values are unique local ids, so 1024 range buckets over [min, max] hold a handful each; a bucket is
 // sorted by one wave (rank-by-counting in registers when <= 64, from LDS otherwise).
 constexpr int NBUCKET = 1024;
+
+// LDS hand-off between the lanes of ONE wave: drain this wave's LDS traffic, then keep the compiler and the
+// lanes from running ahead
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(1024) void row_sort_big_kernel(const int32_t* rowptr, const int32_t* rowend,
                                                             int32_t* col, const int32_t* big_rows,
                                                             const int32_t* big_count, int32_t* overflow) {
@@ -400,6 +458,7 @@ __global__ __launch_bounds__(1024) void row_sort_big_kernel(const int32_t* rowpt
   __shared__ int32_t s_cnt[NBUCKET];
   __shared__ int32_t s_off[NBUCKET + 1];
   __shared__ int32_t s_w[16];
+  __shared__ int32_t s_sub[16][64];  // per-wave sub-bucket counters
   __shared__ int32_t s_min, s_max;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int32_t nb = *big_count;
@@ -464,12 +523,57 @@ __global__ __launch_bounds__(1024) void row_sort_big_kernel(const int32_t* rowpt
         int32_t pos = 0;
         for (int j = 0; j < sz; ++j) pos += __builtin_amdgcn_readlane(v, j) < v ? 1 : 0;
         if (lane < sz) col[s + lo + pos] = v;
-      } else {  // crowded bucket: rank against the whole bucket from LDS
+      } else {
+        // crowded bucket (clustered ids, e.g. a row of a grouped build whose sources sit in one narrow id range
+        // per level): a second, wave-local split into 64 range sub-buckets over the bucket's own [min, max],
+        // staged through A[lo .. lo+sz) (free after the scatter above); sub-buckets are ranked in registers
+        int32_t bmn = 0x7FFFFFFF, bmx = 0;
         for (int q = lane; q < sz; q += 64) {
           const int32_t v = B[lo + q];
-          int32_t pos = 0;
-          for (int j = 0; j < sz; ++j) pos += B[lo + j] < v ? 1 : 0;
-          col[s + lo + pos] = v;
+          bmn = min(bmn, v);
+          bmx = max(bmx, v);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          bmn = min(bmn, __shfl_xor(bmn, off, 64));
+          bmx = max(bmx, __shfl_xor(bmx, off, 64));
+        }
+        const int64_t bspan = (int64_t)bmx - bmn + 1;
+        s_sub[w][lane] = 0;
+        wave_lds_sync();
+        for (int q = lane; q < sz; q += 64)
+          atomicAdd(&s_sub[w][(int)(((int64_t)(B[lo + q] - bmn) * 64) / bspan)], 1);
+        wave_lds_sync();
+        const int32_t c = s_sub[w][lane];
+        int32_t incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+          int32_t o = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += o;
+        }
+        const int32_t sub_lo = incl - c;
+        wave_lds_sync();
+        s_sub[w][lane] = sub_lo;  // scatter cursor
+        wave_lds_sync();
+        for (int q = lane; q < sz; q += 64) {
+          const int32_t v = B[lo + q];
+          A[lo + atomicAdd(&s_sub[w][(int)(((int64_t)(v - bmn) * 64) / bspan)], 1)] = v;
+        }
+        wave_lds_sync();
+        for (int sb = 0; sb < 64; ++sb) {
+          const int32_t slo = __builtin_amdgcn_readlane(sub_lo, sb), ssz = __builtin_amdgcn_readlane(c, sb);
+          if (ssz == 0) continue;
+          if (ssz <= 64) {
+            const int32_t v = lane < ssz ? A[lo + slo + lane] : 0x7FFFFFFF;
+            int32_t pos = 0;
+            for (int j = 0; j < ssz; ++j) pos += __builtin_amdgcn_readlane(v, j) < v ? 1 : 0;
+            if (lane < ssz) col[s + lo + slo + pos] = v;
+          } else {  // still crowded: rank against the sub-bucket from LDS
+            for (int q = lane; q < ssz; q += 64) {
+              const int32_t v = A[lo + slo + q];
+              int32_t pos = 0;
+              for (int j = 0; j < ssz; ++j) pos += A[lo + slo + j] < v ? 1 : 0;
+              col[s + lo + slo + pos] = v;
+            }
+          }
         }
       }
     }
@@ -496,6 +600,13 @@ int32_t gigl_union_capacity(int32_t b, const int32_t* fanouts, int32_t hops, int
 
 int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree,
                          gigl_union* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, tree, "null argument");
+  return gigl_union_build_groups(ctx, roots, tree, tree->b, out);
+}
+
+int32_t gigl_union_build_groups(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree,
+                                int32_t group_roots, gigl_union* out) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   GIGL_REQUIRE(ctx, tree && out && (roots || tree->b == 0), "null argument");
   GIGL_REQUIRE(ctx, out->meta && out->nodes && out->rowptr && out->rowend && out->col && out->root_local,
@@ -530,44 +641,56 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
   }
   a.off[hops] = T;
   a.T = T;
+  GIGL_REQUIRE(ctx, T < (int64_t)1 << 31, "batch too large: %lld stream positions", (long long)T);
+  int64_t n_groups = 1;
+  if (group_roots != b) {
+    GIGL_REQUIRE(ctx, group_roots >= 1 && b % group_roots == 0, "group_roots=%d does not divide b=%d", group_roots, b);
+    n_groups = b / group_roots;
+    a.grouped = 1;
+    a.group_roots = (uint32_t)group_roots;
+    int64_t per_group = group_roots;
+    for (int k = 0; k < hops; ++k) {
+      per_group *= tree->fanouts[k];
+      a.gdiv[k] = (uint32_t)per_group;
+    }
+  }
   const int64_t E = T - b;              // edge occurrences
   const int64_t max_rows = a.off[hops - 1];  // nodes that are the parent of some slot
-  // open-addressing tables at load factor <= 2/3
-  uint64_t cap = 1024;
-  while (cap * 2 < (uint64_t)T * 3) cap <<= 1;
+  // open-addressing tables at load factor <= 2/3: one node sub-table and one edge sub-table per batch, so the
+  // probes of the batches in flight stay inside a few MB instead of scattering over one table of all batches
+  uint64_t cap = 1024, ecap = 1024;
+  while (cap * 2 < (uint64_t)(T / n_groups) * 3) cap <<= 1;
+  while (ecap * 2 < (uint64_t)(E / n_groups) * 3) ecap <<= 1;
   a.mask = (uint32_t)(cap - 1);
+  const int64_t n_slots = (int64_t)cap * n_groups, n_ekeys = (int64_t)ecap * n_groups;
+  GIGL_REQUIRE(ctx, n_slots < (int64_t)1 << 31, "batch too large: %lld table slots", (long long)n_slots);
   const int32_t n_tiles = (int32_t)((T + TILE - 1) / TILE);
-  uint64_t ecap = 1024;
-  while (ecap * 2 < (uint64_t)E * 3) ecap <<= 1;
 
-  // scratch.  Everything that needs an initial pattern is laid out contiguously per pattern so ONE kernel
-  // initialises it: [ekeys | keys | firstpos] = 0xFF.., [level] = +inf, [rowcnt | big_count] = 0
+  // scratch.  Everything that needs an initial pattern is initialised by ONE kernel:
+  // [ekeys] = 0xFF.., [slots] = empty, [rowcnt | big_count] = 0
   int64_t need = 0;
   auto add = [&](int64_t bytes) { need += gigl_align_up(bytes, 256); };
-  const int64_t ff_words = (int64_t)ecap * 2 + (int64_t)cap * 2;  // 32-bit words
   const int64_t zero_words = cap_nodes + 1 + 64;
-  add(ff_words * 4);
-  add((int64_t)cap * 4);             // level
+  add(n_ekeys * 8);
+  add(n_slots * (int64_t)sizeof(Slot));
   add(zero_words * 4);               // rowcnt + big-row counter
-  add((int64_t)cap * 4);             // lid
   add(T * 4);                        // slot_of
   add((int64_t)n_tiles * MAXL * 4);  // tile counts
   add(cap_nodes * 4);                // big-row queue
   add(E + 256);                      // winner flags
+  add((E + 1) * 8);                  // winners' (dst, src) pairs
   int32_t rc = gigl_arena_reset(ctx, need + 4096);
   if (rc != GIGL_OK) return rc;
-  uint32_t* ff = (uint32_t*)gigl_arena_alloc(ctx, ff_words * 4);
-  a.level = (int32_t*)gigl_arena_alloc(ctx, (int64_t)cap * 4);
+  unsigned long long* ekeys = (unsigned long long*)gigl_arena_alloc(ctx, n_ekeys * 8);
+  a.slots = (Slot*)gigl_arena_alloc(ctx, n_slots * (int64_t)sizeof(Slot));
   int32_t* zeros = (int32_t*)gigl_arena_alloc(ctx, zero_words * 4);
-  a.lid = (int32_t*)gigl_arena_alloc(ctx, (int64_t)cap * 4);
   a.slot_of = (int32_t*)gigl_arena_alloc(ctx, T * 4);
   int32_t* tile_counts = (int32_t*)gigl_arena_alloc(ctx, (int64_t)n_tiles * MAXL * 4);
   int32_t* big_rows = (int32_t*)gigl_arena_alloc(ctx, cap_nodes * 4);
   uint8_t* winner = (uint8_t*)gigl_arena_alloc(ctx, E + 256);
-  if (!ff || !zeros || !big_rows || !winner || !a.slot_of) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
-  unsigned long long* ekeys = (unsigned long long*)ff;  // 8-byte aligned (arena blocks are 256-byte aligned)
-  a.keys = ff + ecap * 2;
-  a.firstpos = a.keys + cap;
+  int2* pairs = (int2*)gigl_arena_alloc(ctx, (E + 1) * 8);
+  if (!ekeys || !a.slots || !zeros || !big_rows || !winner || !a.slot_of || !pairs || !tile_counts)
+    return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   int32_t* rowcnt = zeros;
   int32_t* big_count = zeros + cap_nodes + 1;  // [0] = number of queued rows
 
@@ -576,8 +699,8 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_INSERT);
     // one launch initialises every table of this batch (instead of six memset dispatches)
-    hipLaunchKernelGGL(init_scratch_kernel, dim3(1024), dim3(256), 0, st, (uint4*)ff, ff_words / 4,
-                       (uint4*)a.level, (int64_t)cap / 4, zeros, zero_words, out->meta);
+    hipLaunchKernelGGL(init_scratch_kernel, dim3(1024), dim3(256), 0, st, (uint4*)ekeys, n_ekeys / 2, (uint4*)a.slots,
+                       n_slots, zeros, zero_words, out->meta);
     hipLaunchKernelGGL(insert_roots_kernel, grid(b), dim3(TB), 0, st, a);
     if (E > 0) hipLaunchKernelGGL(insert_slots_kernel, grid(E), dim3(TB), 0, st, a);
   }
@@ -595,10 +718,12 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
     gigl_prof_scope ps(ctx, GIGL_K_UNION_EDGE_SORT);
     // every node of level < hops may be a row (also leaf-only ones reached under a root parent)
     hipLaunchKernelGGL(edge_dedup_count_kernel, grid(T), dim3(TB), 0, st, a, ekeys, (uint32_t)(ecap - 1), winner,
-                       rowcnt, out->root_local);
+                       pairs, rowcnt, out->root_local);
     hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, st, rowcnt, out->meta, hops, out->cap_nodes,
-                       out->rowptr, out->rowend);
-    if (E > 0) hipLaunchKernelGGL(edge_fill_kernel, grid(E), dim3(TB), 0, st, a, winner, out->rowend, out->col);
+                       out->rowptr, out->rowend, E > 0 ? 0 : 1);
+    if (E > 0)
+      hipLaunchKernelGGL(edge_fill_kernel, grid(E), dim3(TB), 0, st, a, winner, pairs, out->meta, out->rowptr,
+                         out->rowend, out->col);
   }
   if (E > 0) {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_CSR);

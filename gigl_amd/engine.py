@@ -310,10 +310,18 @@ class HipEngine:
         return UnionGraph(meta=meta, nodes=nodes, rowptr=rowptr, rowend=rowend, col=col, root_local=root_local,
                           hops=len(fanouts), c_struct=u)
 
-    def union_build(self, tree: Tree, out: Optional[UnionGraph] = None) -> UnionGraph:
+    def union_build(self, tree: Tree, out: Optional[UnionGraph] = None, group_roots: Optional[int] = None
+                    ) -> UnionGraph:
+        """group_roots: treat the tree's roots as consecutive independent batches of that many roots
+        (gigl_union_build_groups): dedup within a batch only, one level-ordered numbering over all of them"""
         u = out if out is not None else self.alloc_union(tree.b, tree.fanouts)
-        check(self._lib.gigl_union_build(self._ctx, C.c_void_p(tree.roots.data_ptr()), C.byref(tree.c_struct),
-                                         C.byref(u.c_struct)), self._ctx)
+        if group_roots is None or group_roots == tree.b:
+            check(self._lib.gigl_union_build(self._ctx, C.c_void_p(tree.roots.data_ptr()), C.byref(tree.c_struct),
+                                             C.byref(u.c_struct)), self._ctx)
+        else:
+            check(self._lib.gigl_union_build_groups(self._ctx, C.c_void_p(tree.roots.data_ptr()),
+                                                    C.byref(tree.c_struct), int(group_roots), C.byref(u.c_struct)),
+                  self._ctx)
         return u
 
     def gather_mean(self, src: Optional[torch.Tensor], d: int, gather_ids: Optional[torch.Tensor],
@@ -411,20 +419,22 @@ class HipEngine:
 
     # ---- one-call batch pipeline -----------------------------------------------------------
     def make_sage_plan(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], b: int,
-                       fanouts: Sequence[int], act_last: bool = False) -> "SagePlan":
-        """weights[l]: fused fp32 [out_l, 2*in_l] = cat(lin_l.weight, lin_r.weight, dim=1) on this device"""
-        return SagePlan(self, weights, biases, b, fanouts, act_last)
+                       fanouts: Sequence[int], act_last: bool = False, groups: int = 1) -> "SagePlan":
+        """weights[l]: fused fp32 [out_l, 2*in_l] = cat(lin_l.weight, lin_r.weight, dim=1) on this device.
+        groups > 1: one call takes groups*b roots = `groups` independent batches of b roots each."""
+        return SagePlan(self, weights, biases, b, fanouts, act_last, groups)
 
 
 class SagePlan:
     """sample -> union -> GraphSAGE forward -> one row per root, enqueued by ONE library call
     (include/gigl_hip.h `gigl_sage_plan_*`)."""
 
-    def __init__(self, eng: HipEngine, weights, biases, b: int, fanouts, act_last: bool):
+    def __init__(self, eng: HipEngine, weights, biases, b: int, fanouts, act_last: bool, groups: int = 1):
         assert eng._graph is not None and eng._feat is not None, "load the graph and the features first"
         L = len(fanouts)
-        assert len(weights) == L
-        self.eng, self.b, self.fanouts = eng, int(b), [int(f) for f in fanouts]
+        assert len(weights) == L and groups >= 1
+        self.group_roots, self.groups = int(b), int(groups)
+        self.eng, self.b, self.fanouts = eng, int(b) * int(groups), [int(f) for f in fanouts]
         self._lib = eng._lib
         self.dims = [int(weights[0].shape[1]) // 2] + [int(w.shape[0]) for w in weights]
         self._keep = None
@@ -434,6 +444,8 @@ class SagePlan:
         dims = (C.c_int32 * (L + 1))(*self.dims)
         check(self._lib.gigl_sage_plan_create(eng._ctx, eng._graph, eng._feat, self.b, fo, L, dims, w_arr, b_arr,
                                               1 if act_last else 0, C.byref(self._plan)), eng._ctx)
+        if self.groups > 1:
+            check(self._lib.gigl_sage_plan_set_groups(self._plan, self.group_roots), eng._ctx)
         if not hasattr(eng, "_plans"):
             eng._plans = []
         eng._plans.append(self)

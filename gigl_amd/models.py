@@ -111,12 +111,13 @@ class GraphSAGE(nn.Module):
             h = torch.nn.functional.normalize(h, p=2, dim=1)
         return h
 
-    def make_plan(self, eng: HipEngine, b: int, fanouts: Sequence[int]):
+    def make_plan(self, eng: HipEngine, b: int, fanouts: Sequence[int], groups: int = 1):
         """one-call pipeline (sample -> union -> this model's forward -> one row per root) for batches of
-        `b` roots on `eng`; weights are snapshotted — call plan.set_weights(*model.fused_params()) after updates"""
+        `b` roots on `eng`; weights are snapshotted — call plan.set_weights(*model.fused_params()) after updates.
+        groups > 1: each call takes groups*b roots and processes them as `groups` independent batches of b."""
         assert len(fanouts) == self.num_layers, "one hop per layer"
         w, bs = self.fused_params()
-        return eng.make_sage_plan(w, bs, b, fanouts, act_last=self.activation_after_last_conv)
+        return eng.make_sage_plan(w, bs, b, fanouts, act_last=self.activation_after_last_conv, groups=groups)
 
     def fused_params(self):
         return ([c.fused_weight().detach() for c in self.conv_layers],

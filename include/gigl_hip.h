@@ -207,6 +207,15 @@ int32_t gigl_union_capacity(int32_t b, const int32_t* fanouts, int32_t hops, int
                             int64_t* cap_edges);
 int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree,
                          gigl_union* out);
+/* Several INDEPENDENT batches in one set of launches: the b = n_groups*group_roots trees are treated as
+ * n_groups consecutive batches of group_roots roots; nodes and edges are deduplicated WITHIN a batch only
+ * (the same global id in two batches is two local nodes), i.e. the result is the disjoint union of the
+ * n_groups per-batch union graphs — what calling the reference collate once per batch produces — in ONE
+ * level-ordered local numbering (level, first stream position), so layer prefixes still hold and the
+ * relative order of a batch's nodes equals its stand-alone numbering.  Every batch has its own hash
+ * sub-tables.  group_roots must divide b; group_roots == b is gigl_union_build. */
+int32_t gigl_union_build_groups(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree,
+                                int32_t group_roots, gigl_union* out);
 
 /* ---- message passing over the union graph: replaces PyG SAGEConv / GATConv / GCNConv as used by
  *      python/gigl/src/common/models/pyg/homogeneous.py:107-153,171-202,300-343,488-546.
@@ -283,6 +292,12 @@ int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat,
                               const float* const* w, const float* const* bias, int32_t act_last,
                               gigl_sage_plan** out);
 int32_t gigl_sage_plan_set_weights(gigl_sage_plan* plan, const float* const* w, const float* const* bias);
+/* Treat the plan's b roots as b/group_roots INDEPENDENT batches of group_roots roots (the reference's
+ * dataloader batch size): every batch gets its own union graph (gigl_union_build_groups), and all of them go
+ * through ONE set of launches, which amortises the per-launch cost over several batches.  Row i of the output is
+ * bit-identical to what a plan of group_roots roots returns for the batch that holds roots[i].
+ * group_roots == b (the default) is a single batch. */
+int32_t gigl_sage_plan_set_groups(gigl_sage_plan* plan, int32_t group_roots);
 /* borrow the plan's device buffers (valid until the next run overwrites them / destroy) */
 int32_t gigl_sage_plan_buffers(gigl_sage_plan* plan, gigl_tree* tree, gigl_union* un);
 int32_t gigl_sage_plan_run(gigl_sage_plan* plan, const uint32_t* roots, int32_t sampling_seed,
