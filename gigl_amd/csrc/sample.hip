@@ -59,6 +59,11 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t x, int l) {
   return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint32_t readlane32(uint32_t x, int l) { return __builtin_amdgcn_readlane(x, l); }
+// LDS hand-off between the lanes of ONE wave: drain the wave's LDS traffic, keep compiler and lanes in step
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // insert wave-uniform candidate (ck, ci) into the ascending per-lane list (key, idx); the last
 // lane's element falls off
@@ -312,6 +317,58 @@ struct Sel {
       merge(mk(xxh64_i32_ordered((uint32_t)i + base)), (uint32_t)i, i <= i_hi);
     }
   }
+  // FAST only.  Short windows (no table block inside), done without the serial insert chain: hash values are
+  // uniform, so a threshold T = lambda/deg * 2^32 with lambda = f + 4*sqrt(f) + 4 lets ~lambda candidates
+  // through (count them with ballots, compact them into the wave's LDS scratch lk/li), then every survivor
+  // finds its rank among the <= 64 survivors by counting.  Exact: every non-survivor has a proxy >= T > every
+  // survivor's, so the f best of the window are the f best survivors — provided there are at least f of them
+  // and no two survivors share a proxy (-> tie, redone by the exact path).  Too few / too many survivors
+  // (about 1 row in 10^3) -> returns false and the caller runs the serial path.
+  // On success lanes [0, f) hold the selected positions (any order).
+  __device__ __forceinline__ bool filter_select(int64_t deg, uint32_t base, uint32_t* lk, uint32_t* li) {
+    const float lam = (float)f + 4.f * __builtin_sqrtf((float)f) + 4.f;
+    if (lam > 56.f || deg > 65536) return false;
+    const uint32_t n = (uint32_t)deg;
+    const bool all = n <= 64u;
+    const uint32_t T = all ? 0xFFFFFFFFu : (uint32_t)fminf(lam * 4294967296.f / (float)n, 4294967040.f);
+    uint32_t count = 0;
+    const uint32_t nchunks = (n + 63u) >> 6;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+      const uint32_t i = c * 64u + (uint32_t)lane + 1u;
+      const key_t k = mk(xxh64_i32_ordered(i + base));
+      const bool pass = i <= n && (all || k < T);
+      const unsigned long long m = __ballot(pass);
+      if (pass) {
+        const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (pos < 64u) {
+          lk[pos] = (uint32_t)k;
+          li[pos] = i;
+        }
+      }
+      count += (uint32_t)__popcll(m);
+    }
+    if (count < (uint32_t)f || count > 64u) return false;
+    wave_lds_sync();
+    const bool valid = (uint32_t)lane < count;
+    const uint32_t k = valid ? lk[lane] : 0xFFFFFFFFu;
+    const uint32_t i = valid ? li[lane] : 0xFFFFFFFFu;
+    uint32_t rank = 0, eq = 0;
+    for (uint32_t j = 0; j < count; ++j) {
+      const uint32_t kj = readlane32(k, (int)j);
+      rank += kj < k ? 1u : 0u;
+      eq += kj == k ? 1u : 0u;
+    }
+    if (__ballot(valid && eq != 1u)) {
+      tie = true;
+      return true;
+    }
+    wave_lds_sync();
+    if (valid && rank < (uint32_t)f) li[rank] = i;
+    wave_lds_sync();
+    idx = lane < f ? li[lane] : 0xFFFFFFFFu;
+    return true;
+  }
   __device__ __forceinline__ key_t table_key(const RangeTable& tb, int64_t e) const {
     if constexpr (FAST)  // high word (little endian)
       return (reinterpret_cast<const uint32_t*>(tb.keys)[2 * e + 1] >> drop) << drop;
@@ -335,12 +392,16 @@ struct Sel {
     }
   }
   // the whole row: window of positions [1, deg] with hash offset `base`
-  __device__ __forceinline__ void select(const RangeTable& tb, int64_t deg, uint32_t base, bool in_table) {
+  __device__ __forceinline__ void select(const RangeTable& tb, int64_t deg, uint32_t base, bool in_table,
+                                         uint32_t* lk = nullptr, uint32_t* li = nullptr) {
     const uint64_t j_lo = (uint64_t)base + 1, j_hi = (uint64_t)base + (uint64_t)deg;  // inclusive window
     // aligned level-0 blocks fully inside the window come from the table
     const uint64_t b_first = (j_lo + ((1u << TBL_S0_SHIFT) - 1)) >> TBL_S0_SHIFT;
     const uint64_t b_last = (j_hi + 1) >> TBL_S0_SHIFT;  // one past the last full block
     if (!in_table || b_first >= b_last) {
+      if constexpr (FAST) {
+        if (lk && filter_select(deg, base, lk, li)) return;
+      }
       scan_direct(1, deg, base);
       return;
     }
@@ -405,8 +466,11 @@ struct Sel {
 };
 
 __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a, RangeTable tb) {
+  __shared__ uint32_t s_lk[4][64], s_li[4][64];  // per-wave survivor scratch of Sel::filter_select
   const int lane = threadIdx.x & 63;
-  const int wave_in_block = threadIdx.x >> 6;
+  // the parent slot, its row and every window bound are the same for all lanes: say so (readfirstlane), and the
+  // per-row control flow below runs on the scalar unit with scalar loads instead of 64-bit vector arithmetic
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t waves_total = (int64_t)gridDim.x * 4;
   for (int64_t p = (int64_t)blockIdx.x * 4 + wave_in_block; p < a.n_parents; p += waves_total) {
     uint32_t v, ksum;
@@ -433,7 +497,7 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a, RangeTable tb
     {
       Sel<true> fast;
       fast.init(f, lane, a.proxy_drop);
-      fast.select(tb, deg, base, in_table);
+      fast.select(tb, deg, base, in_table, s_lk[wave_in_block], s_li[wave_in_block]);
       sel_idx = fast.idx;
       if (fast.tie) {  // a 32-bit proxy tie touched the result (about once per 10^7 rows): redo exactly
         Sel<false> exact;
