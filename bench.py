@@ -11,11 +11,14 @@ pairs bidirectionalised, D=100 fp32), fanout [25,10], B=1024, GraphSAGE 100->256
 §8(d) C2).  MAG240M (the config the metric is quoted on) does not fit one GPU (375 GB of features),
 so per the contract the N=1 line is the largest single-GPU configuration.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--group G] [--small]
 
-Steps are independent batches, so they are pipelined over S HIP streams (one library ctx + one host
-thread per stream, all sharing the HBM-resident graph): while one batch is in its MFMA projection
-another is sampling.  Exactly K steps are timed in total.
+Steps are independent batches.  One library call takes G consecutive batches through ONE set of ~28 launches
+(gigl_sage_plan_set_groups: every batch keeps its own union graph, rows are bit-identical to G single-batch
+calls — tests/test_gpu_groups.py), because at B=1024 a launch set costs ~0.07 ms of dispatch floor against
+~0.08 ms of work per batch; calls are pipelined over S HIP streams (one library ctx + one host thread per
+stream, all sharing the HBM-resident graph).  Exactly K steps (K*B roots) are timed in total; a remainder of
+K mod G steps runs batch by batch.
 N>1: one process per GPU (torch.distributed, RCCL); every rank holds a replica of the graph and takes
 its own root batches — the path shards by roots with no data-path collective ("weak" scaling);
 time = max over ranks, value = total edges of all ranks / that time.
@@ -113,12 +116,12 @@ def build_workload(eng, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1600)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--fanouts", type=str, default="25,10")
-    ap.add_argument("--streams", type=int, default=8)
-    ap.add_argument("--group", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=2)
+    ap.add_argument("--group", type=int, default=16,
                     help="batches per library call: G independent batches of B roots share one set of launches "
                          "(each keeps its own union graph; results are bit-identical to G single-batch calls)")
     ap.add_argument("--small", action="store_true", help="200k-node graph (debug)")

@@ -405,26 +405,59 @@ struct Sel {
       scan_direct(1, deg, base);
       return;
     }
-    // pass A of the greedy aligned decomposition of [b_first, b_last): find the largest block.  Its sorted
-    // top-64 list becomes the initial best list, so the threshold is tight before anything is inserted.
-    int best_l = -1;
-    uint64_t best_b = 0;
-    for (uint64_t b = b_first; b < b_last;) {
-      int l = 0;
-      while (l + 1 < tb.levels) {
-        const int sh = TBL_FAN_SHIFT * (l + 1);
-        if ((b & ((1ull << sh) - 1)) != 0 || b + (1ull << sh) > b_last || (int64_t)(b >> sh) >= tb.nblocks[l + 1])
-          break;
-        ++l;
-      }
-      if (l > best_l) {
-        best_l = l;
-        best_b = b;
-      }
-      b += 1ull << (TBL_FAN_SHIFT * l);
-    }
+    // Aligned decomposition of the block range [b_first, b_last), level by level (the segment-tree cover): at
+    // level l the blocks left of the next 16-alignment and right of the last one are taken (<= 15 each), the
+    // aligned middle moves up a level.  O(levels) scalar work; the lists are enumerated level-ascending, left
+    // then right, so that the LAST list is a block of the highest level reached.  That one seeds the best
+    // list (its sorted top-64 makes the threshold tight before anything is inserted); list x < n_lists-1 is
+    // located by lane arithmetic below.
+    uint32_t ls[TBL_MAX_LEVELS], ln[TBL_MAX_LEVELS], rs[TBL_MAX_LEVELS], rn[TBL_MAX_LEVELS];
+    uint32_t n_lists = 0;
     {
-      const int64_t ent = (tb.lvl_off[best_l] + (int64_t)(best_b >> (TBL_FAN_SHIFT * best_l))) * TBL_TOPK;
+      uint32_t lo = (uint32_t)b_first, hi = (uint32_t)b_last;
+#pragma unroll
+      for (int l = 0; l < TBL_MAX_LEVELS; ++l) {
+        uint32_t nl = 0, nr = 0;
+        if (l < tb.levels && lo < hi) {
+          if (l == tb.levels - 1) {
+            nl = hi - lo;
+          } else {
+            nl = min((16u - (lo & 15u)) & 15u, hi - lo);
+            nr = min(hi & 15u, hi - lo - nl);
+          }
+        }
+        ls[l] = lo;
+        ln[l] = nl;
+        rs[l] = hi - nr;
+        rn[l] = nr;
+        n_lists += nl + nr;
+        lo = (lo + nl) >> TBL_FAN_SHIFT;
+        hi = (hi - nr) >> TBL_FAN_SHIFT;
+      }
+    }
+    // entry index of the first element of list x (enumeration order above); wave-uniform or per-lane x
+    // (global block ids fit 32 bits: <= 2^24 level-0 blocks plus 1/15 of that above them)
+    auto list_entry = [&](uint32_t x) -> int64_t {
+      uint32_t gb = 0;
+      bool found = false;
+#pragma unroll
+      for (int l = 0; l < TBL_MAX_LEVELS; ++l) {
+        const uint32_t off = (uint32_t)tb.lvl_off[l];
+        if (!found && x < ln[l]) {
+          gb = off + ls[l] + x;
+          found = true;
+        }
+        x -= ln[l];  // (wraps once found: harmless)
+        if (!found && x < rn[l]) {
+          gb = off + rs[l] + x;
+          found = true;
+        }
+        x -= rn[l];
+      }
+      return found ? (int64_t)gb * TBL_TOPK : (int64_t)-1;
+    };
+    {
+      const int64_t ent = list_entry(n_lists - 1);
       key = table_key(tb, ent + lane);
       idx = tb.js[ent + lane] - base;  // position i = j - base
       if constexpr (FAST) {  // equal proxies inside the seed list (adjacent: it is sorted by the full key)
@@ -433,29 +466,10 @@ struct Sel {
       }
       refresh_threshold();
     }
-    // pass B: the other lists, 64 per batch, list q of a batch owned by lane q, merged by rounds
-    uint64_t b = b_first;
-    int q = 0;
-    int64_t my_ent = -1;
-    while (b < b_last) {
-      int l = 0;
-      while (l + 1 < tb.levels) {
-        const int sh = TBL_FAN_SHIFT * (l + 1);
-        if ((b & ((1ull << sh) - 1)) != 0 || b + (1ull << sh) > b_last || (int64_t)(b >> sh) >= tb.nblocks[l + 1])
-          break;
-        ++l;
-      }
-      if (b != best_b) {
-        const int64_t ent = (tb.lvl_off[l] + (int64_t)(b >> (TBL_FAN_SHIFT * l))) * TBL_TOPK;
-        if (lane == q) my_ent = ent;
-        ++q;
-      }
-      b += 1ull << (TBL_FAN_SHIFT * l);
-      if (q == 64 || (b >= b_last && q > 0)) {
-        merge_lists(tb, my_ent, base);
-        q = 0;
-        my_ent = -1;
-      }
+    // the other lists, 64 per batch, list q of a batch owned by lane q, merged by rounds
+    for (uint32_t x0 = 0; x0 + 1 < n_lists; x0 += 64) {
+      const uint32_t x = x0 + (uint32_t)lane;
+      merge_lists(tb, x + 1 < n_lists ? list_entry(x) : -1, base);
     }
     // head: positions before the first block boundary; tail: after the last full block
     const int64_t head_hi = (int64_t)((b_first << TBL_S0_SHIFT) - 1 - base);  // position of the last head j

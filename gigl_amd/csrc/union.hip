@@ -344,23 +344,59 @@ __global__ void edge_dedup_count_kernel(UnionArgs a, unsigned long long* ekeys, 
 }
 
 // exclusive scan of rowcnt[0..n) -> rowptr[0..n], rowend[i] = rowptr[i] (fill cursor); rows >= n get
-// rowptr = rowend = total.  n = nodes that can have in-edges (levels < hops).  One workgroup.
+// rowptr = rowend = total.  n = nodes that can have in-edges (levels < hops).
+// SCAN_BLOCKS workgroups, each owning one contiguous chunk of the rows: chunk sums are published, ONE grid
+// barrier (arrival counter; 16 workgroups are always co-resident, also with 16 streams doing the same), then
+// every workgroup scans its chunk starting from the sum of the chunks before it.  `sync` = {partials[16],
+// arrival counter}, zeroed per batch by init_scratch.
+constexpr int SCAN_BLOCKS = 16;
 __global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* rowcnt, int32_t* meta, int hops,
                                                         int64_t cap_nodes, int32_t* rowptr, int32_t* rowend,
-                                                        int tail_here) {
+                                                        int tail_here, int32_t* sync) {
   __shared__ int32_t s_w[16];
   __shared__ int32_t s_carry;
+  __shared__ int32_t s_total;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int32_t n = meta[GIGL_META_LEVEL0 + hops - 1];
   const int32_t n_nodes = meta[GIGL_META_N_NODES];
-  if (tid == 0) s_carry = 0;
-  __syncthreads();
   constexpr int PER = 8;  // consecutive rows per thread: 8192 rows per pass of the workgroup
-  for (int32_t base = 0; base < n; base += 1024 * PER) {
+  const int32_t chunk = ((n + SCAN_BLOCKS - 1) / SCAN_BLOCKS + 1024 * PER - 1) / (1024 * PER) * (1024 * PER);
+  const int32_t c_lo = min(n, (int32_t)blockIdx.x * chunk), c_hi = min(n, c_lo + chunk);
+  {  // chunk sum -> partials[blockIdx], arrive, wait for everybody, carry = sum of the chunks before mine
+    int32_t v = 0;
+    for (int32_t i = c_lo + tid; i < c_hi; i += 1024) v += rowcnt[i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) s_w[w] = v;
+    __syncthreads();
+    if (tid == 0) {
+      int32_t s = 0;
+      for (int q = 0; q < 16; ++q) s += s_w[q];
+      __hip_atomic_store(&sync[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&sync[SCAN_BLOCKS], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t spins = 0;
+      while (__hip_atomic_load(&sync[SCAN_BLOCKS], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < SCAN_BLOCKS) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1ll << 26)) {  // (seconds) never expected: report instead of hanging the device
+          atomicAdd(&meta[GIGL_META_OVERFLOW], 1);
+          break;
+        }
+      }
+      int32_t before = 0, total = 0;
+      for (int q = 0; q < SCAN_BLOCKS; ++q) {
+        const int32_t pq = __hip_atomic_load(&sync[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (q < (int)blockIdx.x) before += pq;
+        total += pq;
+      }
+      s_carry = before;
+      s_total = total;
+    }
+    __syncthreads();
+  }
+  for (int32_t base = c_lo; base < c_hi; base += 1024 * PER) {
     const int32_t i0 = base + tid * PER;
     int32_t c[PER];
 #pragma unroll
-    for (int q = 0; q < PER; ++q) c[q] = (i0 + q) < n ? rowcnt[i0 + q] : 0;
+    for (int q = 0; q < PER; ++q) c[q] = (i0 + q) < c_hi ? rowcnt[i0 + q] : 0;
     int32_t v = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) v += c[q];
@@ -377,7 +413,7 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* rowcnt, i
     int32_t ex = carry + wave_off + incl - v;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-      if (i0 + q < n) {
+      if (i0 + q < c_hi) {
         rowptr[i0 + q] = ex;
         rowend[i0 + q] = ex;
       }
@@ -387,7 +423,8 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* rowcnt, i
     if (tid == 1023) s_carry = carry + wave_off + incl;
     __syncthreads();
   }
-  const int32_t total = s_carry;
+  if (blockIdx.x != 0) return;
+  const int32_t total = s_total;
   if (tail_here)  // no edge_fill launch follows (a batch without slots): close the row arrays here
     for (int64_t i = (int64_t)n + tid; i <= n_nodes && i <= cap_nodes; i += 1024) {
       rowptr[i] = total;
@@ -719,8 +756,8 @@ int32_t gigl_union_build_groups(gigl_ctx* ctx, const uint32_t* roots, const gigl
     // every node of level < hops may be a row (also leaf-only ones reached under a root parent)
     hipLaunchKernelGGL(edge_dedup_count_kernel, grid(T), dim3(TB), 0, st, a, ekeys, (uint32_t)(ecap - 1), winner,
                        pairs, rowcnt, out->root_local);
-    hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, st, rowcnt, out->meta, hops, out->cap_nodes,
-                       out->rowptr, out->rowend, E > 0 ? 0 : 1);
+    hipLaunchKernelGGL(row_scan_kernel, dim3(SCAN_BLOCKS), dim3(1024), 0, st, rowcnt, out->meta, hops,
+                       out->cap_nodes, out->rowptr, out->rowend, E > 0 ? 0 : 1, big_count + 8);
     if (E > 0)
       hipLaunchKernelGGL(edge_fill_kernel, grid(E), dim3(TB), 0, st, a, winner, pairs, out->meta, out->rowptr,
                          out->rowend, out->col);
