@@ -37,11 +37,11 @@ constexpr int BIG_ROW_CAP = 16384;  // LDS bitonic capacity (64 KiB of int32)
 // one open-addressing slot: everything the passes need about a node sits in ONE 16-byte entry, so a probe
 // costs one random memory access instead of one per attribute array
 struct __attribute__((aligned(16))) Slot {
-  uint32_t key;       // node id, GIGL_INVALID = empty
-  int32_t lid;        // local id (assign)
-  uint32_t firstpos;  // smallest stream position holding the node   } read together (8-byte aligned pair)
-  int32_t level;      // BFS level in the batch's union graph        }
+  unsigned long long kf;  // (node id << 32) | smallest stream position holding the node; ~0 = empty
+  int32_t level;          // BFS level in the batch's union graph (starts at hops)
+  int32_t lid;            // local id (assign)
 };
+__device__ __forceinline__ uint32_t slot_key(unsigned long long kf) { return (uint32_t)(kf >> 32); }
 
 struct UnionArgs {
   const uint32_t* roots;
@@ -79,61 +79,86 @@ __device__ __forceinline__ void locate(const UnionArgs& a, int64_t t, int& k, in
     return;
   }
   int kk = 0;
+  int64_t o = a.off[0];
 #pragma unroll
   for (int i = 1; i < GIGL_MAX_HOPS; ++i)
-    if (i < a.hops && t >= a.off[i]) kk = i;
+    if (i < a.hops && t >= a.off[i]) {
+      kk = i;
+      o = a.off[i];
+    }
   k = kk;
-  j = t - a.off[kk];
+  j = t - o;
+}
+
+// arr[k] for a kernel-argument array WITHOUT a dynamic index: indexing the by-value argument struct with a
+// run-time k makes the compiler spill the whole struct to scratch memory in every thread (168 B per thread in
+// insert_slots: measured 3x on the kernel); a chain of selects over constant indices stays in registers
+template <typename T, int N>
+__device__ __forceinline__ T pick(const T (&arr)[N], int k) {
+  T v = arr[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i)
+    if (k == i) v = arr[i];
+  return v;
 }
 
 // stream position -> (node id, hop k or -1 for roots, slot index j within the hop)
 __device__ __forceinline__ uint32_t stream_at(const UnionArgs& a, int64_t t, int& k, int64_t& j) {
   locate(a, t, k, j);
-  return k < 0 ? a.roots[j] : a.nbr[k][j];
+  return k < 0 ? a.roots[j] : pick(a.nbr, k)[j];
 }
 
 // first slot of the sub-table of the batch that stream slot (k, j) belongs to (0 when there is one batch)
 __device__ __forceinline__ uint32_t group_base(const UnionArgs& a, int k, int64_t j) {
   if (!a.grouped) return 0u;
-  const uint32_t g = k < 0 ? (uint32_t)j / a.group_roots : (uint32_t)j / a.gdiv[k];
+  const uint32_t g = (uint32_t)j / (k < 0 ? a.group_roots : pick(a.gdiv, k));
   return g * (a.mask + 1u);
 }
 
-// stream position of the destination (parent) of the occurrence at hop k, slot j
+// stream position of the destination (parent) of the occurrence at hop k, slot j (positions fit 31 bits)
 __device__ __forceinline__ int64_t parent_pos(const UnionArgs& a, int k, int64_t j) {
-  int64_t p = j / a.fan[k];
-  return k == 0 ? p : a.off[k - 1] + p;
+  const int64_t p = (int64_t)((uint32_t)j / (uint32_t)pick(a.fan, k));
+  return k == 0 ? p : pick(a.off, k - 1) + p;
 }
 
-// claim / find the slot of `id` in the sub-table starting at `base`; returns the global slot index
-__device__ __forceinline__ uint32_t table_insert(const UnionArgs& a, uint32_t base, uint32_t id) {
+// Claim / find the slot of `id` in the sub-table starting at `base` and fold stream position t into the
+// node's first position — in ONE 64-bit atomic for a first occurrence: the slot word is (key << 32 |
+// first position), so the claiming CAS deposits the position with the key, and a later occurrence of the same
+// key lowers the word with a 64-bit atomicMin (equal high halves: the min picks the smaller position).
+// Scattered atomics are what bounds the insert kernels; this makes it ~1.1 instead of 2 per occurrence.
+// Returns the global slot index.
+__device__ __forceinline__ uint32_t table_insert(const UnionArgs& a, uint32_t base, uint32_t id, uint32_t t) {
+  const unsigned long long mine = ((unsigned long long)id << 32) | t;
   uint32_t s = hash_u32(id) & a.mask;
   while (true) {
-    uint32_t prev = atomicCAS(&a.slots[base + s].key, GIGL_INVALID, id);
-    if (prev == GIGL_INVALID || prev == id) return base + s;
-    s = (s + 1) & a.mask;
-  }
-}
-
-// slot of `id` or -1 (read-only probe; keys written by an EARLIER kernel are always found)
-__device__ __forceinline__ int32_t table_find(const UnionArgs& a, uint32_t base, uint32_t id) {
-  uint32_t s = hash_u32(id) & a.mask;
-  while (true) {
-    uint32_t k = __hip_atomic_load(&a.slots[base + s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (k == id) return (int32_t)(base + s);
-    if (k == GIGL_INVALID) return -1;
+    unsigned long long* w = &a.slots[base + s].kf;
+    // look before the read-modify-write: a hub node sits in thousands of positions of one batch, and same-address
+    // atomics are serialised by the memory system, while plain reads of a hot word are not.  Once the hub is in
+    // the table with a smaller position (almost always: blocks run in stream order) its occurrences cost a load.
+    // (an ordinary cached load: a stale view is either "empty" -> the CAS decides, or the same key with an older,
+    // larger position -> at worst a redundant atomicMin)
+    unsigned long long prev = *(const volatile unsigned long long*)w;
+    if (prev == ~0ULL) {
+      prev = atomicCAS(w, ~0ULL, mine);
+      if (prev == ~0ULL) return base + s;
+    }
+    if ((uint32_t)(prev >> 32) == id) {
+      if ((uint32_t)prev > t) atomicMin(w, mine);  // (positions only go down: prev <= t needs no update)
+      return base + s;
+    }
     s = (s + 1) & a.mask;
   }
 }
 
 // all per-batch table initialisation in one dispatch: empty edge keys (0xFF..), empty node slots
-// {INVALID, +inf position, +inf level, -}, zeros, meta
+// {INVALID key | +inf position, level = hops, -}, zeros, meta
 __global__ __launch_bounds__(256) void init_scratch_kernel(uint4* ff, int64_t ff_vec, uint4* slots, int64_t n_slots,
-                                                           int32_t* zeros, int64_t zero_words, int32_t* meta) {
+                                                           uint32_t hops, int32_t* zeros, int64_t zero_words,
+                                                           int32_t* meta) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint4 f4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-  const uint4 s4 = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0x7F7F7F7Fu);  // {key, lid, firstpos, level}
+  const uint4 s4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, hops, 0u);  // {kf lo = firstpos, kf hi = key, level, lid}
   for (int64_t i = t0; i < ff_vec; i += stride) ff[i] = f4;
   for (int64_t i = t0; i < n_slots; i += stride) slots[i] = s4;
   for (int64_t i = t0; i < zero_words; i += stride) zeros[i] = 0;
@@ -148,15 +173,17 @@ __global__ void insert_roots_kernel(UnionArgs a) {
     a.slot_of[t] = -1;
     return;
   }
-  uint32_t s = table_insert(a, group_base(a, -1, t), id);
-  atomicMin(&a.slots[s].firstpos, (uint32_t)t);
+  uint32_t s = table_insert(a, group_base(a, -1, t), id, (uint32_t)t);
   a.slots[s].level = 0;
   a.slot_of[t] = (int32_t)s;
 }
 
-__global__ void insert_slots_kernel(UnionArgs a) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + a.b;
-  if (t >= a.T) return;
+// stream positions [lo, hi): launched once for the hop-0 slots and once for all later hops, so that a hop-1
+// slot finds its parent's table slot in slot_of (written by the first launch) instead of probing for it.
+// A slot's level starts at `hops` (the deepest possible), so only shallower occurrences write it.
+__global__ void insert_slots_kernel(UnionArgs a, int64_t lo, int64_t hi) {
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x + lo;
+  if (t >= hi) return;
   int k;
   int64_t j;
   uint32_t id = stream_at(a, t, k, j);
@@ -164,21 +191,20 @@ __global__ void insert_slots_kernel(UnionArgs a) {
     a.slot_of[t] = -1;
     return;
   }
-  const uint32_t base = group_base(a, k, j);
-  uint32_t s = table_insert(a, base, id);
-  atomicMin(&a.slots[s].firstpos, (uint32_t)t);
+  uint32_t s = table_insert(a, group_base(a, k, j), id, (uint32_t)t);
   int32_t lvl;
   if (k == 0) {
     lvl = 1;
   } else if (k == 1) {
-    // parent = hop-0 slot node: level 0 iff it is a root (roots were inserted by the previous kernel)
-    uint32_t pid = a.nbr[0][j / a.fan[1]];
-    int32_t ps = table_find(a, base, pid);
-    lvl = (ps >= 0 && __hip_atomic_load(&a.slots[ps].level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) ? 1 : 2;
+    // parent = a hop-0 slot node, whose level is final since the previous launch: 0 iff it is a root
+    const int32_t ps = a.slot_of[parent_pos(a, 1, j)];
+    lvl = a.slots[ps].level == 0 ? 1 : 2;
   } else {
     lvl = k + 1;  // upper bound; relaxed below
   }
-  atomicMin(&a.slots[s].level, lvl);
+  if (lvl < a.hops &&  // (same look-before-atomic: levels only go down, a stale read only costs a redundant atomic)
+      *(const volatile int32_t*)&a.slots[s].level > lvl)
+    atomicMin(&a.slots[s].level, lvl);
   a.slot_of[t] = (int32_t)s;
 }
 
@@ -201,8 +227,8 @@ __device__ __forceinline__ int first_level(const UnionArgs& a, int64_t t) {
   if (t >= a.T) return -1;
   int32_t s = a.slot_of[t];
   if (s < 0) return -1;
-  const uint2 fl = *reinterpret_cast<const uint2*>(&a.slots[s].firstpos);  // {firstpos, level}
-  return fl.x == (uint32_t)t ? (int)fl.y : -1;
+  const uint4 q = *reinterpret_cast<const uint4*>(&a.slots[s]);  // {firstpos, key, level, lid}
+  return q.x == (uint32_t)t ? (int)q.z : -1;
 }
 
 // tile_counts[tile][l] = number of first occurrences of level l in the tile
@@ -290,7 +316,7 @@ __global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t*
     for (int ll = 0; ll < l; ++ll) id += s_total[ll];
     const int32_t s = a.slot_of[base + r * 256 + tid];
     a.slots[s].lid = id;
-    nodes[id] = a.slots[s].key;
+    nodes[id] = slot_key(a.slots[s].kf);
   }
   if (blockIdx.x == 0 && tid == 0) {
     int32_t cum = 0;
@@ -302,29 +328,47 @@ __global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t*
   }
 }
 
+// Lanes holding equal `key` in a contiguous run form a segment (every lane of the wave must call this).
+// total = flagged lanes of my segment, rank = flagged lanes before me in it, first = its first flagged lane
+// (or my own lane if it has none).
+__device__ __forceinline__ void seg_rank(uint32_t key, bool flag, int lane, int& total, int& rank, int& first) {
+  const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)~key, (int)key, 0x138 /* wave_shr:1 */, 0xF, 0xF,
+                                                              false);  // lane 0 keeps ~key: always a leader
+  const unsigned long long leaders = __ballot(prev != key);
+  const unsigned long long flags = __ballot(flag);
+  const unsigned long long upto = (2ull << lane) - 1ull;  // lanes <= me (lane 63: all ones)
+  const int start = 63 - __clzll((long long)(leaders & upto));
+  const unsigned long long above = leaders & ~upto;
+  const unsigned long long below_end = above ? ((1ull << (__ffsll((long long)above) - 1)) - 1ull) : ~0ull;
+  const unsigned long long seg = below_end & ~((1ull << start) - 1ull);
+  const unsigned long long fs = flags & seg;
+  total = __popcll(fs);
+  rank = __popcll(fs & ((1ull << lane) - 1ull));
+  first = fs ? __ffsll((long long)fs) - 1 : lane;
+}
+
 // edge dedup: the first occurrence to claim (dst_local, src_local) in the edge hash set is the edge's
 // "winner"; winners are counted per destination row.  Which occurrence wins is irrelevant (rows are
 // sorted afterwards).  A winner leaves its (dst_local, src_local) pair for edge_fill.  Threads t < b also
 // publish root_local.  The edge set has one sub-table of (emask+1) keys per batch, like the node table.
 __global__ void edge_dedup_count_kernel(UnionArgs a, unsigned long long* ekeys, uint32_t emask,
                                         uint8_t* winner, int2* pairs, int32_t* rowcnt, int32_t* root_local) {
-  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.T) return;
-  int32_t s = a.slot_of[t];
-  if (t < a.b) {
-    root_local[t] = s >= 0 ? a.slots[s].lid : -1;
-    return;
-  }
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool in = t < a.T;
+  const int32_t s = in ? a.slot_of[t] : -1;
+  if (in && t < a.b) root_local[t] = s >= 0 ? a.slots[s].lid : -1;
   bool win = false;
-  if (s >= 0) {
+  int32_t dl = 0, sl = 0;
+  if (in && t >= a.b && s >= 0) {
     int k;
     int64_t j;
     locate(a, t, k, j);
-    const int32_t dl = a.slots[a.slot_of[parent_pos(a, k, j)]].lid;
-    const int32_t sl = a.slots[s].lid;
+    dl = a.slots[a.slot_of[parent_pos(a, k, j)]].lid;
+    sl = a.slots[s].lid;
     const unsigned long long key = ((unsigned long long)(uint32_t)dl << 32) | (uint32_t)sl;
     unsigned long long* sub = ekeys;
-    if (a.grouped) sub += (uint64_t)((uint32_t)j / a.gdiv[k]) * (emask + 1u);
+    if (a.grouped) sub += (uint64_t)((uint32_t)j / pick(a.gdiv, k)) * (emask + 1u);
     uint32_t h = hash_u32((uint32_t)sl * 0x9E3779B1u ^ (uint32_t)dl) & emask;
     while (true) {
       unsigned long long prev = atomicCAS(&sub[h], ~0ULL, key);
@@ -335,12 +379,13 @@ __global__ void edge_dedup_count_kernel(UnionArgs a, unsigned long long* ekeys, 
       if (prev == key) break;
       h = (h + 1) & emask;
     }
-    if (win) {
-      atomicAdd(&rowcnt[dl], 1);
-      pairs[t - a.b] = make_int2(dl, sl);
-    }
+    if (win) pairs[t - a.b] = make_int2(dl, sl);
   }
-  winner[t - a.b] = win ? 1 : 0;
+  // the children of one parent sit in adjacent lanes: one atomicAdd per run of equal destinations
+  int total, rank, first;
+  seg_rank(win ? (uint32_t)dl : (0x80000000u | (uint32_t)lane), win, lane, total, rank, first);
+  if (win && rank == 0) atomicAdd(&rowcnt[dl], total);
+  if (in && t >= a.b) winner[t - a.b] = win ? 1 : 0;
 }
 
 // exclusive scan of rowcnt[0..n) -> rowptr[0..n], rowend[i] = rowptr[i] (fill cursor); rows >= n get
@@ -438,18 +483,25 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* rowcnt, i
 __global__ void edge_fill_kernel(UnionArgs a, const uint8_t* winner, const int2* pairs, const int32_t* meta,
                                  int32_t* rowptr, int32_t* rowend, int32_t* col) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int64_t t = e + a.b;
-  if (t >= a.T) return;
-  {
+  const int lane = threadIdx.x & 63;
+  const bool in = e + a.b < a.T;
+  if (in) {
     const int32_t n = meta[GIGL_META_LEVEL0 + a.hops - 1], n_nodes = meta[GIGL_META_N_NODES];
     const int32_t total = meta[GIGL_META_N_EDGES];
     const int64_t i = (int64_t)n + e;
     if (i < n_nodes) rowptr[i] = rowend[i] = total;
     if (e == 0) rowptr[n_nodes] = rowend[n_nodes] = total;
   }
-  if (!winner[e]) return;
-  const int2 p = pairs[e];  // (dst_local, src_local) left by edge_dedup_count
-  col[atomicAdd(&rowend[p.x], 1)] = p.y;
+  const bool w = in && winner[e];
+  int2 p = make_int2(0, 0);
+  if (w) p = pairs[e];  // (dst_local, src_local) left by edge_dedup_count
+  // one cursor bump per run of equal destinations (the children of one parent are adjacent lanes)
+  int total, rank, first;
+  seg_rank(w ? (uint32_t)p.x : (0x80000000u | (uint32_t)lane), w, lane, total, rank, first);
+  int32_t base = 0;
+  if (w && rank == 0) base = atomicAdd(&rowend[p.x], total);
+  base = __shfl(base, first, 64);
+  if (w) col[base + rank] = p.y;
 }
 
 // one wave per row: sort ascending in place (rows <= 64, values are unique); longer rows are queued
@@ -737,9 +789,11 @@ int32_t gigl_union_build_groups(gigl_ctx* ctx, const uint32_t* roots, const gigl
     gigl_prof_scope ps(ctx, GIGL_K_UNION_INSERT);
     // one launch initialises every table of this batch (instead of six memset dispatches)
     hipLaunchKernelGGL(init_scratch_kernel, dim3(1024), dim3(256), 0, st, (uint4*)ekeys, n_ekeys / 2, (uint4*)a.slots,
-                       n_slots, zeros, zero_words, out->meta);
+                       n_slots, (uint32_t)hops, zeros, zero_words, out->meta);
     hipLaunchKernelGGL(insert_roots_kernel, grid(b), dim3(TB), 0, st, a);
-    if (E > 0) hipLaunchKernelGGL(insert_slots_kernel, grid(E), dim3(TB), 0, st, a);
+    if (E > 0) hipLaunchKernelGGL(insert_slots_kernel, grid(a.off[1] - b), dim3(TB), 0, st, a, (int64_t)b, a.off[1]);
+    if (hops > 1 && T > a.off[1])
+      hipLaunchKernelGGL(insert_slots_kernel, grid(T - a.off[1]), dim3(TB), 0, st, a, a.off[1], T);
   }
   if (hops > 2 && E > 0) {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_RELAX);
