@@ -31,7 +31,7 @@ SYMBOLS = [
     "gigl_sage_plan_create", "gigl_sage_plan_set_weights", "gigl_sage_plan_buffers", "gigl_sage_plan_run",
     "gigl_sage_plan_destroy", "gigl_gather_mean_backward", "gigl_expand_frontier", "gigl_gcn_aggregate",
     "gigl_gat_aggregate", "gigl_gather_rows", "gigl_sage_plan_use_graph", "gigl_sage_plan_flush_profile",
-    "gigl_union_build_groups", "gigl_sage_plan_set_groups",
+    "gigl_union_build_groups", "gigl_sage_plan_set_groups", "gigl_records_capacity", "gigl_records_encode",
 ]
 
 KERNEL_IDS = {
@@ -61,6 +61,22 @@ class GiglUnion(C.Structure):
         ("cap_nodes", C.c_int64),
         ("cap_edges", C.c_int64),
     ]
+
+
+class GiglRecordOpts(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("trees_per_record", C.c_int32),
+        ("condensed_node_type", C.c_int32),
+        ("condensed_edge_type", C.c_int32),
+        ("tfrecord_frame", C.c_int32),
+        ("emit", C.c_void_p),
+        ("suffix", C.c_void_p),
+        ("suffix_off", C.c_void_p),
+    ]
+
+
+REC_ROOTED_NODE_NEIGHBORHOOD, REC_NODE_ANCHOR_LINK_PRED = 0, 1
 
 
 class GiglError(RuntimeError):
@@ -127,6 +143,8 @@ def load() -> C.CDLL:
         "gigl_gather_mean_backward": [vp, vp, i32, vp, vp, vp, vp, i64, vp],
         "gigl_expand_frontier": [vp, vp, vp, vp, i64, i32, i32, i32, i64, vp, vp],
         "gigl_gather_rows": [vp, vp, i32, i32, vp, vp, i64, vp],
+        "gigl_records_capacity": [P(i32), i32, i32, P(GiglRecordOpts), i64, i64, P(i64)],
+        "gigl_records_encode": [vp, vp, P(GiglTree), vp, P(GiglRecordOpts), i64, vp, i64, vp, vp],
         "gigl_gcn_aggregate": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, vp],
         "gigl_gat_aggregate": [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, vp],
     }

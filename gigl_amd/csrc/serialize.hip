@@ -1,0 +1,715 @@
+// serialize.hip — sampled trees -> serialized training-sample protos in TFRecord framing, on the device.
+//
+// Replaces the per-root assembly + hydration + proto encoding + record writing of the Spark sampler
+// (paths relative to the reference root):
+//   hydrateNodes / hydrateEdges / createSubgraph        scala/subgraph_sampler/src/main/scala/libs/task/pureSpark/
+//                                                        SGSPureSparkV1Task.scala:496-593, :671-820
+//   createNodeAnchorBasedLinkPredictionSubgraph         .../pureSpark/NodeAnchorBasedLinkPredictionTask.scala:146-312
+//   castToRootedNodeNeighborhoodProtoSchema             SGSPureSparkV1Task.scala:1019-1040
+//   TFRecordIO.writeDatasetToTfrecord                   scala/common/src/main/scala/utils/TFRecordIO.scala:53-69
+// Messages: proto/snapchat/research/gbml/graph_schema.proto:5-62 (Node, Edge, Graph),
+//           proto/snapchat/research/gbml/training_samples_schema.proto:16-43.
+//
+// Byte/integer work, HBM-bound: a record is ~ nodes*(4*D + 10) + edges*12 bytes and the feature payload of
+// every DISTINCT node of a root's neighbourhood is copied once from the resident table (the reference joins D
+// floats per sampled OCCURRENCE and dedups afterwards).
+//
+// One 256-thread workgroup per record, three passes over the same plan:
+//   size  : dedup the record's node stream (LDS hash set keyed by id, value = first stream position), sizes of
+//           the distinct nodes / edges, block scan -> byte offset of every item inside the record
+//   (one single-workgroup scan over the record sizes gives each record's offset in the output)
+//   write : same plan again (cheap: a few hundred ids), then headers by byte stores, feature payloads by
+//           funnel-shifted aligned dword stores (record offsets are arbitrary byte offsets), and finally the
+//           CRC-32C of the payload: 256 lanes each fold a chunk (slicing-by-4 tables in LDS) and the partial
+//           states are combined with x^(8*bytes_after) mod P.
+#include "common.h"
+
+#include <hip/hip_fp16.h>
+
+namespace {
+
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t CRC_POLY = 0x82F63B78u;  // CRC-32C (Castagnoli), reflected
+
+struct RecArgs {
+  const uint32_t* roots;  // [n_records * trees_per_record]
+  const uint32_t* nbr[GIGL_MAX_HOPS];
+  int32_t fan[GIGL_MAX_HOPS];
+  int32_t slots[GIGL_MAX_HOPS];  // slots per tree at hop k
+  int32_t hops;
+  int32_t trees;      // trees per record
+  int32_t tree_len;   // node-stream positions per tree = sum slots + 1
+  int32_t edge_len;   // edge-stream positions per tree = sum slots
+  int32_t kind;
+  int32_t node_type, edge_type;
+  int32_t frame;
+  const void* feat;
+  int32_t d, feat_dtype;
+  int64_t feat_n;
+  const uint8_t* emit;
+  const uint8_t* suffix;
+  const int64_t* suffix_off;
+  int64_t n_records;
+  uint32_t hash_cap;   // node hash entries (pow2)
+  uint32_t ehash_cap;  // edge hash entries (pow2; 0 when trees == 1: edges are distinct by construction)
+  uint32_t x2n[32];    // x^(2^k) mod P, reflected
+};
+
+__device__ __forceinline__ int vlen(uint32_t v) {
+  return v < (1u << 7) ? 1 : v < (1u << 14) ? 2 : v < (1u << 21) ? 3 : v < (1u << 28) ? 4 : 5;
+}
+__device__ __forceinline__ uint8_t* put_varint(uint8_t* p, uint64_t v) {
+  while (v >= 128) {
+    *p++ = (uint8_t)(v | 0x80);
+    v >>= 7;
+  }
+  *p++ = (uint8_t)v;
+  return p;
+}
+
+// Node message body length (graph_schema.proto:5-12): node_id elided when 0 (proto3 scalar), condensed_node_type
+// is `optional` (explicit presence), feature_values packed
+__device__ __forceinline__ uint32_t node_body_len(const RecArgs& a, uint32_t id) {
+  uint32_t n = 0;
+  if (id) n += 1 + vlen(id);
+  if (a.node_type >= 0) n += 1 + vlen((uint32_t)a.node_type);
+  if (a.d > 0) n += 1 + vlen(4u * (uint32_t)a.d) + 4u * (uint32_t)a.d;
+  return n;
+}
+__device__ __forceinline__ uint32_t edge_body_len(const RecArgs& a, uint32_t s, uint32_t d) {
+  uint32_t n = 0;
+  if (s) n += 1 + vlen(s);
+  if (d) n += 1 + vlen(d);
+  if (a.edge_type >= 0) n += 1 + vlen((uint32_t)a.edge_type);
+  return n;
+}
+__device__ __forceinline__ uint32_t field_len(uint32_t body) { return 1 + vlen(body) + body; }
+
+// node id at stream position q of record r (NONE = empty slot)
+__device__ __forceinline__ uint32_t stream_node(const RecArgs& a, int64_t r, uint32_t q) {
+  const uint32_t tt = q / (uint32_t)a.tree_len;
+  uint32_t local = q - tt * (uint32_t)a.tree_len;
+  const int64_t t = r * a.trees + tt;
+  const uint32_t root = a.roots[t];
+  if (root == NONE) return NONE;
+  for (int k = 0; k < a.hops; ++k) {
+    if (local < (uint32_t)a.slots[k]) return a.nbr[k][t * a.slots[k] + local];
+    local -= (uint32_t)a.slots[k];
+  }
+  return root;
+}
+// edge at edge-stream position q of record r: src NONE = no edge
+__device__ __forceinline__ void stream_edge(const RecArgs& a, int64_t r, uint32_t q, uint32_t& s, uint32_t& d) {
+  const uint32_t tt = q / (uint32_t)a.edge_len;
+  uint32_t local = q - tt * (uint32_t)a.edge_len;
+  const int64_t t = r * a.trees + tt;
+  const uint32_t root = a.roots[t];
+  s = d = NONE;
+  if (root == NONE) return;
+  for (int k = 0; k < a.hops; ++k) {
+    if (local < (uint32_t)a.slots[k]) {
+      s = a.nbr[k][t * a.slots[k] + local];
+      d = k == 0 ? root : a.nbr[k - 1][t * a.slots[k - 1] + local / (uint32_t)a.fan[k]];
+      return;
+    }
+    local -= (uint32_t)a.slots[k];
+  }
+}
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads = 4 waves); returns the exclusive prefix,
+// total through `total`.  s_w: 8 uint32 of LDS.
+__device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* s_w, uint32_t& total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  __syncthreads();
+  if (lane == 63) s_w[w] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int i = 0; i < w; ++i) base += s_w[i];
+  total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  return base + inc - v;
+}
+
+// The per-record plan, kept in LDS.
+struct Plan {
+  uint32_t* node_off;   // [n_s]  byte offset of the node's field inside the Graph body, NONE = duplicate / empty
+  uint32_t* uniq;       // [n_s]  stream positions of the distinct nodes, in order
+  uint32_t* edge_off;   // [n_e]  byte offset inside the edge region, NONE = duplicate / empty
+  uint32_t n_uniq, nodes_bytes, edges_bytes;
+};
+
+// builds the plan of record r.  LDS: hkeys/hpos = node hash (a.hash_cap entries), ekeys/epos = edge hash.
+__device__ void build_plan(const RecArgs& a, int64_t r, Plan& pl, uint32_t* hkeys, uint32_t* hpos,
+                           unsigned long long* ekeys, uint32_t* epos, uint32_t* s_w) {
+  const uint32_t n_s = (uint32_t)(a.trees * a.tree_len), n_e = (uint32_t)(a.trees * a.edge_len);
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < a.hash_cap; i += 256) {
+    hkeys[i] = NONE;
+    hpos[i] = NONE;
+  }
+  for (uint32_t i = tid; i < a.ehash_cap; i += 256) {
+    ekeys[i] = ~0ull;
+    epos[i] = NONE;
+  }
+  __syncthreads();
+  // first occurrence of every id in stream order
+  for (uint32_t q = tid; q < n_s; q += 256) {
+    const uint32_t id = stream_node(a, r, q);
+    if (id == NONE) continue;
+    uint32_t h = hash32(id) & (a.hash_cap - 1);
+    for (;;) {
+      const uint32_t prev = atomicCAS(&hkeys[h], NONE, id);
+      if (prev == NONE || prev == id) break;
+      h = (h + 1) & (a.hash_cap - 1);
+    }
+    atomicMin(&hpos[h], q);
+  }
+  if (a.ehash_cap) {
+    for (uint32_t q = tid; q < n_e; q += 256) {
+      uint32_t s, d;
+      stream_edge(a, r, q, s, d);
+      if (s == NONE) continue;
+      const unsigned long long key = ((unsigned long long)s << 32) | d;
+      uint32_t h = hash32(s * 0x9E3779B1u ^ hash32(d)) & (a.ehash_cap - 1);
+      for (;;) {
+        const unsigned long long prev = atomicCAS(&ekeys[h], ~0ull, key);
+        if (prev == ~0ull || prev == key) break;
+        h = (h + 1) & (a.ehash_cap - 1);
+      }
+      atomicMin(&epos[h], q);
+    }
+  }
+  __syncthreads();
+  // nodes: sizes of first occurrences, scanned in stream order (thread i owns a contiguous run)
+  {
+    const uint32_t per = (n_s + 255) / 256, lo = min(tid * per, n_s), hi = min(lo + per, n_s);
+    uint32_t bytes = 0, cnt = 0;
+    for (uint32_t q = lo; q < hi; ++q) {
+      const uint32_t id = stream_node(a, r, q);
+      bool first = false;
+      if (id != NONE) {
+        uint32_t h = hash32(id) & (a.hash_cap - 1);
+        while (hkeys[h] != id) h = (h + 1) & (a.hash_cap - 1);
+        first = hpos[h] == q;
+      }
+      pl.node_off[q] = first ? field_len(node_body_len(a, id)) : NONE;  // size for now
+      if (first) {
+        bytes += pl.node_off[q];
+        ++cnt;
+      }
+    }
+    uint32_t tot_b, tot_c;
+    uint32_t off_b = block_exscan(bytes, s_w, tot_b);
+    uint32_t off_c = block_exscan(cnt, s_w + 4, tot_c);
+    for (uint32_t q = lo; q < hi; ++q) {
+      const uint32_t sz = pl.node_off[q];
+      if (sz != NONE) {
+        pl.node_off[q] = off_b;
+        pl.uniq[off_c++] = q;
+        off_b += sz;
+      }
+    }
+    pl.nodes_bytes = tot_b;
+    pl.n_uniq = tot_c;
+  }
+  // edges
+  {
+    const uint32_t per = (n_e + 255) / 256, lo = min(tid * per, n_e), hi = min(lo + per, n_e);
+    uint32_t bytes = 0;
+    for (uint32_t q = lo; q < hi; ++q) {
+      uint32_t s, d;
+      stream_edge(a, r, q, s, d);
+      bool first = s != NONE;
+      if (first && a.ehash_cap) {
+        const unsigned long long key = ((unsigned long long)s << 32) | d;
+        uint32_t h = hash32(s * 0x9E3779B1u ^ hash32(d)) & (a.ehash_cap - 1);
+        while (ekeys[h] != key) h = (h + 1) & (a.ehash_cap - 1);
+        first = epos[h] == q;
+      }
+      pl.edge_off[q] = first ? field_len(edge_body_len(a, s, d)) : NONE;
+      if (first) bytes += pl.edge_off[q];
+    }
+    uint32_t tot_b;
+    uint32_t off_b = block_exscan(bytes, s_w, tot_b);
+    for (uint32_t q = lo; q < hi; ++q) {
+      const uint32_t sz = pl.edge_off[q];
+      if (sz != NONE) {
+        pl.edge_off[q] = off_b;
+        off_b += sz;
+      }
+    }
+    pl.edges_bytes = tot_b;
+  }
+  __syncthreads();
+}
+
+// sizes of the fixed parts of record r (uniform over the workgroup)
+struct Layout {
+  uint32_t root_id, root_body, graph_body, pos_bytes;
+  uint64_t suffix_len, payload;
+};
+__device__ __forceinline__ Layout layout_of(const RecArgs& a, int64_t r, const Plan& pl) {
+  Layout L;
+  L.root_id = a.roots[r * a.trees];
+  L.root_body = node_body_len(a, L.root_id);
+  L.graph_body = pl.nodes_bytes + pl.edges_bytes;
+  L.pos_bytes = 0;
+  if (a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED)
+    for (int tt = 1; tt < a.trees; ++tt) {
+      const uint32_t p = a.roots[r * a.trees + tt];
+      if (p != NONE) L.pos_bytes += field_len(edge_body_len(a, L.root_id, p));
+    }
+  L.suffix_len = a.suffix_off ? (uint64_t)(a.suffix_off[r + 1] - a.suffix_off[r]) : 0;
+  L.payload = (uint64_t)field_len(L.root_body) + field_len(L.graph_body) + L.pos_bytes + L.suffix_len;
+  return L;
+}
+
+extern __shared__ __align__(16) unsigned char s_dyn[];
+
+// carve the dynamic LDS (layout shared by both kernels)
+__device__ __forceinline__ void carve(const RecArgs& a, Plan& pl, uint32_t*& hkeys, uint32_t*& hpos,
+                                      unsigned long long*& ekeys, uint32_t*& epos, uint32_t*& crc_t) {
+  const uint32_t n_s = (uint32_t)(a.trees * a.tree_len), n_e = (uint32_t)(a.trees * a.edge_len);
+  unsigned char* p = s_dyn;
+  ekeys = (unsigned long long*)p;
+  p += (size_t)a.ehash_cap * 8;
+  epos = (uint32_t*)p;
+  p += (size_t)a.ehash_cap * 4;
+  hkeys = (uint32_t*)p;
+  p += (size_t)a.hash_cap * 4;
+  hpos = (uint32_t*)p;
+  p += (size_t)a.hash_cap * 4;
+  pl.node_off = (uint32_t*)p;
+  p += (size_t)n_s * 4;
+  pl.uniq = (uint32_t*)p;
+  p += (size_t)n_s * 4;
+  pl.edge_off = (uint32_t*)p;
+  p += (size_t)n_e * 4;
+  crc_t = (uint32_t*)p;  // [4][256] (write kernel only)
+}
+
+size_t lds_bytes(const RecArgs& a, bool with_crc) {
+  const size_t n_s = (size_t)a.trees * a.tree_len, n_e = (size_t)a.trees * a.edge_len;
+  return (size_t)a.ehash_cap * 12 + (size_t)a.hash_cap * 8 + n_s * 8 + n_e * 4 + (with_crc ? 4096 : 0);
+}
+
+__global__ __launch_bounds__(256) void record_size_kernel(RecArgs a, int64_t* rec_size) {
+  __shared__ uint32_t s_w[8];
+  const int64_t r = blockIdx.x;
+  if (a.emit && !a.emit[r]) {
+    if (threadIdx.x == 0) rec_size[r] = 0;
+    return;
+  }
+  Plan pl;
+  uint32_t *hkeys, *hpos, *epos, *crc_t;
+  unsigned long long* ekeys;
+  carve(a, pl, hkeys, hpos, ekeys, epos, crc_t);
+  build_plan(a, r, pl, hkeys, hpos, ekeys, epos, s_w);
+  if (threadIdx.x == 0) {
+    const Layout L = layout_of(a, r, pl);
+    rec_size[r] = (int64_t)L.payload + (a.frame ? 16 : 0);
+  }
+}
+
+// exclusive scan of the record sizes (one workgroup); status = 1 when the output does not fit
+__global__ __launch_bounds__(1024) void record_scan_kernel(const int64_t* rec_size, int64_t n, int64_t cap,
+                                                           int64_t* rec_off, int32_t* status) {
+  __shared__ int64_t s_w[16];
+  __shared__ int64_t s_run;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_run = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const int64_t v = i < n ? rec_size[i] : 0;
+    int64_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int64_t u = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int64_t pre = s_run;
+    for (int j = 0; j < w; ++j) pre += s_w[j];
+    if (i < n) rec_off[i] = pre + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_run = pre + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    rec_off[n] = s_run;
+    *status = s_run > cap ? 1 : 0;
+  }
+}
+
+// feature row element k of node `id` as the fp32 bit pattern the proto carries
+__device__ __forceinline__ uint32_t feat_word(const RecArgs& a, uint32_t id, uint32_t k) {
+  if ((int64_t)id >= a.feat_n) return 0u;  // id outside the table: zeros (never happens for a consistent ingest)
+  if (a.feat_dtype == GIGL_DTYPE_F32) return ((const uint32_t*)a.feat)[(int64_t)id * a.d + k];
+  return __float_as_uint(__half2float(((const __half*)a.feat)[(int64_t)id * a.d + k]));
+}
+
+// one wave writes a Node field (tag `tag`) at p: header by lane 0, the packed float payload by all lanes with
+// aligned dword stores (p is an arbitrary byte address: funnel-shift two source words per output word)
+__device__ __forceinline__ void write_node(const RecArgs& a, uint8_t* p, uint8_t tag, uint32_t id, int lane) {
+  const uint32_t body = node_body_len(a, id);
+  uint32_t hdr = 1 + vlen(body);
+  if (id) hdr += 1 + vlen(id);
+  if (a.node_type >= 0) hdr += 1 + vlen((uint32_t)a.node_type);
+  if (a.d > 0) hdr += 1 + vlen(4u * (uint32_t)a.d);
+  if (lane == 0) {
+    uint8_t* q = p;
+    *q++ = tag;
+    q = put_varint(q, body);
+    if (id) {
+      *q++ = 0x08;
+      q = put_varint(q, id);
+    }
+    if (a.node_type >= 0) {
+      *q++ = 0x10;
+      q = put_varint(q, (uint32_t)a.node_type);
+    }
+    if (a.d > 0) {
+      *q++ = 0x1A;
+      q = put_varint(q, 4u * (uint32_t)a.d);
+    }
+  }
+  if (a.d <= 0) return;
+  uint8_t* dst = p + hdr;
+  const uint32_t D = (uint32_t)a.d;
+  const uint32_t rr = (uint32_t)((uintptr_t)dst & 3u);
+  if (rr == 0) {
+    uint32_t* o = (uint32_t*)dst;
+    for (uint32_t k = lane; k < D; k += 64) o[k] = feat_word(a, id, k);
+    return;
+  }
+  uint32_t* o = (uint32_t*)(dst - rr);
+  const uint32_t sh = 8u * rr;
+  for (uint32_t k = lane; k <= D; k += 64) {
+    const uint32_t prev = k > 0 ? feat_word(a, id, k - 1) : 0u;
+    const uint32_t cur = k < D ? feat_word(a, id, k) : 0u;
+    const uint32_t v = (prev >> (32u - sh)) | (cur << sh);
+    if (k == 0) {
+      for (uint32_t b = rr; b < 4; ++b) ((uint8_t*)o)[b] = (uint8_t)(v >> (8u * b));
+    } else if (k == D) {
+      for (uint32_t b = 0; b < rr; ++b) ((uint8_t*)(o + k))[b] = (uint8_t)(v >> (8u * b));
+    } else {
+      o[k] = v;
+    }
+  }
+}
+
+__device__ __forceinline__ uint8_t* write_edge(const RecArgs& a, uint8_t* p, uint8_t tag, uint32_t s, uint32_t d) {
+  *p++ = tag;
+  *p++ = (uint8_t)edge_body_len(a, s, d);  // <= 18 < 128: one byte
+  if (s) {
+    *p++ = 0x08;
+    p = put_varint(p, s);
+  }
+  if (d) {
+    *p++ = 0x10;
+    p = put_varint(p, d);
+  }
+  if (a.edge_type >= 0) {
+    *p++ = 0x18;
+    p = put_varint(p, (uint32_t)a.edge_type);
+  }
+  return p;
+}
+
+// ---- CRC-32C pieces (reflected domain: bit 31 of a word is the coefficient of x^0)
+__device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b) {
+  uint32_t m = 1u << 31, p = 0;
+  for (;;) {
+    if (a & m) {
+      p ^= b;
+      if ((a & (m - 1)) == 0) break;
+    }
+    m >>= 1;
+    b = (b & 1u) ? (b >> 1) ^ CRC_POLY : b >> 1;
+  }
+  return p;
+}
+// x^(8*n) mod P
+__device__ __forceinline__ uint32_t x8n_modp(const RecArgs& a, uint64_t n) {
+  uint32_t p = 1u << 31;
+  int k = 3;
+  while (n) {
+    if (n & 1) p = multmodp(a.x2n[k & 31], p);
+    n >>= 1;
+    ++k;
+  }
+  return p;
+}
+__device__ __forceinline__ uint32_t crc_byte(const uint32_t* t, uint32_t c, uint32_t b) {
+  return t[(c ^ b) & 0xFF] ^ (c >> 8);
+}
+__device__ __forceinline__ uint32_t crc_word(const uint32_t* t, uint32_t c, uint32_t w) {
+  c ^= w;
+  return t[768 + (c & 0xFF)] ^ t[512 + ((c >> 8) & 0xFF)] ^ t[256 + ((c >> 16) & 0xFF)] ^ t[c >> 24];
+}
+__device__ __forceinline__ uint32_t mask_crc(uint32_t c) { return ((c >> 15) | (c << 17)) + 0xA282EAD8u; }
+
+__global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int64_t* rec_off,
+                                                           const int32_t* status, uint8_t* out) {
+  __shared__ uint32_t s_w[8];
+  __shared__ uint32_t s_x[4];
+  if (*status != 0) return;
+  const int64_t r = blockIdx.x;
+  if (a.emit && !a.emit[r]) return;
+  const uint32_t tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  Plan pl;
+  uint32_t *hkeys, *hpos, *epos, *crc_t;
+  unsigned long long* ekeys;
+  carve(a, pl, hkeys, hpos, ekeys, epos, crc_t);
+  // slicing-by-4 tables
+  {
+    uint32_t c = tid;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+    crc_t[tid] = c;
+  }
+  __syncthreads();
+  for (int j = 1; j < 4; ++j) {
+    const uint32_t prev = crc_t[(j - 1) * 256 + tid];
+    crc_t[j * 256 + tid] = (prev >> 8) ^ crc_t[prev & 0xFF];
+    __syncthreads();
+  }
+  build_plan(a, r, pl, hkeys, hpos, ekeys, epos, s_w);
+  const Layout L = layout_of(a, r, pl);
+  uint8_t* const rec = out + rec_off[r];
+  uint8_t* const payload = rec + (a.frame ? 12 : 0);
+  uint8_t* const graph_hdr = payload + field_len(L.root_body);
+  uint8_t* const graph = graph_hdr + 1 + vlen(L.graph_body);
+  uint8_t* const edges = graph + pl.nodes_bytes;
+  uint8_t* const pos = graph + L.graph_body;
+  uint8_t* const suffix = pos + L.pos_bytes;
+  uint8_t* const payload_end = suffix + L.suffix_len;
+
+  if (tid == 0) {
+    if (a.frame) {
+      uint32_t c = 0xFFFFFFFFu;
+      for (int b = 0; b < 8; ++b) {
+        const uint32_t byte = (uint32_t)((L.payload >> (8 * b)) & 0xFF);
+        rec[b] = (uint8_t)byte;
+        c = crc_byte(crc_t, c, byte);
+      }
+      const uint32_t m = mask_crc(c ^ 0xFFFFFFFFu);
+      for (int b = 0; b < 4; ++b) rec[8 + b] = (uint8_t)(m >> (8 * b));
+    }
+    uint8_t* q = graph_hdr;
+    *q++ = a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED ? 0x1A : 0x12;  // neighborhood = 3 / 2
+    put_varint(q, L.graph_body);
+    if (a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED) {
+      uint8_t* e = pos;
+      for (int tt = 1; tt < a.trees; ++tt) {
+        const uint32_t p = a.roots[r * a.trees + tt];
+        if (p != NONE) e = write_edge(a, e, 0x22, L.root_id, p);  // pos_edges = 4
+      }
+    }
+  }
+  // root_node = 1, then the distinct nodes of the neighbourhood (Graph.nodes = 2): one wave per node
+  if (w == 0) write_node(a, payload, 0x0A, L.root_id, lane);
+  for (uint32_t u = w; u < pl.n_uniq; u += 4) {
+    const uint32_t q = pl.uniq[u];
+    write_node(a, graph + pl.node_off[q], 0x12, stream_node(a, r, q), lane);
+  }
+  // Graph.edges = 3: one thread per edge
+  const uint32_t n_e = (uint32_t)(a.trees * a.edge_len);
+  for (uint32_t q = tid; q < n_e; q += 256) {
+    if (pl.edge_off[q] == NONE) continue;
+    uint32_t s, d;
+    stream_edge(a, r, q, s, d);
+    write_edge(a, edges + pl.edge_off[q], 0x1A, s, d);
+  }
+  if (L.suffix_len) {
+    const uint8_t* src = a.suffix + a.suffix_off[r];
+    for (uint64_t i = tid; i < L.suffix_len; i += 256) suffix[i] = src[i];
+  }
+  if (!a.frame) return;
+  __threadfence_block();
+  __syncthreads();
+  // CRC-32C of the payload: lane l folds bytes [l*C, (l+1)*C) (C a multiple of 4), lane 0 carries the 0xFFFFFFFF
+  // initial state; state_l * x^(8*bytes_after_l) summed over lanes = the state after the whole message
+  {
+    const uint64_t n = L.payload;
+    const uint64_t C = ((n + 255) / 256 + 3) & ~3ull;
+    const uint64_t lo = min((uint64_t)tid * C, n), hi = min(lo + C, n);
+    uint32_t c = tid == 0 ? 0xFFFFFFFFu : 0u;
+    const uint8_t* p = payload + lo;
+    const uint8_t* const e = payload + hi;
+    while (p < e && ((uintptr_t)p & 3u)) c = crc_byte(crc_t, c, *p++);
+    for (; p + 4 <= e; p += 4) c = crc_word(crc_t, c, *(const uint32_t*)p);
+    while (p < e) c = crc_byte(crc_t, c, *p++);
+    uint32_t part = 0;
+    if (c) part = multmodp(x8n_modp(a, n - hi), c);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part ^= __shfl_xor(part, o, 64);
+    if (lane == 0) s_x[w] = part;
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t m = mask_crc((s_x[0] ^ s_x[1] ^ s_x[2] ^ s_x[3]) ^ 0xFFFFFFFFu);
+      for (int b = 0; b < 4; ++b) payload_end[b] = (uint8_t)(m >> (8 * b));
+    }
+  }
+}
+
+uint32_t host_multmodp(uint32_t a, uint32_t b) {
+  uint32_t m = 1u << 31, p = 0;
+  for (;;) {
+    if (a & m) {
+      p ^= b;
+      if ((a & (m - 1)) == 0) break;
+    }
+    m >>= 1;
+    b = (b & 1u) ? (b >> 1) ^ CRC_POLY : b >> 1;
+  }
+  return p;
+}
+
+uint32_t next_pow2(uint32_t x) {
+  uint32_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+constexpr int64_t MAX_STREAM = 4096;  // node-stream positions per record the LDS plan is sized for
+
+int32_t fill_args(gigl_ctx* ctx, const int32_t* fanouts, int32_t hops, const gigl_record_opts* o, RecArgs& a) {
+  GIGL_REQUIRE(ctx, fanouts && o, "null argument");
+  GIGL_REQUIRE(ctx, hops >= 1 && hops <= GIGL_MAX_HOPS, "hops must be in [1,%d]", GIGL_MAX_HOPS);
+  GIGL_REQUIRE(ctx, o->kind == GIGL_REC_ROOTED_NODE_NEIGHBORHOOD || o->kind == GIGL_REC_NODE_ANCHOR_LINK_PRED,
+               "bad record kind %d", o->kind);
+  GIGL_REQUIRE(ctx, o->trees_per_record >= 1, "trees_per_record must be >= 1");
+  GIGL_REQUIRE(ctx, o->kind == GIGL_REC_NODE_ANCHOR_LINK_PRED || o->trees_per_record == 1,
+               "a RootedNodeNeighborhood record is built from exactly one tree");
+  GIGL_REQUIRE(ctx, (o->suffix == nullptr) == (o->suffix_off == nullptr), "suffix and suffix_off go together");
+  int64_t s = 1, sum = 0;
+  for (int k = 0; k < hops; ++k) {
+    GIGL_REQUIRE(ctx, fanouts[k] >= 1 && fanouts[k] <= GIGL_MAX_FANOUT, "fanout[%d]=%d outside [1,%d]", k,
+                 fanouts[k], GIGL_MAX_FANOUT);
+    s *= fanouts[k];
+    sum += s;
+    if (sum > MAX_STREAM) break;
+    a.fan[k] = fanouts[k];
+    a.slots[k] = (int32_t)s;
+  }
+  if ((sum + 1) * o->trees_per_record > MAX_STREAM)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "record of %lld tree slots exceeds the %lld the in-LDS plan holds",
+                     (long long)((sum + 1) * o->trees_per_record), (long long)MAX_STREAM);
+  a.hops = hops;
+  a.trees = o->trees_per_record;
+  a.tree_len = (int32_t)sum + 1;
+  a.edge_len = (int32_t)sum;
+  a.kind = o->kind;
+  a.node_type = o->condensed_node_type;
+  a.edge_type = o->condensed_edge_type;
+  a.frame = o->tfrecord_frame;
+  a.emit = o->emit;
+  a.suffix = o->suffix;
+  a.suffix_off = o->suffix_off;
+  a.hash_cap = next_pow2((uint32_t)(2 * a.trees * a.tree_len));
+  a.ehash_cap = a.trees > 1 ? next_pow2((uint32_t)(2 * a.trees * a.edge_len)) : 0;
+  uint32_t p = 1u << 30;  // x^1
+  a.x2n[0] = p;
+  for (int k = 1; k < 32; ++k) a.x2n[k] = p = host_multmodp(p, p);
+  return GIGL_OK;
+}
+
+int hvlen(uint64_t v) {
+  int n = 1;
+  while (v >= 128) {
+    v >>= 7;
+    ++n;
+  }
+  return n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t gigl_records_capacity(const int32_t* fanouts, int32_t hops, int32_t d, const gigl_record_opts* opts,
+                              int64_t n_records, int64_t suffix_total, int64_t* bytes) {
+  if (!fanouts || !opts || !bytes || hops < 1 || hops > GIGL_MAX_HOPS || d < 0 || n_records < 0 ||
+      opts->trees_per_record < 1)
+    return GIGL_E_INVALID_ARG;
+  int64_t s = 1, sum = 0;
+  for (int k = 0; k < hops; ++k) {
+    if (fanouts[k] < 1) return GIGL_E_INVALID_ARG;
+    s *= fanouts[k];
+    sum += s;
+  }
+  const int64_t node_body = 6 + 6 + (d > 0 ? 1 + hvlen(4ull * d) + 4ll * d : 0);
+  const int64_t node_field = 1 + hvlen(node_body) + node_body;
+  const int64_t edge_field = 2 + 6 + 6 + 6;
+  const int64_t t = opts->trees_per_record;
+  const int64_t graph = t * ((sum + 1) * node_field + sum * edge_field);
+  const int64_t per = node_field + 1 + hvlen(graph) + graph + (t - 1) * edge_field + 16;
+  *bytes = n_records * per + suffix_total;
+  return GIGL_OK;
+}
+
+int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gigl_tree* tree, gigl_feat* feat,
+                            const gigl_record_opts* opts, int64_t n_records, uint8_t* out, int64_t out_cap,
+                            int64_t* rec_off, int32_t* status) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, tree && opts && rec_off && status && (out || out_cap == 0), "null argument");
+  GIGL_REQUIRE(ctx, n_records >= 0 && n_records < ((int64_t)1 << 31) && out_cap >= 0, "bad sizes");
+  RecArgs a{};
+  int32_t rc = fill_args(ctx, tree->fanouts, tree->hops, opts, a);
+  if (rc != GIGL_OK) return rc;
+  GIGL_REQUIRE(ctx, (int64_t)tree->b == n_records * a.trees, "tree holds %d roots, %lld records x %d trees expected",
+               tree->b, (long long)n_records, a.trees);
+  GIGL_REQUIRE(ctx, tree_roots || n_records == 0, "null roots");
+  a.roots = tree_roots;
+  for (int k = 0; k < a.hops; ++k) {
+    GIGL_REQUIRE(ctx, tree->nbr[k], "tree buffers for hop %d are null", k);
+    a.nbr[k] = tree->nbr[k];
+  }
+  if (feat) {
+    a.feat = feat->rows;
+    a.d = feat->d;
+    a.feat_dtype = feat->dtype;
+    a.feat_n = feat->n;
+  }
+  a.n_records = n_records;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  rc = gigl_arena_reset(ctx, (n_records + 1) * 8 + 256);
+  if (rc != GIGL_OK) return rc;
+  int64_t* rec_size = (int64_t*)gigl_arena_alloc(ctx, (n_records + 1) * 8);
+  if (!rec_size) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  const size_t lds_a = lds_bytes(a, false), lds_b = lds_bytes(a, true);
+  if (lds_b > 60 * 1024) {
+    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)record_size_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
+    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)record_write_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+  }
+  if (n_records > 0)
+    hipLaunchKernelGGL(record_size_kernel, dim3((unsigned)n_records), dim3(256), lds_a, ctx->stream, a, rec_size);
+  hipLaunchKernelGGL(record_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, rec_size, n_records, out_cap,
+                     rec_off, status);
+  if (n_records > 0)
+    hipLaunchKernelGGL(record_write_kernel, dim3((unsigned)n_records), dim3(256), lds_b, ctx->stream, a, rec_off,
+                       status, out);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+}  // extern "C"

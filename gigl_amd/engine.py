@@ -287,6 +287,57 @@ class HipEngine:
                                               C.c_void_p(cnt.data_ptr())), self._ctx)
         return pos[: b * num_positives], cnt[:b]
 
+    def encode_records(self, tree: Tree, *, kind: int = _lib.REC_ROOTED_NODE_NEIGHBORHOOD, trees_per_record: int = 1,
+                       condensed_node_type: Optional[int] = 0, condensed_edge_type: Optional[int] = 0,
+                       tfrecord_frame: bool = True, emit: Optional[torch.Tensor] = None,
+                       suffix: Optional[torch.Tensor] = None, suffix_off: Optional[torch.Tensor] = None,
+                       with_features: bool = True):
+        """sampled trees -> serialized RootedNodeNeighborhood / SupervisedNodeClassificationSample (suffix = encoded
+        labels) / NodeAnchorBasedLinkPredictionSample records, encoded on the device (gigl_records_encode).
+        -> (uint8 device tensor of all records back to back, int64 device tensor rec_off[n_records+1])"""
+        assert tree.roots is not None and tree.b % trees_per_record == 0
+        n_rec = tree.b // trees_per_record
+        o = _lib.GiglRecordOpts()
+        o.kind, o.trees_per_record = kind, trees_per_record
+        o.condensed_node_type = -1 if condensed_node_type is None else int(condensed_node_type)
+        o.condensed_edge_type = -1 if condensed_edge_type is None else int(condensed_edge_type)
+        o.tfrecord_frame = 1 if tfrecord_frame else 0
+        keep = []
+        if emit is not None:
+            emit = emit.to(device=self.device, dtype=torch.uint8).contiguous()
+            assert emit.numel() == n_rec
+            o.emit = emit.data_ptr()
+            keep.append(emit)
+        suffix_total = 0
+        if suffix is not None:
+            suffix = suffix.to(device=self.device, dtype=torch.uint8).contiguous()
+            suffix_off = suffix_off.to(device=self.device, dtype=torch.int64).contiguous()
+            assert suffix_off.numel() == n_rec + 1
+            suffix_total = int(suffix.numel())
+            if suffix_total == 0:  # data_ptr() of an empty tensor is NULL
+                suffix = torch.zeros(1, dtype=torch.uint8, device=self.device)
+            o.suffix, o.suffix_off = suffix.data_ptr(), suffix_off.data_ptr()
+            keep += [suffix, suffix_off]
+        feat = self._feat if with_features else None
+        fo = (C.c_int32 * len(tree.fanouts))(*tree.fanouts)
+        cap = C.c_int64()
+        check(self._lib.gigl_records_capacity(fo, len(tree.fanouts), self.feat_dim if feat else 0, C.byref(o), n_rec,
+                                              suffix_total, C.byref(cap)))
+        out = torch.empty(max(cap.value, 1), dtype=torch.uint8, device=self.device)
+        rec_off = torch.empty(n_rec + 1, dtype=torch.int64, device=self.device)
+        status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        tree.c_struct.hops, tree.c_struct.b = len(tree.fanouts), tree.b
+        for k, f in enumerate(tree.fanouts):
+            tree.c_struct.fanouts[k] = f
+        check(self._lib.gigl_records_encode(self._ctx, C.c_void_p(tree.roots.data_ptr()), C.byref(tree.c_struct), feat,
+                                            C.byref(o), n_rec, C.c_void_p(out.data_ptr()), cap.value,
+                                            C.c_void_p(rec_off.data_ptr()), C.c_void_p(status.data_ptr())), self._ctx)
+        self._stream.synchronize()
+        if int(status.item()) != 0:
+            raise RuntimeError("gigl_records_encode: output capacity too small (status=1)")
+        del keep
+        return out[: int(rec_off[-1].item())], rec_off
+
     def union_capacity(self, b: int, fanouts: Sequence[int]):
         fo = (C.c_int32 * len(fanouts))(*[int(f) for f in fanouts])
         cn, ce = C.c_int64(), C.c_int64()

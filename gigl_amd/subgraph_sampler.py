@@ -31,8 +31,7 @@ import numpy as np
 
 from . import wire
 from .config import GbmlConfigPbWrapper, tfrecord_files
-from .sampler_service import (HipKHopSamplerService, build_rooted_node_neighborhood, tree_to_edge_lists,
-                              validate_rooted_node_neighborhood)
+from .sampler_service import HipKHopSamplerService
 
 
 def load_preprocessed_graph(cfg: GbmlConfigPbWrapper):
@@ -71,20 +70,64 @@ def _res(cfg: GbmlConfigPbWrapper, uri: str) -> str:
     return resolve_uri(uri, cfg.uri_base)
 
 
-def _write(prefix: str, payloads: List[bytes], records_per_file: int = 100_000) -> List[str]:
-    """spark-tfrecord writes part files under the prefix directory (TFRecordIO.scala:53-69, overwrite mode)"""
-    is_dir = prefix.endswith("/") or prefix.endswith(os.sep)
-    d = prefix if is_dir else os.path.dirname(prefix)
-    os.makedirs(d or ".", exist_ok=True)
-    for old in tfrecord_files(prefix):
-        os.remove(old)
-    out = []
-    for i in range(0, max(len(payloads), 1), records_per_file):
-        name = (os.path.join(prefix, f"part-{i // records_per_file:05d}.tfrecord") if is_dir
-                else f"{prefix}{i // records_per_file:05d}.tfrecord")
-        wire.write_tfrecords(name, payloads[i:i + records_per_file])
-        out.append(name)
-    return out
+class _PartWriter:
+    """spark-tfrecord writes part files under the prefix directory (TFRecordIO.scala:53-69, overwrite mode);
+    takes already framed records (bytes + record offsets) and rolls to a new part every records_per_file"""
+
+    def __init__(self, prefix: str, records_per_file: int = 100_000):
+        self.prefix, self.per = prefix, records_per_file
+        self.is_dir = prefix.endswith("/") or prefix.endswith(os.sep)
+        d = prefix if self.is_dir else os.path.dirname(prefix)
+        os.makedirs(d or ".", exist_ok=True)
+        for old in tfrecord_files(prefix):
+            os.remove(old)
+        self.files: List[str] = []
+        self.fh = None
+        self.in_part = 0
+        self.n_records = 0
+
+    def _roll(self):
+        if self.fh:
+            self.fh.close()
+        i = len(self.files)
+        name = (os.path.join(self.prefix, f"part-{i:05d}.tfrecord") if self.is_dir else f"{self.prefix}{i:05d}.tfrecord")
+        self.fh = open(name, "wb")
+        self.files.append(name)
+        self.in_part = 0
+
+    def add(self, buf: np.ndarray, rec_off: np.ndarray) -> None:
+        """buf: uint8 frames back to back; rec_off[i]..rec_off[i+1] = record i (empty = skipped)"""
+        sizes = np.diff(rec_off)
+        idx = np.flatnonzero(sizes > 0)
+        k = 0
+        while k < idx.size:
+            if self.fh is None or self.in_part >= self.per:
+                self._roll()
+            take = min(self.per - self.in_part, idx.size - k)
+            lo, hi = int(rec_off[idx[k]]), int(rec_off[idx[k + take - 1] + 1])
+            self.fh.write(memoryview(buf[lo:hi]))  # skipped records take 0 bytes: the range is contiguous frames
+            self.in_part += take
+            self.n_records += take
+            k += take
+
+    def close(self) -> List[str]:
+        if self.fh is None:
+            self._roll()  # an empty dataset still leaves one (empty) part file
+        self.fh.close()
+        self.fh = None
+        return self.files
+
+
+def _encode_labels(label_keys: Sequence[str], labels: Dict[str, Dict[int, int]], ids: np.ndarray):
+    """root_node_labels (field 3 of SupervisedNodeClassificationSample, training_samples_schema.proto:23-27) of
+    every root, pre-encoded: the device encoder appends them to the RootedNodeNeighborhood fields"""
+    parts, off = [], np.zeros(ids.size + 1, dtype=np.int64)
+    for i, nid in enumerate(ids.tolist()):
+        b = b"".join(wire._len_delim(3, wire.Label(label_type=lk, label=labels[lk][nid]).SerializeToString())
+                     for lk in label_keys if nid in labels.get(lk, {}))
+        parts.append(b)
+        off[i + 1] = off[i] + len(b)
+    return np.frombuffer(b"".join(parts), dtype=np.uint8).copy(), off
 
 
 class SubgraphSampler:
@@ -98,71 +141,66 @@ class SubgraphSampler:
             raise NotImplementedError("only experimental_flags.permutation_strategy=deterministic is implemented "
                                       "(SamplingStrategy.scala:16-82); the non-deterministic F.shuffle has no parity")
         n, src, dst, x, labels, node_ids = load_preprocessed_graph(cfg)
+        ids = np.asarray(node_ids, dtype=np.uint32)
         with HipKHopSamplerService(n, src, dst, x, cfg.is_graph_directed, device=device) as svc:
-            rnns = self._sample_all(svc, node_ids, cfg.fanouts, batch_size)
             if cfg.task_kind == "node_classification":
-                return self._run_node_classification(cfg, rnns, labels)
-            return self._run_nablp(cfg, svc, rnns)
+                return self._run_node_classification(cfg, svc, ids, labels, batch_size)
+            return self._run_nablp(cfg, svc, ids, batch_size)
 
-    # ---- shared: one RootedNodeNeighborhood per node (createRootedNodeNeighborhoodSubgraph)
+    # Sampling, per-root assembly (createSubgraph), hydration, proto encoding and TFRecord framing all run on the
+    # device (gigl_sample_khop + gigl_records_encode); the host only copies finished frames into the part files.
     @staticmethod
-    def _sample_all(svc: HipKHopSamplerService, node_ids: Sequence[int], fanouts: Sequence[int], batch_size: int):
-        out: Dict[int, wire.RootedNodeNeighborhood] = {}
-        for i in range(0, len(node_ids), batch_size):
-            chunk = node_ids[i:i + batch_size]
-            for nid, rnn in zip(chunk, svc.getKHopSubgraphForRootNodes(chunk, fanouts)):
-                out[int(nid)] = rnn
-        return out
-
-    @staticmethod
-    def _run_node_classification(cfg, rnns, labels):
-        unl = [rnns[k].SerializeToString() for k in sorted(rnns)]
-        files = {"unlabeled": _write(cfg.unlabeled_tfrecord_uri_prefix, unl)}
+    def _run_node_classification(cfg, svc: HipKHopSamplerService, ids: np.ndarray, labels, batch_size: int):
+        """createRootedNodeNeighborhoodSubgraph (SGSPureSparkV1Task.scala:973-1017): one RootedNodeNeighborhood per
+        node; createSupervisedNodeClassificationSubgraph (SupervisedNodeClassificationTask.scala:166-236): labeled
+        samples for the roots that have a label and at least one edge"""
+        import torch
+        eng = svc.engine
         pm = cfg.preprocessed_metadata.nodes[0]
-        lab = []
-        for k in sorted(rnns):
-            r = rnns[k]
-            if not r.neighborhood.edges:  # isolated nodes produce no training samples
-                continue
-            lbs = [wire.Label(label_type=lk, label=labels[lk][k]) for lk in pm.label_keys if k in labels.get(lk, {})]
-            if not lbs:
-                continue
-            lab.append(wire.SupervisedNodeClassificationSample(root_node=r.root_node, neighborhood=r.neighborhood,
-                                                               root_node_labels=lbs).SerializeToString())
-        files["labeled"] = _write(cfg.labeled_tfrecord_uri_prefix, lab)
-        return files
+        unl = _PartWriter(cfg.unlabeled_tfrecord_uri_prefix)
+        lab = _PartWriter(cfg.labeled_tfrecord_uri_prefix)
+        for i in range(0, ids.size, batch_size):
+            chunk = ids[i:i + batch_size]
+            tree = eng.sample_khop(chunk, cfg.fanouts, sampling_seed=svc.sampling_seed)
+            buf, off = eng.encode_records(tree)
+            unl.add(buf.cpu().numpy(), off.cpu().numpy())
+            sfx, sfx_off = _encode_labels(pm.label_keys, labels, chunk)
+            has_label = torch.from_numpy(np.diff(sfx_off) > 0).to(eng.device)
+            emit = (has_label & (tree.cnt[0] > 0)).to(torch.uint8)  # isolated nodes produce no training samples
+            buf, off = eng.encode_records(tree, emit=emit, suffix=torch.from_numpy(sfx), suffix_off=torch.from_numpy(sfx_off))
+            lab.add(buf.cpu().numpy(), off.cpu().numpy())
+        return {"unlabeled": unl.close(), "labeled": lab.close()}
 
     @staticmethod
-    def _run_nablp(cfg, svc: HipKHopSamplerService, rnns):
+    def _run_nablp(cfg, svc: HipKHopSamplerService, ids: np.ndarray, batch_size: int):
         """createNodeAnchorBasedLinkPredictionSubgraph (NodeAnchorBasedLinkPredictionTask.scala:146-312):
-        neighborhood = array_distinct(root nbhd ++ union of the positives' nbhds) looked up from the cached
-        per-node subgraphs; pos_edges = [root -> pos]; hard_neg_edges = neg_edges = []"""
-        num_pos = cfg.num_positive_samples
-        ids = sorted(rnns)
-        roots = np.asarray(ids, dtype=np.uint32)
-        pos, cnt = svc.engine.sample_positives(roots, num_pos, sampling_seed=svc.sampling_seed)
-        pos = pos.cpu().numpy().view(np.uint32).reshape(len(ids), num_pos)
-        cnt = cnt.cpu().numpy()
-        samples = []
-        for i, r in enumerate(ids):
-            if cnt[i] == 0:
-                continue  # anchors need at least one positive (out-edge)
-            nodes = {n.node_id: n for n in rnns[r].neighborhood.nodes}
-            edges = {(e.src_node_id, e.dst_node_id): e for e in rnns[r].neighborhood.edges}
-            pos_edges = []
-            for p in pos[i][: cnt[i]].tolist():
-                pos_edges.append(wire.Edge(src_node_id=int(r), dst_node_id=int(p), condensed_edge_type=0))
-                for nn in rnns[p].neighborhood.nodes:
-                    nodes.setdefault(nn.node_id, nn)
-                for e in rnns[p].neighborhood.edges:
-                    edges.setdefault((e.src_node_id, e.dst_node_id), e)
-            samples.append(wire.NodeAnchorBasedLinkPredictionSample(
-                root_node=rnns[r].root_node, pos_edges=pos_edges,
-                neighborhood=wire.Graph(nodes=list(nodes.values()), edges=list(edges.values()))).SerializeToString())
-        files = {"node_anchor_based_link_prediction": _write(cfg.nablp_tfrecord_uri_prefix, samples)}
-        rn = [rnns[k].SerializeToString() for k in ids]
-        for node_type, prefix in cfg.random_negative_tfrecord_uri_prefixes.items():
-            files[f"random_negative/{node_type}"] = _write(prefix, rn)
+        neighborhood = array_distinct(root nbhd ++ union of the positives' nbhds) — the positives' rooted samples are
+        re-derived on the device (the sample of a root is a pure function of the root and the seed, so this equals
+        the reference's lookup in its cached per-node table); pos_edges = [root -> pos]; hard_neg_edges = neg_edges = []"""
+        import torch
+        from . import _lib
+        eng = svc.engine
+        P = cfg.num_positive_samples
+        main = _PartWriter(cfg.nablp_tfrecord_uri_prefix)
+        rn = {t: _PartWriter(p) for t, p in cfg.random_negative_tfrecord_uri_prefixes.items()}
+        for i in range(0, ids.size, max(1, batch_size // (1 + P))):
+            chunk = ids[i:i + max(1, batch_size // (1 + P))]
+            roots = eng._roots_tensor(chunk)
+            pos, cnt = eng.sample_positives(roots, P, sampling_seed=svc.sampling_seed)
+            grouped = torch.cat([roots.view(-1, 1), pos.view(-1, P)], dim=1).reshape(-1).contiguous()
+            tree = eng.sample_khop(grouped, cfg.fanouts, sampling_seed=svc.sampling_seed)
+            buf, off = eng.encode_records(tree, kind=_lib.REC_NODE_ANCHOR_LINK_PRED, trees_per_record=1 + P,
+                                          emit=(cnt > 0).to(torch.uint8))  # anchors need at least one positive
+            main.add(buf.cpu().numpy(), off.cpu().numpy())
+            if rn:
+                tree = eng.sample_khop(roots, cfg.fanouts, sampling_seed=svc.sampling_seed)
+                buf, off = eng.encode_records(tree)
+                b_h, o_h = buf.cpu().numpy(), off.cpu().numpy()
+                for w in rn.values():
+                    w.add(b_h, o_h)
+        files = {"node_anchor_based_link_prediction": main.close()}
+        for t, w in rn.items():
+            files[f"random_negative/{t}"] = w.close()
         return files
 
 

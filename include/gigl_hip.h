@@ -166,6 +166,52 @@ int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* 
                               int32_t f, int32_t sampling_seed, int32_t mode, uint32_t* pos,
                               int32_t* cnt);
 
+/* ---- sampled trees -> serialized training samples in TFRecord framing, encoded on the device.
+ *      Replaces the per-root assembly, hydration, proto cast and record writer of the Spark sampler:
+ *      hydrateNodes / hydrateEdges / createSubgraph (SGSPureSparkV1Task.scala:496-593, :671-820),
+ *      createNodeAnchorBasedLinkPredictionSubgraph (pureSpark/NodeAnchorBasedLinkPredictionTask.scala:146-312),
+ *      castToRootedNodeNeighborhoodProtoSchema (SGSPureSparkV1Task.scala:1019-1040) and
+ *      TFRecordIO.writeDatasetToTfrecord (scala/common/src/main/scala/utils/TFRecordIO.scala:53-69).
+ *
+ * Record r is built from trees_per_record consecutive trees of `tree` (tree r*T is the root's; for
+ * GIGL_REC_NODE_ANCHOR_LINK_PRED trees r*T+1 .. are the rooted samples of the root's positives, root id
+ * GIGL_INVALID = no such positive, lookupDstNodeNeighborhood NodeAnchorBasedLinkPredictionBaseTask.scala:106-198):
+ *   nodes  = distinct ids in stream order: per tree the hop-1 slots, hop-2 slots, ..., then the tree's root
+ *            (array_distinct(hop nodes ++ [root]), SGSPureSparkV1Task.scala:737-780; across trees
+ *            array_distinct(root nbhd ++ positives' nbhds)), each written once with its feature row
+ *   edges  = per tree the hop-1 edges (src = slot, dst = root), then hop-2 edges (dst = parent slot), ...;
+ *            distinct (src,dst) pairs across the trees of a record
+ *   GIGL_REC_ROOTED_NODE_NEIGHBORHOOD: RootedNodeNeighborhood{root_node=1, neighborhood=2}
+ *            (training_samples_schema.proto:16-19) followed by the opaque `suffix` bytes of the record —
+ *            already-encoded `root_node_labels` (field 3) turn it into a SupervisedNodeClassificationSample (:23-27)
+ *   GIGL_REC_NODE_ANCHOR_LINK_PRED: NodeAnchorBasedLinkPredictionSample{root_node=1, neighborhood=3,
+ *            pos_edges=4: root -> root of tree j} (:31-43)
+ * Encoding is byte-identical to ScalaPB / protobuf (field-number order, proto3 zero elision for node/edge ids,
+ * explicit presence for the `optional` condensed types, packed floats).  tfrecord_frame != 0 wraps every
+ * record as u64 length | masked crc32c(length) | payload | masked crc32c(payload).
+ * All pointers DEVICE.  rec_off[r] = byte offset of record r in `out`, rec_off[n_records] = total bytes;
+ * *status = 1 (and nothing is written) when the total exceeds out_cap.  Never synchronises with the host. */
+#define GIGL_REC_ROOTED_NODE_NEIGHBORHOOD 0
+#define GIGL_REC_NODE_ANCHOR_LINK_PRED 1
+
+typedef struct gigl_record_opts {
+  int32_t kind;                /* GIGL_REC_* */
+  int32_t trees_per_record;    /* 1, or 1 + num_positive_samples for GIGL_REC_NODE_ANCHOR_LINK_PRED */
+  int32_t condensed_node_type; /* >= 0: written in every Node; < 0: field absent */
+  int32_t condensed_edge_type; /* >= 0: written in every Edge; < 0: field absent */
+  int32_t tfrecord_frame;
+  const uint8_t* emit;         /* [n_records] or NULL; 0 = the record is skipped (takes 0 bytes) */
+  const uint8_t* suffix;       /* bytes appended to the payload of record r: suffix[suffix_off[r] .. suffix_off[r+1]) */
+  const int64_t* suffix_off;   /* [n_records+1] or NULL (with suffix) */
+} gigl_record_opts;
+
+/* upper bound of the bytes n_records records can take (d = feature dim, suffix_total = all suffix bytes) */
+int32_t gigl_records_capacity(const int32_t* fanouts, int32_t hops, int32_t d, const gigl_record_opts* opts,
+                              int64_t n_records, int64_t suffix_total, int64_t* bytes);
+int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gigl_tree* tree, gigl_feat* feat,
+                            const gigl_record_opts* opts, int64_t n_records, uint8_t* out, int64_t out_cap,
+                            int64_t* rec_off, int32_t* status);
+
 /* ---- batch union graph ("collate"): replaces GraphBuilder.add_graph_data/add_edge dedup
  *      (python/gigl/src/common/graph_builder/abstract_graph_builder.py:49-150), the collate
  *      functions (python/gigl/src/training/v1/lib/data_loaders/
