@@ -45,6 +45,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # same guide: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 
 # library timer id -> the device functions it brackets (names as rocprofv3 prints them, see scripts/pmc_summary.py)
 PMC_KERNELS = {
@@ -91,25 +92,40 @@ def rmat_edges_gpu(scale: int, n_edges: int, seed: int, device, a=0.57, b=0.19, 
     return src, dst
 
 
+# workload -> (nodes, rmat scale, edges drawn, feature dim, feature dtype, directed, hidden, out, rmat seed, label)
+WORKLOADS = {
+    # BASELINE.json configs[1] / SURVEY.md §8(d) C2
+    "products": (2_449_029, 22, 61_859_140, 100, torch.float32, False, 256, 47, 2, "ogbn-products-shaped RMAT"),
+    # the per-GPU share of BASELINE.json configs[2] (MAG240M, SURVEY.md §8(d) C3: N=244,160,499, E=1,728,364,232
+    # directed, D=768 fp16, SAGE 768->256->256) held as ONE self-contained graph: 1/8 of the nodes, edges and
+    # feature bytes (47 GB) — what each of the 8 shards stores; the full graph needs 375 GB of features
+    "mag-shard": (30_520_062, 25, 216_045_529, 768, torch.float16, True, 256, 256, 3,
+                  "MAG240M/8-shaped RMAT (one GPU's share of the 8-way sharded graph)"),
+    "small": (200_000, 18, 3_000_000, 100, torch.float32, False, 256, 47, 2, "products-shaped-small"),
+}
+
+
 def build_workload(eng, args):
     dev = eng.device
-    if args.small:
-        n, scale, pairs, d = 200_000, 18, 3_000_000, 100
-    else:
-        n, scale, pairs, d = 2_449_029, 22, 61_859_140, 100
-    src, dst = rmat_edges_gpu(scale, pairs, seed=2, device=dev)
+    name = "small" if getattr(args, "small", False) else getattr(args, "workload", "products")
+    n, scale, pairs, d, dtype, directed, hid, out_dim, seed, label = WORKLOADS[name]
+    src, dst = rmat_edges_gpu(scale, pairs, seed=seed, device=dev)
     # fold the 2^scale id space onto [0, n) and scatter ids so hubs are not the low ids
     perm_mul = 0x9E3779B1
     src = ((src * perm_mul) % n).to(torch.int32)
     dst = ((dst * perm_mul) % n).to(torch.int32)
-    eng.build_from_coo(n, src, dst, is_directed=False)
+    eng.build_from_coo(n, src, dst, is_directed=directed)
     del src, dst
     g = torch.Generator(device=dev)
     g.manual_seed(1234)
-    x = torch.randn((n, d), generator=g, device=dev, dtype=torch.float32)
+    x = torch.empty((n, d), device=dev, dtype=dtype)
+    step = max(1, (1 << 28) // d)  # generate in <= 1 GiB fp32 pieces (the fp16 table alone is 47 GB for mag-shard)
+    for i in range(0, n, step):
+        x[i:i + step] = torch.randn((min(step, n - i), d), generator=g, device=dev, dtype=torch.float32).to(dtype)
     eng.load_features(x)
     del x
     torch.cuda.empty_cache()
+    args._workload = (name, label, hid, out_dim, directed, dtype)
     return n, d
 
 
@@ -124,6 +140,9 @@ def main():
     ap.add_argument("--group", type=int, default=16,
                     help="batches per library call: G independent batches of B roots share one set of launches "
                          "(each keeps its own union graph; results are bit-identical to G single-batch calls)")
+    ap.add_argument("--workload", type=str, default="products", choices=["products", "mag-shard"],
+                    help="products = BASELINE configs[1] (default, the N=1 workload); mag-shard = one GPU's 1/8 share "
+                         "of the MAG240M-shaped graph (D=768 fp16, SAGE 768->256->256)")
     ap.add_argument("--small", action="store_true", help="200k-node graph (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -154,7 +173,8 @@ def main():
 
     t0 = time.time()
     n, d = build_workload(eng0, args)
-    hid, out_dim = 256, 47
+    wl_name, wl_label, hid, out_dim, wl_directed, wl_dtype = args._workload
+    esz = 4 if wl_dtype == torch.float32 else 2  # bytes per feature element in the resident table
     torch.manual_seed(0)
     model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
     # roots: seeded permutation of node ids (seed 42); rank r takes batches r, r+world, ...
@@ -186,7 +206,7 @@ def main():
     plan1 = model.make_plan(engines[0], B, fanouts) if G > 1 else plans[0]
     out1 = torch.empty((B, out_dim), dtype=torch.float32, device=dev)
 
-    def run_range(lo, hi):
+    def run_range(lo, hi, S=S):
         """steps (= batches of B roots) lo..hi-1: call c takes the G consecutive batches lo+c*G.. on pipeline
         c % S (one host thread per pipeline); a remainder of < G steps runs batch by batch on pipeline 0"""
         n_calls = (hi - lo) // G
@@ -211,11 +231,15 @@ def main():
     torch.cuda.synchronize()
     for e in engines:
         e.profile_enable(names, capacity=64 * 16)
-    run_range(0, P)
-    run_range(0, P)  # (graph mode: the first call after a mask change re-captures)
+    # the probe runs on ONE stream so that an event interval is the kernel's own duration (with S streams the
+    # intervals include time shared with the other streams' kernels)
+    run_range(0, P, S=1)
+    run_range(0, P, S=1)  # (graph mode: the first call after a mask change re-captures)
     for p in plans:
         p.flush_profile()
     prof = {k: [sum(x) for x in zip(*[e.profile_read(k) for e in engines])] for k in names}
+    # graph mode: the first call after the mask change runs untimed (it is the eager pass before the re-capture)
+    probe_steps_counted = 2 * P - (0 if args.no_graph else min(G, P))
     dominant = max(prof, key=lambda k: prof[k][0])
     for e in engines:
         e.profile_enable([dominant], capacity=(K // S + 8) * 8)
@@ -248,6 +272,7 @@ def main():
     deg_all = np.diff(rp_host)
     sampled = aggregated = ref_equiv = 0
     alg_bytes = {k: 0.0 for k in names}
+    flops_l = []
     dims = [d] + [hid] * (L - 1)
     heavy_thr = 4096
     count_steps = range(W, W + K)  # every timed batch, exactly
@@ -268,7 +293,8 @@ def main():
         #  gather layer l: E_l*(4 + D_l*s) + N_dst*(8 + D_l*s_out) (+ the fused self-row copy D_l*s read + write)
         for l in range(L):
             n_dst = int(meta[2 + (L - 1 - l)])
-            alg_bytes["gather_mean"] += agg_l[l] * (4 + dims[l] * 4) + n_dst * (8 + 3 * dims[l] * 4)
+            s_in = esz if l == 0 else 4  # layer 0 gathers rows of the resident table, later layers fp32 activations
+            alg_bytes["gather_mean"] += agg_l[l] * (4 + dims[l] * s_in) + n_dst * (8 + dims[l] * s_in + 2 * dims[l] * 4)
         #  union: 16 B per sampled edge + 4 B per unique node, attributed evenly to its phases
         for k in ("union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr"):
             alg_bytes[k] += (16 * s_edges + 4 * nn) / 4.0
@@ -286,9 +312,11 @@ def main():
             n_dst = int(meta[2 + (L - 1 - l)])
             dout = hid if l < L - 1 else out_dim
             alg_bytes["linear"] += n_dst * (2 * dims[l] + dout) * 4 + dout * 2 * dims[l] * 4
+            flops_l.append(2.0 * n_dst * 2 * dims[l] * dout)
     scale = K / len(count_steps)
     sampled, aggregated, ref_equiv = sampled * scale, aggregated * scale, ref_equiv * scale
     alg_bytes = {k: v * scale for k, v in alg_bytes.items()}
+    alg_flops_linear = scale * sum(flops_l)
 
     # ---- reduce over ranks
     if world > 1:
@@ -305,14 +333,44 @@ def main():
     avg_launch_ms = dom_ms / max(dom_launches, 1)
     bytes_per_launch = alg_bytes[dominant] / max(dom_launches, 1)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    probe_steps = max(P, 1)
+    probe_steps = max(probe_steps_counted, 1)
     traffic, traffic_src = pmc_traffic(dominant)
-    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+    # every kernel group against its own bound, from the untimed all-timers-on probe (approximate: the probe steps
+    # are other batches than the K counted ones; per-step averages)
+    by_kernel = {}
+    for k, v in prof.items():
+        ms_step = v[0] / probe_steps
+        if ms_step <= 0:
+            continue
+        if k == "linear":
+            tf = alg_flops_linear / K / (ms_step * 1e-3) / 1e12
+            by_kernel[k] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": round(tf / MFMA_F32_PEAK_TF, 4), "ms_per_step": round(ms_step, 4)}
+        else:
+            gbs = alg_bytes[k] / K / (ms_step * 1e-3) / 1e9
+            by_kernel[k] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_step": round(ms_step, 4)}
+    note = None
+    if dominant == "expand" and args.mode == "parity":
+        note = ("algorithmic bytes of parity sampling count the whole adjacency row of every frontier node "
+                "(16 + 4*deg + 8*min(deg,f), SURVEY.md 8(d)); the kernel answers long rows from the precomputed "
+                "hash range-top-K table and reads only the f selected ids, so measured HBM traffic is far BELOW the "
+                "algorithmic bytes and the kernel is VALU-bound (64-bit hash multiplies), not HBM-bound: frac is the "
+                "contract's figure, not a bandwidth utilisation; see by_kernel.gather_mean for the HBM-bound kernel")
+    if dominant == "linear":  # the dense projection is the one MFMA-bound kernel
+        tf = alg_flops_linear / max(dom_launches, 1) / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
+        head = {"bound": "mfma", "kernel": dominant, "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 5)}
+    else:
+        head = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)}
+    roofline = {**head,
                 "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
                 "avg_launch_us": round(avg_launch_ms * 1e3, 2), "alg_bytes_per_launch": round(bytes_per_launch),
-                "launches": int(dom_launches),
-                "kernel_ms_per_step_untimed_probe": {k: round(v[0] / probe_steps, 4) for k, v in prof.items()}}
+                "launches": int(dom_launches), "note": note,
+                "timing": f"HIP events on the kernel's stream over the timed region ({S} streams: intervals include "
+                          "overlap with the other streams' kernels); by_kernel: single-stream untimed probe",
+                "by_kernel": by_kernel}
 
     cpu_baseline = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -323,9 +381,11 @@ def main():
             "metric": "sampled+aggregated edges/s", "value": value, "unit": "edges/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("products-shaped-small" if args.small else "ogbn-products-shaped RMAT") +
-                       f" N={n} E={eng0.n_edges} D={d} fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}"
-                       " inference step (sample+union+forward), sampler mode=" + args.mode,
+            "config": {"workload": wl_label +
+                       f" N={n} E={eng0.n_edges} {'directed' if wl_directed else 'bidirectionalised'} D={d} "
+                       f"{'fp32' if esz == 4 else 'fp16'} features, fanout={fanouts} B={B}/GPU GraphSAGE "
+                       f"{d}->{hid}->{out_dim} (fp32 accumulate) inference step (sample+union+forward), sampler mode="
+                       + args.mode,
                        "graph": "replica per GPU, roots sharded across ranks",
                        "streams": S, "batches_per_call": G,
                        "sampled_edges_per_step": sampled_all / (K * world),
@@ -351,8 +411,6 @@ def run_cpu_baseline(eng, model, my, fanouts, W, n, d):
     from oracle import gnn_ref
 
     rowptr, col = eng.graph_to_host()
-    x = np.empty((n, d), dtype=np.float32)
-    eng._lib.gigl_memcpy(eng._ctx, C.c_void_p(x.ctypes.data), 0, eng._feat_ptr, 1, x.nbytes)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     L = len(fanouts)
     budget_s, t_used, edges, batches = 20.0, 0.0, 0, 0
@@ -365,7 +423,13 @@ def run_cpu_baseline(eng, model, my, fanouts, W, n, d):
         nbr, cnt = oracle.sample_khop(rowptr, col, roots, fanouts, canonical=True)
         u = oracle.union_build(roots, fanouts, nbr)
         ei = gnn_ref.union_edge_index(u["rowptr"], u["col"])
-        xs = torch.from_numpy(x[u["nodes"]])
+        t_used += time.perf_counter() - t0
+        # the union graph's feature rows as fp32 (the reference's records carry them): fetched from the resident
+        # table, outside the timed region
+        ids = torch.from_numpy(u["nodes"].astype(np.int64)).to(torch.int32).to(eng.device)
+        n_dev = torch.tensor([ids.numel()], dtype=torch.int32, device=eng.device)
+        xs = eng.gather_rows(ids, n_dev, int(ids.numel())).cpu()
+        t0 = time.perf_counter()
         out = gnn_ref.graphsage_forward(xs, ei, sd, L)
         _ = out[u["root_local"]]
         t_used += time.perf_counter() - t0

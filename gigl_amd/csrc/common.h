@@ -34,6 +34,8 @@ struct gigl_ctx {
   int64_t prof_acc_n[16] = {0};
   // sampler: range-top-K table over the xxhash sequence (sample.hip), built lazily
   void* sampler_table = nullptr;
+  // record encoder: x^(8*b*256^j) mod P tables of the CRC-32C combine step (serialize.hip), built lazily
+  uint32_t* crc_shift_tbl = nullptr;
 };
 
 void gigl_sampler_table_free(gigl_ctx* ctx);

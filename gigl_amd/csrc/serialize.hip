@@ -18,10 +18,15 @@
 //   size  : dedup the record's node stream (LDS hash set keyed by id, value = first stream position), sizes of
 //           the distinct nodes / edges, block scan -> byte offset of every item inside the record
 //   (one single-workgroup scan over the record sizes gives each record's offset in the output)
-//   write : same plan again (cheap: a few hundred ids), then headers by byte stores, feature payloads by
-//           funnel-shifted aligned dword stores (record offsets are arbitrary byte offsets), and finally the
-//           CRC-32C of the payload: 256 lanes each fold a chunk (slicing-by-4 tables in LDS) and the partial
-//           states are combined with x^(8*bytes_after) mod P.
+//   write : same plan again (cheap: a few hundred ids), then headers by byte stores (one thread per node / edge),
+//           feature payloads as (node, 4-word chunk) items spread evenly over the workgroup: 16-byte row loads,
+//           funnel shift by the destination's byte misalignment (record offsets are arbitrary byte offsets),
+//           dword-aligned 16-byte stores; finally the CRC-32C of the payload: 256 lanes each fold a chunk
+//           (slicing-by-4 tables in LDS) and the partial states are combined with x^(8*bytes_after) mod P
+//           taken from byte-indexed power tables.
+// Measured (MI355X, products-shaped graph, [25,10], D=100, 4096 roots = 165 MB of records): size 29 us + scan 7 us
+// + write 253 us (payload copy ~97 us = 3.4 TB/s of mixed read+write, CRC re-read ~53 us, plan + tables ~40 us,
+// headers + edges ~27 us) = 0.57 TB/s of finished TFRecord bytes.
 #include "common.h"
 
 #include <hip/hip_fp16.h>
@@ -52,7 +57,7 @@ struct RecArgs {
   int64_t n_records;
   uint32_t hash_cap;   // node hash entries (pow2)
   uint32_t ehash_cap;  // edge hash entries (pow2; 0 when trees == 1: edges are distinct by construction)
-  uint32_t x2n[32];    // x^(2^k) mod P, reflected
+  const uint32_t* shift_tbl;  // [3][256]: x^(8*b*256^j) mod P, reflected (CRC combine)
 };
 
 __device__ __forceinline__ int vlen(uint32_t v) {
@@ -84,6 +89,14 @@ __device__ __forceinline__ uint32_t edge_body_len(const RecArgs& a, uint32_t s, 
   return n;
 }
 __device__ __forceinline__ uint32_t field_len(uint32_t body) { return 1 + vlen(body) + body; }
+// bytes of a Node field before its float payload: tag, length, node_id, condensed_node_type, feature_values header
+__device__ __forceinline__ uint32_t node_hdr_len(const RecArgs& a, uint32_t id) {
+  uint32_t n = 1 + vlen(node_body_len(a, id));
+  if (id) n += 1 + vlen(id);
+  if (a.node_type >= 0) n += 1 + vlen((uint32_t)a.node_type);
+  if (a.d > 0) n += 1 + vlen(4u * (uint32_t)a.d);
+  return n;
+}
 
 // node id at stream position q of record r (NONE = empty slot)
 __device__ __forceinline__ uint32_t stream_node(const RecArgs& a, int64_t r, uint32_t q) {
@@ -146,9 +159,11 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* s_w, uint
 
 // The per-record plan, kept in LDS.
 struct Plan {
-  uint32_t* node_off;   // [n_s]  byte offset of the node's field inside the Graph body, NONE = duplicate / empty
-  uint32_t* uniq;       // [n_s]  stream positions of the distinct nodes, in order
-  uint32_t* edge_off;   // [n_e]  byte offset inside the edge region, NONE = duplicate / empty
+  uint32_t* tmp;        // [n_s]    scratch of the node scan (field size of first occurrences)
+  uint32_t* uid;        // [n_s+1]  ids of the distinct nodes in stream order; entry n_uniq = the root (root_node field)
+  uint32_t* fld;        // [n_s+1]  byte offset of the node's field inside the Graph body
+  uint32_t* pay;        // [n_s+1]  byte offset of its float payload (field offset + header length)
+  uint32_t* edge_off;   // [n_e]    byte offset inside the edge region, NONE = duplicate / empty
   uint32_t n_uniq, nodes_bytes, edges_bytes;
 };
 
@@ -206,9 +221,9 @@ __device__ void build_plan(const RecArgs& a, int64_t r, Plan& pl, uint32_t* hkey
         while (hkeys[h] != id) h = (h + 1) & (a.hash_cap - 1);
         first = hpos[h] == q;
       }
-      pl.node_off[q] = first ? field_len(node_body_len(a, id)) : NONE;  // size for now
+      pl.tmp[q] = first ? field_len(node_body_len(a, id)) : NONE;
       if (first) {
-        bytes += pl.node_off[q];
+        bytes += pl.tmp[q];
         ++cnt;
       }
     }
@@ -216,12 +231,21 @@ __device__ void build_plan(const RecArgs& a, int64_t r, Plan& pl, uint32_t* hkey
     uint32_t off_b = block_exscan(bytes, s_w, tot_b);
     uint32_t off_c = block_exscan(cnt, s_w + 4, tot_c);
     for (uint32_t q = lo; q < hi; ++q) {
-      const uint32_t sz = pl.node_off[q];
+      const uint32_t sz = pl.tmp[q];
       if (sz != NONE) {
-        pl.node_off[q] = off_b;
-        pl.uniq[off_c++] = q;
+        const uint32_t id = stream_node(a, r, q);
+        pl.uid[off_c] = id;
+        pl.fld[off_c] = off_b;
+        pl.pay[off_c] = off_b + node_hdr_len(a, id);
+        ++off_c;
         off_b += sz;
       }
+    }
+    if (tid == 0) {  // pseudo-node n_uniq: the record's root_node field (offsets relative to the payload start)
+      const uint32_t root = a.roots[r * a.trees];
+      pl.uid[tot_c] = root;
+      pl.fld[tot_c] = 0;
+      pl.pay[tot_c] = node_hdr_len(a, root);
     }
     pl.nodes_bytes = tot_b;
     pl.n_uniq = tot_c;
@@ -293,10 +317,14 @@ __device__ __forceinline__ void carve(const RecArgs& a, Plan& pl, uint32_t*& hke
   p += (size_t)a.hash_cap * 4;
   hpos = (uint32_t*)p;
   p += (size_t)a.hash_cap * 4;
-  pl.node_off = (uint32_t*)p;
+  pl.tmp = (uint32_t*)p;
   p += (size_t)n_s * 4;
-  pl.uniq = (uint32_t*)p;
-  p += (size_t)n_s * 4;
+  pl.uid = (uint32_t*)p;
+  p += (size_t)(n_s + 1) * 4;
+  pl.fld = (uint32_t*)p;
+  p += (size_t)(n_s + 1) * 4;
+  pl.pay = (uint32_t*)p;
+  p += (size_t)(n_s + 1) * 4;
   pl.edge_off = (uint32_t*)p;
   p += (size_t)n_e * 4;
   crc_t = (uint32_t*)p;  // [4][256] (write kernel only)
@@ -304,7 +332,7 @@ __device__ __forceinline__ void carve(const RecArgs& a, Plan& pl, uint32_t*& hke
 
 size_t lds_bytes(const RecArgs& a, bool with_crc) {
   const size_t n_s = (size_t)a.trees * a.tree_len, n_e = (size_t)a.trees * a.edge_len;
-  return (size_t)a.ehash_cap * 12 + (size_t)a.hash_cap * 8 + n_s * 8 + n_e * 4 + (with_crc ? 4096 : 0);
+  return (size_t)a.ehash_cap * 12 + (size_t)a.hash_cap * 8 + n_s * 4 + (n_s + 1) * 12 + n_e * 4 + (with_crc ? 4096 : 0);
 }
 
 __global__ __launch_bounds__(256) void record_size_kernel(RecArgs a, int64_t* rec_size) {
@@ -364,53 +392,21 @@ __device__ __forceinline__ uint32_t feat_word(const RecArgs& a, uint32_t id, uin
   return __float_as_uint(__half2float(((const __half*)a.feat)[(int64_t)id * a.d + k]));
 }
 
-// one wave writes a Node field (tag `tag`) at p: header by lane 0, the packed float payload by all lanes with
-// aligned dword stores (p is an arbitrary byte address: funnel-shift two source words per output word)
-__device__ __forceinline__ void write_node(const RecArgs& a, uint8_t* p, uint8_t tag, uint32_t id, int lane) {
-  const uint32_t body = node_body_len(a, id);
-  uint32_t hdr = 1 + vlen(body);
-  if (id) hdr += 1 + vlen(id);
-  if (a.node_type >= 0) hdr += 1 + vlen((uint32_t)a.node_type);
-  if (a.d > 0) hdr += 1 + vlen(4u * (uint32_t)a.d);
-  if (lane == 0) {
-    uint8_t* q = p;
-    *q++ = tag;
-    q = put_varint(q, body);
-    if (id) {
-      *q++ = 0x08;
-      q = put_varint(q, id);
-    }
-    if (a.node_type >= 0) {
-      *q++ = 0x10;
-      q = put_varint(q, (uint32_t)a.node_type);
-    }
-    if (a.d > 0) {
-      *q++ = 0x1A;
-      q = put_varint(q, 4u * (uint32_t)a.d);
-    }
+// header of a Node field (everything before the float payload), byte stores by one thread
+__device__ __forceinline__ void write_node_header(const RecArgs& a, uint8_t* q, uint8_t tag, uint32_t id) {
+  *q++ = tag;
+  q = put_varint(q, node_body_len(a, id));
+  if (id) {
+    *q++ = 0x08;
+    q = put_varint(q, id);
   }
-  if (a.d <= 0) return;
-  uint8_t* dst = p + hdr;
-  const uint32_t D = (uint32_t)a.d;
-  const uint32_t rr = (uint32_t)((uintptr_t)dst & 3u);
-  if (rr == 0) {
-    uint32_t* o = (uint32_t*)dst;
-    for (uint32_t k = lane; k < D; k += 64) o[k] = feat_word(a, id, k);
-    return;
+  if (a.node_type >= 0) {
+    *q++ = 0x10;
+    q = put_varint(q, (uint32_t)a.node_type);
   }
-  uint32_t* o = (uint32_t*)(dst - rr);
-  const uint32_t sh = 8u * rr;
-  for (uint32_t k = lane; k <= D; k += 64) {
-    const uint32_t prev = k > 0 ? feat_word(a, id, k - 1) : 0u;
-    const uint32_t cur = k < D ? feat_word(a, id, k) : 0u;
-    const uint32_t v = (prev >> (32u - sh)) | (cur << sh);
-    if (k == 0) {
-      for (uint32_t b = rr; b < 4; ++b) ((uint8_t*)o)[b] = (uint8_t)(v >> (8u * b));
-    } else if (k == D) {
-      for (uint32_t b = 0; b < rr; ++b) ((uint8_t*)(o + k))[b] = (uint8_t)(v >> (8u * b));
-    } else {
-      o[k] = v;
-    }
+  if (a.d > 0) {
+    *q++ = 0x1A;
+    put_varint(q, 4u * (uint32_t)a.d);
   }
 }
 
@@ -445,15 +441,11 @@ __device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b) {
   }
   return p;
 }
-// x^(8*n) mod P
-__device__ __forceinline__ uint32_t x8n_modp(const RecArgs& a, uint64_t n) {
-  uint32_t p = 1u << 31;
-  int k = 3;
-  while (n) {
-    if (n & 1) p = multmodp(a.x2n[k & 31], p);
-    n >>= 1;
-    ++k;
-  }
+// x^(8*n) mod P for n < 2^24 from the byte-indexed tables (two multiplies instead of one per bit of n)
+__device__ __forceinline__ uint32_t x8n_modp(const uint32_t* tbl, uint64_t n) {
+  uint32_t p = tbl[n & 0xFF];
+  if (n >> 8) p = multmodp(tbl[256 + ((n >> 8) & 0xFF)], p);
+  if (n >> 16) p = multmodp(tbl[512 + ((n >> 16) & 0xFF)], p);
   return p;
 }
 __device__ __forceinline__ uint32_t crc_byte(const uint32_t* t, uint32_t c, uint32_t b) {
@@ -523,11 +515,101 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
       }
     }
   }
-  // root_node = 1, then the distinct nodes of the neighbourhood (Graph.nodes = 2): one wave per node
-  if (w == 0) write_node(a, payload, 0x0A, L.root_id, lane);
-  for (uint32_t u = w; u < pl.n_uniq; u += 4) {
-    const uint32_t q = pl.uniq[u];
-    write_node(a, graph + pl.node_off[q], 0x12, stream_node(a, r, q), lane);
+  // root_node = 1 (pseudo-node n_uniq) and the distinct nodes of the neighbourhood (Graph.nodes = 2).
+  // headers: one thread per node
+  const uint32_t n_items = pl.n_uniq + 1;
+  for (uint32_t u = tid; u < n_items; u += 256) {
+    const bool is_root = u == pl.n_uniq;
+    write_node_header(a, (is_root ? payload : graph) + pl.fld[u], is_root ? 0x0A : 0x12, pl.uid[u]);
+  }
+  // float payloads: the (node, word) pairs are spread evenly over the 256 threads.  A payload starts at an
+  // arbitrary byte address: output word k of a node = funnel shift of source words k-1 and k, stored as an
+  // aligned dword (head and tail bytes of a payload by byte stores, they share their dwords with headers).
+  if (a.d > 0) {
+    // item = (node, chunk of 4 output words); output words k = 0..D (word D only holds the tail bytes of a
+    // misaligned payload)
+    const uint32_t D = (uint32_t)a.d, nch = (D + 4) / 4;
+    const uint32_t total = n_items * nch, du = 256u / nch, dc = 256u % nch;
+    const bool vec_rows = a.feat_dtype == GIGL_DTYPE_F32 && (D & 3u) == 0;  // rows are 16-byte aligned
+    uint32_t u = tid / nch, c = tid % nch;
+    struct __attribute__((packed, aligned(4))) W4 {
+      uint32_t x, y, z, w;
+    };
+    constexpr int UNR = 2;  // row loads of UNR items are issued before any of them is consumed
+    for (uint32_t i0 = 0; i0 < total; i0 += 256 * UNR) {
+      uint32_t id[UNR], k0[UNR], w[UNR][4], pw[UNR];
+      uint8_t* dst[UNR];
+      bool valid[UNR];
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) {
+        valid[j] = i0 + j * 256 + tid < total;
+        k0[j] = 4u * c;
+        id[j] = pw[j] = w[j][0] = w[j][1] = w[j][2] = w[j][3] = 0;
+        dst[j] = nullptr;
+        if (valid[j]) {
+          id[j] = pl.uid[u];
+          dst[j] = (u == pl.n_uniq ? payload : graph) + pl.pay[u];
+          if (vec_rows && k0[j] + 3 < D && (int64_t)id[j] < a.feat_n) {
+            const uint4 q = *(const uint4*)((const uint32_t*)a.feat + (int64_t)id[j] * D + k0[j]);
+            w[j][0] = q.x;
+            w[j][1] = q.y;
+            w[j][2] = q.z;
+            w[j][3] = q.w;
+          } else {
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t)
+              if (k0[j] + t < D) w[j][t] = feat_word(a, id[j], k0[j] + t);
+          }
+          // word k0-1: lane-1 holds it (previous chunk of the same node) except in lane 0
+          if (lane == 0 && c > 0) pw[j] = feat_word(a, id[j], k0[j] - 1);
+        }
+        u += du;
+        c += dc;
+        if (c >= nch) {
+          c -= nch;
+          ++u;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < UNR; ++j) {
+        uint32_t prev = __shfl_up(w[j][3], 1, 64);
+        if (!valid[j]) continue;
+        if (k0[j] == 0) prev = 0;
+        else if (lane == 0) prev = pw[j];
+        const uint32_t rr = (uint32_t)((uintptr_t)dst[j] & 3u);
+        if (rr == 0) {
+          uint32_t* o = (uint32_t*)dst[j] + k0[j];
+          if (k0[j] + 3 < D) {
+            *(W4*)o = W4{w[j][0], w[j][1], w[j][2], w[j][3]};
+          } else {
+#pragma unroll
+            for (uint32_t t = 0; t < 3; ++t)
+              if (k0[j] + t < D) o[t] = w[j][t];
+          }
+        } else {
+          uint32_t* o = (uint32_t*)(dst[j] - rr) + k0[j];
+          const uint32_t sh = 8u * rr, sl = 32u - sh;
+          const uint32_t vs[4] = {(prev >> sl) | (w[j][0] << sh), (w[j][0] >> sl) | (w[j][1] << sh),
+                                  (w[j][1] >> sl) | (w[j][2] << sh), (w[j][2] >> sl) | (w[j][3] << sh)};
+          if (k0[j] > 0 && k0[j] + 3 < D) {
+            *(W4*)o = W4{vs[0], vs[1], vs[2], vs[3]};
+          } else {
+#pragma unroll
+            for (uint32_t t = 0; t < 4; ++t) {
+              const uint32_t k = k0[j] + t;
+              if (k > D) break;
+              if (k == 0) {
+                for (uint32_t b = rr; b < 4; ++b) ((uint8_t*)o)[b] = (uint8_t)(vs[t] >> (8u * b));
+              } else if (k == D) {
+                for (uint32_t b = 0; b < rr; ++b) ((uint8_t*)(o + t))[b] = (uint8_t)(vs[t] >> (8u * b));
+              } else {
+                o[t] = vs[t];
+              }
+            }
+          }
+        }
+      }
+    }
   }
   // Graph.edges = 3: one thread per edge
   const uint32_t n_e = (uint32_t)(a.trees * a.edge_len);
@@ -554,10 +636,18 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
     const uint8_t* p = payload + lo;
     const uint8_t* const e = payload + hi;
     while (p < e && ((uintptr_t)p & 3u)) c = crc_byte(crc_t, c, *p++);
+    for (; p + 16 <= e; p += 16) {  // four loads in flight per lane
+      const uint32_t w0 = ((const uint32_t*)p)[0], w1 = ((const uint32_t*)p)[1], w2 = ((const uint32_t*)p)[2],
+                     w3 = ((const uint32_t*)p)[3];
+      c = crc_word(crc_t, c, w0);
+      c = crc_word(crc_t, c, w1);
+      c = crc_word(crc_t, c, w2);
+      c = crc_word(crc_t, c, w3);
+    }
     for (; p + 4 <= e; p += 4) c = crc_word(crc_t, c, *(const uint32_t*)p);
     while (p < e) c = crc_byte(crc_t, c, *p++);
     uint32_t part = 0;
-    if (c) part = multmodp(x8n_modp(a, n - hi), c);
+    if (c) part = multmodp(x8n_modp(a.shift_tbl, n - hi), c);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) part ^= __shfl_xor(part, o, 64);
     if (lane == 0) s_x[w] = part;
@@ -588,7 +678,7 @@ uint32_t next_pow2(uint32_t x) {
   return p;
 }
 
-constexpr int64_t MAX_STREAM = 4096;  // node-stream positions per record the LDS plan is sized for
+constexpr int64_t MAX_STREAM = 2048;  // node-stream positions per record the LDS plan is sized for
 
 int32_t fill_args(gigl_ctx* ctx, const int32_t* fanouts, int32_t hops, const gigl_record_opts* o, RecArgs& a) {
   GIGL_REQUIRE(ctx, fanouts && o, "null argument");
@@ -625,9 +715,27 @@ int32_t fill_args(gigl_ctx* ctx, const int32_t* fanouts, int32_t hops, const gig
   a.suffix_off = o->suffix_off;
   a.hash_cap = next_pow2((uint32_t)(2 * a.trees * a.tree_len));
   a.ehash_cap = a.trees > 1 ? next_pow2((uint32_t)(2 * a.trees * a.edge_len)) : 0;
+  return GIGL_OK;
+}
+
+// x^(8*b*256^j) mod P for j = 0..2, b = 0..255 (ctx-owned device table, built once)
+int32_t ensure_shift_table(gigl_ctx* ctx) {
+  if (ctx->crc_shift_tbl) return GIGL_OK;
+  std::vector<uint32_t> t(768);
+  uint32_t x2n[32];
   uint32_t p = 1u << 30;  // x^1
-  a.x2n[0] = p;
-  for (int k = 1; k < 32; ++k) a.x2n[k] = p = host_multmodp(p, p);
+  x2n[0] = p;
+  for (int k = 1; k < 32; ++k) x2n[k] = p = host_multmodp(p, p);
+  for (int j = 0; j < 3; ++j) {
+    const uint32_t step = x2n[3 + 8 * j];  // x^(8*256^j)
+    uint32_t acc = 1u << 31;               // x^0
+    for (int b = 0; b < 256; ++b) {
+      t[j * 256 + b] = acc;
+      acc = host_multmodp(step, acc);
+    }
+  }
+  GIGL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->crc_shift_tbl, 768 * 4));
+  GIGL_HIP_CHECK(ctx, hipMemcpy(ctx->crc_shift_tbl, t.data(), 768 * 4, hipMemcpyHostToDevice));
   return GIGL_OK;
 }
 
@@ -690,6 +798,9 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
   }
   a.n_records = n_records;
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  rc = ensure_shift_table(ctx);
+  if (rc != GIGL_OK) return rc;
+  a.shift_tbl = ctx->crc_shift_tbl;
   rc = gigl_arena_reset(ctx, (n_records + 1) * 8 + 256);
   if (rc != GIGL_OK) return rc;
   int64_t* rec_size = (int64_t*)gigl_arena_alloc(ctx, (n_records + 1) * 8);

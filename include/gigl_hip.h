@@ -190,7 +190,9 @@ int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* 
  * explicit presence for the `optional` condensed types, packed floats).  tfrecord_frame != 0 wraps every
  * record as u64 length | masked crc32c(length) | payload | masked crc32c(payload).
  * All pointers DEVICE.  rec_off[r] = byte offset of record r in `out`, rec_off[n_records] = total bytes;
- * *status = 1 (and nothing is written) when the total exceeds out_cap.  Never synchronises with the host. */
+ * *status = 1 (and nothing is written) when the total exceeds out_cap.  Never synchronises with the host.
+ * A record's plan lives in LDS: trees_per_record * (1 + sum of slots per tree) must be <= 2048
+ * (GIGL_E_UNSUPPORTED otherwise; [25,10] allows up to 6 positives). */
 #define GIGL_REC_ROOTED_NODE_NEIGHBORHOOD 0
 #define GIGL_REC_NODE_ANCHOR_LINK_PRED 1
 

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Throughput of the device-side record encoder (gigl_records_encode) on the bench workload:
+products-shaped graph, fanout [25,10], D=100 fp32; B roots per call.  Prints bytes/s of finished TFRecord
+frames and the HBM-roofline fraction (algorithmic bytes = record bytes written + 4*D per distinct node read +
+4 B per tree slot read three times (plan x2, write))."""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from gigl_amd.engine import HipEngine  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=4096)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--small", action="store_true")
+a = ap.parse_args()
+eng = HipEngine(0)
+n, d = bench.build_workload(eng, a)
+g = torch.Generator().manual_seed(42)
+fan = [25, 10]
+roots = torch.randperm(n, generator=g)[: a.batch].to(torch.int32).cuda()
+tree = eng.sample_khop(roots, fan)
+buf, off = eng.encode_records(tree)
+nbytes = buf.numel()
+recs = wire_ok = None
+from gigl_amd import wire  # noqa: E402
+recs = list(wire.iter_tfrecords(buf[: int(off[8])].cpu().numpy().tobytes()))  # CRCs verified by the reader
+slots = sum(fan[0] * (fan[1] if k else 1) for k in range(2)) + 1
+torch.cuda.synchronize()
+for label, fn in (("sample+encode", lambda: eng.encode_records(eng.sample_khop(roots, fan, out=tree))),
+                  ("encode", lambda: eng.encode_records(tree))):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.iters):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.iters
+    print(f"{label:14s} B={a.batch} {dt*1e3:8.3f} ms/call  {nbytes/dt/1e9:7.1f} GB/s of records "
+          f"({nbytes/a.batch/1e3:.1f} KB/record, {a.batch/dt/1e6:.2f} M records/s)  "
+          f"roofline(write+feature read) ~{(2*nbytes + 3*4*slots*a.batch)/dt/8e12:.3f} of 8 TB/s")
+eng.close()
