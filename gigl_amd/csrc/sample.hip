@@ -151,8 +151,10 @@ struct ExpandArgs {
   int32_t proxy_drop;  // test knob (env GIGL_SAMPLER_PROXY_BITS): 32 - bits kept by the fast path's proxy keys
 };
 
-// CSC row of the parent in slot p and K (wrapping int32 sum of the path ids) — wave-uniform
-__device__ __forceinline__ void parent_of(const ExpandArgs& a, int64_t p, uint32_t& v, uint32_t& ksum) {
+// CSC row of the parent in slot p and K (wrapping int32 sum of the path ids) — wave-uniform.  Slot numbers are
+// < 2^31 (checked by the callers): 32-bit divisions (a 64-bit one costs ~150 scalar instructions, and the CU's
+// single scalar ALU was as busy as the vector units).
+__device__ __forceinline__ void parent_of(const ExpandArgs& a, uint32_t p, uint32_t& v, uint32_t& ksum) {
   if (a.ex_nodes) {
     v = a.ex_nodes[p];
     ksum = a.ex_ksum[p];
@@ -164,14 +166,19 @@ __device__ __forceinline__ void parent_of(const ExpandArgs& a, int64_t p, uint32
     ksum = v;
     return;
   }
+  if (a.hop == 1) {  // the common two-hop case without the generic loop
+    v = a.anc[0][p];
+    ksum = v + a.roots[p / (uint32_t)a.fan[0]];
+    return;
+  }
   v = a.anc[a.hop - 1][p];
   uint32_t s = v;
-  int64_t q = p;
+  uint32_t q = p;
   for (int l = a.hop - 1; l >= 1; --l) {
-    q /= a.fan[l];
+    q /= (uint32_t)a.fan[l];
     s += a.anc[l - 1][q];
   }
-  q /= a.fan[0];
+  q /= (uint32_t)a.fan[0];
   s += a.roots[q];
   ksum = s;
 }
@@ -183,32 +190,86 @@ constexpr int64_t HEAVY_DEG = 4096;
 //
 // Every parity-mode query is "the f smallest (g(j), j) for j in [base+1, base+deg]" where
 // g(j) = xxhash64_int32(j) is ONE fixed function of the integer j = i + K + seed*counter — the graph,
-// the roots and the sampling seed only move the window.  So the top-64 of g over aligned blocks of
-// the j axis is computed once per ctx and shared by all queries: a hub row of degree 10^5 then costs
-// two partial blocks of direct hashing (< 2*256 hashes) plus a handful of list-merge rounds instead
-// of 10^5 hashes.  Results are bit-identical to the direct evaluation: a block's top-64 by (g, j)
-// contains every element of that block that can be in the window's top-f (f <= 64), and j order ==
-// i order inside a non-wrapping window.
-//   level 0 block = 256 consecutive j; level l block = 16 level-(l-1) blocks.
-//   memory: 64/256 * 12 B = 3 B per covered j (+1/16 per extra level).
-// A window decomposes into <= 15 blocks per level and side.  The lists are merged by ROUNDS: lane q
-// owns list q and offers its next entry each round (one parallel load for all lists); a list stays
-// in play only while its offer still beats the running threshold, so the serial chain per row is
-// the largest number of winners coming from one block, not the number of blocks.
+// the roots and the sampling seed only move the window.  So g is tabulated once per ctx, sorted inside aligned
+// blocks of the j axis, and shared by all queries:
+//   level 0 block = 64 consecutive j, ALL of them, sorted by (g, j);
+//   level l block = 16 level-(l-1) blocks, its 64 smallest (g, j), sorted.
+//   memory: 12 B per covered j (+1/16 per extra level); hi and lo key words are separate arrays, the 32-bit
+//   proxy path reads only the hi words.
+// A window = a partial level-0 block at each end (read whole, one entry per lane, entries outside the window
+// dropped) + full blocks, decomposed into <= 15 blocks per level and side (the segment-tree cover).  A row never
+// hashes anything: the sampler kernel was VALU-bound on the 64-bit multiplies of xxhash64 (SQ counters: 88 % VALU
+// busy, half of the instructions in head/tail hashing when level 0 was 256 wide and only its top-64 was kept).
+// Results are bit-identical to the direct evaluation: a block's list contains every element of that block that
+// can be in the window's top-f (f <= 64), and j order == i order inside a non-wrapping window.
 // Windows that leave the covered domain or wrap around 2^32 fall back to direct hashing.
 // ------------------------------------------------------------------------------------------
-constexpr int TBL_S0_SHIFT = 8;   // 256 j per level-0 block
+constexpr int TBL_S0_SHIFT = 6;   // 64 j per level-0 block (the whole block is kept, sorted)
 constexpr int TBL_FAN_SHIFT = 4;  // 16 children per block
 constexpr int TBL_MAX_LEVELS = 7;
 constexpr int TBL_TOPK = 64;
 
 struct RangeTable {
   int levels;
-  uint64_t dom;          // covered j domain [0, dom), multiple of 256
-  const uint64_t* keys;  // entry e of block blk at level l: [(lvl_off[l] + blk) * 64 + e]
+  uint64_t dom;         // covered j domain [0, dom), multiple of 64
+  const uint32_t* khi;  // entry e of block blk at level l: [(lvl_off[l] + blk) * 64 + e]; ordered-hash bits 63..32
+  const uint32_t* klo;  //                                                                  ordered-hash bits 31..0
   const uint32_t* js;
   int64_t lvl_off[TBL_MAX_LEVELS];
   int64_t nblocks[TBL_MAX_LEVELS];
+};
+
+// Aligned decomposition of the level-0 block range [lo, hi), level by level (the segment-tree cover): at level l
+// the blocks left of the next 16-alignment and right of the last one are taken (<= 15 each), the aligned middle
+// moves up a level.  O(levels) scalar work; the lists are enumerated level-ascending, left then right, so that
+// the LAST list is a block of the highest level reached.
+struct Cover {
+  uint32_t ls[TBL_MAX_LEVELS], ln[TBL_MAX_LEVELS], rs[TBL_MAX_LEVELS], rn[TBL_MAX_LEVELS];
+  uint32_t n_lists;
+  __device__ __forceinline__ void build(const RangeTable& tb, uint32_t lo, uint32_t hi) {
+    n_lists = 0;
+#pragma unroll
+    for (int l = 0; l < TBL_MAX_LEVELS; ++l) {
+      uint32_t nl = 0, nr = 0;
+      if (l < tb.levels && lo < hi) {
+        if (l == tb.levels - 1) {
+          nl = hi - lo;
+        } else {
+          nl = min((16u - (lo & 15u)) & 15u, hi - lo);
+          nr = min(hi & 15u, hi - lo - nl);
+        }
+      }
+      ls[l] = lo;
+      ln[l] = nl;
+      rs[l] = hi - nr;
+      rn[l] = nr;
+      n_lists += nl + nr;
+      lo = (lo + nl) >> TBL_FAN_SHIFT;
+      hi = (hi - nr) >> TBL_FAN_SHIFT;
+    }
+  }
+  // entry index of the first element of list x (enumeration order above); wave-uniform or per-lane x
+  // (global block ids fit 32 bits: <= 2^24 level-0 blocks plus 1/15 of that above them)
+  __device__ __forceinline__ int64_t entry(const RangeTable& tb, uint32_t x) const {
+    uint32_t gb = 0;
+    bool found = false;
+#pragma unroll
+    for (int l = 0; l < TBL_MAX_LEVELS; ++l) {
+      if ((ln[l] | rn[l]) == 0) continue;  // (uniform) most windows touch two or three levels
+      const uint32_t off = (uint32_t)tb.lvl_off[l];
+      if (!found && x < ln[l]) {
+        gb = off + ls[l] + x;
+        found = true;
+      }
+      x -= ln[l];  // (wraps once found: harmless)
+      if (!found && x < rn[l]) {
+        gb = off + rs[l] + x;
+        found = true;
+      }
+      x -= rn[l];
+    }
+    return found ? (int64_t)gb * TBL_TOPK : (int64_t)-1;
+  }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -370,9 +431,116 @@ struct Sel {
     return true;
   }
   __device__ __forceinline__ key_t table_key(const RangeTable& tb, int64_t e) const {
-    if constexpr (FAST)  // high word (little endian)
-      return (reinterpret_cast<const uint32_t*>(tb.keys)[2 * e + 1] >> drop) << drop;
-    else return tb.keys[e];
+    if constexpr (FAST) return (tb.khi[e] >> drop) << drop;
+    else return ((uint64_t)tb.khi[e] << 32) | tb.klo[e];
+  }
+  // FAST only.  The whole row from the table, without a serial insert chain: with T = lambda/deg * 2^32
+  // (lambda = f + 4 sqrt(f) + 4) about lambda elements of the window have a proxy below T.  The partial blocks at
+  // the window's ends are read whole, one entry per lane; a full block's list is sorted, so the lane that owns it
+  // reads entries only while they stay below T (one parallel load per round for 64 lists).  The <= 64 survivors
+  // are compacted into the wave's LDS scratch and ranked by counting.  Exact: an element that is not a survivor
+  // has a proxy >= T (for a list: it is at or after the first entry >= T) > every survivor's.  Needs >= f
+  // survivors, <= 64, no list exhausted below T, and no proxy shared by two survivors (-> tie -> exact path).
+  // Returns false when the row must take the insert-based path instead.
+  __device__ __forceinline__ bool table_filter(const RangeTable& tb, int64_t deg, uint32_t base, const Cover& cv,
+                                               uint32_t* lk, uint32_t* li) {
+    const float lam = (float)f + 4.f * __builtin_sqrtf((float)f) + 4.f;
+    if (lam > 56.f) return false;
+    const uint32_t n = (uint32_t)deg;
+    const bool all = n <= 64u;
+    const uint32_t T = all ? 0xFFFFFFFFu : (uint32_t)fminf(lam * 4294967296.f / (float)n, 4294967040.f);
+    uint32_t count = 0;
+    bool exhausted = false;
+    auto offer = [&](key_t k, uint32_t i, bool pass) {
+      const unsigned long long m = __ballot(pass);
+      if (pass) {
+        const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (pos < 64u) {
+          lk[pos] = (uint32_t)k;
+          li[pos] = i;
+        }
+      }
+      count += (uint32_t)__popcll(m);
+    };
+    // All table loads of a phase are issued before any of them is consumed: the kernel is otherwise bound by
+    // the round-trip latency of dependent loads (SQ counters: 75 % of the wave cycles waiting).
+    const uint64_t j_lo = (uint64_t)base + 1, j_hi = (uint64_t)base + (uint64_t)deg;
+    const uint32_t first_blk = (uint32_t)(j_lo >> TBL_S0_SHIFT), last_blk = (uint32_t)(j_hi >> TBL_S0_SHIFT);
+    constexpr uint32_t WIDE_MAX = 8;
+    // level-0 blocks read whole, one entry per lane (entries outside the window dropped): every block of a short
+    // row (few blocks: wide reads beat owned-list rounds), else just the partial blocks at the window's ends
+    const bool short_row = last_blk - first_blk < WIDE_MAX;
+    const bool head_partial = (j_lo & 63u) != 0, tail_partial = ((j_hi + 1) & 63u) != 0;
+    const uint32_t nw = short_row ? last_blk - first_blk + 1 : (head_partial ? 1u : 0u) + (tail_partial ? 1u : 0u);
+    const uint32_t wb1 = short_row ? first_blk + 1 : last_blk;
+    const uint32_t wb0 = short_row || head_partial ? first_blk : last_blk;
+    {
+      key_t wk[WIDE_MAX];
+      uint32_t wj[WIDE_MAX];
+#pragma unroll
+      for (uint32_t t = 0; t < WIDE_MAX; ++t)
+        if (t < nw) {
+          const uint32_t blk = t == 0 ? wb0 : t == 1 ? wb1 : first_blk + t;
+          const int64_t e = (int64_t)blk * TBL_TOPK + lane;
+          wk[t] = table_key(tb, e);
+          wj[t] = tb.js[e];
+        }
+#pragma unroll
+      for (uint32_t t = 0; t < WIDE_MAX; ++t)
+        if (t < nw) {
+          const uint32_t i = wj[t] - base;  // position; outside [1, deg] = not in the window
+          offer(wk[t], i, (uint32_t)(i - 1u) < n && (all || wk[t] < T));
+        }
+    }
+    if (!short_row) {  // (a long row has full blocks: the cover is built)
+      for (uint32_t x0 = 0; x0 < cv.n_lists; x0 += 64) {
+        const uint32_t x = x0 + (uint32_t)lane;
+        const int64_t ent = x < cv.n_lists ? cv.entry(tb, x) : -1;
+        bool active = ent >= 0;
+        for (int cur = 0; cur < TBL_TOPK && __ballot(active); cur += 4) {  // 4 entries per lane and round
+          uint4 k4 = make_uint4(~0u, ~0u, ~0u, ~0u), j4 = make_uint4(0, 0, 0, 0);
+          if (active) {
+            k4 = *(const uint4*)(tb.khi + ent + cur);
+            j4 = *(const uint4*)(tb.js + ent + cur);
+          }
+          const uint32_t ks[4] = {(k4.x >> drop) << drop, (k4.y >> drop) << drop, (k4.z >> drop) << drop,
+                                  (k4.w >> drop) << drop};
+          const uint32_t jj[4] = {j4.x, j4.y, j4.z, j4.w};
+          bool pass = active;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            pass = pass && ks[t] < T;  // sorted list: once an entry fails, the rest fail
+            offer((key_t)ks[t], jj[t] - base, pass);
+          }
+          active = pass;
+          if (pass && cur + 4 == TBL_TOPK) exhausted = true;
+        }
+      }
+    }
+    if (__ballot(exhausted) || count < (uint32_t)f || count > 64u) {
+      wave_lds_sync();
+      return false;
+    }
+    wave_lds_sync();
+    const bool valid = (uint32_t)lane < count;
+    const uint32_t k = valid ? lk[lane] : 0xFFFFFFFFu;
+    const uint32_t i = valid ? li[lane] : 0xFFFFFFFFu;
+    uint32_t rank = 0;  // survivors with a strictly smaller proxy
+    for (uint32_t j = 0; j < count; ++j) rank += readlane32(k, (int)j) < k ? 1u : 0u;
+    // two survivors share a proxy <=> they share a rank: every survivor writes its lane under its rank and reads
+    // it back (the ranks of distinct proxies are distinct)
+    wave_lds_sync();
+    if (valid) lk[rank] = (uint32_t)lane;
+    wave_lds_sync();
+    if (__ballot(valid && lk[rank] != (uint32_t)lane)) {
+      tie = true;
+      return true;
+    }
+    if (valid && rank < (uint32_t)f) li[rank] = i;
+    wave_lds_sync();
+    idx = lane < f ? li[lane] : 0xFFFFFFFFu;
+    return true;
   }
   // merge the lists owned by the lanes (my_ent = first entry of the lane's list, or -1) by rounds
   __device__ __forceinline__ void merge_lists(const RangeTable& tb, int64_t my_ent, uint32_t base) {
@@ -394,70 +562,32 @@ struct Sel {
   // the whole row: window of positions [1, deg] with hash offset `base`
   __device__ __forceinline__ void select(const RangeTable& tb, int64_t deg, uint32_t base, bool in_table,
                                          uint32_t* lk = nullptr, uint32_t* li = nullptr) {
-    const uint64_t j_lo = (uint64_t)base + 1, j_hi = (uint64_t)base + (uint64_t)deg;  // inclusive window
-    // aligned level-0 blocks fully inside the window come from the table
-    const uint64_t b_first = (j_lo + ((1u << TBL_S0_SHIFT) - 1)) >> TBL_S0_SHIFT;
-    const uint64_t b_last = (j_hi + 1) >> TBL_S0_SHIFT;  // one past the last full block
-    if (!in_table || b_first >= b_last) {
+    if (!in_table) {
       if constexpr (FAST) {
         if (lk && filter_select(deg, base, lk, li)) return;
       }
       scan_direct(1, deg, base);
       return;
     }
-    // Aligned decomposition of the block range [b_first, b_last), level by level (the segment-tree cover): at
-    // level l the blocks left of the next 16-alignment and right of the last one are taken (<= 15 each), the
-    // aligned middle moves up a level.  O(levels) scalar work; the lists are enumerated level-ascending, left
-    // then right, so that the LAST list is a block of the highest level reached.  That one seeds the best
-    // list (its sorted top-64 makes the threshold tight before anything is inserted); list x < n_lists-1 is
-    // located by lane arithmetic below.
-    uint32_t ls[TBL_MAX_LEVELS], ln[TBL_MAX_LEVELS], rs[TBL_MAX_LEVELS], rn[TBL_MAX_LEVELS];
-    uint32_t n_lists = 0;
-    {
-      uint32_t lo = (uint32_t)b_first, hi = (uint32_t)b_last;
-#pragma unroll
-      for (int l = 0; l < TBL_MAX_LEVELS; ++l) {
-        uint32_t nl = 0, nr = 0;
-        if (l < tb.levels && lo < hi) {
-          if (l == tb.levels - 1) {
-            nl = hi - lo;
-          } else {
-            nl = min((16u - (lo & 15u)) & 15u, hi - lo);
-            nr = min(hi & 15u, hi - lo - nl);
-          }
-        }
-        ls[l] = lo;
-        ln[l] = nl;
-        rs[l] = hi - nr;
-        rn[l] = nr;
-        n_lists += nl + nr;
-        lo = (lo + nl) >> TBL_FAN_SHIFT;
-        hi = (hi - nr) >> TBL_FAN_SHIFT;
-      }
+    const uint64_t j_lo = (uint64_t)base + 1, j_hi = (uint64_t)base + (uint64_t)deg;  // inclusive window
+    // aligned level-0 blocks fully inside the window
+    const uint64_t b_first = (j_lo + ((1u << TBL_S0_SHIFT) - 1)) >> TBL_S0_SHIFT;
+    const uint64_t b_last = (j_hi + 1) >> TBL_S0_SHIFT;  // one past the last full block
+    const bool has_full = b_first < b_last;
+    Cover cv;
+    cv.build(tb, (uint32_t)b_first, has_full ? (uint32_t)b_last : (uint32_t)b_first);  // (empty cover: n_lists 0)
+    if constexpr (FAST) {
+      if (lk && table_filter(tb, deg, base, cv, lk, li)) return;
     }
-    // entry index of the first element of list x (enumeration order above); wave-uniform or per-lane x
-    // (global block ids fit 32 bits: <= 2^24 level-0 blocks plus 1/15 of that above them)
-    auto list_entry = [&](uint32_t x) -> int64_t {
-      uint32_t gb = 0;
-      bool found = false;
-#pragma unroll
-      for (int l = 0; l < TBL_MAX_LEVELS; ++l) {
-        const uint32_t off = (uint32_t)tb.lvl_off[l];
-        if (!found && x < ln[l]) {
-          gb = off + ls[l] + x;
-          found = true;
-        }
-        x -= ln[l];  // (wraps once found: harmless)
-        if (!found && x < rn[l]) {
-          gb = off + rs[l] + x;
-          found = true;
-        }
-        x -= rn[l];
-      }
-      return found ? (int64_t)gb * TBL_TOPK : (int64_t)-1;
-    };
+    // insert-based path (exact keys; proxy rows the filter could not settle): the last list — a block of the
+    // highest level reached — seeds the best list (its sorted entries make the threshold tight before anything
+    // is inserted); the other lists are merged by rounds; head and tail positions are hashed directly.
+    if (!has_full) {
+      scan_direct(1, deg, base);
+      return;
+    }
     {
-      const int64_t ent = list_entry(n_lists - 1);
+      const int64_t ent = cv.entry(tb, cv.n_lists - 1);
       key = table_key(tb, ent + lane);
       idx = tb.js[ent + lane] - base;  // position i = j - base
       if constexpr (FAST) {  // equal proxies inside the seed list (adjacent: it is sorted by the full key)
@@ -467,9 +597,9 @@ struct Sel {
       refresh_threshold();
     }
     // the other lists, 64 per batch, list q of a batch owned by lane q, merged by rounds
-    for (uint32_t x0 = 0; x0 + 1 < n_lists; x0 += 64) {
+    for (uint32_t x0 = 0; x0 + 1 < cv.n_lists; x0 += 64) {
       const uint32_t x = x0 + (uint32_t)lane;
-      merge_lists(tb, x + 1 < n_lists ? list_entry(x) : -1, base);
+      merge_lists(tb, x + 1 < cv.n_lists ? cv.entry(tb, x) : -1, base);
     }
     // head: positions before the first block boundary; tail: after the last full block
     const int64_t head_hi = (int64_t)((b_first << TBL_S0_SHIFT) - 1 - base);  // position of the last head j
@@ -480,17 +610,18 @@ struct Sel {
 };
 
 __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a, RangeTable tb) {
-  __shared__ uint32_t s_lk[4][64], s_li[4][64];  // per-wave survivor scratch of Sel::filter_select
+  __shared__ uint32_t s_lk[4][64], s_li[4][64];  // per-wave survivor scratch of the filter selections
   const int lane = threadIdx.x & 63;
   // the parent slot, its row and every window bound are the same for all lanes: say so (readfirstlane), and the
   // per-row control flow below runs on the scalar unit with scalar loads instead of 64-bit vector arithmetic
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t waves_total = (int64_t)gridDim.x * 4;
-  for (int64_t p = (int64_t)blockIdx.x * 4 + wave_in_block; p < a.n_parents; p += waves_total) {
+  const uint32_t waves_total = gridDim.x * 4u;
+  const uint32_t n_parents = (uint32_t)a.n_parents;  // < 2^31 (checked by the callers)
+  const int f = a.f;
+  for (uint32_t p = blockIdx.x * 4u + (uint32_t)wave_in_block; p < n_parents; p += waves_total) {
     uint32_t v, ksum;
     parent_of(a, p, v, ksum);
-    uint32_t* out = a.out_nbr + p * a.f;
-    const int f = a.f;
+    uint32_t* out = a.out_nbr + (int64_t)p * f;
     if (v == GIGL_INVALID || (int64_t)v >= a.n_nodes) {
       if (lane < f) out[lane] = GIGL_INVALID;
       if (lane == 0) a.out_cnt[p] = 0;
@@ -525,8 +656,8 @@ __global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a, RangeTable tb
   }
 }
 
-// table construction, level 0: one wave per block of 256 consecutive j
-__global__ __launch_bounds__(256) void table_l0_kernel(uint64_t* keys, uint32_t* js, int64_t nblocks) {
+// table construction, level 0: one wave per block of 64 consecutive j, all of them, sorted
+__global__ __launch_bounds__(256) void table_l0_kernel(uint32_t* khi, uint32_t* klo, uint32_t* js, int64_t nblocks) {
   const int lane = threadIdx.x & 63;
   const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blk >= nblocks) return;
@@ -538,25 +669,28 @@ __global__ __launch_bounds__(256) void table_l0_kernel(uint64_t* keys, uint32_t*
     uint32_t j = j0 + c * 64 + lane;
     merge_candidates(key, idx, xxh64_i32_ordered(j), j, true, tk, ti, 64, lane);
   }
-  keys[blk * TBL_TOPK + lane] = key;
+  khi[blk * TBL_TOPK + lane] = (uint32_t)(key >> 32);
+  klo[blk * TBL_TOPK + lane] = (uint32_t)key;
   js[blk * TBL_TOPK + lane] = idx;
 }
 
 // level l+1 from level l: one wave per parent block, merging its 16 children's lists
-__global__ __launch_bounds__(256) void table_up_kernel(const uint64_t* ckeys, const uint32_t* cjs,
-                                                       uint64_t* keys, uint32_t* js, int64_t nblocks) {
+__global__ __launch_bounds__(256) void table_up_kernel(const uint32_t* chi, const uint32_t* clo, const uint32_t* cjs,
+                                                       uint32_t* khi, uint32_t* klo, uint32_t* js, int64_t nblocks) {
   const int lane = threadIdx.x & 63;
   const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blk >= nblocks) return;
   const int64_t c0 = blk << TBL_FAN_SHIFT;
-  uint64_t key = ckeys[c0 * TBL_TOPK + lane];
+  auto ckey = [&](int64_t e) { return ((uint64_t)chi[e] << 32) | clo[e]; };
+  uint64_t key = ckey(c0 * TBL_TOPK + lane);
   uint32_t idx = cjs[c0 * TBL_TOPK + lane];  // child lists are ascending already
   uint64_t tk = readlane64(key, 63);
   uint32_t ti = readlane32(idx, 63);
   for (int c = 1; c < (1 << TBL_FAN_SHIFT); ++c)
-    merge_candidates(key, idx, ckeys[(c0 + c) * TBL_TOPK + lane], cjs[(c0 + c) * TBL_TOPK + lane], true, tk,
-                     ti, 64, lane);
-  keys[blk * TBL_TOPK + lane] = key;
+    merge_candidates(key, idx, ckey((c0 + c) * TBL_TOPK + lane), cjs[(c0 + c) * TBL_TOPK + lane], true, tk, ti, 64,
+                     lane);
+  khi[blk * TBL_TOPK + lane] = (uint32_t)(key >> 32);
+  klo[blk * TBL_TOPK + lane] = (uint32_t)key;
   js[blk * TBL_TOPK + lane] = idx;
 }
 
@@ -655,22 +789,25 @@ int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
     nb >>= TBL_FAN_SHIFT;
   }
   t.levels = L;
-  const size_t key_bytes = (size_t)total_blocks * TBL_TOPK * 8;
-  const size_t total = key_bytes + (size_t)total_blocks * TBL_TOPK * 4;
+  const size_t arr_bytes = (size_t)total_blocks * TBL_TOPK * 4;
+  const size_t total = 3 * arr_bytes;
   if (hipMalloc(&own->mem, total ? total : 256) != hipSuccess) {
     own->mem = nullptr;
     return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the %zu-byte hash range table failed", total);
   }
-  uint64_t* keys = (uint64_t*)own->mem;
-  uint32_t* js = (uint32_t*)((char*)own->mem + key_bytes);
-  t.keys = keys;
+  uint32_t* khi = (uint32_t*)own->mem;
+  uint32_t* klo = (uint32_t*)((char*)own->mem + arr_bytes);
+  uint32_t* js = (uint32_t*)((char*)own->mem + 2 * arr_bytes);
+  t.khi = khi;
+  t.klo = klo;
   t.js = js;
-  hipLaunchKernelGGL(table_l0_kernel, dim3((unsigned)((t.nblocks[0] + 3) / 4)), dim3(256), 0, ctx->stream,
-                     keys, js, t.nblocks[0]);
-  for (int l = 1; l < L; ++l)
-    hipLaunchKernelGGL(table_up_kernel, dim3((unsigned)((t.nblocks[l] + 3) / 4)), dim3(256), 0, ctx->stream,
-                       keys + t.lvl_off[l - 1] * TBL_TOPK, js + t.lvl_off[l - 1] * TBL_TOPK,
-                       keys + t.lvl_off[l] * TBL_TOPK, js + t.lvl_off[l] * TBL_TOPK, t.nblocks[l]);
+  hipLaunchKernelGGL(table_l0_kernel, dim3((unsigned)((t.nblocks[0] + 3) / 4)), dim3(256), 0, ctx->stream, khi, klo,
+                     js, t.nblocks[0]);
+  for (int l = 1; l < L; ++l) {
+    const int64_t c = t.lvl_off[l - 1] * TBL_TOPK, q = t.lvl_off[l] * TBL_TOPK;
+    hipLaunchKernelGGL(table_up_kernel, dim3((unsigned)((t.nblocks[l] + 3) / 4)), dim3(256), 0, ctx->stream, khi + c,
+                       klo + c, js + c, khi + q, klo + q, js + q, t.nblocks[l]);
+  }
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   own->t = t;
@@ -806,7 +943,7 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
   if (mode == GIGL_MODE_SPARK_HASH) {
     // size the hash range table for this graph/seed (built once, reused by every later call)
     const uint64_t bound = window_bound(g, hops, 1, sampling_seed);
-    const uint64_t cap = 1ull << 31;  // 6 GiB of table at most; windows beyond fall back to direct hashing
+    const uint64_t cap = 1ull << 30;  // 13.7 GiB of table at most; windows beyond fall back to direct hashing
     rc = ensure_table(ctx, bound == ~0ULL ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));
     if (rc != GIGL_OK) return rc;
     tb = ((TableOwner*)ctx->sampler_table)->t;
@@ -869,7 +1006,7 @@ int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* n
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "fanout %d outside [1,%d]", f, GIGL_MAX_FANOUT);
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (m == 0) return GIGL_OK;
-  const uint64_t cap = 1ull << 31;
+  const uint64_t cap = 1ull << 30;
   const bool bounded = max_window_end >= 0;
   const uint64_t bound = bounded ? (uint64_t)max_window_end : ~0ULL;
   int32_t rc = ensure_table(ctx, !bounded ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));
@@ -932,7 +1069,7 @@ int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* 
   a.out_nbr = pos;
   a.out_cnt = cnt;
   const uint64_t bound = window_bound(g_out, 1, 3, sampling_seed);
-  const uint64_t cap = 1ull << 31;
+  const uint64_t cap = 1ull << 30;
   rc = ensure_table(ctx, bound == ~0ULL ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));
   if (rc != GIGL_OK) return rc;
   const RangeTable tb = ((TableOwner*)ctx->sampler_table)->t;
