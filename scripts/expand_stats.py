@@ -27,6 +27,14 @@ for _ in range(10):
 ms, nl = eng.profile_read("expand")
 eng.profile_enable([], 0)
 print(f"expand: {ms/nl*1e3*2:.1f} us per sample_khop call of {a.batch} roots (both hops)")
+t1 = eng.alloc_tree(a.batch, fan[:1])
+eng.sample_khop(roots, fan[:1], out=t1)
+eng.profile_enable(["expand"], 64)
+for _ in range(10):
+    eng.sample_khop(roots, fan[:1], out=t1)
+ms1, nl1 = eng.profile_read("expand")
+eng.profile_enable([], 0)
+print(f"expand hop 1 alone: {ms1/nl1*1e3:.1f} us")
 par = [roots.cpu().numpy().view(np.uint32), tree.nbr[0].cpu().numpy().view(np.uint32)]
 edges = [0, 256, 512, 1024, 4096, 16384, 65536, 1 << 30]
 for k, p in enumerate(par):
