@@ -32,6 +32,7 @@ SYMBOLS = [
     "gigl_sage_plan_destroy", "gigl_gather_mean_backward", "gigl_expand_frontier", "gigl_gcn_aggregate",
     "gigl_gat_aggregate", "gigl_gather_rows", "gigl_sage_plan_use_graph", "gigl_sage_plan_flush_profile",
     "gigl_union_build_groups", "gigl_sage_plan_set_groups", "gigl_records_capacity", "gigl_records_encode",
+    "gigl_tfrecord_index", "gigl_tfexample_decode",
 ]
 
 KERNEL_IDS = {
@@ -77,6 +78,17 @@ class GiglRecordOpts(C.Structure):
 
 
 REC_ROOTED_NODE_NEIGHBORHOOD, REC_NODE_ANCHOR_LINK_PRED = 0, 1
+COL_I64, COL_F32 = 0, 1
+
+
+class GiglColumn(C.Structure):
+    _fields_ = [
+        ("name", C.c_char_p),
+        ("kind", C.c_int32),
+        ("width", C.c_int32),
+        ("out", C.c_void_p),
+        ("counts", C.c_void_p),
+    ]
 
 
 class GiglError(RuntimeError):
@@ -143,6 +155,8 @@ def load() -> C.CDLL:
         "gigl_gather_mean_backward": [vp, vp, i32, vp, vp, vp, vp, i64, vp],
         "gigl_expand_frontier": [vp, vp, vp, vp, i64, i32, i32, i32, i64, vp, vp],
         "gigl_gather_rows": [vp, vp, i32, i32, vp, vp, i64, vp],
+        "gigl_tfrecord_index": [vp, i64, i32, i64, vp, vp, P(i64)],
+        "gigl_tfexample_decode": [vp, vp, vp, i64, P(GiglColumn), i32, i32, P(i64)],
         "gigl_records_capacity": [P(i32), i32, i32, P(GiglRecordOpts), i64, i64, P(i64)],
         "gigl_records_encode": [vp, vp, P(GiglTree), vp, P(GiglRecordOpts), i64, vp, i64, vp, vp],
         "gigl_gcn_aggregate": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, vp],

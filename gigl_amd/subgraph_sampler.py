@@ -37,32 +37,32 @@ from .sampler_service import HipKHopSamplerService
 def load_preprocessed_graph(cfg: GbmlConfigPbWrapper):
     """loadNodeDataframeIntoSparkSql / loadEdgeDataframeIntoSparkSql (SGSPureSparkV1Task.scala:52-118,120-286):
     node ids are the dense enumerated ids of the Data Preprocessor; features = the featureKeys columns
-    concatenated in order (:90-104)."""
+    concatenated in order (:90-104).  Decoded by the native reader (gigl_amd/ingest.py)."""
+    from .ingest import COL_F32, COL_I64, feature_widths, read_columns
     pm = cfg.preprocessed_metadata
     nm, em = pm.nodes[0], pm.edges[0]
-    ids, feats, labels = [], [], {}
-    for f in tfrecord_files(os.path.join(_res(cfg, nm.tfrecord_uri_prefix), "")):
-        for rec in wire.read_tfrecords(f):
-            ex = wire.decode_tf_example(rec)
-            nid = int(np.asarray(ex[nm.node_id_key])[0])
-            ids.append(nid)
-            feats.append(np.concatenate([np.asarray(ex[k], dtype=np.float32).reshape(-1) for k in nm.feature_keys])
-                         if nm.feature_keys else np.zeros(0, np.float32))
-            for lk in nm.label_keys:
-                if ex.get(lk) is not None and len(ex[lk]):
-                    labels.setdefault(lk, {})[nid] = int(np.asarray(ex[lk])[0])
-    n = (max(ids) + 1) if ids else 0
-    d = feats[0].size if feats else 0
+    nfiles = tfrecord_files(os.path.join(_res(cfg, nm.tfrecord_uri_prefix), ""))
+    cols = [(nm.node_id_key, COL_I64, 1)]
+    widths = feature_widths(nfiles[0], nm.feature_keys) if nfiles and nm.feature_keys else []
+    cols += [(k, COL_F32, max(w, 1)) for k, w in zip(nm.feature_keys, widths)]
+    cols += [(lk, COL_I64, 1) for lk in nm.label_keys if lk not in nm.feature_keys and lk != nm.node_id_key]
+    data, cnt = read_columns(nfiles, cols)
+    ids = data[nm.node_id_key][:, 0]
+    n = int(ids.max()) + 1 if ids.size else 0
+    d = int(sum(widths))
     x = np.zeros((n, d), dtype=np.float32)
-    for nid, fv in zip(ids, feats):
-        x[nid] = fv
-    src, dst = [], []
-    for f in tfrecord_files(os.path.join(_res(cfg, em.tfrecord_uri_prefix), "")):
-        for rec in wire.read_tfrecords(f):
-            ex = wire.decode_tf_example(rec)
-            src.append(int(np.asarray(ex[em.src_node_id_key])[0]))
-            dst.append(int(np.asarray(ex[em.dst_node_id_key])[0]))
-    return n, np.asarray(src, dtype=np.uint32), np.asarray(dst, dtype=np.uint32), x, labels, sorted(set(ids))
+    if d:
+        x[ids] = np.concatenate([data[k][:, :w] for k, w in zip(nm.feature_keys, widths) if w], axis=1)
+    labels: Dict[str, Dict[int, int]] = {}
+    for lk in nm.label_keys:
+        if lk in data and data[lk].dtype == np.int64:
+            have = cnt[lk] > 0
+            labels[lk] = dict(zip(ids[have].tolist(), data[lk][have, 0].tolist()))
+    efiles = tfrecord_files(os.path.join(_res(cfg, em.tfrecord_uri_prefix), ""))
+    ed, _ = read_columns(efiles, [(em.src_node_id_key, COL_I64, 1), (em.dst_node_id_key, COL_I64, 1)])
+    src = ed[em.src_node_id_key][:, 0].astype(np.uint32)  # ids cast to int32 (:164-168)
+    dst = ed[em.dst_node_id_key][:, 0].astype(np.uint32)
+    return n, src, dst, x, labels, sorted(set(ids.tolist()))
 
 
 def _res(cfg: GbmlConfigPbWrapper, uri: str) -> str:

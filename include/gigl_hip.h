@@ -110,6 +110,31 @@ int32_t gigl_graph_info(gigl_graph* g, int64_t* n, int64_t* e);
 int32_t gigl_graph_device_ptrs(gigl_graph* g, const int64_t** rowptr, const uint32_t** col);
 int32_t gigl_graph_destroy(gigl_graph* g);
 
+/* ---- preprocessed-table reader (HOST code, no ctx): TFRecord framing + tf.Example decoding into dense columns.
+ *      Replaces the spark-tfrecord reads and the column selection / casts of loadNodeDataframeIntoSparkSql and
+ *      loadEdgeDataframeIntoSparkSql (SGSPureSparkV1Task.scala:52-118, :120-216; TFRecordIO.scala:20-51).
+ * gigl_tfrecord_index: walks the frames of a TFRecord file image (HOST buffer), optionally verifying both masked
+ *   CRC-32C words; writes payload offset / length of the first `cap` records and the record count (call with
+ *   cap = 0 to count).  GIGL_E_INVALID_ARG on a truncated file or a CRC mismatch.
+ * gigl_tfexample_decode: column c of record i <- the values of feature `name` (Int64List -> int64, or cast to
+ *   float for an F32 column, as the reference concatenates integer feature columns into array<float>; FloatList ->
+ *   float), first `width` values, zero-filled when the key is absent or shorter; counts[i] (optional) = values
+ *   present.  Multi-threaded over records.  A malformed record or a kind mismatch returns GIGL_E_INVALID_ARG and
+ *   *bad_record = its index. */
+#define GIGL_COL_I64 0
+#define GIGL_COL_F32 1
+typedef struct gigl_column {
+  const char* name;
+  int32_t kind;    /* GIGL_COL_* */
+  int32_t width;   /* values per record */
+  void* out;       /* HOST [n][width] int64 or float */
+  int32_t* counts; /* HOST [n] or NULL */
+} gigl_column;
+int32_t gigl_tfrecord_index(const uint8_t* buf, int64_t len, int32_t verify_crc, int64_t cap, int64_t* payload_off,
+                            int64_t* payload_len, int64_t* n_records);
+int32_t gigl_tfexample_decode(const uint8_t* buf, const int64_t* payload_off, const int64_t* payload_len, int64_t n,
+                              const gigl_column* cols, int32_t n_cols, int32_t n_threads, int64_t* bad_record);
+
 /* ---- node features: replaces loadNodeDataframeIntoSparkSql (SGSPureSparkV1Task.scala:52-118):
  * dense row-major [n][d], row index == node id. */
 int32_t gigl_features_load(gigl_ctx* ctx, int64_t n, int32_t d, int32_t dtype, const void* rows,
