@@ -32,7 +32,8 @@ SYMBOLS = [
     "gigl_sage_plan_destroy", "gigl_gather_mean_backward", "gigl_expand_frontier", "gigl_gcn_aggregate",
     "gigl_gat_aggregate", "gigl_gather_rows", "gigl_sage_plan_use_graph", "gigl_sage_plan_flush_profile",
     "gigl_union_build_groups", "gigl_sage_plan_set_groups", "gigl_records_capacity", "gigl_records_encode",
-    "gigl_tfrecord_index", "gigl_tfexample_decode",
+    "gigl_tfrecord_index", "gigl_tfexample_decode", "gigl_collate_records", "gigl_collated_info", "gigl_collated_copy",
+    "gigl_collated_destroy",
 ]
 
 KERNEL_IDS = {
@@ -156,6 +157,10 @@ def load() -> C.CDLL:
         "gigl_expand_frontier": [vp, vp, vp, vp, i64, i32, i32, i32, i64, vp, vp],
         "gigl_gather_rows": [vp, vp, i32, i32, vp, vp, i64, vp],
         "gigl_tfrecord_index": [vp, i64, i32, i64, vp, vp, P(i64)],
+        "gigl_collate_records": [vp, vp, vp, i64, i32, i32, P(vp), C.c_char_p, i32],
+        "gigl_collated_info": [vp, P(i64), P(i64), P(i32), P(i64), P(i64)],
+        "gigl_collated_copy": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "gigl_collated_destroy": [vp],
         "gigl_tfexample_decode": [vp, vp, vp, i64, P(GiglColumn), i32, i32, P(i64)],
         "gigl_records_capacity": [P(i32), i32, i32, P(GiglRecordOpts), i64, i64, P(i64)],
         "gigl_records_encode": [vp, vp, P(GiglTree), vp, P(GiglRecordOpts), i64, vp, i64, vp, vp],

@@ -73,6 +73,52 @@ def build_batch_graph(samples: Sequence[Tuple[Sequence[wire.Node], Sequence[wire
     return x, ei, g2l, order_ids
 
 
+def collate_serialized(batch: Sequence[bytes], kind: int, n_threads: int = 0):
+    """native collate of serialized samples (libgigl_hip.so gigl_collate_records, host C++: parallel proto parsing,
+    first-seen numbering, edge dedup, coalesce).  -> dict(x, edge_index, node_ids, root_local, labels, has_label,
+    pos_off, pos_dst, neg_off, neg_dst) as numpy arrays.  Raises what the reference's Python loops raise:
+    AssertionError (node re-added with different features), TypeError (edge endpoint unknown), KeyError (root or
+    supervision target not in the batch graph), ValueError (malformed record)."""
+    import ctypes as C
+    import os
+
+    from . import _lib
+    lib = _lib.load()
+    payloads = [bytes(b) for b in batch]
+    lens = np.array([len(b) for b in payloads], dtype=np.int64)
+    off = np.zeros(len(payloads), dtype=np.int64)
+    if len(payloads) > 1:
+        np.cumsum(lens[:-1], out=off[1:])
+    blob = b"".join(payloads) or b"\0"
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = lib.gigl_collate_records(blob, C.c_void_p(off.ctypes.data), C.c_void_p(lens.ctypes.data), len(payloads), kind,
+                                  n_threads or min(16, os.cpu_count() or 1), C.byref(h), err, 512)
+    if rc != 0:
+        msg = err.value.decode("utf-8", "replace")
+        exc = (AssertionError if "re-added" in msg else TypeError if "Tried to fetch" in msg
+               else KeyError if "not in the batch graph" in msg else ValueError)
+        raise exc(msg or "gigl_collate_records failed")
+    try:
+        n, e, d, npos, nneg = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int64(), C.c_int64()
+        lib.gigl_collated_info(h, C.byref(n), C.byref(e), C.byref(d), C.byref(npos), C.byref(nneg))
+        b = len(payloads)
+        out = dict(node_ids=np.empty(n.value, np.uint32), x=np.empty((n.value, d.value), np.float32),
+                   edge_index=np.empty((2, e.value), np.int64), root_local=np.empty(b, np.int64),
+                   labels=np.empty(b, np.int64), has_label=np.empty(b, np.uint8), pos_off=np.empty(b + 1, np.int64),
+                   pos_dst=np.empty(npos.value, np.int64), neg_off=np.empty(b + 1, np.int64),
+                   neg_dst=np.empty(nneg.value, np.int64))
+        ptr = lambda a: C.c_void_p(a.ctypes.data)
+        lib.gigl_collated_copy(h, ptr(out["node_ids"]), ptr(out["x"]), ptr(out["edge_index"]), ptr(out["root_local"]),
+                               ptr(out["labels"]), ptr(out["has_label"]), ptr(out["pos_off"]), ptr(out["pos_dst"]),
+                               ptr(out["neg_off"]), ptr(out["neg_dst"]))
+    finally:
+        lib.gigl_collated_destroy(h)
+    if n.value and d.value == 0:  # PygGraphBuilder: nodes without features get ones(1) (pyg_graph_builder.py:25-38)
+        out["x"] = np.ones((n.value, 1), dtype=np.float32)
+    return out
+
+
 @dataclass
 class RootedNodeNeighborhoodBatch:
     graph: GraphData
@@ -94,8 +140,17 @@ class RootedNodeNeighborhoodBatch:
 
     @staticmethod
     def process_raw_pyg_samples_and_collate_fn(batch: Sequence[bytes], node_type: str = "node"):
-        return RootedNodeNeighborhoodBatch.collate_pyg_rooted_node_neighborhood_minibatch(
-            [wire.RootedNodeNeighborhood.FromString(b) for b in batch], node_type=node_type)
+        """serialized RootedNodeNeighborhood records -> batch (native collate; same result as decoding with
+        wire.RootedNodeNeighborhood.FromString and calling collate_pyg_rooted_node_neighborhood_minibatch)"""
+        from ._lib import REC_ROOTED_NODE_NEIGHBORHOOD
+        c = collate_serialized(batch, REC_ROOTED_NODE_NEIGHBORHOOD)
+        order = c["node_ids"].tolist()
+        idx = torch.from_numpy(c["root_local"])
+        return RootedNodeNeighborhoodBatch(
+            graph=GraphData(x=torch.from_numpy(c["x"]), edge_index=torch.from_numpy(c["edge_index"])),
+            condensed_node_type_to_root_node_indices_map={0: idx},
+            root_nodes=[Node(type=node_type, id=int(order[l])) for l in c["root_local"].tolist()],
+            condensed_node_type_to_subgraph_id_to_global_node_id={0: {l: g for l, g in enumerate(order)}})
 
 
 @dataclass
@@ -120,8 +175,16 @@ class SupervisedNodeClassificationBatch:
 
     @staticmethod
     def process_raw_pyg_samples_and_collate_fn(batch: Sequence[bytes], node_type: str = "node"):
-        return SupervisedNodeClassificationBatch.collate_pyg_node_classification_minibatch(
-            [wire.SupervisedNodeClassificationSample.FromString(b) for b in batch], node_type=node_type)
+        """serialized SupervisedNodeClassificationSample records -> batch (native collate)"""
+        from ._lib import REC_ROOTED_NODE_NEIGHBORHOOD
+        c = collate_serialized(batch, REC_ROOTED_NODE_NEIGHBORHOOD)
+        order = c["node_ids"]
+        labels = torch.from_numpy(c["labels"]) if len(batch) and c["has_label"].all() else None
+        return SupervisedNodeClassificationBatch(
+            graph=GraphData(x=torch.from_numpy(c["x"]), edge_index=torch.from_numpy(c["edge_index"])),
+            root_node_indices=torch.from_numpy(c["root_local"]),
+            root_nodes=[Node(type=node_type, id=int(order[l])) for l in c["root_local"].tolist()],
+            root_node_labels=labels)
 
 
 @dataclass
@@ -166,8 +229,20 @@ class NodeAnchorBasedLinkPredictionBatch:
 
     @staticmethod
     def process_raw_pyg_samples_and_collate_fn(batch: Sequence[bytes]):
-        return NodeAnchorBasedLinkPredictionBatch.collate_pyg_node_anchor_based_link_prediction_minibatch(
-            [wire.NodeAnchorBasedLinkPredictionSample.FromString(b) for b in batch])
+        """serialized NodeAnchorBasedLinkPredictionSample records -> batch (native collate)"""
+        from ._lib import REC_NODE_ANCHOR_LINK_PRED
+        c = collate_serialized(batch, REC_NODE_ANCHOR_LINK_PRED)
+        pos = BatchSupervisionEdgeData(root_node_to_target_node_id={})
+        neg = BatchSupervisionEdgeData(root_node_to_target_node_id={})
+        po, pd, no, nd = c["pos_off"], torch.from_numpy(c["pos_dst"]), c["neg_off"], torch.from_numpy(c["neg_dst"])
+        for i, r in enumerate(c["root_local"].tolist()):
+            pos.root_node_to_target_node_id[r] = pd[po[i]:po[i + 1]].clone()
+            neg.root_node_to_target_node_id[r] = nd[no[i]:no[i + 1]].clone()
+        return NodeAnchorBasedLinkPredictionBatch(
+            graph=GraphData(x=torch.from_numpy(c["x"]), edge_index=torch.from_numpy(c["edge_index"])),
+            root_node_indices=torch.from_numpy(c["root_local"]),
+            pos_supervision_edge_data={0: pos}, hard_neg_supervision_edge_data={0: neg},
+            condensed_node_type_to_subgraph_id_to_global_node_id={0: {l: g for l, g in enumerate(c["node_ids"].tolist())}})
 
 
 def iterate_tfrecord_batches(files: Sequence[str], batch_size: int, rank: int = 0, world_size: int = 1,

@@ -47,6 +47,10 @@ extern "C" {
 #define GIGL_DTYPE_F32 0
 #define GIGL_DTYPE_F16 1
 
+/* serialized training-sample kinds (training_samples_schema.proto) */
+#define GIGL_REC_ROOTED_NODE_NEIGHBORHOOD 0 /* also SupervisedNodeClassificationSample: same fields + labels */
+#define GIGL_REC_NODE_ANCHOR_LINK_PRED 1
+
 /* sampling modes */
 #define GIGL_MODE_SPARK_HASH 0 /* parity: xxhash64-keyed permutation, SamplingStrategy.scala:16-82 */
 #define GIGL_MODE_FAST 1       /* NOT parity: counter-based RNG positions; labelled as such everywhere */
@@ -135,6 +139,32 @@ int32_t gigl_tfrecord_index(const uint8_t* buf, int64_t len, int32_t verify_crc,
 int32_t gigl_tfexample_decode(const uint8_t* buf, const int64_t* payload_off, const int64_t* payload_len, int64_t n,
                               const gigl_column* cols, int32_t n_cols, int32_t n_threads, int64_t* bad_record);
 
+/* ---- serialized training samples -> one batch graph (HOST code, no ctx): the collate step for samples that
+ *      arrive as TFRecords.  Replaces GbmlProtosTranslator.graph_data_from_GraphPb
+ *      (python/gigl/src/common/translators/gbml_protos_translator.py:101-121), GraphBuilder.add_node/add_edge
+ *      (python/gigl/src/common/graph_builder/abstract_graph_builder.py:16-24,49-150), PygGraphBuilder.build
+ *      (.../pyg_graph_builder.py:20-69) and the loops of the three collate functions
+ *      (python/gigl/src/training/v1/lib/data_loaders/{rooted_node_neighborhood,supervised_node_classification,
+ *      node_anchor_based_link_prediction}_data_loader.py).
+ * `kind` GIGL_REC_ROOTED_NODE_NEIGHBORHOOD reads root_node=1, neighborhood=2 and, when present, root_node_labels=3
+ * (a SupervisedNodeClassificationSample); GIGL_REC_NODE_ANCHOR_LINK_PRED reads root_node=1, neighborhood=3,
+ * pos_edges=4, hard_neg_edges=2.  Result: local ids in first-seen order (a sample's nodes, then its edges), a node
+ * seen again must carry allclose features, duplicate (src,dst) edges dropped, edge_index sorted by (src,dst),
+ * root_local[b], labels[b]/has_label[b] (root_node_labels[0]), pos/hard-neg targets as offsets[b+1] + local ids.
+ * Errors (GIGL_E_INVALID_ARG + message in `err`): malformed record, node re-added with different features, edge /
+ * root / supervision target naming a node the batch has no information on — the reference's AssertionError /
+ * TypeError / KeyError cases. */
+typedef struct gigl_collated gigl_collated;
+int32_t gigl_collate_records(const uint8_t* buf, const int64_t* payload_off, const int64_t* payload_len, int64_t b,
+                             int32_t kind, int32_t n_threads, gigl_collated** out, char* err, int32_t err_cap);
+int32_t gigl_collated_info(const gigl_collated* c, int64_t* n_nodes, int64_t* n_edges, int32_t* feat_dim,
+                           int64_t* n_pos, int64_t* n_hard_neg);
+/* any destination may be NULL; edge_index is [2][n_edges] int64 */
+int32_t gigl_collated_copy(const gigl_collated* c, uint32_t* node_ids, float* x, int64_t* edge_index,
+                           int64_t* root_local, int64_t* labels, uint8_t* has_label, int64_t* pos_off,
+                           int64_t* pos_dst, int64_t* neg_off, int64_t* neg_dst);
+int32_t gigl_collated_destroy(gigl_collated* c);
+
 /* ---- node features: replaces loadNodeDataframeIntoSparkSql (SGSPureSparkV1Task.scala:52-118):
  * dense row-major [n][d], row index == node id. */
 int32_t gigl_features_load(gigl_ctx* ctx, int64_t n, int32_t d, int32_t dtype, const void* rows,
@@ -218,9 +248,6 @@ int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* 
  * *status = 1 (and nothing is written) when the total exceeds out_cap.  Never synchronises with the host.
  * A record's plan lives in LDS: trees_per_record * (1 + sum of slots per tree) must be <= 2048
  * (GIGL_E_UNSUPPORTED otherwise; [25,10] allows up to 6 positives). */
-#define GIGL_REC_ROOTED_NODE_NEIGHBORHOOD 0
-#define GIGL_REC_NODE_ANCHOR_LINK_PRED 1
-
 typedef struct gigl_record_opts {
   int32_t kind;                /* GIGL_REC_* */
   int32_t trees_per_record;    /* 1, or 1 + num_positive_samples for GIGL_REC_NODE_ANCHOR_LINK_PRED */
