@@ -1,20 +1,30 @@
-"""Per-call kernel time of the grouped launches in a bench.py kernel trace: for each library kernel take the
-N longest launches (N = number of grouped calls x launches per call) — the single-batch launches of the untimed
-counting pass are the short ones.  usage: python scripts/percall.py <kernel_trace.csv> <n_calls>"""
-import collections, csv, re, sys
+"""Per-call kernel time of the grouped (G-batch) launches in a bench.py kernel trace: launches are keyed by
+(kernel, grid size); per kernel the grids that belong to grouped calls are the largest ones (the single-batch
+launches of the untimed counting pass use smaller grids).  Prints the MEDIAN duration per (kernel, grid) for grids
+with at least `min_calls` launches.  usage: python scripts/percall.py <kernel_trace.csv> [min_calls]"""
+import collections, csv, re, statistics, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-n_calls = int(sys.argv[2])
+min_calls = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 by = collections.defaultdict(list)
 for r in rows:
     name = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))[:40]
-    by[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-tot = 0
-for k, d in sorted(by.items(), key=lambda kv: -sum(sorted(kv[1], reverse=True)[:2 * n_calls])):
-    if k.startswith("at::") or "rocprim" in k or k.startswith("__amd") or "uniq" in k or "csc_" in k or "coo_" in k or "table_" in k or "maxdeg" in k:
+    if name.startswith("at::") or "rocprim" in name or name.startswith("__amd"):
         continue
-    per = 2 if k in ("expand_kernel", "linear_lds_kernel<2>", "insert_slots_kernel") else 1
-    top = sorted(d, reverse=True)[:per * n_calls]
-    t = sum(top) / n_calls / 1e3
+    by[(name, int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+names = collections.defaultdict(list)
+for (name, g), d in by.items():
+    if len(d) >= min_calls:
+        names[name].append((g, d))
+tot = 0.0
+out = []
+for name, lst in names.items():
+    lst.sort(reverse=True)
+    gmax = lst[0][0]
+    # grouped-call grids: within 64x of the kernel's largest grid and not the most frequent small one
+    keep = [(g, d) for g, d in lst if len(d) <= 2 * min(len(x[1]) for x in lst)]
+    t = sum(statistics.median(d) for g, d in keep) / 1e3
+    out.append((t, name, [(g, len(d), round(statistics.median(d) / 1e3, 1)) for g, d in keep]))
+for t, name, detail in sorted(out, reverse=True):
     tot += t
-    print(f"{k:40s} launches/call={per} per-call={t:8.1f} us")
+    print(f"{name:40s} per-call={t:8.1f} us   {detail}")
 print(f"sum per call {tot:.1f} us")
