@@ -190,6 +190,20 @@ class GbmlConfigPbWrapper:
                            "nodeTypeToRandomNegativeTfrecordUriPrefix", {}) or {}
         return {k: resolve_uri(v, self.uri_base) for k, v in m.items()}
 
+    # ---- split generator outputs (dataset_metadata.proto: SupervisedNodeClassificationDataset /
+    #      NodeAnchorBasedLinkPredictionDataset); None when the config names none
+    def dataset_split_uri(self, split: str) -> Optional[str]:
+        dm = _get(self.doc, "sharedConfig.datasetMetadata", {}) or {}
+        snc = dm.get("supervisedNodeClassificationDataset") or {}
+        lp = dm.get("nodeAnchorBasedLinkPredictionDataset") or {}
+        v = snc.get(f"{split}DataUri") or lp.get(f"{split}MainDataUri")
+        return resolve_uri(v, self.uri_base) if v else None
+
+    def random_negative_split_uris(self, split: str) -> Dict[str, str]:
+        lp = _get(self.doc, "sharedConfig.datasetMetadata.nodeAnchorBasedLinkPredictionDataset", {}) or {}
+        m = lp.get(f"{split}NodeTypeToRandomNegativeDataUri") or {}
+        return {k: resolve_uri(v, self.uri_base) for k, v in m.items()}
+
     @property
     def preprocessed_metadata(self) -> PreprocessedMetadata:
         if self._preprocessed is None:

@@ -16,9 +16,10 @@ loss/metric algebra on the [queries x candidates] score matrix is the reference'
 Scope: homogeneous graphs (one condensed node type 0 and edge type 0), the Retrieval task, no candidate
 sampling correction (count-min sketch) — other tasks (Margin, Softmax, GRACE, ...) are out of scope.
 Data: main samples are the NodeAnchorBasedLinkPredictionSample TFRecords and random negatives the
-RootedNodeNeighborhood TFRecords the sampler wrote.  The Split Generator that re-files them into
-train/val/test is out of scope: the split is root id % 10 (0-7 train, 8 val, 9 test),
-and tiny fixtures (< 100 samples) use every sample in every split.
+RootedNodeNeighborhood TFRecords the sampler wrote, re-filed into train/val/test by the split generator
+(gigl_amd/split_generator.py; datasetMetadata.nodeAnchorBasedLinkPredictionDataset URIs).  Without split outputs
+the sampler's files are used directly: root id % 10 (0-7 train, 8 val, 9 test), tiny fixtures (< 100 samples)
+whole in every split.
 """
 from __future__ import annotations
 
@@ -322,6 +323,15 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
     # ---- data (dataset/dataloader roles of NodeAnchorBasedLinkPredictionDatasetDataloaders)
     def _main_batches(self, cfg: GbmlConfigPbWrapper, split: str, loop: bool):
         rank, world = _rank_world()
+        uri = cfg.dataset_split_uri(split)
+        if uri and tfrecord_files(uri):
+            raw = [b for chunk in iterate_tfrecord_batches(tfrecord_files(uri), 10 ** 9, rank=rank, world_size=world)
+                   for b in chunk]
+            bs = self.main_sample_batch_size
+            chunks = [raw[i:i + bs] for i in range(0, len(raw), bs)]
+            for chunk in (cycle(chunks) if (loop and chunks) else chunks):
+                yield NodeAnchorBasedLinkPredictionBatch.process_raw_pyg_samples_and_collate_fn(chunk)
+            return
         files = tfrecord_files(cfg.nablp_tfrecord_uri_prefix)
         want = {"train": range(0, 8), "val": (8,), "test": (9,)}[split]
         raw = [b for chunk in iterate_tfrecord_batches(files, 10 ** 9, rank=rank, world_size=world) for b in chunk]
@@ -332,10 +342,13 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         for chunk in (cycle(chunks) if (loop and chunks) else chunks):
             yield NodeAnchorBasedLinkPredictionBatch.collate_pyg_node_anchor_based_link_prediction_minibatch(chunk)
 
-    def _random_negative_batches(self, cfg: GbmlConfigPbWrapper, batch_size: int):
+    def _random_negative_batches(self, cfg: GbmlConfigPbWrapper, batch_size: int, split: str = "train"):
         """always looped, like the reference's LoopyIterableDataset for random negatives"""
         rank, world = _rank_world()
-        prefix = next(iter(cfg.random_negative_tfrecord_uri_prefixes.values()))
+        split_uris = cfg.random_negative_split_uris(split)
+        prefix = next(iter(split_uris.values()), None)
+        if not (prefix and tfrecord_files(prefix)):
+            prefix = next(iter(cfg.random_negative_tfrecord_uri_prefixes.values()))
         for raw in iterate_tfrecord_batches(tfrecord_files(prefix), batch_size, rank=rank, world_size=world, loop=True):
             yield RootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(raw, node_type=cfg.node_types[0])
 
@@ -347,7 +360,7 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         main = self._main_batches(cfg, "train", loop=False)
         rn = self._random_negative_batches(cfg, self.random_negative_sample_batch_size)
         val_main = self._main_batches(cfg, "val", loop=True)
-        val_rn = self._random_negative_batches(cfg, self.random_negative_sample_batch_size_for_evaluation)
+        val_rn = self._random_negative_batches(cfg, self.random_negative_sample_batch_size_for_evaluation, split="val")
         self.model.train()
         every = max(self.validate_every_n_batches // world, 1)
         for batch_index, (main_batch, rn_batch) in enumerate(zip(main, rn), start=1):
@@ -416,7 +429,8 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         self._ensure_engine(device)
         m = self.validate(self._main_batches(gbml_config_pb_wrapper, "test", loop=False),
                           self._random_negative_batches(gbml_config_pb_wrapper,
-                                                        self.random_negative_sample_batch_size_for_evaluation),
+                                                        self.random_negative_sample_batch_size_for_evaluation,
+                                                        split="test"),
                           gbml_config_pb_wrapper, device, self.num_test_batches)
         hits = [EvalMetric(name=f"HitRate_at_{k}", value=rate) for k, rate in zip(KS_FOR_EVAL, m[EvalMetricType.hits])]
         return EvalMetricsCollection(metrics=[

@@ -1,0 +1,339 @@
+"""SplitGenerator — drop-in for the reference component between the sampler and the trainer
+
+    python -m gigl.src.split_generator.split_generator --job_name --task_config_uri --resource_config_uri
+    Scala job: scala/split_generator/src/main/scala/Main.scala:14-38, lib/SplitGeneratorTaskRunner.scala:20-94
+
+Restated reference pieces (paths under scala/split_generator/src/main/scala/lib/):
+  assigners/AbstractAssigners.scala:30-111            HashingAssigner: slot = floorMod(MurmurHash3.bytesHash(coder(obj)),
+                                                      10000), bucket = the span of the cumulative normalised weights
+                                                      (float32 arithmetic, math.round) the slot falls in
+  assigners/NodeToDatasetSplitHashingAssigner.scala    coder = "<nodeId>-<condensedNodeType>"   (GraphPbWrappers.scala:37-39)
+  assigners/TransductiveEdgeToLinkSplitHashingAssigner.scala
+                                                      coder = "<src>-<condensedEdgeType>-<dst>" of the canonically
+                                                      ordered edge when should_split_edges_symmetrically (:66-78);
+                                                      disjoint_train_ratio > 0 adds TRAIN/MESSAGE + TRAIN/SUPERVISION
+  split_strategies/TransductiveSupervisedNodeClassificationSplitStrategy.scala:25-49
+  split_strategies/InductiveSupervisedNodeClassificationSplitStrategy.scala:20-89
+  split_strategies/TransductiveNodeAnchorBasedLinkPredictionSplitStrategy.scala:37-268
+  tasks/SupervisedNodeClassificationTask.scala, tasks/NodeAnchorBasedLinkPredictionTask.scala   (input / output URIs)
+
+Parity: the reference's tests for this component are property tests (determinism, symmetric assignment, split
+ratios, message-passing visibility rules — scala/split_generator/src/test/scala/*.scala); no reference artefact pins
+a concrete hash slot -> "parity unpinned" for the exact assignment.  MurmurHash3.bytesHash is scala.util.hashing's
+MurmurHash3_x86_32 with seed 0x3c074a61 (its `arraySeed`), restated here and checked against the public
+MurmurHash3_x86_32 vectors (tests/test_split_generator.py).  `subsample` draws scala.util.Random.nextFloat in the
+reference (unseeded): any ratio < 1 is therefore non-reproducible there; a seeded numpy generator is used here.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import wire
+from .config import GbmlConfigPbWrapper, _get, resolve_uri, tfrecord_files
+
+TRAIN, VAL, TEST = "train", "val", "test"
+MESSAGE, SUPERVISION, MESSAGE_AND_SUPERVISION = "message", "supervision", "message_and_supervision"
+HASH_SPACE_GRANULARITY = 10000
+SCALA_ARRAY_SEED = 0x3C074A61
+
+
+def murmur3_bytes_hash(data: bytes, seed: int = SCALA_ARRAY_SEED) -> int:
+    """scala.util.hashing.MurmurHash3.bytesHash == MurmurHash3_x86_32; returns a signed int32"""
+    c1, c2, m32 = 0xCC9E2D51, 0x1B873593, 0xFFFFFFFF
+    h = seed & m32
+    n = len(data)
+    for i in range(0, n - n % 4, 4):
+        k = data[i] | (data[i + 1] << 8) | (data[i + 2] << 16) | (data[i + 3] << 24)
+        k = (k * c1) & m32
+        k = ((k << 15) | (k >> 17)) & m32
+        k = (k * c2) & m32
+        h ^= k
+        h = ((h << 13) | (h >> 19)) & m32
+        h = (h * 5 + 0xE6546B64) & m32
+    k = 0
+    t = n % 4
+    if t:
+        base = n - t
+        if t == 3:
+            k ^= data[base + 2] << 16
+        if t >= 2:
+            k ^= data[base + 1] << 8
+        k ^= data[base]
+        k = (k * c1) & m32
+        k = ((k << 15) | (k >> 17)) & m32
+        k = (k * c2) & m32
+        h ^= k
+    h ^= n
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & m32
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & m32
+    h ^= h >> 16
+    return h - (1 << 32) if h & 0x80000000 else h
+
+
+class HashingAssigner:
+    """AbstractAssigners.HashingAssigner: buckets in insertion order of bucketWeights (an immutable Map of <= 4
+    entries keeps insertion order), transition indices from float32 cumulative normalised weights"""
+
+    def __init__(self, bucket_weights: Sequence[Tuple[object, float]]):
+        self.buckets = [b for b, _ in bucket_weights]
+        w = np.array([x for _, x in bucket_weights], dtype=np.float32)
+        total = np.float32(0)
+        for x in w:  # Seq[Float].sum: left fold in float32
+            total = np.float32(total + x)
+        normed = (w / total).astype(np.float32)
+        cum = [np.float32(0)]
+        for x in normed:
+            cum.append(np.float32(cum[-1] + x))
+        # math.round(Float): floor(x + 0.5) as int
+        self.indices = [int(np.floor(np.float32(c * np.float32(HASH_SPACE_GRANULARITY)) + np.float32(0.5))) for c in cum]
+        self._cache: Dict[bytes, object] = {}
+
+    def assign_bytes(self, byte_string: bytes):
+        hit = self._cache.get(byte_string)
+        if hit is not None:
+            return hit
+        slot = murmur3_bytes_hash(byte_string) % HASH_SPACE_GRANULARITY  # Python % == floorMod for a positive modulus
+        for b, lo, hi in zip(self.buckets, self.indices, self.indices[1:]):
+            if lo <= slot < hi:
+                self._cache[byte_string] = b
+                return b
+        raise AssertionError(f"hash slot {slot} falls in no bucket (indices {self.indices})")
+
+
+def node_unique_id(node_id: int, condensed_node_type: Optional[int]) -> bytes:
+    return f"{node_id}-{condensed_node_type or 0}".encode()
+
+
+def edge_unique_id(src: int, dst: int, condensed_edge_type: Optional[int]) -> bytes:
+    return f"{src}-{condensed_edge_type or 0}-{dst}".encode()
+
+
+class NodeToDatasetSplitHashingAssigner(HashingAssigner):
+    def __init__(self, assigner_args: Dict[str, str]):
+        f = lambda k, d: float(np.float32(assigner_args.get(k, d)))
+        super().__init__([(TRAIN, f("train_split", "0.8")), (VAL, f("val_split", "0.1")), (TEST, f("test_split", "0.1"))])
+
+    def assign(self, node: wire.Node) -> str:
+        return self.assign_bytes(node_unique_id(node.node_id, node.condensed_node_type))
+
+    def assign_id(self, node_id: int, condensed_node_type: Optional[int] = 0) -> str:
+        return self.assign_bytes(node_unique_id(node_id, condensed_node_type))
+
+
+class TransductiveEdgeToLinkSplitHashingAssigner(HashingAssigner):
+    """-> (dataset split, link usage)"""
+
+    def __init__(self, assigner_args: Dict[str, str]):
+        f32 = np.float32
+        train = f32(assigner_args.get("train_split", "0.8"))
+        val = f32(assigner_args.get("val_split", "0.1"))
+        test = f32(assigner_args.get("test_split", "0.1"))
+        disjoint = f32(assigner_args.get("disjoint_train_ratio", "0.0"))
+        self.symmetric = str(assigner_args.get("should_split_edges_symmetrically", "True")).lower() == "true"
+        if disjoint > 0:
+            sup = f32(disjoint * train)
+            msg = f32(train - sup)
+            weights = [((TRAIN, MESSAGE), float(msg)), ((TRAIN, SUPERVISION), float(sup)),
+                       ((VAL, MESSAGE_AND_SUPERVISION), float(val)), ((TEST, MESSAGE_AND_SUPERVISION), float(test))]
+        else:
+            weights = [((TRAIN, MESSAGE_AND_SUPERVISION), float(train)), ((VAL, MESSAGE_AND_SUPERVISION), float(val)),
+                       ((TEST, MESSAGE_AND_SUPERVISION), float(test))]
+        super().__init__(weights)
+
+    def assign(self, edge: wire.Edge) -> Tuple[str, str]:
+        s, d = edge.src_node_id, edge.dst_node_id
+        if self.symmetric and not s <= d:  # hash the canonically ordered edge: a->b and b->a land together
+            s, d = d, s
+        return self.assign_bytes(edge_unique_id(s, d, edge.condensed_edge_type))
+
+
+class _Subsampler:
+    def __init__(self, args: Dict[str, str], prefix: str = "", seed: int = 42):
+        self.ratio = {TRAIN: float(args.get(prefix + "train_subsampling_ratio", "1.0")),
+                      VAL: float(args.get(prefix + "val_subsampling_ratio", "1.0")),
+                      TEST: float(args.get(prefix + "test_subsampling_ratio", "1.0"))}
+        self.rng = np.random.default_rng(seed)
+
+    def __call__(self, samples: list, split: str) -> list:
+        """SplitStrategy.subsample (SplitStrategy.scala:48-64) — note the reference DROPS the sample when the draw is
+        BELOW the ratio (ratio < 1), kept verbatim"""
+        r = self.ratio[split]
+        if r < 1.0 and float(self.rng.random()) < r:
+            return []
+        return samples
+
+
+class TransductiveSupervisedNodeClassificationSplitStrategy:
+    def __init__(self, args: Dict[str, str], assigner: NodeToDatasetSplitHashingAssigner):
+        self.assigner, self.subsample = assigner, _Subsampler(args)
+
+    def split_training_sample(self, sample: wire.SupervisedNodeClassificationSample, split: str):
+        if sample.root_node is None:
+            raise RuntimeError("Root node does not exist for sample.")
+        out = [sample] if self.assigner.assign(sample.root_node) == split else []
+        return self.subsample(out, split)
+
+
+class InductiveSupervisedNodeClassificationSplitStrategy(TransductiveSupervisedNodeClassificationSplitStrategy):
+    def split_training_sample(self, sample: wire.SupervisedNodeClassificationSample, split: str):
+        if sample.root_node is None:
+            raise RuntimeError("Root node does not exist for sample.")
+        out = []
+        if self.assigner.assign(sample.root_node) == split:
+            if sample.neighborhood is None:
+                raise RuntimeError("Neighborhood does not exist in the sample")
+            nodes = [n for n in sample.neighborhood.nodes if self.assigner.assign(n) == split]
+            # homogeneous graphs: both endpoints carry the (single) condensed node type 0
+            edges = [e for e in sample.neighborhood.edges
+                     if self.assigner.assign_id(e.src_node_id, 0) == split and self.assigner.assign_id(e.dst_node_id, 0) == split]
+            out = [wire.SupervisedNodeClassificationSample(root_node=sample.root_node, root_node_labels=sample.root_node_labels,
+                                                           neighborhood=wire.Graph(nodes=nodes, edges=edges))]
+        return self.subsample(out, split)
+
+
+class TransductiveNodeAnchorBasedLinkPredictionSplitStrategy:
+    def __init__(self, args: Dict[str, str], assigner: TransductiveEdgeToLinkSplitHashingAssigner):
+        self.assigner = assigner
+        self.is_disjoint_mode = str(args.get("is_disjoint_mode", "false")).lower() == "true"
+        self.subsample = _Subsampler(args)
+        self.subsample_rn = _Subsampler(args, prefix="random_negative_")
+
+    def _message_edge_visible(self, edge: wire.Edge, split: str) -> bool:
+        ds, usage = self.assigner.assign(edge)
+        if split == TRAIN:
+            return ds == TRAIN and (not self.is_disjoint_mode or usage == MESSAGE)
+        if split == VAL:
+            return ds == TRAIN
+        return ds in (TRAIN, VAL)  # test edges are never used for message passing
+
+    def _supervision_edge_in_split(self, edge: wire.Edge, split: str) -> bool:
+        ds, usage = self.assigner.assign(edge)
+        is_message_edge = usage == MESSAGE and split == TRAIN  # training MESSAGE edges are not supervision
+        return not is_message_edge and ds == split
+
+    @staticmethod
+    def _graph(sample_graph: Optional[wire.Graph], root: Optional[wire.Node], mp_edges, sup_edges) -> wire.Graph:
+        if sample_graph is None:
+            raise RuntimeError("Neighborhood does not exist in the sample")
+        if root is None:
+            raise RuntimeError("Root Node does not exist for the sample")
+        # featureless Node(nodeId, condensedNodeType) set: the root as it is, edge endpoints with the condensed node
+        # type graph metadata gives the edge type's endpoints (getFeaturelessNodePbsFromEdge; homogeneous: Some(0))
+        keep = {(root.node_id, root.condensed_node_type)}
+        for e in list(mp_edges) + list(sup_edges):
+            keep.add((e.src_node_id, 0))
+            keep.add((e.dst_node_id, 0))
+        nodes = [n for n in sample_graph.nodes if (n.node_id, n.condensed_node_type) in keep]
+        return wire.Graph(nodes=nodes, edges=list(mp_edges))
+
+    def split_training_sample(self, sample: wire.NodeAnchorBasedLinkPredictionSample, split: str):
+        pos = [e for e in sample.pos_edges if self._supervision_edge_in_split(e, split)]
+        neg = [e for e in sample.neg_edges if self._supervision_edge_in_split(e, split)]
+        hard = [e for e in sample.hard_neg_edges if self._supervision_edge_in_split(e, split)]
+        if not pos and split == TRAIN:  # a train sample needs a positive for the loss
+            return []
+        if sample.neighborhood is None:
+            raise RuntimeError("Neighborhood does not exist in the sample")
+        mp = [e for e in sample.neighborhood.edges if self._message_edge_visible(e, split)]
+        out = [wire.NodeAnchorBasedLinkPredictionSample(
+            root_node=sample.root_node, hard_neg_edges=hard, pos_edges=pos, neg_edges=neg,
+            neighborhood=self._graph(sample.neighborhood, sample.root_node, mp, pos + neg + hard))]
+        return self.subsample(out, split)
+
+    def split_rooted_node_neighborhood_training_sample(self, sample: wire.RootedNodeNeighborhood, split: str):
+        if sample.neighborhood is None:
+            raise RuntimeError("Neighborhood does not exist in the sample")
+        mp = [e for e in sample.neighborhood.edges if self._message_edge_visible(e, split)]
+        out = [wire.RootedNodeNeighborhood(root_node=sample.root_node,
+                                           neighborhood=self._graph(sample.neighborhood, sample.root_node, mp, []))]
+        return self.subsample_rn(out, split)
+
+
+_ASSIGNERS = {"NodeToDatasetSplitHashingAssigner": NodeToDatasetSplitHashingAssigner,
+              "TransductiveEdgeToLinkSplitHashingAssigner": TransductiveEdgeToLinkSplitHashingAssigner}
+_STRATEGIES = {"TransductiveSupervisedNodeClassificationSplitStrategy": TransductiveSupervisedNodeClassificationSplitStrategy,
+               "InductiveSupervisedNodeClassificationSplitStrategy": InductiveSupervisedNodeClassificationSplitStrategy,
+               "TransductiveNodeAnchorBasedLinkPredictionSplitStrategy": TransductiveNodeAnchorBasedLinkPredictionSplitStrategy}
+
+
+def build_strategy(cfg: GbmlConfigPbWrapper):
+    """SplitGeneratorTaskRunner (lib/SplitGeneratorTaskRunner.scala:20-94): class paths are the reference's Scala
+    names (splitgenerator.lib.assigners.* / .split_strategies.*); the last path component selects the class"""
+    sg = _get(cfg.doc, "datasetConfig.splitGeneratorConfig", {}) or {}
+    a_name = str(sg.get("assignerClsPath", "")).rsplit(".", 1)[-1]
+    s_name = str(sg.get("splitStrategyClsPath", "")).rsplit(".", 1)[-1]
+    if a_name not in _ASSIGNERS or s_name not in _STRATEGIES:
+        raise NotImplementedError(f"split generator classes {a_name!r} / {s_name!r} are not implemented "
+                                  f"(have {sorted(_ASSIGNERS)} / {sorted(_STRATEGIES)})")
+    assigner = _ASSIGNERS[a_name]({k: str(v) for k, v in (sg.get("assignerArgs") or {}).items()})
+    return _STRATEGIES[s_name]({k: str(v) for k, v in (sg.get("splitStrategyArgs") or {}).items()}, assigner)
+
+
+def _write_dir(prefix: str, payloads: List[bytes]) -> List[str]:
+    is_dir = prefix.endswith("/") or prefix.endswith(os.sep)
+    d = prefix if is_dir else os.path.dirname(prefix)
+    os.makedirs(d or ".", exist_ok=True)
+    for old in tfrecord_files(prefix):
+        os.remove(old)
+    name = os.path.join(prefix, "part-00000.tfrecord") if is_dir else f"{prefix}00000.tfrecord"
+    wire.write_tfrecords(name, payloads)
+    return [name]
+
+
+def _split_and_write(in_prefix: str, out_prefixes: Dict[str, str], decode: Callable, split_fn: Callable):
+    """SplitGeneratorTask.splitSamplesAndWriteToOutputPath (lib/tasks/SplitGeneratorTask.scala:60-103)"""
+    samples = [decode(r) for f in tfrecord_files(in_prefix) for r in wire.read_tfrecords(f)]
+    files = {}
+    for split in (TRAIN, VAL, TEST):
+        out = [s.SerializeToString() for smp in samples for s in split_fn(smp, split)]
+        files[split] = _write_dir(out_prefixes[split], out)
+    return files
+
+
+class SplitGenerator:
+    def run(self, applied_task_identifier: str, task_config_uri: str, resource_config_uri: Optional[str] = None, *,
+            uri_base: Optional[str] = None) -> Dict[str, Dict[str, List[str]]]:
+        cfg = GbmlConfigPbWrapper.from_uri(task_config_uri, uri_base=uri_base)
+        strat = build_strategy(cfg)
+        res = lambda u: resolve_uri(u, cfg.uri_base)
+        dm = _get(cfg.doc, "sharedConfig.datasetMetadata", {}) or {}
+        if cfg.task_kind == "node_classification":
+            ds = dm["supervisedNodeClassificationDataset"]
+            outs = {TRAIN: res(ds["trainDataUri"]), VAL: res(ds["valDataUri"]), TEST: res(ds["testDataUri"])}
+            return {"main": _split_and_write(cfg.labeled_tfrecord_uri_prefix, outs,
+                                             wire.SupervisedNodeClassificationSample.FromString,
+                                             strat.split_training_sample)}
+        ds = dm["nodeAnchorBasedLinkPredictionDataset"]
+        outs = {TRAIN: res(ds["trainMainDataUri"]), VAL: res(ds["valMainDataUri"]), TEST: res(ds["testMainDataUri"])}
+        files = {"main": _split_and_write(cfg.nablp_tfrecord_uri_prefix, outs,
+                                          wire.NodeAnchorBasedLinkPredictionSample.FromString,
+                                          strat.split_training_sample)}
+        for node_type, in_prefix in cfg.random_negative_tfrecord_uri_prefixes.items():
+            outs = {TRAIN: res(ds["trainNodeTypeToRandomNegativeDataUri"][node_type]),
+                    VAL: res(ds["valNodeTypeToRandomNegativeDataUri"][node_type]),
+                    TEST: res(ds["testNodeTypeToRandomNegativeDataUri"][node_type])}
+            files[f"random_negative/{node_type}"] = _split_and_write(
+                in_prefix, outs, wire.RootedNodeNeighborhood.FromString,
+                strat.split_rooted_node_neighborhood_training_sample)
+        return files
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="split generator (drop-in for gigl.src.split_generator)")
+    ap.add_argument("--job_name", required=True)
+    ap.add_argument("--task_config_uri", required=True)
+    ap.add_argument("--resource_config_uri", default=None)
+    ap.add_argument("--uri_base", default=None)
+    a = ap.parse_args(argv)
+    for k, v in SplitGenerator().run(a.job_name, a.task_config_uri, a.resource_config_uri, uri_base=a.uri_base).items():
+        print(k, {s: len(f) for s, f in v.items()})
+
+
+if __name__ == "__main__":
+    main()

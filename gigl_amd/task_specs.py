@@ -89,7 +89,16 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
 
     # ---- data
     def _split_batches(self, cfg: GbmlConfigPbWrapper, split: str):
+        """the split generator's output for `split` (datasetMetadata.supervisedNodeClassificationDataset.*DataUri,
+        read like the reference's dataloaders); without one configured / written, the labeled sampler output is
+        used directly: root id % 10 (0-7 train, 8 val, 9 test), tiny fixtures (< 100 samples) whole in every split"""
         rank, world = _rank_world()
+        uri = cfg.dataset_split_uri(split)
+        if uri and tfrecord_files(uri):
+            for raw in iterate_tfrecord_batches(tfrecord_files(uri), self._batch_size, rank=rank, world_size=world):
+                yield SupervisedNodeClassificationBatch.process_raw_pyg_samples_and_collate_fn(
+                    raw, node_type=cfg.node_types[0])
+            return
         files = tfrecord_files(cfg.labeled_tfrecord_uri_prefix)
         want = {"train": range(0, 8), "val": (8,), "test": (9,)}[split]
         for raw in iterate_tfrecord_batches(files, 10 ** 9, rank=rank, world_size=world):

@@ -142,3 +142,27 @@ def test_trainer_then_inferencer(workdir, golden_dir):
     for row, p in zip(rows, preds):
         np.testing.assert_allclose(np.array(row["emb"], np.float32), want[row["node_id"]], rtol=1e-5, atol=1e-5)
         assert p["node_id"] == row["node_id"] and p["pred"] == int(np.argmax(want[row["node_id"]]))
+
+
+def test_sampler_split_generator_trainer_chain(workdir):
+    """sampler -> split generator -> trainer: the trainer reads the train/val/test files the split generator wrote
+    (datasetMetadata.supervisedNodeClassificationDataset), as the reference's pipeline does"""
+    from gigl_amd.split_generator import NodeToDatasetSplitHashingAssigner, SplitGenerator
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    from gigl_amd.trainer import Trainer
+    cfg_uri = "configs/snc_frozen_gbml_config.yaml"
+    SubgraphSampler().run("job", cfg_uri, None, uri_base=workdir)
+    files = SplitGenerator().run("job", cfg_uri, None, uri_base=workdir)["main"]
+    assigner = NodeToDatasetSplitHashingAssigner({"train_split": "0.4", "val_split": "0.3", "test_split": "0.3"})
+    roots = {}
+    for split, fs in files.items():
+        recs = [wire.SupervisedNodeClassificationSample.FromString(r) for f in fs for r in wire.read_tfrecords(f)]
+        roots[split] = sorted(s.root_node.node_id for s in recs)
+        assert all(assigner.assign(s.root_node) == split for s in recs)
+    assert sorted(sum(roots.values(), [])) == [i for i in range(16) if i not in (14, 15)]  # each labeled sample once
+    assert all(roots[s] for s in ("train", "val", "test"))
+    tr = Trainer()
+    metrics = tr.run("job", cfg_uri, None, uri_base=workdir)
+    hist = tr.training_process.trainer.history
+    assert len(hist) == 3 and all(np.isfinite(h["loss"]) for h in hist)
+    assert 0.0 <= metrics.metrics["acc"].value <= 1.0

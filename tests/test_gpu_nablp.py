@@ -123,3 +123,26 @@ def test_trainer_then_inferencer(workdir):
             want[r.id] = o[i].numpy()
     for row in rows:
         np.testing.assert_allclose(np.array(row["emb"], np.float32), want[row["node_id"]], rtol=1e-5, atol=1e-5)
+
+
+def test_sampler_split_generator_trainer_chain(workdir):
+    """sampler -> split generator -> trainer on the toy graph: train/val/test main samples and random negatives are
+    read from the datasetMetadata.nodeAnchorBasedLinkPredictionDataset URIs the split generator filled"""
+    from gigl_amd.split_generator import SplitGenerator, TransductiveEdgeToLinkSplitHashingAssigner
+    from gigl_amd.trainer import Trainer
+    files = SplitGenerator().run("job", CFG, None, uri_base=workdir)
+    cfg = GbmlConfigPbWrapper.from_uri(CFG, uri_base=workdir)
+    assigner = TransductiveEdgeToLinkSplitHashingAssigner({"train_split": "0.6", "val_split": "0.2", "test_split": "0.2"})
+    n_in = sum(1 for f in tfrecord_files(cfg.nablp_tfrecord_uri_prefix) for _ in wire.read_tfrecords(f))
+    for split in ("train", "val", "test"):
+        smp = [wire.NodeAnchorBasedLinkPredictionSample.FromString(r) for f in files["main"][split]
+               for r in wire.read_tfrecords(f)]
+        assert (len(smp) == n_in) if split != "train" else (0 < len(smp) <= n_in)
+        for s in smp:
+            assert all(assigner.assign(e)[0] == split for e in s.pos_edges)
+        assert tfrecord_files(cfg.dataset_split_uri(split)) == files["main"][split]
+        assert len([r for f in files["random_negative/user"][split] for r in wire.read_tfrecords(f)]) == 27
+    tr = Trainer()
+    metrics = tr.run("job", CFG, None, uri_base=workdir)
+    assert np.isfinite(metrics.metrics["loss"].value) and 0.0 <= metrics.metrics["mrr"].value <= 1.0
+    assert all(np.isfinite(h["loss"]) for h in tr.training_process.trainer.history)
