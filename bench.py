@@ -373,7 +373,7 @@ def main():
                 "by_kernel": by_kernel}
 
     cpu_baseline = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (a reported baseline: N=1 only)
         cpu_baseline = run_cpu_baseline(eng0, model, my, fanouts, W, n, d)
 
     if rank == 0:
