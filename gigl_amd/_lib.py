@@ -16,6 +16,7 @@ GIGL_META_N_NODES, GIGL_META_N_EDGES, GIGL_META_LEVEL0, GIGL_META_OVERFLOW = 0, 
 LOC_HOST, LOC_DEVICE = 0, 1
 DTYPE_F32, DTYPE_F16 = 0, 1
 MODE_SPARK_HASH, MODE_FAST = 0, 1
+AGGR = {"mean": 0, "sum": 1, "add": 1, "max": 2}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgigl_hip.so")
@@ -33,7 +34,7 @@ SYMBOLS = [
     "gigl_gat_aggregate", "gigl_gather_rows", "gigl_sage_plan_use_graph", "gigl_sage_plan_flush_profile",
     "gigl_union_build_groups", "gigl_sage_plan_set_groups", "gigl_records_capacity", "gigl_records_encode",
     "gigl_tfrecord_index", "gigl_tfexample_decode", "gigl_collate_records", "gigl_collated_info", "gigl_collated_copy",
-    "gigl_collated_destroy",
+    "gigl_collated_destroy", "gigl_gather_reduce", "gigl_gather_reduce_backward",
 ]
 
 KERNEL_IDS = {
@@ -156,6 +157,8 @@ def load() -> C.CDLL:
         "gigl_gather_mean_backward": [vp, vp, i32, vp, vp, vp, vp, i64, vp],
         "gigl_expand_frontier": [vp, vp, vp, vp, i64, i32, i32, i32, i64, vp, vp],
         "gigl_gather_rows": [vp, vp, i32, i32, vp, vp, i64, vp],
+        "gigl_gather_reduce": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, i32, vp],
+        "gigl_gather_reduce_backward": [vp, vp, i32, vp, vp, vp, vp, i64, i32, vp, vp],
         "gigl_tfrecord_index": [vp, i64, i32, i64, vp, vp, P(i64)],
         "gigl_collate_records": [vp, vp, vp, i64, i32, i32, P(vp), C.c_char_p, i32],
         "gigl_collated_info": [vp, P(i64), P(i64), P(i32), P(i64), P(i64)],

@@ -50,7 +50,18 @@ struct RowLoader<__half> {
 
 // LPR lanes cooperate on one source row; VPL float4 vectors per lane cover d (d % 4 == 0,
 // d <= LPR*VPL*4)
-template <typename T, int LPR, int VPL>
+// OP: GIGL_AGGR_MEAN / GIGL_AGGR_SUM / GIGL_AGGR_MAX (PyG aggr="mean" | "sum" | "max"; an empty row reduces to 0)
+template <int OP>
+__device__ __forceinline__ float4_t aggr_combine(float4_t a, float4_t b) {
+  if constexpr (OP == GIGL_AGGR_MAX) {
+    float4_t r = {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+    return r;
+  } else {
+    return a + b;
+  }
+}
+
+template <typename T, int LPR, int VPL, int OP = GIGL_AGGR_MEAN>
 __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ src, int d,
                                                           const uint32_t* __restrict__ gather_ids,
                                                           const int32_t* __restrict__ rowptr,
@@ -65,7 +76,8 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_rows = *n_rows_dev;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
-  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  constexpr float IDV = OP == GIGL_AGGR_MAX ? -__builtin_inff() : 0.f;  // identity of the reduction
+  const float4_t zero4 = {IDV, IDV, IDV, IDV};
   for (int i = wave; i < n_rows; i += waves_total) {
     const int e0 = rowptr[i], m = rowend[i] - e0;
     const int self = gather_ids ? (int)gather_ids[i] : i;
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
             float4_t b = eb < mm ? RowLoader<T>::load4(pb, el) : zero4;
             float4_t c = ec < mm ? RowLoader<T>::load4(pc, el) : zero4;
             float4_t dd = ed < mm ? RowLoader<T>::load4(pd, el) : zero4;
-            acc[v] += (a + b) + (c + dd);
+            acc[v] = aggr_combine<OP>(acc[v], aggr_combine<OP>(aggr_combine<OP>(a, b), aggr_combine<OP>(c, dd)));
           }
         }
       }
@@ -105,21 +117,21 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
     for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
-        acc[v].x += __shfl_xor(acc[v].x, off, 64);
-        acc[v].y += __shfl_xor(acc[v].y, off, 64);
-        acc[v].z += __shfl_xor(acc[v].z, off, 64);
-        acc[v].w += __shfl_xor(acc[v].w, off, 64);
+        const float4_t o4 = {__shfl_xor(acc[v].x, off, 64), __shfl_xor(acc[v].y, off, 64),
+                             __shfl_xor(acc[v].z, off, 64), __shfl_xor(acc[v].w, off, 64)};
+        acc[v] = aggr_combine<OP>(acc[v], o4);
       }
     }
     float* o = out + (int64_t)i * 2 * d;
     const T* ps = src + (int64_t)self * d;
     if (sub == 0) {
       // mean = sum / deg (a true division, like torch's scatter-mean), 0 for an empty row
-      const float dv = m > 0 ? (float)m : 1.f;
+      const float dv = (OP == GIGL_AGGR_MEAN && m > 0) ? (float)m : 1.f;
+      const float4_t none4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         const int el = (v * LPR + sl) * 4;
-        if (el < d) *reinterpret_cast<float4_t*>(o + el) = acc[v] / dv;
+        if (el < d) *reinterpret_cast<float4_t*>(o + el) = (OP == GIGL_AGGR_MAX && m == 0) ? none4 : acc[v] / dv;
       }
     }
     // self row copy, spread over all lanes of the wave
@@ -128,15 +140,19 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
   }
 }
 
-// backward of gather_mean w.r.t. a dense local source matrix (layers >= 2; raw input features need no
-// gradient):  dsrc[i] += dout[i][d:2d];  dsrc[col[e]] += dout[i][0:d] / deg_i for every edge e of row i.
+// backward of the segmented reduce w.r.t. a dense local source matrix (layers >= 2; raw input features need no
+// gradient):  dsrc[i] += dout[i][d:2d];  for every edge e of row i
+//   mean: dsrc[col[e]] += dout[i][0:d] / deg_i      sum: += dout[i][0:d]
+//   max:  += dout[i][0:d] / ties  for the sources that attain the maximum (torch's amax backward: the gradient
+//         is shared evenly among ties); needs src to find them again.
 // One wave per destination row; fp32 atomics (several rows can share a source).
 __global__ __launch_bounds__(256) void gather_mean_backward_kernel(const float* __restrict__ dout, int d,
                                                                    const int32_t* __restrict__ rowptr,
                                                                    const int32_t* __restrict__ rowend,
                                                                    const int32_t* __restrict__ col,
                                                                    const int32_t* __restrict__ n_rows_dev,
-                                                                   float* __restrict__ dsrc) {
+                                                                   float* __restrict__ dsrc, int op,
+                                                                   const float* __restrict__ src) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_rows = *n_rows_dev;
@@ -146,7 +162,21 @@ __global__ __launch_bounds__(256) void gather_mean_backward_kernel(const float* 
     const float* g = dout + (int64_t)i * 2 * d;
     for (int el = lane; el < d; el += 64) atomicAdd(&dsrc[(int64_t)i * d + el], g[d + el]);
     if (m == 0) continue;
-    const float inv = 1.0f / (float)m;
+    if (op == GIGL_AGGR_MAX) {
+      for (int el = lane; el < d; el += 64) {
+        float mx = -__builtin_inff();
+        for (int e = 0; e < m; ++e) mx = fmaxf(mx, src[(int64_t)col[e0 + e] * d + el]);
+        int ties = 0;
+        for (int e = 0; e < m; ++e) ties += src[(int64_t)col[e0 + e] * d + el] == mx ? 1 : 0;
+        const float share = g[el] / (float)ties;
+        for (int e = 0; e < m; ++e) {
+          const int j = col[e0 + e];
+          if (src[(int64_t)j * d + el] == mx) atomicAdd(&dsrc[(int64_t)j * d + el], share);
+        }
+      }
+      continue;
+    }
+    const float inv = op == GIGL_AGGR_MEAN ? 1.0f / (float)m : 1.0f;
     for (int e = 0; e < m; ++e) {
       const int j = col[e0 + e];
       for (int el = lane; el < d; el += 64) atomicAdd(&dsrc[(int64_t)j * d + el], g[el] * inv);
@@ -162,7 +192,7 @@ __global__ __launch_bounds__(256) void gather_mean_generic_kernel(const T* __res
                                                                   const int32_t* __restrict__ rowend,
                                                                   const int32_t* __restrict__ col,
                                                                   const int32_t* __restrict__ n_rows_dev,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, int op) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_rows = *n_rows_dev;
@@ -173,13 +203,14 @@ __global__ __launch_bounds__(256) void gather_mean_generic_kernel(const T* __res
     float* o = out + (int64_t)i * 2 * d;
     const int self = gather_ids ? (int)gather_ids[i] : i;
     for (int el = lane; el < d; el += 64) {
-      float acc = 0.f;
+      float acc = op == GIGL_AGGR_MAX ? -__builtin_inff() : 0.f;
       for (int e = e0; e < e1; ++e) {
         int j = col[e];
         if (gather_ids) j = (int)gather_ids[j];
-        acc += (float)src[(int64_t)j * d + el];
+        const float v = (float)src[(int64_t)j * d + el];
+        acc = op == GIGL_AGGR_MAX ? fmaxf(acc, v) : acc + v;
       }
-      o[el] = deg > 0 ? acc / (float)deg : 0.f;
+      o[el] = deg > 0 ? (op == GIGL_AGGR_MEAN ? acc / (float)deg : acc) : 0.f;
       o[d + el] = (float)src[(int64_t)self * d + el];
     }
   }
@@ -534,19 +565,25 @@ __global__ __launch_bounds__(256) void gat_gather_kernel(const float* __restrict
 template <typename T>
 int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather_ids,
                       const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
-                      const int32_t* n_rows_dev, int64_t rows_cap, float* out) {
+                      const int32_t* n_rows_dev, int64_t rows_cap, float* out, int op = GIGL_AGGR_MEAN) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
   dim3 g((unsigned)blocks), b(256);
   hipStream_t st = ctx->stream;
   const int vecs = d / 4;
-#define GL(LPR, VPL)                                                                             \
-  hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL>), g, b, 0, st, src, d, gather_ids, rowptr, \
+#define GLO(LPR, VPL, OP)                                                                            \
+  hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, 0, st, src, d, gather_ids, rowptr, \
                      rowend, col, n_rows_dev, out)
+#define GL(LPR, VPL)                                        \
+  do {                                                      \
+    if (op == GIGL_AGGR_MEAN) GLO(LPR, VPL, GIGL_AGGR_MEAN); \
+    else if (op == GIGL_AGGR_SUM) GLO(LPR, VPL, GIGL_AGGR_SUM); \
+    else GLO(LPR, VPL, GIGL_AGGR_MAX);                      \
+  } while (0)
   if ((d & 3) != 0 || vecs > 512) {
     hipLaunchKernelGGL((gather_mean_generic_kernel<T>), g, b, 0, st, src, d, gather_ids, rowptr, rowend,
-                       col, n_rows_dev, out);
+                       col, n_rows_dev, out, op);
   } else if (vecs <= 8) GL(8, 1);
   else if (vecs <= 16) GL(16, 1);
   else if (vecs <= 32) GL(32, 1);
@@ -555,6 +592,7 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
   else if (vecs <= 256) GL(64, 4);
   else GL(64, 8);
 #undef GL
+#undef GLO
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
@@ -578,6 +616,25 @@ int32_t gigl_gather_mean(gigl_ctx* ctx, const void* src, int32_t src_dtype, int3
   if (src_dtype == GIGL_DTYPE_F16)
     return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev,
                                  rows_cap, out);
+  return gigl_fail(ctx, GIGL_E_INVALID_ARG, "bad dtype %d", src_dtype);
+}
+
+int32_t gigl_gather_reduce(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* gather_ids,
+                           const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                           const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr, float* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, src && rowptr && rowend && col && n_rows_dev && out, "null argument");
+  GIGL_REQUIRE(ctx, d > 0 && rows_cap >= 0, "bad sizes");
+  GIGL_REQUIRE(ctx, aggr == GIGL_AGGR_MEAN || aggr == GIGL_AGGR_SUM || aggr == GIGL_AGGR_MAX, "bad aggr %d", aggr);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  if (src_dtype == GIGL_DTYPE_F32)
+    return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
+                                aggr);
+  if (src_dtype == GIGL_DTYPE_F16)
+    return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap,
+                                 out, aggr);
   return gigl_fail(ctx, GIGL_E_INVALID_ARG, "bad dtype %d", src_dtype);
 }
 
@@ -660,7 +717,25 @@ int32_t gigl_gather_mean_backward(gigl_ctx* ctx, const float* dout, int32_t d, c
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(gather_mean_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dout, d,
-                     rowptr, rowend, col, n_rows_dev, dsrc);
+                     rowptr, rowend, col, n_rows_dev, dsrc, GIGL_AGGR_MEAN, (const float*)nullptr);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_gather_reduce_backward(gigl_ctx* ctx, const float* dout, int32_t d, const int32_t* rowptr,
+                                    const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
+                                    int64_t rows_cap, int32_t aggr, const float* src, float* dsrc) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, dout && rowptr && rowend && col && n_rows_dev && dsrc, "null argument");
+  GIGL_REQUIRE(ctx, d > 0 && rows_cap >= 0, "bad sizes");
+  GIGL_REQUIRE(ctx, aggr == GIGL_AGGR_MEAN || aggr == GIGL_AGGR_SUM || aggr == GIGL_AGGR_MAX, "bad aggr %d", aggr);
+  GIGL_REQUIRE(ctx, aggr != GIGL_AGGR_MAX || src, "max needs the forward's source matrix");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(gather_mean_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dout, d,
+                     rowptr, rowend, col, n_rows_dev, dsrc, aggr, src);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

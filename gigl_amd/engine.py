@@ -377,8 +377,10 @@ class HipEngine:
 
     def gather_mean(self, src: Optional[torch.Tensor], d: int, gather_ids: Optional[torch.Tensor],
                     rowptr: torch.Tensor, rowend: Optional[torch.Tensor], col: torch.Tensor,
-                    n_rows_dev: torch.Tensor, rows_cap: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """src None -> the resident feature table; rowend None -> packed CSR (rowend = rowptr[1:])."""
+                    n_rows_dev: torch.Tensor, rows_cap: int, out: Optional[torch.Tensor] = None,
+                    aggr: str = "mean") -> torch.Tensor:
+        """src None -> the resident feature table; rowend None -> packed CSR (rowend = rowptr[1:]).
+        aggr: "mean" | "sum" | "max" (PyG SAGEConv aggr)."""
         if rowend is None:
             rowend = rowptr[1:]
         if src is None:
@@ -390,9 +392,10 @@ class HipEngine:
         if out is None:
             out = torch.empty((rows_cap, 2 * d), dtype=torch.float32, device=self.device)
         gid = C.c_void_p(gather_ids.data_ptr()) if gather_ids is not None else None
-        check(self._lib.gigl_gather_mean(self._ctx, src_ptr, dt, d, gid, C.c_void_p(rowptr.data_ptr()),
-                                         C.c_void_p(rowend.data_ptr()), C.c_void_p(col.data_ptr()), C.c_void_p(n_rows_dev.data_ptr()), rows_cap,
-                                         C.c_void_p(out.data_ptr())), self._ctx)
+        check(self._lib.gigl_gather_reduce(self._ctx, src_ptr, dt, d, gid, C.c_void_p(rowptr.data_ptr()),
+                                           C.c_void_p(rowend.data_ptr()), C.c_void_p(col.data_ptr()),
+                                           C.c_void_p(n_rows_dev.data_ptr()), rows_cap, _lib.AGGR[aggr],
+                                           C.c_void_p(out.data_ptr())), self._ctx)
         return out
 
     def gather_rows(self, ids: torch.Tensor, n_dev: torch.Tensor, cap: int,
@@ -444,15 +447,19 @@ class HipEngine:
         return out
 
     def gather_mean_backward(self, dout: torch.Tensor, d: int, rowptr: torch.Tensor, rowend: Optional[torch.Tensor],
-                             col: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int, dsrc: torch.Tensor) -> None:
-        """dsrc (zero-filled, [n_src, d] fp32) += the gradient of gather_mean w.r.t. its dense local source"""
+                             col: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int, dsrc: torch.Tensor,
+                             aggr: str = "mean", src: Optional[torch.Tensor] = None) -> None:
+        """dsrc (zero-filled, [n_src, d] fp32) += the gradient of gather_mean w.r.t. its dense local source
+        (aggr "max" needs the forward's source matrix `src`)"""
         if rowend is None:
             rowend = rowptr[1:]
         assert dout.is_cuda and dout.is_contiguous() and dsrc.is_contiguous() and dout.dtype == torch.float32
-        check(self._lib.gigl_gather_mean_backward(self._ctx, C.c_void_p(dout.data_ptr()), d,
-                                                  C.c_void_p(rowptr.data_ptr()), C.c_void_p(rowend.data_ptr()),
-                                                  C.c_void_p(col.data_ptr()), C.c_void_p(n_rows_dev.data_ptr()),
-                                                  rows_cap, C.c_void_p(dsrc.data_ptr())), self._ctx)
+        sp = C.c_void_p(src.data_ptr()) if src is not None else None
+        check(self._lib.gigl_gather_reduce_backward(self._ctx, C.c_void_p(dout.data_ptr()), d,
+                                                    C.c_void_p(rowptr.data_ptr()), C.c_void_p(rowend.data_ptr()),
+                                                    C.c_void_p(col.data_ptr()), C.c_void_p(n_rows_dev.data_ptr()),
+                                                    rows_cap, _lib.AGGR[aggr], sp, C.c_void_p(dsrc.data_ptr())),
+              self._ctx)
 
     def linear(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m_dev: torch.Tensor,
                m_cap: int, act: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:

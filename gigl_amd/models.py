@@ -52,19 +52,70 @@ class SAGEConv(nn.Module):
 
 
 class GraphSAGE(nn.Module):
+    """BasicHomogeneousGNN + GraphSAGE.init_conv_layers (python/gigl/src/common/models/pyg/homogeneous.py:30-153,
+    171-202): per layer conv -> [activation | BatchNorm1d | activation] -> dropout (not after the last layer unless
+    activation_after_last_conv), optional L2 normalisation, return_emb, final Linear.  conv_kwargs: aggr ("mean" |
+    "sum" | "max"), bias, root_weight (PyG SAGEConv).  jk_mode, feature embedding / interaction layers are not built.
+    State-dict keys follow the reference (conv_layers.{i}.lin_l/lin_r, batchnorm_layers.{i}, linear)."""
+
     def __init__(self, in_dim: int, hid_dim: int, out_dim: int, num_layers: int = 2,
                  activation_after_last_conv: bool = False, should_l2_normalize_embedding_layer_output: bool = False,
-                 **conv_kwargs):
+                 activation_before_norm: bool = False, dropout: float = 0.0, batchnorm: bool = False,
+                 linear_layer: bool = False, return_emb: bool = False, jk_mode: Optional[str] = None, **conv_kwargs):
         super().__init__()
+        if jk_mode:
+            raise NotImplementedError("jk_mode (JumpingKnowledge) is not implemented")
+        conv_kwargs = dict(conv_kwargs.get("conv_kwargs") or conv_kwargs)
         self.in_dim, self.hid_dim, self.out_dim, self.num_layers = in_dim, hid_dim, out_dim, num_layers
         self.activation_after_last_conv = activation_after_last_conv
+        self.activation_before_norm = activation_before_norm
         self.should_l2_normalize_embedding_layer_output = should_l2_normalize_embedding_layer_output
+        self.aggr = str(conv_kwargs.get("aggr", "mean"))
+        if self.aggr == "add":
+            self.aggr = "sum"
+        if self.aggr not in ("mean", "sum", "max"):
+            raise NotImplementedError(f"SAGEConv aggr={self.aggr!r} is not implemented (mean, sum, max)")
         bias = bool(conv_kwargs.get("bias", True))
         root_weight = bool(conv_kwargs.get("root_weight", True))
+        last = hid_dim if linear_layer else out_dim
         self.conv_layers = nn.ModuleList([
-            SAGEConv(in_dim if i == 0 else hid_dim, hid_dim if i < num_layers - 1 else out_dim, bias=bias,
+            SAGEConv(in_dim if i == 0 else hid_dim, hid_dim if i < num_layers - 1 else last, bias=bias,
                      root_weight=root_weight) for i in range(num_layers)])
+        self.dropout = nn.Dropout(p=dropout)
+        self.batchnorm = batchnorm
+        if batchnorm:
+            self.batchnorm_layers = nn.ModuleList([nn.BatchNorm1d(hid_dim) for _ in range(num_layers - 1)])
+        self.return_emb, self.linear_layer = return_emb, linear_layer
+        if linear_layer:
+            self.linear = nn.Linear(hid_dim, out_dim)
         self._ws = None  # workspace cache
+
+    @property
+    def _plain(self) -> bool:
+        """conv -> relu only: what the fused kernels' epilogue and the one-call plan compute"""
+        return (not self.batchnorm and self.dropout.p == 0.0 and not self.linear_layer
+                and not self.activation_before_norm)
+
+    def _post(self, h: torch.Tensor, l: int, fused_act: bool) -> torch.Tensor:
+        """what follows conv l (homogeneous.py:126-141); fused_act: relu already applied by the kernel epilogue"""
+        if l == self.num_layers - 1 and not self.activation_after_last_conv:
+            return h
+        if self._plain:
+            return h if fused_act else torch.relu(h)
+        if self.activation_before_norm:
+            h = torch.relu(h)
+        if self.batchnorm and l < len(self.batchnorm_layers):
+            h = self.batchnorm_layers[l](h)
+        if not self.activation_before_norm:
+            h = torch.relu(h)
+        return self.dropout(h)
+
+    def _head(self, h: torch.Tensor) -> torch.Tensor:
+        if self.should_l2_normalize_embedding_layer_output:
+            h = torch.nn.functional.normalize(h, p=2, dim=1)
+        if self.return_emb:
+            return h
+        return self.linear(h) if self.linear_layer else h
 
     def forward(self, batch, engine: Optional[HipEngine] = None) -> torch.Tensor:
         """HipBatch  -> inference over the level-ordered union graph (trimmed schedule, no autograd): returns
@@ -79,12 +130,11 @@ class GraphSAGE(nn.Module):
                 raise RuntimeError("GraphSAGE.forward(GraphData) needs the HipEngine (model.engine = eng)")
             h = batch.x
             for l, conv in enumerate(self.conv_layers):
-                act = l < self.num_layers - 1 or self.activation_after_last_conv
+                fused = self._plain and (l < self.num_layers - 1 or self.activation_after_last_conv)
                 w_r = conv.lin_r.weight if conv.lin_r is not None else torch.zeros_like(conv.lin_l.weight)
-                h = sage_conv(h, conv.lin_l.weight, conv.lin_l.bias, w_r, eng, batch, act)
-            if self.should_l2_normalize_embedding_layer_output:
-                h = torch.nn.functional.normalize(h, p=2, dim=1)
-            return h
+                h = sage_conv(h, conv.lin_l.weight, conv.lin_l.bias, w_r, eng, batch, fused, self.aggr)
+                h = self._post(h, l, fused)
+            return self._head(h)
         with torch.no_grad():
             return self._forward_union(batch)
 
@@ -99,23 +149,25 @@ class GraphSAGE(nn.Module):
             d = conv.in_channels
             abuf = self._buf("a", l, cap, 2 * d)
             if l == 0 and batch.x is None:
-                a = eng.gather_mean(None, d, u.nodes, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf)
+                a = eng.gather_mean(None, d, u.nodes, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf, aggr=self.aggr)
             elif l == 0:
-                a = eng.gather_mean(batch.x, d, None, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf)
+                a = eng.gather_mean(batch.x, d, None, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf, aggr=self.aggr)
             else:
-                a = eng.gather_mean(h, d, None, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf)
-            act = 1 if (l < L - 1 or self.activation_after_last_conv) else 0
-            bias = conv.lin_l.bias
-            h = eng.linear(a, conv.fused_weight(), bias, n_rows, cap, act, out=self._buf("h", l, cap, conv.out_channels))
-        if self.should_l2_normalize_embedding_layer_output:
-            h = torch.nn.functional.normalize(h, p=2, dim=1)
-        return h
+                a = eng.gather_mean(h, d, None, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf, aggr=self.aggr)
+            fused = self._plain and (l < L - 1 or self.activation_after_last_conv)
+            h = eng.linear(a, conv.fused_weight(), conv.lin_l.bias, n_rows, cap, 1 if fused else 0,
+                           out=self._buf("h", l, cap, conv.out_channels))
+            if not self._plain:
+                h = self._post(h, l, fused).contiguous()
+        return self._head(h)
 
     def make_plan(self, eng: HipEngine, b: int, fanouts: Sequence[int], groups: int = 1):
         """one-call pipeline (sample -> union -> this model's forward -> one row per root) for batches of
         `b` roots on `eng`; weights are snapshotted — call plan.set_weights(*model.fused_params()) after updates.
         groups > 1: each call takes groups*b roots and processes them as `groups` independent batches of b."""
         assert len(fanouts) == self.num_layers, "one hop per layer"
+        if not (self._plain and self.aggr == "mean" and not self.should_l2_normalize_embedding_layer_output):
+            raise NotImplementedError("the one-call plan computes conv(mean) -> relu layers only; use forward(HipBatch)")
         w, bs = self.fused_params()
         return eng.make_sage_plan(w, bs, b, fanouts, act_last=self.activation_after_last_conv, groups=groups)
 

@@ -63,20 +63,20 @@ class _SageConvFn(torch.autograd.Function):
     """y = act([mean_{j->i} h_j | h_i] @ [W_l | W_r]^T + b) over ALL rows of the graph"""
 
     @staticmethod
-    def forward(ctx, h, w_l, b_l, w_r, eng: HipEngine, g: GraphData, act: int):
+    def forward(ctx, h, w_l, b_l, w_r, eng: HipEngine, g: GraphData, act: int, aggr: str = "mean"):
         n, d = int(h.shape[0]), int(h.shape[1])
         h = h.contiguous()
-        a = eng.gather_mean(h, d, None, g.rowptr, None, g.col, g.n_dev, n)
+        a = eng.gather_mean(h, d, None, g.rowptr, None, g.col, g.n_dev, n, aggr=aggr)
         wcat = torch.cat([w_l, w_r], dim=1).contiguous()
         y = eng.linear(a, wcat, b_l, g.n_dev, n, act)
-        ctx.eng, ctx.g, ctx.act, ctx.d = eng, g, act, d
+        ctx.eng, ctx.g, ctx.act, ctx.d, ctx.aggr = eng, g, act, d, aggr
         ctx.has_bias = b_l is not None
-        ctx.save_for_backward(a, wcat, y)
+        ctx.save_for_backward(a, wcat, y, *([h] if aggr == "max" else []))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        a, wcat, y = ctx.saved_tensors
+        a, wcat, y = ctx.saved_tensors[:3]
         eng, g, d = ctx.eng, ctx.g, ctx.d
         n = int(a.shape[0])
         dy = dy.contiguous()
@@ -91,11 +91,12 @@ class _SageConvFn(torch.autograd.Function):
         dh = None
         if ctx.needs_input_grad[0]:
             dh = torch.zeros((n, d), dtype=torch.float32, device=dev)
-            eng.gather_mean_backward(da, d, g.rowptr, None, g.col, g.n_dev, n, dh)
+            eng.gather_mean_backward(da, d, g.rowptr, None, g.col, g.n_dev, n, dh, aggr=ctx.aggr,
+                                     src=ctx.saved_tensors[3] if ctx.aggr == "max" else None)
         db = dy.sum(0) if ctx.has_bias else None
-        return dh, dw[:, :d].contiguous(), db, dw[:, d:].contiguous(), None, None, None
+        return dh, dw[:, :d].contiguous(), db, dw[:, d:].contiguous(), None, None, None, None
 
 
 def sage_conv(h: torch.Tensor, w_l: torch.Tensor, b_l: Optional[torch.Tensor], w_r: torch.Tensor, eng: HipEngine,
-              g: GraphData, act: bool) -> torch.Tensor:
-    return _SageConvFn.apply(h, w_l, b_l, w_r, eng, g, 1 if act else 0)
+              g: GraphData, act: bool, aggr: str = "mean") -> torch.Tensor:
+    return _SageConvFn.apply(h, w_l, b_l, w_r, eng, g, 1 if act else 0, aggr)

@@ -332,6 +332,21 @@ int32_t gigl_gather_mean(gigl_ctx* ctx, const void* src, int32_t src_dtype, int3
                          const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* rowend,
                          const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, float* out);
 
+/* the same with the reduction chosen: PyG SAGEConv(aggr = "mean" | "sum" | "max") via conv_kwargs
+ * (python/gigl/src/common/models/pyg/homogeneous.py:171-202); an empty row reduces to 0 */
+#define GIGL_AGGR_MEAN 0
+#define GIGL_AGGR_SUM 1
+#define GIGL_AGGR_MAX 2
+int32_t gigl_gather_reduce(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* gather_ids,
+                           const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                           const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr, float* out);
+/* its backward w.r.t. a dense local fp32 source (dsrc zero-filled by the caller): mean / sum scatter dout[i][0:d]
+ * (over deg_i for mean); max shares dout[i][k] evenly among the sources attaining the maximum (torch amax) and
+ * needs the forward's `src` */
+int32_t gigl_gather_reduce_backward(gigl_ctx* ctx, const float* dout, int32_t d, const int32_t* rowptr,
+                                    const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
+                                    int64_t rows_cap, int32_t aggr, const float* src, float* dsrc);
+
 /* feature hydration alone (hydrateNodes, SGSPureSparkV1Task.scala:496-547): out[i][0:d] = src[ids[i]][0:d] as fp32
  * for i < *n_dev.  Needed when a layer projects before it aggregates (GAT). */
 int32_t gigl_gather_rows(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* ids,
