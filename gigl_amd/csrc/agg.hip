@@ -348,29 +348,30 @@ __global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict
   // W loader: thread tid -> rows (tid>>3) + 32*i, i < NT
   const int wr = tid >> 3, wc = tid & 7;
 
-  float4_t ga[4], gw[NT];
-  auto gload = [&](int k0) {
+  // operands of TWO chunks ahead are kept in flight in registers: a chunk's MFMAs take ~2k cycles, a global load
+  // under load more (the kernel sat at 57 % of the fp32-MFMA peak with a one-chunk prefetch distance)
+  float4_t ga[2][4], gw[2][NT];
+  auto gload = [&](int k0, float4_t (&da)[4], float4_t (&dw)[NT]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = m0 + lr + 8 * i, kk = k0 + lc * 4;
-      ga[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(a + (int64_t)row * K + kk) : zero4;
+      da[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(a + (int64_t)row * K + kk) : zero4;
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int row = n0 + wr + 32 * i, kk = k0 + wc * 4;
-      gw[i] = (row < N && kk < K) ? *reinterpret_cast<const float4_t*>(w + (int64_t)row * K + kk) : zero4;
+      dw[i] = (row < N && kk < K) ? *reinterpret_cast<const float4_t*>(w + (int64_t)row * K + kk) : zero4;
     }
   };
-  gload(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
+  auto chunk = [&](int k0, float4_t (&ra)[4], float4_t (&rw)[NT]) {
     __syncthreads();  // previous chunk's LDS reads are done
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4_t*>(&s_a[wv_id][(lr + 8 * i) * LDK + lc * 4]) = ga[i];
+      *reinterpret_cast<float4_t*>(&s_a[wv_id][(lr + 8 * i) * LDK + lc * 4]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) *reinterpret_cast<float4_t*>(&s_w[(wr + 32 * i) * LDK + wc * 4]) = gw[i];
+    for (int i = 0; i < NT; ++i) *reinterpret_cast<float4_t*>(&s_w[(wr + 32 * i) * LDK + wc * 4]) = rw[i];
     __syncthreads();
-    if (k0 + BK < K) gload(k0 + BK);  // in flight under the MFMAs below
+    if (k0 + 2 * BK < K) gload(k0 + 2 * BK, ra, rw);  // lands during this chunk's and the next chunk's MFMAs
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 8) {
       if (k0 + ks >= K) break;
@@ -385,6 +386,12 @@ __global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict
         for (int j = 0; j < NT; ++j)
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], wv[j][t], acc[j], 0, 0, 0);
     }
+  };
+  gload(0, ga[0], gw[0]);
+  if (BK < K) gload(BK, ga[1], gw[1]);
+  for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+    chunk(k0, ga[0], gw[0]);
+    if (k0 + BK < K) chunk(k0 + BK, ga[1], gw[1]);
   }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
