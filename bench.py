@@ -140,9 +140,14 @@ def main():
     ap.add_argument("--group", type=int, default=16,
                     help="batches per library call: G independent batches of B roots share one set of launches "
                          "(each keeps its own union graph; results are bit-identical to G single-batch calls)")
-    ap.add_argument("--workload", type=str, default="products", choices=["products", "mag-shard"],
-                    help="products = BASELINE configs[1] (default, the N=1 workload); mag-shard = one GPU's 1/8 share "
-                         "of the MAG240M-shaped graph (D=768 fp16, SAGE 768->256->256)")
+    ap.add_argument("--workload", type=str, default="products", choices=["products", "mag-shard", "mag240m-sharded"],
+                    help="products = BASELINE configs[1] (default, the N=1 workload; N>1: a replica per GPU); mag-shard = "
+                         "one GPU's 1/8 share of the MAG240M-shaped graph as a self-contained graph (D=768 fp16, SAGE "
+                         "768->256->256); mag240m-sharded = BASELINE configs[2]: the MAG240M-shaped graph hash-"
+                         "partitioned over the ranks (owner = id %% world), per-hop all_to_all frontier exchange and "
+                         "feature pull over RCCL — needs >= 2 GPUs at full size (--shard-scale shrinks it)")
+    ap.add_argument("--shard-scale", type=float, default=1.0,
+                    help="mag240m-sharded: fraction of MAG240M's nodes and edges to generate (1.0 needs 8 GPUs' HBM)")
     ap.add_argument("--small", action="store_true", help="200k-node graph (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true",
@@ -160,6 +165,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert world == max(args.gpus, 1) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    if args.workload == "mag240m-sharded":
+        return run_sharded(args, rank, world, local_rank)
 
     from gigl_amd._lib import KERNEL_IDS, MODE_FAST, MODE_SPARK_HASH
     from gigl_amd.engine import HipEngine
@@ -417,6 +424,184 @@ def main():
         dist.destroy_process_group()
     for e in reversed(engines):
         e.close()
+
+
+def run_sharded(args, rank, world, local_rank):
+    """BASELINE.json configs[2]: MAG240M-shaped graph (N=244,160,499, E=1,728,364,232 directed RMAT, D=768 fp16,
+    SURVEY.md 8(d) C3) hash-partitioned over the ranks: rank r holds the CSC rows and feature rows of the nodes
+    with id % world == r (gigl_amd/dist.py).  A step = one batch of B roots per rank: per hop one all_to_all of
+    (node, K) requests to the owners, gigl_expand_frontier there, one all_to_all back; union graph locally; the
+    UNIQUE node ids pulled from their owners (all_to_all of ids, all_to_all of rows); 2-layer GraphSAGE 768->256->256.
+    Frontier buckets are filled and scattered on the device (gigl_frontier_bucket / gigl_frontier_scatter) and move
+    through equal-split all_to_alls; the only host read of a step is the split sizes of the feature-row exchange, and
+    it is taken while the NEXT batch's sampling exchange is already queued on a second stream (two batches in flight:
+    remote fetch overlapped with local expansion).  The collectives are still issued from Python (torch.distributed)."""
+    import torch.distributed as dist
+    from gigl_amd._lib import GIGL_META_LEVEL0
+    from gigl_amd.dist import HipDistKHopSampler, HipFeaturePuller
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE, HipBatch
+
+    torch.cuda.set_device(local_rank)
+    if world == 1 and not dist.is_initialized():  # single-rank group: same code path, the exchange is a self-copy
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    eng = HipEngine(local_rank)
+    dev = eng.device
+    fanouts = [int(v) for v in args.fanouts.split(",")]
+    L = len(fanouts)
+    B, K, W = args.batch, args.steps, args.warmup
+    n = max(int(244_160_499 * args.shard_scale), world * 1024)
+    e_total = max(int(1_728_364_232 * args.shard_scale), 1)
+    d, hid, out_dim = 768, 256, 256
+    t0 = time.time()
+    # ---- this rank's shard: every rank draws the same seeded edge chunks and keeps the edges it owns
+    scale_bits = max(int(np.ceil(np.log2(n))), 10)
+    chunk, keys = 1 << 26, []
+    for ci, c0 in enumerate(range(0, e_total, chunk)):
+        m = min(chunk, e_total - c0)
+        src, dst = rmat_edges_gpu(scale_bits, m, seed=3 + 7919 * ci, device=dev)
+        src = (src * 0x9E3779B1) % n
+        dst = (dst * 0x9E3779B1) % n
+        keep = (dst % world) == rank
+        keys.append(((dst[keep] // world) << 32) | src[keep])
+        del src, dst, keep
+    key = torch.unique(torch.cat(keys))  # sorted by (local row, src), duplicates dropped
+    del keys
+    n_local = (n - rank + world - 1) // world
+    rowptr = torch.zeros(n_local + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(key >> 32, minlength=n_local), 0)
+    col = (key & 0xFFFFFFFF).to(torch.int32)
+    maxdeg = torch.tensor([int((rowptr[1:] - rowptr[:-1]).max())], dtype=torch.int64, device=dev)
+    e_local = torch.tensor([int(col.numel())], dtype=torch.int64, device=dev)
+    dist.all_reduce(maxdeg, op=dist.ReduceOp.MAX)
+    dist.all_reduce(e_local, op=dist.ReduceOp.SUM)
+    eng.load_csc(rowptr, col)
+    del key, rowptr, col
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    x_local = torch.empty((n_local, d), device=dev, dtype=torch.float16)
+    step_rows = max(1, (1 << 28) // d)
+    for i in range(0, n_local, step_rows):
+        x_local[i:i + step_rows] = torch.randn((min(step_rows, n_local - i), d), generator=g, device=dev).to(torch.float16)
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
+    # every hash window ends below (hops+1)*n + seed*hops + maxdeg: lets the owners use the range table throughout
+    bound = (L + 1) * n + 42 * L + int(maxdeg.item())
+    gp = torch.Generator(device="cpu")
+    gp.manual_seed(42)
+    total_batches = (W + K) * world
+    perm = torch.randint(0, n, (total_batches * B,), generator=gp)
+    my = perm.view(total_batches, B)[rank::world].to(torch.int32).to(dev).contiguous()
+
+    class Slot:  # everything one in-flight batch owns; two slots alternate so that the host read of batch i's split
+        pass     # sizes waits while batch i+1's sampling is already queued on the other stream
+
+    slots = []
+    for si in range(2):
+        sl = Slot()
+        sl.stream = torch.cuda.Stream(device=dev)
+        sl.eng = eng if si == 0 else HipEngine(local_rank)  # a ctx (stream, arena, hash table) per in-flight batch
+        if si:
+            sl.eng.share_resident(eng)
+        sl.eng.bind_stream(sl.stream)
+        sl.tree = sl.eng.alloc_tree(B, fanouts)
+        sl.tree.c_struct.hops, sl.tree.c_struct.b = L, B
+        for k, f in enumerate(fanouts):
+            sl.tree.c_struct.fanouts[k] = f
+        sl.u = sl.eng.alloc_union(B, fanouts)
+        sl.sampler = HipDistKHopSampler(sl.eng, world, max_window_end=bound if bound < (1 << 30) else -1, sampling_seed=42)
+        sl.puller = HipFeaturePuller(sl.eng, world, x_local, int(sl.u.nodes.numel()))
+        slots.append(sl)
+    acc = torch.zeros(3, dtype=torch.int64, device=dev)  # sampled, aggregated, pulled (counted on the device)
+    lvl = [GIGL_META_LEVEL0 + (L - 1 - l) for l in range(L)]
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+
+    def phase1(sl, i):
+        """sampling (2 all_to_all per hop) + union graph + feature requests (2 all_to_all): queued, never waited for"""
+        with torch.cuda.stream(sl.stream):
+            sl.tree.roots = my[i]
+            _, sl.cnt = sl.sampler.sample_khop(sl.tree.roots, fanouts, tree=sl.tree)
+            sl.eng.union_build(sl.tree, out=sl.u)
+            p = sl.puller
+            req = p.request(sl.u.nodes, sl.u.meta[0])
+            dist.all_to_all_single(p.got, req)
+            dist.all_to_all_single(p.recv_counts[:world], p.counts[:world])
+            sl.host = torch.cat([p.counts, p.recv_counts[:world], sl.u.meta[:1]]).to("cpu", non_blocking=True)
+            sl.ready = torch.cuda.Event()
+            sl.ready.record(sl.stream)
+
+    def phase2(sl, count):
+        """the step's one host read (split sizes), the row exchange, the forward"""
+        sl.ready.synchronize()
+        host = sl.host.tolist()
+        sc, overflow, rc, n_rows = host[:world], host[world], host[world + 1: 2 * world + 1], host[-1]
+        if overflow:
+            raise RuntimeError("feature-pull bucket overflow")
+        with torch.cuda.stream(sl.stream):
+            p = sl.puller
+            rows = p.serve(p.got, rc)
+            back = rows.new_empty((int(sum(sc)), rows.shape[1]))
+            dist.all_to_all_single(back, rows, output_split_sizes=sc, input_split_sizes=rc)
+            x = p.place(back, sc, n_rows)
+            out = model(HipBatch(engine=sl.eng, tree=sl.tree, union=sl.u, x=x))
+            sl.rows = out[sl.u.root_local[:B].to(torch.int64)]
+            if count:
+                u = sl.u
+                rowlen = (u.rowend - u.rowptr).to(torch.int64)
+                ar = torch.arange(rowlen.numel(), device=dev)
+                agg = sum((rowlen * (ar < u.meta[j])).sum() for j in lvl)
+                acc.add_(torch.stack([sum(c.sum() for c in sl.cnt).to(torch.int64), agg.to(torch.int64),
+                                      u.meta[0].to(torch.int64)]))
+
+    def run(lo, hi, count):
+        phase1(slots[lo % 2], lo)
+        for i in range(lo, hi):
+            if i + 1 < hi:
+                phase1(slots[(i + 1) % 2], i + 1)
+            phase2(slots[i % 2], count)
+
+    run(0, W, False)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    run(W, W + K, True)
+    if int(max(int(sl.sampler.overflow.item()) for sl in slots)):
+        raise RuntimeError("frontier bucket overflow: rerun with a larger slack")
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t1
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    cc = acc.to(torch.float64)
+    dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+    elapsed = float(tt.item())
+    sampled_all, aggregated_all, pulled_all = [float(v) for v in cc.tolist()]
+    if rank == 0:
+        line = {
+            "metric": "sampled+aggregated edges/s", "value": (sampled_all + aggregated_all) / elapsed,
+            "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"MAG240M-shaped RMAT x{args.shard_scale:g}: N={n} E={int(e_local.item())} directed, "
+                                   f"D={d} fp16 features, hash-partitioned over {world} rank(s) (owner = id % world), "
+                                   f"fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}, sampler mode=parity",
+                       "graph": "CSC rows + feature rows of the owned nodes per rank; per-hop all_to_all frontier "
+                                "exchange, feature pull of the unique union-graph nodes",
+                       "sampled_edges_per_step": sampled_all / (K * world),
+                       "aggregated_edges_per_step": aggregated_all / (K * world),
+                       "pulled_feature_rows_per_step": pulled_all / (K * world),
+                       "pulled_feature_bytes_per_s": pulled_all * d * 2 / elapsed, "setup_s": round(setup_s, 1)},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(line))
+    dist.barrier()
+    dist.destroy_process_group()
+    for sl in reversed(slots):
+        sl.eng.close()
 
 
 def run_cpu_baseline(eng, model, my, fanouts, W, n, d):

@@ -35,6 +35,7 @@ SYMBOLS = [
     "gigl_union_build_groups", "gigl_sage_plan_set_groups", "gigl_records_capacity", "gigl_records_encode",
     "gigl_tfrecord_index", "gigl_tfexample_decode", "gigl_collate_records", "gigl_collated_info", "gigl_collated_copy",
     "gigl_collated_destroy", "gigl_gather_reduce", "gigl_gather_reduce_backward",
+    "gigl_frontier_bucket", "gigl_frontier_scatter",
 ]
 
 KERNEL_IDS = {
@@ -157,6 +158,8 @@ def load() -> C.CDLL:
         "gigl_gather_mean_backward": [vp, vp, i32, vp, vp, vp, vp, i64, vp],
         "gigl_expand_frontier": [vp, vp, vp, vp, i64, i32, i32, i32, i64, vp, vp],
         "gigl_gather_rows": [vp, vp, i32, i32, vp, vp, i64, vp],
+        "gigl_frontier_bucket": [vp, vp, vp, i64, i32, i64, vp, vp, vp],
+        "gigl_frontier_scatter": [vp, vp, vp, vp, vp, i64, i32, i64, i32, vp, vp, vp],
         "gigl_gather_reduce": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, i32, vp],
         "gigl_gather_reduce_backward": [vp, vp, i32, vp, vp, vp, vp, i64, i32, vp, vp],
         "gigl_tfrecord_index": [vp, i64, i32, i64, vp, vp, P(i64)],

@@ -1,0 +1,109 @@
+// frontier.hip — the two device-side ends of the per-hop frontier exchange on a hash-partitioned graph.
+//
+// The reference's distributed loader asks the owner of every frontier node for its sampled neighbours through one
+// RPC per batch and partition (GLT DistNeighborLoader, python/gigl/distributed/distributed_neighborloader.py:26-192;
+// owner(v) = v % world, dist_link_prediction_data_partitioner.py:692-695).  Here a hop is ONE equal-split
+// all_to_all of fixed-capacity request buckets out and one of the answers back; these kernels fill the buckets and
+// scatter the answers into the tree layout without any host-side bookkeeping (no sort, no counts on the host, no
+// synchronisation: the step stays a pure stream of device work + two collectives per hop):
+//   gigl_frontier_bucket   slot i (node v, path sum K) -> bucket owner(v): position by atomicAdd, the slot number is
+//                          remembered locally; empty slots (GIGL_INVALID) are not sent; unused entries stay INVALID
+//   (all_to_all of the buckets -> owners run gigl_expand_frontier on what they received -> all_to_all back)
+//   gigl_frontier_scatter  answer p of bucket r -> tree slot slot_idx[r][p]: f ids, their count, and the path sums
+//                          of the children (K accumulates along the path with uint32 wrap == the reference's int32 add)
+// A bucket holds `cap` requests per peer; counts[world] is raised if one overflows (the caller sizes cap = m for
+// small worlds, else 1.5 m / world + 512: owner(v) is a uniform hash).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void frontier_bucket_kernel(const uint32_t* __restrict__ nodes,
+                                                              const uint32_t* __restrict__ ksums, int64_t m,
+                                                              uint32_t world, int64_t cap, uint32_t* __restrict__ req,
+                                                              int32_t* __restrict__ slot_idx,
+                                                              int32_t* __restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t v = nodes[i];
+  if (v == GIGL_INVALID) return;
+  const uint32_t r = v % world;
+  const int32_t p = atomicAdd(&counts[r], 1);
+  if (p >= cap) {
+    atomicOr(&counts[world], 1);
+    return;
+  }
+  req[((int64_t)r * 2 + 0) * cap + p] = v;
+  req[((int64_t)r * 2 + 1) * cap + p] = ksums ? ksums[i] : v;
+  slot_idx[(int64_t)r * cap + p] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void frontier_scatter_kernel(const uint32_t* __restrict__ resp,
+                                                               const int32_t* __restrict__ slot_idx,
+                                                               const int32_t* __restrict__ counts,
+                                                               const uint32_t* __restrict__ parent_ksums,
+                                                               uint32_t world, int64_t cap, int f,
+                                                               uint32_t* __restrict__ out_nbr,
+                                                               int32_t* __restrict__ out_cnt,
+                                                               uint32_t* __restrict__ child_ksums) {
+  // one thread per (bucket entry, j): consecutive threads copy consecutive ids of one answer
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t entry = t / f;
+  const int j = (int)(t - entry * f);
+  if (entry >= (int64_t)world * cap) return;
+  const uint32_t r = (uint32_t)(entry / cap);
+  const int64_t p = entry - (int64_t)r * cap;
+  int32_t c = counts[r];
+  if (c > cap) c = (int32_t)cap;
+  if (p >= c) return;
+  const int32_t i = slot_idx[entry];
+  const uint32_t v = resp[entry * f + j];
+  out_nbr[(int64_t)i * f + j] = v;
+  if (child_ksums) child_ksums[(int64_t)i * f + j] = v == GIGL_INVALID ? 0u : parent_ksums[i] + v;
+  if (j == 0) {
+    int n = 0;
+    for (int q = 0; q < f; ++q) n += resp[entry * f + q] != GIGL_INVALID ? 1 : 0;
+    out_cnt[i] = n;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t gigl_frontier_bucket(gigl_ctx* ctx, const uint32_t* nodes, const uint32_t* ksums, int64_t m, int32_t world,
+                             int64_t cap, uint32_t* req, int32_t* slot_idx, int32_t* counts) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, (nodes || m == 0) && req && slot_idx && counts, "null argument");
+  GIGL_REQUIRE(ctx, world >= 1 && m >= 0 && cap >= 1 && m < ((int64_t)1 << 31) && cap < ((int64_t)1 << 31),
+               "bad sizes");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GIGL_HIP_CHECK(ctx, hipMemsetAsync(req, 0xFF, (size_t)world * 2 * cap * 4, ctx->stream));
+  GIGL_HIP_CHECK(ctx, hipMemsetAsync(counts, 0, (size_t)(world + 1) * 4, ctx->stream));
+  if (m > 0)
+    hipLaunchKernelGGL(frontier_bucket_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, nodes,
+                       ksums, m, (uint32_t)world, cap, req, slot_idx, counts);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_frontier_scatter(gigl_ctx* ctx, const uint32_t* resp, const int32_t* slot_idx, const int32_t* counts,
+                              const uint32_t* parent_ksums, int64_t m, int32_t world, int64_t cap, int32_t f,
+                              uint32_t* out_nbr, int32_t* out_cnt, uint32_t* child_ksums) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, resp && slot_idx && counts && out_nbr && out_cnt, "null argument");
+  GIGL_REQUIRE(ctx, !child_ksums || parent_ksums, "child path sums need the parents' path sums");
+  GIGL_REQUIRE(ctx, world >= 1 && m >= 0 && cap >= 1 && f >= 1 && f <= GIGL_MAX_FANOUT, "bad sizes");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (m == 0) return GIGL_OK;
+  // slots that were not sent (empty parents) have no children
+  GIGL_HIP_CHECK(ctx, hipMemsetAsync(out_nbr, 0xFF, (size_t)m * f * 4, ctx->stream));
+  GIGL_HIP_CHECK(ctx, hipMemsetAsync(out_cnt, 0, (size_t)m * 4, ctx->stream));
+  if (child_ksums) GIGL_HIP_CHECK(ctx, hipMemsetAsync(child_ksums, 0, (size_t)m * f * 4, ctx->stream));
+  const int64_t threads = (int64_t)world * cap * f;
+  hipLaunchKernelGGL(frontier_scatter_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, resp,
+                     slot_idx, counts, parent_ksums, (uint32_t)world, cap, f, out_nbr, out_cnt, child_ksums);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+}  // extern "C"

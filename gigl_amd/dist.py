@@ -45,16 +45,23 @@ def partition_rows(x: np.ndarray, rank: int, world: int) -> np.ndarray:
     return np.ascontiguousarray(x[rank::world])
 
 
-def _all_to_all_v(payload: torch.Tensor, send_counts: torch.Tensor, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+def _all_to_all_v(payload: torch.Tensor, send_counts, group=None, recv_counts=None):
     """payload rows are grouped by destination rank (send_counts[r] rows each); returns (received rows,
-    recv_counts).  Rows may have trailing dims."""
-    world = dist.get_world_size(group)
-    recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)
-    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    recv_counts as a list).  Rows may have trailing dims.  send_counts: tensor or list; recv_counts: the list of
+    rows each rank will send us when the caller already knows it (the way back of a request/response pair: no
+    count exchange, no host synchronisation)."""
+    sc = send_counts.tolist() if isinstance(send_counts, torch.Tensor) else list(send_counts)
+    if recv_counts is None:
+        sct = (send_counts if isinstance(send_counts, torch.Tensor)
+               else torch.tensor(sc, dtype=torch.int64, device=payload.device))
+        rct = torch.empty_like(sct)
+        dist.all_to_all_single(rct, sct, group=group)
+        rc = rct.tolist()
+    else:
+        rc = list(recv_counts)
     out = payload.new_empty((int(sum(rc)),) + tuple(payload.shape[1:]))
     dist.all_to_all_single(out, payload.contiguous(), output_split_sizes=rc, input_split_sizes=sc, group=group)
-    return out, recv_counts
+    return out, rc
 
 
 class DistKHopSampler:
@@ -79,10 +86,11 @@ class DistKHopSampler:
         order = idx[torch.argsort(owner[idx], stable=True)]
         send_counts = torch.bincount(owner[idx], minlength=self.world).to(torch.int64)
         req = torch.stack([nodes[order], ksums[order]], dim=1)
-        got, recv_counts = _all_to_all_v(req, send_counts, self.group)
+        sc = send_counts.tolist()
+        got, recv_counts = _all_to_all_v(req, sc, self.group)
         nbr_loc, cnt_loc = self.expand(got[:, 0].contiguous(), got[:, 1].contiguous(), f, hash_add)
         resp = torch.cat([nbr_loc.view(-1, f).to(torch.int64), cnt_loc.view(-1, 1).to(torch.int64)], dim=1)
-        back, _ = _all_to_all_v(resp, recv_counts, self.group)
+        back, _ = _all_to_all_v(resp, recv_counts, self.group, recv_counts=sc)  # one answer per request
         nbr = torch.full((m, f), INVALID, dtype=torch.int64, device=nodes.device)
         cnt = torch.zeros(m, dtype=torch.int64, device=nodes.device)
         nbr[order] = back[:, :f]
@@ -107,6 +115,134 @@ class DistKHopSampler:
         return out_nbr, out_cnt
 
 
+class HipDistKHopSampler:
+    """k-hop sampling over the hash-partitioned graph with the whole exchange on the device: per hop the frontier is
+    bucketed by owner into fixed-capacity buffers (gigl_frontier_bucket), ONE equal-split all_to_all carries the
+    requests, the owners answer with gigl_expand_frontier, one all_to_all carries the answers, and
+    gigl_frontier_scatter writes the tree layout — no sort, no split sizes, no host synchronisation anywhere in a
+    hop (DistKHopSampler above is the backend-agnostic torch version the CPU tests drive).
+    Buckets hold `cap` requests per peer (cap = m for world <= 2, else 1.5 m / world + 512: owner(v) = v % world
+    is a uniform hash); `overflow` (device int32) becomes non-zero if a bucket overflowed: check it when the step
+    is synchronised anyway and redo the batch with slack=world."""
+
+    def __init__(self, eng, world: int, max_window_end: int = -1, sampling_seed: int = 42, group=None,
+                 slack: float = 1.5):
+        self.eng, self.world, self.mwe, self.seed, self.group, self.slack = eng, world, max_window_end, sampling_seed, group, slack
+        self._bufs = {}
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=eng.device)
+
+    def capacity(self, m: int) -> int:
+        if self.world <= 2 or self.slack >= self.world:
+            return max(m, 1)
+        return max(1, min(m, int(self.slack * m / self.world) + 512))
+
+    def _hop_buffers(self, k: int, m: int, f: int):
+        key = (k, m, f)
+        b = self._bufs.get(key)
+        if b is None:
+            dev, w, cap = self.eng.device, self.world, self.capacity(m)
+            i32 = dict(dtype=torch.int32, device=dev)
+            b = dict(cap=cap, req=torch.empty((w, 2, cap), **i32), got=torch.empty((w, 2, cap), **i32),
+                     slot_idx=torch.empty((w, cap), **i32), counts=torch.zeros(w + 1, **i32),
+                     back=torch.empty((w, cap, f), **i32), child_ksums=torch.empty(m * f, **i32))
+            self._bufs[key] = b
+        return b
+
+    # the three phases of a hop (split so that a test can play all ranks of a world inside one process)
+    def bucket(self, k: int, nodes: torch.Tensor, ksums: Optional[torch.Tensor], f: int) -> torch.Tensor:
+        b = self._hop_buffers(k, int(nodes.numel()), f)
+        self.eng.frontier_bucket(nodes, ksums, self.world, b["cap"], b["req"], b["slot_idx"], b["counts"])
+        torch.maximum(self.overflow, b["counts"][self.world:], out=self.overflow)
+        return b["req"]
+
+    def serve(self, got: torch.Tensor, k: int, f: int) -> torch.Tensor:
+        """owner side: requests received from every peer [world, 2, cap] -> answers [world, cap, f]"""
+        cap = int(got.shape[2])
+        nodes = got[:, 0, :].reshape(-1).contiguous()
+        ksums = got[:, 1, :].reshape(-1).contiguous()
+        hash_add = (self.seed * (k + 1)) & 0xFFFFFFFF
+        nbr, _ = self.eng.expand_frontier(nodes, ksums, f, hash_add, self.world, self.mwe)
+        return nbr.view(self.world, cap, f)
+
+    def scatter(self, k: int, back: torch.Tensor, parent_ksums: torch.Tensor, m: int, f: int, out_nbr: torch.Tensor,
+                out_cnt: torch.Tensor) -> torch.Tensor:
+        b = self._hop_buffers(k, m, f)
+        self.eng.frontier_scatter(back.contiguous(), b["slot_idx"], b["counts"], parent_ksums, m, self.world, b["cap"],
+                                  f, out_nbr, out_cnt, b["child_ksums"])
+        return b["child_ksums"]
+
+    def sample_khop(self, roots: torch.Tensor, fanouts: Sequence[int], tree=None):
+        """roots: int32 device tensor (uint32 ids).  Fills `tree` (HipEngine.alloc_tree) or fresh tensors; returns
+        (nbr list, cnt list) of int32 device tensors in the tree layout of include/gigl_hip.h."""
+        dev = self.eng.device
+        nodes, ksums, parent_k = roots.contiguous(), None, roots.contiguous()
+        m = int(roots.numel())
+        out_nbr, out_cnt = [], []
+        for k, f in enumerate(int(v) for v in fanouts):
+            b = self._hop_buffers(k, m, f)
+            req = self.bucket(k, nodes, ksums, f)
+            dist.all_to_all_single(b["got"], req, group=self.group)
+            resp = self.serve(b["got"], k, f)
+            dist.all_to_all_single(b["back"], resp.contiguous(), group=self.group)
+            nbr = tree.nbr[k] if tree is not None else torch.empty(m * f, dtype=torch.int32, device=dev)
+            cnt = tree.cnt[k] if tree is not None else torch.empty(m, dtype=torch.int32, device=dev)
+            child_k = self.scatter(k, b["back"], parent_k, m, f, nbr, cnt)
+            out_nbr.append(nbr)
+            out_cnt.append(cnt)
+            nodes, ksums, parent_k, m = nbr, child_k, child_k, m * f
+        return out_nbr, out_cnt
+
+
+class HipFeaturePuller:
+    """feature pull of a batch's UNIQUE node ids from their owners, bucketed on the device (gigl_frontier_bucket):
+    ids go out in one equal-split all_to_all of fixed-capacity buckets, the per-peer counts in a second tiny one, and
+    ONE host read of those counts (the only synchronisation of a sharded step) gives the split sizes of the row
+    exchange — rows are never padded.  Phases are separate methods so that a test can play every rank of a world."""
+
+    def __init__(self, eng, world: int, local_rows: torch.Tensor, cap_ids: int, group=None, slack: float = 1.5):
+        self.eng, self.world, self.x_local, self.group = eng, world, local_rows, group
+        m = int(cap_ids)
+        self.m = m
+        self.cap = max(m, 1) if (world <= 2 or slack >= world) else max(1, min(m, int(slack * m / world) + 512))
+        i32 = dict(dtype=torch.int32, device=eng.device)
+        self.req = torch.empty((world, 2, self.cap), **i32)
+        self.got = torch.empty((world, 2, self.cap), **i32)
+        self.slot_idx = torch.empty((world, self.cap), **i32)
+        self.counts = torch.zeros(world + 1, **i32)
+        self.recv_counts = torch.zeros(world + 1, **i32)
+        self._arange = torch.arange(m, **i32)
+
+    def request(self, ids: torch.Tensor, n_valid_dev: torch.Tensor) -> torch.Tensor:
+        """ids: int32 [cap_ids] device (uint32 payload), the first *n_valid_dev are real -> request buckets"""
+        masked = torch.where(self._arange < n_valid_dev, ids[: self.m], torch.full_like(self._arange, -1))
+        self.eng.frontier_bucket(masked, None, self.world, self.cap, self.req, self.slot_idx, self.counts)
+        return self.req
+
+    def serve(self, got: torch.Tensor, recv_counts: Sequence[int]) -> torch.Tensor:
+        """owner side: the feature rows of the ids received from every peer, in request order"""
+        ids = torch.cat([got[r, 0, : int(recv_counts[r])] for r in range(self.world)]).to(torch.int64) & 0xFFFFFFFF
+        return self.x_local.index_select(0, ids // self.world)
+
+    def place(self, back: torch.Tensor, send_counts: Sequence[int], n_rows: int) -> torch.Tensor:
+        """rows received for our requests (bucket order) -> x[local id] for the batch's n_rows union-graph nodes"""
+        slots = torch.cat([self.slot_idx[r, : int(send_counts[r])] for r in range(self.world)]).to(torch.int64)
+        x = torch.empty((n_rows, back.shape[1]), dtype=back.dtype, device=back.device)
+        x.index_copy_(0, slots, back)
+        return x
+
+    def pull(self, ids: torch.Tensor, n_valid_dev: torch.Tensor) -> torch.Tensor:
+        req = self.request(ids, n_valid_dev)
+        dist.all_to_all_single(self.got, req, group=self.group)
+        dist.all_to_all_single(self.recv_counts[: self.world], self.counts[: self.world], group=self.group)
+        host = torch.cat([self.counts, self.recv_counts[: self.world], n_valid_dev.view(1).to(torch.int32)]).tolist()
+        sc, overflow, rc, n_rows = host[: self.world], host[self.world], host[self.world + 1: 2 * self.world + 1], host[-1]
+        if overflow:
+            raise RuntimeError("feature-pull bucket overflow: raise slack (owner(v) = v % world is badly skewed here)")
+        rows = self.serve(self.got, rc)
+        back, _ = _all_to_all_v(rows, rc, self.group, recv_counts=sc)
+        return self.place(back, sc, n_rows)
+
+
 def hip_expand(eng, world: int, max_window_end: int = -1) -> Callable:
     """owner-side expansion on the GPU: adapter from DistKHopSampler's int64 tensors to
     HipEngine.expand_frontier (gigl_expand_frontier on this rank's shard)"""
@@ -123,9 +259,10 @@ def pull_features(ids: torch.Tensor, local_rows: torch.Tensor, world: int, group
     owner = ids % world
     order = torch.argsort(owner, stable=True)
     send_counts = torch.bincount(owner, minlength=world).to(torch.int64)
-    got, recv_counts = _all_to_all_v(ids[order].view(-1, 1), send_counts, group)
+    sc = send_counts.tolist()
+    got, recv_counts = _all_to_all_v(ids[order].view(-1, 1), sc, group)
     rows = local_rows[(got.view(-1) // world)]
-    back, _ = _all_to_all_v(rows, recv_counts, group)
+    back, _ = _all_to_all_v(rows, recv_counts, group, recv_counts=sc)  # one row per requested id
     out = torch.empty_like(back)
     out[order] = back
     return out

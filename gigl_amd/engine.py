@@ -276,6 +276,27 @@ class HipEngine:
                                              C.c_void_p(nbr.data_ptr()), C.c_void_p(cnt.data_ptr())), self._ctx)
         return nbr[: m * f], cnt[:m]
 
+    def frontier_bucket(self, nodes: torch.Tensor, ksums: Optional[torch.Tensor], world: int, cap: int,
+                        req: torch.Tensor, slot_idx: torch.Tensor, counts: torch.Tensor) -> None:
+        """bucket frontier slots by owner (gigl_frontier_bucket): req int32 [world, 2, cap], slot_idx int32
+        [world, cap], counts int32 [world + 1] (last = overflow flag); all device tensors, no host sync"""
+        m = int(nodes.numel())
+        check(self._lib.gigl_frontier_bucket(self._ctx, C.c_void_p(nodes.data_ptr()),
+                                             C.c_void_p(ksums.data_ptr()) if ksums is not None else None, m, world, cap,
+                                             C.c_void_p(req.data_ptr()), C.c_void_p(slot_idx.data_ptr()),
+                                             C.c_void_p(counts.data_ptr())), self._ctx)
+
+    def frontier_scatter(self, resp: torch.Tensor, slot_idx: torch.Tensor, counts: torch.Tensor,
+                         parent_ksums: torch.Tensor, m: int, world: int, cap: int, f: int, out_nbr: torch.Tensor,
+                         out_cnt: torch.Tensor, child_ksums: Optional[torch.Tensor]) -> None:
+        """owners' answers [world, cap, f] -> tree slots (gigl_frontier_scatter)"""
+        check(self._lib.gigl_frontier_scatter(self._ctx, C.c_void_p(resp.data_ptr()), C.c_void_p(slot_idx.data_ptr()),
+                                              C.c_void_p(counts.data_ptr()), C.c_void_p(parent_ksums.data_ptr()), m,
+                                              world, cap, f, C.c_void_p(out_nbr.data_ptr()),
+                                              C.c_void_p(out_cnt.data_ptr()),
+                                              C.c_void_p(child_ksums.data_ptr()) if child_ksums is not None else None),
+              self._ctx)
+
     def sample_positives(self, roots, num_positives: int, sampling_seed: int = 42):
         assert self._graph_out is not None, "load the out-edge graph first (out_graph=True)"
         r = self._roots_tensor(roots)

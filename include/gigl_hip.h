@@ -214,6 +214,25 @@ int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* n
                              int64_t m, int32_t f, int32_t hash_add, int32_t world, int64_t max_window_end,
                              uint32_t* out_nbr, int32_t* out_cnt);
 
+/* the requester side of a hop on a hash-partitioned graph (see gigl_expand_frontier for the owner side): bucket the
+ * frontier by owner for ONE equal-split all_to_all, and scatter the owners' answers back into the tree layout.
+ * Replaces the per-batch RPC fan-out of the reference's distributed loader
+ * (python/gigl/distributed/distributed_neighborloader.py:26-192; owner(v) = v % world,
+ * dist_link_prediction_data_partitioner.py:692-695).  All pointers DEVICE; nothing synchronises with the host.
+ *   bucket:  slot i (nodes[i], ksums[i] or nodes[i] itself when ksums == NULL) goes to bucket r = nodes[i] % world at
+ *            the next free position p (GIGL_INVALID slots are not sent):
+ *              req[(2r) * cap + p] = node, req[(2r+1) * cap + p] = K  (req is [world][2][cap], unused entries
+ *              GIGL_INVALID), slot_idx[r * cap + p] = i, counts[r] = requests for peer r,
+ *              counts[world] != 0 iff some bucket overflowed `cap` (the batch must be redone with a larger cap)
+ *   scatter: resp is [world][cap][f] (the owners' out_nbr for the requests in bucket order): answer p of bucket r
+ *            becomes out_nbr[i*f .. i*f+f), out_cnt[i] = its valid ids, child_ksums[i*f + j] = parent_ksums[i] + id
+ *            (uint32 wrap; optional) for i = slot_idx[r*cap+p]; slots that were not sent get GIGL_INVALID / 0. */
+int32_t gigl_frontier_bucket(gigl_ctx* ctx, const uint32_t* nodes, const uint32_t* ksums, int64_t m, int32_t world,
+                             int64_t cap, uint32_t* req, int32_t* slot_idx, int32_t* counts);
+int32_t gigl_frontier_scatter(gigl_ctx* ctx, const uint32_t* resp, const int32_t* slot_idx, const int32_t* counts,
+                              const uint32_t* parent_ksums, int64_t m, int32_t world, int64_t cap, int32_t f,
+                              uint32_t* out_nbr, int32_t* out_cnt, uint32_t* child_ksums);
+
 /* positives for node-anchor link prediction: `f` OUT-neighbours of each root, counter = 3
  * (sampleDstNodesUniformly, NodeAnchorBasedLinkPredictionBaseTask.scala:19-104).  `g_out` is the
  * CSR-by-source graph loaded through gigl_graph_load_csc with the roles of src/dst swapped. */

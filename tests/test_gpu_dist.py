@@ -79,3 +79,122 @@ def test_dist_sampler_with_hip_expander_single_rank(graph):
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_device_side_frontier_exchange_all_ranks_in_one_process(graph, world):
+    """HipDistKHopSampler played for every rank of a `world`-rank job inside one process: the all_to_all is done by
+    hand (transpose of the per-rank buffers).  Every rank's tree must be bit-identical to sampling the whole graph in
+    one process (gigl_sample_khop) and to the oracle."""
+    from gigl_amd.dist import HipDistKHopSampler, partition_csc
+    from gigl_amd.engine import HipEngine
+    n, rowptr, col = graph
+    fan = [25, 10]
+    bound = int(3 * n + 42 * 2 + np.diff(rowptr).max())
+    engs, samplers = [], []
+    for r in range(world):
+        e = HipEngine(0)
+        e.load_csc(*partition_csc(rowptr, col, r, world))
+        engs.append(e)
+        samplers.append(HipDistKHopSampler(e, world, max_window_end=bound, slack=1.5))
+    dev = engs[0].device
+    rng = np.random.default_rng(world)
+    roots = [rng.integers(0, n, size=300).astype(np.uint32) for _ in range(world)]
+    for r in range(world):
+        roots[r][::37] = 0xFFFFFFFF  # empty root slots are legal
+    nodes = [torch.from_numpy(x.view(np.int32)).to(dev) for x in roots]
+    ksums = [None] * world
+    parent_k = list(nodes)
+    m = 300
+    trees = [([], []) for _ in range(world)]
+    for k, f in enumerate(fan):
+        reqs = [samplers[r].bucket(k, nodes[r], ksums[r], f) for r in range(world)]
+        # all_to_all: rank r receives block [r] of every sender s, in sender order
+        gots = [torch.stack([reqs[s][r] for s in range(world)]) for r in range(world)]
+        resps = [samplers[r].serve(gots[r], k, f) for r in range(world)]
+        backs = [torch.stack([resps[s][r] for s in range(world)]) for r in range(world)]
+        for r in range(world):
+            nbr = torch.empty(m * f, dtype=torch.int32, device=dev)
+            cnt = torch.empty(m, dtype=torch.int32, device=dev)
+            child = samplers[r].scatter(k, backs[r], parent_k[r], m, f, nbr, cnt)
+            trees[r][0].append(nbr)
+            trees[r][1].append(cnt)
+            nodes[r], ksums[r], parent_k[r] = nbr, child, child
+        m *= f
+    whole = HipEngine(0)
+    whole.load_csc(rowptr, col)
+    for r in range(world):
+        assert int(samplers[r].overflow.item()) == 0
+        ref = whole.sample_khop(roots[r], fan)
+        nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots[r], fan, canonical=True)
+        for k in range(2):
+            assert torch.equal(trees[r][0][k], ref.nbr[k]) and torch.equal(trees[r][1][k], ref.cnt[k])
+            assert np.array_equal(trees[r][0][k].cpu().numpy().view(np.uint32), nbr_o[k])
+    # a bucket that is too small is reported, never silently truncated
+    tiny = HipDistKHopSampler(engs[0], world, max_window_end=bound, slack=0.01)
+    if world > 2:
+        tiny.bucket(0, torch.arange(0, 4000 * world, world, dtype=torch.int32, device=dev), None, 25)  # one owner
+        assert int(tiny.overflow.item()) != 0
+    for e in engs + [whole]:
+        e.close()
+
+
+def test_device_side_exchange_over_rccl_single_rank(graph):
+    from gigl_amd.dist import HipDistKHopSampler
+    from gigl_amd.engine import HipEngine
+    n, rowptr, col = graph
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29750 + os.getpid() % 200))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        eng = HipEngine(0)
+        eng.load_csc(rowptr, col)
+        s = HipDistKHopSampler(eng, 1)
+        roots = np.random.default_rng(5).integers(0, n, size=257).astype(np.uint32)
+        tree = eng.alloc_tree(257, [25, 10])
+        nbr, cnt = s.sample_khop(torch.from_numpy(roots.view(np.int32)).to(eng.device), [25, 10], tree=tree)
+        nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots, [25, 10], canonical=True)
+        for k in range(2):
+            assert np.array_equal(nbr[k].cpu().numpy().view(np.uint32), nbr_o[k])
+            assert np.array_equal(cnt[k].cpu().numpy(), cnt_o[k])
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_bucketed_feature_pull_all_ranks_in_one_process(world):
+    """HipFeaturePuller for every rank of a world inside one process (all_to_all by hand): x == table[ids]"""
+    from gigl_amd.dist import HipFeaturePuller
+    from gigl_amd.engine import HipEngine
+    eng = HipEngine(0)
+    dev = eng.device
+    rng = np.random.default_rng(7)
+    n, d, cap = 5000, 24, 900
+    table = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(dev).to(torch.float16)
+    shards = [table[r::world].contiguous() for r in range(world)]
+    pullers = [HipFeaturePuller(eng, world, shards[r], cap) for r in range(world)]
+    ids, n_valid = [], []
+    for r in range(world):
+        k = int(rng.integers(100, cap))
+        v = rng.choice(n, size=k, replace=False).astype(np.uint32)
+        buf = np.full(cap, 0xDEADBEEF, dtype=np.uint32)  # garbage past n_valid must be ignored
+        buf[:k] = v
+        ids.append(torch.from_numpy(buf.view(np.int32)).to(dev))
+        n_valid.append(torch.tensor(k, dtype=torch.int32, device=dev))
+    reqs = [pullers[r].request(ids[r], n_valid[r]).clone() for r in range(world)]
+    sc = [pullers[r].counts[:world].tolist() for r in range(world)]
+    gots = [torch.stack([reqs[s][r] for s in range(world)]) for r in range(world)]
+    rc = [[sc[s][r] for s in range(world)] for r in range(world)]
+    rows = [pullers[r].serve(gots[r], rc[r]) for r in range(world)]
+    for r in range(world):
+        # what rank r gets back: from each owner s, the block of rows answering r's requests
+        parts = []
+        for s in range(world):
+            off = sum(rc[s][:r])
+            parts.append(rows[s][off: off + rc[s][r]])
+        x = pullers[r].place(torch.cat(parts), sc[r], int(n_valid[r].item()))
+        want = table[(ids[r][: int(n_valid[r].item())].to(torch.int64) & 0xFFFFFFFF)]
+        assert torch.equal(x, want)
+    eng.close()
