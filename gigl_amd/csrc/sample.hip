@@ -609,7 +609,7 @@ struct Sel {
   }
 };
 
-__global__ __launch_bounds__(256) void expand_kernel(ExpandArgs a, RangeTable tb) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void expand_kernel(ExpandArgs a, RangeTable tb) {
   __shared__ uint32_t s_lk[4][64], s_li[4][64];  // per-wave survivor scratch of the filter selections
   const int lane = threadIdx.x & 63;
   // the parent slot, its row and every window bound are the same for all lanes: say so (readfirstlane), and the
