@@ -68,13 +68,16 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
                                                           const int32_t* __restrict__ rowend,
                                                           const int32_t* __restrict__ col,
                                                           const int32_t* __restrict__ n_rows_dev,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out,
+                                                          const int32_t* __restrict__ n_local_dev) {
   constexpr int G = 64 / LPR;  // source rows per wave-instruction
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR;  // which source row of the instruction
   const int sl = lane % LPR;   // lane within the row
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_rows = *n_rows_dev;
+  // rows >= n_local hold GLOBAL source ids already (leaf-global union): no gather_ids translation for them
+  const int n_local = n_local_dev ? *n_local_dev : 0x7FFFFFFF;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
   constexpr float IDV = OP == GIGL_AGGR_MAX ? -__builtin_inff() : 0.f;  // identity of the reduction
   const float4_t zero4 = {IDV, IDV, IDV, IDV};
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
       int my = 0;
       if (lane < mm) {
         my = col[e0 + c0 + lane];
-        if (gather_ids) my = (int)gather_ids[my];
+        if (gather_ids && i < n_local) my = (int)gather_ids[my];
       }
       for (int e = 0; e < mm; e += 4 * G) {  // wave-uniform trip count (shuffles need every lane)
         const int ea = e + sub, eb = ea + G, ec = ea + 2 * G, ed = ea + 3 * G;
@@ -192,10 +195,12 @@ __global__ __launch_bounds__(256) void gather_mean_generic_kernel(const T* __res
                                                                   const int32_t* __restrict__ rowend,
                                                                   const int32_t* __restrict__ col,
                                                                   const int32_t* __restrict__ n_rows_dev,
-                                                                  float* __restrict__ out, int op) {
+                                                                  float* __restrict__ out, int op,
+                                                                  const int32_t* __restrict__ n_local_dev) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int n_rows = *n_rows_dev;
+  const int n_local = n_local_dev ? *n_local_dev : 0x7FFFFFFF;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
   for (int i = wave; i < n_rows; i += waves_total) {
     const int e0 = rowptr[i], e1 = rowend[i];
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256) void gather_mean_generic_kernel(const T* __res
       float acc = op == GIGL_AGGR_MAX ? -__builtin_inff() : 0.f;
       for (int e = e0; e < e1; ++e) {
         int j = col[e];
-        if (gather_ids) j = (int)gather_ids[j];
+        if (gather_ids && i < n_local) j = (int)gather_ids[j];
         const float v = (float)src[(int64_t)j * d + el];
         acc = op == GIGL_AGGR_MAX ? fmaxf(acc, v) : acc + v;
       }
@@ -572,7 +577,8 @@ __global__ __launch_bounds__(256) void gat_gather_kernel(const float* __restrict
 template <typename T>
 int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather_ids,
                       const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
-                      const int32_t* n_rows_dev, int64_t rows_cap, float* out, int op = GIGL_AGGR_MEAN) {
+                      const int32_t* n_rows_dev, int64_t rows_cap, float* out, int op = GIGL_AGGR_MEAN,
+                      const int32_t* n_local_dev = nullptr) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
@@ -581,7 +587,7 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
   const int vecs = d / 4;
 #define GLO(LPR, VPL, OP)                                                                            \
   hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, 0, st, src, d, gather_ids, rowptr, \
-                     rowend, col, n_rows_dev, out)
+                     rowend, col, n_rows_dev, out, n_local_dev)
 #define GL(LPR, VPL)                                        \
   do {                                                      \
     if (op == GIGL_AGGR_MEAN) GLO(LPR, VPL, GIGL_AGGR_MEAN); \
@@ -590,7 +596,7 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
   } while (0)
   if ((d & 3) != 0 || vecs > 512) {
     hipLaunchKernelGGL((gather_mean_generic_kernel<T>), g, b, 0, st, src, d, gather_ids, rowptr, rowend,
-                       col, n_rows_dev, out, op);
+                       col, n_rows_dev, out, op, n_local_dev);
   } else if (vecs <= 8) GL(8, 1);
   else if (vecs <= 16) GL(16, 1);
   else if (vecs <= 32) GL(32, 1);
@@ -644,6 +650,24 @@ int32_t gigl_gather_reduce(gigl_ctx* ctx, const void* src, int32_t src_dtype, in
                                  out, aggr);
   return gigl_fail(ctx, GIGL_E_INVALID_ARG, "bad dtype %d", src_dtype);
 }
+
+}  // extern "C"
+
+int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* gather_ids,
+                                 const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                 const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
+                                 const int32_t* n_local_rows_dev, float* out) {
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  if (src_dtype == GIGL_DTYPE_F32)
+    return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
+                                aggr, n_local_rows_dev);
+  return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
+                               aggr, n_local_rows_dev);
+}
+
+extern "C" {
 
 int32_t gigl_gather_rows(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* ids,
                          const int32_t* n_dev, int64_t cap, float* out) {

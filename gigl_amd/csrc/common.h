@@ -88,4 +88,14 @@ void* gigl_arena_alloc(gigl_ctx* ctx, int64_t bytes);
 // fills g->maxdeg from the resident rowptr (synchronises the ctx stream)
 int32_t gigl_graph_compute_maxdeg(gigl_ctx* ctx, gigl_graph* g);
 
+// union build with the plan-internal leaf-global option (union.hip)
+int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree, int32_t group_roots,
+                              gigl_union* out, int32_t leaf_global);
+// gather + reduce where the rows i >= *n_local_rows_dev hold GLOBAL source ids (no gather_ids translation): the
+// plan's layer-0 gather over a leaf-global union (agg.hip); n_local_rows_dev == NULL: every row is translated
+int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* gather_ids,
+                                 const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                 const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
+                                 const int32_t* n_local_rows_dev, float* out);
+
 static inline int64_t gigl_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }

@@ -37,6 +37,11 @@ struct gigl_sage_plan {
   const float* w[GIGL_MAX_HOPS] = {nullptr};     // fused [dims[l+1]][2*dims[l]] (= [W_l | W_r]), device, borrowed
   const float* bias[GIGL_MAX_HOPS] = {nullptr};  // device, borrowed, may be null
   int32_t act_last = 0;
+  // leaf-global union (union.hip): pure leaves get no local id and stay global ids in their parents' rows — the
+  // plan never computes anything for them, it only gathers their feature rows
+  bool leaf_global = false;
+  int64_t act_rows = 0;         // rows of abuf / hbuf
+  int32_t* zero_dev = nullptr;  // a device int32 0 (hops == 1: no row of the layer-0 gather holds local ids)
   gigl_tree tree{};
   gigl_union un{};
   float* abuf = nullptr;  // [act_rows][2*max_in], act_rows = b*(1 + f0 + f0*f1 + ...) over hops-1 terms
@@ -63,6 +68,21 @@ __global__ void take_rows_kernel(const float* __restrict__ h, const int32_t* __r
   out[i] = l >= 0 ? h[(int64_t)l * d + c] : 0.f;
 }
 
+// The activation buffers hold b*(1 + f0 + ...) rows — the number of nodes of level < hops when no root is another
+// root's sampled neighbour.  Roots that ARE neighbours of each other add the children of those occurrences to the
+// inner levels (up to the whole tree in a clique of roots): such a batch does not fit the workspace; its level
+// counts are zeroed so that no later kernel touches the buffers, and it is reported through
+// meta[GIGL_META_OVERFLOW] (the batch's rows are then invalid, like an LDS-sort overflow).
+__global__ void guard_levels_kernel(int32_t* meta, int hops, int32_t act_rows) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  bool over = false;
+  for (int l = 0; l < hops; ++l) over = over || meta[GIGL_META_LEVEL0 + l] > act_rows;
+  if (over) {  // nothing is computed for this batch (rows would index past the workspace)
+    for (int l = 0; l < hops; ++l) meta[GIGL_META_LEVEL0 + l] = 0;
+    atomicAdd(&meta[GIGL_META_OVERFLOW], 1);
+  }
+}
+
 // stages of one batch: 0 sample, 1 union, 2+2l gather l, 3+2l linear l, 2+2L take_rows
 int n_stages(const gigl_sage_plan* p) { return 3 + 2 * p->hops; }
 
@@ -81,7 +101,14 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
   const int L = p->hops;
   if (s == 0)
     return gigl_sample_khop(ctx, p->graph, roots, p->b, p->fanouts, p->hops, sampling_seed, mode, &p->tree);
-  if (s == 1) return gigl_union_build_groups(ctx, roots, &p->tree, p->group_roots, &p->un);
+  if (s == 1) {
+    int32_t rc = gigl_union_build_impl(ctx, roots, &p->tree, p->group_roots, &p->un, p->leaf_global ? 1 : 0);
+    if (rc != GIGL_OK) return rc;
+    hipLaunchKernelGGL(guard_levels_kernel, dim3(1), dim3(64), 0, ctx->stream, p->un.meta, p->hops,
+                       (int32_t)(p->act_rows < 0x7FFFFFFF ? p->act_rows : 0x7FFFFFFF));
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    return GIGL_OK;
+  }
   if (s == n_stages(p) - 1) {
     const int dout = p->dims[L];
     const int64_t total = (int64_t)p->b * dout;
@@ -101,6 +128,10 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
     width *= p->fanouts[i];
   }
   if (((s - 2) & 1) == 0) {
+    if (l == 0 && p->leaf_global)  // rows of level L-1 (>= the count through level L-2) hold global source ids
+      return gigl_gather_reduce_mixed(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend,
+                                      p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN,
+                                      L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev, p->abuf);
     if (l == 0)
       return gigl_gather_mean(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend,
                               p->un.col, n_rows, rows_cap, p->abuf);
@@ -257,7 +288,11 @@ int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat,
   p->hbuf[1] = hops > 1 ? (float*)alloc((size_t)act_rows * max_out * 4) : p->hbuf[0];
   p->roots_buf = (uint32_t*)alloc((size_t)b * 4);
   p->out_buf = (float*)alloc((size_t)b * dims[hops] * 4);
-  ok = ok && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col && p->un.root_local &&
+  p->zero_dev = (int32_t*)alloc(16);
+  if (p->zero_dev && hipMemset(p->zero_dev, 0, 16) != hipSuccess) ok = false;
+  p->act_rows = act_rows;
+  p->leaf_global = hops <= 2 && graph->n < ((int64_t)1 << 31);
+  ok = ok && p->zero_dev && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col && p->un.root_local &&
        p->abuf && p->hbuf[0] && p->hbuf[1] && p->roots_buf && p->out_buf;
   if (!ok) {
     gigl_sage_plan_destroy(p);

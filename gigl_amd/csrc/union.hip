@@ -60,7 +60,12 @@ struct UnionArgs {
   int32_t grouped;
   uint32_t group_roots;
   uint32_t gdiv[GIGL_MAX_HOPS];  // stream slots of ONE batch at hop k
+  // leaf-global mode (hops <= 2, the one-call plan): a last-hop slot whose parent is not a root is a pure LEAF — it
+  // is never computed, only read as a feature row — so it gets no table slot and no local id (slot_of = LEAF) and
+  // stays a GLOBAL id in its parent's row: rows of level hops-1 hold global ids, rows of lower levels local ids
+  int32_t leaf_global;
 };
+constexpr int32_t LEAF = -2;  // slot_of value of a leaf occurrence in leaf-global mode
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
   x ^= x >> 16;
@@ -191,7 +196,6 @@ __global__ void insert_slots_kernel(UnionArgs a, int64_t lo, int64_t hi) {
     a.slot_of[t] = -1;
     return;
   }
-  uint32_t s = table_insert(a, group_base(a, k, j), id, (uint32_t)t);
   int32_t lvl;
   if (k == 0) {
     lvl = 1;
@@ -202,6 +206,11 @@ __global__ void insert_slots_kernel(UnionArgs a, int64_t lo, int64_t hi) {
   } else {
     lvl = k + 1;  // upper bound; relaxed below
   }
+  if (a.leaf_global && lvl == a.hops) {  // (hops <= 2: lvl is exact here) nothing will ever be computed for it
+    a.slot_of[t] = LEAF;
+    return;
+  }
+  uint32_t s = table_insert(a, group_base(a, k, j), id, (uint32_t)t);
   if (lvl < a.hops &&  // (same look-before-atomic: levels only go down, a stale read only costs a redundant atomic)
       *(const volatile int32_t*)&a.slots[s].level > lvl)
     atomicMin(&a.slots[s].level, lvl);
@@ -360,12 +369,12 @@ __global__ void edge_dedup_count_kernel(UnionArgs a, unsigned long long* ekeys, 
   if (in && t < a.b) root_local[t] = s >= 0 ? a.slots[s].lid : -1;
   bool win = false;
   int32_t dl = 0, sl = 0;
-  if (in && t >= a.b && s >= 0) {
+  if (in && t >= a.b && (s >= 0 || s == LEAF)) {
     int k;
     int64_t j;
     locate(a, t, k, j);
     dl = a.slots[a.slot_of[parent_pos(a, k, j)]].lid;
-    sl = a.slots[s].lid;
+    sl = s >= 0 ? a.slots[s].lid : (int32_t)pick(a.nbr, k)[j];  // a leaf keeps its global id
     const unsigned long long key = ((unsigned long long)(uint32_t)dl << 32) | (uint32_t)sl;
     unsigned long long* sub = ekeys;
     if (a.grouped) sub += (uint64_t)((uint32_t)j / pick(a.gdiv, k)) * (emask + 1u);
@@ -696,8 +705,20 @@ int32_t gigl_union_build(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* 
 
 int32_t gigl_union_build_groups(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree,
                                 int32_t group_roots, gigl_union* out) {
+  return gigl_union_build_impl(ctx, roots, tree, group_roots, out, 0);
+}
+
+}  // extern "C"
+
+// leaf_global != 0 (internal, the one-call plan): see UnionArgs::leaf_global.  Only for hops <= 2 and node ids
+// < 2^31 (row values are compared as int32).  Differences of the output: nodes / meta count the nodes of level <
+// hops only (meta[LEVEL0 + hops] == meta[LEVEL0 + hops - 1] == n_nodes), and the rows of level hops-1 hold global
+// ids; everything else (rows of lower levels, root_local, n_edges, row order) is as documented in gigl_hip.h.
+int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree, int32_t group_roots,
+                              gigl_union* out, int32_t leaf_global) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   GIGL_REQUIRE(ctx, tree && out && (roots || tree->b == 0), "null argument");
+  GIGL_REQUIRE(ctx, !leaf_global || tree->hops <= 2, "leaf-global union needs hops <= 2");
   GIGL_REQUIRE(ctx, out->meta && out->nodes && out->rowptr && out->rowend && out->col && out->root_local,
                "union output buffers are null");
   const int hops = tree->hops, b = tree->b;
@@ -720,6 +741,7 @@ int32_t gigl_union_build_groups(gigl_ctx* ctx, const uint32_t* roots, const gigl
   a.roots = roots;
   a.b = b;
   a.hops = hops;
+  a.leaf_global = leaf_global ? 1 : 0;
   int64_t T = b, parents = b;
   for (int k = 0; k < hops; ++k) {
     a.nbr[k] = tree->nbr[k];
@@ -835,5 +857,3 @@ int32_t gigl_union_build_groups(gigl_ctx* ctx, const uint32_t* roots, const gigl
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
-
-}  // extern "C"
