@@ -39,8 +39,12 @@ constexpr int BIG_ROW_CAP = 16384;  // LDS bitonic capacity (64 KiB of int32)
 struct __attribute__((aligned(16))) Slot {
   unsigned long long kf;  // (node id << 32) | smallest stream position holding the node; ~0 = empty
   int32_t level;          // BFS level in the batch's union graph (starts at hops)
-  int32_t lid;            // local id (assign)
+  int32_t lid;            // local id (assign) | LID_MULTI
 };
+// set in Slot::lid when the node occurs at more than one stream position: only then can a row of it (or an edge out
+// of it) repeat, so only then does edge dedup need the hash set — a node that occurs once has f DISTINCT sampled
+// in-edges by construction (local ids are < 2^30: T < 2^31 positions)
+constexpr int32_t LID_MULTI = 1 << 30;
 __device__ __forceinline__ uint32_t slot_key(unsigned long long kf) { return (uint32_t)(kf >> 32); }
 
 struct UnionArgs {
@@ -64,6 +68,10 @@ struct UnionArgs {
   // is never computed, only read as a feature row — so it gets no table slot and no local id (slot_of = LEAF) and
   // stays a GLOBAL id in its parent's row: rows of level hops-1 hold global ids, rows of lower levels local ids
   int32_t leaf_global;
+  // hops >= 2: [slots of hop 0] 1 iff that slot's node is a root — written by the hop-0 insert launch, read by the
+  // hop-1 launch instead of a random probe of the parent's table slot (scratch shared with the winner flags, which
+  // are written later)
+  uint8_t* root_parent;
 };
 constexpr int32_t LEAF = -2;  // slot_of value of a leaf occurrence in leaf-global mode
 
@@ -149,6 +157,7 @@ __device__ __forceinline__ uint32_t table_insert(const UnionArgs& a, uint32_t ba
     }
     if ((uint32_t)(prev >> 32) == id) {
       if ((uint32_t)prev > t) atomicMin(w, mine);  // (positions only go down: prev <= t needs no update)
+      if (a.slots[base + s].lid != LID_MULTI) a.slots[base + s].lid = LID_MULTI;  // (benign race: same value)
       return base + s;
     }
     s = (s + 1) & a.mask;
@@ -201,8 +210,7 @@ __global__ void insert_slots_kernel(UnionArgs a, int64_t lo, int64_t hi) {
     lvl = 1;
   } else if (k == 1) {
     // parent = a hop-0 slot node, whose level is final since the previous launch: 0 iff it is a root
-    const int32_t ps = a.slot_of[parent_pos(a, 1, j)];
-    lvl = a.slots[ps].level == 0 ? 1 : 2;
+    lvl = a.root_parent[(uint32_t)j / (uint32_t)a.fan[1]] ? 1 : 2;
   } else {
     lvl = k + 1;  // upper bound; relaxed below
   }
@@ -211,8 +219,9 @@ __global__ void insert_slots_kernel(UnionArgs a, int64_t lo, int64_t hi) {
     return;
   }
   uint32_t s = table_insert(a, group_base(a, k, j), id, (uint32_t)t);
-  if (lvl < a.hops &&  // (same look-before-atomic: levels only go down, a stale read only costs a redundant atomic)
-      *(const volatile int32_t*)&a.slots[s].level > lvl)
+  const int32_t cur = *(const volatile int32_t*)&a.slots[s].level;  // roots were inserted by the previous launch
+  if (k == 0 && a.hops >= 2) a.root_parent[j] = cur == 0 ? 1 : 0;
+  if (lvl < a.hops && cur > lvl)  // (look-before-atomic: levels only go down, a stale read costs a redundant atomic)
     atomicMin(&a.slots[s].level, lvl);
   a.slot_of[t] = (int32_t)s;
 }
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t*
     for (int q = 0; q < r * 4 + w; ++q) id += s_wave[q][l];
     for (int ll = 0; ll < l; ++ll) id += s_total[ll];
     const int32_t s = a.slot_of[base + r * 256 + tid];
-    a.slots[s].lid = id;
+    a.slots[s].lid = id | (a.slots[s].lid & LID_MULTI);
     nodes[id] = slot_key(a.slots[s].kf);
   }
   if (blockIdx.x == 0 && tid == 0) {
@@ -366,27 +375,32 @@ __global__ void edge_dedup_count_kernel(UnionArgs a, unsigned long long* ekeys, 
   const int lane = threadIdx.x & 63;
   const bool in = t < a.T;
   const int32_t s = in ? a.slot_of[t] : -1;
-  if (in && t < a.b) root_local[t] = s >= 0 ? a.slots[s].lid : -1;
+  if (in && t < a.b) root_local[t] = s >= 0 ? (a.slots[s].lid & ~LID_MULTI) : -1;
   bool win = false;
   int32_t dl = 0, sl = 0;
   if (in && t >= a.b && (s >= 0 || s == LEAF)) {
     int k;
     int64_t j;
     locate(a, t, k, j);
-    dl = a.slots[a.slot_of[parent_pos(a, k, j)]].lid;
-    sl = s >= 0 ? a.slots[s].lid : (int32_t)pick(a.nbr, k)[j];  // a leaf keeps its global id
-    const unsigned long long key = ((unsigned long long)(uint32_t)dl << 32) | (uint32_t)sl;
-    unsigned long long* sub = ekeys;
-    if (a.grouped) sub += (uint64_t)((uint32_t)j / pick(a.gdiv, k)) * (emask + 1u);
-    uint32_t h = hash_u32((uint32_t)sl * 0x9E3779B1u ^ (uint32_t)dl) & emask;
-    while (true) {
-      unsigned long long prev = atomicCAS(&sub[h], ~0ULL, key);
-      if (prev == ~0ULL) {
-        win = true;
-        break;
+    const int32_t dlf = a.slots[a.slot_of[parent_pos(a, k, j)]].lid;
+    dl = dlf & ~LID_MULTI;
+    sl = s >= 0 ? (a.slots[s].lid & ~LID_MULTI) : (int32_t)pick(a.nbr, k)[j];  // a leaf keeps its global id
+    if (!(dlf & LID_MULTI)) {
+      win = true;  // the destination occurs once in the batch: its f sampled in-edges are distinct already
+    } else {
+      const unsigned long long key = ((unsigned long long)(uint32_t)dl << 32) | (uint32_t)sl;
+      unsigned long long* sub = ekeys;
+      if (a.grouped) sub += (uint64_t)((uint32_t)j / pick(a.gdiv, k)) * (emask + 1u);
+      uint32_t h = hash_u32((uint32_t)sl * 0x9E3779B1u ^ (uint32_t)dl) & emask;
+      while (true) {
+        unsigned long long prev = atomicCAS(&sub[h], ~0ULL, key);
+        if (prev == ~0ULL) {
+          win = true;
+          break;
+        }
+        if (prev == key) break;
+        h = (h + 1) & emask;
       }
-      if (prev == key) break;
-      h = (h + 1) & emask;
     }
     if (win) pairs[t - a.b] = make_int2(dl, sl);
   }
@@ -802,6 +816,7 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
   int2* pairs = (int2*)gigl_arena_alloc(ctx, (E + 1) * 8);
   if (!ekeys || !a.slots || !zeros || !big_rows || !winner || !a.slot_of || !pairs || !tile_counts)
     return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  a.root_parent = winner;  // (free until edge_dedup_count writes the winner flags)
   int32_t* rowcnt = zeros;
   int32_t* big_count = zeros + cap_nodes + 1;  // [0] = number of queued rows
 
