@@ -274,6 +274,45 @@ __global__ __launch_bounds__(256) void count_kernel(UnionArgs a, int32_t* tile_c
   if (threadIdx.x < MAXL) tile_counts[blockIdx.x * MAXL + threadIdx.x] = s_cnt[threadIdx.x];
 }
 
+// tile_counts[tile][l] -> exclusive prefix over the tiles, in place; row n_tiles receives the totals.  One
+// workgroup: thread i owns a contiguous run of tiles (every assign workgroup used to re-add all the tiles before
+// it: O(tiles^2) loads per build).
+__global__ __launch_bounds__(1024) void tile_scan_kernel(int32_t* tile_counts, int32_t n_tiles) {
+  __shared__ int32_t s_w[16][MAXL];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int per = (n_tiles + 1023) / 1024;
+  const int lo = min(tid * per, n_tiles), hi = min(lo + per, n_tiles);
+  int32_t sum[MAXL];
+#pragma unroll
+  for (int l = 0; l < MAXL; ++l) sum[l] = 0;
+  for (int i = lo; i < hi; ++i)
+#pragma unroll
+    for (int l = 0; l < MAXL; ++l) sum[l] += tile_counts[i * MAXL + l];
+  int32_t incl[MAXL];
+#pragma unroll
+  for (int l = 0; l < MAXL; ++l) {
+    int32_t v = sum[l];
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t o = __shfl_up(v, off, 64);
+      if (lane >= off) v += o;
+    }
+    incl[l] = v;
+    if (lane == 63) s_w[w][l] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 0; l < MAXL; ++l) {
+    int32_t run = incl[l] - sum[l];
+    for (int q = 0; q < w; ++q) run += s_w[q][l];
+    for (int i = lo; i < hi; ++i) {
+      const int32_t c = tile_counts[i * MAXL + l];
+      tile_counts[i * MAXL + l] = run;
+      run += c;
+    }
+    if (tid == 1023) tile_counts[n_tiles * MAXL + l] = run;  // (the last thread's run ends at the total)
+  }
+}
+
 // local id = base[level] + (first occurrences of that level at smaller stream positions)
 __global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t* tile_counts, int32_t n_tiles,
                                                      uint32_t* nodes, int32_t* meta) {
@@ -281,34 +320,11 @@ __global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t*
   __shared__ int32_t s_total[MAXL];   // totals per level
   __shared__ int32_t s_wave[TILE / 64][MAXL];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  {
-    int32_t bef[MAXL], tot[MAXL];
-#pragma unroll
-    for (int l = 0; l < MAXL; ++l) bef[l] = tot[l] = 0;
-    for (int i = tid; i < n_tiles; i += 256) {
-#pragma unroll
-      for (int l = 0; l < MAXL; ++l) {
-        int32_t v = tile_counts[i * MAXL + l];
-        tot[l] += v;
-        if (i < (int)blockIdx.x) bef[l] += v;
-      }
-    }
-    if (tid < MAXL) s_before[tid] = s_total[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int l = 0; l < MAXL; ++l) {
-      int vb = bef[l], vt = tot[l];
-      for (int off = 32; off > 0; off >>= 1) {
-        vb += __shfl_xor(vb, off, 64);
-        vt += __shfl_xor(vt, off, 64);
-      }
-      if (lane == 0) {
-        if (vb) atomicAdd(&s_before[l], vb);
-        if (vt) atomicAdd(&s_total[l], vt);
-      }
-    }
-    __syncthreads();
+  if (tid < MAXL) {
+    s_before[tid] = tile_counts[blockIdx.x * MAXL + tid];
+    s_total[tid] = tile_counts[n_tiles * MAXL + tid];
   }
+  __syncthreads();
   // ranks inside the tile: sub-tile r = 256 consecutive positions = 4 waves
   const int64_t base = (int64_t)blockIdx.x * TILE;
   int lv[TILE / 256];
@@ -800,7 +816,7 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
   add(n_slots * (int64_t)sizeof(Slot));
   add(zero_words * 4);               // rowcnt + big-row counter
   add(T * 4);                        // slot_of
-  add((int64_t)n_tiles * MAXL * 4);  // tile counts
+  add((int64_t)(n_tiles + 1) * MAXL * 4);  // tile counts + totals
   add(cap_nodes * 4);                // big-row queue
   add(E + 256);                      // winner flags
   add((E + 1) * 8);                  // winners' (dst, src) pairs
@@ -810,7 +826,7 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
   a.slots = (Slot*)gigl_arena_alloc(ctx, n_slots * (int64_t)sizeof(Slot));
   int32_t* zeros = (int32_t*)gigl_arena_alloc(ctx, zero_words * 4);
   a.slot_of = (int32_t*)gigl_arena_alloc(ctx, T * 4);
-  int32_t* tile_counts = (int32_t*)gigl_arena_alloc(ctx, (int64_t)n_tiles * MAXL * 4);
+  int32_t* tile_counts = (int32_t*)gigl_arena_alloc(ctx, (int64_t)(n_tiles + 1) * MAXL * 4);
   int32_t* big_rows = (int32_t*)gigl_arena_alloc(ctx, cap_nodes * 4);
   uint8_t* winner = (uint8_t*)gigl_arena_alloc(ctx, E + 256);
   int2* pairs = (int2*)gigl_arena_alloc(ctx, (E + 1) * 8);
@@ -839,6 +855,7 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_NODES);
     hipLaunchKernelGGL(count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, a, tile_counts);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_counts, n_tiles);
     hipLaunchKernelGGL(assign_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, a, tile_counts, n_tiles,
                        out->nodes, out->meta);
   }
