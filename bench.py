@@ -17,7 +17,8 @@ Steps are independent batches.  One library call takes G consecutive batches thr
 (gigl_sage_plan_set_groups: every batch keeps its own union graph, rows are bit-identical to G single-batch
 calls — tests/test_gpu_groups.py), because at B=1024 a launch set costs ~0.07 ms of dispatch floor against
 ~0.08 ms of work per batch; calls are pipelined over S HIP streams (one library ctx + one host thread per
-stream, all sharing the HBM-resident graph).  Exactly K steps (K*B roots) are timed in total; a remainder of
+stream, all sharing the HBM-resident graph; defaults S = 3, G = 32 — a sweep of S in 2..4, G in 8..32 stays within
+±5 % of the best).  Exactly K steps (K*B roots) are timed in total; a remainder of
 K mod G steps runs batch by batch.
 N>1: one process per GPU (torch.distributed, RCCL); every rank holds a replica of the graph and takes
 its own root batches — the path shards by roots with no data-path collective ("weak" scaling);
@@ -136,10 +137,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--fanouts", type=str, default="25,10")
-    ap.add_argument("--streams", type=int, default=2)
-    ap.add_argument("--group", type=int, default=16,
+    ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--group", type=int, default=0,
                     help="batches per library call: G independent batches of B roots share one set of launches "
-                         "(each keeps its own union graph; results are bit-identical to G single-batch calls)")
+                         "(each keeps its own union graph; results are bit-identical to G single-batch calls); "
+                         "0 = the largest power of two <= min(32, steps / streams)")
     ap.add_argument("--workload", type=str, default="products", choices=["products", "mag-shard", "mag240m-sharded"],
                     help="products = BASELINE configs[1] (default, the N=1 workload; N>1: a replica per GPU); mag-shard = "
                          "one GPU's 1/8 share of the MAG240M-shaped graph as a self-contained graph (D=768 fp16, SAGE "
@@ -177,7 +179,12 @@ def main():
     dev = eng0.device
     fanouts = [int(v) for v in args.fanouts.split(",")]
     B, K, W, S = args.batch, args.steps, args.warmup, max(1, args.streams)
-    G = max(1, args.group)
+    if args.group > 0:
+        G = args.group
+    else:  # as few pipelines as keep >= 16 steps each, G <= 32 batches per call, calls spread evenly
+        S = min(S, max(1, K // 16))
+        calls_per_stream = -(-K // (S * 32))
+        G = max(1, K // (S * calls_per_stream))
     L = len(fanouts)
     mode = MODE_SPARK_HASH if args.mode == "parity" else MODE_FAST
 
@@ -215,10 +222,17 @@ def main():
     # single-batch plan: the tail of a step range that is not a multiple of G, and the untimed counting pass
     plan1 = model.make_plan(engines[0], B, fanouts) if G > 1 else plans[0]
     out1 = torch.empty((B, out_dim), dtype=torch.float32, device=dev)
+    # the timed range's remainder (K mod G steps) goes through one more grouped call of its own size
+    R = K % G
+    plan_rem = model.make_plan(engines[0], B, fanouts, groups=R) if R > 1 else None
+    if plan_rem is not None and not args.no_graph:
+        plan_rem.use_graph(True)
+    out_rem = torch.empty((max(R, 1) * B, out_dim), dtype=torch.float32, device=dev)
 
     def run_range(lo, hi, S=S):
         """steps (= batches of B roots) lo..hi-1: call c takes the G consecutive batches lo+c*G.. on pipeline
-        c % S (one host thread per pipeline); a remainder of < G steps runs batch by batch on pipeline 0"""
+        c % S (one host thread per pipeline); a remainder of < G steps runs as one call of its own size (timed range) or
+        batch by batch, on pipeline 0"""
         n_calls = (hi - lo) // G
 
         def worker(s):
@@ -226,8 +240,12 @@ def main():
                 i = lo + c * G
                 plans[s].run(my[i:i + G].view(-1), out=outs[s], mode=mode)
             if s == 0:
-                for i in range(lo + n_calls * G, hi):
-                    plan1.run(my[i], out=out1, mode=mode)
+                i0 = lo + n_calls * G
+                if plan_rem is not None and hi - i0 == R:
+                    plan_rem.run(my[i0:hi].view(-1), out=out_rem, mode=mode)
+                else:
+                    for i in range(i0, hi):
+                        plan1.run(my[i], out=out1, mode=mode)
         ths = [threading.Thread(target=worker, args=(s,)) for s in range(S)]
         for t in ths:
             t.start()
@@ -264,6 +282,15 @@ def main():
     for e in engines:
         e.profile_enable([dominant], capacity=(K // S + 8) * 8)
     run_range(0, W)
+    # every plan replays from its hipGraph in the timed region: one untimed call each re-captures after the timer
+    # mask change (warm-up alone does not reach all plans when W < S*G)
+    for s_i in range(S):
+        plans[s_i].run(my[:G].view(-1), out=outs[s_i], mode=mode)
+        plans[s_i].run(my[:G].view(-1), out=outs[s_i], mode=mode)
+    if plan_rem is not None:
+        plan_rem.run(my[:R].view(-1), out=out_rem, mode=mode)
+        plan_rem.run(my[:R].view(-1), out=out_rem, mode=mode)
+    torch.cuda.synchronize()
     for e in engines:
         e.profile_reset()
 
@@ -277,7 +304,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t1
-    for p in plans:
+    for p in plans + ([plan_rem] if plan_rem is not None else []):
         p.flush_profile()
     dom_ms, dom_launches = [sum(x) for x in zip(*[e.profile_read(dominant) for e in engines])]
     for e in engines:
