@@ -72,6 +72,7 @@ struct UnionArgs {
   // hop-1 launch instead of a random probe of the parent's table slot (scratch shared with the winner flags, which
   // are written later)
   uint8_t* root_parent;
+  int32_t* overflow;  // meta[GIGL_META_OVERFLOW]
 };
 constexpr int32_t LEAF = -2;  // slot_of value of a leaf occurrence in leaf-global mode
 
@@ -143,7 +144,7 @@ __device__ __forceinline__ int64_t parent_pos(const UnionArgs& a, int k, int64_t
 __device__ __forceinline__ uint32_t table_insert(const UnionArgs& a, uint32_t base, uint32_t id, uint32_t t) {
   const unsigned long long mine = ((unsigned long long)id << 32) | t;
   uint32_t s = hash_u32(id) & a.mask;
-  while (true) {
+  for (uint32_t probes = 0; probes <= a.mask; ++probes) {
     unsigned long long* w = &a.slots[base + s].kf;
     // look before the read-modify-write: a hub node sits in thousands of positions of one batch, and same-address
     // atomics are serialised by the memory system, while plain reads of a hot word are not.  Once the hub is in
@@ -162,6 +163,7 @@ __device__ __forceinline__ uint32_t table_insert(const UnionArgs& a, uint32_t ba
     }
     s = (s + 1) & a.mask;
   }
+  return GIGL_INVALID;  // the sub-table is full (leaf-global mode sizes it for the batches the plan can hold)
 }
 
 // all per-batch table initialisation in one dispatch: empty edge keys (0xFF..), empty node slots
@@ -187,7 +189,7 @@ __global__ void insert_roots_kernel(UnionArgs a) {
     a.slot_of[t] = -1;
     return;
   }
-  uint32_t s = table_insert(a, group_base(a, -1, t), id, (uint32_t)t);
+  uint32_t s = table_insert(a, group_base(a, -1, t), id, (uint32_t)t);  // (never full: every table holds its roots)
   a.slots[s].level = 0;
   a.slot_of[t] = (int32_t)s;
 }
@@ -219,6 +221,12 @@ __global__ void insert_slots_kernel(UnionArgs a, int64_t lo, int64_t hi) {
     return;
   }
   uint32_t s = table_insert(a, group_base(a, k, j), id, (uint32_t)t);
+  if (s == GIGL_INVALID) {  // table full: more inner-level nodes than the plan's workspace holds — batch reported failed
+    atomicAdd(a.overflow, 1);
+    if (k == 0 && a.hops >= 2) a.root_parent[j] = 0;
+    a.slot_of[t] = LEAF;
+    return;
+  }
   const int32_t cur = *(const volatile int32_t*)&a.slots[s].level;  // roots were inserted by the previous launch
   if (k == 0 && a.hops >= 2) a.root_parent[j] = cur == 0 ? 1 : 0;
   if (lvl < a.hops && cur > lvl)  // (look-before-atomic: levels only go down, a stale read costs a redundant atomic)
@@ -800,7 +808,17 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
   // open-addressing tables at load factor <= 2/3: one node sub-table and one edge sub-table per batch, so the
   // probes of the batches in flight stay inside a few MB instead of scattering over one table of all batches
   uint64_t cap = 1024, ecap = 1024;
-  while (cap * 2 < (uint64_t)(T / n_groups) * 3) cap <<= 1;
+  // leaf-global mode: the table holds the nodes of level < hops only.  The plan's activation buffers hold
+  // b*(1 + f0 + ...) of them (pipeline.hip guard_levels_kernel fails a batch with more), so the sub-table is sized
+  // for twice that — a legitimate batch loads it <= 50 % — and a batch that fills it is reported through
+  // meta[GIGL_META_OVERFLOW] by the insert kernels (its surplus occurrences are treated as leaves).
+  int64_t inner = b / n_groups, width = b / n_groups;
+  for (int k = 0; k + 1 < hops; ++k) {
+    width *= tree->fanouts[k];
+    inner += width;
+  }
+  const uint64_t want = a.leaf_global ? (uint64_t)inner * 4 : (uint64_t)(T / n_groups) * 3;
+  while (cap * 2 < want) cap <<= 1;
   while (ecap * 2 < (uint64_t)(E / n_groups) * 3) ecap <<= 1;
   a.mask = (uint32_t)(cap - 1);
   const int64_t n_slots = (int64_t)cap * n_groups, n_ekeys = (int64_t)ecap * n_groups;
@@ -833,6 +851,7 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
   if (!ekeys || !a.slots || !zeros || !big_rows || !winner || !a.slot_of || !pairs || !tile_counts)
     return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   a.root_parent = winner;  // (free until edge_dedup_count writes the winner flags)
+  a.overflow = out->meta + GIGL_META_OVERFLOW;
   int32_t* rowcnt = zeros;
   int32_t* big_count = zeros + cap_nodes + 1;  // [0] = number of queued rows
 
@@ -872,8 +891,9 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
   }
   if (E > 0) {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_CSR);
+    // a row costs a chain of dependent loads and a few instructions: latency-bound, so a wave per (possible) row
     int64_t blocks = (max_rows + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 256 * 256) blocks = 256 * 256;
     hipLaunchKernelGGL(row_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out->meta, hops, out->rowptr,
                        out->rowend, out->col, big_rows, big_count);
     static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs the opt-in once per process
