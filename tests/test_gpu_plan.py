@@ -117,3 +117,39 @@ def test_plans_on_several_streams_and_threads(setup):
     for e in engines:
         e.close()
     serial_plan.close()
+
+
+def test_plan_reports_batches_that_do_not_fit_its_workspace():
+    """a root that is its own sampled neighbour makes the children of that occurrence inner-level nodes: with b = 1,
+    fanout [64, 64] the activation workspace holds 1 + 64 rows, the batch needs more -> nothing is computed for it
+    and meta[GIGL_META_OVERFLOW] says so (instead of writing past the buffers)"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE
+    n, d = 400, 8
+    found = None
+    for r in range(1, 200):  # a root whose hop-1 sample contains the root itself (self loop in the CSC)
+        nbrs = np.unique(np.concatenate([[r], np.arange(200, 320)])).astype(np.uint32)
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        rowptr[r + 1:] = nbrs.size
+        nbr_o, _ = oracle.sample_khop(rowptr, nbrs, np.array([r], np.uint32), [64, 64], canonical=True)
+        if r in nbr_o[0]:
+            u = oracle.union_build(np.array([r], np.uint32), [64, 64], nbr_o)
+            if int(u["meta"][3]) > 65:
+                found = (r, rowptr, nbrs)
+                break
+    assert found is not None
+    r, rowptr, col = found
+    eng = HipEngine(0)
+    eng.load_csc(rowptr, col)
+    eng.load_features(np.random.default_rng(0).standard_normal((n, d)).astype(np.float32))
+    model = GraphSAGE(d, 8, 4, num_layers=2).to(eng.device)
+    plan = model.make_plan(eng, 1, [64, 64])
+    plan.run(torch.tensor([r], dtype=torch.int32, device=eng.device))
+    hb = plan.last_batch_to_host()
+    assert hb["meta"][8] != 0  # GIGL_META_OVERFLOW
+    # the step-by-step path (public union + per-layer calls sized by the caller) still computes this batch
+    tree = eng.sample_khop(np.array([r], np.uint32), [64, 64])
+    u = eng.union_build(tree)
+    assert u.counts()["levels"][1] > 65
+    plan.close()
+    eng.close()
