@@ -40,6 +40,8 @@ struct gigl_sage_plan {
   // leaf-global union (union.hip): pure leaves get no local id and stay global ids in their parents' rows — the
   // plan never computes anything for them, it only gathers their feature rows
   bool leaf_global = false;
+  bool alias_rows = false;  // tree.nbr[hops-1] == un.col + un.cap_edges (rows may alias tree segments)
+  int64_t last_slots = 0;
   int64_t act_rows = 0;         // rows of abuf / hbuf
   int32_t* zero_dev = nullptr;  // a device int32 0 (hops == 1: no row of the layer-0 gather holds local ids)
   gigl_tree tree{};
@@ -262,18 +264,27 @@ int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat,
     return q;
   };
   bool ok = true;
+  p->leaf_global = hops <= 2 && graph->n < ((int64_t)1 << 31);
+  // two hops, leaf-global union: the last hop's sampled ids live right behind the union's col array, so that the
+  // rows of level-1 nodes that occur once can BE their tree segments (union.hip, row aliasing)
+  int64_t last_slots = b;
+  for (int k = 0; k < hops; ++k) last_slots *= fanouts[k];
+  p->alias_rows = p->leaf_global && hops == 2;
+  p->last_slots = last_slots;
+  p->un.col = (int32_t*)alloc((size_t)(cap_edges + (p->alias_rows ? last_slots : 0)) * 4);
+  ok = p->un.col != nullptr;
   int64_t parents = b;
   for (int k = 0; k < hops && ok; ++k) {
     p->tree.cnt[k] = (int32_t*)alloc((size_t)parents * 4);
     parents *= fanouts[k];
-    p->tree.nbr[k] = (uint32_t*)alloc((size_t)parents * 4);
+    p->tree.nbr[k] = (p->alias_rows && k == hops - 1) ? (uint32_t*)(p->un.col + cap_edges)
+                                                      : (uint32_t*)alloc((size_t)parents * 4);
     ok = p->tree.cnt[k] && p->tree.nbr[k];
   }
   p->un.meta = (int32_t*)alloc(GIGL_META_LEN * 4);
   p->un.nodes = (uint32_t*)alloc((size_t)cap_nodes * 4);
   p->un.rowptr = (int32_t*)alloc((size_t)(cap_nodes + 2) * 4);
   p->un.rowend = (int32_t*)alloc((size_t)(cap_nodes + 2) * 4);
-  p->un.col = (int32_t*)alloc((size_t)cap_edges * 4);
   p->un.root_local = (int32_t*)alloc((size_t)b * 4);
   p->un.cap_nodes = cap_nodes;
   p->un.cap_edges = cap_edges;
@@ -291,7 +302,6 @@ int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat,
   p->zero_dev = (int32_t*)alloc(16);
   if (p->zero_dev && hipMemset(p->zero_dev, 0, 16) != hipSuccess) ok = false;
   p->act_rows = act_rows;
-  p->leaf_global = hops <= 2 && graph->n < ((int64_t)1 << 31);
   ok = ok && p->zero_dev && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col && p->un.root_local &&
        p->abuf && p->hbuf[0] && p->hbuf[1] && p->roots_buf && p->out_buf;
   if (!ok) {
@@ -333,7 +343,10 @@ int32_t gigl_sage_plan_set_groups(gigl_sage_plan* p, int32_t group_roots) {
 int32_t gigl_sage_plan_buffers(gigl_sage_plan* p, gigl_tree* tree, gigl_union* un) {
   if (!p) return GIGL_E_INVALID_ARG;
   if (tree) *tree = p->tree;
-  if (un) *un = p->un;
+  if (un) {
+    *un = p->un;
+    if (p->alias_rows) un->cap_edges += p->last_slots;  // rowptr / rowend may point into the aliased tree segments
+  }
   return GIGL_OK;
 }
 

@@ -73,6 +73,12 @@ struct UnionArgs {
   // are written later)
   uint8_t* root_parent;
   int32_t* overflow;  // meta[GIGL_META_OVERFLOW]
+  // row aliasing (leaf-global, hops == 2, the last hop's nbr array laid out right behind the col buffer): a level-1
+  // node that occurs ONCE in the batch has exactly the in-edges its one parent occurrence sampled — ascending,
+  // duplicate-free global ids sitting in nbr[1][slot*f1 ..) already — so its row is that tree segment itself
+  // (rowptr = alias_base + slot*f1, rowend = rowptr + cnt): no dedup, no fill, no sort for ~90 % of the edges
+  int32_t alias_base;       // index of nbr[1][0] in the col array, or -1
+  const int32_t* cnt_last;  // tree cnt of the last hop
 };
 constexpr int32_t LEAF = -2;  // slot_of value of a leaf occurrence in leaf-global mode
 
@@ -256,6 +262,16 @@ __device__ __forceinline__ int first_level(const UnionArgs& a, int64_t t) {
   const uint4 q = *reinterpret_cast<const uint4*>(&a.slots[s]);  // {firstpos, key, level, lid}
   return q.x == (uint32_t)t ? (int)q.z : -1;
 }
+// the same, also handing out the slot's lid word (the LID_MULTI flag at this point)
+__device__ __forceinline__ int first_level_flags(const UnionArgs& a, int64_t t, int32_t& lidw) {
+  lidw = 0;
+  if (t >= a.T) return -1;
+  int32_t s = a.slot_of[t];
+  if (s < 0) return -1;
+  const uint4 q = *reinterpret_cast<const uint4*>(&a.slots[s]);
+  lidw = (int32_t)q.w;
+  return q.x == (uint32_t)t ? (int)q.z : -1;
+}
 
 // tile_counts[tile][l] = number of first occurrences of level l in the tile
 __global__ __launch_bounds__(256) void count_kernel(UnionArgs a, int32_t* tile_counts) {
@@ -323,7 +339,8 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int32_t* tile_counts, i
 
 // local id = base[level] + (first occurrences of that level at smaller stream positions)
 __global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t* tile_counts, int32_t n_tiles,
-                                                     uint32_t* nodes, int32_t* meta) {
+                                                     uint32_t* nodes, int32_t* meta, int32_t* rowptr, int32_t* rowend,
+                                                     int32_t* rowcnt, int32_t* alias_edges) {
   __shared__ int32_t s_before[MAXL];  // this level's firsts in earlier tiles
   __shared__ int32_t s_total[MAXL];   // totals per level
   __shared__ int32_t s_wave[TILE / 64][MAXL];
@@ -336,10 +353,11 @@ __global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t*
   // ranks inside the tile: sub-tile r = 256 consecutive positions = 4 waves
   const int64_t base = (int64_t)blockIdx.x * TILE;
   int lv[TILE / 256];
+  int32_t lidw[TILE / 256];
   int rank_in_wave[TILE / 256];
 #pragma unroll
   for (int r = 0; r < TILE / 256; ++r) {
-    lv[r] = first_level(a, base + r * 256 + tid);
+    lv[r] = first_level_flags(a, base + r * 256 + tid, lidw[r]);
     rank_in_wave[r] = 0;
 #pragma unroll
     for (int l = 0; l < MAXL; ++l) {
@@ -349,6 +367,7 @@ __global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t*
     }
   }
   __syncthreads();
+  int32_t alias_c = 0;
 #pragma unroll
   for (int r = 0; r < TILE / 256; ++r) {
     if (lv[r] < 0) continue;
@@ -356,9 +375,23 @@ __global__ __launch_bounds__(256) void assign_kernel(UnionArgs a, const int32_t*
     int32_t id = s_before[l] + rank_in_wave[r];
     for (int q = 0; q < r * 4 + w; ++q) id += s_wave[q][l];
     for (int ll = 0; ll < l; ++ll) id += s_total[ll];
-    const int32_t s = a.slot_of[base + r * 256 + tid];
-    a.slots[s].lid = id | (a.slots[s].lid & LID_MULTI);
+    const int64_t t = base + r * 256 + tid;
+    const int32_t s = a.slot_of[t];
+    a.slots[s].lid = id | (lidw[r] & LID_MULTI);
     nodes[id] = slot_key(a.slots[s].kf);
+    // row aliasing: a node whose ONE occurrence is this hop-0 slot owns the tree segment of its children as its
+    // row; rowcnt = -1 tells row_scan to leave the row alone (no winner is ever counted for it)
+    if (a.alias_base >= 0 && !(lidw[r] & LID_MULTI) && t >= a.b && t < a.off[1]) {
+      const int32_t e = (int32_t)(t - a.b), c = a.cnt_last[e];
+      rowptr[id] = a.alias_base + e * a.fan[1];
+      rowend[id] = a.alias_base + e * a.fan[1] + c;
+      rowcnt[id] = -1;
+      alias_c += c;
+    }
+  }
+  if (a.alias_base >= 0) {  // one counter bump per wave, spread over 32 addresses (same-address atomics ~13 ns each)
+    for (int off = 32; off > 0; off >>= 1) alias_c += __shfl_xor(alias_c, off, 64);
+    if (lane == 0 && alias_c) atomicAdd(&alias_edges[blockIdx.x & 31], alias_c);
   }
   if (blockIdx.x == 0 && tid == 0) {
     int32_t cum = 0;
@@ -409,7 +442,9 @@ __global__ void edge_dedup_count_kernel(UnionArgs a, unsigned long long* ekeys, 
     const int32_t dlf = a.slots[a.slot_of[parent_pos(a, k, j)]].lid;
     dl = dlf & ~LID_MULTI;
     sl = s >= 0 ? (a.slots[s].lid & ~LID_MULTI) : (int32_t)pick(a.nbr, k)[j];  // a leaf keeps its global id
-    if (!(dlf & LID_MULTI)) {
+    if (!(dlf & LID_MULTI) && a.alias_base >= 0 && k == a.hops - 1) {
+      // the destination's row is the tree segment itself (patched in by edge_fill): nothing to do for this edge
+    } else if (!(dlf & LID_MULTI)) {
       win = true;  // the destination occurs once in the batch: its f sampled in-edges are distinct already
     } else {
       const unsigned long long key = ((unsigned long long)(uint32_t)dl << 32) | (uint32_t)sl;
@@ -456,7 +491,7 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* rowcnt, i
   const int32_t c_lo = min(n, (int32_t)blockIdx.x * chunk), c_hi = min(n, c_lo + chunk);
   {  // chunk sum -> partials[blockIdx], arrive, wait for everybody, carry = sum of the chunks before mine
     int32_t v = 0;
-    for (int32_t i = c_lo + tid; i < c_hi; i += 1024) v += rowcnt[i];
+    for (int32_t i = c_lo + tid; i < c_hi; i += 1024) v += max(rowcnt[i], 0);  // (-1 = aliased row: no entries)
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     if (lane == 0) s_w[w] = v;
     __syncthreads();
@@ -487,8 +522,13 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* rowcnt, i
   for (int32_t base = c_lo; base < c_hi; base += 1024 * PER) {
     const int32_t i0 = base + tid * PER;
     int32_t c[PER];
+    bool aliased[PER];
 #pragma unroll
-    for (int q = 0; q < PER; ++q) c[q] = (i0 + q) < c_hi ? rowcnt[i0 + q] : 0;
+    for (int q = 0; q < PER; ++q) {
+      c[q] = (i0 + q) < c_hi ? rowcnt[i0 + q] : 0;
+      aliased[q] = c[q] < 0;  // the row is a tree segment (assign_kernel set its rowptr / rowend): left alone
+      c[q] = max(c[q], 0);
+    }
     int32_t v = 0;
 #pragma unroll
     for (int q = 0; q < PER; ++q) v += c[q];
@@ -505,7 +545,7 @@ __global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* rowcnt, i
     int32_t ex = carry + wave_off + incl - v;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
-      if (i0 + q < c_hi) {
+      if (i0 + q < c_hi && !aliased[q]) {
         rowptr[i0 + q] = ex;
         rowend[i0 + q] = ex;
       }
@@ -554,14 +594,20 @@ __global__ void edge_fill_kernel(UnionArgs a, const uint8_t* winner, const int2*
 // one wave per row: sort ascending in place (rows <= 64, values are unique); longer rows are queued
 __global__ __launch_bounds__(256) void row_sort_kernel(const int32_t* meta, int hops, const int32_t* rowptr,
                                                        const int32_t* rowend, int32_t* col, int32_t* big_rows,
-                                                       int32_t* big_count) {
+                                                       int32_t* big_count, int32_t alias_base, int32_t* meta_rw) {
   const int lane = threadIdx.x & 63;
   const int32_t n = meta[GIGL_META_LEVEL0 + hops - 1];
   const int32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int32_t waves_total = (gridDim.x * blockDim.x) >> 6;
+  if (alias_base >= 0 && blockIdx.x == 0 && threadIdx.x == 0)
+  {
+    int32_t extra = 0;  // the edges of the aliased rows (counted by edge_fill)
+    for (int q = 0; q < 32; ++q) extra += big_count[32 + q];
+    meta_rw[GIGL_META_N_EDGES] += extra;
+  }
   for (int32_t i = wave; i < n; i += waves_total) {
     const int32_t s = rowptr[i], m = rowend[i] - s;
-    if (m <= 1) continue;
+    if (m <= 1 || (alias_base >= 0 && s >= alias_base)) continue;  // (an aliased row is a sorted tree segment)
     if (m > 64) {
       if (lane == 0) big_rows[atomicAdd(big_count, 1)] = i;
       continue;
@@ -851,6 +897,11 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
   if (!ekeys || !a.slots || !zeros || !big_rows || !winner || !a.slot_of || !pairs || !tile_counts)
     return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   a.root_parent = winner;  // (free until edge_dedup_count writes the winner flags)
+  a.alias_base = -1;
+  a.cnt_last = tree->cnt[hops - 1];
+  if (a.leaf_global && hops == 2 && tree->nbr[1] == (const uint32_t*)(out->col + out->cap_edges) &&
+      out->cap_edges + (a.off[2] - a.off[1]) < ((int64_t)1 << 31))
+    a.alias_base = (int32_t)out->cap_edges;
   a.overflow = out->meta + GIGL_META_OVERFLOW;
   int32_t* rowcnt = zeros;
   int32_t* big_count = zeros + cap_nodes + 1;  // [0] = number of queued rows
@@ -876,7 +927,7 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
     hipLaunchKernelGGL(count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, a, tile_counts);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_counts, n_tiles);
     hipLaunchKernelGGL(assign_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, a, tile_counts, n_tiles,
-                       out->nodes, out->meta);
+                       out->nodes, out->meta, out->rowptr, out->rowend, rowcnt, big_count + 32);
   }
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_EDGE_SORT);
@@ -893,9 +944,9 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
     gigl_prof_scope ps(ctx, GIGL_K_UNION_CSR);
     // a row costs a chain of dependent loads and a few instructions: latency-bound, so a wave per (possible) row
     int64_t blocks = (max_rows + 3) / 4;
-    if (blocks > 256 * 256) blocks = 256 * 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(row_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out->meta, hops, out->rowptr,
-                       out->rowend, out->col, big_rows, big_count);
+                       out->rowend, out->col, big_rows, big_count, a.alias_base, out->meta);
     static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs the opt-in once per process
     if (!lds_attr_set) {
       GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)row_sort_big_kernel,
