@@ -291,12 +291,14 @@ struct Sel {
 
   static __device__ __forceinline__ key_t inf() { return (key_t)~(key_t)0; }
   int drop;           // FAST only: low proxy bits discarded (0 in production; tests raise it to force ties)
+  uint32_t dmask;     // ~0 << drop
   __device__ __forceinline__ key_t mk(uint64_t ordered) const {
-    if constexpr (FAST) return ((uint32_t)(ordered >> 32) >> drop) << drop;
+    if constexpr (FAST) return (uint32_t)(ordered >> 32) & dmask;
     else return ordered;
   }
   __device__ __forceinline__ void init(int f_, int lane_, int drop_ = 0) {
     drop = drop_;
+    dmask = drop_ >= 32 ? 0u : (0xFFFFFFFFu << drop_);
     key = tk = inf();
     idx = ti = 0xFFFFFFFFu;
     tie = false;
@@ -431,7 +433,7 @@ struct Sel {
     return true;
   }
   __device__ __forceinline__ key_t table_key(const RangeTable& tb, int64_t e) const {
-    if constexpr (FAST) return (tb.khi[e] >> drop) << drop;
+    if constexpr (FAST) return tb.khi[e] & dmask;
     else return ((uint64_t)tb.khi[e] << 32) | tb.klo[e];
   }
   // FAST only.  The whole row from the table, without a serial insert chain: with T = lambda/deg * 2^32
@@ -504,8 +506,7 @@ struct Sel {
             k4 = *(const uint4*)(tb.khi + ent + cur);
             j4 = *(const uint4*)(tb.js + ent + cur);
           }
-          const uint32_t ks[4] = {(k4.x >> drop) << drop, (k4.y >> drop) << drop, (k4.z >> drop) << drop,
-                                  (k4.w >> drop) << drop};
+          const uint32_t ks[4] = {k4.x & dmask, k4.y & dmask, k4.z & dmask, k4.w & dmask};
           const uint32_t jj[4] = {j4.x, j4.y, j4.z, j4.w};
           bool pass = active;
 #pragma unroll
