@@ -155,6 +155,11 @@ class GbmlConfigPbWrapper:
         return [f] * self.num_hops
 
     @property
+    def num_max_training_samples_to_output(self) -> int:
+        """0 = no cap (gbml_config.proto:111; downsampleNumberOfNodes, SGSPureSparkV1Task.scala:1042-1081)"""
+        return int(_get(self.doc, "datasetConfig.subgraphSamplerConfig.numMaxTrainingSamplesToOutput", 0) or 0)
+
+    @property
     def num_positive_samples(self) -> int:
         return int(_get(self.doc, "datasetConfig.subgraphSamplerConfig.numPositiveSamples", 0) or 0)
 

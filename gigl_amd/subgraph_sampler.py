@@ -159,6 +159,9 @@ class SubgraphSampler:
         pm = cfg.preprocessed_metadata.nodes[0]
         unl = _PartWriter(cfg.unlabeled_tfrecord_uri_prefix)
         lab = _PartWriter(cfg.labeled_tfrecord_uri_prefix)
+        # numMaxTrainingSamplesToOutput: the reference keeps an arbitrary `LIMIT n` of the training samples
+        # (downsampleNumberOfNodes, SGSPureSparkV1Task.scala:1042-1081); here: the first n in node-id order
+        limit = cfg.num_max_training_samples_to_output
         for i in range(0, ids.size, batch_size):
             chunk = ids[i:i + batch_size]
             tree = eng.sample_khop(chunk, cfg.fanouts, sampling_seed=svc.sampling_seed)
@@ -166,7 +169,10 @@ class SubgraphSampler:
             unl.add(buf.cpu().numpy(), off.cpu().numpy())
             sfx, sfx_off = _encode_labels(pm.label_keys, labels, chunk)
             has_label = torch.from_numpy(np.diff(sfx_off) > 0).to(eng.device)
-            emit = (has_label & (tree.cnt[0] > 0)).to(torch.uint8)  # isolated nodes produce no training samples
+            emit = has_label & (tree.cnt[0] > 0)  # isolated nodes produce no training samples
+            if limit > 0:
+                emit = emit & ((torch.cumsum(emit.to(torch.int64), 0) + lab.n_records) <= limit)
+            emit = emit.to(torch.uint8)
             buf, off = eng.encode_records(tree, emit=emit, suffix=torch.from_numpy(sfx), suffix_off=torch.from_numpy(sfx_off))
             lab.add(buf.cpu().numpy(), off.cpu().numpy())
         return {"unlabeled": unl.close(), "labeled": lab.close()}
@@ -183,14 +189,18 @@ class SubgraphSampler:
         P = cfg.num_positive_samples
         main = _PartWriter(cfg.nablp_tfrecord_uri_prefix)
         rn = {t: _PartWriter(p) for t, p in cfg.random_negative_tfrecord_uri_prefixes.items()}
+        limit = cfg.num_max_training_samples_to_output  # LIMIT n of the main samples (first n in node-id order)
         for i in range(0, ids.size, max(1, batch_size // (1 + P))):
             chunk = ids[i:i + max(1, batch_size // (1 + P))]
             roots = eng._roots_tensor(chunk)
             pos, cnt = eng.sample_positives(roots, P, sampling_seed=svc.sampling_seed)
             grouped = torch.cat([roots.view(-1, 1), pos.view(-1, P)], dim=1).reshape(-1).contiguous()
             tree = eng.sample_khop(grouped, cfg.fanouts, sampling_seed=svc.sampling_seed)
+            emit = cnt > 0  # anchors need at least one positive
+            if limit > 0:
+                emit = emit & ((torch.cumsum(emit.to(torch.int64), 0) + main.n_records) <= limit)
             buf, off = eng.encode_records(tree, kind=_lib.REC_NODE_ANCHOR_LINK_PRED, trees_per_record=1 + P,
-                                          emit=(cnt > 0).to(torch.uint8))  # anchors need at least one positive
+                                          emit=emit.to(torch.uint8))
             main.add(buf.cpu().numpy(), off.cpu().numpy())
             if rn:
                 tree = eng.sample_khop(roots, cfg.fanouts, sampling_seed=svc.sampling_seed)

@@ -166,3 +166,21 @@ def test_sampler_split_generator_trainer_chain(workdir):
     hist = tr.training_process.trainer.history
     assert len(hist) == 3 and all(np.isfinite(h["loss"]) for h in hist)
     assert 0.0 <= metrics.metrics["acc"].value <= 1.0
+
+
+def test_subgraph_sampler_caps_training_samples(workdir):
+    """numMaxTrainingSamplesToOutput (downsampleNumberOfNodes): at most n labeled samples, all nodes keep their
+    RootedNodeNeighborhood"""
+    import yaml
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    doc = yaml.safe_load(open(os.path.join(workdir, "configs/snc_frozen_gbml_config.yaml")))
+    doc["datasetConfig"]["subgraphSamplerConfig"]["numMaxTrainingSamplesToOutput"] = 5
+    doc["sharedConfig"]["flattenedGraphMetadata"]["supervisedNodeClassificationOutput"] = {
+        "labeledTfrecordUriPrefix": "out/snc_cap/labeled/samples/", "unlabeledTfrecordUriPrefix": "out/snc_cap/unlabeled/samples/"}
+    with open(os.path.join(workdir, "configs/snc_cap.yaml"), "w") as fh:
+        yaml.safe_dump(doc, fh)
+    files = SubgraphSampler().run("job", "configs/snc_cap.yaml", None, uri_base=workdir, batch_size=4)
+    lab = [wire.SupervisedNodeClassificationSample.FromString(r) for f in files["labeled"] for r in wire.read_tfrecords(f)]
+    unl = [r for f in files["unlabeled"] for r in wire.read_tfrecords(f)]
+    assert len(lab) == 5 and len(unl) == 16
+    assert [s.root_node.node_id for s in lab] == [0, 1, 2, 3, 4]
