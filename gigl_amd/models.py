@@ -51,20 +51,56 @@ class SAGEConv(nn.Module):
         return torch.cat([self.lin_l.weight, wr], dim=1).contiguous()
 
 
+class JumpingKnowledge(nn.Module):
+    """layer-wise representations -> one embedding: "cat" | "max" | "lstm" attention, then a Linear to out_dim
+    (python/gigl/src/common/models/pyg/nn/models/jumping_knowledge.py:10-121; same parameter names: lstm, att,
+    output_linear)"""
+
+    def __init__(self, mode: str, hid_dim: int, out_dim: int, num_layers: Optional[int] = None,
+                 lstm_dim: Optional[int] = None):
+        super().__init__()
+        self.mode = mode.lower()
+        assert self.mode in ("cat", "max", "lstm")
+        self.lstm = self.att = None
+        if self.mode == "lstm":
+            assert num_layers is not None, "num_layers cannot be None for lstm mode"
+            lstm_dim = lstm_dim if lstm_dim else hid_dim
+            self.lstm = nn.LSTM(input_size=hid_dim, hidden_size=(num_layers * lstm_dim) // 2, bidirectional=True,
+                                batch_first=True)
+            self.att = nn.Linear(2 * ((num_layers * lstm_dim) // 2), 1)
+            self.output_linear = nn.Linear(hid_dim, out_dim)
+        elif self.mode == "cat":
+            assert num_layers is not None, "num_layers cannot be none for cat mode"
+            self.output_linear = nn.Linear(num_layers * hid_dim, out_dim)
+        else:
+            self.output_linear = nn.Linear(hid_dim, out_dim)
+
+    def forward(self, xs) -> torch.Tensor:
+        if self.mode == "cat":
+            return self.output_linear(torch.cat(xs, dim=-1))
+        if self.mode == "max":
+            return self.output_linear(torch.stack(xs, dim=-1).max(dim=-1)[0])
+        x = torch.stack(xs, dim=1)  # [num_nodes, num_layers, hid_dim]
+        alpha, _ = self.lstm(x)
+        alpha = torch.softmax(self.att(alpha).squeeze(-1), dim=-1)
+        return self.output_linear((x * alpha.unsqueeze(-1)).sum(dim=1))
+
+
 class GraphSAGE(nn.Module):
     """BasicHomogeneousGNN + GraphSAGE.init_conv_layers (python/gigl/src/common/models/pyg/homogeneous.py:30-153,
     171-202): per layer conv -> [activation | BatchNorm1d | activation] -> dropout (not after the last layer unless
     activation_after_last_conv), optional L2 normalisation, return_emb, final Linear.  conv_kwargs: aggr ("mean" |
-    "sum" | "max"), bias, root_weight (PyG SAGEConv).  jk_mode, feature embedding / interaction layers are not built.
-    State-dict keys follow the reference (conv_layers.{i}.lin_l/lin_r, batchnorm_layers.{i}, linear)."""
+    "sum" | "max"), bias, root_weight (PyG SAGEConv); jk_mode ("cat" | "max" | "lstm") adds the JumpingKnowledge
+    head over all layers' outputs (every conv then has hid_dim outputs and is followed by norm / activation).
+    Feature embedding / interaction layers are not built.
+    State-dict keys follow the reference (conv_layers.{i}.lin_l/lin_r, batchnorm_layers.{i}, jk_layer.*, linear)."""
 
     def __init__(self, in_dim: int, hid_dim: int, out_dim: int, num_layers: int = 2,
                  activation_after_last_conv: bool = False, should_l2_normalize_embedding_layer_output: bool = False,
                  activation_before_norm: bool = False, dropout: float = 0.0, batchnorm: bool = False,
-                 linear_layer: bool = False, return_emb: bool = False, jk_mode: Optional[str] = None, **conv_kwargs):
+                 linear_layer: bool = False, return_emb: bool = False, jk_mode: Optional[str] = None,
+                 jk_lstm_dim: Optional[int] = None, **conv_kwargs):
         super().__init__()
-        if jk_mode:
-            raise NotImplementedError("jk_mode (JumpingKnowledge) is not implemented")
         conv_kwargs = dict(conv_kwargs.get("conv_kwargs") or conv_kwargs)
         self.in_dim, self.hid_dim, self.out_dim, self.num_layers = in_dim, hid_dim, out_dim, num_layers
         self.activation_after_last_conv = activation_after_last_conv
@@ -77,14 +113,17 @@ class GraphSAGE(nn.Module):
             raise NotImplementedError(f"SAGEConv aggr={self.aggr!r} is not implemented (mean, sum, max)")
         bias = bool(conv_kwargs.get("bias", True))
         root_weight = bool(conv_kwargs.get("root_weight", True))
-        last = hid_dim if linear_layer else out_dim
+        last = hid_dim if (linear_layer or jk_mode) else out_dim
         self.conv_layers = nn.ModuleList([
             SAGEConv(in_dim if i == 0 else hid_dim, hid_dim if i < num_layers - 1 else last, bias=bias,
                      root_weight=root_weight) for i in range(num_layers)])
         self.dropout = nn.Dropout(p=dropout)
         self.batchnorm = batchnorm
         if batchnorm:
-            self.batchnorm_layers = nn.ModuleList([nn.BatchNorm1d(hid_dim) for _ in range(num_layers - 1)])
+            self.batchnorm_layers = nn.ModuleList([nn.BatchNorm1d(hid_dim)
+                                                   for _ in range(num_layers if jk_mode else num_layers - 1)])
+        self.jk_layer = (JumpingKnowledge(jk_mode, hid_dim, out_dim if not linear_layer else hid_dim, num_layers,
+                                          jk_lstm_dim) if jk_mode else None)
         self.return_emb, self.linear_layer = return_emb, linear_layer
         if linear_layer:
             self.linear = nn.Linear(hid_dim, out_dim)
@@ -94,11 +133,11 @@ class GraphSAGE(nn.Module):
     def _plain(self) -> bool:
         """conv -> relu only: what the fused kernels' epilogue and the one-call plan compute"""
         return (not self.batchnorm and self.dropout.p == 0.0 and not self.linear_layer
-                and not self.activation_before_norm)
+                and not self.activation_before_norm and self.jk_layer is None)
 
     def _post(self, h: torch.Tensor, l: int, fused_act: bool) -> torch.Tensor:
         """what follows conv l (homogeneous.py:126-141); fused_act: relu already applied by the kernel epilogue"""
-        if l == self.num_layers - 1 and not self.activation_after_last_conv:
+        if l == self.num_layers - 1 and not self.activation_after_last_conv and self.jk_layer is None:
             return h
         if self._plain:
             return h if fused_act else torch.relu(h)
@@ -129,11 +168,15 @@ class GraphSAGE(nn.Module):
             if eng is None:
                 raise RuntimeError("GraphSAGE.forward(GraphData) needs the HipEngine (model.engine = eng)")
             h = batch.x
+            xs = []
             for l, conv in enumerate(self.conv_layers):
                 fused = self._plain and (l < self.num_layers - 1 or self.activation_after_last_conv)
                 w_r = conv.lin_r.weight if conv.lin_r is not None else torch.zeros_like(conv.lin_l.weight)
                 h = sage_conv(h, conv.lin_l.weight, conv.lin_l.bias, w_r, eng, batch, fused, self.aggr)
                 h = self._post(h, l, fused)
+                xs.append(h)
+            if self.jk_layer is not None:
+                h = self.jk_layer(xs)
             return self._head(h)
         with torch.no_grad():
             return self._forward_union(batch)
@@ -144,6 +187,7 @@ class GraphSAGE(nn.Module):
         assert u.hops == L, "one hop per layer"
         cap = int(u.nodes.numel())
         h = None
+        xs = []
         for l, conv in enumerate(self.conv_layers):
             n_rows = u.meta[GIGL_META_LEVEL0 + (L - 1 - l): GIGL_META_LEVEL0 + (L - l)]
             d = conv.in_channels
@@ -159,6 +203,14 @@ class GraphSAGE(nn.Module):
                            out=self._buf("h", l, cap, conv.out_channels))
             if not self._plain:
                 h = self._post(h, l, fused).contiguous()
+            xs.append(h)
+        if self.jk_layer is not None:
+            # layer l's output exists for the nodes of level <= L-1-l; the roots (a prefix of every layer's rows)
+            # are the only nodes whose representation is complete at all layers: JK is taken over them
+            n_roots = int(u.meta[GIGL_META_LEVEL0].item())
+            out = torch.zeros((cap, self.jk_layer.output_linear.out_features), dtype=torch.float32, device=h.device)
+            out[:n_roots] = self.jk_layer([x[:n_roots] for x in xs])
+            h = out
         return self._head(h)
 
     def make_plan(self, eng: HipEngine, b: int, fanouts: Sequence[int], groups: int = 1):

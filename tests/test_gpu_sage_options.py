@@ -31,10 +31,11 @@ def _ref_conv(x, ei, wl, bl, wr, aggr):
 
 def _ref_forward(model, x, ei):
     h = x
+    xs = []
     L = model.num_layers
     for l, conv in enumerate(model.conv_layers):
         h = _ref_conv(h, ei, conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight, model.aggr)
-        if l == L - 1 and not model.activation_after_last_conv:
+        if l == L - 1 and not model.activation_after_last_conv and model.jk_layer is None:
             break
         if model.activation_before_norm:
             h = torch.relu(h)
@@ -43,6 +44,9 @@ def _ref_forward(model, x, ei):
         if not model.activation_before_norm:
             h = torch.relu(h)
         h = model.dropout(h)
+        xs.append(h)
+    if model.jk_layer is not None:
+        h = model.jk_layer(xs)
     if model.should_l2_normalize_embedding_layer_output:
         h = torch.nn.functional.normalize(h, p=2, dim=1)
     if model.return_emb:
@@ -102,7 +106,8 @@ def test_max_gradient_is_shared_among_ties():
 @pytest.mark.parametrize("opts", [dict(batchnorm=True), dict(batchnorm=True, activation_before_norm=True),
                                   dict(linear_layer=True), dict(linear_layer=True, return_emb=True),
                                   dict(activation_after_last_conv=True, should_l2_normalize_embedding_layer_output=True),
-                                  dict(dropout=0.5)])
+                                  dict(dropout=0.5), dict(jk_mode="cat"), dict(jk_mode="max", batchnorm=True),
+                                  dict(jk_mode="lstm", linear_layer=True)])
 def test_model_options_eval_mode(opts):
     from gigl_amd.engine import HipEngine
     eng = HipEngine(0)
@@ -122,6 +127,7 @@ def test_model_options_eval_mode(opts):
     sd = model.state_dict()
     assert "conv_layers.0.lin_l.weight" in sd and ("linear.weight" in sd) == bool(opts.get("linear_layer"))
     assert ("batchnorm_layers.0.running_mean" in sd) == bool(opts.get("batchnorm"))
+    assert ("jk_layer.output_linear.weight" in sd) == bool(opts.get("jk_mode"))
     eng.close()
 
 
@@ -144,7 +150,7 @@ def test_union_inference_with_options_matches_whole_graph():
     tree = eng.sample_khop(roots, [6, 4])
     u = eng.union_build(tree)
     torch.manual_seed(2)
-    model = GraphSAGE(d, 16, 5, num_layers=2, aggr="max", batchnorm=True, linear_layer=True).eval()
+    model = GraphSAGE(d, 16, 5, num_layers=2, aggr="max", batchnorm=True, linear_layer=True, jk_mode="cat").eval()
     with torch.no_grad():
         model.batchnorm_layers[0].running_mean.uniform_(-0.5, 0.5)
     nodes, rp, col = u.to_csr()
