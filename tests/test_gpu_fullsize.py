@@ -1,0 +1,176 @@
+"""Size-independent properties at BASELINE.json's full single-GPU size (configs[1]: products-shaped graph,
+N = 2,449,029, ~118 M directed edges, D = 100, fanout [25, 10], B = 1024) — where the CPU oracle would need minutes
+per batch, the domain's own invariants are checked on the device instead:
+  sampling   every parent gets exactly min(deg, f) neighbours, ascending and duplicate-free, all of them real
+             in-edges (binary search in the resident CSC); a root's subtree depends only on the root (the same roots
+             in another batch composition give the same subtrees); repeated calls are identical; a random subset of
+             rows is compared with the oracle's hash permutation
+  union      local ids are a bijection onto the distinct sampled nodes, rows are ascending and duplicate-free, and
+             the union's edge set equals the set of sampled (src, dst) pairs (checksum of sorted 64-bit keys)
+  forward    the one-call plan (leaf-global union, grouped launches) == the step-by-step entry points to 2e-6
+  records    the device-encoded TFRecords decode (CRCs verified) to exactly the sampled trees"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gigl_amd import wire
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INV = 0xFFFFFFFF
+
+
+@pytest.fixture(scope="module")
+def world():
+    sys.path.insert(0, ROOT)
+    import bench
+    from gigl_amd.engine import HipEngine
+
+    class A:
+        small, workload = False, "products"
+    eng = HipEngine(0)
+    n, d = bench.build_workload(eng, A)
+    rowptr, col = eng.graph_to_host()
+    g = torch.Generator().manual_seed(7)
+    roots = torch.randperm(n, generator=g)[:4096].to(torch.int32).to(eng.device)
+    yield eng, n, d, rowptr, col, roots
+    eng.close()
+
+
+def test_sampling_invariants(world):
+    eng, n, d, rowptr_h, col_h, roots = world
+    dev = eng.device
+    fan = [25, 10]
+    rowptr = torch.from_numpy(rowptr_h).to(dev)
+    col = torch.from_numpy(col_h.astype(np.int64)).to(dev)
+    deg = rowptr[1:] - rowptr[:-1]
+    # globally sorted (row, col) keys: rows ascending, columns ascending inside a row
+    row_of = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+    keys = (row_of << 32) | col
+    assert bool((keys[1:] > keys[:-1]).all())  # the resident CSC itself: ascending, duplicate-free rows
+    tree = eng.sample_khop(roots[:1024], fan)
+    again = eng.sample_khop(roots[:1024], fan)
+    parents = roots[:1024].to(torch.int64) & INV
+    for k, f in enumerate(fan):
+        nbr = tree.nbr[k].to(torch.int64) & INV
+        cnt = tree.cnt[k].to(torch.int64)
+        assert torch.equal(tree.nbr[k], again.nbr[k]) and torch.equal(tree.cnt[k], again.cnt[k])  # idempotent
+        pvalid = parents != INV
+        want = torch.where(pvalid, torch.minimum(deg[parents.clamp(max=n - 1)], torch.tensor(f, device=dev)),
+                           torch.zeros_like(parents))
+        assert torch.equal(cnt, want)  # exactly min(deg, f), 0 under an empty parent
+        m = nbr.view(-1, f)
+        slot = torch.arange(f, device=dev).view(1, -1)
+        filled = slot < cnt.view(-1, 1)
+        assert bool(((m != INV) == filled).all())  # valid entries first, then padding
+        asc = (m[:, 1:] > m[:, :-1]) | ~filled[:, 1:]
+        assert bool(asc.all())  # ascending ids: duplicate-free
+        q = (parents.view(-1, 1) << 32) | m
+        q = q[filled]
+        pos = torch.searchsorted(keys, q)
+        assert bool((keys[pos.clamp(max=keys.numel() - 1)] == q).all())  # every sampled edge is an in-edge
+        parents = nbr
+    # a root's subtree is a function of the root alone: another batch composition, same subtrees
+    perm = torch.randperm(1024, generator=torch.Generator().manual_seed(1)).to(dev)
+    mixed = torch.cat([roots[:1024][perm][:512], roots[2048:2560]])
+    t2 = eng.sample_khop(mixed, fan)
+    a0 = tree.nbr[0].view(1024, 25)[perm][:512]
+    a1 = tree.nbr[1].view(1024, 250)[perm][:512]
+    assert torch.equal(t2.nbr[0].view(1024, 25)[:512], a0) and torch.equal(t2.nbr[1].view(1024, 250)[:512], a1)
+    # oracle spot check: 300 hop-2 parents of moderate degree against the restated hash permutation
+    par = (tree.nbr[0].to(torch.int64) & INV).cpu().numpy()
+    rts = np.repeat((roots[:1024].to(torch.int64) & INV).cpu().numpy(), 25)
+    got = (tree.nbr[1].to(torch.int64) & INV).view(-1, 10).cpu().numpy()
+    dg = np.diff(rowptr_h)
+    cand = np.flatnonzero((par != INV) & (dg[np.minimum(par, n - 1)] > 10) & (dg[np.minimum(par, n - 1)] < 5000))
+    rng = np.random.default_rng(0)
+    for i in rng.choice(cand, size=300, replace=False):
+        p = int(par[i])
+        row = col_h[rowptr_h[p]:rowptr_h[p + 1]]
+        want = np.sort(oracle.hash_permutation(row, (int(rts[i]) + p) & INV, sampling_seed=84, counter=1)[:10])
+        assert np.array_equal(got[i], want)
+
+
+def test_union_invariants_and_edge_set(world):
+    eng, n, d, rowptr_h, col_h, roots = world
+    dev = eng.device
+    fan = [25, 10]
+    tree = eng.sample_khop(roots[1024:2048], fan)
+    u = eng.union_build(tree)
+    c = u.counts()
+    nn, ne = c["n_nodes"], c["n_edges"]
+    nodes = u.nodes[:nn].to(torch.int64) & INV
+    assert int(torch.unique(nodes).numel()) == nn  # local ids <-> distinct global ids
+    sampled = torch.cat([roots[1024:2048].to(torch.int64) & INV] + [t.to(torch.int64) & INV for t in tree.nbr])
+    assert torch.equal(torch.unique(sampled[sampled != INV]), torch.sort(nodes).values)
+    assert torch.equal(nodes[u.root_local[:1024].to(torch.int64)], roots[1024:2048].to(torch.int64) & INV)
+    rp, re_ = u.rowptr[:nn].to(torch.int64), u.rowend[:nn].to(torch.int64)
+    lens = re_ - rp
+    assert int(lens.sum()) == ne
+    dst_l = torch.repeat_interleave(torch.arange(nn, device=dev), lens)
+    idx = torch.repeat_interleave(rp - torch.cumsum(lens, 0) + lens, lens) + torch.arange(ne, device=dev)
+    src_l = u.col.to(torch.int64)[idx]
+    k_union = (dst_l << 32) | src_l
+    assert bool((k_union[1:] > k_union[:-1]).all())  # rows ascending and duplicate-free, rows in id order
+    got = torch.sort((nodes[dst_l] << 32) | nodes[src_l]).values
+    # the sampled (dst, src) pairs of the tree
+    r64 = roots[1024:2048].to(torch.int64) & INV
+    n0 = tree.nbr[0].to(torch.int64) & INV
+    n1 = tree.nbr[1].to(torch.int64) & INV
+    e0 = (torch.repeat_interleave(r64, 25) << 32) | n0
+    e1 = (torch.repeat_interleave(n0, 10) << 32) | n1
+    want = torch.unique(torch.cat([e0[n0 != INV], e1[n1 != INV]]))
+    assert torch.equal(got, want)  # the union's edge set == the set of sampled pairs (sum of keys is then equal too)
+
+
+def test_plan_equals_stepwise_at_full_size(world):
+    from gigl_amd.models import GraphSAGE, HipBatch
+    eng, n, d, rowptr_h, col_h, roots = world
+    torch.manual_seed(0)
+    model = GraphSAGE(d, 256, 47, num_layers=2).to(eng.device)
+    fan = [25, 10]
+    plan = model.make_plan(eng, 1024, fan, groups=4)
+    out = plan.run(roots.view(-1))
+    hb = plan.last_batch_to_host()
+    assert hb["meta"][8] == 0
+    for g in range(4):
+        r = roots[g * 1024:(g + 1) * 1024]
+        tree = eng.sample_khop(r, fan)
+        u = eng.union_build(tree)
+        ref = model(HipBatch(eng, tree, u))[u.root_local[:1024].long()]
+        torch.testing.assert_close(out[g * 1024:(g + 1) * 1024], ref, rtol=2e-6, atol=2e-6)
+    plan.close()
+
+
+def test_records_round_trip_at_full_size(world):
+    eng, n, d, rowptr_h, col_h, roots = world
+    fan = [25, 10]
+    r = roots[:2048]
+    tree = eng.sample_khop(r, fan)
+    buf, off = eng.encode_records(tree)
+    data = buf.cpu().numpy().tobytes()
+    off_h = off.cpu().numpy()
+    nbr0 = (tree.nbr[0].to(torch.int64) & INV).view(-1, 25).cpu().numpy()
+    nbr1 = (tree.nbr[1].to(torch.int64) & INV).view(-1, 250).cpu().numpy()
+    roots_h = (r.to(torch.int64) & INV).cpu().numpy()
+    assert off_h[-1] == len(data)
+    # frame-level walk of the whole buffer (every CRC), full decode of every 64th record
+    n_frames = sum(1 for _ in wire.iter_tfrecords(data))
+    assert n_frames == 2048
+    x_host = None
+    for i in range(0, 2048, 64):
+        rec = next(iter(wire.iter_tfrecords(data[off_h[i]:off_h[i + 1]])))
+        m = wire.RootedNodeNeighborhood.FromString(rec)
+        assert m.root_node.node_id == roots_h[i]
+        e_want = [(int(s), int(roots_h[i])) for s in nbr0[i] if s != INV]
+        for j, a in enumerate(nbr0[i]):
+            if a != INV:
+                e_want += [(int(s), int(a)) for s in nbr1[i][j * 10:(j + 1) * 10] if s != INV]
+        assert [(e.src_node_id, e.dst_node_id) for e in m.neighborhood.edges] == e_want
+        ids = [nd.node_id for nd in m.neighborhood.nodes]
+        assert len(set(ids)) == len(ids) and set(ids) == {s for s, _ in e_want} | {int(roots_h[i])}
+        assert all(nd.feature_values.size == d for nd in m.neighborhood.nodes)
