@@ -35,7 +35,7 @@ SYMBOLS = [
     "gigl_union_build_groups", "gigl_sage_plan_set_groups", "gigl_records_capacity", "gigl_records_encode",
     "gigl_tfrecord_index", "gigl_tfexample_decode", "gigl_collate_records", "gigl_collated_info", "gigl_collated_copy",
     "gigl_collated_destroy", "gigl_gather_reduce", "gigl_gather_reduce_backward",
-    "gigl_frontier_bucket", "gigl_frontier_scatter",
+    "gigl_frontier_bucket", "gigl_frontier_scatter", "gigl_avro_embeddings_layout", "gigl_avro_embeddings_encode",
 ]
 
 KERNEL_IDS = {
@@ -168,6 +168,8 @@ def load() -> C.CDLL:
         "gigl_collated_copy": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "gigl_collated_destroy": [vp],
         "gigl_tfexample_decode": [vp, vp, vp, i64, P(GiglColumn), i32, i32, P(i64)],
+        "gigl_avro_embeddings_layout": [i64, i32, i32, P(i32), P(i64), P(i64)],
+        "gigl_avro_embeddings_encode": [vp, vp, vp, i64, i64, i32, C.c_char_p, i32, C.c_char_p, vp, i64, vp, vp, vp],
         "gigl_records_capacity": [P(i32), i32, i32, P(GiglRecordOpts), i64, i64, P(i64)],
         "gigl_records_encode": [vp, vp, P(GiglTree), vp, P(GiglRecordOpts), i64, vp, i64, vp, vp],
         "gigl_gcn_aggregate": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, vp],

@@ -91,6 +91,8 @@ int32_t gigl_graph_compute_maxdeg(gigl_ctx* ctx, gigl_graph* g);
 // union build with the plan-internal leaf-global option (union.hip)
 int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree, int32_t group_roots,
                               gigl_union* out, int32_t leaf_global);
+// exclusive scan of n int64 sizes on ctx->stream (one workgroup); out[n] = total, *status = total > cap (serialize.hip)
+void gigl_scan_i64(gigl_ctx* ctx, const int64_t* sizes, int64_t n, int64_t cap, int64_t* out, int32_t* status);
 // gather + reduce where the rows i >= *n_local_rows_dev hold GLOBAL source ids (no gather_ids translation): the
 // plan's layer-0 gather over a leaf-global union (agg.hip); n_local_rows_dev == NULL: every row is translated
 int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* gather_ids,

@@ -750,6 +750,10 @@ int hvlen(uint64_t v) {
 
 }  // namespace
 
+void gigl_scan_i64(gigl_ctx* ctx, const int64_t* sizes, int64_t n, int64_t cap, int64_t* out, int32_t* status) {
+  hipLaunchKernelGGL(record_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, sizes, n, cap, out, status);
+}
+
 extern "C" {
 
 int32_t gigl_records_capacity(const int32_t* fanouts, int32_t hops, int32_t d, const gigl_record_opts* opts,

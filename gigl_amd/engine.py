@@ -359,6 +359,34 @@ class HipEngine:
         del keep
         return out[: int(rec_off[-1].item())], rec_off
 
+    def encode_avro_embeddings(self, ids: torch.Tensor, emb: torch.Tensor, node_type: str, sync_marker: bytes):
+        """(ids [n], emb [n, D]) -> Avro data blocks of `Embedding` records, encoded on the device
+        (gigl_avro_embeddings_encode).  -> (uint8 device tensor of the blocks, int64 device tensor rec_off[n])"""
+        assert len(sync_marker) == 16 and ids.dim() == 1 and emb.dim() == 2 and emb.shape[0] == ids.numel()
+        ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
+        emb = emb.to(device=self.device, dtype=torch.float32)
+        if emb.stride(1) != 1 and emb.numel():
+            emb = emb.contiguous()
+        n, d = int(ids.numel()), int(emb.shape[1])
+        stride = int(emb.stride(0)) if n > 1 else d
+        ty = node_type.encode("utf-8")
+        per, nblk, cap = C.c_int32(), C.c_int64(), C.c_int64()
+        rc = self._lib.gigl_avro_embeddings_layout(n, d, len(ty), C.byref(per), C.byref(nblk), C.byref(cap))
+        if rc != 0:
+            raise ValueError(f"node type of {len(ty)} UTF-8 bytes is too long for the device encoder")
+        out = torch.empty(max(cap.value, 1), dtype=torch.uint8, device=self.device)
+        rec_off = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        scal = torch.zeros(2, dtype=torch.int64, device=self.device)  # total bytes | status (int32 in the low half)
+        check(self._lib.gigl_avro_embeddings_encode(
+            self._ctx, C.c_void_p(ids.data_ptr()), C.c_void_p(emb.data_ptr()), max(stride, d), n, d, ty, len(ty),
+            bytes(sync_marker), C.c_void_p(out.data_ptr()), cap.value, C.c_void_p(rec_off.data_ptr()),
+            C.c_void_p(scal.data_ptr()), C.c_void_p(scal.data_ptr() + 8)), self._ctx)
+        self._stream.synchronize()
+        total, status = (int(v) for v in scal.tolist())
+        if status & 0xFFFFFFFF:
+            raise RuntimeError("gigl_avro_embeddings_encode: output capacity too small (status=1)")
+        return out[:total], rec_off[:n]
+
     def union_capacity(self, b: int, fanouts: Sequence[int]):
         fo = (C.c_int32 * len(fanouts))(*[int(f) for f in fanouts])
         cn, ce = C.c_int64(), C.c_int64()

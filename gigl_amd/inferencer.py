@@ -61,7 +61,14 @@ class Inferencer:
                 out_files["predictions"] = resolve_uri(v["predictionsPath"], cfg.uri_base)
         for p in out_files.values():
             os.makedirs(os.path.dirname(p) or ".", exist_ok=True)
-        if "embeddings" in out_files:
+        # an embeddingsPath ending in "/" is a directory of Avro shards written by the device-side EmbeddingExporter
+        # (the format the reference's exporter hands to BigQuery, python/gigl/common/data/export.py); a file path
+        # keeps the line-per-root JSON output
+        exporter = None
+        if out_files.get("embeddings", "").endswith("/"):
+            from .export import EmbeddingExporter
+            exporter = EmbeddingExporter(out_files["embeddings"], min_shard_size_threshold_bytes=1 << 28)
+        elif "embeddings" in out_files:
             emb_fh = open(out_files["embeddings"], "w")
         if "predictions" in out_files:
             pred_fh = open(out_files["predictions"], "w")
@@ -76,7 +83,10 @@ class Inferencer:
                 else:  # link prediction plugins take the RootedNodeNeighborhoodBatch (utils.py:78-228)
                     batch = rnn
                 res = inferencer.infer_batch(batch=batch, device=dev)
-                emb = res.embeddings.cpu() if res.embeddings is not None else None
+                if exporter is not None and res.embeddings is not None:
+                    ids = torch.tensor([r.id for r in batch.root_nodes], dtype=torch.int64)
+                    exporter.add_embedding(ids, res.embeddings, str(cfg.node_types[0]))
+                emb = res.embeddings.cpu() if res.embeddings is not None and emb_fh is not None else None
                 pred = res.predictions.cpu() if res.predictions is not None else None
                 for i, root in enumerate(batch.root_nodes):  # one row per root, in batch order
                     if emb_fh is not None and emb is not None:
@@ -85,6 +95,8 @@ class Inferencer:
                         pred_fh.write(json.dumps({"node_id": root.id, "pred": int(pred[i])}) + "\n")
                     n_rows += 1
         finally:
+            if exporter is not None:
+                exporter.flush_embeddings()
             for fh in (emb_fh, pred_fh):
                 if fh is not None:
                     fh.close()

@@ -285,6 +285,27 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
                             const gigl_record_opts* opts, int64_t n_records, uint8_t* out, int64_t out_cap,
                             int64_t* rec_off, int32_t* status);
 
+/* ---- inference output: (node id, embedding row) batches -> Avro object-container DATA BLOCKS, encoded on the device.
+ *      Replaces the record loop of EmbeddingExporter.add_embedding (python/gigl/common/data/export.py:103-135:
+ *      {"node_id": int(id), "node_type": type, "emb": row.tolist()} through fastavro.writer) for AVRO_SCHEMA
+ *      (export.py:34-43: record Embedding {node_id: long, node_type: string, emb: array<float>}).
+ * Encoding per the Apache Avro 1.x specification (fastavro, the reference's writer, is a third-party package):
+ * long = zig-zag varint, string = long length + UTF-8, float = 4 bytes LE, array = long count + items + long 0
+ * (only the 0 when empty); a data block = long record count | long byte size | records | 16-byte sync marker.
+ * The file header (magic, metadata map with the schema, sync marker) is host work (gigl_amd/export.py).
+ * gigl_avro_embeddings_layout: records per data block (~16 kB blocks, the writer's sync interval), the number
+ * of blocks and an upper bound of the bytes `n` records of dimension `dim` take.
+ * gigl_avro_embeddings_encode: ids [n] int64, emb [n, dim] fp32 with `emb_stride` floats between rows, out: all
+ * DEVICE; type_utf8 / sync_marker (16 bytes): HOST.  rec_off[i] = byte offset of record i in `out` (device, [n]);
+ * *total_bytes (device) = bytes written; *status (device) = 1 and nothing written when they exceed out_cap.
+ * Copies the type / marker bytes to the device first (one small synchronous upload), then never synchronises. */
+int32_t gigl_avro_embeddings_layout(int64_t n, int32_t dim, int32_t type_len, int32_t* records_per_block,
+                                    int64_t* n_blocks, int64_t* bytes);
+int32_t gigl_avro_embeddings_encode(gigl_ctx* ctx, const int64_t* ids, const float* emb, int64_t emb_stride,
+                                    int64_t n, int32_t dim, const uint8_t* type_utf8, int32_t type_len,
+                                    const uint8_t* sync_marker, uint8_t* out, int64_t out_cap, int64_t* rec_off,
+                                    int64_t* total_bytes, int32_t* status);
+
 /* ---- batch union graph ("collate"): replaces GraphBuilder.add_graph_data/add_edge dedup
  *      (python/gigl/src/common/graph_builder/abstract_graph_builder.py:49-150), the collate
  *      functions (python/gigl/src/training/v1/lib/data_loaders/

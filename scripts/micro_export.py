@@ -1,0 +1,26 @@
+"""timing of the device-side Avro embedding encoder (gigl_avro_embeddings_encode) at the products-sized output"""
+import time
+
+import torch
+
+from gigl_amd.engine import HipEngine
+
+eng = HipEngine(0)
+for n, d in ((2_449_029, 128), (2_449_029, 32), (1_000_000, 768)):
+    emb = torch.randn(n, d, device=eng.device)
+    ids = torch.randperm(n, device=eng.device)
+    for _ in range(2):
+        blocks, off = eng.encode_avro_embeddings(ids, emb, "user", bytes(16))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    R = 5
+    for _ in range(R):
+        blocks, off = eng.encode_avro_embeddings(ids, emb, "user", bytes(16))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / R
+    t0 = time.perf_counter()
+    host = blocks.cpu()
+    t1 = time.perf_counter() - t0
+    print(f"n={n} d={d}: {blocks.numel() / 1e6:.1f} MB in {dt * 1e3:.2f} ms = {blocks.numel() / dt / 1e9:.1f} GB/s of Avro bytes "
+          f"({n / dt / 1e6:.1f} M records/s); device->host copy {t1 * 1e3:.1f} ms")
+    del emb, ids, blocks, off, host

@@ -144,6 +144,35 @@ def test_trainer_then_inferencer(workdir, golden_dir):
         assert p["node_id"] == row["node_id"] and p["pred"] == int(np.argmax(want[row["node_id"]]))
 
 
+def test_inferencer_avro_embedding_shards(workdir):
+    """an embeddingsPath that names a directory gets the reference exporter's Avro shards (device-encoded); the decoded
+    records equal the line-per-root JSON output of the same run configuration"""
+    import yaml
+    from gigl_amd.inferencer import Inferencer
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    from gigl_amd.trainer import Trainer
+    from oracle import avro
+    cfg_uri = "configs/snc_frozen_gbml_config.yaml"
+    SubgraphSampler().run("job", cfg_uri, None, uri_base=workdir)
+    Trainer().run("job", cfg_uri, None, uri_base=workdir)
+    out_json = Inferencer().run("job", cfg_uri, None, uri_base=workdir)
+    rows = [json.loads(l) for l in open(out_json["embeddings"])]
+    doc = yaml.safe_load(open(os.path.join(workdir, cfg_uri)))
+    doc["sharedConfig"]["inferenceMetadata"]["nodeTypeToInferencerOutputInfoMap"]["user"]["embeddingsPath"] = \
+        "out/snc/inference/embeddings_avro/"
+    avro_cfg = "configs/snc_avro_gbml_config.yaml"
+    yaml.safe_dump(doc, open(os.path.join(workdir, avro_cfg), "w"))
+    out = Inferencer().run("job", avro_cfg, None, uri_base=workdir)
+    shards = sorted(os.listdir(out["embeddings"]))
+    assert shards == ["shard_00000000.avro"]
+    schema, recs = avro.read_embedding_file(open(os.path.join(out["embeddings"], shards[0]), "rb").read())
+    assert [f["name"] for f in schema["fields"]] == ["node_id", "node_type", "emb"]
+    assert len(recs) == 16 and [r["node_id"] for r in recs] == [r["node_id"] for r in rows]
+    for a, b in zip(recs, rows):
+        assert a["node_type"] == "user"
+        np.testing.assert_array_equal(np.array(a["emb"], np.float32), np.array(b["emb"], np.float32))
+
+
 def test_sampler_split_generator_trainer_chain(workdir):
     """sampler -> split generator -> trainer: the trainer reads the train/val/test files the split generator wrote
     (datasetMetadata.supervisedNodeClassificationDataset), as the reference's pipeline does"""
