@@ -36,6 +36,7 @@ SYMBOLS = [
     "gigl_tfrecord_index", "gigl_tfexample_decode", "gigl_collate_records", "gigl_collated_info", "gigl_collated_copy",
     "gigl_collated_destroy", "gigl_gather_reduce", "gigl_gather_reduce_backward",
     "gigl_frontier_bucket", "gigl_frontier_scatter", "gigl_avro_embeddings_layout", "gigl_avro_embeddings_encode",
+    "gigl_edge_ids", "gigl_union_edge_ids", "gigl_gat_aggregate_edge",
 ]
 
 KERNEL_IDS = {
@@ -168,6 +169,10 @@ def load() -> C.CDLL:
         "gigl_collated_copy": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "gigl_collated_destroy": [vp],
         "gigl_tfexample_decode": [vp, vp, vp, i64, P(GiglColumn), i32, i32, P(i64)],
+        "gigl_gat_aggregate_edge": [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, i32,
+                                    i64, vp, vp, vp, vp],
+        "gigl_edge_ids": [vp, vp, vp, vp, i64, vp],
+        "gigl_union_edge_ids": [vp, vp, P(GiglUnion), vp],
         "gigl_avro_embeddings_layout": [i64, i32, i32, P(i32), P(i64), P(i64)],
         "gigl_avro_embeddings_encode": [vp, vp, vp, i64, i64, i32, C.c_char_p, i32, C.c_char_p, vp, i64, vp, vp, vp],
         "gigl_records_capacity": [P(i32), i32, i32, P(GiglRecordOpts), i64, i64, P(i64)],

@@ -574,6 +574,127 @@ __global__ __launch_bounds__(256) void gat_gather_kernel(const float* __restrict
   }
 }
 
+// ---- GATConv with edge features (edge_dim) and EdgeAttrGATConv's edge messages
+// a_edge[p][hd] = <edge_attr[p], v_att[hd]>   with v_att[hd][k] = sum_c W_e[hd*C+c][k] * att_edge[hd][c] folded by
+// the caller: (W_e e) . att_edge == e . (W_e^T att_edge)     (one thread per (col position, head))
+__global__ void gat_edge_alpha_kernel(const float* __restrict__ edge_attr, int De, const float* __restrict__ v_att,
+                                      int heads, int64_t cap_edges, float* __restrict__ a_edge) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cap_edges * heads) return;
+  const int64_t p = t / heads;
+  const int hd = (int)(t % heads);
+  const float* e = edge_attr + p * De;
+  const float* v = v_att + (int64_t)hd * De;
+  float s = 0.f;
+  for (int k = 0; k < De; ++k) s += e[k] * v[k];
+  a_edge[t] = s;
+}
+
+constexpr int GAT_MAX_EDGE_DIM = 256;
+
+// As gat_gather_kernel, with e_ij += a_edge[p] for the edge stored at col position p.  The self loop carries the
+// MEAN of the row's (non-self) edge attributes (PyG add_self_loops(fill_value="mean")), hence — by linearity — the
+// mean of their a_edge, 0 for a row without in-edges.  w_msg != NULL (EdgeAttrGATConv, edge_attr_gat_conv.py:131-144):
+// the message is h_j + W_msg e_ij, so out_i += W_msg (sum_j alpha_ij e_ij) with the self loop's mean attribute.
+__global__ __launch_bounds__(256) void gat_edge_gather_kernel(
+    const float* __restrict__ h, const float* __restrict__ a_src, const float* __restrict__ a_dst,
+    const float* __restrict__ a_edge, const float* __restrict__ edge_attr, int De, const float* __restrict__ w_msg,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ n_rows_dev, int heads, int C, float slope, int concat,
+    const float* __restrict__ bias, int act, float* __restrict__ out) {
+  __shared__ float s_z[4][GAT_MAX_EDGE_DIM];
+  const int lane = threadIdx.x & 63, wl = threadIdx.x >> 6;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_rows = *n_rows_dev;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int HC = heads * C;
+  float* z = s_z[wl];
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    int cnt = 0;
+    for (int e = lane; e < m; e += 64) cnt += col[e0 + e] != i;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    const float inv_cnt = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+    for (int hd = 0; hd < heads; ++hd) {
+      const float ad = a_dst[(int64_t)i * heads + hd];
+      float ae_self = 0.f;
+      for (int e = lane; e < m; e += 64)
+        if (col[e0 + e] != i) ae_self += a_edge[(int64_t)(e0 + e) * heads + hd];
+      for (int off = 32; off > 0; off >>= 1) ae_self += __shfl_xor(ae_self, off, 64);
+      ae_self *= inv_cnt;
+      float self_e = a_src[(int64_t)i * heads + hd] + ad + ae_self;
+      self_e = self_e > 0.f ? self_e : slope * self_e;
+      float mx = self_e;
+      for (int e = lane; e < m; e += 64) {
+        const int j = col[e0 + e];
+        if (j == i) continue;
+        float x = a_src[(int64_t)j * heads + hd] + ad + a_edge[(int64_t)(e0 + e) * heads + hd];
+        x = x > 0.f ? x : slope * x;
+        mx = fmaxf(mx, x);
+      }
+      for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      float den = lane == 0 ? expf(self_e - mx) : 0.f;
+      for (int e = lane; e < m; e += 64) {
+        const int j = col[e0 + e];
+        if (j == i) continue;
+        float x = a_src[(int64_t)j * heads + hd] + ad + a_edge[(int64_t)(e0 + e) * heads + hd];
+        x = x > 0.f ? x : slope * x;
+        den += expf(x - mx);
+      }
+      for (int off = 32; off > 0; off >>= 1) den += __shfl_xor(den, off, 64);
+      const float inv = 1.0f / (den + 1e-16f);
+      const float al_self = expf(self_e - mx) * inv;
+      if (w_msg) {
+        // z[k] = sum_j alpha_ij e_ij[k] + alpha_self * mean_j e_ij[k]   (lanes over k)
+        for (int k = lane; k < De; k += 64) {
+          float zz = 0.f, mean = 0.f;
+          for (int e = 0; e < m; ++e) {
+            const int j = col[e0 + e];
+            if (j == i) continue;
+            float x = a_src[(int64_t)j * heads + hd] + ad + a_edge[(int64_t)(e0 + e) * heads + hd];
+            x = x > 0.f ? x : slope * x;
+            const float ev = edge_attr[(int64_t)(e0 + e) * De + k];
+            zz += expf(x - mx) * inv * ev;
+            mean += ev;
+          }
+          z[k] = zz + al_self * mean * inv_cnt;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int c = lane; c < C; c += 64) {
+        float acc = al_self * h[(int64_t)i * HC + hd * C + c];
+        for (int e = 0; e < m; ++e) {
+          const int j = col[e0 + e];
+          if (j == i) continue;
+          float x = a_src[(int64_t)j * heads + hd] + ad + a_edge[(int64_t)(e0 + e) * heads + hd];
+          x = x > 0.f ? x : slope * x;
+          acc += expf(x - mx) * inv * h[(int64_t)j * HC + hd * C + c];
+        }
+        if (w_msg) {
+          const float* wr = w_msg + (int64_t)(hd * C + c) * De;
+          float t = 0.f;
+          for (int k = 0; k < De; ++k) t += wr[k] * z[k];
+          acc += t;
+        }
+        if (concat) {
+          float v = acc + (bias ? bias[hd * C + c] : 0.f);
+          if (act == 1) v = v > 0.f ? v : 0.f;
+          out[(int64_t)i * HC + hd * C + c] = v;
+        } else {
+          float prev = hd == 0 ? 0.f : out[(int64_t)i * C + c];
+          float v = prev + acc / (float)heads;
+          if (hd == heads - 1) {
+            v += bias ? bias[c] : 0.f;
+            if (act == 1) v = v > 0.f ? v : 0.f;
+          }
+          out[(int64_t)i * C + c] = v;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 template <typename T>
 int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather_ids,
                       const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
@@ -733,6 +854,39 @@ int32_t gigl_gat_aggregate(gigl_ctx* ctx, const float* h, const float* att_src, 
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(gat_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, h, a_src, a_dst, rowptr,
                      rowend, col, n_rows_dev, heads, channels, negative_slope, concat, bias, act, out);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_gat_aggregate_edge(gigl_ctx* ctx, const float* h, const float* att_src, const float* att_dst,
+                                int32_t heads, int32_t channels, float negative_slope, int32_t concat,
+                                const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                const int32_t* n_nodes_dev, int64_t nodes_cap, const int32_t* n_rows_dev,
+                                int64_t rows_cap, const float* bias, int32_t act, const float* edge_attr,
+                                int32_t edge_dim, int64_t cap_edges, const float* att_edge_folded,
+                                const float* w_edge_msg, float* alpha_scratch, float* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, h && att_src && att_dst && rowptr && rowend && col && n_nodes_dev && n_rows_dev &&
+                        alpha_scratch && out && edge_attr && att_edge_folded, "null argument");
+  GIGL_REQUIRE(ctx, heads > 0 && channels > 0 && rows_cap >= 0 && nodes_cap >= rows_cap && cap_edges >= 0, "bad sizes");
+  GIGL_REQUIRE(ctx, edge_dim > 0 && edge_dim <= GAT_MAX_EDGE_DIM, "edge_dim %d outside [1,%d]", edge_dim,
+               GAT_MAX_EDGE_DIM);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  float* a_src = alpha_scratch;
+  float* a_dst = alpha_scratch + nodes_cap * heads;
+  float* a_edge = alpha_scratch + 2 * nodes_cap * heads;
+  hipLaunchKernelGGL(gat_alpha_kernel, dim3((unsigned)((nodes_cap * heads + 255) / 256)), dim3(256), 0, ctx->stream,
+                     h, att_src, att_dst, n_nodes_dev, heads, channels, a_src, a_dst);
+  if (cap_edges > 0)
+    hipLaunchKernelGGL(gat_edge_alpha_kernel, dim3((unsigned)((cap_edges * heads + 255) / 256)), dim3(256), 0,
+                       ctx->stream, edge_attr, edge_dim, att_edge_folded, heads, cap_edges, a_edge);
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(gat_edge_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, h, a_src, a_dst,
+                     a_edge, edge_attr, edge_dim, w_edge_msg, rowptr, rowend, col, n_rows_dev, heads, channels,
+                     negative_slope, concat, bias, act, out);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -90,6 +90,54 @@ int32_t gigl_graph_compute_maxdeg(gigl_ctx* ctx, gigl_graph* g) {
   return GIGL_OK;
 }
 
+
+namespace {
+// position of edge (src -> dst) in `col`: rowptr[dst] + index of src in the ascending row; -1 when absent
+__global__ __launch_bounds__(256) void edge_ids_kernel(const int64_t* __restrict__ rowptr,
+                                                       const uint32_t* __restrict__ col, int64_t n,
+                                                       const uint32_t* __restrict__ src,
+                                                       const uint32_t* __restrict__ dst, int64_t m,
+                                                       int64_t* __restrict__ eid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t s = src[i], d = dst[i];
+  int64_t r = -1;
+  if ((int64_t)d < n && s != GIGL_INVALID) {
+    int64_t lo = rowptr[d], hi = rowptr[d + 1];
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (col[mid] < s) lo = mid + 1;
+      else hi = mid;
+    }
+    if (lo < rowptr[d + 1] && col[lo] == s) r = lo;
+  }
+  eid[i] = r;
+}
+
+// the same lookup for every edge of a union graph, by position in its `col` buffer: one thread per row
+__global__ __launch_bounds__(256) void union_edge_ids_kernel(const int64_t* __restrict__ rowptr,
+                                                             const uint32_t* __restrict__ col, int64_t n,
+                                                             gigl_union u, int64_t* __restrict__ eid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= u.meta[GIGL_META_N_NODES]) return;
+  const uint32_t d = u.nodes[i];
+  const int32_t p0 = u.rowptr[i], p1 = u.rowend[i];
+  if (p1 <= p0 || (int64_t)d >= n) return;
+  const int64_t r0 = rowptr[d], r1 = rowptr[d + 1];
+  int64_t from = r0;  // the union row is ascending in LOCAL ids, not in global ids: search the whole row each time
+  for (int32_t p = p0; p < p1; ++p) {
+    const uint32_t s = u.nodes[u.col[p]];
+    int64_t lo = from, hi = r1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (col[mid] < s) lo = mid + 1;
+      else hi = mid;
+    }
+    eid[p] = (lo < r1 && col[lo] == s) ? lo : -1;
+  }
+}
+}  // namespace
+
 extern "C" int32_t gigl_graph_build_from_coo(gigl_ctx* ctx, int64_t n, int64_t e, const uint32_t* src,
                                              const uint32_t* dst, int32_t loc, int32_t is_directed,
                                              gigl_graph** out) {
@@ -199,5 +247,28 @@ extern "C" int32_t gigl_graph_build_from_coo(gigl_ctx* ctx, int64_t n, int64_t e
     }
   }
   *out = g;
+  return GIGL_OK;
+}
+
+extern "C" int32_t gigl_edge_ids(gigl_ctx* ctx, gigl_graph* g, const uint32_t* src, const uint32_t* dst, int64_t m,
+                      int64_t* eid) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, g && m >= 0 && (m == 0 || (src && dst && eid)), "null argument");
+  if (m == 0) return GIGL_OK;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(edge_ids_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream, g->rowptr,
+                     g->col, g->n, src, dst, m, eid);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+extern "C" int32_t gigl_union_edge_ids(gigl_ctx* ctx, gigl_graph* g, const gigl_union* u, int64_t* eid) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, g && u && eid && u->meta && u->nodes && u->rowptr && u->rowend && u->col, "null argument");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GIGL_HIP_CHECK(ctx, hipMemsetAsync(eid, 0xFF, (size_t)u->cap_edges * 8, ctx->stream));
+  hipLaunchKernelGGL(union_edge_ids_kernel, dim3((unsigned)((u->cap_nodes + 255) / 256)), dim3(256), 0, ctx->stream,
+                     g->rowptr, g->col, g->n, *u, eid);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -119,6 +119,7 @@ class HipEngine:
         assert other.device == self.device
         self._graph, self._graph_out, self._feat = other._graph, other._graph_out, other._feat
         self._feat_ptr = getattr(other, "_feat_ptr", None)
+        self._efeat = getattr(other, "_efeat", None)
         self.n_nodes, self.n_edges = other.n_nodes, other.n_edges
         self.feat_dim, self.feat_dtype = other.feat_dim, other.feat_dtype
         self._borrowed = True
@@ -205,6 +206,66 @@ class HipEngine:
             check(self._lib.gigl_memcpy(self._ctx, C.c_void_p(col.ctypes.data), LOC_HOST, cl, LOC_DEVICE,
                                         e.value * 4), self._ctx)
         return rowptr, col[: e.value]
+
+    # ---- edge features (S1 `_edge_features`, S6 hydrateEdges): one fp32 row per resident edge, in `col` order
+    @property
+    def edge_feat_dim(self) -> int:
+        ef = getattr(self, "_efeat", None)
+        return 0 if ef is None else int(ef.shape[1])
+
+    def edge_ids(self, src: torch.Tensor, dst: torch.Tensor, *, out_graph: bool = False) -> torch.Tensor:
+        """position of every edge src[i] -> dst[i] in the resident CSC `col` array (-1: no such edge)"""
+        g = self._graph_out if out_graph else self._graph
+        src = src.to(device=self.device).contiguous()
+        dst = dst.to(device=self.device).contiguous()
+        assert src.dtype in (torch.int32, torch.uint32) and dst.dtype == src.dtype and src.shape == dst.shape
+        eid = torch.empty(src.numel(), dtype=torch.int64, device=self.device)
+        check(self._lib.gigl_edge_ids(self._ctx, g, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()),
+                                      src.numel(), C.c_void_p(eid.data_ptr())), self._ctx)
+        return eid
+
+    def load_edge_features(self, src, dst, feats, is_directed: bool) -> None:
+        """edge feature rows given in the order of the COO list the graph was built from -> a table in `col` order.
+        Undirected graphs: the row of (a,b) also serves (b,a); where several input rows name the same edge the
+        first one in input order wins (the reference keeps an arbitrary one: dropDuplicates after canonicalising,
+        SGSPureSparkV1Task.scala:218-258)."""
+        def as_ids(v):
+            v = v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v).astype(np.int64))
+            return v.to(self.device).to(torch.int32)
+        s, d = as_ids(src), as_ids(dst)
+        f = feats if isinstance(feats, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(feats))
+        f = f.to(device=self.device, dtype=torch.float32)
+        assert f.dim() == 2 and f.shape[0] == s.numel()
+        m = s.numel()
+        row = torch.arange(m, device=self.device)
+        eid = self.edge_ids(s, d)
+        if not is_directed:
+            eid = torch.cat([eid, self.edge_ids(d, s)])
+            row = torch.cat([row, row])
+        self._stream.synchronize()
+        keep = eid >= 0
+        win = torch.full((self.n_edges,), m, dtype=torch.int64, device=self.device)
+        win.scatter_reduce_(0, eid[keep], row[keep], reduce="amin")
+        if bool((win == m).any()):
+            raise ValueError("edge features do not cover every resident edge (was the graph built from this list?)")
+        self._efeat = f[win].contiguous()
+
+    def union_edge_ids(self, u: "UnionGraph") -> torch.Tensor:
+        """[cap_edges] int64: resident edge id of the union edge stored at each position of u.col (-1: unused)"""
+        eid = torch.empty(int(u.col.numel()), dtype=torch.int64, device=self.device)
+        check(self._lib.gigl_union_edge_ids(self._ctx, self._graph, C.byref(u.c_struct), C.c_void_p(eid.data_ptr())),
+              self._ctx)
+        return eid
+
+    def union_edge_attr(self, u: "UnionGraph") -> torch.Tensor:
+        """[cap_edges, De] fp32 edge feature rows aligned with u.col (zeros at unused positions)"""
+        if getattr(self, "_efeat", None) is None:
+            raise RuntimeError("no edge features loaded (load_edge_features)")
+        eid = self.union_edge_ids(u)
+        with torch.cuda.stream(self._stream):
+            rows = self._efeat[eid.clamp(min=0)]
+            rows.masked_fill_((eid < 0).unsqueeze(1), 0.0)
+        return rows
 
     def load_features(self, x) -> None:
         if isinstance(x, np.ndarray):
@@ -480,19 +541,35 @@ class HipEngine:
 
     def gat_aggregate(self, h: torch.Tensor, att_src: torch.Tensor, att_dst: torch.Tensor, heads: int, channels: int,
                       u: "UnionGraph", n_rows_dev: torch.Tensor, bias: Optional[torch.Tensor], concat: bool = True,
-                      negative_slope: float = 0.2, act: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      negative_slope: float = 0.2, act: int = 0, out: Optional[torch.Tensor] = None,
+                      edge_attr: Optional[torch.Tensor] = None, att_edge_folded: Optional[torch.Tensor] = None,
+                      w_edge_msg: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """edge_attr: [cap_edges, De] rows aligned with u.col (union_edge_attr); att_edge_folded: [heads, De];
+        w_edge_msg: [heads*channels, De] adds W e_ij to every message (EdgeAttrGATConv)"""
         cap = int(u.nodes.numel())
         assert h.is_cuda and h.is_contiguous() and h.dtype == torch.float32 and h.shape[1] == heads * channels
         if out is None:
             out = torch.empty((cap, heads * channels if concat else channels), dtype=torch.float32, device=self.device)
-        scratch = torch.empty(2 * cap * heads, dtype=torch.float32, device=self.device)
-        check(self._lib.gigl_gat_aggregate(self._ctx, C.c_void_p(h.data_ptr()), C.c_void_p(att_src.data_ptr()),
-                                           C.c_void_p(att_dst.data_ptr()), heads, channels, negative_slope,
-                                           1 if concat else 0, C.c_void_p(u.rowptr.data_ptr()),
-                                           C.c_void_p(u.rowend.data_ptr()), C.c_void_p(u.col.data_ptr()),
-                                           C.c_void_p(u.meta.data_ptr()), cap, C.c_void_p(n_rows_dev.data_ptr()), cap,
-                                           C.c_void_p(bias.data_ptr()) if bias is not None else None, act,
-                                           C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr())), self._ctx)
+        common = (self._ctx, C.c_void_p(h.data_ptr()), C.c_void_p(att_src.data_ptr()), C.c_void_p(att_dst.data_ptr()),
+                  heads, channels, negative_slope, 1 if concat else 0, C.c_void_p(u.rowptr.data_ptr()),
+                  C.c_void_p(u.rowend.data_ptr()), C.c_void_p(u.col.data_ptr()), C.c_void_p(u.meta.data_ptr()), cap,
+                  C.c_void_p(n_rows_dev.data_ptr()), cap, C.c_void_p(bias.data_ptr()) if bias is not None else None, act)
+        if edge_attr is None:
+            scratch = torch.empty(2 * cap * heads, dtype=torch.float32, device=self.device)
+            check(self._lib.gigl_gat_aggregate(*common, C.c_void_p(scratch.data_ptr()), C.c_void_p(out.data_ptr())),
+                  self._ctx)
+            return out
+        ce = int(u.col.numel())
+        de = int(edge_attr.shape[1])
+        assert edge_attr.is_contiguous() and edge_attr.dtype == torch.float32 and edge_attr.shape[0] == ce
+        assert att_edge_folded.is_contiguous() and tuple(att_edge_folded.shape) == (heads, de)
+        if w_edge_msg is not None:
+            assert w_edge_msg.is_contiguous() and tuple(w_edge_msg.shape) == (heads * channels, de)
+        scratch = torch.empty(2 * cap * heads + ce * heads, dtype=torch.float32, device=self.device)
+        check(self._lib.gigl_gat_aggregate_edge(
+            *common, C.c_void_p(edge_attr.data_ptr()), de, ce, C.c_void_p(att_edge_folded.data_ptr()),
+            C.c_void_p(w_edge_msg.data_ptr()) if w_edge_msg is not None else None, C.c_void_p(scratch.data_ptr()),
+            C.c_void_p(out.data_ptr())), self._ctx)
         return out
 
     def gather_mean_backward(self, dout: torch.Tensor, d: int, rowptr: torch.Tensor, rowend: Optional[torch.Tensor],

@@ -30,6 +30,7 @@ class HipBatch:
     tree: Tree
     union: UnionGraph
     x: Optional[torch.Tensor] = None  # None: hydrate from the engine's resident feature table
+    edge_attr: Optional[torch.Tensor] = None  # [cap_edges, De] rows aligned with union.col; None: engine.union_edge_attr
 
     @property
     def root_local(self) -> torch.Tensor:

@@ -14,6 +14,8 @@ Trimmed schedule as in models.GraphSAGE: layer l computes only the prefix of row
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 import torch.nn as nn
 
@@ -58,11 +60,14 @@ class TwoLayerGCN(nn.Module):
 
 
 class GATConv(nn.Module):
+    """parameter holder with PyG GATConv's layout (lin / att_src / att_dst / bias; with edge_dim also lin_edge and
+    att_edge)"""
+
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
-                 negative_slope: float = 0.2, bias: bool = True):
+                 negative_slope: float = 0.2, bias: bool = True, edge_dim: Optional[int] = None):
         super().__init__()
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
-        self.concat, self.negative_slope = concat, negative_slope
+        self.concat, self.negative_slope, self.edge_dim = concat, negative_slope, edge_dim
         self.lin = nn.Linear(in_channels, heads * out_channels, bias=False)
         self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
         self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
@@ -70,20 +75,64 @@ class GATConv(nn.Module):
         nn.init.xavier_uniform_(self.lin.weight)
         nn.init.xavier_uniform_(self.att_src)
         nn.init.xavier_uniform_(self.att_dst)
+        if edge_dim is not None:
+            self.lin_edge = nn.Linear(edge_dim, heads * out_channels, bias=False)
+            self.att_edge = nn.Parameter(torch.empty(1, heads, out_channels))
+            nn.init.xavier_uniform_(self.lin_edge.weight)
+            nn.init.xavier_uniform_(self.att_edge)
+        else:
+            self.lin_edge = self.att_edge = None
+
+    def folded_att_edge(self) -> torch.Tensor:
+        """[heads, edge_dim]: <lin_edge(e), att_edge> == <e, lin_edge.weight^T att_edge> per head"""
+        w = self.lin_edge.weight.view(self.heads, self.out_channels, self.edge_dim)
+        return (w * self.att_edge.view(self.heads, self.out_channels, 1)).sum(1).contiguous()
+
+    def edge_message_weight(self) -> Optional[torch.Tensor]:
+        return None  # plain GATConv: edge features only enter the attention logits
+
+
+class EdgeAttrGATConv(GATConv):
+    """GATConv whose messages are h_j + W e_ij (python/gigl/src/common/models/pyg/nn/conv/edge_attr_gat_conv.py:11-144):
+    W = lin_edge's weight when share_edge_att_message_weight, a separate lin_edge_message otherwise"""
+
+    def __init__(self, *args, share_edge_att_message_weight: bool = True, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.edge_dim is not None and not share_edge_att_message_weight:
+            self.lin_edge_message = nn.Linear(self.edge_dim, self.heads * self.out_channels, bias=False)
+            nn.init.xavier_uniform_(self.lin_edge_message.weight)
+        else:
+            self.lin_edge_message = None
+
+    def edge_message_weight(self) -> Optional[torch.Tensor]:
+        if self.edge_dim is None:
+            return None
+        lin = self.lin_edge_message if self.lin_edge_message is not None else self.lin_edge
+        return lin.weight.contiguous()
 
 
 class GAT(nn.Module):
+    """GAT / EdgeAttrGAT of python/gigl/src/common/models/pyg/homogeneous.py:300-343, :391-440: `edge_dim` switches the
+    edge-feature terms on, `conv="edge_attr_gat"` selects EdgeAttrGATConv"""
+
     def __init__(self, in_dim: int, hid_dim: int, out_dim: int, num_layers: int = 2, heads: int = 1,
                  activation_after_last_conv: bool = False, should_l2_normalize_embedding_layer_output: bool = False,
-                 **conv_kwargs):
+                 edge_dim: Optional[int] = None, conv: str = "gat", **conv_kwargs):
         super().__init__()
         self.num_layers = num_layers
+        self.edge_dim = edge_dim
         self.activation_after_last_conv = activation_after_last_conv
         self.should_l2_normalize_embedding_layer_output = should_l2_normalize_embedding_layer_output
+        assert conv in ("gat", "edge_attr_gat")
+        extra = {}
+        if conv == "edge_attr_gat":
+            extra["share_edge_att_message_weight"] = bool(conv_kwargs.get("share_edge_att_message_weight", True))
+        cls = EdgeAttrGATConv if conv == "edge_attr_gat" else GATConv
         self.conv_layers = nn.ModuleList([
-            GATConv(in_dim if i == 0 else hid_dim * heads, hid_dim if i < num_layers - 1 else out_dim,
-                    heads=heads if i < num_layers - 1 else 1, concat=bool(conv_kwargs.get("concat", True)),
-                    negative_slope=float(conv_kwargs.get("negative_slope", 0.2)), bias=bool(conv_kwargs.get("bias", True)))
+            cls(in_dim if i == 0 else hid_dim * heads, hid_dim if i < num_layers - 1 else out_dim,
+                heads=heads if i < num_layers - 1 else 1, concat=bool(conv_kwargs.get("concat", True)),
+                negative_slope=float(conv_kwargs.get("negative_slope", 0.2)), bias=bool(conv_kwargs.get("bias", True)),
+                edge_dim=edge_dim, **extra)
             for i in range(num_layers)])
 
     @torch.no_grad()
@@ -92,6 +141,10 @@ class GAT(nn.Module):
         L = self.num_layers
         assert u.hops == L, "one hop per layer"
         cap = int(u.nodes.numel())
+        edge_attr = None
+        if self.edge_dim is not None:
+            edge_attr = batch.edge_attr if getattr(batch, "edge_attr", None) is not None else eng.union_edge_attr(u)
+            assert edge_attr.shape[1] == self.edge_dim
         h = None
         for l, conv in enumerate(self.conv_layers):
             # sources of layer l are the rows computed by layer l-1 (all union nodes for the first layer)
@@ -100,9 +153,13 @@ class GAT(nn.Module):
             x = eng.gather_rows(u.nodes, n_src, cap) if l == 0 else h
             hw = eng.linear(x, conv.lin.weight.contiguous(), None, n_src, cap, act=0)
             act = 1 if (l < L - 1 or self.activation_after_last_conv) else 0
+            kw = {}
+            if edge_attr is not None:
+                kw = dict(edge_attr=edge_attr, att_edge_folded=conv.folded_att_edge(),
+                          w_edge_msg=conv.edge_message_weight())
             h = eng.gat_aggregate(hw, conv.att_src.reshape(-1).contiguous(), conv.att_dst.reshape(-1).contiguous(),
                                   conv.heads, conv.out_channels, u, n_dst, conv.bias, concat=conv.concat,
-                                  negative_slope=conv.negative_slope, act=act)
+                                  negative_slope=conv.negative_slope, act=act, **kw)
         if self.should_l2_normalize_embedding_layer_output:
             h = torch.nn.functional.normalize(h, p=2, dim=1)
         return h

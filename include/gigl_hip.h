@@ -109,6 +109,17 @@ int32_t gigl_graph_load_csc(gigl_ctx* ctx, int64_t n, int64_t e, const int64_t* 
 int32_t gigl_graph_build_from_coo(gigl_ctx* ctx, int64_t n, int64_t e, const uint32_t* src,
                                   const uint32_t* dst, int32_t loc, int32_t is_directed,
                                   gigl_graph** out);
+/* edge hydration keys: replaces the JOIN on (_from, _to) of hydrateEdges (SGSPureSparkV1Task.scala:549-593).
+ * eid[i] = position of the edge src[i] -> dst[i] in the resident `col` array (= rowptr[dst] + index of src in the
+ * ascending row), -1 when the graph has no such edge.  An edge-feature table stored in `col` order (row p = the
+ * `_edge_features` of edge p; both directions of a bidirectionalised edge carry the same row, :218-258) is then
+ * indexed by eid.  All pointers DEVICE.  gigl_union_edge_ids does the lookup for every edge of a union graph:
+ * eid[p] for the positions p of u->col that hold an edge (global src = nodes[col[p]], dst = nodes[row]),
+ * -1 elsewhere; eid: [u->cap_edges]. */
+int32_t gigl_edge_ids(gigl_ctx* ctx, gigl_graph* g, const uint32_t* src, const uint32_t* dst, int64_t m,
+                      int64_t* eid);
+struct gigl_union;
+int32_t gigl_union_edge_ids(gigl_ctx* ctx, gigl_graph* g, const struct gigl_union* u, int64_t* eid);
 int32_t gigl_graph_info(gigl_graph* g, int64_t* n, int64_t* e);
 /* DEVICE pointers to the resident CSC (borrowed; valid until gigl_graph_destroy) */
 int32_t gigl_graph_device_ptrs(gigl_graph* g, const int64_t** rowptr, const uint32_t** col);
@@ -414,6 +425,23 @@ int32_t gigl_gat_aggregate(gigl_ctx* ctx, const float* h, const float* att_src, 
                            const int32_t* rowend, const int32_t* col, const int32_t* n_nodes_dev, int64_t nodes_cap,
                            const int32_t* n_rows_dev, int64_t rows_cap, const float* bias, int32_t act,
                            float* alpha_scratch, float* out);
+
+/* GATConv with edge features (edge_dim = De; GAT.init_conv_layers passes edge_dim, homogeneous.py:300-343) and
+ * EdgeAttrGATConv (python/gigl/src/common/models/pyg/nn/conv/edge_attr_gat_conv.py:11-144):
+ *   e_ij = leaky_relu(<h_j, att_src> + <h_i, att_dst> + <W_e e_ij, att_edge>); the added self loop carries the mean
+ *   attribute of the row's in-edges (PyG add_self_loops fill_value="mean"; 0 for a row without in-edges);
+ *   w_edge_msg != NULL (EdgeAttrGATConv): messages are h_j + W_msg e_ij  ([heads*channels][De]; lin_edge's weight
+ *   when share_edge_att_message_weight, lin_edge_message's otherwise).
+ * edge_attr: [cap_edges][De] fp32 rows aligned with the positions of `col` (gigl_union_edge_ids -> feature table);
+ * att_edge_folded: [heads][De] = W_e^T att_edge per head (the caller folds: <W_e e, att> == <e, W_e^T att>).
+ * alpha_scratch: DEVICE fp32 [2*nodes_cap*heads + cap_edges*heads]. */
+int32_t gigl_gat_aggregate_edge(gigl_ctx* ctx, const float* h, const float* att_src, const float* att_dst,
+                                int32_t heads, int32_t channels, float negative_slope, int32_t concat,
+                                const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                const int32_t* n_nodes_dev, int64_t nodes_cap, const int32_t* n_rows_dev,
+                                int64_t rows_cap, const float* bias, int32_t act, const float* edge_attr,
+                                int32_t edge_dim, int64_t cap_edges, const float* att_edge_folded,
+                                const float* w_edge_msg, float* alpha_scratch, float* out);
 
 /* backward of gigl_gather_mean w.r.t. a dense local fp32 source (gather_ids == NULL; layers >= 2):
  *   dsrc[i][0:d] += dout[i][d:2d];  dsrc[col[e]][0:d] += dout[i][0:d] / deg_i  for e in row i, i < n_rows.

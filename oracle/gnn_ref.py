@@ -66,9 +66,13 @@ def gcn_conv(x: torch.Tensor, edge_index: torch.Tensor, w: torch.Tensor, b: Opti
 
 def gat_conv(x: torch.Tensor, edge_index: torch.Tensor, w: torch.Tensor, att_src: torch.Tensor,
              att_dst: torch.Tensor, bias: Optional[torch.Tensor], heads: int, concat: bool = True,
-             negative_slope: float = 0.2) -> torch.Tensor:
-    """PyG GATConv: h = xW viewed [N,H,C]; e_ij = leaky_relu(a_src·h_j + a_dst·h_i); softmax over the
-    in-edges of i (self loops removed then added); out_i = sum_j alpha_ij h_j; concat or mean heads."""
+             negative_slope: float = 0.2, edge_attr: Optional[torch.Tensor] = None,
+             w_edge: Optional[torch.Tensor] = None, att_edge: Optional[torch.Tensor] = None,
+             w_edge_msg: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PyG GATConv: h = xW viewed [N,H,C]; e_ij = leaky_relu(a_src·h_j + a_dst·h_i [+ a_edge·(W_e e_ij)]); softmax
+    over the in-edges of i (self loops removed then added; with edge features the added loops carry the MEAN attribute
+    of the node's remaining in-edges, add_self_loops(fill_value="mean")); out_i = sum_j alpha_ij h_j; concat or mean
+    heads.  w_edge_msg (EdgeAttrGATConv.message, edge_attr_gat_conv.py:131-144): messages are h_j + W_msg e_ij."""
     n = x.shape[0]
     c = w.shape[0] // heads
     h = (x @ w.T).view(n, heads, c)
@@ -78,13 +82,23 @@ def gat_conv(x: torch.Tensor, edge_index: torch.Tensor, w: torch.Tensor, att_src
     dst = torch.cat([edge_index[1][keep], loops])
     a_s = (h * att_src.view(1, heads, c)).sum(-1)
     a_d = (h * att_dst.view(1, heads, c)).sum(-1)
-    e = torch.nn.functional.leaky_relu(a_s[src] + a_d[dst], negative_slope)
+    logit = a_s[src] + a_d[dst]
+    ea = None
+    if edge_attr is not None:
+        kept = edge_attr[keep]
+        loop_attr = scatter_mean(kept, edge_index[1][keep], n)
+        ea = torch.cat([kept, loop_attr])
+        logit = logit + ((ea @ w_edge.T).view(-1, heads, c) * att_edge.view(1, heads, c)).sum(-1)
+    e = torch.nn.functional.leaky_relu(logit, negative_slope)
     emax = torch.full((n, heads), float("-inf"), dtype=x.dtype).scatter_reduce(0, dst[:, None].expand(-1, heads), e,
                                                                               reduce="amax", include_self=True)
     ex = torch.exp(e - emax[dst])
     den = torch.zeros((n, heads), dtype=x.dtype).index_add_(0, dst, ex)
     alpha = ex / (den[dst] + 1e-16)
-    out = torch.zeros((n, heads, c), dtype=x.dtype).index_add_(0, dst, h[src] * alpha[:, :, None])
+    msg = h[src]
+    if ea is not None and w_edge_msg is not None:
+        msg = msg + (ea @ w_edge_msg.T).view(-1, heads, c)
+    out = torch.zeros((n, heads, c), dtype=x.dtype).index_add_(0, dst, msg * alpha[:, :, None])
     out = out.reshape(n, heads * c) if concat else out.mean(1)
     return out + bias if bias is not None else out
 
