@@ -78,6 +78,8 @@ class GiglRecordOpts(C.Structure):
         ("emit", C.c_void_p),
         ("suffix", C.c_void_p),
         ("suffix_off", C.c_void_p),
+        ("graph", C.c_void_p),
+        ("edge_feat", C.c_void_p),
     ]
 
 

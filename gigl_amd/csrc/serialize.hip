@@ -58,6 +58,12 @@ struct RecArgs {
   uint32_t hash_cap;   // node hash entries (pow2)
   uint32_t ehash_cap;  // edge hash entries (pow2; 0 when trees == 1: edges are distinct by construction)
   const uint32_t* shift_tbl;  // [3][256]: x^(8*b*256^j) mod P, reflected (CRC combine)
+  // edge features (Edge.feature_values = 4): row p of `efeat` belongs to the edge at position p of the resident CSC
+  const float* efeat;
+  int32_t de;
+  const int64_t* g_rowptr;
+  const uint32_t* g_col;
+  int64_t g_n;
 };
 
 __device__ __forceinline__ int vlen(uint32_t v) {
@@ -86,9 +92,23 @@ __device__ __forceinline__ uint32_t edge_body_len(const RecArgs& a, uint32_t s, 
   if (s) n += 1 + vlen(s);
   if (d) n += 1 + vlen(d);
   if (a.edge_type >= 0) n += 1 + vlen((uint32_t)a.edge_type);
+  if (a.de > 0) n += 1 + vlen(4u * (uint32_t)a.de) + 4u * (uint32_t)a.de;
   return n;
 }
 __device__ __forceinline__ uint32_t field_len(uint32_t body) { return 1 + vlen(body) + body; }
+// position of the edge s -> d in the resident CSC (row d ascending), NONE when absent
+__device__ __forceinline__ uint32_t edge_pos(const RecArgs& a, uint32_t s, uint32_t d) {
+  if ((int64_t)d >= a.g_n) return NONE;
+  int64_t lo = a.g_rowptr[d];
+  const int64_t end = a.g_rowptr[d + 1];
+  int64_t hi = end;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a.g_col[mid] < s) lo = mid + 1;
+    else hi = mid;
+  }
+  return (lo < end && a.g_col[lo] == s) ? (uint32_t)lo : NONE;
+}
 // bytes of a Node field before its float payload: tag, length, node_id, condensed_node_type, feature_values header
 __device__ __forceinline__ uint32_t node_hdr_len(const RecArgs& a, uint32_t id) {
   uint32_t n = 1 + vlen(node_body_len(a, id));
@@ -164,6 +184,8 @@ struct Plan {
   uint32_t* fld;        // [n_s+1]  byte offset of the node's field inside the Graph body
   uint32_t* pay;        // [n_s+1]  byte offset of its float payload (field offset + header length)
   uint32_t* edge_off;   // [n_e]    byte offset inside the edge region, NONE = duplicate / empty
+  uint32_t* edge_pay;   // [n_e]    (edge features only, write kernel) byte offset of the edge's float payload
+  uint32_t* edge_pos;   // [n_e]    (edge features only, write kernel) its position in the resident CSC
   uint32_t n_uniq, nodes_bytes, edges_bytes;
 };
 
@@ -328,11 +350,16 @@ __device__ __forceinline__ void carve(const RecArgs& a, Plan& pl, uint32_t*& hke
   pl.edge_off = (uint32_t*)p;
   p += (size_t)n_e * 4;
   crc_t = (uint32_t*)p;  // [4][256] (write kernel only)
+  p += 4096;
+  pl.edge_pay = (uint32_t*)p;  // (write kernel with edge features only)
+  p += (size_t)n_e * 4;
+  pl.edge_pos = (uint32_t*)p;
 }
 
 size_t lds_bytes(const RecArgs& a, bool with_crc) {
   const size_t n_s = (size_t)a.trees * a.tree_len, n_e = (size_t)a.trees * a.edge_len;
-  return (size_t)a.ehash_cap * 12 + (size_t)a.hash_cap * 8 + n_s * 4 + (n_s + 1) * 12 + n_e * 4 + (with_crc ? 4096 : 0);
+  return (size_t)a.ehash_cap * 12 + (size_t)a.hash_cap * 8 + n_s * 4 + (n_s + 1) * 12 + n_e * 4 +
+         (with_crc ? 4096 + (a.de > 0 ? n_e * 8 : 0) : 0);
 }
 
 __global__ __launch_bounds__(256) void record_size_kernel(RecArgs a, int64_t* rec_size) {
@@ -410,9 +437,11 @@ __device__ __forceinline__ void write_node_header(const RecArgs& a, uint8_t* q, 
   }
 }
 
+// header of an Edge field (everything before the float payload; the whole field without edge features); returns
+// the address right after it
 __device__ __forceinline__ uint8_t* write_edge(const RecArgs& a, uint8_t* p, uint8_t tag, uint32_t s, uint32_t d) {
   *p++ = tag;
-  *p++ = (uint8_t)edge_body_len(a, s, d);  // <= 18 < 128: one byte
+  p = put_varint(p, edge_body_len(a, s, d));
   if (s) {
     *p++ = 0x08;
     p = put_varint(p, s);
@@ -425,7 +454,21 @@ __device__ __forceinline__ uint8_t* write_edge(const RecArgs& a, uint8_t* p, uin
     *p++ = 0x18;
     p = put_varint(p, (uint32_t)a.edge_type);
   }
+  if (a.de > 0) {
+    *p++ = 0x22;
+    p = put_varint(p, 4u * (uint32_t)a.de);
+  }
   return p;
+}
+// feature word k of the edge at CSC position `pos` as the bit pattern the proto carries (zeros for an unknown edge)
+__device__ __forceinline__ uint32_t efeat_word(const RecArgs& a, uint32_t pos, uint32_t k) {
+  return pos == NONE ? 0u : __float_as_uint(a.efeat[(int64_t)pos * a.de + k]);
+}
+__device__ __forceinline__ void put_word(uint8_t* p, uint32_t v) {
+  p[0] = (uint8_t)v;
+  p[1] = (uint8_t)(v >> 8);
+  p[2] = (uint8_t)(v >> 16);
+  p[3] = (uint8_t)(v >> 24);
 }
 
 // ---- CRC-32C pieces (reflected domain: bit 31 of a word is the coefficient of x^0)
@@ -511,7 +554,12 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
       uint8_t* e = pos;
       for (int tt = 1; tt < a.trees; ++tt) {
         const uint32_t p = a.roots[r * a.trees + tt];
-        if (p != NONE) e = write_edge(a, e, 0x22, L.root_id, p);  // pos_edges = 4
+        if (p == NONE) continue;
+        e = write_edge(a, e, 0x22, L.root_id, p);  // pos_edges = 4
+        if (a.de > 0) {
+          const uint32_t at = edge_pos(a, L.root_id, p);
+          for (int k = 0; k < a.de; ++k, e += 4) put_word(e, efeat_word(a, at, (uint32_t)k));
+        }
       }
     }
   }
@@ -617,7 +665,20 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
     if (pl.edge_off[q] == NONE) continue;
     uint32_t s, d;
     stream_edge(a, r, q, s, d);
-    write_edge(a, edges + pl.edge_off[q], 0x1A, s, d);
+    uint8_t* const pay = write_edge(a, edges + pl.edge_off[q], 0x1A, s, d);
+    if (a.de > 0) {
+      pl.edge_pay[q] = (uint32_t)(pay - edges);
+      pl.edge_pos[q] = edge_pos(a, s, d);
+    }
+  }
+  if (a.de > 0) {  // float payloads of the edges: the (edge, word) pairs spread over the workgroup
+    __syncthreads();
+    const uint32_t De = (uint32_t)a.de, total = n_e * De;
+    for (uint32_t i = tid; i < total; i += 256) {
+      const uint32_t q = i / De, k = i - q * De;
+      if (pl.edge_off[q] == NONE) continue;
+      put_word(edges + pl.edge_pay[q] + 4u * k, efeat_word(a, pl.edge_pos[q], k));
+    }
   }
   if (L.suffix_len) {
     const uint8_t* src = a.suffix + a.suffix_off[r];
@@ -769,7 +830,8 @@ int32_t gigl_records_capacity(const int32_t* fanouts, int32_t hops, int32_t d, c
   }
   const int64_t node_body = 6 + 6 + (d > 0 ? 1 + hvlen(4ull * d) + 4ll * d : 0);
   const int64_t node_field = 1 + hvlen(node_body) + node_body;
-  const int64_t edge_field = 2 + 6 + 6 + 6;
+  const int64_t de = opts->edge_feat ? opts->edge_feat->d : 0;
+  const int64_t edge_field = 1 + 5 + 6 + 6 + 6 + (de > 0 ? 1 + hvlen(4ull * de) + 4 * de : 0);
   const int64_t t = opts->trees_per_record;
   const int64_t graph = t * ((sum + 1) * node_field + sum * edge_field);
   const int64_t per = node_field + 1 + hvlen(graph) + graph + (t - 1) * edge_field + 16;
@@ -799,6 +861,18 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
     a.d = feat->d;
     a.feat_dtype = feat->dtype;
     a.feat_n = feat->n;
+  }
+  if (opts->edge_feat && opts->edge_feat->d > 0) {
+    GIGL_REQUIRE(ctx, opts->graph, "edge features need the resident graph (opts->graph) for the edge lookup");
+    GIGL_REQUIRE(ctx, opts->edge_feat->dtype == GIGL_DTYPE_F32, "edge features must be fp32");
+    GIGL_REQUIRE(ctx, opts->edge_feat->n == opts->graph->e && opts->graph->e < ((int64_t)1 << 32) - 1,
+                 "edge feature table of %lld rows for a graph of %lld edges", (long long)opts->edge_feat->n,
+                 (long long)opts->graph->e);
+    a.efeat = (const float*)opts->edge_feat->rows;
+    a.de = opts->edge_feat->d;
+    a.g_rowptr = opts->graph->rowptr;
+    a.g_col = opts->graph->col;
+    a.g_n = opts->graph->n;
   }
   a.n_records = n_records;
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));

@@ -120,6 +120,7 @@ class HipEngine:
         self._graph, self._graph_out, self._feat = other._graph, other._graph_out, other._feat
         self._feat_ptr = getattr(other, "_feat_ptr", None)
         self._efeat = getattr(other, "_efeat", None)
+        self._efeat_handle = getattr(other, "_efeat_handle", None)
         self.n_nodes, self.n_edges = other.n_nodes, other.n_edges
         self.feat_dim, self.feat_dtype = other.feat_dim, other.feat_dtype
         self._borrowed = True
@@ -131,10 +132,11 @@ class HipEngine:
             if not getattr(self, "_borrowed", False):
                 for h, fn in ((self._graph, self._lib.gigl_graph_destroy),
                               (self._graph_out, self._lib.gigl_graph_destroy),
-                              (self._feat, self._lib.gigl_features_destroy)):
+                              (self._feat, self._lib.gigl_features_destroy),
+                              (getattr(self, "_efeat_handle", None), self._lib.gigl_features_destroy)):
                     if h:
                         fn(h)
-            self._graph = self._graph_out = self._feat = None
+            self._graph = self._graph_out = self._feat = self._efeat_handle = self._efeat = None
             self._lib.gigl_ctx_destroy(self._ctx)
             self._ctx = None
 
@@ -248,7 +250,18 @@ class HipEngine:
         win.scatter_reduce_(0, eid[keep], row[keep], reduce="amin")
         if bool((win == m).any()):
             raise ValueError("edge features do not cover every resident edge (was the graph built from this list?)")
-        self._efeat = f[win].contiguous()
+        self._set_edge_table(f[win].contiguous())
+
+    def _set_edge_table(self, table: torch.Tensor) -> None:
+        """`table`: [n_edges, De] fp32 on the device, row p = features of the edge at col[p]"""
+        assert table.shape[0] == self.n_edges and table.dtype == torch.float32 and table.is_cuda
+        self._efeat = table
+        h = C.c_void_p()
+        check(self._lib.gigl_features_load(self._ctx, table.shape[0], table.shape[1], DTYPE_F32,
+                                           C.c_void_p(table.data_ptr()), LOC_DEVICE, C.byref(h)), self._ctx)
+        if getattr(self, "_efeat_handle", None) and not getattr(self, "_borrowed", False):
+            self._lib.gigl_features_destroy(self._efeat_handle)
+        self._efeat_handle = h
 
     def union_edge_ids(self, u: "UnionGraph") -> torch.Tensor:
         """[cap_edges] int64: resident edge id of the union edge stored at each position of u.col (-1: unused)"""
@@ -373,7 +386,7 @@ class HipEngine:
                        condensed_node_type: Optional[int] = 0, condensed_edge_type: Optional[int] = 0,
                        tfrecord_frame: bool = True, emit: Optional[torch.Tensor] = None,
                        suffix: Optional[torch.Tensor] = None, suffix_off: Optional[torch.Tensor] = None,
-                       with_features: bool = True):
+                       with_features: bool = True, with_edge_features: bool = True):
         """sampled trees -> serialized RootedNodeNeighborhood / SupervisedNodeClassificationSample (suffix = encoded
         labels) / NodeAnchorBasedLinkPredictionSample records, encoded on the device (gigl_records_encode).
         -> (uint8 device tensor of all records back to back, int64 device tensor rec_off[n_records+1])"""
@@ -401,6 +414,8 @@ class HipEngine:
             o.suffix, o.suffix_off = suffix.data_ptr(), suffix_off.data_ptr()
             keep += [suffix, suffix_off]
         feat = self._feat if with_features else None
+        if with_edge_features and getattr(self, "_efeat_handle", None):
+            o.graph, o.edge_feat = self._graph, self._efeat_handle  # Edge.feature_values from the resident table
         fo = (C.c_int32 * len(tree.fanouts))(*tree.fanouts)
         cap = C.c_int64()
         check(self._lib.gigl_records_capacity(fo, len(tree.fanouts), self.feat_dim if feat else 0, C.byref(o), n_rec,

@@ -287,6 +287,12 @@ typedef struct gigl_record_opts {
   const uint8_t* emit;         /* [n_records] or NULL; 0 = the record is skipped (takes 0 bytes) */
   const uint8_t* suffix;       /* bytes appended to the payload of record r: suffix[suffix_off[r] .. suffix_off[r+1]) */
   const int64_t* suffix_off;   /* [n_records+1] or NULL (with suffix) */
+  /* edge features (hydrateEdges, SGSPureSparkV1Task.scala:549-593; Edge.feature_values, graph_schema.proto:29-30):
+   * `edge_feat` = fp32 table with one row per edge of `graph`, in the order of its `col` array (gigl_features_load
+   * with n = #edges).  Every emitted Edge — the neighbourhood's and the pos_edges — then carries the row of its
+   * (src, dst) pair, found by binary search in the destination's row.  NULL / d == 0: no feature_values. */
+  gigl_graph* graph;
+  gigl_feat* edge_feat;
 } gigl_record_opts;
 
 /* upper bound of the bytes n_records records can take (d = feature dim, suffix_total = all suffix bytes) */

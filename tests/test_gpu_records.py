@@ -164,6 +164,100 @@ def test_link_prediction_samples_match_host_assembly():
     eng.close()
 
 
+def _pair_features(de):
+    """deterministic feature row of an undirected edge {a, b}: both directions and every duplicate input row agree"""
+    def f(s, d):
+        a, b = (s, d) if s < d else (d, s)
+        return np.sin(np.arange(1, de + 1, dtype=np.float64) * (a * 0.37 + b * 1.13 + 1.0)).astype(np.float32)
+    return f
+
+
+@pytest.mark.parametrize("de,d,fanouts", [(1, 4, [5, 3]), (3, 0, [6, 2]), (40, 9, [25, 10]), (16, 3, [3, 2, 2])])
+def test_rnn_records_with_edge_features(de, d, fanouts):
+    """Edge.feature_values (hydrateEdges): every neighbourhood edge carries the row of its (src, dst) pair; de = 40
+    pushes the Edge body past 127 bytes (two-byte length varint)"""
+    rng = np.random.default_rng(de)
+    n = 20_000
+    src, dst = rmat_edges(15, 90_000, seed=21)
+    src, dst = (src % n).astype(np.uint32), (dst.astype(np.int64) * 7 % n).astype(np.uint32)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    feats = rng.standard_normal((n, d)).astype(np.float32) if d else None
+    f = _pair_features(de)
+    eng = _engine(n, src, dst, feats)
+    eng.load_edge_features(src, dst, np.stack([f(int(a), int(b)) for a, b in zip(src, dst)]), is_directed=False)
+    roots = rng.integers(0, n, 80).astype(np.uint32)
+    roots[:2] = [0, n - 1]
+    tree = eng.sample_khop(roots, fanouts)
+    buf, off = eng.encode_records(tree, with_features=d > 0)
+    nbr = [t.cpu().numpy().view(np.uint32) for t in tree.nbr]
+    want = []
+    for r, (s_, d_) in zip(roots.tolist(), tree_to_edge_lists(roots, fanouts, nbr)):
+        rnn = build_rooted_node_neighborhood(r, s_, d_, feats, edge_features=f)
+        want.append(wire.tfrecord_frame(rnn.SerializeToString()))
+    got = _split(buf, off)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, f"record {i} differs"
+    big = max(got, key=len)
+    m = wire.RootedNodeNeighborhood.FromString(next(iter(wire.iter_tfrecords(big))))
+    assert all(e.feature_values.size == de for e in m.neighborhood.edges) and len(m.neighborhood.edges) > 0
+    # without the table attached the same call writes feature-less edges
+    plain, _ = eng.encode_records(tree, with_features=d > 0, with_edge_features=False)
+    assert plain.numel() < buf.numel()
+    eng.close()
+
+
+def test_link_prediction_samples_with_edge_features():
+    """pos_edges and the merged neighbourhood both carry Edge.feature_values (hydrateTaskBasedEdges,
+    NodeAnchorBasedLinkPredictionBaseTask.scala:280-334)"""
+    rng = np.random.default_rng(19)
+    n, de = 3000, 5
+    src, dst = rmat_edges(12, 20_000, seed=8)
+    src, dst = (src % n).astype(np.uint32), (dst.astype(np.int64) * 11 % n).astype(np.uint32)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    feats = rng.standard_normal((n, 3)).astype(np.float32)
+    f = _pair_features(de)
+    eng = _engine(n, src, dst, feats)
+    eng.load_edge_features(src, dst, np.stack([f(int(a), int(b)) for a, b in zip(src, dst)]), is_directed=False)
+    roots = rng.integers(0, n, 48).astype(np.uint32)
+    fanouts, P = [4, 3], 2
+    pos, cnt = eng.sample_positives(roots, P)
+    pos_h = pos.cpu().numpy().view(np.uint32).reshape(-1, P)
+    cnt_h = cnt.cpu().numpy()
+    all_roots = np.concatenate([roots[:, None], pos_h], axis=1).reshape(-1)
+    tree = eng.sample_khop(all_roots, fanouts)
+    buf, off = eng.encode_records(tree, kind=_lib.REC_NODE_ANCHOR_LINK_PRED, trees_per_record=1 + P,
+                                  emit=(cnt > 0).to(torch.uint8))
+    nbr = [t.cpu().numpy().view(np.uint32) for t in tree.nbr]
+    lists = tree_to_edge_lists(all_roots, fanouts, nbr)
+    want = []
+    for i, r in enumerate(roots.tolist()):
+        if cnt_h[i] == 0:
+            continue
+        base = build_rooted_node_neighborhood(r, *lists[i * (1 + P)], feats, edge_features=f)
+        nodes = {nd.node_id: nd for nd in base.neighborhood.nodes}
+        edges = {(e.src_node_id, e.dst_node_id): e for e in base.neighborhood.edges}
+        pos_edges = []
+        for j in range(int(cnt_h[i])):
+            p = int(pos_h[i, j])
+            pos_edges.append(wire.Edge(src_node_id=r, dst_node_id=p, condensed_edge_type=0, feature_values=f(r, p)))
+            pr = build_rooted_node_neighborhood(p, *lists[i * (1 + P) + 1 + j], feats, edge_features=f)
+            for nd in pr.neighborhood.nodes:
+                nodes.setdefault(nd.node_id, nd)
+            for e in pr.neighborhood.edges:
+                edges.setdefault((e.src_node_id, e.dst_node_id), e)
+        msg = wire.NodeAnchorBasedLinkPredictionSample(
+            root_node=base.root_node, pos_edges=pos_edges,
+            neighborhood=wire.Graph(nodes=list(nodes.values()), edges=list(edges.values())))
+        want.append(wire.tfrecord_frame(msg.SerializeToString()))
+    got = [g for g in _split(buf, off) if g]
+    assert len(got) == len(want) and len(want) > 10
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, f"sample {i} differs"
+    eng.close()
+
+
 def test_oversized_record_is_rejected():
     from gigl_amd.engine import HipEngine
     eng = HipEngine(0)
