@@ -30,13 +30,20 @@ class Node:
     id: int
 
 
+def _opt_tensor(a):
+    return None if a is None else torch.from_numpy(a)
+
+
 def build_batch_graph(samples: Sequence[Tuple[Sequence[wire.Node], Sequence[wire.Edge]]]):
-    """-> (x [n,D] float32, edge_index [2,E] int64, global_to_local dict, node_order list of global ids)"""
+    """-> (x [n,D] float32, edge_index [2,E] int64, global_to_local dict, node_order list of global ids,
+    edge_attr [E,De] float32 in edge_index order or None when the samples' edges carry no features)"""
     g2l: Dict[int, int] = {}
     feats: List[np.ndarray] = []
     es: List[int] = []
     ed: List[int] = []
     seen = set()
+    efeats: List[np.ndarray] = []
+    edge_dim: Optional[int] = None  # GraphBuilder.should_register_edge_features: fixed by the first edge added
     feat_dim: Optional[int] = None
     for nodes, edges in samples:
         for nd in nodes:
@@ -52,25 +59,35 @@ def build_batch_graph(samples: Sequence[Tuple[Sequence[wire.Node], Sequence[wire
             if e.src_node_id not in g2l or e.dst_node_id not in g2l:  # :26-30
                 raise TypeError(f"Tried to fetch a node which we have no information on (edge "
                                 f"{e.src_node_id}->{e.dst_node_id})")
+            fv = np.asarray(e.feature_values, dtype=np.float32)
+            if edge_dim is None:
+                edge_dim = int(fv.size)
+            if int(fv.size) != edge_dim:  # abstract_graph_builder.py:121-132
+                raise TypeError(f"edge feature registration is inconsistent: edge {e.src_node_id}->{e.dst_node_id} "
+                                "differs from the first edge")
             key = (g2l[e.src_node_id], g2l[e.dst_node_id])
             if key in seen:
                 continue
             seen.add(key)
             es.append(key[0])
             ed.append(key[1])
+            efeats.append(fv)
     n = len(feats)
     if n and feat_dim == 0:  # PygGraphBuilder: nodes without features get ones(1) (pyg_graph_builder.py:25-38)
         x = np.ones((n, 1), dtype=np.float32)
     else:
         x = np.stack(feats).astype(np.float32) if n else np.zeros((0, feat_dim or 0), np.float32)
     ei = np.array([es, ed], dtype=np.int64).reshape(2, -1)
+    ea = np.stack(efeats).astype(np.float32) if edge_dim and efeats else None
     if ei.shape[1]:  # coalesce(): sort by (src, dst); duplicates were already dropped
         order = np.lexsort((ei[1], ei[0]))
         ei = ei[:, order]
+        if ea is not None:
+            ea = ea[order]
     order_ids = [None] * n
     for g, l in g2l.items():
         order_ids[l] = g
-    return x, ei, g2l, order_ids
+    return x, ei, g2l, order_ids, ea
 
 
 def collate_serialized(batch: Sequence[bytes], kind: int, n_threads: int = 0):
@@ -96,7 +113,7 @@ def collate_serialized(batch: Sequence[bytes], kind: int, n_threads: int = 0):
                                   n_threads or min(16, os.cpu_count() or 1), C.byref(h), err, 512)
     if rc != 0:
         msg = err.value.decode("utf-8", "replace")
-        exc = (AssertionError if "re-added" in msg else TypeError if "Tried to fetch" in msg
+        exc = (AssertionError if "re-added" in msg else TypeError if ("Tried to fetch" in msg or "edge feature" in msg)
                else KeyError if "not in the batch graph" in msg else ValueError)
         raise exc(msg or "gigl_collate_records failed")
     try:
@@ -112,6 +129,12 @@ def collate_serialized(batch: Sequence[bytes], kind: int, n_threads: int = 0):
         lib.gigl_collated_copy(h, ptr(out["node_ids"]), ptr(out["x"]), ptr(out["edge_index"]), ptr(out["root_local"]),
                                ptr(out["labels"]), ptr(out["has_label"]), ptr(out["pos_off"]), ptr(out["pos_dst"]),
                                ptr(out["neg_off"]), ptr(out["neg_dst"]))
+        de = C.c_int32()
+        lib.gigl_collated_edge_attr(h, C.byref(de), None)
+        out["edge_attr"] = None
+        if de.value:
+            out["edge_attr"] = np.empty((e.value, de.value), np.float32)
+            lib.gigl_collated_edge_attr(h, C.byref(de), ptr(out["edge_attr"]))
     finally:
         lib.gigl_collated_destroy(h)
     if n.value and d.value == 0:  # PygGraphBuilder: nodes without features get ones(1) (pyg_graph_builder.py:25-38)
@@ -129,12 +152,12 @@ class RootedNodeNeighborhoodBatch:
     @staticmethod
     def collate_pyg_rooted_node_neighborhood_minibatch(samples: Sequence[wire.RootedNodeNeighborhood],
                                                        node_type: str = "node") -> "RootedNodeNeighborhoodBatch":
-        x, ei, g2l, order = build_batch_graph([(s.neighborhood.nodes if s.neighborhood else [s.root_node],
+        x, ei, g2l, order, ea = build_batch_graph([(s.neighborhood.nodes if s.neighborhood else [s.root_node],
                                                 s.neighborhood.edges if s.neighborhood else []) for s in samples])
         roots = [Node(type=node_type, id=int(s.root_node.node_id)) for s in samples]
         idx = torch.tensor([g2l[r.id] for r in roots], dtype=torch.int64)
         return RootedNodeNeighborhoodBatch(
-            graph=GraphData(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei)),
+            graph=GraphData(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei), edge_attr=_opt_tensor(ea)),
             condensed_node_type_to_root_node_indices_map={0: idx}, root_nodes=roots,
             condensed_node_type_to_subgraph_id_to_global_node_id={0: {l: g for l, g in enumerate(order)}})
 
@@ -147,7 +170,8 @@ class RootedNodeNeighborhoodBatch:
         order = c["node_ids"].tolist()
         idx = torch.from_numpy(c["root_local"])
         return RootedNodeNeighborhoodBatch(
-            graph=GraphData(x=torch.from_numpy(c["x"]), edge_index=torch.from_numpy(c["edge_index"])),
+            graph=GraphData(x=torch.from_numpy(c["x"]), edge_index=torch.from_numpy(c["edge_index"]),
+                            edge_attr=_opt_tensor(c["edge_attr"])),
             condensed_node_type_to_root_node_indices_map={0: idx},
             root_nodes=[Node(type=node_type, id=int(order[l])) for l in c["root_local"].tolist()],
             condensed_node_type_to_subgraph_id_to_global_node_id={0: {l: g for l, g in enumerate(order)}})
@@ -163,13 +187,13 @@ class SupervisedNodeClassificationBatch:
     @staticmethod
     def collate_pyg_node_classification_minibatch(samples: Sequence[wire.SupervisedNodeClassificationSample],
                                                   node_type: str = "node") -> "SupervisedNodeClassificationBatch":
-        x, ei, g2l, _ = build_batch_graph([(s.neighborhood.nodes, s.neighborhood.edges) for s in samples])
+        x, ei, g2l, _, ea = build_batch_graph([(s.neighborhood.nodes, s.neighborhood.edges) for s in samples])
         roots = [Node(type=node_type, id=int(s.root_node.node_id)) for s in samples]
         labels = None
         if all(s.root_node_labels for s in samples) and samples:
             labels = torch.tensor([s.root_node_labels[0].label for s in samples], dtype=torch.int64)
         return SupervisedNodeClassificationBatch(
-            graph=GraphData(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei)),
+            graph=GraphData(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei), edge_attr=_opt_tensor(ea)),
             root_node_indices=torch.tensor([g2l[r.id] for r in roots], dtype=torch.int64), root_nodes=roots,
             root_node_labels=labels)
 
@@ -181,7 +205,8 @@ class SupervisedNodeClassificationBatch:
         order = c["node_ids"]
         labels = torch.from_numpy(c["labels"]) if len(batch) and c["has_label"].all() else None
         return SupervisedNodeClassificationBatch(
-            graph=GraphData(x=torch.from_numpy(c["x"]), edge_index=torch.from_numpy(c["edge_index"])),
+            graph=GraphData(x=torch.from_numpy(c["x"]), edge_index=torch.from_numpy(c["edge_index"]),
+                            edge_attr=_opt_tensor(c["edge_attr"])),
             root_node_indices=torch.from_numpy(c["root_local"]),
             root_nodes=[Node(type=node_type, id=int(order[l])) for l in c["root_local"].tolist()],
             root_node_labels=labels)
@@ -209,7 +234,7 @@ class NodeAnchorBasedLinkPredictionBatch:
     @staticmethod
     def collate_pyg_node_anchor_based_link_prediction_minibatch(
             samples: Sequence[wire.NodeAnchorBasedLinkPredictionSample]) -> "NodeAnchorBasedLinkPredictionBatch":
-        x, ei, g2l, order = build_batch_graph([(s.neighborhood.nodes, s.neighborhood.edges) for s in samples])
+        x, ei, g2l, order, ea = build_batch_graph([(s.neighborhood.nodes, s.neighborhood.edges) for s in samples])
         pos = BatchSupervisionEdgeData(root_node_to_target_node_id={})
         neg = BatchSupervisionEdgeData(root_node_to_target_node_id={})
         roots: List[int] = []
@@ -222,7 +247,7 @@ class NodeAnchorBasedLinkPredictionBatch:
             neg.root_node_to_target_node_id[r] = torch.tensor([g2l[e.dst_node_id] for e in s.hard_neg_edges],
                                                               dtype=torch.int64)
         return NodeAnchorBasedLinkPredictionBatch(
-            graph=GraphData(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei)),
+            graph=GraphData(x=torch.from_numpy(x), edge_index=torch.from_numpy(ei), edge_attr=_opt_tensor(ea)),
             root_node_indices=torch.tensor(roots, dtype=torch.int64),
             pos_supervision_edge_data={0: pos}, hard_neg_supervision_edge_data={0: neg},
             condensed_node_type_to_subgraph_id_to_global_node_id={0: {l: g for l, g in enumerate(order)}})
@@ -239,7 +264,8 @@ class NodeAnchorBasedLinkPredictionBatch:
             pos.root_node_to_target_node_id[r] = pd[po[i]:po[i + 1]].clone()
             neg.root_node_to_target_node_id[r] = nd[no[i]:no[i + 1]].clone()
         return NodeAnchorBasedLinkPredictionBatch(
-            graph=GraphData(x=torch.from_numpy(c["x"]), edge_index=torch.from_numpy(c["edge_index"])),
+            graph=GraphData(x=torch.from_numpy(c["x"]), edge_index=torch.from_numpy(c["edge_index"]),
+                            edge_attr=_opt_tensor(c["edge_attr"])),
             root_node_indices=torch.from_numpy(c["root_local"]),
             pos_supervision_edge_data={0: pos}, hard_neg_supervision_edge_data={0: neg},
             condensed_node_type_to_subgraph_id_to_global_node_id={0: {l: g for l, g in enumerate(c["node_ids"].tolist())}})

@@ -23,9 +23,9 @@
 #include <thread>
 
 struct gigl_collated {
-  int32_t feat_dim = 0;
+  int32_t feat_dim = 0, edge_dim = 0;
   std::vector<uint32_t> node_ids;
-  std::vector<float> x;
+  std::vector<float> x, edge_attr;
   std::vector<int64_t> edge_src, edge_dst;
   std::vector<int64_t> root_local, labels, pos_off, pos_dst, neg_off, neg_dst;
   std::vector<uint8_t> has_label;
@@ -71,12 +71,17 @@ struct NodeRef {
   int32_t n;          // floats
   const uint8_t* f;   // packed little-endian floats (record bytes, or the record's side arena)
 };
+struct EdgeRef {
+  uint32_t src, dst;
+  int32_t n;          // floats (Edge.feature_values)
+  const uint8_t* f;
+};
 struct Rec {
   NodeRef root{0, 0, nullptr};
   bool has_root = false, has_graph = false, has_label = false, ok = true;
   int64_t label = 0;
   std::vector<NodeRef> nodes;
-  std::vector<std::pair<uint32_t, uint32_t>> edges;
+  std::vector<EdgeRef> edges;
   std::vector<uint32_t> pos, neg;
   std::vector<std::vector<uint8_t>> arena;  // features that were not one packed run
 };
@@ -109,16 +114,33 @@ bool parse_node(Span s, Rec& r, NodeRef& out) {
   }
   return true;
 }
-bool parse_edge(Span s, uint32_t& src, uint32_t& dst) {
-  src = dst = 0;
+bool parse_edge(Span s, Rec& r, EdgeRef& out) {
+  out = EdgeRef{0, 0, 0, nullptr};
   uint32_t fno, wt;
   Span x{nullptr, nullptr};
   uint64_t v;
+  int runs = 0;
+  std::vector<uint8_t> acc;
   while (s.p < s.e) {
     if (!field(s, fno, wt, x, v)) return false;
-    if (wt != 0) continue;
-    if (fno == 1) src = (uint32_t)v;
-    else if (fno == 2) dst = (uint32_t)v;
+    if (wt == 0) {
+      if (fno == 1) out.src = (uint32_t)v;
+      else if (fno == 2) out.dst = (uint32_t)v;
+    } else if (fno == 4 && (wt == 2 || wt == 5)) {
+      if (runs == 0 && wt == 2) {
+        out.f = x.p;
+        out.n = (int32_t)((x.e - x.p) / 4);
+      } else {
+        if (runs == 1 && acc.empty() && out.f) acc.assign(out.f, out.f + 4 * (size_t)out.n);
+        acc.insert(acc.end(), x.p, x.p + (wt == 5 ? 4 : ((x.e - x.p) / 4) * 4));
+      }
+      ++runs;
+    }
+  }
+  if (!acc.empty()) {
+    r.arena.push_back(std::move(acc));
+    out.f = r.arena.back().data();
+    out.n = (int32_t)(r.arena.back().size() / 4);
   }
   return true;
 }
@@ -134,9 +156,9 @@ bool parse_graph(Span s, Rec& r) {
       if (!parse_node(x, r, n)) return false;
       r.nodes.push_back(n);
     } else if (fno == 3) {
-      uint32_t a, b;
-      if (!parse_edge(x, a, b)) return false;
-      r.edges.emplace_back(a, b);
+      EdgeRef e;
+      if (!parse_edge(x, r, e)) return false;
+      r.edges.push_back(e);
     }
   }
   return true;
@@ -167,9 +189,9 @@ bool parse_record(Span s, int32_t kind, Rec& r) {
       r.has_label = true;
       r.label = (int64_t)(int32_t)(uint32_t)lv;  // int32 field: sign-extended 64-bit varint
     } else if (kind == GIGL_REC_NODE_ANCHOR_LINK_PRED && (fno == 4 || fno == 2)) {
-      uint32_t a, b;
-      if (!parse_edge(x, a, b)) return false;
-      (fno == 4 ? r.pos : r.neg).push_back(b);
+      EdgeRef e;
+      if (!parse_edge(x, r, e)) return false;
+      (fno == 4 ? r.pos : r.neg).push_back(e.dst);
     }
   }
   return true;
@@ -294,7 +316,10 @@ int32_t gigl_collate_records(const uint8_t* buf, const int64_t* payload_off, con
     }
   } eset(total_edges + 1);
   std::vector<uint64_t> ekeys;
+  std::vector<const uint8_t*> erows;  // feature run of the edge that registered the key (first one wins)
   ekeys.reserve(total_edges);
+  erows.reserve(total_edges);
+  int32_t edim = -1;  // set by the first edge added (GraphBuilder.should_register_edge_features)
   for (int64_t i = 0; i < b; ++i) {
     for (const NodeRef& n : recs[i].nodes) {
       int32_t* s = ids.slot(n.id);
@@ -318,16 +343,26 @@ int32_t gigl_collate_records(const uint8_t* buf, const int64_t* payload_off, con
       c->node_ids.push_back(n.id);
       src_rows.push_back(n.f ? n.f : buf);
     }
-    for (const auto& e : recs[i].edges) {
-      const int32_t ls = ids.find(e.first), ld = ids.find(e.second);
+    for (const EdgeRef& e : recs[i].edges) {
+      const int32_t ls = ids.find(e.src), ld = ids.find(e.dst);
       if (ls < 0 || ld < 0) {
         set_err(err, err_cap, "Tried to fetch a node which we have no information on (edge %lld->%lld)",
-                (long long)e.first, (long long)e.second);
+                (long long)e.src, (long long)e.dst);
+        delete c;
+        return GIGL_E_INVALID_ARG;
+      }
+      if (edim < 0) edim = e.n;
+      if (e.n != edim) {  // abstract_graph_builder.py:121-132 (features on some edges only), torch.stack otherwise
+        set_err(err, err_cap, "edge feature registration is inconsistent: edge %lld->%lld differs from the first edge",
+                (long long)e.src, (long long)e.dst);
         delete c;
         return GIGL_E_INVALID_ARG;
       }
       const uint64_t key = ((uint64_t)(uint32_t)ls << 32) | (uint32_t)ld;
-      if (eset.insert(key)) ekeys.push_back(key);
+      if (eset.insert(key)) {
+        ekeys.push_back(key);
+        erows.push_back(e.f ? e.f : buf);
+      }
     }
   }
   c->feat_dim = dim < 0 ? 0 : dim;
@@ -338,13 +373,22 @@ int32_t gigl_collate_records(const uint8_t* buf, const int64_t* payload_off, con
     parallel([&](int64_t lo, int64_t hi) {
       for (int64_t i = lo; i < hi; ++i) memcpy(&c->x[(size_t)i * c->feat_dim], src_rows[i], 4 * (size_t)c->feat_dim);
     }, n);
-  std::sort(ekeys.begin(), ekeys.end());
+  c->edge_dim = edim < 0 ? 0 : edim;
+  std::vector<uint32_t> eorder(ekeys.size());
+  for (size_t i = 0; i < eorder.size(); ++i) eorder[i] = (uint32_t)i;
+  std::sort(eorder.begin(), eorder.end(), [&](uint32_t a, uint32_t b) { return ekeys[a] < ekeys[b]; });
   c->edge_src.resize(ekeys.size());
   c->edge_dst.resize(ekeys.size());
   for (size_t i = 0; i < ekeys.size(); ++i) {
-    c->edge_src[i] = (int64_t)(ekeys[i] >> 32);
-    c->edge_dst[i] = (int64_t)(ekeys[i] & 0xFFFFFFFFull);
+    c->edge_src[i] = (int64_t)(ekeys[eorder[i]] >> 32);
+    c->edge_dst[i] = (int64_t)(ekeys[eorder[i]] & 0xFFFFFFFFull);
   }
+  c->edge_attr.resize(ekeys.size() * (size_t)c->edge_dim);
+  if (c->edge_dim)
+    parallel([&](int64_t lo, int64_t hi) {
+      for (int64_t i = lo; i < hi; ++i)
+        memcpy(&c->edge_attr[(size_t)i * c->edge_dim], erows[eorder[i]], 4 * (size_t)c->edge_dim);
+    }, (int64_t)ekeys.size());
   // ---- per-sample outputs
   c->root_local.resize((size_t)b);
   c->labels.assign((size_t)b, 0);
@@ -413,6 +457,13 @@ int32_t gigl_collated_copy(const gigl_collated* c, uint32_t* node_ids, float* x,
   cp(pos_dst, c->pos_dst.data(), c->pos_dst.size() * 8);
   cp(neg_off, c->neg_off.data(), c->neg_off.size() * 8);
   cp(neg_dst, c->neg_dst.data(), c->neg_dst.size() * 8);
+  return GIGL_OK;
+}
+
+int32_t gigl_collated_edge_attr(const gigl_collated* c, int32_t* edge_dim, float* edge_attr) {
+  if (!c) return GIGL_E_INVALID_ARG;
+  if (edge_dim) *edge_dim = c->edge_dim;
+  if (edge_attr && !c->edge_attr.empty()) memcpy(edge_attr, c->edge_attr.data(), c->edge_attr.size() * 4);
   return GIGL_OK;
 }
 

@@ -136,7 +136,13 @@ class GAT(nn.Module):
             for i in range(num_layers)])
 
     @torch.no_grad()
-    def forward(self, batch: HipBatch) -> torch.Tensor:
+    def forward(self, batch, engine=None) -> torch.Tensor:
+        """HipBatch  -> trimmed schedule over the level-ordered union graph: [cap, out]; index with batch.root_local
+        GraphData -> every layer over the whole coalesced batch graph (samples that arrived as TFRecords; the
+                     reference's execution order): [n, out]; edge features from GraphData.edge_attr"""
+        from .nn import GraphData
+        if isinstance(batch, GraphData):
+            return self._forward_graph(batch, engine or getattr(self, "engine", None))
         eng, u = batch.engine, batch.union
         L = self.num_layers
         assert u.hops == L, "one hop per layer"
@@ -151,15 +157,47 @@ class GAT(nn.Module):
             n_src = u.meta[GIGL_META_LEVEL0 + (L - l): GIGL_META_LEVEL0 + (L - l) + 1]
             n_dst = u.meta[GIGL_META_LEVEL0 + (L - 1 - l): GIGL_META_LEVEL0 + (L - l)]
             x = eng.gather_rows(u.nodes, n_src, cap) if l == 0 else h
-            hw = eng.linear(x, conv.lin.weight.contiguous(), None, n_src, cap, act=0)
-            act = 1 if (l < L - 1 or self.activation_after_last_conv) else 0
-            kw = {}
-            if edge_attr is not None:
-                kw = dict(edge_attr=edge_attr, att_edge_folded=conv.folded_att_edge(),
-                          w_edge_msg=conv.edge_message_weight())
-            h = eng.gat_aggregate(hw, conv.att_src.reshape(-1).contiguous(), conv.att_dst.reshape(-1).contiguous(),
-                                  conv.heads, conv.out_channels, u, n_dst, conv.bias, concat=conv.concat,
-                                  negative_slope=conv.negative_slope, act=act, **kw)
+            h = self._layer(eng, conv, l, x, u, n_src, n_dst, cap, edge_attr)
         if self.should_l2_normalize_embedding_layer_output:
             h = torch.nn.functional.normalize(h, p=2, dim=1)
         return h
+
+    def _layer(self, eng, conv, l, x, u, n_src, n_dst, cap, edge_attr):
+        hw = eng.linear(x, conv.lin.weight.contiguous(), None, n_src, cap, act=0)
+        act = 1 if (l < self.num_layers - 1 or self.activation_after_last_conv) else 0
+        kw = {}
+        if edge_attr is not None:
+            kw = dict(edge_attr=edge_attr, att_edge_folded=conv.folded_att_edge(), w_edge_msg=conv.edge_message_weight())
+        return eng.gat_aggregate(hw, conv.att_src.reshape(-1).contiguous(), conv.att_dst.reshape(-1).contiguous(),
+                                 conv.heads, conv.out_channels, u, n_dst, conv.bias, concat=conv.concat,
+                                 negative_slope=conv.negative_slope, act=act, **kw)
+
+    def _forward_graph(self, g, eng) -> torch.Tensor:
+        if eng is None:
+            raise RuntimeError("GAT.forward(GraphData) needs the HipEngine (model.engine = eng)")
+        assert g.rowptr is not None, "move the GraphData to the device first (GraphData.to)"
+        n = g.num_nodes
+        view = _CsrView(g)
+        edge_attr = None
+        if self.edge_dim is not None:
+            if g.edge_attr_csr is None:
+                raise ValueError(f"the model was built with edge_dim={self.edge_dim} but the batch has no edge features")
+            edge_attr = g.edge_attr_csr
+            assert edge_attr.shape[1] == self.edge_dim
+            if edge_attr.shape[0] != view.col.numel():  # edgeless batch: col holds one padding entry
+                edge_attr = torch.zeros((view.col.numel(), self.edge_dim), dtype=torch.float32, device=g.x.device)
+        h = g.x.contiguous()
+        for l, conv in enumerate(self.conv_layers):
+            h = self._layer(eng, conv, l, h, view, g.n_dev, g.n_dev, n, edge_attr)
+        if self.should_l2_normalize_embedding_layer_output:
+            h = torch.nn.functional.normalize(h, p=2, dim=1)
+        return h
+
+
+class _CsrView:
+    """the CSR of a coalesced GraphData in the shape gat_aggregate reads from a UnionGraph"""
+
+    def __init__(self, g):
+        self.rowptr, self.rowend, self.col = g.rowptr, g.rowptr[1:], g.col
+        self.meta = g.n_dev           # meta[0] = number of nodes
+        self.nodes = g.rowptr[1:]     # only its length (= node capacity) is read

@@ -27,6 +27,8 @@ class GraphData:
     rowptr: Optional[torch.Tensor] = None  # int32 [n+1]
     col: Optional[torch.Tensor] = None     # int32 [E], sources, rows ascending
     n_dev: Optional[torch.Tensor] = None   # int32 [1] = n (device-side row count for the kernels)
+    edge_attr: Optional[torch.Tensor] = None      # [E, De] fp32 in edge_index order (PyG Data.edge_attr)
+    edge_attr_csr: Optional[torch.Tensor] = None  # the same rows in `col` order
 
     @property
     def num_nodes(self) -> int:
@@ -40,7 +42,8 @@ class GraphData:
         device = torch.device(device)
         x = self.x.to(device=device, dtype=torch.float32).contiguous()
         ei = self.edge_index.to(device)
-        g = GraphData(x=x, edge_index=ei)
+        ea = None if self.edge_attr is None else self.edge_attr.to(device=device, dtype=torch.float32).contiguous()
+        g = GraphData(x=x, edge_index=ei, edge_attr=ea)
         if device.type == "cuda":
             g._build_csr()
         return g
@@ -50,6 +53,8 @@ class GraphData:
         src, dst = self.edge_index[0], self.edge_index[1]
         order = torch.argsort(dst * max(n, 1) + src)  # by destination, sources ascending
         self.col = src[order].to(torch.int32).contiguous()
+        if self.edge_attr is not None:
+            self.edge_attr_csr = self.edge_attr[order].contiguous()
         deg = torch.bincount(dst, minlength=n)
         rp = torch.zeros(n + 1, dtype=torch.int64, device=dev)
         rp[1:] = torch.cumsum(deg, 0)

@@ -174,6 +174,12 @@ int32_t gigl_collated_info(const gigl_collated* c, int64_t* n_nodes, int64_t* n_
 int32_t gigl_collated_copy(const gigl_collated* c, uint32_t* node_ids, float* x, int64_t* edge_index,
                            int64_t* root_local, int64_t* labels, uint8_t* has_label, int64_t* pos_off,
                            int64_t* pos_dst, int64_t* neg_off, int64_t* neg_dst);
+/* edge features of the collated batch (GraphBuilder.add_edge(feature_values), abstract_graph_builder.py:102-150;
+ * PygGraphBuilder.build stacks them into edge_attr, pyg_graph_builder.py:41-56): *edge_dim = floats per edge (0: the
+ * samples carry none), edge_attr [n_edges][edge_dim] in the order of edge_index (an edge keeps the features of the
+ * FIRST sample edge that registered it).  edge_attr may be NULL to query the dimension.  A batch whose edges do not
+ * all carry the same number of feature values fails in gigl_collate_records (the reference raises TypeError). */
+int32_t gigl_collated_edge_attr(const gigl_collated* c, int32_t* edge_dim, float* edge_attr);
 int32_t gigl_collated_destroy(gigl_collated* c);
 
 /* ---- node features: replaces loadNodeDataframeIntoSparkSql (SGSPureSparkV1Task.scala:52-118):

@@ -148,3 +148,45 @@ def test_gat_with_edge_features(setup, conv, share, heads, hid, out, fan):
         if l < L - 1:
             h = torch.relu(h)
     np.testing.assert_allclose(got, h[o["root_local"]].numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_tfrecord_path_carries_edge_features_end_to_end(setup):
+    """sampler -> device-encoded records (Edge.feature_values) -> native collate (edge_attr) -> GAT over the coalesced
+    batch graph == fp32 restatement on the collated arrays == the in-HBM union path, per root"""
+    from gigl_amd.batches import RootedNodeNeighborhoodBatch
+    from gigl_amd.models import HipBatch
+    from gigl_amd.models_attn import GAT
+    from gigl_amd import wire
+    eng, rowptr, col, x, efeat, n = setup
+    torch.manual_seed(3)
+    model = GAT(20, 12, 10, num_layers=2, heads=2, edge_dim=DE, conv="edge_attr_gat",
+                share_edge_att_message_weight=False).to(eng.device)
+    model.engine = eng
+    roots = np.random.default_rng(8).integers(0, n, size=64).astype(np.uint32)
+    tree = eng.sample_khop(roots, [5, 3])
+    buf, off = eng.encode_records(tree)
+    recs = list(wire.iter_tfrecords(buf.cpu().numpy().tobytes()))
+    assert len(recs) == 64
+    batch = RootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(recs)
+    g = batch.graph
+    assert g.edge_attr is not None and g.edge_attr.shape == (g.num_edges, DE)
+    # every collated edge carries the table row of its global (src, dst) pair
+    l2g = batch.condensed_node_type_to_subgraph_id_to_global_node_id[0]
+    gsrc = np.array([l2g[int(v)] for v in g.edge_index[0]], dtype=np.uint32)
+    gdst = np.array([l2g[int(v)] for v in g.edge_index[1]], dtype=np.uint32)
+    np.testing.assert_array_equal(g.edge_attr.numpy(), efeat[_csc_positions(rowptr, col, gsrc, gdst)])
+    idx = batch.condensed_node_type_to_root_node_indices_map[0]
+    got = model(g.to(eng.device))[idx.to(eng.device)].cpu().numpy()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    h = g.x
+    for l in range(2):
+        p = f"conv_layers.{l}."
+        h = gnn_ref.gat_conv(h, g.edge_index, sd[p + "lin.weight"], sd[p + "att_src"], sd[p + "att_dst"], sd[p + "bias"],
+                             2 if l == 0 else 1, edge_attr=g.edge_attr, w_edge=sd[p + "lin_edge.weight"],
+                             att_edge=sd[p + "att_edge"], w_edge_msg=sd[p + "lin_edge_message.weight"])
+        if l == 0:
+            h = torch.relu(h)
+    np.testing.assert_allclose(got, h[idx].numpy(), rtol=1e-5, atol=1e-5)
+    u = eng.union_build(tree)
+    via_union = model(HipBatch(eng, tree, u))[u.root_local[:64].long()].cpu().numpy()
+    np.testing.assert_allclose(via_union, got, rtol=1e-5, atol=1e-5)

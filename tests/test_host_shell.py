@@ -121,7 +121,7 @@ def test_collate_known_answers_and_traces(golden_dir):
                 if (a, c) not in seen:
                     seen.add((a, c)); es.append(_e(a, c))
             samples.append(([_n(v) for v in s["nodes"]], es))
-        x, ei, g2l, order = build_batch_graph(samples)
+        x, ei, g2l, order, _ = build_batch_graph(samples)
         assert g2l == {int(k): v for k, v in t["global_to_local"].items()}
         want = sorted(map(tuple, t["ordered_edges_local"]))  # coalesce(): sorted by (src, dst)
         assert [tuple(p) for p in ei.T.tolist()] == want

@@ -128,3 +128,78 @@ def test_error_cases_match_the_python_loops():
     lone = wire.RootedNodeNeighborhood(root_node=a).SerializeToString()
     out = fn([lone])
     assert out.graph.x.shape == (1, 2) and out.graph.edge_index.shape == (2, 0)
+
+
+# ---- edge features (Edge.feature_values -> edge_attr): pinned by traces of the reference GraphBuilder
+def _edge_feature_traces(golden_dir):
+    import json
+    return json.load(open(os.path.join(golden_dir, "graph_builder_edge_feature_traces.json")))
+
+
+def test_edge_features_match_reference_graph_builder_traces(golden_dir):
+    """tests/golden/graph_builder_edge_feature_traces.json (scripts/make_golden_edge_features.py imports the
+    reference's abstract_graph_builder.py): the registration that is kept for an edge seen in several samples"""
+    doc = _edge_feature_traces(golden_dir)
+    for t in doc["traces"]:
+        de = t["edge_dim"]
+        samples = []
+        for smp in t["samples"]:
+            nodes = [wire.Node(node_id=v, condensed_node_type=0, feature_values=np.array([v], np.float32))
+                     for v in smp["nodes"]]
+            edges = [wire.Edge(src_node_id=s, dst_node_id=d, condensed_edge_type=0,
+                               feature_values=np.array(f, np.float32)) for s, d, f in smp["edges"]]
+            samples.append(wire.RootedNodeNeighborhood(root_node=nodes[0],
+                                                       neighborhood=wire.Graph(nodes=nodes, edges=edges)))
+        want = {(s, d): np.array(f, np.float32)
+                for (s, d), f in zip(map(tuple, t["ordered_edges_local"]), t["ordered_edge_features"])}
+        ref = RootedNodeNeighborhoodBatch.collate_pyg_rooted_node_neighborhood_minibatch(samples)
+        nat = RootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn([s.SerializeToString() for s in samples])
+        g2l = {int(k): v for k, v in t["global_to_local"].items()}
+        for b in (ref, nat):
+            assert {g: l for l, g in b.condensed_node_type_to_subgraph_id_to_global_node_id[0].items()} == g2l
+            ei = b.graph.edge_index.numpy()
+            assert ei.shape[1] == len(want)
+            if not want:
+                assert b.graph.edge_attr is None or b.graph.edge_attr.shape[0] == 0
+                continue
+            assert b.graph.edge_attr.shape == (len(want), de)
+            for k in range(ei.shape[1]):
+                np.testing.assert_array_equal(b.graph.edge_attr[k].numpy(), want[(int(ei[0, k]), int(ei[1, k]))])
+        _same_graph(nat, ref)
+        if want:
+            assert torch.equal(nat.graph.edge_attr, ref.graph.edge_attr)
+
+
+def test_mixed_edge_feature_registration_raises_like_the_reference(golden_dir):
+    doc = _edge_feature_traces(golden_dir)
+    assert all(c["raises"] == "TypeError" for c in doc["mixed_registration"])
+    a = wire.Node(node_id=1, condensed_node_type=0, feature_values=np.array([1.0], np.float32))
+    b = wire.Node(node_id=2, condensed_node_type=0, feature_values=np.array([2.0], np.float32))
+    f = np.array([1.0, 2.0], np.float32)
+    for first_has in (True, False):
+        edges = [wire.Edge(src_node_id=1, dst_node_id=2, condensed_edge_type=0,
+                           feature_values=f if first_has else wire._EMPTY_F32),
+                 wire.Edge(src_node_id=2, dst_node_id=1, condensed_edge_type=0,
+                           feature_values=wire._EMPTY_F32 if first_has else f)]
+        s = wire.RootedNodeNeighborhood(root_node=a, neighborhood=wire.Graph(nodes=[a, b], edges=edges))
+        with pytest.raises(TypeError):
+            RootedNodeNeighborhoodBatch.collate_pyg_rooted_node_neighborhood_minibatch([s])
+        with pytest.raises(TypeError):
+            RootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn([s.SerializeToString()])
+
+
+def test_edge_features_random_batches_native_vs_python_loops():
+    rng = np.random.default_rng(11)
+    samples = []
+    for _ in range(200):
+        ids = rng.choice(300, size=rng.integers(1, 10), replace=False)
+        nodes = [wire.Node(node_id=int(v), condensed_node_type=0, feature_values=FEATS[v, :4]) for v in ids]
+        edges = [wire.Edge(src_node_id=int(rng.choice(ids)), dst_node_id=int(rng.choice(ids)), condensed_edge_type=0,
+                           feature_values=rng.standard_normal(3).astype(np.float32)) for _ in range(rng.integers(0, 15))]
+        samples.append(wire.SupervisedNodeClassificationSample(
+            root_node=nodes[0], neighborhood=wire.Graph(nodes=nodes, edges=edges),
+            root_node_labels=[wire.Label(label_type="y", label=1)]))
+    nat = SupervisedNodeClassificationBatch.process_raw_pyg_samples_and_collate_fn([s.SerializeToString() for s in samples])
+    ref = SupervisedNodeClassificationBatch.collate_pyg_node_classification_minibatch(samples)
+    _same_graph(nat, ref)
+    assert nat.graph.edge_attr.shape[1] == 3 and torch.equal(nat.graph.edge_attr, ref.graph.edge_attr)
