@@ -59,9 +59,16 @@ def load_preprocessed_graph(cfg: GbmlConfigPbWrapper):
             have = cnt[lk] > 0
             labels[lk] = dict(zip(ids[have].tolist(), data[lk][have, 0].tolist()))
     efiles = tfrecord_files(os.path.join(_res(cfg, em.tfrecord_uri_prefix), ""))
-    ed, _ = read_columns(efiles, [(em.src_node_id_key, COL_I64, 1), (em.dst_node_id_key, COL_I64, 1)])
+    ecols = [(em.src_node_id_key, COL_I64, 1), (em.dst_node_id_key, COL_I64, 1)]
+    # `_edge_features` = the main edge info's featureKeys columns concatenated in order (:172-193); empty without keys
+    ewidths = feature_widths(efiles[0], em.feature_keys) if efiles and em.feature_keys else []
+    ecols += [(k, COL_F32, max(w, 1)) for k, w in zip(em.feature_keys, ewidths)]
+    ed, _ = read_columns(efiles, ecols)
     src = ed[em.src_node_id_key][:, 0].astype(np.uint32)  # ids cast to int32 (:164-168)
     dst = ed[em.dst_node_id_key][:, 0].astype(np.uint32)
+    cfg.edge_features = None
+    if sum(ewidths):
+        cfg.edge_features = np.concatenate([ed[k][:, :w] for k, w in zip(em.feature_keys, ewidths) if w], axis=1)
     return n, src, dst, x, labels, sorted(set(ids.tolist()))
 
 
@@ -143,6 +150,8 @@ class SubgraphSampler:
         n, src, dst, x, labels, node_ids = load_preprocessed_graph(cfg)
         ids = np.asarray(node_ids, dtype=np.uint32)
         with HipKHopSamplerService(n, src, dst, x, cfg.is_graph_directed, device=device) as svc:
+            if getattr(cfg, "edge_features", None) is not None:  # hydrateEdges: records carry Edge.feature_values
+                svc.engine.load_edge_features(src, dst, cfg.edge_features, cfg.is_graph_directed)
             if cfg.task_kind == "node_classification":
                 return self._run_node_classification(cfg, svc, ids, labels, batch_size)
             return self._run_nablp(cfg, svc, ids, batch_size)

@@ -173,6 +173,61 @@ def test_inferencer_avro_embedding_shards(workdir):
         np.testing.assert_array_equal(np.array(a["emb"], np.float32), np.array(b["emb"], np.float32))
 
 
+def test_subgraph_sampler_hydrates_edge_features(workdir, golden_dir):
+    """mainEdgeInfo.featureKeys -> `_edge_features` (SGSPureSparkV1Task.scala:172-193) -> Edge.feature_values of every
+    neighbourhood edge (hydrateEdges :549-593): the fixture's edge table re-written with two feature columns (a scalar
+    and a 2-vector, symmetric in the endpoints because the graph is bidirectionalised)"""
+    import yaml
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    src_dir = os.path.join(workdir, "ref_assets/subgraph_sampler/supervised_node_classification/edge_data")
+    rows = [wire.decode_tf_example(r) for f in tfrecord_files(src_dir + "/") for r in wire.read_tfrecords(f)]
+
+    def feats(a, b):
+        lo, hi = min(a, b), max(a, b)
+        return np.float32(lo * 10 + hi), np.array([lo - hi, 0.5 * hi], np.float32)
+    ef_dir = os.path.join(workdir, "edge_data_with_features")
+    os.makedirs(ef_dir, exist_ok=True)
+    out = []
+    for r in rows:
+        a, b = int(np.asarray(r["src"]).ravel()[0]), int(np.asarray(r["dst"]).ravel()[0])
+        w, v = feats(a, b)
+        out.append(wire.encode_tf_example({"src": np.array([a], np.int64), "dst": np.array([b], np.int64),
+                                           "w": np.array([w], np.float32), "v": v}))
+    wire.write_tfrecords(os.path.join(ef_dir, "data.tfrecord"), out)
+    pm = yaml.safe_load(open(os.path.join(workdir, "configs/snc_preprocessed_metadata.yaml")))
+    em = pm["condensedEdgeTypeToPreprocessedMetadata"]["0"]
+    em["mainEdgeInfo"].update(tfrecordUriPrefix="edge_data_with_features", featureKeys=["w", "v"], featureDim=3)
+    yaml.safe_dump(pm, open(os.path.join(workdir, "configs/snc_ef_preprocessed_metadata.yaml"), "w"))
+    doc = yaml.safe_load(open(os.path.join(workdir, "configs/snc_frozen_gbml_config.yaml")))
+    doc["sharedConfig"]["preprocessedMetadataUri"] = "configs/snc_ef_preprocessed_metadata.yaml"
+    flat = doc["sharedConfig"]["flattenedGraphMetadata"]["supervisedNodeClassificationOutput"]
+    flat["labeledTfrecordUriPrefix"] = "out/snc_ef/labeled/samples/"
+    flat["unlabeledTfrecordUriPrefix"] = "out/snc_ef/unlabeled/samples/"
+    yaml.safe_dump(doc, open(os.path.join(workdir, "configs/snc_ef_gbml_config.yaml"), "w"))
+    SubgraphSampler().run("job", "configs/snc_ef_gbml_config.yaml", None, uri_base=workdir)
+    cfg = GbmlConfigPbWrapper.from_uri("configs/snc_ef_gbml_config.yaml", uri_base=workdir)
+    plain = GbmlConfigPbWrapper.from_uri("configs/snc_frozen_gbml_config.yaml", uri_base=workdir)
+    SubgraphSampler().run("job", "configs/snc_frozen_gbml_config.yaml", None, uri_base=workdir)
+    got = [wire.RootedNodeNeighborhood.FromString(r) for f in tfrecord_files(cfg.unlabeled_tfrecord_uri_prefix)
+           for r in wire.read_tfrecords(f)]
+    base = [wire.RootedNodeNeighborhood.FromString(r) for f in tfrecord_files(plain.unlabeled_tfrecord_uri_prefix)
+            for r in wire.read_tfrecords(f)]
+    assert len(got) == len(base) == 16
+    n_edges = 0
+    for g, b in zip(got, base):  # same sample, plus the features
+        assert g.root_node == b.root_node and g.neighborhood.nodes == b.neighborhood.nodes
+        assert [(e.src_node_id, e.dst_node_id) for e in g.neighborhood.edges] == \
+               [(e.src_node_id, e.dst_node_id) for e in b.neighborhood.edges]
+        for e in g.neighborhood.edges:
+            w, v = feats(e.src_node_id, e.dst_node_id)
+            np.testing.assert_array_equal(e.feature_values, np.concatenate([[w], v]).astype(np.float32))
+            n_edges += 1
+    assert n_edges > 20
+    lab = [wire.SupervisedNodeClassificationSample.FromString(r) for f in tfrecord_files(cfg.labeled_tfrecord_uri_prefix)
+           for r in wire.read_tfrecords(f)]
+    assert len(lab) == 14 and all(e.feature_values.size == 3 for s_ in lab for e in s_.neighborhood.edges)
+
+
 def test_sampler_split_generator_trainer_chain(workdir):
     """sampler -> split generator -> trainer: the trainer reads the train/val/test files the split generator wrote
     (datasetMetadata.supervisedNodeClassificationDataset), as the reference's pipeline does"""
