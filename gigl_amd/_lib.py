@@ -36,7 +36,7 @@ SYMBOLS = [
     "gigl_tfrecord_index", "gigl_tfexample_decode", "gigl_collate_records", "gigl_collated_info", "gigl_collated_copy",
     "gigl_collated_destroy", "gigl_gather_reduce", "gigl_gather_reduce_backward",
     "gigl_frontier_bucket", "gigl_frontier_scatter", "gigl_avro_embeddings_layout", "gigl_avro_embeddings_encode",
-    "gigl_edge_ids", "gigl_union_edge_ids", "gigl_gat_aggregate_edge", "gigl_collated_edge_attr",
+    "gigl_edge_ids", "gigl_union_edge_ids", "gigl_gat_aggregate_edge", "gigl_collated_edge_attr", "gigl_sample_out_neighbors",
 ]
 
 KERNEL_IDS = {
@@ -80,6 +80,11 @@ class GiglRecordOpts(C.Structure):
         ("suffix_off", C.c_void_p),
         ("graph", C.c_void_p),
         ("edge_feat", C.c_void_p),
+        ("n_neg_trees", C.c_int32),
+        ("pos_edges_graph", C.c_void_p),
+        ("pos_edge_feat", C.c_void_p),
+        ("neg_edges_graph", C.c_void_p),
+        ("neg_edge_feat", C.c_void_p),
     ]
 
 
@@ -142,6 +147,7 @@ def load() -> C.CDLL:
         "gigl_features_destroy": [vp],
         "gigl_sample_khop": [vp, vp, vp, i32, P(i32), i32, i32, i32, P(GiglTree)],
         "gigl_sample_positives": [vp, vp, vp, i32, i32, i32, i32, vp, vp],
+        "gigl_sample_out_neighbors": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
         "gigl_union_capacity": [i32, P(i32), i32, P(i64), P(i64)],
         "gigl_union_build": [vp, vp, P(GiglTree), P(GiglUnion)],
         "gigl_union_build_groups": [vp, vp, P(GiglTree), i32, P(GiglUnion)],

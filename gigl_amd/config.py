@@ -58,12 +58,22 @@ class NodeMetadata:
 
 
 @dataclass
+class EdgeInfo:
+    """EdgeMetadataInfo (preprocessed_metadata.proto:28-43) of the user-defined positive / negative label edges"""
+    tfrecord_uri_prefix: str
+    feature_keys: List[str]
+    feature_dim: int
+
+
+@dataclass
 class EdgeMetadata:
     tfrecord_uri_prefix: str
     src_node_id_key: str
     dst_node_id_key: str
     feature_keys: List[str]
     feature_dim: int
+    positive_edge_info: Optional[EdgeInfo] = None  # :54-57: present = user-defined positives / hard negatives
+    negative_edge_info: Optional[EdgeInfo] = None
 
 
 @dataclass
@@ -83,10 +93,16 @@ class PreprocessedMetadata:
                 feature_dim=int(v.get("featureDim", 0)))
         for k, v in (doc.get("condensedEdgeTypeToPreprocessedMetadata") or {}).items():
             main = v.get("mainEdgeInfo") or {}
+            def info(d):
+                if not d or not d.get("tfrecordUriPrefix"):
+                    return None
+                return EdgeInfo(tfrecord_uri_prefix=d["tfrecordUriPrefix"], feature_keys=list(d.get("featureKeys") or []),
+                                feature_dim=int(d.get("featureDim", 0)))
             m.edges[int(k)] = EdgeMetadata(
                 tfrecord_uri_prefix=main["tfrecordUriPrefix"], src_node_id_key=v["srcNodeIdKey"],
                 dst_node_id_key=v["dstNodeIdKey"], feature_keys=list(main.get("featureKeys") or []),
-                feature_dim=int(main.get("featureDim", 0)))
+                feature_dim=int(main.get("featureDim", 0)), positive_edge_info=info(v.get("positiveEdgeInfo")),
+                negative_edge_info=info(v.get("negativeEdgeInfo")))
         return m
 
 
@@ -162,6 +178,14 @@ class GbmlConfigPbWrapper:
     @property
     def num_positive_samples(self) -> int:
         return int(_get(self.doc, "datasetConfig.subgraphSamplerConfig.numPositiveSamples", 0) or 0)
+
+    @property
+    def num_user_defined_positive_samples(self) -> int:
+        return int(_get(self.doc, "datasetConfig.subgraphSamplerConfig.numUserDefinedPositiveSamples", 0) or 0)
+
+    @property
+    def num_user_defined_negative_samples(self) -> int:
+        return int(_get(self.doc, "datasetConfig.subgraphSamplerConfig.numUserDefinedNegativeSamples", 0) or 0)
 
     @property
     def experimental_flags(self) -> Dict[str, str]:

@@ -1043,7 +1043,16 @@ int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* n
 int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* roots, int32_t b,
                               int32_t f, int32_t sampling_seed, int32_t mode, uint32_t* pos,
                               int32_t* cnt) {
+  // sampleDstNodesUniformly is the third hashBasedUniformPermutation call of the job: _counter = 3
+  // (NodeAnchorBasedLinkPredictionTask.scala:171-172)
+  return gigl_sample_out_neighbors(ctx, g_out, roots, b, f, sampling_seed, 3, mode, pos, cnt);
+}
+
+int32_t gigl_sample_out_neighbors(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* roots, int32_t b,
+                                  int32_t f, int32_t sampling_seed, int32_t counter, int32_t mode, uint32_t* pos,
+                                  int32_t* cnt) {
   if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, counter >= 1 && counter <= 64, "permutation call counter %d outside [1,64]", counter);
   GIGL_REQUIRE(ctx, g_out && (roots || b == 0) && pos && cnt, "null argument");
   GIGL_REQUIRE(ctx, mode == GIGL_MODE_SPARK_HASH, "positives are parity-mode only");
   if (f < 1 || f > GIGL_MAX_FANOUT)
@@ -1064,12 +1073,10 @@ int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* 
   a.n_parents = b;
   a.f = f;
   a.fan[0] = f;
-  // sampleDstNodesUniformly is the third hashBasedUniformPermutation call of the job: _counter = 3
-  // (NodeAnchorBasedLinkPredictionTask.scala:171-172)
-  a.hash_add = (int32_t)((uint32_t)sampling_seed * 3u);
+  a.hash_add = (int32_t)((uint32_t)sampling_seed * (uint32_t)counter);
   a.out_nbr = pos;
   a.out_cnt = cnt;
-  const uint64_t bound = window_bound(g_out, 1, 3, sampling_seed);
+  const uint64_t bound = window_bound(g_out, 1, counter, sampling_seed);
   const uint64_t cap = 1ull << 30;
   rc = ensure_table(ctx, bound == ~0ULL ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));
   if (rc != GIGL_OK) return rc;

@@ -64,6 +64,16 @@ struct RecArgs {
   const int64_t* g_rowptr;
   const uint32_t* g_col;
   int64_t g_n;
+  // user-defined label edges (UserDefinedLabelsNodeAnchorBasedLinkPredictionTask.scala): the last neg_trees trees of
+  // a record are the hard negatives; lab[0] / lab[1] = where the features of the pos / hard-neg edges come from
+  int32_t neg_trees;
+  struct LabelEdges {
+    const int64_t* rowptr;  // CSR by SOURCE of the label edge list (NULL: pos edges are main edges, see edge_pos)
+    const uint32_t* col;
+    int64_t n;
+    const float* feat;  // rows in `col` order
+    int32_t de;
+  } lab[2];
 };
 
 __device__ __forceinline__ int vlen(uint32_t v) {
@@ -87,13 +97,20 @@ __device__ __forceinline__ uint32_t node_body_len(const RecArgs& a, uint32_t id)
   if (a.d > 0) n += 1 + vlen(4u * (uint32_t)a.d) + 4u * (uint32_t)a.d;
   return n;
 }
-__device__ __forceinline__ uint32_t edge_body_len(const RecArgs& a, uint32_t s, uint32_t d) {
+__device__ __forceinline__ uint32_t edge_body_len_de(const RecArgs& a, uint32_t s, uint32_t d, int32_t de) {
   uint32_t n = 0;
   if (s) n += 1 + vlen(s);
   if (d) n += 1 + vlen(d);
   if (a.edge_type >= 0) n += 1 + vlen((uint32_t)a.edge_type);
-  if (a.de > 0) n += 1 + vlen(4u * (uint32_t)a.de) + 4u * (uint32_t)a.de;
+  if (de > 0) n += 1 + vlen(4u * (uint32_t)de) + 4u * (uint32_t)de;
   return n;
+}
+__device__ __forceinline__ uint32_t edge_body_len(const RecArgs& a, uint32_t s, uint32_t d) {
+  return edge_body_len_de(a, s, d, a.de);
+}
+// feature dimension of the pos (which = 0) / hard-neg (1) label edges
+__device__ __forceinline__ int32_t label_de(const RecArgs& a, int which) {
+  return a.lab[which].rowptr ? a.lab[which].de : (which == 0 ? a.de : 0);
 }
 __device__ __forceinline__ uint32_t field_len(uint32_t body) { return 1 + vlen(body) + body; }
 // position of the edge s -> d in the resident CSC (row d ascending), NONE when absent
@@ -305,7 +322,7 @@ __device__ void build_plan(const RecArgs& a, int64_t r, Plan& pl, uint32_t* hkey
 
 // sizes of the fixed parts of record r (uniform over the workgroup)
 struct Layout {
-  uint32_t root_id, root_body, graph_body, pos_bytes;
+  uint32_t root_id, root_body, graph_body, pos_bytes, neg_bytes;
   uint64_t suffix_len, payload;
 };
 __device__ __forceinline__ Layout layout_of(const RecArgs& a, int64_t r, const Plan& pl) {
@@ -313,14 +330,16 @@ __device__ __forceinline__ Layout layout_of(const RecArgs& a, int64_t r, const P
   L.root_id = a.roots[r * a.trees];
   L.root_body = node_body_len(a, L.root_id);
   L.graph_body = pl.nodes_bytes + pl.edges_bytes;
-  L.pos_bytes = 0;
+  L.pos_bytes = L.neg_bytes = 0;
   if (a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED)
     for (int tt = 1; tt < a.trees; ++tt) {
       const uint32_t p = a.roots[r * a.trees + tt];
-      if (p != NONE) L.pos_bytes += field_len(edge_body_len(a, L.root_id, p));
+      if (p == NONE) continue;
+      const int which = tt >= a.trees - a.neg_trees ? 1 : 0;
+      (which ? L.neg_bytes : L.pos_bytes) += field_len(edge_body_len_de(a, L.root_id, p, label_de(a, which)));
     }
   L.suffix_len = a.suffix_off ? (uint64_t)(a.suffix_off[r + 1] - a.suffix_off[r]) : 0;
-  L.payload = (uint64_t)field_len(L.root_body) + field_len(L.graph_body) + L.pos_bytes + L.suffix_len;
+  L.payload = (uint64_t)field_len(L.root_body) + L.neg_bytes + field_len(L.graph_body) + L.pos_bytes + L.suffix_len;
   return L;
 }
 
@@ -439,9 +458,10 @@ __device__ __forceinline__ void write_node_header(const RecArgs& a, uint8_t* q, 
 
 // header of an Edge field (everything before the float payload; the whole field without edge features); returns
 // the address right after it
-__device__ __forceinline__ uint8_t* write_edge(const RecArgs& a, uint8_t* p, uint8_t tag, uint32_t s, uint32_t d) {
+__device__ __forceinline__ uint8_t* write_edge(const RecArgs& a, uint8_t* p, uint8_t tag, uint32_t s, uint32_t d,
+                                               int32_t de) {
   *p++ = tag;
-  p = put_varint(p, edge_body_len(a, s, d));
+  p = put_varint(p, edge_body_len_de(a, s, d, de));
   if (s) {
     *p++ = 0x08;
     p = put_varint(p, s);
@@ -454,21 +474,48 @@ __device__ __forceinline__ uint8_t* write_edge(const RecArgs& a, uint8_t* p, uin
     *p++ = 0x18;
     p = put_varint(p, (uint32_t)a.edge_type);
   }
-  if (a.de > 0) {
+  if (de > 0) {
     *p++ = 0x22;
-    p = put_varint(p, 4u * (uint32_t)a.de);
+    p = put_varint(p, 4u * (uint32_t)de);
   }
   return p;
-}
-// feature word k of the edge at CSC position `pos` as the bit pattern the proto carries (zeros for an unknown edge)
-__device__ __forceinline__ uint32_t efeat_word(const RecArgs& a, uint32_t pos, uint32_t k) {
-  return pos == NONE ? 0u : __float_as_uint(a.efeat[(int64_t)pos * a.de + k]);
 }
 __device__ __forceinline__ void put_word(uint8_t* p, uint32_t v) {
   p[0] = (uint8_t)v;
   p[1] = (uint8_t)(v >> 8);
   p[2] = (uint8_t)(v >> 16);
   p[3] = (uint8_t)(v >> 24);
+}
+// a label edge root -> t (pos_edges = 4 / hard_neg_edges = 2) with its features; returns the address after it
+__device__ __forceinline__ uint8_t* write_label_edge(const RecArgs& a, uint8_t* e, int which, uint32_t root,
+                                                     uint32_t t) {
+  const int32_t de = label_de(a, which);
+  e = write_edge(a, e, which == 0 ? 0x22 : 0x12, root, t, de);
+  if (de <= 0) return e;
+  const RecArgs::LabelEdges& lb = a.lab[which];
+  const float* row = nullptr;
+  if (lb.rowptr) {  // CSR by source: row `root`, ascending destinations
+    if ((int64_t)root < lb.n) {
+      int64_t lo = lb.rowptr[root];
+      const int64_t end = lb.rowptr[root + 1];
+      int64_t hi = end;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (lb.col[mid] < t) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo < end && lb.col[lo] == t) row = lb.feat + lo * de;
+    }
+  } else {
+    const uint32_t at = edge_pos(a, root, t);
+    if (at != NONE) row = a.efeat + (int64_t)at * de;
+  }
+  for (int k = 0; k < de; ++k, e += 4) put_word(e, row ? __float_as_uint(row[k]) : 0u);
+  return e;
+}
+// feature word k of the edge at CSC position `pos` as the bit pattern the proto carries (zeros for an unknown edge)
+__device__ __forceinline__ uint32_t efeat_word(const RecArgs& a, uint32_t pos, uint32_t k) {
+  return pos == NONE ? 0u : __float_as_uint(a.efeat[(int64_t)pos * a.de + k]);
 }
 
 // ---- CRC-32C pieces (reflected domain: bit 31 of a word is the coefficient of x^0)
@@ -529,7 +576,8 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
   const Layout L = layout_of(a, r, pl);
   uint8_t* const rec = out + rec_off[r];
   uint8_t* const payload = rec + (a.frame ? 12 : 0);
-  uint8_t* const graph_hdr = payload + field_len(L.root_body);
+  uint8_t* const hard_neg = payload + field_len(L.root_body);  // hard_neg_edges = 2 sits between root_node and neighborhood
+  uint8_t* const graph_hdr = hard_neg + L.neg_bytes;
   uint8_t* const graph = graph_hdr + 1 + vlen(L.graph_body);
   uint8_t* const edges = graph + pl.nodes_bytes;
   uint8_t* const pos = graph + L.graph_body;
@@ -552,14 +600,12 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
     put_varint(q, L.graph_body);
     if (a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED) {
       uint8_t* e = pos;
+      uint8_t* ng = hard_neg;
       for (int tt = 1; tt < a.trees; ++tt) {
         const uint32_t p = a.roots[r * a.trees + tt];
         if (p == NONE) continue;
-        e = write_edge(a, e, 0x22, L.root_id, p);  // pos_edges = 4
-        if (a.de > 0) {
-          const uint32_t at = edge_pos(a, L.root_id, p);
-          for (int k = 0; k < a.de; ++k, e += 4) put_word(e, efeat_word(a, at, (uint32_t)k));
-        }
+        if (tt >= a.trees - a.neg_trees) ng = write_label_edge(a, ng, 1, L.root_id, p);  // hard_neg_edges = 2
+        else e = write_label_edge(a, e, 0, L.root_id, p);                                  // pos_edges = 4
       }
     }
   }
@@ -665,7 +711,7 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
     if (pl.edge_off[q] == NONE) continue;
     uint32_t s, d;
     stream_edge(a, r, q, s, d);
-    uint8_t* const pay = write_edge(a, edges + pl.edge_off[q], 0x1A, s, d);
+    uint8_t* const pay = write_edge(a, edges + pl.edge_off[q], 0x1A, s, d, a.de);
     if (a.de > 0) {
       pl.edge_pay[q] = (uint32_t)(pay - edges);
       pl.edge_pos[q] = edge_pos(a, s, d);
@@ -830,11 +876,15 @@ int32_t gigl_records_capacity(const int32_t* fanouts, int32_t hops, int32_t d, c
   }
   const int64_t node_body = 6 + 6 + (d > 0 ? 1 + hvlen(4ull * d) + 4ll * d : 0);
   const int64_t node_field = 1 + hvlen(node_body) + node_body;
-  const int64_t de = opts->edge_feat ? opts->edge_feat->d : 0;
-  const int64_t edge_field = 1 + 5 + 6 + 6 + 6 + (de > 0 ? 1 + hvlen(4ull * de) + 4 * de : 0);
+  int64_t de = opts->edge_feat ? opts->edge_feat->d : 0;
+  auto edge_bytes = [](int64_t k) { return 1 + 5 + 6 + 6 + 6 + (k > 0 ? 1 + hvlen(4ull * k) + 4 * k : 0); };
+  const int64_t edge_field = edge_bytes(de);
+  if (opts->pos_edge_feat && opts->pos_edge_feat->d > de) de = opts->pos_edge_feat->d;
+  if (opts->neg_edge_feat && opts->neg_edge_feat->d > de) de = opts->neg_edge_feat->d;
+  const int64_t label_field = edge_bytes(de);
   const int64_t t = opts->trees_per_record;
   const int64_t graph = t * ((sum + 1) * node_field + sum * edge_field);
-  const int64_t per = node_field + 1 + hvlen(graph) + graph + (t - 1) * edge_field + 16;
+  const int64_t per = node_field + 1 + hvlen(graph) + graph + (t - 1) * label_field + 16;
   *bytes = n_records * per + suffix_total;
   return GIGL_OK;
 }
@@ -873,6 +923,30 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
     a.g_rowptr = opts->graph->rowptr;
     a.g_col = opts->graph->col;
     a.g_n = opts->graph->n;
+  }
+  GIGL_REQUIRE(ctx, opts->n_neg_trees >= 0 && opts->n_neg_trees < a.trees, "n_neg_trees %d outside [0,%d)",
+               opts->n_neg_trees, a.trees);
+  GIGL_REQUIRE(ctx, opts->n_neg_trees == 0 || opts->kind == GIGL_REC_NODE_ANCHOR_LINK_PRED,
+               "hard negatives belong to NodeAnchorBasedLinkPredictionSample records");
+  a.neg_trees = opts->n_neg_trees;
+  for (int which = 0; which < 2; ++which) {
+    gigl_graph* lg = which ? opts->neg_edges_graph : opts->pos_edges_graph;
+    gigl_feat* lf = which ? opts->neg_edge_feat : opts->pos_edge_feat;
+    if (!lf || lf->d <= 0) continue;
+    GIGL_REQUIRE(ctx, lg, "label-edge features need the label edge list as a CSR-by-source graph");
+    GIGL_REQUIRE(ctx, lf->dtype == GIGL_DTYPE_F32 && lf->n == lg->e, "label-edge feature table does not match its graph");
+    a.lab[which].rowptr = lg->rowptr;
+    a.lab[which].col = lg->col;
+    a.lab[which].n = lg->n;
+    a.lab[which].feat = (const float*)lf->rows;
+    a.lab[which].de = lf->d;
+  }
+  // user-defined positives without features: pos_edges must not pick up the MAIN edge table
+  if (opts->pos_edges_graph && !a.lab[0].rowptr) {
+    a.lab[0].rowptr = opts->pos_edges_graph->rowptr;
+    a.lab[0].col = opts->pos_edges_graph->col;
+    a.lab[0].n = opts->pos_edges_graph->n;
+    a.lab[0].de = 0;
   }
   a.n_records = n_records;
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));

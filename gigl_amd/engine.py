@@ -129,6 +129,9 @@ class HipEngine:
         if getattr(self, "_ctx", None):
             for p in list(getattr(self, "_plans", [])):
                 p.close()
+            for entry in getattr(self, "_label_edges", {}).values():
+                self._free_label_edges(entry)
+            self._label_edges = {}
             if not getattr(self, "_borrowed", False):
                 for h, fn in ((self._graph, self._lib.gigl_graph_destroy),
                               (self._graph_out, self._lib.gigl_graph_destroy),
@@ -371,22 +374,70 @@ class HipEngine:
                                               C.c_void_p(child_ksums.data_ptr()) if child_ksums is not None else None),
               self._ctx)
 
-    def sample_positives(self, roots, num_positives: int, sampling_seed: int = 42):
-        assert self._graph_out is not None, "load the out-edge graph first (out_graph=True)"
+    def sample_positives(self, roots, num_positives: int, sampling_seed: int = 42, *, counter: int = 3,
+                         label_edges: Optional[str] = None):
+        """`num_positives` out-neighbours of every root (sampleDstNodesUniformly): of the main out-edge graph, or of a
+        user-defined label edge list loaded with load_label_edges(label_edges, ...).  `counter` = the job's
+        hashBasedUniformPermutation call number (3 for positives, 4 for user-defined hard negatives)."""
+        g = self._label_edges[label_edges]["graph"] if label_edges else self._graph_out
+        assert g is not None, "load the out-edge graph first (out_graph=True)"
         r = self._roots_tensor(roots)
         b = int(r.numel())
         pos = torch.empty(max(b * num_positives, 1), dtype=torch.int32, device=self.device)
         cnt = torch.empty(max(b, 1), dtype=torch.int32, device=self.device)
-        check(self._lib.gigl_sample_positives(self._ctx, self._graph_out, C.c_void_p(r.data_ptr()), b, num_positives,
-                                              sampling_seed, MODE_SPARK_HASH, C.c_void_p(pos.data_ptr()),
-                                              C.c_void_p(cnt.data_ptr())), self._ctx)
+        check(self._lib.gigl_sample_out_neighbors(self._ctx, g, C.c_void_p(r.data_ptr()), b, num_positives,
+                                                  sampling_seed, counter, MODE_SPARK_HASH, C.c_void_p(pos.data_ptr()),
+                                                  C.c_void_p(cnt.data_ptr())), self._ctx)
         return pos[: b * num_positives], cnt[:b]
+
+    def load_label_edges(self, name: str, n: int, src, dst, feats=None) -> None:
+        """a user-defined label edge list ("pos" / "neg": loadEdgeDataframeIntoSparkSql with EdgeUsageType.POS / NEG —
+        never bidirectionalised) as CSR by source, plus its feature rows put in that graph's `col` order (several
+        input rows for one (src, dst): the first wins)"""
+        if not hasattr(self, "_label_edges"):
+            self._label_edges = {}
+        old = self._label_edges.pop(name, None)
+        if old:
+            self._free_label_edges(old)
+        s = np.ascontiguousarray(np.asarray(src).astype(np.uint32))
+        d = np.ascontiguousarray(np.asarray(dst).astype(np.uint32))
+        g = C.c_void_p()
+        # roles swapped: rows = sources, columns = destinations
+        check(self._lib.gigl_graph_build_from_coo(self._ctx, n, int(s.shape[0]), C.c_void_p(d.ctypes.data),
+                                                  C.c_void_p(s.ctypes.data), LOC_HOST, 1, C.byref(g)), self._ctx)
+        nn, ee = C.c_int64(), C.c_int64()
+        check(self._lib.gigl_graph_info(g, C.byref(nn), C.byref(ee)), self._ctx)
+        entry = {"graph": g, "feat": None, "table": None, "n_edges": ee.value}
+        if feats is not None and np.asarray(feats).size:
+            f = torch.from_numpy(np.ascontiguousarray(np.asarray(feats, dtype=np.float32))).to(self.device)
+            assert f.dim() == 2 and f.shape[0] == s.shape[0]
+            st = torch.from_numpy(s.view(np.int32)).to(self.device)
+            dt = torch.from_numpy(d.view(np.int32)).to(self.device)
+            eid = torch.empty(st.numel(), dtype=torch.int64, device=self.device)
+            check(self._lib.gigl_edge_ids(self._ctx, g, C.c_void_p(dt.data_ptr()), C.c_void_p(st.data_ptr()), st.numel(),
+                                          C.c_void_p(eid.data_ptr())), self._ctx)
+            self._stream.synchronize()
+            win = torch.full((ee.value,), st.numel(), dtype=torch.int64, device=self.device)
+            win.scatter_reduce_(0, eid, torch.arange(st.numel(), device=self.device), reduce="amin")
+            table = f[win].contiguous()
+            h = C.c_void_p()
+            check(self._lib.gigl_features_load(self._ctx, table.shape[0], table.shape[1], DTYPE_F32,
+                                               C.c_void_p(table.data_ptr()), LOC_DEVICE, C.byref(h)), self._ctx)
+            entry["feat"], entry["table"] = h, table
+        self._label_edges[name] = entry
+
+    def _free_label_edges(self, entry) -> None:
+        if entry.get("feat"):
+            self._lib.gigl_features_destroy(entry["feat"])
+        if entry.get("graph"):
+            self._lib.gigl_graph_destroy(entry["graph"])
 
     def encode_records(self, tree: Tree, *, kind: int = _lib.REC_ROOTED_NODE_NEIGHBORHOOD, trees_per_record: int = 1,
                        condensed_node_type: Optional[int] = 0, condensed_edge_type: Optional[int] = 0,
                        tfrecord_frame: bool = True, emit: Optional[torch.Tensor] = None,
                        suffix: Optional[torch.Tensor] = None, suffix_off: Optional[torch.Tensor] = None,
-                       with_features: bool = True, with_edge_features: bool = True):
+                       with_features: bool = True, with_edge_features: bool = True, n_neg_trees: int = 0,
+                       pos_label_edges: Optional[str] = None, neg_label_edges: Optional[str] = None):
         """sampled trees -> serialized RootedNodeNeighborhood / SupervisedNodeClassificationSample (suffix = encoded
         labels) / NodeAnchorBasedLinkPredictionSample records, encoded on the device (gigl_records_encode).
         -> (uint8 device tensor of all records back to back, int64 device tensor rec_off[n_records+1])"""
@@ -416,6 +467,13 @@ class HipEngine:
         feat = self._feat if with_features else None
         if with_edge_features and getattr(self, "_efeat_handle", None):
             o.graph, o.edge_feat = self._graph, self._efeat_handle  # Edge.feature_values from the resident table
+        o.n_neg_trees = int(n_neg_trees)
+        if pos_label_edges:  # user-defined label edges: their own edge list (and feature table)
+            e = self._label_edges[pos_label_edges]
+            o.pos_edges_graph, o.pos_edge_feat = e["graph"], e["feat"]
+        if neg_label_edges:
+            e = self._label_edges[neg_label_edges]
+            o.neg_edges_graph, o.neg_edge_feat = e["graph"], e["feat"]
         fo = (C.c_int32 * len(tree.fanouts))(*tree.fanouts)
         cap = C.c_int64()
         check(self._lib.gigl_records_capacity(fo, len(tree.fanouts), self.feat_dim if feat else 0, C.byref(o), n_rec,

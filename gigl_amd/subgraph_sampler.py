@@ -72,6 +72,24 @@ def load_preprocessed_graph(cfg: GbmlConfigPbWrapper):
     return n, src, dst, x, labels, sorted(set(ids.tolist()))
 
 
+def load_label_edge_table(cfg: GbmlConfigPbWrapper, info):
+    """loadEdgeDataframeIntoSparkSql with EdgeUsageType.POS / NEG (SGSPureSparkV1Task.scala:120-216): the user-defined
+    label edges and their feature columns; never bidirectionalised (:218-258 applies to MAIN edges only)"""
+    from .ingest import COL_F32, COL_I64, feature_widths, read_columns
+    em = cfg.preprocessed_metadata.edges[0]
+    files = tfrecord_files(os.path.join(_res(cfg, info.tfrecord_uri_prefix), ""))
+    cols = [(em.src_node_id_key, COL_I64, 1), (em.dst_node_id_key, COL_I64, 1)]
+    widths = feature_widths(files[0], info.feature_keys) if files and info.feature_keys else []
+    cols += [(k, COL_F32, max(w, 1)) for k, w in zip(info.feature_keys, widths)]
+    ed, _ = read_columns(files, cols)
+    src = ed[em.src_node_id_key][:, 0].astype(np.uint32)
+    dst = ed[em.dst_node_id_key][:, 0].astype(np.uint32)
+    feats = None
+    if sum(widths):
+        feats = np.concatenate([ed[k][:, :w] for k, w in zip(info.feature_keys, widths) if w], axis=1)
+    return src, dst, feats
+
+
 def _res(cfg: GbmlConfigPbWrapper, uri: str) -> str:
     from .config import resolve_uri
     return resolve_uri(uri, cfg.uri_base)
@@ -191,25 +209,50 @@ class SubgraphSampler:
         """createNodeAnchorBasedLinkPredictionSubgraph (NodeAnchorBasedLinkPredictionTask.scala:146-312):
         neighborhood = array_distinct(root nbhd ++ union of the positives' nbhds) — the positives' rooted samples are
         re-derived on the device (the sample of a root is a pure function of the root and the seed, so this equals
-        the reference's lookup in its cached per-node table); pos_edges = [root -> pos]; hard_neg_edges = neg_edges = []"""
+        the reference's lookup in its cached per-node table); pos_edges = [root -> pos]; hard_neg_edges = [] unless the
+        preprocessed metadata names user-defined label edges (see below); neg_edges = []"""
         import torch
         from . import _lib
         eng = svc.engine
-        P = cfg.num_positive_samples
+        # User-defined labels (UserDefinedLabelsNodeAnchorBasedLinkPredictionTask.scala): positives / hard negatives are
+        # sampled from the user's own edge lists (counter 3 / 4), their neighbourhoods are merged into the sample and
+        # the label edges carry the user tables' features; roots = nodes with at least one user-defined positive.
+        em = cfg.preprocessed_metadata.edges[0]
+        pos_ud, neg_ud = em.positive_edge_info is not None, em.negative_edge_info is not None
+        P, Q = cfg.num_positive_samples, 0
+        n_ids = eng.n_nodes
+        if pos_ud:
+            P = cfg.num_user_defined_positive_samples
+            assert P > 0, ("numUserDefinedPositiveSamples must be provided in subgraphSamplerConfig and > 0 if user "
+                           "defined pos edges are provided")
+            eng.load_label_edges("pos", n_ids, *load_label_edge_table(cfg, em.positive_edge_info))
+        if neg_ud:
+            Q = cfg.num_user_defined_negative_samples
+            assert Q > 0, ("numUserDefinedNegativeSamples must be provided in subgraphSamplerConfig and > 0 if user "
+                           "defined neg edges are provided")
+            eng.load_label_edges("neg", n_ids, *load_label_edge_table(cfg, em.negative_edge_info))
+        T = 1 + P + Q
         main = _PartWriter(cfg.nablp_tfrecord_uri_prefix)
         rn = {t: _PartWriter(p) for t, p in cfg.random_negative_tfrecord_uri_prefixes.items()}
         limit = cfg.num_max_training_samples_to_output  # LIMIT n of the main samples (first n in node-id order)
-        for i in range(0, ids.size, max(1, batch_size // (1 + P))):
-            chunk = ids[i:i + max(1, batch_size // (1 + P))]
+        for i in range(0, ids.size, max(1, batch_size // T)):
+            chunk = ids[i:i + max(1, batch_size // T)]
             roots = eng._roots_tensor(chunk)
-            pos, cnt = eng.sample_positives(roots, P, sampling_seed=svc.sampling_seed)
-            grouped = torch.cat([roots.view(-1, 1), pos.view(-1, P)], dim=1).reshape(-1).contiguous()
+            pos, cnt = eng.sample_positives(roots, P, sampling_seed=svc.sampling_seed,
+                                            label_edges="pos" if pos_ud else None)
+            cols = [roots.view(-1, 1), pos.view(-1, P)]
+            if neg_ud:
+                neg, _ = eng.sample_positives(roots, Q, sampling_seed=svc.sampling_seed, counter=4, label_edges="neg")
+                cols.append(neg.view(-1, Q))
+            grouped = torch.cat(cols, dim=1).reshape(-1).contiguous()
             tree = eng.sample_khop(grouped, cfg.fanouts, sampling_seed=svc.sampling_seed)
             emit = cnt > 0  # anchors need at least one positive
             if limit > 0:
                 emit = emit & ((torch.cumsum(emit.to(torch.int64), 0) + main.n_records) <= limit)
-            buf, off = eng.encode_records(tree, kind=_lib.REC_NODE_ANCHOR_LINK_PRED, trees_per_record=1 + P,
-                                          emit=emit.to(torch.uint8))
+            buf, off = eng.encode_records(tree, kind=_lib.REC_NODE_ANCHOR_LINK_PRED, trees_per_record=T,
+                                          emit=emit.to(torch.uint8), n_neg_trees=Q,
+                                          pos_label_edges="pos" if pos_ud else None,
+                                          neg_label_edges="neg" if neg_ud else None)
             main.add(buf.cpu().numpy(), off.cpu().numpy())
             if rn:
                 tree = eng.sample_khop(roots, cfg.fanouts, sampling_seed=svc.sampling_seed)

@@ -256,6 +256,12 @@ int32_t gigl_frontier_scatter(gigl_ctx* ctx, const uint32_t* resp, const int32_t
 int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* roots, int32_t b,
                               int32_t f, int32_t sampling_seed, int32_t mode, uint32_t* pos,
                               int32_t* cnt);
+/* the same with an explicit permutation call counter (hashBasedUniformPermutation's process-global `_counter`,
+ * SamplingStrategy.scala:14,79): the user-defined-labels task samples positives with counter 3 and hard negatives
+ * with counter 4 from the user-defined edge lists (UserDefinedLabelsNodeAnchorBasedLinkPredictionTask.scala:171-199). */
+int32_t gigl_sample_out_neighbors(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* roots, int32_t b,
+                                  int32_t f, int32_t sampling_seed, int32_t counter, int32_t mode, uint32_t* pos,
+                                  int32_t* cnt);
 
 /* ---- sampled trees -> serialized training samples in TFRecord framing, encoded on the device.
  *      Replaces the per-root assembly, hydration, proto cast and record writer of the Spark sampler:
@@ -299,6 +305,18 @@ typedef struct gigl_record_opts {
    * (src, dst) pair, found by binary search in the destination's row.  NULL / d == 0: no feature_values. */
   gigl_graph* graph;
   gigl_feat* edge_feat;
+  /* user-defined label edges (UserDefinedLabelsNodeAnchorBasedLinkPredictionTask.scala:171-232, :385-486): the LAST
+   * n_neg_trees trees of a record are the sampled hard negatives — their neighbourhoods are merged like the
+   * positives' and `hard_neg_edges` (= 2: root -> root of the tree) is written between root_node and neighborhood.
+   * pos_edges_graph / neg_edges_graph: the user-defined edge list as CSR by SOURCE (gigl_graph_build_from_coo with
+   * src/dst swapped, is_directed = 1); pos_edge_feat / neg_edge_feat: its feature rows in that graph's `col` order
+   * (NULL: the label edges carry no feature_values).  pos_edges_graph == NULL: positives are main edges and take
+   * their features from graph / edge_feat. */
+  int32_t n_neg_trees;
+  gigl_graph* pos_edges_graph;
+  gigl_feat* pos_edge_feat;
+  gigl_graph* neg_edges_graph;
+  gigl_feat* neg_edge_feat;
 } gigl_record_opts;
 
 /* upper bound of the bytes n_records records can take (d = feature dim, suffix_total = all suffix bytes) */

@@ -146,3 +146,69 @@ def test_sampler_split_generator_trainer_chain(workdir):
     metrics = tr.run("job", CFG, None, uri_base=workdir)
     assert np.isfinite(metrics.metrics["loss"].value) and 0.0 <= metrics.metrics["mrr"].value <= 1.0
     assert all(np.isfinite(h["loss"]) for h in tr.training_process.trainer.history)
+
+
+def test_user_defined_labels_on_the_reference_fixture_tables(workdir, golden_dir):
+    """the reference's own UDL fixture (scala/common/src/test/assets/subgraph_sampler/node_anchor_based_link_prediction/
+    {user_defined_pos,user_defined_neg}, preprocessed_metadata.yaml positiveEdgeInfo / negativeEdgeInfo with f0..f2,
+    numUserDefined{Positive,Negative}Samples: 2) through SubgraphSampler.run, checked with the predicates of
+    UserDefinedLabelsNodeAnchorBasedLinkPredictionTaskTest.scala (samples come from the user's lists, direction is
+    src -> dst, the negatives' neighbourhoods are the reference subgraph's) plus the record contents"""
+    import yaml
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    base = "ref_assets/subgraph_sampler/node_anchor_based_link_prediction/"
+    pm = yaml.safe_load(open(os.path.join(workdir, "configs/nablp_preprocessed_metadata.yaml")))
+    em = pm["condensedEdgeTypeToPreprocessedMetadata"]["0"]
+    for key, d in (("positiveEdgeInfo", "user_defined_pos"), ("negativeEdgeInfo", "user_defined_neg")):
+        em[key] = {"featureDim": 3, "featureKeys": ["f0", "f1", "f2"], "tfrecordUriPrefix": base + d}
+    yaml.safe_dump(pm, open(os.path.join(workdir, "configs/nablp_udl_preprocessed_metadata.yaml"), "w"))
+    doc = yaml.safe_load(open(os.path.join(workdir, CFG)))
+    doc["sharedConfig"]["preprocessedMetadataUri"] = "configs/nablp_udl_preprocessed_metadata.yaml"
+    doc["datasetConfig"]["subgraphSamplerConfig"].update(numUserDefinedPositiveSamples=2, numUserDefinedNegativeSamples=2)
+    out = doc["sharedConfig"]["flattenedGraphMetadata"]["nodeAnchorBasedLinkPredictionOutput"]
+    out["tfrecordUriPrefix"] = "out/nablp_udl/main/samples/"
+    out["nodeTypeToRandomNegativeTfrecordUriPrefix"] = {k: "out/nablp_udl/random_negative/" + k + "/samples/"
+                                                        for k in out["nodeTypeToRandomNegativeTfrecordUriPrefix"]}
+    udl_cfg = "configs/nablp_udl_gbml_config.yaml"
+    yaml.safe_dump(doc, open(os.path.join(workdir, udl_cfg), "w"))
+    SubgraphSampler().run("job", udl_cfg, None, uri_base=workdir)
+    cfg = GbmlConfigPbWrapper.from_uri(udl_cfg, uri_base=workdir)
+
+    def table(d):
+        rows = [wire.decode_tf_example(r) for f in tfrecord_files(os.path.join(workdir, base + d, ""))
+                for r in wire.read_tfrecords(f)]
+        return {(int(np.ravel(r["src"])[0]), int(np.ravel(r["dst"])[0])):
+                np.concatenate([np.ravel(r[k]) for k in ("f0", "f1", "f2")]).astype(np.float32) for r in rows}
+    pos_t, neg_t = table("user_defined_pos"), table("user_defined_neg")
+    assert pos_t and neg_t
+    samples = [wire.NodeAnchorBasedLinkPredictionSample.FromString(r)
+               for f in tfrecord_files(cfg.nablp_tfrecord_uri_prefix) for r in wire.read_tfrecords(f)]
+    rnn = {m.root_node.node_id: m for f in tfrecord_files(next(iter(cfg.random_negative_tfrecord_uri_prefixes.values())))
+           for m in [wire.RootedNodeNeighborhood.FromString(r) for r in wire.read_tfrecords(f)]}
+    # one sample per node with at least one user-defined positive (inner join on the positives, left join on negatives)
+    assert sorted(s.root_node.node_id for s in samples) == sorted({s for s, _ in pos_t})
+    saw_neg = False
+    for s in samples:
+        r = s.root_node.node_id
+        out_pos = sorted(d for (a, d) in pos_t if a == r)
+        out_neg = sorted(d for (a, d) in neg_t if a == r)
+        assert len(s.pos_edges) == min(2, len(out_pos)) and len(s.hard_neg_edges) == min(2, len(out_neg))
+        ids = {n.node_id for n in s.neighborhood.nodes}
+        edges = {(e.src_node_id, e.dst_node_id) for e in s.neighborhood.edges}
+        for e, tbl in [(e, pos_t) for e in s.pos_edges] + [(e, neg_t) for e in s.hard_neg_edges]:
+            assert e.src_node_id == r and (r, e.dst_node_id) in tbl  # direction kept: root -> label node
+            np.testing.assert_array_equal(e.feature_values, tbl[(r, e.dst_node_id)])
+            # lookupDstNodeNeighborhood: the label node's own rooted neighbourhood is part of the sample
+            sub = rnn[e.dst_node_id].neighborhood
+            assert {n.node_id for n in sub.nodes} <= ids
+            assert {(x.src_node_id, x.dst_node_id) for x in sub.edges} <= edges
+        own = rnn[r].neighborhood
+        assert {n.node_id for n in own.nodes} <= ids and {(x.src_node_id, x.dst_node_id) for x in own.edges} <= edges
+        assert all(a in ids and b in ids for a, b in edges)  # TaskOutputValidator
+        saw_neg |= bool(s.hard_neg_edges)
+    assert saw_neg
+    # and the trainer-side collate reads them: hard negatives arrive as supervision edges
+    from gigl_amd.batches import NodeAnchorBasedLinkPredictionBatch
+    b = NodeAnchorBasedLinkPredictionBatch.process_raw_pyg_samples_and_collate_fn([s.SerializeToString() for s in samples])
+    hn = b.hard_neg_supervision_edge_data[0].root_node_to_target_node_id
+    assert sum(v.numel() for v in hn.values()) == sum(len(s.hard_neg_edges) for s in samples)

@@ -258,6 +258,82 @@ def test_link_prediction_samples_with_edge_features():
     eng.close()
 
 
+def test_user_defined_label_samples_match_host_assembly():
+    """UserDefinedLabelsNodeAnchorBasedLinkPredictionTask: positives (counter 3) and hard negatives (counter 4) drawn
+    from the user's edge lists; sample = root nbhd ++ positives' nbhds ++ negatives' nbhds; hard_neg_edges (= 2) sits
+    between root_node and neighborhood on the wire; label edges carry the user tables' features (3 and 2 floats),
+    neighbourhood edges the main table's (4 floats)"""
+    rng = np.random.default_rng(23)
+    n = 4000
+    src, dst = rmat_edges(12, 30_000, seed=4)
+    src, dst = (src % n).astype(np.uint32), (dst.astype(np.int64) * 13 % n).astype(np.uint32)
+    keep = src != dst
+    src, dst = src[keep], dst[keep]
+    feats = rng.standard_normal((n, 3)).astype(np.float32)
+    f_main = _pair_features(4)
+    eng = _engine(n, src, dst, feats)
+    eng.load_edge_features(src, dst, np.stack([f_main(int(a), int(b)) for a, b in zip(src, dst)]), is_directed=False)
+    # user-defined label edges: directed, with duplicates (first row's features win), some sources without negatives
+    ps, pd = rng.integers(0, 400, 1500).astype(np.uint32), rng.integers(0, n, 1500).astype(np.uint32)
+    ns, nd = rng.integers(0, 200, 500).astype(np.uint32), rng.integers(0, n, 500).astype(np.uint32)
+    pf = rng.standard_normal((1500, 3)).astype(np.float32)
+    nf = rng.standard_normal((500, 2)).astype(np.float32)
+    eng.load_label_edges("pos", n, ps, pd, pf)
+    eng.load_label_edges("neg", n, ns, nd, nf)
+    first = lambda s_, d_, f_: {k: f_[i] for i, k in reversed(list(enumerate(zip(s_.tolist(), d_.tolist()))))}
+    pos_feat, neg_feat = first(ps, pd, pf), first(ns, nd, nf)
+    roots = np.concatenate([np.arange(0, 60), rng.integers(0, n, 20)]).astype(np.uint32)
+    fanouts, P, Q = [4, 3], 2, 2
+    pos, pcnt = eng.sample_positives(roots, P, label_edges="pos")
+    neg, ncnt = eng.sample_positives(roots, Q, counter=4, label_edges="neg")
+    pos_h, neg_h = pos.cpu().numpy().view(np.uint32).reshape(-1, P), neg.cpu().numpy().view(np.uint32).reshape(-1, Q)
+    pc, nc = pcnt.cpu().numpy(), ncnt.cpu().numpy()
+    # the label samples themselves: the oracle's permutation of the sorted distinct destinations
+    for i, r in enumerate(roots.tolist()):
+        for arr_s, arr_d, got, c, counter, f in ((ps, pd, pos_h[i], pc[i], 3, P), (ns, nd, neg_h[i], nc[i], 4, Q)):
+            row = np.unique(arr_d[arr_s == r])
+            want = np.sort(oracle.hash_permutation(row, r, sampling_seed=42, counter=counter)[:f]) if row.size else row
+            assert c == want.size and np.array_equal(got[:c], want.astype(np.uint32))
+    T = 1 + P + Q
+    all_roots = np.concatenate([roots[:, None], pos_h, neg_h], axis=1).reshape(-1)
+    tree = eng.sample_khop(all_roots, fanouts)
+    buf, off = eng.encode_records(tree, kind=_lib.REC_NODE_ANCHOR_LINK_PRED, trees_per_record=T,
+                                  emit=(pcnt > 0).to(torch.uint8), n_neg_trees=Q, pos_label_edges="pos",
+                                  neg_label_edges="neg")
+    nbr = [t.cpu().numpy().view(np.uint32) for t in tree.nbr]
+    lists = tree_to_edge_lists(all_roots, fanouts, nbr)
+    want = []
+    for i, r in enumerate(roots.tolist()):
+        if pc[i] == 0:
+            continue
+        base = build_rooted_node_neighborhood(r, *lists[i * T], feats, edge_features=f_main)
+        nodes = {nd_.node_id: nd_ for nd_ in base.neighborhood.nodes}
+        edges = {(e.src_node_id, e.dst_node_id): e for e in base.neighborhood.edges}
+        pos_edges, neg_edges = [], []
+        for j in range(P + Q):
+            is_neg = j >= P
+            if (j - P if is_neg else j) >= (nc[i] if is_neg else pc[i]):
+                continue
+            t = int(neg_h[i, j - P] if is_neg else pos_h[i, j])
+            (neg_edges if is_neg else pos_edges).append(wire.Edge(
+                src_node_id=r, dst_node_id=t, condensed_edge_type=0,
+                feature_values=(neg_feat if is_neg else pos_feat)[(r, t)]))
+            tr = build_rooted_node_neighborhood(t, *lists[i * T + 1 + j], feats, edge_features=f_main)
+            for nd_ in tr.neighborhood.nodes:
+                nodes.setdefault(nd_.node_id, nd_)
+            for e in tr.neighborhood.edges:
+                edges.setdefault((e.src_node_id, e.dst_node_id), e)
+        msg = wire.NodeAnchorBasedLinkPredictionSample(
+            root_node=base.root_node, pos_edges=pos_edges, hard_neg_edges=neg_edges,
+            neighborhood=wire.Graph(nodes=list(nodes.values()), edges=list(edges.values())))
+        want.append(wire.tfrecord_frame(msg.SerializeToString()))
+    got = [g for g in _split(buf, off) if g]
+    assert len(got) == len(want) and len(want) > 30 and (nc > 0).sum() > 10 and ((pc > 0) & (nc == 0)).sum() > 5
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, f"sample {i} differs"
+    eng.close()
+
+
 def test_oversized_record_is_rejected():
     from gigl_amd.engine import HipEngine
     eng = HipEngine(0)
