@@ -153,6 +153,25 @@ class TransductiveEdgeToLinkSplitHashingAssigner(HashingAssigner):
         return self.assign_bytes(edge_unique_id(s, d, edge.condensed_edge_type))
 
 
+class UserDefinedLabelsEdgeToLinkSplitHashingAssigner(HashingAssigner):
+    """user-provided pos / hard-neg edges -> (TRAIN | VAL | TEST, SUPERVISION)
+    (lib/assigners/UserDefinedLabelsEdgeToLinkSplitHashingAssigner.scala:16-60; symmetric hashing defaults to False)"""
+
+    def __init__(self, assigner_args: Dict[str, str]):
+        f32 = np.float32
+        weights = [((TRAIN, SUPERVISION), float(f32(assigner_args.get("train_split", "0.8")))),
+                   ((VAL, SUPERVISION), float(f32(assigner_args.get("val_split", "0.1")))),
+                   ((TEST, SUPERVISION), float(f32(assigner_args.get("test_split", "0.1"))))]
+        self.symmetric = str(assigner_args.get("should_split_edges_symmetrically", "False")).lower() == "true"
+        super().__init__(weights)
+
+    def assign(self, edge: wire.Edge) -> Tuple[str, str]:
+        s, d = edge.src_node_id, edge.dst_node_id
+        if self.symmetric and not s <= d:
+            s, d = d, s
+        return self.assign_bytes(edge_unique_id(s, d, edge.condensed_edge_type))
+
+
 class _Subsampler:
     def __init__(self, args: Dict[str, str], prefix: str = "", seed: int = 42):
         self.ratio = {TRAIN: float(args.get(prefix + "train_subsampling_ratio", "1.0")),
@@ -255,11 +274,41 @@ class TransductiveNodeAnchorBasedLinkPredictionSplitStrategy:
         return self.subsample_rn(out, split)
 
 
+class UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy(TransductiveNodeAnchorBasedLinkPredictionSplitStrategy):
+    """samples whose pos_edges / hard_neg_edges are user-defined labels
+    (lib/split_strategies/UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy.scala:21-153): the neighbourhood
+    is message-passing structure and stays whole in every split; only the label edges are assigned to splits; a train
+    sample without a positive is dropped, val / test samples may come out without any label edge"""
+
+    def _label_edge_in_split(self, edge: wire.Edge, split: str) -> bool:
+        ds, usage = self.assigner.assign(edge)
+        if usage != SUPERVISION:
+            raise RuntimeError(f"Unexpected edgeUsage type {usage} for supervision edge {edge}")
+        return ds == split
+
+    def split_training_sample(self, sample: wire.NodeAnchorBasedLinkPredictionSample, split: str):
+        pos = [e for e in sample.pos_edges if self._label_edge_in_split(e, split)]
+        neg = [e for e in sample.neg_edges if self._label_edge_in_split(e, split)]
+        hard = [e for e in sample.hard_neg_edges if self._label_edge_in_split(e, split)]
+        if not pos and split == TRAIN:
+            return []
+        out = [wire.NodeAnchorBasedLinkPredictionSample(root_node=sample.root_node, hard_neg_edges=hard, pos_edges=pos,
+                                                        neg_edges=neg, neighborhood=sample.neighborhood)]
+        return self.subsample(out, split)
+
+    def split_rooted_node_neighborhood_training_sample(self, sample: wire.RootedNodeNeighborhood, split: str):
+        out = [wire.RootedNodeNeighborhood(root_node=sample.root_node, neighborhood=sample.neighborhood)]
+        return self.subsample_rn(out, split)
+
+
 _ASSIGNERS = {"NodeToDatasetSplitHashingAssigner": NodeToDatasetSplitHashingAssigner,
-              "TransductiveEdgeToLinkSplitHashingAssigner": TransductiveEdgeToLinkSplitHashingAssigner}
+              "TransductiveEdgeToLinkSplitHashingAssigner": TransductiveEdgeToLinkSplitHashingAssigner,
+              "UserDefinedLabelsEdgeToLinkSplitHashingAssigner": UserDefinedLabelsEdgeToLinkSplitHashingAssigner}
 _STRATEGIES = {"TransductiveSupervisedNodeClassificationSplitStrategy": TransductiveSupervisedNodeClassificationSplitStrategy,
                "InductiveSupervisedNodeClassificationSplitStrategy": InductiveSupervisedNodeClassificationSplitStrategy,
-               "TransductiveNodeAnchorBasedLinkPredictionSplitStrategy": TransductiveNodeAnchorBasedLinkPredictionSplitStrategy}
+               "TransductiveNodeAnchorBasedLinkPredictionSplitStrategy": TransductiveNodeAnchorBasedLinkPredictionSplitStrategy,
+               "UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy":
+                   UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy}
 
 
 def build_strategy(cfg: GbmlConfigPbWrapper):

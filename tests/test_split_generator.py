@@ -156,6 +156,59 @@ def test_link_prediction_strategy_rules(golden_dir):
         assert seen_pos > 0
 
 
+def test_user_defined_labels_strategy_and_assigner(golden_dir):
+    """UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategyTest.scala: the message-passing edges are the same in
+    every split (and equal the input's), rooted neighbourhoods pass through whole, the assigner only ever answers
+    SUPERVISION buckets; plus: every label edge lands in exactly one split and a train sample keeps a positive"""
+    from gigl_amd.split_generator import (UserDefinedLabelsEdgeToLinkSplitHashingAssigner,
+                                          UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy, build_strategy)
+    a = UserDefinedLabelsEdgeToLinkSplitHashingAssigner(ARGS)
+    assert a.indices == [0, 5000, 7500, 10000] and not a.symmetric
+    got = {a.assign(e) for e in _mock_edges()}
+    assert got == {(TRAIN, SUPERVISION), (VAL, SUPERVISION), (TEST, SUPERVISION)}
+    sym = UserDefinedLabelsEdgeToLinkSplitHashingAssigner({**ARGS, "should_split_edges_symmetrically": "True"})
+    edges = _mock_edges()
+    assert all(sym.assign(edges[i]) == sym.assign(edges[i + 1]) for i in range(0, len(edges), 2))
+    assert any(a.assign(edges[i]) != a.assign(edges[i + 1]) for i in range(0, len(edges), 2))
+    strat = UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy(
+        {}, UserDefinedLabelsEdgeToLinkSplitHashingAssigner({"train_split": "0.8", "val_split": "0.1", "test_split": "0.1"}))
+    samples = _nablp_samples(golden_dir)
+    # give the fixture samples hard negatives too (root -> some neighbourhood node)
+    for s in samples:
+        s.hard_neg_edges = [wire.Edge(src_node_id=s.root_node.node_id, dst_node_id=n.node_id, condensed_edge_type=0)
+                            for n in s.neighborhood.nodes[:2]]
+    n_train = 0
+    for s in samples:
+        placed = {"pos": 0, "hard": 0}
+        for sp in (TRAIN, VAL, TEST):
+            outs = strat.split_training_sample(s, sp)
+            if not outs:
+                assert sp == TRAIN and not [e for e in s.pos_edges if strat.assigner.assign(e)[0] == TRAIN]
+                continue
+            o = outs[0]
+            assert o.neighborhood == s.neighborhood and o.root_node == s.root_node  # no masking of message edges
+            assert all(strat.assigner.assign(e) == (sp, SUPERVISION) for e in o.pos_edges + o.hard_neg_edges)
+            placed["pos"] += len(o.pos_edges)
+            placed["hard"] += len(o.hard_neg_edges)
+            n_train += sp == TRAIN
+        kept_pos = len(s.pos_edges) if any(strat.assigner.assign(e)[0] == TRAIN for e in s.pos_edges) else \
+            sum(1 for e in s.pos_edges if strat.assigner.assign(e)[0] != TRAIN)
+        assert placed["pos"] == kept_pos
+    assert n_train > 0
+    f = os.path.join(golden_dir, SG, "node_anchor_based_link_prediction/sgs_output/"
+                                     "random_negative_rooted_neighborhood_samples/user/data.tfrecord")
+    for r in wire.read_tfrecords(f):
+        m = wire.RootedNodeNeighborhood.FromString(r)
+        for sp in (TRAIN, VAL, TEST):
+            assert strat.split_rooted_node_neighborhood_training_sample(m, sp) == [m]
+    from gigl_amd.config import GbmlConfigPbWrapper
+    cfg = GbmlConfigPbWrapper({"datasetConfig": {"splitGeneratorConfig": {
+        "assignerClsPath": "splitgenerator.lib.assigners.UserDefinedLabelsEdgeToLinkSplitHashingAssigner",
+        "splitStrategyClsPath": "splitgenerator.lib.split_strategies.UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy",
+        "assignerArgs": {"train_split": 0.6}}}})
+    assert isinstance(build_strategy(cfg), UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy)
+
+
 def test_end_to_end_over_reference_sampler_outputs(golden_dir, tmp_path):
     base = tmp_path / "sg"
     shutil.copytree(os.path.join(golden_dir, "ref_assets"), base / "ref_assets")
