@@ -695,6 +695,314 @@ __global__ __launch_bounds__(256) void gat_edge_gather_kernel(
   }
 }
 
+// ---- fast GAT path: one wave per row, every lane owns V float4 chunks of the H*C-wide row (chunk q = v*64 + lane
+// covers channels [4q, 4q+4), all inside one head because C % 4 == 0), so all heads advance together and each source
+// row is read exactly once, coalesced.  Shapes: C/4 a power of two <= 64 (a head = C/4 adjacent lanes of one chunk
+// row), or C a multiple of 256 (a head = whole chunk rows).  Anything else takes the generic kernels above.
+struct GatShape {
+  int V;        // float4 chunks per lane
+  int group;    // lanes per head inside a chunk row (64 when a head spans whole chunk rows)
+  int rows_per_head;  // chunk rows per head (1 unless C is a multiple of 256)
+};
+static bool gat_fast_shape(int heads, int C, GatShape& g) {
+  const int HC = heads * C;
+  if (C % 4 || HC % 4) return false;
+  const int chunks = HC / 4;
+  g.V = (chunks + 63) / 64;
+  if (g.V != 1 && g.V != 2 && g.V != 4) return false;
+  if (C % 256 == 0) {
+    g.group = 64;
+    g.rows_per_head = C / 256;
+    return chunks % 64 == 0;
+  }
+  const int gl = C / 4;
+  if (gl > 64 || (gl & (gl - 1))) return false;
+  g.group = gl;
+  g.rows_per_head = 1;
+  return true;
+}
+__device__ __forceinline__ int gat_head_of(int v, int lane, int group, int rows_per_head) {
+  return rows_per_head > 1 ? v / rows_per_head : (v * 64 + lane) / group;
+}
+
+// a_src / a_dst for every node: lanes over channels, segmented shuffle reduction per head
+template <int V>
+__global__ __launch_bounds__(256) void gat_alpha_fast_kernel(const float* __restrict__ h,
+                                                             const float* __restrict__ att_src,
+                                                             const float* __restrict__ att_dst,
+                                                             const int32_t* __restrict__ n_dev, int heads, int C,
+                                                             int group, int rows_per_head,
+                                                             float* __restrict__ a_src, float* __restrict__ a_dst) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n = *n_dev, HC = heads * C, chunks = HC >> 2;
+  float4 ws[V], wd[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int q = v * 64 + lane;
+    ws[v] = q < chunks ? ((const float4*)att_src)[q] : float4{0, 0, 0, 0};
+    wd[v] = q < chunks ? ((const float4*)att_dst)[q] : float4{0, 0, 0, 0};
+  }
+  for (int i = wave; i < n; i += waves_total) {
+    const float4* row = (const float4*)(h + (int64_t)i * HC);
+    float ps[V], pd[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int q = v * 64 + lane;
+      const float4 x = q < chunks ? row[q] : float4{0, 0, 0, 0};
+      ps[v] = x.x * ws[v].x + x.y * ws[v].y + x.z * ws[v].z + x.w * ws[v].w;
+      pd[v] = x.x * wd[v].x + x.y * wd[v].y + x.z * wd[v].z + x.w * wd[v].w;
+    }
+    if (rows_per_head > 1) {  // a head = rows_per_head whole chunk rows
+      for (int hd = 0; hd < heads; ++hd) {
+        float s = 0.f, d = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          if (v / rows_per_head == hd) {
+            s += ps[v];
+            d += pd[v];
+          }
+        for (int off = 32; off > 0; off >>= 1) {
+          s += __shfl_xor(s, off, 64);
+          d += __shfl_xor(d, off, 64);
+        }
+        if (lane == 0) {
+          a_src[(int64_t)i * heads + hd] = s;
+          a_dst[(int64_t)i * heads + hd] = d;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float s = ps[v], d = pd[v];
+        for (int off = group >> 1; off > 0; off >>= 1) {
+          s += __shfl_xor(s, off, 64);
+          d += __shfl_xor(d, off, 64);
+        }
+        const int q = v * 64 + lane;
+        if ((lane & (group - 1)) == 0 && q < chunks) {
+          const int hd = q / group;
+          a_src[(int64_t)i * heads + hd] = s;
+          a_dst[(int64_t)i * heads + hd] = d;
+        }
+      }
+    }
+  }
+}
+
+// attention + aggregation, single pass (online softmax: running max m, denominator l, weighted sum acc, rescaled when
+// the max grows).  The self loop is folded in LAST so that, with edge features, the mean of the row's a_edge is
+// known when its logit is formed.  a_edge == NULL: no edge term.
+// MSG (EdgeAttrGATConv): messages are h_j + W_msg e_ij, i.e. out_i += W_msg z_i with z_i = sum_j alpha_ij e_ij (per head,
+// De values) — accumulated online next to acc: the lanes of a head split the De components (component k lives in lane
+// k % group of the head's group, register k / group; at most GAT_ZR registers), the self loop adds alpha_self * mean e;
+// the final product reads the TRANSPOSED weight wt[k][H*C] so that a k-row is one coalesced float4 per lane.
+constexpr int GAT_ZR = 4;
+template <int V, bool MSG>
+__global__ __launch_bounds__(256) void gat_gather_fast_kernel(
+    const float* __restrict__ h, const float* __restrict__ a_src, const float* __restrict__ a_dst,
+    const float* __restrict__ a_edge, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ n_rows_dev, int heads, int C, int group,
+    int rows_per_head, float slope, const float* __restrict__ bias, int act, const float* __restrict__ edge_attr,
+    int De, const float* __restrict__ wt, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n_rows = *n_rows_dev, HC = heads * C, chunks = HC >> 2;
+  int hd[V];
+  bool on[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    on[v] = v * 64 + lane < chunks;
+    hd[v] = on[v] ? gat_head_of(v, lane, group, rows_per_head) : 0;
+  }
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    float ad[V], mx[V], den[V], sum_ae[V];
+    float4 acc[V];
+    float zz[MSG ? V : 1][GAT_ZR], es[GAT_ZR];  // z per chunk row (rows of one head carry the same values), sum of e
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      ad[v] = a_dst[(int64_t)i * heads + hd[v]];
+      mx[v] = -INFINITY;
+      den[v] = 0.f;
+      sum_ae[v] = 0.f;
+      acc[v] = float4{0, 0, 0, 0};
+      if (MSG) {
+#pragma unroll
+        for (int r = 0; r < GAT_ZR; ++r) zz[v][r] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < GAT_ZR; ++r) es[r] = 0.f;
+    const int kl = lane & (group - 1);  // this lane's component slot inside its head group
+    int cnt = 0;
+    constexpr int U = 4;  // edges in flight
+    for (int e = 0; e < m; e += U) {
+      int j[U];
+      float4 x[U][V];
+      float lg[U][V];
+      float ev[MSG ? U : 1][GAT_ZR];
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        j[t] = e + t < m ? col[e0 + e + t] : -1;
+        if (j[t] == i) j[t] = -1;  // self loops are removed, one is added back below
+      }
+      if (MSG) {
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          if (j[t] < 0) continue;
+#pragma unroll
+          for (int r = 0; r < GAT_ZR; ++r) {
+            const int k = r * group + kl;
+            ev[t][r] = k < De ? edge_attr[(int64_t)(e0 + e + t) * De + k] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        if (j[t] < 0) continue;
+        const float4* row = (const float4*)(h + (int64_t)j[t] * HC);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          x[t][v] = on[v] ? row[v * 64 + lane] : float4{0, 0, 0, 0};
+          lg[t][v] = a_src[(int64_t)j[t] * heads + hd[v]] + ad[v];
+          if (a_edge) {
+            const float ae = a_edge[(int64_t)(e0 + e + t) * heads + hd[v]];
+            lg[t][v] += ae;
+            sum_ae[v] += ae;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        if (j[t] < 0) continue;
+        ++cnt;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float z = lg[t][v];
+          z = z > 0.f ? z : slope * z;
+          const float nm = fmaxf(mx[v], z);
+          const float sc = __expf(mx[v] - nm), pw = __expf(z - nm);
+          den[v] = den[v] * sc + pw;
+          acc[v].x = acc[v].x * sc + pw * x[t][v].x;
+          acc[v].y = acc[v].y * sc + pw * x[t][v].y;
+          acc[v].z = acc[v].z * sc + pw * x[t][v].z;
+          acc[v].w = acc[v].w * sc + pw * x[t][v].w;
+          mx[v] = nm;
+          if (MSG) {
+#pragma unroll
+            for (int r = 0; r < GAT_ZR; ++r) zz[v][r] = zz[v][r] * sc + pw * ev[t][r];
+          }
+        }
+        if (MSG) {
+#pragma unroll
+          for (int r = 0; r < GAT_ZR; ++r) es[r] += ev[t][r];
+        }
+      }
+    }
+    // the self loop (mean edge attribute of the row -> mean a_edge), then normalise
+    const float4* self = (const float4*)(h + (int64_t)i * HC);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      if (!MSG && !on[v]) continue;  // (MSG: whole chunk rows only, see launch_gat_fast — the shuffles need every lane)
+      float z = a_src[(int64_t)i * heads + hd[v]] + ad[v] + (a_edge && cnt > 0 ? sum_ae[v] / (float)cnt : 0.f);
+      z = z > 0.f ? z : slope * z;
+      const float nm = fmaxf(mx[v], z);
+      const float sc = __expf(mx[v] - nm), pw = __expf(z - nm);
+      const float4 xs = self[v * 64 + lane];
+      const float inv = 1.0f / (den[v] * sc + pw + 1e-16f);
+      float4 o;
+      o.x = (acc[v].x * sc + pw * xs.x) * inv;
+      o.y = (acc[v].y * sc + pw * xs.y) * inv;
+      o.z = (acc[v].z * sc + pw * xs.z) * inv;
+      o.w = (acc[v].w * sc + pw * xs.w) * inv;
+      const int q = v * 64 + lane;
+      if (MSG) {
+        const float mean_w = cnt > 0 ? pw / (float)cnt : 0.f;
+        const int base = lane & ~(group - 1);
+#pragma unroll
+        for (int r = 0; r < GAT_ZR; ++r) {
+          const float zr = (zz[v][r] * sc + mean_w * es[r]) * inv;
+          for (int kk = 0; kk < group; ++kk) {
+            const int k = r * group + kk;
+            if (k >= De) break;
+            const float zk = __shfl(zr, base + kk, 64);
+            const float4 w4 = ((const float4*)(wt + (int64_t)k * HC))[q];
+            o.x += w4.x * zk;
+            o.y += w4.y * zk;
+            o.z += w4.z * zk;
+            o.w += w4.w * zk;
+          }
+        }
+      }
+      if (bias) {
+        const float4 b = ((const float4*)bias)[q];
+        o.x += b.x;
+        o.y += b.y;
+        o.z += b.z;
+        o.w += b.w;
+      }
+      if (act == 1) {
+        o.x = fmaxf(o.x, 0.f);
+        o.y = fmaxf(o.y, 0.f);
+        o.z = fmaxf(o.z, 0.f);
+        o.w = fmaxf(o.w, 0.f);
+      }
+      ((float4*)(out + (int64_t)i * HC))[q] = o;
+    }
+  }
+}
+
+__global__ void gat_transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < rows * cols) wt[(int64_t)(t % cols) * rows + t / cols] = w[t];
+}
+
+// launches the fast pair when the shape allows it (concatenated heads, or a single head); false = use the generic path
+static bool launch_gat_fast(gigl_ctx* ctx, const float* h, const float* att_src, const float* att_dst, int heads, int C,
+                            float slope, int concat, const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                            const int32_t* n_nodes_dev, int64_t nodes_cap, const int32_t* n_rows_dev, int64_t rows_cap,
+                            const float* bias, int act, float* a_src, float* a_dst, const float* a_edge, float* out,
+                            const float* edge_attr = nullptr, int De = 0, const float* w_msg = nullptr) {
+  GatShape g;
+  if (!(concat || heads == 1) || !gat_fast_shape(heads, C, g)) return false;
+  float* wt = nullptr;
+  if (w_msg) {  // the z registers hold at most GAT_ZR * group components; the shuffles need whole chunk rows
+    if (De > GAT_ZR * g.group || (heads * C / 4) % 64) return false;
+    if (gigl_arena_reset(ctx, (int64_t)heads * C * De * 4 + 256) != GIGL_OK) return false;
+    wt = (float*)gigl_arena_alloc(ctx, (int64_t)heads * C * De * 4);
+    if (!wt) return false;
+    hipLaunchKernelGGL(gat_transpose_kernel, dim3((unsigned)((heads * C * De + 255) / 256)), dim3(256), 0, ctx->stream,
+                       w_msg, heads * C, De, wt);
+  }
+  if (((uintptr_t)h | (uintptr_t)out | (uintptr_t)att_src | (uintptr_t)att_dst | (uintptr_t)bias) & 15) return false;
+  int64_t ablocks = (nodes_cap + 3) / 4, gblocks = (rows_cap + 3) / 4;
+  if (ablocks > 256 * 32) ablocks = 256 * 32;
+  if (gblocks > 256 * 32) gblocks = 256 * 32;
+#define GAT_FAST(VV)                                                                                                  \
+  hipLaunchKernelGGL((gat_alpha_fast_kernel<VV>), dim3((unsigned)ablocks), dim3(256), 0, ctx->stream, h, att_src,    \
+                     att_dst, n_nodes_dev, heads, C, g.group, g.rows_per_head, a_src, a_dst);                         \
+  if (wt)                                                                                                            \
+    hipLaunchKernelGGL((gat_gather_fast_kernel<VV, true>), dim3((unsigned)gblocks), dim3(256), 0, ctx->stream, h,    \
+                       a_src, a_dst, a_edge, rowptr, rowend, col, n_rows_dev, heads, C, g.group, g.rows_per_head,    \
+                       slope, bias, act, edge_attr, De, wt, out);                                                    \
+  else                                                                                                               \
+    hipLaunchKernelGGL((gat_gather_fast_kernel<VV, false>), dim3((unsigned)gblocks), dim3(256), 0, ctx->stream, h,   \
+                       a_src, a_dst, a_edge, rowptr, rowend, col, n_rows_dev, heads, C, g.group, g.rows_per_head,    \
+                       slope, bias, act, edge_attr, De, wt, out)
+  if (g.V == 1) {
+    GAT_FAST(1);
+  } else if (g.V == 2) {
+    GAT_FAST(2);
+  } else {
+    GAT_FAST(4);
+  }
+#undef GAT_FAST
+  return true;
+}
+
 template <typename T>
 int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather_ids,
                       const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
@@ -848,6 +1156,11 @@ int32_t gigl_gat_aggregate(gigl_ctx* ctx, const float* h, const float* att_src, 
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   float* a_src = alpha_scratch;
   float* a_dst = alpha_scratch + nodes_cap * heads;
+  if (launch_gat_fast(ctx, h, att_src, att_dst, heads, channels, negative_slope, concat, rowptr, rowend, col,
+                      n_nodes_dev, nodes_cap, n_rows_dev, rows_cap, bias, act, a_src, a_dst, nullptr, out)) {
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    return GIGL_OK;
+  }
   hipLaunchKernelGGL(gat_alpha_kernel, dim3((unsigned)((nodes_cap * heads + 255) / 256)), dim3(256), 0, ctx->stream,
                      h, att_src, att_dst, n_nodes_dev, heads, channels, a_src, a_dst);
   int64_t blocks = (rows_cap + 3) / 4;
@@ -877,11 +1190,18 @@ int32_t gigl_gat_aggregate_edge(gigl_ctx* ctx, const float* h, const float* att_
   float* a_src = alpha_scratch;
   float* a_dst = alpha_scratch + nodes_cap * heads;
   float* a_edge = alpha_scratch + 2 * nodes_cap * heads;
-  hipLaunchKernelGGL(gat_alpha_kernel, dim3((unsigned)((nodes_cap * heads + 255) / 256)), dim3(256), 0, ctx->stream,
-                     h, att_src, att_dst, n_nodes_dev, heads, channels, a_src, a_dst);
   if (cap_edges > 0)
     hipLaunchKernelGGL(gat_edge_alpha_kernel, dim3((unsigned)((cap_edges * heads + 255) / 256)), dim3(256), 0,
                        ctx->stream, edge_attr, edge_dim, att_edge_folded, heads, cap_edges, a_edge);
+  if (cap_edges > 0 &&
+      launch_gat_fast(ctx, h, att_src, att_dst, heads, channels, negative_slope, concat, rowptr, rowend, col,
+                      n_nodes_dev, nodes_cap, n_rows_dev, rows_cap, bias, act, a_src, a_dst, a_edge, out, edge_attr,
+                      edge_dim, w_edge_msg)) {
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    return GIGL_OK;
+  }
+  hipLaunchKernelGGL(gat_alpha_kernel, dim3((unsigned)((nodes_cap * heads + 255) / 256)), dim3(256), 0, ctx->stream,
+                     h, att_src, att_dst, n_nodes_dev, heads, channels, a_src, a_dst);
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(gat_edge_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, h, a_src, a_dst,

@@ -59,7 +59,11 @@ def test_two_layer_gcn(setup, hid, out, norm):
     np.testing.assert_allclose(got, ref[o["root_local"]].numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("heads,hid,out,fan", [(1, 32, 16, [8, 5]), (2, 16, 24, [10, 4]), (4, 8, 8, [5, 3, 2])])
+@pytest.mark.parametrize("heads,hid,out,fan", [(1, 32, 16, [8, 5]), (2, 16, 24, [10, 4]), (4, 8, 8, [5, 3, 2]),
+                                               # single-pass kernels: 4 x 64 = one float4 per lane; 4 x 128 and 2 x 256
+                                               # = two chunk rows; one 512-wide head spanning two chunk rows; 4 x 256
+                                               (4, 64, 256, [8, 5]), (4, 128, 64, [6, 4]), (2, 256, 512, [6, 4]),
+                                               (4, 256, 1024, [5, 3]), (3, 20, 12, [6, 4])])
 def test_gat(setup, heads, hid, out, fan):
     from gigl_amd.models_attn import GAT
     eng, rowptr, col, x, n = setup

@@ -114,9 +114,13 @@ def test_union_edge_attr(setup):
 
 
 @pytest.mark.parametrize("conv,share,heads,hid,out,fan", [
-    ("gat", True, 1, 16, 8, [6, 4]), ("gat", True, 3, 8, 12, [5, 3]),
+    ("gat", True, 1, 16, 8, [6, 4]), ("gat", True, 3, 8, 12, [5, 3]), ("gat", True, 4, 64, 128, [6, 4]),
+    ("gat", True, 2, 256, 32, [5, 3]),
     ("edge_attr_gat", True, 2, 8, 8, [6, 4]), ("edge_attr_gat", False, 2, 16, 5, [4, 3, 2]),
-    ("edge_attr_gat", False, 1, 80, 70, [5, 3])])
+    ("edge_attr_gat", False, 1, 80, 70, [5, 3]),
+    # single-pass kernels with the online z accumulation: 4 x 64 -> 256; 2 x 256 -> 512 (two chunk rows); 1 x 512
+    ("edge_attr_gat", True, 4, 64, 256, [6, 4]), ("edge_attr_gat", False, 2, 256, 512, [5, 3]),
+    ("edge_attr_gat", False, 1, 512, 256, [5, 3])])
 def test_gat_with_edge_features(setup, conv, share, heads, hid, out, fan):
     from gigl_amd.models_attn import GAT
     eng, rowptr, col, x, efeat, n = setup
