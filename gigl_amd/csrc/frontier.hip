@@ -68,6 +68,48 @@ __global__ __launch_bounds__(256) void frontier_scatter_kernel(const uint32_t* _
 
 }  // namespace
 
+namespace {
+// SamplingOp DAG frontiers: row r of `ids` ([rows][width], GIGL_INVALID = empty) is the concatenation of the node
+// sets the parent ops returned for root r; the op's input frontier is their set union
+// (GraphDBSampler.getKHopSubgraphForRootNode, scala_spark35/.../sampler/GraphDBSampler.scala:78-82): every later
+// occurrence of an id inside a row becomes GIGL_INVALID (the first one stays where it is).  One workgroup per row,
+// LDS hash of (id -> first position).
+__global__ __launch_bounds__(256) void rows_dedup_kernel(uint32_t* __restrict__ ids, int64_t rows, int32_t width,
+                                                         uint32_t cap) {
+  extern __shared__ uint32_t s_tab[];  // keys[cap] | pos[cap]
+  uint32_t* keys = s_tab;
+  uint32_t* pos = s_tab + cap;
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    uint32_t* row = ids + r * width;
+    for (uint32_t i = threadIdx.x; i < cap; i += blockDim.x) {
+      keys[i] = GIGL_INVALID;
+      pos[i] = GIGL_INVALID;
+    }
+    __syncthreads();
+    for (int32_t q = threadIdx.x; q < width; q += blockDim.x) {
+      const uint32_t id = row[q];
+      if (id == GIGL_INVALID) continue;
+      uint32_t h = (id * 0x9E3779B1u) >> 7 & (cap - 1);
+      for (;;) {
+        const uint32_t prev = atomicCAS(&keys[h], GIGL_INVALID, id);
+        if (prev == GIGL_INVALID || prev == id) break;
+        h = (h + 1) & (cap - 1);
+      }
+      atomicMin(&pos[h], (uint32_t)q);
+    }
+    __syncthreads();
+    for (int32_t q = threadIdx.x; q < width; q += blockDim.x) {
+      const uint32_t id = row[q];
+      if (id == GIGL_INVALID) continue;
+      uint32_t h = (id * 0x9E3779B1u) >> 7 & (cap - 1);
+      while (keys[h] != id) h = (h + 1) & (cap - 1);
+      if (pos[h] != (uint32_t)q) row[q] = GIGL_INVALID;
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
 extern "C" {
 
 int32_t gigl_frontier_bucket(gigl_ctx* ctx, const uint32_t* nodes, const uint32_t* ksums, int64_t m, int32_t world,
@@ -102,6 +144,24 @@ int32_t gigl_frontier_scatter(gigl_ctx* ctx, const uint32_t* resp, const int32_t
   const int64_t threads = (int64_t)world * cap * f;
   hipLaunchKernelGGL(frontier_scatter_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, resp,
                      slot_idx, counts, parent_ksums, (uint32_t)world, cap, f, out_nbr, out_cnt, child_ksums);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_rows_dedup(gigl_ctx* ctx, uint32_t* ids, int64_t rows, int32_t width) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, rows >= 0 && width >= 0 && (ids || rows * width == 0), "bad arguments");
+  if (rows == 0 || width == 0) return GIGL_OK;
+  uint32_t cap = 64;
+  while (cap < 2u * (uint32_t)width) cap <<= 1;
+  if (cap > 16384)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "frontier rows of %d ids exceed the %d the in-LDS set holds", width, 8192);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (cap * 8 > 48 * 1024)
+    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)rows_dedup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(cap * 8)));
+  const int64_t grid = rows < 256 * 32 ? rows : 256 * 32;
+  hipLaunchKernelGGL(rows_dedup_kernel, dim3((unsigned)grid), dim3(256), cap * 8, ctx->stream, ids, rows, width, cap);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -339,16 +339,25 @@ class HipEngine:
                 tree.nbr[k] = tree.nbr[k][:parents]
         return tree
 
+    def rows_dedup(self, ids: torch.Tensor) -> torch.Tensor:
+        """in place: later occurrences of an id inside a row of `ids` [rows, width] (int32, uint32 payload) become
+        GIGL_INVALID — the set union that forms a SamplingOp's input frontier (gigl_rows_dedup)"""
+        assert ids.dim() == 2 and ids.is_contiguous() and ids.dtype == torch.int32 and ids.is_cuda
+        check(self._lib.gigl_rows_dedup(self._ctx, C.c_void_p(ids.data_ptr()), ids.shape[0], ids.shape[1]), self._ctx)
+        return ids
+
     def expand_frontier(self, nodes: torch.Tensor, ksums: torch.Tensor, f: int, hash_add: int, world: int,
-                        max_window_end: int = -1):
-        """one hop over an explicit frontier on this rank's shard (resident graph = rows of owned nodes);
+                        max_window_end: int = -1, label_edges: Optional[str] = None):
+        """one hop over an explicit frontier on this rank's shard (resident graph = rows of owned nodes), or on a
+        named edge list loaded with load_label_edges (rows = its sources);
         nodes/ksums: int32 device tensors (uint32 payload).  -> (nbr [m*f] int32, cnt [m] int32)"""
-        assert self._graph is not None
+        graph = self._label_edges[label_edges]["graph"] if label_edges else self._graph
+        assert graph is not None
         m = int(nodes.numel())
         nbr = torch.empty(max(m * f, 1), dtype=torch.int32, device=self.device)
         cnt = torch.empty(max(m, 1), dtype=torch.int32, device=self.device)
         hash_add = ((int(hash_add) + 2**31) % 2**32) - 2**31
-        check(self._lib.gigl_expand_frontier(self._ctx, self._graph, C.c_void_p(nodes.data_ptr()),
+        check(self._lib.gigl_expand_frontier(self._ctx, graph, C.c_void_p(nodes.data_ptr()),
                                              C.c_void_p(ksums.data_ptr()), m, f, hash_add, world, max_window_end,
                                              C.c_void_p(nbr.data_ptr()), C.c_void_p(cnt.data_ptr())), self._ctx)
         return nbr[: m * f], cnt[:m]

@@ -1,0 +1,193 @@
+"""SamplingOp-DAG sampler on the device — the heterogeneous `KHopSamplerService` of the reference's Spark-3.5 sampler.
+
+Mirror of (paths relative to the reference root):
+  SamplingOpDAG.from            scala_spark35/common/src/main/scala/types/SamplingOpDAG.scala:19-53
+  GraphDBSampler                scala_spark35/subgraph_sampler/src/main/scala/libs/sampler/GraphDBSampler.scala:40-148
+  LocalDbClient.executeQuery    scala_spark35/common/src/main/scala/graphdb/local/LocalDbClient.scala:156-237
+  SamplingOp / SamplingDirection  proto/snapchat/research/gbml/subgraph_sampling_strategy.proto
+
+Semantics kept: ops run breadth-first from the DAG's roots, an op runs once all its parents have; its input frontier for
+a root node is the SET UNION of the node sets its parents returned for that root (the root itself for a root op); it
+returns, per frontier node, up to `num_nodes_to_sample` neighbours along `edge_type` — INCOMING: sources of edges INTO
+the frontier node, edge = (sampled -> frontier); OUTGOING: destinations, edge = (frontier -> sampled); the result is the
+set union of every op's edges and nodes plus the root.  An op whose frontier is empty ends its path.
+
+WHICH neighbours are taken is the one thing the reference leaves open (LocalDbClient keeps the first n of a Scala
+HashSet, Nebula samples server-side; no seed reaches either) -> "parity unpinned" for the choice itself; here it is the
+deterministic rule of the Spark sampler (SamplingStrategy.scala:16-82): permute the node's sorted neighbour list with
+xxhash64 keys, K = root id + frontier node id, counter = 1 + the op's position in the DAG's op list.
+
+Device work per op: one gigl_rows_dedup (frontier union, LDS hash per root) + one gigl_expand_frontier over B * width
+slots on the op's edge-type graph; B roots advance together.  Assembly of the typed RootedNodeNeighborhood messages
+(set union across ops, hydration with per-type features) is host code: the typed records are not produced by
+serialize.hip, whose plan assumes one node type and one edge type."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Set, Tuple
+
+import numpy as np
+import torch
+
+from . import wire
+
+INCOMING, OUTGOING = "INCOMING", "OUTGOING"
+INVALID = 0xFFFFFFFF
+
+
+@dataclass(frozen=True)
+class EdgeType:
+    src_node_type: str
+    relation: str
+    dst_node_type: str
+
+
+@dataclass
+class SamplingOp:
+    op_name: str
+    edge_type: EdgeType
+    num_nodes_to_sample: int
+    input_op_names: Sequence[str] = ()
+    sampling_direction: str = INCOMING  # proto default
+
+
+@dataclass
+class SamplingOpNode:
+    sampling_op: SamplingOp
+    parent_op_names: List[str] = field(default_factory=list)
+    child_op_names: List[str] = field(default_factory=list)
+
+
+class SamplingOpDAG:
+    def __init__(self, nodes: Dict[str, SamplingOpNode], root_op_names: List[str], op_order: List[str]):
+        self.nodes, self.root_op_names, self.op_order = nodes, root_op_names, op_order
+
+    @classmethod
+    def from_ops(cls, ops: Sequence[SamplingOp]) -> "SamplingOpDAG":
+        nodes = {op.op_name: SamplingOpNode(op) for op in ops}
+        if len(nodes) != len(ops):
+            raise ValueError("sampling op names must be unique")
+        roots = [op.op_name for op in ops if not op.input_op_names]
+        for op in ops:
+            for p in op.input_op_names:
+                if p in nodes:  # unknown parents are dropped like filterKeys does (SamplingOpDAG.scala:44-45)
+                    nodes[p].child_op_names.append(op.op_name)
+                    nodes[op.op_name].parent_op_names.append(p)
+        return cls(nodes, roots, [op.op_name for op in ops])
+
+    def execution_order(self) -> List[str]:
+        """the reference's queue discipline (GraphDBSampler.scala:54-127): dequeue, run when every parent has run
+        (otherwise wait for the last parent to enqueue it again), enqueue the children"""
+        done: List[str] = []
+        queue = list(self.root_op_names)
+        while queue:
+            name = queue.pop(0)
+            node = self.nodes[name]
+            if name in done or any(p not in done for p in node.parent_op_names):
+                continue
+            done.append(name)
+            queue.extend(node.child_op_names)
+        return done
+
+
+@dataclass
+class OpResult:
+    frontier: torch.Tensor  # [B, w] int32 (uint32 payload), INVALID = empty
+    nbr: torch.Tensor       # [B, w, n]
+    cnt: torch.Tensor       # [B, w]
+
+
+class HipGraphDBSampler:
+    """typed graph resident in HBM (one CSR per edge type and direction) + the op-DAG executor"""
+
+    def __init__(self, node_types: Dict[str, int], num_nodes: Dict[str, int],
+                 edges: Dict[EdgeType, Tuple[np.ndarray, np.ndarray]], condensed_edge_types: Dict[EdgeType, int],
+                 features: Optional[Dict[str, np.ndarray]] = None, device: int = 0, sampling_seed: int = 42):
+        from .engine import HipEngine
+        self.node_types, self.num_nodes, self.condensed_edge_types = node_types, num_nodes, condensed_edge_types
+        self.features = features or {}
+        self.sampling_seed = sampling_seed
+        self.engine = HipEngine(device)
+        n_all = max(num_nodes.values())
+        for et, (src, dst) in edges.items():
+            src, dst = np.asarray(src), np.asarray(dst)
+            # rows = the node a query starts from, columns = what it returns
+            self.engine.load_label_edges(self._key(et, INCOMING), n_all, dst, src)
+            self.engine.load_label_edges(self._key(et, OUTGOING), n_all, src, dst)
+
+    @staticmethod
+    def _key(et: EdgeType, direction: str) -> str:
+        return f"{et.src_node_type}|{et.relation}|{et.dst_node_type}|{direction}"
+
+    def close(self):
+        self.engine.close()
+
+    def run_dag(self, roots: torch.Tensor, dag: SamplingOpDAG) -> Dict[str, OpResult]:
+        eng = self.engine
+        roots = roots.to(device=eng.device, dtype=torch.int32).contiguous()
+        b = int(roots.numel())
+        res: Dict[str, OpResult] = {}
+        ran: Dict[str, torch.Tensor] = {}  # per root: did the op run (GraphDBSampler.scala:66-86)?
+        for name in dag.execution_order():
+            node = dag.nodes[name]
+            op = node.sampling_op
+            if not node.parent_op_names:
+                front = roots.view(b, 1).clone()
+                ran[name] = torch.ones(b, dtype=torch.bool, device=eng.device)
+            else:
+                front = torch.cat([res[p].nbr.view(b, -1) for p in node.parent_op_names], dim=1).contiguous()
+                eng.rows_dedup(front)
+                # an op runs for a root only when every parent ran for it and the united frontier is not empty;
+                # a root for which it did not run contributes nothing and stops its children too
+                ok = (front != -1).any(dim=1)
+                for p in node.parent_op_names:
+                    ok = ok & ran[p]
+                ran[name] = ok
+                front.masked_fill_(~ok.view(b, 1), -1)
+            w, f = int(front.shape[1]), int(op.num_nodes_to_sample)
+            ksum = (front + roots.view(b, 1)).contiguous()  # int32 add wraps like the sampler's K sums
+            counter = 1 + dag.op_order.index(name)
+            nbr, cnt = eng.expand_frontier(front.view(-1), ksum.view(-1), f, self.sampling_seed * counter, 1,
+                                           label_edges=self._key(op.edge_type, op.sampling_direction))
+            res[name] = OpResult(front, nbr.view(b, w, f), cnt.view(b, w))
+        return res
+
+    # ---- KHopSamplerService surface ------------------------------------------------------------------------------
+    def getKHopSubgraphForRootNodes(self, root_ids: Sequence[int], root_node_type: str,
+                                    dag: SamplingOpDAG) -> List[wire.RootedNodeNeighborhood]:
+        roots = torch.tensor(np.asarray(root_ids, dtype=np.int64).astype(np.uint32).view(np.int32))
+        res = self.run_dag(roots, dag)
+        self.engine.synchronize()
+        host = {k: (r.frontier.cpu().numpy().view(np.uint32), r.nbr.cpu().numpy().view(np.uint32)) for k, r in res.items()}
+        out = []
+        for i, root in enumerate(root_ids):
+            edges: Set[Tuple[int, int, int]] = set()
+            nodes: Set[Tuple[int, int]] = {(int(root), self.node_types[root_node_type])}
+            for name, (front, nbr) in host.items():
+                op = dag.nodes[name].sampling_op
+                cet = self.condensed_edge_types[op.edge_type]
+                outgoing = op.sampling_direction == OUTGOING
+                got_type = self.node_types[op.edge_type.dst_node_type if outgoing else op.edge_type.src_node_type]
+                fr, nb = front[i], nbr[i]
+                for q in np.flatnonzero(fr != INVALID):
+                    for v in nb[q][nb[q] != INVALID].tolist():
+                        edges.add((int(fr[q]), v, cet) if outgoing else (v, int(fr[q]), cet))
+                        nodes.add((v, got_type))
+            out.append(self._message(int(root), root_node_type, sorted(nodes), sorted(edges)))
+        return out
+
+    def getKHopSubgraphForRootNode(self, root_id: int, root_node_type: str, dag: SamplingOpDAG):
+        return self.getKHopSubgraphForRootNodes([root_id], root_node_type, dag)[0]
+
+    def _message(self, root: int, root_type: str, nodes, edges) -> wire.RootedNodeNeighborhood:
+        by_cnt = {c: t for t, c in self.node_types.items()}
+
+        def node(v: int, cnt: int) -> wire.Node:
+            x = self.features.get(by_cnt[cnt])
+            fv = x[v] if x is not None else wire._EMPTY_F32
+            return wire.Node(node_id=v, condensed_node_type=cnt, feature_values=np.asarray(fv, dtype=np.float32))
+        return wire.RootedNodeNeighborhood(
+            root_node=node(root, self.node_types[root_type]),
+            neighborhood=wire.Graph(nodes=[node(v, c) for v, c in nodes],
+                                    edges=[wire.Edge(src_node_id=s, dst_node_id=d, condensed_edge_type=c)
+                                           for s, d, c in edges]))

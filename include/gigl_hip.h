@@ -250,6 +250,15 @@ int32_t gigl_frontier_scatter(gigl_ctx* ctx, const uint32_t* resp, const int32_t
                               const uint32_t* parent_ksums, int64_t m, int32_t world, int64_t cap, int32_t f,
                               uint32_t* out_nbr, int32_t* out_cnt, uint32_t* child_ksums);
 
+/* SamplingOp DAG frontiers (SamplingOpDAG.from, scala_spark35/common/src/main/scala/types/SamplingOpDAG.scala:19-53;
+ * GraphDBSampler.getKHopSubgraphForRootNode, scala_spark35/subgraph_sampler/src/main/scala/libs/sampler/
+ * GraphDBSampler.scala:40-148): an op's input frontier for a root is the SET UNION of the node sets its parent ops
+ * returned for that root.  ids: DEVICE [rows][width] (row r = the parents' results for root r back to back,
+ * GIGL_INVALID = empty): later occurrences of an id inside a row are overwritten with GIGL_INVALID in place.
+ * width <= 8192.  The op itself is then one gigl_expand_frontier call over rows*width slots on the op's edge-type
+ * graph (world = 1). */
+int32_t gigl_rows_dedup(gigl_ctx* ctx, uint32_t* ids, int64_t rows, int32_t width);
+
 /* positives for node-anchor link prediction: `f` OUT-neighbours of each root, counter = 3
  * (sampleDstNodesUniformly, NodeAnchorBasedLinkPredictionBaseTask.scala:19-104).  `g_out` is the
  * CSR-by-source graph loaded through gigl_graph_load_csc with the roles of src/dst swapped. */

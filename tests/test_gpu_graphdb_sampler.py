@@ -1,0 +1,121 @@
+"""SamplingOp-DAG sampler on the device (gigl_rows_dedup + gigl_expand_frontier per op) against the per-root CPU
+restatement of GraphDBSampler (oracle/dag_sampler.py) on a DBLP-shaped heterogeneous graph (author / paper / venue as
+in the reference's heterogeneous fixtures): identical edge and node sets per root, plus the contract's properties."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dag_sampler
+from gigl_amd.graphdb_sampler import (INCOMING, OUTGOING, EdgeType, HipGraphDBSampler, SamplingOp, SamplingOpDAG)
+
+pytestmark = pytest.mark.gpu
+
+A2P = EdgeType("author", "author_to_paper", "paper")
+P2A = EdgeType("paper", "paper_to_author", "author")
+P2V = EdgeType("paper", "published_in", "venue")
+NODE_TYPES = {"author": 0, "paper": 1, "venue": 2}
+CET = {A2P: 0, P2A: 1, P2V: 2}
+
+
+@pytest.fixture(scope="module")
+def world():
+    rng = np.random.default_rng(0)
+    n = {"author": 3000, "paper": 5000, "venue": 40}
+    k = 20000
+    a = (rng.zipf(1.6, k) % n["author"]).astype(np.uint32)
+    p = rng.integers(0, n["paper"], k).astype(np.uint32)
+    edges = {A2P: (a, p), P2A: (p, a),
+             P2V: (np.arange(0, n["paper"], 2, dtype=np.uint32), rng.integers(0, n["venue"], n["paper"] // 2).astype(np.uint32))}
+    feats = {t: rng.standard_normal((n[t], d)).astype(np.float32) for t, d in (("author", 3), ("paper", 5), ("venue", 2))}
+    s = HipGraphDBSampler(NODE_TYPES, n, edges, CET, feats)
+    yield s, n, edges, feats, dag_sampler.neighbour_lists(edges)
+    s.close()
+
+
+def _dag_two_paths():
+    # root paper: its authors (op0) and its venue (op1); op2 = other papers of those authors; op3 (two parents, mixed
+    # directions) = papers of the venue UNITED with op2's papers -> their authors
+    return [SamplingOp("op0", A2P, 4, [], INCOMING),            # authors writing the root paper
+            SamplingOp("op1", P2V, 1, [], OUTGOING),            # the root paper's venue
+            SamplingOp("op2", A2P, 3, ["op0"], OUTGOING),       # papers of those authors
+            SamplingOp("op3", P2V, 5, ["op1"], INCOMING),       # papers published in that venue
+            SamplingOp("op4", P2A, 2, ["op2", "op3"], OUTGOING)]  # authors of the united paper set
+
+
+def _check(world, ops, root_type, roots):
+    s, n, edges, feats, nbrs = world
+    dag = SamplingOpDAG.from_ops(ops)
+    msgs = s.getKHopSubgraphForRootNodes(roots, root_type, dag)
+    assert len(msgs) == len(roots)
+    n_multi = 0
+    for r, m in zip(roots, msgs):
+        want_e, want_n = dag_sampler.sample_for_root(int(r), ops, nbrs, NODE_TYPES, CET, root_type)
+        got_e = {(e.src_node_id, e.dst_node_id, e.condensed_edge_type) for e in m.neighborhood.edges}
+        got_n = {(x.node_id, x.condensed_node_type) for x in m.neighborhood.nodes}
+        assert got_e == want_e and got_n == want_n
+        assert len(m.neighborhood.edges) == len(got_e) and len(m.neighborhood.nodes) == len(got_n)  # sets
+        assert (m.root_node.node_id, m.root_node.condensed_node_type) == (int(r), NODE_TYPES[root_type])
+        by_cnt = {c: t for t, c in NODE_TYPES.items()}
+        for x in m.neighborhood.nodes:  # hydrated with the features of its own type
+            np.testing.assert_array_equal(x.feature_values, feats[by_cnt[x.condensed_node_type]][x.node_id])
+        n_multi += len(want_e) > 8
+    return msgs, n_multi
+
+
+def test_dag_matches_the_per_root_restatement(world):
+    rng = np.random.default_rng(1)
+    roots = rng.integers(0, 5000, 96)
+    roots[:4] = [0, 2, 4998, 4999]
+    msgs, n_multi = _check(world, _dag_two_paths(), "paper", roots)
+    assert n_multi > 30
+
+
+def test_chain_dag_and_skipped_paths(world):
+    s, n, edges, feats, nbrs = world
+    # an author root: papers (op0) -> venues (op1, OUTGOING) and co-authors (op2); odd papers have no venue: for such
+    # roots op1 returns nothing and op3 (child of op1) must not run at all
+    ops = [SamplingOp("op0", A2P, 2, [], OUTGOING), SamplingOp("op1", P2V, 1, ["op0"], OUTGOING),
+           SamplingOp("op2", P2A, 3, ["op0"], OUTGOING), SamplingOp("op3", P2V, 4, ["op1", "op2"], INCOMING)]
+    rng = np.random.default_rng(2)
+    roots = rng.integers(0, 3000, 128)
+    msgs, _ = _check(world, ops, "author", roots)
+    dag = SamplingOpDAG.from_ops(ops)
+    assert dag.execution_order() == ["op0", "op1", "op2", "op3"] and dag.root_op_names == ["op0"]
+    # properties of the contract: at most n neighbours per frontier node and op; frontier rows are sets
+    res = s.run_dag(torch.tensor(roots.astype(np.int32)), dag)
+    for name, r in res.items():
+        f = dag.nodes[name].sampling_op.num_nodes_to_sample
+        cnt = r.cnt.cpu().numpy()
+        assert cnt.max() <= f
+        fr = r.frontier.cpu().numpy().view(np.uint32)
+        for row in fr:
+            v = row[row != 0xFFFFFFFF]
+            assert len(np.unique(v)) == len(v)
+    # some roots have no venue on any of their papers: op3 contributed nothing for them although op2 returned nodes
+    lonely = [m for m in msgs if not any(e.condensed_edge_type == CET[P2V] for e in m.neighborhood.edges)]
+    assert lonely and all(all(x.condensed_node_type != NODE_TYPES["venue"] for x in m.neighborhood.nodes) for m in lonely)
+
+
+def test_rows_dedup_kernel(world):
+    s = world[0]
+    eng = s.engine
+    rng = np.random.default_rng(3)
+    for rows, width in ((1, 1), (7, 33), (300, 700), (4, 8192)):
+        a = rng.integers(0, max(width // 3, 2), (rows, width)).astype(np.uint32)
+        a[rng.random((rows, width)) < 0.2] = 0xFFFFFFFF
+        t = torch.from_numpy(a.view(np.int32)).to(eng.device).contiguous()
+        eng.rows_dedup(t)
+        got = t.cpu().numpy().view(np.uint32)
+        for r in range(rows):
+            want = a[r].copy()
+            seen = set()
+            for q, v in enumerate(a[r].tolist()):
+                if v == 0xFFFFFFFF:
+                    continue
+                if v in seen:
+                    want[q] = 0xFFFFFFFF
+                seen.add(v)
+            np.testing.assert_array_equal(got[r], want)
+    from gigl_amd import _lib
+    with pytest.raises(_lib.GiglError):
+        eng.rows_dedup(torch.zeros((2, 9000), dtype=torch.int32, device=eng.device))
