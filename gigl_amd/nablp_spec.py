@@ -246,6 +246,15 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         self.hidden_dim = int(kwargs.get("hidden_dim", 16))
         self.num_layers = int(kwargs.get("num_layers", 2))
         self.out_channels = int(kwargs.get("out_channels", 16))
+        # encoder-specific arguments (GAT: heads; GAT / EdgeAttrGAT: edge_dim, conv), handed on when the class takes them
+        self._encoder_kwargs = {}
+        if "num_heads" in kwargs or "heads" in kwargs:
+            self._encoder_kwargs["heads"] = int(kwargs.get("num_heads", kwargs.get("heads")))
+        if kwargs.get("edge_dim") not in (None, "", "None"):
+            self._encoder_kwargs["edge_dim"] = int(kwargs["edge_dim"])
+        for k in ("conv", "share_edge_att_message_weight"):
+            if k in kwargs:
+                self._encoder_kwargs[k] = kwargs[k] if k == "conv" else _strtobool(kwargs[k])
         self.should_l2_normalize_embedding_layer_output = bool(
             kwargs.get("should_l2_normalize_embedding_layer_output", True))
         self.validate_every_n_batches = int(kwargs.get("val_every_num_batches", 20))
@@ -295,9 +304,13 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
     def init_model(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, state_dict=None) -> nn.Module:
         self._cfg = gbml_config_pb_wrapper
         in_dim = gbml_config_pb_wrapper.preprocessed_metadata.nodes[0].feature_dim
+        import inspect
+        accepted = inspect.signature(self.gnn_model.__init__).parameters
+        takes_any = any(p.kind == p.VAR_KEYWORD for p in accepted.values())
+        extra = {k: v for k, v in self._encoder_kwargs.items() if k in accepted or takes_any}
         encoder = self.gnn_model(
             in_dim=max(in_dim, 1), hid_dim=self.hidden_dim, out_dim=self.out_channels, num_layers=self.num_layers,
-            should_l2_normalize_embedding_layer_output=self.should_l2_normalize_embedding_layer_output)
+            should_l2_normalize_embedding_layer_output=self.should_l2_normalize_embedding_layer_output, **extra)
         model = LinkPredictionGNN(encoder=encoder, decoder=LinkPredictionDecoder())
         if state_dict is not None:
             model.load_state_dict(state_dict)
