@@ -1,9 +1,12 @@
 """timing of the device-side Avro embedding encoder (gigl_avro_embeddings_encode) at the products-sized output"""
+import os
+import sys
 import time
 
 import torch
 
-from gigl_amd.engine import HipEngine
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gigl_amd.engine import HipEngine  # noqa: E402
 
 eng = HipEngine(0)
 for n, d in ((2_449_029, 128), (2_449_029, 32), (1_000_000, 768)):
