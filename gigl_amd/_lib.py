@@ -36,7 +36,7 @@ SYMBOLS = [
     "gigl_tfrecord_index", "gigl_tfexample_decode", "gigl_collate_records", "gigl_collated_info", "gigl_collated_copy",
     "gigl_collated_destroy", "gigl_gather_reduce", "gigl_gather_reduce_backward",
     "gigl_frontier_bucket", "gigl_frontier_scatter", "gigl_avro_embeddings_layout", "gigl_avro_embeddings_encode",
-    "gigl_edge_ids", "gigl_union_edge_ids", "gigl_gat_aggregate_edge", "gigl_collated_edge_attr", "gigl_sample_out_neighbors", "gigl_rows_dedup",
+    "gigl_edge_ids", "gigl_union_edge_ids", "gigl_gat_aggregate_edge", "gigl_collated_edge_attr", "gigl_sample_out_neighbors", "gigl_rows_dedup", "gigl_gat_aggregate_backward",
 ]
 
 KERNEL_IDS = {
@@ -180,6 +180,8 @@ def load() -> C.CDLL:
         "gigl_tfexample_decode": [vp, vp, vp, i64, P(GiglColumn), i32, i32, P(i64)],
         "gigl_gat_aggregate_edge": [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, i32,
                                     i64, vp, vp, vp, vp],
+        "gigl_gat_aggregate_backward": [vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i32,
+                                        i64, vp, vp, vp, vp, vp, vp],
         "gigl_rows_dedup": [vp, vp, i64, i32],
         "gigl_edge_ids": [vp, vp, vp, vp, i64, vp],
         "gigl_union_edge_ids": [vp, vp, P(GiglUnion), vp],

@@ -955,6 +955,153 @@ __global__ __launch_bounds__(256) void gat_gather_fast_kernel(
   }
 }
 
+// ---- backward of the attention aggregation (training): one wave per destination row, same lane layout as the
+// forward.  With alpha_e = softmax_e(z_e), out_i = sum_e alpha_e x_e (e over the in-edges and the added self loop):
+//   d alpha_e = <g_i, x_e>,  S = sum_e alpha_e d alpha_e = <g_i, out_i>,  dz_e = alpha_e (d alpha_e - S),
+//   dpre_e = dz_e * leaky'(pre_e);  dx_e += alpha_e g_i;  d a_src[j] += dpre_e;  d a_dst[i] += dpre_e;
+//   d a_edge[e] = dpre_e (+ dpre_self / cnt: the self loop's logit holds the MEAN a_edge of the row).
+// Pass 1 recomputes max and denominator from the scalars, pass 2 reads every source row once.
+template <int V>
+__global__ __launch_bounds__(256) void gat_backward_kernel(
+    const float* __restrict__ h, const float* __restrict__ a_src, const float* __restrict__ a_dst,
+    const float* __restrict__ a_edge, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ n_rows_dev, int heads, int C, int group,
+    int rows_per_head, float slope, const float* __restrict__ out_pre, const float* __restrict__ dout,
+    float* __restrict__ dh, float* __restrict__ d_src, float* __restrict__ d_dst, float* __restrict__ d_edge) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n_rows = *n_rows_dev, HC = heads * C, chunks = HC >> 2;
+  int hd[V];
+  bool on[V], writer[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    on[v] = v * 64 + lane < chunks;
+    hd[v] = on[v] ? gat_head_of(v, lane, group, rows_per_head) : 0;
+    // one lane per head publishes the per-head scalars
+    writer[v] = on[v] && (rows_per_head > 1 ? (lane == 0 && v % rows_per_head == 0) : (lane & (group - 1)) == 0);
+  }
+  // sum of a per-lane partial over the lanes (and chunk rows) of the lane's head, returned to every lane of the head
+  auto head_sum = [&](float (&p)[V]) {
+    if (rows_per_head > 1) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < V; ++u)
+          if (u / rows_per_head == v / rows_per_head) t += p[u];
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+        p[v] = t;
+      }
+      return;
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+      for (int off = group >> 1; off > 0; off >>= 1) p[v] += __shfl_xor(p[v], off, 64);
+  };
+  auto dot4 = [](const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; };
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    float ad[V], as_i[V], mx[V], den[V], sum_ae[V], S[V], dd[V];
+    float4 g[V], xi[V];
+    int cnt = 0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      ad[v] = a_dst[(int64_t)i * heads + hd[v]];
+      as_i[v] = a_src[(int64_t)i * heads + hd[v]];
+      g[v] = on[v] ? ((const float4*)(dout + (int64_t)i * HC))[v * 64 + lane] : float4{0, 0, 0, 0};
+      xi[v] = on[v] ? ((const float4*)(h + (int64_t)i * HC))[v * 64 + lane] : float4{0, 0, 0, 0};
+      const float4 o = on[v] ? ((const float4*)(out_pre + (int64_t)i * HC))[v * 64 + lane] : float4{0, 0, 0, 0};
+      S[v] = dot4(g[v], o);
+      mx[v] = -INFINITY;
+      den[v] = 0.f;
+      sum_ae[v] = 0.f;
+      dd[v] = 0.f;
+    }
+    head_sum(S);
+    // pass 1: max / denominator (every lane of a head computes the same scalars)
+    for (int e = 0; e < m; ++e) {
+      const int j = col[e0 + e];
+      if (j == i) continue;
+      ++cnt;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float z = a_src[(int64_t)j * heads + hd[v]] + ad[v];
+        if (a_edge) {
+          const float ae = a_edge[(int64_t)(e0 + e) * heads + hd[v]];
+          z += ae;
+          sum_ae[v] += ae;
+        }
+        z = z > 0.f ? z : slope * z;
+        const float nm = fmaxf(mx[v], z);
+        den[v] = den[v] * __expf(mx[v] - nm) + __expf(z - nm);
+        mx[v] = nm;
+      }
+    }
+    float pre_self[V], al_self[V], dpre_self[V], dal[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      pre_self[v] = as_i[v] + ad[v] + (a_edge && cnt > 0 ? sum_ae[v] / (float)cnt : 0.f);
+      const float z = pre_self[v] > 0.f ? pre_self[v] : slope * pre_self[v];
+      const float nm = fmaxf(mx[v], z);
+      den[v] = den[v] * __expf(mx[v] - nm) + __expf(z - nm);
+      mx[v] = nm;
+      den[v] = 1.0f / (den[v] + 1e-16f);
+      al_self[v] = __expf(z - nm) * den[v];
+      dal[v] = dot4(g[v], xi[v]);
+    }
+    head_sum(dal);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      dpre_self[v] = al_self[v] * (dal[v] - S[v]) * (pre_self[v] > 0.f ? 1.f : slope);
+      dd[v] += dpre_self[v];
+      if (on[v]) {
+        float* o = dh + (int64_t)i * HC + 4 * (v * 64 + lane);
+        atomicAdd(o + 0, al_self[v] * g[v].x);
+        atomicAdd(o + 1, al_self[v] * g[v].y);
+        atomicAdd(o + 2, al_self[v] * g[v].z);
+        atomicAdd(o + 3, al_self[v] * g[v].w);
+      }
+      if (writer[v]) atomicAdd(d_src + (int64_t)i * heads + hd[v], dpre_self[v]);
+    }
+    // pass 2: the in-edges
+    for (int e = 0; e < m; ++e) {
+      const int j = col[e0 + e];
+      if (j == i) continue;
+      float4 x[V];
+      float da[V], pre[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        x[v] = on[v] ? ((const float4*)(h + (int64_t)j * HC))[v * 64 + lane] : float4{0, 0, 0, 0};
+        da[v] = dot4(g[v], x[v]);
+        pre[v] = a_src[(int64_t)j * heads + hd[v]] + ad[v] + (a_edge ? a_edge[(int64_t)(e0 + e) * heads + hd[v]] : 0.f);
+      }
+      head_sum(da);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float z = pre[v] > 0.f ? pre[v] : slope * pre[v];
+        const float al = __expf(z - mx[v]) * den[v];
+        const float dpre = al * (da[v] - S[v]) * (pre[v] > 0.f ? 1.f : slope);
+        dd[v] += dpre;
+        if (on[v]) {
+          float* o = dh + (int64_t)j * HC + 4 * (v * 64 + lane);
+          atomicAdd(o + 0, al * g[v].x);
+          atomicAdd(o + 1, al * g[v].y);
+          atomicAdd(o + 2, al * g[v].z);
+          atomicAdd(o + 3, al * g[v].w);
+        }
+        if (writer[v]) {
+          atomicAdd(d_src + (int64_t)j * heads + hd[v], dpre);
+          if (d_edge) d_edge[(int64_t)(e0 + e) * heads + hd[v]] = dpre + (cnt > 0 ? dpre_self[v] / (float)cnt : 0.f);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+      if (writer[v]) atomicAdd(d_dst + (int64_t)i * heads + hd[v], dd[v]);
+  }
+}
+
 __global__ void gat_transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < rows * cols) wt[(int64_t)(t % cols) * rows + t / cols] = w[t];
@@ -1207,6 +1354,54 @@ int32_t gigl_gat_aggregate_edge(gigl_ctx* ctx, const float* h, const float* att_
   hipLaunchKernelGGL(gat_edge_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, h, a_src, a_dst,
                      a_edge, edge_attr, edge_dim, w_edge_msg, rowptr, rowend, col, n_rows_dev, heads, channels,
                      negative_slope, concat, bias, act, out);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_gat_aggregate_backward(gigl_ctx* ctx, const float* h, const float* att_src, const float* att_dst,
+                                    int32_t heads, int32_t channels, float negative_slope, const int32_t* rowptr,
+                                    const int32_t* rowend, const int32_t* col, const int32_t* n_nodes_dev,
+                                    int64_t nodes_cap, const int32_t* n_rows_dev, int64_t rows_cap,
+                                    const float* out_pre, const float* dout, const float* edge_attr, int32_t edge_dim,
+                                    int64_t cap_edges, const float* att_edge_folded, float* alpha_scratch, float* dh,
+                                    float* d_alpha_src, float* d_alpha_dst, float* d_alpha_edge) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, h && att_src && att_dst && rowptr && rowend && col && n_nodes_dev && n_rows_dev && out_pre &&
+                        dout && alpha_scratch && dh && d_alpha_src && d_alpha_dst, "null argument");
+  GIGL_REQUIRE(ctx, heads > 0 && channels > 0 && rows_cap >= 0 && nodes_cap >= rows_cap && cap_edges >= 0, "bad sizes");
+  GIGL_REQUIRE(ctx, (edge_attr == nullptr) == (att_edge_folded == nullptr) && (!edge_attr || d_alpha_edge),
+               "edge_attr, att_edge_folded and d_alpha_edge go together");
+  GatShape g;
+  if (!gat_fast_shape(heads, channels, g) ||
+      (((uintptr_t)h | (uintptr_t)dout | (uintptr_t)out_pre | (uintptr_t)dh | (uintptr_t)att_src | (uintptr_t)att_dst) & 15))
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED,
+                     "GAT backward needs channels %% 4 == 0 and channels/4 a power of two <= 64 (or channels %% 256 == 0), "
+                     "heads*channels <= 1024, 16-byte aligned matrices; got heads=%d channels=%d", heads, channels);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  float* a_src = alpha_scratch;
+  float* a_dst = alpha_scratch + nodes_cap * heads;
+  float* a_edge = edge_attr ? alpha_scratch + 2 * nodes_cap * heads : nullptr;
+  if (edge_attr && cap_edges > 0)
+    hipLaunchKernelGGL(gat_edge_alpha_kernel, dim3((unsigned)((cap_edges * heads + 255) / 256)), dim3(256), 0,
+                       ctx->stream, edge_attr, edge_dim, att_edge_folded, heads, cap_edges, a_edge);
+  int64_t ablocks = (nodes_cap + 3) / 4, gblocks = (rows_cap + 3) / 4;
+  if (ablocks > 256 * 32) ablocks = 256 * 32;
+  if (gblocks > 256 * 32) gblocks = 256 * 32;
+#define GAT_BWD(VV)                                                                                                  \
+  hipLaunchKernelGGL((gat_alpha_fast_kernel<VV>), dim3((unsigned)ablocks), dim3(256), 0, ctx->stream, h, att_src,   \
+                     att_dst, n_nodes_dev, heads, channels, g.group, g.rows_per_head, a_src, a_dst);                \
+  hipLaunchKernelGGL((gat_backward_kernel<VV>), dim3((unsigned)gblocks), dim3(256), 0, ctx->stream, h, a_src, a_dst, \
+                     a_edge, rowptr, rowend, col, n_rows_dev, heads, channels, g.group, g.rows_per_head,            \
+                     negative_slope, out_pre, dout, dh, d_alpha_src, d_alpha_dst, d_alpha_edge)
+  if (g.V == 1) {
+    GAT_BWD(1);
+  } else if (g.V == 2) {
+    GAT_BWD(2);
+  } else {
+    GAT_BWD(4);
+  }
+#undef GAT_BWD
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -654,6 +654,31 @@ class HipEngine:
             C.c_void_p(out.data_ptr())), self._ctx)
         return out
 
+    def gat_aggregate_backward(self, h: torch.Tensor, att_src: torch.Tensor, att_dst: torch.Tensor, heads: int,
+                               channels: int, u, n_rows_dev: torch.Tensor, out_pre: torch.Tensor, dout: torch.Tensor,
+                               negative_slope: float = 0.2, edge_attr: Optional[torch.Tensor] = None,
+                               att_edge_folded: Optional[torch.Tensor] = None):
+        """-> (dh [cap, H*C], d_alpha_src [cap, H], d_alpha_dst [cap, H], d_alpha_edge [cap_edges, H] | None): the
+        edge-wise part of the GAT layer's backward (gigl_gat_aggregate_backward); see include/gigl_hip.h"""
+        cap, ce = int(u.nodes.numel()), int(u.col.numel())
+        hc = heads * channels
+        for t in (h, out_pre, dout):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.shape[1] == hc
+        dev = self.device
+        dh = torch.zeros((cap, hc), dtype=torch.float32, device=dev)
+        ds = torch.zeros((cap, heads), dtype=torch.float32, device=dev)
+        dd = torch.zeros((cap, heads), dtype=torch.float32, device=dev)
+        dae = torch.zeros((ce, heads), dtype=torch.float32, device=dev) if edge_attr is not None else None
+        scratch = torch.empty(2 * cap * heads + (ce * heads if edge_attr is not None else 0), dtype=torch.float32,
+                              device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(self._lib.gigl_gat_aggregate_backward(
+            self._ctx, p(h), p(att_src), p(att_dst), heads, channels, negative_slope, p(u.rowptr), p(u.rowend),
+            p(u.col), p(u.meta), cap, p(n_rows_dev), cap, p(out_pre), p(dout), p(edge_attr),
+            int(edge_attr.shape[1]) if edge_attr is not None else 0, ce, p(att_edge_folded), p(scratch), p(dh), p(ds),
+            p(dd), p(dae)), self._ctx)
+        return dh, ds, dd, dae
+
     def gather_mean_backward(self, dout: torch.Tensor, d: int, rowptr: torch.Tensor, rowend: Optional[torch.Tensor],
                              col: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int, dsrc: torch.Tensor,
                              aggr: str = "mean", src: Optional[torch.Tensor] = None) -> None:

@@ -59,6 +59,49 @@ class TwoLayerGCN(nn.Module):
         return out
 
 
+class _GatConvFn(torch.autograd.Function):
+    """out = GATConv(x) over ALL rows of a coalesced batch graph, before the activation; heads concatenated (or one
+    head).  Forward: gigl_linear + gigl_gat_aggregate[_edge]; backward: gigl_gat_aggregate_backward for the edge-wise
+    part, dense algebra (attention vectors, projection) through gigl_linear / small torch reductions."""
+
+    @staticmethod
+    def forward(ctx, x, w, att_src, att_dst, bias, v_att, eng, view, n_dev, heads, channels, slope, edge_attr):
+        n = int(x.shape[0])
+        x = x.contiguous()
+        xw = eng.linear(x, w.contiguous(), None, n_dev, n, act=0)
+        kw = {} if edge_attr is None else dict(edge_attr=edge_attr, att_edge_folded=v_att.contiguous())
+        out = eng.gat_aggregate(xw, att_src.reshape(-1).contiguous(), att_dst.reshape(-1).contiguous(), heads, channels,
+                                view, n_dev, bias, concat=True, negative_slope=slope, act=0, **kw)
+        ctx.eng, ctx.view, ctx.n_dev, ctx.dims, ctx.slope, ctx.edge_attr = eng, view, n_dev, (heads, channels), slope, edge_attr
+        ctx.save_for_backward(x, w, xw, att_src, att_dst, bias if bias is not None else x.new_zeros(0), out,
+                              v_att if v_att is not None else x.new_zeros(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, xw, att_src, att_dst, bias, out, v_att = ctx.saved_tensors
+        eng, view, n_dev, (heads, ch), slope, edge_attr = ctx.eng, ctx.view, ctx.n_dev, ctx.dims, ctx.slope, ctx.edge_attr
+        n, hc = int(x.shape[0]), heads * ch
+        dy = dy.contiguous()
+        out_pre = (out - bias) if bias.numel() else out
+        dh, ds, dd, dae = eng.gat_aggregate_backward(
+            xw, att_src.reshape(-1).contiguous(), att_dst.reshape(-1).contiguous(), heads, ch, view, n_dev,
+            out_pre.contiguous(), dy, negative_slope=slope, edge_attr=edge_attr,
+            att_edge_folded=v_att.contiguous() if v_att.numel() else None)
+        xw3 = xw.view(n, heads, ch)
+        d_att_src = (ds.unsqueeze(-1) * xw3).sum(0).view_as(att_src)
+        d_att_dst = (dd.unsqueeze(-1) * xw3).sum(0).view_as(att_dst)
+        dxw = (dh.view(n, heads, ch) + ds.unsqueeze(-1) * att_src.view(1, heads, ch)
+               + dd.unsqueeze(-1) * att_dst.view(1, heads, ch)).reshape(n, hc).contiguous()
+        dev = dy.device
+        n_out = torch.tensor([hc], dtype=torch.int32, device=dev)
+        dw = eng.linear(dxw.t().contiguous(), x.t().contiguous(), None, n_out, hc, 0)        # dW = dxw^T x
+        dx = eng.linear(dxw, w.t().contiguous(), None, n_dev, n, 0) if ctx.needs_input_grad[0] else None
+        db = dy.sum(0) if bias.numel() else None
+        dv = dae.t().mm(edge_attr) if dae is not None else None
+        return dx, dw, d_att_src, d_att_dst, db, dv, None, None, None, None, None, None, None
+
+
 class GATConv(nn.Module):
     """parameter holder with PyG GATConv's layout (lin / att_src / att_dst / bias; with edge_dim also lin_edge and
     att_edge)"""
@@ -135,14 +178,17 @@ class GAT(nn.Module):
                 edge_dim=edge_dim, **extra)
             for i in range(num_layers)])
 
-    @torch.no_grad()
     def forward(self, batch, engine=None) -> torch.Tensor:
         """HipBatch  -> trimmed schedule over the level-ordered union graph: [cap, out]; index with batch.root_local
         GraphData -> every layer over the whole coalesced batch graph (samples that arrived as TFRecords; the
                      reference's execution order): [n, out]; edge features from GraphData.edge_attr"""
         from .nn import GraphData
-        if isinstance(batch, GraphData):
+        if isinstance(batch, GraphData):  # autograd-capable (training through the plugins); under no_grad: inference
             return self._forward_graph(batch, engine or getattr(self, "engine", None))
+        with torch.no_grad():
+            return self._forward_union(batch)
+
+    def _forward_union(self, batch: HipBatch) -> torch.Tensor:
         eng, u = batch.engine, batch.union
         L = self.num_layers
         assert u.hops == L, "one hop per layer"
@@ -187,8 +233,21 @@ class GAT(nn.Module):
             if edge_attr.shape[0] != view.col.numel():  # edgeless batch: col holds one padding entry
                 edge_attr = torch.zeros((view.col.numel(), self.edge_dim), dtype=torch.float32, device=g.x.device)
         h = g.x.contiguous()
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         for l, conv in enumerate(self.conv_layers):
-            h = self._layer(eng, conv, l, h, view, g.n_dev, g.n_dev, n, edge_attr)
+            if not train:
+                with torch.no_grad():
+                    h = self._layer(eng, conv, l, h, view, g.n_dev, g.n_dev, n, edge_attr)
+                continue
+            if conv.edge_message_weight() is not None:
+                raise NotImplementedError("training EdgeAttrGATConv's edge messages is not built (inference is)")
+            if not conv.concat and conv.heads > 1:
+                raise NotImplementedError("training with heads averaged (concat=False) is not built")
+            v_att = conv.folded_att_edge() if edge_attr is not None else None
+            h = _GatConvFn.apply(h, conv.lin.weight, conv.att_src, conv.att_dst, conv.bias, v_att, eng, view, g.n_dev,
+                                 conv.heads, conv.out_channels, conv.negative_slope, edge_attr)
+            if l < self.num_layers - 1 or self.activation_after_last_conv:
+                h = torch.relu(h)
         if self.should_l2_normalize_embedding_layer_output:
             h = torch.nn.functional.normalize(h, p=2, dim=1)
         return h

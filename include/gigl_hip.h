@@ -482,6 +482,25 @@ int32_t gigl_gat_aggregate_edge(gigl_ctx* ctx, const float* h, const float* att_
                                 int32_t edge_dim, int64_t cap_edges, const float* att_edge_folded,
                                 const float* w_edge_msg, float* alpha_scratch, float* out);
 
+/* backward of gigl_gat_aggregate / gigl_gat_aggregate_edge (concatenated heads or one head; no W_msg messages) for
+ * training through the reference's plugins (GnnTrainingProcess, training_process.py:153-370): given dout = dL/d(out
+ * before bias and activation) and out_pre = that output, both [rows][heads*channels]:
+ *   dh[nodes][heads*channels]  += the gradient w.r.t. the projected rows through the messages (zero-filled by the
+ *                                 caller, accumulated with fp32 atomics),
+ *   d_alpha_src / d_alpha_dst [nodes][heads] += the gradients w.r.t. <h, att_src> and <h, att_dst> (zero-filled),
+ *   d_alpha_edge [cap_edges][heads] = the gradient w.r.t. the per-edge attention term (with edge_attr only).
+ * The caller finishes with dense algebra: dh += d_alpha_src (x) att_src + d_alpha_dst (x) att_dst, d att_src =
+ * sum_i d_alpha_src[i] h[i], d att_edge_folded = d_alpha_edge^T edge_attr, and the projection's own backward.
+ * Shapes: channels % 4 == 0 with channels/4 a power of two <= 64, or channels % 256 == 0; heads*channels <= 1024
+ * (GIGL_E_UNSUPPORTED otherwise).  alpha_scratch as for gigl_gat_aggregate_edge. */
+int32_t gigl_gat_aggregate_backward(gigl_ctx* ctx, const float* h, const float* att_src, const float* att_dst,
+                                    int32_t heads, int32_t channels, float negative_slope, const int32_t* rowptr,
+                                    const int32_t* rowend, const int32_t* col, const int32_t* n_nodes_dev,
+                                    int64_t nodes_cap, const int32_t* n_rows_dev, int64_t rows_cap,
+                                    const float* out_pre, const float* dout, const float* edge_attr, int32_t edge_dim,
+                                    int64_t cap_edges, const float* att_edge_folded, float* alpha_scratch, float* dh,
+                                    float* d_alpha_src, float* d_alpha_dst, float* d_alpha_edge);
+
 /* backward of gigl_gather_mean w.r.t. a dense local fp32 source (gather_ids == NULL; layers >= 2):
  *   dsrc[i][0:d] += dout[i][d:2d];  dsrc[col[e]][0:d] += dout[i][0:d] / deg_i  for e in row i, i < n_rows.
  * dsrc must be zero-filled by the caller.  (PyG's autograd of MessagePassing.propagate + scatter-mean.) */
