@@ -799,13 +799,15 @@ __global__ __launch_bounds__(256) void gat_alpha_fast_kernel(const float* __rest
 // k % group of the head's group, register k / group; at most GAT_ZR registers), the self loop adds alpha_self * mean e;
 // the final product reads the TRANSPOSED weight wt[k][H*C] so that a k-row is one coalesced float4 per lane.
 constexpr int GAT_ZR = 4;
+constexpr int GAT_HEAVY_MIN = 128;  // in-edges from which a row is split over the 8 waves of a workgroup
 template <int V, bool MSG>
 __global__ __launch_bounds__(256) void gat_gather_fast_kernel(
     const float* __restrict__ h, const float* __restrict__ a_src, const float* __restrict__ a_dst,
     const float* __restrict__ a_edge, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
     const int32_t* __restrict__ col, const int32_t* __restrict__ n_rows_dev, int heads, int C, int group,
     int rows_per_head, float slope, const float* __restrict__ bias, int act, const float* __restrict__ edge_attr,
-    int De, const float* __restrict__ wt, float* __restrict__ out) {
+    int De, const float* __restrict__ wt, float* __restrict__ out, int32_t* __restrict__ heavy_count,
+    int32_t* __restrict__ heavy_list) {
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
@@ -819,6 +821,10 @@ __global__ __launch_bounds__(256) void gat_gather_fast_kernel(
   }
   for (int i = wave; i < n_rows; i += waves_total) {
     const int e0 = rowptr[i], m = rowend[i] - e0;
+    if (!MSG && heavy_list && m >= GAT_HEAVY_MIN) {  // hub rows: a whole workgroup each (gat_gather_heavy_kernel)
+      if (lane == 0) heavy_list[atomicAdd(heavy_count, 1)] = i;
+      continue;
+    }
     float ad[V], mx[V], den[V], sum_ae[V];
     float4 acc[V];
     float zz[MSG ? V : 1][GAT_ZR], es[GAT_ZR];  // z per chunk row (rows of one head carry the same values), sum of e
@@ -1102,6 +1108,159 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
   }
 }
 
+// Rows with many in-edges (a hub sampled by many parents keeps one edge set per parent: thousands of edges in one
+// row) would serialise on one wave: here the 8 waves of a workgroup take contiguous slices of the row, each builds its
+// online-softmax state (max, denominator, weighted sum), and wave 0 merges the states — they combine like the edges
+// themselves: rescale both to the common max — then folds in the self loop and writes the row.
+template <int V>
+__global__ __launch_bounds__(512) void gat_gather_heavy_kernel(
+    const float* __restrict__ h, const float* __restrict__ a_src, const float* __restrict__ a_dst,
+    const float* __restrict__ a_edge, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ heavy_count, const int32_t* __restrict__ heavy_list,
+    int heads, int C, int group, int rows_per_head, float slope, const float* __restrict__ bias, int act,
+    float* __restrict__ out) {
+  extern __shared__ float s_part[];  // [8 waves][V][7][64]: acc.x .y .z .w, max, denominator, sum of a_edge
+  __shared__ int s_cnt[8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int HC = heads * C, chunks = HC >> 2;
+  int hd[V];
+  bool on[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    on[v] = v * 64 + lane < chunks;
+    hd[v] = on[v] ? gat_head_of(v, lane, group, rows_per_head) : 0;
+  }
+  const int n_heavy = *heavy_count;
+  for (int idx = blockIdx.x; idx < n_heavy; idx += gridDim.x) {
+    const int i = heavy_list[idx];
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    const int per = (((m + 7) >> 3) + 3) & ~3;
+    const int lo = min(w * per, m), hi = min(lo + per, m);
+    float ad[V], mx[V], den[V], sum_ae[V];
+    float4 acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      ad[v] = a_dst[(int64_t)i * heads + hd[v]];
+      mx[v] = -INFINITY;
+      den[v] = 0.f;
+      sum_ae[v] = 0.f;
+      acc[v] = float4{0, 0, 0, 0};
+    }
+    int cnt = 0;
+    constexpr int U = 4;
+    for (int e = lo; e < hi; e += U) {
+      int j[U];
+      float4 x[U][V];
+      float lg[U][V];
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        j[t] = e + t < hi ? col[e0 + e + t] : -1;
+        if (j[t] == i) j[t] = -1;
+      }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        if (j[t] < 0) continue;
+        const float4* row = (const float4*)(h + (int64_t)j[t] * HC);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          x[t][v] = on[v] ? row[v * 64 + lane] : float4{0, 0, 0, 0};
+          lg[t][v] = a_src[(int64_t)j[t] * heads + hd[v]] + ad[v];
+          if (a_edge) {
+            const float ae = a_edge[(int64_t)(e0 + e + t) * heads + hd[v]];
+            lg[t][v] += ae;
+            sum_ae[v] += ae;
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        if (j[t] < 0) continue;
+        ++cnt;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float z = lg[t][v];
+          z = z > 0.f ? z : slope * z;
+          const float nm = fmaxf(mx[v], z);
+          const float sc = __expf(mx[v] - nm), pw = __expf(z - nm);
+          den[v] = den[v] * sc + pw;
+          acc[v].x = acc[v].x * sc + pw * x[t][v].x;
+          acc[v].y = acc[v].y * sc + pw * x[t][v].y;
+          acc[v].z = acc[v].z * sc + pw * x[t][v].z;
+          acc[v].w = acc[v].w * sc + pw * x[t][v].w;
+          mx[v] = nm;
+        }
+      }
+    }
+    if (w > 0) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float* p = s_part + ((w * V + v) * 7) * 64 + lane;
+        p[0] = acc[v].x;
+        p[64] = acc[v].y;
+        p[128] = acc[v].z;
+        p[192] = acc[v].w;
+        p[256] = mx[v];
+        p[320] = den[v];
+        p[384] = sum_ae[v];
+      }
+      if (lane == 0) s_cnt[w] = cnt;
+    }
+    __syncthreads();
+    if (w == 0) {
+      for (int pw_ = 1; pw_ < 8; ++pw_) {
+        cnt += s_cnt[pw_];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const float* p = s_part + ((pw_ * V + v) * 7) * 64 + lane;
+          const float pm = p[256];
+          if (pm == -INFINITY) continue;  // an empty slice
+          const float nm = fmaxf(mx[v], pm);
+          const float s1 = __expf(mx[v] - nm), s2 = __expf(pm - nm);
+          den[v] = den[v] * s1 + p[320] * s2;
+          acc[v].x = acc[v].x * s1 + p[0] * s2;
+          acc[v].y = acc[v].y * s1 + p[64] * s2;
+          acc[v].z = acc[v].z * s1 + p[128] * s2;
+          acc[v].w = acc[v].w * s1 + p[192] * s2;
+          sum_ae[v] += p[384];
+          mx[v] = nm;
+        }
+      }
+      const float4* self = (const float4*)(h + (int64_t)i * HC);
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        if (!on[v]) continue;
+        float z = a_src[(int64_t)i * heads + hd[v]] + ad[v] + (a_edge && cnt > 0 ? sum_ae[v] / (float)cnt : 0.f);
+        z = z > 0.f ? z : slope * z;
+        const float nm = fmaxf(mx[v], z);
+        const float sc = __expf(mx[v] - nm), pw = __expf(z - nm);
+        const float4 xs = self[v * 64 + lane];
+        const float inv = 1.0f / (den[v] * sc + pw + 1e-16f);
+        float4 o;
+        o.x = (acc[v].x * sc + pw * xs.x) * inv;
+        o.y = (acc[v].y * sc + pw * xs.y) * inv;
+        o.z = (acc[v].z * sc + pw * xs.z) * inv;
+        o.w = (acc[v].w * sc + pw * xs.w) * inv;
+        const int q = v * 64 + lane;
+        if (bias) {
+          const float4 b = ((const float4*)bias)[q];
+          o.x += b.x;
+          o.y += b.y;
+          o.z += b.z;
+          o.w += b.w;
+        }
+        if (act == 1) {
+          o.x = fmaxf(o.x, 0.f);
+          o.y = fmaxf(o.y, 0.f);
+          o.z = fmaxf(o.z, 0.f);
+          o.w = fmaxf(o.w, 0.f);
+        }
+        ((float4*)(out + (int64_t)i * HC))[q] = o;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void gat_transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < rows * cols) wt[(int64_t)(t % cols) * rows + t / cols] = w[t];
@@ -1116,9 +1275,18 @@ static bool launch_gat_fast(gigl_ctx* ctx, const float* h, const float* att_src,
   GatShape g;
   if (!(concat || heads == 1) || !gat_fast_shape(heads, C, g)) return false;
   float* wt = nullptr;
+  int32_t *heavy_count = nullptr, *heavy_list = nullptr;
   if (w_msg) {  // the z registers hold at most GAT_ZR * group components; the shuffles need whole chunk rows
     if (De > GAT_ZR * g.group || (heads * C / 4) % 64) return false;
-    if (gigl_arena_reset(ctx, (int64_t)heads * C * De * 4 + 256) != GIGL_OK) return false;
+  }
+  if (gigl_arena_reset(ctx, (int64_t)heads * C * De * 4 + rows_cap * 4 + 1024) != GIGL_OK) return false;
+  if (!w_msg) {
+    heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
+    heavy_list = (int32_t*)gigl_arena_alloc(ctx, rows_cap * 4);
+    if (!heavy_count || !heavy_list) return false;
+    if (hipMemsetAsync(heavy_count, 0, 4, ctx->stream) != hipSuccess) return false;
+  }
+  if (w_msg) {
     wt = (float*)gigl_arena_alloc(ctx, (int64_t)heads * C * De * 4);
     if (!wt) return false;
     hipLaunchKernelGGL(gat_transpose_kernel, dim3((unsigned)((heads * C * De + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -1134,11 +1302,19 @@ static bool launch_gat_fast(gigl_ctx* ctx, const float* h, const float* att_src,
   if (wt)                                                                                                            \
     hipLaunchKernelGGL((gat_gather_fast_kernel<VV, true>), dim3((unsigned)gblocks), dim3(256), 0, ctx->stream, h,    \
                        a_src, a_dst, a_edge, rowptr, rowend, col, n_rows_dev, heads, C, g.group, g.rows_per_head,    \
-                       slope, bias, act, edge_attr, De, wt, out);                                                    \
-  else                                                                                                               \
+                       slope, bias, act, edge_attr, De, wt, out, heavy_count, heavy_list);                           \
+  else {                                                                                                             \
     hipLaunchKernelGGL((gat_gather_fast_kernel<VV, false>), dim3((unsigned)gblocks), dim3(256), 0, ctx->stream, h,   \
                        a_src, a_dst, a_edge, rowptr, rowend, col, n_rows_dev, heads, C, g.group, g.rows_per_head,    \
-                       slope, bias, act, edge_attr, De, wt, out)
+                       slope, bias, act, edge_attr, De, wt, out, heavy_count, heavy_list);                           \
+    const size_t lds = (size_t)8 * VV * 7 * 64 * 4;                                                                  \
+    if (lds > 48 * 1024)                                                                                             \
+      hipFuncSetAttribute((const void*)gat_gather_heavy_kernel<VV>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                          (int)lds);                                                                                 \
+    hipLaunchKernelGGL((gat_gather_heavy_kernel<VV>), dim3(1024), dim3(512), lds, ctx->stream, h, a_src, a_dst,      \
+                       a_edge, rowptr, rowend, col, heavy_count, heavy_list, heads, C, g.group, g.rows_per_head,     \
+                       slope, bias, act, out);                                                                       \
+  }
   if (g.V == 1) {
     GAT_FAST(1);
   } else if (g.V == 2) {

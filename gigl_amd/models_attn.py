@@ -233,7 +233,8 @@ class GAT(nn.Module):
             if edge_attr.shape[0] != view.col.numel():  # edgeless batch: col holds one padding entry
                 edge_attr = torch.zeros((view.col.numel(), self.edge_dim), dtype=torch.float32, device=g.x.device)
         h = g.x.contiguous()
-        train = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        # autograd path: grad mode on, module in training mode (model.eval() or torch.no_grad() select inference)
+        train = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
         for l, conv in enumerate(self.conv_layers):
             if not train:
                 with torch.no_grad():

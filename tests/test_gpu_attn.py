@@ -125,7 +125,7 @@ def test_gat_training_gradients_match_torch_autograd(heads, hid, out, de):
     ea = torch.from_numpy(rng.standard_normal((ei.shape[1], de)).astype(np.float32)) if de else None
     eng = HipEngine(0)
     torch.manual_seed(1)
-    model = GAT(d, hid, out, num_layers=2, heads=heads, edge_dim=de or None).to(eng.device)
+    model = GAT(d, hid, out, num_layers=2, heads=heads, edge_dim=de or None).to(eng.device).train()
     model.engine = eng
     with torch.no_grad():
         for c in model.conv_layers:
@@ -157,4 +157,41 @@ def test_gat_training_gradients_match_torch_autograd(heads, hid, out, de):
         np.testing.assert_allclose(prm.grad.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4 * scale, err_msg=name)
     np.testing.assert_allclose(g.x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4,
                                atol=1e-4 * float(xr.grad.abs().max()))
+    eng.close()
+
+
+@pytest.mark.parametrize("heads,hid,de", [(4, 64, 0), (2, 256, 0), (4, 16, 3)])
+def test_gat_hub_rows_are_split_over_a_workgroup(heads, hid, de):
+    """rows with >= 128 in-edges take the cooperative kernel (8 waves build partial softmax states that are merged):
+    a hub with 2500 in-edges, one with exactly 128 (one of them a self loop), one with 127, against the restatement"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models_attn import GAT
+    from gigl_amd.nn import GraphData
+    rng = np.random.default_rng(hid + de)
+    n, d = 3000, 10
+    src = [rng.choice(n, 2500, replace=False), np.concatenate([[1], rng.choice(np.arange(2, n), 127, replace=False)]),
+           rng.choice(n, 127, replace=False), rng.integers(0, n, 6000)]
+    dst = [np.zeros(2500, np.int64), np.ones(128, np.int64), np.full(127, 2), rng.integers(3, n, 6000)]
+    ei = np.unique(np.stack([np.concatenate(src), np.concatenate(dst)]), axis=1)
+    ei = torch.from_numpy(ei[:, np.lexsort((ei[1], ei[0]))])
+    x = torch.from_numpy((rng.standard_normal((n, d)) / 2).astype(np.float32))
+    ea = torch.from_numpy(rng.standard_normal((ei.shape[1], de)).astype(np.float32)) if de else None
+    eng = HipEngine(0)
+    torch.manual_seed(2)
+    model = GAT(d, hid, 64, num_layers=2, heads=heads, edge_dim=de or None).to(eng.device)
+    model.engine = eng
+    with torch.no_grad():
+        for c in model.conv_layers:
+            c.bias.normal_(0, 0.1)
+        got = model(GraphData(x=x, edge_index=ei, edge_attr=ea).to(eng.device)).cpu().numpy()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    h = x
+    for l in range(2):
+        p = f"conv_layers.{l}."
+        kw = dict(edge_attr=ea, w_edge=sd[p + "lin_edge.weight"], att_edge=sd[p + "att_edge"]) if de else {}
+        h = gnn_ref.gat_conv(h, ei, sd[p + "lin.weight"], sd[p + "att_src"], sd[p + "att_dst"], sd[p + "bias"],
+                             heads if l == 0 else 1, **kw)
+        if l == 0:
+            h = torch.relu(h)
+    np.testing.assert_allclose(got, h.numpy(), rtol=1e-5, atol=1e-5)
     eng.close()

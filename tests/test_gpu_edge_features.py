@@ -164,7 +164,7 @@ def test_tfrecord_path_carries_edge_features_end_to_end(setup):
     eng, rowptr, col, x, efeat, n = setup
     torch.manual_seed(3)
     model = GAT(20, 12, 10, num_layers=2, heads=2, edge_dim=DE, conv="edge_attr_gat",
-                share_edge_att_message_weight=False).to(eng.device)
+                share_edge_att_message_weight=False).to(eng.device).eval()
     model.engine = eng
     roots = np.random.default_rng(8).integers(0, n, size=64).astype(np.uint32)
     tree = eng.sample_khop(roots, [5, 3])
