@@ -174,3 +174,43 @@ def test_records_round_trip_at_full_size(world):
         ids = [nd.node_id for nd in m.neighborhood.nodes]
         assert len(set(ids)) == len(ids) and set(ids) == {s for s, _ in e_want} | {int(roots_h[i])}
         assert all(nd.feature_values.size == d for nd in m.neighborhood.nodes)
+
+
+def test_edge_features_at_full_size(world):
+    """118 M resident edges x 4 floats: the `col`-ordered table is addressed by gigl_edge_ids for every sampled edge and
+    the encoder writes exactly those rows (feature k of edge at position p is a function of p, so it is checked
+    without any host table)"""
+    eng, n, d, rowptr_h, col_h, roots = world
+    e = eng.n_edges
+    pos = torch.arange(e, device=eng.device, dtype=torch.float32)
+    table = torch.stack([pos, pos * 0.5, -pos, torch.ones_like(pos)], dim=1).contiguous()
+    eng._set_edge_table(table)
+    try:
+        fan = [25, 10]
+        r = roots[:512]
+        tree = eng.sample_khop(r, fan)
+        # every sampled (src -> dst) pair resolves to its position in the resident CSC
+        src = tree.nbr[0]
+        dst = torch.repeat_interleave(r, 25)
+        ok = src != -1
+        eid = eng.edge_ids(src[ok], dst[ok])
+        assert bool((eid >= 0).all())
+        col_at = torch.from_numpy(col_h.astype(np.int64)).to(eng.device)[eid]
+        assert torch.equal(col_at, src[ok].to(torch.int64) & INV)
+        rp = torch.from_numpy(rowptr_h).to(eng.device)
+        d64 = dst[ok].to(torch.int64) & INV
+        assert bool(((eid >= rp[d64]) & (eid < rp[d64 + 1])).all())
+        buf, off = eng.encode_records(tree)
+        data = buf.cpu().numpy().tobytes()
+        off_h = off.cpu().numpy()
+        for i in range(0, 512, 37):
+            m = wire.RootedNodeNeighborhood.FromString(next(iter(wire.iter_tfrecords(data[off_h[i]:off_h[i + 1]]))))
+            for ed in m.neighborhood.edges:
+                lo, hi = rowptr_h[ed.dst_node_id], rowptr_h[ed.dst_node_id + 1]
+                p = lo + int(np.searchsorted(col_h[lo:hi], ed.src_node_id))
+                want = np.array([p, p * 0.5, -p, 1.0], dtype=np.float32)
+                np.testing.assert_array_equal(ed.feature_values, want)
+    finally:
+        eng._efeat = None
+        eng._lib.gigl_features_destroy(eng._efeat_handle)
+        eng._efeat_handle = None
