@@ -148,6 +148,8 @@ def main():
                          "768->256->256); mag240m-sharded = BASELINE configs[2]: the MAG240M-shaped graph hash-"
                          "partitioned over the ranks (owner = id %% world), per-hop all_to_all frontier exchange and "
                          "feature pull over RCCL — needs >= 2 GPUs at full size (--shard-scale shrinks it)")
+    ap.add_argument("--shard-group", type=int, default=8,
+                    help="mag240m-sharded: batches of B roots exchanged per set of collectives (dedup stays per batch)")
     ap.add_argument("--shard-scale", type=float, default=1.0,
                     help="mag240m-sharded: fraction of MAG240M's nodes and edges to generate (1.0 needs 8 GPUs' HBM)")
     ap.add_argument("--small", action="store_true", help="200k-node graph (debug)")
@@ -522,6 +524,13 @@ def run_sharded(args, rank, world, local_rank):
     total_batches = (W + K) * world
     perm = torch.randint(0, n, (total_batches * B,), generator=gp)
     my = perm.view(total_batches, B)[rank::world].to(torch.int32).to(dev).contiguous()
+    # G consecutive batches travel together: one set of collectives and launches per G steps; the union graph keeps
+    # the batches apart (gigl_union_build_groups: dedup within a batch only), so a step's edges are those of its batch
+    G = max(1, min(args.shard_group, K))
+    while K % G or W % G:
+        G -= 1
+    GB = G * B
+    my = my.view(-1, GB)
 
     class Slot:  # everything one in-flight batch owns; two slots alternate so that the host read of batch i's split
         pass     # sizes waits while batch i+1's sampling is already queued on the other stream
@@ -534,11 +543,11 @@ def run_sharded(args, rank, world, local_rank):
         if si:
             sl.eng.share_resident(eng)
         sl.eng.bind_stream(sl.stream)
-        sl.tree = sl.eng.alloc_tree(B, fanouts)
-        sl.tree.c_struct.hops, sl.tree.c_struct.b = L, B
+        sl.tree = sl.eng.alloc_tree(GB, fanouts)
+        sl.tree.c_struct.hops, sl.tree.c_struct.b = L, GB
         for k, f in enumerate(fanouts):
             sl.tree.c_struct.fanouts[k] = f
-        sl.u = sl.eng.alloc_union(B, fanouts)
+        sl.u = sl.eng.alloc_union(GB, fanouts)
         sl.sampler = HipDistKHopSampler(sl.eng, world, max_window_end=bound if bound < (1 << 30) else -1, sampling_seed=42)
         sl.puller = HipFeaturePuller(sl.eng, world, x_local, int(sl.u.nodes.numel()))
         slots.append(sl)
@@ -552,7 +561,7 @@ def run_sharded(args, rank, world, local_rank):
         with torch.cuda.stream(sl.stream):
             sl.tree.roots = my[i]
             _, sl.cnt = sl.sampler.sample_khop(sl.tree.roots, fanouts, tree=sl.tree)
-            sl.eng.union_build(sl.tree, out=sl.u)
+            sl.eng.union_build(sl.tree, out=sl.u, group_roots=B)
             p = sl.puller
             req = p.request(sl.u.nodes, sl.u.meta[0])
             dist.all_to_all_single(p.got, req)
@@ -573,9 +582,8 @@ def run_sharded(args, rank, world, local_rank):
             rows = p.serve(p.got, rc)
             back = rows.new_empty((int(sum(sc)), rows.shape[1]))
             dist.all_to_all_single(back, rows, output_split_sizes=sc, input_split_sizes=rc)
-            x = p.place(back, sc, n_rows)
-            out = model(HipBatch(engine=sl.eng, tree=sl.tree, union=sl.u, x=x))
-            sl.rows = out[sl.u.root_local[:B].to(torch.int64)]
+            out = model(HipBatch(engine=sl.eng, tree=sl.tree, union=sl.u, x=back, x_index=p.place_index(sc)))
+            sl.rows = out[sl.u.root_local[:GB].to(torch.int64)]
             if count:
                 u = sl.u
                 rowlen = (u.rowend - u.rowptr).to(torch.int64)
@@ -584,19 +592,33 @@ def run_sharded(args, rank, world, local_rank):
                 acc.add_(torch.stack([sum(c.sum() for c in sl.cnt).to(torch.int64), agg.to(torch.int64),
                                       u.meta[0].to(torch.int64)]))
 
+    tim = {"phase1_enqueue": 0.0, "wait_split_sizes": 0.0, "phase2_enqueue": 0.0} if os.environ.get("GIGL_SHARD_TIMING") else None
+
     def run(lo, hi, count):
         phase1(slots[lo % 2], lo)
         for i in range(lo, hi):
+            ta = time.perf_counter()
             if i + 1 < hi:
                 phase1(slots[(i + 1) % 2], i + 1)
+            tb = time.perf_counter()
+            if tim is not None:
+                slots[i % 2].ready.synchronize()
+            tc = time.perf_counter()
             phase2(slots[i % 2], count)
+            if tim is not None:
+                tim["phase1_enqueue"] += tb - ta
+                tim["wait_split_sizes"] += tc - tb
+                tim["phase2_enqueue"] += time.perf_counter() - tc
 
-    run(0, W, False)
+    run(0, W // G, False)
+    run(W // G, (W + K) // G, True)  # untimed: the edge counts of the timed batches (sampling is deterministic)
+    for k_ in (tim or {}):
+        tim[k_] = 0.0
     torch.cuda.synchronize()
     dist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    run(W, W + K, True)
+    run(W // G, (W + K) // G, False)
     if int(max(int(sl.sampler.overflow.item()) for sl in slots)):
         raise RuntimeError("frontier bucket overflow: rerun with a larger slack")
     torch.cuda.synchronize()
@@ -608,6 +630,8 @@ def run_sharded(args, rank, world, local_rank):
     dist.all_reduce(cc, op=dist.ReduceOp.SUM)
     elapsed = float(tt.item())
     sampled_all, aggregated_all, pulled_all = [float(v) for v in cc.tolist()]
+    if rank == 0 and tim is not None:
+        print("host time per step (ms):", {k: round(v / K * 1e3, 4) for k, v in tim.items()}, file=sys.stderr)
     if rank == 0:
         line = {
             "metric": "sampled+aggregated edges/s", "value": (sampled_all + aggregated_all) / elapsed,
@@ -615,7 +639,8 @@ def run_sharded(args, rank, world, local_rank):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"MAG240M-shaped RMAT x{args.shard_scale:g}: N={n} E={int(e_local.item())} directed, "
                                    f"D={d} fp16 features, hash-partitioned over {world} rank(s) (owner = id % world), "
-                                   f"fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}, sampler mode=parity",
+                                   f"fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}, sampler mode=parity, "
+                                   f"{G} batches per exchange",
                        "graph": "CSC rows + feature rows of the owned nodes per rank; per-hop all_to_all frontier "
                                 "exchange, feature pull of the unique union-graph nodes",
                        "sampled_edges_per_step": sampled_all / (K * world),

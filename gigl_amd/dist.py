@@ -230,6 +230,15 @@ class HipFeaturePuller:
         x.index_copy_(0, slots, back)
         return x
 
+    def place_index(self, send_counts: Sequence[int]) -> torch.Tensor:
+        """instead of copying the received rows into node order (place): pos[local id] = row of `back` that holds the
+        node's features — handed to the first layer as gather_ids (HipBatch.x_index), so the rows are read once, where
+        they arrived"""
+        slots = torch.cat([self.slot_idx[r, : int(send_counts[r])] for r in range(self.world)]).to(torch.int64)
+        pos = torch.zeros(self.m, dtype=torch.int32, device=slots.device)
+        pos[slots] = torch.arange(slots.numel(), dtype=torch.int32, device=slots.device)
+        return pos
+
     def pull(self, ids: torch.Tensor, n_valid_dev: torch.Tensor) -> torch.Tensor:
         req = self.request(ids, n_valid_dev)
         dist.all_to_all_single(self.got, req, group=self.group)

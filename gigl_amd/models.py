@@ -31,6 +31,7 @@ class HipBatch:
     union: UnionGraph
     x: Optional[torch.Tensor] = None  # None: hydrate from the engine's resident feature table
     edge_attr: Optional[torch.Tensor] = None  # [cap_edges, De] rows aligned with union.col; None: engine.union_edge_attr
+    x_index: Optional[torch.Tensor] = None  # int32 [cap]: row of `x` holding local node i (x is then NOT in node order)
 
     @property
     def root_local(self) -> torch.Tensor:
@@ -196,7 +197,8 @@ class GraphSAGE(nn.Module):
             if l == 0 and batch.x is None:
                 a = eng.gather_mean(None, d, u.nodes, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf, aggr=self.aggr)
             elif l == 0:
-                a = eng.gather_mean(batch.x, d, None, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf, aggr=self.aggr)
+                a = eng.gather_mean(batch.x, d, batch.x_index, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf,
+                                    aggr=self.aggr)
             else:
                 a = eng.gather_mean(h, d, None, u.rowptr, u.rowend, u.col, n_rows, cap, out=abuf, aggr=self.aggr)
             fused = self._plain and (l < L - 1 or self.activation_after_last_conv)

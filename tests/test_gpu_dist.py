@@ -194,7 +194,40 @@ def test_bucketed_feature_pull_all_ranks_in_one_process(world):
         for s in range(world):
             off = sum(rc[s][:r])
             parts.append(rows[s][off: off + rc[s][r]])
-        x = pullers[r].place(torch.cat(parts), sc[r], int(n_valid[r].item()))
+        back = torch.cat(parts)
+        x = pullers[r].place(back, sc[r], int(n_valid[r].item()))
         want = table[(ids[r][: int(n_valid[r].item())].to(torch.int64) & 0xFFFFFFFF)]
         assert torch.equal(x, want)
+        # the copy-free variant: rows stay where they arrived, the first layer reads them through an index
+        pos = pullers[r].place_index(sc[r])
+        assert torch.equal(back[pos[: int(n_valid[r].item())].to(torch.int64)], want)
+    eng.close()
+
+
+def test_forward_over_pulled_rows_through_an_index(graph):
+    """the sharded step hands the first layer the feature rows in ARRIVAL order plus an index (HipBatch.x_index) instead
+    of copying them into node order; per-root outputs equal the resident-table forward, grouped batches included"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE, HipBatch
+    n, rowptr, col = graph
+    rng = np.random.default_rng(9)
+    feats = torch.from_numpy((rng.standard_normal((n, 24)) / 2).astype(np.float32)).to(torch.float16)
+    eng = HipEngine(0)
+    eng.load_csc(rowptr, col)
+    eng.load_features(feats)
+    torch.manual_seed(0)
+    model = GraphSAGE(24, 32, 16, num_layers=2).to(eng.device)
+    roots = torch.from_numpy(rng.integers(0, n, 256).astype(np.int32)).to(eng.device)
+    tree = eng.sample_khop(roots, [6, 4])
+    for group_roots in (None, 64):
+        u = eng.union_build(tree, group_roots=group_roots)
+        want = model(HipBatch(eng, tree, u))[u.root_local[:256].long()]
+        nn = int(u.meta[0])
+        ids = u.nodes[:nn].to(torch.int64) & 0xFFFFFFFF
+        perm = torch.randperm(nn, device=eng.device)
+        back = feats.to(eng.device)[ids[perm]].contiguous()  # row k of `back` = features of local node perm[k]
+        pos = torch.zeros(int(u.nodes.numel()), dtype=torch.int32, device=eng.device)
+        pos[perm] = torch.arange(nn, dtype=torch.int32, device=eng.device)
+        got = model(HipBatch(eng, tree, u, x=back, x_index=pos))[u.root_local[:256].long()]
+        assert torch.equal(got, want)
     eng.close()
