@@ -301,6 +301,51 @@ class UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy(TransductiveNo
         return self.subsample_rn(out, split)
 
 
+class UDLAnchorBasedSupervisionEdgeSplitStrategy:
+    """user-defined labels split by ANCHOR node (lib/split_strategies/UDLAnchorBasedSupervisionEdgeSplitStrategy.scala:
+    28-233): a sample goes, whole, to the split its root node hashes to (NodeToDatasetSplitHashingAssigner); in the
+    splits named by should_filter_{train,val,test} (default all) the neighbourhood loses every edge that is also a
+    pos / neg / hard-neg label edge (and its reverse unless should_filter_reverse_supervision_edge=false) together with
+    the nodes no remaining edge touches; a sample whose neighbourhood has no edge left — or, in train, no positive —
+    is dropped.  Rooted neighbourhoods pass through unmasked."""
+
+    def __init__(self, args: Dict[str, str], assigner: NodeToDatasetSplitHashingAssigner):
+        self.assigner = assigner
+        flag = lambda k, d="true": str(args.get(k, d)).lower() == "true"
+        self.filter_reverse = flag("should_filter_reverse_supervision_edge")
+        self.filter_in = {TRAIN: flag("should_filter_train"), VAL: flag("should_filter_val"),
+                          TEST: flag("should_filter_test")}
+        self.subsample = _Subsampler(args)
+        self.subsample_rn = _Subsampler(args, prefix="random_negative_")
+
+    def _without_label_overlap(self, sample: wire.NodeAnchorBasedLinkPredictionSample):
+        labels = list(sample.pos_edges) + list(sample.neg_edges) + list(sample.hard_neg_edges)
+        unusable = {(e.src_node_id, e.dst_node_id) for e in labels}
+        if self.filter_reverse:
+            unusable |= {(e.dst_node_id, e.src_node_id) for e in labels}
+        edges = [e for e in sample.neighborhood.edges if (e.src_node_id, e.dst_node_id) not in unusable]
+        touched = {v for e in edges for v in (e.src_node_id, e.dst_node_id)}
+        nodes = [n for n in sample.neighborhood.nodes if n.node_id in touched]
+        return wire.NodeAnchorBasedLinkPredictionSample(
+            root_node=sample.root_node, hard_neg_edges=sample.hard_neg_edges, pos_edges=sample.pos_edges,
+            neg_edges=sample.neg_edges, neighborhood=wire.Graph(nodes=nodes, edges=edges))
+
+    def split_training_sample(self, sample: wire.NodeAnchorBasedLinkPredictionSample, split: str):
+        if sample.root_node is None:
+            raise RuntimeError("Root node does not exist for sample.")
+        if sample.neighborhood is None:
+            raise RuntimeError("Neighborhood does not exist in the sample")
+        if self.assigner.assign(sample.root_node) != split:
+            return []
+        usable = self._without_label_overlap(sample) if self.filter_in[split] else sample
+        if not usable.neighborhood.edges or (not usable.pos_edges and split == TRAIN):
+            return []
+        return self.subsample([usable], split)
+
+    def split_rooted_node_neighborhood_training_sample(self, sample: wire.RootedNodeNeighborhood, split: str):
+        return self.subsample_rn([sample], split)
+
+
 _ASSIGNERS = {"NodeToDatasetSplitHashingAssigner": NodeToDatasetSplitHashingAssigner,
               "TransductiveEdgeToLinkSplitHashingAssigner": TransductiveEdgeToLinkSplitHashingAssigner,
               "UserDefinedLabelsEdgeToLinkSplitHashingAssigner": UserDefinedLabelsEdgeToLinkSplitHashingAssigner}
@@ -308,7 +353,8 @@ _STRATEGIES = {"TransductiveSupervisedNodeClassificationSplitStrategy": Transduc
                "InductiveSupervisedNodeClassificationSplitStrategy": InductiveSupervisedNodeClassificationSplitStrategy,
                "TransductiveNodeAnchorBasedLinkPredictionSplitStrategy": TransductiveNodeAnchorBasedLinkPredictionSplitStrategy,
                "UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy":
-                   UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy}
+                   UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy,
+               "UDLAnchorBasedSupervisionEdgeSplitStrategy": UDLAnchorBasedSupervisionEdgeSplitStrategy}
 
 
 def build_strategy(cfg: GbmlConfigPbWrapper):

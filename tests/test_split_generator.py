@@ -209,6 +209,53 @@ def test_user_defined_labels_strategy_and_assigner(golden_dir):
     assert isinstance(build_strategy(cfg), UserDefinedLabelsNodeAnchorBasedLinkPredictionSplitStrategy)
 
 
+def test_udl_anchor_based_supervision_edge_strategy_known_answers():
+    """UDLAnchorBasedSupervisionEdgeSplitStrategyTest.scala:71-151, restated case by case"""
+    from gigl_amd.split_generator import NodeToDatasetSplitHashingAssigner, UDLAnchorBasedSupervisionEdgeSplitStrategy
+    one = np.array([1.0], np.float32)
+
+    def rnn(root, edge_list):
+        ids = []
+        for s_, d_ in edge_list:
+            for v in (s_, d_):
+                if v not in ids:
+                    ids.append(v)
+        return wire.RootedNodeNeighborhood(
+            root_node=wire.Node(node_id=root, feature_values=one),
+            neighborhood=wire.Graph(nodes=[wire.Node(node_id=v, feature_values=one) for v in ids],
+                                    edges=[wire.Edge(src_node_id=a, dst_node_id=b, feature_values=one) for a, b in edge_list]))
+
+    def nalp(root, edge_list, pos, neg):
+        r = rnn(root, edge_list)
+        mk = lambda lst: [wire.Edge(src_node_id=a, dst_node_id=b, feature_values=one) for a, b in lst]
+        return wire.NodeAnchorBasedLinkPredictionSample(root_node=r.root_node, neighborhood=r.neighborhood,
+                                                        pos_edges=mk(pos), neg_edges=mk(neg))
+    strat = UDLAnchorBasedSupervisionEdgeSplitStrategy(
+        {}, NodeToDatasetSplitHashingAssigner({"train_split": "1.0", "val_split": "0.0", "test_split": "0.0"}))
+    # every neighbourhood edge is a label edge or the reverse of one: nothing left for message passing -> dropped
+    assert strat.split_training_sample(nalp(1, [(1, 2), (2, 1), (3, 1)], [(1, 2)], [(1, 3)]), TRAIN) == []
+    # no positive to begin with
+    assert strat.split_training_sample(nalp(1, [(1, 2), (1, 5)], [], [(1, 3)]), TRAIN) == []
+    sample = nalp(1, [(1, 2), (1, 5), (3, 2), (10, 5)], [(1, 2)], [(3, 2)])
+    out = strat.split_training_sample(sample, TRAIN)
+    assert out == [nalp(1, [(1, 5), (10, 5)], [(1, 2)], [(3, 2)])]
+    assert strat.split_training_sample(sample, TEST) == []  # train_split = 1.0: the anchor is a train node
+    r = rnn(1, [(1, 2)])
+    for sp in (TRAIN, TEST):  # rooted neighbourhoods are emitted for every split, unchanged
+        assert strat.split_rooted_node_neighborhood_training_sample(r, sp) == [r]
+    # the filters can be switched off per split, and the reverse direction kept
+    keep = UDLAnchorBasedSupervisionEdgeSplitStrategy(
+        {"should_filter_train": "false"}, NodeToDatasetSplitHashingAssigner({"train_split": "1.0", "val_split": "0.0",
+                                                                            "test_split": "0.0"}))
+    assert keep.split_training_sample(sample, TRAIN) == [sample]
+    fwd_only = UDLAnchorBasedSupervisionEdgeSplitStrategy(
+        {"should_filter_reverse_supervision_edge": "false"},
+        NodeToDatasetSplitHashingAssigner({"train_split": "1.0", "val_split": "0.0", "test_split": "0.0"}))
+    got = fwd_only.split_training_sample(nalp(1, [(1, 2), (2, 1), (3, 1)], [(1, 2)], [(1, 3)]), TRAIN)
+    assert [(e.src_node_id, e.dst_node_id) for e in got[0].neighborhood.edges] == [(2, 1), (3, 1)]
+    assert [n.node_id for n in got[0].neighborhood.nodes] == [1, 2, 3]  # the sample's own node order is kept
+
+
 def test_end_to_end_over_reference_sampler_outputs(golden_dir, tmp_path):
     base = tmp_path / "sg"
     shutil.copytree(os.path.join(golden_dir, "ref_assets"), base / "ref_assets")
