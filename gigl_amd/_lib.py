@@ -181,7 +181,7 @@ def load() -> C.CDLL:
         "gigl_gat_aggregate_edge": [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, i32,
                                     i64, vp, vp, vp, vp],
         "gigl_gat_aggregate_backward": [vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i32,
-                                        i64, vp, vp, vp, vp, vp, vp],
+                                        i64, vp, vp, vp, vp, vp, vp, vp, vp],
         "gigl_rows_dedup": [vp, vp, i64, i32],
         "gigl_edge_ids": [vp, vp, vp, vp, i64, vp],
         "gigl_union_edge_ids": [vp, vp, P(GiglUnion), vp],

@@ -973,11 +973,17 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
     const float* __restrict__ a_edge, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
     const int32_t* __restrict__ col, const int32_t* __restrict__ n_rows_dev, int heads, int C, int group,
     int rows_per_head, float slope, const float* __restrict__ out_pre, const float* __restrict__ dout,
-    float* __restrict__ dh, float* __restrict__ d_src, float* __restrict__ d_dst, float* __restrict__ d_edge) {
+    float* __restrict__ dh, float* __restrict__ d_src, float* __restrict__ d_dst, float* __restrict__ d_edge,
+    const float* __restrict__ edge_attr, int De, const float* __restrict__ umsg, float* __restrict__ zout) {
+  // message term (EdgeAttrGATConv, umsg != NULL): out_i also holds W_msg z_i with z_i = sum_e alpha_e e_e, so
+  // d alpha_e gains <u_i, e_e> with u_i = W_msg^T g_i (umsg [rows][heads][De], dense, from the caller) and the kernel
+  // returns z_i (zout, same shape) for d W_msg = sum_i g_i (x) z_i.  Component k of a head lives in lane k % group of
+  // the head's lanes, register k / group (as in the forward).
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
   const int n_rows = *n_rows_dev, HC = heads * C, chunks = HC >> 2;
+  const int kl = lane & (group - 1);
   int hd[V];
   bool on[V], writer[V];
 #pragma unroll
@@ -1044,6 +1050,28 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
         mx[v] = nm;
       }
     }
+    // message term: this lane's components of u_i per chunk row (first chunk row of a head only: no double count)
+    float ul[V][GAT_ZR], es[GAT_ZR], zl[V][GAT_ZR];
+#pragma unroll
+    for (int r = 0; r < GAT_ZR; ++r) es[r] = 0.f;
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int r = 0; r < GAT_ZR; ++r) {
+        const int k = r * group + kl;
+        const bool mine = umsg && on[v] && k < De && (rows_per_head == 1 || v % rows_per_head == 0);
+        ul[v][r] = mine ? umsg[((int64_t)i * heads + hd[v]) * De + k] : 0.f;
+        zl[v][r] = 0.f;
+      }
+    if (umsg)
+      for (int e = 0; e < m; ++e) {
+        if (col[e0 + e] == i) continue;
+#pragma unroll
+        for (int r = 0; r < GAT_ZR; ++r) {
+          const int k = r * group + kl;
+          if (k < De) es[r] += edge_attr[(int64_t)(e0 + e) * De + k];
+        }
+      }
     float pre_self[V], al_self[V], dpre_self[V], dal[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -1055,6 +1083,13 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
       den[v] = 1.0f / (den[v] + 1e-16f);
       al_self[v] = __expf(z - nm) * den[v];
       dal[v] = dot4(g[v], xi[v]);
+      if (umsg && cnt > 0) {
+#pragma unroll
+        for (int r = 0; r < GAT_ZR; ++r) {
+          dal[v] += ul[v][r] * es[r] / (float)cnt;            // <u_i, mean e>
+          zl[v][r] = al_self[v] * es[r] / (float)cnt;          // the self loop's share of z_i
+        }
+      }
     }
     head_sum(dal);
 #pragma unroll
@@ -1075,11 +1110,22 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
       const int j = col[e0 + e];
       if (j == i) continue;
       float4 x[V];
-      float da[V], pre[V];
+      float da[V], pre[V], ev[GAT_ZR];
+      if (umsg) {
+#pragma unroll
+        for (int r = 0; r < GAT_ZR; ++r) {
+          const int k = r * group + kl;
+          ev[r] = k < De ? edge_attr[(int64_t)(e0 + e) * De + k] : 0.f;
+        }
+      }
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         x[v] = on[v] ? ((const float4*)(h + (int64_t)j * HC))[v * 64 + lane] : float4{0, 0, 0, 0};
         da[v] = dot4(g[v], x[v]);
+        if (umsg) {
+#pragma unroll
+          for (int r = 0; r < GAT_ZR; ++r) da[v] += ul[v][r] * ev[r];
+        }
         pre[v] = a_src[(int64_t)j * heads + hd[v]] + ad[v] + (a_edge ? a_edge[(int64_t)(e0 + e) * heads + hd[v]] : 0.f);
       }
       head_sum(da);
@@ -1089,6 +1135,10 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
         const float al = __expf(z - mx[v]) * den[v];
         const float dpre = al * (da[v] - S[v]) * (pre[v] > 0.f ? 1.f : slope);
         dd[v] += dpre;
+        if (umsg) {
+#pragma unroll
+          for (int r = 0; r < GAT_ZR; ++r) zl[v][r] += al * ev[r];
+        }
         if (on[v]) {
           float* o = dh + (int64_t)j * HC + 4 * (v * 64 + lane);
           atomicAdd(o + 0, al * g[v].x);
@@ -1103,8 +1153,16 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
       }
     }
 #pragma unroll
-    for (int v = 0; v < V; ++v)
+    for (int v = 0; v < V; ++v) {
       if (writer[v]) atomicAdd(d_dst + (int64_t)i * heads + hd[v], dd[v]);
+      if (zout && on[v] && (rows_per_head == 1 || v % rows_per_head == 0)) {
+#pragma unroll
+        for (int r = 0; r < GAT_ZR; ++r) {
+          const int k = r * group + kl;
+          if (k < De) zout[((int64_t)i * heads + hd[v]) * De + k] = zl[v][r];
+        }
+      }
+    }
   }
 }
 
@@ -1540,8 +1598,11 @@ int32_t gigl_gat_aggregate_backward(gigl_ctx* ctx, const float* h, const float* 
                                     int64_t nodes_cap, const int32_t* n_rows_dev, int64_t rows_cap,
                                     const float* out_pre, const float* dout, const float* edge_attr, int32_t edge_dim,
                                     int64_t cap_edges, const float* att_edge_folded, float* alpha_scratch, float* dh,
-                                    float* d_alpha_src, float* d_alpha_dst, float* d_alpha_edge) {
+                                    float* d_alpha_src, float* d_alpha_dst, float* d_alpha_edge,
+                                    const float* u_msg, float* z_out) {
   if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, (u_msg == nullptr) == (z_out == nullptr) && (!u_msg || edge_attr),
+               "u_msg and z_out go together and need edge_attr");
   GIGL_REQUIRE(ctx, h && att_src && att_dst && rowptr && rowend && col && n_nodes_dev && n_rows_dev && out_pre &&
                         dout && alpha_scratch && dh && d_alpha_src && d_alpha_dst, "null argument");
   GIGL_REQUIRE(ctx, heads > 0 && channels > 0 && rows_cap >= 0 && nodes_cap >= rows_cap && cap_edges >= 0, "bad sizes");
@@ -1553,6 +1614,9 @@ int32_t gigl_gat_aggregate_backward(gigl_ctx* ctx, const float* h, const float* 
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED,
                      "GAT backward needs channels %% 4 == 0 and channels/4 a power of two <= 64 (or channels %% 256 == 0), "
                      "heads*channels <= 1024, 16-byte aligned matrices; got heads=%d channels=%d", heads, channels);
+  if (u_msg && (edge_dim > GAT_ZR * g.group || (heads * channels / 4) % 64))
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "message-term backward: edge_dim %d > %d or heads*channels %% 256 != 0",
+                     edge_dim, GAT_ZR * g.group);
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   float* a_src = alpha_scratch;
@@ -1569,7 +1633,8 @@ int32_t gigl_gat_aggregate_backward(gigl_ctx* ctx, const float* h, const float* 
                      att_dst, n_nodes_dev, heads, channels, g.group, g.rows_per_head, a_src, a_dst);                \
   hipLaunchKernelGGL((gat_backward_kernel<VV>), dim3((unsigned)gblocks), dim3(256), 0, ctx->stream, h, a_src, a_dst, \
                      a_edge, rowptr, rowend, col, n_rows_dev, heads, channels, g.group, g.rows_per_head,            \
-                     negative_slope, out_pre, dout, dh, d_alpha_src, d_alpha_dst, d_alpha_edge)
+                     negative_slope, out_pre, dout, dh, d_alpha_src, d_alpha_dst, d_alpha_edge, edge_attr, edge_dim,  \
+                     u_msg, z_out)
   if (g.V == 1) {
     GAT_BWD(1);
   } else if (g.V == 2) {

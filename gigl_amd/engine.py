@@ -657,9 +657,10 @@ class HipEngine:
     def gat_aggregate_backward(self, h: torch.Tensor, att_src: torch.Tensor, att_dst: torch.Tensor, heads: int,
                                channels: int, u, n_rows_dev: torch.Tensor, out_pre: torch.Tensor, dout: torch.Tensor,
                                negative_slope: float = 0.2, edge_attr: Optional[torch.Tensor] = None,
-                               att_edge_folded: Optional[torch.Tensor] = None):
-        """-> (dh [cap, H*C], d_alpha_src [cap, H], d_alpha_dst [cap, H], d_alpha_edge [cap_edges, H] | None): the
-        edge-wise part of the GAT layer's backward (gigl_gat_aggregate_backward); see include/gigl_hip.h"""
+                               att_edge_folded: Optional[torch.Tensor] = None, u_msg: Optional[torch.Tensor] = None):
+        """-> (dh [cap, H*C], d_alpha_src [cap, H], d_alpha_dst [cap, H], d_alpha_edge [cap_edges, H] | None,
+        z [cap, H, De] | None): the edge-wise part of the GAT layer's backward (gigl_gat_aggregate_backward); u_msg
+        [cap, H, De] = W_msg^T dout per head switches the EdgeAttrGATConv message term on; see include/gigl_hip.h"""
         cap, ce = int(u.nodes.numel()), int(u.col.numel())
         hc = heads * channels
         for t in (h, out_pre, dout):
@@ -669,6 +670,10 @@ class HipEngine:
         ds = torch.zeros((cap, heads), dtype=torch.float32, device=dev)
         dd = torch.zeros((cap, heads), dtype=torch.float32, device=dev)
         dae = torch.zeros((ce, heads), dtype=torch.float32, device=dev) if edge_attr is not None else None
+        z = None
+        if u_msg is not None:
+            assert u_msg.is_contiguous() and tuple(u_msg.shape) == (cap, heads, int(edge_attr.shape[1]))
+            z = torch.zeros_like(u_msg)
         scratch = torch.empty(2 * cap * heads + (ce * heads if edge_attr is not None else 0), dtype=torch.float32,
                               device=dev)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
@@ -676,8 +681,8 @@ class HipEngine:
             self._ctx, p(h), p(att_src), p(att_dst), heads, channels, negative_slope, p(u.rowptr), p(u.rowend),
             p(u.col), p(u.meta), cap, p(n_rows_dev), cap, p(out_pre), p(dout), p(edge_attr),
             int(edge_attr.shape[1]) if edge_attr is not None else 0, ce, p(att_edge_folded), p(scratch), p(dh), p(ds),
-            p(dd), p(dae)), self._ctx)
-        return dh, ds, dd, dae
+            p(dd), p(dae), p(u_msg), p(z)), self._ctx)
+        return dh, ds, dd, dae, z
 
     def gather_mean_backward(self, dout: torch.Tensor, d: int, rowptr: torch.Tensor, rowend: Optional[torch.Tensor],
                              col: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int, dsrc: torch.Tensor,

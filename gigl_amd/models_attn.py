@@ -65,29 +65,37 @@ class _GatConvFn(torch.autograd.Function):
     part, dense algebra (attention vectors, projection) through gigl_linear / small torch reductions."""
 
     @staticmethod
-    def forward(ctx, x, w, att_src, att_dst, bias, v_att, eng, view, n_dev, heads, channels, slope, edge_attr):
+    def forward(ctx, x, w, att_src, att_dst, bias, v_att, w_msg, eng, view, n_dev, heads, channels, slope, edge_attr):
         n = int(x.shape[0])
         x = x.contiguous()
         xw = eng.linear(x, w.contiguous(), None, n_dev, n, act=0)
-        kw = {} if edge_attr is None else dict(edge_attr=edge_attr, att_edge_folded=v_att.contiguous())
+        kw = {} if edge_attr is None else dict(edge_attr=edge_attr, att_edge_folded=v_att.contiguous(),
+                                               w_edge_msg=w_msg.contiguous() if w_msg is not None else None)
         out = eng.gat_aggregate(xw, att_src.reshape(-1).contiguous(), att_dst.reshape(-1).contiguous(), heads, channels,
                                 view, n_dev, bias, concat=True, negative_slope=slope, act=0, **kw)
         ctx.eng, ctx.view, ctx.n_dev, ctx.dims, ctx.slope, ctx.edge_attr = eng, view, n_dev, (heads, channels), slope, edge_attr
         ctx.save_for_backward(x, w, xw, att_src, att_dst, bias if bias is not None else x.new_zeros(0), out,
-                              v_att if v_att is not None else x.new_zeros(0))
+                              v_att if v_att is not None else x.new_zeros(0),
+                              w_msg if w_msg is not None else x.new_zeros(0))
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, xw, att_src, att_dst, bias, out, v_att = ctx.saved_tensors
+        x, w, xw, att_src, att_dst, bias, out, v_att, w_msg = ctx.saved_tensors
         eng, view, n_dev, (heads, ch), slope, edge_attr = ctx.eng, ctx.view, ctx.n_dev, ctx.dims, ctx.slope, ctx.edge_attr
         n, hc = int(x.shape[0]), heads * ch
         dy = dy.contiguous()
         out_pre = (out - bias) if bias.numel() else out
-        dh, ds, dd, dae = eng.gat_aggregate_backward(
+        u_msg = None
+        if w_msg.numel():  # EdgeAttrGATConv: u_i = W_msg^T g_i per head
+            u_msg = torch.einsum("nhc,hck->nhk", dy.view(n, heads, ch), w_msg.view(heads, ch, -1)).contiguous()
+        dh, ds, dd, dae, z = eng.gat_aggregate_backward(
             xw, att_src.reshape(-1).contiguous(), att_dst.reshape(-1).contiguous(), heads, ch, view, n_dev,
             out_pre.contiguous(), dy, negative_slope=slope, edge_attr=edge_attr,
-            att_edge_folded=v_att.contiguous() if v_att.numel() else None)
+            att_edge_folded=v_att.contiguous() if v_att.numel() else None, u_msg=u_msg)
+        dw_msg = None
+        if z is not None:
+            dw_msg = torch.einsum("nhc,nhk->hck", dy.view(n, heads, ch), z).reshape(hc, -1)
         xw3 = xw.view(n, heads, ch)
         d_att_src = (ds.unsqueeze(-1) * xw3).sum(0).view_as(att_src)
         d_att_dst = (dd.unsqueeze(-1) * xw3).sum(0).view_as(att_dst)
@@ -99,7 +107,7 @@ class _GatConvFn(torch.autograd.Function):
         dx = eng.linear(dxw, w.t().contiguous(), None, n_dev, n, 0) if ctx.needs_input_grad[0] else None
         db = dy.sum(0) if bias.numel() else None
         dv = dae.t().mm(edge_attr) if dae is not None else None
-        return dx, dw, d_att_src, d_att_dst, db, dv, None, None, None, None, None, None, None
+        return dx, dw, d_att_src, d_att_dst, db, dv, dw_msg, None, None, None, None, None, None, None
 
 
 class GATConv(nn.Module):
@@ -240,13 +248,12 @@ class GAT(nn.Module):
                 with torch.no_grad():
                     h = self._layer(eng, conv, l, h, view, g.n_dev, g.n_dev, n, edge_attr)
                 continue
-            if conv.edge_message_weight() is not None:
-                raise NotImplementedError("training EdgeAttrGATConv's edge messages is not built (inference is)")
             if not conv.concat and conv.heads > 1:
                 raise NotImplementedError("training with heads averaged (concat=False) is not built")
             v_att = conv.folded_att_edge() if edge_attr is not None else None
-            h = _GatConvFn.apply(h, conv.lin.weight, conv.att_src, conv.att_dst, conv.bias, v_att, eng, view, g.n_dev,
-                                 conv.heads, conv.out_channels, conv.negative_slope, edge_attr)
+            w_msg = conv.edge_message_weight() if edge_attr is not None else None
+            h = _GatConvFn.apply(h, conv.lin.weight, conv.att_src, conv.att_dst, conv.bias, v_att, w_msg, eng, view,
+                                 g.n_dev, conv.heads, conv.out_channels, conv.negative_slope, edge_attr)
             if l < self.num_layers - 1 or self.activation_after_last_conv:
                 h = torch.relu(h)
         if self.should_l2_normalize_embedding_layer_output:

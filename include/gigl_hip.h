@@ -492,14 +492,19 @@ int32_t gigl_gat_aggregate_edge(gigl_ctx* ctx, const float* h, const float* att_
  * The caller finishes with dense algebra: dh += d_alpha_src (x) att_src + d_alpha_dst (x) att_dst, d att_src =
  * sum_i d_alpha_src[i] h[i], d att_edge_folded = d_alpha_edge^T edge_attr, and the projection's own backward.
  * Shapes: channels % 4 == 0 with channels/4 a power of two <= 64, or channels % 256 == 0; heads*channels <= 1024
- * (GIGL_E_UNSUPPORTED otherwise).  alpha_scratch as for gigl_gat_aggregate_edge. */
+ * (GIGL_E_UNSUPPORTED otherwise).  alpha_scratch as for gigl_gat_aggregate_edge.
+ * EdgeAttrGATConv's messages (out_i += W_msg sum_e alpha_e e_e): pass u_msg [rows][heads][De] = W_msg^T dout per
+ * head (dense, the caller's) and receive z_out [rows][heads][De] = sum_e alpha_e e_e (self loop: the row's mean
+ * attribute), from which d W_msg = sum_i dout_i (x) z_i; both NULL for plain GATConv.  Needs heads*channels % 256 == 0
+ * and De <= 4 * (lanes per head). */
 int32_t gigl_gat_aggregate_backward(gigl_ctx* ctx, const float* h, const float* att_src, const float* att_dst,
                                     int32_t heads, int32_t channels, float negative_slope, const int32_t* rowptr,
                                     const int32_t* rowend, const int32_t* col, const int32_t* n_nodes_dev,
                                     int64_t nodes_cap, const int32_t* n_rows_dev, int64_t rows_cap,
                                     const float* out_pre, const float* dout, const float* edge_attr, int32_t edge_dim,
                                     int64_t cap_edges, const float* att_edge_folded, float* alpha_scratch, float* dh,
-                                    float* d_alpha_src, float* d_alpha_dst, float* d_alpha_edge);
+                                    float* d_alpha_src, float* d_alpha_dst, float* d_alpha_edge,
+                                    const float* u_msg, float* z_out);
 
 /* backward of gigl_gather_mean w.r.t. a dense local fp32 source (gather_ids == NULL; layers >= 2):
  *   dsrc[i][0:d] += dout[i][d:2d];  dsrc[col[e]][0:d] += dout[i][0:d] / deg_i  for e in row i, i < n_rows.

@@ -108,8 +108,12 @@ def test_gnn_ref_identities():
     assert torch.allclose(out, mean, atol=1e-5)
 
 
-@pytest.mark.parametrize("heads,hid,out,de", [(2, 8, 8, 0), (4, 16, 32, 0), (2, 32, 64, 5), (1, 256, 512, 3)])
-def test_gat_training_gradients_match_torch_autograd(heads, hid, out, de):
+@pytest.mark.parametrize("heads,hid,out,de,conv,share", [
+    (2, 8, 8, 0, "gat", True), (4, 16, 32, 0, "gat", True), (2, 32, 64, 5, "gat", True), (1, 256, 512, 3, "gat", True),
+    # EdgeAttrGATConv: W_msg e_ij in the messages (shared with the attention's lin_edge, or its own lin_edge_message)
+    (4, 64, 256, 5, "edge_attr_gat", True), (4, 64, 256, 5, "edge_attr_gat", False),
+    (1, 512, 256, 70, "edge_attr_gat", False)])
+def test_gat_training_gradients_match_torch_autograd(heads, hid, out, de, conv, share):
     """loss = sum(w * GAT(graph)) over a coalesced batch graph: every parameter's gradient and the input gradient from
     the HIP backward (gigl_gat_aggregate_backward + dense algebra) == torch autograd through the fp32 restatement
     (oracle/gnn_ref.gat_conv); 1e-4 relative like the SAGE gradients"""
@@ -125,7 +129,8 @@ def test_gat_training_gradients_match_torch_autograd(heads, hid, out, de):
     ea = torch.from_numpy(rng.standard_normal((ei.shape[1], de)).astype(np.float32)) if de else None
     eng = HipEngine(0)
     torch.manual_seed(1)
-    model = GAT(d, hid, out, num_layers=2, heads=heads, edge_dim=de or None).to(eng.device).train()
+    model = GAT(d, hid, out, num_layers=2, heads=heads, edge_dim=de or None, conv=conv,
+                share_edge_att_message_weight=share).to(eng.device).train()
     model.engine = eng
     with torch.no_grad():
         for c in model.conv_layers:
@@ -144,6 +149,8 @@ def test_gat_training_gradients_match_torch_autograd(heads, hid, out, de):
         kw = {}
         if de:
             kw = dict(edge_attr=ea, w_edge=ref[p + "lin_edge.weight"], att_edge=ref[p + "att_edge"])
+            if conv == "edge_attr_gat":
+                kw["w_edge_msg"] = ref[p + ("lin_edge.weight" if share else "lin_edge_message.weight")]
         h = gnn_ref.gat_conv(h, ei, ref[p + "lin.weight"], ref[p + "att_src"], ref[p + "att_dst"], ref[p + "bias"],
                              heads if l == 0 else 1, **kw)
         if l == 0:
