@@ -105,11 +105,22 @@ class EmbeddingExporter:
             self._sync_marker = os.urandom(16)
             self._buffer.write(avro_file_header(self._sync_marker))
         blocks, _ = eng.encode_avro_embeddings(id_batch, embedding_batch, embedding_type, self._sync_marker)
-        self._buffer.write(memoryview(blocks.cpu().numpy()))
+        self._buffer.write(memoryview(self._to_host(blocks).numpy()))
         self._num_records_written += int(id_batch.numel())
         self._write_time += time.perf_counter() - start
         if self._min_shard_size_threshold_bytes and self._buffer.tell() >= self._min_shard_size_threshold_bytes:
             self.flush_embeddings()
+
+    def _to_host(self, blocks: torch.Tensor) -> torch.Tensor:
+        """device -> host through a reusable pinned staging buffer (pageable copies run at a fraction of the link)"""
+        n = int(blocks.numel())
+        stage = getattr(self, "_stage", None)
+        if stage is None or stage.numel() < n:
+            self._stage = stage = torch.empty(max(n, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        out = stage[:n]
+        out.copy_(blocks, non_blocking=True)
+        torch.cuda.current_stream(blocks.device).synchronize()
+        return out
 
     def _flush(self):
         filename = (f"shard_{self._num_files_written:08}.avro" if not self._prefix
