@@ -95,6 +95,23 @@ def _res(cfg: GbmlConfigPbWrapper, uri: str) -> str:
     return resolve_uri(uri, cfg.uri_base)
 
 
+_STAGE = {}
+
+
+def _frames_to_host(buf) -> np.ndarray:
+    """finished TFRecord frames, device -> host through a reusable pinned staging buffer (the part-file writer consumes
+    the bytes before the next batch overwrites them)"""
+    import torch
+    n = int(buf.numel())
+    st = _STAGE.get("buf")
+    if st is None or st.numel() < n:
+        _STAGE["buf"] = st = torch.empty(max(n, 1 << 22), dtype=torch.uint8, pin_memory=True)
+    out = st[:n]
+    out.copy_(buf, non_blocking=True)
+    torch.cuda.current_stream(buf.device).synchronize()
+    return out.numpy()
+
+
 class _PartWriter:
     """spark-tfrecord writes part files under the prefix directory (TFRecordIO.scala:53-69, overwrite mode);
     takes already framed records (bytes + record offsets) and rolls to a new part every records_per_file"""
@@ -193,7 +210,7 @@ class SubgraphSampler:
             chunk = ids[i:i + batch_size]
             tree = eng.sample_khop(chunk, cfg.fanouts, sampling_seed=svc.sampling_seed)
             buf, off = eng.encode_records(tree)
-            unl.add(buf.cpu().numpy(), off.cpu().numpy())
+            unl.add(_frames_to_host(buf), off.cpu().numpy())
             sfx, sfx_off = _encode_labels(pm.label_keys, labels, chunk)
             has_label = torch.from_numpy(np.diff(sfx_off) > 0).to(eng.device)
             emit = has_label & (tree.cnt[0] > 0)  # isolated nodes produce no training samples
@@ -201,7 +218,7 @@ class SubgraphSampler:
                 emit = emit & ((torch.cumsum(emit.to(torch.int64), 0) + lab.n_records) <= limit)
             emit = emit.to(torch.uint8)
             buf, off = eng.encode_records(tree, emit=emit, suffix=torch.from_numpy(sfx), suffix_off=torch.from_numpy(sfx_off))
-            lab.add(buf.cpu().numpy(), off.cpu().numpy())
+            lab.add(_frames_to_host(buf), off.cpu().numpy())
         return {"unlabeled": unl.close(), "labeled": lab.close()}
 
     @staticmethod
@@ -253,11 +270,11 @@ class SubgraphSampler:
                                           emit=emit.to(torch.uint8), n_neg_trees=Q,
                                           pos_label_edges="pos" if pos_ud else None,
                                           neg_label_edges="neg" if neg_ud else None)
-            main.add(buf.cpu().numpy(), off.cpu().numpy())
+            main.add(_frames_to_host(buf), off.cpu().numpy())
             if rn:
                 tree = eng.sample_khop(roots, cfg.fanouts, sampling_seed=svc.sampling_seed)
                 buf, off = eng.encode_records(tree)
-                b_h, o_h = buf.cpu().numpy(), off.cpu().numpy()
+                b_h, o_h = _frames_to_host(buf), off.cpu().numpy()
                 for w in rn.values():
                     w.add(b_h, o_h)
         files = {"node_anchor_based_link_prediction": main.close()}
