@@ -25,21 +25,35 @@ __global__ __launch_bounds__(256) void frontier_bucket_kernel(const uint32_t* __
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t v = i < m ? nodes[i] : GIGL_INVALID;
   const uint32_t r = v == GIGL_INVALID ? 0xFFFFFFFFu : v % world;
-  // one atomic per (wave, owner) instead of one per slot: same-address atomics serialise (~13 ns each), and with a
-  // small world every slot of a hop hits one of `world` counters.  Lanes of the same owner are served together:
-  // the leader reserves popcount positions, each lane takes base + its rank among them (slot order is kept).
+  // One global atomic per (workgroup, owner) instead of one per slot: same-address atomics serialise (~13 ns each)
+  // and with a small world every slot of a hop hits one of `world` counters.  Slots take a rank inside the
+  // workgroup from LDS counters, one thread per owner reserves the workgroup's range.  (world > 64: per wave — the
+  // lanes of an owner are served together by their first lane.)
   const int lane = threadIdx.x & 63;
   int32_t p = 0;
-  unsigned long long todo = __ballot(r != 0xFFFFFFFFu);
-  while (todo) {
-    const int lead = __ffsll((long long)todo) - 1;
-    const uint32_t r_lead = __shfl(r, lead, 64);
-    const unsigned long long same = __ballot(r == r_lead);
-    int32_t base = 0;
-    if (lane == lead) base = atomicAdd(&counts[r_lead], (int32_t)__popcll(same));
-    base = __shfl(base, lead, 64);
-    if (r == r_lead) p = base + (int32_t)__popcll(same & ((1ull << lane) - 1ull));
-    todo &= ~same;
+  if (world <= 64) {
+    __shared__ int32_t s_cnt[64], s_base[64];
+    if (threadIdx.x < world) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int32_t rank = 0;
+    if (r != 0xFFFFFFFFu) rank = atomicAdd(&s_cnt[r], 1);
+    __syncthreads();
+    if (threadIdx.x < world && s_cnt[threadIdx.x] > 0)
+      s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (r != 0xFFFFFFFFu) p = s_base[r] + rank;
+  } else {
+    unsigned long long todo = __ballot(r != 0xFFFFFFFFu);
+    while (todo) {
+      const int lead = __ffsll((long long)todo) - 1;
+      const uint32_t r_lead = __shfl(r, lead, 64);
+      const unsigned long long same = __ballot(r == r_lead);
+      int32_t base = 0;
+      if (lane == lead) base = atomicAdd(&counts[r_lead], (int32_t)__popcll(same));
+      base = __shfl(base, lead, 64);
+      if (r == r_lead) p = base + (int32_t)__popcll(same & ((1ull << lane) - 1ull));
+      todo &= ~same;
+    }
   }
   if (r == 0xFFFFFFFFu) return;
   if (p >= cap) {
