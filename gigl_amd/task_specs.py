@@ -43,6 +43,16 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
         self._hid_dim = int(kwargs.get("hid_dim", 16))
         self._num_layers = int(kwargs.get("num_layers", 2))
         self._batch_size = int(kwargs.get("main_sample_batch_size", 16))
+        # the encoder class is pluggable like the link-prediction spec's (gnn_model_class_path); GAT takes num_heads
+        from .base import import_obj
+        self._gnn_model = import_obj(str(kwargs.get("gnn_model_class_path", "gigl_amd.models.GraphSAGE")))
+        self._encoder_kwargs = {}
+        if "num_heads" in kwargs or "heads" in kwargs:
+            self._encoder_kwargs["heads"] = int(kwargs.get("num_heads", kwargs.get("heads")))
+        if kwargs.get("edge_dim") not in (None, "", "None"):
+            self._encoder_kwargs["edge_dim"] = int(kwargs["edge_dim"])
+        if "conv" in kwargs:
+            self._encoder_kwargs["conv"] = str(kwargs["conv"])
         self._is_training = is_training
         self._model: Optional[torch.nn.Module] = None
         self._engine = None
@@ -64,8 +74,12 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
     def init_model(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, state_dict=None) -> torch.nn.Module:
         self._cfg = gbml_config_pb_wrapper
         in_dim = gbml_config_pb_wrapper.preprocessed_metadata.nodes[0].feature_dim
-        model = GraphSAGE(in_dim=max(in_dim, 1), hid_dim=self._hid_dim, out_dim=self._out_dim,
-                          num_layers=self._num_layers)
+        import inspect
+        accepted = inspect.signature(self._gnn_model.__init__).parameters
+        takes_any = any(p.kind == p.VAR_KEYWORD for p in accepted.values())
+        extra = {k: v for k, v in self._encoder_kwargs.items() if k in accepted or takes_any}
+        model = self._gnn_model(in_dim=max(in_dim, 1), hid_dim=self._hid_dim, out_dim=self._out_dim,
+                                num_layers=self._num_layers, **extra)
         if state_dict is not None:
             model.load_state_dict(state_dict)
         self.model = model

@@ -228,6 +228,55 @@ def test_subgraph_sampler_hydrates_edge_features(workdir, golden_dir):
     assert len(lab) == 14 and all(e.feature_values.size == 3 for s_ in lab for e in s_.neighborhood.edges)
 
 
+def test_node_classification_with_gat_encoder(workdir):
+    """gnn_model_class_path swaps the encoder of the node-classification plugin: a 2-head GAT trains through the HIP
+    backward, is saved with PyG GATConv's parameter names, and the inferencer's predictions equal the fp32 restatement"""
+    import yaml
+    from gigl_amd.batches import RootedNodeNeighborhoodBatch, iterate_tfrecord_batches
+    from gigl_amd.inferencer import Inferencer
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    from gigl_amd.trainer import Trainer
+    from oracle import gnn_ref
+    base = "configs/snc_frozen_gbml_config.yaml"
+    SubgraphSampler().run("job", base, None, uri_base=workdir)
+    doc = yaml.safe_load(open(os.path.join(workdir, base)))
+    for sect, key in (("trainerConfig", "trainerArgs"), ("inferencerConfig", "inferencerArgs")):
+        doc[sect][key].update(gnn_model_class_path="gigl_amd.models_attn.GAT", num_heads="2", hid_dim="8", out_dim="4")
+    doc["sharedConfig"]["trainedModelMetadata"].update(trainedModelUri="out/snc_gat/model.pt",
+                                                        evalMetricsUri="out/snc_gat/eval_metrics.json")
+    info = doc["sharedConfig"]["inferenceMetadata"]["nodeTypeToInferencerOutputInfoMap"]["user"]
+    info.update(embeddingsPath="out/snc_gat/embeddings.jsonl", predictionsPath="out/snc_gat/predictions.jsonl")
+    cfg_uri = "configs/snc_gat_gbml_config.yaml"
+    yaml.safe_dump(doc, open(os.path.join(workdir, cfg_uri), "w"))
+    tr = Trainer()
+    tr.run("job", cfg_uri, None, uri_base=workdir)
+    hist = tr.training_process.trainer.history
+    assert all(np.isfinite(h["loss"]) for h in hist) and hist[-1]["loss"] < hist[0]["loss"]
+    cfg = GbmlConfigPbWrapper.from_uri(cfg_uri, uri_base=workdir)
+    sd = torch.load(cfg.trained_model_uri, map_location="cpu")
+    assert {"conv_layers.0.lin.weight", "conv_layers.0.att_src", "conv_layers.0.att_dst", "conv_layers.0.bias",
+            "conv_layers.1.lin.weight"} <= set(sd) and sd["conv_layers.0.lin.weight"].shape[0] == 16
+    out = Inferencer().run("job", cfg_uri, None, uri_base=workdir)
+    rows = [json.loads(l) for l in open(out["embeddings"])]
+    preds = [json.loads(l) for l in open(out["predictions"])]
+    want = {}
+    for raw in iterate_tfrecord_batches(tfrecord_files(cfg.unlabeled_tfrecord_uri_prefix), 8):
+        b = RootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(raw)
+        h = b.graph.x
+        for l in range(2):
+            p = f"conv_layers.{l}."
+            h = gnn_ref.gat_conv(h, b.graph.edge_index, sd[p + "lin.weight"], sd[p + "att_src"], sd[p + "att_dst"],
+                                 sd[p + "bias"], 2 if l == 0 else 1)
+            if l == 0:
+                h = torch.relu(h)
+        for r, i in zip(b.root_nodes, b.condensed_node_type_to_root_node_indices_map[0].tolist()):
+            want[r.id] = h[i].numpy()
+    assert len(rows) == 16
+    for row, p in zip(rows, preds):
+        np.testing.assert_allclose(np.array(row["emb"], np.float32), want[row["node_id"]], rtol=1e-5, atol=1e-5)
+        assert p["pred"] == int(np.argmax(want[row["node_id"]]))
+
+
 def test_sampler_split_generator_trainer_chain(workdir):
     """sampler -> split generator -> trainer: the trainer reads the train/val/test files the split generator wrote
     (datasetMetadata.supervisedNodeClassificationDataset), as the reference's pipeline does"""
