@@ -32,6 +32,57 @@ class GCNConv(nn.Module):
         nn.init.xavier_uniform_(self.lin.weight)  # PyG: glorot weight, zero bias
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = x @ w^T on the exact-fp32 MFMA kernel (gigl_linear), with its two backward GEMMs"""
+
+    @staticmethod
+    def forward(ctx, x, w, eng, n_dev):
+        x = x.contiguous()
+        ctx.eng, ctx.n_dev = eng, n_dev
+        ctx.save_for_backward(x, w)
+        return eng.linear(x, w.contiguous(), None, n_dev, int(x.shape[0]), act=0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        eng, dy = ctx.eng, dy.contiguous()
+        n_out = torch.tensor([dy.shape[1]], dtype=torch.int32, device=dy.device)
+        dw = eng.linear(dy.t().contiguous(), x.t().contiguous(), None, n_out, int(dy.shape[1]), 0)
+        dx = eng.linear(dy, w.t().contiguous(), None, ctx.n_dev, int(x.shape[0]), 0) if ctx.needs_input_grad[0] else None
+        return dx, dw, None, None
+
+
+class _GcnAggFn(torch.autograd.Function):
+    """a = A_hat h over a coalesced batch graph (gigl_gcn_aggregate: self loops removed, one added, symmetric
+    normalisation with deg = 1 + #non-self in-edges).  Backward = A_hat^T: scale the incoming gradient by dinv of
+    the destination, scatter it along the edges (gigl_gather_reduce_backward, sum), swap a stored self-loop edge for
+    the added one, scale by dinv of the source."""
+
+    @staticmethod
+    def forward(ctx, h, eng, g, view):
+        n = int(h.shape[0])
+        ctx.eng, ctx.g = eng, g
+        return eng.gcn_aggregate(h.contiguous(), int(h.shape[1]), None, view, g.n_dev, None, 0)[:n]
+
+    @staticmethod
+    def backward(ctx, da):
+        eng, g = ctx.eng, ctx.g
+        n, d = int(da.shape[0]), int(da.shape[1])
+        dev = da.device
+        rowlen = (g.rowptr[1:] - g.rowptr[:-1]).to(torch.int64)
+        dst_of = torch.repeat_interleave(torch.arange(n, device=dev), rowlen)
+        e = int(dst_of.numel())
+        self_edges = torch.bincount(dst_of[g.col[:e].to(torch.int64) == dst_of], minlength=n) if e else rowlen * 0
+        dinv = (1.0 + (rowlen - self_edges).to(torch.float32)).rsqrt()
+        gs = (da * dinv[:, None]).contiguous()
+        acc = torch.zeros((n, d), dtype=torch.float32, device=dev)
+        # the kernel is the backward of the [reduce | self] operand of the SAGE layer: the self half gets zeros here
+        eng.gather_mean_backward(torch.cat([gs, torch.zeros_like(gs)], dim=1).contiguous(), d, g.rowptr, None, g.col,
+                                 g.n_dev, n, acc, aggr="sum")
+        acc += gs * (1.0 - self_edges.to(torch.float32))[:, None]
+        return acc * dinv[:, None], None, None, None
+
+
 class TwoLayerGCN(nn.Module):
     def __init__(self, in_dim: int, out_dim: int, hid_dim: int = 16, is_training: bool = True,
                  should_l2_normalize_output: bool = False, **kwargs):
@@ -41,9 +92,33 @@ class TwoLayerGCN(nn.Module):
         self.conv1 = GCNConv(in_dim, hid_dim, bias=bool(kwargs.get("bias", True)))
         self.conv2 = GCNConv(hid_dim, out_dim, bias=bool(kwargs.get("bias", True)))
 
-    @torch.no_grad()
-    def forward(self, batch: HipBatch) -> torch.Tensor:
-        """[cap, out_dim]; rows [0, n_level0) = distinct roots (index with batch.root_local)"""
+    def forward(self, batch, engine=None) -> torch.Tensor:
+        """HipBatch  -> [cap, out_dim]; rows [0, n_level0) = distinct roots (index with batch.root_local)
+        GraphData -> [n, out_dim] over the whole coalesced batch graph, autograd-capable (the reference's default
+                     node-classification model trains through this): conv1 -> relu -> dropout(p=0.5,
+                     training=is_training) -> conv2 (homogeneous.py:488-546)"""
+        from .nn import GraphData
+        if isinstance(batch, GraphData):
+            return self._forward_graph(batch, engine or getattr(self, "engine", None))
+        with torch.no_grad():
+            return self._forward_union(batch)
+
+    def _forward_graph(self, g, eng) -> torch.Tensor:
+        if eng is None:
+            raise RuntimeError("TwoLayerGCN.forward(GraphData) needs the HipEngine (model.engine = eng)")
+        view = _CsrView(g)
+        h = g.x.contiguous()
+        for k, conv in enumerate((self.conv1, self.conv2)):
+            h = _GcnAggFn.apply(_LinearFn.apply(h, conv.lin.weight, eng, g.n_dev), eng, g, view)
+            if conv.bias is not None:
+                h = h + conv.bias
+            if k == 0:
+                h = torch.nn.functional.dropout(torch.relu(h), p=0.5, training=self.is_training)
+        if self.should_normalize:
+            h = torch.nn.functional.normalize(h, p=2, dim=1)
+        return h
+
+    def _forward_union(self, batch: HipBatch) -> torch.Tensor:
         eng, u = batch.engine, batch.union
         assert u.hops == 2, "TwoLayerGCN needs 2-hop samples"
         cap = int(u.nodes.numel())

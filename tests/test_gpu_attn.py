@@ -202,3 +202,41 @@ def test_gat_hub_rows_are_split_over_a_workgroup(heads, hid, de):
             h = torch.relu(h)
     np.testing.assert_allclose(got, h.numpy(), rtol=1e-5, atol=1e-5)
     eng.close()
+
+
+def test_two_layer_gcn_trains_over_a_batch_graph():
+    """TwoLayerGCN (the reference's default node-classification model) over a coalesced batch graph with autograd:
+    outputs, parameter gradients and the input gradient == torch autograd through the restated GCNConv formula"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models_attn import TwoLayerGCN
+    from gigl_amd.nn import GraphData
+    rng = np.random.default_rng(4)
+    n, d = 400, 9
+    ei = torch.from_numpy(np.unique(rng.integers(0, n, (2, 3000)), axis=1))
+    ei = ei[:, np.lexsort((ei[1].numpy(), ei[0].numpy()))]
+    assert bool((ei[0] == ei[1]).any())
+    x = torch.from_numpy((rng.standard_normal((n, d)) / 2).astype(np.float32))
+    eng = HipEngine(0)
+    torch.manual_seed(3)
+    model = TwoLayerGCN(d, 5, hid_dim=12, is_training=False).to(eng.device).train()
+    model.engine = eng
+    with torch.no_grad():
+        model.conv1.bias.normal_(0, 0.1)
+        model.conv2.bias.normal_(0, 0.1)
+    g = GraphData(x=x.clone(), edge_index=ei).to(eng.device)
+    g.x.requires_grad_(True)
+    wsum = torch.from_numpy(rng.standard_normal((n, 5)).astype(np.float32))
+    y = model(g)
+    (y * wsum.to(eng.device)).sum().backward()
+    ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    h = torch.relu(gnn_ref.gcn_conv(xr, ei, ref["conv1.lin.weight"], ref["conv1.bias"]))
+    h = gnn_ref.gcn_conv(h, ei, ref["conv2.lin.weight"], ref["conv2.bias"])
+    np.testing.assert_allclose(y.detach().cpu().numpy(), h.detach().numpy(), rtol=1e-5, atol=1e-5)
+    (h * wsum).sum().backward()
+    for name, prm in model.named_parameters():
+        want = ref[name].grad
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4 * float(want.abs().max()),
+                                   err_msg=name)
+    np.testing.assert_allclose(g.x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-4 * float(xr.grad.abs().max()))
+    eng.close()

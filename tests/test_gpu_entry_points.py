@@ -277,6 +277,38 @@ def test_node_classification_with_gat_encoder(workdir):
         assert p["pred"] == int(np.argmax(want[row["node_id"]]))
 
 
+def test_node_classification_with_the_stock_two_layer_gcn(workdir):
+    """the reference's default node-classification model (TwoLayerGCN) behind the same plugin: trains through the HIP
+    kernels (GCN aggregation forward + its transpose backward, MFMA projections) and serves the inferencer"""
+    import yaml
+    from gigl_amd.inferencer import Inferencer
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    from gigl_amd.trainer import Trainer
+    base = "configs/snc_frozen_gbml_config.yaml"
+    SubgraphSampler().run("job", base, None, uri_base=workdir)
+    doc = yaml.safe_load(open(os.path.join(workdir, base)))
+    for sect, key in (("trainerConfig", "trainerArgs"), ("inferencerConfig", "inferencerArgs")):
+        doc[sect][key].update(gnn_model_class_path="gigl_amd.models_attn.TwoLayerGCN", hid_dim="8", out_dim="3")
+    doc["trainerConfig"]["trainerArgs"]["num_epochs"] = "6"
+    doc["sharedConfig"]["trainedModelMetadata"].update(trainedModelUri="out/snc_gcn/model.pt",
+                                                        evalMetricsUri="out/snc_gcn/eval_metrics.json")
+    info = doc["sharedConfig"]["inferenceMetadata"]["nodeTypeToInferencerOutputInfoMap"]["user"]
+    info.update(embeddingsPath="out/snc_gcn/embeddings.jsonl", predictionsPath="out/snc_gcn/predictions.jsonl")
+    cfg_uri = "configs/snc_gcn_gbml_config.yaml"
+    yaml.safe_dump(doc, open(os.path.join(workdir, cfg_uri), "w"))
+    tr = Trainer()
+    metrics = tr.run("job", cfg_uri, None, uri_base=workdir)
+    hist = tr.training_process.trainer.history
+    assert len(hist) == 6 and all(np.isfinite(h["loss"]) for h in hist) and min(h["loss"] for h in hist[1:]) < hist[0]["loss"]
+    assert 0.0 <= metrics.metrics["acc"].value <= 1.0
+    cfg = GbmlConfigPbWrapper.from_uri(cfg_uri, uri_base=workdir)
+    sd = torch.load(cfg.trained_model_uri, map_location="cpu")
+    assert set(sd) == {"conv1.lin.weight", "conv1.bias", "conv2.lin.weight", "conv2.bias"}  # PyG GCNConv's names
+    inf = Inferencer()
+    inf.run("job", cfg_uri, None, uri_base=workdir)
+    assert inf.rows_written == 16
+
+
 def test_sampler_split_generator_trainer_chain(workdir):
     """sampler -> split generator -> trainer: the trainer reads the train/val/test files the split generator wrote
     (datasetMetadata.supervisedNodeClassificationDataset), as the reference's pipeline does"""
