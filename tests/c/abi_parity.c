@@ -107,6 +107,50 @@ int main(void) {
   for (int64_t i = 0; i < b; ++i) sampled += o_cnt[0][i];
   for (int64_t i = 0; i < s0; ++i) sampled += o_cnt[1][i];
 
+  /* edge hydration keys (gigl_edge_ids): every sampled hop-1 edge resolves to its position in the resident CSC */
+  const int64_t extra_words = s0 + 2 * s0;
+  float* zeros2 = calloc(extra_words, 4);
+  gigl_feat* buf2 = NULL;
+  CHECK(gigl_features_load(ctx, extra_words, 1, GIGL_DTYPE_F32, zeros2, GIGL_LOC_HOST, &buf2), 15);
+  const void* base2 = NULL;
+  CHECK(gigl_features_device_ptr(buf2, &base2, NULL, NULL, NULL), 15);
+  uint32_t* d_dst = (uint32_t*)base2;
+  int64_t* d_eid = (int64_t*)((uint32_t*)base2 + s0);
+  uint32_t* h_dst = malloc(s0 * 4);
+  for (int64_t i = 0; i < s0; ++i) h_dst[i] = roots[i / fanouts[0]];
+  CHECK(gigl_memcpy(ctx, d_dst, GIGL_LOC_DEVICE, h_dst, GIGL_LOC_HOST, s0 * 4), 16);
+  CHECK(gigl_edge_ids(ctx, g, tree.nbr[0], d_dst, s0, d_eid), 17);
+  int64_t* h_eid = malloc(s0 * 8);
+  CHECK(gigl_memcpy(ctx, h_eid, GIGL_LOC_HOST, d_eid, GIGL_LOC_DEVICE, s0 * 8), 18);
+  for (int64_t i = 0; i < s0; ++i) {
+    if (h_nbr0[i] == GIGL_INVALID) {
+      if (h_eid[i] != -1) return 19;
+      continue;
+    }
+    const int64_t p = h_eid[i];
+    if (p < rowptr[h_dst[i]] || p >= rowptr[h_dst[i] + 1] || col[p] != h_nbr0[i]) return 20;
+  }
+  /* SamplingOp-DAG frontier union (gigl_rows_dedup): hop-2 slots of a root as one row */
+  const int32_t width = fanouts[0] * fanouts[1];
+  CHECK(gigl_rows_dedup(ctx, tree.nbr[1], b, width), 21);
+  uint32_t* h_dd = malloc(s1 * 4);
+  CHECK(gigl_memcpy(ctx, h_dd, GIGL_LOC_HOST, tree.nbr[1], GIGL_LOC_DEVICE, s1 * 4), 22);
+  for (int64_t r = 0; r < b; ++r)
+    for (int32_t q = 0; q < width; ++q) {
+      const uint32_t before = h_nbr1[r * width + q], after = h_dd[r * width + q];
+      int first = 1;
+      for (int32_t t = 0; t < q; ++t)
+        if (h_nbr1[r * width + t] == before) first = 0;
+      if (after != (before != GIGL_INVALID && first ? before : GIGL_INVALID)) return 23;
+    }
+  /* Avro layout is host arithmetic: 128 floats + "user" -> 16 kB blocks of 30 records */
+  int32_t per_block = 0;
+  int64_t n_blocks = 0, avro_bytes = 0;
+  CHECK(gigl_avro_embeddings_layout(1000, 128, 4, &per_block, &n_blocks, &avro_bytes), 24);
+  if (per_block < 1 || n_blocks != (1000 + per_block - 1) / per_block || avro_bytes < 1000 * (128 * 4 + 8)) return 25;
+  if (gigl_avro_embeddings_layout(10, 4, 100000, &per_block, &n_blocks, &avro_bytes) != GIGL_E_INVALID_ARG) return 26;
+  gigl_features_destroy(buf2);
+
   /* error behaviour of the boundary */
   int32_t bad_fan[2] = {65, 1};
   if (gigl_sample_khop(ctx, g, d_roots, b, bad_fan, 2, 42, 0, &tree) != GIGL_E_UNSUPPORTED) return 12;
