@@ -33,8 +33,17 @@ from gigl_amd import wire  # noqa: E402
 recs = list(wire.iter_tfrecords(buf[: int(off[8])].cpu().numpy().tobytes()))  # CRCs verified by the reader
 slots = sum(fan[0] * (fan[1] if k else 1) for k in range(2)) + 1
 torch.cuda.synchronize()
+from gigl_amd.subgraph_sampler import _frames_to_host  # noqa: E402
+
+
+def to_host():
+    b, o = eng.encode_records(eng.sample_khop(roots, fan, out=tree))
+    return _frames_to_host(b), o.cpu()
+
+
 for label, fn in (("sample+encode", lambda: eng.encode_records(eng.sample_khop(roots, fan, out=tree))),
-                  ("encode", lambda: eng.encode_records(tree))):
+                  ("encode", lambda: eng.encode_records(tree)),
+                  ("sample+encode+PCIe", to_host)):
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
