@@ -799,7 +799,8 @@ __global__ __launch_bounds__(256) void gat_alpha_fast_kernel(const float* __rest
 // k % group of the head's group, register k / group; at most GAT_ZR registers), the self loop adds alpha_self * mean e;
 // the final product reads the TRANSPOSED weight wt[k][H*C] so that a k-row is one coalesced float4 per lane.
 constexpr int GAT_ZR = 4;
-constexpr int GAT_HEAVY_MIN = 128;  // in-edges from which a row is split over the 8 waves of a workgroup
+constexpr int GAT_HEAVY_MIN = 128;   // in-edges from which a row is split over the waves of a workgroup
+constexpr int GAT_HEAVY_WAVES = 16;  // waves (of a 1024-thread workgroup) sharing one hub row
 template <int V, bool MSG>
 __global__ __launch_bounds__(256) void gat_gather_fast_kernel(
     const float* __restrict__ h, const float* __restrict__ a_src, const float* __restrict__ a_dst,
@@ -1167,18 +1168,18 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
 }
 
 // Rows with many in-edges (a hub sampled by many parents keeps one edge set per parent: thousands of edges in one
-// row) would serialise on one wave: here the 8 waves of a workgroup take contiguous slices of the row, each builds its
+// row) would serialise on one wave: here the 16 waves of a workgroup take contiguous slices of the row, each builds its
 // online-softmax state (max, denominator, weighted sum), and wave 0 merges the states — they combine like the edges
 // themselves: rescale both to the common max — then folds in the self loop and writes the row.
 template <int V>
-__global__ __launch_bounds__(512) void gat_gather_heavy_kernel(
+__global__ __launch_bounds__(1024) void gat_gather_heavy_kernel(
     const float* __restrict__ h, const float* __restrict__ a_src, const float* __restrict__ a_dst,
     const float* __restrict__ a_edge, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
     const int32_t* __restrict__ col, const int32_t* __restrict__ heavy_count, const int32_t* __restrict__ heavy_list,
     int heads, int C, int group, int rows_per_head, float slope, const float* __restrict__ bias, int act,
     float* __restrict__ out) {
-  extern __shared__ float s_part[];  // [8 waves][V][7][64]: acc.x .y .z .w, max, denominator, sum of a_edge
-  __shared__ int s_cnt[8];
+  extern __shared__ float s_part[];  // [GAT_HEAVY_WAVES][V][7][64]: acc.x .y .z .w, max, denominator, sum of a_edge
+  __shared__ int s_cnt[GAT_HEAVY_WAVES];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int HC = heads * C, chunks = HC >> 2;
   int hd[V];
@@ -1192,7 +1193,7 @@ __global__ __launch_bounds__(512) void gat_gather_heavy_kernel(
   for (int idx = blockIdx.x; idx < n_heavy; idx += gridDim.x) {
     const int i = heavy_list[idx];
     const int e0 = rowptr[i], m = rowend[i] - e0;
-    const int per = (((m + 7) >> 3) + 3) & ~3;
+    const int per = (((m + GAT_HEAVY_WAVES - 1) / GAT_HEAVY_WAVES) + 3) & ~3;
     const int lo = min(w * per, m), hi = min(lo + per, m);
     float ad[V], mx[V], den[V], sum_ae[V];
     float4 acc[V];
@@ -1265,7 +1266,7 @@ __global__ __launch_bounds__(512) void gat_gather_heavy_kernel(
     }
     __syncthreads();
     if (w == 0) {
-      for (int pw_ = 1; pw_ < 8; ++pw_) {
+      for (int pw_ = 1; pw_ < GAT_HEAVY_WAVES; ++pw_) {
         cnt += s_cnt[pw_];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -1365,11 +1366,11 @@ static bool launch_gat_fast(gigl_ctx* ctx, const float* h, const float* att_src,
     hipLaunchKernelGGL((gat_gather_fast_kernel<VV, false>), dim3((unsigned)gblocks), dim3(256), 0, ctx->stream, h,   \
                        a_src, a_dst, a_edge, rowptr, rowend, col, n_rows_dev, heads, C, g.group, g.rows_per_head,    \
                        slope, bias, act, edge_attr, De, wt, out, heavy_count, heavy_list);                           \
-    const size_t lds = (size_t)8 * VV * 7 * 64 * 4;                                                                  \
+    const size_t lds = (size_t)GAT_HEAVY_WAVES * VV * 7 * 64 * 4;                                                                  \
     if (lds > 48 * 1024)                                                                                             \
       hipFuncSetAttribute((const void*)gat_gather_heavy_kernel<VV>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                           (int)lds);                                                                                 \
-    hipLaunchKernelGGL((gat_gather_heavy_kernel<VV>), dim3(1024), dim3(512), lds, ctx->stream, h, a_src, a_dst,      \
+    hipLaunchKernelGGL((gat_gather_heavy_kernel<VV>), dim3(1024), dim3(1024), lds, ctx->stream, h, a_src, a_dst,      \
                        a_edge, rowptr, rowend, col, heavy_count, heavy_list, heads, C, g.group, g.rows_per_head,     \
                        slope, bias, act, out);                                                                       \
   }
