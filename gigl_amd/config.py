@@ -193,7 +193,7 @@ class GbmlConfigPbWrapper:
 
     @property
     def permutation_strategy(self) -> str:
-        # this library only implements the reproducible strategy (SamplingStrategy.scala:16-82)
+        # "deterministic" = the reproducible hash permutation (SamplingStrategy.scala:16-82); other values = F.shuffle
         return self.experimental_flags.get("permutation_strategy", "deterministic")
 
     # ---- data locations (flattened_graph_metadata.proto:6-39)

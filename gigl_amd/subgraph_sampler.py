@@ -179,12 +179,20 @@ class SubgraphSampler:
             additional_spark35_jar_file_uris: Sequence[str] = (), *, uri_base: Optional[str] = None,
             device: int = 0, batch_size: int = 4096) -> Dict[str, List[str]]:
         cfg = GbmlConfigPbWrapper.from_uri(task_config_uri, uri_base=uri_base)
+        if str(cfg.experimental_flags.get("sample_with_replacement", "false")).lower() == "true":
+            raise NotImplementedError("experimental_flags.sample_with_replacement (the unseeded with-replacement UDF, "
+                                      "SGSPureSparkV1Task.scala:42-50,355-364) is not implemented")
+        # permutation_strategy: "deterministic" = the hash permutation with samplingSeed 42 (SamplingStrategy.scala:16-82,
+        # reproducible, the parity mode).  Anything else is the reference's F.shuffle (:84-101): a uniformly random
+        # permutation with no seed and no parity definition — served by the same kernel under a fresh random seed per
+        # job (a different uniform sample every run; seeds < 2^20 keep every hash window inside the range table).
+        seed = 42
         if cfg.permutation_strategy != "deterministic":
-            raise NotImplementedError("only experimental_flags.permutation_strategy=deterministic is implemented "
-                                      "(SamplingStrategy.scala:16-82); the non-deterministic F.shuffle has no parity")
+            seed = 1 + int.from_bytes(os.urandom(3), "little") % ((1 << 20) - 1)
+        self.sampling_seed = seed
         n, src, dst, x, labels, node_ids = load_preprocessed_graph(cfg)
         ids = np.asarray(node_ids, dtype=np.uint32)
-        with HipKHopSamplerService(n, src, dst, x, cfg.is_graph_directed, device=device) as svc:
+        with HipKHopSamplerService(n, src, dst, x, cfg.is_graph_directed, device=device, sampling_seed=seed) as svc:
             if getattr(cfg, "edge_features", None) is not None:  # hydrateEdges: records carry Edge.feature_values
                 svc.engine.load_edge_features(src, dst, cfg.edge_features, cfg.is_graph_directed)
             if cfg.task_kind == "node_classification":
