@@ -31,6 +31,11 @@ ASSETS = [
     "subgraph_sampler/node_anchor_based_link_prediction/edge_data/data.tfrecord",
     "subgraph_sampler/node_anchor_based_link_prediction/user_defined_pos/data.tfrecord",
     "subgraph_sampler/node_anchor_based_link_prediction/user_defined_neg/data.tfrecord",
+    # the heterogeneous fixture of the Spark-3.5 graph-DB sampler (two node types, two edge types, tf.Example tables)
+    "subgraph_sampler/heterogeneous/node_anchor_based_link_prediction/node_features_dir/user/features/data.tfrecord",
+    "subgraph_sampler/heterogeneous/node_anchor_based_link_prediction/node_features_dir/story/features/data.tfrecord",
+    "subgraph_sampler/heterogeneous/node_anchor_based_link_prediction/edge_features_dir/user-to-story/main_edges/features/data.tfrecord",
+    "subgraph_sampler/heterogeneous/node_anchor_based_link_prediction/edge_features_dir/story-to-user/main_edges/features/data.tfrecord",
     "split_generator/supervised_node_classification/sgs_output/unlabeled/samples/data.tfrecord",
     "split_generator/supervised_node_classification/sgs_output/labeled/samples/data.tfrecord",
     "split_generator/node_anchor_based_link_prediction/sgs_output/random_negative_rooted_neighborhood_samples/user/data.tfrecord",

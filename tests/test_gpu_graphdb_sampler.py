@@ -119,3 +119,55 @@ def test_rows_dedup_kernel(world):
     from gigl_amd import _lib
     with pytest.raises(_lib.GiglError):
         eng.rows_dedup(torch.zeros((2, 9000), dtype=torch.int32, device=eng.device))
+
+
+def test_reference_heterogeneous_fixture(golden_dir):
+    """the reference's own heterogeneous sampler fixture (scala/common/src/test/assets/subgraph_sampler/heterogeneous/
+    node_anchor_based_link_prediction: users / stories named author / paper in its graph metadata, edge types
+    author_to_paper = 0 and paper_to_author = 1, tf.Example tables with f0, f1) read by the native ingest and sampled
+    with a two-hop op DAG per root type: identical to the per-root restatement, hydrated with the typed features"""
+    import os
+    from gigl_amd.ingest import COL_F32, COL_I64, read_columns
+    base = os.path.join(golden_dir, "ref_assets/subgraph_sampler/heterogeneous/node_anchor_based_link_prediction")
+
+    def table(rel, cols):
+        data, _ = read_columns([os.path.join(base, rel, "data.tfrecord")], cols)
+        return data
+    nodes = {"author": table("node_features_dir/user/features", [("node_id", COL_I64, 1), ("f0", COL_F32, 1), ("f1", COL_F32, 1)]),
+             "paper": table("node_features_dir/story/features", [("node_id", COL_I64, 1), ("f0", COL_F32, 1), ("f1", COL_F32, 1)])}
+    a2p, p2a = EdgeType("author", "author_to_paper", "paper"), EdgeType("paper", "paper_to_author", "author")
+    et_tables = {a2p: table("edge_features_dir/user-to-story/main_edges/features", [("src", COL_I64, 1), ("dst", COL_I64, 1)]),
+                 p2a: table("edge_features_dir/story-to-user/main_edges/features", [("src", COL_I64, 1), ("dst", COL_I64, 1)])}
+    n = {t: int(d["node_id"].max()) + 1 for t, d in nodes.items()}
+    assert n == {"author": 15, "paper": 19}
+    feats = {}
+    for t, d in nodes.items():
+        x = np.zeros((n[t], 2), np.float32)
+        x[d["node_id"][:, 0]] = np.concatenate([d["f0"], d["f1"]], axis=1)
+        feats[t] = x
+    edges = {et: (d["src"][:, 0].astype(np.uint32), d["dst"][:, 0].astype(np.uint32)) for et, d in et_tables.items()}
+    for et, (s_, d_) in edges.items():  # ids stay inside their own type's id space
+        assert s_.max() < n[et.src_node_type] and d_.max() < n[et.dst_node_type]
+    types, cet = {"author": 0, "paper": 1}, {a2p: 0, p2a: 1}
+    s = HipGraphDBSampler(types, n, edges, cet, feats)
+    nbrs = dag_sampler.neighbour_lists(edges)
+    plans = {"paper": [SamplingOp("h1", a2p, 3, [], INCOMING), SamplingOp("h2", p2a, 3, ["h1"], INCOMING)],
+             "author": [SamplingOp("h1", p2a, 3, [], INCOMING), SamplingOp("h2", a2p, 3, ["h1"], INCOMING),
+                        SamplingOp("out", a2p, 2, [], OUTGOING)]}
+    total_edges = 0
+    for root_type, ops in plans.items():
+        roots = np.arange(n[root_type])
+        msgs = s.getKHopSubgraphForRootNodes(roots, root_type, SamplingOpDAG.from_ops(ops))
+        by_cnt = {c: t for t, c in types.items()}
+        for r, m in zip(roots, msgs):
+            want_e, want_n = dag_sampler.sample_for_root(int(r), ops, nbrs, types, cet, root_type)
+            assert {(e.src_node_id, e.dst_node_id, e.condensed_edge_type) for e in m.neighborhood.edges} == want_e
+            assert {(x.node_id, x.condensed_node_type) for x in m.neighborhood.nodes} == want_n
+            for x in m.neighborhood.nodes:
+                np.testing.assert_array_equal(x.feature_values, feats[by_cnt[x.condensed_node_type]][x.node_id])
+            for e in m.neighborhood.edges:  # every sampled edge is an edge of its type's table
+                src, dst = edges[a2p if e.condensed_edge_type == 0 else p2a]
+                assert bool(((src == e.src_node_id) & (dst == e.dst_node_id)).any())
+            total_edges += len(want_e)
+    assert total_edges > 100
+    s.close()
