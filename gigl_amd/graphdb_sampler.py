@@ -102,12 +102,21 @@ class HipGraphDBSampler:
 
     def __init__(self, node_types: Dict[str, int], num_nodes: Dict[str, int],
                  edges: Dict[EdgeType, Tuple[np.ndarray, np.ndarray]], condensed_edge_types: Dict[EdgeType, int],
-                 features: Optional[Dict[str, np.ndarray]] = None, device: int = 0, sampling_seed: int = 42):
+                 features: Optional[Dict[str, np.ndarray]] = None, device: int = 0, sampling_seed: int = 42,
+                 edge_features: Optional[Dict[EdgeType, np.ndarray]] = None):
         from .engine import HipEngine
         self.node_types, self.num_nodes, self.condensed_edge_types = node_types, num_nodes, condensed_edge_types
         self.features = features or {}
         self.sampling_seed = sampling_seed
         self.engine = HipEngine(device)
+        # Edge.feature_values of the typed messages (hydrated on the host with the message assembly): row i of
+        # edge_features[et] belongs to edge i of edges[et]; several rows for one (src, dst): the first wins
+        self._edge_rows: Dict[Tuple[int, int, int], np.ndarray] = {}
+        for et, rows in (edge_features or {}).items():
+            c = condensed_edge_types[et]
+            for s_, d_, row in zip(np.asarray(edges[et][0]).tolist(), np.asarray(edges[et][1]).tolist(),
+                                   np.asarray(rows, dtype=np.float32)):
+                self._edge_rows.setdefault((int(s_), int(d_), c), row)
         n_all = max(num_nodes.values())
         for et, (src, dst) in edges.items():
             src, dst = np.asarray(src), np.asarray(dst)
@@ -189,5 +198,6 @@ class HipGraphDBSampler:
         return wire.RootedNodeNeighborhood(
             root_node=node(root, self.node_types[root_type]),
             neighborhood=wire.Graph(nodes=[node(v, c) for v, c in nodes],
-                                    edges=[wire.Edge(src_node_id=s, dst_node_id=d, condensed_edge_type=c)
+                                    edges=[wire.Edge(src_node_id=s, dst_node_id=d, condensed_edge_type=c,
+                                                     feature_values=self._edge_rows.get((s, d, c), wire._EMPTY_F32))
                                            for s, d, c in edges]))

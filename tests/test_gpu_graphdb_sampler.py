@@ -136,8 +136,9 @@ def test_reference_heterogeneous_fixture(golden_dir):
     nodes = {"author": table("node_features_dir/user/features", [("node_id", COL_I64, 1), ("f0", COL_F32, 1), ("f1", COL_F32, 1)]),
              "paper": table("node_features_dir/story/features", [("node_id", COL_I64, 1), ("f0", COL_F32, 1), ("f1", COL_F32, 1)])}
     a2p, p2a = EdgeType("author", "author_to_paper", "paper"), EdgeType("paper", "paper_to_author", "author")
-    et_tables = {a2p: table("edge_features_dir/user-to-story/main_edges/features", [("src", COL_I64, 1), ("dst", COL_I64, 1)]),
-                 p2a: table("edge_features_dir/story-to-user/main_edges/features", [("src", COL_I64, 1), ("dst", COL_I64, 1)])}
+    ecols = [("src", COL_I64, 1), ("dst", COL_I64, 1), ("f0", COL_F32, 1), ("f1", COL_F32, 1)]
+    et_tables = {a2p: table("edge_features_dir/user-to-story/main_edges/features", ecols),
+                 p2a: table("edge_features_dir/story-to-user/main_edges/features", ecols)}
     n = {t: int(d["node_id"].max()) + 1 for t, d in nodes.items()}
     assert n == {"author": 15, "paper": 19}
     feats = {}
@@ -149,7 +150,8 @@ def test_reference_heterogeneous_fixture(golden_dir):
     for et, (s_, d_) in edges.items():  # ids stay inside their own type's id space
         assert s_.max() < n[et.src_node_type] and d_.max() < n[et.dst_node_type]
     types, cet = {"author": 0, "paper": 1}, {a2p: 0, p2a: 1}
-    s = HipGraphDBSampler(types, n, edges, cet, feats)
+    efeats = {et: np.concatenate([d["f0"], d["f1"]], axis=1) for et, d in et_tables.items()}
+    s = HipGraphDBSampler(types, n, edges, cet, feats, edge_features=efeats)
     nbrs = dag_sampler.neighbour_lists(edges)
     plans = {"paper": [SamplingOp("h1", a2p, 3, [], INCOMING), SamplingOp("h2", p2a, 3, ["h1"], INCOMING)],
              "author": [SamplingOp("h1", p2a, 3, [], INCOMING), SamplingOp("h2", a2p, 3, ["h1"], INCOMING),
@@ -166,8 +168,11 @@ def test_reference_heterogeneous_fixture(golden_dir):
             for x in m.neighborhood.nodes:
                 np.testing.assert_array_equal(x.feature_values, feats[by_cnt[x.condensed_node_type]][x.node_id])
             for e in m.neighborhood.edges:  # every sampled edge is an edge of its type's table
-                src, dst = edges[a2p if e.condensed_edge_type == 0 else p2a]
-                assert bool(((src == e.src_node_id) & (dst == e.dst_node_id)).any())
+                et = a2p if e.condensed_edge_type == 0 else p2a
+                src, dst = edges[et]
+                hit = np.flatnonzero((src == e.src_node_id) & (dst == e.dst_node_id))
+                assert hit.size > 0
+                np.testing.assert_array_equal(e.feature_values, efeats[et][hit[0]])  # the edge table's own row
             total_edges += len(want_e)
     assert total_edges > 100
     s.close()
