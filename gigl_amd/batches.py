@@ -275,10 +275,14 @@ def iterate_tfrecord_batches(files: Sequence[str], batch_size: int, rank: int = 
                              seed: int = 42, loop: bool = False):
     """TfRecordsIterableDataset (tf_records_iterable_dataset.py:49-82) + get_data_split_for_current_worker
     (data_loaders/utils.py:23-56): the file list is permuted once with RandomState(seed=42), files are strided
-    across ranks, records are batched in order; loop=True cycles forever (LoopyIterableDataset :85-109)"""
+    across ranks, records are batched in order; loop=True cycles forever (LoopyIterableDataset :85-109).  With
+    more ranks than files the list is tiled first (utils.py:38-47: data is replicated rather than leaving a rank
+    without batches — a rank that skips the loop would leave the others waiting in the DDP gradient all-reduce)."""
     files = list(files)
     if files:
         files = list(np.random.RandomState(seed).permutation(np.array(files, dtype=object)))
+        if world_size > len(files):
+            files = files * (-(-world_size // len(files)))
     mine = files[rank::world_size]
     while True:
         buf: List[bytes] = []

@@ -193,8 +193,10 @@ class GbmlConfigPbWrapper:
 
     @property
     def permutation_strategy(self) -> str:
-        # "deterministic" = the reproducible hash permutation (SamplingStrategy.scala:16-82); other values = F.shuffle
-        return self.experimental_flags.get("permutation_strategy", "deterministic")
+        # "deterministic" = the reproducible hash permutation (SamplingStrategy.scala:16-82); other values = F.shuffle.
+        # Default as the reference's: experimentalFlags.getOrElse("permutation_strategy", NonDeterministic)
+        # (SubgraphSamplerTask.scala:15 / SGSPureSparkV1Task callers)
+        return self.experimental_flags.get("permutation_strategy", "non-deterministic")
 
     # ---- data locations (flattened_graph_metadata.proto:6-39)
     def _fgm(self, path: str) -> Optional[str]:
@@ -287,3 +289,7 @@ class GbmlConfigPbWrapper:
     @property
     def should_skip_training(self) -> bool:
         return bool(_get(self.doc, "sharedConfig.shouldSkipTraining", False))
+
+    @property
+    def should_skip_model_evaluation(self) -> bool:
+        return bool(_get(self.doc, "sharedConfig.shouldSkipModelEvaluation", False))

@@ -214,11 +214,15 @@ class SubgraphSampler:
         # numMaxTrainingSamplesToOutput: the reference keeps an arbitrary `LIMIT n` of the training samples
         # (downsampleNumberOfNodes, SGSPureSparkV1Task.scala:1042-1081); here: the first n in node-id order
         limit = cfg.num_max_training_samples_to_output
+        # shouldSkipTraining && shouldSkipModelEvaluation: no labeled samples (SupervisedNodeClassificationTask.scala:101-106)
+        skip_labeled = cfg.should_skip_training and cfg.should_skip_model_evaluation
         for i in range(0, ids.size, batch_size):
             chunk = ids[i:i + batch_size]
             tree = eng.sample_khop(chunk, cfg.fanouts, sampling_seed=svc.sampling_seed)
             buf, off = eng.encode_records(tree)
             unl.add(_frames_to_host(buf), off.cpu().numpy())
+            if skip_labeled:
+                continue
             sfx, sfx_off = _encode_labels(pm.label_keys, labels, chunk)
             has_label = torch.from_numpy(np.diff(sfx_off) > 0).to(eng.device)
             emit = has_label & (tree.cnt[0] > 0)  # isolated nodes produce no training samples
@@ -260,9 +264,15 @@ class SubgraphSampler:
         main = _PartWriter(cfg.nablp_tfrecord_uri_prefix)
         rn = {t: _PartWriter(p) for t, p in cfg.random_negative_tfrecord_uri_prefixes.items()}
         limit = cfg.num_max_training_samples_to_output  # LIMIT n of the main samples (first n in node-id order)
+        # shouldSkipTraining && shouldSkipModelEvaluation: only the RootedNodeNeighborhood samples are written
+        # (NodeAnchorBasedLinkPredictionTask.scala:111-116)
+        skip_main = cfg.should_skip_training and cfg.should_skip_model_evaluation
         for i in range(0, ids.size, max(1, batch_size // T)):
             chunk = ids[i:i + max(1, batch_size // T)]
             roots = eng._roots_tensor(chunk)
+            if skip_main:
+                self_write_rn(eng, svc, cfg, roots, rn)
+                continue
             pos, cnt = eng.sample_positives(roots, P, sampling_seed=svc.sampling_seed,
                                             label_edges="pos" if pos_ud else None)
             cols = [roots.view(-1, 1), pos.view(-1, P)]
@@ -279,16 +289,22 @@ class SubgraphSampler:
                                           pos_label_edges="pos" if pos_ud else None,
                                           neg_label_edges="neg" if neg_ud else None)
             main.add(_frames_to_host(buf), off.cpu().numpy())
-            if rn:
-                tree = eng.sample_khop(roots, cfg.fanouts, sampling_seed=svc.sampling_seed)
-                buf, off = eng.encode_records(tree)
-                b_h, o_h = _frames_to_host(buf), off.cpu().numpy()
-                for w in rn.values():
-                    w.add(b_h, o_h)
+            self_write_rn(eng, svc, cfg, roots, rn)
         files = {"node_anchor_based_link_prediction": main.close()}
         for t, w in rn.items():
             files[f"random_negative/{t}"] = w.close()
         return files
+
+
+def self_write_rn(eng, svc, cfg, roots, rn) -> None:
+    """the RootedNodeNeighborhood sample of every node (random-negative stream / inference input) for one chunk"""
+    if not rn:
+        return
+    tree = eng.sample_khop(roots, cfg.fanouts, sampling_seed=svc.sampling_seed)
+    buf, off = eng.encode_records(tree)
+    b_h, o_h = _frames_to_host(buf), off.cpu().numpy()
+    for w in rn.values():
+        w.add(b_h, o_h)
 
 
 def main(argv=None):

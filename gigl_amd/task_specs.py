@@ -7,10 +7,11 @@ HipGraphSageNodeClassificationSpec — the node-classification loop of the refer
   main_sample_batch_size 16), same `_train` / `score` / `train` / `eval` / `infer_batch` bodies, with
   `GraphSAGE` wired in place of the stock `TwoLayerGCN` (BASELINE config 1 is
   GraphSAGE node classification; the plugin API allows exactly this substitution).
-Data: the labeled SupervisedNodeClassificationSample TFRecords written by the sampler.  The reference
-reads the Split Generator's train/val/test re-filing of those samples (out of scope, SURVEY.md §2 row 5);
-here the split is a deterministic function of the root id (id % 10: 0-7 train, 8 val, 9 test), falling
-back to "all samples in every split" for tiny fixtures.
+Data: the Split Generator's train/val/test re-filing of the labeled SupervisedNodeClassificationSample TFRecords
+(gigl_amd/split_generator.py writes it; datasetMetadata.supervisedNodeClassificationDataset.*DataUri), read like
+the reference's dataloaders.  Without a split-generator output the reference fails on the missing URIs; here the
+labeled sampler output is split by root id with a warning (id % 10: 0-7 train, 8 val, 9 test; fixtures of fewer
+than 100 samples go whole into every split — metrics are then computed on training data, test use only).
 """
 from __future__ import annotations
 
@@ -113,6 +114,10 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
                 yield SupervisedNodeClassificationBatch.process_raw_pyg_samples_and_collate_fn(
                     raw, node_type=cfg.node_types[0])
             return
+        import warnings
+        warnings.warn(f"no split-generator output for the {split!r} split (datasetMetadata.*DataUri is absent or empty):"
+                      " falling back to a root-id split of the labeled sampler output; run the SplitGenerator for the"
+                      " reference's splits", RuntimeWarning, stacklevel=2)
         files = tfrecord_files(cfg.labeled_tfrecord_uri_prefix)
         want = {"train": range(0, 8), "val": (8,), "test": (9,)}[split]
         for raw in iterate_tfrecord_batches(files, 10 ** 9, rank=rank, world_size=world):

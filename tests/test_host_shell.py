@@ -161,6 +161,14 @@ def test_tfrecord_batch_iteration_and_rank_sharding(golden_dir, tmp_path):
     assert len(r0) == len(r1) == 8 and sorted(r0 + r1) == sorted(recs)  # files strided across ranks
     it = iterate_tfrecord_batches(files[:1], 3, loop=True)
     assert sum(len(next(it)) for _ in range(5)) > 4  # loopy dataset keeps going
+    # more ranks than files: the list is tiled (get_data_split_for_current_worker, data_loaders/utils.py:38-47) —
+    # every rank gets batches (a rank without any would leave the others waiting in the DDP all-reduce)
+    for world in (2, 3, 5):
+        per_rank = [[r for b in iterate_tfrecord_batches(files[:1], 3, rank=k, world_size=world) for r in b]
+                    for k in range(world)]
+        assert all(len(x) == 4 for x in per_rank)
+    per_rank = [[r for b in iterate_tfrecord_batches(files[:3], 3, rank=k, world_size=4) for r in b] for k in range(4)]
+    assert all(len(x) >= 4 for x in per_rank)
 
 
 def test_entry_points_fail_loudly_without_gpu(golden_dir):
