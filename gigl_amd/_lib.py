@@ -37,6 +37,7 @@ SYMBOLS = [
     "gigl_collated_destroy", "gigl_gather_reduce", "gigl_gather_reduce_backward",
     "gigl_frontier_bucket", "gigl_frontier_scatter", "gigl_avro_embeddings_layout", "gigl_avro_embeddings_encode",
     "gigl_edge_ids", "gigl_union_edge_ids", "gigl_gat_aggregate_edge", "gigl_collated_edge_attr", "gigl_sample_out_neighbors", "gigl_rows_dedup", "gigl_gat_aggregate_backward",
+    "gigl_sage_plan_stats",
 ]
 
 KERNEL_IDS = {
@@ -89,6 +90,9 @@ class GiglRecordOpts(C.Structure):
 
 
 REC_ROOTED_NODE_NEIGHBORHOOD, REC_NODE_ANCHOR_LINK_PRED = 0, 1
+STATS = {"sampled": 0, "aggregated": 1, "union_edges": 2, "union_nodes": 3, "expand_bytes": 4, "agg_layer0": 5,
+         "rows_layer0": 9, "overflow": 13}
+STATS_LEN = 16
 COL_I64, COL_F32 = 0, 1
 
 
@@ -164,6 +168,7 @@ def load() -> C.CDLL:
         "gigl_sage_plan_destroy": [vp],
         "gigl_sage_plan_use_graph": [vp, i32],
         "gigl_sage_plan_flush_profile": [vp],
+        "gigl_sage_plan_stats": [vp, vp, vp],
         "gigl_gather_mean_backward": [vp, vp, i32, vp, vp, vp, vp, i64, vp],
         "gigl_expand_frontier": [vp, vp, vp, vp, i64, i32, i32, i32, i64, vp, vp],
         "gigl_gather_rows": [vp, vp, i32, i32, vp, vp, i64, vp],

@@ -85,6 +85,68 @@ __global__ void guard_levels_kernel(int32_t* meta, int hops, int32_t act_rows) {
   }
 }
 
+// exact work counts of the last batch set, accumulated into acc[GIGL_STATS_LEN] (see gigl_sage_plan_stats)
+struct StatsArgs {
+  const uint32_t* roots;
+  const uint32_t* nbr[GIGL_MAX_HOPS];
+  const int32_t* cnt[GIGL_MAX_HOPS];
+  int32_t fan[GIGL_MAX_HOPS];
+  int64_t parents[GIGL_MAX_HOPS];  // parent slots of hop k
+  int32_t hops;
+  const int64_t* g_rowptr;  // resident graph (in-degrees of the frontier nodes)
+  const int32_t* meta;
+  const int32_t* rowptr;
+  const int32_t* rowend;
+  int64_t rows_cap;
+};
+
+__device__ __forceinline__ void stats_add(unsigned long long* acc, int slot, long long v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(&acc[slot], (unsigned long long)v);
+}
+
+__global__ __launch_bounds__(256) void plan_stats_kernel(StatsArgs a, unsigned long long* acc) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int L = a.hops;
+  long long sampled = 0, bytes = 0;
+#pragma unroll
+  for (int k = 0; k < GIGL_MAX_HOPS; ++k) {
+    if (k >= L) break;
+    const uint32_t* par = k == 0 ? a.roots : a.nbr[k - 1];
+    for (int64_t p = t0; p < a.parents[k]; p += stride) {
+      const uint32_t v = par[p];
+      if (v == GIGL_INVALID) continue;
+      const long long deg = a.g_rowptr[(int64_t)v + 1] - a.g_rowptr[v];
+      bytes += 16 + 4 * deg + 8 * (deg < a.fan[k] ? deg : (long long)a.fan[k]);
+      sampled += a.cnt[k][p];
+    }
+  }
+  long long agg[GIGL_MAX_HOPS] = {0, 0, 0, 0};
+  const int32_t n_rows = a.meta[GIGL_META_LEVEL0 + L - 1];
+  for (int64_t i = t0; i < n_rows && i < a.rows_cap; i += stride) {
+    const long long len = a.rowend[i] - a.rowptr[i];
+#pragma unroll
+    for (int l = 0; l < GIGL_MAX_HOPS; ++l)
+      if (l < L && i < a.meta[GIGL_META_LEVEL0 + (L - 1 - l)]) agg[l] += len;  // layer l computes rows of level <= L-1-l
+  }
+  long long agg_all = 0;
+#pragma unroll
+  for (int l = 0; l < GIGL_MAX_HOPS; ++l) agg_all += agg[l];
+  stats_add(acc, GIGL_STATS_SAMPLED, sampled);
+  stats_add(acc, GIGL_STATS_AGGREGATED, agg_all);
+  stats_add(acc, GIGL_STATS_EXPAND_BYTES, bytes);
+#pragma unroll
+  for (int l = 0; l < GIGL_MAX_HOPS; ++l) stats_add(acc, GIGL_STATS_AGG_LAYER0 + l, agg[l]);
+  if (t0 == 0) {
+    atomicAdd(&acc[GIGL_STATS_UNION_EDGES], (unsigned long long)a.meta[GIGL_META_N_EDGES]);
+    atomicAdd(&acc[GIGL_STATS_UNION_NODES], (unsigned long long)a.meta[GIGL_META_N_NODES]);
+    atomicAdd(&acc[GIGL_STATS_OVERFLOW], (unsigned long long)a.meta[GIGL_META_OVERFLOW]);
+    for (int l = 0; l < L; ++l)
+      atomicAdd(&acc[GIGL_STATS_ROWS_LAYER0 + l], (unsigned long long)a.meta[GIGL_META_LEVEL0 + (L - 1 - l)]);
+  }
+}
+
 // stages of one batch: 0 sample, 1 union, 2+2l gather l, 3+2l linear l, 2+2L take_rows
 int n_stages(const gigl_sage_plan* p) { return 3 + 2 * p->hops; }
 
@@ -347,6 +409,35 @@ int32_t gigl_sage_plan_buffers(gigl_sage_plan* p, gigl_tree* tree, gigl_union* u
     *un = p->un;
     if (p->alias_rows) un->cap_edges += p->last_slots;  // rowptr / rowend may point into the aliased tree segments
   }
+  return GIGL_OK;
+}
+
+int32_t gigl_sage_plan_stats(gigl_sage_plan* p, const uint32_t* roots, int64_t* acc) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, roots && acc, "null argument");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  StatsArgs a{};
+  a.roots = roots;
+  a.hops = p->hops;
+  int64_t parents = p->b, most = p->b;
+  for (int k = 0; k < p->hops; ++k) {
+    a.nbr[k] = p->tree.nbr[k];
+    a.cnt[k] = p->tree.cnt[k];
+    a.fan[k] = p->fanouts[k];
+    a.parents[k] = parents;
+    if (parents > most) most = parents;
+    parents *= p->fanouts[k];
+  }
+  a.g_rowptr = p->graph->rowptr;
+  a.meta = p->un.meta;
+  a.rowptr = p->un.rowptr;
+  a.rowend = p->un.rowend;
+  a.rows_cap = p->un.cap_nodes;
+  int64_t blocks = (most + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(plan_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a, (unsigned long long*)acc);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
 

@@ -777,6 +777,12 @@ class SagePlan:
                                            C.c_void_p(out.data_ptr())), self.eng._ctx)
         return out
 
+    def stats(self, roots: torch.Tensor, acc: torch.Tensor) -> None:
+        """add the exact work counts of the batch set run last (with `roots`) to acc (int64 [STATS_LEN], device)"""
+        assert acc.is_cuda and acc.dtype == torch.int64 and acc.numel() >= _lib.STATS_LEN
+        check(self._lib.gigl_sage_plan_stats(self._plan, C.c_void_p(roots.data_ptr()), C.c_void_p(acc.data_ptr())),
+              self.eng._ctx)
+
     def _d2h(self, ptr, n, dtype):
         a = np.empty(n, dtype=dtype)
         if n:

@@ -548,6 +548,25 @@ int32_t gigl_sage_plan_set_groups(gigl_sage_plan* plan, int32_t group_roots);
 int32_t gigl_sage_plan_buffers(gigl_sage_plan* plan, gigl_tree* tree, gigl_union* un);
 int32_t gigl_sage_plan_run(gigl_sage_plan* plan, const uint32_t* roots, int32_t sampling_seed,
                            int32_t mode, float* out);
+/* exact work counts of the batch set the plan ran LAST (its tree and union graph are still in the workspace), added
+ * to acc[GIGL_STATS_LEN] (DEVICE int64, caller-zeroed, accumulates over calls; enqueued on the ctx stream, no host
+ * synchronisation) — the units of BASELINE.json's metric and the algorithmic bytes of SURVEY.md 8(d):
+ *   SAMPLED       sum of cnt[k][*]: (src -> dst) pairs emitted by the hop expansions, before batch dedup
+ *   AGGREGATED    sum over layers l of the in-edges of the rows layer l computes (levels <= hops-1-l): edges actually
+ *                 consumed by a segmented reduce (the reference executes hops * UNION_EDGES)
+ *   EXPAND_BYTES  sum over frontier nodes of 16 + 4*deg + 8*min(deg, fanout)
+ *   AGG_LAYER0+l / ROWS_LAYER0+l   aggregated edges / computed rows of layer l
+ * `roots` = the roots passed to that run. */
+#define GIGL_STATS_SAMPLED 0
+#define GIGL_STATS_AGGREGATED 1
+#define GIGL_STATS_UNION_EDGES 2
+#define GIGL_STATS_UNION_NODES 3
+#define GIGL_STATS_EXPAND_BYTES 4
+#define GIGL_STATS_AGG_LAYER0 5  /* + l, l < GIGL_MAX_HOPS */
+#define GIGL_STATS_ROWS_LAYER0 9 /* + l */
+#define GIGL_STATS_OVERFLOW 13
+#define GIGL_STATS_LEN 16
+int32_t gigl_sage_plan_stats(gigl_sage_plan* plan, const uint32_t* roots, int64_t* acc);
 /* hipGraph replay: on != 0 captures the plan's launches once (per seed/mode/profile mask) and replays them
  * with one graph launch per batch plus the D2D copies of the root ids in and the rows out.  Weights and the
  * graph/feature tables are baked into the captured kernels: call again (or set_weights + use_graph) after

@@ -44,7 +44,15 @@ def main():
             known = json.loads(lines[-1])
         except (OSError, IndexError):
             pass
-    out = {"tag": tag, "counter_unit": "KB (rocprofv3 FETCH_SIZE / WRITE_SIZE)", "known_bytes": known,
+    shape = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):  # the launch shape of the profiled bench run (its --timed-only line)
+        try:
+            lines = [l for l in open(f"{base}_{ctr}_bench.log") if l.startswith("{")]
+            shape = json.loads(lines[-1])
+        except (OSError, IndexError):
+            pass
+    out = {"tag": tag, "batches_per_call": shape.get("batches_per_call"), "streams": shape.get("streams"),
+           "counter_unit": "KB (rocprofv3 FETCH_SIZE / WRITE_SIZE)", "known_bytes": known,
            "calibration": {}, "kernels": {}}
     corr = {}
     for ctr, key in (("FETCH_SIZE", "read"), ("WRITE_SIZE", "write")):
