@@ -37,7 +37,7 @@ SYMBOLS = [
     "gigl_collated_destroy", "gigl_gather_reduce", "gigl_gather_reduce_backward",
     "gigl_frontier_bucket", "gigl_frontier_scatter", "gigl_avro_embeddings_layout", "gigl_avro_embeddings_encode",
     "gigl_edge_ids", "gigl_union_edge_ids", "gigl_gat_aggregate_edge", "gigl_collated_edge_attr", "gigl_sample_out_neighbors", "gigl_rows_dedup", "gigl_gat_aggregate_backward",
-    "gigl_sage_plan_stats",
+    "gigl_sage_plan_stats", "gigl_retrieval_loss", "gigl_retrieval_loss_backward",
 ]
 
 KERNEL_IDS = {
@@ -169,6 +169,8 @@ def load() -> C.CDLL:
         "gigl_sage_plan_use_graph": [vp, i32],
         "gigl_sage_plan_flush_profile": [vp],
         "gigl_sage_plan_stats": [vp, vp, vp],
+        "gigl_retrieval_loss": [vp, vp, i64, i32, i32, C.c_float, vp, vp, vp, vp, vp, vp, vp],
+        "gigl_retrieval_loss_backward": [vp, vp, i64, i32, i32, C.c_float, vp, vp, vp, vp, vp, vp],
         "gigl_gather_mean_backward": [vp, vp, i32, vp, vp, vp, vp, i64, vp],
         "gigl_expand_frontier": [vp, vp, vp, vp, i64, i32, i32, i32, i64, vp, vp],
         "gigl_gather_rows": [vp, vp, i32, i32, vp, vp, i64, vp],

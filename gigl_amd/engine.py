@@ -68,6 +68,25 @@ class UnionGraph:
         return self.nodes[:n].cpu().numpy().view(np.uint32), out_rp, col[idx]
 
 
+_DEFAULT_ENGINES = {}
+
+
+def default_engine(device) -> "HipEngine":
+    """one shared ctx per device for the stateless ops (loss, decoder) that the reference calls as free functions;
+    bound to torch's current stream of that device at every use"""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError(f"gigl_amd runs on a HIP device only (got {dev}); there is no CPU fallback")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    eng = _DEFAULT_ENGINES.get(idx)
+    if eng is None or not eng._ctx:
+        eng = _DEFAULT_ENGINES[idx] = HipEngine(idx)
+    cur = torch.cuda.current_stream(eng.device)
+    if eng._stream.cuda_stream != cur.cuda_stream:
+        eng.bind_stream(cur)
+    return eng
+
+
 class HipEngine:
     def __init__(self, device: int = 0):
         self._lib = _lib.load()  # raises if the HIP library is missing
@@ -712,6 +731,33 @@ class HipEngine:
                                     C.c_void_p(m_dev.data_ptr()), m_cap, k, n, act, C.c_void_p(out.data_ptr())),
               self._ctx)
         return out
+
+    def retrieval_loss(self, scores: torch.Tensor, temperature: Optional[float], cand_prob: Optional[torch.Tensor],
+                       query_ids: Optional[torch.Tensor], cand_ids: Optional[torch.Tensor], want_masked: bool = False):
+        """-> (loss [] fp32, row_lse [q], masked logits [q, c] | None): gigl_retrieval_loss"""
+        assert scores.is_cuda and scores.dtype == torch.float32 and scores.dim() == 2 and scores.stride(1) == 1
+        q, c = int(scores.shape[0]), int(scores.shape[1])
+        dev = self.device
+        lse = torch.empty(q, dtype=torch.float32, device=dev)
+        row_loss = torch.empty(q, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        masked = torch.empty((q, c), dtype=torch.float32, device=dev) if want_masked else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(self._lib.gigl_retrieval_loss(self._ctx, p(scores), int(scores.stride(0)), q, c,
+                                            float(temperature) if temperature is not None else 0.0, p(cand_prob),
+                                            p(query_ids), p(cand_ids), p(masked), p(lse), p(row_loss), p(loss)),
+              self._ctx)
+        return loss, lse, masked
+
+    def retrieval_loss_backward(self, scores, temperature, cand_prob, query_ids, cand_ids, lse, grad_loss):
+        q, c = int(scores.shape[0]), int(scores.shape[1])
+        d = torch.empty((q, c), dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(self._lib.gigl_retrieval_loss_backward(self._ctx, p(scores), int(scores.stride(0)), q, c,
+                                                     float(temperature) if temperature is not None else 0.0,
+                                                     p(cand_prob), p(query_ids), p(cand_ids), p(lse), p(grad_loss),
+                                                     p(d)), self._ctx)
+        return d
 
     # ---- one-call batch pipeline -----------------------------------------------------------
     def make_sage_plan(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], b: int,

@@ -7,9 +7,9 @@ Mirror of (paths relative to the reference root):
   LinkPredictionGNN                    python/gigl/src/common/models/pyg/link_prediction.py:33-60
   RetrievalLoss                        python/gigl/src/common/models/layers/loss.py:177-360
       calculate_batch_retrieval_loss :209-277, _mask_by_query_ids :279-305, _mask_by_candidate_ids :307-331
-The loss is small dense tensor algebra that the reference itself writes in torch; it is restated 1:1 (same
-masks, `finfo.min` masking, CrossEntropyLoss(reduction="sum") against eye) and pinned by the reference's
-known-answer tests (tests/test_link_prediction.py restates loss_test.py:61-166 and decoder_test.py:44-62).
+The loss is one fused device pass over the score matrix (csrc/loss.hip: temperature, sampling-probability correction,
+both masks, log-softmax and the summed cross-entropy, plus its backward), pinned by the reference's known-answer tests
+(tests/test_link_prediction.py restates loss_test.py:61-166 and decoder_test.py:44-62).
 """
 from __future__ import annotations
 
@@ -101,15 +101,65 @@ class LinkPredictionGNN(nn.Module):
         return self._decoder
 
 
+def _ids_on(t: Optional[torch.Tensor], dev, n: int, what: str) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    t = t.to(device=dev, dtype=torch.int64).reshape(-1).contiguous()
+    if t.numel() != n:
+        raise ValueError(f"{what}: expected {n} ids, got {t.numel()}")
+    return t
+
+
+class _FusedRetrievalLoss(torch.autograd.Function):
+    """scores -> summed softmax cross-entropy against the diagonal, with the temperature, the sampling-probability
+    correction and both masks applied inside the kernel (csrc/loss.hip); backward = one more pass over the scores"""
+
+    @staticmethod
+    def forward(ctx, scores, eng, temperature, cand_prob, query_ids, cand_ids):
+        scores = scores.contiguous()
+        loss, lse, _ = eng.retrieval_loss(scores, temperature, cand_prob, query_ids, cand_ids)
+        ctx.eng, ctx.temperature = eng, temperature
+        ctx.save_for_backward(scores, lse, cand_prob, query_ids, cand_ids)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        scores, lse, cand_prob, query_ids, cand_ids = ctx.saved_tensors
+        d = ctx.eng.retrieval_loss_backward(scores, ctx.temperature, cand_prob, query_ids, cand_ids, lse,
+                                            g.to(torch.float32).contiguous())
+        return d, None, None, None, None, None
+
+
+class _MaskedLogits(torch.autograd.Function):
+    """the masked logits themselves (for a caller-supplied loss module): the masks add constants, so the gradient is
+    the incoming one over the temperature"""
+
+    @staticmethod
+    def forward(ctx, scores, eng, temperature, cand_prob, query_ids, cand_ids):
+        _, _, masked = eng.retrieval_loss(scores.contiguous(), temperature, cand_prob, query_ids, cand_ids,
+                                          want_masked=True)
+        ctx.temperature = temperature
+        return masked
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g / ctx.temperature if ctx.temperature is not None else g), None, None, None, None, None
+
+
 class RetrievalLoss(nn.Module):
+    """Same constructor and `calculate_batch_retrieval_loss` signature as the reference's RetrievalLoss
+    (python/gigl/src/common/models/layers/loss.py:177-277); the body is ONE fused device pass (gigl_retrieval_loss)
+    instead of the mask tensors + CrossEntropyLoss.  A caller-supplied `loss` module receives the masked logits and
+    eye(Q, C) targets, as in the reference.  Device tensors only: there is no CPU path."""
+
     def __init__(self, loss: Optional[nn.Module] = None, temperature: Optional[float] = None,
                  remove_accidental_hits: bool = False):
         super().__init__()
-        self._loss = loss if loss is not None else nn.CrossEntropyLoss(reduction="sum")
-        self._temperature = temperature
-        if self._temperature is not None and self._temperature < 1e-12:
+        if temperature is not None and temperature < 1e-12:
             raise ValueError("The temperature is expected to be greater than 1e-12, however you provided "
-                             f"{self._temperature}")
+                             f"{temperature}")
+        self._loss = loss  # None: summed cross-entropy, computed inside the kernel
+        self._temperature = temperature
         self._remove_accidental_hits = remove_accidental_hits
 
     def calculate_batch_retrieval_loss(self, scores: torch.Tensor,
@@ -117,39 +167,23 @@ class RetrievalLoss(nn.Module):
                                        query_ids: Optional[torch.Tensor] = None,
                                        candidate_ids: Optional[torch.Tensor] = None,
                                        device: torch.device = torch.device("cpu")) -> torch.Tensor:
-        num_queries, num_candidates = scores.shape[0], scores.shape[1]
-        torch._assert(num_queries <= num_candidates,
-                      "Number of queries should be less than or equal to number of candidates in a batch")
-        labels = torch.eye(num_queries, num_candidates).to(device=device)
-        duplicates = torch.zeros_like(labels).to(device=device)
-        if self._temperature is not None:
-            scores = scores / self._temperature
+        from .engine import default_engine
+        if self._remove_accidental_hits and candidate_ids is None:
+            raise ValueError("When accidental hit removal is enabled, candidate ids must be supplied.")
+        if not scores.is_cuda:
+            raise RuntimeError("RetrievalLoss runs on the HIP device only (scores is a CPU tensor); no CPU fallback")
+        q, c = int(scores.shape[0]), int(scores.shape[1])
+        if q > c:
+            raise AssertionError("Number of queries should be less than or equal to number of candidates in a batch")
+        dev = scores.device
+        eng = default_engine(dev)
+        scores = scores.to(torch.float32)
+        prob = None
         if candidate_sampling_probability is not None:
-            scores = scores - torch.log(torch.clamp(candidate_sampling_probability, min=1e-10)).type(scores.dtype)
-        if query_ids is not None:
-            duplicates = torch.maximum(duplicates, self._mask_by_query_ids(query_ids, num_queries, num_candidates,
-                                                                            labels.dtype, device))
-        if self._remove_accidental_hits:
-            if candidate_ids is None:
-                raise ValueError("When accidental hit removal is enabled, candidate ids must be supplied.")
-            duplicates = torch.maximum(duplicates, self._mask_by_candidate_ids(candidate_ids, num_queries,
-                                                                                labels.dtype, device))
-        if query_ids is not None or self._remove_accidental_hits:
-            scores = scores + (duplicates - labels) * torch.finfo(scores.dtype).min
-        return self._loss(scores, target=labels)
-
-    def _mask_by_query_ids(self, query_ids: torch.Tensor, num_queries: int, num_candidates: int, dtype: torch.dtype,
-                           device: torch.device = torch.device("cpu")) -> torch.Tensor:
-        query_ids = torch.unsqueeze(query_ids, 1)
-        duplicates = torch.eq(query_ids, query_ids.T).type(dtype)
-        if num_queries < num_candidates:
-            padding_zeros = torch.zeros((num_queries, num_candidates - num_queries), dtype=dtype).to(device=device)
-            return torch.cat((duplicates, padding_zeros), dim=1)
-        return duplicates
-
-    def _mask_by_candidate_ids(self, candidate_ids: torch.Tensor, num_queries: int, dtype: torch.dtype,
-                               device: torch.device = torch.device("cpu")) -> torch.Tensor:
-        positive_indices = torch.arange(num_queries).to(device=device)
-        positive_candidate_ids = torch.gather(candidate_ids, 0, positive_indices).unsqueeze(1)
-        all_candidate_ids = torch.unsqueeze(candidate_ids, 1)
-        return torch.eq(positive_candidate_ids, all_candidate_ids.T).type(dtype)
+            prob = candidate_sampling_probability.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        qid = _ids_on(query_ids, dev, q, "query_ids")
+        cid = _ids_on(candidate_ids, dev, c, "candidate_ids") if self._remove_accidental_hits else None
+        if self._loss is None:
+            return _FusedRetrievalLoss.apply(scores, eng, self._temperature, prob, qid, cid)
+        masked = _MaskedLogits.apply(scores, eng, self._temperature, prob, qid, cid)
+        return self._loss(masked, target=torch.eye(q, c, device=dev))

@@ -520,6 +520,26 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
                     const int32_t* m_dev, int64_t m_cap, int32_t k, int32_t n, int32_t act,
                     float* y);
 
+/* ---- retrieval loss of the link-prediction head, fused (temperature -> sampling-probability correction -> duplicate
+ *      / accidental-hit masking -> log-softmax -> cross-entropy against the diagonal, one pass over the scores).
+ *      Replaces RetrievalLoss.calculate_batch_retrieval_loss with _mask_by_query_ids / _mask_by_candidate_ids
+ *      (python/gigl/src/common/models/layers/loss.py:209-277, :279-305, :307-331) and the CrossEntropyLoss(
+ *      reduction="sum") against eye(Q, C) it feeds.
+ * scores: DEVICE fp32 [q][c] with `ld` floats between rows, q <= c (row i's positive is column i);
+ *   s_ij = scores_ij / temperature (temperature <= 0: none) - log(max(cand_prob[j], 1e-10)) (cand_prob NULL: none);
+ *   column j != i is masked (the reference adds finfo.min: softmax term 0) when query_ids != NULL and j < q and
+ *   query_ids[j] == query_ids[i], or cand_ids != NULL (remove_accidental_hits) and cand_ids[j] == cand_ids[i];
+ *   row_lse[i] = logsumexp_j s_ij, row_loss[i] = row_lse[i] - s_ii, *loss = sum_i row_loss[i] (fixed order).
+ * masked_scores (optional, [q][c]): the masked logits themselves (for a caller-supplied loss module).
+ * backward: dscores[q][c] = *grad_loss * d loss / d scores (grad_loss NULL: 1).  All pointers DEVICE. */
+int32_t gigl_retrieval_loss(gigl_ctx* ctx, const float* scores, int64_t ld, int32_t q, int32_t c, float temperature,
+                            const float* cand_prob, const int64_t* query_ids, const int64_t* cand_ids,
+                            float* masked_scores, float* row_lse, float* row_loss, float* loss);
+int32_t gigl_retrieval_loss_backward(gigl_ctx* ctx, const float* scores, int64_t ld, int32_t q, int32_t c,
+                                     float temperature, const float* cand_prob, const int64_t* query_ids,
+                                     const int64_t* cand_ids, const float* row_lse, const float* grad_loss,
+                                     float* dscores);
+
 /* ---- one-call batch pipeline: sample -> union -> GraphSAGE forward -> one output row per root.
  *      Replaces `infer_batch` of the reference's task specs for a RootedNodeNeighborhood batch
  *      (python/gigl/src/common/modeling_task_specs/node_anchor_based_link_prediction_modeling_task_spec.py:626-655,
