@@ -38,6 +38,10 @@ SYMBOLS = [
     "gigl_frontier_bucket", "gigl_frontier_scatter", "gigl_avro_embeddings_layout", "gigl_avro_embeddings_encode",
     "gigl_edge_ids", "gigl_union_edge_ids", "gigl_gat_aggregate_edge", "gigl_collated_edge_attr", "gigl_sample_out_neighbors", "gigl_rows_dedup", "gigl_gat_aggregate_backward",
     "gigl_sage_plan_stats", "gigl_retrieval_loss", "gigl_retrieval_loss_backward",
+    "gigl_comm_unique_id", "gigl_dist_init", "gigl_dist_init_local", "gigl_dist_init_callback", "gigl_comm_info",
+    "gigl_comm_all_to_all", "gigl_comm_flush_local", "gigl_comm_destroy", "gigl_dist_plan_create",
+    "gigl_dist_plan_set_weights", "gigl_dist_plan_phases", "gigl_dist_plan_phase", "gigl_dist_plan_run",
+    "gigl_dist_plan_run_local", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
 ]
 
 KERNEL_IDS = {
@@ -91,7 +95,20 @@ class GiglRecordOpts(C.Structure):
 
 REC_ROOTED_NODE_NEIGHBORHOOD, REC_NODE_ANCHOR_LINK_PRED = 0, 1
 STATS = {"sampled": 0, "aggregated": 1, "union_edges": 2, "union_nodes": 3, "expand_bytes": 4, "agg_layer0": 5,
-         "rows_layer0": 9, "overflow": 13}
+         "rows_layer0": 9, "overflow": 13, "pulled_rows": 14, "pull_bucket_max": 15}
+COMM_RCCL, COMM_LOCAL, COMM_CALLBACK = 0, 1, 2
+COMM_ID_BYTES = 128
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
+
+
+class GiglDistPlanOpts(C.Structure):
+    _fields_ = [
+        ("group_roots", C.c_int32),
+        ("project_on_owner", C.c_int32),
+        ("pull_cap", C.c_int64),
+        ("hop_slack", C.c_float),
+        ("max_window_end", C.c_int64),
+    ]
 STATS_LEN = 16
 COL_I64, COL_F32 = 0, 1
 
@@ -169,6 +186,23 @@ def load() -> C.CDLL:
         "gigl_sage_plan_use_graph": [vp, i32],
         "gigl_sage_plan_flush_profile": [vp],
         "gigl_sage_plan_stats": [vp, vp, vp],
+        "gigl_comm_unique_id": [vp],
+        "gigl_dist_init": [vp, i32, i32, vp, P(vp)],
+        "gigl_dist_init_local": [P(vp), i32, P(vp)],
+        "gigl_dist_init_callback": [vp, i32, i32, EXCHANGE_FN, vp, P(vp)],
+        "gigl_comm_info": [vp, P(i32), P(i32), P(i32)],
+        "gigl_comm_all_to_all": [vp, vp, vp, i64],
+        "gigl_comm_flush_local": [vp],
+        "gigl_comm_destroy": [vp],
+        "gigl_dist_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), P(vp), P(vp), i32, P(GiglDistPlanOpts), P(vp)],
+        "gigl_dist_plan_set_weights": [vp, P(vp), P(vp)],
+        "gigl_dist_plan_phases": [vp, P(i32)],
+        "gigl_dist_plan_phase": [vp, i32, vp, i32, vp],
+        "gigl_dist_plan_run": [vp, vp, i32, vp],
+        "gigl_dist_plan_run_local": [P(vp), i32, P(vp), i32, P(vp)],
+        "gigl_dist_plan_buffers": [vp, P(GiglTree), P(GiglUnion)],
+        "gigl_dist_plan_stats": [vp, vp],
+        "gigl_dist_plan_destroy": [vp],
         "gigl_retrieval_loss": [vp, vp, i64, i32, i32, C.c_float, vp, vp, vp, vp, vp, vp, vp],
         "gigl_retrieval_loss_backward": [vp, vp, i64, i32, i32, C.c_float, vp, vp, vp, vp, vp, vp],
         "gigl_gather_mean_backward": [vp, vp, i32, vp, vp, vp, vp, i64, vp],

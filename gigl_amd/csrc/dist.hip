@@ -1,0 +1,922 @@
+// dist.hip — the hash-partitioned (multi-GPU) step inside the library: communicators + the sharded batch plan.
+//
+// One process per GPU.  owner(v) = v % world (python/gigl/distributed/dist_link_prediction_data_partitioner.py:
+// 692-695): rank r holds the CSC rows (in-edges) and the feature rows of the nodes it owns (row v / world).  Where
+// the reference's distributed loader issues one RPC per batch and partition from Python worker processes
+// (python/gigl/distributed/distributed_neighborloader.py:162-192), a step here is a fixed schedule of device work
+// and equal-split all-to-alls issued from C++ on the ctx stream — no host read anywhere in a step:
+//
+//   per hop k:   bucket the frontier by owner (fixed-capacity buckets, counts stay on the requester)
+//                -> all_to_all (node ids, path sums) -> owners expand on their shard (same selection rule and hash
+//                table as the single-GPU sampler) -> all_to_all (f ids per request) -> scatter into the tree layout
+//   union graph: built locally (gigl_union_build_groups: node / edge dedup per batch, level-ordered numbering)
+//   feature pull: the UNIQUE node ids of the union graph go to their owners in buckets -> all_to_all -> the owners
+//                gather the rows STRAIGHT INTO THE SEND BUFFER (raw rows, or rows already projected by the first
+//                layer's weights so that dims[1] floats travel instead of the raw row: lin_l(mean x) == mean(lin_l x))
+//                -> all_to_all -> the first layer reads the rows where they arrived, through an index
+//   forward:     the remaining layers are local (gigl_gather_mean + gigl_linear), one row per root comes out
+//
+// Transports (gigl_comm): RCCL (ncclSend/ncclRecv groups on the ctx stream — librccl is opened at run time, the
+// one torch already mapped when there is one), an in-process group (every rank of a world is a ctx of this process
+// on one device: exchanges are device copies, ranks advance phase by phase — tests and single-process drivers), and
+// a host callback (the caller moves the bytes: MPI, gloo, ... — synchronises the stream around every exchange).
+#include "common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------ communicators
+namespace {
+
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok = false;
+};
+
+RcclApi& rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api;
+  tried = true;
+  // the copy another library of this process (torch) already mapped wins: two RCCL instances must not share a GPU
+  const char* names[] = {"librccl.so.1", "librccl.so"};
+  for (const char* n : names)
+    if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+  for (const char* n : names)
+    if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  if (!api.handle) return api;
+#define GIGL_RCCL_SYM(field, name) api.field = (decltype(api.field))dlsym(api.handle, name)
+  GIGL_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+  GIGL_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+  GIGL_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+  GIGL_RCCL_SYM(GroupStart, "ncclGroupStart");
+  GIGL_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+  GIGL_RCCL_SYM(Send, "ncclSend");
+  GIGL_RCCL_SYM(Recv, "ncclRecv");
+  GIGL_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef GIGL_RCCL_SYM
+  api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.GroupStart && api.GroupEnd && api.Send &&
+           api.Recv && api.GetErrorString;
+  return api;
+}
+
+struct Pending {
+  const void* send;
+  void* recv;
+  int64_t bytes;
+};
+
+struct LocalGroup {
+  int world = 0;
+  std::vector<gigl_comm*> members;
+};
+
+}  // namespace
+
+struct gigl_comm {
+  int32_t kind = 0;  // GIGL_COMM_*
+  gigl_ctx* ctx = nullptr;
+  int32_t rank = 0, world = 1;
+  ncclComm_t nccl = nullptr;
+  LocalGroup* group = nullptr;      // in-process group (shared by its members, freed with the last one)
+  std::vector<Pending> pending;     // in-process group: exchanges registered since the last flush
+  gigl_exchange_fn fn = nullptr;    // host callback
+  void* user = nullptr;
+};
+
+namespace {
+
+int32_t comm_exchange(gigl_comm* c, const void* send, void* recv, int64_t bytes) {
+  gigl_ctx* ctx = c->ctx;
+  if (bytes == 0) return GIGL_OK;
+  if (c->kind == GIGL_COMM_RCCL) {
+    RcclApi& api = rccl();
+    ncclResult_t r = api.GroupStart();
+    for (int p = 0; p < c->world && r == ncclSuccess; ++p) {
+      r = api.Send((const char*)send + (int64_t)p * bytes, (size_t)bytes, ncclInt8, p, c->nccl, ctx->stream);
+      if (r == ncclSuccess)
+        r = api.Recv((char*)recv + (int64_t)p * bytes, (size_t)bytes, ncclInt8, p, c->nccl, ctx->stream);
+    }
+    ncclResult_t r2 = api.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) return gigl_fail(ctx, GIGL_E_HIP, "RCCL all-to-all failed: %s", api.GetErrorString(r));
+    return GIGL_OK;
+  }
+  if (c->kind == GIGL_COMM_LOCAL) {
+    c->pending.push_back(Pending{send, recv, bytes});  // performed by gigl_comm_flush_local once every rank is here
+    return GIGL_OK;
+  }
+  // host callback: the bytes leave through the caller's transport
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const int32_t rc = c->fn(c->user, send, recv, bytes);
+  if (rc != 0) return gigl_fail(ctx, GIGL_E_HIP, "the exchange callback failed (%d)", rc);
+  return GIGL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t gigl_comm_unique_id(void* id) {
+  if (!id) return GIGL_E_INVALID_ARG;
+  RcclApi& api = rccl();
+  if (!api.ok) return GIGL_E_UNSUPPORTED;
+  static_assert(sizeof(ncclUniqueId) == GIGL_COMM_ID_BYTES, "unique id size");
+  return api.GetUniqueId((ncclUniqueId*)id) == ncclSuccess ? GIGL_OK : GIGL_E_HIP;
+}
+
+int32_t gigl_dist_init(gigl_ctx* ctx, int32_t rank, int32_t world, const void* rccl_unique_id, gigl_comm** out) {
+  if (!ctx || !out) return GIGL_E_INVALID_ARG;
+  *out = nullptr;
+  GIGL_REQUIRE(ctx, world >= 1 && rank >= 0 && rank < world && rccl_unique_id, "bad rank / world / id");
+  RcclApi& api = rccl();
+  if (!api.ok) return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "librccl.so.1 could not be loaded: %s", dlerror());
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  gigl_comm* c = new (std::nothrow) gigl_comm();
+  if (!c) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
+  c->kind = GIGL_COMM_RCCL;
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  ncclUniqueId id;
+  memcpy(&id, rccl_unique_id, sizeof(id));
+  ncclResult_t r = api.CommInitRank(&c->nccl, world, id, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return gigl_fail(ctx, GIGL_E_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world,
+                     api.GetErrorString(r));
+  }
+  *out = c;
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_init_local(gigl_ctx* const* ctxs, int32_t world, gigl_comm** out) {
+  if (!ctxs || !out || world < 1) return GIGL_E_INVALID_ARG;
+  for (int r = 0; r < world; ++r) {
+    if (!ctxs[r]) return GIGL_E_INVALID_ARG;
+    GIGL_REQUIRE(ctxs[r], ctxs[r]->device == ctxs[0]->device && ctxs[r]->stream == ctxs[0]->stream,
+                 "the ctxs of an in-process group must share one device and one stream (gigl_ctx_set_stream)");
+  }
+  LocalGroup* g = new (std::nothrow) LocalGroup();
+  if (!g) return GIGL_E_OOM;
+  g->world = world;
+  for (int r = 0; r < world; ++r) {
+    gigl_comm* c = new (std::nothrow) gigl_comm();
+    if (!c) return GIGL_E_OOM;
+    c->kind = GIGL_COMM_LOCAL;
+    c->ctx = ctxs[r];
+    c->rank = r;
+    c->world = world;
+    c->group = g;
+    g->members.push_back(c);
+    out[r] = c;
+  }
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_init_callback(gigl_ctx* ctx, int32_t rank, int32_t world, gigl_exchange_fn fn, void* user,
+                                gigl_comm** out) {
+  if (!ctx || !out) return GIGL_E_INVALID_ARG;
+  *out = nullptr;
+  GIGL_REQUIRE(ctx, world >= 1 && rank >= 0 && rank < world && fn, "bad rank / world / callback");
+  gigl_comm* c = new (std::nothrow) gigl_comm();
+  if (!c) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
+  c->kind = GIGL_COMM_CALLBACK;
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  c->fn = fn;
+  c->user = user;
+  *out = c;
+  return GIGL_OK;
+}
+
+int32_t gigl_comm_info(gigl_comm* c, int32_t* rank, int32_t* world, int32_t* kind) {
+  if (!c) return GIGL_E_INVALID_ARG;
+  if (rank) *rank = c->rank;
+  if (world) *world = c->world;
+  if (kind) *kind = c->kind;
+  return GIGL_OK;
+}
+
+int32_t gigl_comm_all_to_all(gigl_comm* c, const void* send, void* recv, int64_t bytes_per_peer) {
+  if (!c) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(c->ctx, bytes_per_peer >= 0 && (bytes_per_peer == 0 || (send && recv)), "bad all-to-all arguments");
+  GIGL_HIP_CHECK(c->ctx, hipSetDevice(c->ctx->device));
+  return comm_exchange(c, send, recv, bytes_per_peer);
+}
+
+int32_t gigl_comm_flush_local(gigl_comm* any) {
+  if (!any) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = any->ctx;
+  GIGL_REQUIRE(ctx, any->kind == GIGL_COMM_LOCAL && any->group, "not an in-process group");
+  LocalGroup* g = any->group;
+  const size_t n = g->members[0]->pending.size();
+  for (gigl_comm* m : g->members)
+    GIGL_REQUIRE(ctx, m->pending.size() == n, "ranks of the in-process group registered different exchange counts");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  for (size_t x = 0; x < n; ++x) {
+    const int64_t bytes = g->members[0]->pending[x].bytes;
+    for (gigl_comm* m : g->members)
+      GIGL_REQUIRE(ctx, m->pending[x].bytes == bytes, "ranks disagree on the exchange size");
+    for (int r = 0; r < g->world; ++r)    // sender
+      for (int p = 0; p < g->world; ++p)  // receiver: block r of p's receive buffer <- block p of r's send buffer
+        GIGL_HIP_CHECK(ctx, hipMemcpyAsync((char*)g->members[p]->pending[x].recv + (int64_t)r * bytes,
+                                           (const char*)g->members[r]->pending[x].send + (int64_t)p * bytes,
+                                           (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  for (gigl_comm* m : g->members) m->pending.clear();
+  return GIGL_OK;
+}
+
+int32_t gigl_comm_destroy(gigl_comm* c) {
+  if (!c) return GIGL_OK;
+  if (c->ctx) {
+    hipSetDevice(c->ctx->device);
+    hipStreamSynchronize(c->ctx->stream);
+  }
+  if (c->kind == GIGL_COMM_RCCL && c->nccl) rccl().CommDestroy(c->nccl);
+  if (c->group) {
+    LocalGroup* g = c->group;
+    for (auto& m : g->members)
+      if (m == c) m = nullptr;
+    bool any = false;
+    for (auto m : g->members) any = any || m != nullptr;
+    if (!any) delete g;
+  }
+  delete c;
+  return GIGL_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------ kernels
+namespace {
+
+// frontier slot i (node v, path sum K) -> bucket owner(v) = v % world, at the next free position p (fixed capacity):
+// nodes_out[r*cap + p] = v, ksum_out[r*cap + p] = K, slot_idx[r*cap + p] = i, pos[i] = r*cap + p (optional).
+// One global atomic per (workgroup, owner): slots take a rank inside the workgroup from LDS counters (same-address
+// atomics serialise; with a small world every slot hits one of `world` counters).  n_valid (optional, device): only
+// the first *n_valid slots exist.
+__global__ __launch_bounds__(256) void bucket_kernel(const uint32_t* __restrict__ nodes,
+                                                     const uint32_t* __restrict__ ksums, int64_t m,
+                                                     const int32_t* __restrict__ n_valid, uint32_t world, int64_t cap,
+                                                     uint32_t* __restrict__ nodes_out, uint32_t* __restrict__ ksum_out,
+                                                     int32_t* __restrict__ slot_idx, int32_t* __restrict__ pos,
+                                                     int32_t* __restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t lim = n_valid ? (int64_t)*n_valid : m;
+  const uint32_t v = (i < m && i < lim) ? nodes[i] : GIGL_INVALID;
+  const uint32_t r = v == GIGL_INVALID ? 0xFFFFFFFFu : v % world;
+  const int lane = threadIdx.x & 63;
+  int32_t p = 0;
+  if (world <= 64) {
+    __shared__ int32_t s_cnt[64], s_base[64];
+    if (threadIdx.x < world) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int32_t rank = 0;
+    if (r != 0xFFFFFFFFu) rank = atomicAdd(&s_cnt[r], 1);
+    __syncthreads();
+    if (threadIdx.x < world && s_cnt[threadIdx.x] > 0)
+      s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (r != 0xFFFFFFFFu) p = s_base[r] + rank;
+  } else {
+    unsigned long long todo = __ballot(r != 0xFFFFFFFFu);
+    while (todo) {
+      const int lead = __ffsll((long long)todo) - 1;
+      const uint32_t r_lead = __shfl(r, lead, 64);
+      const unsigned long long same = __ballot(r == r_lead);
+      int32_t base = 0;
+      if (lane == lead) base = atomicAdd(&counts[r_lead], (int32_t)__popcll(same));
+      base = __shfl(base, lead, 64);
+      if (r == r_lead) p = base + (int32_t)__popcll(same & ((1ull << lane) - 1ull));
+      todo &= ~same;
+    }
+  }
+  if (r == 0xFFFFFFFFu) {
+    if (pos && i < m) pos[i] = 0;
+    return;
+  }
+  if (p >= cap) {
+    atomicOr(&counts[world], 1);
+    if (pos) pos[i] = 0;
+    return;
+  }
+  const int64_t e = (int64_t)r * cap + p;
+  nodes_out[e] = v;
+  if (ksum_out) ksum_out[e] = ksums ? ksums[i] : v;
+  if (slot_idx) slot_idx[e] = (int32_t)i;
+  if (pos) pos[i] = (int32_t)e;
+}
+
+// owner side of the feature pull: entry e of the received id buckets -> its feature row, written at row e of the send
+// buffer (raw copy, any element type), or widened to fp32 for the projection.  One wave per entry, 16-byte lanes.
+template <bool TO_F32>
+__global__ __launch_bounds__(256) void serve_rows_kernel(const uint32_t* __restrict__ ids, int64_t n_entries,
+                                                         uint32_t world, const void* __restrict__ rows, int64_t n_rows,
+                                                         int32_t d, int32_t dtype, void* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (e >= n_entries) return;
+  const uint32_t v = ids[e];
+  if (v == GIGL_INVALID) return;
+  const int64_t row = (int64_t)(v / world);
+  if (row >= n_rows) return;
+  const int esz = dtype == GIGL_DTYPE_F32 ? 4 : 2;
+  if (!TO_F32) {
+    const int64_t rb = (int64_t)d * esz;
+    const char* s = (const char*)rows + row * rb;
+    char* o = (char*)out + e * rb;
+    if ((rb & 15) == 0) {
+      for (int64_t q = lane * 16; q < rb; q += 64 * 16) *(uint4*)(o + q) = *(const uint4*)(s + q);
+    } else {
+      for (int64_t q = lane * 2; q < rb; q += 64 * 2) *(uint16_t*)(o + q) = *(const uint16_t*)(s + q);
+    }
+  } else {
+    float* o = (float*)out + e * (int64_t)d;
+    if (dtype == GIGL_DTYPE_F32) {
+      const float* s = (const float*)rows + row * (int64_t)d;
+      for (int q = lane; q < d; q += 64) o[q] = s[q];
+    } else {
+      const __half* s = (const __half*)rows + row * (int64_t)d;
+      for (int q = lane; q < d; q += 64) o[q] = __half2float(s[q]);
+    }
+  }
+}
+
+// first layer on owner-projected rows: h[i][c] = act( mean[i][c] + self[posb[i]][c] + bias[c] ) for i < *n_rows;
+// mean = left half of the gather operand [rows][2*dout] (mean of the neighbours' W_l x), self rows = W_r x
+__global__ __launch_bounds__(256) void projected_layer_kernel(const float* __restrict__ a2, const float* __restrict__ self,
+                                                              const int32_t* __restrict__ posb,
+                                                              const float* __restrict__ bias, int dout, int act,
+                                                              const int32_t* __restrict__ n_rows, int64_t rows_cap,
+                                                              float* __restrict__ h) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = t / dout;
+  const int c = (int)(t - i * dout);
+  if (i >= rows_cap || i >= *n_rows) return;
+  float v = a2[i * 2 * dout + c] + self[(int64_t)posb[i] * dout + c] + (bias ? bias[c] : 0.f);
+  h[i * dout + c] = act ? fmaxf(v, 0.f) : v;
+}
+
+__global__ void take_root_rows_kernel(const float* __restrict__ h, const int32_t* __restrict__ root_local, int b, int d,
+                                      float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)b * d) return;
+  const int r = (int)(i / d), c = (int)(i % d);
+  const int32_t l = root_local[r];
+  out[i] = l >= 0 ? h[(int64_t)l * d + c] : 0.f;
+}
+
+// fold the bucket-overflow flags of the step into meta[GIGL_META_OVERFLOW]; a failed step computes nothing
+__global__ void fold_overflow_kernel(int32_t* meta, const int32_t* const* flags, int n_flags, int hops,
+                                     int32_t act_rows) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int32_t over = 0;
+  for (int q = 0; q < n_flags; ++q) over |= *flags[q];
+  // the activation buffers hold b*(1 + f0 + ...) rows: roots that are each other's sampled neighbours can push the
+  // inner levels past that (pipeline.hip guard_levels_kernel) — such a batch is reported failed too
+  for (int l = 0; l < hops; ++l) over |= meta[GIGL_META_LEVEL0 + l] > act_rows ? 1 : 0;
+  if (over) {
+    for (int l = 0; l <= hops; ++l) meta[GIGL_META_LEVEL0 + l] = 0;
+    atomicAdd(&meta[GIGL_META_OVERFLOW], 1);
+  }
+}
+
+struct DistStatsArgs {
+  const int32_t* cnt[GIGL_MAX_HOPS];
+  int64_t parents[GIGL_MAX_HOPS];
+  int32_t hops;
+  const int32_t* meta;
+  const int32_t* rowptr;
+  const int32_t* rowend;
+  const int32_t* pull_counts;  // [world]
+  int32_t world;
+};
+
+__global__ __launch_bounds__(256) void dist_stats_kernel(DistStatsArgs a, unsigned long long* acc) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int L = a.hops;
+  long long sampled = 0;
+#pragma unroll
+  for (int k = 0; k < GIGL_MAX_HOPS; ++k)
+    if (k < L)
+      for (int64_t p = t0; p < a.parents[k]; p += stride) sampled += a.cnt[k][p];
+  long long agg[GIGL_MAX_HOPS] = {0, 0, 0, 0};
+  const int32_t n_rows = a.meta[GIGL_META_LEVEL0 + L - 1];
+  for (int64_t i = t0; i < n_rows; i += stride) {
+    const long long len = a.rowend[i] - a.rowptr[i];
+#pragma unroll
+    for (int l = 0; l < GIGL_MAX_HOPS; ++l)
+      if (l < L && i < a.meta[GIGL_META_LEVEL0 + (L - 1 - l)]) agg[l] += len;
+  }
+  auto add = [&](int slot, long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&acc[slot], (unsigned long long)v);
+  };
+  long long agg_all = 0;
+#pragma unroll
+  for (int l = 0; l < GIGL_MAX_HOPS; ++l) agg_all += agg[l];
+  add(GIGL_STATS_SAMPLED, sampled);
+  add(GIGL_STATS_AGGREGATED, agg_all);
+#pragma unroll
+  for (int l = 0; l < GIGL_MAX_HOPS; ++l) add(GIGL_STATS_AGG_LAYER0 + l, agg[l]);
+  if (t0 == 0) {
+    atomicAdd(&acc[GIGL_STATS_UNION_EDGES], (unsigned long long)a.meta[GIGL_META_N_EDGES]);
+    atomicAdd(&acc[GIGL_STATS_UNION_NODES], (unsigned long long)a.meta[GIGL_META_N_NODES]);
+    atomicAdd(&acc[GIGL_STATS_OVERFLOW], (unsigned long long)a.meta[GIGL_META_OVERFLOW]);
+    for (int l = 0; l < L; ++l)
+      atomicAdd(&acc[GIGL_STATS_ROWS_LAYER0 + l], (unsigned long long)a.meta[GIGL_META_LEVEL0 + (L - 1 - l)]);
+    long long pulled = 0, most = 0;
+    for (int r = 0; r < a.world; ++r) {
+      pulled += a.pull_counts[r];
+      most = a.pull_counts[r] > most ? a.pull_counts[r] : most;
+    }
+    atomicAdd(&acc[GIGL_STATS_PULLED_ROWS], (unsigned long long)pulled);
+    atomicMax(&acc[GIGL_STATS_PULL_BUCKET_MAX], (unsigned long long)most);
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ the sharded plan
+struct gigl_dist_plan {
+  gigl_comm* comm = nullptr;
+  gigl_ctx* ctx = nullptr;
+  gigl_graph* shard = nullptr;
+  gigl_feat* feat = nullptr;
+  int32_t world = 1, rank = 0;
+  int32_t b = 0, group_roots = 0, hops = 0;
+  int32_t fan[GIGL_MAX_HOPS] = {0};
+  int32_t dims[GIGL_MAX_HOPS + 1] = {0};
+  const float* w[GIGL_MAX_HOPS] = {nullptr};
+  const float* bias[GIGL_MAX_HOPS] = {nullptr};
+  int32_t act_last = 0;
+  bool project = false;
+  int64_t mwe = -1;
+  // sampling
+  gigl_tree tree{};
+  uint32_t* child_ksum[GIGL_MAX_HOPS] = {nullptr};  // [slots of hop k]: K of the path root..slot
+  int64_t m[GIGL_MAX_HOPS] = {0}, cap[GIGL_MAX_HOPS] = {0};
+  uint32_t *rq_nodes_s[GIGL_MAX_HOPS] = {nullptr}, *rq_ksum_s[GIGL_MAX_HOPS] = {nullptr};
+  uint32_t *rq_nodes_r[GIGL_MAX_HOPS] = {nullptr}, *rq_ksum_r[GIGL_MAX_HOPS] = {nullptr};
+  uint32_t *resp_s[GIGL_MAX_HOPS] = {nullptr}, *resp_r[GIGL_MAX_HOPS] = {nullptr};
+  int32_t* slot_idx[GIGL_MAX_HOPS] = {nullptr};
+  int32_t* counts[GIGL_MAX_HOPS] = {nullptr};  // [world + 1], last = overflow flag
+  int32_t* own_cnt = nullptr;                  // owner-side out_cnt scratch
+  // union
+  gigl_union un{};
+  // feature pull: A = every union node (rows the first layer aggregates), B = nodes of level < hops (their own row;
+  // projected mode only — raw rows serve both)
+  int64_t pull_cap = 0, pull_cap_b = 0;
+  uint32_t *ids_s = nullptr, *ids_r = nullptr, *idsb_s = nullptr, *idsb_r = nullptr;
+  int32_t *pos = nullptr, *posb = nullptr;
+  int32_t *pull_counts = nullptr, *pullb_counts = nullptr;
+  void *rows_s = nullptr, *rows_r = nullptr, *rowsb_s = nullptr, *rowsb_r = nullptr;
+  int64_t row_bytes = 0;
+  float* stage = nullptr;             // projected mode: fp32 operand of the owner-side projection
+  float *wl0 = nullptr, *wr0 = nullptr;  // projected mode: contiguous [dims[1]][dims[0]] halves of w[0]
+  int32_t* n_entries_dev = nullptr;   // device constants: world*pull_cap, world*pull_cap_b
+  const int32_t** flag_ptrs = nullptr;  // device array of the overflow flags
+  int n_flags = 0;
+  // activations
+  float* abuf = nullptr;
+  float* hbuf[2] = {nullptr, nullptr};
+  int64_t act_rows = 0;
+  std::vector<void*> owned;
+};
+
+namespace {
+
+int n_phases(const gigl_dist_plan* p) { return 2 * p->hops + 3; }
+
+int64_t grid256(int64_t n) { return (n + 255) / 256; }
+
+int32_t split_w0(gigl_dist_plan* p) {  // w[0] = [W_l | W_r] row-interleaved -> two contiguous matrices
+  const size_t in = (size_t)p->dims[0], out = (size_t)p->dims[1];
+  GIGL_HIP_CHECK(p->ctx, hipMemcpy2DAsync(p->wl0, in * 4, p->w[0], 2 * in * 4, in * 4, out, hipMemcpyDeviceToDevice,
+                                          p->ctx->stream));
+  GIGL_HIP_CHECK(p->ctx, hipMemcpy2DAsync(p->wr0, in * 4, p->w[0] + in, 2 * in * 4, in * 4, out,
+                                          hipMemcpyDeviceToDevice, p->ctx->stream));
+  return GIGL_OK;
+}
+
+int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t seed, float* out) {
+  gigl_ctx* ctx = p->ctx;
+  hipStream_t st = ctx->stream;
+  const int L = p->hops;
+  const uint32_t world = (uint32_t)p->world;
+  int32_t rc = GIGL_OK;
+  if (phase < 2 * L && (phase & 1) == 0) {
+    // ---- requester: (scatter the previous hop's answers,) bucket this hop's frontier by owner
+    const int k = phase >> 1;
+    if (k > 0) {
+      rc = gigl_frontier_scatter(ctx, p->resp_r[k - 1], p->slot_idx[k - 1], p->counts[k - 1],
+                                 k == 1 ? roots : p->child_ksum[k - 2], p->m[k - 1], p->world, p->cap[k - 1],
+                                 p->fan[k - 1], p->tree.nbr[k - 1], p->tree.cnt[k - 1], p->child_ksum[k - 1]);
+      if (rc != GIGL_OK) return rc;
+    }
+    const uint32_t* nodes = k == 0 ? roots : p->tree.nbr[k - 1];
+    const uint32_t* ksums = k == 0 ? nullptr : p->child_ksum[k - 1];
+    const size_t bb = (size_t)world * p->cap[k] * 4;
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->rq_nodes_s[k], 0xFF, bb, st));
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->counts[k], 0, (size_t)(world + 1) * 4, st));
+    hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->m[k])), dim3(256), 0, st, nodes, ksums, p->m[k],
+                       (const int32_t*)nullptr, world, p->cap[k], p->rq_nodes_s[k], p->rq_ksum_s[k], p->slot_idx[k],
+                       (int32_t*)nullptr, p->counts[k]);
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    rc = comm_exchange(p->comm, p->rq_nodes_s[k], p->rq_nodes_r[k], p->cap[k] * 4);
+    if (rc == GIGL_OK) rc = comm_exchange(p->comm, p->rq_ksum_s[k], p->rq_ksum_r[k], p->cap[k] * 4);
+    return rc;
+  }
+  if (phase < 2 * L) {
+    // ---- owner: expand the requests of every peer on this shard
+    const int k = phase >> 1;
+    const int32_t hash_add = (int32_t)((uint32_t)seed * (uint32_t)(k + 1));
+    rc = gigl_expand_frontier(ctx, p->shard, p->rq_nodes_r[k], p->rq_ksum_r[k], (int64_t)world * p->cap[k], p->fan[k],
+                              hash_add, p->world, p->mwe, p->resp_s[k], p->own_cnt);
+    if (rc != GIGL_OK) return rc;
+    return comm_exchange(p->comm, p->resp_s[k], p->resp_r[k], p->cap[k] * p->fan[k] * 4);
+  }
+  if (phase == 2 * L) {
+    // ---- requester: last scatter, union graph, feature requests
+    rc = gigl_frontier_scatter(ctx, p->resp_r[L - 1], p->slot_idx[L - 1], p->counts[L - 1],
+                               L == 1 ? roots : p->child_ksum[L - 2], p->m[L - 1], p->world, p->cap[L - 1],
+                               p->fan[L - 1], p->tree.nbr[L - 1], p->tree.cnt[L - 1], p->child_ksum[L - 1]);
+    if (rc != GIGL_OK) return rc;
+    rc = gigl_union_build_groups(ctx, roots, &p->tree, p->group_roots, &p->un);
+    if (rc != GIGL_OK) return rc;
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->ids_s, 0xFF, (size_t)world * p->pull_cap * 4, st));
+    GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->pull_counts, 0, (size_t)(world + 1) * 4, st));
+    hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->un.cap_nodes)), dim3(256), 0, st, p->un.nodes,
+                       (const uint32_t*)nullptr, p->un.cap_nodes, p->un.meta + GIGL_META_N_NODES, world, p->pull_cap,
+                       p->ids_s, (uint32_t*)nullptr, (int32_t*)nullptr, p->pos, p->pull_counts);
+    if (p->project) {
+      GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->idsb_s, 0xFF, (size_t)world * p->pull_cap_b * 4, st));
+      GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->pullb_counts, 0, (size_t)(world + 1) * 4, st));
+      hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes,
+                         (const uint32_t*)nullptr, p->act_rows, p->un.meta + GIGL_META_LEVEL0 + (L - 1), world,
+                         p->pull_cap_b, p->idsb_s, (uint32_t*)nullptr, (int32_t*)nullptr, p->posb, p->pullb_counts);
+    }
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    rc = comm_exchange(p->comm, p->ids_s, p->ids_r, p->pull_cap * 4);
+    if (rc == GIGL_OK && p->project) rc = comm_exchange(p->comm, p->idsb_s, p->idsb_r, p->pull_cap_b * 4);
+    return rc;
+  }
+  if (phase == 2 * L + 1) {
+    // ---- owner: the requested rows, gathered straight into the send buffer (or projected into it)
+    const int64_t na = (int64_t)world * p->pull_cap, nb = (int64_t)world * p->pull_cap_b;
+    if (!p->project) {
+      hipLaunchKernelGGL(serve_rows_kernel<false>, dim3((unsigned)grid256(na * 64)), dim3(256), 0, st, p->ids_r, na,
+                         world, p->feat->rows, p->feat->n, p->feat->d, p->feat->dtype, p->rows_s);
+      GIGL_HIP_CHECK(ctx, hipGetLastError());
+      return comm_exchange(p->comm, p->rows_s, p->rows_r, p->pull_cap * p->row_bytes);
+    }
+    // (entries without a request keep whatever the operand held: their output rows are never read)
+    hipLaunchKernelGGL(serve_rows_kernel<true>, dim3((unsigned)grid256(na * 64)), dim3(256), 0, st, p->ids_r, na, world,
+                       p->feat->rows, p->feat->n, p->feat->d, p->feat->dtype, (void*)p->stage);
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    rc = gigl_linear(ctx, p->stage, p->wl0, nullptr, p->n_entries_dev, na, p->dims[0], p->dims[1], 0,
+                     (float*)p->rows_s);
+    if (rc != GIGL_OK) return rc;
+    hipLaunchKernelGGL(serve_rows_kernel<true>, dim3((unsigned)grid256(nb * 64)), dim3(256), 0, st, p->idsb_r, nb, world,
+                       p->feat->rows, p->feat->n, p->feat->d, p->feat->dtype, (void*)p->stage);
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    rc = gigl_linear(ctx, p->stage, p->wr0, nullptr, p->n_entries_dev + 1, nb, p->dims[0], p->dims[1], 0,
+                     (float*)p->rowsb_s);
+    if (rc != GIGL_OK) return rc;
+    rc = comm_exchange(p->comm, p->rows_s, p->rows_r, p->pull_cap * p->row_bytes);
+    if (rc == GIGL_OK) rc = comm_exchange(p->comm, p->rowsb_s, p->rowsb_r, p->pull_cap_b * p->row_bytes);
+    return rc;
+  }
+  // ---- requester: forward over the union graph, one row per root
+  hipLaunchKernelGGL(fold_overflow_kernel, dim3(1), dim3(64), 0, st, p->un.meta, (const int32_t* const*)p->flag_ptrs,
+                     p->n_flags, L, (int32_t)(p->act_rows < 0x7FFFFFFF ? p->act_rows : 0x7FFFFFFF));
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  for (int l = 0; l < L; ++l) {
+    const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
+    int64_t rows_cap = 0, width = p->b;
+    for (int i = 0; i <= L - 1 - l; ++i) {
+      rows_cap += width;
+      width *= p->fan[i];
+    }
+    const int act = (l < L - 1 || p->act_last) ? 1 : 0;
+    if (l == 0 && p->project) {
+      const int dout = p->dims[1];
+      rc = gigl_gather_reduce(ctx, p->rows_r, GIGL_DTYPE_F32, dout, (const uint32_t*)p->pos, p->un.rowptr, p->un.rowend,
+                              p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN, p->abuf);
+      if (rc != GIGL_OK) return rc;
+      hipLaunchKernelGGL(projected_layer_kernel, dim3((unsigned)grid256(rows_cap * dout)), dim3(256), 0, st, p->abuf,
+                         (const float*)p->rowsb_r, p->posb, p->bias[0], dout, act, n_rows, rows_cap, p->hbuf[0]);
+      GIGL_HIP_CHECK(ctx, hipGetLastError());
+      continue;
+    }
+    if (l == 0)
+      rc = gigl_gather_reduce(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, p->un.rowptr,
+                              p->un.rowend, p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN, p->abuf);
+    else
+      rc = gigl_gather_reduce(ctx, p->hbuf[(l - 1) & 1], GIGL_DTYPE_F32, p->dims[l], nullptr, p->un.rowptr, p->un.rowend,
+                              p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN, p->abuf);
+    if (rc != GIGL_OK) return rc;
+    rc = gigl_linear(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * p->dims[l], p->dims[l + 1], act,
+                     p->hbuf[l & 1]);
+    if (rc != GIGL_OK) return rc;
+  }
+  const int dout = p->dims[L];
+  hipLaunchKernelGGL(take_root_rows_kernel, dim3((unsigned)grid256((int64_t)p->b * dout)), dim3(256), 0, st,
+                     p->hbuf[(L - 1) & 1], p->un.root_local, p->b, dout, out);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t gigl_dist_plan_destroy(gigl_dist_plan* p) {
+  if (!p) return GIGL_OK;
+  if (p->ctx) {
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+  }
+  for (void* q : p->owned) hipFree(q);
+  delete p;
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
+                              const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,
+                              const float* const* bias, int32_t act_last, const gigl_dist_plan_opts* opts,
+                              gigl_dist_plan** out) {
+  if (!comm || !out) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = comm->ctx;
+  *out = nullptr;
+  GIGL_REQUIRE(ctx, shard && shard_feat && fanouts && dims && w, "null argument");
+  GIGL_REQUIRE(ctx, hops >= 1 && hops <= GIGL_MAX_HOPS && b >= 1, "bad plan shape");
+  GIGL_REQUIRE(ctx, dims[0] == shard_feat->d, "dims[0]=%d != feature dim %d", dims[0], shard_feat->d);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  gigl_dist_plan* p = new (std::nothrow) gigl_dist_plan();
+  if (!p) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
+  p->comm = comm;
+  p->ctx = ctx;
+  p->shard = shard;
+  p->feat = shard_feat;
+  p->world = comm->world;
+  p->rank = comm->rank;
+  p->b = b;
+  p->hops = hops;
+  p->act_last = act_last;
+  p->group_roots = opts && opts->group_roots > 0 ? opts->group_roots : b;
+  p->project = opts && opts->project_on_owner != 0;
+  p->mwe = opts ? opts->max_window_end : -1;
+  const double slack = opts && opts->hop_slack > 0.f ? opts->hop_slack : 0.5;
+  auto fail = [&](int32_t code, const char* msg) {
+    gigl_dist_plan_destroy(p);
+    return gigl_fail(ctx, code, "%s", msg);
+  };
+  if (p->group_roots < 1 || b % p->group_roots) return fail(GIGL_E_INVALID_ARG, "group_roots must divide b");
+  for (int k = 0; k < hops; ++k) {
+    if (fanouts[k] < 1 || fanouts[k] > GIGL_MAX_FANOUT) return fail(GIGL_E_UNSUPPORTED, "fanout outside [1,64]");
+    if (!w[k]) return fail(GIGL_E_INVALID_ARG, "null weight");
+    p->fan[k] = fanouts[k];
+    p->w[k] = w[k];
+    p->bias[k] = bias ? bias[k] : nullptr;
+  }
+  int32_t max_in = 0, max_out = 0;
+  for (int k = 0; k <= hops; ++k) {
+    if (dims[k] < 1) return fail(GIGL_E_INVALID_ARG, "bad dims");
+    p->dims[k] = dims[k];
+    if (k < hops && dims[k] > max_in) max_in = dims[k];
+    if (k > 0 && dims[k] > max_out) max_out = dims[k];
+  }
+  auto alloc = [&](size_t bytes) -> void* {
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    p->owned.push_back(q);
+    return q;
+  };
+  bool ok = true;
+  const int64_t W = p->world;
+  // ---- tree + per-hop exchange buffers
+  int64_t parents = b, max_served = 0;
+  for (int k = 0; k < hops && ok; ++k) {
+    p->m[k] = parents;
+    // owner(v) is a uniform hash of distinct ids, but a frontier repeats hubs: buckets get `slack` headroom (ids and
+    // path sums are 8 B per entry — cheap to pad, unlike feature rows); small worlds take the whole frontier
+    int64_t cap = parents;
+    if (W > 2) {
+      cap = (int64_t)std::ceil((double)parents / (double)W * (1.0 + slack)) + 512;
+      if (cap > parents) cap = parents;
+    }
+    p->cap[k] = cap;
+    if (W * cap > max_served) max_served = W * cap;
+    p->tree.cnt[k] = (int32_t*)alloc((size_t)parents * 4);
+    parents *= fanouts[k];
+    p->tree.nbr[k] = (uint32_t*)alloc((size_t)parents * 4);
+    p->child_ksum[k] = (uint32_t*)alloc((size_t)parents * 4);
+    p->rq_nodes_s[k] = (uint32_t*)alloc((size_t)W * cap * 4);
+    p->rq_ksum_s[k] = (uint32_t*)alloc((size_t)W * cap * 4);
+    p->rq_nodes_r[k] = (uint32_t*)alloc((size_t)W * cap * 4);
+    p->rq_ksum_r[k] = (uint32_t*)alloc((size_t)W * cap * 4);
+    p->resp_s[k] = (uint32_t*)alloc((size_t)W * cap * fanouts[k] * 4);
+    p->resp_r[k] = (uint32_t*)alloc((size_t)W * cap * fanouts[k] * 4);
+    p->slot_idx[k] = (int32_t*)alloc((size_t)W * cap * 4);
+    p->counts[k] = (int32_t*)alloc((size_t)(W + 1) * 4);
+    ok = p->tree.cnt[k] && p->tree.nbr[k] && p->child_ksum[k] && p->rq_nodes_s[k] && p->rq_ksum_s[k] &&
+         p->rq_nodes_r[k] && p->rq_ksum_r[k] && p->resp_s[k] && p->resp_r[k] && p->slot_idx[k] && p->counts[k];
+    if (parents >= ((int64_t)1 << 31)) return fail(GIGL_E_INVALID_ARG, "tree too large");
+  }
+  p->tree.hops = hops;
+  p->tree.b = b;
+  for (int k = 0; k < hops; ++k) p->tree.fanouts[k] = fanouts[k];
+  p->own_cnt = (int32_t*)alloc((size_t)max_served * 4);
+  // ---- union graph
+  int64_t cap_nodes = 0, cap_edges = 0;
+  gigl_union_capacity(b, fanouts, hops, &cap_nodes, &cap_edges);
+  p->un.meta = (int32_t*)alloc(GIGL_META_LEN * 4);
+  p->un.nodes = (uint32_t*)alloc((size_t)cap_nodes * 4);
+  p->un.rowptr = (int32_t*)alloc((size_t)(cap_nodes + 2) * 4);
+  p->un.rowend = (int32_t*)alloc((size_t)(cap_nodes + 2) * 4);
+  p->un.col = (int32_t*)alloc((size_t)cap_edges * 4);
+  p->un.root_local = (int32_t*)alloc((size_t)b * 4);
+  p->un.cap_nodes = cap_nodes;
+  p->un.cap_edges = cap_edges;
+  int64_t act_rows = 0, width = b;
+  for (int k = 0; k < hops; ++k) {
+    act_rows += width;
+    width *= fanouts[k];
+  }
+  p->act_rows = act_rows;
+  // ---- feature pull.  Rows are the expensive bytes: the bucket capacity per peer is the caller's bound when given
+  // (calibrated on warm-up steps, see GIGL_STATS_PULL_BUCKET_MAX), else the worst case / world + 10 %
+  int64_t pc = opts && opts->pull_cap > 0 ? opts->pull_cap : (int64_t)std::ceil((double)cap_nodes / (double)W * 1.1) + 512;
+  if (pc > cap_nodes) pc = cap_nodes;
+  p->pull_cap = pc;
+  p->row_bytes = p->project ? (int64_t)dims[1] * 4 : (int64_t)dims[0] * (shard_feat->dtype == GIGL_DTYPE_F32 ? 4 : 2);
+  p->ids_s = (uint32_t*)alloc((size_t)W * pc * 4);
+  p->ids_r = (uint32_t*)alloc((size_t)W * pc * 4);
+  p->pos = (int32_t*)alloc((size_t)cap_nodes * 4);
+  p->pull_counts = (int32_t*)alloc((size_t)(W + 1) * 4);
+  p->rows_s = alloc((size_t)W * pc * p->row_bytes);
+  p->rows_r = alloc((size_t)W * pc * p->row_bytes);
+  ok = ok && p->own_cnt && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col &&
+       p->un.root_local && p->ids_s && p->ids_r && p->pos && p->pull_counts && p->rows_s && p->rows_r;
+  p->n_entries_dev = (int32_t*)alloc(16);
+  if (p->project && ok) {
+    int64_t pcb = (int64_t)std::ceil((double)act_rows / (double)W * (W > 1 ? 1.25 : 1.0)) + 512;
+    if (pcb > act_rows) pcb = act_rows;
+    p->pull_cap_b = pcb;
+    p->idsb_s = (uint32_t*)alloc((size_t)W * pcb * 4);
+    p->idsb_r = (uint32_t*)alloc((size_t)W * pcb * 4);
+    p->posb = (int32_t*)alloc((size_t)act_rows * 4);
+    p->pullb_counts = (int32_t*)alloc((size_t)(W + 1) * 4);
+    p->rowsb_s = alloc((size_t)W * pcb * p->row_bytes);
+    p->rowsb_r = alloc((size_t)W * pcb * p->row_bytes);
+    p->stage = (float*)alloc((size_t)W * (pc > pcb ? pc : pcb) * dims[0] * 4);
+    p->wl0 = (float*)alloc((size_t)dims[1] * dims[0] * 4);
+    p->wr0 = (float*)alloc((size_t)dims[1] * dims[0] * 4);
+    ok = p->idsb_s && p->idsb_r && p->posb && p->pullb_counts && p->rowsb_s && p->rowsb_r && p->stage && p->wl0 &&
+         p->wr0;
+    if (ok && W * pc >= ((int64_t)1 << 31)) ok = false;
+  }
+  // ---- activations
+  const int64_t a_cols = 2 * (int64_t)(max_in > max_out ? max_in : max_out);
+  p->abuf = (float*)alloc((size_t)act_rows * a_cols * 4);
+  p->hbuf[0] = (float*)alloc((size_t)act_rows * max_out * 4);
+  p->hbuf[1] = hops > 1 ? (float*)alloc((size_t)act_rows * max_out * 4) : p->hbuf[0];
+  // ---- overflow flags of the step
+  std::vector<const int32_t*> flags;
+  for (int k = 0; k < hops; ++k) flags.push_back(p->counts[k] + W);
+  flags.push_back(p->pull_counts + W);
+  if (p->project) flags.push_back(p->pullb_counts + W);
+  p->n_flags = (int)flags.size();
+  p->flag_ptrs = (const int32_t**)alloc(flags.size() * sizeof(void*));
+  ok = ok && p->abuf && p->hbuf[0] && p->hbuf[1] && p->n_entries_dev && p->flag_ptrs;
+  if (!ok) return fail(GIGL_E_OOM, "hipMalloc of the sharded batch workspace failed");
+  const int32_t ne[2] = {(int32_t)(W * pc), (int32_t)(W * p->pull_cap_b)};
+  if (hipMemcpy(p->n_entries_dev, ne, sizeof(ne), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(p->flag_ptrs, flags.data(), flags.size() * sizeof(void*), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(GIGL_E_HIP, "uploading plan constants failed");
+  if (p->project) {
+    int32_t rc = split_w0(p);
+    if (rc != GIGL_OK) {
+      gigl_dist_plan_destroy(p);
+      return rc;
+    }
+    hipMemsetAsync(p->stage, 0, (size_t)W * (pc > p->pull_cap_b ? pc : p->pull_cap_b) * dims[0] * 4, ctx->stream);
+  }
+  hipMemsetAsync(p->rows_r, 0, (size_t)W * pc * p->row_bytes, ctx->stream);
+  hipStreamSynchronize(ctx->stream);
+  *out = p;
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_plan_set_weights(gigl_dist_plan* p, const float* const* w, const float* const* bias) {
+  if (!p || !w) return GIGL_E_INVALID_ARG;
+  for (int k = 0; k < p->hops; ++k) {
+    if (!w[k]) return gigl_fail(p->ctx, GIGL_E_INVALID_ARG, "weight %d is null", k);
+    p->w[k] = w[k];
+    p->bias[k] = bias ? bias[k] : nullptr;
+  }
+  return p->project ? split_w0(p) : GIGL_OK;
+}
+
+int32_t gigl_dist_plan_phases(gigl_dist_plan* p, int32_t* n) {
+  if (!p || !n) return GIGL_E_INVALID_ARG;
+  *n = n_phases(p);
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_plan_phase(gigl_dist_plan* p, int32_t phase, const uint32_t* roots, int32_t sampling_seed,
+                             float* out) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(p->ctx, roots && out && phase >= 0 && phase < n_phases(p), "bad phase arguments");
+  GIGL_HIP_CHECK(p->ctx, hipSetDevice(p->ctx->device));
+  return phase_impl(p, phase, roots, sampling_seed, out);
+}
+
+int32_t gigl_dist_plan_run(gigl_dist_plan* p, const uint32_t* roots, int32_t sampling_seed, float* out) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(p->ctx, roots && out, "null argument");
+  GIGL_REQUIRE(p->ctx, p->comm->kind != GIGL_COMM_LOCAL,
+               "ranks of an in-process group advance together: use gigl_dist_plan_run_local");
+  GIGL_HIP_CHECK(p->ctx, hipSetDevice(p->ctx->device));
+  for (int ph = 0; ph < n_phases(p); ++ph) {
+    int32_t rc = phase_impl(p, ph, roots, sampling_seed, out);
+    if (rc != GIGL_OK) return rc;
+  }
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_plan_run_local(gigl_dist_plan* const* plans, int32_t world, const uint32_t* const* roots,
+                                 int32_t sampling_seed, float* const* out) {
+  if (!plans || world < 1 || !plans[0]) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx0 = plans[0]->ctx;
+  GIGL_REQUIRE(ctx0, roots && out && plans[0]->comm->kind == GIGL_COMM_LOCAL && plans[0]->world == world,
+               "not the plans of one in-process group");
+  const int np = n_phases(plans[0]);
+  for (int ph = 0; ph < np; ++ph) {
+    for (int r = 0; r < world; ++r) {
+      GIGL_REQUIRE(ctx0, plans[r] && plans[r]->rank == r && plans[r]->comm->group == plans[0]->comm->group,
+                   "plans[r] must be rank r of the same in-process group");
+      int32_t rc = phase_impl(plans[r], ph, roots[r], sampling_seed, out[r]);
+      if (rc != GIGL_OK) {
+        if (plans[r]->ctx != ctx0) ctx0->err = plans[r]->ctx->err;
+        return rc;
+      }
+    }
+    if (ph + 1 < np) {
+      int32_t rc = gigl_comm_flush_local(plans[0]->comm);
+      if (rc != GIGL_OK) return rc;
+    }
+  }
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_plan_buffers(gigl_dist_plan* p, gigl_tree* tree, gigl_union* un) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  if (tree) *tree = p->tree;
+  if (un) *un = p->un;
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_plan_stats(gigl_dist_plan* p, int64_t* acc) {
+  if (!p || !acc) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  DistStatsArgs a{};
+  a.hops = p->hops;
+  int64_t most = p->b;
+  for (int k = 0; k < p->hops; ++k) {
+    a.cnt[k] = p->tree.cnt[k];
+    a.parents[k] = p->m[k];
+    if (p->m[k] > most) most = p->m[k];
+  }
+  a.meta = p->un.meta;
+  a.rowptr = p->un.rowptr;
+  a.rowend = p->un.rowend;
+  a.pull_counts = p->pull_counts;
+  a.world = p->world;
+  int64_t blocks = grid256(most);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(dist_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a, (unsigned long long*)acc);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+}  // extern "C"

@@ -20,6 +20,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 namespace {
@@ -752,12 +753,28 @@ __global__ void find_heavy_kernel(ExpandArgs a, uint64_t dom, int64_t* heavy_lis
   }
 }
 
+// The table is a function of the integer axis alone (not of the graph, the roots or the seed), so ONE table per device
+// serves every ctx of the process: ctxs hold a reference to the device's current table; a request beyond its domain
+// builds a larger one, which replaces it in the registry, and the old one is freed when the last ctx that still
+// points to it has moved on (a ctx only moves on after synchronising its own stream, so no kernel reads freed memory).
 struct TableOwner {
   RangeTable t{};
   void* mem = nullptr;
+  int device = 0;
+  int refs = 0;
 };
 
-// (re)build the ctx's range table so that it covers [0, want_dom)
+std::mutex g_table_mu;
+TableOwner* g_device_table[64] = {nullptr};
+
+void table_unref(TableOwner* own) {  // g_table_mu held
+  if (!own || --own->refs > 0) return;
+  if (g_device_table[own->device] == own) g_device_table[own->device] = nullptr;
+  if (own->mem) hipFree(own->mem);
+  delete own;
+}
+
+// make ctx->sampler_table a table that covers [0, want_dom)
 int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
   constexpr uint64_t S0 = 1ull << TBL_S0_SHIFT;
   constexpr uint64_t DOM_CAP = 1ull << 32;  // j is a uint32
@@ -765,15 +782,21 @@ int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
   want_dom = (want_dom + S0 - 1) / S0 * S0;
   TableOwner* own = (TableOwner*)ctx->sampler_table;
   if (own && own->t.dom >= want_dom) return GIGL_OK;
-  if (own) {
+  std::lock_guard<std::mutex> lock(g_table_mu);
+  if (own) {  // this ctx moves on to a larger table: its in-flight kernels still read the old one
     GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (own->mem) hipFree(own->mem);
-    own->mem = nullptr;
-    own->t = RangeTable{};
-  } else {
-    own = new TableOwner();
-    ctx->sampler_table = own;
+    table_unref(own);
+    ctx->sampler_table = nullptr;
   }
+  const int dev = ctx->device & 63;
+  TableOwner* shared = g_device_table[dev];
+  if (shared && shared->t.dom >= want_dom) {
+    ++shared->refs;
+    ctx->sampler_table = shared;
+    return GIGL_OK;
+  }
+  own = new TableOwner();
+  own->device = dev;
   // grow geometrically so that slightly larger requests do not rebuild
   uint64_t dom = want_dom + want_dom / 4;
   if (dom > DOM_CAP) dom = DOM_CAP;
@@ -793,7 +816,7 @@ int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
   const size_t arr_bytes = (size_t)total_blocks * TBL_TOPK * 4;
   const size_t total = 3 * arr_bytes;
   if (hipMalloc(&own->mem, total ? total : 256) != hipSuccess) {
-    own->mem = nullptr;
+    delete own;
     return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the %zu-byte hash range table failed", total);
   }
   uint32_t* khi = (uint32_t*)own->mem;
@@ -809,9 +832,18 @@ int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
     hipLaunchKernelGGL(table_up_kernel, dim3((unsigned)((t.nblocks[l] + 3) / 4)), dim3(256), 0, ctx->stream, khi + c,
                        klo + c, js + c, khi + q, klo + q, js + q, t.nblocks[l]);
   }
-  GIGL_HIP_CHECK(ctx, hipGetLastError());
-  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  hipError_t berr = hipGetLastError();
+  if (berr == hipSuccess) berr = hipStreamSynchronize(ctx->stream);
+  if (berr != hipSuccess) {
+    hipFree(own->mem);
+    delete own;
+    return gigl_fail(ctx, GIGL_E_HIP, "building the hash range table failed: %s", hipGetErrorString(berr));
+  }
   own->t = t;
+  own->refs = 1;  // this ctx
+  // the registry points to the largest table; earlier ones live on until their ctxs let go
+  g_device_table[dev] = own;
+  ctx->sampler_table = own;
   return GIGL_OK;
 }
 
@@ -905,11 +937,11 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(ExpandArgs a) {
 
 }  // namespace
 
-void gigl_sampler_table_free(gigl_ctx* ctx) {
+void gigl_sampler_table_free(gigl_ctx* ctx) {  // (the caller has synchronised the ctx stream)
   TableOwner* own = (TableOwner*)ctx->sampler_table;
   if (!own) return;
-  if (own->mem) hipFree(own->mem);
-  delete own;
+  std::lock_guard<std::mutex> lock(g_table_mu);
+  table_unref(own);
   ctx->sampler_table = nullptr;
 }
 

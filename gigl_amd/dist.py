@@ -17,6 +17,7 @@ rank's shard); tests on CPU plug in the oracle.  The exchange itself is backend-
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -24,6 +25,11 @@ import torch
 import torch.distributed as dist
 
 INVALID = 0xFFFFFFFF
+
+
+def _check(rc, ctx=None):
+    from ._lib import check
+    check(rc, ctx)
 
 
 def node_owner(ids: torch.Tensor, world: int) -> torch.Tensor:
@@ -250,6 +256,213 @@ class HipFeaturePuller:
         rows = self.serve(self.got, rc)
         back, _ = _all_to_all_v(rows, rc, self.group, recv_counts=sc)
         return self.place(back, sc, n_rows)
+
+
+class Comm:
+    """a communicator of the library (include/gigl_hip.h `gigl_comm`): the transport of the sharded plan's exchanges.
+    Comm.rccl: RCCL over xGMI (production; one per ctx); Comm.local: every rank of a world inside this process on one
+    device (tests / single-process drivers); Comm.callback: the caller moves the bytes (e.g. gloo through
+    torch.distributed — see torch_exchange)"""
+
+    def __init__(self, eng, handle, keep=None):
+        self.eng, self._h, self._keep = eng, handle, keep
+        rank, world, kind = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(eng._lib.gigl_comm_info(handle, C.byref(rank), C.byref(world), C.byref(kind)), eng._ctx)
+        self.rank, self.world, self.kind = rank.value, world.value, kind.value
+
+    @staticmethod
+    def unique_id() -> bytes:
+        from . import _lib
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _check(_lib.load().gigl_comm_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def rccl(eng, rank: int, world: int, unique_id: bytes) -> "Comm":
+        h = C.c_void_p()
+        _check(eng._lib.gigl_dist_init(eng._ctx, rank, world, C.c_char_p(unique_id), C.byref(h)), eng._ctx)
+        return Comm(eng, h)
+
+    @staticmethod
+    def rccl_from_torch(eng, group=None) -> "Comm":
+        """RCCL communicator for the ranks of a torch.distributed group: rank 0's id travels through the group"""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [Comm.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return Comm.rccl(eng, rank, world, box[0])
+
+    @staticmethod
+    def local(engines) -> List["Comm"]:
+        world = len(engines)
+        ctxs = (C.c_void_p * world)(*[e._ctx for e in engines])
+        out = (C.c_void_p * world)()
+        _check(engines[0]._lib.gigl_dist_init_local(ctxs, world, out), engines[0]._ctx)
+        return [Comm(engines[r], C.c_void_p(out[r])) for r in range(world)]
+
+    @staticmethod
+    def callback(eng, rank: int, world: int, fn: Callable[[int, int, int], None]) -> "Comm":
+        """fn(send_ptr, recv_ptr, bytes_per_peer) with DEVICE addresses; exceptions fail the exchange"""
+        from . import _lib
+
+        def tramp(_user, send, recv, nbytes):
+            try:
+                fn(send, recv, nbytes)
+                return 0
+            except Exception:  # noqa: BLE001 — reported through the C status
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = _lib.EXCHANGE_FN(tramp)
+        h = C.c_void_p()
+        _check(eng._lib.gigl_dist_init_callback(eng._ctx, rank, world, cb, None, C.byref(h)), eng._ctx)
+        return Comm(eng, h, keep=cb)
+
+    def all_to_all(self, send: torch.Tensor, recv: torch.Tensor) -> None:
+        assert send.is_cuda and recv.is_cuda and send.is_contiguous() and recv.is_contiguous()
+        nbytes = send.numel() * send.element_size()
+        assert nbytes == recv.numel() * recv.element_size() and nbytes % self.world == 0
+        _check(self.eng._lib.gigl_comm_all_to_all(self._h, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()),
+                                                  nbytes // self.world), self.eng._ctx)
+
+    def flush_local(self) -> None:
+        _check(self.eng._lib.gigl_comm_flush_local(self._h), self.eng._ctx)
+
+    def close(self) -> None:
+        if self._h:
+            self.eng._lib.gigl_comm_destroy(self._h)
+            self._h = None
+
+
+def torch_exchange(eng, group=None) -> Callable[[int, int, int], None]:
+    """Comm.callback transport over a torch.distributed group of ANY backend: blocks are staged through host
+    memory (gloo) — a test / fallback transport, the production one is Comm.rccl"""
+    world = dist.get_world_size(group)
+
+    def fn(send_ptr, recv_ptr, nbytes):
+        from ._lib import LOC_DEVICE, LOC_HOST
+        total = nbytes * world
+        hs = np.empty(total, dtype=np.uint8)
+        _check(eng._lib.gigl_memcpy(eng._ctx, C.c_void_p(hs.ctypes.data), LOC_HOST, C.c_void_p(send_ptr), LOC_DEVICE,
+                                    total), eng._ctx)
+        ts, tr = torch.from_numpy(hs), torch.empty(total, dtype=torch.uint8)
+        dist.all_to_all_single(tr, ts, group=group) if dist.get_backend(group) != "gloo" else _gloo_all_to_all(tr, ts, world, group)
+        hr = tr.numpy()
+        _check(eng._lib.gigl_memcpy(eng._ctx, C.c_void_p(recv_ptr), LOC_DEVICE, C.c_void_p(hr.ctypes.data), LOC_HOST,
+                                    total), eng._ctx)
+    return fn
+
+
+def _gloo_all_to_all(out: torch.Tensor, inp: torch.Tensor, world: int, group=None) -> None:
+    """all_to_all over gloo (which has no all_to_all_single for every build): pairwise isend / irecv"""
+    rank = dist.get_rank(group)
+    n = inp.numel() // world
+    reqs = []
+    for p in range(world):
+        if p == rank:
+            out[p * n:(p + 1) * n] = inp[p * n:(p + 1) * n]
+            continue
+        reqs.append(dist.isend(inp[p * n:(p + 1) * n].contiguous(), dst=p, group=group))
+        reqs.append(dist.irecv(out[p * n:(p + 1) * n], src=p, group=group))
+    for r in reqs:
+        r.wait()
+
+
+class DistSagePlan:
+    """the sharded batch plan (include/gigl_hip.h `gigl_dist_plan_*`): sample over the hash-partitioned graph ->
+    union graph -> feature pull -> GraphSAGE forward -> one row per root, every exchange issued by the library.
+    `eng` holds THIS rank's shard: load_csc(partition_csc(...)) and load_features(partition_rows(...))."""
+
+    def __init__(self, comm: Comm, weights, biases, b: int, fanouts: Sequence[int], act_last: bool = False,
+                 group_roots: Optional[int] = None, project_on_owner: bool = False, pull_cap: int = 0,
+                 hop_slack: float = 0.0, max_window_end: int = -1):
+        from . import _lib
+        eng = comm.eng
+        assert eng._graph is not None and eng._feat is not None, "load this rank's shard first"
+        L = len(fanouts)
+        self.comm, self.eng, self.b, self.fanouts = comm, eng, int(b), [int(f) for f in fanouts]
+        self.dims = [int(weights[0].shape[1]) // 2] + [int(w.shape[0]) for w in weights]
+        self._lib = eng._lib
+        self._plan = C.c_void_p()
+        w_arr, b_arr = self._ptr_arrays(weights, biases)
+        o = _lib.GiglDistPlanOpts()
+        o.group_roots = int(group_roots or b)
+        o.project_on_owner = 1 if project_on_owner else 0
+        o.pull_cap, o.hop_slack, o.max_window_end = int(pull_cap), float(hop_slack), int(max_window_end)
+        fo = (C.c_int32 * L)(*self.fanouts)
+        dims = (C.c_int32 * (L + 1))(*self.dims)
+        _check(self._lib.gigl_dist_plan_create(comm._h, eng._graph, eng._feat, self.b, fo, L, dims, w_arr, b_arr,
+                                               1 if act_last else 0, C.byref(o), C.byref(self._plan)), eng._ctx)
+        n = C.c_int32()
+        _check(self._lib.gigl_dist_plan_phases(self._plan, C.byref(n)), eng._ctx)
+        self.n_phases = n.value
+
+    def _ptr_arrays(self, weights, biases):
+        L = len(weights)
+        ws = [w.detach().to(device=self.eng.device, dtype=torch.float32).contiguous() for w in weights]
+        bs = [None if x is None else x.detach().to(device=self.eng.device, dtype=torch.float32).contiguous()
+              for x in biases]
+        self._keep = (ws, bs)  # the plan borrows these device buffers
+        return ((C.c_void_p * L)(*[w.data_ptr() for w in ws]),
+                (C.c_void_p * L)(*[(x.data_ptr() if x is not None else None) for x in bs]))
+
+    def set_weights(self, weights, biases) -> None:
+        w_arr, b_arr = self._ptr_arrays(weights, biases)
+        _check(self._lib.gigl_dist_plan_set_weights(self._plan, w_arr, b_arr), self.eng._ctx)
+
+    def new_out(self) -> torch.Tensor:
+        return torch.empty((self.b, self.dims[-1]), dtype=torch.float32, device=self.eng.device)
+
+    def run(self, roots: torch.Tensor, out: Optional[torch.Tensor] = None, sampling_seed: int = 42) -> torch.Tensor:
+        assert roots.is_cuda and roots.dtype == torch.int32 and roots.numel() == self.b and roots.is_contiguous()
+        out = out if out is not None else self.new_out()
+        _check(self._lib.gigl_dist_plan_run(self._plan, C.c_void_p(roots.data_ptr()), sampling_seed,
+                                            C.c_void_p(out.data_ptr())), self.eng._ctx)
+        return out
+
+    @staticmethod
+    def run_local(plans: Sequence["DistSagePlan"], roots: Sequence[torch.Tensor],
+                  outs: Optional[Sequence[torch.Tensor]] = None, sampling_seed: int = 42):
+        """one step of every rank of an in-process group (Comm.local), phase by phase"""
+        world = len(plans)
+        outs = list(outs) if outs is not None else [p.new_out() for p in plans]
+        pa = (C.c_void_p * world)(*[p._plan for p in plans])
+        ra = (C.c_void_p * world)(*[r.data_ptr() for r in roots])
+        oa = (C.c_void_p * world)(*[o.data_ptr() for o in outs])
+        _check(plans[0]._lib.gigl_dist_plan_run_local(pa, world, ra, sampling_seed, oa), plans[0].eng._ctx)
+        return outs
+
+    def stats(self, acc: torch.Tensor) -> None:
+        assert acc.is_cuda and acc.dtype == torch.int64 and acc.numel() >= 16
+        _check(self._lib.gigl_dist_plan_stats(self._plan, C.c_void_p(acc.data_ptr())), self.eng._ctx)
+
+    def buffers_to_host(self):
+        """host copies of the last step's tree and union graph (like SagePlan.last_batch_to_host)"""
+        from ._lib import GIGL_META_LEN, GiglTree, GiglUnion, LOC_DEVICE, LOC_HOST
+        t, u = GiglTree(), GiglUnion()
+        _check(self._lib.gigl_dist_plan_buffers(self._plan, C.byref(t), C.byref(u)), self.eng._ctx)
+
+        def d2h(ptr, n, dtype):
+            a = np.empty(n, dtype=dtype)
+            if n:
+                _check(self._lib.gigl_memcpy(self.eng._ctx, C.c_void_p(a.ctypes.data), LOC_HOST, C.c_void_p(ptr),
+                                             LOC_DEVICE, a.nbytes), self.eng._ctx)
+            return a
+        nbr, cnt, parents = [], [], self.b
+        for k, f in enumerate(self.fanouts):
+            cnt.append(d2h(t.cnt[k], parents, np.int32))
+            parents *= f
+            nbr.append(d2h(t.nbr[k], parents, np.uint32))
+        meta = d2h(u.meta, GIGL_META_LEN, np.int32)
+        nn = int(meta[0])
+        return dict(nbr=nbr, cnt=cnt, meta=meta, nodes=d2h(u.nodes, nn, np.uint32),
+                    rowptr=d2h(u.rowptr, nn + 1, np.int32), rowend=d2h(u.rowend, nn + 1, np.int32),
+                    col=d2h(u.col, int(u.cap_edges), np.int32), root_local=d2h(u.root_local, self.b, np.int32))
+
+    def close(self) -> None:
+        if getattr(self, "_plan", None):
+            self._lib.gigl_dist_plan_destroy(self._plan)
+            self._plan = None
 
 
 def hip_expand(eng, world: int, max_window_end: int = -1) -> Callable:

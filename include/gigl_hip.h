@@ -596,6 +596,84 @@ int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
 int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);
 
+/* ---- the hash-partitioned (multi-GPU) step inside the library.
+ *      Replaces the reference's distributed loader path: DistLinkPredictionDataPartitioner (owner(v) = v % world,
+ *      python/gigl/distributed/dist_link_prediction_data_partitioner.py:692-695) + DistNeighborLoader's per-batch RPC
+ *      fan-out to the partitions' sampling workers (python/gigl/distributed/distributed_neighborloader.py:26-192) and
+ *      the feature lookup that follows — here one process per GPU, the exchanges are equal-split all-to-alls issued
+ *      from C++ on the ctx stream, and nothing in a step reads device memory from the host.
+ *
+ * Communicators.  A gigl_comm belongs to ONE ctx (its stream carries the exchanges).
+ *   gigl_comm_unique_id   rank 0 creates the 128-byte RCCL id; the caller hands it to the other ranks (its own
+ *                         channel: torch.distributed store, MPI, a file)
+ *   gigl_dist_init        RCCL communicator (librccl is opened at run time; GIGL_E_UNSUPPORTED when absent)
+ *   gigl_dist_init_local  every rank of a world is a ctx of THIS process (same device, same stream): exchanges are
+ *                         device copies, performed when all ranks have registered theirs (gigl_comm_flush_local);
+ *                         ranks advance phase by phase (gigl_dist_plan_run_local) — tests, single-process drivers
+ *   gigl_dist_init_callback  the caller moves the bytes (MPI, gloo, ...): fn(user, send, recv, bytes_per_peer) gets
+ *                         DEVICE pointers ([world][bytes_per_peer] each) after the stream was synchronised, returns 0
+ *   gigl_comm_all_to_all  block p of `send` goes to rank p, block r of `recv` comes from rank r */
+#define GIGL_COMM_RCCL 0
+#define GIGL_COMM_LOCAL 1
+#define GIGL_COMM_CALLBACK 2
+#define GIGL_COMM_ID_BYTES 128
+typedef struct gigl_comm gigl_comm;
+typedef int32_t (*gigl_exchange_fn)(void* user, const void* send, void* recv, int64_t bytes_per_peer);
+int32_t gigl_comm_unique_id(void* id /* HOST [GIGL_COMM_ID_BYTES] */);
+int32_t gigl_dist_init(gigl_ctx* ctx, int32_t rank, int32_t world, const void* rccl_unique_id, gigl_comm** out);
+int32_t gigl_dist_init_local(gigl_ctx* const* ctxs, int32_t world, gigl_comm** out /* [world] */);
+int32_t gigl_dist_init_callback(gigl_ctx* ctx, int32_t rank, int32_t world, gigl_exchange_fn fn, void* user,
+                                gigl_comm** out);
+int32_t gigl_comm_info(gigl_comm* comm, int32_t* rank, int32_t* world, int32_t* kind);
+int32_t gigl_comm_all_to_all(gigl_comm* comm, const void* send, void* recv, int64_t bytes_per_peer);
+int32_t gigl_comm_flush_local(gigl_comm* any_member);
+int32_t gigl_comm_destroy(gigl_comm* comm);
+
+/* The sharded batch plan: gigl_sage_plan's step on a hash-partitioned graph.  `shard` holds the CSC rows of the nodes
+ * this rank owns (row v / world, ids inside rows global), `shard_feat` their feature rows (row v / world).  A step =
+ * 2*hops + 3 phases; every phase but the last ends in an exchange:
+ *   2k    requester: scatter hop k-1's answers into the tree, bucket hop k's frontier by owner  -> (ids, path sums)
+ *   2k+1  owner: gigl_expand_frontier over the requests of every peer                           -> f ids per request
+ *   2L    requester: last scatter, gigl_union_build_groups, bucket the union graph's node ids   -> ids
+ *   2L+1  owner: the requested feature rows gathered straight into the send buffer              -> rows
+ *   2L+2  requester: GraphSAGE forward over the union graph (first layer reads the rows where they arrived), out[b]
+ * Buckets have fixed capacities, so no count ever travels and the host never reads the device: hop buckets hold
+ * ceil(m/world * (1 + hop_slack)) + 512 requests per peer (8 B each), the row buckets pull_cap rows per peer (0: the
+ * worst case / world + 10 %; tune it with GIGL_STATS_PULL_BUCKET_MAX from warm-up steps — rows are the bytes that
+ * matter on xGMI).  A bucket that overflows fails the batch: meta[GIGL_META_OVERFLOW] != 0, levels zeroed.
+ * project_on_owner: the owners apply the first layer's weights before sending — lin_l's for every requested node, lin_r's
+ * for the nodes of level < hops — so dims[1] fp32 travel per row instead of the raw row (exact up to fp32 rounding:
+ * lin_l(mean_j x_j) == mean_j lin_l(x_j)); pays when dims[1]*4 < the raw row bytes and the links, not the MFMAs, bound
+ * the step.  max_window_end: see gigl_expand_frontier.  Same weights layout as gigl_sage_plan_create. */
+typedef struct gigl_dist_plan gigl_dist_plan;
+typedef struct gigl_dist_plan_opts {
+  int32_t group_roots;       /* roots per independent batch (0: b) */
+  int32_t project_on_owner;
+  int64_t pull_cap;          /* feature rows per peer and step (0: default bound) */
+  float hop_slack;           /* 0: 0.5 */
+  int64_t max_window_end;    /* -1: unknown */
+} gigl_dist_plan_opts;
+int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
+                              const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,
+                              const float* const* bias, int32_t act_last, const gigl_dist_plan_opts* opts,
+                              gigl_dist_plan** out);
+int32_t gigl_dist_plan_set_weights(gigl_dist_plan* plan, const float* const* w, const float* const* bias);
+int32_t gigl_dist_plan_phases(gigl_dist_plan* plan, int32_t* n);
+int32_t gigl_dist_plan_phase(gigl_dist_plan* plan, int32_t phase, const uint32_t* roots, int32_t sampling_seed,
+                             float* out);
+/* all phases of one step on an RCCL / callback communicator */
+int32_t gigl_dist_plan_run(gigl_dist_plan* plan, const uint32_t* roots, int32_t sampling_seed, float* out);
+/* one step of every rank of an in-process group, phase by phase; plans[r] = rank r's plan */
+int32_t gigl_dist_plan_run_local(gigl_dist_plan* const* plans, int32_t world, const uint32_t* const* roots,
+                                 int32_t sampling_seed, float* const* out);
+int32_t gigl_dist_plan_buffers(gigl_dist_plan* plan, gigl_tree* tree, gigl_union* un);
+/* like gigl_sage_plan_stats for the step run last, plus the feature rows requested (PULLED_ROWS, summed) and the
+ * fullest row bucket seen (PULL_BUCKET_MAX, a running maximum) */
+#define GIGL_STATS_PULLED_ROWS 14
+#define GIGL_STATS_PULL_BUCKET_MAX 15
+int32_t gigl_dist_plan_stats(gigl_dist_plan* plan, int64_t* acc);
+int32_t gigl_dist_plan_destroy(gigl_dist_plan* plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,235 @@
+"""The sharded batch plan (gigl_dist_plan_*: every exchange issued by the library) end to end.
+
+  * every rank of a 2- and 8-rank world played inside one process (in-process communicator group): the sampled
+    trees are bit-identical to the oracle on the WHOLE graph and the root embeddings match oracle + gnn_ref
+    (sample -> collate -> fp32 forward over the whole union graph) to 1e-5 — raw-row pull and owner-side projection;
+  * the same step over a 1-rank RCCL communicator on the test GPU;
+  * two PROCESSES sharing the test GPU, exchanging through the callback transport over gloo (the production C++
+    path crossing a real process boundary on a 1-GPU box);
+  * two RCCL ranks on two GPUs (self-skips below 2 devices)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import rmat_edges
+from oracle import gnn_ref
+
+pytestmark = pytest.mark.gpu
+
+N, D, HID, OUT = 1 << 12, 24, 32, 16
+FAN = [6, 4]
+
+
+def make_graph():
+    s, d = rmat_edges(12, 60000, seed=77)
+    rowptr, col = oracle.build_csc(N, s, d, is_directed=False)
+    x = np.random.default_rng(5).standard_normal((N, D)).astype(np.float32)
+    return rowptr, col, x
+
+
+def make_model():
+    from gigl_amd.models import GraphSAGE
+    torch.manual_seed(11)
+    return GraphSAGE(D, HID, OUT, num_layers=len(FAN))
+
+
+def reference_rows(rowptr, col, x, model, roots, group_roots):
+    """oracle sample -> oracle collate -> fp32 forward over the whole union graph, batch by batch"""
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    rows = []
+    for g0 in range(0, roots.size, group_roots):
+        rs = roots[g0:g0 + group_roots]
+        nbr, _ = oracle.sample_khop(rowptr, col, rs, FAN, canonical=True)
+        u = oracle.union_build(rs, FAN, nbr)
+        xs = torch.from_numpy(x[u["nodes"].astype(np.int64)].astype(np.float32))
+        out = gnn_ref.graphsage_forward(xs, gnn_ref.union_edge_index(u["rowptr"], u["col"]), sd, len(FAN))
+        rows.append(out[torch.from_numpy(u["root_local"].astype(np.int64))])
+    return torch.cat(rows).numpy()
+
+
+def shard_engine(rowptr, col, x, rank, world, dtype, stream=None):
+    from gigl_amd.dist import partition_csc, partition_rows
+    from gigl_amd.engine import HipEngine
+    e = HipEngine(0)
+    if stream is not None:
+        e.bind_stream(stream)
+    e.load_csc(*partition_csc(rowptr, col, rank, world))
+    e.load_features(torch.from_numpy(partition_rows(x, rank, world)).to(dtype))
+    return e
+
+
+def rank_roots(rank, b):
+    r = np.random.default_rng(100 + rank).integers(0, N, size=b).astype(np.uint32)
+    r[3] = r[0]  # a repeated root
+    return r
+
+
+def bound_for(rowptr):
+    return int(3 * N + 42 * 2 + np.diff(rowptr).max())
+
+
+@pytest.mark.parametrize("world,project,dtype", [(2, False, torch.float32), (8, False, torch.float16),
+                                                 (2, True, torch.float32), (8, True, torch.float16),
+                                                 (3, True, torch.float32)])
+def test_all_ranks_in_one_process_end_to_end(world, project, dtype):
+    from gigl_amd.dist import Comm, DistSagePlan
+    rowptr, col, x = make_graph()
+    xq = x.astype(np.float16).astype(np.float32) if dtype == torch.float16 else x  # what the shards really hold
+    model = make_model()
+    w, bs = model.fused_params()
+    b, gr = 96, 32
+    st = torch.cuda.Stream()
+    engs = [shard_engine(rowptr, col, x, r, world, dtype, st) for r in range(world)]
+    comms = Comm.local(engs)
+    plans = [DistSagePlan(comms[r], w, bs, b, FAN, group_roots=gr, project_on_owner=project,
+                          max_window_end=bound_for(rowptr)) for r in range(world)]
+    roots = [rank_roots(r, b) for r in range(world)]
+    roots_d = [torch.from_numpy(r.view(np.int32)).to(engs[0].device) for r in roots]
+    for _ in range(2):  # twice: buffers are reused step to step
+        outs = DistSagePlan.run_local(plans, roots_d)
+    st.synchronize()
+    for r in range(world):
+        hb = plans[r].buffers_to_host()
+        assert hb["meta"][8] == 0, "bucket overflow"
+        nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots[r], FAN, canonical=True)
+        for k in range(len(FAN)):
+            assert np.array_equal(hb["nbr"][k], nbr_o[k]), (r, k)
+            assert np.array_equal(hb["cnt"][k], cnt_o[k]), (r, k)
+        want = reference_rows(rowptr, col, xq, model, roots[r], gr)
+        np.testing.assert_allclose(outs[r].cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    acc = torch.zeros(16, dtype=torch.int64, device=engs[0].device)
+    with torch.cuda.stream(st):
+        plans[0].stats(acc)
+    st.synchronize()
+    a = acc.cpu().numpy()
+    nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots[0], FAN, canonical=True)
+    assert a[0] == sum(int(c.sum()) for c in cnt_o) and a[13] == 0 and a[14] > 0 and a[15] > 0
+    for p in plans:
+        p.close()
+    for c in comms:
+        c.close()
+    for e in engs:
+        e.close()
+
+
+def test_pull_bucket_overflow_is_reported():
+    """a row bucket too small for the step fails the batch loudly (meta[GIGL_META_OVERFLOW]) instead of computing on
+    missing rows"""
+    from gigl_amd.dist import Comm, DistSagePlan
+    rowptr, col, x = make_graph()
+    model = make_model()
+    w, bs = model.fused_params()
+    st = torch.cuda.Stream()
+    engs = [shard_engine(rowptr, col, x, r, 2, torch.float32, st) for r in range(2)]
+    comms = Comm.local(engs)
+    plans = [DistSagePlan(comms[r], w, bs, 64, FAN, pull_cap=8, max_window_end=bound_for(rowptr)) for r in range(2)]
+    roots_d = [torch.from_numpy(rank_roots(r, 64).view(np.int32)).to(engs[0].device) for r in range(2)]
+    DistSagePlan.run_local(plans, roots_d)
+    st.synchronize()
+    assert plans[0].buffers_to_host()["meta"][8] != 0
+    for p in plans:
+        p.close()
+    for c in comms:
+        c.close()
+    for e in engs:
+        e.close()
+
+
+def test_single_rank_rccl():
+    from gigl_amd.dist import Comm, DistSagePlan
+    rowptr, col, x = make_graph()
+    model = make_model()
+    w, bs = model.fused_params()
+    st = torch.cuda.Stream()
+    eng = shard_engine(rowptr, col, x, 0, 1, torch.float32, st)
+    comm = Comm.rccl(eng, 0, 1, Comm.unique_id())
+    roots = rank_roots(0, 64)
+    for project in (False, True):
+        plan = DistSagePlan(comm, w, bs, 64, FAN, project_on_owner=project, max_window_end=bound_for(rowptr))
+        out = plan.run(torch.from_numpy(roots.view(np.int32)).to(eng.device))
+        st.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), reference_rows(rowptr, col, x, model, roots, 64), rtol=1e-5,
+                                   atol=1e-5)
+        plan.close()
+    # the communicator alone: an all-to-all with itself is a copy
+    a = torch.arange(1024, dtype=torch.int32, device=eng.device)
+    bb = torch.zeros_like(a)
+    with torch.cuda.stream(st):
+        comm.all_to_all(a, bb)
+    st.synchronize()
+    assert torch.equal(a, bb)
+    comm.close()
+    eng.close()
+
+
+def _worker(rank, world, port, transport, q):
+    try:
+        import torch.distributed as dist
+        from gigl_amd.dist import Comm, DistSagePlan, torch_exchange
+        dev_idx = rank if transport == "rccl" else 0
+        torch.cuda.set_device(dev_idx)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        rowptr, col, x = make_graph()
+        model = make_model()
+        w, bs = model.fused_params()
+        from gigl_amd.dist import partition_csc, partition_rows
+        from gigl_amd.engine import HipEngine
+        eng = HipEngine(dev_idx)
+        st = torch.cuda.Stream(device=eng.device)
+        eng.bind_stream(st)
+        eng.load_csc(*partition_csc(rowptr, col, rank, world))
+        eng.load_features(torch.from_numpy(partition_rows(x, rank, world)))
+        comm = Comm.rccl_from_torch(eng) if transport == "rccl" else Comm.callback(eng, rank, world, torch_exchange(eng))
+        roots = rank_roots(rank, 64)
+        worst = 0.0
+        for project in (False, True):
+            plan = DistSagePlan(comm, w, bs, 64, FAN, group_roots=32, project_on_owner=project,
+                                max_window_end=bound_for(rowptr))
+            out = plan.run(torch.from_numpy(roots.view(np.int32)).to(eng.device))
+            st.synchronize()
+            hb = plan.buffers_to_host()
+            nbr_o, _ = oracle.sample_khop(rowptr, col, roots, FAN, canonical=True)
+            assert hb["meta"][8] == 0 and all(np.array_equal(hb["nbr"][k], nbr_o[k]) for k in range(len(FAN)))
+            want = reference_rows(rowptr, col, x, model, roots, 32)
+            worst = max(worst, float(np.abs(out.cpu().numpy() - want).max()))
+            plan.close()
+        dist.barrier()
+        comm.close()
+        eng.close()
+        dist.destroy_process_group()
+        q.put((rank, "ok", worst))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc() + repr(e)))
+
+
+def _spawn(world, transport):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 150
+    procs = [ctx.Process(target=_worker, args=(r, world, port, transport, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in range(world):
+        res.append(q.get(timeout=300))
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    for rank, status, info in res:
+        assert status == "ok", f"rank {rank}: {info}"
+        assert info < 1e-5, (rank, info)
+
+
+def test_two_processes_one_gpu_callback_transport_over_gloo():
+    _spawn(2, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the build boxes have one)")
+def test_two_rccl_ranks_on_two_gpus():
+    _spawn(2, "rccl")

@@ -17,49 +17,103 @@ LABELS = torch.eye(4, 6)
 MINF = torch.finfo(torch.float).min
 
 
-def test_mask_by_query_ids():
-    got = RetrievalLoss()._mask_by_query_ids(QUERY_IDS, 4, 6, torch.float32)
-    want = torch.tensor([[1., 1, 0, 0, 0, 0], [1, 1, 0, 0, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 1, 1, 0, 0]])
-    assert torch.allclose(got, want)
+def _masked(loss, scores, **kw):
+    """the masked logits the fused kernel feeds to the cross-entropy (what the reference builds as tensors)"""
+    got = {}
+
+    class Capture(torch.nn.Module):
+        def forward(self, inp, target):
+            got["logits"], got["target"] = inp.detach().cpu(), target.detach().cpu()
+            return inp.sum() * 0
+
+    probe = RetrievalLoss(loss=Capture(), temperature=loss._temperature,
+                          remove_accidental_hits=loss._remove_accidental_hits)
+    probe.calculate_batch_retrieval_loss(scores, **kw)
+    return got["logits"], got["target"]
 
 
-def test_mask_by_candidate_ids():
-    got = RetrievalLoss()._mask_by_candidate_ids(CAND_IDS, 4, torch.float32)
-    want = torch.tensor([[1., 0, 0, 0, 1, 0], [0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0]])
-    assert torch.allclose(got, want)
+@pytest.mark.gpu
+def test_masks_match_the_reference_tests():
+    """loss_test.py:61-113: the duplicate masks by query id and by candidate id, read off the masked logits"""
+    dev = torch.device("cuda", 0)
+    scores = torch.mm(Q, CAND.T).to(dev)
+    logits, target = _masked(RetrievalLoss(), scores, query_ids=QUERY_IDS.to(dev))
+    assert torch.equal(target, LABELS)
+    want_q = torch.tensor([[1., 1, 0, 0, 0, 0], [1, 1, 0, 0, 0, 0], [0, 0, 1, 1, 0, 0], [0, 0, 1, 1, 0, 0]])
+    assert torch.equal((logits < -1e30).float(), want_q - LABELS)  # masked = duplicates minus the positive itself
+    logits, _ = _masked(RetrievalLoss(remove_accidental_hits=True), scores, candidate_ids=CAND_IDS.to(dev))
+    want_c = torch.tensor([[1., 0, 0, 0, 1, 0], [0, 1, 0, 0, 0, 0], [0, 0, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0]])
+    assert torch.equal((logits < -1e30).float(), want_c - LABELS)
+    assert torch.allclose(logits[logits > -1e30], scores.cpu()[logits > -1e30])
 
 
+@pytest.mark.gpu
 def test_loss_values():
-    scores = torch.mm(Q, CAND.T)
+    """loss_test.py:115-166 known answers, on the device"""
+    dev = torch.device("cuda", 0)
+    scores = torch.mm(Q, CAND.T).to(dev)
     e1 = torch.tensor([[0.8321, 0.8647, 0.0, 0.0, 0.6748, 0.7376], [0.8321, 0.8647, 0.0, 0.0, 0.6748, 0.7376],
                        [0.0, 0.1191, 0.8754, 0.9644, 0.7355, 0.6699], [0.0, 0.1191, 0.8754, 0.9644, 0.7355, 0.6699]])
-    a1 = RetrievalLoss(remove_accidental_hits=False).calculate_batch_retrieval_loss(scores)
+    a1 = RetrievalLoss(remove_accidental_hits=False).calculate_batch_retrieval_loss(scores).cpu()
     assert torch.isclose(F.cross_entropy(e1, LABELS, reduction="sum"), a1, atol=1e-3)
     loss = RetrievalLoss(remove_accidental_hits=True)
     e2 = e1.clone()
     e2[0, 4] = MINF
-    a2 = loss.calculate_batch_retrieval_loss(scores, candidate_ids=CAND_IDS)
+    a2 = loss.calculate_batch_retrieval_loss(scores, candidate_ids=CAND_IDS.to(dev)).cpu()
     assert torch.isclose(F.cross_entropy(e2, LABELS, reduction="sum"), a2, atol=1e-3)
     e3 = e2.clone()
     e3[0, 1] = e3[1, 0] = e3[2, 3] = e3[3, 2] = MINF
-    a3 = loss.calculate_batch_retrieval_loss(scores, candidate_ids=CAND_IDS, query_ids=QUERY_IDS)
+    a3 = loss.calculate_batch_retrieval_loss(scores, candidate_ids=CAND_IDS.to(dev), query_ids=QUERY_IDS.to(dev)).cpu()
     assert torch.isclose(F.cross_entropy(e3, LABELS, reduction="sum"), a3, atol=1e-3)
     assert a3 < a2 < a1 + 1e-6  # masking other positives / accidental hits can only lower the loss
     with pytest.raises(ValueError):
         loss.calculate_batch_retrieval_loss(scores)  # accidental-hit removal needs candidate ids
-    with pytest.raises(ValueError):
-        RetrievalLoss(temperature=1e-13)
-    t = RetrievalLoss(temperature=0.07).calculate_batch_retrieval_loss(scores)
-    assert torch.isclose(t, F.cross_entropy(scores / 0.07, LABELS, reduction="sum"))
+    t = RetrievalLoss(temperature=0.07).calculate_batch_retrieval_loss(scores).cpu()
+    assert torch.isclose(t, F.cross_entropy(scores.cpu() / 0.07, LABELS, reduction="sum"), rtol=1e-5)
+    # sampled-softmax correction (loss.py:240-246) against the same algebra in torch
+    prob = torch.tensor([0.5, 0.25, 1e-12, 0.125, 0.0625, 0.03125])
+    c = RetrievalLoss().calculate_batch_retrieval_loss(scores, candidate_sampling_probability=prob.to(dev)).cpu()
+    want = F.cross_entropy(scores.cpu() - torch.log(torch.clamp(prob, min=1e-10)), LABELS, reduction="sum")
+    assert torch.isclose(c, want, rtol=1e-5)
     # the oracle's row-by-row restatement is pinned on the same known answers
     from oracle import gnn_ref
-    o2 = gnn_ref.retrieval_loss_rows(scores, list(range(4)), CAND_IDS.tolist(), temperature=1.0)
+    sc = scores.cpu()
+    o2 = gnn_ref.retrieval_loss_rows(sc, list(range(4)), CAND_IDS.tolist(), temperature=1.0)
     assert torch.isclose(F.cross_entropy(e2, LABELS, reduction="sum"), o2, atol=1e-3)
-    o3 = gnn_ref.retrieval_loss_rows(scores, QUERY_IDS.tolist(), CAND_IDS.tolist(), temperature=1.0)
+    o3 = gnn_ref.retrieval_loss_rows(sc, QUERY_IDS.tolist(), CAND_IDS.tolist(), temperature=1.0)
     assert torch.isclose(F.cross_entropy(e3, LABELS, reduction="sum"), o3, atol=1e-3) and torch.isclose(o3, a3)
-    o1 = gnn_ref.retrieval_loss_rows(scores, list(range(4)), CAND_IDS.tolist(), temperature=1.0,
+    o1 = gnn_ref.retrieval_loss_rows(sc, list(range(4)), CAND_IDS.tolist(), temperature=1.0,
                                      remove_accidental_hits=False)
     assert torch.isclose(o1, a1)
+
+
+@pytest.mark.gpu
+def test_fused_loss_matches_the_oracle_and_autograd_at_size():
+    """random [Q, C] scores with colliding ids: value vs the oracle's row-by-row restatement, gradient vs torch
+    autograd through the same masked cross-entropy"""
+    from oracle import gnn_ref
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(3)
+    q, c = 37, 301
+    scores = torch.randn(q, c, generator=g)
+    qid = torch.randint(0, 12, (q,), generator=g)
+    cid = torch.randint(0, 60, (c,), generator=g)
+    loss = RetrievalLoss(temperature=0.07, remove_accidental_hits=True)
+    s_dev = scores.to(dev).requires_grad_(True)
+    got = loss.calculate_batch_retrieval_loss(s_dev, query_ids=qid.to(dev), candidate_ids=cid.to(dev))
+    want = gnn_ref.retrieval_loss_rows(scores, qid.tolist(), cid.tolist(), temperature=0.07)
+    assert abs(float(got) - float(want)) <= 1e-5 * abs(float(want))
+    (got * 0.5).backward()
+    s_ref = scores.clone().requires_grad_(True)
+    (gnn_ref.retrieval_loss_rows(s_ref, qid.tolist(), cid.tolist(), temperature=0.07) * 0.5).backward()
+    np.testing.assert_allclose(s_dev.grad.cpu().numpy(), s_ref.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_loss_construction_and_cpu_inputs():
+    with pytest.raises(ValueError):
+        RetrievalLoss(temperature=1e-13)
+    with pytest.raises(RuntimeError):  # device tensors only: no CPU fallback
+        RetrievalLoss().calculate_batch_retrieval_loss(torch.mm(Q, CAND.T))
 
 
 def test_decoder_construction_errors():
@@ -107,6 +161,7 @@ def test_inner_product_decoder_known_answer_and_grads():
     loss = RetrievalLoss(temperature=0.07, remove_accidental_hits=True)
     s = dec(Q.to(dev), CAND.to(dev))
     got_l = loss.calculate_batch_retrieval_loss(s, query_ids=QUERY_IDS.to(dev), candidate_ids=CAND_IDS.to(dev), device=dev)
-    ref_l = loss.calculate_batch_retrieval_loss(torch.mm(Q, CAND.T), query_ids=QUERY_IDS, candidate_ids=CAND_IDS)
+    from oracle import gnn_ref
+    ref_l = gnn_ref.retrieval_loss_rows(torch.mm(Q, CAND.T), QUERY_IDS.tolist(), CAND_IDS.tolist(), temperature=0.07)
     assert abs(float(got_l) - float(ref_l)) < 1e-4
     eng.close()
