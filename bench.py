@@ -160,6 +160,9 @@ def main():
                     help="mag240m-sharded: batches of B roots exchanged per set of collectives (dedup stays per batch)")
     ap.add_argument("--shard-scale", type=float, default=1.0,
                     help="mag240m-sharded: fraction of MAG240M's nodes and edges to generate (1.0 needs 8 GPUs' HBM)")
+    ap.add_argument("--project-on-owner", action="store_true",
+                    help="mag240m-sharded: owners apply the first layer's weights before sending (256 fp32 per row "
+                         "instead of 768 fp16)")
     ap.add_argument("--small", action="store_true", help="200k-node graph (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true",
@@ -500,21 +503,22 @@ def main():
 def run_sharded(args, rank, world, local_rank):
     """BASELINE.json configs[2]: MAG240M-shaped graph (N=244,160,499, E=1,728,364,232 directed RMAT, D=768 fp16,
     SURVEY.md 8(d) C3) hash-partitioned over the ranks: rank r holds the CSC rows and feature rows of the nodes
-    with id % world == r (gigl_amd/dist.py).  A step = one batch of B roots per rank: per hop one all_to_all of
-    (node, K) requests to the owners, gigl_expand_frontier there, one all_to_all back; union graph locally; the
-    UNIQUE node ids pulled from their owners (all_to_all of ids, all_to_all of rows); 2-layer GraphSAGE 768->256->256.
-    Frontier buckets are filled and scattered on the device (gigl_frontier_bucket / gigl_frontier_scatter) and move
-    through equal-split all_to_alls; the only host read of a step is the split sizes of the feature-row exchange, and
-    it is taken while the NEXT batch's sampling exchange is already queued on a second stream (two batches in flight:
-    remote fetch overlapped with local expansion).  The collectives are still issued from Python (torch.distributed)."""
+    with id % world == r.  A step = one batch of B roots per rank through the library's sharded plan
+    (gigl_dist_plan_*, csrc/dist.hip): per hop one all-to-all of (node, K) requests to the owners,
+    gigl_expand_frontier there, one all-to-all back; union graph locally; the UNIQUE node ids pulled from their owners
+    (rows gathered — or projected by the first layer, --project-on-owner — straight into the send buffer); 2-layer
+    GraphSAGE 768->256->256.  Every exchange is issued by the library over RCCL on the plan's stream and nothing in
+    a step reads the device from the host.  Two plans (ctx + stream + communicator each) are in flight: one host
+    thread issues their phases interleaved, in the same order on every rank, so one plan's exchange overlaps the
+    other's expansion / forward."""
     import torch.distributed as dist
-    from gigl_amd._lib import GIGL_META_LEVEL0
-    from gigl_amd.dist import HipDistKHopSampler, HipFeaturePuller
+    from gigl_amd._lib import STATS, STATS_LEN
+    from gigl_amd.dist import Comm, DistSagePlan
     from gigl_amd.engine import HipEngine
-    from gigl_amd.models import GraphSAGE, HipBatch
+    from gigl_amd.models import GraphSAGE
 
     torch.cuda.set_device(local_rank)
-    if world == 1 and not dist.is_initialized():  # single-rank group: same code path, the exchange is a self-copy
+    if not dist.is_initialized():  # single rank: RCCL with itself (same code path, the exchange is a device copy)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
@@ -522,7 +526,7 @@ def run_sharded(args, rank, world, local_rank):
     dev = eng.device
     fanouts = [int(v) for v in args.fanouts.split(",")]
     L = len(fanouts)
-    B, K, W = args.batch, args.steps, args.warmup
+    B, K, W = args.batch, max(1, args.steps), max(0, args.warmup)
     n = max(int(244_160_499 * args.shard_scale), world * 1024)
     e_total = max(int(1_728_364_232 * args.shard_scale), 1)
     d, hid, out_dim = 768, 256, 256
@@ -556,146 +560,171 @@ def run_sharded(args, rank, world, local_rank):
     step_rows = max(1, (1 << 28) // d)
     for i in range(0, n_local, step_rows):
         x_local[i:i + step_rows] = torch.randn((min(step_rows, n_local - i), d), generator=g, device=dev).to(torch.float16)
+    eng.load_features(x_local)
+    del x_local
     torch.cuda.empty_cache()
     torch.manual_seed(0)
     model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
+    w, bs = model.fused_params()
     # every hash window ends below (hops+1)*n + seed*hops + maxdeg: lets the owners use the range table throughout
     bound = (L + 1) * n + 42 * L + int(maxdeg.item())
+    mwe = bound if bound < (1 << 30) else -1
+    # G consecutive batches travel together: one set of exchanges and launches per G steps; the union graph keeps the
+    # batches apart (dedup within a batch only), so a step's edges are those of its batch
+    G, S = max(1, args.shard_group), 2
+    rnd = S * G
+    K_rep = max(-(-K // rnd), args.min_rounds) * rnd
+    Wp = -(-max(W, 1) // rnd) * rnd
+    N_SEG = 2
+    pool = Wp + N_SEG * K_rep
     gp = torch.Generator(device="cpu")
     gp.manual_seed(42)
-    total_batches = (W + K) * world
-    perm = torch.randint(0, n, (total_batches * B,), generator=gp)
-    my = perm.view(total_batches, B)[rank::world].to(torch.int32).to(dev).contiguous()
-    # G consecutive batches travel together: one set of collectives and launches per G steps; the union graph keeps
-    # the batches apart (gigl_union_build_groups: dedup within a batch only), so a step's edges are those of its batch
-    G = max(1, min(args.shard_group, K))
-    while K % G or W % G:
-        G -= 1
-    GB = G * B
-    my = my.view(-1, GB)
+    perm = torch.randint(0, n, (pool * world * B,), generator=gp)
+    my = perm.view(pool * world, B)[rank::world].to(torch.int32).to(dev).contiguous().view(-1, G * B)  # [calls, G*B]
 
-    class Slot:  # everything one in-flight batch owns; two slots alternate so that the host read of batch i's split
-        pass     # sizes waits while batch i+1's sampling is already queued on the other stream
+    class Slot:  # one plan in flight: ctx + stream + communicator + plan
+        pass
 
-    slots = []
-    for si in range(2):
-        sl = Slot()
-        sl.stream = torch.cuda.Stream(device=dev)
-        sl.eng = eng if si == 0 else HipEngine(local_rank)  # a ctx (stream, arena, hash table) per in-flight batch
-        if si:
-            sl.eng.share_resident(eng)
-        sl.eng.bind_stream(sl.stream)
-        sl.tree = sl.eng.alloc_tree(GB, fanouts)
-        sl.tree.c_struct.hops, sl.tree.c_struct.b = L, GB
-        for k, f in enumerate(fanouts):
-            sl.tree.c_struct.fanouts[k] = f
-        sl.u = sl.eng.alloc_union(GB, fanouts)
-        sl.sampler = HipDistKHopSampler(sl.eng, world, max_window_end=bound if bound < (1 << 30) else -1, sampling_seed=42)
-        sl.puller = HipFeaturePuller(sl.eng, world, x_local, int(sl.u.nodes.numel()))
-        slots.append(sl)
-    acc = torch.zeros(3, dtype=torch.int64, device=dev)  # sampled, aggregated, pulled (counted on the device)
-    lvl = [GIGL_META_LEVEL0 + (L - 1 - l) for l in range(L)]
-    torch.cuda.synchronize()
+    def make_slots(pull_cap):
+        slots = []
+        for si in range(S):
+            sl = Slot()
+            sl.stream = torch.cuda.Stream(device=dev)
+            sl.eng = eng if si == 0 else HipEngine(local_rank)
+            if si:
+                sl.eng.share_resident(eng)
+            sl.eng.bind_stream(sl.stream)
+            sl.comm = Comm.rccl_from_torch(sl.eng)
+            sl.plan = DistSagePlan(sl.comm, w, bs, G * B, fanouts, group_roots=B,
+                                   project_on_owner=args.project_on_owner, pull_cap=pull_cap, max_window_end=mwe)
+            sl.out = sl.plan.new_out()
+            slots.append(sl)
+        return slots
+
+    def close_slots(slots):
+        for sl in slots:
+            sl.plan.close()
+            sl.comm.close()
+        for sl in reversed(slots[1:]):
+            sl.eng.close()
+
+    def run_calls(slots, lo, hi, acc=None):
+        """library calls lo..hi-1 (G batches each), S at a time: the phases of the S plans are issued interleaved by
+        this one thread — the same order on every rank"""
+        lib, nph = slots[0].plan._lib, slots[0].plan.n_phases
+        for c0 in range(lo, hi, S):
+            live = [(slots[j], my[c0 + j]) for j in range(min(S, hi - c0))]
+            for ph in range(nph):
+                for sl, roots in live:
+                    rc = lib.gigl_dist_plan_phase(sl.plan._plan, ph, C.c_void_p(roots.data_ptr()), 42,
+                                                  C.c_void_p(sl.out.data_ptr()))
+                    if rc != 0:
+                        from gigl_amd._lib import check
+                        check(rc, sl.eng._ctx)
+            if acc is not None:
+                for sl, _ in live:
+                    sl.plan.stats(acc)
+
+    def sync_all(slots):
+        for sl in slots:
+            sl.stream.synchronize()
+
+    # ---- warm-up with default row buckets, then size them from what the warm-up saw (+10 %): rows are the bytes that
+    # matter on the links, so the send buffers should not be padded more than that
+    slots = make_slots(0)
+    acc0 = torch.zeros(STATS_LEN, dtype=torch.int64, device=dev)
+    run_calls(slots, 0, Wp // G, acc0)
+    sync_all(slots)
+    most = acc0[STATS["pull_bucket_max"]:STATS["pull_bucket_max"] + 1].clone()
+    dist.all_reduce(most, op=dist.ReduceOp.MAX)
+    if int(acc0[STATS["overflow"]].item()):
+        raise RuntimeError("bucket overflow during warm-up")
+    pull_cap = int(int(most.item()) * 1.1) + 64
+    close_slots(slots)
+    slots = make_slots(pull_cap)
+    run_calls(slots, 0, Wp // G)
+    sync_all(slots)
     setup_s = time.time() - t0
 
-    def phase1(sl, i):
-        """sampling (2 all_to_all per hop) + union graph + feature requests (2 all_to_all): queued, never waited for"""
-        with torch.cuda.stream(sl.stream):
-            sl.tree.roots = my[i]
-            _, sl.cnt = sl.sampler.sample_khop(sl.tree.roots, fanouts, tree=sl.tree)
-            sl.eng.union_build(sl.tree, out=sl.u, group_roots=B)
-            p = sl.puller
-            req = p.request(sl.u.nodes, sl.u.meta[0])
-            dist.all_to_all_single(p.got, req)
-            dist.all_to_all_single(p.recv_counts[:world], p.counts[:world])
-            sl.host = torch.cat([p.counts, p.recv_counts[:world], sl.u.meta[:1]]).to("cpu", non_blocking=True)
-            sl.ready = torch.cuda.Event()
-            sl.ready.record(sl.stream)
+    def seg_calls(r):
+        lo = (Wp + (r % N_SEG) * K_rep) // G
+        return lo, lo + K_rep // G
 
-    def phase2(sl, count):
-        """the step's one host read (split sizes), the row exchange, the forward"""
-        sl.ready.synchronize()
-        host = sl.host.tolist()
-        sc, overflow, rc, n_rows = host[:world], host[world], host[world + 1: 2 * world + 1], host[-1]
-        if overflow:
-            raise RuntimeError("feature-pull bucket overflow")
-        with torch.cuda.stream(sl.stream):
-            p = sl.puller
-            rows = p.serve(p.got, rc)
-            back = rows.new_empty((int(sum(sc)), rows.shape[1]))
-            dist.all_to_all_single(back, rows, output_split_sizes=sc, input_split_sizes=rc)
-            out = model(HipBatch(engine=sl.eng, tree=sl.tree, union=sl.u, x=back, x_index=p.place_index(sc)))
-            sl.rows = out[sl.u.root_local[:GB].to(torch.int64)]
-            if count:
-                u = sl.u
-                rowlen = (u.rowend - u.rowptr).to(torch.int64)
-                ar = torch.arange(rowlen.numel(), device=dev)
-                agg = sum((rowlen * (ar < u.meta[j])).sum() for j in lvl)
-                acc.add_(torch.stack([sum(c.sum() for c in sl.cnt).to(torch.int64), agg.to(torch.int64),
-                                      u.meta[0].to(torch.int64)]))
-
-    tim = {"phase1_enqueue": 0.0, "wait_split_sizes": 0.0, "phase2_enqueue": 0.0} if os.environ.get("GIGL_SHARD_TIMING") else None
-
-    def run(lo, hi, count):
-        phase1(slots[lo % 2], lo)
-        for i in range(lo, hi):
-            ta = time.perf_counter()
-            if i + 1 < hi:
-                phase1(slots[(i + 1) % 2], i + 1)
-            tb = time.perf_counter()
-            if tim is not None:
-                slots[i % 2].ready.synchronize()
-            tc = time.perf_counter()
-            phase2(slots[i % 2], count)
-            if tim is not None:
-                tim["phase1_enqueue"] += tb - ta
-                tim["wait_split_sizes"] += tc - tb
-                tim["phase2_enqueue"] += time.perf_counter() - tc
-
-    run(0, W // G, False)
-    run(W // G, (W + K) // G, True)  # untimed: the edge counts of the timed batches (sampling is deterministic)
-    for k_ in (tim or {}):
-        tim[k_] = 0.0
+    # ---- untimed: exact counts of the pool segments (sampling is deterministic)
+    seg_acc = torch.zeros((N_SEG, STATS_LEN), dtype=torch.int64, device=dev)
+    for sg in range(N_SEG):
+        run_calls(slots, *seg_calls(sg), acc=seg_acc[sg])
+    sync_all(slots)
+    seg_stats = seg_acc.cpu().numpy().astype(np.float64)
+    if seg_stats[:, STATS["overflow"]].any():
+        raise RuntimeError("bucket overflow in a benchmark batch: rerun with a larger --shard-group slack")
+    # ---- calibration repetition, then the timed region
     torch.cuda.synchronize()
+    tc = time.perf_counter()
+    run_calls(slots, *seg_calls(0))
+    sync_all(slots)
+    t_cal = time.perf_counter() - tc
+    rr = torch.tensor([int(min(max(np.ceil(args.min_seconds / max(t_cal, 1e-6)), args.min_reps), 2000))],
+                      dtype=torch.int64, device=dev)
+    dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+    reps = int(rr.item())
+    rep_s = []
+    for r in range(reps):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_calls(slots, *seg_calls(r))
+        sync_all(slots)
+        torch.cuda.synchronize()
+        rep_s.append(time.perf_counter() - t1)
     dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    run(W // G, (W + K) // G, False)
-    if int(max(int(sl.sampler.overflow.item()) for sl in slots)):
-        raise RuntimeError("frontier bucket overflow: rerun with a larger slack")
-    torch.cuda.synchronize()
-    dist.barrier()
-    elapsed = time.perf_counter() - t1
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    cc = acc.to(torch.float64)
-    dist.all_reduce(cc, op=dist.ReduceOp.SUM)
-    elapsed = float(tt.item())
-    sampled_all, aggregated_all, pulled_all = [float(v) for v in cc.tolist()]
-    if rank == 0 and tim is not None:
-        print("host time per step (ms):", {k: round(v / K * 1e3, 4) for k, v in tim.items()}, file=sys.stderr)
+    rep_t = torch.tensor(rep_s, dtype=torch.float64, device=dev)
+    dist.all_reduce(rep_t, op=dist.ReduceOp.MAX)
+    seg_use = np.array([sum(1 for r in range(reps) if r % N_SEG == sg) for sg in range(N_SEG)], dtype=np.float64)
+    tot = torch.tensor((seg_stats * seg_use[:, None]).sum(0), dtype=torch.float64, device=dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    tot = tot.cpu().numpy()
+    rep_np = rep_t.cpu().numpy()
+    elapsed = float(rep_np.sum())
+    steps_total = reps * K_rep
+    sampled_all, aggregated_all = float(tot[STATS["sampled"]]), float(tot[STATS["aggregated"]])
+    pulled_all = float(tot[STATS["pulled_rows"]])
+    row_bytes = hid * 4 if args.project_on_owner else d * 2
+    ms_rep = rep_np / K_rep * 1e3
     if rank == 0:
+        q = lambda a, p: float(np.percentile(a, p))
+        sent_per_step = world * pull_cap * row_bytes * (2 if args.project_on_owner else 1) / G  # (approx. for B rows)
         line = {
             "metric": "sampled+aggregated edges/s", "value": (sampled_all + aggregated_all) / elapsed,
-            "unit": "edges/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "unit": "edges/s", "n_gpus": world, "steps": steps_total, "warmup": Wp,
+            "ms_per_step": elapsed / steps_total * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "steps_requested": K,
+            "timing": {"repetitions": reps, "steps_per_repetition": K_rep, "timed_region_s": round(elapsed, 3),
+                       "ms_per_step_median": q(ms_rep, 50), "ms_per_step_p10": q(ms_rep, 10),
+                       "ms_per_step_p90": q(ms_rep, 90)},
             "config": {"workload": f"MAG240M-shaped RMAT x{args.shard_scale:g}: N={n} E={int(e_local.item())} directed, "
                                    f"D={d} fp16 features, hash-partitioned over {world} rank(s) (owner = id % world), "
                                    f"fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}, sampler mode=parity, "
-                                   f"{G} batches per exchange",
-                       "graph": "CSC rows + feature rows of the owned nodes per rank; per-hop all_to_all frontier "
-                                "exchange, feature pull of the unique union-graph nodes",
-                       "sampled_edges_per_step": sampled_all / (K * world),
-                       "aggregated_edges_per_step": aggregated_all / (K * world),
-                       "pulled_feature_rows_per_step": pulled_all / (K * world),
-                       "pulled_feature_bytes_per_s": pulled_all * d * 2 / elapsed, "setup_s": round(setup_s, 1)},
+                                   f"{G} batches per exchange, 2 plans in flight, "
+                                   f"{'rows projected on the owner (256 fp32)' if args.project_on_owner else 'raw rows (768 fp16)'}",
+                       "graph": "CSC rows + feature rows of the owned nodes per rank; per-hop all-to-all frontier "
+                                "exchange and feature pull of the unique union-graph nodes, issued by the library "
+                                "(gigl_dist_plan, RCCL)",
+                       "sampled_edges_per_step": sampled_all / (steps_total * world),
+                       "aggregated_edges_per_step": aggregated_all / (steps_total * world),
+                       "pulled_feature_rows_per_step": pulled_all / (steps_total * world),
+                       "pulled_feature_bytes_per_s": pulled_all * row_bytes / elapsed,
+                       "row_bucket_rows_per_peer": pull_cap,
+                       "row_bytes_sent_per_step_per_rank": sent_per_step,
+                       "row_bucket_fill": pulled_all / (steps_total * world) / max(world * pull_cap / G, 1),
+                       "setup_s": round(setup_s, 1)},
             "roofline": None, "cpu_baseline": None,
         }
         print(json.dumps(line))
     dist.barrier()
+    close_slots(slots)
     dist.destroy_process_group()
-    for sl in reversed(slots):
-        sl.eng.close()
+    eng.close()
 
 
 def run_cpu_baseline(eng, model, my, fanouts, W, n, d):
