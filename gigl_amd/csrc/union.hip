@@ -28,6 +28,8 @@
 // Rows keep their pre-dedup capacity: row i is col[rowptr[i] .. rowend[i]).
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int MAXL = GIGL_MAX_HOPS + 1;
@@ -763,6 +765,873 @@ __global__ __launch_bounds__(1024) void row_sort_big_kernel(const int32_t* rowpt
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Leaf-global two-hop build ("LG2"): the one-call plan's union graph for hops == 2, in 8 launches.
+//
+// In leaf-global mode only the INNER stream — the b roots and the b*f0 hop-0 slots — can hold nodes that need a local
+// id (plus, rarely, the children of a hop-0 slot whose node is itself a root: "extras"); the b*f0*f1 last-hop slots
+// are pure leaves that stay global ids in their parents' rows.  The generic build above still walks all T = b +
+// b*f0 + b*f0*f1 stream positions in four of its passes and keeps a 64-bit edge hash set sized for every edge; here
+//   * every pass walks the inner stream only (10x fewer positions at [25,10]); the leaves are touched once, by the
+//     threads of the hop-0 slots whose node occurs more than once in the batch (a node that occurs once owns its
+//     tree segment as its row: row aliasing, as above),
+//   * a node's level is read off its first stream position (a root iff that position is < b): roots and hop-0 slots
+//     are inserted by ONE launch, the rare extras by a second one,
+//   * rows are sized per destination TABLE SLOT while first occurrences are counted (one pass), and get their
+//     storage from one atomic cursor bump per workgroup in the assign pass — no row scan, no grid barrier (where a
+//     row lands in `col` does not matter: rows are addressed through rowptr / rowend),
+//   * duplicate edges are removed where the rows are sorted (registers for rows <= 64 entries, an LDS hash set for
+//     longer ones) instead of by a global hash set that had to be cleared for every batch,
+//   * the tile prefix of the numbering is computed by the last workgroup of the counting pass to finish.
+// Numbering: level 0 = distinct roots by first stream position (== the documented numbering, so root_local is the
+// oracle's); level 1 = the other inner nodes by the position of the hop-0 slot (or extra) that holds their first
+// occurrence — the plan's own order inside the level, deterministic.  Everything else is as documented for
+// gigl_union_build_impl(leaf_global = 1).
+struct Lg2Args {
+  const uint32_t* roots;
+  const uint32_t* nbr0;
+  const uint32_t* nbr1;
+  const int32_t* cnt1;
+  int32_t b, f0, f1;
+  int64_t S0;  // b * f0
+  int32_t grouped;
+  uint32_t group_roots, gdiv0;  // stream slots of ONE batch: roots, hop-0
+  int32_t* slot_of;             // [b + S0]
+  int32_t alias_base;
+};
+
+__device__ __forceinline__ uint32_t lg2_base(const Lg2Args& g, const UnionArgs& a, int64_t t) {
+  if (!g.grouped) return 0u;
+  const uint32_t grp = t < g.b ? (uint32_t)t / g.group_roots : (uint32_t)(t - g.b) / g.gdiv0;
+  return grp * (a.mask + 1u);
+}
+
+// find the table slot of a key that IS in the sub-table (extras are looked up, not cached per position)
+__device__ __forceinline__ int32_t lg2_find(const UnionArgs& a, uint32_t base, uint32_t id) {
+  uint32_t s = hash_u32(id) & a.mask;
+  for (uint32_t probes = 0; probes <= a.mask; ++probes) {
+    const unsigned long long kf = a.slots[base + s].kf;
+    if ((uint32_t)(kf >> 32) == id) return (int32_t)(base + s);
+    if (kf == ~0ULL) return -1;
+    s = (s + 1) & a.mask;
+  }
+  return -1;
+}
+
+// does the hop-0 occurrence at stream position t (node in table slot s, c sampled children) add its children to the
+// node's row?  An occurrence with c < f1 children sampled the node's WHOLE in-neighbourhood, and so did every other
+// occurrence of that node: the list is taken once, from the node's first occurrence (for a node that is also a root
+// the first occurrence is a root position, which has no hop-1 children of its own: every occurrence contributes).
+__device__ __forceinline__ bool lg2_contributes(const UnionArgs& a, const Lg2Args& g, int32_t s, int64_t t, int c) {
+  if (c >= g.f1) return true;
+  const uint32_t fp = (uint32_t)a.slots[s].kf;
+  return fp == (uint32_t)t || fp < (uint32_t)g.b;
+}
+
+__global__ __launch_bounds__(256) void lg2_init_kernel(uint4* slots, int64_t n_slots, int32_t* zeros, int64_t zero_words,
+                                                       int32_t* meta) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint4 s4 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u);  // {kf lo = firstpos, kf hi = key, rowcnt, lid}
+  for (int64_t i = t0; i < n_slots; i += stride) slots[i] = s4;
+  for (int64_t i = t0; i < zero_words; i += stride) zeros[i] = 0;
+  if (t0 < GIGL_META_LEN) meta[t0] = 0;
+}
+
+__global__ __launch_bounds__(256) void lg2_insert_kernel(UnionArgs a, Lg2Args g) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= g.b + g.S0) return;
+  const uint32_t id = t < g.b ? g.roots[t] : g.nbr0[t - g.b];
+  if (id == GIGL_INVALID) {
+    g.slot_of[t] = -1;
+    return;
+  }
+  const uint32_t s = table_insert(a, lg2_base(g, a, t), id, (uint32_t)t);
+  if (s == GIGL_INVALID) {  // sub-table full: more inner nodes than the plan's workspace holds — batch reported failed
+    atomicAdd(a.overflow, 1);
+    g.slot_of[t] = -1;
+    return;
+  }
+  g.slot_of[t] = (int32_t)s;
+}
+
+// hop-0 slots whose node is a root: the children of that occurrence are in-neighbours of a root, i.e. inner nodes
+__global__ __launch_bounds__(256) void lg2_extras_kernel(UnionArgs a, Lg2Args g) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= g.S0) return;
+  const int32_t s = g.slot_of[g.b + p];
+  if (s < 0) return;
+  if ((uint32_t)a.slots[s].kf >= (uint32_t)g.b) return;  // first position is not a root position
+  const int c = g.cnt1[p];
+  const uint32_t base = lg2_base(g, a, g.b + p);
+  for (int j = 0; j < c; ++j) {
+    const uint32_t id = g.nbr1[p * g.f1 + j];
+    if (table_insert(a, base, id, (uint32_t)(g.b + g.S0 + p * g.f1 + j)) == GIGL_INVALID) atomicAdd(a.overflow, 1);
+  }
+}
+
+// first occurrences held by inner stream position t: c0 = level-0 firsts (0/1), c1 = level-1 firsts (the position's
+// own and those of its extras).  xmask: bit j set iff extra child j is a first occurrence.
+__device__ __forceinline__ void lg2_firsts(const UnionArgs& a, const Lg2Args& g, int64_t t, int32_t& s_out, int& c0,
+                                           int& c1, uint32_t& own_first, unsigned long long& xmask, bool& root_parent) {
+  c0 = c1 = 0;
+  own_first = 0;
+  xmask = 0;
+  root_parent = false;
+  s_out = -1;
+  if (t >= g.b + g.S0) return;
+  const int32_t s = g.slot_of[t];
+  s_out = s;
+  if (s < 0) return;
+  const uint32_t fp = (uint32_t)a.slots[s].kf;
+  if (fp == (uint32_t)t) {
+    own_first = 1;
+    if (t < g.b) c0 = 1; else c1 = 1;
+  }
+  if (t >= g.b && fp < (uint32_t)g.b) {
+    root_parent = true;
+    const int64_t p = t - g.b;
+    const int c = g.cnt1[p];
+    const uint32_t base = lg2_base(g, a, t);
+    for (int j = 0; j < c; ++j) {
+      const int32_t sx = lg2_find(a, base, g.nbr1[p * g.f1 + j]);
+      if (sx >= 0 && (uint32_t)a.slots[sx].kf == (uint32_t)(g.b + g.S0 + p * g.f1 + j)) {
+        xmask |= 1ull << j;
+        ++c1;
+      }
+    }
+  }
+}
+
+// per 1024-position tile of the inner stream: first-occurrence counts per level; in-edge occurrence counts per
+// destination table slot (Slot::level is the counter here); the LAST workgroup to finish turns the tile counts into
+// exclusive prefixes (row n_tiles = totals).
+__global__ __launch_bounds__(256) void lg2_count_kernel(UnionArgs a, Lg2Args g, int32_t* tile_counts, int32_t n_tiles,
+                                                        int32_t* ticket) {
+  __shared__ int32_t s_c[2];
+  __shared__ int32_t s_last;
+  __shared__ int32_t s_w[4][2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < 2) s_c[tid] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+  int c0 = 0, c1 = 0;
+#pragma unroll
+  for (int r = 0; r < TILE / 256; ++r) {
+    const int64_t t = base + r * 256 + tid;
+    int32_t s;
+    int k0, k1;
+    uint32_t own;
+    unsigned long long xm;
+    bool rp;
+    lg2_firsts(a, g, t, s, k0, k1, own, xm, rp);
+    c0 += k0;
+    c1 += k1;
+    // row sizes: the hop-0 edge (node of slot p -> root p / f0), one bump per run of children of the same root;
+    // the children of a node that occurs more than once go to that node's row (a node that occurs once keeps its
+    // tree segment as its row)
+    const bool edge = s >= 0 && t >= g.b && t < g.b + g.S0;
+    int32_t sr = -1;
+    if (edge) sr = g.slot_of[(uint32_t)(t - g.b) / (uint32_t)g.f0];
+    const bool e_ok = edge && sr >= 0;
+    int total, rank, first;
+    seg_rank(e_ok ? (uint32_t)sr : (0x80000000u | (uint32_t)lane), e_ok, lane, total, rank, first);
+    if (e_ok && rank == 0) atomicAdd(&a.slots[sr].level, total);
+    if (edge && ((a.slots[s].lid & LID_MULTI) || g.alias_base < 0)) {
+      const int c = g.cnt1[t - g.b];
+      if (c > 0 && lg2_contributes(a, g, s, t, c)) atomicAdd(&a.slots[s].level, c);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    c0 += __shfl_xor(c0, off, 64);
+    c1 += __shfl_xor(c1, off, 64);
+  }
+  if (lane == 0) {
+    if (c0) atomicAdd(&s_c[0], c0);
+    if (c1) atomicAdd(&s_c[1], c1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    tile_counts[blockIdx.x * 2 + 0] = s_c[0];
+    tile_counts[blockIdx.x * 2 + 1] = s_c[1];
+    __threadfence();  // the counts are visible device-wide before the ticket is taken
+    s_last = atomicAdd(ticket, 1) == (int32_t)gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // this CU's L1 holds nothing stale of the other workgroups' counts
+  // exclusive prefix over the tiles, 256 tiles per round, both levels
+  int32_t run0 = 0, run1 = 0;
+  for (int32_t t0 = 0; t0 < n_tiles; t0 += 256) {
+    const int32_t i = t0 + tid;
+    const int32_t v0 = i < n_tiles ? __hip_atomic_load(&tile_counts[i * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const int32_t v1 = i < n_tiles ? __hip_atomic_load(&tile_counts[i * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    int32_t i0 = v0, i1 = v1;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t o0 = __shfl_up(i0, off, 64), o1 = __shfl_up(i1, off, 64);
+      if (lane >= off) {
+        i0 += o0;
+        i1 += o1;
+      }
+    }
+    if (lane == 63) {
+      s_w[w][0] = i0;
+      s_w[w][1] = i1;
+    }
+    __syncthreads();
+    int32_t w0 = 0, w1 = 0, tot0 = 0, tot1 = 0;
+    for (int q = 0; q < 4; ++q) {
+      if (q < w) {
+        w0 += s_w[q][0];
+        w1 += s_w[q][1];
+      }
+      tot0 += s_w[q][0];
+      tot1 += s_w[q][1];
+    }
+    if (i < n_tiles) {
+      tile_counts[i * 2 + 0] = run0 + w0 + i0 - v0;
+      tile_counts[i * 2 + 1] = run1 + w1 + i1 - v1;
+    }
+    run0 += tot0;
+    run1 += tot1;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    tile_counts[n_tiles * 2 + 0] = run0;
+    tile_counts[n_tiles * 2 + 1] = run1;
+  }
+}
+
+// rows of 2..TINY_ROW entries (a node with two or three occurrences): one THREAD per row — insertion sort with
+// duplicate removal in a private LDS strip (stride TINY_ROW + 1 words: conflict-free across the threads of a wave).
+// A wave per such row spends its time waiting on four dependent loads; a thread per row keeps 64 rows in flight per
+// wave.
+constexpr int TINY_ROW = 32;
+
+__global__ __launch_bounds__(256) void lg2_row_sort_tiny_kernel(const int32_t* tiny_rows, const int32_t* tiny_count,
+                                                                const int32_t* rowptr, int32_t* rowend, int32_t* col,
+                                                                int32_t* edge_counters) {
+  __shared__ int32_t s_v[256 * (TINY_ROW + 1)];
+  const int32_t nq = *tiny_count;
+  int32_t* v = s_v + threadIdx.x * (TINY_ROW + 1);
+  int32_t edges = 0;
+  for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+    const int32_t i = tiny_rows[q];
+    const int32_t s = rowptr[i], m = rowend[i] - s;
+    const int mm = m < TINY_ROW ? m : TINY_ROW;
+    for (int j = 0; j < mm; ++j) v[j] = col[s + j];  // (independent loads: all in flight together)
+    int u = 0;
+    for (int j = 0; j < mm; ++j) {  // in place: the sorted distinct prefix [0, u) never passes j
+      const int32_t x = v[j];
+      int k = u;
+      while (k > 0 && v[k - 1] > x) --k;           // insertion point
+      if (k > 0 && v[k - 1] == x) continue;        // already there
+      for (int z = u; z > k; --z) v[z] = v[z - 1];
+      v[k] = x;
+      ++u;
+    }
+    for (int j = 0; j < u; ++j) col[s + j] = v[j];
+    rowend[i] = s + u;
+    edges += u;
+  }
+  for (int off = 32; off > 0; off >>= 1) edges += __shfl_xor(edges, off, 64);
+  if ((threadIdx.x & 63) == 0 && edges) atomicAdd(&edge_counters[blockIdx.x & 31], edges);
+}
+
+// local ids, node list, row storage.  A thread numbers the first occurrences it holds (its own position, then its
+// extras in child order); threads in position order.  Row storage: one cursor bump per workgroup.
+__global__ __launch_bounds__(256) void lg2_assign_kernel(UnionArgs a, Lg2Args g, const int32_t* tile_counts,
+                                                         int32_t n_tiles, uint32_t* nodes, int32_t* meta,
+                                                         int32_t* rowptr, int32_t* rowend, int32_t* cursor,
+                                                         int32_t* alias_edges, int32_t* sort_rows,
+                                                         int32_t* sort_count, int32_t* tiny_rows,
+                                                         int32_t* tiny_count) {
+  // per (sub-row, wave): level-0 firsts, level-1 firsts, row entries needed, rows queued for sorting (long | tiny)
+  __shared__ int32_t s_w[TILE / 64][5];
+  __shared__ int32_t s_row_base, s_q_base, s_t_base;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int32_t before0 = tile_counts[blockIdx.x * 2 + 0], before1 = tile_counts[blockIdx.x * 2 + 1];
+  const int32_t total0 = tile_counts[n_tiles * 2 + 0], total1 = tile_counts[n_tiles * 2 + 1];
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+  int32_t sl[TILE / 256];
+  int k0[TILE / 256], k1[TILE / 256];
+  uint32_t own[TILE / 256];
+  unsigned long long xm[TILE / 256];
+  bool rp[TILE / 256];
+  int32_t own_len[TILE / 256];  // entries of the own first's row, -1: the row is a tree segment (aliased)
+  int32_t x0[TILE / 256], x1[TILE / 256], xn[TILE / 256], xq[TILE / 256], xt[TILE / 256];  // exclusive wave prefixes
+#pragma unroll
+  for (int r = 0; r < TILE / 256; ++r) {
+    const int64_t t = base + r * 256 + tid;
+    lg2_firsts(a, g, t, sl[r], k0[r], k1[r], own[r], xm[r], rp[r]);
+    int32_t nd = 0, nq = 0, nt = 0;
+    own_len[r] = 0;
+    if (own[r]) {
+      const int32_t lidw = a.slots[sl[r]].lid;
+      const bool alias = g.alias_base >= 0 && t >= g.b && !(lidw & LID_MULTI);
+      own_len[r] = alias ? -1 : a.slots[sl[r]].level;
+      if (!alias) {
+        nd += own_len[r];
+        // needs dedup + sort — unless it is the row of a root that occurs once: its entries are the (distinct) nodes
+        // of its hop-0 slots, placed by slot number in the fill pass
+        const bool sort_it = own_len[r] >= 2 && (lidw & LID_MULTI);
+        nq = sort_it && own_len[r] > TINY_ROW ? 1 : 0;
+        nt = sort_it && own_len[r] <= TINY_ROW ? 1 : 0;
+      }
+    }
+    // (an extra can be a destination only through a hop-0 occurrence of its own, which then holds its first
+    // occurrence: a node first seen as an extra has no in-edges; its counted size is 0)
+    if (xm[r]) {
+      const int64_t p = t - g.b;
+      const uint32_t tb = lg2_base(g, a, t);
+      for (int j = 0; j < g.f1; ++j)
+        if (xm[r] >> j & 1ull) nd += a.slots[lg2_find(a, tb, g.nbr1[p * g.f1 + j])].level;
+    }
+    int32_t i0 = k0[r], i1 = k1[r], in = nd, iq = nq, it = nt;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t o0 = __shfl_up(i0, off, 64), o1 = __shfl_up(i1, off, 64), on = __shfl_up(in, off, 64),
+                    oq = __shfl_up(iq, off, 64), ot = __shfl_up(it, off, 64);
+      if (lane >= off) {
+        i0 += o0;
+        i1 += o1;
+        in += on;
+        iq += oq;
+        it += ot;
+      }
+    }
+    x0[r] = i0 - k0[r];
+    x1[r] = i1 - k1[r];
+    xn[r] = in - nd;
+    xq[r] = iq - nq;
+    xt[r] = it - nt;
+    if (lane == 63) {
+      s_w[r * 4 + w][0] = i0;
+      s_w[r * 4 + w][1] = i1;
+      s_w[r * 4 + w][2] = in;
+      s_w[r * 4 + w][3] = iq;
+      s_w[r * 4 + w][4] = it;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {  // row storage and queue positions of the whole tile: one bump each
+    int32_t tot = 0, totq = 0, tott = 0;
+    for (int q = 0; q < TILE / 64; ++q) {
+      tot += s_w[q][2];
+      totq += s_w[q][3];
+      tott += s_w[q][4];
+    }
+    s_row_base = tot ? atomicAdd(cursor, tot) : 0;
+    s_q_base = totq ? atomicAdd(sort_count, totq) : 0;
+    s_t_base = tott ? atomicAdd(tiny_count, tott) : 0;
+  }
+  __syncthreads();
+  int32_t alias_c = 0;
+#pragma unroll
+  for (int r = 0; r < TILE / 256; ++r) {
+    if (!(k0[r] | k1[r])) continue;
+    int32_t p0 = before0 + x0[r], p1 = total0 + before1 + x1[r], pn = s_row_base + xn[r], pq = s_q_base + xq[r],
+            pt = s_t_base + xt[r];
+    for (int q = 0; q < r * 4 + w; ++q) {
+      p0 += s_w[q][0];
+      p1 += s_w[q][1];
+      pn += s_w[q][2];
+      pq += s_w[q][3];
+      pt += s_w[q][4];
+    }
+    const int64_t t = base + r * 256 + tid;
+    if (own[r]) {
+      const int32_t s = sl[r];
+      const int32_t lidw = a.slots[s].lid;
+      const int32_t id = k0[r] ? p0 : p1++;
+      a.slots[s].lid = id | (lidw & LID_MULTI);
+      nodes[id] = slot_key(a.slots[s].kf);
+      if (own_len[r] < 0) {  // the row IS the tree segment of its children
+        const int64_t p = t - g.b;
+        const int32_t c = g.cnt1[p];
+        rowptr[id] = g.alias_base + (int32_t)(p * g.f1);
+        rowend[id] = g.alias_base + (int32_t)(p * g.f1) + c;
+        alias_c += c;
+      } else {
+        const bool sorted_later = own_len[r] >= 2 && (lidw & LID_MULTI);
+        rowptr[id] = pn;
+        rowend[id] = sorted_later || own_len[r] < 2 ? pn : pn + own_len[r];  // fill cursor | final end
+        pn += own_len[r];
+        if (sorted_later && own_len[r] > TINY_ROW) sort_rows[pq] = id;
+        else if (sorted_later) tiny_rows[pt] = id;
+        else alias_c += own_len[r];  // (the row is final: counted with the aliased edges)
+      }
+    }
+    if (xm[r]) {
+      const int64_t p = t - g.b;
+      const uint32_t tb = lg2_base(g, a, t);
+      for (int j = 0; j < g.f1; ++j) {
+        if (!(xm[r] >> j & 1ull)) continue;
+        const int32_t s = lg2_find(a, tb, g.nbr1[p * g.f1 + j]);
+        const int32_t id = p1++;
+        a.slots[s].lid = id | (a.slots[s].lid & LID_MULTI);
+        nodes[id] = slot_key(a.slots[s].kf);
+        rowptr[id] = pn;
+        rowend[id] = pn;
+        pn += a.slots[s].level;
+      }
+    }
+  }
+  {  // one counter bump per wave, spread over 32 addresses
+    for (int off = 32; off > 0; off >>= 1) alias_c += __shfl_xor(alias_c, off, 64);
+    if (lane == 0 && alias_c) atomicAdd(&alias_edges[blockIdx.x & 31], alias_c);
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    meta[GIGL_META_LEVEL0] = total0;
+    meta[GIGL_META_LEVEL0 + 1] = total0 + total1;
+    meta[GIGL_META_LEVEL0 + 2] = total0 + total1;
+    meta[GIGL_META_N_NODES] = total0 + total1;
+    rowptr[total0 + total1] = 0;  // (rows past the inner nodes do not exist in leaf-global mode)
+    rowend[total0 + total1] = 0;
+  }
+}
+
+// write the rows: hop-0 edges into the roots' rows, the children of multiply-occurring nodes into those nodes' rows;
+// root positions publish root_local
+__global__ __launch_bounds__(256) void lg2_fill_kernel(UnionArgs a, Lg2Args g, int32_t* rowend, int32_t* col,
+                                                       int32_t* root_local, const int32_t* rowptr) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool in = t < g.b + g.S0;
+  const int32_t s = in ? g.slot_of[t] : -1;
+  if (in && t < g.b) root_local[t] = s >= 0 ? (a.slots[s].lid & ~LID_MULTI) : -1;
+  const bool edge = in && t >= g.b && s >= 0;
+  int32_t sr = -1, lidw = 0;
+  if (edge) {
+    sr = g.slot_of[(uint32_t)(t - g.b) / (uint32_t)g.f0];
+    lidw = a.slots[s].lid;
+  }
+  bool e_ok = edge && sr >= 0;
+  int32_t dlw = e_ok ? a.slots[sr].lid : 0;
+  const int32_t dl = dlw & ~LID_MULTI;
+  if (e_ok && !(dlw & LID_MULTI) && a.slots[sr].level >= 2) {
+    // the root occurs once: its row is its hop-0 slots' nodes in slot order (valid slots are a prefix) — no cursor
+    col[rowptr[dl] + (int32_t)((uint32_t)(t - g.b) % (uint32_t)g.f0)] = lidw & ~LID_MULTI;
+    e_ok = false;
+  }
+  int total, rank, first;
+  seg_rank(e_ok ? (uint32_t)dl : (0x80000000u | (uint32_t)lane), e_ok, lane, total, rank, first);
+  int32_t basep = 0;
+  if (e_ok && rank == 0) basep = atomicAdd(&rowend[dl], total);
+  basep = __shfl(basep, first, 64);
+  if (e_ok) col[basep + rank] = lidw & ~LID_MULTI;
+  if (edge && ((lidw & LID_MULTI) || g.alias_base < 0)) {
+    const int64_t p = t - g.b;
+    const int c = g.cnt1[p];
+    if (c > 0 && lg2_contributes(a, g, s, t, c)) {
+      const int32_t da = lidw & ~LID_MULTI;
+      const int32_t at = atomicAdd(&rowend[da], c);
+      const bool local = (uint32_t)a.slots[s].kf < (uint32_t)g.b;  // the node is a root: its row holds local ids
+      const uint32_t tb = lg2_base(g, a, t);
+      for (int j = 0; j < c; ++j) {
+        const uint32_t id = g.nbr1[p * g.f1 + j];
+        int32_t v = (int32_t)id;
+        if (local) {
+          const int32_t sx = lg2_find(a, tb, id);
+          v = sx >= 0 ? (a.slots[sx].lid & ~LID_MULTI) : 0;
+        }
+        col[at + j] = v;
+      }
+    }
+  }
+}
+
+// one wave per QUEUED row (rows of >= 2 entries that are not tree segments): <= 64 entries are deduplicated and
+// sorted in registers; <= MED_ROW entries through a per-wave LDS hash set + rank by counting; longer ones go to the
+// workgroup-per-row kernel.  Edges are counted after dedup (spread counters).
+constexpr int MED_ROW = 512;
+constexpr int MED_HASH = 1024;
+
+__global__ __launch_bounds__(256) void lg2_row_sort_kernel(const int32_t* sort_rows, const int32_t* sort_count,
+                                                           const int32_t* rowptr, int32_t* rowend, int32_t* col,
+                                                           int32_t* big_rows, int32_t* big_count,
+                                                           int32_t* edge_counters) {
+  __shared__ int32_t s_h[4][MED_HASH];
+  __shared__ int32_t s_u[4][MED_ROW];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int32_t nq = *sort_count;
+  const int32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int32_t waves_total = (gridDim.x * blockDim.x) >> 6;
+  int32_t edges = 0;
+  for (int32_t q = wave; q < nq; q += waves_total) {
+    const int32_t i = sort_rows[q];
+    const int32_t s = rowptr[i], m = rowend[i] - s;
+    if (m > MED_ROW) {
+      if (lane == 0) big_rows[atomicAdd(big_count, 1)] = i;
+      continue;
+    }
+    if (m <= 64) {
+      const int32_t v = lane < m ? col[s + lane] : 0x7FFFFFFF;
+      bool firstv = lane < m;  // no earlier lane holds the same value
+      for (int j = 0; j < m; ++j) {
+        const int32_t vj = __builtin_amdgcn_readlane(v, j);
+        if (j < lane && vj == v) firstv = false;
+      }
+      const unsigned long long fm = __ballot(firstv);
+      int32_t pos = 0;
+      for (int j = 0; j < m; ++j) {
+        const int32_t vj = __builtin_amdgcn_readlane(v, j);
+        pos += ((fm >> j) & 1ull) && vj < v ? 1 : 0;
+      }
+      if (firstv) col[s + pos] = v;
+      const int32_t len = (int32_t)__popcll(fm);
+      if (lane == 0) rowend[i] = s + len;
+      edges += len;
+      continue;
+    }
+    // ---- 65 .. MED_ROW entries: distinct values through this wave's LDS hash set
+    int32_t* H = s_h[w];
+    int32_t* U = s_u[w];
+#pragma unroll
+    for (int r = 0; r < MED_HASH / 64; ++r) H[lane + 64 * r] = -1;
+    wave_lds_sync();
+    for (int r = 0; r * 64 < m; ++r) {
+      const int idx = lane + 64 * r;
+      if (idx < m) {
+        const int32_t v = col[s + idx];
+        uint32_t h = hash_u32((uint32_t)v) & (MED_HASH - 1);
+        for (;;) {
+          const int32_t prev = atomicCAS(&H[h], -1, v);
+          if (prev == -1 || prev == v) break;
+          h = (h + 1) & (MED_HASH - 1);
+        }
+      }
+    }
+    wave_lds_sync();
+    int32_t u = 0;
+#pragma unroll
+    for (int r = 0; r < MED_HASH / 64; ++r) {
+      const int32_t v = H[lane + 64 * r];
+      const unsigned long long vm = __ballot(v != -1);
+      if (v != -1) U[u + (int32_t)__popcll(vm & ((1ull << lane) - 1ull))] = v;
+      u += (int32_t)__popcll(vm);
+    }
+    wave_lds_sync();
+    // rank by counting: every lane owns the values U[lane + 64 r]; U[j] is read once (a broadcast) for all of them
+    int32_t mine[MED_ROW / 64], pos[MED_ROW / 64];
+#pragma unroll
+    for (int r = 0; r < MED_ROW / 64; ++r) {
+      mine[r] = lane + 64 * r < u ? U[lane + 64 * r] : 0x7FFFFFFF;
+      pos[r] = 0;
+    }
+    for (int j = 0; j < u; ++j) {
+      const int32_t x = U[j];
+#pragma unroll
+      for (int r = 0; r < MED_ROW / 64; ++r) pos[r] += x < mine[r] ? 1 : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < MED_ROW / 64; ++r)
+      if (lane + 64 * r < u) col[s + pos[r]] = mine[r];
+    if (lane == 0) rowend[i] = s + u;
+    edges += u;
+    wave_lds_sync();
+  }
+  if (lane == 0 && edges) atomicAdd(&edge_counters[blockIdx.x & 31], edges);
+}
+
+// queued rows: duplicates removed through an LDS hash set (any number of entries, <= BIG_ROW_CAP distinct), the
+// distinct values written back to the head of the row, then the bucket sort of row_sort_big_kernel.  The last
+// workgroup to finish publishes meta[N_EDGES].
+__global__ __launch_bounds__(1024) void lg2_row_sort_big_kernel(const int32_t* rowptr, int32_t* rowend, int32_t* col,
+                                                                const int32_t* big_rows, const int32_t* big_count,
+                                                                int32_t* overflow, int32_t* edge_counters,
+                                                                int32_t* ticket, int32_t* meta) {
+  extern __shared__ int32_t lds[];  // hash set of 2*CAP keys, then A = lds[0..CAP), B = lds[CAP..2CAP)
+  int32_t* A = lds;
+  int32_t* B = lds + BIG_ROW_CAP;
+  __shared__ int32_t s_cnt[NBUCKET];
+  __shared__ int32_t s_off[NBUCKET + 1];
+  __shared__ int32_t s_w[16];
+  __shared__ int32_t s_sub[16][64];  // per-wave sub-bucket counters
+  __shared__ int32_t s_min, s_max, s_uniq, s_last;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int32_t nb = *big_count;
+  constexpr uint32_t HMASK = 2 * BIG_ROW_CAP - 1;
+  int32_t edges = 0;
+  for (int32_t r = blockIdx.x; r < nb; r += gridDim.x) {
+    const int32_t i = big_rows[r];
+    const int32_t s = rowptr[i], m_raw = rowend[i] - s;
+    // ---- distinct values
+    for (int q = tid; q < 2 * BIG_ROW_CAP; q += 1024) lds[q] = -1;
+    if (tid == 0) s_uniq = 0;
+    __syncthreads();
+    for (int q = tid; q < m_raw; q += 1024) {
+      const int32_t v = col[s + q];
+      uint32_t h = hash_u32((uint32_t)v) & HMASK;
+      for (uint32_t probes = 0; probes <= HMASK; ++probes) {
+        const int32_t prev = atomicCAS(&lds[h], -1, v);
+        if (prev == -1) {
+          atomicAdd(&s_uniq, 1);
+          break;
+        }
+        if (prev == v) break;
+        h = (h + 1) & HMASK;
+      }
+    }
+    __syncthreads();
+    const int32_t m = s_uniq;
+    __syncthreads();  // (everybody has read the count before it is reused as the compaction cursor)
+    if (m > BIG_ROW_CAP) {  // does not fit the LDS sort: left as it is, reported through meta
+      if (tid == 0) atomicAdd(overflow, 1);
+      edges += tid == 0 ? m_raw : 0;
+      continue;
+    }
+    // compact the set into the head of the row (order irrelevant: sorted next)
+    if (tid == 0) s_uniq = 0;
+    __syncthreads();
+    for (int q = tid; q < 2 * BIG_ROW_CAP; q += 1024) {
+      const int32_t v = lds[q];
+      if (v != -1) col[s + atomicAdd(&s_uniq, 1)] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      rowend[i] = s + m;
+      edges += m;
+      s_min = 0x7FFFFFFF;
+      s_max = 0;
+    }
+    s_cnt[tid] = 0;
+    __syncthreads();
+    if (m <= 1) continue;
+    // ---- bucket sort of the m distinct values (as row_sort_big_kernel)
+    int32_t mn = 0x7FFFFFFF, mx = 0;
+    for (int q = tid; q < m; q += 1024) {
+      const int32_t v = col[s + q];
+      A[q] = v;
+      mn = min(mn, v);
+      mx = max(mx, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      mn = min(mn, __shfl_xor(mn, off, 64));
+      mx = max(mx, __shfl_xor(mx, off, 64));
+    }
+    if (lane == 0) {
+      atomicMin(&s_min, mn);
+      atomicMax(&s_max, mx);
+    }
+    __syncthreads();
+    const int64_t vmin = s_min, span = (int64_t)s_max - s_min + 1;
+    for (int q = tid; q < m; q += 1024) atomicAdd(&s_cnt[(int)(((int64_t)(A[q] - vmin) * NBUCKET) / span)], 1);
+    __syncthreads();
+    {
+      const int32_t v = s_cnt[tid];
+      int32_t incl = v;
+      for (int off = 1; off < 64; off <<= 1) {
+        int32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) s_w[w] = incl;
+      __syncthreads();
+      int32_t wave_off = 0;
+      for (int q = 0; q < w; ++q) wave_off += s_w[q];
+      s_off[tid] = wave_off + incl - v;
+      if (tid == 1023) s_off[NBUCKET] = wave_off + incl;
+      s_cnt[tid] = wave_off + incl - v;
+    }
+    __syncthreads();
+    for (int q = tid; q < m; q += 1024) {
+      const int32_t v = A[q];
+      B[atomicAdd(&s_cnt[(int)(((int64_t)(v - vmin) * NBUCKET) / span)], 1)] = v;
+    }
+    __syncthreads();
+    for (int bk = w; bk < NBUCKET; bk += 16) {
+      const int32_t lo = s_off[bk], sz = s_off[bk + 1] - lo;
+      if (sz == 0) continue;
+      if (sz <= 64) {
+        const int32_t v = lane < sz ? B[lo + lane] : 0x7FFFFFFF;
+        int32_t pos = 0;
+        for (int j = 0; j < sz; ++j) pos += __builtin_amdgcn_readlane(v, j) < v ? 1 : 0;
+        if (lane < sz) col[s + lo + pos] = v;
+      } else {
+        // crowded bucket (clustered ids, e.g. a row of a grouped build whose sources sit in one narrow id range
+        // per level): a second, wave-local split into 64 range sub-buckets over the bucket's own [min, max],
+        // staged through A[lo .. lo+sz) (free after the scatter above); sub-buckets are ranked in registers
+        int32_t bmn = 0x7FFFFFFF, bmx = 0;
+        for (int q = lane; q < sz; q += 64) {
+          const int32_t v = B[lo + q];
+          bmn = min(bmn, v);
+          bmx = max(bmx, v);
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+          bmn = min(bmn, __shfl_xor(bmn, off, 64));
+          bmx = max(bmx, __shfl_xor(bmx, off, 64));
+        }
+        const int64_t bspan = (int64_t)bmx - bmn + 1;
+        s_sub[w][lane] = 0;
+        wave_lds_sync();
+        for (int q = lane; q < sz; q += 64)
+          atomicAdd(&s_sub[w][(int)(((int64_t)(B[lo + q] - bmn) * 64) / bspan)], 1);
+        wave_lds_sync();
+        const int32_t c = s_sub[w][lane];
+        int32_t incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+          int32_t o = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += o;
+        }
+        const int32_t sub_lo = incl - c;
+        wave_lds_sync();
+        s_sub[w][lane] = sub_lo;  // scatter cursor
+        wave_lds_sync();
+        for (int q = lane; q < sz; q += 64) {
+          const int32_t v = B[lo + q];
+          A[lo + atomicAdd(&s_sub[w][(int)(((int64_t)(v - bmn) * 64) / bspan)], 1)] = v;
+        }
+        wave_lds_sync();
+        for (int sb = 0; sb < 64; ++sb) {
+          const int32_t slo = __builtin_amdgcn_readlane(sub_lo, sb), ssz = __builtin_amdgcn_readlane(c, sb);
+          if (ssz == 0) continue;
+          if (ssz <= 64) {
+            const int32_t v = lane < ssz ? A[lo + slo + lane] : 0x7FFFFFFF;
+            int32_t pos = 0;
+            for (int j = 0; j < ssz; ++j) pos += __builtin_amdgcn_readlane(v, j) < v ? 1 : 0;
+            if (lane < ssz) col[s + lo + slo + pos] = v;
+          } else {  // still crowded: rank against the sub-bucket from LDS
+            for (int q = lane; q < ssz; q += 64) {
+              const int32_t v = A[lo + slo + q];
+              int32_t pos = 0;
+              for (int j = 0; j < ssz; ++j) pos += A[lo + slo + j] < v ? 1 : 0;
+              col[s + lo + slo + pos] = v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (edges) atomicAdd(&edge_counters[blockIdx.x & 31], edges);
+    __threadfence();
+    s_last = atomicAdd(ticket, 1) == (int32_t)gridDim.x - 1 ? 1 : 0;
+    if (s_last) {
+      int32_t total = 0;  // sorted rows + queued rows + aliased rows
+      for (int q = 0; q < 64; ++q)
+        total += __hip_atomic_load(&edge_counters[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      meta[GIGL_META_N_EDGES] = total;
+    }
+  }
+}
+
+int32_t union_build_lg2(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree, int32_t group_roots,
+                        gigl_union* out) {
+  const int b = tree->b;
+  const int f0 = tree->fanouts[0], f1 = tree->fanouts[1];
+  const int64_t S0 = (int64_t)b * f0, S1 = S0 * f1, T_in = b + S0;
+  hipStream_t st = ctx->stream;
+  int64_t n_groups = 1;
+  Lg2Args g{};
+  g.roots = roots;
+  g.nbr0 = tree->nbr[0];
+  g.nbr1 = tree->nbr[1];
+  g.cnt1 = tree->cnt[1];
+  g.b = b;
+  g.f0 = f0;
+  g.f1 = f1;
+  g.S0 = S0;
+  if (group_roots != b) {
+    n_groups = b / group_roots;
+    g.grouped = 1;
+    g.group_roots = (uint32_t)group_roots;
+    g.gdiv0 = (uint32_t)group_roots * (uint32_t)f0;
+  }
+  // node sub-table per batch: the inner stream of one batch at load factor <= 1/2 (a batch that fills it has more
+  // inner nodes than the plan's activation workspace: reported through meta[GIGL_META_OVERFLOW])
+  const int64_t inner = (int64_t)(b / n_groups) * (1 + f0);
+  uint64_t cap = 1024;
+  while (cap < (uint64_t)inner * 2) cap <<= 1;
+  const int64_t n_slots = (int64_t)cap * n_groups;
+  GIGL_REQUIRE(ctx, n_slots < (int64_t)1 << 31 && b + S0 + S1 < (int64_t)1 << 31, "batch too large");
+  const int32_t n_tiles = (int32_t)((T_in + TILE - 1) / TILE);
+  const int64_t zero_words = 256;  // cursor | tickets | queue counter | edge / alias counters
+  int64_t need = 0;
+  auto add = [&](int64_t bytes) { need += gigl_align_up(bytes, 256); };
+  add(n_slots * (int64_t)sizeof(Slot));
+  add(zero_words * 4);
+  add(T_in * 4);
+  add((int64_t)(n_tiles + 1) * 2 * 4);
+  add(T_in * 4);  // queue of long rows
+  add(T_in * 4);  // queue of rows to sort
+  add(T_in * 4);  // queue of tiny rows to sort
+  int32_t rc = gigl_arena_reset(ctx, need + 4096);
+  if (rc != GIGL_OK) return rc;
+  UnionArgs a{};
+  a.slots = (Slot*)gigl_arena_alloc(ctx, n_slots * (int64_t)sizeof(Slot));
+  int32_t* zeros = (int32_t*)gigl_arena_alloc(ctx, zero_words * 4);
+  g.slot_of = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
+  int32_t* tile_counts = (int32_t*)gigl_arena_alloc(ctx, (int64_t)(n_tiles + 1) * 2 * 4);
+  int32_t* big_rows = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
+  int32_t* sort_rows = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
+  int32_t* tiny_rows = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
+  if (!a.slots || !zeros || !g.slot_of || !tile_counts || !big_rows || !sort_rows || !tiny_rows)
+    return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  a.mask = (uint32_t)(cap - 1);
+  a.overflow = out->meta + GIGL_META_OVERFLOW;
+  g.alias_base = -1;
+  if (tree->nbr[1] == (const uint32_t*)(out->col + out->cap_edges) && out->cap_edges + S1 < ((int64_t)1 << 31))
+    g.alias_base = (int32_t)out->cap_edges;
+  int32_t* cursor = zeros;            // [0]
+  int32_t* ticket_count = zeros + 1;  // [1]
+  int32_t* ticket_big = zeros + 2;    // [2]
+  int32_t* big_count = zeros + 3;     // [3]
+  int32_t* sort_count = zeros + 4;    // [4]
+  int32_t* tiny_count = zeros + 5;    // [5]
+  int32_t* edge_counters = zeros + 64;   // [64..96): sorted + queued rows, [96..128): aliased rows
+  const int TB = 256;
+  auto grid = [&](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_INSERT);
+    hipLaunchKernelGGL(lg2_init_kernel, dim3(512), dim3(256), 0, st, (uint4*)a.slots, n_slots, zeros, zero_words,
+                       out->meta);
+    hipLaunchKernelGGL(lg2_insert_kernel, grid(T_in), dim3(TB), 0, st, a, g);
+    hipLaunchKernelGGL(lg2_extras_kernel, grid(S0), dim3(TB), 0, st, a, g);
+  }
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_NODES);
+    hipLaunchKernelGGL(lg2_count_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, a, g, tile_counts, n_tiles,
+                       ticket_count);
+    hipLaunchKernelGGL(lg2_assign_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, a, g, tile_counts, n_tiles,
+                       out->nodes, out->meta, out->rowptr, out->rowend, cursor, edge_counters + 32, sort_rows,
+                       sort_count, tiny_rows, tiny_count);
+  }
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_EDGE_SORT);
+    hipLaunchKernelGGL(lg2_fill_kernel, grid(T_in), dim3(TB), 0, st, a, g, out->rowend, out->col, out->root_local,
+                       out->rowptr);
+  }
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_CSR);
+    {
+      int64_t tb = (T_in / 16 + 255) / 256;
+      if (tb > 1024) tb = 1024;
+      if (tb < 16) tb = 16;
+      hipLaunchKernelGGL(lg2_row_sort_tiny_kernel, dim3((unsigned)tb), dim3(256), 0, st, tiny_rows, tiny_count,
+                         out->rowptr, out->rowend, out->col, edge_counters);
+    }
+    // (the queue holds the rows of nodes that occur more than once: a fraction of T_in)
+    int64_t blocks = (T_in / 8 + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 64) blocks = 64;
+    hipLaunchKernelGGL(lg2_row_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, sort_rows, sort_count,
+                       out->rowptr, out->rowend, out->col, big_rows, big_count, edge_counters);
+    static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs the opt-in once per process
+    if (!lds_attr_set) {
+      GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)lg2_row_sort_big_kernel,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
+      lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(lg2_row_sort_big_kernel, dim3(64), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st,
+                       out->rowptr, out->rowend, out->col, big_rows, big_count, out->meta + GIGL_META_OVERFLOW,
+                       edge_counters, ticket_big, out->meta);
+  }
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -819,6 +1688,10 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
     GIGL_HIP_CHECK(ctx, hipMemsetAsync(out->rowptr, 0, sizeof(int32_t), st));
     GIGL_HIP_CHECK(ctx, hipMemsetAsync(out->rowend, 0, sizeof(int32_t), st));
     return GIGL_OK;
+  }
+  if (leaf_global && hops == 2 && !getenv("GIGL_UNION_GENERIC")) {
+    GIGL_REQUIRE(ctx, group_roots >= 1 && b % group_roots == 0, "group_roots=%d does not divide b=%d", group_roots, b);
+    return union_build_lg2(ctx, roots, tree, group_roots, out);
   }
 
   UnionArgs a{};
