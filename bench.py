@@ -156,7 +156,7 @@ def main():
                          "768->256->256); mag240m-sharded = BASELINE configs[2]: the MAG240M-shaped graph hash-"
                          "partitioned over the ranks (owner = id %% world), per-hop all_to_all frontier exchange and "
                          "feature pull over RCCL — needs >= 2 GPUs at full size (--shard-scale shrinks it)")
-    ap.add_argument("--shard-group", type=int, default=8,
+    ap.add_argument("--shard-group", type=int, default=16,
                     help="mag240m-sharded: batches of B roots exchanged per set of collectives (dedup stays per batch)")
     ap.add_argument("--shard-scale", type=float, default=1.0,
                     help="mag240m-sharded: fraction of MAG240M's nodes and edges to generate (1.0 needs 8 GPUs' HBM)")

@@ -77,6 +77,7 @@ struct Pending {
   const void* send;
   void* recv;
   int64_t bytes;
+  bool self_in_place;
 };
 
 struct LocalGroup {
@@ -99,13 +100,23 @@ struct gigl_comm {
 
 namespace {
 
-int32_t comm_exchange(gigl_comm* c, const void* send, void* recv, int64_t bytes) {
+// self_in_place: the producer already wrote this rank's own block into `recv` (comm_self_in_place() said it may):
+// nothing moves for it.  Otherwise the own block is a device copy — it never goes through the transport.
+bool comm_self_in_place(const gigl_comm* c) { return c->kind != GIGL_COMM_CALLBACK; }
+
+int32_t comm_exchange(gigl_comm* c, const void* send, void* recv, int64_t bytes, bool self_in_place = false) {
   gigl_ctx* ctx = c->ctx;
   if (bytes == 0) return GIGL_OK;
   if (c->kind == GIGL_COMM_RCCL) {
+    if (!self_in_place)
+      GIGL_HIP_CHECK(ctx, hipMemcpyAsync((char*)recv + (int64_t)c->rank * bytes,
+                                         (const char*)send + (int64_t)c->rank * bytes, (size_t)bytes,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+    if (c->world == 1) return GIGL_OK;
     RcclApi& api = rccl();
     ncclResult_t r = api.GroupStart();
     for (int p = 0; p < c->world && r == ncclSuccess; ++p) {
+      if (p == c->rank) continue;
       r = api.Send((const char*)send + (int64_t)p * bytes, (size_t)bytes, ncclInt8, p, c->nccl, ctx->stream);
       if (r == ncclSuccess)
         r = api.Recv((char*)recv + (int64_t)p * bytes, (size_t)bytes, ncclInt8, p, c->nccl, ctx->stream);
@@ -116,7 +127,8 @@ int32_t comm_exchange(gigl_comm* c, const void* send, void* recv, int64_t bytes)
     return GIGL_OK;
   }
   if (c->kind == GIGL_COMM_LOCAL) {
-    c->pending.push_back(Pending{send, recv, bytes});  // performed by gigl_comm_flush_local once every rank is here
+    // performed by gigl_comm_flush_local once every rank is here
+    c->pending.push_back(Pending{send, recv, bytes, self_in_place});
     return GIGL_OK;
   }
   // host callback: the bytes leave through the caller's transport
@@ -233,10 +245,12 @@ int32_t gigl_comm_flush_local(gigl_comm* any) {
     for (gigl_comm* m : g->members)
       GIGL_REQUIRE(ctx, m->pending[x].bytes == bytes, "ranks disagree on the exchange size");
     for (int r = 0; r < g->world; ++r)    // sender
-      for (int p = 0; p < g->world; ++p)  // receiver: block r of p's receive buffer <- block p of r's send buffer
+      for (int p = 0; p < g->world; ++p) {  // receiver: block r of p's receive buffer <- block p of r's send buffer
+        if (r == p && g->members[r]->pending[x].self_in_place) continue;
         GIGL_HIP_CHECK(ctx, hipMemcpyAsync((char*)g->members[p]->pending[x].recv + (int64_t)r * bytes,
                                            (const char*)g->members[r]->pending[x].send + (int64_t)p * bytes,
                                            (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+      }
   }
   for (gigl_comm* m : g->members) m->pending.clear();
   return GIGL_OK;
@@ -276,7 +290,8 @@ __global__ __launch_bounds__(256) void bucket_kernel(const uint32_t* __restrict_
                                                      const int32_t* __restrict__ n_valid, uint32_t world, int64_t cap,
                                                      uint32_t* __restrict__ nodes_out, uint32_t* __restrict__ ksum_out,
                                                      int32_t* __restrict__ slot_idx, int32_t* __restrict__ pos,
-                                                     int32_t* __restrict__ counts) {
+                                                     int32_t* __restrict__ counts, uint32_t self_rank,
+                                                     uint32_t* __restrict__ self_nodes, uint32_t* __restrict__ self_ksum) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t lim = n_valid ? (int64_t)*n_valid : m;
   const uint32_t v = (i < m && i < lim) ? nodes[i] : GIGL_INVALID;
@@ -308,15 +323,19 @@ __global__ __launch_bounds__(256) void bucket_kernel(const uint32_t* __restrict_
     }
   }
   if (r == 0xFFFFFFFFu) {
-    if (pos && i < m) pos[i] = 0;
+    if (pos && i < m) pos[i] = -1;
     return;
   }
   if (p >= cap) {
     atomicOr(&counts[world], 1);
-    if (pos) pos[i] = 0;
+    if (pos) pos[i] = -1;
     return;
   }
   const int64_t e = (int64_t)r * cap + p;
+  if (self_nodes && r == self_rank) {  // this rank's own requests need no exchange: written where they are read
+    nodes_out = self_nodes;
+    ksum_out = self_ksum;
+  }
   nodes_out[e] = v;
   if (ksum_out) ksum_out[e] = ksums ? ksums[i] : v;
   if (slot_idx) slot_idx[e] = (int32_t)i;
@@ -324,11 +343,35 @@ __global__ __launch_bounds__(256) void bucket_kernel(const uint32_t* __restrict_
 }
 
 // owner side of the feature pull: entry e of the received id buckets -> its feature row, written at row e of the send
-// buffer (raw copy, any element type), or widened to fp32 for the projection.  One wave per entry, 16-byte lanes.
-template <bool TO_F32>
-__global__ __launch_bounds__(256) void serve_rows_kernel(const uint32_t* __restrict__ ids, int64_t n_entries,
-                                                         uint32_t world, const void* __restrict__ rows, int64_t n_rows,
-                                                         int32_t d, int32_t dtype, void* __restrict__ out) {
+// buffer.  Raw copy (any element type): the rows are flattened into 16-byte chunks, one per lane, so every lane of
+// every wave moves data whatever the row length; this rank's own requests land straight in the receive buffer.
+__global__ __launch_bounds__(256) void serve_rows_copy_kernel(const uint32_t* __restrict__ ids, int64_t n_entries,
+                                                              uint32_t world, const char* __restrict__ rows,
+                                                              int64_t n_rows, uint32_t row_bytes, uint32_t unit,
+                                                              uint32_t units_per_row, char* __restrict__ out,
+                                                              int64_t self_lo, int64_t self_hi,
+                                                              char* __restrict__ self_out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t e = t / units_per_row;
+  const uint32_t c = (uint32_t)(t - e * units_per_row);
+  if (e >= n_entries) return;
+  const uint32_t v = ids[e];
+  if (v == GIGL_INVALID) return;
+  const int64_t row = (int64_t)(v / world);
+  if (row >= n_rows) return;
+  char* o = (self_out && e >= self_lo && e < self_hi) ? self_out : out;
+  const char* sp = rows + row * (int64_t)row_bytes + (int64_t)c * unit;
+  char* op = o + e * (int64_t)row_bytes + (int64_t)c * unit;
+  if (unit == 16) *(uint4*)op = *(const uint4*)sp;
+  else if (unit == 4) *(uint32_t*)op = *(const uint32_t*)sp;
+  else *(uint16_t*)op = *(const uint16_t*)sp;
+}
+
+// the same rows widened to fp32 (operand of the owner-side projection).  One wave per entry.
+__global__ __launch_bounds__(256) void serve_rows_f32_kernel(const uint32_t* __restrict__ ids, int64_t n_entries,
+                                                             uint32_t world, const void* __restrict__ rows,
+                                                             int64_t n_rows, int32_t d, int32_t dtype,
+                                                             float* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (e >= n_entries) return;
@@ -336,25 +379,38 @@ __global__ __launch_bounds__(256) void serve_rows_kernel(const uint32_t* __restr
   if (v == GIGL_INVALID) return;
   const int64_t row = (int64_t)(v / world);
   if (row >= n_rows) return;
-  const int esz = dtype == GIGL_DTYPE_F32 ? 4 : 2;
-  if (!TO_F32) {
-    const int64_t rb = (int64_t)d * esz;
-    const char* s = (const char*)rows + row * rb;
-    char* o = (char*)out + e * rb;
-    if ((rb & 15) == 0) {
-      for (int64_t q = lane * 16; q < rb; q += 64 * 16) *(uint4*)(o + q) = *(const uint4*)(s + q);
-    } else {
-      for (int64_t q = lane * 2; q < rb; q += 64 * 2) *(uint16_t*)(o + q) = *(const uint16_t*)(s + q);
-    }
+  float* o = out + e * (int64_t)d;
+  if (dtype == GIGL_DTYPE_F32) {
+    const float* sp = (const float*)rows + row * (int64_t)d;
+    for (int q = lane; q < d; q += 64) o[q] = sp[q];
   } else {
-    float* o = (float*)out + e * (int64_t)d;
-    if (dtype == GIGL_DTYPE_F32) {
-      const float* s = (const float*)rows + row * (int64_t)d;
-      for (int q = lane; q < d; q += 64) o[q] = s[q];
-    } else {
-      const __half* s = (const __half*)rows + row * (int64_t)d;
-      for (int q = lane; q < d; q += 64) o[q] = __half2float(s[q]);
-    }
+    const __half* sp = (const __half*)rows + row * (int64_t)d;
+    for (int q = lane; q < d; q += 64) o[q] = __half2float(sp[q]);
+  }
+}
+
+// answers of the owners -> tree layout, one thread per (frontier slot, j): slot i's answer sits at bucket entry
+// pos[i] (-1: the slot was not sent — an empty parent — and has no children).  Writes every output word, so
+// nothing has to be cleared first.
+__global__ __launch_bounds__(256) void scatter_slots_kernel(const uint32_t* __restrict__ resp,
+                                                            const int32_t* __restrict__ pos,
+                                                            const uint32_t* __restrict__ parent_ksums, int64_t m,
+                                                            int f, uint32_t* __restrict__ out_nbr,
+                                                            int32_t* __restrict__ out_cnt,
+                                                            uint32_t* __restrict__ child_ksums) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = t / f;
+  const int j = (int)(t - i * f);
+  if (i >= m) return;
+  const int32_t e = pos[i];
+  const uint32_t v = e >= 0 ? resp[(int64_t)e * f + j] : GIGL_INVALID;
+  out_nbr[t] = v;
+  child_ksums[t] = v == GIGL_INVALID ? 0u : parent_ksums[i] + v;
+  if (j == 0) {
+    int n = 0;
+    if (e >= 0)
+      for (int q = 0; q < f; ++q) n += resp[(int64_t)e * f + q] != GIGL_INVALID ? 1 : 0;
+    out_cnt[i] = n;
   }
 }
 
@@ -476,7 +532,7 @@ struct gigl_dist_plan {
   uint32_t *rq_nodes_s[GIGL_MAX_HOPS] = {nullptr}, *rq_ksum_s[GIGL_MAX_HOPS] = {nullptr};
   uint32_t *rq_nodes_r[GIGL_MAX_HOPS] = {nullptr}, *rq_ksum_r[GIGL_MAX_HOPS] = {nullptr};
   uint32_t *resp_s[GIGL_MAX_HOPS] = {nullptr}, *resp_r[GIGL_MAX_HOPS] = {nullptr};
-  int32_t* slot_idx[GIGL_MAX_HOPS] = {nullptr};
+  int32_t* hop_pos[GIGL_MAX_HOPS] = {nullptr};  // [m[k]]: bucket entry of frontier slot i, -1 = not sent
   int32_t* counts[GIGL_MAX_HOPS] = {nullptr};  // [world + 1], last = overflow flag
   int32_t* own_cnt = nullptr;                  // owner-side out_cnt scratch
   // union
@@ -516,6 +572,16 @@ int32_t split_w0(gigl_dist_plan* p) {  // w[0] = [W_l | W_r] row-interleaved -> 
   return GIGL_OK;
 }
 
+// hop k's answers -> tree slots, counts and the children's path sums (K of a root's path is the root id)
+int32_t scatter_hop(gigl_dist_plan* p, int k, const uint32_t* roots) {
+  const int64_t total = p->m[k] * p->fan[k];
+  hipLaunchKernelGGL(scatter_slots_kernel, dim3((unsigned)grid256(total)), dim3(256), 0, p->ctx->stream, p->resp_r[k],
+                     p->hop_pos[k], k == 0 ? roots : p->child_ksum[k - 1], p->m[k], p->fan[k], p->tree.nbr[k],
+                     p->tree.cnt[k], p->child_ksum[k]);
+  GIGL_HIP_CHECK(p->ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
 int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t seed, float* out) {
   gigl_ctx* ctx = p->ctx;
   hipStream_t st = ctx->stream;
@@ -526,22 +592,24 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     // ---- requester: (scatter the previous hop's answers,) bucket this hop's frontier by owner
     const int k = phase >> 1;
     if (k > 0) {
-      rc = gigl_frontier_scatter(ctx, p->resp_r[k - 1], p->slot_idx[k - 1], p->counts[k - 1],
-                                 k == 1 ? roots : p->child_ksum[k - 2], p->m[k - 1], p->world, p->cap[k - 1],
-                                 p->fan[k - 1], p->tree.nbr[k - 1], p->tree.cnt[k - 1], p->child_ksum[k - 1]);
+      rc = scatter_hop(p, k - 1, roots);
       if (rc != GIGL_OK) return rc;
     }
     const uint32_t* nodes = k == 0 ? roots : p->tree.nbr[k - 1];
     const uint32_t* ksums = k == 0 ? nullptr : p->child_ksum[k - 1];
+    const bool in_place = comm_self_in_place(p->comm);
     const size_t bb = (size_t)world * p->cap[k] * 4;
     GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->rq_nodes_s[k], 0xFF, bb, st));
+    if (in_place)  // (unused entries of the own block must read as empty too)
+      GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->rq_nodes_r[k] + (int64_t)p->rank * p->cap[k], 0xFF, (size_t)p->cap[k] * 4, st));
     GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->counts[k], 0, (size_t)(world + 1) * 4, st));
     hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->m[k])), dim3(256), 0, st, nodes, ksums, p->m[k],
-                       (const int32_t*)nullptr, world, p->cap[k], p->rq_nodes_s[k], p->rq_ksum_s[k], p->slot_idx[k],
-                       (int32_t*)nullptr, p->counts[k]);
+                       (const int32_t*)nullptr, world, p->cap[k], p->rq_nodes_s[k], p->rq_ksum_s[k], (int32_t*)nullptr,
+                       p->hop_pos[k], p->counts[k], (uint32_t)p->rank, in_place ? p->rq_nodes_r[k] : (uint32_t*)nullptr,
+                       in_place ? p->rq_ksum_r[k] : (uint32_t*)nullptr);
     GIGL_HIP_CHECK(ctx, hipGetLastError());
-    rc = comm_exchange(p->comm, p->rq_nodes_s[k], p->rq_nodes_r[k], p->cap[k] * 4);
-    if (rc == GIGL_OK) rc = comm_exchange(p->comm, p->rq_ksum_s[k], p->rq_ksum_r[k], p->cap[k] * 4);
+    rc = comm_exchange(p->comm, p->rq_nodes_s[k], p->rq_nodes_r[k], p->cap[k] * 4, in_place);
+    if (rc == GIGL_OK) rc = comm_exchange(p->comm, p->rq_ksum_s[k], p->rq_ksum_r[k], p->cap[k] * 4, in_place);
     return rc;
   }
   if (phase < 2 * L) {
@@ -555,9 +623,7 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
   }
   if (phase == 2 * L) {
     // ---- requester: last scatter, union graph, feature requests
-    rc = gigl_frontier_scatter(ctx, p->resp_r[L - 1], p->slot_idx[L - 1], p->counts[L - 1],
-                               L == 1 ? roots : p->child_ksum[L - 2], p->m[L - 1], p->world, p->cap[L - 1],
-                               p->fan[L - 1], p->tree.nbr[L - 1], p->tree.cnt[L - 1], p->child_ksum[L - 1]);
+    rc = scatter_hop(p, L - 1, roots);
     if (rc != GIGL_OK) return rc;
     rc = gigl_union_build_groups(ctx, roots, &p->tree, p->group_roots, &p->un);
     if (rc != GIGL_OK) return rc;
@@ -565,13 +631,15 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->pull_counts, 0, (size_t)(world + 1) * 4, st));
     hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->un.cap_nodes)), dim3(256), 0, st, p->un.nodes,
                        (const uint32_t*)nullptr, p->un.cap_nodes, p->un.meta + GIGL_META_N_NODES, world, p->pull_cap,
-                       p->ids_s, (uint32_t*)nullptr, (int32_t*)nullptr, p->pos, p->pull_counts);
+                       p->ids_s, (uint32_t*)nullptr, (int32_t*)nullptr, p->pos, p->pull_counts, 0u, (uint32_t*)nullptr,
+                       (uint32_t*)nullptr);
     if (p->project) {
       GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->idsb_s, 0xFF, (size_t)world * p->pull_cap_b * 4, st));
       GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->pullb_counts, 0, (size_t)(world + 1) * 4, st));
       hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes,
                          (const uint32_t*)nullptr, p->act_rows, p->un.meta + GIGL_META_LEVEL0 + (L - 1), world,
-                         p->pull_cap_b, p->idsb_s, (uint32_t*)nullptr, (int32_t*)nullptr, p->posb, p->pullb_counts);
+                         p->pull_cap_b, p->idsb_s, (uint32_t*)nullptr, (int32_t*)nullptr, p->posb, p->pullb_counts,
+                         0u, (uint32_t*)nullptr, (uint32_t*)nullptr);
     }
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     rc = comm_exchange(p->comm, p->ids_s, p->ids_r, p->pull_cap * 4);
@@ -582,20 +650,25 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     // ---- owner: the requested rows, gathered straight into the send buffer (or projected into it)
     const int64_t na = (int64_t)world * p->pull_cap, nb = (int64_t)world * p->pull_cap_b;
     if (!p->project) {
-      hipLaunchKernelGGL(serve_rows_kernel<false>, dim3((unsigned)grid256(na * 64)), dim3(256), 0, st, p->ids_r, na,
-                         world, p->feat->rows, p->feat->n, p->feat->d, p->feat->dtype, p->rows_s);
+      const bool in_place = comm_self_in_place(p->comm);
+      const uint32_t unit = (p->row_bytes & 15) == 0 ? 16u : ((p->row_bytes & 3) == 0 ? 4u : 2u);
+      const uint32_t upr = (uint32_t)(p->row_bytes / unit);
+      hipLaunchKernelGGL(serve_rows_copy_kernel, dim3((unsigned)grid256(na * upr)), dim3(256), 0, st, p->ids_r, na,
+                         world, (const char*)p->feat->rows, p->feat->n, (uint32_t)p->row_bytes, unit, upr,
+                         (char*)p->rows_s, (int64_t)p->rank * p->pull_cap, (int64_t)(p->rank + 1) * p->pull_cap,
+                         in_place ? (char*)p->rows_r : (char*)nullptr);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
-      return comm_exchange(p->comm, p->rows_s, p->rows_r, p->pull_cap * p->row_bytes);
+      return comm_exchange(p->comm, p->rows_s, p->rows_r, p->pull_cap * p->row_bytes, in_place);
     }
     // (entries without a request keep whatever the operand held: their output rows are never read)
-    hipLaunchKernelGGL(serve_rows_kernel<true>, dim3((unsigned)grid256(na * 64)), dim3(256), 0, st, p->ids_r, na, world,
-                       p->feat->rows, p->feat->n, p->feat->d, p->feat->dtype, (void*)p->stage);
+    hipLaunchKernelGGL(serve_rows_f32_kernel, dim3((unsigned)grid256(na * 64)), dim3(256), 0, st, p->ids_r, na, world,
+                       p->feat->rows, p->feat->n, p->feat->d, p->feat->dtype, p->stage);
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     rc = gigl_linear(ctx, p->stage, p->wl0, nullptr, p->n_entries_dev, na, p->dims[0], p->dims[1], 0,
                      (float*)p->rows_s);
     if (rc != GIGL_OK) return rc;
-    hipLaunchKernelGGL(serve_rows_kernel<true>, dim3((unsigned)grid256(nb * 64)), dim3(256), 0, st, p->idsb_r, nb, world,
-                       p->feat->rows, p->feat->n, p->feat->d, p->feat->dtype, (void*)p->stage);
+    hipLaunchKernelGGL(serve_rows_f32_kernel, dim3((unsigned)grid256(nb * 64)), dim3(256), 0, st, p->idsb_r, nb, world,
+                       p->feat->rows, p->feat->n, p->feat->d, p->feat->dtype, p->stage);
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     rc = gigl_linear(ctx, p->stage, p->wr0, nullptr, p->n_entries_dev + 1, nb, p->dims[0], p->dims[1], 0,
                      (float*)p->rowsb_s);
@@ -735,10 +808,10 @@ int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* sha
     p->rq_ksum_r[k] = (uint32_t*)alloc((size_t)W * cap * 4);
     p->resp_s[k] = (uint32_t*)alloc((size_t)W * cap * fanouts[k] * 4);
     p->resp_r[k] = (uint32_t*)alloc((size_t)W * cap * fanouts[k] * 4);
-    p->slot_idx[k] = (int32_t*)alloc((size_t)W * cap * 4);
+    p->hop_pos[k] = (int32_t*)alloc((size_t)p->m[k] * 4);
     p->counts[k] = (int32_t*)alloc((size_t)(W + 1) * 4);
     ok = p->tree.cnt[k] && p->tree.nbr[k] && p->child_ksum[k] && p->rq_nodes_s[k] && p->rq_ksum_s[k] &&
-         p->rq_nodes_r[k] && p->rq_ksum_r[k] && p->resp_s[k] && p->resp_r[k] && p->slot_idx[k] && p->counts[k];
+         p->rq_nodes_r[k] && p->rq_ksum_r[k] && p->resp_s[k] && p->resp_r[k] && p->hop_pos[k] && p->counts[k];
     if (parents >= ((int64_t)1 << 31)) return fail(GIGL_E_INVALID_ARG, "tree too large");
   }
   p->tree.hops = hops;
