@@ -106,18 +106,39 @@ WORKLOADS = {
     "mag-shard": (30_520_062, 25, 216_045_529, 768, torch.float16, True, 256, 256, 3,
                   "MAG240M/8-shaped RMAT (one GPU's share of the 8-way sharded graph)"),
     "small": (200_000, 18, 3_000_000, 100, torch.float32, False, 256, 47, 2, "products-shaped-small"),
+    # BASELINE.json configs[0] / SURVEY.md §8(d) C1: Cora-shaped (2,708 nodes, 5,278 undirected edges, D=1,433,
+    # 7 classes), GraphSAGE 1433->16->7, fanout [10,5] (--fanouts 10,5 --batch 512)
+    "cora": (2_708, 12, 5_278, 1_433, torch.float32, False, 16, 7, 1, "Cora-shaped random graph"),
+    # the per-GPU share of BASELINE.json configs[3] / C4: RMAT scale-30 (N=2^30, E=1.6e10, D=128 fp16) over 8 GPUs
+    # held as one self-contained graph: 2^27 nodes, 2e9 directed edges, 34 GB of features; fanout [15,10], B=4096
+    # (--fanouts 15,10 --batch 4096), SAGE 128->256->256
+    "rmat-shard": (1 << 27, 27, 2_000_000_000, 128, torch.float16, True, 256, 256, 4,
+                   "RMAT scale-30 / 8 (one GPU's share of the 8-way sharded graph)"),
 }
+WORKLOAD_DEFAULTS = {"cora": ("10,5", 512), "rmat-shard": ("15,10", 4096)}
 
 
 def build_workload(eng, args):
     dev = eng.device
     name = "small" if getattr(args, "small", False) else getattr(args, "workload", "products")
     n, scale, pairs, d, dtype, directed, hid, out_dim, seed, label = WORKLOADS[name]
-    src, dst = rmat_edges_gpu(scale, pairs, seed=seed, device=dev)
-    # fold the 2^scale id space onto [0, n) and scatter ids so hubs are not the low ids
     perm_mul = 0x9E3779B1
-    src = ((src * perm_mul) % n).to(torch.int32)
-    dst = ((dst * perm_mul) % n).to(torch.int32)
+    if name == "cora":  # (uniform random pairs: Cora is not power-law)
+        g0 = torch.Generator(device=dev)
+        g0.manual_seed(seed)
+        src = torch.randint(0, n, (pairs,), generator=g0, device=dev).to(torch.int32)
+        dst = torch.randint(0, n, (pairs,), generator=g0, device=dev).to(torch.int32)
+    else:
+        # fold the 2^scale id space onto [0, n) and scatter ids so hubs are not the low ids; drawn in chunks (the
+        # int64 temporaries of 2e9 edges would not leave room for the sort)
+        parts, chunk = [], 1 << 28
+        for ci, c0 in enumerate(range(0, pairs, chunk)):
+            a_, b_ = rmat_edges_gpu(scale, min(chunk, pairs - c0), seed=seed + 7919 * ci, device=dev)
+            parts.append((((a_ * perm_mul) % n).to(torch.int32), ((b_ * perm_mul) % n).to(torch.int32)))
+            del a_, b_
+        src = torch.cat([q[0] for q in parts]) if len(parts) > 1 else parts[0][0]
+        dst = torch.cat([q[1] for q in parts]) if len(parts) > 1 else parts[0][1]
+        del parts
     eng.build_from_coo(n, src, dst, is_directed=directed)
     del src, dst
     g = torch.Generator(device=dev)
@@ -144,13 +165,14 @@ def main():
     ap.add_argument("--min-rounds", type=int, default=10,
                     help="rounds (streams x batches-per-call steps) per timed repetition, at least")
     ap.add_argument("--min-reps", type=int, default=7, help="timed repetitions, at least (median / p10 / p90)")
-    ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--fanouts", type=str, default="25,10")
+    ap.add_argument("--batch", type=int, default=0, help="roots per batch (0: the workload's: 1024)")
+    ap.add_argument("--fanouts", type=str, default="", help="per-hop fanouts (empty: the workload's: 25,10)")
     ap.add_argument("--streams", type=int, default=3)
     ap.add_argument("--group", type=int, default=32,
                     help="batches per library call: G independent batches of B roots share one set of launches "
                          "(each keeps its own union graph; results are bit-identical to G single-batch calls)")
-    ap.add_argument("--workload", type=str, default="products", choices=["products", "mag-shard", "mag240m-sharded"],
+    ap.add_argument("--workload", type=str, default="products",
+                    choices=["products", "mag-shard", "mag240m-sharded", "cora", "rmat-shard", "gat-lp"],
                     help="products = BASELINE configs[1] (default, the N=1 workload; N>1: a replica per GPU); mag-shard = "
                          "one GPU's 1/8 share of the MAG240M-shaped graph as a self-contained graph (D=768 fp16, SAGE "
                          "768->256->256); mag240m-sharded = BASELINE configs[2]: the MAG240M-shaped graph hash-"
@@ -171,6 +193,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--mode", type=str, default="parity", choices=["parity", "fast"])
     args = ap.parse_args()
+    wl_fan, wl_b = WORKLOAD_DEFAULTS.get(args.workload, ("25,10", 1024))
+    args.fanouts = args.fanouts or wl_fan
+    args.batch = args.batch or wl_b
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,6 +207,8 @@ def main():
     assert world == max(args.gpus, 1) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
     if args.workload == "mag240m-sharded":
         return run_sharded(args, rank, world, local_rank)
+    if args.workload == "gat-lp":
+        return run_gat_lp(args, rank, world, local_rank)
 
     from gigl_amd._lib import KERNEL_IDS, MODE_FAST, MODE_SPARK_HASH, STATS, STATS_LEN
     from gigl_amd.engine import HipEngine
@@ -724,6 +751,126 @@ def run_sharded(args, rank, world, local_rank):
     dist.barrier()
     close_slots(slots)
     dist.destroy_process_group()
+    eng.close()
+
+
+def run_gat_lp(args, rank, world, local_rank):
+    """BASELINE.json configs[4] / SURVEY.md 8(d) C5 on one GPU's share of the MAG240M-shaped graph (--shard-scale of
+    it as a self-contained graph): link-prediction step of the GAT encoder — anchors + one positive each (sampled
+    out-neighbour, counter 3) and 512 random negatives go through sample -> union graph -> 2-layer GAT (heads 2, hid
+    128, out 128: attention-weighted segmented reduce) -> root embeddings; inner-product scores against positives +
+    random negatives and the fused retrieval loss (infer_task_inputs + Retrieval, python/gigl/src/common/
+    modeling_task_specs/utils/infer.py, models/layers/task.py:140-205).  Driven through the per-stage entry points
+    from Python (no one-call plan for attention layers yet): a secondary line, host-bound at this batch size."""
+    from gigl_amd._lib import GIGL_META_LEVEL0
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.link_prediction import DecoderType, LinkPredictionDecoder, RetrievalLoss
+    from gigl_amd.models import HipBatch
+    from gigl_amd.models_attn import GAT
+
+    torch.cuda.set_device(local_rank)
+    eng = HipEngine(local_rank)
+    dev = eng.device
+    fanouts = [int(v) for v in args.fanouts.split(",")]
+    L = len(fanouts)
+    B, n_neg = args.batch, 512
+    scale = args.shard_scale if args.shard_scale < 1.0 else 0.125
+    n = int(244_160_499 * scale)
+    e_total = int(1_728_364_232 * scale)
+    d, hid, out_dim, heads = 768, 128, 128, 2
+    t0 = time.time()
+    bits = int(np.ceil(np.log2(n)))
+    parts = []
+    for ci, c0 in enumerate(range(0, e_total, 1 << 27)):
+        a_, b_ = rmat_edges_gpu(bits, min(1 << 27, e_total - c0), seed=3 + 7919 * ci, device=dev)
+        parts.append((((a_ * 0x9E3779B1) % n).to(torch.int32), ((b_ * 0x9E3779B1) % n).to(torch.int32)))
+    src, dst = torch.cat([q[0] for q in parts]), torch.cat([q[1] for q in parts])
+    del parts
+    eng.build_from_coo(n, src, dst, is_directed=True)
+    eng.build_from_coo(n, dst, src, is_directed=True, out_graph=True)  # CSR by source: the positives' graph
+    del src, dst
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    x = torch.empty((n, d), device=dev, dtype=torch.float16)
+    step_rows = max(1, (1 << 28) // d)
+    for i in range(0, n, step_rows):
+        x[i:i + step_rows] = torch.randn((min(step_rows, n - i), d), generator=g, device=dev).to(torch.float16)
+    eng.load_features(x)
+    del x
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    model = GAT(d, hid, out_dim, num_layers=L, heads=heads).to(dev)
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream(device=dev)  # (the resident data was written on torch's default stream)
+    eng.bind_stream(st)
+    dec = LinkPredictionDecoder(DecoderType.inner_product)
+    dec.engine = eng
+    loss_fn = RetrievalLoss(temperature=0.07, remove_accidental_hits=True)
+    gp = torch.Generator(device="cpu")
+    gp.manual_seed(42)
+    K, W = max(args.steps, 8), max(args.warmup, 2)
+    pool = 64
+    anchors = torch.randint(0, n, (pool, B), generator=gp).to(torch.int32).to(dev)
+    negs = torch.randint(0, n, (pool, n_neg), generator=gp).to(torch.int32).to(dev)
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    lvl = [GIGL_META_LEVEL0 + (L - 1 - l) for l in range(L)]
+    setup_s = time.time() - t0
+
+    def encode(roots, count):
+        tree = eng.sample_khop(roots, fanouts)
+        u = eng.union_build(tree)
+        emb = model(HipBatch(eng, tree, u))[u.root_local[: roots.numel()].long()]
+        if count:
+            rowlen = (u.rowend - u.rowptr).to(torch.int64)
+            ar = torch.arange(rowlen.numel(), device=dev)
+            agg = sum((rowlen * (ar < u.meta[j])).sum() for j in lvl)
+            acc.add_(torch.stack([sum(c.sum() for c in tree.cnt).to(torch.int64), agg.to(torch.int64)]))
+        return emb
+
+    def step(i, count=False):
+        with torch.cuda.stream(st), torch.no_grad():
+            a = anchors[i % pool]
+            pos, cnt = eng.sample_positives(a, 1)
+            main = encode(torch.cat([a, pos]), count)  # anchors, then their positives (INVALID: no out-edge)
+            rn = encode(negs[i % pool], count)
+            q, pe = main[:B], main[B:]
+            scores = dec(q, torch.cat([pe, rn]))
+            return loss_fn.calculate_batch_retrieval_loss(scores, query_ids=a.long(),
+                                                          candidate_ids=torch.cat([pos, negs[i % pool]]).long())
+
+    for i in range(W):
+        step(i)
+    for i in range(pool):
+        step(i, count=True)
+    st.synchronize()
+    per_step = acc.cpu().numpy().astype(np.float64) / pool
+    rep_s, steps = [], 0
+    t_all = time.perf_counter()
+    while time.perf_counter() - t_all < args.min_seconds or len(rep_s) < args.min_reps:
+        st.synchronize()
+        t1 = time.perf_counter()
+        for i in range(pool):
+            step(i)
+        st.synchronize()
+        rep_s.append(time.perf_counter() - t1)
+        steps += pool
+    elapsed = float(sum(rep_s))
+    ms_rep = np.array(rep_s) / pool * 1e3
+    q_ = lambda a, p: float(np.percentile(a, p))
+    line = {
+        "metric": "sampled+aggregated edges/s", "value": float(per_step.sum()) * steps / elapsed, "unit": "edges/s",
+        "n_gpus": 1, "steps": steps, "warmup": W, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "timing": {"repetitions": len(rep_s), "steps_per_repetition": pool, "timed_region_s": round(elapsed, 3),
+                   "ms_per_step_median": q_(ms_rep, 50), "ms_per_step_p10": q_(ms_rep, 10), "ms_per_step_p90": q_(ms_rep, 90)},
+        "config": {"workload": f"MAG240M-shaped RMAT x{scale:g} (N={n}, E={eng.n_edges} directed, D={d} fp16), link-prediction "
+                               f"step: {B} anchors + 1 positive each + {n_neg} random negatives, fanout={fanouts}, 2-layer GAT "
+                               f"heads={heads} hid={hid} out={out_dim}, inner-product scores + fused retrieval loss",
+                   "sampled_edges_per_step": float(per_step[0]), "aggregated_edges_per_step": float(per_step[1]),
+                   "driver": "per-stage entry points from Python, one stream", "setup_s": round(setup_s, 1)},
+        "roofline": None, "cpu_baseline": None,
+    }
+    print(json.dumps(line))
     eng.close()
 
 

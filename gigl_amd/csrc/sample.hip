@@ -857,7 +857,12 @@ int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a_in, const RangeTable& tb, 
     if (bits >= 1 && bits <= 32) a.proxy_drop = 32 - bits;
   }
   int64_t blocks = (a.n_parents + 3) / 4;
-  if (blocks > 256 * 32) blocks = 256 * 32;
+  static const int64_t max_blocks = [] {  // (tuning knob: workgroups of the persistent expand grid)
+    const char* e = getenv("GIGL_EXPAND_BLOCKS");
+    const int64_t v = e ? atoll(e) : 0;
+    return v > 0 ? v : (int64_t)256 * 32;
+  }();
+  if (blocks > max_blocks) blocks = max_blocks;
   if (!covered) {
     gigl_prof_scope ps(ctx, GIGL_K_FIND_HEAVY);
     GIGL_HIP_CHECK(ctx, hipMemsetAsync(heavy_count, 0, 4, ctx->stream));
