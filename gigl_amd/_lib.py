@@ -15,7 +15,7 @@ GIGL_META_LEN = 16
 GIGL_META_N_NODES, GIGL_META_N_EDGES, GIGL_META_LEVEL0, GIGL_META_OVERFLOW = 0, 1, 2, 8
 LOC_HOST, LOC_DEVICE = 0, 1
 DTYPE_F32, DTYPE_F16 = 0, 1
-MODE_SPARK_HASH, MODE_FAST = 0, 1
+MODE_SPARK_HASH, MODE_FAST, MODE_REPLACE = 0, 1, 2
 AGGR = {"mean": 0, "sum": 1, "add": 1, "max": 2}
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -466,6 +466,8 @@ int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sam
   if (!p) return GIGL_E_INVALID_ARG;
   gigl_ctx* ctx = p->ctx;
   GIGL_REQUIRE(ctx, roots && out, "null argument");
+  if (mode == GIGL_MODE_REPLACE)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the one-call plan needs duplicate-free trees (no with-replacement mode)");
   if (!p->use_graph) return enqueue_range(p, 0, n_stages(p), roots, sampling_seed, mode, out);
 
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));

@@ -774,6 +774,24 @@ void table_unref(TableOwner* own) {  // g_table_mu held
   delete own;
 }
 
+// Largest j domain a table may cover.  12.8 B per j: at least 2^30 j (13.7 GB, as sized for a 2-hop MAG240M job) and
+// up to the whole uint32 axis (55 GB) when a quarter of the device's free memory allows it — a scale-30 RMAT job
+// (windows up to ~3.2e9) then never leaves the table path; windows beyond it are hashed directly (same result).
+// GIGL_TABLE_MAX_J overrides (tests).
+uint64_t table_cap_j() {
+  if (const char* e = getenv("GIGL_TABLE_MAX_J")) {
+    const unsigned long long v = strtoull(e, nullptr, 10);
+    if (v >= 64) return (uint64_t)v;
+  }
+  uint64_t cap = 1ull << 30;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    const uint64_t by_mem = (uint64_t)(free_b / 4) / 13;
+    if (by_mem > cap) cap = by_mem;
+  }
+  return cap < (1ull << 32) ? cap : (1ull << 32);
+}
+
 // make ctx->sampler_table a table that covers [0, want_dom)
 int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
   constexpr uint64_t S0 = 1ull << TBL_S0_SHIFT;
@@ -940,6 +958,45 @@ __global__ __launch_bounds__(256) void expand_fast_kernel(ExpandArgs a) {
   }
 }
 
+// with-replacement mode (the reference's sampleWithReplacementUDF, SGSPureSparkV1Task.scala:42-50: `numSamples`
+// independent uniform draws from the neighbour list, an UNSEEDED java.util.Random there): f draws per parent from a
+// counter-based generator keyed by (K + seed*counter, draw number) — reproducible; every parent with in-edges gets
+// exactly f entries (repeats possible, also when deg < f), written in ascending id order.  Not a parity mode: the
+// reference's draws cannot be reproduced.
+__global__ __launch_bounds__(256) void expand_replace_kernel(ExpandArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int64_t waves_total = (int64_t)gridDim.x * 4;
+  for (int64_t p = (int64_t)blockIdx.x * 4 + wave_in_block; p < a.n_parents; p += waves_total) {
+    uint32_t v, ksum;
+    parent_of(a, p, v, ksum);
+    uint32_t* out = a.out_nbr + p * a.f;
+    const int f = a.f;
+    int64_t deg = 0, s = 0;
+    if (v != GIGL_INVALID && (int64_t)v < a.n_nodes) {
+      s = a.rowptr[v];
+      deg = a.rowptr[v + 1] - s;
+    }
+    if (deg == 0) {
+      if (lane < f) out[lane] = GIGL_INVALID;
+      if (lane == 0) a.out_cnt[p] = 0;
+      continue;
+    }
+    uint32_t id = GIGL_INVALID;
+    if (lane < f) {
+      const uint32_t r = mix32(mix32(ksum + (uint32_t)a.hash_add) ^ (uint32_t)((lane + 1) * 0x9E3779B9u));
+      id = a.col[s + (int64_t)(((uint64_t)r * (uint64_t)deg) >> 32)];
+    }
+    int rank = 0;  // ascending ids, equal ids in lane order
+    for (int l = 0; l < f; ++l) {
+      const uint32_t o = readlane32(id, l);
+      rank += (o < id || (o == id && l < lane)) ? 1 : 0;
+    }
+    if (lane < f) out[rank] = id;
+    if (lane == 0) a.out_cnt[p] = f;
+  }
+}
+
 }  // namespace
 
 void gigl_sampler_table_free(gigl_ctx* ctx) {  // (the caller has synchronised the ctx stream)
@@ -959,7 +1016,8 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
   GIGL_REQUIRE(ctx, g && (roots || b == 0) && fanouts && out, "null argument");
   GIGL_REQUIRE(ctx, hops >= 1 && hops <= GIGL_MAX_HOPS, "hops must be in [1,%d]", GIGL_MAX_HOPS);
   GIGL_REQUIRE(ctx, b >= 0, "negative batch");
-  GIGL_REQUIRE(ctx, mode == GIGL_MODE_SPARK_HASH || mode == GIGL_MODE_FAST, "bad mode %d", mode);
+  GIGL_REQUIRE(ctx, mode == GIGL_MODE_SPARK_HASH || mode == GIGL_MODE_FAST || mode == GIGL_MODE_REPLACE,
+               "bad mode %d", mode);
   int64_t parents = b;
   for (int k = 0; k < hops; ++k) {
     if (fanouts[k] < 1 || fanouts[k] > GIGL_MAX_FANOUT)
@@ -981,7 +1039,7 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
   if (mode == GIGL_MODE_SPARK_HASH) {
     // size the hash range table for this graph/seed (built once, reused by every later call)
     const uint64_t bound = window_bound(g, hops, 1, sampling_seed);
-    const uint64_t cap = 1ull << 30;  // 13.7 GiB of table at most; windows beyond fall back to direct hashing
+    const uint64_t cap = table_cap_j();  // windows beyond the table fall back to direct hashing
     rc = ensure_table(ctx, bound == ~0ULL ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));
     if (rc != GIGL_OK) return rc;
     tb = ((TableOwner*)ctx->sampler_table)->t;
@@ -1018,11 +1076,14 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
     a.hash_add = (int32_t)((uint32_t)sampling_seed * (uint32_t)(k + 1));
     a.out_nbr = out->nbr[k];
     a.out_cnt = out->cnt[k];
-    if (mode == GIGL_MODE_FAST) {
+    if (mode == GIGL_MODE_FAST || mode == GIGL_MODE_REPLACE) {
       int64_t blocks = (parents + 3) / 4;
       if (blocks > 256 * 32) blocks = 256 * 32;
       gigl_prof_scope ps(ctx, GIGL_K_EXPAND);
-      hipLaunchKernelGGL(expand_fast_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+      if (mode == GIGL_MODE_FAST)
+        hipLaunchKernelGGL(expand_fast_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
+      else
+        hipLaunchKernelGGL(expand_replace_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
     } else {
       rc = run_expand(ctx, a, tb, covered, heavy_list, heavy_count);
@@ -1044,7 +1105,7 @@ int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* n
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "fanout %d outside [1,%d]", f, GIGL_MAX_FANOUT);
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (m == 0) return GIGL_OK;
-  const uint64_t cap = 1ull << 30;
+  const uint64_t cap = table_cap_j();
   const bool bounded = max_window_end >= 0;
   const uint64_t bound = bounded ? (uint64_t)max_window_end : ~0ULL;
   int32_t rc = ensure_table(ctx, !bounded ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));
@@ -1114,7 +1175,7 @@ int32_t gigl_sample_out_neighbors(gigl_ctx* ctx, gigl_graph* g_out, const uint32
   a.out_nbr = pos;
   a.out_cnt = cnt;
   const uint64_t bound = window_bound(g_out, 1, counter, sampling_seed);
-  const uint64_t cap = 1ull << 30;
+  const uint64_t cap = table_cap_j();
   rc = ensure_table(ctx, bound == ~0ULL ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));
   if (rc != GIGL_OK) return rc;
   const RangeTable tb = ((TableOwner*)ctx->sampler_table)->t;

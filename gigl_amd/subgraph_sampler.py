@@ -179,9 +179,12 @@ class SubgraphSampler:
             additional_spark35_jar_file_uris: Sequence[str] = (), *, uri_base: Optional[str] = None,
             device: int = 0, batch_size: int = 4096) -> Dict[str, List[str]]:
         cfg = GbmlConfigPbWrapper.from_uri(task_config_uri, uri_base=uri_base)
-        if str(cfg.experimental_flags.get("sample_with_replacement", "false")).lower() == "true":
-            raise NotImplementedError("experimental_flags.sample_with_replacement (the unseeded with-replacement UDF, "
-                                      "SGSPureSparkV1Task.scala:42-50,355-364) is not implemented")
+        # experimental_flags.sample_with_replacement: numNeighborsToSample independent uniform draws per parent
+        # (sampleWithReplacementUDF, SGSPureSparkV1Task.scala:42-50,355-364; an unseeded java.util.Random there, a
+        # counter-based generator keyed by the path here: valid samples, no parity definition)
+        from ._lib import MODE_REPLACE, MODE_SPARK_HASH
+        self.sampling_mode = (MODE_REPLACE if str(cfg.experimental_flags.get("sample_with_replacement", "false")).lower()
+                              == "true" else MODE_SPARK_HASH)
         # permutation_strategy: "deterministic" = the hash permutation with samplingSeed 42 (SamplingStrategy.scala:16-82,
         # reproducible, the parity mode).  Anything else is the reference's F.shuffle (:84-101): a uniformly random
         # permutation with no seed and no parity definition — served by the same kernel under a fresh random seed per
@@ -193,6 +196,7 @@ class SubgraphSampler:
         n, src, dst, x, labels, node_ids = load_preprocessed_graph(cfg)
         ids = np.asarray(node_ids, dtype=np.uint32)
         with HipKHopSamplerService(n, src, dst, x, cfg.is_graph_directed, device=device, sampling_seed=seed) as svc:
+            svc.sampling_mode = self.sampling_mode
             if getattr(cfg, "edge_features", None) is not None:  # hydrateEdges: records carry Edge.feature_values
                 svc.engine.load_edge_features(src, dst, cfg.edge_features, cfg.is_graph_directed)
             if cfg.task_kind == "node_classification":
@@ -218,7 +222,7 @@ class SubgraphSampler:
         skip_labeled = cfg.should_skip_training and cfg.should_skip_model_evaluation
         for i in range(0, ids.size, batch_size):
             chunk = ids[i:i + batch_size]
-            tree = eng.sample_khop(chunk, cfg.fanouts, sampling_seed=svc.sampling_seed)
+            tree = eng.sample_khop(chunk, cfg.fanouts, sampling_seed=svc.sampling_seed, mode=getattr(svc, 'sampling_mode', 0))
             buf, off = eng.encode_records(tree)
             unl.add(_frames_to_host(buf), off.cpu().numpy())
             if skip_labeled:
@@ -280,7 +284,7 @@ class SubgraphSampler:
                 neg, _ = eng.sample_positives(roots, Q, sampling_seed=svc.sampling_seed, counter=4, label_edges="neg")
                 cols.append(neg.view(-1, Q))
             grouped = torch.cat(cols, dim=1).reshape(-1).contiguous()
-            tree = eng.sample_khop(grouped, cfg.fanouts, sampling_seed=svc.sampling_seed)
+            tree = eng.sample_khop(grouped, cfg.fanouts, sampling_seed=svc.sampling_seed, mode=getattr(svc, 'sampling_mode', 0))
             emit = cnt > 0  # anchors need at least one positive
             if limit > 0:
                 emit = emit & ((torch.cumsum(emit.to(torch.int64), 0) + main.n_records) <= limit)
@@ -300,7 +304,7 @@ def self_write_rn(eng, svc, cfg, roots, rn) -> None:
     """the RootedNodeNeighborhood sample of every node (random-negative stream / inference input) for one chunk"""
     if not rn:
         return
-    tree = eng.sample_khop(roots, cfg.fanouts, sampling_seed=svc.sampling_seed)
+    tree = eng.sample_khop(roots, cfg.fanouts, sampling_seed=svc.sampling_seed, mode=getattr(svc, 'sampling_mode', 0))
     buf, off = eng.encode_records(tree)
     b_h, o_h = _frames_to_host(buf), off.cpu().numpy()
     for w in rn.values():

@@ -54,6 +54,12 @@ extern "C" {
 /* sampling modes */
 #define GIGL_MODE_SPARK_HASH 0 /* parity: xxhash64-keyed permutation, SamplingStrategy.scala:16-82 */
 #define GIGL_MODE_FAST 1       /* NOT parity: counter-based RNG positions; labelled as such everywhere */
+#define GIGL_MODE_REPLACE 2    /* sampling WITH replacement (experimental_flags.sample_with_replacement: the reference's
+                                  sampleWithReplacementUDF, SGSPureSparkV1Task.scala:42-50,355-364, draws from an
+                                  unseeded java.util.Random — no parity definition): f uniform draws per parent from a
+                                  counter-based generator keyed by the path sum, repeats possible, cnt = f whenever
+                                  the parent has in-edges.  gigl_sample_khop only: trees with repeated ids are not
+                                  valid input of the one-call plan */
 
 typedef struct gigl_ctx gigl_ctx;
 typedef struct gigl_graph gigl_graph;

@@ -256,3 +256,37 @@ def test_graphsage_forward_matches_reference_semantics(eng, d, hid, out, fanouts
     ref = gnn_ref.graphsage_forward(torch.from_numpy(x[nodes]), torch.from_numpy(np.stack([ls, ld])), sd, len(fanouts))
     want = ref[[g2l[int(r)] for r in roots]].numpy()
     np.testing.assert_allclose(emb, want, rtol=1e-5, atol=1e-5)
+
+
+def test_with_replacement_mode_draws_f_valid_neighbours():
+    """GIGL_MODE_REPLACE (sampleWithReplacementUDF, SGSPureSparkV1Task.scala:42-50): f draws per parent with in-edges
+    (also when deg < f), every draw an in-neighbour, ascending within a parent, reproducible"""
+    from gigl_amd._lib import MODE_REPLACE
+    from gigl_amd.engine import HipEngine
+    from helpers import rmat_edges
+    s, d = rmat_edges(10, 6000, seed=5)
+    n = 1 << 10
+    rowptr, col = oracle.build_csc(n, s, d, is_directed=False)
+    eng = HipEngine(0)
+    eng.load_csc(rowptr, col)
+    roots = np.arange(0, 300, dtype=np.uint32)
+    fan = [7, 4]
+    t1 = eng.sample_khop(roots, fan, mode=MODE_REPLACE)
+    nbr = [x.cpu().numpy().view(np.uint32) for x in t1.nbr]
+    cnt = [x.cpu().numpy() for x in t1.cnt]
+    t2 = eng.sample_khop(roots, fan, mode=MODE_REPLACE)
+    assert all(np.array_equal(nbr[k], t2.nbr[k].cpu().numpy().view(np.uint32)) for k in range(2))
+    parents = roots
+    saw_repeat = False
+    for k, f in enumerate(fan):
+        for p, v in enumerate(parents.tolist()):
+            seg = nbr[k][p * f:(p + 1) * f]
+            if v == 0xFFFFFFFF or rowptr[v + 1] == rowptr[v]:
+                assert cnt[k][p] == 0 and np.all(seg == 0xFFFFFFFF)
+                continue
+            row = set(col[rowptr[v]:rowptr[v + 1]].tolist())
+            assert cnt[k][p] == f and all(int(x) in row for x in seg) and np.all(np.diff(seg.astype(np.int64)) >= 0)
+            saw_repeat = saw_repeat or len(set(seg.tolist())) < f
+        parents = nbr[k]
+    assert saw_repeat
+    eng.close()

@@ -66,3 +66,37 @@ def test_many_windows_rmat(eng):
     for k in range(2):
         assert np.array_equal(tree.cnt[k].cpu().numpy(), cnt_o[k])
         assert np.array_equal(_u32(tree.nbr[k]), nbr_o[k])
+
+
+def test_million_edge_hub_beyond_2_pow_30(eng):
+    """BASELINE configs[3] territory (RMAT scale-30: hubs of ~10^6 in-edges, path sums up to 3 * 2^30): a hub row of
+    1.2 M in-edges asked for at window offsets inside the table, straddling 2^30, far beyond it, and wrapping 2^32 —
+    with the table allowed to grow past 2^30 (max_window_end says so) and with the bound unknown (-1: windows past
+    the table take the workgroup-per-row direct-hash path).  Every answer == the oracle's permutation."""
+    import torch
+    rng = np.random.default_rng(9)
+    n, deg = 1_400_000, 1_200_000
+    hub_src = rng.choice(n - 1, size=deg, replace=False).astype(np.uint32) + 1
+    small_src = rng.integers(1, n, size=4000).astype(np.uint32)
+    src = np.concatenate([hub_src, small_src])
+    dst = np.concatenate([np.zeros(deg, np.uint32), rng.integers(1, 50, size=4000).astype(np.uint32)])
+    rowptr, col = oracle.build_csc(n, src, dst, is_directed=True)
+    eng.load_csc(rowptr, col)
+    ksums = np.array([5, (1 << 30) - 600_000, (1 << 30) + 1_000_000, 3 * (1 << 30) - 7, (1 << 32) - 500_000, 17],
+                     dtype=np.uint64)
+    nodes = np.array([0, 0, 0, 0, 0, 3], dtype=np.uint32)
+    f, hash_add = 10, 84
+    dev = eng.device
+    nd = torch.from_numpy(nodes.view(np.int32)).to(dev)
+    kd = torch.from_numpy(ksums.astype(np.uint32).view(np.int32)).to(dev)
+    bound = int(3 * (1 << 30) + deg + hash_add)
+    for mwe in (bound, -1):
+        # a bound promises that no window ends beyond it: the request that wraps 2^32 is only legal without one
+        keep = [i for i in range(nodes.size) if mwe < 0 or int(ksums[i]) + hash_add + deg <= mwe]
+        nbr, cnt = eng.expand_frontier(nd[keep].contiguous(), kd[keep].contiguous(), f, hash_add, 1, mwe)
+        nbr = nbr.cpu().numpy().view(np.uint32).reshape(-1, f)
+        cnt = cnt.cpu().numpy()
+        for i, (v, k) in enumerate(zip(nodes[keep].tolist(), ksums[keep].tolist())):
+            row = col[rowptr[v]:rowptr[v + 1]]
+            want = np.sort(oracle.hash_permutation(row, int(k) & 0xFFFFFFFF, sampling_seed=hash_add, counter=1)[:f])
+            assert cnt[i] == want.size and np.array_equal(nbr[i][: want.size], want), (mwe, i)
