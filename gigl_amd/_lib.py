@@ -42,6 +42,7 @@ SYMBOLS = [
     "gigl_comm_all_to_all", "gigl_comm_flush_local", "gigl_comm_destroy", "gigl_dist_plan_create",
     "gigl_dist_plan_set_weights", "gigl_dist_plan_phases", "gigl_dist_plan_phase", "gigl_dist_plan_run",
     "gigl_dist_plan_run_local", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
+    "gigl_split_hash_slots",
 ]
 
 KERNEL_IDS = {
@@ -186,6 +187,7 @@ def load() -> C.CDLL:
         "gigl_sage_plan_use_graph": [vp, i32],
         "gigl_sage_plan_flush_profile": [vp],
         "gigl_sage_plan_stats": [vp, vp, vp],
+        "gigl_split_hash_slots": [vp, vp, vp, i64, i32, i32, vp],
         "gigl_comm_unique_id": [vp],
         "gigl_dist_init": [vp, i32, i32, vp, P(vp)],
         "gigl_dist_init_local": [P(vp), i32, P(vp)],

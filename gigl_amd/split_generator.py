@@ -23,6 +23,11 @@ a concrete hash slot -> "parity unpinned" for the exact assignment.  MurmurHash3
 MurmurHash3_x86_32 with seed 0x3c074a61 (its `arraySeed`), restated here and checked against the public
 MurmurHash3_x86_32 vectors (tests/test_split_generator.py).  `subsample` draws scala.util.Random.nextFloat in the
 reference (unseeded): any ratio < 1 is therefore non-reproducible there; a seeded numpy generator is used here.
+
+Hashing in bulk: SplitGenerator.run hashes every node / edge of the input samples in one device pass
+(gigl_split_hash_slots, csrc/split.hip — the strategies' per-object `assign` calls then hit a cache); the device
+kernel, this module's host routine and the C restatement in oracle/ are checked against each other and against the
+public MurmurHash3_x86_32 vectors (tests/test_split_generator.py, tests/test_gpu_split.py).
 """
 from __future__ import annotations
 
@@ -93,6 +98,48 @@ class HashingAssigner:
         # math.round(Float): floor(x + 0.5) as int
         self.indices = [int(np.floor(np.float32(c * np.float32(HASH_SPACE_GRANULARITY)) + np.float32(0.5))) for c in cum]
         self._cache: Dict[bytes, object] = {}
+
+    def _bucket_of_slot(self, slot: int):
+        for b, lo, hi in zip(self.buckets, self.indices, self.indices[1:]):
+            if lo <= slot < hi:
+                return b
+        raise AssertionError(f"hash slot {slot} falls in no bucket (indices {self.indices})")
+
+    def prefill(self, engine, a, b=None, condensed_type: int = 0, symmetric: bool = False) -> int:
+        """hash many objects at once on the device (gigl_split_hash_slots, csrc/split.hip) and remember their buckets:
+        nodes `a` (keys "<id>-<type>") or edges `a` -> `b` (keys "<src>-<type>-<dst>").  The per-object `assign`
+        calls of the strategies then hit the cache instead of hashing in Python.  -> objects hashed"""
+        import ctypes as C
+        import torch
+        from ._lib import check
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        if a.size == 0:
+            return 0
+        dev = engine.device
+        ta = torch.from_numpy(a.view(np.int32)).to(dev)
+        tb = None
+        if b is not None:
+            b = np.ascontiguousarray(b, dtype=np.uint32)
+            tb = torch.from_numpy(b.view(np.int32)).to(dev)
+        slots = torch.empty(a.size, dtype=torch.int32, device=dev)
+        engine._stream.synchronize()
+        check(engine._lib.gigl_split_hash_slots(engine._ctx, C.c_void_p(ta.data_ptr()),
+                                                C.c_void_p(tb.data_ptr()) if tb is not None else None, a.size,
+                                                int(condensed_type), 1 if symmetric else 0,
+                                                C.c_void_p(slots.data_ptr())), engine._ctx)
+        engine._stream.synchronize()
+        sl = slots.cpu().numpy()
+        bounds = np.asarray(self.indices)
+        which = np.searchsorted(bounds, sl, side="right") - 1
+        if b is None:
+            for x, w in zip(a.tolist(), which.tolist()):
+                self._cache[node_unique_id(x, condensed_type)] = self.buckets[w]
+        else:
+            for x, y, w in zip(a.tolist(), b.tolist(), which.tolist()):
+                if symmetric and x > y:
+                    x, y = y, x
+                self._cache[edge_unique_id(x, y, condensed_type)] = self.buckets[w]
+        return int(a.size)
 
     def assign_bytes(self, byte_string: bytes):
         hit = self._cache.get(byte_string)
@@ -381,9 +428,53 @@ def _write_dir(prefix: str, payloads: List[bytes]) -> List[str]:
     return [name]
 
 
-def _split_and_write(in_prefix: str, out_prefixes: Dict[str, str], decode: Callable, split_fn: Callable):
+def _prefill_assigner(strat, samples) -> int:
+    """hash every node / edge the strategy will ask about in ONE device pass (HashingAssigner.prefill); without a HIP
+    device the assigner hashes on demand on the host, as the reference's JVM does"""
+    assigner = getattr(strat, "assigner", None)
+    try:
+        import torch
+        if assigner is None or not torch.cuda.is_available():
+            return 0
+        from .engine import default_engine
+        eng = default_engine(torch.device("cuda", torch.cuda.current_device()))
+    except Exception:  # noqa: BLE001 — no device / no library: host hashing
+        return 0
+    graphs = [g for g in (getattr(smp, "neighborhood", None) for smp in samples) if g is not None]
+    if isinstance(assigner, NodeToDatasetSplitHashingAssigner):
+        by_type: Dict[int, set] = {}
+        for smp in samples:
+            r = getattr(smp, "root_node", None)
+            if r is not None:
+                by_type.setdefault(r.condensed_node_type or 0, set()).add(r.node_id)
+        for g in graphs:
+            for nd in g.nodes:
+                by_type.setdefault(nd.condensed_node_type or 0, set()).add(nd.node_id)
+            for e in g.edges:
+                by_type.setdefault(0, set()).update((e.src_node_id, e.dst_node_id))
+        return sum(assigner.prefill(eng, np.fromiter(ids, dtype=np.uint32, count=len(ids)), condensed_type=t)
+                   for t, ids in by_type.items())
+    by_type_e: Dict[int, set] = {}
+    for smp in samples:
+        for fld in ("pos_edges", "hard_neg_edges", "neg_edges"):
+            for e in getattr(smp, fld, None) or ():
+                by_type_e.setdefault(e.condensed_edge_type or 0, set()).add((e.src_node_id, e.dst_node_id))
+    for g in graphs:
+        for e in g.edges:
+            by_type_e.setdefault(e.condensed_edge_type or 0, set()).add((e.src_node_id, e.dst_node_id))
+    n = 0
+    for t, pairs in by_type_e.items():
+        arr = np.array(sorted(pairs), dtype=np.uint32).reshape(-1, 2)
+        n += assigner.prefill(eng, arr[:, 0], arr[:, 1], condensed_type=t, symmetric=getattr(assigner, "symmetric", False))
+    return n
+
+
+def _split_and_write(in_prefix: str, out_prefixes: Dict[str, str], decode: Callable, split_fn: Callable,
+                     strat=None):
     """SplitGeneratorTask.splitSamplesAndWriteToOutputPath (lib/tasks/SplitGeneratorTask.scala:60-103)"""
     samples = [decode(r) for f in tfrecord_files(in_prefix) for r in wire.read_tfrecords(f)]
+    if strat is not None:
+        _prefill_assigner(strat, samples)
     files = {}
     for split in (TRAIN, VAL, TEST):
         out = [s.SerializeToString() for smp in samples for s in split_fn(smp, split)]
@@ -403,19 +494,19 @@ class SplitGenerator:
             outs = {TRAIN: res(ds["trainDataUri"]), VAL: res(ds["valDataUri"]), TEST: res(ds["testDataUri"])}
             return {"main": _split_and_write(cfg.labeled_tfrecord_uri_prefix, outs,
                                              wire.SupervisedNodeClassificationSample.FromString,
-                                             strat.split_training_sample)}
+                                             strat.split_training_sample, strat)}
         ds = dm["nodeAnchorBasedLinkPredictionDataset"]
         outs = {TRAIN: res(ds["trainMainDataUri"]), VAL: res(ds["valMainDataUri"]), TEST: res(ds["testMainDataUri"])}
         files = {"main": _split_and_write(cfg.nablp_tfrecord_uri_prefix, outs,
                                           wire.NodeAnchorBasedLinkPredictionSample.FromString,
-                                          strat.split_training_sample)}
+                                          strat.split_training_sample, strat)}
         for node_type, in_prefix in cfg.random_negative_tfrecord_uri_prefixes.items():
             outs = {TRAIN: res(ds["trainNodeTypeToRandomNegativeDataUri"][node_type]),
                     VAL: res(ds["valNodeTypeToRandomNegativeDataUri"][node_type]),
                     TEST: res(ds["testNodeTypeToRandomNegativeDataUri"][node_type])}
             files[f"random_negative/{node_type}"] = _split_and_write(
                 in_prefix, outs, wire.RootedNodeNeighborhood.FromString,
-                strat.split_rooted_node_neighborhood_training_sample)
+                strat.split_rooted_node_neighborhood_training_sample, strat)
         return files
 
 

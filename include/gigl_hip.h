@@ -602,6 +602,15 @@ int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
 int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);
 
+/* ---- split generator: hash slots of the assigners, in bulk.  Replaces HashingAssigner.assign's per-object hashing
+ *      (scala/split_generator/src/main/scala/lib/assigners/AbstractAssigners.scala:30-111):
+ *      slots[i] = floorMod(MurmurHash3.bytesHash(key_i), 10000), key = "<a>-<type>" for nodes (b == NULL;
+ *      NodeToDatasetSplitHashingAssigner.scala) or "<src>-<type>-<dst>" for edges (a = src, b = dst; endpoints ordered
+ *      (min, max) first when symmetric != 0: TransductiveEdgeToLinkSplitHashingAssigner.scala:66-78).  The bucket a
+ *      slot belongs to (cumulative float32 weights) stays with the caller.  All pointers DEVICE. */
+int32_t gigl_split_hash_slots(gigl_ctx* ctx, const uint32_t* a, const uint32_t* b, int64_t n, int32_t condensed_type,
+                              int32_t symmetric, int32_t* slots);
+
 /* ---- the hash-partitioned (multi-GPU) step inside the library.
  *      Replaces the reference's distributed loader path: DistLinkPredictionDataPartitioner (owner(v) = v % world,
  *      python/gigl/distributed/dist_link_prediction_data_partitioner.py:692-695) + DistNeighborLoader's per-batch RPC

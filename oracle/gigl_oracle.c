@@ -17,6 +17,7 @@
  * All paths below are relative to the reference root.
  */
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -453,5 +454,63 @@ int gigl_oracle_build_csc(int64_t n, int64_t e, const uint32_t* src, const uint3
     for (int64_t i = 0; i < n; ++i) rowptr[i + 1] += rowptr[i];
   }
   free(keys);
+  return 0;
+}
+
+/* ---- split generator hash slots (scala/split_generator/src/main/scala/lib/assigners/AbstractAssigners.scala:30-111).
+ * scala.util.hashing.MurmurHash3.bytesHash(data) == MurmurHash3_x86_32(data, seed = 0x3c074a61 "arraySeed") — the
+ * published algorithm of Austin Appleby's MurmurHash3 (scala-library is a third-party dependency absent from
+ * /root/reference: restated from the public reference implementation, pinned on its public known answers in
+ * tests/test_split_generator.py).  slot = Math.floorMod(hash, 10000). */
+int32_t gigl_oracle_murmur3_x86_32(const uint8_t* data, int64_t len, uint32_t seed) {
+  uint32_t h = seed;
+  const int64_t nblocks = len / 4;
+  for (int64_t i = 0; i < nblocks; ++i) {
+    uint32_t k;
+    memcpy(&k, data + 4 * i, 4); /* little-endian host */
+    k *= 0xcc9e2d51u;
+    k = (k << 15) | (k >> 17);
+    k *= 0x1b873593u;
+    h ^= k;
+    h = (h << 13) | (h >> 19);
+    h = h * 5u + 0xe6546b64u;
+  }
+  const uint8_t* tail = data + nblocks * 4;
+  uint32_t k1 = 0;
+  switch (len & 3) {
+    case 3: k1 ^= (uint32_t)tail[2] << 16; /* fall through */
+    case 2: k1 ^= (uint32_t)tail[1] << 8;  /* fall through */
+    case 1:
+      k1 ^= tail[0];
+      k1 *= 0xcc9e2d51u;
+      k1 = (k1 << 15) | (k1 >> 17);
+      k1 *= 0x1b873593u;
+      h ^= k1;
+  }
+  h ^= (uint32_t)len;
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return (int32_t)h;
+}
+
+/* key = "<a>-<type>" (has_b == 0) or "<a>-<type>-<b>" with (a, b) ordered (min, max) first when symmetric */
+int gigl_oracle_split_slots(const uint32_t* a, const uint32_t* b, int64_t n, int32_t type, int32_t has_b,
+                            int32_t symmetric, int32_t* slots) {
+  char key[64];
+  for (int64_t i = 0; i < n; ++i) {
+    uint32_t x = a[i], y = has_b ? b[i] : 0;
+    if (has_b && symmetric && x > y) {
+      uint32_t t = x;
+      x = y;
+      y = t;
+    }
+    int len = has_b ? snprintf(key, sizeof(key), "%u-%d-%u", x, type, y) : snprintf(key, sizeof(key), "%u-%d", x, type);
+    int32_t h = gigl_oracle_murmur3_x86_32((const uint8_t*)key, len, 0x3c074a61u);
+    int32_t m = h % 10000;
+    slots[i] = m < 0 ? m + 10000 : m;
+  }
   return 0;
 }

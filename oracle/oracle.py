@@ -163,3 +163,29 @@ def build_csc(n: int, src, dst, is_directed: bool):
     rc = _L().gigl_oracle_build_csc(*args, _p(rowptr, C.c_int64), _p(col, C.c_uint32), C.byref(e_out))
     assert rc == 0, rc
     return rowptr, col[: e_out.value].copy()
+
+
+def murmur3_x86_32(data: bytes, seed: int) -> int:
+    """MurmurHash3_x86_32 (signed int32)"""
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+    lib = _L()
+    lib.gigl_oracle_murmur3_x86_32.restype = C.c_int32
+    return int(lib.gigl_oracle_murmur3_x86_32(_p(np.ascontiguousarray(buf), C.c_uint8), C.c_int64(len(data)),
+                                              C.c_uint32(seed & 0xFFFFFFFF)))
+
+
+def split_slots(a, b=None, condensed_type: int = 0, symmetric: bool = False) -> np.ndarray:
+    """hash slots in [0, 10000) of node keys "<a>-<type>" (b None) or edge keys "<a>-<type>-<b>"
+    (HashingAssigner, AbstractAssigners.scala:30-111)"""
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    out = np.zeros(a.size, dtype=np.int32)
+    if b is None:
+        rc = _L().gigl_oracle_split_slots(_p(a, C.c_uint32), None, C.c_int64(a.size), C.c_int32(condensed_type),
+                                          C.c_int32(0), C.c_int32(0), _p(out, C.c_int32))
+    else:
+        bb = np.ascontiguousarray(b, dtype=np.uint32)
+        rc = _L().gigl_oracle_split_slots(_p(a, C.c_uint32), _p(bb, C.c_uint32), C.c_int64(a.size),
+                                          C.c_int32(condensed_type), C.c_int32(1), C.c_int32(1 if symmetric else 0),
+                                          _p(out, C.c_int32))
+    assert rc == 0
+    return out

@@ -36,6 +36,19 @@ def test_murmur3_x86_32_known_answers():
     assert u(b"Hello, world!", 0) == 0xC0363E43
     assert u(b"The quick brown fox jumps over the lazy dog", 0) == 0x2E4FF723
     assert -2**31 <= murmur3_bytes_hash(b"12-0-7") < 2**31  # signed like Scala's Int
+    # the oracle's C restatement is pinned on the same public vectors and agrees with the host routine on keys
+    import oracle.oracle as orc
+    for data, seed, want in ((b"", 1, 0x514E28B7), (b"\x21\x43\x65\x87", 0x5082EDEE, 0x2362F9DE), (b"test", 0, 0xBA6BD213),
+                             (b"Hello, world!", 0, 0xC0363E43),
+                             (b"The quick brown fox jumps over the lazy dog", 0, 0x2E4FF723), (b"\x21\x43\x65", 0, 0x7E4A8634)):
+        assert orc.murmur3_x86_32(data, seed) & 0xFFFFFFFF == want
+    ids = np.array([0, 7, 12, 4096, 123456789, 4294967295], dtype=np.uint32)
+    from gigl_amd.split_generator import HASH_SPACE_GRANULARITY, SCALA_ARRAY_SEED, edge_unique_id, node_unique_id
+    assert orc.split_slots(ids, condensed_type=1).tolist() == [
+        murmur3_bytes_hash(node_unique_id(int(x), 1), SCALA_ARRAY_SEED) % HASH_SPACE_GRANULARITY for x in ids]
+    assert orc.split_slots(ids, ids[::-1], condensed_type=0, symmetric=True).tolist() == [
+        murmur3_bytes_hash(edge_unique_id(min(int(x), int(y)), max(int(x), int(y)), 0), SCALA_ARRAY_SEED)
+        % HASH_SPACE_GRANULARITY for x, y in zip(ids, ids[::-1])]
 
 
 def _mock_edges(n=100):
