@@ -42,7 +42,7 @@ SYMBOLS = [
     "gigl_comm_all_to_all", "gigl_comm_flush_local", "gigl_comm_destroy", "gigl_dist_plan_create",
     "gigl_dist_plan_set_weights", "gigl_dist_plan_phases", "gigl_dist_plan_phase", "gigl_dist_plan_run",
     "gigl_dist_plan_run_local", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
-    "gigl_split_hash_slots",
+    "gigl_split_hash_slots", "gigl_hgt_aggregate", "gigl_simplehgn_alpha", "gigl_weighted_aggregate",
 ]
 
 KERNEL_IDS = {
@@ -188,6 +188,9 @@ def load() -> C.CDLL:
         "gigl_sage_plan_flush_profile": [vp],
         "gigl_sage_plan_stats": [vp, vp, vp],
         "gigl_split_hash_slots": [vp, vp, vp, i64, i32, i32, vp],
+        "gigl_hgt_aggregate": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp],
+        "gigl_simplehgn_alpha": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, C.c_float, vp, vp],
+        "gigl_weighted_aggregate": [vp, vp, vp, i32, i32, vp, vp, i64, vp],
         "gigl_comm_unique_id": [vp],
         "gigl_dist_init": [vp, i32, i32, vp, P(vp)],
         "gigl_dist_init_local": [P(vp), i32, P(vp)],

@@ -732,6 +732,30 @@ class HipEngine:
               self._ctx)
         return out
 
+    # ---- heterogeneous encoders (csrc/hetero.hip) ------------------------------------------------
+    def hgt_aggregate(self, q, k, v, heads: int, dim: int, rowptr, col, etype, p_rel, n_dst: int, out) -> None:
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        for t in (q, k, v, out):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+        check(self._lib.gigl_hgt_aggregate(self._ctx, p(q), p(k), p(v), heads, dim, p(rowptr), p(col), p(etype),
+                                           p(p_rel), n_dst, p(out)), self._ctx)
+
+    def simplehgn_alpha(self, hl, hr, het, hef, src, dst, etype, n_nodes: int, heads: int, slope: float):
+        """-> alpha [E, heads] (softmax over the edges sharing a SOURCE node), in the order of src / dst / etype"""
+        ne = int(src.numel())
+        alpha = torch.empty((ne, heads), dtype=torch.float32, device=self.device)
+        scratch = torch.empty(2 * max(n_nodes, 1) * heads, dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(self._lib.gigl_simplehgn_alpha(self._ctx, p(hl), p(hr), p(het), p(hef), p(src), p(dst), p(etype), ne,
+                                             n_nodes, heads, float(slope), p(scratch), p(alpha)), self._ctx)
+        return alpha
+
+    def weighted_aggregate(self, alpha, v, heads: int, dim: int, rowptr, col, n_dst: int, out) -> None:
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        assert v.is_contiguous() and alpha.is_contiguous() and out.is_contiguous()
+        check(self._lib.gigl_weighted_aggregate(self._ctx, p(alpha), p(v), heads, dim, p(rowptr), p(col), n_dst,
+                                                p(out)), self._ctx)
+
     def retrieval_loss(self, scores: torch.Tensor, temperature: Optional[float], cand_prob: Optional[torch.Tensor],
                        query_ids: Optional[torch.Tensor], cand_ids: Optional[torch.Tensor], want_masked: bool = False):
         """-> (loss [] fp32, row_lse [q], masked logits [q, c] | None): gigl_retrieval_loss"""

@@ -1,0 +1,312 @@
+"""Heterogeneous encoders over typed batch graphs: HGT and SimpleHGN.
+
+Mirror of the reference's models (paths relative to the reference root)
+  HGT, SimpleHGN      python/gigl/src/common/models/pyg/heterogeneous.py:18-122, :123-273
+  HGTConv             python/gigl/src/common/models/pyg/nn/conv/hgt_conv.py:16-252   (PyG's, modified to keep node
+                                                                                    types without incoming edges)
+  SimpleHGNConv       python/gigl/src/common/models/pyg/nn/conv/simplehgn_conv.py:10-180
+Same constructor arguments and parameter names (PyG's HeteroDictLinear / HeteroLinear / ParameterDict layouts:
+`kqv_lin.lins.<type>.weight`, `k_rel.weight [H*T, D, D]`, `skip.<type>`, `p_rel.<src__rel__dst>`, ... — names come
+from the un-vendored PyG 2.5.3: "parity unpinned").  The dense parts are GEMMs on gigl_linear; the
+attention-weighted segmented reductions are gigl_hgt_aggregate / gigl_simplehgn_alpha / gigl_weighted_aggregate
+(csrc/hetero.hip).  Inference (forward) only: training these encoders through the plugins is not built.
+Input: HeteroGraphData — the typed counterpart of nn.GraphData (what PygGraphBuilder's HeteroData carries: x per node
+type, edge_index / edge_attr per (src type, relation, dst type)).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+EdgeType = Tuple[str, str, str]
+
+
+@dataclass
+class HeteroGraphData:
+    x_dict: Dict[str, torch.Tensor]
+    edge_index_dict: Dict[EdgeType, torch.Tensor]            # int64 [2, e]: row 0 = source, row 1 = destination
+    edge_attr_dict: Dict[EdgeType, torch.Tensor] = field(default_factory=dict)
+
+    def to(self, device):
+        mv = lambda d: {k: v.to(device) for k, v in d.items()}
+        return HeteroGraphData(mv(self.x_dict), mv(self.edge_index_dict), mv(self.edge_attr_dict))
+
+    @property
+    def node_types(self) -> List[str]:
+        return list(self.x_dict)
+
+    @property
+    def edge_types(self) -> List[EdgeType]:
+        return list(self.edge_index_dict)
+
+
+def _engine_for(module: nn.Module, t: torch.Tensor):
+    eng = getattr(module, "engine", None)
+    if eng is not None:
+        return eng
+    from .engine import default_engine
+    return default_engine(t.device)
+
+
+def _linear(eng, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """x [m, k] @ w[n, k]^T + b on the fp32 MFMA GEMM"""
+    x = x.contiguous().to(torch.float32)
+    m = torch.tensor([x.shape[0]], dtype=torch.int32, device=x.device)
+    if x.shape[0] == 0:
+        return x.new_zeros((0, w.shape[0]))
+    return eng.linear(x, w.contiguous(), b, m, int(x.shape[0]), 0)
+
+
+def _csr_by_dst(src: torch.Tensor, dst: torch.Tensor, n_dst: int, *more):
+    """edges sorted by destination -> (rowptr int32 [n_dst+1], col int32, order) and `more` arrays in that order"""
+    order = torch.sort(dst, stable=True).indices
+    rowptr = torch.zeros(n_dst + 1, dtype=torch.int64, device=dst.device)
+    rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_dst), 0)
+    return (rowptr.to(torch.int32), src[order].to(torch.int32).contiguous(), order,
+            *[m[order].contiguous() for m in more])
+
+
+class _HeteroDictLinear(nn.Module):
+    """PyG HeteroDictLinear: one Linear per key"""
+
+    def __init__(self, in_channels: Dict[str, int], out_channels: int):
+        super().__init__()
+        self.lins = nn.ModuleDict({k: nn.Linear(c, out_channels) for k, c in in_channels.items()})
+
+
+class _HeteroLinear(nn.Module):
+    """PyG HeteroLinear: weight [num_types, in, out] (x @ weight[type]), optional bias [num_types, out]"""
+
+    def __init__(self, in_channels: int, out_channels: int, num_types: int, bias: bool = True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(num_types, in_channels, out_channels))
+        self.bias = nn.Parameter(torch.zeros(num_types, out_channels)) if bias else None
+        bound = 1.0 / math.sqrt(in_channels)
+        nn.init.uniform_(self.weight, -bound, bound)
+
+
+class HGTConv(nn.Module):
+    def __init__(self, in_channels, out_channels: int, metadata, heads: int = 1, **kwargs):
+        super().__init__()
+        if out_channels % heads != 0:
+            raise ValueError(f"'out_channels' (got {out_channels}) must be divisible by the number of heads (got {heads})")
+        node_types, edge_types = list(metadata[0]), [tuple(e) for e in metadata[1]]
+        if not isinstance(in_channels, dict):
+            in_channels = {t: in_channels for t in node_types}
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.node_types, self.edge_types = node_types, edge_types
+        self.edge_types_map = {e: i for i, e in enumerate(edge_types)}
+        self.kqv_lin = _HeteroDictLinear(in_channels, out_channels * 3)
+        self.out_lin = _HeteroDictLinear({t: out_channels for t in node_types}, out_channels)
+        dim = out_channels // heads
+        self.k_rel = _HeteroLinear(dim, dim, heads * len(edge_types), bias=False)
+        self.v_rel = _HeteroLinear(dim, dim, heads * len(edge_types), bias=False)
+        self.skip = nn.ParameterDict({t: nn.Parameter(torch.ones(1)) for t in node_types})
+        self.p_rel = nn.ParameterDict({"__".join(e): nn.Parameter(torch.ones(1, heads)) for e in edge_types})
+
+    def _block_diag(self, rel: _HeteroLinear, ti: int) -> torch.Tensor:
+        """[H*D, H*D] weight (gigl_linear layout: out x in) applying head h's D x D relation matrix to head h's slice"""
+        H, T = self.heads, len(self.edge_types)
+        return torch.block_diag(*[rel.weight[h * T + ti].t() for h in range(H)]).contiguous()
+
+    def forward(self, x_dict: Dict[str, torch.Tensor], edge_index_dict: Dict[EdgeType, torch.Tensor]):
+        any_x = next(iter(x_dict.values()))
+        eng = _engine_for(self, any_x)
+        dev = any_x.device
+        H, Fo = self.heads, self.out_channels
+        D = Fo // H
+        k, q, v = {}, {}, {}
+        for t, x in x_dict.items():
+            lin = self.kqv_lin.lins[t]
+            kqv = _linear(eng, x, lin.weight, lin.bias)
+            k[t], q[t], v[t] = (z.contiguous() for z in torch.tensor_split(kqv, 3, dim=1))
+        dst_off, n_dst = {}, 0
+        for t, x in x_dict.items():
+            dst_off[t] = n_dst
+            n_dst += int(x.shape[0])
+        qq = torch.cat([q[t] for t in x_dict]).contiguous()
+        ks, vs, srcs, dsts, ets, n_src = [], [], [], [], [], 0
+        for et, ei in edge_index_dict.items():
+            et = tuple(et)
+            ti = self.edge_types_map[et]
+            ks.append(_linear(eng, k[et[0]], self._block_diag(self.k_rel, ti), None))
+            vs.append(_linear(eng, v[et[0]], self._block_diag(self.v_rel, ti), None))
+            srcs.append(ei[0] + n_src)
+            dsts.append(ei[1] + dst_off[et[2]])
+            ets.append(torch.full((ei.shape[1],), ti, dtype=torch.int32, device=dev))
+            n_src += int(k[et[0]].shape[0])
+        out = torch.zeros((n_dst, Fo), dtype=torch.float32, device=dev)
+        if srcs and n_dst:
+            rowptr, col, _, ety = _csr_by_dst(torch.cat(srcs), torch.cat(dsts), n_dst, torch.cat(ets))
+            p_rel = torch.cat([self.p_rel["__".join(e)].reshape(1, H) for e in self.edge_types]).contiguous()
+            eng.hgt_aggregate(qq, torch.cat(ks).contiguous(), torch.cat(vs).contiguous(), H, D, rowptr, col, ety,
+                              p_rel.detach(), n_dst, out)
+        res = {}
+        for t, x in x_dict.items():
+            lin = self.out_lin.lins[t]
+            o = _linear(eng, F.gelu(out[dst_off[t]: dst_off[t] + x.shape[0]]), lin.weight, lin.bias)
+            if o.shape[-1] == x.shape[-1]:
+                a = self.skip[t].sigmoid()
+                o = a * o + (1 - a) * x
+            res[t] = o
+        return res
+
+
+class HGT(nn.Module):
+    def __init__(self, node_type_to_feat_dim_map: Dict[str, int], edge_type_to_feat_dim_map: Dict[EdgeType, int],
+                 hid_dim: int, out_dim: int = 128, num_layers: int = 2, num_heads: int = 2,
+                 should_l2_normalize_embedding_layer_output: bool = False, feature_embedding_layers=None, **kwargs):
+        super().__init__()
+        if feature_embedding_layers:
+            raise NotImplementedError("feature embedding layers are not built")
+        node_types = list(node_type_to_feat_dim_map)
+        edge_types = [tuple(e) for e in edge_type_to_feat_dim_map]
+        self.lin_dict = nn.ModuleDict({t: nn.Linear(d, hid_dim) for t, d in node_type_to_feat_dim_map.items()})
+        self.convs = nn.ModuleList([HGTConv(hid_dim, hid_dim, (node_types, edge_types), heads=num_heads)
+                                    for _ in range(num_layers)])
+        self.lin = nn.Linear(hid_dim, out_dim)
+        self.should_l2_normalize_embedding_layer_output = should_l2_normalize_embedding_layer_output
+
+    @torch.no_grad()
+    def forward(self, data: HeteroGraphData, output_node_types: List[str], device=None) -> Dict[str, torch.Tensor]:
+        any_x = next(iter(data.x_dict.values()))
+        eng = _engine_for(self, any_x)
+        for c in self.convs:
+            c.engine = eng
+        h = {t: torch.relu(_linear(eng, x, self.lin_dict[t].weight, self.lin_dict[t].bias))
+             for t, x in data.x_dict.items()}
+        for conv in self.convs:
+            h = conv(h, data.edge_index_dict)
+        out = {}
+        for t in output_node_types:
+            out[t] = (_linear(eng, h[t], self.lin.weight, self.lin.bias) if t in h
+                      else torch.empty(0, dtype=torch.float32, device=any_x.device))
+        if self.should_l2_normalize_embedding_layer_output:
+            out = {t: F.normalize(o, p=2, dim=1) if o.numel() else o for t, o in out.items()}
+        return out
+
+
+class SimpleHGNConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, num_edge_types: int, edge_in_channels: Optional[int] = None,
+                 num_heads: int = 1, edge_type_dim: int = 16, should_use_node_residual: bool = True,
+                 negative_slope: float = 0.2, dropout: float = 0.0):
+        super().__init__()
+        self.in_dim, self.out_dim, self.edge_in_dim = in_channels, out_channels, edge_in_channels
+        self.edge_type_dim, self.num_edge_types, self.num_heads = edge_type_dim, num_edge_types, num_heads
+        self.negative_slope = negative_slope
+        H = num_heads
+        self.edge_type_emb = nn.Parameter(torch.empty(num_edge_types, edge_type_dim))
+        self.W_etype = _HeteroLinear(edge_type_dim, edge_type_dim * H, num_edge_types)
+        self.W_nfeat = nn.Parameter(torch.empty(in_channels, out_channels * H))
+        if edge_in_channels:
+            self.W_efeat = nn.Parameter(torch.empty(edge_in_channels, edge_in_channels * H))
+            self.a_efeat = nn.Parameter(torch.empty(1, H, edge_in_channels))
+        self.a_l = nn.Parameter(torch.empty(1, H, out_channels))
+        self.a_r = nn.Parameter(torch.empty(1, H, out_channels))
+        self.a_etype = nn.Parameter(torch.empty(1, H, edge_type_dim))
+        self.residual = nn.Linear(in_channels, out_channels * H) if should_use_node_residual else None
+        for p in [self.edge_type_emb, self.W_nfeat, self.a_l, self.a_r, self.a_etype] + (
+                [self.W_efeat, self.a_efeat] if edge_in_channels else []):
+            nn.init.xavier_uniform_(p, gain=1.414)
+
+    def forward(self, edge_index: torch.Tensor, node_feat: torch.Tensor, edge_type: torch.Tensor,
+                edge_feat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        eng = _engine_for(self, node_feat)
+        n, H, D = int(node_feat.shape[0]), self.num_heads, self.out_dim
+        dev = node_feat.device
+        emb = torch.nan_to_num(_linear(eng, node_feat, self.W_nfeat.t().contiguous(), None), nan=0.0)  # [n, H*D]
+        e3 = emb.view(n, H, D)
+        hl = (self.a_l * e3).sum(-1).contiguous()
+        hr = (self.a_r * e3).sum(-1).contiguous()
+        et_vec = torch.stack([self.edge_type_emb[t] @ self.W_etype.weight[t] + self.W_etype.bias[t]
+                              for t in range(self.num_edge_types)]).view(-1, H, self.edge_type_dim)
+        het = (self.a_etype * et_vec).sum(-1).contiguous()  # [T, H]
+        src, dst = edge_index[0], edge_index[1]
+        rowptr, col, order, dst_s, ety = _csr_by_dst(src, dst, n, dst.to(torch.int32), edge_type.to(torch.int32))
+        hef = None
+        if edge_feat is not None and self.edge_in_dim:
+            # <a_efeat[h], (e W_efeat)[h-block]> == e . (W_efeat[:, h-block] a_efeat[h]): one [H, Ein] matrix
+            folded = (self.W_efeat.view(self.edge_in_dim, H, self.edge_in_dim) * self.a_efeat).sum(-1).t().contiguous()
+            hef = _linear(eng, torch.nan_to_num(edge_feat[order], nan=0.0), folded, None)
+        alpha = eng.simplehgn_alpha(hl.detach(), hr.detach(), het.detach(), hef, col, dst_s, ety, n, H,
+                                    self.negative_slope)
+        out = torch.empty((n, H * D), dtype=torch.float32, device=dev)
+        eng.weighted_aggregate(alpha, emb.contiguous(), H, D, rowptr, col, n, out)
+        if self.residual is not None:
+            out = out + _linear(eng, node_feat, self.residual.weight, self.residual.bias)
+        return out
+
+
+class SimpleHGN(nn.Module):
+    def __init__(self, node_type_to_feat_dim_map: Dict[str, int], edge_type_to_feat_dim_map: Dict[EdgeType, int],
+                 node_hid_dim: int, edge_hid_dim: int, edge_type_dim: int, node_out_dim: int = 128, num_layers: int = 2,
+                 num_heads: int = 2, should_use_node_residual: bool = True, negative_slope: float = 0.2,
+                 dropout: float = 0.0, activation=F.elu, should_l2_normalize_embedding_layer_output: bool = False,
+                 **kwargs):
+        super().__init__()
+        self.num_layers = num_layers
+        self.should_l2_normalize_embedding_layer_output = should_l2_normalize_embedding_layer_output
+        self.node_type_lin_dict = nn.ModuleDict({str(t): nn.Linear(d, node_hid_dim)
+                                                 for t, d in node_type_to_feat_dim_map.items()})
+        self.should_have_edge_features = any(edge_type_to_feat_dim_map.values())
+        self.edge_types = [tuple(e) for e in edge_type_to_feat_dim_map]
+        self.edge_type_lin_dict = nn.ModuleDict({self._ekey(e): nn.Linear(d, edge_hid_dim)
+                                                 for e, d in edge_type_to_feat_dim_map.items() if d})
+        self.convs = nn.ModuleList([
+            SimpleHGNConv(in_channels=node_hid_dim if i == 0 else node_hid_dim * num_heads,
+                          edge_in_channels=edge_hid_dim if self.should_have_edge_features else None,
+                          edge_type_dim=edge_type_dim, out_channels=node_hid_dim, num_heads=num_heads,
+                          num_edge_types=len(edge_type_to_feat_dim_map),
+                          should_use_node_residual=should_use_node_residual, negative_slope=negative_slope,
+                          dropout=dropout) for i in range(num_layers)])
+        self.lin = nn.Linear(node_hid_dim * num_heads, node_out_dim)
+        self.activation = activation
+
+    @staticmethod
+    def _ekey(e) -> str:
+        return f"{e[0]}-{e[1]}-{e[2]}"
+
+    @torch.no_grad()
+    def forward(self, data: HeteroGraphData, output_node_types: List[str], device=None) -> Dict[str, torch.Tensor]:
+        any_x = next(iter(data.x_dict.values()))
+        eng = _engine_for(self, any_x)
+        dev = any_x.device
+        # to_homogeneous(): nodes concatenated in node-type order, edge_type = index in the data's edge-type order
+        node_off, n = {}, 0
+        xs = []
+        for t, x in data.x_dict.items():
+            lin = self.node_type_lin_dict[str(t)]
+            xs.append(_linear(eng, x, lin.weight, lin.bias))
+            node_off[t] = n
+            n += int(x.shape[0])
+        h = torch.cat(xs)
+        eis, ets, efs = [], [], []
+        for i, (et, ei) in enumerate(data.edge_index_dict.items()):
+            off = torch.tensor([[node_off[et[0]]], [node_off[et[2]]]], dtype=ei.dtype, device=dev)
+            eis.append(ei + off)
+            ets.append(torch.full((ei.shape[1],), i, dtype=torch.int64, device=dev))
+            if self.should_have_edge_features:
+                ea = data.edge_attr_dict[et]
+                lin = self.edge_type_lin_dict[self._ekey(et)]
+                efs.append(_linear(eng, ea, lin.weight, lin.bias))
+        edge_index = torch.cat(eis, dim=1) if eis else torch.zeros((2, 0), dtype=torch.int64, device=dev)
+        edge_type = torch.cat(ets) if ets else torch.zeros(0, dtype=torch.int64, device=dev)
+        edge_feat = torch.cat(efs) if efs else None
+        for i, conv in enumerate(self.convs):
+            conv.engine = eng
+            h = conv(edge_index, h, edge_type, edge_feat)
+            if i != self.num_layers - 1:
+                h = self.activation(h)
+        emb = _linear(eng, h, self.lin.weight, self.lin.bias)
+        out = {t: emb[node_off[t]: node_off[t] + data.x_dict[t].shape[0]] for t in data.x_dict}
+        for t in output_node_types:
+            if t not in out:
+                raise ValueError(f"Requested node type {t} does not exist in output tensor.")
+        if self.should_l2_normalize_embedding_layer_output:
+            out = {t: F.normalize(o, p=2, dim=1) for t, o in out.items()}
+        return out

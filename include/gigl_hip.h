@@ -602,6 +602,26 @@ int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
 int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);
 
+/* ---- heterogeneous encoders: the attention-weighted segmented reductions of HGTConv and SimpleHGNConv
+ *      (python/gigl/src/common/models/pyg/nn/conv/hgt_conv.py:161-244, simplehgn_conv.py:113-180; the models are
+ *      python/gigl/src/common/models/pyg/heterogeneous.py:18-273).  Rows are [heads*dim] fp32; dim % 4 == 0 with dim/4
+ *      a power of two <= 64, heads*dim <= 1024 (GIGL_E_UNSUPPORTED otherwise).  The merged ("bipartite") graph of all
+ *      edge types is a CSR by destination: rowptr[n_dst+1], col[e] = row of the source in k / v.  All pointers DEVICE.
+ * gigl_hgt_aggregate: alpha_e = <q_i, k_col[e]> * p_rel[etype[e]][h] / sqrt(dim) per head, softmax over ALL in-edges
+ *      of i, out_i = sum_e alpha_e v_col[e] (0 for a row without in-edges).  k / v are the relation-transformed source
+ *      rows (one block of rows per edge type, :115-159); p_rel: [n_edge_types][heads] (NULL: 1), etype NULL: type 0.
+ * gigl_simplehgn_alpha: alpha[e][h] = softmax over the edges that share the SOURCE node (softmax(alpha, row), :154-155)
+ *      of leaky_relu(hl[src[e]][h] + hr[dst[e]][h] + het[etype[e]][h] (+ hef[e][h])); group_scratch: [2*n_nodes*heads].
+ * gigl_weighted_aggregate: out_i = sum_{e in row i} alpha[e][h] * v[col[e]] (alpha in the CSR's edge order). */
+int32_t gigl_hgt_aggregate(gigl_ctx* ctx, const float* q, const float* k, const float* v, int32_t heads, int32_t dim,
+                           const int32_t* rowptr, const int32_t* col, const int32_t* etype, const float* p_rel,
+                           int64_t n_dst, float* out);
+int32_t gigl_simplehgn_alpha(gigl_ctx* ctx, const float* hl, const float* hr, const float* het, const float* hef,
+                             const int32_t* src, const int32_t* dst, const int32_t* etype, int64_t n_edges,
+                             int64_t n_nodes, int32_t heads, float negative_slope, float* group_scratch, float* alpha);
+int32_t gigl_weighted_aggregate(gigl_ctx* ctx, const float* alpha, const float* v, int32_t heads, int32_t dim,
+                                const int32_t* rowptr, const int32_t* col, int64_t n_dst, float* out);
+
 /* ---- split generator: hash slots of the assigners, in bulk.  Replaces HashingAssigner.assign's per-object hashing
  *      (scala/split_generator/src/main/scala/lib/assigners/AbstractAssigners.scala:30-111):
  *      slots[i] = floorMod(MurmurHash3.bytesHash(key_i), 10000), key = "<a>-<type>" for nodes (b == NULL;

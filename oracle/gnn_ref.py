@@ -136,3 +136,89 @@ def union_edge_index(rowptr, col) -> torch.Tensor:
     deg = rowptr[1:] - rowptr[:-1]
     dst = torch.repeat_interleave(torch.arange(deg.numel(), dtype=torch.int64), deg)
     return torch.stack([col, dst])
+
+
+# ---- heterogeneous convolutions (TEST INFRASTRUCTURE): edge-list restatements in plain torch ------------------------
+def _segment_softmax(logits: torch.Tensor, index: torch.Tensor, n: int) -> torch.Tensor:
+    """softmax of logits [E, H] within the groups given by index [E] (torch_geometric.utils.softmax: max-shifted,
+    denominator + 1e-16)"""
+    mx = torch.full((n, logits.shape[1]), float("-inf"), dtype=logits.dtype)
+    mx = mx.scatter_reduce(0, index[:, None].expand_as(logits), logits, reduce="amax", include_self=True)
+    ex = torch.exp(logits - mx[index])
+    den = torch.zeros((n, logits.shape[1]), dtype=logits.dtype).index_add_(0, index, ex)
+    return ex / (den[index] + 1e-16)
+
+
+def hgt_conv(x_dict, edge_index_dict, p, heads: int):
+    """HGTConv.forward (python/gigl/src/common/models/pyg/nn/conv/hgt_conv.py:161-244) on edge lists.
+    p: dict with kqv[type] = (W [3F, in], b [3F]), out[type] = (W [F, F], b [F]), k_rel / v_rel [H*T, D, D] (type index
+    h * T + t, :131-141), skip[type] scalar, p_rel[edge type] [H], edge_types (list: index t).  Every node type of
+    x_dict comes back (types without in-edges aggregate zeros: the in-repo modification, :19-23)."""
+    types = list(x_dict)
+    F_ = p["out"][types[0]][0].shape[0]
+    D = F_ // heads
+    T = len(p["edge_types"])
+    k, q, v = {}, {}, {}
+    for t in types:
+        w, b = p["kqv"][t]
+        kqv = x_dict[t] @ w.T + b
+        k[t], q[t], v[t] = (z.reshape(-1, heads, D) for z in torch.tensor_split(kqv, 3, dim=1))
+    dst_off, c = {}, 0
+    for t in types:
+        dst_off[t] = c
+        c += x_dict[t].shape[0]
+    n_dst = c
+    qq = torch.cat([q[t] for t in types])
+    agg = torch.zeros((n_dst, heads, D), dtype=qq.dtype)
+    logits, srcs_k, srcs_v, dsts = [], [], [], []
+    for et, ei in edge_index_dict.items():
+        ti = p["edge_types"].index(et)
+        wk = torch.stack([p["k_rel"][h * T + ti] for h in range(heads)])  # [H, D, D]
+        wv = torch.stack([p["v_rel"][h * T + ti] for h in range(heads)])
+        kk = torch.einsum("nhd,hde->nhe", k[et[0]], wk)
+        vv = torch.einsum("nhd,hde->nhe", v[et[0]], wv)
+        d = ei[1] + dst_off[et[2]]
+        a = (qq[d] * kk[ei[0]]).sum(-1) * p["p_rel"][et].reshape(1, heads) / (D ** 0.5)
+        logits.append(a)
+        srcs_v.append(vv[ei[0]])
+        dsts.append(d)
+    if logits:
+        a = _segment_softmax(torch.cat(logits), torch.cat(dsts), n_dst)
+        agg.index_add_(0, torch.cat(dsts), torch.cat(srcs_v) * a[:, :, None])
+    out = {}
+    for t in types:
+        o = agg[dst_off[t]: dst_off[t] + x_dict[t].shape[0]].reshape(-1, F_)
+        w, b = p["out"][t]
+        o = torch.nn.functional.gelu(o) @ w.T + b
+        if o.shape[1] == x_dict[t].shape[1]:
+            al = torch.sigmoid(p["skip"][t])
+            o = al * o + (1 - al) * x_dict[t]
+        out[t] = o
+    return out
+
+
+def simplehgn_conv(edge_index, node_feat, edge_type, p, heads: int, out_dim: int, negative_slope: float = 0.2,
+                   edge_feat=None):
+    """SimpleHGNConv.forward (python/gigl/src/common/models/pyg/nn/conv/simplehgn_conv.py:113-180) on an edge list.
+    Note the reference normalises alpha over the edges that share the SOURCE node (softmax(alpha, row), row =
+    edge_index[0], :154-155) and sums the messages at the target.  p: W_nfeat [in, H*out], a_l / a_r [1, H, out],
+    a_etype [1, H, Te], edge_type_emb [T, Te], W_etype (weight [T, Te, H*Te], bias [T, H*Te]), residual (W, b) | None,
+    and with edge features W_efeat [Ein, H*Ein], a_efeat [1, H, Ein]."""
+    n = node_feat.shape[0]
+    emb = torch.nan_to_num(node_feat @ p["W_nfeat"], nan=0.0).reshape(n, heads, out_dim)
+    row, col = edge_index[0], edge_index[1]
+    te = p["edge_type_emb"].shape[1]
+    w_et, b_et = p["W_etype"]
+    et_vec = torch.stack([p["edge_type_emb"][t] @ w_et[t] + b_et[t] for t in range(w_et.shape[0])]).reshape(-1, heads, te)
+    logit = (p["a_l"] * emb).sum(-1)[row] + (p["a_r"] * emb).sum(-1)[col] + (p["a_etype"] * et_vec).sum(-1)[edge_type]
+    if edge_feat is not None:
+        ein = edge_feat.shape[1]
+        ee = torch.nan_to_num(edge_feat @ p["W_efeat"], nan=0.0).reshape(-1, heads, ein)
+        logit = logit + (p["a_efeat"] * ee).sum(-1)
+    alpha = _segment_softmax(torch.nn.functional.leaky_relu(logit, negative_slope), row, n)
+    out = torch.zeros((n, heads, out_dim), dtype=emb.dtype).index_add_(0, col, emb[row] * alpha[:, :, None])
+    out = out.reshape(n, heads * out_dim)
+    if p.get("residual") is not None:
+        w, b = p["residual"]
+        out = out + node_feat @ w.T + b
+    return out

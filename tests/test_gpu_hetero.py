@@ -1,0 +1,114 @@
+"""HGT / SimpleHGN on the device (csrc/hetero.hip + gigl_linear) vs the edge-list restatements in oracle/gnn_ref.py of
+HGTConv (python/gigl/src/common/models/pyg/nn/conv/hgt_conv.py) and SimpleHGNConv (.../simplehgn_conv.py), 1e-5."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import gnn_ref
+
+pytestmark = pytest.mark.gpu
+
+NT = {"user": (300, 12), "item": (200, 20), "tag": (50, 8)}
+ET = [("user", "follows", "user"), ("user", "buys", "item"), ("item", "bought_by", "user"), ("tag", "labels", "item")]
+
+
+def make_data(seed=0, with_edge_attr=False):
+    from gigl_amd.models_hetero import HeteroGraphData
+    g = torch.Generator().manual_seed(seed)
+    x = {t: torch.randn(n, d, generator=g) for t, (n, d) in NT.items()}
+    ei, ea = {}, {}
+    for (s, r, d), e in zip(ET, (2500, 1800, 1700, 300)):
+        src = torch.randint(0, NT[s][0], (e,), generator=g)
+        # skewed destinations: hubs and nodes without in-edges both occur
+        dst = (torch.rand(e, generator=g) ** 2 * NT[d][0]).long().clamp(max=NT[d][0] - 1)
+        ei[(s, r, d)] = torch.stack([src, dst])
+        if with_edge_attr:
+            ea[(s, r, d)] = torch.randn(e, 5, generator=g)
+    return HeteroGraphData(x, ei, ea)
+
+
+def test_hgt_matches_the_restatement():
+    from gigl_amd.models_hetero import HGT
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    heads, hid, out_dim = 4, 64, 32
+    model = HGT({t: d for t, (_, d) in NT.items()}, {e: 0 for e in ET}, hid_dim=hid, out_dim=out_dim, num_layers=2,
+                num_heads=heads)
+    with torch.no_grad():  # non-trivial gates / priors
+        for conv in model.convs:
+            for p in conv.skip.values():
+                p.uniform_(-1, 1)
+            for p in conv.p_rel.values():
+                p.uniform_(0.5, 1.5)
+    data = make_data()
+    got = model.to(dev)(data.to(dev), ["user", "item", "tag"])
+    # the same forward from the parameters, on the CPU
+    model = model.cpu()
+    h = {t: torch.relu(F.linear(x, model.lin_dict[t].weight, model.lin_dict[t].bias)) for t, x in data.x_dict.items()}
+    for conv in model.convs:
+        p = dict(kqv={t: (conv.kqv_lin.lins[t].weight, conv.kqv_lin.lins[t].bias) for t in NT},
+                 out={t: (conv.out_lin.lins[t].weight, conv.out_lin.lins[t].bias) for t in NT},
+                 k_rel=conv.k_rel.weight, v_rel=conv.v_rel.weight, skip={t: conv.skip[t] for t in NT},
+                 p_rel={e: conv.p_rel["__".join(e)] for e in ET}, edge_types=ET)
+        with torch.no_grad():
+            h = gnn_ref.hgt_conv(h, data.edge_index_dict, p, heads)
+    for t in NT:
+        want = F.linear(h[t], model.lin.weight, model.lin.bias).detach().numpy()
+        np.testing.assert_allclose(got[t].cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # a node type nobody points at still comes back (the in-repo modification of PyG's HGTConv)
+    assert got["tag"].shape == (50, out_dim)
+
+
+@pytest.mark.parametrize("with_edge_attr", [False, True])
+def test_simplehgn_matches_the_restatement(with_edge_attr):
+    from gigl_amd.models_hetero import SimpleHGN
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(2)
+    heads, hid, out_dim = 2, 32, 24
+    model = SimpleHGN({t: d for t, (_, d) in NT.items()}, {e: (5 if with_edge_attr else 0) for e in ET}, node_hid_dim=hid,
+                      edge_hid_dim=8, edge_type_dim=16, node_out_dim=out_dim, num_layers=2, num_heads=heads)
+    data = make_data(3, with_edge_attr)
+    got = model.to(dev)(data.to(dev), ["user", "item"])
+    model = model.cpu()
+    off, n, xs = {}, 0, []
+    for t, x in data.x_dict.items():
+        lin = model.node_type_lin_dict[t]
+        xs.append(F.linear(x, lin.weight, lin.bias))
+        off[t] = n
+        n += x.shape[0]
+    h = torch.cat(xs)
+    ei = torch.cat([e + torch.tensor([[off[k[0]]], [off[k[2]]]]) for k, e in data.edge_index_dict.items()], dim=1)
+    ety = torch.cat([torch.full((e.shape[1],), i) for i, e in enumerate(data.edge_index_dict.values())])
+    ef = None
+    if with_edge_attr:
+        ef = torch.cat([F.linear(data.edge_attr_dict[k], model.edge_type_lin_dict[f"{k[0]}-{k[1]}-{k[2]}"].weight,
+                                 model.edge_type_lin_dict[f"{k[0]}-{k[1]}-{k[2]}"].bias) for k in data.edge_index_dict])
+    with torch.no_grad():
+        for i, conv in enumerate(model.convs):
+            p = dict(W_nfeat=conv.W_nfeat, a_l=conv.a_l, a_r=conv.a_r, a_etype=conv.a_etype,
+                     edge_type_emb=conv.edge_type_emb, W_etype=(conv.W_etype.weight, conv.W_etype.bias),
+                     residual=(conv.residual.weight, conv.residual.bias))
+            if with_edge_attr:
+                p.update(W_efeat=conv.W_efeat, a_efeat=conv.a_efeat)
+            h = gnn_ref.simplehgn_conv(ei, h, ety, p, heads, hid, edge_feat=ef)
+            if i != len(model.convs) - 1:
+                h = F.elu(h)
+        emb = F.linear(h, model.lin.weight, model.lin.bias)
+    for t in ("user", "item"):
+        want = emb[off[t]: off[t] + NT[t][0]].numpy()
+        np.testing.assert_allclose(got[t].cpu().numpy(), want, rtol=1e-5, atol=2e-5)
+    with pytest.raises(ValueError):
+        model.to(dev)(data.to(dev), ["nobody"])
+
+
+def test_attention_kernels_reject_unsupported_shapes():
+    from gigl_amd._lib import GiglError
+    from gigl_amd.engine import HipEngine
+    eng = HipEngine(0)
+    z = torch.zeros((4, 6 * 5), device=eng.device)
+    rp = torch.zeros(5, dtype=torch.int32, device=eng.device)
+    col = torch.zeros(1, dtype=torch.int32, device=eng.device)
+    with pytest.raises(GiglError):
+        eng.hgt_aggregate(z, z, z, 6, 5, rp, col, None, None, 4, z.clone())  # dim % 4 != 0
+    eng.close()
