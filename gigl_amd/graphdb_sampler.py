@@ -161,6 +161,60 @@ class HipGraphDBSampler:
             res[name] = OpResult(front, nbr.view(b, w, f), cnt.view(b, w))
         return res
 
+    # ---- typed batch graph on the device (what the reference's collate + PygGraphBuilder produce from the typed
+    #      RootedNodeNeighborhood samples of a batch: per node type the distinct nodes, per edge type the distinct
+    #      edges, python/gigl/src/common/graph_builder/abstract_graph_builder.py:49-150) ---------------------------
+    def batch_graph(self, root_ids: Sequence[int], root_node_type: str, dag: SamplingOpDAG):
+        """-> (HeteroGraphData on the device, root_index int64 [B] into x_dict[root_node_type], {type: global ids}).
+        The samples never leave HBM: the op results are merged there (ids of a type sorted ascending = its local
+        numbering, edges distinct per edge type) and the rows of every type are gathered from its feature table."""
+        from .models_hetero import HeteroGraphData
+        eng = self.engine
+        dev = eng.device
+        roots = torch.tensor(np.asarray(root_ids, dtype=np.int64), device=dev)
+        res = self.run_dag(roots.to(torch.int32), dag)
+        b = int(roots.numel())
+        ids: Dict[str, List[torch.Tensor]] = {root_node_type: [roots]}
+        pairs: Dict[EdgeType, List[torch.Tensor]] = {}
+        with torch.cuda.stream(eng._stream):
+            for name, r in res.items():
+                op = dag.nodes[name].sampling_op
+                outgoing = op.sampling_direction == OUTGOING
+                et = op.edge_type
+                front_t = et.src_node_type if outgoing else et.dst_node_type
+                got_t = et.dst_node_type if outgoing else et.src_node_type
+                w, f = int(r.frontier.shape[1]), int(r.nbr.shape[2])
+                fr = (r.frontier.to(torch.int64) & 0xFFFFFFFF).view(b, w, 1).expand(b, w, f).reshape(-1)
+                nb = (r.nbr.to(torch.int64) & 0xFFFFFFFF).reshape(-1)
+                ok = (nb != INVALID) & (fr != INVALID)
+                fr, nb = fr[ok], nb[ok]
+                ids.setdefault(front_t, []).append(fr)
+                ids.setdefault(got_t, []).append(nb)
+                pairs.setdefault(et, []).append(torch.stack([fr, nb] if outgoing else [nb, fr]))
+            uniq = {t: torch.unique(torch.cat(v)) for t, v in ids.items()}  # sorted: local id = rank
+            x_dict = {}
+            for t, u in uniq.items():
+                tab = self._feature_table(t)
+                x_dict[t] = tab.index_select(0, u) if tab is not None else torch.ones((u.numel(), 1), device=dev)
+            ei = {}
+            for et, ps in pairs.items():
+                p2 = torch.cat(ps, dim=1)
+                src = torch.searchsorted(uniq[et.src_node_type], p2[0])
+                dst = torch.searchsorted(uniq[et.dst_node_type], p2[1])
+                key = torch.unique(src * int(uniq[et.dst_node_type].numel()) + dst)
+                nd = int(uniq[et.dst_node_type].numel())
+                ei[(et.src_node_type, et.relation, et.dst_node_type)] = torch.stack([key // nd, key % nd])
+            root_index = torch.searchsorted(uniq[root_node_type], roots)
+        return HeteroGraphData(x_dict, ei), root_index, uniq
+
+    def _feature_table(self, node_type: str) -> Optional[torch.Tensor]:
+        if not hasattr(self, "_dev_feats"):
+            self._dev_feats: Dict[str, torch.Tensor] = {}
+        if node_type not in self._dev_feats and self.features.get(node_type) is not None:
+            self._dev_feats[node_type] = torch.from_numpy(
+                np.ascontiguousarray(self.features[node_type], dtype=np.float32)).to(self.engine.device)
+        return self._dev_feats.get(node_type)
+
     # ---- KHopSamplerService surface ------------------------------------------------------------------------------
     def getKHopSubgraphForRootNodes(self, root_ids: Sequence[int], root_node_type: str,
                                     dag: SamplingOpDAG) -> List[wire.RootedNodeNeighborhood]:

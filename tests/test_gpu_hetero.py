@@ -112,3 +112,66 @@ def test_attention_kernels_reject_unsupported_shapes():
     with pytest.raises(GiglError):
         eng.hgt_aggregate(z, z, z, 6, 5, rp, col, None, None, 4, z.clone())  # dim % 4 != 0
     eng.close()
+
+
+def test_dag_sampler_to_hgt_end_to_end():
+    """typed samples stay in HBM: SamplingOp-DAG sampler -> typed batch graph -> HGT; the batch graph equals the union
+    of the per-root restatement's samples (oracle/dag_sampler.py) and the root embeddings equal the CPU forward over it"""
+    from gigl_amd.graphdb_sampler import (INCOMING, OUTGOING, EdgeType, HipGraphDBSampler, SamplingOp, SamplingOpDAG)
+    from gigl_amd.models_hetero import HGT
+    from oracle import dag_sampler
+    A2P, P2A = EdgeType("author", "writes", "paper"), EdgeType("paper", "written_by", "author")
+    node_types, cet = {"author": 0, "paper": 1}, {A2P: 0, P2A: 1}
+    rng = np.random.default_rng(0)
+    n = {"author": 800, "paper": 1200}
+    a = (rng.zipf(1.7, 6000) % n["author"]).astype(np.uint32)
+    p = rng.integers(0, n["paper"], 6000).astype(np.uint32)
+    edges = {A2P: (a, p), P2A: (p, a)}
+    feats = {"author": rng.standard_normal((800, 6)).astype(np.float32), "paper": rng.standard_normal((1200, 10)).astype(np.float32)}
+    s = HipGraphDBSampler(node_types, n, edges, cet, feats)
+    ops = [SamplingOp("op0", A2P, 4, [], INCOMING), SamplingOp("op1", A2P, 3, ["op0"], OUTGOING),
+           SamplingOp("op2", P2A, 2, ["op1"], OUTGOING)]
+    dag = SamplingOpDAG.from_ops(ops)
+    roots = rng.integers(0, n["paper"], 64)
+    data, root_index, uniq = s.batch_graph(roots, "paper", dag)
+    s.engine.synchronize()
+    # == union of the per-root samples
+    nbrs = dag_sampler.neighbour_lists(edges)
+    want_e, want_n = set(), set()
+    for r in roots:
+        e_, n_ = dag_sampler.sample_for_root(int(r), ops, nbrs, node_types, cet, "paper")
+        want_e |= e_
+        want_n |= n_
+    got_n = {(int(v), node_types[t]) for t, u in uniq.items() for v in u.cpu().tolist()}
+    assert got_n == want_n
+    got_e = set()
+    for (st_, rel, dt_), ei in data.edge_index_dict.items():
+        c = cet[A2P] if rel == "writes" else cet[P2A]
+        for sl, dl in ei.t().cpu().tolist():
+            got_e.add((int(uniq[st_][sl]), int(uniq[dt_][dl]), c))
+    assert got_e == want_e
+    for t in uniq:
+        np.testing.assert_array_equal(data.x_dict[t].cpu().numpy(), feats[t][uniq[t].cpu().numpy()])
+    assert torch.equal(uniq["paper"][root_index].cpu(), torch.from_numpy(roots))
+    # encoder over it
+    torch.manual_seed(5)
+    ets = [("author", "writes", "paper"), ("paper", "written_by", "author")]
+    model = HGT({"author": 6, "paper": 10}, {e: 0 for e in ets}, hid_dim=32, out_dim=16, num_layers=2, num_heads=2)
+    model.engine = s.engine
+    with torch.cuda.stream(s.engine._stream):
+        got = model.to(s.engine.device)(data, ["paper"])["paper"][root_index]
+    s.engine.synchronize()
+    model = model.cpu()
+    xd = {t: x.cpu() for t, x in data.x_dict.items()}
+    eid = {k: v.cpu() for k, v in data.edge_index_dict.items()}
+    h = {t: torch.relu(F.linear(x, model.lin_dict[t].weight, model.lin_dict[t].bias)) for t, x in xd.items()}
+    with torch.no_grad():
+        for conv in model.convs:
+            pr = dict(kqv={t: (conv.kqv_lin.lins[t].weight, conv.kqv_lin.lins[t].bias) for t in xd},
+                      out={t: (conv.out_lin.lins[t].weight, conv.out_lin.lins[t].bias) for t in xd},
+                      k_rel=conv.k_rel.weight, v_rel=conv.v_rel.weight, skip={t: conv.skip[t] for t in xd},
+                      p_rel={e: conv.p_rel["__".join(e)] for e in ets}, edge_types=ets)
+            h = gnn_ref.hgt_conv(h, eid, pr, 2)
+        want = F.linear(h["paper"], model.lin.weight, model.lin.bias)[root_index.cpu()]
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+    s.close()
