@@ -21,6 +21,8 @@
 //              and W, so no LDS staging or transposes are needed.
 #include "common.h"
 
+#include <cstdlib>
+
 #include <hip/hip_fp16.h>
 
 namespace {
@@ -224,6 +226,49 @@ __global__ __launch_bounds__(256) void gather_mean_generic_kernel(const T* __res
 // ------------------------------------------------------------------------------------------
 // y[m][n] = act(sum_k a[m][k] * w[n][k] + bias[n])       a: [M][K], w: [N][K] row-major, fp32
 // ------------------------------------------------------------------------------------------
+// Epilogue of one 32x32 accumulator block: bias / activation, then out through a 32 x 36-float LDS strip owned by the
+// wave so that the block leaves as 16-byte stores of full 128-byte row segments (8 lanes per row) instead of 16 dword
+// stores per lane — the row-per-lane pattern of the MFMA D layout is store-ISSUE bound (cdna guide T21).
+// D layout (32x32, 16 regs): reg v -> row 8*(v/4) + 4*g + (v%4), col r.
+__device__ __forceinline__ void store_block_32x32(const float16_t& acc, float* strip, int lane, const float* bias,
+                                                  int act, int row0, int col0, int M, int N, float* y) {
+  const int r = lane & 31, g = lane >> 5;
+  const float bv = (bias && col0 + r < N) ? bias[col0 + r] : 0.f;
+  if ((N & 3) != 0) {  // rows are not 16-byte aligned: dword stores
+    if (col0 + r >= N) return;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = row0 + 8 * (v >> 2) + 4 * g + (v & 3);
+      if (row < M) {
+        float val = acc[v] + bv;
+        if (act == 1) val = val > 0.f ? val : 0.f;
+        y[(int64_t)row * N + col0 + r] = val;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    float val = acc[v] + bv;
+    if (act == 1) val = val > 0.f ? val : 0.f;
+    strip[(8 * (v >> 2) + 4 * g + (v & 3)) * 36 + r] = val;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const int c4 = (lane & 7) * 4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int rr = (lane >> 3) + 8 * t;
+    const int row = row0 + rr, col = col0 + c4;
+    if (row < M && col < N) {  // (N % 4 == 0: a float4 is inside or outside as a whole)
+      const float4_t q = *reinterpret_cast<const float4_t*>(&strip[rr * 36 + c4]);
+      *reinterpret_cast<float4_t*>(y + (int64_t)row * N + col) = q;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ a,
                                                           const float* __restrict__ w,
@@ -398,21 +443,139 @@ __global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict
     chunk(k0, ga[0], gw[0]);
     if (k0 + BK < K) chunk(k0 + BK, ga[1], gw[1]);
   }
+  // (s_a[wv_id] is read by this wave only: it is free for the epilogue once the wave's own reads are done)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int coln = n0 + j * 32 + r;
-    if (coln >= N) continue;
-    const float bv = bias ? bias[coln] : 0.f;
+  for (int j = 0; j < NT; ++j) store_block_32x32(acc[j], s_a[wv_id], lane, bias, act, m0, n0 + j * 32, M, N, y);
+}
+
+// Split-precision variant: every fp32 operand is the exact sum of three bf16 numbers (x = b1 + b2 + b3: b1 = x with its
+// low 16 bits cleared, b2 = (x - b1) truncated the same way, b3 = the rest — 8 + 8 + 8 significand bits, the
+// subtractions are exact), so a.w = sum over the pairs (i, j) of a_i.w_j; the six pairs with i + j <= 4 carry every
+// term down to 2^-24 of the product (the dropped ones are <= 2^-24 relative: fp32's own rounding class), each as ONE
+// v_mfma_f32_32x32x16_bf16 — sixteen times the rate of the fp32 MFMA, so 6/16 of its matrix-pipe time — with fp32
+// accumulation inside the instruction.  The split happens on the way from the prefetch registers into LDS (and/sub/
+// and/sub + packing per element, VALU work that runs beside the matrix pipe); LDS holds the three bf16 planes of the
+// A and W tiles with 80-byte rows (conflict-free ds_read_b128 in the operand layout: lane l reads k = 8*(l/32) .. +8
+// of row l%32).  Workgroup tile 128 x 64*NJ, four waves as 2 x 2, each 64 rows x 32*NJ columns.
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float x, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
+  b1 = __float_as_uint(x) & 0xFFFF0000u;
+  const float r1 = x - __uint_as_float(b1);
+  b2 = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(b2);
+  b3 = __float_as_uint(r2) & 0xFFFF0000u;
+}
+
+// four consecutive k of one row -> four bf16 of each plane, stored as 8 bytes per plane
+__device__ __forceinline__ void split_store(const float4_t v, short* p1, short* p2, short* p3) {
+  uint32_t a1[4], a2[4], a3[4];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      const int row = m0 + 8 * (v >> 2) + 4 * h + (v & 3);
-      if (row < M) {
-        float val = acc[j][v] + bv;
-        if (act == 1) val = val > 0.f ? val : 0.f;
-        y[(int64_t)row * N + coln] = val;
-      }
+  for (int t = 0; t < 4; ++t) split3(v[t], a1[t], a2[t], a3[t]);
+  *reinterpret_cast<uint2*>(p1) = make_uint2((a1[0] >> 16) | a1[1], (a1[2] >> 16) | a1[3]);
+  *reinterpret_cast<uint2*>(p2) = make_uint2((a2[0] >> 16) | a2[1], (a2[2] >> 16) | a2[3]);
+  *reinterpret_cast<uint2*>(p3) = make_uint2((a3[0] >> 16) | a3[1], (a3[2] >> 16) | a3[3]);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(256) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           const int32_t* __restrict__ m_dev, int K, int N, int act,
+                                                           float* __restrict__ y) {
+  constexpr int BK = 32, LDK = 40;          // bf16 elements per LDS row (32 + 8 of padding = 80 bytes)
+  constexpr int BM = 128, BN = 64 * NJ;
+  __shared__ short s_a[3][BM * LDK];
+  __shared__ short s_w[3][BN * LDK];
+  const int M = *m_dev;
+  const int tiles_n = (N + BN - 1) / BN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int m0b = tm * BM, n0b = tn * BN;
+  if (m0b >= M) return;  // whole workgroup
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, g = lane >> 5;
+  const int wm = wv >> 1, wn = wv & 1;  // wave -> rows [64 wm, +64), columns [32 NJ wn, +32 NJ)
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  float16_t acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+  // loaders: thread -> rows (tid >> 3) + 32 i, k segment (tid & 7) * 4 .. +4 (128-byte row pieces per 8 lanes)
+  const int lr = tid >> 3, lc = tid & 7;
+  // operands of TWO chunks ahead stay in flight in registers (a chunk's MFMAs are shorter than a global load under load)
+  float4_t ga[2][4], gw[2][2 * NJ];
+  auto gload = [&](int k0, float4_t (&da)[4], float4_t (&dw)[2 * NJ]) {
+    const int kk = k0 + lc * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0b + lr + 32 * i;
+      da[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(a + (int64_t)row * K + kk) : zero4;
     }
+#pragma unroll
+    for (int i = 0; i < 2 * NJ; ++i) {
+      const int row = n0b + lr + 32 * i;
+      dw[i] = (row < N && kk < K) ? *reinterpret_cast<const float4_t*>(w + (int64_t)row * K + kk) : zero4;
+    }
+  };
+  auto chunk = [&](int k0, float4_t (&ra)[4], float4_t (&rw)[2 * NJ]) {
+    __syncthreads();  // the previous chunk's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = (lr + 32 * i) * LDK + lc * 4;
+      split_store(ra[i], &s_a[0][o], &s_a[1][o], &s_a[2][o]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * NJ; ++i) {
+      const int o = (lr + 32 * i) * LDK + lc * 4;
+      split_store(rw[i], &s_w[0][o], &s_w[1][o], &s_w[2][o]);
+    }
+    __syncthreads();
+    if (k0 + 2 * BK < K) gload(k0 + 2 * BK, ra, rw);  // lands during this chunk's and the next chunk's MFMAs
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      if (k0 + ks >= K) break;
+      bf16x8_t fa[2][3], fw[NJ][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          fa[i][p] = *reinterpret_cast<const bf16x8_t*>(&s_a[p][(wm * 64 + i * 32 + r) * LDK + ks + 8 * g]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          fw[j][p] = *reinterpret_cast<const bf16x8_t*>(&s_w[p][(wn * 32 * NJ + j * 32 + r) * LDK + ks + 8 * g]);
+      // six products per accumulator, smallest terms first; the 2*NJ accumulators are interleaved so that two MFMAs
+      // on the same accumulator are never back to back (a dependent MFMA waits for the previous one's 16 passes)
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[t]], fw[j][PW[t]], acc[i][j], 0, 0, 0);
+    }
+  };
+  gload(0, ga[0], gw[0]);
+  if (BK < K) gload(BK, ga[1], gw[1]);
+  for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+    chunk(k0, ga[0], gw[0]);
+    if (k0 + BK < K) chunk(k0 + BK, ga[1], gw[1]);
   }
+  __syncthreads();  // every wave is done with the operand planes: s_a becomes the waves' epilogue strips
+  float* strip = reinterpret_cast<float*>(&s_a[0][0]) + wv * (32 * 36);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      store_block_32x32(acc[i][j], strip, lane, bias, act, m0b + wm * 64 + i * 32, n0b + wn * 32 * NJ + j * 32, M, N, y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1694,7 +1857,16 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
   hipStream_t st = ctx->stream;
   gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
   const int64_t tiles_m = (m_cap + 31) / 32;
-  if ((k & 3) == 0) {  // LDS-staged, coalesced operand fetch
+  static const bool exact_only = getenv("GIGL_LINEAR_EXACT") != nullptr;  // (test / comparison knob)
+  if ((k & 3) == 0 && m_cap >= 512 && !exact_only) {  // split-precision bf16 MFMA (fp32-class accuracy)
+    const int64_t bm = (m_cap + 127) / 128;
+    if (n > 64)
+      hipLaunchKernelGGL((linear_split_kernel<2>), dim3((unsigned)(bm * ((n + 127) / 128))), dim3(256), 0, st, a, w,
+                         bias, m_dev, k, n, act, y);
+    else
+      hipLaunchKernelGGL((linear_split_kernel<1>), dim3((unsigned)(bm * ((n + 63) / 64))), dim3(256), 0, st, a, w,
+                         bias, m_dev, k, n, act, y);
+  } else if ((k & 3) == 0) {  // LDS-staged, coalesced operand fetch
     const int64_t bm = (m_cap + 127) / 128;
     if (n > 32) {
       hipLaunchKernelGGL((linear_lds_kernel<2>), dim3((unsigned)(bm * ((n + 63) / 64))), dim3(256), 0, st, a, w,
