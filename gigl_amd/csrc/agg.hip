@@ -1858,7 +1858,9 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
   gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
   const int64_t tiles_m = (m_cap + 31) / 32;
   static const bool exact_only = getenv("GIGL_LINEAR_EXACT") != nullptr;  // (test / comparison knob)
-  if ((k & 3) == 0 && m_cap >= 512 && !exact_only) {  // split-precision bf16 MFMA (fp32-class accuracy)
+  // (which kernel runs depends on k alone — never on the row count: the rows of a batch must come out bit-identical
+  // whether the batch is computed alone or inside a group of batches)
+  if ((k & 3) == 0 && !exact_only) {  // split-precision bf16 MFMA (fp32-class accuracy)
     const int64_t bm = (m_cap + 127) / 128;
     if (n > 64)
       hipLaunchKernelGGL((linear_split_kernel<2>), dim3((unsigned)(bm * ((n + 127) / 128))), dim3(256), 0, st, a, w,
