@@ -100,3 +100,38 @@ def test_partition_helpers():
         assert np.array_equal(partition_rows(x, r, 3), x[owned])
     assert seen == col.size
     assert sorted(list(shard_batches(7, 0, 2)) + list(shard_batches(7, 1, 2))) == list(range(7))
+
+
+def _a2a_worker(rank, world, port, ret):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from gigl_amd.dist import _gloo_all_to_all
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        n = 1000
+        # block p of rank r's send buffer = bytes (r, p, i): what must arrive as block r at rank p
+        send = torch.cat([(torch.arange(n) * 7 + rank * 31 + p * 5).to(torch.uint8) for p in range(world)])
+        recv = torch.zeros_like(send)
+        _gloo_all_to_all(recv, send, world)
+        want = torch.cat([(torch.arange(n) * 7 + s * 31 + rank * 5).to(torch.uint8) for s in range(world)])
+        ret[rank] = bool(torch.equal(recv, want))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_host_transport_of_the_callback_communicator_world3():
+    """the byte mover behind Comm.callback / torch_exchange (the transport a GPU test drives between two processes
+    sharing one device) is an all-to-all: block p of rank r's buffer arrives as block r at rank p"""
+    world = 3
+    port = 31500 + (os.getpid() % 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_a2a_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert dict(ret) == {0: True, 1: True, 2: True}
