@@ -11,15 +11,15 @@ pairs bidirectionalised, D=100 fp32), fanout [25,10], B=1024, GraphSAGE 100->256
 §8(d) C2).  MAG240M (the config the metric is quoted on) does not fit one GPU (375 GB of features),
 so per the contract the N=1 line is the largest single-GPU configuration.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--group G] [--small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--streams S] [--group G] [--workload W]
 
-Steps are independent batches.  One library call takes G consecutive batches through ONE set of ~28 launches
+Steps are independent batches.  One library call takes G consecutive batches through ONE set of ~20 launches
 (gigl_sage_plan_set_groups: every batch keeps its own union graph, rows are bit-identical to G single-batch
-calls — tests/test_gpu_groups.py), because at B=1024 a launch set costs ~0.07 ms of dispatch floor against
-~0.08 ms of work per batch; calls are pipelined over S HIP streams (one library ctx + one host thread per
-stream, all sharing the HBM-resident graph; defaults S = 3, G = 32 — a sweep of S in 2..4, G in 8..32 stays within
-±5 % of the best).  Exactly K steps (K*B roots) are timed in total; a remainder of
-K mod G steps runs batch by batch.
+calls — tests/test_gpu_groups.py); calls are pipelined over S HIP streams (one library ctx + one host thread per
+stream, all sharing the HBM-resident graph and hash table; defaults S = 3, G = 64 — a sweep of S in 2..6, G in
+16..128 stays within 7 % of the best).  The regime does not depend on --steps: --steps is a MINIMUM, the timed range is
+a whole number of rounds (S*G steps) repeated until the timed region lasts >= --min-seconds; median / p10 / p90 over
+the repetitions are reported next to the aggregate.
 N>1: one process per GPU (torch.distributed, RCCL); every rank holds a replica of the graph and takes
 its own root batches — the path shards by roots with no data-path collective ("weak" scaling);
 time = max over ranks, value = total edges of all ranks / that time.
@@ -168,7 +168,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="roots per batch (0: the workload's: 1024)")
     ap.add_argument("--fanouts", type=str, default="", help="per-hop fanouts (empty: the workload's: 25,10)")
     ap.add_argument("--streams", type=int, default=3)
-    ap.add_argument("--group", type=int, default=32,
+    ap.add_argument("--group", type=int, default=64,
                     help="batches per library call: G independent batches of B roots share one set of launches "
                          "(each keeps its own union graph; results are bit-identical to G single-batch calls)")
     ap.add_argument("--workload", type=str, default="products",
