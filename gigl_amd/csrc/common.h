@@ -53,6 +53,8 @@ struct gigl_graph {
   gigl_ctx* ctx = nullptr;
   int64_t n = 0, e = 0;
   int64_t maxdeg = 0;         // largest in-degree (bounds the sampler's hash windows)
+  bool multi = false;         // some row repeats an id (directed multi-edges kept at ingest): the sampler draws over
+                              // the multiset and writes every sampled id once
   int64_t* rowptr = nullptr;  // device [n+1]
   uint32_t* col = nullptr;    // device [e]
 };

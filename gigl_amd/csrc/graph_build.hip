@@ -29,10 +29,14 @@ __global__ void coo_keys_kernel(const uint32_t* src, const uint32_t* dst, int64_
   }
 }
 
-__global__ void uniq_flag_kernel(const uint64_t* sorted, int64_t m, int32_t* flags) {
+// keep_all != 0: every record stays (directed multi-edges: the reference's collect_list keeps repeated (src, dst)
+// rows, SGSPureSparkV1Task.scala:337,442); *any_dup reports whether a record repeats
+__global__ void uniq_flag_kernel(const uint64_t* sorted, int64_t m, int32_t* flags, int keep_all, int32_t* any_dup) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
-  flags[i] = (i == 0 || sorted[i] != sorted[i - 1]) ? 1 : 0;
+  const bool first = i == 0 || sorted[i] != sorted[i - 1];
+  if (!first && keep_all) *any_dup = 1;
+  flags[i] = (first || keep_all) ? 1 : 0;
 }
 
 __global__ void uniq_write_kernel(const uint64_t* sorted, const int32_t* flags, const int32_t* scan,
@@ -71,22 +75,39 @@ __global__ void maxdeg_kernel(const int64_t* rowptr, int64_t n, unsigned long lo
   if ((threadIdx.x & 63) == 0 && d) atomicMax(out, d);
 }
 
+// does a row repeat an id?  Rows are ascending, so a repeat is two equal neighbours of `col` that are not separated by
+// a row boundary (checked by a search of rowptr only when the ids are equal)
+__global__ void multi_kernel(const int64_t* rowptr, const uint32_t* col, int64_t n, int64_t e, unsigned long long* out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p + 1 >= e || col[p] != col[p + 1]) return;
+  int64_t lo = 0, hi = n;  // first row whose end is > p: the row that holds position p
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid + 1] > p) hi = mid; else lo = mid + 1;
+  }
+  if (rowptr[lo + 1] > p + 1) out[1] = 1ull;  // position p + 1 is in the same row
+}
+
 }  // namespace
 
 int32_t gigl_graph_compute_maxdeg(gigl_ctx* ctx, gigl_graph* g) {
   g->maxdeg = 0;
   if (g->n == 0) return GIGL_OK;
   unsigned long long* d_out = nullptr;
-  GIGL_HIP_CHECK(ctx, hipMalloc((void**)&d_out, 8));
-  hipMemsetAsync(d_out, 0, 8, ctx->stream);
+  GIGL_HIP_CHECK(ctx, hipMalloc((void**)&d_out, 16));
+  hipMemsetAsync(d_out, 0, 16, ctx->stream);
   hipLaunchKernelGGL(maxdeg_kernel, dim3((unsigned)((g->n + 255) / 256)), dim3(256), 0, ctx->stream, g->rowptr,
                      g->n, d_out);
-  unsigned long long h = 0;
-  hipError_t e = hipMemcpyAsync(&h, d_out, 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (g->e > 1)
+    hipLaunchKernelGGL(multi_kernel, dim3((unsigned)((g->e + 255) / 256)), dim3(256), 0, ctx->stream, g->rowptr, g->col,
+                       g->n, g->e, d_out);
+  unsigned long long h[2] = {0, 0};
+  hipError_t e = hipMemcpyAsync(h, d_out, 16, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   hipFree(d_out);
   if (e != hipSuccess) return gigl_fail(ctx, GIGL_E_HIP, "maxdeg reduction failed: %s", hipGetErrorString(e));
-  g->maxdeg = (int64_t)h;
+  g->maxdeg = (int64_t)h[0];
+  g->multi = h[1] != 0;
   return GIGL_OK;
 }
 
@@ -218,15 +239,18 @@ extern "C" int32_t gigl_graph_build_from_coo(gigl_ctx* ctx, int64_t n, int64_t e
   void* work;
   BUILD_CHECK(tmp.alloc(&work, tb));
   BUILD_CHECK(hipcub::DeviceRadixSort::SortKeys(work, tb, keys, sorted, (int)m, 0, key_bits, st));
-  hipLaunchKernelGGL(uniq_flag_kernel, grid(m), dim3(TB), 0, st, sorted, m, flags);
+  const int keep_all = is_directed == 2 ? 1 : 0;
+  hipLaunchKernelGGL(uniq_flag_kernel, grid(m), dim3(TB), 0, st, sorted, m, flags, keep_all, bad + 1);
   BUILD_CHECK(hipcub::DeviceScan::ExclusiveSum(work, tb, flags, scan, (int)m, st));
   // unique keys overwrite `keys`
   hipLaunchKernelGGL(uniq_write_kernel, grid(m), dim3(TB), 0, st, sorted, flags, scan, m, keys, count);
   int64_t h_count = 0;
-  int32_t h_bad = 0;
+  int32_t h_bad = 0, h_dup = 0;
   BUILD_CHECK(hipMemcpyAsync(&h_count, count, 8, hipMemcpyDeviceToHost, st));
   BUILD_CHECK(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, st));
+  BUILD_CHECK(hipMemcpyAsync(&h_dup, bad + 1, 4, hipMemcpyDeviceToHost, st));
   BUILD_CHECK(hipStreamSynchronize(st));
+  (void)h_dup;  // (gigl_graph_compute_maxdeg below looks at the finished rows)
   if (h_bad) {
     gigl_graph_destroy(g);
     return gigl_fail(ctx, GIGL_E_INVALID_ARG, "%d edges reference node ids >= n=%lld", h_bad,

@@ -166,7 +166,8 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
   if (s == 0)
     return gigl_sample_khop(ctx, p->graph, roots, p->b, p->fanouts, p->hops, sampling_seed, mode, &p->tree);
   if (s == 1) {
-    int32_t rc = gigl_union_build_impl(ctx, roots, &p->tree, p->group_roots, &p->un, p->leaf_global ? 1 : 0);
+    int32_t rc = gigl_union_build_impl(ctx, roots, &p->tree, p->group_roots, &p->un,
+                                       p->leaf_global ? (1 | (p->graph->multi ? 2 : 0)) : 0);
     if (rc != GIGL_OK) return rc;
     hipLaunchKernelGGL(guard_levels_kernel, dim3(1), dim3(64), 0, ctx->stream, p->un.meta, p->hops,
                        (int32_t)(p->act_rows < 0x7FFFFFFF ? p->act_rows : 0x7FFFFFFF));

@@ -107,6 +107,26 @@ __device__ __forceinline__ void emit_sorted(const uint32_t* row, uint32_t idx, i
   if (lane < f) out[rank] = row[idx - 1];
 }
 
+// the same on a row that may repeat ids (ascending, so repeats are adjacent in position order): every id once;
+// returns the number of ids written, the rest of the f slots become GIGL_INVALID
+__device__ __forceinline__ int emit_sorted_distinct(const uint32_t* row, uint32_t idx, int f, int lane, uint32_t* out) {
+  const bool mine = lane < f && idx != 0xFFFFFFFFu;
+  const uint32_t val = mine ? row[idx - 1] : GIGL_INVALID;
+  bool dup = false;  // an equal id sits at a smaller selected position
+  for (int l = 0; l < f; ++l) {
+    const uint32_t il = readlane32(idx, l), vl = readlane32(val, l);
+    if (mine && vl == val && il < idx) dup = true;
+  }
+  const unsigned long long keep = __ballot(mine && !dup);
+  int rank = 0;
+  for (int l = 0; l < f; ++l)
+    if ((keep >> l) & 1ull) rank += readlane32(idx, l) < idx ? 1 : 0;
+  const int n = (int)__popcll(keep);
+  if (lane < f) out[lane] = GIGL_INVALID;
+  if (mine && !dup) out[rank] = val;
+  return n;
+}
+
 // direct hashing of positions i in [i_lo, i_hi] (1-based, inclusive); chunks c0, c0+cstride, ...
 // Four chunks are hashed before their merges so the multiply chains overlap.
 __device__ __forceinline__ void scan_direct(uint64_t& key, uint32_t& idx, uint64_t& tk, uint32_t& ti,
@@ -150,6 +170,8 @@ struct ExpandArgs {
   const uint32_t* ex_ksum;
   uint32_t row_div;
   int32_t proxy_drop;  // test knob (env GIGL_SAMPLER_PROXY_BITS): 32 - bits kept by the fast path's proxy keys
+  int32_t multi;       // rows may repeat an id (directed multi-edges): sampled positions are drawn over the multiset,
+                       // the ids they hold are written once each (the reference's output is a set of edges)
 };
 
 // CSC row of the parent in slot p and K (wrapping int32 sum of the path ids) — wave-uniform.  Slot numbers are
@@ -633,6 +655,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int64_t deg = a.rowptr[v + 1] - s;
     const uint32_t* row = a.col + s;
     if (deg <= f) {  // copy-through: the row is already the canonical ascending set
+      if (a.multi) {
+        const int nw = emit_sorted_distinct(row, lane < deg ? (uint32_t)lane + 1u : 0xFFFFFFFFu, f, lane, out);
+        if (lane == 0) a.out_cnt[p] = nw;
+        continue;
+      }
       if (lane < f) out[lane] = lane < deg ? row[lane] : GIGL_INVALID;
       if (lane == 0) a.out_cnt[p] = (int32_t)deg;
       continue;
@@ -652,6 +679,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         exact.select(tb, deg, base, in_table);
         sel_idx = exact.idx;
       }
+    }
+    if (a.multi) {
+      const int nw = emit_sorted_distinct(row, sel_idx, f, lane, out);
+      if (lane == 0) a.out_cnt[p] = nw;
+      continue;
     }
     emit_sorted(row, sel_idx, f, lane, out);
     if (lane == 0) a.out_cnt[p] = f;
@@ -729,8 +761,13 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(ExpandArgs a, const i
       uint32_t ti = readlane32(idx, f - 1);
       for (int ow = 1; ow < 4; ++ow)
         merge_candidates(key, idx, s_key[ow][lane], s_idx[ow][lane], true, tk, ti, f, lane);
-      emit_sorted(row, idx, f, lane, a.out_nbr + p * f);
-      if (lane == 0) a.out_cnt[p] = f;
+      if (a.multi) {
+        const int nw = emit_sorted_distinct(row, idx, f, lane, a.out_nbr + p * f);
+        if (lane == 0) a.out_cnt[p] = nw;
+      } else {
+        emit_sorted(row, idx, f, lane, a.out_nbr + p * f);
+        if (lane == 0) a.out_cnt[p] = f;
+      }
     }
     __syncthreads();
   }
@@ -1066,6 +1103,7 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
   a.rowptr = g->rowptr;
   a.col = g->col;
   a.n_nodes = g->n;
+  a.multi = g->multi ? 1 : 0;
   a.roots = roots;
   parents = b;
   for (int k = 0; k < hops; ++k) {
@@ -1125,6 +1163,7 @@ int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* n
   a.rowptr = shard->rowptr;
   a.col = shard->col;
   a.n_nodes = shard->n;  // local rows
+  a.multi = shard->multi ? 1 : 0;
   a.hop = 0;
   a.n_parents = m;
   a.f = f;
@@ -1166,6 +1205,7 @@ int32_t gigl_sample_out_neighbors(gigl_ctx* ctx, gigl_graph* g_out, const uint32
   a.rowptr = g_out->rowptr;
   a.col = g_out->col;
   a.n_nodes = g_out->n;
+  a.multi = g_out->multi ? 1 : 0;
   a.roots = roots;
   a.hop = 0;
   a.n_parents = b;

@@ -799,6 +799,7 @@ struct Lg2Args {
   uint32_t group_roots, gdiv0;  // stream slots of ONE batch: roots, hop-0
   int32_t* slot_of;             // [b + S0]
   int32_t alias_base;
+  int32_t whole_rows;           // a slot with fewer than f1 children holds its node's WHOLE in-neighbourhood (simple graphs)
 };
 
 __device__ __forceinline__ uint32_t lg2_base(const Lg2Args& g, const UnionArgs& a, int64_t t) {
@@ -824,7 +825,7 @@ __device__ __forceinline__ int32_t lg2_find(const UnionArgs& a, uint32_t base, u
 // occurrence of that node: the list is taken once, from the node's first occurrence (for a node that is also a root
 // the first occurrence is a root position, which has no hop-1 children of its own: every occurrence contributes).
 __device__ __forceinline__ bool lg2_contributes(const UnionArgs& a, const Lg2Args& g, int32_t s, int64_t t, int c) {
-  if (c >= g.f1) return true;
+  if (c >= g.f1 || !g.whole_rows) return true;
   const uint32_t fp = (uint32_t)a.slots[s].kf;
   return fp == (uint32_t)t || fp < (uint32_t)g.b;
 }
@@ -1517,7 +1518,7 @@ __global__ __launch_bounds__(1024) void lg2_row_sort_big_kernel(const int32_t* r
 }
 
 int32_t union_build_lg2(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree, int32_t group_roots,
-                        gigl_union* out) {
+                        gigl_union* out, bool multiset_rows) {
   const int b = tree->b;
   const int f0 = tree->fanouts[0], f1 = tree->fanouts[1];
   const int64_t S0 = (int64_t)b * f0, S1 = S0 * f1, T_in = b + S0;
@@ -1532,6 +1533,8 @@ int32_t union_build_lg2(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   g.f0 = f0;
   g.f1 = f1;
   g.S0 = S0;
+  // (rows of a multi-edge graph: fewer ids than the fanout can also mean that several drawn positions held one id)
+  g.whole_rows = multiset_rows ? 0 : 1;
   if (group_roots != b) {
     n_groups = b / group_roots;
     g.grouped = 1;
@@ -1691,14 +1694,14 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
   }
   if (leaf_global && hops == 2 && !getenv("GIGL_UNION_GENERIC")) {
     GIGL_REQUIRE(ctx, group_roots >= 1 && b % group_roots == 0, "group_roots=%d does not divide b=%d", group_roots, b);
-    return union_build_lg2(ctx, roots, tree, group_roots, out);
+    return union_build_lg2(ctx, roots, tree, group_roots, out, (leaf_global & 2) != 0);
   }
 
   UnionArgs a{};
   a.roots = roots;
   a.b = b;
   a.hops = hops;
-  a.leaf_global = leaf_global ? 1 : 0;
+  a.leaf_global = leaf_global ? 1 : 0;  // (bit 1 of the argument: the sampled graph keeps multi-edges)
   int64_t T = b, parents = b;
   for (int k = 0; k < hops; ++k) {
     a.nbr[k] = tree->nbr[k];

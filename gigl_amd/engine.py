@@ -196,13 +196,17 @@ class HipEngine:
         check(self._lib.gigl_graph_load_csc(self._ctx, n, e, rp_p, cl_p, loc1, C.byref(g)), self._ctx)
         self._set_graph(g, n, e, out_graph)
 
-    def build_from_coo(self, n: int, src, dst, is_directed: bool, *, out_graph: bool = False) -> None:
+    def build_from_coo(self, n: int, src, dst, is_directed: bool, *, out_graph: bool = False,
+                       keep_multi_edges: bool = False) -> None:
+        """keep_multi_edges (directed graphs): repeated (src, dst) records stay, as in the reference's directed path;
+        the sampler then draws over the multiset (GIGL_DIRECTED_MULTI, include/gigl_hip.h)"""
         s, s_p, loc1 = self._ptr_loc(src if isinstance(src, torch.Tensor) else np.asarray(src).astype(np.uint32))
         d, d_p, loc2 = self._ptr_loc(dst if isinstance(dst, torch.Tensor) else np.asarray(dst).astype(np.uint32))
         assert loc1 == loc2
         g = C.c_void_p()
-        check(self._lib.gigl_graph_build_from_coo(self._ctx, n, int(s.shape[0]), s_p, d_p, loc1,
-                                                  1 if is_directed else 0, C.byref(g)), self._ctx)
+        mode = (2 if keep_multi_edges else 1) if is_directed else 0
+        check(self._lib.gigl_graph_build_from_coo(self._ctx, n, int(s.shape[0]), s_p, d_p, loc1, mode, C.byref(g)),
+              self._ctx)
         nn, ee = C.c_int64(), C.c_int64()
         check(self._lib.gigl_graph_info(g, C.byref(nn), C.byref(ee)), self._ctx)
         self._set_graph(g, nn.value, ee.value, out_graph)

@@ -92,7 +92,10 @@ class HipKHopSamplerService:
     """one instance per worker/partition, like the reference; owns a HipEngine between setup/teardown"""
 
     def __init__(self, n_nodes: int, src, dst, features: Optional[np.ndarray], is_graph_directed: bool,
-                 device: int = 0, sampling_seed: int = 42):
+                 device: int = 0, sampling_seed: int = 42, keep_multi_edges: bool = True):
+        # keep_multi_edges: a directed graph keeps repeated (src, dst) records, as the reference's directed path does
+        # (SGSPureSparkV1Task.scala:337,442); switched off when edge features are hydrated (one row per distinct edge)
+        self.keep_multi_edges = keep_multi_edges
         self._args = (n_nodes, src, dst, is_graph_directed)
         self.features = None if features is None else np.ascontiguousarray(features, dtype=np.float32)
         self.device = device
@@ -103,9 +106,10 @@ class HipKHopSamplerService:
         from .engine import HipEngine  # raises without the HIP library / a GPU: no CPU fallback
         n, src, dst, directed = self._args
         self.engine = HipEngine(self.device)
-        self.engine.build_from_coo(n, src, dst, is_directed=directed)
+        multi = bool(directed and self.keep_multi_edges)
+        self.engine.build_from_coo(n, src, dst, is_directed=directed, keep_multi_edges=multi)
         # out-edge graph for positives: CSR by source == CSC of the reversed edges
-        self.engine.build_from_coo(n, dst, src, is_directed=directed, out_graph=True)
+        self.engine.build_from_coo(n, dst, src, is_directed=directed, out_graph=True, keep_multi_edges=multi)
         if self.features is not None:
             self.engine.load_features(self.features)
 

@@ -195,7 +195,8 @@ class SubgraphSampler:
         self.sampling_seed = seed
         n, src, dst, x, labels, node_ids = load_preprocessed_graph(cfg)
         ids = np.asarray(node_ids, dtype=np.uint32)
-        with HipKHopSamplerService(n, src, dst, x, cfg.is_graph_directed, device=device, sampling_seed=seed) as svc:
+        with HipKHopSamplerService(n, src, dst, x, cfg.is_graph_directed, device=device, sampling_seed=seed,
+                                   keep_multi_edges=getattr(cfg, "edge_features", None) is None) as svc:
             svc.sampling_mode = self.sampling_mode
             if getattr(cfg, "edge_features", None) is not None:  # hydrateEdges: records carry Edge.feature_values
                 svc.engine.load_edge_features(src, dst, cfg.edge_features, cfg.is_graph_directed)

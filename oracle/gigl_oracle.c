@@ -157,6 +157,12 @@ int gigl_oracle_sample_khop(int64_t n_nodes, const int64_t* rowptr, const uint32
               }
               o[q + 1] = x;
             }
+            /* a multiset row (directed multi-edges) can put one id at several sampled positions: the canonical
+             * form is the SET of sampled ids */
+            int32_t w = 0;
+            for (int32_t j = 0; j < c; ++j)
+              if (j == 0 || o[j] != o[w - 1]) o[w++] = o[j];
+            c = w;
           }
         }
       }
@@ -442,8 +448,10 @@ int gigl_oracle_build_csc(int64_t n, int64_t e, const uint32_t* src, const uint3
   }
   qsort(keys, (size_t)c, sizeof(uint64_t), u64_cmp);
   int64_t u = 0;
+  /* is_directed == 2: the directed path's collect_list keeps repeated (src, dst) rows (SGSPureSparkV1Task.scala:337,
+   * 442): rows are ascending multisets */
   for (int64_t i = 0; i < c; ++i)
-    if (i == 0 || keys[i] != keys[i - 1]) keys[u++] = keys[i];
+    if (is_directed == 2 || i == 0 || keys[i] != keys[i - 1]) keys[u++] = keys[i];
   *e_out = u;
   if (col) {
     for (int64_t i = 0; i <= n; ++i) rowptr[i] = 0;

@@ -150,12 +150,13 @@ def union_build(roots, fanouts: Sequence[int], nbr: Sequence[np.ndarray]):
                 col=col[:ne].copy(), root_local=root_local[:b].copy())
 
 
-def build_csc(n: int, src, dst, is_directed: bool):
+def build_csc(n: int, src, dst, is_directed: bool, keep_multi_edges: bool = False):
+    """keep_multi_edges (directed only): repeated (src, dst) records stay — rows are ascending multisets"""
     src = np.ascontiguousarray(src, dtype=np.uint32)
     dst = np.ascontiguousarray(dst, dtype=np.uint32)
     e_out = C.c_int64(0)
     args = [C.c_int64(n), C.c_int64(src.size), _p(src, C.c_uint32), _p(dst, C.c_uint32),
-            C.c_int32(1 if is_directed else 0)]
+            C.c_int32((2 if keep_multi_edges else 1) if is_directed else 0)]
     rc = _L().gigl_oracle_build_csc(*args, None, None, C.byref(e_out))
     assert rc == 0, rc
     rowptr = np.zeros(n + 1, dtype=np.int64)
