@@ -1627,7 +1627,8 @@ int32_t union_build_lg2(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
                                               2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
       lds_attr_set = true;
     }
-    hipLaunchKernelGGL(lg2_row_sort_big_kernel, dim3(64), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st,
+    // (a handful of workgroups: each needs most of a CU's LDS, and rows of more than MED_ROW entries are rare)
+    hipLaunchKernelGGL(lg2_row_sort_big_kernel, dim3(8), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st,
                        out->rowptr, out->rowend, out->col, big_rows, big_count, out->meta + GIGL_META_OVERFLOW,
                        edge_counters, ticket_big, out->meta);
   }
