@@ -52,11 +52,12 @@ MFMA_F32_PEAK_TF = 157.3  # same guide: dense fp32 matrix peak (v_mfma_f32_32x32
 PMC_KERNELS = {
     "expand": ["expand_kernel"],
     "gather_mean": ["gather_mean_kernel"],
-    "linear": ["linear_lds_kernel", "linear_mfma_kernel"],
-    "union_insert": ["init_scratch_kernel", "insert_roots_kernel", "insert_slots_kernel"],
-    "union_nodes": ["count_kernel", "tile_scan_kernel", "assign_kernel"],
-    "union_edge_sort": ["edge_dedup_count_kernel", "row_scan_kernel", "edge_fill_kernel"],
-    "union_csr": ["row_sort_kernel", "row_sort_big_kernel"],
+    "linear": ["linear_split_kernel", "linear_lds_kernel", "linear_mfma_kernel"],
+    # (the one-call plan's two-hop union build, union.hip "LG2"; the generic build's kernels have other names)
+    "union_insert": ["lg2_init_kernel", "lg2_insert_kernel", "lg2_extras_kernel"],
+    "union_nodes": ["lg2_count_kernel", "lg2_assign_kernel"],
+    "union_edge_sort": ["lg2_fill_kernel"],
+    "union_csr": ["lg2_row_sort_tiny_kernel", "lg2_row_sort_kernel", "lg2_row_sort_big_kernel"],
 }
 
 
