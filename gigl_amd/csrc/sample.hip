@@ -170,6 +170,7 @@ struct ExpandArgs {
   const uint32_t* ex_ksum;
   uint32_t row_div;
   int32_t proxy_drop;  // test knob (env GIGL_SAMPLER_PROXY_BITS): 32 - bits kept by the fast path's proxy keys
+  int32_t flat_max;    // rows up to this length read their hash window from the table's flat array
   int32_t multi;       // rows may repeat an id (directed multi-edges): sampled positions are drawn over the multiset,
                        // the ids they hold are written once each (the reference's output is a set of edges)
 };
@@ -209,124 +210,80 @@ __device__ __forceinline__ void parent_of(const ExpandArgs& a, uint32_t p, uint3
 constexpr int64_t HEAVY_DEG = 4096;
 
 // ------------------------------------------------------------------------------------------
-// Range-top-K table over the hash sequence.
+// Threshold lists over the hash sequence.
 //
 // Every parity-mode query is "the f smallest (g(j), j) for j in [base+1, base+deg]" where
 // g(j) = xxhash64_int32(j) is ONE fixed function of the integer j = i + K + seed*counter — the graph,
-// the roots and the sampling seed only move the window.  So g is tabulated once per ctx, sorted inside aligned
-// blocks of the j axis, and shared by all queries:
-//   level 0 block = 64 consecutive j, ALL of them, sorted by (g, j);
-//   level l block = 16 level-(l-1) blocks, its 64 smallest (g, j), sorted.
-//   memory: 12 B per covered j (+1/16 per extra level); hi and lo key words are separate arrays, the 32-bit
-//   proxy path reads only the hi words.
-// A window = a partial level-0 block at each end (read whole, one entry per lane, entries outside the window
-// dropped) + full blocks, decomposed into <= 15 blocks per level and side (the segment-tree cover).  A row never
-// hashes anything: the sampler kernel was VALU-bound on the 64-bit multiplies of xxhash64 (SQ counters: 88 % VALU
-// busy, half of the instructions in head/tail hashing when level 0 was 256 wide and only its top-64 was kept).
-// Results are bit-identical to the direct evaluation: a block's list contains every element of that block that
-// can be in the window's top-f (f <= 64), and j order == i order inside a non-wrapping window.
-// Windows that leave the covered domain or wrap around 2^32 fall back to direct hashing.
+// the roots and the sampling seed only move the window.  Hash values are uniform, so the f smallest of a window of
+// deg elements lie, with overwhelming probability, below T = lambda/deg * 2^32 (lambda = f + 4 sqrt(f) + 4), and only
+// ~lambda elements of the window do.  So g is tabulated once per device, by threshold:
+//   flat[j]        = top 32 bits of the ordered hash of j ("proxy"), every j of the covered domain, in j order;
+//   level l >= 1   = the (j, proxy) pairs of every j whose proxy is < 2^(32-l), ascending j (half of level l-1);
+//   off[l][b]      = number of level-l pairs with j < b * 16 * 2^l (where a window starts and ends in the list).
+//   memory: 4 + 8 (1 - 2^-24) + 0.25 (+ 0.1 build scratch) = 12.4 B per covered j.
+// A row picks the deepest level whose threshold still covers its T (l = clz(T - 1): deg/2^l in [lambda, 2 lambda)),
+// reads the pairs between two `off` entries — its window's members of that level plus at most one index block of
+// slack at either end, one or two 64-pair chunks, coalesced — and keeps those inside the window and below T.  A short
+// row reads flat[base+1 .. base+deg] instead.  Either way the survivors arrive in POSITION order.  No row hashes
+// anything, and a row of a million neighbours costs what a row of a hundred does.  Results are bit-identical to the
+// direct evaluation (see Sel::finish); windows that leave the covered domain or wrap around 2^32 hash directly.
 // ------------------------------------------------------------------------------------------
-constexpr int TBL_S0_SHIFT = 6;   // 64 j per level-0 block (the whole block is kept, sorted)
-constexpr int TBL_FAN_SHIFT = 4;  // 16 children per block
-constexpr int TBL_MAX_LEVELS = 7;
-constexpr int TBL_TOPK = 64;
+constexpr int TBL_MAX_LEVELS = 24;
+constexpr int TBL_TILE_SHIFT = 10;  // the table is built (and its domain rounded) in tiles of 1024 j
+constexpr int TBL_IDX_SHIFT = 4;    // index block of level l = 16 * 2^l consecutive j (16 expected pairs)
 
 struct RangeTable {
   int levels;
-  uint64_t dom;         // covered j domain [0, dom), multiple of 64
-  const uint32_t* khi;  // entry e of block blk at level l: [(lvl_off[l] + blk) * 64 + e]; ordered-hash bits 63..32
-  const uint32_t* klo;  //                                                                  ordered-hash bits 31..0
-  const uint32_t* js;
-  int64_t lvl_off[TBL_MAX_LEVELS];
-  int64_t nblocks[TBL_MAX_LEVELS];
-};
-
-// Aligned decomposition of the level-0 block range [lo, hi), level by level (the segment-tree cover): at level l
-// the blocks left of the next 16-alignment and right of the last one are taken (<= 15 each), the aligned middle
-// moves up a level.  O(levels) scalar work; the lists are enumerated level-ascending, left then right, so that
-// the LAST list is a block of the highest level reached.
-struct Cover {
-  uint32_t ls[TBL_MAX_LEVELS], ln[TBL_MAX_LEVELS], rs[TBL_MAX_LEVELS], rn[TBL_MAX_LEVELS];
-  uint32_t n_lists;
-  __device__ __forceinline__ void build(const RangeTable& tb, uint32_t lo, uint32_t hi) {
-    n_lists = 0;
-#pragma unroll
-    for (int l = 0; l < TBL_MAX_LEVELS; ++l) {
-      uint32_t nl = 0, nr = 0;
-      if (l < tb.levels && lo < hi) {
-        if (l == tb.levels - 1) {
-          nl = hi - lo;
-        } else {
-          nl = min((16u - (lo & 15u)) & 15u, hi - lo);
-          nr = min(hi & 15u, hi - lo - nl);
-        }
-      }
-      ls[l] = lo;
-      ln[l] = nl;
-      rs[l] = hi - nr;
-      rn[l] = nr;
-      n_lists += nl + nr;
-      lo = (lo + nl) >> TBL_FAN_SHIFT;
-      hi = (hi - nr) >> TBL_FAN_SHIFT;
-    }
-  }
-  // entry index of the first element of list x (enumeration order above); wave-uniform or per-lane x
-  // (global block ids fit 32 bits: <= 2^24 level-0 blocks plus 1/15 of that above them)
-  __device__ __forceinline__ int64_t entry(const RangeTable& tb, uint32_t x) const {
-    uint32_t gb = 0;
-    bool found = false;
-#pragma unroll
-    for (int l = 0; l < TBL_MAX_LEVELS; ++l) {
-      if ((ln[l] | rn[l]) == 0) continue;  // (uniform) most windows touch two or three levels
-      const uint32_t off = (uint32_t)tb.lvl_off[l];
-      if (!found && x < ln[l]) {
-        gb = off + ls[l] + x;
-        found = true;
-      }
-      x -= ln[l];  // (wraps once found: harmless)
-      if (!found && x < rn[l]) {
-        gb = off + rs[l] + x;
-        found = true;
-      }
-      x -= rn[l];
-    }
-    return found ? (int64_t)gb * TBL_TOPK : (int64_t)-1;
-  }
+  uint64_t dom;          // covered j domain [0, dom), multiple of 1024
+  const uint32_t* flat;  // [dom]
+  const uint2* lvl[TBL_MAX_LEVELS + 1];     // [l] -> pairs (j, proxy), ascending j; [0] unused
+  const uint32_t* off[TBL_MAX_LEVELS + 1];  // [l] -> ceil(dom / (16 * 2^l)) + 1 pair offsets
 };
 
 // ------------------------------------------------------------------------------------------
 // Per-row selection, in two precisions.
 //   FAST  keys are the top 32 bits of the ordered hash ("proxy").  Orders exactly like the 64-bit key
-//         whenever two proxies differ; any proxy EQUALITY that could matter (candidate vs. threshold,
-//         candidate vs. a list element) raises `tie` and the row is redone by the exact path.  An insert
-//         costs about half the instructions of the exact one (1 compare instead of 5, 3 DPP moves
-//         instead of 4, 2 broadcasts instead of 3).
-//   exact 64-bit key + position tie-break: SamplingStrategy.scala:63 verbatim.
+//         whenever two proxies differ; any proxy EQUALITY that could matter raises `tie` and the row is redone by
+//         the exact path.
+//   exact 64-bit key + position tie-break: SamplingStrategy.scala:63 verbatim (the 64-bit keys of the few
+//         candidates under the threshold are hashed on the spot).
 // ------------------------------------------------------------------------------------------
+enum { SRC_HASH = 0, SRC_FLAT = 1, SRC_LEVEL = 2 };
+
 template <bool FAST>
 struct Sel {
   using key_t = typename std::conditional<FAST, uint32_t, uint64_t>::type;
-  key_t key, tk;      // per-lane best key (ascending over lanes), threshold = f-th key
-  uint32_t idx, ti;   // per-lane best position, threshold position
+  key_t key, tk;      // serial path: per-lane best key (ascending over lanes), threshold = f-th key
+  uint32_t idx, ti;   // per-lane position (serial path: lanes [0, f), by key), threshold position
   bool tie;           // FAST only: a proxy equality was seen -> result not trustworthy
+  bool ordered;       // FAST only: the result is in position order: the lanes of `selmask` hold the f positions, ascending
+  unsigned long long selmask;
   int f, lane;
-
-  static __device__ __forceinline__ key_t inf() { return (key_t)~(key_t)0; }
   int drop;           // FAST only: low proxy bits discarded (0 in production; tests raise it to force ties)
   uint32_t dmask;     // ~0 << drop
-  __device__ __forceinline__ key_t mk(uint64_t ordered) const {
-    if constexpr (FAST) return (uint32_t)(ordered >> 32) & dmask;
-    else return ordered;
+  uint32_t flat_max;  // FAST only: rows up to this length read their window from the flat array whatever their level
+  float lam;
+
+  static __device__ __forceinline__ key_t inf() { return (key_t)~(key_t)0; }
+  __device__ __forceinline__ key_t mk(uint64_t ordered_hash) const {
+    if constexpr (FAST) return (uint32_t)(ordered_hash >> 32) & dmask;
+    else return ordered_hash;
   }
-  __device__ __forceinline__ void init(int f_, int lane_, int drop_ = 0) {
-    drop = drop_;
-    dmask = drop_ >= 32 ? 0u : (0xFFFFFFFFu << drop_);
+  __device__ __forceinline__ void reset_best() {
     key = tk = inf();
     idx = ti = 0xFFFFFFFFu;
+  }
+  __device__ __forceinline__ void init(int f_, int lane_, int drop_ = 0, uint32_t flat_max_ = 0) {
+    flat_max = flat_max_;
+    drop = drop_;
+    dmask = drop_ >= 32 ? 0u : (0xFFFFFFFFu << drop_);
+    reset_best();
     tie = false;
+    ordered = false;
+    selmask = 0;
     f = f_;
     lane = lane_;
+    lam = (float)f_ + 4.f * __builtin_sqrtf((float)f_) + 4.f;
   }
   __device__ __forceinline__ bool lt(key_t k1, uint32_t i1, key_t k2, uint32_t i2) const {
     if constexpr (FAST) return k1 < k2;
@@ -365,7 +322,7 @@ struct Sel {
       }
     }
   }
-  // merge one candidate per lane
+  // serial path: merge one candidate per lane into the best list
   __device__ __forceinline__ void merge(key_t ck, uint32_t ci, bool valid) {
     if constexpr (FAST) {
       if (__ballot(valid && ck == tk && tk != inf())) tie = true;
@@ -385,256 +342,195 @@ struct Sel {
       }
     }
   }
-  // direct hashing of positions [i_lo, i_hi] (1-based, inclusive); 4 chunks hashed ahead of their merges
-  __device__ __forceinline__ void scan_direct(int64_t i_lo, int64_t i_hi, uint32_t base) {
-    const int64_t nchunks = (i_hi - i_lo + 1 + 63) >> 6;
+  // serial path over the whole row: positions [1, deg], keys hashed on the spot (flat == nullptr) or, FAST only,
+  // read from the flat array; 4 chunks ahead of their merges
+  __device__ __forceinline__ void scan_row(const uint32_t* flat, int64_t deg, uint32_t base) {
+    const int64_t nchunks = (deg + 63) >> 6;
+    const uint32_t* src = flat + base;
+    auto key_at = [&](int64_t i) -> key_t {
+      if constexpr (FAST) {
+        if (flat) return i <= deg ? (key_t)(src[i] & dmask) : inf();
+      }
+      return mk(xxh64_i32_ordered((uint32_t)i + base));
+    };
     int64_t c = 0;
     for (; c + 3 < nchunks; c += 4) {
-      const int64_t ia = i_lo + c * 64 + lane, ib = ia + 64, ic = ib + 64, id = ic + 64;
-      const key_t ka = mk(xxh64_i32_ordered((uint32_t)ia + base)), kb = mk(xxh64_i32_ordered((uint32_t)ib + base)),
-                  kc = mk(xxh64_i32_ordered((uint32_t)ic + base)), kd = mk(xxh64_i32_ordered((uint32_t)id + base));
-      merge(ka, (uint32_t)ia, ia <= i_hi);
-      merge(kb, (uint32_t)ib, ib <= i_hi);
-      merge(kc, (uint32_t)ic, ic <= i_hi);
-      merge(kd, (uint32_t)id, id <= i_hi);
+      const int64_t ia = 1 + c * 64 + lane, ib = ia + 64, ic = ib + 64, id = ic + 64;
+      const key_t ka = key_at(ia), kb = key_at(ib), kc = key_at(ic), kd = key_at(id);
+      merge(ka, (uint32_t)ia, ia <= deg);
+      merge(kb, (uint32_t)ib, ib <= deg);
+      merge(kc, (uint32_t)ic, ic <= deg);
+      merge(kd, (uint32_t)id, id <= deg);
     }
     for (; c < nchunks; ++c) {
-      const int64_t i = i_lo + c * 64 + lane;
-      merge(mk(xxh64_i32_ordered((uint32_t)i + base)), (uint32_t)i, i <= i_hi);
+      const int64_t i = 1 + c * 64 + lane;
+      merge(key_at(i), (uint32_t)i, i <= deg);
     }
   }
-  // FAST only.  Short windows (no table block inside), done without the serial insert chain: hash values are
-  // uniform, so a threshold T = lambda/deg * 2^32 with lambda = f + 4*sqrt(f) + 4 lets ~lambda candidates
-  // through (count them with ballots, compact them into the wave's LDS scratch lk/li), then every survivor
-  // finds its rank among the <= 64 survivors by counting.  Exact: every non-survivor has a proxy >= T > every
-  // survivor's, so the f best of the window are the f best survivors — provided there are at least f of them
-  // and no two survivors share a proxy (-> tie, redone by the exact path).  Too few / too many survivors
-  // (about 1 row in 10^3) -> returns false and the caller runs the serial path.
-  // On success lanes [0, f) hold the selected positions (any order).
-  __device__ __forceinline__ bool filter_select(int64_t deg, uint32_t base, uint32_t* lk, uint32_t* li) {
-    const float lam = (float)f + 4.f * __builtin_sqrtf((float)f) + 4.f;
-    if (lam > 56.f || deg > 65536) return false;
-    const uint32_t n = (uint32_t)deg;
-    const bool all = n <= 64u;
-    const uint32_t T = all ? 0xFFFFFFFFu : (uint32_t)fminf(lam * 4294967296.f / (float)n, 4294967040.f);
-    uint32_t count = 0;
-    const uint32_t nchunks = (n + 63u) >> 6;
-    for (uint32_t c = 0; c < nchunks; ++c) {
-      const uint32_t i = c * 64u + (uint32_t)lane + 1u;
-      const key_t k = mk(xxh64_i32_ordered(i + base));
-      const bool pass = i <= n && (all || k < T);
-      const unsigned long long m = __ballot(pass);
-      if (pass) {
-        const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (pos < 64u) {
-          lk[pos] = (uint32_t)k;
-          li[pos] = i;
-        }
-      }
-      count += (uint32_t)__popcll(m);
+  // serial path over the level-l pairs of the window whose proxy is below T (T <= 2^(32-l): every element of the
+  // window with a proxy below T is in the list); returns whether f elements were found (then they are the row's f best:
+  // everything left out has a larger proxy, hence a larger key)
+  __device__ __forceinline__ bool scan_level(const RangeTable& tb, int l, uint32_t T, uint32_t n, uint32_t base) {
+    const int gs = TBL_IDX_SHIFT + l;
+    const uint32_t* off = tb.off[l];
+    const uint2* ent = tb.lvl[l];
+    const uint32_t start = off[(base + 1u) >> gs], end = off[((base + n) >> gs) + 1u];
+    for (uint32_t e0 = start; e0 < end; e0 += 64u) {
+      const uint32_t e = e0 + (uint32_t)lane;
+      uint2 x = make_uint2(0u, 0xFFFFFFFFu);
+      if (e < end) x = ent[e];
+      const uint32_t i = x.x - base;
+      const bool pass = e < end && (uint32_t)(i - 1u) < n && x.y < T;
+      key_t ck;
+      if constexpr (FAST) ck = x.y & dmask;
+      else ck = xxh64_i32_ordered(x.x);
+      merge(ck, i, pass);
     }
-    if (count < (uint32_t)f || count > 64u) return false;
-    wave_lds_sync();
-    const bool valid = (uint32_t)lane < count;
-    const uint32_t k = valid ? lk[lane] : 0xFFFFFFFFu;
-    const uint32_t i = valid ? li[lane] : 0xFFFFFFFFu;
-    uint32_t rank = 0, eq = 0;
-    for (uint32_t j = 0; j < count; ++j) {
-      const uint32_t kj = readlane32(k, (int)j);
-      rank += kj < k ? 1u : 0u;
-      eq += kj == k ? 1u : 0u;
-    }
-    if (__ballot(valid && eq != 1u)) {
-      tie = true;
-      return true;
-    }
-    wave_lds_sync();
-    if (valid && rank < (uint32_t)f) li[rank] = i;
-    wave_lds_sync();
-    idx = lane < f ? li[lane] : 0xFFFFFFFFu;
-    return true;
+    return readlane32(idx, f - 1) != 0xFFFFFFFFu;
   }
-  __device__ __forceinline__ key_t table_key(const RangeTable& tb, int64_t e) const {
-    if constexpr (FAST) return tb.khi[e] & dmask;
-    else return ((uint64_t)tb.khi[e] << 32) | tb.klo[e];
-  }
-  // FAST only.  The whole row from the table, without a serial insert chain: with T = lambda/deg * 2^32
-  // (lambda = f + 4 sqrt(f) + 4) about lambda elements of the window have a proxy below T.  The partial blocks at
-  // the window's ends are read whole, one entry per lane; a full block's list is sorted, so the lane that owns it
-  // reads entries only while they stay below T (one parallel load per round for 64 lists).  The <= 64 survivors
-  // are compacted into the wave's LDS scratch and ranked by counting.  Exact: an element that is not a survivor
-  // has a proxy >= T (for a list: it is at or after the first entry >= T) > every survivor's.  Needs >= f
-  // survivors, <= 64, no list exhausted below T, and no proxy shared by two survivors (-> tie -> exact path).
-  // Returns false when the row must take the insert-based path instead.
-  __device__ __forceinline__ bool table_filter(const RangeTable& tb, int64_t deg, uint32_t base, const Cover& cv,
-                                               uint32_t* lk, uint32_t* li) {
-    const float lam = (float)f + 4.f * __builtin_sqrtf((float)f) + 4.f;
-    if (lam > 56.f) return false;
-    const uint32_t n = (uint32_t)deg;
-    const bool all = n <= 64u;
-    const uint32_t T = all ? 0xFFFFFFFFu : (uint32_t)fminf(lam * 4294967296.f / (float)n, 4294967040.f);
-    uint32_t count = 0;
-    bool exhausted = false;
-    auto offer = [&](key_t k, uint32_t i, bool pass) {
-      const unsigned long long m = __ballot(pass);
-      if (pass) {
-        const uint32_t pos = count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                               __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (pos < 64u) {
-          lk[pos] = (uint32_t)k;
-          li[pos] = i;
-        }
-      }
-      count += (uint32_t)__popcll(m);
-    };
-    // All table loads of a phase are issued before any of them is consumed: the kernel is otherwise bound by
-    // the round-trip latency of dependent loads (SQ counters: 75 % of the wave cycles waiting).
-    const uint64_t j_lo = (uint64_t)base + 1, j_hi = (uint64_t)base + (uint64_t)deg;
-    const uint32_t first_blk = (uint32_t)(j_lo >> TBL_S0_SHIFT), last_blk = (uint32_t)(j_hi >> TBL_S0_SHIFT);
-    constexpr uint32_t WIDE_MAX = 8;
-    // level-0 blocks read whole, one entry per lane (entries outside the window dropped): every block of a short
-    // row (few blocks: wide reads beat owned-list rounds), else just the partial blocks at the window's ends
-    const bool short_row = last_blk - first_blk < WIDE_MAX;
-    const bool head_partial = (j_lo & 63u) != 0, tail_partial = ((j_hi + 1) & 63u) != 0;
-    const uint32_t nw = short_row ? last_blk - first_blk + 1 : (head_partial ? 1u : 0u) + (tail_partial ? 1u : 0u);
-    const uint32_t wb1 = short_row ? first_blk + 1 : last_blk;
-    const uint32_t wb0 = short_row || head_partial ? first_blk : last_blk;
-    {
-      key_t wk[WIDE_MAX];
-      uint32_t wj[WIDE_MAX];
-#pragma unroll
-      for (uint32_t t = 0; t < WIDE_MAX; ++t)
-        if (t < nw) {
-          const uint32_t blk = t == 0 ? wb0 : t == 1 ? wb1 : first_blk + t;
-          const int64_t e = (int64_t)blk * TBL_TOPK + lane;
-          wk[t] = table_key(tb, e);
-          wj[t] = tb.js[e];
-        }
-#pragma unroll
-      for (uint32_t t = 0; t < WIDE_MAX; ++t)
-        if (t < nw) {
-          const uint32_t i = wj[t] - base;  // position; outside [1, deg] = not in the window
-          offer(wk[t], i, (uint32_t)(i - 1u) < n && (all || wk[t] < T));
-        }
-    }
-    if (!short_row) {  // (a long row has full blocks: the cover is built)
-      for (uint32_t x0 = 0; x0 < cv.n_lists; x0 += 64) {
-        const uint32_t x = x0 + (uint32_t)lane;
-        const int64_t ent = x < cv.n_lists ? cv.entry(tb, x) : -1;
-        bool active = ent >= 0;
-        for (int cur = 0; cur < TBL_TOPK && __ballot(active); cur += 4) {  // 4 entries per lane and round
-          uint4 k4 = make_uint4(~0u, ~0u, ~0u, ~0u), j4 = make_uint4(0, 0, 0, 0);
-          if (active) {
-            k4 = *(const uint4*)(tb.khi + ent + cur);
-            j4 = *(const uint4*)(tb.js + ent + cur);
-          }
-          const uint32_t ks[4] = {k4.x & dmask, k4.y & dmask, k4.z & dmask, k4.w & dmask};
-          const uint32_t jj[4] = {j4.x, j4.y, j4.z, j4.w};
-          bool pass = active;
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            pass = pass && ks[t] < T;  // sorted list: once an entry fails, the rest fail
-            offer((key_t)ks[t], jj[t] - base, pass);
-          }
-          active = pass;
-          if (pass && cur + 4 == TBL_TOPK) exhausted = true;
-        }
-      }
-    }
-    if (__ballot(exhausted) || count < (uint32_t)f || count > 64u) {
+  // FAST only: the tail of the filter selections.  `count` survivors (every element of the window with a proxy below
+  // the row's threshold) sit in the wave's LDS scratch lk (proxies) / li (positions), in ascending position order.
+  // Every survivor finds its rank among them by counting (keys read back four at a time as LDS broadcasts); the f
+  // best of the window are the f best survivors — every non-survivor has a larger proxy — provided there are at
+  // least f of them and no two survivors share a proxy (-> tie, redone exactly).  Too few / too many survivors
+  // (about 1 row in 10^3) -> false, the caller runs the serial path.  On success `ordered` is set: the lanes of
+  // `selmask` hold the selected positions in ascending order, so the caller's output slot is a popcount.
+  __device__ __forceinline__ bool finish(uint32_t count, uint32_t* lk, uint32_t* li) {
+    if (count < (uint32_t)f || count > 64u) {
       wave_lds_sync();
       return false;
     }
+    if (lane < 3) lk[count + (uint32_t)lane] = 0xFFFFFFFFu;  // padding of the last 4-wide read
     wave_lds_sync();
     const bool valid = (uint32_t)lane < count;
     const uint32_t k = valid ? lk[lane] : 0xFFFFFFFFu;
     const uint32_t i = valid ? li[lane] : 0xFFFFFFFFu;
     uint32_t rank = 0;  // survivors with a strictly smaller proxy
-    for (uint32_t j = 0; j < count; ++j) rank += readlane32(k, (int)j) < k ? 1u : 0u;
+    for (uint32_t j = 0; j < count; j += 4) {
+      const uint4 q = *(const uint4*)(lk + j);  // same address in every lane: one broadcast read
+      rank += (q.x < k ? 1u : 0u) + (q.y < k ? 1u : 0u) + (q.z < k ? 1u : 0u) + (q.w < k ? 1u : 0u);
+    }
     // two survivors share a proxy <=> they share a rank: every survivor writes its lane under its rank and reads
     // it back (the ranks of distinct proxies are distinct)
     wave_lds_sync();
     if (valid) lk[rank] = (uint32_t)lane;
     wave_lds_sync();
-    if (__ballot(valid && lk[rank] != (uint32_t)lane)) {
+    const bool clash = valid && lk[rank] != (uint32_t)lane;
+    wave_lds_sync();
+    if (__ballot(clash)) {
       tie = true;
       return true;
     }
-    if (valid && rank < (uint32_t)f) li[rank] = i;
-    wave_lds_sync();
-    idx = lane < f ? li[lane] : 0xFFFFFFFFu;
+    selmask = __ballot(valid && rank < (uint32_t)f);
+    idx = i;
+    ordered = true;
     return true;
   }
-  // merge the lists owned by the lanes (my_ent = first entry of the lane's list, or -1) by rounds
-  __device__ __forceinline__ void merge_lists(const RangeTable& tb, int64_t my_ent, uint32_t base) {
-    bool active = my_ent >= 0;
-    int cur = 0;
-    while (__ballot(active)) {
-      key_t ck = inf();
-      uint32_t ci = 0xFFFFFFFFu;
-      if (active) {
-        ck = table_key(tb, my_ent + cur);
-        ci = tb.js[my_ent + cur] - base;  // position i = j - base
+  // survivors of one 64-candidate chunk appended to the scratch, order kept
+  __device__ __forceinline__ void offer(uint32_t k, uint32_t i, bool pass, uint32_t& count, uint32_t* lk, uint32_t* li) {
+    const unsigned long long m = __ballot(pass);
+    if (pass) {
+      const uint32_t pos =
+          count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (pos < 64u) {
+        lk[pos] = k;
+        li[pos] = i;
       }
-      merge(ck, ci, active);
-      ++cur;
-      // my list can still contribute only if this offer made it into the best f (offer <= threshold)
-      active = active && cur < TBL_TOPK && !lt(tk, ti, ck, ci);
     }
+    count += (uint32_t)__popcll(m);
+  }
+  // FAST only.  The window's proxies in position order, hashed on the spot (SRC_HASH: windows outside the table) or
+  // read from the flat array, filtered by T; four chunks' loads (or hashes) in flight before any is consumed.
+  template <int SRC>
+  __device__ __forceinline__ bool filter_positions(const uint32_t* flat, uint32_t n, uint32_t T, uint32_t base,
+                                                   uint32_t* lk, uint32_t* li) {
+    const bool all = n <= 64u;
+    uint32_t count = 0;
+    const uint32_t nchunks = (n + 63u) >> 6;
+    const uint32_t* src = flat + base;  // position i -> j = base + i (inside the table: the caller checked)
+    for (uint32_t c = 0; c < nchunks; c += 4) {
+      uint32_t kk[4];
+#pragma unroll
+      for (uint32_t t = 0; t < 4; ++t) {
+        const uint32_t i = (c + t) * 64u + (uint32_t)lane + 1u;
+        kk[t] = 0xFFFFFFFFu;
+        if (i <= n) {
+          if constexpr (SRC == SRC_FLAT) kk[t] = src[i] & dmask;
+          else kk[t] = (uint32_t)mk(xxh64_i32_ordered(i + base));
+        }
+      }
+#pragma unroll
+      for (uint32_t t = 0; t < 4; ++t) {
+        if (c + t >= nchunks) break;
+        const uint32_t i = (c + t) * 64u + (uint32_t)lane + 1u;
+        offer(kk[t], i, i <= n && (all || kk[t] < T), count, lk, li);
+      }
+    }
+    return finish(count, lk, li);
+  }
+  // FAST only.  The window's members of level l (T <= 2^(32-l)), between two index entries, filtered by window and T.
+  __device__ __forceinline__ bool filter_level(const RangeTable& tb, int l, uint32_t n, uint32_t T, uint32_t base,
+                                               uint32_t* lk, uint32_t* li) {
+    const int gs = TBL_IDX_SHIFT + l;
+    const uint32_t* off = tb.off[l];
+    const uint2* ent = tb.lvl[l];
+    const uint32_t start = off[(base + 1u) >> gs], end = off[((base + n) >> gs) + 1u];
+    if (end - start > 256u) return false;  // (a row longer than the deepest level is made for)
+    uint32_t count = 0;
+    for (uint32_t e0 = start; e0 < end; e0 += 128u) {  // two chunks' loads in flight
+      const uint32_t ea = e0 + (uint32_t)lane, eb = ea + 64u;
+      uint2 xa = make_uint2(0u, 0xFFFFFFFFu), xb = xa;
+      if (ea < end) xa = ent[ea];
+      if (eb < end) xb = ent[eb];
+      const uint32_t ia = xa.x - base, ib = xb.x - base;
+      offer(xa.y & dmask, ia, ea < end && (uint32_t)(ia - 1u) < n && xa.y < T, count, lk, li);
+      if (e0 + 64u < end) offer(xb.y & dmask, ib, eb < end && (uint32_t)(ib - 1u) < n && xb.y < T, count, lk, li);
+    }
+    return finish(count, lk, li);
   }
   // the whole row: window of positions [1, deg] with hash offset `base`
   __device__ __forceinline__ void select(const RangeTable& tb, int64_t deg, uint32_t base, bool in_table,
                                          uint32_t* lk = nullptr, uint32_t* li = nullptr) {
+    // (any T is a valid filter: the approximate reciprocal is fine; uniform, so it moves to the scalar side)
+    const uint32_t n = (uint32_t)deg;
+    const uint32_t T = n <= 64u ? 0xFFFFFFFFu
+                                : (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)fminf(
+                                      lam * 4294967296.f * __builtin_amdgcn_rcpf((float)n), 4294967040.f));
     if (!in_table) {
       if constexpr (FAST) {
-        if (lk && filter_select(deg, base, lk, li)) return;
+        if (lk && lam <= 56.f && deg <= 65536 && filter_positions<SRC_HASH>(nullptr, n, T, base, lk, li)) return;
       }
-      scan_direct(1, deg, base);
+      scan_row(nullptr, deg, base);
       return;
     }
-    const uint64_t j_lo = (uint64_t)base + 1, j_hi = (uint64_t)base + (uint64_t)deg;  // inclusive window
-    // aligned level-0 blocks fully inside the window
-    const uint64_t b_first = (j_lo + ((1u << TBL_S0_SHIFT) - 1)) >> TBL_S0_SHIFT;
-    const uint64_t b_last = (j_hi + 1) >> TBL_S0_SHIFT;  // one past the last full block
-    const bool has_full = b_first < b_last;
-    Cover cv;
-    cv.build(tb, (uint32_t)b_first, has_full ? (uint32_t)b_last : (uint32_t)b_first);  // (empty cover: n_lists 0)
     if constexpr (FAST) {
-      if (lk && table_filter(tb, deg, base, cv, lk, li)) return;
-    }
-    // insert-based path (exact keys; proxy rows the filter could not settle): the last list — a block of the
-    // highest level reached — seeds the best list (its sorted entries make the threshold tight before anything
-    // is inserted); the other lists are merged by rounds; head and tail positions are hashed directly.
-    if (!has_full) {
-      scan_direct(1, deg, base);
-      return;
-    }
-    {
-      const int64_t ent = cv.entry(tb, cv.n_lists - 1);
-      key = table_key(tb, ent + lane);
-      idx = tb.js[ent + lane] - base;  // position i = j - base
-      if constexpr (FAST) {  // equal proxies inside the seed list (adjacent: it is sorted by the full key)
-        const uint32_t up = dpp_shr1(key);
-        if (__ballot(lane > 0 && lane <= f && up == key)) tie = true;
+      if (lk && lam <= 56.f) {
+        const int l = min((int)__builtin_clz(T - 1u), tb.levels);  // deepest level with 2^(32-l) >= T  (T >= 2)
+        const bool ok = (l == 0 || n <= flat_max) ? filter_positions<SRC_FLAT>(tb.flat, n, T, base, lk, li)
+                                                  : filter_level(tb, l, n, T, base, lk, li);
+        if (ok) return;
       }
-      refresh_threshold();
     }
-    // the other lists, 64 per batch, list q of a batch owned by lane q, merged by rounds
-    for (uint32_t x0 = 0; x0 + 1 < cv.n_lists; x0 += 64) {
-      const uint32_t x = x0 + (uint32_t)lane;
-      merge_lists(tb, x + 1 < cv.n_lists ? cv.entry(tb, x) : -1, base);
+    // serial path (exact keys; rows the filter could not settle; fanouts too large for the filter): the candidates
+    // under four times the threshold, best f kept by insertion; in the (practically impossible) case that fewer than f
+    // lie below it, the whole row
+    const uint32_t T4 = T >= (1u << 30) ? 0xFFFFFFFFu : 4u * T;
+    const int l4 = T4 == 0xFFFFFFFFu ? 0 : min((int)__builtin_clz(T4 - 1u), tb.levels);
+    if (l4 > 0) {
+      if (scan_level(tb, l4, T4, n, base)) return;
+      reset_best();
     }
-    // head: positions before the first block boundary; tail: after the last full block
-    const int64_t head_hi = (int64_t)((b_first << TBL_S0_SHIFT) - 1 - base);  // position of the last head j
-    if (head_hi >= 1) scan_direct(1, head_hi, base);
-    const int64_t tail_lo = (int64_t)((b_last << TBL_S0_SHIFT) - base);
-    if (tail_lo <= deg) scan_direct(tail_lo, deg, base);
+    if constexpr (FAST) {
+      scan_row(tb.flat, deg, base);
+      if (readlane32(idx, f - 1) == 0xFFFFFFFFu) tie = true;  // (a proxy of all ones never enters the list)
+    } else {
+      scan_row(nullptr, deg, base);
+    }
   }
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void expand_kernel(ExpandArgs a, RangeTable tb) {
-  __shared__ uint32_t s_lk[4][64], s_li[4][64];  // per-wave survivor scratch of the filter selections
+  __shared__ __attribute__((aligned(16))) uint32_t s_lk[4][68], s_li[4][64];  // per-wave survivor scratch of the filter selections
   const int lane = threadIdx.x & 63;
   // the parent slot, its row and every window bound are the same for all lanes: say so (readfirstlane), and the
   // per-row control flow below runs on the scalar unit with scalar loads instead of 64-bit vector arithmetic
@@ -670,7 +566,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t sel_idx;
     {
       Sel<true> fast;
-      fast.init(f, lane, a.proxy_drop);
+      fast.init(f, lane, a.proxy_drop, a.flat_max);
       fast.select(tb, deg, base, in_table, s_lk[wave_in_block], s_li[wave_in_block]);
       sel_idx = fast.idx;
       if (fast.tie) {  // a 32-bit proxy tie touched the result (about once per 10^7 rows): redo exactly
@@ -678,6 +574,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         exact.init(f, lane);
         exact.select(tb, deg, base, in_table);
         sel_idx = exact.idx;
+      } else if (fast.ordered) {  // selected lanes hold the positions in ascending order
+        const unsigned long long m = fast.selmask;
+        const bool sel = (m >> lane) & 1ull;
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const uint32_t val = sel ? row[sel_idx - 1] : GIGL_INVALID;
+        if (!a.multi) {
+          if (sel) out[slot] = val;
+          if (lane == 0) a.out_cnt[p] = f;
+          continue;
+        }
+        // ascending positions of an ascending row: a repeated id sits right after its first copy
+        uint32_t* lk = s_lk[wave_in_block];
+        if (sel) lk[slot] = val;
+        wave_lds_sync();
+        const bool keep = sel && (slot == 0 || lk[slot - 1] != val);
+        wave_lds_sync();
+        const unsigned long long km = __ballot(keep);
+        if (lane < f) out[lane] = GIGL_INVALID;
+        if (keep) out[__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u))] = val;
+        if (lane == 0) a.out_cnt[p] = (int32_t)__popcll(km);
+        continue;
       }
     }
     if (a.multi) {
@@ -690,42 +607,117 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   }
 }
 
-// table construction, level 0: one wave per block of 64 consecutive j, all of them, sorted
-__global__ __launch_bounds__(256) void table_l0_kernel(uint32_t* khi, uint32_t* klo, uint32_t* js, int64_t nblocks) {
-  const int lane = threadIdx.x & 63;
-  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (blk >= nblocks) return;
-  const uint32_t j0 = (uint32_t)(blk << TBL_S0_SHIFT);
-  uint32_t idx = 0xFFFFFFFFu;
-  uint64_t key = ~0ULL, tk = ~0ULL;
-  uint32_t ti = 0xFFFFFFFFu;
-  for (int c = 0; c < (1 << TBL_S0_SHIFT) / 64; ++c) {
-    uint32_t j = j0 + c * 64 + lane;
-    merge_candidates(key, idx, xxh64_i32_ordered(j), j, true, tk, ti, 64, lane);
-  }
-  khi[blk * TBL_TOPK + lane] = (uint32_t)(key >> 32);
-  klo[blk * TBL_TOPK + lane] = (uint32_t)key;
-  js[blk * TBL_TOPK + lane] = idx;
+// ---- table construction.  A workgroup owns a tile of 1024 consecutive j; wave w the 256 j from tile*1024 + w*256,
+// as 4 rows of 64 (lane = j offset inside the row), so ballots enumerate a level's members in j order.
+__global__ __launch_bounds__(256) void table_flat_kernel(uint32_t* flat, uint64_t dom) {
+  const uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < dom) flat[j] = (uint32_t)(xxh64_i32_ordered((uint32_t)j) >> 32);
 }
 
-// level l+1 from level l: one wave per parent block, merging its 16 children's lists
-__global__ __launch_bounds__(256) void table_up_kernel(const uint32_t* chi, const uint32_t* clo, const uint32_t* cjs,
-                                                       uint32_t* khi, uint32_t* klo, uint32_t* js, int64_t nblocks) {
-  const int lane = threadIdx.x & 63;
-  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (blk >= nblocks) return;
-  const int64_t c0 = blk << TBL_FAN_SHIFT;
-  auto ckey = [&](int64_t e) { return ((uint64_t)chi[e] << 32) | clo[e]; };
-  uint64_t key = ckey(c0 * TBL_TOPK + lane);
-  uint32_t idx = cjs[c0 * TBL_TOPK + lane];  // child lists are ascending already
-  uint64_t tk = readlane64(key, 63);
-  uint32_t ti = readlane32(idx, 63);
-  for (int c = 1; c < (1 << TBL_FAN_SHIFT); ++c)
-    merge_candidates(key, idx, ckey((c0 + c) * TBL_TOPK + lane), cjs[(c0 + c) * TBL_TOPK + lane], true, tk, ti, 64,
-                     lane);
-  khi[blk * TBL_TOPK + lane] = (uint32_t)(key >> 32);
-  klo[blk * TBL_TOPK + lane] = (uint32_t)key;
-  js[blk * TBL_TOPK + lane] = idx;
+// deepest level that lists a proxy: its leading zeros (level l lists the proxies < 2^(32-l))
+__device__ __forceinline__ int level_of(uint32_t proxy, int levels) { return min((int)__clz((int)proxy), levels); }
+
+// per tile and level: number of members.  cnt[(l-1) * n_tiles + tile]
+__global__ __launch_bounds__(256) void table_count_kernel(const uint32_t* flat, uint32_t* cnt, uint32_t n_tiles,
+                                                          int levels) {
+  __shared__ uint32_t s_cnt[TBL_MAX_LEVELS + 1][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t tile = blockIdx.x;
+  const uint64_t j0 = ((uint64_t)tile << TBL_TILE_SHIFT) + (uint64_t)w * 256 + lane;
+  int m[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) m[r] = level_of(flat[j0 + r * 64], levels);
+  for (int l = 1; l <= levels; ++l) {  // (members of level l+1 are members of level l)
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c += (uint32_t)__popcll(__ballot(m[r] >= l));
+    if (lane == 0) s_cnt[l][w] = c;
+  }
+  __syncthreads();
+  const int l = threadIdx.x + 1;
+  if (l <= levels) cnt[(uint64_t)(l - 1) * n_tiles + tile] = s_cnt[l][0] + s_cnt[l][1] + s_cnt[l][2] + s_cnt[l][3];
+}
+
+// per level (blockIdx.x = l - 1): exclusive scan of the tile counts, in place; total[l] = members of the level
+__global__ __launch_bounds__(1024) void table_scan_kernel(uint32_t* cnt, uint32_t n_tiles, uint32_t* total) {
+  __shared__ uint32_t s_sum[1024];
+  uint32_t* c = cnt + (uint64_t)blockIdx.x * n_tiles;
+  const uint32_t span = (n_tiles + 1023u) / 1024u;
+  const uint32_t lo = min(threadIdx.x * span, n_tiles), hi = min(lo + span, n_tiles);
+  uint32_t s = 0;
+  for (uint32_t t = lo; t < hi; ++t) s += c[t];
+  s_sum[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {  // (Hillis-Steele: built once per table)
+    const uint32_t v = threadIdx.x >= (unsigned)d ? s_sum[threadIdx.x - d] : 0u;
+    __syncthreads();
+    s_sum[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = s_sum[threadIdx.x] - s;
+  for (uint32_t t = lo; t < hi; ++t) {
+    const uint32_t v = c[t];
+    c[t] = run;
+    run += v;
+  }
+  if (threadIdx.x == 1023) total[blockIdx.x + 1] = s_sum[1023];
+}
+
+struct TableBuild {
+  const uint32_t* flat;
+  const uint32_t* tile_off;  // scanned counts, [(l-1) * n_tiles + tile]
+  const uint32_t* total;     // [l]
+  uint2* lvl[TBL_MAX_LEVELS + 1];
+  uint32_t* off[TBL_MAX_LEVELS + 1];
+  uint32_t n_tiles;
+  int levels;
+  uint64_t dom;
+};
+
+// members written in j order; index entries of the blocks that start inside the tile
+__global__ __launch_bounds__(256) void table_fill_kernel(TableBuild t) {
+  __shared__ uint32_t s_cnt[TBL_MAX_LEVELS + 1][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t tile = blockIdx.x;
+  const uint64_t jw = ((uint64_t)tile << TBL_TILE_SHIFT) + (uint64_t)w * 256;
+  uint32_t px[4];
+  int m[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    px[r] = t.flat[jw + r * 64 + lane];
+    m[r] = level_of(px[r], t.levels);
+  }
+  for (int l = 1; l <= t.levels; ++l) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c += (uint32_t)__popcll(__ballot(m[r] >= l));
+    if (lane == 0) s_cnt[l][w] = c;
+  }
+  __syncthreads();
+  for (int l = 1; l <= t.levels; ++l) {
+    uint32_t run = t.tile_off[(uint64_t)(l - 1) * t.n_tiles + tile];  // members before this wave's first j
+    for (int ww = 0; ww < w; ++ww) run += s_cnt[l][ww];
+    const int gs = TBL_IDX_SHIFT + l;
+    if (gs > TBL_TILE_SHIFT && s_cnt[l][w] == 0) continue;  // (index blocks of these levels start at tile starts)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned long long mm = __ballot(m[r] >= l);
+      const uint32_t before = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+      const uint64_t j = jw + r * 64 + lane;
+      if (m[r] >= l) t.lvl[l][before] = make_uint2((uint32_t)j, px[r]);
+      if (gs <= TBL_TILE_SHIFT && (j & ((1ull << gs) - 1)) == 0) t.off[l][j >> gs] = before;
+      run += (uint32_t)__popcll(mm);
+    }
+  }
+  if (threadIdx.x == 0) {
+    const uint64_t j = (uint64_t)tile << TBL_TILE_SHIFT;
+    for (int l = 1; l <= t.levels; ++l) {
+      const int gs = TBL_IDX_SHIFT + l;
+      if (gs > TBL_TILE_SHIFT && (j & ((1ull << gs) - 1)) == 0)
+        t.off[l][j >> gs] = t.tile_off[(uint64_t)(l - 1) * t.n_tiles + tile];
+      if (tile == t.n_tiles - 1) t.off[l][(t.dom + (1ull << gs) - 1) >> gs] = t.total[l];  // the sentinel
+    }
+  }
 }
 
 // fallback for rows with deg > HEAVY_DEG whose window is outside the table: one workgroup (4 waves)
@@ -796,7 +788,8 @@ __global__ void find_heavy_kernel(ExpandArgs a, uint64_t dom, int64_t* heavy_lis
 // points to it has moved on (a ctx only moves on after synchronising its own stream, so no kernel reads freed memory).
 struct TableOwner {
   RangeTable t{};
-  void* mem = nullptr;
+  void* mem = nullptr;   // flat array, index arrays
+  void* mem2 = nullptr;  // level lists
   int device = 0;
   int refs = 0;
 };
@@ -808,11 +801,12 @@ void table_unref(TableOwner* own) {  // g_table_mu held
   if (!own || --own->refs > 0) return;
   if (g_device_table[own->device] == own) g_device_table[own->device] = nullptr;
   if (own->mem) hipFree(own->mem);
+  if (own->mem2) hipFree(own->mem2);
   delete own;
 }
 
-// Largest j domain a table may cover.  12.8 B per j: at least 2^30 j (13.7 GB, as sized for a 2-hop MAG240M job) and
-// up to the whole uint32 axis (55 GB) when a quarter of the device's free memory allows it — a scale-30 RMAT job
+// Largest j domain a table may cover.  12.4 B per j: at least 2^30 j (13.3 GB, as sized for a 2-hop MAG240M job) and
+// up to the whole uint32 axis (53 GB) when a quarter of the device's free memory allows it — a scale-30 RMAT job
 // (windows up to ~3.2e9) then never leaves the table path; windows beyond it are hashed directly (same result).
 // GIGL_TABLE_MAX_J overrides (tests).
 uint64_t table_cap_j() {
@@ -831,7 +825,7 @@ uint64_t table_cap_j() {
 
 // make ctx->sampler_table a table that covers [0, want_dom)
 int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
-  constexpr uint64_t S0 = 1ull << TBL_S0_SHIFT;
+  constexpr uint64_t S0 = 1ull << TBL_TILE_SHIFT;
   constexpr uint64_t DOM_CAP = 1ull << 32;  // j is a uint32
   if (want_dom > DOM_CAP) want_dom = DOM_CAP;
   want_dom = (want_dom + S0 - 1) / S0 * S0;
@@ -856,44 +850,78 @@ int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
   uint64_t dom = want_dom + want_dom / 4;
   if (dom > DOM_CAP) dom = DOM_CAP;
   dom = dom / S0 * S0;
+  if (dom < S0) dom = S0;
+  const int L = TBL_MAX_LEVELS;
+  const uint32_t n_tiles = (uint32_t)(dom >> TBL_TILE_SHIFT);
+  // first allocation: flat | per-level index arrays | tile counts (build scratch) | level totals
+  auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t off_elems[TBL_MAX_LEVELS + 1] = {0}, off_at[TBL_MAX_LEVELS + 1] = {0};
+  size_t bytes = up((size_t)dom * 4);
+  for (int l = 1; l <= L; ++l) {
+    const int gs = TBL_IDX_SHIFT + l;
+    off_elems[l] = (size_t)((dom + (1ull << gs) - 1) >> gs) + 1;
+    off_at[l] = bytes;
+    bytes = up(bytes + off_elems[l] * 4);
+  }
+  const size_t cnt_at = bytes;
+  bytes = up(bytes + (size_t)L * n_tiles * 4);
+  const size_t total_at = bytes;
+  bytes += 256;
+  auto fail_build = [&](int32_t code, const char* what, hipError_t e) {
+    if (own->mem) hipFree(own->mem);
+    if (own->mem2) hipFree(own->mem2);
+    delete own;
+    return gigl_fail(ctx, code, "%s (hash threshold table over %llu j): %s", what, (unsigned long long)dom,
+                     hipGetErrorString(e));
+  };
+  hipError_t e = hipMalloc(&own->mem, bytes);
+  if (e != hipSuccess) {
+    own->mem = nullptr;
+    return fail_build(GIGL_E_OOM, "hipMalloc failed", e);
+  }
+  char* m0 = (char*)own->mem;
+  uint32_t* flat = (uint32_t*)m0;
+  uint32_t* cnt = (uint32_t*)(m0 + cnt_at);
+  uint32_t* total = (uint32_t*)(m0 + total_at);
+  hipLaunchKernelGGL(table_flat_kernel, dim3((unsigned)((dom + 255) / 256)), dim3(256), 0, ctx->stream, flat, dom);
+  hipLaunchKernelGGL(table_count_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, flat, cnt, n_tiles, L);
+  hipLaunchKernelGGL(table_scan_kernel, dim3((unsigned)L), dim3(1024), 0, ctx->stream, cnt, n_tiles, total);
+  uint32_t h_total[TBL_MAX_LEVELS + 1] = {0};
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(h_total, total, sizeof(h_total), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return fail_build(GIGL_E_HIP, "counting failed", e);
+  size_t lvl_at[TBL_MAX_LEVELS + 1] = {0}, bytes2 = 0;
+  for (int l = 1; l <= L; ++l) {
+    lvl_at[l] = bytes2;
+    bytes2 = up(bytes2 + (size_t)h_total[l] * 8 + 8);
+  }
+  e = hipMalloc(&own->mem2, bytes2);
+  if (e != hipSuccess) {
+    own->mem2 = nullptr;
+    return fail_build(GIGL_E_OOM, "hipMalloc of the level lists failed", e);
+  }
   RangeTable t{};
   t.dom = dom;
-  int64_t nb = (int64_t)(dom >> TBL_S0_SHIFT), total_blocks = 0;
-  int L = 0;
-  while (nb >= 1 && L < TBL_MAX_LEVELS) {
-    t.nblocks[L] = nb;
-    t.lvl_off[L] = total_blocks;
-    total_blocks += nb;
-    ++L;
-    nb >>= TBL_FAN_SHIFT;
-  }
   t.levels = L;
-  const size_t arr_bytes = (size_t)total_blocks * TBL_TOPK * 4;
-  const size_t total = 3 * arr_bytes;
-  if (hipMalloc(&own->mem, total ? total : 256) != hipSuccess) {
-    delete own;
-    return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the %zu-byte hash range table failed", total);
+  t.flat = flat;
+  TableBuild tbuild{};
+  tbuild.flat = flat;
+  tbuild.tile_off = cnt;
+  tbuild.total = total;
+  tbuild.n_tiles = n_tiles;
+  tbuild.levels = L;
+  tbuild.dom = dom;
+  for (int l = 1; l <= L; ++l) {
+    tbuild.lvl[l] = (uint2*)((char*)own->mem2 + lvl_at[l]);
+    tbuild.off[l] = (uint32_t*)(m0 + off_at[l]);
+    t.lvl[l] = tbuild.lvl[l];
+    t.off[l] = tbuild.off[l];
   }
-  uint32_t* khi = (uint32_t*)own->mem;
-  uint32_t* klo = (uint32_t*)((char*)own->mem + arr_bytes);
-  uint32_t* js = (uint32_t*)((char*)own->mem + 2 * arr_bytes);
-  t.khi = khi;
-  t.klo = klo;
-  t.js = js;
-  hipLaunchKernelGGL(table_l0_kernel, dim3((unsigned)((t.nblocks[0] + 3) / 4)), dim3(256), 0, ctx->stream, khi, klo,
-                     js, t.nblocks[0]);
-  for (int l = 1; l < L; ++l) {
-    const int64_t c = t.lvl_off[l - 1] * TBL_TOPK, q = t.lvl_off[l] * TBL_TOPK;
-    hipLaunchKernelGGL(table_up_kernel, dim3((unsigned)((t.nblocks[l] + 3) / 4)), dim3(256), 0, ctx->stream, khi + c,
-                       klo + c, js + c, khi + q, klo + q, js + q, t.nblocks[l]);
-  }
-  hipError_t berr = hipGetLastError();
-  if (berr == hipSuccess) berr = hipStreamSynchronize(ctx->stream);
-  if (berr != hipSuccess) {
-    hipFree(own->mem);
-    delete own;
-    return gigl_fail(ctx, GIGL_E_HIP, "building the hash range table failed: %s", hipGetErrorString(berr));
-  }
+  hipLaunchKernelGGL(table_fill_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, tbuild);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return fail_build(GIGL_E_HIP, "filling failed", e);
   own->t = t;
   own->refs = 1;  // this ctx
   // the registry points to the largest table; earlier ones live on until their ctxs let go
@@ -912,6 +940,11 @@ int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a_in, const RangeTable& tb, 
     if (bits >= 1 && bits <= 32) a.proxy_drop = 32 - bits;
   }
   int64_t blocks = (a.n_parents + 3) / 4;
+  static const int32_t flat_max = [] {  // (tuning knob: longest row that reads its hash window flat)
+    const char* e = getenv("GIGL_EXPAND_FLAT_MAX");
+    return e ? atoi(e) : 128;
+  }();
+  a.flat_max = flat_max;
   static const int64_t max_blocks = [] {  // (tuning knob: workgroups of the persistent expand grid)
     const char* e = getenv("GIGL_EXPAND_BLOCKS");
     const int64_t v = e ? atoll(e) : 0;
