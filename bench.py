@@ -50,7 +50,7 @@ MFMA_F32_PEAK_TF = 157.3  # same guide: dense fp32 matrix peak (v_mfma_f32_32x32
 
 # library timer id -> name prefixes of the device functions it brackets (as rocprofv3 prints them, scripts/pmc_summary.py)
 PMC_KERNELS = {
-    "expand": ["expand_kernel"],
+    "expand": ["plan_rows_kernel", "expand_rows_kernel"],
     "gather_mean": ["gather_mean_kernel"],
     "linear": ["linear_split_kernel", "linear_lds_kernel", "linear_mfma_kernel"],
     # (the one-call plan's two-hop union build, union.hip "LG2"; the generic build's kernels have other names)

@@ -261,8 +261,6 @@ struct Sel {
   int f, lane;
   int drop;           // FAST only: low proxy bits discarded (0 in production; tests raise it to force ties)
   uint32_t dmask;     // ~0 << drop
-  uint32_t flat_max;  // FAST only: rows up to this length read their window from the flat array whatever their level
-  float lam;
 
   static __device__ __forceinline__ key_t inf() { return (key_t)~(key_t)0; }
   __device__ __forceinline__ key_t mk(uint64_t ordered_hash) const {
@@ -273,8 +271,7 @@ struct Sel {
     key = tk = inf();
     idx = ti = 0xFFFFFFFFu;
   }
-  __device__ __forceinline__ void init(int f_, int lane_, int drop_ = 0, uint32_t flat_max_ = 0) {
-    flat_max = flat_max_;
+  __device__ __forceinline__ void init(int f_, int lane_, int drop_ = 0) {
     drop = drop_;
     dmask = drop_ >= 32 ? 0u : (0xFFFFFFFFu << drop_);
     reset_best();
@@ -283,7 +280,6 @@ struct Sel {
     selmask = 0;
     f = f_;
     lane = lane_;
-    lam = (float)f_ + 4.f * __builtin_sqrtf((float)f_) + 4.f;
   }
   __device__ __forceinline__ bool lt(key_t k1, uint32_t i1, key_t k2, uint32_t i2) const {
     if constexpr (FAST) return k1 < k2;
@@ -429,13 +425,11 @@ struct Sel {
   // survivors of one 64-candidate chunk appended to the scratch, order kept
   __device__ __forceinline__ void offer(uint32_t k, uint32_t i, bool pass, uint32_t& count, uint32_t* lk, uint32_t* li) {
     const unsigned long long m = __ballot(pass);
-    if (pass) {
-      const uint32_t pos =
-          count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (pos < 64u) {
-        lk[pos] = k;
-        li[pos] = i;
-      }
+    const uint32_t pos =
+        count + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (pass && pos < 64u) {
+      lk[pos] = k;
+      li[pos] = i;
     }
     count += (uint32_t)__popcll(m);
   }
@@ -444,76 +438,58 @@ struct Sel {
   template <int SRC>
   __device__ __forceinline__ bool filter_positions(const uint32_t* flat, uint32_t n, uint32_t T, uint32_t base,
                                                    uint32_t* lk, uint32_t* li) {
-    const bool all = n <= 64u;
+    const bool all = T == 0xFFFFFFFFu;  // (rows of <= 64 positions)
     uint32_t count = 0;
     const uint32_t nchunks = (n + 63u) >> 6;
-    const uint32_t* src = flat + base;  // position i -> j = base + i (inside the table: the caller checked)
+    const uint32_t* src = flat + base;  // position i -> j = base + i (inside the table: the planner checked)
     for (uint32_t c = 0; c < nchunks; c += 4) {
       uint32_t kk[4];
 #pragma unroll
       for (uint32_t t = 0; t < 4; ++t) {
         const uint32_t i = (c + t) * 64u + (uint32_t)lane + 1u;
         kk[t] = 0xFFFFFFFFu;
-        if (i <= n) {
-          if constexpr (SRC == SRC_FLAT) kk[t] = src[i] & dmask;
-          else kk[t] = (uint32_t)mk(xxh64_i32_ordered(i + base));
+        // (a chunk's last lanes may read up to 63 proxies past the window: inside the table's allocation, dropped below)
+        if constexpr (SRC == SRC_FLAT) {
+          if (c + t < nchunks) kk[t] = src[i];
+        } else {
+          kk[t] = (uint32_t)(xxh64_i32_ordered(i + base) >> 32);
         }
       }
 #pragma unroll
       for (uint32_t t = 0; t < 4; ++t) {
         if (c + t >= nchunks) break;
         const uint32_t i = (c + t) * 64u + (uint32_t)lane + 1u;
-        offer(kk[t], i, i <= n && (all || kk[t] < T), count, lk, li);
+        const uint32_t k = kk[t] & dmask;
+        offer(k, i, i <= n && (all || k < T), count, lk, li);
       }
     }
     return finish(count, lk, li);
   }
-  // FAST only.  The window's members of level l (T <= 2^(32-l)), between two index entries, filtered by window and T.
-  __device__ __forceinline__ bool filter_level(const RangeTable& tb, int l, uint32_t n, uint32_t T, uint32_t base,
+  // FAST only.  The window's members of its level (T <= 2^(32-l)) — `cnt` pairs from `ent`: the run between two index
+  // entries — filtered by window and T.
+  __device__ __forceinline__ bool filter_level(const uint2* ent, uint32_t cnt, uint32_t n, uint32_t T, uint32_t base,
                                                uint32_t* lk, uint32_t* li) {
-    const int gs = TBL_IDX_SHIFT + l;
-    const uint32_t* off = tb.off[l];
-    const uint2* ent = tb.lvl[l];
-    const uint32_t start = off[(base + 1u) >> gs], end = off[((base + n) >> gs) + 1u];
-    if (end - start > 256u) return false;  // (a row longer than the deepest level is made for)
     uint32_t count = 0;
-    for (uint32_t e0 = start; e0 < end; e0 += 128u) {  // two chunks' loads in flight
+    for (uint32_t e0 = 0; e0 < cnt; e0 += 128u) {  // two chunks' loads in flight
       const uint32_t ea = e0 + (uint32_t)lane, eb = ea + 64u;
       uint2 xa = make_uint2(0u, 0xFFFFFFFFu), xb = xa;
-      if (ea < end) xa = ent[ea];
-      if (eb < end) xb = ent[eb];
+      if (ea < cnt) xa = ent[ea];
+      if (eb < cnt) xb = ent[eb];
       const uint32_t ia = xa.x - base, ib = xb.x - base;
-      offer(xa.y & dmask, ia, ea < end && (uint32_t)(ia - 1u) < n && xa.y < T, count, lk, li);
-      if (e0 + 64u < end) offer(xb.y & dmask, ib, eb < end && (uint32_t)(ib - 1u) < n && xb.y < T, count, lk, li);
+      offer(xa.y & dmask, ia, (uint32_t)(ia - 1u) < n && xa.y < T, count, lk, li);
+      if (e0 + 64u < cnt) offer(xb.y & dmask, ib, (uint32_t)(ib - 1u) < n && xb.y < T, count, lk, li);
     }
     return finish(count, lk, li);
   }
-  // the whole row: window of positions [1, deg] with hash offset `base`
-  __device__ __forceinline__ void select(const RangeTable& tb, int64_t deg, uint32_t base, bool in_table,
-                                         uint32_t* lk = nullptr, uint32_t* li = nullptr) {
-    // (any T is a valid filter: the approximate reciprocal is fine; uniform, so it moves to the scalar side)
-    const uint32_t n = (uint32_t)deg;
-    const uint32_t T = n <= 64u ? 0xFFFFFFFFu
-                                : (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)fminf(
-                                      lam * 4294967296.f * __builtin_amdgcn_rcpf((float)n), 4294967040.f));
+  // serial path (exact keys; rows the filter could not settle; fanouts too large for the filter): the candidates
+  // under four times the row's threshold T, best f kept by insertion; in the (practically impossible) case that fewer
+  // than f lie below it, the whole row.  Windows outside the table hash every position.
+  __device__ __forceinline__ void serial(const RangeTable& tb, uint32_t n, uint32_t base, uint32_t T, bool in_table) {
+    reset_best();
     if (!in_table) {
-      if constexpr (FAST) {
-        if (lk && lam <= 56.f && deg <= 65536 && filter_positions<SRC_HASH>(nullptr, n, T, base, lk, li)) return;
-      }
-      scan_row(nullptr, deg, base);
+      scan_row(nullptr, (int64_t)n, base);
       return;
     }
-    if constexpr (FAST) {
-      if (lk && lam <= 56.f) {
-        const int l = min((int)__builtin_clz(T - 1u), tb.levels);  // deepest level with 2^(32-l) >= T  (T >= 2)
-        const bool ok = (l == 0 || n <= flat_max) ? filter_positions<SRC_FLAT>(tb.flat, n, T, base, lk, li)
-                                                  : filter_level(tb, l, n, T, base, lk, li);
-        if (ok) return;
-      }
-    }
-    // serial path (exact keys; rows the filter could not settle; fanouts too large for the filter): the candidates
-    // under four times the threshold, best f kept by insertion; in the (practically impossible) case that fewer than f
-    // lie below it, the whole row
     const uint32_t T4 = T >= (1u << 30) ? 0xFFFFFFFFu : 4u * T;
     const int l4 = T4 == 0xFFFFFFFFu ? 0 : min((int)__builtin_clz(T4 - 1u), tb.levels);
     if (l4 > 0) {
@@ -521,90 +497,172 @@ struct Sel {
       reset_best();
     }
     if constexpr (FAST) {
-      scan_row(tb.flat, deg, base);
+      scan_row(tb.flat, (int64_t)n, base);
       if (readlane32(idx, f - 1) == 0xFFFFFFFFu) tie = true;  // (a proxy of all ones never enters the list)
     } else {
-      scan_row(nullptr, deg, base);
+      scan_row(nullptr, (int64_t)n, base);
     }
   }
 };
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void expand_kernel(ExpandArgs a, RangeTable tb) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_lk[4][68], s_li[4][64];  // per-wave survivor scratch of the filter selections
-  const int lane = threadIdx.x & 63;
-  // the parent slot, its row and every window bound are the same for all lanes: say so (readfirstlane), and the
-  // per-row control flow below runs on the scalar unit with scalar loads instead of 64-bit vector arithmetic
-  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t waves_total = gridDim.x * 4u;
-  const uint32_t n_parents = (uint32_t)a.n_parents;  // < 2^31 (checked by the callers)
-  const int f = a.f;
-  for (uint32_t p = blockIdx.x * 4u + (uint32_t)wave_in_block; p < n_parents; p += waves_total) {
-    uint32_t v, ksum;
-    parent_of(a, p, v, ksum);
-    uint32_t* out = a.out_nbr + (int64_t)p * f;
-    if (v == GIGL_INVALID || (int64_t)v >= a.n_nodes) {
-      if (lane < f) out[lane] = GIGL_INVALID;
-      if (lane == 0) a.out_cnt[p] = 0;
-      continue;
-    }
-    const int64_t s = a.rowptr[v];
-    const int64_t deg = a.rowptr[v + 1] - s;
-    const uint32_t* row = a.col + s;
-    if (deg <= f) {  // copy-through: the row is already the canonical ascending set
-      if (a.multi) {
-        const int nw = emit_sorted_distinct(row, lane < deg ? (uint32_t)lane + 1u : 0xFFFFFFFFu, f, lane, out);
-        if (lane == 0) a.out_cnt[p] = nw;
-        continue;
-      }
-      if (lane < f) out[lane] = lane < deg ? row[lane] : GIGL_INVALID;
-      if (lane == 0) a.out_cnt[p] = (int32_t)deg;
-      continue;
-    }
-    const uint32_t base = ksum + (uint32_t)a.hash_add;  // int32 wrap == uint32 wrap
-    const bool in_table = (uint64_t)base + (uint64_t)deg < tb.dom;  // also excludes 2^32 wrap-around
-    if (!in_table && deg > HEAVY_DEG) continue;  // left to expand_heavy_kernel (workgroup per parent)
-    uint32_t sel_idx;
-    {
-      Sel<true> fast;
-      fast.init(f, lane, a.proxy_drop, a.flat_max);
-      fast.select(tb, deg, base, in_table, s_lk[wave_in_block], s_li[wave_in_block]);
-      sel_idx = fast.idx;
-      if (fast.tie) {  // a 32-bit proxy tie touched the result (about once per 10^7 rows): redo exactly
-        Sel<false> exact;
-        exact.init(f, lane);
-        exact.select(tb, deg, base, in_table);
-        sel_idx = exact.idx;
-      } else if (fast.ordered) {  // selected lanes hold the positions in ascending order
-        const unsigned long long m = fast.selmask;
-        const bool sel = (m >> lane) & 1ull;
-        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        const uint32_t val = sel ? row[sel_idx - 1] : GIGL_INVALID;
-        if (!a.multi) {
-          if (sel) out[slot] = val;
-          if (lane == 0) a.out_cnt[p] = f;
-          continue;
-        }
-        // ascending positions of an ascending row: a repeated id sits right after its first copy
-        uint32_t* lk = s_lk[wave_in_block];
-        if (sel) lk[slot] = val;
-        wave_lds_sync();
-        const bool keep = sel && (slot == 0 || lk[slot - 1] != val);
-        wave_lds_sync();
-        const unsigned long long km = __ballot(keep);
-        if (lane < f) out[lane] = GIGL_INVALID;
-        if (keep) out[__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u))] = val;
-        if (lane == 0) a.out_cnt[p] = (int32_t)__popcll(km);
-        continue;
-      }
-    }
-    if (a.multi) {
-      const int nw = emit_sorted_distinct(row, sel_idx, f, lane, out);
-      if (lane == 0) a.out_cnt[p] = nw;
-      continue;
-    }
-    emit_sorted(row, sel_idx, f, lane, out);
-    if (lane == 0) a.out_cnt[p] = f;
+// ------------------------------------------------------------------------------------------
+// One hop = two launches.
+//   plan_rows_kernel    one THREAD per parent slot: parent id and K (the path sums), the CSC row, the hash window and
+//                       where its candidates are (threshold T, level, the run of pairs between two index entries):
+//                       a chain of three dependent loads that a wave-per-row kernel would sit through serially, here
+//                       issued for 64 rows at once; 32-byte descriptor per slot.
+//   expand_rows_kernel  one WAVE per parent slot, driven by the descriptor: candidates -> survivors -> f best ->
+//                       neighbour ids; what is left of the dependent chain is descriptor -> pairs -> ids.
+// ------------------------------------------------------------------------------------------
+enum { ROW_INVALID = 0, ROW_COPY = 1, ROW_FLAT = 2, ROW_LEVEL = 3, ROW_HASH = 4, ROW_SERIAL = 5, ROW_SERIAL_HASH = 6,
+       ROW_SKIP = 7 };
+
+struct __attribute__((aligned(32))) RowDesc {
+  int64_t s;         // first position of the row in col
+  uint32_t n;        // row length
+  uint32_t base;     // hash offset of the window: position i -> j = base + i
+  uint32_t T;        // proxy threshold (2^32 - 1: every position is a candidate)
+  uint32_t kind_cnt; // ROW_* in bits 0..2, pair count of a ROW_LEVEL run above
+  const void* ptr;   // ROW_LEVEL: first pair of the run; ROW_FLAT: the flat array
+};
+
+__device__ __forceinline__ float filter_lambda(int f) { return (float)f + 4.f * __builtin_sqrtf((float)f) + 4.f; }
+
+__global__ __launch_bounds__(256) void plan_rows_kernel(ExpandArgs a, RangeTable tb, RowDesc* __restrict__ desc,
+                                                        int64_t* heavy_list, int32_t* heavy_count) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= (uint32_t)a.n_parents) return;
+  RowDesc d{};
+  uint32_t v, ksum;
+  parent_of(a, p, v, ksum);
+  if (v == GIGL_INVALID || (int64_t)v >= a.n_nodes) {
+    d.kind_cnt = ROW_INVALID;
+    desc[p] = d;
+    return;
   }
+  d.s = a.rowptr[v];
+  const int64_t deg = a.rowptr[v + 1] - d.s;
+  d.n = (uint32_t)deg;
+  d.base = ksum + (uint32_t)a.hash_add;  // int32 wrap == uint32 wrap
+  if (deg <= a.f) {
+    d.kind_cnt = ROW_COPY;
+    desc[p] = d;
+    return;
+  }
+  const bool in_table = (uint64_t)d.base + (uint64_t)deg < tb.dom;  // also excludes 2^32 wrap-around
+  const float lam = filter_lambda(a.f);
+  // (any T is a valid filter: the approximate reciprocal is fine)
+  d.T = d.n <= 64u ? 0xFFFFFFFFu
+                   : (uint32_t)fminf(lam * 4294967296.f * __builtin_amdgcn_rcpf((float)d.n), 4294967040.f);
+  uint32_t kind;
+  if (!in_table) {
+    if (deg > HEAVY_DEG) {  // left to expand_heavy_kernel (workgroup per parent)
+      kind = ROW_SKIP;
+      if (heavy_list) heavy_list[atomicAdd(heavy_count, 1)] = (int64_t)p;
+    } else {
+      kind = lam <= 56.f ? ROW_HASH : ROW_SERIAL_HASH;
+    }
+  } else if (lam > 56.f) {
+    kind = ROW_SERIAL;
+  } else {
+    const int l = min((int)__builtin_clz(d.T - 1u), tb.levels);  // deepest level with 2^(32-l) >= T  (T >= 2)
+    if (l == 0 || d.n <= (uint32_t)a.flat_max) {
+      kind = ROW_FLAT;
+      d.ptr = tb.flat;
+    } else {
+      const int gs = TBL_IDX_SHIFT + l;
+      const uint32_t* off = tb.off[l];
+      const uint32_t start = off[(d.base + 1u) >> gs], end = off[((d.base + d.n) >> gs) + 1u];
+      if (end - start > 256u) {  // (a row longer than the deepest level is made for)
+        kind = ROW_SERIAL;
+      } else {
+        kind = ROW_LEVEL | ((end - start) << 3);
+        d.ptr = tb.lvl[l] + start;
+      }
+    }
+  }
+  d.kind_cnt = kind;
+  desc[p] = d;
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void expand_rows_kernel(
+    ExpandArgs a, RangeTable tb, const RowDesc* __restrict__ desc) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_lk[4][68], s_li[4][64];  // per-wave survivor scratch
+  const int lane = threadIdx.x & 63;
+  // the parent slot and everything in its descriptor are the same for all lanes: say so (readfirstlane), and the
+  // per-row control flow below runs on the scalar unit with scalar loads
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t p = blockIdx.x * 4u + (uint32_t)wave_in_block;
+  if (p >= (uint32_t)a.n_parents) return;
+  const int f = a.f;
+  const RowDesc d = desc[p];
+  const uint32_t kind = d.kind_cnt & 7u;
+  uint32_t* out = a.out_nbr + (int64_t)p * f;
+  if (kind == ROW_SKIP) return;
+  if (kind == ROW_INVALID) {
+    if (lane < f) out[lane] = GIGL_INVALID;
+    if (lane == 0) a.out_cnt[p] = 0;
+    return;
+  }
+  const uint32_t* row = a.col + d.s;
+  const uint32_t n = d.n, base = d.base, T = d.T;
+  if (kind == ROW_COPY) {  // copy-through: the row is already the canonical ascending set
+    if (a.multi) {
+      const int nw = emit_sorted_distinct(row, (uint32_t)lane < n ? (uint32_t)lane + 1u : 0xFFFFFFFFu, f, lane, out);
+      if (lane == 0) a.out_cnt[p] = nw;
+      return;
+    }
+    if (lane < f) out[lane] = (uint32_t)lane < n ? row[lane] : GIGL_INVALID;
+    if (lane == 0) a.out_cnt[p] = (int32_t)n;
+    return;
+  }
+  uint32_t* lk = s_lk[wave_in_block];
+  uint32_t* li = s_li[wave_in_block];
+  const bool in_table = kind != ROW_HASH && kind != ROW_SERIAL_HASH;
+  uint32_t sel_idx;
+  {
+    Sel<true> fast;
+    fast.init(f, lane, a.proxy_drop);
+    bool done = false;
+    if (kind == ROW_LEVEL) done = fast.filter_level((const uint2*)d.ptr, d.kind_cnt >> 3, n, T, base, lk, li);
+    else if (kind == ROW_FLAT) done = fast.template filter_positions<SRC_FLAT>((const uint32_t*)d.ptr, n, T, base, lk, li);
+    else if (kind == ROW_HASH) done = fast.template filter_positions<SRC_HASH>(nullptr, n, T, base, lk, li);
+    if (!done) fast.serial(tb, n, base, T, in_table);
+    sel_idx = fast.idx;
+    if (fast.tie) {  // a 32-bit proxy tie touched the result (about once per 10^7 rows): redo exactly
+      Sel<false> exact;
+      exact.init(f, lane);
+      exact.serial(tb, n, base, T, in_table);
+      sel_idx = exact.idx;
+    } else if (fast.ordered) {  // selected lanes hold the positions in ascending order
+      const unsigned long long m = fast.selmask;
+      const bool sel = (m >> lane) & 1ull;
+      const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      const uint32_t val = sel ? row[sel_idx - 1] : GIGL_INVALID;
+      if (!a.multi) {
+        if (sel) out[slot] = val;
+        if (lane == 0) a.out_cnt[p] = f;
+        return;
+      }
+      // ascending positions of an ascending row: a repeated id sits right after its first copy
+      if (sel) lk[slot] = val;
+      wave_lds_sync();
+      const bool keep = sel && (slot == 0 || lk[slot - 1] != val);
+      wave_lds_sync();
+      const unsigned long long km = __ballot(keep);
+      if (lane < f) out[lane] = GIGL_INVALID;
+      if (keep) out[__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u))] = val;
+      if (lane == 0) a.out_cnt[p] = (int32_t)__popcll(km);
+      return;
+    }
+  }
+  if (a.multi) {
+    const int nw = emit_sorted_distinct(row, sel_idx, f, lane, out);
+    if (lane == 0) a.out_cnt[p] = nw;
+    return;
+  }
+  emit_sorted(row, sel_idx, f, lane, out);
+  if (lane == 0) a.out_cnt[p] = f;
 }
 
 // ---- table construction.  A workgroup owns a tile of 1024 consecutive j; wave w the 256 j from tile*1024 + w*256,
@@ -765,23 +823,6 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(ExpandArgs a, const i
   }
 }
 
-// compacts the parent slots with degree > HEAVY_DEG whose hash window is NOT covered by the table
-// (only launched when the host cannot prove that every window is covered)
-__global__ void find_heavy_kernel(ExpandArgs a, uint64_t dom, int64_t* heavy_list, int32_t* heavy_count) {
-  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= a.n_parents) return;
-  uint32_t v, ksum;
-  parent_of(a, p, v, ksum);
-  if (v == GIGL_INVALID || (int64_t)v >= a.n_nodes) return;
-  int64_t deg = a.rowptr[v + 1] - a.rowptr[v];
-  const uint32_t base = ksum + (uint32_t)a.hash_add;
-  const bool in_table = (uint64_t)base + (uint64_t)deg < dom;
-  if (deg > HEAVY_DEG && deg > a.f && !in_table) {
-    int32_t at = atomicAdd(heavy_count, 1);
-    heavy_list[at] = p;
-  }
-}
-
 // The table is a function of the integer axis alone (not of the graph, the roots or the seed), so ONE table per device
 // serves every ctx of the process: ctxs hold a reference to the device's current table; a request beyond its domain
 // builds a larger one, which replaces it in the registry, and the old one is freed when the last ctx that still
@@ -932,34 +973,25 @@ int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
 
 // one hop of parity-mode expansion.  `covered` = the host proved every window lies inside the table.
 int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a_in, const RangeTable& tb, bool covered,
-                   int64_t* heavy_list, int32_t* heavy_count) {
+                   int64_t* heavy_list, int32_t* heavy_count, RowDesc* desc) {
   ExpandArgs a = a_in;
   a.proxy_drop = 0;
   if (const char* e = getenv("GIGL_SAMPLER_PROXY_BITS")) {  // test knob: fewer proxy bits -> forced ties
     int bits = atoi(e);
     if (bits >= 1 && bits <= 32) a.proxy_drop = 32 - bits;
   }
-  int64_t blocks = (a.n_parents + 3) / 4;
   static const int32_t flat_max = [] {  // (tuning knob: longest row that reads its hash window flat)
     const char* e = getenv("GIGL_EXPAND_FLAT_MAX");
     return e ? atoi(e) : 128;
   }();
   a.flat_max = flat_max;
-  static const int64_t max_blocks = [] {  // (tuning knob: workgroups of the persistent expand grid)
-    const char* e = getenv("GIGL_EXPAND_BLOCKS");
-    const int64_t v = e ? atoll(e) : 0;
-    return v > 0 ? v : (int64_t)256 * 32;
-  }();
-  if (blocks > max_blocks) blocks = max_blocks;
-  if (!covered) {
-    gigl_prof_scope ps(ctx, GIGL_K_FIND_HEAVY);
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(heavy_count, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(find_heavy_kernel, dim3((unsigned)((a.n_parents + 255) / 256)), dim3(256), 0,
-                       ctx->stream, a, tb.dom, heavy_list, heavy_count);
-  }
+  if (!covered) GIGL_HIP_CHECK(ctx, hipMemsetAsync(heavy_count, 0, 4, ctx->stream));
   {
     gigl_prof_scope ps(ctx, GIGL_K_EXPAND);
-    hipLaunchKernelGGL(expand_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a, tb);
+    hipLaunchKernelGGL(plan_rows_kernel, dim3((unsigned)((a.n_parents + 255) / 256)), dim3(256), 0, ctx->stream, a, tb,
+                       desc, covered ? nullptr : heavy_list, heavy_count);
+    hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((a.n_parents + 3) / 4)), dim3(256), 0, ctx->stream, a, tb,
+                       (const RowDesc*)desc);
   }
   if (!covered) {
     gigl_prof_scope ps(ctx, GIGL_K_EXPAND_HEAVY);
@@ -1116,20 +1148,25 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
     covered = bound != ~0ULL && bound < tb.dom;
   }
 
-  // scratch (only needed when some window may fall outside the table): heavy list + counter
+  // scratch: one row descriptor per parent slot of the widest hop; heavy list + counter when some window may fall
+  // outside the table
   int64_t* heavy_list = nullptr;
   int32_t* heavy_count = nullptr;
-  if (mode == GIGL_MODE_SPARK_HASH && !covered) {
+  RowDesc* desc = nullptr;
+  if (mode == GIGL_MODE_SPARK_HASH) {
     int64_t max_parents = b, q = b;
     for (int k = 0; k + 1 < hops; ++k) {
       q *= fanouts[k];
       if (q > max_parents) max_parents = q;
     }
-    rc = gigl_arena_reset(ctx, max_parents * 8 + 256 * 4);
+    rc = gigl_arena_reset(ctx, max_parents * (int64_t)sizeof(RowDesc) + max_parents * 8 + 1024);
     if (rc != GIGL_OK) return rc;
-    heavy_list = (int64_t*)gigl_arena_alloc(ctx, max_parents * 8);
-    heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
-    if (!heavy_list || !heavy_count) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+    desc = (RowDesc*)gigl_arena_alloc(ctx, max_parents * (int64_t)sizeof(RowDesc));
+    if (!covered) {
+      heavy_list = (int64_t*)gigl_arena_alloc(ctx, max_parents * 8);
+      heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
+    }
+    if (!desc || (!covered && (!heavy_list || !heavy_count))) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   }
 
   ExpandArgs a{};
@@ -1157,7 +1194,7 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
         hipLaunchKernelGGL(expand_replace_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
     } else {
-      rc = run_expand(ctx, a, tb, covered, heavy_list, heavy_count);
+      rc = run_expand(ctx, a, tb, covered, heavy_list, heavy_count, desc);
       if (rc != GIGL_OK) return rc;
     }
     a.anc[k] = out->nbr[k];
@@ -1185,13 +1222,14 @@ int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* n
   const bool covered = bounded && bound < tb.dom;
   int64_t* heavy_list = nullptr;
   int32_t* heavy_count = nullptr;
+  rc = gigl_arena_reset(ctx, m * (int64_t)sizeof(RowDesc) + m * 8 + 1024);
+  if (rc != GIGL_OK) return rc;
+  RowDesc* desc = (RowDesc*)gigl_arena_alloc(ctx, m * (int64_t)sizeof(RowDesc));
   if (!covered) {
-    rc = gigl_arena_reset(ctx, m * 8 + 256 * 4);
-    if (rc != GIGL_OK) return rc;
     heavy_list = (int64_t*)gigl_arena_alloc(ctx, m * 8);
     heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
-    if (!heavy_list || !heavy_count) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   }
+  if (!desc || (!covered && (!heavy_list || !heavy_count))) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   ExpandArgs a{};
   a.rowptr = shard->rowptr;
   a.col = shard->col;
@@ -1207,7 +1245,7 @@ int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* n
   a.ex_nodes = nodes;
   a.ex_ksum = ksums;
   a.row_div = (uint32_t)world;
-  return run_expand(ctx, a, tb, covered, heavy_list, heavy_count);
+  return run_expand(ctx, a, tb, covered, heavy_list, heavy_count, desc);
 }
 
 int32_t gigl_sample_positives(gigl_ctx* ctx, gigl_graph* g_out, const uint32_t* roots, int32_t b,
@@ -1229,11 +1267,12 @@ int32_t gigl_sample_out_neighbors(gigl_ctx* ctx, gigl_graph* g_out, const uint32
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "num positives %d outside [1,%d]", f, GIGL_MAX_FANOUT);
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (b == 0) return GIGL_OK;
-  int32_t rc = gigl_arena_reset(ctx, (int64_t)b * 8 + 256 * 4);
+  int32_t rc = gigl_arena_reset(ctx, (int64_t)b * ((int64_t)sizeof(RowDesc) + 8) + 1024);
   if (rc != GIGL_OK) return rc;
+  RowDesc* desc = (RowDesc*)gigl_arena_alloc(ctx, (int64_t)b * (int64_t)sizeof(RowDesc));
   int64_t* heavy_list = (int64_t*)gigl_arena_alloc(ctx, (int64_t)b * 8);
   int32_t* heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
-  if (!heavy_list || !heavy_count) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  if (!desc || !heavy_list || !heavy_count) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   ExpandArgs a{};
   a.rowptr = g_out->rowptr;
   a.col = g_out->col;
@@ -1252,7 +1291,7 @@ int32_t gigl_sample_out_neighbors(gigl_ctx* ctx, gigl_graph* g_out, const uint32
   rc = ensure_table(ctx, bound == ~0ULL ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));
   if (rc != GIGL_OK) return rc;
   const RangeTable tb = ((TableOwner*)ctx->sampler_table)->t;
-  return run_expand(ctx, a, tb, bound != ~0ULL && bound < tb.dom, heavy_list, heavy_count);
+  return run_expand(ctx, a, tb, bound != ~0ULL && bound < tb.dom, heavy_list, heavy_count, desc);
 }
 
 }  // extern "C"
