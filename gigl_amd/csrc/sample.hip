@@ -388,7 +388,7 @@ struct Sel {
   // the row's threshold) sit in the wave's LDS scratch lk (proxies) / li (positions), in ascending position order.
   // Every survivor finds its rank among them by counting (keys read back four at a time as LDS broadcasts); the f
   // best of the window are the f best survivors — every non-survivor has a larger proxy — provided there are at
-  // least f of them and no two survivors share a proxy (-> tie, redone exactly).  Too few / too many survivors
+  // least f of them and no proxy tie straddles the f-th place (-> tie, redone exactly).  Too few / too many survivors
   // (about 1 row in 10^3) -> false, the caller runs the serial path.  On success `ordered` is set: the lanes of
   // `selmask` hold the selected positions in ascending order, so the caller's output slot is a popcount.
   __device__ __forceinline__ bool finish(uint32_t count, uint32_t* lk, uint32_t* li) {
@@ -396,28 +396,26 @@ struct Sel {
       wave_lds_sync();
       return false;
     }
-    if (lane < 3) lk[count + (uint32_t)lane] = 0xFFFFFFFFu;  // padding of the last 4-wide read
+    if (lane < 7) lk[count + (uint32_t)lane] = 0xFFFFFFFFu;  // padding of the last 8-wide read
     wave_lds_sync();
     const bool valid = (uint32_t)lane < count;
     const uint32_t k = valid ? lk[lane] : 0xFFFFFFFFu;
     const uint32_t i = valid ? li[lane] : 0xFFFFFFFFu;
     uint32_t rank = 0;  // survivors with a strictly smaller proxy
-    for (uint32_t j = 0; j < count; j += 4) {
-      const uint4 q = *(const uint4*)(lk + j);  // same address in every lane: one broadcast read
+    for (uint32_t j = 0; j < count; j += 8) {
+      const uint4 q = *(const uint4*)(lk + j), r = *(const uint4*)(lk + j + 4);  // same address in every lane: broadcasts
       rank += (q.x < k ? 1u : 0u) + (q.y < k ? 1u : 0u) + (q.z < k ? 1u : 0u) + (q.w < k ? 1u : 0u);
+      rank += (r.x < k ? 1u : 0u) + (r.y < k ? 1u : 0u) + (r.z < k ? 1u : 0u) + (r.w < k ? 1u : 0u);
     }
-    // two survivors share a proxy <=> they share a rank: every survivor writes its lane under its rank and reads
-    // it back (the ranks of distinct proxies are distinct)
-    wave_lds_sync();
-    if (valid) lk[rank] = (uint32_t)lane;
-    wave_lds_sync();
-    const bool clash = valid && lk[rank] != (uint32_t)lane;
-    wave_lds_sync();
-    if (__ballot(clash)) {
+    wave_lds_sync();  // (the scratch is free for the next row)
+    // Survivors that share a proxy share a rank.  A group of equals that lies wholly inside or wholly outside the best
+    // f leaves exactly f lanes with rank < f, and the selected SET is the exact one either way; a group that
+    // straddles the boundary — the only tie that matters — puts more than f lanes below f.
+    selmask = __ballot(valid && rank < (uint32_t)f);
+    if (__popcll(selmask) != f) {
       tie = true;
       return true;
     }
-    selmask = __ballot(valid && rank < (uint32_t)f);
     idx = i;
     ordered = true;
     return true;
@@ -531,8 +529,13 @@ __device__ __forceinline__ float filter_lambda(int f) { return (float)f + 4.f * 
 __global__ __launch_bounds__(256) void plan_rows_kernel(ExpandArgs a, RangeTable tb, RowDesc* __restrict__ desc,
                                                         int64_t* heavy_list, int32_t* heavy_count) {
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  if (p >= (uint32_t)a.n_parents) return;
+  if (p > (uint32_t)a.n_parents) return;
   RowDesc d{};
+  if (p == (uint32_t)a.n_parents) {  // the slot after the last: the partner of an odd last row
+    d.kind_cnt = ROW_SKIP;
+    desc[p] = d;
+    return;
+  }
   uint32_t v, ksum;
   parent_of(a, p, v, ksum);
   if (v == GIGL_INVALID || (int64_t)v >= a.n_nodes) {
@@ -585,84 +588,178 @@ __global__ __launch_bounds__(256) void plan_rows_kernel(ExpandArgs a, RangeTable
   desc[p] = d;
 }
 
+// candidates of one row fetched ahead of their use: up to two 64-wide chunks of (proxy, j)
+struct Cand {
+  uint32_t k0, j0, k1, j1;
+  bool ahead;  // (wave-uniform) all of the row's candidates are here
+};
+
+__device__ __forceinline__ Cand fetch_candidates(const RowDesc& d, int lane) {
+  Cand c;
+  c.k0 = c.k1 = 0xFFFFFFFFu;
+  c.j0 = c.j1 = d.base;  // position 0: never inside a window
+  c.ahead = false;
+  const uint32_t kind = d.kind_cnt & 7u, cnt = d.kind_cnt >> 3;
+  if (kind == ROW_LEVEL && cnt <= 128u) {
+    const uint2* ent = (const uint2*)d.ptr;
+    if ((uint32_t)lane < cnt) {
+      const uint2 x = ent[lane];
+      c.j0 = x.x;
+      c.k0 = x.y;
+    }
+    if ((uint32_t)lane + 64u < cnt) {
+      const uint2 x = ent[lane + 64];
+      c.j1 = x.x;
+      c.k1 = x.y;
+    }
+    c.ahead = true;
+  } else if (kind == ROW_FLAT && d.n <= 128u) {
+    const uint32_t* src = (const uint32_t*)d.ptr + d.base;
+    c.j0 = d.base + (uint32_t)lane + 1u;
+    c.k0 = src[lane + 1];  // (the last lanes may read past the window: inside the table's allocation, dropped later)
+    if (d.n > 64u) {
+      c.j1 = c.j0 + 64u;
+      c.k1 = src[lane + 65];
+    }
+    c.ahead = true;
+  }
+  return c;
+}
+
+// the filter selection over candidates fetched ahead; false: the row goes to the general path
+__device__ __forceinline__ bool select_ahead(Sel<true>& sel, const RowDesc& d, const Cand& c, uint32_t* lk, uint32_t* li) {
+  const uint32_t n = d.n, T = d.T, base = d.base;
+  const bool all = T == 0xFFFFFFFFu;
+  uint32_t count = 0;
+  const uint32_t i0 = c.j0 - base, i1 = c.j1 - base;
+  sel.offer(c.k0 & sel.dmask, i0, (uint32_t)(i0 - 1u) < n && (all || c.k0 < T), count, lk, li);
+  if ((d.kind_cnt & 7u) == ROW_LEVEL ? (d.kind_cnt >> 3) > 64u : n > 64u)
+    sel.offer(c.k1 & sel.dmask, i1, (uint32_t)(i1 - 1u) < n && (all || c.k1 < T), count, lk, li);
+  return sel.finish(count, lk, li);
+}
+
+// Two parent slots per wave: both descriptors, then both rows' candidates, are requested before anything is consumed,
+// and the first row's neighbour ids are in flight while the second row is ranked — the kernel is bound by the latency
+// of its dependent loads (SQ counters: waves wait 3/4 of their cycles at the 8 waves a SIMD holds), so two rows per
+// wave is twice the loads in flight.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void expand_rows_kernel(
     ExpandArgs a, RangeTable tb, const RowDesc* __restrict__ desc) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_lk[4][68], s_li[4][64];  // per-wave survivor scratch
+  __shared__ __attribute__((aligned(16))) uint32_t s_lk[4][72], s_li[4][64];  // per-wave survivor scratch
   const int lane = threadIdx.x & 63;
-  // the parent slot and everything in its descriptor are the same for all lanes: say so (readfirstlane), and the
+  // the parent slots and everything in their descriptors are the same for all lanes: say so (readfirstlane), and the
   // per-row control flow below runs on the scalar unit with scalar loads
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t p = blockIdx.x * 4u + (uint32_t)wave_in_block;
-  if (p >= (uint32_t)a.n_parents) return;
+  const uint32_t p0 = (blockIdx.x * 4u + (uint32_t)wave_in_block) * 2u;
+  if (p0 >= (uint32_t)a.n_parents) return;
   const int f = a.f;
-  const RowDesc d = desc[p];
-  const uint32_t kind = d.kind_cnt & 7u;
-  uint32_t* out = a.out_nbr + (int64_t)p * f;
-  if (kind == ROW_SKIP) return;
-  if (kind == ROW_INVALID) {
-    if (lane < f) out[lane] = GIGL_INVALID;
-    if (lane == 0) a.out_cnt[p] = 0;
-    return;
-  }
-  const uint32_t* row = a.col + d.s;
-  const uint32_t n = d.n, base = d.base, T = d.T;
-  if (kind == ROW_COPY) {  // copy-through: the row is already the canonical ascending set
-    if (a.multi) {
-      const int nw = emit_sorted_distinct(row, (uint32_t)lane < n ? (uint32_t)lane + 1u : 0xFFFFFFFFu, f, lane, out);
-      if (lane == 0) a.out_cnt[p] = nw;
-      return;
-    }
-    if (lane < f) out[lane] = (uint32_t)lane < n ? row[lane] : GIGL_INVALID;
-    if (lane == 0) a.out_cnt[p] = (int32_t)n;
-    return;
-  }
   uint32_t* lk = s_lk[wave_in_block];
   uint32_t* li = s_li[wave_in_block];
-  const bool in_table = kind != ROW_HASH && kind != ROW_SERIAL_HASH;
-  uint32_t sel_idx;
-  {
-    Sel<true> fast;
-    fast.init(f, lane, a.proxy_drop);
-    bool done = false;
-    if (kind == ROW_LEVEL) done = fast.filter_level((const uint2*)d.ptr, d.kind_cnt >> 3, n, T, base, lk, li);
-    else if (kind == ROW_FLAT) done = fast.template filter_positions<SRC_FLAT>((const uint32_t*)d.ptr, n, T, base, lk, li);
-    else if (kind == ROW_HASH) done = fast.template filter_positions<SRC_HASH>(nullptr, n, T, base, lk, li);
-    if (!done) fast.serial(tb, n, base, T, in_table);
-    sel_idx = fast.idx;
-    if (fast.tie) {  // a 32-bit proxy tie touched the result (about once per 10^7 rows): redo exactly
-      Sel<false> exact;
-      exact.init(f, lane);
-      exact.serial(tb, n, base, T, in_table);
-      sel_idx = exact.idx;
-    } else if (fast.ordered) {  // selected lanes hold the positions in ascending order
-      const unsigned long long m = fast.selmask;
-      const bool sel = (m >> lane) & 1ull;
-      const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      const uint32_t val = sel ? row[sel_idx - 1] : GIGL_INVALID;
-      if (!a.multi) {
-        if (sel) out[slot] = val;
-        if (lane == 0) a.out_cnt[p] = f;
-        return;
-      }
-      // ascending positions of an ascending row: a repeated id sits right after its first copy
-      if (sel) lk[slot] = val;
-      wave_lds_sync();
-      const bool keep = sel && (slot == 0 || lk[slot - 1] != val);
-      wave_lds_sync();
-      const unsigned long long km = __ballot(keep);
+  const RowDesc d0 = desc[p0], d1 = desc[p0 + 1];  // (slot n_parents holds a ROW_SKIP descriptor)
+  const Cand c0 = fetch_candidates(d0, lane), c1 = fetch_candidates(d1, lane);
+  Sel<true> s0, s1;
+  s0.init(f, lane, a.proxy_drop);
+  s1.init(f, lane, a.proxy_drop);
+  // fast path: ordered selections straight to the output
+  const bool done0 = c0.ahead && !a.multi && select_ahead(s0, d0, c0, lk, li) && !s0.tie;
+  uint32_t slot0 = 0, val0 = 0;
+  bool sel0 = false;
+  if (done0) {
+    const unsigned long long m = s0.selmask;
+    sel0 = (m >> lane) & 1ull;
+    slot0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (sel0) val0 = (a.col + d0.s)[s0.idx - 1];
+  }
+  const bool done1 = c1.ahead && !a.multi && select_ahead(s1, d1, c1, lk, li) && !s1.tie;
+  uint32_t slot1 = 0, val1 = 0;
+  bool sel1 = false;
+  if (done1) {
+    const unsigned long long m = s1.selmask;
+    sel1 = (m >> lane) & 1ull;
+    slot1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (sel1) val1 = (a.col + d1.s)[s1.idx - 1];
+  }
+  if (done0) {
+    if (sel0) a.out_nbr[(int64_t)p0 * f + slot0] = val0;
+    if (lane == 0) a.out_cnt[p0] = f;
+  }
+  if (done1) {
+    if (sel1) a.out_nbr[(int64_t)(p0 + 1) * f + slot1] = val1;
+    if (lane == 0) a.out_cnt[p0 + 1] = f;
+  }
+  if (done0 && done1) return;
+  // general path: everything else (copies, invalid parents, long runs, windows outside the table, multi-edge graphs,
+  // rows the filter could not settle, ties), one row after the other
+#pragma nounroll
+  for (int r = 0; r < 2; ++r) {
+    if (r == 0 ? done0 : done1) continue;
+    const RowDesc d = r == 0 ? d0 : d1;
+    const uint32_t p = p0 + (uint32_t)r;
+    const uint32_t kind = d.kind_cnt & 7u;
+    if (kind == ROW_SKIP) continue;
+    uint32_t* out = a.out_nbr + (int64_t)p * f;
+    if (kind == ROW_INVALID) {
       if (lane < f) out[lane] = GIGL_INVALID;
-      if (keep) out[__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u))] = val;
-      if (lane == 0) a.out_cnt[p] = (int32_t)__popcll(km);
-      return;
+      if (lane == 0) a.out_cnt[p] = 0;
+      continue;
     }
+    const uint32_t* row = a.col + d.s;
+    const uint32_t n = d.n, base = d.base, T = d.T;
+    if (kind == ROW_COPY) {  // copy-through: the row is already the canonical ascending set
+      if (a.multi) {
+        const int nw = emit_sorted_distinct(row, (uint32_t)lane < n ? (uint32_t)lane + 1u : 0xFFFFFFFFu, f, lane, out);
+        if (lane == 0) a.out_cnt[p] = nw;
+        continue;
+      }
+      if (lane < f) out[lane] = (uint32_t)lane < n ? row[lane] : GIGL_INVALID;
+      if (lane == 0) a.out_cnt[p] = (int32_t)n;
+      continue;
+    }
+    const bool in_table = kind != ROW_HASH && kind != ROW_SERIAL_HASH;
+    uint32_t sel_idx;
+    {
+      Sel<true> fast;
+      fast.init(f, lane, a.proxy_drop);
+      bool done = false;
+      if (kind == ROW_LEVEL) done = fast.filter_level((const uint2*)d.ptr, d.kind_cnt >> 3, n, T, base, lk, li);
+      else if (kind == ROW_FLAT) done = fast.template filter_positions<SRC_FLAT>((const uint32_t*)d.ptr, n, T, base, lk, li);
+      else if (kind == ROW_HASH) done = fast.template filter_positions<SRC_HASH>(nullptr, n, T, base, lk, li);
+      if (!done) fast.serial(tb, n, base, T, in_table);
+      sel_idx = fast.idx;
+      if (fast.tie) {  // a 32-bit proxy tie touched the result (about once per 10^7 rows): redo exactly
+        Sel<false> exact;
+        exact.init(f, lane);
+        exact.serial(tb, n, base, T, in_table);
+        sel_idx = exact.idx;
+      } else if (fast.ordered) {  // selected lanes hold the positions in ascending order
+        const unsigned long long m = fast.selmask;
+        const bool sel = (m >> lane) & 1ull;
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const uint32_t val = sel ? row[sel_idx - 1] : GIGL_INVALID;
+        if (!a.multi) {
+          if (sel) out[slot] = val;
+          if (lane == 0) a.out_cnt[p] = f;
+          continue;
+        }
+        // ascending positions of an ascending row: a repeated id sits right after its first copy
+        if (sel) lk[slot] = val;
+        wave_lds_sync();
+        const bool keep = sel && (slot == 0 || lk[slot - 1] != val);
+        wave_lds_sync();
+        const unsigned long long km = __ballot(keep);
+        if (lane < f) out[lane] = GIGL_INVALID;
+        if (keep) out[__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u))] = val;
+        if (lane == 0) a.out_cnt[p] = (int32_t)__popcll(km);
+        continue;
+      }
+    }
+    if (a.multi) {
+      const int nw = emit_sorted_distinct(row, sel_idx, f, lane, out);
+      if (lane == 0) a.out_cnt[p] = nw;
+      continue;
+    }
+    emit_sorted(row, sel_idx, f, lane, out);
+    if (lane == 0) a.out_cnt[p] = f;
   }
-  if (a.multi) {
-    const int nw = emit_sorted_distinct(row, sel_idx, f, lane, out);
-    if (lane == 0) a.out_cnt[p] = nw;
-    return;
-  }
-  emit_sorted(row, sel_idx, f, lane, out);
-  if (lane == 0) a.out_cnt[p] = f;
 }
 
 // ---- table construction.  A workgroup owns a tile of 1024 consecutive j; wave w the 256 j from tile*1024 + w*256,
@@ -988,9 +1085,9 @@ int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a_in, const RangeTable& tb, 
   if (!covered) GIGL_HIP_CHECK(ctx, hipMemsetAsync(heavy_count, 0, 4, ctx->stream));
   {
     gigl_prof_scope ps(ctx, GIGL_K_EXPAND);
-    hipLaunchKernelGGL(plan_rows_kernel, dim3((unsigned)((a.n_parents + 255) / 256)), dim3(256), 0, ctx->stream, a, tb,
+    hipLaunchKernelGGL(plan_rows_kernel, dim3((unsigned)(a.n_parents / 256 + 1)), dim3(256), 0, ctx->stream, a, tb,
                        desc, covered ? nullptr : heavy_list, heavy_count);
-    hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((a.n_parents + 3) / 4)), dim3(256), 0, ctx->stream, a, tb,
+    hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((a.n_parents + 7) / 8)), dim3(256), 0, ctx->stream, a, tb,
                        (const RowDesc*)desc);
   }
   if (!covered) {
@@ -1159,9 +1256,9 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
       q *= fanouts[k];
       if (q > max_parents) max_parents = q;
     }
-    rc = gigl_arena_reset(ctx, max_parents * (int64_t)sizeof(RowDesc) + max_parents * 8 + 1024);
+    rc = gigl_arena_reset(ctx, (max_parents + 1) * (int64_t)sizeof(RowDesc) + max_parents * 8 + 1024);
     if (rc != GIGL_OK) return rc;
-    desc = (RowDesc*)gigl_arena_alloc(ctx, max_parents * (int64_t)sizeof(RowDesc));
+    desc = (RowDesc*)gigl_arena_alloc(ctx, (max_parents + 1) * (int64_t)sizeof(RowDesc));
     if (!covered) {
       heavy_list = (int64_t*)gigl_arena_alloc(ctx, max_parents * 8);
       heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
@@ -1222,9 +1319,9 @@ int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* n
   const bool covered = bounded && bound < tb.dom;
   int64_t* heavy_list = nullptr;
   int32_t* heavy_count = nullptr;
-  rc = gigl_arena_reset(ctx, m * (int64_t)sizeof(RowDesc) + m * 8 + 1024);
+  rc = gigl_arena_reset(ctx, (m + 1) * (int64_t)sizeof(RowDesc) + m * 8 + 1024);
   if (rc != GIGL_OK) return rc;
-  RowDesc* desc = (RowDesc*)gigl_arena_alloc(ctx, m * (int64_t)sizeof(RowDesc));
+  RowDesc* desc = (RowDesc*)gigl_arena_alloc(ctx, (m + 1) * (int64_t)sizeof(RowDesc));
   if (!covered) {
     heavy_list = (int64_t*)gigl_arena_alloc(ctx, m * 8);
     heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
@@ -1267,9 +1364,9 @@ int32_t gigl_sample_out_neighbors(gigl_ctx* ctx, gigl_graph* g_out, const uint32
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "num positives %d outside [1,%d]", f, GIGL_MAX_FANOUT);
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (b == 0) return GIGL_OK;
-  int32_t rc = gigl_arena_reset(ctx, (int64_t)b * ((int64_t)sizeof(RowDesc) + 8) + 1024);
+  int32_t rc = gigl_arena_reset(ctx, (int64_t)(b + 1) * ((int64_t)sizeof(RowDesc) + 8) + 1024);
   if (rc != GIGL_OK) return rc;
-  RowDesc* desc = (RowDesc*)gigl_arena_alloc(ctx, (int64_t)b * (int64_t)sizeof(RowDesc));
+  RowDesc* desc = (RowDesc*)gigl_arena_alloc(ctx, (int64_t)(b + 1) * (int64_t)sizeof(RowDesc));
   int64_t* heavy_list = (int64_t*)gigl_arena_alloc(ctx, (int64_t)b * 8);
   int32_t* heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
   if (!desc || !heavy_list || !heavy_count) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
