@@ -43,6 +43,8 @@ SYMBOLS = [
     "gigl_dist_plan_set_weights", "gigl_dist_plan_phases", "gigl_dist_plan_phase", "gigl_dist_plan_run",
     "gigl_dist_plan_run_local", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
     "gigl_split_hash_slots", "gigl_hgt_aggregate", "gigl_simplehgn_alpha", "gigl_weighted_aggregate",
+    "gigl_collate_typed_records", "gigl_collated_typed_info", "gigl_collated_typed_nodes", "gigl_collated_typed_edges",
+    "gigl_collated_typed_samples", "gigl_collated_typed_destroy",
 ]
 
 KERNEL_IDS = {
@@ -223,6 +225,12 @@ def load() -> C.CDLL:
         "gigl_collated_copy": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "gigl_collated_destroy": [vp],
         "gigl_collated_edge_attr": [vp, P(i32), vp],
+        "gigl_collate_typed_records": [vp, vp, vp, i64, i32, i32, i32, vp, vp, i32, P(vp), C.c_char_p, i32],
+        "gigl_collated_typed_info": [vp, vp, vp, vp, vp, P(i64), P(i64)],
+        "gigl_collated_typed_nodes": [vp, i32, vp, vp],
+        "gigl_collated_typed_edges": [vp, i32, vp, vp],
+        "gigl_collated_typed_samples": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        "gigl_collated_typed_destroy": [vp],
         "gigl_tfexample_decode": [vp, vp, vp, i64, P(GiglColumn), i32, i32, P(i64)],
         "gigl_gat_aggregate_edge": [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, i32,
                                     i64, vp, vp, vp, vp],

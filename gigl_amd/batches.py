@@ -142,6 +142,72 @@ def collate_serialized(batch: Sequence[bytes], kind: int, n_threads: int = 0):
     return out
 
 
+def collate_serialized_typed(batch: Sequence[bytes], kind: int, n_node_types: int,
+                             edge_type_endpoints: Sequence[Tuple[int, int]], n_threads: int = 0):
+    """native collate of serialized HETEROGENEOUS samples (gigl_collate_typed_records): nodes carry
+    condensed_node_type, edges condensed_edge_type; `edge_type_endpoints[t]` = (condensed src node type, condensed dst
+    node type) of condensed edge type t (GraphMetadataPbWrapper.condensed_edge_type_to_edge_type_map).
+    -> dict(node_ids={nt: uint32[n]}, x={nt: float32[n, d]}, edge_index={et: int64[2, e]}, edge_attr={et: float32[e, de]
+    or None}, root_type, root_local, labels, has_label, pos_off, pos_dst, pos_type, neg_off, neg_dst, neg_type).
+    Per type the reference's semantics: first-seen numbering (one counter per node type), edges de-duplicated and
+    coalesced per edge type; the same exceptions as collate_serialized."""
+    import ctypes as C
+    import os
+
+    from . import _lib
+    lib = _lib.load()
+    payloads = [bytes(b) for b in batch]
+    lens = np.array([len(b) for b in payloads], dtype=np.int64)
+    off = np.zeros(len(payloads), dtype=np.int64)
+    if len(payloads) > 1:
+        np.cumsum(lens[:-1], out=off[1:])
+    blob = b"".join(payloads) or b"\0"
+    n_et = len(edge_type_endpoints)
+    e_src = np.array([p[0] for p in edge_type_endpoints] or [0], dtype=np.int32)
+    e_dst = np.array([p[1] for p in edge_type_endpoints] or [0], dtype=np.int32)
+    ptr = lambda a: C.c_void_p(a.ctypes.data)
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = lib.gigl_collate_typed_records(blob, ptr(off), ptr(lens), len(payloads), kind, n_node_types, n_et, ptr(e_src),
+                                        ptr(e_dst), n_threads or min(16, os.cpu_count() or 1), C.byref(h), err, 512)
+    if rc != 0:
+        msg = err.value.decode("utf-8", "replace")
+        exc = (AssertionError if "re-added" in msg else TypeError if ("Tried to fetch" in msg or "edge feature" in msg)
+               else KeyError if "not in the batch graph" in msg else ValueError)
+        raise exc(msg or "gigl_collate_typed_records failed")
+    try:
+        nn, nd = np.zeros(n_node_types, np.int64), np.zeros(n_node_types, np.int32)
+        en, ed = np.zeros(max(n_et, 1), np.int64), np.zeros(max(n_et, 1), np.int32)
+        npos, nneg = C.c_int64(), C.c_int64()
+        lib.gigl_collated_typed_info(h, ptr(nn), ptr(nd), ptr(en), ptr(ed), C.byref(npos), C.byref(nneg))
+        b = len(payloads)
+        out = dict(node_ids={}, x={}, edge_index={}, edge_attr={})
+        for t in range(n_node_types):
+            ids = np.empty(int(nn[t]), np.uint32)
+            x = np.empty((int(nn[t]), int(nd[t])), np.float32)
+            lib.gigl_collated_typed_nodes(h, t, ptr(ids), ptr(x))
+            if nn[t] and nd[t] == 0:  # PygGraphBuilder: nodes without features get ones(1)
+                x = np.ones((int(nn[t]), 1), dtype=np.float32)
+            out["node_ids"][t], out["x"][t] = ids, x
+        for t in range(n_et):
+            ei = np.empty((2, int(en[t])), np.int64)
+            ea = np.empty((int(en[t]), int(ed[t])), np.float32) if ed[t] else None
+            lib.gigl_collated_typed_edges(h, t, ptr(ei), ptr(ea) if ea is not None else None)
+            out["edge_index"][t], out["edge_attr"][t] = ei, ea
+        out.update(root_type=np.empty(b, np.int32), root_local=np.empty(b, np.int64), labels=np.empty(b, np.int64),
+                   has_label=np.empty(b, np.uint8), pos_off=np.empty(b + 1, np.int64),
+                   pos_dst=np.empty(npos.value, np.int64), pos_type=np.empty(npos.value, np.int32),
+                   neg_off=np.empty(b + 1, np.int64), neg_dst=np.empty(nneg.value, np.int64),
+                   neg_type=np.empty(nneg.value, np.int32))
+        lib.gigl_collated_typed_samples(h, ptr(out["root_type"]), ptr(out["root_local"]), ptr(out["labels"]),
+                                        ptr(out["has_label"]), ptr(out["pos_off"]), ptr(out["pos_dst"]),
+                                        ptr(out["pos_type"]), ptr(out["neg_off"]), ptr(out["neg_dst"]),
+                                        ptr(out["neg_type"]))
+    finally:
+        lib.gigl_collated_typed_destroy(h)
+    return out
+
+
 @dataclass
 class RootedNodeNeighborhoodBatch:
     graph: GraphData

@@ -188,6 +188,33 @@ int32_t gigl_collated_copy(const gigl_collated* c, uint32_t* node_ids, float* x,
 int32_t gigl_collated_edge_attr(const gigl_collated* c, int32_t* edge_dim, float* edge_attr);
 int32_t gigl_collated_destroy(gigl_collated* c);
 
+/* Typed (heterogeneous) samples: RootedNodeNeighborhood / NodeAnchorBasedLinkPredictionSample payloads whose nodes
+ * and edges carry condensed_node_type / condensed_edge_type (graph_schema.proto:5-25) -> one batch graph per type, as
+ * the reference's collate builds it through GraphBuilder (abstract_graph_builder.py:16-24: one first-seen counter per
+ * node type; :100-150: one ordered, de-duplicated edge list per edge type) and PygGraphBuilder.build
+ * (pyg_graph_builder.py:20-69: x_dict / edge_index_dict of a HeteroData), then coalesce() per edge type.
+ * et_src_nt[t] / et_dst_nt[t]: condensed node types of the endpoints of condensed edge type t
+ * (GraphMetadataPbWrapper.condensed_edge_type_to_edge_type_map).  Host pointers, host C++ (like
+ * gigl_collate_records).  Errors as there: malformed record, a node outside the metadata's types, a node re-added
+ * with other features, an edge whose endpoint is unknown, mixed edge-feature registration, a root / supervision
+ * target outside the batch graph. */
+typedef struct gigl_collated_typed gigl_collated_typed;
+int32_t gigl_collate_typed_records(const uint8_t* buf, const int64_t* payload_off, const int64_t* payload_len, int64_t b,
+                                   int32_t kind, int32_t n_node_types, int32_t n_edge_types, const int32_t* et_src_nt,
+                                   const int32_t* et_dst_nt, int32_t n_threads, gigl_collated_typed** out, char* err,
+                                   int32_t err_cap);
+/* per node type: nodes, feature dim; per edge type: edges, edge-feature dim (arrays sized by the caller) */
+int32_t gigl_collated_typed_info(const gigl_collated_typed* c, int64_t* nodes_per_type, int32_t* feat_dim_per_type,
+                                 int64_t* edges_per_type, int32_t* edge_dim_per_type, int64_t* n_pos, int64_t* n_hard_neg);
+int32_t gigl_collated_typed_nodes(const gigl_collated_typed* c, int32_t node_type, uint32_t* node_ids, float* x);
+/* edge_index = [2, E] (row 0 sources, row 1 destinations), local to the edge type's endpoint node types */
+int32_t gigl_collated_typed_edges(const gigl_collated_typed* c, int32_t edge_type, int64_t* edge_index, float* edge_attr);
+/* per sample: root (type, local id), root label; supervision targets local to their edge type's destination type */
+int32_t gigl_collated_typed_samples(const gigl_collated_typed* c, int32_t* root_type, int64_t* root_local, int64_t* labels,
+                                    uint8_t* has_label, int64_t* pos_off, int64_t* pos_dst, int32_t* pos_type,
+                                    int64_t* neg_off, int64_t* neg_dst, int32_t* neg_type);
+int32_t gigl_collated_typed_destroy(gigl_collated_typed* c);
+
 /* ---- node features: replaces loadNodeDataframeIntoSparkSql (SGSPureSparkV1Task.scala:52-118):
  * dense row-major [n][d], row index == node id. */
 int32_t gigl_features_load(gigl_ctx* ctx, int64_t n, int32_t d, int32_t dtype, const void* rows,

@@ -203,3 +203,77 @@ def test_edge_features_random_batches_native_vs_python_loops():
     ref = SupervisedNodeClassificationBatch.collate_pyg_node_classification_minibatch(samples)
     _same_graph(nat, ref)
     assert nat.graph.edge_attr.shape[1] == 3 and torch.equal(nat.graph.edge_attr, ref.graph.edge_attr)
+
+
+# ---- heterogeneous samples: gigl_collate_typed_records vs traces of the reference GraphBuilder ----------------------
+def _typed_records(case):
+    recs = []
+    for s in case["samples"]:
+        nodes = [wire.Node(node_id=v, condensed_node_type=t, feature_values=np.asarray(f, np.float32))
+                 for t, v, f in s["nodes"]]
+        edges = [wire.Edge(src_node_id=a, dst_node_id=b, condensed_edge_type=c,
+                           feature_values=np.asarray(ef, np.float32)) for c, a, b, ef in s["edges"]]
+        recs.append(wire.RootedNodeNeighborhood(root_node=nodes[0],
+                                                neighborhood=wire.Graph(nodes=nodes, edges=edges)).SerializeToString())
+    return recs
+
+
+def test_typed_collate_matches_reference_graph_builder_traces(golden_dir):
+    import json
+
+    from gigl_amd._lib import REC_ROOTED_NODE_NEIGHBORHOOD
+    from gigl_amd.batches import collate_serialized_typed
+    traces = json.load(open(os.path.join(golden_dir, "graph_builder_hetero_traces.json")))
+    assert len(traces) >= 10
+    for case in traces:
+        ends = [tuple(p) for p in case["edge_type_endpoints"]]
+        out = collate_serialized_typed(_typed_records(case), REC_ROOTED_NODE_NEIGHBORHOOD, case["n_node_types"], ends)
+        feats = {}
+        for s in case["samples"]:
+            for t, v, f in s["nodes"]:
+                feats[(t, v)] = np.asarray(f, np.float32)
+        for t in range(case["n_node_types"]):
+            g2l = {int(k): v for k, v in case["global_to_local"][t].items()}
+            ids = out["node_ids"][t]
+            assert len(ids) == len(g2l)
+            for local, g in enumerate(ids.tolist()):  # first-seen numbering of the reference, per node type
+                assert g2l[g] == local
+                assert np.array_equal(out["x"][t][local], feats[(t, g)])
+        for c in range(len(ends)):
+            ordered = case["ordered_edges_local"][c]
+            order = sorted(range(len(ordered)), key=lambda i: tuple(ordered[i]))  # coalesce(): sorted by (src, dst)
+            want = np.array([ordered[i] for i in order], dtype=np.int64).reshape(-1, 2).T
+            assert np.array_equal(out["edge_index"][c], want), c
+            ef = case["ordered_edge_features"][c]
+            if ordered and ef[0]:
+                assert np.allclose(out["edge_attr"][c], np.array([ef[i] for i in order], np.float32))
+            else:
+                assert out["edge_attr"][c] is None
+        # roots: (type, local id) of each record's root node
+        for i, s in enumerate(case["samples"]):
+            t, v, _ = s["nodes"][0]
+            assert out["root_type"][i] == t
+            assert out["root_local"][i] == case["global_to_local"][t][str(v)]
+
+
+def test_typed_collate_errors():
+    from gigl_amd._lib import REC_ROOTED_NODE_NEIGHBORHOOD
+    from gigl_amd.batches import collate_serialized_typed
+    f = np.ones(2, np.float32)
+    a = wire.Node(node_id=1, condensed_node_type=0, feature_values=f)
+    b = wire.Node(node_id=1, condensed_node_type=1, feature_values=f)  # same id, another type: another node
+    ok = wire.RootedNodeNeighborhood(root_node=a, neighborhood=wire.Graph(
+        nodes=[a, b], edges=[wire.Edge(src_node_id=1, dst_node_id=1, condensed_edge_type=0)]))
+    out = collate_serialized_typed([ok.SerializeToString()], REC_ROOTED_NODE_NEIGHBORHOOD, 2, [(0, 1)])
+    assert out["node_ids"][0].tolist() == [1] and out["node_ids"][1].tolist() == [1]
+    assert out["edge_index"][0].tolist() == [[0], [0]]
+    bad = wire.RootedNodeNeighborhood(root_node=a, neighborhood=wire.Graph(
+        nodes=[a], edges=[wire.Edge(src_node_id=1, dst_node_id=1, condensed_edge_type=0)]))  # type-1 node 1 unknown
+    with pytest.raises(TypeError):
+        collate_serialized_typed([bad.SerializeToString()], REC_ROOTED_NODE_NEIGHBORHOOD, 2, [(0, 1)])
+    other = wire.Node(node_id=1, condensed_node_type=0, feature_values=2 * f)
+    clash = wire.RootedNodeNeighborhood(root_node=a, neighborhood=wire.Graph(nodes=[a, other], edges=[]))
+    with pytest.raises(AssertionError):
+        collate_serialized_typed([clash.SerializeToString()], REC_ROOTED_NODE_NEIGHBORHOOD, 2, [(0, 1)])
+    with pytest.raises(ValueError):  # a node type outside the metadata
+        collate_serialized_typed([ok.SerializeToString()], REC_ROOTED_NODE_NEIGHBORHOOD, 1, [(0, 0)])
