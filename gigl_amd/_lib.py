@@ -44,7 +44,8 @@ SYMBOLS = [
     "gigl_dist_plan_run_local", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
     "gigl_split_hash_slots", "gigl_hgt_aggregate", "gigl_simplehgn_alpha", "gigl_weighted_aggregate",
     "gigl_collate_typed_records", "gigl_collated_typed_info", "gigl_collated_typed_nodes", "gigl_collated_typed_edges",
-    "gigl_collated_typed_samples", "gigl_collated_typed_destroy",
+    "gigl_collated_typed_samples", "gigl_collated_typed_destroy", "gigl_typed_records_capacity",
+    "gigl_typed_records_encode",
 ]
 
 KERNEL_IDS = {
@@ -94,6 +95,15 @@ class GiglRecordOpts(C.Structure):
         ("neg_edges_graph", C.c_void_p),
         ("neg_edge_feat", C.c_void_p),
     ]
+
+
+class GiglTypedOp(C.Structure):
+    _fields_ = [("frontier", C.c_void_p), ("nbr", C.c_void_p), ("w", C.c_int32), ("f", C.c_int32),
+                ("condensed_edge_type", C.c_int32), ("result_node_type", C.c_int32), ("outgoing", C.c_int32)]
+
+
+class GiglTypedFeat(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("d", C.c_int32), ("n", C.c_int64)]
 
 
 REC_ROOTED_NODE_NEIGHBORHOOD, REC_NODE_ANCHOR_LINK_PRED = 0, 1
@@ -231,6 +241,8 @@ def load() -> C.CDLL:
         "gigl_collated_typed_edges": [vp, i32, vp, vp],
         "gigl_collated_typed_samples": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "gigl_collated_typed_destroy": [vp],
+        "gigl_typed_records_capacity": [P(GiglTypedOp), i32, P(GiglTypedFeat), i32, i64, i32, P(i64)],
+        "gigl_typed_records_encode": [vp, vp, i32, P(GiglTypedOp), i32, P(GiglTypedFeat), i32, i64, i32, vp, i64, vp, vp],
         "gigl_tfexample_decode": [vp, vp, vp, i64, P(GiglColumn), i32, i32, P(i64)],
         "gigl_gat_aggregate_edge": [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, i32,
                                     i64, vp, vp, vp, vp],

@@ -766,6 +766,302 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Typed (heterogeneous) RootedNodeNeighborhood records: the result of a SamplingOp DAG on a typed graph — per op a
+// frontier [b, w] and its sampled neighbours [b, w, f] — encoded on the device.  Replaces the per-root assembly of
+// GraphDBSampler (scala_spark35/common/src/main/scala/graphdb/GraphDBSampler.scala:45-113: the union of all ops'
+// edges and nodes + the root, as sets) and the proto cast / TFRecord write of the task
+// (GraphDBNodeAnchorBasedLinkPredictionTask.scala:62-78).  Per root, one workgroup:
+//   plan   every (node id, node type) and (src, dst, edge type) the ops produced goes into LDS, is bitonic-sorted and
+//          de-duplicated — nodes ascending by (id, type), edges by (src, dst, type): the canonical order of the host
+//          assembly (gigl_amd/graphdb_sampler.py) — and written to a per-root scratch segment with the record's size;
+//   scan   record offsets (record_scan_kernel);
+//   write  headers by one thread per node / edge (offsets from block scans of the field lengths), feature rows by one
+//          wave per node, TFRecord framing + CRC-32C as in record_write_kernel.
+// Edge features are not carried by this path (a sampler that hydrates typed edge features assembles on the host).
+// ------------------------------------------------------------------------------------------
+constexpr int TYPED_MAX_OPS = 16, TYPED_MAX_NODE_TYPES = 16;
+constexpr uint32_t TYPED_MAX_ITEMS = 4096;  // candidate nodes / edges per root the LDS sort is sized for
+constexpr unsigned long long PAD64 = ~0ull;
+
+struct TypedArgs {
+  gigl_typed_op ops[TYPED_MAX_OPS];
+  int32_t n_ops;
+  const uint32_t* roots;
+  int32_t root_type;
+  gigl_typed_feat feat[TYPED_MAX_NODE_TYPES];
+  int32_t n_node_types;
+  int32_t frame;
+  uint32_t items;  // candidates per root = sum of w * f over the ops
+  uint32_t pow2;   // sort size: next power of two >= items + 1
+  // per-root scratch
+  unsigned long long* u_nodes;  // [b][items + 1]  (id << 32 | type), ascending
+  unsigned long long* u_edges;  // [b][items]      (src << 32 | dst), ascending with u_etype as the minor key
+  uint32_t* u_etype;            // [b][items]
+  uint32_t* u_info;             // [b][4]: distinct nodes, distinct edges, bytes of the node fields, graph body bytes
+  const uint32_t* shift_tbl;
+};
+
+__device__ __forceinline__ uint32_t typed_node_body(const TypedArgs& a, unsigned long long key) {
+  const uint32_t id = (uint32_t)(key >> 32), t = (uint32_t)key;
+  uint32_t n = 1 + vlen(t);  // condensed_node_type is `optional`: written even when 0
+  if (id) n += 1 + vlen(id);
+  const int32_t d = t < (uint32_t)a.n_node_types && a.feat[t].x ? a.feat[t].d : 0;
+  if (d > 0) n += 1 + vlen(4u * (uint32_t)d) + 4u * (uint32_t)d;
+  return n;
+}
+__device__ __forceinline__ uint32_t typed_edge_body(unsigned long long k1, uint32_t cet) {
+  const uint32_t s = (uint32_t)(k1 >> 32), d = (uint32_t)k1;
+  uint32_t n = 1 + vlen(cet);
+  if (s) n += 1 + vlen(s);
+  if (d) n += 1 + vlen(d);
+  return n;
+}
+
+// bitonic sort of n = 2^k (key, minor) pairs in LDS, ascending by (key, minor); minor may be null
+__device__ void lds_bitonic(unsigned long long* key, uint32_t* minor, uint32_t n) {
+  for (uint32_t k = 2; k <= n; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t p = i ^ j;
+        if (p > i) {
+          const unsigned long long a = key[i], b = key[p];
+          const uint32_t ma = minor ? minor[i] : 0u, mb = minor ? minor[p] : 0u;
+          const bool gt = a > b || (a == b && ma > mb);
+          if (gt == ((i & k) == 0)) {
+            key[i] = b;
+            key[p] = a;
+            if (minor) {
+              minor[i] = mb;
+              minor[p] = ma;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void typed_plan_kernel(TypedArgs a, int64_t* rec_size) {
+  __shared__ uint32_t s_w[8];
+  const uint32_t r = blockIdx.x, tid = threadIdx.x, P = a.pow2;
+  unsigned long long* nk = (unsigned long long*)s_dyn;  // [P]
+  unsigned long long* ek = nk + P;                      // [P]
+  uint32_t* et = (uint32_t*)(ek + P);                   // [P]
+  for (uint32_t i = tid; i < P; i += 256) {
+    nk[i] = PAD64;
+    ek[i] = PAD64;
+    et[i] = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  const uint32_t root = a.roots[r];
+  if (tid == 0) nk[0] = ((unsigned long long)root << 32) | (uint32_t)a.root_type;
+  uint32_t base = 0;
+  for (int o = 0; o < a.n_ops; ++o) {
+    const gigl_typed_op& op = a.ops[o];
+    const uint32_t wf = (uint32_t)(op.w * op.f);
+    for (uint32_t idx = tid; idx < wf; idx += 256) {
+      const uint32_t q = idx / (uint32_t)op.f;
+      const uint32_t fr = op.frontier[(int64_t)r * op.w + q];
+      const uint32_t v = op.nbr[((int64_t)r * op.w + q) * op.f + (idx - q * (uint32_t)op.f)];
+      if (fr == GIGL_INVALID || v == GIGL_INVALID) continue;
+      nk[1 + base + idx] = ((unsigned long long)v << 32) | (uint32_t)op.result_node_type;
+      ek[base + idx] = op.outgoing ? ((unsigned long long)fr << 32) | v : ((unsigned long long)v << 32) | fr;
+      et[base + idx] = (uint32_t)op.condensed_edge_type;
+    }
+    base += wf;
+  }
+  __syncthreads();
+  lds_bitonic(nk, nullptr, P);
+  lds_bitonic(ek, et, P);
+  // distinct items -> scratch, field bytes summed
+  unsigned long long* un = a.u_nodes + (int64_t)r * (a.items + 1);
+  unsigned long long* ue = a.u_edges + (int64_t)r * a.items;
+  uint32_t* ut = a.u_etype + (int64_t)r * a.items;
+  uint32_t n_nodes = 0, n_edges = 0, node_bytes = 0, edge_bytes = 0;
+  for (uint32_t c0 = 0; c0 < P; c0 += 256) {
+    const uint32_t i = c0 + tid;
+    const unsigned long long k = i < P ? nk[i] : PAD64;
+    const bool keep = k != PAD64 && (i == 0 || nk[i - 1] != k);
+    uint32_t tot, tot_b;
+    const uint32_t pos = block_exscan(keep ? 1u : 0u, s_w, tot);
+    const uint32_t fb = keep ? field_len(typed_node_body(a, k)) : 0u;
+    block_exscan(fb, s_w, tot_b);
+    if (keep) un[n_nodes + pos] = k;
+    n_nodes += tot;
+    node_bytes += tot_b;
+  }
+  for (uint32_t c0 = 0; c0 < P; c0 += 256) {
+    const uint32_t i = c0 + tid;
+    const unsigned long long k = i < P ? ek[i] : PAD64;
+    const uint32_t t = i < P ? et[i] : 0u;
+    const bool keep = k != PAD64 && (i == 0 || ek[i - 1] != k || et[i - 1] != t);
+    uint32_t tot, tot_b;
+    const uint32_t pos = block_exscan(keep ? 1u : 0u, s_w, tot);
+    const uint32_t fb = keep ? field_len(typed_edge_body(k, t)) : 0u;
+    block_exscan(fb, s_w, tot_b);
+    if (keep) {
+      ue[n_edges + pos] = k;
+      ut[n_edges + pos] = t;
+    }
+    n_edges += tot;
+    edge_bytes += tot_b;
+  }
+  if (tid == 0) {
+    const uint32_t graph_body = node_bytes + edge_bytes;
+    const uint32_t root_body = typed_node_body(a, ((unsigned long long)root << 32) | (uint32_t)a.root_type);
+    uint32_t* info = a.u_info + (int64_t)r * 4;
+    info[0] = n_nodes;
+    info[1] = n_edges;
+    info[2] = node_bytes;
+    info[3] = graph_body;
+    rec_size[r] = (int64_t)field_len(root_body) + field_len(graph_body) + (a.frame ? 16 : 0);
+  }
+}
+
+__device__ __forceinline__ uint8_t* typed_write_node_header(const TypedArgs& a, uint8_t* q, uint8_t tag,
+                                                            unsigned long long key) {
+  const uint32_t id = (uint32_t)(key >> 32), t = (uint32_t)key;
+  *q++ = tag;
+  q = put_varint(q, typed_node_body(a, key));
+  if (id) {
+    *q++ = 0x08;
+    q = put_varint(q, id);
+  }
+  *q++ = 0x10;
+  q = put_varint(q, t);
+  const int32_t d = t < (uint32_t)a.n_node_types && a.feat[t].x ? a.feat[t].d : 0;
+  if (d > 0) {
+    *q++ = 0x1A;
+    q = put_varint(q, 4u * (uint32_t)d);
+  }
+  return q;  // the float payload starts here
+}
+
+__global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int64_t* rec_off, const int32_t* status,
+                                                          uint8_t* out) {
+  __shared__ uint32_t s_w[8];
+  __shared__ uint32_t s_x[4];
+  __shared__ uint32_t crc_t[1024];
+  if (*status != 0) return;
+  const uint32_t r = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+  uint32_t* pay = (uint32_t*)s_dyn;  // [items + 2]: offset of every node's float payload from the record start
+  {
+    uint32_t c = tid;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+    crc_t[tid] = c;
+  }
+  __syncthreads();
+  for (int j = 1; j < 4; ++j) {
+    const uint32_t prev = crc_t[(j - 1) * 256 + tid];
+    crc_t[j * 256 + tid] = (prev >> 8) ^ crc_t[prev & 0xFF];
+    __syncthreads();
+  }
+  const uint32_t* info = a.u_info + (int64_t)r * 4;
+  const uint32_t n_nodes = info[0], n_edges = info[1], node_bytes = info[2], graph_body = info[3];
+  const unsigned long long* un = a.u_nodes + (int64_t)r * (a.items + 1);
+  const unsigned long long* ue = a.u_edges + (int64_t)r * a.items;
+  const uint32_t* ut = a.u_etype + (int64_t)r * a.items;
+  const unsigned long long root_key = ((unsigned long long)a.roots[r] << 32) | (uint32_t)a.root_type;
+  const uint32_t root_body = typed_node_body(a, root_key);
+  const uint64_t payload_len = (uint64_t)field_len(root_body) + field_len(graph_body);
+  uint8_t* const rec = out + rec_off[r];
+  uint8_t* const payload = rec + (a.frame ? 12 : 0);
+  uint8_t* const graph_hdr = payload + field_len(root_body);
+  uint8_t* const graph = graph_hdr + 1 + vlen(graph_body);
+  uint8_t* const edges = graph + node_bytes;
+  uint8_t* const payload_end = payload + payload_len;
+  if (tid == 0) {
+    if (a.frame) {
+      uint32_t c = 0xFFFFFFFFu;
+      for (int b = 0; b < 8; ++b) {
+        const uint32_t byte = (uint32_t)((payload_len >> (8 * b)) & 0xFF);
+        rec[b] = (uint8_t)byte;
+        c = crc_byte(crc_t, c, byte);
+      }
+      const uint32_t m = mask_crc(c ^ 0xFFFFFFFFu);
+      for (int b = 0; b < 4; ++b) rec[8 + b] = (uint8_t)(m >> (8 * b));
+    }
+    uint8_t* q = typed_write_node_header(a, payload, 0x0A, root_key);  // root_node = 1
+    pay[n_nodes] = (uint32_t)(q - rec);
+    q = graph_hdr;
+    *q++ = 0x12;  // neighborhood = 2
+    put_varint(q, graph_body);
+  }
+  // Graph.nodes = 2: one thread per node writes the header; offsets from block scans of the field lengths
+  uint32_t run = 0;
+  for (uint32_t c0 = 0; c0 < n_nodes; c0 += 256) {
+    const uint32_t i = c0 + tid;
+    const unsigned long long k = i < n_nodes ? un[i] : 0ull;
+    uint32_t tot;
+    const uint32_t off = block_exscan(i < n_nodes ? field_len(typed_node_body(a, k)) : 0u, s_w, tot);
+    if (i < n_nodes) pay[i] = (uint32_t)(typed_write_node_header(a, graph + run + off, 0x12, k) - rec);
+    run += tot;
+  }
+  run = 0;
+  for (uint32_t c0 = 0; c0 < n_edges; c0 += 256) {  // Graph.edges = 3
+    const uint32_t i = c0 + tid;
+    const unsigned long long k = i < n_edges ? ue[i] : 0ull;
+    const uint32_t t = i < n_edges ? ut[i] : 0u;
+    uint32_t tot;
+    const uint32_t off = block_exscan(i < n_edges ? field_len(typed_edge_body(k, t)) : 0u, s_w, tot);
+    if (i < n_edges) {
+      uint8_t* q = edges + run + off;
+      const uint32_t s = (uint32_t)(k >> 32), d = (uint32_t)k;
+      *q++ = 0x1A;
+      q = put_varint(q, typed_edge_body(k, t));
+      if (s) {
+        *q++ = 0x08;
+        q = put_varint(q, s);
+      }
+      if (d) {
+        *q++ = 0x10;
+        q = put_varint(q, d);
+      }
+      *q++ = 0x18;
+      put_varint(q, t);
+    }
+    run += tot;
+  }
+  __syncthreads();
+  // feature rows: one wave per node (entry n_nodes = the root_node field)
+  for (uint32_t i = (uint32_t)w; i <= n_nodes; i += 4) {
+    const unsigned long long k = i < n_nodes ? un[i] : root_key;
+    const uint32_t id = (uint32_t)(k >> 32), t = (uint32_t)k;
+    if (t >= (uint32_t)a.n_node_types || !a.feat[t].x || a.feat[t].d <= 0) continue;
+    const float* src = a.feat[t].x + (int64_t)id * a.feat[t].d;
+    uint8_t* dst = rec + pay[i];
+    for (int e = lane; e < a.feat[t].d; e += 64) put_word(dst + 4 * e, __float_as_uint(src[e]));
+  }
+  if (!a.frame) return;
+  __threadfence_block();
+  __syncthreads();
+  {  // CRC-32C of the payload (as record_write_kernel: per-thread slices combined by x^(8*bytes after the slice))
+    const uint64_t n = payload_len;
+    const uint64_t C = ((n + 255) / 256 + 3) & ~3ull;
+    const uint64_t lo = min((uint64_t)tid * C, n), hi = min(lo + C, n);
+    uint32_t c = tid == 0 ? 0xFFFFFFFFu : 0u;
+    const uint8_t* p = payload + lo;
+    const uint8_t* const e = payload + hi;
+    while (p < e && ((uintptr_t)p & 3u)) c = crc_byte(crc_t, c, *p++);
+    for (; p + 4 <= e; p += 4) c = crc_word(crc_t, c, *(const uint32_t*)p);
+    while (p < e) c = crc_byte(crc_t, c, *p++);
+    uint32_t part = 0;
+    if (c) part = multmodp(x8n_modp(a.shift_tbl, n - hi), c);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part ^= __shfl_xor(part, o, 64);
+    if (lane == 0) s_x[w] = part;
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t m = mask_crc((s_x[0] ^ s_x[1] ^ s_x[2] ^ s_x[3]) ^ 0xFFFFFFFFu);
+      for (int b = 0; b < 4; ++b) payload_end[b] = (uint8_t)(m >> (8 * b));
+    }
+  }
+}
+
+
 uint32_t host_multmodp(uint32_t a, uint32_t b) {
   uint32_t m = 1u << 31, p = 0;
   for (;;) {
@@ -974,5 +1270,79 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
+
+int32_t gigl_typed_records_capacity(const gigl_typed_op* ops, int32_t n_ops, const gigl_typed_feat* feats,
+                                    int32_t n_node_types, int64_t n_records, int32_t tfrecord_frame, int64_t* bytes) {
+  if (!ops || n_ops < 1 || n_ops > TYPED_MAX_OPS || n_node_types < 1 || n_node_types > TYPED_MAX_NODE_TYPES || !bytes)
+    return GIGL_E_INVALID_ARG;
+  int64_t items = 0, dmax = 0;
+  for (int o = 0; o < n_ops; ++o) items += (int64_t)ops[o].w * ops[o].f;
+  for (int t = 0; t < n_node_types; ++t)
+    if (feats && feats[t].x && feats[t].d > dmax) dmax = feats[t].d;
+  // node field <= 2 + 6 + 6 + 6 + 4 d (+ length bytes), edge field <= 2 + 6 + 6 + 6; root field, graph header, frame
+  const int64_t node = 26 + 4 * dmax, edge = 20;
+  *bytes = n_records * ((items + 2) * node + items * edge + 16 + (tfrecord_frame ? 16 : 0));
+  return GIGL_OK;
+}
+
+int32_t gigl_typed_records_encode(gigl_ctx* ctx, const uint32_t* roots, int32_t root_node_type, const gigl_typed_op* ops,
+                                  int32_t n_ops, const gigl_typed_feat* feats, int32_t n_node_types, int64_t n_records,
+                                  int32_t tfrecord_frame, uint8_t* out, int64_t out_cap, int64_t* rec_off,
+                                  int32_t* status) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, roots && ops && out && rec_off && status && n_records >= 0, "null argument");
+  GIGL_REQUIRE(ctx, n_ops >= 1 && n_ops <= TYPED_MAX_OPS, "between 1 and %d sampling ops", TYPED_MAX_OPS);
+  GIGL_REQUIRE(ctx, n_node_types >= 1 && n_node_types <= TYPED_MAX_NODE_TYPES && root_node_type >= 0 &&
+                        root_node_type < n_node_types,
+               "node types outside [1,%d]", TYPED_MAX_NODE_TYPES);
+  TypedArgs a{};
+  int64_t items = 0;
+  for (int o = 0; o < n_ops; ++o) {
+    GIGL_REQUIRE(ctx, ops[o].frontier && ops[o].nbr && ops[o].w >= 1 && ops[o].f >= 1, "op %d has no buffers", o);
+    GIGL_REQUIRE(ctx, ops[o].result_node_type >= 0 && ops[o].result_node_type < n_node_types && ops[o].condensed_edge_type >= 0,
+                 "op %d has a type outside the metadata", o);
+    a.ops[o] = ops[o];
+    items += (int64_t)ops[o].w * ops[o].f;
+  }
+  if (items + 1 > (int64_t)TYPED_MAX_ITEMS)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "%lld sampled slots per root: the typed record encoder holds up to %u",
+                     (long long)items, TYPED_MAX_ITEMS - 1);
+  a.n_ops = n_ops;
+  a.roots = roots;
+  a.root_type = root_node_type;
+  for (int t = 0; t < n_node_types; ++t)
+    if (feats) a.feat[t] = feats[t];
+  a.n_node_types = n_node_types;
+  a.frame = tfrecord_frame ? 1 : 0;
+  a.items = (uint32_t)items;
+  a.pow2 = next_pow2((uint32_t)items + 1);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int32_t rc = ensure_shift_table(ctx);
+  if (rc != GIGL_OK) return rc;
+  a.shift_tbl = ctx->crc_shift_tbl;
+  const int64_t nb = n_records > 0 ? n_records : 1;
+  rc = gigl_arena_reset(ctx, (n_records + 1) * 8 + nb * ((items + 1) * 8 + items * 12 + 16) + 4096);
+  if (rc != GIGL_OK) return rc;
+  int64_t* rec_size = (int64_t*)gigl_arena_alloc(ctx, (n_records + 1) * 8);
+  a.u_nodes = (unsigned long long*)gigl_arena_alloc(ctx, nb * (items + 1) * 8);
+  a.u_edges = (unsigned long long*)gigl_arena_alloc(ctx, nb * (items > 0 ? items : 1) * 8);
+  a.u_etype = (uint32_t*)gigl_arena_alloc(ctx, nb * (items > 0 ? items : 1) * 4);
+  a.u_info = (uint32_t*)gigl_arena_alloc(ctx, nb * 16);
+  if (!rec_size || !a.u_nodes || !a.u_edges || !a.u_etype || !a.u_info) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  const size_t lds_plan = (size_t)a.pow2 * 20, lds_write = ((size_t)items + 2) * 4;
+  if (lds_plan > 60 * 1024)
+    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)typed_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds_plan));
+  if (n_records > 0)
+    hipLaunchKernelGGL(typed_plan_kernel, dim3((unsigned)n_records), dim3(256), lds_plan, ctx->stream, a, rec_size);
+  hipLaunchKernelGGL(record_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, rec_size, n_records, out_cap, rec_off,
+                     status);
+  if (n_records > 0)
+    hipLaunchKernelGGL(typed_write_kernel, dim3((unsigned)n_records), dim3(256), lds_write, ctx->stream, a, rec_off,
+                       status, out);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
 
 }  // extern "C"

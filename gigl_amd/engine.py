@@ -464,6 +464,52 @@ class HipEngine:
         if entry.get("graph"):
             self._lib.gigl_graph_destroy(entry["graph"])
 
+    def encode_typed_records(self, roots: torch.Tensor, root_node_type: int, ops, feats, *, tfrecord_frame: bool = True):
+        """typed (heterogeneous) RootedNodeNeighborhood records on the device (gigl_typed_records_encode).
+        roots: int32 [b] on the device; ops: sequence of (frontier [b, w], nbr [b, w, f], condensed_edge_type,
+        result_node_type, outgoing); feats: per condensed node type a float32 [n, d] device tensor or None.
+        -> (uint8 device tensor of all records back to back, int64 device tensor rec_off[b + 1])"""
+        b = int(roots.numel())
+        roots = roots.to(device=self.device, dtype=torch.int32).contiguous()
+        c_ops = (_lib.GiglTypedOp * len(ops))()
+        keep = [roots]
+        for i, (front, nbr, cet, res_t, outgoing) in enumerate(ops):
+            front = front.to(device=self.device, dtype=torch.int32).contiguous()
+            nbr = nbr.to(device=self.device, dtype=torch.int32).contiguous()
+            keep += [front, nbr]
+            w = int(front.numel() // max(b, 1))
+            f = int(nbr.numel() // max(b * w, 1))
+            c_ops[i].frontier, c_ops[i].nbr = front.data_ptr(), nbr.data_ptr()
+            c_ops[i].w, c_ops[i].f = w, f
+            c_ops[i].condensed_edge_type, c_ops[i].result_node_type = int(cet), int(res_t)
+            c_ops[i].outgoing = 1 if outgoing else 0
+        c_feats = (_lib.GiglTypedFeat * len(feats))()
+        for t, x in enumerate(feats):
+            if x is None:
+                continue
+            x = x.to(device=self.device, dtype=torch.float32).contiguous()
+            keep.append(x)
+            c_feats[t].x, c_feats[t].d, c_feats[t].n = x.data_ptr(), int(x.shape[1]), int(x.shape[0])
+        cap = C.c_int64()
+        rc = self._lib.gigl_typed_records_capacity(c_ops, len(ops), c_feats, len(feats), b, 1 if tfrecord_frame else 0,
+                                                   C.byref(cap))
+        if rc != 0:
+            raise ValueError("gigl_typed_records_capacity: between 1 and 16 ops / node types")
+        out = torch.empty(max(cap.value, 1), dtype=torch.uint8, device=self.device)
+        rec_off = torch.empty(b + 1, dtype=torch.int64, device=self.device)
+        status = torch.zeros(1, dtype=torch.int32, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()  # the op results may come from torch's stream
+        check(self._lib.gigl_typed_records_encode(self._ctx, C.c_void_p(roots.data_ptr()), int(root_node_type), c_ops,
+                                                  len(ops), c_feats, len(feats), b, 1 if tfrecord_frame else 0,
+                                                  C.c_void_p(out.data_ptr()), cap.value,
+                                                  C.c_void_p(rec_off.data_ptr()), C.c_void_p(status.data_ptr())),
+              self._ctx)
+        self._stream.synchronize()
+        if int(status.item()) != 0:
+            raise RuntimeError("gigl_typed_records_encode: output capacity too small (status=1)")
+        del keep
+        return out[: int(rec_off[-1].item())], rec_off
+
     def encode_records(self, tree: Tree, *, kind: int = _lib.REC_ROOTED_NODE_NEIGHBORHOOD, trees_per_record: int = 1,
                        condensed_node_type: Optional[int] = 0, condensed_edge_type: Optional[int] = 0,
                        tfrecord_frame: bool = True, emit: Optional[torch.Tensor] = None,

@@ -239,6 +239,38 @@ class HipGraphDBSampler:
             out.append(self._message(int(root), root_node_type, sorted(nodes), sorted(edges)))
         return out
 
+    def encode_records(self, root_ids: Sequence[int], root_node_type: str, dag: SamplingOpDAG,
+                       tfrecord_frame: bool = True) -> List[bytes]:
+        """the same RootedNodeNeighborhood messages as getKHopSubgraphForRootNodes, serialized ON THE DEVICE
+        (gigl_typed_records_encode: per root the distinct typed nodes and edges of every op, sorted, with the nodes'
+        feature rows) — the host only slices the finished byte string.  Edge feature_values are a host-assembly
+        feature: a sampler built with edge_features raises here."""
+        if self._edge_rows:
+            raise NotImplementedError("typed edge features are hydrated by the host assembly (getKHopSubgraphForRootNodes)")
+        roots = torch.tensor(np.asarray(root_ids, dtype=np.int64).astype(np.uint32).view(np.int32))
+        res = self.run_dag(roots, dag)
+        n_types = max(self.node_types.values()) + 1
+        by_cnt = {c: t for t, c in self.node_types.items()}
+        feats = [self._feature_table(by_cnt[c]) if c in by_cnt else None for c in range(n_types)]
+        ops = []
+        for name, r in res.items():
+            op = dag.nodes[name].sampling_op
+            outgoing = op.sampling_direction == OUTGOING
+            got = self.node_types[op.edge_type.dst_node_type if outgoing else op.edge_type.src_node_type]
+            ops.append((r.frontier, r.nbr, self.condensed_edge_types[op.edge_type], got, outgoing))
+        out, off = self.engine.encode_typed_records(roots.to(self.engine.device), self.node_types[root_node_type], ops,
+                                                    feats, tfrecord_frame=tfrecord_frame)
+        blob, off = out.cpu().numpy().tobytes(), off.cpu().numpy()
+        return [blob[int(off[i]):int(off[i + 1])] for i in range(len(root_ids))]
+
+    def write_tfrecords(self, path: str, root_ids: Sequence[int], root_node_type: str, dag: SamplingOpDAG) -> int:
+        """a part file of the sampler job: the device-encoded frames of encode_records written back to back"""
+        frames = self.encode_records(root_ids, root_node_type, dag, tfrecord_frame=True)
+        with open(path, "wb") as f:
+            for fr in frames:
+                f.write(fr)
+        return len(frames)
+
     def getKHopSubgraphForRootNode(self, root_id: int, root_node_type: str, dag: SamplingOpDAG):
         return self.getKHopSubgraphForRootNodes([root_id], root_node_type, dag)[0]
 

@@ -368,6 +368,38 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
                             const gigl_record_opts* opts, int64_t n_records, uint8_t* out, int64_t out_cap,
                             int64_t* rec_off, int32_t* status);
 
+/* ---- typed (heterogeneous) RootedNodeNeighborhood records of a SamplingOp DAG, encoded on the device.
+ *      Replaces GraphDBSampler's per-root assembly (scala_spark35/common/src/main/scala/graphdb/GraphDBSampler.scala:
+ *      45-113: the union, as sets, of every op's edges and nodes + the root) and the proto cast / TFRecord write of the
+ *      task around it (GraphDBNodeAnchorBasedLinkPredictionTask.scala:62-78).  One gigl_typed_op per sampling op, as
+ *      gigl_rows_dedup + gigl_expand_frontier produced it: `frontier` [b, w] node ids (GIGL_INVALID = none), `nbr`
+ *      [b, w, f] sampled neighbours, the op's condensed edge type, the condensed node type of the ids in `nbr`, and the
+ *      direction (outgoing: edges are frontier -> nbr; else nbr -> frontier).  feats[t]: fp32 feature table of
+ *      condensed node type t (x NULL: nodes of that type carry no feature_values).  Records: root_node = 1 (id, type,
+ *      features), neighborhood = 2 with the distinct nodes ascending by (id, type) and the distinct edges ascending by
+ *      (src, dst, type) — byte-identical to the host assembly in gigl_amd/graphdb_sampler.py.  Edge feature_values
+ *      are not written by this path.  Up to 16 ops, 16 node types, 4095 sampled slots (sum of w*f) per root
+ *      (GIGL_E_UNSUPPORTED beyond).  out / rec_off / status as gigl_records_encode. */
+typedef struct gigl_typed_op {
+  const uint32_t* frontier;
+  const uint32_t* nbr;
+  int32_t w, f;
+  int32_t condensed_edge_type;
+  int32_t result_node_type;
+  int32_t outgoing;
+} gigl_typed_op;
+typedef struct gigl_typed_feat {
+  const float* x; /* device, [n, d] */
+  int32_t d;
+  int64_t n;
+} gigl_typed_feat;
+int32_t gigl_typed_records_capacity(const gigl_typed_op* ops, int32_t n_ops, const gigl_typed_feat* feats,
+                                    int32_t n_node_types, int64_t n_records, int32_t tfrecord_frame, int64_t* bytes);
+int32_t gigl_typed_records_encode(gigl_ctx* ctx, const uint32_t* roots, int32_t root_node_type, const gigl_typed_op* ops,
+                                  int32_t n_ops, const gigl_typed_feat* feats, int32_t n_node_types, int64_t n_records,
+                                  int32_t tfrecord_frame, uint8_t* out, int64_t out_cap, int64_t* rec_off,
+                                  int32_t* status);
+
 /* ---- inference output: (node id, embedding row) batches -> Avro object-container DATA BLOCKS, encoded on the device.
  *      Replaces the record loop of EmbeddingExporter.add_embedding (python/gigl/common/data/export.py:103-135:
  *      {"node_id": int(id), "node_type": type, "emb": row.tolist()} through fastavro.writer) for AVRO_SCHEMA

@@ -176,3 +176,63 @@ def test_reference_heterogeneous_fixture(golden_dir):
             total_edges += len(want_e)
     assert total_edges > 100
     s.close()
+
+
+def test_typed_records_encoded_on_the_device_match_the_host_assembly(world):
+    """gigl_typed_records_encode: the DAG's typed RootedNodeNeighborhood records written on the device are, byte for
+    byte (TFRecord frame and CRCs included), the host assembly's messages; read back by the typed native collate they
+    give the batch graph of HipGraphDBSampler.batch_graph."""
+    from gigl_amd import wire
+    from gigl_amd._lib import REC_ROOTED_NODE_NEIGHBORHOOD
+    from gigl_amd.batches import collate_serialized_typed
+    s, n, edges, feats, nbrs = world
+    rng = np.random.default_rng(11)
+    for ops, root_type, roots in ((_dag_two_paths(), "paper", rng.integers(0, 5000, 70)),
+                                  ([SamplingOp("op0", A2P, 2, [], OUTGOING), SamplingOp("op1", P2V, 1, ["op0"], OUTGOING),
+                                    SamplingOp("op2", P2A, 3, ["op0"], OUTGOING)], "author",
+                                   np.concatenate([[0, 1, 2999], rng.integers(0, 3000, 61)]))):
+        dag = SamplingOpDAG.from_ops(ops)
+        msgs = s.getKHopSubgraphForRootNodes(roots, root_type, dag)
+        framed = s.encode_records(roots, root_type, dag, tfrecord_frame=True)
+        bare = s.encode_records(roots, root_type, dag, tfrecord_frame=False)
+        assert len(framed) == len(msgs) == len(bare)
+        for m, fr, br in zip(msgs, framed, bare):
+            want = m.SerializeToString()
+            assert br == want
+            assert fr == wire.tfrecord_frame(want)
+        # device records -> typed collate == the batch graph built on the device from the same samples
+        ends = [None] * len(CET)
+        for et, c in CET.items():
+            ends[c] = (NODE_TYPES[et.src_node_type], NODE_TYPES[et.dst_node_type])
+        col = collate_serialized_typed(bare, REC_ROOTED_NODE_NEIGHBORHOOD, len(NODE_TYPES), ends)
+        g, root_index, uniq = s.batch_graph(roots, root_type, dag)
+        for tname, c in NODE_TYPES.items():
+            if tname not in uniq:
+                assert col["node_ids"][c].size == 0
+                continue
+            ids = col["node_ids"][c].astype(np.int64)
+            assert np.array_equal(np.sort(ids), uniq[tname].cpu().numpy())
+            order = np.argsort(ids)  # collate numbers first-seen, the device graph ascending
+            np.testing.assert_array_equal(col["x"][c][order], g.x_dict[tname].cpu().numpy())
+        for et, c in CET.items():
+            key = (et.src_node_type, et.relation, et.dst_node_type)
+            ei = col["edge_index"][c]
+            got = set(zip(col["node_ids"][NODE_TYPES[et.src_node_type]][ei[0]].tolist(),
+                          col["node_ids"][NODE_TYPES[et.dst_node_type]][ei[1]].tolist())) if ei.size else set()
+            if key not in g.edge_index_dict:
+                assert not got
+                continue
+            e2 = g.edge_index_dict[key].cpu().numpy()
+            want = set(zip(uniq[et.src_node_type].cpu().numpy()[e2[0]].tolist(),
+                           uniq[et.dst_node_type].cpu().numpy()[e2[1]].tolist()))
+            assert got == want
+        assert np.array_equal(col["root_type"], np.full(len(roots), NODE_TYPES[root_type]))
+        assert np.array_equal(col["node_ids"][NODE_TYPES[root_type]][col["root_local"]].astype(np.int64), np.asarray(roots))
+
+
+def test_typed_record_encoder_limits(world):
+    s = world[0]
+    from gigl_amd import _lib
+    big = [SamplingOp("op0", A2P, 64, [], INCOMING), SamplingOp("op1", A2P, 64, ["op0"], OUTGOING)]  # 64 + 4096 slots
+    with pytest.raises(_lib.GiglError):
+        s.encode_records([1, 2], "paper", SamplingOpDAG.from_ops(big))

@@ -175,3 +175,43 @@ def test_dag_sampler_to_hgt_end_to_end():
         want = F.linear(h["paper"], model.lin.weight, model.lin.bias)[root_index.cpu()]
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
     s.close()
+
+
+def test_typed_records_to_hgt_through_the_trainer_side_loader(tmp_path):
+    """the two halves as the reference wires them: the typed sampler writes TFRecords of RootedNodeNeighborhood
+    (encoded on the device), the trainer-side loader collates them natively into a typed batch graph and HGT embeds the
+    roots — the same embeddings as over the batch graph that never left HBM"""
+    from gigl_amd import wire
+    from gigl_amd.batches import HeteroRootedNodeNeighborhoodBatch
+    from gigl_amd.graphdb_sampler import (INCOMING, OUTGOING, EdgeType, HipGraphDBSampler, SamplingOp, SamplingOpDAG)
+    from gigl_amd.models_hetero import HGT
+    A2P, P2A = EdgeType("author", "writes", "paper"), EdgeType("paper", "written_by", "author")
+    node_types, cet = {"author": 0, "paper": 1}, {A2P: 0, P2A: 1}
+    rng = np.random.default_rng(3)
+    n = {"author": 500, "paper": 900}
+    a = (rng.zipf(1.7, 4000) % n["author"]).astype(np.uint32)
+    p = rng.integers(0, n["paper"], 4000).astype(np.uint32)
+    feats = {"author": rng.standard_normal((500, 6)).astype(np.float32), "paper": rng.standard_normal((900, 10)).astype(np.float32)}
+    s = HipGraphDBSampler(node_types, n, {A2P: (a, p), P2A: (p, a)}, cet, feats)
+    dag = SamplingOpDAG.from_ops([SamplingOp("op0", A2P, 4, [], INCOMING), SamplingOp("op1", A2P, 3, ["op0"], OUTGOING),
+                                  SamplingOp("op2", P2A, 2, ["op1"], OUTGOING)])
+    roots = rng.integers(0, n["paper"], 80)
+    part = str(tmp_path / "part-00000.tfrecord")
+    assert s.write_tfrecords(part, roots, "paper", dag) == 80
+    recs = list(wire.read_tfrecords(part))  # (verifies both CRCs of every frame)
+    batch = HeteroRootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(
+        recs, {0: "author", 1: "paper"}, {0: ("author", "writes", "paper"), 1: ("paper", "written_by", "author")})
+    assert [g for _, g in batch.root_nodes] == roots.tolist()
+    data, root_index, uniq = s.batch_graph(roots, "paper", dag)
+    torch.manual_seed(5)
+    ets = [("author", "writes", "paper"), ("paper", "written_by", "author")]
+    model = HGT({"author": 6, "paper": 10}, {e: 0 for e in ets}, hid_dim=32, out_dim=16, num_layers=2, num_heads=2)
+    model.engine = s.engine
+    model = model.to(s.engine.device)
+    with torch.cuda.stream(s.engine._stream):
+        want = model(data, ["paper"])["paper"][root_index]
+        got = model(batch.graph.to(s.engine.device), ["paper"])["paper"][
+            batch.condensed_node_type_to_root_node_indices_map[1].to(s.engine.device)]
+    s.engine.synchronize()
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    s.close()
