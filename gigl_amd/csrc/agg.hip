@@ -490,7 +490,22 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
   __shared__ short s_w[3][BN * LDK];
   const int M = *m_dev;
   const int tiles_n = (N + BN - 1) / BN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  // Workgroups are dealt to the 8 XCDs round-robin by id and every XCD has its own L2: the column tiles of one row
+  // tile are given ids that differ by 8, so they run on the same XCD back to back and the A tile comes from HBM once
+  // (PMC: FETCH_SIZE of the kernel was 2.1x the A matrix with adjacent ids).
+  int tm, tn;
+  {
+    const unsigned bid = blockIdx.x, span = 8u * (unsigned)tiles_n;
+    const unsigned full = (gridDim.x / span) * span;  // ids beyond the last whole group keep the plain mapping
+    if (bid < full) {
+      const unsigned grp = bid / span, in = bid % span;
+      tm = (int)(grp * 8u + (in & 7u));
+      tn = (int)(in >> 3);
+    } else {
+      tm = (int)(bid / (unsigned)tiles_n);
+      tn = (int)(bid % (unsigned)tiles_n);
+    }
+  }
   const int m0b = tm * BM, n0b = tn * BN;
   if (m0b >= M) return;  // whole workgroup
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
