@@ -60,7 +60,8 @@ class GnnTrainingProcess:
         world = int(os.environ.get("WORLD_SIZE", "1"))
         started_pg = False
         if world > 1 and not dist.is_initialized():
-            backend = "nccl" if device.type == "cuda" else "gloo"
+            # (GIGL_DIST_BACKEND: e.g. gloo when several ranks share one GPU, where RCCL refuses duplicate devices)
+            backend = os.environ.get("GIGL_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
             dist.init_process_group(backend=backend)
             started_pg = True
         try:

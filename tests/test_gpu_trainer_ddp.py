@@ -1,0 +1,87 @@
+"""Trainer at world size 2 (training_process.py:86-119: DistributedDataParallel around the spec's model, records
+sharded by rank, metrics all-reduced): two processes train the reference's node-classification fixture, the
+gradients are averaged by DDP — both ranks end with the SAME weights, which differ from what either rank's half of the
+data alone gives — and rank 0 writes the model and the metrics file.
+  * two processes sharing the test GPU over gloo (runs on the 1-GPU boxes);
+  * two RCCL ranks on two GPUs (self-skips below 2 devices)."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CFG = "configs/snc_frozen_gbml_config.yaml"
+
+
+def _worker(rank, world, port, backend, workdir, q):
+    try:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank if backend == "nccl" else 0),
+                          MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GIGL_DIST_BACKEND=backend)
+        from gigl_amd.trainer import Trainer
+        torch.manual_seed(0)
+        tr = Trainer()
+        metrics = tr.run("job", CFG, None, uri_base=workdir)
+        spec = tr.training_process.trainer
+        model = spec.model.module if hasattr(spec.model, "module") else spec.model
+        flat = torch.cat([p.detach().float().cpu().reshape(-1) for p in model.parameters()]).numpy()
+        q.put((rank, "ok", flat, float(metrics.metrics["acc"].value), [h["loss"] for h in spec.history],
+               type(spec.model).__name__))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc() + repr(e), None, None, None))
+
+
+def _run(world, backend, golden_dir, tmp_path):
+    import torch.multiprocessing as mp
+    base = tmp_path / "ddp"
+    shutil.copytree(os.path.join(golden_dir, "configs"), base / "configs")
+    shutil.copytree(os.path.join(golden_dir, "ref_assets"), base / "ref_assets")
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    SubgraphSampler().run("job", CFG, None, uri_base=str(base))
+    # the reference shards FILES across ranks (data_loaders/utils.py:23-56): two part files -> each rank its own half
+    from gigl_amd import wire
+    from gigl_amd.config import GbmlConfigPbWrapper, tfrecord_files
+    cfg = GbmlConfigPbWrapper.from_uri(CFG, uri_base=str(base))
+    files = tfrecord_files(cfg.labeled_tfrecord_uri_prefix)
+    recs = [r for f in files for r in wire.read_tfrecords(f)]
+    assert len(recs) == 14
+    for f in files:
+        os.remove(f)
+    d = os.path.dirname(files[0])
+    wire.write_tfrecords(os.path.join(d, "part-00000.tfrecord"), recs[:7])
+    wire.write_tfrecords(os.path.join(d, "part-00001.tfrecord"), recs[7:])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + os.getpid() % 40
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, str(base), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    for rank, status, info, *_ in res:
+        assert status == "ok", f"rank {rank}: {info}"
+    (_, _, w0, acc0, loss0, kind0), (_, _, w1, acc1, loss1, kind1) = res
+    assert kind0 == kind1 == "DistributedDataParallel"
+    np.testing.assert_array_equal(w0, w1)          # one model: DDP averaged the gradients of the two halves
+    assert acc0 == acc1                            # metrics are all-reduced
+    assert all(np.isfinite(loss0)) and all(np.isfinite(loss1)) and loss0 != loss1  # each rank saw its own records
+    sd = torch.load(cfg.trained_model_uri, map_location="cpu")  # written by rank 0, without the DDP prefix
+    assert "conv_layers.0.lin_l.weight" in sd
+    np.testing.assert_array_equal(torch.cat([v.float().reshape(-1) for v in sd.values()]).numpy().sum(), w0.sum())
+    assert json.load(open(cfg.eval_metrics_uri))["metrics"][0]["name"] == "acc"
+
+
+def test_two_ranks_on_one_gpu_over_gloo(golden_dir, tmp_path):
+    _run(2, "gloo", golden_dir, tmp_path)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the build boxes have one)")
+def test_two_rccl_ranks_on_two_gpus(golden_dir, tmp_path):
+    _run(2, "nccl", golden_dir, tmp_path)
