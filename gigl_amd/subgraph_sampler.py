@@ -286,7 +286,14 @@ class SubgraphSampler:
                 cols.append(neg.view(-1, Q))
             grouped = torch.cat(cols, dim=1).reshape(-1).contiguous()
             tree = eng.sample_khop(grouped, cfg.fanouts, sampling_seed=svc.sampling_seed, mode=getattr(svc, 'sampling_mode', 0))
-            emit = cnt > 0  # anchors need at least one positive
+            # anchors need at least one positive and, in the task without user-defined labels, a neighbourhood of their
+            # own: the reference INNER JOINs the sampled positives with subgraphVIEW, which holds the roots with at least
+            # one in-edge (NodeAnchorBasedLinkPredictionTask.scala:186-194; createSubgraph "does not include isolated
+            # nodes", :69).  The user-defined-labels task joins against the RootedNodeNeighborhood view instead, which
+            # has the neighbourless nodes too (UserDefinedLabelsNodeAnchorBasedLinkPredictionTask.scala:365-384).
+            emit = cnt > 0
+            if not (pos_ud or neg_ud):
+                emit = emit & (tree.cnt[0].view(-1, T)[:, 0] > 0)
             if limit > 0:
                 emit = emit & ((torch.cumsum(emit.to(torch.int64), 0) + main.n_records) <= limit)
             buf, off = eng.encode_records(tree, kind=_lib.REC_NODE_ANCHOR_LINK_PRED, trees_per_record=T,

@@ -402,3 +402,37 @@ def test_subgraph_sampler_caps_training_samples(workdir):
     unl = [r for f in files["unlabeled"] for r in wire.read_tfrecords(f)]
     assert len(lab) == 5 and len(unl) == 16
     assert [s.root_node.node_id for s in lab] == [0, 1, 2, 3, 4]
+
+
+def test_link_prediction_on_a_directed_graph_skips_anchors_without_in_edges(workdir):
+    """directed graph: an anchor with out-edges (positives exist) but no in-edge has no rooted subgraph in the
+    reference's subgraphVIEW, and the INNER JOIN of NodeAnchorBasedLinkPredictionTask.scala:186-194 drops it — no main
+    sample for it, while its RootedNodeNeighborhood (random-negative stream) is still written"""
+    import yaml
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    doc = yaml.safe_load(open(os.path.join(workdir, "configs/nablp_frozen_gbml_config.yaml")))
+    doc["sharedConfig"]["isGraphDirected"] = True
+    flat = doc["sharedConfig"]["flattenedGraphMetadata"]["nodeAnchorBasedLinkPredictionOutput"]
+    flat["tfrecordUriPrefix"] = "out/nablp_dir/main/"
+    flat["nodeTypeToRandomNegativeTfrecordUriPrefix"] = {k: "out/nablp_dir/rn/" + k + "/"
+                                                         for k in flat["nodeTypeToRandomNegativeTfrecordUriPrefix"]}
+    yaml.safe_dump(doc, open(os.path.join(workdir, "configs/nablp_dir_gbml_config.yaml"), "w"))
+    SubgraphSampler().run("job", "configs/nablp_dir_gbml_config.yaml", None, uri_base=workdir)
+    cfg = GbmlConfigPbWrapper.from_uri("configs/nablp_dir_gbml_config.yaml", uri_base=workdir)
+    smp = [wire.NodeAnchorBasedLinkPredictionSample.FromString(r) for f in tfrecord_files(cfg.nablp_tfrecord_uri_prefix)
+           for r in wire.read_tfrecords(f)]
+    rn = [wire.RootedNodeNeighborhood.FromString(r) for p in cfg.random_negative_tfrecord_uri_prefixes.values()
+          for f in tfrecord_files(p) for r in wire.read_tfrecords(f)]
+    edge_rows = [wire.decode_tf_example(r) for f in tfrecord_files(os.path.join(
+        workdir, "ref_assets/subgraph_sampler/node_anchor_based_link_prediction/edge_data/")) for r in wire.read_tfrecords(f)]
+    edges = {(int(np.ravel(r["src"])[0]), int(np.ravel(r["dst"])[0])) for r in edge_rows}
+    has_in, has_out = {d for _, d in edges}, {s for s, _ in edges}
+    only_out = has_out - has_in
+    assert only_out, "the fixture has nodes with out-edges only when read as a directed graph"
+    anchors = {s.root_node.node_id for s in smp}
+    assert anchors == (has_out & has_in)                 # a positive AND a neighbourhood of its own
+    assert not (anchors & only_out)
+    assert len(rn) == 27                                  # every node still gets its RootedNodeNeighborhood
+    for s in smp:
+        for e in s.neighborhood.edges:
+            assert (e.src_node_id, e.dst_node_id) in edges   # directed: edges as given, never reversed
