@@ -181,6 +181,7 @@ def main():
                          "feature pull over RCCL — needs >= 2 GPUs at full size (--shard-scale shrinks it)")
     ap.add_argument("--shard-group", type=int, default=16,
                     help="mag240m-sharded: batches of B roots exchanged per set of collectives (dedup stays per batch)")
+    ap.add_argument("--shard-plans", type=int, default=3, help="mag240m-sharded: sharded plans in flight per rank")
     ap.add_argument("--shard-scale", type=float, default=1.0,
                     help="mag240m-sharded: fraction of MAG240M's nodes and edges to generate (1.0 needs 8 GPUs' HBM)")
     ap.add_argument("--project-on-owner", action="store_true",
@@ -599,7 +600,7 @@ def run_sharded(args, rank, world, local_rank):
     mwe = bound if bound < (1 << 30) else -1
     # G consecutive batches travel together: one set of exchanges and launches per G steps; the union graph keeps the
     # batches apart (dedup within a batch only), so a step's edges are those of its batch
-    G, S = max(1, args.shard_group), 2
+    G, S = max(1, args.shard_group), max(1, args.shard_plans)
     rnd = S * G
     K_rep = max(-(-K // rnd), args.min_rounds) * rnd
     Wp = -(-max(W, 1) // rnd) * rnd
@@ -733,7 +734,7 @@ def run_sharded(args, rank, world, local_rank):
             "config": {"workload": f"MAG240M-shaped RMAT x{args.shard_scale:g}: N={n} E={int(e_local.item())} directed, "
                                    f"D={d} fp16 features, hash-partitioned over {world} rank(s) (owner = id % world), "
                                    f"fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}, sampler mode=parity, "
-                                   f"{G} batches per exchange, 2 plans in flight, "
+                                   f"{G} batches per exchange, {S} plans in flight, "
                                    f"{'rows projected on the owner (256 fp32)' if args.project_on_owner else 'raw rows (768 fp16)'}",
                        "graph": "CSC rows + feature rows of the owned nodes per rank; per-hop all-to-all frontier "
                                 "exchange and feature pull of the unique union-graph nodes, issued by the library "
