@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
                                                           const int32_t* __restrict__ col,
                                                           const int32_t* __restrict__ n_rows_dev,
                                                           float* __restrict__ out,
-                                                          const int32_t* __restrict__ n_local_dev) {
+                                                          const int32_t* __restrict__ n_local_dev, int tiled_nkc) {
   constexpr int G = 64 / LPR;  // source rows per wave-instruction
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR;  // which source row of the instruction
@@ -127,12 +127,29 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
         acc[v] = aggr_combine<OP>(acc[v], o4);
       }
     }
-    float* o = out + (int64_t)i * 2 * d;
     const T* ps = src + (int64_t)self * d;
+    // mean = sum / deg (a true division, like torch's scatter-mean), 0 for an empty row
+    const float dv = (OP == GIGL_AGGR_MEAN && m > 0) ? (float)m : 1.f;
+    const float4_t none4 = {0.f, 0.f, 0.f, 0.f};
+    if (tiled_nkc) {  // the projection's operand layout: [row tile of 128][K chunk of 32][128 rows][32 floats]
+      float* tbase = out + ((int64_t)(i >> 7) * tiled_nkc) * 4096 + (i & 127) * 32;
+      if (sub == 0) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int el = (v * LPR + sl) * 4;
+          if (el < d)
+            *reinterpret_cast<float4_t*>(tbase + (int64_t)(el >> 5) * 4096 + (el & 31)) =
+                (OP == GIGL_AGGR_MAX && m == 0) ? none4 : acc[v] / dv;
+        }
+      }
+      for (int el = lane * 4; el < d; el += 64 * 4) {
+        const int k = d + el;
+        *reinterpret_cast<float4_t*>(tbase + (int64_t)(k >> 5) * 4096 + (k & 31)) = RowLoader<T>::load4(ps, el);
+      }
+      continue;
+    }
+    float* o = out + (int64_t)i * 2 * d;
     if (sub == 0) {
-      // mean = sum / deg (a true division, like torch's scatter-mean), 0 for an empty row
-      const float dv = (OP == GIGL_AGGR_MEAN && m > 0) ? (float)m : 1.f;
-      const float4_t none4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int v = 0; v < VPL; ++v) {
         const int el = (v * LPR + sl) * 4;
@@ -483,7 +500,7 @@ template <int NJ>
 __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            const int32_t* __restrict__ m_dev, int K, int N, int act,
-                                                           float* __restrict__ y) {
+                                                           float* __restrict__ y, int a_tiled) {
   constexpr int BK = 32, LDK = 40;          // bf16 elements per LDS row (32 + 8 of padding = 80 bytes)
   constexpr int BM = 128, BN = 64 * NJ;
   __shared__ short s_a[3][BM * LDK];
@@ -527,10 +544,13 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
   float4_t ga[2][4], gw[2][2 * NJ];
   auto gload = [&](int k0, float4_t (&da)[4], float4_t (&dw)[2 * NJ]) {
     const int kk = k0 + lc * 4;
+    // (a_tiled: A is stored [row tile of 128][K chunk of 32][128][32] — this tile's chunk is 16 KB contiguous)
+    const float* at = a + ((int64_t)tm * a_tiled + (k0 >> 5)) * 4096 + lc * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = m0b + lr + 32 * i;
-      da[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(a + (int64_t)row * K + kk) : zero4;
+      const float* src = a_tiled ? at + (lr + 32 * i) * 32 : a + (int64_t)row * K + kk;
+      da[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(src) : zero4;
     }
 #pragma unroll
     for (int i = 0; i < 2 * NJ; ++i) {
@@ -1567,7 +1587,7 @@ template <typename T>
 int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather_ids,
                       const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                       const int32_t* n_rows_dev, int64_t rows_cap, float* out, int op = GIGL_AGGR_MEAN,
-                      const int32_t* n_local_dev = nullptr) {
+                      const int32_t* n_local_dev = nullptr, int tiled_nkc = 0) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
@@ -1576,7 +1596,7 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
   const int vecs = d / 4;
 #define GLO(LPR, VPL, OP)                                                                            \
   hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, 0, st, src, d, gather_ids, rowptr, \
-                     rowend, col, n_rows_dev, out, n_local_dev)
+                     rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc)
 #define GL(LPR, VPL)                                        \
   do {                                                      \
     if (op == GIGL_AGGR_MEAN) GLO(LPR, VPL, GIGL_AGGR_MEAN); \
@@ -1584,6 +1604,7 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
     else GLO(LPR, VPL, GIGL_AGGR_MAX);                      \
   } while (0)
   if ((d & 3) != 0 || vecs > 512) {
+    if (tiled_nkc) return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the tiled operand layout needs d %% 4 == 0 and d <= 2048");
     hipLaunchKernelGGL((gather_mean_generic_kernel<T>), g, b, 0, st, src, d, gather_ids, rowptr, rowend,
                        col, n_rows_dev, out, op, n_local_dev);
   } else if (vecs <= 8) GL(8, 1);
@@ -1645,15 +1666,15 @@ int32_t gigl_gather_reduce(gigl_ctx* ctx, const void* src, int32_t src_dtype, in
 int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* gather_ids,
                                  const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                                  const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
-                                 const int32_t* n_local_rows_dev, float* out) {
+                                 const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc) {
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   if (src_dtype == GIGL_DTYPE_F32)
     return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
-                                aggr, n_local_rows_dev);
+                                aggr, n_local_rows_dev, tiled_nkc);
   return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
-                               aggr, n_local_rows_dev);
+                               aggr, n_local_rows_dev, tiled_nkc);
 }
 
 extern "C" {
@@ -1879,10 +1900,10 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
     const int64_t bm = (m_cap + 127) / 128;
     if (n > 64)
       hipLaunchKernelGGL((linear_split_kernel<2>), dim3((unsigned)(bm * ((n + 127) / 128))), dim3(256), 0, st, a, w,
-                         bias, m_dev, k, n, act, y);
+                         bias, m_dev, k, n, act, y, 0);
     else
       hipLaunchKernelGGL((linear_split_kernel<1>), dim3((unsigned)(bm * ((n + 63) / 64))), dim3(256), 0, st, a, w,
-                         bias, m_dev, k, n, act, y);
+                         bias, m_dev, k, n, act, y, 0);
   } else if ((k & 3) == 0) {  // LDS-staged, coalesced operand fetch
     const int64_t bm = (m_cap + 127) / 128;
     if (n > 32) {
@@ -1908,3 +1929,25 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
 }
 
 }  // extern "C"
+
+// the projection over an A operand in the tiled layout gigl_gather_reduce_mixed(..., tiled_nkc) writes
+// ([row tile of 128][K chunk of 32][128 rows][32 floats], tiled_nkc = ceil(k / 32)); k % 4 == 0
+int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
+                          int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y) {
+  GIGL_REQUIRE(ctx, a_tiled && w && m_dev && y && (k & 3) == 0 && n > 0, "bad arguments");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (m_cap == 0) return GIGL_OK;
+  hipStream_t st = ctx->stream;
+  gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
+  const int nkc = (k + 31) / 32;
+  const int64_t bm = (m_cap + 127) / 128;
+  if (n > 64)
+    hipLaunchKernelGGL((linear_split_kernel<2>), dim3((unsigned)(bm * ((n + 127) / 128))), dim3(256), 0, st, a_tiled, w,
+                       bias, m_dev, k, n, act, y, nkc);
+  else
+    hipLaunchKernelGGL((linear_split_kernel<1>), dim3((unsigned)(bm * ((n + 63) / 64))), dim3(256), 0, st, a_tiled, w,
+                       bias, m_dev, k, n, act, y, nkc);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+

@@ -47,6 +47,9 @@ struct gigl_sage_plan {
   gigl_tree tree{};
   gigl_union un{};
   float* abuf = nullptr;  // [act_rows][2*max_in], act_rows = b*(1 + f0 + f0*f1 + ...) over hops-1 terms
+  // the aggregated matrix in the projection's tiled layout ([row tile of 128][K chunk of 32][128][32]): a tile's chunk
+  // is 16 KB contiguous instead of 128 pieces of 128 B at a stride of one row (agg.hip)
+  bool tiled = false;
   float* hbuf[2] = {nullptr, nullptr};  // ping-pong [act_rows][max_out]
   std::vector<void*> owned;
   // hipGraph replay
@@ -192,7 +195,17 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
     rows_cap += width;
     width *= p->fanouts[i];
   }
+  const int32_t nkc = p->tiled ? (2 * d + 31) / 32 : 0;
   if (((s - 2) & 1) == 0) {
+    if (p->tiled) {
+      if (l == 0)  // (leaf-global: rows of level L-1 — >= the count through level L-2 — hold global source ids)
+        return gigl_gather_reduce_mixed(
+            ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend, p->un.col, n_rows, rows_cap,
+            GIGL_AGGR_MEAN, p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr,
+            p->abuf, nkc);
+      return gigl_gather_reduce_mixed(ctx, p->hbuf[(l - 1) & 1], GIGL_DTYPE_F32, d, nullptr, p->un.rowptr, p->un.rowend,
+                                      p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN, nullptr, p->abuf, nkc);
+    }
     if (l == 0 && p->leaf_global)  // rows of level L-1 (>= the count through level L-2) hold global source ids
       return gigl_gather_reduce_mixed(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend,
                                       p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN,
@@ -204,6 +217,9 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
                             p->un.col, n_rows, rows_cap, p->abuf);
   }
   const int act = (l < L - 1 || p->act_last) ? 1 : 0;
+  if (p->tiled)
+    return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
+                             p->hbuf[l & 1]);
   return gigl_linear(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
                      p->hbuf[l & 1]);
 }
@@ -357,7 +373,13 @@ int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat,
     act_rows += width;
     width *= fanouts[k];
   }
-  p->abuf = (float*)alloc((size_t)act_rows * 2 * max_in * 4);
+  p->tiled = getenv("GIGL_PLAN_ROW_MAJOR") == nullptr;  // (A/B knob)
+  for (int k = 0; k < hops; ++k)
+    if ((dims[k] & 3) != 0 || dims[k] > 2048) p->tiled = false;
+  {
+    const size_t row_tiles = ((size_t)act_rows + 127) / 128, nkc = ((size_t)2 * max_in + 31) / 32;
+    p->abuf = (float*)alloc(p->tiled ? row_tiles * nkc * 4096 * 4 : (size_t)act_rows * 2 * max_in * 4);
+  }
   p->hbuf[0] = (float*)alloc((size_t)act_rows * max_out * 4);
   p->hbuf[1] = hops > 1 ? (float*)alloc((size_t)act_rows * max_out * 4) : p->hbuf[0];
   p->roots_buf = (uint32_t*)alloc((size_t)b * 4);
