@@ -45,7 +45,7 @@ SYMBOLS = [
     "gigl_split_hash_slots", "gigl_hgt_aggregate", "gigl_simplehgn_alpha", "gigl_weighted_aggregate",
     "gigl_collate_typed_records", "gigl_collated_typed_info", "gigl_collated_typed_nodes", "gigl_collated_typed_edges",
     "gigl_collated_typed_samples", "gigl_collated_typed_destroy", "gigl_typed_records_capacity",
-    "gigl_typed_records_encode",
+    "gigl_typed_records_encode", "gigl_hgt_aggregate_backward", "gigl_weighted_aggregate_backward",
 ]
 
 KERNEL_IDS = {
@@ -203,6 +203,8 @@ def load() -> C.CDLL:
         "gigl_hgt_aggregate": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp],
         "gigl_simplehgn_alpha": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i32, C.c_float, vp, vp],
         "gigl_weighted_aggregate": [vp, vp, vp, i32, i32, vp, vp, i64, vp],
+        "gigl_hgt_aggregate_backward": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp],
+        "gigl_weighted_aggregate_backward": [vp, vp, vp, i32, i32, vp, vp, i64, vp, vp, vp],
         "gigl_comm_unique_id": [vp],
         "gigl_dist_init": [vp, i32, i32, vp, P(vp)],
         "gigl_dist_init_local": [P(vp), i32, P(vp)],

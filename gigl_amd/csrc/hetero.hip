@@ -116,6 +116,134 @@ __global__ __launch_bounds__(256) void weighted_aggregate_kernel(const float* __
   }
 }
 
+// Backward of hgt_aggregate_kernel: one wave per destination row.  The softmax statistics are recomputed (first pass over
+// the row's edges: running max and sum per head), then with alpha_e = exp(logit_e - m) / s and D_i = <dout_i, out_i>
+// per head (= sum_e alpha_e <dout_i, v_e>):
+//     dv[j]  += alpha_e * dout_i                        (atomics: a source row has many destinations)
+//     dlogit  = alpha_e * (<dout_i, v_e> - D_i)
+//     dq[i]  += dlogit * scale * k_e    dk[j] += dlogit * scale * q_i    dp_rel[t][h] += dlogit * <q_i, k_e> / sqrt(D)
+// with scale = p_rel[t][h] / sqrt(D).  dq is accumulated in registers and written once.
+template <int PASSES>
+__global__ __launch_bounds__(256) void hgt_aggregate_backward_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, int heads, int dim,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ etype,
+    const float* __restrict__ p_rel, int64_t n_dst, const float* __restrict__ out, const float* __restrict__ dout,
+    float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv, float* __restrict__ dp_rel) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n_dst) return;
+  const int hd = heads * dim;
+  const int lph = dim / 4;
+  const float inv_sqrt_d = 1.0f / sqrtf((float)dim);
+  float4 qv[PASSES], go[PASSES], gq[PASSES];
+  float m[PASSES], s[PASSES], di[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int c = (p * 64 + lane) * 4;
+    const bool in = c < hd;
+    qv[p] = in ? *(const float4*)(q + i * hd + c) : make_float4(0, 0, 0, 0);
+    go[p] = in ? *(const float4*)(dout + i * hd + c) : make_float4(0, 0, 0, 0);
+    const float4 o = in ? *(const float4*)(out + i * hd + c) : make_float4(0, 0, 0, 0);
+    di[p] = head_sum(go[p].x * o.x + go[p].y * o.y + go[p].z * o.z + go[p].w * o.w, lph);
+    gq[p] = make_float4(0, 0, 0, 0);
+    m[p] = -INFINITY;
+    s[p] = 0.f;
+  }
+  const int32_t e0 = rowptr[i], e1 = rowptr[i + 1];
+  for (int32_t e = e0; e < e1; ++e) {  // softmax statistics
+    const int64_t j = col[e];
+    const int t = etype ? etype[e] : 0;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int c = (p * 64 + lane) * 4;
+      const bool in = c < hd;
+      const float4 kv = in ? *(const float4*)(k + j * hd + c) : make_float4(0, 0, 0, 0);
+      const float d = head_sum(qv[p].x * kv.x + qv[p].y * kv.y + qv[p].z * kv.z + qv[p].w * kv.w, lph);
+      const int h = in ? c / dim : 0;
+      const float logit = d * (p_rel ? p_rel[t * heads + h] : 1.f) * inv_sqrt_d;
+      const float mn = fmaxf(m[p], logit);
+      s[p] = s[p] * expf(m[p] - mn) + expf(logit - mn);
+      m[p] = mn;
+    }
+  }
+  for (int32_t e = e0; e < e1; ++e) {
+    const int64_t j = col[e];
+    const int t = etype ? etype[e] : 0;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int c = (p * 64 + lane) * 4;
+      if (c >= hd) continue;  // (whole head groups are in or out together: head_sum stays inside the active lanes)
+      const float4 kv = *(const float4*)(k + j * hd + c);
+      const float4 vv = *(const float4*)(v + j * hd + c);
+      const float d = head_sum(qv[p].x * kv.x + qv[p].y * kv.y + qv[p].z * kv.z + qv[p].w * kv.w, lph);
+      const int h = c / dim;
+      const float pr = p_rel ? p_rel[t * heads + h] : 1.f;
+      const float alpha = expf(d * pr * inv_sqrt_d - m[p]) / s[p];
+      const float da = head_sum(go[p].x * vv.x + go[p].y * vv.y + go[p].z * vv.z + go[p].w * vv.w, lph);
+      const float dl = alpha * (da - di[p]);
+      const float sc = dl * pr * inv_sqrt_d;
+      float* gv = dv + j * hd + c;
+      atomicAdd(gv + 0, alpha * go[p].x);
+      atomicAdd(gv + 1, alpha * go[p].y);
+      atomicAdd(gv + 2, alpha * go[p].z);
+      atomicAdd(gv + 3, alpha * go[p].w);
+      float* gk = dk + j * hd + c;
+      atomicAdd(gk + 0, sc * qv[p].x);
+      atomicAdd(gk + 1, sc * qv[p].y);
+      atomicAdd(gk + 2, sc * qv[p].z);
+      atomicAdd(gk + 3, sc * qv[p].w);
+      gq[p].x += sc * kv.x;
+      gq[p].y += sc * kv.y;
+      gq[p].z += sc * kv.z;
+      gq[p].w += sc * kv.w;
+      if (dp_rel && (c % dim) == 0) atomicAdd(dp_rel + t * heads + h, dl * d * inv_sqrt_d);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int c = (p * 64 + lane) * 4;
+    if (c < hd) *(float4*)(dq + i * hd + c) = gq[p];
+  }
+}
+
+// backward of weighted_aggregate_kernel: dalpha[e][h] = <dout_i[h], v_j[h]>, dv[j] += alpha[e][h] * dout_i
+template <int PASSES>
+__global__ __launch_bounds__(256) void weighted_aggregate_backward_kernel(
+    const float* __restrict__ alpha, const float* __restrict__ v, int heads, int dim, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ col, int64_t n_dst, const float* __restrict__ dout, float* __restrict__ dalpha,
+    float* __restrict__ dv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= n_dst) return;
+  const int hd = heads * dim;
+  const int lph = dim / 4;
+  float4 go[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int c = (p * 64 + lane) * 4;
+    go[p] = c < hd ? *(const float4*)(dout + i * hd + c) : make_float4(0, 0, 0, 0);
+  }
+  const int32_t e0 = rowptr[i], e1 = rowptr[i + 1];
+  for (int32_t e = e0; e < e1; ++e) {
+    const int64_t j = col[e];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int c = (p * 64 + lane) * 4;
+      if (c >= hd) continue;
+      const int h = c / dim;
+      const float4 vv = *(const float4*)(v + j * hd + c);
+      const float da = head_sum(go[p].x * vv.x + go[p].y * vv.y + go[p].z * vv.z + go[p].w * vv.w, lph);
+      if ((c % dim) == 0) dalpha[(int64_t)e * heads + h] = da;
+      const float w = alpha[(int64_t)e * heads + h];
+      float* gv = dv + j * hd + c;
+      atomicAdd(gv + 0, w * go[p].x);
+      atomicAdd(gv + 1, w * go[p].y);
+      atomicAdd(gv + 2, w * go[p].z);
+      atomicAdd(gv + 3, w * go[p].w);
+    }
+  }
+}
+
 __device__ __forceinline__ void atomic_max_float(float* addr, float val) {
   // floats order like sign-magnitude integers: positive values as int, negative as reversed unsigned
   if (val >= 0.f) atomicMax((int*)addr, __float_as_int(val));
@@ -242,6 +370,52 @@ int32_t gigl_simplehgn_alpha(gigl_ctx* ctx, const float* hl, const float* hr, co
                      n_edges, heads, negative_slope, gmax, alpha);
   hipLaunchKernelGGL(shgn_expsum_kernel, grid(ne), dim3(256), 0, ctx->stream, src, n_edges, heads, gmax, gsum, alpha);
   hipLaunchKernelGGL(shgn_normalise_kernel, grid(ne), dim3(256), 0, ctx->stream, src, n_edges, heads, gsum, alpha);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_hgt_aggregate_backward(gigl_ctx* ctx, const float* q, const float* k, const float* v, int32_t heads,
+                                    int32_t dim, const int32_t* rowptr, const int32_t* col, const int32_t* etype,
+                                    const float* p_rel, int64_t n_dst, const float* out, const float* dout, float* dq,
+                                    float* dk, float* dv, float* dp_rel) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, n_dst >= 0 && (n_dst == 0 || (q && k && v && rowptr && col && out && dout && dq && dk && dv)),
+               "null argument");
+  int32_t rc = check_shape(ctx, heads, dim);
+  if (rc != GIGL_OK) return rc;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (n_dst == 0) return GIGL_OK;
+  const int passes = (heads * dim + 255) / 256;
+  const dim3 grid((unsigned)((n_dst + 3) / 4)), block(256);
+#define GIGL_LAUNCH_HGTB(P)                                                                                          \
+  hipLaunchKernelGGL(hgt_aggregate_backward_kernel<P>, grid, block, 0, ctx->stream, q, k, v, heads, dim, rowptr, col, \
+                     etype, p_rel, n_dst, out, dout, dq, dk, dv, dp_rel)
+  if (passes == 1) GIGL_LAUNCH_HGTB(1);
+  else if (passes == 2) GIGL_LAUNCH_HGTB(2);
+  else GIGL_LAUNCH_HGTB(4);
+#undef GIGL_LAUNCH_HGTB
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_weighted_aggregate_backward(gigl_ctx* ctx, const float* alpha, const float* v, int32_t heads, int32_t dim,
+                                         const int32_t* rowptr, const int32_t* col, int64_t n_dst, const float* dout,
+                                         float* dalpha, float* dv) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, n_dst >= 0 && (n_dst == 0 || (alpha && v && rowptr && col && dout && dalpha && dv)), "null argument");
+  int32_t rc = check_shape(ctx, heads, dim);
+  if (rc != GIGL_OK) return rc;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (n_dst == 0) return GIGL_OK;
+  const int passes = (heads * dim + 255) / 256;
+  const dim3 grid((unsigned)((n_dst + 3) / 4)), block(256);
+#define GIGL_LAUNCH_WAB(P)                                                                                            \
+  hipLaunchKernelGGL(weighted_aggregate_backward_kernel<P>, grid, block, 0, ctx->stream, alpha, v, heads, dim, rowptr, \
+                     col, n_dst, dout, dalpha, dv)
+  if (passes == 1) GIGL_LAUNCH_WAB(1);
+  else if (passes == 2) GIGL_LAUNCH_WAB(2);
+  else GIGL_LAUNCH_WAB(4);
+#undef GIGL_LAUNCH_WAB
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -790,6 +790,27 @@ class HipEngine:
         check(self._lib.gigl_hgt_aggregate(self._ctx, p(q), p(k), p(v), heads, dim, p(rowptr), p(col), p(etype),
                                            p(p_rel), n_dst, p(out)), self._ctx)
 
+    def hgt_aggregate_backward(self, q, k, v, heads: int, dim: int, rowptr, col, etype, p_rel, n_dst: int, out, dout):
+        """-> (dq, dk, dv, dp_rel): gigl_hgt_aggregate_backward"""
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        dout = dout.contiguous()
+        dq = torch.zeros_like(q)
+        dk, dv = torch.zeros_like(k), torch.zeros_like(v)
+        dp = torch.zeros_like(p_rel) if p_rel is not None else None
+        check(self._lib.gigl_hgt_aggregate_backward(self._ctx, p(q), p(k), p(v), heads, dim, p(rowptr), p(col), p(etype),
+                                                    p(p_rel), n_dst, p(out), p(dout), p(dq), p(dk), p(dv), p(dp)),
+              self._ctx)
+        return dq, dk, dv, dp
+
+    def weighted_aggregate_backward(self, alpha, v, heads: int, dim: int, rowptr, col, n_dst: int, dout):
+        """-> (dalpha [E, heads], dv): gigl_weighted_aggregate_backward"""
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        dout = dout.contiguous()
+        dalpha, dv = torch.zeros_like(alpha), torch.zeros_like(v)
+        check(self._lib.gigl_weighted_aggregate_backward(self._ctx, p(alpha), p(v), heads, dim, p(rowptr), p(col), n_dst,
+                                                         p(dout), p(dalpha), p(dv)), self._ctx)
+        return dalpha, dv
+
     def simplehgn_alpha(self, hl, hr, het, hef, src, dst, etype, n_nodes: int, heads: int, slope: float):
         """-> alpha [E, heads] (softmax over the edges sharing a SOURCE node), in the order of src / dst / etype"""
         ne = int(src.numel())

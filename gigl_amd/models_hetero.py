@@ -54,12 +54,84 @@ def _engine_for(module: nn.Module, t: torch.Tensor):
 
 
 def _linear(eng, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
-    """x [m, k] @ w[n, k]^T + b on the fp32 MFMA GEMM"""
+    """x [m, k] @ w[n, k]^T + b on the fp32 MFMA GEMM (under autograd: with its two backward GEMMs)"""
     x = x.contiguous().to(torch.float32)
     m = torch.tensor([x.shape[0]], dtype=torch.int32, device=x.device)
     if x.shape[0] == 0:
         return x.new_zeros((0, w.shape[0]))
+    if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+        from .models_attn import _LinearFn
+        y = _LinearFn.apply(x, w, eng, m)
+        return y + b if b is not None else y
     return eng.linear(x, w.contiguous(), b, m, int(x.shape[0]), 0)
+
+
+class _HgtAggFn(torch.autograd.Function):
+    """gigl_hgt_aggregate / gigl_hgt_aggregate_backward"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, p_rel, eng, heads, dim, rowptr, col, ety, n_dst):
+        q, k, v, p_rel = q.contiguous(), k.contiguous(), v.contiguous(), p_rel.contiguous()
+        out = torch.zeros((n_dst, heads * dim), dtype=torch.float32, device=q.device)
+        eng.hgt_aggregate(q, k, v, heads, dim, rowptr, col, ety, p_rel, n_dst, out)
+        ctx.save_for_backward(q, k, v, p_rel, out, rowptr, col, ety)
+        ctx.meta = (eng, heads, dim, n_dst)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, p_rel, out, rowptr, col, ety = ctx.saved_tensors
+        eng, heads, dim, n_dst = ctx.meta
+        dq, dk, dv, dp = eng.hgt_aggregate_backward(q, k, v, heads, dim, rowptr, col, ety, p_rel, n_dst, out, dout)
+        return dq, dk, dv, dp, None, None, None, None, None, None, None
+
+
+class _WeightedAggFn(torch.autograd.Function):
+    """gigl_weighted_aggregate / gigl_weighted_aggregate_backward"""
+
+    @staticmethod
+    def forward(ctx, alpha, v, eng, heads, dim, rowptr, col, n_dst):
+        alpha, v = alpha.contiguous(), v.contiguous()
+        out = torch.empty((n_dst, heads * dim), dtype=torch.float32, device=v.device)
+        eng.weighted_aggregate(alpha, v, heads, dim, rowptr, col, n_dst, out)
+        ctx.save_for_backward(alpha, v, rowptr, col)
+        ctx.meta = (eng, heads, dim, n_dst)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        alpha, v, rowptr, col = ctx.saved_tensors
+        eng, heads, dim, n_dst = ctx.meta
+        dalpha, dv = eng.weighted_aggregate_backward(alpha, v, heads, dim, rowptr, col, n_dst, dout)
+        return dalpha, dv, None, None, None, None, None, None
+
+
+class _ShgnAlphaFn(torch.autograd.Function):
+    """gigl_simplehgn_alpha (softmax over the edges that share a SOURCE node of leaky_relu(hl[src] + hr[dst] +
+    het[type] [+ hef])); its backward is E x heads element work: device tensor ops (index_add over the groups)"""
+
+    @staticmethod
+    def forward(ctx, hl, hr, het, hef, eng, src, dst, ety, n, heads, slope):
+        alpha = eng.simplehgn_alpha(hl.contiguous(), hr.contiguous(), het.contiguous(),
+                                    hef.contiguous() if hef is not None else None, src, dst, ety, n, heads, slope)
+        ctx.save_for_backward(hl, hr, het, hef if hef is not None else hl.new_zeros(0), alpha, src, dst, ety)
+        ctx.meta = (n, heads, slope, hef is not None)
+        return alpha
+
+    @staticmethod
+    def backward(ctx, dalpha):
+        hl, hr, het, hef, alpha, src, dst, ety = ctx.saved_tensors
+        n, heads, slope, has_ef = ctx.meta
+        s, d, t = src.long(), dst.long(), ety.long()
+        x = hl[s] + hr[d] + het[t]
+        if has_ef:
+            x = x + hef
+        g = torch.zeros((n, heads), dtype=alpha.dtype, device=alpha.device).index_add_(0, s, alpha * dalpha)
+        dx = alpha * (dalpha - g[s]) * torch.where(x > 0, torch.ones_like(x), torch.full_like(x, slope))
+        dhl = torch.zeros_like(hl).index_add_(0, s, dx)
+        dhr = torch.zeros_like(hr).index_add_(0, d, dx)
+        dhet = torch.zeros_like(het).index_add_(0, t, dx)
+        return dhl, dhr, dhet, (dx if has_ef else None), None, None, None, None, None, None, None
 
 
 def _csr_by_dst(src: torch.Tensor, dst: torch.Tensor, n_dst: int, *more):
@@ -144,8 +216,7 @@ class HGTConv(nn.Module):
         if srcs and n_dst:
             rowptr, col, _, ety = _csr_by_dst(torch.cat(srcs), torch.cat(dsts), n_dst, torch.cat(ets))
             p_rel = torch.cat([self.p_rel["__".join(e)].reshape(1, H) for e in self.edge_types]).contiguous()
-            eng.hgt_aggregate(qq, torch.cat(ks).contiguous(), torch.cat(vs).contiguous(), H, D, rowptr, col, ety,
-                              p_rel.detach(), n_dst, out)
+            out = _HgtAggFn.apply(qq, torch.cat(ks), torch.cat(vs), p_rel, eng, H, D, rowptr, col, ety, n_dst)
         res = {}
         for t, x in x_dict.items():
             lin = self.out_lin.lins[t]
@@ -172,7 +243,6 @@ class HGT(nn.Module):
         self.lin = nn.Linear(hid_dim, out_dim)
         self.should_l2_normalize_embedding_layer_output = should_l2_normalize_embedding_layer_output
 
-    @torch.no_grad()
     def forward(self, data: HeteroGraphData, output_node_types: List[str], device=None) -> Dict[str, torch.Tensor]:
         any_x = next(iter(data.x_dict.values()))
         eng = _engine_for(self, any_x)
@@ -233,10 +303,8 @@ class SimpleHGNConv(nn.Module):
             # <a_efeat[h], (e W_efeat)[h-block]> == e . (W_efeat[:, h-block] a_efeat[h]): one [H, Ein] matrix
             folded = (self.W_efeat.view(self.edge_in_dim, H, self.edge_in_dim) * self.a_efeat).sum(-1).t().contiguous()
             hef = _linear(eng, torch.nan_to_num(edge_feat[order], nan=0.0), folded, None)
-        alpha = eng.simplehgn_alpha(hl.detach(), hr.detach(), het.detach(), hef, col, dst_s, ety, n, H,
-                                    self.negative_slope)
-        out = torch.empty((n, H * D), dtype=torch.float32, device=dev)
-        eng.weighted_aggregate(alpha, emb.contiguous(), H, D, rowptr, col, n, out)
+        alpha = _ShgnAlphaFn.apply(hl, hr, het, hef, eng, col, dst_s, ety, n, H, self.negative_slope)
+        out = _WeightedAggFn.apply(alpha, emb, eng, H, D, rowptr, col, n)
         if self.residual is not None:
             out = out + _linear(eng, node_feat, self.residual.weight, self.residual.bias)
         return out
@@ -271,7 +339,6 @@ class SimpleHGN(nn.Module):
     def _ekey(e) -> str:
         return f"{e[0]}-{e[1]}-{e[2]}"
 
-    @torch.no_grad()
     def forward(self, data: HeteroGraphData, output_node_types: List[str], device=None) -> Dict[str, torch.Tensor]:
         any_x = next(iter(data.x_dict.values()))
         eng = _engine_for(self, any_x)

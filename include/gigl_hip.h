@@ -680,6 +680,18 @@ int32_t gigl_simplehgn_alpha(gigl_ctx* ctx, const float* hl, const float* hr, co
                              int64_t n_nodes, int32_t heads, float negative_slope, float* group_scratch, float* alpha);
 int32_t gigl_weighted_aggregate(gigl_ctx* ctx, const float* alpha, const float* v, int32_t heads, int32_t dim,
                                 const int32_t* rowptr, const int32_t* col, int64_t n_dst, float* out);
+/* Backward of gigl_hgt_aggregate (training HGT: heterogeneous.py:18-119 under autograd): `out` = what the forward
+ * wrote, `dout` its gradient.  dq [n_dst, heads*dim] is written; dk, dv [n_src, heads*dim] and dp_rel [n_types, heads]
+ * (may be NULL) are ACCUMULATED into (zero them first): a source row has many destinations.  The softmax statistics
+ * are recomputed from q / k, nothing else needs saving. */
+int32_t gigl_hgt_aggregate_backward(gigl_ctx* ctx, const float* q, const float* k, const float* v, int32_t heads,
+                                    int32_t dim, const int32_t* rowptr, const int32_t* col, const int32_t* etype,
+                                    const float* p_rel, int64_t n_dst, const float* out, const float* dout, float* dq,
+                                    float* dk, float* dv, float* dp_rel);
+/* Backward of gigl_weighted_aggregate: dalpha [E, heads] is written, dv [n_src, heads*dim] accumulated into. */
+int32_t gigl_weighted_aggregate_backward(gigl_ctx* ctx, const float* alpha, const float* v, int32_t heads, int32_t dim,
+                                         const int32_t* rowptr, const int32_t* col, int64_t n_dst, const float* dout,
+                                         float* dalpha, float* dv);
 
 /* ---- split generator: hash slots of the assigners, in bulk.  Replaces HashingAssigner.assign's per-object hashing
  *      (scala/split_generator/src/main/scala/lib/assigners/AbstractAssigners.scala:30-111):

@@ -55,7 +55,7 @@ def test_hgt_matches_the_restatement():
             h = gnn_ref.hgt_conv(h, data.edge_index_dict, p, heads)
     for t in NT:
         want = F.linear(h[t], model.lin.weight, model.lin.bias).detach().numpy()
-        np.testing.assert_allclose(got[t].cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(got[t].detach().cpu().numpy(), want, rtol=1e-5, atol=1e-5)
     # a node type nobody points at still comes back (the in-repo modification of PyG's HGTConv)
     assert got["tag"].shape == (50, out_dim)
 
@@ -97,7 +97,7 @@ def test_simplehgn_matches_the_restatement(with_edge_attr):
         emb = F.linear(h, model.lin.weight, model.lin.bias)
     for t in ("user", "item"):
         want = emb[off[t]: off[t] + NT[t][0]].numpy()
-        np.testing.assert_allclose(got[t].cpu().numpy(), want, rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(got[t].detach().cpu().numpy(), want, rtol=1e-5, atol=2e-5)
     with pytest.raises(ValueError):
         model.to(dev)(data.to(dev), ["nobody"])
 
@@ -173,7 +173,7 @@ def test_dag_sampler_to_hgt_end_to_end():
                       p_rel={e: conv.p_rel["__".join(e)] for e in ets}, edge_types=ets)
             h = gnn_ref.hgt_conv(h, eid, pr, 2)
         want = F.linear(h["paper"], model.lin.weight, model.lin.bias)[root_index.cpu()]
-    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-5)
     s.close()
 
 
@@ -215,3 +215,87 @@ def test_typed_records_to_hgt_through_the_trainer_side_loader(tmp_path):
     s.engine.synchronize()
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
     s.close()
+
+
+def _grad_dict(model):
+    return {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def test_hgt_training_gradients_match_torch_autograd():
+    """HGT under autograd: gigl_hgt_aggregate_backward + the projections' backward GEMMs give the parameter gradients
+    torch autograd gives through the CPU restatement (oracle/gnn_ref.hgt_conv) for the same loss"""
+    import copy
+    from gigl_amd.models_hetero import HGT
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    heads, hid, out_dim = 2, 32, 16
+    model = HGT({t: d for t, (_, d) in NT.items()}, {e: 0 for e in ET}, hid_dim=hid, out_dim=out_dim, num_layers=2,
+                num_heads=heads)
+    with torch.no_grad():
+        for conv in model.convs:
+            for p in conv.skip.values():
+                p.uniform_(-1, 1)
+            for p in conv.p_rel.values():
+                p.uniform_(0.5, 1.5)
+    ref = copy.deepcopy(model)
+    data = make_data()
+    target = {t: torch.randn(n, out_dim) for t, (n, _) in NT.items() if t != "tag"}
+    model = model.to(dev)
+    out = model(data.to(dev), ["user", "item"])
+    loss = sum(((out[t] - target[t].to(dev)) ** 2).mean() for t in target)
+    loss.backward()
+    got = _grad_dict(model)
+    # the same loss through the CPU restatement
+    h = {t: torch.relu(F.linear(x, ref.lin_dict[t].weight, ref.lin_dict[t].bias)) for t, x in data.x_dict.items()}
+    for conv in ref.convs:
+        p = dict(kqv={t: (conv.kqv_lin.lins[t].weight, conv.kqv_lin.lins[t].bias) for t in NT},
+                 out={t: (conv.out_lin.lins[t].weight, conv.out_lin.lins[t].bias) for t in NT},
+                 k_rel=conv.k_rel.weight, v_rel=conv.v_rel.weight, skip={t: conv.skip[t] for t in NT},
+                 p_rel={e: conv.p_rel["__".join(e)] for e in ET}, edge_types=ET)
+        h = gnn_ref.hgt_conv(h, data.edge_index_dict, p, heads)
+    ref_loss = sum(((F.linear(h[t], ref.lin.weight, ref.lin.bias) - target[t]) ** 2).mean() for t in target)
+    ref_loss.backward()
+    want = _grad_dict(ref)
+    assert abs(float(loss) - float(ref_loss)) < 1e-5 * max(1.0, abs(float(ref_loss)))
+    assert set(got) == set(want) and len(got) > 20
+    for name in want:
+        np.testing.assert_allclose(got[name].numpy(), want[name].numpy(), rtol=2e-4, atol=2e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("with_edge_attr", [False, True])
+def test_simplehgn_conv_training_gradients_match_torch_autograd(with_edge_attr):
+    """SimpleHGNConv under autograd (source-grouped softmax, weighted aggregate, projections) vs torch autograd through
+    oracle/gnn_ref.simplehgn_conv"""
+    import copy
+    from gigl_amd.models_hetero import SimpleHGNConv
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(4)
+    n, ne, H, D, T, Ein = 300, 2500, 2, 16, 3, 8
+    conv = SimpleHGNConv(24, D, T, edge_in_channels=Ein if with_edge_attr else None, num_heads=H, edge_type_dim=8)
+    ref = copy.deepcopy(conv)
+    g = torch.Generator().manual_seed(5)
+    ei = torch.randint(0, n, (2, ne), generator=g)
+    et = torch.randint(0, T, (ne,), generator=g)
+    x = torch.randn(n, 24, generator=g)
+    ef = torch.randn(ne, Ein, generator=g) if with_edge_attr else None
+    tgt = torch.randn(n, H * D, generator=g)
+    conv = conv.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    out = conv(ei.to(dev), xd, et.to(dev), ef.to(dev) if ef is not None else None)
+    loss = ((out - tgt.to(dev)) ** 2).mean()
+    loss.backward()
+    got = _grad_dict(conv)
+    p = dict(W_nfeat=ref.W_nfeat, a_l=ref.a_l, a_r=ref.a_r, a_etype=ref.a_etype, edge_type_emb=ref.edge_type_emb,
+             W_etype=(ref.W_etype.weight, ref.W_etype.bias), residual=(ref.residual.weight, ref.residual.bias))
+    if with_edge_attr:
+        p.update(W_efeat=ref.W_efeat, a_efeat=ref.a_efeat)
+    xr = x.clone().requires_grad_(True)
+    ro = gnn_ref.simplehgn_conv(ei, xr, et, p, H, D, 0.2, edge_feat=ef)
+    rl = ((ro - tgt) ** 2).mean()
+    rl.backward()
+    want = _grad_dict(ref)
+    assert abs(float(loss) - float(rl)) < 1e-5 * max(1.0, abs(float(rl)))
+    assert set(got) == set(want)
+    for name in want:
+        np.testing.assert_allclose(got[name].numpy(), want[name].numpy(), rtol=2e-4, atol=2e-5, err_msg=name)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=2e-5)
