@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
                                                           const int32_t* __restrict__ col,
                                                           const int32_t* __restrict__ n_rows_dev,
                                                           float* __restrict__ out,
-                                                          const int32_t* __restrict__ n_local_dev, int tiled_nkc) {
+                                                          const int32_t* __restrict__ n_local_dev, int tiled_nkc,
+                                                          const int32_t* __restrict__ global_map) {
   constexpr int G = 64 / LPR;  // source rows per wave-instruction
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR;  // which source row of the instruction
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
       if (lane < mm) {
         my = col[e0 + c0 + lane];
         if (gather_ids && i < n_local) my = (int)gather_ids[my];
+        else if (global_map && i >= n_local) my = global_map[(uint32_t)my];  // global id -> its row in `src`
       }
       for (int e = 0; e < mm; e += 4 * G) {  // wave-uniform trip count (shuffles need every lane)
         const int ea = e + sub, eb = ea + G, ec = ea + 2 * G, ed = ea + 3 * G;
@@ -1587,7 +1589,7 @@ template <typename T>
 int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather_ids,
                       const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                       const int32_t* n_rows_dev, int64_t rows_cap, float* out, int op = GIGL_AGGR_MEAN,
-                      const int32_t* n_local_dev = nullptr, int tiled_nkc = 0) {
+                      const int32_t* n_local_dev = nullptr, int tiled_nkc = 0, const int32_t* global_map = nullptr) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
@@ -1596,7 +1598,7 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
   const int vecs = d / 4;
 #define GLO(LPR, VPL, OP)                                                                            \
   hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, 0, st, src, d, gather_ids, rowptr, \
-                     rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc)
+                     rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc, global_map)
 #define GL(LPR, VPL)                                        \
   do {                                                      \
     if (op == GIGL_AGGR_MEAN) GLO(LPR, VPL, GIGL_AGGR_MEAN); \
@@ -1604,7 +1606,8 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
     else GLO(LPR, VPL, GIGL_AGGR_MAX);                      \
   } while (0)
   if ((d & 3) != 0 || vecs > 512) {
-    if (tiled_nkc) return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the tiled operand layout needs d %% 4 == 0 and d <= 2048");
+    if (tiled_nkc || global_map)
+      return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the tiled operand layout / global row map need d %% 4 == 0 and d <= 2048");
     hipLaunchKernelGGL((gather_mean_generic_kernel<T>), g, b, 0, st, src, d, gather_ids, rowptr, rowend,
                        col, n_rows_dev, out, op, n_local_dev);
   } else if (vecs <= 8) GL(8, 1);
@@ -1666,15 +1669,16 @@ int32_t gigl_gather_reduce(gigl_ctx* ctx, const void* src, int32_t src_dtype, in
 int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* gather_ids,
                                  const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                                  const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
-                                 const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc) {
+                                 const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc,
+                                 const int32_t* global_map) {
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   if (src_dtype == GIGL_DTYPE_F32)
     return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
-                                aggr, n_local_rows_dev, tiled_nkc);
+                                aggr, n_local_rows_dev, tiled_nkc, global_map);
   return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
-                               aggr, n_local_rows_dev, tiled_nkc);
+                               aggr, n_local_rows_dev, tiled_nkc, global_map);
 }
 
 extern "C" {

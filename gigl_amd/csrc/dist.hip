@@ -342,6 +342,70 @@ __global__ __launch_bounds__(256) void bucket_kernel(const uint32_t* __restrict_
   if (pos) pos[i] = (int32_t)e;
 }
 
+// Dense pull bookkeeping (two-hop plans): a node id is requested ONCE per call — the first thread to stamp it with the
+// call's tag wins, takes the next entry of its owner's bucket and records that entry in slot_map[id]; everybody else
+// (other occurrences, other batches of the call) finds it there.  Replaces hashing the leaves into the union's node
+// table: one atomic exchange per occurrence on an array indexed by the id.  Workgroup-aggregated bucket counters as in
+// bucket_kernel.
+__global__ __launch_bounds__(256) void claim_bucket_kernel(const uint32_t* __restrict__ nodes, int64_t m,
+                                                           const int32_t* __restrict__ n_valid, uint32_t world,
+                                                           int64_t cap, uint32_t* __restrict__ ids_out,
+                                                           int32_t* __restrict__ counts, uint32_t* __restrict__ stamp,
+                                                           uint32_t tag, int32_t* __restrict__ slot_map,
+                                                           int64_t n_global) {
+  __shared__ int32_t s_cnt[64], s_base[64];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t lim = n_valid ? (int64_t)*n_valid : m;
+  uint32_t v = (i < m && i < lim) ? nodes[i] : GIGL_INVALID;
+  if (v != GIGL_INVALID && ((int64_t)v >= n_global || atomicExch(&stamp[v], tag) == tag)) v = GIGL_INVALID;
+  const uint32_t r = v == GIGL_INVALID ? 0xFFFFFFFFu : v % world;
+  const int lane = threadIdx.x & 63;
+  int32_t p = 0;
+  if (world <= 64) {
+    if (threadIdx.x < world) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int32_t rank = 0;
+    if (r != 0xFFFFFFFFu) rank = atomicAdd(&s_cnt[r], 1);
+    __syncthreads();
+    if (threadIdx.x < world && s_cnt[threadIdx.x] > 0)
+      s_base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (r != 0xFFFFFFFFu) p = s_base[r] + rank;
+  } else {
+    unsigned long long todo = __ballot(r != 0xFFFFFFFFu);
+    while (todo) {
+      const int lead = __ffsll((long long)todo) - 1;
+      const uint32_t r_lead = __shfl(r, lead, 64);
+      const unsigned long long same = __ballot(r == r_lead);
+      int32_t base = 0;
+      if (lane == lead) base = atomicAdd(&counts[r_lead], (int32_t)__popcll(same));
+      base = __shfl(base, lead, 64);
+      if (r == r_lead) p = base + (int32_t)__popcll(same & ((1ull << lane) - 1ull));
+      todo &= ~same;
+    }
+  }
+  if (r == 0xFFFFFFFFu) return;
+  if (p >= cap) {
+    atomicOr(&counts[world], 1);
+    slot_map[v] = 0;  // (the step is reported failed; keep the map inside the receive buffer)
+    return;
+  }
+  const int64_t e = (int64_t)r * cap + p;
+  ids_out[e] = v;
+  slot_map[v] = (int32_t)e;
+}
+
+// pos[i] = receive-buffer row of union node i (its own feature row)
+__global__ __launch_bounds__(256) void pos_from_map_kernel(const uint32_t* __restrict__ nodes,
+                                                           const int32_t* __restrict__ n_valid, int64_t m,
+                                                           const int32_t* __restrict__ slot_map, int64_t n_global,
+                                                           int32_t* __restrict__ pos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m || i >= (int64_t)*n_valid) return;
+  const uint32_t v = nodes[i];
+  pos[i] = (int64_t)v < n_global ? slot_map[v] : 0;
+}
+
 // owner side of the feature pull: entry e of the received id buckets -> its feature row, written at row e of the send
 // buffer.  Raw copy (any element type): the rows are flattened into 16-byte chunks, one per lane, so every lane of
 // every wave moves data whatever the row length; this rank's own requests land straight in the receive buffer.
@@ -550,6 +614,13 @@ struct gigl_dist_plan {
   int32_t* n_entries_dev = nullptr;   // device constants: world*pull_cap, world*pull_cap_b
   const int32_t** flag_ptrs = nullptr;  // device array of the overflow flags
   int n_flags = 0;
+  // dense pull bookkeeping (two hops, raw rows): the union graph is the leaf-global build (leaves stay global ids in
+  // their parents' rows), ids are claimed through stamp[] and located through slot_map[] (claim_bucket_kernel)
+  bool dense = false;
+  uint32_t* stamp = nullptr;   // [n_global] tag of the call that last requested the id
+  int32_t* slot_map = nullptr; // [n_global] receive-buffer row of the id in that call
+  uint32_t tag = 0;
+  int64_t n_global = 0, last_slots = 0;
   // activations
   float* abuf = nullptr;
   float* hbuf[2] = {nullptr, nullptr};
@@ -625,10 +696,30 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     // ---- requester: last scatter, union graph, feature requests
     rc = scatter_hop(p, L - 1, roots);
     if (rc != GIGL_OK) return rc;
-    rc = gigl_union_build_groups(ctx, roots, &p->tree, p->group_roots, &p->un);
-    if (rc != GIGL_OK) return rc;
     GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->ids_s, 0xFF, (size_t)world * p->pull_cap * 4, st));
     GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->pull_counts, 0, (size_t)(world + 1) * 4, st));
+    if (p->dense) {
+      rc = gigl_union_build_impl(ctx, roots, &p->tree, p->group_roots, &p->un, 1 | (p->shard->multi ? 2 : 0));
+      if (rc != GIGL_OK) return rc;
+      if (++p->tag == 0) {  // (the tag wrapped: forget every stamp)
+        GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->stamp, 0, (size_t)p->n_global * 4, st));
+        p->tag = 1;
+      }
+      const int32_t* n_inner = p->un.meta + GIGL_META_LEVEL0 + (L - 1);
+      // the inner nodes first (their own rows: pos), then every sampled leaf
+      hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes,
+                         p->act_rows, n_inner, world, p->pull_cap, p->ids_s, p->pull_counts, p->stamp, p->tag,
+                         p->slot_map, p->n_global);
+      hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->last_slots)), dim3(256), 0, st,
+                         (const uint32_t*)p->tree.nbr[L - 1], p->last_slots, (const int32_t*)nullptr, world, p->pull_cap,
+                         p->ids_s, p->pull_counts, p->stamp, p->tag, p->slot_map, p->n_global);
+      hipLaunchKernelGGL(pos_from_map_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes, n_inner,
+                         p->act_rows, p->slot_map, p->n_global, p->pos);
+      GIGL_HIP_CHECK(ctx, hipGetLastError());
+      return comm_exchange(p->comm, p->ids_s, p->ids_r, p->pull_cap * 4);
+    }
+    rc = gigl_union_build_groups(ctx, roots, &p->tree, p->group_roots, &p->un);
+    if (rc != GIGL_OK) return rc;
     hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->un.cap_nodes)), dim3(256), 0, st, p->un.nodes,
                        (const uint32_t*)nullptr, p->un.cap_nodes, p->un.meta + GIGL_META_N_NODES, world, p->pull_cap,
                        p->ids_s, (uint32_t*)nullptr, (int32_t*)nullptr, p->pos, p->pull_counts, 0u, (uint32_t*)nullptr,
@@ -699,7 +790,11 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       GIGL_HIP_CHECK(ctx, hipGetLastError());
       continue;
     }
-    if (l == 0)
+    if (l == 0 && p->dense)  // rows of level L-1 hold global ids: located through slot_map
+      rc = gigl_gather_reduce_mixed(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, p->un.rowptr,
+                                    p->un.rowend, p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN,
+                                    p->un.meta + GIGL_META_LEVEL0 + (L - 2), p->abuf, 0, p->slot_map);
+    else if (l == 0)
       rc = gigl_gather_reduce(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, p->un.rowptr,
                               p->un.rowend, p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN, p->abuf);
     else
@@ -785,6 +880,17 @@ int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* sha
   };
   bool ok = true;
   const int64_t W = p->world;
+  int64_t cap_nodes = 0, cap_edges = 0;
+  gigl_union_capacity(b, fanouts, hops, &cap_nodes, &cap_edges);
+  int64_t last_slots = b;
+  for (int k = 0; k < hops; ++k) last_slots *= fanouts[k];
+  p->last_slots = last_slots;
+  p->n_global = shard->n * W;
+  p->dense = hops == 2 && !p->project && p->n_global < ((int64_t)1 << 32) && (shard_feat->d & 3) == 0 &&
+             getenv("GIGL_DIST_GENERIC_UNION") == nullptr;
+  // (dense: the last hop's ids live right behind the union's col array so that rows can alias tree segments)
+  p->un.col = (int32_t*)alloc((size_t)(cap_edges + (p->dense ? last_slots : 0)) * 4);
+  ok = p->un.col != nullptr;
   // ---- tree + per-hop exchange buffers
   int64_t parents = b, max_served = 0;
   for (int k = 0; k < hops && ok; ++k) {
@@ -800,7 +906,7 @@ int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* sha
     if (W * cap > max_served) max_served = W * cap;
     p->tree.cnt[k] = (int32_t*)alloc((size_t)parents * 4);
     parents *= fanouts[k];
-    p->tree.nbr[k] = (uint32_t*)alloc((size_t)parents * 4);
+    p->tree.nbr[k] = (p->dense && k == hops - 1) ? (uint32_t*)(p->un.col + cap_edges) : (uint32_t*)alloc((size_t)parents * 4);
     p->child_ksum[k] = (uint32_t*)alloc((size_t)parents * 4);
     p->rq_nodes_s[k] = (uint32_t*)alloc((size_t)W * cap * 4);
     p->rq_ksum_s[k] = (uint32_t*)alloc((size_t)W * cap * 4);
@@ -819,14 +925,19 @@ int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* sha
   for (int k = 0; k < hops; ++k) p->tree.fanouts[k] = fanouts[k];
   p->own_cnt = (int32_t*)alloc((size_t)max_served * 4);
   // ---- union graph
-  int64_t cap_nodes = 0, cap_edges = 0;
-  gigl_union_capacity(b, fanouts, hops, &cap_nodes, &cap_edges);
   p->un.meta = (int32_t*)alloc(GIGL_META_LEN * 4);
   p->un.nodes = (uint32_t*)alloc((size_t)cap_nodes * 4);
   p->un.rowptr = (int32_t*)alloc((size_t)(cap_nodes + 2) * 4);
   p->un.rowend = (int32_t*)alloc((size_t)(cap_nodes + 2) * 4);
-  p->un.col = (int32_t*)alloc((size_t)cap_edges * 4);
   p->un.root_local = (int32_t*)alloc((size_t)b * 4);
+  if (p->dense) {
+    p->stamp = (uint32_t*)alloc((size_t)p->n_global * 4);
+    p->slot_map = (int32_t*)alloc((size_t)p->n_global * 4);
+    ok = ok && p->stamp && p->slot_map;
+    if (ok && (hipMemsetAsync(p->stamp, 0, (size_t)p->n_global * 4, ctx->stream) != hipSuccess ||
+               hipMemsetAsync(p->slot_map, 0, (size_t)p->n_global * 4, ctx->stream) != hipSuccess))
+      ok = false;
+  }
   p->un.cap_nodes = cap_nodes;
   p->un.cap_edges = cap_edges;
   int64_t act_rows = 0, width = b;
