@@ -181,6 +181,9 @@ def main():
                          "feature pull over RCCL — needs >= 2 GPUs at full size (--shard-scale shrinks it)")
     ap.add_argument("--shard-group", type=int, default=16,
                     help="mag240m-sharded: batches of B roots exchanged per set of collectives (dedup stays per batch)")
+    ap.add_argument("--shard-hot-frac", type=float, default=0.0,
+                    help="mag240m-sharded: fraction of the nodes (the most-referenced ones) whose feature rows are "
+                         "replicated on every rank and never pulled (hub-row replication)")
     ap.add_argument("--shard-plans", type=int, default=3, help="mag240m-sharded: sharded plans in flight per rank")
     ap.add_argument("--shard-scale", type=float, default=1.0,
                     help="mag240m-sharded: fraction of MAG240M's nodes and edges to generate (1.0 needs 8 GPUs' HBM)")
@@ -582,6 +585,15 @@ def run_sharded(args, rank, world, local_rank):
     dist.all_reduce(maxdeg, op=dist.ReduceOp.MAX)
     dist.all_reduce(e_local, op=dist.ReduceOp.SUM)
     eng.load_csc(rowptr, col)
+    # replicated hot rows (--shard-hot-frac): the nodes that occur most often as in-neighbours, the same set on every rank
+    hot_ids = None
+    n_hot = int(n * max(0.0, args.shard_hot_frac))
+    if n_hot > 0:
+        occ = torch.bincount(col.to(torch.int64) & 0xFFFFFFFF, minlength=n).to(torch.int32)
+        dist.all_reduce(occ, op=dist.ReduceOp.SUM)
+        hot_ids = torch.topk(occ.to(torch.int64) * (1 << 32) + (n - 1 - torch.arange(n, device=dev)), n_hot).indices
+        hot_ids = hot_ids.to(torch.int32).contiguous()  # (ties broken by id: identical on every rank)
+        del occ
     del key, rowptr, col
     g = torch.Generator(device=dev)
     g.manual_seed(1234 + rank)
@@ -590,6 +602,13 @@ def run_sharded(args, rank, world, local_rank):
     for i in range(0, n_local, step_rows):
         x_local[i:i + step_rows] = torch.randn((min(step_rows, n_local - i), d), generator=g, device=dev).to(torch.float16)
     eng.load_features(x_local)
+    hot_rows = None
+    if hot_ids is not None:  # every rank contributes the rows it owns; the sum over ranks is the replicated table
+        hi = hot_ids.to(torch.int64) & 0xFFFFFFFF
+        mine_hot = (hi % world) == rank
+        hot_rows = torch.zeros((n_hot, d), device=dev, dtype=torch.float16)
+        hot_rows[mine_hot] = x_local[hi[mine_hot] // world]
+        dist.all_reduce(hot_rows, op=dist.ReduceOp.SUM)
     del x_local
     torch.cuda.empty_cache()
     torch.manual_seed(0)
@@ -627,6 +646,8 @@ def run_sharded(args, rank, world, local_rank):
             sl.plan = DistSagePlan(sl.comm, w, bs, G * B, fanouts, group_roots=B,
                                    project_on_owner=args.project_on_owner, pull_cap=pull_cap, max_window_end=mwe)
             sl.out = sl.plan.new_out()
+            if hot_ids is not None:
+                sl.plan.set_hot_rows(hot_ids, hot_rows)
             slots.append(sl)
         return slots
 
@@ -735,6 +756,7 @@ def run_sharded(args, rank, world, local_rank):
                                    f"D={d} fp16 features, hash-partitioned over {world} rank(s) (owner = id % world), "
                                    f"fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}, sampler mode=parity, "
                                    f"{G} batches per exchange, {S} plans in flight, "
+                                   f"{'%g %% of the nodes replicated as hot rows, ' % (100 * args.shard_hot_frac) if n_hot else ''}"
                                    f"{'rows projected on the owner (256 fp32)' if args.project_on_owner else 'raw rows (768 fp16)'}",
                        "graph": "CSC rows + feature rows of the owned nodes per rank; per-hop all-to-all frontier "
                                 "exchange and feature pull of the unique union-graph nodes, issued by the library "

@@ -42,6 +42,7 @@ SYMBOLS = [
     "gigl_comm_all_to_all", "gigl_comm_flush_local", "gigl_comm_destroy", "gigl_dist_plan_create",
     "gigl_dist_plan_set_weights", "gigl_dist_plan_phases", "gigl_dist_plan_phase", "gigl_dist_plan_run",
     "gigl_dist_plan_run_local", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
+    "gigl_dist_plan_set_hot_rows",
     "gigl_split_hash_slots", "gigl_hgt_aggregate", "gigl_simplehgn_alpha", "gigl_weighted_aggregate",
     "gigl_collate_typed_records", "gigl_collated_typed_info", "gigl_collated_typed_nodes", "gigl_collated_typed_edges",
     "gigl_collated_typed_samples", "gigl_collated_typed_destroy", "gigl_typed_records_capacity",
@@ -221,6 +222,7 @@ def load() -> C.CDLL:
         "gigl_dist_plan_run_local": [P(vp), i32, P(vp), i32, P(vp)],
         "gigl_dist_plan_buffers": [vp, P(GiglTree), P(GiglUnion)],
         "gigl_dist_plan_stats": [vp, vp],
+        "gigl_dist_plan_set_hot_rows": [vp, vp, i64, vp],
         "gigl_dist_plan_destroy": [vp],
         "gigl_retrieval_loss": [vp, vp, i64, i32, i32, C.c_float, vp, vp, vp, vp, vp, vp, vp],
         "gigl_retrieval_loss_backward": [vp, vp, i64, i32, i32, C.c_float, vp, vp, vp, vp, vp, vp],

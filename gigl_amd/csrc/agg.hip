@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
                                                           const int32_t* __restrict__ n_rows_dev,
                                                           float* __restrict__ out,
                                                           const int32_t* __restrict__ n_local_dev, int tiled_nkc,
-                                                          const int32_t* __restrict__ global_map) {
+                                                          const int32_t* __restrict__ global_map,
+                                                          const T* __restrict__ src2) {
   constexpr int G = 64 / LPR;  // source rows per wave-instruction
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR;  // which source row of the instruction
@@ -102,10 +103,11 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
         const int ea = e + sub, eb = ea + G, ec = ea + 2 * G, ed = ea + 3 * G;
         const int ja = __shfl(my, ea & 63, 64), jb = __shfl(my, eb & 63, 64), jc = __shfl(my, ec & 63, 64),
                   jd = __shfl(my, ed & 63, 64);
-        const T* pa = src + (int64_t)ja * d;
-        const T* pb = src + (int64_t)jb * d;
-        const T* pc = src + (int64_t)jc * d;
-        const T* pd = src + (int64_t)jd * d;
+        // (a negative row index -1-h = row h of the second source: the sharded plan's replicated hot rows)
+        const T* pa = ja >= 0 ? src + (int64_t)ja * d : src2 + (int64_t)(-1 - ja) * d;
+        const T* pb = jb >= 0 ? src + (int64_t)jb * d : src2 + (int64_t)(-1 - jb) * d;
+        const T* pc = jc >= 0 ? src + (int64_t)jc * d : src2 + (int64_t)(-1 - jc) * d;
+        const T* pd = jd >= 0 ? src + (int64_t)jd * d : src2 + (int64_t)(-1 - jd) * d;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
           const int el = (v * LPR + sl) * 4;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
         acc[v] = aggr_combine<OP>(acc[v], o4);
       }
     }
-    const T* ps = src + (int64_t)self * d;
+    const T* ps = self >= 0 ? src + (int64_t)self * d : src2 + (int64_t)(-1 - self) * d;
     // mean = sum / deg (a true division, like torch's scatter-mean), 0 for an empty row
     const float dv = (OP == GIGL_AGGR_MEAN && m > 0) ? (float)m : 1.f;
     const float4_t none4 = {0.f, 0.f, 0.f, 0.f};
@@ -1589,7 +1591,8 @@ template <typename T>
 int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather_ids,
                       const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                       const int32_t* n_rows_dev, int64_t rows_cap, float* out, int op = GIGL_AGGR_MEAN,
-                      const int32_t* n_local_dev = nullptr, int tiled_nkc = 0, const int32_t* global_map = nullptr) {
+                      const int32_t* n_local_dev = nullptr, int tiled_nkc = 0, const int32_t* global_map = nullptr,
+                      const T* src2 = nullptr) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
@@ -1598,7 +1601,7 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
   const int vecs = d / 4;
 #define GLO(LPR, VPL, OP)                                                                            \
   hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, 0, st, src, d, gather_ids, rowptr, \
-                     rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc, global_map)
+                     rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc, global_map, src2)
 #define GL(LPR, VPL)                                        \
   do {                                                      \
     if (op == GIGL_AGGR_MEAN) GLO(LPR, VPL, GIGL_AGGR_MEAN); \
@@ -1670,15 +1673,15 @@ int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dty
                                  const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                                  const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
                                  const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc,
-                                 const int32_t* global_map) {
+                                 const int32_t* global_map, const void* src2) {
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   if (src_dtype == GIGL_DTYPE_F32)
     return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
-                                aggr, n_local_rows_dev, tiled_nkc, global_map);
+                                aggr, n_local_rows_dev, tiled_nkc, global_map, (const float*)src2);
   return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
-                               aggr, n_local_rows_dev, tiled_nkc, global_map);
+                               aggr, n_local_rows_dev, tiled_nkc, global_map, (const __half*)src2);
 }
 
 extern "C" {

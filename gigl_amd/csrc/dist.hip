@@ -352,12 +352,20 @@ __global__ __launch_bounds__(256) void claim_bucket_kernel(const uint32_t* __res
                                                            int64_t cap, uint32_t* __restrict__ ids_out,
                                                            int32_t* __restrict__ counts, uint32_t* __restrict__ stamp,
                                                            uint32_t tag, int32_t* __restrict__ slot_map,
-                                                           int64_t n_global) {
+                                                           int64_t n_global, const int32_t* __restrict__ hot_of) {
   __shared__ int32_t s_cnt[64], s_base[64];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t lim = n_valid ? (int64_t)*n_valid : m;
   uint32_t v = (i < m && i < lim) ? nodes[i] : GIGL_INVALID;
-  if (v != GIGL_INVALID && ((int64_t)v >= n_global || atomicExch(&stamp[v], tag) == tag)) v = GIGL_INVALID;
+  if (v != GIGL_INVALID && (int64_t)v >= n_global) v = GIGL_INVALID;
+  if (v != GIGL_INVALID && hot_of) {  // a replicated row: read locally, never requested (row -1-h of the hot table)
+    const int32_t h = hot_of[v];
+    if (h >= 0) {
+      slot_map[v] = -1 - h;
+      v = GIGL_INVALID;
+    }
+  }
+  if (v != GIGL_INVALID && atomicExch(&stamp[v], tag) == tag) v = GIGL_INVALID;
   const uint32_t r = v == GIGL_INVALID ? 0xFFFFFFFFu : v % world;
   const int lane = threadIdx.x & 63;
   int32_t p = 0;
@@ -617,6 +625,9 @@ struct gigl_dist_plan {
   // dense pull bookkeeping (two hops, raw rows): the union graph is the leaf-global build (leaves stay global ids in
   // their parents' rows), ids are claimed through stamp[] and located through slot_map[] (claim_bucket_kernel)
   bool dense = false;
+  // replicated hot rows (gigl_dist_plan_set_hot_rows): hot_of[id] = row of the id in hot_rows, -1 = not replicated
+  int32_t* hot_of = nullptr;
+  const void* hot_rows = nullptr;
   uint32_t* stamp = nullptr;   // [n_global] tag of the call that last requested the id
   int32_t* slot_map = nullptr; // [n_global] receive-buffer row of the id in that call
   uint32_t tag = 0;
@@ -709,10 +720,10 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       // the inner nodes first (their own rows: pos), then every sampled leaf
       hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes,
                          p->act_rows, n_inner, world, p->pull_cap, p->ids_s, p->pull_counts, p->stamp, p->tag,
-                         p->slot_map, p->n_global);
+                         p->slot_map, p->n_global, (const int32_t*)p->hot_of);
       hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->last_slots)), dim3(256), 0, st,
                          (const uint32_t*)p->tree.nbr[L - 1], p->last_slots, (const int32_t*)nullptr, world, p->pull_cap,
-                         p->ids_s, p->pull_counts, p->stamp, p->tag, p->slot_map, p->n_global);
+                         p->ids_s, p->pull_counts, p->stamp, p->tag, p->slot_map, p->n_global, (const int32_t*)p->hot_of);
       hipLaunchKernelGGL(pos_from_map_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes, n_inner,
                          p->act_rows, p->slot_map, p->n_global, p->pos);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
@@ -793,7 +804,7 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     if (l == 0 && p->dense)  // rows of level L-1 hold global ids: located through slot_map
       rc = gigl_gather_reduce_mixed(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, p->un.rowptr,
                                     p->un.rowend, p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN,
-                                    p->un.meta + GIGL_META_LEVEL0 + (L - 2), p->abuf, 0, p->slot_map);
+                                    p->un.meta + GIGL_META_LEVEL0 + (L - 2), p->abuf, 0, p->slot_map, p->hot_rows);
     else if (l == 0)
       rc = gigl_gather_reduce(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, p->un.rowptr,
                               p->un.rowend, p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN, p->abuf);
@@ -1007,6 +1018,43 @@ int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* sha
   hipMemsetAsync(p->rows_r, 0, (size_t)W * pc * p->row_bytes, ctx->stream);
   hipStreamSynchronize(ctx->stream);
   *out = p;
+  return GIGL_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void hot_fill_kernel(int32_t* hot_of, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) hot_of[i] = -1;
+}
+__global__ __launch_bounds__(256) void hot_scatter_kernel(const uint32_t* __restrict__ ids, int64_t n_hot, int64_t n_global,
+                                                          int32_t* __restrict__ hot_of) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_hot && (int64_t)ids[i] < n_global) hot_of[ids[i]] = (int32_t)i;
+}
+}  // namespace
+
+int32_t gigl_dist_plan_set_hot_rows(gigl_dist_plan* p, const uint32_t* hot_ids, int64_t n_hot, const void* hot_rows) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, p->dense, "replicated hot rows need the dense pull bookkeeping (two hops, raw rows)");
+  GIGL_REQUIRE(ctx, n_hot >= 0 && n_hot < ((int64_t)1 << 31) && (n_hot == 0 || (hot_ids && hot_rows)), "bad hot set");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!p->hot_of) {
+    void* q = nullptr;
+    if (hipMalloc(&q, (size_t)p->n_global * 4) != hipSuccess) return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the hot map failed");
+    p->owned.push_back(q);
+    p->hot_of = (int32_t*)q;
+  }
+  hipLaunchKernelGGL(hot_fill_kernel, dim3((unsigned)grid256(p->n_global)), dim3(256), 0, ctx->stream, p->hot_of, p->n_global);
+  if (n_hot > 0)
+    hipLaunchKernelGGL(hot_scatter_kernel, dim3((unsigned)grid256(n_hot)), dim3(256), 0, ctx->stream, hot_ids, n_hot,
+                       p->n_global, p->hot_of);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (hot_ids may be freed by the caller after this returns)
+  p->hot_rows = n_hot > 0 ? hot_rows : nullptr;
+  if (n_hot == 0) {  // back to "nothing replicated"
+    p->hot_rows = nullptr;
+  }
   return GIGL_OK;
 }
 

@@ -413,6 +413,22 @@ class DistSagePlan:
     def new_out(self) -> torch.Tensor:
         return torch.empty((self.b, self.dims[-1]), dtype=torch.float32, device=self.eng.device)
 
+    def set_hot_rows(self, hot_ids: Optional[torch.Tensor], hot_rows: Optional[torch.Tensor]) -> None:
+        """replicated hot rows (gigl_dist_plan_set_hot_rows): `hot_ids` distinct GLOBAL node ids, `hot_rows` their
+        feature rows [n_hot, d] in the shard's feature dtype — the same set on every rank; such rows are read locally
+        and never pulled.  None / empty clears the set."""
+        n = 0 if hot_ids is None else int(hot_ids.numel())
+        if n == 0:
+            _check(self._lib.gigl_dist_plan_set_hot_rows(self._plan, None, 0, None), self.eng._ctx)
+            self._hot = None
+            return
+        ids = hot_ids.to(device=self.eng.device, dtype=torch.int32).contiguous()
+        rows = hot_rows.to(device=self.eng.device).contiguous()
+        assert rows.shape[0] == n and rows.shape[1] == self.dims[0]
+        _check(self._lib.gigl_dist_plan_set_hot_rows(self._plan, C.c_void_p(ids.data_ptr()), n,
+                                                     C.c_void_p(rows.data_ptr())), self.eng._ctx)
+        self._hot = (ids, rows)  # the plan borrows the rows
+
     def run(self, roots: torch.Tensor, out: Optional[torch.Tensor] = None, sampling_seed: int = 42) -> torch.Tensor:
         assert roots.is_cuda and roots.dtype == torch.int32 and roots.numel() == self.b and roots.is_contiguous()
         out = out if out is not None else self.new_out()

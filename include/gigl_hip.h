@@ -772,6 +772,12 @@ int32_t gigl_dist_plan_run(gigl_dist_plan* plan, const uint32_t* roots, int32_t 
 /* one step of every rank of an in-process group, phase by phase; plans[r] = rank r's plan */
 int32_t gigl_dist_plan_run_local(gigl_dist_plan* const* plans, int32_t world, const uint32_t* const* roots,
                                  int32_t sampling_seed, float* const* out);
+/* Replicated hot rows (hub-row replication): feature rows that every rank keeps a copy of are read locally and never
+ * requested over the links.  hot_ids: n_hot distinct GLOBAL node ids (device), hot_rows: their feature rows [n_hot, d]
+ * in the shard's feature dtype (device; BORROWED: keep it alive while the plan runs) — the same set on every rank (the
+ * job replicates it at setup, e.g. the nodes that occur most often as in-neighbours).  Results are unchanged; needs
+ * the plan's dense pull bookkeeping (two hops, raw rows; GIGL_E_INVALID_ARG otherwise).  n_hot = 0 clears the set. */
+int32_t gigl_dist_plan_set_hot_rows(gigl_dist_plan* plan, const uint32_t* hot_ids, int64_t n_hot, const void* hot_rows);
 int32_t gigl_dist_plan_buffers(gigl_dist_plan* plan, gigl_tree* tree, gigl_union* un);
 /* like gigl_sage_plan_stats for the step run last, plus the feature rows requested (PULLED_ROWS, summed) and the
  * fullest row bucket seen (PULL_BUCKET_MAX, a running maximum) */

@@ -115,6 +115,75 @@ def test_all_ranks_in_one_process_end_to_end(world, project, dtype):
         e.close()
 
 
+@pytest.mark.parametrize("world,dtype", [(2, torch.float32), (8, torch.float16)])
+def test_replicated_hot_rows_are_not_pulled(world, dtype):
+    """hub-row replication (gigl_dist_plan_set_hot_rows): the most-referenced nodes' rows are kept on every rank and read
+    locally — the results do not change (trees bit-identical, embeddings 1e-5 vs the oracle), the number of rows that
+    travel drops, and clearing the set restores the plain pull"""
+    from gigl_amd.dist import Comm, DistSagePlan
+    rowptr, col, x = make_graph()
+    xq = x.astype(np.float16).astype(np.float32) if dtype == torch.float16 else x
+    model = make_model()
+    w, bs = model.fused_params()
+    b, gr = 96, 32
+    st = torch.cuda.Stream()
+    engs = [shard_engine(rowptr, col, x, r, world, dtype, st) for r in range(world)]
+    comms = Comm.local(engs)
+    plans = [DistSagePlan(comms[r], w, bs, b, FAN, group_roots=gr, max_window_end=bound_for(rowptr)) for r in range(world)]
+    roots = [rank_roots(r, b) for r in range(world)]
+    roots_d = [torch.from_numpy(r.view(np.int32)).to(engs[0].device) for r in roots]
+    # hot set: the 5 % of the nodes that occur most often as in-neighbours (the same set on every rank)
+    occ = np.bincount(col.astype(np.int64), minlength=N)
+    hot = np.argsort(-occ, kind="stable")[: N // 20].astype(np.uint32)
+    hot_ids = torch.from_numpy(hot.view(np.int32))
+    hot_rows = torch.from_numpy(x[hot.astype(np.int64)]).to(dtype)
+
+    def pulled(plan):
+        acc = torch.zeros(16, dtype=torch.int64, device=engs[0].device)
+        with torch.cuda.stream(st):
+            plan.stats(acc)
+        st.synchronize()
+        return int(acc[14].item())
+
+    DistSagePlan.run_local(plans, roots_d)
+    st.synchronize()
+    plain = [pulled(p) for p in plans]
+    for p in plans:
+        p.set_hot_rows(hot_ids, hot_rows)
+    for _ in range(2):
+        outs = DistSagePlan.run_local(plans, roots_d)
+    st.synchronize()
+    with_hot = [pulled(p) for p in plans]
+    assert all(h < 0.8 * q for h, q in zip(with_hot, plain)), (plain, with_hot)
+    for r in range(world):
+        hb = plans[r].buffers_to_host()
+        assert hb["meta"][8] == 0
+        nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots[r], FAN, canonical=True)
+        for k in range(len(FAN)):
+            assert np.array_equal(hb["nbr"][k], nbr_o[k]) and np.array_equal(hb["cnt"][k], cnt_o[k])
+        np.testing.assert_allclose(outs[r].cpu().numpy(), reference_rows(rowptr, col, xq, model, roots[r], gr),
+                                   rtol=1e-5, atol=1e-5)
+    for p in plans:
+        p.set_hot_rows(None, None)
+    outs2 = DistSagePlan.run_local(plans, roots_d)
+    st.synchronize()
+    assert [pulled(p) for p in plans] == plain
+    for r in range(world):
+        assert torch.equal(outs2[r], outs[r])  # same arithmetic: only where the rows are read from changed
+    # the projected-rows plan has no dense bookkeeping: replication is refused there
+    from gigl_amd import _lib
+    pp = DistSagePlan(comms[0], w, bs, b, FAN, group_roots=gr, project_on_owner=True, max_window_end=bound_for(rowptr))
+    with pytest.raises(_lib.GiglError):
+        pp.set_hot_rows(hot_ids, hot_rows)
+    pp.close()
+    for p in plans:
+        p.close()
+    for c in comms:
+        c.close()
+    for e in engs:
+        e.close()
+
+
 def test_pull_bucket_overflow_is_reported():
     """a row bucket too small for the step fails the batch loudly (meta[GIGL_META_OVERFLOW]) instead of computing on
     missing rows"""
