@@ -73,8 +73,15 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
                                                           float* __restrict__ out,
                                                           const int32_t* __restrict__ n_local_dev, int tiled_nkc,
                                                           const int32_t* __restrict__ global_map,
-                                                          const T* __restrict__ src2) {
+                                                          const T* __restrict__ src2, const T* __restrict__ src3) {
   constexpr int G = 64 / LPR;  // source rows per wave-instruction
+  // a NEGATIVE row index -1-h names a row outside `src` (the sharded plan): h < 2^30 = row h of src2 (replicated hot
+  // rows), else row h - 2^30 of src3 (this rank's own feature table)
+  auto row_of = [&](int j) -> const T* {
+    if (j >= 0) return src + (int64_t)j * d;
+    const int h = -1 - j;
+    return h < (1 << 30) ? src2 + (int64_t)h * d : src3 + (int64_t)(h - (1 << 30)) * d;
+  };
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR;  // which source row of the instruction
   const int sl = lane % LPR;   // lane within the row
@@ -103,11 +110,10 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
         const int ea = e + sub, eb = ea + G, ec = ea + 2 * G, ed = ea + 3 * G;
         const int ja = __shfl(my, ea & 63, 64), jb = __shfl(my, eb & 63, 64), jc = __shfl(my, ec & 63, 64),
                   jd = __shfl(my, ed & 63, 64);
-        // (a negative row index -1-h = row h of the second source: the sharded plan's replicated hot rows)
-        const T* pa = ja >= 0 ? src + (int64_t)ja * d : src2 + (int64_t)(-1 - ja) * d;
-        const T* pb = jb >= 0 ? src + (int64_t)jb * d : src2 + (int64_t)(-1 - jb) * d;
-        const T* pc = jc >= 0 ? src + (int64_t)jc * d : src2 + (int64_t)(-1 - jc) * d;
-        const T* pd = jd >= 0 ? src + (int64_t)jd * d : src2 + (int64_t)(-1 - jd) * d;
+        const T* pa = row_of(ja);
+        const T* pb = row_of(jb);
+        const T* pc = row_of(jc);
+        const T* pd = row_of(jd);
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
           const int el = (v * LPR + sl) * 4;
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
         acc[v] = aggr_combine<OP>(acc[v], o4);
       }
     }
-    const T* ps = self >= 0 ? src + (int64_t)self * d : src2 + (int64_t)(-1 - self) * d;
+    const T* ps = row_of(self);
     // mean = sum / deg (a true division, like torch's scatter-mean), 0 for an empty row
     const float dv = (OP == GIGL_AGGR_MEAN && m > 0) ? (float)m : 1.f;
     const float4_t none4 = {0.f, 0.f, 0.f, 0.f};
@@ -1592,7 +1598,7 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
                       const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                       const int32_t* n_rows_dev, int64_t rows_cap, float* out, int op = GIGL_AGGR_MEAN,
                       const int32_t* n_local_dev = nullptr, int tiled_nkc = 0, const int32_t* global_map = nullptr,
-                      const T* src2 = nullptr) {
+                      const T* src2 = nullptr, const T* src3 = nullptr) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
@@ -1601,7 +1607,7 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
   const int vecs = d / 4;
 #define GLO(LPR, VPL, OP)                                                                            \
   hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, 0, st, src, d, gather_ids, rowptr, \
-                     rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc, global_map, src2)
+                     rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc, global_map, src2, src3)
 #define GL(LPR, VPL)                                        \
   do {                                                      \
     if (op == GIGL_AGGR_MEAN) GLO(LPR, VPL, GIGL_AGGR_MEAN); \
@@ -1673,15 +1679,15 @@ int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dty
                                  const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                                  const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
                                  const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc,
-                                 const int32_t* global_map, const void* src2) {
+                                 const int32_t* global_map, const void* src2, const void* src3) {
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   if (src_dtype == GIGL_DTYPE_F32)
     return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
-                                aggr, n_local_rows_dev, tiled_nkc, global_map, (const float*)src2);
+                                aggr, n_local_rows_dev, tiled_nkc, global_map, (const float*)src2, (const float*)src3);
   return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
-                               aggr, n_local_rows_dev, tiled_nkc, global_map, (const __half*)src2);
+                               aggr, n_local_rows_dev, tiled_nkc, global_map, (const __half*)src2, (const __half*)src3);
 }
 
 extern "C" {

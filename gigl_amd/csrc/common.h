@@ -101,10 +101,11 @@ int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dty
                                  const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                                  const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
                                  const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc = 0,
-                                 const int32_t* global_map = nullptr, const void* src2 = nullptr);
+                                 const int32_t* global_map = nullptr, const void* src2 = nullptr,
+                                 const void* src3 = nullptr);
 // global_map: the rows i >= *n_local_rows_dev hold GLOBAL ids whose row in `src` is global_map[id] (the sharded plan's
 // receive buffer, dist.hip); a NEGATIVE row index -1-h (from gather_ids or global_map) is row h of `src2` (replicated
-// hot rows)
+// hot rows) when h < 2^30, else row h - 2^30 of `src3` (the rank's own feature table)
 // tiled_nkc > 0: `out` is written in the projection's tiled operand layout ([row tile of 128][K chunk of 32][128 rows]
 // [32 floats], tiled_nkc = ceil(2d / 32); capacity: whole row tiles) and read by gigl_linear_tiled (agg.hip)
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,

@@ -352,7 +352,8 @@ __global__ __launch_bounds__(256) void claim_bucket_kernel(const uint32_t* __res
                                                            int64_t cap, uint32_t* __restrict__ ids_out,
                                                            int32_t* __restrict__ counts, uint32_t* __restrict__ stamp,
                                                            uint32_t tag, int32_t* __restrict__ slot_map,
-                                                           int64_t n_global, const int32_t* __restrict__ hot_of) {
+                                                           int64_t n_global, const int32_t* __restrict__ hot_of,
+                                                           int32_t own_rank) {
   __shared__ int32_t s_cnt[64], s_base[64];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t lim = n_valid ? (int64_t)*n_valid : m;
@@ -364,6 +365,10 @@ __global__ __launch_bounds__(256) void claim_bucket_kernel(const uint32_t* __res
       slot_map[v] = -1 - h;
       v = GIGL_INVALID;
     }
+  }
+  if (v != GIGL_INVALID && own_rank >= 0 && v % world == (uint32_t)own_rank) {  // this rank's own row: read in place
+    slot_map[v] = -1 - ((1 << 30) + (int32_t)(v / world));
+    v = GIGL_INVALID;
   }
   if (v != GIGL_INVALID && atomicExch(&stamp[v], tag) == tag) v = GIGL_INVALID;
   const uint32_t r = v == GIGL_INVALID ? 0xFFFFFFFFu : v % world;
@@ -625,6 +630,9 @@ struct gigl_dist_plan {
   // dense pull bookkeeping (two hops, raw rows): the union graph is the leaf-global build (leaves stay global ids in
   // their parents' rows), ids are claimed through stamp[] and located through slot_map[] (claim_bucket_kernel)
   bool dense = false;
+  // dense mode: a rank's OWN rows are never requested, served or copied — the aggregation reads them from the feature
+  // table (GIGL_DIST_COPY_OWN_ROWS=1: through the receive buffer like everybody else's, for measurements)
+  bool own_in_place = false;
   // replicated hot rows (gigl_dist_plan_set_hot_rows): hot_of[id] = row of the id in hot_rows, -1 = not replicated
   int32_t* hot_of = nullptr;
   const void* hot_rows = nullptr;
@@ -720,10 +728,11 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       // the inner nodes first (their own rows: pos), then every sampled leaf
       hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes,
                          p->act_rows, n_inner, world, p->pull_cap, p->ids_s, p->pull_counts, p->stamp, p->tag,
-                         p->slot_map, p->n_global, (const int32_t*)p->hot_of);
+                         p->slot_map, p->n_global, (const int32_t*)p->hot_of, p->own_in_place ? p->rank : -1);
       hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->last_slots)), dim3(256), 0, st,
                          (const uint32_t*)p->tree.nbr[L - 1], p->last_slots, (const int32_t*)nullptr, world, p->pull_cap,
-                         p->ids_s, p->pull_counts, p->stamp, p->tag, p->slot_map, p->n_global, (const int32_t*)p->hot_of);
+                         p->ids_s, p->pull_counts, p->stamp, p->tag, p->slot_map, p->n_global, (const int32_t*)p->hot_of,
+                         p->own_in_place ? p->rank : -1);
       hipLaunchKernelGGL(pos_from_map_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes, n_inner,
                          p->act_rows, p->slot_map, p->n_global, p->pos);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
@@ -804,7 +813,8 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     if (l == 0 && p->dense)  // rows of level L-1 hold global ids: located through slot_map
       rc = gigl_gather_reduce_mixed(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, p->un.rowptr,
                                     p->un.rowend, p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN,
-                                    p->un.meta + GIGL_META_LEVEL0 + (L - 2), p->abuf, 0, p->slot_map, p->hot_rows);
+                                    p->un.meta + GIGL_META_LEVEL0 + (L - 2), p->abuf, 0, p->slot_map, p->hot_rows,
+                                    p->feat->rows);
     else if (l == 0)
       rc = gigl_gather_reduce(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, p->un.rowptr,
                               p->un.rowend, p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN, p->abuf);
@@ -899,6 +909,7 @@ int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* sha
   p->n_global = shard->n * W;
   p->dense = hops == 2 && !p->project && p->n_global < ((int64_t)1 << 32) && (shard_feat->d & 3) == 0 &&
              getenv("GIGL_DIST_GENERIC_UNION") == nullptr;
+  p->own_in_place = p->dense && shard->n < ((int64_t)1 << 30) && getenv("GIGL_DIST_COPY_OWN_ROWS") == nullptr;
   // (dense: the last hop's ids live right behind the union's col array so that rows can alias tree segments)
   p->un.col = (int32_t*)alloc((size_t)(cap_edges + (p->dense ? last_slots : 0)) * 4);
   ok = p->un.col != nullptr;
