@@ -32,7 +32,7 @@ struct gigl_ctx {
   bool capturing = false;            // stream capture in progress: events become EXTERNAL event-record nodes
   double prof_acc_ms[16] = {0};      // + durations harvested from hipGraph replays (pipeline.hip)
   int64_t prof_acc_n[16] = {0};
-  // sampler: range-top-K table over the xxhash sequence (sample.hip), built lazily
+  // sampler: threshold-list table over the xxhash sequence (sample.hip), built lazily, shared per device
   void* sampler_table = nullptr;
   // record encoder: x^(8*b*256^j) mod P tables of the CRC-32C combine step (serialize.hip), built lazily
   uint32_t* crc_shift_tbl = nullptr;

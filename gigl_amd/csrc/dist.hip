@@ -1062,10 +1062,7 @@ int32_t gigl_dist_plan_set_hot_rows(gigl_dist_plan* p, const uint32_t* hot_ids, 
                        p->n_global, p->hot_of);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (hot_ids may be freed by the caller after this returns)
-  p->hot_rows = n_hot > 0 ? hot_rows : nullptr;
-  if (n_hot == 0) {  // back to "nothing replicated"
-    p->hot_rows = nullptr;
-  }
+  p->hot_rows = n_hot > 0 ? hot_rows : nullptr;  // (n_hot == 0: back to "nothing replicated")
   return GIGL_OK;
 }
 

@@ -497,7 +497,7 @@ int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sam
   if (!p->captured || p->cap_mode != mode || p->cap_seed != sampling_seed || p->cap_prof_mask != ctx->prof_mask) {
     GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     drop_graphs(p);
-    // one eager run first: sizes the arena, builds the hash range table, sets kernel attributes — none of
+    // one eager run first: sizes the arena, builds the hash threshold table, sets kernel attributes — none of
     // which may happen inside a capture.  (This batch is produced by that run.)
     const uint32_t keep_mask = ctx->prof_mask;
     ctx->prof_mask = 0;

@@ -11,12 +11,14 @@
 // (xxhash64_int32(i + K + seed*counter) as signed int64, i); K = int32-wrapping sum of the ids on the
 // path root..parent, counter = hop number (1-based).  n <= f copies the row through.
 //
-// Kernel shape (gfx950): one 64-lane wavefront per parent slot.  Top-f selection never leaves the
-// wave: the first 64 candidates are bitonic-sorted across lanes (shuffles), later candidates are
-// filtered against the running f-th key with one ballot and the (rare) survivors are inserted by a
-// one-step lane shift.  Long rows do not hash their whole adjacency: see "Range-top-K table" below.
-// The selected indices are re-sorted ascending so the output is the canonical (ascending id) form
-// of the sampled set.
+// Kernel shape (gfx950): a hop is two launches — plan_rows_kernel (one THREAD per parent slot: parent, row, hash window,
+// where its candidates are -> a 32-byte descriptor) and expand_rows_kernel (one wave per TWO parent slots).  A row
+// never hashes its adjacency and never reads it: the ~lambda positions whose hash lies under the row's threshold come
+// from the device-wide "threshold lists" table (below) in one or two coalesced chunks, already in position order; the
+// wave compacts the survivors into LDS (ballot + mbcnt), ranks them by counting, and the f lanes with rank < f ARE
+// the sample in ascending-id order.  Rows the filter cannot settle (too few / too many survivors, a proxy tie at the
+// f-th place) take a serial path: candidates inserted into a wave-resident sorted list by DPP lane shifts, 64-bit
+// keys when a tie was seen.
 #include "common.h"
 
 #include <cstdlib>
@@ -1236,7 +1238,7 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
   bool covered = false;
   int32_t rc = GIGL_OK;
   if (mode == GIGL_MODE_SPARK_HASH) {
-    // size the hash range table for this graph/seed (built once, reused by every later call)
+    // size the hash threshold table for this graph/seed (built once, reused by every later call)
     const uint64_t bound = window_bound(g, hops, 1, sampling_seed);
     const uint64_t cap = table_cap_j();  // windows beyond the table fall back to direct hashing
     rc = ensure_table(ctx, bound == ~0ULL ? (1ull << 20) : (bound + 1 < cap ? bound + 1 : cap));

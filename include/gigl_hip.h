@@ -259,7 +259,7 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
  * GIGL_INVALID) and ksums[i] (K of the path root..nodes[i], computed by the requesting rank) arrive through the
  * frontier all-to-all.  Same selection rule as gigl_sample_khop with hash_add = seed * counter; output
  * out_nbr[i*f + j], out_cnt[i].  max_window_end >= 0 bounds ksum + hash_add + degree over all requests (lets
- * every window use the hash range table); -1 = unknown. */
+ * every window use the hash threshold table); -1 = unknown. */
 int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* nodes, const uint32_t* ksums,
                              int64_t m, int32_t f, int32_t hash_add, int32_t world, int64_t max_window_end,
                              uint32_t* out_nbr, int32_t* out_cnt);

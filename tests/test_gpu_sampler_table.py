@@ -1,4 +1,4 @@
-"""The range-top-K hash table (sample.hip) must be invisible: table path, direct path and the
+"""The hash threshold table (sample.hip) must be invisible: table path, direct path and the
 out-of-domain fallback all return exactly the oracle's sample."""
 import numpy as np
 import pytest
