@@ -107,6 +107,10 @@ class GiglTypedFeat(C.Structure):
     _fields_ = [("x", C.c_void_p), ("d", C.c_int32), ("n", C.c_int64)]
 
 
+class GiglTypedEdgeFeat(C.Structure):
+    _fields_ = [("by_source", C.c_void_p), ("feat", C.c_void_p), ("d", C.c_int32)]
+
+
 REC_ROOTED_NODE_NEIGHBORHOOD, REC_NODE_ANCHOR_LINK_PRED = 0, 1
 STATS = {"sampled": 0, "aggregated": 1, "union_edges": 2, "union_nodes": 3, "expand_bytes": 4, "agg_layer0": 5,
          "rows_layer0": 9, "overflow": 13, "pulled_rows": 14, "pull_bucket_max": 15}
@@ -245,8 +249,10 @@ def load() -> C.CDLL:
         "gigl_collated_typed_edges": [vp, i32, vp, vp],
         "gigl_collated_typed_samples": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         "gigl_collated_typed_destroy": [vp],
-        "gigl_typed_records_capacity": [P(GiglTypedOp), i32, P(GiglTypedFeat), i32, i64, i32, P(i64)],
-        "gigl_typed_records_encode": [vp, vp, i32, P(GiglTypedOp), i32, P(GiglTypedFeat), i32, i64, i32, vp, i64, vp, vp],
+        "gigl_typed_records_capacity": [P(GiglTypedOp), i32, P(GiglTypedFeat), i32, P(GiglTypedEdgeFeat), i32, i64, i32,
+                                        P(i64)],
+        "gigl_typed_records_encode": [vp, vp, i32, P(GiglTypedOp), i32, P(GiglTypedFeat), i32, P(GiglTypedEdgeFeat), i32,
+                                      i64, i32, vp, i64, vp, vp],
         "gigl_tfexample_decode": [vp, vp, vp, i64, P(GiglColumn), i32, i32, P(i64)],
         "gigl_gat_aggregate_edge": [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, i32,
                                     i64, vp, vp, vp, vp],

@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
 //          wave per node, TFRecord framing + CRC-32C as in record_write_kernel.
 // Edge features are not carried by this path (a sampler that hydrates typed edge features assembles on the host).
 // ------------------------------------------------------------------------------------------
-constexpr int TYPED_MAX_OPS = 16, TYPED_MAX_NODE_TYPES = 16;
+constexpr int TYPED_MAX_OPS = 16, TYPED_MAX_NODE_TYPES = 16, TYPED_MAX_EDGE_TYPES = 16;
 constexpr uint32_t TYPED_MAX_ITEMS = 4096;  // candidate nodes / edges per root the LDS sort is sized for
 constexpr unsigned long long PAD64 = ~0ull;
 
@@ -800,7 +800,34 @@ struct TypedArgs {
   uint32_t* u_etype;            // [b][items]
   uint32_t* u_info;             // [b][4]: distinct nodes, distinct edges, bytes of the node fields, graph body bytes
   const uint32_t* shift_tbl;
+  // Edge.feature_values per condensed edge type: the type's edge list as CSR by SOURCE + one fp32 row per edge in its
+  // `col` order (feat == NULL: edges of the type carry no features)
+  struct EdgeFeat {
+    const int64_t* rowptr;
+    const uint32_t* col;
+    int64_t n_rows;
+    const float* feat;
+    int32_t d;
+  } efeat[TYPED_MAX_EDGE_TYPES];
+  int32_t n_edge_types;
 };
+
+// position of edge (s -> d) in its type's CSR by source, NONE when the type has no features or the edge is not listed
+__device__ __forceinline__ uint32_t typed_edge_pos(const TypedArgs& a, unsigned long long k1, uint32_t cet) {
+  if (cet >= (uint32_t)a.n_edge_types || !a.efeat[cet].feat) return NONE;
+  const TypedArgs::EdgeFeat& g = a.efeat[cet];
+  const uint32_t s = (uint32_t)(k1 >> 32), d = (uint32_t)k1;
+  if ((int64_t)s >= g.n_rows) return NONE;
+  int64_t lo = g.rowptr[s];
+  const int64_t end = g.rowptr[s + 1];
+  int64_t hi = end;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (g.col[mid] < d) lo = mid + 1;
+    else hi = mid;
+  }
+  return (lo < end && g.col[lo] == d) ? (uint32_t)lo : NONE;
+}
 
 __device__ __forceinline__ uint32_t typed_node_body(const TypedArgs& a, unsigned long long key) {
   const uint32_t id = (uint32_t)(key >> 32), t = (uint32_t)key;
@@ -810,11 +837,15 @@ __device__ __forceinline__ uint32_t typed_node_body(const TypedArgs& a, unsigned
   if (d > 0) n += 1 + vlen(4u * (uint32_t)d) + 4u * (uint32_t)d;
   return n;
 }
-__device__ __forceinline__ uint32_t typed_edge_body(unsigned long long k1, uint32_t cet) {
+__device__ __forceinline__ uint32_t typed_edge_body(const TypedArgs& a, unsigned long long k1, uint32_t cet) {
   const uint32_t s = (uint32_t)(k1 >> 32), d = (uint32_t)k1;
   uint32_t n = 1 + vlen(cet);
   if (s) n += 1 + vlen(s);
   if (d) n += 1 + vlen(d);
+  if (typed_edge_pos(a, k1, cet) != NONE) {
+    const uint32_t de = (uint32_t)a.efeat[cet].d;
+    n += 1 + vlen(4u * de) + 4u * de;
+  }
   return n;
 }
 
@@ -899,7 +930,7 @@ __global__ __launch_bounds__(256) void typed_plan_kernel(TypedArgs a, int64_t* r
     const bool keep = k != PAD64 && (i == 0 || ek[i - 1] != k || et[i - 1] != t);
     uint32_t tot, tot_b;
     const uint32_t pos = block_exscan(keep ? 1u : 0u, s_w, tot);
-    const uint32_t fb = keep ? field_len(typed_edge_body(k, t)) : 0u;
+    const uint32_t fb = keep ? field_len(typed_edge_body(a, k, t)) : 0u;
     block_exscan(fb, s_w, tot_b);
     if (keep) {
       ue[n_edges + pos] = k;
@@ -1006,12 +1037,12 @@ __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int
     const unsigned long long k = i < n_edges ? ue[i] : 0ull;
     const uint32_t t = i < n_edges ? ut[i] : 0u;
     uint32_t tot;
-    const uint32_t off = block_exscan(i < n_edges ? field_len(typed_edge_body(k, t)) : 0u, s_w, tot);
+    const uint32_t off = block_exscan(i < n_edges ? field_len(typed_edge_body(a, k, t)) : 0u, s_w, tot);
     if (i < n_edges) {
       uint8_t* q = edges + run + off;
       const uint32_t s = (uint32_t)(k >> 32), d = (uint32_t)k;
       *q++ = 0x1A;
-      q = put_varint(q, typed_edge_body(k, t));
+      q = put_varint(q, typed_edge_body(a, k, t));
       if (s) {
         *q++ = 0x08;
         q = put_varint(q, s);
@@ -1021,7 +1052,15 @@ __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int
         q = put_varint(q, d);
       }
       *q++ = 0x18;
-      put_varint(q, t);
+      q = put_varint(q, t);
+      const uint32_t pe = typed_edge_pos(a, k, t);
+      if (pe != NONE) {  // feature_values = 4, packed floats (a few words per edge: written by the edge's thread)
+        const uint32_t de = (uint32_t)a.efeat[t].d;
+        *q++ = 0x22;
+        q = put_varint(q, 4u * de);
+        const float* fr = a.efeat[t].feat + (int64_t)pe * de;
+        for (uint32_t w2 = 0; w2 < de; ++w2) put_word(q + 4u * w2, __float_as_uint(fr[w2]));
+      }
     }
     run += tot;
   }
@@ -1272,7 +1311,8 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
 }
 
 int32_t gigl_typed_records_capacity(const gigl_typed_op* ops, int32_t n_ops, const gigl_typed_feat* feats,
-                                    int32_t n_node_types, int64_t n_records, int32_t tfrecord_frame, int64_t* bytes) {
+                                    int32_t n_node_types, const gigl_typed_edge_feat* efeats, int32_t n_edge_types,
+                                    int64_t n_records, int32_t tfrecord_frame, int64_t* bytes) {
   if (!ops || n_ops < 1 || n_ops > TYPED_MAX_OPS || n_node_types < 1 || n_node_types > TYPED_MAX_NODE_TYPES || !bytes)
     return GIGL_E_INVALID_ARG;
   int64_t items = 0, dmax = 0;
@@ -1280,13 +1320,17 @@ int32_t gigl_typed_records_capacity(const gigl_typed_op* ops, int32_t n_ops, con
   for (int t = 0; t < n_node_types; ++t)
     if (feats && feats[t].x && feats[t].d > dmax) dmax = feats[t].d;
   // node field <= 2 + 6 + 6 + 6 + 4 d (+ length bytes), edge field <= 2 + 6 + 6 + 6; root field, graph header, frame
-  const int64_t node = 26 + 4 * dmax, edge = 20;
+  int64_t demax = 0;
+  for (int t = 0; efeats && t < n_edge_types; ++t)
+    if (efeats[t].feat && efeats[t].d > demax) demax = efeats[t].d;
+  const int64_t node = 26 + 4 * dmax, edge = 26 + 4 * demax;
   *bytes = n_records * ((items + 2) * node + items * edge + 16 + (tfrecord_frame ? 16 : 0));
   return GIGL_OK;
 }
 
 int32_t gigl_typed_records_encode(gigl_ctx* ctx, const uint32_t* roots, int32_t root_node_type, const gigl_typed_op* ops,
-                                  int32_t n_ops, const gigl_typed_feat* feats, int32_t n_node_types, int64_t n_records,
+                                  int32_t n_ops, const gigl_typed_feat* feats, int32_t n_node_types,
+                                  const gigl_typed_edge_feat* efeats, int32_t n_edge_types, int64_t n_records,
                                   int32_t tfrecord_frame, uint8_t* out, int64_t out_cap, int64_t* rec_off,
                                   int32_t* status) {
   if (!ctx) return GIGL_E_INVALID_ARG;
@@ -1313,6 +1357,18 @@ int32_t gigl_typed_records_encode(gigl_ctx* ctx, const uint32_t* roots, int32_t 
   for (int t = 0; t < n_node_types; ++t)
     if (feats) a.feat[t] = feats[t];
   a.n_node_types = n_node_types;
+  GIGL_REQUIRE(ctx, n_edge_types >= 0 && n_edge_types <= TYPED_MAX_EDGE_TYPES, "edge types outside [0,%d]",
+               TYPED_MAX_EDGE_TYPES);
+  a.n_edge_types = efeats ? n_edge_types : 0;
+  for (int t = 0; t < a.n_edge_types; ++t) {
+    if (!efeats[t].feat) continue;
+    GIGL_REQUIRE(ctx, efeats[t].by_source && efeats[t].d >= 1, "edge type %d: features need the edge list as CSR by source", t);
+    a.efeat[t].rowptr = efeats[t].by_source->rowptr;
+    a.efeat[t].col = efeats[t].by_source->col;
+    a.efeat[t].n_rows = efeats[t].by_source->n;
+    a.efeat[t].feat = efeats[t].feat;
+    a.efeat[t].d = efeats[t].d;
+  }
   a.frame = tfrecord_frame ? 1 : 0;
   a.items = (uint32_t)items;
   a.pow2 = next_pow2((uint32_t)items + 1);

@@ -464,10 +464,13 @@ class HipEngine:
         if entry.get("graph"):
             self._lib.gigl_graph_destroy(entry["graph"])
 
-    def encode_typed_records(self, roots: torch.Tensor, root_node_type: int, ops, feats, *, tfrecord_frame: bool = True):
+    def encode_typed_records(self, roots: torch.Tensor, root_node_type: int, ops, feats, *, tfrecord_frame: bool = True,
+                             edge_feats=None):
         """typed (heterogeneous) RootedNodeNeighborhood records on the device (gigl_typed_records_encode).
         roots: int32 [b] on the device; ops: sequence of (frontier [b, w], nbr [b, w, f], condensed_edge_type,
-        result_node_type, outgoing); feats: per condensed node type a float32 [n, d] device tensor or None.
+        result_node_type, outgoing); feats: per condensed node type a float32 [n, d] device tensor or None;
+        edge_feats: per condensed edge type the name of a load_label_edges entry (the type's edges as CSR by source with
+        their feature rows) or None.
         -> (uint8 device tensor of all records back to back, int64 device tensor rec_off[b + 1])"""
         b = int(roots.numel())
         roots = roots.to(device=self.device, dtype=torch.int32).contiguous()
@@ -490,9 +493,18 @@ class HipEngine:
             x = x.to(device=self.device, dtype=torch.float32).contiguous()
             keep.append(x)
             c_feats[t].x, c_feats[t].d, c_feats[t].n = x.data_ptr(), int(x.shape[1]), int(x.shape[0])
+        edge_feats = list(edge_feats or [])
+        c_ef = (_lib.GiglTypedEdgeFeat * max(len(edge_feats), 1))()
+        for t, name in enumerate(edge_feats):
+            if name is None:
+                continue
+            e = self._label_edges[name]
+            if e["table"] is None:
+                continue
+            c_ef[t].by_source, c_ef[t].feat, c_ef[t].d = e["graph"], e["table"].data_ptr(), int(e["table"].shape[1])
         cap = C.c_int64()
-        rc = self._lib.gigl_typed_records_capacity(c_ops, len(ops), c_feats, len(feats), b, 1 if tfrecord_frame else 0,
-                                                   C.byref(cap))
+        rc = self._lib.gigl_typed_records_capacity(c_ops, len(ops), c_feats, len(feats), c_ef, len(edge_feats), b,
+                                                   1 if tfrecord_frame else 0, C.byref(cap))
         if rc != 0:
             raise ValueError("gigl_typed_records_capacity: between 1 and 16 ops / node types")
         out = torch.empty(max(cap.value, 1), dtype=torch.uint8, device=self.device)
@@ -500,7 +512,8 @@ class HipEngine:
         status = torch.zeros(1, dtype=torch.int32, device=self.device)
         torch.cuda.current_stream(self.device).synchronize()  # the op results may come from torch's stream
         check(self._lib.gigl_typed_records_encode(self._ctx, C.c_void_p(roots.data_ptr()), int(root_node_type), c_ops,
-                                                  len(ops), c_feats, len(feats), b, 1 if tfrecord_frame else 0,
+                                                  len(ops), c_feats, len(feats), c_ef, len(edge_feats), b,
+                                                  1 if tfrecord_frame else 0,
                                                   C.c_void_p(out.data_ptr()), cap.value,
                                                   C.c_void_p(rec_off.data_ptr()), C.c_void_p(status.data_ptr())),
               self._ctx)

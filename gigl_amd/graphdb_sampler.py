@@ -112,6 +112,7 @@ class HipGraphDBSampler:
         # Edge.feature_values of the typed messages (hydrated on the host with the message assembly): row i of
         # edge_features[et] belongs to edge i of edges[et]; several rows for one (src, dst): the first wins
         self._edge_rows: Dict[Tuple[int, int, int], np.ndarray] = {}
+        self._has_edge_feats = {et: bool(np.asarray(rows).size) for et, rows in (edge_features or {}).items()}
         for et, rows in (edge_features or {}).items():
             c = condensed_edge_types[et]
             for s_, d_, row in zip(np.asarray(edges[et][0]).tolist(), np.asarray(edges[et][1]).tolist(),
@@ -122,7 +123,9 @@ class HipGraphDBSampler:
             src, dst = np.asarray(src), np.asarray(dst)
             # rows = the node a query starts from, columns = what it returns
             self.engine.load_label_edges(self._key(et, INCOMING), n_all, dst, src)
-            self.engine.load_label_edges(self._key(et, OUTGOING), n_all, src, dst)
+            # (the by-source list also carries the type's edge features for the device-side record encoder)
+            self.engine.load_label_edges(self._key(et, OUTGOING), n_all, src, dst,
+                                         feats=(edge_features or {}).get(et))
 
     @staticmethod
     def _key(et: EdgeType, direction: str) -> str:
@@ -243,10 +246,8 @@ class HipGraphDBSampler:
                        tfrecord_frame: bool = True) -> List[bytes]:
         """the same RootedNodeNeighborhood messages as getKHopSubgraphForRootNodes, serialized ON THE DEVICE
         (gigl_typed_records_encode: per root the distinct typed nodes and edges of every op, sorted, with the nodes'
-        feature rows) — the host only slices the finished byte string.  Edge feature_values are a host-assembly
-        feature: a sampler built with edge_features raises here."""
-        if self._edge_rows:
-            raise NotImplementedError("typed edge features are hydrated by the host assembly (getKHopSubgraphForRootNodes)")
+        feature rows, the edges' feature rows joined by binary search in their type's edge list) — the host only
+        slices the finished byte string."""
         roots = torch.tensor(np.asarray(root_ids, dtype=np.int64).astype(np.uint32).view(np.int32))
         res = self.run_dag(roots, dag)
         n_types = max(self.node_types.values()) + 1
@@ -258,8 +259,12 @@ class HipGraphDBSampler:
             outgoing = op.sampling_direction == OUTGOING
             got = self.node_types[op.edge_type.dst_node_type if outgoing else op.edge_type.src_node_type]
             ops.append((r.frontier, r.nbr, self.condensed_edge_types[op.edge_type], got, outgoing))
+        n_et = max(self.condensed_edge_types.values()) + 1
+        by_c = {c: et for et, c in self.condensed_edge_types.items()}
+        edge_feats = [self._key(by_c[c], OUTGOING) if c in by_c and self._has_edge_feats.get(by_c[c]) else None
+                      for c in range(n_et)]
         out, off = self.engine.encode_typed_records(roots.to(self.engine.device), self.node_types[root_node_type], ops,
-                                                    feats, tfrecord_frame=tfrecord_frame)
+                                                    feats, tfrecord_frame=tfrecord_frame, edge_feats=edge_feats)
         blob, off = out.cpu().numpy().tobytes(), off.cpu().numpy()
         return [blob[int(off[i]):int(off[i + 1])] for i in range(len(root_ids))]
 

@@ -377,9 +377,12 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
  *      direction (outgoing: edges are frontier -> nbr; else nbr -> frontier).  feats[t]: fp32 feature table of
  *      condensed node type t (x NULL: nodes of that type carry no feature_values).  Records: root_node = 1 (id, type,
  *      features), neighborhood = 2 with the distinct nodes ascending by (id, type) and the distinct edges ascending by
- *      (src, dst, type) — byte-identical to the host assembly in gigl_amd/graphdb_sampler.py.  Edge feature_values
- *      are not written by this path.  Up to 16 ops, 16 node types, 4095 sampled slots (sum of w*f) per root
- *      (GIGL_E_UNSUPPORTED beyond).  out / rec_off / status as gigl_records_encode. */
+ *      (src, dst, type) — byte-identical to the host assembly in gigl_amd/graphdb_sampler.py.  efeats[t] (optional):
+ *      Edge.feature_values of condensed edge type t — the type's edge list as a CSR-by-source graph
+ *      (gigl_graph_build_from_coo with the roles swapped) and one fp32 row per edge in that graph's `col` order; the
+ *      row of edge (s -> d) is found by binary search in row s (hydrateEdges' join).  Up to 16 ops, 16 node types, 16
+ *      edge types, 4095 sampled slots (sum of w*f) per root (GIGL_E_UNSUPPORTED beyond).  out / rec_off / status as
+ *      gigl_records_encode. */
 typedef struct gigl_typed_op {
   const uint32_t* frontier;
   const uint32_t* nbr;
@@ -393,10 +396,17 @@ typedef struct gigl_typed_feat {
   int32_t d;
   int64_t n;
 } gigl_typed_feat;
+typedef struct gigl_typed_edge_feat {
+  gigl_graph* by_source; /* the edge type's edges, CSR by source */
+  const float* feat;     /* device, [edges, d] in by_source's col order; NULL: no features for this type */
+  int32_t d;
+} gigl_typed_edge_feat;
 int32_t gigl_typed_records_capacity(const gigl_typed_op* ops, int32_t n_ops, const gigl_typed_feat* feats,
-                                    int32_t n_node_types, int64_t n_records, int32_t tfrecord_frame, int64_t* bytes);
+                                    int32_t n_node_types, const gigl_typed_edge_feat* efeats, int32_t n_edge_types,
+                                    int64_t n_records, int32_t tfrecord_frame, int64_t* bytes);
 int32_t gigl_typed_records_encode(gigl_ctx* ctx, const uint32_t* roots, int32_t root_node_type, const gigl_typed_op* ops,
-                                  int32_t n_ops, const gigl_typed_feat* feats, int32_t n_node_types, int64_t n_records,
+                                  int32_t n_ops, const gigl_typed_feat* feats, int32_t n_node_types,
+                                  const gigl_typed_edge_feat* efeats, int32_t n_edge_types, int64_t n_records,
                                   int32_t tfrecord_frame, uint8_t* out, int64_t out_cap, int64_t* rec_off,
                                   int32_t* status);
 

@@ -174,6 +174,10 @@ def test_reference_heterogeneous_fixture(golden_dir):
                 assert hit.size > 0
                 np.testing.assert_array_equal(e.feature_values, efeats[et][hit[0]])  # the edge table's own row
             total_edges += len(want_e)
+        # the same messages written by the device encoder, edge features included: byte for byte
+        dev_recs = s.encode_records(roots, root_type, SamplingOpDAG.from_ops(ops), tfrecord_frame=False)
+        assert [m.SerializeToString() for m in msgs] == dev_recs
+        assert any(e.feature_values.size for m in msgs for e in m.neighborhood.edges)
     assert total_edges > 100
     s.close()
 
