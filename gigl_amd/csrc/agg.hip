@@ -258,10 +258,12 @@ __global__ __launch_bounds__(256) void gather_mean_generic_kernel(const T* __res
 // stores per lane — the row-per-lane pattern of the MFMA D layout is store-ISSUE bound (cdna guide T21).
 // D layout (32x32, 16 regs): reg v -> row 8*(v/4) + 4*g + (v%4), col r.
 __device__ __forceinline__ void store_block_32x32(const float16_t& acc, float* strip, int lane, const float* bias,
-                                                  int act, int row0, int col0, int M, int N, float* y) {
+                                                  int act, int row0, int col0, int M, int N, float* y,
+                                                  int ldy = 0) {
   const int r = lane & 31, g = lane >> 5;
   const float bv = (bias && col0 + r < N) ? bias[col0 + r] : 0.f;
-  if ((N & 3) != 0) {  // rows are not 16-byte aligned: dword stores
+  if (ldy == 0) ldy = N;  // (ldy: row stride of y when the N columns are a slice of wider rows)
+  if (((N | ldy) & 3) != 0) {  // rows are not 16-byte aligned: dword stores
     if (col0 + r >= N) return;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
@@ -269,7 +271,7 @@ __device__ __forceinline__ void store_block_32x32(const float16_t& acc, float* s
       if (row < M) {
         float val = acc[v] + bv;
         if (act == 1) val = val > 0.f ? val : 0.f;
-        y[(int64_t)row * N + col0 + r] = val;
+        y[(int64_t)row * ldy + col0 + r] = val;
       }
     }
     return;
@@ -289,7 +291,7 @@ __device__ __forceinline__ void store_block_32x32(const float16_t& acc, float* s
     const int row = row0 + rr, col = col0 + c4;
     if (row < M && col < N) {  // (N % 4 == 0: a float4 is inside or outside as a whole)
       const float4_t q = *reinterpret_cast<const float4_t*>(&strip[rr * 36 + c4]);
-      *reinterpret_cast<float4_t*>(y + (int64_t)row * N + col) = q;
+      *reinterpret_cast<float4_t*>(y + (int64_t)row * ldy + col) = q;
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -510,7 +512,14 @@ template <int NJ>
 __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            const int32_t* __restrict__ m_dev, int K, int N, int act,
-                                                           float* __restrict__ y, int a_tiled) {
+                                                           float* __restrict__ y, int a_tiled, int ldy,
+                                                           int64_t a_bstride, int64_t w_bstride) {
+  // (grid.y = batch of independent products sharing M/K/N: operand b of a / w is a_bstride / w_bstride floats on, its
+  // bias and its N output columns follow the previous batch's)
+  a += blockIdx.y * a_bstride;
+  w += blockIdx.y * w_bstride;
+  if (bias) bias += blockIdx.y * N;
+  y += blockIdx.y * N;
   constexpr int BK = 32, LDK = 40;          // bf16 elements per LDS row (32 + 8 of padding = 80 bytes)
   constexpr int BM = 128, BN = 64 * NJ;
   __shared__ short s_a[3][BM * LDK];
@@ -620,7 +629,8 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
-      store_block_32x32(acc[i][j], strip, lane, bias, act, m0b + wm * 64 + i * 32, n0b + wn * 32 * NJ + j * 32, M, N, y);
+      store_block_32x32(acc[i][j], strip, lane, bias, act, m0b + wm * 64 + i * 32, n0b + wn * 32 * NJ + j * 32, M, N, y,
+                        ldy);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -900,6 +910,279 @@ __global__ __launch_bounds__(256) void gat_edge_gather_kernel(
       }
       __builtin_amdgcn_wave_barrier();
     }
+  }
+}
+
+// ---- first GAT layer from the INPUT side (inference).  With x the stored feature rows (d wide, d > H*C is where it
+// pays) and W_h the C x d block of head h:  <W_h x_j, att_h> = <x_j, W_h^T att_h>,  so the attention logits need two
+// d-vectors per head and never the projected rows; and  sum_j alpha_ij W_h x_j = W_h (sum_j alpha_ij x_j),  so the
+// projection runs on the n_dst aggregated rows instead of on all n_src source rows (the union of a [25,10] batch has
+// ~4.5x more sources than destinations) and the feature rows are read straight from the resident table in their
+// storage type — no fp32 copy of the union's features is made.
+//   gat_fold_kernel    u[t][k] = sum_c att_t[h*C+c] * W[h*C+c][k]      (t = h: source side, t = H+h: destination side)
+//   gat_score_kernel   s[j][t] = <x[ids[j]], u[t]>                      one wave per source row
+//   gat_input_gather   z_h[i] = softmax-weighted mean of x over row i (+ the self loop), per head, written in the
+//                      projection's tiled operand layout; the logits are scalars known up front, so the row's maximum
+//                      and weights are formed lanes-over-edges before any feature row is touched
+// (one workgroup per 64 columns of one folded vector: 4 channel groups x 64 columns, summed through LDS)
+__global__ __launch_bounds__(256) void gat_fold_kernel(const float* __restrict__ w, const float* __restrict__ att_src,
+                                                       const float* __restrict__ att_dst, int H, int C, int d,
+                                                       float* __restrict__ u) {
+  __shared__ float part[4][64];
+  const int t = blockIdx.y, h = t % H;
+  const int kx = threadIdx.x & 63, cg = threadIdx.x >> 6, k = blockIdx.x * 64 + kx;
+  const float* att = (t < H ? att_src : att_dst) + h * C;
+  float acc = 0.f;
+  if (k < d) {
+    const float* wp = w + (int64_t)h * C * d + k;
+    for (int c = cg; c < C; c += 4) acc += att[c] * wp[(int64_t)c * d];
+  }
+  part[cg][kx] = acc;
+  __syncthreads();
+  if (cg == 0 && k < d) u[(int64_t)t * d + k] = part[0][kx] + part[1][kx] + part[2][kx] + part[3][kx];
+}
+
+// The two row-reading kernels cut a row into column chunks of 256 elements (one float4 per lane) and give every chunk
+// its own waves: the per-wave state stays small and a chunk of a row is still 512 B (fp16) / 1 KB (fp32) of
+// consecutive bytes.  Rows of a sampled batch are short (a handful of in-edges), so both kernels are organised around
+// keeping feature-row loads in flight rather than around the rows: everything a row load depends on (ids, weights)
+// is fetched lanes-over-items ahead of time.
+// NV partial sums per lane -> totals over the wave by a halving butterfly: at each step a lane keeps the half of its
+// values its own lane bit selects and hands the other half to its partner (NV - 1 exchanges in all, against 6 per
+// value for plain xor reductions); the total of value v ends up in val[0] of the lanes [v * 64 / NV, (v + 1) * 64 / NV).
+template <int NV, int OFF>
+__device__ __forceinline__ void wave_halving_sum(float* val, int lane) {
+  if constexpr (NV > 1) {
+    const bool hi = (lane & OFF) != 0;
+#pragma unroll
+    for (int k = 0; k < NV / 2; ++k) {
+      const float keep = hi ? val[k + NV / 2] : val[k], send = hi ? val[k] : val[k + NV / 2];
+      val[k] = keep + __shfl_xor(send, OFF, 64);
+    }
+    wave_halving_sum<NV / 2, OFF / 2>(val, lane);
+  } else if constexpr (OFF > 0) {
+    val[0] += __shfl_xor(val[0], OFF, 64);
+    wave_halving_sum<1, OFF / 2>(val, lane);
+  }
+}
+
+// scores: sp[c][j][t] = <x[ids[j]][chunk c], u[t][chunk c]>  (partial dot products; the reader adds the chunks).
+// A wave takes RB consecutive source rows: their ids in one load (lane r holds ids[jb + r]), then the rows R at a time.
+template <typename T, int H>
+__global__ __launch_bounds__(256) void gat_score_kernel(const T* __restrict__ src, int d,
+                                                        const uint32_t* __restrict__ ids,
+                                                        const int32_t* __restrict__ n_dev, int64_t cap,
+                                                        const float* __restrict__ u, float* __restrict__ sp) {
+  constexpr int R = 8, RB = 16;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n = *n_dev, c = blockIdx.y, el = (c * 64 + lane) * 4;
+  const bool on = el < d;
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  float4_t uu[2 * H];
+#pragma unroll
+  for (int t = 0; t < 2 * H; ++t) uu[t] = on ? *reinterpret_cast<const float4_t*>(u + (int64_t)t * d + el) : zero4;
+  float* out = sp + (int64_t)c * cap * 2 * H;
+  for (int jb = wave * RB; jb < n; jb += waves_total * RB) {
+    const uint32_t my_id = (lane < RB && jb + lane < n) ? ids[jb + lane] : 0u;
+    const int nb = min(RB, n - jb);
+    for (int r0 = 0; r0 < nb; r0 += R) {
+      float4_t x[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t id = __shfl(my_id, (r0 + r) & 63, 64);  // (outside the `on` branch: every lane takes part)
+        x[r] = on ? RowLoader<T>::load4(src + (int64_t)id * d, el) : zero4;
+      }
+      constexpr int NV = R * 2 * H;
+      float val[NV];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int t = 0; t < 2 * H; ++t)
+          val[r * 2 * H + t] = x[r].x * uu[t].x + x[r].y * uu[t].y + x[r].z * uu[t].z + x[r].w * uu[t].w;
+      wave_halving_sum<NV, 32>(val, lane);
+      // value v = r * 2H + t of this group is element v of the R rows' contiguous output
+      constexpr int LPV = 64 / NV;  // lanes holding the same value
+      const int v = lane / LPV;
+      if (lane % LPV == 0 && r0 + v / (2 * H) < nb) out[(int64_t)(jb + r0) * 2 * H + v] = val[0];
+    }
+  }
+}
+
+// attention weights of every in-edge, normalised, next to the feature row each edge reads:
+//   gid_e[e] = ids[col[e]],  alpha_e[e][h] = softmax weight of edge e in its row (0 for a self loop among the edges),
+//   alpha_self[i][h] = weight of the added self loop.   One wave per destination row, lanes over its edges.
+template <int H>
+__global__ __launch_bounds__(256) void gat_edge_weight_kernel(
+    const uint32_t* __restrict__ ids, const float* __restrict__ sp, int n_chunks, int64_t cap,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ n_rows_dev, float slope, uint32_t* __restrict__ gid_e, float* __restrict__ alpha_e,
+    float* __restrict__ alpha_self) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n_rows = *n_rows_dev;
+  auto leaky = [&](float v) { return v > 0.f ? v : slope * v; };
+  auto score = [&](int j, int t) {  // s[j][t] = sum of the chunk partials
+    float v = 0.f;
+    for (int c = 0; c < n_chunks; ++c) v += sp[((int64_t)c * cap + j) * 2 * H + t];
+    return v;
+  };
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    float sd[H], zs[H], mx[H], den[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      sd[h] = score(i, H + h);
+      zs[h] = leaky(score(i, h) + sd[h]);  // the self loop's logit
+      mx[h] = zs[h];
+    }
+    // the first 64 edges stay in registers
+    const int j0 = lane < m ? col[e0 + lane] : i;
+    float lg0[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      lg0[h] = j0 != i ? leaky(score(j0, h) + sd[h]) : -INFINITY;  // (self loops among the edges are dropped)
+      mx[h] = fmaxf(mx[h], lg0[h]);
+    }
+    if (lane < m) gid_e[e0 + lane] = ids[j0];
+    for (int c0 = 64; c0 < m; c0 += 64) {
+      const int j = c0 + lane < m ? col[e0 + c0 + lane] : i;
+      if (c0 + lane < m) gid_e[e0 + c0 + lane] = ids[j];
+      if (j != i) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) mx[h] = fmaxf(mx[h], leaky(score(j, h) + sd[h]));
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int h = 0; h < H; ++h) mx[h] = fmaxf(mx[h], __shfl_xor(mx[h], off, 64));
+    float w0[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      w0[h] = __expf(lg0[h] - mx[h]);  // (exp(-inf) = 0 for dropped lanes)
+      den[h] = w0[h] + (lane == 0 ? __expf(zs[h] - mx[h]) : 0.f);
+    }
+    for (int c0 = 64; c0 < m; c0 += 64) {
+      const int j = c0 + lane < m ? col[e0 + c0 + lane] : i;
+      if (j != i) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) den[h] += __expf(leaky(score(j, h) + sd[h]) - mx[h]);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int h = 0; h < H; ++h) den[h] += __shfl_xor(den[h], off, 64);
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float inv = 1.0f / den[h];
+      if (lane < m) alpha_e[(int64_t)(e0 + lane) * H + h] = w0[h] * inv;
+      if (lane == 0) alpha_self[(int64_t)i * H + h] = __expf(zs[h] - mx[h]) * inv;
+      for (int c0 = 64; c0 < m; c0 += 64) {
+        if (c0 + lane >= m) continue;
+        const int j = col[e0 + c0 + lane];
+        alpha_e[(int64_t)(e0 + c0 + lane) * H + h] = j != i ? __expf(leaky(score(j, h) + sd[h]) - mx[h]) * inv : 0.f;
+      }
+    }
+  }
+}
+
+// z_h[i] = alpha_self[i][h] x[ids[i]] + sum_e alpha_e[e][h] x[gid_e[e]]  for one 256-column chunk, written in the
+// projection's tiled operand layout.  A wave walks its (row, chunk) items with the NEXT item's row bounds and edge
+// list (ids + weights, lanes over edges; lane 63 carries the self loop) already on their way while the current
+// item's feature rows are in flight, U at a time.
+template <typename T, int H>
+__global__ __launch_bounds__(256) void gat_input_gather_kernel(
+    const T* __restrict__ src, int d, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ gid_e,
+    const float* __restrict__ alpha_e, const float* __restrict__ alpha_self, int n_chunks,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ n_rows_dev,
+    int nkc, int64_t head_stride, float* __restrict__ z) {
+  constexpr int U = 8;  // feature rows in flight
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n_rows = *n_rows_dev;
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int64_t work = (int64_t)n_rows * n_chunks;
+  struct Bounds { int e0, m; };
+  struct Edges { uint32_t gid; float w[H]; };
+  auto bounds = [&](int64_t wk) {
+    Bounds b{0, 0};
+    if (wk < work) {
+      const int i = (int)(wk / n_chunks);
+      b.e0 = rowptr[i];
+      b.m = rowend[i] - b.e0;
+    }
+    return b;
+  };
+  auto edges = [&](int64_t wk, const Bounds& b, int c0) {  // lanes over the edges [c0, c0 + 63) of the item's row
+    Edges e;
+    e.gid = 0u;
+#pragma unroll
+    for (int h = 0; h < H; ++h) e.w[h] = 0.f;
+    if (wk >= work) return e;
+    const int i = (int)(wk / n_chunks);
+    if (lane == 63) {  // the self loop rides in the last lane of the first group
+      if (c0 == 0) {
+        e.gid = ids[i];
+#pragma unroll
+        for (int h = 0; h < H; ++h) e.w[h] = alpha_self[(int64_t)i * H + h];
+      }
+    } else if (c0 + lane < b.m) {
+      e.gid = gid_e[b.e0 + c0 + lane];
+#pragma unroll
+      for (int h = 0; h < H; ++h) e.w[h] = alpha_e[(int64_t)(b.e0 + c0 + lane) * H + h];
+    }
+    return e;
+  };
+  int64_t wk = wave;
+  Bounds b0 = bounds(wk), b1 = bounds(wk + waves_total);
+  Edges e0 = edges(wk, b0, 0);
+  for (; wk < work; wk += waves_total) {
+    const Bounds b2 = bounds(wk + 2 * (int64_t)waves_total);
+    const Edges e1 = edges(wk + waves_total, b1, 0);
+    const int i = (int)(wk / n_chunks), c = (int)(wk - (int64_t)i * n_chunks);
+    const int el = (c * 64 + lane) * 4;
+    const bool on = el < d;
+    float4_t acc[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) acc[h] = zero4;
+    Edges cur = e0;
+    for (int c0 = 0; c0 < b0.m + 1; c0 += 63) {  // (+1: the self loop; 63 edges per group, lane 63 = self / unused)
+      if (c0 > 0) cur = edges(wk, b0, c0);
+      const int mm = min(63, b0.m - c0);            // edges of this group; the self loop follows them in group 0
+      const int cnt = mm + (c0 == 0 ? 1 : 0);
+      for (int e = 0; e < cnt; e += U) {
+        float4_t x[U];
+        float we[U][H];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          const int ee = e + t < mm ? e + t : 63;  // past the edges: the self-loop lane (weight 0 outside group 0)
+          const T* row = src + (int64_t)__shfl(cur.gid, ee, 64) * d;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const float v = __shfl(cur.w[h], ee, 64);
+            we[t][h] = e + t < cnt ? v : 0.f;
+          }
+          x[t] = (on && e + t < cnt) ? RowLoader<T>::load4(row, el) : zero4;
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t)
+#pragma unroll
+          for (int h = 0; h < H; ++h) acc[h] += we[t][h] * x[t];
+      }
+    }
+    if (on) {
+      float* tbase = z + ((int64_t)(i >> 7) * nkc) * 4096 + (i & 127) * 32 + (int64_t)(el >> 5) * 4096 + (el & 31);
+#pragma unroll
+      for (int h = 0; h < H; ++h) *reinterpret_cast<float4_t*>(tbase + h * head_stride) = acc[h];
+    }
+    b0 = b1;
+    b1 = b2;
+    e0 = e1;
   }
 }
 
@@ -1913,10 +2196,10 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
     const int64_t bm = (m_cap + 127) / 128;
     if (n > 64)
       hipLaunchKernelGGL((linear_split_kernel<2>), dim3((unsigned)(bm * ((n + 127) / 128))), dim3(256), 0, st, a, w,
-                         bias, m_dev, k, n, act, y, 0);
+                         bias, m_dev, k, n, act, y, 0, 0, (int64_t)0, (int64_t)0);
     else
       hipLaunchKernelGGL((linear_split_kernel<1>), dim3((unsigned)(bm * ((n + 63) / 64))), dim3(256), 0, st, a, w,
-                         bias, m_dev, k, n, act, y, 0);
+                         bias, m_dev, k, n, act, y, 0, 0, (int64_t)0, (int64_t)0);
   } else if ((k & 3) == 0) {  // LDS-staged, coalesced operand fetch
     const int64_t bm = (m_cap + 127) / 128;
     if (n > 32) {
@@ -1945,9 +2228,12 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
 
 // the projection over an A operand in the tiled layout gigl_gather_reduce_mixed(..., tiled_nkc) writes
 // ([row tile of 128][K chunk of 32][128 rows][32 floats], tiled_nkc = ceil(k / 32)); k % 4 == 0
-int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
-                          int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y) {
-  GIGL_REQUIRE(ctx, a_tiled && w && m_dev && y && (k & 3) == 0 && n > 0, "bad arguments");
+// y rows may be a column slice of wider rows (ldy floats apart): the per-head projections of gigl_gat_input_layer
+static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias,
+                                    const int32_t* m_dev, int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y,
+                                    int32_t ldy, int32_t batch = 1, int64_t a_bstride = 0, int64_t w_bstride = 0) {
+  GIGL_REQUIRE(ctx, a_tiled && w && m_dev && y && (k & 3) == 0 && n > 0 && ldy >= n * batch && batch >= 1,
+               "bad arguments");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (m_cap == 0) return GIGL_OK;
   hipStream_t st = ctx->stream;
@@ -1955,12 +2241,85 @@ int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, c
   const int nkc = (k + 31) / 32;
   const int64_t bm = (m_cap + 127) / 128;
   if (n > 64)
-    hipLaunchKernelGGL((linear_split_kernel<2>), dim3((unsigned)(bm * ((n + 127) / 128))), dim3(256), 0, st, a_tiled, w,
-                       bias, m_dev, k, n, act, y, nkc);
+    hipLaunchKernelGGL((linear_split_kernel<2>), dim3((unsigned)(bm * ((n + 127) / 128)), (unsigned)batch), dim3(256), 0,
+                       st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
   else
-    hipLaunchKernelGGL((linear_split_kernel<1>), dim3((unsigned)(bm * ((n + 63) / 64))), dim3(256), 0, st, a_tiled, w,
-                       bias, m_dev, k, n, act, y, nkc);
+    hipLaunchKernelGGL((linear_split_kernel<1>), dim3((unsigned)(bm * ((n + 63) / 64)), (unsigned)batch), dim3(256), 0,
+                       st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
 
+int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
+                          int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  return linear_tiled_strided(ctx, a_tiled, w, bias, m_dev, m_cap, k, n, act, y, n);
+}
+
+int64_t gigl_gat_input_layer_scratch(int32_t d, int32_t heads, int64_t cap_nodes, int64_t rows_cap, int64_t cap_edges) {
+  const int64_t nkc = (d + 31) / 32, row_tiles = (rows_cap + 127) / 128, chunks = (d + 255) / 256;
+  return (int64_t)2 * heads * d + chunks * cap_nodes * 2 * heads + cap_edges * (1 + heads) + rows_cap * heads +
+         (int64_t)heads * row_tiles * nkc * 4096;
+}
+
+int32_t gigl_gat_input_layer(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* ids,
+                             const float* w, const float* att_src, const float* att_dst, int32_t heads,
+                             int32_t channels, float negative_slope, const int32_t* rowptr, const int32_t* rowend,
+                             const int32_t* col, int64_t cap_edges, const int32_t* n_src_dev, int64_t cap_nodes,
+                             const int32_t* n_rows_dev, int64_t rows_cap, const float* bias, int32_t act,
+                             float* scratch, float* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, src && ids && w && att_src && att_dst && rowptr && rowend && col && n_src_dev && n_rows_dev &&
+                        scratch && out, "null argument");
+  GIGL_REQUIRE(ctx, d > 0 && heads > 0 && channels > 0 && cap_nodes >= rows_cap && rows_cap >= 0 && cap_edges >= 0,
+               "bad sizes");
+  GIGL_REQUIRE(ctx, src_dtype == GIGL_DTYPE_F32 || src_dtype == GIGL_DTYPE_F16, "bad dtype %d", src_dtype);
+  GIGL_REQUIRE(ctx, act == 0 || act == 1, "bad act %d", act);
+  if ((d & 3) || (heads != 1 && heads != 2 && heads != 4))
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "gigl_gat_input_layer: d=%d heads=%d outside the built shapes (d %% 4 == 0, "
+                     "heads 1|2|4)", d, heads);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  hipStream_t st = ctx->stream;
+  const int H = heads, C = channels;
+  const int nkc = (d + 31) / 32, chunks = (d + 255) / 256;
+  const int64_t row_tiles = (rows_cap + 127) / 128, head_stride = row_tiles * nkc * 4096;
+  float* z = scratch;  // (first: its float4 accesses need the base's 16-byte alignment)
+  float* u = z + H * head_stride;
+  float* sp = u + (int64_t)2 * H * d;
+  uint32_t* gid_e = reinterpret_cast<uint32_t*>(sp + (int64_t)chunks * cap_nodes * 2 * H);
+  float* alpha_e = reinterpret_cast<float*>(gid_e + cap_edges);
+  float* alpha_self = alpha_e + cap_edges * H;
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+    hipLaunchKernelGGL(gat_fold_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)(2 * H)), dim3(256), 0, st, w, att_src,
+                       att_dst, H, C, d, u);
+    int64_t sblocks = (cap_nodes + 63) / 64, wblocks = (rows_cap + 3) / 4, gblocks = (rows_cap * chunks + 3) / 4;
+    if (sblocks > 256 * 8) sblocks = 256 * 8;
+    if (wblocks > 256 * 16) wblocks = 256 * 16;
+    if (gblocks > 256 * 8) gblocks = 256 * 8;
+#define GIGL_GAT_IN(TT, HH)                                                                                             \
+  do {                                                                                                                  \
+    hipLaunchKernelGGL((gat_score_kernel<TT, HH>), dim3((unsigned)sblocks, (unsigned)chunks), dim3(256), 0, st,        \
+                       (const TT*)src, d, ids, n_src_dev, cap_nodes, u, sp);                                            \
+    hipLaunchKernelGGL((gat_edge_weight_kernel<HH>), dim3((unsigned)wblocks), dim3(256), 0, st, ids, sp, chunks,       \
+                       cap_nodes, rowptr, rowend, col, n_rows_dev, negative_slope, gid_e, alpha_e, alpha_self);         \
+    hipLaunchKernelGGL((gat_input_gather_kernel<TT, HH>), dim3((unsigned)gblocks), dim3(256), 0, st, (const TT*)src,   \
+                       d, ids, gid_e, alpha_e, alpha_self, chunks, rowptr, rowend, n_rows_dev, nkc, head_stride, z);    \
+  } while (0)
+#define GIGL_GAT_IN_H(TT)                                                                                               \
+  do {                                                                                                                  \
+    if (H == 1) GIGL_GAT_IN(TT, 1);                                                                                     \
+    else if (H == 2) GIGL_GAT_IN(TT, 2);                                                                                \
+    else GIGL_GAT_IN(TT, 4);                                                                                            \
+  } while (0)
+    if (src_dtype == GIGL_DTYPE_F32) GIGL_GAT_IN_H(float);
+    else GIGL_GAT_IN_H(__half);
+#undef GIGL_GAT_IN_H
+#undef GIGL_GAT_IN
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+  }
+  // the heads' projections in one launch (grid.y = head): z_h [rows][d] (tiled) x W_h^T -> columns [h*C, +C) of out
+  return linear_tiled_strided(ctx, z, w, bias, n_rows_dev, rows_cap, d, C, act, out, H * C, H, head_stride,
+                              (int64_t)C * d);
+}

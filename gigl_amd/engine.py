@@ -736,6 +736,29 @@ class HipEngine:
             C.c_void_p(out.data_ptr())), self._ctx)
         return out
 
+    def gat_input_layer(self, ids: torch.Tensor, w: torch.Tensor, att_src: torch.Tensor, att_dst: torch.Tensor,
+                        heads: int, channels: int, u: "UnionGraph", n_src_dev: torch.Tensor, n_rows_dev: torch.Tensor,
+                        bias: Optional[torch.Tensor], negative_slope: float = 0.2, act: int = 0) -> Optional[torch.Tensor]:
+        """first GATConv layer over the resident feature table from the input side (gigl_gat_input_layer): logits
+        from folded attention vectors, projection after the aggregation.  None when the shape is outside the built
+        ones (the caller takes gather_rows + linear + gat_aggregate)."""
+        d, cap = self.feat_dim, int(u.nodes.numel())
+        if d % 4 or heads not in (1, 2, 4) or self.feat_dtype not in (DTYPE_F32, DTYPE_F16):
+            return None
+        assert w.is_contiguous() and tuple(w.shape) == (heads * channels, d) and w.dtype == torch.float32
+        ce = int(u.col.numel())
+        n_scr = int(self._lib.gigl_gat_input_layer_scratch(d, heads, cap, cap, ce))
+        scratch = torch.empty(n_scr, dtype=torch.float32, device=self.device)
+        out = torch.empty((cap, heads * channels), dtype=torch.float32, device=self.device)
+        check(self._lib.gigl_gat_input_layer(
+            self._ctx, self._feat_ptr, self.feat_dtype, d, C.c_void_p(ids.data_ptr()), C.c_void_p(w.data_ptr()),
+            C.c_void_p(att_src.data_ptr()), C.c_void_p(att_dst.data_ptr()), heads, channels, negative_slope,
+            C.c_void_p(u.rowptr.data_ptr()), C.c_void_p(u.rowend.data_ptr()), C.c_void_p(u.col.data_ptr()),
+            ce, C.c_void_p(n_src_dev.data_ptr()), cap, C.c_void_p(n_rows_dev.data_ptr()), cap,
+            C.c_void_p(bias.data_ptr()) if bias is not None else None, act, C.c_void_p(scratch.data_ptr()),
+            C.c_void_p(out.data_ptr())), self._ctx)
+        return out
+
     def gat_aggregate_backward(self, h: torch.Tensor, att_src: torch.Tensor, att_dst: torch.Tensor, heads: int,
                                channels: int, u, n_rows_dev: torch.Tensor, out_pre: torch.Tensor, dout: torch.Tensor,
                                negative_slope: float = 0.2, edge_attr: Optional[torch.Tensor] = None,
@@ -873,6 +896,21 @@ class HipEngine:
         """weights[l]: fused fp32 [out_l, 2*in_l] = cat(lin_l.weight, lin_r.weight, dim=1) on this device.
         groups > 1: one call takes groups*b roots = `groups` independent batches of b roots each."""
         return SagePlan(self, weights, biases, b, fanouts, act_last, groups)
+
+
+_DEV_I32 = {}
+
+
+def dev_i32(device, value: int) -> torch.Tensor:
+    """a cached one-element int32 device tensor (row counts handed to the library by pointer): created once per
+    (device, value) — a fresh torch.tensor([...], device=...) per call is a pageable host-to-device copy, which
+    synchronises and cannot be captured in a graph"""
+    key = (str(device), int(value))
+    t = _DEV_I32.get(key)
+    if t is None:
+        t = torch.tensor([int(value)], dtype=torch.int32, device=device)
+        _DEV_I32[key] = t
+    return t
 
 
 class SagePlan:

@@ -18,6 +18,7 @@ from typing import List, Optional
 
 import torch
 import torch.nn as nn
+from .engine import dev_i32
 
 
 class DecoderType(Enum):
@@ -35,7 +36,7 @@ class _InnerProductFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, c, eng):
         q, c = q.contiguous(), c.contiguous()
-        m = torch.tensor([q.shape[0]], dtype=torch.int32, device=q.device)
+        m = dev_i32(q.device, q.shape[0])
         ctx.eng = eng
         ctx.save_for_backward(q, c)
         return eng.linear(q, c, None, m, int(q.shape[0]), 0)
@@ -45,8 +46,8 @@ class _InnerProductFn(torch.autograd.Function):
         q, c = ctx.saved_tensors
         eng = ctx.eng
         ds = ds.contiguous()
-        mq = torch.tensor([q.shape[0]], dtype=torch.int32, device=q.device)
-        mc = torch.tensor([c.shape[0]], dtype=torch.int32, device=q.device)
+        mq = dev_i32(q.device, q.shape[0])
+        mc = dev_i32(q.device, c.shape[0])
         dq = eng.linear(ds, c.t().contiguous(), None, mq, int(q.shape[0]), 0)               # [Q,C]@[C,D]
         dc = eng.linear(ds.t().contiguous(), q.t().contiguous(), None, mc, int(c.shape[0]), 0)  # [C,Q]@[Q,D]
         return dq, dc, None

@@ -21,6 +21,7 @@ import torch.nn as nn
 
 from ._lib import GIGL_META_LEVEL0
 from .models import HipBatch
+from .engine import dev_i32
 
 
 class GCNConv(nn.Module):
@@ -46,7 +47,7 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         eng, dy = ctx.eng, dy.contiguous()
-        n_out = torch.tensor([dy.shape[1]], dtype=torch.int32, device=dy.device)
+        n_out = dev_i32(dy.device, dy.shape[1])
         dw = eng.linear(dy.t().contiguous(), x.t().contiguous(), None, n_out, int(dy.shape[1]), 0)
         dx = eng.linear(dy, w.t().contiguous(), None, ctx.n_dev, int(x.shape[0]), 0) if ctx.needs_input_grad[0] else None
         return dx, dw, None, None
@@ -177,7 +178,7 @@ class _GatConvFn(torch.autograd.Function):
         dxw = (dh.view(n, heads, ch) + ds.unsqueeze(-1) * att_src.view(1, heads, ch)
                + dd.unsqueeze(-1) * att_dst.view(1, heads, ch)).reshape(n, hc).contiguous()
         dev = dy.device
-        n_out = torch.tensor([hc], dtype=torch.int32, device=dev)
+        n_out = dev_i32(dev, hc)
         dw = eng.linear(dxw.t().contiguous(), x.t().contiguous(), None, n_out, hc, 0)        # dW = dxw^T x
         dx = eng.linear(dxw, w.t().contiguous(), None, n_dev, n, 0) if ctx.needs_input_grad[0] else None
         db = dy.sum(0) if bias.numel() else None
@@ -249,6 +250,7 @@ class GAT(nn.Module):
         self.edge_dim = edge_dim
         self.activation_after_last_conv = activation_after_last_conv
         self.should_l2_normalize_embedding_layer_output = should_l2_normalize_embedding_layer_output
+        self.input_side_first_layer = True  # (False: always project first — the comparison knob of the tests)
         assert conv in ("gat", "edge_attr_gat")
         extra = {}
         if conv == "edge_attr_gat":
@@ -285,6 +287,15 @@ class GAT(nn.Module):
             # sources of layer l are the rows computed by layer l-1 (all union nodes for the first layer)
             n_src = u.meta[GIGL_META_LEVEL0 + (L - l): GIGL_META_LEVEL0 + (L - l) + 1]
             n_dst = u.meta[GIGL_META_LEVEL0 + (L - 1 - l): GIGL_META_LEVEL0 + (L - l)]
+            if l == 0 and edge_attr is None and conv.concat and self.input_side_first_layer \
+                    and conv.in_channels > conv.heads * conv.out_channels:
+                # wide input rows: logits from folded attention vectors, projection after the aggregation
+                act = 1 if (L > 1 or self.activation_after_last_conv) else 0
+                h = eng.gat_input_layer(u.nodes, conv.lin.weight.contiguous(), conv.att_src.reshape(-1).contiguous(),
+                                        conv.att_dst.reshape(-1).contiguous(), conv.heads, conv.out_channels, u, n_src,
+                                        n_dst, conv.bias, negative_slope=conv.negative_slope, act=act)
+                if h is not None:
+                    continue
             x = eng.gather_rows(u.nodes, n_src, cap) if l == 0 else h
             h = self._layer(eng, conv, l, x, u, n_src, n_dst, cap, edge_attr)
         if self.should_l2_normalize_embedding_layer_output:

@@ -22,6 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+from .engine import dev_i32
 
 EdgeType = Tuple[str, str, str]
 
@@ -56,7 +57,7 @@ def _engine_for(module: nn.Module, t: torch.Tensor):
 def _linear(eng, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
     """x [m, k] @ w[n, k]^T + b on the fp32 MFMA GEMM (under autograd: with its two backward GEMMs)"""
     x = x.contiguous().to(torch.float32)
-    m = torch.tensor([x.shape[0]], dtype=torch.int32, device=x.device)
+    m = dev_i32(x.device, x.shape[0])
     if x.shape[0] == 0:
         return x.new_zeros((0, w.shape[0]))
     if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):

@@ -16,6 +16,7 @@ from typing import Optional
 import torch
 
 from .engine import HipEngine
+from .engine import dev_i32
 
 
 @dataclass
@@ -89,7 +90,7 @@ class _SageConvFn(torch.autograd.Function):
             dy = dy * (y > 0).to(dy.dtype)
         dev = dy.device
         # dW[N, 2d] = dy^T[N, n] @ a[n, 2d]  ->  linear(a = dy^T, w = a^T)
-        n_out = torch.tensor([dy.shape[1]], dtype=torch.int32, device=dev)
+        n_out = dev_i32(dev, dy.shape[1])
         dw = eng.linear(dy.t().contiguous(), a.t().contiguous(), None, n_out, int(dy.shape[1]), 0)
         # da[n, 2d] = dy[n, N] @ wcat[N, 2d]  ->  linear(a = dy, w = wcat^T)
         da = eng.linear(dy, wcat.t().contiguous(), None, g.n_dev, n, 0)

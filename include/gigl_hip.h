@@ -540,6 +540,24 @@ int32_t gigl_gat_aggregate(gigl_ctx* ctx, const float* h, const float* att_src, 
                            const int32_t* n_rows_dev, int64_t rows_cap, const float* bias, int32_t act,
                            float* alpha_scratch, float* out);
 
+/* The FIRST GATConv layer of an inference pass, computed from the input side (same layer as gigl_gather_rows +
+ * gigl_linear + gigl_gat_aggregate with concat=1 and no edge features; GAT.forward's first conv, homogeneous.py:300-343):
+ *   <W_h x_j, att_h> = <x_j, W_h^T att_h>  — the logits come from two folded d-vectors per head, and
+ *   sum_j alpha_ij W_h x_j = W_h (sum_j alpha_ij x_j)  — the projection runs on the *n_rows_dev aggregated rows, not on
+ *   all *n_src_dev source rows; x rows are read from the table `src` (fp32 / fp16, [*, d]) through ids (union.nodes).
+ * w: [heads*channels][d]; out: [rows_cap][heads*channels] (rows < *n_rows_dev written); fp32-class results that differ
+ * from the projection-first order by rounding only.  Built shapes: d % 4 == 0, heads in {1, 2, 4}
+ * (GIGL_E_UNSUPPORTED otherwise: take the projection-first entry points).
+ * cap_edges: length of `col`.  scratch: DEVICE fp32 [gigl_gat_input_layer_scratch(d, heads, cap_nodes, rows_cap,
+ * cap_edges)]. */
+int64_t gigl_gat_input_layer_scratch(int32_t d, int32_t heads, int64_t cap_nodes, int64_t rows_cap, int64_t cap_edges);
+int32_t gigl_gat_input_layer(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* ids,
+                             const float* w, const float* att_src, const float* att_dst, int32_t heads,
+                             int32_t channels, float negative_slope, const int32_t* rowptr, const int32_t* rowend,
+                             const int32_t* col, int64_t cap_edges, const int32_t* n_src_dev, int64_t cap_nodes,
+                             const int32_t* n_rows_dev, int64_t rows_cap, const float* bias, int32_t act,
+                             float* scratch, float* out);
+
 /* GATConv with edge features (edge_dim = De; GAT.init_conv_layers passes edge_dim, homogeneous.py:300-343) and
  * EdgeAttrGATConv (python/gigl/src/common/models/pyg/nn/conv/edge_attr_gat_conv.py:11-144):
  *   e_ij = leaky_relu(<h_j, att_src> + <h_i, att_dst> + <W_e e_ij, att_edge>); the added self loop carries the mean

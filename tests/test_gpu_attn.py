@@ -88,6 +88,51 @@ def test_gat(setup, heads, hid, out, fan):
     np.testing.assert_allclose(got, h[o["root_local"]].numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("d,dtype,heads,hid", [(768, np.float16, 2, 128), (320, np.float16, 4, 32), (1000, np.float32, 1, 64),
+                                               (260, np.float32, 2, 16)])
+def test_gat_first_layer_from_the_input_side(d, dtype, heads, hid):
+    """wide stored rows (d > heads*hid): logits from the folded attention vectors and the projection after the
+    aggregation (gigl_gat_input_layer) == the projection-first order of the same layer == the CPU forward"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models_attn import GAT
+    s, t = rmat_edges(11, 30000, seed=5)
+    n = 1 << 11
+    s = np.concatenate([s, np.arange(0, 100, dtype=np.uint32)])
+    t = np.concatenate([t, np.arange(0, 100, dtype=np.uint32)])
+    rowptr, col = oracle.build_csc(n, s, t, is_directed=True)
+    x = (np.random.default_rng(d).standard_normal((n, d)) / 4).astype(dtype)
+    eng = HipEngine(0)
+    try:
+        eng.load_csc(rowptr, col)
+        eng.load_features(torch.from_numpy(x) if dtype == np.float16 else x)
+        torch.manual_seed(d)
+        model = GAT(d, hid, 24, num_layers=2, heads=heads).to(eng.device)
+        with torch.no_grad():
+            for c in model.conv_layers:
+                c.bias.normal_(0, 0.1)
+        roots = np.random.default_rng(3).integers(0, n, size=300).astype(np.uint32)
+        batch, u, o = _union(eng, rowptr, col, roots, [9, 6])
+        idx = u.root_local[:300].long()
+        got = model(batch)[idx].cpu().numpy()
+        model.input_side_first_layer = False
+        plain = model(batch)[idx].cpu().numpy()
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        ei = gnn_ref.union_edge_index(o["rowptr"], o["col"])
+        h = torch.from_numpy(x[o["nodes"]].astype(np.float32))
+        for l in range(2):
+            p = f"conv_layers.{l}."
+            h = gnn_ref.gat_conv(h, ei, sd[p + "lin.weight"], sd[p + "att_src"], sd[p + "att_dst"], sd[p + "bias"],
+                                 heads if l == 0 else 1)
+            if l == 0:
+                h = torch.relu(h)
+        ref = h[o["root_local"]].numpy()
+        np.testing.assert_allclose(plain, ref, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(got, plain, rtol=2e-5, atol=2e-5)
+    finally:
+        eng.close()
+
+
 def test_gnn_ref_identities():
     """algebraic pins of the restated formulas: GCN == dense D^-1/2 (A+I) D^-1/2 X W; GAT rows are convex
     combinations (softmax sums to 1) -> with W = I, att = 0 the output is the plain mean over N(i) u {i}"""
