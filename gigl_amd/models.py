@@ -94,15 +94,21 @@ class GraphSAGE(nn.Module):
     activation_after_last_conv), optional L2 normalisation, return_emb, final Linear.  conv_kwargs: aggr ("mean" |
     "sum" | "max"), bias, root_weight (PyG SAGEConv); jk_mode ("cat" | "max" | "lstm") adds the JumpingKnowledge
     head over all layers' outputs (every conv then has hid_dim outputs and is followed by norm / activation).
-    Feature embedding / interaction layers are not built.
+    feature_interaction_layer (e.g. models_more.DCNv2) runs on the node features before the first conv; the
+    vocabulary-backed feature_embedding_layer is not built.
     State-dict keys follow the reference (conv_layers.{i}.lin_l/lin_r, batchnorm_layers.{i}, jk_layer.*, linear)."""
 
     def __init__(self, in_dim: int, hid_dim: int, out_dim: int, num_layers: int = 2,
                  activation_after_last_conv: bool = False, should_l2_normalize_embedding_layer_output: bool = False,
                  activation_before_norm: bool = False, dropout: float = 0.0, batchnorm: bool = False,
                  linear_layer: bool = False, return_emb: bool = False, jk_mode: Optional[str] = None,
-                 jk_lstm_dim: Optional[int] = None, **conv_kwargs):
+                 jk_lstm_dim: Optional[int] = None, feature_interaction_layer: Optional[nn.Module] = None,
+                 feature_embedding_layer: Optional[nn.Module] = None, **conv_kwargs):
         super().__init__()
+        if feature_embedding_layer is not None:
+            raise NotImplementedError("feature_embedding_layer (vocabulary-backed nn.Embedding columns) is not built")
+        # node feature interaction before the convolutions (homogeneous.py:117-119), e.g. models_more.DCNv2
+        self.feats_interaction = feature_interaction_layer
         conv_kwargs = dict(conv_kwargs.get("conv_kwargs") or conv_kwargs)
         self.in_dim, self.hid_dim, self.out_dim, self.num_layers = in_dim, hid_dim, out_dim, num_layers
         self.activation_after_last_conv = activation_after_last_conv
@@ -169,7 +175,7 @@ class GraphSAGE(nn.Module):
             eng = engine or getattr(self, "engine", None)
             if eng is None:
                 raise RuntimeError("GraphSAGE.forward(GraphData) needs the HipEngine (model.engine = eng)")
-            h = batch.x
+            h = self._interact(batch.x, eng)
             xs = []
             for l, conv in enumerate(self.conv_layers):
                 fused = self._plain and (l < self.num_layers - 1 or self.activation_after_last_conv)
@@ -190,6 +196,7 @@ class GraphSAGE(nn.Module):
         cap = int(u.nodes.numel())
         h = None
         xs = []
+        batch = self._interacted(batch)
         for l, conv in enumerate(self.conv_layers):
             n_rows = u.meta[GIGL_META_LEVEL0 + (L - 1 - l): GIGL_META_LEVEL0 + (L - l)]
             d = conv.in_channels
@@ -216,12 +223,33 @@ class GraphSAGE(nn.Module):
             h = out
         return self._head(h)
 
+    def _interact(self, x: torch.Tensor, eng: HipEngine) -> torch.Tensor:
+        if self.feats_interaction is None:
+            return x
+        self.feats_interaction.engine = eng  # (its products run on this model's engine and stream)
+        return self.feats_interaction(x)
+
+    def _interacted(self, batch: HipBatch) -> HipBatch:
+        """the batch with the feature-interaction layer applied to its nodes' rows (a local fp32 matrix in node order)"""
+        if self.feats_interaction is None:
+            return batch
+        eng, u = batch.engine, batch.union
+        cap = int(u.nodes.numel())
+        if batch.x is None:
+            x = eng.gather_rows(u.nodes, u.meta[0:1], cap)
+        else:
+            x = batch.x if batch.x_index is None else batch.x[batch.x_index.long()]
+        valid = (torch.arange(cap, device=x.device) < u.meta[0:1].to(torch.int64))[:, None]
+        x = torch.where(valid, x, torch.zeros_like(x))
+        return HipBatch(eng, batch.tree, u, x=self._interact(x, eng).contiguous(), edge_attr=batch.edge_attr)
+
     def make_plan(self, eng: HipEngine, b: int, fanouts: Sequence[int], groups: int = 1):
         """one-call pipeline (sample -> union -> this model's forward -> one row per root) for batches of
         `b` roots on `eng`; weights are snapshotted — call plan.set_weights(*model.fused_params()) after updates.
         groups > 1: each call takes groups*b roots and processes them as `groups` independent batches of b."""
         assert len(fanouts) == self.num_layers, "one hop per layer"
-        if not (self._plain and self.aggr == "mean" and not self.should_l2_normalize_embedding_layer_output):
+        if not (self._plain and self.aggr == "mean" and not self.should_l2_normalize_embedding_layer_output
+                and self.feats_interaction is None):
             raise NotImplementedError("the one-call plan computes conv(mean) -> relu layers only; use forward(HipBatch)")
         w, bs = self.fused_params()
         return eng.make_sage_plan(w, bs, b, fanouts, act_last=self.activation_after_last_conv, groups=groups)

@@ -222,3 +222,50 @@ def simplehgn_conv(edge_index, node_feat, edge_type, p, heads: int, out_dim: int
         w, b = p["residual"]
         out = out + node_feat @ w.T + b
     return out
+
+
+def gin_conv(x: torch.Tensor, edge_index: torch.Tensor, w0: torch.Tensor, b0: torch.Tensor, w1: torch.Tensor,
+             b1: torch.Tensor, eps: float = 0.0, act_first: bool = False, bn=None) -> torch.Tensor:
+    """PyG 2.5.3 GINConv(nn=MLP([in, o, o], norm=batch_norm|None, plain_last)) as GIN.init_conv_layers builds it
+    (python/gigl/src/common/models/pyg/homogeneous.py:205-249):  nn((1 + eps) x_i + sum_{j->i} x_j) with
+    nn = lin0 -> [act] -> norm -> [act] -> lin1.   bn: (weight, bias, running_mean, running_var, eps) in eval mode."""
+    src, dst = edge_index[0], edge_index[1]
+    agg = torch.zeros_like(x)
+    agg.index_add_(0, dst, x[src])
+    h = (agg + (1.0 + eps) * x) @ w0.T + b0
+    if act_first:
+        h = torch.relu(h)
+    if bn is not None:
+        g, b, mu, var, e = bn
+        h = (h - mu) / torch.sqrt(var + e) * g + b
+    if not act_first:
+        h = torch.relu(h)
+    return h @ w1.T + b1
+
+
+def transformer_conv(x: torch.Tensor, edge_index: torch.Tensor, p, heads: int, channels: int, concat: bool = True,
+                     root_weight: bool = True, beta: bool = False) -> torch.Tensor:
+    """PyG 2.5.3 TransformerConv without edge features (Transformer.init_conv_layers, homogeneous.py:440-487):
+    alpha_ij = softmax_j(<W_q x_i + b_q, W_k x_j + b_k> / sqrt(C)) over the in-edges of i (no self loops are added),
+    out_i = sum_j alpha_ij (W_v x_j + b_v), heads concatenated or averaged, + lin_skip(x_i) (beta: gated).
+    p: dict with lin_query/lin_key/lin_value/lin_skip .weight/.bias and lin_beta.weight"""
+    n = x.shape[0]
+    src, dst = edge_index[0], edge_index[1]
+    q = (x @ p["lin_query.weight"].T + p["lin_query.bias"]).view(n, heads, channels)
+    k = (x @ p["lin_key.weight"].T + p["lin_key.bias"]).view(n, heads, channels)
+    v = (x @ p["lin_value.weight"].T + p["lin_value.bias"]).view(n, heads, channels)
+    logits = (q[dst] * k[src]).sum(-1) / (channels ** 0.5)
+    alpha = _segment_softmax(logits, dst, n)
+    out = torch.zeros((n, heads, channels), dtype=x.dtype)
+    out.index_add_(0, dst, v[src] * alpha.unsqueeze(-1))
+    out = out.reshape(n, heads * channels) if concat else out.mean(1)
+    if root_weight:
+        xr = x @ p["lin_skip.weight"].T
+        if p.get("lin_skip.bias") is not None:
+            xr = xr + p["lin_skip.bias"]
+        if beta:
+            b = torch.sigmoid(torch.cat([out, xr, out - xr], dim=-1) @ p["lin_beta.weight"].T)
+            out = b * xr + (1 - b) * out
+        else:
+            out = out + xr
+    return out

@@ -295,3 +295,36 @@ def test_trainer_with_gat_encoder(workdir):
     out = inf.run("job", cfg_uri, None, uri_base=workdir)
     rows = [json.loads(l) for l in open(out["embeddings"])]
     assert len(rows) == 27 and all(abs(np.linalg.norm(r["emb"]) - 1.0) < 1e-4 for r in rows)  # L2-normalised outputs
+
+
+@pytest.mark.parametrize("cls,extra,key", [("gigl_amd.models_more.GIN", {}, "_encoder.conv_layers.0.nn.lins.0.weight"),
+                                           ("gigl_amd.models_more.Transformer", {"num_heads": "2"},
+                                            "_encoder.conv_layers.0.lin_query.weight")])
+def test_trainer_with_gin_and_transformer_encoders(workdir, cls, extra, key):
+    """gnn_model_class_path selects the other encoders of the reference's homogeneous zoo (homogeneous.py:205-249,
+    440-487): the plugin trains them through the HIP backward kernels, saves PyG-named parameters, and the inferencer
+    loads the result"""
+    import yaml
+    from gigl_amd.inferencer import Inferencer
+    from gigl_amd.trainer import Trainer
+    tag = cls.rsplit(".", 1)[1].lower()
+    doc = yaml.safe_load(open(os.path.join(workdir, CFG)))
+    for sect, k in (("trainerConfig", "trainerArgs"), ("inferencerConfig", "inferencerArgs")):
+        doc[sect][k].update(gnn_model_class_path=cls, hidden_dim="8", out_channels="8", **extra)
+    doc["sharedConfig"]["trainedModelMetadata"]["trainedModelUri"] = f"out/nablp_{tag}_train/model.pt"
+    doc["sharedConfig"]["trainedModelMetadata"]["evalMetricsUri"] = f"out/nablp_{tag}_train/eval_metrics.json"
+    for v in doc["sharedConfig"]["inferenceMetadata"]["nodeTypeToInferencerOutputInfoMap"].values():
+        v["embeddingsPath"] = f"out/nablp_{tag}_train/embeddings.jsonl"
+    cfg_uri = f"configs/nablp_{tag}_train_gbml_config.yaml"
+    yaml.safe_dump(doc, open(os.path.join(workdir, cfg_uri), "w"))
+    tr = Trainer()
+    metrics = tr.run("job", cfg_uri, None, uri_base=workdir)
+    assert np.isfinite(metrics.metrics["loss"].value) and 0.0 < metrics.metrics["mrr"].value <= 1.0
+    hist = [h["loss"] for h in tr.training_process.trainer.history]
+    assert len(hist) >= 2 and all(np.isfinite(hist)) and min(hist[1:]) < hist[0]
+    cfg = GbmlConfigPbWrapper.from_uri(cfg_uri, uri_base=workdir)
+    sd = torch.load(cfg.trained_model_uri, map_location="cpu")
+    assert key in sd
+    out = Inferencer().run("job", cfg_uri, None, uri_base=workdir)
+    rows = [json.loads(l) for l in open(out["embeddings"])]
+    assert len(rows) == 27 and all(abs(np.linalg.norm(r["emb"]) - 1.0) < 1e-4 for r in rows)
