@@ -1,0 +1,267 @@
+// GATv2Conv attention + aggregation, forward and backward (PyG 2.5.3 GATv2Conv as configured by GATv2.init_conv_layers,
+// python/gigl/src/common/models/pyg/homogeneous.py:346-386; no edge features):
+//   s_ij = xl_j + xr_i,  z_ij = <att_h, leaky_relu(s_ij)> per head,  alpha = softmax_j z_ij over the in-edges of i
+//   (self loops removed, one added back),  out_i = sum_j alpha_ij xl_j  (heads concatenated) + bias.
+// Unlike GATConv the logit is not a sum of two per-node scalars: every edge needs the C-wide elementwise pass, so the
+// logits are formed from the source rows as they are read for the aggregation — one pass, online softmax.
+// One wave per destination row; lane l of chunk row v owns the float4 of channels [4q, 4q+4), q = 64 v + l; a head
+// is C/4 adjacent lanes (C/4 a power of two <= 64), so all heads advance together and a source row is read once.
+#include "common.h"
+
+namespace {
+
+constexpr int U = 4;  // source rows in flight
+
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+__device__ __forceinline__ float4 leaky4(const float4& s, float slope) {
+  return float4{s.x > 0.f ? s.x : slope * s.x, s.y > 0.f ? s.y : slope * s.y, s.z > 0.f ? s.z : slope * s.z,
+                s.w > 0.f ? s.w : slope * s.w};
+}
+__device__ __forceinline__ float4 add4(const float4& a, const float4& b) {
+  return float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+}
+// sum over the `group` adjacent lanes of a head, returned to each of them
+__device__ __forceinline__ float head_sum(float p, int group) {
+  for (int off = group >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+  return p;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void gatv2_forward_kernel(
+    const float* __restrict__ xl, const float* __restrict__ xr, const float* __restrict__ att,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ n_rows_dev, int HC, int group, float slope, const float* __restrict__ bias, int act,
+    float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n_rows = *n_rows_dev, chunks = HC >> 2;
+  const float4 zero4{0.f, 0.f, 0.f, 0.f};
+  bool on[V];
+  float4 a4[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    on[v] = v * 64 + lane < chunks;
+    a4[v] = on[v] ? ((const float4*)att)[v * 64 + lane] : zero4;
+  }
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    float4 r4[V], acc[V];
+    float mx[V], den[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      r4[v] = on[v] ? ((const float4*)(xr + (int64_t)i * HC))[v * 64 + lane] : zero4;
+      acc[v] = zero4;
+      mx[v] = -INFINITY;
+      den[v] = 0.f;
+    }
+    // the in-edges, then the self loop as one more "edge" (index m)
+    for (int e = 0; e <= m; e += U) {
+      int j[U];
+      float4 x[U][V];
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        const int ee = e + t;
+        j[t] = ee < m ? col[e0 + ee] : (ee == m ? i : -1);
+        if (ee < m && j[t] == i) j[t] = -1;  // self loops among the edges are dropped
+      }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        if (j[t] < 0) continue;
+#pragma unroll
+        for (int v = 0; v < V; ++v) x[t][v] = on[v] ? ((const float4*)(xl + (int64_t)j[t] * HC))[v * 64 + lane] : zero4;
+      }
+#pragma unroll
+      for (int t = 0; t < U; ++t) {
+        if (j[t] < 0) continue;  // (wave-uniform)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const float z = head_sum(dot4(a4[v], leaky4(add4(x[t][v], r4[v]), slope)), group);
+          const float nm = fmaxf(mx[v], z);
+          const float sc = __expf(mx[v] - nm), pw = __expf(z - nm);
+          den[v] = den[v] * sc + pw;
+          acc[v].x = acc[v].x * sc + pw * x[t][v].x;
+          acc[v].y = acc[v].y * sc + pw * x[t][v].y;
+          acc[v].z = acc[v].z * sc + pw * x[t][v].z;
+          acc[v].w = acc[v].w * sc + pw * x[t][v].w;
+          mx[v] = nm;
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      if (!on[v]) continue;
+      const int q = v * 64 + lane;
+      const float inv = 1.0f / (den[v] + 1e-16f);
+      float4 o{acc[v].x * inv, acc[v].y * inv, acc[v].z * inv, acc[v].w * inv};
+      if (bias) o = add4(o, ((const float4*)bias)[q]);
+      if (act == 1) o = float4{fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)};
+      ((float4*)(out + (int64_t)i * HC))[q] = o;
+    }
+  }
+}
+
+// backward: with g = d out_i (bias / activation already peeled off by the caller), S = <g, out_i> per head,
+//   d alpha_ij = <g, xl_j>,  dz_ij = alpha_ij (d alpha_ij - S),  ds_ij = dz_ij * att * leaky'(s_ij)   (C-wide)
+//   d xl_j += alpha_ij g + ds_ij  (atomics: a source has many destinations),  d xr_i = sum_j ds_ij,
+//   d att  += sum_ij dz_ij * leaky(s_ij)   (per-wave partial sums, one atomic per lane component at the end).
+// Pass 1 recomputes max / denominator, pass 2 the gradients; both read the source rows.
+template <int V>
+__global__ __launch_bounds__(256) void gatv2_backward_kernel(
+    const float* __restrict__ xl, const float* __restrict__ xr, const float* __restrict__ att,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ n_rows_dev, int HC, int group, float slope, const float* __restrict__ out_pre,
+    const float* __restrict__ dout, float* __restrict__ dxl, float* __restrict__ dxr, float* __restrict__ datt) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n_rows = *n_rows_dev, chunks = HC >> 2;
+  const float4 zero4{0.f, 0.f, 0.f, 0.f};
+  bool on[V];
+  float4 a4[V], da4[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    on[v] = v * 64 + lane < chunks;
+    a4[v] = on[v] ? ((const float4*)att)[v * 64 + lane] : zero4;
+    da4[v] = zero4;
+  }
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    float4 r4[V], g[V], dr[V];
+    float mx[V], den[V], S[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int q = v * 64 + lane;
+      r4[v] = on[v] ? ((const float4*)(xr + (int64_t)i * HC))[q] : zero4;
+      g[v] = on[v] ? ((const float4*)(dout + (int64_t)i * HC))[q] : zero4;
+      const float4 o = on[v] ? ((const float4*)(out_pre + (int64_t)i * HC))[q] : zero4;
+      S[v] = head_sum(dot4(g[v], o), group);
+      dr[v] = zero4;
+      mx[v] = -INFINITY;
+      den[v] = 0.f;
+    }
+    for (int e = 0; e <= m; ++e) {  // pass 1
+      const int j = e < m ? col[e0 + e] : i;
+      if (e < m && j == i) continue;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float4 x = on[v] ? ((const float4*)(xl + (int64_t)j * HC))[v * 64 + lane] : zero4;
+        const float z = head_sum(dot4(a4[v], leaky4(add4(x, r4[v]), slope)), group);
+        const float nm = fmaxf(mx[v], z);
+        den[v] = den[v] * __expf(mx[v] - nm) + __expf(z - nm);
+        mx[v] = nm;
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) den[v] = 1.0f / (den[v] + 1e-16f);
+    for (int e = 0; e <= m; ++e) {  // pass 2
+      const int j = e < m ? col[e0 + e] : i;
+      if (e < m && j == i) continue;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float4 x = on[v] ? ((const float4*)(xl + (int64_t)j * HC))[v * 64 + lane] : zero4;
+        const float4 s = add4(x, r4[v]);
+        const float4 l = leaky4(s, slope);
+        const float z = head_sum(dot4(a4[v], l), group);
+        const float al = __expf(z - mx[v]) * den[v];
+        const float dal = head_sum(dot4(g[v], x), group);
+        const float dz = al * (dal - S[v]);
+        const float4 ds{dz * a4[v].x * (s.x > 0.f ? 1.f : slope), dz * a4[v].y * (s.y > 0.f ? 1.f : slope),
+                        dz * a4[v].z * (s.z > 0.f ? 1.f : slope), dz * a4[v].w * (s.w > 0.f ? 1.f : slope)};
+        dr[v] = add4(dr[v], ds);
+        da4[v].x += dz * l.x;
+        da4[v].y += dz * l.y;
+        da4[v].z += dz * l.z;
+        da4[v].w += dz * l.w;
+        if (on[v]) {
+          float* o = dxl + (int64_t)j * HC + 4 * (v * 64 + lane);
+          atomicAdd(o + 0, al * g[v].x + ds.x);
+          atomicAdd(o + 1, al * g[v].y + ds.y);
+          atomicAdd(o + 2, al * g[v].z + ds.z);
+          atomicAdd(o + 3, al * g[v].w + ds.w);
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+      if (on[v]) ((float4*)(dxr + (int64_t)i * HC))[v * 64 + lane] = dr[v];
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    if (!on[v]) continue;
+    float* o = datt + 4 * (v * 64 + lane);
+    atomicAdd(o + 0, da4[v].x);
+    atomicAdd(o + 1, da4[v].y);
+    atomicAdd(o + 2, da4[v].z);
+    atomicAdd(o + 3, da4[v].w);
+  }
+}
+
+bool gatv2_shape(gigl_ctx* ctx, int heads, int C, int& V, int& group) {
+  const int gl = C / 4, chunks = heads * C / 4;
+  V = (chunks + 63) / 64;
+  group = gl;
+  const bool ok = C % 4 == 0 && gl >= 1 && gl <= 64 && (gl & (gl - 1)) == 0 && (V == 1 || V == 2 || V == 4);
+  if (!ok)
+    gigl_fail(ctx, GIGL_E_UNSUPPORTED, "heads=%d channels=%d: the GATv2 kernels need channels %% 4 == 0, channels/4 a "
+              "power of two <= 64 and heads*channels <= 1024", heads, C);
+  return ok;
+}
+
+}  // namespace
+
+int32_t gigl_gatv2_aggregate(gigl_ctx* ctx, const float* xl, const float* xr, const float* att, int32_t heads,
+                             int32_t channels, float negative_slope, const int32_t* rowptr, const int32_t* rowend,
+                             const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
+                             int32_t act, float* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, xl && xr && att && rowptr && rowend && col && n_rows_dev && out, "null argument");
+  GIGL_REQUIRE(ctx, heads > 0 && channels > 0 && rows_cap >= 0 && (act == 0 || act == 1), "bad sizes");
+  int V, group;
+  if (!gatv2_shape(ctx, heads, channels, V, group)) return GIGL_E_UNSUPPORTED;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  const int HC = heads * channels;
+#define GIGL_V2_FWD(VV)                                                                                              \
+  hipLaunchKernelGGL((gatv2_forward_kernel<VV>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, xl, xr, att,    \
+                     rowptr, rowend, col, n_rows_dev, HC, group, negative_slope, bias, act, out)
+  if (V == 1) GIGL_V2_FWD(1);
+  else if (V == 2) GIGL_V2_FWD(2);
+  else GIGL_V2_FWD(4);
+#undef GIGL_V2_FWD
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_gatv2_aggregate_backward(gigl_ctx* ctx, const float* xl, const float* xr, const float* att,
+                                      int32_t heads, int32_t channels, float negative_slope, const int32_t* rowptr,
+                                      const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
+                                      int64_t rows_cap, const float* out_pre, const float* dout, float* dxl,
+                                      float* dxr, float* datt) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, xl && xr && att && rowptr && rowend && col && n_rows_dev && out_pre && dout && dxl && dxr && datt,
+               "null argument");
+  GIGL_REQUIRE(ctx, heads > 0 && channels > 0 && rows_cap >= 0, "bad sizes");
+  int V, group;
+  if (!gatv2_shape(ctx, heads, channels, V, group)) return GIGL_E_UNSUPPORTED;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 4) blocks = 256 * 4;  // (every wave ends with one atomic per att component)
+  const int HC = heads * channels;
+#define GIGL_V2_BWD(VV)                                                                                              \
+  hipLaunchKernelGGL((gatv2_backward_kernel<VV>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, xl, xr, att,   \
+                     rowptr, rowend, col, n_rows_dev, HC, group, negative_slope, out_pre, dout, dxl, dxr, datt)
+  if (V == 1) GIGL_V2_BWD(1);
+  else if (V == 2) GIGL_V2_BWD(2);
+  else GIGL_V2_BWD(4);
+#undef GIGL_V2_BWD
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}

@@ -2,6 +2,7 @@
 
   GIN          python/gigl/src/common/models/pyg/homogeneous.py:205-249  (PyG GINConv over an MLP([in, o, o]))
   Transformer  python/gigl/src/common/models/pyg/homogeneous.py:440-487  (PyG TransformerConv, heads=1 on the last layer)
+  GATv2        python/gigl/src/common/models/pyg/homogeneous.py:346-386  (PyG GATv2Conv, heads=1 on the last layer)
 both under BasicHomogeneousGNN.forward (:107-153: activation / BatchNorm1d / dropout between layers, JumpingKnowledge,
 L2 normalisation, return_emb, final Linear — shared with GraphSAGE here).  Parameter names follow PyG 2.5.3
 (`conv_layers.{i}.nn.lins.{0,1}`, `conv_layers.{i}.nn.norms.0.module`, `conv_layers.{i}.eps`;
@@ -10,7 +11,8 @@ L2 normalisation, return_emb, final Linear — shared with GraphSAGE here).  Par
 No new kernels: a GIN layer is the segmented SUM + projection of a SAGE layer with the weights [W0 | (1+eps) W0]
 (gigl_gather_reduce + gigl_linear, autograd through nn.sage_conv) followed by one more gigl_linear; a Transformer
 layer is three projections + the dot-product attention reduce of HGTConv with one edge type (gigl_hgt_aggregate and
-its backward).  Not built: TransformerConv / GINEConv edge features, GATv2Conv.
+its backward).  GATv2 (homogeneous.py:346-386) has its own kernels (csrc/gatv2.hip: the logit is a C-wide pass per edge).
+Not built: edge features for TransformerConv / GATv2Conv, GINEConv.
 
   DCNv2 / DCNCross  python/gigl/src/common/models/layers/feature_interaction.py:7-155 — the feature-interaction layer
 BasicHomogeneousGNN applies to the node features before the first conv (`feature_interaction_layer=`): x_{i+1} =
@@ -265,6 +267,132 @@ class Transformer(GraphSAGE):
             x = torch.where((torch.arange(cap, device=x.device) < n_nodes.to(torch.int64))[:, None], x, torch.zeros_like(x))
             x = self._interact(x, eng)
             return self._layers(x.contiguous(), rowptr.to(torch.int32).contiguous(), col, eng)
+
+    def make_plan(self, *args, **kwargs):
+        raise NotImplementedError("the one-call plan computes GraphSAGE layers only; use forward(HipBatch)")
+
+
+class _Gatv2AggFn(torch.autograd.Function):
+    """gigl_gatv2_aggregate / gigl_gatv2_aggregate_backward over a CSR view (rowptr / rowend / col), before the bias"""
+
+    @staticmethod
+    def forward(ctx, xl, xr, att, eng, view, n_dev, heads, channels, slope):
+        xl, xr, att = xl.contiguous(), xr.contiguous(), att.reshape(-1).contiguous()
+        out = eng.gatv2_aggregate(xl, xr, att, heads, channels, view, n_dev, None, negative_slope=slope, act=0)
+        ctx.save_for_backward(xl, xr, att, out)
+        ctx.meta = (eng, view, n_dev, heads, channels, slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xl, xr, att, out = ctx.saved_tensors
+        eng, view, n_dev, heads, channels, slope = ctx.meta
+        dxl, dxr, datt = eng.gatv2_aggregate_backward(xl, xr, att, heads, channels, view, n_dev, out, dout,
+                                                      negative_slope=slope)
+        return dxl, dxr, datt.view(1, heads, channels), None, None, None, None, None, None
+
+
+class GATv2Conv(nn.Module):
+    """parameter holder with PyG GATv2Conv's layout (lin_l / lin_r / att / bias)"""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
+                 negative_slope: float = 0.2, bias: bool = True, share_weights: bool = False,
+                 edge_dim: Optional[int] = None, dropout: float = 0.0):
+        super().__init__()
+        if edge_dim is not None:
+            raise NotImplementedError("GATv2Conv edge features (edge_dim) are not built")
+        if dropout:
+            raise NotImplementedError("GATv2Conv attention dropout is not built")
+        if not concat and heads > 1:
+            raise NotImplementedError("GATv2Conv with averaged heads (concat=False, heads > 1) is not built")
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.negative_slope, self.share_weights = negative_slope, share_weights
+        self.lin_l = nn.Linear(in_channels, heads * out_channels, bias=bias)
+        self.lin_r = self.lin_l if share_weights else nn.Linear(in_channels, heads * out_channels, bias=bias)
+        self.att = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels)) if bias else None
+        nn.init.xavier_uniform_(self.lin_l.weight)
+        nn.init.xavier_uniform_(self.lin_r.weight)
+        nn.init.xavier_uniform_(self.att)
+
+    def forward(self, x: torch.Tensor, view, n_dev: torch.Tensor, eng: HipEngine) -> torch.Tensor:
+        xl = _linear(eng, x, self.lin_l.weight, self.lin_l.bias)
+        xr = xl if self.share_weights else _linear(eng, x, self.lin_r.weight, self.lin_r.bias)
+        out = _Gatv2AggFn.apply(xl, xr, self.att, eng, view, n_dev, self.heads, self.out_channels, self.negative_slope)
+        return out + self.bias if self.bias is not None else out
+
+
+class GATv2(GraphSAGE):
+    """conv_kwargs: heads, share_weights, negative_slope, bias, concat.  Head sizes the kernels are built for: channels a
+    multiple of 4 with channels/4 a power of two <= 64, heads*channels <= 1024."""
+
+    def __init__(self, in_dim: int, hid_dim: int, out_dim: int, num_layers: int = 2, edge_dim: Optional[int] = None,
+                 **kwargs):
+        ck = dict(kwargs.get("conv_kwargs") or {})
+        for key in ("heads", "share_weights", "negative_slope", "bias", "concat"):
+            if key in kwargs:
+                ck[key] = kwargs.pop(key)
+        kwargs.pop("conv_kwargs", None)
+        heads = int(ck.get("heads", 1))
+        super().__init__(in_dim, hid_dim, out_dim, num_layers=num_layers, **kwargs)
+        last = hid_dim if (self.linear_layer or self.jk_layer is not None) else out_dim
+        self.heads = heads
+        self.conv_layers = nn.ModuleList([
+            GATv2Conv(in_dim if i == 0 else hid_dim * heads, hid_dim if i < num_layers - 1 else last,
+                      heads=heads if i < num_layers - 1 else 1, concat=bool(ck.get("concat", True)),
+                      negative_slope=float(ck.get("negative_slope", 0.2)), bias=bool(ck.get("bias", True)),
+                      share_weights=bool(ck.get("share_weights", False)), edge_dim=edge_dim)
+            for i in range(num_layers)])
+        if self.batchnorm:  # BatchNorm1d(hid_dim * num_heads), homogeneous.py:78-87
+            self.batchnorm_layers = nn.ModuleList([nn.BatchNorm1d(hid_dim * heads)
+                                                   for _ in range(len(self.batchnorm_layers))])
+
+    def forward(self, batch, engine: Optional[HipEngine] = None) -> torch.Tensor:
+        """GraphData -> every layer over the whole batch graph (autograd when grad mode is on): [n, out_dim]
+        HipBatch  -> the trimmed schedule over the level-ordered union graph: [cap, out_dim], index with root_local"""
+        from .models_attn import _CsrView
+        from .nn import GraphData
+        if isinstance(batch, GraphData):
+            eng = engine or getattr(self, "engine", None)
+            if eng is None:
+                raise RuntimeError("GATv2.forward(GraphData) needs the HipEngine (model.engine = eng)")
+            view = _CsrView(batch)
+            h, xs = self._interact(batch.x, eng), []
+            for l, conv in enumerate(self.conv_layers):
+                h = self._post(conv(h, view, batch.n_dev, eng), l, False)
+                xs.append(h)
+            if self.jk_layer is not None:
+                h = self.jk_layer(xs)
+            return self._head(h)
+        with torch.no_grad():
+            eng, u = batch.engine, batch.union
+            L = self.num_layers
+            assert u.hops == L, "one hop per layer"
+            cap = int(u.nodes.numel())
+            batch = self._interacted(batch)
+            if batch.x is None:
+                h = eng.gather_rows(u.nodes, u.meta[0:1], cap)
+            else:
+                h = batch.x if batch.x_index is None else batch.x[batch.x_index.long()].contiguous()
+            xs = []
+            for l, conv in enumerate(self.conv_layers):
+                # rows computed by layer l: the nodes that can still reach a root (a prefix of the level order); their
+                # sources are the rows layer l-1 computed
+                n_src = u.meta[GIGL_META_LEVEL0 + (L - l): GIGL_META_LEVEL0 + (L - l) + 1]
+                n_dst = u.meta[GIGL_META_LEVEL0 + (L - 1 - l): GIGL_META_LEVEL0 + (L - l)]
+                xl = eng.linear(h, conv.lin_l.weight.contiguous(), conv.lin_l.bias, n_src, cap, 0)
+                xr = xl if conv.share_weights else eng.linear(h, conv.lin_r.weight.contiguous(), conv.lin_r.bias, n_dst,
+                                                              cap, 0)
+                h = eng.gatv2_aggregate(xl, xr, conv.att.reshape(-1).contiguous(), conv.heads, conv.out_channels, u,
+                                        n_dst, conv.bias, negative_slope=conv.negative_slope, act=0)
+                h = self._post(h, l, False).contiguous()
+                xs.append(h)
+            if self.jk_layer is not None:
+                n_roots = int(u.meta[GIGL_META_LEVEL0].item())
+                out = torch.zeros((cap, self.jk_layer.output_linear.out_features), dtype=torch.float32, device=h.device)
+                out[:n_roots] = self.jk_layer([x[:n_roots] for x in xs])
+                h = out
+            return self._head(h)
 
     def make_plan(self, *args, **kwargs):
         raise NotImplementedError("the one-call plan computes GraphSAGE layers only; use forward(HipBatch)")

@@ -575,6 +575,25 @@ int32_t gigl_gat_aggregate_edge(gigl_ctx* ctx, const float* h, const float* att_
                                 int32_t edge_dim, int64_t cap_edges, const float* att_edge_folded,
                                 const float* w_edge_msg, float* alpha_scratch, float* out);
 
+/* GATv2Conv attention + aggregation (PyG 2.5.3 GATv2Conv as configured by GATv2.init_conv_layers, homogeneous.py:
+ * 346-386; no edge features): xl = lin_l(x), xr = lin_r(x) as fp32 [nodes][heads*channels] rows (gigl_linear; the same
+ * pointer twice for share_weights), att: [heads*channels];
+ *   z_ij = <att_h, leaky_relu(xl_j + xr_i, negative_slope)> per head over the in-edges of i (self loops removed) plus one
+ *   self loop; alpha = softmax_j z_ij; out[i] = sum_j alpha_ij xl_j, heads concatenated, + bias; optional relu.
+ * Built shapes: channels % 4 == 0, channels/4 a power of two <= 64, heads*channels <= 1024 (GIGL_E_UNSUPPORTED
+ * otherwise).  The backward takes out_pre (the forward's rows before bias / activation) and dout (the gradient with the
+ * activation already peeled off): dxl [nodes][H*C] and datt [H*C] are ACCUMULATED into (zero them first), dxr
+ * [rows_cap][H*C] is written for rows < *n_rows_dev. */
+int32_t gigl_gatv2_aggregate(gigl_ctx* ctx, const float* xl, const float* xr, const float* att, int32_t heads,
+                             int32_t channels, float negative_slope, const int32_t* rowptr, const int32_t* rowend,
+                             const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
+                             int32_t act, float* out);
+int32_t gigl_gatv2_aggregate_backward(gigl_ctx* ctx, const float* xl, const float* xr, const float* att,
+                                      int32_t heads, int32_t channels, float negative_slope, const int32_t* rowptr,
+                                      const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
+                                      int64_t rows_cap, const float* out_pre, const float* dout, float* dxl,
+                                      float* dxr, float* datt);
+
 /* backward of gigl_gat_aggregate / gigl_gat_aggregate_edge (concatenated heads or one head; no W_msg messages) for
  * training through the reference's plugins (GnnTrainingProcess, training_process.py:153-370): given dout = dL/d(out
  * before bias and activation) and out_pre = that output, both [rows][heads*channels]:

@@ -253,3 +253,76 @@ def test_dcn_v2_feature_interaction_before_the_convs(setup, proj, diag):
         want = refp[name].grad
         scale = float(want.abs().max()) + 1e-6
         np.testing.assert_allclose(prm.grad.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4 * scale, err_msg=name)
+
+
+def _gatv2_ref(x, ei, sd, L, heads, hid, out, share):
+    h = x
+    for l in range(L):
+        pre = f"conv_layers.{l}."
+        p = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        h = gnn_ref.gatv2_conv(h, ei, p, heads if l < L - 1 else 1, hid if l < L - 1 else out, share_weights=share)
+        if l < L - 1:
+            h = torch.relu(h)
+    return h
+
+
+@pytest.mark.parametrize("heads,hid,out,share,fan", [(2, 16, 32, False, [7, 4]), (4, 64, 64, True, [6, 4]),
+                                                     (1, 256, 128, False, [5, 3]), (4, 8, 16, False, [5, 3, 2])])
+def test_gatv2_roots_match_the_whole_graph_forward(setup, heads, hid, out, share, fan):
+    from gigl_amd.models_more import GATv2
+    eng, rowptr, col, x, n = setup
+    torch.manual_seed(heads)
+    L = len(fan)
+    model = GATv2(40, hid, out, num_layers=L, heads=heads, share_weights=share).to(eng.device).eval()
+    with torch.no_grad():
+        for c in model.conv_layers:
+            c.bias.normal_(0, 0.1)
+    roots = np.random.default_rng(6).integers(0, n, size=110).astype(np.uint32)
+    batch, u, o = _union(eng, rowptr, col, roots, fan)
+    got = model(batch)[u.root_local[:110].long()].cpu().numpy()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ei = gnn_ref.union_edge_index(o["rowptr"], o["col"])
+    ref = _gatv2_ref(torch.from_numpy(x[o["nodes"]]), ei, sd, L, heads, hid, out, share)
+    np.testing.assert_allclose(got, ref[o["root_local"]].numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("heads,hid,out,share", [(2, 16, 32, False), (4, 32, 16, True), (1, 128, 64, False)])
+def test_gatv2_training_gradients_match_torch_autograd(heads, hid, out, share):
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models_more import GATv2
+    from gigl_amd.nn import GraphData
+    rng = np.random.default_rng(heads + 20)
+    n, d = 280, 12
+    ei, x = _graph(rng, n, 2000, d)
+    assert bool((ei[0] == ei[1]).any())  # a few self loops: removed, then one per node added back
+    eng = HipEngine(0)
+    try:
+        torch.manual_seed(5)
+        model = GATv2(d, hid, out, num_layers=2, heads=heads, share_weights=share).to(eng.device).train()
+        model.engine = eng
+        with torch.no_grad():
+            for c in model.conv_layers:
+                c.bias.normal_(0, 0.1)
+        g = GraphData(x=x.clone(), edge_index=ei).to(eng.device)
+        g.x.requires_grad_(True)
+        wsum = torch.from_numpy(rng.standard_normal((n, out)).astype(np.float32))
+        y = model(g)
+        (y * wsum.to(eng.device)).sum().backward()
+        ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        if share:
+            for l in range(2):  # one tensor behind both names, as in the module
+                ref[f"conv_layers.{l}.lin_r.weight"] = ref[f"conv_layers.{l}.lin_l.weight"]
+                ref[f"conv_layers.{l}.lin_r.bias"] = ref[f"conv_layers.{l}.lin_l.bias"]
+        xr = x.clone().requires_grad_(True)
+        h = _gatv2_ref(xr, ei, ref, 2, heads, hid, out, share)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), h.detach().numpy(), rtol=1e-5, atol=1e-5)
+        (h * wsum).sum().backward()
+        for name, prm in model.named_parameters():
+            want = ref[name].grad
+            assert prm.grad is not None and want is not None, name
+            scale = float(want.abs().max()) + 1e-6
+            np.testing.assert_allclose(prm.grad.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4 * scale, err_msg=name)
+        np.testing.assert_allclose(g.x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4,
+                                   atol=1e-4 * float(xr.grad.abs().max()))
+    finally:
+        eng.close()
