@@ -622,10 +622,13 @@ class HipEngine:
         cn, ce = self.union_capacity(b, fanouts)
         dev = self.device
         u = GiglUnion()
-        meta = torch.zeros(GIGL_META_LEN, dtype=torch.int32, device=dev)
+        # (one zero fill for the three arrays that start cleared; each slice starts on a 16-byte boundary)
+        pad = lambda k: (k + 3) // 4 * 4
+        z = torch.zeros(pad(GIGL_META_LEN) + 2 * pad(cn + 2), dtype=torch.int32, device=dev)
+        meta = z[:GIGL_META_LEN]
+        rowptr = z[pad(GIGL_META_LEN): pad(GIGL_META_LEN) + cn + 2]
+        rowend = z[pad(GIGL_META_LEN) + pad(cn + 2): pad(GIGL_META_LEN) + pad(cn + 2) + cn + 2]
         nodes = torch.empty(max(cn, 1), dtype=torch.int32, device=dev)
-        rowptr = torch.zeros(cn + 2, dtype=torch.int32, device=dev)
-        rowend = torch.zeros(cn + 2, dtype=torch.int32, device=dev)
         col = torch.empty(max(ce, 1), dtype=torch.int32, device=dev)
         root_local = torch.empty(max(b, 1), dtype=torch.int32, device=dev)
         u.meta, u.nodes, u.rowptr, u.rowend, u.col, u.root_local = (
