@@ -3,7 +3,8 @@
 Mirror of (paths relative to the reference root):
   DecoderType, LinkPredictionDecoder   python/gigl/src/common/models/layers/decoder.py:10-70
       inner_product: scores = torch.mm(q, c.T)   (:64-66)  -> gigl_linear(q, c) (same NT GEMM, exact fp32 MFMA)
-      hadamard_MLP uses torch_geometric.nn.models.MLP (third-party, un-vendored) -> not implemented
+      hadamard_MLP: scores = MLP(q.unsqueeze(1) * c).sum(-1)  (:67-69, PyG MLP, un-vendored: "parity unpinned")
+          -> the first layer of all pairs as one projection by query-scaled weights, the rest on gigl_linear
   LinkPredictionGNN                    python/gigl/src/common/models/pyg/link_prediction.py:33-60
   RetrievalLoss                        python/gigl/src/common/models/layers/loss.py:177-360
       calculate_batch_retrieval_loss :209-277, _mask_by_query_ids :279-305, _mask_by_candidate_ids :307-331
@@ -69,14 +70,56 @@ class LinkPredictionDecoder(nn.Module):
             raise ValueError("The last element in decoder channel list must be equal to 1, however you provided "
                              f"{decoder_channel_list[-1]}")
         if self.decoder_type.value == "hadamard_MLP":
-            raise NotImplementedError("hadamard_MLP needs torch_geometric.nn.models.MLP (third-party); only the "
-                                      "inner-product decoder is on this path")
+            self.mlp_decoder = _DecoderMLP(decoder_channel_list, **mlp_kwargs)
         self.engine = None
 
     def forward(self, query_embeddings: torch.Tensor, candidate_embeddings: torch.Tensor) -> torch.Tensor:
         if self.engine is None:
             raise RuntimeError("LinkPredictionDecoder needs a HipEngine (decoder.engine = eng); no CPU fallback")
+        if self.decoder_type.value == "hadamard_MLP":
+            return self.mlp_decoder.pair_scores(query_embeddings, candidate_embeddings, self.engine)
         return _InnerProductFn.apply(query_embeddings, candidate_embeddings, self.engine)
+
+
+class _DecoderMLP(nn.Module):
+    """the hadamard_MLP decoder's MLP with PyG MLP's parameter layout (`lins.{i}`; decoder.py:52-60 passes act,
+    act_first, bias, plain_last, norm) evaluated on every (query, candidate) pair WITHOUT materialising the
+    [Q*C, D] matrix of elementwise products: lin_0(q * c) = (W_0 * q) c, so the first layer of all pairs is ONE
+    projection of the candidates by the [Q*h_1, D] matrix of query-scaled weights; the remaining layers run on the
+    resulting [C*Q, h_1] rows.  score = sum over the last layer's (single) output."""
+
+    def __init__(self, channel_list: List[int], act=torch.relu, act_first: bool = False, bias=False,
+                 plain_last: bool = False, norm=None):
+        super().__init__()
+        if norm is not None:
+            raise NotImplementedError("hadamard_MLP with a normalisation layer is not built")
+        if isinstance(act, str):
+            if act != "relu":
+                raise NotImplementedError(f"hadamard_MLP activation {act!r} is not built (relu)")
+            act = torch.relu
+        n = len(channel_list) - 1
+        biases = list(bias) if isinstance(bias, (list, tuple)) else [bool(bias)] * n
+        if len(biases) != n:
+            raise ValueError(f"Number of bias values provided ({len(biases)}) does not match the number of layers ({n})")
+        self.lins = nn.ModuleList([nn.Linear(channel_list[i], channel_list[i + 1], bias=biases[i]) for i in range(n)])
+        self.act, self.plain_last = act, plain_last
+
+    def pair_scores(self, q: torch.Tensor, c: torch.Tensor, eng) -> torch.Tensor:
+        from .models_hetero import _linear
+        nq, nc = int(q.shape[0]), int(c.shape[0])
+        n = len(self.lins)
+        w0 = self.lins[0].weight                                     # [h1, D]
+        h1 = int(w0.shape[0])
+        scaled = (q.unsqueeze(1) * w0.unsqueeze(0)).reshape(nq * h1, -1)  # row (q, j) = W_0[j] * q
+        x = _linear(eng, c, scaled, None).view(nc * nq, h1)            # row (c, q) = lin_0(q * c) before the bias
+        if self.lins[0].bias is not None:
+            x = x + self.lins[0].bias
+        for i in range(n):
+            if i > 0:
+                x = _linear(eng, x, self.lins[i].weight, self.lins[i].bias)
+            if self.act is not None and not (self.plain_last and i == n - 1):
+                x = self.act(x)
+        return x.view(nc, nq, -1).sum(dim=-1).t().contiguous()
 
 
 class LinkPredictionGNN(nn.Module):

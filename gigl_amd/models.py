@@ -14,7 +14,7 @@ layer over the whole union graph (SURVEY.md §0 fact 4, §7 "Batch-union semanti
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 import torch.nn as nn

@@ -92,12 +92,6 @@ def _graph(rng, n, e, d):
     return ei, x
 
 
-def _check_grads(model, g, y, h, xr, wsum):
-    (y * wsum.to(y.device)).sum().backward()
-    (h * wsum).sum().backward()
-    return
-
-
 @pytest.mark.parametrize("train_eps", [False, True])
 def test_gin_training_gradients_match_torch_autograd(train_eps):
     from gigl_amd.engine import HipEngine

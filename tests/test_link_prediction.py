@@ -165,3 +165,45 @@ def test_inner_product_decoder_known_answer_and_grads():
     ref_l = gnn_ref.retrieval_loss_rows(torch.mm(Q, CAND.T), QUERY_IDS.tolist(), CAND_IDS.tolist(), temperature=0.07)
     assert abs(float(got_l) - float(ref_l)) < 1e-4
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("channels,bias,plain_last", [([4, 2, 1], False, False), ([32, 16, 8, 1], True, False),
+                                                      ([32, 16, 1], [True, False], True)])
+def test_hadamard_mlp_decoder_scores_and_grads(channels, bias, plain_last):
+    """scores[q, c] = MLP(q * c).sum(-1) (decoder.py:67-69; decoder_test.py:44-50 checks the [Q, C] shape) against the
+    same MLP evaluated pair by pair with torch ops, forward and gradients"""
+    from gigl_amd.engine import HipEngine
+    eng = HipEngine(0)
+    try:
+        torch.manual_seed(len(channels))
+        dec = LinkPredictionDecoder(decoder_type=DecoderType.hadamard_MLP, decoder_channel_list=channels, bias=bias,
+                                    plain_last=plain_last).to(eng.device)
+        dec.engine = eng
+        d = channels[0]
+        q = (Q if d == 4 else torch.randn(5, d) / 3).clone()
+        c = (CAND if d == 4 else torch.randn(6, d) / 3).clone()
+        qd, cd = q.to(eng.device).requires_grad_(True), c.to(eng.device).requires_grad_(True)
+        got = dec(qd, cd)
+        assert tuple(got.shape) == (q.shape[0], c.shape[0])
+        sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+        qr, cr = q.clone().requires_grad_(True), c.clone().requires_grad_(True)
+        x = qr.unsqueeze(1) * cr
+        n = len(channels) - 1
+        for i in range(n):
+            x = x @ sd[f"mlp_decoder.lins.{i}.weight"].T
+            if f"mlp_decoder.lins.{i}.bias" in sd:
+                x = x + sd[f"mlp_decoder.lins.{i}.bias"]
+            if not (plain_last and i == n - 1):
+                x = torch.relu(x)
+        want = x.sum(-1)
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5, atol=1e-6)
+        w = torch.randn(q.shape[0], c.shape[0])
+        (got * w.to(eng.device)).sum().backward()
+        (want * w).sum().backward()
+        for name, prm in dec.named_parameters():
+            np.testing.assert_allclose(prm.grad.cpu().numpy(), sd[name].grad.numpy(), rtol=1e-4, atol=1e-6, err_msg=name)
+        np.testing.assert_allclose(qd.grad.cpu().numpy(), qr.grad.numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(cd.grad.cpu().numpy(), cr.grad.numpy(), rtol=1e-4, atol=1e-6)
+    finally:
+        eng.close()
