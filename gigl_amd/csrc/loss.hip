@@ -137,6 +137,59 @@ int32_t make_args(gigl_ctx* ctx, LossArgs& a, const float* scores, int64_t ld, i
   return GIGL_OK;
 }
 
+
+// ---- count-min sketch of candidate ids (the Retrieval task's candidate-sampling correction,
+// python/gigl/src/common/models/layers/count_min_sketch.py:11-95 used by task.py:140-205).  The reference keeps a
+// depth x width int32 table on the host and walks ids one at a time through Python's hash((item, i)) % width; here
+// the table lives in HBM, one thread per (id, row) adds with an atomic, one thread per id takes the minimum.  The
+// hash is CPython's (>= 3.8) tuple hash of two ints restated — lanes hash(int) = x mod (2^61 - 1) with the sign kept,
+// xxHash-style accumulation — so a table built here equals the reference's for the same ids, cell for cell.
+__device__ __forceinline__ uint64_t py_int_hash(int64_t x) {
+  const uint64_t P = (1ull << 61) - 1;
+  const uint64_t ax = x < 0 ? (uint64_t)0 - (uint64_t)x : (uint64_t)x;
+  int64_t h = (int64_t)(ax % P);
+  if (x < 0) h = -h;
+  if (h == -1) h = -2;
+  return (uint64_t)h;
+}
+__device__ __forceinline__ int64_t py_tuple2_hash(int64_t x, int64_t i) {
+  const uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P5 = 2870177450012600261ull;
+  uint64_t acc = P5;
+  acc += py_int_hash(x) * P2;
+  acc = (acc << 31) | (acc >> 33);
+  acc *= P1;
+  acc += py_int_hash(i) * P2;
+  acc = (acc << 31) | (acc >> 33);
+  acc *= P1;
+  acc += 2ull ^ (P5 ^ 3527539ull);
+  if (acc == ~0ull) return 1546275796;
+  return (int64_t)acc;
+}
+__device__ __forceinline__ int cms_cell(int64_t id, int row, int width) {
+  const int64_t h = py_tuple2_hash(id, row);
+  int64_t r = h % width;  // Python's %: the result takes the divisor's sign
+  if (r < 0) r += width;
+  return (int)r;
+}
+__global__ __launch_bounds__(256) void cms_add_kernel(int32_t* __restrict__ table, int width, int depth,
+                                                      const int64_t* __restrict__ ids, int64_t n) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * depth) return;
+  const int64_t k = t / depth;
+  const int row = (int)(t - k * depth);
+  atomicAdd(&table[(int64_t)row * width + cms_cell(ids[k], row, width)], 1);
+}
+__global__ __launch_bounds__(256) void cms_estimate_kernel(const int32_t* __restrict__ table, int width, int depth,
+                                                           const int64_t* __restrict__ ids, int64_t n,
+                                                           int64_t* __restrict__ out) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int64_t id = ids[k];
+  int32_t best = 0x7FFFFFFF;
+  for (int row = 0; row < depth; ++row) best = min(best, table[(int64_t)row * width + cms_cell(id, row, width)]);
+  out[k] = best;
+}
+
 }  // namespace
 
 extern "C" {
@@ -169,6 +222,29 @@ int32_t gigl_retrieval_loss_backward(gigl_ctx* ctx, const float* scores, int64_t
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipLaunchKernelGGL(retrieval_backward_kernel, dim3((unsigned)q), dim3(256), 0, ctx->stream, a, row_lse, grad_loss,
                      dscores);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_cms_add(gigl_ctx* ctx, int32_t* table, int32_t width, int32_t depth, const int64_t* ids, int64_t n) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, table && width > 0 && depth > 0 && n >= 0 && (ids || n == 0), "bad arguments");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return GIGL_OK;
+  hipLaunchKernelGGL(cms_add_kernel, dim3((unsigned)((n * depth + 255) / 256)), dim3(256), 0, ctx->stream, table, width,
+                     depth, ids, n);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_cms_estimate(gigl_ctx* ctx, const int32_t* table, int32_t width, int32_t depth, const int64_t* ids,
+                          int64_t n, int64_t* counts) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, table && width > 0 && depth > 0 && n >= 0 && ((ids && counts) || n == 0), "bad arguments");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (n == 0) return GIGL_OK;
+  hipLaunchKernelGGL(cms_estimate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, table, width,
+                     depth, ids, n, counts);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -155,15 +155,35 @@ def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrap
 
 
 class Retrieval(nn.Module):
-    """task.py:108-214 without candidate-sampling correction; forward -> (summed loss, number of query rows)"""
+    """task.py:108-214; forward -> (summed loss, number of query rows).  With
+    should_enable_candidate_sampling_correction the ids of every training batch go through two device-resident count-min
+    sketches (positives + hard negatives / random negatives) and logQ of the estimated in-batch probability is taken
+    off the logits inside the fused loss"""
     task_name = "Retrieval"
 
     def __init__(self, loss: Optional[nn.Module] = None, temperature: float = 0.07,
-                 remove_accidental_hits: bool = True, should_enable_candidate_sampling_correction: bool = False):
+                 remove_accidental_hits: bool = True, should_enable_candidate_sampling_correction: bool = False,
+                 count_min_sketch_width: int = 10000, count_min_sketch_depth: int = 10):
         super().__init__()
-        if should_enable_candidate_sampling_correction:
-            raise NotImplementedError("candidate sampling correction (count-min sketch) is out of scope")
+        self.should_enable_candidate_sampling_correction = should_enable_candidate_sampling_correction
         self.loss = RetrievalLoss(loss=loss, temperature=temperature, remove_accidental_hits=remove_accidental_hits)
+        if should_enable_candidate_sampling_correction:
+            from .count_min_sketch import CountMinSketch
+            self.main_batch_cm_sketch = CountMinSketch(width=count_min_sketch_width, depth=count_min_sketch_depth)
+            self.random_neg_batch_cm_sketch = CountMinSketch(width=count_min_sketch_width, depth=count_min_sketch_depth)
+
+    def _sampling_probability(self, bcs, device: torch.device) -> torch.Tensor:
+        from .count_min_sketch import calculate_in_batch_candidate_sampling_probability as in_batch_q
+        main, rn = self.main_batch_cm_sketch, self.random_neg_batch_cm_sketch
+        main.add_torch_long_tensor(bcs.positive_ids)
+        main.add_torch_long_tensor(bcs.hard_neg_ids)
+        rn.add_torch_long_tensor(bcs.random_neg_ids)
+        n_main = int(bcs.positive_ids.numel() + bcs.hard_neg_ids.numel())  # the two share a sketch
+        return torch.cat((
+            in_batch_q(main.estimate_torch_long_tensor(bcs.positive_ids), main.total(), n_main),
+            in_batch_q(main.estimate_torch_long_tensor(bcs.hard_neg_ids), main.total(), n_main),
+            in_batch_q(rn.estimate_torch_long_tensor(bcs.random_neg_ids), rn.total(), int(bcs.random_neg_ids.numel())),
+        )).to(device)
 
     def forward(self, task_input: NodeAnchorBasedLinkPredictionTaskInputs, gbml_config_pb_wrapper=None,
                 should_eval: bool = False, device: torch.device = torch.device("cpu")):
@@ -172,11 +192,14 @@ class Retrieval(nn.Module):
         running_loss = torch.tensor(0.0, device=device)
         running_batch_size = 0
         for cet, bcs in task_input.batch_combined_scores.items():
+            prob = None
+            if self.should_enable_candidate_sampling_correction and not should_eval:
+                prob = self._sampling_probability(bcs, device)
             rq = task_input.batch_embeddings.repeated_query_embeddings[cet]
             if rq.numel():  # loss.py:333-359
                 cand_ids = torch.cat((bcs.positive_ids, bcs.hard_neg_ids, bcs.random_neg_ids)).to(device)
                 loss = self.loss.calculate_batch_retrieval_loss(
-                    scores=bcs.repeated_candidate_scores, candidate_sampling_probability=None,
+                    scores=bcs.repeated_candidate_scores, candidate_sampling_probability=prob,
                     query_ids=bcs.repeated_query_ids, candidate_ids=cand_ids, device=device)
                 n = int(rq.shape[0])
             else:

@@ -708,6 +708,16 @@ int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
 int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);
 
+/* Count-min sketch of candidate ids for the Retrieval task's candidate-sampling correction
+ * (python/gigl/src/common/models/layers/count_min_sketch.py:11-95, used by task.py:140-205): table = DEVICE int32
+ * [depth][width], zeroed by the caller; cell of (id, row) = hash((id, row)) % width with CPython's tuple hash of two
+ * ints and Python's non-negative remainder, so the table equals the reference's for the same ids.
+ * gigl_cms_add: table[row][cell] += 1 for every id and row (duplicates count).  gigl_cms_estimate: counts[k] = min over
+ * rows of the id's cells.  ids / counts: DEVICE int64 [n]. */
+int32_t gigl_cms_add(gigl_ctx* ctx, int32_t* table, int32_t width, int32_t depth, const int64_t* ids, int64_t n);
+int32_t gigl_cms_estimate(gigl_ctx* ctx, const int32_t* table, int32_t width, int32_t depth, const int64_t* ids,
+                          int64_t n, int64_t* counts);
+
 /* ---- heterogeneous encoders: the attention-weighted segmented reductions of HGTConv and SimpleHGNConv
  *      (python/gigl/src/common/models/pyg/nn/conv/hgt_conv.py:161-244, simplehgn_conv.py:113-180; the models are
  *      python/gigl/src/common/models/pyg/heterogeneous.py:18-273).  Rows are [heads*dim] fp32; dim % 4 == 0 with dim/4
