@@ -47,7 +47,7 @@ SYMBOLS = [
     "gigl_split_hash_slots", "gigl_hgt_aggregate", "gigl_simplehgn_alpha", "gigl_weighted_aggregate",
     "gigl_collate_typed_records", "gigl_collated_typed_info", "gigl_collated_typed_nodes", "gigl_collated_typed_edges",
     "gigl_collated_typed_samples", "gigl_collated_typed_destroy", "gigl_typed_records_capacity",
-    "gigl_typed_records_encode", "gigl_hgt_aggregate_backward", "gigl_weighted_aggregate_backward",
+    "gigl_typed_records_encode", "gigl_typed_samples_encode", "gigl_hgt_aggregate_backward", "gigl_weighted_aggregate_backward",
 ]
 
 KERNEL_IDS = {
@@ -254,6 +254,8 @@ def load() -> C.CDLL:
                                         P(i64)],
         "gigl_typed_records_encode": [vp, vp, i32, P(GiglTypedOp), i32, P(GiglTypedFeat), i32, P(GiglTypedEdgeFeat), i32,
                                       i64, i32, vp, i64, vp, vp],
+        "gigl_typed_samples_encode": [vp, i32, vp, i32, P(GiglTypedOp), i32, P(GiglTypedFeat), i32, P(GiglTypedEdgeFeat),
+                                      i32, i64, i32, vp, i64, vp, vp],
         "gigl_tfexample_decode": [vp, vp, vp, i64, P(GiglColumn), i32, i32, P(i64)],
         "gigl_gat_aggregate_edge": [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, i32,
                                     i64, vp, vp, vp, vp],

@@ -784,6 +784,8 @@ constexpr int TYPED_MAX_OPS = 16, TYPED_MAX_NODE_TYPES = 16, TYPED_MAX_EDGE_TYPE
 constexpr uint32_t TYPED_MAX_ITEMS = 4096;  // candidate nodes / edges per root the LDS sort is sized for
 constexpr unsigned long long PAD64 = ~0ull;
 
+constexpr uint32_t TYPED_POS_BIT = 0x80000000u;  // class bit of a sorted edge's type word: a positive edge
+
 struct TypedArgs {
   gigl_typed_op ops[TYPED_MAX_OPS];
   int32_t n_ops;
@@ -792,13 +794,15 @@ struct TypedArgs {
   gigl_typed_feat feat[TYPED_MAX_NODE_TYPES];
   int32_t n_node_types;
   int32_t frame;
+  int32_t kind;    // GIGL_REC_ROOTED_NODE_NEIGHBORHOOD | GIGL_REC_NODE_ANCHOR_LINK_PRED (pos_edges after the graph)
   uint32_t items;  // candidates per root = sum of w * f over the ops
   uint32_t pow2;   // sort size: next power of two >= items + 1
   // per-root scratch
   unsigned long long* u_nodes;  // [b][items + 1]  (id << 32 | type), ascending
   unsigned long long* u_edges;  // [b][items]      (src << 32 | dst), ascending with u_etype as the minor key
   uint32_t* u_etype;            // [b][items]
-  uint32_t* u_info;             // [b][4]: distinct nodes, distinct edges, bytes of the node fields, graph body bytes
+  uint32_t* u_info;             // [b][8]: distinct nodes, distinct edges (both classes), bytes of the node fields,
+                                //         graph body bytes, bytes of the pos_edges fields
   const uint32_t* shift_tbl;
   // Edge.feature_values per condensed edge type: the type's edge list as CSR by SOURCE + one fp32 row per edge in its
   // `col` order (feat == NULL: edges of the type carry no features)
@@ -898,8 +902,9 @@ __global__ __launch_bounds__(256) void typed_plan_kernel(TypedArgs a, int64_t* r
       const uint32_t v = op.nbr[((int64_t)r * op.w + q) * op.f + (idx - q * (uint32_t)op.f)];
       if (fr == GIGL_INVALID || v == GIGL_INVALID) continue;
       nk[1 + base + idx] = ((unsigned long long)v << 32) | (uint32_t)op.result_node_type;
-      ek[base + idx] = op.outgoing ? ((unsigned long long)fr << 32) | v : ((unsigned long long)v << 32) | fr;
-      et[base + idx] = (uint32_t)op.condensed_edge_type;
+      ek[base + idx] = (op.outgoing & 1) ? ((unsigned long long)fr << 32) | v : ((unsigned long long)v << 32) | fr;
+      // (bit 31: an edge of a positive-edge op — listed as a pos_edges field, not inside the neighbourhood graph)
+      et[base + idx] = (uint32_t)op.condensed_edge_type | ((op.outgoing & GIGL_TYPED_OP_POSITIVE) ? TYPED_POS_BIT : 0u);
     }
     base += wf;
   }
@@ -910,7 +915,7 @@ __global__ __launch_bounds__(256) void typed_plan_kernel(TypedArgs a, int64_t* r
   unsigned long long* un = a.u_nodes + (int64_t)r * (a.items + 1);
   unsigned long long* ue = a.u_edges + (int64_t)r * a.items;
   uint32_t* ut = a.u_etype + (int64_t)r * a.items;
-  uint32_t n_nodes = 0, n_edges = 0, node_bytes = 0, edge_bytes = 0;
+  uint32_t n_nodes = 0, n_edges = 0, node_bytes = 0, edge_bytes = 0, pos_bytes = 0;
   for (uint32_t c0 = 0; c0 < P; c0 += 256) {
     const uint32_t i = c0 + tid;
     const unsigned long long k = i < P ? nk[i] : PAD64;
@@ -928,26 +933,29 @@ __global__ __launch_bounds__(256) void typed_plan_kernel(TypedArgs a, int64_t* r
     const unsigned long long k = i < P ? ek[i] : PAD64;
     const uint32_t t = i < P ? et[i] : 0u;
     const bool keep = k != PAD64 && (i == 0 || ek[i - 1] != k || et[i - 1] != t);
-    uint32_t tot, tot_b;
+    uint32_t tot, tot_b, tot_p;
     const uint32_t pos = block_exscan(keep ? 1u : 0u, s_w, tot);
-    const uint32_t fb = keep ? field_len(typed_edge_body(a, k, t)) : 0u;
-    block_exscan(fb, s_w, tot_b);
+    const uint32_t fb = keep ? field_len(typed_edge_body(a, k, t & ~TYPED_POS_BIT)) : 0u;
+    block_exscan((t & TYPED_POS_BIT) ? 0u : fb, s_w, tot_b);
+    block_exscan((t & TYPED_POS_BIT) ? fb : 0u, s_w, tot_p);
     if (keep) {
       ue[n_edges + pos] = k;
       ut[n_edges + pos] = t;
     }
     n_edges += tot;
     edge_bytes += tot_b;
+    pos_bytes += tot_p;
   }
   if (tid == 0) {
     const uint32_t graph_body = node_bytes + edge_bytes;
     const uint32_t root_body = typed_node_body(a, ((unsigned long long)root << 32) | (uint32_t)a.root_type);
-    uint32_t* info = a.u_info + (int64_t)r * 4;
+    uint32_t* info = a.u_info + (int64_t)r * 8;
     info[0] = n_nodes;
     info[1] = n_edges;
     info[2] = node_bytes;
     info[3] = graph_body;
-    rec_size[r] = (int64_t)field_len(root_body) + field_len(graph_body) + (a.frame ? 16 : 0);
+    info[4] = pos_bytes;
+    rec_size[r] = (int64_t)field_len(root_body) + field_len(graph_body) + pos_bytes + (a.frame ? 16 : 0);
   }
 }
 
@@ -990,19 +998,20 @@ __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int
     crc_t[j * 256 + tid] = (prev >> 8) ^ crc_t[prev & 0xFF];
     __syncthreads();
   }
-  const uint32_t* info = a.u_info + (int64_t)r * 4;
-  const uint32_t n_nodes = info[0], n_edges = info[1], node_bytes = info[2], graph_body = info[3];
+  const uint32_t* info = a.u_info + (int64_t)r * 8;
+  const uint32_t n_nodes = info[0], n_edges = info[1], node_bytes = info[2], graph_body = info[3], pos_bytes = info[4];
   const unsigned long long* un = a.u_nodes + (int64_t)r * (a.items + 1);
   const unsigned long long* ue = a.u_edges + (int64_t)r * a.items;
   const uint32_t* ut = a.u_etype + (int64_t)r * a.items;
   const unsigned long long root_key = ((unsigned long long)a.roots[r] << 32) | (uint32_t)a.root_type;
   const uint32_t root_body = typed_node_body(a, root_key);
-  const uint64_t payload_len = (uint64_t)field_len(root_body) + field_len(graph_body);
+  const uint64_t payload_len = (uint64_t)field_len(root_body) + field_len(graph_body) + pos_bytes;
   uint8_t* const rec = out + rec_off[r];
   uint8_t* const payload = rec + (a.frame ? 12 : 0);
   uint8_t* const graph_hdr = payload + field_len(root_body);
   uint8_t* const graph = graph_hdr + 1 + vlen(graph_body);
   uint8_t* const edges = graph + node_bytes;
+  uint8_t* const pos_edges = graph + graph_body;  // NodeAnchorBasedLinkPredictionSample.pos_edges = 4, after the graph
   uint8_t* const payload_end = payload + payload_len;
   if (tid == 0) {
     if (a.frame) {
@@ -1018,7 +1027,7 @@ __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int
     uint8_t* q = typed_write_node_header(a, payload, 0x0A, root_key);  // root_node = 1
     pay[n_nodes] = (uint32_t)(q - rec);
     q = graph_hdr;
-    *q++ = 0x12;  // neighborhood = 2
+    *q++ = a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED ? 0x1A : 0x12;  // neighborhood = 3 | 2
     put_varint(q, graph_body);
   }
   // Graph.nodes = 2: one thread per node writes the header; offsets from block scans of the field lengths
@@ -1032,16 +1041,21 @@ __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int
     run += tot;
   }
   run = 0;
-  for (uint32_t c0 = 0; c0 < n_edges; c0 += 256) {  // Graph.edges = 3
+  uint32_t run_p = 0;
+  for (uint32_t c0 = 0; c0 < n_edges; c0 += 256) {  // Graph.edges = 3; the positive-edge class: pos_edges = 4
     const uint32_t i = c0 + tid;
     const unsigned long long k = i < n_edges ? ue[i] : 0ull;
-    const uint32_t t = i < n_edges ? ut[i] : 0u;
-    uint32_t tot;
-    const uint32_t off = block_exscan(i < n_edges ? field_len(typed_edge_body(a, k, t)) : 0u, s_w, tot);
+    const uint32_t tc = i < n_edges ? ut[i] : 0u;
+    const uint32_t t = tc & ~TYPED_POS_BIT;
+    const bool is_pos = (tc & TYPED_POS_BIT) != 0;
+    const uint32_t fl = i < n_edges ? field_len(typed_edge_body(a, k, t)) : 0u;
+    uint32_t tot, tot_p;
+    const uint32_t off = block_exscan(is_pos ? 0u : fl, s_w, tot);
+    const uint32_t off_p = block_exscan(is_pos ? fl : 0u, s_w, tot_p);
     if (i < n_edges) {
-      uint8_t* q = edges + run + off;
+      uint8_t* q = is_pos ? pos_edges + run_p + off_p : edges + run + off;
       const uint32_t s = (uint32_t)(k >> 32), d = (uint32_t)k;
-      *q++ = 0x1A;
+      *q++ = is_pos ? 0x22 : 0x1A;
       q = put_varint(q, typed_edge_body(a, k, t));
       if (s) {
         *q++ = 0x08;
@@ -1063,6 +1077,7 @@ __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int
       }
     }
     run += tot;
+    run_p += tot_p;
   }
   __syncthreads();
   // feature rows: one wave per node (entry n_nodes = the root_node field)
@@ -1333,7 +1348,18 @@ int32_t gigl_typed_records_encode(gigl_ctx* ctx, const uint32_t* roots, int32_t 
                                   const gigl_typed_edge_feat* efeats, int32_t n_edge_types, int64_t n_records,
                                   int32_t tfrecord_frame, uint8_t* out, int64_t out_cap, int64_t* rec_off,
                                   int32_t* status) {
+  return gigl_typed_samples_encode(ctx, GIGL_REC_ROOTED_NODE_NEIGHBORHOOD, roots, root_node_type, ops, n_ops, feats,
+                                   n_node_types, efeats, n_edge_types, n_records, tfrecord_frame, out, out_cap, rec_off,
+                                   status);
+}
+
+int32_t gigl_typed_samples_encode(gigl_ctx* ctx, int32_t kind, const uint32_t* roots, int32_t root_node_type,
+                                  const gigl_typed_op* ops, int32_t n_ops, const gigl_typed_feat* feats,
+                                  int32_t n_node_types, const gigl_typed_edge_feat* efeats, int32_t n_edge_types,
+                                  int64_t n_records, int32_t tfrecord_frame, uint8_t* out, int64_t out_cap,
+                                  int64_t* rec_off, int32_t* status) {
   if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, kind == GIGL_REC_ROOTED_NODE_NEIGHBORHOOD || kind == GIGL_REC_NODE_ANCHOR_LINK_PRED, "bad kind %d", kind);
   GIGL_REQUIRE(ctx, roots && ops && out && rec_off && status && n_records >= 0, "null argument");
   GIGL_REQUIRE(ctx, n_ops >= 1 && n_ops <= TYPED_MAX_OPS, "between 1 and %d sampling ops", TYPED_MAX_OPS);
   GIGL_REQUIRE(ctx, n_node_types >= 1 && n_node_types <= TYPED_MAX_NODE_TYPES && root_node_type >= 0 &&
@@ -1345,6 +1371,8 @@ int32_t gigl_typed_records_encode(gigl_ctx* ctx, const uint32_t* roots, int32_t 
     GIGL_REQUIRE(ctx, ops[o].frontier && ops[o].nbr && ops[o].w >= 1 && ops[o].f >= 1, "op %d has no buffers", o);
     GIGL_REQUIRE(ctx, ops[o].result_node_type >= 0 && ops[o].result_node_type < n_node_types && ops[o].condensed_edge_type >= 0,
                  "op %d has a type outside the metadata", o);
+    GIGL_REQUIRE(ctx, !(ops[o].outgoing & GIGL_TYPED_OP_POSITIVE) || kind == GIGL_REC_NODE_ANCHOR_LINK_PRED,
+                 "op %d: a positive-edge op needs kind GIGL_REC_NODE_ANCHOR_LINK_PRED", o);
     a.ops[o] = ops[o];
     items += (int64_t)ops[o].w * ops[o].f;
   }
@@ -1370,6 +1398,7 @@ int32_t gigl_typed_records_encode(gigl_ctx* ctx, const uint32_t* roots, int32_t 
     a.efeat[t].d = efeats[t].d;
   }
   a.frame = tfrecord_frame ? 1 : 0;
+  a.kind = kind;
   a.items = (uint32_t)items;
   a.pow2 = next_pow2((uint32_t)items + 1);
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -1377,13 +1406,13 @@ int32_t gigl_typed_records_encode(gigl_ctx* ctx, const uint32_t* roots, int32_t 
   if (rc != GIGL_OK) return rc;
   a.shift_tbl = ctx->crc_shift_tbl;
   const int64_t nb = n_records > 0 ? n_records : 1;
-  rc = gigl_arena_reset(ctx, (n_records + 1) * 8 + nb * ((items + 1) * 8 + items * 12 + 16) + 4096);
+  rc = gigl_arena_reset(ctx, (n_records + 1) * 8 + nb * ((items + 1) * 8 + items * 12 + 32) + 4096);
   if (rc != GIGL_OK) return rc;
   int64_t* rec_size = (int64_t*)gigl_arena_alloc(ctx, (n_records + 1) * 8);
   a.u_nodes = (unsigned long long*)gigl_arena_alloc(ctx, nb * (items + 1) * 8);
   a.u_edges = (unsigned long long*)gigl_arena_alloc(ctx, nb * (items > 0 ? items : 1) * 8);
   a.u_etype = (uint32_t*)gigl_arena_alloc(ctx, nb * (items > 0 ? items : 1) * 4);
-  a.u_info = (uint32_t*)gigl_arena_alloc(ctx, nb * 16);
+  a.u_info = (uint32_t*)gigl_arena_alloc(ctx, nb * 32);
   if (!rec_size || !a.u_nodes || !a.u_edges || !a.u_etype || !a.u_info) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   const size_t lds_plan = (size_t)a.pow2 * 20, lds_write = ((size_t)items + 2) * 4;
   if (lds_plan > 60 * 1024)

@@ -465,10 +465,12 @@ class HipEngine:
             self._lib.gigl_graph_destroy(entry["graph"])
 
     def encode_typed_records(self, roots: torch.Tensor, root_node_type: int, ops, feats, *, tfrecord_frame: bool = True,
-                             edge_feats=None):
-        """typed (heterogeneous) RootedNodeNeighborhood records on the device (gigl_typed_records_encode).
+                             edge_feats=None, kind: int = _lib.REC_ROOTED_NODE_NEIGHBORHOOD):
+        """typed (heterogeneous) RootedNodeNeighborhood records — or, kind REC_NODE_ANCHOR_LINK_PRED, the typed
+        NodeAnchorBasedLinkPredictionSample records — on the device (gigl_typed_samples_encode).
         roots: int32 [b] on the device; ops: sequence of (frontier [b, w], nbr [b, w, f], condensed_edge_type,
-        result_node_type, outgoing); feats: per condensed node type a float32 [n, d] device tensor or None;
+        result_node_type, outgoing[, positive]) — positive: the op sampled the roots' positive edges (pos_edges);
+        feats: per condensed node type a float32 [n, d] device tensor or None;
         edge_feats: per condensed edge type the name of a load_label_edges entry (the type's edges as CSR by source with
         their feature rows) or None.
         -> (uint8 device tensor of all records back to back, int64 device tensor rec_off[b + 1])"""
@@ -476,7 +478,9 @@ class HipEngine:
         roots = roots.to(device=self.device, dtype=torch.int32).contiguous()
         c_ops = (_lib.GiglTypedOp * len(ops))()
         keep = [roots]
-        for i, (front, nbr, cet, res_t, outgoing) in enumerate(ops):
+        for i, op in enumerate(ops):
+            front, nbr, cet, res_t, outgoing = op[:5]
+            positive = bool(op[5]) if len(op) > 5 else False
             front = front.to(device=self.device, dtype=torch.int32).contiguous()
             nbr = nbr.to(device=self.device, dtype=torch.int32).contiguous()
             keep += [front, nbr]
@@ -485,7 +489,7 @@ class HipEngine:
             c_ops[i].frontier, c_ops[i].nbr = front.data_ptr(), nbr.data_ptr()
             c_ops[i].w, c_ops[i].f = w, f
             c_ops[i].condensed_edge_type, c_ops[i].result_node_type = int(cet), int(res_t)
-            c_ops[i].outgoing = 1 if outgoing else 0
+            c_ops[i].outgoing = (1 if outgoing else 0) | (2 if positive else 0)  # GIGL_TYPED_OP_POSITIVE
         c_feats = (_lib.GiglTypedFeat * len(feats))()
         for t, x in enumerate(feats):
             if x is None:
@@ -511,15 +515,15 @@ class HipEngine:
         rec_off = torch.empty(b + 1, dtype=torch.int64, device=self.device)
         status = torch.zeros(1, dtype=torch.int32, device=self.device)
         torch.cuda.current_stream(self.device).synchronize()  # the op results may come from torch's stream
-        check(self._lib.gigl_typed_records_encode(self._ctx, C.c_void_p(roots.data_ptr()), int(root_node_type), c_ops,
-                                                  len(ops), c_feats, len(feats), c_ef, len(edge_feats), b,
+        check(self._lib.gigl_typed_samples_encode(self._ctx, int(kind), C.c_void_p(roots.data_ptr()), int(root_node_type),
+                                                  c_ops, len(ops), c_feats, len(feats), c_ef, len(edge_feats), b,
                                                   1 if tfrecord_frame else 0,
                                                   C.c_void_p(out.data_ptr()), cap.value,
                                                   C.c_void_p(rec_off.data_ptr()), C.c_void_p(status.data_ptr())),
               self._ctx)
         self._stream.synchronize()
         if int(status.item()) != 0:
-            raise RuntimeError("gigl_typed_records_encode: output capacity too small (status=1)")
+            raise RuntimeError("gigl_typed_samples_encode: output capacity too small (status=1)")
         del keep
         return out[: int(rec_off[-1].item())], rec_off
 

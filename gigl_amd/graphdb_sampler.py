@@ -18,9 +18,11 @@ deterministic rule of the Spark sampler (SamplingStrategy.scala:16-82): permute 
 xxhash64 keys, K = root id + frontier node id, counter = 1 + the op's position in the DAG's op list.
 
 Device work per op: one gigl_rows_dedup (frontier union, LDS hash per root) + one gigl_expand_frontier over B * width
-slots on the op's edge-type graph; B roots advance together.  Assembly of the typed RootedNodeNeighborhood messages
-(set union across ops, hydration with per-type features) is host code: the typed records are not produced by
-serialize.hip, whose plan assumes one node type and one edge type."""
+slots on the op's edge-type graph; B roots advance together.  The typed RootedNodeNeighborhood /
+NodeAnchorBasedLinkPredictionSample records (set union across ops, hydration with per-type node and edge features,
+TFRecord framing) are written on the device too (gigl_typed_samples_encode: encode_records / encode_nablp_records); the
+host assembly of the same messages (getKHopSubgraphForRootNodes / getNablpSamplesForRootNodes) is the surface the
+reference's KHopSamplerService exposes and what the device bytes are checked against."""
 from __future__ import annotations
 
 from dataclasses import dataclass, field
@@ -267,6 +269,109 @@ class HipGraphDBSampler:
                                                     feats, tfrecord_frame=tfrecord_frame, edge_feats=edge_feats)
         blob, off = out.cpu().numpy().tobytes(), off.cpu().numpy()
         return [blob[int(off[i]):int(off[i + 1])] for i in range(len(root_ids))]
+
+    # ---- typed training samples (GraphDBNodeAnchorBasedLinkPredictionTask.scala:80-116, 333-470;
+    #      GraphDBSampler.samplePositiveEdgeNeighborhoods :175-218) ------------------------------------------------
+    POSITIVE_OP_NAME = "samplePositiveEdges"
+
+    def _run_nablp(self, root_ids: Sequence[int], positive_edge_type: EdgeType, num_positives: int,
+                   root_dag: SamplingOpDAG, positive_dag: SamplingOpDAG):
+        """-> (roots int32 [b], root DAG results, positives OpResult ([b, 1] / [b, 1, P]), positives' DAG results over
+        the b*P flattened positives).  The positives are sampled OUTGOING along the supervision edge type with the
+        sampler's rule (K = 2 * root id, counter 1 + the number of ops of the root's DAG: the op after them); every
+        positive's neighbourhood is the one it gets as a root of its own node type's DAG."""
+        for name in positive_dag.root_op_names:
+            et = positive_dag.nodes[name].sampling_op.edge_type
+            if et.dst_node_type != positive_edge_type.dst_node_type:
+                raise ValueError(f"SamplingOpDAG should have edgeType {positive_edge_type} matching for all sampling "
+                                 f"ops. Mismatch for {name}")
+        eng = self.engine
+        roots = torch.tensor(np.asarray(root_ids, dtype=np.int64).astype(np.uint32).view(np.int32)).to(eng.device)
+        b, P = int(roots.numel()), int(num_positives)
+        res = self.run_dag(roots, root_dag)
+        front = roots.view(b, 1).contiguous()
+        ksum = (front + roots.view(b, 1)).contiguous()
+        counter = 1 + len(root_dag.op_order)
+        nbr, cnt = eng.expand_frontier(front.view(-1), ksum.view(-1), P, self.sampling_seed * counter, 1,
+                                       label_edges=self._key(positive_edge_type, OUTGOING))
+        pos = OpResult(front, nbr.view(b, 1, P), cnt.view(b, 1))
+        pos_res = self.run_dag(nbr.reshape(-1), positive_dag)  # INVALID positives sample nothing
+        return roots, res, pos, pos_res
+
+    def getNablpSamplesForRootNodes(self, root_ids: Sequence[int], positive_edge_type: EdgeType, num_positives: int,
+                                    root_dag: SamplingOpDAG, positive_dag: SamplingOpDAG
+                                    ) -> List[wire.NodeAnchorBasedLinkPredictionSample]:
+        """host assembly: root node, pos_edges (root -> positive, hydrated), neighbourhood = the root's merged with its
+        positives' (mergeGraphs); a root without positives gets empty pos_edges and its own neighbourhood"""
+        root_type = positive_edge_type.src_node_type
+        roots, res, pos, pos_res = self._run_nablp(root_ids, positive_edge_type, num_positives, root_dag, positive_dag)
+        self.engine.synchronize()
+        b, P = len(root_ids), int(num_positives)
+        to_h = lambda t: t.cpu().numpy().view(np.uint32)
+        pos_h = to_h(pos.nbr).reshape(b, P)
+        cet_pos = self.condensed_edge_types[positive_edge_type]
+        out = []
+        parts = [(root_dag, {k: (to_h(r.frontier), to_h(r.nbr)) for k, r in res.items()}, 1),
+                 (positive_dag, {k: (to_h(r.frontier), to_h(r.nbr)) for k, r in pos_res.items()}, P)]
+        for i, root in enumerate(root_ids):
+            edges: Set[Tuple[int, int, int]] = set()
+            nodes: Set[Tuple[int, int]] = {(int(root), self.node_types[root_type])}
+            pos_edges = sorted({(int(root), int(v), cet_pos) for v in pos_h[i] if v != INVALID})
+            nodes |= {(d, self.node_types[positive_edge_type.dst_node_type]) for _, d, _ in pos_edges}
+            for dag, host, rows in parts:
+                for name, (front, nbr) in host.items():
+                    op = dag.nodes[name].sampling_op
+                    cet = self.condensed_edge_types[op.edge_type]
+                    outgoing = op.sampling_direction == OUTGOING
+                    got_type = self.node_types[op.edge_type.dst_node_type if outgoing else op.edge_type.src_node_type]
+                    for row in range(i * rows, (i + 1) * rows):
+                        fr, nb = front[row], nbr[row]
+                        for q in np.flatnonzero(fr != INVALID):
+                            for v in nb[q][nb[q] != INVALID].tolist():
+                                edges.add((int(fr[q]), v, cet) if outgoing else (v, int(fr[q]), cet))
+                                nodes.add((v, got_type))
+            rnn = self._message(int(root), root_type, sorted(nodes), sorted(edges))
+            out.append(wire.NodeAnchorBasedLinkPredictionSample(
+                root_node=rnn.root_node, neighborhood=rnn.neighborhood,
+                pos_edges=[wire.Edge(src_node_id=s_, dst_node_id=d_, condensed_edge_type=c_,
+                                     feature_values=self._edge_rows.get((s_, d_, c_), wire._EMPTY_F32))
+                           for s_, d_, c_ in pos_edges]))
+        return out
+
+    def encode_nablp_records(self, root_ids: Sequence[int], positive_edge_type: EdgeType, num_positives: int,
+                             root_dag: SamplingOpDAG, positive_dag: SamplingOpDAG, tfrecord_frame: bool = True):
+        """the messages of getNablpSamplesForRootNodes serialized ON THE DEVICE (gigl_typed_samples_encode, kind
+        NODE_ANCHOR_LINK_PRED) -> (list of record bytes, number of positives per root)"""
+        from ._lib import REC_NODE_ANCHOR_LINK_PRED
+        root_type = positive_edge_type.src_node_type
+        roots, res, pos, pos_res = self._run_nablp(root_ids, positive_edge_type, num_positives, root_dag, positive_dag)
+        b, P = len(root_ids), int(num_positives)
+        n_types = max(self.node_types.values()) + 1
+        by_cnt = {c: t for t, c in self.node_types.items()}
+        feats = [self._feature_table(by_cnt[c]) if c in by_cnt else None for c in range(n_types)]
+
+        def typed(dag, name, r, rows):
+            op = dag.nodes[name].sampling_op
+            outgoing = op.sampling_direction == OUTGOING
+            got = self.node_types[op.edge_type.dst_node_type if outgoing else op.edge_type.src_node_type]
+            f = int(r.nbr.shape[-1])
+            # (the P positives of a root are consecutive rows: side by side they are one [b, P*w] frontier)
+            return (r.frontier.reshape(b, -1), r.nbr.reshape(b, -1, f), self.condensed_edge_types[op.edge_type], got,
+                    outgoing)
+        ops = [typed(root_dag, n_, r, 1) for n_, r in res.items()]
+        ops.append((pos.frontier, pos.nbr, self.condensed_edge_types[positive_edge_type],
+                    self.node_types[positive_edge_type.dst_node_type], True, True))
+        ops += [typed(positive_dag, n_, r, P) for n_, r in pos_res.items()]
+        n_et = max(self.condensed_edge_types.values()) + 1
+        by_c = {c: et for et, c in self.condensed_edge_types.items()}
+        edge_feats = [self._key(by_c[c], OUTGOING) if c in by_c and self._has_edge_feats.get(by_c[c]) else None
+                      for c in range(n_et)]
+        out, off = self.engine.encode_typed_records(roots, self.node_types[root_type], ops, feats,
+                                                    tfrecord_frame=tfrecord_frame, edge_feats=edge_feats,
+                                                    kind=REC_NODE_ANCHOR_LINK_PRED)
+        blob, off = out.cpu().numpy().tobytes(), off.cpu().numpy()
+        n_pos = (pos.nbr.view(b, P) != -1).sum(dim=1).cpu().numpy()
+        return [blob[int(off[i]):int(off[i + 1])] for i in range(b)], n_pos
 
     def write_tfrecords(self, path: str, root_ids: Sequence[int], root_node_type: str, dag: SamplingOpDAG) -> int:
         """a part file of the sampler job: the device-encoded frames of encode_records written back to back"""

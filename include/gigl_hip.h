@@ -389,8 +389,9 @@ typedef struct gigl_typed_op {
   int32_t w, f;
   int32_t condensed_edge_type;
   int32_t result_node_type;
-  int32_t outgoing;
+  int32_t outgoing; /* bit 0: outgoing; GIGL_TYPED_OP_POSITIVE: the op sampled the sample's positive edges */
 } gigl_typed_op;
+#define GIGL_TYPED_OP_POSITIVE 2
 typedef struct gigl_typed_feat {
   const float* x; /* device, [n, d] */
   int32_t d;
@@ -409,6 +410,19 @@ int32_t gigl_typed_records_encode(gigl_ctx* ctx, const uint32_t* roots, int32_t 
                                   const gigl_typed_edge_feat* efeats, int32_t n_edge_types, int64_t n_records,
                                   int32_t tfrecord_frame, uint8_t* out, int64_t out_cap, int64_t* rec_off,
                                   int32_t* status);
+/* The same encoder for the typed TRAINING samples of GraphDBNodeAnchorBasedLinkPredictionTask.scala:118-496
+ * (kind GIGL_REC_NODE_ANCHOR_LINK_PRED): NodeAnchorBasedLinkPredictionSample{root_node = 1, neighborhood = 3,
+ * pos_edges = 4}.  The ops of the root's own DAG, one op flagged GIGL_TYPED_OP_POSITIVE (the root's sampled positive
+ * edges, samplePositiveEdgeNeighborhoods, GraphDBSampler.scala:175-218: its edges become pos_edges — distinct, ascending
+ * by (src, dst, type), features joined like any edge — and its result nodes join the neighbourhood's nodes), and the
+ * ops of the positives' DAG with `frontier` / `nbr` holding the results of the root's P positives side by side
+ * ([b][P*w] / [b][P*w][f]): the neighbourhood is the union over all of them = mergeGraphs of the root's and the
+ * positives' neighbourhoods.  kind GIGL_REC_ROOTED_NODE_NEIGHBORHOOD = gigl_typed_records_encode. */
+int32_t gigl_typed_samples_encode(gigl_ctx* ctx, int32_t kind, const uint32_t* roots, int32_t root_node_type,
+                                  const gigl_typed_op* ops, int32_t n_ops, const gigl_typed_feat* feats,
+                                  int32_t n_node_types, const gigl_typed_edge_feat* efeats, int32_t n_edge_types,
+                                  int64_t n_records, int32_t tfrecord_frame, uint8_t* out, int64_t out_cap,
+                                  int64_t* rec_off, int32_t* status);
 
 /* ---- inference output: (node id, embedding row) batches -> Avro object-container DATA BLOCKS, encoded on the device.
  *      Replaces the record loop of EmbeddingExporter.add_embedding (python/gigl/common/data/export.py:103-135:

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from gigl_amd import wire
 from oracle import dag_sampler
 from gigl_amd.graphdb_sampler import (INCOMING, OUTGOING, EdgeType, HipGraphDBSampler, SamplingOp, SamplingOpDAG)
 
@@ -179,6 +180,42 @@ def test_reference_heterogeneous_fixture(golden_dir):
         assert [m.SerializeToString() for m in msgs] == dev_recs
         assert any(e.feature_values.size for m in msgs for e in m.neighborhood.edges)
     assert total_edges > 100
+    # typed TRAINING samples (GraphDBNodeAnchorBasedLinkPredictionTask.scala:333-470): supervision edge type
+    # paper -> author; pos_edges sampled OUTGOING from the root, neighbourhood = the root's merged with its positives'
+    root_dag = SamplingOpDAG.from_ops(plans["paper"])
+    pos_ops = [op for op in plans["author"] if op.op_name != "out"]
+    pos_dag = SamplingOpDAG.from_ops(pos_ops)
+    with pytest.raises(ValueError):  # a root op of the positives' DAG must end in the positive node type
+        s.getNablpSamplesForRootNodes([0], p2a, 1, root_dag, SamplingOpDAG.from_ops(plans["author"]))
+    papers = np.arange(n["paper"])
+    src_p2a, dst_p2a = edges[p2a]
+    for P in (1, 3):
+        samples = s.getNablpSamplesForRootNodes(papers, p2a, P, root_dag, pos_dag)
+        recs, n_pos = s.encode_nablp_records(papers, p2a, P, root_dag, pos_dag, tfrecord_frame=False)
+        assert [m.SerializeToString() for m in samples] == recs
+        rnn_paper = s.getKHopSubgraphForRootNodes(papers, "paper", root_dag)
+        seen_pos = 0
+        for r, m, own, k in zip(papers, samples, rnn_paper, n_pos):
+            out_nbrs = set(dst_p2a[src_p2a == r].tolist())
+            assert len(m.pos_edges) == k == min(P, len(out_nbrs))
+            got_n = {(x.node_id, x.condensed_node_type) for x in m.neighborhood.nodes}
+            got_e = {(e.src_node_id, e.dst_node_id, e.condensed_edge_type) for e in m.neighborhood.edges}
+            assert {(x.node_id, x.condensed_node_type) for x in own.neighborhood.nodes} <= got_n
+            assert {(e.src_node_id, e.dst_node_id, e.condensed_edge_type) for e in own.neighborhood.edges} <= got_e
+            want_n = {(x.node_id, x.condensed_node_type) for x in own.neighborhood.nodes}
+            want_e = {(e.src_node_id, e.dst_node_id, e.condensed_edge_type) for e in own.neighborhood.edges}
+            for e in m.pos_edges:
+                assert e.src_node_id == r and e.dst_node_id in out_nbrs and e.condensed_edge_type == cet[p2a]
+                hit = np.flatnonzero((src_p2a == r) & (dst_p2a == e.dst_node_id))
+                np.testing.assert_array_equal(e.feature_values, efeats[p2a][hit[0]])
+                pos_rnn = s.getKHopSubgraphForRootNode(e.dst_node_id, "author", pos_dag)  # the positive's own RNN
+                want_n |= {(x.node_id, x.condensed_node_type) for x in pos_rnn.neighborhood.nodes}
+                want_e |= {(x.src_node_id, x.dst_node_id, x.condensed_edge_type) for x in pos_rnn.neighborhood.edges}
+                seen_pos += 1
+            assert (got_n, got_e) == (want_n, want_e)  # mergeGraphs(root's, positives'), nothing else
+            parsed = wire.NodeAnchorBasedLinkPredictionSample.FromString(recs[int(r)])
+            assert parsed.root_node.node_id == r and len(parsed.pos_edges) == k
+        assert seen_pos > 10
     s.close()
 
 
