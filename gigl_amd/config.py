@@ -246,6 +246,38 @@ class GbmlConfigPbWrapper:
     def node_types(self) -> List[str]:
         return list(_get(self.doc, "graphMetadata.nodeTypes", ["node"]) or ["node"])
 
+    # ---- typed graphs (graph_schema.proto GraphMetadata; gbml_config.proto TaskMetadata)
+    @property
+    def condensed_node_type_map(self) -> Dict[int, str]:
+        m = _get(self.doc, "graphMetadata.condensedNodeTypeMap") or {}
+        return {int(k): str(v) for k, v in m.items()} or {0: self.node_types[0]}
+
+    @property
+    def condensed_edge_type_map(self) -> Dict[int, tuple]:
+        """condensed edge type -> (srcNodeType, relation, dstNodeType)"""
+        m = _get(self.doc, "graphMetadata.condensedEdgeTypeMap") or {}
+        return {int(k): (str(v["srcNodeType"]), str(v["relation"]), str(v["dstNodeType"])) for k, v in m.items()}
+
+    @property
+    def is_heterogeneous(self) -> bool:
+        return len(self.condensed_node_type_map) > 1 or len(self.condensed_edge_type_map) > 1
+
+    @property
+    def supervision_edge_types(self) -> List[tuple]:
+        ets = _get(self.doc, "taskMetadata.nodeAnchorBasedLinkPredictionTaskMetadata.supervisionEdgeTypes") or []
+        return [(str(e["srcNodeType"]), str(e["relation"]), str(e["dstNodeType"])) for e in ets]
+
+    @property
+    def should_include_isolated_nodes_in_training(self) -> bool:
+        return bool(_get(self.doc, "sharedConfig.shouldIncludeIsolatedNodesInTraining", False))
+
+    @property
+    def message_passing_paths(self) -> List[dict]:
+        """subgraphSamplingStrategy.messagePassingPaths.paths (subgraph_sampling_strategy.proto:38-58): one
+        {rootNodeType, samplingOps} entry per root node type; empty when the config carries no strategy"""
+        strat = _get(self.doc, "datasetConfig.subgraphSamplerConfig.subgraphSamplingStrategy") or {}
+        return list(_get(strat, "messagePassingPaths.paths") or [])
+
     # ---- plugins (gbml_config.proto:172-237)
     @property
     def trainer_cls_path(self) -> Optional[str]:

@@ -152,6 +152,14 @@ class _PartWriter:
             self.n_records += take
             k += take
 
+    def add_frame(self, frame: bytes) -> None:
+        """one finished TFRecord frame"""
+        if self.fh is None or self.in_part >= self.per:
+            self._roll()
+        self.fh.write(frame)
+        self.in_part += 1
+        self.n_records += 1
+
     def close(self) -> List[str]:
         if self.fh is None:
             self._roll()  # an empty dataset still leaves one (empty) part file
@@ -193,6 +201,8 @@ class SubgraphSampler:
         if cfg.permutation_strategy != "deterministic":
             seed = 1 + int.from_bytes(os.urandom(3), "little") % ((1 << 20) - 1)
         self.sampling_seed = seed
+        if cfg.is_heterogeneous:
+            return self._run_graphdb_nablp(cfg, device, seed, batch_size)
         n, src, dst, x, labels, node_ids = load_preprocessed_graph(cfg)
         ids = np.asarray(node_ids, dtype=np.uint32)
         with HipKHopSamplerService(n, src, dst, x, cfg.is_graph_directed, device=device, sampling_seed=seed,
@@ -203,6 +213,53 @@ class SubgraphSampler:
             if cfg.task_kind == "node_classification":
                 return self._run_node_classification(cfg, svc, ids, labels, batch_size)
             return self._run_nablp(cfg, svc, ids, batch_size)
+
+    def _run_graphdb_nablp(self, cfg: GbmlConfigPbWrapper, device: int, seed: int, batch_size: int):
+        """GraphDBNodeAnchorBasedLinkPredictionTask.run (scala_spark35 .../task/graphdb/GraphDBNodeAnchorBasedLinkPredictionTask
+        .scala:118-496) on a typed graph: one RootedNodeNeighborhood per node of every anchor / target node type, written
+        under nodeTypeToRandomNegativeTfrecordUriPrefix[type]; then for the first supervision edge type one
+        NodeAnchorBasedLinkPredictionSample per root of its source type (numMaxTrainingSamplesToOutput caps them), with
+        numPositiveSamples sampled positive edges and the positives' neighbourhoods merged in; roots without a positive
+        are dropped unless shouldIncludeIsolatedNodesInTraining.  Sampling, assembly, hydration, proto encoding and
+        TFRecord framing run on the device."""
+        from .graphdb_sampler import EdgeType, HipGraphDBSampler
+        if cfg.task_kind != "node_anchor_based_link_prediction":
+            raise NotImplementedError("typed graphs: only the node-anchor-based link-prediction sampler task is built")
+        sup = cfg.supervision_edge_types
+        if not sup:
+            raise ValueError("nodeAnchorBasedLinkPredictionTaskMetadata.supervisionEdgeTypes is empty")
+        pos_et = EdgeType(*sup[0])  # (stage 1 of the reference: one supervision edge type)
+        anchor_target = list(dict.fromkeys([t for e in sup for t in (e[0],)] + [t for e in sup for t in (e[2],)]))
+        node_types, num, ids, feats, edges, cet, efeats = load_preprocessed_typed_graph(cfg)
+        dags = sampling_op_dags(cfg, anchor_target)
+        rn_prefixes = cfg.random_negative_tfrecord_uri_prefixes
+        out: Dict[str, List[str]] = {}
+        s = HipGraphDBSampler(node_types, num, edges, cet, feats, device=device, sampling_seed=seed, edge_features=efeats)
+        try:
+            for t in anchor_target:
+                if t not in rn_prefixes:
+                    raise ValueError(f"nodeTypeToRandomNegativeTfrecordUriPrefix is missing node type {t!r}")
+                w = _PartWriter(_res(cfg, rn_prefixes[t]))
+                for i in range(0, ids[t].size, batch_size):
+                    for fr in s.encode_records(ids[t][i:i + batch_size], t, dags[t], tfrecord_frame=True):
+                        w.add_frame(fr)
+                out[f"random_negative/{t}"] = w.close()
+            roots = ids[pos_et.src_node_type]
+            cap = cfg.num_max_training_samples_to_output
+            if 0 < cap < roots.size:  # (the reference samples a fraction; a seeded choice of exactly `cap` roots here)
+                roots = np.sort(np.random.default_rng(seed).choice(roots, size=cap, replace=False))
+            w = _PartWriter(_res(cfg, cfg.nablp_tfrecord_uri_prefix))
+            keep_isolated = cfg.should_include_isolated_nodes_in_training
+            for i in range(0, roots.size, batch_size):
+                frames, n_pos = s.encode_nablp_records(roots[i:i + batch_size], pos_et, cfg.num_positive_samples,
+                                                       dags[pos_et.src_node_type], dags[pos_et.dst_node_type])
+                for fr, k in zip(frames, n_pos):
+                    if k > 0 or keep_isolated:
+                        w.add_frame(fr)
+            out["node_anchor_based_link_prediction"] = w.close()
+        finally:
+            s.close()
+        return out
 
     # Sampling, per-root assembly (createSubgraph), hydration, proto encoding and TFRecord framing all run on the
     # device (gigl_sample_khop + gigl_records_encode); the host only copies finished frames into the part files.
@@ -306,6 +363,87 @@ class SubgraphSampler:
         for t, w in rn.items():
             files[f"random_negative/{t}"] = w.close()
         return files
+
+
+def load_preprocessed_typed_graph(cfg: GbmlConfigPbWrapper):
+    """loadHydratedNodeDataFrame / loadHydratedEdgeDataFrame for every condensed type (scala_spark35 SGSTask.scala;
+    GraphDBNodeAnchorBasedLinkPredictionTask.scala:156-166): per node type its ids and feature rows, per edge type its
+    (src, dst) list and edge feature rows, decoded by the native reader"""
+    from .graphdb_sampler import EdgeType
+    from .ingest import COL_F32, COL_I64, feature_widths, read_columns
+    pm = cfg.preprocessed_metadata
+    node_types = {name: c for c, name in cfg.condensed_node_type_map.items()}
+    ids: Dict[str, np.ndarray] = {}
+    feats: Dict[str, np.ndarray] = {}
+    num: Dict[str, int] = {}
+    for c, name in cfg.condensed_node_type_map.items():
+        nm = pm.nodes[c]
+        files = tfrecord_files(os.path.join(_res(cfg, nm.tfrecord_uri_prefix), ""))
+        widths = feature_widths(files[0], nm.feature_keys) if files and nm.feature_keys else []
+        cols = [(nm.node_id_key, COL_I64, 1)] + [(k, COL_F32, max(w, 1)) for k, w in zip(nm.feature_keys, widths)]
+        data, _ = read_columns(files, cols)
+        nid = data[nm.node_id_key][:, 0]
+        ids[name] = np.unique(nid)
+        num[name] = int(nid.max()) + 1 if nid.size else 0
+        if sum(widths):
+            x = np.zeros((num[name], int(sum(widths))), dtype=np.float32)
+            x[nid] = np.concatenate([data[k][:, :w] for k, w in zip(nm.feature_keys, widths) if w], axis=1)
+            feats[name] = x
+    edges, efeats, cet = {}, {}, {}
+    for c, (s_t, rel, d_t) in cfg.condensed_edge_type_map.items():
+        em = pm.edges[c]
+        et = EdgeType(s_t, rel, d_t)
+        files = tfrecord_files(os.path.join(_res(cfg, em.tfrecord_uri_prefix), ""))
+        widths = feature_widths(files[0], em.feature_keys) if files and em.feature_keys else []
+        cols = [(em.src_node_id_key, COL_I64, 1), (em.dst_node_id_key, COL_I64, 1)]
+        cols += [(k, COL_F32, max(w, 1)) for k, w in zip(em.feature_keys, widths)]
+        ed, _ = read_columns(files, cols)
+        edges[et] = (ed[em.src_node_id_key][:, 0].astype(np.uint32), ed[em.dst_node_id_key][:, 0].astype(np.uint32))
+        cet[et] = c
+        if sum(widths):
+            efeats[et] = np.concatenate([ed[k][:, :w] for k, w in zip(em.feature_keys, widths) if w], axis=1)
+    return node_types, num, ids, feats, edges, cet, efeats
+
+
+def default_sampling_op_dag(cfg: GbmlConfigPbWrapper, root_node_type: str):
+    """the k-hop message-passing DAG of a root node type when the config names no SubgraphSamplingStrategy: hop 1 =
+    one INCOMING op per edge type that ends in the root type, hop h+1 = for every hop-h op one INCOMING op per edge
+    type that ends in that op's source type; numNeighborsToSample neighbours each, numHops hops (the uniform k-hop
+    sampling the homogeneous sampler does, per edge type)"""
+    from .graphdb_sampler import INCOMING, EdgeType, SamplingOp, SamplingOpDAG
+    ets = [EdgeType(*t) for _, t in sorted(cfg.condensed_edge_type_map.items())]
+    f = cfg.num_neighbors_to_sample
+    ops, level = [], [(None, root_node_type)]
+    for hop in range(1, cfg.num_hops + 1):
+        nxt = []
+        for parent, ntype in level:
+            for et in ets:
+                if et.dst_node_type != ntype:
+                    continue
+                name = f"hop{hop}_{len(ops)}_{et.relation}"
+                ops.append(SamplingOp(name, et, f, [parent] if parent else [], INCOMING))
+                nxt.append((name, et.src_node_type))
+        level = nxt
+    return SamplingOpDAG.from_ops(ops)
+
+
+def sampling_op_dags(cfg: GbmlConfigPbWrapper, node_types: Sequence[str]):
+    """getNodeTypeToSamplingOpDagMap (SubgraphSamplingStrategyWrapper.scala:10-20) for the node types asked for"""
+    from .graphdb_sampler import EdgeType, SamplingOp, SamplingOpDAG
+    out = {}
+    for path in cfg.message_passing_paths:
+        ops = []
+        for op in path.get("samplingOps") or []:
+            et = op["edgeType"]
+            ops.append(SamplingOp(
+                op["opName"], EdgeType(et["srcNodeType"], et["relation"], et["dstNodeType"]),
+                int((op.get("randomUniform") or {}).get("numNodesToSample", 0) or op.get("numNodesToSample", 0)),
+                list(op.get("inputOpNames") or []), str(op.get("samplingDirection", "INCOMING"))))
+        out[str(path["rootNodeType"])] = SamplingOpDAG.from_ops(ops)
+    for t in node_types:
+        if t not in out:
+            out[t] = default_sampling_op_dag(cfg, t)
+    return out
 
 
 def self_write_rn(eng, svc, cfg, roots, rn) -> None:

@@ -72,9 +72,25 @@ def graph_d(g):
     return {"nodes": [node_d(n) for n in g.nodes], "edges": [edge_d(e) for e in g.edges]}
 
 
+def hetero_sampler_configs(base):
+    """the reference's heterogeneous sampler fixture config + its preprocessed metadata as test data, with the asset
+    paths re-rooted to tests/golden/ and the outputs to out/ (tests/golden/configs/hetero_nablp_*.yaml)"""
+    rel = "subgraph_sampler/heterogeneous/node_anchor_based_link_prediction/"
+    pre = "common/src/test/assets/" + rel
+    cfg = open(os.path.join(base, rel, "frozen_gbml_config_graphdb_dblp_local.yaml")).read()
+    meta = open(os.path.join(base, rel, "preprocessed_metadata.yaml")).read()
+    cfg = cfg.replace(pre + "preprocessed_metadata.yaml", "configs/hetero_nablp_preprocessed_metadata.yaml")
+    cfg = cfg.replace(pre + "output/", "out/hetero_nablp/")
+    meta = meta.replace(pre, "ref_assets/" + rel)
+    os.makedirs(os.path.join(OUT, "configs"), exist_ok=True)
+    open(os.path.join(OUT, "configs", "hetero_nablp_frozen_gbml_config.yaml"), "w").write(cfg)
+    open(os.path.join(OUT, "configs", "hetero_nablp_preprocessed_metadata.yaml"), "w").write(meta)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     base = os.path.join(REF, "scala/common/src/test/assets")
+    hetero_sampler_configs(base)
     for rel in ASSETS:
         dst = os.path.join(OUT, "ref_assets", rel)
         os.makedirs(os.path.dirname(dst), exist_ok=True)

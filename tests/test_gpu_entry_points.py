@@ -436,3 +436,52 @@ def test_link_prediction_on_a_directed_graph_skips_anchors_without_in_edges(work
     for s in smp:
         for e in s.neighborhood.edges:
             assert (e.src_node_id, e.dst_node_id) in edges   # directed: edges as given, never reversed
+
+
+def test_subgraph_sampler_on_the_reference_heterogeneous_config(workdir):
+    """SubgraphSampler.run on the reference's heterogeneous fixture config (scala/common/src/test/assets/
+    subgraph_sampler/heterogeneous/node_anchor_based_link_prediction/frozen_gbml_config_graphdb_dblp_local.yaml, paths
+    re-rooted): the typed flow of GraphDBNodeAnchorBasedLinkPredictionTask — one RootedNodeNeighborhood per author and
+    per paper under the per-type random-negative prefixes, one NodeAnchorBasedLinkPredictionSample per paper with a
+    positive (supervision edge type paper -> author), every record valid against the typed graph"""
+    from gigl_amd.subgraph_sampler import SubgraphSampler, load_preprocessed_typed_graph
+    uri = "configs/hetero_nablp_frozen_gbml_config.yaml"
+    files = SubgraphSampler().run("job", uri, None, uri_base=workdir)
+    cfg = GbmlConfigPbWrapper.from_uri(uri, uri_base=workdir)
+    assert cfg.is_heterogeneous and cfg.supervision_edge_types == [("paper", "paper_to_author", "author")]
+    node_types, num, ids, feats, edges, cet, efeats = load_preprocessed_typed_graph(cfg)
+    assert num == {"author": 15, "paper": 19}
+    edge_sets = {c: set(zip(edges[et][0].tolist(), edges[et][1].tolist())) for et, c in cet.items()}
+    by_cnt = {c: t for t, c in node_types.items()}
+
+    def check_graph(g):
+        for x in g.nodes:
+            np.testing.assert_array_equal(x.feature_values, feats[by_cnt[x.condensed_node_type]][x.node_id])
+        have = {(x.node_id, x.condensed_node_type) for x in g.nodes}
+        for e in g.edges:
+            assert (e.src_node_id, e.dst_node_id) in edge_sets[e.condensed_edge_type] and e.feature_values.size == 2
+            s_t, _, d_t = cfg.condensed_edge_type_map[e.condensed_edge_type]
+            assert (e.src_node_id, node_types[s_t]) in have and (e.dst_node_id, node_types[d_t]) in have
+
+    prefixes = cfg.random_negative_tfrecord_uri_prefixes
+    for t in ("author", "paper"):
+        recs = [wire.RootedNodeNeighborhood.FromString(r) for f in tfrecord_files(prefixes[t])
+                for r in wire.read_tfrecords(f)]
+        assert sorted(m.root_node.node_id for m in recs) == ids[t].tolist() and files[f"random_negative/{t}"]
+        assert all(m.root_node.condensed_node_type == node_types[t] for m in recs)
+        for m in recs:
+            check_graph(m.neighborhood)
+            # two hops of 3 along the edge types that end in the frontier's type: at most 3 + 9 sampled edges
+            assert len(m.neighborhood.edges) <= 12
+    samples = [wire.NodeAnchorBasedLinkPredictionSample.FromString(r)
+               for f in tfrecord_files(cfg.nablp_tfrecord_uri_prefix) for r in wire.read_tfrecords(f)]
+    p2a = cet[[et for et in cet if et.relation == "paper_to_author"][0]]
+    with_pos = {int(s_) for s_ in set(edges[[et for et in cet if et.relation == "paper_to_author"][0]][0].tolist())}
+    assert sorted(m.root_node.node_id for m in samples) == sorted(with_pos)  # isolated roots are dropped
+    for m in samples:
+        assert m.root_node.condensed_node_type == node_types["paper"] and len(m.pos_edges) == 1  # numPositiveSamples: 1
+        e = m.pos_edges[0]
+        assert e.src_node_id == m.root_node.node_id and e.condensed_edge_type == p2a
+        assert (e.src_node_id, e.dst_node_id) in edge_sets[p2a] and e.feature_values.size == 2
+        check_graph(m.neighborhood)
+        assert (e.dst_node_id, node_types["author"]) in {(x.node_id, x.condensed_node_type) for x in m.neighborhood.nodes}
