@@ -41,6 +41,13 @@ ASSETS = [
     "split_generator/node_anchor_based_link_prediction/sgs_output/random_negative_rooted_neighborhood_samples/user/data.tfrecord",
     "split_generator/node_anchor_based_link_prediction/sgs_output/node_anchor_based_link_prediction_samples/data.tfrecord",
 ]
+# typed sampler outputs the reference holds as split-generator input (scala_spark35 assets; HeterogeneousNodeAnchorBased
+# LinkPredictionTaskTest.scala): the part files keep their directory, renamed data.tfrecord
+HETERO_SPLIT_ASSETS = [
+    "split_generator/hetero_node_anchor_based_link_prediction/sgs_output/node_anchor_based_link_prediction_samples/samples",
+    "split_generator/hetero_node_anchor_based_link_prediction/sgs_output/random_negative_rooted_neighborhood_samples/user/samples",
+    "split_generator/hetero_node_anchor_based_link_prediction/sgs_output/random_negative_rooted_neighborhood_samples/story/samples",
+]
 
 
 def raw_records(path):
@@ -87,10 +94,21 @@ def hetero_sampler_configs(base):
     open(os.path.join(OUT, "configs", "hetero_nablp_preprocessed_metadata.yaml"), "w").write(meta)
 
 
+def hetero_split_assets():
+    import glob
+    base35 = os.path.join(REF, "scala_spark35/common/src/test/assets")
+    for rel in HETERO_SPLIT_ASSETS:
+        (src,) = glob.glob(os.path.join(base35, rel, "*.tfrecord"))
+        dst = os.path.join(OUT, "ref_assets", rel, "data.tfrecord")
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        shutil.copyfile(src, dst)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     base = os.path.join(REF, "scala/common/src/test/assets")
     hetero_sampler_configs(base)
+    hetero_split_assets()
     for rel in ASSETS:
         dst = os.path.join(OUT, "ref_assets", rel)
         os.makedirs(os.path.dirname(dst), exist_ok=True)
