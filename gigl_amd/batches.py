@@ -252,6 +252,58 @@ class HeteroRootedNodeNeighborhoodBatch:
 
 
 @dataclass
+class HeteroNodeAnchorBasedLinkPredictionBatch:
+    """NodeAnchorBasedLinkPredictionBatch of a heterogeneous job (node_anchor_based_link_prediction_data_loader.py with a
+    HeteroData graph): typed training samples collated natively into one graph per node / edge type; the supervision
+    (positive / hard-negative) targets of every root as LOCAL ids of the supervision edge type's destination node type."""
+    graph: object                                   # models_hetero.HeteroGraphData
+    root_condensed_node_type: int
+    root_node_indices: torch.Tensor                 # int64 [B]: local ids inside the root node type
+    pos_targets: Dict[int, List[torch.Tensor]]      # condensed supervision edge type -> per root int64 local dst ids
+    hard_neg_targets: Dict[int, List[torch.Tensor]]
+    condensed_node_type_to_subgraph_id_to_global_node_id: Dict[int, np.ndarray]  # local id -> global id, per node type
+
+    @staticmethod
+    def process_raw_pyg_samples_and_collate_fn(batch: Sequence[bytes], condensed_node_type_to_name: Dict[int, str],
+                                               condensed_edge_type_to_triple: Dict[int, Tuple[str, str, str]]):
+        from ._lib import REC_NODE_ANCHOR_LINK_PRED
+        from .models_hetero import HeteroGraphData
+        name_to_cnt = {v: k for k, v in condensed_node_type_to_name.items()}
+        n_nt = max(condensed_node_type_to_name) + 1
+        n_et = max(condensed_edge_type_to_triple) + 1
+        ends = [(0, 0)] * n_et
+        for c, (s_, _, d_) in condensed_edge_type_to_triple.items():
+            ends[c] = (name_to_cnt[s_], name_to_cnt[d_])
+        out = collate_serialized_typed(batch, REC_NODE_ANCHOR_LINK_PRED, n_nt, ends)
+        x_dict = {condensed_node_type_to_name[t]: torch.from_numpy(out["x"][t]) for t in condensed_node_type_to_name
+                  if out["node_ids"][t].size}
+        ei, ea = {}, {}
+        for c, triple in condensed_edge_type_to_triple.items():
+            ei[tuple(triple)] = torch.from_numpy(out["edge_index"][c])
+            if out["edge_attr"][c] is not None:
+                ea[tuple(triple)] = torch.from_numpy(out["edge_attr"][c])
+        root_types = set(out["root_type"].tolist())
+        if len(root_types) > 1:
+            raise ValueError(f"training samples of one batch must share their root node type, found {sorted(root_types)}")
+        b = len(batch)
+
+        def per_root(off, dst, typ):
+            res: Dict[int, List[torch.Tensor]] = {}
+            for c in sorted(set(typ.tolist())):
+                res[c] = [torch.from_numpy(dst[off[i]:off[i + 1]][typ[off[i]:off[i + 1]] == c].astype(np.int64))
+                          for i in range(b)]
+            return res
+        return HeteroNodeAnchorBasedLinkPredictionBatch(
+            graph=HeteroGraphData(x_dict, ei, ea),
+            root_condensed_node_type=int(out["root_type"][0]) if b else 0,
+            root_node_indices=torch.from_numpy(out["root_local"].astype(np.int64)),
+            pos_targets=per_root(out["pos_off"], out["pos_dst"], out["pos_type"]),
+            hard_neg_targets=per_root(out["neg_off"], out["neg_dst"], out["neg_type"]),
+            condensed_node_type_to_subgraph_id_to_global_node_id={t: out["node_ids"][t].astype(np.int64)
+                                                                  for t in condensed_node_type_to_name})
+
+
+@dataclass
 class RootedNodeNeighborhoodBatch:
     graph: GraphData
     condensed_node_type_to_root_node_indices_map: Dict[int, torch.Tensor]

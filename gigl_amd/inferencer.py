@@ -47,6 +47,8 @@ class Inferencer:
         dev = torch.device("cuda", device)
         inferencer = generate_inferencer_instance(cfg)
         inferencer.model = inferencer.model.to(dev)
+        if cfg.is_heterogeneous:
+            return self._run_typed(cfg, inferencer, dev)
         if cfg.task_kind == "node_classification":
             files = tfrecord_files(cfg.unlabeled_tfrecord_uri_prefix)
         else:
@@ -102,6 +104,35 @@ class Inferencer:
                     fh.close()
         self.rows_written = n_rows
         return out_files
+
+
+def _typed_run(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str, str]:
+    """heterogeneous jobs: every node type named in nodeTypeToInferencerOutputInfoMap gets the embeddings of its own
+    RootedNodeNeighborhood samples (typed collate -> the encoder's rows of that type), one JSON line per root"""
+    from .batches import HeteroRootedNodeNeighborhoodBatch
+    info = (_get(cfg.doc, "sharedConfig.inferenceMetadata.nodeTypeToInferencerOutputInfoMap", {}) or {})
+    prefixes = cfg.random_negative_tfrecord_uri_prefixes
+    out_files: Dict[str, str] = {}
+    n_rows = 0
+    for node_type, v in info.items():
+        if not v.get("embeddingsPath") or node_type not in prefixes:
+            continue
+        path = resolve_uri(v["embeddingsPath"], cfg.uri_base)
+        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+        out_files[f"embeddings/{node_type}"] = path
+        with open(path, "w") as fh:
+            for raw in iterate_tfrecord_batches(tfrecord_files(prefixes[node_type]), cfg.inference_batch_size):
+                batch = HeteroRootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(
+                    raw, cfg.condensed_node_type_map, cfg.condensed_edge_type_map)
+                emb = inferencer.infer_batch(batch=batch, device=dev).embeddings.cpu()
+                for i, (_, gid) in enumerate(batch.root_nodes):
+                    fh.write(json.dumps({"node_id": int(gid), "node_type": node_type, "emb": emb[i].tolist()}) + "\n")
+                    n_rows += 1
+    self.rows_written = n_rows
+    return out_files
+
+
+Inferencer._run_typed = _typed_run
 
 
 def main(argv=None):

@@ -9,7 +9,8 @@ Same constructor arguments and parameter names (PyG's HeteroDictLinear / HeteroL
 `kqv_lin.lins.<type>.weight`, `k_rel.weight [H*T, D, D]`, `skip.<type>`, `p_rel.<src__rel__dst>`, ... — names come
 from the un-vendored PyG 2.5.3: "parity unpinned").  The dense parts are GEMMs on gigl_linear; the
 attention-weighted segmented reductions are gigl_hgt_aggregate / gigl_simplehgn_alpha / gigl_weighted_aggregate
-(csrc/hetero.hip).  Inference (forward) only: training these encoders through the plugins is not built.
+(csrc/hetero.hip) with their backward kernels: the encoders train through the link-prediction plugin
+(nablp_spec.HipNodeAnchorLinkPredictionSpec on a typed config; tests/test_gpu_hetero_pipeline.py).
 Input: HeteroGraphData — the typed counterpart of nn.GraphData (what PygGraphBuilder's HeteroData carries: x per node
 type, edge_index / edge_attr per (src type, relation, dst type)).
 """

@@ -11,10 +11,12 @@ Mirror of (paths relative to the reference root):
   EarlyStopper           python/gigl/src/common/modeling_task_specs/utils/early_stop.py:12-59
   KS_FOR_EVAL            python/gigl/src/training/v1/lib/eval_metrics.py
 What runs where: the encoder (GraphSAGE over the coalesced batch graph: gather-mean + fp32 MFMA GEMM, with
-autograd through gigl_gather_mean_backward) and the inner-product decoder (gigl_linear) are HIP kernels; the
-loss/metric algebra on the [queries x candidates] score matrix is the reference's own small torch code.
-Scope: homogeneous graphs (one condensed node type 0 and edge type 0), the Retrieval task, no candidate
-sampling correction (count-min sketch) — other tasks (Margin, Softmax, GRACE, ...) are out of scope.
+autograd through gigl_gather_mean_backward) and the inner-product decoder (gigl_linear) are HIP kernels, and so is the
+retrieval loss over the [queries x candidates] score matrix (gigl_retrieval_loss, with the count-min-sketch candidate
+sampling correction when enabled).
+Scope: homogeneous graphs (one condensed node type / edge type) and heterogeneous ones (typed batches through the
+native typed collate, HGT / SimpleHGN encoders, first supervision edge type: spec :245-271, infer.py on HeteroData); the
+Retrieval task — the other tasks (Margin, Softmax, GRACE, ...) are not built.
 Data: main samples are the NodeAnchorBasedLinkPredictionSample TFRecords and random negatives the
 RootedNodeNeighborhood TFRecords the sampler wrote, re-filed into train/val/test by the split generator
 (gigl_amd/split_generator.py; datasetMetadata.nodeAnchorBasedLinkPredictionDataset URIs).  Without split outputs
@@ -28,6 +30,7 @@ from dataclasses import dataclass, field
 from itertools import cycle
 from typing import Any, Dict, List, Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -95,6 +98,9 @@ def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrap
                       should_eval: bool, device: torch.device) -> NodeAnchorBasedLinkPredictionTaskInputs:
     """infer.py:103-456 for one condensed edge type: encode both batch graphs, then per root gather the
     positive / hard-negative rows, and build the [sum(num_pos) x (pos | hard_neg | random_neg)] score matrix"""
+    from .batches import HeteroNodeAnchorBasedLinkPredictionBatch
+    if isinstance(main_batch, HeteroNodeAnchorBasedLinkPredictionBatch):
+        return _infer_task_inputs_hetero(model, gbml_config_pb_wrapper, main_batch, random_neg_batch, should_eval, device)
     inner = model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
     decoder = inner.decode
     cet = 0
@@ -151,6 +157,61 @@ def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrap
         batch_embeddings=BatchEmbeddings(query_embeddings=query, repeated_query_embeddings={cet: rep_query},
                                          pos_embeddings={cet: pos_emb}, hard_neg_embeddings={cet: neg_emb},
                                          random_neg_embeddings={0: rn_root_emb}),
+        batch_scores=batch_scores, batch_combined_scores={cet: combined})
+
+
+def _infer_task_inputs_hetero(model: nn.Module, cfg: GbmlConfigPbWrapper, main_batch, random_neg_batch,
+                              should_eval: bool, device: torch.device) -> NodeAnchorBasedLinkPredictionTaskInputs:
+    """infer.py:103-456 on typed batches, first supervision edge type (src -> dst): the encoder returns one embedding
+    matrix per node type; queries are the roots' rows of the src type, positives / hard negatives rows of the dst type
+    (local ids from the typed collate), random negatives the roots of the dst type's RootedNodeNeighborhood batch"""
+    inner = model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
+    decoder = inner.decode
+    src_t, rel, dst_t = cfg.supervision_edge_types[0]
+    name_to_cnt = {v: k for k, v in cfg.condensed_node_type_map.items()}
+    cet = [c for c, triple in cfg.condensed_edge_type_map.items() if tuple(triple) == (src_t, rel, dst_t)][0]
+    main = model(main_batch.graph.to(device), [src_t, dst_t])
+    rn = model(random_neg_batch.graph.to(device), [dst_t])[dst_t]
+    root_idx = main_batch.root_node_indices.to(device)
+    query = main[src_t][root_idx]
+    dst_emb = main[dst_t]
+    d = query.shape[1]
+    empty = torch.zeros((0,), dtype=torch.float32, device=device)
+    rn_root_idx = random_neg_batch.condensed_node_type_to_root_node_indices_map.get(name_to_cnt[dst_t])
+    rn_root_emb = rn[rn_root_idx.to(device)] if rn_root_idx is not None and rn_root_idx.numel() else empty
+    rn_scores = decoder(query, rn_root_emb) if (should_eval and rn_root_emb.numel()) else empty
+    b = int(root_idx.numel())
+    none = [torch.zeros(0, dtype=torch.int64)] * b
+    pos_l, neg_l = main_batch.pos_targets.get(cet, none), main_batch.hard_neg_targets.get(cet, none)
+    batch_scores: List[Dict[int, BatchScores]] = []
+    if should_eval:
+        for i in range(b):
+            q1 = query[i:i + 1]
+            batch_scores.append({cet: BatchScores(
+                pos_scores=decoder(q1, dst_emb[pos_l[i].to(device)]) if pos_l[i].numel() else empty,
+                hard_neg_scores=decoder(q1, dst_emb[neg_l[i].to(device)]) if neg_l[i].numel() else empty,
+                random_neg_scores=rn_scores[[i], :] if rn_scores.numel() else empty)})
+    rep = torch.tensor([p.numel() for p in pos_l], dtype=torch.int64)
+    pos_ids = torch.cat(pos_l) if b else torch.zeros(0, dtype=torch.int64)
+    neg_ids = torch.cat(neg_l) if b else torch.zeros(0, dtype=torch.int64)
+    pos_emb = dst_emb[pos_ids.to(device)] if pos_ids.numel() else torch.zeros((0, d), device=device)
+    neg_emb = dst_emb[neg_ids.to(device)] if neg_ids.numel() else torch.zeros((0, d), device=device)
+    rep_query = query.repeat_interleave(rep.to(device), dim=0)
+    cand = torch.cat((pos_emb, neg_emb, rn_root_emb.reshape(-1, d)))
+    g_main = main_batch.condensed_node_type_to_subgraph_id_to_global_node_id
+    g_dst = torch.from_numpy(np.asarray(g_main[name_to_cnt[dst_t]], dtype=np.int64))
+    g_src = torch.from_numpy(np.asarray(g_main[name_to_cnt[src_t]], dtype=np.int64))
+    rn_globals = torch.tensor([g for t, g in random_neg_batch.root_nodes if t == name_to_cnt[dst_t]], dtype=torch.int64)
+    combined = BatchCombinedScores(
+        repeated_candidate_scores=decoder(rep_query, cand) if rep_query.numel() else empty,
+        positive_ids=g_dst[pos_ids].to(device), hard_neg_ids=g_dst[neg_ids].to(device), random_neg_ids=rn_globals.to(device),
+        repeated_query_ids=g_src[main_batch.root_node_indices].repeat_interleave(rep).to(device),
+        num_unique_query_ids=b)
+    return NodeAnchorBasedLinkPredictionTaskInputs(
+        main_batch=main_batch, random_neg_batch=random_neg_batch,
+        batch_embeddings=BatchEmbeddings(query_embeddings=query, repeated_query_embeddings={cet: rep_query},
+                                         pos_embeddings={cet: pos_emb}, hard_neg_embeddings={cet: neg_emb},
+                                         random_neg_embeddings={name_to_cnt[dst_t]: rn_root_emb}),
         batch_scores=batch_scores, batch_combined_scores={cet: combined})
 
 
@@ -326,6 +387,8 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
 
     def init_model(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, state_dict=None) -> nn.Module:
         self._cfg = gbml_config_pb_wrapper
+        if gbml_config_pb_wrapper.is_heterogeneous:
+            return self._init_hetero_model(gbml_config_pb_wrapper, state_dict)
         in_dim = gbml_config_pb_wrapper.preprocessed_metadata.nodes[0].feature_dim
         import inspect
         accepted = inspect.signature(self.gnn_model.__init__).parameters
@@ -334,6 +397,27 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         encoder = self.gnn_model(
             in_dim=max(in_dim, 1), hid_dim=self.hidden_dim, out_dim=self.out_channels, num_layers=self.num_layers,
             should_l2_normalize_embedding_layer_output=self.should_l2_normalize_embedding_layer_output, **extra)
+        model = LinkPredictionGNN(encoder=encoder, decoder=LinkPredictionDecoder())
+        if state_dict is not None:
+            model.load_state_dict(state_dict)
+        self.model = model
+        return model
+
+    def _init_hetero_model(self, cfg: GbmlConfigPbWrapper, state_dict=None) -> nn.Module:
+        """the heterogeneous branch of init_model (node_anchor_based_link_prediction_modeling_task_spec.py:245-271): the
+        encoder class (gnn_model_class_path; default HGT) takes the per-type feature dims, hid / out dims, num_layers,
+        num_heads"""
+        pm = cfg.preprocessed_metadata
+        node_dims = {name: max(pm.nodes[c].feature_dim, 1) for c, name in cfg.condensed_node_type_map.items()}
+        edge_dims = {tuple(t): pm.edges[c].feature_dim for c, t in cfg.condensed_edge_type_map.items()}
+        gnn = self.gnn_model
+        if gnn is GraphSAGE:  # (the homogeneous default was not overridden)
+            from .models_hetero import HGT
+            gnn = HGT
+        encoder = gnn(node_type_to_feat_dim_map=node_dims, edge_type_to_feat_dim_map=edge_dims, hid_dim=self.hidden_dim,
+                      out_dim=self.out_channels, num_layers=self.num_layers,
+                      num_heads=int(self._encoder_kwargs.get("heads", 2)),
+                      should_l2_normalize_embedding_layer_output=self.should_l2_normalize_embedding_layer_output)
         model = LinkPredictionGNN(encoder=encoder, decoder=LinkPredictionDecoder())
         if state_dict is not None:
             model.load_state_dict(state_dict)
@@ -360,6 +444,20 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
     def _main_batches(self, cfg: GbmlConfigPbWrapper, split: str, loop: bool):
         rank, world = _rank_world()
         uri = cfg.dataset_split_uri(split)
+        if cfg.is_heterogeneous:
+            from .batches import HeteroNodeAnchorBasedLinkPredictionBatch
+            files = tfrecord_files(uri) if uri and tfrecord_files(uri) else tfrecord_files(cfg.nablp_tfrecord_uri_prefix)
+            raw = [b for chunk in iterate_tfrecord_batches(files, 10 ** 9, rank=rank, world_size=world) for b in chunk]
+            if not (uri and tfrecord_files(uri)) and len(raw) >= 100:  # no split-generator output: a root-id split
+                want = {"train": range(0, 8), "val": (8,), "test": (9,)}[split]
+                raw = [r for r in raw
+                       if wire.NodeAnchorBasedLinkPredictionSample.FromString(r).root_node.node_id % 10 in want]
+            bs = self.main_sample_batch_size
+            chunks = [raw[i:i + bs] for i in range(0, len(raw), bs)]
+            for chunk in (cycle(chunks) if (loop and chunks) else chunks):
+                yield HeteroNodeAnchorBasedLinkPredictionBatch.process_raw_pyg_samples_and_collate_fn(
+                    chunk, cfg.condensed_node_type_map, cfg.condensed_edge_type_map)
+            return
         if uri and tfrecord_files(uri):
             raw = [b for chunk in iterate_tfrecord_batches(tfrecord_files(uri), 10 ** 9, rank=rank, world_size=world)
                    for b in chunk]
@@ -382,6 +480,16 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         """always looped, like the reference's LoopyIterableDataset for random negatives"""
         rank, world = _rank_world()
         split_uris = cfg.random_negative_split_uris(split)
+        if cfg.is_heterogeneous:  # random negatives of the supervision edge type's destination node type
+            from .batches import HeteroRootedNodeNeighborhoodBatch
+            dst_t = cfg.supervision_edge_types[0][2]
+            prefix = split_uris.get(dst_t)
+            if not (prefix and tfrecord_files(prefix)):
+                prefix = cfg.random_negative_tfrecord_uri_prefixes[dst_t]
+            for raw in iterate_tfrecord_batches(tfrecord_files(prefix), batch_size, rank=rank, world_size=world, loop=True):
+                yield HeteroRootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(
+                    raw, cfg.condensed_node_type_map, cfg.condensed_edge_type_map)
+            return
         prefix = next(iter(split_uris.values()), None)
         if not (prefix and tfrecord_files(prefix)):
             prefix = next(iter(cfg.random_negative_tfrecord_uri_prefixes.values()))
@@ -481,5 +589,9 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         assert len(keys) == 1, ("RootedNodeNeighborhoodBatch for inference must have only one root node type. "
                                 f"Found root node types: {keys}")
         idx = batch.condensed_node_type_to_root_node_indices_map[keys[0]].to(device)
+        if self._cfg is not None and self._cfg.is_heterogeneous:  # (spec :632-660: the batch's one root node type)
+            node_type = self._cfg.condensed_node_type_map[keys[0]]
+            out = self.model(batch.graph.to(device), [node_type])[node_type]
+            return InferBatchResults(embeddings=out[idx], predictions=None)
         out = self.model(batch.graph.to(device))
         return InferBatchResults(embeddings=out[idx], predictions=None)

@@ -1,0 +1,100 @@
+"""Heterogeneous job end to end on the reference's typed fixture graph (authors / papers, supervision edge type
+paper -> author): SubgraphSampler (typed records on the device) -> Trainer with the link-prediction plugin and an HGT
+encoder (typed native collate, HIP forward + backward) -> Inferencer (embeddings per node type)."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from gigl_amd.config import GbmlConfigPbWrapper
+
+pytestmark = pytest.mark.gpu
+
+CFG = "configs/hetero_train_gbml_config.yaml"
+
+
+@pytest.fixture(scope="module")
+def workdir(golden_dir, tmp_path_factory):
+    base = tmp_path_factory.mktemp("gigl_hetero")
+    shutil.copytree(os.path.join(golden_dir, "configs"), base / "configs")
+    shutil.copytree(os.path.join(golden_dir, "ref_assets"), base / "ref_assets")
+    doc = yaml.safe_load(open(base / "configs" / "hetero_nablp_frozen_gbml_config.yaml"))
+    doc["datasetConfig"]["subgraphSamplerConfig"]["numPositiveSamples"] = 2
+    spec = "gigl_amd.nablp_spec.HipNodeAnchorLinkPredictionSpec"
+    args = {"hidden_dim": "16", "out_channels": "8", "num_heads": "2", "main_sample_batch_size": "6",
+            "random_negative_sample_batch_size": "5", "random_negative_sample_batch_size_for_evaluation": "5",
+            "val_every_num_batches": "2", "num_val_batches": "2", "num_test_batches": "2", "early_stop_patience": "50",
+            "optim_lr": "0.02", "gnn_model_class_path": "gigl_amd.models_hetero.HGT"}
+    doc["trainerConfig"] = {"trainerClsPath": spec, "trainerArgs": dict(args)}
+    doc["inferencerConfig"] = {"inferencerClsPath": spec, "inferencerArgs": dict(args), "inferenceBatchSize": 8}
+    doc["sharedConfig"]["trainedModelMetadata"] = {"trainedModelUri": "out/hetero_train/model.pt",
+                                                   "evalMetricsUri": "out/hetero_train/eval_metrics.json"}
+    doc["sharedConfig"]["inferenceMetadata"] = {"nodeTypeToInferencerOutputInfoMap": {
+        "author": {"embeddingsPath": "out/hetero_train/emb_author.jsonl"},
+        "paper": {"embeddingsPath": "out/hetero_train/emb_paper.jsonl"}}}
+    yaml.safe_dump(doc, open(base / CFG, "w"))
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    SubgraphSampler().run("job", CFG, None, uri_base=str(base))
+    return str(base)
+
+
+def test_typed_training_step_matches_a_cpu_restatement(workdir):
+    """one training step: HGT over the typed main / random-negative batch graphs (its numerics are pinned in
+    test_gpu_hetero.py), inner-product scores of the paper roots against [positives | random negative authors], and the
+    fused retrieval loss == the row-wise CPU restatement over those scores with the batch's global ids as masks;
+    parameters receive finite gradients; queries / positives are real (paper, author) edges of the graph"""
+    from gigl_amd.nablp_spec import HipNodeAnchorLinkPredictionSpec, infer_task_inputs
+    from oracle import gnn_ref
+    cfg = GbmlConfigPbWrapper.from_uri(CFG, uri_base=workdir)
+    spec = HipNodeAnchorLinkPredictionSpec(**cfg.trainer_args)
+    torch.manual_seed(3)
+    spec.init_model(cfg)
+    dev = torch.device("cuda", 0)
+    spec.model = spec.model.to(dev)
+    spec._ensure_engine(dev)
+    spec.model.train()
+    main_batch = next(spec._main_batches(cfg, "train", loop=False))
+    rn_batch = next(spec._random_negative_batches(cfg, 5))
+    assert main_batch.root_condensed_node_type == 1 and main_batch.root_node_indices.numel() == 6
+    cet = 1  # paper -> author
+    assert all(1 <= p.numel() <= 2 for p in main_batch.pos_targets[cet])
+    ti = infer_task_inputs(spec.model, cfg, main_batch, rn_batch, should_eval=False, device=dev)
+    loss, _ = spec.tasks.calculate_losses(ti, cfg, should_eval=False, device=dev)
+    loss.backward()
+    grads = [p.grad for p in spec.model.parameters() if p.requires_grad]
+    assert all(g is None or torch.isfinite(g).all() for g in grads) and sum(g is not None and g.abs().sum() > 0 for g in grads) > 10
+    bcs = ti.batch_combined_scores[cet]
+    scores = bcs.repeated_candidate_scores.detach().cpu()
+    n_rep = int(sum(p.numel() for p in main_batch.pos_targets[cet]))
+    assert tuple(scores.shape) == (n_rep, n_rep + 5)
+    cand_ids = torch.cat((bcs.positive_ids, bcs.hard_neg_ids, bcs.random_neg_ids)).cpu().tolist()
+    want = gnn_ref.retrieval_loss_rows(scores, bcs.repeated_query_ids.cpu().tolist(), cand_ids, temperature=0.07) / n_rep
+    assert abs(float(loss) - float(want)) <= 1e-4 * abs(float(want))
+    # the ids are GLOBAL ids of their node types: positives are authors the paper really links to
+    from gigl_amd.subgraph_sampler import load_preprocessed_typed_graph
+    _, _, _, _, edges, cet_map, _ = load_preprocessed_typed_graph(cfg)
+    p2a = [et for et in cet_map if et.relation == "paper_to_author"][0]
+    real = set(zip(edges[p2a][0].tolist(), edges[p2a][1].tolist()))
+    assert all((q, p) in real for q, p in zip(bcs.repeated_query_ids.cpu().tolist(), bcs.positive_ids.cpu().tolist()))
+
+
+def test_trainer_then_inferencer_on_the_typed_graph(workdir):
+    from gigl_amd.inferencer import Inferencer
+    from gigl_amd.trainer import Trainer
+    tr = Trainer()
+    metrics = tr.run("job", CFG, None, uri_base=workdir)
+    assert np.isfinite(metrics.metrics["loss"].value) and 0.0 < metrics.metrics["mrr"].value <= 1.0
+    hist = [h["loss"] for h in tr.training_process.trainer.history]
+    assert len(hist) >= 2 and all(np.isfinite(hist)) and min(hist[1:]) < hist[0]
+    cfg = GbmlConfigPbWrapper.from_uri(CFG, uri_base=workdir)
+    sd = torch.load(cfg.trained_model_uri, map_location="cpu")
+    assert any(k.startswith("_encoder.convs.0.kqv_lin") for k in sd) and "_encoder.lin_dict.author.weight" in sd
+    out = Inferencer().run("job", CFG, None, uri_base=workdir)
+    for t, n in (("author", 15), ("paper", 19)):
+        rows = [json.loads(l) for l in open(out[f"embeddings/{t}"])]
+        assert sorted(r["node_id"] for r in rows) == list(range(n)) and all(r["node_type"] == t for r in rows)
+        assert all(len(r["emb"]) == 8 and np.isfinite(r["emb"]).all() for r in rows)
