@@ -246,10 +246,17 @@ class HipGraphDBSampler:
 
     def encode_records(self, root_ids: Sequence[int], root_node_type: str, dag: SamplingOpDAG,
                        tfrecord_frame: bool = True) -> List[bytes]:
-        """the same RootedNodeNeighborhood messages as getKHopSubgraphForRootNodes, serialized ON THE DEVICE
+        """the same RootedNodeNeighborhood messages as getKHopSubgraphForRootNodes, serialized ON THE DEVICE — one
+        bytes object per root (the host only slices the finished byte string)"""
+        out, off = self.encode_records_device(root_ids, root_node_type, dag, tfrecord_frame)
+        blob, off = out.cpu().numpy().tobytes(), off.cpu().numpy()
+        return [blob[int(off[i]):int(off[i + 1])] for i in range(len(root_ids))]
+
+    def encode_records_device(self, root_ids: Sequence[int], root_node_type: str, dag: SamplingOpDAG,
+                              tfrecord_frame: bool = True):
+        """-> (uint8 device tensor: the records back to back, int64 device tensor rec_off[b + 1])
         (gigl_typed_records_encode: per root the distinct typed nodes and edges of every op, sorted, with the nodes'
-        feature rows, the edges' feature rows joined by binary search in their type's edge list) — the host only
-        slices the finished byte string."""
+        feature rows, the edges' feature rows joined by binary search in their type's edge list)"""
         roots = torch.tensor(np.asarray(root_ids, dtype=np.int64).astype(np.uint32).view(np.int32))
         res = self.run_dag(roots, dag)
         n_types = max(self.node_types.values()) + 1
@@ -265,10 +272,8 @@ class HipGraphDBSampler:
         by_c = {c: et for et, c in self.condensed_edge_types.items()}
         edge_feats = [self._key(by_c[c], OUTGOING) if c in by_c and self._has_edge_feats.get(by_c[c]) else None
                       for c in range(n_et)]
-        out, off = self.engine.encode_typed_records(roots.to(self.engine.device), self.node_types[root_node_type], ops,
-                                                    feats, tfrecord_frame=tfrecord_frame, edge_feats=edge_feats)
-        blob, off = out.cpu().numpy().tobytes(), off.cpu().numpy()
-        return [blob[int(off[i]):int(off[i + 1])] for i in range(len(root_ids))]
+        return self.engine.encode_typed_records(roots.to(self.engine.device), self.node_types[root_node_type], ops,
+                                                feats, tfrecord_frame=tfrecord_frame, edge_feats=edge_feats)
 
     # ---- typed training samples (GraphDBNodeAnchorBasedLinkPredictionTask.scala:80-116, 333-470;
     #      GraphDBSampler.samplePositiveEdgeNeighborhoods :175-218) ------------------------------------------------
@@ -340,8 +345,17 @@ class HipGraphDBSampler:
 
     def encode_nablp_records(self, root_ids: Sequence[int], positive_edge_type: EdgeType, num_positives: int,
                              root_dag: SamplingOpDAG, positive_dag: SamplingOpDAG, tfrecord_frame: bool = True):
-        """the messages of getNablpSamplesForRootNodes serialized ON THE DEVICE (gigl_typed_samples_encode, kind
-        NODE_ANCHOR_LINK_PRED) -> (list of record bytes, number of positives per root)"""
+        """the messages of getNablpSamplesForRootNodes serialized ON THE DEVICE -> (list of record bytes, number of
+        positives per root)"""
+        out, off, n_pos = self.encode_nablp_records_device(root_ids, positive_edge_type, num_positives, root_dag,
+                                                           positive_dag, tfrecord_frame)
+        blob, off = out.cpu().numpy().tobytes(), off.cpu().numpy()
+        return [blob[int(off[i]):int(off[i + 1])] for i in range(len(root_ids))], n_pos.cpu().numpy()
+
+    def encode_nablp_records_device(self, root_ids: Sequence[int], positive_edge_type: EdgeType, num_positives: int,
+                                    root_dag: SamplingOpDAG, positive_dag: SamplingOpDAG, tfrecord_frame: bool = True):
+        """gigl_typed_samples_encode, kind NODE_ANCHOR_LINK_PRED -> (uint8 device records, int64 device rec_off[b + 1],
+        int64 device positives per root)"""
         from ._lib import REC_NODE_ANCHOR_LINK_PRED
         root_type = positive_edge_type.src_node_type
         roots, res, pos, pos_res = self._run_nablp(root_ids, positive_edge_type, num_positives, root_dag, positive_dag)
@@ -369,9 +383,8 @@ class HipGraphDBSampler:
         out, off = self.engine.encode_typed_records(roots, self.node_types[root_type], ops, feats,
                                                     tfrecord_frame=tfrecord_frame, edge_feats=edge_feats,
                                                     kind=REC_NODE_ANCHOR_LINK_PRED)
-        blob, off = out.cpu().numpy().tobytes(), off.cpu().numpy()
-        n_pos = (pos.nbr.view(b, P) != -1).sum(dim=1).cpu().numpy()
-        return [blob[int(off[i]):int(off[i + 1])] for i in range(b)], n_pos
+        n_pos = (pos.nbr.view(b, P) != -1).sum(dim=1)
+        return out, off, n_pos
 
     def write_tfrecords(self, path: str, root_ids: Sequence[int], root_node_type: str, dag: SamplingOpDAG) -> int:
         """a part file of the sampler job: the device-encoded frames of encode_records written back to back"""

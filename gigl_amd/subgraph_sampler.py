@@ -137,9 +137,17 @@ class _PartWriter:
         self.files.append(name)
         self.in_part = 0
 
-    def add(self, buf: np.ndarray, rec_off: np.ndarray) -> None:
-        """buf: uint8 frames back to back; rec_off[i]..rec_off[i+1] = record i (empty = skipped)"""
+    def add(self, buf: np.ndarray, rec_off: np.ndarray, keep: Optional[np.ndarray] = None) -> None:
+        """buf: uint8 frames back to back; rec_off[i]..rec_off[i+1] = record i (empty = skipped); keep: optional mask of
+        the records to write"""
         sizes = np.diff(rec_off)
+        if keep is not None and not bool(np.all(keep)):  # runs of consecutive kept records, each a contiguous range
+            k = np.asarray(keep, dtype=bool) & (sizes > 0)
+            edges = np.flatnonzero(np.diff(np.concatenate(([0], k.view(np.int8), [0]))))
+            for lo, hi in zip(edges[0::2], edges[1::2]):
+                sub = rec_off[lo:hi + 1]
+                self.add(buf, sub)
+            return
         idx = np.flatnonzero(sizes > 0)
         k = 0
         while k < idx.size:
@@ -241,8 +249,8 @@ class SubgraphSampler:
                     raise ValueError(f"nodeTypeToRandomNegativeTfrecordUriPrefix is missing node type {t!r}")
                 w = _PartWriter(_res(cfg, rn_prefixes[t]))
                 for i in range(0, ids[t].size, batch_size):
-                    for fr in s.encode_records(ids[t][i:i + batch_size], t, dags[t], tfrecord_frame=True):
-                        w.add_frame(fr)
+                    buf, off = s.encode_records_device(ids[t][i:i + batch_size], t, dags[t], tfrecord_frame=True)
+                    w.add(_frames_to_host(buf), off.cpu().numpy())
                 out[f"random_negative/{t}"] = w.close()
             roots = ids[pos_et.src_node_type]
             cap = cfg.num_max_training_samples_to_output
@@ -251,11 +259,9 @@ class SubgraphSampler:
             w = _PartWriter(_res(cfg, cfg.nablp_tfrecord_uri_prefix))
             keep_isolated = cfg.should_include_isolated_nodes_in_training
             for i in range(0, roots.size, batch_size):
-                frames, n_pos = s.encode_nablp_records(roots[i:i + batch_size], pos_et, cfg.num_positive_samples,
-                                                       dags[pos_et.src_node_type], dags[pos_et.dst_node_type])
-                for fr, k in zip(frames, n_pos):
-                    if k > 0 or keep_isolated:
-                        w.add_frame(fr)
+                buf, off, n_pos = s.encode_nablp_records_device(roots[i:i + batch_size], pos_et, cfg.num_positive_samples,
+                                                                dags[pos_et.src_node_type], dags[pos_et.dst_node_type])
+                w.add(_frames_to_host(buf), off.cpu().numpy(), None if keep_isolated else (n_pos > 0).cpu().numpy())
             out["node_anchor_based_link_prediction"] = w.close()
         finally:
             s.close()
