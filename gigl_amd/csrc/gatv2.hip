@@ -265,3 +265,105 @@ int32_t gigl_gatv2_aggregate_backward(gigl_ctx* ctx, const float* xl, const floa
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
+
+// ---- GINEConv aggregation (PyG 2.5.3 GINEConv as configured by GINE.init_conv_layers, homogeneous.py:252-297):
+//   out_i = (1 + eps) x_i + sum_{e = (j -> i)} relu(x_j + ee_e),   ee = lin(edge_attr) rows in the CSR's edge order
+// (the MLP that follows is gigl_linear).  One wave per destination row, lanes over the d channels.
+// Backward: with m_e = [x_j + ee_e > 0]:  dee_e = g_i * m_e (row-owned),  dx_j += g_i * m_e (atomics),
+// dx_i += (1 + eps) g_i (atomics: i is also a source of other rows),  deps += <g_i, x_i> (one atomic per row).
+namespace {
+
+__global__ __launch_bounds__(256) void gine_forward_kernel(const float* __restrict__ x, const float* __restrict__ ee,
+                                                           const float* __restrict__ eps, int d,
+                                                           const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ rowend,
+                                                           const int32_t* __restrict__ col,
+                                                           const int32_t* __restrict__ n_rows_dev,
+                                                           float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n_rows = *n_rows_dev;
+  const float self_w = 1.0f + *eps;
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    for (int el = lane; el < d; el += 64) {
+      float acc = self_w * x[(int64_t)i * d + el];
+      for (int e = 0; e < m; ++e) {
+        const float v = x[(int64_t)col[e0 + e] * d + el] + ee[(int64_t)(e0 + e) * d + el];
+        acc += v > 0.f ? v : 0.f;
+      }
+      out[(int64_t)i * d + el] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void gine_backward_kernel(const float* __restrict__ x, const float* __restrict__ ee,
+                                                            const float* __restrict__ eps, int d,
+                                                            const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ rowend,
+                                                            const int32_t* __restrict__ col,
+                                                            const int32_t* __restrict__ n_rows_dev,
+                                                            const float* __restrict__ dout, float* __restrict__ dx,
+                                                            float* __restrict__ dee, float* __restrict__ deps) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n_rows = *n_rows_dev;
+  const float self_w = 1.0f + *eps;
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    float gx = 0.f;
+    for (int el = lane; el < d; el += 64) {
+      const float g = dout[(int64_t)i * d + el];
+      gx += g * x[(int64_t)i * d + el];
+      atomicAdd(&dx[(int64_t)i * d + el], self_w * g);
+      for (int e = 0; e < m; ++e) {
+        const int j = col[e0 + e];
+        const float v = x[(int64_t)j * d + el] + ee[(int64_t)(e0 + e) * d + el];
+        const float ge = v > 0.f ? g : 0.f;
+        dee[(int64_t)(e0 + e) * d + el] = ge;
+        if (ge != 0.f) atomicAdd(&dx[(int64_t)j * d + el], ge);
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) gx += __shfl_xor(gx, off, 64);
+    if (lane == 0) atomicAdd(deps, gx);
+  }
+}
+
+}  // namespace
+
+int32_t gigl_gine_aggregate(gigl_ctx* ctx, const float* x, const float* edge_rows, const float* eps, int32_t d,
+                            const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                            const int32_t* n_rows_dev, int64_t rows_cap, float* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, x && edge_rows && eps && rowptr && rowend && col && n_rows_dev && out && d > 0 && rows_cap >= 0,
+               "bad arguments");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(gine_forward_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x, edge_rows, eps, d, rowptr,
+                     rowend, col, n_rows_dev, out);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_gine_aggregate_backward(gigl_ctx* ctx, const float* x, const float* edge_rows, const float* eps, int32_t d,
+                                     const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                     const int32_t* n_rows_dev, int64_t rows_cap, const float* dout, float* dx,
+                                     float* dedge_rows, float* deps) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, x && edge_rows && eps && rowptr && rowend && col && n_rows_dev && dout && dx && dedge_rows && deps &&
+                        d > 0 && rows_cap >= 0, "bad arguments");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(gine_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, x, edge_rows, eps, d,
+                     rowptr, rowend, col, n_rows_dev, dout, dx, dedge_rows, deps);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}

@@ -766,6 +766,27 @@ class HipEngine:
             C.c_void_p(out.data_ptr())), self._ctx)
         return out
 
+    def gine_aggregate(self, x: torch.Tensor, edge_rows: torch.Tensor, eps: torch.Tensor, u, n_rows_dev: torch.Tensor
+                       ) -> torch.Tensor:
+        """(1 + eps) x_i + sum_e relu(x_j + edge_rows_e) over the CSR view `u` (gigl_gine_aggregate): [rows, d]"""
+        rows, d = int(x.shape[0]), int(x.shape[1])
+        assert x.is_cuda and x.is_contiguous() and edge_rows.is_contiguous() and edge_rows.shape[1] == d
+        out = torch.zeros((rows, d), dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(self._lib.gigl_gine_aggregate(self._ctx, p(x), p(edge_rows), p(eps), d, p(u.rowptr), p(u.rowend), p(u.col),
+                                            p(n_rows_dev), rows, p(out)), self._ctx)
+        return out
+
+    def gine_aggregate_backward(self, x, edge_rows, eps, u, n_rows_dev, dout):
+        """-> (dx, dedge_rows, deps): gigl_gine_aggregate_backward"""
+        dout = dout.contiguous()
+        dx, dee, deps = torch.zeros_like(x), torch.zeros_like(edge_rows), torch.zeros(1, dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(self._lib.gigl_gine_aggregate_backward(self._ctx, p(x), p(edge_rows), p(eps), int(x.shape[1]), p(u.rowptr),
+                                                     p(u.rowend), p(u.col), p(n_rows_dev), int(x.shape[0]), p(dout), p(dx),
+                                                     p(dee), p(deps)), self._ctx)
+        return dx, dee, deps
+
     def gatv2_aggregate(self, xl: torch.Tensor, xr: torch.Tensor, att: torch.Tensor, heads: int, channels: int, u,
                         n_rows_dev: torch.Tensor, bias: Optional[torch.Tensor], negative_slope: float = 0.2,
                         act: int = 0) -> torch.Tensor:

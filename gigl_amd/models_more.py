@@ -12,7 +12,8 @@ No new kernels: a GIN layer is the segmented SUM + projection of a SAGE layer wi
 (gigl_gather_reduce + gigl_linear, autograd through nn.sage_conv) followed by one more gigl_linear; a Transformer
 layer is three projections + the dot-product attention reduce of HGTConv with one edge type (gigl_hgt_aggregate and
 its backward).  GATv2 (homogeneous.py:346-386) has its own kernels (csrc/gatv2.hip: the logit is a C-wide pass per edge).
-Not built: edge features for TransformerConv / GATv2Conv, GINEConv.
+GINE (homogeneous.py:252-297) adds gigl_gine_aggregate (messages relu(x_j + lin(e_ji))).
+Not built: edge features for TransformerConv / GATv2Conv.
 
   DCNv2 / DCNCross  python/gigl/src/common/models/layers/feature_interaction.py:7-155 — the feature-interaction layer
 BasicHomogeneousGNN applies to the node features before the first conv (`feature_interaction_layer=`): x_{i+1} =
@@ -160,6 +161,100 @@ class GIN(GraphSAGE):
 
     def make_plan(self, *args, **kwargs):
         raise NotImplementedError("the one-call plan computes GraphSAGE layers only; use forward(HipBatch)")
+
+
+class _GineAggFn(torch.autograd.Function):
+    """gigl_gine_aggregate / gigl_gine_aggregate_backward over a CSR view: (1 + eps) x_i + sum_e relu(x_j + ee_e)"""
+
+    @staticmethod
+    def forward(ctx, x, ee, eps, eng, view, n_dev):
+        x, ee, eps = x.contiguous(), ee.contiguous(), eps.to(torch.float32).contiguous()
+        ctx.save_for_backward(x, ee, eps)
+        ctx.meta = (eng, view, n_dev)
+        return eng.gine_aggregate(x, ee, eps, view, n_dev)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, ee, eps = ctx.saved_tensors
+        eng, view, n_dev = ctx.meta
+        dx, dee, deps = eng.gine_aggregate_backward(x, ee, eps, view, n_dev, dout)
+        return dx, dee, (deps if ctx.needs_input_grad[2] else None), None, None, None
+
+
+class GINEConv(GINConv):
+    """out_i = nn((1 + eps) x_i + sum_{j->i} relu(x_j + lin(e_ji))); lin = Linear(edge_dim, in_channels) (PyG's name)"""
+
+    def __init__(self, in_channels: int, out_channels: int, edge_dim: int, **kwargs):
+        super().__init__(in_channels, out_channels, **kwargs)
+        self.lin = nn.Linear(edge_dim, in_channels)
+
+
+class GINE(GIN):
+    """GIN with edge features in the messages (edge_dim required); conv_kwargs: eps, train_eps"""
+
+    def __init__(self, in_dim: int, hid_dim: int, out_dim: int, num_layers: int = 2, edge_dim: Optional[int] = None,
+                 **kwargs):
+        if not edge_dim:
+            raise ValueError("GINE needs edge_dim (the edge features' width)")
+        super().__init__(in_dim, hid_dim, out_dim, num_layers=num_layers, **kwargs)
+        self.edge_dim = int(edge_dim)
+        old = list(self.conv_layers)
+        self.conv_layers = nn.ModuleList([
+            GINEConv(c.in_channels, c.out_channels, self.edge_dim, eps=float(c.eps.detach()), train_eps=isinstance(c.eps, nn.Parameter),
+                     batchnorm=c.nn.has_norm, act_first=c.nn.act_first) for c in old])
+
+    def _conv_rows(self, conv: GINEConv, h: torch.Tensor, edge_attr: torch.Tensor, eng: HipEngine, view, n_dev):
+        ee = _linear(eng, edge_attr, conv.lin.weight, conv.lin.bias)
+        agg = _GineAggFn.apply(h, ee, conv.eps, eng, view, n_dev)
+        z = _linear(eng, agg, conv.nn.lins[0].weight, conv.nn.lins[0].bias)
+        return conv.nn.tail(eng, z, False)
+
+    def forward(self, batch, engine: Optional[HipEngine] = None) -> torch.Tensor:
+        """GraphData (with edge_attr) -> every layer over the whole batch graph, autograd when grad mode is on
+        HipBatch  -> the trimmed schedule over the union graph, edge rows from the resident edge-feature table"""
+        from .models_attn import _CsrView
+        from .nn import GraphData
+        if isinstance(batch, GraphData):
+            eng = engine or getattr(self, "engine", None)
+            if eng is None:
+                raise RuntimeError("GINE.forward(GraphData) needs the HipEngine (model.engine = eng)")
+            if batch.edge_attr_csr is None:
+                raise ValueError(f"the model was built with edge_dim={self.edge_dim} but the batch has no edge features")
+            view, ea = _CsrView(batch), batch.edge_attr_csr
+            if ea.shape[0] != view.col.numel():  # edgeless batch: col holds one padding entry
+                ea = torch.zeros((view.col.numel(), self.edge_dim), dtype=torch.float32, device=batch.x.device)
+            h, xs = self._interact(batch.x, eng), []
+            for l, conv in enumerate(self.conv_layers):
+                h = self._post(self._conv_rows(conv, h, ea, eng, view, batch.n_dev), l, False)
+                xs.append(h)
+            if self.jk_layer is not None:
+                h = self.jk_layer(xs)
+            return self._head(h)
+        with torch.no_grad():
+            eng, u = batch.engine, batch.union
+            L = self.num_layers
+            assert u.hops == L, "one hop per layer"
+            cap = int(u.nodes.numel())
+            ea = batch.edge_attr if batch.edge_attr is not None else eng.union_edge_attr(u)
+            assert ea.shape[1] == self.edge_dim
+            batch = self._interacted(batch)
+            if batch.x is None:
+                h = eng.gather_rows(u.nodes, u.meta[0:1], cap)
+            else:
+                h = batch.x if batch.x_index is None else batch.x[batch.x_index.long()].contiguous()
+            valid = (torch.arange(cap, device=h.device) < u.meta[0:1].to(torch.int64))[:, None]
+            h = torch.where(valid, h, torch.zeros_like(h))
+            xs = []
+            for l, conv in enumerate(self.conv_layers):
+                n_dst = u.meta[GIGL_META_LEVEL0 + (L - 1 - l): GIGL_META_LEVEL0 + (L - l)]
+                h = self._post(self._conv_rows(conv, h.contiguous(), ea, eng, u, n_dst), l, False).contiguous()
+                xs.append(h)
+            if self.jk_layer is not None:
+                n_roots = int(u.meta[GIGL_META_LEVEL0].item())
+                out = torch.zeros((cap, self.jk_layer.output_linear.out_features), dtype=torch.float32, device=h.device)
+                out[:n_roots] = self.jk_layer([x[:n_roots] for x in xs])
+                h = out
+            return self._head(h)
 
 
 class TransformerConv(nn.Module):

@@ -608,6 +608,19 @@ int32_t gigl_gatv2_aggregate_backward(gigl_ctx* ctx, const float* xl, const floa
                                       int64_t rows_cap, const float* out_pre, const float* dout, float* dxl,
                                       float* dxr, float* datt);
 
+/* GINEConv aggregation (PyG 2.5.3 GINEConv as configured by GINE.init_conv_layers, homogeneous.py:252-297):
+ *   out[i] = (1 + *eps) x[i] + sum over the in-edges e = (j -> i) of relu(x[j] + edge_rows[e]),
+ * x: fp32 [nodes][d], edge_rows: fp32 [edges][d] = lin(edge_attr) in the CSR's edge order (`col` positions), eps: DEVICE
+ * scalar; rows < *n_rows_dev are written (the conv's MLP is gigl_linear).  Backward: dx [nodes][d] and *deps are
+ * ACCUMULATED into (zero them first), dedge_rows [edges][d] is written for the rows' edges. */
+int32_t gigl_gine_aggregate(gigl_ctx* ctx, const float* x, const float* edge_rows, const float* eps, int32_t d,
+                            const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                            const int32_t* n_rows_dev, int64_t rows_cap, float* out);
+int32_t gigl_gine_aggregate_backward(gigl_ctx* ctx, const float* x, const float* edge_rows, const float* eps, int32_t d,
+                                     const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                     const int32_t* n_rows_dev, int64_t rows_cap, const float* dout, float* dx,
+                                     float* dedge_rows, float* deps);
+
 /* backward of gigl_gat_aggregate / gigl_gat_aggregate_edge (concatenated heads or one head; no W_msg messages) for
  * training through the reference's plugins (GnnTrainingProcess, training_process.py:153-370): given dout = dL/d(out
  * before bias and activation) and out_pre = that output, both [rows][heads*channels]:

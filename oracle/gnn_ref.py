@@ -288,3 +288,14 @@ def gatv2_conv(x: torch.Tensor, edge_index: torch.Tensor, p, heads: int, channel
     alpha = _segment_softmax((s * p["att"].view(1, heads, channels)).sum(-1), dst, n)
     out = torch.zeros((n, heads, channels), dtype=x.dtype).index_add_(0, dst, xl[src] * alpha.unsqueeze(-1))
     return out.reshape(n, heads * channels) + p["bias"]
+
+
+def gine_conv(x: torch.Tensor, edge_index: torch.Tensor, edge_attr: torch.Tensor, w_e: torch.Tensor, b_e: torch.Tensor,
+              w0: torch.Tensor, b0: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, eps: float = 0.0) -> torch.Tensor:
+    """PyG 2.5.3 GINEConv(nn=MLP([in, o, o]), edge_dim) as GINE.init_conv_layers builds it (homogeneous.py:252-297):
+    nn((1 + eps) x_i + sum_{j->i} relu(x_j + lin(e_ji))),  lin = Linear(edge_dim, in), nn = lin0 -> relu -> lin1"""
+    src, dst = edge_index[0], edge_index[1]
+    msg = torch.relu(x[src] + edge_attr @ w_e.T + b_e)
+    agg = torch.zeros_like(x).index_add(0, dst, msg)
+    h = torch.relu((agg + (1.0 + eps) * x) @ w0.T + b0)
+    return h @ w1.T + b1
