@@ -33,7 +33,10 @@ __global__ __launch_bounds__(256) void gatv2_forward_kernel(
     const float* __restrict__ xl, const float* __restrict__ xr, const float* __restrict__ att,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ col,
     const int32_t* __restrict__ n_rows_dev, int HC, int group, float slope, const float* __restrict__ bias, int act,
-    float* __restrict__ out) {
+    const float* __restrict__ xe, float* __restrict__ out) {
+  // xe (optional): lin_edge(edge_attr) rows [edges][HC] in the CSR's edge order, added inside the leaky_relu; the added
+  // self loop carries the MEAN of the row's rows (PyG fill_value="mean"; lin_edge has no bias, so mean(lin(e)) =
+  // lin(mean e)) — known when the self loop is folded in, last.
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
@@ -48,19 +51,21 @@ __global__ __launch_bounds__(256) void gatv2_forward_kernel(
   }
   for (int i = wave; i < n_rows; i += waves_total) {
     const int e0 = rowptr[i], m = rowend[i] - e0;
-    float4 r4[V], acc[V];
+    float4 r4[V], acc[V], se[V];
     float mx[V], den[V];
+    int cnt = 0;
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       r4[v] = on[v] ? ((const float4*)(xr + (int64_t)i * HC))[v * 64 + lane] : zero4;
       acc[v] = zero4;
+      se[v] = zero4;
       mx[v] = -INFINITY;
       den[v] = 0.f;
     }
     // the in-edges, then the self loop as one more "edge" (index m)
     for (int e = 0; e <= m; e += U) {
       int j[U];
-      float4 x[U][V];
+      float4 x[U][V], ev[U][V];
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         const int ee = e + t;
@@ -71,14 +76,26 @@ __global__ __launch_bounds__(256) void gatv2_forward_kernel(
       for (int t = 0; t < U; ++t) {
         if (j[t] < 0) continue;
 #pragma unroll
-        for (int v = 0; v < V; ++v) x[t][v] = on[v] ? ((const float4*)(xl + (int64_t)j[t] * HC))[v * 64 + lane] : zero4;
+        for (int v = 0; v < V; ++v) {
+          x[t][v] = on[v] ? ((const float4*)(xl + (int64_t)j[t] * HC))[v * 64 + lane] : zero4;
+          ev[t][v] = zero4;
+          if (xe && on[v] && e + t < m) ev[t][v] = ((const float4*)(xe + (int64_t)(e0 + e + t) * HC))[v * 64 + lane];
+        }
       }
 #pragma unroll
       for (int t = 0; t < U; ++t) {
         if (j[t] < 0) continue;  // (wave-uniform)
+        const bool self = e + t == m;
+        if (!self) ++cnt;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          const float z = head_sum(dot4(a4[v], leaky4(add4(x[t][v], r4[v]), slope)), group);
+          if (self && xe && cnt > 0) {
+            const float ic = 1.0f / (float)cnt;
+            ev[t][v] = float4{se[v].x * ic, se[v].y * ic, se[v].z * ic, se[v].w * ic};
+          } else if (!self) {
+            se[v] = add4(se[v], ev[t][v]);
+          }
+          const float z = head_sum(dot4(a4[v], leaky4(add4(add4(x[t][v], r4[v]), ev[t][v]), slope)), group);
           const float nm = fmaxf(mx[v], z);
           const float sc = __expf(mx[v] - nm), pw = __expf(z - nm);
           den[v] = den[v] * sc + pw;
@@ -113,7 +130,10 @@ __global__ __launch_bounds__(256) void gatv2_backward_kernel(
     const float* __restrict__ xl, const float* __restrict__ xr, const float* __restrict__ att,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ col,
     const int32_t* __restrict__ n_rows_dev, int HC, int group, float slope, const float* __restrict__ out_pre,
-    const float* __restrict__ dout, float* __restrict__ dxl, float* __restrict__ dxr, float* __restrict__ datt) {
+    const float* __restrict__ dout, float* __restrict__ dxl, float* __restrict__ dxr, float* __restrict__ datt,
+    const float* __restrict__ xe, float* __restrict__ dxe) {
+  // xe / dxe as in the forward: d xe_e = ds_e + ds_self / cnt (the self loop's mean row), so pass 2 starts with the
+  // self loop
   const int lane = threadIdx.x & 63;
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
@@ -142,13 +162,34 @@ __global__ __launch_bounds__(256) void gatv2_backward_kernel(
       mx[v] = -INFINITY;
       den[v] = 0.f;
     }
+    float4 se[V];
+    int cnt = 0;
+#pragma unroll
+    for (int v = 0; v < V; ++v) se[v] = zero4;
+    if (xe)
+      for (int e = 0; e < m; ++e) {
+        if (col[e0 + e] == i) continue;
+        ++cnt;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+          if (on[v]) se[v] = add4(se[v], ((const float4*)(xe + (int64_t)(e0 + e) * HC))[v * 64 + lane]);
+      }
+    if (cnt > 0) {
+      const float ic = 1.0f / (float)cnt;
+#pragma unroll
+      for (int v = 0; v < V; ++v) se[v] = float4{se[v].x * ic, se[v].y * ic, se[v].z * ic, se[v].w * ic};  // the mean row
+    }
+    auto edge_row = [&](int e, int v) -> float4 {
+      if (!xe || !on[v]) return zero4;
+      return e < m ? ((const float4*)(xe + (int64_t)(e0 + e) * HC))[v * 64 + lane] : se[v];
+    };
     for (int e = 0; e <= m; ++e) {  // pass 1
       const int j = e < m ? col[e0 + e] : i;
       if (e < m && j == i) continue;
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         const float4 x = on[v] ? ((const float4*)(xl + (int64_t)j * HC))[v * 64 + lane] : zero4;
-        const float z = head_sum(dot4(a4[v], leaky4(add4(x, r4[v]), slope)), group);
+        const float z = head_sum(dot4(a4[v], leaky4(add4(add4(x, r4[v]), edge_row(e, v)), slope)), group);
         const float nm = fmaxf(mx[v], z);
         den[v] = den[v] * __expf(mx[v] - nm) + __expf(z - nm);
         mx[v] = nm;
@@ -156,13 +197,17 @@ __global__ __launch_bounds__(256) void gatv2_backward_kernel(
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) den[v] = 1.0f / (den[v] + 1e-16f);
-    for (int e = 0; e <= m; ++e) {  // pass 2
+    float4 ds_self[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) ds_self[v] = zero4;
+    for (int ee = 0; ee <= m; ++ee) {  // pass 2: the self loop (index m) first, then the edges
+      const int e = ee == 0 ? m : ee - 1;
       const int j = e < m ? col[e0 + e] : i;
       if (e < m && j == i) continue;
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         const float4 x = on[v] ? ((const float4*)(xl + (int64_t)j * HC))[v * 64 + lane] : zero4;
-        const float4 s = add4(x, r4[v]);
+        const float4 s = add4(add4(x, r4[v]), edge_row(e, v));
         const float4 l = leaky4(s, slope);
         const float z = head_sum(dot4(a4[v], l), group);
         const float al = __expf(z - mx[v]) * den[v];
@@ -175,12 +220,19 @@ __global__ __launch_bounds__(256) void gatv2_backward_kernel(
         da4[v].y += dz * l.y;
         da4[v].z += dz * l.z;
         da4[v].w += dz * l.w;
+        if (e == m) ds_self[v] = ds;
         if (on[v]) {
           float* o = dxl + (int64_t)j * HC + 4 * (v * 64 + lane);
           atomicAdd(o + 0, al * g[v].x + ds.x);
           atomicAdd(o + 1, al * g[v].y + ds.y);
           atomicAdd(o + 2, al * g[v].z + ds.z);
           atomicAdd(o + 3, al * g[v].w + ds.w);
+          if (dxe && e < m) {
+            const float ic = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+            ((float4*)(dxe + (int64_t)(e0 + e) * HC))[v * 64 + lane] =
+                float4{ds.x + ds_self[v].x * ic, ds.y + ds_self[v].y * ic, ds.z + ds_self[v].z * ic,
+                       ds.w + ds_self[v].w * ic};
+          }
         }
       }
     }
@@ -216,6 +268,14 @@ int32_t gigl_gatv2_aggregate(gigl_ctx* ctx, const float* xl, const float* xr, co
                              int32_t channels, float negative_slope, const int32_t* rowptr, const int32_t* rowend,
                              const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
                              int32_t act, float* out) {
+  return gigl_gatv2_aggregate_edge(ctx, xl, xr, att, heads, channels, negative_slope, rowptr, rowend, col, n_rows_dev,
+                                   rows_cap, bias, act, nullptr, out);
+}
+
+int32_t gigl_gatv2_aggregate_edge(gigl_ctx* ctx, const float* xl, const float* xr, const float* att, int32_t heads,
+                                  int32_t channels, float negative_slope, const int32_t* rowptr, const int32_t* rowend,
+                                  const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
+                                  int32_t act, const float* edge_rows, float* out) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   GIGL_REQUIRE(ctx, xl && xr && att && rowptr && rowend && col && n_rows_dev && out, "null argument");
   GIGL_REQUIRE(ctx, heads > 0 && channels > 0 && rows_cap >= 0 && (act == 0 || act == 1), "bad sizes");
@@ -229,7 +289,7 @@ int32_t gigl_gatv2_aggregate(gigl_ctx* ctx, const float* xl, const float* xr, co
   const int HC = heads * channels;
 #define GIGL_V2_FWD(VV)                                                                                              \
   hipLaunchKernelGGL((gatv2_forward_kernel<VV>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, xl, xr, att,    \
-                     rowptr, rowend, col, n_rows_dev, HC, group, negative_slope, bias, act, out)
+                     rowptr, rowend, col, n_rows_dev, HC, group, negative_slope, bias, act, edge_rows, out)
   if (V == 1) GIGL_V2_FWD(1);
   else if (V == 2) GIGL_V2_FWD(2);
   else GIGL_V2_FWD(4);
@@ -243,7 +303,18 @@ int32_t gigl_gatv2_aggregate_backward(gigl_ctx* ctx, const float* xl, const floa
                                       const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
                                       int64_t rows_cap, const float* out_pre, const float* dout, float* dxl,
                                       float* dxr, float* datt) {
+  return gigl_gatv2_aggregate_edge_backward(ctx, xl, xr, att, heads, channels, negative_slope, rowptr, rowend, col,
+                                            n_rows_dev, rows_cap, out_pre, dout, nullptr, dxl, dxr, datt, nullptr);
+}
+
+int32_t gigl_gatv2_aggregate_edge_backward(gigl_ctx* ctx, const float* xl, const float* xr, const float* att,
+                                           int32_t heads, int32_t channels, float negative_slope,
+                                           const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                           const int32_t* n_rows_dev, int64_t rows_cap, const float* out_pre,
+                                           const float* dout, const float* edge_rows, float* dxl, float* dxr,
+                                           float* datt, float* dedge_rows) {
   if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, !edge_rows == !dedge_rows, "edge_rows and dedge_rows come together");
   GIGL_REQUIRE(ctx, xl && xr && att && rowptr && rowend && col && n_rows_dev && out_pre && dout && dxl && dxr && datt,
                "null argument");
   GIGL_REQUIRE(ctx, heads > 0 && channels > 0 && rows_cap >= 0, "bad sizes");
@@ -257,7 +328,8 @@ int32_t gigl_gatv2_aggregate_backward(gigl_ctx* ctx, const float* xl, const floa
   const int HC = heads * channels;
 #define GIGL_V2_BWD(VV)                                                                                              \
   hipLaunchKernelGGL((gatv2_backward_kernel<VV>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, xl, xr, att,   \
-                     rowptr, rowend, col, n_rows_dev, HC, group, negative_slope, out_pre, dout, dxl, dxr, datt)
+                     rowptr, rowend, col, n_rows_dev, HC, group, negative_slope, out_pre, dout, dxl, dxr, datt, edge_rows,  \
+                     dedge_rows)
   if (V == 1) GIGL_V2_BWD(1);
   else if (V == 2) GIGL_V2_BWD(2);
   else GIGL_V2_BWD(4);

@@ -789,27 +789,32 @@ class HipEngine:
 
     def gatv2_aggregate(self, xl: torch.Tensor, xr: torch.Tensor, att: torch.Tensor, heads: int, channels: int, u,
                         n_rows_dev: torch.Tensor, bias: Optional[torch.Tensor], negative_slope: float = 0.2,
-                        act: int = 0) -> torch.Tensor:
-        """GATv2Conv attention + aggregation over the CSR view `u` (rowptr / rowend / col): [rows, heads*channels]"""
+                        act: int = 0, edge_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """GATv2Conv attention + aggregation over the CSR view `u` (rowptr / rowend / col): [rows, heads*channels];
+        edge_rows: lin_edge(edge_attr) [edges, heads*channels] in `col` order (GATv2Conv(edge_dim))"""
         rows = int(xr.shape[0])
         for t in (xl, xr):
             assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.shape[1] == heads * channels
         out = torch.empty((rows, heads * channels), dtype=torch.float32, device=self.device)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        check(self._lib.gigl_gatv2_aggregate(self._ctx, p(xl), p(xr), p(att), heads, channels, negative_slope, p(u.rowptr),
-                                             p(u.rowend), p(u.col), p(n_rows_dev), rows, p(bias), act, p(out)), self._ctx)
+        if edge_rows is not None:
+            assert edge_rows.is_contiguous() and tuple(edge_rows.shape) == (int(u.col.numel()), heads * channels)
+        check(self._lib.gigl_gatv2_aggregate_edge(self._ctx, p(xl), p(xr), p(att), heads, channels, negative_slope,
+                                                  p(u.rowptr), p(u.rowend), p(u.col), p(n_rows_dev), rows, p(bias), act,
+                                                  p(edge_rows), p(out)), self._ctx)
         return out
 
     def gatv2_aggregate_backward(self, xl, xr, att, heads: int, channels: int, u, n_rows_dev, out_pre, dout,
-                                 negative_slope: float = 0.2):
-        """-> (dxl, dxr, datt): gigl_gatv2_aggregate_backward"""
+                                 negative_slope: float = 0.2, edge_rows: Optional[torch.Tensor] = None):
+        """-> (dxl, dxr, datt, dedge_rows | None): gigl_gatv2_aggregate_edge_backward"""
         dout = dout.contiguous()
         dxl, dxr, datt = torch.zeros_like(xl), torch.zeros_like(xr), torch.zeros_like(att)
-        p = lambda t: C.c_void_p(t.data_ptr())
-        check(self._lib.gigl_gatv2_aggregate_backward(self._ctx, p(xl), p(xr), p(att), heads, channels, negative_slope,
-                                                      p(u.rowptr), p(u.rowend), p(u.col), p(n_rows_dev), int(xr.shape[0]),
-                                                      p(out_pre), p(dout), p(dxl), p(dxr), p(datt)), self._ctx)
-        return dxl, dxr, datt
+        dxe = torch.zeros_like(edge_rows) if edge_rows is not None else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(self._lib.gigl_gatv2_aggregate_edge_backward(
+            self._ctx, p(xl), p(xr), p(att), heads, channels, negative_slope, p(u.rowptr), p(u.rowend), p(u.col),
+            p(n_rows_dev), int(xr.shape[0]), p(out_pre), p(dout), p(edge_rows), p(dxl), p(dxr), p(datt), p(dxe)), self._ctx)
+        return dxl, dxr, datt, dxe
 
     def gat_aggregate_backward(self, h: torch.Tensor, att_src: torch.Tensor, att_dst: torch.Tensor, heads: int,
                                channels: int, u, n_rows_dev: torch.Tensor, out_pre: torch.Tensor, dout: torch.Tensor,

@@ -13,7 +13,7 @@ No new kernels: a GIN layer is the segmented SUM + projection of a SAGE layer wi
 layer is three projections + the dot-product attention reduce of HGTConv with one edge type (gigl_hgt_aggregate and
 its backward).  GATv2 (homogeneous.py:346-386) has its own kernels (csrc/gatv2.hip: the logit is a C-wide pass per edge).
 GINE (homogeneous.py:252-297) adds gigl_gine_aggregate (messages relu(x_j + lin(e_ji))).
-Not built: edge features for TransformerConv / GATv2Conv.
+GATv2(edge_dim) adds lin_edge(e) inside the logit's leaky_relu.  Not built: edge features for TransformerConv.
 
   DCNv2 / DCNCross  python/gigl/src/common/models/layers/feature_interaction.py:7-155 — the feature-interaction layer
 BasicHomogeneousGNN applies to the node features before the first conv (`feature_interaction_layer=`): x_{i+1} =
@@ -27,8 +27,13 @@ import torch
 import torch.nn as nn
 
 from ._lib import GIGL_META_LEVEL0
-from .engine import HipEngine
+from .engine import HipEngine, dev_i32
 from .models import GraphSAGE, HipBatch
+
+
+def dev_rows(t: torch.Tensor) -> torch.Tensor:
+    """device-side row count of a matrix (the m_dev argument of gigl_linear)"""
+    return dev_i32(t.device, int(t.shape[0]))
 
 
 def _linear(eng: HipEngine, x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
@@ -368,52 +373,59 @@ class Transformer(GraphSAGE):
 
 
 class _Gatv2AggFn(torch.autograd.Function):
-    """gigl_gatv2_aggregate / gigl_gatv2_aggregate_backward over a CSR view (rowptr / rowend / col), before the bias"""
+    """gigl_gatv2_aggregate[_edge] / its backward over a CSR view (rowptr / rowend / col), before the bias; xe = the
+    projected edge rows (lin_edge(edge_attr), `col` order) or None"""
 
     @staticmethod
-    def forward(ctx, xl, xr, att, eng, view, n_dev, heads, channels, slope):
+    def forward(ctx, xl, xr, att, xe, eng, view, n_dev, heads, channels, slope):
         xl, xr, att = xl.contiguous(), xr.contiguous(), att.reshape(-1).contiguous()
-        out = eng.gatv2_aggregate(xl, xr, att, heads, channels, view, n_dev, None, negative_slope=slope, act=0)
-        ctx.save_for_backward(xl, xr, att, out)
+        xe = xe.contiguous() if xe is not None else None
+        out = eng.gatv2_aggregate(xl, xr, att, heads, channels, view, n_dev, None, negative_slope=slope, act=0,
+                                  edge_rows=xe)
+        ctx.save_for_backward(xl, xr, att, out, *([xe] if xe is not None else []))
         ctx.meta = (eng, view, n_dev, heads, channels, slope)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        xl, xr, att, out = ctx.saved_tensors
+        xl, xr, att, out = ctx.saved_tensors[:4]
+        xe = ctx.saved_tensors[4] if len(ctx.saved_tensors) > 4 else None
         eng, view, n_dev, heads, channels, slope = ctx.meta
-        dxl, dxr, datt = eng.gatv2_aggregate_backward(xl, xr, att, heads, channels, view, n_dev, out, dout,
-                                                      negative_slope=slope)
-        return dxl, dxr, datt.view(1, heads, channels), None, None, None, None, None, None
+        dxl, dxr, datt, dxe = eng.gatv2_aggregate_backward(xl, xr, att, heads, channels, view, n_dev, out, dout,
+                                                           negative_slope=slope, edge_rows=xe)
+        return dxl, dxr, datt.view(1, heads, channels), dxe, None, None, None, None, None, None
 
 
 class GATv2Conv(nn.Module):
-    """parameter holder with PyG GATv2Conv's layout (lin_l / lin_r / att / bias)"""
+    """parameter holder with PyG GATv2Conv's layout (lin_l / lin_r / att / bias; with edge_dim also lin_edge, no bias)"""
 
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True,
                  negative_slope: float = 0.2, bias: bool = True, share_weights: bool = False,
                  edge_dim: Optional[int] = None, dropout: float = 0.0):
         super().__init__()
-        if edge_dim is not None:
-            raise NotImplementedError("GATv2Conv edge features (edge_dim) are not built")
         if dropout:
             raise NotImplementedError("GATv2Conv attention dropout is not built")
         if not concat and heads > 1:
             raise NotImplementedError("GATv2Conv with averaged heads (concat=False, heads > 1) is not built")
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
-        self.negative_slope, self.share_weights = negative_slope, share_weights
+        self.negative_slope, self.share_weights, self.edge_dim = negative_slope, share_weights, edge_dim
         self.lin_l = nn.Linear(in_channels, heads * out_channels, bias=bias)
         self.lin_r = self.lin_l if share_weights else nn.Linear(in_channels, heads * out_channels, bias=bias)
         self.att = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.lin_edge = nn.Linear(edge_dim, heads * out_channels, bias=False) if edge_dim is not None else None
         self.bias = nn.Parameter(torch.zeros(heads * out_channels)) if bias else None
         nn.init.xavier_uniform_(self.lin_l.weight)
         nn.init.xavier_uniform_(self.lin_r.weight)
         nn.init.xavier_uniform_(self.att)
+        if self.lin_edge is not None:
+            nn.init.xavier_uniform_(self.lin_edge.weight)
 
-    def forward(self, x: torch.Tensor, view, n_dev: torch.Tensor, eng: HipEngine) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, view, n_dev: torch.Tensor, eng: HipEngine,
+                edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:
         xl = _linear(eng, x, self.lin_l.weight, self.lin_l.bias)
         xr = xl if self.share_weights else _linear(eng, x, self.lin_r.weight, self.lin_r.bias)
-        out = _Gatv2AggFn.apply(xl, xr, self.att, eng, view, n_dev, self.heads, self.out_channels, self.negative_slope)
+        xe = _linear(eng, edge_attr, self.lin_edge.weight, None) if self.lin_edge is not None else None
+        out = _Gatv2AggFn.apply(xl, xr, self.att, xe, eng, view, n_dev, self.heads, self.out_channels, self.negative_slope)
         return out + self.bias if self.bias is not None else out
 
 
@@ -431,7 +443,7 @@ class GATv2(GraphSAGE):
         heads = int(ck.get("heads", 1))
         super().__init__(in_dim, hid_dim, out_dim, num_layers=num_layers, **kwargs)
         last = hid_dim if (self.linear_layer or self.jk_layer is not None) else out_dim
-        self.heads = heads
+        self.heads, self.edge_dim = heads, edge_dim
         self.conv_layers = nn.ModuleList([
             GATv2Conv(in_dim if i == 0 else hid_dim * heads, hid_dim if i < num_layers - 1 else last,
                       heads=heads if i < num_layers - 1 else 1, concat=bool(ck.get("concat", True)),
@@ -452,9 +464,16 @@ class GATv2(GraphSAGE):
             if eng is None:
                 raise RuntimeError("GATv2.forward(GraphData) needs the HipEngine (model.engine = eng)")
             view = _CsrView(batch)
+            ea = None
+            if self.edge_dim is not None:
+                if batch.edge_attr_csr is None:
+                    raise ValueError(f"the model was built with edge_dim={self.edge_dim} but the batch has no edge features")
+                ea = batch.edge_attr_csr
+                if ea.shape[0] != view.col.numel():  # edgeless batch: col holds one padding entry
+                    ea = torch.zeros((view.col.numel(), self.edge_dim), dtype=torch.float32, device=batch.x.device)
             h, xs = self._interact(batch.x, eng), []
             for l, conv in enumerate(self.conv_layers):
-                h = self._post(conv(h, view, batch.n_dev, eng), l, False)
+                h = self._post(conv(h, view, batch.n_dev, eng, ea), l, False)
                 xs.append(h)
             if self.jk_layer is not None:
                 h = self.jk_layer(xs)
@@ -464,6 +483,10 @@ class GATv2(GraphSAGE):
             L = self.num_layers
             assert u.hops == L, "one hop per layer"
             cap = int(u.nodes.numel())
+            ea = None
+            if self.edge_dim is not None:
+                ea = batch.edge_attr if batch.edge_attr is not None else eng.union_edge_attr(u)
+                assert ea.shape[1] == self.edge_dim
             batch = self._interacted(batch)
             if batch.x is None:
                 h = eng.gather_rows(u.nodes, u.meta[0:1], cap)
@@ -478,8 +501,11 @@ class GATv2(GraphSAGE):
                 xl = eng.linear(h, conv.lin_l.weight.contiguous(), conv.lin_l.bias, n_src, cap, 0)
                 xr = xl if conv.share_weights else eng.linear(h, conv.lin_r.weight.contiguous(), conv.lin_r.bias, n_dst,
                                                               cap, 0)
+                xe = None
+                if conv.lin_edge is not None:
+                    xe = eng.linear(ea, conv.lin_edge.weight.contiguous(), None, dev_rows(ea), int(ea.shape[0]), 0)
                 h = eng.gatv2_aggregate(xl, xr, conv.att.reshape(-1).contiguous(), conv.heads, conv.out_channels, u,
-                                        n_dst, conv.bias, negative_slope=conv.negative_slope, act=0)
+                                        n_dst, conv.bias, negative_slope=conv.negative_slope, act=0, edge_rows=xe)
                 h = self._post(h, l, False).contiguous()
                 xs.append(h)
             if self.jk_layer is not None:

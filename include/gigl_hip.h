@@ -607,6 +607,20 @@ int32_t gigl_gatv2_aggregate_backward(gigl_ctx* ctx, const float* xl, const floa
                                       const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
                                       int64_t rows_cap, const float* out_pre, const float* dout, float* dxl,
                                       float* dxr, float* datt);
+/* GATv2Conv with edge features (edge_dim): edge_rows = lin_edge(edge_attr) as fp32 [edges][heads*channels] rows in the
+ * CSR's edge order (lin_edge has no bias), added inside the leaky_relu: z_ij = <att, leaky_relu(xl_j + xr_i + edge_rows_e)>;
+ * the added self loop carries the mean of the row's edge rows (fill_value="mean").  dedge_rows [edges][H*C] is written
+ * for the rows' edges. */
+int32_t gigl_gatv2_aggregate_edge(gigl_ctx* ctx, const float* xl, const float* xr, const float* att, int32_t heads,
+                                  int32_t channels, float negative_slope, const int32_t* rowptr, const int32_t* rowend,
+                                  const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
+                                  int32_t act, const float* edge_rows, float* out);
+int32_t gigl_gatv2_aggregate_edge_backward(gigl_ctx* ctx, const float* xl, const float* xr, const float* att,
+                                           int32_t heads, int32_t channels, float negative_slope,
+                                           const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                           const int32_t* n_rows_dev, int64_t rows_cap, const float* out_pre,
+                                           const float* dout, const float* edge_rows, float* dxl, float* dxr,
+                                           float* datt, float* dedge_rows);
 
 /* GINEConv aggregation (PyG 2.5.3 GINEConv as configured by GINE.init_conv_layers, homogeneous.py:252-297):
  *   out[i] = (1 + *eps) x[i] + sum over the in-edges e = (j -> i) of relu(x[j] + edge_rows[e]),

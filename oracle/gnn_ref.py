@@ -272,11 +272,12 @@ def transformer_conv(x: torch.Tensor, edge_index: torch.Tensor, p, heads: int, c
 
 
 def gatv2_conv(x: torch.Tensor, edge_index: torch.Tensor, p, heads: int, channels: int, negative_slope: float = 0.2,
-               share_weights: bool = False) -> torch.Tensor:
-    """PyG 2.5.3 GATv2Conv without edge features (GATv2.init_conv_layers, homogeneous.py:346-386): xl = lin_l(x),
-    xr = lin_r(x) (= xl when share_weights); self loops removed then one added per node;
-    z_ij = <att_h, leaky_relu(xl_j + xr_i)>; alpha = softmax over the in-edges of i; out_i = sum_j alpha_ij xl_j, heads
-    concatenated, + bias.   p: lin_l.weight/.bias, lin_r.weight/.bias, att [1, H, C], bias"""
+               share_weights: bool = False, edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PyG 2.5.3 GATv2Conv (GATv2.init_conv_layers, homogeneous.py:346-386): xl = lin_l(x), xr = lin_r(x) (= xl when
+    share_weights); self loops removed then one added per node (with edge features: carrying the MEAN attribute of the
+    node's in-edges, fill_value="mean"); z_ij = <att_h, leaky_relu(xl_j + xr_i [+ lin_edge(e_ij)])>; alpha = softmax over
+    the in-edges of i; out_i = sum_j alpha_ij xl_j, heads concatenated, + bias.
+    p: lin_l.weight/.bias, lin_r.weight/.bias, att [1, H, C], bias[, lin_edge.weight]"""
     n = x.shape[0]
     xl = (x @ p["lin_l.weight"].T + p["lin_l.bias"]).view(n, heads, channels)
     xr = xl if share_weights else (x @ p["lin_r.weight"].T + p["lin_r.bias"]).view(n, heads, channels)
@@ -284,7 +285,14 @@ def gatv2_conv(x: torch.Tensor, edge_index: torch.Tensor, p, heads: int, channel
     loops = torch.arange(n, dtype=edge_index.dtype)
     src = torch.cat([edge_index[0][keep], loops])
     dst = torch.cat([edge_index[1][keep], loops])
-    s = torch.nn.functional.leaky_relu(xl[src] + xr[dst], negative_slope)
+    s = xl[src] + xr[dst]
+    if edge_attr is not None:
+        ea = edge_attr[keep]
+        mean = torch.zeros((n, ea.shape[1]), dtype=ea.dtype).index_add_(0, edge_index[1][keep], ea)
+        cnt = torch.bincount(edge_index[1][keep], minlength=n).clamp(min=1).to(ea.dtype)
+        ea = torch.cat([ea, mean / cnt[:, None]])
+        s = s + (ea @ p["lin_edge.weight"].T).view(-1, heads, channels)
+    s = torch.nn.functional.leaky_relu(s, negative_slope)
     alpha = _segment_softmax((s * p["att"].view(1, heads, channels)).sum(-1), dst, n)
     out = torch.zeros((n, heads, channels), dtype=x.dtype).index_add_(0, dst, xl[src] * alpha.unsqueeze(-1))
     return out.reshape(n, heads * channels) + p["bias"]

@@ -392,3 +392,52 @@ def test_gine_gradients_and_sampled_batch():
         np.testing.assert_allclose(got, h[o["root_local"]].numpy(), rtol=2e-5, atol=2e-5)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("heads,hid,out,share", [(2, 16, 32, False), (4, 32, 16, True)])
+def test_gatv2_with_edge_features_gradients(heads, hid, out, share):
+    """GATv2Conv(edge_dim): lin_edge(e) inside the logit's leaky_relu, self loops filled with the row's mean attribute;
+    forward and every gradient (lin_edge included) against torch autograd through the restatement"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models_more import GATv2
+    from gigl_amd.nn import GraphData
+    rng = np.random.default_rng(heads + 40)
+    n, d, de = 240, 12, 6
+    ei, x = _graph(rng, n, 1700, d)
+    ea = torch.from_numpy(rng.standard_normal((ei.shape[1], de)).astype(np.float32))
+    eng = HipEngine(0)
+    try:
+        torch.manual_seed(6)
+        model = GATv2(d, hid, out, num_layers=2, heads=heads, share_weights=share, edge_dim=de).to(eng.device).train()
+        model.engine = eng
+        g = GraphData(x=x.clone(), edge_index=ei, edge_attr=ea).to(eng.device)
+        g.x.requires_grad_(True)
+        wsum = torch.from_numpy(rng.standard_normal((n, out)).astype(np.float32))
+        y = model(g)
+        (y * wsum.to(eng.device)).sum().backward()
+        ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        if share:
+            for l in range(2):
+                ref[f"conv_layers.{l}.lin_r.weight"] = ref[f"conv_layers.{l}.lin_l.weight"]
+                ref[f"conv_layers.{l}.lin_r.bias"] = ref[f"conv_layers.{l}.lin_l.bias"]
+        xr = x.clone().requires_grad_(True)
+        h = xr
+        for l in range(2):
+            pre = f"conv_layers.{l}."
+            p = {k[len(pre):]: v for k, v in ref.items() if k.startswith(pre)}
+            h = gnn_ref.gatv2_conv(h, ei, p, heads if l == 0 else 1, hid if l == 0 else out, share_weights=share,
+                                   edge_attr=ea)
+            if l == 0:
+                h = torch.relu(h)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), h.detach().numpy(), rtol=1e-5, atol=1e-5)
+        (h * wsum).sum().backward()
+        assert "conv_layers.0.lin_edge.weight" in dict(model.named_parameters())
+        for name, prm in model.named_parameters():
+            want = ref[name].grad
+            assert prm.grad is not None and want is not None, name
+            scale = float(want.abs().max()) + 1e-6
+            np.testing.assert_allclose(prm.grad.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4 * scale, err_msg=name)
+        np.testing.assert_allclose(g.x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4,
+                                   atol=1e-4 * float(xr.grad.abs().max()))
+    finally:
+        eng.close()
