@@ -485,3 +485,49 @@ def test_subgraph_sampler_on_the_reference_heterogeneous_config(workdir):
         assert (e.src_node_id, e.dst_node_id) in edge_sets[p2a] and e.feature_values.size == 2
         check_graph(m.neighborhood)
         assert (e.dst_node_id, node_types["author"]) in {(x.node_id, x.condensed_node_type) for x in m.neighborhood.nodes}
+
+
+def test_typed_sampler_job_options(workdir):
+    """numMaxTrainingSamplesToOutput caps the typed training samples; shouldIncludeIsolatedNodesInTraining keeps the roots
+    without a positive (empty pos_edges, their own neighbourhood); an explicit SubgraphSamplingStrategy replaces the
+    k-hop default DAG (GraphDBNodeAnchorBasedLinkPredictionTask.scala:186-187, 262-283, 428-470)"""
+    import yaml
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    doc = yaml.safe_load(open(os.path.join(workdir, "configs/hetero_nablp_frozen_gbml_config.yaml")))
+    ssc = doc["datasetConfig"]["subgraphSamplerConfig"]
+    ssc["numMaxTrainingSamplesToOutput"] = 5
+    a2p = {"srcNodeType": "author", "relation": "author_to_paper", "dstNodeType": "paper"}
+    p2a = {"srcNodeType": "paper", "relation": "paper_to_author", "dstNodeType": "author"}
+    ssc["subgraphSamplingStrategy"] = {"messagePassingPaths": {"paths": [
+        {"rootNodeType": "paper", "samplingOps": [
+            {"opName": "one", "edgeType": a2p, "randomUniform": {"numNodesToSample": 2}}]},
+        {"rootNodeType": "author", "samplingOps": [
+            {"opName": "one", "edgeType": p2a, "randomUniform": {"numNodesToSample": 1}}]}]}}
+    for k, v in doc["sharedConfig"]["flattenedGraphMetadata"]["nodeAnchorBasedLinkPredictionOutput"].items():
+        if isinstance(v, str):
+            doc["sharedConfig"]["flattenedGraphMetadata"]["nodeAnchorBasedLinkPredictionOutput"][k] = v.replace("hetero_nablp", "hetero_opts")
+        else:
+            for t in v:
+                v[t] = v[t].replace("hetero_nablp", "hetero_opts")
+    uri = "configs/hetero_opts_gbml_config.yaml"
+    yaml.safe_dump(doc, open(os.path.join(workdir, uri), "w"))
+    SubgraphSampler().run("job", uri, None, uri_base=workdir)
+    cfg = GbmlConfigPbWrapper.from_uri(uri, uri_base=workdir)
+    read = lambda: [wire.NodeAnchorBasedLinkPredictionSample.FromString(r)
+                    for f in tfrecord_files(cfg.nablp_tfrecord_uri_prefix) for r in wire.read_tfrecords(f)]
+    capped = read()
+    assert 0 < len(capped) <= 5 and all(len(m.pos_edges) == 1 for m in capped)
+    # one hop of 2 for the paper + one hop of 1 for its positive author: at most 3 neighbourhood edges
+    assert all(len(m.neighborhood.edges) <= 3 for m in capped)
+    rn = [wire.RootedNodeNeighborhood.FromString(r) for f in tfrecord_files(cfg.random_negative_tfrecord_uri_prefixes["author"])
+          for r in wire.read_tfrecords(f)]
+    assert len(rn) == 15 and all(len(m.neighborhood.edges) <= 1 for m in rn)
+    ssc["numMaxTrainingSamplesToOutput"] = 0
+    doc["sharedConfig"]["shouldIncludeIsolatedNodesInTraining"] = True
+    yaml.safe_dump(doc, open(os.path.join(workdir, uri), "w"))
+    SubgraphSampler().run("job", uri, None, uri_base=workdir)
+    everyone = read()
+    assert len(everyone) == 19 and any(len(m.pos_edges) == 0 for m in everyone)
+    for m in everyone:
+        if not m.pos_edges:
+            assert (m.root_node.node_id, 1) in {(x.node_id, x.condensed_node_type) for x in m.neighborhood.nodes}
