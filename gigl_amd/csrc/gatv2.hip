@@ -439,3 +439,201 @@ int32_t gigl_gine_aggregate_backward(gigl_ctx* ctx, const float* x, const float*
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
+
+// ---- TransformerConv attention with edge features (PyG 2.5.3 TransformerConv(edge_dim), Transformer.init_conv_layers,
+// homogeneous.py:440-487): with xe = lin_edge(edge_attr) rows in the CSR's edge order,
+//   alpha_e = softmax over the in-edges of i of <q_i, k_j + xe_e> / sqrt(C),  out_i = sum_e alpha_e (v_j + xe_e)
+// (no self loops are added; an empty row gives 0).  Same lane layout as the GATv2 kernels: one wave per destination row,
+// a head = C/4 adjacent lanes.  (Without edge features the layer runs on gigl_hgt_aggregate.)
+namespace {
+
+template <int V>
+__global__ __launch_bounds__(256) void transformer_edge_forward_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ xe,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ n_rows_dev, int HC, int group, float scale, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n_rows = *n_rows_dev, chunks = HC >> 2;
+  const float4 zero4{0.f, 0.f, 0.f, 0.f};
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    float4 q4[V], acc[V];
+    float mx[V], den[V];
+    bool on[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+      on[c] = c * 64 + lane < chunks;
+      q4[c] = on[c] ? ((const float4*)(q + (int64_t)i * HC))[c * 64 + lane] : zero4;
+      acc[c] = zero4;
+      mx[c] = -INFINITY;
+      den[c] = 0.f;
+    }
+    for (int e = 0; e < m; ++e) {
+      const int j = col[e0 + e];
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        const int o = c * 64 + lane;
+        const float4 ee = on[c] ? ((const float4*)(xe + (int64_t)(e0 + e) * HC))[o] : zero4;
+        const float4 kk = add4(on[c] ? ((const float4*)(k + (int64_t)j * HC))[o] : zero4, ee);
+        const float4 vv = add4(on[c] ? ((const float4*)(v + (int64_t)j * HC))[o] : zero4, ee);
+        const float z = head_sum(dot4(q4[c], kk), group) * scale;
+        const float nm = fmaxf(mx[c], z);
+        const float sc = __expf(mx[c] - nm), pw = __expf(z - nm);
+        den[c] = den[c] * sc + pw;
+        acc[c] = float4{acc[c].x * sc + pw * vv.x, acc[c].y * sc + pw * vv.y, acc[c].z * sc + pw * vv.z,
+                        acc[c].w * sc + pw * vv.w};
+        mx[c] = nm;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+      if (!on[c]) continue;
+      const float inv = m > 0 ? 1.0f / (den[c] + 1e-16f) : 0.f;
+      ((float4*)(out + (int64_t)i * HC))[c * 64 + lane] =
+          float4{acc[c].x * inv, acc[c].y * inv, acc[c].z * inv, acc[c].w * inv};
+    }
+  }
+}
+
+// backward: g = d out_i, S = <g, out_i> per head; per edge kk = k_j + xe_e, vv = v_j + xe_e,
+//   d alpha_e = <g, vv>,  dz_e = alpha_e (d alpha_e - S),  dq_i += dz_e kk * scale,  dk_j += dz_e q_i * scale (atomics),
+//   dv_j += alpha_e g (atomics),  dxe_e = dz_e q_i * scale + alpha_e g (row-owned).
+template <int V>
+__global__ __launch_bounds__(256) void transformer_edge_backward_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ xe,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ n_rows_dev, int HC, int group, float scale, const float* __restrict__ out,
+    const float* __restrict__ dout, float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv,
+    float* __restrict__ dxe) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n_rows = *n_rows_dev, chunks = HC >> 2;
+  const float4 zero4{0.f, 0.f, 0.f, 0.f};
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    float4 q4[V], g[V], dq4[V];
+    float mx[V], den[V], S[V];
+    bool on[V];
+#pragma unroll
+    for (int c = 0; c < V; ++c) {
+      const int o = c * 64 + lane;
+      on[c] = o < chunks;
+      q4[c] = on[c] ? ((const float4*)(q + (int64_t)i * HC))[o] : zero4;
+      g[c] = on[c] ? ((const float4*)(dout + (int64_t)i * HC))[o] : zero4;
+      const float4 oo = on[c] ? ((const float4*)(out + (int64_t)i * HC))[o] : zero4;
+      S[c] = head_sum(dot4(g[c], oo), group);
+      dq4[c] = zero4;
+      mx[c] = -INFINITY;
+      den[c] = 0.f;
+    }
+    for (int e = 0; e < m; ++e) {  // pass 1: max / denominator
+      const int j = col[e0 + e];
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        const int o = c * 64 + lane;
+        const float4 kk = add4(on[c] ? ((const float4*)(k + (int64_t)j * HC))[o] : zero4,
+                               on[c] ? ((const float4*)(xe + (int64_t)(e0 + e) * HC))[o] : zero4);
+        const float z = head_sum(dot4(q4[c], kk), group) * scale;
+        const float nm = fmaxf(mx[c], z);
+        den[c] = den[c] * __expf(mx[c] - nm) + __expf(z - nm);
+        mx[c] = nm;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < V; ++c) den[c] = 1.0f / (den[c] + 1e-16f);
+    for (int e = 0; e < m; ++e) {  // pass 2
+      const int j = col[e0 + e];
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        const int o = c * 64 + lane;
+        const float4 ee = on[c] ? ((const float4*)(xe + (int64_t)(e0 + e) * HC))[o] : zero4;
+        const float4 kk = add4(on[c] ? ((const float4*)(k + (int64_t)j * HC))[o] : zero4, ee);
+        const float4 vv = add4(on[c] ? ((const float4*)(v + (int64_t)j * HC))[o] : zero4, ee);
+        const float z = head_sum(dot4(q4[c], kk), group) * scale;
+        const float al = __expf(z - mx[c]) * den[c];
+        const float dz = al * (head_sum(dot4(g[c], vv), group) - S[c]) * scale;
+        dq4[c] = float4{dq4[c].x + dz * kk.x, dq4[c].y + dz * kk.y, dq4[c].z + dz * kk.z, dq4[c].w + dz * kk.w};
+        if (on[c]) {
+          const float4 dkk{dz * q4[c].x, dz * q4[c].y, dz * q4[c].z, dz * q4[c].w};
+          const float4 dvv{al * g[c].x, al * g[c].y, al * g[c].z, al * g[c].w};
+          float* pk = dk + (int64_t)j * HC + 4 * o;
+          float* pv = dv + (int64_t)j * HC + 4 * o;
+          atomicAdd(pk + 0, dkk.x);
+          atomicAdd(pk + 1, dkk.y);
+          atomicAdd(pk + 2, dkk.z);
+          atomicAdd(pk + 3, dkk.w);
+          atomicAdd(pv + 0, dvv.x);
+          atomicAdd(pv + 1, dvv.y);
+          atomicAdd(pv + 2, dvv.z);
+          atomicAdd(pv + 3, dvv.w);
+          ((float4*)(dxe + (int64_t)(e0 + e) * HC))[o] = add4(dkk, dvv);
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < V; ++c)
+      if (on[c]) ((float4*)(dq + (int64_t)i * HC))[c * 64 + lane] = dq4[c];
+  }
+}
+
+}  // namespace
+
+int32_t gigl_transformer_aggregate_edge(gigl_ctx* ctx, const float* q, const float* k, const float* v,
+                                        const float* edge_rows, int32_t heads, int32_t channels, const int32_t* rowptr,
+                                        const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
+                                        int64_t rows_cap, float* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, q && k && v && edge_rows && rowptr && rowend && col && n_rows_dev && out, "null argument");
+  GIGL_REQUIRE(ctx, heads > 0 && channels > 0 && rows_cap >= 0, "bad sizes");
+  int V, group;
+  if (!gatv2_shape(ctx, heads, channels, V, group)) return GIGL_E_UNSUPPORTED;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  const int HC = heads * channels;
+  const float scale = 1.0f / sqrtf((float)channels);
+#define GIGL_TR_FWD(VV)                                                                                                \
+  hipLaunchKernelGGL((transformer_edge_forward_kernel<VV>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, q, k, v, \
+                     edge_rows, rowptr, rowend, col, n_rows_dev, HC, group, scale, out)
+  if (V == 1) GIGL_TR_FWD(1);
+  else if (V == 2) GIGL_TR_FWD(2);
+  else GIGL_TR_FWD(4);
+#undef GIGL_TR_FWD
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_transformer_aggregate_edge_backward(gigl_ctx* ctx, const float* q, const float* k, const float* v,
+                                                 const float* edge_rows, int32_t heads, int32_t channels,
+                                                 const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                                 const int32_t* n_rows_dev, int64_t rows_cap, const float* out,
+                                                 const float* dout, float* dq, float* dk, float* dv,
+                                                 float* dedge_rows) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, q && k && v && edge_rows && rowptr && rowend && col && n_rows_dev && out && dout && dq && dk && dv &&
+                        dedge_rows, "null argument");
+  GIGL_REQUIRE(ctx, heads > 0 && channels > 0 && rows_cap >= 0, "bad sizes");
+  int V, group;
+  if (!gatv2_shape(ctx, heads, channels, V, group)) return GIGL_E_UNSUPPORTED;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  const int HC = heads * channels;
+  const float scale = 1.0f / sqrtf((float)channels);
+#define GIGL_TR_BWD(VV)                                                                                                \
+  hipLaunchKernelGGL((transformer_edge_backward_kernel<VV>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, q, k,  \
+                     v, edge_rows, rowptr, rowend, col, n_rows_dev, HC, group, scale, out, dout, dq, dk, dv, dedge_rows)
+  if (V == 1) GIGL_TR_BWD(1);
+  else if (V == 2) GIGL_TR_BWD(2);
+  else GIGL_TR_BWD(4);
+#undef GIGL_TR_BWD
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}

@@ -787,6 +787,26 @@ class HipEngine:
                                                      p(dee), p(deps)), self._ctx)
         return dx, dee, deps
 
+    def transformer_aggregate_edge(self, q, k, v, edge_rows, heads: int, channels: int, u, n_rows_dev) -> torch.Tensor:
+        """TransformerConv attention with edge rows (gigl_transformer_aggregate_edge) over the CSR view `u`"""
+        rows = int(q.shape[0])
+        out = torch.zeros((rows, heads * channels), dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(self._lib.gigl_transformer_aggregate_edge(self._ctx, p(q), p(k), p(v), p(edge_rows), heads, channels,
+                                                        p(u.rowptr), p(u.rowend), p(u.col), p(n_rows_dev), rows, p(out)),
+              self._ctx)
+        return out
+
+    def transformer_aggregate_edge_backward(self, q, k, v, edge_rows, heads: int, channels: int, u, n_rows_dev, out, dout):
+        """-> (dq, dk, dv, dedge_rows)"""
+        dout = dout.contiguous()
+        dq, dk, dv, dxe = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v), torch.zeros_like(edge_rows)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(self._lib.gigl_transformer_aggregate_edge_backward(
+            self._ctx, p(q), p(k), p(v), p(edge_rows), heads, channels, p(u.rowptr), p(u.rowend), p(u.col), p(n_rows_dev),
+            int(q.shape[0]), p(out), p(dout), p(dq), p(dk), p(dv), p(dxe)), self._ctx)
+        return dq, dk, dv, dxe
+
     def gatv2_aggregate(self, xl: torch.Tensor, xr: torch.Tensor, att: torch.Tensor, heads: int, channels: int, u,
                         n_rows_dev: torch.Tensor, bias: Optional[torch.Tensor], negative_slope: float = 0.2,
                         act: int = 0, edge_rows: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -13,7 +13,8 @@ No new kernels: a GIN layer is the segmented SUM + projection of a SAGE layer wi
 layer is three projections + the dot-product attention reduce of HGTConv with one edge type (gigl_hgt_aggregate and
 its backward).  GATv2 (homogeneous.py:346-386) has its own kernels (csrc/gatv2.hip: the logit is a C-wide pass per edge).
 GINE (homogeneous.py:252-297) adds gigl_gine_aggregate (messages relu(x_j + lin(e_ji))).
-GATv2(edge_dim) adds lin_edge(e) inside the logit's leaky_relu.  Not built: edge features for TransformerConv.
+GATv2(edge_dim) adds lin_edge(e) inside the logit's leaky_relu; Transformer(edge_dim) adds it to the keys and values
+(gigl_transformer_aggregate_edge).
 
   DCNv2 / DCNCross  python/gigl/src/common/models/layers/feature_interaction.py:7-155 — the feature-interaction layer
 BasicHomogeneousGNN applies to the node features before the first conv (`feature_interaction_layer=`): x_{i+1} =
@@ -262,14 +263,32 @@ class GINE(GIN):
             return self._head(h)
 
 
+class _TransformerEdgeAggFn(torch.autograd.Function):
+    """gigl_transformer_aggregate_edge / its backward over a CSR view (rowptr / rowend / col)"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, xe, eng, view, n_dev, heads, channels):
+        q, k, v, xe = q.contiguous(), k.contiguous(), v.contiguous(), xe.contiguous()
+        out = eng.transformer_aggregate_edge(q, k, v, xe, heads, channels, view, n_dev)
+        ctx.save_for_backward(q, k, v, xe, out)
+        ctx.meta = (eng, view, n_dev, heads, channels)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, xe, out = ctx.saved_tensors
+        eng, view, n_dev, heads, channels = ctx.meta
+        dq, dk, dv, dxe = eng.transformer_aggregate_edge_backward(q, k, v, xe, heads, channels, view, n_dev, out, dout)
+        return dq, dk, dv, dxe, None, None, None, None, None
+
+
 class TransformerConv(nn.Module):
-    """parameter holder with PyG TransformerConv's layout (lin_key / lin_query / lin_value / lin_skip / lin_beta)"""
+    """parameter holder with PyG TransformerConv's layout (lin_key / lin_query / lin_value / lin_skip / lin_beta; with
+    edge_dim also lin_edge, no bias: added to the keys and to the values of every edge)"""
 
     def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True, beta: bool = False,
                  bias: bool = True, root_weight: bool = True, edge_dim: Optional[int] = None, dropout: float = 0.0):
         super().__init__()
-        if edge_dim is not None:
-            raise NotImplementedError("TransformerConv edge features (edge_dim) are not built")
         if dropout:
             raise NotImplementedError("TransformerConv attention dropout is not built")
         self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
@@ -278,18 +297,26 @@ class TransformerConv(nn.Module):
         self.lin_key = nn.Linear(in_channels, hc)
         self.lin_query = nn.Linear(in_channels, hc)
         self.lin_value = nn.Linear(in_channels, hc)
+        self.lin_edge = nn.Linear(edge_dim, hc, bias=False) if edge_dim is not None else None
         out_w = hc if concat else out_channels
         self.lin_skip = nn.Linear(in_channels, out_w, bias=bias) if root_weight else None
         self.lin_beta = nn.Linear(3 * out_w, 1, bias=False) if self.beta else None
 
-    def forward(self, x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, eng: HipEngine) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, eng: HipEngine,
+                edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:
         from .models_hetero import _HgtAggFn
         n, H, C = int(x.shape[0]), self.heads, self.out_channels
         q = _linear(eng, x, self.lin_query.weight, self.lin_query.bias)
         k = _linear(eng, x, self.lin_key.weight, self.lin_key.bias)
         v = _linear(eng, x, self.lin_value.weight, self.lin_value.bias)
-        p_rel = torch.ones((1, H), dtype=torch.float32, device=x.device)
-        out = _HgtAggFn.apply(q, k, v, p_rel, eng, H, C, rowptr, col, None, n)
+        if self.lin_edge is not None:
+            from types import SimpleNamespace
+            xe = _linear(eng, edge_attr, self.lin_edge.weight, None)
+            view = SimpleNamespace(rowptr=rowptr, rowend=rowptr[1:], col=col)
+            out = _TransformerEdgeAggFn.apply(q, k, v, xe, eng, view, dev_rows(x), H, C)
+        else:
+            p_rel = torch.ones((1, H), dtype=torch.float32, device=x.device)
+            out = _HgtAggFn.apply(q, k, v, p_rel, eng, H, C, rowptr, col, None, n)
         if not self.concat:
             out = out.view(n, H, C).mean(1)
         if self.lin_skip is not None:
@@ -316,7 +343,7 @@ class Transformer(GraphSAGE):
         heads = int(ck.get("heads", 1))
         super().__init__(in_dim, hid_dim, out_dim, num_layers=num_layers, **kwargs)
         last = hid_dim if (self.linear_layer or self.jk_layer is not None) else out_dim
-        self.heads = heads
+        self.heads, self.edge_dim = heads, edge_dim
         self.conv_layers = nn.ModuleList([
             TransformerConv(in_dim if i == 0 else hid_dim * heads, hid_dim if i < num_layers - 1 else last,
                             heads=heads if i < num_layers - 1 else 1, concat=bool(ck.get("concat", True)),
@@ -327,10 +354,11 @@ class Transformer(GraphSAGE):
             self.batchnorm_layers = nn.ModuleList([nn.BatchNorm1d(hid_dim * heads)
                                                    for _ in range(len(self.batchnorm_layers))])
 
-    def _layers(self, x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, eng: HipEngine) -> torch.Tensor:
+    def _layers(self, x: torch.Tensor, rowptr: torch.Tensor, col: torch.Tensor, eng: HipEngine,
+                edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:
         h, xs = x, []
         for l, conv in enumerate(self.conv_layers):
-            h = self._post(conv(h, rowptr, col, eng), l, False)
+            h = self._post(conv(h, rowptr, col, eng, edge_attr), l, False)
             xs.append(h)
         if self.jk_layer is not None:
             h = self.jk_layer(xs)
@@ -345,7 +373,14 @@ class Transformer(GraphSAGE):
             eng = engine or getattr(self, "engine", None)
             if eng is None:
                 raise RuntimeError("Transformer.forward(GraphData) needs the HipEngine (model.engine = eng)")
-            return self._layers(self._interact(batch.x, eng), batch.rowptr, batch.col, eng)
+            ea = None
+            if self.edge_dim is not None:
+                if batch.edge_attr_csr is None:
+                    raise ValueError(f"the model was built with edge_dim={self.edge_dim} but the batch has no edge features")
+                ea = batch.edge_attr_csr
+                if ea.shape[0] != batch.col.numel():  # edgeless batch: col holds one padding entry
+                    ea = torch.zeros((batch.col.numel(), self.edge_dim), dtype=torch.float32, device=batch.x.device)
+            return self._layers(self._interact(batch.x, eng), batch.rowptr, batch.col, eng, ea)
         with torch.no_grad():
             eng, u = batch.engine, batch.union
             cap = int(u.nodes.numel())
@@ -361,12 +396,17 @@ class Transformer(GraphSAGE):
             e = int(rowptr[-1].item())
             pos = torch.arange(e, device=deg.device)
             row = torch.searchsorted(rowptr[1:], pos, right=True)
-            col = u.col[(u.rowptr.to(torch.int64)[row] + (pos - rowptr[row]))].to(torch.int32).contiguous()
+            at = u.rowptr.to(torch.int64)[row] + (pos - rowptr[row])  # positions in the union's col
+            col = u.col[at].to(torch.int32).contiguous()
+            ea = None
+            if self.edge_dim is not None:
+                ea_all = batch.edge_attr if batch.edge_attr is not None else eng.union_edge_attr(u)
+                ea = ea_all[at].contiguous() if e else torch.zeros((1, self.edge_dim), device=deg.device)
             if e == 0:
                 col = torch.zeros(1, dtype=torch.int32, device=deg.device)
             x = torch.where((torch.arange(cap, device=x.device) < n_nodes.to(torch.int64))[:, None], x, torch.zeros_like(x))
             x = self._interact(x, eng)
-            return self._layers(x.contiguous(), rowptr.to(torch.int32).contiguous(), col, eng)
+            return self._layers(x.contiguous(), rowptr.to(torch.int32).contiguous(), col, eng, ea)
 
     def make_plan(self, *args, **kwargs):
         raise NotImplementedError("the one-call plan computes GraphSAGE layers only; use forward(HipBatch)")

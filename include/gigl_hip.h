@@ -622,6 +622,25 @@ int32_t gigl_gatv2_aggregate_edge_backward(gigl_ctx* ctx, const float* xl, const
                                            const float* dout, const float* edge_rows, float* dxl, float* dxr,
                                            float* datt, float* dedge_rows);
 
+/* TransformerConv attention with edge features (PyG 2.5.3 TransformerConv(edge_dim) as configured by
+ * Transformer.init_conv_layers, homogeneous.py:440-487): q / k / v = lin_query / lin_key / lin_value rows fp32
+ * [nodes][heads*channels], edge_rows = lin_edge(edge_attr) [edges][H*C] in the CSR's edge order;
+ *   alpha_e = softmax over the in-edges of i of <q_i, k_j + edge_rows_e> / sqrt(channels),
+ *   out[i] = sum_e alpha_e (v_j + edge_rows_e)   (no self loops are added; 0 for a row without in-edges).
+ * Shapes as gigl_gatv2_aggregate.  Backward: dq [rows_cap][H*C] and dedge_rows [edges][H*C] are written (rows <
+ * *n_rows_dev / their edges), dk and dv [nodes][H*C] ACCUMULATED into (zero them first).  Without edge features the
+ * layer is gigl_hgt_aggregate with one edge type. */
+int32_t gigl_transformer_aggregate_edge(gigl_ctx* ctx, const float* q, const float* k, const float* v,
+                                        const float* edge_rows, int32_t heads, int32_t channels, const int32_t* rowptr,
+                                        const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
+                                        int64_t rows_cap, float* out);
+int32_t gigl_transformer_aggregate_edge_backward(gigl_ctx* ctx, const float* q, const float* k, const float* v,
+                                                 const float* edge_rows, int32_t heads, int32_t channels,
+                                                 const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                                 const int32_t* n_rows_dev, int64_t rows_cap, const float* out,
+                                                 const float* dout, float* dq, float* dk, float* dv,
+                                                 float* dedge_rows);
+
 /* GINEConv aggregation (PyG 2.5.3 GINEConv as configured by GINE.init_conv_layers, homogeneous.py:252-297):
  *   out[i] = (1 + *eps) x[i] + sum over the in-edges e = (j -> i) of relu(x[j] + edge_rows[e]),
  * x: fp32 [nodes][d], edge_rows: fp32 [edges][d] = lin(edge_attr) in the CSR's edge order (`col` positions), eps: DEVICE

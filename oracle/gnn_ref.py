@@ -244,7 +244,7 @@ def gin_conv(x: torch.Tensor, edge_index: torch.Tensor, w0: torch.Tensor, b0: to
 
 
 def transformer_conv(x: torch.Tensor, edge_index: torch.Tensor, p, heads: int, channels: int, concat: bool = True,
-                     root_weight: bool = True, beta: bool = False) -> torch.Tensor:
+                     root_weight: bool = True, beta: bool = False, edge_attr: Optional[torch.Tensor] = None) -> torch.Tensor:
     """PyG 2.5.3 TransformerConv without edge features (Transformer.init_conv_layers, homogeneous.py:440-487):
     alpha_ij = softmax_j(<W_q x_i + b_q, W_k x_j + b_k> / sqrt(C)) over the in-edges of i (no self loops are added),
     out_i = sum_j alpha_ij (W_v x_j + b_v), heads concatenated or averaged, + lin_skip(x_i) (beta: gated).
@@ -254,10 +254,14 @@ def transformer_conv(x: torch.Tensor, edge_index: torch.Tensor, p, heads: int, c
     q = (x @ p["lin_query.weight"].T + p["lin_query.bias"]).view(n, heads, channels)
     k = (x @ p["lin_key.weight"].T + p["lin_key.bias"]).view(n, heads, channels)
     v = (x @ p["lin_value.weight"].T + p["lin_value.bias"]).view(n, heads, channels)
-    logits = (q[dst] * k[src]).sum(-1) / (channels ** 0.5)
+    kj, vj = k[src], v[src]
+    if edge_attr is not None:  # lin_edge(e) (no bias) joins the keys and the values of every edge
+        e = (edge_attr @ p["lin_edge.weight"].T).view(-1, heads, channels)
+        kj, vj = kj + e, vj + e
+    logits = (q[dst] * kj).sum(-1) / (channels ** 0.5)
     alpha = _segment_softmax(logits, dst, n)
     out = torch.zeros((n, heads, channels), dtype=x.dtype)
-    out.index_add_(0, dst, v[src] * alpha.unsqueeze(-1))
+    out.index_add_(0, dst, vj * alpha.unsqueeze(-1))
     out = out.reshape(n, heads * channels) if concat else out.mean(1)
     if root_weight:
         xr = x @ p["lin_skip.weight"].T

@@ -441,3 +441,49 @@ def test_gatv2_with_edge_features_gradients(heads, hid, out, share):
                                    atol=1e-4 * float(xr.grad.abs().max()))
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("heads,hid,out,beta", [(2, 16, 32, False), (4, 32, 16, True)])
+def test_transformer_with_edge_features_gradients(heads, hid, out, beta):
+    """TransformerConv(edge_dim): lin_edge(e) joins the keys and the values of every edge
+    (gigl_transformer_aggregate_edge); forward and every gradient against torch autograd through the restatement"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models_more import Transformer
+    from gigl_amd.nn import GraphData
+    rng = np.random.default_rng(heads + 60)
+    n, d, de = 230, 12, 5
+    ei, x = _graph(rng, n, 1600, d)
+    ea = torch.from_numpy(rng.standard_normal((ei.shape[1], de)).astype(np.float32))
+    eng = HipEngine(0)
+    try:
+        torch.manual_seed(8)
+        model = Transformer(d, hid, out, num_layers=2, heads=heads, beta=beta, edge_dim=de).to(eng.device).train()
+        model.engine = eng
+        g = GraphData(x=x.clone(), edge_index=ei, edge_attr=ea).to(eng.device)
+        g.x.requires_grad_(True)
+        wsum = torch.from_numpy(rng.standard_normal((n, out)).astype(np.float32))
+        y = model(g)
+        (y * wsum.to(eng.device)).sum().backward()
+        ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+        xr = x.clone().requires_grad_(True)
+        h = xr
+        for l in range(2):
+            pre = f"conv_layers.{l}."
+            p = {k[len(pre):]: v for k, v in ref.items() if k.startswith(pre)}
+            h = gnn_ref.transformer_conv(h, ei, p, heads if l == 0 else 1, hid if l == 0 else out, beta=beta, edge_attr=ea)
+            if l == 0:
+                h = torch.relu(h)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), h.detach().numpy(), rtol=1e-5, atol=1e-5)
+        (h * wsum).sum().backward()
+        floor = 1e-4 * max(float(ref[k].grad.abs().max()) for k, _ in model.named_parameters())
+        assert "conv_layers.0.lin_edge.weight" in dict(model.named_parameters())
+        for name, prm in model.named_parameters():
+            want = ref[name].grad
+            assert prm.grad is not None and want is not None, name
+            scale = float(want.abs().max()) + 1e-6
+            np.testing.assert_allclose(prm.grad.cpu().numpy(), want.numpy(), rtol=1e-4,
+                                       atol=max(1e-4 * scale, floor if "lin_key.bias" in name else 0.0), err_msg=name)
+        np.testing.assert_allclose(g.x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4,
+                                   atol=1e-4 * float(xr.grad.abs().max()))
+    finally:
+        eng.close()
