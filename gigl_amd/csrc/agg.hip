@@ -508,7 +508,7 @@ __device__ __forceinline__ void split_store(const float4_t v, short* p1, short* 
   *reinterpret_cast<uint2*>(p3) = make_uint2((a3[0] >> 16) | a3[1], (a3[2] >> 16) | a3[3]);
 }
 
-template <int NJ>
+template <int NJ, bool KVEC = true>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
 __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            const int32_t* __restrict__ m_dev, int K, int N, int act,
@@ -559,6 +559,7 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
 
   // loaders: thread -> rows (tid >> 3) + 32 i, k segment (tid & 7) * 4 .. +4 (128-byte row pieces per 8 lanes)
   const int lr = tid >> 3, lc = tid & 7;
+  constexpr bool k_vec = KVEC;
   // operands of TWO chunks ahead stay in flight in registers (a chunk's MFMAs are shorter than a global load under load)
   float4_t ga[2][4], gw[2][2 * NJ];
   auto gload = [&](int k0, float4_t (&da)[4], float4_t (&dw)[2 * NJ]) {
@@ -569,12 +570,23 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
     for (int i = 0; i < 4; ++i) {
       const int row = m0b + lr + 32 * i;
       const float* src = a_tiled ? at + (lr + 32 * i) * 32 : a + (int64_t)row * K + kk;
-      da[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(src) : zero4;
+      if constexpr (k_vec) {
+        da[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(src) : zero4;
+      } else {  // K % 4 != 0: rows are not 16-byte aligned and the last segment is partial — element loads
+#pragma unroll
+        for (int t = 0; t < 4; ++t) da[i][t] = (row < M && kk + t < K) ? src[t] : 0.f;
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2 * NJ; ++i) {
       const int row = n0b + lr + 32 * i;
-      dw[i] = (row < N && kk < K) ? *reinterpret_cast<const float4_t*>(w + (int64_t)row * K + kk) : zero4;
+      const float* src = w + (int64_t)row * K + kk;
+      if constexpr (k_vec) {
+        dw[i] = (row < N && kk < K) ? *reinterpret_cast<const float4_t*>(src) : zero4;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dw[i][t] = (row < N && kk + t < K) ? src[t] : 0.f;
+      }
     }
   };
   auto chunk = [&](int k0, float4_t (&ra)[4], float4_t (&rw)[2 * NJ]) {
@@ -2192,14 +2204,22 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
   static const bool exact_only = getenv("GIGL_LINEAR_EXACT") != nullptr;  // (test / comparison knob)
   // (which kernel runs depends on k alone — never on the row count: the rows of a batch must come out bit-identical
   // whether the batch is computed alone or inside a group of batches)
-  if ((k & 3) == 0 && !exact_only) {  // split-precision bf16 MFMA (fp32-class accuracy)
+  if (!exact_only) {  // split-precision bf16 MFMA (fp32-class accuracy); K % 4 != 0: the element-load instantiation
     const int64_t bm = (m_cap + 127) / 128;
-    if (n > 64)
-      hipLaunchKernelGGL((linear_split_kernel<2>), dim3((unsigned)(bm * ((n + 127) / 128))), dim3(256), 0, st, a, w,
-                         bias, m_dev, k, n, act, y, 0, 0, (int64_t)0, (int64_t)0);
+    const bool kv = (k & 3) == 0;
+    const dim3 g2((unsigned)(bm * ((n + 127) / 128))), g1((unsigned)(bm * ((n + 63) / 64)));
+    if (n > 64 && kv)
+      hipLaunchKernelGGL((linear_split_kernel<2, true>), g2, dim3(256), 0, st, a, w, bias, m_dev, k, n, act, y, 0, 0,
+                         (int64_t)0, (int64_t)0);
+    else if (n > 64)
+      hipLaunchKernelGGL((linear_split_kernel<2, false>), g2, dim3(256), 0, st, a, w, bias, m_dev, k, n, act, y, 0, 0,
+                         (int64_t)0, (int64_t)0);
+    else if (kv)
+      hipLaunchKernelGGL((linear_split_kernel<1, true>), g1, dim3(256), 0, st, a, w, bias, m_dev, k, n, act, y, 0, 0,
+                         (int64_t)0, (int64_t)0);
     else
-      hipLaunchKernelGGL((linear_split_kernel<1>), dim3((unsigned)(bm * ((n + 63) / 64))), dim3(256), 0, st, a, w,
-                         bias, m_dev, k, n, act, y, 0, 0, (int64_t)0, (int64_t)0);
+      hipLaunchKernelGGL((linear_split_kernel<1, false>), g1, dim3(256), 0, st, a, w, bias, m_dev, k, n, act, y, 0, 0,
+                         (int64_t)0, (int64_t)0);
   } else if ((k & 3) == 0) {  // LDS-staged, coalesced operand fetch
     const int64_t bm = (m_cap + 127) / 128;
     if (n > 32) {
