@@ -835,6 +835,9 @@ def run_gat_lp(args, rank, world, local_rank):
     torch.cuda.empty_cache()
     torch.manual_seed(0)
     model = GAT(d, hid, out_dim, num_layers=L, heads=heads).to(dev)
+    if os.environ.get("GIGL_BENCH_GAT_FIRST_LAYER"):  # (A/B knob: "fused" | "0" = projection first)
+        v = os.environ["GIGL_BENCH_GAT_FIRST_LAYER"]
+        model.input_side_first_layer = False if v == "0" else v
     torch.cuda.synchronize()
     st = torch.cuda.Stream(device=dev)  # (the resident data was written on torch's default stream)
     eng.bind_stream(st)

@@ -1198,6 +1198,130 @@ __global__ __launch_bounds__(256) void gat_input_gather_kernel(
   }
 }
 
+// ---- the same first layer in ONE row pass (the one-call plan's layer 0): a wave owns a destination row, holds the
+// source-side folded vectors in registers, and forms every edge's logit from the feature row it has just read for the
+// aggregation (a 64-lane reduction per head and edge), online softmax over the row.  No per-node score array exists,
+// so the sources need no dense numbering: rows >= *n_local_dev hold GLOBAL source ids in `col` (the leaf-global union
+// of the plan: pure leaves are never relabelled), rows below it local ids translated through gather_ids.  Every source
+// row is read once per edge it appears in; z is written in the projection's tiled layout, one operand per head.
+template <typename T, int P, int H>
+__global__ __launch_bounds__(256) void gat_input_online_kernel(
+    const T* __restrict__ src, int d, const uint32_t* __restrict__ gather_ids, const int32_t* __restrict__ n_local_dev,
+    const float* __restrict__ u, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
+    const int32_t* __restrict__ col, const int32_t* __restrict__ n_rows_dev, float slope, int nkc, int64_t head_stride,
+    float* __restrict__ z) {
+  constexpr int U = 4;  // feature rows in flight
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int n_rows = *n_rows_dev;
+  const int n_local = n_local_dev ? *n_local_dev : 0x7FFFFFFF;
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto leaky = [&](float v) { return v > 0.f ? v : slope * v; };
+  auto wsum = [](float v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  };
+  auto dotp = [](const float4_t (&a)[P], const float4_t (&b)[P]) {
+    float r = 0.f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) r += a[p].x * b[p].x + a[p].y * b[p].y + a[p].z * b[p].z + a[p].w * b[p].w;
+    return r;
+  };
+  float4_t us[H][P];
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int el = (p * 64 + lane) * 4;
+      us[h][p] = el < d ? *reinterpret_cast<const float4_t*>(u + (int64_t)h * d + el) : zero4;
+    }
+  auto load_row = [&](uint32_t gid, float4_t (&x)[P]) {
+    const T* row = src + (int64_t)gid * d;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int el = (p * 64 + lane) * 4;
+      x[p] = el < d ? RowLoader<T>::load4(row, el) : zero4;
+    }
+  };
+  for (int i = wave; i < n_rows; i += waves_total) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    const uint32_t self_gid = gather_ids[i];
+    const bool local = i < n_local;
+    float sd[H], mx[H], den[H];
+    float4_t acc[H][P];
+    {
+      float4_t xs[P];
+      load_row(self_gid, xs);
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float4_t ud[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+          const int el = (p * 64 + lane) * 4;
+          ud[p] = el < d ? *reinterpret_cast<const float4_t*>(u + (int64_t)(H + h) * d + el) : zero4;
+        }
+        sd[h] = wsum(dotp(xs, ud));
+        mx[h] = leaky(wsum(dotp(xs, us[h])) + sd[h]);  // the self loop opens the running softmax with weight 1
+        den[h] = 1.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[h][p] = xs[p];
+      }
+    }
+    for (int c0 = 0; c0 < m; c0 += 64) {
+      const int mm = min(64, m - c0);
+      uint32_t gid = self_gid;  // (lanes past the row and self loops among the edges: skipped below)
+      bool take = false;
+      if (lane < mm) {
+        const int j = col[e0 + c0 + lane];
+        if (local) {
+          take = j != i;
+          gid = gather_ids[j];
+        } else {
+          gid = (uint32_t)j;
+          take = gid != self_gid;
+        }
+      }
+      const unsigned long long keep = __ballot(take);
+      for (int e = 0; e < mm; e += U) {
+        float4_t x[U][P];
+        bool on[U];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          on[t] = e + t < mm && ((keep >> (e + t)) & 1ull);  // (wave-uniform)
+          const uint32_t g = __shfl(gid, (e + t) & 63, 64);
+          if (on[t]) load_row(g, x[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          if (!on[t]) continue;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const float zl = leaky(wsum(dotp(x[t], us[h])) + sd[h]);
+            const float nm = fmaxf(mx[h], zl);
+            const float sc = __expf(mx[h] - nm), pw = __expf(zl - nm);
+            den[h] = den[h] * sc + pw;
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[h][p] = acc[h][p] * sc + pw * x[t][p];
+            mx[h] = nm;
+          }
+        }
+      }
+    }
+    float* tbase = z + ((int64_t)(i >> 7) * nkc) * 4096 + (i & 127) * 32;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float inv = 1.0f / den[h];
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int el = (p * 64 + lane) * 4;
+        if (el < d)
+          *reinterpret_cast<float4_t*>(tbase + h * head_stride + (int64_t)(el >> 5) * 4096 + (el & 31)) = acc[h][p] * inv;
+      }
+    }
+  }
+}
+
 // ---- fast GAT path: one wave per row, every lane owns V float4 chunks of the H*C-wide row (chunk q = v*64 + lane
 // covers channels [4q, 4q+4), all inside one head because C % 4 == 0), so all heads advance together and each source
 // row is read exactly once, coalesced.  Shapes: C/4 a power of two <= 64 (a head = C/4 adjacent lanes of one chunk
@@ -2342,4 +2466,65 @@ int32_t gigl_gat_input_layer(gigl_ctx* ctx, const void* src, int32_t src_dtype, 
   // the heads' projections in one launch (grid.y = head): z_h [rows][d] (tiled) x W_h^T -> columns [h*C, +C) of out
   return linear_tiled_strided(ctx, z, w, bias, n_rows_dev, rows_cap, d, C, act, out, H * C, H, head_stride,
                               (int64_t)C * d);
+}
+
+int64_t gigl_gat_input_layer_fused_scratch(int32_t d, int32_t heads, int64_t rows_cap) {
+  const int64_t nkc = (d + 31) / 32, row_tiles = (rows_cap + 127) / 128;
+  return (int64_t)heads * row_tiles * nkc * 4096 + (int64_t)2 * heads * d;
+}
+
+int32_t gigl_gat_input_layer_fused(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
+                                   const uint32_t* gather_ids, const int32_t* n_local_dev, const float* w,
+                                   const float* att_src, const float* att_dst, int32_t heads, int32_t channels,
+                                   float negative_slope, const int32_t* rowptr, const int32_t* rowend,
+                                   const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
+                                   int32_t act, float* scratch, float* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, src && gather_ids && w && att_src && att_dst && rowptr && rowend && col && n_rows_dev && scratch && out,
+               "null argument");
+  GIGL_REQUIRE(ctx, d > 0 && heads > 0 && channels > 0 && rows_cap >= 0, "bad sizes");
+  GIGL_REQUIRE(ctx, src_dtype == GIGL_DTYPE_F32 || src_dtype == GIGL_DTYPE_F16, "bad dtype %d", src_dtype);
+  GIGL_REQUIRE(ctx, act == 0 || act == 1, "bad act %d", act);
+  const int P = (d + 255) / 256;
+  if ((d & 3) || (heads != 1 && heads != 2 && heads != 4) || P > 4 || heads * P > 8)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "gigl_gat_input_layer_fused: d=%d heads=%d outside the built shapes (d %% 4 "
+                     "== 0, d <= 1024, heads 1|2|4, heads*ceil(d/256) <= 8)", d, heads);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  hipStream_t st = ctx->stream;
+  const int H = heads, C = channels;
+  const int nkc = (d + 31) / 32;
+  const int64_t row_tiles = (rows_cap + 127) / 128, head_stride = row_tiles * nkc * 4096;
+  float* z = scratch;  // (first: 16-byte aligned)
+  float* u = z + H * head_stride;
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+    hipLaunchKernelGGL(gat_fold_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)(2 * H)), dim3(256), 0, st, w, att_src,
+                       att_dst, H, C, d, u);
+    int64_t blocks = (rows_cap + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+#define GIGL_GAT_ON(TT, PP, HH)                                                                                         \
+  hipLaunchKernelGGL((gat_input_online_kernel<TT, PP, HH>), dim3((unsigned)blocks), dim3(256), 0, st, (const TT*)src,  \
+                     d, gather_ids, n_local_dev, u, rowptr, rowend, col, n_rows_dev, negative_slope, nkc, head_stride, z)
+#define GIGL_GAT_ON_P(TT, HH)                                                                                           \
+  do {                                                                                                                  \
+    if (P == 1) GIGL_GAT_ON(TT, 1, HH);                                                                                 \
+    else if (P == 2) GIGL_GAT_ON(TT, 2, HH);                                                                            \
+    else if (P == 3) GIGL_GAT_ON(TT, (HH * 3 <= 8 ? 3 : 1), HH);                                                        \
+    else GIGL_GAT_ON(TT, (HH * 4 <= 8 ? 4 : 1), HH);                                                                    \
+  } while (0)
+#define GIGL_GAT_ON_H(TT)                                                                                               \
+  do {                                                                                                                  \
+    if (H == 1) GIGL_GAT_ON_P(TT, 1);                                                                                   \
+    else if (H == 2) GIGL_GAT_ON_P(TT, 2);                                                                              \
+    else GIGL_GAT_ON_P(TT, 4);                                                                                          \
+  } while (0)
+    if (src_dtype == GIGL_DTYPE_F32) GIGL_GAT_ON_H(float);
+    else GIGL_GAT_ON_H(__half);
+#undef GIGL_GAT_ON_H
+#undef GIGL_GAT_ON_P
+#undef GIGL_GAT_ON
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+  }
+  return linear_tiled_strided(ctx, z, w, bias, n_rows_dev, rows_cap, d, C, act, out, H * C, H, head_stride, (int64_t)C * d);
 }

@@ -37,6 +37,16 @@ struct gigl_sage_plan {
   const float* w[GIGL_MAX_HOPS] = {nullptr};     // fused [dims[l+1]][2*dims[l]] (= [W_l | W_r]), device, borrowed
   const float* bias[GIGL_MAX_HOPS] = {nullptr};  // device, borrowed, may be null
   int32_t act_last = 0;
+  // kind 1: GAT layers instead of SAGE layers (gigl_gat_plan_create): w[l] = lin weight [heads*channels][dims[l]],
+  // layer 0 from the input side in one row pass (gigl_gat_input_layer_fused), layers >= 1 projection + attention
+  int32_t kind = 0;
+  int32_t heads[GIGL_MAX_HOPS] = {0}, channels[GIGL_MAX_HOPS] = {0};
+  const float* att_src[GIGL_MAX_HOPS] = {nullptr};
+  const float* att_dst[GIGL_MAX_HOPS] = {nullptr};
+  float slope = 0.2f;
+  float* gat_scratch = nullptr;    // first layer: folded vectors + the per-head tiled operands
+  float* alpha_scratch = nullptr;  // layers >= 1: per-node attention dots [2 * act_rows * max heads]
+  float* hw = nullptr;             // layers >= 1: projected source rows [act_rows][max heads*channels]
   // leaf-global union (union.hip): pure leaves get no local id and stay global ids in their parents' rows — the
   // plan never computes anything for them, it only gathers their feature rows
   bool leaf_global = false;
@@ -194,6 +204,25 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
   for (int i = 0; i <= L - 1 - l; ++i) {
     rows_cap += width;
     width *= p->fanouts[i];
+  }
+  if (p->kind == 1) {
+    const int act = (l < L - 1 || p->act_last) ? 1 : 0;
+    const bool first = ((s - 2) & 1) == 0;
+    if (l == 0) {
+      if (!first) return GIGL_OK;  // (the first layer is one stage: aggregation + both heads' projection)
+      const int32_t* n_local = p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr;
+      return gigl_gat_input_layer_fused(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, n_local, p->w[0], p->att_src[0],
+                                        p->att_dst[0], p->heads[0], p->channels[0], p->slope, p->un.rowptr, p->un.rowend,
+                                        p->un.col, n_rows, rows_cap, p->bias[0], act, p->gat_scratch, p->hbuf[0]);
+    }
+    // sources of layer l: the rows layer l-1 computed (level <= L-l)
+    const int32_t* n_src = p->un.meta + GIGL_META_LEVEL0 + (L - l);
+    int64_t src_cap = rows_cap + width;
+    if (first)
+      return gigl_linear(ctx, p->hbuf[(l - 1) & 1], p->w[l], nullptr, n_src, src_cap, d, p->dims[l + 1], 0, p->hw);
+    return gigl_gat_aggregate(ctx, p->hw, p->att_src[l], p->att_dst[l], p->heads[l], p->channels[l], p->slope, 1,
+                              p->un.rowptr, p->un.rowend, p->un.col, n_src, src_cap, n_rows, rows_cap, p->bias[l], act,
+                              p->alpha_scratch, p->hbuf[l & 1]);
   }
   const int32_t nkc = p->tiled ? (2 * d + 31) / 32 : 0;
   if (((s - 2) & 1) == 0) {
@@ -395,6 +424,73 @@ int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat,
                      (long long)cap_nodes);
   }
   *out = p;
+  return GIGL_OK;
+}
+
+int32_t gigl_gat_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b, const int32_t* fanouts,
+                             int32_t hops, const int32_t* heads, const int32_t* channels, const float* const* w,
+                             const float* const* att_src, const float* const* att_dst, const float* const* bias,
+                             float negative_slope, int32_t act_last, gigl_sage_plan** out) {
+  if (!ctx || !out) return GIGL_E_INVALID_ARG;
+  *out = nullptr;
+  GIGL_REQUIRE(ctx, graph && feat && fanouts && heads && channels && w && att_src && att_dst, "null argument");
+  GIGL_REQUIRE(ctx, hops >= 1 && hops <= GIGL_MAX_HOPS && b >= 1, "bad plan shape");
+  int32_t dims[GIGL_MAX_HOPS + 1];
+  dims[0] = feat->d;
+  int32_t max_h = 1, max_hc = 1;
+  for (int l = 0; l < hops; ++l) {
+    GIGL_REQUIRE(ctx, heads[l] >= 1 && channels[l] >= 1 && att_src[l] && att_dst[l], "layer %d: bad heads / channels", l);
+    dims[l + 1] = heads[l] * channels[l];
+    if (heads[l] > max_h) max_h = heads[l];
+    if (dims[l + 1] > max_hc) max_hc = dims[l + 1];
+  }
+  const int P = (feat->d + 255) / 256;
+  if ((feat->d & 3) || (heads[0] != 1 && heads[0] != 2 && heads[0] != 4) || P > 4 || heads[0] * P > 8 ||
+      (feat->dtype != GIGL_DTYPE_F32 && feat->dtype != GIGL_DTYPE_F16))
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "GAT plan: feature dim %d / %d heads outside the shapes the first layer is "
+                     "built for (gigl_gat_input_layer_fused)", feat->d, heads[0]);
+  gigl_sage_plan* p = nullptr;
+  int32_t rc = gigl_sage_plan_create(ctx, graph, feat, b, fanouts, hops, dims, w, bias, act_last, &p);
+  if (rc != GIGL_OK) return rc;
+  p->kind = 1;
+  p->slope = negative_slope;
+  for (int l = 0; l < hops; ++l) {
+    p->heads[l] = heads[l];
+    p->channels[l] = channels[l];
+    p->att_src[l] = att_src[l];
+    p->att_dst[l] = att_dst[l];
+  }
+  auto alloc = [&](size_t bytes) -> void* {
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    p->owned.push_back(q);
+    return q;
+  };
+  p->gat_scratch = (float*)alloc((size_t)gigl_gat_input_layer_fused_scratch(feat->d, heads[0], p->act_rows) * 4);
+  p->alpha_scratch = (float*)alloc((size_t)2 * p->act_rows * max_h * 4);
+  p->hw = (float*)alloc((size_t)p->act_rows * max_hc * 4);
+  if (!p->gat_scratch || !p->alpha_scratch || !p->hw) {
+    gigl_sage_plan_destroy(p);
+    return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the GAT plan's workspace failed");
+  }
+  *out = p;
+  return GIGL_OK;
+}
+
+int32_t gigl_gat_plan_set_weights(gigl_sage_plan* p, const float* const* w, const float* const* att_src,
+                                  const float* const* att_dst, const float* const* bias) {
+  if (!p || !w || !att_src || !att_dst || p->kind != 1) return GIGL_E_INVALID_ARG;
+  for (int l = 0; l < p->hops; ++l) {
+    GIGL_REQUIRE(p->ctx, w[l] && att_src[l] && att_dst[l], "layer %d: null weight", l);
+    p->w[l] = w[l];
+    p->att_src[l] = att_src[l];
+    p->att_dst[l] = att_dst[l];
+    p->bias[l] = bias ? bias[l] : nullptr;
+  }
+  if (p->captured) {  // weight pointers are baked into the captured kernels
+    hipStreamSynchronize(p->ctx->stream);
+    drop_graphs(p);
+  }
   return GIGL_OK;
 }
 

@@ -836,6 +836,25 @@ class HipEngine:
             p(n_rows_dev), int(xr.shape[0]), p(out_pre), p(dout), p(edge_rows), p(dxl), p(dxr), p(datt), p(dxe)), self._ctx)
         return dxl, dxr, datt, dxe
 
+    def gat_input_layer_fused(self, ids: torch.Tensor, w: torch.Tensor, att_src: torch.Tensor, att_dst: torch.Tensor,
+                              heads: int, channels: int, u: "UnionGraph", n_rows_dev: torch.Tensor,
+                              bias: Optional[torch.Tensor], negative_slope: float = 0.2, act: int = 0,
+                              n_local_dev: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """gigl_gat_input_layer_fused (one pass, logits formed on the fly); None outside the built shapes"""
+        d, cap = self.feat_dim, int(u.nodes.numel())
+        if d % 4 or d > 1024 or heads not in (1, 2, 4) or heads * ((d + 255) // 256) > 8 or \
+                self.feat_dtype not in (DTYPE_F32, DTYPE_F16):
+            return None
+        n_scr = int(self._lib.gigl_gat_input_layer_fused_scratch(d, heads, cap))
+        scratch = torch.empty(n_scr, dtype=torch.float32, device=self.device)
+        out = torch.empty((cap, heads * channels), dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(self._lib.gigl_gat_input_layer_fused(
+            self._ctx, self._feat_ptr, self.feat_dtype, d, p(ids), p(n_local_dev), p(w), p(att_src), p(att_dst), heads,
+            channels, negative_slope, p(u.rowptr), p(u.rowend), p(u.col), p(n_rows_dev), cap, p(bias), act, p(scratch),
+            p(out)), self._ctx)
+        return out
+
     def gat_aggregate_backward(self, h: torch.Tensor, att_src: torch.Tensor, att_dst: torch.Tensor, heads: int,
                                channels: int, u, n_rows_dev: torch.Tensor, out_pre: torch.Tensor, dout: torch.Tensor,
                                negative_slope: float = 0.2, edge_attr: Optional[torch.Tensor] = None,
@@ -1081,3 +1100,43 @@ class SagePlan:
             self._plan = None
             if self in getattr(self.eng, "_plans", []):
                 self.eng._plans.remove(self)
+
+
+class GatPlan(SagePlan):
+    """sample -> union -> GAT forward -> one row per root, enqueued by ONE library call (gigl_gat_plan_create; the
+    handle is a gigl_sage_plan: run / use_graph / stats / last_batch_to_host are SagePlan's)"""
+
+    def __init__(self, eng: HipEngine, weights, att_src, att_dst, biases, heads, channels, b: int, fanouts,
+                 negative_slope: float = 0.2, act_last: bool = False, groups: int = 1):
+        assert eng._graph is not None and eng._feat is not None, "load the graph and the features first"
+        L = len(fanouts)
+        assert len(weights) == len(att_src) == len(att_dst) == len(heads) == len(channels) == L and groups >= 1
+        self.group_roots, self.groups = int(b), int(groups)
+        self.eng, self.b, self.fanouts = eng, int(b) * int(groups), [int(f) for f in fanouts]
+        self._lib = eng._lib
+        self.dims = [int(weights[0].shape[1])] + [int(h) * int(c) for h, c in zip(heads, channels)]
+        self._keep = None
+        self._plan = C.c_void_p()
+        arrs = self._gat_ptr_arrays(weights, att_src, att_dst, biases)
+        fo = (C.c_int32 * L)(*self.fanouts)
+        hd, ch = (C.c_int32 * L)(*[int(h) for h in heads]), (C.c_int32 * L)(*[int(c) for c in channels])
+        check(self._lib.gigl_gat_plan_create(eng._ctx, eng._graph, eng._feat, self.b, fo, L, hd, ch, *arrs,
+                                             float(negative_slope), 1 if act_last else 0, C.byref(self._plan)), eng._ctx)
+        if self.groups > 1:
+            check(self._lib.gigl_sage_plan_set_groups(self._plan, self.group_roots), eng._ctx)
+        if not hasattr(eng, "_plans"):
+            eng._plans = []
+        eng._plans.append(self)
+
+    def _gat_ptr_arrays(self, weights, att_src, att_dst, biases):
+        L = len(weights)
+        dev = lambda t: t.detach().to(device=self.eng.device, dtype=torch.float32).reshape(t.shape).contiguous()
+        ws, a_s, a_d = [dev(w) for w in weights], [dev(a.reshape(-1)) for a in att_src], [dev(a.reshape(-1)) for a in att_dst]
+        bs = [None if x is None else dev(x) for x in biases]
+        self._keep = (ws, a_s, a_d, bs)  # the plan borrows these device buffers
+        arr = lambda ts: (C.c_void_p * L)(*[(t.data_ptr() if t is not None else None) for t in ts])
+        return arr(ws), arr(a_s), arr(a_d), arr(bs)
+
+    def set_weights(self, weights, att_src, att_dst, biases) -> None:
+        check(self._lib.gigl_gat_plan_set_weights(self._plan, *self._gat_ptr_arrays(weights, att_src, att_dst, biases)),
+              self.eng._ctx)

@@ -291,9 +291,15 @@ class GAT(nn.Module):
                     and conv.in_channels > conv.heads * conv.out_channels:
                 # wide input rows: logits from folded attention vectors, projection after the aggregation
                 act = 1 if (L > 1 or self.activation_after_last_conv) else 0
-                h = eng.gat_input_layer(u.nodes, conv.lin.weight.contiguous(), conv.att_src.reshape(-1).contiguous(),
-                                        conv.att_dst.reshape(-1).contiguous(), conv.heads, conv.out_channels, u, n_src,
-                                        n_dst, conv.bias, negative_slope=conv.negative_slope, act=act)
+                if self.input_side_first_layer == "fused":  # one pass, logits on the fly (what the one-call plan runs)
+                    h = eng.gat_input_layer_fused(u.nodes, conv.lin.weight.contiguous(),
+                                                  conv.att_src.reshape(-1).contiguous(),
+                                                  conv.att_dst.reshape(-1).contiguous(), conv.heads, conv.out_channels, u,
+                                                  n_dst, conv.bias, negative_slope=conv.negative_slope, act=act)
+                else:
+                    h = eng.gat_input_layer(u.nodes, conv.lin.weight.contiguous(), conv.att_src.reshape(-1).contiguous(),
+                                            conv.att_dst.reshape(-1).contiguous(), conv.heads, conv.out_channels, u, n_src,
+                                            n_dst, conv.bias, negative_slope=conv.negative_slope, act=act)
                 if h is not None:
                     continue
             x = eng.gather_rows(u.nodes, n_src, cap) if l == 0 else h
@@ -311,6 +317,27 @@ class GAT(nn.Module):
         return eng.gat_aggregate(hw, conv.att_src.reshape(-1).contiguous(), conv.att_dst.reshape(-1).contiguous(),
                                  conv.heads, conv.out_channels, u, n_dst, conv.bias, concat=conv.concat,
                                  negative_slope=conv.negative_slope, act=act, **kw)
+
+    def make_plan(self, eng, b: int, fanouts, groups: int = 1):
+        """one-call pipeline (sample -> union -> this model's forward -> one row per root) for batches of `b` roots on
+        `eng` (engine.GatPlan); weights are snapshotted — plan.set_weights(*model.plan_params()) after updates.  The
+        first layer runs from the input side (gigl_gat_input_layer_fused): plain GATConv layers, heads concatenated."""
+        from .engine import GatPlan
+        assert len(fanouts) == self.num_layers, "one hop per layer"
+        if self.edge_dim is not None or any(not c.concat and c.heads > 1 for c in self.conv_layers) or \
+                self.should_l2_normalize_embedding_layer_output:
+            raise NotImplementedError("the one-call plan computes plain GATConv layers (no edge features, concatenated "
+                                      "heads, no output normalisation); use forward(HipBatch)")
+        w, a_s, a_d, bs = self.plan_params()
+        return GatPlan(eng, w, a_s, a_d, bs, [c.heads for c in self.conv_layers],
+                       [c.out_channels for c in self.conv_layers], b, fanouts,
+                       negative_slope=self.conv_layers[0].negative_slope, act_last=self.activation_after_last_conv,
+                       groups=groups)
+
+    def plan_params(self):
+        cs = self.conv_layers
+        return ([c.lin.weight.detach() for c in cs], [c.att_src.detach() for c in cs], [c.att_dst.detach() for c in cs],
+                [None if c.bias is None else c.bias.detach() for c in cs])
 
     def _forward_graph(self, g, eng) -> torch.Tensor:
         if eng is None:

@@ -572,6 +572,20 @@ int32_t gigl_gat_input_layer(gigl_ctx* ctx, const void* src, int32_t src_dtype, 
                              const int32_t* n_rows_dev, int64_t rows_cap, const float* bias, int32_t act,
                              float* scratch, float* out);
 
+/* gigl_gat_input_layer in ONE pass over the destination rows (the one-call plan's first GAT layer): every edge's logit is
+ * formed from the feature row as it is read for the aggregation (online softmax), so the sources need no dense
+ * numbering: rows >= *n_local_dev hold GLOBAL source ids in `col` (the leaf-global union of gigl_sage_plan), rows below
+ * it — all rows when n_local_dev is NULL — local ids translated through gather_ids (gather_ids[i] is also row i's own
+ * feature row).  Built shapes: d % 4 == 0, d <= 1024, heads in {1, 2, 4}, heads * ceil(d/256) <= 8.
+ * scratch: DEVICE fp32 [gigl_gat_input_layer_fused_scratch(d, heads, rows_cap)]. */
+int64_t gigl_gat_input_layer_fused_scratch(int32_t d, int32_t heads, int64_t rows_cap);
+int32_t gigl_gat_input_layer_fused(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
+                                   const uint32_t* gather_ids, const int32_t* n_local_dev, const float* w,
+                                   const float* att_src, const float* att_dst, int32_t heads, int32_t channels,
+                                   float negative_slope, const int32_t* rowptr, const int32_t* rowend,
+                                   const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
+                                   int32_t act, float* scratch, float* out);
+
 /* GATConv with edge features (edge_dim = De; GAT.init_conv_layers passes edge_dim, homogeneous.py:300-343) and
  * EdgeAttrGATConv (python/gigl/src/common/models/pyg/nn/conv/edge_attr_gat_conv.py:11-144):
  *   e_ij = leaky_relu(<h_j, att_src> + <h_i, att_dst> + <W_e e_ij, att_edge>); the added self loop carries the mean
@@ -764,6 +778,19 @@ int32_t gigl_sage_plan_stats(gigl_sage_plan* plan, const uint32_t* roots, int64_
  * graph/feature tables are baked into the captured kernels: call again (or set_weights + use_graph) after
  * changing them.  gigl_sage_plan_flush_profile folds the timing events of in-flight replays into
  * gigl_profile_read (synchronises). */
+/* The same one-call pipeline with GAT layers (GAT.init_conv_layers, homogeneous.py:300-343; no edge features):
+ * sample -> union -> layer 0 from the input side in one row pass (gigl_gat_input_layer_fused: the plan's leaf-global
+ * union needs no dense numbering of the leaves) -> layers >= 1 as projection + gigl_gat_aggregate -> one row per root.
+ * w[l]: lin weight [heads[l]*channels[l]][in_l] (in_0 = the feature dim, in_l = heads[l-1]*channels[l-1]: heads are
+ * concatenated), att_src / att_dst [heads[l]*channels[l]], bias[l] (may be NULL): DEVICE, borrowed.  The plan handle is
+ * a gigl_sage_plan: run / set_groups / use_graph / stats / buffers / destroy are the gigl_sage_plan_* calls.
+ * GIGL_E_UNSUPPORTED when the first layer's shape is outside gigl_gat_input_layer_fused's. */
+int32_t gigl_gat_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b, const int32_t* fanouts,
+                             int32_t hops, const int32_t* heads, const int32_t* channels, const float* const* w,
+                             const float* const* att_src, const float* const* att_dst, const float* const* bias,
+                             float negative_slope, int32_t act_last, gigl_sage_plan** out);
+int32_t gigl_gat_plan_set_weights(gigl_sage_plan* plan, const float* const* w, const float* const* att_src,
+                                  const float* const* att_dst, const float* const* bias);
 int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
 int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);

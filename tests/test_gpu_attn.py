@@ -129,6 +129,9 @@ def test_gat_first_layer_from_the_input_side(d, dtype, heads, hid):
         np.testing.assert_allclose(plain, ref, rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
         np.testing.assert_allclose(got, plain, rtol=2e-5, atol=2e-5)
+        model.input_side_first_layer = "fused"  # one pass, logits formed from the rows as they are read
+        fused = model(batch)[idx].cpu().numpy()
+        np.testing.assert_allclose(fused, ref, rtol=2e-5, atol=2e-5)
     finally:
         eng.close()
 
@@ -285,3 +288,63 @@ def test_two_layer_gcn_trains_over_a_batch_graph():
                                    err_msg=name)
     np.testing.assert_allclose(g.x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-4 * float(xr.grad.abs().max()))
     eng.close()
+
+
+@pytest.mark.parametrize("d,dtype,heads,hid,fan,groups", [(768, np.float16, 2, 128, [9, 6], 1), (320, np.float32, 4, 32, [7, 5], 3),
+                                                           (260, np.float32, 1, 16, [4, 3, 2], 1)])
+def test_gat_one_call_plan_matches_the_staged_forward(d, dtype, heads, hid, fan, groups):
+    """GAT.make_plan (gigl_gat_plan_create: sample -> leaf-global union -> first layer in one row pass -> projection +
+    attention layers -> one row per root, one library call, replayable as a HIP graph) == forward(HipBatch) over the
+    staged sample / union of the same roots, per group of roots"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import HipBatch
+    from gigl_amd.models_attn import GAT
+    s, t = rmat_edges(11, 30000, seed=7)
+    n = 1 << 11
+    s = np.concatenate([s, np.arange(0, 100, dtype=np.uint32)])
+    t = np.concatenate([t, np.arange(0, 100, dtype=np.uint32)])
+    rowptr, col = oracle.build_csc(n, s, t, is_directed=True)
+    x = (np.random.default_rng(d).standard_normal((n, d)) / 4).astype(dtype)
+    eng = HipEngine(0)
+    try:
+        eng.load_csc(rowptr, col)
+        eng.load_features(torch.from_numpy(x) if dtype == np.float16 else x)
+        torch.manual_seed(d)
+        L = len(fan)
+        model = GAT(d, hid, 24, num_layers=L, heads=heads).to(eng.device)
+        with torch.no_grad():
+            for c in model.conv_layers:
+                c.bias.normal_(0, 0.1)
+        b = 96
+        roots = np.random.default_rng(3).integers(0, n, size=b * groups).astype(np.uint32)
+        roots[5] = roots[6]  # a duplicated root inside a batch
+        plan = model.make_plan(eng, b, fan, groups=groups)
+        r_dev = torch.from_numpy(roots.view(np.int32)).to(eng.device)
+        got = plan.run(r_dev).cpu().numpy()
+        for gi in range(groups):
+            part = roots[gi * b:(gi + 1) * b]
+            tree = eng.sample_khop(part, fan)
+            u = eng.union_build(tree)
+            want = model(HipBatch(eng, tree, u))[u.root_local[:b].long()].cpu().numpy()
+            np.testing.assert_allclose(got[gi * b:(gi + 1) * b], want, rtol=2e-5, atol=2e-5)
+        st = torch.cuda.Stream(device=eng.device)  # (the legacy default stream cannot be captured)
+        torch.cuda.synchronize()
+        eng.bind_stream(st)
+        torch.cuda.set_stream(st)
+        try:
+            plan.use_graph(True)
+            again = plan.run(r_dev).cpu().numpy()   # captures
+            replay = plan.run(r_dev).cpu().numpy()  # replays
+            np.testing.assert_array_equal(again, got)
+            np.testing.assert_array_equal(replay, got)
+            with torch.no_grad():
+                model.conv_layers[0].att_src.mul_(0.5)
+            plan.set_weights(*model.plan_params())
+            changed = plan.run(r_dev).cpu().numpy()
+            assert np.abs(changed - got).max() > 1e-4
+        finally:
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(torch.cuda.default_stream(eng.device))
+            eng.bind_stream(None)
+    finally:
+        eng.close()
