@@ -789,6 +789,11 @@ def run_sharded(args, rank, world, local_rank):
     eng.close()
 
 
+def _lib_stats_len():
+    from gigl_amd._lib import STATS_LEN
+    return STATS_LEN
+
+
 def run_gat_lp(args, rank, world, local_rank):
     """BASELINE.json configs[4] / SURVEY.md 8(d) C5 on one GPU's share of the MAG240M-shaped graph (--shard-scale of
     it as a self-contained graph): link-prediction step of the GAT encoder — anchors + one positive each (sampled
@@ -854,6 +859,18 @@ def run_gat_lp(args, rank, world, local_rank):
     lvl = [GIGL_META_LEVEL0 + (L - 1 - l) for l in range(L)]
     setup_s = time.time() - t0
 
+    # The two encodes as one-call plans (GAT.make_plan: sample -> union -> layers -> one row per root in one library
+    # call each), G consecutive steps per call like the headline's batches_per_call (a step's batches stay independent:
+    # dedup, union and attention never cross a group); GIGL_BENCH_GAT_STAGED=1 keeps the per-stage entry points, one
+    # step per call.
+    plans, G = None, 1
+    if not os.environ.get("GIGL_BENCH_GAT_STAGED"):
+        G = max(1, int(os.environ.get("GIGL_BENCH_GAT_GROUPS", "32")))
+        while pool % G:
+            G -= 1
+        plans = (model.make_plan(eng, 2 * B, fanouts, groups=G), model.make_plan(eng, n_neg, fanouts, groups=G))
+        stats_acc = torch.zeros(_lib_stats_len(), dtype=torch.int64, device=dev)
+
     def encode(roots, count):
         tree = eng.sample_khop(roots, fanouts)
         u = eng.union_build(tree)
@@ -865,70 +882,81 @@ def run_gat_lp(args, rank, world, local_rank):
             acc.add_(torch.stack([sum(c.sum() for c in tree.cnt).to(torch.int64), agg.to(torch.int64)]))
         return emb
 
-    def step(i, count=False):
-        with torch.cuda.stream(st), torch.no_grad():
-            a = anchors[i % pool]
-            pos, cnt = eng.sample_positives(a, 1)
-            main = encode(torch.cat([a, pos]), count)  # anchors, then their positives (INVALID: no out-edge)
-            rn = encode(negs[i % pool], count)
-            q, pe = main[:B], main[B:]
-            scores = dec(q, torch.cat([pe, rn]))
-            return loss_fn.calculate_batch_retrieval_loss(scores, query_ids=a.long(),
-                                                          candidate_ids=torch.cat([pos, negs[i % pool]]).long())
+    def steps_of(a, ng, count):
+        """G steps: a [G, B] anchors, ng [G, n_neg] random negatives -> the G losses"""
+        pos, cnt = eng.sample_positives(a.reshape(-1), 1)
+        pos = pos.view(G, B)
+        if plans is not None:
+            roots = torch.cat([a, pos], dim=1).reshape(-1).contiguous()  # per step: anchors, then their positives
+            nroots = ng.reshape(-1).contiguous()
+            main = plans[0].run(roots).view(G, 2 * B, -1)
+            rn = plans[1].run(nroots).view(G, n_neg, -1)
+            if count:
+                plans[0].stats(roots, stats_acc)
+                plans[1].stats(nroots, stats_acc)
+        else:
+            main = encode(torch.cat([a[0], pos[0]]), count).unsqueeze(0)  # (INVALID positive: no out-edge)
+            rn = encode(ng[0], count).unsqueeze(0)
+        losses = []
+        for g_ in range(G):
+            scores = dec(main[g_, :B], torch.cat([main[g_, B:], rn[g_]]))
+            losses.append(loss_fn.calculate_batch_retrieval_loss(
+                scores, query_ids=a[g_].long(), candidate_ids=torch.cat([pos[g_], ng[g_]]).long()))
+        return torch.stack(losses)
 
-    for i in range(W):
-        step(i)
-    for i in range(pool):
-        step(i, count=True)
+    def call(i0, count=False):
+        with torch.cuda.stream(st), torch.no_grad():
+            return steps_of(anchors[i0:i0 + G], negs[i0:i0 + G], count)
+
+    for i in range(0, max(W, G), G):
+        call(i % pool)
+    for i0 in range(0, pool, G):
+        call(i0, count=True)
     st.synchronize()
     per_step = acc.cpu().numpy().astype(np.float64) / pool
-    # The step's shapes are all capacities (counts stay on the device), so one step replays as a HIP graph over static
-    # input rows; kept only when a replay reproduces the eager losses bit for bit, otherwise the eager driver stays.
-    driver = "per-stage entry points from Python, one stream"
-    eager_step = step
+    if plans is not None:
+        from gigl_amd._lib import STATS_AGGREGATED, STATS_SAMPLED
+        sa = stats_acc.cpu().numpy().astype(np.float64)
+        per_step = np.array([sa[STATS_SAMPLED], sa[STATS_AGGREGATED]]) / pool
+    # The shapes are all capacities (counts stay on the device), so a call replays as a HIP graph over static input
+    # rows; kept only when a replay reproduces the eager losses bit for bit, otherwise the eager driver stays.
+    driver = (f"one-call GAT plans ({G} steps per call: anchors + positives, random negatives) + decoder + fused loss, "
+              "one stream" if plans is not None else "per-stage entry points from Python, one stream")
+    eager_call = call
     if not os.environ.get("GIGL_BENCH_NO_GRAPH"):
         try:
-            a_buf, n_buf = anchors[0].clone(), negs[0].clone()
-
-            def static_step():
-                with torch.no_grad():
-                    pos, cnt = eng.sample_positives(a_buf, 1)
-                    main = encode(torch.cat([a_buf, pos]), False)
-                    rn = encode(n_buf, False)
-                    scores = dec(main[:B], torch.cat([main[B:], rn]))
-                    return loss_fn.calculate_batch_retrieval_loss(scores, query_ids=a_buf.long(),
-                                                                  candidate_ids=torch.cat([pos, n_buf]).long())
-
+            a_buf, n_buf = anchors[:G].clone(), negs[:G].clone()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=st):
-                loss_buf = static_step()
+                with torch.no_grad():
+                    loss_buf = steps_of(a_buf, n_buf, False)
 
-            def graph_step(i, count=False):
+            def graph_call(i0, count=False):
                 with torch.cuda.stream(st):
-                    a_buf.copy_(anchors[i % pool], non_blocking=True)
-                    n_buf.copy_(negs[i % pool], non_blocking=True)
+                    a_buf.copy_(anchors[i0:i0 + G], non_blocking=True)
+                    n_buf.copy_(negs[i0:i0 + G], non_blocking=True)
                     graph.replay()
                 return loss_buf
 
-            for i in (0, 7, pool - 1):
+            for i0 in (0, pool - G):
                 with torch.cuda.stream(st):
-                    want = eager_step(i).clone()
-                    got = graph_step(i).clone()
+                    want = eager_call(i0).clone()
+                    got = graph_call(i0).clone()
                 st.synchronize()
                 if not torch.equal(want, got):
-                    raise RuntimeError(f"replayed loss {got.item()} != eager {want.item()} at pool entry {i}")
-            step = graph_step
-            driver = "one HIP graph per step (captured from the per-stage entry points), replayed over static inputs"
+                    raise RuntimeError(f"replayed losses {got.tolist()[:2]} != eager {want.tolist()[:2]} at pool entry {i0}")
+            call = graph_call
+            driver = "one HIP graph per call (captured from " + driver.split(" + decoder")[0] + "), replayed over static inputs"
         except Exception as exc:  # noqa: BLE001 — the eager driver is the same path, only slower
             print(f"gat-lp: graph capture unavailable ({type(exc).__name__}: {str(exc)[:200]})", file=sys.stderr)
-            step = eager_step
+            call = eager_call
     rep_s, steps = [], 0
     t_all = time.perf_counter()
     while time.perf_counter() - t_all < args.min_seconds or len(rep_s) < args.min_reps:
         st.synchronize()
         t1 = time.perf_counter()
-        for i in range(pool):
-            step(i)
+        for i0 in range(0, pool, G):
+            call(i0)
         st.synchronize()
         rep_s.append(time.perf_counter() - t1)
         steps += pool
@@ -945,7 +973,7 @@ def run_gat_lp(args, rank, world, local_rank):
                                f"step: {B} anchors + 1 positive each + {n_neg} random negatives, fanout={fanouts}, 2-layer GAT "
                                f"heads={heads} hid={hid} out={out_dim}, inner-product scores + fused retrieval loss",
                    "sampled_edges_per_step": float(per_step[0]), "aggregated_edges_per_step": float(per_step[1]),
-                   "driver": driver, "setup_s": round(setup_s, 1)},
+                   "steps_per_call": G, "driver": driver, "setup_s": round(setup_s, 1)},
         "roofline": None, "cpu_baseline": None,
     }
     print(json.dumps(line))

@@ -131,6 +131,7 @@ class GiglDistPlanOpts(C.Structure):
         ("max_window_end", C.c_int64),
     ]
 STATS_LEN = 16
+STATS_SAMPLED, STATS_AGGREGATED = 0, 1  # GIGL_STATS_* slots of gigl_sage_plan_stats
 COL_I64, COL_F32 = 0, 1
 
 
