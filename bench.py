@@ -800,8 +800,8 @@ def run_gat_lp(args, rank, world, local_rank):
     out-neighbour, counter 3) and 512 random negatives go through sample -> union graph -> 2-layer GAT (heads 2, hid
     128, out 128: attention-weighted segmented reduce) -> root embeddings; inner-product scores against positives +
     random negatives and the fused retrieval loss (infer_task_inputs + Retrieval, python/gigl/src/common/
-    modeling_task_specs/utils/infer.py, models/layers/task.py:140-205).  Driven through the per-stage entry points
-    from Python (no one-call plan for attention layers yet): a secondary line, host-bound at this batch size."""
+    modeling_task_specs/utils/infer.py, models/layers/task.py:140-205).  The two encodes are GAT one-call plans
+    (gigl_gat_plan_create), G steps per call; the decoder and the loss run per step; a secondary line."""
     from gigl_amd._lib import GIGL_META_LEVEL0
     from gigl_amd.engine import HipEngine
     from gigl_amd.link_prediction import DecoderType, LinkPredictionDecoder, RetrievalLoss
