@@ -1198,75 +1198,75 @@ __global__ __launch_bounds__(256) void gat_input_gather_kernel(
   }
 }
 
-// ---- the same first layer in ONE row pass (the one-call plan's layer 0): a wave owns a destination row, holds the
-// source-side folded vectors in registers, and forms every edge's logit from the feature row it has just read for the
-// aggregation (a 64-lane reduction per head and edge), online softmax over the row.  No per-node score array exists,
+// ---- the same first layer in ONE row pass (the one-call plan's layer 0): the folded source vectors stay in
+// registers and every edge's logit is formed from the feature row that has just been read for the aggregation, online
+// softmax over the row.  No per-node score array exists,
 // so the sources need no dense numbering: rows >= *n_local_dev hold GLOBAL source ids in `col` (the leaf-global union
 // of the plan: pure leaves are never relabelled), rows below it local ids translated through gather_ids.  Every source
 // row is read once per edge it appears in; z is written in the projection's tiled layout, one operand per head.
+// A workgroup of P waves owns a destination row, wave c its c-th 256-column chunk (one float4 per lane): per-wave
+// state is one accumulator per head and the U rows in flight, so many waves fit a SIMD and their loads overlap.  The
+// logit needs the whole row's dot product: every wave reduces its chunk's partial, publishes it through LDS, and after
+// one barrier per group of U edges all P waves add the partials in the same order — the softmax state is replicated,
+// bit-identical, in every wave of the row.
 template <typename T, int P, int H>
-__global__ __launch_bounds__(256) void gat_input_online_kernel(
+__global__ __launch_bounds__(64 * P) void gat_input_online_kernel(
     const T* __restrict__ src, int d, const uint32_t* __restrict__ gather_ids, const int32_t* __restrict__ n_local_dev,
     const float* __restrict__ u, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
     const int32_t* __restrict__ col, const int32_t* __restrict__ n_rows_dev, float slope, int nkc, int64_t head_stride,
     float* __restrict__ z) {
-  constexpr int U = 4;  // feature rows in flight
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  constexpr int U = 8;  // feature rows in flight per wave
+  __shared__ float s_part[2][P][U + 1][2 * H];  // [buffer][chunk][edge of the group | the self row][head (src | dst)]
+  const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
   const int n_rows = *n_rows_dev;
   const int n_local = n_local_dev ? *n_local_dev : 0x7FFFFFFF;
   const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int el = (c * 64 + lane) * 4;
+  const bool on = el < d;
   auto leaky = [&](float v) { return v > 0.f ? v : slope * v; };
   auto wsum = [](float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
   };
-  auto dotp = [](const float4_t (&a)[P], const float4_t (&b)[P]) {
-    float r = 0.f;
+  auto dot4 = [](const float4_t& a, const float4_t& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; };
+  float4_t us[H], ud[H];
 #pragma unroll
-    for (int p = 0; p < P; ++p) r += a[p].x * b[p].x + a[p].y * b[p].y + a[p].z * b[p].z + a[p].w * b[p].w;
-    return r;
-  };
-  float4_t us[H][P];
-#pragma unroll
-  for (int h = 0; h < H; ++h)
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int el = (p * 64 + lane) * 4;
-      us[h][p] = el < d ? *reinterpret_cast<const float4_t*>(u + (int64_t)h * d + el) : zero4;
-    }
-  auto load_row = [&](uint32_t gid, float4_t (&x)[P]) {
-    const T* row = src + (int64_t)gid * d;
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int el = (p * 64 + lane) * 4;
-      x[p] = el < d ? RowLoader<T>::load4(row, el) : zero4;
-    }
-  };
-  for (int i = wave; i < n_rows; i += waves_total) {
+  for (int h = 0; h < H; ++h) {
+    us[h] = on ? *reinterpret_cast<const float4_t*>(u + (int64_t)h * d + el) : zero4;
+    ud[h] = on ? *reinterpret_cast<const float4_t*>(u + (int64_t)(H + h) * d + el) : zero4;
+  }
+  int buf = 0;
+  for (int i = blockIdx.x; i < n_rows; i += gridDim.x) {  // (uniform over the workgroup: the barriers below are safe)
     const int e0 = rowptr[i], m = rowend[i] - e0;
     const uint32_t self_gid = gather_ids[i];
     const bool local = i < n_local;
     float sd[H], mx[H], den[H];
-    float4_t acc[H][P];
+    float4_t acc[H];
     {
-      float4_t xs[P];
-      load_row(self_gid, xs);
+      const float4_t xs = on ? RowLoader<T>::load4(src + (int64_t)self_gid * d, el) : zero4;
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        float4_t ud[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-          const int el = (p * 64 + lane) * 4;
-          ud[p] = el < d ? *reinterpret_cast<const float4_t*>(u + (int64_t)(H + h) * d + el) : zero4;
+        const float ps = wsum(dot4(xs, us[h])), pd = wsum(dot4(xs, ud[h]));
+        if (lane == 0) {
+          s_part[buf][c][U][h] = ps;
+          s_part[buf][c][U][H + h] = pd;
         }
-        sd[h] = wsum(dotp(xs, ud));
-        mx[h] = leaky(wsum(dotp(xs, us[h])) + sd[h]);  // the self loop opens the running softmax with weight 1
-        den[h] = 1.f;
-#pragma unroll
-        for (int p = 0; p < P; ++p) acc[h][p] = xs[p];
+        acc[h] = xs;  // the self loop opens the running softmax with weight 1
       }
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float fs = 0.f, fd = 0.f;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+          fs += s_part[buf][q][U][h];
+          fd += s_part[buf][q][U][H + h];
+        }
+        sd[h] = fd;
+        mx[h] = leaky(fs + fd);
+        den[h] = 1.f;
+      }
+      buf ^= 1;
     }
     for (int c0 = 0; c0 < m; c0 += 64) {
       const int mm = min(64, m - c0);
@@ -1284,40 +1284,47 @@ __global__ __launch_bounds__(256) void gat_input_online_kernel(
       }
       const unsigned long long keep = __ballot(take);
       for (int e = 0; e < mm; e += U) {
-        float4_t x[U][P];
-        bool on[U];
+        float4_t x[U];
+        bool live[U];
 #pragma unroll
         for (int t = 0; t < U; ++t) {
-          on[t] = e + t < mm && ((keep >> (e + t)) & 1ull);  // (wave-uniform)
+          live[t] = e + t < mm && ((keep >> (e + t)) & 1ull);  // (uniform over the workgroup)
           const uint32_t g = __shfl(gid, (e + t) & 63, 64);
-          if (on[t]) load_row(g, x[t]);
+          x[t] = (live[t] && on) ? RowLoader<T>::load4(src + (int64_t)g * d, el) : zero4;
         }
 #pragma unroll
         for (int t = 0; t < U; ++t) {
-          if (!on[t]) continue;
+          if (!live[t]) continue;
 #pragma unroll
           for (int h = 0; h < H; ++h) {
-            const float zl = leaky(wsum(dotp(x[t], us[h])) + sd[h]);
+            const float ps = wsum(dot4(x[t], us[h]));
+            if (lane == 0) s_part[buf][c][t][h] = ps;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          if (!live[t]) continue;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            float fs = 0.f;
+#pragma unroll
+            for (int q = 0; q < P; ++q) fs += s_part[buf][q][t][h];
+            const float zl = leaky(fs + sd[h]);
             const float nm = fmaxf(mx[h], zl);
             const float sc = __expf(mx[h] - nm), pw = __expf(zl - nm);
             den[h] = den[h] * sc + pw;
-#pragma unroll
-            for (int p = 0; p < P; ++p) acc[h][p] = acc[h][p] * sc + pw * x[t][p];
+            acc[h] = acc[h] * sc + pw * x[t];
             mx[h] = nm;
           }
         }
+        buf ^= 1;  // (the next group writes the other buffer: one barrier per group)
       }
     }
-    float* tbase = z + ((int64_t)(i >> 7) * nkc) * 4096 + (i & 127) * 32;
+    if (on) {
+      float* tbase = z + ((int64_t)(i >> 7) * nkc) * 4096 + (i & 127) * 32 + (int64_t)(el >> 5) * 4096 + (el & 31);
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const float inv = 1.0f / den[h];
-#pragma unroll
-      for (int p = 0; p < P; ++p) {
-        const int el = (p * 64 + lane) * 4;
-        if (el < d)
-          *reinterpret_cast<float4_t*>(tbase + h * head_stride + (int64_t)(el >> 5) * 4096 + (el & 31)) = acc[h][p] * inv;
-      }
+      for (int h = 0; h < H; ++h) *reinterpret_cast<float4_t*>(tbase + h * head_stride) = acc[h] * (1.0f / den[h]);
     }
   }
 }
@@ -2486,9 +2493,9 @@ int32_t gigl_gat_input_layer_fused(gigl_ctx* ctx, const void* src, int32_t src_d
   GIGL_REQUIRE(ctx, src_dtype == GIGL_DTYPE_F32 || src_dtype == GIGL_DTYPE_F16, "bad dtype %d", src_dtype);
   GIGL_REQUIRE(ctx, act == 0 || act == 1, "bad act %d", act);
   const int P = (d + 255) / 256;
-  if ((d & 3) || (heads != 1 && heads != 2 && heads != 4) || P > 4 || heads * P > 8)
+  if ((d & 3) || (heads != 1 && heads != 2 && heads != 4) || P > 4)
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "gigl_gat_input_layer_fused: d=%d heads=%d outside the built shapes (d %% 4 "
-                     "== 0, d <= 1024, heads 1|2|4, heads*ceil(d/256) <= 8)", d, heads);
+                     "== 0, d <= 1024, heads 1|2|4)", d, heads);
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   hipStream_t st = ctx->stream;
@@ -2501,17 +2508,18 @@ int32_t gigl_gat_input_layer_fused(gigl_ctx* ctx, const void* src, int32_t src_d
     gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
     hipLaunchKernelGGL(gat_fold_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)(2 * H)), dim3(256), 0, st, w, att_src,
                        att_dst, H, C, d, u);
-    int64_t blocks = (rows_cap + 3) / 4;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    int64_t blocks = rows_cap;  // one workgroup of P waves per row
+    if (blocks > 256 * 64) blocks = 256 * 64;
 #define GIGL_GAT_ON(TT, PP, HH)                                                                                         \
-  hipLaunchKernelGGL((gat_input_online_kernel<TT, PP, HH>), dim3((unsigned)blocks), dim3(256), 0, st, (const TT*)src,  \
-                     d, gather_ids, n_local_dev, u, rowptr, rowend, col, n_rows_dev, negative_slope, nkc, head_stride, z)
+  hipLaunchKernelGGL((gat_input_online_kernel<TT, PP, HH>), dim3((unsigned)blocks), dim3(64 * PP), 0, st,             \
+                     (const TT*)src, d, gather_ids, n_local_dev, u, rowptr, rowend, col, n_rows_dev, negative_slope,    \
+                     nkc, head_stride, z)
 #define GIGL_GAT_ON_P(TT, HH)                                                                                           \
   do {                                                                                                                  \
     if (P == 1) GIGL_GAT_ON(TT, 1, HH);                                                                                 \
     else if (P == 2) GIGL_GAT_ON(TT, 2, HH);                                                                            \
-    else if (P == 3) GIGL_GAT_ON(TT, (HH * 3 <= 8 ? 3 : 1), HH);                                                        \
-    else GIGL_GAT_ON(TT, (HH * 4 <= 8 ? 4 : 1), HH);                                                                    \
+    else if (P == 3) GIGL_GAT_ON(TT, 3, HH);                                                                            \
+    else GIGL_GAT_ON(TT, 4, HH);                                                                                        \
   } while (0)
 #define GIGL_GAT_ON_H(TT)                                                                                               \
   do {                                                                                                                  \

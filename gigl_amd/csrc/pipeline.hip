@@ -445,7 +445,7 @@ int32_t gigl_gat_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, 
     if (dims[l + 1] > max_hc) max_hc = dims[l + 1];
   }
   const int P = (feat->d + 255) / 256;
-  if ((feat->d & 3) || (heads[0] != 1 && heads[0] != 2 && heads[0] != 4) || P > 4 || heads[0] * P > 8 ||
+  if ((feat->d & 3) || (heads[0] != 1 && heads[0] != 2 && heads[0] != 4) || P > 4 ||
       (feat->dtype != GIGL_DTYPE_F32 && feat->dtype != GIGL_DTYPE_F16))
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "GAT plan: feature dim %d / %d heads outside the shapes the first layer is "
                      "built for (gigl_gat_input_layer_fused)", feat->d, heads[0]);

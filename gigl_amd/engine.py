@@ -842,8 +842,7 @@ class HipEngine:
                               n_local_dev: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """gigl_gat_input_layer_fused (one pass, logits formed on the fly); None outside the built shapes"""
         d, cap = self.feat_dim, int(u.nodes.numel())
-        if d % 4 or d > 1024 or heads not in (1, 2, 4) or heads * ((d + 255) // 256) > 8 or \
-                self.feat_dtype not in (DTYPE_F32, DTYPE_F16):
+        if d % 4 or d > 1024 or heads not in (1, 2, 4) or self.feat_dtype not in (DTYPE_F32, DTYPE_F16):
             return None
         n_scr = int(self._lib.gigl_gat_input_layer_fused_scratch(d, heads, cap))
         scratch = torch.empty(n_scr, dtype=torch.float32, device=self.device)

@@ -576,7 +576,7 @@ int32_t gigl_gat_input_layer(gigl_ctx* ctx, const void* src, int32_t src_dtype, 
  * formed from the feature row as it is read for the aggregation (online softmax), so the sources need no dense
  * numbering: rows >= *n_local_dev hold GLOBAL source ids in `col` (the leaf-global union of gigl_sage_plan), rows below
  * it — all rows when n_local_dev is NULL — local ids translated through gather_ids (gather_ids[i] is also row i's own
- * feature row).  Built shapes: d % 4 == 0, d <= 1024, heads in {1, 2, 4}, heads * ceil(d/256) <= 8.
+ * feature row).  Built shapes: d % 4 == 0, d <= 1024, heads in {1, 2, 4}.
  * scratch: DEVICE fp32 [gigl_gat_input_layer_fused_scratch(d, heads, rows_cap)]. */
 int64_t gigl_gat_input_layer_fused_scratch(int32_t d, int32_t heads, int64_t rows_cap);
 int32_t gigl_gat_input_layer_fused(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
