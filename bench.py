@@ -976,8 +976,19 @@ def run_gat_lp(args, rank, world, local_rank):
                    "steps_per_call": G, "driver": driver, "setup_s": round(setup_s, 1)},
         "roofline": None, "cpu_baseline": None,
     }
-    print(json.dumps(line))
+    if world > 1:  # a replica per GPU: whole-job rate = sum over the ranks, step time = the slowest rank's
+        import torch.distributed as dist
+        v = torch.tensor([line["value"]], dtype=torch.float64, device=dev)
+        t = torch.tensor([line["ms_per_step"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        line.update(value=float(v.item()), ms_per_step=float(t.item()), n_gpus=world)
+    if rank == 0:
+        print(json.dumps(line))
     eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def run_cpu_baseline(eng, model, my, fanouts, W, n, d):
