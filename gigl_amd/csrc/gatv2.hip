@@ -1,5 +1,8 @@
+// Per-edge C-wide convolutions of the homogeneous zoo, forward and backward: GATv2Conv (this header), GINEConv
+// (gigl_gine_aggregate, below) and TransformerConv with edge features (gigl_transformer_aggregate_edge, at the end).
+//
 // GATv2Conv attention + aggregation, forward and backward (PyG 2.5.3 GATv2Conv as configured by GATv2.init_conv_layers,
-// python/gigl/src/common/models/pyg/homogeneous.py:346-386; no edge features):
+// python/gigl/src/common/models/pyg/homogeneous.py:346-386; edge features through the optional edge rows):
 //   s_ij = xl_j + xr_i,  z_ij = <att_h, leaky_relu(s_ij)> per head,  alpha = softmax_j z_ij over the in-edges of i
 //   (self loops removed, one added back),  out_i = sum_j alpha_ij xl_j  (heads concatenated) + bias.
 // Unlike GATConv the logit is not a sum of two per-node scalars: every edge needs the C-wide elementwise pass, so the
