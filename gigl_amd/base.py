@@ -120,23 +120,22 @@ def import_obj(path: str):
     return getattr(importlib.import_module(mod), name)
 
 
+def _positive_ranks(pos_scores: torch.Tensor, neg_scores: torch.Tensor) -> torch.Tensor:
+    """rank of every positive among {itself} + the negatives, 1 = best: one more than the number of negatives scoring
+    strictly higher (a tie counts for the positive; the reference sorts [pos | negs] and leaves ties to argsort)"""
+    return 1 + (neg_scores.reshape(1, -1) > pos_scores.reshape(-1, 1)).sum(dim=1)
+
+
 def hit_rate_at_k(pos_scores: torch.Tensor, neg_scores: torch.Tensor, ks: torch.Tensor) -> torch.Tensor:
-    max_k_requested = int(torch.max(ks).item())
-    max_viable_k = 1 + neg_scores.numel()
-    assert torch.min(ks).item() >= 1, "ks must be greater-or-equal to 1"
-    pos = pos_scores.view(-1, 1)
-    neg = neg_scores.view(1, -1).repeat(pos.shape[0], 1)
-    all_scores = torch.hstack((pos, neg))
-    order = torch.argsort(all_scores, dim=1, descending=True)
-    hit_rates = torch.cumsum(order == 0, dim=1).float().mean(dim=0)
-    if max_k_requested > max_viable_k:
-        hit_rates = torch.cat((hit_rates, torch.ones(max_k_requested - hit_rates.numel(), device=hit_rates.device)))
-    return torch.gather(hit_rates, 0, ks - 1)
+    """Hits@k for every k of `ks` (python/gigl/src/common/utils/eval_metrics.py:6-48; known answers restated in
+    tests/test_reference_host_answers.py): the fraction of positives ranked within the top k of [positive | negatives];
+    a k beyond 1 + #negatives is always a hit"""
+    if int(torch.min(ks).item()) < 1:
+        raise AssertionError(f"ks must be greater-or-equal to 1 (got {int(torch.min(ks).item())})")
+    ranks = _positive_ranks(pos_scores, neg_scores)
+    return (ranks.reshape(1, -1) <= ks.reshape(-1, 1).to(ranks.device)).float().mean(dim=1)
 
 
 def mean_reciprocal_rank(pos_scores: torch.Tensor, neg_scores: torch.Tensor) -> torch.Tensor:
-    pos = pos_scores.view(-1, 1)
-    neg = neg_scores.view(1, -1).repeat(pos.shape[0], 1)
-    order = torch.argsort(torch.hstack((pos, neg)), dim=1, descending=True)
-    _, ranks = torch.where(order == 0)
-    return torch.mean(1.0 / (ranks + 1))
+    """mean of 1 / rank over the positives (eval_metrics.py:51-73)"""
+    return (1.0 / _positive_ranks(pos_scores, neg_scores).float()).mean()
