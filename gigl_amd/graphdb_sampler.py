@@ -92,6 +92,78 @@ class SamplingOpDAG:
         return done
 
 
+class SubgraphSamplingValidationError(ValueError):
+    """a sampling-op DAG that cannot be traversed (python/gigl/src/common/types/exception.py
+    SubgraphSamplingValidationErrorType: `error_type` carries the reference's category name)"""
+
+    def __init__(self, error_type: str, message: str):
+        super().__init__(f"{error_type}: {message}")
+        self.error_type = error_type
+
+
+def _frontier_type(op: SamplingOp) -> str:
+    """node type an op starts from: INCOMING samples sources of edges INTO the frontier (frontier = dst type),
+    OUTGOING destinations of edges out of it (frontier = src type)"""
+    return op.edge_type.src_node_type if op.sampling_direction == OUTGOING else op.edge_type.dst_node_type
+
+
+def _result_type(op: SamplingOp) -> str:
+    return op.edge_type.dst_node_type if op.sampling_direction == OUTGOING else op.edge_type.src_node_type
+
+
+def validate_sampling_op_dags(root_type_to_ops: Dict[str, Sequence[SamplingOp]], node_types: Sequence[str],
+                              edge_types: Sequence[EdgeType], expected_root_node_types: Sequence[str] = ()) -> None:
+    """the checks of SubgraphSamplingStrategyPbWrapper / SamplingOpPbWrapper (python/gigl/src/common/types/pb_wrappers/
+    subgraph_sampling_strategy.py:26-260, sampling_op.py): unique op names, known input ops, no cycles, root node types
+    known to the graph (and to the task, when given), a root op per non-empty DAG, edge types of the graph, and edge
+    alignment — a root op starts from the DAG's root node type, a child op starts from the node type its parent returns.
+    On typed graphs a misaligned edge would index one type's id space with another type's ids."""
+    known_et = {(e.src_node_type, e.relation, e.dst_node_type) for e in edge_types}
+    for root_type, ops in root_type_to_ops.items():
+        if root_type not in node_types:
+            raise SubgraphSamplingValidationError("ROOT_NODE_TYPE_NOT_IN_GRAPH_METADATA", f"root node type {root_type!r}")
+        if expected_root_node_types and root_type not in expected_root_node_types:
+            raise SubgraphSamplingValidationError("ROOT_NODE_TYPE_NOT_IN_TASK_METADATA", f"root node type {root_type!r}")
+        by_name: Dict[str, SamplingOp] = {}
+        for op in ops:
+            if op.op_name in by_name:
+                raise SubgraphSamplingValidationError("REPEATED_OP_NAME", f"op name {op.op_name!r} in the DAG of {root_type!r}")
+            by_name[op.op_name] = op
+        if ops and not any(not op.input_op_names for op in ops):
+            raise SubgraphSamplingValidationError("MISSING_ROOT_SAMPLING_OP", f"the DAG of {root_type!r} has no op without inputs")
+        for op in ops:
+            et = op.edge_type
+            if (et.src_node_type, et.relation, et.dst_node_type) not in known_et:
+                raise SubgraphSamplingValidationError("SAMPLING_OP_EDGE_TYPE_NOT_IN_GRAPH_METADATA", f"{et} of op {op.op_name!r}")
+            if not op.input_op_names and _frontier_type(op) != root_type:
+                raise SubgraphSamplingValidationError(
+                    "CONTAINS_INVALID_EDGE_IN_DAG", f"root op {op.op_name!r} ({op.sampling_direction}) starts from "
+                    f"{_frontier_type(op)!r}, the DAG's root node type is {root_type!r}")
+            for pname in op.input_op_names:
+                if pname not in by_name:
+                    raise SubgraphSamplingValidationError("BAD_INPUT_OP_NAME", f"op {op.op_name!r} names input {pname!r}")
+                if _frontier_type(op) != _result_type(by_name[pname]):
+                    raise SubgraphSamplingValidationError(
+                        "CONTAINS_INVALID_EDGE_IN_DAG", f"op {op.op_name!r} starts from {_frontier_type(op)!r} but its "
+                        f"input {pname!r} returns {_result_type(by_name[pname])!r}")
+        state: Dict[str, int] = {}
+
+        def visit(name: str) -> None:  # depth-first over the input edges: a node met again while open closes a cycle
+            if state.get(name) == 1:
+                raise SubgraphSamplingValidationError("DAG_CONTAINS_CYCLE", f"through op {name!r} in the DAG of {root_type!r}")
+            if state.get(name) == 2:
+                return
+            state[name] = 1
+            for pname in by_name[name].input_op_names:
+                visit(pname)
+            state[name] = 2
+        for name in by_name:
+            visit(name)
+    for t in expected_root_node_types:
+        if t not in root_type_to_ops:
+            raise SubgraphSamplingValidationError("MISSING_EXPECTED_ROOT_NODE_TYPE", f"no DAG for node type {t!r}")
+
+
 @dataclass
 class OpResult:
     frontier: torch.Tensor  # [B, w] int32 (uint32 payload), INVALID = empty

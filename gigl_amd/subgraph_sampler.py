@@ -435,9 +435,13 @@ def default_sampling_op_dag(cfg: GbmlConfigPbWrapper, root_node_type: str):
 
 def sampling_op_dags(cfg: GbmlConfigPbWrapper, node_types: Sequence[str]):
     """getNodeTypeToSamplingOpDagMap (SubgraphSamplingStrategyWrapper.scala:10-20) for the node types asked for"""
-    from .graphdb_sampler import EdgeType, SamplingOp, SamplingOpDAG
+    from .graphdb_sampler import (EdgeType, SamplingOp, SamplingOpDAG, SubgraphSamplingValidationError,
+                                  validate_sampling_op_dags)
     out = {}
+    raw: Dict[str, list] = {}
     for path in cfg.message_passing_paths:
+        if str(path["rootNodeType"]) in raw:
+            raise SubgraphSamplingValidationError("REPEATED_ROOT_NODE_TYPE", f"two DAGs for {path['rootNodeType']!r}")
         ops = []
         for op in path.get("samplingOps") or []:
             et = op["edgeType"]
@@ -445,7 +449,11 @@ def sampling_op_dags(cfg: GbmlConfigPbWrapper, node_types: Sequence[str]):
                 op["opName"], EdgeType(et["srcNodeType"], et["relation"], et["dstNodeType"]),
                 int((op.get("randomUniform") or {}).get("numNodesToSample", 0) or op.get("numNodesToSample", 0)),
                 list(op.get("inputOpNames") or []), str(op.get("samplingDirection", "INCOMING"))))
-        out[str(path["rootNodeType"])] = SamplingOpDAG.from_ops(ops)
+        raw[str(path["rootNodeType"])] = ops
+    validate_sampling_op_dags(raw, list(cfg.condensed_node_type_map.values()),
+                              [EdgeType(*t) for t in cfg.condensed_edge_type_map.values()])
+    for root_type, ops in raw.items():
+        out[root_type] = SamplingOpDAG.from_ops(ops)
     for t in node_types:
         if t not in out:
             out[t] = default_sampling_op_dag(cfg, t)

@@ -68,3 +68,45 @@ def test_sampling_op_dag_construction():
     assert order.index("j") > max(order.index("r1"), order.index("r2")) and order[-1] == "leaf" and len(order) == 4
     with pytest.raises(ValueError):
         SamplingOpDAG.from_ops([SamplingOp("x", et, 1), SamplingOp("x", et, 1)])
+
+
+def test_sampling_op_dag_validation_categories():
+    """the failure categories of the reference's strategy / sampling-op validation tests (python/tests/unit/src/
+    validation/subgraph_sampling_strategy_validation_test.py:190-625, sampling_op_validation_test.py:77-400) on the same
+    shapes of DAG: node types '0' / '1' / '2', edge types 0->1, 1->2, 2->0"""
+    from gigl_amd.graphdb_sampler import (INCOMING, OUTGOING, EdgeType, SamplingOp, SubgraphSamplingValidationError,
+                                          validate_sampling_op_dags)
+    nts = ["0", "1", "2"]
+    e01, e12, e20 = EdgeType("0", "to", "1"), EdgeType("1", "to", "2"), EdgeType("2", "to", "0")
+    ets = [e01, e12, e20]
+
+    def fails(kind, dags, expected=()):
+        with pytest.raises(SubgraphSamplingValidationError) as ei:
+            validate_sampling_op_dags(dags, nts, ets, expected)
+        assert ei.value.error_type == kind
+
+    ok = {"1": [SamplingOp("a", e01, 10, [], INCOMING), SamplingOp("b", e20, 5, ["a"], INCOMING)],
+          "0": [SamplingOp("a", e01, 10, [], OUTGOING), SamplingOp("b", e12, 5, ["a"], OUTGOING)],
+          "2": []}  # a zero-hop DAG is valid
+    validate_sampling_op_dags(ok, nts, ets, ["0", "1", "2"])
+    # root ops: INCOMING needs edge_type.dst == root type, OUTGOING edge_type.src == root type
+    fails("CONTAINS_INVALID_EDGE_IN_DAG", {"0": [SamplingOp("a", e01, 10, [], INCOMING)]})
+    fails("CONTAINS_INVALID_EDGE_IN_DAG", {"1": [SamplingOp("a", e01, 10, [], OUTGOING)]})
+    # child INCOMING after parent INCOMING: child.dst == parent.src;  after parent OUTGOING: child.dst == parent.dst
+    fails("CONTAINS_INVALID_EDGE_IN_DAG", {"2": [SamplingOp("p", e12, 3, [], INCOMING), SamplingOp("c", e12, 3, ["p"], INCOMING)]})
+    validate_sampling_op_dags({"2": [SamplingOp("p", e12, 3, [], INCOMING), SamplingOp("c", e01, 3, ["p"], INCOMING)]}, nts, ets)
+    validate_sampling_op_dags({"1": [SamplingOp("p", e12, 3, [], OUTGOING), SamplingOp("c", e12, 3, ["p"], INCOMING)]}, nts, ets)
+    fails("CONTAINS_INVALID_EDGE_IN_DAG", {"1": [SamplingOp("p", e12, 3, [], OUTGOING), SamplingOp("c", e01, 3, ["p"], INCOMING)]})
+    # child OUTGOING after parent INCOMING: child.src == parent.src;  after parent OUTGOING: child.src == parent.dst
+    validate_sampling_op_dags({"2": [SamplingOp("p", e12, 3, [], INCOMING), SamplingOp("c", e12, 3, ["p"], OUTGOING)]}, nts, ets)
+    fails("CONTAINS_INVALID_EDGE_IN_DAG", {"2": [SamplingOp("p", e12, 3, [], INCOMING), SamplingOp("c", e20, 3, ["p"], OUTGOING)]})
+    fails("REPEATED_OP_NAME", {"1": [SamplingOp("a", e01, 1, [], INCOMING), SamplingOp("a", e01, 1, [], INCOMING)]})
+    fails("BAD_INPUT_OP_NAME", {"1": [SamplingOp("a", e01, 1, [], INCOMING), SamplingOp("b", e20, 1, ["nope"], INCOMING)]})
+    fails("SAMPLING_OP_EDGE_TYPE_NOT_IN_GRAPH_METADATA", {"1": [SamplingOp("a", EdgeType("0", "other", "1"), 1, [], INCOMING)]})
+    fails("ROOT_NODE_TYPE_NOT_IN_GRAPH_METADATA", {"9": []})
+    fails("ROOT_NODE_TYPE_NOT_IN_TASK_METADATA", {"2": []}, expected=["0"])
+    fails("MISSING_EXPECTED_ROOT_NODE_TYPE", {"0": []}, expected=["0", "1"])
+    cyc = [SamplingOp("r", e01, 1, [], INCOMING), SamplingOp("x", e20, 1, ["r", "z"], INCOMING),
+           SamplingOp("y", e12, 1, ["x"], INCOMING), SamplingOp("z", e01, 1, ["y"], INCOMING)]
+    fails("DAG_CONTAINS_CYCLE", {"1": cyc})
+    fails("MISSING_ROOT_SAMPLING_OP", {"1": [SamplingOp("x", e01, 1, ["y"], INCOMING), SamplingOp("y", e20, 1, ["x"], INCOMING)]})
