@@ -560,13 +560,14 @@ class GATv2(GraphSAGE):
 
 
 class DCNCross(nn.Module):
-    """one cross layer: x0 * (W x + b + diag_scale * x) + x, W = `_lin` or the low-rank `_lin_v(_lin_u(.))`
-    (feature_interaction.py:7-101; same parameter names)"""
+    """one cross layer of DCN-v2: out = x0 * (W x + b + diag_scale * x) + x, with W full (`_lin`) or low-rank
+    (`_lin_v` after `_lin_u`, projection_dim wide) — the parameter names of the reference's layer
+    (feature_interaction.py:7-101) so that its checkpoints load; the matrix products run on gigl_linear"""
 
     def __init__(self, in_dim: int, projection_dim: Optional[int] = None, diag_scale: float = 0.0, use_bias: bool = True):
         super().__init__()
         if diag_scale < 0.0:
-            raise ValueError(f"`diag_scale` should be non-negative. Got `diag_scale` = {diag_scale}")
+            raise ValueError(f"diag_scale must not be negative (got {diag_scale})")
         self._in_dim, self._projection_dim, self._diag_scale, self._use_bias = in_dim, projection_dim, diag_scale, use_bias
         if projection_dim is None:
             self._lin = nn.Linear(in_dim, in_dim, bias=use_bias)
@@ -574,21 +575,23 @@ class DCNCross(nn.Module):
             self._lin_u = nn.Linear(in_dim, projection_dim, bias=use_bias)
             self._lin_v = nn.Linear(projection_dim, in_dim, bias=use_bias)
 
+    def _product(self, eng: HipEngine, x: torch.Tensor) -> torch.Tensor:
+        """W x + b through the full matrix or its two low-rank factors"""
+        stages = [self._lin] if self._projection_dim is None else [self._lin_u, self._lin_v]
+        for lin in stages:
+            x = _linear(eng, x, lin.weight, lin.bias)
+        return x
+
     def forward(self, x0: torch.Tensor, x: Optional[torch.Tensor] = None) -> torch.Tensor:
         from .models_hetero import _engine_for
-        if x is None:
-            x = x0
+        x = x0 if x is None else x
         if x0.shape[-1] != x.shape[-1]:
-            raise ValueError(f"`x0` and `x` dimension mismatch! Got `x0` dimension {x0.shape[-1]}, and x dimension "
-                             f"{x.shape[-1]}. This case is not supported yet.")
-        eng = _engine_for(self, x)
-        if self._projection_dim is None:
-            prod = _linear(eng, x, self._lin.weight, self._lin.bias)
-        else:
-            prod = _linear(eng, _linear(eng, x, self._lin_u.weight, self._lin_u.bias), self._lin_v.weight, self._lin_v.bias)
+            raise ValueError(f"the base features ({x0.shape[-1]} wide) and the layer input ({x.shape[-1]} wide) must "
+                             "have the same width")
+        wx = self._product(_engine_for(self, x), x)
         if self._diag_scale:
-            prod = prod + self._diag_scale * x
-        return x0 * prod + x
+            wx = wx + self._diag_scale * x
+        return x0 * wx + x
 
     def reset_parameters(self):
         for m in self.children():
