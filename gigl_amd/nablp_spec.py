@@ -115,26 +115,23 @@ def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrap
 
     pos_map = main_batch.pos_supervision_edge_data[cet].root_node_to_target_node_id
     neg_map = main_batch.hard_neg_supervision_edge_data[cet].root_node_to_target_node_id
-    pos_e, neg_e, pos_ids, neg_ids, rep = [], [], [], [], []
+    pos_e, neg_e, pos_ids, neg_ids, rep, nrep = [], [], [], [], [], []
     batch_scores: List[Dict[int, BatchScores]] = []
-    for i, r in enumerate(main_batch.root_node_indices.tolist()):
+    for r in main_batch.root_node_indices.tolist():
         p, h = pos_map[r], neg_map[r]
         rep.append(p.numel())
+        nrep.append(h.numel())
         if p.numel():
             pos_e.append(main_emb[p.to(device)])
             pos_ids.append(p)
         if h.numel():
             neg_e.append(main_emb[h.to(device)])
             neg_ids.append(h)
-        if should_eval:
-            q1 = main_emb[root_idx[i:i + 1]]
-            batch_scores.append({cet: BatchScores(
-                pos_scores=decoder(q1, main_emb[p.to(device)]) if p.numel() else empty,
-                hard_neg_scores=decoder(q1, main_emb[h.to(device)]) if h.numel() else empty,
-                random_neg_scores=rn_scores[[i], :] if rn_scores.numel() else empty)})
     d = query.shape[1]
     pos_emb = torch.cat(pos_e) if pos_e else torch.zeros((0, d), device=device)
     neg_emb = torch.cat(neg_e) if neg_e else torch.zeros((0, d), device=device)
+    if should_eval:
+        batch_scores = _per_root_scores(decoder, query, pos_emb, neg_emb, rep, nrep, rn_scores, cet, empty)
     rep_t = torch.tensor(rep, device=device)
     rep_query = query.repeat_interleave(rep_t, dim=0)
     cand = torch.cat((pos_emb, neg_emb, rn_root_emb.reshape(-1, d)))
@@ -158,6 +155,27 @@ def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrap
                                          pos_embeddings={cet: pos_emb}, hard_neg_embeddings={cet: neg_emb},
                                          random_neg_embeddings={0: rn_root_emb}),
         batch_scores=batch_scores, batch_combined_scores={cet: combined})
+
+
+def _per_root_scores(decoder, query: torch.Tensor, pos_emb: torch.Tensor, neg_emb: torch.Tensor, n_pos: List[int],
+                     n_neg: List[int], rn_scores: torch.Tensor, cet: int, empty: torch.Tensor) -> List[Dict[int, BatchScores]]:
+    """the evaluation's per-root BatchScores (infer.py:279-310) from TWO projections of the whole batch — every root
+    against all positives / all hard negatives — sliced per root, instead of two small products per root (a row of a
+    product is the same bits whatever else is in the batch)"""
+    b = int(query.shape[0])
+    pos_all = decoder(query, pos_emb) if pos_emb.shape[0] else None
+    neg_all = decoder(query, neg_emb) if neg_emb.shape[0] else None
+    out: List[Dict[int, BatchScores]] = []
+    po = no = 0
+    for i in range(b):
+        p, h = n_pos[i], n_neg[i]
+        out.append({cet: BatchScores(
+            pos_scores=pos_all[i:i + 1, po:po + p] if p else empty,
+            hard_neg_scores=neg_all[i:i + 1, no:no + h] if h else empty,
+            random_neg_scores=rn_scores[[i], :] if rn_scores.numel() else empty)})
+        po += p
+        no += h
+    return out
 
 
 def _infer_task_inputs_hetero(model: nn.Module, cfg: GbmlConfigPbWrapper, main_batch, random_neg_batch,
@@ -184,18 +202,14 @@ def _infer_task_inputs_hetero(model: nn.Module, cfg: GbmlConfigPbWrapper, main_b
     none = [torch.zeros(0, dtype=torch.int64)] * b
     pos_l, neg_l = main_batch.pos_targets.get(cet, none), main_batch.hard_neg_targets.get(cet, none)
     batch_scores: List[Dict[int, BatchScores]] = []
-    if should_eval:
-        for i in range(b):
-            q1 = query[i:i + 1]
-            batch_scores.append({cet: BatchScores(
-                pos_scores=decoder(q1, dst_emb[pos_l[i].to(device)]) if pos_l[i].numel() else empty,
-                hard_neg_scores=decoder(q1, dst_emb[neg_l[i].to(device)]) if neg_l[i].numel() else empty,
-                random_neg_scores=rn_scores[[i], :] if rn_scores.numel() else empty)})
     rep = torch.tensor([p.numel() for p in pos_l], dtype=torch.int64)
     pos_ids = torch.cat(pos_l) if b else torch.zeros(0, dtype=torch.int64)
     neg_ids = torch.cat(neg_l) if b else torch.zeros(0, dtype=torch.int64)
     pos_emb = dst_emb[pos_ids.to(device)] if pos_ids.numel() else torch.zeros((0, d), device=device)
     neg_emb = dst_emb[neg_ids.to(device)] if neg_ids.numel() else torch.zeros((0, d), device=device)
+    if should_eval:
+        batch_scores = _per_root_scores(decoder, query, pos_emb, neg_emb, rep.tolist(), [h.numel() for h in neg_l],
+                                        rn_scores, cet, empty)
     rep_query = query.repeat_interleave(rep.to(device), dim=0)
     cand = torch.cat((pos_emb, neg_emb, rn_root_emb.reshape(-1, d)))
     g_main = main_batch.condensed_node_type_to_subgraph_id_to_global_node_id
