@@ -115,21 +115,20 @@ def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrap
 
     pos_map = main_batch.pos_supervision_edge_data[cet].root_node_to_target_node_id
     neg_map = main_batch.hard_neg_supervision_edge_data[cet].root_node_to_target_node_id
-    pos_e, neg_e, pos_ids, neg_ids, rep, nrep = [], [], [], [], [], []
+    pos_ids, neg_ids, rep, nrep = [], [], [], []
     batch_scores: List[Dict[int, BatchScores]] = []
     for r in main_batch.root_node_indices.tolist():
         p, h = pos_map[r], neg_map[r]
         rep.append(p.numel())
         nrep.append(h.numel())
         if p.numel():
-            pos_e.append(main_emb[p.to(device)])
             pos_ids.append(p)
         if h.numel():
-            neg_e.append(main_emb[h.to(device)])
             neg_ids.append(h)
     d = query.shape[1]
-    pos_emb = torch.cat(pos_e) if pos_e else torch.zeros((0, d), device=device)
-    neg_emb = torch.cat(neg_e) if neg_e else torch.zeros((0, d), device=device)
+    # (one index upload + one row gather per list, not one per root)
+    pos_emb = main_emb[torch.cat(pos_ids).to(device)] if pos_ids else torch.zeros((0, d), device=device)
+    neg_emb = main_emb[torch.cat(neg_ids).to(device)] if neg_ids else torch.zeros((0, d), device=device)
     if should_eval:
         batch_scores = _per_root_scores(decoder, query, pos_emb, neg_emb, rep, nrep, rn_scores, cet, empty)
     rep_t = torch.tensor(rep, device=device)
