@@ -38,7 +38,7 @@ SYMBOLS = [
     "gigl_frontier_bucket", "gigl_frontier_scatter", "gigl_avro_embeddings_layout", "gigl_avro_embeddings_encode",
     "gigl_edge_ids", "gigl_union_edge_ids", "gigl_gat_aggregate_edge", "gigl_collated_edge_attr", "gigl_sample_out_neighbors", "gigl_rows_dedup", "gigl_gat_aggregate_backward",
     "gigl_cms_add", "gigl_cms_estimate", "gigl_gine_aggregate", "gigl_gine_aggregate_backward", "gigl_gat_input_layer", "gigl_gat_input_layer_scratch", "gigl_gat_input_layer_fused",
-    "gigl_gat_input_layer_fused_scratch", "gigl_gat_plan_create", "gigl_gat_plan_set_weights", "gigl_gatv2_aggregate", "gigl_gatv2_aggregate_backward", "gigl_gatv2_aggregate_edge",
+    "gigl_gat_input_layer_fused_scratch", "gigl_gat_plan_create", "gigl_gat_plan_set_weights", "gigl_sage_plan_set_aggr", "gigl_gatv2_aggregate", "gigl_gatv2_aggregate_backward", "gigl_gatv2_aggregate_edge",
     "gigl_gatv2_aggregate_edge_backward", "gigl_transformer_aggregate_edge", "gigl_transformer_aggregate_edge_backward",
     "gigl_sage_plan_stats", "gigl_retrieval_loss", "gigl_retrieval_loss_backward",
     "gigl_comm_unique_id", "gigl_dist_init", "gigl_dist_init_local", "gigl_dist_init_callback", "gigl_comm_info",
@@ -287,6 +287,7 @@ def load() -> C.CDLL:
                                                vp, vp, vp],
         "gigl_gat_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), P(i32), vp, vp, vp, vp, C.c_float, i32, vp],
         "gigl_gat_plan_set_weights": [vp, vp, vp, vp, vp],
+        "gigl_sage_plan_set_aggr": [vp, i32],
         "gigl_gat_input_layer_fused": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, i64, vp, i32,
                                        vp, vp],
         "gigl_gat_input_layer": [vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, i64, vp, i64, vp, i64,

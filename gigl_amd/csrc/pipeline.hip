@@ -37,6 +37,7 @@ struct gigl_sage_plan {
   const float* w[GIGL_MAX_HOPS] = {nullptr};     // fused [dims[l+1]][2*dims[l]] (= [W_l | W_r]), device, borrowed
   const float* bias[GIGL_MAX_HOPS] = {nullptr};  // device, borrowed, may be null
   int32_t act_last = 0;
+  int32_t aggr = GIGL_AGGR_MEAN;  // the SAGE layers' reduction (gigl_sage_plan_set_aggr)
   // kind 1: GAT layers instead of SAGE layers (gigl_gat_plan_create): w[l] = lin weight [heads*channels][dims[l]],
   // layer 0 from the input side in one row pass (gigl_gat_input_layer_fused), layers >= 1 projection + attention
   int32_t kind = 0;
@@ -230,20 +231,20 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
       if (l == 0)  // (leaf-global: rows of level L-1 — >= the count through level L-2 — hold global source ids)
         return gigl_gather_reduce_mixed(
             ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend, p->un.col, n_rows, rows_cap,
-            GIGL_AGGR_MEAN, p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr,
+            p->aggr, p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr,
             p->abuf, nkc);
       return gigl_gather_reduce_mixed(ctx, p->hbuf[(l - 1) & 1], GIGL_DTYPE_F32, d, nullptr, p->un.rowptr, p->un.rowend,
-                                      p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN, nullptr, p->abuf, nkc);
+                                      p->un.col, n_rows, rows_cap, p->aggr, nullptr, p->abuf, nkc);
     }
     if (l == 0 && p->leaf_global)  // rows of level L-1 (>= the count through level L-2) hold global source ids
       return gigl_gather_reduce_mixed(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend,
-                                      p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN,
+                                      p->un.col, n_rows, rows_cap, p->aggr,
                                       L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev, p->abuf);
     if (l == 0)
-      return gigl_gather_mean(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend,
-                              p->un.col, n_rows, rows_cap, p->abuf);
-    return gigl_gather_mean(ctx, p->hbuf[(l - 1) & 1], GIGL_DTYPE_F32, d, nullptr, p->un.rowptr, p->un.rowend,
-                            p->un.col, n_rows, rows_cap, p->abuf);
+      return gigl_gather_reduce(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend,
+                                p->un.col, n_rows, rows_cap, p->aggr, p->abuf);
+    return gigl_gather_reduce(ctx, p->hbuf[(l - 1) & 1], GIGL_DTYPE_F32, d, nullptr, p->un.rowptr, p->un.rowend,
+                              p->un.col, n_rows, rows_cap, p->aggr, p->abuf);
   }
   const int act = (l < L - 1 || p->act_last) ? 1 : 0;
   if (p->tiled)
@@ -505,6 +506,18 @@ int32_t gigl_sage_plan_set_weights(gigl_sage_plan* p, const float* const* w, con
     hipStreamSynchronize(p->ctx->stream);
     drop_graphs(p);
   }
+  return GIGL_OK;
+}
+
+int32_t gigl_sage_plan_set_aggr(gigl_sage_plan* p, int32_t aggr) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(p->ctx, aggr == GIGL_AGGR_MEAN || aggr == GIGL_AGGR_SUM || aggr == GIGL_AGGR_MAX, "bad aggr %d", aggr);
+  GIGL_REQUIRE(p->ctx, p->kind == 0, "the reduction applies to SAGE layers");
+  if (p->aggr != aggr && p->captured) {  // (the reduction is baked into the captured launches)
+    hipStreamSynchronize(p->ctx->stream);
+    drop_graphs(p);
+  }
+  p->aggr = aggr;
   return GIGL_OK;
 }
 

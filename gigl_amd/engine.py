@@ -987,10 +987,14 @@ class HipEngine:
 
     # ---- one-call batch pipeline -----------------------------------------------------------
     def make_sage_plan(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], b: int,
-                       fanouts: Sequence[int], act_last: bool = False, groups: int = 1) -> "SagePlan":
+                       fanouts: Sequence[int], act_last: bool = False, groups: int = 1, aggr: str = "mean") -> "SagePlan":
         """weights[l]: fused fp32 [out_l, 2*in_l] = cat(lin_l.weight, lin_r.weight, dim=1) on this device.
-        groups > 1: one call takes groups*b roots = `groups` independent batches of b roots each."""
-        return SagePlan(self, weights, biases, b, fanouts, act_last, groups)
+        groups > 1: one call takes groups*b roots = `groups` independent batches of b roots each.
+        aggr: "mean" | "sum" | "max" (PyG SAGEConv aggr)."""
+        plan = SagePlan(self, weights, biases, b, fanouts, act_last, groups)
+        if aggr != "mean":
+            check(self._lib.gigl_sage_plan_set_aggr(plan._plan, _lib.AGGR[aggr]), self._ctx)
+        return plan
 
 
 _DEV_I32 = {}

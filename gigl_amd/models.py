@@ -248,11 +248,11 @@ class GraphSAGE(nn.Module):
         `b` roots on `eng`; weights are snapshotted — call plan.set_weights(*model.fused_params()) after updates.
         groups > 1: each call takes groups*b roots and processes them as `groups` independent batches of b."""
         assert len(fanouts) == self.num_layers, "one hop per layer"
-        if not (self._plain and self.aggr == "mean" and not self.should_l2_normalize_embedding_layer_output
-                and self.feats_interaction is None):
-            raise NotImplementedError("the one-call plan computes conv(mean) -> relu layers only; use forward(HipBatch)")
+        if not (self._plain and not self.should_l2_normalize_embedding_layer_output and self.feats_interaction is None):
+            raise NotImplementedError("the one-call plan computes conv -> relu layers only; use forward(HipBatch)")
         w, bs = self.fused_params()
-        return eng.make_sage_plan(w, bs, b, fanouts, act_last=self.activation_after_last_conv, groups=groups)
+        return eng.make_sage_plan(w, bs, b, fanouts, act_last=self.activation_after_last_conv, groups=groups,
+                                  aggr=self.aggr)
 
     def fused_params(self):
         return ([c.fused_weight().detach() for c in self.conv_layers],

@@ -791,6 +791,8 @@ int32_t gigl_gat_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, 
                              float negative_slope, int32_t act_last, gigl_sage_plan** out);
 int32_t gigl_gat_plan_set_weights(gigl_sage_plan* plan, const float* const* w, const float* const* att_src,
                                   const float* const* att_dst, const float* const* bias);
+/* the SAGE layers' reduction: GIGL_AGGR_MEAN (default) | GIGL_AGGR_SUM | GIGL_AGGR_MAX (PyG SAGEConv aggr) */
+int32_t gigl_sage_plan_set_aggr(gigl_sage_plan* plan, int32_t aggr);
 int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
 int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);

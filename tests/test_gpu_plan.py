@@ -153,3 +153,20 @@ def test_plan_reports_batches_that_do_not_fit_its_workspace():
     assert u.counts()["levels"][1] > 65
     plan.close()
     eng.close()
+
+
+@pytest.mark.parametrize("aggr,fan", [("sum", [25, 10]), ("max", [25, 10]), ("max", [6, 4, 3])])
+def test_plan_with_sum_and_max_reductions(setup, aggr, fan):
+    """SAGEConv aggr sum / max through the one-call plan (gigl_sage_plan_set_aggr) == the staged forward"""
+    from gigl_amd.models import GraphSAGE, HipBatch
+    eng, rowptr, col, x, n = setup
+    torch.manual_seed(4)
+    model = GraphSAGE(100, 32, 16, num_layers=len(fan), aggr=aggr).to(eng.device)
+    b = 128
+    plan = model.make_plan(eng, b, fan)
+    roots = np.random.default_rng(9).integers(0, n, size=b).astype(np.uint32)
+    out = plan.run(torch.from_numpy(roots.view(np.int32)).to(eng.device)).cpu().numpy()
+    tree = eng.sample_khop(roots, fan)
+    u = eng.union_build(tree)
+    want = model(HipBatch(eng, tree, u))[u.root_local[:b].long()].cpu().numpy()
+    np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-5)
