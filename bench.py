@@ -188,8 +188,9 @@ def main():
                     help="mag240m-sharded: fraction of the nodes (the most-referenced ones) whose feature rows are "
                          "replicated on every rank and never pulled (hub-row replication)")
     ap.add_argument("--shard-plans", type=int, default=3, help="mag240m-sharded: sharded plans in flight per rank")
-    ap.add_argument("--shard-scale", type=float, default=1.0,
-                    help="mag240m-sharded: fraction of MAG240M's nodes and edges to generate (1.0 needs 8 GPUs' HBM)")
+    ap.add_argument("--shard-scale", type=float, default=0.0,
+                    help="mag240m-sharded: fraction of MAG240M's nodes and edges to generate (0 = world/8, capped at 1: "
+                         "every GPU holds the share it has in the 8-GPU job; 1.0 needs 8 GPUs' HBM)")
     ap.add_argument("--project-on-owner", action="store_true",
                     help="mag240m-sharded: owners apply the first layer's weights before sending (256 fp32 per row "
                          "instead of 768 fp16)")
@@ -570,6 +571,8 @@ def run_sharded(args, rank, world, local_rank):
     fanouts = [int(v) for v in args.fanouts.split(",")]
     L = len(fanouts)
     B, K, W = args.batch, max(1, args.steps), max(0, args.warmup)
+    if args.shard_scale <= 0.0:  # weak scaling: a rank's shard is 1/8 of MAG240M whatever the world size
+        args.shard_scale = min(1.0, world / 8.0)
     n = max(int(244_160_499 * args.shard_scale), world * 1024)
     e_total = max(int(1_728_364_232 * args.shard_scale), 1)
     d, hid, out_dim = 768, 256, 256
@@ -814,7 +817,7 @@ def run_gat_lp(args, rank, world, local_rank):
     fanouts = [int(v) for v in args.fanouts.split(",")]
     L = len(fanouts)
     B, n_neg = args.batch, 512
-    scale = args.shard_scale if args.shard_scale < 1.0 else 0.125
+    scale = args.shard_scale if 0.0 < args.shard_scale < 1.0 else 0.125
     n = int(244_160_499 * scale)
     e_total = int(1_728_364_232 * scale)
     d, hid, out_dim, heads = 768, 128, 128, 2
