@@ -323,10 +323,21 @@ int32_t gigl_sage_plan_destroy(gigl_sage_plan* p) {
   return GIGL_OK;
 }
 
+static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b, const int32_t* fanouts,
+                           int32_t hops, const int32_t* dims, const float* const* w, const float* const* bias,
+                           int32_t act_last, bool with_abuf, gigl_sage_plan** out);
+
 int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b,
                               const int32_t* fanouts, int32_t hops, const int32_t* dims,
                               const float* const* w, const float* const* bias, int32_t act_last,
                               gigl_sage_plan** out) {
+  return plan_create(ctx, graph, feat, b, fanouts, hops, dims, w, bias, act_last, true, out);
+}
+
+// with_abuf false: no [mean | self] operand buffer (the GAT plan aggregates into its own per-head operands)
+static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b, const int32_t* fanouts,
+                           int32_t hops, const int32_t* dims, const float* const* w, const float* const* bias,
+                           int32_t act_last, bool with_abuf, gigl_sage_plan** out) {
   if (!ctx || !out) return GIGL_E_INVALID_ARG;
   *out = nullptr;
   GIGL_REQUIRE(ctx, graph && feat && fanouts && dims && w, "null argument");
@@ -406,7 +417,7 @@ int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat,
   p->tiled = getenv("GIGL_PLAN_ROW_MAJOR") == nullptr;  // (A/B knob)
   for (int k = 0; k < hops; ++k)
     if ((dims[k] & 3) != 0 || dims[k] > 2048) p->tiled = false;
-  {
+  if (with_abuf) {
     const size_t row_tiles = ((size_t)act_rows + 127) / 128, nkc = ((size_t)2 * max_in + 31) / 32;
     p->abuf = (float*)alloc(p->tiled ? row_tiles * nkc * 4096 * 4 : (size_t)act_rows * 2 * max_in * 4);
   }
@@ -418,7 +429,7 @@ int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat,
   if (p->zero_dev && hipMemset(p->zero_dev, 0, 16) != hipSuccess) ok = false;
   p->act_rows = act_rows;
   ok = ok && p->zero_dev && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col && p->un.root_local &&
-       p->abuf && p->hbuf[0] && p->hbuf[1] && p->roots_buf && p->out_buf;
+       (p->abuf || !with_abuf) && p->hbuf[0] && p->hbuf[1] && p->roots_buf && p->out_buf;
   if (!ok) {
     gigl_sage_plan_destroy(p);
     return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the batch workspace failed (cap_nodes=%lld)",
@@ -451,7 +462,7 @@ int32_t gigl_gat_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, 
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "GAT plan: feature dim %d / %d heads outside the shapes the first layer is "
                      "built for (gigl_gat_input_layer_fused)", feat->d, heads[0]);
   gigl_sage_plan* p = nullptr;
-  int32_t rc = gigl_sage_plan_create(ctx, graph, feat, b, fanouts, hops, dims, w, bias, act_last, &p);
+  int32_t rc = plan_create(ctx, graph, feat, b, fanouts, hops, dims, w, bias, act_last, false, &p);
   if (rc != GIGL_OK) return rc;
   p->kind = 1;
   p->slope = negative_slope;
