@@ -868,7 +868,7 @@ def run_gat_lp(args, rank, world, local_rank):
     # step per call.
     plans, G = None, 1
     if not os.environ.get("GIGL_BENCH_GAT_STAGED"):
-        G = max(1, int(os.environ.get("GIGL_BENCH_GAT_GROUPS", "32")))
+        G = max(1, int(os.environ.get("GIGL_BENCH_GAT_GROUPS", "64")))
         while pool % G:
             G -= 1
         plans = (model.make_plan(eng, 2 * B, fanouts, groups=G), model.make_plan(eng, n_neg, fanouts, groups=G))
