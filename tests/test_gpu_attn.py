@@ -321,12 +321,23 @@ def test_gat_one_call_plan_matches_the_staged_forward(d, dtype, heads, hid, fan,
         plan = model.make_plan(eng, b, fan, groups=groups)
         r_dev = torch.from_numpy(roots.view(np.int32)).to(eng.device)
         got = plan.run(r_dev).cpu().numpy()
+        from gigl_amd._lib import GIGL_META_LEVEL0, STATS_AGGREGATED, STATS_LEN, STATS_SAMPLED
+        acc = torch.zeros(STATS_LEN, dtype=torch.int64, device=eng.device)
+        plan.stats(r_dev, acc)
+        sampled = aggregated = 0
         for gi in range(groups):
             part = roots[gi * b:(gi + 1) * b]
             tree = eng.sample_khop(part, fan)
             u = eng.union_build(tree)
             want = model(HipBatch(eng, tree, u))[u.root_local[:b].long()].cpu().numpy()
             np.testing.assert_allclose(got[gi * b:(gi + 1) * b], want, rtol=2e-5, atol=2e-5)
+            sampled += int(sum(int(c.sum()) for c in tree.cnt))
+            rowlen = (u.rowend - u.rowptr).cpu().numpy().astype(np.int64)
+            meta = u.meta.cpu().numpy()
+            aggregated += int(sum(rowlen[: meta[GIGL_META_LEVEL0 + (L - 1 - l)]].sum() for l in range(L)))
+        # the plan's exact work counts == the staged path's (sampled edges; in-edges of the rows every layer computes)
+        a = acc.cpu().numpy()
+        assert a[STATS_SAMPLED] == sampled and a[STATS_AGGREGATED] == aggregated
         st = torch.cuda.Stream(device=eng.device)  # (the legacy default stream cannot be captured)
         torch.cuda.synchronize()
         eng.bind_stream(st)
