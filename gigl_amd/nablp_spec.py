@@ -427,10 +427,15 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         if gnn is GraphSAGE:  # (the homogeneous default was not overridden)
             from .models_hetero import HGT
             gnn = HGT
-        encoder = gnn(node_type_to_feat_dim_map=node_dims, edge_type_to_feat_dim_map=edge_dims, hid_dim=self.hidden_dim,
-                      out_dim=self.out_channels, num_layers=self.num_layers,
+        import inspect
+        accepted = inspect.signature(gnn.__init__).parameters
+        dims = dict(hid_dim=self.hidden_dim, out_dim=self.out_channels)
+        if "node_hid_dim" in accepted:  # SimpleHGN names its widths per node / edge (heterogeneous.py:122-160)
+            dims = dict(node_hid_dim=self.hidden_dim, edge_hid_dim=self.hidden_dim, node_out_dim=self.out_channels,
+                        edge_type_dim=int(self._encoder_kwargs.get("edge_type_dim", 16)))
+        encoder = gnn(node_type_to_feat_dim_map=node_dims, edge_type_to_feat_dim_map=edge_dims, num_layers=self.num_layers,
                       num_heads=int(self._encoder_kwargs.get("heads", 2)),
-                      should_l2_normalize_embedding_layer_output=self.should_l2_normalize_embedding_layer_output)
+                      should_l2_normalize_embedding_layer_output=self.should_l2_normalize_embedding_layer_output, **dims)
         model = LinkPredictionGNN(encoder=encoder, decoder=LinkPredictionDecoder())
         if state_dict is not None:
             model.load_state_dict(state_dict)

@@ -82,6 +82,26 @@ def test_typed_training_step_matches_a_cpu_restatement(workdir):
     assert all((q, p) in real for q, p in zip(bcs.repeated_query_ids.cpu().tolist(), bcs.positive_ids.cpu().tolist()))
 
 
+def test_simple_hgn_trains_through_the_plugin(workdir):
+    """gnn_model_class_path = SimpleHGN (edge-type embeddings + edge features in the attention): the typed batches carry
+    the edge features of both edge types, the loss falls"""
+    import yaml
+    from gigl_amd.trainer import Trainer
+    doc = yaml.safe_load(open(os.path.join(workdir, CFG)))
+    doc["trainerConfig"]["trainerArgs"]["gnn_model_class_path"] = "gigl_amd.models_hetero.SimpleHGN"
+    doc["sharedConfig"]["trainedModelMetadata"] = {"trainedModelUri": "out/hetero_shgn/model.pt",
+                                                   "evalMetricsUri": "out/hetero_shgn/eval_metrics.json"}
+    uri = "configs/hetero_shgn_gbml_config.yaml"
+    yaml.safe_dump(doc, open(os.path.join(workdir, uri), "w"))
+    tr = Trainer()
+    metrics = tr.run("job", uri, None, uri_base=workdir)
+    assert np.isfinite(metrics.metrics["loss"].value) and 0.0 < metrics.metrics["mrr"].value <= 1.0
+    hist = [h["loss"] for h in tr.training_process.trainer.history]
+    assert len(hist) >= 2 and all(np.isfinite(hist)) and min(hist[1:]) < hist[0]
+    sd = torch.load(GbmlConfigPbWrapper.from_uri(uri, uri_base=workdir).trained_model_uri, map_location="cpu")
+    assert any("edge_type_emb" in k for k in sd) and any("W_efeat" in k for k in sd)
+
+
 def test_trainer_then_inferencer_on_the_typed_graph(workdir):
     from gigl_amd.inferencer import Inferencer
     from gigl_amd.trainer import Trainer
