@@ -360,8 +360,12 @@ class SimpleHGN(nn.Module):
             eis.append(ei + off)
             ets.append(torch.full((ei.shape[1],), i, dtype=torch.int64, device=dev))
             if self.should_have_edge_features:
-                ea = data.edge_attr_dict[et]
                 lin = self.edge_type_lin_dict[self._ekey(et)]
+                ea = data.edge_attr_dict.get(et)
+                if ea is None:  # (an edge type without edges in this batch: no rows, so no feature matrix either)
+                    if ei.shape[1]:
+                        raise KeyError(f"edge type {et} has edges but no edge features in this batch")
+                    ea = torch.zeros((0, lin.in_features), dtype=torch.float32, device=dev)
                 efs.append(_linear(eng, ea, lin.weight, lin.bias))
         edge_index = torch.cat(eis, dim=1) if eis else torch.zeros((2, 0), dtype=torch.int64, device=dev)
         edge_type = torch.cat(ets) if ets else torch.zeros(0, dtype=torch.int64, device=dev)
