@@ -16,7 +16,7 @@ retrieval loss over the [queries x candidates] score matrix (gigl_retrieval_loss
 sampling correction when enabled).
 Scope: homogeneous graphs (one condensed node type / edge type) and heterogeneous ones (typed batches through the
 native typed collate, HGT / SimpleHGN encoders, first supervision edge type: spec :245-271, infer.py on HeteroData); the
-Retrieval task — the other tasks (Margin, Softmax, GRACE, ...) are not built.
+Retrieval, Margin and Softmax tasks — the self-supervised ones (GRACE, BGRL, ...) are not built.
 Data: main samples are the NodeAnchorBasedLinkPredictionSample TFRecords and random negatives the
 RootedNodeNeighborhood TFRecords the sampler wrote, re-filed into train/val/test by the split generator
 (gigl_amd/split_generator.py; datasetMetadata.nodeAnchorBasedLinkPredictionDataset URIs).  Without split outputs
@@ -95,12 +95,14 @@ class NodeAnchorBasedLinkPredictionTaskInputs:
 
 def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrapper,
                       main_batch: NodeAnchorBasedLinkPredictionBatch, random_neg_batch: RootedNodeNeighborhoodBatch,
-                      should_eval: bool, device: torch.device) -> NodeAnchorBasedLinkPredictionTaskInputs:
+                      should_eval: bool, device: torch.device, need_batch_scores: bool = False
+                      ) -> NodeAnchorBasedLinkPredictionTaskInputs:
     """infer.py:103-456 for one condensed edge type: encode both batch graphs, then per root gather the
     positive / hard-negative rows, and build the [sum(num_pos) x (pos | hard_neg | random_neg)] score matrix"""
     from .batches import HeteroNodeAnchorBasedLinkPredictionBatch
     if isinstance(main_batch, HeteroNodeAnchorBasedLinkPredictionBatch):
-        return _infer_task_inputs_hetero(model, gbml_config_pb_wrapper, main_batch, random_neg_batch, should_eval, device)
+        return _infer_task_inputs_hetero(model, gbml_config_pb_wrapper, main_batch, random_neg_batch, should_eval, device,
+                                         need_batch_scores)
     inner = model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
     decoder = inner.decode
     cet = 0
@@ -111,7 +113,8 @@ def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrap
     rn_root_idx = random_neg_batch.condensed_node_type_to_root_node_indices_map[0].to(device)
     empty = torch.zeros((0,), dtype=torch.float32, device=device)
     rn_root_emb = rn_emb[rn_root_idx] if rn_root_idx.numel() else empty
-    rn_scores = decoder(query, rn_root_emb) if (should_eval and rn_root_emb.numel()) else empty
+    want_scores = should_eval or need_batch_scores  # (infer.py:225,279,309: ModelResultType.batch_scores or should_eval)
+    rn_scores = decoder(query, rn_root_emb) if (want_scores and rn_root_emb.numel()) else empty
 
     pos_map = main_batch.pos_supervision_edge_data[cet].root_node_to_target_node_id
     neg_map = main_batch.hard_neg_supervision_edge_data[cet].root_node_to_target_node_id
@@ -129,7 +132,7 @@ def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrap
     # (one index upload + one row gather per list, not one per root)
     pos_emb = main_emb[torch.cat(pos_ids).to(device)] if pos_ids else torch.zeros((0, d), device=device)
     neg_emb = main_emb[torch.cat(neg_ids).to(device)] if neg_ids else torch.zeros((0, d), device=device)
-    if should_eval:
+    if want_scores:
         batch_scores = _per_root_scores(decoder, query, pos_emb, neg_emb, rep, nrep, rn_scores, cet, empty)
     rep_t = torch.tensor(rep, device=device)
     rep_query = query.repeat_interleave(rep_t, dim=0)
@@ -178,7 +181,8 @@ def _per_root_scores(decoder, query: torch.Tensor, pos_emb: torch.Tensor, neg_em
 
 
 def _infer_task_inputs_hetero(model: nn.Module, cfg: GbmlConfigPbWrapper, main_batch, random_neg_batch,
-                              should_eval: bool, device: torch.device) -> NodeAnchorBasedLinkPredictionTaskInputs:
+                              should_eval: bool, device: torch.device, need_batch_scores: bool = False
+                              ) -> NodeAnchorBasedLinkPredictionTaskInputs:
     """infer.py:103-456 on typed batches, first supervision edge type (src -> dst): the encoder returns one embedding
     matrix per node type; queries are the roots' rows of the src type, positives / hard negatives rows of the dst type
     (local ids from the typed collate), random negatives the roots of the dst type's RootedNodeNeighborhood batch"""
@@ -196,7 +200,8 @@ def _infer_task_inputs_hetero(model: nn.Module, cfg: GbmlConfigPbWrapper, main_b
     empty = torch.zeros((0,), dtype=torch.float32, device=device)
     rn_root_idx = random_neg_batch.condensed_node_type_to_root_node_indices_map.get(name_to_cnt[dst_t])
     rn_root_emb = rn[rn_root_idx.to(device)] if rn_root_idx is not None and rn_root_idx.numel() else empty
-    rn_scores = decoder(query, rn_root_emb) if (should_eval and rn_root_emb.numel()) else empty
+    want_scores = should_eval or need_batch_scores  # (infer.py:225,279,309: ModelResultType.batch_scores or should_eval)
+    rn_scores = decoder(query, rn_root_emb) if (want_scores and rn_root_emb.numel()) else empty
     b = int(root_idx.numel())
     none = [torch.zeros(0, dtype=torch.int64)] * b
     pos_l, neg_l = main_batch.pos_targets.get(cet, none), main_batch.hard_neg_targets.get(cet, none)
@@ -206,7 +211,7 @@ def _infer_task_inputs_hetero(model: nn.Module, cfg: GbmlConfigPbWrapper, main_b
     neg_ids = torch.cat(neg_l) if b else torch.zeros(0, dtype=torch.int64)
     pos_emb = dst_emb[pos_ids.to(device)] if pos_ids.numel() else torch.zeros((0, d), device=device)
     neg_emb = dst_emb[neg_ids.to(device)] if neg_ids.numel() else torch.zeros((0, d), device=device)
-    if should_eval:
+    if want_scores:
         batch_scores = _per_root_scores(decoder, query, pos_emb, neg_emb, rep.tolist(), [h.numel() for h in neg_l],
                                         rn_scores, cet, empty)
     rep_query = query.repeat_interleave(rep.to(device), dim=0)
@@ -234,6 +239,7 @@ class Retrieval(nn.Module):
     sketches (positives + hard negatives / random negatives) and logQ of the estimated in-batch probability is taken
     off the logits inside the fused loss"""
     task_name = "Retrieval"
+    result_types = ("batch_combined_scores", "batch_embeddings")
 
     def __init__(self, loss: Optional[nn.Module] = None, temperature: float = 0.07,
                  remove_accidental_hits: bool = True, should_enable_candidate_sampling_correction: bool = False,
@@ -283,6 +289,73 @@ class Retrieval(nn.Module):
         return running_loss, running_batch_size
 
 
+def _ragged_scores(batch_scores: List[Dict[int, BatchScores]], device: torch.device):
+    """the per-root score lists as padded matrices: pos [S, Pmax] + its mask, negatives [S, Nmax] (hard negatives then
+    random negatives; padding -inf) for the S (root, edge type) entries that have a positive"""
+    rows = [bs for result in batch_scores for bs in result.values() if bs.pos_scores.numel()]
+    if not rows:
+        return None
+    pos = [r.pos_scores.reshape(-1) for r in rows]
+    neg = [torch.cat((r.hard_neg_scores.reshape(-1), r.random_neg_scores.reshape(-1))) for r in rows]
+    pmax, nmax = max(p.numel() for p in pos), max(max(n_.numel() for n_ in neg), 1)
+    P = torch.zeros((len(rows), pmax), device=device)
+    M = torch.zeros((len(rows), pmax), dtype=torch.bool, device=device)
+    N = torch.full((len(rows), nmax), float("-inf"), device=device)
+    for i, (p, n_) in enumerate(zip(pos, neg)):
+        P[i, :p.numel()], M[i, :p.numel()] = p, True
+        N[i, :n_.numel()] = n_
+    return P, M, N
+
+
+class Margin(nn.Module):
+    """task.py:85-105 + MarginLoss (loss.py:21-96): for every root, every (positive, negative) pair contributes
+    max(0, margin - pos + neg) — negatives = the root's hard negatives and the batch's random negatives; forward ->
+    (summed loss, number of pairs).  Evaluated on padded score matrices, all roots at once."""
+    task_name = "Margin"
+    result_types = ("batch_scores",)
+
+    def __init__(self, margin: float = 0.5):
+        super().__init__()
+        self.margin = float(margin)
+
+    def forward(self, task_input: NodeAnchorBasedLinkPredictionTaskInputs, gbml_config_pb_wrapper=None,
+                should_eval: bool = False, device: torch.device = torch.device("cpu")):
+        assert len(task_input.batch_scores) > 0
+        r = _ragged_scores(task_input.batch_scores, device)
+        if r is None:
+            return torch.tensor(0.0, device=device), 0
+        P, M, N = r
+        hinge = torch.relu(self.margin - P.unsqueeze(2) + N.unsqueeze(1))  # (-inf padding of N: exactly 0)
+        hinge = hinge * M.unsqueeze(2)
+        pairs = int((M.sum(1) * torch.isfinite(N).sum(1)).sum().item())
+        return hinge.sum(), pairs
+
+
+class Softmax(nn.Module):
+    """task.py:62-82 + SoftmaxLoss (loss.py:99-174): for every (root, positive) the cross-entropy of the positive
+    against the root's hard negatives and the batch's random negatives at temperature T; forward -> (summed loss,
+    number of positives)."""
+    task_name = "Softmax"
+    result_types = ("batch_scores",)
+
+    def __init__(self, softmax_temperature: float = 0.07):
+        super().__init__()
+        self.softmax_temperature = float(softmax_temperature)
+
+    def forward(self, task_input: NodeAnchorBasedLinkPredictionTaskInputs, gbml_config_pb_wrapper=None,
+                should_eval: bool = False, device: torch.device = torch.device("cpu")):
+        assert len(task_input.batch_scores) > 0
+        r = _ragged_scores(task_input.batch_scores, device)
+        if r is None:
+            return torch.tensor(0.0, device=device), 0
+        P, M, N = r
+        t = self.softmax_temperature
+        neg_lse = torch.logsumexp(N / t, dim=1, keepdim=True)                      # [S, 1] (-inf without negatives)
+        lse = torch.logaddexp(P / t, neg_lse)                                      # log(exp(pos) + sum exp(negs))
+        loss = ((lse - P / t) * M).sum()
+        return loss, int(M.sum().item())
+
+
 class NodeAnchorBasedLinkPredictionTasks:
     """task.py:699-758: weighted sum of per-sample task losses"""
 
@@ -294,6 +367,14 @@ class NodeAnchorBasedLinkPredictionTasks:
         self._task_to_fn_map[task.task_name] = task
         self._task_to_weights_map[task.task_name] = weight
 
+    @property
+    def result_types(self) -> set:
+        """what infer_task_inputs has to produce for the registered tasks (task.py result_types)"""
+        out = set()
+        for task in self._task_to_fn_map.values():
+            out |= set(getattr(task, "result_types", ("batch_combined_scores", "batch_embeddings")))
+        return out
+
     def calculate_losses(self, batch_results, gbml_config_pb_wrapper, should_eval: bool, device: torch.device):
         total = torch.tensor(0.0, device=device)
         breakdown: Dict[str, float] = {}
@@ -301,6 +382,7 @@ class NodeAnchorBasedLinkPredictionTasks:
             loss_val, bs = self._task_to_fn_map[name](task_input=batch_results,
                                                       gbml_config_pb_wrapper=gbml_config_pb_wrapper,
                                                       should_eval=should_eval, device=device)
+            bs = max(int(bs), 1)  # (a batch without any positive: zero loss, not a division by zero)
             total = total + weight * loss_val / bs
             breakdown[name] = float("{:.3f}".format(float(weight * loss_val.detach()) / bs))
         return total, breakdown
@@ -372,9 +454,15 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
                                           int(kwargs.get("early_stop_patience", 3)))
         self.tasks = NodeAnchorBasedLinkPredictionTasks()
         task_cls = import_obj(str(kwargs.get("task_path", "gigl_amd.nablp_spec.Retrieval")))
-        self.tasks.add_task(task_cls(temperature=float(kwargs.get("softmax_temp", 0.07)),
-                                     remove_accidental_hits=_strtobool(
-                                         kwargs.get("should_remove_accidental_hits", "True"))), weight=1.0)
+        import inspect
+        offered = {"temperature": float(kwargs.get("softmax_temp", 0.07)),
+                   "softmax_temperature": float(kwargs.get("softmax_temp", 0.07)),
+                   "remove_accidental_hits": _strtobool(kwargs.get("should_remove_accidental_hits", "True")),
+                   "margin": float(kwargs.get("margin", 0.5))}
+        takes = inspect.signature(task_cls.__init__).parameters
+        # (the reference passes temperature / remove_accidental_hits to whatever class task_path names — its Margin and
+        # Softmax tasks cannot be built that way; here every task gets the arguments its constructor declares)
+        self.tasks.add_task(task_cls(**{k: v for k, v in offered.items() if k in takes}), weight=1.0)
         self._model: Optional[nn.Module] = None
         self._engine = None
         self._cfg: Optional[GbmlConfigPbWrapper] = None
@@ -527,7 +615,8 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         every = max(self.validate_every_n_batches // world, 1)
         for batch_index, (main_batch, rn_batch) in enumerate(zip(main, rn), start=1):
             self._optimizer.zero_grad()
-            task_inputs = infer_task_inputs(self.model, cfg, main_batch, rn_batch, should_eval=False, device=device)
+            task_inputs = infer_task_inputs(self.model, cfg, main_batch, rn_batch, should_eval=False, device=device,
+                                            need_batch_scores="batch_scores" in self.tasks.result_types)
             loss, _ = self.tasks.calculate_losses(task_inputs, cfg, should_eval=False, device=device)
             loss.backward()
             if self.clip_grad_norm > 0:

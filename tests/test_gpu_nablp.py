@@ -328,3 +328,25 @@ def test_trainer_with_gin_and_transformer_encoders(workdir, cls, extra, key):
     out = Inferencer().run("job", cfg_uri, None, uri_base=workdir)
     rows = [json.loads(l) for l in open(out["embeddings"])]
     assert len(rows) == 27 and all(abs(np.linalg.norm(r["emb"]) - 1.0) < 1e-4 for r in rows)
+
+
+@pytest.mark.parametrize("task", ["Margin", "Softmax"])
+def test_trainer_with_margin_and_softmax_tasks(workdir, task):
+    """task_path selects the Margin / Softmax tasks (task.py:62-105): per-root scores are produced for training (not
+    only for evaluation), the loss falls, the model evaluates"""
+    import yaml
+    from gigl_amd.trainer import Trainer
+    doc = yaml.safe_load(open(os.path.join(workdir, CFG)))
+    doc["trainerConfig"]["trainerArgs"].update(task_path=f"gigl_amd.nablp_spec.{task}", margin="0.3", softmax_temp="0.1")
+    doc["sharedConfig"]["trainedModelMetadata"]["trainedModelUri"] = f"out/nablp_{task}/model.pt"
+    doc["sharedConfig"]["trainedModelMetadata"]["evalMetricsUri"] = f"out/nablp_{task}/eval_metrics.json"
+    cfg_uri = f"configs/nablp_{task}_gbml_config.yaml"
+    yaml.safe_dump(doc, open(os.path.join(workdir, cfg_uri), "w"))
+    tr = Trainer()
+    metrics = tr.run("job", cfg_uri, None, uri_base=workdir)
+    spec = tr.training_process.trainer
+    assert type(next(iter(spec.tasks._task_to_fn_map.values()))).__name__ == task
+    assert np.isfinite(metrics.metrics["loss"].value) and 0.0 < metrics.metrics["mrr"].value <= 1.0
+    hist = [h["loss"] for h in spec.history]
+    assert len(hist) >= 2 and all(np.isfinite(hist)) and min(hist[1:]) < hist[0]
+
