@@ -94,8 +94,8 @@ class GraphSAGE(nn.Module):
     activation_after_last_conv), optional L2 normalisation, return_emb, final Linear.  conv_kwargs: aggr ("mean" |
     "sum" | "max"), bias, root_weight (PyG SAGEConv); jk_mode ("cat" | "max" | "lstm") adds the JumpingKnowledge
     head over all layers' outputs (every conv then has hid_dim outputs and is followed by norm / activation).
-    feature_interaction_layer (e.g. models_more.DCNv2) runs on the node features before the first conv; the
-    vocabulary-backed feature_embedding_layer is not built.
+    feature_embedding_layer (feature_embedding.FeatureEmbeddingLayer) and feature_interaction_layer (e.g.
+    models_more.DCNv2) run on the node features before the first conv.
     State-dict keys follow the reference (conv_layers.{i}.lin_l/lin_r, batchnorm_layers.{i}, jk_layer.*, linear)."""
 
     def __init__(self, in_dim: int, hid_dim: int, out_dim: int, num_layers: int = 2,
@@ -105,9 +105,9 @@ class GraphSAGE(nn.Module):
                  jk_lstm_dim: Optional[int] = None, feature_interaction_layer: Optional[nn.Module] = None,
                  feature_embedding_layer: Optional[nn.Module] = None, **conv_kwargs):
         super().__init__()
-        if feature_embedding_layer is not None:
-            raise NotImplementedError("feature_embedding_layer (vocabulary-backed nn.Embedding columns) is not built")
-        # node feature interaction before the convolutions (homogeneous.py:117-119), e.g. models_more.DCNv2
+        # selected columns through embedding tables (homogeneous.py:112-115; gigl_amd.feature_embedding), then the node
+        # feature interaction (:117-119, e.g. models_more.DCNv2), both before the convolutions
+        self.feature_embedding_layer = feature_embedding_layer
         self.feats_interaction = feature_interaction_layer
         conv_kwargs = dict(conv_kwargs.get("conv_kwargs") or conv_kwargs)
         self.in_dim, self.hid_dim, self.out_dim, self.num_layers = in_dim, hid_dim, out_dim, num_layers
@@ -224,6 +224,8 @@ class GraphSAGE(nn.Module):
         return self._head(h)
 
     def _interact(self, x: torch.Tensor, eng: HipEngine) -> torch.Tensor:
+        if self.feature_embedding_layer is not None:
+            x = self.feature_embedding_layer(x)
         if self.feats_interaction is None:
             return x
         self.feats_interaction.engine = eng  # (its products run on this model's engine and stream)
@@ -231,7 +233,7 @@ class GraphSAGE(nn.Module):
 
     def _interacted(self, batch: HipBatch) -> HipBatch:
         """the batch with the feature-interaction layer applied to its nodes' rows (a local fp32 matrix in node order)"""
-        if self.feats_interaction is None:
+        if self.feats_interaction is None and self.feature_embedding_layer is None:
             return batch
         eng, u = batch.engine, batch.union
         cap = int(u.nodes.numel())
@@ -248,7 +250,8 @@ class GraphSAGE(nn.Module):
         `b` roots on `eng`; weights are snapshotted — call plan.set_weights(*model.fused_params()) after updates.
         groups > 1: each call takes groups*b roots and processes them as `groups` independent batches of b."""
         assert len(fanouts) == self.num_layers, "one hop per layer"
-        if not (self._plain and not self.should_l2_normalize_embedding_layer_output and self.feats_interaction is None):
+        if not (self._plain and not self.should_l2_normalize_embedding_layer_output and self.feats_interaction is None
+                and self.feature_embedding_layer is None):
             raise NotImplementedError("the one-call plan computes conv -> relu layers only; use forward(HipBatch)")
         w, bs = self.fused_params()
         return eng.make_sage_plan(w, bs, b, fanouts, act_last=self.activation_after_last_conv, groups=groups,
