@@ -235,8 +235,9 @@ class HGT(nn.Module):
                  hid_dim: int, out_dim: int = 128, num_layers: int = 2, num_heads: int = 2,
                  should_l2_normalize_embedding_layer_output: bool = False, feature_embedding_layers=None, **kwargs):
         super().__init__()
-        if feature_embedding_layers:
-            raise NotImplementedError("feature embedding layers are not built")
+        # per node type, selected columns through embedding tables before the input projections (heterogeneous.py:69,
+        # 87-92; gigl_amd.feature_embedding.FeatureEmbeddingLayer); a plain attribute, as in the reference
+        self.feature_embedding_layers = feature_embedding_layers
         node_types = list(node_type_to_feat_dim_map)
         edge_types = [tuple(e) for e in edge_type_to_feat_dim_map]
         self.lin_dict = nn.ModuleDict({t: nn.Linear(d, hid_dim) for t, d in node_type_to_feat_dim_map.items()})
@@ -250,8 +251,12 @@ class HGT(nn.Module):
         eng = _engine_for(self, any_x)
         for c in self.convs:
             c.engine = eng
+        x_dict = data.x_dict
+        if self.feature_embedding_layers:
+            x_dict = {t: (self.feature_embedding_layers[t](x) if t in self.feature_embedding_layers else x)
+                      for t, x in x_dict.items()}
         h = {t: torch.relu(_linear(eng, x, self.lin_dict[t].weight, self.lin_dict[t].bias))
-             for t, x in data.x_dict.items()}
+             for t, x in x_dict.items()}
         for conv in self.convs:
             h = conv(h, data.edge_index_dict)
         out = {}
