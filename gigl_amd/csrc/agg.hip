@@ -22,6 +22,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 #include <hip/hip_fp16.h>
 
@@ -1198,6 +1199,24 @@ __global__ __launch_bounds__(256) void gat_input_gather_kernel(
   }
 }
 
+// sum over the 64 lanes of a wave, returned to every lane, on the VALU / SALU only: four DPP steps give every lane its
+// row-of-16 total (xor 1, xor 2 inside quads, then the half-row and row mirrors), four v_readlane + scalar adds combine
+// the rows.  (__shfl_xor lowers the wide steps to ds_bpermute: the one-pass kernel below spent a quarter of its
+// instructions in the LDS pipeline on them.)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF,
+                                                                   0xF, true));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}
+
 // ---- the same first layer in ONE row pass (the one-call plan's layer 0): the folded source vectors stay in
 // registers and every edge's logit is formed from the feature row that has just been read for the aggregation, online
 // softmax over the row.  No per-node score array exists,
@@ -1224,10 +1243,7 @@ __global__ __launch_bounds__(64 * P) void gat_input_online_kernel(
   const int el = (c * 64 + lane) * 4;
   const bool on = el < d;
   auto leaky = [&](float v) { return v > 0.f ? v : slope * v; };
-  auto wsum = [](float v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-  };
+  auto wsum = [](float v) { return wave_sum_dpp(v); };
   auto dot4 = [](const float4_t& a, const float4_t& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; };
   float4_t us[H], ud[H];
 #pragma unroll
