@@ -112,3 +112,28 @@ int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, c
                           int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y);
 
 static inline int64_t gigl_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+#if defined(__HIPCC__)
+// Sum over aligned groups of `group` adjacent lanes (a power of two <= 64), returned to every lane of the group, on the
+// VALU / SALU only: DPP quad permutes for 2 and 4, the half-row / row mirrors for 8 and 16, v_readlane of the four row
+// totals for 32 and 64.  (__shfl_xor lowers the steps of width >= 4 to ds_bpermute, i.e. LDS-pipeline instructions.)
+__device__ __forceinline__ float gigl_group_sum(float v, int group) {
+#define GIGL_DPP_ADD(CTRL)                                                                                            \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true))
+  if (group >= 2) GIGL_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  if (group >= 4) GIGL_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  if (group >= 8) GIGL_DPP_ADD(0x141);   // row_half_mirror
+  if (group >= 16) GIGL_DPP_ADD(0x140);  // row_mirror
+#undef GIGL_DPP_ADD
+  if (group >= 32) {
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    if (group >= 64) return (r0 + r1) + (r2 + r3);
+    return (threadIdx.x & 32) ? r2 + r3 : r0 + r1;
+  }
+  return v;
+}
+#endif

@@ -26,10 +26,7 @@ __device__ __forceinline__ float4 add4(const float4& a, const float4& b) {
   return float4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
 }
 // sum over the `group` adjacent lanes of a head, returned to each of them
-__device__ __forceinline__ float head_sum(float p, int group) {
-  for (int off = group >> 1; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
-  return p;
-}
+__device__ __forceinline__ float head_sum(float p, int group) { return gigl_group_sum(p, group); }
 
 template <int V>
 __global__ __launch_bounds__(256) void gatv2_forward_kernel(

@@ -16,10 +16,7 @@
 namespace {
 
 // lanes [g*LPH, (g+1)*LPH) hold the chunks of head g: sum over them (LPH a power of two <= 64)
-__device__ __forceinline__ float head_sum(float v, int lph) {
-  for (int off = 1; off < lph; off <<= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ float head_sum(float v, int lph) { return gigl_group_sum(v, lph); }
 
 // HGT: online softmax over the in-edges of row i (all edge types), dot-product logits.  HD = heads * dim floats per
 // row, processed in passes of 256 floats (64 lanes x float4) when HD > 256 is not needed: HD <= 256 * PASSES.
