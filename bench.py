@@ -900,6 +900,12 @@ def run_gat_lp(args, rank, world, local_rank):
         else:
             main = encode(torch.cat([a[0], pos[0]]), count).unsqueeze(0)  # (INVALID positive: no out-edge)
             rn = encode(ng[0], count).unsqueeze(0)
+        if plans is not None and not os.environ.get("GIGL_BENCH_GAT_TAIL_PER_BATCH"):
+            # decoder + loss of the G batches: one GEMM launch (batch in grid.y) and one loss pass, bit-identical to the
+            # per-batch entry points below (tests/test_gpu_entry_points.py::test_batched_decoder_and_loss)
+            scores = eng.linear_batched(main[:, :B], torch.cat([main[:, B:], rn], dim=1))  # [B, G, B + n_neg]
+            return eng.retrieval_loss_batched(scores, 0.07, None, a.long().contiguous(),
+                                              torch.cat([pos, ng], dim=1).long())
         losses = []
         for g_ in range(G):
             scores = dec(main[g_, :B], torch.cat([main[g_, B:], rn[g_]]))

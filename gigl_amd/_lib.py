@@ -28,6 +28,7 @@ SYMBOLS = [
     "gigl_graph_info", "gigl_graph_device_ptrs", "gigl_graph_destroy", "gigl_features_load",
     "gigl_features_device_ptr", "gigl_features_destroy", "gigl_sample_khop", "gigl_sample_positives",
     "gigl_union_capacity", "gigl_union_build", "gigl_gather_mean", "gigl_linear",
+    "gigl_linear_batched", "gigl_retrieval_loss_batched",
     "gigl_profile_enable", "gigl_profile_read", "gigl_profile_reset",
     "gigl_sage_plan_create", "gigl_sage_plan_set_weights", "gigl_sage_plan_buffers", "gigl_sage_plan_run",
     "gigl_sage_plan_destroy", "gigl_gather_mean_backward", "gigl_expand_frontier", "gigl_gcn_aggregate",
@@ -197,6 +198,8 @@ def load() -> C.CDLL:
         "gigl_sage_plan_set_groups": [vp, i32],
         "gigl_gather_mean": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i64, vp],
         "gigl_linear": [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp],
+        "gigl_linear_batched": [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i64, i64, i32, vp],
+        "gigl_retrieval_loss_batched": [vp, vp, i64, i64, i32, i32, i32, C.c_float, vp, vp, vp, vp, vp, vp],
         "gigl_profile_enable": [vp, C.c_uint32, i32],
         "gigl_profile_read": [vp, i32, P(C.c_double), P(i64)],
         "gigl_profile_reset": [vp],

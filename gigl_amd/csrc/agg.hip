@@ -2417,6 +2417,33 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
   return GIGL_OK;
 }
 
+// `batch` independent products of equal shape in one launch (row-major operands, k % 4 == 0): product b reads
+// a + b * a_bstride ([m, k]) and w + b * w_bstride ([n, k]) and writes columns [b * n, (b + 1) * n) of y's rows
+// (ldy >= batch * n floats apart).  The score blocks of a group of link-prediction batches (decoder.py:64-66, one
+// torch.mm per batch in the reference) come out of one launch this way.
+int32_t gigl_linear_batched(gigl_ctx* ctx, const float* a, const float* w, const float* bias, const int32_t* m_dev,
+                            int64_t m_cap, int32_t k, int32_t n, int32_t act, int32_t batch, int64_t a_bstride,
+                            int64_t w_bstride, int32_t ldy, float* y) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, a && w && m_dev && y, "null argument");
+  GIGL_REQUIRE(ctx, k > 0 && (k & 3) == 0 && n > 0 && m_cap >= 0 && batch >= 1 && batch <= 65535 &&
+                        (int64_t)ldy >= (int64_t)n * batch && a_bstride >= 0 && w_bstride >= 0,
+               "bad sizes (k=%d n=%d batch=%d ldy=%d)", k, n, batch, ldy);
+  GIGL_REQUIRE(ctx, act == 0 || act == 1, "bad act %d", act);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (m_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
+  const int64_t bm = (m_cap + 127) / 128;
+  if (n > 64)
+    hipLaunchKernelGGL((linear_split_kernel<2, true>), dim3((unsigned)(bm * ((n + 127) / 128)), (unsigned)batch),
+                       dim3(256), 0, ctx->stream, a, w, bias, m_dev, k, n, act, y, 0, ldy, a_bstride, w_bstride);
+  else
+    hipLaunchKernelGGL((linear_split_kernel<1, true>), dim3((unsigned)(bm * ((n + 63) / 64)), (unsigned)batch),
+                       dim3(256), 0, ctx->stream, a, w, bias, m_dev, k, n, act, y, 0, ldy, a_bstride, w_bstride);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
                           int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y) {
   if (!ctx) return GIGL_E_INVALID_ARG;

@@ -27,6 +27,8 @@ struct LossArgs {
   const float* cand_prob;
   const int64_t* query_ids;
   const int64_t* cand_ids;
+  int64_t g_scores;  // grid.y = independent batches: batch g's score block starts g_scores floats on, its ids / prob
+                     // / per-row outputs follow the previous batch's (q or c entries each)
 };
 
 __device__ __forceinline__ float logit(const LossArgs& a, float raw, int j) {
@@ -49,10 +51,20 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2
   m = mm;
 }
 
-__global__ __launch_bounds__(256) void retrieval_rows_kernel(LossArgs a, float* __restrict__ masked_out,
+__global__ __launch_bounds__(256) void retrieval_rows_kernel(LossArgs a0, float* __restrict__ masked_out,
                                                              float* __restrict__ row_lse,
                                                              float* __restrict__ row_loss) {
   __shared__ float s_m[4], s_s[4];
+  LossArgs a = a0;
+  if (const int64_t g = blockIdx.y) {
+    a.scores += g * a.g_scores;
+    if (a.cand_prob) a.cand_prob += g * a.c;
+    if (a.query_ids) a.query_ids += g * a.q;
+    if (a.cand_ids) a.cand_ids += g * a.c;
+    if (masked_out) masked_out += g * a.q * a.c;
+    row_lse += g * a.q;
+    row_loss += g * a.q;
+  }
   const int i = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const float* row = a.scores + (int64_t)i * a.ld;
@@ -93,6 +105,8 @@ __global__ __launch_bounds__(256) void retrieval_rows_kernel(LossArgs a, float* 
 __global__ __launch_bounds__(1024) void sum_rows_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
   __shared__ double s_w[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  v += (int64_t)blockIdx.x * n;  // (one workgroup per batch)
+  out += blockIdx.x;
   double acc = 0.0;
   for (int i = tid; i < n; i += 1024) acc += (double)v[i];
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
@@ -206,6 +220,25 @@ int32_t gigl_retrieval_loss(gigl_ctx* ctx, const float* scores, int64_t ld, int3
   hipLaunchKernelGGL(retrieval_rows_kernel, dim3((unsigned)q), dim3(256), 0, ctx->stream, a, masked_scores, row_lse,
                      row_loss);
   hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(1024), 0, ctx->stream, row_loss, q, loss);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_retrieval_loss_batched(gigl_ctx* ctx, const float* scores, int64_t ld, int64_t batch_stride, int32_t q,
+                                    int32_t c, int32_t batches, float temperature, const float* cand_prob,
+                                    const int64_t* query_ids, const int64_t* cand_ids, float* row_lse, float* row_loss,
+                                    float* loss) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  LossArgs a{};
+  int32_t rc = make_args(ctx, a, scores, ld, q, c, temperature, cand_prob, query_ids, cand_ids);
+  if (rc != GIGL_OK) return rc;
+  GIGL_REQUIRE(ctx, row_lse && row_loss && loss && batches >= 1 && batches <= 65535 && batch_stride >= 0,
+               "bad arguments (batches=%d)", batches);
+  a.g_scores = batch_stride;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(retrieval_rows_kernel, dim3((unsigned)q, (unsigned)batches), dim3(256), 0, ctx->stream, a,
+                     (float*)nullptr, row_lse, row_loss);
+  hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)batches), dim3(1024), 0, ctx->stream, row_loss, q, loss);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -975,6 +975,41 @@ class HipEngine:
               self._ctx)
         return loss, lse, masked
 
+    def linear_batched(self, a: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """a [G, M, K] (rows contiguous; the batch stride is free), w [G, N, K] -> y [M, G, N] with
+        y[:, g] = a[g] @ w[g]^T: gigl_linear_batched (one launch for the G products)"""
+        assert a.is_cuda and a.dtype == w.dtype == torch.float32 and a.dim() == w.dim() == 3
+        g, m, k = (int(v) for v in a.shape)
+        n = int(w.shape[1])
+        assert w.shape[0] == g and w.shape[2] == k and a.stride(2) == 1 and a.stride(1) == k
+        assert w.stride(2) == 1 and w.stride(1) == k
+        y = torch.empty((m, g, n), dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(self._lib.gigl_linear_batched(self._ctx, p(a), p(w), None, p(dev_i32(self.device, m)), m, k, n, 0, g,
+                                            int(a.stride(0)), int(w.stride(0)), g * n, p(y)), self._ctx)
+        return y
+
+    def retrieval_loss_batched(self, scores: torch.Tensor, temperature: Optional[float],
+                               cand_prob: Optional[torch.Tensor], query_ids: Optional[torch.Tensor],
+                               cand_ids: Optional[torch.Tensor]) -> torch.Tensor:
+        """scores [Q, G, C] (as linear_batched writes them), query_ids [G, Q], cand_ids / cand_prob [G, C] -> the G
+        losses: gigl_retrieval_loss_batched (forward only)"""
+        assert scores.is_cuda and scores.dtype == torch.float32 and scores.dim() == 3 and scores.is_contiguous()
+        q, g, c = (int(v) for v in scores.shape)
+        for t, n in ((cand_prob, c), (query_ids, q), (cand_ids, c)):
+            assert t is None or (t.is_contiguous() and tuple(t.shape) == (g, n))
+        assert query_ids is None or query_ids.dtype == torch.int64
+        assert cand_ids is None or cand_ids.dtype == torch.int64
+        lse = torch.empty((g, q), dtype=torch.float32, device=self.device)
+        row_loss = torch.empty((g, q), dtype=torch.float32, device=self.device)
+        loss = torch.empty(g, dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(self._lib.gigl_retrieval_loss_batched(self._ctx, p(scores), g * c, c, q, c, g,
+                                                    float(temperature) if temperature is not None else 0.0,
+                                                    p(cand_prob), p(query_ids), p(cand_ids), p(lse), p(row_loss),
+                                                    p(loss)), self._ctx)
+        return loss
+
     def retrieval_loss_backward(self, scores, temperature, cand_prob, query_ids, cand_ids, lse, grad_loss):
         q, c = int(scores.shape[0]), int(scores.shape[1])
         d = torch.empty((q, c), dtype=torch.float32, device=self.device)

@@ -706,6 +706,14 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
                     const int32_t* m_dev, int64_t m_cap, int32_t k, int32_t n, int32_t act,
                     float* y);
 
+/* `batch` independent products of equal shape in one launch (row-major operands, k % 4 == 0): product b reads
+ * a + b * a_bstride ([m][k]) and w + b * w_bstride ([n][k]) and writes columns [b * n, (b + 1) * n) of y's rows, which
+ * are ldy >= batch * n floats apart.  The inner-product decoder of a group of batches (decoder.py:64-66: one torch.mm
+ * per batch in the reference) is one call. */
+int32_t gigl_linear_batched(gigl_ctx* ctx, const float* a, const float* w, const float* bias, const int32_t* m_dev,
+                            int64_t m_cap, int32_t k, int32_t n, int32_t act, int32_t batch, int64_t a_bstride,
+                            int64_t w_bstride, int32_t ldy, float* y);
+
 /* ---- retrieval loss of the link-prediction head, fused (temperature -> sampling-probability correction -> duplicate
  *      / accidental-hit masking -> log-softmax -> cross-entropy against the diagonal, one pass over the scores).
  *      Replaces RetrievalLoss.calculate_batch_retrieval_loss with _mask_by_query_ids / _mask_by_candidate_ids
@@ -721,6 +729,14 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
 int32_t gigl_retrieval_loss(gigl_ctx* ctx, const float* scores, int64_t ld, int32_t q, int32_t c, float temperature,
                             const float* cand_prob, const int64_t* query_ids, const int64_t* cand_ids,
                             float* masked_scores, float* row_lse, float* row_loss, float* loss);
+/* `batches` independent retrieval losses of equal shape in one pass (the forward of gigl_retrieval_loss per batch;
+ * RetrievalLoss.calculate_batch_retrieval_loss, loss.py:209-277, called once per batch by the reference): batch g's
+ * scores start batch_stride floats after batch g-1's (rows ld apart), its query_ids / cand_ids / cand_prob / row_lse /
+ * row_loss are the g-th block of q or c entries, loss[g] its summed cross-entropy. */
+int32_t gigl_retrieval_loss_batched(gigl_ctx* ctx, const float* scores, int64_t ld, int64_t batch_stride, int32_t q,
+                                    int32_t c, int32_t batches, float temperature, const float* cand_prob,
+                                    const int64_t* query_ids, const int64_t* cand_ids, float* row_lse, float* row_loss,
+                                    float* loss);
 int32_t gigl_retrieval_loss_backward(gigl_ctx* ctx, const float* scores, int64_t ld, int32_t q, int32_t c,
                                      float temperature, const float* cand_prob, const int64_t* query_ids,
                                      const int64_t* cand_ids, const float* row_lse, const float* grad_loss,

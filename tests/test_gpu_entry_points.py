@@ -531,3 +531,39 @@ def test_typed_sampler_job_options(workdir):
     for m in everyone:
         if not m.pos_edges:
             assert (m.root_node.node_id, 1) in {(x.node_id, x.condensed_node_type) for x in m.neighborhood.nodes}
+
+
+@pytest.mark.gpu
+def test_batched_decoder_and_loss():
+    """gigl_linear_batched + gigl_retrieval_loss_batched over G batches == the per-batch entry points, bit for bit
+    (same kernels, batch in grid.y); the per-batch loss is itself pinned on the reference's known answers in
+    test_link_prediction.py"""
+    import torch
+    from gigl_amd.engine import default_engine
+    from gigl_amd.link_prediction import DecoderType, LinkPredictionDecoder, RetrievalLoss
+    dev = torch.device("cuda:0")
+    eng = default_engine(dev)
+    gen = torch.Generator().manual_seed(5)
+    for G, B, n_neg, D in ((3, 40, 70, 64), (5, 130, 1, 128), (1, 7, 9, 32)):
+        main = torch.randn(G, 2 * B, D, generator=gen).to(dev)
+        rn = torch.randn(G, n_neg, D, generator=gen).to(dev)
+        a = torch.randint(0, 50, (G, B), generator=gen).to(dev)  # (small id range: both masks fire)
+        cid = torch.randint(0, 50, (G, B + n_neg), generator=gen).to(dev)
+        scores = eng.linear_batched(main[:, :B], torch.cat([main[:, B:], rn], dim=1))
+        got = eng.retrieval_loss_batched(scores, 0.07, None, a, cid)
+        dec = LinkPredictionDecoder(DecoderType.inner_product)
+        dec.engine = eng
+        loss_fn = RetrievalLoss(temperature=0.07, remove_accidental_hits=True)
+        for g in range(G):
+            s = dec(main[g, :B], torch.cat([main[g, B:], rn[g]]))
+            assert torch.equal(s, scores[:, g])
+            want = loss_fn.calculate_batch_retrieval_loss(s, query_ids=a[g], candidate_ids=cid[g])
+            assert torch.equal(want, got[g]), (G, B, g, float(want), float(got[g]))
+        # with the sampling-probability correction
+        prob = torch.rand(G, B + n_neg, generator=gen).to(dev)
+        got = eng.retrieval_loss_batched(scores, None, prob, a, None)
+        loss_fn = RetrievalLoss()
+        for g in range(G):
+            want = loss_fn.calculate_batch_retrieval_loss(scores[:, g].contiguous(), candidate_sampling_probability=prob[g],
+                                                          query_ids=a[g])
+            assert torch.equal(want, got[g])
