@@ -51,6 +51,7 @@ SYMBOLS = [
     "gigl_collate_typed_records", "gigl_collated_typed_info", "gigl_collated_typed_nodes", "gigl_collated_typed_edges",
     "gigl_collated_typed_samples", "gigl_collated_typed_destroy", "gigl_typed_records_capacity",
     "gigl_typed_records_encode", "gigl_typed_samples_encode", "gigl_hgt_aggregate_backward", "gigl_weighted_aggregate_backward",
+    "gigl_graph_build_shard_from_coo", "gigl_json_rows_capacity", "gigl_json_rows_format",
 ]
 
 KERNEL_IDS = {
@@ -183,6 +184,8 @@ def load() -> C.CDLL:
         "gigl_memcpy": [vp, vp, i32, vp, i32, i64],
         "gigl_graph_load_csc": [vp, i64, i64, vp, vp, i32, P(vp)],
         "gigl_graph_build_from_coo": [vp, i64, i64, vp, vp, i32, i32, P(vp)],
+        "gigl_graph_build_shard_from_coo": [vp, i64, i32, i32, i64, vp, vp, i32, i32, P(vp)],
+        "gigl_json_rows_format": [vp, vp, i64, vp, i64, i32, vp, i64, P(i64)],
         "gigl_graph_info": [vp, P(i64), P(i64)],
         "gigl_graph_device_ptrs": [vp, P(vp), P(vp)],
         "gigl_graph_destroy": [vp],
@@ -304,6 +307,8 @@ def load() -> C.CDLL:
     lib.gigl_gat_input_layer_scratch.restype = i64
     lib.gigl_gat_input_layer_fused_scratch.argtypes = [i32, i32, i64]
     lib.gigl_gat_input_layer_fused_scratch.restype = i64
+    lib.gigl_json_rows_capacity.argtypes = [i64, i32]
+    lib.gigl_json_rows_capacity.restype = i64
     _lib = lib
     return lib
 

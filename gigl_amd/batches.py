@@ -432,6 +432,14 @@ class NodeAnchorBasedLinkPredictionBatch:
             condensed_node_type_to_subgraph_id_to_global_node_id={0: {l: g for l, g in enumerate(c["node_ids"].tolist())}})
 
 
+def permuted_files(files: Sequence[str], seed: int = 42) -> List[str]:
+    """the file list permuted once with RandomState(seed) (tf_records_iterable_dataset.py:66-68)"""
+    files = list(files)
+    if not files:
+        return files
+    return list(np.random.RandomState(seed).permutation(np.array(files, dtype=object)))
+
+
 def iterate_tfrecord_batches(files: Sequence[str], batch_size: int, rank: int = 0, world_size: int = 1,
                              seed: int = 42, loop: bool = False):
     """TfRecordsIterableDataset (tf_records_iterable_dataset.py:49-82) + get_data_split_for_current_worker
@@ -439,11 +447,9 @@ def iterate_tfrecord_batches(files: Sequence[str], batch_size: int, rank: int = 
     across ranks, records are batched in order; loop=True cycles forever (LoopyIterableDataset :85-109).  With
     more ranks than files the list is tiled first (utils.py:38-47: data is replicated rather than leaving a rank
     without batches — a rank that skips the loop would leave the others waiting in the DDP gradient all-reduce)."""
-    files = list(files)
-    if files:
-        files = list(np.random.RandomState(seed).permutation(np.array(files, dtype=object)))
-        if world_size > len(files):
-            files = files * (-(-world_size // len(files)))
+    files = permuted_files(files, seed)
+    if files and world_size > len(files):
+        files = files * (-(-world_size // len(files)))
     mine = files[rank::world_size]
     while True:
         buf: List[bytes] = []

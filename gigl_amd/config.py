@@ -27,6 +27,11 @@ def _get(d, path, default=None):
     return cur
 
 
+# records per part file the sampler writes (spark-tfrecord part files, TFRecordIO.scala:53-69); the in-HBM route derives
+# the TFRecord route's reading order from it (gigl_amd/hbm.py), so both read it HERE at call time
+RECORDS_PER_PART_FILE = 100_000
+
+
 def resolve_uri(uri: str, uri_base: Optional[str]) -> str:
     if uri is None:
         raise ValueError("missing URI")

@@ -22,6 +22,10 @@
 //           offsets are arbitrary byte offsets), coalesced loads of the row.
 #include "common.h"
 
+#include <charconv>
+#include <cstring>
+#include <thread>
+
 namespace {
 
 constexpr int MAX_BLOCK_RECORDS = 2048;
@@ -231,6 +235,76 @@ int32_t gigl_avro_embeddings_encode(gigl_ctx* ctx, const int64_t* ids, const flo
                        rec_off);
   GIGL_HIP_CHECK(ctx, hipMemcpyAsync(total_bytes, blk_off + n_blocks, 8, hipMemcpyDeviceToDevice, ctx->stream));
   GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+
+// ---- line-per-root JSON rows (the local stand-in for the reference's BigQuery rows: one {"node_id", "emb"} /
+// {"node_id", "pred"} object per root, python/gigl/src/inference/v1/lib/base_inference_blueprint.py:76-103).  Host
+// code: the rows are already on the host when they are written to a file; replaces a per-root Python loop with one
+// call that formats row ranges on worker threads.  Floats are printed with the shortest decimal that parses back to
+// the same fp32 (std::to_chars), non-finite values as Python's json module prints them (NaN / Infinity / -Infinity).
+int64_t gigl_json_rows_capacity(int64_t n, int32_t dim) {
+  if (n < 0 || dim < 0) return -1;
+  return n * (48 + (int64_t)dim * 18) + 16;
+}
+
+int32_t gigl_json_rows_format(const int64_t* ids, const float* emb, int64_t emb_stride, const int32_t* pred, int64_t n,
+                              int32_t dim, char* out, int64_t out_cap, int64_t* bytes) {
+  if (!ids || !out || !bytes || n < 0 || dim < 0 || (!emb && !pred) || (emb && emb_stride < dim))
+    return GIGL_E_INVALID_ARG;
+  if (out_cap < gigl_json_rows_capacity(n, dim)) return GIGL_E_INVALID_ARG;
+  unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)(hw ? (hw > 32 ? 32 : hw) : 4);
+  if (n < 4096) nt = 1;
+  std::vector<std::string> part((size_t)nt);
+  auto work = [&](int t) {
+    const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+    std::string& o = part[(size_t)t];
+    o.reserve((size_t)((hi - lo) * (emb ? 32 + (int64_t)dim * 12 : 40)));
+    char buf[48];
+    for (int64_t i = lo; i < hi; ++i) {
+      o += "{\"node_id\": ";
+      auto r = std::to_chars(buf, buf + sizeof(buf), (long long)ids[i]);
+      o.append(buf, (size_t)(r.ptr - buf));
+      if (emb) {
+        o += ", \"emb\": [";
+        const float* row = emb + i * emb_stride;
+        for (int c = 0; c < dim; ++c) {
+          if (c) o += ", ";
+          const float v = row[c];
+          if (v != v) o += "NaN";
+          else if (v > 3.402823466e38f) o += "Infinity";
+          else if (v < -3.402823466e38f) o += "-Infinity";
+          else {
+            r = std::to_chars(buf, buf + sizeof(buf), v);
+            o.append(buf, (size_t)(r.ptr - buf));
+          }
+        }
+        o += "]";
+      }
+      if (pred) {
+        o += ", \"pred\": ";
+        r = std::to_chars(buf, buf + sizeof(buf), (int)pred[i]);
+        o.append(buf, (size_t)(r.ptr - buf));
+      }
+      o += "}\n";
+    }
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  int64_t at = 0;
+  for (auto& o : part) {
+    if (at + (int64_t)o.size() > out_cap) return GIGL_E_INVALID_ARG;
+    memcpy(out + at, o.data(), o.size());
+    at += (int64_t)o.size();
+  }
+  *bytes = at;
   return GIGL_OK;
 }
 

@@ -29,6 +29,51 @@ __global__ void coo_keys_kernel(const uint32_t* src, const uint32_t* dst, int64_
   }
 }
 
+// ---- sharded ingest (owner(v) = v % world, edges follow the DESTINATION): every input record in one (directed) or both
+// (undirected) orientations; an orientation s -> d is kept by the rank that owns d, as row d / world of its shard, the
+// source id stays global.  Two passes over the input: count the kept records, then append them (order is irrelevant:
+// the keys are sorted afterwards).
+__device__ __forceinline__ bool shard_key(uint32_t s, uint32_t d, int rank, int world, uint64_t* key) {
+  if ((int)(d % (uint32_t)world) != rank) return false;
+  *key = ((uint64_t)(d / (uint32_t)world) << 32) | s;
+  return true;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void coo_shard_keys_kernel(const uint32_t* __restrict__ src,
+                                                             const uint32_t* __restrict__ dst, int64_t e, int64_t n,
+                                                             int directed, int rank, int world,
+                                                             unsigned long long* __restrict__ count,
+                                                             uint64_t* __restrict__ keys, int32_t* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t k[2] = {0, 0};
+  int nk = 0;
+  if (i < e) {
+    const uint32_t s = src[i], d = dst[i];
+    if ((int64_t)s >= n || (int64_t)d >= n) {
+      if (!FILL) atomicAdd(bad, 1);
+    } else {
+      if (shard_key(s, d, rank, world, &k[nk])) ++nk;
+      if (!directed && shard_key(d, s, rank, world, &k[nk])) ++nk;
+    }
+  }
+  // one atomic per wave: lanes take consecutive places
+  int incl = nk;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off, 64);
+    if ((int)(threadIdx.x & 63) >= off) incl += o;
+  }
+  const int total = __shfl(incl, 63, 64);
+  if (total == 0) return;
+  unsigned long long base = 0;
+  if ((threadIdx.x & 63) == 63) base = atomicAdd(count, (unsigned long long)total);
+  base = __shfl(base, 63, 64);
+  if (FILL) {
+    const unsigned long long at = base + (unsigned long long)(incl - nk);
+    for (int q = 0; q < nk; ++q) keys[at + q] = k[q];
+  }
+}
+
 // keep_all != 0: every record stays (directed multi-edges: the reference's collect_list keeps repeated (src, dst)
 // rows, SGSPureSparkV1Task.scala:337,442); *any_dup reports whether a record repeats
 __global__ void uniq_flag_kernel(const uint64_t* sorted, int64_t m, int32_t* flags, int keep_all, int32_t* any_dup) {
@@ -260,6 +305,134 @@ extern "C" int32_t gigl_graph_build_from_coo(gigl_ctx* ctx, int64_t n, int64_t e
   BUILD_CHECK(hipMalloc((void**)&g->col, (size_t)(h_count > 0 ? h_count : 1) * 4));
   hipLaunchKernelGGL(csc_col_kernel, grid(h_count), dim3(TB), 0, st, keys, h_count, g->col);
   hipLaunchKernelGGL(csc_rowptr_kernel, grid(n + 1), dim3(TB), 0, st, keys, h_count, n, g->rowptr);
+  BUILD_CHECK(hipGetLastError());
+  BUILD_CHECK(hipStreamSynchronize(st));
+#undef BUILD_CHECK
+  {
+    int32_t rc = gigl_graph_compute_maxdeg(ctx, g);
+    if (rc != GIGL_OK) {
+      gigl_graph_destroy(g);
+      return rc;
+    }
+  }
+  *out = g;
+  return GIGL_OK;
+}
+
+// Sharded ingest: the shard of rank `rank` of a graph hash-partitioned over `world` ranks (owner(v) = v % world, edges
+// follow the destination: dist_link_prediction_data_partitioner.py:692-695), built straight from the whole edge list:
+// both orientations of every record when the graph is undirected (enforceBidirectionalization,
+// SGSPureSparkV1Task.scala:218-258), the orientations whose destination this rank owns are kept as row dst / world,
+// source ids stay global.  Equal to partitioning the rows of gigl_graph_build_from_coo's result.
+extern "C" int32_t gigl_graph_build_shard_from_coo(gigl_ctx* ctx, int64_t n, int32_t rank, int32_t world, int64_t e,
+                                                   const uint32_t* src, const uint32_t* dst, int32_t loc,
+                                                   int32_t is_directed, gigl_graph** out) {
+  if (!ctx || !out) return GIGL_E_INVALID_ARG;
+  *out = nullptr;
+  GIGL_REQUIRE(ctx, n >= 0 && e >= 0 && (e == 0 || (src && dst)), "bad COO arguments");
+  GIGL_REQUIRE(ctx, n < (int64_t)GIGL_INVALID, "node ids must fit uint32");
+  GIGL_REQUIRE(ctx, world >= 1 && rank >= 0 && rank < world, "bad rank %d / world %d", rank, world);
+  GIGL_REQUIRE(ctx, loc == GIGL_LOC_HOST || loc == GIGL_LOC_DEVICE, "bad loc %d", loc);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int64_t n_rows = n > rank ? (n - rank + world - 1) / world : 0;
+
+  gigl_graph* g = new (std::nothrow) gigl_graph();
+  if (!g) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
+  g->ctx = ctx;
+  g->n = n_rows;
+  struct Tmp {
+    void* p[10] = {nullptr};
+    int k = 0;
+    ~Tmp() { for (int i = 0; i < k; ++i) if (p[i]) hipFree(p[i]); }
+    hipError_t alloc(void** q, size_t bytes) {
+      hipError_t r = hipMalloc(q, bytes ? bytes : 16);
+      if (r == hipSuccess) p[k++] = *q;
+      return r;
+    }
+  } tmp;
+#define BUILD_CHECK(expr)                                                                  \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      gigl_graph_destroy(g);                                                               \
+      return gigl_fail(ctx, _e == hipErrorOutOfMemory ? GIGL_E_OOM : GIGL_E_HIP,           \
+                       "%s failed: %s", #expr, hipGetErrorString(_e));                     \
+    }                                                                                      \
+  } while (0)
+  BUILD_CHECK(hipMalloc((void**)&g->rowptr, (size_t)(n_rows + 1) * sizeof(int64_t)));
+  const uint32_t *dsrc = src, *ddst = dst;
+  if (loc == GIGL_LOC_HOST && e > 0) {
+    uint32_t *a, *b;
+    BUILD_CHECK(tmp.alloc((void**)&a, (size_t)e * 4));
+    BUILD_CHECK(tmp.alloc((void**)&b, (size_t)e * 4));
+    BUILD_CHECK(hipMemcpyAsync(a, src, (size_t)e * 4, hipMemcpyHostToDevice, st));
+    BUILD_CHECK(hipMemcpyAsync(b, dst, (size_t)e * 4, hipMemcpyHostToDevice, st));
+    dsrc = a;
+    ddst = b;
+  }
+  int32_t* bad;
+  BUILD_CHECK(tmp.alloc((void**)&bad, 256));
+  unsigned long long* cnt = (unsigned long long*)((char*)bad + 64);
+  int64_t* count = (int64_t*)((char*)bad + 128);
+  BUILD_CHECK(hipMemsetAsync(bad, 0, 256, st));
+  const int TB = 256;
+  auto grid = [&](int64_t c) { return dim3((unsigned)((c + TB - 1) / TB)); };
+  unsigned long long h_kept = 0;
+  int32_t h_bad = 0;
+  if (e > 0) {
+    hipLaunchKernelGGL(coo_shard_keys_kernel<false>, grid(e), dim3(TB), 0, st, dsrc, ddst, e, n, is_directed ? 1 : 0,
+                       (int)rank, (int)world, cnt, (uint64_t*)nullptr, bad);
+    BUILD_CHECK(hipMemcpyAsync(&h_kept, cnt, 8, hipMemcpyDeviceToHost, st));
+    BUILD_CHECK(hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, st));
+    BUILD_CHECK(hipStreamSynchronize(st));
+  }
+  if (h_bad) {
+    gigl_graph_destroy(g);
+    return gigl_fail(ctx, GIGL_E_INVALID_ARG, "%d edges reference node ids >= n=%lld", h_bad, (long long)n);
+  }
+  const int64_t m = (int64_t)h_kept;
+  if (m >= ((int64_t)1 << 31)) {
+    gigl_graph_destroy(g);
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "more than 2^31 directed edge records in one shard");
+  }
+  if (m == 0) {
+    BUILD_CHECK(hipMalloc((void**)&g->col, 16));
+    BUILD_CHECK(hipMemsetAsync(g->rowptr, 0, (size_t)(n_rows + 1) * sizeof(int64_t), st));
+    BUILD_CHECK(hipStreamSynchronize(st));
+    g->e = 0;
+    *out = g;
+    return GIGL_OK;
+  }
+  uint64_t *keys, *sorted;
+  int32_t *flags, *scan;
+  BUILD_CHECK(tmp.alloc((void**)&keys, (size_t)m * 8));
+  BUILD_CHECK(tmp.alloc((void**)&sorted, (size_t)m * 8));
+  BUILD_CHECK(tmp.alloc((void**)&flags, (size_t)m * 4));
+  BUILD_CHECK(tmp.alloc((void**)&scan, (size_t)m * 4));
+  BUILD_CHECK(hipMemsetAsync(cnt, 0, 8, st));
+  hipLaunchKernelGGL(coo_shard_keys_kernel<true>, grid(e), dim3(TB), 0, st, dsrc, ddst, e, n, is_directed ? 1 : 0,
+                     (int)rank, (int)world, cnt, keys, bad);
+  int key_bits = 33;
+  while (key_bits < 64 && (1LL << (key_bits - 32)) < n_rows) ++key_bits;
+  size_t t1 = 0, t2 = 0;
+  hipcub::DeviceRadixSort::SortKeys((void*)nullptr, t1, keys, sorted, (int)m, 0, key_bits, st);
+  hipcub::DeviceScan::ExclusiveSum((void*)nullptr, t2, flags, scan, (int)m, st);
+  size_t tb = t1 > t2 ? t1 : t2;
+  void* work;
+  BUILD_CHECK(tmp.alloc(&work, tb));
+  BUILD_CHECK(hipcub::DeviceRadixSort::SortKeys(work, tb, keys, sorted, (int)m, 0, key_bits, st));
+  const int keep_all = is_directed == 2 ? 1 : 0;
+  hipLaunchKernelGGL(uniq_flag_kernel, grid(m), dim3(TB), 0, st, sorted, m, flags, keep_all, bad + 1);
+  BUILD_CHECK(hipcub::DeviceScan::ExclusiveSum(work, tb, flags, scan, (int)m, st));
+  hipLaunchKernelGGL(uniq_write_kernel, grid(m), dim3(TB), 0, st, sorted, flags, scan, m, keys, count);
+  int64_t h_count = 0;
+  BUILD_CHECK(hipMemcpyAsync(&h_count, count, 8, hipMemcpyDeviceToHost, st));
+  BUILD_CHECK(hipStreamSynchronize(st));
+  g->e = h_count;
+  BUILD_CHECK(hipMalloc((void**)&g->col, (size_t)(h_count > 0 ? h_count : 1) * 4));
+  hipLaunchKernelGGL(csc_col_kernel, grid(h_count), dim3(TB), 0, st, keys, h_count, g->col);
+  hipLaunchKernelGGL(csc_rowptr_kernel, grid(n_rows + 1), dim3(TB), 0, st, keys, h_count, n_rows, g->rowptr);
   BUILD_CHECK(hipGetLastError());
   BUILD_CHECK(hipStreamSynchronize(st));
 #undef BUILD_CHECK

@@ -75,10 +75,16 @@ struct gigl_sage_plan {
 
 namespace {
 
+// (a failed batch set — meta[GIGL_META_OVERFLOW] != 0: levels zeroed, nothing computed — hands out NaN rows, never the
+// previous call's activations)
 __global__ void take_rows_kernel(const float* __restrict__ h, const int32_t* __restrict__ root_local, int b, int d,
-                                 float* __restrict__ out) {
+                                 const int32_t* __restrict__ meta, float* __restrict__ out) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)b * d) return;
+  if (meta[GIGL_META_OVERFLOW] != 0) {
+    out[i] = __builtin_nanf("");
+    return;
+  }
   int r = (int)(i / d), c = (int)(i % d);
   int32_t l = root_local[r];
   out[i] = l >= 0 ? h[(int64_t)l * d + c] : 0.f;
@@ -192,7 +198,7 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
     const int dout = p->dims[L];
     const int64_t total = (int64_t)p->b * dout;
     hipLaunchKernelGGL(take_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                       p->hbuf[(L - 1) & 1], p->un.root_local, p->b, dout, out);
+                       p->hbuf[(L - 1) & 1], p->un.root_local, p->b, dout, p->un.meta, out);
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     return GIGL_OK;
   }

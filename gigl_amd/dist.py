@@ -452,6 +452,23 @@ class DistSagePlan:
         assert acc.is_cuda and acc.dtype == torch.int64 and acc.numel() >= 16
         _check(self._lib.gigl_dist_plan_stats(self._plan, C.c_void_p(acc.data_ptr())), self.eng._ctx)
 
+    def overflowed(self) -> bool:
+        """True when the step run last failed (a hop / row bucket or the workspace overflowed: its output rows are NaN).
+        Reads meta[GIGL_META_OVERFLOW] from the device: synchronises the plan's stream — call it where the step's rows
+        are consumed anyway"""
+        from ._lib import GIGL_META_LEN, GiglTree, GiglUnion, LOC_DEVICE, LOC_HOST
+        t, u = GiglTree(), GiglUnion()
+        _check(self._lib.gigl_dist_plan_buffers(self._plan, C.byref(t), C.byref(u)), self.eng._ctx)
+        meta = np.empty(GIGL_META_LEN, dtype=np.int32)
+        _check(self._lib.gigl_memcpy(self.eng._ctx, C.c_void_p(meta.ctypes.data), LOC_HOST, C.c_void_p(u.meta), LOC_DEVICE,
+                                     meta.nbytes), self.eng._ctx)
+        return bool(meta[8])
+
+    def raise_on_overflow(self) -> None:
+        if self.overflowed():
+            raise RuntimeError("sharded step failed: a hop / feature-row bucket or the activation workspace overflowed "
+                               "(meta[GIGL_META_OVERFLOW]); its rows are NaN — raise hop_slack / pull_cap and redo the batch")
+
     def buffers_to_host(self):
         """host copies of the last step's tree and union graph (like SagePlan.last_batch_to_host)"""
         from ._lib import GIGL_META_LEN, GiglTree, GiglUnion, LOC_DEVICE, LOC_HOST

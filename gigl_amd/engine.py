@@ -211,6 +211,23 @@ class HipEngine:
         check(self._lib.gigl_graph_info(g, C.byref(nn), C.byref(ee)), self._ctx)
         self._set_graph(g, nn.value, ee.value, out_graph)
 
+    def build_shard_from_coo(self, n: int, rank: int, world: int, src, dst, is_directed: bool,
+                             keep_multi_edges: bool = False) -> None:
+        """this rank's shard of the graph hash-partitioned over `world` ranks, from the WHOLE edge list
+        (gigl_graph_build_shard_from_coo): rows = the nodes with id % world == rank (row id // world), ids inside the
+        rows stay global.  n_nodes stays the GLOBAL node count; n_edges = the shard's."""
+        s, s_p, loc1 = self._ptr_loc(src if isinstance(src, torch.Tensor) else np.asarray(src).astype(np.uint32))
+        d, d_p, loc2 = self._ptr_loc(dst if isinstance(dst, torch.Tensor) else np.asarray(dst).astype(np.uint32))
+        assert loc1 == loc2
+        g = C.c_void_p()
+        mode = (2 if keep_multi_edges else 1) if is_directed else 0
+        check(self._lib.gigl_graph_build_shard_from_coo(self._ctx, n, rank, world, int(s.shape[0]), s_p, d_p, loc1, mode,
+                                                        C.byref(g)), self._ctx)
+        nn, ee = C.c_int64(), C.c_int64()
+        check(self._lib.gigl_graph_info(g, C.byref(nn), C.byref(ee)), self._ctx)
+        self._set_graph(g, int(n), ee.value, False)
+        self.n_shard_rows = nn.value
+
     def _set_graph(self, g, n, e, out_graph):
         attr = "_graph_out" if out_graph else "_graph"
         old = getattr(self, attr)
@@ -1032,18 +1049,28 @@ class HipEngine:
         return plan
 
 
-_DEV_I32 = {}
+from collections import OrderedDict
+
+_DEV_I32: "OrderedDict" = OrderedDict()
+_DEV_I32_MAX = 256
 
 
 def dev_i32(device, value: int) -> torch.Tensor:
     """a cached one-element int32 device tensor (row counts handed to the library by pointer): created once per
-    (device, value) — a fresh torch.tensor([...], device=...) per call is a pageable host-to-device copy, which
-    synchronises and cannot be captured in a graph"""
-    key = (str(device), int(value))
+    (device index, value) — a fresh torch.tensor([...], device=...) per call is a pageable host-to-device copy, which
+    synchronises and cannot be captured in a graph.  A small LRU: callers pass per-batch sizes (numbers of candidates),
+    so the set of values is unbounded over a job; an evicted tensor stays alive while a launch still holds it."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else -1)
+    key = (dev.type, idx, int(value))
     t = _DEV_I32.get(key)
     if t is None:
         t = torch.tensor([int(value)], dtype=torch.int32, device=device)
         _DEV_I32[key] = t
+        if len(_DEV_I32) > _DEV_I32_MAX:
+            _DEV_I32.popitem(last=False)
+    else:
+        _DEV_I32.move_to_end(key)
     return t
 
 

@@ -18,6 +18,7 @@ import json
 import os
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 
 from .base import BaseInferencer, import_obj
@@ -37,73 +38,165 @@ def generate_inferencer_instance(cfg: GbmlConfigPbWrapper) -> BaseInferencer:
     return inferencer
 
 
+class _RowWriter:
+    """one output row per root, in batch order: {"node_id", "emb"} / {"node_id", "pred"}
+    (base_inference_blueprint.py:76-103).  An embeddingsPath that ends in "/" is a directory of Avro shards written by
+    the device-side EmbeddingExporter (the format the reference's exporter hands to BigQuery,
+    python/gigl/common/data/export.py); a file path gets line-per-root JSON, formatted natively
+    (gigl_json_rows_format).  WORLD_SIZE > 1: every rank writes its own files (Avro shards prefixed rank_<r>, JSON
+    files suffixed .rank<r>)."""
+
+    def __init__(self, out_files: Dict[str, str], node_type: str, rank: int = 0, world: int = 1):
+        self.node_type, self.n_rows = node_type, 0
+        self.exporter = self.emb_fh = self.pred_fh = None
+        sfx = f".rank{rank}" if world > 1 else ""
+        for p in out_files.values():
+            os.makedirs(os.path.dirname(p.rstrip("/")) or ".", exist_ok=True)
+        emb = out_files.get("embeddings")
+        if emb and emb.endswith("/"):
+            from .export import EmbeddingExporter
+            self.exporter = EmbeddingExporter(emb, file_prefix=(f"rank_{rank}" if world > 1 else None),
+                                              min_shard_size_threshold_bytes=1 << 28)
+        elif emb:
+            out_files["embeddings"] = emb + sfx
+            self.emb_fh = open(emb + sfx, "wb")
+        if out_files.get("predictions"):
+            out_files["predictions"] += sfx
+            self.pred_fh = open(out_files["predictions"], "wb")
+
+    @staticmethod
+    def _json(ids: np.ndarray, emb: Optional[torch.Tensor], pred: Optional[torch.Tensor]) -> memoryview:
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        n = int(ids.size)
+        e = None if emb is None else np.ascontiguousarray(emb.detach().to("cpu", torch.float32).numpy())
+        pr = None if pred is None else np.ascontiguousarray(pred.detach().to("cpu", torch.int32).numpy())
+        d = 0 if e is None else int(e.shape[1])
+        cap = int(lib.gigl_json_rows_capacity(n, d))
+        buf = np.empty(cap, dtype=np.uint8)
+        used = C.c_int64()
+        _lib.check(lib.gigl_json_rows_format(
+            C.c_void_p(ids.ctypes.data), C.c_void_p(e.ctypes.data) if e is not None else None, d,
+            C.c_void_p(pr.ctypes.data) if pr is not None else None, n, d, C.c_void_p(buf.ctypes.data), cap,
+            C.byref(used)))
+        return memoryview(buf[: used.value])
+
+    def add(self, ids: np.ndarray, embeddings: Optional[torch.Tensor], predictions: Optional[torch.Tensor]) -> None:
+        if self.exporter is not None and embeddings is not None:
+            self.exporter.add_embedding(torch.from_numpy(np.asarray(ids, dtype=np.int64)), embeddings, self.node_type)
+        if self.emb_fh is not None and embeddings is not None:
+            self.emb_fh.write(self._json(ids, embeddings, None))
+        if self.pred_fh is not None and predictions is not None:
+            self.pred_fh.write(self._json(ids, None, predictions))
+        self.n_rows += int(np.asarray(ids).size)
+
+    def close(self) -> None:
+        if self.exporter is not None:
+            self.exporter.flush_embeddings()
+        for fh in (self.emb_fh, self.pred_fh):
+            if fh is not None:
+                fh.close()
+
+
 class Inferencer:
     def run(self, applied_task_identifier: str, task_config_uri: str, resource_config_uri: Optional[str] = None,
             custom_worker_image_uri: Optional[str] = None, cpu_docker_uri: Optional[str] = None,
-            cuda_docker_uri: Optional[str] = None, *, uri_base: Optional[str] = None, device: int = 0) -> Dict[str, str]:
+            cuda_docker_uri: Optional[str] = None, *, uri_base: Optional[str] = None, device: Optional[int] = None,
+            route: Optional[str] = None) -> Dict[str, str]:
+        """route: "hbm" (graph + features resident in HBM, batches sampled there: gigl_amd/hbm.py), "tfrecord" (the
+        sampler's RootedNodeNeighborhood files, the reference's dataflow) or None = the plugin's `data_route` argument /
+        GIGL_AMD_ROUTE / auto.  Both routes walk the same roots in the same batches and write the same rows.
+        One process per GPU: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment, as the trainer."""
         if not torch.cuda.is_available():
             raise RuntimeError("gigl_amd.Inferencer needs a HIP device; there is no CPU fallback")
-        cfg = GbmlConfigPbWrapper.from_uri(task_config_uri, uri_base=uri_base)
-        dev = torch.device("cuda", device)
-        inferencer = generate_inferencer_instance(cfg)
-        inferencer.model = inferencer.model.to(dev)
-        if cfg.is_heterogeneous:
-            return self._run_typed(cfg, inferencer, dev)
+        import torch.distributed as dist
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        dev_index = int(os.environ.get("LOCAL_RANK", "0")) if device is None else int(device)
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
+        started_pg = False
+        if world > 1 and not dist.is_initialized():
+            dist.init_process_group(backend=os.environ.get("GIGL_DIST_BACKEND") or "nccl")
+            started_pg = True
+        try:
+            cfg = GbmlConfigPbWrapper.from_uri(task_config_uri, uri_base=uri_base)
+            inferencer = generate_inferencer_instance(cfg)
+            inferencer.model = inferencer.model.to(dev)
+            if cfg.is_heterogeneous:
+                self.route = "tfrecord"
+                return self._run_typed(cfg, inferencer, dev)
+            from .hbm import route_of
+            self.route = route_of(cfg, cfg.inferencer_args, route)
+            if self.route == "hbm" and not getattr(inferencer, "supports_hbm_batches", False):
+                if route == "hbm":
+                    raise NotImplementedError(f"{type(inferencer).__name__} does not take in-HBM batches")
+                self.route = "tfrecord"
+            info = (_get(cfg.doc, "sharedConfig.inferenceMetadata.nodeTypeToInferencerOutputInfoMap", {}) or {})
+            out_files: Dict[str, str] = {}
+            for _, v in info.items():
+                if v.get("embeddingsPath"):
+                    out_files["embeddings"] = resolve_uri(v["embeddingsPath"], cfg.uri_base)
+                if v.get("predictionsPath"):
+                    out_files["predictions"] = resolve_uri(v["predictionsPath"], cfg.uri_base)
+            writer = _RowWriter(out_files, str(cfg.node_types[0]), rank, world)
+            try:
+                if self.route == "hbm":
+                    self._run_hbm(cfg, inferencer, dev, writer, rank, world)
+                else:
+                    if world > 1:
+                        raise NotImplementedError("the TFRecord route runs in one process; WORLD_SIZE > 1 takes the "
+                                                  "in-HBM route (route='hbm')")
+                    self._run_tfrecord(cfg, inferencer, dev, writer)
+            finally:
+                writer.close()
+            self.rows_written = writer.n_rows
+            return out_files
+        finally:
+            if started_pg:
+                dist.destroy_process_group()
+
+    @staticmethod
+    def _run_tfrecord(cfg: GbmlConfigPbWrapper, inferencer, dev, writer: _RowWriter) -> None:
+        """the reference's dataflow: RootedNodeNeighborhood TFRecords -> collate -> infer_batch"""
         if cfg.task_kind == "node_classification":
             files = tfrecord_files(cfg.unlabeled_tfrecord_uri_prefix)
         else:
             files = [f for p in cfg.random_negative_tfrecord_uri_prefixes.values() for f in tfrecord_files(p)]
-        info = (_get(cfg.doc, "sharedConfig.inferenceMetadata.nodeTypeToInferencerOutputInfoMap", {}) or {})
-        out_files: Dict[str, str] = {}
-        emb_fh = pred_fh = None
-        for _, v in info.items():
-            if v.get("embeddingsPath"):
-                out_files["embeddings"] = resolve_uri(v["embeddingsPath"], cfg.uri_base)
-            if v.get("predictionsPath"):
-                out_files["predictions"] = resolve_uri(v["predictionsPath"], cfg.uri_base)
-        for p in out_files.values():
-            os.makedirs(os.path.dirname(p) or ".", exist_ok=True)
-        # an embeddingsPath ending in "/" is a directory of Avro shards written by the device-side EmbeddingExporter
-        # (the format the reference's exporter hands to BigQuery, python/gigl/common/data/export.py); a file path
-        # keeps the line-per-root JSON output
-        exporter = None
-        if out_files.get("embeddings", "").endswith("/"):
-            from .export import EmbeddingExporter
-            exporter = EmbeddingExporter(out_files["embeddings"], min_shard_size_threshold_bytes=1 << 28)
-        elif "embeddings" in out_files:
-            emb_fh = open(out_files["embeddings"], "w")
-        if "predictions" in out_files:
-            pred_fh = open(out_files["predictions"], "w")
-        n_rows = 0
+        for raw in iterate_tfrecord_batches(files, cfg.inference_batch_size):
+            rnn = RootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(raw, cfg.node_types[0])
+            if cfg.task_kind == "node_classification":
+                batch = SupervisedNodeClassificationBatch(
+                    graph=rnn.graph, root_node_indices=rnn.condensed_node_type_to_root_node_indices_map[0],
+                    root_nodes=rnn.root_nodes, root_node_labels=None)
+            else:  # link prediction plugins take the RootedNodeNeighborhoodBatch (utils.py:78-228)
+                batch = rnn
+            res = inferencer.infer_batch(batch=batch, device=dev)
+            writer.add(np.array([r.id for r in batch.root_nodes], dtype=np.int64), res.embeddings, res.predictions)
+
+    def _run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev, writer: _RowWriter, rank: int, world: int) -> None:
+        """graph + features resident in HBM (this rank's shard at WORLD_SIZE > 1), every batch sampled, union-ed and
+        encoded there by the one-call plan; the same roots in the same batches as _run_tfrecord"""
+        from .hbm import ResidentGraph
+        resident = ResidentGraph(cfg, dev, rank=rank, world=world)
         try:
-            for raw in iterate_tfrecord_batches(files, cfg.inference_batch_size):
-                rnn = RootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(raw, cfg.node_types[0])
-                if cfg.task_kind == "node_classification":
-                    batch = SupervisedNodeClassificationBatch(
-                        graph=rnn.graph, root_node_indices=rnn.condensed_node_type_to_root_node_indices_map[0],
-                        root_nodes=rnn.root_nodes, root_node_labels=None)
-                else:  # link prediction plugins take the RootedNodeNeighborhoodBatch (utils.py:78-228)
-                    batch = rnn
-                res = inferencer.infer_batch(batch=batch, device=dev)
-                if exporter is not None and res.embeddings is not None:
-                    ids = torch.tensor([r.id for r in batch.root_nodes], dtype=torch.int64)
-                    exporter.add_embedding(ids, res.embeddings, str(cfg.node_types[0]))
-                emb = res.embeddings.cpu() if res.embeddings is not None and emb_fh is not None else None
-                pred = res.predictions.cpu() if res.predictions is not None else None
-                for i, root in enumerate(batch.root_nodes):  # one row per root, in batch order
-                    if emb_fh is not None and emb is not None:
-                        emb_fh.write(json.dumps({"node_id": root.id, "emb": emb[i].tolist()}) + "\n")
-                    if pred_fh is not None and pred is not None:
-                        pred_fh.write(json.dumps({"node_id": root.id, "pred": int(pred[i])}) + "\n")
-                    n_rows += 1
+            ids = resident.inference_root_order()
+            b = cfg.inference_batch_size
+            slots = 1
+            for f in reversed(resident.fanouts):
+                slots = 1 + f * slots
+            n_batches = -(-ids.size // b) if ids.size else 0
+            per_rank = max(1, -(-n_batches // world))
+            # batches per library call: as many as keep the call's tree under ~2^26 slots, at most 64
+            groups = int(max(1, min(64, per_rank, (1 << 26) // max(b * slots, 1))))
+            self.hbm_groups = groups
+            for hb in resident.root_batches(ids, b, groups):
+                res = inferencer.infer_batch(batch=hb, device=dev)
+                if hb.root_ids.size:
+                    writer.add(hb.root_ids, res.embeddings, res.predictions)
         finally:
-            if exporter is not None:
-                exporter.flush_embeddings()
-            for fh in (emb_fh, pred_fh):
-                if fh is not None:
-                    fh.close()
-        self.rows_written = n_rows
-        return out_files
+            resident.close()
 
 
 def _typed_run(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str, str]:

@@ -225,6 +225,8 @@ class RetrievalLoss(nn.Module):
         prob = None
         if candidate_sampling_probability is not None:
             prob = candidate_sampling_probability.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+            if prob.numel() != c:  # (the reference's `scores - log(prob)` would fail to broadcast)
+                raise ValueError(f"candidate_sampling_probability has {prob.numel()} entries for {c} candidates")
         qid = _ids_on(query_ids, dev, q, "query_ids")
         cid = _ids_on(candidate_ids, dev, c, "candidate_ids") if self._remove_accidental_hits else None
         if self._loss is None:

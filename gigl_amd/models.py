@@ -32,10 +32,15 @@ class HipBatch:
     x: Optional[torch.Tensor] = None  # None: hydrate from the engine's resident feature table
     edge_attr: Optional[torch.Tensor] = None  # [cap_edges, De] rows aligned with union.col; None: engine.union_edge_attr
     x_index: Optional[torch.Tensor] = None  # int32 [cap]: row of `x` holding local node i (x is then NOT in node order)
+    train: bool = False  # a training batch (gigl_amd/hbm.py): models run it with autograd when gradients are enabled
 
     @property
     def root_local(self) -> torch.Tensor:
         return self.union.root_local[: self.tree.b]
+
+    def to(self, device=None, **_):
+        """the batch already lives in HBM (the loops written for collated batches call batch.graph.to(device))"""
+        return self
 
 
 class SAGEConv(nn.Module):
@@ -186,8 +191,42 @@ class GraphSAGE(nn.Module):
             if self.jk_layer is not None:
                 h = self.jk_layer(xs)
             return self._head(h)
+        if batch.train and torch.is_grad_enabled():
+            return self._forward_union_autograd(batch)
         with torch.no_grad():
             return self._forward_union(batch)
+
+    def _forward_union_autograd(self, batch: HipBatch) -> torch.Tensor:
+        """training over a batch sampled in HBM: the trimmed schedule of _forward_union with autograd — layer l
+        computes the rows of level <= L-1-l (a prefix of the level-ordered union graph, at most b*(1 + f0 + ...) rows:
+        the static bound sizes every buffer, the exact count stays on the device), the first layer reads the resident
+        feature table through union.nodes.  Root rows and every parameter gradient equal the reference's
+        every-layer-over-the-whole-union order (only root rows enter the loss)."""
+        from .nn import RowsView, sage_conv
+        eng, u, tree = batch.engine, batch.union, batch.tree
+        L = self.num_layers
+        assert u.hops == L, "one hop per layer"
+        if batch.x is not None or self.feats_interaction is not None or self.feature_embedding_layer is not None or \
+                self.batchnorm:
+            raise NotImplementedError("training over HipBatch: resident feature table, no feature interaction layers, "
+                                      "no batch norm (rows beyond the layer's count are padding)")
+        h, xs = None, []
+        for l, conv in enumerate(self.conv_layers):
+            rows, width = 0, tree.b
+            for i in range(L - l):
+                rows += width
+                width *= tree.fanouts[i] if i < L else 1
+            rows = min(rows, int(u.nodes.numel()))
+            n_rows = u.meta[GIGL_META_LEVEL0 + (L - 1 - l): GIGL_META_LEVEL0 + (L - l)]
+            view = RowsView(u.rowptr, u.rowend, u.col, n_rows, rows, gather_ids=u.nodes if l == 0 else None)
+            fused = self._plain and (l < L - 1 or self.activation_after_last_conv)
+            w_r = conv.lin_r.weight if conv.lin_r is not None else torch.zeros_like(conv.lin_l.weight)
+            h = sage_conv(h, conv.lin_l.weight, conv.lin_l.bias, w_r, eng, view, fused, self.aggr)
+            h = self._post(h, l, fused)
+            xs.append(h)
+        if self.jk_layer is not None:
+            raise NotImplementedError("training over HipBatch with JumpingKnowledge: use the GraphData route")
+        return self._head(h)
 
     def _forward_union(self, batch: HipBatch) -> torch.Tensor:
         eng, u = batch.engine, batch.union

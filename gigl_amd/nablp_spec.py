@@ -486,6 +486,13 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
     def supports_distributed_training(self) -> bool:
         return True
 
+    @property
+    def supports_hbm_batches(self) -> bool:
+        """infer_batch also takes batches sampled in HBM (gigl_amd/hbm.py) when the encoder runs over a HipBatch"""
+        from .hbm import encoder_takes_hip_batches
+        inner = self.model.module if hasattr(self.model, "module") else self.model
+        return inner is not None and encoder_takes_hip_batches(getattr(inner, "encoder", inner))
+
     def init_model(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, state_dict=None) -> nn.Module:
         self._cfg = gbml_config_pb_wrapper
         if gbml_config_pb_wrapper.is_heterogeneous:
@@ -691,6 +698,11 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
     @no_grad_eval
     def infer_batch(self, batch: RootedNodeNeighborhoodBatch, device: torch.device = torch.device("cpu")
                     ) -> InferBatchResults:
+        from .hbm import HbmRootBatch
+        if isinstance(batch, HbmRootBatch):  # roots of a graph resident in HBM (gigl_amd/hbm.py)
+            inner = self.model.module if hasattr(self.model, "module") else self.model
+            enc = inner.encoder if hasattr(inner, "encoder") else inner
+            return InferBatchResults(embeddings=batch.resident.encode(enc, batch), predictions=None)
         self._ensure_engine(device)
         keys = list(batch.condensed_node_type_to_root_node_indices_map.keys())
         assert len(keys) == 1, ("RootedNodeNeighborhoodBatch for inference must have only one root node type. "

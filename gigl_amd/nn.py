@@ -65,18 +65,41 @@ class GraphData:
         self.n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
 
 
+@dataclass
+class RowsView:
+    """the rows one SAGE layer computes over a device-resident union graph (models.HipBatch): row i < *n_dev is
+    col[rowptr[i] : rowend[i]]; `rows` bounds the launch and sizes the output (static, so nothing is read back from the
+    device); gather_ids translates a column entry into a row of the source (union.nodes -> the resident feature table)"""
+    rowptr: torch.Tensor
+    rowend: Optional[torch.Tensor]
+    col: torch.Tensor
+    n_dev: torch.Tensor
+    rows: int
+    gather_ids: Optional[torch.Tensor] = None
+
+
 class _SageConvFn(torch.autograd.Function):
-    """y = act([mean_{j->i} h_j | h_i] @ [W_l | W_r]^T + b) over ALL rows of the graph"""
+    """y = act([mean_{j->i} h_j | h_i] @ [W_l | W_r]^T + b) over the rows of `g`: a GraphData (every row of the batch
+    graph, packed CSR) or a RowsView (a prefix of a union graph's rows; h None = the engine's resident feature table,
+    which takes no gradient)"""
 
     @staticmethod
-    def forward(ctx, h, w_l, b_l, w_r, eng: HipEngine, g: GraphData, act: int, aggr: str = "mean"):
-        n, d = int(h.shape[0]), int(h.shape[1])
-        h = h.contiguous()
-        a = eng.gather_mean(h, d, None, g.rowptr, None, g.col, g.n_dev, n, aggr=aggr)
+    def forward(ctx, h, w_l, b_l, w_r, eng: HipEngine, g, act: int, aggr: str = "mean"):
+        view = isinstance(g, RowsView)
+        d = int(w_l.shape[1])
+        n = g.rows if view else int(h.shape[0])
+        if h is not None:
+            h = h.contiguous()
+        # rows beyond *n_dev are never written: they must read as zeros in the weight-gradient product
+        out = torch.zeros((n, 2 * d), dtype=torch.float32, device=w_l.device) if view else None
+        a = eng.gather_mean(h, d, g.gather_ids if view else None, g.rowptr, g.rowend if view else None, g.col, g.n_dev,
+                            n, out=out, aggr=aggr)
         wcat = torch.cat([w_l, w_r], dim=1).contiguous()
-        y = eng.linear(a, wcat, b_l, g.n_dev, n, act)
+        y = eng.linear(a, wcat, b_l, g.n_dev, n, act,
+                       out=torch.zeros((n, int(w_l.shape[0])), dtype=torch.float32, device=w_l.device) if view else None)
         ctx.eng, ctx.g, ctx.act, ctx.d, ctx.aggr = eng, g, act, d, aggr
         ctx.has_bias = b_l is not None
+        ctx.src_rows = None if h is None else int(h.shape[0])
         ctx.save_for_backward(a, wcat, y, *([h] if aggr == "max" else []))
         return y
 
@@ -92,17 +115,17 @@ class _SageConvFn(torch.autograd.Function):
         # dW[N, 2d] = dy^T[N, n] @ a[n, 2d]  ->  linear(a = dy^T, w = a^T)
         n_out = dev_i32(dev, dy.shape[1])
         dw = eng.linear(dy.t().contiguous(), a.t().contiguous(), None, n_out, int(dy.shape[1]), 0)
-        # da[n, 2d] = dy[n, N] @ wcat[N, 2d]  ->  linear(a = dy, w = wcat^T)
-        da = eng.linear(dy, wcat.t().contiguous(), None, g.n_dev, n, 0)
         dh = None
         if ctx.needs_input_grad[0]:
-            dh = torch.zeros((n, d), dtype=torch.float32, device=dev)
-            eng.gather_mean_backward(da, d, g.rowptr, None, g.col, g.n_dev, n, dh, aggr=ctx.aggr,
+            # da[n, 2d] = dy[n, N] @ wcat[N, 2d]  ->  linear(a = dy, w = wcat^T)
+            da = eng.linear(dy, wcat.t().contiguous(), None, g.n_dev, n, 0)
+            dh = torch.zeros((ctx.src_rows, d), dtype=torch.float32, device=dev)
+            eng.gather_mean_backward(da, d, g.rowptr, getattr(g, "rowend", None), g.col, g.n_dev, n, dh, aggr=ctx.aggr,
                                      src=ctx.saved_tensors[3] if ctx.aggr == "max" else None)
         db = dy.sum(0) if ctx.has_bias else None
         return dh, dw[:, :d].contiguous(), db, dw[:, d:].contiguous(), None, None, None, None
 
 
-def sage_conv(h: torch.Tensor, w_l: torch.Tensor, b_l: Optional[torch.Tensor], w_r: torch.Tensor, eng: HipEngine,
+def sage_conv(h: Optional[torch.Tensor], w_l: torch.Tensor, b_l: Optional[torch.Tensor], w_r: torch.Tensor, eng: HipEngine,
               g: GraphData, act: bool, aggr: str = "mean") -> torch.Tensor:
     return _SageConvFn.apply(h, w_l, b_l, w_r, eng, g, 1 if act else 0, aggr)

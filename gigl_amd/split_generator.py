@@ -440,8 +440,17 @@ def _prefill_assigner(strat, samples) -> int:
         eng = default_engine(torch.device("cuda", torch.cuda.current_device()))
     except Exception:  # noqa: BLE001 — no device / no library: host hashing
         return 0
+    try:
+        return _prefill(assigner, eng, samples)
+    except Exception:  # noqa: BLE001 — any device-side failure: the assigner hashes on demand on the host instead
+        return 0
+
+
+def _prefill(assigner, eng, samples) -> int:
     graphs = [g for g in (getattr(smp, "neighborhood", None) for smp in samples) if g is not None]
     if isinstance(assigner, NodeToDatasetSplitHashingAssigner):
+        # ids come from Node records only: they carry their condensed type (an edge's endpoints are nodes of the same
+        # neighbourhood, so they are all there — TaskOutputValidator.scala:84-107 — under their real type)
         by_type: Dict[int, set] = {}
         for smp in samples:
             r = getattr(smp, "root_node", None)
@@ -450,8 +459,6 @@ def _prefill_assigner(strat, samples) -> int:
         for g in graphs:
             for nd in g.nodes:
                 by_type.setdefault(nd.condensed_node_type or 0, set()).add(nd.node_id)
-            for e in g.edges:
-                by_type.setdefault(0, set()).update((e.src_node_id, e.dst_node_id))
         return sum(assigner.prefill(eng, np.fromiter(ids, dtype=np.uint32, count=len(ids)), condensed_type=t)
                    for t, ids in by_type.items())
     by_type_e: Dict[int, set] = {}

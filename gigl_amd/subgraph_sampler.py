@@ -116,8 +116,9 @@ class _PartWriter:
     """spark-tfrecord writes part files under the prefix directory (TFRecordIO.scala:53-69, overwrite mode);
     takes already framed records (bytes + record offsets) and rolls to a new part every records_per_file"""
 
-    def __init__(self, prefix: str, records_per_file: int = 100_000):
-        self.prefix, self.per = prefix, records_per_file
+    def __init__(self, prefix: str, records_per_file: Optional[int] = None):
+        from . import config
+        self.prefix, self.per = prefix, int(records_per_file or config.RECORDS_PER_PART_FILE)
         self.is_dir = prefix.endswith("/") or prefix.endswith(os.sep)
         d = prefix if self.is_dir else os.path.dirname(prefix)
         os.makedirs(d or ".", exist_ok=True)

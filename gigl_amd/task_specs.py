@@ -17,6 +17,7 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -58,6 +59,9 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
         self._model: Optional[torch.nn.Module] = None
         self._engine = None
         self._cfg: Optional[GbmlConfigPbWrapper] = None
+        self._kwargs = {k: str(v) for k, v in kwargs.items()}
+        self._resident = None  # gigl_amd.hbm.ResidentGraph of the in-HBM route
+        self._device: Optional[torch.device] = None
 
     # ---- BaseModelOperationsProtocol
     @property
@@ -71,6 +75,15 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
     @property
     def supports_distributed_training(self) -> bool:
         return True
+
+    @property
+    def supports_hbm_batches(self) -> bool:
+        """the in-HBM route (gigl_amd/hbm.py): infer_batch / the training loop also take batches sampled in HBM"""
+        from .hbm import encoder_takes_hip_batches
+        return self.model is not None and encoder_takes_hip_batches(self._inner_model())
+
+    def _inner_model(self) -> torch.nn.Module:
+        return self.model.module if hasattr(self.model, "module") else self.model
 
     def init_model(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, state_dict=None) -> torch.nn.Module:
         self._cfg = gbml_config_pb_wrapper
@@ -102,11 +115,74 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
         self._train_loss_fn = lambda input, target: F.cross_entropy(input=input, target=target)
         self.model.train()
 
-    # ---- data
+    # ---- data: the in-HBM route (gigl_amd/hbm.py) — training batches sampled in HBM from the resident graph
+    def _hbm_split(self, cfg: GbmlConfigPbWrapper):
+        """-> {split: (root ids, labels)} when the job's batches can be sampled in HBM, else None (TFRecord route).
+        The roots of a split and their order are those of the files the TFRecord route reads: the labeled samples the
+        sampler writes (ascending ids with a label and an in-edge), each sent to the split the split generator's
+        node assigner gives its root (TransductiveSupervisedNodeClassificationSplitStrategy, no subsampling); without
+        a splitGeneratorConfig: the root-id rule of _split_batches below."""
+        from .hbm import ResidentGraph, route_of
+        if getattr(self, "_hbm_splits", None) is not None:
+            return self._hbm_splits or None
+        self._hbm_splits = {}
+        route = route_of(cfg, self._kwargs)
+        if route != "hbm" or not self.supports_hbm_batches or self._device is None or self._device.type != "cuda":
+            return None
+        # the same rule as the TFRecord route below: split files written by the SplitGenerator -> its assignment
+        # (recomputed from the job's splitGeneratorConfig, no file is read); none written -> the root-id rule
+        from .config import _get
+        assign = None
+        uri = cfg.dataset_split_uri("train")
+        if uri and tfrecord_files(uri):
+            if not _get(cfg.doc, "datasetConfig.splitGeneratorConfig"):
+                return None  # split files of unknown provenance: read them
+            from .split_generator import TransductiveSupervisedNodeClassificationSplitStrategy, build_strategy
+            try:
+                strat = build_strategy(cfg)
+            except NotImplementedError:
+                return None
+            if type(strat) is not TransductiveSupervisedNodeClassificationSplitStrategy or \
+                    any(r < 1.0 for r in strat.subsample.ratio.values()):
+                return None  # (inductive splits cut the neighbourhoods; subsampling draws per sample: TFRecord route)
+            assign = lambda nid: strat.assigner.assign_id(int(nid), 0)
+        else:
+            import warnings
+            warnings.warn("no split-generator output (datasetMetadata.*DataUri is absent or empty): falling back to a "
+                          "root-id split of the labeled samples; run the SplitGenerator for the reference's splits",
+                          RuntimeWarning, stacklevel=2)
+        rank, world = _rank_world()
+        self._resident = ResidentGraph(cfg, self._device, rank=rank, world=world, sharded=False)
+        ids, labels = self._resident.labeled_root_order()
+        splits = {}
+        if assign is not None:
+            which = np.array([assign(i) for i in ids.tolist()], dtype=object)
+            for sp in ("train", "val", "test"):
+                m = which == sp
+                splits[sp] = (ids[m], labels[m])
+        else:
+            for sp, want in (("train", range(0, 8)), ("val", (8,)), ("test", (9,))):
+                m = np.isin(ids % 10, list(want)) if ids.size >= 100 else np.ones(ids.size, dtype=bool)
+                splits[sp] = (ids[m], labels[m])
+        self._hbm_splits = splits
+        return splits
+
+    def close(self) -> None:
+        if self._resident is not None:
+            self._resident.close()
+            self._resident = None
+        self._hbm_splits = None
+
     def _split_batches(self, cfg: GbmlConfigPbWrapper, split: str):
-        """the split generator's output for `split` (datasetMetadata.supervisedNodeClassificationDataset.*DataUri,
+        """in-HBM route: batches of the split's roots sampled in HBM (see _hbm_split).  TFRecord route: the split
+        generator's output for `split` (datasetMetadata.supervisedNodeClassificationDataset.*DataUri,
         read like the reference's dataloaders); without one configured / written, the labeled sampler output is
         used directly: root id % 10 (0-7 train, 8 val, 9 test), tiny fixtures (< 100 samples) whole in every split"""
+        hbm = self._hbm_split(cfg)
+        if hbm is not None:
+            ids, labels = hbm[split]
+            yield from self._resident.train_batches(ids, labels, self._batch_size)
+            return
         rank, world = _rank_world()
         uri = cfg.dataset_split_uri(split)
         if uri and tfrecord_files(uri):
@@ -151,6 +227,10 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
     @no_grad_eval
     def infer_batch(self, batch: SupervisedNodeClassificationBatch, device: torch.device = torch.device("cpu")
                     ) -> InferBatchResults:
+        from .hbm import HbmRootBatch
+        if isinstance(batch, HbmRootBatch):  # roots of a graph resident in HBM: sampled, union-ed and encoded there
+            embed = batch.resident.encode(self._inner_model(), batch)
+            return InferBatchResults(embeddings=embed, predictions=embed.argmax(dim=1))
         self._ensure_engine(device)
         inputs = batch.graph.to(device)
         root_node_indices = batch.root_node_indices.to(device)
@@ -176,6 +256,7 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
         return num_correct / max(num_evaluated, 1)
 
     def train(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, device: torch.device, profiler=None) -> None:
+        self._device = device
         self._ensure_engine(device)
         best_val_acc = 0.0
         self.history: List[Dict[str, float]] = []
@@ -189,6 +270,7 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
                 profiler.step()
 
     def eval(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, device: torch.device) -> EvalMetricsCollection:
+        self._device = device
         self._ensure_engine(device)
         test_acc = self.score(self._split_batches(gbml_config_pb_wrapper, "test"), device)
         return EvalMetricsCollection(metrics=[EvalMetric.from_eval_metric_type(EvalMetricType.acc, test_acc)])

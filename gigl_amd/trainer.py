@@ -59,6 +59,7 @@ class GnnTrainingProcess:
         import torch.distributed as dist
         world = int(os.environ.get("WORLD_SIZE", "1"))
         started_pg = False
+        trainer = None
         if world > 1 and not dist.is_initialized():
             # (GIGL_DIST_BACKEND: e.g. gloo when several ranks share one GPU, where RCCL refuses duplicate devices)
             backend = os.environ.get("GIGL_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
@@ -87,8 +88,11 @@ class GnnTrainingProcess:
                 json.dump({"metrics": [{"name": m.name, "numberValue": m.value, "format": "RAW"}
                                        for m in metrics.metrics.values()]}, open(cfg.eval_metrics_uri, "w"))
             self.trainer = trainer
+            self.route = "hbm" if getattr(trainer, "_resident", None) is not None else "tfrecord"
             return metrics
         finally:
+            if trainer is not None and hasattr(trainer, "close"):
+                trainer.close()  # (the in-HBM route's resident graph)
             if started_pg:
                 dist.destroy_process_group()
 

@@ -115,6 +115,17 @@ int32_t gigl_graph_load_csc(gigl_ctx* ctx, int64_t n, int64_t e, const int64_t* 
 int32_t gigl_graph_build_from_coo(gigl_ctx* ctx, int64_t n, int64_t e, const uint32_t* src,
                                   const uint32_t* dst, int32_t loc, int32_t is_directed,
                                   gigl_graph** out);
+/* The same ingest for ONE rank of a graph hash-partitioned over `world` ranks — replaces the partitioner of the
+ * reference's distributed path (python/gigl/distributed/dist_link_prediction_data_partitioner.py:666-714: owner(v) =
+ * v % world; edges follow the DESTINATION node, the INCOMING-sampling choice of :692-695) applied to the edge table as
+ * loadEdgeDataframeIntoSparkSql reads it: every record in one (directed) or both (undirected) orientations, the
+ * orientations whose destination `rank` owns are kept as row dst / world of the shard; source ids stay global.  The
+ * result has ceil((n - rank) / world) rows and equals the owned rows of gigl_graph_build_from_coo's graph (what
+ * gigl_expand_frontier / gigl_dist_plan_create take as `shard`).  `src` / `dst` hold the WHOLE edge list (every rank
+ * reads it, each keeps 1 / world of it). */
+int32_t gigl_graph_build_shard_from_coo(gigl_ctx* ctx, int64_t n, int32_t rank, int32_t world, int64_t e,
+                                        const uint32_t* src, const uint32_t* dst, int32_t loc, int32_t is_directed,
+                                        gigl_graph** out);
 /* edge hydration keys: replaces the JOIN on (_from, _to) of hydrateEdges (SGSPureSparkV1Task.scala:549-593).
  * eid[i] = position of the edge src[i] -> dst[i] in the resident `col` array (= rowptr[dst] + index of src in the
  * ascending row), -1 when the graph has no such edge.  An edge-feature table stored in `col` order (row p = the
@@ -444,6 +455,16 @@ int32_t gigl_avro_embeddings_encode(gigl_ctx* ctx, const int64_t* ids, const flo
                                     int64_t n, int32_t dim, const uint8_t* type_utf8, int32_t type_len,
                                     const uint8_t* sync_marker, uint8_t* out, int64_t out_cap, int64_t* rec_off,
                                     int64_t* total_bytes, int32_t* status);
+
+/* line-per-root JSON rows of an inference batch — the local form of the rows the reference's inferencer emits per root
+ * ({"node_id", "emb"} / {"node_id", "pred"}: python/gigl/src/inference/v1/lib/base_inference_blueprint.py:76-103,
+ * loaded into BigQuery there).  HOST pointers: ids [n], emb [n, dim] fp32 with `emb_stride` floats between rows (or
+ * NULL), pred [n] (or NULL; with emb both keys go into one object); out holds >= gigl_json_rows_capacity(n, dim) bytes;
+ * *bytes = bytes written.  Floats print as the shortest decimal that parses back to the same fp32.  Formats row
+ * ranges on worker threads. */
+int64_t gigl_json_rows_capacity(int64_t n, int32_t dim);
+int32_t gigl_json_rows_format(const int64_t* ids, const float* emb, int64_t emb_stride, const int32_t* pred, int64_t n,
+                              int32_t dim, char* out, int64_t out_cap, int64_t* bytes);
 
 /* ---- batch union graph ("collate"): replaces GraphBuilder.add_graph_data/add_edge dedup
  *      (python/gigl/src/common/graph_builder/abstract_graph_builder.py:49-150), the collate

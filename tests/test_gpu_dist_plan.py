@@ -196,9 +196,20 @@ def test_pull_bucket_overflow_is_reported():
     comms = Comm.local(engs)
     plans = [DistSagePlan(comms[r], w, bs, 64, FAN, pull_cap=8, max_window_end=bound_for(rowptr)) for r in range(2)]
     roots_d = [torch.from_numpy(rank_roots(r, 64).view(np.int32)).to(engs[0].device) for r in range(2)]
-    DistSagePlan.run_local(plans, roots_d)
+    # a good step first, so that stale activations of it sit in the plan's buffers
+    ok_plans = [DistSagePlan(comms[r], w, bs, 64, FAN, max_window_end=bound_for(rowptr)) for r in range(2)]
+    DistSagePlan.run_local(ok_plans, roots_d)
+    outs = DistSagePlan.run_local(plans, roots_d)
     st.synchronize()
     assert plans[0].buffers_to_host()["meta"][8] != 0
+    assert plans[0].overflowed()
+    assert not ok_plans[0].overflowed()
+    # the failed step's rows are NaN, never stale activations that look like embeddings
+    assert torch.isnan(outs[0]).all()
+    with pytest.raises(RuntimeError, match="overflow"):
+        plans[0].raise_on_overflow()
+    for p in ok_plans:
+        p.close()
     for p in plans:
         p.close()
     for c in comms:
