@@ -201,6 +201,16 @@ def main():
                          "library launch in the trace is a grouped launch; prints timing without edge counts")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--mode", type=str, default="parity", choices=["parity", "fast"])
+    ap.add_argument("--entry", type=str, default="plan", choices=["plan", "inferencer"],
+                    help="plan = the library's one-call plan driven by this script (the headline); inferencer = the same "
+                         "workload through the drop-in entry point's own loop (gigl_amd.inferencer.Inferencer."
+                         "infer_resident -> plugin.infer_batch -> in-HBM route -> Avro shards): one step = one batch of "
+                         "the full inference pass over every node")
+    ap.add_argument("--entry-sink", type=str, default="avro-device", choices=["avro-device", "avro-files", "none"],
+                    help="--entry inferencer: avro-device (the line's value) = rows encoded as Avro data blocks on the "
+                         "device, the blocks stay in HBM (outputs resident, like the inputs); avro-files = additionally "
+                         "copied out and appended to shard files in a tmpfs scratch directory by the exporter's writer "
+                         "thread (PCIe + file inclusive; always measured and reported next to the value); none = bare rows")
     args = ap.parse_args()
     wl_fan, wl_b = WORKLOAD_DEFAULTS.get(args.workload, ("25,10", 1024))
     args.fanouts = args.fanouts or wl_fan
@@ -214,6 +224,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     assert world == max(args.gpus, 1) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    if args.entry == "inferencer":
+        return run_entry_inferencer(args, rank, world, local_rank)
     if args.workload == "mag240m-sharded":
         return run_sharded(args, rank, world, local_rank)
     if args.workload == "gat-lp":
@@ -790,6 +802,155 @@ def run_sharded(args, rank, world, local_rank):
     close_slots(slots)
     dist.destroy_process_group()
     eng.close()
+
+
+def run_entry_inferencer(args, rank, world, local_rank):
+    """--entry inferencer: the workload's full inference pass (every node a root, batches of B in the TFRecord route's
+    order) through the drop-in entry point's own code: Inferencer.infer_resident -> plugin.infer_batch(HbmRootBatch) ->
+    ResidentGraph.encode -> gigl_sage_plan_run, rows handed to the exporter (Avro encoded on the device, written out by
+    its writer thread).  The graph is built in HBM by this script (ResidentGraph.from_engine) instead of being read from
+    preprocessor tables — ingest is one-time work outside the step.  A replica per GPU at N > 1; a secondary line."""
+    import shutil
+    import tempfile
+    from gigl_amd._lib import MODE_FAST, MODE_SPARK_HASH, STATS, STATS_LEN
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.hbm import ResidentGraph
+    from gigl_amd.inferencer import Inferencer, _RowWriter
+    from gigl_amd.task_specs import HipGraphSageNodeClassificationSpec
+
+    torch.cuda.set_device(local_rank)
+    eng = HipEngine(local_rank)
+    dev = eng.device
+    fanouts = [int(v) for v in args.fanouts.split(",")]
+    B, G = args.batch, max(1, args.group)
+    t0 = time.time()
+    n, d = build_workload(eng, args)
+    wl_name, wl_label, hid, out_dim, wl_directed, wl_dtype = args._workload
+    torch.manual_seed(0)
+    spec = HipGraphSageNodeClassificationSpec(out_dim=out_dim, hid_dim=hid, num_layers=len(fanouts))
+    from gigl_amd.models import GraphSAGE
+    spec.model = GraphSAGE(d, hid, out_dim, num_layers=len(fanouts)).to(dev)
+    mode = MODE_SPARK_HASH if args.mode == "parity" else MODE_FAST
+    resident = ResidentGraph.from_engine(eng, np.arange(n, dtype=np.int64), fanouts, node_type="paper", mode=mode)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+    scratch = tempfile.mkdtemp(prefix="gigl_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+
+    class _NullWriter:  # rows stay in HBM
+        n_rows = 0
+
+        def add(self, ids, emb, pred, ids_dev=None):
+            self.n_rows += int(ids.size)
+
+        def close(self):
+            pass
+
+    inf = Inferencer()
+
+    def one_pass(sink):
+        w = (_RowWriter({"embeddings": os.path.join(scratch, "emb") + "/"}, "paper", keep_on_device=sink == "avro-device")
+             if sink != "none" else _NullWriter())
+        inf.infer_resident(spec, dev, resident, w, B, groups=G)
+        w.close()
+        torch.cuda.synchronize()
+        return w
+
+    try:
+        one_pass("none")  # warm-up: hash table, plan, allocator
+        # exact edge counts of the pass (untimed; sampling is deterministic)
+        acc = torch.zeros(STATS_LEN, dtype=torch.int64, device=dev)
+        n_steps = 0
+        ids = resident.inference_root_order()
+        for hb in resident.root_batches(ids, B, G):
+            plan = resident._plan_for(spec.model, B, G)
+            plan.run(hb.roots, sampling_seed=resident.seed, mode=mode)
+            plan.stats(hb.roots, acc)
+        torch.cuda.synchronize()
+        st = acc.cpu().numpy().astype(np.float64)
+        n_steps = -(-n // B)
+        # the padding batches of the last call (one repeated root each) are part of the pass; their few edges are in `st`
+        edges_pass = float(st[STATS["sampled"]] + st[STATS["aggregated"]])
+        res, sink_trace = {}, None
+        for sink in ("none", "avro-device", "avro-files"):
+            if os.environ.get("GIGL_BENCH_PROFILE") == sink:
+                import cProfile
+                import pstats
+                one_pass(sink)
+                pr = cProfile.Profile()
+                pr.enable()
+                one_pass(sink)
+                pr.disable()
+                pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(25)
+            one_pass(sink)
+            shutil.rmtree(os.path.join(scratch, "emb"), ignore_errors=True)
+            reps = []
+            t_all = time.perf_counter()
+            while time.perf_counter() - t_all < args.min_seconds or len(reps) < 3:
+                if world > 1:
+                    import torch.distributed as dist
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                w = one_pass(sink)
+                reps.append(time.perf_counter() - t1)
+                if sink == "avro-files":
+                    sink_trace = dict(w.exporter.trace, bytes=w.exporter.bytes_written)
+                    shutil.rmtree(os.path.join(scratch, "emb"), ignore_errors=True)  # (untimed)
+            res[sink] = np.array(reps)
+        # plan level on the same roots and call shape, driven directly (no entry-point code, no rows consumed)
+        plan = resident._plan_for(spec.model, B, G)
+        batches = list(resident.root_batches(ids, B, G))
+        out = torch.empty((G * B, out_dim), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for hb in batches:
+            plan.run(hb.roots, out=out, sampling_seed=resident.seed, mode=mode)
+        torch.cuda.synchronize()
+        plan_s = time.perf_counter() - t1
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+    head = res[args.entry_sink]
+    t_med = float(np.median(head))
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([t_med], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_med = float(tt.item())
+    if rank == 0:
+        line = {
+            "metric": "sampled+aggregated edges/s", "value": edges_pass * world / t_med, "unit": "edges/s",
+            "n_gpus": world, "steps": int(n_steps * len(head)), "warmup": n_steps, "ms_per_step": t_med / n_steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl_label + f" N={n} E={eng.n_edges} D={d} fanout={fanouts} B={B} GraphSAGE "
+                                            f"{d}->{hid}->{out_dim}: FULL inference pass over every node through "
+                                            "Inferencer.infer_resident (drop-in entry point, in-HBM route), sampler "
+                                            "mode=" + args.mode,
+                       "entry": "gigl_amd.inferencer.Inferencer.infer_resident -> HipGraphSageNodeClassificationSpec."
+                                "infer_batch(HbmRootBatch) -> ResidentGraph.encode -> gigl_sage_plan_run",
+                       "sink": {"avro-device": "Avro data blocks encoded on the device, left in HBM (outputs resident)",
+                                "avro-files": "Avro shards: device-encoded, copied out and written to tmpfs by the "
+                                              "exporter's writer thread (PCIe + file inclusive)",
+                                "none": "bare rows, left in HBM"}[args.entry_sink],
+                       "pcie_and_file_inclusive_pass_s_median": float(np.median(res["avro-files"])),
+                       "pcie_and_file_inclusive_roots_per_s": n * world / float(np.median(res["avro-files"])),
+                       "batches_per_call": G, "roots_per_s": n * world / t_med,
+                       "pass_s_median": t_med, "pass_s_all": [round(float(v), 4) for v in head],
+                       "compute_only_pass_s_median": float(np.median(res["none"])),
+                       "compute_only_ms_per_step": float(np.median(res["none"])) / n_steps * 1e3,
+                       "plan_level_pass_s": plan_s, "plan_level_ms_per_step": plan_s / n_steps * 1e3,
+                       "entry_over_plan": t_med / plan_s, "sink_trace_last_pass": sink_trace,
+                       "sampled_edges_per_step": float(st[STATS["sampled"]]) / n_steps,
+                       "aggregated_edges_per_step": float(st[STATS["aggregated"]]) / n_steps,
+                       "setup_s": round(setup_s, 1)},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(line))
+    resident.close()
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def _lib_stats_len():

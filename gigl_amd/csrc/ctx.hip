@@ -137,6 +137,7 @@ const char* gigl_last_error(gigl_ctx* ctx) { return ctx ? ctx->err.c_str() : "nu
 
 int32_t gigl_ctx_set_stream(gigl_ctx* ctx, void* hip_stream) {
   if (!ctx) return GIGL_E_INVALID_ARG;
+  if ((hipStream_t)hip_stream == ctx->stream && !ctx->own_stream) return GIGL_OK;  // already bound: nothing to drain
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);

@@ -31,6 +31,14 @@ namespace {
 constexpr int MAX_BLOCK_RECORDS = 2048;
 constexpr int MAX_TYPE_BYTES = 240;
 
+struct AvroText {
+  uint8_t b[16 + MAX_TYPE_BYTES];
+};
+
+__global__ void avro_text_kernel(AvroText t, uint8_t* __restrict__ out) {
+  if (threadIdx.x < sizeof(t.b)) out[threadIdx.x] = t.b[threadIdx.x];
+}
+
 struct AvroArgs {
   const int64_t* ids;
   const float* emb;
@@ -222,8 +230,11 @@ int32_t gigl_avro_embeddings_encode(gigl_ctx* ctx, const int64_t* ids, const flo
   if (rc != GIGL_OK) return rc;
   uint8_t* text_dev = (uint8_t*)gigl_arena_alloc(ctx, sizeof(text));
   if (!text_dev) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
-  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(text_dev, text, sizeof(text), hipMemcpyHostToDevice, ctx->stream));
-  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // `text` is a stack buffer
+  // the marker / type bytes travel as a kernel argument (copied at launch): no upload to wait for, the call never
+  // synchronises with the host
+  AvroText tx;
+  for (size_t i = 0; i < sizeof(text); ++i) tx.b[i] = i < (size_t)(16 + type_len) ? text[i] : 0;
+  hipLaunchKernelGGL(avro_text_kernel, dim3(1), dim3(256), 0, ctx->stream, tx, text_dev);
   a.text = text_dev;
   int64_t* blk_size = (int64_t*)gigl_arena_alloc(ctx, (n_blocks + 1) * 8);
   int64_t* blk_off = (int64_t*)gigl_arena_alloc(ctx, (n_blocks + 1) * 8);

@@ -110,7 +110,10 @@ class HipEngine:
     def bind_stream(self, stream: Optional[torch.cuda.Stream] = None) -> None:
         """run library kernels on `stream` (default: torch's current stream on this device)"""
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        old = getattr(self, "_stream", None)
         self._stream = s
+        if old is not None and old.cuda_stream == s.cuda_stream:
+            return  # (re-binding drains the old stream: skip when nothing changes)
         check(self._lib.gigl_ctx_set_stream(self._ctx, C.c_void_p(s.cuda_stream)), self._ctx)
 
     def synchronize(self) -> None:
@@ -605,10 +608,13 @@ class HipEngine:
         del keep
         return out[: int(rec_off[-1].item())], rec_off
 
-    def encode_avro_embeddings(self, ids: torch.Tensor, emb: torch.Tensor, node_type: str, sync_marker: bytes):
-        """(ids [n], emb [n, D]) -> Avro data blocks of `Embedding` records, encoded on the device
-        (gigl_avro_embeddings_encode).  -> (uint8 device tensor of the blocks, int64 device tensor rec_off[n])"""
+    def encode_avro_embeddings_async(self, ids: torch.Tensor, emb: torch.Tensor, node_type: str, sync_marker: bytes):
+        """enqueue the encoding of (ids [n], emb [n, D]) as Avro data blocks of `Embedding` records on this engine's
+        stream (gigl_avro_embeddings_encode) without waiting for it.
+        -> (out uint8 [capacity] device, rec_off int64 [n] device, scal int64 [2] device: total bytes | status)"""
         assert len(sync_marker) == 16 and ids.dim() == 1 and emb.dim() == 2 and emb.shape[0] == ids.numel()
+        if not ids.is_cuda:  # (a pageable upload would wait for the stream: stage through pinned memory)
+            ids = ids.to(torch.int64).pin_memory().to(self.device, non_blocking=True)
         ids = ids.to(device=self.device, dtype=torch.int64).contiguous()
         emb = emb.to(device=self.device, dtype=torch.float32)
         if emb.stride(1) != 1 and emb.numel():
@@ -627,11 +633,19 @@ class HipEngine:
             self._ctx, C.c_void_p(ids.data_ptr()), C.c_void_p(emb.data_ptr()), max(stride, d), n, d, ty, len(ty),
             bytes(sync_marker), C.c_void_p(out.data_ptr()), cap.value, C.c_void_p(rec_off.data_ptr()),
             C.c_void_p(scal.data_ptr()), C.c_void_p(scal.data_ptr() + 8)), self._ctx)
+        for t in (ids, emb):  # inputs stay alive until the stream has consumed them
+            t.record_stream(self._stream)
+        return out, rec_off[:n], scal
+
+    def encode_avro_embeddings(self, ids: torch.Tensor, emb: torch.Tensor, node_type: str, sync_marker: bytes):
+        """(ids [n], emb [n, D]) -> Avro data blocks of `Embedding` records, encoded on the device
+        (gigl_avro_embeddings_encode).  -> (uint8 device tensor of the blocks, int64 device tensor rec_off[n])"""
+        out, rec_off, scal = self.encode_avro_embeddings_async(ids, emb, node_type, sync_marker)
         self._stream.synchronize()
         total, status = (int(v) for v in scal.tolist())
         if status & 0xFFFFFFFF:
             raise RuntimeError("gigl_avro_embeddings_encode: output capacity too small (status=1)")
-        return out[:total], rec_off[:n]
+        return out[:total], rec_off
 
     def union_capacity(self, b: int, fanouts: Sequence[int]):
         fo = (C.c_int32 * len(fanouts))(*[int(f) for f in fanouts])

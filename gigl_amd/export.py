@@ -15,9 +15,10 @@ Shards are written to a local / mounted directory: object stores are outside thi
 is control-plane and not provided."""
 from __future__ import annotations
 
-import io
 import json
 import os
+import queue
+import threading
 import time
 from typing import Optional
 
@@ -66,8 +67,19 @@ def avro_file_header(sync_marker: bytes, schema=AVRO_SCHEMA, codec: str = "null"
 
 
 class EmbeddingExporter:
+    """`add_embedding` only ENQUEUES work: the batch is encoded on the device on the caller's stream and a writer thread
+    takes it from there — waits for the encode, copies the finished blocks to the host on its own copy stream through
+    two pinned staging buffers and appends them to the shard file — so the caller's next batch computes while this one
+    is written.  `flush_embeddings` (and context exit) wait for everything enqueued so far and close the shard.  One
+    random sync marker serves all shards of an exporter (any 16 bytes are a valid marker)."""
+
     def __init__(self, export_dir, file_prefix: Optional[str] = None, min_shard_size_threshold_bytes: int = 0,
-                 engine=None):
+                 engine=None, keep_on_device: bool = False):
+        """keep_on_device: the encoded data blocks stay in HBM (`device_blocks`: (uint8 buffer, [total bytes | status])
+        pairs in order) instead of being written to shard files — for a consumer on the device, and for measuring the
+        path without the host leg"""
+        self._keep_on_device = bool(keep_on_device)
+        self.device_blocks: list = []
         if min_shard_size_threshold_bytes < 0:
             raise ValueError(
                 f"file_flush_threshold must be a non-negative integer, but got {min_shard_size_threshold_bytes}")
@@ -76,8 +88,7 @@ class EmbeddingExporter:
             raise ValueError(f"EmbeddingExporter writes to a local or mounted directory, got {uri!r}")
         self._export_dir = uri[len("file://"):] if uri.startswith("file://") else uri
         self._engine = engine
-        self._buffer = io.BytesIO()
-        self._sync_marker: Optional[bytes] = None
+        self._sync_marker = os.urandom(16)
         self._num_records_written = 0
         self._num_files_written = 0
         self._in_context = False
@@ -85,6 +96,16 @@ class EmbeddingExporter:
         self._prefix = file_prefix
         self._min_shard_size_threshold_bytes = min_shard_size_threshold_bytes
         self.files_written: list = []
+        self.bytes_written = 0
+        # where the writer thread's time went (seconds): waiting for the device encode, device -> host, file append
+        self.trace = {"wait_encode_s": 0.0, "d2h_s": 0.0, "file_s": 0.0, "batches": 0, "enqueue_s": 0.0}
+        # writer thread state
+        self._q: "queue.Queue" = queue.Queue(maxsize=6)  # (bounds the encoded batches waiting in HBM)
+        self._thread: Optional[threading.Thread] = None
+        self._err: Optional[BaseException] = None
+        self._fh = None
+        self._part_path = self._final_path = None
+        self._shard_bytes = 0
 
     def _eng(self):
         if self._engine is None:
@@ -100,48 +121,128 @@ class EmbeddingExporter:
                              f"{tuple(embedding_batch.shape)}")
         if id_batch.is_floating_point():
             raise TypeError("node ids must be integers")
+        self._raise_pending()
         eng = self._eng()
-        if self._buffer.tell() == 0:
-            self._sync_marker = os.urandom(16)
-            self._buffer.write(avro_file_header(self._sync_marker))
-        blocks, _ = eng.encode_avro_embeddings(id_batch, embedding_batch, embedding_type, self._sync_marker)
-        self._buffer.write(memoryview(self._to_host(blocks).numpy()))
-        self._num_records_written += int(id_batch.numel())
+        cur = torch.cuda.current_stream(eng.device)
+        if eng._stream.cuda_stream != cur.cuda_stream:  # encode where the embeddings were produced
+            eng.bind_stream(cur)
+        out, _, scal = eng.encode_avro_embeddings_async(id_batch, embedding_batch, embedding_type, self._sync_marker)
+        if self._keep_on_device:
+            self.device_blocks.append((out, scal))
+            self._write_time += time.perf_counter() - start
+            return
+        done = torch.cuda.Event()
+        done.record(cur)
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._writer, name="gigl-avro-writer", daemon=True)
+            self._thread.start()
+        self._q.put(("blocks", out, scal, done, int(id_batch.numel())))
         self._write_time += time.perf_counter() - start
-        if self._min_shard_size_threshold_bytes and self._buffer.tell() >= self._min_shard_size_threshold_bytes:
-            self.flush_embeddings()
+        self.trace["enqueue_s"] += time.perf_counter() - start
 
-    def _to_host(self, blocks: torch.Tensor) -> torch.Tensor:
-        """device -> host through a reusable pinned staging buffer (pageable copies run at a fraction of the link)"""
-        n = int(blocks.numel())
-        stage = getattr(self, "_stage", None)
-        if stage is None or stage.numel() < n:
-            self._stage = stage = torch.empty(max(n, 1 << 20), dtype=torch.uint8, pin_memory=True)
-        out = stage[:n]
-        out.copy_(blocks, non_blocking=True)
-        torch.cuda.current_stream(blocks.device).synchronize()
-        return out
+    # ---- writer thread
+    def _writer(self) -> None:
+        dev = self._eng().device
+        copy_stream = torch.cuda.Stream(device=dev)
+        stage = [None, None]
+        k = 0
+        while True:
+            item = self._q.get()
+            try:
+                if item[0] == "stop":
+                    return
+                if item[0] == "flush":
+                    if self._err is None:
+                        self._close_shard()
+                    continue
+                if self._err is not None:
+                    continue  # (drain: the error is raised on the caller's side)
+                _, out, scal, done, n = item
+                t0 = time.perf_counter()
+                done.synchronize()
+                t1 = time.perf_counter()
+                with torch.cuda.stream(copy_stream):
+                    total, status = (int(v) for v in scal.to("cpu", non_blocking=False).tolist())
+                    if status & 0xFFFFFFFF:
+                        raise RuntimeError("gigl_avro_embeddings_encode: output capacity too small (status=1)")
+                    buf = stage[k]
+                    if buf is None or buf.numel() < total:
+                        stage[k] = buf = torch.empty(max(total, 1 << 20), dtype=torch.uint8, pin_memory=True)
+                    host = buf[:total]
+                    host.copy_(out[:total], non_blocking=True)
+                    copy_stream.synchronize()
+                del out, scal
+                t2 = time.perf_counter()
+                self._append(memoryview(host.numpy()), n)
+                t3 = time.perf_counter()
+                tr = self.trace
+                tr["wait_encode_s"] += t1 - t0
+                tr["d2h_s"] += t2 - t1
+                tr["file_s"] += t3 - t2
+                tr["batches"] += 1
+                k ^= 1
+            except BaseException as e:  # noqa: BLE001 — surfaced by the next add / flush on the caller's thread
+                self._err = e
+            finally:
+                if item[0] == "flush":
+                    item[1].set()
+                self._q.task_done()
 
-    def _flush(self):
-        filename = (f"shard_{self._num_files_written:08}.avro" if not self._prefix
-                    else f"{self._prefix}_{self._num_files_written:08}.avro")
-        os.makedirs(self._export_dir, exist_ok=True)
-        path = os.path.join(self._export_dir, filename)
-        tmp = path + ".part"
-        with open(tmp, "wb") as f:
-            f.write(self._buffer.getbuffer())
-        os.replace(tmp, path)
-        self.files_written.append(path)
+    def _append(self, data: memoryview, n_records: int) -> None:
+        if self._fh is None:
+            filename = (f"shard_{self._num_files_written:08}.avro" if not self._prefix
+                        else f"{self._prefix}_{self._num_files_written:08}.avro")
+            os.makedirs(self._export_dir, exist_ok=True)
+            self._final_path = os.path.join(self._export_dir, filename)
+            self._part_path = self._final_path + ".part"
+            self._fh = open(self._part_path, "wb")
+            self._fh.write(avro_file_header(self._sync_marker))
+            self._shard_bytes = self._fh.tell()
+        self._fh.write(data)
+        self._shard_bytes += len(data)
+        self.bytes_written += len(data)
+        self._num_records_written += n_records
+        if self._min_shard_size_threshold_bytes and self._shard_bytes >= self._min_shard_size_threshold_bytes:
+            self._close_shard()
+
+    def _close_shard(self) -> None:
+        if self._fh is None:
+            return
+        self._fh.close()
+        self._fh = None
+        os.replace(self._part_path, self._final_path)
+        self.files_written.append(self._final_path)
         self._num_files_written += 1
-        self._buffer = io.BytesIO()
         self._num_records_written = 0
         self._write_time = 0.0
 
+    def _raise_pending(self) -> None:
+        if self._err is not None:
+            err, self._err = self._err, None
+            raise err
+
     def flush_embeddings(self):
-        """writes the buffered shard; a no-op when nothing was added since the last flush"""
-        if self._buffer.tell() == 0:
-            return
-        self._flush()
+        """waits for every batch added so far and writes the buffered shard; a no-op when nothing was added since the
+        last flush"""
+        if self._thread is not None:
+            ev = threading.Event()
+            self._q.put(("flush", ev))
+            ev.wait()
+        self._raise_pending()
+
+    def close(self) -> None:
+        self.flush_embeddings()
+        if self._thread is not None:
+            self._q.put(("stop",))
+            self._thread.join()
+            self._thread = None
+
+    def __del__(self):
+        try:
+            if self._thread is not None:
+                self._q.put(("stop",))
+        except Exception:  # noqa: BLE001
+            pass
 
     def __enter__(self):
         if self._in_context:

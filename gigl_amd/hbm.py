@@ -71,7 +71,7 @@ class HbmRootBatch:
     resident: "ResidentGraph"
     roots: torch.Tensor             # int32 [groups * group_roots] on the device (uint32 ids)
     group_roots: int
-    valid: torch.Tensor             # int64 [n_valid] on the device: positions of the real roots in `roots`
+    valid: Optional[torch.Tensor]   # int64 [n_valid] on the device: positions of the real roots in `roots`; None = all
     root_ids: np.ndarray            # int64 [n_valid] host: the real roots, in order
     root_node_labels: Optional[torch.Tensor] = None  # int64 [n_valid]
     node_type: str = "node"
@@ -84,6 +84,12 @@ class HbmRootBatch:
     @property
     def groups(self) -> int:
         return int(self.roots.numel()) // self.group_roots
+
+    @property
+    def root_ids_dev(self) -> torch.Tensor:
+        """the real roots as int64 ids on the device (what the device-side Avro encoder takes: no upload per call)"""
+        ids = self.roots.to(torch.int64) & 0xFFFFFFFF
+        return ids if self.valid is None else ids.index_select(0, self.valid)
 
 
 @dataclass
@@ -163,6 +169,26 @@ class ResidentGraph:
             self.max_window_end = bound if bound < (1 << 30) else -1
             self.comm = self._make_comm()
         self.feat_dim = int(x.shape[1])
+        self.node_type = str(cfg.node_types[0])
+        if cfg.task_kind == "node_classification":
+            self._order_prefixes = [cfg.unlabeled_tfrecord_uri_prefix]
+        else:
+            self._order_prefixes = list(cfg.random_negative_tfrecord_uri_prefixes.values())
+
+    @classmethod
+    def from_engine(cls, engine, node_ids: np.ndarray, fanouts: Sequence[int], *, node_type: str = "node",
+                    order_prefix: str = "unlabeled/samples/", sampling_seed: int = 42, mode: int = 0) -> "ResidentGraph":
+        """a resident graph over an engine that already holds the graph and the feature table (built in HBM by the
+        caller — bench.py's synthetic workloads — instead of read from the preprocessor's tables); single rank"""
+        self = cls.__new__(cls)
+        self.cfg, self.device, self.rank, self.world, self.group = None, engine.device, 0, 1, None
+        self.fanouts, self.seed, self.mode = [int(f) for f in fanouts], int(sampling_seed), int(mode)
+        self.n, self.node_ids, self.labels = int(engine.n_nodes), np.asarray(node_ids, dtype=np.int64), {}
+        self.has_in_edge = None
+        self.engine, self.comm, self._plans, self.sharded = engine, None, {}, False
+        self.feat_dim, self.node_type, self._order_prefixes = int(engine.feat_dim), node_type, [order_prefix]
+        self._borrowed_engine = True
+        return self
 
     # ---- multi-GPU transport
     def _make_comm(self):
@@ -179,12 +205,7 @@ class ResidentGraph:
         """every node, in the order the TFRecord route reads the sampler's per-node records (the unlabeled
         RootedNodeNeighborhood samples of a node-classification job; the random-negative stream of a link-prediction
         job: v1/lib/utils.py:78-228)"""
-        cfg = self.cfg
-        if cfg.task_kind == "node_classification":
-            prefixes = [cfg.unlabeled_tfrecord_uri_prefix]
-        else:
-            prefixes = list(cfg.random_negative_tfrecord_uri_prefixes.values())
-        ids = [planned_root_order(self.node_ids, p) for p in prefixes if p]
+        ids = [planned_root_order(self.node_ids, p) for p in self._order_prefixes if p]
         return np.concatenate(ids) if ids else self.node_ids
 
     def labeled_root_order(self, label_key: Optional[str] = None) -> Tuple[np.ndarray, np.ndarray]:
@@ -209,34 +230,37 @@ class ResidentGraph:
         b, g = int(batch_size), max(1, int(groups))
         n_batches = -(-ids.size // b) if ids.size else 0
         world, rank = (self.world, self.rank) if shard else (1, 0)
-        mine = list(range(rank, n_batches, world))
         per_rank = -(-n_batches // world) if n_batches else 0
         calls = -(-per_rank // g) if per_rank else 0
-        node_type = str(self.cfg.node_types[0])
+        if calls == 0:
+            return
+        node_type = self.node_type
+        # every root of this rank's calls in ONE padded array and ONE upload (a pageable upload per call would wait
+        # for the stream and serialise the pipeline): slot (c, k) holds batch rank + (c*g + k)*world of the global order
+        slot_batch = rank + np.arange(calls * g, dtype=np.int64) * world          # global batch index per slot
+        real_slot = slot_batch < n_batches
+        src = np.minimum(slot_batch, max(n_batches - 1, 0))[:, None] * b + np.arange(b)[None, :]  # [slots, b] positions
+        in_range = (src < ids.size) & real_slot[:, None]
+        first = np.where(real_slot, np.minimum(slot_batch, max(n_batches - 1, 0)) * b, 0)  # a batch's first root pads it
+        roots = np.where(in_range, ids[np.minimum(src, ids.size - 1)], ids[first][:, None])   # (all-padding: ids[0])
+        roots_dev = torch.from_numpy(roots.astype(np.uint32).view(np.int32).reshape(calls, g * b)).pin_memory() \
+            .to(self.device, non_blocking=True)
+        valid_mask = in_range.reshape(calls, g * b)
+        labels = None if labels is None else np.asarray(labels)
+        # positions of the real roots of the calls that carry padding, uploaded before the first call runs
+        partial = [c for c in range(calls) if not valid_mask[c].all()]
+        pos_dev = {c: torch.from_numpy(np.flatnonzero(valid_mask[c])).to(self.device) for c in partial}
         for c in range(calls):
-            take = mine[c * g: (c + 1) * g]
-            roots = np.empty(g * b, dtype=np.int64)
-            valid: List[np.ndarray] = []
-            real: List[np.ndarray] = []
-            labs: List[np.ndarray] = []
-            filler = int(ids[0])
-            for k in range(g):
-                if k < len(take):
-                    chunk = ids[take[k] * b: (take[k] + 1) * b]
-                    roots[k * b: k * b + chunk.size] = chunk
-                    roots[k * b + chunk.size: (k + 1) * b] = chunk[0]  # a repeated root changes nothing in its batch
-                    valid.append(np.arange(k * b, k * b + chunk.size))
-                    real.append(chunk)
-                    if labels is not None:
-                        labs.append(labels[take[k] * b: take[k] * b + chunk.size])
-                else:
-                    roots[k * b: (k + 1) * b] = filler  # an all-padding batch (results dropped)
-            r32 = torch.from_numpy(roots.astype(np.uint32).view(np.int32)).to(self.device)
-            v = np.concatenate(valid) if valid else np.zeros(0, np.int64)
+            m = valid_mask[c]
+            pos = np.flatnonzero(m)
+            real_pos = src.reshape(calls, g * b)[c][pos]
+            full = pos.size == g * b
             yield HbmRootBatch(
-                resident=self, roots=r32, group_roots=b, valid=torch.from_numpy(v).to(self.device),
-                root_ids=np.concatenate(real) if real else np.zeros(0, np.int64),
-                root_node_labels=(torch.from_numpy(np.concatenate(labs)) if labs else None), node_type=node_type)
+                resident=self, roots=roots_dev[c], group_roots=b,
+                valid=None if full else pos_dev[c],
+                root_ids=ids[real_pos],
+                root_node_labels=(torch.from_numpy(labels[real_pos]) if labels is not None else None),
+                node_type=node_type)
 
     # ---- forward over a HbmRootBatch
     def _plan_for(self, model, b: int, groups: int):
@@ -248,7 +272,12 @@ class ResidentGraph:
             plan = self._build_plan(model, b, groups)
             self._plans[key] = plan
         if plan is not None:
-            self._refresh(plan, model)
+            # weights are snapshotted by the plan: refresh them when a parameter has changed since (in-place updates by
+            # the optimiser bump `_version`; re-assigned tensors change the pointer)
+            stamp = tuple((p.data_ptr(), p._version) for p in model.parameters())
+            if getattr(plan, "_weights_stamp", None) != stamp:
+                self._refresh(plan, model)
+                plan._weights_stamp = stamp
         return plan
 
     def _build_plan(self, model, b: int, groups: int):
@@ -266,10 +295,15 @@ class ResidentGraph:
         make = getattr(model, "make_plan", None)
         if make is None:
             return None
+        from ._lib import GiglError
         try:
             return make(self.engine, b, self.fanouts, groups=groups)
         except NotImplementedError:
             return None  # options outside the one-call plan: staged forward below
+        except GiglError as e:
+            if e.code != -4:  # GIGL_E_UNSUPPORTED: a shape the plan's kernels are not built for -> staged forward
+                raise
+            return None
 
     @staticmethod
     def _refresh(plan, model) -> None:
@@ -291,12 +325,13 @@ class ResidentGraph:
                     plan.raise_on_overflow()
                 else:
                     out = plan.run(batch.roots, sampling_seed=self.seed, mode=self.mode)
-                return out.index_select(0, batch.valid)
+                return out if batch.valid is None else out.index_select(0, batch.valid)
             outs = []
             for k in range(g):  # staged: sample -> union -> model(HipBatch), one batch at a time
                 hb = self.hip_batch(batch.roots[k * b: (k + 1) * b])
                 outs.append(model(hb)[hb.root_local.long()])
-            return torch.cat(outs).index_select(0, batch.valid)
+            out = torch.cat(outs)
+            return out if batch.valid is None else out.index_select(0, batch.valid)
 
     def hip_batch(self, roots: torch.Tensor, train: bool = False):
         """sampled trees + the batch union graph of `roots` (int32 device ids) as a models.HipBatch"""
@@ -333,7 +368,8 @@ class ResidentGraph:
             self.comm.close()
             self.comm = None
         if self.engine is not None:
-            self.engine.close()
+            if not getattr(self, "_borrowed_engine", False):
+                self.engine.close()
             self.engine = None
 
 
@@ -342,6 +378,13 @@ def encoder_takes_hip_batches(model) -> bool:
     from .models import GraphSAGE
     from .models_attn import GAT, TwoLayerGCN
     return type(model) in (GraphSAGE, GAT, TwoLayerGCN)
+
+
+def encoder_trains_over_hip_batches(model) -> bool:
+    """the encoders with an autograd forward over a HipBatch (models.GraphSAGE._forward_union_autograd)"""
+    from .models import GraphSAGE
+    return (type(model) is GraphSAGE and not model.batchnorm and model.jk_layer is None
+            and model.feats_interaction is None and model.feature_embedding_layer is None)
 
 
 def route_of(cfg: GbmlConfigPbWrapper, args: Dict[str, str], override: Optional[str] = None) -> str:

@@ -46,7 +46,8 @@ class _RowWriter:
     (gigl_json_rows_format).  WORLD_SIZE > 1: every rank writes its own files (Avro shards prefixed rank_<r>, JSON
     files suffixed .rank<r>)."""
 
-    def __init__(self, out_files: Dict[str, str], node_type: str, rank: int = 0, world: int = 1):
+    def __init__(self, out_files: Dict[str, str], node_type: str, rank: int = 0, world: int = 1,
+                 keep_on_device: bool = False):
         self.node_type, self.n_rows = node_type, 0
         self.exporter = self.emb_fh = self.pred_fh = None
         sfx = f".rank{rank}" if world > 1 else ""
@@ -56,7 +57,7 @@ class _RowWriter:
         if emb and emb.endswith("/"):
             from .export import EmbeddingExporter
             self.exporter = EmbeddingExporter(emb, file_prefix=(f"rank_{rank}" if world > 1 else None),
-                                              min_shard_size_threshold_bytes=1 << 28)
+                                              min_shard_size_threshold_bytes=1 << 28, keep_on_device=keep_on_device)
         elif emb:
             out_files["embeddings"] = emb + sfx
             self.emb_fh = open(emb + sfx, "wb")
@@ -83,9 +84,13 @@ class _RowWriter:
             C.byref(used)))
         return memoryview(buf[: used.value])
 
-    def add(self, ids: np.ndarray, embeddings: Optional[torch.Tensor], predictions: Optional[torch.Tensor]) -> None:
+    def add(self, ids: np.ndarray, embeddings: Optional[torch.Tensor], predictions: Optional[torch.Tensor],
+            ids_dev: Optional[torch.Tensor] = None) -> None:
+        """ids: the rows' node ids on the host; ids_dev: the same on the device when the caller has them there (the
+        device-side encoder then needs no upload)"""
         if self.exporter is not None and embeddings is not None:
-            self.exporter.add_embedding(torch.from_numpy(np.asarray(ids, dtype=np.int64)), embeddings, self.node_type)
+            self.exporter.add_embedding(ids_dev if ids_dev is not None else torch.from_numpy(np.asarray(ids, dtype=np.int64)),
+                                        embeddings, self.node_type)
         if self.emb_fh is not None and embeddings is not None:
             self.emb_fh.write(self._json(ids, embeddings, None))
         if self.pred_fh is not None and predictions is not None:
@@ -94,7 +99,7 @@ class _RowWriter:
 
     def close(self) -> None:
         if self.exporter is not None:
-            self.exporter.flush_embeddings()
+            self.exporter.close()
         for fh in (self.emb_fh, self.pred_fh):
             if fh is not None:
                 fh.close()
@@ -181,22 +186,29 @@ class Inferencer:
         from .hbm import ResidentGraph
         resident = ResidentGraph(cfg, dev, rank=rank, world=world)
         try:
-            ids = resident.inference_root_order()
-            b = cfg.inference_batch_size
-            slots = 1
-            for f in reversed(resident.fanouts):
-                slots = 1 + f * slots
-            n_batches = -(-ids.size // b) if ids.size else 0
-            per_rank = max(1, -(-n_batches // world))
-            # batches per library call: as many as keep the call's tree under ~2^26 slots, at most 64
-            groups = int(max(1, min(64, per_rank, (1 << 26) // max(b * slots, 1))))
-            self.hbm_groups = groups
-            for hb in resident.root_batches(ids, b, groups):
-                res = inferencer.infer_batch(batch=hb, device=dev)
-                if hb.root_ids.size:
-                    writer.add(hb.root_ids, res.embeddings, res.predictions)
+            self.infer_resident(inferencer, dev, resident, writer, cfg.inference_batch_size)
         finally:
             resident.close()
+
+    def infer_resident(self, inferencer, dev, resident, writer: _RowWriter, batch_size: int,
+                       groups: Optional[int] = None) -> None:
+        """the in-HBM inference pass over every node of `resident`: batches of `batch_size` roots in the TFRecord
+        route's order, `groups` batches per library call, rows handed to `writer` (device tensors: the Avro writer
+        encodes them on the device and writes them out on its own thread while the next call computes)"""
+        ids = resident.inference_root_order()
+        b = int(batch_size)
+        slots = 1
+        for f in reversed(resident.fanouts):
+            slots = 1 + f * slots
+        n_batches = -(-ids.size // b) if ids.size else 0
+        per_rank = max(1, -(-n_batches // resident.world))
+        if groups is None:  # batches per library call: as many as keep the call's tree under ~2^26 slots, at most 64
+            groups = int(max(1, min(64, per_rank, (1 << 26) // max(b * slots, 1))))
+        self.hbm_groups = groups
+        for hb in resident.root_batches(ids, b, groups):
+            res = inferencer.infer_batch(batch=hb, device=dev)
+            if hb.root_ids.size:
+                writer.add(hb.root_ids, res.embeddings, res.predictions, ids_dev=hb.root_ids_dev)
 
 
 def _typed_run(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str, str]:

@@ -127,8 +127,10 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
             return self._hbm_splits or None
         self._hbm_splits = {}
         route = route_of(cfg, self._kwargs)
-        if route != "hbm" or not self.supports_hbm_batches or self._device is None or self._device.type != "cuda":
-            return None
+        from .hbm import encoder_trains_over_hip_batches
+        if route != "hbm" or self._device is None or self._device.type != "cuda" or \
+                not encoder_trains_over_hip_batches(self._inner_model()):
+            return None  # (e.g. GAT / GCN encoders train over collated batches)
         # the same rule as the TFRecord route below: split files written by the SplitGenerator -> its assignment
         # (recomputed from the job's splitGeneratorConfig, no file is read); none written -> the root-id rule
         from .config import _get

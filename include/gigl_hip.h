@@ -448,7 +448,7 @@ int32_t gigl_typed_samples_encode(gigl_ctx* ctx, int32_t kind, const uint32_t* r
  * gigl_avro_embeddings_encode: ids [n] int64, emb [n, dim] fp32 with `emb_stride` floats between rows, out: all
  * DEVICE; type_utf8 / sync_marker (16 bytes): HOST.  rec_off[i] = byte offset of record i in `out` (device, [n]);
  * *total_bytes (device) = bytes written; *status (device) = 1 and nothing written when they exceed out_cap.
- * Copies the type / marker bytes to the device first (one small synchronous upload), then never synchronises. */
+ * Never synchronises with the host (the type / marker bytes travel as a kernel argument). */
 int32_t gigl_avro_embeddings_layout(int64_t n, int32_t dim, int32_t type_len, int32_t* records_per_block,
                                     int64_t* n_blocks, int64_t* bytes);
 int32_t gigl_avro_embeddings_encode(gigl_ctx* ctx, const int64_t* ids, const float* emb, int64_t emb_stride,
