@@ -100,6 +100,55 @@ def rmat_edges_gpu(scale: int, n_edges: int, seed: int, device, a=0.57, b=0.19, 
     return src, dst
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks here (one process per GPU, the environment
+    torchrun would set: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and wait for them; rank 0's JSON
+    line goes to this process's stdout.  Fewer devices than ranks is an error (exit code 2) — never a silent 1-GPU
+    run — unless GIGL_BENCH_SHARE_GPU=1 (tests: every rank on device 0, gloo collectives, the library's host-callback
+    transport instead of RCCL, which refuses two ranks on one device)."""
+    import socket
+    import subprocess
+    n = int(args.gpus)
+    have = torch.cuda.device_count()
+    share = os.environ.get("GIGL_BENCH_SHARE_GPU") == "1"
+    if have < n and not share:
+        print(f"bench.py: --gpus {n} needs {n} visible HIP devices, this host has {have}; run on a node with {n} GPUs "
+              "(GIGL_BENCH_SHARE_GPU=1 puts every rank on device 0 over gloo — a functional check, not a measurement)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if share else r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for r, p in enumerate(procs):
+        p.wait()
+        if p.returncode != 0:
+            print(f"bench.py: rank {r} exited with code {p.returncode}", file=sys.stderr)
+            rc = rc or p.returncode or 1
+    return rc
+
+
+def dist_backend() -> str:
+    return "gloo" if os.environ.get("GIGL_BENCH_SHARE_GPU") == "1" else "nccl"
+
+
+def all_reduce(t: torch.Tensor, op) -> None:
+    """dist.all_reduce on a device tensor under either backend (gloo reduces a host copy)"""
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+
+
 # workload -> (nodes, rmat scale, edges drawn, feature dim, feature dtype, directed, hidden, out, rmat seed, label)
 WORKLOADS = {
     # BASELINE.json configs[1] / SURVEY.md §8(d) C2
@@ -184,9 +233,12 @@ def main():
                          "feature pull over RCCL — needs >= 2 GPUs at full size (--shard-scale shrinks it)")
     ap.add_argument("--shard-group", type=int, default=16,
                     help="mag240m-sharded: batches of B roots exchanged per set of collectives (dedup stays per batch)")
-    ap.add_argument("--shard-hot-frac", type=float, default=0.0,
+    ap.add_argument("--shard-hot-frac", type=float, default=-1.0,
                     help="mag240m-sharded: fraction of the nodes (the most-referenced ones) whose feature rows are "
-                         "replicated on every rank and never pulled (hub-row replication)")
+                         "replicated on every rank and never pulled (hub-row replication); -1 (default) = auto: on "
+                         "whenever world > 1, sized to 4 %% of the free HBM, at most 5 %% of the nodes")
+    ap.add_argument("--no-sharded-sub", action="store_true",
+                    help="N > 1 headline: skip the `sharded` sub-record (the mag240m-sharded workload at this N)")
     ap.add_argument("--shard-plans", type=int, default=3, help="mag240m-sharded: sharded plans in flight per rank")
     ap.add_argument("--shard-scale", type=float, default=0.0,
                     help="mag240m-sharded: fraction of MAG240M's nodes and edges to generate (0 = world/8, capped at 1: "
@@ -216,14 +268,22 @@ def main():
     args.fanouts = args.fanouts or wl_fan
     args.batch = args.batch or wl_b
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # no launcher: this process becomes one
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node equal to --gpus "
+              "(or without a launcher: bench.py spawns the ranks itself)", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    assert world == max(args.gpus, 1) or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+        if dist_backend() == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     if args.entry == "inferencer":
         return run_entry_inferencer(args, rank, world, local_rank)
     if args.workload == "mag240m-sharded":
@@ -372,7 +432,7 @@ def main():
     reps = int(min(max(np.ceil(args.min_seconds / max(t_cal, 1e-6)), args.min_reps), 2000))
     if world > 1:
         rr = torch.tensor([reps], dtype=torch.int64, device=dev)
-        dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+        all_reduce(rr, dist.ReduceOp.MAX)
         reps = int(rr.item())
     calls_per_rep = K_rep // G
     for e in engines:
@@ -405,9 +465,9 @@ def main():
     seg_use = np.array([sum(1 for r in range(reps) if r % N_SEG == sg) for sg in range(N_SEG)], dtype=np.float64)
     tot = (seg_stats * seg_use[:, None]).sum(0)  # this rank's counts over the whole timed region
     if world > 1:
-        dist.all_reduce(rep_t, op=dist.ReduceOp.MAX)
+        all_reduce(rep_t, dist.ReduceOp.MAX)
         cc = torch.tensor(tot, dtype=torch.float64, device=dev)
-        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        all_reduce(cc, dist.ReduceOp.SUM)
         tot_all = cc.cpu().numpy()
     else:
         tot_all = tot
@@ -548,15 +608,29 @@ def main():
                        "setup_s": round(setup_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_all_cores": cpu_baseline_all,
         }
+    for p_ in plans:
+        p_.close()
+    for e in reversed(engines):
+        e.close()
+    torch.cuda.empty_cache()
+    if world > 1 and wl_name in ("products", "small") and not args.no_sharded_sub:
+        # the graph-larger-than-one-GPU path at this N (BASELINE configs[2]): the MAG240M-shaped graph hash-partitioned
+        # over the ranks, through the library's sharded plan — a sub-record of the line, never its value
+        sa = argparse.Namespace(**vars(args))
+        sa.workload, sa.fanouts, sa.batch = "mag240m-sharded", "25,10", 1024
+        sa.min_seconds, sa.min_reps, sa.min_rounds = min(args.min_seconds, 1.5), 3, 4
+        sub = run_sharded(sa, rank, world, local_rank, sub=True)
+        if rank == 0:
+            line["sharded"] = {k: sub[k] for k in ("value", "ms_per_step", "n_gpus", "steps", "timing", "config",
+                                                   "roofline_xgmi")}
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for e in reversed(engines):
-        e.close()
 
 
-def run_sharded(args, rank, world, local_rank):
+def run_sharded(args, rank, world, local_rank, sub=False):
     """BASELINE.json configs[2]: MAG240M-shaped graph (N=244,160,499, E=1,728,364,232 directed RMAT, D=768 fp16,
     SURVEY.md 8(d) C3) hash-partitioned over the ranks: rank r holds the CSC rows and feature rows of the nodes
     with id % world == r.  A step = one batch of B roots per rank through the library's sharded plan
@@ -564,9 +638,10 @@ def run_sharded(args, rank, world, local_rank):
     gigl_expand_frontier there, one all-to-all back; union graph locally; the UNIQUE node ids pulled from their owners
     (rows gathered — or projected by the first layer, --project-on-owner — straight into the send buffer); 2-layer
     GraphSAGE 768->256->256.  Every exchange is issued by the library over RCCL on the plan's stream and nothing in
-    a step reads the device from the host.  Two plans (ctx + stream + communicator each) are in flight: one host
+    a step reads the device from the host.  Several plans (ctx + stream + communicator each) are in flight: one host
     thread issues their phases interleaved, in the same order on every rank, so one plan's exchange overlaps the
-    other's expansion / forward."""
+    other's expansion / forward.  sub=True: called at the end of the N > 1 headline run for its `sharded` sub-record —
+    returns the record (rank 0) instead of printing it and leaves the process group alone."""
     import torch.distributed as dist
     from gigl_amd._lib import STATS, STATS_LEN
     from gigl_amd.dist import Comm, DistSagePlan
@@ -608,15 +683,28 @@ def run_sharded(args, rank, world, local_rank):
     col = (key & 0xFFFFFFFF).to(torch.int32)
     maxdeg = torch.tensor([int((rowptr[1:] - rowptr[:-1]).max())], dtype=torch.int64, device=dev)
     e_local = torch.tensor([int(col.numel())], dtype=torch.int64, device=dev)
-    dist.all_reduce(maxdeg, op=dist.ReduceOp.MAX)
-    dist.all_reduce(e_local, op=dist.ReduceOp.SUM)
+    all_reduce(maxdeg, dist.ReduceOp.MAX)
+    all_reduce(e_local, dist.ReduceOp.SUM)
     eng.load_csc(rowptr, col)
     # replicated hot rows (--shard-hot-frac): the nodes that occur most often as in-neighbours, the same set on every rank
     hot_ids = None
-    n_hot = int(n * max(0.0, args.shard_hot_frac))
+    hot_frac = float(args.shard_hot_frac)
+    if hot_frac < 0.0:
+        # auto (the default): hub-row replication ON whenever rows travel (world > 1) — the fraction of the nodes whose
+        # replicated rows fit in 4 % of the HBM still free after the shard is loaded, at most 5 %
+        if world == 1:
+            hot_frac = 0.0
+        else:
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            free_b -= ((n + world - 1) // world) * d * 2  # (the rank's feature rows are loaded below)
+            hot_frac = max(0.0, min(0.05, 0.04 * free_b / max(n * d * 2, 1)))
+        fr = torch.tensor([hot_frac], dtype=torch.float64, device=dev)
+        all_reduce(fr, dist.ReduceOp.MIN)  # the same set on every rank
+        hot_frac = float(fr.item())
+    n_hot = int(n * max(0.0, hot_frac))
     if n_hot > 0:
         occ = torch.bincount(col.to(torch.int64) & 0xFFFFFFFF, minlength=n).to(torch.int32)
-        dist.all_reduce(occ, op=dist.ReduceOp.SUM)
+        all_reduce(occ, dist.ReduceOp.SUM)
         hot_ids = torch.topk(occ.to(torch.int64) * (1 << 32) + (n - 1 - torch.arange(n, device=dev)), n_hot).indices
         hot_ids = hot_ids.to(torch.int32).contiguous()  # (ties broken by id: identical on every rank)
         del occ
@@ -634,7 +722,7 @@ def run_sharded(args, rank, world, local_rank):
         mine_hot = (hi % world) == rank
         hot_rows = torch.zeros((n_hot, d), device=dev, dtype=torch.float16)
         hot_rows[mine_hot] = x_local[hi[mine_hot] // world]
-        dist.all_reduce(hot_rows, op=dist.ReduceOp.SUM)
+        all_reduce(hot_rows, dist.ReduceOp.SUM)
     del x_local
     torch.cuda.empty_cache()
     torch.manual_seed(0)
@@ -668,7 +756,7 @@ def run_sharded(args, rank, world, local_rank):
             if si:
                 sl.eng.share_resident(eng)
             sl.eng.bind_stream(sl.stream)
-            sl.comm = Comm.rccl_from_torch(sl.eng)
+            sl.comm = Comm.from_torch(sl.eng)  # RCCL (nccl backend); the host-callback transport under gloo
             sl.plan = DistSagePlan(sl.comm, w, bs, G * B, fanouts, group_roots=B,
                                    project_on_owner=args.project_on_owner, pull_cap=pull_cap, max_window_end=mwe)
             sl.out = sl.plan.new_out()
@@ -712,7 +800,7 @@ def run_sharded(args, rank, world, local_rank):
     run_calls(slots, 0, Wp // G, acc0)
     sync_all(slots)
     most = acc0[STATS["pull_bucket_max"]:STATS["pull_bucket_max"] + 1].clone()
-    dist.all_reduce(most, op=dist.ReduceOp.MAX)
+    all_reduce(most, dist.ReduceOp.MAX)
     if int(acc0[STATS["overflow"]].item()):
         raise RuntimeError("bucket overflow during warm-up")
     pull_cap = int(int(most.item()) * 1.1) + 64
@@ -742,7 +830,7 @@ def run_sharded(args, rank, world, local_rank):
     t_cal = time.perf_counter() - tc
     rr = torch.tensor([int(min(max(np.ceil(args.min_seconds / max(t_cal, 1e-6)), args.min_reps), 2000))],
                       dtype=torch.int64, device=dev)
-    dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+    all_reduce(rr, dist.ReduceOp.MAX)
     reps = int(rr.item())
     rep_s = []
     for r in range(reps):
@@ -755,10 +843,10 @@ def run_sharded(args, rank, world, local_rank):
         rep_s.append(time.perf_counter() - t1)
     dist.barrier()
     rep_t = torch.tensor(rep_s, dtype=torch.float64, device=dev)
-    dist.all_reduce(rep_t, op=dist.ReduceOp.MAX)
+    all_reduce(rep_t, dist.ReduceOp.MAX)
     seg_use = np.array([sum(1 for r in range(reps) if r % N_SEG == sg) for sg in range(N_SEG)], dtype=np.float64)
     tot = torch.tensor((seg_stats * seg_use[:, None]).sum(0), dtype=torch.float64, device=dev)
-    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    all_reduce(tot, dist.ReduceOp.SUM)
     tot = tot.cpu().numpy()
     rep_np = rep_t.cpu().numpy()
     elapsed = float(rep_np.sum())
@@ -782,7 +870,7 @@ def run_sharded(args, rank, world, local_rank):
                                    f"D={d} fp16 features, hash-partitioned over {world} rank(s) (owner = id % world), "
                                    f"fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}, sampler mode=parity, "
                                    f"{G} batches per exchange, {S} plans in flight, "
-                                   f"{'%g %% of the nodes replicated as hot rows, ' % (100 * args.shard_hot_frac) if n_hot else ''}"
+                                   f"{'%.3g %% of the nodes replicated as hot rows, ' % (100 * hot_frac) if n_hot else ''}"
                                    f"{'rows projected on the owner (256 fp32)' if args.project_on_owner else 'raw rows (768 fp16)'}",
                        "graph": "CSC rows + feature rows of the owned nodes per rank; per-hop all-to-all frontier "
                                 "exchange and feature pull of the unique union-graph nodes, issued by the library "
@@ -797,11 +885,40 @@ def run_sharded(args, rank, world, local_rank):
                        "setup_s": round(setup_s, 1)},
             "roofline": None, "cpu_baseline": None,
         }
-        print(json.dumps(line))
+        # ---- second roofline: xGMI.  Bytes a rank puts on its links per step = what it sends to the
+        # other world-1 ranks: per hop the request buckets (8 B per entry) and, as an owner, the answer buckets
+        # (4*f B per entry); then the id buckets of the feature pull (4 B) and the row buckets.  Buckets travel whole
+        # (fixed capacity, equal split), so `sent` counts padding; `payload` counts the requested entries only.
+        step_s = elapsed / steps_total
+        peers = world - 1
+        m_k, hop_sent = G * B, 0.0
+        for f in fanouts:
+            cap_k = m_k if world <= 2 else min(m_k, int(1.5 * m_k / world) + 512)
+            hop_sent += peers * cap_k * (8 + 4 * f)
+            m_k *= f
+        rows_sent = peers * pull_cap * (row_bytes + 4) * (2 if args.project_on_owner else 1)
+        sent_step = (hop_sent + rows_sent) / G
+        payload_step = pulled_all / (steps_total * world) * (row_bytes + 4) + \
+            sampled_all / (steps_total * world) * 4 * peers / max(world, 1)
+        peak_gbs = 7 * 153.0
+        line["roofline_xgmi"] = {
+            "bound": "xgmi", "peak": peak_gbs, "unit": "GB/s per GPU (7 links x 153 GB/s)",
+            "sent_bytes_per_step_per_gpu": sent_step, "payload_bytes_per_step_per_gpu": payload_step,
+            "achieved": sent_step / step_s / 1e9, "frac": sent_step / step_s / 1e9 / peak_gbs,
+            "payload_achieved": payload_step / step_s / 1e9, "links_in_use": min(peers, 7),
+            "transport": ("RCCL ncclSend / ncclRecv groups issued by the library" if dist.get_backend() == "nccl"
+                          else "host callback over " + dist.get_backend() + " (functional check, not xGMI)"),
+            "ranks": world}
+        if not sub:
+            print(json.dumps(line))
+    else:
+        line = None
     dist.barrier()
     close_slots(slots)
-    dist.destroy_process_group()
+    if not sub:
+        dist.destroy_process_group()
     eng.close()
+    return line
 
 
 def run_entry_inferencer(args, rank, world, local_rank):
@@ -914,7 +1031,7 @@ def run_entry_inferencer(args, rank, world, local_rank):
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([t_med], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        all_reduce(tt, dist.ReduceOp.MAX)
         t_med = float(tt.item())
     if rank == 0:
         line = {
@@ -1150,8 +1267,8 @@ def run_gat_lp(args, rank, world, local_rank):
         import torch.distributed as dist
         v = torch.tensor([line["value"]], dtype=torch.float64, device=dev)
         t = torch.tensor([line["ms_per_step"]], dtype=torch.float64, device=dev)
-        dist.all_reduce(v, op=dist.ReduceOp.SUM)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce(v, dist.ReduceOp.SUM)
+        all_reduce(t, dist.ReduceOp.MAX)
         line.update(value=float(v.item()), ms_per_step=float(t.item()), n_gpus=world)
     if rank == 0:
         print(json.dumps(line))

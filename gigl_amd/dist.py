@@ -293,6 +293,15 @@ class Comm:
         return Comm.rccl(eng, rank, world, box[0])
 
     @staticmethod
+    def from_torch(eng, group=None) -> "Comm":
+        """the communicator for the ranks of a torch.distributed group: RCCL over xGMI when the group's backend is nccl
+        (one GPU per rank: the production transport, issued by the library on the plan's stream); any other backend
+        (gloo: ranks sharing one GPU in tests, or no device buffers) moves the blocks through the host callback"""
+        if dist.get_backend(group) == "nccl":
+            return Comm.rccl_from_torch(eng, group)
+        return Comm.callback(eng, dist.get_rank(group), dist.get_world_size(group), torch_exchange(eng, group))
+
+    @staticmethod
     def local(engines) -> List["Comm"]:
         world = len(engines)
         ctxs = (C.c_void_p * world)(*[e._ctx for e in engines])

@@ -192,13 +192,8 @@ class ResidentGraph:
 
     # ---- multi-GPU transport
     def _make_comm(self):
-        import torch.distributed as dist
-        from .dist import Comm, torch_exchange
-        backend = dist.get_backend(self.group)
-        if backend == "nccl":  # one GPU per rank: RCCL over xGMI, issued by the library on the plan's stream
-            return Comm.rccl_from_torch(self.engine, self.group)
-        # ranks that share a GPU (tests) or a backend without device buffers: blocks staged through the host
-        return Comm.callback(self.engine, self.rank, self.world, torch_exchange(self.engine, self.group))
+        from .dist import Comm
+        return Comm.from_torch(self.engine, self.group)
 
     # ---- root order
     def inference_root_order(self) -> np.ndarray:

@@ -1,0 +1,53 @@
+"""bench.py --gpus N: the script launches its own ranks when no launcher did, refuses to measure fewer GPUs than it was
+asked for, and at N > 1 carries the sharded (hash-partitioned graph) sub-record."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_more_ranks_than_devices_is_an_error_not_a_one_gpu_run():
+    import torch
+    n = torch.cuda.device_count() + 1 if torch.cuda.device_count() else 2
+    p = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--small"], env=_env(), capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 2 and "needs" in p.stderr and "visible HIP devices" in p.stderr
+    assert not p.stdout.strip()  # no JSON line: nothing was measured
+
+
+def test_world_size_must_match_gpus():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--small"],
+                       env=_env(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and "WORLD_SIZE=2" in p.stderr and not p.stdout.strip()
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_on_one_gpu():
+    """GIGL_BENCH_SHARE_GPU=1: both ranks on device 0, gloo collectives, the library's host-callback transport — the
+    launcher, the per-rank root sharding, the max-over-ranks timing and the sharded sub-record run end to end"""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--small", "--no-cpu-baseline", "--min-seconds", "0.3",
+                        "--min-reps", "2", "--min-rounds", "2", "--group", "8", "--shard-group", "4", "--shard-scale",
+                        "0.0005", "--steps", "16", "--warmup", "8"],
+                       env=_env(GIGL_BENCH_SHARE_GPU="1"), capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # ONE JSON line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    sh = line["sharded"]
+    assert sh["n_gpus"] == 2 and sh["value"] > 0 and sh["roofline_xgmi"]["ranks"] == 2
+    assert sh["config"]["pulled_feature_rows_per_step"] > 0  # rows really travelled between the ranks
+    assert 0 < sh["config"]["row_bucket_fill"] <= 1.0
+    assert "replicated as hot rows" in sh["config"]["workload"]  # hub replication is on by default at world > 1
