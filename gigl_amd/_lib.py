@@ -52,6 +52,7 @@ SYMBOLS = [
     "gigl_collated_typed_samples", "gigl_collated_typed_destroy", "gigl_typed_records_capacity",
     "gigl_typed_records_encode", "gigl_typed_samples_encode", "gigl_hgt_aggregate_backward", "gigl_weighted_aggregate_backward",
     "gigl_graph_build_shard_from_coo", "gigl_json_rows_capacity", "gigl_json_rows_format",
+    "gigl_sage_project_features", "gigl_sage_plan_set_projected_input",
 ]
 
 KERNEL_IDS = {
@@ -294,6 +295,8 @@ def load() -> C.CDLL:
         "gigl_gat_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), P(i32), vp, vp, vp, vp, C.c_float, i32, vp],
         "gigl_gat_plan_set_weights": [vp, vp, vp, vp, vp],
         "gigl_sage_plan_set_aggr": [vp, i32],
+        "gigl_sage_project_features": [vp, vp, vp, i32, vp],
+        "gigl_sage_plan_set_projected_input": [vp, vp],
         "gigl_gat_input_layer_fused": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, i64, vp, i32,
                                        vp, vp],
         "gigl_gat_input_layer": [vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, i64, vp, i64, vp, i64,

@@ -64,7 +64,10 @@ __device__ __forceinline__ float4_t aggr_combine(float4_t a, float4_t b) {
   }
 }
 
-template <typename T, int LPR, int VPL, int OP = GIGL_AGGR_MEAN>
+// PROJ (the plan's projected-input first layer, pipeline.hip): `src` holds rows ALREADY multiplied by W_l (fp32, d =
+// the layer's output width); the epilogue adds the destination's own W_r row (self_src[self]) and the bias, applies
+// the activation and writes the finished layer output out[i][0:d] — no [mean | self] operand, no projection.
+template <typename T, int LPR, int VPL, int OP = GIGL_AGGR_MEAN, bool PROJ = false>
 __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ src, int d,
                                                           const uint32_t* __restrict__ gather_ids,
                                                           const int32_t* __restrict__ rowptr,
@@ -74,12 +77,16 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
                                                           float* __restrict__ out,
                                                           const int32_t* __restrict__ n_local_dev, int tiled_nkc,
                                                           const int32_t* __restrict__ global_map,
-                                                          const T* __restrict__ src2, const T* __restrict__ src3) {
+                                                          const T* __restrict__ src2, const T* __restrict__ src3,
+                                                          const float* __restrict__ self_src = nullptr,
+                                                          const float* __restrict__ bias = nullptr, int act = 0,
+                                                          int ld = 0) {
   constexpr int G = 64 / LPR;  // source rows per wave-instruction
+  const int64_t rs = PROJ ? (int64_t)ld : (int64_t)d;  // elements between source rows
   // a NEGATIVE row index -1-h names a row outside `src` (the sharded plan): h < 2^30 = row h of src2 (replicated hot
   // rows), else row h - 2^30 of src3 (this rank's own feature table)
   auto row_of = [&](int j) -> const T* {
-    if (j >= 0) return src + (int64_t)j * d;
+    if (j >= 0) return src + (int64_t)j * rs;
     const int h = -1 - j;
     return h < (1 << 30) ? src2 + (int64_t)h * d : src3 + (int64_t)(h - (1 << 30)) * d;
   };
@@ -138,10 +145,28 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
         acc[v] = aggr_combine<OP>(acc[v], o4);
       }
     }
-    const T* ps = row_of(self);
     // mean = sum / deg (a true division, like torch's scatter-mean), 0 for an empty row
     const float dv = (OP == GIGL_AGGR_MEAN && m > 0) ? (float)m : 1.f;
     const float4_t none4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (PROJ) {
+      if (sub == 0) {
+        const float* pr = self_src + (int64_t)(uint32_t)self * rs;
+        float* o = out + (int64_t)i * d;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int el = (v * LPR + sl) * 4;
+          if (el < d) {
+            float4_t r = ((OP == GIGL_AGGR_MAX && m == 0) ? none4 : acc[v] / dv) +
+                         *reinterpret_cast<const float4_t*>(pr + el);
+            if (bias) r += *reinterpret_cast<const float4_t*>(bias + el);
+            if (act) r = float4_t{fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f)};
+            *reinterpret_cast<float4_t*>(o + el) = r;
+          }
+        }
+      }
+      continue;
+    }
+    const T* ps = row_of(self);
     if (tiled_nkc) {  // the projection's operand layout: [row tile of 128][K chunk of 32][128 rows][32 floats]
       float* tbase = out + ((int64_t)(i >> 7) * tiled_nkc) * 4096 + (i & 127) * 32;
       if (sub == 0) {
@@ -487,8 +512,16 @@ __global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict
 // v_mfma_f32_32x32x16_bf16 — sixteen times the rate of the fp32 MFMA, so 6/16 of its matrix-pipe time — with fp32
 // accumulation inside the instruction.  The split happens on the way from the prefetch registers into LDS (and/sub/
 // and/sub + packing per element, VALU work that runs beside the matrix pipe); LDS holds the three bf16 planes of the
-// A and W tiles with 80-byte rows (conflict-free ds_read_b128 in the operand layout: lane l reads k = 8*(l/32) .. +8
-// of row l%32).  Workgroup tile 128 x 64*NJ, four waves as 2 x 2, each 64 rows x 32*NJ columns.
+// A and W tiles in 64-byte rows (32 bf16, no padding) whose four 16-byte slots are XOR-swizzled with the row number
+// (slot' = slot ^ ((row >> 2) & 3), split_lds_off).  On gfx950 a ds_read_b128 is served in four 16-lane groups
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) over 64 banks: lane l reads k = 8*(l/32) .. +8 of row l%32, and the
+// 16 rows of a group fall on 16 distinct 16-byte slots of the 256-byte bank row (rows equal mod 4 share a quarter of
+// it, their row >> 2 differ mod 4 inside every group); a ds_write_b64 is served in contiguous 16-lane groups over 32
+// banks: a row's eight lanes write its 64 bytes, a group = an even row (slots 0-3 of the 128-byte bank row) and the
+// odd row after it (slots 4-7) — every bank once.  (Round 2 padded the rows to 80 bytes: conflict-free reads, but the
+// two rows of a write group overlapped in banks 0-3, one extra LDS cycle per group — SQ_LDS_BANK_CONFLICT was a third
+// of the LDS cycles, exactly the writes' share — and the tile pair took 61 KB; 49 KB now: three workgroups per CU.)
+// Workgroup tile 128 x 64*NJ, four waves as 2 x 2, each 64 rows x 32*NJ columns.
 typedef short bf16x8_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split3(float x, uint32_t& b1, uint32_t& b2, uint32_t& b3) {
@@ -497,6 +530,11 @@ __device__ __forceinline__ void split3(float x, uint32_t& b1, uint32_t& b2, uint
   b2 = __float_as_uint(r1) & 0xFFFF0000u;
   const float r2 = r1 - __uint_as_float(b2);
   b3 = __float_as_uint(r2) & 0xFFFF0000u;
+}
+
+// offset (in bf16 elements) of element k (0..31) of tile row `row` in a swizzled plane
+__device__ __forceinline__ int split_lds_off(int row, int k) {
+  return row * 32 + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7);
 }
 
 // four consecutive k of one row -> four bf16 of each plane, stored as 8 bytes per plane
@@ -521,7 +559,7 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
   w += blockIdx.y * w_bstride;
   if (bias) bias += blockIdx.y * N;
   y += blockIdx.y * N;
-  constexpr int BK = 32, LDK = 40;          // bf16 elements per LDS row (32 + 8 of padding = 80 bytes)
+  constexpr int BK = 32, LDK = 32;          // bf16 elements per LDS row (swizzled slots, no padding: split_lds_off)
   constexpr int BM = 128, BN = 64 * NJ;
   __shared__ short s_a[3][BM * LDK];
   __shared__ short s_w[3][BN * LDK];
@@ -594,12 +632,12 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
     __syncthreads();  // the previous chunk's fragment reads are done
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int o = (lr + 32 * i) * LDK + lc * 4;
+      const int o = split_lds_off(lr + 32 * i, lc * 4);
       split_store(ra[i], &s_a[0][o], &s_a[1][o], &s_a[2][o]);
     }
 #pragma unroll
     for (int i = 0; i < 2 * NJ; ++i) {
-      const int o = (lr + 32 * i) * LDK + lc * 4;
+      const int o = split_lds_off(lr + 32 * i, lc * 4);
       split_store(rw[i], &s_w[0][o], &s_w[1][o], &s_w[2][o]);
     }
     __syncthreads();
@@ -612,12 +650,12 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          fa[i][p] = *reinterpret_cast<const bf16x8_t*>(&s_a[p][(wm * 64 + i * 32 + r) * LDK + ks + 8 * g]);
+          fa[i][p] = *reinterpret_cast<const bf16x8_t*>(&s_a[p][split_lds_off(wm * 64 + i * 32 + r, ks + 8 * g)]);
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int p = 0; p < 3; ++p)
-          fw[j][p] = *reinterpret_cast<const bf16x8_t*>(&s_w[p][(wn * 32 * NJ + j * 32 + r) * LDK + ks + 8 * g]);
+          fw[j][p] = *reinterpret_cast<const bf16x8_t*>(&s_w[p][split_lds_off(wn * 32 * NJ + j * 32 + r, ks + 8 * g)]);
       // six products per accumulator, smallest terms first; the 2*NJ accumulators are interleaved so that two MFMAs
       // on the same accumulator are never back to back (a dependent MFMA waits for the previous one's 16 passes)
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
@@ -2074,9 +2112,123 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
   return GIGL_OK;
 }
 
+// the projected-input first layer: gather + mean over fp32 rows of W_l x, + W_r x_self + bias, activation
+int32_t launch_gather_projected(gigl_ctx* ctx, const float* src_l, const float* src_r, int ld, int d, const uint32_t* gather_ids,
+                                const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                const int32_t* n_rows_dev, int64_t rows_cap, const int32_t* n_local_dev, int op,
+                                const float* bias, int act, float* out) {
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  dim3 g((unsigned)blocks), b(256);
+  const int vecs = d / 4;
+  const float* nul = nullptr;
+#define GLP(LPR, VPL)                                                                                                 \
+  do {                                                                                                                \
+    if (op == GIGL_AGGR_MEAN)                                                                                         \
+      hipLaunchKernelGGL((gather_mean_kernel<float, LPR, VPL, GIGL_AGGR_MEAN, true>), g, b, 0, ctx->stream, src_l, d, \
+                         gather_ids, rowptr, rowend, col, n_rows_dev, out, n_local_dev, 0, (const int32_t*)nullptr,   \
+                         nul, nul, src_r, bias, act, ld);                                                             \
+    else                                                                                                              \
+      hipLaunchKernelGGL((gather_mean_kernel<float, LPR, VPL, GIGL_AGGR_SUM, true>), g, b, 0, ctx->stream, src_l, d,  \
+                         gather_ids, rowptr, rowend, col, n_rows_dev, out, n_local_dev, 0, (const int32_t*)nullptr,   \
+                         nul, nul, src_r, bias, act, ld);                                                             \
+  } while (0)
+  if ((d & 3) != 0 || vecs > 512) return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "projected input: width %d (need d %% 4 == 0, d <= 2048)", d);
+  if (vecs <= 8) GLP(8, 1);
+  else if (vecs <= 16) GLP(16, 1);
+  else if (vecs <= 32) GLP(32, 1);
+  else if (vecs <= 64) GLP(64, 1);
+  else if (vecs <= 128) GLP(64, 2);
+  else if (vecs <= 256) GLP(64, 4);
+  else GLP(64, 8);
+#undef GLP
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+__global__ __launch_bounds__(256) void half_rows_to_f32_kernel(const __half* __restrict__ src, int64_t n,
+                                                               float* __restrict__ out) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const __half2* q = reinterpret_cast<const __half2*>(src + i);
+    const float2 a = __half22float2(q[0]), b = __half22float2(q[1]);
+    *reinterpret_cast<float4_t*>(out + i) = float4_t{a.x, a.y, b.x, b.y};
+  } else {
+    for (int64_t j = i; j < n; ++j) out[j] = __half2float(src[j]);
+  }
+}
+
 }  // namespace
 
+int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float* src_r, int32_t ld, int32_t d,
+                                  const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* rowend,
+                                  const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
+                                  const int32_t* n_local_rows_dev, const float* bias, int32_t act, float* out) {
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  if (aggr != GIGL_AGGR_MEAN && aggr != GIGL_AGGR_SUM)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "projected input needs a linear reduction (mean / sum)");
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  return launch_gather_projected(ctx, src_l, src_r, ld, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap,
+                                 n_local_rows_dev, aggr, bias, act, out);
+}
+
 extern "C" {
+
+// [X W_l^T | X W_r^T] over the whole resident feature table (the table of gigl_sage_plan_set_projected_input): ONE
+// product per row chunk against the stacked weight [W_l ; W_r] — the feature rows are read (and, for an fp16 table,
+// widened) once
+int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* w_fused, int32_t n_out, float* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, feat && w_fused && out && n_out > 0, "null argument");
+  GIGL_REQUIRE(ctx, feat->dtype == GIGL_DTYPE_F32 || feat->dtype == GIGL_DTYPE_F16, "bad feature dtype");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int d = feat->d;
+  const int64_t n = feat->n;
+  hipStream_t st = ctx->stream;
+  const int64_t chunk = (int64_t)1 << 19;
+  float *wcat = nullptr, *stage = nullptr;
+  int32_t* cnt = nullptr;
+  auto cleanup = [&]() {
+    hipStreamSynchronize(st);
+    hipFree(wcat); hipFree(stage); hipFree(cnt);
+  };
+  GIGL_HIP_CHECK(ctx, hipMalloc((void**)&wcat, (size_t)2 * n_out * d * 4));
+  // two staging buffers for an fp16 table: chunk c + 1 is widened while chunk c is multiplied? (one stream: they run
+  // back to back; two buffers only keep the conversion of c + 1 from overwriting the operand of c's product)
+  const int64_t cm = n < chunk ? n : chunk;
+  if (hipMalloc((void**)&cnt, 16) != hipSuccess ||
+      (feat->dtype == GIGL_DTYPE_F16 && hipMalloc((void**)&stage, (size_t)cm * d * 4 + 16) != hipSuccess)) {
+    cleanup();
+    return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the projection workspace failed");
+  }
+  // [W_l | W_r] rows of 2d floats -> the stacked [2 n_out][d] matrix
+  hipMemcpy2DAsync(wcat, (size_t)d * 4, w_fused, (size_t)2 * d * 4, (size_t)d * 4, n_out, hipMemcpyDeviceToDevice, st);
+  hipMemcpy2DAsync(wcat + (size_t)n_out * d, (size_t)d * 4, w_fused + d, (size_t)2 * d * 4, (size_t)d * 4, n_out,
+                   hipMemcpyDeviceToDevice, st);
+  const int32_t counts[2] = {(int32_t)cm, (int32_t)(n % cm)};  // row counts: a whole chunk, the tail
+  if (hipMemcpyAsync(cnt, counts, 8, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+    cleanup();
+    return gigl_fail(ctx, GIGL_E_HIP, "row-count upload failed");
+  }
+  int32_t rc = GIGL_OK;
+  for (int64_t r0 = 0; r0 < n && rc == GIGL_OK; r0 += cm) {
+    const int64_t m = (n - r0) < cm ? (n - r0) : cm;
+    const float* a;
+    if (feat->dtype == GIGL_DTYPE_F16) {
+      const int64_t elems = m * d;
+      hipLaunchKernelGGL(half_rows_to_f32_kernel, dim3((unsigned)((elems / 4 + 256) / 256)), dim3(256), 0, st,
+                         (const __half*)feat->rows + r0 * d, elems, stage);
+      a = stage;
+    } else {
+      a = (const float*)feat->rows + r0 * d;
+    }
+    rc = gigl_linear(ctx, a, wcat, nullptr, cnt + (m == cm ? 0 : 1), m, d, 2 * n_out, 0, out + r0 * 2 * n_out);
+  }
+  cleanup();
+  return rc;
+}
 
 int32_t gigl_gather_mean(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
                          const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* rowend,

@@ -106,6 +106,12 @@ int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dty
 // global_map: the rows i >= *n_local_rows_dev hold GLOBAL ids whose row in `src` is global_map[id] (the sharded plan's
 // receive buffer, dist.hip); a NEGATIVE row index -1-h (from gather_ids or global_map) is row h of `src2` (replicated
 // hot rows) when h < 2^30, else row h - 2^30 of `src3` (the rank's own feature table)
+// the plan's projected-input first layer: src_l / src_r hold W_l x / W_r x for every node (fp32 rows of width d, `ld`
+// floats apart, by global id); out[i][0:d] = act(reduce_{e in row i} src_l[idx(col[e])] + src_r[gather_ids[i]] + bias)
+int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float* src_r, int32_t ld, int32_t d,
+                                  const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* rowend,
+                                  const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
+                                  const int32_t* n_local_rows_dev, const float* bias, int32_t act, float* out);
 // tiled_nkc > 0: `out` is written in the projection's tiled operand layout ([row tile of 128][K chunk of 32][128 rows]
 // [32 floats], tiled_nkc = ceil(2d / 32); capacity: whole row tiles) and read by gigl_linear_tiled (agg.hip)
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,

@@ -38,6 +38,9 @@ struct gigl_sage_plan {
   const float* bias[GIGL_MAX_HOPS] = {nullptr};  // device, borrowed, may be null
   int32_t act_last = 0;
   int32_t aggr = GIGL_AGGR_MEAN;  // the SAGE layers' reduction (gigl_sage_plan_set_aggr)
+  // projected input (gigl_sage_plan_set_projected_input): [W_l x | W_r x] of EVERY node, [graph nodes][2*dims[1]]
+  // fp32, device, borrowed — the first layer is then one gather (+ self row + bias + activation), no projection
+  const float* proj = nullptr;
   // kind 1: GAT layers instead of SAGE layers (gigl_gat_plan_create): w[l] = lin weight [heads*channels][dims[l]],
   // layer 0 from the input side in one row pass (gigl_gat_input_layer_fused), layers >= 1 projection + attention
   int32_t kind = 0;
@@ -230,6 +233,15 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
     return gigl_gat_aggregate(ctx, p->hw, p->att_src[l], p->att_dst[l], p->heads[l], p->channels[l], p->slope, 1,
                               p->un.rowptr, p->un.rowend, p->un.col, n_src, src_cap, n_rows, rows_cap, p->bias[l], act,
                               p->alpha_scratch, p->hbuf[l & 1]);
+  }
+  if (l == 0 && p->proj) {
+    // lin_l(mean_j x_j) = mean_j lin_l(x_j): the rows arrive projected, the layer is the reduction plus the self row
+    if (((s - 2) & 1) != 0) return GIGL_OK;  // (no projection stage)
+    const int act = (l < L - 1 || p->act_last) ? 1 : 0;
+    return gigl_gather_project_mixed(
+        ctx, p->proj, p->proj + p->dims[1], 2 * p->dims[1], p->dims[1], p->un.nodes, p->un.rowptr, p->un.rowend, p->un.col, n_rows, rows_cap,
+        p->aggr, p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr, p->bias[0],
+        act, p->hbuf[0]);
   }
   const int32_t nkc = p->tiled ? (2 * d + 31) / 32 : 0;
   if (((s - 2) & 1) == 0) {
@@ -535,6 +547,23 @@ int32_t gigl_sage_plan_set_aggr(gigl_sage_plan* p, int32_t aggr) {
     drop_graphs(p);
   }
   p->aggr = aggr;
+  return GIGL_OK;
+}
+
+int32_t gigl_sage_plan_set_projected_input(gigl_sage_plan* p, const float* proj) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, p->kind == 0, "projected input applies to SAGE plans");
+  if (proj) {
+    GIGL_REQUIRE(ctx, p->aggr == GIGL_AGGR_MEAN || p->aggr == GIGL_AGGR_SUM,
+                 "projected input needs a linear reduction: lin(max_j x_j) != max_j lin(x_j)");
+    GIGL_REQUIRE(ctx, (p->dims[1] & 3) == 0 && p->dims[1] <= 2048, "projected input: first-layer width %d", p->dims[1]);
+  }
+  if (p->captured && p->proj != proj) {  // the pointer is baked into the captured launches
+    hipStreamSynchronize(ctx->stream);
+    drop_graphs(p);
+  }
+  p->proj = proj;
   return GIGL_OK;
 }
 

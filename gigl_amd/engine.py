@@ -1051,6 +1051,22 @@ class HipEngine:
                                                      p(d)), self._ctx)
         return d
 
+    def project_features(self, w_fused: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[X W_l^T | X W_r^T] over the whole resident feature table for a first-layer fused weight [out, 2*in]
+        (gigl_sage_project_features): one fp32 table [n_rows, 2*out] on the device — the input of
+        SagePlan.set_projected_input"""
+        assert self._feat is not None and w_fused.dim() == 2 and w_fused.shape[1] == 2 * self.feat_dim
+        w = w_fused.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        n_out = int(w.shape[0])
+        n_rows = C.c_int64()
+        check(self._lib.gigl_features_device_ptr(self._feat, None, C.byref(n_rows), None, None), self._ctx)
+        if out is None:  # (a job re-projects after every weight update: pass the previous table back in)
+            out = torch.empty((n_rows.value, 2 * n_out), dtype=torch.float32, device=self.device)
+        assert out.is_cuda and out.is_contiguous() and tuple(out.shape) == (n_rows.value, 2 * n_out)
+        check(self._lib.gigl_sage_project_features(self._ctx, self._feat, C.c_void_p(w.data_ptr()), n_out,
+                                                   C.c_void_p(out.data_ptr())), self._ctx)
+        return out
+
     # ---- one-call batch pipeline -----------------------------------------------------------
     def make_sage_plan(self, weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], b: int,
                        fanouts: Sequence[int], act_last: bool = False, groups: int = 1, aggr: str = "mean") -> "SagePlan":
@@ -1126,6 +1142,18 @@ class SagePlan:
     def set_weights(self, weights, biases) -> None:
         w_arr, b_arr = self._ptr_arrays(weights, biases)
         check(self._lib.gigl_sage_plan_set_weights(self._plan, w_arr, b_arr), self.eng._ctx)
+
+    def set_projected_input(self, proj: Optional[torch.Tensor]) -> None:
+        """first layer over PROJECTED rows (HipEngine.project_features of this plan's first-layer weight): one reduction
+        + the self row + bias, no per-batch projection (gigl_sage_plan_set_projected_input); None switches back.
+        The table belongs to the weights it was computed from: recompute it after a weight update."""
+        if proj is None:
+            check(self._lib.gigl_sage_plan_set_projected_input(self._plan, None), self.eng._ctx)
+            self._proj = None
+            return
+        assert proj.is_cuda and proj.dtype == torch.float32 and proj.is_contiguous() and proj.shape[1] == 2 * self.dims[1]
+        check(self._lib.gigl_sage_plan_set_projected_input(self._plan, C.c_void_p(proj.data_ptr())), self.eng._ctx)
+        self._proj = proj  # borrowed by the plan
 
     def use_graph(self, on: bool = True) -> None:
         """replay the batch as one hipGraph launch (captured on the next run)"""

@@ -300,10 +300,22 @@ class ResidentGraph:
                 raise
             return None
 
-    @staticmethod
-    def _refresh(plan, model) -> None:
+    def _refresh(self, plan, model) -> None:
         if hasattr(model, "fused_params"):
             plan.set_weights(*model.fused_params())
+            # an inference pass over rows wider than the first layer's output: project the table once per model state
+            # (X W_l^T, X W_r^T) and run the first layer over projected rows — one table per resident graph, shared by
+            # the plans of this model
+            if not self.sharded and hasattr(plan, "set_projected_input") and \
+                    getattr(model, "projected_input_pays", lambda e: False)(self.engine) and \
+                    os.environ.get("GIGL_AMD_PROJECT_INPUT", "1") != "0":
+                stamp = tuple((p.data_ptr(), p._version) for p in model.conv_layers[0].parameters())
+                cached = getattr(self, "_proj_tables", None)
+                if cached is None or cached[0] != (id(model), stamp):
+                    w0 = model.conv_layers[0].fused_weight()
+                    old = cached[1] if cached is not None and cached[1].shape[1] == 2 * w0.shape[0] else None
+                    cached = self._proj_tables = ((id(model), stamp), self.engine.project_features(w0, out=old))
+                plan.set_projected_input(cached[1])
         elif hasattr(model, "plan_params"):
             plan.set_weights(*model.plan_params())
 

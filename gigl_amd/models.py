@@ -284,6 +284,16 @@ class GraphSAGE(nn.Module):
         x = torch.where(valid, x, torch.zeros_like(x))
         return HipBatch(eng, batch.tree, u, x=self._interact(x, eng).contiguous(), edge_attr=batch.edge_attr)
 
+    def projected_input_pays(self, eng: HipEngine) -> bool:
+        """True when a first layer over projected rows moves fewer bytes per aggregated edge than one over the stored
+        rows (fp32 rows of the first layer's width against the table's rows) — MAG240M's 768 fp16 -> 256; not
+        ogbn-products' 100 fp32 -> 256"""
+        from ._lib import DTYPE_F32
+        esz = 4 if eng.feat_dtype == DTYPE_F32 else 2
+        return (self._plain and self.aggr in ("mean", "sum") and self.feats_interaction is None
+                and self.feature_embedding_layer is None
+                and self.conv_layers[0].out_channels * 4 < self.conv_layers[0].in_channels * esz)
+
     def make_plan(self, eng: HipEngine, b: int, fanouts: Sequence[int], groups: int = 1):
         """one-call pipeline (sample -> union -> this model's forward -> one row per root) for batches of
         `b` roots on `eng`; weights are snapshotted — call plan.set_weights(*model.fused_params()) after updates.

@@ -830,6 +830,18 @@ int32_t gigl_gat_plan_set_weights(gigl_sage_plan* plan, const float* const* w, c
                                   const float* const* att_dst, const float* const* bias);
 /* the SAGE layers' reduction: GIGL_AGGR_MEAN (default) | GIGL_AGGR_SUM | GIGL_AGGR_MAX (PyG SAGEConv aggr) */
 int32_t gigl_sage_plan_set_aggr(gigl_sage_plan* plan, int32_t aggr);
+/* Projected input (inference passes over a feature table whose rows are wider than the first layer's output — MAG240M:
+ * 768 fp16 in, 256 out): lin_l(mean_j x_j) = mean_j lin_l(x_j), so [X W_l^T | X W_r^T] is computed ONCE per model over
+ * the resident table (gigl_sage_project_features: one gigl_linear pass per row chunk against the stacked weight; w_fused
+ * = the first layer's [W_l | W_r], out = DEVICE fp32 [feature rows][2 * n_out]) instead of once per OCCURRENCE of a node
+ * in a batch, and the plan's first layer becomes one reduction over the projected rows + the destination's own W_r row +
+ * bias (activation fused) — no [mean | self] operand, no per-batch projection; results equal the unprojected order up
+ * to fp32 rounding (the reference computes lin_l AFTER the mean: python/gigl/src/common/models/pyg/homogeneous.py:
+ * 171-202 via PyG SAGEConv).  The table is borrowed; set_projected_input(plan, NULL) returns to the unprojected layer;
+ * it must be recomputed whenever the first layer's weights change (gigl_sage_plan_set_weights does NOT touch it).
+ * Mean / sum reductions only. */
+int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* w_fused, int32_t n_out, float* out);
+int32_t gigl_sage_plan_set_projected_input(gigl_sage_plan* plan, const float* proj);
 int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
 int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);

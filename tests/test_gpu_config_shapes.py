@@ -45,5 +45,41 @@ def test_plan_matches_oracle_at_config_shapes(scale, n_edges, d, hid, out, fan, 
         ref = gnn_ref.graphsage_forward(xs, gnn_ref.union_edge_index(u["rowptr"], u["col"]), sd, 2)
         want = ref[torch.from_numpy(u["root_local"].astype(np.int64))].numpy()
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+        # projected input (gigl_sage_plan_set_projected_input): X W_l^T / X W_r^T computed once over the table, the
+        # first layer is a reduction over projected rows — same trees, the same embeddings to 1e-5
+        proj = eng.project_features(model.conv_layers[0].fused_weight())
+        xw = torch.from_numpy(x16.astype(np.float32)) @ model.conv_layers[0].lin_l.weight.detach().cpu().T
+        np.testing.assert_allclose(proj[:, :hid].cpu().numpy(), xw.numpy(), rtol=1e-5, atol=2e-6)
+        xr = torch.from_numpy(x16.astype(np.float32)) @ model.conv_layers[0].lin_r.weight.detach().cpu().T
+        np.testing.assert_allclose(proj[:, hid:].cpu().numpy(), xr.numpy(), rtol=1e-5, atol=2e-6)
+        plan.set_projected_input(proj)
+        got_p = plan.run(torch.from_numpy(roots.view(np.int32)).to(eng.device)).cpu().numpy()
+        hb2 = plan.last_batch_to_host()
+        assert hb2["meta"][8] == 0 and all(np.array_equal(hb2["nbr"][k], nbr_o[k]) for k in range(2))
+        np.testing.assert_allclose(got_p, want, rtol=1e-5, atol=1e-5)
+        plan.set_projected_input(None)  # and back: bit-identical to the first run
+        again = plan.run(torch.from_numpy(roots.view(np.int32)).to(eng.device)).cpu().numpy()
+        assert np.array_equal(again, got)
+        # groups of batches + hipGraph replay with the projected layer (replay needs a created stream)
+        g = 4
+        st = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        eng.bind_stream(st)
+        plan_g = model.make_plan(eng, b // g, fan, groups=g)
+        plan_g.set_projected_input(proj)
+        r_dev = torch.from_numpy(roots.view(np.int32)).to(eng.device)
+        eager = plan_g.run(r_dev)
+        st.synchronize()
+        eager = eager.clone()
+        plan_g.use_graph(True)
+        for _ in range(2):
+            got_g = plan_g.run(r_dev)
+            st.synchronize()
+            assert torch.equal(got_g, eager)
+        single = model.make_plan(eng, b // g, fan)
+        single.set_projected_input(proj)
+        one = single.run(r_dev[: b // g].contiguous())
+        st.synchronize()
+        assert torch.equal(one, eager[: b // g])
     finally:
         eng.close()
