@@ -64,18 +64,28 @@ PMC_KERNELS = {
 }
 
 
-def pmc_traffic(kernel_id: str, batches_per_call: int):
-    """HBM-side bytes per launch of `kernel_id` from the newest committed rocprofv3 PMC summary (profiles/*_pmc.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes by scripts/gpu_pmc.sh on the same workload and launch
-    shape — `batches_per_call` must match — corrected with the factors calibrated there).  bench.py cannot collect
-    PMC counters on itself, so this is a measured constant of the committed build, refreshed whenever the profile
-    is; None when no matching summary is committed."""
+def pmc_traffic(kernel_id: str, batches_per_call: int, workload: str = "products", projected: bool = False):
+    """HBM-side bytes per launch of `kernel_id` from the newest committed rocprofv3 PMC summary OF THIS WORKLOAD
+    (profiles/*_pmc*.json: FETCH_SIZE and WRITE_SIZE collected in separate passes by scripts/gpu_pmc.sh on the same
+    workload and launch shape — `workload`, `batches_per_call` and the projected-input mode must match — corrected with
+    the factors calibrated there).  bench.py cannot collect PMC counters on itself, so this is a measured constant of
+    the committed build, refreshed whenever the profile is; None when no matching summary is committed."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files or kernel_id not in PMC_KERNELS:
+    if kernel_id not in PMC_KERNELS:
         return None, None
-    doc = json.load(open(files[-1]))
-    if doc.get("batches_per_call") != batches_per_call:
+    doc = src = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc*.json")), reverse=True):
+        try:
+            cand = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if not isinstance(cand, dict) or "kernels" not in cand:
+            continue
+        if cand.get("workload", "products") == workload and cand.get("batches_per_call") == batches_per_call and \
+                bool(cand.get("projected_input")) == bool(projected):
+            doc, src = cand, os.path.basename(f)
+            break
+    if doc is None:
         return None, None
     tot_bytes = tot_calls = 0.0
     for name, e in doc["kernels"].items():
@@ -85,7 +95,7 @@ def pmc_traffic(kernel_id: str, batches_per_call: int):
         tot_bytes += e["hbm_bytes_per_launch"] * calls
         # a union group is several kernels launched once per call each; the others are one kernel launched repeatedly
         tot_calls = max(tot_calls, calls) if kernel_id.startswith("union") else tot_calls + calls
-    return (tot_bytes / tot_calls if tot_calls else None), os.path.basename(files[-1])
+    return (tot_bytes / tot_calls if tot_calls else None), src
 
 
 def rmat_edges_gpu(scale: int, n_edges: int, seed: int, device, a=0.57, b=0.19, c=0.19):
@@ -398,6 +408,7 @@ def main():
         run_range(*seg_range(0))
         torch.cuda.synchronize()
         print(json.dumps({"timed_only": True, "steps": K_rep, "batches_per_call": G, "streams": S,
+                          "workload": wl_name, "projected_input": bool(projected),
                           "ms_per_step": (time.perf_counter() - t1) / K_rep * 1e3}))
         for e in reversed(engines):
             e.close()
@@ -442,6 +453,26 @@ def main():
     seg_stats = seg_acc.cpu().numpy().astype(np.float64)
     if seg_stats[:, STATS["overflow"]].any() or int(probe_acc[STATS["overflow"]].item()):
         raise RuntimeError("union dedup / workspace overflow in a benchmark batch (meta[GIGL_META_OVERFLOW])")
+
+    # ---- untimed: the same timers under the TIMED regime (S streams, G batches per call, launches eager so the events
+    # bracket them): the dominant kernel is the one with the largest share there — with the other streams' kernels
+    # resident a launch lasts longer than alone, and not by the same factor for every kernel
+    prof_alone = prof
+    if S > 1:
+        for e in engines:
+            e.profile_enable(names, capacity=(P // G + 4) * 24)
+        run_range(plo, plo + rnd)
+        for e in engines:
+            e.profile_reset()
+        run_range(plo, plo + P)
+        for p in plans:
+            p.flush_profile()
+        prof_ovl = {k: [sum(x) for x in zip(*[e.profile_read(k) for e in engines])] for k in names}
+        for e in engines:
+            e.profile_enable([], 0)
+        dominant = max(prof_ovl, key=lambda k: prof_ovl[k][0])
+    else:
+        prof_ovl = prof
 
     # ---- calibration repetition (untimed; also re-captures every plan's hipGraph under the final timer mask)
     for e in engines:
@@ -536,7 +567,7 @@ def main():
     avg_launch_ms = dom_ms / max(dom_launches, 1)
     bytes_per_launch = alg_timed[dominant] / max(dom_launches, 1)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    traffic, traffic_src = pmc_traffic(dominant, G)
+    traffic, traffic_src = pmc_traffic(dominant, G, wl_name, projected)
     # every kernel group against its own bound, from the single-stream probe (P steps, all timers on)
     by_kernel = {}
     for k, v in prof.items():
@@ -553,7 +584,7 @@ def main():
             gbs = alg_probe[k] / P / (ms_step * 1e-3) / 1e9
             by_kernel[k] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(gbs / HBM_PEAK_GBS, 4), "ms_per_step": round(ms_step, 5)}
-            tk, _src = pmc_traffic(k, G)
+            tk, _src = pmc_traffic(k, G, wl_name, projected)
             if tk is not None and v[1] > 0:  # counter traffic per launch / the kernel's own (single-stream) duration
                 by_kernel[k]["traffic_frac"] = round(tk / (v[0] / v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             if by_kernel[k]["frac"] > 1.0:  # the byte model counts bytes the kernel does not move (the sampler reads a
@@ -591,9 +622,15 @@ def main():
                 head.update({"kernel": k2, "achieved": cand[k2]["achieved"], "frac": cand[k2]["frac"]})
                 note = (f"dominant kernel `{dominant}` has algorithmic frac > 1 and no PMC summary for this launch "
                         f"shape is committed: headline = `{k2}`, the slowest HBM-bound group (single-stream probe)")
+    head["frac_overlapped"] = head["frac"]  # the kernel while the other streams' kernels share the GPU (timed region)
+    head["frac_alone"] = by_kernel.get(head["kernel"], {}).get("frac")  # ... and on its own (single-stream probe)
     roofline = {**head,
                 "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
-                "dominant": dominant, "avg_launch_us": round(avg_launch_ms * 1e3, 2),
+                "dominant": dominant,
+                "dominant_from": "largest total HIP-event time per kernel group in an untimed repetition of the timed "
+                                 "regime (all timers on, launches eager)",
+                "overlapped_ms_per_step": {k: round(v[0] / P, 5) for k, v in prof_ovl.items() if v[0] > 0},
+                "avg_launch_us": round(avg_launch_ms * 1e3, 2),
                 "alg_bytes_per_launch": round(bytes_per_launch), "launches": int(dom_launches), "note": note,
                 "timing": f"HIP events on the kernel's stream over the timed region ({S} streams: intervals include "
                           "overlap with the other streams' kernels); by_kernel: single-stream untimed probe",

@@ -51,7 +51,8 @@ def main():
             shape = json.loads(lines[-1])
         except (OSError, IndexError):
             pass
-    out = {"tag": tag, "batches_per_call": shape.get("batches_per_call"), "streams": shape.get("streams"),
+    out = {"tag": tag, "workload": shape.get("workload", "products"), "projected_input": shape.get("projected_input"),
+           "batches_per_call": shape.get("batches_per_call"), "streams": shape.get("streams"),
            "counter_unit": "KB (rocprofv3 FETCH_SIZE / WRITE_SIZE)", "known_bytes": known,
            "calibration": {}, "kernels": {}}
     corr = {}
