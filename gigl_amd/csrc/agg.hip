@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
                                                           const T* __restrict__ src2, const T* __restrict__ src3,
                                                           const float* __restrict__ self_src = nullptr,
                                                           const float* __restrict__ bias = nullptr, int act = 0,
-                                                          int ld = 0) {
+                                                          int ld = 0, int no_self = 0) {
   constexpr int G = 64 / LPR;  // source rows per wave-instruction
   const int64_t rs = PROJ ? (int64_t)ld : (int64_t)d;  // elements between source rows
   // a NEGATIVE row index -1-h names a row outside `src` (the sharded plan): h < 2^30 = row h of src2 (replicated hot
@@ -100,24 +100,92 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
   const int waves_total = (gridDim.x * blockDim.x) >> 6;
   constexpr float IDV = OP == GIGL_AGGR_MAX ? -__builtin_inff() : 0.f;  // identity of the reduction
   const float4_t zero4 = {IDV, IDV, IDV, IDV};
-  for (int i = wave; i < n_rows; i += waves_total) {
-    const int e0 = rowptr[i], m = rowend[i] - e0;
+  const float4_t none4 = {0.f, 0.f, 0.f, 0.f};
+
+  // source index of column entry `c` of destination row i
+  auto translate = [&](int c, int i) -> int {
+    if (gather_ids && i < n_local) return (int)gather_ids[c];
+    if (global_map && i >= n_local) return global_map[(uint32_t)c];  // global id -> its row in `src`
+    return c;
+  };
+  // lane `idx` of group `sub`'s LPR lanes (grp), or entry idx + sub of the wave's index vector (wave-wide rows).
+  // (v_readlane + select instead of the ds_bpermute behind __shfl was measured for G <= 2 — rmat-shard 12.8 -> 16.2 us /
+  // step, products 9.56 -> 9.69: the scalar round trip stalls the loads it feeds; dropped)
+  auto pick = [&](int v, int idx, bool grp) -> int {
+    return grp ? __shfl(v, (lane & ~(LPR - 1)) + idx, 64) : __shfl(v, (idx + sub) & 63, 64);
+  };
+  // write the finished row i: `acc` holds the reduction in the lanes sl of group `sub` (grp: every group owns its own
+  // row; else the whole wave owns row i and group 0 holds the total)
+  auto emit = [&](int i, int m, float4_t (&acc)[VPL], bool grp) {
     const int self = gather_ids ? (int)gather_ids[i] : i;
+    const bool writer = grp || sub == 0;
+    // mean = sum / deg (a true division, like torch's scatter-mean), 0 for an empty row
+    const float dv = (OP == GIGL_AGGR_MEAN && m > 0) ? (float)m : 1.f;
+    const int c0 = (grp ? sl : lane) * 4, cstep = (grp ? LPR : 64) * 4;  // the self-row copy's lanes
+    if constexpr (PROJ) {
+      if (writer) {
+        const float* pr = self_src + (int64_t)(uint32_t)self * rs;
+        float* o = out + (int64_t)i * d;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int el = (v * LPR + sl) * 4;
+          if (el < d) {
+            float4_t r = ((OP == GIGL_AGGR_MAX && m == 0) ? none4 : acc[v] / dv) +
+                         *reinterpret_cast<const float4_t*>(pr + el);
+            if (bias) r += *reinterpret_cast<const float4_t*>(bias + el);
+            if (act) r = float4_t{fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f)};
+            *reinterpret_cast<float4_t*>(o + el) = r;
+          }
+        }
+      }
+      return;
+    }
+    const T* ps = row_of(self);
+    if (tiled_nkc) {  // the projection's operand layout: [row tile of 128][K chunk of 32][128 rows][32 floats]
+      float* tbase = out + ((int64_t)(i >> 7) * tiled_nkc) * 4096 + (i & 127) * 32;
+      if (writer) {
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+          const int el = (v * LPR + sl) * 4;
+          if (el < d)
+            *reinterpret_cast<float4_t*>(tbase + (int64_t)(el >> 5) * 4096 + (el & 31)) =
+                (OP == GIGL_AGGR_MAX && m == 0) ? none4 : acc[v] / dv;
+        }
+      }
+      // (no_self: the projection reads the self half of its operand straight from the source rows — two-source A
+      // tile, linear_split_kernel<.., SELF> — so it is neither read nor written here)
+      if (!no_self)
+        for (int el = c0; el < d; el += cstep) {
+          const int k = d + el;
+          *reinterpret_cast<float4_t*>(tbase + (int64_t)(k >> 5) * 4096 + (k & 31)) = RowLoader<T>::load4(ps, el);
+        }
+      return;
+    }
+    float* o = out + (int64_t)i * 2 * d;
+    if (writer) {
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) {
+        const int el = (v * LPR + sl) * 4;
+        if (el < d) *reinterpret_cast<float4_t*>(o + el) = (OP == GIGL_AGGR_MAX && m == 0) ? none4 : acc[v] / dv;
+      }
+    }
+    for (int el = c0; el < d; el += cstep)  // self row copy
+      *reinterpret_cast<float4_t*>(o + d + el) = RowLoader<T>::load4(ps, el);
+  };
+  // one destination row on the whole wave: G source rows per instruction, four instructions in flight
+  auto wave_row = [&](int i) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
     float4_t acc[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) acc[v] = zero4;
     for (int c0 = 0; c0 < m; c0 += 64) {
       const int mm = min(64, m - c0);
       int my = 0;
-      if (lane < mm) {
-        my = col[e0 + c0 + lane];
-        if (gather_ids && i < n_local) my = (int)gather_ids[my];
-        else if (global_map && i >= n_local) my = global_map[(uint32_t)my];  // global id -> its row in `src`
-      }
-      for (int e = 0; e < mm; e += 4 * G) {  // wave-uniform trip count (shuffles need every lane)
+      if (lane < mm) my = translate(col[e0 + c0 + lane], i);
+      for (int e = 0; e < mm; e += 4 * G) {  // wave-uniform trip count (the broadcasts need every lane)
         const int ea = e + sub, eb = ea + G, ec = ea + 2 * G, ed = ea + 3 * G;
-        const int ja = __shfl(my, ea & 63, 64), jb = __shfl(my, eb & 63, 64), jc = __shfl(my, ec & 63, 64),
-                  jd = __shfl(my, ed & 63, 64);
+        const int ja = pick(my, e, false), jb = pick(my, (e + G) & 63, false), jc = pick(my, (e + 2 * G) & 63, false),
+                  jd = pick(my, (e + 3 * G) & 63, false);
         const T* pa = row_of(ja);
         const T* pb = row_of(jb);
         const T* pc = row_of(jc);
@@ -145,56 +213,66 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
         acc[v] = aggr_combine<OP>(acc[v], o4);
       }
     }
-    // mean = sum / deg (a true division, like torch's scatter-mean), 0 for an empty row
-    const float dv = (OP == GIGL_AGGR_MEAN && m > 0) ? (float)m : 1.f;
-    const float4_t none4 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (PROJ) {
-      if (sub == 0) {
-        const float* pr = self_src + (int64_t)(uint32_t)self * rs;
-        float* o = out + (int64_t)i * d;
+    emit(i, m, acc, false);
+  };
+
+  // (GROUP_ROWS: measured on the MI355X — products-shaped 9.56 -> 9.73 us / step, rmat-shard 12.8 -> 14.3: the kernel
+  // already moves its bytes at ~80 % of the HBM peak with a wave per row, more rows in flight per wave buy nothing and
+  // the longer rows' second pass costs; kept for reference, compiled out)
+  constexpr bool GROUP_ROWS = false;
+  if constexpr (G == 1 || !GROUP_ROWS) {
+    for (int i = wave; i < n_rows; i += waves_total) wave_row(i);
+  } else {
+    // Rows narrower than a wave (LPR < 64 lanes cover a source row): a wave takes G consecutive destination rows.  The
+    // SHORT ones (<= SHORT_MAX in-edges — most rows of a sampled batch: a hop-1 node keeps at most f1 in-edges, on a
+    // power-law graph usually a handful) are reduced side by side, one per lane group, four source rows in flight per
+    // group: G times the rows in flight of a wave per row, and no cross-group combine.  Longer rows of the set then take
+    // the whole wave one after another.  Which path a row takes depends on its own length only, so its bits never
+    // depend on its neighbours (groups of batches == single batches).
+    constexpr int SHORT_MAX = LPR < 16 ? LPR : 16;
+    for (int base = wave * G; base < n_rows; base += waves_total * G) {
+      const int ri = base + sub;
+      int e0 = 0, m = 0;
+      if (ri < n_rows) {
+        e0 = rowptr[ri];
+        m = rowend[ri] - e0;
+      }
+      const bool shortrow = ri < n_rows && m <= SHORT_MAX;
+      const int ms = shortrow ? m : 0;
+      int my = 0;
+      if (sl < ms) my = translate(col[e0 + sl], ri);
+      int mmax = 0;  // wave-uniform trip count: the longest short row of the set
+#pragma unroll
+      for (int g = 0; g < G; ++g) mmax = max(mmax, __builtin_amdgcn_readlane(ms, g * LPR));
+      float4_t acc[VPL];
+#pragma unroll
+      for (int v = 0; v < VPL; ++v) acc[v] = zero4;
+      for (int e = 0; e < mmax; e += 4) {
+        const int ja = pick(my, e, true), jb = pick(my, e + 1, true), jc = pick(my, e + 2, true),
+                  jd = pick(my, e + 3, true);
+        const T* pa = row_of(ja);
+        const T* pb = row_of(jb);
+        const T* pc = row_of(jc);
+        const T* pd = row_of(jd);
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
           const int el = (v * LPR + sl) * 4;
           if (el < d) {
-            float4_t r = ((OP == GIGL_AGGR_MAX && m == 0) ? none4 : acc[v] / dv) +
-                         *reinterpret_cast<const float4_t*>(pr + el);
-            if (bias) r += *reinterpret_cast<const float4_t*>(bias + el);
-            if (act) r = float4_t{fmaxf(r.x, 0.f), fmaxf(r.y, 0.f), fmaxf(r.z, 0.f), fmaxf(r.w, 0.f)};
-            *reinterpret_cast<float4_t*>(o + el) = r;
+            float4_t a = e < ms ? RowLoader<T>::load4(pa, el) : zero4;
+            float4_t b = e + 1 < ms ? RowLoader<T>::load4(pb, el) : zero4;
+            float4_t c = e + 2 < ms ? RowLoader<T>::load4(pc, el) : zero4;
+            float4_t dd = e + 3 < ms ? RowLoader<T>::load4(pd, el) : zero4;
+            acc[v] = aggr_combine<OP>(acc[v], aggr_combine<OP>(aggr_combine<OP>(a, b), aggr_combine<OP>(c, dd)));
           }
         }
       }
-      continue;
-    }
-    const T* ps = row_of(self);
-    if (tiled_nkc) {  // the projection's operand layout: [row tile of 128][K chunk of 32][128 rows][32 floats]
-      float* tbase = out + ((int64_t)(i >> 7) * tiled_nkc) * 4096 + (i & 127) * 32;
-      if (sub == 0) {
+      if (shortrow) emit(ri, m, acc, true);
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-          const int el = (v * LPR + sl) * 4;
-          if (el < d)
-            *reinterpret_cast<float4_t*>(tbase + (int64_t)(el >> 5) * 4096 + (el & 31)) =
-                (OP == GIGL_AGGR_MAX && m == 0) ? none4 : acc[v] / dv;
-        }
-      }
-      for (int el = lane * 4; el < d; el += 64 * 4) {
-        const int k = d + el;
-        *reinterpret_cast<float4_t*>(tbase + (int64_t)(k >> 5) * 4096 + (k & 31)) = RowLoader<T>::load4(ps, el);
-      }
-      continue;
-    }
-    float* o = out + (int64_t)i * 2 * d;
-    if (sub == 0) {
-#pragma unroll
-      for (int v = 0; v < VPL; ++v) {
-        const int el = (v * LPR + sl) * 4;
-        if (el < d) *reinterpret_cast<float4_t*>(o + el) = (OP == GIGL_AGGR_MAX && m == 0) ? none4 : acc[v] / dv;
+      for (int g = 0; g < G; ++g) {
+        if (base + g >= n_rows) break;
+        if (__builtin_amdgcn_readlane(m, g * LPR) > SHORT_MAX) wave_row(base + g);
       }
     }
-    // self row copy, spread over all lanes of the wave
-    for (int el = lane * 4; el < d; el += 64 * 4)
-      *reinterpret_cast<float4_t*>(o + d + el) = RowLoader<T>::load4(ps, el);
   }
 }
 
@@ -547,12 +625,21 @@ __device__ __forceinline__ void split_store(const float4_t v, short* p1, short* 
   *reinterpret_cast<uint2*>(p3) = make_uint2((a3[0] >> 16) | a3[1], (a3[2] >> 16) | a3[3]);
 }
 
-template <int NJ, bool KVEC = true>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
+// SELF (the SAGE layer's [mean | self] operand without the self copy): the A operand has TWO sources — columns k <
+// d_mean come from the tiled buffer the gather wrote (a_tiled = its chunks per row tile, ceil(d_mean / 32)), columns
+// k >= d_mean are element k - d_mean of row self_ids[row] (or `row`) of `self_src` (fp32 rows self_ld apart: the
+// resident feature table through union.nodes for the first layer, the previous layer's output after it).  d_mean % 4
+// == 0, so a lane's 4-column segment lies wholly in one source; the K order, and with it every bit of the result, is
+// that of the single-source operand.
+template <int NJ, bool KVEC = true, bool SELF = false>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
 __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            const int32_t* __restrict__ m_dev, int K, int N, int act,
                                                            float* __restrict__ y, int a_tiled, int ldy,
-                                                           int64_t a_bstride, int64_t w_bstride) {
+                                                           int64_t a_bstride, int64_t w_bstride,
+                                                           const float* __restrict__ self_src = nullptr,
+                                                           const uint32_t* __restrict__ self_ids = nullptr,
+                                                           int d_mean = 0, int self_ld = 0) {
   // (grid.y = batch of independent products sharing M/K/N: operand b of a / w is a_bstride / w_bstride floats on, its
   // bias and its N output columns follow the previous batch's)
   a += blockIdx.y * a_bstride;
@@ -601,6 +688,14 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
   constexpr bool k_vec = KVEC;
   // operands of TWO chunks ahead stay in flight in registers (a chunk's MFMAs are shorter than a global load under load)
   float4_t ga[2][4], gw[2][2 * NJ];
+  const float* self_row[4] = {nullptr, nullptr, nullptr, nullptr};  // SELF: this thread's four rows of the self source
+  if constexpr (SELF) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0b + lr + 32 * i;
+      if (row < M) self_row[i] = self_src + (int64_t)(self_ids ? self_ids[row] : (uint32_t)row) * self_ld;
+    }
+  }
   auto gload = [&](int k0, float4_t (&da)[4], float4_t (&dw)[2 * NJ]) {
     const int kk = k0 + lc * 4;
     // (a_tiled: A is stored [row tile of 128][K chunk of 32][128][32] — this tile's chunk is 16 KB contiguous)
@@ -609,6 +704,9 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
     for (int i = 0; i < 4; ++i) {
       const int row = m0b + lr + 32 * i;
       const float* src = a_tiled ? at + (lr + 32 * i) * 32 : a + (int64_t)row * K + kk;
+      if constexpr (SELF) {
+        if (kk >= d_mean && row < M) src = self_row[i] + (kk - d_mean);
+      }
       if constexpr (k_vec) {
         da[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(src) : zero4;
       } else {  // K % 4 != 0: rows are not 16-byte aligned and the last segment is partial — element loads
@@ -2078,7 +2176,7 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
                       const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                       const int32_t* n_rows_dev, int64_t rows_cap, float* out, int op = GIGL_AGGR_MEAN,
                       const int32_t* n_local_dev = nullptr, int tiled_nkc = 0, const int32_t* global_map = nullptr,
-                      const T* src2 = nullptr, const T* src3 = nullptr) {
+                      const T* src2 = nullptr, const T* src3 = nullptr, int no_self = 0) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
@@ -2087,7 +2185,8 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
   const int vecs = d / 4;
 #define GLO(LPR, VPL, OP)                                                                            \
   hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, 0, st, src, d, gather_ids, rowptr, \
-                     rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc, global_map, src2, src3)
+                     rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc, global_map, src2, src3,   \
+                     (const float*)nullptr, (const float*)nullptr, 0, 0, no_self)
 #define GL(LPR, VPL)                                        \
   do {                                                      \
     if (op == GIGL_AGGR_MEAN) GLO(LPR, VPL, GIGL_AGGR_MEAN); \
@@ -2273,15 +2372,17 @@ int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dty
                                  const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                                  const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
                                  const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc,
-                                 const int32_t* global_map, const void* src2, const void* src3) {
+                                 const int32_t* global_map, const void* src2, const void* src3, int32_t no_self) {
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   if (src_dtype == GIGL_DTYPE_F32)
     return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
-                                aggr, n_local_rows_dev, tiled_nkc, global_map, (const float*)src2, (const float*)src3);
+                                aggr, n_local_rows_dev, tiled_nkc, global_map, (const float*)src2, (const float*)src3,
+                                no_self);
   return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
-                               aggr, n_local_rows_dev, tiled_nkc, global_map, (const __half*)src2, (const __half*)src3);
+                               aggr, n_local_rows_dev, tiled_nkc, global_map, (const __half*)src2, (const __half*)src3,
+                               no_self);
 }
 
 extern "C" {
@@ -2550,7 +2651,9 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
 // y rows may be a column slice of wider rows (ldy floats apart): the per-head projections of gigl_gat_input_layer
 static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias,
                                     const int32_t* m_dev, int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y,
-                                    int32_t ldy, int32_t batch = 1, int64_t a_bstride = 0, int64_t w_bstride = 0) {
+                                    int32_t ldy, int32_t batch = 1, int64_t a_bstride = 0, int64_t w_bstride = 0,
+                                    const float* self_src = nullptr, const uint32_t* self_ids = nullptr,
+                                    int32_t d_mean = 0, int32_t self_ld = 0) {
   GIGL_REQUIRE(ctx, a_tiled && w && m_dev && y && (k & 3) == 0 && n > 0 && ldy >= n * batch && batch >= 1,
                "bad arguments");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -2559,6 +2662,20 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
   gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
   const int nkc = (k + 31) / 32;
   const int64_t bm = (m_cap + 127) / 128;
+  if (self_src) {  // two-source operand: the tiled buffer holds the mean chunks only
+    GIGL_REQUIRE(ctx, batch == 1 && d_mean > 0 && (d_mean & 3) == 0 && d_mean < k && self_ld >= k - d_mean, "bad two-source operand");
+    const int nkc_mean = (d_mean + 31) / 32;
+    if (n > 64)
+      hipLaunchKernelGGL((linear_split_kernel<2, true, true>), dim3((unsigned)(bm * ((n + 127) / 128)), 1u), dim3(256), 0, st,
+                         a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0, self_src, self_ids,
+                         d_mean, self_ld);
+    else
+      hipLaunchKernelGGL((linear_split_kernel<1, true, true>), dim3((unsigned)(bm * ((n + 63) / 64)), 1u), dim3(256), 0, st,
+                         a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0, self_src, self_ids,
+                         d_mean, self_ld);
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    return GIGL_OK;
+  }
   if (n > 64)
     hipLaunchKernelGGL((linear_split_kernel<2>), dim3((unsigned)(bm * ((n + 127) / 128)), (unsigned)batch), dim3(256), 0,
                        st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
@@ -2597,9 +2714,11 @@ int32_t gigl_linear_batched(gigl_ctx* ctx, const float* a, const float* w, const
 }
 
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
-                          int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y) {
+                          int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y, const float* self_src,
+                          const uint32_t* self_ids, int32_t d_mean, int32_t self_ld) {
   if (!ctx) return GIGL_E_INVALID_ARG;
-  return linear_tiled_strided(ctx, a_tiled, w, bias, m_dev, m_cap, k, n, act, y, n);
+  return linear_tiled_strided(ctx, a_tiled, w, bias, m_dev, m_cap, k, n, act, y, n, 1, 0, 0, self_src, self_ids, d_mean,
+                              self_ld);
 }
 
 int64_t gigl_gat_input_layer_scratch(int32_t d, int32_t heads, int64_t cap_nodes, int64_t rows_cap, int64_t cap_edges) {

@@ -102,7 +102,9 @@ int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dty
                                  const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
                                  const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc = 0,
                                  const int32_t* global_map = nullptr, const void* src2 = nullptr,
-                                 const void* src3 = nullptr);
+                                 const void* src3 = nullptr, int32_t no_self = 0);
+// no_self (tiled layout): only the reduced half is written, tiled_nkc = ceil(d / 32) chunks per row tile; the
+// projection then takes the self half from the source rows (gigl_linear_tiled with self_src)
 // global_map: the rows i >= *n_local_rows_dev hold GLOBAL ids whose row in `src` is global_map[id] (the sharded plan's
 // receive buffer, dist.hip); a NEGATIVE row index -1-h (from gather_ids or global_map) is row h of `src2` (replicated
 // hot rows) when h < 2^30, else row h - 2^30 of `src3` (the rank's own feature table)
@@ -115,7 +117,10 @@ int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float
 // tiled_nkc > 0: `out` is written in the projection's tiled operand layout ([row tile of 128][K chunk of 32][128 rows]
 // [32 floats], tiled_nkc = ceil(2d / 32); capacity: whole row tiles) and read by gigl_linear_tiled (agg.hip)
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
-                          int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y);
+                          int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y, const float* self_src = nullptr,
+                          const uint32_t* self_ids = nullptr, int32_t d_mean = 0, int32_t self_ld = 0);
+// self_src != NULL: two-source operand — columns k >= d_mean are element k - d_mean of row self_ids[row] (or row) of
+// self_src (fp32 rows, self_ld floats apart); a_tiled then holds ceil(d_mean / 32) chunks per row tile
 
 static inline int64_t gigl_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 

@@ -64,6 +64,7 @@ struct gigl_sage_plan {
   // the aggregated matrix in the projection's tiled layout ([row tile of 128][K chunk of 32][128][32]): a tile's chunk
   // is 16 KB contiguous instead of 128 pieces of 128 B at a stride of one row (agg.hip)
   bool tiled = false;
+  bool two_source = false;  // the projection takes the self half of [mean | self] from the source rows (no self copy)
   float* hbuf[2] = {nullptr, nullptr};  // ping-pong [act_rows][max_out]
   std::vector<void*> owned;
   // hipGraph replay
@@ -243,16 +244,20 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
         p->aggr, p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr, p->bias[0],
         act, p->hbuf[0]);
   }
-  const int32_t nkc = p->tiled ? (2 * d + 31) / 32 : 0;
+  // two-source operand: the projection reads the self half from the fp32 source rows themselves (the feature table
+  // through union.nodes, or the previous layer's output), the gather writes the reduced half only
+  const bool two_src = p->tiled && p->two_source && (l > 0 || p->feat->dtype == GIGL_DTYPE_F32);
+  const int32_t nkc = p->tiled ? ((two_src ? d : 2 * d) + 31) / 32 : 0;
   if (((s - 2) & 1) == 0) {
     if (p->tiled) {
       if (l == 0)  // (leaf-global: rows of level L-1 — >= the count through level L-2 — hold global source ids)
         return gigl_gather_reduce_mixed(
             ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend, p->un.col, n_rows, rows_cap,
             p->aggr, p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr,
-            p->abuf, nkc);
+            p->abuf, nkc, nullptr, nullptr, nullptr, two_src ? 1 : 0);
       return gigl_gather_reduce_mixed(ctx, p->hbuf[(l - 1) & 1], GIGL_DTYPE_F32, d, nullptr, p->un.rowptr, p->un.rowend,
-                                      p->un.col, n_rows, rows_cap, p->aggr, nullptr, p->abuf, nkc);
+                                      p->un.col, n_rows, rows_cap, p->aggr, nullptr, p->abuf, nkc, nullptr, nullptr, nullptr,
+                                      two_src ? 1 : 0);
     }
     if (l == 0 && p->leaf_global)  // rows of level L-1 (>= the count through level L-2) hold global source ids
       return gigl_gather_reduce_mixed(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend,
@@ -265,6 +270,10 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
                               p->un.col, n_rows, rows_cap, p->aggr, p->abuf);
   }
   const int act = (l < L - 1 || p->act_last) ? 1 : 0;
+  if (two_src)
+    return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
+                             p->hbuf[l & 1], l == 0 ? (const float*)p->feat->rows : p->hbuf[(l - 1) & 1],
+                             l == 0 ? p->un.nodes : nullptr, d, d);
   if (p->tiled)
     return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
                              p->hbuf[l & 1]);
@@ -433,6 +442,7 @@ static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, in
     width *= fanouts[k];
   }
   p->tiled = getenv("GIGL_PLAN_ROW_MAJOR") == nullptr;  // (A/B knob)
+  p->two_source = getenv("GIGL_PLAN_SELF_COPY") == nullptr;  // (A/B knob: set = gather writes [mean | self])
   for (int k = 0; k < hops; ++k)
     if ((dims[k] & 3) != 0 || dims[k] > 2048) p->tiled = false;
   if (with_abuf) {

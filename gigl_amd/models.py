@@ -290,8 +290,10 @@ class GraphSAGE(nn.Module):
         ogbn-products' 100 fp32 -> 256"""
         from ._lib import DTYPE_F32
         esz = 4 if eng.feat_dtype == DTYPE_F32 else 2
+        # (a table of a few thousand rows is projected in microseconds of kernel time but milliseconds of fixed
+        # overhead — workspace allocation, synchronisation — which a pass of a handful of batches cannot amortise)
         return (self._plain and self.aggr in ("mean", "sum") and self.feats_interaction is None
-                and self.feature_embedding_layer is None
+                and self.feature_embedding_layer is None and eng.n_nodes >= (1 << 16)
                 and self.conv_layers[0].out_channels * 4 < self.conv_layers[0].in_channels * esz)
 
     def make_plan(self, eng: HipEngine, b: int, fanouts: Sequence[int], groups: int = 1):
