@@ -268,6 +268,11 @@ def main():
                          "gigl_sage_plan_set_projected_input): auto = when projected rows are narrower than stored rows "
                          "(mag-shard: 768 fp16 -> 256 fp32; not products).  The precompute is timed and charged to "
                          "every step as 1 / (steps of a full inference pass = N / B) of its duration")
+    ap.add_argument("--train", action="store_true",
+                    help="training step instead of the inference step: a batch sampled in HBM (sample + union graph), "
+                         "GraphSAGE forward with autograd over the union graph, cross-entropy on the roots, backward "
+                         "(gigl_gather_reduce_backward + the projections' backward GEMMs) and the Adam update — the loop of "
+                         "NodeClassificationModelingTaskSpec._train; a secondary line with its own roofline / cpu_baseline")
     ap.add_argument("--entry", type=str, default="plan", choices=["plan", "inferencer"],
                     help="plan = the library's one-call plan driven by this script (the headline); inferencer = the same "
                          "workload through the drop-in entry point's own loop (gigl_amd.inferencer.Inferencer."
@@ -299,6 +304,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
+    if args.train:
+        return run_train(args, rank, world, local_rank)
     if args.entry == "inferencer":
         return run_entry_inferencer(args, rank, world, local_rank)
     if args.workload == "mag240m-sharded":
@@ -994,6 +1001,214 @@ def run_sharded(args, rank, world, local_rank, sub=False):
         dist.destroy_process_group()
     eng.close()
     return line
+
+
+def run_train(args, rank, world, local_rank):
+    """--train: one TRAINING step per batch on the in-HBM route (gigl_amd/hbm.py, what Trainer.run drives): k-hop sample
+    + batch union graph in HBM, GraphSAGE forward with autograd over the union graph (trimmed schedule), cross-entropy
+    on the root rows, backward (scatter of the layer-1 input gradient by gigl_gather_reduce_backward: fp32 atomics; the
+    projections' backward products) and the Adam update (lr 0.01, weight decay 5e-4: the reference spec's defaults,
+    node_classification_modeling_task_spec.py:51-57,134-173).  One batch per step, one stream, launches eager (autograd
+    drives them from Python).  Edges are counted like the inference line (sampled + the edges the FORWARD reductions
+    consume); the backward scatter's edges are reported next to them."""
+    import torch.nn.functional as F
+    from gigl_amd._lib import GIGL_META_LEVEL0, KERNEL_IDS, MODE_FAST, MODE_SPARK_HASH
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.hbm import ResidentGraph
+    from gigl_amd.models import GraphSAGE
+
+    torch.cuda.set_device(local_rank)
+    eng = HipEngine(local_rank)
+    dev = eng.device
+    fanouts = [int(v) for v in args.fanouts.split(",")]
+    L = len(fanouts)
+    B, K, W = args.batch, max(64, args.steps), max(8, args.warmup)
+    t0 = time.time()
+    n, d = build_workload(eng, args)
+    wl_name, wl_label, hid, out_dim, wl_directed, wl_dtype = args._workload
+    esz = 4 if wl_dtype == torch.float32 else 2
+    torch.manual_seed(0)
+    model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    model.train()
+    mode = MODE_SPARK_HASH if args.mode == "parity" else MODE_FAST
+    st = torch.cuda.Stream(device=dev)
+    eng.bind_stream(st)
+    resident = ResidentGraph.from_engine(eng, np.arange(n, dtype=np.int64), fanouts, mode=mode)
+    gp = torch.Generator(device="cpu")
+    gp.manual_seed(42)
+    pool = W + K
+    perm = torch.randperm(n, generator=gp)
+    if perm.numel() < pool * world * B:
+        perm = perm.repeat((pool * world * B + perm.numel() - 1) // perm.numel())
+    my = perm[: pool * world * B].view(pool * world, B)[rank::world].to(torch.int32).to(dev).contiguous()
+    labels = torch.randint(0, out_dim, (n,), generator=gp).to(dev)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+    counts = torch.zeros(3, dtype=torch.int64, device=dev)  # sampled, forward-aggregated, backward-scattered edges
+
+    def step(i, count=False):
+        with torch.cuda.stream(st):
+            roots = my[i]
+            hb = resident.hip_batch(roots, train=True)
+            out = model(hb)
+            loss = F.cross_entropy(out[hb.root_local.long()], labels[roots.long() & 0xFFFFFFFF])
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            if count:
+                u = hb.union
+                rowlen = (u.rowend - u.rowptr).to(torch.int64)
+                ar = torch.arange(rowlen.numel(), device=dev)
+                per_layer = [(rowlen * (ar < u.meta[GIGL_META_LEVEL0 + (L - 1 - l)])).sum() for l in range(L)]
+                counts.add_(torch.stack([sum(c.sum() for c in hb.tree.cnt).to(torch.int64), sum(per_layer),
+                                         sum(per_layer[1:]) if L > 1 else per_layer[0] * 0]))
+        return loss
+
+    for i in range(W):
+        step(i)
+    st.synchronize()
+    if args.timed_only:  # counter-collection runs
+        t1 = time.perf_counter()
+        for i in range(W, W + K):
+            step(i)
+        st.synchronize()
+        print(json.dumps({"timed_only": True, "train": True, "steps": K, "workload": wl_name, "batches_per_call": 1,
+                          "streams": 1, "ms_per_step": (time.perf_counter() - t1) / K * 1e3}))
+        eng.close()
+        return
+    # ---- untimed: exact counts of the timed batches, then every library kernel group's own time (HIP events)
+    for i in range(W, W + K):
+        step(i, count=True)
+    st.synchronize()
+    cnt = counts.cpu().numpy().astype(np.float64)
+    names = list(KERNEL_IDS)
+    P = min(K, 64)
+    eng.profile_enable(names, capacity=P * 64)
+    for i in range(W, W + P):
+        step(i)
+    st.synchronize()
+    prof = {k: eng.profile_read(k) for k in names}
+    eng.profile_enable([], 0)
+    # ---- timed region
+    reps = []
+    t_all = time.perf_counter()
+    while time.perf_counter() - t_all < args.min_seconds or len(reps) < 3:
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(W, W + K):
+            step(i)
+        torch.cuda.synchronize()
+        reps.append(time.perf_counter() - t1)
+    rep_np = np.array(reps)
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor(rep_np, dtype=torch.float64, device=dev)
+        all_reduce(tt, dist.ReduceOp.MAX)
+        rep_np = tt.cpu().numpy()
+    elapsed, steps_total = float(rep_np.sum()), K * len(rep_np)
+    sampled, agg, bwd = cnt[0] / K, cnt[1] / K, cnt[2] / K  # per step (this rank)
+    # ---- rooflines of the library kernels (single stream: the intervals are the kernels' own)
+    dims = [d] + [hid] * (L - 1)
+    by_kernel = {}
+    for k, (ms, nl) in prof.items():
+        if ms <= 0:
+            continue
+        e = {"ms_per_step": round(ms / P, 5), "launches_per_step": nl / P}
+        if k == "gather_bwd":  # per scattered edge: 4 B index + D*4 read-modify-write (atomic) + the row's gradient read
+            by = bwd * (4 + 2 * hid * 4) + B * (8 + 3 * hid * 4)
+            e.update(bound="hbm", achieved=round(by / (ms / P * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                     frac=round(by / (ms / P * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), alg_bytes_per_step=by)
+        by_kernel[k] = e
+    lib_ms = sum(v[0] for v in prof.values()) / P
+    step_ms = elapsed / steps_total * 1e3
+    dominant = max(prof, key=lambda k: prof[k][0])
+    flops_fwd = sum(2.0 * (B * sum(int(np.prod(fanouts[:j])) for j in range(L - l))) * 2 * dims[l] *
+                    (hid if l < L - 1 else out_dim) for l in range(L))  # (row CAPACITIES: an upper bound)
+    roofline = {"bound": by_kernel.get(dominant, {}).get("bound", "latency"), "kernel": dominant,
+                "achieved": by_kernel.get(dominant, {}).get("achieved"), "peak": by_kernel.get(dominant, {}).get("peak"),
+                "unit": by_kernel.get(dominant, {}).get("unit"), "frac": by_kernel.get(dominant, {}).get("frac"),
+                "traffic": None, "dominant": dominant,
+                "library_kernel_ms_per_step": round(lib_ms, 5), "step_ms": round(step_ms, 5),
+                "library_kernel_share_of_step": round(lib_ms / step_ms, 4),
+                "note": "one batch per step, launches driven by torch autograd from Python on one stream: the step is "
+                        "bound by launch / host overhead between kernels, not by a kernel (library_kernel_share_of_step); "
+                        "the backward scatter (gather_bwd, fp32 atomics) has its own HBM line in by_kernel",
+                "by_kernel": by_kernel}
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_train_baseline(eng, model, my, labels, fanouts, W, out_dim)
+    if rank == 0:
+        q = lambda a, p: float(np.percentile(a, p))
+        ms_rep = rep_np / K * 1e3
+        line = {
+            "metric": "sampled+aggregated edges/s", "value": (sampled + agg) * world * steps_total / elapsed,
+            "unit": "edges/s", "n_gpus": world, "steps": steps_total, "warmup": W, "ms_per_step": step_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "timing": {"repetitions": len(rep_np), "steps_per_repetition": K, "timed_region_s": round(elapsed, 3),
+                       "ms_per_step_median": q(ms_rep, 50), "ms_per_step_p10": q(ms_rep, 10), "ms_per_step_p90": q(ms_rep, 90)},
+            "config": {"workload": wl_label + f" N={n} E={eng.n_edges} D={d} {'fp32' if esz == 4 else 'fp16'} features, "
+                                            f"fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}: TRAINING step "
+                                            "(sample + union in HBM, forward with autograd, cross-entropy, backward, Adam), "
+                                            "sampler mode=" + args.mode,
+                       "entry": "ResidentGraph.hip_batch(train=True) -> GraphSAGE._forward_union_autograd (gigl_amd/hbm.py: "
+                                "the route Trainer.run takes)",
+                       "sampled_edges_per_step": sampled, "aggregated_edges_per_step": agg,
+                       "backward_scattered_edges_per_step": bwd, "setup_s": round(setup_s, 1)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_cpu_train_baseline(eng, model, my, labels, fanouts, W, out_dim):
+    """the CPU port of the training step on one host core: oracle sampler + collate (C), fp32 torch forward over the WHOLE
+    union graph with autograd (the reference's execution order), cross-entropy on the roots, backward, Adam — full
+    batches of the same B roots; counted in the GPU line's unit (sampled + trimmed forward-aggregated edges)"""
+    import torch.nn.functional as F
+
+    import oracle
+    from oracle import gnn_ref
+    rowptr, col = eng.graph_to_host()
+    L, B = len(fanouts), int(my.shape[1])
+    params = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    opt = torch.optim.Adam(list(params.values()), lr=0.01, weight_decay=5e-4)
+    lab = labels.cpu()
+    torch.set_num_threads(1)
+    budget_s, t_used, edges, batches = 20.0, 0.0, 0, 0
+    i = W
+    while t_used < budget_s and batches < 64:
+        roots = my[i % my.shape[0]].cpu().numpy().view(np.uint32)
+        t0 = time.perf_counter()
+        nbr, cnt = oracle.sample_khop(rowptr, col, roots, fanouts, canonical=True)
+        u = oracle.union_build(roots, fanouts, nbr)
+        ei = gnn_ref.union_edge_index(u["rowptr"], u["col"])
+        t_used += time.perf_counter() - t0
+        ids = torch.from_numpy(u["nodes"].astype(np.int64)).to(torch.int32).to(eng.device)
+        xs = eng.gather_rows(ids, torch.tensor([ids.numel()], dtype=torch.int32, device=eng.device), int(ids.numel())).cpu()
+        t0 = time.perf_counter()
+        out = gnn_ref.graphsage_forward(xs, ei, params, L)
+        loss = F.cross_entropy(out[torch.from_numpy(u["root_local"].astype(np.int64))],
+                               lab[torch.from_numpy(roots.astype(np.int64))])
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        t_used += time.perf_counter() - t0
+        meta, rp = u["meta"], u["rowptr"].astype(np.int64)
+        edges += int(sum(int(c.sum()) for c in cnt)) + sum(int(rp[int(meta[2 + (L - 1 - l)])]) for l in range(L))
+        batches += 1
+        i += 1
+    return {"value": edges / t_used, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"{batches} full training batches of {B} roots of the same graph / fanout, {t_used:.1f} s: oracle "
+                      "sampler + collate (oracle/gigl_oracle.c, 1 thread), fp32 torch CPU forward over the whole union graph "
+                      "with autograd, cross-entropy, backward, Adam (1 thread); edges in the GPU line's unit"}
 
 
 def run_entry_inferencer(args, rank, world, local_rank):

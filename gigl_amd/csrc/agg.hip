@@ -288,17 +288,22 @@ __global__ __launch_bounds__(256) void gather_mean_backward_kernel(const float* 
                                                                    const int32_t* __restrict__ col,
                                                                    const int32_t* __restrict__ n_rows_dev,
                                                                    float* __restrict__ dsrc, int op,
-                                                                   const float* __restrict__ src) {
+                                                                   const float* __restrict__ src, int wpr) {
+  // wpr waves share a destination row (a power of two): wave q of the row takes the edges q, q + wpr, ... — a training
+  // batch has ~10^3 rows at its last layer, a wave per row leaves most of the GPU idle behind 25 serial edges
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int part = gw & (wpr - 1);
   const int n_rows = *n_rows_dev;
-  const int waves_total = (gridDim.x * blockDim.x) >> 6;
-  for (int i = wave; i < n_rows; i += waves_total) {
+  const int rows_step = ((gridDim.x * blockDim.x) >> 6) / wpr;
+  for (int i = gw / wpr; i < n_rows; i += rows_step) {
     const int e0 = rowptr[i], m = rowend[i] - e0;
     const float* g = dout + (int64_t)i * 2 * d;
-    for (int el = lane; el < d; el += 64) atomicAdd(&dsrc[(int64_t)i * d + el], g[d + el]);
+    if (part == 0)
+      for (int el = lane; el < d; el += 64) atomicAdd(&dsrc[(int64_t)i * d + el], g[d + el]);
     if (m == 0) continue;
     if (op == GIGL_AGGR_MAX) {
+      if (part != 0) continue;  // (ties need the whole row)
       for (int el = lane; el < d; el += 64) {
         float mx = -__builtin_inff();
         for (int e = 0; e < m; ++e) mx = fmaxf(mx, src[(int64_t)col[e0 + e] * d + el]);
@@ -313,7 +318,29 @@ __global__ __launch_bounds__(256) void gather_mean_backward_kernel(const float* 
       continue;
     }
     const float inv = op == GIGL_AGGR_MEAN ? 1.0f / (float)m : 1.0f;
-    for (int e = 0; e < m; ++e) {
+    if ((d & 3) == 0 && d <= 1024) {  // the row's gradient stays in registers: float4 per lane, 4 atomics per edge
+      float4_t gv[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int el = (v * 64 + lane) * 4;
+        gv[v] = el < d ? *reinterpret_cast<const float4_t*>(g + el) * inv : float4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      for (int e = part; e < m; e += wpr) {
+        float* t = dsrc + (int64_t)col[e0 + e] * d;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int el = (v * 64 + lane) * 4;
+          if (el < d) {
+            atomicAdd(t + el, gv[v].x);
+            atomicAdd(t + el + 1, gv[v].y);
+            atomicAdd(t + el + 2, gv[v].z);
+            atomicAdd(t + el + 3, gv[v].w);
+          }
+        }
+      }
+      continue;
+    }
+    for (int e = part; e < m; e += wpr) {
       const int j = col[e0 + e];
       for (int el = lane; el < d; el += 64) atomicAdd(&dsrc[(int64_t)j * d + el], g[el] * inv);
     }
@@ -2563,10 +2590,12 @@ int32_t gigl_gather_mean_backward(gigl_ctx* ctx, const float* dout, int32_t d, c
   GIGL_REQUIRE(ctx, d > 0 && rows_cap >= 0, "bad sizes");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
-  int64_t blocks = (rows_cap + 3) / 4;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_BWD);
+  const int wpr = rows_cap >= 32768 ? 1 : (rows_cap >= 8192 ? 2 : (rows_cap >= 2048 ? 4 : 8));
+  int64_t blocks = (rows_cap * wpr + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(gather_mean_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dout, d,
-                     rowptr, rowend, col, n_rows_dev, dsrc, GIGL_AGGR_MEAN, (const float*)nullptr);
+                     rowptr, rowend, col, n_rows_dev, dsrc, GIGL_AGGR_MEAN, (const float*)nullptr, wpr);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
@@ -2581,10 +2610,12 @@ int32_t gigl_gather_reduce_backward(gigl_ctx* ctx, const float* dout, int32_t d,
   GIGL_REQUIRE(ctx, aggr != GIGL_AGGR_MAX || src, "max needs the forward's source matrix");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
-  int64_t blocks = (rows_cap + 3) / 4;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_BWD);
+  const int wpr = rows_cap >= 32768 ? 1 : (rows_cap >= 8192 ? 2 : (rows_cap >= 2048 ? 4 : 8));
+  int64_t blocks = (rows_cap * wpr + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(gather_mean_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dout, d,
-                     rowptr, rowend, col, n_rows_dev, dsrc, aggr, src);
+                     rowptr, rowend, col, n_rows_dev, dsrc, aggr, src, wpr);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

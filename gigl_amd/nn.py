@@ -112,9 +112,10 @@ class _SageConvFn(torch.autograd.Function):
         if ctx.act == 1:
             dy = dy * (y > 0).to(dy.dtype)
         dev = dy.device
-        # dW[N, 2d] = dy^T[N, n] @ a[n, 2d]  ->  linear(a = dy^T, w = a^T)
-        n_out = dev_i32(dev, dy.shape[1])
-        dw = eng.linear(dy.t().contiguous(), a.t().contiguous(), None, n_out, int(dy.shape[1]), 0)
+        # dW[N, 2d] = dy^T[N, n] @ a[n, 2d]: a small output with the ROWS as its inner dimension — a plain dense GEMM
+        # that wants split-K; it goes to the library (rocBLAS through torch, as the reference's autograd does), not to
+        # the row-tiled projection kernel, which would put the whole inner dimension on a handful of workgroups
+        dw = torch.mm(dy.t(), a)
         dh = None
         if ctx.needs_input_grad[0]:
             # da[n, 2d] = dy[n, N] @ wcat[N, 2d]  ->  linear(a = dy, w = wcat^T)

@@ -97,7 +97,8 @@ int32_t gigl_memcpy(gigl_ctx* ctx, void* dst, int32_t dst_loc, const void* src, 
 #define GIGL_K_UNION_CSR 7     /* unique + scan + col/rowptr */
 #define GIGL_K_GATHER_MEAN 8
 #define GIGL_K_LINEAR 9
-#define GIGL_K_COUNT 10
+#define GIGL_K_GATHER_BWD 10   /* gigl_gather_reduce_backward (scatter of the layer's input gradient: fp32 atomics) */
+#define GIGL_K_COUNT 11
 int32_t gigl_profile_enable(gigl_ctx* ctx, uint32_t mask, int32_t capacity);
 int32_t gigl_profile_read(gigl_ctx* ctx, int32_t kernel_id, double* total_ms, int64_t* launches);
 int32_t gigl_profile_reset(gigl_ctx* ctx);
