@@ -1,5 +1,7 @@
-"""GPU parity of the device-side record encoder (gigl_records_encode) against the host codec gigl_amd/wire.py,
-which tests/test_wire.py pins byte-for-byte on the reference's own fixture TFRecords.
+"""GPU parity of the device-side record encoder (gigl_records_encode) against oracle/records.py — the CPU restatement
+of the sampler job's output stage (per-root assembly, proto3 encoding, TFRecord framing), which
+tests/test_oracle_records.py pins byte for byte on the reference's own sampler output files.  (gigl_amd/wire.py appears
+here only as a PARSER of the device's bytes; the expected bytes never come from product code.)
 
 Bar: bit-exact (bytes of every TFRecord frame, including both masked CRC-32C words)."""
 import os
@@ -10,8 +12,8 @@ import torch
 
 import oracle
 from gigl_amd import _lib, wire
-from gigl_amd.sampler_service import build_rooted_node_neighborhood, tree_to_edge_lists
 from helpers import load_fixture_graph, rmat_edges
+from oracle import records as R
 
 pytestmark = pytest.mark.gpu
 
@@ -28,13 +30,11 @@ def _engine(n, src, dst, feats, directed=False):
 
 def _host_rnn_frames(roots, fanouts, nbr, feats, node_type=0, edge_type=0, suffixes=None, emit=None):
     frames = []
-    for i, (r, (s, d)) in enumerate(zip(roots.tolist(), tree_to_edge_lists(roots, fanouts, nbr))):
+    for i, (r, (s, d)) in enumerate(zip(roots.tolist(), R.tree_edges(roots, fanouts, nbr))):
         if emit is not None and not emit[i]:
             continue
-        rnn = build_rooted_node_neighborhood(r, s, d, feats, condensed_node_type=node_type,
-                                             condensed_edge_type=edge_type)
-        payload = rnn.SerializeToString() + (suffixes[i] if suffixes is not None else b"")
-        frames.append(wire.tfrecord_frame(payload))
+        frames.append(R.tfrecord_frame(R.rooted_node_neighborhood_record(
+            r, s, d, feats, node_type, edge_type, suffix=suffixes[i] if suffixes is not None else b"")))
     return frames
 
 
@@ -99,8 +99,8 @@ def test_supervised_samples_with_label_suffix_and_emit_mask(golden_dir):
     roots = np.arange(n, dtype=np.uint32)
     fanouts = [3, 3]
     tree = eng.sample_khop(roots, fanouts)
-    labels = [wire.Label(label_type="node_label", label=int(i % 5) - 1) for i in range(n)]  # incl. 0 and negative
-    sfx = [b"" if i % 4 == 3 else wire._len_delim(3, lb.SerializeToString()) for i, lb in enumerate(labels)]
+    labels = [R.encode_label("node_label", int(i % 5) - 1) for i in range(n)]  # incl. 0 and negative
+    sfx = [b"" if i % 4 == 3 else R._ld(3, lb) for i, lb in enumerate(labels)]
     emit = np.array([1 if (i % 4 != 3 and i not in (14, 15)) else 0 for i in range(n)], dtype=np.uint8)
     off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum([len(s) for s in sfx], out=off[1:])
@@ -136,27 +136,14 @@ def test_link_prediction_samples_match_host_assembly():
     buf, off = eng.encode_records(tree, kind=_lib.REC_NODE_ANCHOR_LINK_PRED, trees_per_record=1 + P,
                                   emit=(cnt > 0).to(torch.uint8))
     nbr = [t.cpu().numpy().view(np.uint32) for t in tree.nbr]
-    lists = tree_to_edge_lists(all_roots, fanouts, nbr)
+    lists = R.tree_edges(all_roots, fanouts, nbr)
     want = []
     for i, r in enumerate(roots.tolist()):
         if cnt_h[i] == 0:
             continue
-        base = build_rooted_node_neighborhood(r, *lists[i * (1 + P)], feats)
-        nodes = {nd.node_id: nd for nd in base.neighborhood.nodes}
-        edges = {(e.src_node_id, e.dst_node_id): e for e in base.neighborhood.edges}
-        pos_edges = []
-        for j in range(int(cnt_h[i])):
-            p = int(pos_h[i, j])
-            pos_edges.append(wire.Edge(src_node_id=r, dst_node_id=p, condensed_edge_type=0))
-            pr = build_rooted_node_neighborhood(p, *lists[i * (1 + P) + 1 + j], feats)
-            for nd in pr.neighborhood.nodes:
-                nodes.setdefault(nd.node_id, nd)
-            for e in pr.neighborhood.edges:
-                edges.setdefault((e.src_node_id, e.dst_node_id), e)
-        msg = wire.NodeAnchorBasedLinkPredictionSample(
-            root_node=base.root_node, pos_edges=pos_edges,
-            neighborhood=wire.Graph(nodes=list(nodes.values()), edges=list(edges.values())))
-        want.append(wire.tfrecord_frame(msg.SerializeToString()))
+        c = int(cnt_h[i])
+        want.append(R.tfrecord_frame(R.nablp_sample_record(
+            r, [lists[i * (1 + P) + k] for k in range(1 + c)], pos_h[i, :c].tolist(), c, feats)))
     got = [g for g in _split(buf, off) if g]
     assert len(got) == len(want) and len(want) > 10
     for i, (g, w) in enumerate(zip(got, want)):
@@ -192,9 +179,8 @@ def test_rnn_records_with_edge_features(de, d, fanouts):
     buf, off = eng.encode_records(tree, with_features=d > 0)
     nbr = [t.cpu().numpy().view(np.uint32) for t in tree.nbr]
     want = []
-    for r, (s_, d_) in zip(roots.tolist(), tree_to_edge_lists(roots, fanouts, nbr)):
-        rnn = build_rooted_node_neighborhood(r, s_, d_, feats, edge_features=f)
-        want.append(wire.tfrecord_frame(rnn.SerializeToString()))
+    for r, (s_, d_) in zip(roots.tolist(), R.tree_edges(roots, fanouts, nbr)):
+        want.append(R.tfrecord_frame(R.rooted_node_neighborhood_record(r, s_, d_, feats, edge_features=f)))
     got = _split(buf, off)
     for i, (g, w) in enumerate(zip(got, want)):
         assert g == w, f"record {i} differs"
@@ -230,27 +216,14 @@ def test_link_prediction_samples_with_edge_features():
     buf, off = eng.encode_records(tree, kind=_lib.REC_NODE_ANCHOR_LINK_PRED, trees_per_record=1 + P,
                                   emit=(cnt > 0).to(torch.uint8))
     nbr = [t.cpu().numpy().view(np.uint32) for t in tree.nbr]
-    lists = tree_to_edge_lists(all_roots, fanouts, nbr)
+    lists = R.tree_edges(all_roots, fanouts, nbr)
     want = []
     for i, r in enumerate(roots.tolist()):
         if cnt_h[i] == 0:
             continue
-        base = build_rooted_node_neighborhood(r, *lists[i * (1 + P)], feats, edge_features=f)
-        nodes = {nd.node_id: nd for nd in base.neighborhood.nodes}
-        edges = {(e.src_node_id, e.dst_node_id): e for e in base.neighborhood.edges}
-        pos_edges = []
-        for j in range(int(cnt_h[i])):
-            p = int(pos_h[i, j])
-            pos_edges.append(wire.Edge(src_node_id=r, dst_node_id=p, condensed_edge_type=0, feature_values=f(r, p)))
-            pr = build_rooted_node_neighborhood(p, *lists[i * (1 + P) + 1 + j], feats, edge_features=f)
-            for nd in pr.neighborhood.nodes:
-                nodes.setdefault(nd.node_id, nd)
-            for e in pr.neighborhood.edges:
-                edges.setdefault((e.src_node_id, e.dst_node_id), e)
-        msg = wire.NodeAnchorBasedLinkPredictionSample(
-            root_node=base.root_node, pos_edges=pos_edges,
-            neighborhood=wire.Graph(nodes=list(nodes.values()), edges=list(edges.values())))
-        want.append(wire.tfrecord_frame(msg.SerializeToString()))
+        c = int(cnt_h[i])
+        want.append(R.tfrecord_frame(R.nablp_sample_record(
+            r, [lists[i * (1 + P) + k] for k in range(1 + c)], pos_h[i, :c].tolist(), c, feats, edge_features=f)))
     got = [g for g in _split(buf, off) if g]
     assert len(got) == len(want) and len(want) > 10
     for i, (g, w) in enumerate(zip(got, want)):
@@ -301,32 +274,17 @@ def test_user_defined_label_samples_match_host_assembly():
                                   emit=(pcnt > 0).to(torch.uint8), n_neg_trees=Q, pos_label_edges="pos",
                                   neg_label_edges="neg")
     nbr = [t.cpu().numpy().view(np.uint32) for t in tree.nbr]
-    lists = tree_to_edge_lists(all_roots, fanouts, nbr)
+    lists = R.tree_edges(all_roots, fanouts, nbr)
     want = []
     for i, r in enumerate(roots.tolist()):
         if pc[i] == 0:
             continue
-        base = build_rooted_node_neighborhood(r, *lists[i * T], feats, edge_features=f_main)
-        nodes = {nd_.node_id: nd_ for nd_ in base.neighborhood.nodes}
-        edges = {(e.src_node_id, e.dst_node_id): e for e in base.neighborhood.edges}
-        pos_edges, neg_edges = [], []
-        for j in range(P + Q):
-            is_neg = j >= P
-            if (j - P if is_neg else j) >= (nc[i] if is_neg else pc[i]):
-                continue
-            t = int(neg_h[i, j - P] if is_neg else pos_h[i, j])
-            (neg_edges if is_neg else pos_edges).append(wire.Edge(
-                src_node_id=r, dst_node_id=t, condensed_edge_type=0,
-                feature_values=(neg_feat if is_neg else pos_feat)[(r, t)]))
-            tr = build_rooted_node_neighborhood(t, *lists[i * T + 1 + j], feats, edge_features=f_main)
-            for nd_ in tr.neighborhood.nodes:
-                nodes.setdefault(nd_.node_id, nd_)
-            for e in tr.neighborhood.edges:
-                edges.setdefault((e.src_node_id, e.dst_node_id), e)
-        msg = wire.NodeAnchorBasedLinkPredictionSample(
-            root_node=base.root_node, pos_edges=pos_edges, hard_neg_edges=neg_edges,
-            neighborhood=wire.Graph(nodes=list(nodes.values()), edges=list(edges.values())))
-        want.append(wire.tfrecord_frame(msg.SerializeToString()))
+        np_, nn_ = int(pc[i]), int(nc[i])
+        trees = [lists[i * T]] + [lists[i * T + 1 + j] for j in range(np_)] + [lists[i * T + 1 + P + j] for j in range(nn_)]
+        targets = pos_h[i, :np_].tolist() + neg_h[i, :nn_].tolist()
+        want.append(R.tfrecord_frame(R.nablp_sample_record(
+            r, trees, targets, np_, feats, edge_features=f_main, pos_edge_features=lambda a, b_: pos_feat[(a, b_)],
+            neg_edge_features=lambda a, b_: neg_feat[(a, b_)])))
     got = [g for g in _split(buf, off) if g]
     assert len(got) == len(want) and len(want) > 30 and (nc > 0).sum() > 10 and ((pc > 0) & (nc == 0)).sum() > 5
     for i, (g, w) in enumerate(zip(got, want)):
