@@ -247,6 +247,10 @@ def main():
                     help="mag240m-sharded: fraction of the nodes (the most-referenced ones) whose feature rows are "
                          "replicated on every rank and never pulled (hub-row replication); -1 (default) = auto: on "
                          "whenever world > 1, sized to 4 %% of the free HBM, at most 5 %% of the nodes")
+    ap.add_argument("--shard-encoder", type=str, default="sage", choices=["sage", "gat"],
+                    help="mag240m-sharded: sage = GraphSAGE 768->256->256 through gigl_dist_plan (dense pull bookkeeping, "
+                         "hot rows); gat = BASELINE configs[4]'s encoder, 2-layer GAT heads 2 hid 128 out 128, through "
+                         "gigl_dist_gat_plan (raw rows, generic union)")
     ap.add_argument("--no-sharded-sub", action="store_true",
                     help="N > 1 headline: skip the `sharded` sub-record (the mag240m-sharded workload at this N)")
     ap.add_argument("--shard-plans", type=int, default=3, help="mag240m-sharded: sharded plans in flight per rank")
@@ -808,8 +812,16 @@ def run_sharded(args, rank, world, local_rank, sub=False):
     del x_local
     torch.cuda.empty_cache()
     torch.manual_seed(0)
-    model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
-    w, bs = model.fused_params()
+    gat = getattr(args, "shard_encoder", "sage") == "gat"
+    if gat:
+        from gigl_amd.models_attn import GAT
+        hid, out_dim = 128, 128
+        model = GAT(d, hid, out_dim, num_layers=L, heads=2).to(dev)
+        hot_ids = None  # (replicated hot rows belong to the SAGE plan's dense bookkeeping)
+        n_hot = 0
+    else:
+        model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
+        w, bs = model.fused_params()
     # every hash window ends below (hops+1)*n + seed*hops + maxdeg: lets the owners use the range table throughout
     bound = (L + 1) * n + 42 * L + int(maxdeg.item())
     mwe = bound if bound < (1 << 30) else -1
@@ -839,8 +851,11 @@ def run_sharded(args, rank, world, local_rank, sub=False):
                 sl.eng.share_resident(eng)
             sl.eng.bind_stream(sl.stream)
             sl.comm = Comm.from_torch(sl.eng)  # RCCL (nccl backend); the host-callback transport under gloo
-            sl.plan = DistSagePlan(sl.comm, w, bs, G * B, fanouts, group_roots=B,
-                                   project_on_owner=args.project_on_owner, pull_cap=pull_cap, max_window_end=mwe)
+            if gat:
+                sl.plan = model.make_dist_plan(sl.comm, G * B, fanouts, group_roots=B, max_window_end=mwe, pull_cap=pull_cap)
+            else:
+                sl.plan = DistSagePlan(sl.comm, w, bs, G * B, fanouts, group_roots=B,
+                                       project_on_owner=args.project_on_owner, pull_cap=pull_cap, max_window_end=mwe)
             sl.out = sl.plan.new_out()
             if hot_ids is not None:
                 sl.plan.set_hot_rows(hot_ids, hot_rows)
@@ -950,7 +965,8 @@ def run_sharded(args, rank, world, local_rank, sub=False):
                        "ms_per_step_p90": q(ms_rep, 90)},
             "config": {"workload": f"MAG240M-shaped RMAT x{args.shard_scale:g}: N={n} E={int(e_local.item())} directed, "
                                    f"D={d} fp16 features, hash-partitioned over {world} rank(s) (owner = id % world), "
-                                   f"fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}, sampler mode=parity, "
+                                   f"fanout={fanouts} B={B}/GPU "
+                                   f"{'GAT heads 2 ' if gat else 'GraphSAGE '}{d}->{hid}->{out_dim}, sampler mode=parity, "
                                    f"{G} batches per exchange, {S} plans in flight, "
                                    f"{'%.3g %% of the nodes replicated as hot rows, ' % (100 * hot_frac) if n_hot else ''}"
                                    f"{'rows projected on the owner (256 fp32)' if args.project_on_owner else 'raw rows (768 fp16)'}",

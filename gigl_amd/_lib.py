@@ -53,6 +53,7 @@ SYMBOLS = [
     "gigl_typed_records_encode", "gigl_typed_samples_encode", "gigl_hgt_aggregate_backward", "gigl_weighted_aggregate_backward",
     "gigl_graph_build_shard_from_coo", "gigl_json_rows_capacity", "gigl_json_rows_format",
     "gigl_sage_project_features", "gigl_sage_plan_set_projected_input",
+    "gigl_dist_gat_plan_create", "gigl_dist_gat_plan_set_weights",
 ]
 
 KERNEL_IDS = {
@@ -231,6 +232,9 @@ def load() -> C.CDLL:
         "gigl_comm_destroy": [vp],
         "gigl_dist_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), P(vp), P(vp), i32, P(GiglDistPlanOpts), P(vp)],
         "gigl_dist_plan_set_weights": [vp, P(vp), P(vp)],
+        "gigl_dist_gat_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), P(i32), vp, vp, vp, vp, C.c_float, i32,
+                                      P(GiglDistPlanOpts), P(vp)],
+        "gigl_dist_gat_plan_set_weights": [vp, vp, vp, vp, vp],
         "gigl_dist_plan_phases": [vp, P(i32)],
         "gigl_dist_plan_phase": [vp, i32, vp, i32, vp],
         "gigl_dist_plan_run": [vp, vp, i32, vp],

@@ -608,6 +608,15 @@ struct gigl_dist_plan {
   int32_t act_last = 0;
   bool project = false;
   int64_t mwe = -1;
+  // kind 1 (gigl_dist_gat_plan_create): GAT layers over the pulled rows — w[l] = lin weight [heads*channels][dims[l]],
+  // first layer from the input side (gigl_gat_input_layer_fused over the receive buffer through pos[]), layers >= 1
+  // projection + attention (the layer stages of gigl_gat_plan_create); generic union + raw rows
+  int32_t kind = 0;
+  int32_t heads[GIGL_MAX_HOPS] = {0}, channels[GIGL_MAX_HOPS] = {0};
+  const float* att_src[GIGL_MAX_HOPS] = {nullptr};
+  const float* att_dst[GIGL_MAX_HOPS] = {nullptr};
+  float slope = 0.2f;
+  float *gat_scratch = nullptr, *alpha_scratch = nullptr, *hw = nullptr;
   // sampling
   gigl_tree tree{};
   uint32_t* child_ksum[GIGL_MAX_HOPS] = {nullptr};  // [slots of hop k]: K of the path root..slot
@@ -806,6 +815,25 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       width *= p->fan[i];
     }
     const int act = (l < L - 1 || p->act_last) ? 1 : 0;
+    if (p->kind == 1) {
+      if (l == 0) {  // the pulled rows sit in the receive buffer: local node i -> row pos[i]
+        rc = gigl_gat_input_layer_fused(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, nullptr,
+                                        p->w[0], p->att_src[0], p->att_dst[0], p->heads[0], p->channels[0], p->slope,
+                                        p->un.rowptr, p->un.rowend, p->un.col, n_rows, rows_cap, p->bias[0], act,
+                                        p->gat_scratch, p->hbuf[0]);
+        if (rc != GIGL_OK) return rc;
+        continue;
+      }
+      const int32_t* n_src = p->un.meta + GIGL_META_LEVEL0 + (L - l);  // rows layer l - 1 computed
+      const int64_t src_cap = rows_cap + width;
+      rc = gigl_linear(ctx, p->hbuf[(l - 1) & 1], p->w[l], nullptr, n_src, src_cap, p->dims[l], p->dims[l + 1], 0, p->hw);
+      if (rc != GIGL_OK) return rc;
+      rc = gigl_gat_aggregate(ctx, p->hw, p->att_src[l], p->att_dst[l], p->heads[l], p->channels[l], p->slope, 1,
+                              p->un.rowptr, p->un.rowend, p->un.col, n_src, src_cap, n_rows, rows_cap, p->bias[l], act,
+                              p->alpha_scratch, p->hbuf[l & 1]);
+      if (rc != GIGL_OK) return rc;
+      continue;
+    }
     if (l == 0 && p->project) {
       const int dout = p->dims[1];
       rc = gigl_gather_reduce(ctx, p->rows_r, GIGL_DTYPE_F32, dout, (const uint32_t*)p->pos, p->un.rowptr, p->un.rowend,
@@ -854,10 +882,88 @@ int32_t gigl_dist_plan_destroy(gigl_dist_plan* p) {
   return GIGL_OK;
 }
 
+static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
+                                     const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,
+                                     const float* const* bias, int32_t act_last, const gigl_dist_plan_opts* opts,
+                                     int32_t kind, gigl_dist_plan** out);
+
 int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
                               const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,
                               const float* const* bias, int32_t act_last, const gigl_dist_plan_opts* opts,
                               gigl_dist_plan** out) {
+  return dist_plan_create_impl(comm, shard, shard_feat, b, fanouts, hops, dims, w, bias, act_last, opts, 0, out);
+}
+
+int32_t gigl_dist_gat_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
+                                  const int32_t* fanouts, int32_t hops, const int32_t* heads, const int32_t* channels,
+                                  const float* const* w, const float* const* att_src, const float* const* att_dst,
+                                  const float* const* bias, float negative_slope, int32_t act_last,
+                                  const gigl_dist_plan_opts* opts, gigl_dist_plan** out) {
+  if (!comm || !out) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = comm->ctx;
+  *out = nullptr;
+  GIGL_REQUIRE(ctx, shard && shard_feat && fanouts && heads && channels && w && att_src && att_dst, "null argument");
+  GIGL_REQUIRE(ctx, hops >= 1 && hops <= GIGL_MAX_HOPS && b >= 1, "bad plan shape");
+  GIGL_REQUIRE(ctx, !opts || !opts->project_on_owner, "the sharded GAT plan pulls raw rows");
+  int32_t dims[GIGL_MAX_HOPS + 1];
+  dims[0] = shard_feat->d;
+  int32_t max_h = 1, max_hc = 1;
+  for (int l = 0; l < hops; ++l) {
+    GIGL_REQUIRE(ctx, heads[l] >= 1 && channels[l] >= 1 && att_src[l] && att_dst[l], "layer %d: bad heads / channels", l);
+    dims[l + 1] = heads[l] * channels[l];
+    if (heads[l] > max_h) max_h = heads[l];
+    if (dims[l + 1] > max_hc) max_hc = dims[l + 1];
+  }
+  const int P = (shard_feat->d + 255) / 256;
+  if ((shard_feat->d & 3) || (heads[0] != 1 && heads[0] != 2 && heads[0] != 4) || P > 4 ||
+      (shard_feat->dtype != GIGL_DTYPE_F32 && shard_feat->dtype != GIGL_DTYPE_F16))
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "sharded GAT plan: feature dim %d / %d heads outside the shapes the first "
+                     "layer is built for (gigl_gat_input_layer_fused)", shard_feat->d, heads[0]);
+  gigl_dist_plan* p = nullptr;
+  int32_t rc = dist_plan_create_impl(comm, shard, shard_feat, b, fanouts, hops, dims, w, bias, act_last, opts, 1, &p);
+  if (rc != GIGL_OK) return rc;
+  p->slope = negative_slope;
+  for (int l = 0; l < hops; ++l) {
+    p->heads[l] = heads[l];
+    p->channels[l] = channels[l];
+    p->att_src[l] = att_src[l];
+    p->att_dst[l] = att_dst[l];
+  }
+  auto alloc = [&](size_t bytes) -> void* {
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    p->owned.push_back(q);
+    return q;
+  };
+  p->gat_scratch = (float*)alloc((size_t)gigl_gat_input_layer_fused_scratch(shard_feat->d, heads[0], p->act_rows) * 4);
+  p->alpha_scratch = (float*)alloc((size_t)2 * p->act_rows * max_h * 4);
+  p->hw = (float*)alloc((size_t)p->act_rows * max_hc * 4);
+  if (!p->gat_scratch || !p->alpha_scratch || !p->hw) {
+    gigl_dist_plan_destroy(p);
+    return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the sharded GAT plan's workspace failed");
+  }
+  *out = p;
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_gat_plan_set_weights(gigl_dist_plan* p, const float* const* w, const float* const* att_src,
+                                       const float* const* att_dst, const float* const* bias) {
+  if (!p || !w || !att_src || !att_dst) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(p->ctx, p->kind == 1, "not a sharded GAT plan");
+  for (int k = 0; k < p->hops; ++k) {
+    if (!w[k] || !att_src[k] || !att_dst[k]) return gigl_fail(p->ctx, GIGL_E_INVALID_ARG, "layer %d: null weights", k);
+    p->w[k] = w[k];
+    p->att_src[k] = att_src[k];
+    p->att_dst[k] = att_dst[k];
+    p->bias[k] = bias ? bias[k] : nullptr;
+  }
+  return GIGL_OK;
+}
+
+static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
+                                     const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,
+                                     const float* const* bias, int32_t act_last, const gigl_dist_plan_opts* opts,
+                                     int32_t kind, gigl_dist_plan** out) {
   if (!comm || !out) return GIGL_E_INVALID_ARG;
   gigl_ctx* ctx = comm->ctx;
   *out = nullptr;
@@ -869,6 +975,7 @@ int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* sha
   if (!p) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
   p->comm = comm;
   p->ctx = ctx;
+  p->kind = kind;
   p->shard = shard;
   p->feat = shard_feat;
   p->world = comm->world;
@@ -913,7 +1020,8 @@ int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* sha
   for (int k = 0; k < hops; ++k) last_slots *= fanouts[k];
   p->last_slots = last_slots;
   p->n_global = shard->n * W;
-  p->dense = hops == 2 && !p->project && p->n_global < ((int64_t)1 << 32) && (shard_feat->d & 3) == 0 &&
+  // (the GAT layers number every union node and read the pulled rows through pos[]: generic union)
+  p->dense = kind == 0 && hops == 2 && !p->project && p->n_global < ((int64_t)1 << 32) && (shard_feat->d & 3) == 0 &&
              getenv("GIGL_DIST_GENERIC_UNION") == nullptr;
   p->own_in_place = p->dense && shard->n < ((int64_t)1 << 30) && getenv("GIGL_DIST_COPY_OWN_ROWS") == nullptr;
   // (dense: the last hop's ids live right behind the union's col array so that rows can alias tree segments)

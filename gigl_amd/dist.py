@@ -507,6 +507,54 @@ class DistSagePlan:
             self._plan = None
 
 
+class DistGatPlan(DistSagePlan):
+    """the sharded plan with GAT layers (gigl_dist_gat_plan_create): sampling over the hash-partitioned graph, union
+    graph, pull of the raw feature rows, then the GAT one-call plan's layer stages over the pulled rows.  run /
+    run_local / stats / buffers_to_host / overflowed / close are DistSagePlan's."""
+
+    def __init__(self, comm: Comm, weights, att_src, att_dst, biases, heads, channels, b: int, fanouts: Sequence[int],
+                 negative_slope: float = 0.2, act_last: bool = False, group_roots: Optional[int] = None,
+                 pull_cap: int = 0, hop_slack: float = 0.0, max_window_end: int = -1):
+        from . import _lib
+        eng = comm.eng
+        assert eng._graph is not None and eng._feat is not None, "load this rank's shard first"
+        L = len(fanouts)
+        assert len(weights) == len(att_src) == len(att_dst) == len(heads) == len(channels) == L
+        self.comm, self.eng, self.b, self.fanouts = comm, eng, int(b), [int(f) for f in fanouts]
+        self.dims = [int(weights[0].shape[1])] + [int(h) * int(c) for h, c in zip(heads, channels)]
+        self._lib = eng._lib
+        self._plan = C.c_void_p()
+        arrs = self._gat_arrays(weights, att_src, att_dst, biases)
+        o = _lib.GiglDistPlanOpts()
+        o.group_roots = int(group_roots or b)
+        o.project_on_owner = 0
+        o.pull_cap, o.hop_slack, o.max_window_end = int(pull_cap), float(hop_slack), int(max_window_end)
+        fo = (C.c_int32 * L)(*self.fanouts)
+        hd, ch = (C.c_int32 * L)(*[int(h) for h in heads]), (C.c_int32 * L)(*[int(c) for c in channels])
+        _check(self._lib.gigl_dist_gat_plan_create(comm._h, eng._graph, eng._feat, self.b, fo, L, hd, ch, *arrs,
+                                                   float(negative_slope), 1 if act_last else 0, C.byref(o),
+                                                   C.byref(self._plan)), eng._ctx)
+        n = C.c_int32()
+        _check(self._lib.gigl_dist_plan_phases(self._plan, C.byref(n)), eng._ctx)
+        self.n_phases = n.value
+
+    def _gat_arrays(self, weights, att_src, att_dst, biases):
+        L = len(weights)
+        dev = lambda t: t.detach().to(device=self.eng.device, dtype=torch.float32).contiguous()
+        ws, a_s, a_d = [dev(w) for w in weights], [dev(a.reshape(-1)) for a in att_src], [dev(a.reshape(-1)) for a in att_dst]
+        bs = [None if x is None else dev(x) for x in biases]
+        self._keep = (ws, a_s, a_d, bs)  # the plan borrows these device buffers
+        arr = lambda ts: (C.c_void_p * L)(*[(t.data_ptr() if t is not None else None) for t in ts])
+        return arr(ws), arr(a_s), arr(a_d), arr(bs)
+
+    def set_weights(self, weights, att_src, att_dst, biases) -> None:
+        _check(self._lib.gigl_dist_gat_plan_set_weights(self._plan, *self._gat_arrays(weights, att_src, att_dst, biases)),
+               self.eng._ctx)
+
+    def set_hot_rows(self, hot_ids, hot_rows) -> None:
+        raise NotImplementedError("replicated hot rows belong to the dense pull bookkeeping of the SAGE plan")
+
+
 def hip_expand(eng, world: int, max_window_end: int = -1) -> Callable:
     """owner-side expansion on the GPU: adapter from DistKHopSampler's int64 tensors to
     HipEngine.expand_frontier (gigl_expand_frontier on this rank's shard)"""

@@ -279,6 +279,10 @@ class ResidentGraph:
         if self.sharded:
             from .dist import DistSagePlan
             from .models import GraphSAGE
+            from .models_attn import GAT
+            if type(model) is GAT:  # (raises NotImplementedError for options outside the sharded plan)
+                return model.make_dist_plan(self.comm, groups * b, self.fanouts, group_roots=b,
+                                            max_window_end=self.max_window_end)
             if not isinstance(model, GraphSAGE) or not model._plain or model.aggr != "mean" or \
                     model.should_l2_normalize_embedding_layer_output or model.feats_interaction is not None or \
                     model.feature_embedding_layer is not None:

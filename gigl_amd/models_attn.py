@@ -334,6 +334,21 @@ class GAT(nn.Module):
                        negative_slope=self.conv_layers[0].negative_slope, act_last=self.activation_after_last_conv,
                        groups=groups)
 
+    def make_dist_plan(self, comm, b: int, fanouts, group_roots=None, max_window_end: int = -1, **kw):
+        """the sharded one-call plan of this model on a hash-partitioned graph (dist.DistGatPlan): same layer
+        restrictions as make_plan"""
+        from .dist import DistGatPlan
+        assert len(fanouts) == self.num_layers, "one hop per layer"
+        if self.edge_dim is not None or any(not c.concat and c.heads > 1 for c in self.conv_layers) or \
+                self.should_l2_normalize_embedding_layer_output:
+            raise NotImplementedError("the sharded plan computes plain GATConv layers (no edge features, concatenated "
+                                      "heads, no output normalisation)")
+        w, a_s, a_d, bs = self.plan_params()
+        return DistGatPlan(comm, w, a_s, a_d, bs, [c.heads for c in self.conv_layers],
+                           [c.out_channels for c in self.conv_layers], b, fanouts,
+                           negative_slope=self.conv_layers[0].negative_slope, act_last=self.activation_after_last_conv,
+                           group_roots=group_roots, max_window_end=max_window_end, **kw)
+
     def plan_params(self):
         cs = self.conv_layers
         return ([c.lin.weight.detach() for c in cs], [c.att_src.detach() for c in cs], [c.att_dst.detach() for c in cs],

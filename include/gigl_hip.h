@@ -959,6 +959,19 @@ int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* sha
                               const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,
                               const float* const* bias, int32_t act_last, const gigl_dist_plan_opts* opts,
                               gigl_dist_plan** out);
+/* The sharded plan with GAT layers (BASELINE configs[4]: link-prediction GAT over the hash-partitioned MAG240M-shaped
+ * graph; python/gigl/src/common/models/pyg/homogeneous.py:300-343 via PyG GATConv): the sampling / union / feature-pull
+ * phases of gigl_dist_plan_create (raw rows, every union node numbered), then the layer stages of gigl_gat_plan_create
+ * over the pulled rows — first layer from the input side in one row pass (gigl_gat_input_layer_fused reading the
+ * receive buffer through pos[]), layers >= 1 projection + attention.  Same weight layout as gigl_gat_plan_create; run /
+ * phase / run_local / stats / buffers / destroy are the gigl_dist_plan_* calls. */
+int32_t gigl_dist_gat_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
+                                  const int32_t* fanouts, int32_t hops, const int32_t* heads, const int32_t* channels,
+                                  const float* const* w, const float* const* att_src, const float* const* att_dst,
+                                  const float* const* bias, float negative_slope, int32_t act_last,
+                                  const gigl_dist_plan_opts* opts, gigl_dist_plan** out);
+int32_t gigl_dist_gat_plan_set_weights(gigl_dist_plan* plan, const float* const* w, const float* const* att_src,
+                                       const float* const* att_dst, const float* const* bias);
 int32_t gigl_dist_plan_set_weights(gigl_dist_plan* plan, const float* const* w, const float* const* bias);
 int32_t gigl_dist_plan_phases(gigl_dist_plan* plan, int32_t* n);
 int32_t gigl_dist_plan_phase(gigl_dist_plan* plan, int32_t phase, const uint32_t* roots, int32_t sampling_seed,

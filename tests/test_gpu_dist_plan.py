@@ -313,3 +313,75 @@ def test_two_processes_one_gpu_callback_transport_over_gloo():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the build boxes have one)")
 def test_two_rccl_ranks_on_two_gpus():
     _spawn(2, "rccl")
+
+
+def _gat_reference_rows(rowptr, col, x, model, roots, group_roots):
+    """oracle sample -> oracle collate -> fp32 GAT forward (oracle/gnn_ref.gat_conv) over the whole union graph"""
+    rows = []
+    for g0 in range(0, roots.size, group_roots):
+        rs = roots[g0:g0 + group_roots]
+        nbr, _ = oracle.sample_khop(rowptr, col, rs, FAN, canonical=True)
+        u = oracle.union_build(rs, FAN, nbr)
+        h = torch.from_numpy(x[u["nodes"].astype(np.int64)].astype(np.float32))
+        ei = gnn_ref.union_edge_index(u["rowptr"], u["col"])
+        L = len(model.conv_layers)
+        for l, c in enumerate(model.conv_layers):
+            h = gnn_ref.gat_conv(h, ei, c.lin.weight.detach().cpu(), c.att_src.detach().cpu(), c.att_dst.detach().cpu(),
+                                 c.bias.detach().cpu() if c.bias is not None else None, c.heads, concat=c.concat,
+                                 negative_slope=c.negative_slope)
+            if l < L - 1:
+                h = torch.relu(h)
+        rows.append(h[torch.from_numpy(u["root_local"].astype(np.int64))])
+    return torch.cat(rows).numpy()
+
+
+@pytest.mark.parametrize("world,dtype", [(2, torch.float32), (3, torch.float16), (8, torch.float32)])
+def test_sharded_gat_plan_every_rank_end_to_end(world, dtype):
+    """gigl_dist_gat_plan_create (BASELINE configs[4]'s encoder on the hash-partitioned graph): every rank of an emulated
+    world samples trees bit-identical to the oracle on the whole graph and gets root embeddings within 2e-5 of the
+    oracle's collate + fp32 GAT forward (and of the single-GPU one-call GAT plan)"""
+    from gigl_amd.dist import Comm
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models_attn import GAT
+    rowptr, col, x = make_graph()
+    xq = x.astype(np.float16).astype(np.float32) if dtype == torch.float16 else x
+    torch.manual_seed(13)
+    model = GAT(D, 16, 12, num_layers=len(FAN), heads=2)
+    with torch.no_grad():
+        for c in model.conv_layers:
+            c.bias.normal_(0, 0.1)
+    b, gr = 64, 32
+    st = torch.cuda.Stream()
+    engs = [shard_engine(rowptr, col, x, r, world, dtype, st) for r in range(world)]
+    comms = Comm.local(engs)
+    model = model.to(engs[0].device)
+    plans = [model.make_dist_plan(comms[r], b, FAN, group_roots=gr, max_window_end=bound_for(rowptr)) for r in range(world)]
+    roots = [rank_roots(r, b) for r in range(world)]
+    roots_d = [torch.from_numpy(r.view(np.int32)).to(engs[0].device) for r in roots]
+    from gigl_amd.dist import DistSagePlan
+    for _ in range(2):
+        outs = DistSagePlan.run_local(plans, roots_d)
+    st.synchronize()
+    # the single-GPU one-call GAT plan over the whole graph
+    whole = HipEngine(0)
+    whole.load_csc(rowptr, col)
+    whole.load_features(torch.from_numpy(x).to(dtype))
+    single = model.make_plan(whole, gr, FAN, groups=b // gr)
+    for r in range(world):
+        hb = plans[r].buffers_to_host()
+        assert hb["meta"][8] == 0 and not plans[r].overflowed()
+        nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots[r], FAN, canonical=True)
+        for k in range(len(FAN)):
+            assert np.array_equal(hb["nbr"][k], nbr_o[k]) and np.array_equal(hb["cnt"][k], cnt_o[k])
+        want = _gat_reference_rows(rowptr, col, xq, model, roots[r], gr)
+        np.testing.assert_allclose(outs[r].cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+        one = single.run(roots_d[r]).cpu().numpy()
+        np.testing.assert_allclose(outs[r].cpu().numpy(), one, rtol=2e-5, atol=2e-5)
+    single.close()
+    whole.close()
+    for p in plans:
+        p.close()
+    for c in comms:
+        c.close()
+    for e in engs:
+        e.close()
