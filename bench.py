@@ -822,6 +822,27 @@ def run_sharded(args, rank, world, local_rank, sub=False):
     else:
         model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
         w, bs = model.fused_params()
+    # pre-projected rows: every rank projects ITS shard once ([W_l x | W_r x]); the pull then moves 1 KB W_l x rows
+    # instead of 1.5 KB raw rows and no step projects anything.  Timed, and charged to every step as 1 / (this rank's
+    # steps of a full pass over all nodes = N / (B * world)) of its duration
+    pre_s, proj_table = 0.0, None
+    if not gat and not args.project_on_owner and args.project_input != "off" and L == 2 and \
+            (args.project_input == "on" or model.projected_input_pays(eng)):
+        proj_table = torch.empty((n_local, 2 * hid), dtype=torch.float32, device=dev)
+        proj_table.zero_()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        eng.project_features(w[0], out=proj_table)
+        torch.cuda.synchronize()
+        pre_s = time.perf_counter() - tp
+        if hot_ids is not None:  # the replicas become W_l x rows: every rank contributes the rows it owns
+            hi = hot_ids.to(torch.int64) & 0xFFFFFFFF
+            mine_hot = (hi % world) == rank
+            hot_rows = torch.zeros((n_hot, hid), device=dev, dtype=torch.float32)
+            hot_rows[mine_hot] = proj_table[hi[mine_hot] // world, :hid]
+            all_reduce(hot_rows, dist.ReduceOp.SUM)
+    steps_per_pass = max(1, -(-n // (B * world)))
+    pre_per_step_s = pre_s / steps_per_pass
     # every hash window ends below (hops+1)*n + seed*hops + maxdeg: lets the owners use the range table throughout
     bound = (L + 1) * n + 42 * L + int(maxdeg.item())
     mwe = bound if bound < (1 << 30) else -1
@@ -855,7 +876,8 @@ def run_sharded(args, rank, world, local_rank, sub=False):
                 sl.plan = model.make_dist_plan(sl.comm, G * B, fanouts, group_roots=B, max_window_end=mwe, pull_cap=pull_cap)
             else:
                 sl.plan = DistSagePlan(sl.comm, w, bs, G * B, fanouts, group_roots=B,
-                                       project_on_owner=args.project_on_owner, pull_cap=pull_cap, max_window_end=mwe)
+                                       project_on_owner=args.project_on_owner, pull_cap=pull_cap, max_window_end=mwe,
+                                       projected=proj_table)
             sl.out = sl.plan.new_out()
             if hot_ids is not None:
                 sl.plan.set_hot_rows(hot_ids, hot_rows)
@@ -945,12 +967,12 @@ def run_sharded(args, rank, world, local_rank, sub=False):
     tot = torch.tensor((seg_stats * seg_use[:, None]).sum(0), dtype=torch.float64, device=dev)
     all_reduce(tot, dist.ReduceOp.SUM)
     tot = tot.cpu().numpy()
-    rep_np = rep_t.cpu().numpy()
+    rep_np = rep_t.cpu().numpy() + K_rep * pre_per_step_s  # (+ every step's share of the shard projection, if any)
     elapsed = float(rep_np.sum())
     steps_total = reps * K_rep
     sampled_all, aggregated_all = float(tot[STATS["sampled"]]), float(tot[STATS["aggregated"]])
     pulled_all = float(tot[STATS["pulled_rows"]])
-    row_bytes = hid * 4 if args.project_on_owner else d * 2
+    row_bytes = hid * 4 if (args.project_on_owner or proj_table is not None) else d * 2
     ms_rep = rep_np / K_rep * 1e3
     if rank == 0:
         q = lambda a, p: float(np.percentile(a, p))
@@ -969,7 +991,12 @@ def run_sharded(args, rank, world, local_rank, sub=False):
                                    f"{'GAT heads 2 ' if gat else 'GraphSAGE '}{d}->{hid}->{out_dim}, sampler mode=parity, "
                                    f"{G} batches per exchange, {S} plans in flight, "
                                    f"{'%.3g %% of the nodes replicated as hot rows, ' % (100 * hot_frac) if n_hot else ''}"
-                                   f"{'rows projected on the owner (256 fp32)' if args.project_on_owner else 'raw rows (768 fp16)'}",
+                                   + ("rows projected on the owner (256 fp32)" if args.project_on_owner else
+                                      "rows pre-projected once per rank (256 fp32 W_l x rows pulled)" if proj_table is not None
+                                      else "raw rows (768 fp16)"),
+                       "projected_input": (None if proj_table is None else {
+                           "precompute_s": round(pre_s, 4), "steps_per_pass_per_rank": steps_per_pass,
+                           "charged_ms_per_step": pre_per_step_s * 1e3}),
                        "graph": "CSC rows + feature rows of the owned nodes per rank; per-hop all-to-all frontier "
                                 "exchange and feature pull of the unique union-graph nodes, issued by the library "
                                 "(gigl_dist_plan, RCCL)",

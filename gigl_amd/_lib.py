@@ -133,6 +133,7 @@ class GiglDistPlanOpts(C.Structure):
         ("pull_cap", C.c_int64),
         ("hop_slack", C.c_float),
         ("max_window_end", C.c_int64),
+        ("projected", C.c_void_p),
     ]
 STATS_LEN = 16
 STATS_SAMPLED, STATS_AGGREGATED = 0, 1  # GIGL_STATS_* slots of gigl_sage_plan_stats

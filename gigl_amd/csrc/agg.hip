@@ -80,15 +80,17 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
                                                           const T* __restrict__ src2, const T* __restrict__ src3,
                                                           const float* __restrict__ self_src = nullptr,
                                                           const float* __restrict__ bias = nullptr, int act = 0,
-                                                          int ld = 0, int no_self = 0) {
+                                                          int ld = 0, int no_self = 0,
+                                                          const int32_t* __restrict__ self_ids = nullptr, int ld3 = 0) {
   constexpr int G = 64 / LPR;  // source rows per wave-instruction
   const int64_t rs = PROJ ? (int64_t)ld : (int64_t)d;  // elements between source rows
+  const int64_t rs3 = PROJ && ld3 ? (int64_t)ld3 : (int64_t)d;  // ... of src3 (the rank's own table)
   // a NEGATIVE row index -1-h names a row outside `src` (the sharded plan): h < 2^30 = row h of src2 (replicated hot
   // rows), else row h - 2^30 of src3 (this rank's own feature table)
   auto row_of = [&](int j) -> const T* {
     if (j >= 0) return src + (int64_t)j * rs;
     const int h = -1 - j;
-    return h < (1 << 30) ? src2 + (int64_t)h * d : src3 + (int64_t)(h - (1 << 30)) * d;
+    return h < (1 << 30) ? src2 + (int64_t)h * d : src3 + (int64_t)(h - (1 << 30)) * rs3;
   };
   const int lane = threadIdx.x & 63;
   const int sub = lane / LPR;  // which source row of the instruction
@@ -124,7 +126,9 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
     const int c0 = (grp ? sl : lane) * 4, cstep = (grp ? LPR : 64) * 4;  // the self-row copy's lanes
     if constexpr (PROJ) {
       if (writer) {
-        const float* pr = self_src + (int64_t)(uint32_t)self * rs;
+        // (self_ids: the destination's W_r row sits at row self_ids[i] of self_src — the sharded plan's second receive
+        // buffer — instead of at its source index)
+        const float* pr = self_src + (int64_t)(self_ids ? (uint32_t)self_ids[i] : (uint32_t)self) * rs;
         float* o = out + (int64_t)i * d;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
@@ -2242,23 +2246,23 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
 int32_t launch_gather_projected(gigl_ctx* ctx, const float* src_l, const float* src_r, int ld, int d, const uint32_t* gather_ids,
                                 const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                                 const int32_t* n_rows_dev, int64_t rows_cap, const int32_t* n_local_dev, int op,
-                                const float* bias, int act, float* out) {
+                                const float* bias, int act, float* out, const int32_t* global_map, const float* src2,
+                                const float* src3, int ld3, const int32_t* self_ids) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
   dim3 g((unsigned)blocks), b(256);
   const int vecs = d / 4;
-  const float* nul = nullptr;
 #define GLP(LPR, VPL)                                                                                                 \
   do {                                                                                                                \
     if (op == GIGL_AGGR_MEAN)                                                                                         \
       hipLaunchKernelGGL((gather_mean_kernel<float, LPR, VPL, GIGL_AGGR_MEAN, true>), g, b, 0, ctx->stream, src_l, d, \
-                         gather_ids, rowptr, rowend, col, n_rows_dev, out, n_local_dev, 0, (const int32_t*)nullptr,   \
-                         nul, nul, src_r, bias, act, ld);                                                             \
+                         gather_ids, rowptr, rowend, col, n_rows_dev, out, n_local_dev, 0, global_map, src2, src3,    \
+                         src_r, bias, act, ld, 0, self_ids, ld3);                                                     \
     else                                                                                                              \
       hipLaunchKernelGGL((gather_mean_kernel<float, LPR, VPL, GIGL_AGGR_SUM, true>), g, b, 0, ctx->stream, src_l, d,  \
-                         gather_ids, rowptr, rowend, col, n_rows_dev, out, n_local_dev, 0, (const int32_t*)nullptr,   \
-                         nul, nul, src_r, bias, act, ld);                                                             \
+                         gather_ids, rowptr, rowend, col, n_rows_dev, out, n_local_dev, 0, global_map, src2, src3,    \
+                         src_r, bias, act, ld, 0, self_ids, ld3);                                                     \
   } while (0)
   if ((d & 3) != 0 || vecs > 512) return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "projected input: width %d (need d %% 4 == 0, d <= 2048)", d);
   if (vecs <= 8) GLP(8, 1);
@@ -2290,14 +2294,16 @@ __global__ __launch_bounds__(256) void half_rows_to_f32_kernel(const __half* __r
 int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float* src_r, int32_t ld, int32_t d,
                                   const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* rowend,
                                   const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
-                                  const int32_t* n_local_rows_dev, const float* bias, int32_t act, float* out) {
+                                  const int32_t* n_local_rows_dev, const float* bias, int32_t act, float* out,
+                                  const int32_t* global_map, const float* src2, const float* src3, int32_t ld3,
+                                  const int32_t* self_ids) {
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   if (aggr != GIGL_AGGR_MEAN && aggr != GIGL_AGGR_SUM)
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "projected input needs a linear reduction (mean / sum)");
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   return launch_gather_projected(ctx, src_l, src_r, ld, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap,
-                                 n_local_rows_dev, aggr, bias, act, out);
+                                 n_local_rows_dev, aggr, bias, act, out, global_map, src2, src3, ld3, self_ids);
 }
 
 extern "C" {

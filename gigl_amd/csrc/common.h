@@ -113,7 +113,11 @@ int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dty
 int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float* src_r, int32_t ld, int32_t d,
                                   const uint32_t* gather_ids, const int32_t* rowptr, const int32_t* rowend,
                                   const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
-                                  const int32_t* n_local_rows_dev, const float* bias, int32_t act, float* out);
+                                  const int32_t* n_local_rows_dev, const float* bias, int32_t act, float* out,
+                                  const int32_t* global_map = nullptr, const float* src2 = nullptr,
+                                  const float* src3 = nullptr, int32_t ld3 = 0, const int32_t* self_ids = nullptr);
+// (sharded plan: global_map / src2 / src3 as in gigl_gather_reduce_mixed — src3's rows ld3 floats apart — and
+// self_ids[i] = the row of src_r that holds destination i's W_r x)
 // tiled_nkc > 0: `out` is written in the projection's tiled operand layout ([row tile of 128][K chunk of 32][128 rows]
 // [32 floats], tiled_nkc = ceil(2d / 32); capacity: whole row tiles) and read by gigl_linear_tiled (agg.hip)
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,

@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void serve_rows_copy_kernel(const uint32_t* __
                                                               int64_t n_rows, uint32_t row_bytes, uint32_t unit,
                                                               uint32_t units_per_row, char* __restrict__ out,
                                                               int64_t self_lo, int64_t self_hi,
-                                                              char* __restrict__ self_out) {
+                                                              char* __restrict__ self_out, int64_t src_stride = 0) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t e = t / units_per_row;
   const uint32_t c = (uint32_t)(t - e * units_per_row);
@@ -437,7 +437,8 @@ __global__ __launch_bounds__(256) void serve_rows_copy_kernel(const uint32_t* __
   const int64_t row = (int64_t)(v / world);
   if (row >= n_rows) return;
   char* o = (self_out && e >= self_lo && e < self_hi) ? self_out : out;
-  const char* sp = rows + row * (int64_t)row_bytes + (int64_t)c * unit;
+  // (src_stride: bytes between table rows when a row is a slice of a wider one — the projected table [W_l x | W_r x])
+  const char* sp = rows + row * (src_stride ? src_stride : (int64_t)row_bytes) + (int64_t)c * unit;
   char* op = o + e * (int64_t)row_bytes + (int64_t)c * unit;
   if (unit == 16) *(uint4*)op = *(const uint4*)sp;
   else if (unit == 4) *(uint32_t*)op = *(const uint32_t*)sp;
@@ -607,6 +608,10 @@ struct gigl_dist_plan {
   const float* bias[GIGL_MAX_HOPS] = {nullptr};
   int32_t act_last = 0;
   bool project = false;
+  // pre-projected rows (opts->projected): this rank's [W_l x | W_r x] table, [shard rows][2*dims[1]] fp32, borrowed.  The
+  // dense pull then moves W_l x rows (dims[1] fp32 instead of the raw row), a second small pull brings the W_r x rows of
+  // the nodes of level < hops, and the first layer is one reduction (gigl_gather_project_mixed) — no projection per step
+  const float* preproj = nullptr;
   int64_t mwe = -1;
   // kind 1 (gigl_dist_gat_plan_create): GAT layers over the pulled rows — w[l] = lin weight [heads*channels][dims[l]],
   // first layer from the input side (gigl_gat_input_layer_fused over the receive buffer through pos[]), layers >= 1
@@ -750,8 +755,18 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
                          p->own_in_place ? p->rank : -1);
       hipLaunchKernelGGL(pos_from_map_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes, n_inner,
                          p->act_rows, p->slot_map, p->n_global, p->pos);
+      if (p->preproj) {  // the inner nodes' own W_r x rows: a second, small pull
+        GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->idsb_s, 0xFF, (size_t)world * p->pull_cap_b * 4, st));
+        GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->pullb_counts, 0, (size_t)(world + 1) * 4, st));
+        hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes,
+                           (const uint32_t*)nullptr, p->act_rows, n_inner, world, p->pull_cap_b, p->idsb_s,
+                           (uint32_t*)nullptr, (int32_t*)nullptr, p->posb, p->pullb_counts, 0u, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr);
+      }
       GIGL_HIP_CHECK(ctx, hipGetLastError());
-      return comm_exchange(p->comm, p->ids_s, p->ids_r, p->pull_cap * 4);
+      rc = comm_exchange(p->comm, p->ids_s, p->ids_r, p->pull_cap * 4);
+      if (rc == GIGL_OK && p->preproj) rc = comm_exchange(p->comm, p->idsb_s, p->idsb_r, p->pull_cap_b * 4);
+      return rc;
     }
     rc = gigl_union_build_groups(ctx, roots, &p->tree, p->group_roots, &p->un);
     if (rc != GIGL_OK) return rc;
@@ -779,12 +794,20 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       const bool in_place = comm_self_in_place(p->comm);
       const uint32_t unit = (p->row_bytes & 15) == 0 ? 16u : ((p->row_bytes & 3) == 0 ? 4u : 2u);
       const uint32_t upr = (uint32_t)(p->row_bytes / unit);
+      const char* table = p->preproj ? (const char*)p->preproj : (const char*)p->feat->rows;
+      const int64_t stride = p->preproj ? 2 * p->row_bytes : 0;  // ([W_l x | W_r x]: a served row is half a table row)
       hipLaunchKernelGGL(serve_rows_copy_kernel, dim3((unsigned)grid256(na * upr)), dim3(256), 0, st, p->ids_r, na,
-                         world, (const char*)p->feat->rows, p->feat->n, (uint32_t)p->row_bytes, unit, upr,
+                         world, table, p->feat->n, (uint32_t)p->row_bytes, unit, upr,
                          (char*)p->rows_s, (int64_t)p->rank * p->pull_cap, (int64_t)(p->rank + 1) * p->pull_cap,
-                         in_place ? (char*)p->rows_r : (char*)nullptr);
+                         in_place ? (char*)p->rows_r : (char*)nullptr, stride);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
-      return comm_exchange(p->comm, p->rows_s, p->rows_r, p->pull_cap * p->row_bytes, in_place);
+      rc = comm_exchange(p->comm, p->rows_s, p->rows_r, p->pull_cap * p->row_bytes, in_place);
+      if (rc != GIGL_OK || !p->preproj) return rc;
+      hipLaunchKernelGGL(serve_rows_copy_kernel, dim3((unsigned)grid256(nb * upr)), dim3(256), 0, st, p->idsb_r, nb,
+                         world, table + p->row_bytes, p->feat->n, (uint32_t)p->row_bytes, unit, upr, (char*)p->rowsb_s,
+                         (int64_t)0, (int64_t)0, (char*)nullptr, stride);
+      GIGL_HIP_CHECK(ctx, hipGetLastError());
+      return comm_exchange(p->comm, p->rowsb_s, p->rowsb_r, p->pull_cap_b * p->row_bytes);
     }
     // (entries without a request keep whatever the operand held: their output rows are never read)
     hipLaunchKernelGGL(serve_rows_f32_kernel, dim3((unsigned)grid256(na * 64)), dim3(256), 0, st, p->ids_r, na, world,
@@ -842,6 +865,15 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       hipLaunchKernelGGL(projected_layer_kernel, dim3((unsigned)grid256(rows_cap * dout)), dim3(256), 0, st, p->abuf,
                          (const float*)p->rowsb_r, p->posb, p->bias[0], dout, act, n_rows, rows_cap, p->hbuf[0]);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
+      continue;
+    }
+    if (l == 0 && p->preproj) {  // one reduction over W_l x rows (receive buffer / own table / hot rows) + W_r x + bias
+      const int dout = p->dims[1];
+      rc = gigl_gather_project_mixed(ctx, (const float*)p->rows_r, (const float*)p->rowsb_r, dout, dout,
+                                     (const uint32_t*)p->pos, p->un.rowptr, p->un.rowend, p->un.col, n_rows, rows_cap,
+                                     GIGL_AGGR_MEAN, p->un.meta + GIGL_META_LEVEL0 + (L - 2), p->bias[0], act, p->hbuf[0],
+                                     p->slot_map, (const float*)p->hot_rows, p->preproj, 2 * dout, p->posb);
+      if (rc != GIGL_OK) return rc;
       continue;
     }
     if (l == 0 && p->dense)  // rows of level L-1 hold global ids: located through slot_map
@@ -985,6 +1017,7 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   p->act_last = act_last;
   p->group_roots = opts && opts->group_roots > 0 ? opts->group_roots : b;
   p->project = opts && opts->project_on_owner != 0;
+  p->preproj = opts ? opts->projected : nullptr;
   p->mwe = opts ? opts->max_window_end : -1;
   const double slack = opts && opts->hop_slack > 0.f ? opts->hop_slack : 0.5;
   auto fail = [&](int32_t code, const char* msg) {
@@ -1024,6 +1057,9 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   p->dense = kind == 0 && hops == 2 && !p->project && p->n_global < ((int64_t)1 << 32) && (shard_feat->d & 3) == 0 &&
              getenv("GIGL_DIST_GENERIC_UNION") == nullptr;
   p->own_in_place = p->dense && shard->n < ((int64_t)1 << 30) && getenv("GIGL_DIST_COPY_OWN_ROWS") == nullptr;
+  if (p->preproj && (!p->dense || (dims[1] & 3) != 0 || dims[1] > 2048))
+    return fail(GIGL_E_UNSUPPORTED, "pre-projected rows need the dense pull bookkeeping (two hops, no owner-side "
+                                    "projection) and a first-layer width % 4 == 0, <= 2048");
   // (dense: the last hop's ids live right behind the union's col array so that rows can alias tree segments)
   p->un.col = (int32_t*)alloc((size_t)(cap_edges + (p->dense ? last_slots : 0)) * 4);
   ok = p->un.col != nullptr;
@@ -1087,7 +1123,8 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   int64_t pc = opts && opts->pull_cap > 0 ? opts->pull_cap : (int64_t)std::ceil((double)cap_nodes / (double)W * 1.1) + 512;
   if (pc > cap_nodes) pc = cap_nodes;
   p->pull_cap = pc;
-  p->row_bytes = p->project ? (int64_t)dims[1] * 4 : (int64_t)dims[0] * (shard_feat->dtype == GIGL_DTYPE_F32 ? 4 : 2);
+  p->row_bytes = (p->project || p->preproj) ? (int64_t)dims[1] * 4
+                                            : (int64_t)dims[0] * (shard_feat->dtype == GIGL_DTYPE_F32 ? 4 : 2);
   p->ids_s = (uint32_t*)alloc((size_t)W * pc * 4);
   p->ids_r = (uint32_t*)alloc((size_t)W * pc * 4);
   p->pos = (int32_t*)alloc((size_t)cap_nodes * 4);
@@ -1097,6 +1134,18 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   ok = ok && p->own_cnt && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col &&
        p->un.root_local && p->ids_s && p->ids_r && p->pos && p->pull_counts && p->rows_s && p->rows_r;
   p->n_entries_dev = (int32_t*)alloc(16);
+  if (p->preproj && ok) {  // the second pull's buckets (W_r x of the inner nodes)
+    int64_t pcb = (int64_t)std::ceil((double)act_rows / (double)W * (W > 1 ? 1.25 : 1.0)) + 512;
+    if (pcb > act_rows) pcb = act_rows;
+    p->pull_cap_b = pcb;
+    p->idsb_s = (uint32_t*)alloc((size_t)W * pcb * 4);
+    p->idsb_r = (uint32_t*)alloc((size_t)W * pcb * 4);
+    p->posb = (int32_t*)alloc((size_t)act_rows * 4);
+    p->pullb_counts = (int32_t*)alloc((size_t)(W + 1) * 4);
+    p->rowsb_s = alloc((size_t)W * pcb * p->row_bytes);
+    p->rowsb_r = alloc((size_t)W * pcb * p->row_bytes);
+    ok = p->idsb_s && p->idsb_r && p->posb && p->pullb_counts && p->rowsb_s && p->rowsb_r;
+  }
   if (p->project && ok) {
     int64_t pcb = (int64_t)std::ceil((double)act_rows / (double)W * (W > 1 ? 1.25 : 1.0)) + 512;
     if (pcb > act_rows) pcb = act_rows;
@@ -1123,7 +1172,7 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   std::vector<const int32_t*> flags;
   for (int k = 0; k < hops; ++k) flags.push_back(p->counts[k] + W);
   flags.push_back(p->pull_counts + W);
-  if (p->project) flags.push_back(p->pullb_counts + W);
+  if (p->project || p->preproj) flags.push_back(p->pullb_counts + W);
   p->n_flags = (int)flags.size();
   p->flag_ptrs = (const int32_t**)alloc(flags.size() * sizeof(void*));
   ok = ok && p->abuf && p->hbuf[0] && p->hbuf[1] && p->n_entries_dev && p->flag_ptrs;

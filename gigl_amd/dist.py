@@ -384,7 +384,10 @@ class DistSagePlan:
 
     def __init__(self, comm: Comm, weights, biases, b: int, fanouts: Sequence[int], act_last: bool = False,
                  group_roots: Optional[int] = None, project_on_owner: bool = False, pull_cap: int = 0,
-                 hop_slack: float = 0.0, max_window_end: int = -1):
+                 hop_slack: float = 0.0, max_window_end: int = -1, projected: Optional[torch.Tensor] = None):
+        """projected: this rank's pre-projected rows (HipEngine.project_features of the SHARD's table with weights[0]:
+        [shard rows, 2*out] fp32) — the pull moves W_l x rows, the first layer is one reduction (gigl_dist_plan_opts.
+        projected); recompute and rebuild the plan after a weight update"""
         from . import _lib
         eng = comm.eng
         assert eng._graph is not None and eng._feat is not None, "load this rank's shard first"
@@ -398,6 +401,11 @@ class DistSagePlan:
         o.group_roots = int(group_roots or b)
         o.project_on_owner = 1 if project_on_owner else 0
         o.pull_cap, o.hop_slack, o.max_window_end = int(pull_cap), float(hop_slack), int(max_window_end)
+        self.projected = projected
+        if projected is not None:
+            assert projected.is_cuda and projected.dtype == torch.float32 and projected.is_contiguous() and \
+                projected.shape[1] == 2 * self.dims[1]
+            o.projected = projected.data_ptr()
         fo = (C.c_int32 * L)(*self.fanouts)
         dims = (C.c_int32 * (L + 1))(*self.dims)
         _check(self._lib.gigl_dist_plan_create(comm._h, eng._graph, eng._feat, self.b, fo, L, dims, w_arr, b_arr,
@@ -433,7 +441,11 @@ class DistSagePlan:
             return
         ids = hot_ids.to(device=self.eng.device, dtype=torch.int32).contiguous()
         rows = hot_rows.to(device=self.eng.device).contiguous()
-        assert rows.shape[0] == n and rows.shape[1] == self.dims[0]
+        if getattr(self, "projected", None) is not None:  # pre-projected plan: the replicas are W_l x rows
+            assert rows.dtype == torch.float32 and rows.shape[1] == self.dims[1], "hot rows of a pre-projected plan: [n, out] fp32"
+        else:
+            assert rows.shape[1] == self.dims[0]
+        assert rows.shape[0] == n
         _check(self._lib.gigl_dist_plan_set_hot_rows(self._plan, C.c_void_p(ids.data_ptr()), n,
                                                      C.c_void_p(rows.data_ptr())), self.eng._ctx)
         self._hot = (ids, rows)  # the plan borrows the rows

@@ -289,8 +289,16 @@ class ResidentGraph:
                 raise NotImplementedError("WORLD_SIZE > 1: the sharded plan runs plain mean-GraphSAGE encoders "
                                           f"(got {type(model).__name__})")
             w, bs = model.fused_params()
+            # rows wider than the first layer's output: project this rank's shard once, pull W_l x rows (the table is
+            # refilled in place by _refresh when the weights change)
+            proj = None
+            if len(self.fanouts) == 2 and model.projected_input_pays(self.engine) and \
+                    os.environ.get("GIGL_AMD_PROJECT_INPUT", "1") != "0":
+                proj = getattr(self, "_dist_proj", None)
+                if proj is None:
+                    proj = self._dist_proj = self.engine.project_features(w[0])
             return DistSagePlan(self.comm, w, bs, groups * b, self.fanouts, act_last=model.activation_after_last_conv,
-                                group_roots=b, max_window_end=self.max_window_end)
+                                group_roots=b, max_window_end=self.max_window_end, projected=proj)
         make = getattr(model, "make_plan", None)
         if make is None:
             return None
@@ -307,6 +315,8 @@ class ResidentGraph:
     def _refresh(self, plan, model) -> None:
         if hasattr(model, "fused_params"):
             plan.set_weights(*model.fused_params())
+            if self.sharded and getattr(plan, "projected", None) is not None:  # same table, new weights
+                self.engine.project_features(model.conv_layers[0].fused_weight(), out=plan.projected)
             # an inference pass over rows wider than the first layer's output: project the table once per model state
             # (X W_l^T, X W_r^T) and run the first layer over projected rows — one table per resident graph, shared by
             # the plans of this model

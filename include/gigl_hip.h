@@ -954,6 +954,14 @@ typedef struct gigl_dist_plan_opts {
   int64_t pull_cap;          /* feature rows per peer and step (0: default bound) */
   float hop_slack;           /* 0: 0.5 */
   int64_t max_window_end;    /* -1: unknown */
+  const float* projected;    /* NULL, or this rank's PRE-PROJECTED rows: gigl_sage_project_features over the shard's
+                                feature table with the plan's first-layer weight ([shard rows][2*dims[1]] fp32 =
+                                [W_l x | W_r x], DEVICE, borrowed; recompute after a weight update).  The pull then moves
+                                W_l x rows (dims[1] fp32 instead of the raw row: MAG240M 1.5 KB -> 1 KB), the W_r x rows
+                                of the nodes of level < hops come in a second small pull, and the first layer is one
+                                reduction — no projection per step, on owner or requester.  Two-hop plans, not with
+                                project_on_owner; replicated hot rows (gigl_dist_plan_set_hot_rows) are then W_l x rows
+                                ([n_hot][dims[1]] fp32). */
 } gigl_dist_plan_opts;
 int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
                               const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,

@@ -73,7 +73,8 @@ def bound_for(rowptr):
 
 @pytest.mark.parametrize("world,project,dtype", [(2, False, torch.float32), (8, False, torch.float16),
                                                  (2, True, torch.float32), (8, True, torch.float16),
-                                                 (3, True, torch.float32)])
+                                                 (3, True, torch.float32), (2, "pre", torch.float32),
+                                                 (3, "pre", torch.float16), (8, "pre", torch.float16)])
 def test_all_ranks_in_one_process_end_to_end(world, project, dtype):
     from gigl_amd.dist import Comm, DistSagePlan
     rowptr, col, x = make_graph()
@@ -84,8 +85,14 @@ def test_all_ranks_in_one_process_end_to_end(world, project, dtype):
     st = torch.cuda.Stream()
     engs = [shard_engine(rowptr, col, x, r, world, dtype, st) for r in range(world)]
     comms = Comm.local(engs)
-    plans = [DistSagePlan(comms[r], w, bs, b, FAN, group_roots=gr, project_on_owner=project,
-                          max_window_end=bound_for(rowptr)) for r in range(world)]
+    if project == "pre":  # rows projected ONCE per rank over its shard; the pull moves W_l x rows
+        wdev = w[0].to(engs[0].device)
+        tables = [e.project_features(wdev) for e in engs]
+        plans = [DistSagePlan(comms[r], w, bs, b, FAN, group_roots=gr, max_window_end=bound_for(rowptr),
+                              projected=tables[r]) for r in range(world)]
+    else:
+        plans = [DistSagePlan(comms[r], w, bs, b, FAN, group_roots=gr, project_on_owner=project,
+                              max_window_end=bound_for(rowptr)) for r in range(world)]
     roots = [rank_roots(r, b) for r in range(world)]
     roots_d = [torch.from_numpy(r.view(np.int32)).to(engs[0].device) for r in roots]
     for _ in range(2):  # twice: buffers are reused step to step
@@ -116,7 +123,7 @@ def test_all_ranks_in_one_process_end_to_end(world, project, dtype):
 
 
 @pytest.mark.parametrize("world,dtype", [(2, torch.float32), (8, torch.float16)])
-def test_replicated_hot_rows_are_not_pulled(world, dtype):
+def test_replicated_hot_rows_are_not_pulled(world, dtype, pre=False):
     """hub-row replication (gigl_dist_plan_set_hot_rows): the most-referenced nodes' rows are kept on every rank and read
     locally — the results do not change (trees bit-identical, embeddings 1e-5 vs the oracle), the number of rows that
     travel drops, and clearing the set restores the plain pull"""
@@ -129,7 +136,9 @@ def test_replicated_hot_rows_are_not_pulled(world, dtype):
     st = torch.cuda.Stream()
     engs = [shard_engine(rowptr, col, x, r, world, dtype, st) for r in range(world)]
     comms = Comm.local(engs)
-    plans = [DistSagePlan(comms[r], w, bs, b, FAN, group_roots=gr, max_window_end=bound_for(rowptr)) for r in range(world)]
+    tables = [e.project_features(w[0].to(e.device)) for e in engs] if pre else [None] * world
+    plans = [DistSagePlan(comms[r], w, bs, b, FAN, group_roots=gr, max_window_end=bound_for(rowptr), projected=tables[r])
+             for r in range(world)]
     roots = [rank_roots(r, b) for r in range(world)]
     roots_d = [torch.from_numpy(r.view(np.int32)).to(engs[0].device) for r in roots]
     # hot set: the 5 % of the nodes that occur most often as in-neighbours (the same set on every rank)
@@ -137,6 +146,9 @@ def test_replicated_hot_rows_are_not_pulled(world, dtype):
     hot = np.argsort(-occ, kind="stable")[: N // 20].astype(np.uint32)
     hot_ids = torch.from_numpy(hot.view(np.int32))
     hot_rows = torch.from_numpy(x[hot.astype(np.int64)]).to(dtype)
+    if pre:  # the replicas of a pre-projected plan are W_l x rows: the owners' own projected rows, gathered
+        hl = torch.from_numpy(hot.astype(np.int64))
+        hot_rows = torch.stack([tables[int(v) % world][int(v) // world, :HID] for v in hl]).contiguous()
 
     def pulled(plan):
         acc = torch.zeros(16, dtype=torch.int64, device=engs[0].device)
@@ -170,12 +182,12 @@ def test_replicated_hot_rows_are_not_pulled(world, dtype):
     assert [pulled(p) for p in plans] == plain
     for r in range(world):
         assert torch.equal(outs2[r], outs[r])  # same arithmetic: only where the rows are read from changed
-    # the projected-rows plan has no dense bookkeeping: replication is refused there
-    from gigl_amd import _lib
-    pp = DistSagePlan(comms[0], w, bs, b, FAN, group_roots=gr, project_on_owner=True, max_window_end=bound_for(rowptr))
-    with pytest.raises(_lib.GiglError):
-        pp.set_hot_rows(hot_ids, hot_rows)
-    pp.close()
+    if not pre:  # the owner-projected plan has no dense bookkeeping: replication is refused there
+        from gigl_amd import _lib
+        pp = DistSagePlan(comms[0], w, bs, b, FAN, group_roots=gr, project_on_owner=True, max_window_end=bound_for(rowptr))
+        with pytest.raises(_lib.GiglError):
+            pp.set_hot_rows(hot_ids, hot_rows)
+        pp.close()
     for p in plans:
         p.close()
     for c in comms:
@@ -313,6 +325,11 @@ def test_two_processes_one_gpu_callback_transport_over_gloo():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the build boxes have one)")
 def test_two_rccl_ranks_on_two_gpus():
     _spawn(2, "rccl")
+
+
+@pytest.mark.parametrize("world,dtype", [(2, torch.float32), (8, torch.float16)])
+def test_replicated_hot_rows_with_pre_projected_rows(world, dtype):
+    test_replicated_hot_rows_are_not_pulled(world, dtype, pre=True)
 
 
 def _gat_reference_rows(rowptr, col, x, model, roots, group_roots):
