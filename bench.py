@@ -862,7 +862,7 @@ def run_sharded(args, rank, world, local_rank, sub=False):
     class Slot:  # one plan in flight: ctx + stream + communicator + plan
         pass
 
-    def make_slots(pull_cap):
+    def make_slots(pull_cap, pull_cap_b=0):
         slots = []
         for si in range(S):
             sl = Slot()
@@ -877,7 +877,7 @@ def run_sharded(args, rank, world, local_rank, sub=False):
             else:
                 sl.plan = DistSagePlan(sl.comm, w, bs, G * B, fanouts, group_roots=B,
                                        project_on_owner=args.project_on_owner, pull_cap=pull_cap, max_window_end=mwe,
-                                       projected=proj_table)
+                                       projected=proj_table, pull_cap_b=pull_cap_b)
             sl.out = sl.plan.new_out()
             if hot_ids is not None:
                 sl.plan.set_hot_rows(hot_ids, hot_rows)
@@ -907,6 +907,7 @@ def run_sharded(args, rank, world, local_rank, sub=False):
             if acc is not None:
                 for sl, _ in live:
                     sl.plan.stats(acc)
+                    sl.plan.bucket_fill(fill_acc)
 
     def sync_all(slots):
         for sl in slots:
@@ -914,6 +915,7 @@ def run_sharded(args, rank, world, local_rank, sub=False):
 
     # ---- warm-up with default row buckets, then size them from what the warm-up saw (+10 %): rows are the bytes that
     # matter on the links, so the send buffers should not be padded more than that
+    fill_acc = torch.zeros(4, dtype=torch.int64, device=dev)
     slots = make_slots(0)
     acc0 = torch.zeros(STATS_LEN, dtype=torch.int64, device=dev)
     run_calls(slots, 0, Wp // G, acc0)
@@ -923,8 +925,11 @@ def run_sharded(args, rank, world, local_rank, sub=False):
     if int(acc0[STATS["overflow"]].item()):
         raise RuntimeError("bucket overflow during warm-up")
     pull_cap = int(int(most.item()) * 1.1) + 64
+    most_b = fill_acc[2:3].clone()
+    all_reduce(most_b, dist.ReduceOp.MAX)
+    pull_cap_b = int(int(most_b.item()) * 1.1) + 64 if proj_table is not None else 0
     close_slots(slots)
-    slots = make_slots(pull_cap)
+    slots = make_slots(pull_cap, pull_cap_b)
     run_calls(slots, 0, Wp // G)
     sync_all(slots)
     setup_s = time.time() - t0
@@ -1021,7 +1026,8 @@ def run_sharded(args, rank, world, local_rank, sub=False):
             cap_k = m_k if world <= 2 else min(m_k, int(1.5 * m_k / world) + 512)
             hop_sent += peers * cap_k * (8 + 4 * f)
             m_k *= f
-        rows_sent = peers * pull_cap * (row_bytes + 4) * (2 if args.project_on_owner else 1)
+        rows_sent = peers * pull_cap * (row_bytes + 4) * (2 if args.project_on_owner else 1) + \
+            peers * pull_cap_b * (row_bytes + 4)
         sent_step = (hop_sent + rows_sent) / G
         payload_step = pulled_all / (steps_total * world) * (row_bytes + 4) + \
             sampled_all / (steps_total * world) * 4 * peers / max(world, 1)

@@ -53,7 +53,7 @@ SYMBOLS = [
     "gigl_typed_records_encode", "gigl_typed_samples_encode", "gigl_hgt_aggregate_backward", "gigl_weighted_aggregate_backward",
     "gigl_graph_build_shard_from_coo", "gigl_json_rows_capacity", "gigl_json_rows_format",
     "gigl_sage_project_features", "gigl_sage_plan_set_projected_input",
-    "gigl_dist_gat_plan_create", "gigl_dist_gat_plan_set_weights",
+    "gigl_dist_gat_plan_create", "gigl_dist_gat_plan_set_weights", "gigl_dist_plan_bucket_fill",
 ]
 
 KERNEL_IDS = {
@@ -134,6 +134,7 @@ class GiglDistPlanOpts(C.Structure):
         ("hop_slack", C.c_float),
         ("max_window_end", C.c_int64),
         ("projected", C.c_void_p),
+        ("pull_cap_b", C.c_int64),
     ]
 STATS_LEN = 16
 STATS_SAMPLED, STATS_AGGREGATED = 0, 1  # GIGL_STATS_* slots of gigl_sage_plan_stats
@@ -236,6 +237,7 @@ def load() -> C.CDLL:
         "gigl_dist_gat_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), P(i32), vp, vp, vp, vp, C.c_float, i32,
                                       P(GiglDistPlanOpts), P(vp)],
         "gigl_dist_gat_plan_set_weights": [vp, vp, vp, vp, vp],
+        "gigl_dist_plan_bucket_fill": [vp, vp],
         "gigl_dist_plan_phases": [vp, P(i32)],
         "gigl_dist_plan_phase": [vp, i32, vp, i32, vp],
         "gigl_dist_plan_run": [vp, vp, i32, vp],

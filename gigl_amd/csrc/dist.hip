@@ -726,10 +726,12 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     // ---- owner: expand the requests of every peer on this shard
     const int k = phase >> 1;
     const int32_t hash_add = (int32_t)((uint32_t)seed * (uint32_t)(k + 1));
+    // (a one-rank world answers itself: straight into the receive buffer, no copy of the whole answer block)
+    const bool solo = world == 1 && comm_self_in_place(p->comm);
     rc = gigl_expand_frontier(ctx, p->shard, p->rq_nodes_r[k], p->rq_ksum_r[k], (int64_t)world * p->cap[k], p->fan[k],
-                              hash_add, p->world, p->mwe, p->resp_s[k], p->own_cnt);
+                              hash_add, p->world, p->mwe, solo ? p->resp_r[k] : p->resp_s[k], p->own_cnt);
     if (rc != GIGL_OK) return rc;
-    return comm_exchange(p->comm, p->resp_s[k], p->resp_r[k], p->cap[k] * p->fan[k] * 4);
+    return comm_exchange(p->comm, p->resp_s[k], p->resp_r[k], p->cap[k] * p->fan[k] * 4, solo);
   }
   if (phase == 2 * L) {
     // ---- requester: last scatter, union graph, feature requests
@@ -1135,7 +1137,8 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
        p->un.root_local && p->ids_s && p->ids_r && p->pos && p->pull_counts && p->rows_s && p->rows_r;
   p->n_entries_dev = (int32_t*)alloc(16);
   if (p->preproj && ok) {  // the second pull's buckets (W_r x of the inner nodes)
-    int64_t pcb = (int64_t)std::ceil((double)act_rows / (double)W * (W > 1 ? 1.25 : 1.0)) + 512;
+    int64_t pcb = opts && opts->pull_cap_b > 0 ? opts->pull_cap_b
+                                               : (int64_t)std::ceil((double)act_rows / (double)W * (W > 1 ? 1.25 : 1.0)) + 512;
     if (pcb > act_rows) pcb = act_rows;
     p->pull_cap_b = pcb;
     p->idsb_s = (uint32_t*)alloc((size_t)W * pcb * 4);
@@ -1295,6 +1298,32 @@ int32_t gigl_dist_plan_buffers(gigl_dist_plan* p, gigl_tree* tree, gigl_union* u
   if (!p) return GIGL_E_INVALID_ARG;
   if (tree) *tree = p->tree;
   if (un) *un = p->un;
+  return GIGL_OK;
+}
+
+namespace {
+__global__ void bucket_fill_kernel(const int32_t* pull, const int32_t* pullb, int world, unsigned long long* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int q = 0; q < 2; ++q) {
+    const int32_t* c = q ? pullb : pull;
+    if (!c) continue;
+    long long most = 0, sum = 0;
+    for (int r = 0; r < world; ++r) {
+      sum += c[r];
+      most = c[r] > most ? c[r] : most;
+    }
+    atomicMax(&out[2 * q], (unsigned long long)most);
+    atomicAdd(&out[2 * q + 1], (unsigned long long)sum);
+  }
+}
+}  // namespace
+
+int32_t gigl_dist_plan_bucket_fill(gigl_dist_plan* p, int64_t* acc4) {
+  if (!p || !acc4) return GIGL_E_INVALID_ARG;
+  GIGL_HIP_CHECK(p->ctx, hipSetDevice(p->ctx->device));
+  hipLaunchKernelGGL(bucket_fill_kernel, dim3(1), dim3(64), 0, p->ctx->stream, p->pull_counts, p->pullb_counts, p->world,
+                     (unsigned long long*)acc4);
+  GIGL_HIP_CHECK(p->ctx, hipGetLastError());
   return GIGL_OK;
 }
 

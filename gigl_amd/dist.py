@@ -384,7 +384,8 @@ class DistSagePlan:
 
     def __init__(self, comm: Comm, weights, biases, b: int, fanouts: Sequence[int], act_last: bool = False,
                  group_roots: Optional[int] = None, project_on_owner: bool = False, pull_cap: int = 0,
-                 hop_slack: float = 0.0, max_window_end: int = -1, projected: Optional[torch.Tensor] = None):
+                 hop_slack: float = 0.0, max_window_end: int = -1, projected: Optional[torch.Tensor] = None,
+                 pull_cap_b: int = 0):
         """projected: this rank's pre-projected rows (HipEngine.project_features of the SHARD's table with weights[0]:
         [shard rows, 2*out] fp32) — the pull moves W_l x rows, the first layer is one reduction (gigl_dist_plan_opts.
         projected); recompute and rebuild the plan after a weight update"""
@@ -406,6 +407,7 @@ class DistSagePlan:
             assert projected.is_cuda and projected.dtype == torch.float32 and projected.is_contiguous() and \
                 projected.shape[1] == 2 * self.dims[1]
             o.projected = projected.data_ptr()
+            o.pull_cap_b = int(pull_cap_b)
         fo = (C.c_int32 * L)(*self.fanouts)
         dims = (C.c_int32 * (L + 1))(*self.dims)
         _check(self._lib.gigl_dist_plan_create(comm._h, eng._graph, eng._feat, self.b, fo, L, dims, w_arr, b_arr,
@@ -472,6 +474,12 @@ class DistSagePlan:
     def stats(self, acc: torch.Tensor) -> None:
         assert acc.is_cuda and acc.dtype == torch.int64 and acc.numel() >= 16
         _check(self._lib.gigl_dist_plan_stats(self._plan, C.c_void_p(acc.data_ptr())), self.eng._ctx)
+
+    def bucket_fill(self, acc4: torch.Tensor) -> None:
+        """fold the feature-pull bucket fill of the step run last into acc4 (int64 [4], device): max / sum over peers of
+        the first pull, max / sum of a pre-projected plan's second pull (gigl_dist_plan_bucket_fill)"""
+        assert acc4.is_cuda and acc4.dtype == torch.int64 and acc4.numel() >= 4
+        _check(self._lib.gigl_dist_plan_bucket_fill(self._plan, C.c_void_p(acc4.data_ptr())), self.eng._ctx)
 
     def overflowed(self) -> bool:
         """True when the step run last failed (a hop / row bucket or the workspace overflowed: its output rows are NaN).

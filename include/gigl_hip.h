@@ -962,6 +962,8 @@ typedef struct gigl_dist_plan_opts {
                                 reduction — no projection per step, on owner or requester.  Two-hop plans, not with
                                 project_on_owner; replicated hot rows (gigl_dist_plan_set_hot_rows) are then W_l x rows
                                 ([n_hot][dims[1]] fp32). */
+  int64_t pull_cap_b;        /* rows per peer and step of the SECOND pull of a pre-projected plan (0: the worst case,
+                                every node of level < hops distinct; size it from gigl_dist_plan_bucket_fill) */
 } gigl_dist_plan_opts;
 int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
                               const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,
@@ -1000,6 +1002,10 @@ int32_t gigl_dist_plan_buffers(gigl_dist_plan* plan, gigl_tree* tree, gigl_union
  * fullest row bucket seen (PULL_BUCKET_MAX, a running maximum) */
 #define GIGL_STATS_PULLED_ROWS 14
 #define GIGL_STATS_PULL_BUCKET_MAX 15
+/* fill of the feature-pull buckets of the step run last, folded into acc4 (DEVICE int64[4], caller-zeroed): [0] max
+ * and [1] sum over peers of the rows requested in the first pull, [2] / [3] the same for a pre-projected plan's second
+ * pull — what pull_cap / pull_cap_b are calibrated from on warm-up steps (fixed-capacity buckets travel whole). */
+int32_t gigl_dist_plan_bucket_fill(gigl_dist_plan* plan, int64_t* acc4);
 int32_t gigl_dist_plan_stats(gigl_dist_plan* plan, int64_t* acc);
 int32_t gigl_dist_plan_destroy(gigl_dist_plan* plan);
 
