@@ -1078,7 +1078,7 @@ def run_train(args, rank, world, local_rank):
     esz = 4 if wl_dtype == torch.float32 else 2
     torch.manual_seed(0)
     model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, weight_decay=5e-4, capturable=True)
     model.train()
     mode = MODE_SPARK_HASH if args.mode == "parity" else MODE_FAST
     st = torch.cuda.Stream(device=dev)
@@ -1117,6 +1117,24 @@ def run_train(args, rank, world, local_rank):
     for i in range(W):
         step(i)
     st.synchronize()
+    # the step replayed as ONE HIP graph (gigl_amd.hbm.GraphedTrainStep: what the trainer's in-HBM route runs): the same
+    # launches without the host between them.  The eager step above stays for the per-kernel timers and the counts.
+    eager_step, graphed, driver = step, None, "eager launches from Python (torch autograd)"
+    if not os.environ.get("GIGL_BENCH_TRAIN_EAGER") and not args.timed_only:
+        from gigl_amd.hbm import GraphedTrainStep
+        try:
+            graphed = GraphedTrainStep(resident, model, opt, B, my[0], labels[my[0].long() & 0xFFFFFFFF])
+            lab_pool = labels[my.long() & 0xFFFFFFFF]  # [pool, B]
+
+            def step(i, count=False):  # noqa: F811
+                if count:
+                    return eager_step(i, True)
+                return graphed.step(my[i], lab_pool[i])
+            st = graphed.stream
+            driver = "one HIP graph per step (GraphedTrainStep), replayed over static inputs"
+        except Exception as exc:  # noqa: BLE001 — the eager loop is the same step, only slower
+            print(f"train: graph capture unavailable ({type(exc).__name__}: {str(exc)[:300]})", file=sys.stderr)
+            eng.bind_stream(st)
     if args.timed_only:  # counter-collection runs
         t1 = time.perf_counter()
         for i in range(W, W + K):
@@ -1135,8 +1153,8 @@ def run_train(args, rank, world, local_rank):
     P = min(K, 64)
     eng.profile_enable(names, capacity=P * 64)
     for i in range(W, W + P):
-        step(i)
-    st.synchronize()
+        eager_step(i)  # (timed launches must be eager: events inside a captured graph cannot be read)
+    torch.cuda.synchronize()
     prof = {k: eng.profile_read(k) for k in names}
     eng.profile_enable([], 0)
     # ---- timed region
@@ -1204,7 +1222,7 @@ def run_train(args, rank, world, local_rank):
                                             "(sample + union in HBM, forward with autograd, cross-entropy, backward, Adam), "
                                             "sampler mode=" + args.mode,
                        "entry": "ResidentGraph.hip_batch(train=True) -> GraphSAGE._forward_union_autograd (gigl_amd/hbm.py: "
-                                "the route Trainer.run takes)",
+                                "the route Trainer.run takes)", "driver": driver,
                        "sampled_edges_per_step": sampled, "aggregated_edges_per_step": agg,
                        "backward_scattered_edges_per_step": bwd, "setup_s": round(setup_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,

@@ -54,6 +54,7 @@ SYMBOLS = [
     "gigl_graph_build_shard_from_coo", "gigl_json_rows_capacity", "gigl_json_rows_format",
     "gigl_sage_project_features", "gigl_sage_plan_set_projected_input",
     "gigl_dist_gat_plan_create", "gigl_dist_gat_plan_set_weights", "gigl_dist_plan_bucket_fill",
+    "gigl_linear_weight_grad",
 ]
 
 KERNEL_IDS = {
@@ -238,6 +239,7 @@ def load() -> C.CDLL:
                                       P(GiglDistPlanOpts), P(vp)],
         "gigl_dist_gat_plan_set_weights": [vp, vp, vp, vp, vp],
         "gigl_dist_plan_bucket_fill": [vp, vp],
+        "gigl_linear_weight_grad": [vp, vp, vp, vp, vp, i64, i32, i32, vp, vp],
         "gigl_dist_plan_phases": [vp, P(i32)],
         "gigl_dist_plan_phase": [vp, i32, vp, i32, vp],
         "gigl_dist_plan_run": [vp, vp, i32, vp],

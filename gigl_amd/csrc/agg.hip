@@ -614,6 +614,126 @@ __global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict
   for (int j = 0; j < NT; ++j) store_block_32x32(acc[j], s_a[wv_id], lane, bias, act, m0, n0 + j * 32, M, N, y);
 }
 
+// Weight gradient of the projection: dW[n][k] += sum_{r < m} dy[r][n] * a[r][k]  (and db[n] += sum_r dy[r][n]), the ROWS
+// being the inner dimension — a small output over tens of thousands of rows, of which only the first *m_dev are real.
+// grid = (row chunks of RC rows) x (64-wide n tiles) x (64-wide k tiles): a workgroup stages 32 rows of its dy and a
+// tiles in LDS at a time, every thread keeps a 4 x 4 block of the 64 x 64 partial in registers and adds it to dW with
+// fp32 atomics at the end (one pass over the chunk's rows: the chunks are what parallelises the reduction).  With
+// relu_y, dy is masked by y > 0 on the way in (the activation's backward), so the masked gradient is never
+// materialised for this product.
+constexpr int WG_RC = 256;
+// (the partial tiles go to scratch — part[chunk][n][k], partb[chunk][n] — and a second kernel adds the chunks in order:
+// a fixed summation order, and no atomics piling up on the 256 x 200 addresses of dW)
+__global__ __launch_bounds__(256) void linear_weight_grad_kernel(const float* __restrict__ dy, const float* __restrict__ a,
+                                                                 const float* __restrict__ relu_y,
+                                                                 const int32_t* __restrict__ m_dev, int N, int K,
+                                                                 float* __restrict__ part, float* __restrict__ partb) {
+  __shared__ float s_dy[32][68];
+  __shared__ float s_a[32][68];
+  const int M = *m_dev;
+  const int r0 = blockIdx.x * WG_RC;
+  if (r0 >= M) return;
+  const int r1 = min(M, r0 + WG_RC);
+  const int n0 = blockIdx.y * 64, k0 = blockIdx.z * 64;
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  float colsum = 0.f;  // (k tile 0 only) column sums of dy: thread tid < 64 owns column n0 + tid
+  // staging: thread -> (row tid / 8 of the 32-row block, 8 columns); the NEXT block's operands are already in registers
+  // while the current block is multiplied
+  const int lr = tid >> 3, lc = (tid & 7) * 8;
+  const bool vec = ((N | K) & 3) == 0;
+  float rv[8], ru[8];
+  auto fetch = [&](int rb) {
+    const int row = rb + lr;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) rv[t] = ru[t] = 0.f;
+    if (row >= r1) return;
+    const float* pd = dy + (int64_t)row * N + n0 + lc;
+    const float* py = relu_y ? relu_y + (int64_t)row * N + n0 + lc : nullptr;
+    const float* pa = a + (int64_t)row * K + k0 + lc;
+    if (vec) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (n0 + lc + 4 * h < N) {
+          const float4_t v = *reinterpret_cast<const float4_t*>(pd + 4 * h);
+          float4_t m = {1.f, 1.f, 1.f, 1.f};
+          if (py) m = *reinterpret_cast<const float4_t*>(py + 4 * h);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) rv[4 * h + t] = (!py || m[t] > 0.f) ? v[t] : 0.f;
+        }
+        if (k0 + lc + 4 * h < K) {
+          const float4_t u = *reinterpret_cast<const float4_t*>(pa + 4 * h);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) ru[4 * h + t] = u[t];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (n0 + lc + t < N) rv[t] = (!py || py[t] > 0.f) ? pd[t] : 0.f;
+        if (k0 + lc + t < K) ru[t] = pa[t];
+      }
+    }
+  };
+  fetch(r0);
+  for (int rb = r0; rb < r1; rb += 32) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      s_dy[lr][lc + t] = rv[t];
+      s_a[lr][lc + t] = ru[t];
+    }
+    __syncthreads();
+    if (rb + 32 < r1) fetch(rb + 32);
+#pragma unroll 8
+    for (int r = 0; r < 32; ++r) {
+      const float4_t dv = *reinterpret_cast<const float4_t*>(&s_dy[r][ty * 4]);
+      const float4_t av = *reinterpret_cast<const float4_t*>(&s_a[r][tx * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += dv[i] * av[j];
+    }
+    if (partb && blockIdx.z == 0 && tid < 64)
+      for (int r = 0; r < 32; ++r) colsum += s_dy[r][tid];
+    __syncthreads();
+  }
+  float* pt = part + (int64_t)blockIdx.x * N * K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty * 4 + i;
+    if (n >= N) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + tx * 4 + j;
+      if (k < K) pt[(int64_t)n * K + k] = acc[i][j];
+    }
+  }
+  if (partb && blockIdx.z == 0 && tid < 64 && n0 + tid < N) partb[(int64_t)blockIdx.x * N + n0 + tid] = colsum;
+}
+
+// dw[i] += sum over the chunks that hold real rows of part[c][i] (in chunk order), likewise db
+__global__ __launch_bounds__(256) void linear_weight_grad_reduce_kernel(const float* __restrict__ part,
+                                                                        const float* __restrict__ partb,
+                                                                        const int32_t* __restrict__ m_dev, int64_t nk, int N,
+                                                                        float* __restrict__ dw, float* __restrict__ db) {
+  const int chunks = (*m_dev + WG_RC - 1) / WG_RC;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nk) {
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(int64_t)c * nk + i];
+    dw[i] += s;
+  }
+  if (db && i < N) {
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += partb[(int64_t)c * N + i];
+    db[i] += s;
+  }
+}
+
 // Split-precision variant: every fp32 operand is the exact sum of three bf16 numbers (x = b1 + b2 + b3: b1 = x with its
 // low 16 bits cleared, b2 = (x - b1) truncated the same way, b3 = the rest — 8 + 8 + 8 significand bits, the
 // subtractions are exact), so a.w = sum over the pairs (i, j) of a_i.w_j; the six pairs with i + j <= 4 carry every
@@ -2686,6 +2806,28 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
 // the projection over an A operand in the tiled layout gigl_gather_reduce_mixed(..., tiled_nkc) writes
 // ([row tile of 128][K chunk of 32][128 rows][32 floats], tiled_nkc = ceil(k / 32)); k % 4 == 0
 // y rows may be a column slice of wider rows (ldy floats apart): the per-head projections of gigl_gat_input_layer
+int32_t gigl_linear_weight_grad(gigl_ctx* ctx, const float* dy, const float* a, const float* relu_y, const int32_t* m_dev,
+                                int64_t m_cap, int32_t n, int32_t k, float* dw, float* db) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, dy && a && m_dev && dw, "null argument");
+  GIGL_REQUIRE(ctx, n > 0 && k > 0 && m_cap >= 0, "bad sizes");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (m_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
+  const int64_t chunks = (m_cap + WG_RC - 1) / WG_RC, nk = (int64_t)n * k;
+  int32_t rc = gigl_arena_reset(ctx, chunks * (nk + n) * 4 + 1024);
+  if (rc != GIGL_OK) return rc;
+  float* part = (float*)gigl_arena_alloc(ctx, chunks * nk * 4);
+  float* partb = db ? (float*)gigl_arena_alloc(ctx, chunks * n * 4) : nullptr;
+  if (!part || (db && !partb)) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  const dim3 grid((unsigned)chunks, (unsigned)((n + 63) / 64), (unsigned)((k + 63) / 64));
+  hipLaunchKernelGGL(linear_weight_grad_kernel, grid, dim3(256), 0, ctx->stream, dy, a, relu_y, m_dev, n, k, part, partb);
+  hipLaunchKernelGGL(linear_weight_grad_reduce_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, part,
+                     partb, m_dev, nk, n, dw, db);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
 static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias,
                                     const int32_t* m_dev, int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y,
                                     int32_t ldy, int32_t batch = 1, int64_t a_bstride = 0, int64_t w_bstride = 0,

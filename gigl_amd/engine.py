@@ -944,6 +944,19 @@ class HipEngine:
               self._ctx)
         return out
 
+    def linear_weight_grad(self, dy: torch.Tensor, a: torch.Tensor, m_dev: torch.Tensor, relu_y: Optional[torch.Tensor] = None,
+                           want_bias: bool = False):
+        """(dW [n, k], db [n] | None) = (dy^T a, column sums of dy) over the first *m_dev rows (gigl_linear_weight_grad);
+        relu_y: the layer's activated output, masks dy by relu_y > 0"""
+        assert dy.is_cuda and a.is_cuda and dy.is_contiguous() and a.is_contiguous() and dy.shape[0] == a.shape[0]
+        n, k = int(dy.shape[1]), int(a.shape[1])
+        dw = torch.zeros((n, k), dtype=torch.float32, device=self.device)
+        db = torch.zeros(n, dtype=torch.float32, device=self.device) if want_bias else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(self._lib.gigl_linear_weight_grad(self._ctx, p(dy), p(a), p(relu_y), p(m_dev), int(dy.shape[0]), n, k, p(dw),
+                                                p(db)), self._ctx)
+        return dw, db
+
     # ---- heterogeneous encoders (csrc/hetero.hip) ------------------------------------------------
     def hgt_aggregate(self, q, k, v, heads: int, dim: int, rowptr, col, etype, p_rel, n_dst: int, out) -> None:
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None

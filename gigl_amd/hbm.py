@@ -394,6 +394,78 @@ class ResidentGraph:
             self.engine = None
 
 
+class GraphedTrainStep:
+    """one training step on the in-HBM route — k-hop sample + batch union graph + forward with autograd + cross-entropy on
+    the roots + backward + the optimiser update — captured ONCE as a HIP graph and replayed per batch.  The step is the
+    same sequence of launches the eager loop issues (node_classification_modeling_task_spec.py:134-173 on batches sampled
+    in HBM); eager, it is bound by the host issuing ~60 small launches per batch from Python, replayed it is bound by the
+    kernels.  Every shape is a capacity (row counts stay on the device), so one capture serves every batch; the root ids
+    and labels of a batch are copied into the graph's static inputs.  A batch shorter than `b` is padded with its first
+    root (a repeated root adds nothing to the union graph) and masked out of the loss.
+
+    The optimiser must keep its step counter on the device (torch.optim.Adam(..., capturable=True))."""
+
+    def __init__(self, resident: "ResidentGraph", model, optimizer, b: int, warmup_roots: torch.Tensor,
+                 warmup_labels: torch.Tensor):
+        import copy
+        import torch.nn.functional as F
+        self.resident, self.model, self.opt, self.b = resident, model, optimizer, int(b)
+        dev = resident.device
+        self.roots = torch.zeros(self.b, dtype=torch.int32, device=dev)
+        self.labels = torch.zeros(self.b, dtype=torch.int64, device=dev)
+        self.mask = torch.ones(self.b, dtype=torch.float32, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        eng = resident.engine
+        torch.cuda.synchronize(dev)
+        eng.bind_stream(self.stream)
+        # warm-up iterations (allocator pools, library workspaces, cached constants) must not train: the model and the
+        # optimiser are put back afterwards
+        saved_model = copy.deepcopy(model.state_dict())
+        saved_opt = copy.deepcopy(optimizer.state_dict())
+        self._set(warmup_roots, warmup_labels)
+
+        def body():
+            hb = resident.hip_batch(self.roots, train=True)
+            out = model(hb)
+            per_row = F.cross_entropy(out[hb.root_local.long()], self.labels, reduction="none")
+            loss = (per_row * self.mask).sum() / self.mask.sum()
+            optimizer.zero_grad(set_to_none=True)
+            loss.backward()
+            optimizer.step()
+            return loss
+
+        with torch.cuda.stream(self.stream):
+            for _ in range(3):
+                body()
+        self.stream.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.loss = body()
+        self.stream.synchronize()
+        model.load_state_dict(saved_model)
+        optimizer.load_state_dict(saved_opt)
+
+    def _set(self, roots: torch.Tensor, labels: torch.Tensor) -> None:
+        k = int(roots.numel())
+        assert 0 < k <= self.b
+        with torch.cuda.stream(self.stream):
+            self.roots[:k].copy_(roots.to(torch.int32), non_blocking=True)
+            self.labels[:k].copy_(labels.to(self.labels.device, non_blocking=True), non_blocking=True)
+            if k < self.b:
+                self.roots[k:] = self.roots[0]
+                self.labels[k:] = self.labels[0]
+            self.mask[:k] = 1.0
+            self.mask[k:] = 0.0
+
+    def step(self, roots: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        """one optimiser step on the batch (`roots` int32 device ids [k <= b], labels int64 [k]); returns the loss (a
+        static device scalar, overwritten by the next step)"""
+        self._set(roots, labels)
+        with torch.cuda.stream(self.stream):
+            self.graph.replay()
+        return self.loss
+
+
 def encoder_takes_hip_batches(model) -> bool:
     """the encoders whose forward runs over a device-resident HipBatch (sampled trees + union graph)"""
     from .models import GraphSAGE

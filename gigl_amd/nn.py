@@ -90,13 +90,13 @@ class _SageConvFn(torch.autograd.Function):
         n = g.rows if view else int(h.shape[0])
         if h is not None:
             h = h.contiguous()
-        # rows beyond *n_dev are never written: they must read as zeros in the weight-gradient product
-        out = torch.zeros((n, 2 * d), dtype=torch.float32, device=w_l.device) if view else None
+        # (rows beyond *n_dev are never written and never read: the weight gradient runs over the real rows only)
+        out = torch.empty((n, 2 * d), dtype=torch.float32, device=w_l.device) if view else None
         a = eng.gather_mean(h, d, g.gather_ids if view else None, g.rowptr, g.rowend if view else None, g.col, g.n_dev,
                             n, out=out, aggr=aggr)
         wcat = torch.cat([w_l, w_r], dim=1).contiguous()
         y = eng.linear(a, wcat, b_l, g.n_dev, n, act,
-                       out=torch.zeros((n, int(w_l.shape[0])), dtype=torch.float32, device=w_l.device) if view else None)
+                       out=torch.empty((n, int(w_l.shape[0])), dtype=torch.float32, device=w_l.device) if view else None)
         ctx.eng, ctx.g, ctx.act, ctx.d, ctx.aggr = eng, g, act, d, aggr
         ctx.has_bias = b_l is not None
         ctx.src_rows = None if h is None else int(h.shape[0])
@@ -109,21 +109,19 @@ class _SageConvFn(torch.autograd.Function):
         eng, g, d = ctx.eng, ctx.g, ctx.d
         n = int(a.shape[0])
         dy = dy.contiguous()
-        if ctx.act == 1:
-            dy = dy * (y > 0).to(dy.dtype)
         dev = dy.device
-        # dW[N, 2d] = dy^T[N, n] @ a[n, 2d]: a small output with the ROWS as its inner dimension — a plain dense GEMM
-        # that wants split-K; it goes to the library (rocBLAS through torch, as the reference's autograd does), not to
-        # the row-tiled projection kernel, which would put the whole inner dimension on a handful of workgroups
-        dw = torch.mm(dy.t(), a)
+        # dW[N, 2d] = dy^T[N, n] a[n, 2d] and db = column sums of dy, over the layer's real rows only, the relu mask
+        # applied on the way in: one library launch (gigl_linear_weight_grad)
+        dw, db = eng.linear_weight_grad(dy, a, g.n_dev, relu_y=y if ctx.act == 1 else None, want_bias=ctx.has_bias)
         dh = None
         if ctx.needs_input_grad[0]:
+            if ctx.act == 1:
+                dy = dy * (y > 0).to(dy.dtype)
             # da[n, 2d] = dy[n, N] @ wcat[N, 2d]  ->  linear(a = dy, w = wcat^T)
             da = eng.linear(dy, wcat.t().contiguous(), None, g.n_dev, n, 0)
             dh = torch.zeros((ctx.src_rows, d), dtype=torch.float32, device=dev)
             eng.gather_mean_backward(da, d, g.rowptr, getattr(g, "rowend", None), g.col, g.n_dev, n, dh, aggr=ctx.aggr,
                                      src=ctx.saved_tensors[3] if ctx.aggr == "max" else None)
-        db = dy.sum(0) if ctx.has_bias else None
         return dh, dw[:, :d].contiguous(), db, dw[:, d:].contiguous(), None, None, None, None
 
 

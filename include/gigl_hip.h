@@ -721,6 +721,14 @@ int32_t gigl_gather_mean_backward(gigl_ctx* ctx, const float* dout, int32_t d, c
                                   const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
                                   int64_t rows_cap, float* dsrc);
 
+/* weight gradient of gigl_linear (training: the backward of PyG's Linear inside SAGEConv, which torch autograd computes
+ * as dy^T @ a): dw[n][k] += sum_{i < *m_dev} dy[i][n] a[i][k] and, when db != NULL, db[n] += sum_i dy[i][n] — the rows
+ * are the inner dimension and only the first *m_dev of the m_cap allocated rows are read (the rest may hold anything).
+ * relu_y != NULL ([m_cap][n], the layer's activated output): dy is masked by relu_y > 0 on the way in.  dw / db are
+ * ADDED to (zero them first); partial sums over chunks of 256 rows are combined in chunk order (reproducible). */
+int32_t gigl_linear_weight_grad(gigl_ctx* ctx, const float* dy, const float* a, const float* relu_y, const int32_t* m_dev,
+                                int64_t m_cap, int32_t n, int32_t k, float* dw, float* db);
+
 /* dense projection  y[i][0:n] = act( a[i][0:k] · w[0:n][0:k]^T + bias )  — fp32 MFMA
  * (v_mfma_f32_32x32x2_f32, exact f32).  w is row-major [n][k] (torch Linear layout; for SAGE
  * w = cat(lin_l.weight, lin_r.weight, dim=1)).  act: 0 none, 1 relu.  m read from *m_dev. */
