@@ -360,6 +360,7 @@ class ResidentGraph:
         if self.sharded:
             raise NotImplementedError("staged batches on a hash-partitioned graph: use the sharded plan (encode)")
         eng = self.engine
+        eng.bind_stream(torch.cuda.current_stream(self.device))  # (a no-op unless the caller's stream changed)
         tree = eng.sample_khop(roots, self.fanouts, sampling_seed=self.seed, mode=self.mode)
         u = eng.union_build(tree)
         return HipBatch(eng, tree, u, train=train)
@@ -421,7 +422,8 @@ class GraphedTrainStep:
         # warm-up iterations (allocator pools, library workspaces, cached constants) must not train: the model and the
         # optimiser are put back afterwards
         saved_model = copy.deepcopy(model.state_dict())
-        saved_opt = copy.deepcopy(optimizer.state_dict())
+        saved_opt = {p: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                     for p, st in optimizer.state.items()}
         self._set(warmup_roots, warmup_labels)
 
         def body():
@@ -443,7 +445,15 @@ class GraphedTrainStep:
             self.loss = body()
         self.stream.synchronize()
         model.load_state_dict(saved_model)
-        optimizer.load_state_dict(saved_opt)
+        # the optimiser's state tensors are part of the captured graph: put them back IN PLACE (moments and step counter
+        # to what they were before the warm-up — zeros for a fresh optimiser)
+        with torch.no_grad():
+            for p, st in optimizer.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        old = saved_opt.get(p, {}).get(k)
+                        v.copy_(old) if old is not None else v.zero_()
+        torch.cuda.synchronize(dev)
 
     def _set(self, roots: torch.Tensor, labels: torch.Tensor) -> None:
         k = int(roots.numel())

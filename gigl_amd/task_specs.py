@@ -110,8 +110,11 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
         return self._engine
 
     def setup_for_training(self):
+        # (capturable: the step counter lives on the device, so the in-HBM route can replay a whole training step as one
+        # HIP graph — hbm.GraphedTrainStep; the update itself is the same)
+        on_gpu = any(p.is_cuda for p in self.model.parameters())
         self._optimizer = torch.optim.Adam(self.model.parameters(), lr=self._optim_lr,
-                                           weight_decay=self._optim_weight_decay)
+                                           weight_decay=self._optim_weight_decay, capturable=on_gpu)
         self._train_loss_fn = lambda input, target: F.cross_entropy(input=input, target=target)
         self.model.train()
 
@@ -170,6 +173,7 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
         return splits
 
     def close(self) -> None:
+        self._graphed_step = None
         if self._resident is not None:
             self._resident.close()
             self._resident = None
@@ -226,6 +230,43 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
             dist.barrier()
         return loss
 
+    def _train_graphed(self, cfg: GbmlConfigPbWrapper, device: torch.device) -> Optional[torch.Tensor]:
+        """one epoch of the in-HBM route with every step replayed as one HIP graph (hbm.GraphedTrainStep: the launches of
+        _train over batches sampled in HBM, without the host between them).  Single process only (DistributedDataParallel
+        hooks its all-reduce into the backward pass); None = not applicable, the caller runs the eager loop."""
+        import os
+        if os.environ.get("GIGL_AMD_TRAIN_GRAPH", "1") == "0" or _rank_world()[1] > 1 or hasattr(self.model, "module"):
+            return None
+        hbm = self._hbm_split(cfg)
+        if hbm is None:
+            return None
+        ids, labels = hbm["train"]
+        if ids.size == 0:
+            return None
+        b = self._batch_size
+        res = self._resident
+        step = getattr(self, "_graphed_step", None)
+        if step is None:
+            from .hbm import GraphedTrainStep
+            r0 = torch.from_numpy(ids[:b].astype(np.uint32).view(np.int32)).to(device)
+            try:
+                step = GraphedTrainStep(res, self._inner_model(), self._optimizer, b, r0, torch.from_numpy(labels[:b]))
+            except Exception as exc:  # noqa: BLE001 — the eager loop is the same step
+                import warnings
+                warnings.warn(f"training step not captured ({type(exc).__name__}: {exc}); running it eagerly", RuntimeWarning)
+                os.environ["GIGL_AMD_TRAIN_GRAPH"] = "0"
+                res.engine.bind_stream(torch.cuda.current_stream(device))
+                return None
+            self._graphed_step = step
+        self.model.train()
+        roots_all = torch.from_numpy(ids.astype(np.uint32).view(np.int32)).to(device)
+        labels_all = torch.from_numpy(labels).to(device)
+        loss = None
+        for lo in range(0, ids.size, b):
+            loss = step.step(roots_all[lo:lo + b], labels_all[lo:lo + b])
+        step.stream.synchronize()
+        return loss.detach().clone()
+
     @no_grad_eval
     def infer_batch(self, batch: SupervisedNodeClassificationBatch, device: torch.device = torch.device("cpu")
                     ) -> InferBatchResults:
@@ -263,7 +304,9 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
         best_val_acc = 0.0
         self.history: List[Dict[str, float]] = []
         for epoch in range(self._num_epochs):
-            train_loss = self._train(self._split_batches(gbml_config_pb_wrapper, "train"), device)
+            train_loss = self._train_graphed(gbml_config_pb_wrapper, device)
+            if train_loss is None:
+                train_loss = self._train(self._split_batches(gbml_config_pb_wrapper, "train"), device)
             val_acc = self.score(self._split_batches(gbml_config_pb_wrapper, "val"), device)
             best_val_acc = max(best_val_acc, val_acc)
             self.history.append({"epoch": epoch, "loss": float(train_loss) if train_loss is not None else float("nan"),
