@@ -54,7 +54,7 @@ SYMBOLS = [
     "gigl_graph_build_shard_from_coo", "gigl_json_rows_capacity", "gigl_json_rows_format",
     "gigl_sage_project_features", "gigl_sage_plan_set_projected_input",
     "gigl_dist_gat_plan_create", "gigl_dist_gat_plan_set_weights", "gigl_dist_plan_bucket_fill",
-    "gigl_linear_weight_grad",
+    "gigl_linear_weight_grad", "gigl_features_row_crc",
 ]
 
 KERNEL_IDS = {
@@ -196,6 +196,7 @@ def load() -> C.CDLL:
         "gigl_graph_destroy": [vp],
         "gigl_features_load": [vp, i64, i32, i32, vp, i32, P(vp)],
         "gigl_features_device_ptr": [vp, P(vp), P(i64), P(i32), P(i32)],
+        "gigl_features_row_crc": [vp, vp, P(vp)],
         "gigl_features_destroy": [vp],
         "gigl_sample_khop": [vp, vp, vp, i32, P(i32), i32, i32, i32, P(GiglTree)],
         "gigl_sample_positives": [vp, vp, vp, i32, i32, i32, i32, vp, vp],

@@ -7,6 +7,8 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -65,6 +67,9 @@ struct gigl_feat {
   int32_t d = 0;
   int32_t dtype = 0;
   void* rows = nullptr;  // device [n][d]
+  // [n] raw CRC-32C state of every row's packed feature_values bytes (serialize.hip, built on first use)
+  uint32_t* row_crc = nullptr;
+  std::mutex row_crc_mu;
 };
 
 int32_t gigl_fail(gigl_ctx* ctx, int32_t code, const char* fmt, ...);

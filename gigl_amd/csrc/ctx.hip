@@ -286,6 +286,7 @@ int32_t gigl_features_destroy(gigl_feat* f) {
     hipStreamSynchronize(f->ctx->stream);
   }
   if (f->rows) hipFree(f->rows);
+  if (f->row_crc) hipFree(f->row_crc);
   delete f;
   return GIGL_OK;
 }

@@ -148,24 +148,6 @@ __device__ __forceinline__ uint32_t stream_node(const RecArgs& a, int64_t r, uin
   }
   return root;
 }
-// edge at edge-stream position q of record r: src NONE = no edge
-__device__ __forceinline__ void stream_edge(const RecArgs& a, int64_t r, uint32_t q, uint32_t& s, uint32_t& d) {
-  const uint32_t tt = q / (uint32_t)a.edge_len;
-  uint32_t local = q - tt * (uint32_t)a.edge_len;
-  const int64_t t = r * a.trees + tt;
-  const uint32_t root = a.roots[t];
-  s = d = NONE;
-  if (root == NONE) return;
-  for (int k = 0; k < a.hops; ++k) {
-    if (local < (uint32_t)a.slots[k]) {
-      s = a.nbr[k][t * a.slots[k] + local];
-      d = k == 0 ? root : a.nbr[k - 1][t * a.slots[k - 1] + local / (uint32_t)a.fan[k]];
-      return;
-    }
-    local -= (uint32_t)a.slots[k];
-  }
-}
-
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16;
   x *= 0x7feb352dU;
@@ -194,120 +176,208 @@ __device__ __forceinline__ uint32_t block_exscan(uint32_t v, uint32_t* s_w, uint
   return base + inc - v;
 }
 
-// The per-record plan, kept in LDS.
+// ---- wave-level pieces: one WAVE owns a record, so nothing below needs a workgroup barrier ----
+// LDS written by some lanes of a wave and read by others: the LDS queue is in order per wave; the fence keeps the
+// compiler from moving accesses across it
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// exclusive scan of one 64-bit value per lane; total = sum over the wave
+__device__ __forceinline__ unsigned long long wave_exscan64(unsigned long long v, unsigned long long& total) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  total = __shfl(inc, 63, 64);
+  return inc - v;
+}
+
+// The per-record plan.  It lives in LDS (one segment per wave), or — records whose stream is too long for it — in a
+// per-wave segment of the call's scratch (same code, the arrays are then global memory).
+//   ids      [n_s]       the record's node stream, tree by tree: hop-0 slots, hop-1 slots, ..., the tree's root;
+//                        NONE = empty slot.  Read from the sample ONCE; everything below works on this copy.
+//   hslot    [hash_cap]  open-addressing set over the stream: a slot holds the FIRST stream position of its id
+//                        (the key is ids[position]: 4 bytes per slot)
+//   eslot    [ehash_cap] the same over the edge stream (records that merge several trees only)
+//   uid, fld [n_s+1]     the record's Node fields in RECORD order — entry 0 = the root_node field (offset 0 of the
+//                        payload), entry 1 + u = the u-th distinct node in stream order: id, byte offset of the field
+//                        inside the Graph body (low FLD_BITS bits; the bits above: length of the field's header,
+//                        <= 24 bytes)
+//   edge_off [n_e]       byte offset of the edge inside the edge region, NONE = duplicate / empty
+constexpr uint32_t FLD_BITS = 27, FLD_MASK = (1u << FLD_BITS) - 1;
 struct Plan {
-  uint32_t* tmp;        // [n_s]    scratch of the node scan (field size of first occurrences)
-  uint32_t* uid;        // [n_s+1]  ids of the distinct nodes in stream order; entry n_uniq = the root (root_node field)
-  uint32_t* fld;        // [n_s+1]  byte offset of the node's field inside the Graph body
-  uint32_t* pay;        // [n_s+1]  byte offset of its float payload (field offset + header length)
-  uint32_t* edge_off;   // [n_e]    byte offset inside the edge region, NONE = duplicate / empty
-  uint32_t* edge_pay;   // [n_e]    (edge features only, write kernel) byte offset of the edge's float payload
-  uint32_t* edge_pos;   // [n_e]    (edge features only, write kernel) its position in the resident CSC
+  uint32_t *ids, *hslot, *eslot, *uid, *fld, *edge_off;
   uint32_t n_uniq, nodes_bytes, edges_bytes;
 };
 
-// builds the plan of record r.  LDS: hkeys/hpos = node hash (a.hash_cap entries), ekeys/epos = edge hash.
-__device__ void build_plan(const RecArgs& a, int64_t r, Plan& pl, uint32_t* hkeys, uint32_t* hpos,
-                           unsigned long long* ekeys, uint32_t* epos, uint32_t* s_w) {
+size_t plan_bytes(const RecArgs& a) {
+  const size_t n_s = (size_t)a.trees * a.tree_len, n_e = (size_t)a.trees * a.edge_len;
+  return (4 * (n_s + a.hash_cap + a.ehash_cap + 2 * (n_s + 1) + n_e) + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ void carve(const RecArgs& a, unsigned char* base, Plan& pl) {
+  const uint32_t n_s = (uint32_t)(a.trees * a.tree_len);
+  uint32_t* p = (uint32_t*)base;
+  pl.ids = p;
+  p += n_s;
+  pl.hslot = p;
+  p += a.hash_cap;
+  pl.eslot = p;
+  p += a.ehash_cap;
+  pl.uid = p;
+  p += n_s + 1;
+  pl.fld = p;
+  p += n_s + 1;
+  pl.edge_off = p;
+}
+
+// edge at edge-stream position q, from the plan's copy of the stream: src NONE = no edge
+__device__ __forceinline__ void plan_edge(const RecArgs& a, const uint32_t* ids, uint32_t q, uint32_t& s, uint32_t& d) {
+  const uint32_t tt = q / (uint32_t)a.edge_len;
+  const uint32_t local = q - tt * (uint32_t)a.edge_len;
+  const uint32_t* t_ids = ids + tt * (uint32_t)a.tree_len;
+  s = t_ids[local];
+  d = NONE;
+  if (s == NONE) return;
+  uint32_t prev_base = 0, base = 0;
+  for (int k = 0; k < a.hops; ++k) {
+    const uint32_t sl = (uint32_t)a.slots[k];
+    if (local < base + sl) {
+      d = k == 0 ? t_ids[a.tree_len - 1] : t_ids[prev_base + (local - base) / (uint32_t)a.fan[k]];
+      return;
+    }
+    prev_base = base;
+    base += sl;
+  }
+}
+__device__ __forceinline__ uint32_t edge_hash(uint32_t s, uint32_t d) { return hash32(s * 0x9E3779B1u ^ hash32(d)); }
+
+// first stream position of `id` (which is in the set)
+__device__ __forceinline__ uint32_t node_first(const RecArgs& a, const Plan& pl, uint32_t id) {
+  uint32_t h = hash32(id) & (a.hash_cap - 1);
+  for (;;) {
+    const uint32_t p = pl.hslot[h];
+    if (pl.ids[p] == id) return p;
+    h = (h + 1) & (a.hash_cap - 1);
+  }
+}
+__device__ __forceinline__ uint32_t edge_first(const RecArgs& a, const Plan& pl, uint32_t s, uint32_t d) {
+  uint32_t h = edge_hash(s, d) & (a.ehash_cap - 1);
+  for (;;) {
+    const uint32_t p = pl.eslot[h];
+    uint32_t ps, pd;
+    plan_edge(a, pl.ids, p, ps, pd);
+    if (ps == s && pd == d) return p;
+    h = (h + 1) & (a.ehash_cap - 1);
+  }
+}
+
+// builds the plan of record r (the 64 lanes of one wave)
+struct EncDbg {
+  unsigned long long* dbg;
+};
+#define PLAN_TICK(k)                                                    \
+  do {                                                                  \
+    if (e.dbg) {                                                        \
+      const unsigned long long now_ = wall_clock64();                   \
+      if ((threadIdx.x & 63) == 0) atomicAdd(&e.dbg[k], now_ - tick_);  \
+      tick_ = now_;                                                     \
+    }                                                                   \
+  } while (0)
+__device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int64_t r, Plan& pl, EncDbg e,
+                                                          unsigned long long& tick_) {
   const uint32_t n_s = (uint32_t)(a.trees * a.tree_len), n_e = (uint32_t)(a.trees * a.edge_len);
-  const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < a.hash_cap; i += 256) {
-    hkeys[i] = NONE;
-    hpos[i] = NONE;
-  }
-  for (uint32_t i = tid; i < a.ehash_cap; i += 256) {
-    ekeys[i] = ~0ull;
-    epos[i] = NONE;
-  }
-  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63;
+  for (uint32_t q = lane; q < n_s; q += 64) pl.ids[q] = stream_node(a, r, q);
+  for (uint32_t i = lane; i < a.hash_cap; i += 64) pl.hslot[i] = NONE;
+  for (uint32_t i = lane; i < a.ehash_cap; i += 64) pl.eslot[i] = NONE;
+  wave_sync();
+  PLAN_TICK(1);
   // first occurrence of every id in stream order
-  for (uint32_t q = tid; q < n_s; q += 256) {
-    const uint32_t id = stream_node(a, r, q);
+  for (uint32_t q = lane; q < n_s; q += 64) {
+    const uint32_t id = pl.ids[q];
     if (id == NONE) continue;
     uint32_t h = hash32(id) & (a.hash_cap - 1);
     for (;;) {
-      const uint32_t prev = atomicCAS(&hkeys[h], NONE, id);
-      if (prev == NONE || prev == id) break;
+      const uint32_t prev = atomicCAS(&pl.hslot[h], NONE, q);
+      if (prev == NONE) break;
+      if (pl.ids[prev] == id) {
+        if (prev > q) atomicMin(&pl.hslot[h], q);
+        break;
+      }
       h = (h + 1) & (a.hash_cap - 1);
     }
-    atomicMin(&hpos[h], q);
   }
   if (a.ehash_cap) {
-    for (uint32_t q = tid; q < n_e; q += 256) {
+    for (uint32_t q = lane; q < n_e; q += 64) {
       uint32_t s, d;
-      stream_edge(a, r, q, s, d);
+      plan_edge(a, pl.ids, q, s, d);
       if (s == NONE) continue;
-      const unsigned long long key = ((unsigned long long)s << 32) | d;
-      uint32_t h = hash32(s * 0x9E3779B1u ^ hash32(d)) & (a.ehash_cap - 1);
+      uint32_t h = edge_hash(s, d) & (a.ehash_cap - 1);
       for (;;) {
-        const unsigned long long prev = atomicCAS(&ekeys[h], ~0ull, key);
-        if (prev == ~0ull || prev == key) break;
+        const uint32_t prev = atomicCAS(&pl.eslot[h], NONE, q);
+        if (prev == NONE) break;
+        uint32_t ps, pd;
+        plan_edge(a, pl.ids, prev, ps, pd);
+        if (ps == s && pd == d) {
+          if (prev > q) atomicMin(&pl.eslot[h], q);
+          break;
+        }
         h = (h + 1) & (a.ehash_cap - 1);
       }
-      atomicMin(&epos[h], q);
     }
   }
-  __syncthreads();
-  // nodes: sizes of first occurrences, scanned in stream order (thread i owns a contiguous run)
+  wave_sync();
+  PLAN_TICK(2);
+  // nodes: field sizes of first occurrences, scanned in stream order (a lane owns a contiguous run); bytes in the
+  // low word, count in the high word of one 64-bit scan
   {
-    const uint32_t per = (n_s + 255) / 256, lo = min(tid * per, n_s), hi = min(lo + per, n_s);
-    uint32_t bytes = 0, cnt = 0;
+    const uint32_t per = (n_s + 63) / 64, lo = min(lane * per, n_s), hi = min(lo + per, n_s);
+    unsigned long long mine = 0;
     for (uint32_t q = lo; q < hi; ++q) {
-      const uint32_t id = stream_node(a, r, q);
-      bool first = false;
-      if (id != NONE) {
-        uint32_t h = hash32(id) & (a.hash_cap - 1);
-        while (hkeys[h] != id) h = (h + 1) & (a.hash_cap - 1);
-        first = hpos[h] == q;
-      }
-      pl.tmp[q] = first ? field_len(node_body_len(a, id)) : NONE;
-      if (first) {
-        bytes += pl.tmp[q];
-        ++cnt;
-      }
+      const uint32_t id = pl.ids[q];
+      if (id != NONE && node_first(a, pl, id) == q) mine += (1ull << 32) | field_len(node_body_len(a, id));
     }
-    uint32_t tot_b, tot_c;
-    uint32_t off_b = block_exscan(bytes, s_w, tot_b);
-    uint32_t off_c = block_exscan(cnt, s_w + 4, tot_c);
+    unsigned long long tot;
+    const unsigned long long off = wave_exscan64(mine, tot);
+    uint32_t off_b = (uint32_t)off, off_c = 1u + (uint32_t)(off >> 32);
     for (uint32_t q = lo; q < hi; ++q) {
-      const uint32_t sz = pl.tmp[q];
-      if (sz != NONE) {
-        const uint32_t id = stream_node(a, r, q);
+      const uint32_t id = pl.ids[q];
+      if (id != NONE && node_first(a, pl, id) == q) {
         pl.uid[off_c] = id;
-        pl.fld[off_c] = off_b;
-        pl.pay[off_c] = off_b + node_hdr_len(a, id);
+        pl.fld[off_c] = off_b | (node_hdr_len(a, id) << FLD_BITS);
         ++off_c;
-        off_b += sz;
+        off_b += field_len(node_body_len(a, id));
       }
     }
-    if (tid == 0) {  // pseudo-node n_uniq: the record's root_node field (offsets relative to the payload start)
-      const uint32_t root = a.roots[r * a.trees];
-      pl.uid[tot_c] = root;
-      pl.fld[tot_c] = 0;
-      pl.pay[tot_c] = node_hdr_len(a, root);
+    pl.nodes_bytes = (uint32_t)tot;
+    pl.n_uniq = (uint32_t)(tot >> 32);
+    if (lane == 0) {  // entry 0: the record's root_node field
+      const uint32_t root = pl.ids[a.tree_len - 1];
+      pl.uid[0] = root;
+      pl.fld[0] = node_hdr_len(a, root) << FLD_BITS;
     }
-    pl.nodes_bytes = tot_b;
-    pl.n_uniq = tot_c;
   }
+  PLAN_TICK(3);
   // edges
   {
-    const uint32_t per = (n_e + 255) / 256, lo = min(tid * per, n_e), hi = min(lo + per, n_e);
-    uint32_t bytes = 0;
+    const uint32_t per = (n_e + 63) / 64, lo = min(lane * per, n_e), hi = min(lo + per, n_e);
+    unsigned long long bytes = 0;
     for (uint32_t q = lo; q < hi; ++q) {
       uint32_t s, d;
-      stream_edge(a, r, q, s, d);
+      plan_edge(a, pl.ids, q, s, d);
       bool first = s != NONE;
-      if (first && a.ehash_cap) {
-        const unsigned long long key = ((unsigned long long)s << 32) | d;
-        uint32_t h = hash32(s * 0x9E3779B1u ^ hash32(d)) & (a.ehash_cap - 1);
-        while (ekeys[h] != key) h = (h + 1) & (a.ehash_cap - 1);
-        first = epos[h] == q;
-      }
-      pl.edge_off[q] = first ? field_len(edge_body_len(a, s, d)) : NONE;
-      if (first) bytes += pl.edge_off[q];
+      if (first && a.ehash_cap) first = edge_first(a, pl, s, d) == q;
+      const uint32_t sz = first ? field_len(edge_body_len(a, s, d)) : NONE;
+      pl.edge_off[q] = sz;
+      if (first) bytes += sz;
     }
-    uint32_t tot_b;
-    uint32_t off_b = block_exscan(bytes, s_w, tot_b);
+    unsigned long long tot;
+    uint32_t off_b = (uint32_t)wave_exscan64(bytes, tot);
     for (uint32_t q = lo; q < hi; ++q) {
       const uint32_t sz = pl.edge_off[q];
       if (sz != NONE) {
@@ -315,9 +385,10 @@ __device__ void build_plan(const RecArgs& a, int64_t r, Plan& pl, uint32_t* hkey
         off_b += sz;
       }
     }
-    pl.edges_bytes = tot_b;
+    pl.edges_bytes = (uint32_t)tot;
   }
-  __syncthreads();
+  wave_sync();
+  PLAN_TICK(4);
 }
 
 // sizes of the fixed parts of record r (uniform over the workgroup)
@@ -344,60 +415,6 @@ __device__ __forceinline__ Layout layout_of(const RecArgs& a, int64_t r, const P
 }
 
 extern __shared__ __align__(16) unsigned char s_dyn[];
-
-// carve the dynamic LDS (layout shared by both kernels)
-__device__ __forceinline__ void carve(const RecArgs& a, Plan& pl, uint32_t*& hkeys, uint32_t*& hpos,
-                                      unsigned long long*& ekeys, uint32_t*& epos, uint32_t*& crc_t) {
-  const uint32_t n_s = (uint32_t)(a.trees * a.tree_len), n_e = (uint32_t)(a.trees * a.edge_len);
-  unsigned char* p = s_dyn;
-  ekeys = (unsigned long long*)p;
-  p += (size_t)a.ehash_cap * 8;
-  epos = (uint32_t*)p;
-  p += (size_t)a.ehash_cap * 4;
-  hkeys = (uint32_t*)p;
-  p += (size_t)a.hash_cap * 4;
-  hpos = (uint32_t*)p;
-  p += (size_t)a.hash_cap * 4;
-  pl.tmp = (uint32_t*)p;
-  p += (size_t)n_s * 4;
-  pl.uid = (uint32_t*)p;
-  p += (size_t)(n_s + 1) * 4;
-  pl.fld = (uint32_t*)p;
-  p += (size_t)(n_s + 1) * 4;
-  pl.pay = (uint32_t*)p;
-  p += (size_t)(n_s + 1) * 4;
-  pl.edge_off = (uint32_t*)p;
-  p += (size_t)n_e * 4;
-  crc_t = (uint32_t*)p;  // [4][256] (write kernel only)
-  p += 4096;
-  pl.edge_pay = (uint32_t*)p;  // (write kernel with edge features only)
-  p += (size_t)n_e * 4;
-  pl.edge_pos = (uint32_t*)p;
-}
-
-size_t lds_bytes(const RecArgs& a, bool with_crc) {
-  const size_t n_s = (size_t)a.trees * a.tree_len, n_e = (size_t)a.trees * a.edge_len;
-  return (size_t)a.ehash_cap * 12 + (size_t)a.hash_cap * 8 + n_s * 4 + (n_s + 1) * 12 + n_e * 4 +
-         (with_crc ? 4096 + (a.de > 0 ? n_e * 8 : 0) : 0);
-}
-
-__global__ __launch_bounds__(256) void record_size_kernel(RecArgs a, int64_t* rec_size) {
-  __shared__ uint32_t s_w[8];
-  const int64_t r = blockIdx.x;
-  if (a.emit && !a.emit[r]) {
-    if (threadIdx.x == 0) rec_size[r] = 0;
-    return;
-  }
-  Plan pl;
-  uint32_t *hkeys, *hpos, *epos, *crc_t;
-  unsigned long long* ekeys;
-  carve(a, pl, hkeys, hpos, ekeys, epos, crc_t);
-  build_plan(a, r, pl, hkeys, hpos, ekeys, epos, s_w);
-  if (threadIdx.x == 0) {
-    const Layout L = layout_of(a, r, pl);
-    rec_size[r] = (int64_t)L.payload + (a.frame ? 16 : 0);
-  }
-}
 
 // exclusive scan of the record sizes (one workgroup); status = 1 when the output does not fit
 __global__ __launch_bounds__(1024) void record_scan_kernel(const int64_t* rec_size, int64_t n, int64_t cap,
@@ -437,85 +454,11 @@ __device__ __forceinline__ uint32_t feat_word(const RecArgs& a, uint32_t id, uin
   if (a.feat_dtype == GIGL_DTYPE_F32) return ((const uint32_t*)a.feat)[(int64_t)id * a.d + k];
   return __float_as_uint(__half2float(((const __half*)a.feat)[(int64_t)id * a.d + k]));
 }
-
-// header of a Node field (everything before the float payload), byte stores by one thread
-__device__ __forceinline__ void write_node_header(const RecArgs& a, uint8_t* q, uint8_t tag, uint32_t id) {
-  *q++ = tag;
-  q = put_varint(q, node_body_len(a, id));
-  if (id) {
-    *q++ = 0x08;
-    q = put_varint(q, id);
-  }
-  if (a.node_type >= 0) {
-    *q++ = 0x10;
-    q = put_varint(q, (uint32_t)a.node_type);
-  }
-  if (a.d > 0) {
-    *q++ = 0x1A;
-    put_varint(q, 4u * (uint32_t)a.d);
-  }
-}
-
-// header of an Edge field (everything before the float payload; the whole field without edge features); returns
-// the address right after it
-__device__ __forceinline__ uint8_t* write_edge(const RecArgs& a, uint8_t* p, uint8_t tag, uint32_t s, uint32_t d,
-                                               int32_t de) {
-  *p++ = tag;
-  p = put_varint(p, edge_body_len_de(a, s, d, de));
-  if (s) {
-    *p++ = 0x08;
-    p = put_varint(p, s);
-  }
-  if (d) {
-    *p++ = 0x10;
-    p = put_varint(p, d);
-  }
-  if (a.edge_type >= 0) {
-    *p++ = 0x18;
-    p = put_varint(p, (uint32_t)a.edge_type);
-  }
-  if (de > 0) {
-    *p++ = 0x22;
-    p = put_varint(p, 4u * (uint32_t)de);
-  }
-  return p;
-}
 __device__ __forceinline__ void put_word(uint8_t* p, uint32_t v) {
   p[0] = (uint8_t)v;
   p[1] = (uint8_t)(v >> 8);
   p[2] = (uint8_t)(v >> 16);
   p[3] = (uint8_t)(v >> 24);
-}
-// a label edge root -> t (pos_edges = 4 / hard_neg_edges = 2) with its features; returns the address after it
-__device__ __forceinline__ uint8_t* write_label_edge(const RecArgs& a, uint8_t* e, int which, uint32_t root,
-                                                     uint32_t t) {
-  const int32_t de = label_de(a, which);
-  e = write_edge(a, e, which == 0 ? 0x22 : 0x12, root, t, de);
-  if (de <= 0) return e;
-  const RecArgs::LabelEdges& lb = a.lab[which];
-  const float* row = nullptr;
-  if (lb.rowptr) {  // CSR by source: row `root`, ascending destinations
-    if ((int64_t)root < lb.n) {
-      int64_t lo = lb.rowptr[root];
-      const int64_t end = lb.rowptr[root + 1];
-      int64_t hi = end;
-      while (lo < hi) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (lb.col[mid] < t) lo = mid + 1;
-        else hi = mid;
-      }
-      if (lo < end && lb.col[lo] == t) row = lb.feat + lo * de;
-    }
-  } else {
-    const uint32_t at = edge_pos(a, root, t);
-    if (at != NONE) row = a.efeat + (int64_t)at * de;
-  }
-  for (int k = 0; k < de; ++k, e += 4) put_word(e, row ? __float_as_uint(row[k]) : 0u);
-  return e;
-}
-// feature word k of the edge at CSC position `pos` as the bit pattern the proto carries (zeros for an unknown edge)
-__device__ __forceinline__ uint32_t efeat_word(const RecArgs& a, uint32_t pos, uint32_t k) {
-  return pos == NONE ? 0u : __float_as_uint(a.efeat[(int64_t)pos * a.de + k]);
 }
 
 // ---- CRC-32C pieces (reflected domain: bit 31 of a word is the coefficient of x^0)
@@ -546,35 +489,192 @@ __device__ __forceinline__ uint32_t crc_word(const uint32_t* t, uint32_t c, uint
   return t[768 + (c & 0xFF)] ^ t[512 + ((c >> 8) & 0xFF)] ^ t[256 + ((c >> 16) & 0xFF)] ^ t[c >> 24];
 }
 __device__ __forceinline__ uint32_t mask_crc(uint32_t c) { return ((c >> 15) | (c << 17)) + 0xA282EAD8u; }
-
-__global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int64_t* rec_off,
-                                                           const int32_t* status, uint8_t* out) {
-  __shared__ uint32_t s_w[8];
-  __shared__ uint32_t s_x[4];
-  if (*status != 0) return;
-  const int64_t r = blockIdx.x;
-  if (a.emit && !a.emit[r]) return;
+// slicing-by-4 tables [4][256] built by the 256 threads of a workgroup
+__device__ __forceinline__ void build_crc_tables(uint32_t* crc_t) {
   const uint32_t tid = threadIdx.x;
-  const int lane = tid & 63, w = tid >> 6;
-  Plan pl;
-  uint32_t *hkeys, *hpos, *epos, *crc_t;
-  unsigned long long* ekeys;
-  carve(a, pl, hkeys, hpos, ekeys, epos, crc_t);
-  // slicing-by-4 tables
-  {
-    uint32_t c = tid;
-    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
-    crc_t[tid] = c;
-  }
+  uint32_t c = tid;
+  for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+  crc_t[tid] = c;
   __syncthreads();
   for (int j = 1; j < 4; ++j) {
     const uint32_t prev = crc_t[(j - 1) * 256 + tid];
     crc_t[j * 256 + tid] = (prev >> 8) ^ crc_t[prev & 0xFF];
     __syncthreads();
   }
-  build_plan(a, r, pl, hkeys, hpos, ekeys, epos, s_w);
-  const Layout L = layout_of(a, r, pl);
-  uint8_t* const rec = out + rec_off[r];
+}
+
+// A byte writer that folds what it writes into a CRC state (the bytes between the float payloads of a record are
+// CRC'd from registers while they are written, never re-read)
+struct CrcOut {
+  uint8_t* p;
+  uint32_t c;
+  const uint32_t* t;
+  __device__ __forceinline__ void byte(uint32_t b) {
+    *p++ = (uint8_t)b;
+    c = crc_byte(t, c, b & 0xFFu);
+  }
+  __device__ __forceinline__ void varint(uint64_t v) {
+    while (v >= 128) {
+      byte((uint32_t)(v | 0x80) & 0xFFu);
+      v >>= 7;
+    }
+    byte((uint32_t)v);
+  }
+  __device__ __forceinline__ void word(uint32_t v) {
+    byte(v & 0xFF);
+    byte((v >> 8) & 0xFF);
+    byte((v >> 16) & 0xFF);
+    byte(v >> 24);
+  }
+};
+
+// header of a Node field (everything before the float payload), byte stores by one thread
+__device__ __forceinline__ void write_node_header(const RecArgs& a, CrcOut& o, uint8_t tag, uint32_t id) {
+  o.byte(tag);
+  o.varint(node_body_len(a, id));
+  if (id) {
+    o.byte(0x08);
+    o.varint(id);
+  }
+  if (a.node_type >= 0) {
+    o.byte(0x10);
+    o.varint((uint32_t)a.node_type);
+  }
+  if (a.d > 0) {
+    o.byte(0x1A);
+    o.varint(4u * (uint32_t)a.d);
+  }
+}
+
+// header of an Edge field (everything before the float payload; the whole field without edge features)
+__device__ __forceinline__ void write_edge(const RecArgs& a, CrcOut& o, uint8_t tag, uint32_t s, uint32_t d, int32_t de) {
+  o.byte(tag);
+  o.varint(edge_body_len_de(a, s, d, de));
+  if (s) {
+    o.byte(0x08);
+    o.varint(s);
+  }
+  if (d) {
+    o.byte(0x10);
+    o.varint(d);
+  }
+  if (a.edge_type >= 0) {
+    o.byte(0x18);
+    o.varint((uint32_t)a.edge_type);
+  }
+  if (de > 0) {
+    o.byte(0x22);
+    o.varint(4u * (uint32_t)de);
+  }
+}
+// a label edge root -> t (pos_edges = 4 / hard_neg_edges = 2) with its features
+__device__ __forceinline__ void write_label_edge(const RecArgs& a, CrcOut& o, int which, uint32_t root, uint32_t t) {
+  const int32_t de = label_de(a, which);
+  write_edge(a, o, which == 0 ? 0x22 : 0x12, root, t, de);
+  if (de <= 0) return;
+  const RecArgs::LabelEdges& lb = a.lab[which];
+  const float* row = nullptr;
+  if (lb.rowptr) {  // CSR by source: row `root`, ascending destinations
+    if ((int64_t)root < lb.n) {
+      int64_t lo = lb.rowptr[root];
+      const int64_t end = lb.rowptr[root + 1];
+      int64_t hi = end;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (lb.col[mid] < t) lo = mid + 1;
+        else hi = mid;
+      }
+      if (lo < end && lb.col[lo] == t) row = lb.feat + lo * de;
+    }
+  } else {
+    const uint32_t at = edge_pos(a, root, t);
+    if (at != NONE) row = a.efeat + (int64_t)at * de;
+  }
+  for (int k = 0; k < de; ++k) o.word(row ? __float_as_uint(row[k]) : 0u);
+}
+// feature word k of the edge at CSC position `pos` as the bit pattern the proto carries (zeros for an unknown edge)
+__device__ __forceinline__ uint32_t efeat_word(const RecArgs& a, uint32_t pos, uint32_t k) {
+  return pos == NONE ? 0u : __float_as_uint(a.efeat[(int64_t)pos * a.de + k]);
+}
+
+// ---- per-row CRC table of a feature table ------------------------------------------------------------------------
+// out[id] = the raw CRC-32C state (initial state 0, no final inversion) of the 4*d bytes node id's packed
+// feature_values carry.  CRC-32C is linear over GF(2): the state after a message is (state before) * x^(8*len) +
+// (state of the message alone), so a record's checksum takes one shift + one xor per node instead of a pass over the
+// node's 4*d payload bytes — and a node's payload is the same in every record that holds it.  One wave per row.
+__global__ __launch_bounds__(256) void row_crc_kernel(const void* feat, int32_t dtype, int64_t n, int32_t d,
+                                                      const uint32_t* shift_tbl, uint32_t* out) {
+  __shared__ uint32_t crc_t[1024];
+  build_crc_tables(crc_t);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t per = ((uint32_t)d + 63u) / 64u;
+  const uint32_t lo = min((uint32_t)lane * per, (uint32_t)d), hi = min(lo + per, (uint32_t)d);
+  const uint32_t shift = hi < (uint32_t)d ? x8n_modp(shift_tbl, 4ull * ((uint32_t)d - hi)) : 0u;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + w; row < n; row += (int64_t)gridDim.x * 4) {
+    uint32_t c = 0;
+    if (dtype == GIGL_DTYPE_F32) {
+      const uint32_t* src = (const uint32_t*)feat + row * d;
+      for (uint32_t k = lo; k < hi; ++k) c = crc_word(crc_t, c, src[k]);
+    } else {
+      const __half* src = (const __half*)feat + row * d;
+      for (uint32_t k = lo; k < hi; ++k) c = crc_word(crc_t, c, __float_as_uint(__half2float(src[k])));
+    }
+    uint32_t part = c;
+    if (c && hi < (uint32_t)d) part = multmodp(shift, c);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part ^= __shfl_xor(part, o, 64);
+    if (lane == 0) out[row] = part;
+  }
+}
+
+#define ENC_TICK(k)                                                     \
+  do {                                                                  \
+    if (e.dbg) {                                                        \
+      const unsigned long long now_ = wall_clock64();                   \
+      if ((threadIdx.x & 63) == 0) atomicAdd(&e.dbg[k], now_ - tick_);  \
+      tick_ = now_;                                                     \
+    }                                                                   \
+  } while (0)
+
+// ---- the encoder: ONE pass, one WAVE per record -----------------------------------------------------------------
+// A persistent grid.  Every wave takes the next record from a ticket counter, builds its plan in its own LDS segment,
+// learns where the record starts from a decoupled look-back over the records before it (a record's wave publishes its
+// size as soon as the plan is known, then the running total once the look-back has reached a published total: tickets
+// are handed out in order, so every record looked back at is owned by a running wave) and writes the record.  The work
+// per record is a chain of short dependent steps (ids -> hash set -> scans -> look-back -> headers -> rows): waves
+// that own a record each and never meet at a barrier keep many such chains in flight per CU, which is what hides
+// their latency behind the row copies of the others.
+// Checksum: nothing is read back.  The bytes between the float payloads are folded into a CRC state while they are
+// written (CrcOut); a node's 4*d payload bytes contribute their tabulated state (gigl_features_row_crc) after one
+// table-driven shift of the running state; a lane chains the fields of a contiguous run and shifts its state to the
+// end of the payload once (state * x^(8*bytes_after) mod P), the wave xors the lanes' shares.
+struct EncArgs {
+  unsigned long long* desc;  // [n_records], zeroed per call: flag << 62 | bytes (flag 1 = own size, 2 = running total)
+  uint32_t* ticket;          // zeroed per call
+  unsigned char* scratch;    // plans that do not fit LDS: one segment per wave
+  size_t plan_stride;        // bytes between the plan segments of two waves
+  const uint32_t* row_crc;   // [feat_n] (row_crc_kernel); NULL only when d == 0
+  uint32_t x_row;            // x^(8 * 4d) mod P
+  int64_t out_cap;
+  unsigned long long* dbg;  // (measurement only, GIGL_ENC_DBG=1) [16] summed wall_clock64 ticks per phase
+  uint32_t skip;  // (measurement only, GIGL_ENC_SKIP) phases left out: 1 payload copy, 2 node fields, 4 edges, 16 look-back
+};
+constexpr unsigned long long DESC_SIZE = 1ull << 62, DESC_TOTAL = 2ull << 62, DESC_VAL = DESC_SIZE - 1;
+
+// the state after 4d more bytes of zeros: c * x^(8*4d), from the byte-sliced tables of that constant
+__device__ __forceinline__ uint32_t shift_row(const uint32_t* t, uint32_t c) {
+  return t[c & 0xFF] ^ t[256 + ((c >> 8) & 0xFF)] ^ t[512 + ((c >> 16) & 0xFF)] ^ t[768 + (c >> 24)];
+}
+// a state that ends `after` bytes before the end of the payload, as its share of the final state
+__device__ __forceinline__ uint32_t crc_share(const uint32_t* shift_tbl, uint32_t c, uint64_t after) {
+  return c ? multmodp(x8n_modp(shift_tbl, after), c) : 0u;
+}
+
+__device__ __attribute__((always_inline)) void write_record(const RecArgs& a, const EncArgs& e, const Plan& pl,
+                                                            const Layout& L, int64_t r, uint8_t* rec,
+                                                            const uint32_t* crc_t, const uint32_t* row_t,
+                                                            unsigned long long& tick_) {
+  const uint32_t lane = threadIdx.x & 63;
   uint8_t* const payload = rec + (a.frame ? 12 : 0);
   uint8_t* const hard_neg = payload + field_len(L.root_body);  // hard_neg_edges = 2 sits between root_node and neighborhood
   uint8_t* const graph_hdr = hard_neg + L.neg_bytes;
@@ -583,76 +683,87 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
   uint8_t* const pos = graph + L.graph_body;
   uint8_t* const suffix = pos + L.pos_bytes;
   uint8_t* const payload_end = suffix + L.suffix_len;
-
-  if (tid == 0) {
-    if (a.frame) {
-      uint32_t c = 0xFFFFFFFFu;
-      for (int b = 0; b < 8; ++b) {
-        const uint32_t byte = (uint32_t)((L.payload >> (8 * b)) & 0xFF);
-        rec[b] = (uint8_t)byte;
-        c = crc_byte(crc_t, c, byte);
-      }
-      const uint32_t m = mask_crc(c ^ 0xFFFFFFFFu);
-      for (int b = 0; b < 4; ++b) rec[8 + b] = (uint8_t)(m >> (8 * b));
+  const uint64_t n = L.payload;
+  uint32_t part = 0;  // this lane's share of the payload's CRC state
+  if (lane == 0 && a.frame) {
+    uint32_t c = 0xFFFFFFFFu;
+    for (int b = 0; b < 8; ++b) {
+      const uint32_t byte = (uint32_t)((L.payload >> (8 * b)) & 0xFF);
+      rec[b] = (uint8_t)byte;
+      c = crc_byte(crc_t, c, byte);
     }
-    uint8_t* q = graph_hdr;
-    *q++ = a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED ? 0x1A : 0x12;  // neighborhood = 3 / 2
-    put_varint(q, L.graph_body);
-    if (a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED) {
-      uint8_t* e = pos;
-      uint8_t* ng = hard_neg;
-      for (int tt = 1; tt < a.trees; ++tt) {
-        const uint32_t p = a.roots[r * a.trees + tt];
-        if (p == NONE) continue;
-        if (tt >= a.trees - a.neg_trees) ng = write_label_edge(a, ng, 1, L.root_id, p);  // hard_neg_edges = 2
-        else e = write_label_edge(a, e, 0, L.root_id, p);                                  // pos_edges = 4
-      }
-    }
+    const uint32_t m = mask_crc(c ^ 0xFFFFFFFFu);
+    for (int b = 0; b < 4; ++b) rec[8 + b] = (uint8_t)(m >> (8 * b));
   }
-  // root_node = 1 (pseudo-node n_uniq) and the distinct nodes of the neighbourhood (Graph.nodes = 2).
-  // headers: one thread per node
+  // root_node = 1 (entry 0) and the distinct nodes of the neighbourhood (Graph.nodes = 2; entries 1..n_uniq), in
+  // record order: a lane writes the headers of a contiguous run of entries and chains their checksum
   const uint32_t n_items = pl.n_uniq + 1;
-  for (uint32_t u = tid; u < n_items; u += 256) {
-    const bool is_root = u == pl.n_uniq;
-    write_node_header(a, (is_root ? payload : graph) + pl.fld[u], is_root ? 0x0A : 0x12, pl.uid[u]);
+  const uint32_t D4 = 4u * (uint32_t)a.d;
+  if (!(e.skip & 2)) {
+    const uint32_t per = (n_items + 63) / 64, lo = min(lane * per, n_items), hi = min(lo + per, n_items);
+    if (lo < hi) {
+      CrcOut o{payload, lo == 0 ? 0xFFFFFFFFu : 0u, crc_t};
+      for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t id = pl.uid[i];
+        if (i == 1) {  // hard_neg_edges = 2 and the Graph header sit between root_node and the first node
+          o.p = hard_neg;
+          if (a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED)
+            for (int tt = a.trees - a.neg_trees; tt < a.trees; ++tt) {
+              const uint32_t p = a.roots[r * a.trees + tt];
+              if (p != NONE) write_label_edge(a, o, 1, L.root_id, p);
+            }
+          o.byte(a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED ? 0x1A : 0x12);  // neighborhood = 3 / 2
+          o.varint(L.graph_body);
+        }
+        o.p = (i == 0 ? payload : graph) + (pl.fld[i] & FLD_MASK);
+        write_node_header(a, o, i == 0 ? 0x0A : 0x12, id);
+        if (a.d > 0) {
+          if (e.row_crc) o.c = shift_row(row_t, o.c) ^ ((int64_t)id < a.feat_n ? e.row_crc[id] : 0u);
+          o.p += D4;
+        }
+      }
+      part ^= crc_share(a.shift_tbl, o.c, n - (uint64_t)(o.p - payload));
+    }
   }
-  // float payloads: the (node, word) pairs are spread evenly over the 256 threads.  A payload starts at an
+  ENC_TICK(7);
+  // float payloads: the (entry, word) pairs are spread evenly over the 64 lanes.  A payload starts at an
   // arbitrary byte address: output word k of a node = funnel shift of source words k-1 and k, stored as an
   // aligned dword (head and tail bytes of a payload by byte stores, they share their dwords with headers).
-  if (a.d > 0) {
-    // item = (node, chunk of 4 output words); output words k = 0..D (word D only holds the tail bytes of a
+  if (a.d > 0 && !(e.skip & 1)) {
+    // item = (entry, chunk of 4 output words); output words k = 0..D (word D only holds the tail bytes of a
     // misaligned payload)
     const uint32_t D = (uint32_t)a.d, nch = (D + 4) / 4;
-    const uint32_t total = n_items * nch, du = 256u / nch, dc = 256u % nch;
+    const uint32_t total = n_items * nch, du = 64u / nch, dc = 64u % nch;
     const bool vec_rows = a.feat_dtype == GIGL_DTYPE_F32 && (D & 3u) == 0;  // rows are 16-byte aligned
-    uint32_t u = tid / nch, c = tid % nch;
+    uint32_t u = lane / nch, c = lane % nch;
     struct __attribute__((packed, aligned(4))) W4 {
       uint32_t x, y, z, w;
     };
-    constexpr int UNR = 2;  // row loads of UNR items are issued before any of them is consumed
-    for (uint32_t i0 = 0; i0 < total; i0 += 256 * UNR) {
-      uint32_t id[UNR], k0[UNR], w[UNR][4], pw[UNR];
+    constexpr int UNR = 4;  // row loads of UNR items are issued before any of them is consumed
+    for (uint32_t i0 = 0; i0 < total; i0 += 64 * UNR) {
+      uint32_t id[UNR], k0[UNR], wv[UNR][4], pw[UNR];
       uint8_t* dst[UNR];
       bool valid[UNR];
 #pragma unroll
       for (int j = 0; j < UNR; ++j) {
-        valid[j] = i0 + j * 256 + tid < total;
+        valid[j] = i0 + j * 64 + lane < total;
         k0[j] = 4u * c;
-        id[j] = pw[j] = w[j][0] = w[j][1] = w[j][2] = w[j][3] = 0;
+        id[j] = pw[j] = wv[j][0] = wv[j][1] = wv[j][2] = wv[j][3] = 0;
         dst[j] = nullptr;
         if (valid[j]) {
           id[j] = pl.uid[u];
-          dst[j] = (u == pl.n_uniq ? payload : graph) + pl.pay[u];
+          const uint32_t f = pl.fld[u];
+          dst[j] = (u == 0 ? payload : graph) + (f & FLD_MASK) + (f >> FLD_BITS);
           if (vec_rows && k0[j] + 3 < D && (int64_t)id[j] < a.feat_n) {
             const uint4 q = *(const uint4*)((const uint32_t*)a.feat + (int64_t)id[j] * D + k0[j]);
-            w[j][0] = q.x;
-            w[j][1] = q.y;
-            w[j][2] = q.z;
-            w[j][3] = q.w;
+            wv[j][0] = q.x;
+            wv[j][1] = q.y;
+            wv[j][2] = q.z;
+            wv[j][3] = q.w;
           } else {
 #pragma unroll
             for (uint32_t t = 0; t < 4; ++t)
-              if (k0[j] + t < D) w[j][t] = feat_word(a, id[j], k0[j] + t);
+              if (k0[j] + t < D) wv[j][t] = feat_word(a, id[j], k0[j] + t);
           }
           // word k0-1: lane-1 holds it (previous chunk of the same node) except in lane 0
           if (lane == 0 && c > 0) pw[j] = feat_word(a, id[j], k0[j] - 1);
@@ -666,7 +777,7 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
       }
 #pragma unroll
       for (int j = 0; j < UNR; ++j) {
-        uint32_t prev = __shfl_up(w[j][3], 1, 64);
+        uint32_t prev = __shfl_up(wv[j][3], 1, 64);
         if (!valid[j]) continue;
         if (k0[j] == 0) prev = 0;
         else if (lane == 0) prev = pw[j];
@@ -674,17 +785,17 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
         if (rr == 0) {
           uint32_t* o = (uint32_t*)dst[j] + k0[j];
           if (k0[j] + 3 < D) {
-            *(W4*)o = W4{w[j][0], w[j][1], w[j][2], w[j][3]};
+            *(W4*)o = W4{wv[j][0], wv[j][1], wv[j][2], wv[j][3]};
           } else {
 #pragma unroll
             for (uint32_t t = 0; t < 3; ++t)
-              if (k0[j] + t < D) o[t] = w[j][t];
+              if (k0[j] + t < D) o[t] = wv[j][t];
           }
         } else {
           uint32_t* o = (uint32_t*)(dst[j] - rr) + k0[j];
           const uint32_t sh = 8u * rr, sl = 32u - sh;
-          const uint32_t vs[4] = {(prev >> sl) | (w[j][0] << sh), (w[j][0] >> sl) | (w[j][1] << sh),
-                                  (w[j][1] >> sl) | (w[j][2] << sh), (w[j][2] >> sl) | (w[j][3] << sh)};
+          const uint32_t vs[4] = {(prev >> sl) | (wv[j][0] << sh), (wv[j][0] >> sl) | (wv[j][1] << sh),
+                                  (wv[j][1] >> sl) | (wv[j][2] << sh), (wv[j][2] >> sl) | (wv[j][3] << sh)};
           if (k0[j] > 0 && k0[j] + 3 < D) {
             *(W4*)o = W4{vs[0], vs[1], vs[2], vs[3]};
           } else {
@@ -705,64 +816,135 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, const int6
       }
     }
   }
-  // Graph.edges = 3: one thread per edge
-  const uint32_t n_e = (uint32_t)(a.trees * a.edge_len);
-  for (uint32_t q = tid; q < n_e; q += 256) {
-    if (pl.edge_off[q] == NONE) continue;
-    uint32_t s, d;
-    stream_edge(a, r, q, s, d);
-    uint8_t* const pay = write_edge(a, edges + pl.edge_off[q], 0x1A, s, d, a.de);
-    if (a.de > 0) {
-      pl.edge_pay[q] = (uint32_t)(pay - edges);
-      pl.edge_pos[q] = edge_pos(a, s, d);
+  ENC_TICK(8);
+  // Graph.edges = 3: a lane writes a contiguous run of the edge stream (fields are contiguous in stream order) —
+  // header, then the edge's feature row — and chains the checksum
+  if (!(e.skip & 4)) {
+    const uint32_t n_e = (uint32_t)(a.trees * a.edge_len);
+    const uint32_t per = (n_e + 63) / 64, lo = min(lane * per, n_e), hi = min(lo + per, n_e);
+    CrcOut o{nullptr, 0u, crc_t};
+    for (uint32_t q = lo; q < hi; ++q) {
+      const uint32_t eo = pl.edge_off[q];
+      if (eo == NONE) continue;
+      uint32_t s, d;
+      plan_edge(a, pl.ids, q, s, d);
+      o.p = edges + eo;
+      write_edge(a, o, 0x1A, s, d, a.de);
+      if (a.de > 0) {
+        const uint32_t at = edge_pos(a, s, d);
+        for (int k = 0; k < a.de; ++k) o.word(efeat_word(a, at, (uint32_t)k));
+      }
     }
+    if (o.p) part ^= crc_share(a.shift_tbl, o.c, n - (uint64_t)(o.p - payload));
   }
-  if (a.de > 0) {  // float payloads of the edges: the (edge, word) pairs spread over the workgroup
-    __syncthreads();
-    const uint32_t De = (uint32_t)a.de, total = n_e * De;
-    for (uint32_t i = tid; i < total; i += 256) {
-      const uint32_t q = i / De, k = i - q * De;
-      if (pl.edge_off[q] == NONE) continue;
-      put_word(edges + pl.edge_pay[q] + 4u * k, efeat_word(a, pl.edge_pos[q], k));
+  ENC_TICK(9);
+  if (lane == 63 && L.pos_bytes) {  // pos_edges = 4, after the graph
+    CrcOut o{pos, 0u, crc_t};
+    for (int tt = 1; tt < a.trees - a.neg_trees; ++tt) {
+      const uint32_t p = a.roots[r * a.trees + tt];
+      if (p != NONE) write_label_edge(a, o, 0, L.root_id, p);
     }
+    part ^= crc_share(a.shift_tbl, o.c, n - (uint64_t)(o.p - payload));
   }
-  if (L.suffix_len) {
+  if (L.suffix_len) {  // a contiguous chunk per lane
     const uint8_t* src = a.suffix + a.suffix_off[r];
-    for (uint64_t i = tid; i < L.suffix_len; i += 256) suffix[i] = src[i];
+    const uint64_t C = (L.suffix_len + 63) / 64, lo = min((uint64_t)lane * C, L.suffix_len), hi = min(lo + C, L.suffix_len);
+    if (lo < hi) {
+      CrcOut o{suffix + lo, 0u, crc_t};
+      for (uint64_t i = lo; i < hi; ++i) o.byte(src[i]);
+      part ^= crc_share(a.shift_tbl, o.c, L.suffix_len - hi);
+    }
   }
   if (!a.frame) return;
-  __threadfence_block();
-  __syncthreads();
-  // CRC-32C of the payload: lane l folds bytes [l*C, (l+1)*C) (C a multiple of 4), lane 0 carries the 0xFFFFFFFF
-  // initial state; state_l * x^(8*bytes_after_l) summed over lanes = the state after the whole message
-  {
-    const uint64_t n = L.payload;
-    const uint64_t C = ((n + 255) / 256 + 3) & ~3ull;
-    const uint64_t lo = min((uint64_t)tid * C, n), hi = min(lo + C, n);
-    uint32_t c = tid == 0 ? 0xFFFFFFFFu : 0u;
-    const uint8_t* p = payload + lo;
-    const uint8_t* const e = payload + hi;
-    while (p < e && ((uintptr_t)p & 3u)) c = crc_byte(crc_t, c, *p++);
-    for (; p + 16 <= e; p += 16) {  // four loads in flight per lane
-      const uint32_t w0 = ((const uint32_t*)p)[0], w1 = ((const uint32_t*)p)[1], w2 = ((const uint32_t*)p)[2],
-                     w3 = ((const uint32_t*)p)[3];
-      c = crc_word(crc_t, c, w0);
-      c = crc_word(crc_t, c, w1);
-      c = crc_word(crc_t, c, w2);
-      c = crc_word(crc_t, c, w3);
-    }
-    for (; p + 4 <= e; p += 4) c = crc_word(crc_t, c, *(const uint32_t*)p);
-    while (p < e) c = crc_byte(crc_t, c, *p++);
-    uint32_t part = 0;
-    if (c) part = multmodp(x8n_modp(a.shift_tbl, n - hi), c);
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) part ^= __shfl_xor(part, o, 64);
-    if (lane == 0) s_x[w] = part;
-    __syncthreads();
-    if (tid == 0) {
-      const uint32_t m = mask_crc((s_x[0] ^ s_x[1] ^ s_x[2] ^ s_x[3]) ^ 0xFFFFFFFFu);
-      for (int b = 0; b < 4; ++b) payload_end[b] = (uint8_t)(m >> (8 * b));
+  for (int o = 32; o >= 1; o >>= 1) part ^= __shfl_xor(part, o, 64);
+  if (lane == 0) {
+    const uint32_t m = mask_crc(part ^ 0xFFFFFFFFu);
+    for (int b = 0; b < 4; ++b) payload_end[b] = (uint8_t)(m >> (8 * b));
+  }
+  ENC_TICK(10);
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(1024) void record_encode_kernel(RecArgs a, EncArgs e, uint8_t* out, int64_t* rec_off,
+                                                            int32_t* status) {
+  __shared__ uint32_t crc_t[1024];
+  __shared__ uint32_t row_t[1024];
+  const uint32_t tid = threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6, waves = blockDim.x >> 6;
+  Plan pl;
+  if constexpr (BIG) carve(a, e.scratch + ((size_t)blockIdx.x * waves + w) * e.plan_stride, pl);
+  else carve(a, s_dyn + (size_t)w * e.plan_stride, pl);
+  for (uint32_t i = tid; i < 256; i += blockDim.x) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+    crc_t[i] = c;
+  }
+  __syncthreads();
+  for (int j = 1; j < 4; ++j) {
+    for (uint32_t i = tid; i < 256; i += blockDim.x) {
+      const uint32_t prev = crc_t[(j - 1) * 256 + i];
+      crc_t[j * 256 + i] = (prev >> 8) ^ crc_t[prev & 0xFF];
     }
+    __syncthreads();
+  }
+  for (uint32_t i = tid; i < 1024; i += blockDim.x) row_t[i] = multmodp(e.x_row, (i & 255u) << (8 * (i >> 8)));
+  __syncthreads();
+  // from here on the waves of the workgroup go their own ways
+  unsigned long long tick_ = e.dbg ? wall_clock64() : 0;
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(e.ticket, 1u);
+    const int64_t r = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (r >= a.n_records) break;
+    ENC_TICK(0);
+    const bool emit = !a.emit || a.emit[r];
+    Layout L{};
+    int64_t size = 0;
+    if (emit) {
+      build_plan(a, r, pl, EncDbg{e.dbg}, tick_);
+      L = layout_of(a, r, pl);
+      size = (int64_t)L.payload + (a.frame ? 16 : 0);
+    }
+    ENC_TICK(5);
+    long long excl = 0;  // where the record starts: sizes of the records before it
+    if (e.skip & 16) {
+      excl = r * 41400;
+    } else {
+      if (lane == 0)
+        __hip_atomic_store(&e.desc[r], (r == 0 ? DESC_TOTAL : DESC_SIZE) | (unsigned long long)size, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      for (int64_t j = r - 1; j >= 0; j -= 64) {
+        const int64_t idx = j - lane;
+        unsigned long long v;
+        for (;;) {
+          v = idx >= 0 ? __hip_atomic_load(&e.desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : DESC_TOTAL;
+          if (__ballot((v >> 62) == 0) == 0) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        const unsigned long long totals = __ballot((v >> 62) == 2);
+        long long val = (long long)(v & DESC_VAL);
+        if (totals && lane > __ffsll((long long)totals) - 1) val = 0;  // nothing beyond the nearest running total
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) val += __shfl_xor(val, o, 64);
+        excl += val;
+        if (totals) break;
+      }
+      if (lane == 0 && r > 0)
+        __hip_atomic_store(&e.desc[r], DESC_TOTAL | (unsigned long long)(excl + size), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ENC_TICK(6);
+    const int64_t off = excl;
+    const bool fits = off + size <= e.out_cap;
+    if (lane == 0) {
+      rec_off[r] = off;
+      if (r == a.n_records - 1) rec_off[a.n_records] = off + size;
+      if (!fits) *status = 1;
+    }
+    if (emit && fits) write_record(a, e, pl, L, r, out + off, crc_t, row_t, tick_);
+    wave_sync();
+    ENC_TICK(11);  // the plan's storage is reused by the wave's next record
   }
 }
 
@@ -1135,7 +1317,10 @@ uint32_t next_pow2(uint32_t x) {
   return p;
 }
 
-constexpr int64_t MAX_STREAM = 2048;  // node-stream positions per record the LDS plan is sized for
+// node-stream positions per record: the plan is held in LDS while it fits (PLAN_LDS_BYTES: ~5,000 positions of a
+// one-tree record), in a per-workgroup scratch segment beyond that
+constexpr int64_t MAX_STREAM = 1 << 20;
+constexpr size_t PLAN_LDS_BYTES = 144 * 1024;
 
 int32_t fill_args(gigl_ctx* ctx, const int32_t* fanouts, int32_t hops, const gigl_record_opts* o, RecArgs& a) {
   GIGL_REQUIRE(ctx, fanouts && o, "null argument");
@@ -1157,7 +1342,7 @@ int32_t fill_args(gigl_ctx* ctx, const int32_t* fanouts, int32_t hops, const gig
     a.slots[k] = (int32_t)s;
   }
   if ((sum + 1) * o->trees_per_record > MAX_STREAM)
-    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "record of %lld tree slots exceeds the %lld the in-LDS plan holds",
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "record of %lld tree slots exceeds the %lld the record plan holds",
                      (long long)((sum + 1) * o->trees_per_record), (long long)MAX_STREAM);
   a.hops = hops;
   a.trees = o->trees_per_record;
@@ -1170,9 +1355,21 @@ int32_t fill_args(gigl_ctx* ctx, const int32_t* fanouts, int32_t hops, const gig
   a.emit = o->emit;
   a.suffix = o->suffix;
   a.suffix_off = o->suffix_off;
-  a.hash_cap = next_pow2((uint32_t)(2 * a.trees * a.tree_len));
-  a.ehash_cap = a.trees > 1 ? next_pow2((uint32_t)(2 * a.trees * a.edge_len)) : 0;
+  a.hash_cap = next_pow2((uint32_t)(3 * a.trees * a.tree_len / 2 + 8));  // load factor 1/3 .. 2/3
+  a.ehash_cap = a.trees > 1 ? next_pow2((uint32_t)(3 * a.trees * a.edge_len / 2 + 8)) : 0;
   return GIGL_OK;
+}
+
+// x^(8*n) mod P
+uint32_t host_x8n(uint64_t n) {
+  uint32_t sq = 1u << 30;  // x^1
+  for (int k = 0; k < 3; ++k) sq = host_multmodp(sq, sq);  // x^8
+  uint32_t p = 1u << 31;  // x^0
+  for (; n; n >>= 1) {
+    if (n & 1) p = host_multmodp(sq, p);
+    sq = host_multmodp(sq, sq);
+  }
+  return p;
 }
 
 // x^(8*b*256^j) mod P for j = 0..2, b = 0..255 (ctx-owned device table, built once)
@@ -1303,25 +1500,116 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
   rc = ensure_shift_table(ctx);
   if (rc != GIGL_OK) return rc;
   a.shift_tbl = ctx->crc_shift_tbl;
-  rc = gigl_arena_reset(ctx, (n_records + 1) * 8 + 256);
-  if (rc != GIGL_OK) return rc;
-  int64_t* rec_size = (int64_t*)gigl_arena_alloc(ctx, (n_records + 1) * 8);
-  if (!rec_size) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
-  const size_t lds_a = lds_bytes(a, false), lds_b = lds_bytes(a, true);
-  if (lds_b > 60 * 1024) {
-    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)record_size_kernel,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a));
-    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)record_write_kernel,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+  {  // offsets inside a record are 27-bit (Plan::fld) and its checksum shifts are tabulated below 2^24 bytes
+    int64_t one = 0;
+    gigl_records_capacity(tree->fanouts, tree->hops, a.d, opts, 1, 0, &one);
+    GIGL_REQUIRE(ctx, one < ((int64_t)1 << 24), "a record of up to %lld bytes: the encoder holds records below 16 MiB",
+                 (long long)one);
   }
-  if (n_records > 0)
-    hipLaunchKernelGGL(record_size_kernel, dim3((unsigned)n_records), dim3(256), lds_a, ctx->stream, a, rec_size);
-  hipLaunchKernelGGL(record_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, rec_size, n_records, out_cap,
-                     rec_off, status);
-  if (n_records > 0)
-    hipLaunchKernelGGL(record_write_kernel, dim3((unsigned)n_records), dim3(256), lds_b, ctx->stream, a, rec_off,
-                       status, out);
+  EncArgs e{};
+  e.out_cap = out_cap;
+  e.x_row = host_x8n(4ull * (uint64_t)a.d);
+  if (const char* sk = getenv("GIGL_ENC_SKIP")) e.skip = (uint32_t)atoi(sk);
+  static unsigned long long* dbg_buf = nullptr;
+  if (getenv("GIGL_ENC_DBG")) {
+    if (!dbg_buf) {
+      (void)hipMalloc((void**)&dbg_buf, 16 * 8);
+      (void)hipMemset(dbg_buf, 0, 16 * 8);
+    }
+    e.dbg = dbg_buf;
+    unsigned long long h[16];
+    (void)hipMemcpy(h, dbg_buf, sizeof h, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[enc dbg ticks]");
+    for (int k = 0; k < 12; ++k) fprintf(stderr, " %llu", h[k]);
+    fprintf(stderr, "\n");
+    (void)hipMemset(dbg_buf, 0, 16 * 8);
+  }
+  if (feat && a.frame && a.d > 0) {
+    const uint32_t* rc_tbl = nullptr;
+    rc = gigl_features_row_crc(ctx, feat, &rc_tbl);
+    if (rc != GIGL_OK) return rc;
+    e.row_crc = rc_tbl;
+  }
+  // persistent grid of waves, one record per wave at a time: the workgroup shape that keeps most waves per CU
+  const size_t plan = plan_bytes(a);
+  const bool big = plan > PLAN_LDS_BYTES;
+  const void* kern = big ? (const void*)record_encode_kernel<true> : (const void*)record_encode_kernel<false>;
+  if (!big && plan + 9 * 1024 > 48 * 1024)
+    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLAN_LDS_BYTES));
+  int cus = 0, waves = 1, per_cu = 1;
+  GIGL_HIP_CHECK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+  {
+    int best = 0;
+    for (int w : {16, 12, 8, 6, 4, 2, 1}) {
+      if (!big && (size_t)w * plan > PLAN_LDS_BYTES) continue;
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * w, big ? 0 : (size_t)w * plan) != hipSuccess) {
+        (void)hipGetLastError();
+        continue;
+      }
+      if (nb * w > best) {
+        best = nb * w;
+        waves = w;
+        per_cu = nb;
+      }
+    }
+    GIGL_REQUIRE(ctx, best > 0, "no launch shape for a record plan of %zu bytes", plan);
+  }
+  const size_t lds = big ? 0 : (size_t)waves * plan;
+  int64_t grid = (int64_t)per_cu * (cus > 0 ? cus : 1);
+  if (grid * waves > n_records) grid = (n_records + waves - 1) / waves;
+  if (grid < 1) grid = 1;
+  const int64_t desc_bytes = (n_records + 1) * 8 + 256;
+  e.plan_stride = big ? (plan + 255) & ~(size_t)255 : plan;
+  const int64_t scratch_bytes = big ? (int64_t)e.plan_stride * grid * waves : 0;
+  rc = gigl_arena_reset(ctx, desc_bytes + 512 + scratch_bytes);
+  if (rc != GIGL_OK) return rc;
+  e.desc = (unsigned long long*)gigl_arena_alloc(ctx, desc_bytes);
+  if (!e.desc) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  e.ticket = (uint32_t*)(e.desc + n_records + 1);
+  if (big) {
+    e.scratch = (unsigned char*)gigl_arena_alloc(ctx, scratch_bytes);
+    if (!e.scratch) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  }
+  GIGL_HIP_CHECK(ctx, hipMemsetAsync(e.desc, 0, (size_t)desc_bytes, ctx->stream));
+  GIGL_HIP_CHECK(ctx, hipMemsetAsync(status, 0, 4, ctx->stream));
+  GIGL_HIP_CHECK(ctx, hipMemsetAsync(rec_off, 0, 8, ctx->stream));  // (n_records == 0: rec_off[0] = 0)
+  if (n_records > 0) {
+    if (big)
+      hipLaunchKernelGGL(record_encode_kernel<true>, dim3((unsigned)grid), dim3(64 * waves), 0, ctx->stream, a, e, out,
+                         rec_off, status);
+    else
+      hipLaunchKernelGGL(record_encode_kernel<false>, dim3((unsigned)grid), dim3(64 * waves), lds, ctx->stream, a, e, out,
+                         rec_off, status);
+  }
   GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_features_row_crc(gigl_ctx* ctx, gigl_feat* f, const uint32_t** table) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, f && table, "null argument");
+  std::lock_guard<std::mutex> lock(f->row_crc_mu);
+  if (!f->row_crc) {
+    GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    int32_t rc = ensure_shift_table(ctx);
+    if (rc != GIGL_OK) return rc;
+    uint32_t* t = nullptr;
+    GIGL_HIP_CHECK(ctx, hipMalloc((void**)&t, (size_t)(f->n > 0 ? f->n : 1) * 4));
+    if (f->n > 0) {
+      const int64_t blocks = (f->n + 3) / 4;
+      hipLaunchKernelGGL(row_crc_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, ctx->stream,
+                         (const void*)f->rows, f->dtype, f->n, f->d, (const uint32_t*)ctx->crc_shift_tbl, t);
+    }
+    // finished before anybody else's stream can use it (once per table; not inside a stream capture)
+    const hipError_t err = hipStreamSynchronize(ctx->stream);
+    if (err != hipSuccess) {
+      hipFree(t);
+      return gigl_fail(ctx, GIGL_E_HIP, "row CRC table: %s", hipGetErrorString(err));
+    }
+    f->row_crc = t;
+  }
+  *table = f->row_crc;
   return GIGL_OK;
 }
 

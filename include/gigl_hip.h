@@ -234,6 +234,12 @@ int32_t gigl_features_load(gigl_ctx* ctx, int64_t n, int32_t d, int32_t dtype, c
 int32_t gigl_features_device_ptr(gigl_feat* f, const void** rows, int64_t* n, int32_t* d,
                                  int32_t* dtype);
 int32_t gigl_features_destroy(gigl_feat* f);
+/* table[id] = raw CRC-32C state (initial state 0, no final inversion) of the 4*d bytes node id's packed
+ * Node.feature_values carry in a record (fp16 tables: of the fp32 values the proto carries).  Built on the first call
+ * (one pass over the table on ctx's stream, then synchronised; not inside a stream capture) and owned by `f`.
+ * gigl_records_encode uses it to checksum TFRecord payloads (TFRecordIO.scala:53-69) without reading them back: a
+ * node's payload bytes are the same in every record that holds the node, and CRC-32C is linear. */
+int32_t gigl_features_row_crc(gigl_ctx* ctx, gigl_feat* f, const uint32_t** table);
 
 /* ---- k-hop rooted sampling: replaces sampleOnehopSrcNodesUniformly / sampleTwohopSrcNodesUniformly
  *      (SGSPureSparkV1Task.scala:313-388, :390-494), SamplingStrategy.hashBasedUniformPermutation
@@ -342,8 +348,11 @@ int32_t gigl_sample_out_neighbors(gigl_ctx* ctx, gigl_graph* g_out, const uint32
  * record as u64 length | masked crc32c(length) | payload | masked crc32c(payload).
  * All pointers DEVICE.  rec_off[r] = byte offset of record r in `out`, rec_off[n_records] = total bytes;
  * *status = 1 (and nothing is written) when the total exceeds out_cap.  Never synchronises with the host.
- * A record's plan lives in LDS: trees_per_record * (1 + sum of slots per tree) must be <= 2048
- * (GIGL_E_UNSUPPORTED otherwise; [25,10] allows up to 6 positives). */
+ * One pass: a persistent grid takes records from a ticket counter; a record's plan (distinct nodes / edges and their
+ * byte offsets) lives in LDS while trees_per_record * (1 + sum of slots per tree) stays below ~5,000 positions and
+ * in per-workgroup scratch beyond (up to 2^20 positions; a record must stay below 16 MiB); record offsets come from
+ * a decoupled look-back over the sizes of the records before it.  status = 1: `out` was too small (its contents are
+ * then undefined; nothing is written beyond out_cap). */
 typedef struct gigl_record_opts {
   int32_t kind;                /* GIGL_REC_* */
   int32_t trees_per_record;    /* 1, or 1 + num_positive_samples for GIGL_REC_NODE_ANCHOR_LINK_PRED */

@@ -292,12 +292,108 @@ def test_user_defined_label_samples_match_host_assembly():
     eng.close()
 
 
+def _random_engine(n, d, seed=5):
+    rng = np.random.default_rng(seed)
+    src, dst = rmat_edges(16, 400_000, seed=seed + 6)
+    src, dst = (src.astype(np.int64) * 2654435761 % n).astype(np.uint32), (dst.astype(np.int64) * 40503 % n).astype(np.uint32)
+    feats = rng.standard_normal((n, d)).astype(np.float32)
+    return _engine(n, src, dst, feats), feats, rng
+
+
+@pytest.mark.parametrize("fanouts,where", [([64, 64], "lds"), ([40, 30, 4], "scratch")])
+def test_long_streams_beyond_the_old_2048_position_cap(fanouts, where):
+    """4,161 stream positions still plan in LDS; 6,041 take the per-workgroup scratch plan (same code over global
+    memory).  Both byte-identical to the restatement."""
+    n = 60_000
+    eng, feats, rng = _random_engine(n, 3)
+    roots = rng.integers(0, n, 40).astype(np.uint32)
+    tree = eng.sample_khop(roots, fanouts)
+    buf, off = eng.encode_records(tree)
+    nbr = [t.cpu().numpy().view(np.uint32) for t in tree.nbr]
+    want = _host_rnn_frames(roots, fanouts, nbr, feats)
+    got = _split(buf, off)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g == w, f"record {i} differs ({where} plan): {len(g)} vs {len(w)} bytes"
+    assert len(got) == len(want)
+    eng.close()
+
+
+def test_many_records_and_both_table_types():
+    """many more records than waves in flight (the look-back chain runs over several rounds of tickets), fp32 and fp16
+    tables: every frame's two CRC words against the restatement's CRC-32C (the payload's is assembled from the
+    tabulated per-row states, gigl_features_row_crc, and the header bytes folded while they were written)"""
+    n = 50_000
+    for dtype in (torch.float32, torch.float16):
+        eng, feats, rng = _random_engine(n, 36)
+        if dtype is torch.float16:
+            eng.load_features(torch.from_numpy(feats).to(torch.float16))
+            feats = feats.astype(np.float16).astype(np.float32)
+        roots = rng.integers(0, n, 40_000).astype(np.uint32)
+        fanouts = [5, 3]
+        tree = eng.sample_khop(roots, fanouts)
+        buf, off = eng.encode_records(tree)
+        frames = _split(buf, off)
+        assert len(frames) == 40_000
+        for f in frames[:50] + frames[-50:] + frames[20_000:20_050]:
+            assert R.tfrecord_frame(f[12:-4]) == f
+        nbr = [t.cpu().numpy().view(np.uint32) for t in tree.nbr]
+        idx = np.concatenate([np.arange(40), np.arange(39_960, 40_000)])
+        want = _host_rnn_frames(roots[idx], fanouts, [nb.reshape(40_000, -1)[idx].reshape(-1) for nb in nbr], feats)
+        assert [frames[i] for i in idx.tolist()] == want
+        eng.close()
+
+
+def test_row_crc_table_matches_the_restatement():
+    import ctypes as C
+    n, d = 1000, 37
+    eng, feats, _ = _random_engine(n, d)
+    tbl = C.c_void_p()
+    _lib.check(eng._lib.gigl_features_row_crc(eng._ctx, eng._feat, C.byref(tbl)), eng._ctx)
+    got = np.empty(n, dtype=np.uint32)
+    _lib.check(eng._lib.gigl_memcpy(eng._ctx, got.ctypes.data_as(C.c_void_p), _lib.LOC_HOST, tbl, _lib.LOC_DEVICE, n * 4),
+               eng._ctx)
+
+    def raw(data):  # CRC-32C register after `data` from a zero start, no final inversion
+        R.crc32c(b"")
+        c = 0
+        for b in data:
+            c = R._CRC_TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
+        return c
+    for i in (0, 1, 17, n - 1):
+        assert int(got[i]) == raw(feats[i].astype("<f4").tobytes())
+    eng.close()
+
+
+def test_output_capacity_too_small_is_reported():
+    import ctypes as C
+    n = 20_000
+    eng, feats, rng = _random_engine(n, 8)
+    roots = rng.integers(0, n, 500).astype(np.uint32)
+    tree = eng.sample_khop(roots, [4, 3])
+    buf, off = eng.encode_records(tree)
+    need = int(off[-1].item())
+    o = _lib.GiglRecordOpts()
+    o.kind, o.trees_per_record, o.tfrecord_frame = _lib.REC_ROOTED_NODE_NEIGHBORHOOD, 1, 1
+    cap = need - 1
+    out = torch.zeros(need + 4096, dtype=torch.uint8, device="cuda")
+    rec_off = torch.empty(501, dtype=torch.int64, device="cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(eng._lib.gigl_records_encode(eng._ctx, C.c_void_p(tree.roots.data_ptr()), C.byref(tree.c_struct), eng._feat,
+                                            C.byref(o), 500, C.c_void_p(out.data_ptr()), cap,
+                                            C.c_void_p(rec_off.data_ptr()), C.c_void_p(status.data_ptr())), eng._ctx)
+    eng._stream.synchronize()
+    assert int(status.item()) == 1
+    assert int(out[cap:].sum().item()) == 0  # nothing written beyond the capacity it was given
+    assert torch.equal(rec_off.cpu(), off.cpu())  # the offsets (and so the size to retry with) are still exact
+    eng.close()
+
+
 def test_oversized_record_is_rejected():
     from gigl_amd.engine import HipEngine
     eng = HipEngine(0)
     rowptr = np.zeros(11, dtype=np.int64)
     eng.load_csc(rowptr, np.zeros(0, dtype=np.uint32))
-    tree = eng.sample_khop(np.arange(4, dtype=np.uint32), [64, 64])  # 4160 slots per tree > 4096
+    tree = eng.sample_khop(np.arange(2, dtype=np.uint32), [64, 64, 64, 5])  # 1.58 M slots per tree > 2^20
     with pytest.raises(_lib.GiglError):
         eng.encode_records(tree, with_features=False)
     eng.close()
