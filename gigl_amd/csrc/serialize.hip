@@ -14,19 +14,23 @@
 // every DISTINCT node of a root's neighbourhood is copied once from the resident table (the reference joins D
 // floats per sampled OCCURRENCE and dedups afterwards).
 //
-// One 256-thread workgroup per record, three passes over the same plan:
-//   size  : dedup the record's node stream (LDS hash set keyed by id, value = first stream position), sizes of
-//           the distinct nodes / edges, block scan -> byte offset of every item inside the record
-//   (one single-workgroup scan over the record sizes gives each record's offset in the output)
-//   write : same plan again (cheap: a few hundred ids), then headers by byte stores (one thread per node / edge),
-//           feature payloads as (node, 4-word chunk) items spread evenly over the workgroup: 16-byte row loads,
-//           funnel shift by the destination's byte misalignment (record offsets are arbitrary byte offsets),
-//           dword-aligned 16-byte stores; finally the CRC-32C of the payload: 256 lanes each fold a chunk
-//           (slicing-by-4 tables in LDS) and the partial states are combined with x^(8*bytes_after) mod P
-//           taken from byte-indexed power tables.
-// Measured (MI355X, products-shaped graph, [25,10], D=100, 4096 roots = 165 MB of records): size 29 us + scan 7 us
-// + write 253 us (payload copy ~97 us = 3.4 TB/s of mixed read+write, CRC re-read ~53 us, plan + tables ~40 us,
-// headers + edges ~27 us) = 0.57 TB/s of finished TFRecord bytes.
+// Three launches (details at record_plan_kernel): a plan pass — one WAVE per record: the record's node stream read
+// once into LDS, an LDS hash set for the first occurrences, wave scans for the byte offset of every field, the
+// record's size; the part of the plan the writers need is saved per record —, a scan of the record sizes, and a
+// write pass whose workgroups come in two kinds that run side by side: field writers (one wave per record: frame
+// header, field headers, edges, label edges, suffix and BOTH checksums, bytes gathered in registers and stored 8 at a
+// time at whatever address they belong) and row copiers (every (node field, 16-byte chunk) an independent item:
+// 16-byte load, unaligned 16-byte store).  The payload is never read back for its CRC-32C: CRC is linear, a node's
+// 4*D payload bytes contribute a state tabulated once per feature table (gigl_features_row_crc) after one table-driven
+// shift of the running state, and a lane shifts its chained state to the end of the payload with one multiply mod P.
+// Measured (MI355X, products-shaped graph, [25,10], D=100, ~90 distinct nodes and 40.4 KB per record; device time of
+// back-to-back calls, scripts/micro_records.py --device-only): 4,096 records per call 191 us (plan 54 + scan ~5 + write
+// 129) = 0.87 TB/s of finished TFRecord bytes; 32,768 per call 1.07 ms (plan 0.19 + write 0.83) = 1.20 TB/s =
+// 0.30 of the HBM peak counting the bytes written and the row bytes read (round 2: 289 us per 4,096 = 0.57 TB/s,
+// 0.14).  What the pattern allows: the row copy alone as dense items runs at 4.5 TB/s read + written
+// (scripts/micro_rowcopy.py: 66 us per 4,096 records).  What was learnt on the way (profiles/r03g_encoder.md): per-byte
+// stores and a CRC pass over the payload each cost more than the payload copy; one ticket counter or one look-back
+// chain shared by thousands of waves serialises them; the copy inside a per-record wave runs at half the dense rate.
 #include "common.h"
 
 #include <hip/hip_fp16.h>
@@ -135,19 +139,6 @@ __device__ __forceinline__ uint32_t node_hdr_len(const RecArgs& a, uint32_t id) 
   return n;
 }
 
-// node id at stream position q of record r (NONE = empty slot)
-__device__ __forceinline__ uint32_t stream_node(const RecArgs& a, int64_t r, uint32_t q) {
-  const uint32_t tt = q / (uint32_t)a.tree_len;
-  uint32_t local = q - tt * (uint32_t)a.tree_len;
-  const int64_t t = r * a.trees + tt;
-  const uint32_t root = a.roots[t];
-  if (root == NONE) return NONE;
-  for (int k = 0; k < a.hops; ++k) {
-    if (local < (uint32_t)a.slots[k]) return a.nbr[k][t * a.slots[k] + local];
-    local -= (uint32_t)a.slots[k];
-  }
-  return root;
-}
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
   x ^= x >> 16;
   x *= 0x7feb352dU;
@@ -196,43 +187,56 @@ __device__ __forceinline__ unsigned long long wave_exscan64(unsigned long long v
   return inc - v;
 }
 
-// The per-record plan.  It lives in LDS (one segment per wave), or — records whose stream is too long for it — in a
-// per-wave segment of the call's scratch (same code, the arrays are then global memory).
-//   ids      [n_s]       the record's node stream, tree by tree: hop-0 slots, hop-1 slots, ..., the tree's root;
-//                        NONE = empty slot.  Read from the sample ONCE; everything below works on this copy.
-//   hslot    [hash_cap]  open-addressing set over the stream: a slot holds the FIRST stream position of its id
-//                        (the key is ids[position]: 4 bytes per slot)
-//   eslot    [ehash_cap] the same over the edge stream (records that merge several trees only)
+// The per-record plan: built in LDS (one segment per wave) — or, for streams too long for that, straight in the record's
+// plan segment in scratch (same code, the arrays are then global memory).  Kept for the write pass (kept_words()):
+//   hdr      [4]         n_uniq, nodes_bytes, edges_bytes, bytes of the hard_neg_edges fields
 //   uid, fld [n_s+1]     the record's Node fields in RECORD order — entry 0 = the root_node field (offset 0 of the
 //                        payload), entry 1 + u = the u-th distinct node in stream order: id, byte offset of the field
 //                        inside the Graph body (low FLD_BITS bits; the bits above: length of the field's header,
 //                        <= 24 bytes)
+//   rc       [n_s+1]     the tabulated CRC state of every entry's feature row (gigl_features_row_crc), fetched for
+//                        the whole record at once
 //   edge_off [n_e]       byte offset of the edge inside the edge region, NONE = duplicate / empty
+//   ids      [n_s]       the record's node stream, tree by tree: hop-0 slots, hop-1 slots, ..., the tree's root;
+//                        NONE = empty slot.  Read from the sample ONCE; everything works on this copy.
+// Scratch of the plan pass:
+//   hslot    [hash_cap]  open-addressing set over the stream: a slot holds the FIRST stream position of its id
+//                        (the key is ids[position]: 4 bytes per slot)
+//   eslot    [ehash_cap] the same over the edge stream (records that merge several trees only)
 constexpr uint32_t FLD_BITS = 27, FLD_MASK = (1u << FLD_BITS) - 1;
+constexpr uint32_t PLAN_HDR = 4;
 struct Plan {
-  uint32_t *ids, *hslot, *eslot, *uid, *fld, *edge_off;
+  uint32_t *hdr, *uid, *fld, *rc, *edge_off, *ids, *hslot, *eslot;
   uint32_t n_uniq, nodes_bytes, edges_bytes;
 };
 
+__host__ __device__ inline uint32_t kept_words(const RecArgs& a) {
+  const uint32_t n_s = (uint32_t)(a.trees * a.tree_len), n_e = (uint32_t)(a.trees * a.edge_len);
+  return PLAN_HDR + 3 * (n_s + 1) + n_e + n_s;
+}
+size_t kept_bytes(const RecArgs& a) { return ((size_t)4 * kept_words(a) + 15) & ~(size_t)15; }
 size_t plan_bytes(const RecArgs& a) {
-  const size_t n_s = (size_t)a.trees * a.tree_len, n_e = (size_t)a.trees * a.edge_len;
-  return (4 * (n_s + a.hash_cap + a.ehash_cap + 2 * (n_s + 1) + n_e) + 15) & ~(size_t)15;
+  return ((size_t)4 * (kept_words(a) + a.hash_cap + a.ehash_cap) + 15) & ~(size_t)15;
 }
 
 __device__ __forceinline__ void carve(const RecArgs& a, unsigned char* base, Plan& pl) {
-  const uint32_t n_s = (uint32_t)(a.trees * a.tree_len);
+  const uint32_t n_s = (uint32_t)(a.trees * a.tree_len), n_e = (uint32_t)(a.trees * a.edge_len);
   uint32_t* p = (uint32_t*)base;
+  pl.hdr = p;
+  p += PLAN_HDR;
+  pl.uid = p;
+  p += n_s + 1;
+  pl.fld = p;
+  p += n_s + 1;
+  pl.rc = p;
+  p += n_s + 1;
+  pl.edge_off = p;
+  p += n_e;
   pl.ids = p;
   p += n_s;
   pl.hslot = p;
   p += a.hash_cap;
   pl.eslot = p;
-  p += a.ehash_cap;
-  pl.uid = p;
-  p += n_s + 1;
-  pl.fld = p;
-  p += n_s + 1;
-  pl.edge_off = p;
 }
 
 // edge at edge-stream position q, from the plan's copy of the stream: src NONE = no edge
@@ -277,26 +281,27 @@ __device__ __forceinline__ uint32_t edge_first(const RecArgs& a, const Plan& pl,
 }
 
 // builds the plan of record r (the 64 lanes of one wave)
-struct EncDbg {
-  unsigned long long* dbg;
-};
-#define PLAN_TICK(k)                                                    \
-  do {                                                                  \
-    if (e.dbg) {                                                        \
-      const unsigned long long now_ = wall_clock64();                   \
-      if ((threadIdx.x & 63) == 0) atomicAdd(&e.dbg[k], now_ - tick_);  \
-      tick_ = now_;                                                     \
-    }                                                                   \
-  } while (0)
-__device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int64_t r, Plan& pl, EncDbg e,
-                                                          unsigned long long& tick_) {
+__device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int64_t r, Plan& pl,
+                                                          const uint32_t* row_crc) {
   const uint32_t n_s = (uint32_t)(a.trees * a.tree_len), n_e = (uint32_t)(a.trees * a.edge_len);
   const uint32_t lane = threadIdx.x & 63;
-  for (uint32_t q = lane; q < n_s; q += 64) pl.ids[q] = stream_node(a, r, q);
+  // the stream, tree by tree: one (uniform) root load, then every slot load is independent of the others
+  for (int tt = 0; tt < a.trees; ++tt) {
+    const int64_t t = r * a.trees + tt;
+    const uint32_t root = a.roots[t];
+    uint32_t* t_ids = pl.ids + (uint32_t)tt * (uint32_t)a.tree_len;
+    uint32_t base = 0;
+    for (int k = 0; k < a.hops; ++k) {
+      const uint32_t sl = (uint32_t)a.slots[k];
+      const uint32_t* src = a.nbr[k] + t * sl;
+      for (uint32_t i = lane; i < sl; i += 64) t_ids[base + i] = root == NONE ? NONE : src[i];
+      base += sl;
+    }
+    if (lane == 0) t_ids[base] = root;
+  }
   for (uint32_t i = lane; i < a.hash_cap; i += 64) pl.hslot[i] = NONE;
   for (uint32_t i = lane; i < a.ehash_cap; i += 64) pl.eslot[i] = NONE;
   wave_sync();
-  PLAN_TICK(1);
   // first occurrence of every id in stream order
   for (uint32_t q = lane; q < n_s; q += 64) {
     const uint32_t id = pl.ids[q];
@@ -332,7 +337,6 @@ __device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int6
     }
   }
   wave_sync();
-  PLAN_TICK(2);
   // nodes: field sizes of first occurrences, scanned in stream order (a lane owns a contiguous run); bytes in the
   // low word, count in the high word of one 64-bit scan
   {
@@ -362,7 +366,6 @@ __device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int6
       pl.fld[0] = node_hdr_len(a, root) << FLD_BITS;
     }
   }
-  PLAN_TICK(3);
   // edges
   {
     const uint32_t per = (n_e + 63) / 64, lo = min(lane * per, n_e), hi = min(lo + per, n_e);
@@ -388,7 +391,13 @@ __device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int6
     pl.edges_bytes = (uint32_t)tot;
   }
   wave_sync();
-  PLAN_TICK(4);
+  // the rows' tabulated CRC states: independent loads, one round trip for the whole record
+  if (row_crc)
+    for (uint32_t i = lane; i <= pl.n_uniq; i += 64) {
+      const uint32_t id = pl.uid[i];
+      pl.rc[i] = (int64_t)id < a.feat_n ? row_crc[id] : 0u;
+    }
+  wave_sync();
 }
 
 // sizes of the fixed parts of record r (uniform over the workgroup)
@@ -504,28 +513,70 @@ __device__ __forceinline__ void build_crc_tables(uint32_t* crc_t) {
 }
 
 // A byte writer that folds what it writes into a CRC state (the bytes between the float payloads of a record are
-// CRC'd from registers while they are written, never re-read)
+// CRC'd from registers while they are written, never re-read).  Bytes gather in a 64-bit register and leave as
+// 8-byte stores at whatever byte address they belong (global memory takes unaligned accesses; a byte store per byte
+// costs the memory pipeline a request each), the rest as one 4-, 2- and 1-byte store.
+// the record bytes are global memory, and the stores below say so (a generic pointer makes them FLAT instructions)
+#define GIGL_GLOBAL __attribute__((address_space(1)))
+typedef GIGL_GLOBAL uint8_t* gptr_t;
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
+typedef uint32_t __attribute__((ext_vector_type(4), aligned(1))) u32x4_unaligned;
 struct CrcOut {
-  uint8_t* p;
+  gptr_t p;  // where the next stored byte goes; `nb` more bytes wait in `acc` (not yet folded into c)
   uint32_t c;
   const uint32_t* t;
+  uint64_t acc = 0;
+  uint32_t nb = 0;
   __device__ __forceinline__ void byte(uint32_t b) {
-    *p++ = (uint8_t)b;
-    c = crc_byte(t, c, b & 0xFFu);
+    acc |= (uint64_t)(b & 0xFFu) << (8u * nb);
+    if (++nb == 8) {  // two word steps of the checksum instead of eight dependent byte steps
+      c = crc_word(t, crc_word(t, c, (uint32_t)acc), (uint32_t)(acc >> 32));
+      *(GIGL_GLOBAL u64_unaligned*)p = acc;
+      p += 8;
+      acc = 0;
+      nb = 0;
+    }
   }
   __device__ __forceinline__ void varint(uint64_t v) {
     while (v >= 128) {
-      byte((uint32_t)(v | 0x80) & 0xFFu);
+      byte((uint32_t)(v | 0x80));
       v >>= 7;
     }
     byte((uint32_t)v);
   }
   __device__ __forceinline__ void word(uint32_t v) {
-    byte(v & 0xFF);
-    byte((v >> 8) & 0xFF);
-    byte((v >> 16) & 0xFF);
+    byte(v);
+    byte(v >> 8);
+    byte(v >> 16);
     byte(v >> 24);
   }
+  __device__ __forceinline__ void flush() {
+    if (nb & 4) {
+      c = crc_word(t, c, (uint32_t)acc);
+      *(GIGL_GLOBAL u32_unaligned*)p = (uint32_t)acc;
+      p += 4;
+      acc >>= 32;
+    }
+    if (nb & 2) {
+      c = crc_byte(t, crc_byte(t, c, (uint32_t)acc & 0xFFu), ((uint32_t)acc >> 8) & 0xFFu);
+      *(GIGL_GLOBAL u16_unaligned*)p = (uint16_t)acc;
+      p += 2;
+      acc >>= 16;
+    }
+    if (nb & 1) {
+      c = crc_byte(t, c, (uint32_t)acc & 0xFFu);
+      *p++ = (uint8_t)acc;
+    }
+    acc = 0;
+    nb = 0;
+  }
+  __device__ __forceinline__ void seek(gptr_t q) {
+    flush();
+    p = q;
+  }
+  __device__ __forceinline__ gptr_t pos() const { return p + nb; }
 };
 
 // header of a Node field (everything before the float payload), byte stores by one thread
@@ -627,39 +678,32 @@ __global__ __launch_bounds__(256) void row_crc_kernel(const void* feat, int32_t 
   }
 }
 
-#define ENC_TICK(k)                                                     \
-  do {                                                                  \
-    if (e.dbg) {                                                        \
-      const unsigned long long now_ = wall_clock64();                   \
-      if ((threadIdx.x & 63) == 0) atomicAdd(&e.dbg[k], now_ - tick_);  \
-      tick_ = now_;                                                     \
-    }                                                                   \
-  } while (0)
-
-// ---- the encoder: ONE pass, one WAVE per record -----------------------------------------------------------------
-// A persistent grid.  Every wave takes the next record from a ticket counter, builds its plan in its own LDS segment,
-// learns where the record starts from a decoupled look-back over the records before it (a record's wave publishes its
-// size as soon as the plan is known, then the running total once the look-back has reached a published total: tickets
-// are handed out in order, so every record looked back at is owned by a running wave) and writes the record.  The work
-// per record is a chain of short dependent steps (ids -> hash set -> scans -> look-back -> headers -> rows): waves
-// that own a record each and never meet at a barrier keep many such chains in flight per CU, which is what hides
-// their latency behind the row copies of the others.
+// ---- the encoder: three launches ---------------------------------------------------------------------------------
+// record_plan_kernel   one WAVE per record: the plan (in the wave's LDS segment, or — long streams — straight in the
+//                      record's plan segment in scratch), the record's size, and the part of the plan the write pass
+//                      needs saved to the record's segment (kept_words(): ~3 KB for a [25,10] record).  The work per
+//                      record is a chain of short dependent steps (ids -> hash set -> scans); waves that own a record
+//                      each and never meet at a barrier keep many such chains in flight per CU.
+// record_scan_kernel   record sizes -> offsets, status = 1 when the output does not fit (nothing is written then).
+// record_write_kernel  ONE launch, two kinds of workgroups dealt alternately over the grid so that both are in flight
+//                      together (one kind is bound by latency, the other by bandwidth):
+//   fields  one wave per record: frame header, field headers, edges, label edges, suffix, both checksums, from the
+//           saved plan — everything of the record except the float payloads of its nodes;
+//   rows    the payloads: ROWS_WPR waves per record, every (node field, 16-byte chunk) one independent item: a
+//           16-byte load from the row, a 16-byte store at whatever byte address the payload starts at (global memory
+//           takes unaligned accesses).  Alone this pattern moves rows at ~4.5 TB/s (scripts/micro_rowcopy.py).
 // Checksum: nothing is read back.  The bytes between the float payloads are folded into a CRC state while they are
 // written (CrcOut); a node's 4*d payload bytes contribute their tabulated state (gigl_features_row_crc) after one
 // table-driven shift of the running state; a lane chains the fields of a contiguous run and shifts its state to the
 // end of the payload once (state * x^(8*bytes_after) mod P), the wave xors the lanes' shares.
 struct EncArgs {
-  unsigned long long* desc;  // [n_records], zeroed per call: flag << 62 | bytes (flag 1 = own size, 2 = running total)
-  uint32_t* ticket;          // zeroed per call
-  unsigned char* scratch;    // plans that do not fit LDS: one segment per wave
-  size_t plan_stride;        // bytes between the plan segments of two waves
-  const uint32_t* row_crc;   // [feat_n] (row_crc_kernel); NULL only when d == 0
+  unsigned char* plans;      // [n_records] plan segments
+  size_t plan_stride;        // bytes between the segments of two records
+  size_t lds_stride;         // bytes between the LDS segments of two waves
+  const uint32_t* row_crc;   // [feat_n] (row_crc_kernel); NULL when d == 0 or the records are not framed
   uint32_t x_row;            // x^(8 * 4d) mod P
-  int64_t out_cap;
-  unsigned long long* dbg;  // (measurement only, GIGL_ENC_DBG=1) [16] summed wall_clock64 ticks per phase
-  uint32_t skip;  // (measurement only, GIGL_ENC_SKIP) phases left out: 1 payload copy, 2 node fields, 4 edges, 16 look-back
+  int64_t* rec_size;         // [n_records]
 };
-constexpr unsigned long long DESC_SIZE = 1ull << 62, DESC_TOTAL = 2ull << 62, DESC_VAL = DESC_SIZE - 1;
 
 // the state after 4d more bytes of zeros: c * x^(8*4d), from the byte-sliced tables of that constant
 __device__ __forceinline__ uint32_t shift_row(const uint32_t* t, uint32_t c) {
@@ -670,43 +714,72 @@ __device__ __forceinline__ uint32_t crc_share(const uint32_t* shift_tbl, uint32_
   return c ? multmodp(x8n_modp(shift_tbl, after), c) : 0u;
 }
 
-__device__ __attribute__((always_inline)) void write_record(const RecArgs& a, const EncArgs& e, const Plan& pl,
+template <bool BIG>
+__global__ __launch_bounds__(256) void record_plan_kernel(RecArgs a, EncArgs e) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + w;
+  if (r >= a.n_records) return;
+  uint32_t* const seg = (uint32_t*)(e.plans + (size_t)r * e.plan_stride);
+  if (a.emit && !a.emit[r]) {
+    if (lane == 0) {
+      e.rec_size[r] = 0;
+      seg[0] = NONE;  // no record
+    }
+    return;
+  }
+  Plan pl;
+  if constexpr (BIG) carve(a, (unsigned char*)seg, pl);
+  else carve(a, s_dyn + (size_t)w * e.lds_stride, pl);
+  build_plan(a, r, pl, e.row_crc);
+  const Layout L = layout_of(a, r, pl);
+  if (lane == 0) {
+    e.rec_size[r] = (int64_t)L.payload + (a.frame ? 16 : 0);
+    pl.hdr[0] = pl.n_uniq;
+    pl.hdr[1] = pl.nodes_bytes;
+    pl.hdr[2] = pl.edges_bytes;
+    pl.hdr[3] = L.neg_bytes;
+  }
+  if constexpr (!BIG) {  // the part the write pass reads, out of LDS
+    wave_sync();
+    const uint32_t kw = kept_words(a);
+    for (uint32_t i = lane; i < kw; i += 64) seg[i] = pl.hdr[i];
+  }
+}
+
+__device__ __attribute__((always_inline)) void write_fields(const RecArgs& a, const EncArgs& e, const Plan& pl,
                                                             const Layout& L, int64_t r, uint8_t* rec,
                                                             const uint32_t* crc_t, const uint32_t* row_t,
-                                                            unsigned long long& tick_) {
+                                                            const uint32_t* shift_t) {
   const uint32_t lane = threadIdx.x & 63;
-  uint8_t* const payload = rec + (a.frame ? 12 : 0);
-  uint8_t* const hard_neg = payload + field_len(L.root_body);  // hard_neg_edges = 2 sits between root_node and neighborhood
-  uint8_t* const graph_hdr = hard_neg + L.neg_bytes;
-  uint8_t* const graph = graph_hdr + 1 + vlen(L.graph_body);
-  uint8_t* const edges = graph + pl.nodes_bytes;
-  uint8_t* const pos = graph + L.graph_body;
-  uint8_t* const suffix = pos + L.pos_bytes;
-  uint8_t* const payload_end = suffix + L.suffix_len;
+  const gptr_t grec = (gptr_t)rec;
+  const gptr_t payload = grec + (a.frame ? 12 : 0);
+  const gptr_t hard_neg = payload + field_len(L.root_body);  // hard_neg_edges = 2 sits between root_node and neighborhood
+  const gptr_t graph_hdr = hard_neg + L.neg_bytes;
+  const gptr_t graph = graph_hdr + 1 + vlen(L.graph_body);
+  const gptr_t edges = graph + pl.nodes_bytes;
+  const gptr_t pos = graph + L.graph_body;
+  const gptr_t suffix = pos + L.pos_bytes;
+  const gptr_t payload_end = suffix + L.suffix_len;
   const uint64_t n = L.payload;
   uint32_t part = 0;  // this lane's share of the payload's CRC state
-  if (lane == 0 && a.frame) {
-    uint32_t c = 0xFFFFFFFFu;
-    for (int b = 0; b < 8; ++b) {
-      const uint32_t byte = (uint32_t)((L.payload >> (8 * b)) & 0xFF);
-      rec[b] = (uint8_t)byte;
-      c = crc_byte(crc_t, c, byte);
-    }
-    const uint32_t m = mask_crc(c ^ 0xFFFFFFFFu);
-    for (int b = 0; b < 4; ++b) rec[8 + b] = (uint8_t)(m >> (8 * b));
+  if (lane == 0 && a.frame) {  // u64 length, masked CRC-32C of the length
+    CrcOut o{grec, 0xFFFFFFFFu, crc_t};
+    o.word((uint32_t)L.payload);
+    o.word((uint32_t)(L.payload >> 32));  // (the eighth byte folds and stores the length)
+    *(GIGL_GLOBAL u32_unaligned*)(grec + 8) = mask_crc(o.c ^ 0xFFFFFFFFu);
   }
   // root_node = 1 (entry 0) and the distinct nodes of the neighbourhood (Graph.nodes = 2; entries 1..n_uniq), in
   // record order: a lane writes the headers of a contiguous run of entries and chains their checksum
   const uint32_t n_items = pl.n_uniq + 1;
   const uint32_t D4 = 4u * (uint32_t)a.d;
-  if (!(e.skip & 2)) {
+  {
     const uint32_t per = (n_items + 63) / 64, lo = min(lane * per, n_items), hi = min(lo + per, n_items);
     if (lo < hi) {
       CrcOut o{payload, lo == 0 ? 0xFFFFFFFFu : 0u, crc_t};
       for (uint32_t i = lo; i < hi; ++i) {
         const uint32_t id = pl.uid[i];
         if (i == 1) {  // hard_neg_edges = 2 and the Graph header sit between root_node and the first node
-          o.p = hard_neg;
+          o.seek(hard_neg);
           if (a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED)
             for (int tt = a.trees - a.neg_trees; tt < a.trees; ++tt) {
               const uint32_t p = a.roots[r * a.trees + tt];
@@ -715,111 +788,20 @@ __device__ __attribute__((always_inline)) void write_record(const RecArgs& a, co
           o.byte(a.kind == GIGL_REC_NODE_ANCHOR_LINK_PRED ? 0x1A : 0x12);  // neighborhood = 3 / 2
           o.varint(L.graph_body);
         }
-        o.p = (i == 0 ? payload : graph) + (pl.fld[i] & FLD_MASK);
+        o.seek((i == 0 ? payload : graph) + (pl.fld[i] & FLD_MASK));
         write_node_header(a, o, i == 0 ? 0x0A : 0x12, id);
+        o.flush();
         if (a.d > 0) {
-          if (e.row_crc) o.c = shift_row(row_t, o.c) ^ ((int64_t)id < a.feat_n ? e.row_crc[id] : 0u);
+          if (e.row_crc) o.c = shift_row(row_t, o.c) ^ pl.rc[i];
           o.p += D4;
         }
       }
-      part ^= crc_share(a.shift_tbl, o.c, n - (uint64_t)(o.p - payload));
+      part ^= crc_share(shift_t, o.c, n - (uint64_t)(o.p - payload));
     }
   }
-  ENC_TICK(7);
-  // float payloads: the (entry, word) pairs are spread evenly over the 64 lanes.  A payload starts at an
-  // arbitrary byte address: output word k of a node = funnel shift of source words k-1 and k, stored as an
-  // aligned dword (head and tail bytes of a payload by byte stores, they share their dwords with headers).
-  if (a.d > 0 && !(e.skip & 1)) {
-    // item = (entry, chunk of 4 output words); output words k = 0..D (word D only holds the tail bytes of a
-    // misaligned payload)
-    const uint32_t D = (uint32_t)a.d, nch = (D + 4) / 4;
-    const uint32_t total = n_items * nch, du = 64u / nch, dc = 64u % nch;
-    const bool vec_rows = a.feat_dtype == GIGL_DTYPE_F32 && (D & 3u) == 0;  // rows are 16-byte aligned
-    uint32_t u = lane / nch, c = lane % nch;
-    struct __attribute__((packed, aligned(4))) W4 {
-      uint32_t x, y, z, w;
-    };
-    constexpr int UNR = 4;  // row loads of UNR items are issued before any of them is consumed
-    for (uint32_t i0 = 0; i0 < total; i0 += 64 * UNR) {
-      uint32_t id[UNR], k0[UNR], wv[UNR][4], pw[UNR];
-      uint8_t* dst[UNR];
-      bool valid[UNR];
-#pragma unroll
-      for (int j = 0; j < UNR; ++j) {
-        valid[j] = i0 + j * 64 + lane < total;
-        k0[j] = 4u * c;
-        id[j] = pw[j] = wv[j][0] = wv[j][1] = wv[j][2] = wv[j][3] = 0;
-        dst[j] = nullptr;
-        if (valid[j]) {
-          id[j] = pl.uid[u];
-          const uint32_t f = pl.fld[u];
-          dst[j] = (u == 0 ? payload : graph) + (f & FLD_MASK) + (f >> FLD_BITS);
-          if (vec_rows && k0[j] + 3 < D && (int64_t)id[j] < a.feat_n) {
-            const uint4 q = *(const uint4*)((const uint32_t*)a.feat + (int64_t)id[j] * D + k0[j]);
-            wv[j][0] = q.x;
-            wv[j][1] = q.y;
-            wv[j][2] = q.z;
-            wv[j][3] = q.w;
-          } else {
-#pragma unroll
-            for (uint32_t t = 0; t < 4; ++t)
-              if (k0[j] + t < D) wv[j][t] = feat_word(a, id[j], k0[j] + t);
-          }
-          // word k0-1: lane-1 holds it (previous chunk of the same node) except in lane 0
-          if (lane == 0 && c > 0) pw[j] = feat_word(a, id[j], k0[j] - 1);
-        }
-        u += du;
-        c += dc;
-        if (c >= nch) {
-          c -= nch;
-          ++u;
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < UNR; ++j) {
-        uint32_t prev = __shfl_up(wv[j][3], 1, 64);
-        if (!valid[j]) continue;
-        if (k0[j] == 0) prev = 0;
-        else if (lane == 0) prev = pw[j];
-        const uint32_t rr = (uint32_t)((uintptr_t)dst[j] & 3u);
-        if (rr == 0) {
-          uint32_t* o = (uint32_t*)dst[j] + k0[j];
-          if (k0[j] + 3 < D) {
-            *(W4*)o = W4{wv[j][0], wv[j][1], wv[j][2], wv[j][3]};
-          } else {
-#pragma unroll
-            for (uint32_t t = 0; t < 3; ++t)
-              if (k0[j] + t < D) o[t] = wv[j][t];
-          }
-        } else {
-          uint32_t* o = (uint32_t*)(dst[j] - rr) + k0[j];
-          const uint32_t sh = 8u * rr, sl = 32u - sh;
-          const uint32_t vs[4] = {(prev >> sl) | (wv[j][0] << sh), (wv[j][0] >> sl) | (wv[j][1] << sh),
-                                  (wv[j][1] >> sl) | (wv[j][2] << sh), (wv[j][2] >> sl) | (wv[j][3] << sh)};
-          if (k0[j] > 0 && k0[j] + 3 < D) {
-            *(W4*)o = W4{vs[0], vs[1], vs[2], vs[3]};
-          } else {
-#pragma unroll
-            for (uint32_t t = 0; t < 4; ++t) {
-              const uint32_t k = k0[j] + t;
-              if (k > D) break;
-              if (k == 0) {
-                for (uint32_t b = rr; b < 4; ++b) ((uint8_t*)o)[b] = (uint8_t)(vs[t] >> (8u * b));
-              } else if (k == D) {
-                for (uint32_t b = 0; b < rr; ++b) ((uint8_t*)(o + t))[b] = (uint8_t)(vs[t] >> (8u * b));
-              } else {
-                o[t] = vs[t];
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  ENC_TICK(8);
   // Graph.edges = 3: a lane writes a contiguous run of the edge stream (fields are contiguous in stream order) —
   // header, then the edge's feature row — and chains the checksum
-  if (!(e.skip & 4)) {
+  {
     const uint32_t n_e = (uint32_t)(a.trees * a.edge_len);
     const uint32_t per = (n_e + 63) / 64, lo = min(lane * per, n_e), hi = min(lo + per, n_e);
     CrcOut o{nullptr, 0u, crc_t};
@@ -828,23 +810,26 @@ __device__ __attribute__((always_inline)) void write_record(const RecArgs& a, co
       if (eo == NONE) continue;
       uint32_t s, d;
       plan_edge(a, pl.ids, q, s, d);
-      o.p = edges + eo;
+      if (!o.p) o.p = edges + eo;  // (the fields of a run are contiguous)
       write_edge(a, o, 0x1A, s, d, a.de);
       if (a.de > 0) {
         const uint32_t at = edge_pos(a, s, d);
         for (int k = 0; k < a.de; ++k) o.word(efeat_word(a, at, (uint32_t)k));
       }
     }
-    if (o.p) part ^= crc_share(a.shift_tbl, o.c, n - (uint64_t)(o.p - payload));
+    if (o.p) {
+      o.flush();
+      part ^= crc_share(shift_t, o.c, n - (uint64_t)(o.p - payload));
+    }
   }
-  ENC_TICK(9);
   if (lane == 63 && L.pos_bytes) {  // pos_edges = 4, after the graph
     CrcOut o{pos, 0u, crc_t};
     for (int tt = 1; tt < a.trees - a.neg_trees; ++tt) {
       const uint32_t p = a.roots[r * a.trees + tt];
       if (p != NONE) write_label_edge(a, o, 0, L.root_id, p);
     }
-    part ^= crc_share(a.shift_tbl, o.c, n - (uint64_t)(o.p - payload));
+    o.flush();
+    part ^= crc_share(shift_t, o.c, n - (uint64_t)(o.p - payload));
   }
   if (L.suffix_len) {  // a contiguous chunk per lane
     const uint8_t* src = a.suffix + a.suffix_off[r];
@@ -852,100 +837,135 @@ __device__ __attribute__((always_inline)) void write_record(const RecArgs& a, co
     if (lo < hi) {
       CrcOut o{suffix + lo, 0u, crc_t};
       for (uint64_t i = lo; i < hi; ++i) o.byte(src[i]);
-      part ^= crc_share(a.shift_tbl, o.c, L.suffix_len - hi);
+      o.flush();
+      part ^= crc_share(shift_t, o.c, L.suffix_len - hi);
     }
   }
   if (!a.frame) return;
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) part ^= __shfl_xor(part, o, 64);
-  if (lane == 0) {
-    const uint32_t m = mask_crc(part ^ 0xFFFFFFFFu);
-    for (int b = 0; b < 4; ++b) payload_end[b] = (uint8_t)(m >> (8 * b));
-  }
-  ENC_TICK(10);
+  if (lane == 0) *(GIGL_GLOBAL u32_unaligned*)payload_end = mask_crc(part ^ 0xFFFFFFFFu);
 }
 
+// the float payloads of record r's node fields: this wave's share (wave q of ROWS_WPR) of the (entry, 16-byte chunk)
+// items, dealt in groups of 64 * UNR
+constexpr int ROWS_WPR = 4;
+__device__ __attribute__((always_inline)) void write_rows(const RecArgs& a, const uint32_t* seg, uint8_t* rec_start,
+                                                          uint32_t q) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t n_s = (uint32_t)(a.trees * a.tree_len);
+  const uint32_t n_items = seg[0] + 1;
+  const uint32_t* uid = seg + PLAN_HDR;
+  const uint32_t* fld = uid + n_s + 1;
+  const uint32_t root_body = node_body_len(a, uid[0]);
+  const gptr_t payload = (gptr_t)rec_start + (a.frame ? 12 : 0);
+  // (the Graph body starts after root_node, the hard negatives and the Graph header)
+  const uint32_t neg_bytes = seg[3];
+  const uint32_t graph_body = seg[1] + seg[2];
+  const gptr_t graph = payload + field_len(root_body) + neg_bytes + 1 + vlen(graph_body);
+  const uint32_t D = (uint32_t)a.d, nch = (D + 3) / 4;
+  const uint32_t total = n_items * nch;
+  const bool vec_rows = a.feat_dtype == GIGL_DTYPE_F32 && (D & 3u) == 0;  // rows are 16-byte aligned
+  constexpr int UNR = 4;  // row loads of UNR items are issued before any of them is consumed
+  for (uint32_t i0 = q * 64 * UNR; i0 < total; i0 += ROWS_WPR * 64 * UNR) {
+    uint32_t k0[UNR], wv[UNR][4];
+    gptr_t dst[UNR];
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+      const uint32_t i = i0 + j * 64 + lane;
+      const uint32_t u = i / nch, c = i - u * nch;
+      k0[j] = 4u * c;
+      wv[j][0] = wv[j][1] = wv[j][2] = wv[j][3] = 0;
+      dst[j] = nullptr;
+      if (i < total) {
+        const uint32_t id = uid[u], f = fld[u];
+        dst[j] = (u == 0 ? payload : graph) + (f & FLD_MASK) + (f >> FLD_BITS) + 4u * k0[j];
+        if (vec_rows) {
+          if ((int64_t)id < a.feat_n) {
+            const uint4 v = *(const uint4*)((const uint32_t*)a.feat + (int64_t)id * D + k0[j]);
+            wv[j][0] = v.x;
+            wv[j][1] = v.y;
+            wv[j][2] = v.z;
+            wv[j][3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (uint32_t t = 0; t < 4; ++t)
+            if (k0[j] + t < D) wv[j][t] = feat_word(a, id, k0[j] + t);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+      if (!dst[j]) continue;
+      if (k0[j] + 3 < D) {
+        *(GIGL_GLOBAL u32x4_unaligned*)dst[j] = u32x4_unaligned{wv[j][0], wv[j][1], wv[j][2], wv[j][3]};
+      } else {
+#pragma unroll
+        for (uint32_t t = 0; t < 3; ++t)
+          if (k0[j] + t < D) *(GIGL_GLOBAL u32_unaligned*)(dst[j] + 4u * t) = wv[j][t];
+      }
+    }
+  }
+}
+
+// the first ceil(n / wf) workgroups write the fields of wf records each (one wave per record; wf = as many plans as fit
+// LDS), the n workgroups after them the rows of one record each (ROWS_WPR waves).  The field writers are the long,
+// latency-bound ones: they are dispatched first and the row copiers fill the CUs around them
 template <bool BIG>
-__global__ __launch_bounds__(1024) void record_encode_kernel(RecArgs a, EncArgs e, uint8_t* out, int64_t* rec_off,
-                                                            int32_t* status) {
+__global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, EncArgs e, const int64_t* rec_off,
+                                                           const int32_t* status, uint8_t* out, uint32_t wf) {
+  if (*status != 0) return;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t lane = tid & 63, w = tid >> 6;
+  const uint32_t n_grp = (uint32_t)((a.n_records + wf - 1) / wf);
+  const uint32_t grp = blockIdx.x;
+  if (blockIdx.x >= n_grp) {  // rows
+    if (a.d <= 0) return;
+    const int64_t r = (int64_t)(blockIdx.x - n_grp);
+    if (r >= a.n_records) return;
+    const uint32_t* seg = (const uint32_t*)(e.plans + (size_t)r * e.plan_stride);
+    if (seg[0] == NONE) return;
+    write_rows(a, seg, out + rec_off[r], w);
+    return;
+  }
   __shared__ uint32_t crc_t[1024];
   __shared__ uint32_t row_t[1024];
-  const uint32_t tid = threadIdx.x;
-  const int lane = tid & 63, w = tid >> 6, waves = blockDim.x >> 6;
-  Plan pl;
-  if constexpr (BIG) carve(a, e.scratch + ((size_t)blockIdx.x * waves + w) * e.plan_stride, pl);
-  else carve(a, s_dyn + (size_t)w * e.plan_stride, pl);
-  for (uint32_t i = tid; i < 256; i += blockDim.x) {
+  __shared__ uint32_t shift_t[768];
+  for (uint32_t i = tid; i < 256; i += 256) {
     uint32_t c = i;
     for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
     crc_t[i] = c;
   }
+  for (uint32_t i = tid; i < 768; i += 256) shift_t[i] = a.shift_tbl[i];
   __syncthreads();
   for (int j = 1; j < 4; ++j) {
-    for (uint32_t i = tid; i < 256; i += blockDim.x) {
-      const uint32_t prev = crc_t[(j - 1) * 256 + i];
-      crc_t[j * 256 + i] = (prev >> 8) ^ crc_t[prev & 0xFF];
-    }
+    const uint32_t prev = crc_t[(j - 1) * 256 + tid];
+    crc_t[j * 256 + tid] = (prev >> 8) ^ crc_t[prev & 0xFF];
     __syncthreads();
   }
-  for (uint32_t i = tid; i < 1024; i += blockDim.x) row_t[i] = multmodp(e.x_row, (i & 255u) << (8 * (i >> 8)));
+  for (uint32_t i = tid; i < 1024; i += 256) row_t[i] = multmodp(e.x_row, (i & 255u) << (8 * (i >> 8)));
   __syncthreads();
-  // from here on the waves of the workgroup go their own ways
-  unsigned long long tick_ = e.dbg ? wall_clock64() : 0;
-  for (;;) {
-    uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(e.ticket, 1u);
-    const int64_t r = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-    if (r >= a.n_records) break;
-    ENC_TICK(0);
-    const bool emit = !a.emit || a.emit[r];
-    Layout L{};
-    int64_t size = 0;
-    if (emit) {
-      build_plan(a, r, pl, EncDbg{e.dbg}, tick_);
-      L = layout_of(a, r, pl);
-      size = (int64_t)L.payload + (a.frame ? 16 : 0);
-    }
-    ENC_TICK(5);
-    long long excl = 0;  // where the record starts: sizes of the records before it
-    if (e.skip & 16) {
-      excl = r * 41400;
-    } else {
-      if (lane == 0)
-        __hip_atomic_store(&e.desc[r], (r == 0 ? DESC_TOTAL : DESC_SIZE) | (unsigned long long)size, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      for (int64_t j = r - 1; j >= 0; j -= 64) {
-        const int64_t idx = j - lane;
-        unsigned long long v;
-        for (;;) {
-          v = idx >= 0 ? __hip_atomic_load(&e.desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : DESC_TOTAL;
-          if (__ballot((v >> 62) == 0) == 0) break;
-          __builtin_amdgcn_s_sleep(1);
-        }
-        const unsigned long long totals = __ballot((v >> 62) == 2);
-        long long val = (long long)(v & DESC_VAL);
-        if (totals && lane > __ffsll((long long)totals) - 1) val = 0;  // nothing beyond the nearest running total
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) val += __shfl_xor(val, o, 64);
-        excl += val;
-        if (totals) break;
-      }
-      if (lane == 0 && r > 0)
-        __hip_atomic_store(&e.desc[r], DESC_TOTAL | (unsigned long long)(excl + size), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    ENC_TICK(6);
-    const int64_t off = excl;
-    const bool fits = off + size <= e.out_cap;
-    if (lane == 0) {
-      rec_off[r] = off;
-      if (r == a.n_records - 1) rec_off[a.n_records] = off + size;
-      if (!fits) *status = 1;
-    }
-    if (emit && fits) write_record(a, e, pl, L, r, out + off, crc_t, row_t, tick_);
+  // from here on the waves go their own ways
+  if (w >= wf) return;
+  const int64_t r = (int64_t)grp * wf + w;
+  if (r >= a.n_records) return;
+  uint32_t* seg = (uint32_t*)(e.plans + (size_t)r * e.plan_stride);
+  if (seg[0] == NONE) return;
+  Plan pl;
+  carve(a, (unsigned char*)seg, pl);  // the plan is read where the plan pass left it ...
+  if constexpr (!BIG) {  // ... but for the stream, which every edge looks into twice: into this wave's LDS segment
+    uint32_t* mine = (uint32_t*)(s_dyn + (size_t)w * e.lds_stride);
+    const uint32_t n_s = (uint32_t)(a.trees * a.tree_len);
+    for (uint32_t i = lane; i < n_s; i += 64) mine[i] = pl.ids[i];
     wave_sync();
-    ENC_TICK(11);  // the plan's storage is reused by the wave's next record
+    pl.ids = mine;
   }
+  pl.n_uniq = pl.hdr[0];
+  pl.nodes_bytes = pl.hdr[1];
+  pl.edges_bytes = pl.hdr[2];
+  const Layout L = layout_of(a, r, pl);
+  write_fields(a, e, pl, L, r, out + rec_off[r], crc_t, row_t, shift_t);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1507,80 +1527,52 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
                  (long long)one);
   }
   EncArgs e{};
-  e.out_cap = out_cap;
   e.x_row = host_x8n(4ull * (uint64_t)a.d);
-  if (const char* sk = getenv("GIGL_ENC_SKIP")) e.skip = (uint32_t)atoi(sk);
-  static unsigned long long* dbg_buf = nullptr;
-  if (getenv("GIGL_ENC_DBG")) {
-    if (!dbg_buf) {
-      (void)hipMalloc((void**)&dbg_buf, 16 * 8);
-      (void)hipMemset(dbg_buf, 0, 16 * 8);
-    }
-    e.dbg = dbg_buf;
-    unsigned long long h[16];
-    (void)hipMemcpy(h, dbg_buf, sizeof h, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[enc dbg ticks]");
-    for (int k = 0; k < 12; ++k) fprintf(stderr, " %llu", h[k]);
-    fprintf(stderr, "\n");
-    (void)hipMemset(dbg_buf, 0, 16 * 8);
-  }
   if (feat && a.frame && a.d > 0) {
     const uint32_t* rc_tbl = nullptr;
     rc = gigl_features_row_crc(ctx, feat, &rc_tbl);
     if (rc != GIGL_OK) return rc;
     e.row_crc = rc_tbl;
   }
-  // persistent grid of waves, one record per wave at a time: the workgroup shape that keeps most waves per CU
-  const size_t plan = plan_bytes(a);
+  // waves per workgroup: as many plans as fit LDS (4, 2 or 1); plans beyond LDS are built in scratch
+  const size_t plan = plan_bytes(a), kept = kept_bytes(a);
   const bool big = plan > PLAN_LDS_BYTES;
-  const void* kern = big ? (const void*)record_encode_kernel<true> : (const void*)record_encode_kernel<false>;
-  if (!big && plan + 9 * 1024 > 48 * 1024)
-    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PLAN_LDS_BYTES));
-  int cus = 0, waves = 1, per_cu = 1;
-  GIGL_HIP_CHECK(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-  {
-    int best = 0;
-    for (int w : {16, 12, 8, 6, 4, 2, 1}) {
-      if (!big && (size_t)w * plan > PLAN_LDS_BYTES) continue;
-      int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 64 * w, big ? 0 : (size_t)w * plan) != hipSuccess) {
-        (void)hipGetLastError();
-        continue;
-      }
-      if (nb * w > best) {
-        best = nb * w;
-        waves = w;
-        per_cu = nb;
-      }
-    }
-    GIGL_REQUIRE(ctx, best > 0, "no launch shape for a record plan of %zu bytes", plan);
-  }
-  const size_t lds = big ? 0 : (size_t)waves * plan;
-  int64_t grid = (int64_t)per_cu * (cus > 0 ? cus : 1);
-  if (grid * waves > n_records) grid = (n_records + waves - 1) / waves;
-  if (grid < 1) grid = 1;
-  const int64_t desc_bytes = (n_records + 1) * 8 + 256;
-  e.plan_stride = big ? (plan + 255) & ~(size_t)255 : plan;
-  const int64_t scratch_bytes = big ? (int64_t)e.plan_stride * grid * waves : 0;
-  rc = gigl_arena_reset(ctx, desc_bytes + 512 + scratch_bytes);
+  int wp = 4, wf = 4;
+  while (!big && (size_t)wp * plan > PLAN_LDS_BYTES) wp >>= 1;
+  const size_t stream_bytes = ((size_t)4 * a.trees * a.tree_len + 15) & ~(size_t)15;  // (below 17 KB whenever !big)
+  const size_t lds_p = big ? 0 : (size_t)wp * plan, lds_w = big ? 0 : (size_t)wf * stream_bytes;
+  if (lds_p > 48 * 1024)
+    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)record_plan_kernel<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+  if (lds_w > 32 * 1024)
+    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)record_write_kernel<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_w));
+  e.plan_stride = big ? plan : kept;
+  e.lds_stride = 0;
+  const int64_t nb = n_records > 0 ? n_records : 1;
+  const int64_t plans_bytes = nb * (int64_t)e.plan_stride;
+  rc = gigl_arena_reset(ctx, (n_records + 1) * 8 + plans_bytes + 1024);
   if (rc != GIGL_OK) return rc;
-  e.desc = (unsigned long long*)gigl_arena_alloc(ctx, desc_bytes);
-  if (!e.desc) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
-  e.ticket = (uint32_t*)(e.desc + n_records + 1);
-  if (big) {
-    e.scratch = (unsigned char*)gigl_arena_alloc(ctx, scratch_bytes);
-    if (!e.scratch) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
-  }
-  GIGL_HIP_CHECK(ctx, hipMemsetAsync(e.desc, 0, (size_t)desc_bytes, ctx->stream));
-  GIGL_HIP_CHECK(ctx, hipMemsetAsync(status, 0, 4, ctx->stream));
-  GIGL_HIP_CHECK(ctx, hipMemsetAsync(rec_off, 0, 8, ctx->stream));  // (n_records == 0: rec_off[0] = 0)
+  e.rec_size = (int64_t*)gigl_arena_alloc(ctx, (n_records + 1) * 8);
+  e.plans = (unsigned char*)gigl_arena_alloc(ctx, plans_bytes);
+  if (!e.rec_size || !e.plans) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   if (n_records > 0) {
+    const unsigned gp = (unsigned)((n_records + wp - 1) / wp);
+    e.lds_stride = plan;
+    if (big) hipLaunchKernelGGL(record_plan_kernel<true>, dim3(gp), dim3(64 * wp), 0, ctx->stream, a, e);
+    else hipLaunchKernelGGL(record_plan_kernel<false>, dim3(gp), dim3(64 * wp), lds_p, ctx->stream, a, e);
+  }
+  hipLaunchKernelGGL(record_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int64_t*)e.rec_size, n_records,
+                     out_cap, rec_off, status);
+  if (n_records > 0) {
+    const unsigned gw = (unsigned)((n_records + wf - 1) / wf + (a.d > 0 ? n_records : 0));
+    e.lds_stride = stream_bytes;
     if (big)
-      hipLaunchKernelGGL(record_encode_kernel<true>, dim3((unsigned)grid), dim3(64 * waves), 0, ctx->stream, a, e, out,
-                         rec_off, status);
+      hipLaunchKernelGGL(record_write_kernel<true>, dim3(gw), dim3(256), 0, ctx->stream, a, e, (const int64_t*)rec_off,
+                         (const int32_t*)status, out, (uint32_t)wf);
     else
-      hipLaunchKernelGGL(record_encode_kernel<false>, dim3((unsigned)grid), dim3(64 * waves), lds, ctx->stream, a, e, out,
-                         rec_off, status);
+      hipLaunchKernelGGL(record_write_kernel<false>, dim3(gw), dim3(256), lds_w, ctx->stream, a, e,
+                         (const int64_t*)rec_off, (const int32_t*)status, out, (uint32_t)wf);
   }
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
