@@ -425,18 +425,25 @@ __device__ __forceinline__ Layout layout_of(const RecArgs& a, int64_t r, const P
 
 extern __shared__ __align__(16) unsigned char s_dyn[];
 
-// exclusive scan of the record sizes (one workgroup); status = 1 when the output does not fit
+// exclusive scan of the record sizes (one workgroup, 8 consecutive sizes per thread and round); status = 1 when the
+// output does not fit
 __global__ __launch_bounds__(1024) void record_scan_kernel(const int64_t* rec_size, int64_t n, int64_t cap,
                                                            int64_t* rec_off, int32_t* status) {
   __shared__ int64_t s_w[16];
   __shared__ int64_t s_run;
+  constexpr int PER = 8;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_run = 0;
   __syncthreads();
-  for (int64_t base = 0; base < n; base += 1024) {
-    const int64_t i = base + threadIdx.x;
-    const int64_t v = i < n ? rec_size[i] : 0;
-    int64_t inc = v;
+  for (int64_t base = 0; base < n; base += 1024 * PER) {
+    const int64_t i0 = base + (int64_t)threadIdx.x * PER;
+    int64_t v[PER], mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      v[k] = i0 + k < n ? rec_size[i0 + k] : 0;
+      mine += v[k];
+    }
+    int64_t inc = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int64_t u = __shfl_up(inc, o, 64);
@@ -446,7 +453,12 @@ __global__ __launch_bounds__(1024) void record_scan_kernel(const int64_t* rec_si
     __syncthreads();
     int64_t pre = s_run;
     for (int j = 0; j < w; ++j) pre += s_w[j];
-    if (i < n) rec_off[i] = pre + inc - v;
+    int64_t run = pre + inc - mine;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (i0 + k < n) rec_off[i0 + k] = run;
+      run += v[k];
+    }
     __syncthreads();
     if (threadIdx.x == 1023) s_run = pre + inc;
     __syncthreads();
@@ -462,12 +474,6 @@ __device__ __forceinline__ uint32_t feat_word(const RecArgs& a, uint32_t id, uin
   if ((int64_t)id >= a.feat_n) return 0u;  // id outside the table: zeros (never happens for a consistent ingest)
   if (a.feat_dtype == GIGL_DTYPE_F32) return ((const uint32_t*)a.feat)[(int64_t)id * a.d + k];
   return __float_as_uint(__half2float(((const __half*)a.feat)[(int64_t)id * a.d + k]));
-}
-__device__ __forceinline__ void put_word(uint8_t* p, uint32_t v) {
-  p[0] = (uint8_t)v;
-  p[1] = (uint8_t)(v >> 8);
-  p[2] = (uint8_t)(v >> 16);
-  p[3] = (uint8_t)(v >> 24);
 }
 
 // ---- CRC-32C pieces (reflected domain: bit 31 of a word is the coefficient of x^0)
@@ -1275,7 +1281,7 @@ __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int
         *q++ = 0x22;
         q = put_varint(q, 4u * de);
         const float* fr = a.efeat[t].feat + (int64_t)pe * de;
-        for (uint32_t w2 = 0; w2 < de; ++w2) put_word(q + 4u * w2, __float_as_uint(fr[w2]));
+        for (uint32_t w2 = 0; w2 < de; ++w2) *(u32_unaligned*)(q + 4u * w2) = __float_as_uint(fr[w2]);
       }
     }
     run += tot;
@@ -1289,7 +1295,7 @@ __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int
     if (t >= (uint32_t)a.n_node_types || !a.feat[t].x || a.feat[t].d <= 0) continue;
     const float* src = a.feat[t].x + (int64_t)id * a.feat[t].d;
     uint8_t* dst = rec + pay[i];
-    for (int e = lane; e < a.feat[t].d; e += 64) put_word(dst + 4 * e, __float_as_uint(src[e]));
+    for (int e = lane; e < a.feat[t].d; e += 64) *(u32_unaligned*)(dst + 4 * e) = __float_as_uint(src[e]);  // (unaligned stores)
   }
   if (!a.frame) return;
   __threadfence_block();
