@@ -277,11 +277,14 @@ def main():
                          "GraphSAGE forward with autograd over the union graph, cross-entropy on the roots, backward "
                          "(gigl_gather_reduce_backward + the projections' backward GEMMs) and the Adam update — the loop of "
                          "NodeClassificationModelingTaskSpec._train; a secondary line with its own roofline / cpu_baseline")
-    ap.add_argument("--entry", type=str, default="plan", choices=["plan", "inferencer"],
+    ap.add_argument("--entry", type=str, default="plan", choices=["plan", "inferencer", "sampler"],
                     help="plan = the library's one-call plan driven by this script (the headline); inferencer = the same "
                          "workload through the drop-in entry point's own loop (gigl_amd.inferencer.Inferencer."
                          "infer_resident -> plugin.infer_batch -> in-HBM route -> Avro shards): one step = one batch of "
-                         "the full inference pass over every node")
+                         "the full inference pass over every node; sampler = the Subgraph Sampler job's step (S3-S9): "
+                         "k-hop sample of a batch of roots + its RootedNodeNeighborhood TFRecords encoded on the device "
+                         "(gigl_sample_khop + gigl_records_encode), records left in HBM; --batch defaults to the job's "
+                         "4096 roots")
     ap.add_argument("--entry-sink", type=str, default="avro-device", choices=["avro-device", "avro-files", "none"],
                     help="--entry inferencer: avro-device (the line's value) = rows encoded as Avro data blocks on the "
                          "device, the blocks stay in HBM (outputs resident, like the inputs); avro-files = additionally "
@@ -290,7 +293,7 @@ def main():
     args = ap.parse_args()
     wl_fan, wl_b = WORKLOAD_DEFAULTS.get(args.workload, ("25,10", 1024))
     args.fanouts = args.fanouts or wl_fan
-    args.batch = args.batch or wl_b
+    args.batch = args.batch or (4096 if args.entry == "sampler" else wl_b)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # no launcher: this process becomes one
         sys.exit(self_launch(args))
@@ -312,6 +315,8 @@ def main():
         return run_train(args, rank, world, local_rank)
     if args.entry == "inferencer":
         return run_entry_inferencer(args, rank, world, local_rank)
+    if args.entry == "sampler":
+        return run_entry_sampler(args, rank, world, local_rank)
     if args.workload == "mag240m-sharded":
         return run_sharded(args, rank, world, local_rank)
     if args.workload == "gat-lp":
@@ -1425,6 +1430,208 @@ def run_entry_inferencer(args, rank, world, local_rank):
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_entry_sampler(args, rank, world, local_rank):
+    """--entry sampler: the Subgraph Sampler job's step on the workload's graph — a batch of B roots sampled k hops
+    (gigl_sample_khop, parity mode) and encoded as framed RootedNodeNeighborhood TFRecords on the device
+    (gigl_records_encode: per-root dedup, hydration from the resident table, proto3 + TFRecord framing with both
+    CRC-32C words), SGSPureSparkV1Task.scala:313-820 + TFRecordIO.scala:53-69.  Inputs and outputs resident in HBM (the
+    job's device-to-host copy of finished frames is the PCIe-inclusive figure of scripts/micro_records.py).  Calls are
+    issued back to back on the engine's stream into one output buffer; a replica per GPU at N > 1; a secondary line."""
+    import ctypes as C
+    from gigl_amd import _lib
+    from gigl_amd.engine import HipEngine
+
+    torch.cuda.set_device(local_rank)
+    eng = HipEngine(local_rank)
+    dev = eng.device
+    fanouts = [int(v) for v in args.fanouts.split(",")]
+    B = args.batch
+    t0 = time.time()
+    n, d = build_workload(eng, args)
+    wl_name, wl_label, hid, out_dim, wl_directed, wl_dtype = args._workload
+    g = torch.Generator().manual_seed(42)
+    perm = torch.randperm(n, generator=g)
+    n_batches = max(8, min(64, n // B // max(world, 1)))
+    pool = [perm[(rank + world * i) * B:(rank + world * i + 1) * B].to(torch.int32).to(dev) for i in range(n_batches)]
+    trees = [eng.alloc_tree(B, fanouts) for _ in range(2)]
+    # sizes and content once, through the public entry (also builds the per-row CRC table: one-time, reported)
+    t1 = time.time()
+    tbl = C.c_void_p()
+    _lib.check(eng._lib.gigl_features_row_crc(eng._ctx, eng._feat, C.byref(tbl)), eng._ctx)
+    eng._stream.synchronize()
+    row_crc_s = time.time() - t1
+    sizes, edges_b, nodes_b = [], [], []
+    for r in pool:
+        tree = eng.sample_khop(r, fanouts, out=trees[0])
+        buf, off = eng.encode_records(tree)
+        sizes.append(int(buf.numel()))
+        edges_b.append(int(sum(int((t_ != -1).sum().item()) for t_ in tree.nbr)))
+    from gigl_amd import wire
+    head = buf[: int(off[4].item())].cpu().numpy().tobytes()
+    n_ok = sum(1 for _ in wire.iter_tfrecords(head))  # (the reader verifies both CRC words of every frame)
+    assert n_ok == 4
+    cap = max(sizes) + 4096
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    rec_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    o = _lib.GiglRecordOpts()
+    o.kind, o.trees_per_record, o.tfrecord_frame = _lib.REC_ROOTED_NODE_NEIGHBORHOOD, 1, 1
+    o.condensed_node_type = o.condensed_edge_type = 0
+    fo = (C.c_int32 * len(fanouts))(*fanouts)
+
+    def step(i, encode=True, sample=True):
+        tree = trees[i & 1]
+        r = pool[i % n_batches]
+        if sample:
+            tree.roots = r
+            _lib.check(eng._lib.gigl_sample_khop(eng._ctx, eng._graph, C.c_void_p(r.data_ptr()), B, fo, len(fanouts), 42,
+                                                 _lib.MODE_SPARK_HASH if args.mode == "parity" else _lib.MODE_FAST,
+                                                 C.byref(tree.c_struct)), eng._ctx)
+        if encode:
+            _lib.check(eng._lib.gigl_records_encode(eng._ctx, C.c_void_p(r.data_ptr()), C.byref(tree.c_struct), eng._feat,
+                                                    C.byref(o), B, C.c_void_p(out.data_ptr()), cap,
+                                                    C.c_void_p(rec_off.data_ptr()), C.c_void_p(status.data_ptr())),
+                       eng._ctx)
+
+    for tr in trees:
+        tr.c_struct.hops, tr.c_struct.b = len(fanouts), B
+        for k, f in enumerate(fanouts):
+            tr.c_struct.fanouts[k] = f
+    for i in range(max(4, args.warmup // 8)):
+        step(i)
+    eng._stream.synchronize()
+    assert int(status.item()) == 0
+    setup_s = time.time() - t0
+    K_rep = max(n_batches, -(-max(1, args.steps // 8) // n_batches) * n_batches)
+
+    def timed(reps, **kw):
+        ts = []
+        for _ in range(reps):
+            if world > 1:
+                import torch.distributed as dist
+                dist.barrier()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t_w = time.perf_counter()
+            e0.record(eng._stream)
+            for i in range(K_rep):
+                step(i, **kw)
+            e1.record(eng._stream)
+            e1.synchronize()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t_w, e0.elapsed_time(e1) * 1e-3))
+        return np.array(ts)
+
+    reps = args.min_reps
+    while True:
+        full = timed(reps)
+        if full[:, 0].sum() >= args.min_seconds or reps >= 4096:
+            break
+        reps *= 2
+    enc_only = timed(max(3, reps // 4), sample=False)  # the encoder's share: HIP events on its stream, same calls
+    wall = torch.tensor(full[:, 0], dtype=torch.float64, device=dev)
+    if world > 1:
+        all_reduce(wall, torch.distributed.ReduceOp.MAX)
+    wall = wall.cpu().numpy()
+    elapsed = float(wall.sum())
+    steps_total = reps * K_rep
+    sampled_per_step = float(np.mean(edges_b))
+    bytes_per_step = float(np.mean(sizes))
+    # algorithmic bytes of the encoder per call (SURVEY 8(d), S6-S9): the finished record bytes written + 4*D read per
+    # DISTINCT node of every record (what the payloads are copied from) + the tree slots read once
+    slots = 1 + sum(int(np.prod(fanouts[:k + 1])) for k in range(len(fanouts)))
+    # node fields of a step, from the record sizes: bytes = fields * (4 D + ~10 header bytes) + edges * ~12.5 + ~30 / record
+    fields_per_step = max(0.0, (bytes_per_step - 12.5 * sampled_per_step - 30.0 * B) / (4 * d + 10))
+    enc_ms = float(np.median(enc_only[:, 1])) / K_rep * 1e3
+    alg_bytes = bytes_per_step + min(fields_per_step, B * slots) * 4 * d + 4.0 * slots * B
+    achieved = alg_bytes / (enc_ms * 1e-3) / 1e9
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_records_baseline(eng, pool[0], fanouts, d)
+    if rank == 0:
+        q = lambda a, p: float(np.percentile(a, p))
+        ms_rep = wall / K_rep * 1e3
+        line = {
+            "metric": "sampled edges/s (sampler job step: sample + encode records)",
+            "value": sampled_per_step * steps_total * world / elapsed, "unit": "edges/s", "n_gpus": world,
+            "steps": steps_total, "warmup": max(4, args.warmup // 8), "ms_per_step": elapsed / steps_total * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "timing": {"repetitions": reps, "steps_per_repetition": K_rep, "timed_region_s": round(elapsed, 3),
+                       "ms_per_step_median": q(ms_rep, 50), "ms_per_step_p10": q(ms_rep, 10),
+                       "ms_per_step_p90": q(ms_rep, 90)},
+            "config": {"workload": wl_label + f" N={n} E={eng.n_edges} D={d} fp32 features, fanout={fanouts}, B={B} roots "
+                                            "per step: k-hop sample (sampler mode=" + args.mode + ") + framed "
+                                            "RootedNodeNeighborhood TFRecords encoded on the device, records left in HBM",
+                       "entry": "gigl_sample_khop + gigl_records_encode (what SubgraphSampler.run issues per batch)",
+                       "records_per_s": B * steps_total * world / elapsed,
+                       "record_bytes_per_s": bytes_per_step * steps_total * world / elapsed,
+                       "bytes_per_record": bytes_per_step / B, "sampled_edges_per_step": sampled_per_step,
+                       "encode_only_ms_per_step": enc_ms, "row_crc_table_build_s": round(row_crc_s, 4),
+                       "setup_s": round(setup_s, 1)},
+            "roofline": {"bound": "hbm", "kernel": "gigl_records_encode (record_plan + record_scan + record_write)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "alg_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(enc_ms * 1e3, 1),
+                         "launches": int(max(3, reps // 4) * K_rep),
+                         "timing": "HIP events on the engine's stream around back-to-back encode calls (no sampling "
+                                   "in between), median over repetitions",
+                         "node_fields_per_step": round(fields_per_step),
+                         "bytes": "record bytes written + 4*D read per node field (fields estimated from the record "
+                                  "sizes) + 4 B per tree slot read"},
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line))
+    eng.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_cpu_records_baseline(eng, roots, fanouts, d, budget_s=15.0):
+    """the oracle's sampler + its restatement of the job's output stage (oracle/records.py: per-root assembly, proto3
+    encoding, TFRecord framing with CRC-32C — numpy / pure Python, one core) on a bounded sample of the same roots"""
+    import oracle
+    from oracle import records as R
+    rowptr, col = eng.graph_to_host()
+    r_np = roots.cpu().numpy().view(np.uint32)
+
+    class _Rows:  # feature rows of the sampled nodes on demand (the table stays in HBM: 1 GB; untimed fetches)
+        def __init__(self):
+            self.cache = {}
+
+        def prefetch(self, ids):
+            ids = np.unique(np.asarray(ids, dtype=np.int64))
+            t = torch.from_numpy(ids).to(torch.int32).to(eng.device)
+            n_dev = torch.tensor([t.numel()], dtype=torch.int32, device=eng.device)
+            rows = eng.gather_rows(t, n_dev, int(t.numel())).cpu().numpy()
+            self.cache = {int(i): rows[k] for k, i in enumerate(ids.tolist())}
+
+        def __getitem__(self, v):
+            return self.cache[int(v)]
+    feats = _Rows()
+    done, edges, used = 0, 0, 0.0
+    chunk = 16
+    while used < budget_s and done < r_np.size:
+        rr = r_np[done:done + chunk]
+        t1 = time.perf_counter()
+        nbr, _cnt = oracle.sample_khop(rowptr, col, rr, fanouts, canonical=True)
+        trees_ = R.tree_edges(rr, fanouts, nbr)
+        used += time.perf_counter() - t1
+        feats.prefetch(np.concatenate([rr.astype(np.int64)] + [s_ for s_, _ in trees_]))
+        t1 = time.perf_counter()
+        for root, (s_, d_) in zip(rr.tolist(), trees_):
+            R.tfrecord_frame(R.rooted_node_neighborhood_record(root, s_, d_, feats, 0, 0))
+            edges += int(s_.size)
+        used += time.perf_counter() - t1
+        done += rr.size
+    dt = used
+    return {"value": edges / dt, "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"{done} roots of the same batch in {dt:.1f} s: oracle/gigl_oracle.c sampler (1 thread) + "
+                      "oracle/records.py assembly, proto3 encoding and TFRecord framing (numpy / pure Python, 1 thread); "
+                      f"{done / dt:.1f} records/s"}
 
 
 def _lib_stats_len():
