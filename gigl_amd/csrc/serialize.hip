@@ -855,7 +855,8 @@ __device__ __attribute__((always_inline)) void write_fields(const RecArgs& a, co
 
 // the float payloads of record r's node fields: this wave's share (wave q of ROWS_WPR) of the (entry, 16-byte chunk)
 // items, dealt in groups of 64 * UNR
-constexpr int ROWS_WPR = 4;
+constexpr int ROWS_WGS = 1;             // row-copier workgroups per record (2: no better; more loads in flight per wave: worse)
+constexpr int ROWS_WPR = 4 * ROWS_WGS;  // = waves per record
 __device__ __attribute__((always_inline)) void write_rows(const RecArgs& a, const uint32_t* seg, uint8_t* rec_start,
                                                           uint32_t q) {
   const uint32_t lane = threadIdx.x & 63;
@@ -872,7 +873,7 @@ __device__ __attribute__((always_inline)) void write_rows(const RecArgs& a, cons
   const uint32_t D = (uint32_t)a.d, nch = (D + 3) / 4;
   const uint32_t total = n_items * nch;
   const bool vec_rows = a.feat_dtype == GIGL_DTYPE_F32 && (D & 3u) == 0;  // rows are 16-byte aligned
-  constexpr int UNR = 4;  // row loads of UNR items are issued before any of them is consumed
+  constexpr int UNR = 2;  // row loads of UNR items are issued before any of them is consumed
   for (uint32_t i0 = q * 64 * UNR; i0 < total; i0 += ROWS_WPR * 64 * UNR) {
     uint32_t k0[UNR], wv[UNR][4];
     gptr_t dst[UNR];
@@ -928,11 +929,11 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, EncArgs e,
   const uint32_t grp = blockIdx.x;
   if (blockIdx.x >= n_grp) {  // rows
     if (a.d <= 0) return;
-    const int64_t r = (int64_t)(blockIdx.x - n_grp);
+    const int64_t r = (int64_t)((blockIdx.x - n_grp) / ROWS_WGS);
     if (r >= a.n_records) return;
     const uint32_t* seg = (const uint32_t*)(e.plans + (size_t)r * e.plan_stride);
     if (seg[0] == NONE) return;
-    write_rows(a, seg, out + rec_off[r], w);
+    write_rows(a, seg, out + rec_off[r], ((blockIdx.x - n_grp) % ROWS_WGS) * 4 + w);
     return;
   }
   __shared__ uint32_t crc_t[1024];
@@ -1571,7 +1572,7 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
   hipLaunchKernelGGL(record_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int64_t*)e.rec_size, n_records,
                      out_cap, rec_off, status);
   if (n_records > 0) {
-    const unsigned gw = (unsigned)((n_records + wf - 1) / wf + (a.d > 0 ? n_records : 0));
+    const unsigned gw = (unsigned)((n_records + wf - 1) / wf + (a.d > 0 ? n_records * ROWS_WGS : 0));
     e.lds_stride = stream_bytes;
     if (big)
       hipLaunchKernelGGL(record_write_kernel<true>, dim3(gw), dim3(256), 0, ctx->stream, a, e, (const int64_t*)rec_off,
