@@ -710,12 +710,40 @@ def main():
         sa = argparse.Namespace(**vars(args))
         sa.workload, sa.fanouts, sa.batch = "mag240m-sharded", "25,10", 1024
         sa.min_seconds, sa.min_reps, sa.min_rounds = min(args.min_seconds, 1.5), 3, 4
-        sub = run_sharded(sa, rank, world, local_rank, sub=True)
-        if rank == 0:
-            line["sharded"] = {k: sub[k] for k in ("value", "ms_per_step", "n_gpus", "steps", "timing", "config",
-                                                   "roofline_xgmi")}
+        # The headline above is complete; the sub-record must never cost it.  Its collectives (RCCL issued by the
+        # library) can fail on one rank and leave the others waiting: every rank arms a timer that — should the
+        # sub-record not come back — has rank 0 print the headline with the failure noted and ends the process.
+        done = threading.Event()
+
+        def give_up(reason):
+            if done.is_set():
+                return
+            done.set()
+            if rank == 0:
+                line["sharded"] = {"error": reason}
+                print(json.dumps(line), flush=True)
+            sys.stdout.flush()
+            os._exit(0)
+
+        limit = float(os.environ.get("GIGL_BENCH_SUB_TIMEOUT", "300"))
+        timer = threading.Timer(limit, give_up, args=(f"the sharded sub-record did not finish within {limit:.0f} s "
+                                                      "(GIGL_BENCH_SUB_TIMEOUT)",))
+        timer.daemon = True
+        timer.start()
+        try:
+            sub = run_sharded(sa, rank, world, local_rank, sub=True)
+            if rank == 0:
+                line["sharded"] = {k: sub[k] for k in ("value", "ms_per_step", "n_gpus", "steps", "timing", "config",
+                                                       "roofline_xgmi")}
+        except BaseException as ex:  # noqa: BLE001 — this rank failed; the others are ended by their timers
+            timer.cancel()
+            give_up(f"rank {rank}: {type(ex).__name__}: {str(ex)[:400]}")
+        timer.cancel()
+        if done.is_set():  # (the timer fired while the sub-record was finishing)
+            return
+        done.set()
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -51,3 +51,20 @@ def test_self_launch_two_ranks_on_one_gpu():
     assert sh["config"]["pulled_feature_rows_per_step"] > 0  # rows really travelled between the ranks
     assert 0 < sh["config"]["row_bucket_fill"] <= 1.0
     assert "replicated as hot rows" in sh["config"]["workload"]  # hub replication is on by default at world > 1
+
+
+@pytest.mark.gpu
+def test_a_failing_sharded_sub_record_never_costs_the_headline():
+    """the sub-record's collectives have not run on a real multi-GPU node yet: if it fails or hangs, rank 0 still prints
+    the (complete) headline line, with the failure noted, and every rank exits"""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--small", "--no-cpu-baseline", "--min-seconds", "0.3",
+                        "--min-reps", "2", "--min-rounds", "2", "--group", "8", "--shard-group", "4", "--shard-scale",
+                        "0.0005", "--steps", "16", "--warmup", "8"],
+                       env=_env(GIGL_BENCH_SHARE_GPU="1", GIGL_BENCH_SUB_TIMEOUT="0.001"), capture_output=True, text=True,
+                       timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"] is not None
+    assert "did not finish" in line["sharded"]["error"]
