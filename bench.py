@@ -725,7 +725,7 @@ def main():
             sys.stdout.flush()
             os._exit(0)
 
-        limit = float(os.environ.get("GIGL_BENCH_SUB_TIMEOUT", "300"))
+        limit = float(os.environ.get("GIGL_BENCH_SUB_TIMEOUT", "600"))
         timer = threading.Timer(limit, give_up, args=(f"the sharded sub-record did not finish within {limit:.0f} s "
                                                       "(GIGL_BENCH_SUB_TIMEOUT)",))
         timer.daemon = True
