@@ -55,6 +55,7 @@ SYMBOLS = [
     "gigl_sage_project_features", "gigl_sage_plan_set_projected_input",
     "gigl_dist_gat_plan_create", "gigl_dist_gat_plan_set_weights", "gigl_dist_plan_bucket_fill",
     "gigl_linear_weight_grad", "gigl_features_row_crc",
+    "gigl_typed_plan_create", "gigl_typed_plan_run", "gigl_typed_plan_buffers", "gigl_typed_plan_destroy",
 ]
 
 KERNEL_IDS = {
@@ -104,6 +105,24 @@ class GiglRecordOpts(C.Structure):
         ("neg_edges_graph", C.c_void_p),
         ("neg_edge_feat", C.c_void_p),
     ]
+
+
+GIGL_DAG_MAX_OPS, GIGL_DAG_MAX_PARENTS = 16, 8
+
+
+class GiglDagOp(C.Structure):
+    _fields_ = [("graph", C.c_void_p), ("fanout", C.c_int32), ("n_parents", C.c_int32),
+                ("parents", C.c_int32 * GIGL_DAG_MAX_PARENTS), ("hash_add", C.c_int32),
+                ("frontier_node_type", C.c_int32), ("result_node_type", C.c_int32), ("edge_slot", C.c_int32),
+                ("outgoing", C.c_int32)]
+
+
+class GiglTypedPlanOut(C.Structure):
+    _fields_ = [("n_nodes", C.c_void_p), ("n_edges", C.c_void_p), ("root_index", C.c_void_p),
+                ("nodes", C.c_void_p * 16), ("nodes_cap", C.c_int64 * 16),
+                ("edges", C.c_void_p * 32), ("edges_cap", C.c_int64 * 32),
+                ("op_frontier", C.c_void_p * GIGL_DAG_MAX_OPS), ("op_nbr", C.c_void_p * GIGL_DAG_MAX_OPS),
+                ("op_cnt", C.c_void_p * GIGL_DAG_MAX_OPS), ("op_width", C.c_int32 * GIGL_DAG_MAX_OPS)]
 
 
 class GiglTypedOp(C.Structure):
@@ -197,6 +216,10 @@ def load() -> C.CDLL:
         "gigl_features_load": [vp, i64, i32, i32, vp, i32, P(vp)],
         "gigl_features_device_ptr": [vp, P(vp), P(i64), P(i32), P(i32)],
         "gigl_features_row_crc": [vp, vp, P(vp)],
+        "gigl_typed_plan_create": [vp, P(GiglDagOp), i32, i32, i32, i32, i32, P(vp)],
+        "gigl_typed_plan_run": [vp, vp, i32],
+        "gigl_typed_plan_buffers": [vp, P(GiglTypedPlanOut)],
+        "gigl_typed_plan_destroy": [vp],
         "gigl_features_destroy": [vp],
         "gigl_sample_khop": [vp, vp, vp, i32, P(i32), i32, i32, i32, P(GiglTree)],
         "gigl_sample_positives": [vp, vp, vp, i32, i32, i32, i32, vp, vp],

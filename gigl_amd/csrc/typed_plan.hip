@@ -1,0 +1,457 @@
+// typed_plan.hip — the typed (heterogeneous) batch graph of a SamplingOp DAG in ONE host call.
+//
+// Replaces, for a batch of roots on a typed graph:
+//   GraphDBSampler.getKHopSubgraphForRootNode      scala_spark35/subgraph_sampler/src/main/scala/libs/sampler/
+//                                                   GraphDBSampler.scala:40-148 (per root: every op's frontier = the
+//                                                   set union of its parents' node sets; an op runs for a root only
+//                                                   when all its parents ran and its frontier is not empty)
+//   SamplingOpDAG                                   scala_spark35/common/src/main/scala/types/SamplingOpDAG.scala:19-53
+//   the trainer-side collate of the typed samples   python/gigl/src/common/graph_builder/abstract_graph_builder.py:49-150,
+//                                                   pyg_graph_builder.py:20-69 (per node type the distinct nodes, per
+//                                                   edge type the distinct edges, as local ids)
+// What gigl_amd/graphdb_sampler.py::batch_graph did with one library call per op and a chain of torch.unique /
+// searchsorted calls (each a host synchronisation: their output sizes are data) is one stream of device work here:
+//   per op      frontier = parents' results side by side (dag_frontier_kernel) -> gigl_rows_dedup -> ran / mask / path
+//               sums (dag_mask_kernel) -> gigl_expand_frontier on the op's (edge type, direction) graph
+//   per type    every id the ops produced for the type -> radix sort -> distinct, ascending = the type's local
+//               numbering (the numbering of batch_graph: torch.unique)
+//   per edge    endpoints -> local ids by binary search -> (src << 32 | dst) keys -> radix sort -> distinct
+//   roots       position of every root in its type's node list
+// Counts stay on the device (n_nodes[type], n_edges[edge slot]); the caller reads them once per batch.
+// Integer work; bound by the sorts (rocPRIM radix sort over ~b * sum(w * f) keys per type) and the sampler's
+// dependent loads, not by bandwidth.
+#include "common.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <vector>
+
+struct gigl_typed_plan {
+  gigl_ctx* ctx = nullptr;
+  int32_t n_ops = 0, n_types = 0, n_slots = 0, root_type = 0, b_max = 0;
+  std::vector<gigl_dag_op> ops;
+  std::vector<int32_t> width;          // frontier slots per root of every op
+  // device, per op: frontier [b][w], path sums [b][w], neighbours [b][w][f], counts [b][w], ran [b]
+  std::vector<uint32_t*> front, ksum, nbr;
+  std::vector<int32_t*> cnt;
+  std::vector<uint8_t*> ran;
+  // per node type: candidates / sorted (capacity cand_cap[t] per b_max), distinct ids, count
+  std::vector<int64_t> cand_per_root;  // candidate ids per root of the type
+  std::vector<uint32_t*> cand, sorted, nodes;
+  // per edge slot: keys / sorted keys, distinct (src_local << 32 | dst_local)
+  std::vector<int64_t> pairs_per_root;
+  std::vector<int32_t> slot_src_type, slot_dst_type;
+  std::vector<unsigned long long*> ekeys, esorted, edges;
+  int32_t* n_nodes = nullptr;   // [n_types]
+  int32_t* n_edges = nullptr;   // [n_slots]
+  int32_t* root_index = nullptr;  // [b_max]
+  int32_t *flags = nullptr, *scan = nullptr;  // [max items]
+  void* work = nullptr;
+  size_t work_bytes = 0;
+  int64_t max_items = 0;
+  std::vector<void*> owned;
+};
+
+namespace {
+
+constexpr int TB = 256;
+inline dim3 grid_of(int64_t n) { return dim3((unsigned)((n + TB - 1) / TB > 0 ? (n + TB - 1) / TB : 1)); }
+
+struct FrontierSrc {
+  const uint32_t* nbr[GIGL_DAG_MAX_PARENTS];
+  int32_t len[GIGL_DAG_MAX_PARENTS];  // w_p * f_p
+  int32_t n;
+};
+
+// front[r][off_p + j] = parent p's j-th result for root r (parents side by side); root ops: front[r][0] = roots[r]
+__global__ __launch_bounds__(TB) void dag_frontier_kernel(FrontierSrc s, const uint32_t* roots, int64_t b, int32_t w,
+                                                          uint32_t* front) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b * w) return;
+  const int64_t r = i / w;
+  int32_t j = (int32_t)(i - r * w);
+  if (s.n == 0) {
+    front[i] = roots[r];
+    return;
+  }
+  for (int p = 0; p < s.n; ++p) {
+    if (j < s.len[p]) {
+      front[i] = s.nbr[p][r * s.len[p] + j];
+      return;
+    }
+    j -= s.len[p];
+  }
+}
+
+struct RanSrc {
+  const uint8_t* ran[GIGL_DAG_MAX_PARENTS];
+  int32_t n;
+};
+
+// one wave per root: the op runs for the root when every parent ran and the (deduplicated) frontier is not empty
+// (GraphDBSampler.scala:66-86); otherwise its row is emptied.  ksum = frontier id + root (uint32 wrap == the sampler's
+// int32 add)
+__global__ __launch_bounds__(TB) void dag_mask_kernel(RanSrc s, const uint32_t* roots, int64_t b, int32_t w,
+                                                      uint32_t* front, uint32_t* ksum, uint8_t* ran) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * (TB / 64) + (threadIdx.x >> 6);
+  if (r >= b) return;
+  bool any = false;
+  for (int32_t j = lane; j < w; j += 64) any |= front[r * w + j] != GIGL_INVALID;
+  bool ok = __ballot(any) != 0;
+  for (int p = 0; p < s.n; ++p) ok = ok && s.ran[p][r] != 0;
+  if (lane == 0) ran[r] = ok ? 1 : 0;
+  const uint32_t root = roots[r];
+  for (int32_t j = lane; j < w; j += 64) {
+    const uint32_t v = ok ? front[r * w + j] : GIGL_INVALID;
+    front[r * w + j] = v;
+    ksum[r * w + j] = v + root;
+  }
+}
+
+// the ids an op contributes to its two node types: a frontier id where it has at least one sampled neighbour, every
+// sampled neighbour
+__global__ __launch_bounds__(TB) void cand_frontier_kernel(const uint32_t* front, const int32_t* cnt, int64_t m,
+                                                           uint32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) out[i] = cnt[i] > 0 ? front[i] : GIGL_INVALID;
+}
+__global__ __launch_bounds__(TB) void copy_u32_kernel(const uint32_t* src, int64_t m, uint32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) out[i] = src[i];
+}
+template <typename K>
+__global__ __launch_bounds__(TB) void head_flags_kernel(const K* sorted, int64_t m, K pad, int32_t* flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) flags[i] = (sorted[i] != pad && (i == 0 || sorted[i - 1] != sorted[i])) ? 1 : 0;
+}
+template <typename K>
+__global__ __launch_bounds__(TB) void compact_kernel(const K* sorted, const int32_t* flags, const int32_t* scan,
+                                                     int64_t m, K* out, int32_t* count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  if (flags[i]) out[scan[i]] = sorted[i];
+  if (i == m - 1) *count = scan[i] + flags[i];
+}
+
+// position of v in the ascending list a[0 .. n) (v is in it)
+__device__ __forceinline__ uint32_t lower_bound(const uint32_t* a, int32_t n, uint32_t v) {
+  int32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return (uint32_t)lo;
+}
+
+// an op's sampled edges as (src_local << 32 | dst_local) keys of its edge slot
+__global__ __launch_bounds__(TB) void edge_keys_kernel(const uint32_t* front, const uint32_t* nbr, int64_t m, int32_t f,
+                                                       int32_t outgoing, const uint32_t* nodes_front,
+                                                       const int32_t* n_front, const uint32_t* nodes_got,
+                                                       const int32_t* n_got, unsigned long long* keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * f) return;
+  const uint32_t fr = front[i / f], nb = nbr[i];
+  unsigned long long k = ~0ull;
+  if (fr != GIGL_INVALID && nb != GIGL_INVALID) {
+    const unsigned long long lf = lower_bound(nodes_front, *n_front, fr), lg = lower_bound(nodes_got, *n_got, nb);
+    k = outgoing ? (lf << 32) | lg : (lg << 32) | lf;
+  }
+  keys[i] = k;
+}
+
+__global__ __launch_bounds__(TB) void root_index_kernel(const uint32_t* roots, int64_t b, const uint32_t* nodes,
+                                                        const int32_t* n, int32_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < b) out[i] = (int32_t)lower_bound(nodes, *n, roots[i]);
+}
+
+template <typename T>
+int32_t dev_alloc(gigl_typed_plan* p, T** out, int64_t count) {
+  void* q = nullptr;
+  if (hipMalloc(&q, (size_t)(count > 0 ? count : 1) * sizeof(T)) != hipSuccess)
+    return gigl_fail(p->ctx, GIGL_E_OOM, "typed plan: hipMalloc of %lld bytes failed", (long long)(count * sizeof(T)));
+  p->owned.push_back(q);
+  *out = (T*)q;
+  return GIGL_OK;
+}
+
+int key_bits(int64_t cap) {
+  int bits = 1;
+  while (bits < 32 && ((int64_t)1 << bits) < cap) ++bits;
+  return bits;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t gigl_typed_plan_destroy(gigl_typed_plan* p) {
+  if (!p) return GIGL_OK;
+  if (p->ctx) {
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+  }
+  for (void* q : p->owned) hipFree(q);
+  delete p;
+  return GIGL_OK;
+}
+
+int32_t gigl_typed_plan_create(gigl_ctx* ctx, const gigl_dag_op* ops, int32_t n_ops, int32_t n_node_types,
+                               int32_t root_node_type, int32_t n_edge_slots, int32_t b_max, gigl_typed_plan** out) {
+  if (!ctx || !out) return GIGL_E_INVALID_ARG;
+  *out = nullptr;
+  GIGL_REQUIRE(ctx, ops && n_ops >= 1 && n_ops <= GIGL_DAG_MAX_OPS, "between 1 and %d sampling ops", GIGL_DAG_MAX_OPS);
+  GIGL_REQUIRE(ctx, n_node_types >= 1 && n_node_types <= 16 && root_node_type >= 0 && root_node_type < n_node_types,
+               "node types outside [1,16]");
+  GIGL_REQUIRE(ctx, n_edge_slots >= 1 && n_edge_slots <= 32 && b_max >= 1, "bad edge slots / batch size");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  gigl_typed_plan* p = new (std::nothrow) gigl_typed_plan();
+  if (!p) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
+  p->ctx = ctx;
+  p->n_ops = n_ops;
+  p->n_types = n_node_types;
+  p->n_slots = n_edge_slots;
+  p->root_type = root_node_type;
+  p->b_max = b_max;
+  p->ops.assign(ops, ops + n_ops);
+  p->width.assign(n_ops, 0);
+  p->cand_per_root.assign(n_node_types, 0);
+  p->pairs_per_root.assign(n_edge_slots, 0);
+  p->slot_src_type.assign(n_edge_slots, -1);
+  p->slot_dst_type.assign(n_edge_slots, -1);
+  p->cand_per_root[root_node_type] = 1;
+  int32_t rc = GIGL_OK;
+#define PLAN_FAIL(...)                              \
+  do {                                              \
+    rc = gigl_fail(ctx, GIGL_E_INVALID_ARG, __VA_ARGS__); \
+    gigl_typed_plan_destroy(p);                     \
+    return rc;                                      \
+  } while (0)
+  for (int o = 0; o < n_ops; ++o) {
+    const gigl_dag_op& op = p->ops[o];
+    if (!op.graph || op.fanout < 1 || op.fanout > GIGL_MAX_FANOUT) PLAN_FAIL("op %d: no graph or fanout outside [1,%d]", o, GIGL_MAX_FANOUT);
+    if (op.n_parents < 0 || op.n_parents > GIGL_DAG_MAX_PARENTS) PLAN_FAIL("op %d: more than %d parents", o, GIGL_DAG_MAX_PARENTS);
+    if (op.frontier_node_type < 0 || op.frontier_node_type >= n_node_types || op.result_node_type < 0 ||
+        op.result_node_type >= n_node_types || op.edge_slot < 0 || op.edge_slot >= n_edge_slots)
+      PLAN_FAIL("op %d: a type outside the metadata", o);
+    int64_t w = op.n_parents == 0 ? 1 : 0;
+    for (int k = 0; k < op.n_parents; ++k) {
+      const int pp = op.parents[k];
+      if (pp < 0 || pp >= o) PLAN_FAIL("op %d: parent %d is not an earlier op", o, pp);
+      w += (int64_t)p->width[pp] * p->ops[pp].fanout;
+    }
+    if (op.n_parents == 0 && op.frontier_node_type != root_node_type) PLAN_FAIL("op %d starts at the roots but not at their type", o);
+    if (w > 8192) PLAN_FAIL("op %d: a frontier of %lld ids per root exceeds 8192", o, (long long)w);
+    p->width[o] = (int32_t)w;
+    p->cand_per_root[op.frontier_node_type] += w;
+    p->cand_per_root[op.result_node_type] += w * op.fanout;
+    p->pairs_per_root[op.edge_slot] += w * op.fanout;
+    const int32_t st = op.outgoing ? op.frontier_node_type : op.result_node_type;
+    const int32_t dt = op.outgoing ? op.result_node_type : op.frontier_node_type;
+    if (p->slot_src_type[op.edge_slot] >= 0 && (p->slot_src_type[op.edge_slot] != st || p->slot_dst_type[op.edge_slot] != dt))
+      PLAN_FAIL("op %d: edge slot %d joins two different node type pairs", o, op.edge_slot);
+    p->slot_src_type[op.edge_slot] = st;
+    p->slot_dst_type[op.edge_slot] = dt;
+  }
+#undef PLAN_FAIL
+  const int64_t b = b_max;
+  p->front.resize(n_ops);
+  p->ksum.resize(n_ops);
+  p->nbr.resize(n_ops);
+  p->cnt.resize(n_ops);
+  p->ran.resize(n_ops);
+#define PLAN_ALLOC(ptr, count)                       \
+  do {                                               \
+    rc = dev_alloc(p, &(ptr), (count));              \
+    if (rc != GIGL_OK) {                             \
+      gigl_typed_plan_destroy(p);                    \
+      return rc;                                     \
+    }                                                \
+  } while (0)
+  for (int o = 0; o < n_ops; ++o) {
+    const int64_t w = p->width[o], f = p->ops[o].fanout;
+    PLAN_ALLOC(p->front[o], b * w);
+    PLAN_ALLOC(p->ksum[o], b * w);
+    PLAN_ALLOC(p->nbr[o], b * w * f);
+    PLAN_ALLOC(p->cnt[o], b * w);
+    PLAN_ALLOC(p->ran[o], b);
+  }
+  p->cand.resize(n_node_types);
+  p->sorted.resize(n_node_types);
+  p->nodes.resize(n_node_types);
+  for (int t = 0; t < n_node_types; ++t) {
+    const int64_t m = b * p->cand_per_root[t];
+    p->max_items = m > p->max_items ? m : p->max_items;
+    PLAN_ALLOC(p->cand[t], m);
+    PLAN_ALLOC(p->sorted[t], m);
+    PLAN_ALLOC(p->nodes[t], m);
+  }
+  p->ekeys.resize(n_edge_slots);
+  p->esorted.resize(n_edge_slots);
+  p->edges.resize(n_edge_slots);
+  for (int s = 0; s < n_edge_slots; ++s) {
+    const int64_t m = b * p->pairs_per_root[s];
+    p->max_items = m > p->max_items ? m : p->max_items;
+    PLAN_ALLOC(p->ekeys[s], m);
+    PLAN_ALLOC(p->esorted[s], m);
+    PLAN_ALLOC(p->edges[s], m);
+  }
+  PLAN_ALLOC(p->n_nodes, n_node_types);
+  PLAN_ALLOC(p->n_edges, n_edge_slots);
+  PLAN_ALLOC(p->root_index, b);
+  if (p->max_items >= ((int64_t)1 << 31)) {
+    rc = gigl_fail(ctx, GIGL_E_UNSUPPORTED, "typed plan: %lld items per batch", (long long)p->max_items);
+    gigl_typed_plan_destroy(p);
+    return rc;
+  }
+  PLAN_ALLOC(p->flags, p->max_items);
+  PLAN_ALLOC(p->scan, p->max_items);
+  {
+    size_t t1 = 0, t2 = 0, t3 = 0;
+    hipcub::DeviceRadixSort::SortKeys((void*)nullptr, t1, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)p->max_items, 0, 32,
+                                      ctx->stream);
+    hipcub::DeviceRadixSort::SortKeys((void*)nullptr, t2, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                      (int)p->max_items, 0, 64, ctx->stream);
+    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, t3, (const int32_t*)nullptr, (int32_t*)nullptr, (int)p->max_items,
+                                     ctx->stream);
+    p->work_bytes = t1 > t2 ? t1 : t2;
+    p->work_bytes = p->work_bytes > t3 ? p->work_bytes : t3;
+    char* wk = nullptr;
+    PLAN_ALLOC(wk, (int64_t)p->work_bytes + 256);
+    p->work = wk;
+  }
+#undef PLAN_ALLOC
+  *out = p;
+  return GIGL_OK;
+}
+
+int32_t gigl_typed_plan_run(gigl_typed_plan* p, const uint32_t* roots, int32_t b) {
+  if (!p || !p->ctx) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, roots && b >= 1 && b <= p->b_max, "between 1 and %d roots", p->b_max);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  // ---- the ops, in order
+  for (int o = 0; o < p->n_ops; ++o) {
+    const gigl_dag_op& op = p->ops[o];
+    const int32_t w = p->width[o];
+    FrontierSrc fs{};
+    RanSrc rs{};
+    fs.n = rs.n = op.n_parents;
+    for (int k = 0; k < op.n_parents; ++k) {
+      const int pp = op.parents[k];
+      fs.nbr[k] = p->nbr[pp];
+      fs.len[k] = p->width[pp] * p->ops[pp].fanout;
+      rs.ran[k] = p->ran[pp];
+    }
+    hipLaunchKernelGGL(dag_frontier_kernel, grid_of((int64_t)b * w), dim3(TB), 0, st, fs, roots, (int64_t)b, w, p->front[o]);
+    if (op.n_parents > 0) {
+      const int32_t rc = gigl_rows_dedup(ctx, p->front[o], b, w);
+      if (rc != GIGL_OK) return rc;
+    }
+    hipLaunchKernelGGL(dag_mask_kernel, dim3((unsigned)((b + TB / 64 - 1) / (TB / 64))), dim3(TB), 0, st, rs, roots,
+                       (int64_t)b, w, p->front[o], p->ksum[o], p->ran[o]);
+    const int32_t rc = gigl_expand_frontier(ctx, op.graph, p->front[o], p->ksum[o], (int64_t)b * w, op.fanout, op.hash_add, 1,
+                                            -1, p->nbr[o], p->cnt[o]);
+    if (rc != GIGL_OK) return rc;
+  }
+  // ---- per node type: the distinct ids, ascending
+  for (int t = 0; t < p->n_types; ++t) {
+    const int64_t m = (int64_t)b * p->cand_per_root[t];
+    if (m == 0) {
+      GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->n_nodes + t, 0, 4, st));
+      continue;
+    }
+    int64_t off = 0;
+    if (t == p->root_type) {
+      hipLaunchKernelGGL(copy_u32_kernel, grid_of(b), dim3(TB), 0, st, roots, (int64_t)b, p->cand[t]);
+      off = b;
+    }
+    for (int o = 0; o < p->n_ops; ++o) {
+      const gigl_dag_op& op = p->ops[o];
+      const int64_t mw = (int64_t)b * p->width[o];
+      if (op.frontier_node_type == t) {
+        hipLaunchKernelGGL(cand_frontier_kernel, grid_of(mw), dim3(TB), 0, st, (const uint32_t*)p->front[o],
+                           (const int32_t*)p->cnt[o], mw, p->cand[t] + off);
+        off += mw;
+      }
+      if (op.result_node_type == t) {
+        hipLaunchKernelGGL(copy_u32_kernel, grid_of(mw * op.fanout), dim3(TB), 0, st, (const uint32_t*)p->nbr[o],
+                           mw * op.fanout, p->cand[t] + off);
+        off += mw * op.fanout;
+      }
+    }
+    size_t wb = p->work_bytes;
+    GIGL_HIP_CHECK(ctx, hipcub::DeviceRadixSort::SortKeys(p->work, wb, (const uint32_t*)p->cand[t], p->sorted[t], (int)m, 0, 32, st));
+    hipLaunchKernelGGL(head_flags_kernel<uint32_t>, grid_of(m), dim3(TB), 0, st, (const uint32_t*)p->sorted[t], m,
+                       (uint32_t)GIGL_INVALID, p->flags);
+    wb = p->work_bytes;
+    GIGL_HIP_CHECK(ctx, hipcub::DeviceScan::ExclusiveSum(p->work, wb, (const int32_t*)p->flags, p->scan, (int)m, st));
+    hipLaunchKernelGGL(compact_kernel<uint32_t>, grid_of(m), dim3(TB), 0, st, (const uint32_t*)p->sorted[t],
+                       (const int32_t*)p->flags, (const int32_t*)p->scan, m, p->nodes[t], p->n_nodes + t);
+  }
+  // ---- per edge slot: the distinct (src, dst) pairs as local ids, ascending by (src, dst)
+  for (int s = 0; s < p->n_slots; ++s) {
+    const int64_t m = (int64_t)b * p->pairs_per_root[s];
+    if (m == 0) {
+      GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->n_edges + s, 0, 4, st));
+      continue;
+    }
+    int64_t off = 0;
+    for (int o = 0; o < p->n_ops; ++o) {
+      const gigl_dag_op& op = p->ops[o];
+      if (op.edge_slot != s) continue;
+      const int64_t mw = (int64_t)b * p->width[o];
+      hipLaunchKernelGGL(edge_keys_kernel, grid_of(mw * op.fanout), dim3(TB), 0, st, (const uint32_t*)p->front[o],
+                         (const uint32_t*)p->nbr[o], mw, op.fanout, op.outgoing ? 1 : 0,
+                         (const uint32_t*)p->nodes[op.frontier_node_type], (const int32_t*)(p->n_nodes + op.frontier_node_type),
+                         (const uint32_t*)p->nodes[op.result_node_type], (const int32_t*)(p->n_nodes + op.result_node_type),
+                         p->ekeys[s] + off);
+      off += mw * op.fanout;
+    }
+    const int hi = 32 + key_bits((int64_t)b * p->cand_per_root[p->slot_src_type[s]] + 1);
+    size_t wb = p->work_bytes;
+    // (the empty key ~0 needs all 64 bits to sort last)
+    (void)hi;
+    GIGL_HIP_CHECK(ctx, hipcub::DeviceRadixSort::SortKeys(p->work, wb, (const unsigned long long*)p->ekeys[s], p->esorted[s],
+                                                          (int)m, 0, 64, st));
+    hipLaunchKernelGGL(head_flags_kernel<unsigned long long>, grid_of(m), dim3(TB), 0, st,
+                       (const unsigned long long*)p->esorted[s], m, ~0ull, p->flags);
+    wb = p->work_bytes;
+    GIGL_HIP_CHECK(ctx, hipcub::DeviceScan::ExclusiveSum(p->work, wb, (const int32_t*)p->flags, p->scan, (int)m, st));
+    hipLaunchKernelGGL(compact_kernel<unsigned long long>, grid_of(m), dim3(TB), 0, st,
+                       (const unsigned long long*)p->esorted[s], (const int32_t*)p->flags, (const int32_t*)p->scan, m,
+                       p->edges[s], p->n_edges + s);
+  }
+  hipLaunchKernelGGL(root_index_kernel, grid_of(b), dim3(TB), 0, st, roots, (int64_t)b,
+                     (const uint32_t*)p->nodes[p->root_type], (const int32_t*)(p->n_nodes + p->root_type), p->root_index);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_typed_plan_buffers(gigl_typed_plan* p, gigl_typed_plan_out* out) {
+  if (!p || !out) return GIGL_E_INVALID_ARG;
+  *out = gigl_typed_plan_out{};
+  out->n_nodes = p->n_nodes;
+  out->n_edges = p->n_edges;
+  out->root_index = p->root_index;
+  for (int t = 0; t < p->n_types; ++t) {
+    out->nodes[t] = p->nodes[t];
+    out->nodes_cap[t] = (int64_t)p->b_max * p->cand_per_root[t];
+  }
+  for (int s = 0; s < p->n_slots; ++s) {
+    out->edges[s] = p->edges[s];
+    out->edges_cap[s] = (int64_t)p->b_max * p->pairs_per_root[s];
+  }
+  for (int o = 0; o < p->n_ops; ++o) {
+    out->op_frontier[o] = p->front[o];
+    out->op_nbr[o] = p->nbr[o];
+    out->op_cnt[o] = p->cnt[o];
+    out->op_width[o] = p->width[o];
+  }
+  return GIGL_OK;
+}
+
+}  // extern "C"

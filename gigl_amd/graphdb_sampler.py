@@ -171,6 +171,22 @@ class OpResult:
     cnt: torch.Tensor       # [B, w]
 
 
+class _DevMem:
+    """library-owned device memory under the array interface torch.as_tensor understands (no copy)"""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def _wrap(ptr, n: int, dtype, device) -> torch.Tensor:
+    """a COPY (on the current stream) of n elements of library-owned device memory: the plan reuses its buffers"""
+    n = int(n)
+    if n <= 0 or not ptr:
+        return torch.empty(0, dtype=dtype, device=device)
+    typestr = {torch.int32: "<i4", torch.int64: "<i8"}[dtype]
+    return torch.as_tensor(_DevMem(int(ptr), n, typestr), device=device).clone()
+
+
 class HipGraphDBSampler:
     """typed graph resident in HBM (one CSR per edge type and direction) + the op-DAG executor"""
 
@@ -282,6 +298,87 @@ class HipGraphDBSampler:
                 nd = int(uniq[et.dst_node_type].numel())
                 ei[(et.src_node_type, et.relation, et.dst_node_type)] = torch.stack([key // nd, key % nd])
             root_index = torch.searchsorted(uniq[root_node_type], roots)
+        return HeteroGraphData(x_dict, ei), root_index, uniq
+
+    # ---- the same batch graph from the library's one-call plan (gigl_typed_plan_*, csrc/typed_plan.hip): the ops, the
+    #      per-type distinct ids and the per-edge-type distinct edges are one stream of device work; the host reads
+    #      the counts ONCE per batch (batch_graph above synchronises at every torch.unique / boolean mask)
+    def typed_plan(self, root_node_type: str, dag: SamplingOpDAG, b_max: int):
+        """-> the (cached) one-call plan for batches of up to b_max roots of `root_node_type` through `dag`"""
+        import ctypes as C
+        from . import _lib
+        if not hasattr(self, "_plans"):
+            self._plans: Dict[tuple, dict] = {}
+        key = (root_node_type, id(dag), int(b_max))
+        if key in self._plans:
+            return self._plans[key]
+        eng = self.engine
+        order = dag.execution_order()
+        index = {name: i for i, name in enumerate(order)}
+        types = sorted(self.node_types, key=lambda t: self.node_types[t])
+        tix = {t: i for i, t in enumerate(types)}
+        slots: Dict[EdgeType, int] = {}
+        ops = (_lib.GiglDagOp * len(order))()
+        for i, name in enumerate(order):
+            node = dag.nodes[name]
+            op = node.sampling_op
+            outgoing = op.sampling_direction == OUTGOING
+            et = op.edge_type
+            o = ops[i]
+            o.graph = eng._label_edges[self._key(et, op.sampling_direction)]["graph"]
+            o.fanout = int(op.num_nodes_to_sample)
+            o.n_parents = len(node.parent_op_names)
+            for k, pn in enumerate(node.parent_op_names):
+                o.parents[k] = index[pn]
+            o.hash_add = ((self.sampling_seed * (1 + dag.op_order.index(name)) + 2**31) % 2**32) - 2**31
+            o.frontier_node_type = tix[et.src_node_type if outgoing else et.dst_node_type]
+            o.result_node_type = tix[et.dst_node_type if outgoing else et.src_node_type]
+            o.edge_slot = slots.setdefault(et, len(slots))
+            o.outgoing = 1 if outgoing else 0
+        plan = C.c_void_p()
+        _lib.check(eng._lib.gigl_typed_plan_create(eng._ctx, ops, len(order), len(types), tix[root_node_type], len(slots),
+                                                   int(b_max), C.byref(plan)), eng._ctx)
+        out = _lib.GiglTypedPlanOut()
+        _lib.check(eng._lib.gigl_typed_plan_buffers(plan, C.byref(out)), eng._ctx)
+        entry = {"plan": plan, "out": out, "types": types, "slots": slots, "order": order, "b_max": int(b_max),
+                 "ops": ops}
+        self._plans[key] = entry
+        return entry
+
+    def batch_graph_plan(self, root_ids: Sequence[int], root_node_type: str, dag: SamplingOpDAG, b_max: int = 0):
+        """batch_graph through the one-call plan: identical results (same numbering: a type's distinct ids ascending,
+        an edge type's distinct edges ascending by (src, dst))"""
+        import ctypes as C
+        from . import _lib
+        from .models_hetero import HeteroGraphData
+        eng = self.engine
+        dev = eng.device
+        b = len(root_ids)
+        pl = self.typed_plan(root_node_type, dag, max(int(b_max), b))
+        out = pl["out"]
+        roots64 = torch.from_numpy(np.asarray(root_ids, dtype=np.int64))
+        roots = roots64.to(torch.int32).pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else roots64.to(torch.int32)
+        with torch.cuda.stream(eng._stream):
+            _lib.check(eng._lib.gigl_typed_plan_run(pl["plan"], C.c_void_p(roots.data_ptr()), b), eng._ctx)
+            nt, ns = len(pl["types"]), len(pl["slots"])
+            counts = torch.empty(nt + ns, dtype=torch.int32, device=dev)
+            counts[:nt] = _wrap(out.n_nodes, nt, torch.int32, dev)
+            counts[nt:] = _wrap(out.n_edges, ns, torch.int32, dev)
+            h = counts.cpu()  # the one host read of the batch
+            uniq, x_dict, ei = {}, {}, {}
+            for i, t in enumerate(pl["types"]):
+                n_t = int(h[i])
+                if int(out.nodes_cap[i]) == 0:  # no op touches the type
+                    continue
+                u = _wrap(out.nodes[i], n_t, torch.int32, dev).to(torch.int64) & 0xFFFFFFFF
+                uniq[t] = u
+                tab = self._feature_table(t)
+                x_dict[t] = tab.index_select(0, u) if tab is not None else torch.ones((n_t, 1), device=dev)
+            for et, sl in pl["slots"].items():
+                n_e = int(h[nt + sl])
+                keys = _wrap(out.edges[sl], n_e, torch.int64, dev)
+                ei[(et.src_node_type, et.relation, et.dst_node_type)] = torch.stack([keys >> 32, keys & 0xFFFFFFFF])
+            root_index = _wrap(out.root_index, b, torch.int32, dev).to(torch.int64)
         return HeteroGraphData(x_dict, ei), root_index, uniq
 
     def _feature_table(self, node_type: str) -> Optional[torch.Tensor]:

@@ -445,6 +445,54 @@ int32_t gigl_typed_samples_encode(gigl_ctx* ctx, int32_t kind, const uint32_t* r
                                   int64_t n_records, int32_t tfrecord_frame, uint8_t* out, int64_t out_cap,
                                   int64_t* rec_off, int32_t* status);
 
+/* ---- the typed (heterogeneous) batch graph of a SamplingOp DAG in ONE host call (csrc/typed_plan.hip).
+ *      Replaces, per batch of roots of one node type: GraphDBSampler.getKHopSubgraphForRootNode for every root
+ *      (scala_spark35/subgraph_sampler/src/main/scala/libs/sampler/GraphDBSampler.scala:40-148: an op's frontier is the
+ *      set union of its parents' results; it runs for a root only when all its parents ran and the frontier is not
+ *      empty), SamplingOpDAG (scala_spark35/common/src/main/scala/types/SamplingOpDAG.scala:19-53) and the trainer-side
+ *      collate of the typed samples into one batch graph (python/gigl/src/common/graph_builder/
+ *      abstract_graph_builder.py:49-150, pyg_graph_builder.py:20-69): per node type the distinct nodes, per edge type
+ *      the distinct edges as local ids.  Ops are listed parents first; op.graph = the op's (edge type, direction) edge
+ *      list with one row per FRONTIER node (what gigl_expand_frontier takes, world = 1); hash_add = seed * (1 + the
+ *      op's position in the config's op order); edge_slot = which output edge list the op's edges join (ops of one
+ *      edge type share a slot); outgoing: edges are frontier -> result, else result -> frontier.
+ *      Results (DEVICE, owned by the plan, valid until the next run): nodes[t][0 .. n_nodes[t]) = the distinct ids of
+ *      node type t, ASCENDING (position = local id); edges[s][0 .. n_edges[s]) = the distinct edges of slot s as
+ *      (src_local << 32 | dst_local), ascending; root_index[i] = local id of root i; and every op's frontier
+ *      [b][w] / neighbours [b][w][f] / counts [b][w] (the inputs of gigl_typed_records_encode).  Nothing in a run
+ *      synchronises with the host; the caller reads n_nodes / n_edges when it needs the sizes. */
+#define GIGL_DAG_MAX_OPS 16
+#define GIGL_DAG_MAX_PARENTS 8
+typedef struct gigl_dag_op {
+  gigl_graph* graph;
+  int32_t fanout;
+  int32_t n_parents;
+  int32_t parents[GIGL_DAG_MAX_PARENTS]; /* indices of earlier ops; n_parents == 0: the op starts at the roots */
+  int32_t hash_add;
+  int32_t frontier_node_type, result_node_type; /* condensed node types */
+  int32_t edge_slot;
+  int32_t outgoing;
+} gigl_dag_op;
+typedef struct gigl_typed_plan gigl_typed_plan;
+typedef struct gigl_typed_plan_out {
+  const int32_t* n_nodes;  /* [n_node_types] */
+  const int32_t* n_edges;  /* [n_edge_slots] */
+  const int32_t* root_index; /* [b] */
+  const uint32_t* nodes[16];
+  int64_t nodes_cap[16];
+  const unsigned long long* edges[32];
+  int64_t edges_cap[32];
+  const uint32_t* op_frontier[GIGL_DAG_MAX_OPS];
+  const uint32_t* op_nbr[GIGL_DAG_MAX_OPS];
+  const int32_t* op_cnt[GIGL_DAG_MAX_OPS];
+  int32_t op_width[GIGL_DAG_MAX_OPS];
+} gigl_typed_plan_out;
+int32_t gigl_typed_plan_create(gigl_ctx* ctx, const gigl_dag_op* ops, int32_t n_ops, int32_t n_node_types,
+                               int32_t root_node_type, int32_t n_edge_slots, int32_t b_max, gigl_typed_plan** out);
+int32_t gigl_typed_plan_run(gigl_typed_plan* plan, const uint32_t* roots, int32_t b);
+int32_t gigl_typed_plan_buffers(gigl_typed_plan* plan, gigl_typed_plan_out* out);
+int32_t gigl_typed_plan_destroy(gigl_typed_plan* plan);
+
 /* ---- inference output: (node id, embedding row) batches -> Avro object-container DATA BLOCKS, encoded on the device.
  *      Replaces the record loop of EmbeddingExporter.add_embedding (python/gigl/common/data/export.py:103-135:
  *      {"node_id": int(id), "node_type": type, "emb": row.tolist()} through fastavro.writer) for AVRO_SCHEMA

@@ -277,3 +277,30 @@ def test_typed_record_encoder_limits(world):
     big = [SamplingOp("op0", A2P, 64, [], INCOMING), SamplingOp("op1", A2P, 64, ["op0"], OUTGOING)]  # 64 + 4096 slots
     with pytest.raises(_lib.GiglError):
         s.encode_records([1, 2], "paper", SamplingOpDAG.from_ops(big))
+
+
+def test_one_call_typed_plan_equals_the_staged_batch_graph(world):
+    """gigl_typed_plan_* (the DAG's ops, the per-type distinct ids and the per-edge-type distinct edges as one stream of
+    device work, one host read of the counts) == batch_graph (one library call per op + torch.unique / searchsorted
+    chains): same node numbering, same edge lists, same rows, same root positions — multi-parent ops, both directions,
+    roots whose paths die out, repeated runs of one plan with different batch sizes"""
+    s, n, edges, feats, nbrs = world
+    chain = [SamplingOp("op0", A2P, 2, [], OUTGOING), SamplingOp("op1", P2V, 1, ["op0"], OUTGOING),
+             SamplingOp("op2", P2A, 3, ["op0"], OUTGOING), SamplingOp("op3", P2V, 4, ["op1", "op2"], INCOMING)]
+    for root_type, ops in (("paper", _dag_two_paths()), ("author", chain)):
+        dag = SamplingOpDAG.from_ops(ops)
+        rng = np.random.default_rng(7)
+        for b in (1, 37, 256, 64):
+            roots = rng.choice(n[root_type], size=b, replace=False)
+            g0, ri0, u0 = s.batch_graph(roots, root_type, dag)
+            g1, ri1, u1 = s.batch_graph_plan(roots, root_type, dag, b_max=256)
+            torch.cuda.synchronize()
+            assert set(u0) == set(u1), (root_type, b)
+            for t in u0:
+                assert torch.equal(u0[t], u1[t]), f"{root_type} b={b}: node list of {t}"
+                assert torch.equal(g0.x_dict[t], g1.x_dict[t])
+            assert set(g0.edge_index_dict) == set(g1.edge_index_dict)
+            for k in g0.edge_index_dict:
+                assert torch.equal(g0.edge_index_dict[k], g1.edge_index_dict[k]), f"{root_type} b={b}: edges of {k}"
+            assert torch.equal(ri0, ri1)
+        assert sum(int(v.shape[1]) for v in g1.edge_index_dict.values()) > 100
