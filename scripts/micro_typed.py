@@ -59,4 +59,42 @@ print(f"RootedNodeNeighborhood, frames copied to pinned host memory: {sec * 1e3:
 r32 = torch.tensor(roots.astype(np.int32)).cuda()
 sec_dag, _ = timed(lambda: (s.run_dag(r32, dag_paper), s.engine.synchronize(), 0)[2])
 print(f"  op DAG alone (2 ops): {sec_dag * 1e3:8.2f} ms/batch", flush=True)
+
+# ---- the typed batch graph (what a trainer / inferencer batch needs): staged (one library call per op + torch.unique /
+#      searchsorted chains) against the one-call plan (gigl_typed_plan_*: one stream of device work, one host read)
+
+
+def edges_of(g):
+    return sum(int(v.shape[1]) for v in g.edge_index_dict.values())
+
+
+g0, _, u0 = s.batch_graph(roots, "paper", dag_paper)
+g1, _, u1 = s.batch_graph_plan(roots, "paper", dag_paper, b_max=B)
+assert all(torch.equal(u0[t], u1[t]) for t in u0) and edges_of(g0) == edges_of(g1)
+for label, fn in (("batch graph, staged (torch.unique chains)", lambda: edges_of(s.batch_graph(roots, "paper", dag_paper)[0])),
+                  ("batch graph, one-call plan", lambda: edges_of(s.batch_graph_plan(roots, "paper", dag_paper, b_max=B)[0]))):
+    sec, ne_ = timed(fn)
+    print(f"{label:44s} B={B}: {sec * 1e3:8.2f} ms/batch  {B / sec:10.0f} roots/s  {ne_ / sec / 1e6:8.1f} M distinct edges/s "
+          f"({sum(int(v.numel()) for v in u1.values())} nodes, {int(ne_)} edges per batch)")
+import ctypes as C  # noqa: E402
+from gigl_amd import _lib  # noqa: E402
+pl = s.typed_plan("paper", dag_paper, B)
+r_dev = torch.from_numpy(np.asarray(roots, dtype=np.int64)).to(torch.int32).cuda()
+eng = s.engine
+
+
+def plan_only():
+    _lib.check(eng._lib.gigl_typed_plan_run(pl["plan"], C.c_void_p(r_dev.data_ptr()), B), eng._ctx)
+    return 0
+
+
+plan_only()
+eng._stream.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(eng._stream)
+for _ in range(20):
+    plan_only()
+e1.record(eng._stream)
+e1.synchronize()
+print(f"  gigl_typed_plan_run alone (device time, 20 back to back): {e0.elapsed_time(e1) / 20:8.3f} ms/batch")
 s.close()

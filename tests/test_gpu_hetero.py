@@ -114,7 +114,8 @@ def test_attention_kernels_reject_unsupported_shapes():
     eng.close()
 
 
-def test_dag_sampler_to_hgt_end_to_end():
+@pytest.mark.parametrize("route", ["staged", "one-call plan"])
+def test_dag_sampler_to_hgt_end_to_end(route):
     """typed samples stay in HBM: SamplingOp-DAG sampler -> typed batch graph -> HGT; the batch graph equals the union
     of the per-root restatement's samples (oracle/dag_sampler.py) and the root embeddings equal the CPU forward over it"""
     from gigl_amd.graphdb_sampler import (INCOMING, OUTGOING, EdgeType, HipGraphDBSampler, SamplingOp, SamplingOpDAG)
@@ -133,7 +134,9 @@ def test_dag_sampler_to_hgt_end_to_end():
            SamplingOp("op2", P2A, 2, ["op1"], OUTGOING)]
     dag = SamplingOpDAG.from_ops(ops)
     roots = rng.integers(0, n["paper"], 64)
-    data, root_index, uniq = s.batch_graph(roots, "paper", dag)
+    # (staged: one library call per op + torch.unique chains; one-call plan: gigl_typed_plan_*, csrc/typed_plan.hip)
+    build = s.batch_graph if route == "staged" else s.batch_graph_plan
+    data, root_index, uniq = build(roots, "paper", dag)
     s.engine.synchronize()
     # == union of the per-root samples
     nbrs = dag_sampler.neighbour_lists(edges)
