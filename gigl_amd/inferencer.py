@@ -130,7 +130,16 @@ class Inferencer:
             inferencer = generate_inferencer_instance(cfg)
             inferencer.model = inferencer.model.to(dev)
             if cfg.is_heterogeneous:
-                self.route = "tfrecord"
+                # typed graphs: "hbm" = the typed tables resident in HBM, every batch's typed graph built there by the
+                # one-call plan (gigl_typed_plan_*); auto / "tfrecord" = the sampler's typed RootedNodeNeighborhood files
+                want = (route or cfg.inferencer_args.get("data_route") or os.environ.get("GIGL_AMD_ROUTE") or "auto").lower()
+                if want not in ("hbm", "tfrecord", "auto"):
+                    raise ValueError(f"data route {want!r}: expected hbm, tfrecord or auto")
+                self.route = "hbm" if want == "hbm" else "tfrecord"
+                if self.route == "hbm":
+                    if world > 1:
+                        raise NotImplementedError("typed graphs: the in-HBM route runs in one process")
+                    return self._run_typed_hbm(cfg, inferencer, dev)
                 return self._run_typed(cfg, inferencer, dev)
             from .hbm import route_of
             self.route = route_of(cfg, cfg.inferencer_args, route)
@@ -238,6 +247,59 @@ def _typed_run(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str, str
 
 
 Inferencer._run_typed = _typed_run
+
+
+def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str, str]:
+    """heterogeneous jobs, in-HBM route: the preprocessor's typed tables are read once into HBM (one CSR per edge type
+    and direction, one feature table per node type), every batch's typed graph — the config's SamplingOp DAG for the
+    roots, the distinct nodes per type, the distinct edges per edge type — is built there by the library's one-call
+    plan (HipGraphDBSampler.batch_graph_plan -> gigl_typed_plan_*), and the encoder runs over it.  The same roots in the
+    same batches as the TFRecord route (the sampler writes a type's roots in table order); the rows differ from that
+    route's by fp32 summation order only (a type's nodes are numbered ascending here, first-seen there)."""
+    from .graphdb_sampler import HipGraphDBSampler
+    from .hbm import planned_root_order
+    from .subgraph_sampler import load_preprocessed_typed_graph, sampling_op_dags
+    info = (_get(cfg.doc, "sharedConfig.inferenceMetadata.nodeTypeToInferencerOutputInfoMap", {}) or {})
+    wanted = [t for t, v in info.items() if v.get("embeddingsPath")]
+    node_types, num, ids, feats, edges, cet, efeats = load_preprocessed_typed_graph(cfg)
+    inner = inferencer.model.module if hasattr(inferencer.model, "module") else inferencer.model
+    enc = getattr(inner, "_encoder", getattr(inner, "encoder", inner))
+    if type(enc).__name__ != "HGT" and any(np.asarray(v).size for v in (efeats or {}).values()):
+        raise NotImplementedError("an encoder that reads edge features takes the TFRecord route (the in-HBM typed batch "
+                                  "graph carries no edge attributes)")
+    dags = sampling_op_dags(cfg, wanted)
+    # the sampler job's rule (SubgraphSampler.run): "deterministic" = the hash permutation under seed 42 — the samples of
+    # its files, so both routes see the same neighbourhoods; anything else = a fresh uniform sample per job
+    seed = 42 if cfg.permutation_strategy == "deterministic" else 1 + int.from_bytes(os.urandom(3), "little") % ((1 << 20) - 1)
+    s = HipGraphDBSampler(node_types, num, edges, cet, feats, device=dev.index or 0, sampling_seed=seed)  # (no edge rows)
+    out_files: Dict[str, str] = {}
+    n_rows = 0
+    b = int(cfg.inference_batch_size)
+    try:
+        inferencer._ensure_engine(dev)
+        for node_type in wanted:
+            path = resolve_uri(info[node_type]["embeddingsPath"], cfg.uri_base)
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+            out_files[f"embeddings/{node_type}"] = path
+            with open(path, "w") as fh:
+                prefix = cfg.random_negative_tfrecord_uri_prefixes.get(node_type)
+                order = planned_root_order(np.asarray(ids[node_type]), prefix) if prefix else np.asarray(ids[node_type])
+                for i in range(0, order.size, b):
+                    chunk = order[i:i + b]
+                    graph, root_index, _ = s.batch_graph_plan(chunk, node_type, dags[node_type], b_max=b)
+                    with torch.no_grad():
+                        out = inferencer.model(graph, [node_type])[node_type]
+                    emb = out[root_index.to(out.device)].float().cpu()
+                    for k, gid in enumerate(np.asarray(chunk).tolist()):
+                        fh.write(json.dumps({"node_id": int(gid), "node_type": node_type, "emb": emb[k].tolist()}) + "\n")
+                        n_rows += 1
+    finally:
+        s.close()
+    self.rows_written = n_rows
+    return out_files
+
+
+Inferencer._run_typed_hbm = _typed_run_hbm
 
 
 def main(argv=None):

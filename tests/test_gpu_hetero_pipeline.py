@@ -121,3 +121,48 @@ def test_trainer_then_inferencer_on_the_typed_graph(workdir):
         rows = [json.loads(l) for l in open(out[f"embeddings/{t}"])]
         assert sorted(r["node_id"] for r in rows) == list(range(n)) and all(r["node_type"] == t for r in rows)
         assert all(len(r["emb"]) == 8 and np.isfinite(r["emb"]).all() for r in rows)
+
+
+def test_typed_in_hbm_route_matches_the_tfrecord_route(golden_dir, tmp_path_factory):
+    """Inferencer.run(route="hbm") on a typed job: the typed tables resident in HBM, every batch's typed graph built by
+    the library's one-call plan (gigl_typed_plan_*), HGT over it — against the TFRecord route (the sampler's typed
+    RootedNodeNeighborhood files, typed native collate) on the same trained model: the same roots in the same batches,
+    rows equal up to fp32 summation order.  (permutation_strategy = deterministic: both routes sample under seed 42.)"""
+    from gigl_amd.inferencer import Inferencer
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    from gigl_amd.trainer import Trainer
+    base = tmp_path_factory.mktemp("gigl_hetero_det")
+    shutil.copytree(os.path.join(golden_dir, "configs"), base / "configs")
+    shutil.copytree(os.path.join(golden_dir, "ref_assets"), base / "ref_assets")
+    doc = yaml.safe_load(open(base / "configs" / "hetero_nablp_frozen_gbml_config.yaml"))
+    doc["datasetConfig"]["subgraphSamplerConfig"]["numPositiveSamples"] = 2
+    doc["datasetConfig"]["subgraphSamplerConfig"].setdefault("experimentalFlags", {})["permutation_strategy"] = "deterministic"
+    spec = "gigl_amd.nablp_spec.HipNodeAnchorLinkPredictionSpec"
+    args = {"hidden_dim": "16", "out_channels": "8", "num_heads": "2", "main_sample_batch_size": "6",
+            "random_negative_sample_batch_size": "5", "random_negative_sample_batch_size_for_evaluation": "5",
+            "val_every_num_batches": "2", "num_val_batches": "2", "num_test_batches": "2", "early_stop_patience": "50",
+            "optim_lr": "0.02", "gnn_model_class_path": "gigl_amd.models_hetero.HGT"}
+    doc["trainerConfig"] = {"trainerClsPath": spec, "trainerArgs": dict(args)}
+    doc["inferencerConfig"] = {"inferencerClsPath": spec, "inferencerArgs": dict(args), "inferenceBatchSize": 8}
+    doc["sharedConfig"]["trainedModelMetadata"] = {"trainedModelUri": "out/hetero_train/model.pt",
+                                                   "evalMetricsUri": "out/hetero_train/eval_metrics.json"}
+    doc["sharedConfig"]["inferenceMetadata"] = {"nodeTypeToInferencerOutputInfoMap": {
+        "author": {"embeddingsPath": "out/hetero_train/emb_author.jsonl"},
+        "paper": {"embeddingsPath": "out/hetero_train/emb_paper.jsonl"}}}
+    yaml.safe_dump(doc, open(base / CFG, "w"))
+    wd = str(base)
+    SubgraphSampler().run("job", CFG, None, uri_base=wd)
+    torch.manual_seed(0)
+    Trainer().run("job", CFG, None, uri_base=wd)
+    inf = Inferencer()
+    out = inf.run("job", CFG, None, uri_base=wd)
+    assert inf.route == "tfrecord"
+    first = {t: {r["node_id"]: r["emb"] for r in map(json.loads, open(out[f"embeddings/{t}"]))} for t in ("author", "paper")}
+    inf = Inferencer()
+    out2 = inf.run("job", CFG, None, uri_base=wd, route="hbm")
+    assert inf.route == "hbm" and inf.rows_written == 15 + 19
+    for t, n in (("author", 15), ("paper", 19)):
+        rows = [json.loads(l) for l in open(out2[f"embeddings/{t}"])]
+        assert sorted(r["node_id"] for r in rows) == list(range(n)) == sorted(first[t])
+        for r in rows:
+            np.testing.assert_allclose(r["emb"], first[t][r["node_id"]], rtol=2e-5, atol=2e-5)
