@@ -2334,11 +2334,8 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
   dim3 g((unsigned)blocks), b(256);
   hipStream_t st = ctx->stream;
   const int vecs = d / 4;
-  // (experiment knob: unused dynamic LDS per workgroup caps the gather's workgroups per CU, leaving wave slots,
-  // registers and LDS for a projection workgroup of another stream)
-  static const size_t lds_pad = getenv("GIGL_GATHER_LDS_PAD") ? (size_t)atoi(getenv("GIGL_GATHER_LDS_PAD")) : 0;
 #define GLO(LPR, VPL, OP)                                                                            \
-  hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, lds_pad, st, src, d, gather_ids, rowptr, \
+  hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, 0, st, src, d, gather_ids, rowptr, \
                      rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc, global_map, src2, src3,   \
                      (const float*)nullptr, (const float*)nullptr, 0, 0, no_self)
 #define GL(LPR, VPL)                                        \
