@@ -222,6 +222,12 @@ class HipGraphDBSampler:
         return f"{et.src_node_type}|{et.relation}|{et.dst_node_type}|{direction}"
 
     def close(self):
+        for pl in getattr(self, "_plans", {}).values():  # one-call typed plans hold device buffers of their own
+            try:
+                self.engine._lib.gigl_typed_plan_destroy(pl["plan"])
+            except Exception:  # noqa: BLE001 — closing must not raise
+                pass
+        self._plans = {}
         self.engine.close()
 
     def run_dag(self, roots: torch.Tensor, dag: SamplingOpDAG) -> Dict[str, OpResult]:
