@@ -1675,7 +1675,7 @@ def run_gat_lp(args, rank, world, local_rank):
     random negatives and the fused retrieval loss (infer_task_inputs + Retrieval, python/gigl/src/common/
     modeling_task_specs/utils/infer.py, models/layers/task.py:140-205).  The two encodes are GAT one-call plans
     (gigl_gat_plan_create), G steps per call; the decoder and the loss run per step; a secondary line."""
-    from gigl_amd._lib import GIGL_META_LEVEL0
+    from gigl_amd._lib import GIGL_META_LEVEL0, STATS
     from gigl_amd.engine import HipEngine
     from gigl_amd.link_prediction import DecoderType, LinkPredictionDecoder, RetrievalLoss
     from gigl_amd.models import HipBatch
@@ -1842,6 +1842,48 @@ def run_gat_lp(args, rank, world, local_rank):
     elapsed = float(sum(rep_s))
     ms_rep = np.array(rep_s) / pool * 1e3
     q_ = lambda a, p: float(np.percentile(a, p))
+    # ---- roofline of the step's dominant kernel group: one untimed pass of the same calls with the library's HIP-event
+    # timers on (eager launches: events cannot sit inside a replayed graph).  The attention reductions — the first
+    # layer's one-pass kernel over the stored rows (gat_input_online_kernel) and the second layer's segmented reduce —
+    # are timed as `gather_mean`; algorithmic bytes per SURVEY 8(d): layer 0 reads a stored row (D elements) per
+    # aggregated edge and writes one fp32 D-wide operand row per head and destination; layer 1 reads an H*C fp32 row per
+    # aggregated edge and per destination and writes one.
+    roofline = None
+    if plans is not None:
+        names = ["expand", "union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr", "gather_mean", "linear"]
+        eng.profile_enable(names, capacity=(pool // G + 2) * 64)
+        eng.profile_reset()
+        for i0 in range(0, pool, G):
+            eager_call(i0)
+        st.synchronize()
+        for p_ in plans:
+            p_.flush_profile()
+        prof = {k: eng.profile_read(k) for k in names}
+        eng.profile_enable([], 0)
+        sa = stats_acc.cpu().numpy().astype(np.float64) / pool  # per step (both encodes), counted on the device above
+        agg0, agg1 = sa[STATS["agg_layer0"]], sa[STATS["agg_layer0"] + 1]
+        rows0, rows1 = sa[STATS["rows_layer0"]], sa[STATS["rows_layer0"] + 1]
+        esz_ = 2  # fp16 table
+        alg = {"gather_mean": agg0 * (4 + d * esz_) + rows0 * (8 + heads * d * 4) +
+                              agg1 * (4 + heads * hid * 4) + rows1 * (8 + 2 * heads * hid * 4)}
+        by_kernel = {k: {"ms_per_step": round(v[0] / pool, 5), "launches": int(v[1])} for k, v in prof.items() if v[0] > 0}
+        dominant = max(by_kernel, key=lambda k: by_kernel[k]["ms_per_step"])
+        if "gather_mean" in by_kernel:
+            gm = by_kernel["gather_mean"]
+            gm.update(bound="hbm", achieved=round(alg["gather_mean"] / (gm["ms_per_step"] * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS,
+                      unit="GB/s")
+            gm["frac"] = round(gm["achieved"] / HBM_PEAK_GBS, 4)
+        head_k = "gather_mean" if "gather_mean" in by_kernel else dominant
+        hk = by_kernel[head_k]
+        launches = max(hk["launches"], 1)
+        roofline = {"bound": "hbm", "kernel": "GAT attention reductions (gat_input_online_kernel + gat_gather_fast; timed as gather_mean)",
+                    "achieved": hk.get("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hk.get("frac"),
+                    "traffic": None, "dominant": dominant,
+                    "alg_bytes_per_launch": round(alg["gather_mean"] * pool / launches),
+                    "avg_launch_us": round(hk["ms_per_step"] * pool / launches * 1e3, 2), "launches": launches,
+                    "timing": "HIP events on the plans' stream over one untimed eager pass of the timed calls (one stream: "
+                              "a kernel's interval is its own)",
+                    "share_of_step": round(hk["ms_per_step"] / (elapsed / steps * 1e3), 3), "by_kernel": by_kernel}
     line = {
         "metric": "sampled+aggregated edges/s", "value": float(per_step.sum()) * steps / elapsed, "unit": "edges/s",
         "n_gpus": 1, "steps": steps, "warmup": W, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
@@ -1853,7 +1895,7 @@ def run_gat_lp(args, rank, world, local_rank):
                                f"heads={heads} hid={hid} out={out_dim}, inner-product scores + fused retrieval loss",
                    "sampled_edges_per_step": float(per_step[0]), "aggregated_edges_per_step": float(per_step[1]),
                    "steps_per_call": G, "driver": driver, "setup_s": round(setup_s, 1)},
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roofline, "cpu_baseline": None,
     }
     if world > 1:  # a replica per GPU: whole-job rate = sum over the ranks, step time = the slowest rank's
         import torch.distributed as dist
