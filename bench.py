@@ -999,6 +999,19 @@ def run_sharded(args, rank, world, local_rank, sub=False):
         torch.cuda.synchronize()
         rep_s.append(time.perf_counter() - t1)
     dist.barrier()
+    # ---- per-kernel HIP-event times of one more (untimed) repetition: the library's timers on every plan's ctx; the
+    # plans stay interleaved as in the timed region, so an interval includes what the other plans' kernels took from it
+    prof_names = ["expand", "union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr", "gather_mean",
+                  "linear"]
+    for sl in slots:
+        sl.eng.profile_enable(prof_names, capacity=8192)
+        sl.eng.profile_reset()
+    run_calls(slots, *seg_calls(0))
+    sync_all(slots)
+    prof_sh = {k: [sum(x) for x in zip(*[sl.eng.profile_read(k) for sl in slots])] for k in prof_names}
+    for sl in slots:
+        sl.eng.profile_enable([], 0)
+    dist.barrier()
     rep_t = torch.tensor(rep_s, dtype=torch.float64, device=dev)
     all_reduce(rep_t, dist.ReduceOp.MAX)
     seg_use = np.array([sum(1 for r in range(reps) if r % N_SEG == sg) for sg in range(N_SEG)], dtype=np.float64)
@@ -1048,6 +1061,36 @@ def run_sharded(args, rank, world, local_rank, sub=False):
                        "setup_s": round(setup_s, 1)},
             "roofline": None, "cpu_baseline": None,
         }
+        # ---- roofline of the dominant kernel group (this rank's segment-0 repetition, counted on the device): the byte
+        # model of the single-GPU line; layer 0 reads pre-projected fp32 rows of `hid` columns when the
+        # table was projected, stored fp16 rows of D otherwise
+        if not gat:
+            st0 = seg_stats[0]
+            agg0, agg1 = st0[STATS["agg_layer0"]], st0[STATS["agg_layer0"] + 1]
+            rows0, rows1 = st0[STATS["rows_layer0"]], st0[STATS["rows_layer0"] + 1]
+            if proj_table is not None or args.project_on_owner:
+                b_gather = agg0 * (4 + hid * 4) + rows0 * (8 + 2 * hid * 4)
+            else:
+                b_gather = agg0 * (4 + d * 2) + rows0 * (8 + d * 2 + 2 * d * 4)
+            b_gather += agg1 * (4 + hid * 4) + rows1 * (8 + hid * 4)
+            byk = {k: {"ms_per_step": round(v[0] / K_rep, 5), "launches": int(v[1])} for k, v in prof_sh.items() if v[0] > 0}
+            if byk:
+                dom = max(byk, key=lambda k: byk[k]["ms_per_step"])
+                if "gather_mean" in byk:
+                    gm = byk["gather_mean"]
+                    gm.update(bound="hbm", achieved=round(b_gather / K_rep / (gm["ms_per_step"] * 1e-3) / 1e9, 1),
+                              peak=HBM_PEAK_GBS, unit="GB/s")
+                    gm["frac"] = round(gm["achieved"] / HBM_PEAK_GBS, 4)
+                hk = byk.get("gather_mean", byk[dom])
+                line["roofline"] = {
+                    "bound": "hbm", "kernel": "gather_mean", "achieved": hk.get("achieved"), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": hk.get("frac"), "traffic": None, "dominant": dom,
+                    "alg_bytes_per_launch": round(b_gather / max(hk["launches"], 1)),
+                    "avg_launch_us": round(hk["ms_per_step"] * K_rep / max(hk["launches"], 1) * 1e3, 2),
+                    "launches": hk["launches"],
+                    "timing": f"HIP events on the plans' streams over one untimed repetition of the timed calls ({S} plans "
+                              "in flight: intervals include overlap with the other plans' kernels)",
+                    "by_kernel": byk}
         # ---- second roofline: xGMI.  Bytes a rank puts on its links per step = what it sends to the
         # other world-1 ranks: per hop the request buckets (8 B per entry) and, as an owner, the answer buckets
         # (4*f B per entry); then the id buckets of the feature pull (4 B) and the row buckets.  Buckets travel whole
