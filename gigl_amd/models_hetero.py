@@ -188,7 +188,10 @@ class HGTConv(nn.Module):
         H, T = self.heads, len(self.edge_types)
         return torch.block_diag(*[rel.weight[h * T + ti].t() for h in range(H)]).contiguous()
 
-    def forward(self, x_dict: Dict[str, torch.Tensor], edge_index_dict: Dict[EdgeType, torch.Tensor]):
+    def forward(self, x_dict: Dict[str, torch.Tensor], edge_index_dict: Dict[EdgeType, torch.Tensor],
+                csr_cache: Optional[dict] = None):
+        """csr_cache: a dict the caller keeps for ONE batch graph — the edges of all types merged into one CSR by
+        destination depend on the graph alone, so the layers of a model share it (HGT.forward)"""
         any_x = next(iter(x_dict.values()))
         eng = _engine_for(self, any_x)
         dev = any_x.device
@@ -204,19 +207,26 @@ class HGTConv(nn.Module):
             dst_off[t] = n_dst
             n_dst += int(x.shape[0])
         qq = torch.cat([q[t] for t in x_dict]).contiguous()
+        cached = csr_cache.get("csr") if csr_cache is not None else None
         ks, vs, srcs, dsts, ets, n_src = [], [], [], [], [], 0
         for et, ei in edge_index_dict.items():
             et = tuple(et)
             ti = self.edge_types_map[et]
             ks.append(_linear(eng, k[et[0]], self._block_diag(self.k_rel, ti), None))
             vs.append(_linear(eng, v[et[0]], self._block_diag(self.v_rel, ti), None))
-            srcs.append(ei[0] + n_src)
-            dsts.append(ei[1] + dst_off[et[2]])
-            ets.append(torch.full((ei.shape[1],), ti, dtype=torch.int32, device=dev))
+            if cached is None:
+                srcs.append(ei[0] + n_src)
+                dsts.append(ei[1] + dst_off[et[2]])
+                ets.append(torch.full((ei.shape[1],), ti, dtype=torch.int32, device=dev))
             n_src += int(k[et[0]].shape[0])
         out = torch.zeros((n_dst, Fo), dtype=torch.float32, device=dev)
-        if srcs and n_dst:
-            rowptr, col, _, ety = _csr_by_dst(torch.cat(srcs), torch.cat(dsts), n_dst, torch.cat(ets))
+        if ks and n_dst:
+            if cached is None:
+                rowptr, col, _, ety = _csr_by_dst(torch.cat(srcs), torch.cat(dsts), n_dst, torch.cat(ets))
+                if csr_cache is not None:
+                    csr_cache["csr"] = (rowptr, col, ety)
+            else:
+                rowptr, col, ety = cached
             p_rel = torch.cat([self.p_rel["__".join(e)].reshape(1, H) for e in self.edge_types]).contiguous()
             out = _HgtAggFn.apply(qq, torch.cat(ks), torch.cat(vs), p_rel, eng, H, D, rowptr, col, ety, n_dst)
         res = {}
@@ -257,8 +267,9 @@ class HGT(nn.Module):
                       for t, x in x_dict.items()}
         h = {t: torch.relu(_linear(eng, x, self.lin_dict[t].weight, self.lin_dict[t].bias))
              for t, x in x_dict.items()}
+        csr_cache: dict = {}  # (the merged CSR by destination is the graph's: built by the first layer, reused by the rest)
         for conv in self.convs:
-            h = conv(h, data.edge_index_dict)
+            h = conv(h, data.edge_index_dict, csr_cache)
         out = {}
         for t in output_node_types:
             out[t] = (_linear(eng, h[t], self.lin.weight, self.lin.bias) if t in h
