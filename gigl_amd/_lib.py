@@ -56,6 +56,7 @@ SYMBOLS = [
     "gigl_dist_gat_plan_create", "gigl_dist_gat_plan_set_weights", "gigl_dist_plan_bucket_fill",
     "gigl_linear_weight_grad", "gigl_features_row_crc",
     "gigl_typed_plan_create", "gigl_typed_plan_run", "gigl_typed_plan_buffers", "gigl_typed_plan_destroy",
+    "gigl_sage_plan_run_part",
 ]
 
 KERNEL_IDS = {
@@ -239,6 +240,7 @@ def load() -> C.CDLL:
         "gigl_sage_plan_set_weights": [vp, P(vp), P(vp)],
         "gigl_sage_plan_buffers": [vp, P(GiglTree), P(GiglUnion)],
         "gigl_sage_plan_run": [vp, vp, i32, i32, vp],
+        "gigl_sage_plan_run_part": [vp, vp, i32, i32, vp, i32],
         "gigl_sage_plan_destroy": [vp],
         "gigl_sage_plan_use_graph": [vp, i32],
         "gigl_sage_plan_flush_profile": [vp],

@@ -649,6 +649,18 @@ int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* p) {
   return GIGL_OK;
 }
 
+int32_t gigl_sage_plan_run_part(gigl_sage_plan* p, const uint32_t* roots, int32_t sampling_seed, int32_t mode,
+                                float* out, int32_t part) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, roots && out && (part == GIGL_PLAN_PART_GRAPH || part == GIGL_PLAN_PART_LAYERS), "bad argument");
+  if (mode == GIGL_MODE_REPLACE)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the one-call plan needs duplicate-free trees (no with-replacement mode)");
+  const int n = n_stages(p);
+  return part == GIGL_PLAN_PART_GRAPH ? enqueue_range(p, 0, 2, roots, sampling_seed, mode, out)
+                                      : enqueue_range(p, 2, n, roots, sampling_seed, mode, out);
+}
+
 int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sampling_seed, int32_t mode,
                            float* out) {
   if (!p) return GIGL_E_INVALID_ARG;

@@ -857,6 +857,14 @@ int32_t gigl_sage_plan_set_groups(gigl_sage_plan* plan, int32_t group_roots);
 int32_t gigl_sage_plan_buffers(gigl_sage_plan* plan, gigl_tree* tree, gigl_union* un);
 int32_t gigl_sage_plan_run(gigl_sage_plan* plan, const uint32_t* roots, int32_t sampling_seed,
                            int32_t mode, float* out);
+/* the same call in two parts (eager launches), for callers that pipeline batch sets across two plans on two streams:
+ * GIGL_PLAN_PART_GRAPH = sample + union graph of `roots` (latency-bound: dependent loads), GIGL_PLAN_PART_LAYERS = the
+ * layers over that union graph + the roots' rows (bandwidth- / MFMA-bound).  PART_LAYERS of a batch set must follow
+ * PART_GRAPH of the same set on the plan's stream; while it runs, another plan can build the next set's graph. */
+#define GIGL_PLAN_PART_GRAPH 1
+#define GIGL_PLAN_PART_LAYERS 2
+int32_t gigl_sage_plan_run_part(gigl_sage_plan* plan, const uint32_t* roots, int32_t sampling_seed, int32_t mode,
+                                float* out, int32_t part);
 /* exact work counts of the batch set the plan ran LAST (its tree and union graph are still in the workspace), added
  * to acc[GIGL_STATS_LEN] (DEVICE int64, caller-zeroed, accumulates over calls; enqueued on the ctx stream, no host
  * synchronisation) — the units of BASELINE.json's metric and the algorithmic bytes of SURVEY.md 8(d):

@@ -170,3 +170,27 @@ def test_plan_with_sum_and_max_reductions(setup, aggr, fan):
     u = eng.union_build(tree)
     want = model(HipBatch(eng, tree, u))[u.root_local[:b].long()].cpu().numpy()
     np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-5)
+
+
+def test_plan_in_two_parts_equals_the_one_call(setup):
+    """gigl_sage_plan_run_part: GIGL_PLAN_PART_GRAPH (sample + union) then GIGL_PLAN_PART_LAYERS (layers + rows) on the
+    plan's stream == gigl_sage_plan_run, bit for bit (callers pipeline batch sets across two plans with it)"""
+    import ctypes as C
+    from gigl_amd import _lib
+    from gigl_amd.models import GraphSAGE
+    eng, rowptr, col, x, n = setup
+    torch.manual_seed(1)
+    model = GraphSAGE(100, 64, 47, num_layers=2).to(eng.device)
+    b, fan = 256, [25, 10]
+    plan = model.make_plan(eng, b, fan)
+    rng = np.random.default_rng(5)
+    for _ in range(2):
+        roots = torch.from_numpy(rng.integers(0, n, size=b).astype(np.uint32).view(np.int32)).to(eng.device)
+        want = plan.run(roots).clone()
+        got = torch.full_like(want, float("nan"))
+        for part in (1, 2):
+            _lib.check(eng._lib.gigl_sage_plan_run_part(plan._plan, C.c_void_p(roots.data_ptr()), 42, _lib.MODE_SPARK_HASH,
+                                                        C.c_void_p(got.data_ptr()), part), eng._ctx)
+        eng.synchronize()
+        assert torch.equal(want, got)
+    plan.close()
