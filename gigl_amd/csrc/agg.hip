@@ -776,13 +776,26 @@ __device__ __forceinline__ void split_store(const float4_t v, short* p1, short* 
   *reinterpret_cast<uint2*>(p3) = make_uint2((a3[0] >> 16) | a3[1], (a3[2] >> 16) | a3[3]);
 }
 
+// (values with at most 16 significant bits — widened halves: the third plane would be zero)
+__device__ __forceinline__ void split_store2(const float4_t v, short* p1, short* p2) {
+  uint32_t a1[4], a2[4], a3[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) split3(v[t], a1[t], a2[t], a3[t]);
+  *reinterpret_cast<uint2*>(p1) = make_uint2((a1[0] >> 16) | a1[1], (a1[2] >> 16) | a1[3]);
+  *reinterpret_cast<uint2*>(p2) = make_uint2((a2[0] >> 16) | a2[1], (a2[2] >> 16) | a2[3]);
+}
+
 // SELF (the SAGE layer's [mean | self] operand without the self copy): the A operand has TWO sources — columns k <
 // d_mean come from the tiled buffer the gather wrote (a_tiled = its chunks per row tile, ceil(d_mean / 32)), columns
 // k >= d_mean are element k - d_mean of row self_ids[row] (or `row`) of `self_src` (fp32 rows self_ld apart: the
 // resident feature table through union.nodes for the first layer, the previous layer's output after it).  d_mean % 4
 // == 0, so a lane's 4-column segment lies wholly in one source; the K order, and with it every bit of the result, is
 // that of the single-source operand.
-template <int NJ, bool KVEC = true, bool SELF = false>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
+// AHALF: `a` points at fp16 rows (K % 4 == 0, row-major).  A half has 11 significant bits: it is the exact sum of TWO bf16
+// numbers, so the A operand keeps two planes and the product with its (zero) third plane is dropped — five MFMAs per
+// accumulator instead of six, and the rows are read as stored (2 bytes per element, no widened copy).  The remaining
+// products run in the order of the fp32 path: the same accumulators up to the sign of a zero.
+template <int NJ, bool KVEC = true, bool SELF = false, bool AHALF = false>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
 __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            const int32_t* __restrict__ m_dev, int K, int N, int act,
@@ -858,7 +871,17 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
       if constexpr (SELF) {
         if (kk >= d_mean && row < M) src = self_row[i] + (kk - d_mean);
       }
-      if constexpr (k_vec) {
+      if constexpr (AHALF) {
+        da[i] = zero4;
+        if (row < M && kk < K) {
+          const uint2 h4 = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(a) + (int64_t)row * K + kk);
+          const __half2 lo = *reinterpret_cast<const __half2*>(&h4.x), hi = *reinterpret_cast<const __half2*>(&h4.y);
+          da[i][0] = __low2float(lo);
+          da[i][1] = __high2float(lo);
+          da[i][2] = __low2float(hi);
+          da[i][3] = __high2float(hi);
+        }
+      } else if constexpr (k_vec) {
         da[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(src) : zero4;
       } else {  // K % 4 != 0: rows are not 16-byte aligned and the last segment is partial — element loads
 #pragma unroll
@@ -882,7 +905,8 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int o = split_lds_off(lr + 32 * i, lc * 4);
-      split_store(ra[i], &s_a[0][o], &s_a[1][o], &s_a[2][o]);
+      if constexpr (AHALF) split_store2(ra[i], &s_a[0][o], &s_a[1][o]);
+      else split_store(ra[i], &s_a[0][o], &s_a[1][o], &s_a[2][o]);
     }
 #pragma unroll
     for (int i = 0; i < 2 * NJ; ++i) {
@@ -898,7 +922,7 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < (AHALF ? 2 : 3); ++p)
           fa[i][p] = *reinterpret_cast<const bf16x8_t*>(&s_a[p][split_lds_off(wm * 64 + i * 32 + r, ks + 8 * g)]);
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
@@ -909,12 +933,14 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
       // on the same accumulator are never back to back (a dependent MFMA waits for the previous one's 16 passes)
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < 6; ++t) {
+        if (AHALF && PA[t] == 2) continue;  // (the third plane of a half is zero)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA[t]], fw[j][PW[t]], acc[i][j], 0, 0, 0);
+      }
     }
   };
   gload(0, ga[0], gw[0]);
@@ -2450,8 +2476,12 @@ int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* 
   // two staging buffers for an fp16 table: chunk c + 1 is widened while chunk c is multiplied? (one stream: they run
   // back to back; two buffers only keep the conversion of c + 1 from overwriting the operand of c's product)
   const int64_t cm = n < chunk ? n : chunk;
+  // fp16 rows go through the projection as stored when K % 4 == 0 (GIGL_PROJECT_WIDEN=1, or GIGL_LINEAR_EXACT: the
+  // widened copy + the fp32 path, for comparison)
+  const bool half_direct = feat->dtype == GIGL_DTYPE_F16 && (d & 3) == 0 && !getenv("GIGL_PROJECT_WIDEN") &&
+                           !getenv("GIGL_LINEAR_EXACT");
   if (hipMalloc((void**)&cnt, 16) != hipSuccess ||
-      (feat->dtype == GIGL_DTYPE_F16 && hipMalloc((void**)&stage, (size_t)cm * d * 4 + 16) != hipSuccess)) {
+      (feat->dtype == GIGL_DTYPE_F16 && !half_direct && hipMalloc((void**)&stage, (size_t)cm * d * 4 + 16) != hipSuccess)) {
     cleanup();
     return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the projection workspace failed");
   }
@@ -2468,6 +2498,22 @@ int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* 
   for (int64_t r0 = 0; r0 < n && rc == GIGL_OK; r0 += cm) {
     const int64_t m = (n - r0) < cm ? (n - r0) : cm;
     const float* a;
+    if (feat->dtype == GIGL_DTYPE_F16 && half_direct) {  // the rows as stored: two bf16 planes, five products
+      gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
+      const int nn = 2 * n_out;
+      const int64_t bm = (m + 127) / 128;
+      const float* ah = reinterpret_cast<const float*>((const __half*)feat->rows + r0 * d);
+      if (nn > 64)
+        hipLaunchKernelGGL((linear_split_kernel<2, true, false, true>), dim3((unsigned)(bm * ((nn + 127) / 128))), dim3(256),
+                           0, st, ah, (const float*)wcat, (const float*)nullptr, (const int32_t*)(cnt + (m == cm ? 0 : 1)), d,
+                           nn, 0, out + r0 * 2 * n_out, 0, 0, (int64_t)0, (int64_t)0);
+      else
+        hipLaunchKernelGGL((linear_split_kernel<1, true, false, true>), dim3((unsigned)(bm * ((nn + 63) / 64))), dim3(256),
+                           0, st, ah, (const float*)wcat, (const float*)nullptr, (const int32_t*)(cnt + (m == cm ? 0 : 1)), d,
+                           nn, 0, out + r0 * 2 * n_out, 0, 0, (int64_t)0, (int64_t)0);
+      if (hipGetLastError() != hipSuccess) rc = gigl_fail(ctx, GIGL_E_HIP, "projection launch failed");
+      continue;
+    }
     if (feat->dtype == GIGL_DTYPE_F16) {
       const int64_t elems = m * d;
       hipLaunchKernelGGL(half_rows_to_f32_kernel, dim3((unsigned)((elems / 4 + 256) / 256)), dim3(256), 0, st,
