@@ -276,7 +276,8 @@ def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str,
     n_rows = 0
     b = int(cfg.inference_batch_size)
     try:
-        inferencer._ensure_engine(dev)
+        if hasattr(inferencer, "_ensure_engine"):
+            inferencer._ensure_engine(dev)
         for node_type in wanted:
             path = resolve_uri(info[node_type]["embeddingsPath"], cfg.uri_base)
             os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
