@@ -1618,6 +1618,21 @@ def run_entry_sampler(args, rank, world, local_rank):
     enc_ms = float(np.median(enc_only[:, 1])) / K_rep * 1e3
     alg_bytes = bytes_per_step + min(fields_per_step, B * slots) * 4 * d + 4.0 * slots * B
     achieved = alg_bytes / (enc_ms * 1e-3) / 1e9
+    # HBM traffic of one encode call from the committed counter summary (scripts/pmc_records.sh: FETCH_SIZE / WRITE_SIZE
+    # in separate rocprofv3 passes over the same call shape — products-shaped graph, [25,10], 4,096 records): KB units;
+    # fetches of 16-byte-per-lane reads are tallied at half their bytes on gfx950 (MI355X_MICROARCH.md), hence x2
+    traffic, traffic_src = None, None
+    if wl_name == "products" and B == 4096 and fanouts == [25, 10]:
+        import glob
+        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_encoder_pmc.json")))[::-1]:
+            try:
+                c = json.load(open(f))
+                traffic = sum(1024.0 * c[k + ".WRITE_SIZE"]["mean"] + 2048.0 * c[k + ".FETCH_SIZE"]["mean"]
+                              for k in ("record_plan", "record_write"))
+                traffic_src = os.path.basename(f)
+                break
+            except Exception:  # noqa: BLE001 — another layout: no traffic figure
+                continue
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_records_baseline(eng, pool[0], fanouts, d)
@@ -1643,7 +1658,8 @@ def run_entry_sampler(args, rank, world, local_rank):
                        "setup_s": round(setup_s, 1)},
             "roofline": {"bound": "hbm", "kernel": "gigl_records_encode (record_plan + record_scan + record_write)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if traffic is None else round(traffic),
+                         "traffic_source": traffic_src,
                          "alg_bytes_per_launch": round(alg_bytes), "avg_launch_us": round(enc_ms * 1e3, 1),
                          "launches": int(max(3, reps // 4) * K_rep),
                          "timing": "HIP events on the engine's stream around back-to-back encode calls (no sampling "

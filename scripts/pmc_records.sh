@@ -23,14 +23,19 @@ acc = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$out/p*/*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "record_encode" not in k and "row_crc" not in k:
+        short = next((n for n in ("record_plan", "record_write", "record_scan", "row_crc") if n in k), None)
+        if short is None:
             continue
-        name = ("record_encode" if "record_encode" in k else "row_crc") + "." + row["Counter_Name"]
+        name = short + "." + row["Counter_Name"]
         acc[name][0] += float(row["Counter_Value"]); acc[name][1] += 1
 # a dispatch reports one row per counter (summed over XCDs / instances by the tool's _sum names)
 disp = collections.Counter()
+import json
+out = {}
 for name, (v, n) in sorted(acc.items()):
-    print(f"{name:60s} total {v:16.0f}  rows {n}")
+    print(f"{name:60s} total {v:16.0f}  dispatches {n}  mean {v / max(n, 1):14.1f}")
+    out[name] = {"total": v, "dispatches": n, "mean": v / max(n, 1)}
+json.dump(out, open("gpurun_out/pmc_records_$tag.json", "w"), indent=1)
 PY
 cat gpurun_out/pmc_records_$tag.txt
 find $out -name '*.csv' -size +4M -delete
