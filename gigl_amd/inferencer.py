@@ -264,6 +264,7 @@ def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str,
     node_types, num, ids, feats, edges, cet, efeats = load_preprocessed_typed_graph(cfg)
     inner = inferencer.model.module if hasattr(inferencer.model, "module") else inferencer.model
     enc = getattr(inner, "_encoder", getattr(inner, "encoder", inner))
+    is_hgt = type(enc).__name__ == "HGT"  # (HGT takes the row subset; the link-prediction wrapper passes it through)
     if type(enc).__name__ != "HGT" and any(np.asarray(v).size for v in (efeats or {}).values()):
         raise NotImplementedError("an encoder that reads edge features takes the TFRecord route (the in-HBM typed batch "
                                   "graph carries no edge attributes)")
@@ -289,8 +290,12 @@ def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str,
                     chunk = order[i:i + b]
                     graph, root_index, _ = s.batch_graph_plan(chunk, node_type, dags[node_type], b_max=b)
                     with torch.no_grad():
-                        out = inferencer.model(graph, [node_type])[node_type]
-                    emb = out[root_index.to(out.device)].float().cpu()
+                        if is_hgt:  # the last layer computes the roots' rows only
+                            emb = inferencer.model(graph, [node_type], row_subset={node_type: root_index})[node_type]
+                        else:
+                            out = inferencer.model(graph, [node_type])[node_type]
+                            emb = out[root_index.to(out.device)]
+                    emb = emb.float().cpu()
                     for k, gid in enumerate(np.asarray(chunk).tolist()):
                         fh.write(json.dumps({"node_id": int(gid), "node_type": node_type, "emb": emb[k].tolist()}) + "\n")
                         n_rows += 1

@@ -189,9 +189,12 @@ class HGTConv(nn.Module):
         return torch.block_diag(*[rel.weight[h * T + ti].t() for h in range(H)]).contiguous()
 
     def forward(self, x_dict: Dict[str, torch.Tensor], edge_index_dict: Dict[EdgeType, torch.Tensor],
-                csr_cache: Optional[dict] = None):
+                csr_cache: Optional[dict] = None, dst_subset: Optional[Dict[str, torch.Tensor]] = None):
         """csr_cache: a dict the caller keeps for ONE batch graph — the edges of all types merged into one CSR by
-        destination depend on the graph alone, so the layers of a model share it (HGT.forward)"""
+        destination depend on the graph alone, so the layers of a model share it (HGT.forward).
+        dst_subset {node type: int64 local ids}: compute ONLY these destination rows (the last layer of an inference
+        pass needs the roots' rows, not every node's): the result holds, per listed type, the rows in the subset's
+        order — each identical to the row of the full result (same edges in the same order, row-wise projections)."""
         any_x = next(iter(x_dict.values()))
         eng = _engine_for(self, any_x)
         dev = any_x.device
@@ -228,8 +231,41 @@ class HGTConv(nn.Module):
             else:
                 rowptr, col, ety = cached
             p_rel = torch.cat([self.p_rel["__".join(e)].reshape(1, H) for e in self.edge_types]).contiguous()
+            if dst_subset is not None:  # the listed rows only: their slices of the merged CSR, in the subset's order
+                rows = torch.cat([dst_subset[t].to(dev) + dst_off[t] for t in dst_subset])
+                rp = rowptr.to(torch.int64)
+                lens = rp[rows + 1] - rp[rows]
+                sub_ptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=dev)
+                sub_ptr[1:] = torch.cumsum(lens, 0)
+                idx = torch.repeat_interleave(rp[rows] - sub_ptr[:-1], lens) + torch.arange(int(sub_ptr[-1]), device=dev)
+                sub = _HgtAggFn.apply(qq[rows].contiguous(), torch.cat(ks), torch.cat(vs), p_rel, eng, H, D,
+                                      sub_ptr.to(torch.int32), col[idx].contiguous(), ety[idx].contiguous(),
+                                      int(rows.numel()))
+                res, o0 = {}, 0
+                for t, ids in dst_subset.items():
+                    lin = self.out_lin.lins[t]
+                    o = _linear(eng, F.gelu(sub[o0: o0 + ids.numel()]), lin.weight, lin.bias)
+                    xs = x_dict[t][ids.to(dev)]
+                    if o.shape[-1] == xs.shape[-1]:
+                        a = self.skip[t].sigmoid()
+                        o = a * o + (1 - a) * xs
+                    res[t] = o
+                    o0 += int(ids.numel())
+                return res
             out = _HgtAggFn.apply(qq, torch.cat(ks), torch.cat(vs), p_rel, eng, H, D, rowptr, col, ety, n_dst)
+        elif dst_subset is not None:
+            out = torch.zeros((n_dst, Fo), dtype=torch.float32, device=dev)
         res = {}
+        if dst_subset is not None:  # (no edges at all: the rows of the full result at the subset)
+            for t, ids in dst_subset.items():
+                lin = self.out_lin.lins[t]
+                x = x_dict[t][ids.to(dev)]
+                o = _linear(eng, F.gelu(out[dst_off[t] + ids.to(dev)]), lin.weight, lin.bias)
+                if o.shape[-1] == x.shape[-1]:
+                    a = self.skip[t].sigmoid()
+                    o = a * o + (1 - a) * x
+                res[t] = o
+            return res
         for t, x in x_dict.items():
             lin = self.out_lin.lins[t]
             o = _linear(eng, F.gelu(out[dst_off[t]: dst_off[t] + x.shape[0]]), lin.weight, lin.bias)
@@ -256,7 +292,10 @@ class HGT(nn.Module):
         self.lin = nn.Linear(hid_dim, out_dim)
         self.should_l2_normalize_embedding_layer_output = should_l2_normalize_embedding_layer_output
 
-    def forward(self, data: HeteroGraphData, output_node_types: List[str], device=None) -> Dict[str, torch.Tensor]:
+    def forward(self, data: HeteroGraphData, output_node_types: List[str], device=None,
+                row_subset: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """row_subset {node type: int64 local ids} (inference): return only these rows of the listed types, in that
+        order — the last layer then computes nothing else (identical rows; the earlier layers still need every node)"""
         any_x = next(iter(data.x_dict.values()))
         eng = _engine_for(self, any_x)
         for c in self.convs:
@@ -268,8 +307,13 @@ class HGT(nn.Module):
         h = {t: torch.relu(_linear(eng, x, self.lin_dict[t].weight, self.lin_dict[t].bias))
              for t, x in x_dict.items()}
         csr_cache: dict = {}  # (the merged CSR by destination is the graph's: built by the first layer, reused by the rest)
-        for conv in self.convs:
-            h = conv(h, data.edge_index_dict, csr_cache)
+        subset = None
+        if row_subset is not None and not torch.is_grad_enabled():
+            subset = {t: row_subset[t] for t in output_node_types if t in row_subset and t in h}
+            if len(subset) != len(output_node_types):
+                subset = None
+        for li, conv in enumerate(self.convs):
+            h = conv(h, data.edge_index_dict, csr_cache, subset if li == len(self.convs) - 1 else None)
         out = {}
         for t in output_node_types:
             out[t] = (_linear(eng, h[t], self.lin.weight, self.lin.bias) if t in h

@@ -302,3 +302,33 @@ def test_simplehgn_conv_training_gradients_match_torch_autograd(with_edge_attr):
     for name in want:
         np.testing.assert_allclose(got[name].numpy(), want[name].numpy(), rtol=2e-4, atol=2e-5, err_msg=name)
     np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+
+def test_hgt_last_layer_on_a_row_subset_equals_the_full_forward():
+    """HGT(..., row_subset={type: ids}): the last layer computes the listed rows only (an inference pass needs the roots'
+    rows): bit-identical to the same rows of the full forward"""
+    from gigl_amd.graphdb_sampler import (INCOMING, OUTGOING, EdgeType, HipGraphDBSampler, SamplingOp, SamplingOpDAG)
+    from gigl_amd.models_hetero import HGT
+    A2P, P2A = EdgeType("author", "writes", "paper"), EdgeType("paper", "written_by", "author")
+    rng = np.random.default_rng(3)
+    n = {"author": 900, "paper": 1500}
+    a = (rng.zipf(1.7, 7000) % n["author"]).astype(np.uint32)
+    p = rng.integers(0, n["paper"], 7000).astype(np.uint32)
+    feats = {"author": rng.standard_normal((900, 6)).astype(np.float32), "paper": rng.standard_normal((1500, 10)).astype(np.float32)}
+    s = HipGraphDBSampler({"author": 0, "paper": 1}, n, {A2P: (a, p), P2A: (p, a)}, {A2P: 0, P2A: 1}, feats)
+    dag = SamplingOpDAG.from_ops([SamplingOp("op0", A2P, 4, [], INCOMING), SamplingOp("op1", A2P, 3, ["op0"], OUTGOING),
+                                  SamplingOp("op2", P2A, 2, ["op1"], OUTGOING)])
+    roots = rng.choice(n["paper"], size=96, replace=False)
+    data, root_index, _ = s.batch_graph_plan(roots, "paper", dag)
+    torch.manual_seed(2)
+    ets = [("author", "writes", "paper"), ("paper", "written_by", "author")]
+    for layers in (1, 2, 3):
+        model = HGT({"author": 6, "paper": 10}, {e: 0 for e in ets}, hid_dim=32, out_dim=16, num_layers=layers,
+                    num_heads=2).to(s.engine.device).eval()
+        model.engine = s.engine
+        with torch.no_grad():
+            full = model(data, ["paper"])["paper"][root_index]
+            sub = model(data, ["paper"], row_subset={"paper": root_index})["paper"]
+        s.engine.synchronize()
+        assert sub.shape == full.shape and torch.equal(sub, full), layers
+    s.close()
