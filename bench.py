@@ -707,41 +707,38 @@ def main():
     if world > 1 and wl_name in ("products", "small") and not args.no_sharded_sub:
         # the graph-larger-than-one-GPU path at this N (BASELINE configs[2]): the MAG240M-shaped graph hash-partitioned
         # over the ranks, through the library's sharded plan — a sub-record of the line, never its value
-        sa = argparse.Namespace(**vars(args))
-        sa.workload, sa.fanouts, sa.batch = "mag240m-sharded", "25,10", 1024
-        sa.min_seconds, sa.min_reps, sa.min_rounds = min(args.min_seconds, 1.5), 3, 4
-        # The headline above is complete; the sub-record must never cost it.  Its collectives (RCCL issued by the
-        # library) can fail on one rank and leave the others waiting: every rank arms a timer that — should the
-        # sub-record not come back — has rank 0 print the headline with the failure noted and ends the process.
-        done = threading.Event()
-
-        def give_up(reason):
-            if done.is_set():
-                return
-            done.set()
-            if rank == 0:
-                line["sharded"] = {"error": reason}
-                print(json.dumps(line), flush=True)
-            sys.stdout.flush()
-            os._exit(0)
-
+        # The headline above is complete; the sub-record must never cost it — its collectives (RCCL issued by the
+        # library) have not run on a real multi-GPU node yet.  Every rank therefore runs it in a CHILD process (the
+        # same script as the mag240m-sharded workload, the ranks' own process group on another port): a crash or a
+        # hang there ends the child, not the line.  Rank 0 embeds the child's JSON line, or the reason there is none.
+        import subprocess
         limit = float(os.environ.get("GIGL_BENCH_SUB_TIMEOUT", "600"))
-        timer = threading.Timer(limit, give_up, args=(f"the sharded sub-record did not finish within {limit:.0f} s "
-                                                      "(GIGL_BENCH_SUB_TIMEOUT)",))
-        timer.daemon = True
-        timer.start()
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--workload", "mag240m-sharded",
+               "--fanouts", "25,10", "--batch", "1024", "--min-seconds", str(min(args.min_seconds, 1.5)), "--min-reps", "3",
+               "--min-rounds", "4", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
+               "--shard-group", str(args.shard_group), "--shard-hot-frac", str(args.shard_hot_frac), "--shard-plans",
+               str(args.shard_plans), "--shard-scale", str(args.shard_scale), "--project-input", args.project_input,
+               "--mode", args.mode] + (["--project-on-owner"] if args.project_on_owner else [])
+        env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
+        sub_err = None
         try:
-            sub = run_sharded(sa, rank, world, local_rank, sub=True)
+            cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)
+            lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
             if rank == 0:
-                line["sharded"] = {k: sub[k] for k in ("value", "ms_per_step", "n_gpus", "steps", "timing", "config",
-                                                       "roofline_xgmi")}
-        except BaseException as ex:  # noqa: BLE001 — this rank failed; the others are ended by their timers
-            timer.cancel()
-            give_up(f"rank {rank}: {type(ex).__name__}: {str(ex)[:400]}")
-        timer.cancel()
-        if done.is_set():  # (the timer fired while the sub-record was finishing)
-            return
-        done.set()
+                if cp.returncode == 0 and lines:
+                    sub = json.loads(lines[-1])
+                    line["sharded"] = {k: sub.get(k) for k in ("value", "ms_per_step", "n_gpus", "steps", "timing",
+                                                               "config", "roofline", "roofline_xgmi")}
+                else:
+                    sub_err = f"exit code {cp.returncode}: {cp.stderr.strip()[-400:]}"
+            elif cp.returncode != 0:
+                sub_err = f"rank {rank}: exit code {cp.returncode}"
+        except subprocess.TimeoutExpired:
+            sub_err = f"the sharded sub-record did not finish within {limit:.0f} s (GIGL_BENCH_SUB_TIMEOUT)"
+        except Exception as ex:  # noqa: BLE001
+            sub_err = f"{type(ex).__name__}: {str(ex)[:400]}"
+        if rank == 0 and sub_err:
+            line["sharded"] = {"error": sub_err}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

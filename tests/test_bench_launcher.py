@@ -55,8 +55,8 @@ def test_self_launch_two_ranks_on_one_gpu():
 
 @pytest.mark.gpu
 def test_a_failing_sharded_sub_record_never_costs_the_headline():
-    """the sub-record's collectives have not run on a real multi-GPU node yet: if it fails or hangs, rank 0 still prints
-    the (complete) headline line, with the failure noted, and every rank exits"""
+    """the sub-record's collectives have not run on a real multi-GPU node yet: it runs in child processes, so if it
+    crashes, fails or hangs, rank 0 still prints the (complete) headline line, with the failure noted"""
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--small", "--no-cpu-baseline", "--min-seconds", "0.3",
                         "--min-reps", "2", "--min-rounds", "2", "--group", "8", "--shard-group", "4", "--shard-scale",
                         "0.0005", "--steps", "16", "--warmup", "8"],
