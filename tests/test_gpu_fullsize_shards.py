@@ -7,7 +7,8 @@ tests/test_gpu_fullsize.py does for configs[1]:
 Checked on the device (the CPU oracle would need minutes per batch at these sizes): every parent gets exactly
 min(deg, f) neighbours, ascending, duplicate-free, all of them in-edges of the resident CSC; repeated calls are
 identical; a root's subtree depends on the root alone; 200 sampled rows — hubs included — equal the oracle's hash
-permutation of the row; the one-call plan equals the step-by-step entry points."""
+permutation of the row; the one-call plan equals the step-by-step entry points; on mag-shard also configs[4]'s GAT
+encoder: its one-call plan equals the staged forward."""
 import ctypes as C
 import os
 import sys
@@ -130,5 +131,22 @@ def test_full_size_shard_invariants(workload, fan, b, hid):
             out_p = plan.run(roots[:b].contiguous())
             assert plan.last_batch_to_host()["meta"][8] == 0
             np.testing.assert_allclose(out_p.cpu().numpy(), out.cpu().numpy(), rtol=1e-5, atol=1e-5)
+            # configs[4]'s encoder on the same shard (2-layer GAT, heads 2, 768 -> 128 -> 128): the GAT one-call plan
+            # (first layer from the input side in one row pass) == the staged forward over the same roots
+            from gigl_amd.models_attn import GAT
+            plan.close()
+            torch.manual_seed(1)
+            gat = GAT(d, 128, 128, num_layers=2, heads=2).to(dev)
+            gplan = gat.make_plan(eng, b // 2, fan, groups=2)
+            got_g = gplan.run(roots[:b].contiguous()).clone()
+            for gi in range(2):
+                r = roots[gi * (b // 2):(gi + 1) * (b // 2)].contiguous()
+                tr = eng.sample_khop(r, fan)
+                u = eng.union_build(tr)
+                ref = gat(HipBatch(eng, tr, u))[u.root_local[: b // 2].long()]
+                np.testing.assert_allclose(got_g[gi * (b // 2):(gi + 1) * (b // 2)].cpu().numpy(), ref.detach().cpu().numpy(),
+                                           rtol=2e-5, atol=2e-5)
+            assert bool(torch.isfinite(got_g).all())
+            gplan.close()
     finally:
         eng.close()
