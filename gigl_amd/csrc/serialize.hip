@@ -239,10 +239,18 @@ __device__ __forceinline__ void carve(const RecArgs& a, unsigned char* base, Pla
   pl.eslot = p;
 }
 
+// x / f for x < 2^20 and 1 <= f <= 64 without the (emulated) integer division: x * ceil(2^26 / f) >> 26 is exact there
+__device__ __forceinline__ uint32_t div_fanout(uint32_t x, uint32_t f) {
+  if (f == 1 || x >= (1u << 20)) return x / f;
+  return __umulhi(x, (((1u << 26) + f - 1u) / f) << 6);
+}
 // edge at edge-stream position q, from the plan's copy of the stream: src NONE = no edge
 __device__ __forceinline__ void plan_edge(const RecArgs& a, const uint32_t* ids, uint32_t q, uint32_t& s, uint32_t& d) {
-  const uint32_t tt = q / (uint32_t)a.edge_len;
-  const uint32_t local = q - tt * (uint32_t)a.edge_len;
+  uint32_t tt = 0, local = q;
+  if (a.trees > 1) {
+    tt = q / (uint32_t)a.edge_len;
+    local = q - tt * (uint32_t)a.edge_len;
+  }
   const uint32_t* t_ids = ids + tt * (uint32_t)a.tree_len;
   s = t_ids[local];
   d = NONE;
@@ -251,7 +259,7 @@ __device__ __forceinline__ void plan_edge(const RecArgs& a, const uint32_t* ids,
   for (int k = 0; k < a.hops; ++k) {
     const uint32_t sl = (uint32_t)a.slots[k];
     if (local < base + sl) {
-      d = k == 0 ? t_ids[a.tree_len - 1] : t_ids[prev_base + (local - base) / (uint32_t)a.fan[k]];
+      d = k == 0 ? t_ids[a.tree_len - 1] : t_ids[prev_base + div_fanout(local - base, (uint32_t)a.fan[k])];
       return;
     }
     prev_base = base;
@@ -545,19 +553,43 @@ struct CrcOut {
       nb = 0;
     }
   }
+  // n <= 8 bytes at once (the low n bytes of w, lowest first)
+  __device__ __forceinline__ void bytes(uint64_t w, uint32_t n) {
+    const uint32_t sh = 8u * nb;
+    acc |= w << sh;
+    nb += n;
+    if (nb >= 8) {  // two word steps of the checksum, one 8-byte store
+      c = crc_word(t, crc_word(t, c, (uint32_t)acc), (uint32_t)(acc >> 32));
+      *(GIGL_GLOBAL u64_unaligned*)p = acc;
+      p += 8;
+      nb -= 8;
+      acc = sh ? w >> (64u - sh) : 0ull;  // what did not fit
+    }
+  }
+  // a key byte followed by the varint of a 32-bit value: up to 6 bytes composed in registers
+  __device__ __forceinline__ void key_varint(uint32_t key, uint32_t v) {
+    const uint32_t n = (uint32_t)vlen(v);
+    uint64_t w = (uint64_t)(v & 0x7Fu) | ((uint64_t)((v >> 7) & 0x7Fu) << 8) | ((uint64_t)((v >> 14) & 0x7Fu) << 16) |
+                 ((uint64_t)((v >> 21) & 0x7Fu) << 24) | ((uint64_t)(v >> 28) << 32);
+    w |= 0x0000008080808080ull & ((1ull << (8u * (n - 1u))) - 1ull);  // continuation bits of all but the last byte
+    bytes((uint64_t)key | (w << 8), n + 1u);
+  }
   __device__ __forceinline__ void varint(uint64_t v) {
+    if (v < (1ull << 32)) {
+      const uint32_t x = (uint32_t)v, n = (uint32_t)vlen(x);
+      uint64_t w = (uint64_t)(x & 0x7Fu) | ((uint64_t)((x >> 7) & 0x7Fu) << 8) | ((uint64_t)((x >> 14) & 0x7Fu) << 16) |
+                   ((uint64_t)((x >> 21) & 0x7Fu) << 24) | ((uint64_t)(x >> 28) << 32);
+      w |= 0x0000008080808080ull & ((1ull << (8u * (n - 1u))) - 1ull);
+      bytes(w, n);
+      return;
+    }
     while (v >= 128) {
       byte((uint32_t)(v | 0x80));
       v >>= 7;
     }
     byte((uint32_t)v);
   }
-  __device__ __forceinline__ void word(uint32_t v) {
-    byte(v);
-    byte(v >> 8);
-    byte(v >> 16);
-    byte(v >> 24);
-  }
+  __device__ __forceinline__ void word(uint32_t v) { bytes(v, 4); }
   __device__ __forceinline__ void flush() {
     if (nb & 4) {
       c = crc_word(t, c, (uint32_t)acc);
@@ -585,44 +617,21 @@ struct CrcOut {
   __device__ __forceinline__ gptr_t pos() const { return p + nb; }
 };
 
-// header of a Node field (everything before the float payload), byte stores by one thread
+// header of a Node field (everything before the float payload), composed in registers by one thread
 __device__ __forceinline__ void write_node_header(const RecArgs& a, CrcOut& o, uint8_t tag, uint32_t id) {
-  o.byte(tag);
-  o.varint(node_body_len(a, id));
-  if (id) {
-    o.byte(0x08);
-    o.varint(id);
-  }
-  if (a.node_type >= 0) {
-    o.byte(0x10);
-    o.varint((uint32_t)a.node_type);
-  }
-  if (a.d > 0) {
-    o.byte(0x1A);
-    o.varint(4u * (uint32_t)a.d);
-  }
+  o.key_varint(tag, node_body_len(a, id));
+  if (id) o.key_varint(0x08, id);
+  if (a.node_type >= 0) o.key_varint(0x10, (uint32_t)a.node_type);
+  if (a.d > 0) o.key_varint(0x1A, 4u * (uint32_t)a.d);
 }
 
 // header of an Edge field (everything before the float payload; the whole field without edge features)
 __device__ __forceinline__ void write_edge(const RecArgs& a, CrcOut& o, uint8_t tag, uint32_t s, uint32_t d, int32_t de) {
-  o.byte(tag);
-  o.varint(edge_body_len_de(a, s, d, de));
-  if (s) {
-    o.byte(0x08);
-    o.varint(s);
-  }
-  if (d) {
-    o.byte(0x10);
-    o.varint(d);
-  }
-  if (a.edge_type >= 0) {
-    o.byte(0x18);
-    o.varint((uint32_t)a.edge_type);
-  }
-  if (de > 0) {
-    o.byte(0x22);
-    o.varint(4u * (uint32_t)de);
-  }
+  o.key_varint(tag, edge_body_len_de(a, s, d, de));
+  if (s) o.key_varint(0x08, s);
+  if (d) o.key_varint(0x10, d);
+  if (a.edge_type >= 0) o.key_varint(0x18, (uint32_t)a.edge_type);
+  if (de > 0) o.key_varint(0x22, 4u * (uint32_t)de);
 }
 // a label edge root -> t (pos_edges = 4 / hard_neg_edges = 2) with its features
 __device__ __forceinline__ void write_label_edge(const RecArgs& a, CrcOut& o, int which, uint32_t root, uint32_t t) {
