@@ -24,9 +24,9 @@
 // 4*D payload bytes contribute a state tabulated once per feature table (gigl_features_row_crc) after one table-driven
 // shift of the running state, and a lane shifts its chained state to the end of the payload with one multiply mod P.
 // Measured (MI355X, products-shaped graph, [25,10], D=100, ~90 distinct nodes and 40.4 KB per record; device time of
-// back-to-back calls, scripts/micro_records.py --device-only): 4,096 records per call 191 us (plan 54 + scan ~5 + write
-// 129) = 0.87 TB/s of finished TFRecord bytes; 32,768 per call 1.07 ms (plan 0.19 + write 0.83) = 1.20 TB/s =
-// 0.30 of the HBM peak counting the bytes written and the row bytes read (round 2: 289 us per 4,096 = 0.57 TB/s,
+// back-to-back calls, scripts/micro_records.py --device-only): 4,096 records per call 182 us (plan 54 + scan ~5 + write
+// ~120) = 0.91 TB/s of finished TFRecord bytes; 32,768 per call 1.05 ms (plan 0.19 + write 0.83) = 1.22 TB/s =
+// 0.31 of the HBM peak counting the bytes written and the row bytes read (round 2: 289 us per 4,096 = 0.57 TB/s,
 // 0.14).  What the pattern allows: the row copy alone as dense items runs at 4.5 TB/s read + written
 // (scripts/micro_rowcopy.py: 66 us per 4,096 records).  What was learnt on the way (profiles/r03g_encoder.md): per-byte
 // stores and a CRC pass over the payload each cost more than the payload copy; one ticket counter or one look-back
