@@ -6,8 +6,14 @@ import ctypes as C
 import os
 import torch
 
+import subprocess
+
 here = os.path.dirname(os.path.abspath(__file__))
-lib = C.CDLL(os.path.join(here, "micro", "librowcopy.so"))
+so = os.path.join(here, "micro", "librowcopy.so")
+if not os.path.exists(so):  # (built artefacts are not in the history)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared",
+                           os.path.join(here, "micro", "rowcopy.hip"), "-o", so])
+lib = C.CDLL(so)
 lib.rowcopy_launch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_int,
                                C.c_int, C.c_void_p]
 n, d, rows = 2_449_029, 100, 4096 * 90
