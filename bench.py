@@ -178,7 +178,7 @@ WORKLOADS = {
     "rmat-shard": (1 << 27, 27, 2_000_000_000, 128, torch.float16, True, 256, 256, 4,
                    "RMAT scale-30 / 8 (one GPU's share of the 8-way sharded graph)"),
 }
-WORKLOAD_DEFAULTS = {"cora": ("10,5", 512), "rmat-shard": ("15,10", 4096)}
+WORKLOAD_DEFAULTS = {"cora": ("10,5", 512), "rmat-shard": ("15,10", 4096), "typed-dblp": ("10,5", 4096)}
 
 
 def build_workload(eng, args):
@@ -235,7 +235,7 @@ def main():
                     help="batches per library call: G independent batches of B roots share one set of launches "
                          "(each keeps its own union graph; results are bit-identical to G single-batch calls)")
     ap.add_argument("--workload", type=str, default="products",
-                    choices=["products", "mag-shard", "mag240m-sharded", "cora", "rmat-shard", "gat-lp"],
+                    choices=["products", "mag-shard", "mag240m-sharded", "cora", "rmat-shard", "gat-lp", "typed-dblp"],
                     help="products = BASELINE configs[1] (default, the N=1 workload; N>1: a replica per GPU); mag-shard = "
                          "one GPU's 1/8 share of the MAG240M-shaped graph as a self-contained graph (D=768 fp16, SAGE "
                          "768->256->256); mag240m-sharded = BASELINE configs[2]: the MAG240M-shaped graph hash-"
@@ -321,6 +321,8 @@ def main():
         return run_sharded(args, rank, world, local_rank)
     if args.workload == "gat-lp":
         return run_gat_lp(args, rank, world, local_rank)
+    if args.workload == "typed-dblp":
+        return run_typed(args, rank, world, local_rank)
 
     from gigl_amd._lib import KERNEL_IDS, MODE_FAST, MODE_SPARK_HASH, STATS, STATS_LEN
     from gigl_amd.engine import HipEngine
@@ -1716,6 +1718,191 @@ def run_cpu_records_baseline(eng, roots, fanouts, d, budget_s=15.0):
             "sample": f"{done} roots of the same batch in {dt:.1f} s: oracle/gigl_oracle.c sampler (1 thread) + "
                       "oracle/records.py assembly, proto3 encoding and TFRecord framing (numpy / pure Python, 1 thread); "
                       f"{done / dt:.1f} records/s"}
+
+
+def run_typed(args, rank, world, local_rank):
+    """--workload typed-dblp (the SamplingOp-DAG sampler + HGT over typed graphs): a DBLP-shaped typed
+    graph resident in HBM (2 M authors x 64 floats, 4 M papers x 128 floats, 40 M writes / written_by edges, skewed
+    authors), a step = one batch of B paper roots through the one-call typed plan (gigl_typed_plan_*: the DAG
+    [authors of the paper: f0] -> [papers of those authors: f1], the distinct nodes per type, the distinct edges per edge
+    type) + feature rows + a 2-layer HGT (hidden 64, heads 2; the last layer on the roots only) -> the roots' rows.
+    Edges: sampled = the ops' sampled neighbours; aggregated = the edges the two HGT layers reduce over (all distinct
+    edges of the batch graph, then those into the roots).  A replica per GPU at N > 1; a secondary line."""
+    from gigl_amd.graphdb_sampler import INCOMING, EdgeType, HipGraphDBSampler, SamplingOp, SamplingOpDAG
+    from gigl_amd.models_hetero import HGT
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    f0, f1 = [int(v) for v in args.fanouts.split(",")][:2]
+    B = args.batch
+    na, npp, ne = (20_000, 40_000, 400_000) if args.small else (2_000_000, 4_000_000, 40_000_000)
+    t0 = time.time()
+    rng = np.random.default_rng(0)
+    a2p, p2a = EdgeType("author", "writes", "paper"), EdgeType("paper", "written_by", "author")
+    src = (na * rng.random(ne) ** 2).astype(np.int64)  # skewed authors
+    dst = rng.integers(0, npp, ne)
+    edges = {a2p: (src.astype(np.uint32), dst.astype(np.uint32)), p2a: (dst.astype(np.uint32), src.astype(np.uint32))}
+    feats = {"author": rng.standard_normal((na, 64)).astype(np.float32), "paper": rng.standard_normal((npp, 128)).astype(np.float32)}
+    smp = HipGraphDBSampler({"author": 0, "paper": 1}, {"author": na, "paper": npp}, edges, {a2p: 0, p2a: 1}, feats,
+                            device=local_rank)
+    eng = smp.engine
+    ops = [SamplingOp("h1", a2p, f0, [], INCOMING), SamplingOp("h2", p2a, f1, ["h1"], INCOMING)]
+    dag = SamplingOpDAG.from_ops(ops)
+    torch.manual_seed(0)
+    ets = [("author", "writes", "paper"), ("paper", "written_by", "author")]
+    model = HGT({"author": 64, "paper": 128}, {e: 0 for e in ets}, hid_dim=64, out_dim=64, num_layers=2, num_heads=2).to(dev).eval()
+    model.engine = eng
+    n_batches = 16
+    g = torch.Generator().manual_seed(42)
+    pool = [torch.randperm(npp, generator=g)[:B].numpy().astype(np.int64) for _ in range(n_batches)]
+    setup_s = time.time() - t0
+
+    def step(i):
+        graph, ri, _ = smp.batch_graph_plan(pool[i % n_batches], "paper", dag, b_max=B)
+        with torch.no_grad():
+            return graph, ri, model(graph, ["paper"], row_subset={"paper": ri})["paper"]
+
+    # exact edge counts of every batch of the pool (the same batches are timed)
+    sampled, agg = [], []
+    for i in range(n_batches):
+        graph, ri, out = step(i)
+        res = smp.run_dag(torch.from_numpy(pool[i]).to(torch.int32), dag)
+        sampled.append(sum(int(r.cnt.sum().item()) for r in res.values()))
+        e_all = sum(int(v.shape[1]) for v in graph.edge_index_dict.values())
+        is_root = torch.zeros(int(graph.x_dict["paper"].shape[0]), dtype=torch.bool, device=dev)
+        is_root[ri] = True
+        e_root = sum(int(is_root[v[1]].sum().item()) for k, v in graph.edge_index_dict.items() if k[2] == "paper")
+        agg.append(e_all + e_root)
+        assert bool(torch.isfinite(out).all()) and out.shape[0] == B
+    torch.cuda.synchronize()
+    reps, rep_s = 0, []
+    t_all = time.perf_counter()
+    while time.perf_counter() - t_all < args.min_seconds or reps < args.min_reps:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_batches):
+            step(i)
+        torch.cuda.synchronize()
+        rep_s.append(time.perf_counter() - t1)
+        reps += 1
+    elapsed = float(sum(rep_s))
+    steps = reps * n_batches
+    # per-kernel times of one more pass (the library's HIP-event timers; the typed graphs' segmented reduce
+    # gigl_hgt_aggregate is timed as gather_mean, the projections as linear, the ops of the DAG as expand)
+    names = ["expand", "gather_mean", "linear"]
+    eng.profile_enable(names, capacity=n_batches * 256)
+    eng.profile_reset()
+    for i in range(n_batches):
+        step(i)
+    torch.cuda.synchronize()
+    prof = {k: eng.profile_read(k) for k in names}
+    eng.profile_enable([], 0)
+    by_kernel = {k: {"ms_per_step": round(v[0] / n_batches, 5), "launches": int(v[1])} for k, v in prof.items() if v[0] > 0}
+    step_ms = elapsed / steps * 1e3
+    Fo, H = 64, 2
+    # hgt_aggregate per edge: one k row + one v row of Fo floats; per destination: its q row and its output row
+    graph, ri, _ = step(0)
+    n_dst_all = sum(int(x.shape[0]) for x in graph.x_dict.values())
+    b_agg = (float(np.mean(agg)) * (2 * Fo * 4 + 8) + (n_dst_all + B) * 2 * Fo * 4)
+    roofline = None
+    if "gather_mean" in by_kernel:
+        gm = by_kernel["gather_mean"]
+        ach = b_agg / (gm["ms_per_step"] * 1e-3) / 1e9
+        gm.update(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+        dom = max(by_kernel, key=lambda k: by_kernel[k]["ms_per_step"])
+        roofline = {"bound": "hbm", "kernel": "gigl_hgt_aggregate (timed as gather_mean)", "achieved": gm["achieved"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gm["frac"], "traffic": None, "dominant": dom,
+                    "alg_bytes_per_launch": round(b_agg * n_batches / max(gm["launches"], 1)),
+                    "avg_launch_us": round(gm["ms_per_step"] * n_batches / max(gm["launches"], 1) * 1e3, 2),
+                    "launches": gm["launches"],
+                    "library_kernel_share_of_step": round(sum(v["ms_per_step"] for v in by_kernel.values()) / step_ms, 3),
+                    "note": "the step is bound by its ~100 small launches and device tensor ops between them (typed "
+                            "projections per node / edge type, CSR by destination), not by a kernel",
+                    "timing": "HIP events on the engine's stream over one untimed pass of the timed batches",
+                    "by_kernel": by_kernel}
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_typed_baseline(edges, feats, ops, model, pool[0], B)
+    line = {
+        "metric": "sampled+aggregated edges/s", "value": (float(np.mean(sampled)) + float(np.mean(agg))) * steps / elapsed,
+        "unit": "edges/s", "n_gpus": 1, "steps": steps, "warmup": n_batches, "ms_per_step": step_ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "timing": {"repetitions": reps, "steps_per_repetition": n_batches, "timed_region_s": round(elapsed, 3)},
+        "config": {"workload": f"DBLP-shaped typed graph ({na} authors x 64, {npp} papers x 128, {ne} edges per edge type), "
+                               f"SamplingOp DAG [{f0},{f1}] over {B} paper roots per step through the one-call typed plan + "
+                               "2-layer HGT (hidden 64, heads 2, last layer on the roots)",
+                   "entry": "HipGraphDBSampler.batch_graph_plan (gigl_typed_plan_*) -> HGT.forward(row_subset)",
+                   "roots_per_s": B * steps / elapsed, "sampled_edges_per_step": float(np.mean(sampled)),
+                   "aggregated_edges_per_step": float(np.mean(agg)),
+                   "distinct_nodes_per_step": n_dst_all, "setup_s": round(setup_s, 1)},
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
+    }
+    if world > 1:
+        import torch.distributed as dist
+        v = torch.tensor([line["value"]], dtype=torch.float64, device=dev)
+        t = torch.tensor([line["ms_per_step"]], dtype=torch.float64, device=dev)
+        all_reduce(v, dist.ReduceOp.SUM)
+        all_reduce(t, dist.ReduceOp.MAX)
+        line.update(value=float(v.item()), ms_per_step=float(t.item()), n_gpus=world)
+    if rank == 0:
+        print(json.dumps(line))
+    smp.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_cpu_typed_baseline(edges, feats, ops, model, roots, B, budget_s=15.0):
+    """the CPU restatement of the typed step on a bounded sample of the same roots: oracle/dag_sampler.py (the per-root
+    GraphDBSampler restatement, pure Python) for the DAG, the union of the samples as the batch graph, fp32 torch CPU
+    HGT (oracle/gnn_ref.hgt_conv, one thread) over it; edges counted in the GPU line's unit"""
+    import torch.nn.functional as F
+    from oracle import dag_sampler, gnn_ref
+    torch.set_num_threads(1)
+    nbrs = dag_sampler.neighbour_lists(edges)
+    node_types = {"author": 0, "paper": 1}
+    cet = {et: i for i, et in enumerate(edges)}
+    by_c = {v: k for k, v in node_types.items()}
+    et_of = {i: (et.src_node_type, et.relation, et.dst_node_type) for et, i in cet.items()}
+    ets = list(et_of.values())
+    from gigl_amd.models_hetero import HGT
+    cpu = HGT({"author": 64, "paper": 128}, {e: 0 for e in ets}, hid_dim=64, out_dim=64, num_layers=2, num_heads=2)
+    cpu.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    done, units, used = 0, 0, 0.0
+    chunk = B  # (the GPU line's batch: the union graph, and with it the work per root, depends on the batch size)
+    while used < budget_s and done < min(len(roots), B):
+        rr = roots[done:done + chunk]
+        t1 = time.perf_counter()
+        e_all, n_all = set(), set()
+        for r in rr.tolist():
+            e_, n_ = dag_sampler.sample_for_root(int(r), ops, nbrs, node_types, cet, "paper")
+            e_all |= e_
+            n_all |= n_
+        ids = {t: np.array(sorted(v for v, c in n_all if by_c[c] == t), dtype=np.int64) for t in node_types}
+        pos = {t: {int(v): i for i, v in enumerate(ids[t].tolist())} for t in node_types}
+        ei = {}
+        for c, triple in et_of.items():
+            pr = [(pos[triple[0]][s_], pos[triple[2]][d_]) for s_, d_, cc in e_all if cc == c]
+            ei[triple] = torch.tensor(pr, dtype=torch.int64).t().reshape(2, -1)
+        xd = {t: torch.from_numpy(feats[t][ids[t]]) for t in node_types if ids[t].size}
+        with torch.no_grad():
+            h = {t: torch.relu(F.linear(x, cpu.lin_dict[t].weight, cpu.lin_dict[t].bias)) for t, x in xd.items()}
+            for conv in cpu.convs:
+                pr = dict(kqv={t: (conv.kqv_lin.lins[t].weight, conv.kqv_lin.lins[t].bias) for t in xd},
+                          out={t: (conv.out_lin.lins[t].weight, conv.out_lin.lins[t].bias) for t in xd},
+                          k_rel=conv.k_rel.weight, v_rel=conv.v_rel.weight, skip={t: conv.skip[t] for t in xd},
+                          p_rel={e: conv.p_rel["__".join(e)] for e in ets}, edge_types=ets)
+                h = gnn_ref.hgt_conv(h, {k: v for k, v in ei.items() if v.numel()}, pr, 2)
+            F.linear(h["paper"], cpu.lin.weight, cpu.lin.bias)
+        used += time.perf_counter() - t1
+        root_set = set(int(v) for v in rr.tolist())
+        units += len(e_all) + len(e_all) + sum(1 for s_, d_, c in e_all if et_of[c][2] == "paper" and d_ in root_set)
+        done += len(rr)
+    return {"value": units / max(used, 1e-9), "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"{done} roots of one batch in {used:.1f} s: oracle/dag_sampler.py (pure Python, per root) + fp32 torch "
+                      "CPU HGT over the union of the samples (oracle/gnn_ref.hgt_conv, both layers over the whole graph: "
+                      "the reference's execution order), 1 thread; edges in the GPU line's unit (distinct sampled edges + "
+                      f"the edges the trimmed layers reduce over); {done / max(used, 1e-9):.1f} roots/s"}
 
 
 def _lib_stats_len():

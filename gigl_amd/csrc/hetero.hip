@@ -315,6 +315,7 @@ int32_t gigl_hgt_aggregate(gigl_ctx* ctx, const float* q, const float* k, const 
   if (rc != GIGL_OK) return rc;
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (n_dst == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);  // (the typed graphs' segmented reduce: timed with the others)
   const int passes = (heads * dim + 255) / 256;
   const dim3 grid((unsigned)((n_dst + 3) / 4)), block(256);
 #define GIGL_LAUNCH_HGT(P)                                                                                          \
