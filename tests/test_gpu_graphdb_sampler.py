@@ -304,3 +304,32 @@ def test_one_call_typed_plan_equals_the_staged_batch_graph(world):
                 assert torch.equal(g0.edge_index_dict[k], g1.edge_index_dict[k]), f"{root_type} b={b}: edges of {k}"
             assert torch.equal(ri0, ri1)
         assert sum(int(v.shape[1]) for v in g1.edge_index_dict.values()) > 100
+
+
+def test_one_call_typed_plan_at_scale():
+    """the typed plan against the staged path on a 600k-node DBLP-shaped graph with skewed authors (hub rows in the
+    heavy-row path of the sampler), 2,048 roots per batch: identical node lists, edge lists and root positions; repeated
+    runs are identical; every root is in its type's list at its reported position"""
+    rng = np.random.default_rng(0)
+    na, npp, ne = 200_000, 400_000, 4_000_000
+    a2p, p2a = EdgeType("author", "writes", "paper"), EdgeType("paper", "written_by", "author")
+    src = (na * rng.random(ne) ** 2).astype(np.uint32)
+    dst = rng.integers(0, npp, ne).astype(np.uint32)
+    feats = {"author": rng.standard_normal((na, 8)).astype(np.float32), "paper": rng.standard_normal((npp, 12)).astype(np.float32)}
+    s = HipGraphDBSampler({"author": 0, "paper": 1}, {"author": na, "paper": npp}, {a2p: (src, dst), p2a: (dst, src)},
+                          {a2p: 0, p2a: 1}, feats)
+    dag = SamplingOpDAG.from_ops([SamplingOp("h1", a2p, 10, [], INCOMING), SamplingOp("h2", p2a, 5, ["h1"], INCOMING)])
+    roots = rng.choice(npp, size=2048, replace=False)
+    g0, ri0, u0 = s.batch_graph(roots, "paper", dag)
+    g1, ri1, u1 = s.batch_graph_plan(roots, "paper", dag)
+    g2, ri2, u2 = s.batch_graph_plan(roots, "paper", dag)
+    torch.cuda.synchronize()
+    for t in u0:
+        assert torch.equal(u0[t], u1[t]) and torch.equal(u1[t], u2[t])
+        assert bool((u1[t][1:] > u1[t][:-1]).all())  # ascending, duplicate-free
+        assert torch.equal(g0.x_dict[t], g1.x_dict[t])
+    for k in g0.edge_index_dict:
+        assert torch.equal(g0.edge_index_dict[k], g1.edge_index_dict[k]) and torch.equal(g1.edge_index_dict[k], g2.edge_index_dict[k])
+    assert torch.equal(ri0, ri1) and torch.equal(u1["paper"][ri1].cpu(), torch.from_numpy(roots))
+    assert sum(int(v.shape[1]) for v in g1.edge_index_dict.values()) > 50_000
+    s.close()
