@@ -186,7 +186,18 @@ class HGTConv(nn.Module):
     def _block_diag(self, rel: _HeteroLinear, ti: int) -> torch.Tensor:
         """[H*D, H*D] weight (gigl_linear layout: out x in) applying head h's D x D relation matrix to head h's slice"""
         H, T = self.heads, len(self.edge_types)
-        return torch.block_diag(*[rel.weight[h * T + ti].t() for h in range(H)]).contiguous()
+        if torch.is_grad_enabled():
+            return torch.block_diag(*[rel.weight[h * T + ti].t() for h in range(H)]).contiguous()
+        # inference: the matrix is rebuilt only when the parameter changed (its version counts in-place updates) — the
+        # half-dozen tiny device ops per edge type and layer were a visible part of a typed step
+        cache = self.__dict__.setdefault("_bd_cache", {})
+        key = (id(rel), ti)
+        ver = (rel.weight._version, rel.weight.device, rel.weight.data_ptr())
+        hit = cache.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, torch.block_diag(*[rel.weight[h * T + ti].t() for h in range(H)]).contiguous())
+            cache[key] = hit
+        return hit[1]
 
     def forward(self, x_dict: Dict[str, torch.Tensor], edge_index_dict: Dict[EdgeType, torch.Tensor],
                 csr_cache: Optional[dict] = None, dst_subset: Optional[Dict[str, torch.Tensor]] = None):
