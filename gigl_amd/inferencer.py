@@ -281,13 +281,15 @@ def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str,
             inferencer._ensure_engine(dev)
         for node_type in wanted:
             path = resolve_uri(info[node_type]["embeddingsPath"], cfg.uri_base)
-            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-            out_files[f"embeddings/{node_type}"] = path
-            with open(path, "w") as fh:
+            files = {"embeddings": path}
+            # rows through the same writer as the homogeneous routes: line-per-root JSON formatted natively
+            # (gigl_json_rows_format), or Avro shards encoded on the device when the path names a directory
+            writer = _RowWriter(files, node_type)
+            try:
                 prefix = cfg.random_negative_tfrecord_uri_prefixes.get(node_type)
                 order = planned_root_order(np.asarray(ids[node_type]), prefix) if prefix else np.asarray(ids[node_type])
                 for i in range(0, order.size, b):
-                    chunk = order[i:i + b]
+                    chunk = np.asarray(order[i:i + b], dtype=np.int64)
                     graph, root_index, _ = s.batch_graph_plan(chunk, node_type, dags[node_type], b_max=b)
                     with torch.no_grad():
                         if is_hgt:  # the last layer computes the roots' rows only
@@ -295,10 +297,11 @@ def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str,
                         else:
                             out = inferencer.model(graph, [node_type])[node_type]
                             emb = out[root_index.to(out.device)]
-                    emb = emb.float().cpu()
-                    for k, gid in enumerate(np.asarray(chunk).tolist()):
-                        fh.write(json.dumps({"node_id": int(gid), "node_type": node_type, "emb": emb[k].tolist()}) + "\n")
-                        n_rows += 1
+                    writer.add(chunk, emb.float(), None)
+            finally:
+                writer.close()
+            out_files[f"embeddings/{node_type}"] = files["embeddings"]
+            n_rows += writer.n_rows
     finally:
         s.close()
     self.rows_written = n_rows
