@@ -231,17 +231,20 @@ def _typed_run(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str, str
     for node_type, v in info.items():
         if not v.get("embeddingsPath") or node_type not in prefixes:
             continue
-        path = resolve_uri(v["embeddingsPath"], cfg.uri_base)
-        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        out_files[f"embeddings/{node_type}"] = path
-        with open(path, "w") as fh:
+        files = {"embeddings": resolve_uri(v["embeddingsPath"], cfg.uri_base)}
+        # one output per node type (the reference writes a table per type: rows {"node_id", "emb"}), through the writer
+        # of the homogeneous routes: JSON lines formatted natively, or Avro shards when the path names a directory
+        writer = _RowWriter(files, node_type)
+        try:
             for raw in iterate_tfrecord_batches(tfrecord_files(prefixes[node_type]), cfg.inference_batch_size):
                 batch = HeteroRootedNodeNeighborhoodBatch.process_raw_pyg_samples_and_collate_fn(
                     raw, cfg.condensed_node_type_map, cfg.condensed_edge_type_map)
-                emb = inferencer.infer_batch(batch=batch, device=dev).embeddings.cpu()
-                for i, (_, gid) in enumerate(batch.root_nodes):
-                    fh.write(json.dumps({"node_id": int(gid), "node_type": node_type, "emb": emb[i].tolist()}) + "\n")
-                    n_rows += 1
+                emb = inferencer.infer_batch(batch=batch, device=dev).embeddings
+                writer.add(np.array([gid for _, gid in batch.root_nodes], dtype=np.int64), emb.float(), None)
+        finally:
+            writer.close()
+        out_files[f"embeddings/{node_type}"] = files["embeddings"]
+        n_rows += writer.n_rows
     self.rows_written = n_rows
     return out_files
 
