@@ -1000,6 +1000,8 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, EncArgs e,
 // ------------------------------------------------------------------------------------------
 constexpr int TYPED_MAX_OPS = 16, TYPED_MAX_NODE_TYPES = 16, TYPED_MAX_EDGE_TYPES = 16;
 constexpr uint32_t TYPED_MAX_ITEMS = 4096;  // candidate nodes / edges per root the LDS sort is sized for
+constexpr uint32_t TYPED_BIG_MAX_ITEMS = 1u << 20;  // ... and the sort staged in global scratch (typed_plan_kernel<true>)
+constexpr int64_t TYPED_BIG_STAGE_BYTES = 1ll << 30;  // bound of that staging area (it sets the number of workgroups)
 constexpr unsigned long long PAD64 = ~0ull;
 
 constexpr uint32_t TYPED_POS_BIT = 0x80000000u;  // class bit of a sorted edge's type word: a positive edge
@@ -1022,6 +1024,12 @@ struct TypedArgs {
   uint32_t* u_info;             // [b][8]: distinct nodes, distinct edges (both classes), bytes of the node fields,
                                 //         graph body bytes, bytes of the pos_edges fields
   const uint32_t* shift_tbl;
+  // more than TYPED_MAX_ITEMS - 1 candidates per root: the sort and the payload offsets are staged in global scratch, one
+  // segment per WORKGROUP (a workgroup takes roots blockIdx.x, blockIdx.x + gridDim.x, ...)
+  unsigned long long* g_nk;  // [workgroups][pow2]
+  unsigned long long* g_ek;  // [workgroups][pow2]
+  uint32_t* g_et;            // [workgroups][pow2]
+  uint32_t* g_pay;           // [workgroups][items + 2]
   // Edge.feature_values per condensed edge type: the type's edge list as CSR by SOURCE + one fp32 row per edge in its
   // `col` order (feat == NULL: edges of the type carry no features)
   struct EdgeFeat {
@@ -1096,12 +1104,68 @@ __device__ void lds_bitonic(unsigned long long* key, uint32_t* minor, uint32_t n
   }
 }
 
-__global__ __launch_bounds__(256) void typed_plan_kernel(TypedArgs a, int64_t* rec_size) {
+// one compare-exchange pass of the bitonic network at distance j inside runs of k; idx0 = position of element 0 in the
+// whole sequence (it decides the run's direction)
+__device__ __forceinline__ void bitonic_pass(unsigned long long* key, uint32_t* minor, uint32_t n, uint32_t k, uint32_t j,
+                                             uint32_t idx0) {
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint32_t p = i ^ j;
+    if (p > i) {
+      const unsigned long long a = key[i], b = key[p];
+      const uint32_t ma = minor ? minor[i] : 0u, mb = minor ? minor[p] : 0u;
+      const bool gt = a > b || (a == b && ma > mb);
+      if (gt == (((idx0 + i) & k) == 0)) {
+        key[i] = b;
+        key[p] = a;
+        if (minor) {
+          minor[i] = mb;
+          minor[p] = ma;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// the same network over a sequence in GLOBAL scratch (n = 2^k >= 2 * TYPED_MAX_ITEMS): passes at distances below the
+// chunk size run on chunks staged in LDS (lk / lm: TYPED_MAX_ITEMS entries), the few longer ones in place
+__device__ void big_bitonic(unsigned long long* key, uint32_t* minor, uint32_t n, unsigned long long* lk, uint32_t* lm) {
+  constexpr uint32_t CH = TYPED_MAX_ITEMS;
+  uint32_t* const lminor = minor ? lm : nullptr;
+  for (uint32_t k0 = CH; k0 <= n; k0 <<= 1) {
+    // k0 == CH: every run up to the chunk size, chunk by chunk; above: the long passes of run k0, then the short ones
+    if (k0 > CH)
+      for (uint32_t j = k0 >> 1; j >= CH; j >>= 1) bitonic_pass(key, minor, n, k0, j, 0);
+    for (uint32_t c = 0; c < n; c += CH) {
+      for (uint32_t i = threadIdx.x; i < CH; i += blockDim.x) {
+        lk[i] = key[c + i];
+        if (minor) lm[i] = minor[c + i];
+      }
+      __syncthreads();
+      if (k0 == CH) {
+        for (uint32_t k = 2; k <= CH; k <<= 1)
+          for (uint32_t j = k >> 1; j > 0; j >>= 1) bitonic_pass(lk, lminor, CH, k, j, c);
+      } else {
+        for (uint32_t j = CH >> 1; j > 0; j >>= 1) bitonic_pass(lk, lminor, CH, k0, j, c);
+      }
+      for (uint32_t i = threadIdx.x; i < CH; i += blockDim.x) {
+        key[c + i] = lk[i];
+        if (minor) minor[c + i] = lm[i];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(256) void typed_plan_kernel(TypedArgs a, int64_t* rec_size, uint32_t n_records) {
   __shared__ uint32_t s_w[8];
-  const uint32_t r = blockIdx.x, tid = threadIdx.x, P = a.pow2;
-  unsigned long long* nk = (unsigned long long*)s_dyn;  // [P]
-  unsigned long long* ek = nk + P;                      // [P]
-  uint32_t* et = (uint32_t*)(ek + P);                   // [P]
+  const uint32_t tid = threadIdx.x, P = a.pow2;
+  // [P] each: in LDS, or (BIG) this workgroup's segments of the global staging area
+  unsigned long long* nk = BIG ? a.g_nk + (int64_t)blockIdx.x * P : (unsigned long long*)s_dyn;
+  unsigned long long* ek = BIG ? a.g_ek + (int64_t)blockIdx.x * P : nk + P;
+  uint32_t* et = BIG ? a.g_et + (int64_t)blockIdx.x * P : (uint32_t*)(ek + P);
+  for (uint32_t r = blockIdx.x; r < n_records; r += gridDim.x) {
   for (uint32_t i = tid; i < P; i += 256) {
     nk[i] = PAD64;
     ek[i] = PAD64;
@@ -1127,8 +1191,13 @@ __global__ __launch_bounds__(256) void typed_plan_kernel(TypedArgs a, int64_t* r
     base += wf;
   }
   __syncthreads();
-  lds_bitonic(nk, nullptr, P);
-  lds_bitonic(ek, et, P);
+  if (BIG) {
+    big_bitonic(nk, nullptr, P, (unsigned long long*)s_dyn, nullptr);
+    big_bitonic(ek, et, P, (unsigned long long*)s_dyn, (uint32_t*)((unsigned long long*)s_dyn + TYPED_MAX_ITEMS));
+  } else {
+    lds_bitonic(nk, nullptr, P);
+    lds_bitonic(ek, et, P);
+  }
   // distinct items -> scratch, field bytes summed
   unsigned long long* un = a.u_nodes + (int64_t)r * (a.items + 1);
   unsigned long long* ue = a.u_edges + (int64_t)r * a.items;
@@ -1175,6 +1244,8 @@ __global__ __launch_bounds__(256) void typed_plan_kernel(TypedArgs a, int64_t* r
     info[4] = pos_bytes;
     rec_size[r] = (int64_t)field_len(root_body) + field_len(graph_body) + pos_bytes + (a.frame ? 16 : 0);
   }
+  __syncthreads();  // (the staging buffers and s_w are reused by the workgroup's next root)
+  }
 }
 
 __device__ __forceinline__ uint8_t* typed_write_node_header(const TypedArgs& a, uint8_t* q, uint8_t tag,
@@ -1196,15 +1267,17 @@ __device__ __forceinline__ uint8_t* typed_write_node_header(const TypedArgs& a, 
   return q;  // the float payload starts here
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int64_t* rec_off, const int32_t* status,
-                                                          uint8_t* out) {
+                                                          uint8_t* out, uint32_t n_records) {
   __shared__ uint32_t s_w[8];
   __shared__ uint32_t s_x[4];
   __shared__ uint32_t crc_t[1024];
   if (*status != 0) return;
-  const uint32_t r = blockIdx.x, tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
-  uint32_t* pay = (uint32_t*)s_dyn;  // [items + 2]: offset of every node's float payload from the record start
+  // [items + 2]: offset of every node's float payload from the record start (LDS, or the workgroup's global segment)
+  uint32_t* pay = BIG ? a.g_pay + (int64_t)blockIdx.x * (a.items + 2) : (uint32_t*)s_dyn;
   {
     uint32_t c = tid;
     for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
@@ -1216,6 +1289,7 @@ __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int
     crc_t[j * 256 + tid] = (prev >> 8) ^ crc_t[prev & 0xFF];
     __syncthreads();
   }
+  for (uint32_t r = blockIdx.x; r < n_records; r += gridDim.x) {
   const uint32_t* info = a.u_info + (int64_t)r * 8;
   const uint32_t n_nodes = info[0], n_edges = info[1], node_bytes = info[2], graph_body = info[3], pos_bytes = info[4];
   const unsigned long long* un = a.u_nodes + (int64_t)r * (a.items + 1);
@@ -1307,7 +1381,7 @@ __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int
     uint8_t* dst = rec + pay[i];
     for (int e = lane; e < a.feat[t].d; e += 64) *(u32_unaligned*)(dst + 4 * e) = __float_as_uint(src[e]);  // (unaligned stores)
   }
-  if (!a.frame) return;
+  if (a.frame) {
   __threadfence_block();
   __syncthreads();
   {  // CRC-32C of the payload (as record_write_kernel: per-thread slices combined by x^(8*bytes after the slice))
@@ -1330,6 +1404,9 @@ __global__ __launch_bounds__(256) void typed_write_kernel(TypedArgs a, const int
       const uint32_t m = mask_crc((s_x[0] ^ s_x[1] ^ s_x[2] ^ s_x[3]) ^ 0xFFFFFFFFu);
       for (int b = 0; b < 4; ++b) payload_end[b] = (uint8_t)(m >> (8 * b));
     }
+  }
+  }
+  __syncthreads();  // (pay / s_w / s_x are reused by the workgroup's next root)
   }
 }
 
@@ -1672,9 +1749,9 @@ int32_t gigl_typed_samples_encode(gigl_ctx* ctx, int32_t kind, const uint32_t* r
     a.ops[o] = ops[o];
     items += (int64_t)ops[o].w * ops[o].f;
   }
-  if (items + 1 > (int64_t)TYPED_MAX_ITEMS)
+  if (items + 1 > (int64_t)TYPED_BIG_MAX_ITEMS)
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "%lld sampled slots per root: the typed record encoder holds up to %u",
-                     (long long)items, TYPED_MAX_ITEMS - 1);
+                     (long long)items, TYPED_BIG_MAX_ITEMS - 1);
   a.n_ops = n_ops;
   a.roots = roots;
   a.root_type = root_node_type;
@@ -1702,7 +1779,12 @@ int32_t gigl_typed_samples_encode(gigl_ctx* ctx, int32_t kind, const uint32_t* r
   if (rc != GIGL_OK) return rc;
   a.shift_tbl = ctx->crc_shift_tbl;
   const int64_t nb = n_records > 0 ? n_records : 1;
-  rc = gigl_arena_reset(ctx, (n_records + 1) * 8 + nb * ((items + 1) * 8 + items * 12 + 32) + 4096);
+  // up to TYPED_MAX_ITEMS - 1 slots per root the sort runs in LDS, a workgroup per root; beyond, in global staging
+  // segments owned by a bounded number of workgroups that walk the roots
+  const bool big = items + 1 > (int64_t)TYPED_MAX_ITEMS;
+  const int64_t wgs = big ? std::min<int64_t>(nb, std::max<int64_t>(64, (TYPED_BIG_STAGE_BYTES / 24) / a.pow2)) : 0;
+  rc = gigl_arena_reset(ctx, (n_records + 1) * 8 + nb * ((items + 1) * 8 + items * 12 + 32) + 4096 +
+                                 wgs * ((int64_t)a.pow2 * 20 + (items + 2) * 4) + 1024);
   if (rc != GIGL_OK) return rc;
   int64_t* rec_size = (int64_t*)gigl_arena_alloc(ctx, (n_records + 1) * 8);
   a.u_nodes = (unsigned long long*)gigl_arena_alloc(ctx, nb * (items + 1) * 8);
@@ -1710,17 +1792,36 @@ int32_t gigl_typed_samples_encode(gigl_ctx* ctx, int32_t kind, const uint32_t* r
   a.u_etype = (uint32_t*)gigl_arena_alloc(ctx, nb * (items > 0 ? items : 1) * 4);
   a.u_info = (uint32_t*)gigl_arena_alloc(ctx, nb * 32);
   if (!rec_size || !a.u_nodes || !a.u_edges || !a.u_etype || !a.u_info) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
-  const size_t lds_plan = (size_t)a.pow2 * 20, lds_write = ((size_t)items + 2) * 4;
-  if (lds_plan > 60 * 1024)
-    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)typed_plan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds_plan));
-  if (n_records > 0)
-    hipLaunchKernelGGL(typed_plan_kernel, dim3((unsigned)n_records), dim3(256), lds_plan, ctx->stream, a, rec_size);
+  if (big) {
+    a.g_nk = (unsigned long long*)gigl_arena_alloc(ctx, wgs * (int64_t)a.pow2 * 8);
+    a.g_ek = (unsigned long long*)gigl_arena_alloc(ctx, wgs * (int64_t)a.pow2 * 8);
+    a.g_et = (uint32_t*)gigl_arena_alloc(ctx, wgs * (int64_t)a.pow2 * 4);
+    a.g_pay = (uint32_t*)gigl_arena_alloc(ctx, wgs * (items + 2) * 4);
+    if (!a.g_nk || !a.g_ek || !a.g_et || !a.g_pay) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  }
+  const size_t lds_plan = big ? (size_t)TYPED_MAX_ITEMS * 12 : (size_t)a.pow2 * 20;
+  const size_t lds_write = big ? 0 : ((size_t)items + 2) * 4;
+  const uint32_t nrec = (uint32_t)n_records;
+  if (!big && lds_plan > 60 * 1024)
+    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)typed_plan_kernel<false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_plan));
+  if (n_records > 0) {
+    if (big)
+      hipLaunchKernelGGL(typed_plan_kernel<true>, dim3((unsigned)wgs), dim3(256), lds_plan, ctx->stream, a, rec_size, nrec);
+    else
+      hipLaunchKernelGGL(typed_plan_kernel<false>, dim3((unsigned)n_records), dim3(256), lds_plan, ctx->stream, a, rec_size,
+                         nrec);
+  }
   hipLaunchKernelGGL(record_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, rec_size, n_records, out_cap, rec_off,
                      status);
-  if (n_records > 0)
-    hipLaunchKernelGGL(typed_write_kernel, dim3((unsigned)n_records), dim3(256), lds_write, ctx->stream, a, rec_off,
-                       status, out);
+  if (n_records > 0) {
+    if (big)
+      hipLaunchKernelGGL(typed_write_kernel<true>, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a, rec_off, status, out,
+                         nrec);
+    else
+      hipLaunchKernelGGL(typed_write_kernel<false>, dim3((unsigned)n_records), dim3(256), lds_write, ctx->stream, a, rec_off,
+                         status, out, nrec);
+  }
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -402,7 +402,8 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
  *      Edge.feature_values of condensed edge type t — the type's edge list as a CSR-by-source graph
  *      (gigl_graph_build_from_coo with the roles swapped) and one fp32 row per edge in that graph's `col` order; the
  *      row of edge (s -> d) is found by binary search in row s (hydrateEdges' join).  Up to 16 ops, 16 node types, 16
- *      edge types, 4095 sampled slots (sum of w*f) per root (GIGL_E_UNSUPPORTED beyond).  out / rec_off / status as
+ *      edge types, 2^20 - 1 sampled slots (sum of w*f) per root (GIGL_E_UNSUPPORTED beyond; up to 4095 the per-root sort
+ *      runs in LDS, above it in global scratch, <= 1.5 GB of the context's arena).  out / rec_off / status as
  *      gigl_records_encode. */
 typedef struct gigl_typed_op {
   const uint32_t* frontier;

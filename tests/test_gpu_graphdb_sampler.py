@@ -271,12 +271,39 @@ def test_typed_records_encoded_on_the_device_match_the_host_assembly(world):
         assert np.array_equal(col["node_ids"][NODE_TYPES[root_type]][col["root_local"]].astype(np.int64), np.asarray(roots))
 
 
-def test_typed_record_encoder_limits(world):
-    s = world[0]
-    from gigl_amd import _lib
-    big = [SamplingOp("op0", A2P, 64, [], INCOMING), SamplingOp("op1", A2P, 64, ["op0"], OUTGOING)]  # 64 + 4096 slots
+def test_typed_records_beyond_the_lds_sort(world):
+    """more than 4,095 sampled slots per root: the encoder's sort is staged in global scratch (typed_plan_kernel<true>,
+    chunks of 4,096 through LDS) — records stay byte-identical to the host assembly: 4,160 slots per root on the skewed
+    fixture (mostly duplicates), 16,448 on a dense one (> 8,000 distinct edges per record); the limit is 2^20 - 1"""
+    from gigl_amd import _lib, wire
+    rng = np.random.default_rng(3)
+    nd = {"author": 5000, "paper": 5000, "venue": 4}
+    a = rng.integers(0, 5000, 320000).astype(np.uint32)
+    p_ = rng.integers(0, 5000, 320000).astype(np.uint32)
+    dense_edges = {A2P: (a, p_), P2A: (p_, a), P2V: (np.arange(8, dtype=np.uint32), np.arange(8, dtype=np.uint32) % 4)}
+    dense = HipGraphDBSampler(NODE_TYPES, nd, dense_edges, CET,
+                              {t: rng.standard_normal((nd[t], d)).astype(np.float32) for t, d in (("author", 3), ("paper", 5), ("venue", 2))})
+    cases = ((world[0], [SamplingOp("op0", A2P, 64, [], INCOMING), SamplingOp("op1", A2P, 64, ["op0"], OUTGOING)], "paper",
+              [1, 2, 77, 4999], 100),
+             (dense, [SamplingOp("op0", A2P, 64, [], OUTGOING), SamplingOp("op1", P2A, 64, ["op0"], OUTGOING),
+                      SamplingOp("op2", A2P, 3, ["op1"], OUTGOING)], "author", [0, 1, 2500, 4999], 8000))
+    try:
+        for s, ops, root_type, roots, floor in cases:
+            dag = SamplingOpDAG.from_ops(ops)
+            msgs = s.getKHopSubgraphForRootNodes(roots, root_type, dag)
+            framed = s.encode_records(roots, root_type, dag, tfrecord_frame=True)
+            bare = s.encode_records(roots, root_type, dag, tfrecord_frame=False)
+            assert max(len(m.neighborhood.edges) for m in msgs) > floor
+            for m, fr, br in zip(msgs, framed, bare):
+                want = m.SerializeToString()
+                assert br == want
+                assert fr == wire.tfrecord_frame(want)
+    finally:
+        dense.close()
+    huge = [SamplingOp("op0", A2P, 64, [], INCOMING), SamplingOp("op1", A2P, 64, ["op0"], OUTGOING),
+            SamplingOp("op2", P2A, 64, ["op1"], OUTGOING), SamplingOp("op3", A2P, 4, ["op2"], OUTGOING)]  # > 2^20 slots
     with pytest.raises(_lib.GiglError):
-        s.encode_records([1, 2], "paper", SamplingOpDAG.from_ops(big))
+        world[0].encode_records([1, 2], "paper", SamplingOpDAG.from_ops(huge))
 
 
 def test_one_call_typed_plan_equals_the_staged_batch_graph(world):
