@@ -56,6 +56,7 @@ SYMBOLS = [
     "gigl_dist_gat_plan_create", "gigl_dist_gat_plan_set_weights", "gigl_dist_plan_bucket_fill",
     "gigl_linear_weight_grad", "gigl_features_row_crc",
     "gigl_typed_plan_create", "gigl_typed_plan_run", "gigl_typed_plan_buffers", "gigl_typed_plan_destroy",
+    "gigl_typed_plan_merged_csr",
     "gigl_sage_plan_run_part",
 ]
 
@@ -124,6 +125,12 @@ class GiglTypedPlanOut(C.Structure):
                 ("edges", C.c_void_p * 32), ("edges_cap", C.c_int64 * 32),
                 ("op_frontier", C.c_void_p * GIGL_DAG_MAX_OPS), ("op_nbr", C.c_void_p * GIGL_DAG_MAX_OPS),
                 ("op_cnt", C.c_void_p * GIGL_DAG_MAX_OPS), ("op_width", C.c_int32 * GIGL_DAG_MAX_OPS)]
+
+
+class GiglTypedCsrOut(C.Structure):
+    _fields_ = [("rowptr", C.c_void_p), ("col", C.c_void_p), ("etype", C.c_void_p), ("counts", C.c_void_p),
+                ("root_rowptr", C.c_void_p), ("root_col", C.c_void_p), ("root_etype", C.c_void_p),
+                ("edges_cap", C.c_int64), ("rows_cap", C.c_int64)]
 
 
 class GiglTypedOp(C.Structure):
@@ -221,6 +228,7 @@ def load() -> C.CDLL:
         "gigl_typed_plan_run": [vp, vp, i32],
         "gigl_typed_plan_buffers": [vp, P(GiglTypedPlanOut)],
         "gigl_typed_plan_destroy": [vp],
+        "gigl_typed_plan_merged_csr": [vp, i32, P(i32), i32, P(i32), P(i32), i32, P(GiglTypedCsrOut)],
         "gigl_features_destroy": [vp],
         "gigl_sample_khop": [vp, vp, vp, i32, P(i32), i32, i32, i32, P(GiglTree)],
         "gigl_sample_positives": [vp, vp, vp, i32, i32, i32, i32, vp, vp],

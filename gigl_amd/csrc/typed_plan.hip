@@ -49,6 +49,14 @@ struct gigl_typed_plan {
   void* work = nullptr;
   size_t work_bytes = 0;
   int64_t max_items = 0;
+  // merged CSR by destination over all edge slots (gigl_typed_plan_merged_csr; allocated on its first call)
+  int64_t m_edges_cap = 0, m_rows_cap = 0;
+  unsigned long long *m_keys = nullptr, *m_sorted = nullptr;
+  int32_t *m_rowptr = nullptr, *m_col = nullptr, *m_etype = nullptr, *m_counts = nullptr;
+  int32_t *m_root_len = nullptr, *m_root_rowptr = nullptr, *m_root_col = nullptr, *m_root_etype = nullptr;
+  struct MergedOffsets* m_off = nullptr;
+  void* m_work = nullptr;
+  size_t m_work_bytes = 0;
   std::vector<void*> owned;
 };
 
@@ -165,6 +173,121 @@ __global__ __launch_bounds__(TB) void root_index_kernel(const uint32_t* roots, i
                                                         const int32_t* n, int32_t* out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < b) out[i] = (int32_t)lower_bound(nodes, *n, roots[i]);
+}
+
+// ---- merged CSR by destination (the operand of the typed attention layers) ------------------------------------------
+// What gigl_amd/models_hetero.py::HGTConv built per batch with a chain of torch ops (three concatenations, a stable sort
+// by destination, bincount + cumsum, three gathers; for the roots' rows another cumsum / repeat_interleave chain with a
+// host read of its size): destinations numbered type after type in the caller's type order, sources slot after slot
+// in the caller's slot order (source index = offset of the slot + src_local, as the layer concatenates its per-edge-type
+// K / V blocks), edges of one destination in slot order then (src, dst) order = torch.sort(dst, stable=True).
+struct MergedArgs {
+  int32_t n_types, n_slots, root_type;
+  int32_t type_order[16];
+  int32_t slot_order[32], slot_src_type[32], slot_dst_type[32], slot_etype[32];
+  int64_t cap_off[33];  // capacity prefix of the listed slots (positions of merged_keys_kernel's grid)
+  const unsigned long long* edges[32];
+};
+}  // namespace
+struct MergedOffsets {
+  int32_t dst_off[16];   // by node type id (-1: the type is not listed)
+  int32_t src_off[32];   // by position in slot_order
+  int32_t edge_off[33];  // by position in slot_order; [n_slots] = E
+  int32_t n_dst, n_edges;
+};
+namespace {
+
+__global__ void merged_offsets_kernel(MergedArgs a, const int32_t* n_nodes, const int32_t* n_edges, MergedOffsets* off,
+                                      int32_t* counts) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int32_t run = 0;
+  for (int t = 0; t < 16; ++t) off->dst_off[t] = -1;
+  for (int j = 0; j < a.n_types; ++j) {
+    off->dst_off[a.type_order[j]] = run;
+    run += n_nodes[a.type_order[j]];
+  }
+  off->n_dst = run;
+  int32_t srun = 0, erun = 0;
+  for (int j = 0; j < a.n_slots; ++j) {
+    off->src_off[j] = srun;
+    off->edge_off[j] = erun;
+    srun += n_nodes[a.slot_src_type[j]];
+    erun += n_edges[a.slot_order[j]];
+  }
+  off->edge_off[a.n_slots] = erun;
+  off->n_edges = erun;
+  counts[0] = run;
+  counts[1] = erun;
+}
+
+__global__ __launch_bounds__(TB) void merged_keys_kernel(MergedArgs a, const int32_t* n_edges, const MergedOffsets* off,
+                                                         int64_t m, unsigned long long* keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  int j = 0;
+  while (j + 1 < a.n_slots && i >= a.cap_off[j + 1]) ++j;
+  const int64_t q = i - a.cap_off[j];
+  unsigned long long k = ~0ull;
+  if (q < n_edges[a.slot_order[j]]) {
+    const unsigned long long e = a.edges[j][q];
+    const unsigned long long dst = (unsigned long long)(uint32_t)off->dst_off[a.slot_dst_type[j]] + (e & 0xFFFFFFFFull);
+    k = (dst << 32) | (uint32_t)(off->edge_off[j] + (int32_t)q);
+  }
+  keys[i] = k;
+}
+
+__global__ __launch_bounds__(TB) void merged_fill_kernel(MergedArgs a, const MergedOffsets* off,
+                                                         const unsigned long long* sorted, int64_t m, int32_t* col,
+                                                         int32_t* etype) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m || i >= off->n_edges) return;
+  const int32_t pos = (int32_t)(uint32_t)sorted[i];
+  int j = 0;
+  while (j + 1 < a.n_slots && pos >= off->edge_off[j + 1]) ++j;
+  const unsigned long long e = a.edges[j][pos - off->edge_off[j]];
+  col[i] = off->src_off[j] + (int32_t)(e >> 32);
+  etype[i] = a.slot_etype[j];
+}
+
+__global__ __launch_bounds__(TB) void merged_rowptr_kernel(const MergedOffsets* off, const unsigned long long* sorted,
+                                                           int64_t rows_cap, int32_t* rowptr) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > rows_cap || r > off->n_dst) return;
+  const unsigned long long want = (unsigned long long)r << 32;
+  int32_t lo = 0, hi = off->n_edges;
+  while (lo < hi) {
+    const int32_t mid = (lo + hi) >> 1;
+    if (sorted[mid] < want) lo = mid + 1;
+    else hi = mid;
+  }
+  rowptr[r] = lo;
+}
+
+// the roots' rows alone, in root order: lengths -> exclusive sum -> one wave per root copies its slice
+__global__ __launch_bounds__(TB) void root_len_kernel(const MergedOffsets* off, int32_t root_type, const int32_t* root_index,
+                                                      int32_t b, const int32_t* rowptr, int32_t* len) {
+  const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > b) return;
+  int32_t v = 0;
+  if (i < b) {
+    const int32_t row = off->dst_off[root_type] + root_index[i];
+    v = rowptr[row + 1] - rowptr[row];
+  }
+  len[i] = v;
+}
+
+__global__ __launch_bounds__(TB) void root_rows_kernel(const MergedOffsets* off, int32_t root_type, const int32_t* root_index,
+                                                       int32_t b, const int32_t* rowptr, const int32_t* col,
+                                                       const int32_t* etype, const int32_t* root_rowptr, int32_t* root_col,
+                                                       int32_t* root_etype) {
+  const int32_t i = (int32_t)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (i >= b) return;
+  const int32_t row = off->dst_off[root_type] + root_index[i];
+  const int32_t lo = rowptr[row], n = rowptr[row + 1] - lo, out = root_rowptr[i];
+  for (int32_t e = lane; e < n; e += 64) {
+    root_col[out + e] = col[lo + e];
+    root_etype[out + e] = etype[lo + e];
+  }
 }
 
 template <typename T>
@@ -428,6 +551,114 @@ int32_t gigl_typed_plan_run(gigl_typed_plan* p, const uint32_t* roots, int32_t b
   hipLaunchKernelGGL(root_index_kernel, grid_of(b), dim3(TB), 0, st, roots, (int64_t)b,
                      (const uint32_t*)p->nodes[p->root_type], (const int32_t*)(p->n_nodes + p->root_type), p->root_index);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_typed_plan_merged_csr(gigl_typed_plan* p, int32_t b, const int32_t* type_order, int32_t n_types_used,
+                                   const int32_t* slot_order, const int32_t* slot_etype, int32_t n_slots_used,
+                                   gigl_typed_csr_out* out) {
+  if (!p || !out) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  *out = gigl_typed_csr_out{};
+  GIGL_REQUIRE(ctx, type_order && slot_order && n_types_used >= 1 && n_types_used <= p->n_types && n_slots_used >= 1 &&
+                        n_slots_used <= p->n_slots && b >= 1 && b <= p->b_max,
+               "typed plan merged CSR: bad arguments");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  MergedArgs a{};
+  a.n_types = n_types_used;
+  a.n_slots = n_slots_used;
+  a.root_type = p->root_type;
+  bool root_listed = false;
+  uint32_t seen_t = 0, seen_s = 0;
+  int64_t rows_cap = 0;
+  for (int j = 0; j < n_types_used; ++j) {
+    const int32_t t = type_order[j];
+    GIGL_REQUIRE(ctx, t >= 0 && t < p->n_types && !(seen_t >> t & 1), "typed plan merged CSR: node type %d", t);
+    seen_t |= 1u << t;
+    a.type_order[j] = t;
+    rows_cap += (int64_t)p->b_max * p->cand_per_root[t];
+    root_listed |= t == p->root_type;
+  }
+  GIGL_REQUIRE(ctx, root_listed, "typed plan merged CSR: the roots' node type is not listed");
+  for (int j = 0; j < n_slots_used; ++j) {
+    const int32_t sl = slot_order[j];
+    GIGL_REQUIRE(ctx, sl >= 0 && sl < p->n_slots && !(seen_s >> sl & 1) && p->slot_src_type[sl] >= 0,
+                 "typed plan merged CSR: edge slot %d", sl);
+    seen_s |= 1u << sl;
+    GIGL_REQUIRE(ctx, (seen_t >> p->slot_src_type[sl] & 1) && (seen_t >> p->slot_dst_type[sl] & 1),
+                 "typed plan merged CSR: slot %d joins a node type that is not listed", sl);
+    a.slot_order[j] = sl;
+    a.slot_src_type[j] = p->slot_src_type[sl];
+    a.slot_dst_type[j] = p->slot_dst_type[sl];
+    a.slot_etype[j] = slot_etype ? slot_etype[j] : j;
+    a.cap_off[j + 1] = a.cap_off[j] + (int64_t)p->b_max * p->pairs_per_root[sl];
+    a.edges[j] = p->edges[sl];
+  }
+  const int64_t m = a.cap_off[n_slots_used];
+  GIGL_REQUIRE(ctx, m < ((int64_t)1 << 31) && rows_cap < ((int64_t)1 << 31) - 1, "typed plan merged CSR: batch too large");
+  if (m > p->m_edges_cap || rows_cap > p->m_rows_cap) {  // (first call, or a wider listing than before)
+    hipStreamSynchronize(ctx->stream);
+    int32_t rc = GIGL_OK;
+    const int64_t me = m > 0 ? m : 1;
+#define CSR_ALLOC(ptr, count)            \
+  do {                                   \
+    rc = dev_alloc(p, &(ptr), (count));  \
+    if (rc != GIGL_OK) return rc;        \
+  } while (0)
+    CSR_ALLOC(p->m_keys, me);
+    CSR_ALLOC(p->m_sorted, me);
+    CSR_ALLOC(p->m_col, me);
+    CSR_ALLOC(p->m_etype, me);
+    CSR_ALLOC(p->m_root_col, me);
+    CSR_ALLOC(p->m_root_etype, me);
+    CSR_ALLOC(p->m_rowptr, rows_cap + 2);
+    CSR_ALLOC(p->m_root_len, (int64_t)p->b_max + 1);
+    CSR_ALLOC(p->m_root_rowptr, (int64_t)p->b_max + 1);
+    CSR_ALLOC(p->m_counts, 2);
+    if (!p->m_off) CSR_ALLOC(p->m_off, 1);
+    size_t t1 = 0, t2 = 0;
+    hipcub::DeviceRadixSort::SortKeys((void*)nullptr, t1, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                      (int)me, 0, 64, ctx->stream);
+    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, t2, (const int32_t*)nullptr, (int32_t*)nullptr, p->b_max + 1, ctx->stream);
+    p->m_work_bytes = t1 > t2 ? t1 : t2;
+    char* wk = nullptr;
+    CSR_ALLOC(wk, (int64_t)p->m_work_bytes + 256);
+    p->m_work = wk;
+#undef CSR_ALLOC
+    p->m_edges_cap = m;
+    p->m_rows_cap = rows_cap;
+  }
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(merged_offsets_kernel, dim3(1), dim3(1), 0, st, a, (const int32_t*)p->n_nodes, (const int32_t*)p->n_edges,
+                     p->m_off, p->m_counts);
+  if (m > 0) {
+    hipLaunchKernelGGL(merged_keys_kernel, grid_of(m), dim3(TB), 0, st, a, (const int32_t*)p->n_edges,
+                       (const MergedOffsets*)p->m_off, m, p->m_keys);
+    size_t wb = p->m_work_bytes;
+    GIGL_HIP_CHECK(ctx, hipcub::DeviceRadixSort::SortKeys(p->m_work, wb, (const unsigned long long*)p->m_keys, p->m_sorted,
+                                                          (int)m, 0, 64, st));
+    hipLaunchKernelGGL(merged_fill_kernel, grid_of(m), dim3(TB), 0, st, a, (const MergedOffsets*)p->m_off,
+                       (const unsigned long long*)p->m_sorted, m, p->m_col, p->m_etype);
+  }
+  hipLaunchKernelGGL(merged_rowptr_kernel, grid_of(p->m_rows_cap + 1), dim3(TB), 0, st, (const MergedOffsets*)p->m_off,
+                     (const unsigned long long*)p->m_sorted, p->m_rows_cap, p->m_rowptr);
+  hipLaunchKernelGGL(root_len_kernel, grid_of((int64_t)b + 1), dim3(TB), 0, st, (const MergedOffsets*)p->m_off, p->root_type,
+                     (const int32_t*)p->root_index, b, (const int32_t*)p->m_rowptr, p->m_root_len);
+  size_t wb = p->m_work_bytes;
+  GIGL_HIP_CHECK(ctx, hipcub::DeviceScan::ExclusiveSum(p->m_work, wb, (const int32_t*)p->m_root_len, p->m_root_rowptr, b + 1, st));
+  hipLaunchKernelGGL(root_rows_kernel, grid_of((int64_t)b * 64), dim3(TB), 0, st, (const MergedOffsets*)p->m_off, p->root_type,
+                     (const int32_t*)p->root_index, b, (const int32_t*)p->m_rowptr, (const int32_t*)p->m_col,
+                     (const int32_t*)p->m_etype, (const int32_t*)p->m_root_rowptr, p->m_root_col, p->m_root_etype);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  out->rowptr = p->m_rowptr;
+  out->col = p->m_col;
+  out->etype = p->m_etype;
+  out->counts = p->m_counts;
+  out->root_rowptr = p->m_root_rowptr;
+  out->root_col = p->m_root_col;
+  out->root_etype = p->m_root_etype;
+  out->edges_cap = m;
+  out->rows_cap = p->m_rows_cap;
   return GIGL_OK;
 }
 

@@ -351,12 +351,23 @@ class HipGraphDBSampler:
         self._plans[key] = entry
         return entry
 
-    def batch_graph_plan(self, root_ids: Sequence[int], root_node_type: str, dag: SamplingOpDAG, b_max: int = 0):
+    def batch_graph_plan(self, root_ids: Sequence[int], root_node_type: str, dag: SamplingOpDAG, b_max: int = 0,
+                         edge_type_ids: Optional[Dict[tuple, int]] = None):
         """batch_graph through the one-call plan: identical results (same numbering: a type's distinct ids ascending,
-        an edge type's distinct edges ascending by (src, dst))"""
+        an edge type's distinct edges ascending by (src, dst)).
+        edge_type_ids {(src type, relation, dst type): id} (a typed attention model's edge-type numbering, e.g.
+        HGTConv.edge_types_map): the plan also merges the batch's edges into ONE CSR by destination
+        (gigl_typed_plan_merged_csr) — graph.merged_csr, which HGT.forward takes instead of building it with torch ops"""
+        return self.batch_graph_plan_finish(self.batch_graph_plan_issue(root_ids, root_node_type, dag, b_max, edge_type_ids))
+
+    def batch_graph_plan_issue(self, root_ids: Sequence[int], root_node_type: str, dag: SamplingOpDAG, b_max: int = 0,
+                               edge_type_ids: Optional[Dict[tuple, int]] = None) -> dict:
+        """first half of batch_graph_plan: the batch's device work is enqueued (plan, merged CSR, the counts on their way
+        to pinned host memory) and nothing is waited for.  A loop that issues batch i+1 BEFORE it launches the model over
+        batch i never idles on the counts: `finish(i) -> issue(i+1) -> model(i)` (Inferencer's typed in-HBM route).
+        One batch per plan may be in flight: finish a ticket before the next issue on the same (type, dag, b_max)."""
         import ctypes as C
         from . import _lib
-        from .models_hetero import HeteroGraphData
         eng = self.engine
         dev = eng.device
         b = len(root_ids)
@@ -364,13 +375,44 @@ class HipGraphDBSampler:
         out = pl["out"]
         roots64 = torch.from_numpy(np.asarray(root_ids, dtype=np.int64))
         roots = roots64.to(torch.int32).pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else roots64.to(torch.int32)
+        nt, ns = len(pl["types"]), len(pl["slots"])
+        ticket = {"pl": pl, "b": b, "root_type": root_node_type, "roots": roots, "edge_type_ids": edge_type_ids}
         with torch.cuda.stream(eng._stream):
             _lib.check(eng._lib.gigl_typed_plan_run(pl["plan"], C.c_void_p(roots.data_ptr()), b), eng._ctx)
-            nt, ns = len(pl["types"]), len(pl["slots"])
             counts = torch.empty(nt + ns, dtype=torch.int32, device=dev)
             counts[:nt] = _wrap(out.n_nodes, nt, torch.int32, dev)
             counts[nt:] = _wrap(out.n_edges, ns, torch.int32, dev)
-            h = counts.cpu()  # the one host read of the batch
+            ring = pl.setdefault("host_counts", [torch.empty(nt + ns, dtype=torch.int32).pin_memory() for _ in range(2)])
+            pl["host_turn"] = (pl.get("host_turn", 0) + 1) % len(ring)
+            host = ring[pl["host_turn"]]
+            host.copy_(counts, non_blocking=True)  # the one host read of the batch
+            ev = torch.cuda.Event()
+            ev.record(eng._stream)
+            ticket["counts"], ticket["event"] = host, ev
+            if edge_type_ids is not None:
+                used = [i for i, t in enumerate(pl["types"]) if int(out.nodes_cap[i]) > 0]
+                slot_ets = [(et.src_node_type, et.relation, et.dst_node_type) for et in pl["slots"]]
+                t_arr = (C.c_int32 * len(used))(*used)
+                s_arr = (C.c_int32 * len(slot_ets))(*[pl["slots"][et] for et in pl["slots"]])
+                e_arr = (C.c_int32 * len(slot_ets))(*[int(edge_type_ids[k]) for k in slot_ets])
+                csr = _lib.GiglTypedCsrOut()
+                _lib.check(eng._lib.gigl_typed_plan_merged_csr(pl["plan"], b, t_arr, len(used), s_arr, e_arr, len(slot_ets),
+                                                               C.byref(csr)), eng._ctx)
+                ticket["csr"], ticket["used"], ticket["slot_ets"] = csr, used, slot_ets
+        return ticket
+
+    def batch_graph_plan_finish(self, ticket: dict):
+        """second half: waits for the batch's counts and hands out its tensors (copies: the plan's buffers are
+        overwritten by its next batch) -> (graph, root_index, distinct ids per type)"""
+        from .models_hetero import HeteroGraphData
+        eng = self.engine
+        dev = eng.device
+        pl, b, root_node_type = ticket["pl"], ticket["b"], ticket["root_type"]
+        out = pl["out"]
+        nt = len(pl["types"])
+        ticket["event"].synchronize()
+        h = ticket["counts"].tolist()
+        with torch.cuda.stream(eng._stream):
             uniq, x_dict, ei = {}, {}, {}
             for i, t in enumerate(pl["types"]):
                 n_t = int(h[i])
@@ -385,7 +427,19 @@ class HipGraphDBSampler:
                 keys = _wrap(out.edges[sl], n_e, torch.int64, dev)
                 ei[(et.src_node_type, et.relation, et.dst_node_type)] = torch.stack([keys >> 32, keys & 0xFFFFFFFF])
             root_index = _wrap(out.root_index, b, torch.int32, dev).to(torch.int64)
-        return HeteroGraphData(x_dict, ei), root_index, uniq
+            graph = HeteroGraphData(x_dict, ei)
+            if ticket.get("csr") is not None:
+                csr, used, slot_ets, edge_type_ids = ticket["csr"], ticket["used"], ticket["slot_ets"], ticket["edge_type_ids"]
+                n_dst = sum(int(h[i]) for i in used)
+                n_e = sum(int(h[nt + pl["slots"][et]]) for et in pl["slots"])
+                take = lambda ptr, n: _wrap(ptr, n, torch.int32, dev).clone()
+                graph.merged_csr = {
+                    "node_types": [pl["types"][i] for i in used], "edge_types": slot_ets,
+                    "edge_type_ids": {k: int(edge_type_ids[k]) for k in slot_ets},
+                    "csr": (take(csr.rowptr, n_dst + 1), take(csr.col, n_e), take(csr.etype, n_e)),
+                    "root_type": root_node_type, "root_index": root_index,
+                    "root_csr": (take(csr.root_rowptr, b + 1), take(csr.root_col, n_e), take(csr.root_etype, n_e))}
+        return graph, root_index, uniq
 
     def _feature_table(self, node_type: str) -> Optional[torch.Tensor]:
         if not hasattr(self, "_dev_feats"):

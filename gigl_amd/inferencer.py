@@ -291,9 +291,16 @@ def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str,
             try:
                 prefix = cfg.random_negative_tfrecord_uri_prefixes.get(node_type)
                 order = planned_root_order(np.asarray(ids[node_type]), prefix) if prefix else np.asarray(ids[node_type])
-                for i in range(0, order.size, b):
-                    chunk = np.asarray(order[i:i + b], dtype=np.int64)
-                    graph, root_index, _ = s.batch_graph_plan(chunk, node_type, dags[node_type], b_max=b)
+                # (HGT: the plan also lays out the layers' merged CSR by destination and the roots' rows of it)
+                et_ids = enc.convs[0].edge_types_map if is_hgt and len(enc.convs) else None
+                chunks = [np.asarray(order[i:i + b], dtype=np.int64) for i in range(0, order.size, b)]
+                issue = lambda c: s.batch_graph_plan_issue(c, node_type, dags[node_type], b_max=b, edge_type_ids=et_ids)
+                ticket = issue(chunks[0]) if chunks else None
+                for ci, chunk in enumerate(chunks):
+                    # batch ci+1's sampling is enqueued before the model over batch ci is launched: the host never
+                    # waits for a batch's counts with an idle device
+                    graph, root_index, _ = s.batch_graph_plan_finish(ticket)
+                    ticket = issue(chunks[ci + 1]) if ci + 1 < len(chunks) else None
                     with torch.no_grad():
                         if is_hgt:  # the last layer computes the roots' rows only
                             emb = inferencer.model(graph, [node_type], row_subset={node_type: root_index})[node_type]

@@ -182,6 +182,8 @@ class HGTConv(nn.Module):
         self.v_rel = _HeteroLinear(dim, dim, heads * len(edge_types), bias=False)
         self.skip = nn.ParameterDict({t: nn.Parameter(torch.ones(1)) for t in node_types})
         self.p_rel = nn.ParameterDict({"__".join(e): nn.Parameter(torch.ones(1, heads)) for e in edge_types})
+        # inference (no autograd): projections over composed weights (_forward_composed); False = the staged order
+        self.composed_inference = True
 
     def _block_diag(self, rel: _HeteroLinear, ti: int) -> torch.Tensor:
         """[H*D, H*D] weight (gigl_linear layout: out x in) applying head h's D x D relation matrix to head h's slice"""
@@ -199,6 +201,131 @@ class HGTConv(nn.Module):
             cache[key] = hit
         return hit[1]
 
+    def _composed(self, dev):
+        """inference weights with the linear stages multiplied together once per parameter state (k_rel(K(x)) and
+        v_rel(V(x)) are linear in x, and so is the skip's scale of out_lin): per node type (W_q, b_q) and
+        (a W_out, a b_out, 1 - a); per edge type (BD_k W_k, BD_k b_k, BD_v W_v, BD_v b_v) of its SOURCE type — composed
+        in fp64, stored fp32.  Every per-batch projection then reads the layer's input rows once and writes straight
+        into the aggregate's operands (no split / relation / concatenation passes)."""
+        params = [p for p in self.parameters()]
+        ver = tuple((p._version, p.data_ptr()) for p in params) + (str(dev),)
+        hit = self.__dict__.get("_composed_cache")
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        Fo, H, T = self.out_channels, self.heads, len(self.edge_types)
+        out = {"q": {}, "out": {}, "k": {}, "v": {}}
+        with torch.no_grad():
+            for t in self.node_types:
+                lin = self.kqv_lin.lins[t]
+                out["q"][t] = (lin.weight[Fo:2 * Fo].contiguous(), lin.bias[Fo:2 * Fo].contiguous())
+                ol = self.out_lin.lins[t]
+                if ol.weight.shape[0] == self.in_channels[t]:  # the gated skip applies (out width == in width)
+                    a = self.skip[t].sigmoid().double()
+                    out["out"][t] = ((a * ol.weight.double()).float().contiguous(), (a * ol.bias.double()).float().contiguous(),
+                                     (1 - a).float().contiguous())
+                else:
+                    out["out"][t] = (ol.weight.contiguous(), ol.bias.contiguous(), None)
+            for et, ti in self.edge_types_map.items():
+                lin = self.kqv_lin.lins[et[0]]
+                w, b = lin.weight.double(), lin.bias.double()
+                for name, rel, lo in (("k", self.k_rel, 0), ("v", self.v_rel, 2 * Fo)):
+                    bd = torch.block_diag(*[rel.weight[h * T + ti].t() for h in range(H)]).double()
+                    out[name][et] = ((bd @ w[lo:lo + Fo]).float().contiguous(), (bd @ b[lo:lo + Fo]).float().contiguous())
+        self.__dict__["_composed_cache"] = (ver, out)
+        return out
+
+    def _forward_composed(self, x_dict, edge_index_dict, csr_cache, dst_subset):
+        """the inference forward over composed weights (same result as forward() up to fp32 rounding)"""
+        any_x = next(iter(x_dict.values()))
+        eng = _engine_for(self, any_x)
+        dev = any_x.device
+        H, Fo = self.heads, self.out_channels
+        D = Fo // H
+        cw = self._composed(dev)
+        x_dict = {t: x.contiguous().to(torch.float32) for t, x in x_dict.items()}
+        dst_off, n_dst = {}, 0
+        for t, x in x_dict.items():
+            dst_off[t] = n_dst
+            n_dst += int(x.shape[0])
+
+        def lin_into(x, w, b, dst):
+            if x.shape[0]:
+                eng.linear(x, w, b, dev_i32(dev, x.shape[0]), int(x.shape[0]), 0, out=dst)
+
+        ets_present = [(tuple(et), ei) for et, ei in edge_index_dict.items()]
+        n_src_total = sum(int(x_dict[et[0]].shape[0]) for et, _ in ets_present)
+        cached = csr_cache.get("csr") if csr_cache is not None else None
+        ks = torch.empty((n_src_total, Fo), dtype=torch.float32, device=dev)
+        vs = torch.empty((n_src_total, Fo), dtype=torch.float32, device=dev)
+        srcs, dsts, ets, n_src = [], [], [], 0
+        for et, ei in ets_present:
+            x = x_dict[et[0]]
+            n_t = int(x.shape[0])
+            lin_into(x, *cw["k"][et], ks[n_src:n_src + n_t])
+            lin_into(x, *cw["v"][et], vs[n_src:n_src + n_t])
+            if cached is None:
+                srcs.append(ei[0] + n_src)
+                dsts.append(ei[1] + dst_off[et[2]])
+                ets.append(torch.full((ei.shape[1],), self.edge_types_map[et], dtype=torch.int32, device=dev))
+            n_src += n_t
+        have_edges = bool(ets_present) and n_dst > 0
+        if have_edges:
+            if cached is None:
+                rowptr, col, _, ety = _csr_by_dst(torch.cat(srcs), torch.cat(dsts), n_dst, torch.cat(ets))
+                if csr_cache is not None:
+                    csr_cache["csr"] = (rowptr, col, ety)
+            else:
+                rowptr, col, ety = cached
+            p_rel = torch.cat([self.p_rel["__".join(e)].reshape(1, H) for e in self.edge_types]).contiguous()
+        if dst_subset is not None:
+            ids_dev = {t: ids.to(dev) for t, ids in dst_subset.items()}
+            xs = {t: x_dict[t][ids_dev[t]] for t in dst_subset}
+            n_rows = sum(int(v.numel()) for v in ids_dev.values())
+            if have_edges:
+                rows = torch.cat([ids_dev[t] + dst_off[t] for t in dst_subset])
+                qs = torch.empty((n_rows, Fo), dtype=torch.float32, device=dev)  # q of the listed rows only
+                o0 = 0
+                for t in dst_subset:
+                    lin_into(xs[t], *cw["q"][t], qs[o0:o0 + xs[t].shape[0]])
+                    o0 += int(xs[t].shape[0])
+                planned = csr_cache.get("root") if csr_cache is not None else None
+                if planned is not None and list(dst_subset) == [planned[0]] and dst_subset[planned[0]] is planned[1]:
+                    sub_csr = planned[2]  # the roots' rows, as the typed plan laid them out
+                else:
+                    rp = rowptr.to(torch.int64)  # the listed rows' slices of the merged CSR, in the subset's order
+                    lens = rp[rows + 1] - rp[rows]
+                    sub_ptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=dev)
+                    sub_ptr[1:] = torch.cumsum(lens, 0)
+                    idx = torch.repeat_interleave(rp[rows] - sub_ptr[:-1], lens) + torch.arange(int(sub_ptr[-1]), device=dev)
+                    sub_csr = (sub_ptr.to(torch.int32), col[idx].contiguous(), ety[idx].contiguous())
+                agg = torch.zeros((n_rows, Fo), dtype=torch.float32, device=dev)
+                eng.hgt_aggregate(qs, ks, vs, H, D, sub_csr[0], sub_csr[1], sub_csr[2], p_rel, n_rows, agg)
+            else:
+                agg = torch.zeros((n_rows, Fo), dtype=torch.float32, device=dev)
+            res, o0 = {}, 0
+            for t in dst_subset:
+                w, b, keep = cw["out"][t]
+                n_t = int(xs[t].shape[0])
+                o = torch.empty((n_t, w.shape[0]), dtype=torch.float32, device=dev)
+                lin_into(F.gelu(agg[o0:o0 + n_t]), w, b, o)
+                res[t] = torch.addcmul(o, keep, xs[t]) if keep is not None else o
+                o0 += n_t
+            return res
+        agg = torch.zeros((n_dst, Fo), dtype=torch.float32, device=dev)
+        if have_edges:
+            qq = torch.empty((n_dst, Fo), dtype=torch.float32, device=dev)
+            for t, x in x_dict.items():
+                lin_into(x, *cw["q"][t], qq[dst_off[t]:dst_off[t] + x.shape[0]])
+            eng.hgt_aggregate(qq, ks, vs, H, D, rowptr, col, ety, p_rel, n_dst, agg)
+        act = F.gelu(agg)
+        res = {}
+        for t, x in x_dict.items():
+            w, b, keep = cw["out"][t]
+            o = torch.empty((int(x.shape[0]), w.shape[0]), dtype=torch.float32, device=dev)
+            lin_into(act[dst_off[t]:dst_off[t] + x.shape[0]], w, b, o)
+            res[t] = torch.addcmul(o, keep, x) if keep is not None else o
+        return res
+
     def forward(self, x_dict: Dict[str, torch.Tensor], edge_index_dict: Dict[EdgeType, torch.Tensor],
                 csr_cache: Optional[dict] = None, dst_subset: Optional[Dict[str, torch.Tensor]] = None):
         """csr_cache: a dict the caller keeps for ONE batch graph — the edges of all types merged into one CSR by
@@ -206,6 +333,8 @@ class HGTConv(nn.Module):
         dst_subset {node type: int64 local ids}: compute ONLY these destination rows (the last layer of an inference
         pass needs the roots' rows, not every node's): the result holds, per listed type, the rows in the subset's
         order — each identical to the row of the full result (same edges in the same order, row-wise projections)."""
+        if not torch.is_grad_enabled() and self.composed_inference:
+            return self._forward_composed(x_dict, edge_index_dict, csr_cache, dst_subset)
         any_x = next(iter(x_dict.values()))
         eng = _engine_for(self, any_x)
         dev = any_x.device
@@ -315,9 +444,24 @@ class HGT(nn.Module):
         if self.feature_embedding_layers:
             x_dict = {t: (self.feature_embedding_layers[t](x) if t in self.feature_embedding_layers else x)
                       for t, x in x_dict.items()}
-        h = {t: torch.relu(_linear(eng, x, self.lin_dict[t].weight, self.lin_dict[t].bias))
-             for t, x in x_dict.items()}
+        if torch.is_grad_enabled():
+            h = {t: torch.relu(_linear(eng, x, self.lin_dict[t].weight, self.lin_dict[t].bias))
+                 for t, x in x_dict.items()}
+        else:  # (inference: the ReLU in the projection's epilogue)
+            h = {}
+            for t, x in x_dict.items():
+                x = x.contiguous().to(torch.float32)
+                lin = self.lin_dict[t]
+                h[t] = (eng.linear(x, lin.weight.contiguous(), lin.bias, dev_i32(x.device, x.shape[0]), int(x.shape[0]), 1)
+                        if x.shape[0] else x.new_zeros((0, lin.weight.shape[0])))
         csr_cache: dict = {}  # (the merged CSR by destination is the graph's: built by the first layer, reused by the rest)
+        mc = getattr(data, "merged_csr", None)
+        if mc is not None and self.convs and mc["node_types"] == list(x_dict) and \
+                mc["edge_types"] == [tuple(e) for e in data.edge_index_dict] and \
+                all(self.convs[0].edge_types_map.get(k) == v for k, v in mc["edge_type_ids"].items()):
+            # the typed plan already merged the batch's edges by destination (gigl_typed_plan_merged_csr)
+            csr_cache["csr"] = mc["csr"]
+            csr_cache["root"] = (mc["root_type"], mc["root_index"], mc["root_csr"])
         subset = None
         if row_subset is not None and not torch.is_grad_enabled():
             subset = {t: row_subset[t] for t in output_node_types if t in row_subset and t in h}

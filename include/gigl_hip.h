@@ -492,6 +492,28 @@ int32_t gigl_typed_plan_create(gigl_ctx* ctx, const gigl_dag_op* ops, int32_t n_
                                int32_t root_node_type, int32_t n_edge_slots, int32_t b_max, gigl_typed_plan** out);
 int32_t gigl_typed_plan_run(gigl_typed_plan* plan, const uint32_t* roots, int32_t b);
 int32_t gigl_typed_plan_buffers(gigl_typed_plan* plan, gigl_typed_plan_out* out);
+/* The batch graph's edges of ALL listed slots as ONE CSR by destination — the operand of the typed attention layers
+ * (torch_geometric HGTConv's per-destination softmax over every incoming edge type; python/gigl/src/common/models/pyg/
+ * heterogeneous.py:18-120 builds it inside HGTConv._construct_src_node_feat / propagate).  After gigl_typed_plan_run,
+ * same stream, no host read: destinations are numbered type after type in `type_order` (type t's node i = offset of t +
+ * i), sources slot after slot in `slot_order` (source index = sum of the earlier slots' SOURCE-type node counts +
+ * src_local: the layer's per-edge-type K / V blocks laid side by side), a destination's edges in slot order, then
+ * ascending (src, dst) — the order of a stable sort by destination.  etype[e] = slot_etype[position of e's slot]
+ * (NULL: the position).  root_* = the rows of the batch's roots alone, in root order (an inference pass's last layer).
+ * type_order / slot_order / slot_etype: HOST.  The buffers belong to the plan and are valid until its next run. */
+typedef struct gigl_typed_csr_out {
+  const int32_t* rowptr;      /* [n_dst + 1] */
+  const int32_t* col;         /* [E] */
+  const int32_t* etype;       /* [E] */
+  const int32_t* counts;      /* [2]: n_dst, E (= the sums of the counts the caller already reads) */
+  const int32_t* root_rowptr; /* [b + 1] */
+  const int32_t* root_col;
+  const int32_t* root_etype;
+  int64_t edges_cap, rows_cap;
+} gigl_typed_csr_out;
+int32_t gigl_typed_plan_merged_csr(gigl_typed_plan* plan, int32_t b, const int32_t* type_order, int32_t n_types_used,
+                                   const int32_t* slot_order, const int32_t* slot_etype, int32_t n_slots_used,
+                                   gigl_typed_csr_out* out);
 int32_t gigl_typed_plan_destroy(gigl_typed_plan* plan);
 
 /* ---- inference output: (node id, embedding row) batches -> Avro object-container DATA BLOCKS, encoded on the device.

@@ -106,7 +106,7 @@ model.engine = eng
 
 
 def infer_step():
-    g, ri, _ = s.batch_graph_plan(roots, "paper", dag_paper, b_max=B)
+    g, ri, _ = s.batch_graph_plan(roots, "paper", dag_paper, b_max=B, edge_type_ids=model.convs[0].edge_types_map)
     with torch.no_grad():
         out = model(g, ["paper"], row_subset={"paper": ri})["paper"]  # the last layer computes the roots' rows only
     return int(out.shape[0])

@@ -16,7 +16,7 @@ model = HGT({"author": 64, "paper": 128}, {e: 0 for e in ets}, hid_dim=64, out_d
 model.engine = s.engine
 roots = rng.integers(0, npp, B)
 def step():
-    g, ri, _ = s.batch_graph_plan(roots, "paper", dag, b_max=B)
+    g, ri, _ = s.batch_graph_plan(roots, "paper", dag, b_max=B, edge_type_ids=model.convs[0].edge_types_map)
     with torch.no_grad():
         return model(g, ["paper"], row_subset={"paper": ri})["paper"]
 for _ in range(3): step()

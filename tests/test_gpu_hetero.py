@@ -43,6 +43,24 @@ def test_hgt_matches_the_restatement():
                 p.uniform_(0.5, 1.5)
     data = make_data()
     got = model.to(dev)(data.to(dev), ["user", "item", "tag"])
+    # inference (no autograd) runs over COMPOSED weights (HGTConv._forward_composed: k_rel(K(x)), v_rel(V(x)) and the
+    # gate's scale of out_lin multiplied out once per parameter state); composed_inference = False is the staged order
+    with torch.no_grad():
+        got_c = model(data.to(dev), ["user", "item", "tag"])
+        for conv in model.convs:
+            conv.composed_inference = False
+        got_s = model(data.to(dev), ["user", "item", "tag"])
+        for conv in model.convs:
+            conv.composed_inference = True
+        # a parameter update invalidates the composed weights
+        model.convs[0].k_rel.weight.mul_(1.5)
+        moved = model(data.to(dev), ["user", "item", "tag"])
+        model.convs[0].k_rel.weight.div_(1.5)
+        back = model(data.to(dev), ["user", "item", "tag"])
+    for t in NT:
+        assert torch.equal(got_s[t], got[t].detach())
+        assert not torch.allclose(moved[t], got_c[t], atol=1e-4) or t == "tag"
+        np.testing.assert_allclose(back[t].cpu().numpy(), got_c[t].cpu().numpy(), rtol=1e-5, atol=1e-5)
     # the same forward from the parameters, on the CPU
     model = model.cpu()
     h = {t: torch.relu(F.linear(x, model.lin_dict[t].weight, model.lin_dict[t].bias)) for t, x in data.x_dict.items()}
@@ -56,6 +74,7 @@ def test_hgt_matches_the_restatement():
     for t in NT:
         want = F.linear(h[t], model.lin.weight, model.lin.bias).detach().numpy()
         np.testing.assert_allclose(got[t].detach().cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(got_c[t].cpu().numpy(), want, rtol=1e-5, atol=1e-5)
     # a node type nobody points at still comes back (the in-repo modification of PyG's HGTConv)
     assert got["tag"].shape == (50, out_dim)
 
@@ -331,4 +350,41 @@ def test_hgt_last_layer_on_a_row_subset_equals_the_full_forward():
             sub = model(data, ["paper"], row_subset={"paper": root_index})["paper"]
         s.engine.synchronize()
         assert sub.shape == full.shape and torch.equal(sub, full), layers
+        # the plan's own merged CSR by destination (gigl_typed_plan_merged_csr) and its rows of the roots: the arrays
+        # the layers would have built with torch ops, and the same embeddings bit for bit
+        # (the model's edge-type numbering is the REVERSE of the plan's slot order here)
+        model_r = HGT({"author": 6, "paper": 10}, {e: 0 for e in ets[::-1]}, hid_dim=32, out_dim=16, num_layers=layers,
+                      num_heads=2).to(s.engine.device).eval()
+        model_r.engine = s.engine
+        for mdl in (model, model_r):
+            ids = mdl.convs[0].edge_types_map
+            data_p, ri_p, _ = s.batch_graph_plan(roots, "paper", dag, edge_type_ids=ids)
+            mc = data_p.merged_csr
+            assert torch.equal(ri_p, root_index)
+            srcs, dsts, etys, n_src, dst_off, n_dst = [], [], [], 0, {}, 0
+            for t, x in data_p.x_dict.items():
+                dst_off[t] = n_dst
+                n_dst += x.shape[0]
+            for et, ei in data_p.edge_index_dict.items():
+                srcs.append(ei[0] + n_src)
+                dsts.append(ei[1] + dst_off[et[2]])
+                etys.append(torch.full((ei.shape[1],), ids[tuple(et)], dtype=torch.int32, device=ei.device))
+                n_src += data_p.x_dict[et[0]].shape[0]
+            src, dst, ety = torch.cat(srcs), torch.cat(dsts), torch.cat(etys)
+            order = torch.sort(dst, stable=True).indices
+            rowptr = torch.zeros(n_dst + 1, dtype=torch.int64, device=dst.device)
+            rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_dst), 0)
+            assert torch.equal(mc["csr"][0].long(), rowptr)
+            assert torch.equal(mc["csr"][1].long(), src[order]) and torch.equal(mc["csr"][2], ety[order])
+            rows = root_index + dst_off["paper"]
+            lens = rowptr[rows + 1] - rowptr[rows]
+            assert torch.equal(mc["root_csr"][0][1:].long(), torch.cumsum(lens, 0)) and int(mc["root_csr"][0][0]) == 0
+            want_col = torch.cat([src[order][rowptr[r]:rowptr[r + 1]] for r in rows.tolist()])
+            assert torch.equal(mc["root_csr"][1][: want_col.numel()].long(), want_col)
+            with torch.no_grad():
+                plain = mdl(data, ["paper"], row_subset={"paper": root_index})["paper"]
+                planned = mdl(data_p, ["paper"], row_subset={"paper": ri_p})["paper"]
+                planned_full = mdl(data_p, ["paper"])["paper"][ri_p]
+            s.engine.synchronize()
+            assert torch.equal(planned, plain) and torch.equal(planned_full, plain)
     s.close()
