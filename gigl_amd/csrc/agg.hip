@@ -21,6 +21,8 @@
 //              and W, so no LDS staging or transposes are needed.
 #include "common.h"
 
+#include <cstring>
+
 #include <cstdlib>
 #include <type_traits>
 
@@ -785,6 +787,37 @@ __device__ __forceinline__ void split_store2(const float4_t v, short* p1, short*
   *reinterpret_cast<uint2*>(p2) = make_uint2((a2[0] >> 16) | a2[1], (a2[2] >> 16) | a2[3]);
 }
 
+// HS (half split): x = h1 + h2 with h1 = fp16(x), h2 = fp16(x - h1) — 11 + 11 significand bits, the subtraction exact,
+// subnormal halves honoured by v_mfma_f32_32x32x16_f16 on gfx950 (scripts/micro/mfma_f16_denorm.hip), so the small
+// parts keep an absolute precision of 2^-25.  a.w = h1.h1 + h1.h2 + h2.h1 (the dropped h2.h2 is <= 2^-22 relative): THREE
+// MFMAs per accumulator instead of six, two planes per operand in LDS instead of three.  Only for operands known to lie
+// inside the fp16 range (|x| < 65504: callers check the table's / the weights' largest magnitude, split_fits_half) — the
+// bf16 planes have fp32's range and stay the general path.  With AHALF the A operand IS its h1 plane: two MFMAs.
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void hsplit_store(const float4_t v, short* p1, short* p2) {
+  _Float16 h1[4], h2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    h1[t] = (_Float16)v[t];
+    h2[t] = (_Float16)(v[t] - (float)h1[t]);
+  }
+  uint16_t b1[4], b2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    b1[t] = __builtin_bit_cast(uint16_t, h1[t]);
+    b2[t] = __builtin_bit_cast(uint16_t, h2[t]);
+  }
+  *reinterpret_cast<uint2*>(p1) = make_uint2((uint32_t)b1[0] | ((uint32_t)b1[1] << 16), (uint32_t)b1[2] | ((uint32_t)b1[3] << 16));
+  *reinterpret_cast<uint2*>(p2) = make_uint2((uint32_t)b2[0] | ((uint32_t)b2[1] << 16), (uint32_t)b2[2] | ((uint32_t)b2[3] << 16));
+}
+// (values that ARE halves, widened: one plane)
+__device__ __forceinline__ void hstore1(const float4_t v, short* p1) {
+  uint16_t b1[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) b1[t] = __builtin_bit_cast(uint16_t, (_Float16)v[t]);
+  *reinterpret_cast<uint2*>(p1) = make_uint2((uint32_t)b1[0] | ((uint32_t)b1[1] << 16), (uint32_t)b1[2] | ((uint32_t)b1[3] << 16));
+}
+
 // SELF (the SAGE layer's [mean | self] operand without the self copy): the A operand has TWO sources — columns k <
 // d_mean come from the tiled buffer the gather wrote (a_tiled = its chunks per row tile, ceil(d_mean / 32)), columns
 // k >= d_mean are element k - d_mean of row self_ids[row] (or `row`) of `self_src` (fp32 rows self_ld apart: the
@@ -795,7 +828,7 @@ __device__ __forceinline__ void split_store2(const float4_t v, short* p1, short*
 // numbers, so the A operand keeps two planes and the product with its (zero) third plane is dropped — five MFMAs per
 // accumulator instead of six, and the rows are read as stored (2 bytes per element, no widened copy).  The remaining
 // products run in the order of the fp32 path: the same accumulators up to the sign of a zero.
-template <int NJ, bool KVEC = true, bool SELF = false, bool AHALF = false>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
+template <int NJ, bool KVEC = true, bool SELF = false, bool AHALF = false, bool HS = false>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
 __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            const int32_t* __restrict__ m_dev, int K, int N, int act,
@@ -812,8 +845,11 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
   y += blockIdx.y * N;
   constexpr int BK = 32, LDK = 32;          // bf16 elements per LDS row (swizzled slots, no padding: split_lds_off)
   constexpr int BM = 128, BN = 64 * NJ;
-  __shared__ short s_a[3][BM * LDK];
-  __shared__ short s_w[3][BN * LDK];
+  constexpr int NPA = HS ? (AHALF ? 1 : 2) : 3, NPW = HS ? 2 : 3;  // planes per operand
+  constexpr int A_EL = NPA * BM * LDK, W_EL = NPW * BN * LDK, STRIP_EL = 4 * 32 * 36 * 2;  // (shorts; the epilogue strips)
+  __shared__ __attribute__((aligned(16))) short s_buf[A_EL + W_EL > STRIP_EL ? A_EL + W_EL : STRIP_EL];
+  short(*s_a)[BM * LDK] = reinterpret_cast<short(*)[BM * LDK]>(s_buf);
+  short(*s_w)[BN * LDK] = reinterpret_cast<short(*)[BN * LDK]>(s_buf + A_EL);
   const int M = *m_dev;
   const int tiles_n = (N + BN - 1) / BN;
   // Workgroups are dealt to the 8 XCDs round-robin by id and every XCD has its own L2: the column tiles of one row
@@ -905,13 +941,16 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int o = split_lds_off(lr + 32 * i, lc * 4);
-      if constexpr (AHALF) split_store2(ra[i], &s_a[0][o], &s_a[1][o]);
+      if constexpr (HS && AHALF) hstore1(ra[i], &s_a[0][o]);
+      else if constexpr (HS) hsplit_store(ra[i], &s_a[0][o], &s_a[1][o]);
+      else if constexpr (AHALF) split_store2(ra[i], &s_a[0][o], &s_a[1][o]);
       else split_store(ra[i], &s_a[0][o], &s_a[1][o], &s_a[2][o]);
     }
 #pragma unroll
     for (int i = 0; i < 2 * NJ; ++i) {
       const int o = split_lds_off(lr + 32 * i, lc * 4);
-      split_store(rw[i], &s_w[0][o], &s_w[1][o], &s_w[2][o]);
+      if constexpr (HS) hsplit_store(rw[i], &s_w[0][o], &s_w[1][o]);
+      else split_store(rw[i], &s_w[0][o], &s_w[1][o], &s_w[2][o]);
     }
     __syncthreads();
     if (k0 + 2 * BK < K) gload(k0 + 2 * BK, ra, rw);  // lands during this chunk's and the next chunk's MFMAs
@@ -922,13 +961,27 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int p = 0; p < (AHALF ? 2 : 3); ++p)
+        for (int p = 0; p < (HS ? NPA : (AHALF ? 2 : 3)); ++p)
           fa[i][p] = *reinterpret_cast<const bf16x8_t*>(&s_a[p][split_lds_off(wm * 64 + i * 32 + r, ks + 8 * g)]);
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPW; ++p)
           fw[j][p] = *reinterpret_cast<const bf16x8_t*>(&s_w[p][split_lds_off(wn * 32 * NJ + j * 32 + r, ks + 8 * g)]);
+      if constexpr (HS) {  // three products (two with a one-plane A), smallest terms first, accumulators interleaved
+        constexpr int HA[3] = {1, 0, 0}, HW[3] = {0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          if (AHALF && HA[t] == 1) continue;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, fa[i][HA[t]]),
+                                                                 __builtin_bit_cast(half8_t, fw[j][HW[t]]), acc[i][j], 0, 0, 0);
+        }
+        continue;
+      }
       // six products per accumulator, smallest terms first; the 2*NJ accumulators are interleaved so that two MFMAs
       // on the same accumulator are never back to back (a dependent MFMA waits for the previous one's 16 passes)
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};
@@ -950,7 +1003,7 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
     if (k0 + BK < K) chunk(k0 + BK, ga[1], gw[1]);
   }
   __syncthreads();  // every wave is done with the operand planes: s_a becomes the waves' epilogue strips
-  float* strip = reinterpret_cast<float*>(&s_a[0][0]) + wv * (32 * 36);
+  float* strip = reinterpret_cast<float*>(s_buf) + wv * (32 * 36);
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -2495,6 +2548,18 @@ int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* 
     return gigl_fail(ctx, GIGL_E_HIP, "row-count upload failed");
   }
   int32_t rc = GIGL_OK;
+  // fp16 rows ARE the h1 plane of the half split; the weights join as two fp16 planes when they fit the half range:
+  // two products per accumulator instead of five
+  bool hs = false;
+  if (half_direct && gigl_half_split_enabled()) {
+    float wmax = 0.f;
+    rc = gigl_dev_absmax_f32(ctx, wcat, (int64_t)2 * n_out * d, &wmax);
+    if (rc != GIGL_OK) {
+      cleanup();
+      return rc;
+    }
+    hs = wmax < GIGL_HALF_SPLIT_MAX;
+  }
   for (int64_t r0 = 0; r0 < n && rc == GIGL_OK; r0 += cm) {
     const int64_t m = (n - r0) < cm ? (n - r0) : cm;
     const float* a;
@@ -2503,7 +2568,15 @@ int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* 
       const int nn = 2 * n_out;
       const int64_t bm = (m + 127) / 128;
       const float* ah = reinterpret_cast<const float*>((const __half*)feat->rows + r0 * d);
-      if (nn > 64)
+      if (hs && nn > 64)
+        hipLaunchKernelGGL((linear_split_kernel<2, true, false, true, true>), dim3((unsigned)(bm * ((nn + 127) / 128))), dim3(256),
+                           0, st, ah, (const float*)wcat, (const float*)nullptr, (const int32_t*)(cnt + (m == cm ? 0 : 1)), d,
+                           nn, 0, out + r0 * 2 * n_out, 0, 0, (int64_t)0, (int64_t)0);
+      else if (hs)
+        hipLaunchKernelGGL((linear_split_kernel<1, true, false, true, true>), dim3((unsigned)(bm * ((nn + 63) / 64))), dim3(256),
+                           0, st, ah, (const float*)wcat, (const float*)nullptr, (const int32_t*)(cnt + (m == cm ? 0 : 1)), d,
+                           nn, 0, out + r0 * 2 * n_out, 0, 0, (int64_t)0, (int64_t)0);
+      else if (nn > 64)
         hipLaunchKernelGGL((linear_split_kernel<2, true, false, true>), dim3((unsigned)(bm * ((nn + 127) / 128))), dim3(256),
                            0, st, ah, (const float*)wcat, (const float*)nullptr, (const int32_t*)(cnt + (m == cm ? 0 : 1)), d,
                            nn, 0, out + r0 * 2 * n_out, 0, 0, (int64_t)0, (int64_t)0);
@@ -2874,11 +2947,68 @@ int32_t gigl_linear_weight_grad(gigl_ctx* ctx, const float* dy, const float* a, 
   return GIGL_OK;
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ p, int64_t n, uint32_t* __restrict__ out) {
+  float m = 0.f;
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = fabsf((float)p[i]);
+    bad |= !(v == v);
+    m = fmaxf(m, v);
+  }
+  if (bad) m = __uint_as_float(0x7F800000u);  // a NaN anywhere: "unbounded"
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // (non-negative floats order like their bits)
+}
+
+template <typename T>
+static int32_t dev_absmax(gigl_ctx* ctx, const T* p, int64_t n, float* out) {
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  uint32_t* d = nullptr;
+  GIGL_HIP_CHECK(ctx, hipMalloc((void**)&d, 4));
+  hipMemsetAsync(d, 0, 4, ctx->stream);
+  const int64_t wgs = std::min<int64_t>((n + 255) / 256 > 0 ? (n + 255) / 256 : 1, 8192);
+  hipLaunchKernelGGL(absmax_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, p, n, d);
+  uint32_t h = 0;
+  const hipError_t e1 = hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, ctx->stream);
+  const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  hipFree(d);
+  GIGL_HIP_CHECK(ctx, e1);
+  GIGL_HIP_CHECK(ctx, e2);
+  memcpy(out, &h, 4);
+  return GIGL_OK;
+}
+
+bool gigl_half_split_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("GIGL_GEMM_SPLIT");
+    return !(e && strcmp(e, "bf16") == 0) && !getenv("GIGL_LINEAR_EXACT");
+  }();
+  return on;
+}
+
+int32_t gigl_dev_absmax_f32(gigl_ctx* ctx, const float* p, int64_t n, float* out) { return dev_absmax<float>(ctx, p, n, out); }
+
+int32_t gigl_feat_absmax(gigl_ctx* ctx, gigl_feat* feat, float* out) {
+  std::lock_guard<std::mutex> lk(feat->row_crc_mu);
+  if (feat->absmax < 0.f) {
+    float m = 0.f;
+    const int64_t n = feat->n * feat->d;
+    const int32_t rc = feat->dtype == GIGL_DTYPE_F16 ? dev_absmax<__half>(ctx, (const __half*)feat->rows, n, &m)
+                                                     : dev_absmax<float>(ctx, (const float*)feat->rows, n, &m);
+    if (rc != GIGL_OK) return rc;
+    feat->absmax = m;
+  }
+  *out = feat->absmax;
+  return GIGL_OK;
+}
+
 static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias,
                                     const int32_t* m_dev, int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y,
                                     int32_t ldy, int32_t batch = 1, int64_t a_bstride = 0, int64_t w_bstride = 0,
                                     const float* self_src = nullptr, const uint32_t* self_ids = nullptr,
-                                    int32_t d_mean = 0, int32_t self_ld = 0) {
+                                    int32_t d_mean = 0, int32_t self_ld = 0, bool hs = false) {
   GIGL_REQUIRE(ctx, a_tiled && w && m_dev && y && (k & 3) == 0 && n > 0 && ldy >= n * batch && batch >= 1,
                "bad arguments");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -2890,6 +3020,18 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
   if (self_src) {  // two-source operand: the tiled buffer holds the mean chunks only
     GIGL_REQUIRE(ctx, batch == 1 && d_mean > 0 && (d_mean & 3) == 0 && d_mean < k && self_ld >= k - d_mean, "bad two-source operand");
     const int nkc_mean = (d_mean + 31) / 32;
+    if (hs) {
+      if (n > 64)
+        hipLaunchKernelGGL((linear_split_kernel<2, true, true, false, true>), dim3((unsigned)(bm * ((n + 127) / 128)), 1u),
+                           dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0,
+                           self_src, self_ids, d_mean, self_ld);
+      else
+        hipLaunchKernelGGL((linear_split_kernel<1, true, true, false, true>), dim3((unsigned)(bm * ((n + 63) / 64)), 1u),
+                           dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0,
+                           self_src, self_ids, d_mean, self_ld);
+      GIGL_HIP_CHECK(ctx, hipGetLastError());
+      return GIGL_OK;
+    }
     if (n > 64)
       hipLaunchKernelGGL((linear_split_kernel<2, true, true>), dim3((unsigned)(bm * ((n + 127) / 128)), 1u), dim3(256), 0, st,
                          a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0, self_src, self_ids,
@@ -2898,6 +3040,16 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
       hipLaunchKernelGGL((linear_split_kernel<1, true, true>), dim3((unsigned)(bm * ((n + 63) / 64)), 1u), dim3(256), 0, st,
                          a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0, self_src, self_ids,
                          d_mean, self_ld);
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    return GIGL_OK;
+  }
+  if (hs) {
+    if (n > 64)
+      hipLaunchKernelGGL((linear_split_kernel<2, true, false, false, true>), dim3((unsigned)(bm * ((n + 127) / 128)), (unsigned)batch),
+                         dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
+    else
+      hipLaunchKernelGGL((linear_split_kernel<1, true, false, false, true>), dim3((unsigned)(bm * ((n + 63) / 64)), (unsigned)batch),
+                         dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     return GIGL_OK;
   }
@@ -2940,10 +3092,10 @@ int32_t gigl_linear_batched(gigl_ctx* ctx, const float* a, const float* w, const
 
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
                           int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y, const float* self_src,
-                          const uint32_t* self_ids, int32_t d_mean, int32_t self_ld) {
+                          const uint32_t* self_ids, int32_t d_mean, int32_t self_ld, bool half_split) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   return linear_tiled_strided(ctx, a_tiled, w, bias, m_dev, m_cap, k, n, act, y, n, 1, 0, 0, self_src, self_ids, d_mean,
-                              self_ld);
+                              self_ld, half_split);
 }
 
 int64_t gigl_gat_input_layer_scratch(int32_t d, int32_t heads, int64_t cap_nodes, int64_t rows_cap, int64_t cap_edges) {

@@ -70,6 +70,9 @@ struct gigl_feat {
   // [n] raw CRC-32C state of every row's packed feature_values bytes (serialize.hip, built on first use)
   uint32_t* row_crc = nullptr;
   std::mutex row_crc_mu;
+  // largest |value| of the table (gigl_feat_absmax, found on first use; < 0: not looked at yet): decides whether the
+  // half-split projection applies to operands made of its rows
+  float absmax = -1.f;
 };
 
 int32_t gigl_fail(gigl_ctx* ctx, int32_t code, const char* fmt, ...);
@@ -127,7 +130,14 @@ int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float
 // [32 floats], tiled_nkc = ceil(2d / 32); capacity: whole row tiles) and read by gigl_linear_tiled (agg.hip)
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
                           int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y, const float* self_src = nullptr,
-                          const uint32_t* self_ids = nullptr, int32_t d_mean = 0, int32_t self_ld = 0);
+                          const uint32_t* self_ids = nullptr, int32_t d_mean = 0, int32_t self_ld = 0,
+                          bool half_split = false);
+// half_split: operands as two fp16 planes, three MFMAs per accumulator (linear_split_kernel<.., HS>) — the caller
+// guarantees every |operand value| < GIGL_HALF_SPLIT_MAX (gigl_feat_absmax / gigl_dev_absmax_f32)
+constexpr float GIGL_HALF_SPLIT_MAX = 60000.f;
+bool gigl_half_split_enabled();  // (GIGL_GEMM_SPLIT=bf16 keeps every projection on the bf16 planes)
+int32_t gigl_dev_absmax_f32(gigl_ctx* ctx, const float* p, int64_t n, float* out);  // synchronises the ctx's stream
+int32_t gigl_feat_absmax(gigl_ctx* ctx, gigl_feat* feat, float* out);
 // self_src != NULL: two-source operand — columns k >= d_mean are element k - d_mean of row self_ids[row] (or row) of
 // self_src (fp32 rows, self_ld floats apart); a_tiled then holds ceil(d_mean / 32) chunks per row tile
 

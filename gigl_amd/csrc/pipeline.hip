@@ -41,6 +41,9 @@ struct gigl_sage_plan {
   // projected input (gigl_sage_plan_set_projected_input): [W_l x | W_r x] of EVERY node, [graph nodes][2*dims[1]]
   // fp32, device, borrowed — the first layer is then one gather (+ self row + bias + activation), no projection
   const float* proj = nullptr;
+  // first layer over two fp16 planes per operand (three MFMAs instead of six): the table's and the first layer's
+  // weights' largest magnitudes are known to fit the half range (plan_refresh_half_split: at create / set_weights)
+  bool hs0 = false;
   // kind 1: GAT layers instead of SAGE layers (gigl_gat_plan_create): w[l] = lin weight [heads*channels][dims[l]],
   // layer 0 from the input side in one row pass (gigl_gat_input_layer_fused), layers >= 1 projection + attention
   int32_t kind = 0;
@@ -273,10 +276,10 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
   if (two_src)
     return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
                              p->hbuf[l & 1], l == 0 ? (const float*)p->feat->rows : p->hbuf[(l - 1) & 1],
-                             l == 0 ? p->un.nodes : nullptr, d, d);
+                             l == 0 ? p->un.nodes : nullptr, d, d, l == 0 && p->hs0);
   if (p->tiled)
     return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
-                             p->hbuf[l & 1]);
+                             p->hbuf[l & 1], nullptr, nullptr, 0, 0, l == 0 && p->hs0);
   return gigl_linear(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
                      p->hbuf[l & 1]);
 }
@@ -353,6 +356,7 @@ int32_t gigl_sage_plan_destroy(gigl_sage_plan* p) {
 static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b, const int32_t* fanouts,
                            int32_t hops, const int32_t* dims, const float* const* w, const float* const* bias,
                            int32_t act_last, bool with_abuf, gigl_sage_plan** out);
+static int32_t plan_refresh_half_split(gigl_sage_plan* p);
 
 int32_t gigl_sage_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b,
                               const int32_t* fanouts, int32_t hops, const int32_t* dims,
@@ -463,6 +467,13 @@ static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, in
     return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the batch workspace failed (cap_nodes=%lld)",
                      (long long)cap_nodes);
   }
+  {
+    const int32_t rc_hs = plan_refresh_half_split(p);
+    if (rc_hs != GIGL_OK) {
+      gigl_sage_plan_destroy(p);
+      return rc_hs;
+    }
+  }
   *out = p;
   return GIGL_OK;
 }
@@ -534,6 +545,30 @@ int32_t gigl_gat_plan_set_weights(gigl_sage_plan* p, const float* const* w, cons
   return GIGL_OK;
 }
 
+// the first layer's operands are rows of the feature table reduced by mean / max (|.| <= the table's largest magnitude)
+// or sum (<= fan-out times it), and the layer's weights: when both fit the half range the layer's projection runs over
+// two fp16 planes per operand.  Looked at when the weights are SET: weights rewritten in place afterwards keep the
+// decision (beyond the range the half planes overflow to inf — the rows come out non-finite, not silently wrong).
+static int32_t plan_refresh_half_split(gigl_sage_plan* p) {
+  const bool before = p->hs0;
+  p->hs0 = false;
+  if (p->kind == 0 && p->tiled && p->abuf && p->feat && p->w[0] && gigl_half_split_enabled()) {  // (SAGE plans own abuf)
+    float fmax = 0.f, wmax = 0.f;
+    int32_t rc = gigl_feat_absmax(p->ctx, p->feat, &fmax);
+    if (rc != GIGL_OK) return rc;
+    rc = gigl_dev_absmax_f32(p->ctx, p->w[0], (int64_t)p->dims[1] * 2 * p->dims[0], &wmax);
+    if (rc != GIGL_OK) return rc;
+    int32_t fmax_out = 1;
+    for (int k = 0; k < p->hops; ++k) fmax_out = p->fanouts[k] > fmax_out ? p->fanouts[k] : fmax_out;
+    p->hs0 = fmax * (float)fmax_out < GIGL_HALF_SPLIT_MAX && wmax < GIGL_HALF_SPLIT_MAX;
+  }
+  if (p->captured && before != p->hs0) {
+    hipStreamSynchronize(p->ctx->stream);
+    drop_graphs(p);
+  }
+  return GIGL_OK;
+}
+
 int32_t gigl_sage_plan_set_weights(gigl_sage_plan* p, const float* const* w, const float* const* bias) {
   if (!p || !w) return GIGL_E_INVALID_ARG;
   for (int k = 0; k < p->hops; ++k) {
@@ -545,8 +580,10 @@ int32_t gigl_sage_plan_set_weights(gigl_sage_plan* p, const float* const* w, con
     hipStreamSynchronize(p->ctx->stream);
     drop_graphs(p);
   }
-  return GIGL_OK;
+  return plan_refresh_half_split(p);
 }
+
+int32_t gigl_sage_plan_half_split(gigl_sage_plan* p) { return p && p->hs0 ? 1 : 0; }
 
 int32_t gigl_sage_plan_set_aggr(gigl_sage_plan* p, int32_t aggr) {
   if (!p) return GIGL_E_INVALID_ARG;

@@ -1168,6 +1168,10 @@ class SagePlan:
         check(self._lib.gigl_sage_plan_set_projected_input(self._plan, C.c_void_p(proj.data_ptr())), self.eng._ctx)
         self._proj = proj  # borrowed by the plan
 
+    def half_split(self) -> bool:
+        """the first projection runs over two fp16 planes per operand (gigl_sage_plan_half_split)"""
+        return bool(self._lib.gigl_sage_plan_half_split(self._plan))
+
     def use_graph(self, on: bool = True) -> None:
         """replay the batch as one hipGraph launch (captured on the next run)"""
         check(self._lib.gigl_sage_plan_use_graph(self._plan, 1 if on else 0), self.eng._ctx)

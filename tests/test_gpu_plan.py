@@ -194,3 +194,49 @@ def test_plan_in_two_parts_equals_the_one_call(setup):
         eng.synchronize()
         assert torch.equal(want, got)
     plan.close()
+
+
+def test_first_layer_half_split_is_bounded_by_the_operands(setup):
+    """gigl_sage_plan_half_split: the first projection runs over two fp16 planes per operand (three MFMAs instead of six)
+    only when the table's and the weights' largest magnitudes fit the fp16 range.  On the unit-scale fixture it is on and
+    within 1e-5 of the fp64 forward of the same batch; on a table scaled past the range (and with weights scaled past it)
+    the plan stays on the bf16 planes and keeps the same relative accuracy"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE
+    from oracle import gnn_ref
+    eng, rowptr, col, x, n = setup
+    torch.manual_seed(3)
+    b, fan = 256, [15, 10]
+    roots = np.random.default_rng(4).integers(0, n, size=b).astype(np.uint32)
+    nbr_o, _ = oracle.sample_khop(rowptr, col, roots, fan, canonical=True)
+    o = oracle.union_build(roots, fan, nbr_o)
+    ei = gnn_ref.union_edge_index(o["rowptr"], o["col"])
+
+    def check(engine, feats, model, expect_half, rtol):
+        plan = model.make_plan(engine, b, fan)
+        assert plan.half_split() == expect_half
+        out = plan.run(torch.from_numpy(roots.view(np.int32)).to(engine.device)).double().cpu().numpy()
+        sd = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
+        want = gnn_ref.graphsage_forward(torch.from_numpy(feats[o["nodes"]]).double(), ei, sd, 2)[o["root_local"]].numpy()
+        scale = np.abs(want).max()
+        assert np.abs(out - want).max() <= rtol * scale, (np.abs(out - want).max(), scale)
+        plan.close()
+        return np.abs(out - want).max() / scale
+
+    model = GraphSAGE(100, 256, 64, num_layers=2).to(eng.device)
+    err_half = check(eng, x, model, True, 1e-5)
+    # weights past the range: the decision is taken again when they are set
+    big_w = GraphSAGE(100, 256, 64, num_layers=2).to(eng.device)
+    with torch.no_grad():
+        big_w.conv_layers[0].lin_l.weight.mul_(1e6)
+    check(eng, x, big_w, False, 1e-5)
+    # a table past the range
+    eng2 = HipEngine(0)
+    try:
+        eng2.load_csc(rowptr, col)
+        x_big = (x * 1e6).astype(np.float32)
+        eng2.load_features(x_big)
+        check(eng2, x_big, model, False, 1e-5)
+    finally:
+        eng2.close()
+    assert err_half < 3e-6  # (what the two-plane split leaves: ~2^-22 per product)
