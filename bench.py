@@ -45,6 +45,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+def emit(line: dict) -> None:
+    """the run's ONE JSON line, as the last line of stdout: what native libraries left in C stdio's buffer (RCCL's
+    version banner, printed at communicator creation and otherwise flushed at exit, after this line) goes out first"""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # same guide: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 # The projection runs split-precision: every fp32 product is SIX bf16 MFMA products (agg.hip: linear_split_kernel), so
@@ -765,7 +777,7 @@ def main():
         if rank == 0 and sub_err:
             line["sharded"] = {"error": sub_err}
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1139,7 +1151,7 @@ def run_sharded(args, rank, world, local_rank, sub=False):
                           else "host callback over " + dist.get_backend() + " (functional check, not xGMI)"),
             "ranks": world}
         if not sub:
-            print(json.dumps(line))
+            emit(line)
     else:
         line = None
     dist.barrier()
@@ -1325,7 +1337,7 @@ def run_train(args, rank, world, local_rank):
                        "backward_scattered_edges_per_step": bwd, "setup_s": round(setup_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(line))
+        emit(line)
     eng.close()
     if world > 1:
         import torch.distributed as dist
@@ -1516,7 +1528,7 @@ def run_entry_inferencer(args, rank, world, local_rank):
                        "setup_s": round(setup_s, 1)},
             "roofline": None, "cpu_baseline": None,
         }
-        print(json.dumps(line))
+        emit(line)
     resident.close()
     eng.close()
     if world > 1:
@@ -1691,7 +1703,7 @@ def run_entry_sampler(args, rank, world, local_rank):
                                   "sizes) + 4 B per tree slot read"},
             "cpu_baseline": cpu_baseline,
         }
-        print(json.dumps(line))
+        emit(line)
     eng.close()
     if world > 1:
         import torch.distributed as dist
@@ -1879,7 +1891,7 @@ def run_typed(args, rank, world, local_rank):
         all_reduce(t, dist.ReduceOp.MAX)
         line.update(value=float(v.item()), ms_per_step=float(t.item()), n_gpus=world)
     if rank == 0:
-        print(json.dumps(line))
+        emit(line)
     smp.close()
     if world > 1:
         dist.barrier()
@@ -2182,7 +2194,7 @@ def run_gat_lp(args, rank, world, local_rank):
         all_reduce(t, dist.ReduceOp.MAX)
         line.update(value=float(v.item()), ms_per_step=float(t.item()), n_gpus=world)
     if rank == 0:
-        print(json.dumps(line))
+        emit(line)
     eng.close()
     if world > 1:
         dist.barrier()
