@@ -143,6 +143,41 @@ int32_t gigl_feat_absmax(gigl_ctx* ctx, gigl_feat* feat, float* out);
 
 static inline int64_t gigl_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 
+// out[i] = h[root_local[i]] for the b roots of a batch set (rows of d floats) — the last stage of the one-call plans.
+// (a failed batch set — meta[GIGL_META_OVERFLOW] != 0: levels zeroed, nothing computed — hands out NaN rows, never the
+// previous call's activations)
+template <int V>  // V = 4: d % 4 == 0, a thread moves 16 bytes (rows of h and out are 16-byte aligned); V = 1: any d
+__global__ __launch_bounds__(256) void gigl_take_rows_kernel(const float* __restrict__ h, const int32_t* __restrict__ root_local,
+                                                        int b, int d, const int32_t* __restrict__ meta,
+                                                        float* __restrict__ out) {
+  const uint32_t dv = (uint32_t)d / V;  // items per row (32-bit index math: b * d < 2^31 is checked at plan creation)
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint32_t)b * dv) return;
+  const uint32_t r = i / dv, c = (i - r * dv) * V;
+  const bool failed = meta[GIGL_META_OVERFLOW] != 0;
+  const int32_t l = failed ? -1 : root_local[r];
+  float* dst = out + (int64_t)r * d + c;
+  if constexpr (V == 4) {
+    float4 v = failed ? make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""))
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (l >= 0) v = *reinterpret_cast<const float4*>(h + (int64_t)l * d + c);
+    *reinterpret_cast<float4*>(dst) = v;
+  } else {
+    *dst = failed ? __builtin_nanf("") : (l >= 0 ? h[(int64_t)l * d + c] : 0.f);
+  }
+}
+static inline void gigl_take_rows(hipStream_t st, const float* h, const int32_t* root_local, int b, int d,
+                                  const int32_t* meta, float* out) {
+  const int64_t total = (int64_t)b * d;  // (< 2^31: the plans' activation buffers are smaller than that)
+  // 16-byte items when the rows of both buffers are 16-byte aligned (hipMalloc'ed activations; torch allocations)
+  if ((d & 3) == 0 && (((uintptr_t)out | (uintptr_t)h) & 15) == 0)
+    hipLaunchKernelGGL(gigl_take_rows_kernel<4>, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, h, root_local, b,
+                       d, meta, out);
+  else
+    hipLaunchKernelGGL(gigl_take_rows_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, h, root_local, b, d,
+                       meta, out);
+}
+
 #if defined(__HIPCC__)
 // Sum over aligned groups of `group` adjacent lanes (a power of two <= 64), returned to every lane of the group, on the
 // VALU / SALU only: DPP quad permutes for 2 and 4, the half-row / row mirrors for 8 and 16, v_readlane of the four row

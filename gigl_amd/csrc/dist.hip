@@ -507,21 +507,6 @@ __global__ __launch_bounds__(256) void projected_layer_kernel(const float* __res
   h[i * dout + c] = act ? fmaxf(v, 0.f) : v;
 }
 
-// a failed step (bucket / workspace overflow: meta[GIGL_META_OVERFLOW] != 0, levels zeroed, nothing computed) must
-// not hand out the previous step's activations as embeddings: its rows are NaN
-__global__ void take_root_rows_kernel(const float* __restrict__ h, const int32_t* __restrict__ root_local, int b, int d,
-                                      const int32_t* __restrict__ meta, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)b * d) return;
-  if (meta[GIGL_META_OVERFLOW] != 0) {
-    out[i] = __builtin_nanf("");
-    return;
-  }
-  const int r = (int)(i / d), c = (int)(i % d);
-  const int32_t l = root_local[r];
-  out[i] = l >= 0 ? h[(int64_t)l * d + c] : 0.f;
-}
-
 // fold the bucket-overflow flags of the step into meta[GIGL_META_OVERFLOW]; a failed step computes nothing
 __global__ void fold_overflow_kernel(int32_t* meta, const int32_t* const* flags, int n_flags, int hops,
                                      int32_t act_rows) {
@@ -895,8 +880,8 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     if (rc != GIGL_OK) return rc;
   }
   const int dout = p->dims[L];
-  hipLaunchKernelGGL(take_root_rows_kernel, dim3((unsigned)grid256((int64_t)p->b * dout)), dim3(256), 0, st,
-                     p->hbuf[(L - 1) & 1], p->un.root_local, p->b, dout, p->un.meta, out);
+  // (a failed step must not hand out the previous step's activations as embeddings: its rows are NaN)
+  gigl_take_rows(st, p->hbuf[(L - 1) & 1], p->un.root_local, p->b, dout, p->un.meta, out);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -82,21 +82,6 @@ struct gigl_sage_plan {
 
 namespace {
 
-// (a failed batch set — meta[GIGL_META_OVERFLOW] != 0: levels zeroed, nothing computed — hands out NaN rows, never the
-// previous call's activations)
-__global__ void take_rows_kernel(const float* __restrict__ h, const int32_t* __restrict__ root_local, int b, int d,
-                                 const int32_t* __restrict__ meta, float* __restrict__ out) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)b * d) return;
-  if (meta[GIGL_META_OVERFLOW] != 0) {
-    out[i] = __builtin_nanf("");
-    return;
-  }
-  int r = (int)(i / d), c = (int)(i % d);
-  int32_t l = root_local[r];
-  out[i] = l >= 0 ? h[(int64_t)l * d + c] : 0.f;
-}
-
 // The activation buffers hold b*(1 + f0 + ...) rows — the number of nodes of level < hops when no root is another
 // root's sampled neighbour.  Roots that ARE neighbours of each other add the children of those occurrences to the
 // inner levels (up to the whole tree in a clique of roots): such a batch does not fit the workspace; its level
@@ -203,9 +188,7 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
   }
   if (s == n_stages(p) - 1) {
     const int dout = p->dims[L];
-    const int64_t total = (int64_t)p->b * dout;
-    hipLaunchKernelGGL(take_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                       p->hbuf[(L - 1) & 1], p->un.root_local, p->b, dout, p->un.meta, out);
+    gigl_take_rows(ctx->stream, p->hbuf[(L - 1) & 1], p->un.root_local, p->b, dout, p->un.meta, out);
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     return GIGL_OK;
   }
