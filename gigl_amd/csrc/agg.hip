@@ -810,14 +810,6 @@ __device__ __forceinline__ void hsplit_store(const float4_t v, short* p1, short*
   *reinterpret_cast<uint2*>(p1) = make_uint2((uint32_t)b1[0] | ((uint32_t)b1[1] << 16), (uint32_t)b1[2] | ((uint32_t)b1[3] << 16));
   *reinterpret_cast<uint2*>(p2) = make_uint2((uint32_t)b2[0] | ((uint32_t)b2[1] << 16), (uint32_t)b2[2] | ((uint32_t)b2[3] << 16));
 }
-// (values that ARE halves, widened: one plane)
-__device__ __forceinline__ void hstore1(const float4_t v, short* p1) {
-  uint16_t b1[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) b1[t] = __builtin_bit_cast(uint16_t, (_Float16)v[t]);
-  *reinterpret_cast<uint2*>(p1) = make_uint2((uint32_t)b1[0] | ((uint32_t)b1[1] << 16), (uint32_t)b1[2] | ((uint32_t)b1[3] << 16));
-}
-
 // SELF (the SAGE layer's [mean | self] operand without the self copy): the A operand has TWO sources — columns k <
 // d_mean come from the tiled buffer the gather wrote (a_tiled = its chunks per row tile, ceil(d_mean / 32)), columns
 // k >= d_mean are element k - d_mean of row self_ids[row] (or `row`) of `self_src` (fp32 rows self_ld apart: the
@@ -829,7 +821,7 @@ __device__ __forceinline__ void hstore1(const float4_t v, short* p1) {
 // accumulator instead of six, and the rows are read as stored (2 bytes per element, no widened copy).  The remaining
 // products run in the order of the fp32 path: the same accumulators up to the sign of a zero.
 template <int NJ, bool KVEC = true, bool SELF = false, bool AHALF = false, bool HS = false>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
-__global__ __launch_bounds__(256) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HS && AHALF) ? 3 : 1))) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            const int32_t* __restrict__ m_dev, int K, int N, int act,
                                                            float* __restrict__ y, int a_tiled, int ldy,
@@ -911,11 +903,16 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
         da[i] = zero4;
         if (row < M && kk < K) {
           const uint2 h4 = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(a) + (int64_t)row * K + kk);
-          const __half2 lo = *reinterpret_cast<const __half2*>(&h4.x), hi = *reinterpret_cast<const __half2*>(&h4.y);
-          da[i][0] = __low2float(lo);
-          da[i][1] = __high2float(lo);
-          da[i][2] = __low2float(hi);
-          da[i][3] = __high2float(hi);
+          if constexpr (HS) {  // the halves ARE the operand plane: their bits travel as they are (two registers)
+            da[i][0] = __uint_as_float(h4.x);
+            da[i][1] = __uint_as_float(h4.y);
+          } else {
+            const __half2 lo = *reinterpret_cast<const __half2*>(&h4.x), hi = *reinterpret_cast<const __half2*>(&h4.y);
+            da[i][0] = __low2float(lo);
+            da[i][1] = __high2float(lo);
+            da[i][2] = __low2float(hi);
+            da[i][3] = __high2float(hi);
+          }
         }
       } else if constexpr (k_vec) {
         da[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(src) : zero4;
@@ -941,7 +938,8 @@ __global__ __launch_bounds__(256) void linear_split_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int o = split_lds_off(lr + 32 * i, lc * 4);
-      if constexpr (HS && AHALF) hstore1(ra[i], &s_a[0][o]);
+      if constexpr (HS && AHALF)
+        *reinterpret_cast<uint2*>(&s_a[0][o]) = make_uint2(__float_as_uint(ra[i][0]), __float_as_uint(ra[i][1]));
       else if constexpr (HS) hsplit_store(ra[i], &s_a[0][o], &s_a[1][o]);
       else if constexpr (AHALF) split_store2(ra[i], &s_a[0][o], &s_a[1][o]);
       else split_store(ra[i], &s_a[0][o], &s_a[1][o], &s_a[2][o]);
