@@ -794,6 +794,9 @@ __device__ __forceinline__ void split_store2(const float4_t v, short* p1, short*
 // inside the fp16 range (|x| < 65504: callers check the table's / the weights' largest magnitude, split_fits_half) — the
 // bf16 planes have fp32's range and stay the general path.  With AHALF the A operand IS its h1 plane: two MFMAs.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+#ifndef GIGL_HS_ONE_AHEAD
+#define GIGL_HS_ONE_AHEAD 1
+#endif
 __device__ __forceinline__ void hsplit_store(const float4_t v, short* p1, short* p2) {
   _Float16 h1[4], h2[4];
 #pragma unroll
@@ -821,7 +824,7 @@ __device__ __forceinline__ void hsplit_store(const float4_t v, short* p1, short*
 // accumulator instead of six, and the rows are read as stored (2 bytes per element, no widened copy).  The remaining
 // products run in the order of the fp32 path: the same accumulators up to the sign of a zero.
 template <int NJ, bool KVEC = true, bool SELF = false, bool AHALF = false, bool HS = false>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HS && AHALF) ? 3 : 1))) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HS && (AHALF || GIGL_HS_ONE_AHEAD)) ? 3 : 1))) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            const int32_t* __restrict__ m_dev, int K, int N, int act,
                                                            float* __restrict__ y, int a_tiled, int ldy,
@@ -879,7 +882,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HS && AHAL
   const int lr = tid >> 3, lc = tid & 7;
   constexpr bool k_vec = KVEC;
   // operands of TWO chunks ahead stay in flight in registers (a chunk's MFMAs are shorter than a global load under load)
-  float4_t ga[2][4], gw[2][2 * NJ];
+  // (PF1: ONE chunk ahead — half the prefetch registers, which is what lets the fp32-operand half-split instantiation
+  // fit three waves per SIMD; the third wave hides what the second chunk in flight hid)
+  constexpr bool PF1 = HS && !AHALF && GIGL_HS_ONE_AHEAD;
+  float4_t ga[PF1 ? 1 : 2][4], gw[PF1 ? 1 : 2][2 * NJ];
   const float* self_row[4] = {nullptr, nullptr, nullptr, nullptr};  // SELF: this thread's four rows of the self source
   if constexpr (SELF) {
 #pragma unroll
@@ -951,7 +957,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HS && AHAL
       else split_store(rw[i], &s_w[0][o], &s_w[1][o], &s_w[2][o]);
     }
     __syncthreads();
-    if (k0 + 2 * BK < K) gload(k0 + 2 * BK, ra, rw);  // lands during this chunk's and the next chunk's MFMAs
+    if constexpr (PF1) {
+      if (k0 + BK < K) gload(k0 + BK, ra, rw);  // lands during this chunk's MFMAs
+    } else {
+      if (k0 + 2 * BK < K) gload(k0 + 2 * BK, ra, rw);  // lands during this chunk's and the next chunk's MFMAs
+    }
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 16) {
       if (k0 + ks >= K) break;
@@ -995,10 +1005,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HS && AHAL
     }
   };
   gload(0, ga[0], gw[0]);
-  if (BK < K) gload(BK, ga[1], gw[1]);
-  for (int k0 = 0; k0 < K; k0 += 2 * BK) {
-    chunk(k0, ga[0], gw[0]);
-    if (k0 + BK < K) chunk(k0 + BK, ga[1], gw[1]);
+  if constexpr (PF1) {
+    for (int k0 = 0; k0 < K; k0 += BK) chunk(k0, ga[0], gw[0]);
+  } else {
+    if (BK < K) gload(BK, ga[PF1 ? 0 : 1], gw[PF1 ? 0 : 1]);
+    for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+      chunk(k0, ga[0], gw[0]);
+      if (k0 + BK < K) chunk(k0 + BK, ga[PF1 ? 0 : 1], gw[PF1 ? 0 : 1]);
+    }
   }
   __syncthreads();  // every wave is done with the operand planes: s_a becomes the waves' epilogue strips
   float* strip = reinterpret_cast<float*>(s_buf) + wv * (32 * 36);
