@@ -794,9 +794,6 @@ __device__ __forceinline__ void split_store2(const float4_t v, short* p1, short*
 // inside the fp16 range (|x| < 65504: callers check the table's / the weights' largest magnitude, split_fits_half) — the
 // bf16 planes have fp32's range and stay the general path.  With AHALF the A operand IS its h1 plane: two MFMAs.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-#ifndef GIGL_HS_ONE_AHEAD
-#define GIGL_HS_ONE_AHEAD 1
-#endif
 __device__ __forceinline__ void hsplit_store(const float4_t v, short* p1, short* p2) {
   _Float16 h1[4], h2[4];
 #pragma unroll
@@ -823,8 +820,8 @@ __device__ __forceinline__ void hsplit_store(const float4_t v, short* p1, short*
 // numbers, so the A operand keeps two planes and the product with its (zero) third plane is dropped — five MFMAs per
 // accumulator instead of six, and the rows are read as stored (2 bytes per element, no widened copy).  The remaining
 // products run in the order of the fp32 path: the same accumulators up to the sign of a zero.
-template <int NJ, bool KVEC = true, bool SELF = false, bool AHALF = false, bool HS = false>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HS && (AHALF || GIGL_HS_ONE_AHEAD)) ? 3 : 1))) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
+template <int NJ, bool KVEC = true, bool SELF = false, bool AHALF = false, bool HS = false, bool ONE = false>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ONE || (HS && AHALF)) ? 3 : 1))) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            const int32_t* __restrict__ m_dev, int K, int N, int act,
                                                            float* __restrict__ y, int a_tiled, int ldy,
@@ -882,9 +879,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HS && (AHA
   const int lr = tid >> 3, lc = tid & 7;
   constexpr bool k_vec = KVEC;
   // operands of TWO chunks ahead stay in flight in registers (a chunk's MFMAs are shorter than a global load under load)
-  // (PF1: ONE chunk ahead — half the prefetch registers, which is what lets the fp32-operand half-split instantiation
-  // fit three waves per SIMD; the third wave hides what the second chunk in flight hid)
-  constexpr bool PF1 = HS && !AHALF && GIGL_HS_ONE_AHEAD;
+  // ONE: one chunk of operands in flight instead of two — half the prefetch registers, which lets the instantiation fit
+  // three waves per SIMD (the third wave hides what the second chunk in flight hid).  The plans' tiled launches use
+  // it (several streams' kernels share the CUs: +2 % products, +8 % sharded step); a projection running alone —
+  // gigl_linear in a training step — is faster with two chunks ahead at two waves (training step 0.533 vs 0.551 ms)
+  constexpr bool PF1 = ONE;
   float4_t ga[PF1 ? 1 : 2][4], gw[PF1 ? 1 : 2][2 * NJ];
   const float* self_row[4] = {nullptr, nullptr, nullptr, nullptr};  // SELF: this thread's four rows of the self source
   if constexpr (SELF) {
@@ -3034,11 +3033,11 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
     const int nkc_mean = (d_mean + 31) / 32;
     if (hs) {
       if (n > 64)
-        hipLaunchKernelGGL((linear_split_kernel<2, true, true, false, true>), dim3((unsigned)(bm * ((n + 127) / 128)), 1u),
+        hipLaunchKernelGGL((linear_split_kernel<2, true, true, false, true, true>), dim3((unsigned)(bm * ((n + 127) / 128)), 1u),
                            dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0,
                            self_src, self_ids, d_mean, self_ld);
       else
-        hipLaunchKernelGGL((linear_split_kernel<1, true, true, false, true>), dim3((unsigned)(bm * ((n + 63) / 64)), 1u),
+        hipLaunchKernelGGL((linear_split_kernel<1, true, true, false, true, true>), dim3((unsigned)(bm * ((n + 63) / 64)), 1u),
                            dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0,
                            self_src, self_ids, d_mean, self_ld);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
@@ -3049,7 +3048,7 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
                          a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0, self_src, self_ids,
                          d_mean, self_ld);
     else
-      hipLaunchKernelGGL((linear_split_kernel<1, true, true>), dim3((unsigned)(bm * ((n + 63) / 64)), 1u), dim3(256), 0, st,
+      hipLaunchKernelGGL((linear_split_kernel<1, true, true, false, false, true>), dim3((unsigned)(bm * ((n + 63) / 64)), 1u), dim3(256), 0, st,
                          a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0, self_src, self_ids,
                          d_mean, self_ld);
     GIGL_HIP_CHECK(ctx, hipGetLastError());
@@ -3057,19 +3056,19 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
   }
   if (hs) {
     if (n > 64)
-      hipLaunchKernelGGL((linear_split_kernel<2, true, false, false, true>), dim3((unsigned)(bm * ((n + 127) / 128)), (unsigned)batch),
+      hipLaunchKernelGGL((linear_split_kernel<2, true, false, false, true, true>), dim3((unsigned)(bm * ((n + 127) / 128)), (unsigned)batch),
                          dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
     else
-      hipLaunchKernelGGL((linear_split_kernel<1, true, false, false, true>), dim3((unsigned)(bm * ((n + 63) / 64)), (unsigned)batch),
+      hipLaunchKernelGGL((linear_split_kernel<1, true, false, false, true, true>), dim3((unsigned)(bm * ((n + 63) / 64)), (unsigned)batch),
                          dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     return GIGL_OK;
   }
   if (n > 64)
-    hipLaunchKernelGGL((linear_split_kernel<2>), dim3((unsigned)(bm * ((n + 127) / 128)), (unsigned)batch), dim3(256), 0,
+    hipLaunchKernelGGL((linear_split_kernel<2, true, false, false, false, true>), dim3((unsigned)(bm * ((n + 127) / 128)), (unsigned)batch), dim3(256), 0,
                        st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
   else
-    hipLaunchKernelGGL((linear_split_kernel<1>), dim3((unsigned)(bm * ((n + 63) / 64)), (unsigned)batch), dim3(256), 0,
+    hipLaunchKernelGGL((linear_split_kernel<1, true, false, false, false, true>), dim3((unsigned)(bm * ((n + 63) / 64)), (unsigned)batch), dim3(256), 0,
                        st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
