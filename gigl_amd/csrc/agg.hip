@@ -3188,6 +3188,19 @@ int32_t gigl_gat_input_layer_fused(gigl_ctx* ctx, const void* src, int32_t src_d
                                    float negative_slope, const int32_t* rowptr, const int32_t* rowend,
                                    const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
                                    int32_t act, float* scratch, float* out) {
+  return gigl_gat_input_layer_fused_hs(ctx, src, src_dtype, d, gather_ids, n_local_dev, w, att_src, att_dst, heads, channels,
+                                       negative_slope, rowptr, rowend, col, n_rows_dev, rows_cap, bias, act, scratch, out,
+                                       false);
+}
+
+// half_split: the projection of the aggregated rows over two fp16 planes per operand — the rows are convex combinations
+// of table rows (softmax weights), so the table's largest magnitude bounds them; the caller has checked it and the weights'
+int32_t gigl_gat_input_layer_fused_hs(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
+                                      const uint32_t* gather_ids, const int32_t* n_local_dev, const float* w,
+                                      const float* att_src, const float* att_dst, int32_t heads, int32_t channels,
+                                      float negative_slope, const int32_t* rowptr, const int32_t* rowend,
+                                      const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
+                                      int32_t act, float* scratch, float* out, bool half_split) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   GIGL_REQUIRE(ctx, src && gather_ids && w && att_src && att_dst && rowptr && rowend && col && n_rows_dev && scratch && out,
                "null argument");
@@ -3236,5 +3249,6 @@ int32_t gigl_gat_input_layer_fused(gigl_ctx* ctx, const void* src, int32_t src_d
 #undef GIGL_GAT_ON
     GIGL_HIP_CHECK(ctx, hipGetLastError());
   }
-  return linear_tiled_strided(ctx, z, w, bias, n_rows_dev, rows_cap, d, C, act, out, H * C, H, head_stride, (int64_t)C * d);
+  return linear_tiled_strided(ctx, z, w, bias, n_rows_dev, rows_cap, d, C, act, out, H * C, H, head_stride, (int64_t)C * d,
+                              nullptr, nullptr, 0, 0, half_split);
 }

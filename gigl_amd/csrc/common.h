@@ -135,6 +135,12 @@ int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, c
 // half_split: operands as two fp16 planes, three MFMAs per accumulator (linear_split_kernel<.., HS>) — the caller
 // guarantees every |operand value| < GIGL_HALF_SPLIT_MAX (gigl_feat_absmax / gigl_dev_absmax_f32)
 constexpr float GIGL_HALF_SPLIT_MAX = 60000.f;
+int32_t gigl_gat_input_layer_fused_hs(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
+                                      const uint32_t* gather_ids, const int32_t* n_local_dev, const float* w,
+                                      const float* att_src, const float* att_dst, int32_t heads, int32_t channels,
+                                      float negative_slope, const int32_t* rowptr, const int32_t* rowend,
+                                      const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
+                                      int32_t act, float* scratch, float* out, bool half_split);
 bool gigl_half_split_enabled();  // (GIGL_GEMM_SPLIT=bf16 keeps every projection on the bf16 planes)
 int32_t gigl_dev_absmax_f32(gigl_ctx* ctx, const float* p, int64_t n, float* out);  // synchronises the ctx's stream
 int32_t gigl_feat_absmax(gigl_ctx* ctx, gigl_feat* feat, float* out);

@@ -208,9 +208,9 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
     if (l == 0) {
       if (!first) return GIGL_OK;  // (the first layer is one stage: aggregation + both heads' projection)
       const int32_t* n_local = p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr;
-      return gigl_gat_input_layer_fused(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, n_local, p->w[0], p->att_src[0],
-                                        p->att_dst[0], p->heads[0], p->channels[0], p->slope, p->un.rowptr, p->un.rowend,
-                                        p->un.col, n_rows, rows_cap, p->bias[0], act, p->gat_scratch, p->hbuf[0]);
+      return gigl_gat_input_layer_fused_hs(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, n_local, p->w[0], p->att_src[0],
+                                           p->att_dst[0], p->heads[0], p->channels[0], p->slope, p->un.rowptr, p->un.rowend,
+                                           p->un.col, n_rows, rows_cap, p->bias[0], act, p->gat_scratch, p->hbuf[0], p->hs0);
     }
     // sources of layer l: the rows layer l-1 computed (level <= L-l)
     const int32_t* n_src = p->un.meta + GIGL_META_LEVEL0 + (L - l);
@@ -507,6 +507,11 @@ int32_t gigl_gat_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, 
     gigl_sage_plan_destroy(p);
     return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the GAT plan's workspace failed");
   }
+  rc = plan_refresh_half_split(p);
+  if (rc != GIGL_OK) {
+    gigl_sage_plan_destroy(p);
+    return rc;
+  }
   *out = p;
   return GIGL_OK;
 }
@@ -525,7 +530,7 @@ int32_t gigl_gat_plan_set_weights(gigl_sage_plan* p, const float* const* w, cons
     hipStreamSynchronize(p->ctx->stream);
     drop_graphs(p);
   }
-  return GIGL_OK;
+  return plan_refresh_half_split(p);
 }
 
 // the first layer's operands are rows of the feature table reduced by mean / max (|.| <= the table's largest magnitude)
@@ -535,6 +540,15 @@ int32_t gigl_gat_plan_set_weights(gigl_sage_plan* p, const float* const* w, cons
 static int32_t plan_refresh_half_split(gigl_sage_plan* p) {
   const bool before = p->hs0;
   p->hs0 = false;
+  if (p->kind == 1 && p->feat && p->w[0] && p->gat_scratch && gigl_half_split_enabled()) {
+    // GAT: the first projection's operand rows are softmax-weighted sums of table rows (bounded by the table)
+    float fmax = 0.f, wmax = 0.f;
+    int32_t rc = gigl_feat_absmax(p->ctx, p->feat, &fmax);
+    if (rc != GIGL_OK) return rc;
+    rc = gigl_dev_absmax_f32(p->ctx, p->w[0], (int64_t)p->heads[0] * p->channels[0] * p->dims[0], &wmax);
+    if (rc != GIGL_OK) return rc;
+    p->hs0 = fmax < GIGL_HALF_SPLIT_MAX && wmax < GIGL_HALF_SPLIT_MAX;
+  }
   if (p->kind == 0 && p->tiled && p->abuf && p->feat && p->w[0] && gigl_half_split_enabled()) {  // (SAGE plans own abuf)
     float fmax = 0.f, wmax = 0.f;
     int32_t rc = gigl_feat_absmax(p->ctx, p->feat, &fmax);

@@ -944,7 +944,8 @@ int32_t gigl_sage_plan_set_projected_input(gigl_sage_plan* plan, const float* pr
  * the library at create / set_weights when the feature table's largest magnitude (times the largest fan-out, for a
  * sum reduction) and the first layer's weights' lie inside the fp16 range (< 60000); GIGL_GEMM_SPLIT=bf16 in the
  * environment keeps every projection on the bf16 planes.  Weights rewritten in place keep the decision: call
- * gigl_sage_plan_set_weights again after an update that may leave the range (beyond it the rows come out non-finite). */
+ * gigl_sage_plan_set_weights again after an update that may leave the range (beyond it the rows come out non-finite).
+ * GAT plans (gigl_gat_plan_create / _set_weights) take the same decision for their first layer's projection. */
 int32_t gigl_sage_plan_half_split(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
 int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
