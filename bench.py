@@ -590,7 +590,7 @@ def main():
             #  gather layer l: E_l*(4 + D_l*s) + N_dst*(8 + D_l*s_out); the self half of the projection's operand is
             #  read by the projection itself from the fp32 source rows (two-source operand) — or, for an fp16 table's
             #  first layer, copied alongside by the gather (D_l*s read + D_l*4 written)
-            two_src = (l > 0 or esz == 4) and all(v % 4 == 0 for v in dims) and not os.environ.get("GIGL_PLAN_SELF_COPY")
+            two_src = (l > 0 or esz == 4 or half_split) and all(v % 4 == 0 for v in dims) and not os.environ.get("GIGL_PLAN_SELF_COPY")
             ab["gather_mean"] += agg_l * (4 + dims[l] * s_in) + rows_l * (8 + dims[l] * 4) + \
                 (0 if two_src else rows_l * (dims[l] * s_in + dims[l] * 4))
             ab["linear"] += rows_l * (2 * dims[l] + dout) * 4 + dout * 2 * dims[l] * 4

@@ -820,7 +820,9 @@ __device__ __forceinline__ void hsplit_store(const float4_t v, short* p1, short*
 // numbers, so the A operand keeps two planes and the product with its (zero) third plane is dropped — five MFMAs per
 // accumulator instead of six, and the rows are read as stored (2 bytes per element, no widened copy).  The remaining
 // products run in the order of the fp32 path: the same accumulators up to the sign of a zero.
-template <int NJ, bool KVEC = true, bool SELF = false, bool AHALF = false, bool HS = false, bool ONE = false>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
+// SH (with SELF): the self source's rows are fp16 (the resident table as stored; self_ld in halves) — an fp16 table's first
+// layer then needs no fp32 copy of the self half either (the gather writes the reduced half only)
+template <int NJ, bool KVEC = true, bool SELF = false, bool AHALF = false, bool HS = false, bool ONE = false, bool SH = false>  // KVEC false: K % 4 != 0 (row-major operands only) — element loads
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ONE || (HS && AHALF)) ? 3 : 1))) void linear_split_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            const int32_t* __restrict__ m_dev, int K, int N, int act,
@@ -890,7 +892,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ONE || (HS
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = m0b + lr + 32 * i;
-      if (row < M) self_row[i] = self_src + (int64_t)(self_ids ? self_ids[row] : (uint32_t)row) * self_ld;
+      if (row < M) {
+        const int64_t at = (int64_t)(self_ids ? self_ids[row] : (uint32_t)row) * self_ld;
+        self_row[i] = SH ? reinterpret_cast<const float*>(reinterpret_cast<const __half*>(self_src) + at) : self_src + at;
+      }
     }
   }
   auto gload = [&](int k0, float4_t (&da)[4], float4_t (&dw)[2 * NJ]) {
@@ -903,6 +908,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ONE || (HS
       const float* src = a_tiled ? at + (lr + 32 * i) * 32 : a + (int64_t)row * K + kk;
       if constexpr (SELF) {
         if (kk >= d_mean && row < M) src = self_row[i] + (kk - d_mean);
+      }
+      if constexpr (SELF && SH) {
+        if (kk >= d_mean && row < M && kk < K) {  // four halves of the table row, widened (exact)
+          const uint2 h4 = *reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(self_row[i]) + (kk - d_mean));
+          const __half2 lo = *reinterpret_cast<const __half2*>(&h4.x), hi = *reinterpret_cast<const __half2*>(&h4.y);
+          da[i][0] = __low2float(lo);
+          da[i][1] = __high2float(lo);
+          da[i][2] = __low2float(hi);
+          da[i][3] = __high2float(hi);
+          continue;
+        }
       }
       if constexpr (AHALF) {
         da[i] = zero4;
@@ -3019,7 +3035,7 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
                                     const int32_t* m_dev, int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y,
                                     int32_t ldy, int32_t batch = 1, int64_t a_bstride = 0, int64_t w_bstride = 0,
                                     const float* self_src = nullptr, const uint32_t* self_ids = nullptr,
-                                    int32_t d_mean = 0, int32_t self_ld = 0, bool hs = false) {
+                                    int32_t d_mean = 0, int32_t self_ld = 0, bool hs = false, bool self_half = false) {
   GIGL_REQUIRE(ctx, a_tiled && w && m_dev && y && (k & 3) == 0 && n > 0 && ldy >= n * batch && batch >= 1,
                "bad arguments");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -3031,6 +3047,19 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
   if (self_src) {  // two-source operand: the tiled buffer holds the mean chunks only
     GIGL_REQUIRE(ctx, batch == 1 && d_mean > 0 && (d_mean & 3) == 0 && d_mean < k && self_ld >= k - d_mean, "bad two-source operand");
     const int nkc_mean = (d_mean + 31) / 32;
+    GIGL_REQUIRE(ctx, !self_half || hs, "fp16 self rows go with the half split");
+    if (hs && self_half) {
+      if (n > 64)
+        hipLaunchKernelGGL((linear_split_kernel<2, true, true, false, true, true, true>), dim3((unsigned)(bm * ((n + 127) / 128)), 1u),
+                           dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0,
+                           self_src, self_ids, d_mean, self_ld);
+      else
+        hipLaunchKernelGGL((linear_split_kernel<1, true, true, false, true, true, true>), dim3((unsigned)(bm * ((n + 63) / 64)), 1u),
+                           dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0,
+                           self_src, self_ids, d_mean, self_ld);
+      GIGL_HIP_CHECK(ctx, hipGetLastError());
+      return GIGL_OK;
+    }
     if (hs) {
       if (n > 64)
         hipLaunchKernelGGL((linear_split_kernel<2, true, true, false, true, true>), dim3((unsigned)(bm * ((n + 127) / 128)), 1u),
@@ -3103,10 +3132,10 @@ int32_t gigl_linear_batched(gigl_ctx* ctx, const float* a, const float* w, const
 
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
                           int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y, const float* self_src,
-                          const uint32_t* self_ids, int32_t d_mean, int32_t self_ld, bool half_split) {
+                          const uint32_t* self_ids, int32_t d_mean, int32_t self_ld, bool half_split, bool self_half) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   return linear_tiled_strided(ctx, a_tiled, w, bias, m_dev, m_cap, k, n, act, y, n, 1, 0, 0, self_src, self_ids, d_mean,
-                              self_ld, half_split);
+                              self_ld, half_split, self_half);
 }
 
 int64_t gigl_gat_input_layer_scratch(int32_t d, int32_t heads, int64_t cap_nodes, int64_t rows_cap, int64_t cap_edges) {

@@ -131,7 +131,8 @@ int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
                           int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y, const float* self_src = nullptr,
                           const uint32_t* self_ids = nullptr, int32_t d_mean = 0, int32_t self_ld = 0,
-                          bool half_split = false);
+                          bool half_split = false, bool self_half = false);
+// self_half (with half_split): self_src points at fp16 rows (self_ld halves apart)
 // half_split: operands as two fp16 planes, three MFMAs per accumulator (linear_split_kernel<.., HS>) — the caller
 // guarantees every |operand value| < GIGL_HALF_SPLIT_MAX (gigl_feat_absmax / gigl_dev_absmax_f32)
 constexpr float GIGL_HALF_SPLIT_MAX = 60000.f;

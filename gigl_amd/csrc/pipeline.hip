@@ -232,7 +232,9 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
   }
   // two-source operand: the projection reads the self half from the fp32 source rows themselves (the feature table
   // through union.nodes, or the previous layer's output), the gather writes the reduced half only
-  const bool two_src = p->tiled && p->two_source && (l > 0 || p->feat->dtype == GIGL_DTYPE_F32);
+  // (an fp16 table's rows serve as the self half too when the layer runs the half split: they are its h1 plane)
+  const bool self_half = l == 0 && p->hs0 && p->feat->dtype == GIGL_DTYPE_F16;
+  const bool two_src = p->tiled && p->two_source && (l > 0 || p->feat->dtype == GIGL_DTYPE_F32 || self_half);
   const int32_t nkc = p->tiled ? ((two_src ? d : 2 * d) + 31) / 32 : 0;
   if (((s - 2) & 1) == 0) {
     if (p->tiled) {
@@ -259,7 +261,7 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
   if (two_src)
     return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
                              p->hbuf[l & 1], l == 0 ? (const float*)p->feat->rows : p->hbuf[(l - 1) & 1],
-                             l == 0 ? p->un.nodes : nullptr, d, d, l == 0 && p->hs0);
+                             l == 0 ? p->un.nodes : nullptr, d, d, l == 0 && p->hs0, self_half);
   if (p->tiled)
     return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
                              p->hbuf[l & 1], nullptr, nullptr, 0, 0, l == 0 && p->hs0);
