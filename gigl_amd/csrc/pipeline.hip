@@ -557,8 +557,9 @@ static int32_t plan_refresh_half_split(gigl_sage_plan* p) {
     if (rc != GIGL_OK) return rc;
     rc = gigl_dev_absmax_f32(p->ctx, p->w[0], (int64_t)p->dims[1] * 2 * p->dims[0], &wmax);
     if (rc != GIGL_OK) return rc;
-    int32_t fmax_out = 1;
-    for (int k = 0; k < p->hops; ++k) fmax_out = p->fanouts[k] > fmax_out ? p->fanouts[k] : fmax_out;
+    int32_t fmax_out = 1;  // (a sum over up to `fan-out` rows; mean and max stay inside the table's range)
+    if (p->aggr == GIGL_AGGR_SUM)
+      for (int k = 0; k < p->hops; ++k) fmax_out = p->fanouts[k] > fmax_out ? p->fanouts[k] : fmax_out;
     p->hs0 = fmax * (float)fmax_out < GIGL_HALF_SPLIT_MAX && wmax < GIGL_HALF_SPLIT_MAX;
   }
   if (p->captured && before != p->hs0) {
@@ -593,7 +594,7 @@ int32_t gigl_sage_plan_set_aggr(gigl_sage_plan* p, int32_t aggr) {
     drop_graphs(p);
   }
   p->aggr = aggr;
-  return GIGL_OK;
+  return plan_refresh_half_split(p);  // (a sum's operand is bounded by fan-out times the table's largest magnitude)
 }
 
 int32_t gigl_sage_plan_set_projected_input(gigl_sage_plan* p, const float* proj) {

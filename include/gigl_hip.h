@@ -941,7 +941,7 @@ int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* 
 int32_t gigl_sage_plan_set_projected_input(gigl_sage_plan* plan, const float* proj);
 /* 1 when the plan's first projection runs over TWO fp16 planes per operand (x = h1 + h2, three MFMAs per accumulator
  * instead of the six of the three-bf16-plane split: same 1e-5 parity class, 2^-22 relative per product) — chosen by
- * the library at create / set_weights when the feature table's largest magnitude (times the largest fan-out, for a
+ * the library at create / set_weights / set_aggr when the feature table's largest magnitude (times the largest fan-out, for a
  * sum reduction) and the first layer's weights' lie inside the fp16 range (< 60000); GIGL_GEMM_SPLIT=bf16 in the
  * environment keeps every projection on the bf16 planes.  Weights rewritten in place keep the decision: call
  * gigl_sage_plan_set_weights again after an update that may leave the range (beyond it the rows come out non-finite).

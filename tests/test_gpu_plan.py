@@ -240,3 +240,17 @@ def test_first_layer_half_split_is_bounded_by_the_operands(setup):
     finally:
         eng2.close()
     assert err_half < 3e-6  # (what the two-plane split leaves: ~2^-22 per product)
+    # a sum over up to 15 rows of a table that reaches 5,000: past the range as a sum, inside it as a mean
+    eng3 = HipEngine(0)
+    try:
+        eng3.load_csc(rowptr, col)
+        x_mid = (x * (5000.0 / np.abs(x).max())).astype(np.float32)
+        eng3.load_features(x_mid)
+        plan = model.make_plan(eng3, b, fan)
+        assert plan.half_split()
+        plan.close()
+        plan = GraphSAGE(100, 256, 64, num_layers=2, aggr="sum").to(eng3.device).make_plan(eng3, b, fan)
+        assert not plan.half_split()
+        plan.close()
+    finally:
+        eng3.close()
