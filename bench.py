@@ -196,27 +196,49 @@ WORKLOADS = {
 WORKLOAD_DEFAULTS = {"cora": ("10,5", 512), "rmat-shard": ("15,10", 4096), "typed-dblp": ("10,5", 4096)}
 
 
+def cora_c1(seed: int = 1):
+    """SURVEY.md 8(d) C1 (BASELINE configs[0]) as host arrays: 2,708 nodes, 5,278 distinct undirected random edges
+    (no self loops; 10,556 directed after bidirectionalisation), D = 1,433 fp32 bag-of-words rows ~ Bernoulli(0.0127),
+    L1-normalised (a row without a word stays zero), labels uniform over 7 classes -> (n, src, dst, x, labels)"""
+    import numpy as np
+    n, pairs, d = 2_708, 5_278, 1_433
+    rng = np.random.default_rng(seed)
+    seen, src, dst = set(), [], []
+    while len(src) < pairs:
+        a, b = (int(v) for v in rng.integers(0, n, 2))
+        key = (min(a, b), max(a, b))
+        if a == b or key in seen:
+            continue
+        seen.add(key)
+        src.append(a)
+        dst.append(b)
+    x = (rng.random((n, d)) < 0.0127).astype(np.float32)
+    x /= np.maximum(x.sum(axis=1, keepdims=True), 1.0)
+    labels = rng.integers(0, 7, n).astype(np.int64)
+    return n, np.array(src, np.int32), np.array(dst, np.int32), x, labels
+
+
 def build_workload(eng, args):
     dev = eng.device
     name = "small" if getattr(args, "small", False) else getattr(args, "workload", "products")
     n, scale, pairs, d, dtype, directed, hid, out_dim, seed, label = WORKLOADS[name]
     perm_mul = 0x9E3779B1
-    if name == "cora":  # (uniform random pairs: Cora is not power-law)
-        g0 = torch.Generator(device=dev)
-        g0.manual_seed(seed)
-        src = torch.randint(0, n, (pairs,), generator=g0, device=dev).to(torch.int32)
-        dst = torch.randint(0, n, (pairs,), generator=g0, device=dev).to(torch.int32)
-    else:
-        # fold the 2^scale id space onto [0, n) and scatter ids so hubs are not the low ids; drawn in chunks (the
-        # int64 temporaries of 2e9 edges would not leave room for the sort)
-        parts, chunk = [], 1 << 28
-        for ci, c0 in enumerate(range(0, pairs, chunk)):
-            a_, b_ = rmat_edges_gpu(scale, min(chunk, pairs - c0), seed=seed + 7919 * ci, device=dev)
-            parts.append((((a_ * perm_mul) % n).to(torch.int32), ((b_ * perm_mul) % n).to(torch.int32)))
-            del a_, b_
-        src = torch.cat([q[0] for q in parts]) if len(parts) > 1 else parts[0][0]
-        dst = torch.cat([q[1] for q in parts]) if len(parts) > 1 else parts[0][1]
-        del parts
+    if name == "cora":  # (uniform random pairs: Cora is not power-law; bag-of-words rows)
+        _, src_h, dst_h, x_h, _ = cora_c1(seed)
+        eng.build_from_coo(n, torch.from_numpy(src_h).to(dev), torch.from_numpy(dst_h).to(dev), is_directed=directed)
+        eng.load_features(torch.from_numpy(x_h).to(dev))
+        args._workload = (name, label, hid, out_dim, directed, dtype)
+        return n, d
+    # fold the 2^scale id space onto [0, n) and scatter ids so hubs are not the low ids; drawn in chunks (the
+    # int64 temporaries of 2e9 edges would not leave room for the sort)
+    parts, chunk = [], 1 << 28
+    for ci, c0 in enumerate(range(0, pairs, chunk)):
+        a_, b_ = rmat_edges_gpu(scale, min(chunk, pairs - c0), seed=seed + 7919 * ci, device=dev)
+        parts.append((((a_ * perm_mul) % n).to(torch.int32), ((b_ * perm_mul) % n).to(torch.int32)))
+        del a_, b_
+    src = torch.cat([q[0] for q in parts]) if len(parts) > 1 else parts[0][0]
+    dst = torch.cat([q[1] for q in parts]) if len(parts) > 1 else parts[0][1]
+    del parts
     eng.build_from_coo(n, src, dst, is_directed=directed)
     del src, dst
     g = torch.Generator(device=dev)

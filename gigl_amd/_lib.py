@@ -57,7 +57,7 @@ SYMBOLS = [
     "gigl_linear_weight_grad", "gigl_features_row_crc",
     "gigl_typed_plan_create", "gigl_typed_plan_run", "gigl_typed_plan_buffers", "gigl_typed_plan_destroy",
     "gigl_typed_plan_merged_csr", "gigl_sage_plan_half_split",
-    "gigl_sage_plan_run_part",
+    "gigl_sage_plan_run_part", "gigl_sage_plan_overflow_add",
 ]
 
 KERNEL_IDS = {
@@ -341,6 +341,7 @@ def load() -> C.CDLL:
         "gigl_sage_project_features": [vp, vp, vp, i32, vp],
         "gigl_sage_plan_set_projected_input": [vp, vp],
         "gigl_sage_plan_half_split": [vp],
+        "gigl_sage_plan_overflow_add": [vp, vp],
         "gigl_gat_input_layer_fused": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, i64, vp, i32,
                                        vp, vp],
         "gigl_gat_input_layer": [vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, i64, vp, i64, vp, i64,

@@ -790,16 +790,21 @@ __device__ __forceinline__ void split_store2(const float4_t v, short* p1, short*
 // HS (half split): x = h1 + h2 with h1 = fp16(x), h2 = fp16(x - h1) — 11 + 11 significand bits, the subtraction exact,
 // subnormal halves honoured by v_mfma_f32_32x32x16_f16 on gfx950 (scripts/micro/mfma_f16_denorm.hip), so the small
 // parts keep an absolute precision of 2^-25.  a.w = h1.h1 + h1.h2 + h2.h1 (the dropped h2.h2 is <= 2^-22 relative): THREE
-// MFMAs per accumulator instead of six, two planes per operand in LDS instead of three.  Only for operands known to lie
-// inside the fp16 range (|x| < 65504: callers check the table's / the weights' largest magnitude, split_fits_half) — the
-// bf16 planes have fp32's range and stay the general path.  With AHALF the A operand IS its h1 plane: two MFMAs.
+// MFMAs per accumulator instead of six, two planes per operand in LDS instead of three.  fp16 has a narrow range on
+// BOTH sides (overflow past 65504; below 2^-14 the halves are subnormal and h2 keeps only an ABSOLUTE 2^-25), so each
+// operand is multiplied by a power of two on its way into the planes — hs_scale = {s_a, s_w, 1 / (s_a s_w)} in device
+// memory, chosen so that the operand's largest magnitude lands in [2^14, 2^15) (gigl_hs_scale_update: s_a from the
+// table's largest magnitude, s_w from the weights as they are on the device) — and the accumulators are multiplied by
+// 1 / (s_a s_w) in the epilogue: all three factors are exact, the element error is max(2^-22 |x|, 2^-39 max|x|) whatever
+// the operand's scale.  With AHALF the A operand IS its h1 plane (fp16 rows as stored, s_a = 1): two MFMAs.
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void hsplit_store(const float4_t v, short* p1, short* p2) {
+__device__ __forceinline__ void hsplit_store(const float4_t v, short* p1, short* p2, float s) {
   _Float16 h1[4], h2[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    h1[t] = (_Float16)v[t];
-    h2[t] = (_Float16)(v[t] - (float)h1[t]);
+    const float x = v[t] * s;  // (s is a power of two: exact)
+    h1[t] = (_Float16)x;
+    h2[t] = (_Float16)(x - (float)h1[t]);
   }
   uint16_t b1[4], b2[4];
 #pragma unroll
@@ -830,7 +835,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ONE || (HS
                                                            int64_t a_bstride, int64_t w_bstride,
                                                            const float* __restrict__ self_src = nullptr,
                                                            const uint32_t* __restrict__ self_ids = nullptr,
-                                                           int d_mean = 0, int self_ld = 0) {
+                                                           int d_mean = 0, int self_ld = 0,
+                                                           const float* __restrict__ hs_scale = nullptr) {
   // (grid.y = batch of independent products sharing M/K/N: operand b of a / w is a_bstride / w_bstride floats on, its
   // bias and its N output columns follow the previous batch's)
   a += blockIdx.y * a_bstride;
@@ -846,6 +852,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ONE || (HS
   short(*s_w)[BN * LDK] = reinterpret_cast<short(*)[BN * LDK]>(s_buf + A_EL);
   const int M = *m_dev;
   const int tiles_n = (N + BN - 1) / BN;
+  float hs_a = 1.f, hs_w = 1.f, hs_o = 1.f;  // HS: power-of-two operand scales and the epilogue's inverse (uniform)
+  if constexpr (HS) {
+    if (hs_scale) {
+      hs_a = hs_scale[0];
+      hs_w = hs_scale[1];
+      hs_o = hs_scale[2];
+    }
+  }
   // Workgroups are dealt to the 8 XCDs round-robin by id and every XCD has its own L2: the column tiles of one row
   // tile are given ids that differ by 8, so they run on the same XCD back to back and the A tile comes from HBM once
   // (PMC: FETCH_SIZE of the kernel was 2.1x the A matrix with adjacent ids).
@@ -961,14 +975,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ONE || (HS
       const int o = split_lds_off(lr + 32 * i, lc * 4);
       if constexpr (HS && AHALF)
         *reinterpret_cast<uint2*>(&s_a[0][o]) = make_uint2(__float_as_uint(ra[i][0]), __float_as_uint(ra[i][1]));
-      else if constexpr (HS) hsplit_store(ra[i], &s_a[0][o], &s_a[1][o]);
+      else if constexpr (HS) hsplit_store(ra[i], &s_a[0][o], &s_a[1][o], hs_a);
       else if constexpr (AHALF) split_store2(ra[i], &s_a[0][o], &s_a[1][o]);
       else split_store(ra[i], &s_a[0][o], &s_a[1][o], &s_a[2][o]);
     }
 #pragma unroll
     for (int i = 0; i < 2 * NJ; ++i) {
       const int o = split_lds_off(lr + 32 * i, lc * 4);
-      if constexpr (HS) hsplit_store(rw[i], &s_w[0][o], &s_w[1][o]);
+      if constexpr (HS) hsplit_store(rw[i], &s_w[0][o], &s_w[1][o], hs_w);
       else split_store(rw[i], &s_w[0][o], &s_w[1][o], &s_w[2][o]);
     }
     __syncthreads();
@@ -1031,6 +1045,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ONE || (HS
   }
   __syncthreads();  // every wave is done with the operand planes: s_a becomes the waves' epilogue strips
   float* strip = reinterpret_cast<float*>(s_buf) + wv * (32 * 36);
+  if constexpr (HS) {  // undo the operands' power-of-two scales (exact)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][j][v] *= hs_o;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -2560,7 +2582,7 @@ int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* 
   // widened copy + the fp32 path, for comparison)
   const bool half_direct = feat->dtype == GIGL_DTYPE_F16 && (d & 3) == 0 && !getenv("GIGL_PROJECT_WIDEN") &&
                            !getenv("GIGL_LINEAR_EXACT");
-  if (hipMalloc((void**)&cnt, 16) != hipSuccess ||
+  if (hipMalloc((void**)&cnt, 32) != hipSuccess ||
       (feat->dtype == GIGL_DTYPE_F16 && !half_direct && hipMalloc((void**)&stage, (size_t)cm * d * 4 + 16) != hipSuccess)) {
     cleanup();
     return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the projection workspace failed");
@@ -2577,15 +2599,15 @@ int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* 
   int32_t rc = GIGL_OK;
   // fp16 rows ARE the h1 plane of the half split; the weights join as two fp16 planes when they fit the half range:
   // two products per accumulator instead of five
-  bool hs = false;
-  if (half_direct && gigl_half_split_enabled()) {
-    float wmax = 0.f;
-    rc = gigl_dev_absmax_f32(ctx, wcat, (int64_t)2 * n_out * d, &wmax);
+  // (the halves are taken as stored, s_a = 1; the weights are scaled into the top of the half range on the device)
+  const bool hs = half_direct && gigl_half_split_enabled();
+  float* hs_dev = reinterpret_cast<float*>(cnt + 2);
+  if (hs) {
+    rc = gigl_hs_scale_update(ctx, wcat, (int64_t)2 * n_out * d, 1.f, hs_dev);
     if (rc != GIGL_OK) {
       cleanup();
       return rc;
     }
-    hs = wmax < GIGL_HALF_SPLIT_MAX;
   }
   for (int64_t r0 = 0; r0 < n && rc == GIGL_OK; r0 += cm) {
     const int64_t m = (n - r0) < cm ? (n - r0) : cm;
@@ -2598,11 +2620,13 @@ int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* 
       if (hs && nn > 64)
         hipLaunchKernelGGL((linear_split_kernel<2, true, false, true, true>), dim3((unsigned)(bm * ((nn + 127) / 128))), dim3(256),
                            0, st, ah, (const float*)wcat, (const float*)nullptr, (const int32_t*)(cnt + (m == cm ? 0 : 1)), d,
-                           nn, 0, out + r0 * 2 * n_out, 0, 0, (int64_t)0, (int64_t)0);
+                           nn, 0, out + r0 * 2 * n_out, 0, 0, (int64_t)0, (int64_t)0,
+                           (const float*)nullptr, (const uint32_t*)nullptr, 0, 0, (const float*)hs_dev);
       else if (hs)
         hipLaunchKernelGGL((linear_split_kernel<1, true, false, true, true>), dim3((unsigned)(bm * ((nn + 63) / 64))), dim3(256),
                            0, st, ah, (const float*)wcat, (const float*)nullptr, (const int32_t*)(cnt + (m == cm ? 0 : 1)), d,
-                           nn, 0, out + r0 * 2 * n_out, 0, 0, (int64_t)0, (int64_t)0);
+                           nn, 0, out + r0 * 2 * n_out, 0, 0, (int64_t)0, (int64_t)0,
+                           (const float*)nullptr, (const uint32_t*)nullptr, 0, 0, (const float*)hs_dev);
       else if (nn > 64)
         hipLaunchKernelGGL((linear_split_kernel<2, true, false, true>), dim3((unsigned)(bm * ((nn + 127) / 128))), dim3(256),
                            0, st, ah, (const float*)wcat, (const float*)nullptr, (const int32_t*)(cnt + (m == cm ? 0 : 1)), d,
@@ -2974,36 +2998,56 @@ int32_t gigl_linear_weight_grad(gigl_ctx* ctx, const float* dy, const float* a, 
   return GIGL_OK;
 }
 
+// largest |value|, sum of |value| and number of non-zero values of an array (one pass): what decides whether an operand
+// may take the half split, and with which power-of-two scale
+struct AbsStats {
+  uint32_t max_bits;  // (non-negative floats order like their bits); +inf for a NaN anywhere: "unbounded"
+  float sum;
+  unsigned long long nz;
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ p, int64_t n, uint32_t* __restrict__ out) {
-  float m = 0.f;
+__global__ __launch_bounds__(256) void absmax_kernel(const T* __restrict__ p, int64_t n, AbsStats* __restrict__ out) {
+  float m = 0.f, sum = 0.f;
+  unsigned long long nz = 0;
   bool bad = false;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float v = fabsf((float)p[i]);
     bad |= !(v == v);
     m = fmaxf(m, v);
+    sum += v;
+    nz += v != 0.f;
   }
-  if (bad) m = __uint_as_float(0x7F800000u);  // a NaN anywhere: "unbounded"
+  if (bad) m = __uint_as_float(0x7F800000u);
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));  // (non-negative floats order like their bits)
+  for (int o = 32; o >= 1; o >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, o, 64));
+    sum += __shfl_xor(sum, o, 64);
+    nz += __shfl_xor(nz, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&out->max_bits, __float_as_uint(m));
+    atomicAdd(&out->sum, sum);
+    atomicAdd(&out->nz, nz);
+  }
 }
 
 template <typename T>
-static int32_t dev_absmax(gigl_ctx* ctx, const T* p, int64_t n, float* out) {
+static int32_t dev_absstats(gigl_ctx* ctx, const T* p, int64_t n, float* amax, float* mean_nz) {
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  uint32_t* d = nullptr;
-  GIGL_HIP_CHECK(ctx, hipMalloc((void**)&d, 4));
-  hipMemsetAsync(d, 0, 4, ctx->stream);
+  AbsStats* d = nullptr;
+  GIGL_HIP_CHECK(ctx, hipMalloc((void**)&d, sizeof(AbsStats)));
+  hipMemsetAsync(d, 0, sizeof(AbsStats), ctx->stream);
   const int64_t wgs = std::min<int64_t>((n + 255) / 256 > 0 ? (n + 255) / 256 : 1, 8192);
   hipLaunchKernelGGL(absmax_kernel<T>, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, p, n, d);
-  uint32_t h = 0;
-  const hipError_t e1 = hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, ctx->stream);
+  AbsStats h{};
+  const hipError_t e1 = hipMemcpyAsync(&h, d, sizeof(AbsStats), hipMemcpyDeviceToHost, ctx->stream);
   const hipError_t e2 = hipStreamSynchronize(ctx->stream);
   hipFree(d);
   GIGL_HIP_CHECK(ctx, e1);
   GIGL_HIP_CHECK(ctx, e2);
-  memcpy(out, &h, 4);
+  memcpy(amax, &h.max_bits, 4);
+  if (mean_nz) *mean_nz = h.nz ? h.sum / (float)h.nz : 0.f;
   return GIGL_OK;
 }
 
@@ -3015,19 +3059,80 @@ bool gigl_half_split_enabled() {
   return on;
 }
 
-int32_t gigl_dev_absmax_f32(gigl_ctx* ctx, const float* p, int64_t n, float* out) { return dev_absmax<float>(ctx, p, n, out); }
+int32_t gigl_dev_absmax_f32(gigl_ctx* ctx, const float* p, int64_t n, float* out) {
+  return dev_absstats<float>(ctx, p, n, out, nullptr);
+}
 
 int32_t gigl_feat_absmax(gigl_ctx* ctx, gigl_feat* feat, float* out) {
   std::lock_guard<std::mutex> lk(feat->row_crc_mu);
   if (feat->absmax < 0.f) {
-    float m = 0.f;
+    float m = 0.f, mean = 0.f;
     const int64_t n = feat->n * feat->d;
-    const int32_t rc = feat->dtype == GIGL_DTYPE_F16 ? dev_absmax<__half>(ctx, (const __half*)feat->rows, n, &m)
-                                                     : dev_absmax<float>(ctx, (const float*)feat->rows, n, &m);
+    const int32_t rc = feat->dtype == GIGL_DTYPE_F16 ? dev_absstats<__half>(ctx, (const __half*)feat->rows, n, &m, &mean)
+                                                     : dev_absstats<float>(ctx, (const float*)feat->rows, n, &m, &mean);
     if (rc != GIGL_OK) return rc;
+    feat->absmean_nz = mean;
     feat->absmax = m;
   }
   *out = feat->absmax;
+  return GIGL_OK;
+}
+
+// power of two s with s * m in [2^14, 2^15) (m > 0, finite), held inside [2^-60, 2^60]
+__host__ __device__ static inline float hs_pow2_scale(float m) {
+  uint32_t bits;
+  memcpy(&bits, &m, 4);
+  int e = (int)((bits >> 23) & 0xFF) - 127;  // floor(log2 m) for normal m
+  if (((bits >> 23) & 0xFF) == 0) e = -126;
+  int se = 14 - e;
+  se = se > 60 ? 60 : (se < -60 ? -60 : se);
+  const uint32_t sb = (uint32_t)(se + 127) << 23;
+  float s;
+  memcpy(&s, &sb, 4);
+  return s;
+}
+
+int32_t gigl_feat_half_split_scale(gigl_ctx* ctx, gigl_feat* feat, float fan, float* s_a) {
+  *s_a = 0.f;
+  if (!gigl_half_split_enabled()) return GIGL_OK;
+  float fmax = 0.f;
+  const int32_t rc = gigl_feat_absmax(ctx, feat, &fmax);
+  if (rc != GIGL_OK) return rc;
+  const float top = fmax * fan;
+  // outside [2^-46, 2^74] the scale would leave [2^-60, 2^60]; an operand whose typical (non-zero) magnitude lies more
+  // than 2^10 below its largest (a table dominated by a few outliers) would put most of its elements next to the
+  // subnormal halves — both stay on the bf16 planes, as does a table with a NaN / inf, or an all-zero one
+  if (!(top >= 0x1p-46f && top <= 0x1p74f)) return GIGL_OK;
+  if (!(feat->absmean_nz >= fmax * 0x1p-10f)) return GIGL_OK;
+  *s_a = hs_pow2_scale(top);
+  return GIGL_OK;
+}
+
+// hs[0] = s_a, hs[1] = s_w from the largest |w| as the weights are NOW, hs[2] = 1 / (s_a s_w)      (one workgroup)
+__global__ __launch_bounds__(1024) void hs_scale_kernel(const float* __restrict__ w, int64_t n, float s_a,
+                                                        float* __restrict__ hs) {
+  __shared__ float s_m[16];
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float v = fabsf(w[i]);
+    m = fmaxf(m, v == v ? v : 0.f);  // (a NaN weight makes NaN rows on any path; it does not pick the scale)
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, s_m[i]);
+    const float s_w = (m > 0.f && m < __uint_as_float(0x7F800000u)) ? hs_pow2_scale(m) : 1.f;
+    hs[0] = s_a;
+    hs[1] = s_w;
+    hs[2] = (1.f / s_a) * (1.f / s_w);
+  }
+}
+
+int32_t gigl_hs_scale_update(gigl_ctx* ctx, const float* w, int64_t n, float s_a, float* hs_dev) {
+  hipLaunchKernelGGL(hs_scale_kernel, dim3(1), dim3(1024), 0, ctx->stream, w, n, s_a, hs_dev);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
 
@@ -3035,7 +3140,8 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
                                     const int32_t* m_dev, int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y,
                                     int32_t ldy, int32_t batch = 1, int64_t a_bstride = 0, int64_t w_bstride = 0,
                                     const float* self_src = nullptr, const uint32_t* self_ids = nullptr,
-                                    int32_t d_mean = 0, int32_t self_ld = 0, bool hs = false, bool self_half = false) {
+                                    int32_t d_mean = 0, int32_t self_ld = 0, const float* hs_scale = nullptr, bool self_half = false) {
+  const bool hs = hs_scale != nullptr;  // half split: {s_a, s_w, 1 / (s_a s_w)} on the device (gigl_hs_scale_update)
   GIGL_REQUIRE(ctx, a_tiled && w && m_dev && y && (k & 3) == 0 && n > 0 && ldy >= n * batch && batch >= 1,
                "bad arguments");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -3052,11 +3158,11 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
       if (n > 64)
         hipLaunchKernelGGL((linear_split_kernel<2, true, true, false, true, true, true>), dim3((unsigned)(bm * ((n + 127) / 128)), 1u),
                            dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0,
-                           self_src, self_ids, d_mean, self_ld);
+                           self_src, self_ids, d_mean, self_ld, hs_scale);
       else
         hipLaunchKernelGGL((linear_split_kernel<1, true, true, false, true, true, true>), dim3((unsigned)(bm * ((n + 63) / 64)), 1u),
                            dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0,
-                           self_src, self_ids, d_mean, self_ld);
+                           self_src, self_ids, d_mean, self_ld, hs_scale);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
       return GIGL_OK;
     }
@@ -3064,11 +3170,11 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
       if (n > 64)
         hipLaunchKernelGGL((linear_split_kernel<2, true, true, false, true, true>), dim3((unsigned)(bm * ((n + 127) / 128)), 1u),
                            dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0,
-                           self_src, self_ids, d_mean, self_ld);
+                           self_src, self_ids, d_mean, self_ld, hs_scale);
       else
         hipLaunchKernelGGL((linear_split_kernel<1, true, true, false, true, true>), dim3((unsigned)(bm * ((n + 63) / 64)), 1u),
                            dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc_mean, ldy, (int64_t)0, (int64_t)0,
-                           self_src, self_ids, d_mean, self_ld);
+                           self_src, self_ids, d_mean, self_ld, hs_scale);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
       return GIGL_OK;
     }
@@ -3086,10 +3192,12 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
   if (hs) {
     if (n > 64)
       hipLaunchKernelGGL((linear_split_kernel<2, true, false, false, true, true>), dim3((unsigned)(bm * ((n + 127) / 128)), (unsigned)batch),
-                         dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
+                         dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride,
+                         (const float*)nullptr, (const uint32_t*)nullptr, 0, 0, hs_scale);
     else
       hipLaunchKernelGGL((linear_split_kernel<1, true, false, false, true, true>), dim3((unsigned)(bm * ((n + 63) / 64)), (unsigned)batch),
-                         dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
+                         dim3(256), 0, st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride,
+                         (const float*)nullptr, (const uint32_t*)nullptr, 0, 0, hs_scale);
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     return GIGL_OK;
   }
@@ -3132,10 +3240,10 @@ int32_t gigl_linear_batched(gigl_ctx* ctx, const float* a, const float* w, const
 
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
                           int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y, const float* self_src,
-                          const uint32_t* self_ids, int32_t d_mean, int32_t self_ld, bool half_split, bool self_half) {
+                          const uint32_t* self_ids, int32_t d_mean, int32_t self_ld, const float* hs_scale, bool self_half) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   return linear_tiled_strided(ctx, a_tiled, w, bias, m_dev, m_cap, k, n, act, y, n, 1, 0, 0, self_src, self_ids, d_mean,
-                              self_ld, half_split, self_half);
+                              self_ld, hs_scale, self_half);
 }
 
 int64_t gigl_gat_input_layer_scratch(int32_t d, int32_t heads, int64_t cap_nodes, int64_t rows_cap, int64_t cap_edges) {
@@ -3219,17 +3327,17 @@ int32_t gigl_gat_input_layer_fused(gigl_ctx* ctx, const void* src, int32_t src_d
                                    int32_t act, float* scratch, float* out) {
   return gigl_gat_input_layer_fused_hs(ctx, src, src_dtype, d, gather_ids, n_local_dev, w, att_src, att_dst, heads, channels,
                                        negative_slope, rowptr, rowend, col, n_rows_dev, rows_cap, bias, act, scratch, out,
-                                       false);
+                                       nullptr);
 }
 
-// half_split: the projection of the aggregated rows over two fp16 planes per operand — the rows are convex combinations
-// of table rows (softmax weights), so the table's largest magnitude bounds them; the caller has checked it and the weights'
+// hs_scale != NULL: the projection of the aggregated rows over two fp16 planes per operand — the rows are convex
+// combinations of table rows (softmax weights), so the table's largest magnitude bounds them: s_a comes from it, s_w from the weights'
 int32_t gigl_gat_input_layer_fused_hs(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
                                       const uint32_t* gather_ids, const int32_t* n_local_dev, const float* w,
                                       const float* att_src, const float* att_dst, int32_t heads, int32_t channels,
                                       float negative_slope, const int32_t* rowptr, const int32_t* rowend,
                                       const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
-                                      int32_t act, float* scratch, float* out, bool half_split) {
+                                      int32_t act, float* scratch, float* out, const float* hs_scale) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   GIGL_REQUIRE(ctx, src && gather_ids && w && att_src && att_dst && rowptr && rowend && col && n_rows_dev && scratch && out,
                "null argument");
@@ -3279,5 +3387,5 @@ int32_t gigl_gat_input_layer_fused_hs(gigl_ctx* ctx, const void* src, int32_t sr
     GIGL_HIP_CHECK(ctx, hipGetLastError());
   }
   return linear_tiled_strided(ctx, z, w, bias, n_rows_dev, rows_cap, d, C, act, out, H * C, H, head_stride, (int64_t)C * d,
-                              nullptr, nullptr, 0, 0, half_split);
+                              nullptr, nullptr, 0, 0, hs_scale);
 }

@@ -73,6 +73,7 @@ struct gigl_feat {
   // largest |value| of the table (gigl_feat_absmax, found on first use; < 0: not looked at yet): decides whether the
   // half-split projection applies to operands made of its rows
   float absmax = -1.f;
+  float absmean_nz = 0.f;  // mean |value| over the non-zero values (same pass)
 };
 
 int32_t gigl_fail(gigl_ctx* ctx, int32_t code, const char* fmt, ...);
@@ -131,17 +132,25 @@ int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float
 int32_t gigl_linear_tiled(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
                           int64_t m_cap, int32_t k, int32_t n, int32_t act, float* y, const float* self_src = nullptr,
                           const uint32_t* self_ids = nullptr, int32_t d_mean = 0, int32_t self_ld = 0,
-                          bool half_split = false, bool self_half = false);
-// self_half (with half_split): self_src points at fp16 rows (self_ld halves apart)
-// half_split: operands as two fp16 planes, three MFMAs per accumulator (linear_split_kernel<.., HS>) — the caller
-// guarantees every |operand value| < GIGL_HALF_SPLIT_MAX (gigl_feat_absmax / gigl_dev_absmax_f32)
-constexpr float GIGL_HALF_SPLIT_MAX = 60000.f;
+                          const float* hs_scale = nullptr, bool self_half = false);
+// self_half (with hs_scale): self_src points at fp16 rows (self_ld halves apart)
+// hs_scale != NULL (half split): operands as two fp16 planes, three MFMAs per accumulator (linear_split_kernel<.., HS>);
+// hs_scale = device {s_a, s_w, 1 / (s_a s_w)}: powers of two that bring each operand's largest magnitude into
+// [2^14, 2^15) on its way into the planes, undone in the epilogue (all exact) — written by gigl_hs_scale_update
+// gigl_feat_half_split_scale: *s_a = the power of two for operands made of the table's rows (times `fan` under a sum
+// reduction), or 0 when such operands stay on the bf16 planes (a NaN / inf / all-zero table, a largest magnitude outside
+// [2^-46, 2^74], a table whose typical non-zero magnitude lies 2^10 below its largest, GIGL_GEMM_SPLIT=bf16);
+// looks at the table once (cached in gigl_feat; that first look synchronises the ctx's stream)
+int32_t gigl_feat_half_split_scale(gigl_ctx* ctx, gigl_feat* feat, float fan, float* s_a);
+// hs_dev[0..2] = {s_a, s_w, 1 / (s_a s_w)} with s_w from the largest |w[i]| as the n weights are when the launch runs —
+// one small launch on the ctx's stream, no synchronisation, may be captured
+int32_t gigl_hs_scale_update(gigl_ctx* ctx, const float* w, int64_t n, float s_a, float* hs_dev);
 int32_t gigl_gat_input_layer_fused_hs(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
                                       const uint32_t* gather_ids, const int32_t* n_local_dev, const float* w,
                                       const float* att_src, const float* att_dst, int32_t heads, int32_t channels,
                                       float negative_slope, const int32_t* rowptr, const int32_t* rowend,
                                       const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
-                                      int32_t act, float* scratch, float* out, bool half_split);
+                                      int32_t act, float* scratch, float* out, const float* hs_scale);
 bool gigl_half_split_enabled();  // (GIGL_GEMM_SPLIT=bf16 keeps every projection on the bf16 planes)
 int32_t gigl_dev_absmax_f32(gigl_ctx* ctx, const float* p, int64_t n, float* out);  // synchronises the ctx's stream
 int32_t gigl_feat_absmax(gigl_ctx* ctx, gigl_feat* feat, float* out);

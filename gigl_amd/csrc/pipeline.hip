@@ -41,9 +41,13 @@ struct gigl_sage_plan {
   // projected input (gigl_sage_plan_set_projected_input): [W_l x | W_r x] of EVERY node, [graph nodes][2*dims[1]]
   // fp32, device, borrowed — the first layer is then one gather (+ self row + bias + activation), no projection
   const float* proj = nullptr;
-  // first layer over two fp16 planes per operand (three MFMAs instead of six): the table's and the first layer's
-  // weights' largest magnitudes are known to fit the half range (plan_refresh_half_split: at create / set_weights)
+  // first layer over two fp16 planes per operand (three MFMAs instead of six), each operand brought into the top of the
+  // half range by a power of two: hs_sa from the table's largest magnitude (plan_refresh_half_split: at create /
+  // set_weights / set_aggr; 0 = the table keeps the layer on the bf16 planes), the weights' scale found on the device
+  // at every run from the weights as they are (hs_dev = {s_a, s_w, 1 / (s_a s_w)}, gigl_hs_scale_update)
   bool hs0 = false;
+  float hs_sa = 0.f;
+  float* hs_dev = nullptr;
   // kind 1: GAT layers instead of SAGE layers (gigl_gat_plan_create): w[l] = lin weight [heads*channels][dims[l]],
   // layer 0 from the input side in one row pass (gigl_gat_input_layer_fused), layers >= 1 projection + attention
   int32_t kind = 0;
@@ -95,6 +99,10 @@ __global__ void guard_levels_kernel(int32_t* meta, int hops, int32_t act_rows) {
     for (int l = 0; l < hops; ++l) meta[GIGL_META_LEVEL0 + l] = 0;
     atomicAdd(&meta[GIGL_META_OVERFLOW], 1);
   }
+}
+
+__global__ void overflow_add_kernel(const int32_t* __restrict__ meta, int32_t* __restrict__ acc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && meta[GIGL_META_OVERFLOW] != 0) atomicAdd(acc, 1);
 }
 
 // exact work counts of the last batch set, accumulated into acc[GIGL_STATS_LEN] (see gigl_sage_plan_stats)
@@ -208,9 +216,14 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
     if (l == 0) {
       if (!first) return GIGL_OK;  // (the first layer is one stage: aggregation + both heads' projection)
       const int32_t* n_local = p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr;
+      if (p->hs0) {
+        const int32_t rc = gigl_hs_scale_update(ctx, p->w[0], (int64_t)p->heads[0] * p->channels[0] * d, p->hs_sa, p->hs_dev);
+        if (rc != GIGL_OK) return rc;
+      }
       return gigl_gat_input_layer_fused_hs(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, n_local, p->w[0], p->att_src[0],
                                            p->att_dst[0], p->heads[0], p->channels[0], p->slope, p->un.rowptr, p->un.rowend,
-                                           p->un.col, n_rows, rows_cap, p->bias[0], act, p->gat_scratch, p->hbuf[0], p->hs0);
+                                           p->un.col, n_rows, rows_cap, p->bias[0], act, p->gat_scratch, p->hbuf[0],
+                                           p->hs0 ? p->hs_dev : nullptr);
     }
     // sources of layer l: the rows layer l-1 computed (level <= L-l)
     const int32_t* n_src = p->un.meta + GIGL_META_LEVEL0 + (L - l);
@@ -258,13 +271,19 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
                               p->un.col, n_rows, rows_cap, p->aggr, p->abuf);
   }
   const int act = (l < L - 1 || p->act_last) ? 1 : 0;
+  const float* hs_scale = nullptr;
+  if (l == 0 && p->hs0 && p->tiled) {  // the weights' scale follows the weights as they are now (training rewrites them in place)
+    const int32_t rc = gigl_hs_scale_update(ctx, p->w[0], (int64_t)p->dims[1] * 2 * d, p->hs_sa, p->hs_dev);
+    if (rc != GIGL_OK) return rc;
+    hs_scale = p->hs_dev;
+  }
   if (two_src)
     return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
                              p->hbuf[l & 1], l == 0 ? (const float*)p->feat->rows : p->hbuf[(l - 1) & 1],
-                             l == 0 ? p->un.nodes : nullptr, d, d, l == 0 && p->hs0, self_half);
+                             l == 0 ? p->un.nodes : nullptr, d, d, hs_scale, self_half);
   if (p->tiled)
     return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
-                             p->hbuf[l & 1], nullptr, nullptr, 0, 0, l == 0 && p->hs0);
+                             p->hbuf[l & 1], nullptr, nullptr, 0, 0, hs_scale);
   return gigl_linear(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
                      p->hbuf[l & 1]);
 }
@@ -442,8 +461,9 @@ static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, in
   p->hbuf[1] = hops > 1 ? (float*)alloc((size_t)act_rows * max_out * 4) : p->hbuf[0];
   p->roots_buf = (uint32_t*)alloc((size_t)b * 4);
   p->out_buf = (float*)alloc((size_t)b * dims[hops] * 4);
-  p->zero_dev = (int32_t*)alloc(16);
-  if (p->zero_dev && hipMemset(p->zero_dev, 0, 16) != hipSuccess) ok = false;
+  p->zero_dev = (int32_t*)alloc(32);  // [0]: an int32 0; [4..7): hs_dev
+  if (p->zero_dev && hipMemset(p->zero_dev, 0, 32) != hipSuccess) ok = false;
+  p->hs_dev = p->zero_dev ? reinterpret_cast<float*>(p->zero_dev + 4) : nullptr;
   p->act_rows = act_rows;
   ok = ok && p->zero_dev && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col && p->un.root_local &&
        (p->abuf || !with_abuf) && p->hbuf[0] && p->hbuf[1] && p->roots_buf && p->out_buf;
@@ -535,34 +555,29 @@ int32_t gigl_gat_plan_set_weights(gigl_sage_plan* p, const float* const* w, cons
   return plan_refresh_half_split(p);
 }
 
-// the first layer's operands are rows of the feature table reduced by mean / max (|.| <= the table's largest magnitude)
-// or sum (<= fan-out times it), and the layer's weights: when both fit the half range the layer's projection runs over
-// two fp16 planes per operand.  Looked at when the weights are SET: weights rewritten in place afterwards keep the
-// decision (beyond the range the half planes overflow to inf — the rows come out non-finite, not silently wrong).
+// The first layer's operands are rows of the feature table reduced by mean / max (|.| <= the table's largest magnitude),
+// by sum (<= fan-out times it) or by softmax weights (GAT: convex combinations), and the layer's weights.  The layer's
+// projection runs over two fp16 planes per operand, each operand multiplied by a power of two that puts its largest
+// magnitude into [2^14, 2^15) (undone in the epilogue; all exact): the table's factor is fixed here from the table's
+// cached largest magnitude — or the table keeps the layer on the bf16 planes, see gigl_feat_half_split_scale — and the
+// weights' factor is found on the device at every run.  Nothing here looks at the weights or synchronises (beyond the
+// table's first look), so trainers may call _set_weights every step, also inside a capture.
 static int32_t plan_refresh_half_split(gigl_sage_plan* p) {
   const bool before = p->hs0;
+  const float sa_before = p->hs_sa;
   p->hs0 = false;
-  if (p->kind == 1 && p->feat && p->w[0] && p->gat_scratch && gigl_half_split_enabled()) {
-    // GAT: the first projection's operand rows are softmax-weighted sums of table rows (bounded by the table)
-    float fmax = 0.f, wmax = 0.f;
-    int32_t rc = gigl_feat_absmax(p->ctx, p->feat, &fmax);
+  p->hs_sa = 0.f;
+  const bool gat = p->kind == 1 && p->gat_scratch;
+  const bool sage = p->kind == 0 && p->tiled && p->abuf;  // (SAGE plans own abuf)
+  if ((gat || sage) && p->feat && p->w[0] && p->hs_dev) {
+    float fan = 1.f;  // (a sum over up to `fan-out` rows; mean, max and softmax weights stay inside the table's range)
+    if (sage && p->aggr == GIGL_AGGR_SUM)
+      for (int k = 0; k < p->hops; ++k) fan = (float)p->fanouts[k] > fan ? (float)p->fanouts[k] : fan;
+    const int32_t rc = gigl_feat_half_split_scale(p->ctx, p->feat, fan, &p->hs_sa);
     if (rc != GIGL_OK) return rc;
-    rc = gigl_dev_absmax_f32(p->ctx, p->w[0], (int64_t)p->heads[0] * p->channels[0] * p->dims[0], &wmax);
-    if (rc != GIGL_OK) return rc;
-    p->hs0 = fmax < GIGL_HALF_SPLIT_MAX && wmax < GIGL_HALF_SPLIT_MAX;
+    p->hs0 = p->hs_sa > 0.f;
   }
-  if (p->kind == 0 && p->tiled && p->abuf && p->feat && p->w[0] && gigl_half_split_enabled()) {  // (SAGE plans own abuf)
-    float fmax = 0.f, wmax = 0.f;
-    int32_t rc = gigl_feat_absmax(p->ctx, p->feat, &fmax);
-    if (rc != GIGL_OK) return rc;
-    rc = gigl_dev_absmax_f32(p->ctx, p->w[0], (int64_t)p->dims[1] * 2 * p->dims[0], &wmax);
-    if (rc != GIGL_OK) return rc;
-    int32_t fmax_out = 1;  // (a sum over up to `fan-out` rows; mean and max stay inside the table's range)
-    if (p->aggr == GIGL_AGGR_SUM)
-      for (int k = 0; k < p->hops; ++k) fmax_out = p->fanouts[k] > fmax_out ? p->fanouts[k] : fmax_out;
-    p->hs0 = fmax * (float)fmax_out < GIGL_HALF_SPLIT_MAX && wmax < GIGL_HALF_SPLIT_MAX;
-  }
-  if (p->captured && before != p->hs0) {
+  if (p->captured && (before != p->hs0 || sa_before != p->hs_sa)) {
     hipStreamSynchronize(p->ctx->stream);
     drop_graphs(p);
   }
@@ -662,6 +677,16 @@ int32_t gigl_sage_plan_stats(gigl_sage_plan* p, const uint32_t* roots, int64_t* 
   int64_t blocks = (most + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(plan_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a, (unsigned long long*)acc);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_sage_plan_overflow_add(gigl_sage_plan* p, int32_t* acc) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, acc, "null argument");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(overflow_add_kernel, dim3(1), dim3(64), 0, ctx->stream, p->un.meta, acc);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -1172,6 +1172,12 @@ class SagePlan:
         """the first projection runs over two fp16 planes per operand (gigl_sage_plan_half_split)"""
         return bool(self._lib.gigl_sage_plan_half_split(self._plan))
 
+    def overflow_add(self, acc: torch.Tensor) -> None:
+        """acc (int32 [1], device) += 1 when the batch set run last failed (its rows are NaN): gigl_sage_plan_overflow_add,
+        no synchronisation"""
+        assert acc.is_cuda and acc.dtype == torch.int32 and acc.numel() >= 1
+        check(self._lib.gigl_sage_plan_overflow_add(self._plan, C.c_void_p(acc.data_ptr())), self.eng._ctx)
+
     def use_graph(self, on: bool = True) -> None:
         """replay the batch as one hipGraph launch (captured on the next run)"""
         check(self._lib.gigl_sage_plan_use_graph(self._plan, 1 if on else 0), self.eng._ctx)

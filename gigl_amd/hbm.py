@@ -150,7 +150,12 @@ class ResidentGraph:
         self.engine = eng = HipEngine(self.device.index or 0)
         self.comm = None
         self._plans: Dict[tuple, object] = {}
+        self._overflow_acc: Optional[torch.Tensor] = None  # device int32 [1]: plan calls whose rows came out NaN
         self.sharded = bool(self.world > 1 if sharded is None else (sharded and self.world > 1))
+        if self.sharded and self.mode == MODE_REPLACE:
+            # (the sharded plan samples duplicate-free trees; refused HERE, before anything is built, so that a caller
+            # on the auto route can still fall back to the sampler's files)
+            raise NotImplementedError("sample_with_replacement on a hash-partitioned graph: use the TFRecord route")
         if not self.sharded:
             eng.build_from_coo(n, src, dst, is_directed=directed, keep_multi_edges=multi)
             if need_out_graph:
@@ -186,6 +191,7 @@ class ResidentGraph:
         self.n, self.node_ids, self.labels = int(engine.n_nodes), np.asarray(node_ids, dtype=np.int64), {}
         self.has_in_edge = None
         self.engine, self.comm, self._plans, self.sharded = engine, None, {}, False
+        self._overflow_acc = None
         self.feat_dim, self.node_type, self._order_prefixes = int(engine.feat_dim), node_type, [order_prefix]
         self._borrowed_engine = True
         return self
@@ -294,15 +300,18 @@ class ResidentGraph:
             proj = None
             if len(self.fanouts) == 2 and model.projected_input_pays(self.engine) and \
                     os.environ.get("GIGL_AMD_PROJECT_INPUT", "1") != "0":
-                proj = getattr(self, "_dist_proj", None)
+                cache = self.__dict__.setdefault("_dist_proj", {})  # one projected shard per model
+                proj = cache.get(id(model))
                 if proj is None:
-                    proj = self._dist_proj = self.engine.project_features(w[0])
+                    proj = cache[id(model)] = self.engine.project_features(w[0])
             return DistSagePlan(self.comm, w, bs, groups * b, self.fanouts, act_last=model.activation_after_last_conv,
                                 group_roots=b, max_window_end=self.max_window_end, projected=proj)
         make = getattr(model, "make_plan", None)
         if make is None:
             return None
-        from ._lib import GiglError
+        from ._lib import MODE_REPLACE, GiglError
+        if self.mode == MODE_REPLACE:
+            return None  # the one-call plan needs duplicate-free trees: staged sample -> union -> forward below
         try:
             return make(self.engine, b, self.fanouts, groups=groups)
         except NotImplementedError:
@@ -346,6 +355,11 @@ class ResidentGraph:
                     plan.raise_on_overflow()
                 else:
                     out = plan.run(batch.roots, sampling_seed=self.seed, mode=self.mode)
+                    # a call whose union did not fit its workspace hands out NaN rows: every call's flag is added
+                    # into one device counter (no synchronisation here), read by raise_on_overflow()
+                    if self._overflow_acc is None:
+                        self._overflow_acc = torch.zeros(1, dtype=torch.int32, device=self.device)
+                    plan.overflow_add(self._overflow_acc)
                 return out if batch.valid is None else out.index_select(0, batch.valid)
             outs = []
             for k in range(g):  # staged: sample -> union -> model(HipBatch), one batch at a time
@@ -353,6 +367,18 @@ class ResidentGraph:
                 outs.append(model(hb)[hb.root_local.long()])
             out = torch.cat(outs)
             return out if batch.valid is None else out.index_select(0, batch.valid)
+
+    def raise_on_overflow(self) -> None:
+        """RuntimeError when a one-call plan since the last check failed (a batch's union graph did not fit the plan's
+        workspace — roots that are each other's sampled neighbours, or more than 16,384 distinct in-edges of one node:
+        its rows are NaN).  Synchronises; callers check once per pass, before the rows are declared written."""
+        if self._overflow_acc is None:
+            return
+        n = int(self._overflow_acc.item())
+        self._overflow_acc.zero_()
+        if n:
+            raise RuntimeError(f"{n} plan call(s) overflowed their batch workspace (rows are NaN): rerun with "
+                               "route='tfrecord' or a smaller inference batch size")
 
     def hip_batch(self, roots: torch.Tensor, train: bool = False):
         """sampled trees + the batch union graph of `roots` (int32 device ids) as a models.HipBatch"""
@@ -436,24 +462,28 @@ class GraphedTrainStep:
             optimizer.step()
             return loss
 
-        with torch.cuda.stream(self.stream):
-            for _ in range(3):
-                body()
-        self.stream.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            self.loss = body()
-        self.stream.synchronize()
-        model.load_state_dict(saved_model)
-        # the optimiser's state tensors are part of the captured graph: put them back IN PLACE (moments and step counter
-        # to what they were before the warm-up — zeros for a fresh optimiser)
-        with torch.no_grad():
-            for p, st in optimizer.state.items():
-                for k, v in st.items():
-                    if torch.is_tensor(v):
-                        old = saved_opt.get(p, {}).get(k)
-                        v.copy_(old) if old is not None else v.zero_()
-        torch.cuda.synchronize(dev)
+        try:
+            with torch.cuda.stream(self.stream):
+                for _ in range(3):
+                    body()
+            self.stream.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.loss = body()
+            self.stream.synchronize()
+        finally:
+            # whether or not the capture succeeded, the warm-up must not have trained: the model and the optimiser's
+            # state tensors (part of the captured graph) go back IN PLACE to what they were — moments and step counter
+            # zero for a fresh optimiser — so that an eager fallback starts from the same state
+            torch.cuda.synchronize(dev)
+            model.load_state_dict(saved_model)
+            with torch.no_grad():
+                for p, st in optimizer.state.items():
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            old = saved_opt.get(p, {}).get(k)
+                            v.copy_(old) if old is not None else v.zero_()
+            torch.cuda.synchronize(dev)
 
     def _set(self, roots: torch.Tensor, labels: torch.Tensor) -> None:
         k = int(roots.numel())

@@ -218,6 +218,8 @@ class Inferencer:
             res = inferencer.infer_batch(batch=hb, device=dev)
             if hb.root_ids.size:
                 writer.add(hb.root_ids, res.embeddings, res.predictions, ids_dev=hb.root_ids_dev)
+        if hasattr(resident, "raise_on_overflow"):
+            resident.raise_on_overflow()  # (a failed call's rows are NaN: the pass must not end quietly)
 
 
 def _typed_run(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str, str]:

@@ -235,7 +235,8 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
         _train over batches sampled in HBM, without the host between them).  Single process only (DistributedDataParallel
         hooks its all-reduce into the backward pass); None = not applicable, the caller runs the eager loop."""
         import os
-        if os.environ.get("GIGL_AMD_TRAIN_GRAPH", "1") == "0" or _rank_world()[1] > 1 or hasattr(self.model, "module"):
+        if os.environ.get("GIGL_AMD_TRAIN_GRAPH", "1") == "0" or _rank_world()[1] > 1 or hasattr(self.model, "module") or \
+                getattr(self, "_graph_capture_failed", False):
             return None
         hbm = self._hbm_split(cfg)
         if hbm is None:
@@ -254,7 +255,7 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
             except Exception as exc:  # noqa: BLE001 — the eager loop is the same step
                 import warnings
                 warnings.warn(f"training step not captured ({type(exc).__name__}: {exc}); running it eagerly", RuntimeWarning)
-                os.environ["GIGL_AMD_TRAIN_GRAPH"] = "0"
+                self._graph_capture_failed = True  # (this spec instance only)
                 res.engine.bind_stream(torch.cuda.current_stream(device))
                 return None
             self._graphed_step = step

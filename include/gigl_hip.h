@@ -940,13 +940,23 @@ int32_t gigl_sage_plan_set_aggr(gigl_sage_plan* plan, int32_t aggr);
 int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* w_fused, int32_t n_out, float* out);
 int32_t gigl_sage_plan_set_projected_input(gigl_sage_plan* plan, const float* proj);
 /* 1 when the plan's first projection runs over TWO fp16 planes per operand (x = h1 + h2, three MFMAs per accumulator
- * instead of the six of the three-bf16-plane split: same 1e-5 parity class, 2^-22 relative per product) — chosen by
- * the library at create / set_weights / set_aggr when the feature table's largest magnitude (times the largest fan-out, for a
- * sum reduction) and the first layer's weights' lie inside the fp16 range (< 60000); GIGL_GEMM_SPLIT=bf16 in the
- * environment keeps every projection on the bf16 planes.  Weights rewritten in place keep the decision: call
- * gigl_sage_plan_set_weights again after an update that may leave the range (beyond it the rows come out non-finite).
- * GAT plans (gigl_gat_plan_create / _set_weights) take the same decision for their first layer's projection. */
+ * instead of the six of the three-bf16-plane split: same 1e-5 parity class, 2^-22 relative per product).  fp16's range
+ * is narrow on both sides, so each operand is multiplied by a power of two that brings its largest magnitude into
+ * [2^14, 2^15) on its way into the planes and the accumulators are multiplied by the inverse in the epilogue (all
+ * exact): the element error is max(2^-22 |x|, 2^-39 max|x|) whatever the operand's scale.  The table's factor is fixed
+ * at create / set_weights / set_aggr from the feature table's largest magnitude (times the largest fan-out, for a sum
+ * reduction; looked at once per table); the WEIGHTS' factor is found on the device at every run from the weights as
+ * they are, so weights rewritten in place (a training loop) need no call and gigl_sage_plan_set_weights neither reads
+ * the weights nor synchronises.  0 = bf16 planes: a table with a NaN / inf, an all-zero table, a largest magnitude
+ * outside [2^-46, 2^74], a table whose typical non-zero magnitude lies more than 2^10 below its largest (outlier-
+ * dominated: most elements would sit next to the subnormal halves), shapes outside the tiled projection, or
+ * GIGL_GEMM_SPLIT=bf16 in the environment.  GAT plans (gigl_gat_plan_create / _set_weights) take the same decision for
+ * their first layer's projection. */
 int32_t gigl_sage_plan_half_split(gigl_sage_plan* plan);
+/* *acc (DEVICE int32, caller-zeroed) += 1 when the batch set the plan ran LAST failed (meta[GIGL_META_OVERFLOW] != 0:
+ * its rows are NaN) — enqueued on the ctx stream, no synchronisation: callers that stream many calls add every call's
+ * flag into one counter and read it once (gigl_amd/hbm.py) */
+int32_t gigl_sage_plan_overflow_add(gigl_sage_plan* plan, int32_t* acc);
 int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
 int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);

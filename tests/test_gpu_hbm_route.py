@@ -336,3 +336,72 @@ class _nullcontext:
 
     def __exit__(self, *exc):
         return False
+
+
+@pytest.mark.gpu
+def test_sample_with_replacement_takes_the_staged_forward_on_the_hbm_route(golden_dir, tmp_path):
+    """experimentalFlags.sample_with_replacement = true (SGSPureSparkV1Task.scala:42-50,355-364): the one-call plan needs
+    duplicate-free trees, so the in-HBM route runs such a job through the staged sample -> union -> forward instead of
+    raising, and writes the rows the TFRecord route writes (same seed, same draws)"""
+    from gigl_amd.inferencer import Inferencer
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    from gigl_amd.trainer import Trainer
+    base = str(tmp_path)
+    shutil.copytree(os.path.join(golden_dir, "configs"), os.path.join(base, "configs"))
+    shutil.copytree(os.path.join(golden_dir, "ref_assets"), os.path.join(base, "ref_assets"))
+    doc = yaml.safe_load(open(os.path.join(base, SNC)))
+    doc["datasetConfig"]["subgraphSamplerConfig"].setdefault("experimentalFlags", {})["sample_with_replacement"] = "true"
+    yaml.safe_dump(doc, open(os.path.join(base, SNC), "w"))
+    SubgraphSampler().run("job", SNC, None, uri_base=base)
+    torch.manual_seed(1)
+    Trainer().run("job", SNC, None, uri_base=base)
+    a, b = Inferencer(), Inferencer()
+    out_t = a.run("job", _variant(base, SNC, "tf"), None, uri_base=base, route="tfrecord")
+    out_h = b.run("job", _variant(base, SNC, "auto"), None, uri_base=base)
+    assert b.route == "hbm" and a.rows_written == b.rows_written == 16
+    rt, rh = _rows(out_t["embeddings"]), _rows(out_h["embeddings"])
+    assert [r["node_id"] for r in rt] == [r["node_id"] for r in rh]
+    np.testing.assert_allclose(np.array([r["emb"] for r in rh], np.float32), np.array([r["emb"] for r in rt], np.float32),
+                               rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_overflowed_plan_calls_are_reported_by_the_hbm_route():
+    """a root that is its own sampled neighbour makes the children of that occurrence inner-level nodes: with b = 1,
+    fanout [64, 64] the batch does not fit the plan's activation workspace (tests/test_gpu_plan.py): the call's rows are
+    NaN and ResidentGraph.raise_on_overflow reports it (the Inferencer checks at the end of a pass)"""
+    import oracle
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.hbm import ResidentGraph
+    from gigl_amd.models import GraphSAGE
+    n, d = 400, 8
+    found = None
+    for r in range(1, 200):
+        nbrs = np.unique(np.concatenate([[r], np.arange(200, 320)])).astype(np.uint32)
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        rowptr[r + 1:] = nbrs.size
+        nbr_o, _ = oracle.sample_khop(rowptr, nbrs, np.array([r], np.uint32), [64, 64], canonical=True)
+        if r in nbr_o[0] and int(oracle.union_build(np.array([r], np.uint32), [64, 64], nbr_o)["meta"][3]) > 65:
+            found = (r, rowptr, nbrs)
+            break
+    assert found is not None
+    r, rowptr, col = found
+    eng = HipEngine(0)
+    try:
+        eng.load_csc(rowptr, col)
+        eng.load_features(np.random.default_rng(0).standard_normal((n, d)).astype(np.float32))
+        res = ResidentGraph.from_engine(eng, np.arange(n), [64, 64])
+        torch.manual_seed(0)
+        model = GraphSAGE(d, 8, 4, num_layers=2).to(eng.device)
+        (hb,) = list(res.root_batches(np.array([r]), 1, 1))
+        out = res.encode(model, hb)
+        assert torch.isnan(out).all()
+        with pytest.raises(RuntimeError, match="overflowed"):
+            res.raise_on_overflow()
+        res.raise_on_overflow()  # (the counter was reset)
+        (ok,) = list(res.root_batches(np.array([r + 200 if r + 200 < n else 201]), 1, 1))
+        assert torch.isfinite(res.encode(model, ok)).all()
+        res.raise_on_overflow()
+        res.close()
+    finally:
+        eng.close()

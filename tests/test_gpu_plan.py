@@ -197,10 +197,12 @@ def test_plan_in_two_parts_equals_the_one_call(setup):
 
 
 def test_first_layer_half_split_is_bounded_by_the_operands(setup):
-    """gigl_sage_plan_half_split: the first projection runs over two fp16 planes per operand (three MFMAs instead of six)
-    only when the table's and the weights' largest magnitudes fit the fp16 range.  On the unit-scale fixture it is on and
-    within 1e-5 of the fp64 forward of the same batch; on a table scaled past the range (and with weights scaled past it)
-    the plan stays on the bf16 planes and keeps the same relative accuracy"""
+    """gigl_sage_plan_half_split: the first projection runs over two fp16 planes per operand (three MFMAs instead of
+    six), each operand pre-scaled by a power of two (table: from its largest magnitude; weights: found on the device at
+    every run) and the scales undone in the epilogue — so the layer stays within 1e-5 of the fp64 forward of the same
+    batch whatever the operands' scale: table x 1e-4 / x 1e6, weights x 1e-3 / x 1e6, one column x 1e-5, weights
+    rewritten in place between runs.  A table dominated by a few outliers (typical magnitude 2^10 below the largest)
+    keeps the bf16 planes, and `half_split()` tells"""
     from gigl_amd.engine import HipEngine
     from gigl_amd.models import GraphSAGE
     from oracle import gnn_ref
@@ -212,45 +214,90 @@ def test_first_layer_half_split_is_bounded_by_the_operands(setup):
     o = oracle.union_build(roots, fan, nbr_o)
     ei = gnn_ref.union_edge_index(o["rowptr"], o["col"])
 
-    def check(engine, feats, model, expect_half, rtol):
-        plan = model.make_plan(engine, b, fan)
-        assert plan.half_split() == expect_half
+    def run_check(plan, engine, feats, model, rtol):
         out = plan.run(torch.from_numpy(roots.view(np.int32)).to(engine.device)).double().cpu().numpy()
         sd = {k: v.detach().cpu().double() for k, v in model.state_dict().items()}
         want = gnn_ref.graphsage_forward(torch.from_numpy(feats[o["nodes"]]).double(), ei, sd, 2)[o["root_local"]].numpy()
         scale = np.abs(want).max()
+        assert np.isfinite(out).all()
         assert np.abs(out - want).max() <= rtol * scale, (np.abs(out - want).max(), scale)
-        plan.close()
         return np.abs(out - want).max() / scale
 
-    model = GraphSAGE(100, 256, 64, num_layers=2).to(eng.device)
-    err_half = check(eng, x, model, True, 1e-5)
-    # weights past the range: the decision is taken again when they are set
-    big_w = GraphSAGE(100, 256, 64, num_layers=2).to(eng.device)
-    with torch.no_grad():
-        big_w.conv_layers[0].lin_l.weight.mul_(1e6)
-    check(eng, x, big_w, False, 1e-5)
-    # a table past the range
-    eng2 = HipEngine(0)
-    try:
-        eng2.load_csc(rowptr, col)
-        x_big = (x * 1e6).astype(np.float32)
-        eng2.load_features(x_big)
-        check(eng2, x_big, model, False, 1e-5)
-    finally:
-        eng2.close()
+    def check(engine, feats, model, expect_half, rtol=1e-5):
+        plan = model.make_plan(engine, b, fan)
+        assert plan.half_split() == expect_half
+        err = run_check(plan, engine, feats, model, rtol)
+        plan.close()
+        return err
+
+    def on_table(feats, model, expect_half, rtol=1e-5):
+        e = HipEngine(0)
+        try:
+            e.load_csc(rowptr, col)
+            e.load_features(feats)
+            return check(e, feats, model, expect_half, rtol)
+        finally:
+            e.close()
+
+    def fresh(scale_w=None):
+        m = GraphSAGE(100, 256, 64, num_layers=2).to(eng.device)
+        if scale_w is not None:
+            with torch.no_grad():
+                m.conv_layers[0].lin_l.weight.mul_(scale_w)
+                m.conv_layers[0].lin_r.weight.mul_(scale_w)
+        return m
+
+    model = fresh()
+    err_half = check(eng, x, model, True)
     assert err_half < 3e-6  # (what the two-plane split leaves: ~2^-22 per product)
-    # a sum over up to 15 rows of a table that reaches 5,000: past the range as a sum, inside it as a mean
+    # weights far above / far below the half range: the scale is found from the weights on the device
+    assert check(eng, x, fresh(1e6), True) < 3e-6
+    assert check(eng, x, fresh(1e-3), True) < 3e-6
+    assert check(eng, x, fresh(1e-7), True) < 3e-6
+    # tables far above / far below the half range
+    assert on_table((x * 1e6).astype(np.float32), model, True) < 3e-6
+    assert on_table((x * 1e-4).astype(np.float32), model, True) < 3e-6
+    assert on_table((x * 1e-9).astype(np.float32), model, True) < 3e-6
+    # one column five orders of magnitude below the others
+    x_mixed = x.copy()
+    x_mixed[:, 7] *= 1e-5
+    assert on_table(x_mixed, model, True) < 3e-6
+    # small table AND small weights together
+    assert on_table((x * 1e-4).astype(np.float32), fresh(1e-3), True) < 3e-6
+    # a few outliers six orders above the typical magnitude: the bf16 planes (fp32's range and per-element precision)
+    x_out = x.copy()
+    x_out[5, 3] = 4e6
+    on_table(x_out, model, False)
+    # weights rewritten IN PLACE between runs of one plan (a training loop): the device-side scale follows them
+    m2 = fresh()
+    plan = m2.make_plan(eng, b, fan)
+    assert plan.half_split()
+    run_check(plan, eng, x, m2, 1e-5)
+    with torch.no_grad():
+        m2.conv_layers[0].lin_l.weight.mul_(3e-4)
+        m2.conv_layers[0].lin_r.weight.mul_(3e-4)
+    assert run_check(plan, eng, x, m2, 1e-5) < 3e-6
+    with torch.no_grad():
+        m2.conv_layers[0].lin_l.weight.mul_(1e9)
+        m2.conv_layers[0].lin_r.weight.mul_(1e9)
+    assert run_check(plan, eng, x, m2, 1e-5) < 3e-6
+    plan.close()
+    # a sum over up to 15 rows of a table that reaches 5,000: the table's scale accounts for the fan-out
     eng3 = HipEngine(0)
     try:
         eng3.load_csc(rowptr, col)
         x_mid = (x * (5000.0 / np.abs(x).max())).astype(np.float32)
         eng3.load_features(x_mid)
-        plan = model.make_plan(eng3, b, fan)
+        m_sum = GraphSAGE(100, 256, 64, num_layers=2, aggr="sum").to(eng3.device)
+        plan = m_sum.make_plan(eng3, b, fan)
         assert plan.half_split()
-        plan.close()
-        plan = GraphSAGE(100, 256, 64, num_layers=2, aggr="sum").to(eng3.device).make_plan(eng3, b, fan)
-        assert not plan.half_split()
+        out = plan.run(torch.from_numpy(roots.view(np.int32)).to(eng3.device))
+        assert torch.isfinite(out).all()
+        from gigl_amd.models import HipBatch
+        tree = eng3.sample_khop(roots, fan)
+        u = eng3.union_build(tree)
+        want = m_sum(HipBatch(eng3, tree, u))[u.root_local[:b].long()]
+        assert (out - want).abs().max() <= 1e-5 * want.abs().max()
         plan.close()
     finally:
         eng3.close()
