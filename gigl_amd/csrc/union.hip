@@ -1636,6 +1636,696 @@ int32_t union_build_lg2(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   return GIGL_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// "LG3": the leaf-global two-hop build with the node dedup staged in LDS (round 4).
+//
+// LG2 keeps one open-addressing table of 16-byte slots per batch in HBM: every inner stream position costs a scattered
+// 64-bit atomic to claim / lower its slot, and the counting, numbering and fill passes each pay one or two dependent
+// random 16-byte reads per position (plus a probe sequence per extra child) to get back to it.  The table was 2-8 % of
+// the HBM roofline by bytes and a quarter of the step's kernel time — bound by those dependent accesses.
+//
+// Here the table lives in LDS for the one pass that needs a hash table at all:
+//   * lg3_dedup_kernel: a batch's keys are split by hash bits over P workgroups; each holds its share in a table of
+//     4-byte slots [11-bit fingerprint | 20-bit stream code of the first occurrence | 1 bit "occurs once"] — claim by
+//     ds_cmpst, later occurrences by ds_min (smaller code wins) + ds_and (clears "once"); a fingerprint match is
+//     verified against the stream itself (the id at the slot's code: a cached read), so the set is exact.  Every
+//     workgroup streams the batch's whole inner stream (roots, hop-0 slots; L2-resident, just written by the sampler)
+//     and keeps its own share; the batch's roots also go into a small exact LDS set, so "this hop-0 node is a root"
+//     — whose children are inner nodes too, the extras — is known without the table of another workgroup.
+//     What leaves the kernel is indexed by STREAM POSITION, not by hash: fpw[t] = code of the first occurrence of the
+//     node at inner position t (| bit 31: the node occurs more than once), fpx[p * f1 + j] likewise for the children
+//     of root-valued hop-0 slots, the sizes of the rows that need storage (rowcnt[first position], a few global
+//     atomics per batch), and the per-1024-tile counts of first occurrences (the last workgroup to finish turns
+//     them into prefixes).  insert + extras + count of LG2 in one launch, no HBM table, nothing to clear but rowcnt.
+//   * lg3_assign_kernel / lg3_fill_kernel: LG2's numbering and fill with every `slots[find(id)]` replaced by an array
+//     read at a known position.  Numbering order, row order and every output are LG2's, bit for bit
+//     (GIGL_UNION_LG2=1 in the environment keeps LG2 for A/B runs; shapes whose per-batch stream does not fit 20-bit
+//     codes or 16 partitions fall back to it).
+constexpr int LG3_CODE_BITS = 20;
+constexpr uint32_t LG3_CODE_MASK = (1u << LG3_CODE_BITS) - 1u;
+constexpr uint32_t LG3_EMPTY = 0xFFFFFFFFu;
+constexpr int32_t LG3_XTAG = 1 << 30;  // fpx entry that has become (local id | LG3_XTAG): an extra that is a first occurrence
+constexpr int LG3_MAX_PARTS = 16;
+
+struct Lg3Args {
+  const uint32_t* roots;
+  const uint32_t* nbr0;
+  const uint32_t* nbr1;
+  const int32_t* cnt0;
+  const int32_t* cnt1;
+  int32_t b, f0, f1;
+  int64_t S0;        // b * f0
+  int32_t gr;        // roots per batch (== b: one batch)
+  int32_t S0g;       // gr * f0
+  int32_t Tg;        // gr * (1 + f0): codes of a batch's inner stream; the extra (pl, j) has code Tg + pl * f1 + j
+  int32_t n_groups;
+  int32_t P;         // hash partitions (workgroups) per batch
+  uint32_t cmask;    // LDS table slots - 1
+  uint32_t rmask;    // root set slots - 1
+  int32_t rs_shift;  // 32 - log2(root set slots)
+  int32_t* fpw;      // [b + S0] by global inner position: code of the node's first occurrence | multi << 31; -1: no node
+  int32_t* fpx;      // [S0 * f1] by (global hop-0 slot, child): the same for extras; first occurrences become lid | LG3_XTAG
+  int32_t* lid_in;   // [b + S0] local id, by the global inner position of the node's FIRST occurrence
+  int32_t* rowcnt;   // [b + S0] entries of the node's row before dedup, by the same index (zeroed per call)
+  int32_t alias_base;
+  int32_t whole_rows;
+  int32_t* overflow;
+};
+
+__device__ __forceinline__ uint32_t lg3_part(uint32_t h32, int P) { return (uint32_t)(((uint64_t)h32 * (uint32_t)P) >> 32); }
+
+// id at group-local stream code `code` of batch grp
+__device__ __forceinline__ uint32_t lg3_key_at(const Lg3Args& a, int32_t grp, uint32_t code) {
+  if (code < (uint32_t)a.gr) return a.roots[(int64_t)grp * a.gr + code];
+  if (code < (uint32_t)a.Tg) return a.nbr0[(int64_t)grp * a.S0g + (code - a.gr)];
+  return a.nbr1[(int64_t)grp * a.S0g * a.f1 + (code - a.Tg)];
+}
+
+// global inner position (index into fpw / lid_in / rowcnt) of an INNER code of batch grp
+__device__ __forceinline__ int64_t lg3_gpos(const Lg3Args& a, int32_t grp, uint32_t code) {
+  return code < (uint32_t)a.gr ? (int64_t)grp * a.gr + code : (int64_t)a.b + (int64_t)grp * a.S0g + (code - a.gr);
+}
+
+// batch and group-local code of global inner position t
+__device__ __forceinline__ void lg3_locate(const Lg3Args& a, int64_t t, int32_t& grp, uint32_t& code) {
+  if (t < a.b) {
+    grp = a.n_groups == 1 ? 0 : (int32_t)((uint32_t)t / (uint32_t)a.gr);
+    code = (uint32_t)(t - (int64_t)grp * a.gr);
+  } else {
+    const uint32_t p = (uint32_t)(t - a.b);
+    grp = a.n_groups == 1 ? 0 : (int32_t)(p / (uint32_t)a.S0g);
+    code = (uint32_t)a.gr + (p - (uint32_t)grp * (uint32_t)a.S0g);
+  }
+}
+
+__device__ __forceinline__ bool lg3_insert(uint32_t* table, const Lg3Args& a, int32_t grp, uint32_t id, uint32_t h32,
+                                           uint32_t code) {
+  const uint32_t fpr = (h32 >> 14) & 0x7FFu;
+  const uint32_t mine1 = (fpr << 21) | (code << 1) | 1u, mine0 = mine1 & ~1u;
+  uint32_t s = h32 & a.cmask;
+  for (uint32_t probes = 0; probes <= a.cmask; ++probes) {
+    uint32_t w = table[s];
+    if (w == LG3_EMPTY) {
+      w = atomicCAS(&table[s], LG3_EMPTY, mine1);
+      if (w == LG3_EMPTY) return true;
+    }
+    // (the slot's key never changes; its code only goes down: any code read here names an occurrence of that key)
+    if ((w >> 21) == fpr && lg3_key_at(a, grp, (w >> 1) & LG3_CODE_MASK) == id) {
+      atomicMin(&table[s], mine0);  // same fingerprint: the smaller code wins; "once" is cleared either way
+      atomicAnd(&table[s], ~1u);
+      return true;
+    }
+    s = (s + 1) & a.cmask;
+  }
+  return false;
+}
+
+// the slot word of `id` (LG3_EMPTY: not in the table — only after an overflow); mycode: the caller's own code (a slot
+// that names it needs no verification read)
+__device__ __forceinline__ uint32_t lg3_lookup(const uint32_t* table, const Lg3Args& a, int32_t grp, uint32_t id,
+                                               uint32_t h32, uint32_t mycode) {
+  const uint32_t fpr = (h32 >> 14) & 0x7FFu;
+  uint32_t s = h32 & a.cmask;
+  for (uint32_t probes = 0; probes <= a.cmask; ++probes) {
+    const uint32_t w = table[s];
+    if (w == LG3_EMPTY) return LG3_EMPTY;
+    if ((w >> 21) == fpr) {
+      const uint32_t c = (w >> 1) & LG3_CODE_MASK;
+      if (c == mycode || lg3_key_at(a, grp, c) == id) return w;
+    }
+    s = (s + 1) & a.cmask;
+  }
+  return LG3_EMPTY;
+}
+
+__device__ __forceinline__ bool lg3_rset_has(const uint32_t* rset, const Lg3Args& a, uint32_t id, uint32_t h32) {
+  uint32_t s = (h32 * 0x9E3779B1u) >> a.rs_shift;
+  for (;;) {  // (load factor <= 1/2: an empty slot ends every probe sequence)
+    const uint32_t k = rset[s];
+    if (k == id) return true;
+    if (k == GIGL_INVALID) return false;
+    s = (s + 1) & a.rmask;
+  }
+}
+
+// an occurrence with c < f1 children sampled its node's WHOLE in-neighbourhood: the list is taken once, from the node's
+// first occurrence — or from every occurrence when the node is a root (lg2_contributes)
+__device__ __forceinline__ bool lg3_contributes(const Lg3Args& a, uint32_t first_code, uint32_t my_code, int c) {
+  if (c >= a.f1 || !a.whole_rows) return true;
+  return first_code == my_code || first_code < (uint32_t)a.gr;
+}
+
+__global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* tile_counts, int32_t n_tiles,
+                                                         int32_t* ticket) {
+  extern __shared__ uint32_t lg3_lds[];
+  uint32_t* table = lg3_lds;                   // [cmask + 1]
+  uint32_t* rset = table + (a.cmask + 1u);     // [rmask + 1]
+  int32_t* tcnt = reinterpret_cast<int32_t*>(rset + (a.rmask + 1u));  // [nt_r + nt_h][2]
+  __shared__ int32_t s_last;
+  __shared__ int32_t s_w[16][2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // the P workgroups of a batch read the same stream: ids that are consecutive mod 8 share an XCD's L2
+  uint32_t vid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0) vid = (blockIdx.x >> 3) + (blockIdx.x & 7u) * (gridDim.x >> 3);
+  const int32_t grp = (int32_t)(vid / (uint32_t)a.P);
+  const int q = (int)(vid % (uint32_t)a.P);
+  const int64_t r0 = (int64_t)grp * a.gr, p0 = (int64_t)grp * a.S0g;
+  const int32_t tile_lo_r = (int32_t)(r0 >> 10), nt_r = (int32_t)((r0 + a.gr - 1) >> 10) - tile_lo_r + 1;
+  const int32_t tile_lo_h = (int32_t)((a.b + p0) >> 10), nt_h = (int32_t)((a.b + p0 + a.S0g - 1) >> 10) - tile_lo_h + 1;
+  for (uint32_t i = tid; i <= a.cmask; i += 1024) table[i] = LG3_EMPTY;
+  for (uint32_t i = tid; i <= a.rmask; i += 1024) rset[i] = GIGL_INVALID;
+  for (int i = tid; i < 2 * (nt_r + nt_h); i += 1024) tcnt[i] = 0;
+  __syncthreads();
+  int32_t over = 0;
+  // ---- roots: all of them into the root set, this partition's into the table
+  for (int32_t tl = tid; tl < a.gr; tl += 1024) {
+    const uint32_t id = a.roots[r0 + tl];
+    if (id == GIGL_INVALID) continue;
+    const uint32_t h = hash_u32(id);
+    uint32_t s = (h * 0x9E3779B1u) >> a.rs_shift;
+    for (;;) {
+      const uint32_t prev = atomicCAS(&rset[s], GIGL_INVALID, id);
+      if (prev == GIGL_INVALID || prev == id) break;
+      s = (s + 1) & a.rmask;
+    }
+    if ((int)lg3_part(h, a.P) == q && !lg3_insert(table, a, grp, id, h, (uint32_t)tl)) ++over;
+  }
+  __syncthreads();
+  // ---- hop-0 slots, and the children of those whose node is a root (extras)
+  for (int32_t pl = tid; pl < a.S0g; pl += 1024) {
+    const uint32_t id = a.nbr0[p0 + pl];
+    if (id == GIGL_INVALID) continue;
+    const uint32_t h = hash_u32(id);
+    if ((int)lg3_part(h, a.P) == q && !lg3_insert(table, a, grp, id, h, (uint32_t)(a.gr + pl))) ++over;
+    if (lg3_rset_has(rset, a, id, h)) {
+      const int c = a.cnt1[p0 + pl];
+      const uint32_t* kids = a.nbr1 + (p0 + pl) * a.f1;
+      for (int j = 0; j < c; ++j) {
+        const uint32_t cid = kids[j];
+        const uint32_t ch = hash_u32(cid);
+        if ((int)lg3_part(ch, a.P) == q && !lg3_insert(table, a, grp, cid, ch, (uint32_t)(a.Tg + pl * a.f1 + j))) ++over;
+      }
+    }
+  }
+  if (over) atomicAdd(a.overflow, over);
+  __syncthreads();
+  // ---- what the later passes need, by stream position
+  for (int32_t tl = tid; tl < a.gr; tl += 1024) {
+    const uint32_t id = a.roots[r0 + tl];
+    if (id == GIGL_INVALID) {
+      if (q == 0) a.fpw[r0 + tl] = -1;
+      continue;
+    }
+    const uint32_t h = hash_u32(id);
+    if ((int)lg3_part(h, a.P) != q) continue;
+    const uint32_t w = lg3_lookup(table, a, grp, id, h, (uint32_t)tl);
+    if (w == LG3_EMPTY) {
+      a.fpw[r0 + tl] = -1;
+      continue;
+    }
+    const uint32_t code = (w >> 1) & LG3_CODE_MASK;
+    a.fpw[r0 + tl] = (int32_t)(code | ((w & 1u) ? 0u : 0x80000000u));
+    if (code == (uint32_t)tl) atomicAdd(&tcnt[2 * (int)(((r0 + tl) >> 10) - tile_lo_r) + 0], 1);
+    // the valid hop-0 slots of this root position are entries of its node's row
+    const int c0 = a.cnt0[r0 + tl];
+    if (c0 > 0) atomicAdd(&a.rowcnt[r0 + code], c0);
+  }
+  for (int32_t pl = tid; pl < a.S0g; pl += 1024) {
+    const uint32_t id = a.nbr0[p0 + pl];
+    if (id == GIGL_INVALID) {
+      if (q == 0) a.fpw[a.b + p0 + pl] = -1;
+      continue;
+    }
+    const uint32_t h = hash_u32(id);
+    const uint32_t mycode = (uint32_t)(a.gr + pl);
+    const int c = a.cnt1[p0 + pl];
+    if ((int)lg3_part(h, a.P) == q) {
+      const uint32_t w = lg3_lookup(table, a, grp, id, h, mycode);
+      if (w == LG3_EMPTY) {
+        a.fpw[a.b + p0 + pl] = -1;
+      } else {
+        const uint32_t code = (w >> 1) & LG3_CODE_MASK;
+        const bool multi = !(w & 1u);
+        a.fpw[a.b + p0 + pl] = (int32_t)(code | (multi ? 0x80000000u : 0u));
+        if (code == mycode) atomicAdd(&tcnt[2 * (nt_r + (int)(((a.b + p0 + pl) >> 10) - tile_lo_h)) + 1], 1);
+        // the children of a node that occurs more than once go to that node's row (a node that occurs once keeps its
+        // tree segment as its row)
+        if ((multi || a.alias_base < 0) && c > 0 && lg3_contributes(a, code, mycode, c))
+          atomicAdd(&a.rowcnt[lg3_gpos(a, grp, code)], c);
+      }
+    }
+    if (lg3_rset_has(rset, a, id, h)) {
+      const uint32_t* kids = a.nbr1 + (p0 + pl) * a.f1;
+      for (int j = 0; j < c; ++j) {
+        const uint32_t cid = kids[j];
+        const uint32_t ch = hash_u32(cid);
+        if ((int)lg3_part(ch, a.P) != q) continue;
+        const uint32_t xcode = (uint32_t)(a.Tg + pl * a.f1 + j);
+        const uint32_t w = lg3_lookup(table, a, grp, cid, ch, xcode);
+        int32_t out = -1;
+        if (w != LG3_EMPTY) {
+          const uint32_t code = (w >> 1) & LG3_CODE_MASK;
+          out = (int32_t)(code | ((w & 1u) ? 0u : 0x80000000u));
+          // (an extra that is a first occurrence is numbered by the thread of its parent slot: counted in its tile)
+          if (code == xcode) atomicAdd(&tcnt[2 * (nt_r + (int)(((a.b + p0 + pl) >> 10) - tile_lo_h)) + 1], 1);
+        }
+        a.fpx[(p0 + pl) * a.f1 + j] = out;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * (nt_r + nt_h); i += 1024) {
+    const int32_t v = tcnt[i];
+    if (v) {
+      const int k = i >> 1;
+      const int32_t tile = k < nt_r ? tile_lo_r + k : tile_lo_h + (k - nt_r);
+      atomicAdd(&tile_counts[tile * 2 + (i & 1)], v);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();  // the counts are visible device-wide before the ticket is taken
+    s_last = atomicAdd(ticket, 1) == (int32_t)gridDim.x - 1 ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // exclusive prefix over the tiles, 1024 tiles per round, both levels (row n_tiles = totals)
+  int32_t run0 = 0, run1 = 0;
+  for (int32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
+    const int32_t i = t0 + tid;
+    const int32_t v0 = i < n_tiles ? __hip_atomic_load(&tile_counts[i * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const int32_t v1 = i < n_tiles ? __hip_atomic_load(&tile_counts[i * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    int32_t i0 = v0, i1 = v1;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t o0 = __shfl_up(i0, off, 64), o1 = __shfl_up(i1, off, 64);
+      if (lane >= off) {
+        i0 += o0;
+        i1 += o1;
+      }
+    }
+    if (lane == 63) {
+      s_w[wv][0] = i0;
+      s_w[wv][1] = i1;
+    }
+    __syncthreads();
+    int32_t w0 = 0, w1 = 0, tot0 = 0, tot1 = 0;
+    for (int k = 0; k < 16; ++k) {
+      if (k < wv) {
+        w0 += s_w[k][0];
+        w1 += s_w[k][1];
+      }
+      tot0 += s_w[k][0];
+      tot1 += s_w[k][1];
+    }
+    if (i < n_tiles) {
+      tile_counts[i * 2 + 0] = run0 + w0 + i0 - v0;
+      tile_counts[i * 2 + 1] = run1 + w1 + i1 - v1;
+    }
+    run0 += tot0;
+    run1 += tot1;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    tile_counts[n_tiles * 2 + 0] = run0;
+    tile_counts[n_tiles * 2 + 1] = run1;
+  }
+}
+
+__global__ __launch_bounds__(256) void lg3_init_kernel(int32_t* rowcnt, int64_t n_rowcnt, int32_t* zeros, int64_t zero_words,
+                                                       int32_t* meta) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = t0; i < n_rowcnt; i += stride) rowcnt[i] = 0;
+  for (int64_t i = t0; i < zero_words; i += stride) zeros[i] = 0;
+  if (t0 < GIGL_META_LEN) meta[t0] = 0;
+}
+
+// first occurrences held by inner stream position t (lg2_firsts over the position-indexed arrays)
+__device__ __forceinline__ void lg3_firsts(const Lg3Args& a, int64_t t, int32_t& w_out, int32_t& grp, uint32_t& mycode,
+                                           int& c0, int& c1, uint32_t& own_first, unsigned long long& xmask,
+                                           bool& root_parent) {
+  c0 = c1 = 0;
+  own_first = 0;
+  xmask = 0;
+  root_parent = false;
+  w_out = -1;
+  grp = 0;
+  mycode = 0;
+  if (t >= a.b + a.S0) return;
+  const int32_t w = a.fpw[t];
+  w_out = w;
+  if (w == -1) return;
+  lg3_locate(a, t, grp, mycode);
+  const uint32_t code = (uint32_t)w & 0x7FFFFFFFu;
+  if (code == mycode) {
+    own_first = 1;
+    if (t < a.b) c0 = 1; else c1 = 1;
+  }
+  if (t >= a.b && code < (uint32_t)a.gr) {
+    root_parent = true;
+    const int64_t p = t - a.b;
+    const int c = a.cnt1[p];
+    const uint32_t xbase = (uint32_t)a.Tg + (mycode - (uint32_t)a.gr) * (uint32_t)a.f1;
+    for (int j = 0; j < c; ++j) {
+      const int32_t x = a.fpx[p * a.f1 + j];
+      if (x != -1 && ((uint32_t)x & 0x7FFFFFFFu) == xbase + j) {
+        xmask |= 1ull << j;
+        ++c1;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lg3_assign_kernel(Lg3Args a, const int32_t* tile_counts, int32_t n_tiles,
+                                                         uint32_t* nodes, int32_t* meta, int32_t* rowptr, int32_t* rowend,
+                                                         int32_t* cursor, int32_t* alias_edges, int32_t* sort_rows,
+                                                         int32_t* sort_count, int32_t* tiny_rows, int32_t* tiny_count) {
+  __shared__ int32_t s_w[TILE / 64][5];
+  __shared__ int32_t s_row_base, s_q_base, s_t_base;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int32_t before0 = tile_counts[blockIdx.x * 2 + 0], before1 = tile_counts[blockIdx.x * 2 + 1];
+  const int32_t total0 = tile_counts[n_tiles * 2 + 0], total1 = tile_counts[n_tiles * 2 + 1];
+  const int64_t base = (int64_t)blockIdx.x * TILE;
+  int32_t fw[TILE / 256];
+  int k0[TILE / 256], k1[TILE / 256];
+  uint32_t own[TILE / 256];
+  unsigned long long xm[TILE / 256];
+  int32_t own_len[TILE / 256];  // entries of the own first's row, -1: the row is a tree segment (aliased)
+  int32_t x0[TILE / 256], x1[TILE / 256], xn[TILE / 256], xq[TILE / 256], xt[TILE / 256];  // exclusive wave prefixes
+#pragma unroll
+  for (int r = 0; r < TILE / 256; ++r) {
+    const int64_t t = base + r * 256 + tid;
+    int32_t grp;
+    uint32_t mycode;
+    bool rp;
+    lg3_firsts(a, t, fw[r], grp, mycode, k0[r], k1[r], own[r], xm[r], rp);
+    int32_t nd = 0, nq = 0, nt = 0;
+    own_len[r] = 0;
+    if (own[r]) {
+      const bool multi = fw[r] < 0;
+      const bool alias = a.alias_base >= 0 && t >= a.b && !multi;
+      own_len[r] = alias ? -1 : a.rowcnt[t];
+      if (!alias) {
+        nd += own_len[r];
+        const bool sort_it = own_len[r] >= 2 && multi;
+        nq = sort_it && own_len[r] > TINY_ROW ? 1 : 0;
+        nt = sort_it && own_len[r] <= TINY_ROW ? 1 : 0;
+      }
+    }
+    // (a node first seen as an extra has no hop-0 occurrence, hence no in-edges: its row is empty)
+    int32_t i0 = k0[r], i1 = k1[r], in = nd, iq = nq, it = nt;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t o0 = __shfl_up(i0, off, 64), o1 = __shfl_up(i1, off, 64), on = __shfl_up(in, off, 64),
+                    oq = __shfl_up(iq, off, 64), ot = __shfl_up(it, off, 64);
+      if (lane >= off) {
+        i0 += o0;
+        i1 += o1;
+        in += on;
+        iq += oq;
+        it += ot;
+      }
+    }
+    x0[r] = i0 - k0[r];
+    x1[r] = i1 - k1[r];
+    xn[r] = in - nd;
+    xq[r] = iq - nq;
+    xt[r] = it - nt;
+    if (lane == 63) {
+      s_w[r * 4 + w][0] = i0;
+      s_w[r * 4 + w][1] = i1;
+      s_w[r * 4 + w][2] = in;
+      s_w[r * 4 + w][3] = iq;
+      s_w[r * 4 + w][4] = it;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int32_t tot = 0, totq = 0, tott = 0;
+    for (int q = 0; q < TILE / 64; ++q) {
+      tot += s_w[q][2];
+      totq += s_w[q][3];
+      tott += s_w[q][4];
+    }
+    s_row_base = tot ? atomicAdd(cursor, tot) : 0;
+    s_q_base = totq ? atomicAdd(sort_count, totq) : 0;
+    s_t_base = tott ? atomicAdd(tiny_count, tott) : 0;
+  }
+  __syncthreads();
+  int32_t alias_c = 0;
+#pragma unroll
+  for (int r = 0; r < TILE / 256; ++r) {
+    if (!(k0[r] | k1[r])) continue;
+    int32_t p0 = before0 + x0[r], p1 = total0 + before1 + x1[r], pn = s_row_base + xn[r], pq = s_q_base + xq[r],
+            pt = s_t_base + xt[r];
+    for (int q = 0; q < r * 4 + w; ++q) {
+      p0 += s_w[q][0];
+      p1 += s_w[q][1];
+      pn += s_w[q][2];
+      pq += s_w[q][3];
+      pt += s_w[q][4];
+    }
+    const int64_t t = base + r * 256 + tid;
+    if (own[r]) {
+      const bool multi = fw[r] < 0;
+      const int32_t id = k0[r] ? p0 : p1++;
+      a.lid_in[t] = id;
+      nodes[id] = t < a.b ? a.roots[t] : a.nbr0[t - a.b];
+      if (own_len[r] < 0) {  // the row IS the tree segment of its children
+        const int64_t p = t - a.b;
+        const int32_t c = a.cnt1[p];
+        rowptr[id] = a.alias_base + (int32_t)(p * a.f1);
+        rowend[id] = a.alias_base + (int32_t)(p * a.f1) + c;
+        alias_c += c;
+      } else {
+        const bool sorted_later = own_len[r] >= 2 && multi;
+        rowptr[id] = pn;
+        rowend[id] = sorted_later || own_len[r] < 2 ? pn : pn + own_len[r];  // fill cursor | final end
+        pn += own_len[r];
+        if (sorted_later && own_len[r] > TINY_ROW) sort_rows[pq] = id;
+        else if (sorted_later) tiny_rows[pt] = id;
+        else alias_c += own_len[r];  // (the row is final: counted with the aliased edges)
+      }
+    }
+    if (xm[r]) {
+      const int64_t p = t - a.b;
+      for (int j = 0; j < a.f1; ++j) {
+        if (!(xm[r] >> j & 1ull)) continue;
+        const int32_t id = p1++;
+        a.fpx[p * a.f1 + j] = id | LG3_XTAG;
+        nodes[id] = a.nbr1[p * a.f1 + j];
+        rowptr[id] = pn;
+        rowend[id] = pn;
+      }
+    }
+  }
+  {
+    for (int off = 32; off > 0; off >>= 1) alias_c += __shfl_xor(alias_c, off, 64);
+    if (lane == 0 && alias_c) atomicAdd(&alias_edges[blockIdx.x & 31], alias_c);
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    meta[GIGL_META_LEVEL0] = total0;
+    meta[GIGL_META_LEVEL0 + 1] = total0 + total1;
+    meta[GIGL_META_LEVEL0 + 2] = total0 + total1;
+    meta[GIGL_META_N_NODES] = total0 + total1;
+    rowptr[total0 + total1] = 0;  // (rows past the inner nodes do not exist in leaf-global mode)
+    rowend[total0 + total1] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void lg3_fill_kernel(Lg3Args a, int32_t* rowend, int32_t* col, int32_t* root_local,
+                                                       const int32_t* rowptr) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool in = t < a.b + a.S0;
+  const int32_t w = in ? a.fpw[t] : -1;
+  const bool valid = w != -1;
+  int32_t grp = 0;
+  uint32_t mycode = 0;
+  if (in) lg3_locate(a, t, grp, mycode);
+  const uint32_t code = (uint32_t)w & 0x7FFFFFFFu;
+  const bool multi = valid && w < 0;
+  const int32_t lid = valid ? a.lid_in[lg3_gpos(a, grp, code)] : -1;
+  if (in && t < a.b) root_local[t] = lid;
+  const bool edge = in && t >= a.b && valid;
+  bool e_ok = false;
+  int32_t dl = 0;
+  if (edge) {
+    const int64_t rt = (int64_t)((uint32_t)(t - a.b) / (uint32_t)a.f0);  // the root position this slot hangs under
+    const int32_t wr = a.fpw[rt];
+    if (wr != -1) {
+      e_ok = true;
+      const int64_t rpos = (int64_t)grp * a.gr + ((uint32_t)wr & 0x7FFFFFFFu);  // (a root position's node starts at a root position)
+      dl = a.lid_in[rpos];
+      if (wr >= 0 && a.rowcnt[rpos] >= 2) {
+        // the root occurs once: its row is its hop-0 slots' nodes in slot order (valid slots are a prefix) — no cursor
+        col[rowptr[dl] + (int32_t)((uint32_t)(t - a.b) % (uint32_t)a.f0)] = lid;
+        e_ok = false;
+      }
+    }
+  }
+  int total, rank, first;
+  seg_rank(e_ok ? (uint32_t)dl : (0x80000000u | (uint32_t)lane), e_ok, lane, total, rank, first);
+  int32_t basep = 0;
+  if (e_ok && rank == 0) basep = atomicAdd(&rowend[dl], total);
+  basep = __shfl(basep, first, 64);
+  if (e_ok) col[basep + rank] = lid;
+  if (edge && (multi || a.alias_base < 0)) {
+    const int64_t p = t - a.b;
+    const int c = a.cnt1[p];
+    if (c > 0 && lg3_contributes(a, code, mycode, c)) {
+      const int32_t at = atomicAdd(&rowend[lid], c);
+      const bool local = code < (uint32_t)a.gr;  // the node is a root: its row holds local ids
+      const int64_t xg = (int64_t)grp * a.S0g * a.f1;  // the batch's extras
+      for (int j = 0; j < c; ++j) {
+        int32_t v = (int32_t)a.nbr1[p * a.f1 + j];
+        if (local) {
+          int32_t x = a.fpx[p * a.f1 + j];
+          v = 0;
+          if (x != -1) {
+            if (!(x & LG3_XTAG)) {
+              const uint32_t c2 = (uint32_t)x & 0x7FFFFFFFu;
+              x = c2 < (uint32_t)a.Tg ? a.lid_in[lg3_gpos(a, grp, c2)] | LG3_XTAG : a.fpx[xg + (c2 - a.Tg)];
+            }
+            v = x & (LG3_XTAG - 1);
+          }
+        }
+        col[at + j] = v;
+      }
+    }
+  }
+}
+
+int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree, int32_t group_roots,
+                        gigl_union* out, bool multiset_rows, bool* taken) {
+  *taken = false;
+  const int b = tree->b;
+  const int f0 = tree->fanouts[0], f1 = tree->fanouts[1];
+  const int64_t S0 = (int64_t)b * f0, S1 = S0 * f1, T_in = b + S0;
+  const int64_t n_groups = b / group_roots;
+  const int64_t gr = group_roots, Tg = gr * (1 + f0), S1g = gr * f0 * f1;
+  if (Tg + S1g >= (int64_t)LG3_CODE_MASK || f1 > 64 || b + S0 + S1 >= ((int64_t)1 << 31)) return GIGL_OK;  // -> LG2
+  // LDS table: 4-byte slots at load <= 1/2 for the nodes a batch may hold (more do not fit the plan's workspace)
+  int64_t cap = 1024;
+  while (cap < 2 * Tg && cap < 16384) cap <<= 1;
+  const int64_t P = (2 * Tg + cap - 1) / cap;
+  if (P > LG3_MAX_PARTS) return GIGL_OK;
+  int64_t rs = 64;
+  int rs_log2 = 6;
+  while (rs < 2 * gr) {
+    rs <<= 1;
+    ++rs_log2;
+  }
+  const int64_t n_tcnt = 2 * ((gr >> 10) + 2 + ((gr * f0) >> 10) + 2);
+  const size_t lds_bytes = (size_t)(cap + rs + n_tcnt) * 4;
+  if (lds_bytes > 150 * 1024) return GIGL_OK;
+  *taken = true;
+  hipStream_t st = ctx->stream;
+  const int32_t n_tiles = (int32_t)((T_in + TILE - 1) / TILE);
+  const int64_t zero_words = 256 + (int64_t)(n_tiles + 1) * 2;  // counters | tile counts
+  int64_t need = 0;
+  auto add = [&](int64_t bytes) { need += gigl_align_up(bytes, 256); };
+  add(zero_words * 4);
+  add(T_in * 4);  // fpw
+  add(T_in * 4);  // lid_in
+  add(T_in * 4);  // rowcnt
+  add(S1 * 4);    // fpx
+  add(T_in * 4);  // queue of long rows
+  add(T_in * 4);  // queue of rows to sort
+  add(T_in * 4);  // queue of tiny rows to sort
+  int32_t rc = gigl_arena_reset(ctx, need + 4096);
+  if (rc != GIGL_OK) return rc;
+  int32_t* zeros = (int32_t*)gigl_arena_alloc(ctx, zero_words * 4);
+  Lg3Args a{};
+  a.fpw = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
+  a.lid_in = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
+  a.rowcnt = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
+  a.fpx = (int32_t*)gigl_arena_alloc(ctx, S1 * 4);
+  int32_t* big_rows = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
+  int32_t* sort_rows = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
+  int32_t* tiny_rows = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
+  if (!zeros || !a.fpw || !a.lid_in || !a.rowcnt || !a.fpx || !big_rows || !sort_rows || !tiny_rows)
+    return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  a.roots = roots;
+  a.nbr0 = tree->nbr[0];
+  a.nbr1 = tree->nbr[1];
+  a.cnt0 = tree->cnt[0];
+  a.cnt1 = tree->cnt[1];
+  a.b = b;
+  a.f0 = f0;
+  a.f1 = f1;
+  a.S0 = S0;
+  a.gr = (int32_t)gr;
+  a.S0g = (int32_t)(gr * f0);
+  a.Tg = (int32_t)Tg;
+  a.n_groups = (int32_t)n_groups;
+  a.P = (int32_t)P;
+  a.cmask = (uint32_t)(cap - 1);
+  a.rmask = (uint32_t)(rs - 1);
+  a.rs_shift = 32 - rs_log2;
+  a.whole_rows = multiset_rows ? 0 : 1;
+  a.overflow = out->meta + GIGL_META_OVERFLOW;
+  a.alias_base = -1;
+  if (tree->nbr[1] == (const uint32_t*)(out->col + out->cap_edges) && out->cap_edges + S1 < ((int64_t)1 << 31))
+    a.alias_base = (int32_t)out->cap_edges;
+  int32_t* cursor = zeros;            // [0]
+  int32_t* ticket_count = zeros + 1;  // [1]
+  int32_t* ticket_big = zeros + 2;    // [2]
+  int32_t* big_count = zeros + 3;     // [3]
+  int32_t* sort_count = zeros + 4;    // [4]
+  int32_t* tiny_count = zeros + 5;    // [5]
+  int32_t* edge_counters = zeros + 64;   // [64..96): sorted + queued rows, [96..128): aliased rows
+  int32_t* tile_counts = zeros + 256;
+  const int TB = 256;
+  auto grid = [&](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
+  static bool lds_attr_set = false;  // more than 64 KiB of dynamic LDS needs the opt-in once per process
+  if (!lds_attr_set) {
+    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)lg3_dedup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            150 * 1024));
+    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)lg2_row_sort_big_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
+    lds_attr_set = true;
+  }
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_INSERT);
+    hipLaunchKernelGGL(lg3_init_kernel, dim3(256), dim3(256), 0, st, a.rowcnt, T_in, zeros, zero_words, out->meta);
+    hipLaunchKernelGGL(lg3_dedup_kernel, dim3((unsigned)(n_groups * P)), dim3(1024), lds_bytes, st, a, tile_counts,
+                       n_tiles, ticket_count);
+  }
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_NODES);
+    hipLaunchKernelGGL(lg3_assign_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, a, tile_counts, n_tiles, out->nodes,
+                       out->meta, out->rowptr, out->rowend, cursor, edge_counters + 32, sort_rows, sort_count, tiny_rows,
+                       tiny_count);
+  }
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_EDGE_SORT);
+    hipLaunchKernelGGL(lg3_fill_kernel, grid(T_in), dim3(TB), 0, st, a, out->rowend, out->col, out->root_local, out->rowptr);
+  }
+  {
+    gigl_prof_scope ps(ctx, GIGL_K_UNION_CSR);
+    {
+      int64_t tb = (T_in / 16 + 255) / 256;
+      if (tb > 1024) tb = 1024;
+      if (tb < 16) tb = 16;
+      hipLaunchKernelGGL(lg2_row_sort_tiny_kernel, dim3((unsigned)tb), dim3(256), 0, st, tiny_rows, tiny_count,
+                         out->rowptr, out->rowend, out->col, edge_counters);
+    }
+    int64_t blocks = (T_in / 8 + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 64) blocks = 64;
+    hipLaunchKernelGGL(lg2_row_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, sort_rows, sort_count, out->rowptr,
+                       out->rowend, out->col, big_rows, big_count, edge_counters);
+    hipLaunchKernelGGL(lg2_row_sort_big_kernel, dim3(8), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st, out->rowptr,
+                       out->rowend, out->col, big_rows, big_count, out->meta + GIGL_META_OVERFLOW, edge_counters,
+                       ticket_big, out->meta);
+  }
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1695,6 +2385,12 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
   }
   if (leaf_global && hops == 2 && !getenv("GIGL_UNION_GENERIC")) {
     GIGL_REQUIRE(ctx, group_roots >= 1 && b % group_roots == 0, "group_roots=%d does not divide b=%d", group_roots, b);
+    static const bool keep_lg2 = getenv("GIGL_UNION_LG2") != nullptr;  // (A/B knob)
+    if (!keep_lg2) {
+      bool taken = false;
+      const int32_t rc3 = union_build_lg3(ctx, roots, tree, group_roots, out, (leaf_global & 2) != 0, &taken);
+      if (rc3 != GIGL_OK || taken) return rc3;
+    }
     return union_build_lg2(ctx, roots, tree, group_roots, out, (leaf_global & 2) != 0);
   }
 
