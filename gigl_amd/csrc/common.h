@@ -195,6 +195,18 @@ static inline void gigl_take_rows(hipStream_t st, const float* h, const int32_t*
 }
 
 #if defined(__HIPCC__)
+// inclusive prefix sum over the 64 lanes of a wave on the VALU (DPP row shifts inside the 16-lane rows, then the row
+// totals broadcast into the rows after them): no LDS-pipeline instruction (__shfl_up lowers to ds_bpermute)
+__device__ __forceinline__ int gigl_wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);   // row_shr:1 (lanes without a source read 0)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+
 // Sum over aligned groups of `group` adjacent lanes (a power of two <= 64), returned to every lane of the group, on the
 // VALU / SALU only: DPP quad permutes for 2 and 4, the half-row / row mirrors for 8 and 16, v_readlane of the four row
 // totals for 32 and 64.  (__shfl_xor lowers the steps of width >= 4 to ds_bpermute, i.e. LDS-pipeline instructions.)

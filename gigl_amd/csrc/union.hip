@@ -1012,7 +1012,7 @@ constexpr int TINY_ROW = 32;
 
 __global__ __launch_bounds__(256) void lg2_row_sort_tiny_kernel(const int32_t* tiny_rows, const int32_t* tiny_count,
                                                                 const int32_t* rowptr, int32_t* rowend, int32_t* col,
-                                                                int32_t* edge_counters) {
+                                                                int32_t* edge_counters, int ec_stride = 1) {
   __shared__ int32_t s_v[256 * (TINY_ROW + 1)];
   const int32_t nq = *tiny_count;
   int32_t* v = s_v + threadIdx.x * (TINY_ROW + 1);
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(256) void lg2_row_sort_tiny_kernel(const int32_t* t
     edges += u;
   }
   for (int off = 32; off > 0; off >>= 1) edges += __shfl_xor(edges, off, 64);
-  if ((threadIdx.x & 63) == 0 && edges) atomicAdd(&edge_counters[blockIdx.x & 31], edges);
+  if ((threadIdx.x & 63) == 0 && edges) atomicAdd(&edge_counters[(blockIdx.x & 31) * ec_stride], edges);
 }
 
 // local ids, node list, row storage.  A thread numbers the first occurrences it holds (its own position, then its
@@ -1251,7 +1251,7 @@ constexpr int MED_HASH = 1024;
 __global__ __launch_bounds__(256) void lg2_row_sort_kernel(const int32_t* sort_rows, const int32_t* sort_count,
                                                            const int32_t* rowptr, int32_t* rowend, int32_t* col,
                                                            int32_t* big_rows, int32_t* big_count,
-                                                           int32_t* edge_counters) {
+                                                           int32_t* edge_counters, int ec_stride = 1) {
   __shared__ int32_t s_h[4][MED_HASH];
   __shared__ int32_t s_u[4][MED_ROW];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1332,7 +1332,7 @@ __global__ __launch_bounds__(256) void lg2_row_sort_kernel(const int32_t* sort_r
     edges += u;
     wave_lds_sync();
   }
-  if (lane == 0 && edges) atomicAdd(&edge_counters[blockIdx.x & 31], edges);
+  if (lane == 0 && edges) atomicAdd(&edge_counters[(blockIdx.x & 31) * ec_stride], edges);
 }
 
 // queued rows: duplicates removed through an LDS hash set (any number of entries, <= BIG_ROW_CAP distinct), the
@@ -1341,7 +1341,10 @@ __global__ __launch_bounds__(256) void lg2_row_sort_kernel(const int32_t* sort_r
 __global__ __launch_bounds__(1024) void lg2_row_sort_big_kernel(const int32_t* rowptr, int32_t* rowend, int32_t* col,
                                                                 const int32_t* big_rows, const int32_t* big_count,
                                                                 int32_t* overflow, int32_t* edge_counters,
-                                                                int32_t* ticket, int32_t* meta) {
+                                                                int32_t* ticket, int32_t* meta, int ec_stride = 1,
+                                                                const int32_t* tile_edges = nullptr, int32_t n_tile_edges = 0) {
+  // (ec_stride: the 32 spread edge counters sit ec_stride words apart — LG3 keeps each on its own 128-byte line;
+  // tile_edges: per-tile edge counts written by plain stores, added to the total here)
   extern __shared__ int32_t lds[];  // hash set of 2*CAP keys, then A = lds[0..CAP), B = lds[CAP..2CAP)
   int32_t* A = lds;
   int32_t* B = lds + BIG_ROW_CAP;
@@ -1505,16 +1508,23 @@ __global__ __launch_bounds__(1024) void lg2_row_sort_big_kernel(const int32_t* r
     __syncthreads();
   }
   if (tid == 0) {
-    if (edges) atomicAdd(&edge_counters[blockIdx.x & 31], edges);
+    if (edges) atomicAdd(&edge_counters[(blockIdx.x & 31) * ec_stride], edges);
     __threadfence();
     s_last = atomicAdd(ticket, 1) == (int32_t)gridDim.x - 1 ? 1 : 0;
-    if (s_last) {
-      int32_t total = 0;  // sorted rows + queued rows + aliased rows
-      for (int q = 0; q < 64; ++q)
-        total += __hip_atomic_load(&edge_counters[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      meta[GIGL_META_N_EDGES] = total;
-    }
   }
+  __syncthreads();
+  if (!s_last) return;
+  // the last workgroup to finish: sorted rows + queued rows + aliased rows
+  int32_t total = 0;
+  if (tid < 64 && (tile_edges == nullptr || tid < 32))
+    total = __hip_atomic_load(&edge_counters[tid * ec_stride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int32_t q = tid; q < n_tile_edges; q += 1024) total += tile_edges[q];
+  for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+  if (tid == 0) s_uniq = 0;
+  __syncthreads();
+  if (lane == 0 && total) atomicAdd(&s_uniq, total);
+  __syncthreads();
+  if (tid == 0) meta[GIGL_META_N_EDGES] = s_uniq;
 }
 
 int32_t union_build_lg2(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree, int32_t group_roots,
@@ -1647,9 +1657,10 @@ int32_t union_build_lg2(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
 //
 // Here the table lives in LDS for the one pass that needs a hash table at all:
 //   * lg3_dedup_kernel: a batch's keys are split by hash bits over P workgroups; each holds its share in a table of
-//     4-byte slots [11-bit fingerprint | 20-bit stream code of the first occurrence | 1 bit "occurs once"] — claim by
-//     ds_cmpst, later occurrences by ds_min (smaller code wins) + ds_and (clears "once"); a fingerprint match is
-//     verified against the stream itself (the id at the slot's code: a cached read), so the set is exact.  Every
+//     8-byte slots (node id << 32 | 20-bit stream code of the first occurrence << 1 | "occurs once") — claim by
+//     ds_cmpst_b64, later occurrences by ds_min_u64 (smaller code wins) + ds_and_b64 (clears "once").  (A 4-byte slot
+//     with an 11-bit fingerprint, verified against the stream on a match, was measured first: the verification read
+//     of every repeated node sits inside the probe loop, a whole wave waits on L2 per 64 positions — 3.6 us/step.)  Every
 //     workgroup streams the batch's whole inner stream (roots, hop-0 slots; L2-resident, just written by the sampler)
 //     and keeps its own share; the batch's roots also go into a small exact LDS set, so "this hop-0 node is a root"
 //     — whose children are inner nodes too, the extras — is known without the table of another workgroup.
@@ -1684,6 +1695,7 @@ struct Lg3Args {
   uint32_t cmask;    // LDS table slots - 1
   uint32_t rmask;    // root set slots - 1
   int32_t rs_shift;  // 32 - log2(root set slots)
+  int32_t bl_shift;  // 32 - log2(filter bits): 8 bits per root set slot
   int32_t* fpw;      // [b + S0] by global inner position: code of the node's first occurrence | multi << 31; -1: no node
   int32_t* fpx;      // [S0 * f1] by (global hop-0 slot, child): the same for extras; first occurrences become lid | LG3_XTAG
   int32_t* lid_in;   // [b + S0] local id, by the global inner position of the node's FIRST occurrence
@@ -1694,13 +1706,6 @@ struct Lg3Args {
 };
 
 __device__ __forceinline__ uint32_t lg3_part(uint32_t h32, int P) { return (uint32_t)(((uint64_t)h32 * (uint32_t)P) >> 32); }
-
-// id at group-local stream code `code` of batch grp
-__device__ __forceinline__ uint32_t lg3_key_at(const Lg3Args& a, int32_t grp, uint32_t code) {
-  if (code < (uint32_t)a.gr) return a.roots[(int64_t)grp * a.gr + code];
-  if (code < (uint32_t)a.Tg) return a.nbr0[(int64_t)grp * a.S0g + (code - a.gr)];
-  return a.nbr1[(int64_t)grp * a.S0g * a.f1 + (code - a.Tg)];
-}
 
 // global inner position (index into fpw / lid_in / rowcnt) of an INNER code of batch grp
 __device__ __forceinline__ int64_t lg3_gpos(const Lg3Args& a, int32_t grp, uint32_t code) {
@@ -1719,21 +1724,22 @@ __device__ __forceinline__ void lg3_locate(const Lg3Args& a, int64_t t, int32_t&
   }
 }
 
-__device__ __forceinline__ bool lg3_insert(uint32_t* table, const Lg3Args& a, int32_t grp, uint32_t id, uint32_t h32,
+// slot word: (node id << 32) | (code of the first occurrence << 1) | "occurs once"; ~0 = empty.  One ds_cmpst_b64 claims
+// a slot for a first occurrence; a later occurrence lowers the word with ds_min_u64 (equal high halves: the smaller code
+// wins) and clears "once" with ds_and_b64.
+__device__ __forceinline__ bool lg3_insert(unsigned long long* table, const Lg3Args& a, uint32_t id, uint32_t h32,
                                            uint32_t code) {
-  const uint32_t fpr = (h32 >> 14) & 0x7FFu;
-  const uint32_t mine1 = (fpr << 21) | (code << 1) | 1u, mine0 = mine1 & ~1u;
+  const unsigned long long mine1 = ((unsigned long long)id << 32) | ((unsigned long long)code << 1) | 1ull;
   uint32_t s = h32 & a.cmask;
   for (uint32_t probes = 0; probes <= a.cmask; ++probes) {
-    uint32_t w = table[s];
-    if (w == LG3_EMPTY) {
-      w = atomicCAS(&table[s], LG3_EMPTY, mine1);
-      if (w == LG3_EMPTY) return true;
+    unsigned long long w = table[s];
+    if (w == ~0ull) {
+      w = atomicCAS(&table[s], ~0ull, mine1);
+      if (w == ~0ull) return true;
     }
-    // (the slot's key never changes; its code only goes down: any code read here names an occurrence of that key)
-    if ((w >> 21) == fpr && lg3_key_at(a, grp, (w >> 1) & LG3_CODE_MASK) == id) {
-      atomicMin(&table[s], mine0);  // same fingerprint: the smaller code wins; "once" is cleared either way
-      atomicAnd(&table[s], ~1u);
+    if ((uint32_t)(w >> 32) == id) {
+      atomicMin(&table[s], mine1 & ~1ull);
+      atomicAnd(&table[s], ~1ull);
       return true;
     }
     s = (s + 1) & a.cmask;
@@ -1741,19 +1747,14 @@ __device__ __forceinline__ bool lg3_insert(uint32_t* table, const Lg3Args& a, in
   return false;
 }
 
-// the slot word of `id` (LG3_EMPTY: not in the table — only after an overflow); mycode: the caller's own code (a slot
-// that names it needs no verification read)
-__device__ __forceinline__ uint32_t lg3_lookup(const uint32_t* table, const Lg3Args& a, int32_t grp, uint32_t id,
-                                               uint32_t h32, uint32_t mycode) {
-  const uint32_t fpr = (h32 >> 14) & 0x7FFu;
+// the low word of `id`'s slot: (code << 1) | once; LG3_EMPTY: not in the table (only after an overflow)
+__device__ __forceinline__ uint32_t lg3_lookup(const unsigned long long* table, const Lg3Args& a, uint32_t id,
+                                               uint32_t h32) {
   uint32_t s = h32 & a.cmask;
   for (uint32_t probes = 0; probes <= a.cmask; ++probes) {
-    const uint32_t w = table[s];
-    if (w == LG3_EMPTY) return LG3_EMPTY;
-    if ((w >> 21) == fpr) {
-      const uint32_t c = (w >> 1) & LG3_CODE_MASK;
-      if (c == mycode || lg3_key_at(a, grp, c) == id) return w;
-    }
+    const unsigned long long w = table[s];
+    if (w == ~0ull) return LG3_EMPTY;
+    if ((uint32_t)(w >> 32) == id) return (uint32_t)w;
     s = (s + 1) & a.cmask;
   }
   return LG3_EMPTY;
@@ -1776,14 +1777,25 @@ __device__ __forceinline__ bool lg3_contributes(const Lg3Args& a, uint32_t first
   return first_code == my_code || first_code < (uint32_t)a.gr;
 }
 
+// A level-1 node whose occurrences sampled fewer than f1 children each holds its WHOLE in-neighbourhood under every one
+// of them (simple graphs: the sampler returns the ascending, duplicate-free list): its row is the tree segment of its
+// first occurrence, whether the node occurs once or many times — nothing to count, fill, dedup or sort (round 4; LG2
+// copies the first occurrence's list into row storage and queues the row for sorting).  `code` = the node's first code.
+__device__ __forceinline__ bool lg3_row_is_segment(const Lg3Args& a, uint32_t code, int c) {
+  return a.alias_base >= 0 && a.whole_rows && c < a.f1 && code >= (uint32_t)a.gr;
+}
+
+constexpr int LG3_TC = 5;  // per-tile counts: level-0 firsts, level-1 firsts, row entries to store, long / tiny rows to sort
+
 __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* tile_counts, int32_t n_tiles,
-                                                         int32_t* ticket) {
-  extern __shared__ uint32_t lg3_lds[];
-  uint32_t* table = lg3_lds;                   // [cmask + 1]
-  uint32_t* rset = table + (a.cmask + 1u);     // [rmask + 1]
-  int32_t* tcnt = reinterpret_cast<int32_t*>(rset + (a.rmask + 1u));  // [nt_r + nt_h][2]
+                                                         int32_t* ticket, int32_t* sort_count, int32_t* tiny_count) {
+  extern __shared__ unsigned long long lg3_lds[];
+  unsigned long long* table = lg3_lds;                                      // [cmask + 1]
+  uint32_t* rset = reinterpret_cast<uint32_t*>(table + (a.cmask + 1u));     // [rmask + 1] exact set of the batch's roots
+  uint32_t* bloom = rset + (a.rmask + 1u);                                  // [(rmask + 1) / 4] words: 8 bits per set slot
+  int32_t* tcnt = reinterpret_cast<int32_t*>(bloom + ((a.rmask + 1u) >> 2));  // [nt_r + nt_h][LG3_TC]
   __shared__ int32_t s_last;
-  __shared__ int32_t s_w[16][2];
+  __shared__ int32_t s_w[16][LG3_TC];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // the P workgroups of a batch read the same stream: ids that are consecutive mod 8 share an XCD's L2
   uint32_t vid = blockIdx.x;
@@ -1793,12 +1805,13 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
   const int64_t r0 = (int64_t)grp * a.gr, p0 = (int64_t)grp * a.S0g;
   const int32_t tile_lo_r = (int32_t)(r0 >> 10), nt_r = (int32_t)((r0 + a.gr - 1) >> 10) - tile_lo_r + 1;
   const int32_t tile_lo_h = (int32_t)((a.b + p0) >> 10), nt_h = (int32_t)((a.b + p0 + a.S0g - 1) >> 10) - tile_lo_h + 1;
-  for (uint32_t i = tid; i <= a.cmask; i += 1024) table[i] = LG3_EMPTY;
+  for (uint32_t i = tid; i <= a.cmask; i += 1024) table[i] = ~0ull;
   for (uint32_t i = tid; i <= a.rmask; i += 1024) rset[i] = GIGL_INVALID;
-  for (int i = tid; i < 2 * (nt_r + nt_h); i += 1024) tcnt[i] = 0;
+  for (uint32_t i = tid; i < ((a.rmask + 1u) >> 2); i += 1024) bloom[i] = 0u;
+  for (int i = tid; i < LG3_TC * (nt_r + nt_h); i += 1024) tcnt[i] = 0;
   __syncthreads();
   int32_t over = 0;
-  // ---- roots: all of them into the root set, this partition's into the table
+  // ---- roots: all of them into the root set (+ its one-read filter), this partition's into the table
   for (int32_t tl = tid; tl < a.gr; tl += 1024) {
     const uint32_t id = a.roots[r0 + tl];
     if (id == GIGL_INVALID) continue;
@@ -1809,22 +1822,74 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
       if (prev == GIGL_INVALID || prev == id) break;
       s = (s + 1) & a.rmask;
     }
-    if ((int)lg3_part(h, a.P) == q && !lg3_insert(table, a, grp, id, h, (uint32_t)tl)) ++over;
+    const uint32_t bi = (h * 0x85EBCA6Bu) >> a.bl_shift;
+    atomicOr(&bloom[bi >> 5], 1u << (bi & 31));
+    if ((int)lg3_part(h, a.P) == q && !lg3_insert(table, a, id, h, (uint32_t)tl)) ++over;
   }
   __syncthreads();
-  // ---- hop-0 slots, and the children of those whose node is a root (extras)
-  for (int32_t pl = tid; pl < a.S0g; pl += 1024) {
-    const uint32_t id = a.nbr0[p0 + pl];
-    if (id == GIGL_INVALID) continue;
-    const uint32_t h = hash_u32(id);
-    if ((int)lg3_part(h, a.P) == q && !lg3_insert(table, a, grp, id, h, (uint32_t)(a.gr + pl))) ++over;
-    if (lg3_rset_has(rset, a, id, h)) {
+  // ---- hop-0 slots, and the children of those whose node is a root (extras).  A thread takes its slots PF at a time:
+  // the ids are requested together, and the probe sequences of the PF keys advance in lock step — PF independent LDS
+  // atomics in flight per round instead of one dependent chain per key (the kernel is bound by LDS latency at the four
+  // waves per SIMD its table leaves room for).  Whether a slot's node is a root is decided here once (one filter read,
+  // the exact set only on a hit) and kept as a bit per slot for the second pass.
+  constexpr int PF = 8;
+  unsigned long long rootmask = 0;  // bit (slot / 1024) of this thread: the slot's node is a root
+  for (int32_t base = 0, it0 = 0; base < a.S0g; base += PF * 1024, it0 += PF) {
+    uint32_t ids[PF], hh[PF], sl[PF], bw[PF];
+    uint32_t pend = 0, valid = 0;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int32_t pl = base + u * 1024 + tid;
+      ids[u] = pl < a.S0g ? a.nbr0[p0 + pl] : GIGL_INVALID;
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      hh[u] = hash_u32(ids[u]);
+      sl[u] = hh[u] & a.cmask;
+      const uint32_t bi = (hh[u] * 0x85EBCA6Bu) >> a.bl_shift;
+      bw[u] = (bloom[bi >> 5] >> (bi & 31)) & 1u;
+      if (ids[u] != GIGL_INVALID) {
+        valid |= 1u << u;
+        if ((int)lg3_part(hh[u], a.P) == q) pend |= 1u << u;
+      }
+    }
+    for (uint32_t rounds = 0; pend; ++rounds) {
+      if (rounds > a.cmask) {  // the table is full
+        over += __popc(pend);
+        break;
+      }
+      unsigned long long old[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+        if (pend >> u & 1u)
+          old[u] = atomicCAS(&table[sl[u]], ~0ull,
+                             ((unsigned long long)ids[u] << 32) | ((unsigned long long)(uint32_t)(a.gr + base + u * 1024 + tid) << 1) | 1ull);
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        if (!(pend >> u & 1u)) continue;
+        if (old[u] == ~0ull) {
+          pend &= ~(1u << u);
+        } else if ((uint32_t)(old[u] >> 32) == ids[u]) {
+          atomicMin(&table[sl[u]], ((unsigned long long)ids[u] << 32) | ((unsigned long long)(uint32_t)(a.gr + base + u * 1024 + tid) << 1));
+          atomicAnd(&table[sl[u]], ~1ull);
+          pend &= ~(1u << u);
+        } else {
+          sl[u] = (sl[u] + 1) & a.cmask;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      if (!((valid >> u & 1u) && bw[u])) continue;
+      if (!lg3_rset_has(rset, a, ids[u], hh[u])) continue;
+      rootmask |= 1ull << (it0 + u);
+      const int32_t pl = base + u * 1024 + tid;
       const int c = a.cnt1[p0 + pl];
       const uint32_t* kids = a.nbr1 + (p0 + pl) * a.f1;
       for (int j = 0; j < c; ++j) {
         const uint32_t cid = kids[j];
         const uint32_t ch = hash_u32(cid);
-        if ((int)lg3_part(ch, a.P) == q && !lg3_insert(table, a, grp, cid, ch, (uint32_t)(a.Tg + pl * a.f1 + j))) ++over;
+        if ((int)lg3_part(ch, a.P) == q && !lg3_insert(table, a, cid, ch, (uint32_t)(a.Tg + pl * a.f1 + j))) ++over;
       }
     }
   }
@@ -1839,68 +1904,174 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
     }
     const uint32_t h = hash_u32(id);
     if ((int)lg3_part(h, a.P) != q) continue;
-    const uint32_t w = lg3_lookup(table, a, grp, id, h, (uint32_t)tl);
+    const uint32_t w = lg3_lookup(table, a, id, h);
     if (w == LG3_EMPTY) {
       a.fpw[r0 + tl] = -1;
       continue;
     }
     const uint32_t code = (w >> 1) & LG3_CODE_MASK;
     a.fpw[r0 + tl] = (int32_t)(code | ((w & 1u) ? 0u : 0x80000000u));
-    if (code == (uint32_t)tl) atomicAdd(&tcnt[2 * (int)(((r0 + tl) >> 10) - tile_lo_r) + 0], 1);
+    if (code == (uint32_t)tl) atomicAdd(&tcnt[LG3_TC * (int)(((r0 + tl) >> 10) - tile_lo_r) + 0], 1);
     // the valid hop-0 slots of this root position are entries of its node's row
     const int c0 = a.cnt0[r0 + tl];
     if (c0 > 0) atomicAdd(&a.rowcnt[r0 + code], c0);
   }
-  for (int32_t pl = tid; pl < a.S0g; pl += 1024) {
-    const uint32_t id = a.nbr0[p0 + pl];
-    if (id == GIGL_INVALID) {
-      if (q == 0) a.fpw[a.b + p0 + pl] = -1;
-      continue;
+  for (int32_t base = 0, it0 = 0; base < a.S0g; base += PF * 1024, it0 += PF) {
+    uint32_t ids[PF], sl[PF], lw[PF];
+    int32_t cc[PF];
+    uint32_t pend = 0;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int32_t pl = base + u * 1024 + tid;
+      ids[u] = pl < a.S0g ? a.nbr0[p0 + pl] : GIGL_INVALID;
+      cc[u] = pl < a.S0g ? a.cnt1[p0 + pl] : 0;
     }
-    const uint32_t h = hash_u32(id);
-    const uint32_t mycode = (uint32_t)(a.gr + pl);
-    const int c = a.cnt1[p0 + pl];
-    if ((int)lg3_part(h, a.P) == q) {
-      const uint32_t w = lg3_lookup(table, a, grp, id, h, mycode);
-      if (w == LG3_EMPTY) {
-        a.fpw[a.b + p0 + pl] = -1;
-      } else {
-        const uint32_t code = (w >> 1) & LG3_CODE_MASK;
-        const bool multi = !(w & 1u);
-        a.fpw[a.b + p0 + pl] = (int32_t)(code | (multi ? 0x80000000u : 0u));
-        if (code == mycode) atomicAdd(&tcnt[2 * (nt_r + (int)(((a.b + p0 + pl) >> 10) - tile_lo_h)) + 1], 1);
-        // the children of a node that occurs more than once go to that node's row (a node that occurs once keeps its
-        // tree segment as its row)
-        if ((multi || a.alias_base < 0) && c > 0 && lg3_contributes(a, code, mycode, c))
-          atomicAdd(&a.rowcnt[lg3_gpos(a, grp, code)], c);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const uint32_t h = hash_u32(ids[u]);
+      sl[u] = h & a.cmask;
+      lw[u] = LG3_EMPTY;
+      if (ids[u] != GIGL_INVALID && (int)lg3_part(h, a.P) == q) pend |= 1u << u;
+    }
+    const uint32_t mine = pend;
+    for (uint32_t rounds = 0; pend && rounds <= a.cmask; ++rounds) {
+      unsigned long long wv8[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+        if (pend >> u & 1u) wv8[u] = table[sl[u]];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        if (!(pend >> u & 1u)) continue;
+        if (wv8[u] == ~0ull) {
+          pend &= ~(1u << u);  // not in the table (only after an overflow)
+        } else if ((uint32_t)(wv8[u] >> 32) == ids[u]) {
+          lw[u] = (uint32_t)wv8[u];
+          pend &= ~(1u << u);
+        } else {
+          sl[u] = (sl[u] + 1) & a.cmask;
+        }
       }
     }
-    if (lg3_rset_has(rset, a, id, h)) {
-      const uint32_t* kids = a.nbr1 + (p0 + pl) * a.f1;
-      for (int j = 0; j < c; ++j) {
-        const uint32_t cid = kids[j];
-        const uint32_t ch = hash_u32(cid);
-        if ((int)lg3_part(ch, a.P) != q) continue;
-        const uint32_t xcode = (uint32_t)(a.Tg + pl * a.f1 + j);
-        const uint32_t w = lg3_lookup(table, a, grp, cid, ch, xcode);
-        int32_t out = -1;
-        if (w != LG3_EMPTY) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int32_t pl = base + u * 1024 + tid;  // (a wave's 64 slots are consecutive: they touch at most two tiles)
+      const uint32_t id = ids[u];
+      const int c = cc[u];
+      const bool in = pl < a.S0g;
+      const int32_t my_tile = (int32_t)((a.b + p0 + pl) >> 10) - tile_lo_h;
+      bool first = false;
+      if (in && id == GIGL_INVALID) {
+        if (q == 0) a.fpw[a.b + p0 + pl] = -1;
+      } else if (in && (mine >> u & 1u)) {
+        const uint32_t mycode = (uint32_t)(a.gr + pl);
+        const uint32_t w = lw[u];
+        if (w == LG3_EMPTY) {
+          a.fpw[a.b + p0 + pl] = -1;
+        } else {
           const uint32_t code = (w >> 1) & LG3_CODE_MASK;
-          out = (int32_t)(code | ((w & 1u) ? 0u : 0x80000000u));
-          // (an extra that is a first occurrence is numbered by the thread of its parent slot: counted in its tile)
-          if (code == xcode) atomicAdd(&tcnt[2 * (nt_r + (int)(((a.b + p0 + pl) >> 10) - tile_lo_h)) + 1], 1);
+          const bool multi = !(w & 1u);
+          a.fpw[a.b + p0 + pl] = (int32_t)(code | (multi ? 0x80000000u : 0u));
+          first = code == mycode;
+          // the children of a node that occurs more than once go to that node's row (a node that occurs once keeps
+          // its tree segment as its row)
+          if ((multi || a.alias_base < 0) && c > 0 && !lg3_row_is_segment(a, code, c) && lg3_contributes(a, code, mycode, c))
+            atomicAdd(&a.rowcnt[lg3_gpos(a, grp, code)], c);
         }
-        a.fpx[(p0 + pl) * a.f1 + j] = out;
+      }
+      {  // first occurrences per tile: one LDS atomic per wave and tile
+        const int32_t tile0 = __builtin_amdgcn_readfirstlane(my_tile);
+        const unsigned long long f0m = __ballot(first && my_tile == tile0), f1m = __ballot(first && my_tile != tile0);
+        if (lane == 0) {
+          if (f0m) atomicAdd(&tcnt[LG3_TC * (nt_r + tile0) + 1], (int32_t)__popcll(f0m));
+          if (f1m) atomicAdd(&tcnt[LG3_TC * (nt_r + tile0 + 1) + 1], (int32_t)__popcll(f1m));
+        }
+      }
+      if (rootmask >> (it0 + u) & 1ull) {
+        const uint32_t* kids = a.nbr1 + (p0 + pl) * a.f1;
+        for (int j = 0; j < c; ++j) {
+          const uint32_t cid = kids[j];
+          const uint32_t ch = hash_u32(cid);
+          if ((int)lg3_part(ch, a.P) != q) continue;
+          const uint32_t xcode = (uint32_t)(a.Tg + pl * a.f1 + j);
+          const uint32_t w = lg3_lookup(table, a, cid, ch);
+          int32_t out = -1;
+          if (w != LG3_EMPTY) {
+            const uint32_t code = (w >> 1) & LG3_CODE_MASK;
+            out = (int32_t)(code | ((w & 1u) ? 0u : 0x80000000u));
+            // (an extra that is a first occurrence is numbered by the thread of its parent slot: counted in its tile)
+            if (code == xcode) atomicAdd(&tcnt[LG3_TC * (nt_r + my_tile) + 1], 1);
+          }
+          a.fpx[(p0 + pl) * a.f1 + j] = out;
+        }
+      }
+    }
+  }
+  // ---- third pass: the storage and the sort queue entries the first occurrences of each tile need.  A node's rowcnt is
+  // only ever added to by the workgroup of the node's partition (root positions and hop-0 occurrences of the node
+  // itself), i.e. by THIS workgroup: after the barrier the sizes are final, and the numbering pass finds every offset
+  // as a prefix — no cursor, no atomic, rows land where their position says.
+  __syncthreads();
+  for (int32_t tl = tid; tl < a.gr; tl += 1024) {
+    const uint32_t id = a.roots[r0 + tl];
+    if (id == GIGL_INVALID || (int)lg3_part(hash_u32(id), a.P) != q) continue;
+    const int32_t w = a.fpw[r0 + tl];  // (this thread's own store)
+    if (w == -1 || ((uint32_t)w & 0x7FFFFFFFu) != (uint32_t)tl) continue;
+    const int32_t len = __hip_atomic_load(&a.rowcnt[r0 + tl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int32_t* tc = &tcnt[LG3_TC * (int)(((r0 + tl) >> 10) - tile_lo_r)];
+    if (len) atomicAdd(&tc[2], len);
+    if (len >= 2 && w < 0) atomicAdd(&tc[len > TINY_ROW ? 3 : 4], 1);
+  }
+  for (int32_t base = 0; base < a.S0g; base += PF * 1024) {
+    uint32_t ids[PF];
+    int32_t cc[PF], ww[PF], len[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int32_t pl = base + u * 1024 + tid;
+      ids[u] = pl < a.S0g ? a.nbr0[p0 + pl] : GIGL_INVALID;
+      cc[u] = pl < a.S0g ? a.cnt1[p0 + pl] : 0;
+      ww[u] = pl < a.S0g ? a.fpw[a.b + p0 + pl] : -1;  // (this thread's own store, or another partition's slot)
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int32_t pl = base + u * 1024 + tid;
+      len[u] = -1;  // -1: not a first occurrence of this partition whose row needs storage
+      if (ids[u] == GIGL_INVALID || ww[u] == -1 || (int)lg3_part(hash_u32(ids[u]), a.P) != q) continue;
+      const uint32_t mycode = (uint32_t)(a.gr + pl);
+      if (((uint32_t)ww[u] & 0x7FFFFFFFu) != mycode) continue;
+      const bool multi = ww[u] < 0;
+      if (a.alias_base >= 0 && (!multi || lg3_row_is_segment(a, mycode, cc[u]))) continue;  // the row is a tree segment
+      len[u] = __hip_atomic_load(&a.rowcnt[a.b + p0 + pl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int32_t pl = base + u * 1024 + tid;
+      const int32_t my_tile = (int32_t)((a.b + p0 + pl) >> 10) - tile_lo_h;
+      const int32_t tile0 = __builtin_amdgcn_readfirstlane(my_tile);
+      const bool have = len[u] > 0, sorted = len[u] >= 2 && ww[u] < 0;
+      if (!__ballot(have)) continue;
+      const bool t0 = my_tile == tile0;
+      const unsigned long long q0 = __ballot(sorted && len[u] > TINY_ROW && t0), q1 = __ballot(sorted && len[u] > TINY_ROW && !t0);
+      const unsigned long long s0 = __ballot(sorted && len[u] <= TINY_ROW && t0), s1 = __ballot(sorted && len[u] <= TINY_ROW && !t0);
+      const int32_t n0 = __builtin_amdgcn_readlane(gigl_wave_incl_scan(have && t0 ? len[u] : 0), 63);
+      const int32_t n1 = __builtin_amdgcn_readlane(gigl_wave_incl_scan(have && !t0 ? len[u] : 0), 63);
+      if (lane == 0) {
+        int32_t* tc = &tcnt[LG3_TC * (nt_r + tile0)];
+        if (n0) atomicAdd(&tc[2], n0);
+        if (q0) atomicAdd(&tc[3], (int32_t)__popcll(q0));
+        if (s0) atomicAdd(&tc[4], (int32_t)__popcll(s0));
+        if (n1) atomicAdd(&tc[LG3_TC + 2], n1);
+        if (q1) atomicAdd(&tc[LG3_TC + 3], (int32_t)__popcll(q1));
+        if (s1) atomicAdd(&tc[LG3_TC + 4], (int32_t)__popcll(s1));
       }
     }
   }
   __syncthreads();
-  for (int i = tid; i < 2 * (nt_r + nt_h); i += 1024) {
+  for (int i = tid; i < LG3_TC * (nt_r + nt_h); i += 1024) {
     const int32_t v = tcnt[i];
     if (v) {
-      const int k = i >> 1;
+      const int k = i / LG3_TC;
       const int32_t tile = k < nt_r ? tile_lo_r + k : tile_lo_h + (k - nt_r);
-      atomicAdd(&tile_counts[tile * 2 + (i & 1)], v);
+      atomicAdd(&tile_counts[tile * LG3_TC + (i - k * LG3_TC)], v);
     }
   }
   __syncthreads();
@@ -1911,45 +2082,41 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
   __syncthreads();
   if (!s_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  // exclusive prefix over the tiles, 1024 tiles per round, both levels (row n_tiles = totals)
-  int32_t run0 = 0, run1 = 0;
+  // the last workgroup to finish: exclusive prefixes over the tiles, 1024 tiles per round (row n_tiles = totals)
+  int32_t run[LG3_TC];
+#pragma unroll
+  for (int c = 0; c < LG3_TC; ++c) run[c] = 0;
   for (int32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
     const int32_t i = t0 + tid;
-    const int32_t v0 = i < n_tiles ? __hip_atomic_load(&tile_counts[i * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    const int32_t v1 = i < n_tiles ? __hip_atomic_load(&tile_counts[i * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-    int32_t i0 = v0, i1 = v1;
-    for (int off = 1; off < 64; off <<= 1) {
-      const int32_t o0 = __shfl_up(i0, off, 64), o1 = __shfl_up(i1, off, 64);
-      if (lane >= off) {
-        i0 += o0;
-        i1 += o1;
-      }
+    int32_t v[LG3_TC], inc[LG3_TC];
+#pragma unroll
+    for (int c = 0; c < LG3_TC; ++c) {
+      v[c] = i < n_tiles ? __hip_atomic_load(&tile_counts[i * LG3_TC + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      inc[c] = gigl_wave_incl_scan(v[c]);
     }
     if (lane == 63) {
-      s_w[wv][0] = i0;
-      s_w[wv][1] = i1;
+#pragma unroll
+      for (int c = 0; c < LG3_TC; ++c) s_w[wv][c] = inc[c];
     }
     __syncthreads();
-    int32_t w0 = 0, w1 = 0, tot0 = 0, tot1 = 0;
-    for (int k = 0; k < 16; ++k) {
-      if (k < wv) {
-        w0 += s_w[k][0];
-        w1 += s_w[k][1];
+#pragma unroll
+    for (int c = 0; c < LG3_TC; ++c) {
+      int32_t before = 0, tot = 0;
+      for (int k = 0; k < 16; ++k) {
+        const int32_t x = s_w[k][c];
+        if (k < wv) before += x;
+        tot += x;
       }
-      tot0 += s_w[k][0];
-      tot1 += s_w[k][1];
+      if (i < n_tiles) tile_counts[i * LG3_TC + c] = run[c] + before + inc[c] - v[c];
+      run[c] += tot;
     }
-    if (i < n_tiles) {
-      tile_counts[i * 2 + 0] = run0 + w0 + i0 - v0;
-      tile_counts[i * 2 + 1] = run1 + w1 + i1 - v1;
-    }
-    run0 += tot0;
-    run1 += tot1;
     __syncthreads();
   }
   if (tid == 0) {
-    tile_counts[n_tiles * 2 + 0] = run0;
-    tile_counts[n_tiles * 2 + 1] = run1;
+#pragma unroll
+    for (int c = 0; c < LG3_TC; ++c) tile_counts[n_tiles * LG3_TC + c] = run[c];
+    *sort_count = run[3];  // what the sort kernels read: rows queued by the numbering pass
+    *tiny_count = run[4];
   }
 }
 
@@ -2000,14 +2167,18 @@ __device__ __forceinline__ void lg3_firsts(const Lg3Args& a, int64_t t, int32_t&
 
 __global__ __launch_bounds__(256) void lg3_assign_kernel(Lg3Args a, const int32_t* tile_counts, int32_t n_tiles,
                                                          uint32_t* nodes, int32_t* meta, int32_t* rowptr, int32_t* rowend,
-                                                         int32_t* cursor, int32_t* alias_edges, int32_t* sort_rows,
-                                                         int32_t* sort_count, int32_t* tiny_rows, int32_t* tiny_count) {
-  __shared__ int32_t s_w[TILE / 64][5];
-  __shared__ int32_t s_row_base, s_q_base, s_t_base;
+                                                         int32_t* tile_edges, int32_t* sort_rows, int32_t* tiny_rows) {
+  // per (sub-row, wave): level-0 firsts, level-1 firsts, row entries needed, rows queued for sorting (long | tiny); after
+  // the barrier: their exclusive prefixes in (sub-row, wave) order
+  __shared__ int32_t s_w[TILE / 64 + 1][5];
+  __shared__ int32_t s_alias[4];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int32_t before0 = tile_counts[blockIdx.x * 2 + 0], before1 = tile_counts[blockIdx.x * 2 + 1];
-  const int32_t total0 = tile_counts[n_tiles * 2 + 0], total1 = tile_counts[n_tiles * 2 + 1];
+  const int32_t* tcb = tile_counts + (int64_t)blockIdx.x * LG3_TC;
+  const int32_t before0 = tcb[0], before1 = tcb[1];
+  const int32_t s_row_base = tcb[2], s_q_base = tcb[3], s_t_base = tcb[4];  // (the dedup pass left every prefix: no cursor)
+  const int32_t total0 = tile_counts[n_tiles * LG3_TC + 0], total1 = tile_counts[n_tiles * LG3_TC + 1];
   const int64_t base = (int64_t)blockIdx.x * TILE;
+  const unsigned long long below = (1ull << lane) - 1ull;
   int32_t fw[TILE / 256];
   int k0[TILE / 256], k1[TILE / 256];
   uint32_t own[TILE / 256];
@@ -2025,7 +2196,7 @@ __global__ __launch_bounds__(256) void lg3_assign_kernel(Lg3Args a, const int32_
     own_len[r] = 0;
     if (own[r]) {
       const bool multi = fw[r] < 0;
-      const bool alias = a.alias_base >= 0 && t >= a.b && !multi;
+      const bool alias = a.alias_base >= 0 && t >= a.b && (!multi || lg3_row_is_segment(a, mycode, a.cnt1[t - a.b]));
       own_len[r] = alias ? -1 : a.rowcnt[t];
       if (!alias) {
         nd += own_len[r];
@@ -2035,57 +2206,42 @@ __global__ __launch_bounds__(256) void lg3_assign_kernel(Lg3Args a, const int32_
       }
     }
     // (a node first seen as an extra has no hop-0 occurrence, hence no in-edges: its row is empty)
-    int32_t i0 = k0[r], i1 = k1[r], in = nd, iq = nq, it = nt;
-    for (int off = 1; off < 64; off <<= 1) {
-      const int32_t o0 = __shfl_up(i0, off, 64), o1 = __shfl_up(i1, off, 64), on = __shfl_up(in, off, 64),
-                    oq = __shfl_up(iq, off, 64), ot = __shfl_up(it, off, 64);
-      if (lane >= off) {
-        i0 += o0;
-        i1 += o1;
-        in += on;
-        iq += oq;
-        it += ot;
-      }
-    }
-    x0[r] = i0 - k0[r];
+    // 0 / 1 flags are ranked by ballot + popcount, the two counts by a DPP scan: nothing goes through the LDS pipeline
+    const unsigned long long m0 = __ballot(k0[r] != 0), mq = __ballot(nq != 0), mt = __ballot(nt != 0);
+    const int32_t i1 = gigl_wave_incl_scan(k1[r]), in = gigl_wave_incl_scan(nd);
+    x0[r] = (int32_t)__popcll(m0 & below);
     x1[r] = i1 - k1[r];
     xn[r] = in - nd;
-    xq[r] = iq - nq;
-    xt[r] = it - nt;
+    xq[r] = (int32_t)__popcll(mq & below);
+    xt[r] = (int32_t)__popcll(mt & below);
     if (lane == 63) {
-      s_w[r * 4 + w][0] = i0;
+      s_w[r * 4 + w][0] = (int32_t)__popcll(m0);
       s_w[r * 4 + w][1] = i1;
       s_w[r * 4 + w][2] = in;
-      s_w[r * 4 + w][3] = iq;
-      s_w[r * 4 + w][4] = it;
+      s_w[r * 4 + w][3] = (int32_t)__popcll(mq);
+      s_w[r * 4 + w][4] = (int32_t)__popcll(mt);
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    int32_t tot = 0, totq = 0, tott = 0;
-    for (int q = 0; q < TILE / 64; ++q) {
-      tot += s_w[q][2];
-      totq += s_w[q][3];
-      tott += s_w[q][4];
+  if (w == 0) {  // exclusive prefixes over the TILE / 64 (sub-row, wave) entries, the totals in the entry after them
+    int32_t v[5], e[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      v[c] = lane < TILE / 64 ? s_w[lane][c] : 0;
+      e[c] = gigl_wave_incl_scan(v[c]) - v[c];
     }
-    s_row_base = tot ? atomicAdd(cursor, tot) : 0;
-    s_q_base = totq ? atomicAdd(sort_count, totq) : 0;
-    s_t_base = tott ? atomicAdd(tiny_count, tott) : 0;
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+      if (lane <= TILE / 64) s_w[lane][c] = e[c];  // (lane TILE / 64 holds the sum of all entries)
   }
   __syncthreads();
   int32_t alias_c = 0;
 #pragma unroll
   for (int r = 0; r < TILE / 256; ++r) {
     if (!(k0[r] | k1[r])) continue;
-    int32_t p0 = before0 + x0[r], p1 = total0 + before1 + x1[r], pn = s_row_base + xn[r], pq = s_q_base + xq[r],
-            pt = s_t_base + xt[r];
-    for (int q = 0; q < r * 4 + w; ++q) {
-      p0 += s_w[q][0];
-      p1 += s_w[q][1];
-      pn += s_w[q][2];
-      pq += s_w[q][3];
-      pt += s_w[q][4];
-    }
+    const int32_t* pre = s_w[r * 4 + w];
+    int32_t p0 = before0 + x0[r] + pre[0], p1 = total0 + before1 + x1[r] + pre[1], pn = s_row_base + xn[r] + pre[2],
+            pq = s_q_base + xq[r] + pre[3], pt = s_t_base + xt[r] + pre[4];
     const int64_t t = base + r * 256 + tid;
     if (own[r]) {
       const bool multi = fw[r] < 0;
@@ -2120,9 +2276,11 @@ __global__ __launch_bounds__(256) void lg3_assign_kernel(Lg3Args a, const int32_
       }
     }
   }
-  {
+  {  // edges of rows that are final here (tree segments, rows of roots that occur once): one plain store per tile
     for (int off = 32; off > 0; off >>= 1) alias_c += __shfl_xor(alias_c, off, 64);
-    if (lane == 0 && alias_c) atomicAdd(&alias_edges[blockIdx.x & 31], alias_c);
+    if (lane == 0) s_alias[w] = alias_c;
+    __syncthreads();
+    if (tid == 0) tile_edges[blockIdx.x] = s_alias[0] + s_alias[1] + s_alias[2] + s_alias[3];
   }
   if (blockIdx.x == 0 && tid == 0) {
     meta[GIGL_META_LEVEL0] = total0;
@@ -2174,7 +2332,7 @@ __global__ __launch_bounds__(256) void lg3_fill_kernel(Lg3Args a, int32_t* rowen
   if (edge && (multi || a.alias_base < 0)) {
     const int64_t p = t - a.b;
     const int c = a.cnt1[p];
-    if (c > 0 && lg3_contributes(a, code, mycode, c)) {
+    if (c > 0 && !lg3_row_is_segment(a, code, c) && lg3_contributes(a, code, mycode, c)) {
       const int32_t at = atomicAdd(&rowend[lid], c);
       const bool local = code < (uint32_t)a.gr;  // the node is a root: its row holds local ids
       const int64_t xg = (int64_t)grp * a.S0g * a.f1;  // the batch's extras
@@ -2205,10 +2363,16 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   const int64_t S0 = (int64_t)b * f0, S1 = S0 * f1, T_in = b + S0;
   const int64_t n_groups = b / group_roots;
   const int64_t gr = group_roots, Tg = gr * (1 + f0), S1g = gr * f0 * f1;
-  if (Tg + S1g >= (int64_t)LG3_CODE_MASK || f1 > 64 || b + S0 + S1 >= ((int64_t)1 << 31)) return GIGL_OK;  // -> LG2
-  // LDS table: 4-byte slots at load <= 1/2 for the nodes a batch may hold (more do not fit the plan's workspace)
+  // (20-bit stream codes; a thread of the dedup pass keeps one bit per 1024 hop-0 slots of the batch in a 64-bit mask)
+  if (Tg + S1g >= (int64_t)LG3_CODE_MASK || f1 > 64 || b + S0 + S1 >= ((int64_t)1 << 31) || gr * f0 > 64 * 1024) return GIGL_OK;  // -> LG2
+  // LDS table: 8-byte slots at load <= 1/2 for the nodes a batch may hold (more do not fit the plan's workspace)
+  static const int64_t cap_max = [] {
+    const char* e = getenv("GIGL_LG3_CAP");  // (A/B knob: slots per workgroup, a power of two)
+    const int64_t v = e ? atoll(e) : 0;
+    return v >= 1024 && v <= 16384 && (v & (v - 1)) == 0 ? v : (int64_t)16384;
+  }();
   int64_t cap = 1024;
-  while (cap < 2 * Tg && cap < 16384) cap <<= 1;
+  while (cap < 2 * Tg && cap < cap_max) cap <<= 1;
   const int64_t P = (2 * Tg + cap - 1) / cap;
   if (P > LG3_MAX_PARTS) return GIGL_OK;
   int64_t rs = 64;
@@ -2217,16 +2381,18 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
     rs <<= 1;
     ++rs_log2;
   }
-  const int64_t n_tcnt = 2 * ((gr >> 10) + 2 + ((gr * f0) >> 10) + 2);
-  const size_t lds_bytes = (size_t)(cap + rs + n_tcnt) * 4;
+  const int64_t n_tcnt = LG3_TC * ((gr >> 10) + 2 + ((gr * f0) >> 10) + 2);
+  const size_t lds_bytes = (size_t)cap * 8 + (size_t)(rs + rs / 4 + n_tcnt) * 4;
   if (lds_bytes > 150 * 1024) return GIGL_OK;
   *taken = true;
   hipStream_t st = ctx->stream;
   const int32_t n_tiles = (int32_t)((T_in + TILE - 1) / TILE);
-  const int64_t zero_words = 256 + (int64_t)(n_tiles + 1) * 2;  // counters | tile counts
+  constexpr int EC_STRIDE = 32;  // every spread edge counter on its own 128-byte line (same-line atomics serialise in L2)
+  const int64_t zero_words = 64 + 32 * EC_STRIDE + (int64_t)(n_tiles + 1) * LG3_TC;  // scalars | edge counters | tile counts
   int64_t need = 0;
   auto add = [&](int64_t bytes) { need += gigl_align_up(bytes, 256); };
   add(zero_words * 4);
+  add((int64_t)n_tiles * 4);  // edges of the rows each tile finished
   add(T_in * 4);  // fpw
   add(T_in * 4);  // lid_in
   add(T_in * 4);  // rowcnt
@@ -2237,6 +2403,7 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   int32_t rc = gigl_arena_reset(ctx, need + 4096);
   if (rc != GIGL_OK) return rc;
   int32_t* zeros = (int32_t*)gigl_arena_alloc(ctx, zero_words * 4);
+  int32_t* tile_edges = (int32_t*)gigl_arena_alloc(ctx, (int64_t)n_tiles * 4);
   Lg3Args a{};
   a.fpw = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
   a.lid_in = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
@@ -2245,7 +2412,7 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   int32_t* big_rows = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
   int32_t* sort_rows = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
   int32_t* tiny_rows = (int32_t*)gigl_arena_alloc(ctx, T_in * 4);
-  if (!zeros || !a.fpw || !a.lid_in || !a.rowcnt || !a.fpx || !big_rows || !sort_rows || !tiny_rows)
+  if (!zeros || !tile_edges || !a.fpw || !a.lid_in || !a.rowcnt || !a.fpx || !big_rows || !sort_rows || !tiny_rows)
     return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   a.roots = roots;
   a.nbr0 = tree->nbr[0];
@@ -2264,19 +2431,19 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   a.cmask = (uint32_t)(cap - 1);
   a.rmask = (uint32_t)(rs - 1);
   a.rs_shift = 32 - rs_log2;
+  a.bl_shift = 32 - (rs_log2 + 3);
   a.whole_rows = multiset_rows ? 0 : 1;
   a.overflow = out->meta + GIGL_META_OVERFLOW;
   a.alias_base = -1;
   if (tree->nbr[1] == (const uint32_t*)(out->col + out->cap_edges) && out->cap_edges + S1 < ((int64_t)1 << 31))
     a.alias_base = (int32_t)out->cap_edges;
-  int32_t* cursor = zeros;            // [0]
   int32_t* ticket_count = zeros + 1;  // [1]
   int32_t* ticket_big = zeros + 2;    // [2]
   int32_t* big_count = zeros + 3;     // [3]
   int32_t* sort_count = zeros + 4;    // [4]
   int32_t* tiny_count = zeros + 5;    // [5]
-  int32_t* edge_counters = zeros + 64;   // [64..96): sorted + queued rows, [96..128): aliased rows
-  int32_t* tile_counts = zeros + 256;
+  int32_t* edge_counters = zeros + 64;  // 32 counters EC_STRIDE words apart: sorted + queued rows
+  int32_t* tile_counts = zeros + 64 + 32 * EC_STRIDE;
   const int TB = 256;
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
   static bool lds_attr_set = false;  // more than 64 KiB of dynamic LDS needs the opt-in once per process
@@ -2292,13 +2459,12 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
     gigl_prof_scope ps(ctx, GIGL_K_UNION_INSERT);
     hipLaunchKernelGGL(lg3_init_kernel, dim3(256), dim3(256), 0, st, a.rowcnt, T_in, zeros, zero_words, out->meta);
     hipLaunchKernelGGL(lg3_dedup_kernel, dim3((unsigned)(n_groups * P)), dim3(1024), lds_bytes, st, a, tile_counts,
-                       n_tiles, ticket_count);
+                       n_tiles, ticket_count, sort_count, tiny_count);
   }
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_NODES);
     hipLaunchKernelGGL(lg3_assign_kernel, dim3((unsigned)n_tiles), dim3(256), 0, st, a, tile_counts, n_tiles, out->nodes,
-                       out->meta, out->rowptr, out->rowend, cursor, edge_counters + 32, sort_rows, sort_count, tiny_rows,
-                       tiny_count);
+                       out->meta, out->rowptr, out->rowend, tile_edges, sort_rows, tiny_rows);
   }
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_EDGE_SORT);
@@ -2307,20 +2473,22 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_CSR);
     {
-      int64_t tb = (T_in / 16 + 255) / 256;
-      if (tb > 1024) tb = 1024;
+      // (a thread per row: one pass over the queue when up to a quarter of the inner positions own such a row)
+      static const int64_t tiny_div = getenv("GIGL_LG3_TINY_DIV") ? atoll(getenv("GIGL_LG3_TINY_DIV")) : 4;
+      int64_t tb = (T_in / (tiny_div > 0 ? tiny_div : 4) + 255) / 256;
+      if (tb > 4096) tb = 4096;
       if (tb < 16) tb = 16;
       hipLaunchKernelGGL(lg2_row_sort_tiny_kernel, dim3((unsigned)tb), dim3(256), 0, st, tiny_rows, tiny_count,
-                         out->rowptr, out->rowend, out->col, edge_counters);
+                         out->rowptr, out->rowend, out->col, edge_counters, EC_STRIDE);
     }
     int64_t blocks = (T_in / 8 + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (blocks < 64) blocks = 64;
     hipLaunchKernelGGL(lg2_row_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, sort_rows, sort_count, out->rowptr,
-                       out->rowend, out->col, big_rows, big_count, edge_counters);
+                       out->rowend, out->col, big_rows, big_count, edge_counters, EC_STRIDE);
     hipLaunchKernelGGL(lg2_row_sort_big_kernel, dim3(8), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st, out->rowptr,
                        out->rowend, out->col, big_rows, big_count, out->meta + GIGL_META_OVERFLOW, edge_counters,
-                       ticket_big, out->meta);
+                       ticket_big, out->meta, EC_STRIDE, (const int32_t*)tile_edges, n_tiles);
   }
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
