@@ -72,11 +72,60 @@ PMC_KERNELS = {
     "gather_mean": ["gather_mean_kernel"],
     "linear": ["linear_split_kernel", "linear_lds_kernel", "linear_mfma_kernel"],
     # (the one-call plan's two-hop union build, union.hip "LG2"; the generic build's kernels have other names)
-    "union_insert": ["lg2_init_kernel", "lg2_insert_kernel", "lg2_extras_kernel"],
-    "union_nodes": ["lg2_count_kernel", "lg2_assign_kernel"],
-    "union_edge_sort": ["lg2_fill_kernel"],
+    # (round 4: the LDS-staged build "LG3" — lg3_* — replaced lg2_insert / extras / count / assign / fill)
+    "union_insert": ["lg2_init_kernel", "lg2_insert_kernel", "lg2_extras_kernel", "lg3_init_kernel", "lg3_dedup_kernel"],
+    "union_nodes": ["lg2_count_kernel", "lg2_assign_kernel", "lg3_assign_kernel"],
+    "union_edge_sort": ["lg2_fill_kernel", "lg3_fill_kernel"],
     "union_csr": ["lg2_row_sort_tiny_kernel", "lg2_row_sort_kernel", "lg2_row_sort_big_kernel"],
 }
+_LIVE_PMC = {}  # workload-shape key -> summary collected by THIS run (collect_live_pmc)
+
+
+def collect_live_pmc(extra_args, timeout_s: float = 420.0):
+    """HBM traffic per kernel measured by THIS run: the four rocprofv3 passes of scripts/gpu_pmc.sh (FETCH_SIZE and
+    WRITE_SIZE in separate passes, --kernel-trace only, each over the known-byte calibration launches and over a short
+    single-stream eager --timed-only run of this same workload) as child processes once the timed region is over, folded
+    by scripts/pmc_summary.py with the guide's calibration.  -> (summary dict, None) or (None, reason)."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tag = f"live{os.getpid()}"
+    out_root = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_root, exist_ok=True)
+    env = dict(os.environ, TMPDIR="/tmp", GIGL_BENCH_CHILD="1")
+    t0 = time.time()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            base = os.path.join(out_root, f"pmc_{tag}_{ctr}")
+            for what, cmd in (("calib", [sys.executable, os.path.join(ROOT, "scripts", "pmc_calib.py")]),
+                              ("bench", [sys.executable, os.path.abspath(__file__), "--streams", "1", "--no-graph", "--steps",
+                                         "64", "--min-rounds", "2", "--warmup", "32", "--timed-only", "--no-cpu-baseline",
+                                         "--no-live-pmc"] + list(extra_args))):
+                left = timeout_s - (time.time() - t0)
+                if left < 20:
+                    return None, f"live PMC passes did not fit {timeout_s:.0f} s"
+                with open(os.path.join(out_root, f"pmc_{tag}_{ctr}_{what}.log"), "w") as log:
+                    cp = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "-f", "csv", "-d", os.path.join(base, what),
+                                         "-o", what, "--"] + cmd, cwd=ROOT, env=env, stdout=log, stderr=subprocess.STDOUT,
+                                        timeout=left)
+                if cp.returncode != 0:
+                    return None, f"rocprofv3 --pmc {ctr} ({what}) exited with {cp.returncode}"
+        cp = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_summary.py"), tag], cwd=ROOT, env=env,
+                            capture_output=True, text=True, timeout=120)
+        if cp.returncode != 0:
+            return None, f"pmc_summary failed: {cp.stderr.strip()[-200:]}"
+        doc = json.load(open(os.path.join(out_root, f"pmc_{tag}.json")))
+        doc["collected_s"] = round(time.time() - t0, 1)
+        return doc, None
+    except subprocess.TimeoutExpired:
+        return None, f"live PMC passes did not finish within {timeout_s:.0f} s"
+    except Exception as ex:  # noqa: BLE001
+        return None, f"{type(ex).__name__}: {str(ex)[:200]}"
+    finally:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            shutil.rmtree(os.path.join(out_root, f"pmc_{tag}_{ctr}"), ignore_errors=True)
 
 
 def pmc_traffic(kernel_id: str, batches_per_call: int, workload: str = "products", projected: bool = False):
@@ -89,7 +138,10 @@ def pmc_traffic(kernel_id: str, batches_per_call: int, workload: str = "products
     if kernel_id not in PMC_KERNELS:
         return None, None
     doc = src = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc*.json")), reverse=True):
+    live = _LIVE_PMC.get((workload, batches_per_call, bool(projected)))
+    if live is not None:  # counters collected by this very run take precedence over any committed summary
+        doc, src = live, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (collect_live_pmc)"
+    for f in ([] if doc is not None else sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc*.json")), reverse=True)):
         try:
             cand = json.load(open(f))
         except (OSError, ValueError):
@@ -303,6 +355,10 @@ def main():
                     help="counter-collection runs (scripts/gpu_pmc.sh): only warm-up + the timed region, so every "
                          "library launch in the trace is a grouped launch; prints timing without edge counts")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N=1 headline: skip the rocprofv3 counter passes that measure this run's HBM traffic per kernel "
+                         "(roofline.traffic then comes from the newest committed profiles/*_pmc*.json of the workload, or is "
+                         "null); the passes run as child processes after the timed region, ~1.5 min")
     ap.add_argument("--mode", type=str, default="parity", choices=["parity", "fast"])
     ap.add_argument("--project-input", type=str, default="auto", choices=["auto", "on", "off"],
                     help="first layer over PROJECTED rows (X W_l^T / X W_r^T computed once over the resident table, "
@@ -510,8 +566,8 @@ def main():
         raise RuntimeError("union dedup / workspace overflow in a benchmark batch (meta[GIGL_META_OVERFLOW])")
 
     # ---- untimed: the same timers under the TIMED regime (S streams, G batches per call, launches eager so the events
-    # bracket them): the dominant kernel is the one with the largest share there — with the other streams' kernels
-    # resident a launch lasts longer than alone, and not by the same factor for every kernel
+    # bracket them) — with the other streams' kernels resident a launch lasts longer than alone, and not by the same
+    # factor for every kernel: both figures are reported for every group (roofline.groups)
     prof_alone = prof
     if S > 1:
         for e in engines:
@@ -525,9 +581,11 @@ def main():
         prof_ovl = {k: [sum(x) for x in zip(*[e.profile_read(k) for e in engines])] for k in names}
         for e in engines:
             e.profile_enable([], 0)
-        dominant = max(prof_ovl, key=lambda k: prof_ovl[k][0])
     else:
         prof_ovl = prof
+    # the dominant group = the one with the largest duration of its OWN (single-stream probe): a stable ranking — under
+    # overlap two near-equal groups trade places from run to run; every group's overlapped figure is in roofline.groups
+    dominant = max(prof, key=lambda k: prof[k][0])
 
     # ---- calibration repetition (untimed; also re-captures every plan's hipGraph under the final timer mask)
     for e in engines:
@@ -630,6 +688,17 @@ def main():
     avg_launch_ms = dom_ms / max(dom_launches, 1)
     bytes_per_launch = alg_timed[dominant] / max(dom_launches, 1)
     achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    live_pmc_note = None
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)  # (no nested rocprofv3 runs)
+    if rank == 0 and world == 1 and not args.no_live_pmc and not args.timed_only and not under_profiler and \
+            not os.environ.get("GIGL_BENCH_CHILD"):
+        passthrough = ["--workload", args.workload, "--batch", str(B), "--fanouts", ",".join(str(f) for f in fanouts),
+                       "--group", str(G), "--mode", args.mode, "--project-input", args.project_input] + \
+            (["--small"] if args.small else [])
+        torch.cuda.synchronize()
+        doc_, live_pmc_note = collect_live_pmc(passthrough)
+        if doc_ is not None:
+            _LIVE_PMC[(wl_name, G, bool(projected))] = doc_
     traffic, traffic_src = pmc_traffic(dominant, G, wl_name, projected)
     # every kernel group against its own bound, from the single-stream probe (P steps, all timers on)
     by_kernel = {}
@@ -703,11 +772,45 @@ def main():
                         f"shape is committed: headline = `{k2}`, the slowest HBM-bound group (single-stream probe)")
     head["frac_overlapped"] = head["frac"]  # the kernel while the other streams' kernels share the GPU (timed region)
     head["frac_alone"] = by_kernel.get(head["kernel"], {}).get("frac")  # ... and on its own (single-stream probe)
-    roofline = {**head,
+    # every group, alone and overlapped, against the bytes it must move and the bytes it did move (counters)
+    groups, step_alg, step_traffic, traffic_complete = {}, 0.0, 0.0, True
+    for k in names:
+        if prof[k][0] <= 0:
+            continue
+        alone_ms, ovl_ms = prof[k][0] / P, prof_ovl[k][0] / P
+        ab = alg_probe[k] / P
+        tk, _ = pmc_traffic(k, G, wl_name, projected)
+        tb = None  # counter bytes per step
+        if tk is not None and k.startswith("union"):
+            tb = tk / G  # (a union group's kernels run once per call each: pmc_traffic returns the group's bytes per call)
+        elif tk is not None:
+            tb = tk * (prof[k][1] / max(P // G, 1)) / G  # bytes per launch x launches per call / batches per call
+        step_alg += ab
+        if tb is None:
+            traffic_complete = False
+        else:
+            step_traffic += tb
+        fr = lambda byts, ms: None if byts is None or ms <= 0 else round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        groups[k] = {"ms_per_step_alone": round(alone_ms, 5), "ms_per_step_overlapped": round(ovl_ms, 5),
+                     "alg_bytes_per_step": round(ab), "frac_alone": fr(ab, alone_ms), "frac_overlapped": fr(ab, ovl_ms),
+                     "traffic_bytes_per_step": None if tb is None else round(tb),
+                     "traffic_frac_alone": fr(tb, alone_ms), "traffic_frac_overlapped": fr(tb, ovl_ms)}
+        if k == "linear":
+            groups[k]["mfma_16bit_frac_alone"] = round(issued_probe / P / (alone_ms * 1e-3) / 1e12 / MFMA_16BIT_PEAK_TF, 4)
+            groups[k]["mfma_16bit_frac_overlapped"] = round(issued_probe / P / (max(ovl_ms, 1e-9) * 1e-3) / 1e12 / MFMA_16BIT_PEAK_TF, 4)
+    step_ms = elapsed / steps_total * 1e3
+    step_level = {"ms_per_step": round(step_ms, 5), "alg_bytes_per_step": round(step_alg),
+                  "alg_frac": round(step_alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  "traffic_bytes_per_step": round(step_traffic) if traffic_complete and step_traffic > 0 else None,
+                  "traffic_frac": (round(step_traffic / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                   if traffic_complete and step_traffic > 0 else None),
+                  "note": "all kernel groups of a step together: bytes per step / the timed region's ms_per_step / the HBM "
+                          "peak — independent of which group is called dominant"}
+    roofline = {**head, "groups": groups, "step": step_level, "live_pmc": live_pmc_note or ("collected" if _LIVE_PMC else None),
                 "traffic": None if traffic is None else round(traffic), "traffic_source": traffic_src,
                 "dominant": dominant,
-                "dominant_from": "largest total HIP-event time per kernel group in an untimed repetition of the timed "
-                                 "regime (all timers on, launches eager)",
+                "dominant_from": "largest HIP-event time per kernel group on its own (single-stream untimed probe, all "
+                                 "timers on): stable from run to run; `groups` lists every group alone and overlapped",
                 "overlapped_ms_per_step": {k: round(v[0] / P, 5) for k, v in prof_ovl.items() if v[0] > 0},
                 "avg_launch_us": round(avg_launch_ms * 1e3, 2),
                 "alg_bytes_per_launch": round(bytes_per_launch), "launches": int(dom_launches), "note": note,
