@@ -528,66 +528,117 @@ struct __attribute__((aligned(32))) RowDesc {
 
 __device__ __forceinline__ float filter_lambda(int f) { return (float)f + 4.f * __builtin_sqrtf((float)f) + 4.f; }
 
+// Work lists of the expansion pass (round 4).  On a power-law graph most parent slots of the last hop are empty (a
+// root with 8 neighbours leaves 17 of its 25 hop-1 slots invalid) and many rows are no longer than the fanout
+// (copy-through): a wave per slot pair spent two thirds of the waves of a [25,10] hop on slots with nothing to select.
+// The planning pass — a thread per slot — now finishes those rows itself (f stores) and appends only the rows that need
+// a selection to a work list; the expansion pass is a persistent grid that walks the lists.  WORK_LISTS lists, each
+// with its counter on its own 128-byte line (same-line atomics serialise in L2), one atomic per planning workgroup.
+constexpr int WORK_LISTS = 64;
+constexpr int WORK_CNT_STRIDE = 32;  // int32 words between counters
+
+struct WorkLists {
+  uint32_t* items;  // [WORK_LISTS][cap]
+  int32_t* count;   // [WORK_LISTS * WORK_CNT_STRIDE]
+  int64_t cap;
+};
+
+__host__ __device__ static inline int64_t work_list_cap(int64_t n_parents) {
+  return ((n_parents / 256 + 1 + WORK_LISTS - 1) / WORK_LISTS) * 256;
+}
+// scratch behind the descriptors of a hop with n parents (the callers size their arena with the widest hop)
+static inline int64_t expand_desc_bytes(int64_t n_parents) {
+  return (n_parents + 1) * (int64_t)sizeof(RowDesc) + WORK_LISTS * work_list_cap(n_parents) * 4 +
+         WORK_LISTS * WORK_CNT_STRIDE * 4 + 512;
+}
+
 __global__ __launch_bounds__(256) void plan_rows_kernel(ExpandArgs a, RangeTable tb, RowDesc* __restrict__ desc,
-                                                        int64_t* heavy_list, int32_t* heavy_count) {
+                                                        int64_t* heavy_list, int32_t* heavy_count, WorkLists wl) {
+  __shared__ int32_t s_wave[4];
+  __shared__ int32_t s_base;
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-  if (p > (uint32_t)a.n_parents) return;
-  RowDesc d{};
-  if (p == (uint32_t)a.n_parents) {  // the slot after the last: the partner of an odd last row
-    d.kind_cnt = ROW_SKIP;
-    desc[p] = d;
-    return;
-  }
-  uint32_t v, ksum;
-  parent_of(a, p, v, ksum);
-  if (v == GIGL_INVALID || (int64_t)v >= a.n_nodes) {
-    d.kind_cnt = ROW_INVALID;
-    desc[p] = d;
-    return;
-  }
-  d.s = a.rowptr[v];
-  const int64_t deg = a.rowptr[v + 1] - d.s;
-  d.n = (uint32_t)deg;
-  d.base = ksum + (uint32_t)a.hash_add;  // int32 wrap == uint32 wrap
-  if (deg <= a.f) {
-    d.kind_cnt = ROW_COPY;
-    desc[p] = d;
-    return;
-  }
-  const bool in_table = (uint64_t)d.base + (uint64_t)deg < tb.dom;  // also excludes 2^32 wrap-around
-  const float lam = filter_lambda(a.f);
-  // (any T is a valid filter: the approximate reciprocal is fine)
-  d.T = d.n <= 64u ? 0xFFFFFFFFu
-                   : (uint32_t)fminf(lam * 4294967296.f * __builtin_amdgcn_rcpf((float)d.n), 4294967040.f);
-  uint32_t kind;
-  if (!in_table) {
-    if (deg > HEAVY_DEG) {  // left to expand_heavy_kernel (workgroup per parent)
-      kind = ROW_SKIP;
-      if (heavy_list) heavy_list[atomicAdd(heavy_count, 1)] = (int64_t)p;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  bool real = false;  // the row needs the expansion pass
+  if (p <= (uint32_t)a.n_parents) {
+    RowDesc d{};
+    if (p == (uint32_t)a.n_parents) {  // the slot after the last: the partner of an odd last row
+      d.kind_cnt = ROW_SKIP;
+      desc[p] = d;
     } else {
-      kind = lam <= 56.f ? ROW_HASH : ROW_SERIAL_HASH;
-    }
-  } else if (lam > 56.f) {
-    kind = ROW_SERIAL;
-  } else {
-    const int l = min((int)__builtin_clz(d.T - 1u), tb.levels);  // deepest level with 2^(32-l) >= T  (T >= 2)
-    if (l == 0 || d.n <= (uint32_t)a.flat_max) {
-      kind = ROW_FLAT;
-      d.ptr = tb.flat;
-    } else {
-      const int gs = TBL_IDX_SHIFT + l;
-      const uint32_t* off = tb.off[l];
-      const uint32_t start = off[(d.base + 1u) >> gs], end = off[((d.base + d.n) >> gs) + 1u];
-      if (end - start > 256u) {  // (a row longer than the deepest level is made for)
-        kind = ROW_SERIAL;
+      uint32_t v, ksum;
+      parent_of(a, p, v, ksum);
+      uint32_t* out = a.out_nbr + (int64_t)p * a.f;
+      if (v == GIGL_INVALID || (int64_t)v >= a.n_nodes) {  // finished here: an empty row
+        for (int j = 0; j < a.f; ++j) out[j] = GIGL_INVALID;
+        a.out_cnt[p] = 0;
       } else {
-        kind = ROW_LEVEL | ((end - start) << 3);
-        d.ptr = tb.lvl[l] + start;
+        d.s = a.rowptr[v];
+        const int64_t deg = a.rowptr[v + 1] - d.s;
+        d.n = (uint32_t)deg;
+        d.base = ksum + (uint32_t)a.hash_add;  // int32 wrap == uint32 wrap
+        if (deg <= a.f && !a.multi) {  // finished here: copy-through, the row is already the canonical ascending set
+          const uint32_t* row = a.col + d.s;
+          for (int j = 0; j < a.f; ++j) out[j] = j < (int)deg ? row[j] : GIGL_INVALID;
+          a.out_cnt[p] = (int32_t)deg;
+        } else if (deg <= a.f) {
+          d.kind_cnt = ROW_COPY;
+          desc[p] = d;
+          real = true;
+        } else {
+          const bool in_table = (uint64_t)d.base + (uint64_t)deg < tb.dom;  // also excludes 2^32 wrap-around
+          const float lam = filter_lambda(a.f);
+          // (any T is a valid filter: the approximate reciprocal is fine)
+          d.T = d.n <= 64u ? 0xFFFFFFFFu
+                           : (uint32_t)fminf(lam * 4294967296.f * __builtin_amdgcn_rcpf((float)d.n), 4294967040.f);
+          uint32_t kind;
+          if (!in_table) {
+            if (deg > HEAVY_DEG) {  // left to expand_heavy_kernel (workgroup per parent)
+              kind = ROW_SKIP;
+              if (heavy_list) heavy_list[atomicAdd(heavy_count, 1)] = (int64_t)p;
+            } else {
+              kind = lam <= 56.f ? ROW_HASH : ROW_SERIAL_HASH;
+            }
+          } else if (lam > 56.f) {
+            kind = ROW_SERIAL;
+          } else {
+            const int l = min((int)__builtin_clz(d.T - 1u), tb.levels);  // deepest level with 2^(32-l) >= T  (T >= 2)
+            if (l == 0 || d.n <= (uint32_t)a.flat_max) {
+              kind = ROW_FLAT;
+              d.ptr = tb.flat;
+            } else {
+              const int gs = TBL_IDX_SHIFT + l;
+              const uint32_t* off = tb.off[l];
+              const uint32_t start = off[(d.base + 1u) >> gs], end = off[((d.base + d.n) >> gs) + 1u];
+              if (end - start > 256u) {  // (a row longer than the deepest level is made for)
+                kind = ROW_SERIAL;
+              } else {
+                kind = ROW_LEVEL | ((end - start) << 3);
+                d.ptr = tb.lvl[l] + start;
+              }
+            }
+          }
+          d.kind_cnt = kind;
+          desc[p] = d;
+          real = (kind & 7u) != ROW_SKIP;
+        }
       }
     }
   }
-  d.kind_cnt = kind;
-  desc[p] = d;
+  // append this workgroup's rows to one of the lists: rank inside the workgroup by ballot, one atomic per workgroup
+  const unsigned long long m = __ballot(real);
+  if (lane == 0) s_wave[w] = (int32_t)__popcll(m);
+  __syncthreads();
+  const int list = (int)(blockIdx.x % WORK_LISTS);
+  if (threadIdx.x == 0) {
+    const int32_t tot = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = tot ? atomicAdd(&wl.count[list * WORK_CNT_STRIDE], tot) : 0;
+  }
+  __syncthreads();
+  if (real) {
+    int32_t pos = s_base + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (int k = 0; k < w; ++k) pos += s_wave[k];
+    wl.items[(int64_t)list * wl.cap + pos] = p;
+  }
 }
 
 // candidates of one row fetched ahead of their use: up to two 64-wide chunks of (proxy, j)
@@ -645,122 +696,131 @@ __device__ __forceinline__ bool select_ahead(Sel<true>& sel, const RowDesc& d, c
 // of its dependent loads (SQ counters: waves wait 3/4 of their cycles at the 8 waves a SIMD holds), so two rows per
 // wave is twice the loads in flight.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void expand_rows_kernel(
-    ExpandArgs a, RangeTable tb, const RowDesc* __restrict__ desc) {
+    ExpandArgs a, RangeTable tb, const RowDesc* __restrict__ desc, WorkLists wl) {
   __shared__ __attribute__((aligned(16))) uint32_t s_lk[4][72], s_li[4][64];  // per-wave survivor scratch
   const int lane = threadIdx.x & 63;
   // the parent slots and everything in their descriptors are the same for all lanes: say so (readfirstlane), and the
   // per-row control flow below runs on the scalar unit with scalar loads
   const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t p0 = (blockIdx.x * 4u + (uint32_t)wave_in_block) * 2u;
-  if (p0 >= (uint32_t)a.n_parents) return;
   const int f = a.f;
   uint32_t* lk = s_lk[wave_in_block];
   uint32_t* li = s_li[wave_in_block];
-  const RowDesc d0 = desc[p0], d1 = desc[p0 + 1];  // (slot n_parents holds a ROW_SKIP descriptor)
-  const Cand c0 = fetch_candidates(d0, lane), c1 = fetch_candidates(d1, lane);
-  Sel<true> s0, s1;
-  s0.init(f, lane, a.proxy_drop);
-  s1.init(f, lane, a.proxy_drop);
-  // fast path: ordered selections straight to the output
-  const bool done0 = c0.ahead && !a.multi && select_ahead(s0, d0, c0, lk, li) && !s0.tie;
-  uint32_t slot0 = 0, val0 = 0;
-  bool sel0 = false;
-  if (done0) {
-    const unsigned long long m = s0.selmask;
-    sel0 = (m >> lane) & 1ull;
-    slot0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    if (sel0) val0 = (a.col + d0.s)[s0.idx - 1];
-  }
-  const bool done1 = c1.ahead && !a.multi && select_ahead(s1, d1, c1, lk, li) && !s1.tie;
-  uint32_t slot1 = 0, val1 = 0;
-  bool sel1 = false;
-  if (done1) {
-    const unsigned long long m = s1.selmask;
-    sel1 = (m >> lane) & 1ull;
-    slot1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    if (sel1) val1 = (a.col + d1.s)[s1.idx - 1];
-  }
-  if (done0) {
-    if (sel0) a.out_nbr[(int64_t)p0 * f + slot0] = val0;
-    if (lane == 0) a.out_cnt[p0] = f;
-  }
-  if (done1) {
-    if (sel1) a.out_nbr[(int64_t)(p0 + 1) * f + slot1] = val1;
-    if (lane == 0) a.out_cnt[p0 + 1] = f;
-  }
-  if (done0 && done1) return;
-  // general path: everything else (copies, invalid parents, long runs, windows outside the table, multi-edge graphs,
-  // rows the filter could not settle, ties), one row after the other
-#pragma nounroll
-  for (int r = 0; r < 2; ++r) {
-    if (r == 0 ? done0 : done1) continue;
-    const RowDesc d = r == 0 ? d0 : d1;
-    const uint32_t p = p0 + (uint32_t)r;
-    const uint32_t kind = d.kind_cnt & 7u;
-    if (kind == ROW_SKIP) continue;
-    uint32_t* out = a.out_nbr + (int64_t)p * f;
-    if (kind == ROW_INVALID) {
-      if (lane < f) out[lane] = GIGL_INVALID;
-      if (lane == 0) a.out_cnt[p] = 0;
-      continue;
+  // persistent grid (a multiple of WORK_LISTS waves): wave g walks list g % WORK_LISTS, two rows per step
+  const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave_in_block, n_waves = gridDim.x * 4u;
+  const uint32_t list = gw % WORK_LISTS, stride = n_waves / WORK_LISTS;
+  const int32_t n_items = __builtin_amdgcn_readfirstlane(wl.count[list * WORK_CNT_STRIDE]);
+  const uint32_t* items = wl.items + (int64_t)list * wl.cap;
+  for (uint32_t k = gw / WORK_LISTS; (int32_t)(2u * k) < n_items; k += stride) {
+    const uint32_t p0 = __builtin_amdgcn_readfirstlane(items[2u * k]);
+    const uint32_t p1 = (int32_t)(2u * k + 1u) < n_items ? __builtin_amdgcn_readfirstlane(items[2u * k + 1u])
+                                                         : (uint32_t)a.n_parents;  // (that slot holds a ROW_SKIP descriptor)
+    const RowDesc d0 = desc[p0], d1 = desc[p1];
+    const Cand c0 = fetch_candidates(d0, lane), c1 = fetch_candidates(d1, lane);
+    Sel<true> s0, s1;
+    s0.init(f, lane, a.proxy_drop);
+    s1.init(f, lane, a.proxy_drop);
+    // fast path: ordered selections straight to the output
+    const bool done0 = c0.ahead && !a.multi && select_ahead(s0, d0, c0, lk, li) && !s0.tie;
+    uint32_t slot0 = 0, val0 = 0;
+    bool sel0 = false;
+    if (done0) {
+      const unsigned long long m = s0.selmask;
+      sel0 = (m >> lane) & 1ull;
+      slot0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (sel0) val0 = (a.col + d0.s)[s0.idx - 1];
     }
-    const uint32_t* row = a.col + d.s;
-    const uint32_t n = d.n, base = d.base, T = d.T;
-    if (kind == ROW_COPY) {  // copy-through: the row is already the canonical ascending set
+    const bool done1 = c1.ahead && !a.multi && select_ahead(s1, d1, c1, lk, li) && !s1.tie;
+    uint32_t slot1 = 0, val1 = 0;
+    bool sel1 = false;
+    if (done1) {
+      const unsigned long long m = s1.selmask;
+      sel1 = (m >> lane) & 1ull;
+      slot1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (sel1) val1 = (a.col + d1.s)[s1.idx - 1];
+    }
+    if (done0) {
+      if (sel0) a.out_nbr[(int64_t)p0 * f + slot0] = val0;
+      if (lane == 0) a.out_cnt[p0] = f;
+    }
+    if (done1) {
+      if (sel1) a.out_nbr[(int64_t)p1 * f + slot1] = val1;
+      if (lane == 0) a.out_cnt[p1] = f;
+    }
+    if (done0 && done1) continue;
+    // general path: everything else (copies, invalid parents, long runs, windows outside the table, multi-edge graphs,
+    // rows the filter could not settle, ties), one row after the other
+  #pragma nounroll
+    for (int r = 0; r < 2; ++r) {
+      if (r == 0 ? done0 : done1) continue;
+      const RowDesc d = r == 0 ? d0 : d1;
+      const uint32_t p = r == 0 ? p0 : p1;
+      const uint32_t kind = d.kind_cnt & 7u;
+      if (kind == ROW_SKIP) continue;
+      uint32_t* out = a.out_nbr + (int64_t)p * f;
+      if (kind == ROW_INVALID) {
+        if (lane < f) out[lane] = GIGL_INVALID;
+        if (lane == 0) a.out_cnt[p] = 0;
+        continue;
+      }
+      const uint32_t* row = a.col + d.s;
+      const uint32_t n = d.n, base = d.base, T = d.T;
+      if (kind == ROW_COPY) {  // copy-through: the row is already the canonical ascending set
+        if (a.multi) {
+          const int nw = emit_sorted_distinct(row, (uint32_t)lane < n ? (uint32_t)lane + 1u : 0xFFFFFFFFu, f, lane, out);
+          if (lane == 0) a.out_cnt[p] = nw;
+          continue;
+        }
+        if (lane < f) out[lane] = (uint32_t)lane < n ? row[lane] : GIGL_INVALID;
+        if (lane == 0) a.out_cnt[p] = (int32_t)n;
+        continue;
+      }
+      const bool in_table = kind != ROW_HASH && kind != ROW_SERIAL_HASH;
+      uint32_t sel_idx;
+      {
+        Sel<true> fast;
+        fast.init(f, lane, a.proxy_drop);
+        bool done = false;
+        if (kind == ROW_LEVEL) done = fast.filter_level((const uint2*)d.ptr, d.kind_cnt >> 3, n, T, base, lk, li);
+        else if (kind == ROW_FLAT) done = fast.template filter_positions<SRC_FLAT>((const uint32_t*)d.ptr, n, T, base, lk, li);
+        else if (kind == ROW_HASH) done = fast.template filter_positions<SRC_HASH>(nullptr, n, T, base, lk, li);
+        if (!done) fast.serial(tb, n, base, T, in_table);
+        sel_idx = fast.idx;
+        if (fast.tie) {  // a 32-bit proxy tie touched the result (about once per 10^7 rows): redo exactly
+          Sel<false> exact;
+          exact.init(f, lane);
+          exact.serial(tb, n, base, T, in_table);
+          sel_idx = exact.idx;
+        } else if (fast.ordered) {  // selected lanes hold the positions in ascending order
+          const unsigned long long m = fast.selmask;
+          const bool sel = (m >> lane) & 1ull;
+          const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          const uint32_t val = sel ? row[sel_idx - 1] : GIGL_INVALID;
+          if (!a.multi) {
+            if (sel) out[slot] = val;
+            if (lane == 0) a.out_cnt[p] = f;
+            continue;
+          }
+          // ascending positions of an ascending row: a repeated id sits right after its first copy
+          if (sel) lk[slot] = val;
+          wave_lds_sync();
+          const bool keep = sel && (slot == 0 || lk[slot - 1] != val);
+          wave_lds_sync();
+          const unsigned long long km = __ballot(keep);
+          if (lane < f) out[lane] = GIGL_INVALID;
+          if (keep) out[__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u))] = val;
+          if (lane == 0) a.out_cnt[p] = (int32_t)__popcll(km);
+          continue;
+        }
+      }
       if (a.multi) {
-        const int nw = emit_sorted_distinct(row, (uint32_t)lane < n ? (uint32_t)lane + 1u : 0xFFFFFFFFu, f, lane, out);
+        const int nw = emit_sorted_distinct(row, sel_idx, f, lane, out);
         if (lane == 0) a.out_cnt[p] = nw;
         continue;
       }
-      if (lane < f) out[lane] = (uint32_t)lane < n ? row[lane] : GIGL_INVALID;
-      if (lane == 0) a.out_cnt[p] = (int32_t)n;
-      continue;
+      emit_sorted(row, sel_idx, f, lane, out);
+      if (lane == 0) a.out_cnt[p] = f;
     }
-    const bool in_table = kind != ROW_HASH && kind != ROW_SERIAL_HASH;
-    uint32_t sel_idx;
-    {
-      Sel<true> fast;
-      fast.init(f, lane, a.proxy_drop);
-      bool done = false;
-      if (kind == ROW_LEVEL) done = fast.filter_level((const uint2*)d.ptr, d.kind_cnt >> 3, n, T, base, lk, li);
-      else if (kind == ROW_FLAT) done = fast.template filter_positions<SRC_FLAT>((const uint32_t*)d.ptr, n, T, base, lk, li);
-      else if (kind == ROW_HASH) done = fast.template filter_positions<SRC_HASH>(nullptr, n, T, base, lk, li);
-      if (!done) fast.serial(tb, n, base, T, in_table);
-      sel_idx = fast.idx;
-      if (fast.tie) {  // a 32-bit proxy tie touched the result (about once per 10^7 rows): redo exactly
-        Sel<false> exact;
-        exact.init(f, lane);
-        exact.serial(tb, n, base, T, in_table);
-        sel_idx = exact.idx;
-      } else if (fast.ordered) {  // selected lanes hold the positions in ascending order
-        const unsigned long long m = fast.selmask;
-        const bool sel = (m >> lane) & 1ull;
-        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        const uint32_t val = sel ? row[sel_idx - 1] : GIGL_INVALID;
-        if (!a.multi) {
-          if (sel) out[slot] = val;
-          if (lane == 0) a.out_cnt[p] = f;
-          continue;
-        }
-        // ascending positions of an ascending row: a repeated id sits right after its first copy
-        if (sel) lk[slot] = val;
-        wave_lds_sync();
-        const bool keep = sel && (slot == 0 || lk[slot - 1] != val);
-        wave_lds_sync();
-        const unsigned long long km = __ballot(keep);
-        if (lane < f) out[lane] = GIGL_INVALID;
-        if (keep) out[__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u))] = val;
-        if (lane == 0) a.out_cnt[p] = (int32_t)__popcll(km);
-        continue;
-      }
-    }
-    if (a.multi) {
-      const int nw = emit_sorted_distinct(row, sel_idx, f, lane, out);
-      if (lane == 0) a.out_cnt[p] = nw;
-      continue;
-    }
-    emit_sorted(row, sel_idx, f, lane, out);
-    if (lane == 0) a.out_cnt[p] = f;
+    wave_lds_sync();  // (the next pair reuses this wave's scratch)
   }
 }
 
@@ -1085,12 +1145,21 @@ int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a_in, const RangeTable& tb, 
   }();
   a.flat_max = flat_max;
   if (!covered) GIGL_HIP_CHECK(ctx, hipMemsetAsync(heavy_count, 0, 4, ctx->stream));
+  // the work lists sit behind this hop's descriptors (expand_desc_bytes)
+  WorkLists wl{};
+  wl.cap = work_list_cap(a.n_parents);
+  wl.items = reinterpret_cast<uint32_t*>(desc + a.n_parents + 1);
+  wl.count = reinterpret_cast<int32_t*>(wl.items + (int64_t)WORK_LISTS * wl.cap);
+  wl.count = reinterpret_cast<int32_t*>(((uintptr_t)wl.count + 127) & ~(uintptr_t)127);
+  GIGL_HIP_CHECK(ctx, hipMemsetAsync(wl.count, 0, WORK_LISTS * WORK_CNT_STRIDE * 4, ctx->stream));
   {
     gigl_prof_scope ps(ctx, GIGL_K_EXPAND);
     hipLaunchKernelGGL(plan_rows_kernel, dim3((unsigned)(a.n_parents / 256 + 1)), dim3(256), 0, ctx->stream, a, tb,
-                       desc, covered ? nullptr : heavy_list, heavy_count);
-    hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)((a.n_parents + 7) / 8)), dim3(256), 0, ctx->stream, a, tb,
-                       (const RowDesc*)desc);
+                       desc, covered ? nullptr : heavy_list, heavy_count, wl);
+    // persistent: 8 waves per SIMD on every CU at most, a multiple of WORK_LISTS waves
+    int64_t wgs = ((a.n_parents + 7) / 8 + 15) / 16 * 16;
+    if (wgs > 2048) wgs = 2048;
+    hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a, tb, (const RowDesc*)desc, wl);
   }
   if (!covered) {
     gigl_prof_scope ps(ctx, GIGL_K_EXPAND_HEAVY);
@@ -1258,9 +1327,9 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
       q *= fanouts[k];
       if (q > max_parents) max_parents = q;
     }
-    rc = gigl_arena_reset(ctx, (max_parents + 1) * (int64_t)sizeof(RowDesc) + max_parents * 8 + 1024);
+    rc = gigl_arena_reset(ctx, expand_desc_bytes(max_parents) + max_parents * 8 + 1024);
     if (rc != GIGL_OK) return rc;
-    desc = (RowDesc*)gigl_arena_alloc(ctx, (max_parents + 1) * (int64_t)sizeof(RowDesc));
+    desc = (RowDesc*)gigl_arena_alloc(ctx, expand_desc_bytes(max_parents));
     if (!covered) {
       heavy_list = (int64_t*)gigl_arena_alloc(ctx, max_parents * 8);
       heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
@@ -1321,9 +1390,9 @@ int32_t gigl_expand_frontier(gigl_ctx* ctx, gigl_graph* shard, const uint32_t* n
   const bool covered = bounded && bound < tb.dom;
   int64_t* heavy_list = nullptr;
   int32_t* heavy_count = nullptr;
-  rc = gigl_arena_reset(ctx, (m + 1) * (int64_t)sizeof(RowDesc) + m * 8 + 1024);
+  rc = gigl_arena_reset(ctx, expand_desc_bytes(m) + m * 8 + 1024);
   if (rc != GIGL_OK) return rc;
-  RowDesc* desc = (RowDesc*)gigl_arena_alloc(ctx, (m + 1) * (int64_t)sizeof(RowDesc));
+  RowDesc* desc = (RowDesc*)gigl_arena_alloc(ctx, expand_desc_bytes(m));
   if (!covered) {
     heavy_list = (int64_t*)gigl_arena_alloc(ctx, m * 8);
     heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
@@ -1366,9 +1435,9 @@ int32_t gigl_sample_out_neighbors(gigl_ctx* ctx, gigl_graph* g_out, const uint32
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "num positives %d outside [1,%d]", f, GIGL_MAX_FANOUT);
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (b == 0) return GIGL_OK;
-  int32_t rc = gigl_arena_reset(ctx, (int64_t)(b + 1) * ((int64_t)sizeof(RowDesc) + 8) + 1024);
+  int32_t rc = gigl_arena_reset(ctx, expand_desc_bytes(b) + (int64_t)(b + 1) * 8 + 1024);
   if (rc != GIGL_OK) return rc;
-  RowDesc* desc = (RowDesc*)gigl_arena_alloc(ctx, (int64_t)(b + 1) * (int64_t)sizeof(RowDesc));
+  RowDesc* desc = (RowDesc*)gigl_arena_alloc(ctx, expand_desc_bytes(b));
   int64_t* heavy_list = (int64_t*)gigl_arena_alloc(ctx, (int64_t)b * 8);
   int32_t* heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
   if (!desc || !heavy_list || !heavy_count) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
