@@ -340,6 +340,13 @@ def main():
                     help="mag240m-sharded: sage = GraphSAGE 768->256->256 through gigl_dist_plan (dense pull bookkeeping, "
                          "hot rows); gat = BASELINE configs[4]'s encoder, 2-layer GAT heads 2 hid 128 out 128, through "
                          "gigl_dist_gat_plan (raw rows, generic union)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="mag240m-sharded on ONE GPU: all W ranks of the hash-partitioned job as ctxs of this process "
+                         "(in-process transport): per-rank pulled rows / bytes / bucket fill / hub-row hit rate / compute "
+                         "time are measured, the W-GPU step is projected from them (labelled so)")
+    ap.add_argument("--no-emulated-sub", action="store_true",
+                    help="N=1 headline: skip the `sharded_emulated` sub-record (an 8-rank emulated world at a reduced scale, "
+                         "run in a child process)")
     ap.add_argument("--no-sharded-sub", action="store_true",
                     help="N > 1 headline: skip the `sharded` sub-record (the mag240m-sharded workload at this N)")
     ap.add_argument("--shard-plans", type=int, default=3, help="mag240m-sharded: sharded plans in flight per rank")
@@ -410,6 +417,11 @@ def main():
         return run_entry_inferencer(args, rank, world, local_rank)
     if args.entry == "sampler":
         return run_entry_sampler(args, rank, world, local_rank)
+    if args.workload == "mag240m-sharded" and args.emulate_world > 1:
+        if world != 1:
+            print("bench.py: --emulate-world runs in one process on one GPU", file=sys.stderr)
+            sys.exit(2)
+        return run_emulated_world(args, local_rank)
     if args.workload == "mag240m-sharded":
         return run_sharded(args, rank, world, local_rank)
     if args.workload == "gat-lp":
@@ -901,6 +913,29 @@ def main():
             sub_err = f"{type(ex).__name__}: {str(ex)[:400]}"
         if rank == 0 and sub_err:
             line["sharded"] = {"error": sub_err}
+    if rank == 0 and world == 1 and wl_name == "products" and not args.no_emulated_sub and not args.timed_only and \
+            not os.environ.get("GIGL_BENCH_CHILD") and not under_profiler:
+        # BASELINE configs[2] on the one GPU the driver's N=1 run has: the 8-rank hash-partitioned job emulated in one
+        # process at a reduced scale (run_emulated_world) — measured per-rank bytes / fill / hit rate / compute, and the
+        # 8-GPU step projected from them.  A child process with a time limit: it can never cost the headline.
+        import subprocess
+        limit = float(os.environ.get("GIGL_BENCH_SUB_TIMEOUT", "240"))
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", "mag240m-sharded", "--emulate-world", "8",
+               "--shard-scale", os.environ.get("GIGL_BENCH_EMULATE_SCALE", "0.08"), "--fanouts", "25,10", "--batch", "1024",
+               "--shard-group", str(args.shard_group), "--steps", "256", "--no-cpu-baseline", "--no-live-pmc"]
+        try:
+            cp = subprocess.run(cmd, env=dict(os.environ, GIGL_BENCH_CHILD="1"), capture_output=True, text=True, timeout=limit)
+            lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+            if cp.returncode == 0 and lines:
+                sub = json.loads(lines[-1])
+                line["sharded_emulated"] = {k: sub.get(k) for k in ("emulated_world", "value", "value_is", "ms_per_step",
+                                                                    "config", "emulated")}
+            else:
+                line["sharded_emulated"] = {"error": f"exit code {cp.returncode}: {cp.stderr.strip()[-300:]}"}
+        except subprocess.TimeoutExpired:
+            line["sharded_emulated"] = {"error": f"did not finish within {limit:.0f} s (GIGL_BENCH_SUB_TIMEOUT)"}
+        except Exception as ex:  # noqa: BLE001
+            line["sharded_emulated"] = {"error": f"{type(ex).__name__}: {str(ex)[:300]}"}
     if rank == 0:
         emit(line)
     if world > 1:
@@ -1284,6 +1319,228 @@ def run_sharded(args, rank, world, local_rank, sub=False):
     if not sub:
         dist.destroy_process_group()
     eng.close()
+    return line
+
+
+def run_emulated_world(args, local_rank=0, sub=False):
+    """BASELINE configs[2] without an 8-GPU node: all W ranks of the hash-partitioned job as ctxs of ONE process on one
+    GPU (gigl_dist_init_local: the in-process transport the parity tests use — every exchange is a device copy), at the
+    largest MAG240M-shaped scale the GPU holds.  The step's CODE is the multi-GPU step's (gigl_dist_plan_run_local issues
+    every rank's phases in the order the ranks would), so what each rank would put on its links is MEASURED: pulled rows /
+    bytes per rank and step, bucket fill (padding), what hub-row replication takes off the links, and the per-rank
+    compute time (the W ranks' kernels share this GPU: time of a step of all ranks / W).  What is NOT measured is xGMI:
+    `projection` combines the measured bytes with 7 links x 153 GB/s per GPU and says so."""
+    from gigl_amd._lib import STATS, STATS_LEN
+    from gigl_amd.dist import Comm, DistSagePlan
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE
+
+    W = int(args.emulate_world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    fanouts = [int(v) for v in args.fanouts.split(",")]
+    L = len(fanouts)
+    B, G = args.batch, max(1, args.shard_group)
+    d, hid, out_dim = 768, 256, 256
+    t0 = time.time()
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    per_node = d * 2 + 2 * hid * 4 + 64  # stored row + pre-projected row + graph / bookkeeping share
+    scale = args.shard_scale if args.shard_scale > 0 else min(1.0, 0.7 * free_b / per_node / 244_160_499)
+    n = max(int(244_160_499 * scale), W * 1024)
+    e_total = max(int(1_728_364_232 * scale), 1)
+    scale_bits = max(int(np.ceil(np.log2(n))), 10)
+    # ---- every rank's shard (the generator of run_sharded: same seeded chunks, each edge to the owner of its destination)
+    keys = [[] for _ in range(W)]
+    chunk = 1 << 26
+    for ci, c0 in enumerate(range(0, e_total, chunk)):
+        m = min(chunk, e_total - c0)
+        src, dst = rmat_edges_gpu(scale_bits, m, seed=3 + 7919 * ci, device=dev)
+        src = (src * 0x9E3779B1) % n
+        dst = (dst * 0x9E3779B1) % n
+        for r in range(W):
+            keep = (dst % W) == r
+            keys[r].append(((dst[keep] // W) << 32) | src[keep])
+        del src, dst
+    engs, n_local, maxdeg, e_sum = [], [], 0, 0
+    occ = torch.zeros(n, dtype=torch.int32, device=dev)
+    for r in range(W):
+        key = torch.unique(torch.cat(keys[r]))
+        keys[r] = None
+        nl = (n - r + W - 1) // W
+        rowptr = torch.zeros(nl + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(key >> 32, minlength=nl), 0)
+        col = (key & 0xFFFFFFFF).to(torch.int32)
+        maxdeg = max(maxdeg, int((rowptr[1:] - rowptr[:-1]).max()))
+        e_sum += int(col.numel())
+        occ += torch.bincount(col.to(torch.int64) & 0xFFFFFFFF, minlength=n).to(torch.int32)
+        eng = HipEngine(local_rank)
+        eng.load_csc(rowptr, col)
+        engs.append(eng)
+        n_local.append(nl)
+        del key, rowptr, col
+    torch.manual_seed(0)
+    model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
+    w, bs = model.fused_params()
+    hot_frac = 0.01 if args.shard_hot_frac < 0 else float(args.shard_hot_frac)
+    n_hot = int(n * hot_frac)
+    hot_ids = None
+    if n_hot > 0:
+        hot_ids = torch.topk(occ.to(torch.int64) * (1 << 32) + (n - 1 - torch.arange(n, device=dev)), n_hot).indices
+        hot_ids = hot_ids.to(torch.int32).contiguous()
+    del occ
+    use_proj = args.project_input != "off" and L == 2
+    proj, pre_s = [], 0.0
+    hot_rows = torch.zeros((n_hot, hid if use_proj else d), device=dev, dtype=torch.float32 if use_proj else torch.float16) \
+        if n_hot else None
+    step_rows = max(1, (1 << 28) // d)
+    for r in range(W):
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + r)
+        x_local = torch.empty((n_local[r], d), device=dev, dtype=torch.float16)
+        for i in range(0, n_local[r], step_rows):
+            x_local[i:i + step_rows] = torch.randn((min(step_rows, n_local[r] - i), d), generator=g, device=dev).to(torch.float16)
+        engs[r].load_features(x_local)
+        pt = None
+        if use_proj:
+            pt = torch.empty((n_local[r], 2 * hid), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            engs[r].project_features(w[0], out=pt)
+            torch.cuda.synchronize()
+            pre_s = max(pre_s, time.perf_counter() - tp)
+        proj.append(pt)
+        if n_hot:
+            hi = hot_ids.to(torch.int64) & 0xFFFFFFFF
+            mine = (hi % W) == r
+            hot_rows[mine] = (pt[hi[mine] // W, :hid] if use_proj else x_local[hi[mine] // W])
+        del x_local
+    torch.cuda.empty_cache()
+    bound = (L + 1) * n + 42 * L + maxdeg
+    mwe = bound if bound < (1 << 30) else -1
+    comms = Comm.local(engs)
+    K = max(4, min(args.steps // G, 24))  # calls (G batches per rank each) per measurement
+    gp = torch.Generator(device="cpu")
+    gp.manual_seed(42)
+    roots = torch.randint(0, n, ((K + 2) * W, G * B), generator=gp).to(torch.int32).to(dev)
+
+    def make_plans(pull_cap, pull_cap_b, hot):
+        plans = [DistSagePlan(comms[r], w, bs, G * B, fanouts, group_roots=B, pull_cap=pull_cap, max_window_end=mwe,
+                              projected=proj[r], pull_cap_b=pull_cap_b) for r in range(W)]
+        if hot and n_hot:
+            for pl in plans:
+                pl.set_hot_rows(hot_ids, hot_rows)
+        return plans
+
+    def run_calls(plans, lo, hi, accs=None, fills=None):
+        outs = [pl.new_out() for pl in plans]
+        for c in range(lo, hi):
+            DistSagePlan.run_local(plans, [roots[c * W + r] for r in range(W)], outs)
+            if accs is not None:
+                for r, pl in enumerate(plans):
+                    pl.stats(accs[r])
+                    pl.bucket_fill(fills[r])
+        torch.cuda.synchronize()
+
+    def measure(hot):
+        # bucket capacities from two warm-up calls (+10 %), as the multi-process bench does
+        acc0 = [torch.zeros(STATS_LEN, dtype=torch.int64, device=dev) for _ in range(W)]
+        fill0 = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(W)]
+        plans = make_plans(0, 0, hot)
+        run_calls(plans, 0, 2, acc0, fill0)
+        if any(int(a[STATS["overflow"]]) for a in acc0):
+            raise RuntimeError("bucket overflow during the emulated world's warm-up")
+        pull_cap = int(max(int(a[STATS["pull_bucket_max"]]) for a in acc0) * 1.1) + 64
+        pull_cap_b = (int(max(int(f[2]) for f in fill0) * 1.1) + 64) if use_proj else 0
+        for pl in plans:
+            pl.close()
+        plans = make_plans(pull_cap, pull_cap_b, hot)
+        run_calls(plans, 0, 2)
+        accs = [torch.zeros(STATS_LEN, dtype=torch.int64, device=dev) for _ in range(W)]
+        fills = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(W)]
+        run_calls(plans, 2, 2 + K, accs, fills)  # counted (untimed)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_calls(plans, 2, 2 + K)               # timed: all W ranks' steps on this one GPU
+        dt = time.perf_counter() - t1
+        st = np.stack([a.cpu().numpy().astype(np.float64) for a in accs])
+        fl = np.stack([f.cpu().numpy().astype(np.float64) for f in fills])
+        if st[:, STATS["overflow"]].any():
+            raise RuntimeError("bucket overflow in the emulated world")
+        for pl in plans:
+            pl.close()
+        return st, fl, dt, pull_cap, pull_cap_b
+
+    row_bytes = hid * 4 if use_proj else d * 2
+    steps = K * G  # steps per rank in a measurement
+    res = {}
+    for tag, hot in (("hot_rows", True), ("no_replication", False)) if n_hot else (("no_replication", False),):
+        st, fl, dt, pull_cap, pull_cap_b = measure(hot)
+        pulled = st[:, STATS["pulled_rows"]] / steps  # rows per step, per rank
+        # what a rank sends as an OWNER (= what it receives as a requester, by symmetry of the measured totals): the row
+        # buckets travel whole (fixed capacity, equal split): W - 1 peers x capacity x (row + id) per call
+        sent_rows_bytes = (W - 1) * (pull_cap + pull_cap_b) * (row_bytes + 4) / G
+        m_k, hop_bytes = G * B, 0.0
+        for f in fanouts:
+            cap_k = min(m_k, int(1.5 * m_k / W) + 512)
+            hop_bytes += (W - 1) * cap_k * (8 + 4 * f)
+            m_k *= f
+        hop_bytes /= G
+        payload = pulled * (row_bytes + 4)
+        compute_ms = dt / (K * G * W) * 1e3
+        per_link = (sent_rows_bytes + hop_bytes) / (W - 1)  # bytes per peer pair and step: one xGMI link each (W <= 8)
+        link_ms = per_link / 153e9 * 1e3
+        edges_step = (st[:, STATS["sampled"]] + st[:, STATS["aggregated"]]).sum() / (steps * W)
+        res[tag] = {
+            "pulled_rows_per_step_per_rank": [round(float(v), 1) for v in pulled],
+            "pulled_rows_per_step_mean": float(pulled.mean()),
+            "row_payload_bytes_per_step_per_rank": float(payload.mean()),
+            "row_bytes_sent_per_step_per_rank": float(sent_rows_bytes),
+            "hop_exchange_bytes_sent_per_step_per_rank": float(hop_bytes),
+            "row_bucket_capacity_per_peer": [pull_cap, pull_cap_b],
+            # occupied entries of the row buckets / their capacity, summed over the W - 1 peers (gigl_dist_plan_bucket_fill:
+            # first pull, and the W_r x pull of a pre-projected plan): 1 - fill is padding that would travel over xGMI
+            "row_bucket_fill": float((fl[:, 1].sum() + fl[:, 3].sum()) /
+                                     max(K * W * (W - 1) * (pull_cap + pull_cap_b), 1)),
+            "row_bucket_fill_fullest": float(max(fl[:, 0].max() / max(pull_cap, 1),
+                                                 fl[:, 2].max() / max(pull_cap_b, 1) if pull_cap_b else 0.0)),
+            "rows_in_buckets_per_step_per_rank": float((fl[:, 1].sum() + fl[:, 3].sum()) / (K * G * W)),
+            "sampled_plus_aggregated_edges_per_step_per_rank": float(edges_step),
+            "compute_ms_per_step_per_rank": compute_ms,
+            "measured": "all of the above: counted on the device / timed on this GPU with the W ranks sharing it (eager "
+                        "launches, one plan per rank, phases of the W ranks issued in turn by one host thread: an upper "
+                        "bound of a rank's compute time — the single-rank bench keeps three plans in flight)",
+            "projection": {
+                "label": "PROJECTION, not a measurement: measured bytes over 7 x 153 GB/s xGMI links per GPU (one link per "
+                         "peer at W = 8), measured per-rank compute; exchanges assumed to overlap compute across the plans "
+                         "in flight",
+                "link_ms_per_step": link_ms, "bound": "xgmi" if link_ms > compute_ms else "compute",
+                "step_ms": max(link_ms, compute_ms),
+                "whole_node_edges_per_s": W * edges_step / (max(link_ms, compute_ms) * 1e-3)}}
+    if n_hot:
+        a, b_ = res["no_replication"]["pulled_rows_per_step_mean"], res["hot_rows"]["pulled_rows_per_step_mean"]
+        res["hot_row_hit_rate"] = {"replicated_fraction_of_nodes": hot_frac, "replica_bytes_per_rank": int(n_hot * row_bytes),
+                                   "pulled_rows_without": a, "pulled_rows_with": b_, "rows_taken_off_the_links": 1.0 - b_ / max(a, 1.0)}
+    best = res.get("hot_rows", res["no_replication"])
+    line = {
+        "metric": "sampled+aggregated edges/s", "value": best["projection"]["whole_node_edges_per_s"], "unit": "edges/s",
+        "n_gpus": 1, "emulated_world": W, "steps": steps, "ms_per_step": best["projection"]["step_ms"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value_is": "a PROJECTION for W GPUs from quantities measured on ONE GPU (see emulated.*.projection.label); the "
+                    "measured quantities are in `emulated`",
+        "config": {"workload": f"MAG240M-shaped RMAT x{scale:.3g}: N={n} E={e_sum} directed, D={d} fp16, hash-partitioned "
+                               f"over {W} emulated ranks in one process (owner = id % {W}), fanout={fanouts} B={B}/rank, "
+                               f"GraphSAGE {d}->{hid}->{out_dim}, {G} batches per exchange, "
+                               + ("rows pre-projected once per rank (256 fp32 W_l x rows pulled)" if use_proj else "raw rows"),
+                   "transport": "gigl_dist_init_local (in-process: every exchange is a device copy on this GPU)",
+                   "projection_precompute_s_per_rank": round(pre_s, 4), "setup_s": round(time.time() - t0, 1)},
+        "emulated": res, "roofline": None, "cpu_baseline": None}
+    for c in comms:
+        c.close()
+    for e in reversed(engs):
+        e.close()
+    torch.cuda.empty_cache()
+    if not sub:
+        emit(line)
     return line
 
 

@@ -13,7 +13,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   out=gpurun_out/pmc_${tag}_${ctr}
   timeout 600 rocprofv3 --kernel-trace --pmc $ctr -f csv -d "$out/calib" -o calib -- python scripts/pmc_calib.py \
       > gpurun_out/pmc_${tag}_${ctr}_calib.log 2>&1
-  timeout 900 rocprofv3 --kernel-trace --pmc $ctr -f csv -d "$out/bench" -o bench -- python bench.py --no-live-pmc --streams 1 \
+  timeout 900 rocprofv3 --kernel-trace --pmc $ctr -f csv -d "$out/bench" -o bench -- python bench.py --no-live-pmc --no-emulated-sub --streams 1 \
       --no-graph --steps 64 --min-rounds 2 --warmup 32 --timed-only "$@" > gpurun_out/pmc_${tag}_${ctr}_bench.log 2>&1
 done
 python scripts/pmc_summary.py "$tag"

@@ -17,7 +17,7 @@ for ctrs in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" \
             "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_ADDR_CONFLICT"; do
   out=gpurun_out/sq_${tag}/p$i
   timeout 600 rocprofv3 --kernel-trace --pmc $ctrs --kernel-include-regex "$re" -f csv -d "$out" -o sq -- \
-      python bench.py --no-live-pmc --streams 1 --no-graph --steps 64 --min-rounds 2 --warmup 32 --timed-only "$@" \
+      python bench.py --no-live-pmc --no-emulated-sub --streams 1 --no-graph --steps 64 --min-rounds 2 --warmup 32 --timed-only "$@" \
       > gpurun_out/sq_${tag}_p$i.log 2>&1
   i=$((i+1))
 done

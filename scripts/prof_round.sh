@@ -8,7 +8,7 @@ tag=$1; wl=$2; re=${3:-}
 cd $GRAFT_REPO_ROOT
 o=gpurun_out/$tag; mkdir -p $o
 extra=""; [ "$wl" != "products" ] && extra="--workload $wl"
-timeout 900 python bench.py --no-live-pmc --steps 20 --warmup 5 $extra > $o/bench_${wl}.json 2> $o/bench_${wl}.err
+timeout 900 python bench.py --no-live-pmc --no-emulated-sub --steps 20 --warmup 5 $extra > $o/bench_${wl}.json 2> $o/bench_${wl}.err
 scripts/gpu_profile.sh ${tag}_${wl} --steps 20 --warmup 5 $extra > $o/profile_${wl}.log 2>&1
 f=$(find gpurun_out/prof_${tag}_${wl} -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $o/kernel_stats_${wl}.csv
 cp gpurun_out/bench_${tag}_${wl}.json $o/bench_${wl}_under_rocprof.json

@@ -571,3 +571,26 @@ def test_batched_decoder_and_loss():
             want = loss_fn.calculate_batch_retrieval_loss(scores[:, g].contiguous(), candidate_sampling_probability=prob[g],
                                                           query_ids=a[g])
             assert torch.equal(want, got[g])
+
+
+@pytest.mark.gpu
+def test_bench_emulated_world_line(tmp_path):
+    """bench.py --workload mag240m-sharded --emulate-world 4 at a toy scale: the measured per-rank quantities and the
+    labelled projection are all there, hub-row replication takes rows off the (emulated) links"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    cp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "mag240m-sharded", "--emulate-world",
+                         "4", "--shard-scale", "0.001", "--batch", "128", "--shard-group", "4", "--steps", "16",
+                         "--shard-hot-frac", "0.02"], capture_output=True, text=True, timeout=600,
+                        env=dict(os.environ, GIGL_BENCH_CHILD="1"))
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    line = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["emulated_world"] == 4 and "PROJECTION" in line["value_is"].upper()
+    emu = line["emulated"]
+    for tag in ("hot_rows", "no_replication"):
+        e = emu[tag]
+        assert len(e["pulled_rows_per_step_per_rank"]) == 4 and e["compute_ms_per_step_per_rank"] > 0
+        assert 0.0 < e["row_bucket_fill"] <= 1.0 and e["projection"]["label"].startswith("PROJECTION")
+    assert emu["hot_row_hit_rate"]["pulled_rows_with"] < emu["hot_row_hit_rate"]["pulled_rows_without"]
