@@ -1344,8 +1344,10 @@ def run_emulated_world(args, local_rank=0, sub=False):
     d, hid, out_dim = 768, 256, 256
     t0 = time.time()
     free_b, _ = torch.cuda.mem_get_info(dev)
-    per_node = d * 2 + 2 * hid * 4 + 64  # stored row + pre-projected row + graph / bookkeeping share
-    scale = args.shard_scale if args.shard_scale > 0 else min(1.0, 0.7 * free_b / per_node / 244_160_499)
+    # stored row + pre-projected row + the sampler's threshold table over (hops + 1) * N + graph + the plans' id-indexed pull
+    # bookkeeping (8 B per node and plan); half of the free memory: workspaces and the generator's temporaries need the rest
+    per_node = d * 2 + 2 * hid * 4 + 13 * (L + 1) + 64 + 8 * W
+    scale = args.shard_scale if args.shard_scale > 0 else min(1.0, 0.5 * free_b / per_node / 244_160_499)
     n = max(int(244_160_499 * scale), W * 1024)
     e_total = max(int(1_728_364_232 * scale), 1)
     scale_bits = max(int(np.ceil(np.log2(n))), 10)
