@@ -1614,7 +1614,28 @@ def run_train(args, rank, world, local_rank):
     # the step replayed as ONE HIP graph (gigl_amd.hbm.GraphedTrainStep: what the trainer's in-HBM route runs): the same
     # launches without the host between them.  The eager step above stays for the per-kernel timers and the counts.
     eager_step, graphed, driver = step, None, "eager launches from Python (torch autograd)"
-    if not os.environ.get("GIGL_BENCH_TRAIN_EAGER") and not args.timed_only:
+    lib_plan = None
+    if not os.environ.get("GIGL_BENCH_TRAIN_EAGER") and not os.environ.get("GIGL_BENCH_TRAIN_AUTOGRAD"):
+        # the library's training step (gigl_sage_train_plan_*: what Trainer.run's in-HBM route runs for plain mean-GraphSAGE
+        # encoders): the whole step is one captured library call, no torch kernel in it
+        from gigl_amd.engine import SageTrainPlan
+        try:
+            torch.cuda.synchronize()
+            lib_plan = SageTrainPlan(eng, model, B, fanouts, lr=0.01, weight_decay=5e-4)
+            lab_pool = labels[my.long() & 0xFFFFFFFF]  # [pool, B]
+
+            def step(i, count=False):  # noqa: F811
+                if count:
+                    return eager_step(i, True)
+                return lib_plan.step(my[i], lab_pool[i], sampling_seed=resident.seed, mode=mode)
+            for i in range(min(W, 4)):  # (eager step, capture, replays)
+                step(i)
+            st.synchronize()
+            driver = "gigl_sage_train_plan_step: one library call per step, replayed as one hipGraph"
+        except NotImplementedError as exc:
+            print(f"train: library training plan not applicable ({exc})", file=sys.stderr)
+            lib_plan, step = None, eager_step
+    if lib_plan is None and not os.environ.get("GIGL_BENCH_TRAIN_EAGER") and not args.timed_only:
         from gigl_amd.hbm import GraphedTrainStep
         try:
             graphed = GraphedTrainStep(resident, model, opt, B, my[0], labels[my[0].long() & 0xFFFFFFFF])
@@ -1715,8 +1736,10 @@ def run_train(args, rank, world, local_rank):
                                             f"fanout={fanouts} B={B}/GPU GraphSAGE {d}->{hid}->{out_dim}: TRAINING step "
                                             "(sample + union in HBM, forward with autograd, cross-entropy, backward, Adam), "
                                             "sampler mode=" + args.mode,
-                       "entry": "ResidentGraph.hip_batch(train=True) -> GraphSAGE._forward_union_autograd (gigl_amd/hbm.py: "
-                                "the route Trainer.run takes)", "driver": driver,
+                       "entry": ("engine.SageTrainPlan (gigl_sage_train_plan_*): HipGraphSageNodeClassificationSpec.train on the "
+                                 "in-HBM route" if lib_plan is not None else
+                                 "ResidentGraph.hip_batch(train=True) -> GraphSAGE._forward_union_autograd (gigl_amd/hbm.py)"),
+                       "driver": driver,
                        "sampled_edges_per_step": sampled, "aggregated_edges_per_step": agg,
                        "backward_scattered_edges_per_step": bwd, "setup_s": round(setup_s, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline,

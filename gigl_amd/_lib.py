@@ -58,6 +58,7 @@ SYMBOLS = [
     "gigl_typed_plan_create", "gigl_typed_plan_run", "gigl_typed_plan_buffers", "gigl_typed_plan_destroy",
     "gigl_typed_plan_merged_csr", "gigl_sage_plan_half_split",
     "gigl_sage_plan_run_part", "gigl_sage_plan_overflow_add",
+    "gigl_sage_train_plan_create", "gigl_sage_train_plan_step", "gigl_sage_train_plan_loss", "gigl_sage_train_plan_destroy",
 ]
 
 KERNEL_IDS = {
@@ -342,6 +343,10 @@ def load() -> C.CDLL:
         "gigl_sage_plan_set_projected_input": [vp, vp],
         "gigl_sage_plan_half_split": [vp],
         "gigl_sage_plan_overflow_add": [vp, vp],
+        "gigl_sage_train_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), vp, vp, i32, C.c_float, C.c_float, C.c_float,
+                                        C.c_float, C.c_float, vp],
+        "gigl_sage_train_plan_step": [vp, vp, vp, i32, i32, i32, vp],
+        "gigl_sage_train_plan_destroy": [vp],
         "gigl_gat_input_layer_fused": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, i64, vp, i32,
                                        vp, vp],
         "gigl_gat_input_layer": [vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, i64, vp, i64, vp, i64,
@@ -357,6 +362,8 @@ def load() -> C.CDLL:
     lib.gigl_gat_input_layer_fused_scratch.restype = i64
     lib.gigl_json_rows_capacity.argtypes = [i64, i32]
     lib.gigl_json_rows_capacity.restype = i64
+    lib.gigl_sage_train_plan_loss.argtypes = [vp]
+    lib.gigl_sage_train_plan_loss.restype = vp
     _lib = lib
     return lib
 

@@ -341,6 +341,110 @@ int32_t capture_segments(gigl_sage_plan* p, int32_t sampling_seed, int32_t mode)
   return GIGL_OK;
 }
 
+
+// ---- training step (gigl_sage_train_plan_*)
+
+// cross-entropy on the roots' rows: one wave per root.  loss_rows[i] = lse(out[rl]) - out[rl][label] for the n_valid real
+// roots (0 for padding); the gradient (softmax - onehot) / n_valid is ADDED to dout[rl] (zeroed before; two roots of a
+// batch that are the same node share a row, hence the atomics — a row with one root gets plain values)
+__global__ __launch_bounds__(256) void ce_roots_kernel(const float* __restrict__ out, int width, const int32_t* __restrict__ root_local,
+                                                       const int64_t* __restrict__ labels, const int32_t* __restrict__ n_valid_dev,
+                                                       int b, const int32_t* __restrict__ meta, float* __restrict__ dout,
+                                                       float* __restrict__ loss_rows) {
+  const int lane = threadIdx.x & 63;
+  const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= b) return;
+  const int n_valid = *n_valid_dev;
+  const int32_t rl = root_local[i];
+  if (i >= n_valid || rl < 0 || meta[GIGL_META_OVERFLOW] != 0) {
+    if (lane == 0) loss_rows[i] = meta[GIGL_META_OVERFLOW] != 0 ? __builtin_nanf("") : 0.f;
+    return;
+  }
+  const float* row = out + (int64_t)rl * width;
+  float mx = -3.402823466e38f;
+  for (int c = lane; c < width; c += 64) mx = fmaxf(mx, row[c]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float se = 0.f;
+  for (int c = lane; c < width; c += 64) se += __expf(row[c] - mx);
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+  const float lse = mx + __logf(se);
+  const int64_t lab = labels[i];
+  const float inv = 1.0f / (float)n_valid;
+  for (int c = lane; c < width; c += 64) {
+    const float pr = __expf(row[c] - lse);
+    atomicAdd(&dout[(int64_t)rl * width + c], (pr - (c == (int)lab ? 1.f : 0.f)) * inv);
+  }
+  if (lane == 0) loss_rows[i] = lse - row[lab];
+}
+
+// loss = sum_i loss_rows[i] / n_valid in a fixed order (one workgroup); the optimiser's step counter moves on
+__global__ __launch_bounds__(1024) void loss_sum_kernel(const float* __restrict__ loss_rows, int b,
+                                                        const int32_t* __restrict__ n_valid_dev, float* __restrict__ loss,
+                                                        int32_t* __restrict__ step) {
+  __shared__ float s_p[16];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < b; i += 1024) v += loss_rows[i];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += s_p[k];
+    *loss = t / (float)(*n_valid_dev > 0 ? *n_valid_dev : 1);
+    *step += 1;
+  }
+}
+
+// dy[i][c] = 0 where the layer's activated output is 0 (relu'), rows below *n_rows
+__global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ dy, const float* __restrict__ y,
+                                                        const int32_t* __restrict__ n_rows_dev, int width) {
+  const int64_t n = (int64_t)(*n_rows_dev) * width;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (!(y[i] > 0.f)) dy[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ w, int rows, int cols, float* __restrict__ wt) {
+  const int64_t n = (int64_t)rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+    wt[(int64_t)c * rows + r] = w[i];
+  }
+}
+
+// Adam with L2 weight decay (torch.optim.Adam: the decay joins the gradient), every parameter tensor in one launch
+struct AdamPack {
+  float* p[2 * GIGL_MAX_HOPS];
+  const float* g[2 * GIGL_MAX_HOPS];
+  float* m[2 * GIGL_MAX_HOPS];
+  float* v[2 * GIGL_MAX_HOPS];
+  int64_t n[2 * GIGL_MAX_HOPS];
+  int32_t count;
+  float lr, beta1, beta2, eps, wd;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamPack a, const int32_t* __restrict__ step_dev,
+                                                   const int32_t* __restrict__ meta) {
+  if (meta[GIGL_META_OVERFLOW] != 0) return;  // a failed batch trains nothing (its loss is NaN)
+  const double t = (double)*step_dev;
+  const float bc1 = (float)(1.0 - pow((double)a.beta1, t)), bc2s = (float)sqrt(1.0 - pow((double)a.beta2, t));
+  const float step_size = a.lr / bc1;
+  for (int k = 0; k < a.count; ++k) {
+    float* p = a.p[k];
+    const float* g = a.g[k];
+    float* m = a.m[k];
+    float* v = a.v[k];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += (int64_t)gridDim.x * blockDim.x) {
+      const float w = p[i];
+      const float gr = g[i] + a.wd * w;
+      const float mm = m[i] + (gr - m[i]) * (1.f - a.beta1);
+      const float vv = v[i] * a.beta2 + (1.f - a.beta2) * gr * gr;
+      m[i] = mm;
+      v[i] = vv;
+      p[i] = w - step_size * (mm / (sqrtf(vv) / bc2s + a.eps));
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -768,5 +872,287 @@ int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sam
                                      hipMemcpyDeviceToDevice, ctx->stream));
   return GIGL_OK;
 }
+
+
+// ---- gigl_sage_train_plan: one TRAINING step per call, all of it in the library —
+//   sample -> batch union graph (the one-call plan's leaf-global build) -> GraphSAGE forward keeping every layer's
+//   operand and output -> cross-entropy on the roots -> backward (weight gradients by gigl_linear_weight_grad, the
+//   layers' input gradients by one projection over the transposed weights + gigl_gather_mean_backward) -> Adam.
+// Replaces the loop body of NodeClassificationModelingTaskSpec._train
+// (python/gigl/src/common/modeling_task_specs/node_classification_modeling_task_spec.py:134-173) for batches sampled in
+// HBM: ~25 launches and two memsets, no torch kernel between them, replayed as ONE hipGraph per step.
+struct gigl_sage_train_plan {
+  gigl_sage_plan* base = nullptr;  // tree / union buffers, sample + union stages
+  int32_t L = 0, b = 0;
+  int32_t dims[GIGL_MAX_HOPS + 1] = {0};
+  int64_t rows_cap[GIGL_MAX_HOPS] = {0};  // rows layer l may compute
+  float* w[GIGL_MAX_HOPS] = {nullptr};    // fused [dims[l+1]][2 dims[l]]: borrowed, UPDATED IN PLACE
+  float* bias[GIGL_MAX_HOPS] = {nullptr};
+  float* a[GIGL_MAX_HOPS] = {nullptr};    // [rows_cap[l]][2 dims[l]]: the layer's [mean | self] operand
+  float* h[GIGL_MAX_HOPS] = {nullptr};    // [rows_cap[l]][dims[l+1]]: its output (activated below the last layer)
+  float* dh[GIGL_MAX_HOPS] = {nullptr};   // gradient of h[l]
+  float* da = nullptr;                    // [max rows_cap[l >= 1]][2 max dims]: gradient of a layer's operand
+  float* wt = nullptr;                    // a layer's transposed weight
+  float* gw[GIGL_MAX_HOPS] = {nullptr};
+  float* gb[GIGL_MAX_HOPS] = {nullptr};
+  float* mom[4 * GIGL_MAX_HOPS] = {nullptr};  // m_w, v_w, m_b, v_b per layer
+  void* zero_base = nullptr;              // gw | gb | dh: cleared at the start of every step
+  size_t zero_bytes = 0;
+  int64_t* labels_buf = nullptr;
+  int32_t* n_valid_buf = nullptr;  // [0] real roots of the batch, [1] Adam's step counter
+  float* loss_rows = nullptr;
+  float* loss = nullptr;
+  float lr = 0.01f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, wd = 0.f;
+  std::vector<void*> owned;
+  hipGraphExec_t exec = nullptr;
+  bool warm = false;  // one eager step has run
+  int32_t cap_seed = 0, cap_mode = -1;
+};
+
+namespace {
+
+int32_t train_enqueue(gigl_sage_train_plan* t, int32_t sampling_seed, int32_t mode) {
+  gigl_sage_plan* p = t->base;
+  gigl_ctx* ctx = p->ctx;
+  const int L = t->L;
+  hipStream_t st = ctx->stream;
+  int32_t rc = enqueue_range(p, 0, 2, p->roots_buf, sampling_seed, mode, nullptr);  // sample + union (+ the level guard)
+  if (rc != GIGL_OK) return rc;
+  GIGL_HIP_CHECK(ctx, hipMemsetAsync(t->zero_base, 0, t->zero_bytes, st));
+  const int32_t* n_local = p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr;
+  // ---- forward
+  for (int l = 0; l < L; ++l) {
+    const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
+    const int d = t->dims[l];
+    if (l == 0)
+      rc = gigl_gather_reduce_mixed(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend, p->un.col,
+                                    n_rows, t->rows_cap[0], GIGL_AGGR_MEAN, n_local, t->a[0]);
+    else
+      rc = gigl_gather_reduce(ctx, t->h[l - 1], GIGL_DTYPE_F32, d, nullptr, p->un.rowptr, p->un.rowend, p->un.col, n_rows,
+                              t->rows_cap[l], GIGL_AGGR_MEAN, t->a[l]);
+    if (rc != GIGL_OK) return rc;
+    rc = gigl_linear(ctx, t->a[l], t->w[l], t->bias[l], n_rows, t->rows_cap[l], 2 * d, t->dims[l + 1],
+                     (l < L - 1 || p->act_last) ? 1 : 0, t->h[l]);
+    if (rc != GIGL_OK) return rc;
+  }
+  // ---- loss on the roots, its gradient into dh[L - 1]
+  {
+    const int width = t->dims[L];
+    hipLaunchKernelGGL(ce_roots_kernel, dim3((unsigned)((t->b + 3) / 4)), dim3(256), 0, st, (const float*)t->h[L - 1], width,
+                       (const int32_t*)p->un.root_local, (const int64_t*)t->labels_buf, (const int32_t*)t->n_valid_buf, t->b,
+                       (const int32_t*)p->un.meta, t->dh[L - 1], t->loss_rows);
+    hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)t->loss_rows, t->b,
+                       (const int32_t*)t->n_valid_buf, t->loss, t->n_valid_buf + 1);
+  }
+  // ---- backward
+  for (int l = L - 1; l >= 0; --l) {
+    const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
+    const int d = t->dims[l], n_out = t->dims[l + 1];
+    const bool act = l < L - 1 || p->act_last;
+    rc = gigl_linear_weight_grad(ctx, t->dh[l], t->a[l], act ? t->h[l] : nullptr, n_rows, t->rows_cap[l], n_out, 2 * d,
+                                 t->gw[l], t->bias[l] ? t->gb[l] : nullptr);
+    if (rc != GIGL_OK) return rc;
+    if (l == 0) break;  // (the first layer's input is the feature table: no gradient)
+    if (act) {
+      int64_t blocks = (t->rows_cap[l] * n_out + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, t->dh[l], (const float*)t->h[l], n_rows, n_out);
+    }
+    {
+      int64_t blocks = ((int64_t)n_out * 2 * d + 255) / 256;
+      hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)t->w[l], n_out, 2 * d, t->wt);
+    }
+    rc = gigl_linear(ctx, t->dh[l], t->wt, nullptr, n_rows, t->rows_cap[l], n_out, 2 * d, 0, t->da);
+    if (rc != GIGL_OK) return rc;
+    rc = gigl_gather_mean_backward(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, t->rows_cap[l], t->dh[l - 1]);
+    if (rc != GIGL_OK) return rc;
+  }
+  // ---- Adam
+  AdamPack ap{};
+  for (int l = 0; l < L; ++l) {
+    ap.p[ap.count] = t->w[l];
+    ap.g[ap.count] = t->gw[l];
+    ap.m[ap.count] = t->mom[4 * l];
+    ap.v[ap.count] = t->mom[4 * l + 1];
+    ap.n[ap.count++] = (int64_t)t->dims[l + 1] * 2 * t->dims[l];
+    if (t->bias[l]) {
+      ap.p[ap.count] = t->bias[l];
+      ap.g[ap.count] = t->gb[l];
+      ap.m[ap.count] = t->mom[4 * l + 2];
+      ap.v[ap.count] = t->mom[4 * l + 3];
+      ap.n[ap.count++] = t->dims[l + 1];
+    }
+  }
+  ap.lr = t->lr;
+  ap.beta1 = t->beta1;
+  ap.beta2 = t->beta2;
+  ap.eps = t->eps;
+  ap.wd = t->wd;
+  hipLaunchKernelGGL(adam_kernel, dim3(256), dim3(256), 0, st, ap, (const int32_t*)(t->n_valid_buf + 1),
+                     (const int32_t*)p->un.meta);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+}  // namespace
+
+int32_t gigl_sage_train_plan_destroy(gigl_sage_train_plan* t) {
+  if (!t) return GIGL_OK;
+  if (t->base && t->base->ctx) {
+    hipSetDevice(t->base->ctx->device);
+    hipStreamSynchronize(t->base->ctx->stream);
+  }
+  if (t->exec) hipGraphExecDestroy(t->exec);
+  for (void* q : t->owned) hipFree(q);
+  if (t->base) gigl_sage_plan_destroy(t->base);
+  delete t;
+  return GIGL_OK;
+}
+
+int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b, const int32_t* fanouts,
+                                    int32_t hops, const int32_t* dims, float* const* w, float* const* bias,
+                                    int32_t act_last, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                    gigl_sage_train_plan** out) {
+  if (!ctx || !out) return GIGL_E_INVALID_ARG;
+  *out = nullptr;
+  GIGL_REQUIRE(ctx, graph && feat && fanouts && dims && w, "null argument");
+  gigl_sage_plan* base = nullptr;
+  int32_t rc = plan_create(ctx, graph, feat, b, fanouts, hops, dims, (const float* const*)w, (const float* const*)bias,
+                           act_last, false, &base);
+  if (rc != GIGL_OK) return rc;
+  gigl_sage_train_plan* t = new (std::nothrow) gigl_sage_train_plan();
+  if (!t) {
+    gigl_sage_plan_destroy(base);
+    return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
+  }
+  t->base = base;
+  t->L = hops;
+  t->b = b;
+  t->lr = lr;
+  t->beta1 = beta1;
+  t->beta2 = beta2;
+  t->eps = eps;
+  t->wd = weight_decay;
+  auto alloc = [&](size_t bytes) -> void* {
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    t->owned.push_back(q);
+    return q;
+  };
+  bool ok = true;
+  size_t zero_floats = 0, da_floats = 16, wt_floats = 16;
+  for (int l = 0; l <= hops; ++l) t->dims[l] = dims[l];
+  for (int l = 0; l < hops; ++l) {
+    t->w[l] = w[l];
+    t->bias[l] = bias ? bias[l] : nullptr;
+    int64_t rows = 0, width = b;  // layer l computes the nodes of level <= L-1-l
+    for (int i = 0; i <= hops - 1 - l; ++i) {
+      rows += width;
+      width *= fanouts[i];
+    }
+    t->rows_cap[l] = rows;
+    const size_t nw = (size_t)dims[l + 1] * 2 * dims[l];
+    zero_floats += nw + dims[l + 1] + (size_t)rows * dims[l + 1];
+    if (l >= 1) {
+      da_floats = std::max(da_floats, (size_t)rows * 2 * dims[l]);
+      wt_floats = std::max(wt_floats, nw);
+    }
+    t->a[l] = (float*)alloc((size_t)rows * 2 * dims[l] * 4);
+    t->h[l] = (float*)alloc((size_t)rows * dims[l + 1] * 4);
+    for (int k = 0; k < 4; ++k) {
+      const size_t n = k < 2 ? nw : (size_t)dims[l + 1];
+      t->mom[4 * l + k] = (float*)alloc(n * 4);
+      if (t->mom[4 * l + k] && hipMemset(t->mom[4 * l + k], 0, n * 4) != hipSuccess) ok = false;
+      ok = ok && t->mom[4 * l + k];
+    }
+    ok = ok && t->a[l] && t->h[l];
+  }
+  float* z = (float*)alloc(zero_floats * 4);
+  t->zero_base = z;
+  t->zero_bytes = zero_floats * 4;
+  for (int l = 0; l < hops && z; ++l) {
+    t->gw[l] = z;
+    z += (size_t)dims[l + 1] * 2 * dims[l];
+    t->gb[l] = z;
+    z += dims[l + 1];
+    t->dh[l] = z;
+    z += (size_t)t->rows_cap[l] * dims[l + 1];
+  }
+  t->da = (float*)alloc(da_floats * 4);
+  t->wt = (float*)alloc(wt_floats * 4);
+  t->labels_buf = (int64_t*)alloc((size_t)b * 8);
+  t->n_valid_buf = (int32_t*)alloc(16);
+  t->loss_rows = (float*)alloc((size_t)b * 4);
+  t->loss = (float*)alloc(16);
+  ok = ok && t->zero_base && t->da && t->wt && t->labels_buf && t->n_valid_buf && t->loss_rows && t->loss;
+  if (ok && hipMemset(t->n_valid_buf, 0, 16) != hipSuccess) ok = false;
+  if (!ok) {
+    gigl_sage_train_plan_destroy(t);
+    return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the training workspace failed");
+  }
+  *out = t;
+  return GIGL_OK;
+}
+
+int32_t gigl_sage_train_plan_step(gigl_sage_train_plan* t, const uint32_t* roots, const int64_t* labels, int32_t n_valid,
+                                  int32_t sampling_seed, int32_t mode, float* loss_out) {
+  if (!t) return GIGL_E_INVALID_ARG;
+  gigl_sage_plan* p = t->base;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, roots && labels && n_valid >= 1 && n_valid <= t->b, "bad argument");
+  if (mode == GIGL_MODE_REPLACE)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the training plan needs duplicate-free trees (no with-replacement mode)");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  // the step's inputs go into the static buffers the (captured) launches read: root ids, labels, the number of real
+  // roots (a 32-bit fill: no host memory involved, ordered on the stream)
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(p->roots_buf, roots, (size_t)t->b * 4, hipMemcpyDeviceToDevice, st));
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->labels_buf, labels, (size_t)n_valid * 8, hipMemcpyDeviceToDevice, st));
+  GIGL_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)t->n_valid_buf, n_valid, 1, st));
+  static const bool eager = getenv("GIGL_TRAIN_PLAN_EAGER") != nullptr;  // (A/B knob)
+  int32_t rc = GIGL_OK;
+  if (eager || st == nullptr) {  // (the legacy default stream cannot be captured)
+    rc = train_enqueue(t, sampling_seed, mode);
+  } else {
+    if (t->exec && (t->cap_seed != sampling_seed || t->cap_mode != mode)) {
+      GIGL_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      hipGraphExecDestroy(t->exec);
+      t->exec = nullptr;
+    }
+    if (!t->exec && !t->warm) {
+      // the first step runs eagerly: it sizes the arena, builds the sampler's table and sets kernel attributes — none of
+      // which may happen inside a capture
+      rc = train_enqueue(t, sampling_seed, mode);
+      if (rc != GIGL_OK) return rc;
+      GIGL_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      t->warm = true;
+    } else {
+      if (!t->exec) {
+        hipGraph_t graph = nullptr;
+        hipError_t err = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (err == hipSuccess) {
+          rc = train_enqueue(t, sampling_seed, mode);
+          const hipError_t e2 = hipStreamEndCapture(st, &graph);
+          if (rc == GIGL_OK && e2 != hipSuccess) err = e2;
+        }
+        if (rc == GIGL_OK && err == hipSuccess) err = hipGraphInstantiate(&t->exec, graph, nullptr, nullptr, 0);
+        if (graph) hipGraphDestroy(graph);
+        if (rc != GIGL_OK) return rc;
+        if (err != hipSuccess) {
+          t->exec = nullptr;
+          return gigl_fail(ctx, GIGL_E_HIP, "capturing the training step failed: %s", hipGetErrorString(err));
+        }
+        t->cap_seed = sampling_seed;
+        t->cap_mode = mode;
+      }
+      GIGL_HIP_CHECK(ctx, hipGraphLaunch(t->exec, st));
+    }
+  }
+  if (rc != GIGL_OK) return rc;
+  if (loss_out) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(loss_out, t->loss, 4, hipMemcpyDeviceToDevice, st));
+  return GIGL_OK;
+}
+
+const float* gigl_sage_train_plan_loss(gigl_sage_train_plan* t) { return t ? t->loss : nullptr; }
 
 }  // extern "C"

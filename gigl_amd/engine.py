@@ -1232,6 +1232,83 @@ class SagePlan:
                 self.eng._plans.remove(self)
 
 
+class SageTrainPlan:
+    """one TRAINING step per call in the library (include/gigl_hip.h `gigl_sage_train_plan_*`): sample -> union graph ->
+    GraphSAGE forward -> cross-entropy on the roots -> backward -> Adam, replayed as one hipGraph per step.  The plan
+    trains FUSED weights [W_l | W_r] (and biases) held here as torch tensors and updated in place by every step;
+    `load(model)` / `store(model)` move them from / to a models.GraphSAGE (Adam is element-wise: training the fused
+    matrix is training lin_l.weight and lin_r.weight)."""
+
+    def __init__(self, eng: HipEngine, model, b: int, fanouts, lr: float = 0.01, weight_decay: float = 5e-4,
+                 betas=(0.9, 0.999), eps: float = 1e-8):
+        assert eng._graph is not None and eng._feat is not None, "load the graph and the features first"
+        L = len(fanouts)
+        assert model.num_layers == L, "one hop per layer"
+        if not (model._plain and model.aggr == "mean" and not model.should_l2_normalize_embedding_layer_output
+                and model.feats_interaction is None and model.feature_embedding_layer is None
+                and all(c.lin_r is not None for c in model.conv_layers)):
+            raise NotImplementedError("the training plan runs plain mean-GraphSAGE layers (conv -> relu)")
+        self.eng, self.b, self.fanouts = eng, int(b), [int(f) for f in fanouts]
+        self._lib = eng._lib
+        self.w, self.bias = [], []
+        self.load(model)
+        self.dims = [int(self.w[0].shape[1]) // 2] + [int(w.shape[0]) for w in self.w]
+        self._plan = C.c_void_p()
+        w_arr = (C.c_void_p * L)(*[w.data_ptr() for w in self.w])
+        b_arr = (C.c_void_p * L)(*[(x.data_ptr() if x is not None else None) for x in self.bias])
+        fo = (C.c_int32 * L)(*self.fanouts)
+        dims = (C.c_int32 * (L + 1))(*self.dims)
+        check(self._lib.gigl_sage_train_plan_create(eng._ctx, eng._graph, eng._feat, self.b, fo, L, dims, w_arr, b_arr,
+                                                    1 if model.activation_after_last_conv else 0, float(lr),
+                                                    float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
+                                                    C.byref(self._plan)), eng._ctx)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=eng.device)  # the last step's loss (device scalar)
+
+    def load(self, model) -> None:
+        """(re)read the model's parameters into the fused buffers the plan trains (in place when they exist)"""
+        ws = [c.fused_weight().detach().to(device=self.eng.device, dtype=torch.float32).contiguous() for c in model.conv_layers]
+        bs = [None if c.lin_l.bias is None else c.lin_l.bias.detach().to(device=self.eng.device, dtype=torch.float32)
+              .clone().contiguous() for c in model.conv_layers]
+        if self.w:
+            for dst, src in zip(self.w, ws):
+                dst.copy_(src)
+            for dst, src in zip(self.bias, bs):
+                if dst is not None:
+                    dst.copy_(src)
+        else:
+            self.w, self.bias = ws, bs
+
+    def store(self, model) -> None:
+        """write the trained parameters back into the model (lin_l.weight | lin_r.weight halves of the fused matrix)"""
+        with torch.no_grad():
+            for c, w, b in zip(model.conv_layers, self.w, self.bias):
+                d = c.in_channels
+                c.lin_l.weight.copy_(w[:, :d])
+                c.lin_r.weight.copy_(w[:, d:])
+                if b is not None:
+                    c.lin_l.bias.copy_(b)
+
+    def step(self, roots: torch.Tensor, labels: torch.Tensor, sampling_seed: int = 42, mode: int = MODE_SPARK_HASH) -> torch.Tensor:
+        """one optimiser step on the batch: roots int32 device [k <= b] (uint32 ids), labels int64 device [k]; a short
+        batch is padded with its first root (a repeated root adds nothing to the union graph) and masked out of the loss.
+        Returns the loss (a device scalar owned by the plan, overwritten by the next step)."""
+        k = int(roots.numel())
+        assert roots.is_cuda and roots.dtype == torch.int32 and labels.is_cuda and labels.dtype == torch.int64
+        assert 0 < k <= self.b and labels.numel() == k
+        if k < self.b:
+            roots = torch.cat([roots, roots[:1].expand(self.b - k)])
+        roots, labels = roots.contiguous(), labels.contiguous()
+        check(self._lib.gigl_sage_train_plan_step(self._plan, C.c_void_p(roots.data_ptr()), C.c_void_p(labels.data_ptr()), k,
+                                                  int(sampling_seed), int(mode), C.c_void_p(self.loss.data_ptr())),
+              self.eng._ctx)
+        return self.loss
+
+    def close(self) -> None:
+        if getattr(self, "_plan", None):
+            self._lib.gigl_sage_train_plan_destroy(self._plan)
+            self._plan = None
+
+
 class GatPlan(SagePlan):
     """sample -> union -> GAT forward -> one row per root, enqueued by ONE library call (gigl_gat_plan_create; the
     handle is a gigl_sage_plan: run / use_graph / stats / last_batch_to_host are SagePlan's)"""

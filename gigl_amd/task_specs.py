@@ -174,6 +174,9 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
 
     def close(self) -> None:
         self._graphed_step = None
+        if getattr(self, "_train_plan", None) is not None:
+            self._train_plan.close()
+            self._train_plan = None
         if self._resident is not None:
             self._resident.close()
             self._resident = None
@@ -246,6 +249,9 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
             return None
         b = self._batch_size
         res = self._resident
+        loss = self._train_library_plan(res, ids, labels, b, device)
+        if loss is not None:
+            return loss
         step = getattr(self, "_graphed_step", None)
         if step is None:
             from .hbm import GraphedTrainStep
@@ -267,6 +273,43 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
             loss = step.step(roots_all[lo:lo + b], labels_all[lo:lo + b])
         step.stream.synchronize()
         return loss.detach().clone()
+
+    def _train_library_plan(self, res, ids: np.ndarray, labels: np.ndarray, b: int, device: torch.device):
+        """one epoch through the library's training plan (engine.SageTrainPlan: sample -> union -> forward -> cross-entropy
+        -> backward -> Adam in ONE captured library call per step, no torch kernel in between) — plain mean-GraphSAGE
+        encoders under this spec's optimiser settings; None = not applicable (the autograd step is then used).
+        GIGL_AMD_TRAIN_PLAN=0 keeps the autograd step."""
+        import os
+        if os.environ.get("GIGL_AMD_TRAIN_PLAN", "1") == "0":
+            return None
+        from ._lib import MODE_REPLACE
+        from .engine import SageTrainPlan
+        model = self._inner_model()
+        plan = getattr(self, "_train_plan", None)
+        if plan is None:
+            if getattr(self, "_train_plan_unavailable", False) or res.mode == MODE_REPLACE:
+                return None
+            try:
+                plan = SageTrainPlan(res.engine, model, b, res.fanouts, lr=self._optim_lr,
+                                     weight_decay=self._optim_weight_decay)
+            except NotImplementedError:
+                self._train_plan_unavailable = True
+                return None
+            self._train_plan = plan
+            self._train_stream = torch.cuda.Stream(device=device)  # (a created stream: the step is replayed as a hipGraph)
+        else:
+            plan.load(model)  # (the model may have been touched between epochs)
+        res.engine.bind_stream(self._train_stream)
+        self.model.train()
+        roots_all = torch.from_numpy(ids.astype(np.uint32).view(np.int32)).to(device)
+        labels_all = torch.from_numpy(labels).to(device)
+        torch.cuda.synchronize(device)
+        loss = None
+        for lo in range(0, ids.size, b):
+            loss = plan.step(roots_all[lo:lo + b], labels_all[lo:lo + b], sampling_seed=res.seed, mode=res.mode)
+        res.engine.synchronize()
+        plan.store(model)
+        return loss.detach().clone().reshape(())
 
     @no_grad_eval
     def infer_batch(self, batch: SupervisedNodeClassificationBatch, device: torch.device = torch.device("cpu")

@@ -961,6 +961,31 @@ int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
 int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);
 
+/* ---- one TRAINING step per call, all of it in the library: the loop body of NodeClassificationModelingTaskSpec._train
+ * (python/gigl/src/common/modeling_task_specs/node_classification_modeling_task_spec.py:134-173 — zero_grad, forward,
+ * cross-entropy on `out[root_node_indices]`, backward, Adam step) for batches sampled in HBM:
+ *   k-hop sample -> batch union graph (the one-call plan's build) -> GraphSAGE (mean) forward keeping every layer's
+ *   operand and output -> mean cross-entropy over the batch's real roots -> backward (gigl_linear_weight_grad per layer;
+ *   the input gradient of layers >= 1 by one projection over the transposed weights + gigl_gather_mean_backward) ->
+ *   Adam with L2 weight decay (torch.optim.Adam: the decay joins the gradient),
+ * ~25 launches, no host read, replayed as ONE hipGraph per step after the first two calls.
+ * w[l]: fused [dims[l+1]][2*dims[l]] (= [W_l | W_r]), bias[l] (array or entries may be NULL): DEVICE fp32, borrowed and
+ * UPDATED IN PLACE by every step (the Adam moments live in the plan, zero at creation).  act_last as gigl_sage_plan_create.
+ * gigl_sage_train_plan_step: roots [b] (uint32; a batch of fewer than b real roots is padded by the caller, e.g. with its
+ * first root), labels [n_valid] int64 class ids of the first n_valid roots, both DEVICE; loss_out (DEVICE float, may be
+ * NULL) receives the step's loss; gigl_sage_train_plan_loss returns the plan's own device word.  A batch whose union graph
+ * does not fit the workspace (meta[GIGL_META_OVERFLOW]) trains nothing and reports a NaN loss.  Parity mode and
+ * GIGL_MODE_FAST; no with-replacement trees. */
+typedef struct gigl_sage_train_plan gigl_sage_train_plan;
+int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b, const int32_t* fanouts,
+                                    int32_t hops, const int32_t* dims, float* const* w, float* const* bias,
+                                    int32_t act_last, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                    gigl_sage_train_plan** out);
+int32_t gigl_sage_train_plan_step(gigl_sage_train_plan* plan, const uint32_t* roots, const int64_t* labels, int32_t n_valid,
+                                  int32_t sampling_seed, int32_t mode, float* loss_out);
+const float* gigl_sage_train_plan_loss(gigl_sage_train_plan* plan);
+int32_t gigl_sage_train_plan_destroy(gigl_sage_train_plan* plan);
+
 /* Count-min sketch of candidate ids for the Retrieval task's candidate-sampling correction
  * (python/gigl/src/common/models/layers/count_min_sketch.py:11-95, used by task.py:140-205): table = DEVICE int32
  * [depth][width], zeroed by the caller; cell of (id, row) = hash((id, row)) % width with CPython's tuple hash of two
