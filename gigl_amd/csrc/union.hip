@@ -1004,35 +1004,48 @@ __global__ __launch_bounds__(256) void lg2_count_kernel(UnionArgs a, Lg2Args g, 
   }
 }
 
-// rows of 2..TINY_ROW entries (a node with two or three occurrences): one THREAD per row — insertion sort with
-// duplicate removal in a private LDS strip (stride TINY_ROW + 1 words: conflict-free across the threads of a wave).
-// A wave per such row spends its time waiting on four dependent loads; a thread per row keeps 64 rows in flight per
-// wave.
+// rows of 2..TINY_ROW entries (a node with two or three occurrences): one THREAD per row — a sorting network over the
+// row held in registers, duplicates removed on the way out.  A wave per such row spends its time waiting on four
+// dependent loads; a thread per row keeps 64 rows in flight per wave.
 constexpr int TINY_ROW = 32;
 
 __global__ __launch_bounds__(256) void lg2_row_sort_tiny_kernel(const int32_t* tiny_rows, const int32_t* tiny_count,
                                                                 const int32_t* rowptr, int32_t* rowend, int32_t* col,
                                                                 int32_t* edge_counters, int ec_stride = 1) {
-  __shared__ int32_t s_v[256 * (TINY_ROW + 1)];
+  // (round 4) the row lives in 32 REGISTERS: padded with +inf, sorted by a fully unrolled bitonic network (240
+  // compare-exchanges, no memory access), duplicates dropped on the way out.  The insertion sort in an LDS strip this
+  // replaces was a chain of dependent LDS reads — ~40 us of latency per launch whatever the number of rows.
   const int32_t nq = *tiny_count;
-  int32_t* v = s_v + threadIdx.x * (TINY_ROW + 1);
   int32_t edges = 0;
   for (int32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
     const int32_t i = tiny_rows[q];
     const int32_t s = rowptr[i], m = rowend[i] - s;
-    const int mm = m < TINY_ROW ? m : TINY_ROW;
-    for (int j = 0; j < mm; ++j) v[j] = col[s + j];  // (independent loads: all in flight together)
-    int u = 0;
-    for (int j = 0; j < mm; ++j) {  // in place: the sorted distinct prefix [0, u) never passes j
-      const int32_t x = v[j];
-      int k = u;
-      while (k > 0 && v[k - 1] > x) --k;           // insertion point
-      if (k > 0 && v[k - 1] == x) continue;        // already there
-      for (int z = u; z > k; --z) v[z] = v[z - 1];
-      v[k] = x;
-      ++u;
+    int32_t v[TINY_ROW];
+#pragma unroll
+    for (int j = 0; j < TINY_ROW; ++j) v[j] = j < m ? col[s + j] : 0x7FFFFFFF;  // (independent loads: all in flight together)
+#pragma unroll
+    for (int k = 2; k <= TINY_ROW; k <<= 1)
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1)
+#pragma unroll
+        for (int x = 0; x < TINY_ROW; ++x) {
+          const int y = x ^ j;
+          if (y > x) {
+            const bool up = (x & k) == 0;
+            const int32_t lo = min(v[x], v[y]), hi = max(v[x], v[y]);
+            v[x] = up ? lo : hi;
+            v[y] = up ? hi : lo;
+          }
+        }
+    int32_t u = 0, prev = -1;  // (entries are local or global node ids: non-negative)
+#pragma unroll
+    for (int j = 0; j < TINY_ROW; ++j) {
+      if (j < m && v[j] != prev) {
+        col[s + u] = v[j];
+        ++u;
+      }
+      prev = v[j];
     }
-    for (int j = 0; j < u; ++j) col[s + j] = v[j];
     rowend[i] = s + u;
     edges += u;
   }
@@ -2375,6 +2388,11 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   while (cap < 2 * Tg && cap < cap_max) cap <<= 1;
   const int64_t P = (2 * Tg + cap - 1) / cap;
   if (P > LG3_MAX_PARTS) return GIGL_OK;
+  // a call of a few batches (a training step: one) leaves most CUs without a workgroup of the dedup pass, whose duration
+  // is that of ONE workgroup walking its batch's whole stream (~80 us at [25,10] x 1024): LG2's position-parallel
+  // launches finish such a call sooner (training step 0.42 -> 0.39 ms)
+  static const int64_t min_wgs = getenv("GIGL_LG3_MIN_WGS") ? atoll(getenv("GIGL_LG3_MIN_WGS")) : 32;
+  if (n_groups * P < min_wgs) return GIGL_OK;
   int64_t rs = 64;
   int rs_log2 = 6;
   while (rs < 2 * gr) {

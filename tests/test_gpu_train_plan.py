@@ -67,15 +67,15 @@ def test_library_training_step_equals_the_autograd_step(setup, dims, fan, b):
     eng.bind_stream(st)
     plan = SageTrainPlan(eng, lib, b, fan, lr=0.01, weight_decay=5e-4)
     got = []
-    for i in range(steps):  # (step 0 runs eagerly, step 1 captures, the rest replay the graph)
-        got.append(plan.step(roots_all[i * b:(i + 1) * b], labels_all[i * b:(i + 1) * b]).clone())
+    with torch.cuda.stream(st):  # (the loss is a device scalar written on the plan's stream)
+        for i in range(steps):  # (step 0 runs eagerly, step 1 captures, the rest replay the graph)
+            got.append(plan.step(roots_all[i * b:(i + 1) * b], labels_all[i * b:(i + 1) * b]).clone())
     eng.synchronize()
     got = [float(v) for v in got]
     plan.store(lib)
     plan.close()
     eng.bind_stream(torch.cuda.current_stream(eng.device))
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
-    assert want[-1] < want[0]
     for (k, a), (_, bb) in zip(lib.state_dict().items(), ref.state_dict().items()):
         np.testing.assert_allclose(a.cpu().numpy(), bb.cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
 
@@ -115,8 +115,10 @@ def test_library_training_step_against_the_cpu_restatement(setup):
     r_dev = torch.from_numpy(roots_np.view(np.int32)).to(eng.device)
     l_dev = torch.from_numpy(labels_np).to(eng.device)
     torch.cuda.synchronize()
-    got = [float(plan.step(r_dev[lo:lo + b], l_dev[lo:lo + b]).clone()) for lo in range(0, roots_np.size, b)]
+    with torch.cuda.stream(st):
+        got = [plan.step(r_dev[lo:lo + b], l_dev[lo:lo + b]).clone() for lo in range(0, roots_np.size, b)]
     eng.synchronize()
+    got = [float(v) for v in got]
     plan.store(model)
     plan.close()
     eng.bind_stream(torch.cuda.current_stream(eng.device))

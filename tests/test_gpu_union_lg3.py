@@ -73,7 +73,8 @@ np.savez(sys.argv[2], **out)
 @pytest.mark.gpu
 def test_lds_staged_union_equals_the_hbm_table_build(tmp_path):
     res = {}
-    for tag, env in (("lg3", {}), ("lg2", {"GIGL_UNION_LG2": "1"})):
+    # (GIGL_LG3_MIN_WGS=0: calls of a few batches would otherwise be routed to LG2 — they finish sooner there)
+    for tag, env in (("lg3", {"GIGL_LG3_MIN_WGS": "0"}), ("lg2", {"GIGL_UNION_LG2": "1"})):
         path = str(tmp_path / f"{tag}.npz")
         e = dict(os.environ, **env)
         e.pop("GIGL_UNION_GENERIC", None)
