@@ -1627,7 +1627,10 @@ def run_train(args, rank, world, local_rank):
             def step(i, count=False):  # noqa: F811
                 if count:
                     return eager_step(i, True)
-                return lib_plan.step(my[i], lab_pool[i], sampling_seed=resident.seed, mode=mode)
+                # (the next batch's sampling + union overlap this batch's layers: gigl_sage_train_plan_prefetch)
+                nxt = my[i + 1] if i + 1 < my.shape[0] and not os.environ.get("GIGL_BENCH_TRAIN_NO_PREFETCH") else None
+                with torch.cuda.stream(st):
+                    return lib_plan.step(my[i], lab_pool[i], sampling_seed=resident.seed, mode=mode, next_roots=nxt)
             for i in range(min(W, 4)):  # (eager step, capture, replays)
                 step(i)
             st.synchronize()

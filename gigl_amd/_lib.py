@@ -345,7 +345,7 @@ def load() -> C.CDLL:
         "gigl_sage_plan_overflow_add": [vp, vp],
         "gigl_sage_train_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), vp, vp, i32, C.c_float, C.c_float, C.c_float,
                                         C.c_float, C.c_float, vp],
-        "gigl_sage_train_plan_step": [vp, vp, vp, i32, i32, i32, vp],
+        "gigl_sage_train_plan_step": [vp, vp, vp, i32, vp, i32, i32, vp],
         "gigl_sage_train_plan_destroy": [vp],
         "gigl_gat_input_layer_fused": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, i64, vp, i32,
                                        vp, vp],

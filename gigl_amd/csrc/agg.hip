@@ -2408,7 +2408,7 @@ static bool launch_gat_fast(gigl_ctx* ctx, const float* h, const float* att_src,
     heavy_count = (int32_t*)gigl_arena_alloc(ctx, 256);
     heavy_list = (int32_t*)gigl_arena_alloc(ctx, rows_cap * 4);
     if (!heavy_count || !heavy_list) return false;
-    if (hipMemsetAsync(heavy_count, 0, 4, ctx->stream) != hipSuccess) return false;
+    gigl_fill_u32(ctx->stream, heavy_count, 0u, 1);
   }
   if (w_msg) {
     wt = (float*)gigl_arena_alloc(ctx, (int64_t)heads * C * De * 4);

@@ -25,6 +25,7 @@ struct gigl_ctx {
   char* arena = nullptr;
   int64_t arena_bytes = 0;
   int64_t arena_off = 0;
+  uint64_t arena_gen = 0;  // bumped whenever the arena is reallocated (a larger request): scratch addresses change
   // optional per-kernel HIP-event timing (gigl_profile_*): events are recorded on ctx->stream
   // around the launches whose id bit is set in prof_mask
   uint32_t prof_mask = 0;
@@ -158,6 +159,19 @@ int32_t gigl_feat_absmax(gigl_ctx* ctx, gigl_feat* feat, float* out);
 // self_src (fp32 rows, self_ld floats apart); a_tiled then holds ceil(d_mean / 32) chunks per row tile
 
 static inline int64_t gigl_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+
+// n_words 32-bit words at p = value, as a KERNEL on the stream.  The launches of a plan are replayed from captured hipGraphs;
+// a memset NODE was seen to run out of order with the kernels around it on this runtime (round 4: counters cleared by
+// hipMemsetAsync were read stale by the next kernel of the replayed graph), a kernel node is ordered like any other.
+static __global__ __launch_bounds__(256) void gigl_fill_u32_kernel(uint32_t* __restrict__ p, uint32_t value, int64_t n_words) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (int64_t)gridDim.x * blockDim.x) p[i] = value;
+}
+static inline void gigl_fill_u32(hipStream_t st, void* p, uint32_t value, int64_t n_words) {
+  if (n_words <= 0) return;
+  int64_t blocks = (n_words + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(gigl_fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, value, n_words);
+}
 
 // out[i] = h[root_local[i]] for the b roots of a batch set (rows of d floats) — the last stage of the one-call plans.
 // (a failed batch set — meta[GIGL_META_OVERFLOW] != 0: levels zeroed, nothing computed — hands out NaN rows, never the

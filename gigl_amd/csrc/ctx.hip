@@ -26,6 +26,7 @@ int32_t gigl_arena_reset(gigl_ctx* ctx, int64_t need_bytes) {
   }
   GIGL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->arena, (size_t)want));
   ctx->arena_bytes = want;
+  ++ctx->arena_gen;  // (captured launches that baked scratch addresses of the old arena are stale: pipeline.hip)
   return GIGL_OK;
 }
 

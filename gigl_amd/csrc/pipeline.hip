@@ -11,6 +11,8 @@
 //   fed by process_raw_pyg_samples_and_collate_fn (rooted_node_neighborhood_data_loader.py:161-241).
 #include "common.h"
 
+#include <algorithm>
+#include <functional>
 #include <new>
 #include <vector>
 
@@ -81,6 +83,7 @@ struct gigl_sage_plan {
   std::vector<Segment> segs;
   int32_t cap_seed = 0, cap_mode = -1;
   uint32_t cap_prof_mask = 0;
+  uint64_t cap_arena_gen = 0;  // the ctx arena the captured launches point into
   bool captured = false;
 };
 
@@ -837,7 +840,10 @@ int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sam
   if (!p->use_graph) return enqueue_range(p, 0, n_stages(p), roots, sampling_seed, mode, out);
 
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (!p->captured || p->cap_mode != mode || p->cap_seed != sampling_seed || p->cap_prof_mask != ctx->prof_mask) {
+  // (another plan on this ctx may have grown — reallocated — the arena since the capture: the graphs' scratch addresses
+  // are then stale)
+  if (!p->captured || p->cap_mode != mode || p->cap_seed != sampling_seed || p->cap_prof_mask != ctx->prof_mask ||
+      p->cap_arena_gen != ctx->arena_gen) {
     GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     drop_graphs(p);
     // one eager run first: sizes the arena, builds the hash threshold table, sets kernel attributes — none of
@@ -857,6 +863,7 @@ int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sam
     p->cap_mode = mode;
     p->cap_seed = sampling_seed;
     p->cap_prof_mask = ctx->prof_mask;
+    p->cap_arena_gen = ctx->arena_gen;
     return GIGL_OK;
   }
   GIGL_HIP_CHECK(ctx, hipMemcpyAsync(p->roots_buf, roots, (size_t)p->b * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -880,10 +887,25 @@ int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sam
 //   layers' input gradients by one projection over the transposed weights + gigl_gather_mean_backward) -> Adam.
 // Replaces the loop body of NodeClassificationModelingTaskSpec._train
 // (python/gigl/src/common/modeling_task_specs/node_classification_modeling_task_spec.py:134-173) for batches sampled in
-// HBM: ~25 launches and two memsets, no torch kernel between them, replayed as ONE hipGraph per step.
+// HBM: ~25 launches and two memsets, no torch kernel between them, replayed from hipGraphs.
+// The step has two parts.  The GRAPH part (sample + union) does not depend on the weights: it runs on a ctx and stream of
+// the plan's own, into one of two workspaces, and a step that is told the NEXT batch (roots_next) starts that batch's graph part while the
+// LAYERS part (forward, loss, backward, Adam: the caller's ctx and stream) of the current batch runs — a training step
+// is a chain of small launches (one batch: the weights change between batches), so the two chains share the GPU well.
 struct gigl_sage_train_plan {
-  gigl_sage_plan* base = nullptr;  // tree / union buffers, sample + union stages
-  int32_t L = 0, b = 0;
+  gigl_ctx* ctx = nullptr;         // the caller's (its stream carries the layers part; errors are reported on it)
+  // two ctxs of the plan's own, for their ARENAS: scratch addresses are baked into the captured launches, and another
+  // plan on the caller's ctx (the inference plan of an evaluation pass between epochs) may grow — reallocate — that arena
+  gigl_ctx* lctx = nullptr;        // layers part (bound to the caller's stream at every step)
+  gigl_ctx* side = nullptr;        // graph part: sample + union, on its own stream
+  gigl_sage_plan* base[2] = {nullptr, nullptr};  // tree / union workspaces (on `side`)
+  int32_t cur = 0;                 // workspace of the next step
+  bool fetched[2] = {false, false};  // the workspace holds the graph of a prefetched batch
+  hipEvent_t ev_graph[2] = {nullptr, nullptr};   // graph part of the workspace done (recorded on the side stream)
+  // layers part that read the workspace done (recorded on the caller's stream); [2]: the caller's stream as it stands
+  // when a graph part is issued (the roots it is handed were written there)
+  hipEvent_t ev_layers[3] = {nullptr, nullptr, nullptr};
+  int32_t L = 0, b = 0, act_last = 0;
   int32_t dims[GIGL_MAX_HOPS + 1] = {0};
   int64_t rows_cap[GIGL_MAX_HOPS] = {0};  // rows layer l may compute
   float* w[GIGL_MAX_HOPS] = {nullptr};    // fused [dims[l+1]][2 dims[l]]: borrowed, UPDATED IN PLACE
@@ -904,21 +926,26 @@ struct gigl_sage_train_plan {
   float* loss = nullptr;
   float lr = 0.01f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, wd = 0.f;
   std::vector<void*> owned;
-  hipGraphExec_t exec = nullptr;
-  bool warm = false;  // one eager step has run
+  // hipGraph replay, per workspace and part
+  hipGraphExec_t exec_graph[2] = {nullptr, nullptr}, exec_layers[2] = {nullptr, nullptr};
+  bool warm_graph = false, warm_layers = false;  // one eager run of the part has sized arenas / built tables
   int32_t cap_seed = 0, cap_mode = -1;
 };
 
 namespace {
 
-int32_t train_enqueue(gigl_sage_train_plan* t, int32_t sampling_seed, int32_t mode) {
-  gigl_sage_plan* p = t->base;
-  gigl_ctx* ctx = p->ctx;
+int32_t train_enqueue_graph(gigl_sage_train_plan* t, int k, int32_t sampling_seed, int32_t mode) {
+  gigl_sage_plan* p = t->base[k];
+  return enqueue_range(p, 0, 2, p->roots_buf, sampling_seed, mode, nullptr);  // sample + union (+ the level guard)
+}
+
+int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
+  gigl_sage_plan* p = t->base[k];
+  gigl_ctx* ctx = t->lctx;
   const int L = t->L;
   hipStream_t st = ctx->stream;
-  int32_t rc = enqueue_range(p, 0, 2, p->roots_buf, sampling_seed, mode, nullptr);  // sample + union (+ the level guard)
-  if (rc != GIGL_OK) return rc;
-  GIGL_HIP_CHECK(ctx, hipMemsetAsync(t->zero_base, 0, t->zero_bytes, st));
+  int32_t rc = GIGL_OK;
+  gigl_fill_u32(st, t->zero_base, 0u, (int64_t)(t->zero_bytes / 4));
   const int32_t* n_local = p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr;
   // ---- forward
   for (int l = 0; l < L; ++l) {
@@ -932,7 +959,7 @@ int32_t train_enqueue(gigl_sage_train_plan* t, int32_t sampling_seed, int32_t mo
                               t->rows_cap[l], GIGL_AGGR_MEAN, t->a[l]);
     if (rc != GIGL_OK) return rc;
     rc = gigl_linear(ctx, t->a[l], t->w[l], t->bias[l], n_rows, t->rows_cap[l], 2 * d, t->dims[l + 1],
-                     (l < L - 1 || p->act_last) ? 1 : 0, t->h[l]);
+                     (l < L - 1 || t->act_last) ? 1 : 0, t->h[l]);
     if (rc != GIGL_OK) return rc;
   }
   // ---- loss on the roots, its gradient into dh[L - 1]
@@ -948,7 +975,7 @@ int32_t train_enqueue(gigl_sage_train_plan* t, int32_t sampling_seed, int32_t mo
   for (int l = L - 1; l >= 0; --l) {
     const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
     const int d = t->dims[l], n_out = t->dims[l + 1];
-    const bool act = l < L - 1 || p->act_last;
+    const bool act = l < L - 1 || t->act_last;
     rc = gigl_linear_weight_grad(ctx, t->dh[l], t->a[l], act ? t->h[l] : nullptr, n_rows, t->rows_cap[l], n_out, 2 * d,
                                  t->gw[l], t->bias[l] ? t->gb[l] : nullptr);
     if (rc != GIGL_OK) return rc;
@@ -994,17 +1021,90 @@ int32_t train_enqueue(gigl_sage_train_plan* t, int32_t sampling_seed, int32_t mo
   return GIGL_OK;
 }
 
+// run `body` on ctx->stream: eagerly the first time (arena sizing, table builds and kernel attributes cannot happen inside
+// a capture), captured the second, replayed from then on
+int32_t train_run_part(gigl_ctx* ctx, hipGraphExec_t* exec, bool* warm, const std::function<int32_t()>& body, int part) {
+  // (A/B knob: GIGL_TRAIN_PLAN_EAGER=1 both parts eager, =graph / =layers only that part)
+  static const char* ev = getenv("GIGL_TRAIN_PLAN_EAGER");
+  const bool eager = ev && (ev[0] == '1' || (ev[0] == 'g' && part == 0) || (ev[0] == 'l' && part == 1));
+  hipStream_t st = ctx->stream;
+  if (eager || st == nullptr) return body();  // (the legacy default stream cannot be captured)
+  if (!*exec && !*warm) {
+    const int32_t rc = body();
+    if (rc != GIGL_OK) return rc;
+    GIGL_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    *warm = true;
+    return GIGL_OK;
+  }
+  if (!*exec) {
+    hipGraph_t graph = nullptr;
+    int32_t rc = GIGL_OK;
+    hipError_t err = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (err == hipSuccess) {
+      rc = body();
+      const hipError_t e2 = hipStreamEndCapture(st, &graph);
+      if (rc == GIGL_OK && e2 != hipSuccess) err = e2;
+    }
+    if (rc == GIGL_OK && err == hipSuccess) err = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+    if (graph) hipGraphDestroy(graph);
+    if (rc != GIGL_OK) return rc;
+    if (err != hipSuccess) {
+      *exec = nullptr;
+      return gigl_fail(ctx, GIGL_E_HIP, "capturing a part of the training step failed: %s", hipGetErrorString(err));
+    }
+  }
+  GIGL_HIP_CHECK(ctx, hipGraphLaunch(*exec, st));
+  return GIGL_OK;
+}
+
+// the graph part of workspace k for `roots`, on the side stream; ev_graph[k] marks its end
+int32_t train_graph_part(gigl_sage_train_plan* t, int k, const uint32_t* roots, int32_t sampling_seed, int32_t mode) {
+  gigl_ctx* sc = t->side;
+  if (t->cap_seed != sampling_seed || t->cap_mode != mode) {  // seed and mode are baked into the captured launches
+    GIGL_HIP_CHECK(sc, hipStreamSynchronize(sc->stream));
+    for (int i = 0; i < 2; ++i)
+      if (t->exec_graph[i]) {
+        hipGraphExecDestroy(t->exec_graph[i]);
+        t->exec_graph[i] = nullptr;
+      }
+    t->cap_seed = sampling_seed;
+    t->cap_mode = mode;
+  }
+  // the workspace is free once the layers part that last read it is done; `roots` was written on the caller's stream
+  if (t->ev_layers[k]) GIGL_HIP_CHECK(sc, hipStreamWaitEvent(sc->stream, t->ev_layers[k], 0));
+  GIGL_HIP_CHECK(sc, hipEventRecord(t->ev_layers[2], t->ctx->stream));
+  GIGL_HIP_CHECK(sc, hipStreamWaitEvent(sc->stream, t->ev_layers[2], 0));
+  GIGL_HIP_CHECK(sc, hipMemcpyAsync(t->base[k]->roots_buf, roots, (size_t)t->b * 4, hipMemcpyDeviceToDevice, sc->stream));
+  const int32_t rc = train_run_part(sc, &t->exec_graph[k], &t->warm_graph,
+                                    [&]() { return train_enqueue_graph(t, k, sampling_seed, mode); }, 0);
+  if (rc != GIGL_OK) return rc;
+  GIGL_HIP_CHECK(sc, hipEventRecord(t->ev_graph[k], sc->stream));
+  return GIGL_OK;
+}
+
 }  // namespace
 
 int32_t gigl_sage_train_plan_destroy(gigl_sage_train_plan* t) {
   if (!t) return GIGL_OK;
-  if (t->base && t->base->ctx) {
-    hipSetDevice(t->base->ctx->device);
-    hipStreamSynchronize(t->base->ctx->stream);
+  if (t->ctx) {
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
   }
-  if (t->exec) hipGraphExecDestroy(t->exec);
+  if (t->side) hipStreamSynchronize(t->side->stream);
+  for (int k = 0; k < 2; ++k) {
+    if (t->exec_graph[k]) hipGraphExecDestroy(t->exec_graph[k]);
+    if (t->exec_layers[k]) hipGraphExecDestroy(t->exec_layers[k]);
+    if (t->ev_graph[k]) hipEventDestroy(t->ev_graph[k]);
+    if (t->base[k]) gigl_sage_plan_destroy(t->base[k]);
+  }
+  for (int k = 0; k < 3; ++k)
+    if (t->ev_layers[k]) hipEventDestroy(t->ev_layers[k]);
   for (void* q : t->owned) hipFree(q);
-  if (t->base) gigl_sage_plan_destroy(t->base);
+  if (t->side) gigl_ctx_destroy(t->side);
+  if (t->lctx) {
+    gigl_ctx_set_stream(t->lctx, nullptr);  // (the stream is the caller's)
+    gigl_ctx_destroy(t->lctx);
+  }
   delete t;
   return GIGL_OK;
 }
@@ -1016,18 +1116,28 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
   if (!ctx || !out) return GIGL_E_INVALID_ARG;
   *out = nullptr;
   GIGL_REQUIRE(ctx, graph && feat && fanouts && dims && w, "null argument");
-  gigl_sage_plan* base = nullptr;
-  int32_t rc = plan_create(ctx, graph, feat, b, fanouts, hops, dims, (const float* const*)w, (const float* const*)bias,
-                           act_last, false, &base);
-  if (rc != GIGL_OK) return rc;
+  GIGL_REQUIRE(ctx, hops >= 1 && hops <= GIGL_MAX_HOPS && b >= 1, "bad plan shape");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   gigl_sage_train_plan* t = new (std::nothrow) gigl_sage_train_plan();
-  if (!t) {
-    gigl_sage_plan_destroy(base);
-    return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
+  if (!t) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
+  t->ctx = ctx;
+  int32_t rc = gigl_ctx_create(ctx->device, &t->side);
+  if (rc == GIGL_OK) rc = gigl_ctx_create(ctx->device, &t->lctx);
+  for (int k = 0; k < 2 && rc == GIGL_OK; ++k) {
+    rc = plan_create(t->side, graph, feat, b, fanouts, hops, dims, (const float* const*)w, (const float* const*)bias, act_last,
+                     false, &t->base[k]);
+    if (rc != GIGL_OK) gigl_fail(ctx, rc, "%s", gigl_last_error(t->side));
+    if (rc == GIGL_OK && hipEventCreateWithFlags(&t->ev_graph[k], hipEventDisableTiming) != hipSuccess) rc = GIGL_E_HIP;
   }
-  t->base = base;
+  for (int k = 0; k < 3 && rc == GIGL_OK; ++k)
+    if (hipEventCreateWithFlags(&t->ev_layers[k], hipEventDisableTiming) != hipSuccess) rc = GIGL_E_HIP;
+  if (rc != GIGL_OK) {
+    gigl_sage_train_plan_destroy(t);
+    return rc;
+  }
   t->L = hops;
   t->b = b;
+  t->act_last = act_last;
   t->lr = lr;
   t->beta1 = beta1;
   t->beta2 = beta2;
@@ -1095,60 +1205,41 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
 }
 
 int32_t gigl_sage_train_plan_step(gigl_sage_train_plan* t, const uint32_t* roots, const int64_t* labels, int32_t n_valid,
-                                  int32_t sampling_seed, int32_t mode, float* loss_out) {
+                                  const uint32_t* roots_next, int32_t sampling_seed, int32_t mode, float* loss_out) {
   if (!t) return GIGL_E_INVALID_ARG;
-  gigl_sage_plan* p = t->base;
-  gigl_ctx* ctx = p->ctx;
+  gigl_ctx* ctx = t->ctx;
   GIGL_REQUIRE(ctx, roots && labels && n_valid >= 1 && n_valid <= t->b, "bad argument");
   if (mode == GIGL_MODE_REPLACE)
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the training plan needs duplicate-free trees (no with-replacement mode)");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  // the step's inputs go into the static buffers the (captured) launches read: root ids, labels, the number of real
-  // roots (a 32-bit fill: no host memory involved, ordered on the stream)
-  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(p->roots_buf, roots, (size_t)t->b * 4, hipMemcpyDeviceToDevice, st));
+  const int k = t->cur;
+  if (!t->fetched[k]) {  // not prefetched by the previous step: the graph part of THIS batch now (the layers wait for it)
+    const int32_t rc = train_graph_part(t, k, roots, sampling_seed, mode);
+    if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->side));
+  }
+  t->fetched[k] = false;
+  // the NEXT batch's graph part goes to the side stream BEFORE this batch's layers are enqueued: it waits for what the
+  // caller's stream holds now (roots_next was written there; the layers that last read the other workspace), not for
+  // the layers about to be enqueued
+  if (roots_next) {
+    const int32_t rc = train_graph_part(t, k ^ 1, roots_next, sampling_seed, mode);
+    if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->side));
+    t->fetched[k ^ 1] = true;
+  }
+  // the step's inputs go into the static buffers the (captured) launches read: labels, the number of real roots (a
+  // 32-bit fill: no host memory involved, ordered on the stream)
   GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->labels_buf, labels, (size_t)n_valid * 8, hipMemcpyDeviceToDevice, st));
   GIGL_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)t->n_valid_buf, n_valid, 1, st));
-  static const bool eager = getenv("GIGL_TRAIN_PLAN_EAGER") != nullptr;  // (A/B knob)
-  int32_t rc = GIGL_OK;
-  if (eager || st == nullptr) {  // (the legacy default stream cannot be captured)
-    rc = train_enqueue(t, sampling_seed, mode);
-  } else {
-    if (t->exec && (t->cap_seed != sampling_seed || t->cap_mode != mode)) {
-      GIGL_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      hipGraphExecDestroy(t->exec);
-      t->exec = nullptr;
-    }
-    if (!t->exec && !t->warm) {
-      // the first step runs eagerly: it sizes the arena, builds the sampler's table and sets kernel attributes — none of
-      // which may happen inside a capture
-      rc = train_enqueue(t, sampling_seed, mode);
-      if (rc != GIGL_OK) return rc;
-      GIGL_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      t->warm = true;
-    } else {
-      if (!t->exec) {
-        hipGraph_t graph = nullptr;
-        hipError_t err = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-        if (err == hipSuccess) {
-          rc = train_enqueue(t, sampling_seed, mode);
-          const hipError_t e2 = hipStreamEndCapture(st, &graph);
-          if (rc == GIGL_OK && e2 != hipSuccess) err = e2;
-        }
-        if (rc == GIGL_OK && err == hipSuccess) err = hipGraphInstantiate(&t->exec, graph, nullptr, nullptr, 0);
-        if (graph) hipGraphDestroy(graph);
-        if (rc != GIGL_OK) return rc;
-        if (err != hipSuccess) {
-          t->exec = nullptr;
-          return gigl_fail(ctx, GIGL_E_HIP, "capturing the training step failed: %s", hipGetErrorString(err));
-        }
-        t->cap_seed = sampling_seed;
-        t->cap_mode = mode;
-      }
-      GIGL_HIP_CHECK(ctx, hipGraphLaunch(t->exec, st));
-    }
+  GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, t->ev_graph[k], 0));
+  if (t->lctx->stream != st || t->lctx->own_stream) {
+    const int32_t rs = gigl_ctx_set_stream(t->lctx, st);
+    if (rs != GIGL_OK) return gigl_fail(ctx, rs, "%s", gigl_last_error(t->lctx));
   }
-  if (rc != GIGL_OK) return rc;
+  const int32_t rc = train_run_part(t->lctx, &t->exec_layers[k], &t->warm_layers, [&]() { return train_enqueue_layers(t, k); }, 1);
+  if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->lctx));
+  GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_layers[k], st));
+  t->cur = k ^ 1;
   if (loss_out) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(loss_out, t->loss, 4, hipMemcpyDeviceToDevice, st));
   return GIGL_OK;
 }

@@ -552,6 +552,8 @@ static inline int64_t expand_desc_bytes(int64_t n_parents) {
          WORK_LISTS * WORK_CNT_STRIDE * 4 + 512;
 }
 
+__global__ void work_counts_zero_kernel(int32_t* count) { count[threadIdx.x * WORK_CNT_STRIDE] = 0; }
+
 __global__ __launch_bounds__(256) void plan_rows_kernel(ExpandArgs a, RangeTable tb, RowDesc* __restrict__ desc,
                                                         int64_t* heavy_list, int32_t* heavy_count, WorkLists wl) {
   __shared__ int32_t s_wave[4];
@@ -1144,14 +1146,16 @@ int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a_in, const RangeTable& tb, 
     return e ? atoi(e) : 128;
   }();
   a.flat_max = flat_max;
-  if (!covered) GIGL_HIP_CHECK(ctx, hipMemsetAsync(heavy_count, 0, 4, ctx->stream));
+  if (!covered) gigl_fill_u32(ctx->stream, heavy_count, 0u, 1);
   // the work lists sit behind this hop's descriptors (expand_desc_bytes)
   WorkLists wl{};
   wl.cap = work_list_cap(a.n_parents);
   wl.items = reinterpret_cast<uint32_t*>(desc + a.n_parents + 1);
   wl.count = reinterpret_cast<int32_t*>(wl.items + (int64_t)WORK_LISTS * wl.cap);
   wl.count = reinterpret_cast<int32_t*>(((uintptr_t)wl.count + 127) & ~(uintptr_t)127);
-  GIGL_HIP_CHECK(ctx, hipMemsetAsync(wl.count, 0, WORK_LISTS * WORK_CNT_STRIDE * 4, ctx->stream));
+  // (a kernel, not hipMemsetAsync: a memset NODE of a captured graph was seen to run out of order with the planning
+  // pass's atomics on this runtime — stale counts made the expansion pass read slots past a list's end)
+  hipLaunchKernelGGL(work_counts_zero_kernel, dim3(1), dim3(WORK_LISTS), 0, ctx->stream, wl.count);
   {
     gigl_prof_scope ps(ctx, GIGL_K_EXPAND);
     hipLaunchKernelGGL(plan_rows_kernel, dim3((unsigned)(a.n_parents / 256 + 1)), dim3(256), 0, ctx->stream, a, tb,

@@ -1288,17 +1288,28 @@ class SageTrainPlan:
                 if b is not None:
                     c.lin_l.bias.copy_(b)
 
-    def step(self, roots: torch.Tensor, labels: torch.Tensor, sampling_seed: int = 42, mode: int = MODE_SPARK_HASH) -> torch.Tensor:
-        """one optimiser step on the batch: roots int32 device [k <= b] (uint32 ids), labels int64 device [k]; a short
-        batch is padded with its first root (a repeated root adds nothing to the union graph) and masked out of the loss.
-        Returns the loss (a device scalar owned by the plan, overwritten by the next step)."""
+    def _padded(self, roots: torch.Tensor) -> torch.Tensor:
         k = int(roots.numel())
-        assert roots.is_cuda and roots.dtype == torch.int32 and labels.is_cuda and labels.dtype == torch.int64
-        assert 0 < k <= self.b and labels.numel() == k
+        assert roots.is_cuda and roots.dtype == torch.int32 and 0 < k <= self.b
         if k < self.b:
             roots = torch.cat([roots, roots[:1].expand(self.b - k)])
-        roots, labels = roots.contiguous(), labels.contiguous()
+        return roots.contiguous()
+
+    def step(self, roots: torch.Tensor, labels: torch.Tensor, sampling_seed: int = 42, mode: int = MODE_SPARK_HASH,
+             next_roots: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """one optimiser step on the batch: roots int32 device [k <= b] (uint32 ids), labels int64 device [k]; a short
+        batch is padded with its first root (a repeated root adds nothing to the union graph) and masked out of the loss.
+        next_roots: the roots of the batch the NEXT call will be given — its sampling and union graph then run on the
+        plan's own stream while this step's forward / backward run (roots_next of gigl_sage_train_plan_step).
+        Returns the loss (a device scalar owned by the plan, overwritten by the next step)."""
+        k = int(roots.numel())
+        assert labels.is_cuda and labels.dtype == torch.int64 and labels.numel() == k
+        roots, labels = self._padded(roots), labels.contiguous()
+        nxt = self._padded(next_roots) if next_roots is not None and next_roots.numel() else None
+        # (read asynchronously by the plan's own stream: kept alive until the step after the next)
+        self._keep = (getattr(self, "_keep", (None,))[-1], (roots, nxt))
         check(self._lib.gigl_sage_train_plan_step(self._plan, C.c_void_p(roots.data_ptr()), C.c_void_p(labels.data_ptr()), k,
+                                                  C.c_void_p(nxt.data_ptr()) if nxt is not None else None,
                                                   int(sampling_seed), int(mode), C.c_void_p(self.loss.data_ptr())),
               self.eng._ctx)
         return self.loss

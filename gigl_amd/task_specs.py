@@ -305,8 +305,10 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
         labels_all = torch.from_numpy(labels).to(device)
         torch.cuda.synchronize(device)
         loss = None
-        for lo in range(0, ids.size, b):
-            loss = plan.step(roots_all[lo:lo + b], labels_all[lo:lo + b], sampling_seed=res.seed, mode=res.mode)
+        with torch.cuda.stream(self._train_stream):
+            for lo in range(0, ids.size, b):  # (the next batch's sampling + union overlap this batch's layers)
+                loss = plan.step(roots_all[lo:lo + b], labels_all[lo:lo + b], sampling_seed=res.seed, mode=res.mode,
+                                 next_roots=roots_all[lo + b:lo + 2 * b])
         res.engine.synchronize()
         plan.store(model)
         return loss.detach().clone().reshape(())

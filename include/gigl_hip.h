@@ -968,7 +968,7 @@ int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);
  *   operand and output -> mean cross-entropy over the batch's real roots -> backward (gigl_linear_weight_grad per layer;
  *   the input gradient of layers >= 1 by one projection over the transposed weights + gigl_gather_mean_backward) ->
  *   Adam with L2 weight decay (torch.optim.Adam: the decay joins the gradient),
- * ~25 launches, no host read, replayed as ONE hipGraph per step after the first two calls.
+ * ~25 launches, no host read, replayed from hipGraphs after the first two calls.
  * w[l]: fused [dims[l+1]][2*dims[l]] (= [W_l | W_r]), bias[l] (array or entries may be NULL): DEVICE fp32, borrowed and
  * UPDATED IN PLACE by every step (the Adam moments live in the plan, zero at creation).  act_last as gigl_sage_plan_create.
  * gigl_sage_train_plan_step: roots [b] (uint32; a batch of fewer than b real roots is padded by the caller, e.g. with its
@@ -981,8 +981,12 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
                                     int32_t hops, const int32_t* dims, float* const* w, float* const* bias,
                                     int32_t act_last, float lr, float beta1, float beta2, float eps, float weight_decay,
                                     gigl_sage_train_plan** out);
+/* The step has two parts: the GRAPH part (sample + union: independent of the weights) and the LAYERS part (forward,
+ * loss, backward, Adam).  roots_next (DEVICE [b], may be NULL) = the roots of the batch the NEXT call will be given: its
+ * graph part then runs on a stream of the plan's own, into the second of the plan's two workspaces, while this batch's
+ * layers part runs on the ctx's stream (the next call's `roots` are then not read again).  Results do not depend on it. */
 int32_t gigl_sage_train_plan_step(gigl_sage_train_plan* plan, const uint32_t* roots, const int64_t* labels, int32_t n_valid,
-                                  int32_t sampling_seed, int32_t mode, float* loss_out);
+                                  const uint32_t* roots_next, int32_t sampling_seed, int32_t mode, float* loss_out);
 const float* gigl_sage_train_plan_loss(gigl_sage_train_plan* plan);
 int32_t gigl_sage_train_plan_destroy(gigl_sage_train_plan* plan);
 
