@@ -1310,6 +1310,11 @@ def run_sharded(args, rank, world, local_rank, sub=False):
             "transport": ("RCCL ncclSend / ncclRecv groups issued by the library" if dist.get_backend() == "nccl"
                           else "host callback over " + dist.get_backend() + " (functional check, not xGMI)"),
             "ranks": world}
+        if world == 1 and not gat and not args.no_cpu_baseline and not sub:
+            # (one rank: the shard is the whole graph, so the single-GPU line's CPU port applies as it is — the oracle
+            # sampler + collate and the fp32 CPU forward over full batches of this graph; at N > 1 no host holds the graph)
+            one, allc = run_cpu_baseline(eng, model, my.view(-1, B), fanouts, Wp, n, d)
+            line["cpu_baseline"], line["cpu_baseline_all_cores"] = one, allc
         if not sub:
             emit(line)
     else:
@@ -2596,6 +2601,8 @@ def run_gat_lp(args, rank, world, local_rank):
                    "steps_per_call": G, "driver": driver, "setup_s": round(setup_s, 1)},
         "roofline": roofline, "cpu_baseline": None,
     }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = run_cpu_gat_lp_baseline(eng, model, anchors, negs, fanouts, heads, L)
     if world > 1:  # a replica per GPU: whole-job rate = sum over the ranks, step time = the slowest rank's
         import torch.distributed as dist
         v = torch.tensor([line["value"]], dtype=torch.float64, device=dev)
@@ -2609,6 +2616,67 @@ def run_gat_lp(args, rank, world, local_rank):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_cpu_gat_lp_baseline(eng, model, anchors, negs, fanouts, heads, L, budget_s=15.0):
+    """the CPU port of the GAT link-prediction step on one host core: oracle sampler + collate (C) of the anchors +
+    positives batch and of the random-negative batch, 2-layer GAT forward over the WHOLE union graph in fp32 torch
+    (oracle/gnn_ref.gat_conv: the reference's execution order), inner-product scores and the retrieval loss rows —
+    full steps of the GPU line's shape, counted in its unit (sampled edges + the edges the trimmed schedule aggregates).
+    The positives (one sampled out-neighbour per anchor) are taken from the device, untimed: they are an input here."""
+    import oracle
+    from oracle import gnn_ref
+    rowptr, col = eng.graph_to_host()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.set_num_threads(1)
+
+    def encode(roots):
+        nbr, cnt = oracle.sample_khop(rowptr, col, roots, fanouts, canonical=True)
+        u = oracle.union_build(roots, fanouts, nbr)
+        return u, cnt, gnn_ref.union_edge_index(u["rowptr"], u["col"])
+
+    def units(u, cnt):
+        meta, rp = u["meta"], u["rowptr"].astype(np.int64)
+        return int(sum(int(c.sum()) for c in cnt)) + sum(int(rp[int(meta[2 + (L - 1 - l)])]) for l in range(L))
+
+    def fetch(u):
+        ids = torch.from_numpy(u["nodes"].astype(np.int64)).to(torch.int32).to(eng.device)
+        return eng.gather_rows(ids, torch.tensor([ids.numel()], dtype=torch.int32, device=eng.device), int(ids.numel())).cpu()
+
+    def forward(x, ei):
+        h = x
+        for l in range(L):
+            pfx = f"conv_layers.{l}."
+            h = gnn_ref.gat_conv(h, ei, sd[pfx + "lin.weight"], sd[pfx + "att_src"].reshape(-1), sd[pfx + "att_dst"].reshape(-1),
+                                 sd.get(pfx + "bias"), heads if l < L - 1 else 1)
+            if l < L - 1:
+                h = torch.relu(h)
+        return h
+
+    t_used, edges, steps = 0.0, 0, 0
+    while t_used < budget_s and steps < anchors.shape[0]:
+        a = anchors[steps]
+        pos, _ = eng.sample_positives(a, 1)
+        a_h, p_h = a.cpu().numpy().view(np.uint32), pos.reshape(-1).cpu().numpy().view(np.uint32)
+        ng = negs[steps].cpu().numpy().view(np.uint32)
+        t0 = time.perf_counter()
+        um, cm, eim = encode(np.concatenate([a_h, p_h]))
+        un, cn, ein = encode(ng)
+        t_used += time.perf_counter() - t0
+        xm, xn = fetch(um), fetch(un)
+        t0 = time.perf_counter()
+        em = forward(xm, eim)[torch.from_numpy(um["root_local"].astype(np.int64)).clamp(min=0)]
+        en = forward(xn, ein)[torch.from_numpy(un["root_local"].astype(np.int64)).clamp(min=0)]
+        B = a_h.size
+        scores = em[:B] @ torch.cat([em[B:], en]).T / 0.07
+        _ = (torch.logsumexp(scores, dim=1) - scores.diagonal()).sum()
+        t_used += time.perf_counter() - t0
+        edges += units(um, cm) + units(un, cn)
+        steps += 1
+    return {"value": edges / max(t_used, 1e-9), "unit": "edges/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} full steps ({anchors.shape[1]} anchors + positives, {negs.shape[1]} random negatives) of the "
+                      f"same graph / fanout, {t_used:.1f} s; sampler + collate = oracle/gigl_oracle.c, forward = "
+                      "oracle/gnn_ref.gat_conv over the whole union graph (fp32 torch, 1 thread), scores + loss rows in torch"}
 
 
 def run_cpu_baseline(eng, model, my, fanouts, W, n, d):

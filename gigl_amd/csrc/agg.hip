@@ -3109,20 +3109,29 @@ int32_t gigl_feat_half_split_scale(gigl_ctx* ctx, gigl_feat* feat, float fan, fl
 }
 
 // hs[0] = s_a, hs[1] = s_w from the largest |w| as the weights are NOW, hs[2] = 1 / (s_a s_w)      (one workgroup)
-__global__ __launch_bounds__(1024) void hs_scale_kernel(const float* __restrict__ w, int64_t n, float s_a,
-                                                        float* __restrict__ hs) {
-  __shared__ float s_m[16];
+// (one small workgroup: next to the other streams' kernels a 1024-thread workgroup waited ~100 us for a CU with sixteen
+// free wave slots — 4 waves find room at once)
+__global__ __launch_bounds__(256) void hs_scale_kernel(const float* __restrict__ w, int64_t n, float s_a,
+                                                       float* __restrict__ hs) {
+  __shared__ float s_m[4];
   float m = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(w) & 15) == 0) ? n / 4 : 0;
+  for (int64_t i = threadIdx.x; i < n4; i += 256) {
+    const float4 v = w4[i];
+    const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    m = fmaxf(m, a == a ? a : 0.f);  // (a NaN weight makes NaN rows on any path; it does not pick the scale)
+  }
+  for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
     const float v = fabsf(w[i]);
-    m = fmaxf(m, v == v ? v : 0.f);  // (a NaN weight makes NaN rows on any path; it does not pick the scale)
+    m = fmaxf(m, v == v ? v : 0.f);
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int i = 1; i < 16; ++i) m = fmaxf(m, s_m[i]);
+    for (int i = 1; i < 4; ++i) m = fmaxf(m, s_m[i]);
     const float s_w = (m > 0.f && m < __uint_as_float(0x7F800000u)) ? hs_pow2_scale(m) : 1.f;
     hs[0] = s_a;
     hs[1] = s_w;
@@ -3131,7 +3140,7 @@ __global__ __launch_bounds__(1024) void hs_scale_kernel(const float* __restrict_
 }
 
 int32_t gigl_hs_scale_update(gigl_ctx* ctx, const float* w, int64_t n, float s_a, float* hs_dev) {
-  hipLaunchKernelGGL(hs_scale_kernel, dim3(1), dim3(1024), 0, ctx->stream, w, n, s_a, hs_dev);
+  hipLaunchKernelGGL(hs_scale_kernel, dim3(1), dim3(256), 0, ctx->stream, w, n, s_a, hs_dev);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import seed_trainer
+
 import oracle
 from gigl_amd import wire
 from gigl_amd.config import GbmlConfigPbWrapper, tfrecord_files
@@ -114,7 +116,7 @@ def test_trainer_then_inferencer(workdir, golden_dir):
     from oracle import gnn_ref
     cfg_uri = "configs/snc_frozen_gbml_config.yaml"
     SubgraphSampler().run("job", cfg_uri, None, uri_base=workdir)
-    torch.manual_seed(int(os.environ.get("GIGL_TEST_SEED", "1")))  # (fixed initialisation: nothing in the trainer seeds it)
+    seed_trainer()  # (ONE shared seed for every trainer test: tests/conftest.py; the trainer seeds nothing itself)
     tr = Trainer()
     metrics = tr.run("job", cfg_uri, None, uri_base=workdir)
     assert "acc" in metrics.metrics and 0.0 <= metrics.metrics["acc"].value <= 1.0
@@ -249,7 +251,7 @@ def test_node_classification_with_gat_encoder(workdir):
     info.update(embeddingsPath="out/snc_gat/embeddings.jsonl", predictionsPath="out/snc_gat/predictions.jsonl")
     cfg_uri = "configs/snc_gat_gbml_config.yaml"
     yaml.safe_dump(doc, open(os.path.join(workdir, cfg_uri), "w"))
-    torch.manual_seed(int(os.environ.get("GIGL_TEST_SEED", "1")))  # (fixed initialisation: nothing in the trainer seeds it)
+    seed_trainer()  # (ONE shared seed for every trainer test: tests/conftest.py; the trainer seeds nothing itself)
     tr = Trainer()
     tr.run("job", cfg_uri, None, uri_base=workdir)
     hist = tr.training_process.trainer.history
@@ -298,7 +300,7 @@ def test_node_classification_with_the_stock_two_layer_gcn(workdir):
     info.update(embeddingsPath="out/snc_gcn/embeddings.jsonl", predictionsPath="out/snc_gcn/predictions.jsonl")
     cfg_uri = "configs/snc_gcn_gbml_config.yaml"
     yaml.safe_dump(doc, open(os.path.join(workdir, cfg_uri), "w"))
-    torch.manual_seed(int(os.environ.get("GIGL_TEST_SEED", "1")))  # (fixed initialisation: nothing in the trainer seeds it)
+    seed_trainer()  # (ONE shared seed for every trainer test: tests/conftest.py; the trainer seeds nothing itself)
     tr = Trainer()
     metrics = tr.run("job", cfg_uri, None, uri_base=workdir)
     hist = tr.training_process.trainer.history
@@ -382,7 +384,7 @@ def test_sampler_split_generator_trainer_chain(workdir):
         assert all(assigner.assign(s.root_node) == split for s in recs)
     assert sorted(sum(roots.values(), [])) == [i for i in range(16) if i not in (14, 15)]  # each labeled sample once
     assert all(roots[s] for s in ("train", "val", "test"))
-    torch.manual_seed(int(os.environ.get("GIGL_TEST_SEED", "1")))  # (fixed initialisation: nothing in the trainer seeds it)
+    seed_trainer()  # (ONE shared seed for every trainer test: tests/conftest.py; the trainer seeds nothing itself)
     tr = Trainer()
     metrics = tr.run("job", cfg_uri, None, uri_base=workdir)
     hist = tr.training_process.trainer.history

@@ -8,6 +8,8 @@ import shutil
 import numpy as np
 import pytest
 import torch
+
+from conftest import seed_trainer
 import yaml
 
 from gigl_amd.config import GbmlConfigPbWrapper
@@ -93,7 +95,7 @@ def test_simple_hgn_trains_through_the_plugin(workdir):
                                                    "evalMetricsUri": "out/hetero_shgn/eval_metrics.json"}
     uri = "configs/hetero_shgn_gbml_config.yaml"
     yaml.safe_dump(doc, open(os.path.join(workdir, uri), "w"))
-    torch.manual_seed(int(os.environ.get("GIGL_TEST_SEED", "4")))  # (the trainer seeds nothing, like the reference's: the initialisation is the process RNG's;
+    seed_trainer()  # (ONE shared seed for every trainer test: tests/conftest.py; the trainer seeds nothing itself)
     # three validation losses of a 6-root graph are noisy, so the falling-loss check is made on a fixed initialisation)
     tr = Trainer()
     metrics = tr.run("job", uri, None, uri_base=workdir)
@@ -107,7 +109,7 @@ def test_simple_hgn_trains_through_the_plugin(workdir):
 def test_trainer_then_inferencer_on_the_typed_graph(workdir):
     from gigl_amd.inferencer import Inferencer
     from gigl_amd.trainer import Trainer
-    torch.manual_seed(int(os.environ.get("GIGL_TEST_SEED", "0")))  # (fixed initialisation for the falling-loss check, as above)
+    seed_trainer()  # (ONE shared seed for every trainer test: tests/conftest.py; the trainer seeds nothing itself)
     tr = Trainer()
     metrics = tr.run("job", CFG, None, uri_base=workdir)
     assert np.isfinite(metrics.metrics["loss"].value) and 0.0 < metrics.metrics["mrr"].value <= 1.0

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import seed_trainer
+
 from gigl_amd import wire
 from gigl_amd.config import GbmlConfigPbWrapper, tfrecord_files
 
@@ -92,7 +94,7 @@ def test_trainer_then_inferencer(workdir):
     from gigl_amd.inferencer import Inferencer
     from gigl_amd.trainer import Trainer
     from oracle import gnn_ref
-    torch.manual_seed(int(os.environ.get("GIGL_TEST_SEED", "1")))  # (fixed initialisation: nothing in the trainer seeds it)
+    seed_trainer()  # (ONE shared seed for every trainer test: tests/conftest.py; the trainer seeds nothing itself)
     tr = Trainer()
     metrics = tr.run("job", CFG, None, uri_base=workdir)
     names = set(metrics.metrics)
@@ -143,7 +145,7 @@ def test_sampler_split_generator_trainer_chain(workdir):
             assert all(assigner.assign(e)[0] == split for e in s.pos_edges)
         assert tfrecord_files(cfg.dataset_split_uri(split)) == files["main"][split]
         assert len([r for f in files["random_negative/user"][split] for r in wire.read_tfrecords(f)]) == 27
-    torch.manual_seed(int(os.environ.get("GIGL_TEST_SEED", "1")))  # (fixed initialisation: nothing in the trainer seeds it)
+    seed_trainer()  # (ONE shared seed for every trainer test: tests/conftest.py; the trainer seeds nothing itself)
     tr = Trainer()
     metrics = tr.run("job", CFG, None, uri_base=workdir)
     assert np.isfinite(metrics.metrics["loss"].value) and 0.0 <= metrics.metrics["mrr"].value <= 1.0
@@ -283,7 +285,7 @@ def test_trainer_with_gat_encoder(workdir):
         v["embeddingsPath"] = "out/nablp_gat_train/embeddings.jsonl"
     cfg_uri = "configs/nablp_gat_train_gbml_config.yaml"
     yaml.safe_dump(doc, open(os.path.join(workdir, cfg_uri), "w"))
-    torch.manual_seed(int(os.environ.get("GIGL_TEST_SEED", "1")))  # (fixed initialisation: nothing in the trainer seeds it)
+    seed_trainer()  # (ONE shared seed for every trainer test: tests/conftest.py; the trainer seeds nothing itself)
     tr = Trainer()
     metrics = tr.run("job", cfg_uri, None, uri_base=workdir)
     assert np.isfinite(metrics.metrics["loss"].value) and 0.0 < metrics.metrics["mrr"].value <= 1.0
@@ -320,7 +322,7 @@ def test_trainer_with_gin_and_transformer_encoders(workdir, cls, extra, key):
         v["embeddingsPath"] = f"out/nablp_{tag}_train/embeddings.jsonl"
     cfg_uri = f"configs/nablp_{tag}_train_gbml_config.yaml"
     yaml.safe_dump(doc, open(os.path.join(workdir, cfg_uri), "w"))
-    torch.manual_seed(int(os.environ.get("GIGL_TEST_SEED", "1")))  # (fixed initialisation: nothing in the trainer seeds it)
+    seed_trainer()  # (ONE shared seed for every trainer test: tests/conftest.py; the trainer seeds nothing itself)
     tr = Trainer()
     metrics = tr.run("job", cfg_uri, None, uri_base=workdir)
     assert np.isfinite(metrics.metrics["loss"].value) and 0.0 < metrics.metrics["mrr"].value <= 1.0
@@ -346,7 +348,7 @@ def test_trainer_with_margin_and_softmax_tasks(workdir, task):
     doc["sharedConfig"]["trainedModelMetadata"]["evalMetricsUri"] = f"out/nablp_{task}/eval_metrics.json"
     cfg_uri = f"configs/nablp_{task}_gbml_config.yaml"
     yaml.safe_dump(doc, open(os.path.join(workdir, cfg_uri), "w"))
-    torch.manual_seed(int(os.environ.get("GIGL_TEST_SEED", "1")))  # (fixed initialisation: nothing in the trainer seeds it)
+    seed_trainer()  # (ONE shared seed for every trainer test: tests/conftest.py; the trainer seeds nothing itself)
     tr = Trainer()
     metrics = tr.run("job", cfg_uri, None, uri_base=workdir)
     spec = tr.training_process.trainer
