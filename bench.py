@@ -2660,7 +2660,7 @@ def run_cpu_gat_lp_baseline(eng, model, anchors, negs, fanouts, heads, L, budget
         a_h, p_h = a.cpu().numpy().view(np.uint32), pos.reshape(-1).cpu().numpy().view(np.uint32)
         ng = negs[steps].cpu().numpy().view(np.uint32)
         t0 = time.perf_counter()
-        um, cm, eim = encode(np.concatenate([a_h, p_h]))
+        um, cm, eim = encode(np.concatenate([a_h, p_h[p_h != 0xFFFFFFFF]]))  # (an anchor without an out-edge has no positive)
         un, cn, ein = encode(ng)
         t_used += time.perf_counter() - t0
         xm, xn = fetch(um), fetch(un)
@@ -2669,7 +2669,7 @@ def run_cpu_gat_lp_baseline(eng, model, anchors, negs, fanouts, heads, L, budget
         en = forward(xn, ein)[torch.from_numpy(un["root_local"].astype(np.int64)).clamp(min=0)]
         B = a_h.size
         scores = em[:B] @ torch.cat([em[B:], en]).T / 0.07
-        _ = (torch.logsumexp(scores, dim=1) - scores.diagonal()).sum()
+        _ = torch.logsumexp(scores, dim=1).sum()
         t_used += time.perf_counter() - t0
         edges += units(um, cm) + units(un, cn)
         steps += 1
