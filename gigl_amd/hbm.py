@@ -108,6 +108,28 @@ class HbmTrainBatch:
         return [Node(type="node", id=int(v)) for v in self.root_ids.tolist()]
 
 
+@dataclass
+class HbmNablpBatch:
+    """a link-prediction training batch sampled in HBM: what `infer_task_inputs` reads from a collated
+    NodeAnchorBasedLinkPredictionBatch (node_anchor_based_link_prediction_data_loader.py:33-60) without the samples
+    ever becoming TFRecords.  The batch graph is the union of the k-hop trees of every anchor AND of every sampled
+    positive — the node / edge set the TFRecord route's collate builds from the records' merged neighbourhoods
+    (NodeAnchorBasedLinkPredictionTask.scala:146-312) — rooted at [anchor, pos_1 .. pos_P] per anchor; a positive
+    the anchor does not have repeats the anchor (a repeated root adds nothing to the union graph)."""
+    graph: "object"                # HipBatch over the n_anchors * trees_per_anchor roots
+    n_anchors: int
+    trees_per_anchor: int          # 1 + numPositiveSamples
+    anchor_ids: np.ndarray         # int64 [n_anchors] host
+    n_pos: np.ndarray              # int64 [n_anchors] host: sampled positives per anchor (>= 1)
+    pos_rows: torch.Tensor         # int64 [sum(n_pos)] device: positions of the real positives in the root list, anchor-major
+    root_ids: torch.Tensor         # int64 [n_anchors * trees_per_anchor] device: global ids of the root list
+
+    @property
+    def root_nodes(self):
+        from .batches import Node
+        return [Node(type="node", id=int(v)) for v in self.anchor_ids.tolist()]
+
+
 class ResidentGraph:
     """the job's graph + node features in HBM, with the plans that run batches over it.  One per process (rank)."""
 
@@ -406,6 +428,62 @@ class ResidentGraph:
             yield HbmTrainBatch(graph=hb, root_node_indices=hb.root_local.long(),
                                 root_node_labels=torch.from_numpy(labels[c * batch_size: c * batch_size + chunk.size]),
                                 root_ids=chunk)
+
+    # ---- link-prediction training batches (the homogeneous NABLP trainer's in-HBM route)
+    def nablp_anchor_order(self, num_positives: int) -> Tuple[np.ndarray, np.ndarray]:
+        """(anchors, positives per anchor) of the main samples in the order the TFRecord route reads them: the sampler
+        writes one NodeAnchorBasedLinkPredictionSample per node with at least one sampled positive and a neighbourhood of
+        its own, in ascending id order, capped by numMaxTrainingSamplesToOutput (subgraph_sampler._run_nablp;
+        NodeAnchorBasedLinkPredictionTask.scala:186-194), into part files that are read in permuted order"""
+        ids = self.node_ids
+        cnt = np.zeros(self.n, dtype=np.int64)
+        step = 1 << 20
+        for lo in range(0, ids.size, step):  # (one pass over the nodes at setup; the positives themselves are re-drawn per batch)
+            chunk = ids[lo:lo + step]
+            r32 = torch.from_numpy(chunk.astype(np.uint32).view(np.int32)).to(self.device)
+            _, c = self.engine.sample_positives(r32, num_positives, sampling_seed=self.seed)
+            cnt[chunk] = c.cpu().numpy()
+        emit = ids[(cnt[ids] > 0) & self.has_in_edge[ids]]
+        limit = self.cfg.num_max_training_samples_to_output
+        if limit > 0:
+            emit = emit[:limit]
+        order = planned_root_order(emit, self.cfg.nablp_tfrecord_uri_prefix)
+        return order, cnt[order]
+
+    def nablp_batches(self, ids: np.ndarray, n_pos: np.ndarray, batch_size: int, num_positives: int,
+                      loop: bool = False) -> Iterator[HbmNablpBatch]:
+        """consecutive batches of `batch_size` anchors (`ids`, with `n_pos` positives each) sampled in HBM"""
+        from itertools import cycle
+        P, T = int(num_positives), 1 + int(num_positives)
+        spans = [(lo, min(lo + batch_size, ids.size)) for lo in range(0, ids.size, batch_size)]
+        ar = torch.arange(P, device=self.device).view(1, P)
+        for lo, hi in (cycle(spans) if (loop and spans) else spans):
+            chunk, k = ids[lo:hi], n_pos[lo:hi]
+            anchors = torch.from_numpy(chunk.astype(np.uint32).view(np.int32)).to(self.device)
+            pos, cnt = self.engine.sample_positives(anchors, P, sampling_seed=self.seed)
+            a2 = anchors.view(-1, 1)
+            grouped = torch.where(ar < cnt.view(-1, 1), pos.view(-1, P), a2.expand(-1, P))
+            roots = torch.cat([a2, grouped], dim=1).reshape(-1).contiguous()
+            hb = self.hip_batch(roots, train=True)
+            rows = np.concatenate([i * T + 1 + np.arange(int(c)) for i, c in enumerate(k.tolist())]) if k.size else \
+                np.zeros(0, dtype=np.int64)
+            yield HbmNablpBatch(graph=hb, n_anchors=int(chunk.size), trees_per_anchor=T, anchor_ids=chunk,
+                                n_pos=np.asarray(k, dtype=np.int64),
+                                pos_rows=torch.from_numpy(rows.astype(np.int64)).to(self.device),
+                                root_ids=roots.to(torch.int64) & 0xFFFFFFFF)
+
+    def random_negative_batches(self, batch_size: int) -> Iterator[HbmTrainBatch]:
+        """the random-negative stream of a link-prediction job sampled in HBM: every node's RootedNodeNeighborhood in
+        the order the TFRecord route reads the sampler's files, `batch_size` roots per batch (the last batch of a pass
+        is short), looping forever like the reference's LoopyIterableDataset (tf_records_iterable_dataset.py:85-109)"""
+        order = self.inference_root_order()
+        while order.size:
+            for lo in range(0, order.size, batch_size):
+                chunk = order[lo:lo + batch_size]
+                r32 = torch.from_numpy(chunk.astype(np.uint32).view(np.int32)).to(self.device)
+                hb = self.hip_batch(r32, train=True)
+                yield HbmTrainBatch(graph=hb, root_node_indices=hb.root_local.long(), root_node_labels=None,
+                                    root_ids=chunk)
 
     def close(self) -> None:
         for p in self._plans.values():

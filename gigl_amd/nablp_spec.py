@@ -103,6 +103,9 @@ def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrap
     if isinstance(main_batch, HeteroNodeAnchorBasedLinkPredictionBatch):
         return _infer_task_inputs_hetero(model, gbml_config_pb_wrapper, main_batch, random_neg_batch, should_eval, device,
                                          need_batch_scores)
+    from .hbm import HbmNablpBatch
+    if isinstance(main_batch, HbmNablpBatch):
+        return _infer_task_inputs_hbm(model, main_batch, random_neg_batch, should_eval, device, need_batch_scores)
     inner = model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
     decoder = inner.decode
     cet = 0
@@ -156,6 +159,48 @@ def infer_task_inputs(model: nn.Module, gbml_config_pb_wrapper: GbmlConfigPbWrap
         batch_embeddings=BatchEmbeddings(query_embeddings=query, repeated_query_embeddings={cet: rep_query},
                                          pos_embeddings={cet: pos_emb}, hard_neg_embeddings={cet: neg_emb},
                                          random_neg_embeddings={0: rn_root_emb}),
+        batch_scores=batch_scores, batch_combined_scores={cet: combined})
+
+
+def _infer_task_inputs_hbm(model: nn.Module, main_batch, random_neg_batch, should_eval: bool, device: torch.device,
+                           need_batch_scores: bool = False) -> NodeAnchorBasedLinkPredictionTaskInputs:
+    """infer_task_inputs over batches sampled in HBM (hbm.HbmNablpBatch + the random-negative HbmTrainBatch): the same
+    embeddings, scores and ids as over the collated TFRecord batches of the same anchors — the batch graphs hold the
+    same nodes and edges — with every index already on the device: no per-root host loop, no id dictionaries.  Hard
+    negatives come from user-defined label edges only, which take the TFRecord route."""
+    inner = model.module if isinstance(model, torch.nn.parallel.DistributedDataParallel) else model
+    decoder = inner.decode
+    cet = 0
+    hb = main_batch.graph
+    roots_emb = model(hb)[hb.root_local.long()]                      # [B * (1 + P), d], anchor-major
+    d = int(roots_emb.shape[1])
+    query = roots_emb.view(main_batch.n_anchors, main_batch.trees_per_anchor, d)[:, 0]
+    pos_emb = roots_emb.index_select(0, main_batch.pos_rows)
+    rn_emb = model(random_neg_batch.graph)[random_neg_batch.root_node_indices]
+    empty = torch.zeros((0,), dtype=torch.float32, device=device)
+    neg_emb = torch.zeros((0, d), device=device)
+    want_scores = should_eval or need_batch_scores
+    rn_scores = decoder(query, rn_emb) if (want_scores and rn_emb.numel()) else empty
+    n_pos = main_batch.n_pos.tolist()
+    batch_scores: List[Dict[int, BatchScores]] = []
+    if want_scores:
+        batch_scores = _per_root_scores(decoder, query, pos_emb, neg_emb, n_pos, [0] * len(n_pos), rn_scores, cet, empty)
+    rep_t = torch.from_numpy(main_batch.n_pos).to(device)
+    rep_query = query.repeat_interleave(rep_t, dim=0, output_size=int(main_batch.pos_rows.numel()))
+    cand = torch.cat((pos_emb, rn_emb.reshape(-1, d)))
+    anchor_ids = main_batch.root_ids.view(main_batch.n_anchors, main_batch.trees_per_anchor)[:, 0]
+    combined = BatchCombinedScores(
+        repeated_candidate_scores=decoder(rep_query, cand) if rep_query.numel() else empty,
+        positive_ids=main_batch.root_ids.index_select(0, main_batch.pos_rows),
+        hard_neg_ids=torch.zeros((0,), dtype=torch.int64, device=device),
+        random_neg_ids=torch.from_numpy(np.asarray(random_neg_batch.root_ids, dtype=np.int64)).to(device),
+        repeated_query_ids=anchor_ids.repeat_interleave(rep_t, output_size=int(main_batch.pos_rows.numel())),
+        num_unique_query_ids=int(main_batch.n_anchors))
+    return NodeAnchorBasedLinkPredictionTaskInputs(
+        main_batch=main_batch, random_neg_batch=random_neg_batch,
+        batch_embeddings=BatchEmbeddings(query_embeddings=query, repeated_query_embeddings={cet: rep_query},
+                                         pos_embeddings={cet: pos_emb}, hard_neg_embeddings={cet: neg_emb},
+                                         random_neg_embeddings={0: rn_emb}),
         batch_scores=batch_scores, batch_combined_scores={cet: combined})
 
 
@@ -467,6 +512,9 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         self._engine = None
         self._cfg: Optional[GbmlConfigPbWrapper] = None
         self.history: List[Dict[str, Any]] = []
+        self._kwargs = {k: str(v) for k, v in kwargs.items()}
+        self._resident = None       # gigl_amd.hbm.ResidentGraph of the in-HBM route
+        self._hbm_anchors = None    # {split: (anchor ids, positives per anchor)}; {} = the TFRecord route was chosen
 
     @property
     def gbml_config_pb_wrapper(self) -> GbmlConfigPbWrapper:
@@ -543,6 +591,7 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         if self._engine is None:
             from .engine import HipEngine
             self._engine = HipEngine(device.index or 0)
+        self._device = device
         inner = self.model.module if hasattr(self.model, "module") else self.model
         inner.encoder.engine = self._engine
         inner.decoder.engine = self._engine
@@ -553,8 +602,60 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         self._lr_scheduler = self._lr_scheduler_cls(self._optimizer, **self._lr_scheduler_kwargs)
         self.model.train()
 
+    # ---- data: the in-HBM route (gigl_amd/hbm.py) — main and random-negative batches sampled in HBM
+    def _hbm_split(self, cfg: GbmlConfigPbWrapper):
+        """-> {split: (anchors, positives per anchor)} when this job's training batches can be sampled in HBM from the
+        resident graph, else None (the TFRecord route below).  In HBM: a homogeneous graph whose tables are readable,
+        one process, a GraphSAGE encoder with an autograd forward over HipBatches, positives drawn from the graph's own
+        edges (user-defined label edges: TFRecord route) and NO split-generator output — a transductive link split
+        rewrites every sample's neighbourhood per split (message-passing vs supervision edges), which only the split
+        generator's files carry.  The anchors of a split and their order are those of the TFRecord route without split
+        files: the sampler's main samples in file order, root id % 10 (0-7 train, 8 val, 9 test), fewer than 100
+        samples whole in every split."""
+        if self._hbm_anchors is not None:
+            return self._hbm_anchors or None
+        self._hbm_anchors = {}
+        from .hbm import ResidentGraph, encoder_trains_over_hip_batches, route_of
+        device = getattr(self, "_device", None)
+        inner = self.model.module if hasattr(self.model, "module") else self.model
+        em = cfg.preprocessed_metadata.edges[0]
+        if cfg.is_heterogeneous or device is None or device.type != "cuda" or _rank_world()[1] > 1 or \
+                route_of(cfg, self._kwargs) != "hbm" or not encoder_trains_over_hip_batches(inner.encoder) or \
+                em.positive_edge_info is not None or em.negative_edge_info is not None:
+            return None
+        if any((cfg.dataset_split_uri(sp) and tfrecord_files(cfg.dataset_split_uri(sp))) for sp in ("train", "val", "test")):
+            return None
+        try:
+            res = ResidentGraph(cfg, device, sharded=False, need_out_graph=True)
+        except NotImplementedError:
+            return None
+        self._resident = res
+        # one engine for the job: the encoder / decoder run on the resident graph's engine
+        if self._engine is not None and self._engine is not res.engine:
+            self._engine.close()
+        self._engine = res.engine
+        inner.encoder.engine = inner.decoder.engine = res.engine
+        ids, n_pos = res.nablp_anchor_order(cfg.num_positive_samples)
+        for sp, want in (("train", range(0, 8)), ("val", (8,)), ("test", (9,))):
+            m = np.isin(ids % 10, list(want)) if ids.size >= 100 else np.ones(ids.size, dtype=bool)
+            self._hbm_anchors[sp] = (ids[m], n_pos[m])
+        return self._hbm_anchors
+
+    def close(self) -> None:
+        if self._resident is not None:
+            self._resident.close()  # (its engine is the spec's engine on this route)
+            self._resident = None
+            self._engine = None
+        self._hbm_anchors = None
+
     # ---- data (dataset/dataloader roles of NodeAnchorBasedLinkPredictionDatasetDataloaders)
     def _main_batches(self, cfg: GbmlConfigPbWrapper, split: str, loop: bool):
+        hbm = self._hbm_split(cfg)
+        if hbm is not None:
+            ids, n_pos = hbm[split]
+            yield from self._resident.nablp_batches(ids, n_pos, self.main_sample_batch_size, cfg.num_positive_samples,
+                                                    loop=loop)
+            return
         rank, world = _rank_world()
         uri = cfg.dataset_split_uri(split)
         if cfg.is_heterogeneous:
@@ -591,6 +692,9 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
 
     def _random_negative_batches(self, cfg: GbmlConfigPbWrapper, batch_size: int, split: str = "train"):
         """always looped, like the reference's LoopyIterableDataset for random negatives"""
+        if self._hbm_split(cfg) is not None:
+            yield from self._resident.random_negative_batches(batch_size)
+            return
         rank, world = _rank_world()
         split_uris = cfg.random_negative_split_uris(split)
         if cfg.is_heterogeneous:  # random negatives of the supervision edge type's destination node type

@@ -56,7 +56,9 @@ def _cpu_reference_loss(sd, main_batch, rn_batch, temperature):
 def test_training_step_matches_cpu_reference(workdir):
     from gigl_amd.nablp_spec import HipNodeAnchorLinkPredictionSpec, infer_task_inputs
     cfg = GbmlConfigPbWrapper.from_uri(CFG, uri_base=workdir)
-    spec = HipNodeAnchorLinkPredictionSpec(**cfg.trainer_args)
+    # (collated TFRecord batches: the CPU restatement reads their graphs; the in-HBM batches are checked against these
+    # in test_in_hbm_link_prediction_batches_equal_the_collated_records)
+    spec = HipNodeAnchorLinkPredictionSpec(**cfg.trainer_args, data_route="tfrecord")
     torch.manual_seed(3)
     spec.init_model(cfg)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in spec.model.state_dict().items()}
@@ -126,6 +128,103 @@ def test_trainer_then_inferencer(workdir):
             want[r.id] = o[i].numpy()
     for row in rows:
         np.testing.assert_allclose(np.array(row["emb"], np.float32), want[row["node_id"]], rtol=1e-5, atol=1e-5)
+
+
+def test_trainer_in_hbm_route_matches_the_tfrecord_route(workdir, tmp_path):
+    """the link-prediction trainer over main / random-negative batches SAMPLED IN HBM (hbm.HbmNablpBatch: no sample
+    ever becomes a TFRecord) against the same job over the sampler's files: same anchors per batch, same positives, the
+    same batch graphs as node / edge sets -> the same loss history, validation metrics, trained weights and test
+    metrics (fp32 summation order differs: 1e-4)"""
+    from gigl_amd.trainer import Trainer
+    base = str(tmp_path / "job")
+    shutil.copytree(workdir, base)
+    shutil.rmtree(os.path.join(base, "out", "nablp", "split"), ignore_errors=True)  # (no split-generator output)
+    runs = {}
+    old = os.environ.get("GIGL_AMD_ROUTE")
+    try:
+        for route in ("tfrecord", "hbm"):
+            os.environ["GIGL_AMD_ROUTE"] = route
+            seed_trainer()
+            tr = Trainer()
+            metrics = tr.run("job", CFG, None, uri_base=base)
+            assert tr.training_process.route == route
+            cfg = GbmlConfigPbWrapper.from_uri(CFG, uri_base=base)
+            runs[route] = (tr.training_process.trainer.history, torch.load(cfg.trained_model_uri, map_location="cpu"),
+                           {k: m.value for k, m in metrics.metrics.items()})
+    finally:
+        if old is None:
+            os.environ.pop("GIGL_AMD_ROUTE", None)
+        else:
+            os.environ["GIGL_AMD_ROUTE"] = old
+    (h_t, sd_t, m_t), (h_h, sd_h, m_h) = runs["tfrecord"], runs["hbm"]
+    assert len(h_t) == len(h_h) >= 4
+    np.testing.assert_allclose([h["loss"] for h in h_h], [h["loss"] for h in h_t], rtol=1e-4)
+    for a, b in zip(h_h, h_t):
+        assert ("val" in a) == ("val" in b)
+        if "val" in a:
+            for k in a["val"]:
+                np.testing.assert_allclose(a["val"][k], b["val"][k], rtol=1e-4, atol=1e-6)
+    assert sd_t.keys() == sd_h.keys()
+    for k in sd_t:
+        np.testing.assert_allclose(sd_h[k].numpy(), sd_t[k].numpy(), rtol=1e-3, atol=1e-5)
+    assert m_t.keys() == m_h.keys()
+    for k in m_t:
+        np.testing.assert_allclose(m_h[k], m_t[k], rtol=1e-4, atol=1e-6)
+
+
+def test_in_hbm_link_prediction_batches_equal_the_collated_records(workdir, tmp_path):
+    """batch by batch: anchors, positives per anchor and random-negative roots of the in-HBM generators equal those of
+    the collated TFRecord batches, and so do the root / positive embeddings and the loss of one step"""
+    from gigl_amd.nablp_spec import HipNodeAnchorLinkPredictionSpec, infer_task_inputs
+    base = str(tmp_path / "job")
+    shutil.copytree(workdir, base)
+    shutil.rmtree(os.path.join(base, "out", "nablp", "split"), ignore_errors=True)
+    cfg = GbmlConfigPbWrapper.from_uri(CFG, uri_base=base)
+    dev = torch.device("cuda", 0)
+    specs = {}
+    for route in ("tfrecord", "hbm"):
+        spec = HipNodeAnchorLinkPredictionSpec(**cfg.trainer_args, data_route=route)
+        torch.manual_seed(3)
+        spec.init_model(cfg)
+        spec.model = spec.model.to(dev)
+        spec._ensure_engine(dev)
+        spec.model.train()
+        specs[route] = spec
+    try:
+        mains = {r: list(specs[r]._main_batches(cfg, "train", loop=False)) for r in specs}
+        assert len(mains["hbm"]) == len(mains["tfrecord"]) >= 2 and specs["hbm"]._resident is not None
+        rns = {r: specs[r]._random_negative_batches(cfg, 6) for r in specs}
+        for mb_h, mb_t in zip(mains["hbm"], mains["tfrecord"]):
+            l2g = mb_t.condensed_node_type_to_subgraph_id_to_global_node_id[0]
+            roots_t = [l2g[i] for i in mb_t.root_node_indices.tolist()]
+            assert mb_h.anchor_ids.tolist() == roots_t
+            pos_map = mb_t.pos_supervision_edge_data[0].root_node_to_target_node_id
+            pos_t = [l2g[p] for r in mb_t.root_node_indices.tolist() for p in pos_map[r].tolist()]
+            assert mb_h.root_ids.index_select(0, mb_h.pos_rows).tolist() == pos_t
+            rn_h, rn_t = next(rns["hbm"]), next(rns["tfrecord"])
+            assert rn_h.root_ids.tolist() == [n.id for n in rn_t.root_nodes]
+            ti_h = infer_task_inputs(specs["hbm"].model, cfg, mb_h, rn_h, should_eval=False, device=dev)
+            ti_t = infer_task_inputs(specs["tfrecord"].model, cfg, mb_t, rn_t, should_eval=False, device=dev)
+            for name in ("query_embeddings",):
+                np.testing.assert_allclose(getattr(ti_h.batch_embeddings, name).detach().cpu().numpy(),
+                                           getattr(ti_t.batch_embeddings, name).detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+            np.testing.assert_allclose(ti_h.batch_combined_scores[0].repeated_candidate_scores.detach().cpu().numpy(),
+                                       ti_t.batch_combined_scores[0].repeated_candidate_scores.detach().cpu().numpy(),
+                                       rtol=1e-5, atol=1e-5)
+            for f in ("positive_ids", "random_neg_ids", "repeated_query_ids"):
+                assert getattr(ti_h.batch_combined_scores[0], f).tolist() == getattr(ti_t.batch_combined_scores[0], f).tolist()
+            loss_h, _ = specs["hbm"].tasks.calculate_losses(ti_h, cfg, should_eval=False, device=dev)
+            loss_t, _ = specs["tfrecord"].tasks.calculate_losses(ti_t, cfg, should_eval=False, device=dev)
+            np.testing.assert_allclose(float(loss_h), float(loss_t), rtol=1e-5)
+            for s_, l_ in ((specs["hbm"], loss_h), (specs["tfrecord"], loss_t)):
+                s_.model.zero_grad()
+                l_.backward()
+            for (n1, p1), (n2, p2) in zip(specs["hbm"].model.named_parameters(), specs["tfrecord"].model.named_parameters()):
+                assert n1 == n2
+                np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    finally:
+        for spec in specs.values():
+            spec.close()
 
 
 def test_sampler_split_generator_trainer_chain(workdir):
