@@ -81,7 +81,7 @@ PMC_KERNELS = {
 _LIVE_PMC = {}  # workload-shape key -> summary collected by THIS run (collect_live_pmc)
 
 
-def collect_live_pmc(extra_args, timeout_s: float = 420.0):
+def collect_live_pmc(extra_args, timeout_s: float = 420.0, env_extra=None):
     """HBM traffic per kernel measured by THIS run: the four rocprofv3 passes of scripts/gpu_pmc.sh (FETCH_SIZE and
     WRITE_SIZE in separate passes, --kernel-trace only, each over the known-byte calibration launches and over a short
     single-stream eager --timed-only run of this same workload) as child processes once the timed region is over, folded
@@ -94,7 +94,7 @@ def collect_live_pmc(extra_args, timeout_s: float = 420.0):
     tag = f"live{os.getpid()}"
     out_root = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_root, exist_ok=True)
-    env = dict(os.environ, TMPDIR="/tmp", GIGL_BENCH_CHILD="1")
+    env = dict(os.environ, TMPDIR="/tmp", GIGL_BENCH_CHILD="1", **(env_extra or {}))
     t0 = time.time()
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -126,6 +126,24 @@ def collect_live_pmc(extra_args, timeout_s: float = 420.0):
     finally:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             shutil.rmtree(os.path.join(out_root, f"pmc_{tag}_{ctr}"), ignore_errors=True)
+
+
+def step_traffic_of(doc, steps_executed: int, prefixes=None, min_calls=None):
+    """HBM bytes per step from a live PMC summary of a child run that executed `steps_executed` steps of the path (warm-up
+    included): sum over the LIBRARY's kernels launched at least `min_calls` times (default: once per step) — setup
+    kernels (graph build, threshold table) run a handful of times and drop out, torch / rocPRIM / runtime kernels
+    (synthetic tables, copies of a few bytes) are left out by name — of bytes per launch x launches, / steps.
+    `prefixes`: only kernels whose name starts with one of them.  -> (bytes per step, {kernel: bytes per step})"""
+    per = {}
+    need = steps_executed if min_calls is None else min_calls
+    for name, e in doc.get("kernels", {}).items():
+        calls = e.get("FETCH_SIZE_calls", 0)
+        if calls < need or (prefixes is not None and not any(name.startswith(p) for p in prefixes)):
+            continue
+        if prefixes is None and any(t in name for t in ("at::", "rocprim", "hiprand", "__amd_rocclr", "elementwise")):
+            continue
+        per[name] = e["hbm_bytes_per_launch"] * calls / steps_executed
+    return sum(per.values()), per
 
 
 def pmc_traffic(kernel_id: str, batches_per_call: int, workload: str = "products", projected: bool = False):
@@ -1613,7 +1631,10 @@ def run_train(args, rank, world, local_rank):
                                          sum(per_layer[1:]) if L > 1 else per_layer[0] * 0]))
         return loss
 
-    for i in range(W):
+    # (a counter-collection child of the library-plan line runs the plan's steps only: every kernel it counts is the plan's)
+    plan_only_child = bool(args.timed_only and not os.environ.get("GIGL_BENCH_TRAIN_EAGER") and
+                           not os.environ.get("GIGL_BENCH_TRAIN_AUTOGRAD"))
+    for i in range(0 if plan_only_child else W):
         step(i)
     st.synchronize()
     # the step replayed as ONE HIP graph (gigl_amd.hbm.GraphedTrainStep: what the trainer's in-HBM route runs): the same
@@ -1664,7 +1685,8 @@ def run_train(args, rank, world, local_rank):
             step(i)
         st.synchronize()
         print(json.dumps({"timed_only": True, "train": True, "steps": K, "workload": wl_name, "batches_per_call": 1,
-                          "streams": 1, "ms_per_step": (time.perf_counter() - t1) / K * 1e3}))
+                          "streams": 1, "ms_per_step": (time.perf_counter() - t1) / K * 1e3,
+                          "steps_executed": K + (min(W, 4) if lib_plan is not None else (0 if plan_only_child else W))}))
         eng.close()
         return
     # ---- untimed: exact counts of the timed batches, then every library kernel group's own time (HIP events)
@@ -1728,6 +1750,32 @@ def run_train(args, rank, world, local_rank):
                         "bound by launch / host overhead between kernels, not by a kernel (library_kernel_share_of_step); "
                         "the backward scatter (gather_bwd, fp32 atomics) has its own HBM line in by_kernel",
                 "by_kernel": by_kernel}
+    # ---- HBM traffic of the step by the counters: rocprofv3 PMC passes of a child run of this same command (eager
+    # launches of the library plan's kernels: GIGL_TRAIN_PLAN_EAGER), all kernels launched at least once per step
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if rank == 0 and world == 1 and not args.no_live_pmc and not under_profiler and not os.environ.get("GIGL_BENCH_CHILD"):
+        passthrough = ["--train", "--workload", args.workload, "--batch", str(B), "--fanouts",
+                       ",".join(str(f) for f in fanouts), "--mode", args.mode] + (["--small"] if args.small else [])
+        torch.cuda.synchronize()
+        doc_, note_ = collect_live_pmc(passthrough, env_extra={"GIGL_TRAIN_PLAN_EAGER": "1"})
+        if doc_ is not None:
+            n_exec = int(doc_.get("steps_executed") or 68)  # (the child's timed steps + the plan's warm-up steps)
+            by_step, per_k = step_traffic_of(doc_, n_exec)
+            roofline["step"] = {"bound": "hbm", "traffic_bytes_per_step": round(by_step),
+                                "achieved": round(by_step / (step_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(by_step / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a child run of this command "
+                                          f"({n_exec} steps, eager launches), kernels launched at least once per step",
+                                "by_kernel_bytes_per_step": {k: round(v) for k, v in sorted(per_k.items(), key=lambda kv: -kv[1])[:12]}}
+            dom_pfx = {"linear": ["linear_split_kernel", "linear_weight_grad"], "gather_mean": ["gather_mean_kernel"],
+                       "gather_bwd": ["gather_mean_backward_kernel", "gather_reduce_backward"],
+                       "expand": ["plan_rows_kernel", "expand_rows_kernel"]}.get(dominant)
+            if dom_pfx:
+                roofline["traffic"] = round(step_traffic_of(doc_, n_exec, dom_pfx)[0])
+                roofline["traffic_unit"] = "HBM bytes per step of the dominant group's kernels (same source as roofline.step)"
+            roofline["live_pmc"] = "collected"
+        else:
+            roofline["live_pmc"] = note_
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_train_baseline(eng, model, my, labels, fanouts, W, out_dim)
@@ -2501,6 +2549,17 @@ def run_gat_lp(args, rank, world, local_rank):
         from gigl_amd._lib import STATS_AGGREGATED, STATS_SAMPLED
         sa = stats_acc.cpu().numpy().astype(np.float64)
         per_step = np.array([sa[STATS_SAMPLED], sa[STATS_AGGREGATED]]) / pool
+    if args.timed_only:  # counter-collection child (collect_live_pmc): eager calls only, every kernel counted is the step's
+        n_calls = (max(W, G) + G - 1) // G + pool // G
+        for _ in range(8):
+            for i0 in range(0, pool, G):
+                call(i0)
+                n_calls += 1
+        st.synchronize()
+        print(json.dumps({"timed_only": True, "workload": "gat-lp", "batches_per_call": G, "streams": 1,
+                          "steps_executed": n_calls * G, "calls_executed": n_calls}))
+        eng.close()
+        return
     # The shapes are all capacities (counts stay on the device), so a call replays as a HIP graph over static input
     # rows; kept only when a replay reproduces the eager losses bit for bit, otherwise the eager driver stays.
     driver = (f"one-call GAT plans ({G} steps per call: anchors + positives, random negatives) + decoder + fused loss, "
@@ -2588,6 +2647,32 @@ def run_gat_lp(args, rank, world, local_rank):
                     "timing": "HIP events on the plans' stream over one untimed eager pass of the timed calls (one stream: "
                               "a kernel's interval is its own)",
                     "share_of_step": round(hk["ms_per_step"] / (elapsed / steps * 1e3), 3), "by_kernel": by_kernel}
+    # ---- HBM traffic by the counters: rocprofv3 PMC passes of a child run of this same command (eager calls)
+    under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+    if roofline is not None and rank == 0 and world == 1 and not args.no_live_pmc and not under_profiler and \
+            not os.environ.get("GIGL_BENCH_CHILD"):
+        passthrough = ["--workload", "gat-lp", "--batch", str(B), "--fanouts", ",".join(str(f) for f in fanouts),
+                       "--shard-scale", str(args.shard_scale)]
+        torch.cuda.synchronize()
+        doc_, note_ = collect_live_pmc(passthrough, timeout_s=600.0)
+        if doc_ is not None and doc_.get("steps_executed"):
+            n_exec, n_calls = int(doc_["steps_executed"]), int(doc_.get("calls_executed") or 1)
+            step_ms_ = elapsed / steps * 1e3
+            by_step, per_k = step_traffic_of(doc_, n_exec, min_calls=n_calls)
+            roofline["step"] = {"bound": "hbm", "traffic_bytes_per_step": round(by_step),
+                                "achieved": round(by_step / (step_ms_ * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(by_step / (step_ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of a child run of this command "
+                                          f"({n_exec} steps in {n_calls} eager calls), the library's kernels launched at least "
+                                          "once per call",
+                                "by_kernel_bytes_per_step": {k: round(v) for k, v in sorted(per_k.items(), key=lambda kv: -kv[1])[:12]}}
+            gm_bytes, _ = step_traffic_of(doc_, n_exec, ["gat_input_online_kernel", "gat_gather_fast", "gat_gather_heavy",
+                                                         "gat_alpha_fast"], min_calls=n_calls)
+            roofline["traffic"] = round(gm_bytes * pool / launches)  # per launch, like alg_bytes_per_launch
+            roofline["traffic_frac"] = round(gm_bytes / (hk["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            roofline["live_pmc"] = "collected"
+        else:
+            roofline["live_pmc"] = note_ or "child reported no step count"
     line = {
         "metric": "sampled+aggregated edges/s", "value": float(per_step.sum()) * steps / elapsed, "unit": "edges/s",
         "n_gpus": 1, "steps": steps, "warmup": W, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,

@@ -53,6 +53,7 @@ def main():
             pass
     out = {"tag": tag, "workload": shape.get("workload", "products"), "projected_input": shape.get("projected_input"),
            "batches_per_call": shape.get("batches_per_call"), "streams": shape.get("streams"),
+           "steps_executed": shape.get("steps_executed"), "calls_executed": shape.get("calls_executed"),
            "counter_unit": "KB (rocprofv3 FETCH_SIZE / WRITE_SIZE)", "known_bytes": known,
            "calibration": {}, "kernels": {}}
     corr = {}
