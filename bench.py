@@ -2261,9 +2261,30 @@ def run_typed(args, rank, world, local_rank):
         with torch.no_grad():
             return graph, ri, model(graph, ["paper"], row_subset={"paper": ri})["paper"]
 
+    # the step as ONE library call (gigl_hgt_infer_*: plan -> typed batch graph at capacity prefixes -> HGT over composed
+    # weights -> the roots' rows; replayed as a hipGraph) — what the typed in-HBM inference route runs for HGT encoders;
+    # GIGL_BENCH_TYPED_STAGED=1 keeps the staged launches from Python
+    one_call = None
+    if not os.environ.get("GIGL_BENCH_TYPED_STAGED"):
+        from gigl_amd.models_hetero import HgtInferPlan
+        one_call = HgtInferPlan(model, smp, "paper", dag, B)
+        if os.environ.get("GIGL_BENCH_NO_GRAPH"):
+            one_call.use_graph(False)
+        roots_dev = [torch.from_numpy(p_.astype(np.uint32).view(np.int32)).to(dev) for p_ in pool]
+        for i in (0, 0, 1):  # (eager, captured, replayed) — and the same rows as the staged forward
+            got = one_call.run(roots_dev[i])
+            smp.engine.synchronize()
+            want = step(i)[2]
+            torch.cuda.synchronize()
+            assert torch.allclose(got, want, rtol=1e-4, atol=1e-4), float((got - want).abs().max())
+
     def run_pass():
         """the pool's batches as the typed in-HBM inference route runs them (Inferencer._typed_run_hbm): batch i+1's
         sampling is enqueued before the model over batch i is launched"""
+        if one_call is not None:
+            for i in range(n_batches):
+                one_call.run(roots_dev[i])
+            return
         issue = lambda i: smp.batch_graph_plan_issue(pool[i % n_batches], "paper", dag, b_max=B,
                                                      edge_type_ids=model.convs[0].edge_types_map)
         tk = issue(0)
@@ -2325,8 +2346,11 @@ def run_typed(args, rank, world, local_rank):
                     "avg_launch_us": round(gm["ms_per_step"] * n_batches / max(gm["launches"], 1) * 1e3, 2),
                     "launches": gm["launches"],
                     "library_kernel_share_of_step": round(sum(v["ms_per_step"] for v in by_kernel.values()) / step_ms, 3),
-                    "note": "the step is bound by the host issuing its ~150 small launches (typed projections per "
-                            "node / edge type over composed weights, the plan's sorts), not by a kernel",
+                    "note": ("one library call per step replayed as a hipGraph: bound by its kernels (the typed aggregate, the "
+                             "per-type projections, the plan's sorts: launch latency at ~10^5 keys), not by the host"
+                             if one_call is not None else
+                             "the step is bound by the host issuing its ~150 small launches (typed projections per "
+                             "node / edge type over composed weights, the plan's sorts), not by a kernel"),
                     "timing": "HIP events on the engine's stream over one untimed pass of the timed batches",
                     "by_kernel": by_kernel}
     cpu_baseline = None
@@ -2340,7 +2364,11 @@ def run_typed(args, rank, world, local_rank):
         "config": {"workload": f"DBLP-shaped typed graph ({na} authors x 64, {npp} papers x 128, {ne} edges per edge type), "
                                f"SamplingOp DAG [{f0},{f1}] over {B} paper roots per step through the one-call typed plan + "
                                "2-layer HGT (hidden 64, heads 2, last layer on the roots)",
-                   "entry": "HipGraphDBSampler.batch_graph_plan_issue / _finish (gigl_typed_plan_run + gigl_typed_plan_merged_csr; batch i+1 enqueued before the model over batch i) -> HGT.forward(row_subset) over composed weights",
+                   "entry": ("models_hetero.HgtInferPlan.run (gigl_hgt_infer_run: gigl_typed_plan_run + merged CSR at capacity "
+                             "prefixes + HGT over composed weights, one library call per step, replayed as one hipGraph)"
+                             if one_call is not None else
+                             "HipGraphDBSampler.batch_graph_plan_issue / _finish (gigl_typed_plan_run + gigl_typed_plan_merged_csr; "
+                             "batch i+1 enqueued before the model over batch i) -> HGT.forward(row_subset) over composed weights"),
                    "roots_per_s": B * steps / elapsed, "sampled_edges_per_step": float(np.mean(sampled)),
                    "aggregated_edges_per_step": float(np.mean(agg)),
                    "distinct_nodes_per_step": n_dst_all, "setup_s": round(setup_s, 1)},
@@ -2355,6 +2383,8 @@ def run_typed(args, rank, world, local_rank):
         line.update(value=float(v.item()), ms_per_step=float(t.item()), n_gpus=world)
     if rank == 0:
         emit(line)
+    if one_call is not None:
+        one_call.close()
     smp.close()
     if world > 1:
         dist.barrier()

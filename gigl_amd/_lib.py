@@ -56,7 +56,9 @@ SYMBOLS = [
     "gigl_dist_gat_plan_create", "gigl_dist_gat_plan_set_weights", "gigl_dist_plan_bucket_fill",
     "gigl_linear_weight_grad", "gigl_features_row_crc",
     "gigl_typed_plan_create", "gigl_typed_plan_run", "gigl_typed_plan_buffers", "gigl_typed_plan_destroy",
-    "gigl_typed_plan_merged_csr", "gigl_sage_plan_half_split",
+    "gigl_typed_plan_merged_csr", "gigl_sage_plan_half_split", "gigl_sort_distinct_u64", "gigl_sort_distinct_u32",
+    "gigl_typed_plan_merged_csr_ex", "gigl_hgt_aggregate_act", "gigl_hgt_infer_create", "gigl_hgt_infer_run",
+    "gigl_hgt_infer_set_model", "gigl_hgt_infer_use_graph", "gigl_hgt_infer_destroy",
     "gigl_sage_plan_run_part", "gigl_sage_plan_overflow_add",
     "gigl_sage_train_plan_create", "gigl_sage_train_plan_step", "gigl_sage_train_plan_loss", "gigl_sage_train_plan_destroy",
 ]
@@ -132,6 +134,24 @@ class GiglTypedCsrOut(C.Structure):
     _fields_ = [("rowptr", C.c_void_p), ("col", C.c_void_p), ("etype", C.c_void_p), ("counts", C.c_void_p),
                 ("root_rowptr", C.c_void_p), ("root_col", C.c_void_p), ("root_etype", C.c_void_p),
                 ("edges_cap", C.c_int64), ("rows_cap", C.c_int64)]
+
+
+GIGL_HGT_MAX_LAYERS = 4
+
+
+class GiglHgtLayerWeights(C.Structure):
+    _fields_ = [("wq", C.c_void_p * 16), ("bq", C.c_void_p * 16), ("wout", C.c_void_p * 16), ("bout", C.c_void_p * 16),
+                ("keep", C.c_void_p * 16), ("wk", C.c_void_p * 32), ("bk", C.c_void_p * 32), ("wv", C.c_void_p * 32),
+                ("bv", C.c_void_p * 32), ("p_rel", C.c_void_p)]
+
+
+class GiglHgtModel(C.Structure):
+    _fields_ = [("n_types", C.c_int32), ("n_slots", C.c_int32), ("n_layers", C.c_int32), ("heads", C.c_int32),
+                ("hid", C.c_int32), ("out_dim", C.c_int32), ("l2_normalize", C.c_int32), ("root_type", C.c_int32),
+                ("type_order", C.c_int32 * 16), ("slot_order", C.c_int32 * 32), ("slot_etype", C.c_int32 * 32),
+                ("feat_dim", C.c_int32 * 16), ("feat", C.c_void_p * 16), ("w_in", C.c_void_p * 16),
+                ("b_in", C.c_void_p * 16), ("layer", GiglHgtLayerWeights * GIGL_HGT_MAX_LAYERS),
+                ("w_final", C.c_void_p), ("b_final", C.c_void_p)]
 
 
 class GiglTypedOp(C.Structure):
@@ -229,6 +249,15 @@ def load() -> C.CDLL:
         "gigl_typed_plan_run": [vp, vp, i32],
         "gigl_typed_plan_buffers": [vp, P(GiglTypedPlanOut)],
         "gigl_typed_plan_destroy": [vp],
+        "gigl_typed_plan_merged_csr_ex": [vp, i32, P(i32), i32, P(i32), P(i32), i32, i32, P(GiglTypedCsrOut)],
+        "gigl_hgt_aggregate_act": [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i64, i32, vp],
+        "gigl_hgt_infer_create": [vp, vp, i32, P(GiglHgtModel), P(i32), P(i32), P(vp)],
+        "gigl_hgt_infer_run": [vp, vp, i32, vp],
+        "gigl_hgt_infer_set_model": [vp, P(GiglHgtModel)],
+        "gigl_hgt_infer_use_graph": [vp, i32],
+        "gigl_hgt_infer_destroy": [vp],
+        "gigl_sort_distinct_u64": [vp, vp, i64, i32, i32, C.c_uint64, vp, vp],
+        "gigl_sort_distinct_u32": [vp, vp, i64, i32, C.c_uint32, vp, vp],
         "gigl_typed_plan_merged_csr": [vp, i32, P(i32), i32, P(i32), P(i32), i32, P(GiglTypedCsrOut)],
         "gigl_features_destroy": [vp],
         "gigl_sample_khop": [vp, vp, vp, i32, P(i32), i32, i32, i32, P(GiglTree)],

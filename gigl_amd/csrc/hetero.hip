@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void hgt_aggregate_kernel(const float* __restr
                                                             const int32_t* __restrict__ col,
                                                             const int32_t* __restrict__ etype,
                                                             const float* __restrict__ p_rel, int64_t n_dst,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int gelu) {
   const int lane = threadIdx.x & 63;
   const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (i >= n_dst) return;
@@ -73,7 +73,14 @@ __global__ __launch_bounds__(256) void hgt_aggregate_kernel(const float* __restr
     const int c = (p * 64 + lane) * 4;
     if (c >= hd) continue;
     const float inv = s[p] > 0.f ? 1.f / s[p] : 0.f;  // a row without in-edges aggregates to 0
-    *(float4*)(out + i * hd + c) = make_float4(acc[p].x * inv, acc[p].y * inv, acc[p].z * inv, acc[p].w * inv);
+    float4 o = make_float4(acc[p].x * inv, acc[p].y * inv, acc[p].z * inv, acc[p].w * inv);
+    if (gelu) {  // the layer's activation (exact erf form: torch's F.gelu default) in the reduce's epilogue
+      o.x = 0.5f * o.x * (1.f + erff(o.x * 0.70710678118654752f));
+      o.y = 0.5f * o.y * (1.f + erff(o.y * 0.70710678118654752f));
+      o.z = 0.5f * o.z * (1.f + erff(o.z * 0.70710678118654752f));
+      o.w = 0.5f * o.w * (1.f + erff(o.w * 0.70710678118654752f));
+    }
+    *(float4*)(out + i * hd + c) = o;
   }
 }
 
@@ -309,6 +316,12 @@ extern "C" {
 int32_t gigl_hgt_aggregate(gigl_ctx* ctx, const float* q, const float* k, const float* v, int32_t heads, int32_t dim,
                            const int32_t* rowptr, const int32_t* col, const int32_t* etype, const float* p_rel,
                            int64_t n_dst, float* out) {
+  return gigl_hgt_aggregate_act(ctx, q, k, v, heads, dim, rowptr, col, etype, p_rel, n_dst, 0, out);
+}
+
+int32_t gigl_hgt_aggregate_act(gigl_ctx* ctx, const float* q, const float* k, const float* v, int32_t heads, int32_t dim,
+                               const int32_t* rowptr, const int32_t* col, const int32_t* etype, const float* p_rel,
+                               int64_t n_dst, int32_t gelu, float* out) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   GIGL_REQUIRE(ctx, n_dst >= 0 && (n_dst == 0 || (q && k && v && rowptr && col && out)), "null argument");
   int32_t rc = check_shape(ctx, heads, dim);
@@ -320,7 +333,7 @@ int32_t gigl_hgt_aggregate(gigl_ctx* ctx, const float* q, const float* k, const 
   const dim3 grid((unsigned)((n_dst + 3) / 4)), block(256);
 #define GIGL_LAUNCH_HGT(P)                                                                                          \
   hipLaunchKernelGGL(hgt_aggregate_kernel<P>, grid, block, 0, ctx->stream, q, k, v, heads, dim, rowptr, col, etype, \
-                     p_rel, n_dst, out)
+                     p_rel, n_dst, out, gelu ? 1 : 0)
   if (passes == 1) GIGL_LAUNCH_HGT(1);
   else if (passes == 2) GIGL_LAUNCH_HGT(2);
   else GIGL_LAUNCH_HGT(4);

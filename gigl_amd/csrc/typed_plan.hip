@@ -18,11 +18,10 @@
 //   per edge    endpoints -> local ids by binary search -> (src << 32 | dst) keys -> radix sort -> distinct
 //   roots       position of every root in its type's node list
 // Counts stay on the device (n_nodes[type], n_edges[edge slot]); the caller reads them once per batch.
-// Integer work; bound by the sorts (rocPRIM radix sort over ~b * sum(w * f) keys per type) and the sampler's
-// dependent loads, not by bandwidth.
+// Integer work; bound by the sorts (the library's own LSD radix sort over ~b * sum(w * f) keys per type, sortscan.h:
+// kernels only, so that a plan can be captured into a hipGraph) and the sampler's dependent loads, not by bandwidth.
 #include "common.h"
-
-#include <hipcub/hipcub.hpp>
+#include "sortscan.h"
 
 #include <vector>
 
@@ -45,9 +44,11 @@ struct gigl_typed_plan {
   int32_t* n_nodes = nullptr;   // [n_types]
   int32_t* n_edges = nullptr;   // [n_slots]
   int32_t* root_index = nullptr;  // [b_max]
-  int32_t *flags = nullptr, *scan = nullptr;  // [max items]
-  void* work = nullptr;
-  size_t work_bytes = 0;
+  int32_t* scratch = nullptr;        // gigl_sort::scratch_words(max items): digit histograms / tile counts
+  uint32_t* tmp32 = nullptr;         // [max items] ping-pong buffers of the sorts
+  unsigned long long* tmp64 = nullptr;
+  int64_t tmp32_words = 0, tmp64_words = 0;
+  std::vector<int32_t> id_bits;      // per node type: bits an id of the type can occupy (32: unknown)
   int64_t max_items = 0;
   // merged CSR by destination over all edge slots (gigl_typed_plan_merged_csr; allocated on its first call)
   int64_t m_edges_cap = 0, m_rows_cap = 0;
@@ -55,8 +56,8 @@ struct gigl_typed_plan {
   int32_t *m_rowptr = nullptr, *m_col = nullptr, *m_etype = nullptr, *m_counts = nullptr;
   int32_t *m_root_len = nullptr, *m_root_rowptr = nullptr, *m_root_col = nullptr, *m_root_etype = nullptr;
   struct MergedOffsets* m_off = nullptr;
-  void* m_work = nullptr;
-  size_t m_work_bytes = 0;
+  unsigned long long* m_tmp = nullptr;
+  int32_t* m_scratch = nullptr;
   std::vector<void*> owned;
 };
 
@@ -128,20 +129,6 @@ __global__ __launch_bounds__(TB) void copy_u32_kernel(const uint32_t* src, int64
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) out[i] = src[i];
 }
-template <typename K>
-__global__ __launch_bounds__(TB) void head_flags_kernel(const K* sorted, int64_t m, K pad, int32_t* flags) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) flags[i] = (sorted[i] != pad && (i == 0 || sorted[i - 1] != sorted[i])) ? 1 : 0;
-}
-template <typename K>
-__global__ __launch_bounds__(TB) void compact_kernel(const K* sorted, const int32_t* flags, const int32_t* scan,
-                                                     int64_t m, K* out, int32_t* count) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
-  if (flags[i]) out[scan[i]] = sorted[i];
-  if (i == m - 1) *count = scan[i] + flags[i];
-}
-
 // position of v in the ascending list a[0 .. n) (v is in it)
 __device__ __forceinline__ uint32_t lower_bound(const uint32_t* a, int32_t n, uint32_t v) {
   int32_t lo = 0, hi = n;
@@ -187,6 +174,11 @@ struct MergedArgs {
   int32_t slot_order[32], slot_src_type[32], slot_dst_type[32], slot_etype[32];
   int64_t cap_off[33];  // capacity prefix of the listed slots (positions of merged_keys_kernel's grid)
   const unsigned long long* edges[32];
+  // capacity layout (gigl_typed_plan_merged_csr_ex): destination / source blocks start at CAPACITY prefixes — known when
+  // the plan is made — instead of at the batch's counts: every buffer address of a layer over this CSR is then static
+  int32_t capacity_layout;
+  int32_t type_cap[16];  // by position in type_order
+  int32_t src_cap[32];   // by position in slot_order: capacity of the slot's source type
 };
 }  // namespace
 struct MergedOffsets {
@@ -204,14 +196,14 @@ __global__ void merged_offsets_kernel(MergedArgs a, const int32_t* n_nodes, cons
   for (int t = 0; t < 16; ++t) off->dst_off[t] = -1;
   for (int j = 0; j < a.n_types; ++j) {
     off->dst_off[a.type_order[j]] = run;
-    run += n_nodes[a.type_order[j]];
+    run += a.capacity_layout ? a.type_cap[j] : n_nodes[a.type_order[j]];
   }
   off->n_dst = run;
   int32_t srun = 0, erun = 0;
   for (int j = 0; j < a.n_slots; ++j) {
     off->src_off[j] = srun;
     off->edge_off[j] = erun;
-    srun += n_nodes[a.slot_src_type[j]];
+    srun += a.capacity_layout ? a.src_cap[j] : n_nodes[a.slot_src_type[j]];
     erun += n_edges[a.slot_order[j]];
   }
   off->edge_off[a.n_slots] = erun;
@@ -345,6 +337,7 @@ int32_t gigl_typed_plan_create(gigl_ctx* ctx, const gigl_dag_op* ops, int32_t n_
   p->slot_src_type.assign(n_edge_slots, -1);
   p->slot_dst_type.assign(n_edge_slots, -1);
   p->cand_per_root[root_node_type] = 1;
+  p->id_bits.assign(n_node_types, 0);
   int32_t rc = GIGL_OK;
 #define PLAN_FAIL(...)                              \
   do {                                              \
@@ -377,6 +370,14 @@ int32_t gigl_typed_plan_create(gigl_ctx* ctx, const gigl_dag_op* ops, int32_t n_
       PLAN_FAIL("op %d: edge slot %d joins two different node type pairs", o, op.edge_slot);
     p->slot_src_type[op.edge_slot] = st;
     p->slot_dst_type[op.edge_slot] = dt;
+    // an op's graph has one row per node of its FRONTIER type: ids of that type lie below its row count
+    const int fb = key_bits(op.graph->n + 1);
+    p->id_bits[op.frontier_node_type] = fb > p->id_bits[op.frontier_node_type] ? fb : p->id_bits[op.frontier_node_type];
+  }
+  for (int t = 0; t < n_node_types; ++t) {  // a type that is never a frontier: nothing bounds its ids here
+    bool frontier = false;
+    for (int o = 0; o < n_ops; ++o) frontier |= p->ops[o].frontier_node_type == t;
+    if (!frontier) p->id_bits[t] = 32;
   }
 #undef PLAN_FAIL
   const int64_t b = b_max;
@@ -429,21 +430,18 @@ int32_t gigl_typed_plan_create(gigl_ctx* ctx, const gigl_dag_op* ops, int32_t n_
     gigl_typed_plan_destroy(p);
     return rc;
   }
-  PLAN_ALLOC(p->flags, p->max_items);
-  PLAN_ALLOC(p->scan, p->max_items);
   {
-    size_t t1 = 0, t2 = 0, t3 = 0;
-    hipcub::DeviceRadixSort::SortKeys((void*)nullptr, t1, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)p->max_items, 0, 32,
-                                      ctx->stream);
-    hipcub::DeviceRadixSort::SortKeys((void*)nullptr, t2, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                      (int)p->max_items, 0, 64, ctx->stream);
-    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, t3, (const int32_t*)nullptr, (int32_t*)nullptr, (int)p->max_items,
-                                     ctx->stream);
-    p->work_bytes = t1 > t2 ? t1 : t2;
-    p->work_bytes = p->work_bytes > t3 ? p->work_bytes : t3;
-    char* wk = nullptr;
-    PLAN_ALLOC(wk, (int64_t)p->work_bytes + 256);
-    p->work = wk;
+    const int64_t w1 = gigl_sort::scratch_words(p->max_items), w2 = gigl_sort::batch_scratch_words(gigl_sort::RS_MAX_SEGS);
+    PLAN_ALLOC(p->scratch, w1 > w2 ? w1 : w2);
+  }
+  {
+    int64_t s32 = 0, s64 = 0;  // (the batched sorts give every segment its own ping-pong buffer)
+    for (int t = 0; t < n_node_types; ++t) s32 += b * p->cand_per_root[t];
+    for (int s = 0; s < n_edge_slots; ++s) s64 += b * p->pairs_per_root[s];
+    p->tmp32_words = s32 > p->max_items ? s32 : p->max_items;
+    p->tmp64_words = s64 > p->max_items ? s64 : p->max_items;
+    PLAN_ALLOC(p->tmp32, p->tmp32_words);
+    PLAN_ALLOC(p->tmp64, p->tmp64_words);
   }
 #undef PLAN_ALLOC
   *out = p;
@@ -484,7 +482,7 @@ int32_t gigl_typed_plan_run(gigl_typed_plan* p, const uint32_t* roots, int32_t b
   for (int t = 0; t < p->n_types; ++t) {
     const int64_t m = (int64_t)b * p->cand_per_root[t];
     if (m == 0) {
-      GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->n_nodes + t, 0, 4, st));
+      gigl_fill_u32(st, (uint32_t*)(p->n_nodes + t), 0u, 1);  // (a kernel, not a memset node: the run may be captured)
       continue;
     }
     int64_t off = 0;
@@ -506,20 +504,54 @@ int32_t gigl_typed_plan_run(gigl_typed_plan* p, const uint32_t* roots, int32_t b
         off += mw * op.fanout;
       }
     }
-    size_t wb = p->work_bytes;
-    GIGL_HIP_CHECK(ctx, hipcub::DeviceRadixSort::SortKeys(p->work, wb, (const uint32_t*)p->cand[t], p->sorted[t], (int)m, 0, 32, st));
-    hipLaunchKernelGGL(head_flags_kernel<uint32_t>, grid_of(m), dim3(TB), 0, st, (const uint32_t*)p->sorted[t], m,
-                       (uint32_t)GIGL_INVALID, p->flags);
-    wb = p->work_bytes;
-    GIGL_HIP_CHECK(ctx, hipcub::DeviceScan::ExclusiveSum(p->work, wb, (const int32_t*)p->flags, p->scan, (int)m, st));
-    hipLaunchKernelGGL(compact_kernel<uint32_t>, grid_of(m), dim3(TB), 0, st, (const uint32_t*)p->sorted[t],
-                       (const int32_t*)p->flags, (const int32_t*)p->scan, m, p->nodes[t], p->n_nodes + t);
+  }
+  // ids below 2^id_bits - 1, the empty slot (GIGL_INVALID) all ones: the digits of [0, id_bits) order both.  All types in
+  // the same launches when they fit the batched sort (sortscan.h), else type by type.
+  {
+    gigl_sort::SortSegs<uint32_t> sg{};
+    gigl_sort::UniqSegs<uint32_t> ug{};
+    int bits = 0;
+    bool fused = true;
+    int64_t tmp_off = 0;
+    for (int t = 0; t < p->n_types; ++t) {
+      const int64_t m = (int64_t)b * p->cand_per_root[t];
+      if (m == 0) continue;
+      fused = fused && sg.nseg < gigl_sort::RS_MAX_SEGS && m <= (int64_t)gigl_sort::RS_FUSED_MAX_TILES * gigl_sort::RS_TILE &&
+              tmp_off + m <= p->tmp32_words;
+      if (!fused) break;
+      const int k = sg.nseg++;
+      sg.in[k] = p->cand[t];
+      sg.out[k] = p->sorted[t];
+      sg.tmp[k] = p->tmp32 + tmp_off;
+      sg.n[k] = m;
+      tmp_off += m;
+      ug.sorted[k] = p->sorted[t];
+      ug.out[k] = p->nodes[t];
+      ug.count[k] = p->n_nodes + t;
+      ug.n[k] = m;
+      bits = p->id_bits[t] > bits ? p->id_bits[t] : bits;
+    }
+    ug.nseg = sg.nseg;
+    if (fused) {
+      gigl_sort::gigl_radix_sort_batch<uint32_t>(st, sg, bits, p->scratch);
+      gigl_sort::gigl_unique_compact_batch<uint32_t>(st, ug, (uint32_t)GIGL_INVALID, p->scratch);
+    } else {
+      for (int t = 0; t < p->n_types; ++t) {
+        const int64_t m = (int64_t)b * p->cand_per_root[t];
+        if (m == 0) continue;
+        int shifts[8];
+        const int nd = gigl_sort::add_digits(shifts, 0, 0, p->id_bits[t]);
+        gigl_sort::gigl_radix_sort<uint32_t>(st, p->cand[t], p->sorted[t], p->tmp32, m, shifts, nd, p->scratch);
+        gigl_sort::gigl_unique_compact<uint32_t>(st, p->sorted[t], m, (uint32_t)GIGL_INVALID, p->nodes[t], p->n_nodes + t,
+                                                 p->scratch);
+      }
+    }
   }
   // ---- per edge slot: the distinct (src, dst) pairs as local ids, ascending by (src, dst)
   for (int s = 0; s < p->n_slots; ++s) {
     const int64_t m = (int64_t)b * p->pairs_per_root[s];
     if (m == 0) {
-      GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->n_edges + s, 0, 4, st));
+      gigl_fill_u32(st, (uint32_t*)(p->n_edges + s), 0u, 1);
       continue;
     }
     int64_t off = 0;
@@ -534,19 +566,51 @@ int32_t gigl_typed_plan_run(gigl_typed_plan* p, const uint32_t* roots, int32_t b
                          p->ekeys[s] + off);
       off += mw * op.fanout;
     }
-    const int hi = 32 + key_bits((int64_t)b * p->cand_per_root[p->slot_src_type[s]] + 1);
-    size_t wb = p->work_bytes;
-    // (the empty key ~0 needs all 64 bits to sort last)
-    (void)hi;
-    GIGL_HIP_CHECK(ctx, hipcub::DeviceRadixSort::SortKeys(p->work, wb, (const unsigned long long*)p->ekeys[s], p->esorted[s],
-                                                          (int)m, 0, 64, st));
-    hipLaunchKernelGGL(head_flags_kernel<unsigned long long>, grid_of(m), dim3(TB), 0, st,
-                       (const unsigned long long*)p->esorted[s], m, ~0ull, p->flags);
-    wb = p->work_bytes;
-    GIGL_HIP_CHECK(ctx, hipcub::DeviceScan::ExclusiveSum(p->work, wb, (const int32_t*)p->flags, p->scan, (int)m, st));
-    hipLaunchKernelGGL(compact_kernel<unsigned long long>, grid_of(m), dim3(TB), 0, st,
-                       (const unsigned long long*)p->esorted[s], (const int32_t*)p->flags, (const int32_t*)p->scan, m,
-                       p->edges[s], p->n_edges + s);
+  }
+  // (src_local << 32 | dst_local): local ids lie below their type's candidate capacity, the empty key is all ones — the
+  // two bit fields that can differ, packed side by side, order real keys and keep the empty ones last
+  {
+    gigl_sort::SortSegs<unsigned long long> sg{};
+    gigl_sort::UniqSegs<unsigned long long> ug{};
+    int bits = 0;
+    bool fused = true;
+    int64_t tmp_off = 0;
+    for (int s = 0; s < p->n_slots; ++s) {
+      const int64_t m = (int64_t)b * p->pairs_per_root[s];
+      if (m == 0) continue;
+      fused = fused && sg.nseg < gigl_sort::RS_MAX_SEGS && m <= (int64_t)gigl_sort::RS_FUSED_MAX_TILES * gigl_sort::RS_TILE &&
+              tmp_off + m <= p->tmp64_words;
+      if (!fused) break;
+      const int lo = key_bits((int64_t)p->b_max * p->cand_per_root[p->slot_dst_type[s]] + 1);
+      const int hi = key_bits((int64_t)p->b_max * p->cand_per_root[p->slot_src_type[s]] + 1);
+      const int k = sg.nseg++;
+      sg.in[k] = p->ekeys[s];
+      sg.out[k] = p->esorted[s];
+      sg.tmp[k] = p->tmp64 + tmp_off;
+      sg.n[k] = m;
+      sg.lo_bits[k] = lo;
+      tmp_off += m;
+      ug.sorted[k] = p->esorted[s];
+      ug.out[k] = p->edges[s];
+      ug.count[k] = p->n_edges + s;
+      ug.n[k] = m;
+      bits = lo + hi > bits ? lo + hi : bits;
+    }
+    ug.nseg = sg.nseg;
+    if (fused) {
+      gigl_sort::gigl_radix_sort_batch<unsigned long long>(st, sg, bits, p->scratch);
+      gigl_sort::gigl_unique_compact_batch<unsigned long long>(st, ug, ~0ull, p->scratch);
+    } else {
+      for (int s = 0; s < p->n_slots; ++s) {
+        const int64_t m = (int64_t)b * p->pairs_per_root[s];
+        if (m == 0) continue;
+        int shifts[8];
+        int nd = gigl_sort::add_digits(shifts, 0, 0, key_bits((int64_t)p->b_max * p->cand_per_root[p->slot_dst_type[s]] + 1));
+        nd = gigl_sort::add_digits(shifts, nd, 32, key_bits((int64_t)p->b_max * p->cand_per_root[p->slot_src_type[s]] + 1));
+        gigl_sort::gigl_radix_sort<unsigned long long>(st, p->ekeys[s], p->esorted[s], p->tmp64, m, shifts, nd, p->scratch);
+        gigl_sort::gigl_unique_compact<unsigned long long>(st, p->esorted[s], m, ~0ull, p->edges[s], p->n_edges + s, p->scratch);
+      }
+    }
   }
   hipLaunchKernelGGL(root_index_kernel, grid_of(b), dim3(TB), 0, st, roots, (int64_t)b,
                      (const uint32_t*)p->nodes[p->root_type], (const int32_t*)(p->n_nodes + p->root_type), p->root_index);
@@ -557,6 +621,12 @@ int32_t gigl_typed_plan_run(gigl_typed_plan* p, const uint32_t* roots, int32_t b
 int32_t gigl_typed_plan_merged_csr(gigl_typed_plan* p, int32_t b, const int32_t* type_order, int32_t n_types_used,
                                    const int32_t* slot_order, const int32_t* slot_etype, int32_t n_slots_used,
                                    gigl_typed_csr_out* out) {
+  return gigl_typed_plan_merged_csr_ex(p, b, type_order, n_types_used, slot_order, slot_etype, n_slots_used, 0, out);
+}
+
+int32_t gigl_typed_plan_merged_csr_ex(gigl_typed_plan* p, int32_t b, const int32_t* type_order, int32_t n_types_used,
+                                      const int32_t* slot_order, const int32_t* slot_etype, int32_t n_slots_used,
+                                      int32_t capacity_layout, gigl_typed_csr_out* out) {
   if (!p || !out) return GIGL_E_INVALID_ARG;
   gigl_ctx* ctx = p->ctx;
   *out = gigl_typed_csr_out{};
@@ -576,6 +646,7 @@ int32_t gigl_typed_plan_merged_csr(gigl_typed_plan* p, int32_t b, const int32_t*
     GIGL_REQUIRE(ctx, t >= 0 && t < p->n_types && !(seen_t >> t & 1), "typed plan merged CSR: node type %d", t);
     seen_t |= 1u << t;
     a.type_order[j] = t;
+    a.type_cap[j] = (int32_t)((int64_t)p->b_max * p->cand_per_root[t]);
     rows_cap += (int64_t)p->b_max * p->cand_per_root[t];
     root_listed |= t == p->root_type;
   }
@@ -591,11 +662,18 @@ int32_t gigl_typed_plan_merged_csr(gigl_typed_plan* p, int32_t b, const int32_t*
     a.slot_src_type[j] = p->slot_src_type[sl];
     a.slot_dst_type[j] = p->slot_dst_type[sl];
     a.slot_etype[j] = slot_etype ? slot_etype[j] : j;
+    a.src_cap[j] = (int32_t)((int64_t)p->b_max * p->cand_per_root[p->slot_src_type[sl]]);
     a.cap_off[j + 1] = a.cap_off[j] + (int64_t)p->b_max * p->pairs_per_root[sl];
     a.edges[j] = p->edges[sl];
   }
+  a.capacity_layout = capacity_layout ? 1 : 0;
   const int64_t m = a.cap_off[n_slots_used];
   GIGL_REQUIRE(ctx, m < ((int64_t)1 << 31) && rows_cap < ((int64_t)1 << 31) - 1, "typed plan merged CSR: batch too large");
+  {
+    int64_t src_rows = 0;
+    for (int j = 0; j < n_slots_used; ++j) src_rows += a.src_cap[j];
+    GIGL_REQUIRE(ctx, src_rows < ((int64_t)1 << 31), "typed plan merged CSR: source blocks too large");
+  }
   if (m > p->m_edges_cap || rows_cap > p->m_rows_cap) {  // (first call, or a wider listing than before)
     hipStreamSynchronize(ctx->stream);
     int32_t rc = GIGL_OK;
@@ -616,14 +694,11 @@ int32_t gigl_typed_plan_merged_csr(gigl_typed_plan* p, int32_t b, const int32_t*
     CSR_ALLOC(p->m_root_rowptr, (int64_t)p->b_max + 1);
     CSR_ALLOC(p->m_counts, 2);
     if (!p->m_off) CSR_ALLOC(p->m_off, 1);
-    size_t t1 = 0, t2 = 0;
-    hipcub::DeviceRadixSort::SortKeys((void*)nullptr, t1, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                      (int)me, 0, 64, ctx->stream);
-    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, t2, (const int32_t*)nullptr, (int32_t*)nullptr, p->b_max + 1, ctx->stream);
-    p->m_work_bytes = t1 > t2 ? t1 : t2;
-    char* wk = nullptr;
-    CSR_ALLOC(wk, (int64_t)p->m_work_bytes + 256);
-    p->m_work = wk;
+    CSR_ALLOC(p->m_tmp, me);
+    {
+      const int64_t w1 = gigl_sort::scratch_words(me), w2 = gigl_sort::batch_scratch_words(1);
+      CSR_ALLOC(p->m_scratch, w1 > w2 ? w1 : w2);
+    }
 #undef CSR_ALLOC
     p->m_edges_cap = m;
     p->m_rows_cap = rows_cap;
@@ -634,9 +709,22 @@ int32_t gigl_typed_plan_merged_csr(gigl_typed_plan* p, int32_t b, const int32_t*
   if (m > 0) {
     hipLaunchKernelGGL(merged_keys_kernel, grid_of(m), dim3(TB), 0, st, a, (const int32_t*)p->n_edges,
                        (const MergedOffsets*)p->m_off, m, p->m_keys);
-    size_t wb = p->m_work_bytes;
-    GIGL_HIP_CHECK(ctx, hipcub::DeviceRadixSort::SortKeys(p->m_work, wb, (const unsigned long long*)p->m_keys, p->m_sorted,
-                                                          (int)m, 0, 64, st));
+    // keys are (destination << 32 | position) with positions ascending in input order: a STABLE sort by the destination
+    // field alone is the full order (destinations < rows_cap, the empty key all ones)
+    if (m <= (int64_t)gigl_sort::RS_FUSED_MAX_TILES * gigl_sort::RS_TILE) {
+      gigl_sort::SortSegs<unsigned long long> sg{};
+      sg.nseg = 1;
+      sg.in[0] = p->m_keys;
+      sg.out[0] = p->m_sorted;
+      sg.tmp[0] = p->m_tmp;
+      sg.n[0] = m;
+      sg.lo_bits[0] = 0;  // the virtual key is the destination field alone
+      gigl_sort::gigl_radix_sort_batch<unsigned long long>(st, sg, key_bits(rows_cap + 2), p->m_scratch);
+    } else {
+      int shifts[8];
+      const int nd = gigl_sort::add_digits(shifts, 0, 32, key_bits(rows_cap + 2));
+      gigl_sort::gigl_radix_sort<unsigned long long>(st, p->m_keys, p->m_sorted, p->m_tmp, m, shifts, nd, p->m_scratch);
+    }
     hipLaunchKernelGGL(merged_fill_kernel, grid_of(m), dim3(TB), 0, st, a, (const MergedOffsets*)p->m_off,
                        (const unsigned long long*)p->m_sorted, m, p->m_col, p->m_etype);
   }
@@ -644,8 +732,7 @@ int32_t gigl_typed_plan_merged_csr(gigl_typed_plan* p, int32_t b, const int32_t*
                      (const unsigned long long*)p->m_sorted, p->m_rows_cap, p->m_rowptr);
   hipLaunchKernelGGL(root_len_kernel, grid_of((int64_t)b + 1), dim3(TB), 0, st, (const MergedOffsets*)p->m_off, p->root_type,
                      (const int32_t*)p->root_index, b, (const int32_t*)p->m_rowptr, p->m_root_len);
-  size_t wb = p->m_work_bytes;
-  GIGL_HIP_CHECK(ctx, hipcub::DeviceScan::ExclusiveSum(p->m_work, wb, (const int32_t*)p->m_root_len, p->m_root_rowptr, b + 1, st));
+  gigl_sort::gigl_exclusive_scan_small(st, (const int32_t*)p->m_root_len, p->m_root_rowptr, (int64_t)b + 1);
   hipLaunchKernelGGL(root_rows_kernel, grid_of((int64_t)b * 64), dim3(TB), 0, st, (const MergedOffsets*)p->m_off, p->root_type,
                      (const int32_t*)p->root_index, b, (const int32_t*)p->m_rowptr, (const int32_t*)p->m_col,
                      (const int32_t*)p->m_etype, (const int32_t*)p->m_root_rowptr, p->m_root_col, p->m_root_etype);
@@ -659,6 +746,91 @@ int32_t gigl_typed_plan_merged_csr(gigl_typed_plan* p, int32_t b, const int32_t*
   out->root_etype = p->m_root_etype;
   out->edges_cap = m;
   out->rows_cap = p->m_rows_cap;
+  return GIGL_OK;
+}
+
+// The plan's sort + distinct step as a call of its own (tests; callers that number ids of their own): the distinct
+// keys of keys[0 .. n) other than `pad`, ascending, count on the device.
+int32_t gigl_sort_distinct_u64(gigl_ctx* ctx, const unsigned long long* keys, int64_t n, int32_t low_bits, int32_t high_bits,
+                               unsigned long long pad, unsigned long long* out, int32_t* count) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, keys && out && count && n >= 0 && n < ((int64_t)1 << 31), "bad arguments");
+  GIGL_REQUIRE(ctx, low_bits >= 0 && low_bits <= 32 && high_bits >= 0 && high_bits <= 32, "bit fields outside [0,32]");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  if (n == 0) {
+    gigl_fill_u32(st, (uint32_t*)count, 0u, 1);
+    return GIGL_OK;
+  }
+  const int64_t sw = gigl_sort::scratch_words(n) > gigl_sort::batch_scratch_words(1) ? gigl_sort::scratch_words(n) : gigl_sort::batch_scratch_words(1);
+  int32_t rc = gigl_arena_reset(ctx, n * 16 + sw * 4 + 1024);
+  if (rc != GIGL_OK) return rc;
+  unsigned long long* sorted = (unsigned long long*)gigl_arena_alloc(ctx, n * 8);
+  unsigned long long* tmp = (unsigned long long*)gigl_arena_alloc(ctx, n * 8);
+  int32_t* scratch = (int32_t*)gigl_arena_alloc(ctx, sw * 4);
+  if (!sorted || !tmp || !scratch) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  if (n <= (int64_t)gigl_sort::RS_FUSED_MAX_TILES * gigl_sort::RS_TILE) {  // the batched form the plans use (one segment)
+    gigl_sort::SortSegs<unsigned long long> sg{};
+    gigl_sort::UniqSegs<unsigned long long> ug{};
+    sg.nseg = ug.nseg = 1;
+    sg.in[0] = keys;
+    sg.out[0] = sorted;
+    sg.tmp[0] = tmp;
+    sg.n[0] = ug.n[0] = n;
+    sg.lo_bits[0] = low_bits;
+    ug.sorted[0] = sorted;
+    ug.out[0] = out;
+    ug.count[0] = count;
+    gigl_sort::gigl_radix_sort_batch<unsigned long long>(st, sg, low_bits + high_bits, scratch);
+    gigl_sort::gigl_unique_compact_batch<unsigned long long>(st, ug, pad, scratch);
+  } else {
+    int shifts[8];
+    int nd = gigl_sort::add_digits(shifts, 0, 0, low_bits);
+    nd = gigl_sort::add_digits(shifts, nd, 32, high_bits);
+    gigl_sort::gigl_radix_sort<unsigned long long>(st, keys, sorted, tmp, n, shifts, nd, scratch);
+    gigl_sort::gigl_unique_compact<unsigned long long>(st, sorted, n, pad, out, count, scratch);
+  }
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_sort_distinct_u32(gigl_ctx* ctx, const uint32_t* keys, int64_t n, int32_t bits, uint32_t pad, uint32_t* out,
+                               int32_t* count) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, keys && out && count && n >= 0 && n < ((int64_t)1 << 31) && bits >= 0 && bits <= 32, "bad arguments");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  if (n == 0) {
+    gigl_fill_u32(st, (uint32_t*)count, 0u, 1);
+    return GIGL_OK;
+  }
+  const int64_t sw = gigl_sort::scratch_words(n) > gigl_sort::batch_scratch_words(1) ? gigl_sort::scratch_words(n) : gigl_sort::batch_scratch_words(1);
+  int32_t rc = gigl_arena_reset(ctx, n * 8 + sw * 4 + 1024);
+  if (rc != GIGL_OK) return rc;
+  uint32_t* sorted = (uint32_t*)gigl_arena_alloc(ctx, n * 4);
+  uint32_t* tmp = (uint32_t*)gigl_arena_alloc(ctx, n * 4);
+  int32_t* scratch = (int32_t*)gigl_arena_alloc(ctx, sw * 4);
+  if (!sorted || !tmp || !scratch) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  if (n <= (int64_t)gigl_sort::RS_FUSED_MAX_TILES * gigl_sort::RS_TILE) {
+    gigl_sort::SortSegs<uint32_t> sg{};
+    gigl_sort::UniqSegs<uint32_t> ug{};
+    sg.nseg = ug.nseg = 1;
+    sg.in[0] = keys;
+    sg.out[0] = sorted;
+    sg.tmp[0] = tmp;
+    sg.n[0] = ug.n[0] = n;
+    ug.sorted[0] = sorted;
+    ug.out[0] = out;
+    ug.count[0] = count;
+    gigl_sort::gigl_radix_sort_batch<uint32_t>(st, sg, bits, scratch);
+    gigl_sort::gigl_unique_compact_batch<uint32_t>(st, ug, pad, scratch);
+  } else {
+    int shifts[8];
+    const int nd = gigl_sort::add_digits(shifts, 0, 0, bits);
+    gigl_sort::gigl_radix_sort<uint32_t>(st, keys, sorted, tmp, n, shifts, nd, scratch);
+    gigl_sort::gigl_unique_compact<uint32_t>(st, sorted, n, pad, out, count, scratch);
+  }
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
 

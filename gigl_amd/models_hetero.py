@@ -478,6 +478,136 @@ class HGT(nn.Module):
         return out
 
 
+class HgtInferPlan:
+    """the typed inference step of an HGT encoder as ONE library call per batch (csrc/hgt_plan.hip: gigl_hgt_infer_*):
+    SamplingOp DAG -> typed batch graph -> HGT over composed weights -> the roots' rows, replayed as a hipGraph — what
+    `sampler.batch_graph_plan(...)` + `model(graph, [root_type], row_subset=...)` compute with ~150 launches issued from
+    Python and one host read per batch.  `run(roots)` takes int32 device ids, returns [b, out_dim] on the engine's stream.
+    The model's parameters are read at every run: a changed parameter re-composes the weights (HGTConv._composed)."""
+
+    def __init__(self, model: "HGT", sampler, root_node_type: str, dag, b_max: int):
+        import ctypes as C
+        from . import _lib
+        if model.feature_embedding_layers:
+            raise NotImplementedError("the one-call typed step takes stored feature rows (no feature embedding layers)")
+        if len(model.convs) < 1 or len(model.convs) > _lib.GIGL_HGT_MAX_LAYERS:
+            raise NotImplementedError(f"the one-call typed step runs 1..{_lib.GIGL_HGT_MAX_LAYERS} HGT layers")
+        self.model, self.sampler, self.root_type, self.b_max = model, sampler, root_node_type, int(b_max)
+        eng = self.eng = sampler.engine
+        pl = self.pl = sampler.typed_plan(root_node_type, dag, int(b_max))
+        out = pl["out"]
+        conv0 = model.convs[0]
+        self.used = [i for i, t in enumerate(pl["types"]) if int(out.nodes_cap[i]) > 0]
+        self.slot_ets = [(et.src_node_type, et.relation, et.dst_node_type) for et in pl["slots"]]
+        tix = {t: i for i, t in enumerate(pl["types"])}
+        for et in self.slot_ets:
+            if et not in conv0.edge_types_map:
+                raise NotImplementedError(f"the model has no edge type {et}")
+        self._src = (C.c_int32 * len(self.slot_ets))(*[tix[et[0]] for et in self.slot_ets])
+        self._dst = (C.c_int32 * len(self.slot_ets))(*[tix[et[2]] for et in self.slot_ets])
+        self._root_plan_type = tix[root_node_type]
+        self._keep = None
+        self._stamp = None
+        self._handle = C.c_void_p()
+        m = self._pack()
+        _lib.check(eng._lib.gigl_hgt_infer_create(eng._ctx, pl["plan"], int(b_max), C.byref(m), self._src, self._dst,
+                                                  C.byref(self._handle)), eng._ctx)
+
+    def _pack(self):
+        """the gigl_hgt_model of the model's current parameters (device pointers; the tensors are kept in self._keep)"""
+        from . import _lib
+        model, pl = self.model, self.pl
+        dev = self.eng.device
+        keep: list = []
+
+        def ptr(t):
+            if t is None:
+                return None
+            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        conv0 = model.convs[0]
+        m = _lib.GiglHgtModel()
+        m.n_types, m.n_slots, m.n_layers = len(self.used), len(self.slot_ets), len(model.convs)
+        m.heads, m.hid, m.out_dim = conv0.heads, conv0.out_channels, int(model.lin.weight.shape[0])
+        m.l2_normalize = 1 if model.should_l2_normalize_embedding_layer_output else 0
+        m.root_type = self._root_plan_type
+        names = [pl["types"][i] for i in self.used]
+        for j, (i, t) in enumerate(zip(self.used, names)):
+            m.type_order[j] = i
+            tab = self.sampler._feature_table(t)
+            m.feat[j] = tab.data_ptr() if tab is not None else None
+            m.feat_dim[j] = int(tab.shape[1]) if tab is not None else 1
+            lin = model.lin_dict[t]
+            if int(lin.weight.shape[1]) != int(m.feat_dim[j]):
+                raise ValueError(f"node type {t}: {m.feat_dim[j]} stored columns, the model expects {lin.weight.shape[1]}")
+            m.w_in[j], m.b_in[j] = ptr(lin.weight), ptr(lin.bias)
+        for s, et in enumerate(self.slot_ets):
+            m.slot_order[s] = int(pl["slots"][EdgeTypeOf(pl["slots"], et)])
+            m.slot_etype[s] = int(conv0.edge_types_map[et])
+        for l, conv in enumerate(model.convs):
+            if any(int(v) != conv.out_channels for v in conv.in_channels.values()) or conv.heads != conv0.heads or \
+                    conv.out_channels != conv0.out_channels:
+                raise NotImplementedError("the one-call typed step runs HGT layers of one width")
+            cw = conv._composed(dev)
+            lw = m.layer[l]
+            for j, t in enumerate(names):
+                lw.wq[j], lw.bq[j] = ptr(cw["q"][t][0]), ptr(cw["q"][t][1])
+                w, b, kp = cw["out"][t]
+                lw.wout[j], lw.bout[j], lw.keep[j] = ptr(w), ptr(b), ptr(kp.reshape(1) if kp is not None else None)
+            for s, et in enumerate(self.slot_ets):
+                lw.wk[s], lw.bk[s] = ptr(cw["k"][et][0]), ptr(cw["k"][et][1])
+                lw.wv[s], lw.bv[s] = ptr(cw["v"][et][0]), ptr(cw["v"][et][1])
+            lw.p_rel = ptr(torch.cat([conv.p_rel["__".join(e)].reshape(1, conv.heads) for e in conv.edge_types]))
+        m.w_final, m.b_final = ptr(model.lin.weight), ptr(model.lin.bias)
+        self._keep_next = keep
+        return m
+
+    def _refresh(self):
+        import ctypes as C
+        from . import _lib
+        stamp = tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        if stamp == self._stamp:
+            return
+        m = self._pack()
+        _lib.check(self.eng._lib.gigl_hgt_infer_set_model(self._handle, C.byref(m)), self.eng._ctx)
+        self._keep, self._stamp = self._keep_next, stamp  # (the old tensors are released only after set_model synchronised)
+
+    def use_graph(self, enable: bool) -> None:
+        from . import _lib
+        _lib.check(self.eng._lib.gigl_hgt_infer_use_graph(self._handle, 1 if enable else 0), self.eng._ctx)
+
+    def run(self, roots: torch.Tensor) -> torch.Tensor:
+        import ctypes as C
+        from . import _lib
+        eng = self.eng
+        self._refresh()
+        b = int(roots.numel())
+        r = roots.to(device=eng.device, dtype=torch.int32).contiguous()
+        out = torch.empty((b, int(self.model.lin.weight.shape[0])), dtype=torch.float32, device=eng.device)
+        with torch.cuda.stream(eng._stream):
+            _lib.check(eng._lib.gigl_hgt_infer_run(self._handle, C.c_void_p(r.data_ptr()), b, C.c_void_p(out.data_ptr())),
+                       eng._ctx)
+            r.record_stream(eng._stream)
+            out.record_stream(eng._stream)
+        return out
+
+    def close(self) -> None:
+        if self._handle:
+            self.eng._lib.gigl_hgt_infer_destroy(self._handle)
+            self._handle = None
+        self._keep = None
+
+
+def EdgeTypeOf(slots: dict, et: tuple):
+    """the key of `slots` (graphdb_sampler.EdgeType) that names the (src, relation, dst) tuple"""
+    for k in slots:
+        if (k.src_node_type, k.relation, k.dst_node_type) == tuple(et):
+            return k
+    raise KeyError(et)
+
+
 class SimpleHGNConv(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, num_edge_types: int, edge_in_channels: Optional[int] = None,
                  num_heads: int = 1, edge_type_dim: int = 16, should_use_node_residual: bool = True,

@@ -514,7 +514,80 @@ typedef struct gigl_typed_csr_out {
 int32_t gigl_typed_plan_merged_csr(gigl_typed_plan* plan, int32_t b, const int32_t* type_order, int32_t n_types_used,
                                    const int32_t* slot_order, const int32_t* slot_etype, int32_t n_slots_used,
                                    gigl_typed_csr_out* out);
+/* The same with capacity_layout != 0: destination blocks and source blocks start at CAPACITY prefixes (type t's block =
+ * nodes_cap[t] rows, a slot's source block = its source type's nodes_cap) instead of at the batch's counts, rows beyond a
+ * type's count are empty, counts[0] = the sum of the listed types' capacities.  Every address of a layer over this CSR
+ * is then known when the plan is made: what gigl_hgt_infer_* runs over, captured once and replayed. */
+int32_t gigl_typed_plan_merged_csr_ex(gigl_typed_plan* plan, int32_t b, const int32_t* type_order, int32_t n_types_used,
+                                      const int32_t* slot_order, const int32_t* slot_etype, int32_t n_slots_used,
+                                      int32_t capacity_layout, gigl_typed_csr_out* out);
 int32_t gigl_typed_plan_destroy(gigl_typed_plan* plan);
+
+/* ---- the typed inference step in ONE call (csrc/hgt_plan.hip): gigl_typed_plan_run -> merged CSR at capacity prefixes
+ *      -> HGT encoder -> the roots' rows; no host read inside, the step is captured as a hipGraph on its second run and
+ *      replayed from then on.  Replaces the HGT forward of python/gigl/src/common/models/pyg/heterogeneous.py:18-120
+ *      (torch_geometric HGTConv layers: hgt_conv.py) driven per batch by the inferencer
+ *      (python/gigl/src/inference/v1/gnn_inferencer.py:234-340).
+ *      Weights are DEVICE pointers the caller keeps alive, in the COMPOSED inference form (linear stages multiplied
+ *      together once per parameter state — gigl_amd/models_hetero.py::HGTConv._composed):
+ *        per used node type j   feat[j] [n_j][feat_dim[j]] fp32 rows by global id (NULL: a constant 1-wide input),
+ *                               w_in / b_in: lin_dict[t] ([hid][feat_dim], [hid]; ReLU follows)
+ *        per layer, per type    wq / bq ([hid][hid], [hid]);  wout / bout = a * out_lin, keep = device float (1 - a) with
+ *                               a = sigmoid(skip[t]) (NULL: no skip)
+ *        per layer, per slot    wk / bk = blockdiag(k_rel[etype]) @ K-part of kqv_lin[src type], wv / bv likewise
+ *        per layer              p_rel [model edge types][heads]
+ *        w_final / b_final      the encoder's output Linear ([out_dim][hid]); l2_normalize: F.normalize(p=2, dim=1)
+ *      type_order[j] = the plan's node type of used type j (every type an op touches, the roots' type among them:
+ *      root_type); slot_order[s] = the plan's edge slot of listed slot s, slot_etype[s] = its row of p_rel.
+ *      The LAST layer computes the roots' rows only (identical rows: hgt_conv is row-wise per destination). */
+#define GIGL_HGT_MAX_LAYERS 4
+typedef struct gigl_hgt_layer_weights {
+  const float* wq[16];
+  const float* bq[16];
+  const float* wout[16];
+  const float* bout[16];
+  const float* keep[16];
+  const float* wk[32];
+  const float* bk[32];
+  const float* wv[32];
+  const float* bv[32];
+  const float* p_rel;
+} gigl_hgt_layer_weights;
+typedef struct gigl_hgt_model {
+  int32_t n_types, n_slots, n_layers, heads, hid, out_dim, l2_normalize, root_type;
+  int32_t type_order[16];
+  int32_t slot_order[32];
+  int32_t slot_etype[32];
+  int32_t feat_dim[16];
+  const float* feat[16];
+  const float* w_in[16];
+  const float* b_in[16];
+  gigl_hgt_layer_weights layer[GIGL_HGT_MAX_LAYERS];
+  const float* w_final;
+  const float* b_final;
+} gigl_hgt_model;
+typedef struct gigl_hgt_infer gigl_hgt_infer;
+/* slot_src_type / slot_dst_type [n_slots]: the plan's node types each listed slot joins (HOST).  b_max <= the plan's. */
+int32_t gigl_hgt_infer_create(gigl_ctx* ctx, gigl_typed_plan* plan, int32_t b_max, const gigl_hgt_model* model,
+                              const int32_t* slot_src_type, const int32_t* slot_dst_type, gigl_hgt_infer** out);
+/* roots: DEVICE uint32 [b]; out: DEVICE fp32 [b][out_dim], on the ctx's stream. */
+int32_t gigl_hgt_infer_run(gigl_hgt_infer* infer, const uint32_t* roots, int32_t b, float* out);
+/* new weight pointers of the same shapes (after a parameter update); a changed pointer re-captures the step */
+int32_t gigl_hgt_infer_set_model(gigl_hgt_infer* infer, const gigl_hgt_model* model);
+int32_t gigl_hgt_infer_use_graph(gigl_hgt_infer* infer, int32_t enable);
+int32_t gigl_hgt_infer_destroy(gigl_hgt_infer* infer);
+
+/* The plan's numbering step as a call of its own (csrc/sortscan.h: the library's LSD radix sort + ordered distinct —
+ * kernels only, so a plan that uses them can be captured into a hipGraph; rocPRIM's sort issues memsets).  Replaces
+ * torch.unique(sorted=True) in gigl_amd/graphdb_sampler.py::batch_graph, i.e. the first-seen / sorted numbering of
+ * python/gigl/src/common/graph_builder/abstract_graph_builder.py:100-150.  out[0 .. *count) = the distinct keys of
+ * keys[0 .. n) other than `pad`, ascending; keys, out, count: DEVICE.  Only the bit fields that can differ are sorted:
+ * u64 keys by bits [0, low_bits) and [32, 32 + high_bits), u32 keys by bits [0, bits); every real key must be below the
+ * all-ones value of its fields and `pad` all ones in them (it is dropped wherever it lands last). */
+int32_t gigl_sort_distinct_u64(gigl_ctx* ctx, const unsigned long long* keys, int64_t n, int32_t low_bits, int32_t high_bits,
+                               unsigned long long pad, unsigned long long* out, int32_t* count);
+int32_t gigl_sort_distinct_u32(gigl_ctx* ctx, const uint32_t* keys, int64_t n, int32_t bits, uint32_t pad, uint32_t* out,
+                               int32_t* count);
 
 /* ---- inference output: (node id, embedding row) batches -> Avro object-container DATA BLOCKS, encoded on the device.
  *      Replaces the record loop of EmbeddingExporter.add_embedding (python/gigl/common/data/export.py:103-135:
@@ -1014,6 +1087,11 @@ int32_t gigl_cms_estimate(gigl_ctx* ctx, const int32_t* table, int32_t width, in
 int32_t gigl_hgt_aggregate(gigl_ctx* ctx, const float* q, const float* k, const float* v, int32_t heads, int32_t dim,
                            const int32_t* rowptr, const int32_t* col, const int32_t* etype, const float* p_rel,
                            int64_t n_dst, float* out);
+/* gigl_hgt_aggregate with the layer's GELU (exact erf form, hgt_conv.py: F.gelu before the output projection) applied in
+ * the reduce's epilogue when gelu != 0 */
+int32_t gigl_hgt_aggregate_act(gigl_ctx* ctx, const float* q, const float* k, const float* v, int32_t heads, int32_t dim,
+                               const int32_t* rowptr, const int32_t* col, const int32_t* etype, const float* p_rel,
+                               int64_t n_dst, int32_t gelu, float* out);
 int32_t gigl_simplehgn_alpha(gigl_ctx* ctx, const float* hl, const float* hr, const float* het, const float* hef,
                              const int32_t* src, const int32_t* dst, const int32_t* etype, int64_t n_edges,
                              int64_t n_nodes, int32_t heads, float negative_slope, float* group_scratch, float* alpha);

@@ -388,3 +388,68 @@ def test_hgt_last_layer_on_a_row_subset_equals_the_full_forward():
             s.engine.synchronize()
             assert torch.equal(planned, plain) and torch.equal(planned_full, plain)
     s.close()
+
+
+@pytest.mark.parametrize("layers,l2", [(2, False), (1, True), (3, False)])
+def test_one_call_typed_inference_step_equals_the_staged_forward(layers, l2):
+    """gigl_hgt_infer_* (csrc/hgt_plan.hip: DAG sampler -> typed batch graph at capacity prefixes -> HGT over composed
+    weights -> the roots' rows, one library call, replayed as a hipGraph) against batch_graph_plan + HGT.forward(row_subset)
+    on the same roots: eager first run, captured second run, replays, a smaller batch, weights changed in place"""
+    from gigl_amd.graphdb_sampler import (INCOMING, OUTGOING, EdgeType, HipGraphDBSampler, SamplingOp, SamplingOpDAG)
+    from gigl_amd.models_hetero import HGT, HgtInferPlan
+    A2P, P2A = EdgeType("author", "writes", "paper"), EdgeType("paper", "written_by", "author")
+    node_types, cet = {"author": 0, "paper": 1}, {A2P: 0, P2A: 1}
+    rng = np.random.default_rng(1)
+    n = {"author": 3000, "paper": 5000}
+    a = (rng.zipf(1.6, 40000) % n["author"]).astype(np.uint32)
+    p = rng.integers(0, n["paper"], 40000).astype(np.uint32)
+    edges = {A2P: (a, p), P2A: (p, a)}
+    feats = {"author": rng.standard_normal((3000, 8)).astype(np.float32), "paper": rng.standard_normal((5000, 12)).astype(np.float32)}
+    s = HipGraphDBSampler(node_types, n, edges, cet, feats)
+    ops = [SamplingOp("h1", A2P, 5, [], INCOMING), SamplingOp("h2", P2A, 3, ["h1"], INCOMING),
+           SamplingOp("h3", A2P, 2, ["h2"], OUTGOING)]
+    dag = SamplingOpDAG.from_ops(ops)
+    torch.manual_seed(7)
+    ets = [("author", "writes", "paper"), ("paper", "written_by", "author")]
+    model = HGT({"author": 8, "paper": 12}, {e: 0 for e in ets}, hid_dim=32, out_dim=24, num_layers=layers, num_heads=2,
+                should_l2_normalize_embedding_layer_output=l2).to(s.engine.device).eval()
+    with torch.no_grad():  # (skip gates and relation priors away from their initial 1: both enter the composed weights)
+        for conv in model.convs:
+            for t in conv.skip:
+                conv.skip[t].fill_(0.3)
+            for k in conv.p_rel:
+                conv.p_rel[k].copy_(torch.rand_like(conv.p_rel[k]) + 0.5)
+    model.engine = s.engine
+    B = 256
+    plan = HgtInferPlan(model, s, "paper", dag, B)
+
+    def staged(roots):
+        graph, ri, _ = s.batch_graph_plan(roots, "paper", dag, b_max=B, edge_type_ids=model.convs[0].edge_types_map)
+        with torch.no_grad(), torch.cuda.stream(s.engine._stream):
+            out = model(graph, ["paper"], row_subset={"paper": ri})["paper"]
+        s.engine.synchronize()
+        return out.cpu().numpy()
+
+    def one_call(roots):
+        r = torch.from_numpy(roots.astype(np.uint32).view(np.int32)).to(s.engine.device)
+        out = plan.run(r)
+        s.engine.synchronize()
+        return out.cpu().numpy()
+
+    pools = [rng.integers(0, n["paper"], B) for _ in range(4)]
+    for roots in pools:  # run 1 eager, run 2 captured, then replays
+        np.testing.assert_allclose(one_call(roots), staged(roots), rtol=2e-5, atol=2e-5)
+    short = rng.integers(0, n["paper"], 100)  # a smaller batch: another capture
+    np.testing.assert_allclose(one_call(short), staged(short), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(one_call(short), staged(short), rtol=2e-5, atol=2e-5)
+    dup = np.concatenate([pools[0][:50], pools[0][:50]])  # repeated roots
+    np.testing.assert_allclose(one_call(dup), staged(dup), rtol=2e-5, atol=2e-5)
+    with torch.no_grad():  # a parameter update: the composed weights are rebuilt, the step re-captured
+        model.lin.weight.mul_(1.5)
+        model.convs[0].kqv_lin.lins["author"].weight.add_(0.05)
+    for roots in pools[:3]:
+        np.testing.assert_allclose(one_call(roots), staged(roots), rtol=2e-5, atol=2e-5)
+    plan.use_graph(False)
+    np.testing.assert_allclose(one_call(pools[3]), staged(pools[3]), rtol=2e-5, atol=2e-5)
+    plan.close()
+    s.close()
