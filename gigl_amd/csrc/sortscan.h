@@ -153,9 +153,9 @@ inline int add_digits(int* shifts, int count, int lo, int bits) {
 
 // ---- batched variant for the sizes of a batch graph (every segment <= 256 tiles = 524,288 keys): up to 8 independent
 // sorts share every launch (grid.y = segment), and a pass is TWO launches — the tile histograms are kept tile-major
-// ([tile][digit]) next to per-digit totals (one atomic per tile and digit), so a scatter workgroup finds where its runs
-// start by itself: exclusive prefix of the totals over the digits + the sum of the earlier tiles' counts (coalesced
-// 1-KB reads, <= 256 of them); no scan launch.  64-bit keys are sorted by a VIRTUAL key that packs their two bit fields
+// ([tile][digit]), so a scatter workgroup finds where its runs start by itself: it adds the tiles' histograms up
+// (coalesced 1-KB rows, <= 256 of them) — all of them for the digit totals and their exclusive prefix over the digits,
+// the earlier ones for its own offset; no scan launch, no atomics.  64-bit keys are sorted by a VIRTUAL key that packs their two bit fields
 // ([0, lo_bits) and [32, ..)) side by side: ceil((lo_bits + hi_bits) / 8) passes instead of one set per field.
 constexpr int RS_MAX_SEGS = 8;
 constexpr int RS_FUSED_MAX_TILES = 256;
@@ -170,7 +170,7 @@ struct SortSegs {
   int32_t lo_bits[RS_MAX_SEGS];  // 64-bit keys: width of the low field (>= 32: the key as it is)
   int32_t nseg;
 };
-// scratch words per segment: tile histograms + per-pass digit totals
+// scratch words per segment: tile histograms (+ slack)
 constexpr int64_t RS_SEG_WORDS = 256 * (int64_t)RS_FUSED_MAX_TILES + 256 * RS_MAX_PASSES;
 
 template <typename K>
@@ -194,7 +194,6 @@ __global__ __launch_bounds__(RS_THREADS) void rsb_hist_kernel(SortSegs<K> sg, in
   if (base >= n) return;
   const K* in = src_sel == 0 ? sg.in[seg] : (src_sel == 1 ? sg.out[seg] : sg.tmp[seg]);
   int32_t* hist = scratch + seg * RS_SEG_WORDS;
-  int32_t* total = hist + 256 * (int64_t)RS_FUSED_MAX_TILES + 256 * pass;
   h[threadIdx.x] = 0;
   __syncthreads();
   const int lo = sg.lo_bits[seg];
@@ -204,9 +203,7 @@ __global__ __launch_bounds__(RS_THREADS) void rsb_hist_kernel(SortSegs<K> sg, in
     if (p < n) atomicAdd(&h[vdigit<K>(in[p], lo, shift)], 1);
   }
   __syncthreads();
-  const int32_t c = h[threadIdx.x];
-  hist[(int64_t)blockIdx.x * 256 + threadIdx.x] = c;
-  if (c) atomicAdd(&total[threadIdx.x], c);
+  hist[(int64_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
 }
 
 template <typename K>
@@ -223,14 +220,40 @@ __global__ __launch_bounds__(RS_THREADS) void rsb_scatter_kernel(SortSegs<K> sg,
   const K* in = src_sel == 0 ? sg.in[seg] : (src_sel == 1 ? sg.out[seg] : sg.tmp[seg]);
   K* out = dst_sel == 1 ? sg.out[seg] : sg.tmp[seg];
   const int32_t* hist = scratch + seg * RS_SEG_WORDS;
-  const int32_t* total = hist + 256 * (int64_t)RS_FUSED_MAX_TILES + 256 * pass;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  {  // where this tile's run of digit `tid` starts: digits below it (all tiles) + the same digit in the earlier tiles
-    const int32_t t = total[tid];
+  // the tile's keys: all RS_ITEMS loads in flight before anything waits for one
+  K keys[RS_ITEMS];
+#pragma unroll
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const int64_t p = tb + i * RS_THREADS + tid;
+    keys[i] = p < n ? in[p] : (K)0;
+  }
+  {  // where this tile's run of digit `tid` starts: digits below it (all tiles) + the same digit in the earlier tiles.
+     // Every workgroup adds the tiles' histograms up itself (coalesced 1-KB rows, <= 256 of them, four in flight): no
+     // totals array, no atomics, no scan launch
+    const int n_tiles = (int)((n + RS_TILE - 1) / RS_TILE), me = (int)blockIdx.x;
+    int32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int tt = 0;
+    for (; tt + 3 < n_tiles; tt += 4) {
+      const int32_t v0 = hist[(int64_t)tt * 256 + tid], v1 = hist[(int64_t)(tt + 1) * 256 + tid],
+                    v2 = hist[(int64_t)(tt + 2) * 256 + tid], v3 = hist[(int64_t)(tt + 3) * 256 + tid];
+      a0 += v0;
+      a1 += v1;
+      a2 += v2;
+      a3 += v3;
+      e0 += tt < me ? v0 : 0;
+      e1 += tt + 1 < me ? v1 : 0;
+      e2 += tt + 2 < me ? v2 : 0;
+      e3 += tt + 3 < me ? v3 : 0;
+    }
+    for (; tt < n_tiles; ++tt) {
+      const int32_t v0 = hist[(int64_t)tt * 256 + tid];
+      a0 += v0;
+      e0 += tt < me ? v0 : 0;
+    }
+    const int32_t t = a0 + a1 + a2 + a3, earlier = e0 + e1 + e2 + e3;
     const int32_t incl = gigl_wave_incl_scan(t);
     if (lane == 63) wsum[w] = incl;
-    int32_t earlier = 0;
-    for (int tt = 0; tt < (int)blockIdx.x; ++tt) earlier += hist[(int64_t)tt * 256 + tid];
     __syncthreads();
     int32_t b0 = incl - t + earlier;
     for (int j = 0; j < w; ++j) b0 += wsum[j];
@@ -239,10 +262,11 @@ __global__ __launch_bounds__(RS_THREADS) void rsb_scatter_kernel(SortSegs<K> sg,
   }
   const int lo = sg.lo_bits[seg];
   const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
   for (int i = 0; i < RS_ITEMS; ++i) {
     const int64_t p = tb + i * RS_THREADS + tid;
     const bool valid = p < n;
-    const K k = valid ? in[p] : (K)0;
+    const K k = keys[i];
     const uint32_t d = vdigit<K>(k, lo, shift);
 #pragma unroll
     for (int j = 0; j < 4; ++j) wc[j][tid] = 0;
@@ -293,9 +317,6 @@ inline void gigl_radix_sort_batch(hipStream_t st, const SortSegs<K>& sg, int bit
     hipLaunchKernelGGL((rsb_copy_kernel<K>), dim3((unsigned)((nmax + 255) / 256), (unsigned)sg.nseg), dim3(256), 0, st, sg);
     return;
   }
-  // the per-pass digit totals of every segment, cleared in one launch (they sit behind each segment's histograms)
-  for (int s = 0; s < sg.nseg; ++s)
-    gigl_fill_u32(st, (uint32_t*)(scratch + s * RS_SEG_WORDS + 256 * (int64_t)RS_FUSED_MAX_TILES), 0u, 256 * RS_MAX_PASSES);
   int src = 0;  // 0 = in, 1 = out, 2 = tmp
   for (int d = 0; d < passes; ++d) {
     const int dst = ((passes - 1 - d) & 1) ? 2 : 1;  // the last pass lands in `out`
