@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void hgt_aggregate_kernel(const float* __restr
 
 // The same for NARROW rows (heads * dim <= 128 floats): a row's float4 chunks fill only G = heads * dim / 4 lanes, so a
 // wave takes 64 / G destination rows at once (one lane group each; the wave-per-row kernel above left three quarters of
-// its lanes idle at 64-wide rows) and two edges of every row are in flight per iteration.  Per row the same operations
+// its lanes idle at 64-wide rows); a row's edge list is fetched a chunk at a time by its lane group, four edges' rows are in
+// flight per step.  Per row the same operations
 // in the same order as hgt_aggregate_kernel: identical bits.
 template <int G>
 __global__ __launch_bounds__(256) void hgt_aggregate_packed_kernel(const float* __restrict__ q, const float* __restrict__ k,
@@ -128,15 +129,36 @@ __global__ __launch_bounds__(256) void hgt_aggregate_packed_kernel(const float* 
     acc.w = acc.w * r + w * vv.w;
     m = mn;
   };
+  // a chunk of up to G edges of the row at a time: their source rows and types are fetched by the group's lanes in one
+  // coalesced load each (not one dependent load per edge), then four edges' k / v rows are in flight per step
+  const int gbase = (lane / G) * G, gl = lane % G;
   while (__any(e < e1)) {
-    const bool on0 = e < e1, on1 = e + 1 < e1;
-    const int64_t j0 = on0 ? col[e] : 0, j1 = on1 ? col[e + 1] : 0;
-    const int t0 = (on0 && etype) ? etype[e] : 0, t1 = (on1 && etype) ? etype[e + 1] : 0;
-    const float4 k0 = on0 ? *(const float4*)(k + j0 * hd + c) : z4, v0 = on0 ? *(const float4*)(v + j0 * hd + c) : z4;
-    const float4 k1 = on1 ? *(const float4*)(k + j1 * hd + c) : z4, v1 = on1 ? *(const float4*)(v + j1 * hd + c) : z4;
-    fold(on0, k0, v0, t0);
-    fold(on1, k1, v1, t1);
-    e += 2;
+    const int32_t ce = e + gl;
+    const int32_t cj = ce < e1 ? col[ce] : 0;
+    const int32_t ct = (ce < e1 && etype) ? etype[ce] : 0;
+    const int32_t left = e1 - e;  // (<= 0 for a finished row)
+#pragma unroll 1
+    for (int x = 0; x < G; x += 4) {
+      if (!__any(x < left)) break;
+      int64_t jj[4];
+      int tt[4];
+      bool on[4];
+      float4 kk[4], vv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        on[u] = x + u < left;
+        jj[u] = __shfl(cj, gbase + x + u);
+        tt[u] = __shfl(ct, gbase + x + u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        kk[u] = on[u] ? *(const float4*)(k + jj[u] * hd + c) : z4;
+        vv[u] = on[u] ? *(const float4*)(v + jj[u] * hd + c) : z4;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fold(on[u], kk[u], vv[u], tt[u]);
+    }
+    e += G;
   }
   if (!row_ok) return;
   const float inv = s > 0.f ? 1.f / s : 0.f;

@@ -296,6 +296,25 @@ def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str,
                 # (HGT: the plan also lays out the layers' merged CSR by destination and the roots' rows of it)
                 et_ids = enc.convs[0].edge_types_map if is_hgt and len(enc.convs) else None
                 chunks = [np.asarray(order[i:i + b], dtype=np.int64) for i in range(0, order.size, b)]
+                # HGT encoders: the whole step — DAG sampler, typed batch graph, encoder, the roots' rows — is ONE library
+                # call per batch, replayed as a hipGraph (csrc/hgt_plan.hip; GIGL_AMD_TYPED_ONE_CALL=0: staged launches)
+                one_call = None
+                if is_hgt and chunks and os.environ.get("GIGL_AMD_TYPED_ONE_CALL", "1") != "0":
+                    from .models_hetero import HgtInferPlan
+                    try:
+                        one_call = HgtInferPlan(enc, s, node_type, dags[node_type], b)
+                    except NotImplementedError:
+                        one_call = None
+                if one_call is not None:
+                    try:
+                        for chunk in chunks:
+                            emb = one_call.run(torch.from_numpy(chunk.astype(np.uint32).view(np.int32)))
+                            torch.cuda.current_stream(dev).wait_stream(s.engine._stream)
+                            writer.add(chunk, emb, None)
+                        s.engine.synchronize()
+                    finally:
+                        one_call.close()
+                    chunks = []
                 issue = lambda c: s.batch_graph_plan_issue(c, node_type, dags[node_type], b_max=b, edge_type_ids=et_ids)
                 ticket = issue(chunks[0]) if chunks else None
                 for ci, chunk in enumerate(chunks):
