@@ -30,6 +30,7 @@ struct gigl_typed_plan {
   int32_t n_ops = 0, n_types = 0, n_slots = 0, root_type = 0, b_max = 0;
   std::vector<gigl_dag_op> ops;
   std::vector<int32_t> width;          // frontier slots per root of every op
+  std::vector<int64_t> window_end;     // per op: largest hash-window end any of its rows can reach (-1: unbounded)
   // device, per op: frontier [b][w], path sums [b][w], neighbours [b][w][f], counts [b][w], ran [b]
   std::vector<uint32_t*> front, ksum, nbr;
   std::vector<int32_t*> cnt;
@@ -374,6 +375,20 @@ int32_t gigl_typed_plan_create(gigl_ctx* ctx, const gigl_dag_op* ops, int32_t n_
     const int fb = key_bits(op.graph->n + 1);
     p->id_bits[op.frontier_node_type] = fb > p->id_bits[op.frontier_node_type] ? fb : p->id_bits[op.frontier_node_type];
   }
+  {  // every op's hash windows end below (frontier id + root id) + hash_add + the longest row: lets the sampler serve
+     // all of them from the threshold table (sample.hip) instead of hashing rows whose window it cannot place
+    int64_t n_root = 0;
+    for (int o = 0; o < n_ops; ++o)
+      if (p->ops[o].n_parents == 0 && p->ops[o].graph->n > n_root) n_root = p->ops[o].graph->n;
+    p->window_end.assign(n_ops, -1);
+    for (int o = 0; o < n_ops; ++o) {
+      const gigl_dag_op& op = p->ops[o];
+      if (op.hash_add < 0) continue;
+      const int64_t end = (op.graph->n > 0 ? op.graph->n - 1 : 0) + (n_root > 0 ? n_root - 1 : 0) + (int64_t)op.hash_add +
+                          op.graph->maxdeg;
+      if (end < ((int64_t)1 << 32)) p->window_end[o] = end;
+    }
+  }
   for (int t = 0; t < n_node_types; ++t) {  // a type that is never a frontier: nothing bounds its ids here
     bool frontier = false;
     for (int o = 0; o < n_ops; ++o) frontier |= p->ops[o].frontier_node_type == t;
@@ -475,7 +490,7 @@ int32_t gigl_typed_plan_run(gigl_typed_plan* p, const uint32_t* roots, int32_t b
     hipLaunchKernelGGL(dag_mask_kernel, dim3((unsigned)((b + TB / 64 - 1) / (TB / 64))), dim3(TB), 0, st, rs, roots,
                        (int64_t)b, w, p->front[o], p->ksum[o], p->ran[o]);
     const int32_t rc = gigl_expand_frontier(ctx, op.graph, p->front[o], p->ksum[o], (int64_t)b * w, op.fanout, op.hash_add, 1,
-                                            -1, p->nbr[o], p->cnt[o]);
+                                            p->window_end[o], p->nbr[o], p->cnt[o]);
     if (rc != GIGL_OK) return rc;
   }
   // ---- per node type: the distinct ids, ascending
