@@ -122,6 +122,14 @@ def test_all_ranks_in_one_process_end_to_end(world, project, dtype):
         e.close()
 
 
+@pytest.mark.parametrize("world,project,dtype", [(2, False, torch.float32), (3, "pre", torch.float16), (8, "pre", torch.float16)])
+def test_in_step_overlap_of_the_own_block_gives_the_same_batches(world, project, dtype, monkeypatch):
+    """GIGL_DIST_OVERLAP=1: a rank expands its OWN block of a hop's requests on a side stream while the peers' blocks are
+    exchanged, the peers' blocks on the main stream once they arrived (dist.hip: phase_impl) — trees and rows as without"""
+    monkeypatch.setenv("GIGL_DIST_OVERLAP", "1")
+    test_all_ranks_in_one_process_end_to_end(world, project, dtype)
+
+
 @pytest.mark.parametrize("world,dtype", [(2, torch.float32), (8, torch.float16)])
 def test_replicated_hot_rows_are_not_pulled(world, dtype, pre=False):
     """hub-row replication (gigl_dist_plan_set_hot_rows): the most-referenced nodes' rows are kept on every rank and read
