@@ -296,7 +296,9 @@ class HipGraphDBSampler:
                 tab = self._feature_table(t)
                 x_dict[t] = tab.index_select(0, u) if tab is not None else torch.ones((u.numel(), 1), device=dev)
             ei = {}
-            for et, ps in pairs.items():
+            # (edge types in condensed-type order, like the trainer-side collate's batches: an encoder that numbers the
+            # batch's edge types by their order — SimpleHGN's to_homogeneous() — then sees the same numbering)
+            for et, ps in sorted(pairs.items(), key=lambda kv: self.condensed_edge_types[kv[0]]):
                 p2 = torch.cat(ps, dim=1)
                 src = torch.searchsorted(uniq[et.src_node_type], p2[0])
                 dst = torch.searchsorted(uniq[et.dst_node_type], p2[1])
@@ -304,7 +306,36 @@ class HipGraphDBSampler:
                 nd = int(uniq[et.dst_node_type].numel())
                 ei[(et.src_node_type, et.relation, et.dst_node_type)] = torch.stack([key // nd, key % nd])
             root_index = torch.searchsorted(uniq[root_node_type], roots)
-        return HeteroGraphData(x_dict, ei), root_index, uniq
+            graph = HeteroGraphData(x_dict, ei)
+            self._attach_edge_attr(graph, uniq)
+        return graph, root_index, uniq
+
+    def _attach_edge_attr(self, graph, uniq: Dict[str, torch.Tensor]) -> None:
+        """edge_attr_dict of a batch graph built in HBM: for every edge type that carries features, the feature row of
+        each batch edge (Edge.feature_values of the typed samples, hydrateEdges of the sampler) — the edge's position
+        in the type's resident CSR-by-source (binary search in the source's row: gigl_edge_ids) selects the row of the
+        table load_label_edges laid out in that order.  What the trainer-side collate takes from the records' edge
+        features (abstract_graph_builder.py:100-150: add_edge(feature_values))."""
+        import ctypes as C
+        from . import _lib
+        eng = self.engine
+        for et, has in self._has_edge_feats.items():
+            key3 = (et.src_node_type, et.relation, et.dst_node_type)
+            ei = graph.edge_index_dict.get(key3)
+            if not has or ei is None:
+                continue
+            entry = eng._label_edges[self._key(et, OUTGOING)]
+            table = entry["table"]
+            src_g = uniq[et.src_node_type][ei[0]].to(torch.int32).contiguous()
+            dst_g = uniq[et.dst_node_type][ei[1]].to(torch.int32).contiguous()
+            eid = torch.empty(int(src_g.numel()), dtype=torch.int64, device=eng.device)
+            # (the by-source graph has rows = sources, columns = destinations: roles swapped, as load_label_edges builds it)
+            _lib.check(eng._lib.gigl_edge_ids(eng._ctx, entry["graph"], C.c_void_p(dst_g.data_ptr()),
+                                              C.c_void_p(src_g.data_ptr()), int(src_g.numel()), C.c_void_p(eid.data_ptr())),
+                       eng._ctx)
+            rows = table.index_select(0, eid.clamp(min=0))
+            rows.masked_fill_((eid < 0).unsqueeze(1), 0.0)
+            graph.edge_attr_dict[key3] = rows
 
     # ---- the same batch graph from the library's one-call plan (gigl_typed_plan_*, csrc/typed_plan.hip): the ops, the
     #      per-type distinct ids and the per-edge-type distinct edges are one stream of device work; the host reads
@@ -391,9 +422,10 @@ class HipGraphDBSampler:
             ticket["counts"], ticket["event"] = host, ev
             if edge_type_ids is not None:
                 used = [i for i, t in enumerate(pl["types"]) if int(out.nodes_cap[i]) > 0]
-                slot_ets = [(et.src_node_type, et.relation, et.dst_node_type) for et in pl["slots"]]
+                by_type = sorted(pl["slots"], key=lambda et: self.condensed_edge_types[et])
+                slot_ets = [(et.src_node_type, et.relation, et.dst_node_type) for et in by_type]
                 t_arr = (C.c_int32 * len(used))(*used)
-                s_arr = (C.c_int32 * len(slot_ets))(*[pl["slots"][et] for et in pl["slots"]])
+                s_arr = (C.c_int32 * len(slot_ets))(*[pl["slots"][et] for et in by_type])
                 e_arr = (C.c_int32 * len(slot_ets))(*[int(edge_type_ids[k]) for k in slot_ets])
                 csr = _lib.GiglTypedCsrOut()
                 _lib.check(eng._lib.gigl_typed_plan_merged_csr(pl["plan"], b, t_arr, len(used), s_arr, e_arr, len(slot_ets),
@@ -422,12 +454,13 @@ class HipGraphDBSampler:
                 uniq[t] = u
                 tab = self._feature_table(t)
                 x_dict[t] = tab.index_select(0, u) if tab is not None else torch.ones((n_t, 1), device=dev)
-            for et, sl in pl["slots"].items():
+            for et, sl in sorted(pl["slots"].items(), key=lambda kv: self.condensed_edge_types[kv[0]]):
                 n_e = int(h[nt + sl])
                 keys = _wrap(out.edges[sl], n_e, torch.int64, dev)
                 ei[(et.src_node_type, et.relation, et.dst_node_type)] = torch.stack([keys >> 32, keys & 0xFFFFFFFF])
             root_index = _wrap(out.root_index, b, torch.int32, dev).to(torch.int64)
             graph = HeteroGraphData(x_dict, ei)
+            self._attach_edge_attr(graph, uniq)
             if ticket.get("csr") is not None:
                 csr, used, slot_ets, edge_type_ids = ticket["csr"], ticket["used"], ticket["slot_ets"], ticket["edge_type_ids"]
                 n_dst = sum(int(h[i]) for i in used)

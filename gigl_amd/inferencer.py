@@ -270,14 +270,15 @@ def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str,
     inner = inferencer.model.module if hasattr(inferencer.model, "module") else inferencer.model
     enc = getattr(inner, "_encoder", getattr(inner, "encoder", inner))
     is_hgt = type(enc).__name__ == "HGT"  # (HGT takes the row subset; the link-prediction wrapper passes it through)
-    if type(enc).__name__ != "HGT" and any(np.asarray(v).size for v in (efeats or {}).values()):
-        raise NotImplementedError("an encoder that reads edge features takes the TFRecord route (the in-HBM typed batch "
-                                  "graph carries no edge attributes)")
     dags = sampling_op_dags(cfg, wanted)
     # the sampler job's rule (SubgraphSampler.run): "deterministic" = the hash permutation under seed 42 — the samples of
     # its files, so both routes see the same neighbourhoods; anything else = a fresh uniform sample per job
     seed = 42 if cfg.permutation_strategy == "deterministic" else 1 + int.from_bytes(os.urandom(3), "little") % ((1 << 20) - 1)
-    s = HipGraphDBSampler(node_types, num, edges, cet, feats, device=dev.index or 0, sampling_seed=seed)  # (no edge rows)
+    # (edge feature rows ride along for the encoders that read them — SimpleHGN's attention: the batch graph's
+    # edge_attr_dict, joined on the device; HGT ignores them)
+    has_ef = (not is_hgt) and any(np.asarray(v).size for v in (efeats or {}).values())
+    s = HipGraphDBSampler(node_types, num, edges, cet, feats, device=dev.index or 0, sampling_seed=seed,
+                          edge_features=efeats if has_ef else None)
     out_files: Dict[str, str] = {}
     n_rows = 0
     b = int(cfg.inference_batch_size)

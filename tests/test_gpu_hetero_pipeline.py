@@ -129,8 +129,10 @@ def test_trainer_then_inferencer_on_the_typed_graph(workdir):
         assert all(len(r["emb"]) == 8 and np.isfinite(r["emb"]).all() for r in rows)
 
 
-def test_typed_in_hbm_route_matches_the_tfrecord_route(golden_dir, tmp_path_factory):
-    """Inferencer.run(route="hbm") on a typed job: the typed tables resident in HBM, every batch's typed graph built by
+@pytest.mark.parametrize("encoder", ["HGT", "SimpleHGN"])
+def test_typed_in_hbm_route_matches_the_tfrecord_route(golden_dir, tmp_path_factory, encoder):
+    """(SimpleHGN reads the typed EDGE features: the in-HBM batch graph joins them on the device, edge_attr_dict.)
+    Inferencer.run(route="hbm") on a typed job: the typed tables resident in HBM, every batch's typed graph built by
     the library's one-call plan (gigl_typed_plan_*), HGT over it — against the TFRecord route (the sampler's typed
     RootedNodeNeighborhood files, typed native collate) on the same trained model: the same roots in the same batches,
     rows equal up to fp32 summation order.  (permutation_strategy = deterministic: both routes sample under seed 42.)"""
@@ -147,7 +149,7 @@ def test_typed_in_hbm_route_matches_the_tfrecord_route(golden_dir, tmp_path_fact
     args = {"hidden_dim": "16", "out_channels": "8", "num_heads": "2", "main_sample_batch_size": "6",
             "random_negative_sample_batch_size": "5", "random_negative_sample_batch_size_for_evaluation": "5",
             "val_every_num_batches": "2", "num_val_batches": "2", "num_test_batches": "2", "early_stop_patience": "50",
-            "optim_lr": "0.02", "gnn_model_class_path": "gigl_amd.models_hetero.HGT"}
+            "optim_lr": "0.02", "gnn_model_class_path": "gigl_amd.models_hetero." + encoder}
     doc["trainerConfig"] = {"trainerClsPath": spec, "trainerArgs": dict(args)}
     doc["inferencerConfig"] = {"inferencerClsPath": spec, "inferencerArgs": dict(args), "inferenceBatchSize": 8}
     doc["sharedConfig"]["trainedModelMetadata"] = {"trainedModelUri": "out/hetero_train/model.pt",
