@@ -272,43 +272,84 @@ class HipGraphDBSampler:
         dev = eng.device
         roots = torch.tensor(np.asarray(root_ids, dtype=np.int64), device=dev)
         res = self.run_dag(roots.to(torch.int32), dag)
-        b = int(roots.numel())
-        ids: Dict[str, List[torch.Tensor]] = {root_node_type: [roots]}
+        graph, uniq = self._merge_dag_results([(dag, res)], {root_node_type: [roots]})
+        with torch.cuda.stream(eng._stream):
+            root_index = torch.searchsorted(uniq[root_node_type], roots)
+        return graph, root_index, uniq
+
+    def _merge_dag_results(self, parts, extra_ids: Dict[str, List[torch.Tensor]]):
+        """the batch graph of several DAG runs (parts: [(dag, {op name: OpResult})]) plus `extra_ids` per node type (the
+        roots): per type the distinct ids ascending = local numbering, per edge type the distinct edges, feature rows,
+        edge attributes -> (HeteroGraphData, {type: global ids})"""
+        from .models_hetero import HeteroGraphData
+        eng = self.engine
+        dev = eng.device
+        ids: Dict[str, List[torch.Tensor]] = {t: list(v) for t, v in extra_ids.items()}
         pairs: Dict[EdgeType, List[torch.Tensor]] = {}
         with torch.cuda.stream(eng._stream):
-            for name, r in res.items():
-                op = dag.nodes[name].sampling_op
-                outgoing = op.sampling_direction == OUTGOING
-                et = op.edge_type
-                front_t = et.src_node_type if outgoing else et.dst_node_type
-                got_t = et.dst_node_type if outgoing else et.src_node_type
-                w, f = int(r.frontier.shape[1]), int(r.nbr.shape[2])
-                fr = (r.frontier.to(torch.int64) & 0xFFFFFFFF).view(b, w, 1).expand(b, w, f).reshape(-1)
-                nb = (r.nbr.to(torch.int64) & 0xFFFFFFFF).reshape(-1)
-                ok = (nb != INVALID) & (fr != INVALID)
-                fr, nb = fr[ok], nb[ok]
-                ids.setdefault(front_t, []).append(fr)
-                ids.setdefault(got_t, []).append(nb)
-                pairs.setdefault(et, []).append(torch.stack([fr, nb] if outgoing else [nb, fr]))
+            for dag, res in parts:
+                for name, r in res.items():
+                    op = dag.nodes[name].sampling_op
+                    outgoing = op.sampling_direction == OUTGOING
+                    et = op.edge_type
+                    front_t = et.src_node_type if outgoing else et.dst_node_type
+                    got_t = et.dst_node_type if outgoing else et.src_node_type
+                    b, w, f = int(r.frontier.shape[0]), int(r.frontier.shape[1]), int(r.nbr.shape[2])
+                    fr = (r.frontier.to(torch.int64) & 0xFFFFFFFF).view(b, w, 1).expand(b, w, f).reshape(-1)
+                    nb = (r.nbr.to(torch.int64) & 0xFFFFFFFF).reshape(-1)
+                    ok = (nb != INVALID) & (fr != INVALID)
+                    fr, nb = fr[ok], nb[ok]
+                    ids.setdefault(front_t, []).append(fr)
+                    ids.setdefault(got_t, []).append(nb)
+                    pairs.setdefault(et, []).append(torch.stack([fr, nb] if outgoing else [nb, fr]))
             uniq = {t: torch.unique(torch.cat(v)) for t, v in ids.items()}  # sorted: local id = rank
             x_dict = {}
-            for t, u in uniq.items():
+            for t in sorted(uniq, key=lambda t_: self.node_types[t_]):
+                u = uniq[t]
                 tab = self._feature_table(t)
                 x_dict[t] = tab.index_select(0, u) if tab is not None else torch.ones((u.numel(), 1), device=dev)
             ei = {}
-            # (edge types in condensed-type order, like the trainer-side collate's batches: an encoder that numbers the
-            # batch's edge types by their order — SimpleHGN's to_homogeneous() — then sees the same numbering)
-            for et, ps in sorted(pairs.items(), key=lambda kv: self.condensed_edge_types[kv[0]]):
+            # (EVERY edge type of the graph, in condensed-type order, like the trainer-side collate's batches — a type
+            # without edges in the batch keeps an empty list: an encoder that numbers the batch's edge types by their
+            # order, SimpleHGN's to_homogeneous(), then sees the same numbering on both routes)
+            for et, _c in sorted(self.condensed_edge_types.items(), key=lambda kv: kv[1]):
+                ps = pairs.get(et)
+                if ps is None or et.src_node_type not in uniq or et.dst_node_type not in uniq:
+                    ei[(et.src_node_type, et.relation, et.dst_node_type)] = torch.zeros((2, 0), dtype=torch.int64, device=dev)
+                    continue
                 p2 = torch.cat(ps, dim=1)
                 src = torch.searchsorted(uniq[et.src_node_type], p2[0])
                 dst = torch.searchsorted(uniq[et.dst_node_type], p2[1])
                 key = torch.unique(src * int(uniq[et.dst_node_type].numel()) + dst)
                 nd = int(uniq[et.dst_node_type].numel())
                 ei[(et.src_node_type, et.relation, et.dst_node_type)] = torch.stack([key // nd, key % nd])
-            root_index = torch.searchsorted(uniq[root_node_type], roots)
             graph = HeteroGraphData(x_dict, ei)
             self._attach_edge_attr(graph, uniq)
-        return graph, root_index, uniq
+        return graph, uniq
+
+    def nablp_batch_graph(self, root_ids: Sequence[int], positive_edge_type: EdgeType, num_positives: int,
+                          root_dag: SamplingOpDAG, positive_dag: SamplingOpDAG):
+        """a typed link-prediction TRAINING batch in HBM: the batch graph the trainer-side collate builds from the typed
+        NodeAnchorBasedLinkPredictionSamples of `root_ids` (each sample's neighbourhood = its root's merged with its
+        positives': GraphDBNodeAnchorBasedLinkPredictionTask.scala:118-496, getNablpSamplesForRootNodes above) without the
+        samples becoming records -> (graph, root_index int64 [b] into the source type, pos_local int64 [b, P] local ids in
+        the destination type (-1: no such positive), {type: global ids})"""
+        eng = self.engine
+        roots, res, pos, pos_res = self._run_nablp(root_ids, positive_edge_type, num_positives, root_dag, positive_dag)
+        b, P = len(root_ids), int(num_positives)
+        with torch.cuda.stream(eng._stream):
+            r64 = roots.to(torch.int64) & 0xFFFFFFFF
+            p64 = (pos.nbr.to(torch.int64) & 0xFFFFFFFF).view(b, P)
+            valid = p64 != INVALID
+        extra = {positive_edge_type.src_node_type: [r64]}
+        extra.setdefault(positive_edge_type.dst_node_type, []).append(p64[valid])
+        graph, uniq = self._merge_dag_results([(root_dag, res), (positive_dag, pos_res)], extra)
+        with torch.cuda.stream(eng._stream):
+            root_index = torch.searchsorted(uniq[positive_edge_type.src_node_type], r64)
+            u_dst = uniq[positive_edge_type.dst_node_type]
+            loc = torch.searchsorted(u_dst, p64.clamp(max=int(u_dst[-1]) if u_dst.numel() else 0))
+            pos_local = torch.where(valid, loc, torch.full_like(loc, -1))
+        return graph, root_index, pos_local, uniq
 
     def _attach_edge_attr(self, graph, uniq: Dict[str, torch.Tensor]) -> None:
         """edge_attr_dict of a batch graph built in HBM: for every edge type that carries features, the feature row of
@@ -322,7 +363,7 @@ class HipGraphDBSampler:
         for et, has in self._has_edge_feats.items():
             key3 = (et.src_node_type, et.relation, et.dst_node_type)
             ei = graph.edge_index_dict.get(key3)
-            if not has or ei is None:
+            if not has or ei is None or et.src_node_type not in uniq or et.dst_node_type not in uniq:
                 continue
             entry = eng._label_edges[self._key(et, OUTGOING)]
             table = entry["table"]
@@ -454,7 +495,11 @@ class HipGraphDBSampler:
                 uniq[t] = u
                 tab = self._feature_table(t)
                 x_dict[t] = tab.index_select(0, u) if tab is not None else torch.ones((n_t, 1), device=dev)
-            for et, sl in sorted(pl["slots"].items(), key=lambda kv: self.condensed_edge_types[kv[0]]):
+            for et, _c in sorted(self.condensed_edge_types.items(), key=lambda kv: kv[1]):
+                sl = pl["slots"].get(et)
+                if sl is None:  # (no op samples this edge type: an empty list, like the collate's batches)
+                    ei[(et.src_node_type, et.relation, et.dst_node_type)] = torch.zeros((2, 0), dtype=torch.int64, device=dev)
+                    continue
                 n_e = int(h[nt + sl])
                 keys = _wrap(out.edges[sl], n_e, torch.int64, dev)
                 ei[(et.src_node_type, et.relation, et.dst_node_type)] = torch.stack([keys >> 32, keys & 0xFFFFFFFF])
@@ -554,16 +599,25 @@ class HipGraphDBSampler:
                                  f"ops. Mismatch for {name}")
         eng = self.engine
         roots = torch.tensor(np.asarray(root_ids, dtype=np.int64).astype(np.uint32).view(np.int32)).to(eng.device)
-        b, P = int(roots.numel()), int(num_positives)
         res = self.run_dag(roots, root_dag)
+        pos = self.sample_positives(roots, positive_edge_type, num_positives, root_dag)
+        pos_res = self.run_dag(pos.nbr.reshape(-1), positive_dag)  # INVALID positives sample nothing
+        return roots, res, pos, pos_res
+
+    def sample_positives(self, root_ids, positive_edge_type: EdgeType, num_positives: int, root_dag: SamplingOpDAG) -> OpResult:
+        """the positive-edge op of the typed link-prediction samples alone: `num_positives` OUTGOING neighbours of every
+        root along the supervision edge type (K = 2 * root id, counter 1 + the number of ops of the root's DAG)"""
+        eng = self.engine
+        roots = root_ids if isinstance(root_ids, torch.Tensor) else \
+            torch.tensor(np.asarray(root_ids, dtype=np.int64).astype(np.uint32).view(np.int32))
+        roots = roots.to(device=eng.device, dtype=torch.int32).contiguous()
+        b, P = int(roots.numel()), int(num_positives)
         front = roots.view(b, 1).contiguous()
         ksum = (front + roots.view(b, 1)).contiguous()
         counter = 1 + len(root_dag.op_order)
         nbr, cnt = eng.expand_frontier(front.view(-1), ksum.view(-1), P, self.sampling_seed * counter, 1,
                                        label_edges=self._key(positive_edge_type, OUTGOING))
-        pos = OpResult(front, nbr.view(b, 1, P), cnt.view(b, 1))
-        pos_res = self.run_dag(nbr.reshape(-1), positive_dag)  # INVALID positives sample nothing
-        return roots, res, pos, pos_res
+        return OpResult(front, nbr.view(b, 1, P), cnt.view(b, 1))
 
     def getNablpSamplesForRootNodes(self, root_ids: Sequence[int], positive_edge_type: EdgeType, num_positives: int,
                                     root_dag: SamplingOpDAG, positive_dag: SamplingOpDAG

@@ -456,19 +456,23 @@ class HGT(nn.Module):
                         if x.shape[0] else x.new_zeros((0, lin.weight.shape[0])))
         csr_cache: dict = {}  # (the merged CSR by destination is the graph's: built by the first layer, reused by the rest)
         mc = getattr(data, "merged_csr", None)
+        edge_index_dict = data.edge_index_dict
         if mc is not None and self.convs and mc["node_types"] == list(x_dict) and \
-                mc["edge_types"] == [tuple(e) for e in data.edge_index_dict] and \
+                mc["edge_types"] == [tuple(e) for e, v in edge_index_dict.items()
+                                     if tuple(e) in mc["edge_type_ids"] or v.shape[1]] and \
                 all(self.convs[0].edge_types_map.get(k) == v for k, v in mc["edge_type_ids"].items()):
-            # the typed plan already merged the batch's edges by destination (gigl_typed_plan_merged_csr)
+            # the typed plan already merged the batch's edges by destination (gigl_typed_plan_merged_csr) over the edge
+            # types its ops sample; the graph's other edge types are empty in the batch and take no part
             csr_cache["csr"] = mc["csr"]
             csr_cache["root"] = (mc["root_type"], mc["root_index"], mc["root_csr"])
+            edge_index_dict = {e: v for e, v in edge_index_dict.items() if tuple(e) in mc["edge_type_ids"]}
         subset = None
         if row_subset is not None and not torch.is_grad_enabled():
             subset = {t: row_subset[t] for t in output_node_types if t in row_subset and t in h}
             if len(subset) != len(output_node_types):
                 subset = None
         for li, conv in enumerate(self.convs):
-            h = conv(h, data.edge_index_dict, csr_cache, subset if li == len(self.convs) - 1 else None)
+            h = conv(h, edge_index_dict, csr_cache, subset if li == len(self.convs) - 1 else None)
         out = {}
         for t in output_node_types:
             out[t] = (_linear(eng, h[t], self.lin.weight, self.lin.bias) if t in h

@@ -641,7 +641,99 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
             self._hbm_anchors[sp] = (ids[m], n_pos[m])
         return self._hbm_anchors
 
+    def _hbm_typed(self, cfg: GbmlConfigPbWrapper):
+        """the typed (heterogeneous) link-prediction job on the in-HBM route: -> {"sampler", "dags", "pos_et", "splits":
+        {split: root ids}} when the typed tables are resident in HBM and every training batch is sampled there
+        (graphdb_sampler.nablp_batch_graph / batch_graph), else None.  Asked for explicitly (data_route / GIGL_AMD_ROUTE =
+        hbm: `auto` keeps typed graphs on TFRecords), one process, no split-generator output; the roots of a split and
+        their order are those of the TFRecord route without split files — the sampler's typed main samples (roots of the
+        supervision edge type's source type with at least one sampled positive, numMaxTrainingSamplesToOutput applied)
+        in file order, root id % 10 (0-7 train, 8 val, 9 test), fewer than 100 samples whole in every split."""
+        if getattr(self, "_hbm_typed_state", None) is not None:
+            return self._hbm_typed_state or None
+        self._hbm_typed_state = {}
+        import os
+        from .hbm import planned_root_order, route_of
+        device = getattr(self, "_device", None)
+        if not cfg.is_heterogeneous or device is None or device.type != "cuda" or _rank_world()[1] > 1 or \
+                (self._kwargs.get("data_route") or os.environ.get("GIGL_AMD_ROUTE") or "auto").lower() != "hbm":
+            return None
+        if any((cfg.dataset_split_uri(sp) and tfrecord_files(cfg.dataset_split_uri(sp))) for sp in ("train", "val", "test")):
+            return None
+        from .graphdb_sampler import EdgeType, HipGraphDBSampler
+        from .subgraph_sampler import load_preprocessed_typed_graph, sampling_op_dags
+        pos_et = EdgeType(*cfg.supervision_edge_types[0])
+        node_types, num, ids, feats, edges, cet, efeats = load_preprocessed_typed_graph(cfg)
+        seed = 42 if cfg.permutation_strategy == "deterministic" else 1 + int.from_bytes(os.urandom(3), "little") % ((1 << 20) - 1)
+        smp = HipGraphDBSampler(node_types, num, edges, cet, feats, device=device.index or 0, sampling_seed=seed,
+                                edge_features=efeats)
+        dags = sampling_op_dags(cfg, list(dict.fromkeys([pos_et.src_node_type, pos_et.dst_node_type])))
+        # the sampler job's main samples (SubgraphSampler._run_graphdb_nablp): which roots have one, in which order
+        roots = np.asarray(ids[pos_et.src_node_type], dtype=np.int64)
+        cap = cfg.num_max_training_samples_to_output
+        if 0 < cap < roots.size:
+            roots = np.sort(np.random.default_rng(seed).choice(roots, size=cap, replace=False))
+        if not cfg.should_include_isolated_nodes_in_training:
+            keep = []
+            for lo in range(0, roots.size, 1 << 16):
+                chunk = roots[lo:lo + (1 << 16)]
+                pos = smp.sample_positives(chunk, pos_et, cfg.num_positive_samples, dags[pos_et.src_node_type])
+                keep.append((pos.nbr.view(chunk.size, -1) != -1).any(dim=1).cpu().numpy())
+            roots = roots[np.concatenate(keep)] if keep else roots
+        order = planned_root_order(roots, cfg.nablp_tfrecord_uri_prefix)
+        splits = {}
+        for sp, want in (("train", range(0, 8)), ("val", (8,)), ("test", (9,))):
+            m = np.isin(order % 10, list(want)) if order.size >= 100 else np.ones(order.size, dtype=bool)
+            splits[sp] = order[m]
+        dst_t = pos_et.dst_node_type
+        prefix = cfg.random_negative_tfrecord_uri_prefixes.get(dst_t)
+        rn_order = planned_root_order(np.asarray(ids[dst_t], dtype=np.int64), prefix) if prefix else np.asarray(ids[dst_t], dtype=np.int64)
+        self._hbm_typed_state = {"sampler": smp, "dags": dags, "pos_et": pos_et, "splits": splits, "rn_order": rn_order}
+        self._resident = smp  # (what GnnTrainingProcess reports as the route; closed with the spec)
+        return self._hbm_typed_state
+
+    def _typed_main_batches_hbm(self, cfg: GbmlConfigPbWrapper, st: dict, split: str, loop: bool):
+        from .batches import HeteroNodeAnchorBasedLinkPredictionBatch
+        smp, dags, pos_et = st["sampler"], st["dags"], st["pos_et"]
+        roots, bs, P = st["splits"][split], self.main_sample_batch_size, cfg.num_positive_samples
+        name_to_cnt = {v: k for k, v in cfg.condensed_node_type_map.items()}
+        cet = [c for c, triple in cfg.condensed_edge_type_map.items() if tuple(triple) == (pos_et.src_node_type, pos_et.relation, pos_et.dst_node_type)][0]
+        spans = [(lo, min(lo + bs, roots.size)) for lo in range(0, roots.size, bs)]
+        for lo, hi in (cycle(spans) if (loop and spans) else spans):
+            chunk = roots[lo:hi]
+            graph, root_index, pos_local, uniq = smp.nablp_batch_graph(chunk, pos_et, P, dags[pos_et.src_node_type],
+                                                                       dags[pos_et.dst_node_type])
+            smp.engine.synchronize()
+            pl = pos_local.cpu()
+            yield HeteroNodeAnchorBasedLinkPredictionBatch(
+                graph=graph, root_condensed_node_type=name_to_cnt[pos_et.src_node_type], root_node_indices=root_index.cpu(),
+                pos_targets={cet: [row[row >= 0] for row in pl]}, hard_neg_targets={},
+                condensed_node_type_to_subgraph_id_to_global_node_id={name_to_cnt[t]: u.cpu().numpy().astype(np.int64)
+                                                                      for t, u in uniq.items()})
+
+    def _typed_rn_batches_hbm(self, cfg: GbmlConfigPbWrapper, st: dict, batch_size: int):
+        from .batches import HeteroRootedNodeNeighborhoodBatch
+        smp, dags, dst_t = st["sampler"], st["dags"], st["pos_et"].dst_node_type
+        name_to_cnt = {v: k for k, v in cfg.condensed_node_type_map.items()}
+        order = st["rn_order"]
+        while order.size:
+            for lo in range(0, order.size, batch_size):
+                chunk = order[lo:lo + batch_size]
+                graph, root_index, uniq = smp.batch_graph(chunk, dst_t, dags[dst_t])
+                smp.engine.synchronize()
+                c = name_to_cnt[dst_t]
+                yield HeteroRootedNodeNeighborhoodBatch(
+                    graph=graph, condensed_node_type_to_root_node_indices_map={c: root_index.cpu()},
+                    root_nodes=[(c, int(v)) for v in chunk.tolist()],
+                    condensed_node_type_to_subgraph_id_to_global_node_id={
+                        name_to_cnt[t]: dict(enumerate(u.cpu().tolist())) for t, u in uniq.items()})
+
     def close(self) -> None:
+        st = getattr(self, "_hbm_typed_state", None)
+        if st:
+            st["sampler"].close()
+            self._hbm_typed_state = None
+            self._resident = None
         if self._resident is not None:
             self._resident.close()  # (its engine is the spec's engine on this route)
             self._resident = None
@@ -659,6 +751,10 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         rank, world = _rank_world()
         uri = cfg.dataset_split_uri(split)
         if cfg.is_heterogeneous:
+            st = self._hbm_typed(cfg)
+            if st is not None:
+                yield from self._typed_main_batches_hbm(cfg, st, split, loop)
+                return
             from .batches import HeteroNodeAnchorBasedLinkPredictionBatch
             files = tfrecord_files(uri) if uri and tfrecord_files(uri) else tfrecord_files(cfg.nablp_tfrecord_uri_prefix)
             raw = [b for chunk in iterate_tfrecord_batches(files, 10 ** 9, rank=rank, world_size=world) for b in chunk]
@@ -698,6 +794,10 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         rank, world = _rank_world()
         split_uris = cfg.random_negative_split_uris(split)
         if cfg.is_heterogeneous:  # random negatives of the supervision edge type's destination node type
+            st = self._hbm_typed(cfg)
+            if st is not None:
+                yield from self._typed_rn_batches_hbm(cfg, st, batch_size)
+                return
             from .batches import HeteroRootedNodeNeighborhoodBatch
             dst_t = cfg.supervision_edge_types[0][2]
             prefix = split_uris.get(dst_t)

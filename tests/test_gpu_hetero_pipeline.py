@@ -174,3 +174,50 @@ def test_typed_in_hbm_route_matches_the_tfrecord_route(golden_dir, tmp_path_fact
         assert sorted(r["node_id"] for r in rows) == list(range(n)) == sorted(first[t])
         for r in rows:
             np.testing.assert_allclose(r["emb"], first[t][r["node_id"]], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("encoder", ["HGT", "SimpleHGN"])
+def test_typed_trainer_in_hbm_route_matches_the_tfrecord_route(golden_dir, tmp_path_factory, encoder):
+    """the typed link-prediction TRAINER with data_route = hbm: main batches (anchors + sampled positives, the union of
+    their DAG neighbourhoods: graphdb_sampler.nablp_batch_graph) and random-negative batches sampled in HBM from the
+    resident typed tables, against the same job over the sampler's typed TFRecords — same anchors per batch, same
+    positives, batch graphs equal as node / edge sets (edge features joined on the device), so the loss history, the
+    trained weights and the test metrics agree up to fp32 summation order (gradients are summed by atomics)"""
+    from gigl_amd.subgraph_sampler import SubgraphSampler
+    from gigl_amd.trainer import Trainer
+    base = tmp_path_factory.mktemp("gigl_hetero_train_routes")
+    shutil.copytree(os.path.join(golden_dir, "configs"), base / "configs")
+    shutil.copytree(os.path.join(golden_dir, "ref_assets"), base / "ref_assets")
+    doc = yaml.safe_load(open(base / "configs" / "hetero_nablp_frozen_gbml_config.yaml"))
+    doc["datasetConfig"]["subgraphSamplerConfig"]["numPositiveSamples"] = 2
+    doc["datasetConfig"]["subgraphSamplerConfig"].setdefault("experimentalFlags", {})["permutation_strategy"] = "deterministic"
+    spec = "gigl_amd.nablp_spec.HipNodeAnchorLinkPredictionSpec"
+    args = {"hidden_dim": "16", "out_channels": "8", "num_heads": "2", "main_sample_batch_size": "6",
+            "random_negative_sample_batch_size": "5", "random_negative_sample_batch_size_for_evaluation": "5",
+            "val_every_num_batches": "2", "num_val_batches": "2", "num_test_batches": "2", "early_stop_patience": "50",
+            "optim_lr": "0.005", "gnn_model_class_path": "gigl_amd.models_hetero." + encoder}
+    doc["sharedConfig"]["trainedModelMetadata"] = {"trainedModelUri": "out/hetero_routes/model.pt",
+                                                   "evalMetricsUri": "out/hetero_routes/eval_metrics.json"}
+    wd = str(base)
+    runs = {}
+    for route in ("tfrecord", "hbm"):
+        doc["trainerConfig"] = {"trainerClsPath": spec, "trainerArgs": dict(args, data_route=route)}
+        doc["inferencerConfig"] = {"inferencerClsPath": spec, "inferencerArgs": dict(args), "inferenceBatchSize": 8}
+        yaml.safe_dump(doc, open(base / CFG, "w"))
+        if route == "tfrecord":
+            SubgraphSampler().run("job", CFG, None, uri_base=wd)
+        seed_trainer()
+        tr = Trainer()
+        metrics = tr.run("job", CFG, None, uri_base=wd)
+        assert tr.training_process.route == route
+        cfg = GbmlConfigPbWrapper.from_uri(CFG, uri_base=wd)
+        runs[route] = ([h["loss"] for h in tr.training_process.trainer.history],
+                       torch.load(cfg.trained_model_uri, map_location="cpu"), {k: m.value for k, m in metrics.metrics.items()})
+    (h_t, sd_t, m_t), (h_h, sd_h, m_h) = runs["tfrecord"], runs["hbm"]
+    assert len(h_t) == len(h_h) >= 2
+    np.testing.assert_allclose(h_h, h_t, rtol=2e-3)
+    # (Adam turns a gradient component that is zero up to summation noise into a step of +-lr: weights are compared within
+    # a few such steps, the losses they produce much more tightly)
+    for k in sd_t:
+        np.testing.assert_allclose(sd_h[k].numpy(), sd_t[k].numpy(), rtol=2e-2, atol=0.02)
+    np.testing.assert_allclose(m_h["loss"], m_t["loss"], rtol=5e-3)
