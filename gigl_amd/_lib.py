@@ -10,7 +10,8 @@ import os
 
 GIGL_INVALID = 0xFFFFFFFF
 GIGL_MAX_HOPS = 4
-GIGL_MAX_FANOUT = 64
+GIGL_FAST_FANOUT = 64
+GIGL_MAX_FANOUT = 1024
 GIGL_META_LEN = 16
 GIGL_META_N_NODES, GIGL_META_N_EDGES, GIGL_META_LEVEL0, GIGL_META_OVERFLOW = 0, 1, 2, 8
 LOC_HOST, LOC_DEVICE = 0, 1

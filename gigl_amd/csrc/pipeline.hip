@@ -526,7 +526,9 @@ static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, in
     return q;
   };
   bool ok = true;
-  p->leaf_global = hops <= 2 && graph->n < ((int64_t)1 << 31);
+  // (the two-hop leaf-global builds keep a hop-0 slot's children in a 64-bit mask: last-hop fanouts beyond 64 — the
+  // workgroup-per-row sampler path — take the generic union build)
+  p->leaf_global = hops <= 2 && graph->n < ((int64_t)1 << 31) && !(hops == 2 && fanouts[1] > GIGL_FAST_FANOUT);
   // two hops, leaf-global union: the last hop's sampled ids live right behind the union's col array, so that the
   // rows of level-1 nodes that occur once can BE their tree segments (union.hip, row aliasing)
   int64_t last_slots = b;

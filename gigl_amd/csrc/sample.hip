@@ -984,6 +984,142 @@ __global__ __launch_bounds__(256) void expand_heavy_kernel(ExpandArgs a, const i
   }
 }
 
+// ---- fanouts beyond the wave-resident selection (f > GIGL_FAST_FANOUT = 64, up to GIGL_MAX_FANOUT): one WORKGROUP per
+// parent slot.  The reference's numNeighborsToSample is any integer (SGSPureSparkV1Task.scala:313-388); the wave kernels
+// above keep one candidate per lane.  Same contract, evaluated directly: the f smallest (xxhash64(i + K + seed*counter),
+// i) over the row's positions.  The positions whose ordered hash lies under a threshold T ~ (f + 6 sqrt(f) + 16) / deg
+// are collected into LDS (hash values are uniform: between f and 2,048 of them with overwhelming probability; T is
+// doubled / halved and the row redone otherwise), sorted by (key, position) — bitonic, in LDS — the first f kept and
+// sorted by position: ascending position = ascending id, the order every other path writes.  Rows of <= f neighbours are
+// copied through.  Exact by construction (64-bit keys + position tie-break, SamplingStrategy.scala:63).
+constexpr int WIDE_CAP = 2048;
+
+// ascending bitonic sort of n <= cap (cap a power of two) (key, idx) pairs in LDS by (key, idx); entries [n, cap) must
+// be padded with (~0, ~0) by the caller
+__device__ __forceinline__ void wide_bitonic(uint64_t* k, uint32_t* x, int cap, bool by_idx) {
+  for (int size = 2; size <= cap; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < cap / 2; t += blockDim.x) {
+        const int lo = (t / stride) * (stride << 1) + (t % stride), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint64_t ka = k[lo], kb = k[hi];
+        const uint32_t xa = x[lo], xb = x[hi];
+        const bool a_gt_b = by_idx ? (xa > xb) : less96(kb, xb, ka, xa);
+        if (a_gt_b == up) {
+          k[lo] = kb;
+          k[hi] = ka;
+          x[lo] = xb;
+          x[hi] = xa;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void expand_wide_kernel(ExpandArgs a) {
+  __shared__ uint64_t s_key[WIDE_CAP];
+  __shared__ uint32_t s_idx[WIDE_CAP];
+  __shared__ int32_t s_count;
+  __shared__ int32_t s_scan[256];
+  const int tid = threadIdx.x;
+  const int f = a.f;
+  for (int64_t p = blockIdx.x; p < a.n_parents; p += gridDim.x) {
+    uint32_t v, ksum;
+    parent_of(a, (uint32_t)p, v, ksum);
+    uint32_t* out = a.out_nbr + p * f;
+    __syncthreads();  // (the previous row's LDS state is dead)
+    if (v == GIGL_INVALID || (int64_t)v >= a.n_nodes) {
+      for (int j = tid; j < f; j += 256) out[j] = GIGL_INVALID;
+      if (tid == 0) a.out_cnt[p] = 0;
+      continue;
+    }
+    const int64_t s = a.rowptr[v];
+    const int64_t deg = a.rowptr[v + 1] - s;
+    const uint32_t* row = a.col + s;
+    const uint32_t base = ksum + (uint32_t)a.hash_add;
+    int n_sel;  // positions selected, in s_idx[0 .. n_sel) ascending
+    if (deg <= f) {
+      for (int j = tid; j < f; j += 256) s_idx[j] = j < deg ? (uint32_t)(j + 1) : 0xFFFFFFFFu;
+      n_sel = (int)deg;
+      __syncthreads();
+    } else {
+      const double lam = (double)f + 6.0 * sqrt((double)f) + 16.0;
+      double frac = lam / (double)deg;
+      for (;;) {
+        const uint64_t T = frac >= 1.0 ? ~0ULL : (uint64_t)(frac * 18446744073709551616.0);
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        for (int64_t i = 1 + tid; i <= deg; i += 256) {
+          const uint64_t key = xxh64_i32_ordered((uint32_t)i + base);
+          if (key < T || T == ~0ULL) {
+            const int slot = atomicAdd(&s_count, 1);
+            if (slot < WIDE_CAP) {
+              s_key[slot] = key;
+              s_idx[slot] = (uint32_t)i;
+            }
+          }
+        }
+        __syncthreads();
+        const int count = s_count;
+        __syncthreads();
+        if (count > WIDE_CAP) {
+          frac *= 0.5;
+          continue;
+        }
+        if (count < f) {
+          frac *= 2.0;
+          continue;
+        }
+        for (int j = count + tid; j < WIDE_CAP; j += 256) {
+          s_key[j] = ~0ULL;
+          s_idx[j] = 0xFFFFFFFFu;
+        }
+        int cap = 64;
+        while (cap < count) cap <<= 1;
+        wide_bitonic(s_key, s_idx, cap, false);  // by (key, position): the first f are the sample
+        int cap2 = 64;
+        while (cap2 < f) cap2 <<= 1;
+        for (int j = f + tid; j < cap2; j += 256) {  // (cap2 <= cap: everything past f is dropped)
+          s_key[j] = ~0ULL;
+          s_idx[j] = 0xFFFFFFFFu;
+        }
+        wide_bitonic(s_key, s_idx, cap2, true);  // by position
+        break;
+      }
+      n_sel = f;
+    }
+    // ids of the selected positions in position order; rows that repeat ids (directed multi-edges) write every id once
+    int kept = 0;
+    if (!a.multi) {
+      for (int j = tid; j < f; j += 256) out[j] = j < n_sel ? row[s_idx[j] - 1] : GIGL_INVALID;
+      kept = n_sel;
+    } else {
+      int run = 0;  // (f <= 1024: four slots per thread, consecutive)
+      const int per = (f + 255) / 256;
+      const int j0 = tid * per;
+      for (int j = j0; j < j0 + per && j < n_sel; ++j) {
+        const uint32_t val = row[s_idx[j] - 1];
+        run += (j == 0 || row[s_idx[j - 1] - 1] != val) ? 1 : 0;
+      }
+      s_scan[tid] = run;
+      __syncthreads();
+      int off = 0;
+      for (int t = 0; t < tid; ++t) off += s_scan[t];
+      int total = 0;
+      for (int t = 0; t < 256; ++t) total += s_scan[t];
+      for (int j = j0; j < j0 + per && j < n_sel; ++j) {
+        const uint32_t val = row[s_idx[j] - 1];
+        if (j == 0 || row[s_idx[j - 1] - 1] != val) out[off++] = val;
+      }
+      for (int j = total + tid; j < f; j += 256) out[j] = GIGL_INVALID;
+      kept = total;
+    }
+    if (tid == 0) a.out_cnt[p] = kept;
+  }
+}
+
 // The table is a function of the integer axis alone (not of the graph, the roots or the seed), so ONE table per device
 // serves every ctx of the process: ctxs hold a reference to the device's current table; a request beyond its domain
 // builds a larger one, which replaces it in the registry, and the old one is freed when the last ctx that still
@@ -1136,6 +1272,13 @@ int32_t ensure_table(gigl_ctx* ctx, uint64_t want_dom) {
 int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a_in, const RangeTable& tb, bool covered,
                    int64_t* heavy_list, int32_t* heavy_count, RowDesc* desc) {
   ExpandArgs a = a_in;
+  if (a.f > GIGL_FAST_FANOUT) {  // fanouts beyond the wave-resident selection: a workgroup per parent slot
+    gigl_prof_scope ps(ctx, GIGL_K_EXPAND);
+    int64_t wgs = a.n_parents < 8192 ? a.n_parents : 8192;
+    hipLaunchKernelGGL(expand_wide_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a);
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    return GIGL_OK;
+  }
   a.proxy_drop = 0;
   if (const char* e = getenv("GIGL_SAMPLER_PROXY_BITS")) {  // test knob: fewer proxy bits -> forced ties
     int bits = atoi(e);
@@ -1297,6 +1440,9 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
     if (fanouts[k] < 1 || fanouts[k] > GIGL_MAX_FANOUT)
       return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "fanout[%d]=%d outside [1,%d]", k, fanouts[k],
                        GIGL_MAX_FANOUT);
+    if (mode != GIGL_MODE_SPARK_HASH && fanouts[k] > GIGL_FAST_FANOUT)
+      return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "fanout[%d]=%d: the non-parity modes take fanouts up to %d", k, fanouts[k],
+                       GIGL_FAST_FANOUT);
     GIGL_REQUIRE(ctx, out->nbr[k] && out->cnt[k], "tree buffers for hop %d are null", k);
     parents *= fanouts[k];
     GIGL_REQUIRE(ctx, parents < (int64_t)1 << 31, "tree too large");

@@ -1446,8 +1446,8 @@ int32_t fill_args(gigl_ctx* ctx, const int32_t* fanouts, int32_t hops, const gig
   GIGL_REQUIRE(ctx, (o->suffix == nullptr) == (o->suffix_off == nullptr), "suffix and suffix_off go together");
   int64_t s = 1, sum = 0;
   for (int k = 0; k < hops; ++k) {
-    GIGL_REQUIRE(ctx, fanouts[k] >= 1 && fanouts[k] <= GIGL_MAX_FANOUT, "fanout[%d]=%d outside [1,%d]", k,
-                 fanouts[k], GIGL_MAX_FANOUT);
+    GIGL_REQUIRE(ctx, fanouts[k] >= 1 && fanouts[k] <= GIGL_FAST_FANOUT, "fanout[%d]=%d outside [1,%d]", k,
+                 fanouts[k], GIGL_FAST_FANOUT);
     s *= fanouts[k];
     sum += s;
     if (sum > MAX_STREAM) break;

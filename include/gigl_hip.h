@@ -39,7 +39,11 @@ extern "C" {
 
 #define GIGL_INVALID 0xFFFFFFFFu
 #define GIGL_MAX_HOPS 4
-#define GIGL_MAX_FANOUT 64 /* wave-resident top-f selection: one candidate per lane */
+/* fanouts up to GIGL_FAST_FANOUT take the wave-resident selection (one candidate per lane: the tuned path of every
+ * benchmark configuration); larger ones, up to GIGL_MAX_FANOUT, a workgroup-per-row selection with the same results
+ * contract (parity mode; gigl_sample_khop, gigl_expand_frontier and the plans built on them) */
+#define GIGL_FAST_FANOUT 64
+#define GIGL_MAX_FANOUT 1024
 
 #define GIGL_LOC_HOST 0
 #define GIGL_LOC_DEVICE 1

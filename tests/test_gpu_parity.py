@@ -81,7 +81,62 @@ def test_sampler_heavy_rows_and_edge_cases(eng):
     t = eng.sample_khop(np.zeros(0, np.uint32), [5, 5])
     assert t.b == 0
     with pytest.raises(RuntimeError):
-        eng.sample_khop(roots, [65, 2])  # GIGL_E_UNSUPPORTED: fanout > 64
+        eng.sample_khop(roots, [1025, 2])  # GIGL_E_UNSUPPORTED: fanout > GIGL_MAX_FANOUT
+
+
+@pytest.mark.parametrize("fanouts", [[65, 3], [100, 70], [3, 200], [1024], [300, 2, 80]])
+def test_fanouts_beyond_the_wave_resident_selection(eng, fanouts):
+    """numNeighborsToSample is any integer in the reference (SGSPureSparkV1Task.scala:313-388): fanouts above 64 take a
+    workgroup-per-row selection (sample.hip: expand_wide_kernel) with the same contract — bit-exact vs the oracle on rows
+    shorter than f (copied through), a little longer than f, hubs of 20,000 neighbours, empty rows and INVALID parents"""
+    rng = np.random.default_rng(5)
+    n = 21000
+    hub_src = np.arange(1, 20001)
+    mid = [rng.choice(n, size=k, replace=False) for k in (66, 99, 101, 130, 257, 1023, 1025, 1500, 3000)]
+    s, d = rmat_edges(14, 150000, seed=9)
+    src = np.concatenate([hub_src] + mid + [s % n]).astype(np.uint32)
+    dst = np.concatenate([np.zeros(20000)] + [np.full(m.size, 1 + i) for i, m in enumerate(mid)] + [d % n]).astype(np.uint32)
+    rowptr, col = oracle.build_csc(n, src, dst, is_directed=True)
+    eng.load_csc(rowptr, col)
+    roots = np.concatenate([np.arange(0, 12), rng.integers(0, n, size=40), np.array([20999])]).astype(np.uint32)
+    _check_tree(eng, rowptr, col, roots, fanouts)
+
+
+def test_wide_fanout_downstream_union_and_forward(eng):
+    """a [100, 70] batch through union build (bit-exact vs the oracle) and the GraphSAGE forward (1e-5 vs the fp32
+    restatement): the rest of the path takes rows of any length"""
+    from gigl_amd.models import GraphSAGE, HipBatch
+    from oracle import gnn_ref
+    rng = np.random.default_rng(6)
+    n = 6000
+    s, d = rmat_edges(13, 300000, seed=4)
+    rowptr, col = oracle.build_csc(n, s % n, d % n, is_directed=False)
+    eng.load_csc(rowptr, col)
+    x = rng.standard_normal((n, 24)).astype(np.float32)
+    eng.load_features(x)
+    roots = rng.integers(0, n, size=48).astype(np.uint32)
+    fanouts = [100, 70]
+    tree, nbr_o = _check_tree(eng, rowptr, col, roots, fanouts)
+    u = eng.union_build(tree)
+    o = oracle.union_build(roots, fanouts, nbr_o)
+    assert np.array_equal(u.meta.cpu().numpy()[:5], o["meta"][:5])
+    nodes, rp_h, col_h = u.to_csr()
+    assert np.array_equal(nodes, o["nodes"]) and np.array_equal(rp_h, o["rowptr"]) and np.array_equal(col_h, o["col"])
+    torch.manual_seed(2)
+    model = GraphSAGE(24, 32, 8, num_layers=2).to(eng.device).eval()
+    model.engine = eng
+    with torch.no_grad():
+        got = model(HipBatch(eng, tree, u))[u.root_local[: roots.size].long()].cpu().numpy()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ei = torch.from_numpy(np.stack([o["col"].astype(np.int64), np.repeat(np.arange(o["rowptr"].size - 1), np.diff(o["rowptr"]))]))
+    want = gnn_ref.graphsage_forward(torch.from_numpy(x[o["nodes"]]), ei, sd, 2)[o["root_local"][: roots.size]].numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+    # ... and so does the one-call plan (sample -> union -> layers -> one row per root in one library call)
+    plan = model.make_plan(eng, roots.size, fanouts)
+    r_dev = torch.from_numpy(roots.view(np.int32)).to(eng.device)
+    rows = plan.run(r_dev).cpu().numpy()
+    plan.close()
+    np.testing.assert_allclose(rows, want, rtol=1e-5, atol=1e-5)
 
 
 def test_int32_wraparound_of_key_sum(eng):
@@ -312,7 +367,7 @@ def test_directed_multi_edges_are_sampled_over_the_multiset():
     rp, cl = eng.graph_to_host()
     assert np.array_equal(rp, rowptr_m) and np.array_equal(cl, col_m)
     roots = np.concatenate([np.array([5, 5, 0, 1], dtype=np.uint32), rng.integers(0, n, size=400).astype(np.uint32)])
-    for fan in ([10, 5], [25, 10], [3]):
+    for fan in ([10, 5], [25, 10], [3], [80, 3], [600]):  # (fanouts > 64: the workgroup-per-row selection)
         tree = eng.sample_khop(roots, fan)
         nbr_o, cnt_o = oracle.sample_khop(rowptr_m, col_m, roots, fan, canonical=True)
         for k in range(len(fan)):
