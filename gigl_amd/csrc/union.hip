@@ -633,6 +633,82 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Rows beyond the LDS sort (more than BIG_ROW_CAP entries: a hub that many parents of one batch sampled under different
+// path sums).  The reference has no such bound (its union is a Spark array_distinct / the collate's dict), so neither
+// does the library: the row is sorted IN PLACE in global memory by the whole workgroup — a bitonic network in its
+// "flip" form, every compare-exchange ascending, so positions past the row's end act as +inf and any length works —
+// then made distinct chunk by chunk through LDS (a chunk is read completely before its survivors are written at or
+// before its start).  ~0.3 ms for a row of 65,536: rare by construction.  Returns the number of distinct values.
+__device__ int32_t huge_row_sort_distinct(int32_t* __restrict__ row, int32_t m, int32_t* lds /* >= 2 * BIG_ROW_CAP */,
+                                          int32_t* s_tmp /* >= 20 ints of LDS */) {
+  const int tid = threadIdx.x;
+  int64_t pow2 = 1;
+  while (pow2 < m) pow2 <<= 1;
+  const int64_t half = pow2 >> 1;
+  auto cmpx = [&](int64_t lo, int64_t hi) {
+    if (hi < m) {
+      const int32_t a = row[lo], b = row[hi];
+      if (a > b) {
+        row[lo] = b;
+        row[hi] = a;
+      }
+    }
+  };
+  for (int64_t k = 2; k <= pow2; k <<= 1) {
+    __threadfence_block();
+    __syncthreads();
+    for (int64_t t = tid; t < half; t += blockDim.x) {  // flip: block [s, s + k): position i against s + k - 1 - (i - s)
+      const int64_t blk = t / (k >> 1), off = t % (k >> 1);
+      const int64_t lo = blk * k + off;
+      cmpx(lo, blk * k + (k - 1 - off));
+    }
+    for (int64_t j = k >> 2; j > 0; j >>= 1) {
+      __threadfence_block();
+      __syncthreads();
+      for (int64_t t = tid; t < half; t += blockDim.x) {
+        const int64_t lo = (t / j) * (j << 1) + (t % j);
+        cmpx(lo, lo + j);
+      }
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // distinct, in order: chunks of 2 * BIG_ROW_CAP values through LDS
+  const int32_t CH = 2 * BIG_ROW_CAP;
+  int32_t out = 0;
+  for (int32_t c0 = 0; c0 < m; c0 += CH) {
+    const int32_t n = min(CH, m - c0);
+    const int32_t before = c0 > 0 ? row[c0 - 1] : 0;  // (read by everybody before anything of this chunk is written)
+    for (int q = tid; q < n; q += blockDim.x) lds[q] = row[c0 + q];
+    __syncthreads();
+    // per-thread run of consecutive values: count heads, prefix over the 1024 threads, write
+    const int per = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int q0 = tid * per, q1 = min(n, q0 + per);
+    int32_t cnt = 0;
+    for (int q = q0; q < q1; ++q) cnt += (q == 0 ? (c0 == 0 || lds[0] != before) : lds[q] != lds[q - 1]) ? 1 : 0;
+    int32_t incl = cnt;
+    const int lane = tid & 63, w = tid >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    if (lane == 63) s_tmp[w] = incl;
+    __syncthreads();
+    int32_t base = out, total = 0;
+    for (int q = 0; q < 16; ++q) {
+      if (q < w) base += s_tmp[q];
+      total += s_tmp[q];
+    }
+    int32_t pos = base + incl - cnt;
+    for (int q = q0; q < q1; ++q)
+      if (q == 0 ? (c0 == 0 || lds[0] != before) : lds[q] != lds[q - 1]) row[pos++] = lds[q];
+    out += total;
+    __threadfence_block();
+    __syncthreads();
+  }
+  return out;
+}
+
 __global__ __launch_bounds__(1024) void row_sort_big_kernel(const int32_t* rowptr, const int32_t* rowend,
                                                             int32_t* col, const int32_t* big_rows,
                                                             const int32_t* big_count, int32_t* overflow) {
@@ -649,8 +725,10 @@ __global__ __launch_bounds__(1024) void row_sort_big_kernel(const int32_t* rowpt
   for (int32_t r = blockIdx.x; r < nb; r += gridDim.x) {
     const int32_t i = big_rows[r];
     const int32_t s = rowptr[i], m = rowend[i] - s;
-    if (m > BIG_ROW_CAP) {  // does not fit the LDS sort: left unsorted, reported through meta
-      if (tid == 0) atomicAdd(overflow, 1);
+    if (m > BIG_ROW_CAP) {  // does not fit the LDS sort: sorted in place in global memory (values are unique here)
+      __syncthreads();
+      huge_row_sort_distinct(col + s, m, lds, s_w);
+      __syncthreads();
       continue;
     }
     if (tid == 0) {
@@ -1378,6 +1456,9 @@ __global__ __launch_bounds__(1024) void lg2_row_sort_big_kernel(const int32_t* r
     if (tid == 0) s_uniq = 0;
     __syncthreads();
     for (int q = tid; q < m_raw; q += 1024) {
+      // (more distinct values than the sort holds: the row takes the global-memory path below — stop filling the set,
+      // whose probe chains grow without bound as it fills)
+      if (*(volatile int32_t*)&s_uniq > BIG_ROW_CAP) break;
       const int32_t v = col[s + q];
       uint32_t h = hash_u32((uint32_t)v) & HMASK;
       for (uint32_t probes = 0; probes <= HMASK; ++probes) {
@@ -1393,9 +1474,13 @@ __global__ __launch_bounds__(1024) void lg2_row_sort_big_kernel(const int32_t* r
     __syncthreads();
     const int32_t m = s_uniq;
     __syncthreads();  // (everybody has read the count before it is reused as the compaction cursor)
-    if (m > BIG_ROW_CAP) {  // does not fit the LDS sort: left as it is, reported through meta
-      if (tid == 0) atomicAdd(overflow, 1);
-      edges += tid == 0 ? m_raw : 0;
+    if (m > BIG_ROW_CAP) {  // more distinct values than the LDS set / sort hold: sorted + made distinct in global memory
+      const int32_t md = huge_row_sort_distinct(col + s, m_raw, lds, s_w);
+      if (tid == 0) {
+        rowend[i] = s + md;
+        edges += md;
+      }
+      __syncthreads();
       continue;
     }
     // compact the set into the head of the row (order irrelevant: sorted next)

@@ -392,8 +392,7 @@ class ResidentGraph:
 
     def raise_on_overflow(self) -> None:
         """RuntimeError when a one-call plan since the last check failed (a batch's union graph did not fit the plan's
-        workspace — roots that are each other's sampled neighbours, or more than 16,384 distinct in-edges of one node:
-        its rows are NaN).  Synchronises; callers check once per pass, before the rows are declared written."""
+        workspace — roots that are each other's sampled neighbours beyond the node table's slack: its rows are NaN).  Synchronises; callers check once per pass, before the rows are declared written."""
         if self._overflow_acc is None:
             return
         n = int(self._overflow_acc.item())

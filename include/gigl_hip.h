@@ -635,9 +635,10 @@ int32_t gigl_json_rows_format(const int64_t* ids, const float* emb, int64_t emb_
  * compute are always a prefix (layer-wise trimmed schedule, exact for root outputs).
  * Outputs (DEVICE, caller-allocated, capacities from gigl_union_capacity):
  *   meta[0]=n_nodes, meta[1]=n_edges (unique), meta[2+l]=cumulative node count through level l
- *           (meta[2]=#distinct roots), l=0..hops; meta[GIGL_META_OVERFLOW] != 0 reports rows that
- *           exceeded the in-LDS dedup capacity (16384 sampled in-edges of ONE node in ONE batch):
- *           such a row keeps its duplicates — treat the batch as failed
+ *           (meta[2]=#distinct roots), l=0..hops; meta[GIGL_META_OVERFLOW] != 0 reports a workspace
+ *           that did not hold the batch (a full node table of the leaf-global builds): treat the
+ *           batch as failed.  Rows have no length bound: more than 16,384 distinct in-edges of one
+ *           node in one batch (past the LDS sort) are sorted and made distinct in global memory
  *   nodes[n_nodes]    global id of local node i
  *   rowptr[i], rowend[i]  row i = col[rowptr[i] .. rowend[i]) — CSR by destination over local ids
  *                     whose rows keep their pre-dedup capacity (rowptr is monotone, rowend[i] <=

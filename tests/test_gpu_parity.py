@@ -398,3 +398,42 @@ def test_directed_multi_edges_are_sampled_over_the_multiset():
                                      sd, 2)[u["root_local"]].numpy()
     np.testing.assert_allclose(out, want, rtol=1e-5, atol=1e-5)
     eng.close()
+
+
+def test_rows_beyond_the_lds_sort_capacity(eng):
+    """a hub that every root of a batch reaches through a different path: its in-edge row in the batch's union graph holds
+    ~45,000 distinct sampled neighbours — past the 16,384 the LDS sort takes, sorted and made distinct in global memory
+    instead (union.hip: huge_row_sort_distinct; the reference has no such bound).  Generic build bit-exact vs the oracle,
+    the one-call plan's rows 1e-5 vs the staged forward over it, no overflow reported."""
+    from gigl_amd.models import GraphSAGE, HipBatch
+    H, B, deg = 0, 1024, 100_000
+    n = 2000 + deg
+    # roots 1..B have the hub as their only in-neighbour; the hub's in-neighbours are 2000 .. 2000+deg
+    src = np.concatenate([np.full(B, H), np.arange(2000, 2000 + deg)]).astype(np.uint32)
+    dst = np.concatenate([np.arange(1, B + 1), np.full(deg, H)]).astype(np.uint32)
+    rowptr, col = oracle.build_csc(n, src, dst, is_directed=True)
+    eng.load_csc(rowptr, col)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n, 8)).astype(np.float32)
+    eng.load_features(x)
+    roots = np.arange(1, B + 1, dtype=np.uint32)
+    fanouts = [2, 64]
+    tree, nbr_o = _check_tree(eng, rowptr, col, roots, fanouts)
+    u = eng.union_build(tree)
+    o = oracle.union_build(roots, fanouts, nbr_o)
+    hub_local = int(np.flatnonzero(o["nodes"] == H)[0])
+    assert o["rowptr"][hub_local + 1] - o["rowptr"][hub_local] > 16384
+    m = u.meta.cpu().numpy()
+    assert np.array_equal(m[:5], o["meta"][:5]) and u.counts().get("overflow", 0) == 0
+    nodes, rp_h, col_h = u.to_csr()
+    assert np.array_equal(nodes, o["nodes"]) and np.array_equal(rp_h, o["rowptr"]) and np.array_equal(col_h, o["col"])
+    torch.manual_seed(4)
+    model = GraphSAGE(8, 16, 4, num_layers=2).to(eng.device).eval()
+    model.engine = eng
+    with torch.no_grad():
+        want = model(HipBatch(eng, tree, u))[u.root_local[:B].long()].cpu().numpy()
+    plan = model.make_plan(eng, B, fanouts)
+    rows = plan.run(torch.from_numpy(roots.view(np.int32)).to(eng.device)).cpu().numpy()
+    plan.close()
+    assert np.isfinite(rows).all()
+    np.testing.assert_allclose(rows, want, rtol=1e-5, atol=1e-5)
