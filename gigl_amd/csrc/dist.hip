@@ -592,6 +592,7 @@ struct gigl_dist_plan {
   const float* w[GIGL_MAX_HOPS] = {nullptr};
   const float* bias[GIGL_MAX_HOPS] = {nullptr};
   int32_t act_last = 0;
+  int32_t aggr = GIGL_AGGR_MEAN;  // the SAGE layers' reduction (gigl_dist_plan_set_aggr)
   bool project = false;
   // pre-projected rows (opts->projected): this rank's [W_l x | W_r x] table, [shard rows][2*dims[1]] fp32, borrowed.  The
   // dense pull then moves W_l x rows (dims[1] fp32 instead of the raw row), a second small pull brings the W_r x rows of
@@ -883,7 +884,7 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     if (l == 0 && p->project) {
       const int dout = p->dims[1];
       rc = gigl_gather_reduce(ctx, p->rows_r, GIGL_DTYPE_F32, dout, (const uint32_t*)p->pos, p->un.rowptr, p->un.rowend,
-                              p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN, p->abuf);
+                              p->un.col, n_rows, rows_cap, p->aggr, p->abuf);
       if (rc != GIGL_OK) return rc;
       hipLaunchKernelGGL(projected_layer_kernel, dim3((unsigned)grid256(rows_cap * dout)), dim3(256), 0, st, p->abuf,
                          (const float*)p->rowsb_r, p->posb, p->bias[0], dout, act, n_rows, rows_cap, p->hbuf[0]);
@@ -894,22 +895,22 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       const int dout = p->dims[1];
       rc = gigl_gather_project_mixed(ctx, (const float*)p->rows_r, (const float*)p->rowsb_r, dout, dout,
                                      (const uint32_t*)p->pos, p->un.rowptr, p->un.rowend, p->un.col, n_rows, rows_cap,
-                                     GIGL_AGGR_MEAN, p->un.meta + GIGL_META_LEVEL0 + (L - 2), p->bias[0], act, p->hbuf[0],
+                                     p->aggr, p->un.meta + GIGL_META_LEVEL0 + (L - 2), p->bias[0], act, p->hbuf[0],
                                      p->slot_map, (const float*)p->hot_rows, p->preproj, 2 * dout, p->posb);
       if (rc != GIGL_OK) return rc;
       continue;
     }
     if (l == 0 && p->dense)  // rows of level L-1 hold global ids: located through slot_map
       rc = gigl_gather_reduce_mixed(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, p->un.rowptr,
-                                    p->un.rowend, p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN,
+                                    p->un.rowend, p->un.col, n_rows, rows_cap, p->aggr,
                                     p->un.meta + GIGL_META_LEVEL0 + (L - 2), p->abuf, 0, p->slot_map, p->hot_rows,
                                     p->feat->rows);
     else if (l == 0)
       rc = gigl_gather_reduce(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, p->un.rowptr,
-                              p->un.rowend, p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN, p->abuf);
+                              p->un.rowend, p->un.col, n_rows, rows_cap, p->aggr, p->abuf);
     else
       rc = gigl_gather_reduce(ctx, p->hbuf[(l - 1) & 1], GIGL_DTYPE_F32, p->dims[l], nullptr, p->un.rowptr, p->un.rowend,
-                              p->un.col, n_rows, rows_cap, GIGL_AGGR_MEAN, p->abuf);
+                              p->un.col, n_rows, rows_cap, p->aggr, p->abuf);
     if (rc != GIGL_OK) return rc;
     rc = gigl_linear(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * p->dims[l], p->dims[l + 1], act,
                      p->hbuf[l & 1]);
@@ -1274,6 +1275,18 @@ int32_t gigl_dist_plan_set_hot_rows(gigl_dist_plan* p, const uint32_t* hot_ids, 
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (hot_ids may be freed by the caller after this returns)
   p->hot_rows = n_hot > 0 ? hot_rows : nullptr;  // (n_hot == 0: back to "nothing replicated")
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_plan_set_aggr(gigl_dist_plan* p, int32_t aggr) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(p->ctx, aggr == GIGL_AGGR_MEAN || aggr == GIGL_AGGR_SUM || aggr == GIGL_AGGR_MAX, "aggr %d", aggr);
+  GIGL_REQUIRE(p->ctx, p->kind == 0, "the GAT plan has no segmented reduction to switch");
+  // rows projected before the reduction (on the owner, or once per rank) lean on lin_l(reduce x) = reduce lin_l(x):
+  // true for mean and sum, not for max
+  if (aggr == GIGL_AGGR_MAX && (p->project || p->preproj))
+    return gigl_fail(p->ctx, GIGL_E_UNSUPPORTED, "max aggregation pulls raw rows (no projection before the reduction)");
+  p->aggr = aggr;
   return GIGL_OK;
 }
 

@@ -385,8 +385,9 @@ class DistSagePlan:
     def __init__(self, comm: Comm, weights, biases, b: int, fanouts: Sequence[int], act_last: bool = False,
                  group_roots: Optional[int] = None, project_on_owner: bool = False, pull_cap: int = 0,
                  hop_slack: float = 0.0, max_window_end: int = -1, projected: Optional[torch.Tensor] = None,
-                 pull_cap_b: int = 0):
-        """projected: this rank's pre-projected rows (HipEngine.project_features of the SHARD's table with weights[0]:
+                 pull_cap_b: int = 0, aggr: str = "mean"):
+        """aggr: the SAGE layers' reduction ("mean" | "sum" | "max"; "max" pulls raw rows: not with project_on_owner /
+        projected).  projected: this rank's pre-projected rows (HipEngine.project_features of the SHARD's table with weights[0]:
         [shard rows, 2*out] fp32) — the pull moves W_l x rows, the first layer is one reduction (gigl_dist_plan_opts.
         projected); recompute and rebuild the plan after a weight update"""
         from . import _lib
@@ -412,6 +413,8 @@ class DistSagePlan:
         dims = (C.c_int32 * (L + 1))(*self.dims)
         _check(self._lib.gigl_dist_plan_create(comm._h, eng._graph, eng._feat, self.b, fo, L, dims, w_arr, b_arr,
                                                1 if act_last else 0, C.byref(o), C.byref(self._plan)), eng._ctx)
+        if aggr != "mean":
+            _check(self._lib.gigl_dist_plan_set_aggr(self._plan, _lib.AGGR[aggr]), eng._ctx)
         n = C.c_int32()
         _check(self._lib.gigl_dist_plan_phases(self._plan, C.byref(n)), eng._ctx)
         self.n_phases = n.value

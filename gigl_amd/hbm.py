@@ -311,23 +311,22 @@ class ResidentGraph:
             if type(model) is GAT:  # (raises NotImplementedError for options outside the sharded plan)
                 return model.make_dist_plan(self.comm, groups * b, self.fanouts, group_roots=b,
                                             max_window_end=self.max_window_end)
-            if not isinstance(model, GraphSAGE) or not model._plain or model.aggr != "mean" or \
-                    model.should_l2_normalize_embedding_layer_output or model.feats_interaction is not None or \
-                    model.feature_embedding_layer is not None:
-                raise NotImplementedError("WORLD_SIZE > 1: the sharded plan runs plain mean-GraphSAGE encoders "
-                                          f"(got {type(model).__name__})")
+            if not isinstance(model, GraphSAGE) or not model._plain or model.aggr not in ("mean", "sum", "max") or \
+                    model.feats_interaction is not None or model.feature_embedding_layer is not None:
+                raise NotImplementedError("WORLD_SIZE > 1: the sharded plan runs plain GraphSAGE encoders (aggr mean / sum "
+                                          f"/ max, optional L2-normalised output; got {type(model).__name__})")
             w, bs = model.fused_params()
             # rows wider than the first layer's output: project this rank's shard once, pull W_l x rows (the table is
             # refilled in place by _refresh when the weights change)
             proj = None
-            if len(self.fanouts) == 2 and model.projected_input_pays(self.engine) and \
+            if len(self.fanouts) == 2 and model.aggr != "max" and model.projected_input_pays(self.engine) and \
                     os.environ.get("GIGL_AMD_PROJECT_INPUT", "1") != "0":
                 cache = self.__dict__.setdefault("_dist_proj", {})  # one projected shard per model
                 proj = cache.get(id(model))
                 if proj is None:
                     proj = cache[id(model)] = self.engine.project_features(w[0])
             return DistSagePlan(self.comm, w, bs, groups * b, self.fanouts, act_last=model.activation_after_last_conv,
-                                group_roots=b, max_window_end=self.max_window_end, projected=proj)
+                                group_roots=b, max_window_end=self.max_window_end, projected=proj, aggr=model.aggr)
         make = getattr(model, "make_plan", None)
         if make is None:
             return None
@@ -375,6 +374,9 @@ class ResidentGraph:
                 if self.sharded:
                     out = plan.run(batch.roots, sampling_seed=self.seed)
                     plan.raise_on_overflow()
+                    if getattr(model, "should_l2_normalize_embedding_layer_output", False) and \
+                            type(plan).__name__ == "DistSagePlan":
+                        out = torch.nn.functional.normalize(out, p=2, dim=1)  # (the encoder's last step: row-wise)
                 else:
                     out = plan.run(batch.roots, sampling_seed=self.seed, mode=self.mode)
                     # a call whose union did not fit its workspace hands out NaN rows: every call's flag is added

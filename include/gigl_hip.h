@@ -1195,6 +1195,9 @@ int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* sha
                               const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,
                               const float* const* bias, int32_t act_last, const gigl_dist_plan_opts* opts,
                               gigl_dist_plan** out);
+/* the SAGE layers' reduction (PyG SAGEConv `aggr`: homogeneous.py:107-153 passes it through): GIGL_AGGR_MEAN (default) |
+ * _SUM | _MAX.  MAX needs raw pulled rows (not with project_on_owner / projected: lin_l does not commute with max). */
+int32_t gigl_dist_plan_set_aggr(gigl_dist_plan* plan, int32_t aggr);
 /* The sharded plan with GAT layers (BASELINE configs[4]: link-prediction GAT over the hash-partitioned MAG240M-shaped
  * graph; python/gigl/src/common/models/pyg/homogeneous.py:300-343 via PyG GATConv): the sampling / union / feature-pull
  * phases of gigl_dist_plan_create (raw rows, every union node numbered), then the layer stages of gigl_gat_plan_create

@@ -130,6 +130,56 @@ def test_in_step_overlap_of_the_own_block_gives_the_same_batches(world, project,
     test_all_ranks_in_one_process_end_to_end(world, project, dtype)
 
 
+@pytest.mark.parametrize("world,aggr,pre", [(2, "sum", False), (3, "max", False), (2, "sum", True), (8, "max", False)])
+def test_sharded_plan_with_sum_and_max_aggregation(world, aggr, pre):
+    """gigl_dist_plan_set_aggr: the sharded step with PyG SAGEConv's other reductions (homogeneous.py:107-153 passes
+    `aggr` through) against the single-GPU one-call plan of the same model over the whole graph — itself checked against
+    the fp32 restatement in test_gpu_sage_options; max refuses projected rows (lin_l does not commute with it)"""
+    from gigl_amd._lib import GiglError
+    from gigl_amd.dist import Comm, DistSagePlan
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE
+    rowptr, col, x = make_graph()
+    torch.manual_seed(11)
+    model = GraphSAGE(D, HID, OUT, num_layers=len(FAN), aggr=aggr)
+    w, bs = model.fused_params()
+    b, gr = 96, 32
+    st = torch.cuda.Stream()
+    engs = [shard_engine(rowptr, col, x, r, world, torch.float32, st) for r in range(world)]
+    comms = Comm.local(engs)
+    kw = {}
+    tables = None
+    if pre:
+        tables = [e.project_features(w[0].to(engs[0].device)) for e in engs]
+    plans = [DistSagePlan(comms[r], w, bs, b, FAN, group_roots=gr, max_window_end=bound_for(rowptr), aggr=aggr,
+                          projected=tables[r] if pre else None) for r in range(world)]
+    roots = [rank_roots(r, b) for r in range(world)]
+    roots_d = [torch.from_numpy(r.view(np.int32)).to(engs[0].device) for r in roots]
+    outs = DistSagePlan.run_local(plans, roots_d)
+    st.synchronize()
+    full = HipEngine(0)
+    full.load_csc(rowptr, col)
+    full.load_features(x)
+    model = model.to(full.device).eval()
+    model.engine = full
+    ref_plan = model.make_plan(full, gr, FAN)
+    for r in range(world):
+        want = torch.cat([ref_plan.run(roots_d[r][g0:g0 + gr].contiguous()).clone() for g0 in range(0, b, gr)])
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(outs[r].cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    if aggr == "max":
+        with pytest.raises(GiglError):
+            DistSagePlan(comms[0], w, bs, b, FAN, group_roots=gr, project_on_owner=True, aggr="max")
+    ref_plan.close()
+    full.close()
+    for p in plans:
+        p.close()
+    for c in comms:
+        c.close()
+    for e in engs:
+        e.close()
+
+
 @pytest.mark.parametrize("world,dtype", [(2, torch.float32), (8, torch.float16)])
 def test_replicated_hot_rows_are_not_pulled(world, dtype, pre=False):
     """hub-row replication (gigl_dist_plan_set_hot_rows): the most-referenced nodes' rows are kept on every rank and read
