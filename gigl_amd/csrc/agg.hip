@@ -629,13 +629,14 @@ constexpr int WG_RC = 256;
 __global__ __launch_bounds__(256) void linear_weight_grad_kernel(const float* __restrict__ dy, const float* __restrict__ a,
                                                                  const float* __restrict__ relu_y,
                                                                  const int32_t* __restrict__ m_dev, int N, int K,
-                                                                 float* __restrict__ part, float* __restrict__ partb) {
+                                                                 float* __restrict__ part, float* __restrict__ partb,
+                                                                 int rc) {
   __shared__ float s_dy[32][68];
   __shared__ float s_a[32][68];
   const int M = *m_dev;
-  const int r0 = blockIdx.x * WG_RC;
+  const int r0 = blockIdx.x * rc;
   if (r0 >= M) return;
-  const int r1 = min(M, r0 + WG_RC);
+  const int r1 = min(M, r0 + rc);
   const int n0 = blockIdx.y * 64, k0 = blockIdx.z * 64;
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
   float acc[4][4];
@@ -721,12 +722,21 @@ __global__ __launch_bounds__(256) void linear_weight_grad_kernel(const float* __
 __global__ __launch_bounds__(256) void linear_weight_grad_reduce_kernel(const float* __restrict__ part,
                                                                         const float* __restrict__ partb,
                                                                         const int32_t* __restrict__ m_dev, int64_t nk, int N,
-                                                                        float* __restrict__ dw, float* __restrict__ db) {
-  const int chunks = (*m_dev + WG_RC - 1) / WG_RC;
+                                                                        float* __restrict__ dw, float* __restrict__ db,
+                                                                        int rc) {
+  const int chunks = (*m_dev + rc - 1) / rc;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nk) {
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(int64_t)c * nk + i];
+    int c = 0;
+    for (; c + 7 < chunks; c += 8) {  // eight chunks' loads in flight; the additions keep chunk order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(c + u) * nk + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; c < chunks; ++c) s += part[(int64_t)c * nk + i];
     dw[i] += s;
   }
   if (db && i < N) {
@@ -2984,16 +2994,20 @@ int32_t gigl_linear_weight_grad(gigl_ctx* ctx, const float* dy, const float* a, 
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (m_cap == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
-  const int64_t chunks = (m_cap + WG_RC - 1) / WG_RC, nk = (int64_t)n * k;
+  // rows per chunk: 256 for the tens of thousands of rows of a first layer; fewer rows (the roots' layer: ~10^3) are cut
+  // finer so that the reduction still spreads over a few hundred workgroups
+  int rcw = WG_RC;
+  while (rcw > 32 && m_cap / rcw < 32) rcw >>= 1;
+  const int64_t chunks = (m_cap + rcw - 1) / rcw, nk = (int64_t)n * k;
   int32_t rc = gigl_arena_reset(ctx, chunks * (nk + n) * 4 + 1024);
   if (rc != GIGL_OK) return rc;
   float* part = (float*)gigl_arena_alloc(ctx, chunks * nk * 4);
   float* partb = db ? (float*)gigl_arena_alloc(ctx, chunks * n * 4) : nullptr;
   if (!part || (db && !partb)) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   const dim3 grid((unsigned)chunks, (unsigned)((n + 63) / 64), (unsigned)((k + 63) / 64));
-  hipLaunchKernelGGL(linear_weight_grad_kernel, grid, dim3(256), 0, ctx->stream, dy, a, relu_y, m_dev, n, k, part, partb);
+  hipLaunchKernelGGL(linear_weight_grad_kernel, grid, dim3(256), 0, ctx->stream, dy, a, relu_y, m_dev, n, k, part, partb, rcw);
   hipLaunchKernelGGL(linear_weight_grad_reduce_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, part,
-                     partb, m_dev, nk, n, dw, db);
+                     partb, m_dev, nk, n, dw, db, rcw);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
