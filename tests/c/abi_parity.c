@@ -152,7 +152,7 @@ int main(void) {
   gigl_features_destroy(buf2);
 
   /* error behaviour of the boundary */
-  int32_t bad_fan[2] = {65, 1};
+  int32_t bad_fan[2] = {GIGL_MAX_FANOUT + 1, 1};
   if (gigl_sample_khop(ctx, g, d_roots, b, bad_fan, 2, 42, 0, &tree) != GIGL_E_UNSUPPORTED) return 12;
   if (gigl_sample_khop(ctx, NULL, d_roots, b, fanouts, 2, 42, 0, &tree) != GIGL_E_INVALID_ARG) return 13;
   if (strlen(gigl_last_error(ctx)) == 0) return 14;
