@@ -123,6 +123,7 @@ class HbmNablpBatch:
     n_pos: np.ndarray              # int64 [n_anchors] host: sampled positives per anchor (>= 1)
     pos_rows: torch.Tensor         # int64 [sum(n_pos)] device: positions of the real positives in the root list, anchor-major
     root_ids: torch.Tensor         # int64 [n_anchors * trees_per_anchor] device: global ids of the root list
+    root_index: Optional[torch.Tensor] = None  # int64 [n_anchors * trees_per_anchor] device: the roots' rows of model(graph)
 
     @property
     def root_nodes(self):
@@ -414,6 +415,45 @@ class ResidentGraph:
         u = eng.union_build(tree)
         return HipBatch(eng, tree, u, train=train)
 
+    # encoders without an autograd forward over HipBatches (GAT, GCN, GIN, Transformer, GraphSAGE with batch norm / JK ...)
+    # train over the same in-HBM batch as a GraphData built on the device (set by the task specs)
+    train_as_graph_data: bool = False
+
+    def graph_data(self, roots: torch.Tensor):
+        """the batch of `roots` (int32 device ids) as a nn.GraphData on the device — x = the union nodes' feature rows,
+        edge_index = the batch union graph's distinct edges (src -> dst, local ids), edge_attr when the job has edge
+        features — what the trainer-side collate builds from the samples' records (pyg_graph_builder.py:20-69), for the
+        encoders that train over a PyG-shaped batch; one host read (the batch's node / edge counts) -> (graph, root rows)"""
+        from .nn import GraphData
+        if self.sharded:
+            raise NotImplementedError("staged batches on a hash-partitioned graph: use the sharded plan (encode)")
+        eng = self.engine
+        eng.bind_stream(torch.cuda.current_stream(self.device))
+        tree = eng.sample_khop(roots, self.fanouts, sampling_seed=self.seed, mode=self.mode)
+        u = eng.union_build(tree)
+        c = u.counts()  # (raises when the batch did not fit its workspace)
+        n, e = int(c["n_nodes"]), int(c["n_edges"])
+        dev = self.device
+        rp, re = u.rowptr[:n].to(torch.int64), u.rowend[:n].to(torch.int64)
+        lens = re - rp
+        start = torch.cumsum(lens, 0) - lens
+        dst = torch.repeat_interleave(torch.arange(n, device=dev), lens, output_size=e)
+        idx = torch.repeat_interleave(rp - start, lens, output_size=e) + torch.arange(e, device=dev)
+        src = u.col.index_select(0, idx).to(torch.int64)
+        x = eng.gather_rows(u.nodes, u.meta[:1], n)
+        ea = None
+        if getattr(eng, "_efeat", None) is not None:
+            ea = eng.union_edge_attr(u).index_select(0, idx)
+        g = GraphData(x=x, edge_index=torch.stack([src, dst]), edge_attr=ea).to(dev)
+        return g, u.root_local[: int(roots.numel())].to(torch.int64)
+
+    def train_graph(self, roots: torch.Tensor):
+        """-> (what the model's forward takes, the roots' rows of its output) for a training / validation batch"""
+        if self.train_as_graph_data:
+            return self.graph_data(roots)
+        hb = self.hip_batch(roots, train=True)
+        return hb, hb.root_local.long()
+
     def train_batches(self, ids: np.ndarray, labels: np.ndarray, batch_size: int) -> Iterator[HbmTrainBatch]:
         """training batches sampled in HBM: consecutive `batch_size` roots; rank r takes batches r, r + world, ... and
         every rank takes the same number (a short rank wraps around to the first batches: the gradient all-reduce of
@@ -425,8 +465,8 @@ class ResidentGraph:
             c = (self.rank + k * self.world) % n_batches
             chunk = ids[c * batch_size: (c + 1) * batch_size]
             r32 = torch.from_numpy(chunk.astype(np.uint32).view(np.int32)).to(self.device)
-            hb = self.hip_batch(r32, train=True)
-            yield HbmTrainBatch(graph=hb, root_node_indices=hb.root_local.long(),
+            hb, ri = self.train_graph(r32)
+            yield HbmTrainBatch(graph=hb, root_node_indices=ri,
                                 root_node_labels=torch.from_numpy(labels[c * batch_size: c * batch_size + chunk.size]),
                                 root_ids=chunk)
 
@@ -465,13 +505,13 @@ class ResidentGraph:
             a2 = anchors.view(-1, 1)
             grouped = torch.where(ar < cnt.view(-1, 1), pos.view(-1, P), a2.expand(-1, P))
             roots = torch.cat([a2, grouped], dim=1).reshape(-1).contiguous()
-            hb = self.hip_batch(roots, train=True)
+            hb, ri = self.train_graph(roots)
             rows = np.concatenate([i * T + 1 + np.arange(int(c)) for i, c in enumerate(k.tolist())]) if k.size else \
                 np.zeros(0, dtype=np.int64)
             yield HbmNablpBatch(graph=hb, n_anchors=int(chunk.size), trees_per_anchor=T, anchor_ids=chunk,
                                 n_pos=np.asarray(k, dtype=np.int64),
                                 pos_rows=torch.from_numpy(rows.astype(np.int64)).to(self.device),
-                                root_ids=roots.to(torch.int64) & 0xFFFFFFFF)
+                                root_ids=roots.to(torch.int64) & 0xFFFFFFFF, root_index=ri)
 
     def random_negative_batches(self, batch_size: int) -> Iterator[HbmTrainBatch]:
         """the random-negative stream of a link-prediction job sampled in HBM: every node's RootedNodeNeighborhood in
@@ -482,9 +522,8 @@ class ResidentGraph:
             for lo in range(0, order.size, batch_size):
                 chunk = order[lo:lo + batch_size]
                 r32 = torch.from_numpy(chunk.astype(np.uint32).view(np.int32)).to(self.device)
-                hb = self.hip_batch(r32, train=True)
-                yield HbmTrainBatch(graph=hb, root_node_indices=hb.root_local.long(), root_node_labels=None,
-                                    root_ids=chunk)
+                hb, ri = self.train_graph(r32)
+                yield HbmTrainBatch(graph=hb, root_node_indices=ri, root_node_labels=None, root_ids=chunk)
 
     def close(self) -> None:
         for p in self._plans.values():
@@ -597,6 +636,12 @@ def encoder_trains_over_hip_batches(model) -> bool:
     from .models import GraphSAGE
     return (type(model) is GraphSAGE and not model.batchnorm and model.jk_layer is None
             and model.feats_interaction is None and model.feature_embedding_layer is None)
+
+
+def encoder_trains_over_graph_data(model) -> bool:
+    """the package's homogeneous encoders: every one has an autograd forward over a nn.GraphData batch (what the TFRecord
+    route's collate hands them), so the in-HBM route can hand them the same batch built on the device"""
+    return type(model).__module__ in ("gigl_amd.models", "gigl_amd.models_attn", "gigl_amd.models_more")
 
 
 def route_of(cfg: GbmlConfigPbWrapper, args: Dict[str, str], override: Optional[str] = None) -> str:

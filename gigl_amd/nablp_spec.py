@@ -172,7 +172,8 @@ def _infer_task_inputs_hbm(model: nn.Module, main_batch, random_neg_batch, shoul
     decoder = inner.decode
     cet = 0
     hb = main_batch.graph
-    roots_emb = model(hb)[hb.root_local.long()]                      # [B * (1 + P), d], anchor-major
+    ri = main_batch.root_index if main_batch.root_index is not None else hb.root_local.long()
+    roots_emb = model(hb)[ri]                                        # [B * (1 + P), d], anchor-major
     d = int(roots_emb.shape[1])
     query = roots_emb.view(main_batch.n_anchors, main_batch.trees_per_anchor, d)[:, 0]
     pos_emb = roots_emb.index_select(0, main_batch.pos_rows)
@@ -615,12 +616,13 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         if self._hbm_anchors is not None:
             return self._hbm_anchors or None
         self._hbm_anchors = {}
-        from .hbm import ResidentGraph, encoder_trains_over_hip_batches, route_of
+        from .hbm import ResidentGraph, encoder_trains_over_graph_data, encoder_trains_over_hip_batches, route_of
         device = getattr(self, "_device", None)
         inner = self.model.module if hasattr(self.model, "module") else self.model
         em = cfg.preprocessed_metadata.edges[0]
         if cfg.is_heterogeneous or device is None or device.type != "cuda" or _rank_world()[1] > 1 or \
-                route_of(cfg, self._kwargs) != "hbm" or not encoder_trains_over_hip_batches(inner.encoder) or \
+                route_of(cfg, self._kwargs) != "hbm" or not (encoder_trains_over_hip_batches(inner.encoder) or
+                                                             encoder_trains_over_graph_data(inner.encoder)) or \
                 em.positive_edge_info is not None or em.negative_edge_info is not None:
             return None
         if any((cfg.dataset_split_uri(sp) and tfrecord_files(cfg.dataset_split_uri(sp))) for sp in ("train", "val", "test")):
@@ -630,6 +632,7 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         except NotImplementedError:
             return None
         self._resident = res
+        res.train_as_graph_data = not encoder_trains_over_hip_batches(inner.encoder)
         # one engine for the job: the encoder / decoder run on the resident graph's engine
         if self._engine is not None and self._engine is not res.engine:
             self._engine.close()

@@ -41,6 +41,8 @@ class GraphData:
 
     def to(self, device) -> "GraphData":
         device = torch.device(device)
+        if self.rowptr is not None and self.x.device == device and self.x.dtype == torch.float32:
+            return self  # (already resident with its CSR: batches built in HBM)
         x = self.x.to(device=device, dtype=torch.float32).contiguous()
         ei = self.edge_index.to(device)
         ea = None if self.edge_attr is None else self.edge_attr.to(device=device, dtype=torch.float32).contiguous()

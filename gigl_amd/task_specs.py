@@ -130,10 +130,10 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
             return self._hbm_splits or None
         self._hbm_splits = {}
         route = route_of(cfg, self._kwargs)
-        from .hbm import encoder_trains_over_hip_batches
+        from .hbm import encoder_trains_over_graph_data, encoder_trains_over_hip_batches
         if route != "hbm" or self._device is None or self._device.type != "cuda" or \
-                not encoder_trains_over_hip_batches(self._inner_model()):
-            return None  # (e.g. GAT / GCN encoders train over collated batches)
+                not (encoder_trains_over_hip_batches(self._inner_model()) or encoder_trains_over_graph_data(self._inner_model())):
+            return None
         # the same rule as the TFRecord route below: split files written by the SplitGenerator -> its assignment
         # (recomputed from the job's splitGeneratorConfig, no file is read); none written -> the root-id rule
         from .config import _get
@@ -158,6 +158,9 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
                           RuntimeWarning, stacklevel=2)
         rank, world = _rank_world()
         self._resident = ResidentGraph(cfg, self._device, rank=rank, world=world, sharded=False)
+        # (plain GraphSAGE trains over HipBatches — and through the library's training plan; every other encoder over
+        # the same in-HBM batch as a GraphData built on the device)
+        self._resident.train_as_graph_data = not encoder_trains_over_hip_batches(self._inner_model())
         ids, labels = self._resident.labeled_root_order()
         splits = {}
         if assign is not None:
@@ -242,8 +245,8 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
                 getattr(self, "_graph_capture_failed", False):
             return None
         hbm = self._hbm_split(cfg)
-        if hbm is None:
-            return None
+        if hbm is None or self._resident.train_as_graph_data:
+            return None  # (a GraphData batch reads its sizes on the host: the eager loop)
         ids, labels = hbm["train"]
         if ids.size == 0:
             return None
