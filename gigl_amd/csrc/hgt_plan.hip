@@ -19,6 +19,7 @@
 // the typed aggregate (HBM: two source rows per edge) and launch latency of the small sorts, not by the host.
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -40,6 +41,11 @@ struct gigl_hgt_infer {
   uint32_t* roots = nullptr;         // static copy of the batch's roots (what the captured launches read)
   float* out = nullptr;              // [b_max][out_dim] static result (copied to the caller's buffer)
   int32_t* b_dev = nullptr;          // the batch size as a device count
+  // the first layer's projections need the batch's NODES only: they run on a side stream (own ctx: own scratch) while the
+  // main stream is still numbering the edges and merging them into the CSR — a fork / join inside the captured graph
+  gigl_ctx* side = nullptr;
+  hipEvent_t ev_nodes = nullptr, ev_proj = nullptr;
+  uint64_t cap_side_gen = 0;
   hipGraphExec_t exec = nullptr;
   bool warm = false, use_graph = true;
   int32_t cap_b = -1;
@@ -135,52 +141,82 @@ int32_t hgt_body(gigl_hgt_infer* p, int32_t b) {
   const gigl_hgt_model& m = p->m;
   hipStream_t st = ctx->stream;
   const int Fo = m.hid, H = m.heads, D = Fo / H, L = m.n_layers;
-  int32_t rc = gigl_typed_plan_run(p->plan, p->roots, b);
-  if (rc != GIGL_OK) return rc;
-  gigl_typed_csr_out csr{};
-  rc = gigl_typed_plan_merged_csr_ex(p->plan, b, m.type_order, m.n_types, m.slot_order, m.slot_etype, m.n_slots, 1, &csr);
+  int32_t rc = gigl_typed_plan_run_nodes(p->plan, p->roots, b);
   if (rc != GIGL_OK) return rc;
   gigl_fill_u32(st, (uint32_t*)p->b_dev, (uint32_t)b, 1);
-  // ---- input projections + ReLU: h0[type block] = relu(W_in x + b_in) over the type's distinct nodes
   float* h = p->h[0];
   float* hn = p->h[1];
+  // the projections of layer l (what needs no edge): K / V blocks of the slots the layer reads (the last layer computes the
+  // roots' rows: only edges INTO their type), the queries — every type's rows, or the roots' rows of the last layer
+  auto project_layer = [&](int l, gigl_ctx* pc, const float* hin) -> int32_t {
+    const gigl_hgt_layer_weights& lw = m.layer[l];
+    const bool last = l == L - 1;
+    int32_t r = GIGL_OK;
+    for (int s = 0; s < m.n_slots; ++s) {
+      if (last && p->slot_dst_j[s] != p->root_j) continue;
+      const int sj = p->slot_src_j[s];
+      const int32_t* n_dev = p->po.n_nodes + m.type_order[sj];
+      const float* x = hin + p->dst_off[sj] * Fo;
+      r = gigl_linear(pc, x, lw.wk[s], lw.bk[s], n_dev, p->cap[sj], Fo, Fo, 0, p->ks + p->src_off[s] * Fo);
+      if (r == GIGL_OK) r = gigl_linear(pc, x, lw.wv[s], lw.bv[s], n_dev, p->cap[sj], Fo, Fo, 0, p->vs + p->src_off[s] * Fo);
+      if (r != GIGL_OK) return r;
+    }
+    if (!last) {
+      for (int j = 0; j < m.n_types; ++j) {
+        r = gigl_linear(pc, hin + p->dst_off[j] * Fo, lw.wq[j], lw.bq[j], p->po.n_nodes + m.type_order[j], p->cap[j], Fo, Fo, 0,
+                        p->qq + p->dst_off[j] * Fo);
+        if (r != GIGL_OK) return r;
+      }
+    } else {
+      const int rj = p->root_j;
+      hipLaunchKernelGGL(hgt_take_rows_kernel, grid_of((int64_t)b * (Fo / 4)), dim3(TB), 0, pc->stream, hin + p->dst_off[rj] * Fo,
+                         p->po.root_index, b, Fo, p->xr);
+      r = gigl_linear(pc, p->xr, lw.wq[rj], lw.bq[rj], p->b_dev, p->b_max, Fo, Fo, 0, p->qr);
+    }
+    return r;
+  };
+  // ---- fork: input projections + ReLU (h0[type block] = relu(W_in x + b_in) over the type's distinct nodes) and the
+  // first layer's projections on the side stream ...
+  gigl_ctx* pc = (p->side && ctx->prof_mask == 0) ? p->side : ctx;  // (timed runs keep one stream: the timers are the ctx's)
+  if (pc != ctx) {
+    GIGL_HIP_CHECK(ctx, hipEventRecord(p->ev_nodes, st));
+    GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(pc->stream, p->ev_nodes, 0));
+  }
   for (int j = 0; j < m.n_types; ++j) {
     const int t = m.type_order[j];
     const int32_t* n_dev = p->po.n_nodes + t;
     const int d = m.feat[j] ? m.feat_dim[j] : 1;
     if (m.feat[j]) {
       if ((d & 3) == 0)
-        hipLaunchKernelGGL(hgt_gather_rows_kernel<4>, grid_of(p->cap[j] * (d / 4)), dim3(TB), 0, st, m.feat[j],
+        hipLaunchKernelGGL(hgt_gather_rows_kernel<4>, grid_of(p->cap[j] * (d / 4)), dim3(TB), 0, pc->stream, m.feat[j],
                            p->po.nodes[t], n_dev, p->cap[j], d, p->xin);
       else
-        hipLaunchKernelGGL(hgt_gather_rows_kernel<1>, grid_of(p->cap[j] * d), dim3(TB), 0, st, m.feat[j], p->po.nodes[t],
-                           n_dev, p->cap[j], d, p->xin);
+        hipLaunchKernelGGL(hgt_gather_rows_kernel<1>, grid_of(p->cap[j] * d), dim3(TB), 0, pc->stream, m.feat[j],
+                           p->po.nodes[t], n_dev, p->cap[j], d, p->xin);
     } else {
-      hipLaunchKernelGGL(hgt_ones_kernel, grid_of(p->cap[j]), dim3(TB), 0, st, p->xin, p->cap[j]);
+      hipLaunchKernelGGL(hgt_ones_kernel, grid_of(p->cap[j]), dim3(TB), 0, pc->stream, p->xin, p->cap[j]);
     }
-    rc = gigl_linear(ctx, p->xin, m.w_in[j], m.b_in[j], n_dev, p->cap[j], d, Fo, 1, h + p->dst_off[j] * Fo);
-    if (rc != GIGL_OK) return rc;
+    rc = gigl_linear(pc, p->xin, m.w_in[j], m.b_in[j], n_dev, p->cap[j], d, Fo, 1, h + p->dst_off[j] * Fo);
+    if (rc != GIGL_OK) return pc == ctx ? rc : gigl_fail(ctx, rc, "%s", gigl_last_error(pc));
   }
+  rc = project_layer(0, pc, h);
+  if (rc != GIGL_OK) return pc == ctx ? rc : gigl_fail(ctx, rc, "%s", gigl_last_error(pc));
+  if (pc != ctx) GIGL_HIP_CHECK(ctx, hipEventRecord(p->ev_proj, pc->stream));
+  // ---- ... while the main stream numbers the edges and merges them into the CSR by destination; join
+  rc = gigl_typed_plan_run_edges(p->plan, b);
+  if (rc != GIGL_OK) return rc;
+  gigl_typed_csr_out csr{};
+  rc = gigl_typed_plan_merged_csr_ex(p->plan, b, m.type_order, m.n_types, m.slot_order, m.slot_etype, m.n_slots, 1, &csr);
+  if (rc != GIGL_OK) return rc;
+  if (pc != ctx) GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, p->ev_proj, 0));
   for (int l = 0; l < L; ++l) {
     const gigl_hgt_layer_weights& lw = m.layer[l];
     const bool last = l == L - 1;
-    // K / V blocks of the slots this layer reads (the last layer computes the roots' rows: only edges INTO their type)
-    for (int s = 0; s < m.n_slots; ++s) {
-      if (last && p->slot_dst_j[s] != p->root_j) continue;
-      const int sj = p->slot_src_j[s];
-      const int32_t* n_dev = p->po.n_nodes + m.type_order[sj];
-      const float* x = h + p->dst_off[sj] * Fo;
-      rc = gigl_linear(ctx, x, lw.wk[s], lw.bk[s], n_dev, p->cap[sj], Fo, Fo, 0, p->ks + p->src_off[s] * Fo);
-      if (rc == GIGL_OK)
-        rc = gigl_linear(ctx, x, lw.wv[s], lw.bv[s], n_dev, p->cap[sj], Fo, Fo, 0, p->vs + p->src_off[s] * Fo);
+    if (l > 0) {
+      rc = project_layer(l, ctx, h);
       if (rc != GIGL_OK) return rc;
     }
     if (!last) {
-      for (int j = 0; j < m.n_types; ++j) {
-        rc = gigl_linear(ctx, h + p->dst_off[j] * Fo, lw.wq[j], lw.bq[j], p->po.n_nodes + m.type_order[j], p->cap[j], Fo, Fo, 0,
-                         p->qq + p->dst_off[j] * Fo);
-        if (rc != GIGL_OK) return rc;
-      }
       rc = gigl_hgt_aggregate_act(ctx, p->qq, p->ks, p->vs, H, D, csr.rowptr, csr.col, csr.etype, lw.p_rel, p->rows_cap, 1,
                                   p->agg);
       if (rc != GIGL_OK) return rc;
@@ -198,12 +234,8 @@ int32_t hgt_body(gigl_hgt_infer* p, int32_t b) {
       hn = t;
     } else {
       const int rj = p->root_j;
-      // the roots' rows of the layer's input, their queries, their slices of the merged CSR (laid out by the plan)
-      hipLaunchKernelGGL(hgt_take_rows_kernel, grid_of((int64_t)b * (Fo / 4)), dim3(TB), 0, st, h + p->dst_off[rj] * Fo,
-                         p->po.root_index, b, Fo, p->xr);
-      rc = gigl_linear(ctx, p->xr, lw.wq[rj], lw.bq[rj], p->b_dev, p->b_max, Fo, Fo, 0, p->qr);
-      if (rc == GIGL_OK)
-        rc = gigl_hgt_aggregate_act(ctx, p->qr, p->ks, p->vs, H, D, csr.root_rowptr, csr.root_col, csr.root_etype, lw.p_rel, b,
+      // the roots' queries against their slices of the merged CSR (laid out by the plan)
+      rc = gigl_hgt_aggregate_act(ctx, p->qr, p->ks, p->vs, H, D, csr.root_rowptr, csr.root_col, csr.root_etype, lw.p_rel, b,
                                     1, p->aggr);
       if (rc == GIGL_OK) rc = gigl_linear(ctx, p->aggr, lw.wout[rj], lw.bout[rj], p->b_dev, p->b_max, Fo, Fo, 0, p->orow);
       if (rc != GIGL_OK) return rc;
@@ -231,6 +263,9 @@ int32_t gigl_hgt_infer_destroy(gigl_hgt_infer* p) {
     hipStreamSynchronize(p->ctx->stream);
   }
   if (p->exec) hipGraphExecDestroy(p->exec);
+  if (p->side) gigl_ctx_destroy(p->side);
+  if (p->ev_nodes) hipEventDestroy(p->ev_nodes);
+  if (p->ev_proj) hipEventDestroy(p->ev_proj);
   for (void* q : p->owned) hipFree(q);
   delete p;
   return GIGL_OK;
@@ -346,6 +381,19 @@ int32_t gigl_hgt_infer_create(gigl_ctx* ctx, gigl_typed_plan* plan, int32_t b_ma
   HGT_ALLOC(p->out, (int64_t)b_max * m.out_dim);
   HGT_ALLOC(p->b_dev, 8);
 #undef HGT_ALLOC
+  {  // the side stream of the first layer's projections: OPT-IN (GIGL_HGT_SIDE_STREAM=1) — measured, the replayed graph
+     // gains nothing from the fork (0.7457 against 0.7472 ms/step on typed-dblp: its branches do not run concurrently
+     // under this runtime's graph executor), so the default keeps one stream
+    const char* e = getenv("GIGL_HGT_SIDE_STREAM");
+    if (e && e[0] == '1' && ctx->stream != nullptr) {
+      if (gigl_ctx_create(ctx->device, &p->side) != GIGL_OK ||
+          hipEventCreateWithFlags(&p->ev_nodes, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&p->ev_proj, hipEventDisableTiming) != hipSuccess) {
+        gigl_hgt_infer_destroy(p);
+        return gigl_fail(ctx, GIGL_E_HIP, "hgt plan: side stream");
+      }
+    }
+  }
   *out = p;
   return GIGL_OK;
 }
@@ -359,7 +407,8 @@ int32_t gigl_hgt_infer_run(gigl_hgt_infer* p, const uint32_t* roots, int32_t b, 
   hipLaunchKernelGGL(hgt_copy_u32_kernel, grid_of(b), dim3(TB), 0, st, roots, (int64_t)b, p->roots);
   int32_t rc = GIGL_OK;
   const bool graph_ok = p->use_graph && st != nullptr && ctx->prof_mask == 0;
-  if (p->exec && (p->cap_b != b || p->cap_arena_gen != ctx->arena_gen || !graph_ok)) {
+  if (p->exec && (p->cap_b != b || p->cap_arena_gen != ctx->arena_gen || !graph_ok ||
+                  (p->side && p->cap_side_gen != p->side->arena_gen))) {
     GIGL_HIP_CHECK(ctx, hipStreamSynchronize(st));
     hipGraphExecDestroy(p->exec);
     p->exec = nullptr;
@@ -387,6 +436,7 @@ int32_t gigl_hgt_infer_run(gigl_hgt_infer* p, const uint32_t* roots, int32_t b, 
         return gigl_fail(ctx, GIGL_E_HIP, "capturing the typed inference step failed: %s", hipGetErrorString(err));
       }
       p->cap_arena_gen = ctx->arena_gen;
+      p->cap_side_gen = p->side ? p->side->arena_gen : 0;
     }
     GIGL_HIP_CHECK(ctx, hipGraphLaunch(p->exec, st));
   }

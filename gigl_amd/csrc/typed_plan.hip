@@ -464,6 +464,12 @@ int32_t gigl_typed_plan_create(gigl_ctx* ctx, const gigl_dag_op* ops, int32_t n_
 }
 
 int32_t gigl_typed_plan_run(gigl_typed_plan* p, const uint32_t* roots, int32_t b) {
+  int32_t rc = gigl_typed_plan_run_nodes(p, roots, b);
+  if (rc == GIGL_OK) rc = gigl_typed_plan_run_edges(p, b);
+  return rc;
+}
+
+int32_t gigl_typed_plan_run_nodes(gigl_typed_plan* p, const uint32_t* roots, int32_t b) {
   if (!p || !p->ctx) return GIGL_E_INVALID_ARG;
   gigl_ctx* ctx = p->ctx;
   GIGL_REQUIRE(ctx, roots && b >= 1 && b <= p->b_max, "between 1 and %d roots", p->b_max);
@@ -562,6 +568,18 @@ int32_t gigl_typed_plan_run(gigl_typed_plan* p, const uint32_t* roots, int32_t b
       }
     }
   }
+  hipLaunchKernelGGL(root_index_kernel, grid_of(b), dim3(TB), 0, st, roots, (int64_t)b,
+                     (const uint32_t*)p->nodes[p->root_type], (const int32_t*)(p->n_nodes + p->root_type), p->root_index);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_typed_plan_run_edges(gigl_typed_plan* p, int32_t b) {
+  if (!p || !p->ctx) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, b >= 1 && b <= p->b_max, "between 1 and %d roots", p->b_max);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
   // ---- per edge slot: the distinct (src, dst) pairs as local ids, ascending by (src, dst)
   for (int s = 0; s < p->n_slots; ++s) {
     const int64_t m = (int64_t)b * p->pairs_per_root[s];
@@ -627,8 +645,6 @@ int32_t gigl_typed_plan_run(gigl_typed_plan* p, const uint32_t* roots, int32_t b
       }
     }
   }
-  hipLaunchKernelGGL(root_index_kernel, grid_of(b), dim3(TB), 0, st, roots, (int64_t)b,
-                     (const uint32_t*)p->nodes[p->root_type], (const int32_t*)(p->n_nodes + p->root_type), p->root_index);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

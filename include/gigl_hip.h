@@ -495,6 +495,11 @@ typedef struct gigl_typed_plan_out {
 int32_t gigl_typed_plan_create(gigl_ctx* ctx, const gigl_dag_op* ops, int32_t n_ops, int32_t n_node_types,
                                int32_t root_node_type, int32_t n_edge_slots, int32_t b_max, gigl_typed_plan** out);
 int32_t gigl_typed_plan_run(gigl_typed_plan* plan, const uint32_t* roots, int32_t b);
+/* gigl_typed_plan_run in two halves — the ops, the node numbering and the roots' positions; then the edge lists — so that a
+ * caller can start work that needs only the nodes (feature rows, input projections) on another stream while the edges
+ * are still being numbered (csrc/hgt_plan.hip) */
+int32_t gigl_typed_plan_run_nodes(gigl_typed_plan* plan, const uint32_t* roots, int32_t b);
+int32_t gigl_typed_plan_run_edges(gigl_typed_plan* plan, int32_t b);
 int32_t gigl_typed_plan_buffers(gigl_typed_plan* plan, gigl_typed_plan_out* out);
 /* The batch graph's edges of ALL listed slots as ONE CSR by destination — the operand of the typed attention layers
  * (torch_geometric HGTConv's per-destination softmax over every incoming edge type; python/gigl/src/common/models/pyg/
