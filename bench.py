@@ -2281,9 +2281,9 @@ def run_typed(args, rank, world, local_rank):
     def run_pass():
         """the pool's batches as the typed in-HBM inference route runs them (Inferencer._typed_run_hbm): batch i+1's
         sampling is enqueued before the model over batch i is launched"""
-        if one_call is not None:
+        if one_call is not None:  # (batch i + 1's graph part is announced: it is built under batch i's layers)
             for i in range(n_batches):
-                one_call.run(roots_dev[i])
+                one_call.run(roots_dev[i], roots_dev[i + 1] if i + 1 < n_batches else None)
             return
         issue = lambda i: smp.batch_graph_plan_issue(pool[i % n_batches], "paper", dag, b_max=B,
                                                      edge_type_ids=model.convs[0].edge_types_map)
@@ -2365,7 +2365,8 @@ def run_typed(args, rank, world, local_rank):
                                f"SamplingOp DAG [{f0},{f1}] over {B} paper roots per step through the one-call typed plan + "
                                "2-layer HGT (hidden 64, heads 2, last layer on the roots)",
                    "entry": ("models_hetero.HgtInferPlan.run (gigl_hgt_infer_run: gigl_typed_plan_run + merged CSR at capacity "
-                             "prefixes + HGT over composed weights, one library call per step, replayed as one hipGraph)"
+                             "prefixes + HGT over composed weights, one library call per step: two captured parts, the next batch's graph part "
+                             "under this batch's layers)"
                              if one_call is not None else
                              "HipGraphDBSampler.batch_graph_plan_issue / _finish (gigl_typed_plan_run + gigl_typed_plan_merged_csr; "
                              "batch i+1 enqueued before the model over batch i) -> HGT.forward(row_subset) over composed weights"),

@@ -58,7 +58,7 @@ SYMBOLS = [
     "gigl_linear_weight_grad", "gigl_features_row_crc",
     "gigl_typed_plan_create", "gigl_typed_plan_run", "gigl_typed_plan_buffers", "gigl_typed_plan_destroy",
     "gigl_typed_plan_merged_csr", "gigl_sage_plan_half_split", "gigl_sort_distinct_u64", "gigl_sort_distinct_u32",
-    "gigl_typed_plan_merged_csr_ex", "gigl_hgt_aggregate_act", "gigl_dist_plan_set_aggr", "gigl_typed_plan_run_nodes", "gigl_typed_plan_run_edges", "gigl_hgt_infer_create", "gigl_hgt_infer_run",
+    "gigl_typed_plan_merged_csr_ex", "gigl_hgt_aggregate_act", "gigl_dist_plan_set_aggr", "gigl_typed_plan_run_nodes", "gigl_typed_plan_run_edges", "gigl_typed_plan_clone", "gigl_hgt_infer_create", "gigl_hgt_infer_run",
     "gigl_hgt_infer_set_model", "gigl_hgt_infer_use_graph", "gigl_hgt_infer_destroy",
     "gigl_sage_plan_run_part", "gigl_sage_plan_overflow_add",
     "gigl_sage_train_plan_create", "gigl_sage_train_plan_step", "gigl_sage_train_plan_loss", "gigl_sage_train_plan_destroy",
@@ -255,8 +255,9 @@ def load() -> C.CDLL:
         "gigl_dist_plan_set_aggr": [vp, i32],
         "gigl_typed_plan_run_nodes": [vp, vp, i32],
         "gigl_typed_plan_run_edges": [vp, i32],
+        "gigl_typed_plan_clone": [vp, vp, P(vp)],
         "gigl_hgt_infer_create": [vp, vp, i32, P(GiglHgtModel), P(i32), P(i32), P(vp)],
-        "gigl_hgt_infer_run": [vp, vp, i32, vp],
+        "gigl_hgt_infer_run": [vp, vp, i32, vp, i32, vp],
         "gigl_hgt_infer_set_model": [vp, P(GiglHgtModel)],
         "gigl_hgt_infer_use_graph": [vp, i32],
         "gigl_hgt_infer_destroy": [vp],

@@ -15,8 +15,13 @@
 // Weights are the COMPOSED inference weights (k_rel(K(x)) and v_rel(V(x)) are linear in x: one matrix per edge type;
 // the gated skip folded into the output projection), made once per parameter state by the caller.
 //
-// Per batch (4,096 roots, DBLP-shaped graph): ~40 kernel launches of the plan + 25 of the layers in one replay; bound by
-// the typed aggregate (HBM: two source rows per edge) and launch latency of the small sorts, not by the host.
+// A step is TWO captured parts over two plan workspaces: GRAPH (the typed plan: ops, numbering, merged CSR — latency-bound
+// small sorts) on a side stream, LAYERS (projections, typed aggregate — bandwidth-bound) on the caller's stream; given
+// the NEXT batch's roots, the graph part of batch i + 1 runs under the layers of batch i (as gigl_sage_train_plan does).
+// Branches forked INSIDE one captured graph were measured not to overlap under this runtime's executor; two graphs on
+// two streams do.
+// Per batch (4,096 roots, DBLP-shaped graph): ~45 kernel launches of the plan + 30 of the layers; bound by the typed
+// aggregate (HBM: two source rows per edge) and launch latency of the small sorts, not by the host.
 #include "common.h"
 
 #include <cstdlib>
@@ -24,10 +29,12 @@
 #include <vector>
 
 struct gigl_hgt_infer {
-  gigl_ctx* ctx = nullptr;
-  gigl_typed_plan* plan = nullptr;
+  gigl_ctx* ctx = nullptr;          // the caller's: the LAYERS part runs on its stream
+  gigl_ctx* side = nullptr;         // own ctx + stream: the GRAPH part (both plan workspaces live on it)
+  gigl_typed_plan* wp[2] = {nullptr, nullptr};  // two workspaces: batch i + 1 is built while batch i is encoded
+  gigl_typed_plan_out po[2]{};
+  gigl_typed_csr_out csr[2]{};
   gigl_hgt_model m{};
-  gigl_typed_plan_out po{};
   int32_t b_max = 0, root_j = -1;
   std::vector<int64_t> cap;        // per used type j: row capacity
   std::vector<int64_t> dst_off;    // per used type j: first row of its block (capacity prefix)
@@ -38,18 +45,20 @@ struct gigl_hgt_infer {
   float *xin = nullptr;              // [max cap * max feat dim] gathered input rows of one type at a time
   float *ks = nullptr, *vs = nullptr, *qq = nullptr, *agg = nullptr;
   float *xr = nullptr, *qr = nullptr, *aggr = nullptr, *orow = nullptr;  // the roots' rows of the last layer
-  uint32_t* roots = nullptr;         // static copy of the batch's roots (what the captured launches read)
+  uint32_t* roots[2] = {nullptr, nullptr};  // static copies of the batches' roots (what the captured launches read)
   float* out = nullptr;              // [b_max][out_dim] static result (copied to the caller's buffer)
   int32_t* b_dev = nullptr;          // the batch size as a device count
-  // the first layer's projections need the batch's NODES only: they run on a side stream (own ctx: own scratch) while the
-  // main stream is still numbering the edges and merging them into the CSR — a fork / join inside the captured graph
-  gigl_ctx* side = nullptr;
-  hipEvent_t ev_nodes = nullptr, ev_proj = nullptr;
-  uint64_t cap_side_gen = 0;
-  hipGraphExec_t exec = nullptr;
-  bool warm = false, use_graph = true;
+  // pipeline state
+  int cur = 0;
+  const uint32_t* fetched[2] = {nullptr, nullptr};  // whose GRAPH part a workspace holds (the caller's roots pointer)
+  int32_t fetched_b[2] = {0, 0};
+  hipEvent_t ev_graph[2] = {nullptr, nullptr};   // GRAPH part of the workspace done (side stream)
+  hipEvent_t ev_layers[2] = {nullptr, nullptr};  // LAYERS part done with the workspace (caller's stream)
+  hipGraphExec_t exec_graph[2] = {nullptr, nullptr}, exec_layers[2] = {nullptr, nullptr};
+  bool warm_graph[2] = {false, false}, warm_layers[2] = {false, false};
+  bool use_graph = true;
   int32_t cap_b = -1;
-  uint64_t cap_arena_gen = 0;
+  uint64_t cap_arena_gen = 0, cap_side_gen = 0;
   std::vector<void*> owned;
 };
 
@@ -135,93 +144,71 @@ int32_t dev_alloc(gigl_hgt_infer* p, T** out, int64_t count) {
   return GIGL_OK;
 }
 
-// everything of one batch after the roots are in p->roots: the launches that are captured
-int32_t hgt_body(gigl_hgt_infer* p, int32_t b) {
+// GRAPH part of workspace k (side stream): the ops, the numbering, the merged CSR at capacity prefixes
+int32_t hgt_graph_part(gigl_hgt_infer* p, int k, int32_t b) {
+  const gigl_hgt_model& m = p->m;
+  int32_t rc = gigl_typed_plan_run(p->wp[k], p->roots[k], b);
+  if (rc == GIGL_OK)
+    rc = gigl_typed_plan_merged_csr_ex(p->wp[k], b, m.type_order, m.n_types, m.slot_order, m.slot_etype, m.n_slots, 1,
+                                       &p->csr[k]);
+  if (rc != GIGL_OK) return gigl_fail(p->ctx, rc, "%s", gigl_last_error(p->side));
+  return GIGL_OK;
+}
+
+// LAYERS part over workspace k (the caller's stream): input projections, the HGT layers, the roots' rows
+int32_t hgt_layers_part(gigl_hgt_infer* p, int k, int32_t b) {
   gigl_ctx* ctx = p->ctx;
   const gigl_hgt_model& m = p->m;
+  const gigl_typed_plan_out& po = p->po[k];
+  const gigl_typed_csr_out& csr = p->csr[k];
   hipStream_t st = ctx->stream;
   const int Fo = m.hid, H = m.heads, D = Fo / H, L = m.n_layers;
-  int32_t rc = gigl_typed_plan_run_nodes(p->plan, p->roots, b);
-  if (rc != GIGL_OK) return rc;
+  int32_t rc = GIGL_OK;
   gigl_fill_u32(st, (uint32_t*)p->b_dev, (uint32_t)b, 1);
+  // ---- input projections + ReLU: h0[type block] = relu(W_in x + b_in) over the type's distinct nodes
   float* h = p->h[0];
   float* hn = p->h[1];
-  // the projections of layer l (what needs no edge): K / V blocks of the slots the layer reads (the last layer computes the
-  // roots' rows: only edges INTO their type), the queries — every type's rows, or the roots' rows of the last layer
-  auto project_layer = [&](int l, gigl_ctx* pc, const float* hin) -> int32_t {
-    const gigl_hgt_layer_weights& lw = m.layer[l];
-    const bool last = l == L - 1;
-    int32_t r = GIGL_OK;
-    for (int s = 0; s < m.n_slots; ++s) {
-      if (last && p->slot_dst_j[s] != p->root_j) continue;
-      const int sj = p->slot_src_j[s];
-      const int32_t* n_dev = p->po.n_nodes + m.type_order[sj];
-      const float* x = hin + p->dst_off[sj] * Fo;
-      r = gigl_linear(pc, x, lw.wk[s], lw.bk[s], n_dev, p->cap[sj], Fo, Fo, 0, p->ks + p->src_off[s] * Fo);
-      if (r == GIGL_OK) r = gigl_linear(pc, x, lw.wv[s], lw.bv[s], n_dev, p->cap[sj], Fo, Fo, 0, p->vs + p->src_off[s] * Fo);
-      if (r != GIGL_OK) return r;
-    }
-    if (!last) {
-      for (int j = 0; j < m.n_types; ++j) {
-        r = gigl_linear(pc, hin + p->dst_off[j] * Fo, lw.wq[j], lw.bq[j], p->po.n_nodes + m.type_order[j], p->cap[j], Fo, Fo, 0,
-                        p->qq + p->dst_off[j] * Fo);
-        if (r != GIGL_OK) return r;
-      }
-    } else {
-      const int rj = p->root_j;
-      hipLaunchKernelGGL(hgt_take_rows_kernel, grid_of((int64_t)b * (Fo / 4)), dim3(TB), 0, pc->stream, hin + p->dst_off[rj] * Fo,
-                         p->po.root_index, b, Fo, p->xr);
-      r = gigl_linear(pc, p->xr, lw.wq[rj], lw.bq[rj], p->b_dev, p->b_max, Fo, Fo, 0, p->qr);
-    }
-    return r;
-  };
-  // ---- fork: input projections + ReLU (h0[type block] = relu(W_in x + b_in) over the type's distinct nodes) and the
-  // first layer's projections on the side stream ...
-  gigl_ctx* pc = (p->side && ctx->prof_mask == 0) ? p->side : ctx;  // (timed runs keep one stream: the timers are the ctx's)
-  if (pc != ctx) {
-    GIGL_HIP_CHECK(ctx, hipEventRecord(p->ev_nodes, st));
-    GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(pc->stream, p->ev_nodes, 0));
-  }
   for (int j = 0; j < m.n_types; ++j) {
     const int t = m.type_order[j];
-    const int32_t* n_dev = p->po.n_nodes + t;
+    const int32_t* n_dev = po.n_nodes + t;
     const int d = m.feat[j] ? m.feat_dim[j] : 1;
     if (m.feat[j]) {
       if ((d & 3) == 0)
-        hipLaunchKernelGGL(hgt_gather_rows_kernel<4>, grid_of(p->cap[j] * (d / 4)), dim3(TB), 0, pc->stream, m.feat[j],
-                           p->po.nodes[t], n_dev, p->cap[j], d, p->xin);
+        hipLaunchKernelGGL(hgt_gather_rows_kernel<4>, grid_of(p->cap[j] * (d / 4)), dim3(TB), 0, st, m.feat[j], po.nodes[t],
+                           n_dev, p->cap[j], d, p->xin);
       else
-        hipLaunchKernelGGL(hgt_gather_rows_kernel<1>, grid_of(p->cap[j] * d), dim3(TB), 0, pc->stream, m.feat[j],
-                           p->po.nodes[t], n_dev, p->cap[j], d, p->xin);
+        hipLaunchKernelGGL(hgt_gather_rows_kernel<1>, grid_of(p->cap[j] * d), dim3(TB), 0, st, m.feat[j], po.nodes[t], n_dev,
+                           p->cap[j], d, p->xin);
     } else {
-      hipLaunchKernelGGL(hgt_ones_kernel, grid_of(p->cap[j]), dim3(TB), 0, pc->stream, p->xin, p->cap[j]);
+      hipLaunchKernelGGL(hgt_ones_kernel, grid_of(p->cap[j]), dim3(TB), 0, st, p->xin, p->cap[j]);
     }
-    rc = gigl_linear(pc, p->xin, m.w_in[j], m.b_in[j], n_dev, p->cap[j], d, Fo, 1, h + p->dst_off[j] * Fo);
-    if (rc != GIGL_OK) return pc == ctx ? rc : gigl_fail(ctx, rc, "%s", gigl_last_error(pc));
+    rc = gigl_linear(ctx, p->xin, m.w_in[j], m.b_in[j], n_dev, p->cap[j], d, Fo, 1, h + p->dst_off[j] * Fo);
+    if (rc != GIGL_OK) return rc;
   }
-  rc = project_layer(0, pc, h);
-  if (rc != GIGL_OK) return pc == ctx ? rc : gigl_fail(ctx, rc, "%s", gigl_last_error(pc));
-  if (pc != ctx) GIGL_HIP_CHECK(ctx, hipEventRecord(p->ev_proj, pc->stream));
-  // ---- ... while the main stream numbers the edges and merges them into the CSR by destination; join
-  rc = gigl_typed_plan_run_edges(p->plan, b);
-  if (rc != GIGL_OK) return rc;
-  gigl_typed_csr_out csr{};
-  rc = gigl_typed_plan_merged_csr_ex(p->plan, b, m.type_order, m.n_types, m.slot_order, m.slot_etype, m.n_slots, 1, &csr);
-  if (rc != GIGL_OK) return rc;
-  if (pc != ctx) GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, p->ev_proj, 0));
   for (int l = 0; l < L; ++l) {
     const gigl_hgt_layer_weights& lw = m.layer[l];
     const bool last = l == L - 1;
-    if (l > 0) {
-      rc = project_layer(l, ctx, h);
+    // K / V blocks of the slots this layer reads (the last layer computes the roots' rows: only edges INTO their type)
+    for (int s = 0; s < m.n_slots; ++s) {
+      if (last && p->slot_dst_j[s] != p->root_j) continue;
+      const int sj = p->slot_src_j[s];
+      const int32_t* n_dev = po.n_nodes + m.type_order[sj];
+      const float* x = h + p->dst_off[sj] * Fo;
+      rc = gigl_linear(ctx, x, lw.wk[s], lw.bk[s], n_dev, p->cap[sj], Fo, Fo, 0, p->ks + p->src_off[s] * Fo);
+      if (rc == GIGL_OK) rc = gigl_linear(ctx, x, lw.wv[s], lw.bv[s], n_dev, p->cap[sj], Fo, Fo, 0, p->vs + p->src_off[s] * Fo);
       if (rc != GIGL_OK) return rc;
     }
     if (!last) {
+      for (int j = 0; j < m.n_types; ++j) {
+        rc = gigl_linear(ctx, h + p->dst_off[j] * Fo, lw.wq[j], lw.bq[j], po.n_nodes + m.type_order[j], p->cap[j], Fo, Fo, 0,
+                         p->qq + p->dst_off[j] * Fo);
+        if (rc != GIGL_OK) return rc;
+      }
       rc = gigl_hgt_aggregate_act(ctx, p->qq, p->ks, p->vs, H, D, csr.rowptr, csr.col, csr.etype, lw.p_rel, p->rows_cap, 1,
                                   p->agg);
       if (rc != GIGL_OK) return rc;
       for (int j = 0; j < m.n_types; ++j) {
-        const int32_t* n_dev = p->po.n_nodes + m.type_order[j];
+        const int32_t* n_dev = po.n_nodes + m.type_order[j];
         float* o = hn + p->dst_off[j] * Fo;
         rc = gigl_linear(ctx, p->agg + p->dst_off[j] * Fo, lw.wout[j], lw.bout[j], n_dev, p->cap[j], Fo, Fo, 0, o);
         if (rc != GIGL_OK) return rc;
@@ -234,8 +221,12 @@ int32_t hgt_body(gigl_hgt_infer* p, int32_t b) {
       hn = t;
     } else {
       const int rj = p->root_j;
-      // the roots' queries against their slices of the merged CSR (laid out by the plan)
-      rc = gigl_hgt_aggregate_act(ctx, p->qr, p->ks, p->vs, H, D, csr.root_rowptr, csr.root_col, csr.root_etype, lw.p_rel, b,
+      // the roots' rows of the layer's input, their queries, their slices of the merged CSR (laid out by the plan)
+      hipLaunchKernelGGL(hgt_take_rows_kernel, grid_of((int64_t)b * (Fo / 4)), dim3(TB), 0, st, h + p->dst_off[rj] * Fo,
+                         po.root_index, b, Fo, p->xr);
+      rc = gigl_linear(ctx, p->xr, lw.wq[rj], lw.bq[rj], p->b_dev, p->b_max, Fo, Fo, 0, p->qr);
+      if (rc == GIGL_OK)
+        rc = gigl_hgt_aggregate_act(ctx, p->qr, p->ks, p->vs, H, D, csr.root_rowptr, csr.root_col, csr.root_etype, lw.p_rel, b,
                                     1, p->aggr);
       if (rc == GIGL_OK) rc = gigl_linear(ctx, p->aggr, lw.wout[rj], lw.bout[rj], p->b_dev, p->b_max, Fo, Fo, 0, p->orow);
       if (rc != GIGL_OK) return rc;
@@ -252,6 +243,68 @@ int32_t hgt_body(gigl_hgt_infer* p, int32_t b) {
   return GIGL_OK;
 }
 
+// run a part on `c`'s stream: eagerly the first time (workspace growth, table builds and kernel attributes cannot happen
+// inside a capture), captured the second, replayed from then on
+template <typename F>
+int32_t hgt_run_part(gigl_hgt_infer* p, gigl_ctx* c, hipGraphExec_t* exec, bool* warm, bool graph_ok, F body) {
+  hipStream_t st = c->stream;
+  if (!graph_ok) return body();
+  if (!*exec && !*warm) {
+    const int32_t rc = body();
+    if (rc != GIGL_OK) return rc;
+    *warm = true;
+    return GIGL_OK;
+  }
+  if (!*exec) {
+    hipGraph_t graph = nullptr;
+    int32_t rc = GIGL_OK;
+    hipError_t err = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (err == hipSuccess) {
+      rc = body();
+      const hipError_t e2 = hipStreamEndCapture(st, &graph);
+      if (rc == GIGL_OK && e2 != hipSuccess) err = e2;
+    }
+    if (rc == GIGL_OK && err == hipSuccess) err = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
+    if (graph) hipGraphDestroy(graph);
+    if (rc != GIGL_OK) return rc;
+    if (err != hipSuccess) {
+      *exec = nullptr;
+      return gigl_fail(p->ctx, GIGL_E_HIP, "capturing a part of the typed inference step failed: %s", hipGetErrorString(err));
+    }
+  }
+  GIGL_HIP_CHECK(p->ctx, hipGraphLaunch(*exec, st));
+  return GIGL_OK;
+}
+
+void hgt_drop_graphs(gigl_hgt_infer* p, bool graph_parts, bool layer_parts) {
+  for (int k = 0; k < 2; ++k) {
+    if (graph_parts && p->exec_graph[k]) {
+      hipGraphExecDestroy(p->exec_graph[k]);
+      p->exec_graph[k] = nullptr;
+    }
+    if (layer_parts && p->exec_layers[k]) {
+      hipGraphExecDestroy(p->exec_layers[k]);
+      p->exec_layers[k] = nullptr;
+    }
+  }
+}
+
+// the GRAPH part of `roots` into workspace k, on the side stream; ev_graph[k] marks its end
+int32_t hgt_issue_graph(gigl_hgt_infer* p, int k, const uint32_t* roots, int32_t b, bool graph_ok) {
+  gigl_ctx* sc = p->side;
+  // the workspace is free once the LAYERS part that last read it is done, and the caller's roots are valid at this point
+  // of ITS stream: one event recorded there now says both (it sits behind that part, not behind work enqueued later)
+  GIGL_HIP_CHECK(p->ctx, hipEventRecord(p->ev_layers[k], p->ctx->stream));
+  GIGL_HIP_CHECK(p->ctx, hipStreamWaitEvent(sc->stream, p->ev_layers[k], 0));
+  hipLaunchKernelGGL(hgt_copy_u32_kernel, grid_of(b), dim3(TB), 0, sc->stream, roots, (int64_t)b, p->roots[k]);
+  const int32_t rc = hgt_run_part(p, sc, &p->exec_graph[k], &p->warm_graph[k], graph_ok, [&] { return hgt_graph_part(p, k, b); });
+  if (rc != GIGL_OK) return rc;
+  GIGL_HIP_CHECK(p->ctx, hipEventRecord(p->ev_graph[k], sc->stream));
+  p->fetched[k] = roots;
+  p->fetched_b[k] = b;
+  return GIGL_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -262,10 +315,14 @@ int32_t gigl_hgt_infer_destroy(gigl_hgt_infer* p) {
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
   }
-  if (p->exec) hipGraphExecDestroy(p->exec);
+  if (p->side) hipStreamSynchronize(p->side->stream);
+  hgt_drop_graphs(p, true, true);
+  for (int k = 0; k < 2; ++k) {
+    if (p->wp[k]) gigl_typed_plan_destroy(p->wp[k]);
+    if (p->ev_graph[k]) hipEventDestroy(p->ev_graph[k]);
+    if (p->ev_layers[k]) hipEventDestroy(p->ev_layers[k]);
+  }
   if (p->side) gigl_ctx_destroy(p->side);
-  if (p->ev_nodes) hipEventDestroy(p->ev_nodes);
-  if (p->ev_proj) hipEventDestroy(p->ev_proj);
   for (void* q : p->owned) hipFree(q);
   delete p;
   return GIGL_OK;
@@ -279,14 +336,9 @@ int32_t gigl_hgt_infer_set_model(gigl_hgt_infer* p, const gigl_hgt_model* model)
   GIGL_REQUIRE(ctx, model->n_types == o.n_types && model->n_slots == o.n_slots && model->n_layers == o.n_layers &&
                         model->heads == o.heads && model->hid == o.hid && model->out_dim == o.out_dim,
                "hgt plan: set_model changes the shape");
-  bool same = true;
-  same = same && memcmp(model, &p->m, sizeof(gigl_hgt_model)) == 0;
-  if (!same) {
+  if (memcmp(model, &p->m, sizeof(gigl_hgt_model)) != 0) {
     GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (p->exec) {
-      hipGraphExecDestroy(p->exec);
-      p->exec = nullptr;
-    }
+    hgt_drop_graphs(p, false, true);  // (the GRAPH parts read no weight)
     p->m = *model;
   }
   return GIGL_OK;
@@ -313,13 +365,21 @@ int32_t gigl_hgt_infer_create(gigl_ctx* ctx, gigl_typed_plan* plan, int32_t b_ma
   gigl_hgt_infer* p = new (std::nothrow) gigl_hgt_infer();
   if (!p) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
   p->ctx = ctx;
-  p->plan = plan;
   p->m = m;
   p->b_max = b_max;
-  int32_t rc = gigl_typed_plan_buffers(plan, &p->po);
+  int32_t rc = gigl_ctx_create(ctx->device, &p->side);
+  // the caller's plan is the template: two workspaces of the same DAG on the side ctx
+  for (int k = 0; k < 2 && rc == GIGL_OK; ++k) {
+    rc = gigl_typed_plan_clone(plan, p->side, &p->wp[k]);
+    if (rc == GIGL_OK) rc = gigl_typed_plan_buffers(p->wp[k], &p->po[k]);
+    if (rc == GIGL_OK && (hipEventCreateWithFlags(&p->ev_graph[k], hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&p->ev_layers[k], hipEventDisableTiming) != hipSuccess))
+      rc = GIGL_E_HIP;
+  }
   if (rc != GIGL_OK) {
-    delete p;
-    return rc;
+    const int32_t r2 = gigl_fail(ctx, rc, "hgt plan: side workspaces: %s", p->side ? gigl_last_error(p->side) : "ctx");
+    gigl_hgt_infer_destroy(p);
+    return r2;
   }
 #define HGT_FAIL(...)                                     \
   do {                                                    \
@@ -332,14 +392,14 @@ int32_t gigl_hgt_infer_create(gigl_ctx* ctx, gigl_typed_plan* plan, int32_t b_ma
   for (int t = 0; t < 16; ++t) type_pos[t] = -1;
   for (int j = 0; j < m.n_types; ++j) {
     const int t = m.type_order[j];
-    if (t < 0 || t >= 16 || p->po.nodes_cap[t] <= 0 || type_pos[t] >= 0) HGT_FAIL("hgt plan: node type %d is not one of the plan's", t);
+    if (t < 0 || t >= 16 || p->po[0].nodes_cap[t] <= 0 || type_pos[t] >= 0) HGT_FAIL("hgt plan: node type %d is not one of the plan's", t);
     type_pos[t] = j;
-    p->cap.push_back(p->po.nodes_cap[t]);
+    p->cap.push_back(p->po[0].nodes_cap[t]);
     p->dst_off.push_back(p->rows_cap);
-    p->rows_cap += p->po.nodes_cap[t];
+    p->rows_cap += p->po[0].nodes_cap[t];
     const int64_t d = m.feat[j] ? m.feat_dim[j] : 1;
     if (d < 1 || !m.w_in[j]) HGT_FAIL("hgt plan: node type %d has no input projection", t);
-    max_in = p->po.nodes_cap[t] * d > max_in ? p->po.nodes_cap[t] * d : max_in;
+    max_in = p->po[0].nodes_cap[t] * d > max_in ? p->po[0].nodes_cap[t] * d : max_in;
   }
   for (int s = 0; s < m.n_slots; ++s) {
     const int sj = slot_src_type[s] >= 0 && slot_src_type[s] < 16 ? type_pos[slot_src_type[s]] : -1;
@@ -350,7 +410,6 @@ int32_t gigl_hgt_infer_create(gigl_ctx* ctx, gigl_typed_plan* plan, int32_t b_ma
     p->src_off.push_back(p->src_rows);
     p->src_rows += p->cap[sj];
   }
-  // (the roots' type: the one whose block root_index points into — the caller lists it; found through the plan's CSR call)
   p->root_j = -1;
   for (int j = 0; j < m.n_types; ++j)
     if (m.type_order[j] == m.root_type) p->root_j = j;
@@ -377,69 +436,57 @@ int32_t gigl_hgt_infer_create(gigl_ctx* ctx, gigl_typed_plan* plan, int32_t b_ma
   HGT_ALLOC(p->qr, (int64_t)b_max * Fo);
   HGT_ALLOC(p->aggr, (int64_t)b_max * Fo);
   HGT_ALLOC(p->orow, (int64_t)b_max * Fo);
-  HGT_ALLOC(p->roots, b_max);
+  HGT_ALLOC(p->roots[0], b_max);
+  HGT_ALLOC(p->roots[1], b_max);
   HGT_ALLOC(p->out, (int64_t)b_max * m.out_dim);
   HGT_ALLOC(p->b_dev, 8);
 #undef HGT_ALLOC
-  {  // the side stream of the first layer's projections: OPT-IN (GIGL_HGT_SIDE_STREAM=1) — measured, the replayed graph
-     // gains nothing from the fork (0.7457 against 0.7472 ms/step on typed-dblp: its branches do not run concurrently
-     // under this runtime's graph executor), so the default keeps one stream
-    const char* e = getenv("GIGL_HGT_SIDE_STREAM");
-    if (e && e[0] == '1' && ctx->stream != nullptr) {
-      if (gigl_ctx_create(ctx->device, &p->side) != GIGL_OK ||
-          hipEventCreateWithFlags(&p->ev_nodes, hipEventDisableTiming) != hipSuccess ||
-          hipEventCreateWithFlags(&p->ev_proj, hipEventDisableTiming) != hipSuccess) {
-        gigl_hgt_infer_destroy(p);
-        return gigl_fail(ctx, GIGL_E_HIP, "hgt plan: side stream");
-      }
-    }
-  }
+  // (both workspaces start free)
+  for (int k = 0; k < 2; ++k) GIGL_HIP_CHECK(ctx, hipEventRecord(p->ev_layers[k], ctx->stream));
   *out = p;
   return GIGL_OK;
 }
 
-int32_t gigl_hgt_infer_run(gigl_hgt_infer* p, const uint32_t* roots, int32_t b, float* out) {
+int32_t gigl_hgt_infer_run(gigl_hgt_infer* p, const uint32_t* roots, int32_t b, const uint32_t* roots_next, int32_t b_next,
+                           float* out) {
   if (!p || !p->ctx) return GIGL_E_INVALID_ARG;
   gigl_ctx* ctx = p->ctx;
   GIGL_REQUIRE(ctx, roots && out && b >= 1 && b <= p->b_max, "between 1 and %d roots", p->b_max);
+  GIGL_REQUIRE(ctx, !roots_next || (b_next >= 1 && b_next <= p->b_max), "between 1 and %d next roots", p->b_max);
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  hipLaunchKernelGGL(hgt_copy_u32_kernel, grid_of(b), dim3(TB), 0, st, roots, (int64_t)b, p->roots);
-  int32_t rc = GIGL_OK;
-  const bool graph_ok = p->use_graph && st != nullptr && ctx->prof_mask == 0;
-  if (p->exec && (p->cap_b != b || p->cap_arena_gen != ctx->arena_gen || !graph_ok ||
-                  (p->side && p->cap_side_gen != p->side->arena_gen))) {
+  // graphs are captured for ONE batch size (the job's; a short last batch runs eagerly), off while the ctx's timers are on
+  const bool timers = ctx->prof_mask != 0;
+  if (p->cap_b < 0) p->cap_b = b;
+  if ((p->exec_graph[0] || p->exec_graph[1]) && p->cap_side_gen != p->side->arena_gen) {
+    GIGL_HIP_CHECK(ctx, hipStreamSynchronize(p->side->stream));
+    hgt_drop_graphs(p, true, false);
+  }
+  if ((p->exec_layers[0] || p->exec_layers[1]) && p->cap_arena_gen != ctx->arena_gen) {
     GIGL_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    hipGraphExecDestroy(p->exec);
-    p->exec = nullptr;
+    hgt_drop_graphs(p, false, true);
   }
-  if (!graph_ok || !p->warm || p->cap_b != b) {
-    // eager: the first batch of a size (workspace growth, table builds and kernel attributes cannot happen in a capture)
-    rc = hgt_body(p, b);
+  auto graph_ok = [&](int32_t bb) { return p->use_graph && !timers && bb == p->cap_b; };
+  const int k = p->cur;
+  int32_t rc = GIGL_OK;
+  if (p->fetched[k] != roots || p->fetched_b[k] != b) {  // not prefetched by the previous call
+    rc = hgt_issue_graph(p, k, roots, b, graph_ok(b));
     if (rc != GIGL_OK) return rc;
-    p->warm = true;
-    p->cap_b = b;
-  } else {
-    if (!p->exec) {
-      hipGraph_t graph = nullptr;
-      hipError_t err = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-      if (err == hipSuccess) {
-        rc = hgt_body(p, b);
-        const hipError_t e2 = hipStreamEndCapture(st, &graph);
-        if (rc == GIGL_OK && e2 != hipSuccess) err = e2;
-      }
-      if (rc == GIGL_OK && err == hipSuccess) err = hipGraphInstantiate(&p->exec, graph, nullptr, nullptr, 0);
-      if (graph) hipGraphDestroy(graph);
-      if (rc != GIGL_OK) return rc;
-      if (err != hipSuccess) {
-        p->exec = nullptr;
-        return gigl_fail(ctx, GIGL_E_HIP, "capturing the typed inference step failed: %s", hipGetErrorString(err));
-      }
-      p->cap_arena_gen = ctx->arena_gen;
-      p->cap_side_gen = p->side ? p->side->arena_gen : 0;
-    }
-    GIGL_HIP_CHECK(ctx, hipGraphLaunch(p->exec, st));
   }
+  if (roots_next) {  // the next batch's GRAPH part starts now, under this batch's layers
+    rc = hgt_issue_graph(p, 1 - k, roots_next, b_next, graph_ok(b_next));
+    if (rc != GIGL_OK) return rc;
+  }
+  p->cap_side_gen = p->side->arena_gen;
+  GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, p->ev_graph[k], 0));
+  // (the legacy default stream cannot be captured: the layers then run eagerly, the graph part still replays)
+  rc = hgt_run_part(p, ctx, &p->exec_layers[k], &p->warm_layers[k], graph_ok(b) && st != nullptr,
+                    [&] { return hgt_layers_part(p, k, b); });
+  if (rc != GIGL_OK) return rc;
+  p->cap_arena_gen = ctx->arena_gen;
+  GIGL_HIP_CHECK(ctx, hipEventRecord(p->ev_layers[k], st));
+  p->fetched[k] = nullptr;
+  p->cur = 1 - k;
   hipLaunchKernelGGL(hgt_copy_u32_kernel, grid_of((int64_t)b * p->m.out_dim), dim3(TB), 0, st, (const uint32_t*)p->out,
                      (int64_t)b * p->m.out_dim, (uint32_t*)out);
   GIGL_HIP_CHECK(ctx, hipGetLastError());

@@ -463,6 +463,11 @@ int32_t gigl_typed_plan_create(gigl_ctx* ctx, const gigl_dag_op* ops, int32_t n_
   return GIGL_OK;
 }
 
+int32_t gigl_typed_plan_clone(gigl_typed_plan* src, gigl_ctx* ctx, gigl_typed_plan** out) {
+  if (!src || !ctx || !out) return GIGL_E_INVALID_ARG;
+  return gigl_typed_plan_create(ctx, src->ops.data(), src->n_ops, src->n_types, src->root_type, src->n_slots, src->b_max, out);
+}
+
 int32_t gigl_typed_plan_run(gigl_typed_plan* p, const uint32_t* roots, int32_t b) {
   int32_t rc = gigl_typed_plan_run_nodes(p, roots, b);
   if (rc == GIGL_OK) rc = gigl_typed_plan_run_edges(p, b);

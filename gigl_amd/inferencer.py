@@ -308,8 +308,11 @@ def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str,
                         one_call = None
                 if one_call is not None:
                     try:
-                        for chunk in chunks:
-                            emb = one_call.run(torch.from_numpy(chunk.astype(np.uint32).view(np.int32)))
+                        r_dev = [torch.from_numpy(c.astype(np.uint32).view(np.int32)).to(dev) for c in chunks]
+                        torch.cuda.current_stream(dev).synchronize()  # (the uploads, before the plan's streams read them)
+                        for ci, chunk in enumerate(chunks):
+                            # (batch ci + 1 is announced: its graph part is built under this batch's layers)
+                            emb = one_call.run(r_dev[ci], r_dev[ci + 1] if ci + 1 < len(chunks) else None)
                             torch.cuda.current_stream(dev).wait_stream(s.engine._stream)
                             writer.add(chunk, emb, None)
                         s.engine.synchronize()

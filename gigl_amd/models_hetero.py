@@ -582,19 +582,26 @@ class HgtInferPlan:
         from . import _lib
         _lib.check(self.eng._lib.gigl_hgt_infer_use_graph(self._handle, 1 if enable else 0), self.eng._ctx)
 
-    def run(self, roots: torch.Tensor) -> torch.Tensor:
+    def run(self, roots: torch.Tensor, next_roots: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """roots: int32 device ids [b].  next_roots: the tensor the NEXT call will pass as `roots` (the same object): its
+        batch graph is then built on the plan's own stream while this batch's layers run"""
         import ctypes as C
         from . import _lib
         eng = self.eng
         self._refresh()
         b = int(roots.numel())
-        r = roots.to(device=eng.device, dtype=torch.int32).contiguous()
+        assert roots.is_cuda and roots.dtype == torch.int32 and roots.is_contiguous()
+        nxt, nb = None, 0
+        if next_roots is not None and int(next_roots.numel()):
+            assert next_roots.is_cuda and next_roots.dtype == torch.int32 and next_roots.is_contiguous()
+            nxt, nb = C.c_void_p(next_roots.data_ptr()), int(next_roots.numel())
         out = torch.empty((b, int(self.model.lin.weight.shape[0])), dtype=torch.float32, device=eng.device)
         with torch.cuda.stream(eng._stream):
-            _lib.check(eng._lib.gigl_hgt_infer_run(self._handle, C.c_void_p(r.data_ptr()), b, C.c_void_p(out.data_ptr())),
-                       eng._ctx)
-            r.record_stream(eng._stream)
+            _lib.check(eng._lib.gigl_hgt_infer_run(self._handle, C.c_void_p(roots.data_ptr()), b, nxt, nb,
+                                                   C.c_void_p(out.data_ptr())), eng._ctx)
             out.record_stream(eng._stream)
+        # (the announced roots are read on the plan's stream up to the next call: the caller keeps them alive)
+        self._live = (roots, next_roots)
         return out
 
     def close(self) -> None:

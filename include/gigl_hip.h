@@ -500,6 +500,8 @@ int32_t gigl_typed_plan_run(gigl_typed_plan* plan, const uint32_t* roots, int32_
  * are still being numbered (csrc/hgt_plan.hip) */
 int32_t gigl_typed_plan_run_nodes(gigl_typed_plan* plan, const uint32_t* roots, int32_t b);
 int32_t gigl_typed_plan_run_edges(gigl_typed_plan* plan, int32_t b);
+/* a second workspace of the same DAG on another ctx (its own stream): what lets batch i + 1 be built while batch i is read */
+int32_t gigl_typed_plan_clone(gigl_typed_plan* plan, gigl_ctx* ctx, gigl_typed_plan** out);
 int32_t gigl_typed_plan_buffers(gigl_typed_plan* plan, gigl_typed_plan_out* out);
 /* The batch graph's edges of ALL listed slots as ONE CSR by destination — the operand of the typed attention layers
  * (torch_geometric HGTConv's per-destination softmax over every incoming edge type; python/gigl/src/common/models/pyg/
@@ -533,8 +535,8 @@ int32_t gigl_typed_plan_merged_csr_ex(gigl_typed_plan* plan, int32_t b, const in
 int32_t gigl_typed_plan_destroy(gigl_typed_plan* plan);
 
 /* ---- the typed inference step in ONE call (csrc/hgt_plan.hip): gigl_typed_plan_run -> merged CSR at capacity prefixes
- *      -> HGT encoder -> the roots' rows; no host read inside, the step is captured as a hipGraph on its second run and
- *      replayed from then on.  Replaces the HGT forward of python/gigl/src/common/models/pyg/heterogeneous.py:18-120
+ *      -> HGT encoder -> the roots' rows; no host read inside; the step is two captured parts (graph part on the plan's own
+ *      stream, layers on the caller's), replayed from their second run on.  Replaces the HGT forward of python/gigl/src/common/models/pyg/heterogeneous.py:18-120
  *      (torch_geometric HGTConv layers: hgt_conv.py) driven per batch by the inferencer
  *      (python/gigl/src/inference/v1/gnn_inferencer.py:234-340).
  *      Weights are DEVICE pointers the caller keeps alive, in the COMPOSED inference form (linear stages multiplied
@@ -579,8 +581,12 @@ typedef struct gigl_hgt_infer gigl_hgt_infer;
 /* slot_src_type / slot_dst_type [n_slots]: the plan's node types each listed slot joins (HOST).  b_max <= the plan's. */
 int32_t gigl_hgt_infer_create(gigl_ctx* ctx, gigl_typed_plan* plan, int32_t b_max, const gigl_hgt_model* model,
                               const int32_t* slot_src_type, const int32_t* slot_dst_type, gigl_hgt_infer** out);
-/* roots: DEVICE uint32 [b]; out: DEVICE fp32 [b][out_dim], on the ctx's stream. */
-int32_t gigl_hgt_infer_run(gigl_hgt_infer* infer, const uint32_t* roots, int32_t b, float* out);
+/* roots: DEVICE uint32 [b]; out: DEVICE fp32 [b][out_dim], on the ctx's stream.  roots_next (NULL: none) = the roots the NEXT
+ * call will pass (same pointer, b_next of them): their GRAPH part — ops, numbering, merged CSR — is enqueued on the plan's
+ * own stream before this batch's layers, so the two overlap; a call whose roots were announced finds its graph built.
+ * `plan` of _create is a template: the step keeps two workspaces of its DAG of its own. */
+int32_t gigl_hgt_infer_run(gigl_hgt_infer* infer, const uint32_t* roots, int32_t b, const uint32_t* roots_next,
+                           int32_t b_next, float* out);
 /* new weight pointers of the same shapes (after a parameter update); a changed pointer re-captures the step */
 int32_t gigl_hgt_infer_set_model(gigl_hgt_infer* infer, const gigl_hgt_model* model);
 int32_t gigl_hgt_infer_use_graph(gigl_hgt_infer* infer, int32_t enable);

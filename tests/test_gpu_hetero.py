@@ -430,10 +430,12 @@ def test_one_call_typed_inference_step_equals_the_staged_forward(layers, l2):
         s.engine.synchronize()
         return out.cpu().numpy()
 
-    def one_call(roots):
-        r = torch.from_numpy(roots.astype(np.uint32).view(np.int32)).to(s.engine.device)
-        out = plan.run(r)
+    def one_call(roots, nxt=None):
+        r = roots if torch.is_tensor(roots) else torch.from_numpy(roots.astype(np.uint32).view(np.int32)).to(s.engine.device)
+        torch.cuda.synchronize()
+        out = plan.run(r, nxt)
         s.engine.synchronize()
+        torch.cuda.synchronize()
         return out.cpu().numpy()
 
     pools = [rng.integers(0, n["paper"], B) for _ in range(4)]
@@ -449,6 +451,17 @@ def test_one_call_typed_inference_step_equals_the_staged_forward(layers, l2):
         model.convs[0].kqv_lin.lins["author"].weight.add_(0.05)
     for roots in pools[:3]:
         np.testing.assert_allclose(one_call(roots), staged(roots), rtol=2e-5, atol=2e-5)
+    # announced batches: batch i + 1's graph part is built on the plan's own stream under batch i's layers
+    devs = [torch.from_numpy(r.astype(np.uint32).view(np.int32)).to(s.engine.device) for r in pools]
+    want = [staged(r) for r in pools]
+    for rep in range(2):
+        for i in range(4):
+            got = one_call(devs[i], devs[i + 1] if i + 1 < 4 else None)
+            np.testing.assert_allclose(got, want[i], rtol=2e-5, atol=2e-5)
+    # an announcement that is not honoured (other roots arrive): the workspace is rebuilt
+    got = one_call(devs[2], devs[3])
+    np.testing.assert_allclose(one_call(devs[0]), want[0], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(got, want[2], rtol=2e-5, atol=2e-5)
     plan.use_graph(False)
     np.testing.assert_allclose(one_call(pools[3]), staged(pools[3]), rtol=2e-5, atol=2e-5)
     plan.close()
