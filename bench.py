@@ -2508,7 +2508,11 @@ def run_gat_lp(args, rank, world, local_rank):
     gp = torch.Generator(device="cpu")
     gp.manual_seed(42)
     K, W = max(args.steps, 8), max(args.warmup, 2)
-    pool = 64
+    # calls of G = 64 steps rotate over S streams (own ctx, plans and captured graph each, the resident graph shared) like
+    # the headline's: one call's sampler / union run under another's attention reductions
+    S_gat = max(1, int(args.streams)) if not (os.environ.get("GIGL_BENCH_GAT_STAGED") or os.environ.get("GIGL_BENCH_NO_GRAPH")
+                                              or args.timed_only) else 1
+    pool = 64 * S_gat
     anchors = torch.randint(0, n, (pool, B), generator=gp).to(torch.int32).to(dev)
     negs = torch.randint(0, n, (pool, n_neg), generator=gp).to(torch.int32).to(dev)
     acc = torch.zeros(2, dtype=torch.int64, device=dev)
@@ -2538,8 +2542,8 @@ def run_gat_lp(args, rank, world, local_rank):
             acc.add_(torch.stack([sum(c.sum() for c in tree.cnt).to(torch.int64), agg.to(torch.int64)]))
         return emb
 
-    def steps_of(a, ng, count):
-        """G steps: a [G, B] anchors, ng [G, n_neg] random negatives -> the G losses"""
+    def steps_of(a, ng, count, eng=eng, plans=plans):
+        """G steps: a [G, B] anchors, ng [G, n_neg] random negatives -> the G losses (eng / plans: the slot's)"""
         pos, cnt = eng.sample_positives(a.reshape(-1), 1)
         pos = pos.view(G, B)
         if plans is not None:
@@ -2623,14 +2627,55 @@ def run_gat_lp(args, rank, world, local_rank):
         except Exception as exc:  # noqa: BLE001 — the eager driver is the same path, only slower
             print(f"gat-lp: graph capture unavailable ({type(exc).__name__}: {str(exc)[:200]})", file=sys.stderr)
             call = eager_call
+    # ---- the other streams' slots: own ctx (the resident graph and table shared), own plans, own captured graph
+    slots = [(call, st)]
+    extra_engs = []
+    if call is not eager_call and plans is not None:
+        for k in range(1, S_gat):
+            e_k = HipEngine(local_rank)
+            e_k.share_resident(eng)
+            st_k = torch.cuda.Stream(device=dev)
+            e_k.bind_stream(st_k)
+            pl_k = (model.make_plan(e_k, 2 * B, fanouts, groups=G), model.make_plan(e_k, n_neg, fanouts, groups=G))
+            a_k, n_k = anchors[:G].clone(), negs[:G].clone()
+            with torch.cuda.stream(st_k), torch.no_grad():
+                for _ in range(2):
+                    dbg = steps_of(a_k, n_k, False, e_k, pl_k)
+            st_k.synchronize()
+            if os.environ.get("GIGL_BENCH_DEBUG"):
+                print("slot", k, "eager", dbg[:3].tolist(), file=sys.stderr)
+            g_k = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_k, stream=st_k):
+                with torch.no_grad():
+                    loss_k = steps_of(a_k, n_k, False, e_k, pl_k)
+
+            def call_k(i0, count=False, a_k=a_k, n_k=n_k, g_k=g_k, st_k=st_k, loss_k=loss_k):
+                with torch.cuda.stream(st_k):
+                    a_k.copy_(anchors[i0:i0 + G], non_blocking=True)
+                    n_k.copy_(negs[i0:i0 + G], non_blocking=True)
+                    g_k.replay()
+                return loss_k
+            with torch.cuda.stream(st_k):
+                got = call_k(0).clone()
+            st_k.synchronize()
+            with torch.cuda.stream(st):
+                want = eager_call(0).clone()
+            st.synchronize()
+            if not torch.equal(want, got):
+                raise RuntimeError(f"slot {k}: replayed losses differ from the eager ones: max |diff| "
+                                   f"{float((want - got).abs().max())}, {want[:3].tolist()} vs {got[:3].tolist()}")
+            slots.append((call_k, st_k))
+            extra_engs.append((e_k, pl_k))
+        if len(slots) > 1:
+            driver += f"; {len(slots)} streams in flight (one call each)"
     rep_s, steps = [], 0
     t_all = time.perf_counter()
     while time.perf_counter() - t_all < args.min_seconds or len(rep_s) < args.min_reps:
-        st.synchronize()
+        torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        for i0 in range(0, pool, G):
-            call(i0)
-        st.synchronize()
+        for c, i0 in enumerate(range(0, pool, G)):
+            slots[c % len(slots)][0](i0)
+        torch.cuda.synchronize(dev)
         rep_s.append(time.perf_counter() - t1)
         steps += pool
     elapsed = float(sum(rep_s))
@@ -2728,6 +2773,10 @@ def run_gat_lp(args, rank, world, local_rank):
         line.update(value=float(v.item()), ms_per_step=float(t.item()), n_gpus=world)
     if rank == 0:
         emit(line)
+    for e_k, pl_k in extra_engs:
+        for p_ in pl_k:
+            p_.close()
+        e_k.close()
     eng.close()
     if world > 1:
         dist.barrier()
