@@ -1654,9 +1654,12 @@ def run_train(args, rank, world, local_rank):
                 if count:
                     return eager_step(i, True)
                 # (the next batch's sampling + union overlap this batch's layers: gigl_sage_train_plan_prefetch)
-                nxt = my[i + 1] if i + 1 < my.shape[0] and not os.environ.get("GIGL_BENCH_TRAIN_NO_PREFETCH") else None
+                pf = os.environ.get("GIGL_BENCH_TRAIN_NO_PREFETCH")  # ("1": none, "2": one batch ahead only)
+                nxt = my[i + 1] if i + 1 < my.shape[0] and pf != "1" else None
+                nxt2 = my[i + 2] if i + 2 < my.shape[0] and not pf else None
                 with torch.cuda.stream(st):
-                    return lib_plan.step(my[i], lab_pool[i], sampling_seed=resident.seed, mode=mode, next_roots=nxt)
+                    return lib_plan.step(my[i], lab_pool[i], sampling_seed=resident.seed, mode=mode, next_roots=nxt,
+                                         next_roots2=nxt2)
             for i in range(min(W, 4)):  # (eager step, capture, replays)
                 step(i)
             st.synchronize()

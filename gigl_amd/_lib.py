@@ -61,7 +61,7 @@ SYMBOLS = [
     "gigl_typed_plan_merged_csr_ex", "gigl_hgt_aggregate_act", "gigl_dist_plan_set_aggr", "gigl_typed_plan_run_nodes", "gigl_typed_plan_run_edges", "gigl_typed_plan_clone", "gigl_hgt_infer_create", "gigl_hgt_infer_run",
     "gigl_hgt_infer_set_model", "gigl_hgt_infer_use_graph", "gigl_hgt_infer_destroy",
     "gigl_sage_plan_run_part", "gigl_sage_plan_overflow_add",
-    "gigl_sage_train_plan_create", "gigl_sage_train_plan_step", "gigl_sage_train_plan_loss", "gigl_sage_train_plan_destroy",
+    "gigl_sage_train_plan_create", "gigl_sage_train_plan_step", "gigl_sage_train_plan_step2", "gigl_sage_train_plan_loss", "gigl_sage_train_plan_destroy",
 ]
 
 KERNEL_IDS = {
@@ -380,6 +380,7 @@ def load() -> C.CDLL:
         "gigl_sage_train_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), vp, vp, i32, C.c_float, C.c_float, C.c_float,
                                         C.c_float, C.c_float, vp],
         "gigl_sage_train_plan_step": [vp, vp, vp, i32, vp, i32, i32, vp],
+        "gigl_sage_train_plan_step2": [vp, vp, vp, i32, vp, vp, i32, i32, vp],
         "gigl_sage_train_plan_destroy": [vp],
         "gigl_gat_input_layer_fused": [vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, i64, vp, i32,
                                        vp, vp],

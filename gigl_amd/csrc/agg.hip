@@ -778,6 +778,99 @@ __device__ __forceinline__ int split_lds_off(int row, int k) {
   return row * 32 + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7);
 }
 
+// Weight gradient on the matrix cores: dW[n][k] = sum_r dy[r][n] * a[r][k] is a product whose INNER dimension is the row
+// index, so both operands enter transposed.  A thread stages eight consecutive ROWS of one column (eight dword loads,
+// each coalesced across the 64 lanes = 64 consecutive columns), splits them into the three bf16 planes (split3: the
+// exact-sum split of the projection kernel) and stores eight row-consecutive bf16 per plane as one 16-byte LDS write
+// into a [column][32 rows] tile — the same swizzled tile the projection reads its fragments from, with "column" in the
+// role of the tile row.  Four waves as 2 x 2 over a 64 (n) x 64 (k) tile, six products per 16 rows, two accumulators per
+// wave (one per half of the 32-row block) so that dependent MFMAs alternate.  dy is masked by relu_y > 0 on the way in;
+// column sums of dy (the bias gradient) are taken from the staged values.  Partials per chunk of `rc` rows, reduced in
+// chunk order by linear_weight_grad_reduce_kernel: a fixed summation order.
+__global__ __launch_bounds__(256) void linear_weight_grad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ a,
+                                                                      const float* __restrict__ relu_y,
+                                                                      const int32_t* __restrict__ m_dev, int N, int K,
+                                                                      float* __restrict__ part, float* __restrict__ partb,
+                                                                      int rc) {
+  __shared__ __attribute__((aligned(16))) short s_d[3][64 * 32];
+  __shared__ __attribute__((aligned(16))) short s_w[3][64 * 32];
+  __shared__ float s_strip[4][32 * 36];
+  __shared__ float s_cs[4][64];
+  const int M = *m_dev;
+  const int r0 = blockIdx.x * rc;
+  if (r0 >= M) return;
+  const int r1 = min(M, r0 + rc);
+  const int n0 = blockIdx.y * 64, k0 = blockIdx.z * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int c = lane, rb = wv;  // staging: column c of the tile, rows rb*8 .. rb*8+7 of the 32-row block
+  const bool dcol = n0 + c < N, acol = k0 + c < K;
+  float vd[8], va[8];
+  auto fetch = [&](int rbase) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int row = rbase + rb * 8 + t;
+      float d = 0.f, x = 0.f;
+      if (row < r1) {
+        if (dcol) {
+          d = dy[(int64_t)row * N + n0 + c];
+          if (relu_y && !(relu_y[(int64_t)row * N + n0 + c] > 0.f)) d = 0.f;
+        }
+        if (acol) x = a[(int64_t)row * K + k0 + c];
+      }
+      vd[t] = d;
+      va[t] = x;
+    }
+  };
+  auto stage = [&](const float* v, short (*pl)[64 * 32]) {
+    uint32_t b1[8], b2[8], b3[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) split3(v[t], b1[t], b2[t], b3[t]);
+    const int o = split_lds_off(c, rb * 8);
+    *reinterpret_cast<uint4*>(&pl[0][o]) = make_uint4((b1[0] >> 16) | b1[1], (b1[2] >> 16) | b1[3], (b1[4] >> 16) | b1[5], (b1[6] >> 16) | b1[7]);
+    *reinterpret_cast<uint4*>(&pl[1][o]) = make_uint4((b2[0] >> 16) | b2[1], (b2[2] >> 16) | b2[3], (b2[4] >> 16) | b2[5], (b2[6] >> 16) | b2[7]);
+    *reinterpret_cast<uint4*>(&pl[2][o]) = make_uint4((b3[0] >> 16) | b3[1], (b3[2] >> 16) | b3[3], (b3[4] >> 16) | b3[5], (b3[6] >> 16) | b3[7]);
+  };
+  const int wn = wv >> 1, wk = wv & 1, r = lane & 31, g = lane >> 5;
+  float16_t acc0, acc1;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc0[t] = acc1[t] = 0.f;
+  float colsum = 0.f;
+  fetch(r0);
+  for (int rbase = r0; rbase < r1; rbase += 32) {
+    stage(vd, s_d);
+    stage(va, s_w);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) colsum += vd[t];
+    __syncthreads();
+    if (rbase + 32 < r1) fetch(rbase + 32);  // (in flight during this block's MFMAs)
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PW[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
+    bf16x8_t fa0[3], fw0[3], fa1[3], fw1[3];
+#pragma unroll
+    for (int p_ = 0; p_ < 3; ++p_) {
+      fa0[p_] = *reinterpret_cast<const bf16x8_t*>(&s_d[p_][split_lds_off(wn * 32 + r, 8 * g)]);
+      fw0[p_] = *reinterpret_cast<const bf16x8_t*>(&s_w[p_][split_lds_off(wk * 32 + r, 8 * g)]);
+      fa1[p_] = *reinterpret_cast<const bf16x8_t*>(&s_d[p_][split_lds_off(wn * 32 + r, 16 + 8 * g)]);
+      fw1[p_] = *reinterpret_cast<const bf16x8_t*>(&s_w[p_][split_lds_off(wk * 32 + r, 16 + 8 * g)]);
+    }
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[PA[t]], fw0[PW[t]], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[PA[t]], fw1[PW[t]], acc1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc0[t] += acc1[t];
+  store_block_32x32(acc0, s_strip[wv], lane, nullptr, 0, n0 + wn * 32, k0 + wk * 32, N, K,
+                    part + (int64_t)blockIdx.x * N * K);
+  if (partb && blockIdx.z == 0) {
+    s_cs[rb][c] = colsum;
+    __syncthreads();
+    if (tid < 64 && n0 + tid < N)
+      partb[(int64_t)blockIdx.x * N + n0 + tid] = (s_cs[0][tid] + s_cs[1][tid]) + (s_cs[2][tid] + s_cs[3][tid]);
+  }
+}
+
 // four consecutive k of one row -> four bf16 of each plane, stored as 8 bytes per plane
 __device__ __forceinline__ void split_store(const float4_t v, short* p1, short* p2, short* p3) {
   uint32_t a1[4], a2[4], a3[4];
@@ -3005,7 +3098,12 @@ int32_t gigl_linear_weight_grad(gigl_ctx* ctx, const float* dy, const float* a, 
   float* partb = db ? (float*)gigl_arena_alloc(ctx, chunks * n * 4) : nullptr;
   if (!part || (db && !partb)) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
   const dim3 grid((unsigned)chunks, (unsigned)((n + 63) / 64), (unsigned)((k + 63) / 64));
-  hipLaunchKernelGGL(linear_weight_grad_kernel, grid, dim3(256), 0, ctx->stream, dy, a, relu_y, m_dev, n, k, part, partb, rcw);
+  static const bool valu = getenv("GIGL_WGRAD_VALU") != nullptr;  // (A/B knob: the fp32 FMA kernel)
+  if (valu)
+    hipLaunchKernelGGL(linear_weight_grad_kernel, grid, dim3(256), 0, ctx->stream, dy, a, relu_y, m_dev, n, k, part, partb, rcw);
+  else
+    hipLaunchKernelGGL(linear_weight_grad_mfma_kernel, grid, dim3(256), 0, ctx->stream, dy, a, relu_y, m_dev, n, k, part, partb,
+                       rcw);
   hipLaunchKernelGGL(linear_weight_grad_reduce_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, part,
                      partb, m_dev, nk, n, dw, db, rcw);
   GIGL_HIP_CHECK(ctx, hipGetLastError());

@@ -894,19 +894,24 @@ int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sam
 // the plan's own, into one of two workspaces, and a step that is told the NEXT batch (roots_next) starts that batch's graph part while the
 // LAYERS part (forward, loss, backward, Adam: the caller's ctx and stream) of the current batch runs — a training step
 // is a chain of small launches (one batch: the weights change between batches), so the two chains share the GPU well.
+// graph workspaces of the training plan: the current batch + the next.  (Three — two batches ahead, two graph parts in
+// flight on streams of their own — was measured: 0.266 against 0.245 ms/step; the second graph part takes more from the
+// layers than it hides.  roots_next2 of _step2 is then not used.)
+constexpr int TRAIN_WS = 2;
 struct gigl_sage_train_plan {
   gigl_ctx* ctx = nullptr;         // the caller's (its stream carries the layers part; errors are reported on it)
   // two ctxs of the plan's own, for their ARENAS: scratch addresses are baked into the captured launches, and another
   // plan on the caller's ctx (the inference plan of an evaluation pass between epochs) may grow — reallocate — that arena
   gigl_ctx* lctx = nullptr;        // layers part (bound to the caller's stream at every step)
-  gigl_ctx* side = nullptr;        // graph part: sample + union, on its own stream
-  gigl_sage_plan* base[2] = {nullptr, nullptr};  // tree / union workspaces (on `side`)
+  gigl_ctx* side[TRAIN_WS] = {nullptr};  // graph part: sample + union — a ctx + stream per workspace
+  gigl_sage_plan* base[TRAIN_WS] = {nullptr};  // tree / union workspaces (each on its own side ctx / stream: two graph
+                                               // parts — of the next batch and of the one after — can be in flight)
   int32_t cur = 0;                 // workspace of the next step
-  bool fetched[2] = {false, false};  // the workspace holds the graph of a prefetched batch
-  hipEvent_t ev_graph[2] = {nullptr, nullptr};   // graph part of the workspace done (recorded on the side stream)
+  bool fetched[TRAIN_WS] = {false};  // the workspace holds the graph of a prefetched batch
+  hipEvent_t ev_graph[TRAIN_WS] = {nullptr};   // graph part of the workspace done (recorded on its side stream)
   // layers part that read the workspace done (recorded on the caller's stream); [2]: the caller's stream as it stands
   // when a graph part is issued (the roots it is handed were written there)
-  hipEvent_t ev_layers[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_layers[TRAIN_WS + 1] = {nullptr};
   int32_t L = 0, b = 0, act_last = 0;
   int32_t dims[GIGL_MAX_HOPS + 1] = {0};
   int64_t rows_cap[GIGL_MAX_HOPS] = {0};  // rows layer l may compute
@@ -929,8 +934,8 @@ struct gigl_sage_train_plan {
   float lr = 0.01f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, wd = 0.f;
   std::vector<void*> owned;
   // hipGraph replay, per workspace and part
-  hipGraphExec_t exec_graph[2] = {nullptr, nullptr}, exec_layers[2] = {nullptr, nullptr};
-  bool warm_graph = false, warm_layers = false;  // one eager run of the part has sized arenas / built tables
+  hipGraphExec_t exec_graph[TRAIN_WS] = {nullptr}, exec_layers[TRAIN_WS] = {nullptr};
+  bool warm_graph[TRAIN_WS] = {false}, warm_layers = false;  // one eager run of the part has sized arenas / built tables
   int32_t cap_seed = 0, cap_mode = -1;
 };
 
@@ -1061,11 +1066,12 @@ int32_t train_run_part(gigl_ctx* ctx, hipGraphExec_t* exec, bool* warm, const st
 
 // the graph part of workspace k for `roots`, on the side stream; ev_graph[k] marks its end
 int32_t train_graph_part(gigl_sage_train_plan* t, int k, const uint32_t* roots, int32_t sampling_seed, int32_t mode) {
-  gigl_ctx* sc = t->side;
+  gigl_ctx* sc = t->side[k];
   if (t->cap_seed != sampling_seed || t->cap_mode != mode) {  // seed and mode are baked into the captured launches
     GIGL_HIP_CHECK(sc, hipStreamSynchronize(sc->stream));
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TRAIN_WS; ++i)
       if (t->exec_graph[i]) {
+        if (t->side[i]) hipStreamSynchronize(t->side[i]->stream);
         hipGraphExecDestroy(t->exec_graph[i]);
         t->exec_graph[i] = nullptr;
       }
@@ -1074,10 +1080,10 @@ int32_t train_graph_part(gigl_sage_train_plan* t, int k, const uint32_t* roots, 
   }
   // the workspace is free once the layers part that last read it is done; `roots` was written on the caller's stream
   if (t->ev_layers[k]) GIGL_HIP_CHECK(sc, hipStreamWaitEvent(sc->stream, t->ev_layers[k], 0));
-  GIGL_HIP_CHECK(sc, hipEventRecord(t->ev_layers[2], t->ctx->stream));
-  GIGL_HIP_CHECK(sc, hipStreamWaitEvent(sc->stream, t->ev_layers[2], 0));
+  GIGL_HIP_CHECK(sc, hipEventRecord(t->ev_layers[TRAIN_WS], t->ctx->stream));
+  GIGL_HIP_CHECK(sc, hipStreamWaitEvent(sc->stream, t->ev_layers[TRAIN_WS], 0));
   GIGL_HIP_CHECK(sc, hipMemcpyAsync(t->base[k]->roots_buf, roots, (size_t)t->b * 4, hipMemcpyDeviceToDevice, sc->stream));
-  const int32_t rc = train_run_part(sc, &t->exec_graph[k], &t->warm_graph,
+  const int32_t rc = train_run_part(sc, &t->exec_graph[k], &t->warm_graph[k],
                                     [&]() { return train_enqueue_graph(t, k, sampling_seed, mode); }, 0);
   if (rc != GIGL_OK) return rc;
   GIGL_HIP_CHECK(sc, hipEventRecord(t->ev_graph[k], sc->stream));
@@ -1092,17 +1098,19 @@ int32_t gigl_sage_train_plan_destroy(gigl_sage_train_plan* t) {
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
   }
-  if (t->side) hipStreamSynchronize(t->side->stream);
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < TRAIN_WS; ++k)
+    if (t->side[k]) hipStreamSynchronize(t->side[k]->stream);
+  for (int k = 0; k < TRAIN_WS; ++k) {
     if (t->exec_graph[k]) hipGraphExecDestroy(t->exec_graph[k]);
     if (t->exec_layers[k]) hipGraphExecDestroy(t->exec_layers[k]);
     if (t->ev_graph[k]) hipEventDestroy(t->ev_graph[k]);
     if (t->base[k]) gigl_sage_plan_destroy(t->base[k]);
   }
-  for (int k = 0; k < 3; ++k)
+  for (int k = 0; k < TRAIN_WS + 1; ++k)
     if (t->ev_layers[k]) hipEventDestroy(t->ev_layers[k]);
   for (void* q : t->owned) hipFree(q);
-  if (t->side) gigl_ctx_destroy(t->side);
+  for (int k = 0; k < TRAIN_WS; ++k)
+    if (t->side[k]) gigl_ctx_destroy(t->side[k]);
   if (t->lctx) {
     gigl_ctx_set_stream(t->lctx, nullptr);  // (the stream is the caller's)
     gigl_ctx_destroy(t->lctx);
@@ -1123,15 +1131,16 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
   gigl_sage_train_plan* t = new (std::nothrow) gigl_sage_train_plan();
   if (!t) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
   t->ctx = ctx;
-  int32_t rc = gigl_ctx_create(ctx->device, &t->side);
-  if (rc == GIGL_OK) rc = gigl_ctx_create(ctx->device, &t->lctx);
-  for (int k = 0; k < 2 && rc == GIGL_OK; ++k) {
-    rc = plan_create(t->side, graph, feat, b, fanouts, hops, dims, (const float* const*)w, (const float* const*)bias, act_last,
-                     false, &t->base[k]);
-    if (rc != GIGL_OK) gigl_fail(ctx, rc, "%s", gigl_last_error(t->side));
+  int32_t rc = gigl_ctx_create(ctx->device, &t->lctx);
+  for (int k = 0; k < TRAIN_WS && rc == GIGL_OK; ++k) {
+    rc = gigl_ctx_create(ctx->device, &t->side[k]);
+    if (rc != GIGL_OK) break;
+    rc = plan_create(t->side[k], graph, feat, b, fanouts, hops, dims, (const float* const*)w, (const float* const*)bias,
+                     act_last, false, &t->base[k]);
+    if (rc != GIGL_OK) gigl_fail(ctx, rc, "%s", gigl_last_error(t->side[k]));
     if (rc == GIGL_OK && hipEventCreateWithFlags(&t->ev_graph[k], hipEventDisableTiming) != hipSuccess) rc = GIGL_E_HIP;
   }
-  for (int k = 0; k < 3 && rc == GIGL_OK; ++k)
+  for (int k = 0; k < TRAIN_WS + 1 && rc == GIGL_OK; ++k)
     if (hipEventCreateWithFlags(&t->ev_layers[k], hipEventDisableTiming) != hipSuccess) rc = GIGL_E_HIP;
   if (rc != GIGL_OK) {
     gigl_sage_train_plan_destroy(t);
@@ -1208,6 +1217,12 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
 
 int32_t gigl_sage_train_plan_step(gigl_sage_train_plan* t, const uint32_t* roots, const int64_t* labels, int32_t n_valid,
                                   const uint32_t* roots_next, int32_t sampling_seed, int32_t mode, float* loss_out) {
+  return gigl_sage_train_plan_step2(t, roots, labels, n_valid, roots_next, nullptr, sampling_seed, mode, loss_out);
+}
+
+int32_t gigl_sage_train_plan_step2(gigl_sage_train_plan* t, const uint32_t* roots, const int64_t* labels, int32_t n_valid,
+                                   const uint32_t* roots_next, const uint32_t* roots_next2, int32_t sampling_seed,
+                                   int32_t mode, float* loss_out) {
   if (!t) return GIGL_E_INVALID_ARG;
   gigl_ctx* ctx = t->ctx;
   GIGL_REQUIRE(ctx, roots && labels && n_valid >= 1 && n_valid <= t->b, "bad argument");
@@ -1216,18 +1231,23 @@ int32_t gigl_sage_train_plan_step(gigl_sage_train_plan* t, const uint32_t* roots
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int k = t->cur;
-  if (!t->fetched[k]) {  // not prefetched by the previous step: the graph part of THIS batch now (the layers wait for it)
+  if (!t->fetched[k]) {  // not prefetched by an earlier step: the graph part of THIS batch now (the layers wait for it)
     const int32_t rc = train_graph_part(t, k, roots, sampling_seed, mode);
-    if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->side));
+    if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->side[k]));
   }
   t->fetched[k] = false;
   // the NEXT batch's graph part goes to the side stream BEFORE this batch's layers are enqueued: it waits for what the
   // caller's stream holds now (roots_next was written there; the layers that last read the other workspace), not for
   // the layers about to be enqueued
-  if (roots_next) {
-    const int32_t rc = train_graph_part(t, k ^ 1, roots_next, sampling_seed, mode);
-    if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->side));
-    t->fetched[k ^ 1] = true;
+  // (two batches ahead: the graph parts are chains of small latency-bound launches, two of them in flight on their own
+  // streams take little more than one)
+  const uint32_t* ahead[2] = {roots_next, roots_next ? roots_next2 : nullptr};
+  for (int d = 0; d < 2; ++d) {
+    const int kk = (k + 1 + d) % TRAIN_WS;
+    if (!ahead[d] || t->fetched[kk] || kk == k) continue;
+    const int32_t rc = train_graph_part(t, kk, ahead[d], sampling_seed, mode);
+    if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->side[kk]));
+    t->fetched[kk] = true;
   }
   // the step's inputs go into the static buffers the (captured) launches read: labels, the number of real roots (a
   // 32-bit fill: no host memory involved, ordered on the stream)
@@ -1241,7 +1261,7 @@ int32_t gigl_sage_train_plan_step(gigl_sage_train_plan* t, const uint32_t* roots
   const int32_t rc = train_run_part(t->lctx, &t->exec_layers[k], &t->warm_layers, [&]() { return train_enqueue_layers(t, k); }, 1);
   if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->lctx));
   GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_layers[k], st));
-  t->cur = k ^ 1;
+  t->cur = (k + 1) % TRAIN_WS;
   if (loss_out) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(loss_out, t->loss, 4, hipMemcpyDeviceToDevice, st));
   return GIGL_OK;
 }

@@ -1296,22 +1296,23 @@ class SageTrainPlan:
         return roots.contiguous()
 
     def step(self, roots: torch.Tensor, labels: torch.Tensor, sampling_seed: int = 42, mode: int = MODE_SPARK_HASH,
-             next_roots: Optional[torch.Tensor] = None) -> torch.Tensor:
+             next_roots: Optional[torch.Tensor] = None, next_roots2: Optional[torch.Tensor] = None) -> torch.Tensor:
         """one optimiser step on the batch: roots int32 device [k <= b] (uint32 ids), labels int64 device [k]; a short
         batch is padded with its first root (a repeated root adds nothing to the union graph) and masked out of the loss.
         next_roots: the roots of the batch the NEXT call will be given — its sampling and union graph then run on the
-        plan's own stream while this step's forward / backward run (roots_next of gigl_sage_train_plan_step).
+        plan's own stream while this step's forward / backward run (roots_next of gigl_sage_train_plan_step);
+        next_roots2: the batch after that one (two graph parts in flight: gigl_sage_train_plan_step2).
         Returns the loss (a device scalar owned by the plan, overwritten by the next step)."""
         k = int(roots.numel())
         assert labels.is_cuda and labels.dtype == torch.int64 and labels.numel() == k
         roots, labels = self._padded(roots), labels.contiguous()
         nxt = self._padded(next_roots) if next_roots is not None and next_roots.numel() else None
-        # (read asynchronously by the plan's own stream: kept alive until the step after the next)
-        self._keep = (getattr(self, "_keep", (None,))[-1], (roots, nxt))
-        check(self._lib.gigl_sage_train_plan_step(self._plan, C.c_void_p(roots.data_ptr()), C.c_void_p(labels.data_ptr()), k,
-                                                  C.c_void_p(nxt.data_ptr()) if nxt is not None else None,
-                                                  int(sampling_seed), int(mode), C.c_void_p(self.loss.data_ptr())),
-              self.eng._ctx)
+        nxt2 = self._padded(next_roots2) if nxt is not None and next_roots2 is not None and next_roots2.numel() else None
+        # (read asynchronously by the plan's own streams: kept alive over the next three steps)
+        self._keep = (tuple(getattr(self, "_keep", ()))[-2:]) + ((roots, nxt, nxt2),)
+        p_ = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(self._lib.gigl_sage_train_plan_step2(self._plan, p_(roots), p_(labels), k, p_(nxt), p_(nxt2),
+                                                   int(sampling_seed), int(mode), p_(self.loss)), self.eng._ctx)
         return self.loss
 
     def close(self) -> None:

@@ -311,7 +311,7 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
         with torch.cuda.stream(self._train_stream):
             for lo in range(0, ids.size, b):  # (the next batch's sampling + union overlap this batch's layers)
                 loss = plan.step(roots_all[lo:lo + b], labels_all[lo:lo + b], sampling_seed=res.seed, mode=res.mode,
-                                 next_roots=roots_all[lo + b:lo + 2 * b])
+                                 next_roots=roots_all[lo + b:lo + 2 * b], next_roots2=roots_all[lo + 2 * b:lo + 3 * b])
         res.engine.synchronize()
         plan.store(model)
         return loss.detach().clone().reshape(())

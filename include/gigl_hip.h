@@ -1076,6 +1076,11 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
  * layers part runs on the ctx's stream (the next call's `roots` are then not read again).  Results do not depend on it. */
 int32_t gigl_sage_train_plan_step(gigl_sage_train_plan* plan, const uint32_t* roots, const int64_t* labels, int32_t n_valid,
                                   const uint32_t* roots_next, int32_t sampling_seed, int32_t mode, float* loss_out);
+/* the same with the batch AFTER the next announced too (roots_next2: what the call after the next will pass; NULL: none):
+ * two graph parts — small latency-bound launches — are then in flight on streams of their own next to this batch's layers */
+int32_t gigl_sage_train_plan_step2(gigl_sage_train_plan* plan, const uint32_t* roots, const int64_t* labels, int32_t n_valid,
+                                   const uint32_t* roots_next, const uint32_t* roots_next2, int32_t sampling_seed,
+                                   int32_t mode, float* loss_out);
 const float* gigl_sage_train_plan_loss(gigl_sage_train_plan* plan);
 int32_t gigl_sage_train_plan_destroy(gigl_sage_train_plan* plan);
 
