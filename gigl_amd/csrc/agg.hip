@@ -2685,7 +2685,8 @@ int32_t gigl_sage_project_features(gigl_ctx* ctx, gigl_feat* feat, const float* 
   // widened copy + the fp32 path, for comparison)
   const bool half_direct = feat->dtype == GIGL_DTYPE_F16 && (d & 3) == 0 && !getenv("GIGL_PROJECT_WIDEN") &&
                            !getenv("GIGL_LINEAR_EXACT");
-  if (hipMalloc((void**)&cnt, 32) != hipSuccess ||
+  // (cnt: [0..1] row counts, [2..4] hs scales, [6..7] the scale kernel's running maximum + ticket: zero to begin with)
+  if (hipMalloc((void**)&cnt, 64) != hipSuccess || hipMemsetAsync(cnt, 0, 64, st) != hipSuccess ||
       (feat->dtype == GIGL_DTYPE_F16 && !half_direct && hipMalloc((void**)&stage, (size_t)cm * d * 4 + 16) != hipSuccess)) {
     cleanup();
     return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the projection workspace failed");
@@ -3221,20 +3222,24 @@ int32_t gigl_feat_half_split_scale(gigl_ctx* ctx, gigl_feat* feat, float fan, fl
 }
 
 // hs[0] = s_a, hs[1] = s_w from the largest |w| as the weights are NOW, hs[2] = 1 / (s_a s_w)      (one workgroup)
-// (one small workgroup: next to the other streams' kernels a 1024-thread workgroup waited ~100 us for a CU with sixteen
-// free wave slots — 4 waves find room at once)
+// Spread over up to 64 small workgroups: each takes a slice's largest magnitude and folds it into a running maximum
+// (non-negative floats order like their bits: atomicMax on the word); the LAST one to finish — ticket — turns the maximum
+// into the scales and clears maximum and ticket for the next run.  (As one workgroup walking all the weights the kernel
+// took ~100 us next to the other streams' kernels: a serial loop of 50 loads per thread under contention.)
+// hs: [0..2] = {s_a, s_w, 1 / (s_a s_w)}, [4] = running maximum (bits), [5] = ticket — both zero between runs.
 __global__ __launch_bounds__(256) void hs_scale_kernel(const float* __restrict__ w, int64_t n, float s_a,
                                                        float* __restrict__ hs) {
   __shared__ float s_m[4];
   float m = 0.f;
   const float4* w4 = reinterpret_cast<const float4*>(w);
   const int64_t n4 = ((reinterpret_cast<uintptr_t>(w) & 15) == 0) ? n / 4 : 0;
-  for (int64_t i = threadIdx.x; i < n4; i += 256) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
     const float4 v = w4[i];
     const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
     m = fmaxf(m, a == a ? a : 0.f);  // (a NaN weight makes NaN rows on any path; it does not pick the scale)
   }
-  for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
     const float v = fabsf(w[i]);
     m = fmaxf(m, v == v ? v : 0.f);
   }
@@ -3244,15 +3249,24 @@ __global__ __launch_bounds__(256) void hs_scale_kernel(const float* __restrict__
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int i = 1; i < 4; ++i) m = fmaxf(m, s_m[i]);
-    const float s_w = (m > 0.f && m < __uint_as_float(0x7F800000u)) ? hs_pow2_scale(m) : 1.f;
-    hs[0] = s_a;
-    hs[1] = s_w;
-    hs[2] = (1.f / s_a) * (1.f / s_w);
+    uint32_t* acc = reinterpret_cast<uint32_t*>(hs) + 4;
+    atomicMax(acc, __float_as_uint(m));
+    __threadfence();
+    if (atomicAdd(acc + 1, 1u) == gridDim.x - 1) {  // the last workgroup: every maximum is in
+      const float mm = __uint_as_float(atomicExch(acc, 0u));
+      acc[1] = 0u;
+      const float s_w = (mm > 0.f && mm < __uint_as_float(0x7F800000u)) ? hs_pow2_scale(mm) : 1.f;
+      hs[0] = s_a;
+      hs[1] = s_w;
+      hs[2] = (1.f / s_a) * (1.f / s_w);
+    }
   }
 }
 
 int32_t gigl_hs_scale_update(gigl_ctx* ctx, const float* w, int64_t n, float s_a, float* hs_dev) {
-  hipLaunchKernelGGL(hs_scale_kernel, dim3(1), dim3(256), 0, ctx->stream, w, n, s_a, hs_dev);
+  int64_t wgs = (n / 4 + 255) / 256;  // one float4 per thread where the weights allow it
+  wgs = wgs < 1 ? 1 : (wgs > 64 ? 64 : wgs);
+  hipLaunchKernelGGL(hs_scale_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, w, n, s_a, hs_dev);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

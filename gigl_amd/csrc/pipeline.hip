@@ -570,8 +570,8 @@ static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, in
   p->hbuf[1] = hops > 1 ? (float*)alloc((size_t)act_rows * max_out * 4) : p->hbuf[0];
   p->roots_buf = (uint32_t*)alloc((size_t)b * 4);
   p->out_buf = (float*)alloc((size_t)b * dims[hops] * 4);
-  p->zero_dev = (int32_t*)alloc(32);  // [0]: an int32 0; [4..7): hs_dev
-  if (p->zero_dev && hipMemset(p->zero_dev, 0, 32) != hipSuccess) ok = false;
+  p->zero_dev = (int32_t*)alloc(64);  // [0]: an int32 0; [4..7): hs_dev scales, [8..10): its running maximum + ticket (zero)
+  if (p->zero_dev && hipMemset(p->zero_dev, 0, 64) != hipSuccess) ok = false;
   p->hs_dev = p->zero_dev ? reinterpret_cast<float*>(p->zero_dev + 4) : nullptr;
   p->act_rows = act_rows;
   ok = ok && p->zero_dev && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col && p->un.root_local &&
