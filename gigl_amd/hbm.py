@@ -71,6 +71,7 @@ class HbmRootBatch:
     resident: "ResidentGraph"
     roots: torch.Tensor             # int32 [groups * group_roots] on the device (uint32 ids)
     group_roots: int
+    lane: int = field(default=0, kw_only=True)  # which of the resident graph's ctx / plan sets encodes it (infer_resident)
     valid: Optional[torch.Tensor]   # int64 [n_valid] on the device: positions of the real roots in `roots`; None = all
     root_ids: np.ndarray            # int64 [n_valid] host: the real roots, in order
     root_node_labels: Optional[torch.Tensor] = None  # int64 [n_valid]
@@ -287,13 +288,27 @@ class ResidentGraph:
                 node_type=node_type)
 
     # ---- forward over a HbmRootBatch
-    def _plan_for(self, model, b: int, groups: int):
-        """the one-call plan of `model` for `groups` batches of b roots (None when the model / world has none);
-        weights are refreshed from the model at every use (they may have been trained since)"""
-        key = (id(model), int(b), int(groups))
+    def lane_engine(self, lane: int):
+        """the engine (ctx + scratch + stream binding) of inference lane `lane`: lane 0 is the resident graph's own, the
+        others borrow its HBM-resident graph and table (HipEngine.share_resident) — several calls of the one-call plan
+        can then be in flight on streams of their own, one's sampler / union under another's layers, like bench.py's"""
+        if lane == 0 or self.sharded:
+            return self.engine
+        lanes = self.__dict__.setdefault("_lane_engines", {})
+        if lane not in lanes:
+            from .engine import HipEngine
+            e = HipEngine(self.device.index or 0)
+            e.share_resident(self.engine)
+            lanes[lane] = e
+        return lanes[lane]
+
+    def _plan_for(self, model, b: int, groups: int, lane: int = 0):
+        """the one-call plan of `model` for `groups` batches of b roots (None when the model / world has none) on inference
+        lane `lane`; weights are refreshed from the model at every use (they may have been trained since)"""
+        key = (id(model), int(b), int(groups)) if lane == 0 else (id(model), int(b), int(groups), int(lane))
         plan = self._plans.get(key)
         if plan is None and key not in self._plans:
-            plan = self._build_plan(model, b, groups)
+            plan = self._build_plan(model, b, groups, self.lane_engine(lane))
             self._plans[key] = plan
         if plan is not None:
             # weights are snapshotted by the plan: refresh them when a parameter has changed since (in-place updates by
@@ -304,7 +319,8 @@ class ResidentGraph:
                 plan._weights_stamp = stamp
         return plan
 
-    def _build_plan(self, model, b: int, groups: int):
+    def _build_plan(self, model, b: int, groups: int, eng=None):
+        eng = eng if eng is not None else self.engine
         if self.sharded:
             from .dist import DistSagePlan
             from .models import GraphSAGE
@@ -335,7 +351,7 @@ class ResidentGraph:
         if self.mode == MODE_REPLACE:
             return None  # the one-call plan needs duplicate-free trees: staged sample -> union -> forward below
         try:
-            return make(self.engine, b, self.fanouts, groups=groups)
+            return make(eng, b, self.fanouts, groups=groups)
         except NotImplementedError:
             return None  # options outside the one-call plan: staged forward below
         except GiglError as e:
@@ -360,17 +376,21 @@ class ResidentGraph:
                     w0 = model.conv_layers[0].fused_weight()
                     old = cached[1] if cached is not None and cached[1].shape[1] == 2 * w0.shape[0] else None
                     cached = self._proj_tables = ((id(model), stamp), self.engine.project_features(w0, out=old))
+                    self.engine.synchronize()  # (once per model state: the other lanes' plans read the table too)
                 plan.set_projected_input(cached[1])
         elif hasattr(model, "plan_params"):
             plan.set_weights(*model.plan_params())
 
     def encode(self, model, batch: HbmRootBatch) -> torch.Tensor:
         """root embeddings [n_valid, out] of the batch's real roots, in order (inference: no autograd)"""
-        eng = self.engine
+        lane = int(getattr(batch, "lane", 0))
+        eng = self.lane_engine(lane)
+        if lane:
+            eng.bind_stream()  # (the caller runs this lane under a stream of its own: a no-op once bound)
         eng.bind_stream(torch.cuda.current_stream(self.device))
         b, g = batch.group_roots, batch.groups
         with torch.no_grad():
-            plan = self._plan_for(model, b, g)
+            plan = self._plan_for(model, b, g, lane)
             if plan is not None:
                 if self.sharded:
                     out = plan.run(batch.roots, sampling_seed=self.seed)
@@ -530,6 +550,8 @@ class ResidentGraph:
             if p is not None:
                 p.close()
         self._plans = {}
+        for e in self.__dict__.pop("_lane_engines", {}).values():
+            e.close()
         if self.comm is not None:
             self.comm.close()
             self.comm = None

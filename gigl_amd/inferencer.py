@@ -214,10 +214,46 @@ class Inferencer:
         if groups is None:  # batches per library call: as many as keep the call's tree under ~2^26 slots, at most 64
             groups = int(max(1, min(64, per_rank, (1 << 26) // max(b * slots, 1))))
         self.hbm_groups = groups
-        for hb in resident.root_batches(ids, b, groups):
-            res = inferencer.infer_batch(batch=hb, device=dev)
-            if hb.root_ids.size:
-                writer.add(hb.root_ids, res.embeddings, res.predictions, ids_dev=hb.root_ids_dev)
+        # Calls of the one-call plan rotate over a few lanes — a ctx, plan set and stream each, the resident graph shared
+        # (ResidentGraph.lane_engine) — so that one call's sampler / union run under another's layers, as in bench.py;
+        # rows are handed to the writer on ONE stream, in batch order.  (GIGL_AMD_INFER_STREAMS=1: one stream.)
+        n_lanes = max(1, int(os.environ.get("GIGL_AMD_INFER_STREAMS", "3")))
+        if getattr(resident, "sharded", False) or not hasattr(resident, "lane_engine"):
+            n_lanes = 1
+        main = torch.cuda.current_stream(dev)
+        if getattr(resident, "_overflow_acc", 1) is None:
+            resident._overflow_acc = torch.zeros(1, dtype=torch.int32, device=dev)
+        lanes = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)] if n_lanes > 1 else []
+        wstream = torch.cuda.Stream(device=dev) if n_lanes > 1 else None  # the writer's: rows arrive in batch order
+        use_lanes = False
+        for c, hb in enumerate(resident.root_batches(ids, b, groups)):
+            if not use_lanes:
+                res = inferencer.infer_batch(batch=hb, device=dev)
+                if hb.root_ids.size:
+                    writer.add(hb.root_ids, res.embeddings, res.predictions, ids_dev=hb.root_ids_dev)
+                if c == 0 and n_lanes > 1 and any(p is not None for p in getattr(resident, "_plans", {}).values()):
+                    # the batch went through a one-call plan: from here on a lane (ctx + plan set + stream) per call.
+                    # Everything so far — the roots' upload, the first rows — is on the main stream: the lanes and the
+                    # writer's stream start behind it
+                    use_lanes = True
+                    for st in lanes + [wstream]:
+                        st.wait_stream(main)
+                continue
+            lane = 1 + (c % n_lanes)  # (lane 0 is the main stream's ctx: left to the first batch)
+            hb.lane = lane
+            with torch.cuda.stream(lanes[lane - 1]):
+                res = inferencer.infer_batch(batch=hb, device=dev)
+            wstream.wait_stream(lanes[lane - 1])
+            with torch.cuda.stream(wstream):
+                for t in (res.embeddings, res.predictions):
+                    if t is not None:
+                        t.record_stream(wstream)
+                if hb.root_ids.size:
+                    writer.add(hb.root_ids, res.embeddings, res.predictions, ids_dev=hb.root_ids_dev)
+        if use_lanes:
+            main.wait_stream(wstream)
+            for st in lanes:
+                main.wait_stream(st)
         if hasattr(resident, "raise_on_overflow"):
             resident.raise_on_overflow()  # (a failed call's rows are NaN: the pass must not end quietly)
 
