@@ -429,6 +429,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
+    if args.train and args.workload == "gat-lp":
+        return run_gat_lp_train(args, rank, world, local_rank)
     if args.train:
         return run_train(args, rank, world, local_rank)
     if args.entry == "inferencer":
@@ -2453,20 +2455,11 @@ def _lib_stats_len():
     return STATS_LEN
 
 
-def run_gat_lp(args, rank, world, local_rank):
-    """BASELINE.json configs[4] / SURVEY.md 8(d) C5 on one GPU's share of the MAG240M-shaped graph (--shard-scale of
-    it as a self-contained graph): link-prediction step of the GAT encoder — anchors + one positive each (sampled
-    out-neighbour, counter 3) and 512 random negatives go through sample -> union graph -> 2-layer GAT (heads 2, hid
-    128, out 128: attention-weighted segmented reduce) -> root embeddings; inner-product scores against positives +
-    random negatives and the fused retrieval loss (infer_task_inputs + Retrieval, python/gigl/src/common/
-    modeling_task_specs/utils/infer.py, models/layers/task.py:140-205).  The two encodes are GAT one-call plans
-    (gigl_gat_plan_create), G steps per call; the decoder and the loss run per step; a secondary line."""
-    from gigl_amd._lib import GIGL_META_LEVEL0, STATS
+def gat_lp_world(args, local_rank, want_out_degree=False):
+    """the gat-lp workload in HBM: graph (CSR by destination + CSR by source: the positives' graph), the fp16 table and
+    a 2-layer GAT; -> dict of the names run_gat_lp / run_gat_lp_train use"""
     from gigl_amd.engine import HipEngine
-    from gigl_amd.link_prediction import DecoderType, LinkPredictionDecoder, RetrievalLoss
-    from gigl_amd.models import HipBatch
     from gigl_amd.models_attn import GAT
-
     torch.cuda.set_device(local_rank)
     eng = HipEngine(local_rank)
     dev = eng.device
@@ -2487,6 +2480,7 @@ def run_gat_lp(args, rank, world, local_rank):
     del parts
     eng.build_from_coo(n, src, dst, is_directed=True)
     eng.build_from_coo(n, dst, src, is_directed=True, out_graph=True)  # CSR by source: the positives' graph
+    has_out = (torch.bincount(src.long(), minlength=n) > 0) if want_out_degree else None
     del src, dst
     g = torch.Generator(device=dev)
     g.manual_seed(1234)
@@ -2502,6 +2496,165 @@ def run_gat_lp(args, rank, world, local_rank):
     if os.environ.get("GIGL_BENCH_GAT_FIRST_LAYER"):  # (A/B knob: "fused" | "0" = projection first)
         v = os.environ["GIGL_BENCH_GAT_FIRST_LAYER"]
         model.input_side_first_layer = False if v == "0" else v
+    return dict(eng=eng, dev=dev, fanouts=fanouts, L=L, B=B, n_neg=n_neg, scale=scale, n=n, d=d, hid=hid, out_dim=out_dim,
+                heads=heads, t0=t0, model=model, has_out=has_out)
+
+
+def run_gat_lp_train(args, rank, world, local_rank):
+    """--workload gat-lp --train: the link-prediction TRAINING step of the GAT encoder on the in-HBM route, as
+    HipNodeAnchorLinkPredictionSpec.train issues it (node_anchor_based_link_prediction_modeling_task_spec.py:334-451):
+    per step, B anchors + one sampled positive each (ResidentGraph.nablp_batches) and 512 random negatives are sampled
+    and united in HBM, the batch graphs are handed to the encoder as device-built GraphData (ResidentGraph.graph_data:
+    the GAT layers' autograd functions run HIP forward AND backward kernels), inner-product scores + the fused
+    retrieval loss (nablp_spec._infer_task_inputs_hbm + Retrieval), backward, Adam (lr 5e-3, weight decay 1e-6: the
+    spec's defaults).  Launches are driven by torch autograd from Python, one batch per step, one stream — the step is
+    NOT a library plan (the node-classification step is: --train); a secondary line."""
+    from gigl_amd._lib import GIGL_META_LEVEL0
+    from gigl_amd.hbm import HbmTrainBatch, ResidentGraph
+    from gigl_amd.link_prediction import DecoderType, LinkPredictionDecoder, LinkPredictionGNN
+    from gigl_amd.nablp_spec import NodeAnchorBasedLinkPredictionTasks, Retrieval, _infer_task_inputs_hbm
+
+    w_ = gat_lp_world(args, local_rank, want_out_degree=True)
+    eng, dev, fanouts, L, B, n_neg, scale, n = (w_[k] for k in ("eng", "dev", "fanouts", "L", "B", "n_neg", "scale", "n"))
+    d, hid, out_dim, heads, t0, enc = (w_[k] for k in ("d", "hid", "out_dim", "heads", "t0", "model"))
+    model = LinkPredictionGNN(encoder=enc, decoder=LinkPredictionDecoder(DecoderType.inner_product)).to(dev)
+    model.encoder.engine = eng
+    model.decoder.engine = eng
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, weight_decay=1e-6)
+    tasks = NodeAnchorBasedLinkPredictionTasks()
+    tasks.add_task(Retrieval(temperature=0.07, remove_accidental_hits=True), weight=1.0)
+    K, W = max(args.steps if args.steps != 960 else 64, 8), max(min(args.warmup, 8), 2)
+    pool = K + W + 8
+    gp = torch.Generator(device="cpu")
+    gp.manual_seed(42)
+    # anchors with at least one out-edge (the main samples of the reference's job are positive-edge endpoints)
+    cand = torch.nonzero(w_["has_out"]).view(-1)
+    pick = torch.randint(0, cand.numel(), (pool * B,), generator=gp).to(dev)
+    anchors = cand[pick].cpu().numpy().astype(np.int64)
+    del cand, pick, w_["has_out"]
+    negs = torch.randint(0, n, (pool, n_neg), generator=gp).to(torch.int32).to(dev)
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream(device=dev)
+    eng.bind_stream(st)
+    resident = ResidentGraph.from_engine(eng, np.arange(n, dtype=np.int64), fanouts)
+    resident.train_as_graph_data = True  # (GAT trains over a PyG-shaped batch: hbm.encoder_trains_over_hip_batches)
+    setup_s = time.time() - t0
+    main_it = resident.nablp_batches(anchors, np.ones(anchors.size, dtype=np.int64), B, 1, loop=True)
+
+    def step(i):
+        with torch.cuda.stream(st):
+            mb = next(main_it)
+            g, ri = resident.train_graph(negs[i % pool])
+            rb = HbmTrainBatch(graph=g, root_node_indices=ri, root_node_labels=None,
+                               root_ids=(negs[i % pool].to(torch.int64) & 0xFFFFFFFF).cpu().numpy())
+            opt.zero_grad(set_to_none=True)
+            ti = _infer_task_inputs_hbm(model, mb, rb, False, dev)
+            loss, _ = tasks.calculate_losses(ti, None, should_eval=False, device=dev)
+            loss.backward()
+            opt.step()
+        return loss.detach()
+
+    hist = [step(i) for i in range(W)]
+    st.synchronize()
+    # edges per step, counted on the device over untimed batches of the same shape (sampled + consumed by the FORWARD
+    # attention reductions of both encodes, like the inference line)
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    lvl = [GIGL_META_LEVEL0 + (L - 1 - l) for l in range(L)]
+    n_count = 8
+    with torch.cuda.stream(st), torch.no_grad():
+        for i in range(n_count):
+            a = torch.from_numpy(anchors[i * B:(i + 1) * B].astype(np.uint32).view(np.int32)).to(dev)
+            pos, cnt = eng.sample_positives(a, 1)
+            for roots in (torch.cat([a.view(-1, 1), pos.view(-1, 1)], dim=1).reshape(-1).contiguous(), negs[i]):
+                tree = eng.sample_khop(roots, fanouts)
+                u = eng.union_build(tree)
+                rowlen = (u.rowend - u.rowptr).to(torch.int64)
+                ar = torch.arange(rowlen.numel(), device=dev)
+                agg = sum((rowlen * (ar < u.meta[j])).sum() for j in lvl)
+                acc.add_(torch.stack([sum(c.sum() for c in tree.cnt).to(torch.int64), agg.to(torch.int64)]))
+    st.synchronize()
+    per_step = acc.cpu().numpy().astype(np.float64) / n_count
+    rep_s, steps, i = [], 0, W
+    t_all = time.perf_counter()
+    while time.perf_counter() - t_all < args.min_seconds or len(rep_s) < min(args.min_reps, 3):
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(K):
+            hist.append(step(i))
+            i += 1
+        torch.cuda.synchronize(dev)
+        rep_s.append(time.perf_counter() - t1)
+        steps += K
+    elapsed = float(sum(rep_s))
+    losses = torch.stack(hist).cpu().numpy().astype(np.float64)
+    assert np.isfinite(losses).all(), "the training loss went non-finite"
+    # where the step's library kernel time goes: HIP-event timers over a few untimed steps (eager launches on one stream)
+    names = ["expand", "union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr", "gather_mean",
+             "gather_bwd", "linear"]
+    n_prof = 8
+    eng.profile_enable(names, capacity=4096)
+    eng.profile_reset()
+    for _ in range(n_prof):
+        step(i)
+        i += 1
+    st.synchronize()
+    prof = {k: eng.profile_read(k) for k in names}
+    eng.profile_enable([], 0)
+    by_kernel = {k: {"ms_per_step": round(v[0] / n_prof, 5), "launches_per_step": round(v[1] / n_prof, 1)}
+                 for k, v in prof.items() if v[0] > 0}
+    lib_ms = sum(v["ms_per_step"] for v in by_kernel.values())
+    step_ms = elapsed / steps * 1e3
+    ms_rep = np.array(rep_s) / K * 1e3
+    q_ = lambda a, p: float(np.percentile(a, p))
+    line = {
+        "metric": "sampled+aggregated edges/s", "value": float(per_step.sum()) * steps / elapsed, "unit": "edges/s",
+        "n_gpus": 1, "steps": steps, "warmup": W, "ms_per_step": step_ms, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "timing": {"repetitions": len(rep_s), "steps_per_repetition": K, "timed_region_s": round(elapsed, 3),
+                   "ms_per_step_median": q_(ms_rep, 50), "ms_per_step_p10": q_(ms_rep, 10), "ms_per_step_p90": q_(ms_rep, 90)},
+        "config": {"workload": f"MAG240M-shaped RMAT x{scale:g} (N={n}, E={eng.n_edges} directed, D={d} fp16), link-prediction "
+                               f"TRAINING step: {B} anchors + 1 positive each + {n_neg} random negatives, fanout={fanouts}, "
+                               f"2-layer GAT heads={heads} hid={hid} out={out_dim}, inner-product scores + fused retrieval "
+                               "loss, backward, Adam",
+                   "entry": "ResidentGraph.nablp_batches / train_graph -> nablp_spec._infer_task_inputs_hbm -> Retrieval -> "
+                            "backward -> Adam: the step of HipNodeAnchorLinkPredictionSpec.train on the in-HBM route",
+                   "driver": "torch autograd from Python, one batch per step, one stream, eager launches",
+                   "sampled_edges_per_step": float(per_step[0]), "aggregated_edges_per_step": float(per_step[1]),
+                   "loss_first": float(losses[0]), "loss_last_mean": float(losses[-8:].mean()),
+                   "setup_s": round(setup_s, 1)},
+        "roofline": {"bound": "latency", "kernel": max(by_kernel, key=lambda k: by_kernel[k]["ms_per_step"]) if by_kernel else None,
+                     "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                     "library_kernel_ms_per_step": round(lib_ms, 5), "step_ms": round(step_ms, 5),
+                     "library_kernel_share_of_step": round(lib_ms / step_ms, 4),
+                     "note": "launches driven by torch autograd from Python on one stream, one host read per batch graph "
+                             "(its node / edge counts): the step is bound by the host between kernels where "
+                             "library_kernel_share_of_step is well under 1",
+                     "by_kernel": by_kernel},
+        "cpu_baseline": None,
+    }
+    if rank == 0:
+        emit(line)
+    eng.close()
+
+
+def run_gat_lp(args, rank, world, local_rank):
+    """BASELINE.json configs[4] / SURVEY.md 8(d) C5 on one GPU's share of the MAG240M-shaped graph (--shard-scale of
+    it as a self-contained graph): link-prediction step of the GAT encoder — anchors + one positive each (sampled
+    out-neighbour, counter 3) and 512 random negatives go through sample -> union graph -> 2-layer GAT (heads 2, hid
+    128, out 128: attention-weighted segmented reduce) -> root embeddings; inner-product scores against positives +
+    random negatives and the fused retrieval loss (infer_task_inputs + Retrieval, python/gigl/src/common/
+    modeling_task_specs/utils/infer.py, models/layers/task.py:140-205).  The two encodes are GAT one-call plans
+    (gigl_gat_plan_create), G steps per call; the decoder and the loss run per step; a secondary line."""
+    from gigl_amd._lib import GIGL_META_LEVEL0, STATS
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.link_prediction import DecoderType, LinkPredictionDecoder, RetrievalLoss
+    from gigl_amd.models import HipBatch
+    from gigl_amd.models_attn import GAT
+
+    w_ = gat_lp_world(args, local_rank)
+    eng, dev, fanouts, L, B, n_neg, scale, n = (w_[k] for k in ("eng", "dev", "fanouts", "L", "B", "n_neg", "scale", "n"))
+    d, hid, out_dim, heads, t0, model = (w_[k] for k in ("d", "hid", "out_dim", "heads", "t0", "model"))
     torch.cuda.synchronize()
     st = torch.cuda.Stream(device=dev)  # (the resident data was written on torch's default stream)
     eng.bind_stream(st)

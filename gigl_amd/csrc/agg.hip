@@ -2199,6 +2199,14 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
       sum_ae[v] = 0.f;
       dd[v] = 0.f;
     }
+    {
+      // a row whose output gradient is all zero (every row but the roots' at the last layer of a whole-batch-graph
+      // forward, every row no root depends on below it) contributes zeros only: skipped, wave-uniformly
+      bool nz = false;
+#pragma unroll
+      for (int v = 0; v < V; ++v) nz |= g[v].x != 0.f || g[v].y != 0.f || g[v].z != 0.f || g[v].w != 0.f;
+      if (__ballot(nz) == 0ull) continue;
+    }
     head_sum(S);
     // pass 1: max / denominator (every lane of a head computes the same scalars)
     for (int e = 0; e < m; ++e) {
@@ -2954,6 +2962,7 @@ int32_t gigl_gat_aggregate_backward(gigl_ctx* ctx, const float* h, const float* 
                      edge_dim, GAT_ZR * g.group);
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_BWD);
   float* a_src = alpha_scratch;
   float* a_dst = alpha_scratch + nodes_cap * heads;
   float* a_edge = edge_attr ? alpha_scratch + 2 * nodes_cap * heads : nullptr;
@@ -3092,6 +3101,10 @@ int32_t gigl_linear_weight_grad(gigl_ctx* ctx, const float* dy, const float* a, 
   // finer so that the reduction still spreads over a few hundred workgroups
   int rcw = WG_RC;
   while (rcw > 32 && m_cap / rcw < 32) rcw >>= 1;
+  // ... and hundreds of thousands of rows (a whole batch graph under a wide table: the GAT layers' backward) coarser, so
+  // that the partial sums stay a few tens of MB instead of a copy of dW per 256 rows
+  const int64_t tiles = (int64_t)((n + 63) / 64) * ((k + 63) / 64);
+  while (rcw < 8192 && ((m_cap + rcw - 1) / rcw) * tiles > 8192) rcw <<= 1;
   const int64_t chunks = (m_cap + rcw - 1) / rcw, nk = (int64_t)n * k;
   int32_t rc = gigl_arena_reset(ctx, chunks * (nk + n) * 4 + 1024);
   if (rc != GIGL_OK) return rc;

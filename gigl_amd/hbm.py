@@ -526,8 +526,10 @@ class ResidentGraph:
             grouped = torch.where(ar < cnt.view(-1, 1), pos.view(-1, P), a2.expand(-1, P))
             roots = torch.cat([a2, grouped], dim=1).reshape(-1).contiguous()
             hb, ri = self.train_graph(roots)
-            rows = np.concatenate([i * T + 1 + np.arange(int(c)) for i, c in enumerate(k.tolist())]) if k.size else \
-                np.zeros(0, dtype=np.int64)
+            k64 = np.asarray(k, dtype=np.int64)
+            # rows of the positives in the anchor-major root list: i * T + 1 + j for j < k[i]
+            rows = (np.repeat(np.arange(k64.size, dtype=np.int64) * T + 1 - (np.cumsum(k64) - k64), k64)
+                    + np.arange(int(k64.sum()), dtype=np.int64))
             yield HbmNablpBatch(graph=hb, n_anchors=int(chunk.size), trees_per_anchor=T, anchor_ids=chunk,
                                 n_pos=np.asarray(k, dtype=np.int64),
                                 pos_rows=torch.from_numpy(rows.astype(np.int64)).to(self.device),

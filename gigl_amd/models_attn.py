@@ -48,7 +48,7 @@ class _LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         eng, dy = ctx.eng, dy.contiguous()
         n_out = dev_i32(dy.device, dy.shape[1])
-        dw = eng.linear(dy.t().contiguous(), x.t().contiguous(), None, n_out, int(dy.shape[1]), 0)
+        dw, _ = eng.linear_weight_grad(dy, x, ctx.n_dev)  # dW = dy^T x, the rows as the inner dimension
         dx = eng.linear(dy, w.t().contiguous(), None, ctx.n_dev, int(x.shape[0]), 0) if ctx.needs_input_grad[0] else None
         return dx, dw, None, None
 
@@ -179,7 +179,7 @@ class _GatConvFn(torch.autograd.Function):
                + dd.unsqueeze(-1) * att_dst.view(1, heads, ch)).reshape(n, hc).contiguous()
         dev = dy.device
         n_out = dev_i32(dev, hc)
-        dw = eng.linear(dxw.t().contiguous(), x.t().contiguous(), None, n_out, hc, 0)        # dW = dxw^T x
+        dw, _ = eng.linear_weight_grad(dxw, x, n_dev)                                       # dW = dxw^T x
         dx = eng.linear(dxw, w.t().contiguous(), None, n_dev, n, 0) if ctx.needs_input_grad[0] else None
         db = dy.sum(0) if bias.numel() else None
         dv = dae.t().mm(edge_attr) if dae is not None else None

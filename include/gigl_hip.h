@@ -873,7 +873,8 @@ int32_t gigl_gine_aggregate_backward(gigl_ctx* ctx, const float* x, const float*
  * EdgeAttrGATConv's messages (out_i += W_msg sum_e alpha_e e_e): pass u_msg [rows][heads][De] = W_msg^T dout per
  * head (dense, the caller's) and receive z_out [rows][heads][De] = sum_e alpha_e e_e (self loop: the row's mean
  * attribute), from which d W_msg = sum_i dout_i (x) z_i; both NULL for plain GATConv.  Needs heads*channels % 256 == 0
- * and De <= 4 * (lanes per head). */
+ * and De <= 4 * (lanes per head).  Rows whose dout row is all zero add nothing anywhere and are skipped: their z_out
+ * rows are left as the caller filled them (zero-fill z_out). */
 int32_t gigl_gat_aggregate_backward(gigl_ctx* ctx, const float* h, const float* att_src, const float* att_dst,
                                     int32_t heads, int32_t channels, float negative_slope, const int32_t* rowptr,
                                     const int32_t* rowend, const int32_t* col, const int32_t* n_nodes_dev,

@@ -596,3 +596,21 @@ def test_bench_emulated_world_line(tmp_path):
         assert len(e["pulled_rows_per_step_per_rank"]) == 4 and e["compute_ms_per_step_per_rank"] > 0
         assert 0.0 < e["row_bucket_fill"] <= 1.0 and e["projection"]["label"].startswith("PROJECTION")
     assert emu["hot_row_hit_rate"]["pulled_rows_with"] < emu["hot_row_hit_rate"]["pulled_rows_without"]
+
+
+@pytest.mark.gpu
+def test_bench_gat_lp_train_line(tmp_path):
+    """bench.py --workload gat-lp --train at a toy scale: the link-prediction TRAINING step of the GAT encoder on the
+    in-HBM route (backward + Adam included) emits its line, the loss stays finite and falls from its first value"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    cp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "gat-lp", "--train", "--shard-scale",
+                         "0.001", "--batch", "64", "--steps", "16", "--min-seconds", "0.2"], capture_output=True,
+                        text=True, timeout=600, env=dict(os.environ, GIGL_BENCH_CHILD="1"))
+    assert cp.returncode == 0, cp.stderr[-2000:]
+    line = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["metric"] == "sampled+aggregated edges/s" and line["value"] > 0 and "TRAINING" in line["config"]["workload"]
+    assert line["config"]["loss_last_mean"] < line["config"]["loss_first"]
+    assert "gather_mean" in line["roofline"]["by_kernel"] and "linear" in line["roofline"]["by_kernel"]
