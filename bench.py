@@ -1468,6 +1468,8 @@ def run_emulated_world(args, local_rank=0, sub=False):
                     pl.bucket_fill(fills[r])
         torch.cuda.synchronize()
 
+    traffic = []  # per rank: [moved, full-block] bytes per step of the last measurement
+
     def measure(hot):
         # bucket capacities from two warm-up calls (+10 %), as the multi-process bench does
         acc0 = [torch.zeros(STATS_LEN, dtype=torch.int64, device=dev) for _ in range(W)]
@@ -1486,9 +1488,14 @@ def run_emulated_world(args, local_rank=0, sub=False):
         fills = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(W)]
         run_calls(plans, 2, 2 + K, accs, fills)  # counted (untimed)
         torch.cuda.synchronize()
+        tr0 = np.array([c.traffic() for c in comms], dtype=np.float64)
         t1 = time.perf_counter()
         run_calls(plans, 2, 2 + K)               # timed: all W ranks' steps on this one GPU
         dt = time.perf_counter() - t1
+        # bytes each rank handed to the transport for OTHER ranks over the timed calls (gigl_comm_traffic): as moved —
+        # the feature-row blocks at the size of their request counts — and as full-capacity blocks would have been
+        traffic.clear()
+        traffic.extend(((np.array([c.traffic() for c in comms], dtype=np.float64) - tr0) / (K * G)).tolist())
         st = np.stack([a.cpu().numpy().astype(np.float64) for a in accs])
         fl = np.stack([f.cpu().numpy().astype(np.float64) for f in fills])
         if st[:, STATS["overflow"]].any():
@@ -1514,14 +1521,22 @@ def run_emulated_world(args, local_rank=0, sub=False):
         hop_bytes /= G
         payload = pulled * (row_bytes + 4)
         compute_ms = dt / (K * G * W) * 1e3
-        per_link = (sent_rows_bytes + hop_bytes) / (W - 1)  # bytes per peer pair and step: one xGMI link each (W <= 8)
+        tr = np.array(traffic, dtype=np.float64)  # [W, 2]
+        moved_step, full_step = float(tr[:, 0].max()), float(tr[:, 1].max())  # the busiest rank's
+        per_link = moved_step / (W - 1)  # bytes per peer pair and step: one xGMI link each (W <= 8)
         link_ms = per_link / 153e9 * 1e3
         edges_step = (st[:, STATS["sampled"]] + st[:, STATS["aggregated"]]).sum() / (steps * W)
         res[tag] = {
             "pulled_rows_per_step_per_rank": [round(float(v), 1) for v in pulled],
             "pulled_rows_per_step_mean": float(pulled.mean()),
             "row_payload_bytes_per_step_per_rank": float(payload.mean()),
-            "row_bytes_sent_per_step_per_rank": float(sent_rows_bytes),
+            "bytes_sent_per_step_per_rank": [round(float(v)) for v in tr[:, 0]],
+            "bytes_sent_per_step_busiest_rank": moved_step,
+            "bytes_sent_with_full_blocks_busiest_rank": full_step,
+            "exchange_sizes": "measured by the transport (gigl_comm_traffic) over the timed calls: the feature-row blocks "
+                              "travel at the size of their request counts (the counts ride with the id request), the id / "
+                              "neighbour blocks of the hops and the id buckets at their fixed capacity",
+            "row_bytes_at_full_capacity_per_step_per_rank": float(sent_rows_bytes),
             "hop_exchange_bytes_sent_per_step_per_rank": float(hop_bytes),
             "row_bucket_capacity_per_peer": [pull_cap, pull_cap_b],
             # occupied entries of the row buckets / their capacity, summed over the W - 1 peers (gigl_dist_plan_bucket_fill:

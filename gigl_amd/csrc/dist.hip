@@ -78,11 +78,15 @@ struct Pending {
   void* recv;
   int64_t bytes;
   bool self_in_place;
+  // count-sized blocks (comm_exchange_rows): only the first send_units[p] units of block p are moved
+  const int32_t* send_units = nullptr;  // device [world]
+  int64_t unit = 0;
 };
 
 struct LocalGroup {
   int world = 0;
   std::vector<gigl_comm*> members;
+  std::vector<int32_t> h_units;  // [world][world] unit counts of the count-sized exchange being flushed
 };
 
 }  // namespace
@@ -96,6 +100,8 @@ struct gigl_comm {
   std::vector<Pending> pending;     // in-process group: exchanges registered since the last flush
   gigl_exchange_fn fn = nullptr;    // host callback
   void* user = nullptr;
+  int32_t* h_units = nullptr;       // pinned host [2 * world]: the unit counts of a count-sized exchange
+  int64_t moved_bytes = 0, block_bytes = 0;  // sent to OTHER ranks since creation: as moved / had every block been full
 };
 
 namespace {
@@ -107,6 +113,10 @@ bool comm_self_in_place(const gigl_comm* c) { return c->kind != GIGL_COMM_CALLBA
 int32_t comm_exchange(gigl_comm* c, const void* send, void* recv, int64_t bytes, bool self_in_place = false) {
   gigl_ctx* ctx = c->ctx;
   if (bytes == 0) return GIGL_OK;
+  if (c->kind != GIGL_COMM_LOCAL) {  // (an in-process group counts when it performs the copies)
+    c->moved_bytes += bytes * (c->world - 1);
+    c->block_bytes += bytes * (c->world - 1);
+  }
   if (c->kind == GIGL_COMM_RCCL) {
     if (!self_in_place)
       GIGL_HIP_CHECK(ctx, hipMemcpyAsync((char*)recv + (int64_t)c->rank * bytes,
@@ -135,6 +145,55 @@ int32_t comm_exchange(gigl_comm* c, const void* send, void* recv, int64_t bytes,
   GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   const int32_t rc = c->fn(c->user, send, recv, bytes);
   if (rc != 0) return gigl_fail(ctx, GIGL_E_HIP, "the exchange callback failed (%d)", rc);
+  return GIGL_OK;
+}
+
+// The all-to-all of `bytes`-sized blocks, moving only the head of each block: the first send_units[p] units (of `unit`
+// bytes) of the block for rank p, the first recv_units[r] units of the block from rank r — both arrays on the device,
+// [world], values above the block's capacity are cut to it.  The receiver's tail keeps what it held (the rows behind a
+// count are never read).  RCCL needs the sizes on the host: one small copy + a stream synchronisation per exchange,
+// paid once per call of a plan (many batches); the host-callback transport has a fixed-size contract and moves full
+// blocks.  GIGL_DIST_FIXED_BLOCKS=1: full blocks everywhere (A/B).
+int32_t comm_exchange_rows(gigl_comm* c, const void* send, void* recv, int64_t bytes, const int32_t* send_units,
+                           const int32_t* recv_units, int64_t unit, bool self_in_place) {
+  static const bool fixed = getenv("GIGL_DIST_FIXED_BLOCKS") != nullptr;
+  gigl_ctx* ctx = c->ctx;
+  if (bytes == 0) return GIGL_OK;
+  if (fixed || c->kind == GIGL_COMM_CALLBACK || c->world == 1 || !send_units || !recv_units || unit <= 0)
+    return comm_exchange(c, send, recv, bytes, self_in_place);  // (a single rank: nothing leaves the device)
+  const int64_t cap_units = bytes / unit;
+  if (c->kind == GIGL_COMM_LOCAL) {
+    Pending pd{send, recv, bytes, self_in_place};
+    pd.send_units = send_units;
+    pd.unit = unit;
+    c->pending.push_back(pd);
+    return GIGL_OK;
+  }
+  // RCCL
+  const int W = c->world;
+  if (!c->h_units) GIGL_HIP_CHECK(ctx, hipHostMalloc((void**)&c->h_units, (size_t)2 * W * 4, hipHostMallocDefault));
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(c->h_units, send_units, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(c->h_units + W, recv_units, (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  auto cut = [&](int32_t v) { return (int64_t)(v < 0 ? 0 : (v > cap_units ? cap_units : v)) * unit; };
+  if (!self_in_place && cut(c->h_units[c->rank]) > 0)
+    GIGL_HIP_CHECK(ctx, hipMemcpyAsync((char*)recv + (int64_t)c->rank * bytes, (const char*)send + (int64_t)c->rank * bytes,
+                                       (size_t)cut(c->h_units[c->rank]), hipMemcpyDeviceToDevice, ctx->stream));
+  if (W == 1) return GIGL_OK;
+  RcclApi& api = rccl();
+  ncclResult_t r = api.GroupStart();
+  for (int p = 0; p < W && r == ncclSuccess; ++p) {
+    if (p == c->rank) continue;
+    const int64_t sb = cut(c->h_units[p]), rb = cut(c->h_units[W + p]);
+    c->moved_bytes += sb;
+    c->block_bytes += bytes;
+    if (sb > 0) r = api.Send((const char*)send + (int64_t)p * bytes, (size_t)sb, ncclInt8, p, c->nccl, ctx->stream);
+    if (r == ncclSuccess && rb > 0)
+      r = api.Recv((char*)recv + (int64_t)p * bytes, (size_t)rb, ncclInt8, p, c->nccl, ctx->stream);
+  }
+  ncclResult_t r2 = api.GroupEnd();
+  if (r == ncclSuccess) r = r2;
+  if (r != ncclSuccess) return gigl_fail(ctx, GIGL_E_HIP, "RCCL count-sized all-to-all failed: %s", api.GetErrorString(r));
   return GIGL_OK;
 }
 
@@ -231,6 +290,13 @@ int32_t gigl_comm_all_to_all(gigl_comm* c, const void* send, void* recv, int64_t
   return comm_exchange(c, send, recv, bytes_per_peer);
 }
 
+int32_t gigl_comm_traffic(gigl_comm* c, int64_t* moved_bytes, int64_t* full_block_bytes) {
+  if (!c) return GIGL_E_INVALID_ARG;
+  if (moved_bytes) *moved_bytes = c->moved_bytes;
+  if (full_block_bytes) *full_block_bytes = c->block_bytes;
+  return GIGL_OK;
+}
+
 int32_t gigl_comm_flush_local(gigl_comm* any) {
   if (!any) return GIGL_E_INVALID_ARG;
   gigl_ctx* ctx = any->ctx;
@@ -240,16 +306,39 @@ int32_t gigl_comm_flush_local(gigl_comm* any) {
   for (gigl_comm* m : g->members)
     GIGL_REQUIRE(ctx, m->pending.size() == n, "ranks of the in-process group registered different exchange counts");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int W = g->world;
   for (size_t x = 0; x < n; ++x) {
     const int64_t bytes = g->members[0]->pending[x].bytes;
     for (gigl_comm* m : g->members)
       GIGL_REQUIRE(ctx, m->pending[x].bytes == bytes, "ranks disagree on the exchange size");
-    for (int r = 0; r < g->world; ++r)    // sender
-      for (int p = 0; p < g->world; ++p) {  // receiver: block r of p's receive buffer <- block p of r's send buffer
-        if (r == p && g->members[r]->pending[x].self_in_place) continue;
+    // count-sized blocks: every sender's unit counts come to the host first (one synchronisation per such exchange)
+    const bool sized = g->members[0]->pending[x].send_units != nullptr;
+    if (sized) {
+      g->h_units.resize((size_t)W * W);
+      for (int r = 0; r < W; ++r) {
+        GIGL_REQUIRE(ctx, g->members[r]->pending[x].send_units && g->members[r]->pending[x].unit == g->members[0]->pending[x].unit,
+                     "ranks disagree on the kind of exchange");
+        GIGL_HIP_CHECK(ctx, hipMemcpyAsync(g->h_units.data() + (size_t)r * W, g->members[r]->pending[x].send_units,
+                                           (size_t)W * 4, hipMemcpyDeviceToHost, ctx->stream));
+      }
+      GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const int64_t unit = g->members[0]->pending[x].unit, cap_units = sized ? bytes / unit : 0;
+    for (int r = 0; r < W; ++r)    // sender
+      for (int p = 0; p < W; ++p) {  // receiver: block r of p's receive buffer <- block p of r's send buffer
+        int64_t nb = bytes;
+        if (sized) {
+          const int32_t u = g->h_units[(size_t)r * W + p];
+          nb = (int64_t)(u < 0 ? 0 : (u > cap_units ? cap_units : u)) * unit;
+        }
+        if (r != p) {
+          g->members[r]->moved_bytes += nb;
+          g->members[r]->block_bytes += bytes;
+        }
+        if ((r == p && g->members[r]->pending[x].self_in_place) || nb == 0) continue;
         GIGL_HIP_CHECK(ctx, hipMemcpyAsync((char*)g->members[p]->pending[x].recv + (int64_t)r * bytes,
                                            (const char*)g->members[r]->pending[x].send + (int64_t)p * bytes,
-                                           (size_t)bytes, hipMemcpyDeviceToDevice, ctx->stream));
+                                           (size_t)nb, hipMemcpyDeviceToDevice, ctx->stream));
       }
   }
   for (gigl_comm* m : g->members) m->pending.clear();
@@ -263,6 +352,7 @@ int32_t gigl_comm_destroy(gigl_comm* c) {
     hipStreamSynchronize(c->ctx->stream);
   }
   if (c->kind == GIGL_COMM_RCCL && c->nccl) rccl().CommDestroy(c->nccl);
+  if (c->h_units) hipHostFree(c->h_units);
   if (c->group) {
     LocalGroup* g = c->group;
     for (auto& m : g->members)
@@ -633,6 +723,7 @@ struct gigl_dist_plan {
   uint32_t *ids_s = nullptr, *ids_r = nullptr, *idsb_s = nullptr, *idsb_r = nullptr;
   int32_t *pos = nullptr, *posb = nullptr;
   int32_t *pull_counts = nullptr, *pullb_counts = nullptr;
+  int32_t* req_counts = nullptr;  // [world] rows rank r asked of this rank (its pull_counts[this rank]): the row blocks' sizes
   void *rows_s = nullptr, *rows_r = nullptr, *rowsb_s = nullptr, *rowsb_r = nullptr;
   int64_t row_bytes = 0;
   float* stage = nullptr;             // projected mode: fp32 operand of the owner-side projection
@@ -789,6 +880,7 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       }
       GIGL_HIP_CHECK(ctx, hipGetLastError());
       rc = comm_exchange(p->comm, p->ids_s, p->ids_r, p->pull_cap * 4);
+      if (rc == GIGL_OK) rc = comm_exchange(p->comm, p->pull_counts, p->req_counts, 4);  // (the row blocks' sizes)
       if (rc == GIGL_OK && p->preproj) rc = comm_exchange(p->comm, p->idsb_s, p->idsb_r, p->pull_cap_b * 4);
       return rc;
     }
@@ -808,6 +900,7 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     }
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     rc = comm_exchange(p->comm, p->ids_s, p->ids_r, p->pull_cap * 4);
+    if (rc == GIGL_OK) rc = comm_exchange(p->comm, p->pull_counts, p->req_counts, 4);  // (the row blocks' sizes)
     if (rc == GIGL_OK && p->project) rc = comm_exchange(p->comm, p->idsb_s, p->idsb_r, p->pull_cap_b * 4);
     return rc;
   }
@@ -825,7 +918,9 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
                          (char*)p->rows_s, (int64_t)p->rank * p->pull_cap, (int64_t)(p->rank + 1) * p->pull_cap,
                          in_place ? (char*)p->rows_r : (char*)nullptr, stride);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
-      rc = comm_exchange(p->comm, p->rows_s, p->rows_r, p->pull_cap * p->row_bytes, in_place);
+      // only the requested rows travel: the head of each block (comm_exchange_rows)
+      rc = comm_exchange_rows(p->comm, p->rows_s, p->rows_r, p->pull_cap * p->row_bytes, p->req_counts, p->pull_counts,
+                              p->row_bytes, in_place);
       if (rc != GIGL_OK || !p->preproj) return rc;
       hipLaunchKernelGGL(serve_rows_copy_kernel, dim3((unsigned)grid256(nb * upr)), dim3(256), 0, st, p->idsb_r, nb,
                          world, table + p->row_bytes, p->feat->n, (uint32_t)p->row_bytes, unit, upr, (char*)p->rowsb_s,
@@ -846,7 +941,8 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     rc = gigl_linear(ctx, p->stage, p->wr0, nullptr, p->n_entries_dev + 1, nb, p->dims[0], p->dims[1], 0,
                      (float*)p->rowsb_s);
     if (rc != GIGL_OK) return rc;
-    rc = comm_exchange(p->comm, p->rows_s, p->rows_r, p->pull_cap * p->row_bytes);
+    rc = comm_exchange_rows(p->comm, p->rows_s, p->rows_r, p->pull_cap * p->row_bytes, p->req_counts, p->pull_counts,
+                            p->row_bytes, false);
     if (rc == GIGL_OK) rc = comm_exchange(p->comm, p->rowsb_s, p->rowsb_r, p->pull_cap_b * p->row_bytes);
     return rc;
   }
@@ -1177,10 +1273,11 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   p->ids_r = (uint32_t*)alloc((size_t)W * pc * 4);
   p->pos = (int32_t*)alloc((size_t)cap_nodes * 4);
   p->pull_counts = (int32_t*)alloc((size_t)(W + 1) * 4);
+  p->req_counts = (int32_t*)alloc((size_t)(W + 1) * 4);
   p->rows_s = alloc((size_t)W * pc * p->row_bytes);
   p->rows_r = alloc((size_t)W * pc * p->row_bytes);
   ok = ok && p->own_cnt && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col &&
-       p->un.root_local && p->ids_s && p->ids_r && p->pos && p->pull_counts && p->rows_s && p->rows_r;
+       p->un.root_local && p->ids_s && p->ids_r && p->pos && p->pull_counts && p->req_counts && p->rows_s && p->rows_r;
   p->n_entries_dev = (int32_t*)alloc(16);
   if (p->preproj && ok) {  // the second pull's buckets (W_r x of the inner nodes)
     int64_t pcb = opts && opts->pull_cap_b > 0 ? opts->pull_cap_b

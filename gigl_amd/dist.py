@@ -337,6 +337,13 @@ class Comm:
     def flush_local(self) -> None:
         _check(self.eng._lib.gigl_comm_flush_local(self._h), self.eng._ctx)
 
+    def traffic(self) -> Tuple[int, int]:
+        """(bytes moved, bytes full blocks would have moved) to OTHER ranks since creation (gigl_comm_traffic): the
+        sharded plans send only the requested rows of each feature-row block"""
+        moved, full = C.c_int64(0), C.c_int64(0)
+        _check(self.eng._lib.gigl_comm_traffic(self._h, C.byref(moved), C.byref(full)), self.eng._ctx)
+        return int(moved.value), int(full.value)
+
     def close(self) -> None:
         if self._h:
             self.eng._lib.gigl_comm_destroy(self._h)

@@ -1172,6 +1172,11 @@ int32_t gigl_dist_init_callback(gigl_ctx* ctx, int32_t rank, int32_t world, gigl
 int32_t gigl_comm_info(gigl_comm* comm, int32_t* rank, int32_t* world, int32_t* kind);
 int32_t gigl_comm_all_to_all(gigl_comm* comm, const void* send, void* recv, int64_t bytes_per_peer);
 int32_t gigl_comm_flush_local(gigl_comm* any_member);
+/* bytes this rank has sent to OTHER ranks since the communicator was created: as moved, and as they would have been
+ * with every block sent at its full capacity.  The sharded plans' feature-row exchange moves only the requested rows
+ * of each block (the counts travel with the id request; RCCL and in-process groups — the host-callback transport has a
+ * fixed-size contract and moves full blocks; GIGL_DIST_FIXED_BLOCKS=1 forces full blocks everywhere). */
+int32_t gigl_comm_traffic(gigl_comm* comm, int64_t* moved_bytes, int64_t* full_block_bytes);
 int32_t gigl_comm_destroy(gigl_comm* comm);
 
 /* The sharded batch plan: gigl_sage_plan's step on a hash-partitioned graph.  `shard` holds the CSC rows of the nodes

@@ -114,6 +114,11 @@ def test_all_ranks_in_one_process_end_to_end(world, project, dtype):
     a = acc.cpu().numpy()
     nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots[0], FAN, canonical=True)
     assert a[0] == sum(int(c.sum()) for c in cnt_o) and a[13] == 0 and a[14] > 0 and a[15] > 0
+    # the feature-row blocks travel at the size of their request counts, not at the buckets' capacity
+    # (gigl_comm_traffic; the id / neighbour exchanges of the hops stay fixed-size)
+    for c in comms:
+        moved, full = c.traffic()
+        assert 0 < moved < full, (moved, full)
     for p in plans:
         p.close()
     for c in comms:
