@@ -535,6 +535,31 @@ __global__ __launch_bounds__(256) void serve_rows_copy_kernel(const uint32_t* __
   else *(uint16_t*)op = *(const uint16_t*)sp;
 }
 
+// requester side, staged plans: union node i's pulled row (row pos[i] of the receive buffer) widened to fp32 at row i of
+// the batch's dense feature matrix — what a training batch hands to the encoder as x.  One wave per node; a node whose
+// request did not fit its bucket (pos < 0: the step is flagged as overflowed) gets NaN.
+__global__ __launch_bounds__(256) void batch_features_kernel(const char* __restrict__ rows, int32_t dtype, int32_t d,
+                                                             const int32_t* __restrict__ pos, int64_t cap,
+                                                             const int32_t* __restrict__ n_nodes,
+                                                             float* __restrict__ x) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (i >= cap || i >= (int64_t)*n_nodes) return;
+  const int32_t at = pos[i];
+  float* o = x + i * (int64_t)d;
+  if (at < 0) {
+    for (int q = lane; q < d; q += 64) o[q] = __builtin_nanf("");
+    return;
+  }
+  if (dtype == GIGL_DTYPE_F32) {
+    const float* sp = (const float*)rows + (int64_t)at * d;
+    for (int q = lane; q < d; q += 64) o[q] = sp[q];
+  } else {
+    const __half* sp = (const __half*)rows + (int64_t)at * d;
+    for (int q = lane; q < d; q += 64) o[q] = __half2float(sp[q]);
+  }
+}
+
 // the same rows widened to fp32 (operand of the owner-side projection).  One wave per entry.
 __global__ __launch_bounds__(256) void serve_rows_f32_kernel(const uint32_t* __restrict__ ids, int64_t n_entries,
                                                              uint32_t world, const void* __restrict__ rows,
@@ -1183,7 +1208,7 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   p->n_global = shard->n * W;
   // (the GAT layers number every union node and read the pulled rows through pos[]: generic union)
   p->dense = kind == 0 && hops == 2 && !p->project && p->n_global < ((int64_t)1 << 32) && (shard_feat->d & 3) == 0 &&
-             getenv("GIGL_DIST_GENERIC_UNION") == nullptr;
+             getenv("GIGL_DIST_GENERIC_UNION") == nullptr && !(opts && opts->staged);
   p->own_in_place = p->dense && shard->n < ((int64_t)1 << 30) && getenv("GIGL_DIST_COPY_OWN_ROWS") == nullptr;
   if (p->preproj && (!p->dense || (dims[1] & 3) != 0 || dims[1] > 2048))
     return fail(GIGL_E_UNSUPPORTED, "pre-projected rows need the dense pull bookkeeping (two hops, no owner-side "
@@ -1446,6 +1471,38 @@ int32_t gigl_dist_plan_run_local(gigl_dist_plan* const* plans, int32_t world, co
       if (rc != GIGL_OK) return rc;
     }
   }
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_plan_batch_features(gigl_dist_plan* p, float* x) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, x, "null argument");
+  GIGL_REQUIRE(ctx, !p->dense && !p->project && !p->preproj,
+               "the batch's feature matrix needs a staged plan (gigl_dist_plan_opts.staged: every union node numbered, raw rows)");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(batch_features_kernel, dim3((unsigned)grid256(p->un.cap_nodes * 64)), dim3(256), 0, ctx->stream,
+                     (const char*)p->rows_r, p->feat->dtype, p->feat->d, (const int32_t*)p->pos, p->un.cap_nodes,
+                     (const int32_t*)(p->un.meta + GIGL_META_N_NODES), x);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_plan_batch_graph(gigl_dist_plan* p, int32_t* rowptr, int32_t* rowend, int32_t* col, int32_t* root_local,
+                                   int32_t* meta, uint32_t* nodes) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, rowptr && rowend && col && root_local && meta, "null argument");
+  GIGL_REQUIRE(ctx, !p->dense, "the batch graph with every node numbered needs a staged plan (gigl_dist_plan_opts.staged)");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t cn = (size_t)p->un.cap_nodes, ce = (size_t)p->un.cap_edges;
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(rowptr, p->un.rowptr, (cn + 1) * 4, hipMemcpyDeviceToDevice, st));
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(rowend, p->un.rowend, (cn + 1) * 4, hipMemcpyDeviceToDevice, st));
+  if (ce) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(col, p->un.col, ce * 4, hipMemcpyDeviceToDevice, st));
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(root_local, p->un.root_local, (size_t)p->b * 4, hipMemcpyDeviceToDevice, st));
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(meta, p->un.meta, (size_t)GIGL_META_LEN * 4, hipMemcpyDeviceToDevice, st));
+  if (nodes) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(nodes, p->un.nodes, cn * 4, hipMemcpyDeviceToDevice, st));
   return GIGL_OK;
 }
 

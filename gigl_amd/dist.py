@@ -392,11 +392,13 @@ class DistSagePlan:
     def __init__(self, comm: Comm, weights, biases, b: int, fanouts: Sequence[int], act_last: bool = False,
                  group_roots: Optional[int] = None, project_on_owner: bool = False, pull_cap: int = 0,
                  hop_slack: float = 0.0, max_window_end: int = -1, projected: Optional[torch.Tensor] = None,
-                 pull_cap_b: int = 0, aggr: str = "mean"):
+                 pull_cap_b: int = 0, aggr: str = "mean", staged: bool = False):
         """aggr: the SAGE layers' reduction ("mean" | "sum" | "max"; "max" pulls raw rows: not with project_on_owner /
         projected).  projected: this rank's pre-projected rows (HipEngine.project_features of the SHARD's table with weights[0]:
         [shard rows, 2*out] fp32) — the pull moves W_l x rows, the first layer is one reduction (gigl_dist_plan_opts.
-        projected); recompute and rebuild the plan after a weight update"""
+        projected); recompute and rebuild the plan after a weight update.
+        staged: the plan serves TRAINING batches (gigl_dist_plan_opts.staged): sample_and_pull + batch_tensors hand out the
+        batch union graph and its dense feature matrix; raw rows, every union node numbered"""
         from . import _lib
         eng = comm.eng
         assert eng._graph is not None and eng._feat is not None, "load this rank's shard first"
@@ -410,6 +412,9 @@ class DistSagePlan:
         o.group_roots = int(group_roots or b)
         o.project_on_owner = 1 if project_on_owner else 0
         o.pull_cap, o.hop_slack, o.max_window_end = int(pull_cap), float(hop_slack), int(max_window_end)
+        o.staged = 1 if staged else 0
+        self.staged = bool(staged)
+        assert not (staged and (projected is not None or project_on_owner)), "staged batches pull raw rows"
         self.projected = projected
         if projected is not None:
             assert projected.is_cuda and projected.dtype == torch.float32 and projected.is_contiguous() and \
@@ -467,6 +472,43 @@ class DistSagePlan:
         out = out if out is not None else self.new_out()
         _check(self._lib.gigl_dist_plan_run(self._plan, C.c_void_p(roots.data_ptr()), sampling_seed,
                                             C.c_void_p(out.data_ptr())), self.eng._ctx)
+        return out
+
+    # ---- staged plans: training batches of a hash-partitioned graph
+    def sample_and_pull(self, roots: torch.Tensor, sampling_seed: int = 42) -> None:
+        """the phases before the forward — per-hop requests / answers, union graph, feature pull — of one step on an
+        RCCL / callback communicator (every rank calls it once per step)"""
+        assert self.staged and roots.is_cuda and roots.dtype == torch.int32 and roots.numel() == self.b and roots.is_contiguous()
+        scratch = self.__dict__.setdefault("_scratch_out", self.new_out())
+        for ph in range(self.n_phases - 1):
+            _check(self._lib.gigl_dist_plan_phase(self._plan, ph, C.c_void_p(roots.data_ptr()), sampling_seed,
+                                                  C.c_void_p(scratch.data_ptr())), self.eng._ctx)
+
+    @staticmethod
+    def sample_and_pull_local(plans: Sequence["DistSagePlan"], roots: Sequence[torch.Tensor], sampling_seed: int = 42) -> None:
+        """sample_and_pull of every rank of an in-process group (Comm.local), phase by phase"""
+        for ph in range(plans[0].n_phases - 1):
+            for p, r in zip(plans, roots):
+                scratch = p.__dict__.setdefault("_scratch_out", p.new_out())
+                _check(p._lib.gigl_dist_plan_phase(p._plan, ph, C.c_void_p(r.data_ptr()), sampling_seed,
+                                                   C.c_void_p(scratch.data_ptr())), p.eng._ctx)
+            plans[0].comm.flush_local()
+
+    def batch_tensors(self) -> dict:
+        """the batch of the step run last (sample_and_pull) as device tensors of the caller's: x [cap_nodes, d] fp32 (rows
+        >= meta[0] unset), rowptr / rowend [cap_nodes + 1], col [cap_edges], root_local [b], meta [16], nodes [cap_nodes]
+        (global ids) — copies on the plan's stream: the plan's buffers are reused by the next step"""
+        from ._lib import GIGL_META_LEN, GiglTree, GiglUnion
+        t, u = GiglTree(), GiglUnion()
+        _check(self._lib.gigl_dist_plan_buffers(self._plan, C.byref(t), C.byref(u)), self.eng._ctx)
+        dev, cn, ce = self.eng.device, int(u.cap_nodes), int(u.cap_edges)
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+        out = dict(x=torch.empty((cn, self.dims[0]), dtype=torch.float32, device=dev), rowptr=i32(cn + 1), rowend=i32(cn + 1),
+                   col=i32(max(ce, 1)), root_local=i32(self.b), meta=i32(GIGL_META_LEN), nodes=i32(cn))
+        p = lambda k: C.c_void_p(out[k].data_ptr())
+        _check(self._lib.gigl_dist_plan_batch_features(self._plan, p("x")), self.eng._ctx)
+        _check(self._lib.gigl_dist_plan_batch_graph(self._plan, p("rowptr"), p("rowend"), p("col"), p("root_local"), p("meta"),
+                                                    p("nodes")), self.eng._ctx)
         return out
 
     @staticmethod

@@ -439,38 +439,68 @@ class ResidentGraph:
     # train over the same in-HBM batch as a GraphData built on the device (set by the task specs)
     train_as_graph_data: bool = False
 
-    def graph_data(self, roots: torch.Tensor):
+    def graph_data(self, roots: torch.Tensor, pad_to: Optional[int] = None):
         """the batch of `roots` (int32 device ids) as a nn.GraphData on the device — x = the union nodes' feature rows,
         edge_index = the batch union graph's distinct edges (src -> dst, local ids), edge_attr when the job has edge
         features — what the trainer-side collate builds from the samples' records (pyg_graph_builder.py:20-69), for the
         encoders that train over a PyG-shaped batch; one host read (the batch's node / edge counts) -> (graph, root rows)"""
         from .nn import GraphData
-        if self.sharded:
-            raise NotImplementedError("staged batches on a hash-partitioned graph: use the sharded plan (encode)")
         eng = self.engine
         eng.bind_stream(torch.cuda.current_stream(self.device))
-        tree = eng.sample_khop(roots, self.fanouts, sampling_seed=self.seed, mode=self.mode)
-        u = eng.union_build(tree)
-        c = u.counts()  # (raises when the batch did not fit its workspace)
-        n, e = int(c["n_nodes"]), int(c["n_edges"])
         dev = self.device
-        rp, re = u.rowptr[:n].to(torch.int64), u.rowend[:n].to(torch.int64)
+        n_real = int(roots.numel())
+        if self.sharded:
+            # the graph is hash-partitioned over the ranks: the per-hop requests, the union graph and the feature pull of
+            # the sharded plan (a STAGED plan: every union node numbered, raw rows), then the batch as it stands in this
+            # rank's HBM.  Every rank calls this once per step with the same batch size (short batches are padded with
+            # their first root: a repeated root adds nothing to the union graph).
+            b = int(pad_to or n_real)
+            if n_real < b:
+                roots = torch.cat([roots, roots[:1].expand(b - n_real)]).contiguous()
+            plan = self._staged_plan(b)
+            plan.sample_and_pull(roots, sampling_seed=self.seed)
+            t = plan.batch_tensors()
+            m = t["meta"].cpu().tolist()
+            if m[8]:
+                raise RuntimeError("sharded training batch failed: a hop / feature-row bucket overflowed "
+                                   "(meta[GIGL_META_OVERFLOW]); raise hop_slack / pull_cap")
+            n, e = int(m[0]), int(m[1])
+            rowptr, rowend, col, root_local, x = t["rowptr"], t["rowend"], t["col"], t["root_local"], t["x"][:n]
+        else:
+            tree = eng.sample_khop(roots, self.fanouts, sampling_seed=self.seed, mode=self.mode)
+            u = eng.union_build(tree)
+            c = u.counts()  # (raises when the batch did not fit its workspace)
+            n, e = int(c["n_nodes"]), int(c["n_edges"])
+            rowptr, rowend, col, root_local = u.rowptr, u.rowend, u.col, u.root_local
+            x = eng.gather_rows(u.nodes, u.meta[:1], n)
+        rp, re = rowptr[:n].to(torch.int64), rowend[:n].to(torch.int64)
         lens = re - rp
         start = torch.cumsum(lens, 0) - lens
         dst = torch.repeat_interleave(torch.arange(n, device=dev), lens, output_size=e)
         idx = torch.repeat_interleave(rp - start, lens, output_size=e) + torch.arange(e, device=dev)
-        src = u.col.index_select(0, idx).to(torch.int64)
-        x = eng.gather_rows(u.nodes, u.meta[:1], n)
+        src = col.index_select(0, idx).to(torch.int64)
         ea = None
-        if getattr(eng, "_efeat", None) is not None:
+        if not self.sharded and getattr(eng, "_efeat", None) is not None:
             ea = eng.union_edge_attr(u).index_select(0, idx)
         g = GraphData(x=x, edge_index=torch.stack([src, dst]), edge_attr=ea).to(dev)
-        return g, u.root_local[: int(roots.numel())].to(torch.int64)
+        return g, root_local[:n_real].to(torch.int64)
 
-    def train_graph(self, roots: torch.Tensor):
-        """-> (what the model's forward takes, the roots' rows of its output) for a training / validation batch"""
-        if self.train_as_graph_data:
-            return self.graph_data(roots)
+    def _staged_plan(self, b: int):
+        """the sharded plan that serves training batches of b roots (dist.DistSagePlan(staged=True): its forward is never
+        run, the weights are placeholders)"""
+        plans = self.__dict__.setdefault("_staged_plans", {})
+        if b not in plans:
+            from .dist import DistSagePlan
+            L = len(self.fanouts)
+            w = [torch.zeros((4, 2 * (self.feat_dim if l == 0 else 4)), device=self.device) for l in range(L)]
+            plans[b] = DistSagePlan(self.comm, w, [None] * L, b, self.fanouts, max_window_end=self.max_window_end, staged=True)
+        return plans[b]
+
+    def train_graph(self, roots: torch.Tensor, pad_to: Optional[int] = None):
+        """-> (what the model's forward takes, the roots' rows of its output) for a training / validation batch;
+        pad_to: the job's batch size (a hash-partitioned graph needs every rank's batch at one size)"""
+        if self.train_as_graph_data or self.sharded:
+            return self.graph_data(roots, pad_to)
         hb = self.hip_batch(roots, train=True)
         return hb, hb.root_local.long()
 
@@ -485,7 +515,7 @@ class ResidentGraph:
             c = (self.rank + k * self.world) % n_batches
             chunk = ids[c * batch_size: (c + 1) * batch_size]
             r32 = torch.from_numpy(chunk.astype(np.uint32).view(np.int32)).to(self.device)
-            hb, ri = self.train_graph(r32)
+            hb, ri = self.train_graph(r32, pad_to=batch_size)
             yield HbmTrainBatch(graph=hb, root_node_indices=ri,
                                 root_node_labels=torch.from_numpy(labels[c * batch_size: c * batch_size + chunk.size]),
                                 root_ids=chunk)
@@ -554,6 +584,8 @@ class ResidentGraph:
         self._plans = {}
         for e in self.__dict__.pop("_lane_engines", {}).values():
             e.close()
+        for p in self.__dict__.pop("_staged_plans", {}).values():
+            p.close()
         if self.comm is not None:
             self.comm.close()
             self.comm = None

@@ -157,10 +157,15 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
                           "root-id split of the labeled samples; run the SplitGenerator for the reference's splits",
                           RuntimeWarning, stacklevel=2)
         rank, world = _rank_world()
-        self._resident = ResidentGraph(cfg, self._device, rank=rank, world=world, sharded=False)
-        # (plain GraphSAGE trains over HipBatches — and through the library's training plan; every other encoder over
-        # the same in-HBM batch as a GraphData built on the device)
-        self._resident.train_as_graph_data = not encoder_trains_over_hip_batches(self._inner_model())
+        # trainerArgs hbm_graph: "replica" (default: every rank holds the whole graph, the ranks only split the batches)
+        # | "sharded" (WORLD_SIZE > 1: rank r holds the rows of the nodes with id % world == r; a batch's remote
+        # neighbours and feature rows arrive through the sharded plan's exchanges — graphs larger than one GPU's HBM)
+        want_shards = str(self._kwargs.get("hbm_graph", "replica")).lower() == "sharded" and world > 1
+        self._resident = ResidentGraph(cfg, self._device, rank=rank, world=world, sharded=want_shards)
+        self.hbm_graph = "sharded" if self._resident.sharded else "replica"  # (kept after close(): what the job ran on)
+        # (plain GraphSAGE trains over HipBatches — and through the library's training plan; every other encoder, and
+        # every encoder on a sharded graph, over the same in-HBM batch as a GraphData built on the device)
+        self._resident.train_as_graph_data = want_shards or not encoder_trains_over_hip_batches(self._inner_model())
         ids, labels = self._resident.labeled_root_order()
         splits = {}
         if assign is not None:

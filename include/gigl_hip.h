@@ -1212,6 +1212,12 @@ typedef struct gigl_dist_plan_opts {
                                 ([n_hot][dims[1]] fp32). */
   int64_t pull_cap_b;        /* rows per peer and step of the SECOND pull of a pre-projected plan (0: the worst case,
                                 every node of level < hops distinct; size it from gigl_dist_plan_bucket_fill) */
+  int32_t staged;            /* 1: the plan serves TRAINING batches — every union node is numbered and its pulled row is
+                                located through pos[] (the generic union build; raw rows: not with project_on_owner /
+                                projected).  Run the phases before the last one (gigl_dist_plan_phase 0 .. n-2: sample,
+                                union, feature pull), then read the batch union graph (gigl_dist_plan_buffers) and its
+                                dense feature matrix (gigl_dist_plan_batch_features): what the trainer's collate hands
+                                the encoder (pyg_graph_builder.py:20-69), for a graph sharded over the ranks */
 } gigl_dist_plan_opts;
 int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
                               const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,
@@ -1249,6 +1255,17 @@ int32_t gigl_dist_plan_run_local(gigl_dist_plan* const* plans, int32_t world, co
  * the plan's dense pull bookkeeping (two hops, raw rows; GIGL_E_INVALID_ARG otherwise).  n_hot = 0 clears the set. */
 int32_t gigl_dist_plan_set_hot_rows(gigl_dist_plan* plan, const uint32_t* hot_ids, int64_t n_hot, const void* hot_rows);
 int32_t gigl_dist_plan_buffers(gigl_dist_plan* plan, gigl_tree* tree, gigl_union* un);
+/* staged plans, after the feature-pull phases of a step: x[i][0:d] (DEVICE fp32 [cap_nodes][d], d = the shard's feature
+ * width) = the feature row of union node i for i < meta[GIGL_META_N_NODES] — own rows and rows pulled from their owners
+ * alike; NaN for a node whose request overflowed its bucket (the step is flagged: meta[GIGL_META_OVERFLOW]).
+ * Replaces the feature hydration of the trainer's batches (training_process.py:86-119 over
+ * distributed_neighborloader.py:26-192) when the graph is hash-partitioned. */
+int32_t gigl_dist_plan_batch_features(gigl_dist_plan* plan, float* x);
+/* ... and the batch union graph itself copied into the caller's DEVICE arrays on the plan's stream (no synchronisation;
+ * the plan's own buffers are reused by the next step): rowptr / rowend [cap_nodes + 1], col [cap_edges], root_local [b],
+ * meta [GIGL_META_LEN], nodes [cap_nodes] (global ids; may be NULL) — capacities from gigl_dist_plan_buffers. */
+int32_t gigl_dist_plan_batch_graph(gigl_dist_plan* plan, int32_t* rowptr, int32_t* rowend, int32_t* col,
+                                   int32_t* root_local, int32_t* meta, uint32_t* nodes);
 /* like gigl_sage_plan_stats for the step run last, plus the feature rows requested (PULLED_ROWS, summed) and the
  * fullest row bucket seen (PULL_BUCKET_MAX, a running maximum) */
 #define GIGL_STATS_PULLED_ROWS 14

@@ -465,3 +465,47 @@ def test_sharded_gat_plan_every_rank_end_to_end(world, dtype):
         c.close()
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("world,dtype", [(2, torch.float32), (3, torch.float16), (8, torch.float32)])
+def test_staged_plan_hands_out_the_training_batch_of_a_sharded_graph(world, dtype):
+    """a STAGED sharded plan (gigl_dist_plan_opts.staged): after the sampling / union / feature-pull phases every rank
+    holds its batch union graph with every node numbered — bit-equal to the oracle's sample + collate over the WHOLE
+    graph — and the batch's dense feature matrix (gigl_dist_plan_batch_features): own rows and rows pulled from their
+    owners, bit-equal to the table's rows.  What a trainer's batch needs when the graph is hash-partitioned."""
+    from gigl_amd.dist import Comm, DistSagePlan
+    rowptr, col, x = make_graph()
+    xq = x.astype(np.float16).astype(np.float32) if dtype == torch.float16 else x
+    b = 64
+    st = torch.cuda.Stream()
+    engs = [shard_engine(rowptr, col, x, r, world, dtype, st) for r in range(world)]
+    comms = Comm.local(engs)
+    dev = engs[0].device
+    w = [torch.zeros((4, 2 * D), device=dev), torch.zeros((4, 8), device=dev)]
+    plans = [DistSagePlan(comms[r], w, [None, None], b, FAN, max_window_end=bound_for(rowptr), staged=True)
+             for r in range(world)]
+    roots = [rank_roots(r, b) for r in range(world)]
+    roots_d = [torch.from_numpy(r.view(np.int32)).to(dev) for r in roots]
+    with torch.cuda.stream(st):
+        for _ in range(2):  # twice: buffers are reused step to step
+            DistSagePlan.sample_and_pull_local(plans, roots_d)
+        got = [p.batch_tensors() for p in plans]
+    st.synchronize()
+    for r in range(world):
+        t = {k: v.cpu().numpy() for k, v in got[r].items()}
+        assert t["meta"][8] == 0, "bucket overflow"
+        nbr, _ = oracle.sample_khop(rowptr, col, roots[r], FAN, canonical=True)
+        u = oracle.union_build(roots[r], FAN, nbr)
+        n = int(t["meta"][0])
+        assert n == u["nodes"].size
+        assert np.array_equal(t["nodes"][:n].view(np.uint32), u["nodes"])
+        assert np.array_equal(t["root_local"], u["root_local"])
+        for i in range(n):
+            assert np.array_equal(t["col"][t["rowptr"][i]:t["rowend"][i]], u["col"][u["rowptr"][i]:u["rowptr"][i + 1]]), i
+        assert np.array_equal(t["x"][:n], xq[u["nodes"].astype(np.int64)])
+    for p in plans:
+        p.close()
+    for c in comms:
+        c.close()
+    for e in engs:
+        e.close()
