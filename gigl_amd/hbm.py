@@ -328,10 +328,12 @@ class ResidentGraph:
             if type(model) is GAT:  # (raises NotImplementedError for options outside the sharded plan)
                 return model.make_dist_plan(self.comm, groups * b, self.fanouts, group_roots=b,
                                             max_window_end=self.max_window_end)
-            if not isinstance(model, GraphSAGE) or not model._plain or model.aggr not in ("mean", "sum", "max") or \
+            if type(model) is not GraphSAGE or not model._plain or model.aggr not in ("mean", "sum", "max") or \
                     model.feats_interaction is not None or model.feature_embedding_layer is not None:
-                raise NotImplementedError("WORLD_SIZE > 1: the sharded plan runs plain GraphSAGE encoders (aggr mean / sum "
-                                          f"/ max, optional L2-normalised output; got {type(model).__name__})")
+                if encoder_trains_over_graph_data(model):
+                    return None  # every other encoder of the zoo: staged batches (graph_data) + the encoder's own forward
+                raise NotImplementedError("WORLD_SIZE > 1: the sharded route runs the package's encoders (got "
+                                          f"{type(model).__name__})")
             w, bs = model.fused_params()
             # rows wider than the first layer's output: project this rank's shard once, pull W_l x rows (the table is
             # refilled in place by _refresh when the weights change)
@@ -407,7 +409,15 @@ class ResidentGraph:
                     plan.overflow_add(self._overflow_acc)
                 return out if batch.valid is None else out.index_select(0, batch.valid)
             outs = []
+            as_graph_data = self.sharded or not encoder_takes_hip_batches(model)
+            if as_graph_data and getattr(model, "engine", None) is None:
+                model.engine = self.engine  # (a GraphData batch carries no engine of its own)
             for k in range(g):  # staged: sample -> union -> model(HipBatch), one batch at a time
+                if as_graph_data:  # (a sharded graph: the batch assembled from the ranks' shards; encoders without a
+                    # forward over HipBatches: the same batch as a PyG-shaped GraphData built on the device)
+                    gd, ri = self.graph_data(batch.roots[k * b: (k + 1) * b].contiguous(), pad_to=b)
+                    outs.append(model(gd)[ri])
+                    continue
                 hb = self.hip_batch(batch.roots[k * b: (k + 1) * b])
                 outs.append(model(hb)[hb.root_local.long()])
             out = torch.cat(outs)

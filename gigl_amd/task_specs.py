@@ -79,8 +79,11 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
     @property
     def supports_hbm_batches(self) -> bool:
         """the in-HBM route (gigl_amd/hbm.py): infer_batch / the training loop also take batches sampled in HBM"""
-        from .hbm import encoder_takes_hip_batches
-        return self.model is not None and encoder_takes_hip_batches(self._inner_model())
+        from .hbm import encoder_takes_hip_batches, encoder_trains_over_graph_data
+        # (encoders without a forward over HipBatches — GIN, GATv2, Transformer ... — get the same in-HBM batch as a
+        # GraphData built on the device: hbm.ResidentGraph.encode)
+        return self.model is not None and (encoder_takes_hip_batches(self._inner_model()) or
+                                           encoder_trains_over_graph_data(self._inner_model()))
 
     def _inner_model(self) -> torch.nn.Module:
         return self.model.module if hasattr(self.model, "module") else self.model

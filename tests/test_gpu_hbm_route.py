@@ -258,6 +258,58 @@ def _infer_worker(rank, world, port, base, cfg_uri, q):
 
 
 @pytest.mark.gpu
+def test_two_rank_inferencer_with_an_encoder_outside_the_sharded_plan(small_job, monkeypatch):
+    """WORLD_SIZE = 2 with a GIN encoder (no one-call sharded plan): every batch is assembled from the two shards by the
+    STAGED sharded plan (ResidentGraph.graph_data: union graph + dense feature rows in the rank's HBM) and the encoder's
+    own forward runs over it — rows == the single-process in-HBM rows (1e-5)"""
+    import torch.multiprocessing as mp
+    from gigl_amd import config
+    from gigl_amd.inferencer import Inferencer
+    from gigl_amd.models_more import GIN
+    base, n, *_ = small_job
+    monkeypatch.setattr(config, "RECORDS_PER_PART_FILE", 3000)
+    doc = yaml.safe_load(open(os.path.join(base, "configs/job.yaml")))
+    args = dict(doc["inferencerConfig"].get("inferencerArgs") or {})
+    args["gnn_model_class_path"] = "gigl_amd.models_more.GIN"
+    doc["inferencerConfig"]["inferencerArgs"] = args
+    doc["trainerConfig"]["trainerArgs"] = dict(doc["trainerConfig"].get("trainerArgs") or {}, gnn_model_class_path="gigl_amd.models_more.GIN")
+    doc["sharedConfig"]["trainedModelMetadata"]["trainedModelUri"] = "out/model_gin/model.pt"
+    yaml.safe_dump(doc, open(os.path.join(base, "configs/job_gin.yaml"), "w"))
+    cfg = GbmlConfigPbWrapper.from_uri("configs/job_gin.yaml", uri_base=base)
+    from gigl_amd.task_specs import HipGraphSageNodeClassificationSpec
+    spec = HipGraphSageNodeClassificationSpec(**cfg.inferencer_args)
+    torch.manual_seed(4)
+    model = spec.init_model(cfg)
+    assert isinstance(model, GIN)
+    os.makedirs(os.path.join(base, "out/model_gin"), exist_ok=True)
+    torch.save(model.state_dict(), os.path.join(base, "out/model_gin/model.pt"))
+    single = Inferencer().run("job", _variant(base, "configs/job_gin.yaml", "g1"), None, uri_base=base, route="hbm")
+    want = {r["node_id"]: np.array(r["emb"], np.float32) for r in _rows(single["embeddings"])}
+    cfg2 = _variant(base, "configs/job_gin.yaml", "g2")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29760 + os.getpid() % 40
+    procs = [ctx.Process(target=_infer_worker, args=(r, 2, port, base, cfg2, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    for rank, status, info, _ in res:
+        assert status == "ok", f"rank {rank}: {info}"
+    got = {}
+    for rank, _, out, n_rows in res:
+        for r in _rows(out["embeddings"]):
+            assert r["node_id"] not in got
+            got[r["node_id"]] = np.array(r["emb"], np.float32)
+    assert sorted(got) == sorted(want)
+    ids = sorted(want)
+    np.testing.assert_allclose(np.stack([got[i] for i in ids]), np.stack([want[i] for i in ids]), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
 def test_two_rank_inferencer_over_the_sharded_plan(small_job, monkeypatch):
     """WORLD_SIZE = 2 (two processes sharing the test GPU, gloo + the callback transport): every rank ingests its
     shard (gigl_graph_build_shard_from_coo), batches go to rank c % 2 and run through the sharded plan; the union of the
