@@ -537,10 +537,14 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
 
     @property
     def supports_hbm_batches(self) -> bool:
-        """infer_batch also takes batches sampled in HBM (gigl_amd/hbm.py) when the encoder runs over a HipBatch"""
-        from .hbm import encoder_takes_hip_batches
+        """infer_batch also takes batches sampled in HBM (gigl_amd/hbm.py): encoders with a forward over HipBatches run it,
+        the others (GIN, GATv2, Transformer ...) get the same batch as a GraphData built on the device (ResidentGraph.encode)"""
+        from .hbm import encoder_takes_hip_batches, encoder_trains_over_graph_data
         inner = self.model.module if hasattr(self.model, "module") else self.model
-        return inner is not None and encoder_takes_hip_batches(getattr(inner, "encoder", inner))
+        if inner is None or (self._cfg is not None and self._cfg.is_heterogeneous):
+            return inner is not None and encoder_takes_hip_batches(getattr(inner, "encoder", inner))
+        enc = getattr(inner, "encoder", inner)
+        return encoder_takes_hip_batches(enc) or encoder_trains_over_graph_data(enc)
 
     def init_model(self, gbml_config_pb_wrapper: GbmlConfigPbWrapper, state_dict=None) -> nn.Module:
         self._cfg = gbml_config_pb_wrapper
