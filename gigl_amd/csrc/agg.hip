@@ -19,6 +19,7 @@
 //              double-buffered one K-step (8) ahead.  K is consumed 8 at a time: lane (r, h) loads
 //              k0+4h..k0+4h+3 and the t-th MFMA of the group multiplies the k-pairs {k0+t, k0+4+t} of A
 //              and W, so no LDS staging or transposes are needed.
+#include "wave_reduce.h"
 #include "common.h"
 
 #include <cstring>
@@ -1746,61 +1747,99 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // logit needs the whole row's dot product: every wave reduces its chunk's partial, publishes it through LDS, and after
 // one barrier per group of U edges all P waves add the partials in the same order — the softmax state is replicated,
 // bit-identical, in every wave of the row.
-template <typename T, int P, int H>
-__global__ __launch_bounds__(64 * P) void gat_input_online_kernel(
+// Four row elements as they are stored (the fp16 table: 8 bytes; widened where they are used, so that the U rows in
+// flight cost half the registers and the conversions fold into the multiply-adds)
+template <typename T>
+struct RawRow4;
+template <>
+struct RawRow4<float> {
+  typedef float4_t type;
+  static __device__ __forceinline__ type load(const float* p, int e) { return *reinterpret_cast<const float4_t*>(p + e); }
+  static __device__ __forceinline__ float4_t f4(const type& r) { return r; }
+  static __device__ __forceinline__ type zero() { return float4_t{0.f, 0.f, 0.f, 0.f}; }
+};
+template <>
+struct RawRow4<__half> {
+  typedef uint2 type;
+  static __device__ __forceinline__ type load(const __half* p, int e) { return *reinterpret_cast<const uint2*>(p + e); }
+  static __device__ __forceinline__ float4_t f4(const type& r) {
+    const __half2 lo = *reinterpret_cast<const __half2*>(&r.x), hi = *reinterpret_cast<const __half2*>(&r.y);
+    return float4_t{__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi)};
+  }
+  static __device__ __forceinline__ type zero() { return make_uint2(0u, 0u); }
+};
+
+// ONE WAVE per destination row, lane l owning the V float4 chunks (v*64 + l) of the d-wide row (d <= 256 V).  The kernel
+// is bound by VALU issue, not by the rows' bytes (scripts/micro/rowgather.hip: 1.5-KB rows drawn at random from a 47-GB
+// table arrive at 6 TB/s; the three-waves-per-row form of round 3 ran at 2.7 — every wave repeated the softmax update,
+// every edge cost 2H full-wave butterflies plus an LDS exchange and a barrier per group).  Here, per group of U edges:
+// the U*H partial logits are reduced TOGETHER (gigl_wave_reduce16: 35 instructions per 16 totals), the totals are wave-
+// uniform scalars (v_readlane), and the running softmax is rescaled once per group — the group's largest logit first,
+// then acc = acc*sc + sum_t pw_t x_t.  No LDS, no barrier.
+template <typename T, int V, int H>
+__global__ __launch_bounds__(256) void gat_input_online_kernel(
     const T* __restrict__ src, int d, const uint32_t* __restrict__ gather_ids, const int32_t* __restrict__ n_local_dev,
     const float* __restrict__ u, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend,
     const int32_t* __restrict__ col, const int32_t* __restrict__ n_rows_dev, float slope, int nkc, int64_t head_stride,
     float* __restrict__ z) {
-  constexpr int U = 8;  // feature rows in flight per wave
-  __shared__ float s_part[2][P][U + 1][2 * H];  // [buffer][chunk][edge of the group | the self row][head (src | dst)]
-  const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
+  // feature rows in flight per wave: 8 while they, the accumulators and the source vectors fit the registers of two
+  // waves per SIMD without spilling (the fp16 table at d = 768, two heads: 204 VGPRs; forcing three waves spilled and
+  // ran 30 % slower), 4 for the wide fp32 / four-head shapes
+  constexpr int U = (V * H * (sizeof(T) == 2 ? 2 : 4) > 12) ? 4 : 8;
+  constexpr int NV = U * H, NC = (NV + 15) / 16;
+  typedef RawRow4<T> RR;
+  typedef typename RR::type raw_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
   const int n_rows = *n_rows_dev;
   const int n_local = n_local_dev ? *n_local_dev : 0x7FFFFFFF;
   const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-  const int el = (c * 64 + lane) * 4;
-  const bool on = el < d;
   auto leaky = [&](float v) { return v > 0.f ? v : slope * v; };
-  auto wsum = [](float v) { return wave_sum_dpp(v); };
   auto dot4 = [](const float4_t& a, const float4_t& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; };
-  float4_t us[H], ud[H];
+  auto lane_value = [](float v, int from) {  // (wave-uniform: lands in a scalar register)
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), from));
+  };
+  int el[V];
+  bool on[V];
+  float4_t us[H][V];  // (the destination-side vectors are used once per row: re-read from L2 there, not held)
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
-    us[h] = on ? *reinterpret_cast<const float4_t*>(u + (int64_t)h * d + el) : zero4;
-    ud[h] = on ? *reinterpret_cast<const float4_t*>(u + (int64_t)(H + h) * d + el) : zero4;
+  for (int v = 0; v < V; ++v) {
+    el[v] = (v * 64 + lane) * 4;
+    on[v] = el[v] < d;
+#pragma unroll
+    for (int h = 0; h < H; ++h) us[h][v] = on[v] ? *reinterpret_cast<const float4_t*>(u + (int64_t)h * d + el[v]) : zero4;
   }
-  int buf = 0;
-  for (int i = blockIdx.x; i < n_rows; i += gridDim.x) {  // (uniform over the workgroup: the barriers below are safe)
+  for (int i = wave; i < n_rows; i += waves) {
     const int e0 = rowptr[i], m = rowend[i] - e0;
     const uint32_t self_gid = gather_ids[i];
     const bool local = i < n_local;
     float sd[H], mx[H], den[H];
-    float4_t acc[H];
+    float4_t acc[H][V];
     {
-      const float4_t xs = on ? RowLoader<T>::load4(src + (int64_t)self_gid * d, el) : zero4;
+      float pv[16];
 #pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const float ps = wsum(dot4(xs, us[h])), pd = wsum(dot4(xs, ud[h]));
-        if (lane == 0) {
-          s_part[buf][c][U][h] = ps;
-          s_part[buf][c][U][H + h] = pd;
+      for (int k = 0; k < 16; ++k) pv[k] = 0.f;
+      const T* row = src + (int64_t)self_gid * d;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const float4_t xs = on[v] ? RR::f4(RR::load(row, el[v])) : zero4;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const float4_t udv = on[v] ? *reinterpret_cast<const float4_t*>(u + (int64_t)(H + h) * d + el[v]) : zero4;
+          pv[h] += dot4(xs, us[h][v]);
+          pv[H + h] += dot4(xs, udv);
+          acc[h][v] = xs;  // the self loop opens the running softmax with weight 1
         }
-        acc[h] = xs;  // the self loop opens the running softmax with weight 1
       }
-      __syncthreads();
+      const float tot = gigl_wave_reduce16(pv);
 #pragma unroll
       for (int h = 0; h < H; ++h) {
-        float fs = 0.f, fd = 0.f;
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-          fs += s_part[buf][q][U][h];
-          fd += s_part[buf][q][U][H + h];
-        }
+        const float fs = lane_value(tot, h << 2), fd = lane_value(tot, (H + h) << 2);
         sd[h] = fd;
         mx[h] = leaky(fs + fd);
         den[h] = 1.f;
       }
-      buf ^= 1;
     }
     for (int c0 = 0; c0 < m; c0 += 64) {
       const int mm = min(64, m - c0);
@@ -1818,47 +1857,69 @@ __global__ __launch_bounds__(64 * P) void gat_input_online_kernel(
       }
       const unsigned long long keep = __ballot(take);
       for (int e = 0; e < mm; e += U) {
-        float4_t x[U];
+        raw_t x[U][V];
         bool live[U];
 #pragma unroll
         for (int t = 0; t < U; ++t) {
-          live[t] = e + t < mm && ((keep >> (e + t)) & 1ull);  // (uniform over the workgroup)
-          const uint32_t g = __shfl(gid, (e + t) & 63, 64);
-          x[t] = (live[t] && on) ? RowLoader<T>::load4(src + (int64_t)g * d, el) : zero4;
+          live[t] = e + t < mm && ((keep >> (e + t)) & 1ull);  // (uniform over the wave)
+          const T* row = src + (int64_t)__shfl(gid, (e + t) & 63, 64) * d;
+#pragma unroll
+          for (int v = 0; v < V; ++v) x[t][v] = (live[t] && on[v]) ? RR::load(row, el[v]) : RR::zero();
         }
+        // every edge's source logit, all heads: this lane's partials reduced together, one total per quad of lanes
+        float fsum[NC * 16];
 #pragma unroll
-        for (int t = 0; t < U; ++t) {
-          if (!live[t]) continue;
+        for (int cc = 0; cc < NC; ++cc) {
+          float pv[16];
 #pragma unroll
-          for (int h = 0; h < H; ++h) {
-            const float ps = wsum(dot4(x[t], us[h]));
-            if (lane == 0) s_part[buf][c][t][h] = ps;
+          for (int k = 0; k < 16; ++k) {
+            const int idx = cc * 16 + k;  // = t * H + h
+            float a = 0.f;
+            if (idx < NV) {
+#pragma unroll
+              for (int v = 0; v < V; ++v) a += dot4(RR::f4(x[idx / H][v]), us[idx % H][v]);
+            }
+            pv[k] = a;
           }
+          const float tot = gigl_wave_reduce16(pv);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) fsum[cc * 16 + k] = lane_value(tot, k << 2);
         }
-        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < U; ++t) {
-          if (!live[t]) continue;
+        for (int h = 0; h < H; ++h) {
+          float zl[U];
+          float gmax = mx[h];
 #pragma unroll
-          for (int h = 0; h < H; ++h) {
-            float fs = 0.f;
-#pragma unroll
-            for (int q = 0; q < P; ++q) fs += s_part[buf][q][t][h];
-            const float zl = leaky(fs + sd[h]);
-            const float nm = fmaxf(mx[h], zl);
-            const float sc = __expf(mx[h] - nm), pw = __expf(zl - nm);
-            den[h] = den[h] * sc + pw;
-            acc[h] = acc[h] * sc + pw * x[t];
-            mx[h] = nm;
+          for (int t = 0; t < U; ++t) {
+            zl[t] = live[t] ? leaky(fsum[t * H + h] + sd[h]) : -__builtin_inff();
+            gmax = fmaxf(gmax, zl[t]);
           }
+          const float sc = __expf(mx[h] - gmax);
+          float dn = den[h] * sc;
+          float pw[U];
+#pragma unroll
+          for (int t = 0; t < U; ++t) {
+            pw[t] = __expf(zl[t] - gmax);  // (0 for an edge that is not there)
+            dn += pw[t];
+          }
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            float4_t a = acc[h][v] * sc;
+#pragma unroll
+            for (int t = 0; t < U; ++t) a += pw[t] * RR::f4(x[t][v]);
+            acc[h][v] = a;
+          }
+          den[h] = dn;
+          mx[h] = gmax;
         }
-        buf ^= 1;  // (the next group writes the other buffer: one barrier per group)
       }
     }
-    if (on) {
-      float* tbase = z + ((int64_t)(i >> 7) * nkc) * 4096 + (i & 127) * 32 + (int64_t)(el >> 5) * 4096 + (el & 31);
 #pragma unroll
-      for (int h = 0; h < H; ++h) *reinterpret_cast<float4_t*>(tbase + h * head_stride) = acc[h] * (1.0f / den[h]);
+    for (int v = 0; v < V; ++v) {
+      if (!on[v]) continue;
+      float* tbase = z + ((int64_t)(i >> 7) * nkc) * 4096 + (i & 127) * 32 + (int64_t)(el[v] >> 5) * 4096 + (el[v] & 31);
+#pragma unroll
+      for (int h = 0; h < H; ++h) *reinterpret_cast<float4_t*>(tbase + h * head_stride) = acc[h][v] * (1.0f / den[h]);
     }
   }
 }
@@ -3508,10 +3569,10 @@ int32_t gigl_gat_input_layer_fused_hs(gigl_ctx* ctx, const void* src, int32_t sr
     gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
     hipLaunchKernelGGL(gat_fold_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)(2 * H)), dim3(256), 0, st, w, att_src,
                        att_dst, H, C, d, u);
-    int64_t blocks = rows_cap;  // one workgroup of P waves per row
-    if (blocks > 256 * 64) blocks = 256 * 64;
+    int64_t blocks = (rows_cap + 3) / 4;  // one wave per row, four rows per workgroup
+    if (blocks > 256 * 16) blocks = 256 * 16;
 #define GIGL_GAT_ON(TT, PP, HH)                                                                                         \
-  hipLaunchKernelGGL((gat_input_online_kernel<TT, PP, HH>), dim3((unsigned)blocks), dim3(64 * PP), 0, st,             \
+  hipLaunchKernelGGL((gat_input_online_kernel<TT, PP, HH>), dim3((unsigned)blocks), dim3(256), 0, st,                 \
                      (const TT*)src, d, gather_ids, n_local_dev, u, rowptr, rowend, col, n_rows_dev, negative_slope,    \
                      nkc, head_stride, z)
 #define GIGL_GAT_ON_P(TT, HH)                                                                                           \
