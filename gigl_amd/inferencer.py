@@ -137,9 +137,8 @@ class Inferencer:
                     raise ValueError(f"data route {want!r}: expected hbm, tfrecord or auto")
                 self.route = "hbm" if want == "hbm" else "tfrecord"
                 if self.route == "hbm":
-                    if world > 1:
-                        raise NotImplementedError("typed graphs: the in-HBM route runs in one process")
-                    return self._run_typed_hbm(cfg, inferencer, dev)
+                    # (WORLD_SIZE > 1: every rank holds the typed tables and takes the batches c % world == rank)
+                    return self._run_typed_hbm(cfg, inferencer, dev, rank, world)
                 return self._run_typed(cfg, inferencer, dev)
             from .hbm import route_of
             self.route = route_of(cfg, cfg.inferencer_args, route)
@@ -290,13 +289,16 @@ def _typed_run(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str, str
 Inferencer._run_typed = _typed_run
 
 
-def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str, str]:
+def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev, rank: int = 0, world: int = 1) -> Dict[str, str]:
     """heterogeneous jobs, in-HBM route: the preprocessor's typed tables are read once into HBM (one CSR per edge type
     and direction, one feature table per node type), every batch's typed graph — the config's SamplingOp DAG for the
     roots, the distinct nodes per type, the distinct edges per edge type — is built there by the library's one-call
     plan (HipGraphDBSampler.batch_graph_plan -> gigl_typed_plan_*), and the encoder runs over it.  The same roots in the
     same batches as the TFRecord route (the sampler writes a type's roots in table order); the rows differ from that
-    route's by fp32 summation order only (a type's nodes are numbered ascending here, first-seen there)."""
+    route's by fp32 summation order only (a type's nodes are numbered ascending here, first-seen there).
+    WORLD_SIZE > 1: a replica of the typed tables per rank (they fit one GPU wherever this route is used), rank r takes
+    the batches c with c % world == r and writes its own files (suffix .rank<r> / shard prefix rank_<r>), like the
+    homogeneous route's file sharding (data_loaders/utils.py:23-56)."""
     from .graphdb_sampler import HipGraphDBSampler
     from .hbm import planned_root_order
     from .subgraph_sampler import load_preprocessed_typed_graph, sampling_op_dags
@@ -326,13 +328,13 @@ def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str,
             files = {"embeddings": path}
             # rows through the same writer as the homogeneous routes: line-per-root JSON formatted natively
             # (gigl_json_rows_format), or Avro shards encoded on the device when the path names a directory
-            writer = _RowWriter(files, node_type)
+            writer = _RowWriter(files, node_type, rank, world)
             try:
                 prefix = cfg.random_negative_tfrecord_uri_prefixes.get(node_type)
                 order = planned_root_order(np.asarray(ids[node_type]), prefix) if prefix else np.asarray(ids[node_type])
                 # (HGT: the plan also lays out the layers' merged CSR by destination and the roots' rows of it)
                 et_ids = enc.convs[0].edge_types_map if is_hgt and len(enc.convs) else None
-                chunks = [np.asarray(order[i:i + b], dtype=np.int64) for i in range(0, order.size, b)]
+                chunks = [np.asarray(order[i:i + b], dtype=np.int64) for i in range(0, order.size, b)][rank::world]
                 # HGT encoders: the whole step — DAG sampler, typed batch graph, encoder, the roots' rows — is ONE library
                 # call per batch, replayed as a hipGraph (csrc/hgt_plan.hip; GIGL_AMD_TYPED_ONE_CALL=0: staged launches)
                 one_call = None
@@ -371,7 +373,7 @@ def _typed_run_hbm(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str,
                     writer.add(chunk, emb.float(), None)
             finally:
                 writer.close()
-            out_files[f"embeddings/{node_type}"] = files["embeddings"]
+            out_files[f"embeddings/{node_type}"] = files["embeddings"]  # (the writer has put the rank suffix on it)
             n_rows += writer.n_rows
     finally:
         s.close()

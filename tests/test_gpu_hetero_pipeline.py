@@ -176,6 +176,65 @@ def test_typed_in_hbm_route_matches_the_tfrecord_route(golden_dir, tmp_path_fact
             np.testing.assert_allclose(r["emb"], first[t][r["node_id"]], rtol=2e-5, atol=2e-5)
 
 
+def _typed_infer_worker(rank, world, port, wd, cfg_uri, q):
+    try:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port), GIGL_DIST_BACKEND="gloo")
+        from gigl_amd.inferencer import Inferencer
+        inf = Inferencer()
+        out = inf.run("job", cfg_uri, None, uri_base=wd, route="hbm")
+        q.put((rank, "ok", out, inf.rows_written))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc() + repr(e), 0))
+
+
+def test_typed_in_hbm_route_at_world_size_two(workdir):
+    """the typed in-HBM inference route with WORLD_SIZE = 2 (two processes on the test GPU): every rank holds the typed
+    tables and takes the batches c % 2 == rank, writes its own files — the union of the ranks' rows == the
+    single-process rows (same batches, same one-call plan)"""
+    import torch.multiprocessing as mp
+    from gigl_amd.inferencer import Inferencer
+    from gigl_amd.trainer import Trainer
+    # (permutation_strategy = deterministic: every process samples under seed 42 — otherwise each job draws its own seed)
+    doc = yaml.safe_load(open(os.path.join(workdir, CFG)))
+    doc["datasetConfig"]["subgraphSamplerConfig"].setdefault("experimentalFlags", {})["permutation_strategy"] = "deterministic"
+    doc["sharedConfig"]["inferenceMetadata"] = {"nodeTypeToInferencerOutputInfoMap": {
+        "author": {"embeddingsPath": "out/hetero_w2/emb_author.jsonl"},
+        "paper": {"embeddingsPath": "out/hetero_w2/emb_paper.jsonl"}}}
+    cfg_uri = "configs/hetero_w2_gbml_config.yaml"
+    yaml.safe_dump(doc, open(os.path.join(workdir, cfg_uri), "w"))
+    seed_trainer()
+    Trainer().run("job", cfg_uri, None, uri_base=workdir)
+    single = Inferencer().run("job", cfg_uri, None, uri_base=workdir, route="hbm")
+    want = {t: {r["node_id"]: r["emb"] for r in map(json.loads, open(single[f"embeddings/{t}"]))} for t in ("author", "paper")}
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 40
+    procs = [ctx.Process(target=_typed_infer_worker, args=(r, 2, port, workdir, cfg_uri, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        if p.is_alive():
+            p.kill()
+    for rank, status, info, _ in res:
+        assert status == "ok", f"rank {rank}: {info}"
+    got = {"author": {}, "paper": {}}
+    for rank, _, out, n_rows in res:
+        assert n_rows > 0
+        for t in got:
+            assert out[f"embeddings/{t}"].endswith(f".rank{rank}")
+            for r in map(json.loads, open(out[f"embeddings/{t}"])):
+                assert r["node_id"] not in got[t]
+                got[t][r["node_id"]] = r["emb"]
+    for t in got:
+        assert sorted(got[t]) == sorted(want[t])
+        for k, v in want[t].items():
+            np.testing.assert_allclose(got[t][k], v, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("encoder", ["HGT", "SimpleHGN"])
 def test_typed_trainer_in_hbm_route_matches_the_tfrecord_route(golden_dir, tmp_path_factory, encoder):
     """the typed link-prediction TRAINER with data_route = hbm: main batches (anchors + sampled positives, the union of
