@@ -89,7 +89,10 @@ def test_gat(setup, heads, hid, out, fan):
 
 
 @pytest.mark.parametrize("d,dtype,heads,hid", [(768, np.float16, 2, 128), (320, np.float16, 4, 32), (1000, np.float32, 1, 64),
-                                               (260, np.float32, 2, 16)])
+                                               (260, np.float32, 2, 16),
+                                               # (the one-pass kernel's other shapes: 8 rows x 4 heads = two reductions of
+                                               # 16 logits per group; one head)
+                                               (256, np.float16, 4, 16), (128, np.float16, 1, 32)])
 def test_gat_first_layer_from_the_input_side(d, dtype, heads, hid):
     """wide stored rows (d > heads*hid): logits from the folded attention vectors and the projection after the
     aggregation (gigl_gat_input_layer) == the projection-first order of the same layer == the CPU forward"""
