@@ -906,7 +906,7 @@ def main():
         # same script as the mag240m-sharded workload, the ranks' own process group on another port): a crash or a
         # hang there ends the child, not the line.  Rank 0 embeds the child's JSON line, or the reason there is none.
         import subprocess
-        limit = float(os.environ.get("GIGL_BENCH_SUB_TIMEOUT", "600"))
+        limit = float(os.environ.get("GIGL_BENCH_SUB_TIMEOUT", "300"))
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--workload", "mag240m-sharded",
                "--fanouts", "25,10", "--batch", "1024", "--min-seconds", str(min(args.min_seconds, 1.5)), "--min-reps", "3",
                "--min-rounds", "4", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
