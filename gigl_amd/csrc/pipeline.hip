@@ -79,7 +79,7 @@ struct gigl_sage_plan {
   // hipGraph replay
   bool use_graph = false;
   uint32_t* roots_buf = nullptr;  // static input of the captured graphs
-  float* out_buf = nullptr;       // static output of the captured graphs
+  float* out_buf = nullptr;       // (placeholder `out` of the captures; the stage that writes `out` runs eagerly)
   std::vector<Segment> segs;
   int32_t cap_seed = 0, cap_mode = -1;
   uint32_t cap_prof_mask = 0;
@@ -316,9 +316,11 @@ int32_t capture_segments(gigl_sage_plan* p, int32_t sampling_seed, int32_t mode)
   while (s < n) {
     Segment sg;
     sg.s0 = s;
-    const bool timed = (stage_kernel_mask(p, s) & mask) != 0;
+    // (the last stage — the roots' rows into the caller's `out` — stays out of the graphs: launched eagerly with the
+    // pointer of the call, instead of a captured write to a static buffer and a device copy of it per call)
+    const bool timed = (stage_kernel_mask(p, s) & mask) != 0 || s == n - 1;
     int e = s + 1;
-    while (e < n && ((stage_kernel_mask(p, e) & mask) != 0) == timed) ++e;
+    while (e < n - 1 && ((stage_kernel_mask(p, e) & mask) != 0) == timed && s != n - 1) ++e;
     sg.s1 = e;
     if (!timed) {
       hipGraph_t graph = nullptr;
@@ -873,12 +875,10 @@ int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sam
     if (sg.exec) {
       GIGL_HIP_CHECK(ctx, hipGraphLaunch(sg.exec, ctx->stream));
     } else {
-      int32_t rc = enqueue_range(p, sg.s0, sg.s1, p->roots_buf, sampling_seed, mode, p->out_buf);
+      int32_t rc = enqueue_range(p, sg.s0, sg.s1, p->roots_buf, sampling_seed, mode, out);
       if (rc != GIGL_OK) return rc;
     }
   }
-  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(out, p->out_buf, (size_t)p->b * p->dims[p->hops] * 4,
-                                     hipMemcpyDeviceToDevice, ctx->stream));
   return GIGL_OK;
 }
 
