@@ -492,7 +492,15 @@ class ResidentGraph:
         ea = None
         if not self.sharded and getattr(eng, "_efeat", None) is not None:
             ea = eng.union_edge_attr(u).index_select(0, idx)
-        g = GraphData(x=x, edge_index=torch.stack([src, dst]), edge_attr=ea).to(dev)
+        g = GraphData(x=x, edge_index=torch.stack([src, dst]), edge_attr=ea)
+        # the CSR by destination the kernels read IS the union graph's (rows ascending, a row's sources ascending: the
+        # order GraphData._build_csr sorts into) — packed here, not rebuilt by a sort of the edge list
+        rp = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+        rp[1:] = (start + lens).to(torch.int32)
+        g.rowptr = rp
+        g.col = src.to(torch.int32).contiguous() if e else torch.zeros(1, dtype=torch.int32, device=dev)
+        g.n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+        g.edge_attr_csr = ea
         return g, root_local[:n_real].to(torch.int64)
 
     def _staged_plan(self, b: int):

@@ -457,3 +457,37 @@ def test_overflowed_plan_calls_are_reported_by_the_hbm_route():
         res.close()
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_graph_data_batches_carry_the_union_graphs_csr():
+    """ResidentGraph.graph_data packs the batch union graph's CSR into the GraphData it hands out instead of sorting the
+    edge list again: the same rowptr / col / edge order as GraphData._build_csr gives for that edge_index, nodes and
+    feature rows those of the oracle's collate"""
+    import oracle
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.hbm import ResidentGraph
+    from gigl_amd.nn import GraphData
+    from helpers import rmat_edges
+    n, d = 1 << 11, 12
+    s, t = rmat_edges(11, 40000, seed=9)
+    rowptr, col = oracle.build_csc(n, s, t, is_directed=False)
+    x = np.random.default_rng(2).standard_normal((n, d)).astype(np.float32)
+    eng = HipEngine(0)
+    try:
+        eng.load_csc(rowptr, col)
+        eng.load_features(x)
+        res = ResidentGraph.from_engine(eng, np.arange(n), [7, 5])
+        roots = np.random.default_rng(4).integers(0, n, size=200).astype(np.uint32)
+        g, ri = res.graph_data(torch.from_numpy(roots.view(np.int32)).to(eng.device))
+        ref = GraphData(x=g.x, edge_index=g.edge_index)
+        ref._build_csr()
+        assert torch.equal(g.rowptr, ref.rowptr) and torch.equal(g.col, ref.col) and torch.equal(g.n_dev, ref.n_dev)
+        nbr, _ = oracle.sample_khop(rowptr, col, roots, [7, 5], canonical=True)
+        u = oracle.union_build(roots, [7, 5], nbr)
+        assert g.num_nodes == u["nodes"].size and g.num_edges == int(u["rowptr"][-1])
+        assert np.array_equal(g.x.cpu().numpy(), x[u["nodes"].astype(np.int64)])
+        assert np.array_equal(ri.cpu().numpy(), u["root_local"])
+        assert np.array_equal(g.col.cpu().numpy()[: g.num_edges], u["col"][: g.num_edges])
+    finally:
+        eng.close()
