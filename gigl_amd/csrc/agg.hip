@@ -2191,6 +2191,37 @@ __global__ __launch_bounds__(256) void gat_gather_fast_kernel(
   }
 }
 
+// the dense tail of the GAT layer's backward in ONE pass over the projected rows (what torch ran as ~10 elementwise /
+// reduction passes over [nodes][H*C] tensors): per row r and column c of head h
+//   dxw[r][c] = dh[r][c] + ds[r][h] att_src[c] + dd[r][h] att_dst[c]        (in place in dh)
+//   d att_src[c] += ds[r][h] xw[r][c];   d att_dst[c] += dd[r][h] xw[r][c]  (per-thread partials, one atomic pair per
+//                                                                             thread at the end)
+// a row whose ds / dd are both zero for the head adds nothing and is not read.  A thread owns one column.
+__global__ __launch_bounds__(1024) void gat_backward_epilogue_kernel(float* __restrict__ dh, const float* __restrict__ ds,
+                                                                     const float* __restrict__ dd,
+                                                                     const float* __restrict__ xw,
+                                                                     const float* __restrict__ att_src,
+                                                                     const float* __restrict__ att_dst,
+                                                                     const int32_t* __restrict__ n_dev, int H, int C,
+                                                                     float* __restrict__ d_att_src,
+                                                                     float* __restrict__ d_att_dst) {
+  const int HC = H * C, c = threadIdx.x;
+  if (c >= HC) return;
+  const int h = c / C, n = *n_dev;
+  const float as = att_src[c], ad = att_dst[c];
+  float acc_s = 0.f, acc_d = 0.f;
+  for (int r = blockIdx.x; r < n; r += gridDim.x) {
+    const float a = ds[(int64_t)r * H + h], b = dd[(int64_t)r * H + h];
+    if (a == 0.f && b == 0.f) continue;
+    const float x = xw[(int64_t)r * HC + c];
+    dh[(int64_t)r * HC + c] += a * as + b * ad;
+    acc_s += a * x;
+    acc_d += b * x;
+  }
+  if (acc_s != 0.f) atomicAdd(d_att_src + c, acc_s);
+  if (acc_d != 0.f) atomicAdd(d_att_dst + c, acc_d);
+}
+
 // ---- backward of the attention aggregation (training): one wave per destination row, same lane layout as the
 // forward.  With alpha_e = softmax_e(z_e), out_i = sum_e alpha_e x_e (e over the in-edges and the added self loop):
 //   d alpha_e = <g_i, x_e>,  S = sum_e alpha_e d alpha_e = <g_i, out_i>,  dz_e = alpha_e (d alpha_e - S),
@@ -2992,6 +3023,26 @@ int32_t gigl_gat_aggregate_edge(gigl_ctx* ctx, const float* h, const float* att_
   hipLaunchKernelGGL(gat_edge_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, h, a_src, a_dst,
                      a_edge, edge_attr, edge_dim, w_edge_msg, rowptr, rowend, col, n_rows_dev, heads, channels,
                      negative_slope, concat, bias, act, out);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_gat_backward_epilogue(gigl_ctx* ctx, float* dh, const float* ds, const float* dd, const float* xw,
+                                   const float* att_src, const float* att_dst, const int32_t* n_nodes_dev, int64_t nodes_cap,
+                                   int32_t heads, int32_t channels, float* d_att_src, float* d_att_dst) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, dh && ds && dd && xw && att_src && att_dst && n_nodes_dev && d_att_src && d_att_dst, "null argument");
+  GIGL_REQUIRE(ctx, heads > 0 && channels > 0 && nodes_cap >= 0, "bad sizes");
+  if ((int64_t)heads * channels > 1024)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "gigl_gat_backward_epilogue: heads*channels = %lld > 1024",
+                     (long long)heads * channels);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (nodes_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_BWD);
+  const int hc = heads * channels, threads = (hc + 63) / 64 * 64;
+  int64_t blocks = nodes_cap < 2048 ? nodes_cap : 2048;
+  hipLaunchKernelGGL(gat_backward_epilogue_kernel, dim3((unsigned)blocks), dim3((unsigned)threads), 0, ctx->stream, dh, ds, dd,
+                     xw, att_src, att_dst, n_nodes_dev, heads, channels, d_att_src, d_att_dst);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

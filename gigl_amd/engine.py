@@ -915,6 +915,24 @@ class HipEngine:
             p(dd), p(dae), p(u_msg), p(z)), self._ctx)
         return dh, ds, dd, dae, z
 
+    def gat_backward_epilogue(self, dh: torch.Tensor, ds: torch.Tensor, dd: torch.Tensor, xw: torch.Tensor,
+                              att_src: torch.Tensor, att_dst: torch.Tensor, heads: int, channels: int,
+                              n_nodes_dev: torch.Tensor):
+        """-> (dxw = dh, updated in place; d_att_src [H*C]; d_att_dst [H*C]): the dense tail of the GAT layer's backward
+        in one pass (gigl_gat_backward_epilogue)"""
+        hc = heads * channels
+        for t in (dh, xw):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.shape[1] == hc
+        assert ds.is_contiguous() and dd.is_contiguous() and ds.shape == dd.shape == (dh.shape[0], heads)
+        a_s = att_src.detach().reshape(-1).to(torch.float32).contiguous()
+        a_d = att_dst.detach().reshape(-1).to(torch.float32).contiguous()
+        g_s = torch.zeros(hc, dtype=torch.float32, device=self.device)
+        g_d = torch.zeros(hc, dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(self._lib.gigl_gat_backward_epilogue(self._ctx, p(dh), p(ds), p(dd), p(xw), p(a_s), p(a_d), p(n_nodes_dev),
+                                                   int(dh.shape[0]), heads, channels, p(g_s), p(g_d)), self._ctx)
+        return dh, g_s, g_d
+
     def gather_mean_backward(self, dout: torch.Tensor, d: int, rowptr: torch.Tensor, rowend: Optional[torch.Tensor],
                              col: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int, dsrc: torch.Tensor,
                              aggr: str = "mean", src: Optional[torch.Tensor] = None) -> None:

@@ -172,11 +172,15 @@ class _GatConvFn(torch.autograd.Function):
         dw_msg = None
         if z is not None:
             dw_msg = torch.einsum("nhc,nhk->hck", dy.view(n, heads, ch), z).reshape(hc, -1)
-        xw3 = xw.view(n, heads, ch)
-        d_att_src = (ds.unsqueeze(-1) * xw3).sum(0).view_as(att_src)
-        d_att_dst = (dd.unsqueeze(-1) * xw3).sum(0).view_as(att_dst)
-        dxw = (dh.view(n, heads, ch) + ds.unsqueeze(-1) * att_src.view(1, heads, ch)
-               + dd.unsqueeze(-1) * att_dst.view(1, heads, ch)).reshape(n, hc).contiguous()
+        if hc <= 1024:  # one pass over the projected rows (gigl_gat_backward_epilogue), dh updated in place
+            dxw, g_s, g_d = eng.gat_backward_epilogue(dh, ds, dd, xw, att_src, att_dst, heads, ch, n_dev)
+            d_att_src, d_att_dst = g_s.view_as(att_src), g_d.view_as(att_dst)
+        else:
+            xw3 = xw.view(n, heads, ch)
+            d_att_src = (ds.unsqueeze(-1) * xw3).sum(0).view_as(att_src)
+            d_att_dst = (dd.unsqueeze(-1) * xw3).sum(0).view_as(att_dst)
+            dxw = (dh.view(n, heads, ch) + ds.unsqueeze(-1) * att_src.view(1, heads, ch)
+                   + dd.unsqueeze(-1) * att_dst.view(1, heads, ch)).reshape(n, hc).contiguous()
         dev = dy.device
         n_out = dev_i32(dev, hc)
         dw, _ = eng.linear_weight_grad(dxw, x, n_dev)                                       # dW = dxw^T x

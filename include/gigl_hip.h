@@ -883,6 +883,15 @@ int32_t gigl_gat_aggregate_backward(gigl_ctx* ctx, const float* h, const float* 
                                     int64_t cap_edges, const float* att_edge_folded, float* alpha_scratch, float* dh,
                                     float* d_alpha_src, float* d_alpha_dst, float* d_alpha_edge,
                                     const float* u_msg, float* z_out);
+/* the dense tail of that backward, one pass over the projected rows xw [nodes][heads*channels] (heads*channels <= 1024):
+ *   dh[r][c] += d_alpha_src[r][h] att_src[c] + d_alpha_dst[r][h] att_dst[c]   (dh becomes the gradient w.r.t. xw)
+ *   d_att_src[c] += sum_r d_alpha_src[r][h] xw[r][c];  d_att_dst[c] += sum_r d_alpha_dst[r][h] xw[r][c]   (h = c / channels)
+ * over the first *n_nodes_dev rows; d_att_src / d_att_dst [heads*channels] are ADDED to (zero them first; fp32 atomics).
+ * What PyG's autograd of GATConv spreads over a dozen elementwise / reduction kernels. */
+int32_t gigl_gat_backward_epilogue(gigl_ctx* ctx, float* dh, const float* d_alpha_src, const float* d_alpha_dst,
+                                   const float* xw, const float* att_src, const float* att_dst,
+                                   const int32_t* n_nodes_dev, int64_t nodes_cap, int32_t heads, int32_t channels,
+                                   float* d_att_src, float* d_att_dst);
 
 /* backward of gigl_gather_mean w.r.t. a dense local fp32 source (gather_ids == NULL; layers >= 2):
  *   dsrc[i][0:d] += dout[i][d:2d];  dsrc[col[e]][0:d] += dout[i][0:d] / deg_i  for e in row i, i < n_rows.
