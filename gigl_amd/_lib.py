@@ -38,7 +38,7 @@ SYMBOLS = [
     "gigl_tfrecord_index", "gigl_tfexample_decode", "gigl_collate_records", "gigl_collated_info", "gigl_collated_copy",
     "gigl_collated_destroy", "gigl_gather_reduce", "gigl_gather_reduce_backward",
     "gigl_frontier_bucket", "gigl_frontier_scatter", "gigl_avro_embeddings_layout", "gigl_avro_embeddings_encode",
-    "gigl_edge_ids", "gigl_union_edge_ids", "gigl_gat_aggregate_edge", "gigl_collated_edge_attr", "gigl_sample_out_neighbors", "gigl_rows_dedup", "gigl_gat_aggregate_backward", "gigl_gat_backward_epilogue",
+    "gigl_edge_ids", "gigl_union_edge_ids", "gigl_gat_aggregate_edge", "gigl_collated_edge_attr", "gigl_sample_out_neighbors", "gigl_rows_dedup", "gigl_gat_aggregate_backward", "gigl_gat_backward_epilogue", "gigl_gat_input_aggregate", "gigl_gat_input_aggregate_backward",
     "gigl_cms_add", "gigl_cms_estimate", "gigl_gine_aggregate", "gigl_gine_aggregate_backward", "gigl_gat_input_layer", "gigl_gat_input_layer_scratch", "gigl_gat_input_layer_fused",
     "gigl_gat_input_layer_fused_scratch", "gigl_gat_plan_create", "gigl_gat_plan_set_weights", "gigl_sage_plan_set_aggr", "gigl_gatv2_aggregate", "gigl_gatv2_aggregate_backward", "gigl_gatv2_aggregate_edge",
     "gigl_gatv2_aggregate_edge_backward", "gigl_transformer_aggregate_edge", "gigl_transformer_aggregate_edge_backward",
@@ -351,6 +351,8 @@ def load() -> C.CDLL:
         "gigl_tfexample_decode": [vp, vp, vp, i64, P(GiglColumn), i32, i32, P(i64)],
         "gigl_gat_aggregate_edge": [vp, vp, vp, vp, i32, i32, C.c_float, i32, vp, vp, vp, vp, i64, vp, i64, vp, i32, vp, i32,
                                     i64, vp, vp, vp, vp],
+        "gigl_gat_input_aggregate": [vp, vp, i32, i32, vp, vp, i32, C.c_float, vp, vp, vp, vp, i64, vp],
+        "gigl_gat_input_aggregate_backward": [vp, vp, i32, i32, vp, vp, i32, C.c_float, vp, vp, vp, vp, i64, vp, vp, vp],
         "gigl_gat_backward_epilogue": [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp],
         "gigl_gat_aggregate_backward": [vp, vp, vp, vp, i32, i32, C.c_float, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i32,
                                         i64, vp, vp, vp, vp, vp, vp, vp, vp],

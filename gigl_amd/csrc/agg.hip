@@ -1917,11 +1917,249 @@ __global__ __launch_bounds__(256) void gat_input_online_kernel(
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       if (!on[v]) continue;
-      float* tbase = z + ((int64_t)(i >> 7) * nkc) * 4096 + (i & 127) * 32 + (int64_t)(el[v] >> 5) * 4096 + (el[v] & 31);
+      // (nkc == 0: plain rows, z[h][i][0:d] — what the training path keeps for the projection's weight gradient)
+      float* tbase = nkc ? z + ((int64_t)(i >> 7) * nkc) * 4096 + (i & 127) * 32 + (int64_t)(el[v] >> 5) * 4096 + (el[v] & 31)
+                         : z + (int64_t)i * d + el[v];
 #pragma unroll
       for (int h = 0; h < H; ++h) *reinterpret_cast<float4_t*>(tbase + h * head_stride) = acc[h][v] * (1.0f / den[h]);
     }
   }
+}
+
+// ---- backward of that aggregation w.r.t. the folded attention vectors (the rows themselves are inputs: no gradient).
+//   z_i^h = sum_e alpha_e^h x_e,  alpha = softmax_e leaky(<x_e, us^h> + <x_i, ud^h>)  (e over the in-edges and the self loop)
+//   given dz_i^h:  d alpha_e = <dz_i^h, x_e>,  S = sum_e alpha_e d alpha_e,  dpre_e = alpha_e (d alpha_e - S) leaky'(pre_e),
+//                  d us^h += sum_e dpre_e x_e,   d ud^h += (sum_e dpre_e) x_i
+// One wave per destination row (the forward's lane layout), two sweeps over the row's edges: the first forms every
+// edge's logit and d alpha from the source row as it is read (reduced together, gigl_wave_reduce16) and parks the two
+// scalars per head in edge_scr; the second re-reads the rows (L2 / MALL hits) and accumulates d us.  A wave keeps its
+// d us / d ud sums in registers over all its rows and adds them to `du` once, at the end (fp32 atomics).
+template <typename T, int V, int H>
+__global__ __launch_bounds__(256) void gat_input_backward_kernel(
+    const T* __restrict__ src, int d, const uint32_t* __restrict__ gather_ids, const float* __restrict__ u,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ n_rows_dev, float slope, const float* __restrict__ dz, int64_t head_stride,
+    float* __restrict__ edge_scr, float* __restrict__ du) {
+  constexpr int U = 4;                                  // feature rows in flight per wave
+  constexpr int NV = U * 2 * H, NC = (NV + 15) / 16;    // (logit, d alpha) per head and edge of a group
+  typedef RawRow4<T> RR;
+  typedef typename RR::type raw_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+  const int n_rows = *n_rows_dev;
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto leaky = [&](float v) { return v > 0.f ? v : slope * v; };
+  auto dot4 = [](const float4_t& a, const float4_t& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; };
+  auto lane_value = [](float v, int from) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), from));
+  };
+  int el[V];
+  bool on[V];
+  float4_t us[H][V], acc_s[H][V], acc_d[H][V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    el[v] = (v * 64 + lane) * 4;
+    on[v] = el[v] < d;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      us[h][v] = on[v] ? *reinterpret_cast<const float4_t*>(u + (int64_t)h * d + el[v]) : zero4;
+      acc_s[h][v] = zero4;
+      acc_d[h][v] = zero4;
+    }
+  }
+  for (int i = wave; i < n_rows; i += waves) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    const uint32_t self_gid = gather_ids[i];
+    float4_t xs[V], dzv[H][V];
+    float sd[H], das[H], mx[H], den[H], pre_self[H];
+    {
+      float pv[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pv[k] = 0.f;
+      const T* row = src + (int64_t)self_gid * d;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        xs[v] = on[v] ? RR::f4(RR::load(row, el[v])) : zero4;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          dzv[h][v] = on[v] ? *reinterpret_cast<const float4_t*>(dz + h * head_stride + (int64_t)i * d + el[v]) : zero4;
+          const float4_t udv = on[v] ? *reinterpret_cast<const float4_t*>(u + (int64_t)(H + h) * d + el[v]) : zero4;
+          pv[h] += dot4(xs[v], us[h][v]);
+          pv[H + h] += dot4(xs[v], udv);
+          pv[2 * H + h] += dot4(xs[v], dzv[h][v]);
+        }
+      }
+      const float tot = gigl_wave_reduce16(pv);  // (3H <= 12 values)
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float fs = lane_value(tot, h << 2);
+        sd[h] = lane_value(tot, (H + h) << 2);
+        das[h] = lane_value(tot, (2 * H + h) << 2);
+        pre_self[h] = fs + sd[h];
+        mx[h] = leaky(pre_self[h]);
+        den[h] = 1.f;
+      }
+    }
+    // a row whose dz is all zero adds nothing (padding rows, rows no root depends on): skipped, wave-uniformly
+    {
+      bool nz = false;
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int v = 0; v < V; ++v) nz |= dzv[h][v].x != 0.f || dzv[h][v].y != 0.f || dzv[h][v].z != 0.f || dzv[h][v].w != 0.f;
+      if (__ballot(nz) == 0ull) continue;
+    }
+    // ---- sweep 1: logits and d alpha of every edge -> edge_scr[e][h] = (zl, d alpha); running max / denominator
+    for (int c0 = 0; c0 < m; c0 += 64) {
+      const int mm = min(64, m - c0);
+      uint32_t gid = self_gid;
+      bool take = false;
+      if (lane < mm) {
+        const int j = col[e0 + c0 + lane];
+        take = j != i;
+        gid = gather_ids[j];
+      }
+      const unsigned long long keep = __ballot(take);
+      for (int e = 0; e < mm; e += U) {
+        raw_t x[U][V];
+        bool live[U];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          live[t] = e + t < mm && ((keep >> (e + t)) & 1ull);
+          const T* row = src + (int64_t)__shfl(gid, (e + t) & 63, 64) * d;
+#pragma unroll
+          for (int v = 0; v < V; ++v) x[t][v] = (live[t] && on[v]) ? RR::load(row, el[v]) : RR::zero();
+        }
+        float vals[NC * 16];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+          float pv[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int idx = cc * 16 + k;  // = (t * H + h) * 2 + which
+            float a = 0.f;
+            if (idx < NV) {
+              const int t = idx / (2 * H), h = (idx / 2) % H, which = idx & 1;
+#pragma unroll
+              for (int v = 0; v < V; ++v) a += dot4(RR::f4(x[t][v]), which ? dzv[h][v] : us[h][v]);
+            }
+            pv[k] = a;
+          }
+          const float tot = gigl_wave_reduce16(pv);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) vals[cc * 16 + k] = lane_value(tot, k << 2);
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          if (!live[t]) continue;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const float zl = leaky(vals[(t * H + h) * 2] + sd[h]), da = vals[(t * H + h) * 2 + 1];
+            const float nm = fmaxf(mx[h], zl);
+            den[h] = den[h] * __expf(mx[h] - nm) + __expf(zl - nm);
+            mx[h] = nm;
+            if (lane == 0) {
+              float* sp = edge_scr + ((int64_t)(e0 + c0 + e + t) * H + h) * 2;
+              sp[0] = zl;
+              sp[1] = da;
+            }
+          }
+        }
+      }
+    }
+    // ---- S = sum_e alpha_e d alpha_e (edges: a lane per edge of a chunk; plus the self loop)
+    float inv[H], al_self[H], S[H], dpre_self[H], sum_dpre[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      inv[h] = 1.0f / (den[h] + 1e-16f);
+      al_self[h] = __expf(leaky(pre_self[h]) - mx[h]) * inv[h];
+      S[h] = al_self[h] * das[h];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (lane 0's parked scalars, read below by their lanes)
+    for (int c0 = 0; c0 < m; c0 += 64) {
+      const int mm = min(64, m - c0);
+      const bool mine = lane < mm && col[e0 + c0 + lane] != i;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        float part = 0.f;
+        if (mine) {
+          const float* sp = edge_scr + ((int64_t)(e0 + c0 + lane) * H + h) * 2;
+          part = __expf(sp[0] - mx[h]) * inv[h] * sp[1];
+        }
+        S[h] += wave_sum_dpp(part);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      dpre_self[h] = al_self[h] * (das[h] - S[h]) * (pre_self[h] > 0.f ? 1.f : slope);
+      sum_dpre[h] = dpre_self[h];
+    }
+    // ---- sweep 2: d us += dpre_e x_e
+    for (int c0 = 0; c0 < m; c0 += 64) {
+      const int mm = min(64, m - c0);
+      uint32_t gid = self_gid;
+      bool take = false;
+      if (lane < mm) {
+        const int j = col[e0 + c0 + lane];
+        take = j != i;
+        gid = gather_ids[j];
+      }
+      float dpre[H];
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        dpre[h] = 0.f;
+        if (take) {
+          const float* sp = edge_scr + ((int64_t)(e0 + c0 + lane) * H + h) * 2;
+          const float zl = sp[0];
+          dpre[h] = __expf(zl - mx[h]) * inv[h] * (sp[1] - S[h]) * (zl > 0.f ? 1.f : slope);
+        }
+        sum_dpre[h] += wave_sum_dpp(dpre[h]);
+      }
+      const unsigned long long keep = __ballot(take);
+      for (int e = 0; e < mm; e += U) {
+        raw_t x[U][V];
+        bool live[U];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          live[t] = e + t < mm && ((keep >> (e + t)) & 1ull);
+          const T* row = src + (int64_t)__shfl(gid, (e + t) & 63, 64) * d;
+#pragma unroll
+          for (int v = 0; v < V; ++v) x[t][v] = (live[t] && on[v]) ? RR::load(row, el[v]) : RR::zero();
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          if (!live[t]) continue;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const float dp = __shfl(dpre[h], (e + t) & 63, 64);
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc_s[h][v] += dp * RR::f4(x[t][v]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        acc_s[h][v] += dpre_self[h] * xs[v];
+        acc_d[h][v] += sum_dpre[h] * xs[v];
+      }
+  }
+#pragma unroll
+  for (int h = 0; h < H; ++h)
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      if (!on[v]) continue;
+      float* ps = du + (int64_t)h * d + el[v];
+      float* pd = du + (int64_t)(H + h) * d + el[v];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (acc_s[h][v][q] != 0.f) atomicAdd(ps + q, acc_s[h][v][q]);
+        if (acc_d[h][v][q] != 0.f) atomicAdd(pd + q, acc_d[h][v][q]);
+      }
+    }
 }
 
 // ---- fast GAT path: one wave per row, every lane owns V float4 chunks of the H*C-wide row (chunk q = v*64 + lane
@@ -3577,6 +3815,106 @@ int32_t gigl_gat_input_layer(gigl_ctx* ctx, const void* src, int32_t src_dtype, 
 int64_t gigl_gat_input_layer_fused_scratch(int32_t d, int32_t heads, int64_t rows_cap) {
   const int64_t nkc = (d + 31) / 32, row_tiles = (rows_cap + 127) / 128;
   return (int64_t)heads * row_tiles * nkc * 4096 + (int64_t)2 * heads * d;
+}
+
+// the training path's two halves of that layer: the aggregation alone over folded vectors the caller supplies (plain
+// rows out), and its backward w.r.t. those vectors
+static int32_t gat_input_shape_ok(gigl_ctx* ctx, int32_t d, int32_t heads, int32_t src_dtype, const char* who) {
+  if ((d & 3) || (heads != 1 && heads != 2 && heads != 4) || d > 1024)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "%s: d=%d heads=%d outside the built shapes (d %% 4 == 0, d <= 1024, heads 1|2|4)",
+                     who, d, heads);
+  if (src_dtype != GIGL_DTYPE_F32 && src_dtype != GIGL_DTYPE_F16)
+    return gigl_fail(ctx, GIGL_E_INVALID_ARG, "%s: bad dtype %d", who, src_dtype);
+  return GIGL_OK;
+}
+
+int32_t gigl_gat_input_aggregate(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* gather_ids,
+                                 const float* u, int32_t heads, float negative_slope, const int32_t* rowptr,
+                                 const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap,
+                                 float* z) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, src && gather_ids && u && rowptr && rowend && col && n_rows_dev && z, "null argument");
+  GIGL_REQUIRE(ctx, d > 0 && rows_cap >= 0, "bad sizes");
+  int32_t rc = gat_input_shape_ok(ctx, d, heads, src_dtype, "gigl_gat_input_aggregate");
+  if (rc != GIGL_OK) return rc;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  hipStream_t st = ctx->stream;
+  const int P = (d + 255) / 256, H = heads;
+  const int64_t head_stride = rows_cap * d;
+  const int32_t* n_local_dev = nullptr;
+  const int nkc = 0;
+  const float slope = negative_slope;
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+#define GIGL_GAT_AG(TT, PP, HH)                                                                                        \
+  hipLaunchKernelGGL((gat_input_online_kernel<TT, PP, HH>), dim3((unsigned)blocks), dim3(256), 0, st, (const TT*)src, d, \
+                     gather_ids, n_local_dev, u, rowptr, rowend, col, n_rows_dev, slope, nkc, head_stride, z)
+#define GIGL_GAT_AG_P(TT, HH)                                                                                          \
+  do {                                                                                                                  \
+    if (P == 1) GIGL_GAT_AG(TT, 1, HH);                                                                                \
+    else if (P == 2) GIGL_GAT_AG(TT, 2, HH);                                                                           \
+    else if (P == 3) GIGL_GAT_AG(TT, 3, HH);                                                                           \
+    else GIGL_GAT_AG(TT, 4, HH);                                                                                       \
+  } while (0)
+#define GIGL_GAT_AG_H(TT)                                                                                              \
+  do {                                                                                                                  \
+    if (H == 1) GIGL_GAT_AG_P(TT, 1);                                                                                  \
+    else if (H == 2) GIGL_GAT_AG_P(TT, 2);                                                                             \
+    else GIGL_GAT_AG_P(TT, 4);                                                                                         \
+  } while (0)
+  if (src_dtype == GIGL_DTYPE_F32) GIGL_GAT_AG_H(float);
+  else GIGL_GAT_AG_H(__half);
+#undef GIGL_GAT_AG_H
+#undef GIGL_GAT_AG_P
+#undef GIGL_GAT_AG
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_gat_input_aggregate_backward(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
+                                          const uint32_t* gather_ids, const float* u, int32_t heads, float negative_slope,
+                                          const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                          const int32_t* n_rows_dev, int64_t rows_cap, const float* dz, float* edge_scratch,
+                                          float* du) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, src && gather_ids && u && rowptr && rowend && col && n_rows_dev && dz && edge_scratch && du, "null argument");
+  GIGL_REQUIRE(ctx, d > 0 && rows_cap >= 0, "bad sizes");
+  int32_t rc = gat_input_shape_ok(ctx, d, heads, src_dtype, "gigl_gat_input_aggregate_backward");
+  if (rc != GIGL_OK) return rc;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (rows_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_BWD);
+  hipStream_t st = ctx->stream;
+  const int P = (d + 255) / 256, H = heads;
+  const int64_t head_stride = rows_cap * d;
+  const float slope = negative_slope;
+  int64_t blocks = (rows_cap + 3) / 4;
+  if (blocks > 256 * 8) blocks = 256 * 8;
+#define GIGL_GAT_BW(TT, PP, HH)                                                                                        \
+  hipLaunchKernelGGL((gat_input_backward_kernel<TT, PP, HH>), dim3((unsigned)blocks), dim3(256), 0, st, (const TT*)src, d, \
+                     gather_ids, u, rowptr, rowend, col, n_rows_dev, slope, dz, head_stride, edge_scratch, du)
+#define GIGL_GAT_BW_P(TT, HH)                                                                                          \
+  do {                                                                                                                  \
+    if (P == 1) GIGL_GAT_BW(TT, 1, HH);                                                                                \
+    else if (P == 2) GIGL_GAT_BW(TT, 2, HH);                                                                           \
+    else if (P == 3) GIGL_GAT_BW(TT, 3, HH);                                                                           \
+    else GIGL_GAT_BW(TT, 4, HH);                                                                                       \
+  } while (0)
+#define GIGL_GAT_BW_H(TT)                                                                                              \
+  do {                                                                                                                  \
+    if (H == 1) GIGL_GAT_BW_P(TT, 1);                                                                                  \
+    else if (H == 2) GIGL_GAT_BW_P(TT, 2);                                                                             \
+    else GIGL_GAT_BW_P(TT, 4);                                                                                         \
+  } while (0)
+  if (src_dtype == GIGL_DTYPE_F32) GIGL_GAT_BW_H(float);
+  else GIGL_GAT_BW_H(__half);
+#undef GIGL_GAT_BW_H
+#undef GIGL_GAT_BW_P
+#undef GIGL_GAT_BW
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
 }
 
 int32_t gigl_gat_input_layer_fused(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,

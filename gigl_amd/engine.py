@@ -915,6 +915,34 @@ class HipEngine:
             p(dd), p(dae), p(u_msg), p(z)), self._ctx)
         return dh, ds, dd, dae, z
 
+    def gat_input_aggregate(self, u_fold: torch.Tensor, heads: int, rowptr: torch.Tensor, rowend: torch.Tensor,
+                            col: torch.Tensor, node_ids: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int,
+                            negative_slope: float = 0.2) -> torch.Tensor:
+        """z [heads, rows_cap, d]: the attention-weighted sums of the stored rows for the first rows_cap rows of a staged
+        batch graph (gigl_gat_input_aggregate; u_fold [2*heads, d] = the folded attention vectors)"""
+        d = self.feat_dim
+        assert u_fold.is_cuda and u_fold.is_contiguous() and tuple(u_fold.shape) == (2 * heads, d)
+        z = torch.empty((heads, rows_cap, d), dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(self._lib.gigl_gat_input_aggregate(self._ctx, self._feat_ptr, self.feat_dtype, d, p(node_ids), p(u_fold), heads,
+                                                 negative_slope, p(rowptr), p(rowend), p(col), p(n_rows_dev), rows_cap,
+                                                 p(z)), self._ctx)
+        return z
+
+    def gat_input_aggregate_backward(self, u_fold: torch.Tensor, heads: int, rowptr: torch.Tensor, rowend: torch.Tensor,
+                                     col: torch.Tensor, node_ids: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int,
+                                     dz: torch.Tensor, negative_slope: float = 0.2) -> torch.Tensor:
+        """du [2*heads, d] = the gradient of gat_input_aggregate w.r.t. the folded vectors, given dz [heads, rows_cap, d]"""
+        d = self.feat_dim
+        assert dz.is_cuda and dz.is_contiguous() and tuple(dz.shape) == (heads, rows_cap, d) and dz.dtype == torch.float32
+        du = torch.zeros((2 * heads, d), dtype=torch.float32, device=self.device)
+        scr = torch.empty(2 * heads * max(int(col.numel()), 1), dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(self._lib.gigl_gat_input_aggregate_backward(self._ctx, self._feat_ptr, self.feat_dtype, d, p(node_ids),
+                                                          p(u_fold), heads, negative_slope, p(rowptr), p(rowend), p(col),
+                                                          p(n_rows_dev), rows_cap, p(dz), p(scr), p(du)), self._ctx)
+        return du
+
     def gat_backward_epilogue(self, dh: torch.Tensor, ds: torch.Tensor, dd: torch.Tensor, xw: torch.Tensor,
                               att_src: torch.Tensor, att_dst: torch.Tensor, heads: int, channels: int,
                               n_nodes_dev: torch.Tensor):

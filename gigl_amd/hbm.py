@@ -476,6 +476,7 @@ class ResidentGraph:
                                    "(meta[GIGL_META_OVERFLOW]); raise hop_slack / pull_cap")
             n, e = int(m[0]), int(m[1])
             rowptr, rowend, col, root_local, x = t["rowptr"], t["rowend"], t["col"], t["root_local"], t["x"][:n]
+            node_ids = levels = None  # (the rows were pulled from their owners: no resident table to read in place)
         else:
             tree = eng.sample_khop(roots, self.fanouts, sampling_seed=self.seed, mode=self.mode)
             u = eng.union_build(tree)
@@ -483,6 +484,7 @@ class ResidentGraph:
             n, e = int(c["n_nodes"]), int(c["n_edges"])
             rowptr, rowend, col, root_local = u.rowptr, u.rowend, u.col, u.root_local
             x = eng.gather_rows(u.nodes, u.meta[:1], n)
+            node_ids, levels = u.nodes[:n], [int(v) for v in c["levels"]]
         rp, re = rowptr[:n].to(torch.int64), rowend[:n].to(torch.int64)
         lens = re - rp
         start = torch.cumsum(lens, 0) - lens
@@ -501,6 +503,8 @@ class ResidentGraph:
         g.col = src.to(torch.int32).contiguous() if e else torch.zeros(1, dtype=torch.int32, device=dev)
         g.n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
         g.edge_attr_csr = ea
+        if node_ids is not None and getattr(eng, "_feat", None) is not None:
+            g.node_ids, g.table, g.levels = node_ids, eng, levels
         return g, root_local[:n_real].to(torch.int64)
 
     def _staged_plan(self, b: int):

@@ -144,7 +144,9 @@ class _GatConvFn(torch.autograd.Function):
     def forward(ctx, x, w, att_src, att_dst, bias, v_att, w_msg, eng, view, n_dev, heads, channels, slope, edge_attr):
         n = int(x.shape[0])
         x = x.contiguous()
-        xw = eng.linear(x, w.contiguous(), None, n_dev, n, act=0)
+        # (view.meta = the number of SOURCE rows, n_dev = the rows to compute: the same for a whole batch graph, fewer
+        # destination rows when only the first levels of a level-ordered graph are needed)
+        xw = eng.linear(x, w.contiguous(), None, view.meta, n, act=0)
         kw = {} if edge_attr is None else dict(edge_attr=edge_attr, att_edge_folded=v_att.contiguous(),
                                                w_edge_msg=w_msg.contiguous() if w_msg is not None else None)
         out = eng.gat_aggregate(xw, att_src.reshape(-1).contiguous(), att_dst.reshape(-1).contiguous(), heads, channels,
@@ -173,7 +175,7 @@ class _GatConvFn(torch.autograd.Function):
         if z is not None:
             dw_msg = torch.einsum("nhc,nhk->hck", dy.view(n, heads, ch), z).reshape(hc, -1)
         if hc <= 1024:  # one pass over the projected rows (gigl_gat_backward_epilogue), dh updated in place
-            dxw, g_s, g_d = eng.gat_backward_epilogue(dh, ds, dd, xw, att_src, att_dst, heads, ch, n_dev)
+            dxw, g_s, g_d = eng.gat_backward_epilogue(dh, ds, dd, xw, att_src, att_dst, heads, ch, view.meta)
             d_att_src, d_att_dst = g_s.view_as(att_src), g_d.view_as(att_dst)
         else:
             xw3 = xw.view(n, heads, ch)
@@ -183,11 +185,34 @@ class _GatConvFn(torch.autograd.Function):
                    + dd.unsqueeze(-1) * att_dst.view(1, heads, ch)).reshape(n, hc).contiguous()
         dev = dy.device
         n_out = dev_i32(dev, hc)
-        dw, _ = eng.linear_weight_grad(dxw, x, n_dev)                                       # dW = dxw^T x
-        dx = eng.linear(dxw, w.t().contiguous(), None, n_dev, n, 0) if ctx.needs_input_grad[0] else None
+        dw, _ = eng.linear_weight_grad(dxw, x, view.meta)                                   # dW = dxw^T x
+        dx = eng.linear(dxw, w.t().contiguous(), None, view.meta, n, 0) if ctx.needs_input_grad[0] else None
         db = dy.sum(0) if bias.numel() else None
         dv = dae.t().mm(edge_attr) if dae is not None else None
         return dx, dw, d_att_src, d_att_dst, db, dv, dw_msg, None, None, None, None, None, None, None
+
+
+class _GatInputAggFn(torch.autograd.Function):
+    """z [H, rows, d] = the attention-weighted sums of the STORED feature rows for the first `rows` nodes of a batch graph
+    built in HBM, as a function of the folded attention vectors u [2H, d] (gigl_gat_input_aggregate + its backward); the
+    rows are inputs: no gradient"""
+
+    @staticmethod
+    def forward(ctx, u, table, g, n_rows_dev, rows, heads, slope):
+        u = u.contiguous()
+        z = table.gat_input_aggregate(u, heads, g.rowptr, g.rowptr[1:], g.col, g.node_ids, n_rows_dev, rows, slope)
+        ctx.table, ctx.g, ctx.n_rows_dev, ctx.dims = table, g, n_rows_dev, (rows, heads, slope)
+        ctx.save_for_backward(u)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (u,) = ctx.saved_tensors
+        rows, heads, slope = ctx.dims
+        g = ctx.g
+        du = ctx.table.gat_input_aggregate_backward(u, heads, g.rowptr, g.rowptr[1:], g.col, g.node_ids, ctx.n_rows_dev,
+                                                    rows, dz.contiguous(), slope)
+        return du, None, None, None, None, None, None
 
 
 class GATConv(nn.Module):
@@ -375,6 +400,8 @@ class GAT(nn.Module):
         h = g.x.contiguous()
         # autograd path: grad mode on, module in training mode (model.eval() or torch.no_grad() select inference)
         train = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
+        if train and edge_attr is None and self._input_side_training_applies(g):
+            return self._forward_graph_input_side(g, eng)
         for l, conv in enumerate(self.conv_layers):
             if not train:
                 with torch.no_grad():
@@ -393,6 +420,50 @@ class GAT(nn.Module):
         return h
 
 
+def _gat_input_side_training_applies(self, g) -> bool:
+    """a two-layer GAT over a batch built in HBM (level-ordered nodes, the feature table at hand) whose stored rows are
+    wider than the first layer's output: the first layer can run from the input side for the rows the second reads"""
+    if not self.input_side_first_layer or self.num_layers != 2 or g.table is None or g.levels is None or \
+            g.node_ids is None or len(g.levels) != 3:
+        return False
+    c0 = self.conv_layers[0]
+    d = int(getattr(g.table, "feat_dim", 0))
+    return (c0.concat and c0.edge_dim is None and d == c0.in_channels and d > c0.heads * c0.out_channels and d % 4 == 0
+            and d <= 1024 and c0.heads in (1, 2, 4) and self.conv_layers[1].edge_dim is None)
+
+
+def _gat_forward_graph_input_side(self, g, eng) -> torch.Tensor:
+    """training forward over a batch built in HBM, the work cut to what the roots' rows depend on:
+    layer 0 for the nodes of level <= 1 only, from the INPUT side — attention-weighted sums of the stored rows
+    (_GatInputAggFn: every edge's logit <x_j, W_h^T att_h> formed from the row as it is read), then one projection per head
+    over those sums — instead of projecting every source row of the batch graph first; layer 1 for the roots only.
+    The same function of the parameters as the whole-graph forward (rows of the roots; 1e-5), a fraction of its work:
+    the batch graph of 1,024 anchors has ~330 k nodes, ~53 k of level <= 1."""
+    n0, n1, n = (int(v) for v in g.levels)
+    dev = g.x.device
+    c0, c1 = self.conv_layers
+    H, C, d = c0.heads, c0.out_channels, c0.in_channels
+    n1_dev = torch.tensor([n1], dtype=torch.int32, device=dev)
+    n0_dev = torch.tensor([n0], dtype=torch.int32, device=dev)
+    w3 = c0.lin.weight.view(H, C, d)
+    u = torch.cat([torch.einsum("hcd,hc->hd", w3, c0.att_src.view(H, C)),
+                   torch.einsum("hcd,hc->hd", w3, c0.att_dst.view(H, C))]).contiguous()      # [2H, d], differentiable
+    z = _GatInputAggFn.apply(u, g.table, g, n1_dev, n1, H, c0.negative_slope)                  # [H, n1, d]
+    h = torch.cat([_LinearFn.apply(z[k], w3[k], eng, n1_dev) for k in range(H)], dim=1)       # [n1, H*C]
+    if c0.bias is not None:
+        h = h + c0.bias
+    h = torch.relu(h)
+    view = _CsrView(g)
+    view.meta, view.nodes = n1_dev, g.rowptr[1:n1 + 1]  # (sources: the n1 rows of h; only the length of `nodes` is read)
+    h = _GatConvFn.apply(h, c1.lin.weight, c1.att_src, c1.att_dst, c1.bias, None, None, eng, view, n0_dev, c1.heads,
+                         c1.out_channels, c1.negative_slope, None)[:n0]
+    if self.activation_after_last_conv:
+        h = torch.relu(h)
+    if self.should_l2_normalize_embedding_layer_output:
+        h = torch.nn.functional.normalize(h, p=2, dim=1)
+    return h
+
+
 class _CsrView:
     """the CSR of a coalesced GraphData in the shape gat_aggregate reads from a UnionGraph"""
 
@@ -400,3 +471,7 @@ class _CsrView:
         self.rowptr, self.rowend, self.col = g.rowptr, g.rowptr[1:], g.col
         self.meta = g.n_dev           # meta[0] = number of nodes
         self.nodes = g.rowptr[1:]     # only its length (= node capacity) is read
+
+
+GAT._input_side_training_applies = _gat_input_side_training_applies
+GAT._forward_graph_input_side = _gat_forward_graph_input_side

@@ -30,6 +30,12 @@ class GraphData:
     n_dev: Optional[torch.Tensor] = None   # int32 [1] = n (device-side row count for the kernels)
     edge_attr: Optional[torch.Tensor] = None      # [E, De] fp32 in edge_index order (PyG Data.edge_attr)
     edge_attr_csr: Optional[torch.Tensor] = None  # the same rows in `col` order
+    # batches built in HBM (hbm.ResidentGraph.graph_data) also say where their rows came from: the nodes' global ids, the
+    # engine that holds the resident feature table, and the number of nodes of level <= k (level-ordered union graph) —
+    # what an encoder needs to read stored rows in place and to compute a layer only for the rows the next one reads
+    node_ids: Optional[torch.Tensor] = None       # int32 [n] (uint32 global ids)
+    table: Optional[object] = None                # engine.HipEngine with the feature table
+    levels: Optional[list] = None                 # host ints, levels[k] = nodes of level <= k; levels[-1] = n
 
     @property
     def num_nodes(self) -> int:

@@ -763,6 +763,28 @@ int32_t gigl_gat_input_layer(gigl_ctx* ctx, const void* src, int32_t src_dtype, 
                              const int32_t* n_rows_dev, int64_t rows_cap, const float* bias, int32_t act,
                              float* scratch, float* out);
 
+/* TRAINING over in-HBM batches: the aggregation half of that layer and its backward.  u [2*heads][d] (DEVICE fp32) holds
+ * the folded vectors: u[h] = W_h^T att_src_h, u[heads + h] = W_h^T att_dst_h (the caller folds them — a small
+ * differentiable product — and projects the aggregated rows itself: out_h = z_h W_h^T, gigl_linear /
+ * gigl_linear_weight_grad).
+ *   gigl_gat_input_aggregate           z[h][i][0:d] = sum_e alpha_e^h x_e over row i's in-edges and its self loop
+ *                                      (z: DEVICE fp32 [heads][rows_cap][d], plain rows), alpha the layer's attention
+ *   gigl_gat_input_aggregate_backward  given dz (same shape): du[0:heads] += d u_src, du[heads:2 heads] += d u_dst
+ *                                      (du [2*heads][d] is ADDED to: zero it first; fp32 atomics).  The feature rows are
+ *                                      inputs: no gradient.  edge_scratch: DEVICE fp32 [2 * heads * cap_edges].
+ * Every `col` entry is a local id translated through gather_ids (all rows numbered: a staged union graph).  Rows whose
+ * dz is all zero are skipped.  PyG's autograd of GATConv reaches the same gradients through x W first; this order reads
+ * each d-wide stored row per edge instead of projecting every source row (python/gigl/src/common/models/pyg/
+ * homogeneous.py:300-343 under node_anchor_based_link_prediction_modeling_task_spec.py:334-451). */
+int32_t gigl_gat_input_aggregate(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d, const uint32_t* gather_ids,
+                                 const float* u, int32_t heads, float negative_slope, const int32_t* rowptr,
+                                 const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap,
+                                 float* z);
+int32_t gigl_gat_input_aggregate_backward(gigl_ctx* ctx, const void* src, int32_t src_dtype, int32_t d,
+                                          const uint32_t* gather_ids, const float* u, int32_t heads, float negative_slope,
+                                          const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                          const int32_t* n_rows_dev, int64_t rows_cap, const float* dz,
+                                          float* edge_scratch, float* du);
 /* gigl_gat_input_layer in ONE pass over the destination rows (the one-call plan's first GAT layer): every edge's logit is
  * formed from the feature row as it is read for the aggregation (online softmax), so the sources need no dense
  * numbering: rows >= *n_local_dev hold GLOBAL source ids in `col` (the leaf-global union of gigl_sage_plan), rows below

@@ -362,3 +362,52 @@ def test_gat_one_call_plan_matches_the_staged_forward(d, dtype, heads, hid, fan,
             eng.bind_stream(None)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("d,dtype,heads,hid", [(768, np.float16, 2, 128), (320, np.float16, 4, 32), (260, np.float32, 2, 16),
+                                               (128, np.float16, 1, 32)])
+def test_gat_training_from_the_input_side_equals_the_whole_graph_autograd(d, dtype, heads, hid):
+    """training over a batch built in HBM (hbm.ResidentGraph.graph_data: level-ordered nodes + the resident table): the
+    first layer computed from the input side for the nodes of level <= 1 only and the second for the roots only
+    (gigl_gat_input_aggregate + its backward) — the same root rows and the same parameter gradients as autograd through
+    every layer over the whole batch graph (which test_gat_training_gradients_match_torch_autograd pins on the CPU
+    restatement)"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.hbm import ResidentGraph
+    from gigl_amd.models_attn import GAT
+    s, t = rmat_edges(11, 30000, seed=5)
+    n = 1 << 11
+    rowptr, col = oracle.build_csc(n, s, t, is_directed=True)
+    x = (np.random.default_rng(d).standard_normal((n, d)) / 4).astype(dtype)
+    eng, meng = HipEngine(0), HipEngine(0)
+    try:
+        eng.load_csc(rowptr, col)
+        eng.load_features(torch.from_numpy(x) if dtype == np.float16 else x)
+        res = ResidentGraph.from_engine(eng, np.arange(n), [9, 6])
+        torch.manual_seed(d)
+        model = GAT(d, hid, 32, num_layers=2, heads=heads, should_l2_normalize_embedding_layer_output=True).to(eng.device)
+        with torch.no_grad():
+            for c in model.conv_layers:
+                c.bias.normal_(0, 0.1)
+        model.engine = meng
+        model.train()
+        roots = np.random.default_rng(3).integers(0, n, size=300).astype(np.uint32)
+        roots[7] = roots[2]  # a repeated root
+        g, ri = res.graph_data(torch.from_numpy(roots.view(np.int32)).to(eng.device))
+        assert g.table is eng and g.levels[-1] == g.num_nodes and model._input_side_training_applies(g)
+        tgt = torch.from_numpy(np.random.default_rng(9).standard_normal((300, 32)).astype(np.float32)).to(eng.device)
+        runs = {}
+        for side in (True, False):
+            model.input_side_first_layer = side
+            model.zero_grad(set_to_none=True)
+            out = model(g)[ri]
+            loss = ((out - tgt) ** 2).sum()
+            loss.backward()
+            runs[side] = (out.detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()})
+        np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=2e-5, atol=2e-5)
+        for k, gr in runs[False][1].items():
+            scale = max(float(np.abs(gr).max()), 1e-6)
+            np.testing.assert_allclose(runs[True][1][k], gr, rtol=2e-3, atol=2e-4 * scale, err_msg=k)
+    finally:
+        meng.close()
+        eng.close()
