@@ -364,9 +364,11 @@ def test_gat_one_call_plan_matches_the_staged_forward(d, dtype, heads, hid, fan,
         eng.close()
 
 
-@pytest.mark.parametrize("d,dtype,heads,hid", [(768, np.float16, 2, 128), (320, np.float16, 4, 32), (260, np.float32, 2, 16),
-                                               (128, np.float16, 1, 32)])
-def test_gat_training_from_the_input_side_equals_the_whole_graph_autograd(d, dtype, heads, hid):
+@pytest.mark.parametrize("d,dtype,heads,hid,fanouts", [(768, np.float16, 2, 128, [9, 6]), (320, np.float16, 4, 32, [9, 6]),
+                                                       (260, np.float32, 2, 16, [9, 6]), (128, np.float16, 1, 32, [9, 6]),
+                                                       # (rows of more than 64 in-edges: several chunks per row)
+                                                       (256, np.float16, 2, 32, [90, 3])])
+def test_gat_training_from_the_input_side_equals_the_whole_graph_autograd(d, dtype, heads, hid, fanouts):
     """training over a batch built in HBM (hbm.ResidentGraph.graph_data: level-ordered nodes + the resident table): the
     first layer computed from the input side for the nodes of level <= 1 only and the second for the roots only
     (gigl_gat_input_aggregate + its backward) — the same root rows and the same parameter gradients as autograd through
@@ -375,7 +377,7 @@ def test_gat_training_from_the_input_side_equals_the_whole_graph_autograd(d, dty
     from gigl_amd.engine import HipEngine
     from gigl_amd.hbm import ResidentGraph
     from gigl_amd.models_attn import GAT
-    s, t = rmat_edges(11, 30000, seed=5)
+    s, t = rmat_edges(11, 30000 if fanouts[0] < 64 else 200000, seed=5)
     n = 1 << 11
     rowptr, col = oracle.build_csc(n, s, t, is_directed=True)
     x = (np.random.default_rng(d).standard_normal((n, d)) / 4).astype(dtype)
@@ -383,7 +385,7 @@ def test_gat_training_from_the_input_side_equals_the_whole_graph_autograd(d, dty
     try:
         eng.load_csc(rowptr, col)
         eng.load_features(torch.from_numpy(x) if dtype == np.float16 else x)
-        res = ResidentGraph.from_engine(eng, np.arange(n), [9, 6])
+        res = ResidentGraph.from_engine(eng, np.arange(n), fanouts)
         torch.manual_seed(d)
         model = GAT(d, hid, 32, num_layers=2, heads=heads, should_l2_normalize_embedding_layer_output=True).to(eng.device)
         with torch.no_grad():
@@ -395,6 +397,8 @@ def test_gat_training_from_the_input_side_equals_the_whole_graph_autograd(d, dty
         roots[7] = roots[2]  # a repeated root
         g, ri = res.graph_data(torch.from_numpy(roots.view(np.int32)).to(eng.device))
         assert g.table is eng and g.levels[-1] == g.num_nodes and model._input_side_training_applies(g)
+        if fanouts[0] > 64:
+            assert int((g.rowptr[1:] - g.rowptr[:-1]).max()) > 64
         tgt = torch.from_numpy(np.random.default_rng(9).standard_normal((300, 32)).astype(np.float32)).to(eng.device)
         runs = {}
         for side in (True, False):
