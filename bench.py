@@ -2554,6 +2554,7 @@ def run_gat_lp_train(args, rank, world, local_rank):
     eng.bind_stream(st)
     resident = ResidentGraph.from_engine(eng, np.arange(n, dtype=np.int64), fanouts)
     resident.train_as_graph_data = True  # (GAT trains over a PyG-shaped batch: hbm.encoder_trains_over_hip_batches)
+    resident.defer_x = True              # (... whose first layer reads the stored rows in place: no dense x per batch)
     setup_s = time.time() - t0
     main_it = resident.nablp_batches(anchors, np.ones(anchors.size, dtype=np.int64), B, 1, loop=True)
 

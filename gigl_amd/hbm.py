@@ -448,6 +448,7 @@ class ResidentGraph:
     # encoders without an autograd forward over HipBatches (GAT, GCN, GIN, Transformer, GraphSAGE with batch norm / JK ...)
     # train over the same in-HBM batch as a GraphData built on the device (set by the task specs)
     train_as_graph_data: bool = False
+    defer_x: bool = False  # graph_data leaves the dense feature matrix out (GraphData.x_fn builds it on demand)
 
     def graph_data(self, roots: torch.Tensor, pad_to: Optional[int] = None):
         """the batch of `roots` (int32 device ids) as a nn.GraphData on the device — x = the union nodes' feature rows,
@@ -483,8 +484,11 @@ class ResidentGraph:
             c = u.counts()  # (raises when the batch did not fit its workspace)
             n, e = int(c["n_nodes"]), int(c["n_edges"])
             rowptr, rowend, col, root_local = u.rowptr, u.rowend, u.col, u.root_local
-            x = eng.gather_rows(u.nodes, u.meta[:1], n)
             node_ids, levels = u.nodes[:n], [int(v) for v in c["levels"]]
+            # (defer_x: the consumer reads the stored rows in place — models_attn.GAT's input-side training forward — and
+            # asks for the dense matrix only if it falls back: GraphData.features())
+            x_fn = (lambda nodes=u.nodes, cnt=u.meta[:1], n=n: eng.gather_rows(nodes, cnt, n))
+            x = None if self.defer_x else x_fn()
         rp, re = rowptr[:n].to(torch.int64), rowend[:n].to(torch.int64)
         lens = re - rp
         start = torch.cumsum(lens, 0) - lens
@@ -495,6 +499,8 @@ class ResidentGraph:
         if not self.sharded and getattr(eng, "_efeat", None) is not None:
             ea = eng.union_edge_attr(u).index_select(0, idx)
         g = GraphData(x=x, edge_index=torch.stack([src, dst]), edge_attr=ea)
+        if x is None:
+            g.x_fn = x_fn
         # the CSR by destination the kernels read IS the union graph's (rows ascending, a row's sources ascending: the
         # order GraphData._build_csr sorts into) — packed here, not rebuilt by a sort of the edge list
         rp = torch.zeros(n + 1, dtype=torch.int32, device=dev)

@@ -396,12 +396,12 @@ class GAT(nn.Module):
             edge_attr = g.edge_attr_csr
             assert edge_attr.shape[1] == self.edge_dim
             if edge_attr.shape[0] != view.col.numel():  # edgeless batch: col holds one padding entry
-                edge_attr = torch.zeros((view.col.numel(), self.edge_dim), dtype=torch.float32, device=g.x.device)
-        h = g.x.contiguous()
+                edge_attr = torch.zeros((view.col.numel(), self.edge_dim), dtype=torch.float32, device=g.rowptr.device)
         # autograd path: grad mode on, module in training mode (model.eval() or torch.no_grad() select inference)
         train = torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())
         if train and edge_attr is None and self._input_side_training_applies(g):
             return self._forward_graph_input_side(g, eng)
+        h = g.features().contiguous()
         for l, conv in enumerate(self.conv_layers):
             if not train:
                 with torch.no_grad():
@@ -440,7 +440,7 @@ def _gat_forward_graph_input_side(self, g, eng) -> torch.Tensor:
     The same function of the parameters as the whole-graph forward (rows of the roots; 1e-5), a fraction of its work:
     the batch graph of 1,024 anchors has ~330 k nodes, ~53 k of level <= 1."""
     n0, n1, n = (int(v) for v in g.levels)
-    dev = g.x.device
+    dev = g.rowptr.device
     c0, c1 = self.conv_layers
     H, C, d = c0.heads, c0.out_channels, c0.in_channels
     n1_dev = torch.tensor([n1], dtype=torch.int32, device=dev)

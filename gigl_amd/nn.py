@@ -36,10 +36,18 @@ class GraphData:
     node_ids: Optional[torch.Tensor] = None       # int32 [n] (uint32 global ids)
     table: Optional[object] = None                # engine.HipEngine with the feature table
     levels: Optional[list] = None                 # host ints, levels[k] = nodes of level <= k; levels[-1] = n
+    x_fn: Optional[object] = None                 # () -> x, when x was left out (see features())
 
     @property
     def num_nodes(self) -> int:
-        return int(self.x.shape[0])
+        return int(self.x.shape[0]) if self.x is not None else int(self.rowptr.numel()) - 1
+
+    def features(self) -> torch.Tensor:
+        """x — gathered now when the batch was built without it (x_fn: batches whose consumer reads the stored rows in
+        place and asks for the dense matrix only when it falls back to a whole-graph forward)"""
+        if self.x is None:
+            self.x = self.x_fn()
+        return self.x
 
     @property
     def num_edges(self) -> int:
@@ -47,7 +55,7 @@ class GraphData:
 
     def to(self, device) -> "GraphData":
         device = torch.device(device)
-        if self.rowptr is not None and self.x.device == device and self.x.dtype == torch.float32:
+        if self.rowptr is not None and (self.x is None or (self.x.device == device and self.x.dtype == torch.float32)):
             return self  # (already resident with its CSR: batches built in HBM)
         x = self.x.to(device=device, dtype=torch.float32).contiguous()
         ei = self.edge_index.to(device)
