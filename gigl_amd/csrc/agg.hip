@@ -1940,7 +1940,8 @@ __global__ __launch_bounds__(256) void gat_input_backward_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ col,
     const int32_t* __restrict__ n_rows_dev, float slope, const float* __restrict__ dz, int64_t head_stride,
     float* __restrict__ edge_scr, float* __restrict__ du) {
-  constexpr int U = 4;                                  // feature rows in flight per wave
+  constexpr int U = 4;                                  // feature rows in flight per wave (first sweep)
+  constexpr int U2 = (V * H * (sizeof(T) == 2 ? 2 : 4) > 12) ? 4 : 8;  // ... second sweep (no logits to hold)
   constexpr int NV = U * 2 * H, NC = (NV + 15) / 16;    // (logit, d alpha) per head and edge of a group
   typedef RawRow4<T> RR;
   typedef typename RR::type raw_t;
@@ -2117,22 +2118,22 @@ __global__ __launch_bounds__(256) void gat_input_backward_kernel(
         sum_dpre[h] += wave_sum_dpp(dpre[h]);
       }
       const unsigned long long keep = __ballot(take);
-      for (int e = 0; e < mm; e += U) {
-        raw_t x[U][V];
-        bool live[U];
+      for (int e = 0; e < mm; e += U2) {
+        raw_t x[U2][V];
+        bool live[U2];
 #pragma unroll
-        for (int t = 0; t < U; ++t) {
+        for (int t = 0; t < U2; ++t) {
           live[t] = e + t < mm && ((keep >> (e + t)) & 1ull);
           const T* row = src + (int64_t)__shfl(gid, (e + t) & 63, 64) * d;
 #pragma unroll
           for (int v = 0; v < V; ++v) x[t][v] = (live[t] && on[v]) ? RR::load(row, el[v]) : RR::zero();
         }
 #pragma unroll
-        for (int t = 0; t < U; ++t) {
+        for (int t = 0; t < U2; ++t) {
           if (!live[t]) continue;
 #pragma unroll
           for (int h = 0; h < H; ++h) {
-            const float dp = __shfl(dpre[h], (e + t) & 63, 64);
+            const float dp = lane_value(dpre[h], (e + t) & 63);  // (a uniform lane: v_readlane, not an LDS permute)
 #pragma unroll
             for (int v = 0; v < V; ++v) acc_s[h][v] += dp * RR::f4(x[t][v]);
           }
@@ -2147,18 +2148,35 @@ __global__ __launch_bounds__(256) void gat_input_backward_kernel(
         acc_d[h][v] += sum_dpre[h] * xs[v];
       }
   }
+  // the workgroup's four waves add their sums in LDS first, in wave order, and one wave adds the total to `du`: every
+  // atomic lands on one of only 2 H d addresses, so their number — (workgroups) x 2 H d — is what this tail costs
+  __shared__ float4_t s_red[2 * H * V * 64];
+  const int wv = threadIdx.x >> 6;
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
 #pragma unroll
-  for (int h = 0; h < H; ++h)
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float4_t& rs = s_red[(h * V + v) * 64 + lane];
+          float4_t& rd = s_red[((H + h) * V + v) * 64 + lane];
+          rs = w == 0 ? acc_s[h][v] : rs + acc_s[h][v];
+          rd = w == 0 ? acc_d[h][v] : rd + acc_d[h][v];
+        }
+    }
+    __syncthreads();
+  }
+  if (wv != 0) return;
+#pragma unroll
+  for (int h = 0; h < 2 * H; ++h)
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       if (!on[v]) continue;
-      float* ps = du + (int64_t)h * d + el[v];
-      float* pd = du + (int64_t)(H + h) * d + el[v];
+      const float4_t t = s_red[(h * V + v) * 64 + lane];
+      float* pu = du + (int64_t)h * d + el[v];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (acc_s[h][v][q] != 0.f) atomicAdd(ps + q, acc_s[h][v][q]);
-        if (acc_d[h][v][q] != 0.f) atomicAdd(pd + q, acc_d[h][v][q]);
-      }
+      for (int q = 0; q < 4; ++q)
+        if (t[q] != 0.f) atomicAdd(pu + q, t[q]);
     }
 }
 
@@ -3278,7 +3296,7 @@ int32_t gigl_gat_backward_epilogue(gigl_ctx* ctx, float* dh, const float* ds, co
   if (nodes_cap == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_BWD);
   const int hc = heads * channels, threads = (hc + 63) / 64 * 64;
-  int64_t blocks = nodes_cap < 2048 ? nodes_cap : 2048;
+  int64_t blocks = nodes_cap < 512 ? nodes_cap : 512;  // (every workgroup ends with 2 H C atomics on the same 2 H C addresses)
   hipLaunchKernelGGL(gat_backward_epilogue_kernel, dim3((unsigned)blocks), dim3((unsigned)threads), 0, ctx->stream, dh, ds, dd,
                      xw, att_src, att_dst, n_nodes_dev, heads, channels, d_att_src, d_att_dst);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
@@ -3891,7 +3909,7 @@ int32_t gigl_gat_input_aggregate_backward(gigl_ctx* ctx, const void* src, int32_
   const int64_t head_stride = rows_cap * d;
   const float slope = negative_slope;
   int64_t blocks = (rows_cap + 3) / 4;
-  if (blocks > 256 * 8) blocks = 256 * 8;
+  if (blocks > 256 * 2) blocks = 256 * 2;  // (two workgroups per CU fill its registers; fewer workgroups = fewer final atomics)
 #define GIGL_GAT_BW(TT, PP, HH)                                                                                        \
   hipLaunchKernelGGL((gat_input_backward_kernel<TT, PP, HH>), dim3((unsigned)blocks), dim3(256), 0, st, (const TT*)src, d, \
                      gather_ids, u, rowptr, rowend, col, n_rows_dev, slope, dz, head_stride, edge_scratch, du)
