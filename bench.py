@@ -2548,7 +2548,9 @@ def run_gat_lp_train(args, rank, world, local_rank):
     pick = torch.randint(0, cand.numel(), (pool * B,), generator=gp).to(dev)
     anchors = cand[pick].cpu().numpy().astype(np.int64)
     del cand, pick, w_["has_out"]
-    negs = torch.randint(0, n, (pool, n_neg), generator=gp).to(torch.int32).to(dev)
+    negs_cpu = torch.randint(0, n, (pool, n_neg), generator=gp)
+    negs_host = negs_cpu.numpy().astype(np.int64)  # (the ids as the random-negative stream hands them out: host arrays)
+    negs = negs_cpu.to(torch.int32).to(dev)
     torch.cuda.synchronize()
     st = torch.cuda.Stream(device=dev)
     eng.bind_stream(st)
@@ -2562,8 +2564,7 @@ def run_gat_lp_train(args, rank, world, local_rank):
         with torch.cuda.stream(st):
             mb = next(main_it)
             g, ri = resident.train_graph(negs[i % pool])
-            rb = HbmTrainBatch(graph=g, root_node_indices=ri, root_node_labels=None,
-                               root_ids=(negs[i % pool].to(torch.int64) & 0xFFFFFFFF).cpu().numpy())
+            rb = HbmTrainBatch(graph=g, root_node_indices=ri, root_node_labels=None, root_ids=negs_host[i % pool])
             opt.zero_grad(set_to_none=True)
             ti = _infer_task_inputs_hbm(model, mb, rb, False, dev)
             loss, _ = tasks.calculate_losses(ti, None, should_eval=False, device=dev)
