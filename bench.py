@@ -2650,6 +2650,11 @@ def run_gat_lp_train(args, rank, world, local_rank):
                      "by_kernel": by_kernel},
         "cpu_baseline": None,
     }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.cuda.synchronize(dev)
+        eng.bind_stream(torch.cuda.current_stream(dev))  # (the baseline's device helpers run on torch's current stream)
+        a_dev = torch.from_numpy(anchors[: 4 * B].astype(np.uint32).view(np.int32)).view(4, B).to(dev)
+        line["cpu_baseline"] = run_cpu_gat_lp_baseline(eng, enc, a_dev, negs[:4], fanouts, heads, L, budget_s=20.0, train=True)
     if rank == 0:
         emit(line)
     eng.close()
@@ -2936,6 +2941,8 @@ def run_gat_lp(args, rank, world, local_rank):
         "roofline": roofline, "cpu_baseline": None,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.cuda.synchronize(dev)
+        eng.bind_stream(torch.cuda.current_stream(dev))  # (the baseline's device helpers run on torch's current stream)
         line["cpu_baseline"] = run_cpu_gat_lp_baseline(eng, model, anchors, negs, fanouts, heads, L)
     if world > 1:  # a replica per GPU: whole-job rate = sum over the ranks, step time = the slowest rank's
         import torch.distributed as dist
@@ -2956,17 +2963,22 @@ def run_gat_lp(args, rank, world, local_rank):
         dist.destroy_process_group()
 
 
-def run_cpu_gat_lp_baseline(eng, model, anchors, negs, fanouts, heads, L, budget_s=15.0):
+def run_cpu_gat_lp_baseline(eng, model, anchors, negs, fanouts, heads, L, budget_s=15.0, train=False):
     """the CPU port of the GAT link-prediction step on one host core: oracle sampler + collate (C) of the anchors +
     positives batch and of the random-negative batch, 2-layer GAT forward over the WHOLE union graph in fp32 torch
     (oracle/gnn_ref.gat_conv: the reference's execution order), inner-product scores and the retrieval loss rows —
     full steps of the GPU line's shape, counted in its unit (sampled edges + the edges the trimmed schedule aggregates).
-    The positives (one sampled out-neighbour per anchor) are taken from the device, untimed: they are an input here."""
+    The positives (one sampled out-neighbour per anchor) are taken from the device, untimed: they are an input here.
+    train: the TRAINING step — the same forward with autograd, an in-batch softmax loss, backward and an Adam update."""
     import oracle
     from oracle import gnn_ref
     rowptr, col = eng.graph_to_host()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     torch.set_num_threads(1)
+    opt = None
+    if train:
+        sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        opt = torch.optim.Adam(list(sd.values()), lr=5e-3, weight_decay=1e-6)
 
     def encode(roots):
         nbr, cnt = oracle.sample_khop(rowptr, col, roots, fanouts, canonical=True)
@@ -3007,14 +3019,19 @@ def run_cpu_gat_lp_baseline(eng, model, anchors, negs, fanouts, heads, L, budget
         en = forward(xn, ein)[torch.from_numpy(un["root_local"].astype(np.int64)).clamp(min=0)]
         B = a_h.size
         scores = em[:B] @ torch.cat([em[B:], en]).T / 0.07
-        _ = torch.logsumexp(scores, dim=1).sum()
+        loss = torch.logsumexp(scores, dim=1).sum()
+        if train:
+            opt.zero_grad()
+            (loss - scores[:, : min(B, scores.shape[1])].diagonal().sum()).div(B).backward()
+            opt.step()
         t_used += time.perf_counter() - t0
         edges += units(um, cm) + units(un, cn)
         steps += 1
     return {"value": edges / max(t_used, 1e-9), "unit": "edges/s", "cores": 1, "kind": "port",
             "sample": f"{steps} full steps ({anchors.shape[1]} anchors + positives, {negs.shape[1]} random negatives) of the "
                       f"same graph / fanout, {t_used:.1f} s; sampler + collate = oracle/gigl_oracle.c, forward = "
-                      "oracle/gnn_ref.gat_conv over the whole union graph (fp32 torch, 1 thread), scores + loss rows in torch"}
+                      "oracle/gnn_ref.gat_conv over the whole union graph (fp32 torch, 1 thread), scores + loss rows in torch"
+                      + (", autograd backward + Adam" if train else "")}
 
 
 def run_cpu_baseline(eng, model, my, fanouts, W, n, d):
