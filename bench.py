@@ -686,6 +686,9 @@ def main():
     # ---- algorithmic bytes / flops from the exact counts
     dims = [d] + [hid] * (L - 1)
     half_split = (not projected) and hasattr(plans[0], "half_split") and plans[0].half_split()
+    # both projections in one kernel (gigl_sage_plan_fused_layers): 2 x 96 floats of [W_l h | W_r h] (two K-split planes)
+    # leave the first projection per row instead of the hidden row, the last layer is one reduction over them
+    fused_layers = (not projected) and hasattr(plans[0], "fused_layers") and plans[0].fused_layers()
 
     def alg_of(st):
         """st: a STATS vector -> (bytes per kernel group, projection flops)"""
@@ -698,6 +701,19 @@ def main():
             dout = hid if l < L - 1 else out_dim
             if l == 0 and projected:  # fp32 rows of W_l x per edge, the W_r x row of the destination, the output row
                 ab["gather_mean"] += agg_l * (4 + dout * 4) + rows_l * (8 + 2 * dout * 4)
+                continue
+            if fused_layers and l == 1:
+                # the last layer over p rows: per edge the W_l half (48 floats) of both planes, per root the W_r half of
+                # both planes + the output row; no projection
+                ab["gather_mean"] += agg_l * (4 + 2 * 48 * 4) + rows_l * (8 + 2 * 48 * 4 + out_dim * 4)
+                continue
+            if fused_layers and l == 0:
+                two_src = True
+                ab["gather_mean"] += agg_l * (4 + dims[l] * s_in) + rows_l * (8 + dims[l] * 4)
+                # operand rows in, two planes of 96 floats out; + the second product's flops (256 -> 96, three products)
+                ab["linear"] += rows_l * (2 * dims[l] + 2 * 96) * 4 + dout * 2 * dims[l] * 4 + 96 * dout * 4
+                fl += 2.0 * rows_l * (2 * dims[l] * dout + dout * 96)
+                alg_of.issued += 2.0 * rows_l * (2 * dims[l] * dout + dout * 96) * 3
                 continue
             #  gather layer l: E_l*(4 + D_l*s) + N_dst*(8 + D_l*s_out); the self half of the projection's operand is
             #  read by the projection itself from the fp32 source rows (two-source operand) — or, for an fp16 table's
@@ -875,7 +891,7 @@ def main():
                        f"{d}->{hid}->{out_dim} (fp32 accumulate) inference step (sample+union+forward), sampler mode="
                        + args.mode,
                        "graph": "replica per GPU, roots sharded across ranks",
-                       "streams": S, "batches_per_call": G,
+                       "streams": S, "batches_per_call": G, "fused_layers": bool(fused_layers),
                        "projected_input": (None if not projected else {
                            "precompute_s": round(pre_s, 4), "steps_per_pass": steps_per_pass,
                            "charged_ms_per_step": pre_per_step_s * 1e3,
@@ -906,10 +922,11 @@ def main():
         # same script as the mag240m-sharded workload, the ranks' own process group on another port): a crash or a
         # hang there ends the child, not the line.  Rank 0 embeds the child's JSON line, or the reason there is none.
         import subprocess
-        limit = float(os.environ.get("GIGL_BENCH_SUB_TIMEOUT", "300"))
+        limit = float(os.environ.get("GIGL_BENCH_SUB_TIMEOUT", "600"))
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--workload", "mag240m-sharded",
-               "--fanouts", "25,10", "--batch", "1024", "--min-seconds", str(min(args.min_seconds, 1.5)), "--min-reps", "3",
-               "--min-rounds", "4", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
+               "--fanouts", "25,10", "--batch", "1024", "--min-seconds", str(args.min_seconds), "--min-reps",
+               str(args.min_reps), "--min-rounds", str(args.min_rounds), "--steps", str(args.steps), "--warmup",
+               str(args.warmup), "--no-cpu-baseline",
                "--shard-group", str(args.shard_group), "--shard-hot-frac", str(args.shard_hot_frac), "--shard-plans",
                str(args.shard_plans), "--shard-scale", str(args.shard_scale), "--project-input", args.project_input,
                "--mode", args.mode] + (["--project-on-owner"] if args.project_on_owner else [])
@@ -920,9 +937,18 @@ def main():
             lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
             if rank == 0:
                 if cp.returncode == 0 and lines:
+                    # N > 1: the line's value / config.workload ARE the north-star workload — BASELINE configs[2], the
+                    # MAG240M-shaped graph hash-partitioned over the N ranks (weak scaling: N/8 of the graph, each GPU
+                    # holding the share it has in the 8-GPU job), exchanges over RCCL; the replica run above (every rank
+                    # a copy of the products-shaped graph, no data-path collective) becomes the sub-record
                     sub = json.loads(lines[-1])
-                    line["sharded"] = {k: sub.get(k) for k in ("value", "ms_per_step", "n_gpus", "steps", "timing",
-                                                               "config", "roofline", "roofline_xgmi")}
+                    rep_roof = {k: v for k, v in (line.get("roofline") or {}).items() if k not in ("groups", "by_kernel")}
+                    sub["replicas"] = {**{k: line.get(k) for k in ("value", "ms_per_step", "n_gpus", "steps", "warmup",
+                                                                   "timing", "config")}, "roofline": rep_roof}
+                    sub["headline_is"] = ("mag240m-sharded (BASELINE configs[2]) at shard scale N/8 over the N ranks' RCCL "
+                                          "communicators; `replicas` = the products-shaped replica-per-GPU run of the same "
+                                          "launch (no data-path collective)")
+                    line = sub
                 else:
                     sub_err = f"exit code {cp.returncode}: {cp.stderr.strip()[-400:]}"
             elif cp.returncode != 0:
@@ -933,6 +959,8 @@ def main():
             sub_err = f"{type(ex).__name__}: {str(ex)[:400]}"
         if rank == 0 and sub_err:
             line["sharded"] = {"error": sub_err}
+            line["headline_is"] = ("FALLBACK: the mag240m-sharded run of this launch failed (see `sharded.error`); value / "
+                                   "config are the products-shaped replica-per-GPU run, not the hash-partitioned workload")
     if rank == 0 and world == 1 and wl_name == "products" and not args.no_emulated_sub and not args.timed_only and \
             not os.environ.get("GIGL_BENCH_CHILD") and not under_profiler:
         # BASELINE configs[2] on the one GPU the driver's N=1 run has: the 8-rank hash-partitioned job emulated in one
@@ -1141,16 +1169,18 @@ def run_sharded(args, rank, world, local_rank, sub=False):
     def run_calls(slots, lo, hi, acc=None):
         """library calls lo..hi-1 (G batches each), S at a time: the phases of the S plans are issued interleaved by
         this one thread — the same order on every rank"""
-        lib, nph = slots[0].plan._lib, slots[0].plan.n_phases
+        lib = slots[0].plan._lib
         for c0 in range(lo, hi, S):
             live = [(slots[j], my[c0 + j]) for j in range(min(S, hi - c0))]
-            for ph in range(nph):
-                for sl, roots in live:
-                    rc = lib.gigl_dist_plan_phase(sl.plan._plan, ph, C.c_void_p(roots.data_ptr()), 42,
-                                                  C.c_void_p(sl.out.data_ptr()))
-                    if rc != 0:
-                        from gigl_amd._lib import check
-                        check(rc, sl.eng._ctx)
+            nl = len(live)
+            # (gigl_dist_plan_run_interleaved: phase 0 of every plan in flight, then phase 1 of every plan, ... from C++)
+            pa = (C.c_void_p * nl)(*[sl.plan._plan for sl, _ in live])
+            ra = (C.c_void_p * nl)(*[r_.data_ptr() for _, r_ in live])
+            oa = (C.c_void_p * nl)(*[sl.out.data_ptr() for sl, _ in live])
+            rc = lib.gigl_dist_plan_run_interleaved(pa, nl, ra, 42, oa)
+            if rc != 0:
+                from gigl_amd._lib import check
+                check(rc, slots[0].eng._ctx)
             if acc is not None:
                 for sl, _ in live:
                     sl.plan.stats(acc)
@@ -1204,6 +1234,7 @@ def run_sharded(args, rank, world, local_rank, sub=False):
     all_reduce(rr, dist.ReduceOp.MAX)
     reps = int(rr.item())
     rep_s = []
+    moved0 = [sl.comm.traffic() for sl in slots]  # (bytes this rank's communicators put on the links so far)
     for r in range(reps):
         dist.barrier()
         torch.cuda.synchronize()
@@ -1213,6 +1244,13 @@ def run_sharded(args, rank, world, local_rank, sub=False):
         torch.cuda.synchronize()
         rep_s.append(time.perf_counter() - t1)
     dist.barrier()
+    moved1 = [sl.comm.traffic() for sl in slots]
+    moved_t = torch.tensor([sum(b_[0] - a_[0] for a_, b_ in zip(moved0, moved1)),
+                            sum(b_[1] - a_[1] for a_, b_ in zip(moved0, moved1))], dtype=torch.float64, device=dev)
+    moved_max = moved_t.clone()
+    all_reduce(moved_t, dist.ReduceOp.SUM)
+    all_reduce(moved_max, dist.ReduceOp.MAX)
+    comm_ranks, comm_kind = slots[0].comm.world, slots[0].comm.kind  # (from the communicator: gigl_comm_info)
     # ---- per-kernel HIP-event times of one more (untimed) repetition: the library's timers on every plan's ctx; the
     # plans stay interleaved as in the timed region, so an interval includes what the other plans' kernels took from it
     prof_names = ["expand", "union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr", "gather_mean",
@@ -1247,6 +1285,16 @@ def run_sharded(args, rank, world, local_rank, sub=False):
             "unit": "edges/s", "n_gpus": world, "steps": steps_total, "warmup": Wp,
             "ms_per_step": elapsed / steps_total * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic", "steps_requested": K,
+            # the communicator's own view (gigl_comm_info / gigl_comm_traffic), not WORLD_SIZE: how many ranks the
+            # exchanges of the timed region ran between, through which transport, and the bytes they put on the links
+            "rccl_ranks": int(comm_ranks) if comm_kind == 0 else 0,
+            "comm": {"ranks": int(comm_ranks),
+                     "transport": {0: "rccl", 1: "in-process", 2: "host-callback"}.get(int(comm_kind), str(comm_kind)),
+                     "xgmi_bytes_per_step_per_gpu_mean": float(moved_t[0].item()) / max(steps_total * world, 1),
+                     "xgmi_bytes_per_step_busiest_gpu": float(moved_max[0].item()) / max(steps_total, 1),
+                     "xgmi_bytes_per_step_had_blocks_been_full": float(moved_t[1].item()) / max(steps_total * world, 1),
+                     "measured": "gigl_comm_traffic over the timed region: bytes sent to OTHER ranks by this rank's "
+                                 "communicators (all plans in flight); 0 at one rank"},
             "timing": {"repetitions": reps, "steps_per_repetition": K_rep, "timed_region_s": round(elapsed, 3),
                        "ms_per_step_median": q(ms_rep, 50), "ms_per_step_p10": q(ms_rep, 10),
                        "ms_per_step_p90": q(ms_rep, 90)},

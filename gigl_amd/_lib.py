@@ -46,7 +46,7 @@ SYMBOLS = [
     "gigl_comm_unique_id", "gigl_dist_init", "gigl_dist_init_local", "gigl_dist_init_callback", "gigl_comm_info",
     "gigl_comm_all_to_all", "gigl_comm_flush_local", "gigl_comm_traffic", "gigl_comm_destroy", "gigl_dist_plan_batch_features", "gigl_dist_plan_batch_graph", "gigl_dist_plan_create",
     "gigl_dist_plan_set_weights", "gigl_dist_plan_phases", "gigl_dist_plan_phase", "gigl_dist_plan_run",
-    "gigl_dist_plan_run_local", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
+    "gigl_dist_plan_run_local", "gigl_dist_plan_run_interleaved", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
     "gigl_dist_plan_set_hot_rows",
     "gigl_split_hash_slots", "gigl_hgt_aggregate", "gigl_simplehgn_alpha", "gigl_weighted_aggregate",
     "gigl_collate_typed_records", "gigl_collated_typed_info", "gigl_collated_typed_nodes", "gigl_collated_typed_edges",
@@ -57,7 +57,7 @@ SYMBOLS = [
     "gigl_dist_gat_plan_create", "gigl_dist_gat_plan_set_weights", "gigl_dist_plan_bucket_fill",
     "gigl_linear_weight_grad", "gigl_features_row_crc",
     "gigl_typed_plan_create", "gigl_typed_plan_run", "gigl_typed_plan_buffers", "gigl_typed_plan_destroy",
-    "gigl_typed_plan_merged_csr", "gigl_sage_plan_half_split", "gigl_sort_distinct_u64", "gigl_sort_distinct_u32",
+    "gigl_typed_plan_merged_csr", "gigl_sage_plan_half_split", "gigl_sage_plan_fused_layers", "gigl_sort_distinct_u64", "gigl_sort_distinct_u32",
     "gigl_typed_plan_merged_csr_ex", "gigl_hgt_aggregate_act", "gigl_dist_plan_set_aggr", "gigl_typed_plan_run_nodes", "gigl_typed_plan_run_edges", "gigl_typed_plan_clone", "gigl_hgt_infer_create", "gigl_hgt_infer_run",
     "gigl_hgt_infer_set_model", "gigl_hgt_infer_use_graph", "gigl_hgt_infer_destroy",
     "gigl_sage_plan_run_part", "gigl_sage_plan_overflow_add",
@@ -317,6 +317,7 @@ def load() -> C.CDLL:
         "gigl_dist_plan_phase": [vp, i32, vp, i32, vp],
         "gigl_dist_plan_run": [vp, vp, i32, vp],
         "gigl_dist_plan_run_local": [P(vp), i32, P(vp), i32, P(vp)],
+        "gigl_dist_plan_run_interleaved": [P(vp), i32, P(vp), i32, P(vp)],
         "gigl_dist_plan_buffers": [vp, P(GiglTree), P(GiglUnion)],
         "gigl_dist_plan_stats": [vp, vp],
         "gigl_dist_plan_set_hot_rows": [vp, vp, i64, vp],
@@ -383,6 +384,7 @@ def load() -> C.CDLL:
         "gigl_sage_project_features": [vp, vp, vp, i32, vp],
         "gigl_sage_plan_set_projected_input": [vp, vp],
         "gigl_sage_plan_half_split": [vp],
+        "gigl_sage_plan_fused_layers": [vp],
         "gigl_sage_plan_overflow_add": [vp, vp],
         "gigl_sage_train_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), vp, vp, i32, C.c_float, C.c_float, C.c_float,
                                         C.c_float, C.c_float, vp],

@@ -29,6 +29,20 @@
 
 #include <hip/hip_fp16.h>
 
+// power of two s with s * m in [2^14, 2^15) (m > 0, finite), held inside [2^-60, 2^60]
+__host__ __device__ static inline float hs_pow2_scale(float m) {
+  uint32_t bits;
+  memcpy(&bits, &m, 4);
+  int e = (int)((bits >> 23) & 0xFF) - 127;  // floor(log2 m) for normal m
+  if (((bits >> 23) & 0xFF) == 0) e = -126;
+  int se = 14 - e;
+  se = se > 60 ? 60 : (se < -60 ? -60 : se);
+  const uint32_t sb = (uint32_t)(se + 127) << 23;
+  float s;
+  memcpy(&s, &sb, 4);
+  return s;
+}
+
 namespace {
 
 typedef float float4_t __attribute__((ext_vector_type(4)));
@@ -84,7 +98,8 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
                                                           const float* __restrict__ self_src = nullptr,
                                                           const float* __restrict__ bias = nullptr, int act = 0,
                                                           int ld = 0, int no_self = 0,
-                                                          const int32_t* __restrict__ self_ids = nullptr, int ld3 = 0) {
+                                                          const int32_t* __restrict__ self_ids = nullptr, int ld3 = 0,
+                                                          int own_world = 0, int own_rank = 0) {
   constexpr int G = 64 / LPR;  // source rows per wave-instruction
   const int64_t rs = PROJ ? (int64_t)ld : (int64_t)d;  // elements between source rows
   const int64_t rs3 = PROJ && ld3 ? (int64_t)ld3 : (int64_t)d;  // ... of src3 (the rank's own table)
@@ -110,7 +125,15 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
   // source index of column entry `c` of destination row i
   auto translate = [&](int c, int i) -> int {
     if (gather_ids && i < n_local) return (int)gather_ids[c];
-    if (global_map && i >= n_local) return global_map[(uint32_t)c];  // global id -> its row in `src`
+    if (global_map && i >= n_local) {  // global id -> its row in `src`
+      // (own_world: the ids this rank owns — id % world == rank — are row id / world of src3, by arithmetic: they are
+      // neither claimed nor looked up, dist.hip)
+      if (own_world) {
+        const uint32_t q = (uint32_t)c / (uint32_t)own_world;
+        if ((uint32_t)c - q * (uint32_t)own_world == (uint32_t)own_rank) return -1 - ((1 << 30) + (int)q);
+      }
+      return global_map[(uint32_t)c];
+    }
     return c;
   };
   // lane `idx` of group `sub`'s LPR lanes (grp), or entry idx + sub of the wave's index vector (wave-wide rows).
@@ -131,7 +154,11 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
       if (writer) {
         // (self_ids: the destination's W_r row sits at row self_ids[i] of self_src — the sharded plan's second receive
         // buffer — instead of at its source index)
-        const float* pr = self_src + (int64_t)(self_ids ? (uint32_t)self_ids[i] : (uint32_t)self) * rs;
+        // (a NEGATIVE self_ids[i] = -1 - (2^30 + r): the destination is a node of this rank — its W_r row is the right half
+        // of row r of src3, the rank's own [W_l x | W_r x] table, read in place)
+        const int sj = self_ids ? self_ids[i] : self;
+        const float* pr = sj >= 0 ? self_src + (int64_t)(uint32_t)sj * rs
+                                  : src3 + (int64_t)((-1 - sj) - (1 << 30)) * rs3 + d;
         float* o = out + (int64_t)i * d;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
@@ -1163,6 +1190,319 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ONE || (HS
     for (int j = 0; j < NJ; ++j)
       store_block_32x32(acc[i][j], strip, lane, bias, act, m0b + wm * 64 + i * 32, n0b + wn * 32 * NJ + j * 32, M, N, y,
                         ldy);
+}
+
+// ------------------------------------------------------------------------------------------
+// Two SAGE layers' projections in one kernel (round 5): the first layer's [mean | self] projection with the LAST layer's
+// [W_l | W_r] applied to its hidden rows before they leave the workgroup.
+//   SAGEConv layer 1 (homogeneous.py:122-126 -> PyG SAGEConv): out_r = W_l mean_j h_j + b + W_r h_r, and W_l mean_j h_j =
+//   mean_j (W_l h_j): with p_j = [W_l h_j | W_r h_j] (2 x 47 floats instead of the 256-float h_j) the second layer is ONE
+//   reduction over p rows (sage_fused_out_kernel) — the 1-KB hidden rows are never written, the second gather reads
+//   192-byte pieces, the second projection disappears.
+// Shape: hidden width = 256 (two column tiles of 128), 2 * out <= 96.  A workgroup (row tile tm, column tile tn) holds
+// hidden columns [128 tn, +128) of 128 rows, so the second product is K-split over the two column tiles: each writes
+// its PARTIAL p rows to plane tn of y2 ([2][rows][96] floats) and the reduction kernel adds the planes (a fixed order:
+// plane 0 + plane 1 — no atomics).
+// First product: as linear_split_kernel<2, KVEC, SELF, false, HS, ONE> (two fp16 planes per operand, three MFMAs, the
+// same loaders, LDS planes and swizzle), except that the four waves split the ROWS (wave = 32 rows x 128 hidden) and the
+// MFMA operands are swapped, acc = W-fragment x A-fragment = the TRANSPOSED block: lane r holds row r, its 16 registers
+// hidden columns 8 (v / 4) + 4 g + v % 4 — which IS the A-fragment layout of the next product (lane = row, registers = k)
+// up to a permutation of k inside each 16-block, applied to W2's planes when they are prepared (fused2_prepare_kernel):
+// the hidden tile goes from accumulators to operand registers without touching LDS.
+// Second product: h = relu(acc / (s_a s_w) + b1) is bounded by K max|W1| max|a| + max|b1| =: B (found on the device
+// from the scales of the first product), so it takes the half split too: h s_h = h1 + h2 with s_h a power of two that
+// brings B under 2^14; element error max(2^-22 |h|, 2^-39 B).  W2's planes (fp16, scaled by s_w2) are staged through LDS
+// 64 hidden columns at a time (rows padded to 144 bytes: conflict-free 16-byte reads).
+typedef _Float16 half8v_t __attribute__((ext_vector_type(8)));
+constexpr int F2_N2 = 96;     // padded width of a p row: [W_l h (out, padded to 48) | W_r h (out, padded to 48)]
+constexpr int F2_HID = 256;   // hidden width the kernel is built for
+constexpr int F2_W2LD = 72;   // halves per staged W2 row (64 + 8 of padding)
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void linear_fused2_kernel(
+    const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
+    const int32_t* __restrict__ m_dev, int K, float* __restrict__ y2, int64_t plane_stride, int a_tiled,
+    const float* __restrict__ self_src, const uint32_t* __restrict__ self_ids, int d_mean, int self_ld,
+    const float* __restrict__ hs_scale, const float* __restrict__ f2_scale, const _Float16* __restrict__ w2h) {
+  constexpr int BK = 32, LDK = 32, BM = 128, BN = 128, NJ = 2;
+  constexpr int A_EL = 2 * BM * LDK, W_EL = 2 * BN * LDK;  // (shorts) 16 KB + 16 KB
+  static_assert(2 * F2_N2 * F2_W2LD <= A_EL + W_EL, "the staged W2 planes reuse the operand planes");
+  __shared__ __attribute__((aligned(16))) short s_buf[A_EL + W_EL];
+  short(*s_a)[BM * LDK] = reinterpret_cast<short(*)[BM * LDK]>(s_buf);
+  short(*s_w)[BN * LDK] = reinterpret_cast<short(*)[BN * LDK]>(s_buf + A_EL);
+  const int M = *m_dev;
+  constexpr int N = F2_HID, tiles_n = 2;
+  const float hs_a = hs_scale[0], hs_w = hs_scale[1], hs_o = hs_scale[2];
+  int tm, tn;
+  {  // the two column tiles of a row tile run back to back on one XCD (ids 8 apart): the A tile comes from HBM once
+    const unsigned bid = blockIdx.x, span = 8u * (unsigned)tiles_n;
+    const unsigned full = (gridDim.x / span) * span;
+    if (bid < full) {
+      const unsigned grp = bid / span, in = bid % span;
+      tm = (int)(grp * 8u + (in & 7u));
+      tn = (int)(in >> 3);
+    } else {
+      tm = (int)(bid / (unsigned)tiles_n);
+      tn = (int)(bid % (unsigned)tiles_n);
+    }
+  }
+  const int m0b = tm * BM, n0b = tn * BN;
+  if (m0b >= M) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, g = lane >> 5;
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  float16_t acc[4];  // [hidden block j of 32][.]: lane r = row 32 wv + r, register v = hidden 8 (v / 4) + 4 g + v % 4
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+  const int lr = tid >> 3, lc = tid & 7;
+  float4_t ga[4], gw[2 * NJ];
+  const float* self_row[4] = {nullptr, nullptr, nullptr, nullptr};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0b + lr + 32 * i;
+    if (row < M) self_row[i] = self_src + (int64_t)(self_ids ? self_ids[row] : (uint32_t)row) * self_ld;
+  }
+  auto gload = [&](int k0) {
+    const int kk = k0 + lc * 4;
+    const float* at = a + ((int64_t)tm * a_tiled + (k0 >> 5)) * 4096 + lc * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0b + lr + 32 * i;
+      const float* src = at + (lr + 32 * i) * 32;
+      if (kk >= d_mean && row < M) src = self_row[i] + (kk - d_mean);
+      ga[i] = (row < M && kk < K) ? *reinterpret_cast<const float4_t*>(src) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * NJ; ++i) {
+      const int row = n0b + lr + 32 * i;
+      gw[i] = (row < N && kk < K) ? *reinterpret_cast<const float4_t*>(w + (int64_t)row * K + kk) : zero4;
+    }
+  };
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = split_lds_off(lr + 32 * i, lc * 4);
+      hsplit_store(ga[i], &s_a[0][o], &s_a[1][o], hs_a);
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * NJ; ++i) {
+      const int o = split_lds_off(lr + 32 * i, lc * 4);
+      hsplit_store(gw[i], &s_w[0][o], &s_w[1][o], hs_w);
+    }
+    __syncthreads();
+    if (k0 + BK < K) gload(k0 + BK);
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      if (k0 + ks >= K) break;
+      half8v_t fa[2], fw[4][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        fa[p] = *reinterpret_cast<const half8v_t*>(&s_a[p][split_lds_off(wv * 32 + r, ks + 8 * g)]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          fw[j][p] = *reinterpret_cast<const half8v_t*>(&s_w[p][split_lds_off(j * 32 + r, ks + 8 * g)]);
+      // three products, smallest terms first, the four accumulators interleaved; operands swapped: the block comes out
+      // transposed (lane = row)
+      constexpr int HA[3] = {1, 0, 0}, HW[3] = {0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j][HW[t]], fa[HA[t]], acc[j], 0, 0, 0);
+    }
+  }
+  // ---- second product: p[row][0:96] (partial over this tile's 128 hidden columns) = relu(h) . W2p[:, 128 tn ..]^T
+  const float s_h = f2_scale[0], o2 = f2_scale[2];
+  _Float16* s_w2 = reinterpret_cast<_Float16*>(s_buf);  // [2 planes][96][F2_W2LD]
+  float16_t acc2[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc2[n][v] = 0.f;
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    __syncthreads();  // the operand planes (rd = 0) / the previous 64 columns' W2 fragments are done with
+    // stage W2p[plane][n2][n0b + 64 rd .. +64) (halves, k already permuted per 16-block): 2 * 96 rows of 128 bytes
+    for (int q = tid; q < 2 * F2_N2 * 8; q += 256) {
+      const int pl = q / (F2_N2 * 8), rem = q - pl * (F2_N2 * 8), row = rem >> 3, pc = rem & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(w2h + ((int64_t)pl * F2_N2 + row) * F2_HID + n0b + 64 * rd + 8 * pc);
+      *reinterpret_cast<uint4*>(s_w2 + (pl * F2_N2 + row) * F2_W2LD + 8 * pc) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * rd + jj;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        // this lane's 8 hidden values of the 16-block: registers v = 8 hf .. 8 hf + 7 = hidden 32 j + 16 hf + {4 g + t, 8 + 4 g + t}
+        half8v_t h1, h2;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float4_t bq = bias ? *reinterpret_cast<const float4_t*>(bias + n0b + 32 * j + 8 * (2 * hf + q) + 4 * g) : zero4;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float x = acc[j][8 * hf + 4 * q + t] * hs_o + bq[t];
+            x = (x > 0.f ? x : 0.f) * s_h;
+            const _Float16 a1 = (_Float16)x;
+            h1[4 * q + t] = a1;
+            h2[4 * q + t] = (_Float16)(x - (float)a1);
+          }
+        }
+        const int kb = 2 * jj + hf;  // 16-block of the staged 64 columns
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          const half8v_t w1 = *reinterpret_cast<const half8v_t*>(s_w2 + (n * 32 + r) * F2_W2LD + 16 * kb + 8 * g);
+          const half8v_t w2 = *reinterpret_cast<const half8v_t*>(s_w2 + (F2_N2 + n * 32 + r) * F2_W2LD + 16 * kb + 8 * g);
+          acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, w1, acc2[n], 0, 0, 0);
+          acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, w2, acc2[n], 0, 0, 0);
+          acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, w1, acc2[n], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D layout of acc2[n]: lane r = column 32 n + r of p, register v = row 8 (v / 4) + 4 g + v % 4 of the wave's 32 rows:
+  // one store instruction covers two rows x 32 columns = two whole 128-byte lines (p rows are 384 bytes)
+  float* yp = y2 + (int64_t)tn * plane_stride;
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int row = m0b + wv * 32 + 8 * (v >> 2) + 4 * g + (v & 3);
+      if (row < M) yp[(int64_t)row * F2_N2 + n * 32 + r] = acc2[n][v] * o2;
+    }
+}
+
+// f2[0..2] = {s_h, s_w2, 1 / (s_h s_w2)} and the fp16 planes of W2p = [W_l ; W_r] of the last layer ([96][256]: rows
+// 0..out-1 = W_l, 48..48+out-1 = W_r, the rest zero), scaled by s_w2, each 16-block of k stored in the order the fused
+// kernel's accumulator registers hold it: position 8 g + e <- element 8 (e / 4) + 4 g + e % 4.  One workgroup, per run
+// (the weights are read as they are now).  hs = the first product's scales {s_a, s_w, ...} (gigl_hs_scale_update ran
+// before on the same stream): max|a| < 2^15 / s_a, max|W1| < 2^15 / s_w.
+__global__ __launch_bounds__(1024) void fused2_prepare_kernel(const float* __restrict__ hs, const float* __restrict__ b1,
+                                                              const float* __restrict__ w2, int n_out, int K1,
+                                                              float* __restrict__ f2, _Float16* __restrict__ w2h) {
+  __shared__ float s_m[2][16];
+  __shared__ float s_sc[2];
+  const int tid = threadIdx.x;
+  float mb = 0.f, mw = 0.f;
+  if (b1)
+    for (int i = tid; i < F2_HID; i += 1024) {
+      const float v = fabsf(b1[i]);
+      mb = fmaxf(mb, v == v ? v : 0.f);
+    }
+  for (int i = tid; i < n_out * 2 * F2_HID; i += 1024) {
+    const float v = fabsf(w2[i]);
+    mw = fmaxf(mw, v == v ? v : 0.f);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+    mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    s_m[0][tid >> 6] = mb;
+    s_m[1][tid >> 6] = mw;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int i = 1; i < 16; ++i) {
+      mb = fmaxf(mb, s_m[0][i]);
+      mw = fmaxf(mw, s_m[1][i]);
+    }
+    // |h| <= K max|W1| max|a| + max|b1| < K 2^30 / (s_a s_w) + max|b1|
+    const float inf = __uint_as_float(0x7F800000u);
+    float bound = (float)K1 * 1073741824.f * (1.f / hs[0]) * (1.f / hs[1]) + mb;
+    if (!(bound > 0.f) || !(bound < inf)) bound = 1.f;
+    const float s_h = hs_pow2_scale(bound) * 0.5f;  // bound * s_h in [2^13, 2^14)
+    const float s_w2 = (mw > 0.f && mw < inf) ? hs_pow2_scale(mw) : 1.f;
+    f2[0] = s_h;
+    f2[1] = s_w2;
+    f2[2] = (1.f / s_h) * (1.f / s_w2);
+    s_sc[0] = s_w2;
+  }
+  __syncthreads();
+  const float s_w2 = s_sc[0];
+  for (int i = tid; i < F2_N2 * F2_HID; i += 1024) {
+    const int c = i / F2_HID, pos = i - c * F2_HID;
+    const int blk = pos >> 4, in = pos & 15, gg = in >> 3, e = in & 7;
+    const int k = blk * 16 + 8 * (e >> 2) + 4 * gg + (e & 3);  // the element that sits at position `pos`
+    float x = 0.f;
+    if (c < n_out) x = w2[(int64_t)c * 2 * F2_HID + k];
+    else if (c >= F2_N2 / 2 && c - F2_N2 / 2 < n_out) x = w2[(int64_t)(c - F2_N2 / 2) * 2 * F2_HID + F2_HID + k];
+    x *= s_w2;
+    const _Float16 a1 = (_Float16)x;
+    w2h[i] = a1;
+    w2h[F2_N2 * F2_HID + i] = (_Float16)(x - (float)a1);
+  }
+}
+
+// The last SAGE layer over the p rows of linear_fused2_kernel: for root slot s (local id i = root_local[s]):
+//   out[s][c] = act( reduce_{e in row i} (p0 + p1)[col[e]][c] + (p0 + p1)[i][48 + c] + b2[c] ),  c < n_out
+// (reduce = mean / sum; p0 / p1 = the two K-split partial planes, added plane 0 first).  One wave per root slot: four
+// groups of 16 lanes take every fourth edge, 12 lanes of a group a float4 of the 48-float half row each.  Writes the
+// roots' rows straight into the caller's buffer (a failed batch set: NaN rows, as gigl_take_rows).
+template <int OP>
+__global__ __launch_bounds__(256) void sage_fused_out_kernel(const float* __restrict__ p, int64_t plane_stride,
+                                                             const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ rowend,
+                                                             const int32_t* __restrict__ col,
+                                                             const int32_t* __restrict__ root_local, int b, int n_out,
+                                                             const float* __restrict__ bias, int act,
+                                                             const int32_t* __restrict__ meta, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, sub = lane >> 4, sl = lane & 15;
+  const int s = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (s >= b) return;
+  const bool failed = meta[GIGL_META_OVERFLOW] != 0;
+  const int i = failed ? -1 : root_local[s];
+  float* o = out + (int64_t)s * n_out;
+  if (i < 0) {
+    const float v = failed ? __builtin_nanf("") : 0.f;
+    for (int c = lane; c < n_out; c += 64) o[c] = v;
+    return;
+  }
+  const float* p0 = p;
+  const float* p1 = p + plane_stride;
+  const int e0 = rowptr[i], m = rowend[i] - e0;
+  float4_t acc = {0.f, 0.f, 0.f, 0.f};
+  if (sl < 12) {
+    for (int e = sub; e < m; e += 8) {  // two edges of this group in flight
+      const int ja = col[e0 + e], eb = e + 4;
+      const int jb = eb < m ? col[e0 + eb] : ja;
+      const float4_t a0 = *reinterpret_cast<const float4_t*>(p0 + (int64_t)ja * F2_N2 + 4 * sl);
+      const float4_t a1 = *reinterpret_cast<const float4_t*>(p1 + (int64_t)ja * F2_N2 + 4 * sl);
+      float4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+      if (eb < m) {
+        b0 = *reinterpret_cast<const float4_t*>(p0 + (int64_t)jb * F2_N2 + 4 * sl);
+        b1 = *reinterpret_cast<const float4_t*>(p1 + (int64_t)jb * F2_N2 + 4 * sl);
+      }
+      acc += (a0 + a1) + (b0 + b1);
+    }
+  }
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) {
+    const float4_t o4 = {__shfl_xor(acc.x, off, 64), __shfl_xor(acc.y, off, 64), __shfl_xor(acc.z, off, 64),
+                         __shfl_xor(acc.w, off, 64)};
+    acc += o4;
+  }
+  if (sub == 0 && sl < 12) {
+    const float dv = (OP == GIGL_AGGR_MEAN && m > 0) ? (float)m : 1.f;
+    const float4_t s0 = *reinterpret_cast<const float4_t*>(p0 + (int64_t)i * F2_N2 + F2_N2 / 2 + 4 * sl);
+    const float4_t s1 = *reinterpret_cast<const float4_t*>(p1 + (int64_t)i * F2_N2 + F2_N2 / 2 + 4 * sl);
+    float4_t rr = acc / dv + (s0 + s1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int c = 4 * sl + t;
+      if (c < n_out) {
+        float v = rr[t] + (bias ? bias[c] : 0.f);
+        if (act) v = fmaxf(v, 0.f);
+        o[c] = v;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2914,7 +3254,8 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
                       const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                       const int32_t* n_rows_dev, int64_t rows_cap, float* out, int op = GIGL_AGGR_MEAN,
                       const int32_t* n_local_dev = nullptr, int tiled_nkc = 0, const int32_t* global_map = nullptr,
-                      const T* src2 = nullptr, const T* src3 = nullptr, int no_self = 0) {
+                      const T* src2 = nullptr, const T* src3 = nullptr, int no_self = 0, int own_world = 0,
+                      int own_rank = 0) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
@@ -2924,7 +3265,8 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
 #define GLO(LPR, VPL, OP)                                                                            \
   hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, 0, st, src, d, gather_ids, rowptr, \
                      rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc, global_map, src2, src3,   \
-                     (const float*)nullptr, (const float*)nullptr, 0, 0, no_self)
+                     (const float*)nullptr, (const float*)nullptr, 0, 0, no_self, (const int32_t*)nullptr, 0,     \
+                     own_world, own_rank)
 #define GL(LPR, VPL)                                        \
   do {                                                      \
     if (op == GIGL_AGGR_MEAN) GLO(LPR, VPL, GIGL_AGGR_MEAN); \
@@ -2954,7 +3296,7 @@ int32_t launch_gather_projected(gigl_ctx* ctx, const float* src_l, const float* 
                                 const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                                 const int32_t* n_rows_dev, int64_t rows_cap, const int32_t* n_local_dev, int op,
                                 const float* bias, int act, float* out, const int32_t* global_map, const float* src2,
-                                const float* src3, int ld3, const int32_t* self_ids) {
+                                const float* src3, int ld3, const int32_t* self_ids, int own_world, int own_rank) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
@@ -2965,11 +3307,11 @@ int32_t launch_gather_projected(gigl_ctx* ctx, const float* src_l, const float* 
     if (op == GIGL_AGGR_MEAN)                                                                                         \
       hipLaunchKernelGGL((gather_mean_kernel<float, LPR, VPL, GIGL_AGGR_MEAN, true>), g, b, 0, ctx->stream, src_l, d, \
                          gather_ids, rowptr, rowend, col, n_rows_dev, out, n_local_dev, 0, global_map, src2, src3,    \
-                         src_r, bias, act, ld, 0, self_ids, ld3);                                                     \
+                         src_r, bias, act, ld, 0, self_ids, ld3, own_world, own_rank);                                \
     else                                                                                                              \
       hipLaunchKernelGGL((gather_mean_kernel<float, LPR, VPL, GIGL_AGGR_SUM, true>), g, b, 0, ctx->stream, src_l, d,  \
                          gather_ids, rowptr, rowend, col, n_rows_dev, out, n_local_dev, 0, global_map, src2, src3,    \
-                         src_r, bias, act, ld, 0, self_ids, ld3);                                                     \
+                         src_r, bias, act, ld, 0, self_ids, ld3, own_world, own_rank);                                \
   } while (0)
   if ((d & 3) != 0 || vecs > 512) return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "projected input: width %d (need d %% 4 == 0, d <= 2048)", d);
   if (vecs <= 8) GLP(8, 1);
@@ -3003,14 +3345,15 @@ int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float
                                   const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
                                   const int32_t* n_local_rows_dev, const float* bias, int32_t act, float* out,
                                   const int32_t* global_map, const float* src2, const float* src3, int32_t ld3,
-                                  const int32_t* self_ids) {
+                                  const int32_t* self_ids, int32_t own_world, int32_t own_rank) {
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   if (aggr != GIGL_AGGR_MEAN && aggr != GIGL_AGGR_SUM)
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "projected input needs a linear reduction (mean / sum)");
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   return launch_gather_projected(ctx, src_l, src_r, ld, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap,
-                                 n_local_rows_dev, aggr, bias, act, out, global_map, src2, src3, ld3, self_ids);
+                                 n_local_rows_dev, aggr, bias, act, out, global_map, src2, src3, ld3, self_ids, own_world,
+                                 own_rank);
 }
 
 extern "C" {
@@ -3155,17 +3498,18 @@ int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dty
                                  const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                                  const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
                                  const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc,
-                                 const int32_t* global_map, const void* src2, const void* src3, int32_t no_self) {
+                                 const int32_t* global_map, const void* src2, const void* src3, int32_t no_self,
+                                 int32_t own_world, int32_t own_rank) {
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   if (src_dtype == GIGL_DTYPE_F32)
     return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
                                 aggr, n_local_rows_dev, tiled_nkc, global_map, (const float*)src2, (const float*)src3,
-                                no_self);
+                                no_self, own_world, own_rank);
   return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
                                aggr, n_local_rows_dev, tiled_nkc, global_map, (const __half*)src2, (const __half*)src3,
-                               no_self);
+                               no_self, own_world, own_rank);
 }
 
 extern "C" {
@@ -3572,19 +3916,6 @@ int32_t gigl_feat_absmax(gigl_ctx* ctx, gigl_feat* feat, float* out) {
   return GIGL_OK;
 }
 
-// power of two s with s * m in [2^14, 2^15) (m > 0, finite), held inside [2^-60, 2^60]
-__host__ __device__ static inline float hs_pow2_scale(float m) {
-  uint32_t bits;
-  memcpy(&bits, &m, 4);
-  int e = (int)((bits >> 23) & 0xFF) - 127;  // floor(log2 m) for normal m
-  if (((bits >> 23) & 0xFF) == 0) e = -126;
-  int se = 14 - e;
-  se = se > 60 ? 60 : (se < -60 ? -60 : se);
-  const uint32_t sb = (uint32_t)(se + 127) << 23;
-  float s;
-  memcpy(&s, &sb, 4);
-  return s;
-}
 
 int32_t gigl_feat_half_split_scale(gigl_ctx* ctx, gigl_feat* feat, float fan, float* s_a) {
   *s_a = 0.f;
@@ -3723,6 +4054,56 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
   else
     hipLaunchKernelGGL((linear_split_kernel<1, true, false, false, false, true>), dim3((unsigned)(bm * ((n + 63) / 64)), (unsigned)batch), dim3(256), 0,
                        st, a_tiled, w, bias, m_dev, k, n, act, y, nkc, ldy, a_bstride, w_bstride);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+// ---- the fused two-layer projection (linear_fused2_kernel) and its companions
+bool gigl_fused2_shape_ok(int32_t d0, int32_t hid, int32_t n_out) {
+  return hid == F2_HID && n_out >= 1 && n_out <= F2_N2 / 2 && (d0 & 3) == 0 && d0 >= 4;
+}
+int64_t gigl_fused2_w2h_bytes() { return (int64_t)2 * F2_N2 * F2_HID * 2; }
+int32_t gigl_fused2_row_floats() { return F2_N2; }
+
+int32_t gigl_fused2_prepare(gigl_ctx* ctx, const float* hs_dev, const float* b1, const float* w2, int32_t n_out, int32_t k1,
+                            float* f2, void* w2h) {
+  hipLaunchKernelGGL(fused2_prepare_kernel, dim3(1), dim3(1024), 0, ctx->stream, hs_dev, b1, w2, n_out, k1, f2,
+                     (_Float16*)w2h);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_linear_fused2(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
+                           int64_t m_cap, int32_t k, float* y2, int64_t plane_stride, const float* self_src,
+                           const uint32_t* self_ids, int32_t d_mean, int32_t self_ld, const float* hs_scale,
+                           const float* f2, const void* w2h) {
+  GIGL_REQUIRE(ctx, a_tiled && w && m_dev && y2 && self_src && hs_scale && f2 && w2h && (k & 3) == 0 && d_mean > 0 &&
+                        (d_mean & 3) == 0 && d_mean < k && self_ld >= k - d_mean && (((uintptr_t)bias) & 15) == 0,
+               "bad arguments");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (m_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
+  const int64_t bm = (m_cap + 127) / 128;
+  hipLaunchKernelGGL(linear_fused2_kernel, dim3((unsigned)(bm * 2)), dim3(256), 0, ctx->stream, a_tiled, w, bias, m_dev, k,
+                     y2, plane_stride, (d_mean + 31) / 32, self_src, self_ids, d_mean, self_ld, hs_scale, f2,
+                     (const _Float16*)w2h);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_sage_fused_out(gigl_ctx* ctx, const float* p, int64_t plane_stride, const int32_t* rowptr,
+                            const int32_t* rowend, const int32_t* col, const int32_t* root_local, int32_t b,
+                            int32_t n_out, const float* bias, int32_t act, int32_t aggr, const int32_t* meta, float* out) {
+  GIGL_REQUIRE(ctx, aggr == GIGL_AGGR_MEAN || aggr == GIGL_AGGR_SUM, "the fused last layer needs a linear reduction");
+  if (b == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
+  const dim3 g((unsigned)(((int64_t)b + 3) / 4)), blk(256);
+  if (aggr == GIGL_AGGR_MEAN)
+    hipLaunchKernelGGL((sage_fused_out_kernel<GIGL_AGGR_MEAN>), g, blk, 0, ctx->stream, p, plane_stride, rowptr, rowend, col,
+                       root_local, b, n_out, bias, act, meta, out);
+  else
+    hipLaunchKernelGGL((sage_fused_out_kernel<GIGL_AGGR_SUM>), g, blk, 0, ctx->stream, p, plane_stride, rowptr, rowend, col,
+                       root_local, b, n_out, bias, act, meta, out);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

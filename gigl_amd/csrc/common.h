@@ -112,7 +112,10 @@ int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dty
                                  const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
                                  const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc = 0,
                                  const int32_t* global_map = nullptr, const void* src2 = nullptr,
-                                 const void* src3 = nullptr, int32_t no_self = 0);
+                                 const void* src3 = nullptr, int32_t no_self = 0, int32_t own_world = 0,
+                                 int32_t own_rank = 0);
+// own_world > 0 (with global_map): a global id with id % own_world == own_rank is row id / own_world of src3 by arithmetic
+// (the rank's own nodes are never claimed into global_map)
 // no_self (tiled layout): only the reduced half is written, tiled_nkc = ceil(d / 32) chunks per row tile; the
 // projection then takes the self half from the source rows (gigl_linear_tiled with self_src)
 // global_map: the rows i >= *n_local_rows_dev hold GLOBAL ids whose row in `src` is global_map[id] (the sharded plan's
@@ -125,7 +128,9 @@ int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float
                                   const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
                                   const int32_t* n_local_rows_dev, const float* bias, int32_t act, float* out,
                                   const int32_t* global_map = nullptr, const float* src2 = nullptr,
-                                  const float* src3 = nullptr, int32_t ld3 = 0, const int32_t* self_ids = nullptr);
+                                  const float* src3 = nullptr, int32_t ld3 = 0, const int32_t* self_ids = nullptr,
+                                  int32_t own_world = 0, int32_t own_rank = 0);
+// (self_ids[i] < 0, = -1 - (2^30 + r): destination i is a node of this rank — its W_r x is the right half of row r of src3)
 // (sharded plan: global_map / src2 / src3 as in gigl_gather_reduce_mixed — src3's rows ld3 floats apart — and
 // self_ids[i] = the row of src_r that holds destination i's W_r x)
 // tiled_nkc > 0: `out` is written in the projection's tiled operand layout ([row tile of 128][K chunk of 32][128 rows]
@@ -152,6 +157,24 @@ int32_t gigl_gat_input_layer_fused_hs(gigl_ctx* ctx, const void* src, int32_t sr
                                       float negative_slope, const int32_t* rowptr, const int32_t* rowend,
                                       const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, const float* bias,
                                       int32_t act, float* scratch, float* out, const float* hs_scale);
+// The fused two-layer projection (agg.hip, linear_fused2_kernel): layer 0's [mean | self] projection (half split, two-source
+// tiled operand) with the LAST layer's [W_l | W_r] applied to the hidden rows before they leave the workgroup — y2 =
+// [2 K-split partial planes][rows][gigl_fused2_row_floats()] of p = [W_l h | W_r h]; gigl_sage_fused_out is the last
+// layer over those rows (one reduction + self half + bias per root, written straight into the caller's `out`);
+// gigl_fused2_prepare (per run, after gigl_hs_scale_update on the same stream) finds the second product's scales and
+// lays out W2's fp16 planes.  gigl_fused2_shape_ok: hidden width 256, 2 * out <= row floats, d0 % 4 == 0.
+bool gigl_fused2_shape_ok(int32_t d0, int32_t hid, int32_t n_out);
+int64_t gigl_fused2_w2h_bytes();
+int32_t gigl_fused2_row_floats();
+int32_t gigl_fused2_prepare(gigl_ctx* ctx, const float* hs_dev, const float* b1, const float* w2, int32_t n_out, int32_t k1,
+                            float* f2, void* w2h);
+int32_t gigl_linear_fused2(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
+                           int64_t m_cap, int32_t k, float* y2, int64_t plane_stride, const float* self_src,
+                           const uint32_t* self_ids, int32_t d_mean, int32_t self_ld, const float* hs_scale,
+                           const float* f2, const void* w2h);
+int32_t gigl_sage_fused_out(gigl_ctx* ctx, const float* p, int64_t plane_stride, const int32_t* rowptr,
+                            const int32_t* rowend, const int32_t* col, const int32_t* root_local, int32_t b,
+                            int32_t n_out, const float* bias, int32_t act, int32_t aggr, const int32_t* meta, float* out);
 bool gigl_half_split_enabled();  // (GIGL_GEMM_SPLIT=bf16 keeps every projection on the bf16 planes)
 int32_t gigl_dev_absmax_f32(gigl_ctx* ctx, const float* p, int64_t n, float* out);  // synchronises the ctx's stream
 int32_t gigl_feat_absmax(gigl_ctx* ctx, gigl_feat* feat, float* out);

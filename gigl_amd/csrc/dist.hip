@@ -370,6 +370,33 @@ int32_t gigl_comm_destroy(gigl_comm* c) {
 // ------------------------------------------------------------------------------------------ kernels
 namespace {
 
+// Everything a call of the plan must find cleared — the request buckets of every hop (0xFFFFFFFF = no entry), the id
+// buckets of the feature pull, every bucket counter — in ONE launch at the start of the call (round 5: a dozen
+// hipMemsetAsync launches per call were 9 % of the world-1 step's GPU time and a quarter of its host time).  The
+// buffers belong to this plan and are next touched by later phases of the same call on the same stream.
+struct ClearSegs {
+  uint32_t* p[20];
+  int64_t end[20];  // cumulative length in 4-word units (a segment's length is rounded up to a multiple of 4 words)
+  int64_t words[20];
+  uint32_t val[20];
+  int n;
+};
+__global__ __launch_bounds__(256) void dist_clear_kernel(ClearSegs s) {
+  const int64_t total = s.end[s.n - 1];
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (int64_t)gridDim.x * blockDim.x) {
+    int k = 0;
+    while (u >= s.end[k]) ++k;
+    const int64_t w0 = (u - (k ? s.end[k - 1] : 0)) * 4;
+    uint32_t* q = s.p[k] + w0;
+    const uint32_t v = s.val[k];
+    if (w0 + 4 <= s.words[k]) {
+      *reinterpret_cast<uint4*>(q) = make_uint4(v, v, v, v);
+    } else {
+      for (int64_t t = w0; t < s.words[k]; ++t) s.p[k][t] = v;
+    }
+  }
+}
+
 // frontier slot i (node v, path sum K) -> bucket owner(v) = v % world, at the next free position p (fixed capacity):
 // nodes_out[r*cap + p] = v, ksum_out[r*cap + p] = K, slot_idx[r*cap + p] = i, pos[i] = r*cap + p (optional).
 // One global atomic per (workgroup, owner): slots take a rank inside the workgroup from LDS counters (same-address
@@ -381,10 +408,19 @@ __global__ __launch_bounds__(256) void bucket_kernel(const uint32_t* __restrict_
                                                      uint32_t* __restrict__ nodes_out, uint32_t* __restrict__ ksum_out,
                                                      int32_t* __restrict__ slot_idx, int32_t* __restrict__ pos,
                                                      int32_t* __restrict__ counts, uint32_t self_rank,
-                                                     uint32_t* __restrict__ self_nodes, uint32_t* __restrict__ self_ksum) {
+                                                     uint32_t* __restrict__ self_nodes, uint32_t* __restrict__ self_ksum,
+                                                     int32_t own_skip_rank = -1) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t lim = n_valid ? (int64_t)*n_valid : m;
-  const uint32_t v = (i < m && i < lim) ? nodes[i] : GIGL_INVALID;
+  uint32_t v = (i < m && i < lim) ? nodes[i] : GIGL_INVALID;
+  // own_skip_rank >= 0: a node of this rank is not bucketed at all — pos[i] = -1 - (2^30 + its row of the rank's own
+  // table), read in place by the consumer
+  bool own = false;
+  if (own_skip_rank >= 0 && v != GIGL_INVALID && v % world == (uint32_t)own_skip_rank) {
+    if (pos) pos[i] = -1 - ((1 << 30) + (int32_t)(v / world));
+    own = true;
+    v = GIGL_INVALID;
+  }
   const uint32_t r = v == GIGL_INVALID ? 0xFFFFFFFFu : v % world;
   const int lane = threadIdx.x & 63;
   int32_t p = 0;
@@ -413,7 +449,7 @@ __global__ __launch_bounds__(256) void bucket_kernel(const uint32_t* __restrict_
     }
   }
   if (r == 0xFFFFFFFFu) {
-    if (pos && i < m) pos[i] = -1;
+    if (pos && i < m && !own) pos[i] = -1;
     return;
   }
   if (p >= cap) {
@@ -449,16 +485,15 @@ __global__ __launch_bounds__(256) void claim_bucket_kernel(const uint32_t* __res
   const int64_t lim = n_valid ? (int64_t)*n_valid : m;
   uint32_t v = (i < m && i < lim) ? nodes[i] : GIGL_INVALID;
   if (v != GIGL_INVALID && (int64_t)v >= n_global) v = GIGL_INVALID;
+  // this rank's own row: read in place — the consumers find it by arithmetic (id % world == rank -> row id / world of the
+  // rank's table: gather_mean_kernel's own_world), so it is neither stamped nor entered in slot_map
+  if (v != GIGL_INVALID && own_rank >= 0 && v % world == (uint32_t)own_rank) v = GIGL_INVALID;
   if (v != GIGL_INVALID && hot_of) {  // a replicated row: read locally, never requested (row -1-h of the hot table)
     const int32_t h = hot_of[v];
     if (h >= 0) {
       slot_map[v] = -1 - h;
       v = GIGL_INVALID;
     }
-  }
-  if (v != GIGL_INVALID && own_rank >= 0 && v % world == (uint32_t)own_rank) {  // this rank's own row: read in place
-    slot_map[v] = -1 - ((1 << 30) + (int32_t)(v / world));
-    v = GIGL_INVALID;
   }
   if (v != GIGL_INVALID && atomicExch(&stamp[v], tag) == tag) v = GIGL_INVALID;
   const uint32_t r = v == GIGL_INVALID ? 0xFFFFFFFFu : v % world;
@@ -502,10 +537,14 @@ __global__ __launch_bounds__(256) void claim_bucket_kernel(const uint32_t* __res
 __global__ __launch_bounds__(256) void pos_from_map_kernel(const uint32_t* __restrict__ nodes,
                                                            const int32_t* __restrict__ n_valid, int64_t m,
                                                            const int32_t* __restrict__ slot_map, int64_t n_global,
-                                                           int32_t* __restrict__ pos) {
+                                                           int32_t* __restrict__ pos, uint32_t world, int32_t own_rank) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m || i >= (int64_t)*n_valid) return;
   const uint32_t v = nodes[i];
+  if (own_rank >= 0 && v % world == (uint32_t)own_rank) {  // (own rows are not in slot_map: claim_bucket_kernel)
+    pos[i] = -1 - ((1 << 30) + (int32_t)(v / world));
+    return;
+  }
   pos[i] = (int64_t)v < n_global ? slot_map[v] : 0;
 }
 
@@ -770,6 +809,7 @@ struct gigl_dist_plan {
   uint32_t tag = 0;
   int64_t n_global = 0, last_slots = 0;
   // activations
+  bool tiled_layers = false;  // layers >= 1: tiled gather operand + two-source projection (every dims[l], l >= 1, % 4 == 0)
   float* abuf = nullptr;
   float* hbuf[2] = {nullptr, nullptr};
   int64_t act_rows = 0;
@@ -788,6 +828,48 @@ int32_t split_w0(gigl_dist_plan* p) {  // w[0] = [W_l | W_r] row-interleaved -> 
                                           p->ctx->stream));
   GIGL_HIP_CHECK(p->ctx, hipMemcpy2DAsync(p->wr0, in * 4, p->w[0] + in, 2 * in * 4, in * 4, out,
                                           hipMemcpyDeviceToDevice, p->ctx->stream));
+  return GIGL_OK;
+}
+
+// the rows this rank owns are read in place and found by arithmetic: never claimed, requested or served
+bool own_rows_in_place(const gigl_dist_plan* p) { return p->dense && p->own_in_place; }
+// ... and then nothing of a rank's own ever sits in the id / row buckets: their self blocks stay empty (cleared at
+// creation) and no exchange touches them
+bool pull_self_in_place(const gigl_dist_plan* p) { return own_rows_in_place(p) && comm_self_in_place(p->comm); }
+
+// one launch at the start of a call: every bucket and counter the call's phases expect cleared (dist_clear_kernel)
+int32_t clear_call(gigl_dist_plan* p) {
+  ClearSegs sg{};
+  int n = 0;
+  int64_t at = 0;
+  auto add = [&](void* q, int64_t words, uint32_t val) {
+    if (!q || words <= 0) return;
+    sg.p[n] = (uint32_t*)q;
+    sg.words[n] = words;
+    sg.val[n] = val;
+    at += (words + 3) / 4;
+    sg.end[n] = at;
+    ++n;
+  };
+  const int64_t W = p->world;
+  const bool in_place = comm_self_in_place(p->comm);
+  for (int k = 0; k < p->hops; ++k) {
+    if (!(W == 1 && in_place)) add(p->rq_nodes_s[k], W * p->cap[k], 0xFFFFFFFFu);  // (a lone rank buckets into the receive side)
+    if (in_place) add(p->rq_nodes_r[k] + (int64_t)p->rank * p->cap[k], p->cap[k], 0xFFFFFFFFu);
+    add(p->counts[k], W + 1, 0u);
+  }
+  if (!(W == 1 && pull_self_in_place(p))) add(p->ids_s, W * p->pull_cap, 0xFFFFFFFFu);  // (... and requests no row)
+  add(p->pull_counts, W + 1, 0u);
+  if (p->project || p->preproj) {
+    if (!(W == 1 && pull_self_in_place(p))) add(p->idsb_s, W * p->pull_cap_b, 0xFFFFFFFFu);
+    add(p->pullb_counts, W + 1, 0u);
+  }
+  if (n == 0) return GIGL_OK;
+  sg.n = n;
+  int64_t blocks = (at + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(dist_clear_kernel, dim3((unsigned)blocks), dim3(256), 0, p->ctx->stream, sg);
+  GIGL_HIP_CHECK(p->ctx, hipGetLastError());
   return GIGL_OK;
 }
 
@@ -817,11 +899,10 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     const uint32_t* nodes = k == 0 ? roots : p->tree.nbr[k - 1];
     const uint32_t* ksums = k == 0 ? nullptr : p->child_ksum[k - 1];
     const bool in_place = comm_self_in_place(p->comm);
-    const size_t bb = (size_t)world * p->cap[k] * 4;
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->rq_nodes_s[k], 0xFF, bb, st));
-    if (in_place)  // (unused entries of the own block must read as empty too)
-      GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->rq_nodes_r[k] + (int64_t)p->rank * p->cap[k], 0xFF, (size_t)p->cap[k] * 4, st));
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->counts[k], 0, (size_t)(world + 1) * 4, st));
+    if (k == 0) {
+      rc = clear_call(p);
+      if (rc != GIGL_OK) return rc;
+    }
     hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->m[k])), dim3(256), 0, st, nodes, ksums, p->m[k],
                        (const int32_t*)nullptr, world, p->cap[k], p->rq_nodes_s[k], p->rq_ksum_s[k], (int32_t*)nullptr,
                        p->hop_pos[k], p->counts[k], (uint32_t)p->rank, in_place ? p->rq_nodes_r[k] : (uint32_t*)nullptr,
@@ -875,8 +956,6 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     // ---- requester: last scatter, union graph, feature requests
     rc = scatter_hop(p, L - 1, roots);
     if (rc != GIGL_OK) return rc;
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->ids_s, 0xFF, (size_t)world * p->pull_cap * 4, st));
-    GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->pull_counts, 0, (size_t)(world + 1) * 4, st));
     if (p->dense) {
       rc = gigl_union_build_impl(ctx, roots, &p->tree, p->group_roots, &p->un, 1 | (p->shard->multi ? 2 : 0));
       if (rc != GIGL_OK) return rc;
@@ -885,28 +964,31 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
         p->tag = 1;
       }
       const int32_t* n_inner = p->un.meta + GIGL_META_LEVEL0 + (L - 1);
+      const int32_t own = p->own_in_place ? p->rank : -1;
+      const bool self_ip = pull_self_in_place(p);
+      const bool lone = world == 1 && self_ip;  // a lone rank owns every row: nothing to claim, request or serve
       // the inner nodes first (their own rows: pos), then every sampled leaf
-      hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes,
-                         p->act_rows, n_inner, world, p->pull_cap, p->ids_s, p->pull_counts, p->stamp, p->tag,
-                         p->slot_map, p->n_global, (const int32_t*)p->hot_of, p->own_in_place ? p->rank : -1);
-      hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->last_slots)), dim3(256), 0, st,
-                         (const uint32_t*)p->tree.nbr[L - 1], p->last_slots, (const int32_t*)nullptr, world, p->pull_cap,
-                         p->ids_s, p->pull_counts, p->stamp, p->tag, p->slot_map, p->n_global, (const int32_t*)p->hot_of,
-                         p->own_in_place ? p->rank : -1);
+      if (!lone) {
+        hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes,
+                           p->act_rows, n_inner, world, p->pull_cap, p->ids_s, p->pull_counts, p->stamp, p->tag,
+                           p->slot_map, p->n_global, (const int32_t*)p->hot_of, own);
+        hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->last_slots)), dim3(256), 0, st,
+                           (const uint32_t*)p->tree.nbr[L - 1], p->last_slots, (const int32_t*)nullptr, world, p->pull_cap,
+                           p->ids_s, p->pull_counts, p->stamp, p->tag, p->slot_map, p->n_global, (const int32_t*)p->hot_of,
+                           own);
+      }
       hipLaunchKernelGGL(pos_from_map_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes, n_inner,
-                         p->act_rows, p->slot_map, p->n_global, p->pos);
-      if (p->preproj) {  // the inner nodes' own W_r x rows: a second, small pull
-        GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->idsb_s, 0xFF, (size_t)world * p->pull_cap_b * 4, st));
-        GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->pullb_counts, 0, (size_t)(world + 1) * 4, st));
+                         p->act_rows, p->slot_map, p->n_global, p->pos, world, own);
+      if (p->preproj)  // the inner nodes' own W_r x rows: a second, small pull (a rank's own nodes: read in place)
         hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes,
                            (const uint32_t*)nullptr, p->act_rows, n_inner, world, p->pull_cap_b, p->idsb_s,
                            (uint32_t*)nullptr, (int32_t*)nullptr, p->posb, p->pullb_counts, 0u, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr);
-      }
+                           (uint32_t*)nullptr, own);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
-      rc = comm_exchange(p->comm, p->ids_s, p->ids_r, p->pull_cap * 4);
-      if (rc == GIGL_OK) rc = comm_exchange(p->comm, p->pull_counts, p->req_counts, 4);  // (the row blocks' sizes)
-      if (rc == GIGL_OK && p->preproj) rc = comm_exchange(p->comm, p->idsb_s, p->idsb_r, p->pull_cap_b * 4);
+      if (lone) return GIGL_OK;
+      rc = comm_exchange(p->comm, p->ids_s, p->ids_r, p->pull_cap * 4, self_ip);
+      if (rc == GIGL_OK) rc = comm_exchange(p->comm, p->pull_counts, p->req_counts, 4, self_ip);  // (the row blocks' sizes)
+      if (rc == GIGL_OK && p->preproj) rc = comm_exchange(p->comm, p->idsb_s, p->idsb_r, p->pull_cap_b * 4, self_ip);
       return rc;
     }
     rc = gigl_union_build_groups(ctx, roots, &p->tree, p->group_roots, &p->un);
@@ -916,8 +998,6 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
                        p->ids_s, (uint32_t*)nullptr, (int32_t*)nullptr, p->pos, p->pull_counts, 0u, (uint32_t*)nullptr,
                        (uint32_t*)nullptr);
     if (p->project) {
-      GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->idsb_s, 0xFF, (size_t)world * p->pull_cap_b * 4, st));
-      GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->pullb_counts, 0, (size_t)(world + 1) * 4, st));
       hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes,
                          (const uint32_t*)nullptr, p->act_rows, p->un.meta + GIGL_META_LEVEL0 + (L - 1), world,
                          p->pull_cap_b, p->idsb_s, (uint32_t*)nullptr, (int32_t*)nullptr, p->posb, p->pullb_counts,
@@ -934,6 +1014,7 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     const int64_t na = (int64_t)world * p->pull_cap, nb = (int64_t)world * p->pull_cap_b;
     if (!p->project) {
       const bool in_place = comm_self_in_place(p->comm);
+      if (world == 1 && pull_self_in_place(p)) return GIGL_OK;  // (a lone rank requested nothing)
       const uint32_t unit = (p->row_bytes & 15) == 0 ? 16u : ((p->row_bytes & 3) == 0 ? 4u : 2u);
       const uint32_t upr = (uint32_t)(p->row_bytes / unit);
       const char* table = p->preproj ? (const char*)p->preproj : (const char*)p->feat->rows;
@@ -951,7 +1032,7 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
                          world, table + p->row_bytes, p->feat->n, (uint32_t)p->row_bytes, unit, upr, (char*)p->rowsb_s,
                          (int64_t)0, (int64_t)0, (char*)nullptr, stride);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
-      return comm_exchange(p->comm, p->rowsb_s, p->rowsb_r, p->pull_cap_b * p->row_bytes);
+      return comm_exchange(p->comm, p->rowsb_s, p->rowsb_r, p->pull_cap_b * p->row_bytes, pull_self_in_place(p));
     }
     // (entries without a request keep whatever the operand held: their output rows are never read)
     hipLaunchKernelGGL(serve_rows_f32_kernel, dim3((unsigned)grid256(na * 64)), dim3(256), 0, st, p->ids_r, na, world,
@@ -1017,7 +1098,21 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       rc = gigl_gather_project_mixed(ctx, (const float*)p->rows_r, (const float*)p->rowsb_r, dout, dout,
                                      (const uint32_t*)p->pos, p->un.rowptr, p->un.rowend, p->un.col, n_rows, rows_cap,
                                      p->aggr, p->un.meta + GIGL_META_LEVEL0 + (L - 2), p->bias[0], act, p->hbuf[0],
-                                     p->slot_map, (const float*)p->hot_rows, p->preproj, 2 * dout, p->posb);
+                                     p->slot_map, (const float*)p->hot_rows, p->preproj, 2 * dout, p->posb,
+                                     p->own_in_place ? p->world : 0, p->rank);
+      if (rc != GIGL_OK) return rc;
+      continue;
+    }
+    if (l > 0 && p->tiled_layers) {
+      // layers >= 1 as in the one-call plan (pipeline.hip): the gather writes the reduced half only, in the projection's
+      // tiled operand layout; the projection reads the self half from the previous layer's rows (two-source operand)
+      const int d = p->dims[l];
+      rc = gigl_gather_reduce_mixed(ctx, p->hbuf[(l - 1) & 1], GIGL_DTYPE_F32, d, nullptr, p->un.rowptr, p->un.rowend,
+                                    p->un.col, n_rows, rows_cap, p->aggr, nullptr, p->abuf, (d + 31) / 32, nullptr, nullptr,
+                                    nullptr, 1);
+      if (rc != GIGL_OK) return rc;
+      rc = gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
+                             p->hbuf[l & 1], p->hbuf[(l - 1) & 1], nullptr, d, d, nullptr);
       if (rc != GIGL_OK) return rc;
       continue;
     }
@@ -1025,7 +1120,7 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       rc = gigl_gather_reduce_mixed(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, p->un.rowptr,
                                     p->un.rowend, p->un.col, n_rows, rows_cap, p->aggr,
                                     p->un.meta + GIGL_META_LEVEL0 + (L - 2), p->abuf, 0, p->slot_map, p->hot_rows,
-                                    p->feat->rows);
+                                    p->feat->rows, 0, p->own_in_place ? p->world : 0, p->rank);
     else if (l == 0)
       rc = gigl_gather_reduce(ctx, p->rows_r, p->feat->dtype, p->dims[0], (const uint32_t*)p->pos, p->un.rowptr,
                               p->un.rowend, p->un.col, n_rows, rows_cap, p->aggr, p->abuf);
@@ -1336,7 +1431,11 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   }
   // ---- activations
   const int64_t a_cols = 2 * (int64_t)(max_in > max_out ? max_in : max_out);
-  p->abuf = (float*)alloc((size_t)act_rows * a_cols * 4);
+  // (+ whole row tiles of 128 and whole K chunks of 32 for the tiled operand of layers >= 1)
+  p->abuf = (float*)alloc((size_t)(act_rows + 128) * (a_cols + 64) * 4);
+  p->tiled_layers = kind == 0 && getenv("GIGL_DIST_ROW_MAJOR") == nullptr;
+  for (int k = 1; k < hops; ++k)
+    if ((dims[k] & 3) != 0 || dims[k] > 2048) p->tiled_layers = false;
   p->hbuf[0] = (float*)alloc((size_t)act_rows * max_out * 4);
   p->hbuf[1] = hops > 1 ? (float*)alloc((size_t)act_rows * max_out * 4) : p->hbuf[0];
   // ---- overflow flags of the step
@@ -1361,6 +1460,10 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
     hipMemsetAsync(p->stage, 0, (size_t)W * (pc > p->pull_cap_b ? pc : p->pull_cap_b) * dims[0] * 4, ctx->stream);
   }
   hipMemsetAsync(p->rows_r, 0, (size_t)W * pc * p->row_bytes, ctx->stream);
+  // (pull_self_in_place: the id buckets' self blocks are never written — a rank requests no row of its own — and must
+  // read as empty on the owner side)
+  hipMemsetAsync(p->ids_r, 0xFF, (size_t)W * pc * 4, ctx->stream);
+  if (p->idsb_r) hipMemsetAsync(p->idsb_r, 0xFF, (size_t)W * p->pull_cap_b * 4, ctx->stream);
   hipStreamSynchronize(ctx->stream);
   *out = p;
   return GIGL_OK;
@@ -1449,6 +1552,27 @@ int32_t gigl_dist_plan_run(gigl_dist_plan* p, const uint32_t* roots, int32_t sam
   return GIGL_OK;
 }
 
+int32_t gigl_dist_plan_run_interleaved(gigl_dist_plan* const* plans, int32_t n, const uint32_t* const* roots,
+                                       int32_t sampling_seed, float* const* out) {
+  if (!plans || n < 1 || !plans[0]) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx0 = plans[0]->ctx;
+  GIGL_REQUIRE(ctx0, roots && out, "null argument");
+  const int np = n_phases(plans[0]);
+  for (int i = 0; i < n; ++i)
+    GIGL_REQUIRE(ctx0, plans[i] && roots[i] && out[i] && n_phases(plans[i]) == np && plans[i]->comm->kind != GIGL_COMM_LOCAL,
+                 "plans[%d]: not a plan of this rank with the phases of plans[0]", i);
+  GIGL_HIP_CHECK(ctx0, hipSetDevice(ctx0->device));
+  for (int ph = 0; ph < np; ++ph)
+    for (int i = 0; i < n; ++i) {
+      int32_t rc = phase_impl(plans[i], ph, roots[i], sampling_seed, out[i]);
+      if (rc != GIGL_OK) {
+        if (plans[i]->ctx != ctx0) ctx0->err = plans[i]->ctx->err;
+        return rc;
+      }
+    }
+  return GIGL_OK;
+}
+
 int32_t gigl_dist_plan_run_local(gigl_dist_plan* const* plans, int32_t world, const uint32_t* const* roots,
                                  int32_t sampling_seed, float* const* out) {
   if (!plans || world < 1 || !plans[0]) return GIGL_E_INVALID_ARG;
@@ -1497,6 +1621,13 @@ int32_t gigl_dist_plan_batch_graph(gigl_dist_plan* p, int32_t* rowptr, int32_t* 
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const size_t cn = (size_t)p->un.cap_nodes, ce = (size_t)p->un.cap_edges;
+  // A staged step never runs the plan's last phase, which is where the hop / row bucket flags are folded into
+  // meta[GIGL_META_OVERFLOW]: fold them here, before meta is handed out — a batch whose requests did not fit a bucket
+  // (truncated neighbourhoods, NaN feature rows) must read as failed.  (No activation workspace is involved: the
+  // level counts are not held against act_rows.)
+  hipLaunchKernelGGL(fold_overflow_kernel, dim3(1), dim3(64), 0, st, p->un.meta, (const int32_t* const*)p->flag_ptrs,
+                     p->n_flags, p->hops, (int32_t)0x7FFFFFFF);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
   GIGL_HIP_CHECK(ctx, hipMemcpyAsync(rowptr, p->un.rowptr, (cn + 1) * 4, hipMemcpyDeviceToDevice, st));
   GIGL_HIP_CHECK(ctx, hipMemcpyAsync(rowend, p->un.rowend, (cn + 1) * 4, hipMemcpyDeviceToDevice, st));
   if (ce) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(col, p->un.col, ce * 4, hipMemcpyDeviceToDevice, st));

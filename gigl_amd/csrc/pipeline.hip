@@ -75,6 +75,13 @@ struct gigl_sage_plan {
   bool tiled = false;
   bool two_source = false;  // the projection takes the self half of [mean | self] from the source rows (no self copy)
   float* hbuf[2] = {nullptr, nullptr};  // ping-pong [act_rows][max_out]
+  // fused two-layer projection (agg.hip linear_fused2_kernel; two-layer SAGE, hidden 256, 2 * out <= 96, half-split first
+  // layer over an fp32 table): layer 0's projection applies the last layer's [W_l | W_r] to its hidden rows before they
+  // leave the workgroup — hbuf[0] then holds the two K-split planes of p = [W_l h | W_r h] ([2][act_rows][96]) instead of
+  // hidden rows, and the last layer is one reduction over p rows written straight into the caller's `out`
+  bool f2_ok = false;
+  float* f2_dev = nullptr;  // {s_h, s_w2, 1 / (s_h s_w2)}: the second product's scales (gigl_fused2_prepare, per run)
+  void* w2h = nullptr;      // W2's fp16 planes
   std::vector<void*> owned;
   // hipGraph replay
   bool use_graph = false;
@@ -173,6 +180,14 @@ __global__ __launch_bounds__(256) void plan_stats_kernel(StatsArgs a, unsigned l
 // stages of one batch: 0 sample, 1 union, 2+2l gather l, 3+2l linear l, 2+2L take_rows
 int n_stages(const gigl_sage_plan* p) { return 3 + 2 * p->hops; }
 
+// the fused two-layer projection applies to this plan as it is configured now (every input of the decision drops the
+// captured graphs when it changes: weights, reduction, projected input, half split)
+bool fused2_on(const gigl_sage_plan* p) {
+  return p->f2_ok && p->kind == 0 && p->hops == 2 && p->tiled && p->two_source && p->hs0 && !p->proj &&
+         p->feat->dtype == GIGL_DTYPE_F32 && (p->aggr == GIGL_AGGR_MEAN || p->aggr == GIGL_AGGR_SUM) &&
+         (((uintptr_t)p->bias[0]) & 15) == 0;
+}
+
 uint32_t stage_kernel_mask(const gigl_sage_plan* p, int s) {
   if (s == 0) return (1u << GIGL_K_EXPAND) | (1u << GIGL_K_EXPAND_HEAVY) | (1u << GIGL_K_FIND_HEAVY);
   if (s == 1)
@@ -199,11 +214,16 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
   }
   if (s == n_stages(p) - 1) {
     const int dout = p->dims[L];
+    if (fused2_on(p))  // the last layer over the p rows of the fused projection, one row per root, into `out`
+      return gigl_sage_fused_out(ctx, p->hbuf[0], (int64_t)p->act_rows * gigl_fused2_row_floats(), p->un.rowptr, p->un.rowend,
+                                 p->un.col, p->un.root_local, p->b, dout, p->bias[L - 1], p->act_last ? 1 : 0, p->aggr,
+                                 p->un.meta, out);
     gigl_take_rows(ctx->stream, p->hbuf[(L - 1) & 1], p->un.root_local, p->b, dout, p->un.meta, out);
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     return GIGL_OK;
   }
   const int l = (s - 2) >> 1;
+  if (l == 1 && fused2_on(p)) return GIGL_OK;  // (layer 1 runs as the last stage)
   const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
   const int d = p->dims[l];
   // layer l computes the nodes of level <= L-1-l: at most b*(1 + f0 + f0*f1 + ...) of them — the launch is
@@ -279,6 +299,13 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
     const int32_t rc = gigl_hs_scale_update(ctx, p->w[0], (int64_t)p->dims[1] * 2 * d, p->hs_sa, p->hs_dev);
     if (rc != GIGL_OK) return rc;
     hs_scale = p->hs_dev;
+  }
+  if (l == 0 && fused2_on(p)) {
+    int32_t rc = gigl_fused2_prepare(ctx, p->hs_dev, p->bias[0], p->w[1], p->dims[2], 2 * d, p->f2_dev, p->w2h);
+    if (rc != GIGL_OK) return rc;
+    return gigl_linear_fused2(ctx, p->abuf, p->w[0], p->bias[0], n_rows, rows_cap, 2 * d, p->hbuf[0],
+                              (int64_t)p->act_rows * gigl_fused2_row_floats(), (const float*)p->feat->rows, p->un.nodes, d, d,
+                              hs_scale, p->f2_dev, p->w2h);
   }
   if (two_src)
     return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
@@ -576,6 +603,13 @@ static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, in
   if (p->zero_dev && hipMemset(p->zero_dev, 0, 64) != hipSuccess) ok = false;
   p->hs_dev = p->zero_dev ? reinterpret_cast<float*>(p->zero_dev + 4) : nullptr;
   p->act_rows = act_rows;
+  if (with_abuf && hops == 2 && gigl_fused2_shape_ok(dims[0], dims[1], dims[2]) && getenv("GIGL_PLAN_NO_FUSE2") == nullptr &&
+      (int64_t)max_out >= 2 * gigl_fused2_row_floats()) {
+    p->f2_dev = (float*)alloc(64);
+    p->w2h = alloc((size_t)gigl_fused2_w2h_bytes());
+    p->f2_ok = p->f2_dev && p->w2h;
+    ok = ok && p->f2_ok;
+  }
   ok = ok && p->zero_dev && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col && p->un.root_local &&
        (p->abuf || !with_abuf) && p->hbuf[0] && p->hbuf[1] && p->roots_buf && p->out_buf;
   if (!ok) {
@@ -710,6 +744,8 @@ int32_t gigl_sage_plan_set_weights(gigl_sage_plan* p, const float* const* w, con
 }
 
 int32_t gigl_sage_plan_half_split(gigl_sage_plan* p) { return p && p->hs0 ? 1 : 0; }
+
+int32_t gigl_sage_plan_fused_layers(gigl_sage_plan* p) { return p && fused2_on(p) ? 1 : 0; }
 
 int32_t gigl_sage_plan_set_aggr(gigl_sage_plan* p, int32_t aggr) {
   if (!p) return GIGL_E_INVALID_ARG;

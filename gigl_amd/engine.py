@@ -1218,6 +1218,11 @@ class SagePlan:
         """the first projection runs over two fp16 planes per operand (gigl_sage_plan_half_split)"""
         return bool(self._lib.gigl_sage_plan_half_split(self._plan))
 
+    def fused_layers(self) -> bool:
+        """both SAGE layers' projections run in one kernel and the last layer is one reduction over [W_l h | W_r h] rows
+        (gigl_sage_plan_fused_layers)"""
+        return bool(self._lib.gigl_sage_plan_fused_layers(self._plan))
+
     def overflow_add(self, acc: torch.Tensor) -> None:
         """acc (int32 [1], device) += 1 when the batch set run last failed (its rows are NaN): gigl_sage_plan_overflow_add,
         no synchronisation"""

@@ -1074,6 +1074,13 @@ int32_t gigl_sage_plan_set_projected_input(gigl_sage_plan* plan, const float* pr
  * GIGL_GEMM_SPLIT=bf16 in the environment.  GAT plans (gigl_gat_plan_create / _set_weights) take the same decision for
  * their first layer's projection. */
 int32_t gigl_sage_plan_half_split(gigl_sage_plan* plan);
+/* 1 when the plan runs its two SAGE layers' projections in ONE kernel: layer 0's hidden rows are multiplied by the last
+ * layer's [W_l | W_r] before they leave the workgroup (W_l mean_j h_j = mean_j W_l h_j), 2 x out floats per node leave
+ * instead of the hidden row, and the last layer (homogeneous.py:122-126 -> SAGEConv: W_l mean + b + W_r self) is one
+ * reduction over those rows.  Two layers, hidden width 256, 2 x out <= 96, half-split first layer over an fp32 table, a
+ * linear reduction (mean / sum); GIGL_PLAN_NO_FUSE2=1 at plan creation keeps the layers apart (A/B).  Same rows up to
+ * rounding (1e-5 of the fp32 CPU forward: tests/test_gpu_plan.py). */
+int32_t gigl_sage_plan_fused_layers(gigl_sage_plan* plan);
 /* *acc (DEVICE int32, caller-zeroed) += 1 when the batch set the plan ran LAST failed (meta[GIGL_META_OVERFLOW] != 0:
  * its rows are NaN) — enqueued on the ctx stream, no synchronisation: callers that stream many calls add every call's
  * flag into one counter and read it once (gigl_amd/hbm.py) */
@@ -1276,6 +1283,13 @@ int32_t gigl_dist_plan_phase(gigl_dist_plan* plan, int32_t phase, const uint32_t
                              float* out);
 /* all phases of one step on an RCCL / callback communicator */
 int32_t gigl_dist_plan_run(gigl_dist_plan* plan, const uint32_t* roots, int32_t sampling_seed, float* out);
+/* one step of EACH of `n` plans of this rank (their own ctx / stream / communicator each: the plans a rank keeps in
+ * flight), the phases issued interleaved — phase 0 of every plan, then phase 1 of every plan, ... — by one host call, so
+ * that one plan's exchange overlaps another's expansion / forward and every rank issues its collectives in the same order
+ * (what the reference's loader gets from worker processes: python/gigl/distributed/distributed_neighborloader.py:162-192).
+ * RCCL / callback communicators; roots[i] / out[i] belong to plans[i]. */
+int32_t gigl_dist_plan_run_interleaved(gigl_dist_plan* const* plans, int32_t n, const uint32_t* const* roots,
+                                       int32_t sampling_seed, float* const* out);
 /* one step of every rank of an in-process group, phase by phase; plans[r] = rank r's plan */
 int32_t gigl_dist_plan_run_local(gigl_dist_plan* const* plans, int32_t world, const uint32_t* const* roots,
                                  int32_t sampling_seed, float* const* out);

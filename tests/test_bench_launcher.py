@@ -1,5 +1,5 @@
 """bench.py --gpus N: the script launches its own ranks when no launcher did, refuses to measure fewer GPUs than it was
-asked for, and at N > 1 carries the sharded (hash-partitioned graph) sub-record."""
+asked for, and at N > 1 headlines the sharded (hash-partitioned MAG240M-shaped) workload with the replica run as a sub-record."""
 import json
 import os
 import subprocess
@@ -46,11 +46,17 @@ def test_self_launch_two_ranks_on_one_gpu():
     assert len(lines) == 1  # ONE JSON line, from rank 0
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
-    sh = line["sharded"]
-    assert sh["n_gpus"] == 2 and sh["value"] > 0 and sh["roofline_xgmi"]["ranks"] == 2
-    assert sh["config"]["pulled_feature_rows_per_step"] > 0  # rows really travelled between the ranks
-    assert 0 < sh["config"]["row_bucket_fill"] <= 1.0
-    assert "replicated as hot rows" in sh["config"]["workload"]  # hub replication is on by default at world > 1
+    # the N > 1 headline IS the hash-partitioned MAG240M-shaped workload, and says between how many ranks its exchanges ran
+    assert "MAG240M-shaped" in line["config"]["workload"] and "hash-partitioned over 2 rank(s)" in line["config"]["workload"]
+    assert line["comm"]["ranks"] == 2 and line["comm"]["transport"] == "host-callback"  # (gloo here; "rccl" on real GPUs)
+    assert line["rccl_ranks"] == 0  # ... so no RCCL rank is claimed for this functional run
+    assert line["comm"]["xgmi_bytes_per_step_per_gpu_mean"] > 0
+    assert line["roofline_xgmi"]["ranks"] == 2
+    assert line["config"]["pulled_feature_rows_per_step"] > 0  # rows really travelled between the ranks
+    assert 0 < line["config"]["row_bucket_fill"] <= 1.0
+    assert "replicated as hot rows" in line["config"]["workload"]  # hub replication is on by default at world > 1
+    rep = line["replicas"]  # the replica-per-GPU run of the same launch: a sub-record now
+    assert rep["n_gpus"] == 2 and rep["value"] > 0 and "replica per GPU" in rep["config"]["graph"]
 
 
 @pytest.mark.gpu
@@ -68,3 +74,4 @@ def test_a_failing_sharded_sub_record_never_costs_the_headline():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"] is not None
     assert "did not finish" in line["sharded"]["error"]
+    assert line["headline_is"].startswith("FALLBACK") and "replica per GPU" in line["config"]["graph"]

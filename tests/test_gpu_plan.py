@@ -76,6 +76,101 @@ def test_plan_matches_stepwise_and_oracle(setup):
     plan.close()
 
 
+def _oracle_rows(rowptr, col, x, roots, fan, model, L=2):
+    """oracle sample -> collate -> fp32 CPU forward over the whole union graph (the reference's execution order): the
+    roots' rows"""
+    from oracle import gnn_ref
+    nbr_o, _ = oracle.sample_khop(rowptr, col, roots, fan, canonical=True)
+    o = oracle.union_build(roots, fan, nbr_o)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ei = gnn_ref.union_edge_index(o["rowptr"], o["col"])
+    return gnn_ref.graphsage_forward(torch.from_numpy(x[o["nodes"]].astype(np.float32)), ei, sd, L)[o["root_local"]].numpy()
+
+
+@pytest.mark.parametrize("aggr,scale,bias", [("mean", 1.0, True), ("sum", 1.0, True), ("mean", 300.0, True),
+                                             ("mean", 1e-4, False)])
+def test_fused_two_layer_projection_equals_the_separate_layers_and_the_oracle(setup, aggr, scale, bias):
+    """100 -> 256 -> 47 (BASELINE configs[1]'s model): the plan applies the last layer's [W_l | W_r] to the hidden rows
+    inside the first projection (gigl_sage_plan_fused_layers) — same rows as the layers run apart (GIGL_PLAN_NO_FUSE2) and
+    within 1e-5 of the fp32 CPU forward of the reference's execution order; table and weights at several scales (the
+    second product's half split is bounded from the first one's scales), mean and sum, groups of batches"""
+    import os
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE
+    eng0, rowptr, col, x0, n = setup
+    x = (x0 * scale).astype(np.float32)
+    eng = HipEngine(0)
+    eng.load_csc(rowptr, col)
+    eng.load_features(x)
+    torch.manual_seed(11)
+    model = GraphSAGE(100, 256, 47, num_layers=2, conv_kwargs={"aggr": aggr, "bias": bias}).to(eng.device)
+    if scale != 1.0:
+        with torch.no_grad():
+            for q in model.parameters():
+                q.mul_(1.0 / min(scale, 30.0) if scale > 1 else 3.0)
+    b, fan, G = 200, [25, 10], 3
+    plan = model.make_plan(eng, b, fan, groups=G)
+    assert plan.fused_layers()
+    os.environ["GIGL_PLAN_NO_FUSE2"] = "1"
+    try:
+        apart = model.make_plan(eng, b, fan, groups=G)
+    finally:
+        del os.environ["GIGL_PLAN_NO_FUSE2"]
+    assert not apart.fused_layers()
+    rng = np.random.default_rng(7)
+    for it in range(2):
+        roots = rng.integers(0, n, size=G * b).astype(np.uint32)
+        r_dev = torch.from_numpy(roots.view(np.int32)).to(eng.device)
+        out = plan.run(r_dev).cpu().numpy()
+        ref = apart.run(r_dev).cpu().numpy()
+        top = np.abs(ref).max()
+        assert np.isfinite(out).all() and out.shape == (G * b, 47)
+        assert np.abs(out - ref).max() <= 4e-6 * top
+        for gi in range(G if aggr == "mean" else 0):  # (the CPU restatement is SAGEConv's default mean)
+            want = _oracle_rows(rowptr, col, x, roots[gi * b:(gi + 1) * b], fan, model)
+            assert np.abs(out[gi * b:(gi + 1) * b] - want).max() <= 1e-5 * max(np.abs(want).max(), 1e-30)
+    # replayed as a hipGraph: same bits
+    plan.use_graph(True)
+    a1 = plan.run(r_dev).clone()
+    a2 = plan.run(r_dev).clone()
+    assert torch.equal(a1, a2) and np.array_equal(a1.cpu().numpy(), out)
+    plan.close()
+    apart.close()
+    eng.close()
+
+
+def test_bench_size_batch_against_the_oracle_forward():
+    """one B = 1024, [25, 10] batch group of the HEADLINE's shape — a products-shaped power-law graph (2^18 nodes here, the
+    bench's generator and degree skew), D = 100 fp32, GraphSAGE 100 -> 256 -> 47, 64 batches per call as bench.py runs them
+    — against oracle.sample_khop -> union_build -> gnn_ref.graphsage_forward at 1e-5 (homogeneous.py:107-153)"""
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE
+    s, d_ = rmat_edges(18, 6_000_000, seed=2)
+    n = 1 << 18
+    rowptr, col = oracle.build_csc(n, s, d_, is_directed=False)
+    x = np.random.default_rng(1234).standard_normal((n, 100)).astype(np.float32)
+    eng = HipEngine(0)
+    eng.load_csc(rowptr, col)
+    eng.load_features(x)
+    torch.manual_seed(0)
+    model = GraphSAGE(100, 256, 47, num_layers=2).to(eng.device)
+    B, G, fan = 1024, 64, [25, 10]
+    plan = model.make_plan(eng, B, fan, groups=G)
+    plan.use_graph(True)
+    roots = np.random.default_rng(42).permutation(n)[:G * B].astype(np.uint32)
+    r_dev = torch.from_numpy(roots.view(np.int32)).to(eng.device)
+    plan.run(r_dev)
+    out = plan.run(r_dev).cpu().numpy()  # (the replayed graph)
+    assert plan.fused_layers()
+    for gi in (0, 37, G - 1):
+        want = _oracle_rows(rowptr, col, x, roots[gi * B:(gi + 1) * B], fan, model)
+        err = np.abs(out[gi * B:(gi + 1) * B] - want).max()
+        print(f"batch {gi}: max |err| = {err:.3e} of max |row| = {np.abs(want).max():.3e}")
+        assert err <= 1e-5 * np.abs(want).max()
+    plan.close()
+    eng.close()
+
+
 def test_plans_on_several_streams_and_threads(setup):
     """S ctxs sharing one resident graph, each on its own stream and host thread: same results as serial"""
     from gigl_amd.engine import HipEngine
