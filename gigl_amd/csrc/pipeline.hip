@@ -401,6 +401,15 @@ __global__ __launch_bounds__(256) void ce_roots_kernel(const float* __restrict__
   for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
   const float lse = mx + __logf(se);
   const int64_t lab = labels[i];
+  if (lab < 0 || lab >= width) {
+    // (torch's cross_entropy asserts on such a target; here the batch is reported failed — NaN loss, no update — instead
+    // of reading past the row: an ignore_index-style -1 or an output narrower than the label space)
+    if (lane == 0) {
+      loss_rows[i] = __builtin_nanf("");
+      atomicAdd(const_cast<int32_t*>(&meta[GIGL_META_OVERFLOW]), 1);
+    }
+    return;
+  }
   const float inv = 1.0f / (float)n_valid;
   for (int c = lane; c < width; c += 64) {
     const float pr = __expf(row[c] - lse);
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(256) void ce_roots_kernel(const float* __restrict__
 // loss = sum_i loss_rows[i] / n_valid in a fixed order (one workgroup); the optimiser's step counter moves on
 __global__ __launch_bounds__(1024) void loss_sum_kernel(const float* __restrict__ loss_rows, int b,
                                                         const int32_t* __restrict__ n_valid_dev, float* __restrict__ loss,
-                                                        int32_t* __restrict__ step) {
+                                                        int32_t* __restrict__ step, const int32_t* __restrict__ meta) {
   __shared__ float s_p[16];
   float v = 0.f;
   for (int i = threadIdx.x; i < b; i += 1024) v += loss_rows[i];
@@ -423,7 +432,8 @@ __global__ __launch_bounds__(1024) void loss_sum_kernel(const float* __restrict_
     float t = 0.f;
     for (int k = 0; k < 16; ++k) t += s_p[k];
     *loss = t / (float)(*n_valid_dev > 0 ? *n_valid_dev : 1);
-    *step += 1;
+    // (a failed batch applies no update — adam_kernel returns — so Adam's bias-correction exponent must not move either)
+    if (meta[GIGL_META_OVERFLOW] == 0) *step += 1;
   }
 }
 
@@ -946,6 +956,7 @@ struct gigl_sage_train_plan {
                                                // parts — of the next batch and of the one after — can be in flight)
   int32_t cur = 0;                 // workspace of the next step
   bool fetched[TRAIN_WS] = {false};  // the workspace holds the graph of a prefetched batch
+  const uint32_t* fetched_roots[TRAIN_WS] = {nullptr};  // ... announced as these roots (the step must name the same ones)
   hipEvent_t ev_graph[TRAIN_WS] = {nullptr};   // graph part of the workspace done (recorded on its side stream)
   // layers part that read the workspace done (recorded on the caller's stream); [2]: the caller's stream as it stands
   // when a graph part is issued (the roots it is handed were written there)
@@ -1014,7 +1025,7 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
                        (const int32_t*)p->un.root_local, (const int64_t*)t->labels_buf, (const int32_t*)t->n_valid_buf, t->b,
                        (const int32_t*)p->un.meta, t->dh[L - 1], t->loss_rows);
     hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)t->loss_rows, t->b,
-                       (const int32_t*)t->n_valid_buf, t->loss, t->n_valid_buf + 1);
+                       (const int32_t*)t->n_valid_buf, t->loss, t->n_valid_buf + 1, (const int32_t*)p->un.meta);
   }
   // ---- backward
   for (int l = L - 1; l >= 0; --l) {
@@ -1269,7 +1280,10 @@ int32_t gigl_sage_train_plan_step2(gigl_sage_train_plan* t, const uint32_t* root
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int k = t->cur;
-  if (!t->fetched[k]) {  // not prefetched by an earlier step: the graph part of THIS batch now (the layers wait for it)
+  // (a prefetched workspace belongs to the roots it was announced with: an epoch cut short, a reshuffle or an evaluation
+  // between two steps hands in other roots — the graph part is then issued again instead of training these labels
+  // against the old batch's graph; as gigl_hgt_infer_run's guard)
+  if (!t->fetched[k] || t->fetched_roots[k] != roots) {  // the graph part of THIS batch now (the layers wait for it)
     const int32_t rc = train_graph_part(t, k, roots, sampling_seed, mode);
     if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->side[k]));
   }
@@ -1282,10 +1296,11 @@ int32_t gigl_sage_train_plan_step2(gigl_sage_train_plan* t, const uint32_t* root
   const uint32_t* ahead[2] = {roots_next, roots_next ? roots_next2 : nullptr};
   for (int d = 0; d < 2; ++d) {
     const int kk = (k + 1 + d) % TRAIN_WS;
-    if (!ahead[d] || t->fetched[kk] || kk == k) continue;
+    if (!ahead[d] || (t->fetched[kk] && t->fetched_roots[kk] == ahead[d]) || kk == k) continue;
     const int32_t rc = train_graph_part(t, kk, ahead[d], sampling_seed, mode);
     if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->side[kk]));
     t->fetched[kk] = true;
+    t->fetched_roots[kk] = ahead[d];
   }
   // the step's inputs go into the static buffers the (captured) launches read: labels, the number of real roots (a
   // 32-bit fill: no host memory involved, ordered on the stream)

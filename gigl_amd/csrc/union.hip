@@ -28,7 +28,26 @@
 // Rows keep their pre-dedup capacity: row i is col[rowptr[i] .. rowend[i]).
 #include "common.h"
 
+#include <mutex>
+
 #include <cstdlib>
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: a process that drives several GPUs (lane
+// engines, in-process worlds on different devices) must opt in on each of them — done once per (device, site), and
+// UNDER a lock (ctxs of different host threads build union graphs concurrently: the second one must not launch before
+// the first one's opt-in has happened)
+static hipError_t lds_opt_in(int device, int site, const void* fn, int bytes, const void* fn2 = nullptr, int bytes2 = 0) {
+  static std::mutex mu;
+  static uint32_t done[256] = {0};
+  std::lock_guard<std::mutex> lk(mu);
+  const uint32_t bit = 1u << site;
+  uint32_t& d = done[device & 255];
+  if (d & bit) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && fn2) e = hipFuncSetAttribute(fn2, hipFuncAttributeMaxDynamicSharedMemorySize, bytes2);
+  if (e == hipSuccess) d |= bit;
+  return e;
+}
 
 namespace {
 
@@ -1728,13 +1747,7 @@ int32_t union_build_lg2(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
     if (blocks < 64) blocks = 64;
     hipLaunchKernelGGL(lg2_row_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, sort_rows, sort_count,
                        out->rowptr, out->rowend, out->col, big_rows, big_count, edge_counters);
-    static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs the opt-in once per process
-    if (!lds_attr_set) {
-      GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)lg2_row_sort_big_kernel,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
-      lds_attr_set = true;
-    }
+    GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 0, (const void*)lg2_row_sort_big_kernel, 2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
     // (a handful of workgroups: each needs most of a CU's LDS, and rows of more than MED_ROW entries are rare)
     hipLaunchKernelGGL(lg2_row_sort_big_kernel, dim3(8), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st,
                        out->rowptr, out->rowend, out->col, big_rows, big_count, out->meta + GIGL_META_OVERFLOW,
@@ -2549,15 +2562,8 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   int32_t* tile_counts = zeros + 64 + 32 * EC_STRIDE;
   const int TB = 256;
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
-  static bool lds_attr_set = false;  // more than 64 KiB of dynamic LDS needs the opt-in once per process
-  if (!lds_attr_set) {
-    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)lg3_dedup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            150 * 1024));
-    GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)lg2_row_sort_big_kernel,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
-    lds_attr_set = true;
-  }
+  GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 1, (const void*)lg3_dedup_kernel, 150 * 1024, (const void*)lg2_row_sort_big_kernel,
+                                 2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_INSERT);
     hipLaunchKernelGGL(lg3_init_kernel, dim3(256), dim3(256), 0, st, a.rowcnt, T_in, zeros, zero_words, out->meta);
@@ -2791,13 +2797,7 @@ int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_t
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(row_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out->meta, hops, out->rowptr,
                        out->rowend, out->col, big_rows, big_count, a.alias_base, out->meta);
-    static bool lds_attr_set = false;  // 128 KiB of dynamic LDS needs the opt-in once per process
-    if (!lds_attr_set) {
-      GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)row_sort_big_kernel,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
-      lds_attr_set = true;
-    }
+    GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 2, (const void*)row_sort_big_kernel, 2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
     hipLaunchKernelGGL(row_sort_big_kernel, dim3(256), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st,
                        out->rowptr, out->rowend, out->col, big_rows, big_count, out->meta + GIGL_META_OVERFLOW);
   }

@@ -509,3 +509,41 @@ def test_staged_plan_hands_out_the_training_batch_of_a_sharded_graph(world, dtyp
         c.close()
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("knob", ["pull_cap", "hop_slack"])
+def test_staged_plan_reports_bucket_overflow(knob):
+    """a staged step never runs the plan's last phase — where the hop / row bucket flags used to be folded into
+    meta[GIGL_META_OVERFLOW] — so gigl_dist_plan_batch_graph folds them before it hands meta out: a batch whose requests
+    did not fit a bucket (truncated neighbourhoods, NaN feature rows) reads as FAILED, never as a batch"""
+    from gigl_amd.dist import Comm, DistSagePlan
+    rowptr, col, x = make_graph()
+    world, b = 3, 64
+    st = torch.cuda.Stream()
+    engs = [shard_engine(rowptr, col, x, r, world, torch.float32, st) for r in range(world)]
+    comms = Comm.local(engs)
+    dev = engs[0].device
+    w = [torch.zeros((4, 2 * D), device=dev), torch.zeros((4, 8), device=dev)]
+    kw = dict(pull_cap=8) if knob == "pull_cap" else dict(hop_slack=1e-6)
+    plans = [DistSagePlan(comms[r], w, [None, None], b if knob == "pull_cap" else 4096, FAN,
+                          max_window_end=bound_for(rowptr), staged=True, **kw) for r in range(world)]
+    nb = plans[0].b
+    if knob == "pull_cap":
+        roots_h = [rank_roots(r, b) for r in range(world)]
+    else:  # every root owned by rank 0: its hop-0 request bucket (nb / world + slack) cannot hold them
+        roots_h = [(np.random.default_rng(200 + r).integers(0, N // world, size=nb) * world).astype(np.uint32) for r in range(world)]
+    roots_d = [torch.from_numpy(r_.view(np.int32)).to(dev) for r_ in roots_h]
+    with torch.cuda.stream(st):
+        DistSagePlan.sample_and_pull_local(plans, roots_d)
+        got = [p.batch_tensors() for p in plans]
+    st.synchronize()
+    assert any(int(t["meta"].cpu()[8]) != 0 for t in got), "an overflowed staged step must be flagged in meta"
+    for r in range(world):
+        if int(got[r]["meta"].cpu()[8]) != 0:
+            assert plans[r].overflowed()
+    for p in plans:
+        p.close()
+    for c in comms:
+        c.close()
+    for e in engs:
+        e.close()

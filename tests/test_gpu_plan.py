@@ -100,6 +100,9 @@ def test_fused_two_layer_projection_equals_the_separate_layers_and_the_oracle(se
     eng0, rowptr, col, x0, n = setup
     x = (x0 * scale).astype(np.float32)
     eng = HipEngine(0)
+    st = torch.cuda.Stream()
+    eng.bind_stream(st)  # (hipGraph replay needs a created stream)
+    torch.cuda.set_stream(st)
     eng.load_csc(rowptr, col)
     eng.load_features(x)
     torch.manual_seed(11)
@@ -134,6 +137,7 @@ def test_fused_two_layer_projection_equals_the_separate_layers_and_the_oracle(se
     a1 = plan.run(r_dev).clone()
     a2 = plan.run(r_dev).clone()
     assert torch.equal(a1, a2) and np.array_equal(a1.cpu().numpy(), out)
+    torch.cuda.set_stream(torch.cuda.default_stream())
     plan.close()
     apart.close()
     eng.close()
@@ -150,6 +154,9 @@ def test_bench_size_batch_against_the_oracle_forward():
     rowptr, col = oracle.build_csc(n, s, d_, is_directed=False)
     x = np.random.default_rng(1234).standard_normal((n, 100)).astype(np.float32)
     eng = HipEngine(0)
+    st = torch.cuda.Stream()
+    eng.bind_stream(st)
+    torch.cuda.set_stream(st)
     eng.load_csc(rowptr, col)
     eng.load_features(x)
     torch.manual_seed(0)
@@ -167,6 +174,7 @@ def test_bench_size_batch_against_the_oracle_forward():
         err = np.abs(out[gi * B:(gi + 1) * B] - want).max()
         print(f"batch {gi}: max |err| = {err:.3e} of max |row| = {np.abs(want).max():.3e}")
         assert err <= 1e-5 * np.abs(want).max()
+    torch.cuda.set_stream(torch.cuda.default_stream())
     plan.close()
     eng.close()
 
