@@ -67,6 +67,7 @@ SYMBOLS = [
 KERNEL_IDS = {
     "expand": 0, "expand_heavy": 1, "find_heavy": 2, "union_insert": 3, "union_relax": 4, "union_nodes": 5,
     "union_edge_sort": 6, "union_csr": 7, "gather_mean": 8, "linear": 9, "gather_bwd": 10,
+    "dist_prep": 11, "dist_serve": 12,
 }
 
 

@@ -468,6 +468,8 @@ __global__ __launch_bounds__(256) void bucket_kernel(const uint32_t* __restrict_
   if (pos) pos[i] = (int32_t)e;
 }
 
+constexpr uint32_t DIST_HOT_STAMP = 0xFFFFFFFFu;  // stamp of a replicated (hot) id: above every tag
+
 // Dense pull bookkeeping (two-hop plans): a node id is requested ONCE per call — the first thread to stamp it with the
 // call's tag wins, takes the next entry of its owner's bucket and records that entry in slot_map[id]; everybody else
 // (other occurrences, other batches of the call) finds it there.  Replaces hashing the leaves into the union's node
@@ -478,8 +480,7 @@ __global__ __launch_bounds__(256) void claim_bucket_kernel(const uint32_t* __res
                                                            int64_t cap, uint32_t* __restrict__ ids_out,
                                                            int32_t* __restrict__ counts, uint32_t* __restrict__ stamp,
                                                            uint32_t tag, int32_t* __restrict__ slot_map,
-                                                           int64_t n_global, const int32_t* __restrict__ hot_of,
-                                                           int32_t own_rank) {
+                                                           int64_t n_global, int32_t own_rank) {
   __shared__ int32_t s_cnt[64], s_base[64];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t lim = n_valid ? (int64_t)*n_valid : m;
@@ -488,14 +489,13 @@ __global__ __launch_bounds__(256) void claim_bucket_kernel(const uint32_t* __res
   // this rank's own row: read in place — the consumers find it by arithmetic (id % world == rank -> row id / world of the
   // rank's table: gather_mean_kernel's own_world), so it is neither stamped nor entered in slot_map
   if (v != GIGL_INVALID && own_rank >= 0 && v % world == (uint32_t)own_rank) v = GIGL_INVALID;
-  if (v != GIGL_INVALID && hot_of) {  // a replicated row: read locally, never requested (row -1-h of the hot table)
-    const int32_t h = hot_of[v];
-    if (h >= 0) {
-      slot_map[v] = -1 - h;
-      v = GIGL_INVALID;
-    }
+  // tags only grow, so atomicMax returns the call that last requested the id: this one -> somebody holds its entry
+  // already; DIST_HOT_STAMP (never overwritten by a max) -> a replicated row, read locally through its permanent
+  // slot_map entry -1-h (gigl_dist_plan_set_hot_rows) and never requested.  One random access per occurrence.
+  if (v != GIGL_INVALID) {
+    const uint32_t was = atomicMax(&stamp[v], tag);
+    if (was == tag || was == DIST_HOT_STAMP) v = GIGL_INVALID;
   }
-  if (v != GIGL_INVALID && atomicExch(&stamp[v], tag) == tag) v = GIGL_INVALID;
   const uint32_t r = v == GIGL_INVALID ? 0xFFFFFFFFu : v % world;
   const int lane = threadIdx.x & 63;
   int32_t p = 0;
@@ -531,6 +531,14 @@ __global__ __launch_bounds__(256) void claim_bucket_kernel(const uint32_t* __res
   const int64_t e = (int64_t)r * cap + p;
   ids_out[e] = v;
   slot_map[v] = (int32_t)e;
+}
+
+// stamps back to 0: all == 1 the hot marks (a new hot set is coming), all == 0 everything BUT the hot marks (tag wrap)
+__global__ __launch_bounds__(256) void hot_unmark_kernel(uint32_t* __restrict__ stamp, int64_t n, int all_hot) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool hot = stamp[i] == DIST_HOT_STAMP;
+  if (all_hot ? hot : !hot) stamp[i] = 0u;
 }
 
 // pos[i] = receive-buffer row of union node i (its own feature row)
@@ -572,6 +580,46 @@ __global__ __launch_bounds__(256) void serve_rows_copy_kernel(const uint32_t* __
   if (unit == 16) *(uint4*)op = *(const uint4*)sp;
   else if (unit == 4) *(uint32_t*)op = *(const uint32_t*)sp;
   else *(uint16_t*)op = *(const uint16_t*)sp;
+}
+
+// the same copy for rows made of 16-byte units (every shape the plans produce): a wave takes RPW entries at a time, lane l
+// the units l, l + 64, ... of each of them — the RPW rows' loads are issued before the first store, so a 1-KB row costs a
+// wave one load + one store instruction per row with four rows in flight (the flat kernel above keeps ONE 16-byte load
+// in flight per thread: 2.7 TB/s of copy on the emulated 8-rank world, round 5)
+template <int RPW>
+__global__ __launch_bounds__(256) void serve_rows_wave_kernel(const uint32_t* __restrict__ ids, int64_t n_entries,
+                                                              uint32_t world, const char* __restrict__ rows,
+                                                              int64_t n_rows, uint32_t row_bytes, uint32_t upr,
+                                                              char* __restrict__ out, int64_t self_lo, int64_t self_hi,
+                                                              char* __restrict__ self_out, int64_t src_stride) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t e0 = wave * RPW;
+  if (e0 >= n_entries) return;
+  const char* sp[RPW];
+  char* op[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int64_t e = e0 + r;
+    sp[r] = nullptr;
+    op[r] = nullptr;
+    if (e >= n_entries) continue;
+    const uint32_t v = ids[e];
+    if (v == GIGL_INVALID) continue;
+    const int64_t row = (int64_t)(v / world);
+    if (row >= n_rows) continue;
+    sp[r] = rows + row * (src_stride ? src_stride : (int64_t)row_bytes);
+    op[r] = ((self_out && e >= self_lo && e < self_hi) ? self_out : out) + e * (int64_t)row_bytes;
+  }
+  for (uint32_t u = lane; u < upr; u += 64) {
+    uint4 v[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+      if (sp[r]) v[r] = *reinterpret_cast<const uint4*>(sp[r] + (int64_t)u * 16);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+      if (sp[r]) *reinterpret_cast<uint4*>(op[r] + (int64_t)u * 16) = v[r];
+  }
 }
 
 // requester side, staged plans: union node i's pulled row (row pos[i] of the receive buffer) widened to fp32 at row i of
@@ -801,8 +849,8 @@ struct gigl_dist_plan {
   // dense mode: a rank's OWN rows are never requested, served or copied — the aggregation reads them from the feature
   // table (GIGL_DIST_COPY_OWN_ROWS=1: through the receive buffer like everybody else's, for measurements)
   bool own_in_place = false;
-  // replicated hot rows (gigl_dist_plan_set_hot_rows): hot_of[id] = row of the id in hot_rows, -1 = not replicated
-  int32_t* hot_of = nullptr;
+  // replicated hot rows (gigl_dist_plan_set_hot_rows)
+  bool has_hot = false;  // stamp[] carries DIST_HOT_STAMP marks (and slot_map[] the rows' entries -1-h)
   const void* hot_rows = nullptr;
   uint32_t* stamp = nullptr;   // [n_global] tag of the call that last requested the id
   int32_t* slot_map = nullptr; // [n_global] receive-buffer row of the id in that call
@@ -868,7 +916,30 @@ int32_t clear_call(gigl_dist_plan* p) {
   sg.n = n;
   int64_t blocks = (at + 255) / 256;
   if (blocks > 1024) blocks = 1024;
+  gigl_prof_scope ps(p->ctx, GIGL_K_DIST_PREP);
   hipLaunchKernelGGL(dist_clear_kernel, dim3((unsigned)blocks), dim3(256), 0, p->ctx->stream, sg);
+  GIGL_HIP_CHECK(p->ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+// owner side of a row pull: entries -> their rows in the send buffer (the self block straight into the receive buffer)
+int32_t serve_rows(gigl_dist_plan* p, const uint32_t* ids, int64_t n_entries, const char* table, int64_t stride, char* out,
+                   int64_t self_lo, int64_t self_hi, char* self_out) {
+  gigl_prof_scope ps(p->ctx, GIGL_K_DIST_SERVE);
+  hipStream_t st = p->ctx->stream;
+  const uint32_t world = (uint32_t)p->world;
+  if ((p->row_bytes & 15) == 0 && ((uintptr_t)table & 15) == 0 && (stride & 15) == 0) {
+    constexpr int RPW = 4;
+    const int64_t waves = (n_entries + RPW - 1) / RPW;
+    hipLaunchKernelGGL(serve_rows_wave_kernel<RPW>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ids, n_entries, world,
+                       table, p->feat->n, (uint32_t)p->row_bytes, (uint32_t)(p->row_bytes / 16), out, self_lo, self_hi,
+                       self_out, stride);
+  } else {
+    const uint32_t unit = (p->row_bytes & 3) == 0 ? 4u : 2u;
+    const uint32_t upr = (uint32_t)(p->row_bytes / unit);
+    hipLaunchKernelGGL(serve_rows_copy_kernel, dim3((unsigned)grid256(n_entries * upr)), dim3(256), 0, st, ids, n_entries,
+                       world, table, p->feat->n, (uint32_t)p->row_bytes, unit, upr, out, self_lo, self_hi, self_out, stride);
+  }
   GIGL_HIP_CHECK(p->ctx, hipGetLastError());
   return GIGL_OK;
 }
@@ -876,6 +947,7 @@ int32_t clear_call(gigl_dist_plan* p) {
 // hop k's answers -> tree slots, counts and the children's path sums (K of a root's path is the root id)
 int32_t scatter_hop(gigl_dist_plan* p, int k, const uint32_t* roots) {
   const int64_t total = p->m[k] * p->fan[k];
+  gigl_prof_scope ps(p->ctx, GIGL_K_DIST_PREP);
   hipLaunchKernelGGL(scatter_slots_kernel, dim3((unsigned)grid256(total)), dim3(256), 0, p->ctx->stream, p->resp_r[k],
                      p->hop_pos[k], k == 0 ? roots : p->child_ksum[k - 1], p->m[k], p->fan[k], p->tree.nbr[k],
                      p->tree.cnt[k], p->child_ksum[k]);
@@ -903,10 +975,13 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       rc = clear_call(p);
       if (rc != GIGL_OK) return rc;
     }
-    hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->m[k])), dim3(256), 0, st, nodes, ksums, p->m[k],
-                       (const int32_t*)nullptr, world, p->cap[k], p->rq_nodes_s[k], p->rq_ksum_s[k], (int32_t*)nullptr,
-                       p->hop_pos[k], p->counts[k], (uint32_t)p->rank, in_place ? p->rq_nodes_r[k] : (uint32_t*)nullptr,
-                       in_place ? p->rq_ksum_r[k] : (uint32_t*)nullptr);
+    {
+      gigl_prof_scope ps(ctx, GIGL_K_DIST_PREP);
+      hipLaunchKernelGGL(bucket_kernel, dim3((unsigned)grid256(p->m[k])), dim3(256), 0, st, nodes, ksums, p->m[k],
+                         (const int32_t*)nullptr, world, p->cap[k], p->rq_nodes_s[k], p->rq_ksum_s[k], (int32_t*)nullptr,
+                         p->hop_pos[k], p->counts[k], (uint32_t)p->rank, in_place ? p->rq_nodes_r[k] : (uint32_t*)nullptr,
+                         in_place ? p->rq_ksum_r[k] : (uint32_t*)nullptr);
+    }
     GIGL_HIP_CHECK(ctx, hipGetLastError());
     if (p->overlap) {
       // the own block sits in the receive buffer already (bucket_kernel wrote it there): expand it NOW, on the side
@@ -959,23 +1034,23 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     if (p->dense) {
       rc = gigl_union_build_impl(ctx, roots, &p->tree, p->group_roots, &p->un, 1 | (p->shard->multi ? 2 : 0));
       if (rc != GIGL_OK) return rc;
-      if (++p->tag == 0) {  // (the tag wrapped: forget every stamp)
-        GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->stamp, 0, (size_t)p->n_global * 4, st));
+      if (++p->tag == DIST_HOT_STAMP) {  // (the tags are used up: forget every stamp but the hot marks)
+        hipLaunchKernelGGL(hot_unmark_kernel, dim3((unsigned)grid256(p->n_global)), dim3(256), 0, st, p->stamp, p->n_global, 0);
         p->tag = 1;
       }
       const int32_t* n_inner = p->un.meta + GIGL_META_LEVEL0 + (L - 1);
       const int32_t own = p->own_in_place ? p->rank : -1;
       const bool self_ip = pull_self_in_place(p);
       const bool lone = world == 1 && self_ip;  // a lone rank owns every row: nothing to claim, request or serve
+      gigl_prof_scope ps(ctx, GIGL_K_DIST_PREP);
       // the inner nodes first (their own rows: pos), then every sampled leaf
       if (!lone) {
         hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes,
                            p->act_rows, n_inner, world, p->pull_cap, p->ids_s, p->pull_counts, p->stamp, p->tag,
-                           p->slot_map, p->n_global, (const int32_t*)p->hot_of, own);
+                           p->slot_map, p->n_global, own);
         hipLaunchKernelGGL(claim_bucket_kernel, dim3((unsigned)grid256(p->last_slots)), dim3(256), 0, st,
                            (const uint32_t*)p->tree.nbr[L - 1], p->last_slots, (const int32_t*)nullptr, world, p->pull_cap,
-                           p->ids_s, p->pull_counts, p->stamp, p->tag, p->slot_map, p->n_global, (const int32_t*)p->hot_of,
-                           own);
+                           p->ids_s, p->pull_counts, p->stamp, p->tag, p->slot_map, p->n_global, own);
       }
       hipLaunchKernelGGL(pos_from_map_kernel, dim3((unsigned)grid256(p->act_rows)), dim3(256), 0, st, p->un.nodes, n_inner,
                          p->act_rows, p->slot_map, p->n_global, p->pos, world, own);
@@ -1015,23 +1090,17 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     if (!p->project) {
       const bool in_place = comm_self_in_place(p->comm);
       if (world == 1 && pull_self_in_place(p)) return GIGL_OK;  // (a lone rank requested nothing)
-      const uint32_t unit = (p->row_bytes & 15) == 0 ? 16u : ((p->row_bytes & 3) == 0 ? 4u : 2u);
-      const uint32_t upr = (uint32_t)(p->row_bytes / unit);
       const char* table = p->preproj ? (const char*)p->preproj : (const char*)p->feat->rows;
       const int64_t stride = p->preproj ? 2 * p->row_bytes : 0;  // ([W_l x | W_r x]: a served row is half a table row)
-      hipLaunchKernelGGL(serve_rows_copy_kernel, dim3((unsigned)grid256(na * upr)), dim3(256), 0, st, p->ids_r, na,
-                         world, table, p->feat->n, (uint32_t)p->row_bytes, unit, upr,
-                         (char*)p->rows_s, (int64_t)p->rank * p->pull_cap, (int64_t)(p->rank + 1) * p->pull_cap,
-                         in_place ? (char*)p->rows_r : (char*)nullptr, stride);
-      GIGL_HIP_CHECK(ctx, hipGetLastError());
+      rc = serve_rows(p, p->ids_r, na, table, stride, (char*)p->rows_s, (int64_t)p->rank * p->pull_cap,
+                      (int64_t)(p->rank + 1) * p->pull_cap, in_place ? (char*)p->rows_r : (char*)nullptr);
+      if (rc != GIGL_OK) return rc;
       // only the requested rows travel: the head of each block (comm_exchange_rows)
       rc = comm_exchange_rows(p->comm, p->rows_s, p->rows_r, p->pull_cap * p->row_bytes, p->req_counts, p->pull_counts,
                               p->row_bytes, in_place);
       if (rc != GIGL_OK || !p->preproj) return rc;
-      hipLaunchKernelGGL(serve_rows_copy_kernel, dim3((unsigned)grid256(nb * upr)), dim3(256), 0, st, p->idsb_r, nb,
-                         world, table + p->row_bytes, p->feat->n, (uint32_t)p->row_bytes, unit, upr, (char*)p->rowsb_s,
-                         (int64_t)0, (int64_t)0, (char*)nullptr, stride);
-      GIGL_HIP_CHECK(ctx, hipGetLastError());
+      rc = serve_rows(p, p->idsb_r, nb, table + p->row_bytes, stride, (char*)p->rowsb_s, (int64_t)0, (int64_t)0, (char*)nullptr);
+      if (rc != GIGL_OK) return rc;
       return comm_exchange(p->comm, p->rowsb_s, p->rowsb_r, p->pull_cap_b * p->row_bytes, pull_self_in_place(p));
     }
     // (entries without a request keep whatever the operand held: their output rows are never read)
@@ -1470,14 +1539,14 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
 }
 
 namespace {
-__global__ __launch_bounds__(256) void hot_fill_kernel(int32_t* hot_of, int64_t n) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) hot_of[i] = -1;
-}
+// replicated ids carry DIST_HOT_STAMP in stamp[] and their permanent entry -1-h in slot_map[]
 __global__ __launch_bounds__(256) void hot_scatter_kernel(const uint32_t* __restrict__ ids, int64_t n_hot, int64_t n_global,
-                                                          int32_t* __restrict__ hot_of) {
+                                                          uint32_t* __restrict__ stamp, int32_t* __restrict__ slot_map) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_hot && (int64_t)ids[i] < n_global) hot_of[ids[i]] = (int32_t)i;
+  if (i < n_hot && (int64_t)ids[i] < n_global) {
+    stamp[ids[i]] = DIST_HOT_STAMP;
+    slot_map[ids[i]] = -1 - (int32_t)i;
+  }
 }
 }  // namespace
 
@@ -1487,16 +1556,12 @@ int32_t gigl_dist_plan_set_hot_rows(gigl_dist_plan* p, const uint32_t* hot_ids, 
   GIGL_REQUIRE(ctx, p->dense, "replicated hot rows need the dense pull bookkeeping (two hops, raw rows)");
   GIGL_REQUIRE(ctx, n_hot >= 0 && n_hot < ((int64_t)1 << 31) && (n_hot == 0 || (hot_ids && hot_rows)), "bad hot set");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (!p->hot_of) {
-    void* q = nullptr;
-    if (hipMalloc(&q, (size_t)p->n_global * 4) != hipSuccess) return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the hot map failed");
-    p->owned.push_back(q);
-    p->hot_of = (int32_t*)q;
-  }
-  hipLaunchKernelGGL(hot_fill_kernel, dim3((unsigned)grid256(p->n_global)), dim3(256), 0, ctx->stream, p->hot_of, p->n_global);
+  if (p->has_hot)  // (the previous set's marks)
+    hipLaunchKernelGGL(hot_unmark_kernel, dim3((unsigned)grid256(p->n_global)), dim3(256), 0, ctx->stream, p->stamp, p->n_global, 1);
   if (n_hot > 0)
     hipLaunchKernelGGL(hot_scatter_kernel, dim3((unsigned)grid256(n_hot)), dim3(256), 0, ctx->stream, hot_ids, n_hot,
-                       p->n_global, p->hot_of);
+                       p->n_global, p->stamp, p->slot_map);
+  p->has_hot = n_hot > 0;
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (hot_ids may be freed by the caller after this returns)
   p->hot_rows = n_hot > 0 ? hot_rows : nullptr;  // (n_hot == 0: back to "nothing replicated")

@@ -1789,6 +1789,8 @@ constexpr uint32_t LG3_CODE_MASK = (1u << LG3_CODE_BITS) - 1u;
 constexpr uint32_t LG3_EMPTY = 0xFFFFFFFFu;
 constexpr int32_t LG3_XTAG = 1 << 30;  // fpx entry that has become (local id | LG3_XTAG): an extra that is a first occurrence
 constexpr int LG3_MAX_PARTS = 16;
+constexpr int LG3_NT_DEFAULT = 512;      // threads per dedup workgroup (round 5: 512 x 128-KB tables find a CU sooner next to other kernels than 1024 — 7.0 vs 10.7 us/step under three streams; smaller tables lose to their redundant stream scans: profiles/r05d_lg3_shapes.txt)
+constexpr int LG3_CAP_DEFAULT = 16384;   // slots of its LDS table (8 bytes each)
 
 struct Lg3Args {
   const uint32_t* roots;
@@ -1898,7 +1900,9 @@ __device__ __forceinline__ bool lg3_row_is_segment(const Lg3Args& a, uint32_t co
 
 constexpr int LG3_TC = 5;  // per-tile counts: level-0 firsts, level-1 firsts, row entries to store, long / tiny rows to sort
 
-__global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* tile_counts, int32_t n_tiles,
+// NT: threads per workgroup (1024, or 512 with smaller tables: more, smaller workgroups that fit next to other kernels)
+template <int NT>
+__global__ __launch_bounds__(NT) void lg3_dedup_kernel(Lg3Args a, int32_t* tile_counts, int32_t n_tiles,
                                                          int32_t* ticket, int32_t* sort_count, int32_t* tiny_count) {
   extern __shared__ unsigned long long lg3_lds[];
   unsigned long long* table = lg3_lds;                                      // [cmask + 1]
@@ -1906,7 +1910,7 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
   uint32_t* bloom = rset + (a.rmask + 1u);                                  // [(rmask + 1) / 4] words: 8 bits per set slot
   int32_t* tcnt = reinterpret_cast<int32_t*>(bloom + ((a.rmask + 1u) >> 2));  // [nt_r + nt_h][LG3_TC]
   __shared__ int32_t s_last;
-  __shared__ int32_t s_w[16][LG3_TC];
+  __shared__ int32_t s_w[NT / 64][LG3_TC];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   // the P workgroups of a batch read the same stream: ids that are consecutive mod 8 share an XCD's L2
   uint32_t vid = blockIdx.x;
@@ -1916,14 +1920,14 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
   const int64_t r0 = (int64_t)grp * a.gr, p0 = (int64_t)grp * a.S0g;
   const int32_t tile_lo_r = (int32_t)(r0 >> 10), nt_r = (int32_t)((r0 + a.gr - 1) >> 10) - tile_lo_r + 1;
   const int32_t tile_lo_h = (int32_t)((a.b + p0) >> 10), nt_h = (int32_t)((a.b + p0 + a.S0g - 1) >> 10) - tile_lo_h + 1;
-  for (uint32_t i = tid; i <= a.cmask; i += 1024) table[i] = ~0ull;
-  for (uint32_t i = tid; i <= a.rmask; i += 1024) rset[i] = GIGL_INVALID;
-  for (uint32_t i = tid; i < ((a.rmask + 1u) >> 2); i += 1024) bloom[i] = 0u;
-  for (int i = tid; i < LG3_TC * (nt_r + nt_h); i += 1024) tcnt[i] = 0;
+  for (uint32_t i = tid; i <= a.cmask; i += NT) table[i] = ~0ull;
+  for (uint32_t i = tid; i <= a.rmask; i += NT) rset[i] = GIGL_INVALID;
+  for (uint32_t i = tid; i < ((a.rmask + 1u) >> 2); i += NT) bloom[i] = 0u;
+  for (int i = tid; i < LG3_TC * (nt_r + nt_h); i += NT) tcnt[i] = 0;
   __syncthreads();
   int32_t over = 0;
   // ---- roots: all of them into the root set (+ its one-read filter), this partition's into the table
-  for (int32_t tl = tid; tl < a.gr; tl += 1024) {
+  for (int32_t tl = tid; tl < a.gr; tl += NT) {
     const uint32_t id = a.roots[r0 + tl];
     if (id == GIGL_INVALID) continue;
     const uint32_t h = hash_u32(id);
@@ -1944,13 +1948,13 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
   // waves per SIMD its table leaves room for).  Whether a slot's node is a root is decided here once (one filter read,
   // the exact set only on a hit) and kept as a bit per slot for the second pass.
   constexpr int PF = 8;
-  unsigned long long rootmask = 0;  // bit (slot / 1024) of this thread: the slot's node is a root
-  for (int32_t base = 0, it0 = 0; base < a.S0g; base += PF * 1024, it0 += PF) {
+  unsigned long long rootmask = 0;  // bit (slot / NT) of this thread: the slot's node is a root
+  for (int32_t base = 0, it0 = 0; base < a.S0g; base += PF * NT, it0 += PF) {
     uint32_t ids[PF], hh[PF], sl[PF], bw[PF];
     uint32_t pend = 0, valid = 0;
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int32_t pl = base + u * 1024 + tid;
+      const int32_t pl = base + u * NT + tid;
       ids[u] = pl < a.S0g ? a.nbr0[p0 + pl] : GIGL_INVALID;
     }
 #pragma unroll
@@ -1974,14 +1978,14 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
       for (int u = 0; u < PF; ++u)
         if (pend >> u & 1u)
           old[u] = atomicCAS(&table[sl[u]], ~0ull,
-                             ((unsigned long long)ids[u] << 32) | ((unsigned long long)(uint32_t)(a.gr + base + u * 1024 + tid) << 1) | 1ull);
+                             ((unsigned long long)ids[u] << 32) | ((unsigned long long)(uint32_t)(a.gr + base + u * NT + tid) << 1) | 1ull);
 #pragma unroll
       for (int u = 0; u < PF; ++u) {
         if (!(pend >> u & 1u)) continue;
         if (old[u] == ~0ull) {
           pend &= ~(1u << u);
         } else if ((uint32_t)(old[u] >> 32) == ids[u]) {
-          atomicMin(&table[sl[u]], ((unsigned long long)ids[u] << 32) | ((unsigned long long)(uint32_t)(a.gr + base + u * 1024 + tid) << 1));
+          atomicMin(&table[sl[u]], ((unsigned long long)ids[u] << 32) | ((unsigned long long)(uint32_t)(a.gr + base + u * NT + tid) << 1));
           atomicAnd(&table[sl[u]], ~1ull);
           pend &= ~(1u << u);
         } else {
@@ -1994,7 +1998,7 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
       if (!((valid >> u & 1u) && bw[u])) continue;
       if (!lg3_rset_has(rset, a, ids[u], hh[u])) continue;
       rootmask |= 1ull << (it0 + u);
-      const int32_t pl = base + u * 1024 + tid;
+      const int32_t pl = base + u * NT + tid;
       const int c = a.cnt1[p0 + pl];
       const uint32_t* kids = a.nbr1 + (p0 + pl) * a.f1;
       for (int j = 0; j < c; ++j) {
@@ -2007,7 +2011,7 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
   if (over) atomicAdd(a.overflow, over);
   __syncthreads();
   // ---- what the later passes need, by stream position
-  for (int32_t tl = tid; tl < a.gr; tl += 1024) {
+  for (int32_t tl = tid; tl < a.gr; tl += NT) {
     const uint32_t id = a.roots[r0 + tl];
     if (id == GIGL_INVALID) {
       if (q == 0) a.fpw[r0 + tl] = -1;
@@ -2027,13 +2031,13 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
     const int c0 = a.cnt0[r0 + tl];
     if (c0 > 0) atomicAdd(&a.rowcnt[r0 + code], c0);
   }
-  for (int32_t base = 0, it0 = 0; base < a.S0g; base += PF * 1024, it0 += PF) {
+  for (int32_t base = 0, it0 = 0; base < a.S0g; base += PF * NT, it0 += PF) {
     uint32_t ids[PF], sl[PF], lw[PF];
     int32_t cc[PF];
     uint32_t pend = 0;
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int32_t pl = base + u * 1024 + tid;
+      const int32_t pl = base + u * NT + tid;
       ids[u] = pl < a.S0g ? a.nbr0[p0 + pl] : GIGL_INVALID;
       cc[u] = pl < a.S0g ? a.cnt1[p0 + pl] : 0;
     }
@@ -2065,7 +2069,7 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int32_t pl = base + u * 1024 + tid;  // (a wave's 64 slots are consecutive: they touch at most two tiles)
+      const int32_t pl = base + u * NT + tid;  // (a wave's 64 slots are consecutive: they touch at most two tiles)
       const uint32_t id = ids[u];
       const int c = cc[u];
       const bool in = pl < a.S0g;
@@ -2122,7 +2126,7 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
   // itself), i.e. by THIS workgroup: after the barrier the sizes are final, and the numbering pass finds every offset
   // as a prefix — no cursor, no atomic, rows land where their position says.
   __syncthreads();
-  for (int32_t tl = tid; tl < a.gr; tl += 1024) {
+  for (int32_t tl = tid; tl < a.gr; tl += NT) {
     const uint32_t id = a.roots[r0 + tl];
     if (id == GIGL_INVALID || (int)lg3_part(hash_u32(id), a.P) != q) continue;
     const int32_t w = a.fpw[r0 + tl];  // (this thread's own store)
@@ -2132,19 +2136,19 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
     if (len) atomicAdd(&tc[2], len);
     if (len >= 2 && w < 0) atomicAdd(&tc[len > TINY_ROW ? 3 : 4], 1);
   }
-  for (int32_t base = 0; base < a.S0g; base += PF * 1024) {
+  for (int32_t base = 0; base < a.S0g; base += PF * NT) {
     uint32_t ids[PF];
     int32_t cc[PF], ww[PF], len[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int32_t pl = base + u * 1024 + tid;
+      const int32_t pl = base + u * NT + tid;
       ids[u] = pl < a.S0g ? a.nbr0[p0 + pl] : GIGL_INVALID;
       cc[u] = pl < a.S0g ? a.cnt1[p0 + pl] : 0;
       ww[u] = pl < a.S0g ? a.fpw[a.b + p0 + pl] : -1;  // (this thread's own store, or another partition's slot)
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int32_t pl = base + u * 1024 + tid;
+      const int32_t pl = base + u * NT + tid;
       len[u] = -1;  // -1: not a first occurrence of this partition whose row needs storage
       if (ids[u] == GIGL_INVALID || ww[u] == -1 || (int)lg3_part(hash_u32(ids[u]), a.P) != q) continue;
       const uint32_t mycode = (uint32_t)(a.gr + pl);
@@ -2155,7 +2159,7 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
     }
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-      const int32_t pl = base + u * 1024 + tid;
+      const int32_t pl = base + u * NT + tid;
       const int32_t my_tile = (int32_t)((a.b + p0 + pl) >> 10) - tile_lo_h;
       const int32_t tile0 = __builtin_amdgcn_readfirstlane(my_tile);
       const bool have = len[u] > 0, sorted = len[u] >= 2 && ww[u] < 0;
@@ -2177,7 +2181,7 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
     }
   }
   __syncthreads();
-  for (int i = tid; i < LG3_TC * (nt_r + nt_h); i += 1024) {
+  for (int i = tid; i < LG3_TC * (nt_r + nt_h); i += NT) {
     const int32_t v = tcnt[i];
     if (v) {
       const int k = i / LG3_TC;
@@ -2193,11 +2197,11 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
   __syncthreads();
   if (!s_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  // the last workgroup to finish: exclusive prefixes over the tiles, 1024 tiles per round (row n_tiles = totals)
+  // the last workgroup to finish: exclusive prefixes over the tiles, NT tiles per round (row n_tiles = totals)
   int32_t run[LG3_TC];
 #pragma unroll
   for (int c = 0; c < LG3_TC; ++c) run[c] = 0;
-  for (int32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
+  for (int32_t t0 = 0; t0 < n_tiles; t0 += NT) {
     const int32_t i = t0 + tid;
     int32_t v[LG3_TC], inc[LG3_TC];
 #pragma unroll
@@ -2213,7 +2217,7 @@ __global__ __launch_bounds__(1024) void lg3_dedup_kernel(Lg3Args a, int32_t* til
 #pragma unroll
     for (int c = 0; c < LG3_TC; ++c) {
       int32_t before = 0, tot = 0;
-      for (int k = 0; k < 16; ++k) {
+      for (int k = 0; k < NT / 64; ++k) {
         const int32_t x = s_w[k][c];
         if (k < wv) before += x;
         tot += x;
@@ -2475,12 +2479,21 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   const int64_t n_groups = b / group_roots;
   const int64_t gr = group_roots, Tg = gr * (1 + f0), S1g = gr * f0 * f1;
   // (20-bit stream codes; a thread of the dedup pass keeps one bit per 1024 hop-0 slots of the batch in a 64-bit mask)
-  if (Tg + S1g >= (int64_t)LG3_CODE_MASK || f1 > 64 || b + S0 + S1 >= ((int64_t)1 << 31) || gr * f0 > 64 * 1024) return GIGL_OK;  // -> LG2
+  // workgroup shape of the dedup pass (round 5): GIGL_LG3_NT = 512 | 1024 threads, GIGL_LG3_CAP slots per table
+  static const int lg3_nt_env = [] {
+    const char* e = getenv("GIGL_LG3_NT");
+    const int v = e ? atoi(e) : 0;
+    return v == 512 || v == 1024 ? v : 0;
+  }();
+  // (a thread keeps one bit per NT hop-0 slots of its batch in a 64-bit mask: batches of more than 64 * 512 slots — B = 4096
+  // at fan-out 15 — take the 1024-thread shape)
+  const int lg3_nt = lg3_nt_env ? lg3_nt_env : (gr * f0 <= 64 * (int64_t)LG3_NT_DEFAULT ? LG3_NT_DEFAULT : 1024);
+  if (Tg + S1g >= (int64_t)LG3_CODE_MASK || f1 > 64 || b + S0 + S1 >= ((int64_t)1 << 31) || gr * f0 > 64 * (int64_t)lg3_nt) return GIGL_OK;  // -> LG2
   // LDS table: 8-byte slots at load <= 1/2 for the nodes a batch may hold (more do not fit the plan's workspace)
   static const int64_t cap_max = [] {
     const char* e = getenv("GIGL_LG3_CAP");  // (A/B knob: slots per workgroup, a power of two)
     const int64_t v = e ? atoll(e) : 0;
-    return v >= 1024 && v <= 16384 && (v & (v - 1)) == 0 ? v : (int64_t)16384;
+    return v >= 1024 && v <= 16384 && (v & (v - 1)) == 0 ? v : (int64_t)LG3_CAP_DEFAULT;
   }();
   int64_t cap = 1024;
   while (cap < 2 * Tg && cap < cap_max) cap <<= 1;
@@ -2562,13 +2575,18 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   int32_t* tile_counts = zeros + 64 + 32 * EC_STRIDE;
   const int TB = 256;
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
-  GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 1, (const void*)lg3_dedup_kernel, 150 * 1024, (const void*)lg2_row_sort_big_kernel,
+  GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 1, (const void*)lg3_dedup_kernel<1024>, 150 * 1024, (const void*)lg2_row_sort_big_kernel,
                                  2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
+  GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 3, (const void*)lg3_dedup_kernel<512>, 150 * 1024));
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_INSERT);
     hipLaunchKernelGGL(lg3_init_kernel, dim3(256), dim3(256), 0, st, a.rowcnt, T_in, zeros, zero_words, out->meta);
-    hipLaunchKernelGGL(lg3_dedup_kernel, dim3((unsigned)(n_groups * P)), dim3(1024), lds_bytes, st, a, tile_counts,
-                       n_tiles, ticket_count, sort_count, tiny_count);
+    if (lg3_nt == 512)
+      hipLaunchKernelGGL(lg3_dedup_kernel<512>, dim3((unsigned)(n_groups * P)), dim3(512), lds_bytes, st, a, tile_counts,
+                         n_tiles, ticket_count, sort_count, tiny_count);
+    else
+      hipLaunchKernelGGL(lg3_dedup_kernel<1024>, dim3((unsigned)(n_groups * P)), dim3(1024), lds_bytes, st, a, tile_counts,
+                         n_tiles, ticket_count, sort_count, tiny_count);
   }
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_NODES);

@@ -102,7 +102,9 @@ int32_t gigl_memcpy(gigl_ctx* ctx, void* dst, int32_t dst_loc, const void* src, 
 #define GIGL_K_GATHER_MEAN 8
 #define GIGL_K_LINEAR 9
 #define GIGL_K_GATHER_BWD 10   /* gigl_gather_reduce_backward (scatter of the layer's input gradient: fp32 atomics) */
-#define GIGL_K_COUNT 11
+#define GIGL_K_DIST_PREP 11    /* sharded plan: clear / bucket / claim / scatter / locate (what the exchanges need around them) */
+#define GIGL_K_DIST_SERVE 12   /* sharded plan, owner side: the requested feature rows gathered into the send buffer */
+#define GIGL_K_COUNT 13
 int32_t gigl_profile_enable(gigl_ctx* ctx, uint32_t mask, int32_t capacity);
 int32_t gigl_profile_read(gigl_ctx* ctx, int32_t kernel_id, double* total_ms, int64_t* launches);
 int32_t gigl_profile_reset(gigl_ctx* ctx);
