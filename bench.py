@@ -1254,7 +1254,7 @@ def run_sharded(args, rank, world, local_rank, sub=False):
     # ---- per-kernel HIP-event times of one more (untimed) repetition: the library's timers on every plan's ctx; the
     # plans stay interleaved as in the timed region, so an interval includes what the other plans' kernels took from it
     prof_names = ["expand", "union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr", "gather_mean",
-                  "linear"]
+                  "linear", "dist_prep", "dist_serve"]
     for sl in slots:
         sl.eng.profile_enable(prof_names, capacity=8192)
         sl.eng.profile_reset()
@@ -1517,6 +1517,9 @@ def run_emulated_world(args, local_rank=0, sub=False):
         torch.cuda.synchronize()
 
     traffic = []  # per rank: [moved, full-block] bytes per step of the last measurement
+    ktime = {}    # kernel group -> [ms, launches] summed over the W ranks, last measurement
+    EMU_PROF = ["expand", "expand_heavy", "union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr",
+                "gather_mean", "linear", "dist_prep", "dist_serve"]
 
     def measure(hot):
         # bucket capacities from two warm-up calls (+10 %), as the multi-process bench does
@@ -1544,6 +1547,19 @@ def run_emulated_world(args, local_rank=0, sub=False):
         # the feature-row blocks at the size of their request counts — and as full-capacity blocks would have been
         traffic.clear()
         traffic.extend(((np.array([c.traffic() for c in comms], dtype=np.float64) - tr0) / (K * G)).tolist())
+        # ---- the ranks' own KERNEL time (untimed repetition, every HIP-event timer of the library on): the W ranks share
+        # one stream here, so an interval is its kernels' duration (+ the host's gap between the two event records when
+        # the launch queue runs dry, which it does: an upper bound).  The in-process transport's device copies stand in
+        # for RCCL and are not kernels of a rank: not counted.
+        for e_ in engs:
+            e_.profile_enable(EMU_PROF, capacity=(K + 2) * 64)
+            e_.profile_reset()
+        run_calls(plans, 2, 2 + K)
+        kt = {k: [sum(x) for x in zip(*[e_.profile_read(k) for e_ in engs])] for k in EMU_PROF}
+        for e_ in engs:
+            e_.profile_enable([], 0)
+        ktime.clear()
+        ktime.update({k: v for k, v in kt.items() if v[0] > 0})
         st = np.stack([a.cpu().numpy().astype(np.float64) for a in accs])
         fl = np.stack([f.cpu().numpy().astype(np.float64) for f in fills])
         if st[:, STATS["overflow"]].any():
@@ -1569,6 +1585,16 @@ def run_emulated_world(args, local_rank=0, sub=False):
         hop_bytes /= G
         payload = pulled * (row_bytes + 4)
         compute_ms = dt / (K * G * W) * 1e3
+        # kernel time per rank-step by group (HIP events), and the byte model of the dominant one (as run_sharded's)
+        kg = {k: round(v[0] / (K * G * W), 6) for k, v in ktime.items()}
+        kernel_ms = float(sum(kg.values()))
+        agg0 = st[:, STATS["agg_layer0"]].sum() / (steps * W)
+        agg1 = st[:, STATS["agg_layer0"] + 1].sum() / (steps * W)
+        rows0 = st[:, STATS["rows_layer0"]].sum() / (steps * W)
+        rows1 = st[:, STATS["rows_layer0"] + 1].sum() / (steps * W)
+        b_gather = (agg0 * (4 + hid * 4) + rows0 * (8 + 2 * hid * 4) if use_proj else
+                    agg0 * (4 + d * 2) + rows0 * (8 + d * 2 + 2 * d * 4)) + agg1 * (4 + hid * 4) + rows1 * (8 + hid * 4)
+        gm_ms = kg.get("gather_mean", 0.0)
         tr = np.array(traffic, dtype=np.float64)  # [W, 2]
         moved_step, full_step = float(tr[:, 0].max()), float(tr[:, 1].max())  # the busiest rank's
         per_link = moved_step / (W - 1)  # bytes per peer pair and step: one xGMI link each (W <= 8)
@@ -1595,17 +1621,29 @@ def run_emulated_world(args, local_rank=0, sub=False):
                                                  fl[:, 2].max() / max(pull_cap_b, 1) if pull_cap_b else 0.0)),
             "rows_in_buckets_per_step_per_rank": float((fl[:, 1].sum() + fl[:, 3].sum()) / (K * G * W)),
             "sampled_plus_aggregated_edges_per_step_per_rank": float(edges_step),
-            "compute_ms_per_step_per_rank": compute_ms,
-            "measured": "all of the above: counted on the device / timed on this GPU with the W ranks sharing it (eager "
-                        "launches, one plan per rank, phases of the W ranks issued in turn by one host thread: an upper "
-                        "bound of a rank's compute time — the single-rank bench keeps three plans in flight)",
+            "wall_ms_per_step_per_rank": compute_ms,
+            "kernel_ms_per_step_per_rank": kernel_ms,
+            "kernel_ms_by_group": kg,
+            "sharded_only_kernel_share": round((kg.get("dist_prep", 0.0) + kg.get("dist_serve", 0.0)) / max(kernel_ms, 1e-12), 4),
+            "roofline": {"bound": "hbm", "kernel": "gather_mean", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "achieved": round(b_gather / max(gm_ms * 1e-3, 1e-12) / 1e9, 1),
+                         "frac": round(b_gather / max(gm_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+                         "alg_bytes_per_rank_step": round(b_gather), "ms_per_rank_step": gm_ms,
+                         "timing": "HIP events around the rank's launches; one stream for all W ranks: kernels run alone"},
+            "measured": "all of the above: counted on the device / timed on this GPU with the W ranks sharing it.  wall_ms = "
+                        "host wall clock of eager launches, one plan per rank, phases of the W ranks issued in turn by one "
+                        "host thread (host-bound: the GPU idles most of it); kernel_ms = the HIP-event time of the ranks' own "
+                        "kernels (an upper bound of the kernel time: profiles/r05*_emulated_world8_kernel_time.txt has the "
+                        "rocprofv3 figure of the same run); the in-process transport's copies stand in for RCCL and are in "
+                        "neither",
             "projection": {
                 "label": "PROJECTION, not a measurement: measured bytes over 7 x 153 GB/s xGMI links per GPU (one link per "
-                         "peer at W = 8), measured per-rank compute; exchanges assumed to overlap compute across the plans "
-                         "in flight",
-                "link_ms_per_step": link_ms, "bound": "xgmi" if link_ms > compute_ms else "compute",
-                "step_ms": max(link_ms, compute_ms),
-                "whole_node_edges_per_s": W * edges_step / (max(link_ms, compute_ms) * 1e-3)}}
+                         "peer at W = 8) against the measured per-rank KERNEL time with NO overlap between a rank's kernels "
+                         "assumed (the single-rank bench overlaps three plans); exchanges assumed to overlap compute across "
+                         "the plans in flight",
+                "link_ms_per_step": link_ms, "bound": "xgmi" if link_ms > kernel_ms else "compute",
+                "step_ms": max(link_ms, kernel_ms),
+                "whole_node_edges_per_s": W * edges_step / (max(link_ms, kernel_ms) * 1e-3)}}
     if n_hot:
         a, b_ = res["no_replication"]["pulled_rows_per_step_mean"], res["hot_rows"]["pulled_rows_per_step_mean"]
         res["hot_row_hit_rate"] = {"replicated_fraction_of_nodes": hot_frac, "replica_bytes_per_rank": int(n_hot * row_bytes),
@@ -1623,7 +1661,7 @@ def run_emulated_world(args, local_rank=0, sub=False):
                                + ("rows pre-projected once per rank (256 fp32 W_l x rows pulled)" if use_proj else "raw rows"),
                    "transport": "gigl_dist_init_local (in-process: every exchange is a device copy on this GPU)",
                    "projection_precompute_s_per_rank": round(pre_s, 4), "setup_s": round(time.time() - t0, 1)},
-        "emulated": res, "roofline": None, "cpu_baseline": None}
+        "emulated": res, "roofline": best["roofline"], "cpu_baseline": None}
     for c in comms:
         c.close()
     for e in reversed(engs):

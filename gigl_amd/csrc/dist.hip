@@ -582,46 +582,6 @@ __global__ __launch_bounds__(256) void serve_rows_copy_kernel(const uint32_t* __
   else *(uint16_t*)op = *(const uint16_t*)sp;
 }
 
-// the same copy for rows made of 16-byte units (every shape the plans produce): a wave takes RPW entries at a time, lane l
-// the units l, l + 64, ... of each of them — the RPW rows' loads are issued before the first store, so a 1-KB row costs a
-// wave one load + one store instruction per row with four rows in flight (the flat kernel above keeps ONE 16-byte load
-// in flight per thread: 2.7 TB/s of copy on the emulated 8-rank world, round 5)
-template <int RPW>
-__global__ __launch_bounds__(256) void serve_rows_wave_kernel(const uint32_t* __restrict__ ids, int64_t n_entries,
-                                                              uint32_t world, const char* __restrict__ rows,
-                                                              int64_t n_rows, uint32_t row_bytes, uint32_t upr,
-                                                              char* __restrict__ out, int64_t self_lo, int64_t self_hi,
-                                                              char* __restrict__ self_out, int64_t src_stride) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int64_t e0 = wave * RPW;
-  if (e0 >= n_entries) return;
-  const char* sp[RPW];
-  char* op[RPW];
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int64_t e = e0 + r;
-    sp[r] = nullptr;
-    op[r] = nullptr;
-    if (e >= n_entries) continue;
-    const uint32_t v = ids[e];
-    if (v == GIGL_INVALID) continue;
-    const int64_t row = (int64_t)(v / world);
-    if (row >= n_rows) continue;
-    sp[r] = rows + row * (src_stride ? src_stride : (int64_t)row_bytes);
-    op[r] = ((self_out && e >= self_lo && e < self_hi) ? self_out : out) + e * (int64_t)row_bytes;
-  }
-  for (uint32_t u = lane; u < upr; u += 64) {
-    uint4 v[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r)
-      if (sp[r]) v[r] = *reinterpret_cast<const uint4*>(sp[r] + (int64_t)u * 16);
-#pragma unroll
-    for (int r = 0; r < RPW; ++r)
-      if (sp[r]) *reinterpret_cast<uint4*>(op[r] + (int64_t)u * 16) = v[r];
-  }
-}
-
 // requester side, staged plans: union node i's pulled row (row pos[i] of the receive buffer) widened to fp32 at row i of
 // the batch's dense feature matrix — what a training batch hands to the encoder as x.  One wave per node; a node whose
 // request did not fit its bucket (pos < 0: the step is flagged as overflowed) gets NaN.
@@ -928,18 +888,14 @@ int32_t serve_rows(gigl_dist_plan* p, const uint32_t* ids, int64_t n_entries, co
   gigl_prof_scope ps(p->ctx, GIGL_K_DIST_SERVE);
   hipStream_t st = p->ctx->stream;
   const uint32_t world = (uint32_t)p->world;
-  if ((p->row_bytes & 15) == 0 && ((uintptr_t)table & 15) == 0 && (stride & 15) == 0) {
-    constexpr int RPW = 4;
-    const int64_t waves = (n_entries + RPW - 1) / RPW;
-    hipLaunchKernelGGL(serve_rows_wave_kernel<RPW>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, ids, n_entries, world,
-                       table, p->feat->n, (uint32_t)p->row_bytes, (uint32_t)(p->row_bytes / 16), out, self_lo, self_hi,
-                       self_out, stride);
-  } else {
-    const uint32_t unit = (p->row_bytes & 3) == 0 ? 4u : 2u;
-    const uint32_t upr = (uint32_t)(p->row_bytes / unit);
-    hipLaunchKernelGGL(serve_rows_copy_kernel, dim3((unsigned)grid256(n_entries * upr)), dim3(256), 0, st, ids, n_entries,
-                       world, table, p->feat->n, (uint32_t)p->row_bytes, unit, upr, out, self_lo, self_hi, self_out, stride);
-  }
+  // (one 16-byte unit per thread: 64 lanes = one 1-KB row per wave.  The copy runs at the rate of its bytes — 163 MB in and
+  // out per 16-batch call in ~70 us on the emulated 8-rank world = 4.7 TB/s; a wave-per-four-rows variant with four loads
+  // in flight per lane was measured at 9.2 vs 8.5 us per rank-step and dropped: round 5)
+  const bool a16 = (p->row_bytes & 15) == 0 && ((uintptr_t)table & 15) == 0 && (stride & 15) == 0;
+  const uint32_t unit = a16 ? 16u : ((p->row_bytes & 3) == 0 ? 4u : 2u);
+  const uint32_t upr = (uint32_t)(p->row_bytes / unit);
+  hipLaunchKernelGGL(serve_rows_copy_kernel, dim3((unsigned)grid256(n_entries * upr)), dim3(256), 0, st, ids, n_entries,
+                     world, table, p->feat->n, (uint32_t)p->row_bytes, unit, upr, out, self_lo, self_hi, self_out, stride);
   GIGL_HIP_CHECK(p->ctx, hipGetLastError());
   return GIGL_OK;
 }

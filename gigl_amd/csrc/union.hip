@@ -2487,7 +2487,7 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   }();
   // (a thread keeps one bit per NT hop-0 slots of its batch in a 64-bit mask: batches of more than 64 * 512 slots — B = 4096
   // at fan-out 15 — take the 1024-thread shape)
-  const int lg3_nt = lg3_nt_env ? lg3_nt_env : (gr * f0 <= 64 * (int64_t)LG3_NT_DEFAULT ? LG3_NT_DEFAULT : 1024);
+  int lg3_nt = lg3_nt_env ? lg3_nt_env : (gr * f0 <= 64 * (int64_t)LG3_NT_DEFAULT ? LG3_NT_DEFAULT : 1024);
   if (Tg + S1g >= (int64_t)LG3_CODE_MASK || f1 > 64 || b + S0 + S1 >= ((int64_t)1 << 31) || gr * f0 > 64 * (int64_t)lg3_nt) return GIGL_OK;  // -> LG2
   // LDS table: 8-byte slots at load <= 1/2 for the nodes a batch may hold (more do not fit the plan's workspace)
   static const int64_t cap_max = [] {
@@ -2499,6 +2499,10 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   while (cap < 2 * Tg && cap < cap_max) cap <<= 1;
   const int64_t P = (2 * Tg + cap - 1) / cap;
   if (P > LG3_MAX_PARTS) return GIGL_OK;
+  // (the 512-thread shape pays when the launch fills the GPU — a workgroup per CU and more, other streams' kernels beside
+  // it; a launch of fewer workgroups than CUs is over sooner with 1024 threads each: the sharded plan's 16-batch calls,
+  // lg3_dedup 3.6 -> 5.0 us per rank-step with 512, profiles/r05e_emulated_world8_kernel_time.txt)
+  if (!lg3_nt_env && n_groups * P < 256) lg3_nt = 1024;
   // a call of a few batches (a training step: one) leaves most CUs without a workgroup of the dedup pass, whose duration
   // is that of ONE workgroup walking its batch's whole stream (~80 us at [25,10] x 1024): LG2's position-parallel
   // launches finish such a call sooner (training step 0.42 -> 0.39 ms)

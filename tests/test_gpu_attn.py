@@ -129,12 +129,16 @@ def test_gat_first_layer_from_the_input_side(d, dtype, heads, hid):
             if l == 0:
                 h = torch.relu(h)
         ref = h[o["root_local"]].numpy()
-        np.testing.assert_allclose(plain, ref, rtol=2e-5, atol=2e-5)
-        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
-        np.testing.assert_allclose(got, plain, rtol=2e-5, atol=2e-5)
         model.input_side_first_layer = "fused"  # one pass, logits formed from the rows as they are read
         fused = model(batch)[idx].cpu().numpy()
-        np.testing.assert_allclose(fused, ref, rtol=2e-5, atol=2e-5)
+        # the north star's bar for layer embeddings: 1e-5 of the fp32 CPU forward (BASELINE.json); measured, printed
+        print(f"GAT input side d={d} heads={heads} hid={hid}: max |err| vs CPU forward: projection-first "
+              f"{np.abs(plain - ref).max():.2e}, input-side {np.abs(got - ref).max():.2e}, one-pass {np.abs(fused - ref).max():.2e} "
+              f"(max |row| {np.abs(ref).max():.2e})")
+        np.testing.assert_allclose(plain, ref, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(got, plain, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(fused, ref, rtol=1e-5, atol=1e-5)
     finally:
         eng.close()
 
@@ -333,7 +337,7 @@ def test_gat_one_call_plan_matches_the_staged_forward(d, dtype, heads, hid, fan,
             tree = eng.sample_khop(part, fan)
             u = eng.union_build(tree)
             want = model(HipBatch(eng, tree, u))[u.root_local[:b].long()].cpu().numpy()
-            np.testing.assert_allclose(got[gi * b:(gi + 1) * b], want, rtol=2e-5, atol=2e-5)
+            np.testing.assert_allclose(got[gi * b:(gi + 1) * b], want, rtol=1e-5, atol=1e-5)
             sampled += int(sum(int(c.sum()) for c in tree.cnt))
             rowlen = (u.rowend - u.rowptr).cpu().numpy().astype(np.int64)
             meta = u.meta.cpu().numpy()
@@ -408,7 +412,7 @@ def test_gat_training_from_the_input_side_equals_the_whole_graph_autograd(d, dty
             loss = ((out - tgt) ** 2).sum()
             loss.backward()
             runs[side] = (out.detach().cpu().numpy(), {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()})
-        np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(runs[True][0], runs[False][0], rtol=1e-5, atol=1e-5)
         for k, gr in runs[False][1].items():
             scale = max(float(np.abs(gr).max()), 1e-6)
             np.testing.assert_allclose(runs[True][1][k], gr, rtol=2e-3, atol=2e-4 * scale, err_msg=k)

@@ -418,7 +418,7 @@ def _gat_reference_rows(rowptr, col, x, model, roots, group_roots):
 @pytest.mark.parametrize("world,dtype", [(2, torch.float32), (3, torch.float16), (8, torch.float32)])
 def test_sharded_gat_plan_every_rank_end_to_end(world, dtype):
     """gigl_dist_gat_plan_create (BASELINE configs[4]'s encoder on the hash-partitioned graph): every rank of an emulated
-    world samples trees bit-identical to the oracle on the whole graph and gets root embeddings within 2e-5 of the
+    world samples trees bit-identical to the oracle on the whole graph and gets root embeddings within 1e-5 of the
     oracle's collate + fp32 GAT forward (and of the single-GPU one-call GAT plan)"""
     from gigl_amd.dist import Comm
     from gigl_amd.engine import HipEngine
@@ -454,9 +454,11 @@ def test_sharded_gat_plan_every_rank_end_to_end(world, dtype):
         for k in range(len(FAN)):
             assert np.array_equal(hb["nbr"][k], nbr_o[k]) and np.array_equal(hb["cnt"][k], cnt_o[k])
         want = _gat_reference_rows(rowptr, col, xq, model, roots[r], gr)
-        np.testing.assert_allclose(outs[r].cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+        print(f"sharded GAT world={world} rank {r}: max |err| vs CPU forward {np.abs(outs[r].cpu().numpy() - want).max():.2e} "
+              f"(max |row| {np.abs(want).max():.2e})")
+        np.testing.assert_allclose(outs[r].cpu().numpy(), want, rtol=1e-5, atol=1e-5)  # (the north star's 1e-5)
         one = single.run(roots_d[r]).cpu().numpy()
-        np.testing.assert_allclose(outs[r].cpu().numpy(), one, rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(outs[r].cpu().numpy(), one, rtol=1e-5, atol=1e-5)
     single.close()
     whole.close()
     for p in plans:

@@ -593,8 +593,13 @@ def test_bench_emulated_world_line(tmp_path):
     emu = line["emulated"]
     for tag in ("hot_rows", "no_replication"):
         e = emu[tag]
-        assert len(e["pulled_rows_per_step_per_rank"]) == 4 and e["compute_ms_per_step_per_rank"] > 0
+        assert len(e["pulled_rows_per_step_per_rank"]) == 4 and e["wall_ms_per_step_per_rank"] > 0
+        # the ranks' own kernel time (HIP events), with the sharded-only groups named, and a roofline on the record
+        assert 0 < e["kernel_ms_per_step_per_rank"] <= e["wall_ms_per_step_per_rank"] * 1.05
+        assert e["kernel_ms_by_group"]["dist_prep"] > 0 and e["kernel_ms_by_group"]["dist_serve"] > 0
+        assert 0 < e["sharded_only_kernel_share"] < 1 and e["roofline"]["kernel"] == "gather_mean" and e["roofline"]["frac"] > 0
         assert 0.0 < e["row_bucket_fill"] <= 1.0 and e["projection"]["label"].startswith("PROJECTION")
+    assert line["roofline"]["bound"] == "hbm"
     assert emu["hot_row_hit_rate"]["pulled_rows_with"] < emu["hot_row_hit_rate"]["pulled_rows_without"]
 
 

@@ -7,7 +7,9 @@ per batch, the domain's own invariants are checked on the device instead:
              rows is compared with the oracle's hash permutation
   union      local ids are a bijection onto the distinct sampled nodes, rows are ascending and duplicate-free, and
              the union's edge set equals the set of sampled (src, dst) pairs (checksum of sorted 64-bit keys)
-  forward    the one-call plan (leaf-global union, grouped launches) == the step-by-step entry points to 2e-6
+  forward    the one-call plan (leaf-global union, grouped launches) == the step-by-step entry points to 2e-6, and one
+             B = 1024 batch of a 64-batch call against the CPU restatement end to end (oracle sample -> collate -> fp32
+             forward) at 1e-5
   records    the device-encoded TFRecords decode (CRCs verified) to exactly the sampled trees"""
 import os
 import sys
@@ -144,6 +146,46 @@ def test_plan_equals_stepwise_at_full_size(world):
         ref = model(HipBatch(eng, tree, u))[u.root_local[:1024].long()]
         torch.testing.assert_close(out[g * 1024:(g + 1) * 1024], ref, rtol=2e-6, atol=2e-6)
     plan.close()
+
+
+def test_plan_against_the_oracle_forward_at_full_size(world):
+    """one B = 1024 batch of the HEADLINE workload as bench.py runs it — the full products-shaped graph, GraphSAGE
+    100 -> 256 -> 47, a 64-batch plan call replayed as a hipGraph, both projections fused — against the CPU restatement
+    end to end: oracle.sample_khop -> union_build -> gnn_ref.graphsage_forward over the whole union graph
+    (homogeneous.py:107-153), 1e-5 (the measured error is printed)"""
+    from gigl_amd.models import GraphSAGE
+    from oracle import gnn_ref
+    eng, n, d, rowptr_h, col_h, roots = world
+    st = torch.cuda.Stream()
+    eng.bind_stream(st)
+    torch.cuda.set_stream(st)
+    try:
+        torch.manual_seed(0)
+        model = GraphSAGE(d, 256, 47, num_layers=2).to(eng.device)
+        fan, B, G = [25, 10], 1024, 64
+        g = torch.Generator().manual_seed(42)
+        rts = torch.randperm(n, generator=g)[:G * B].to(torch.int32).to(eng.device)
+        plan = model.make_plan(eng, B, fan, groups=G)
+        plan.use_graph(True)
+        plan.run(rts)
+        out = plan.run(rts).cpu().numpy()
+        assert plan.fused_layers()
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        for gi in (5,):
+            r_h = rts[gi * B:(gi + 1) * B].cpu().numpy().view(np.uint32)
+            nbr_o, _ = oracle.sample_khop(rowptr_h, col_h, r_h, fan, canonical=True)
+            o = oracle.union_build(r_h, fan, nbr_o)
+            ids = torch.from_numpy(o["nodes"].astype(np.int64)).to(torch.int32).to(eng.device)
+            x = eng.gather_rows(ids, torch.tensor([ids.numel()], dtype=torch.int32, device=eng.device), int(ids.numel())).cpu()
+            ei = gnn_ref.union_edge_index(o["rowptr"], o["col"])
+            want = gnn_ref.graphsage_forward(x, ei, sd, 2)[o["root_local"]].numpy()
+            err = np.abs(out[gi * B:(gi + 1) * B] - want).max()
+            print(f"products full size, batch {gi}: max |err| = {err:.3e}, max |row| = {np.abs(want).max():.3e}")
+            np.testing.assert_allclose(out[gi * B:(gi + 1) * B], want, rtol=1e-5, atol=1e-5)
+        plan.close()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        eng.bind_stream(torch.cuda.default_stream())
 
 
 def test_records_round_trip_at_full_size(world):
