@@ -69,8 +69,9 @@ MFMA_16BIT_PEAK_TF = 2500.0
 # library timer id -> name prefixes of the device functions it brackets (as rocprofv3 prints them, scripts/pmc_summary.py)
 PMC_KERNELS = {
     "expand": ["plan_rows_kernel", "expand_rows_kernel"],
-    "gather_mean": ["gather_mean_kernel"],
-    "linear": ["linear_split_kernel", "linear_lds_kernel", "linear_mfma_kernel"],
+    # (round 5, fused layers: the last layer is sage_fused_out_kernel, both projections linear_fused2_kernel)
+    "gather_mean": ["gather_mean_kernel", "sage_fused_out_kernel"],
+    "linear": ["linear_split_kernel", "linear_lds_kernel", "linear_mfma_kernel", "linear_fused2_kernel"],
     # (the one-call plan's two-hop union build, union.hip "LG2"; the generic build's kernels have other names)
     # (round 4: the LDS-staged build "LG3" — lg3_* — replaced lg2_insert / extras / count / assign / fill)
     "union_insert": ["lg2_init_kernel", "lg2_insert_kernel", "lg2_extras_kernel", "lg3_init_kernel", "lg3_dedup_kernel"],
@@ -348,7 +349,7 @@ def main():
                          "768->256->256); mag240m-sharded = BASELINE configs[2]: the MAG240M-shaped graph hash-"
                          "partitioned over the ranks (owner = id %% world), per-hop all_to_all frontier exchange and "
                          "feature pull over RCCL — needs >= 2 GPUs at full size (--shard-scale shrinks it)")
-    ap.add_argument("--shard-group", type=int, default=16,
+    ap.add_argument("--shard-group", type=int, default=32,
                     help="mag240m-sharded: batches of B roots exchanged per set of collectives (dedup stays per batch)")
     ap.add_argument("--shard-hot-frac", type=float, default=-1.0,
                     help="mag240m-sharded: fraction of the nodes (the most-referenced ones) whose feature rows are "
@@ -727,7 +728,9 @@ def main():
         #  union: 16 B per sampled edge + 4 B per unique node, attributed evenly to its phases
         for k in ("union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr"):
             ab[k] = (16 * st[STATS["sampled"]] + 4 * st[STATS["union_nodes"]]) / 4.0
-        ab["expand"] = st[STATS["expand_bytes"]]  # parity mode: 16 + 4*deg + 8*min(deg, f) per frontier node
+        # parity mode, what a position-keyed sampler must move per frontier node (gigl_sage_plan_stats): 16 + (a row of
+        # <= f neighbours: 4 deg, else the <= lambda threshold-list pairs 8 lambda + the f chosen ids 4 f) + 8 min(deg, f)
+        ab["expand"] = st[STATS["expand_bytes"]]
         return ab, fl
 
     alg_timed, _ = alg_of(tot)  # this rank's timed region (the event timers are this rank's too)
@@ -826,6 +829,10 @@ def main():
         if prof[k][0] <= 0:
             continue
         alone_ms, ovl_ms = prof[k][0] / P, prof_ovl[k][0] / P
+        if k == dominant and dom_ms > 0:
+            # ONE overlapped figure per group: the dominant group's comes from the timed region itself (its HIP-event
+            # timer stays on there), the others' from the untimed probe of the same regime
+            ovl_ms = dom_ms / steps_total
         ab = alg_probe[k] / P
         tk, _ = pmc_traffic(k, G, wl_name, projected)
         tb = None  # counter bytes per step
@@ -859,7 +866,6 @@ def main():
                 "dominant": dominant,
                 "dominant_from": "largest HIP-event time per kernel group on its own (single-stream untimed probe, all "
                                  "timers on): stable from run to run; `groups` lists every group alone and overlapped",
-                "overlapped_ms_per_step": {k: round(v[0] / P, 5) for k, v in prof_ovl.items() if v[0] > 0},
                 "avg_launch_us": round(avg_launch_ms * 1e3, 2),
                 "alg_bytes_per_launch": round(bytes_per_launch), "launches": int(dom_launches), "note": note,
                 "timing": f"HIP events on the kernel's stream over the timed region ({S} streams: intervals include "
@@ -970,7 +976,7 @@ def main():
         limit = float(os.environ.get("GIGL_BENCH_SUB_TIMEOUT", "240"))
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", "mag240m-sharded", "--emulate-world", "8",
                "--shard-scale", os.environ.get("GIGL_BENCH_EMULATE_SCALE", "0.08"), "--fanouts", "25,10", "--batch", "1024",
-               "--shard-group", str(args.shard_group), "--steps", "256", "--no-cpu-baseline", "--no-live-pmc"]
+               "--shard-group", "16", "--steps", "256", "--no-cpu-baseline", "--no-live-pmc"]
         try:
             cp = subprocess.run(cmd, env=dict(os.environ, GIGL_BENCH_CHILD="1"), capture_output=True, text=True, timeout=limit)
             lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]

@@ -1455,6 +1455,12 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
     if (ok && W * pc >= ((int64_t)1 << 31)) ok = false;
   }
   // ---- activations
+  // (a plan over pre-projected rows never forms the first layer's [mean | self] operand: its abuf serves layers >= 1 only —
+  // 8 plans x 32 batches of a 768-wide first layer were 43 GB of workspace nobody wrote)
+  if (p->preproj) {
+    max_in = 0;
+    for (int k = 1; k < hops; ++k) max_in = dims[k] > max_in ? dims[k] : max_in;
+  }
   const int64_t a_cols = 2 * (int64_t)(max_in > max_out ? max_in : max_out);
   // (+ whole row tiles of 128 and whole K chunks of 32 for the tiled operand of layers >= 1)
   p->abuf = (float*)alloc((size_t)(act_rows + 128) * (a_cols + 64) * 4);

@@ -148,7 +148,14 @@ __global__ __launch_bounds__(256) void plan_stats_kernel(StatsArgs a, unsigned l
       const uint32_t v = par[p];
       if (v == GIGL_INVALID) continue;
       const long long deg = a.g_rowptr[(int64_t)v + 1] - a.g_rowptr[v];
-      bytes += 16 + 4 * deg + 8 * (deg < a.fan[k] ? deg : (long long)a.fan[k]);
+      // what a POSITION-keyed sampler must move per frontier node (round 5; SURVEY 8(d)'s `16 + 4 deg + 8 min(deg, f)`
+      // charges the whole adjacency row, which the reference's rule never needs: the key of entry i is a function of the
+      // position i alone, SamplingStrategy.scala:55): the row bounds (16 B); a row of <= f neighbours itself (4 deg);
+      // otherwise the <= lambda = f + 4 sqrt(f) + 4 (position, key) pairs of the window's threshold list that can hold
+      // the f smallest keys (8 B each) and the f chosen ids (4 f); the sampled (src, dst) pairs out (8 min(deg, f))
+      const long long f = a.fan[k];
+      const long long lam = f + (long long)(4.0f * sqrtf((float)f)) + 4;
+      bytes += 16 + (deg <= f ? 4 * deg : 8 * (deg < lam ? deg : lam) + 4 * f) + 8 * (deg < f ? deg : f);
       sampled += a.cnt[k][p];
     }
   }

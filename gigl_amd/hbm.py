@@ -191,6 +191,12 @@ class ResidentGraph:
             if efeat is not None:
                 raise NotImplementedError("edge features on a hash-partitioned graph: use the TFRecord route")
             eng.build_shard_from_coo(n, self.rank, self.world, src, dst, is_directed=directed, keep_multi_edges=multi)
+            if need_out_graph:
+                # the SUPERVISION edges (a link-prediction job draws an anchor's positives from its out-edges: counter 3) stay
+                # a replica on every rank — 4 bytes per edge, 7 GB at MAG240M — while the message-passing graph (in-edge
+                # rows) and the feature rows, the 375 GB, are the partitioned part: any rank can draw the positives of any
+                # anchor without an exchange
+                eng.build_from_coo(n, dst, src, is_directed=directed, out_graph=True, keep_multi_edges=multi)
             eng.load_features(np.ascontiguousarray(x[self.rank:: self.world]))
             # every hash window of the job ends below (hops + 1) * n + seed * hops + max degree (an upper bound of the
             # degree is enough): lets the owners serve every request from the threshold table
@@ -575,6 +581,11 @@ class ResidentGraph:
         from itertools import cycle
         P, T = int(num_positives), 1 + int(num_positives)
         spans = [(lo, min(lo + batch_size, ids.size)) for lo in range(0, ids.size, batch_size)]
+        if self.world > 1 and spans:
+            # rank r takes batches r, r + world, ...; every rank the same number (a short rank wraps around: the gradient
+            # all-reduce of DistributedDataParallel — and a hash-partitioned graph's exchanges — need equal step counts)
+            per_rank = -(-len(spans) // self.world)
+            spans = [spans[(self.rank + k * self.world) % len(spans)] for k in range(per_rank)]
         ar = torch.arange(P, device=self.device).view(1, P)
         for lo, hi in (cycle(spans) if (loop and spans) else spans):
             chunk, k = ids[lo:hi], n_pos[lo:hi]
@@ -583,7 +594,7 @@ class ResidentGraph:
             a2 = anchors.view(-1, 1)
             grouped = torch.where(ar < cnt.view(-1, 1), pos.view(-1, P), a2.expand(-1, P))
             roots = torch.cat([a2, grouped], dim=1).reshape(-1).contiguous()
-            hb, ri = self.train_graph(roots)
+            hb, ri = self.train_graph(roots, pad_to=batch_size * T)
             k64 = np.asarray(k, dtype=np.int64)
             # rows of the positives in the anchor-major root list: i * T + 1 + j for j < k[i]
             rows = (np.repeat(np.arange(k64.size, dtype=np.int64) * T + 1 - (np.cumsum(k64) - k64), k64)
@@ -598,11 +609,15 @@ class ResidentGraph:
         the order the TFRecord route reads the sampler's files, `batch_size` roots per batch (the last batch of a pass
         is short), looping forever like the reference's LoopyIterableDataset (tf_records_iterable_dataset.py:85-109)"""
         order = self.inference_root_order()
+        los = list(range(0, order.size, batch_size))
+        if self.world > 1 and los:  # (rank r: chunks r, r + world, ... of the pass, the same number on every rank)
+            per_rank = -(-len(los) // self.world)
+            los = [los[(self.rank + k * self.world) % len(los)] for k in range(per_rank)]
         while order.size:
-            for lo in range(0, order.size, batch_size):
+            for lo in los:
                 chunk = order[lo:lo + batch_size]
                 r32 = torch.from_numpy(chunk.astype(np.uint32).view(np.int32)).to(self.device)
-                hb, ri = self.train_graph(r32)
+                hb, ri = self.train_graph(r32, pad_to=batch_size)
                 yield HbmTrainBatch(graph=hb, root_node_indices=ri, root_node_labels=None, root_ids=chunk)
 
     def close(self) -> None:

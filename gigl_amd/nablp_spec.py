@@ -624,22 +624,30 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         device = getattr(self, "_device", None)
         inner = self.model.module if hasattr(self.model, "module") else self.model
         em = cfg.preprocessed_metadata.edges[0]
-        if cfg.is_heterogeneous or device is None or device.type != "cuda" or _rank_world()[1] > 1 or \
+        rank, world = _rank_world()
+        if cfg.is_heterogeneous or device is None or device.type != "cuda" or \
                 route_of(cfg, self._kwargs) != "hbm" or not (encoder_trains_over_hip_batches(inner.encoder) or
                                                              encoder_trains_over_graph_data(inner.encoder)) or \
                 em.positive_edge_info is not None or em.negative_edge_info is not None:
             return None
+        # WORLD_SIZE > 1 (round 5; training_process.py:86-119: DDP around the model, the ranks split the batches): trainerArgs
+        # hbm_graph = "replica" (default: the whole graph on every rank) | "sharded" (rank r holds the in-edge rows and
+        # feature rows of the nodes with id % world == r — configs[4] on a graph larger than one GPU; a batch's remote
+        # neighbours and rows arrive through the staged sharded plan, the supervision edges stay a replica)
+        want_shards = str(self._kwargs.get("hbm_graph", "replica")).lower() == "sharded" and world > 1
         if any((cfg.dataset_split_uri(sp) and tfrecord_files(cfg.dataset_split_uri(sp))) for sp in ("train", "val", "test")):
             return None
         try:
-            res = ResidentGraph(cfg, device, sharded=False, need_out_graph=True)
+            res = ResidentGraph(cfg, device, rank=rank, world=world, sharded=want_shards, need_out_graph=True)
         except NotImplementedError:
             return None
         self._resident = res
-        res.train_as_graph_data = not encoder_trains_over_hip_batches(inner.encoder)
+        self.hbm_graph = "sharded" if res.sharded else "replica"
+        res.train_as_graph_data = res.sharded or not encoder_trains_over_hip_batches(inner.encoder)
         # (a GAT encoder reads the stored rows in place where its input-side training forward applies, and gathers the dense
-        # matrix itself where it does not: GraphData.features())
-        res.defer_x = type(inner.encoder).__name__ == "GAT" and type(inner.encoder).__module__ == "gigl_amd.models_attn"
+        # matrix itself where it does not: GraphData.features(); on a sharded graph the rows are the pulled ones)
+        res.defer_x = (not res.sharded) and type(inner.encoder).__name__ == "GAT" and \
+            type(inner.encoder).__module__ == "gigl_amd.models_attn"
         # one engine for the job: the encoder / decoder run on the resident graph's engine
         if self._engine is not None and self._engine is not res.engine:
             self._engine.close()

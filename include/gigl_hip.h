@@ -1017,7 +1017,11 @@ int32_t gigl_sage_plan_run_part(gigl_sage_plan* plan, const uint32_t* roots, int
  *   SAMPLED       sum of cnt[k][*]: (src -> dst) pairs emitted by the hop expansions, before batch dedup
  *   AGGREGATED    sum over layers l of the in-edges of the rows layer l computes (levels <= hops-1-l): edges actually
  *                 consumed by a segmented reduce (the reference executes hops * UNION_EDGES)
- *   EXPAND_BYTES  sum over frontier nodes of 16 + 4*deg + 8*min(deg, fanout)
+ *   EXPAND_BYTES  sum over frontier nodes of what a position-keyed sampler must move: 16 (row bounds) + 4*deg for a row of
+ *                 <= fanout neighbours, else 8*min(deg, lambda) + 4*fanout (the lambda = f + 4 sqrt(f) + 4 threshold-list
+ *                 pairs that can hold the f smallest keys, and the f chosen ids) + 8*min(deg, fanout) written.  (SURVEY
+ *                 8(d)'s 4*deg for every row charges an adjacency read the reference's rule never needs: the key of
+ *                 entry i depends on the position i only, SamplingStrategy.scala:55.)
  *   AGG_LAYER0+l / ROWS_LAYER0+l   aggregated edges / computed rows of layer l
  * `roots` = the roots passed to that run. */
 #define GIGL_STATS_SAMPLED 0
