@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ONE || (HS
 // same loaders, LDS planes and swizzle), except that the four waves split the ROWS (wave = 32 rows x 128 hidden) and the
 // MFMA operands are swapped, acc = W-fragment x A-fragment = the TRANSPOSED block: lane r holds row r, its 16 registers
 // hidden columns 8 (v / 4) + 4 g + v % 4 — which IS the A-fragment layout of the next product (lane = row, registers = k)
-// up to a permutation of k inside each 16-block, applied to W2's planes when they are prepared (fused2_prepare_kernel):
+// up to a permutation of k inside each 16-block, applied to W2's planes when they are prepared (fused2_split_kernel):
 // the hidden tile goes from accumulators to operand registers without touching LDS.
 // Second product: h = relu(acc / (s_a s_w) + b1) is bounded by K max|W1| max|a| + max|b1| =: B (found on the device
 // from the scales of the first product), so it takes the half split too: h s_h = h1 + h2 with s_h a power of two that
@@ -1377,24 +1377,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
     }
 }
 
-// f2[0..2] = {s_h, s_w2, 1 / (s_h s_w2)} and the fp16 planes of W2p = [W_l ; W_r] of the last layer ([96][256]: rows
-// 0..out-1 = W_l, 48..48+out-1 = W_r, the rest zero), scaled by s_w2, each 16-block of k stored in the order the fused
-// kernel's accumulator registers hold it: position 8 g + e <- element 8 (e / 4) + 4 g + e % 4.  One workgroup, per run
-// (the weights are read as they are now).  hs = the first product's scales {s_a, s_w, ...} (gigl_hs_scale_update ran
-// before on the same stream): max|a| < 2^15 / s_a, max|W1| < 2^15 / s_w.
-__global__ __launch_bounds__(1024) void fused2_prepare_kernel(const float* __restrict__ hs, const float* __restrict__ b1,
-                                                              const float* __restrict__ w2, int n_out, int K1,
-                                                              float* __restrict__ f2, _Float16* __restrict__ w2h) {
-  __shared__ float s_m[2][16];
-  __shared__ float s_sc[2];
-  const int tid = threadIdx.x;
+// f2[0..2] = {s_h, s_w2, 1 / (s_h s_w2)}, per run (the weights are read as they are now): max|b1| and max|W2| over a few
+// small workgroups folded with atomicMax (non-negative floats order like their bits), the LAST one to finish — ticket —
+// turns them into the scales and clears maxima and ticket for the next run (f2[4], f2[5] = the maxima, f2[6] = ticket:
+// zero between runs).  hs = the first product's scales {s_a, s_w, ...} (gigl_hs_scale_update ran before on the same
+// stream): max|a| < 2^15 / s_a, max|W1| < 2^15 / s_w.  (As ONE workgroup doing this and the split below the kernel took
+// 70 us per call on the stream's critical path next to the other streams' kernels: round 5.)
+__global__ __launch_bounds__(256) void fused2_scale_kernel(const float* __restrict__ hs, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2, int n_w2, int K1,
+                                                           float* __restrict__ f2) {
+  __shared__ float s_m[2][4];
+  const int tid = threadIdx.x, gt = blockIdx.x * 256 + tid, stride = gridDim.x * 256;
   float mb = 0.f, mw = 0.f;
   if (b1)
-    for (int i = tid; i < F2_HID; i += 1024) {
+    for (int i = gt; i < F2_HID; i += stride) {
       const float v = fabsf(b1[i]);
       mb = fmaxf(mb, v == v ? v : 0.f);
     }
-  for (int i = tid; i < n_out * 2 * F2_HID; i += 1024) {
+  for (int i = gt; i < n_w2; i += stride) {
     const float v = fabsf(w2[i]);
     mw = fmaxf(mw, v == v ? v : 0.f);
   }
@@ -1409,34 +1409,111 @@ __global__ __launch_bounds__(1024) void fused2_prepare_kernel(const float* __res
   }
   __syncthreads();
   if (tid == 0) {
-    for (int i = 1; i < 16; ++i) {
+    for (int i = 1; i < 4; ++i) {
       mb = fmaxf(mb, s_m[0][i]);
       mw = fmaxf(mw, s_m[1][i]);
     }
-    // |h| <= K max|W1| max|a| + max|b1| < K 2^30 / (s_a s_w) + max|b1|
-    const float inf = __uint_as_float(0x7F800000u);
-    float bound = (float)K1 * 1073741824.f * (1.f / hs[0]) * (1.f / hs[1]) + mb;
-    if (!(bound > 0.f) || !(bound < inf)) bound = 1.f;
-    const float s_h = hs_pow2_scale(bound) * 0.5f;  // bound * s_h in [2^13, 2^14)
-    const float s_w2 = (mw > 0.f && mw < inf) ? hs_pow2_scale(mw) : 1.f;
-    f2[0] = s_h;
-    f2[1] = s_w2;
-    f2[2] = (1.f / s_h) * (1.f / s_w2);
-    s_sc[0] = s_w2;
+    uint32_t* acc = reinterpret_cast<uint32_t*>(f2) + 4;
+    atomicMax(acc, __float_as_uint(mb));
+    atomicMax(acc + 1, __float_as_uint(mw));
+    __threadfence();
+    if (atomicAdd(acc + 2, 1u) == gridDim.x - 1) {  // the last workgroup: both maxima are in
+      const float b = __uint_as_float(atomicExch(acc, 0u)), w = __uint_as_float(atomicExch(acc + 1, 0u));
+      acc[2] = 0u;
+      // |h| <= K max|W1| max|a| + max|b1| < K 2^30 / (s_a s_w) + max|b1|
+      const float inf = __uint_as_float(0x7F800000u);
+      float bound = (float)K1 * 1073741824.f * (1.f / hs[0]) * (1.f / hs[1]) + b;
+      if (!(bound > 0.f) || !(bound < inf)) bound = 1.f;
+      const float s_h = hs_pow2_scale(bound) * 0.5f;  // bound * s_h in [2^13, 2^14)
+      const float s_w2 = (w > 0.f && w < inf) ? hs_pow2_scale(w) : 1.f;
+      f2[0] = s_h;
+      f2[1] = s_w2;
+      f2[2] = (1.f / s_h) * (1.f / s_w2);
+    }
+  }
+}
+
+// the fp16 planes of W2p = [W_l ; W_r] of the last layer ([96][256]: rows 0..out-1 = W_l, 48..48+out-1 = W_r, the rest
+// zero), scaled by s_w2 = f2[1], each 16-block of k stored in the order the fused kernel's accumulator registers hold it:
+// position 8 g + e <- element 8 (e / 4) + 4 g + e % 4.  One thread per element.
+__global__ __launch_bounds__(256) void fused2_split_kernel(const float* __restrict__ f2, const float* __restrict__ w2,
+                                                           int n_out, _Float16* __restrict__ w2h) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= F2_N2 * F2_HID) return;
+  const float s_w2 = f2[1];
+  const int c = i / F2_HID, pos = i - c * F2_HID;
+  const int blk = pos >> 4, in = pos & 15, gg = in >> 3, e = in & 7;
+  const int k = blk * 16 + 8 * (e >> 2) + 4 * gg + (e & 3);  // the element that sits at position `pos`
+  float x = 0.f;
+  if (c < n_out) x = w2[(int64_t)c * 2 * F2_HID + k];
+  else if (c >= F2_N2 / 2 && c - F2_N2 / 2 < n_out) x = w2[(int64_t)(c - F2_N2 / 2) * 2 * F2_HID + F2_HID + k];
+  x *= s_w2;
+  const _Float16 a1 = (_Float16)x;
+  w2h[i] = a1;
+  w2h[F2_N2 * F2_HID + i] = (_Float16)(x - (float)a1);
+}
+
+// Half-split scales of a layer >= 1 (round 5): its operand [reduce(h) | h] is made of the previous layer's outputs h =
+// act(a . W^T + b), bounded by K max|W| max|a| + max|b| — and max|a| < 2^15 / s_a, max|W| < 2^15 / s_w are what the
+// previous layer's own scales hs_prev = {s_a, s_w, ..} say.  hs_out = {s_h, s_w', 1 / (s_h s_w')}: s_h brings that bound
+// under 2^14 (a mean / max of rows stays inside it; a SUM over up to `fan` rows: the bound times fan), s_w' the largest
+// |w'| of THIS layer's weights into [2^14, 2^15).  Per run (the weights are read as they are now); hs_out: 8 floats,
+// zero-initialised once by the caller.
+__global__ __launch_bounds__(256) void hs_chain_kernel(const float* __restrict__ hs_prev, const float* __restrict__ b_prev,
+                                                       int n_b, int k_prev, float fan, const float* __restrict__ w,
+                                                       int64_t n_w, float* __restrict__ hs_out) {
+  // (a few small workgroups + a ticket, as hs_scale_kernel: hs_out[4], [5] = running maxima, [6] = ticket, zero between runs)
+  __shared__ float s_m[2][4];
+  const int tid = threadIdx.x;
+  const int64_t gt = (int64_t)blockIdx.x * 256 + tid, stride = (int64_t)gridDim.x * 256;
+  float mb = 0.f, mw = 0.f;
+  if (b_prev)
+    for (int64_t i = gt; i < n_b; i += stride) {
+      const float v = fabsf(b_prev[i]);
+      mb = fmaxf(mb, v == v ? v : 0.f);
+    }
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(w) & 15) == 0) ? n_w / 4 : 0;
+  for (int64_t i = gt; i < n4; i += stride) {
+    const float4 v = w4[i];
+    const float a = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+    mw = fmaxf(mw, a == a ? a : 0.f);
+  }
+  for (int64_t i = n4 * 4 + gt; i < n_w; i += stride) {
+    const float v = fabsf(w[i]);
+    mw = fmaxf(mw, v == v ? v : 0.f);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    mb = fmaxf(mb, __shfl_xor(mb, o, 64));
+    mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+  }
+  if ((tid & 63) == 0) {
+    s_m[0][tid >> 6] = mb;
+    s_m[1][tid >> 6] = mw;
   }
   __syncthreads();
-  const float s_w2 = s_sc[0];
-  for (int i = tid; i < F2_N2 * F2_HID; i += 1024) {
-    const int c = i / F2_HID, pos = i - c * F2_HID;
-    const int blk = pos >> 4, in = pos & 15, gg = in >> 3, e = in & 7;
-    const int k = blk * 16 + 8 * (e >> 2) + 4 * gg + (e & 3);  // the element that sits at position `pos`
-    float x = 0.f;
-    if (c < n_out) x = w2[(int64_t)c * 2 * F2_HID + k];
-    else if (c >= F2_N2 / 2 && c - F2_N2 / 2 < n_out) x = w2[(int64_t)(c - F2_N2 / 2) * 2 * F2_HID + F2_HID + k];
-    x *= s_w2;
-    const _Float16 a1 = (_Float16)x;
-    w2h[i] = a1;
-    w2h[F2_N2 * F2_HID + i] = (_Float16)(x - (float)a1);
+  if (tid == 0) {
+    for (int i = 1; i < 4; ++i) {
+      mb = fmaxf(mb, s_m[0][i]);
+      mw = fmaxf(mw, s_m[1][i]);
+    }
+    uint32_t* acc = reinterpret_cast<uint32_t*>(hs_out) + 4;
+    atomicMax(acc, __float_as_uint(mb));
+    atomicMax(acc + 1, __float_as_uint(mw));
+    __threadfence();
+    if (atomicAdd(acc + 2, 1u) == gridDim.x - 1) {
+      const float b = __uint_as_float(atomicExch(acc, 0u)), wm = __uint_as_float(atomicExch(acc + 1, 0u));
+      acc[2] = 0u;
+      const float inf = __uint_as_float(0x7F800000u);
+      float bound = ((float)k_prev * 1073741824.f * (1.f / hs_prev[0]) * (1.f / hs_prev[1]) + b) * fan;
+      if (!(bound > 0.f) || !(bound < inf)) bound = 1.f;
+      const float s_h = hs_pow2_scale(bound) * 0.5f;
+      const float s_w = (wm > 0.f && wm < inf) ? hs_pow2_scale(wm) : 1.f;
+      hs_out[0] = s_h;
+      hs_out[1] = s_w;
+      hs_out[2] = (1.f / s_h) * (1.f / s_w);
+    }
   }
 }
 
@@ -4067,8 +4144,20 @@ int32_t gigl_fused2_row_floats() { return F2_N2; }
 
 int32_t gigl_fused2_prepare(gigl_ctx* ctx, const float* hs_dev, const float* b1, const float* w2, int32_t n_out, int32_t k1,
                             float* f2, void* w2h) {
-  hipLaunchKernelGGL(fused2_prepare_kernel, dim3(1), dim3(1024), 0, ctx->stream, hs_dev, b1, w2, n_out, k1, f2,
+  // (f2: 16 floats, zero-initialised by the caller once: [4..6] are the scale kernel's accumulators + ticket)
+  hipLaunchKernelGGL(fused2_scale_kernel, dim3(24), dim3(256), 0, ctx->stream, hs_dev, b1, w2, n_out * 2 * F2_HID, k1, f2);
+  hipLaunchKernelGGL(fused2_split_kernel, dim3((F2_N2 * F2_HID + 255) / 256), dim3(256), 0, ctx->stream, f2, w2, n_out,
                      (_Float16*)w2h);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_hs_chain_update(gigl_ctx* ctx, const float* hs_prev, const float* b_prev, int32_t n_b, int32_t k_prev, float fan,
+                             const float* w, int64_t n_w, float* hs_out) {
+  int64_t wgs = (n_w / 4 + 255) / 256;
+  wgs = wgs < 1 ? 1 : (wgs > 64 ? 64 : wgs);
+  hipLaunchKernelGGL(hs_chain_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, hs_prev, b_prev, n_b, k_prev, fan, w, n_w,
+                     hs_out);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

@@ -163,6 +163,10 @@ int32_t gigl_gat_input_layer_fused_hs(gigl_ctx* ctx, const void* src, int32_t sr
 // layer over those rows (one reduction + self half + bias per root, written straight into the caller's `out`);
 // gigl_fused2_prepare (per run, after gigl_hs_scale_update on the same stream) finds the second product's scales and
 // lays out W2's fp16 planes.  gigl_fused2_shape_ok: hidden width 256, 2 * out <= row floats, d0 % 4 == 0.
+// half-split scales of a layer >= 1 from the previous layer's (its outputs are bounded by K max|W| max|a| + max|b|): hs_out
+// = {s_h, s_w, 1 / (s_h s_w)} for gigl_linear_tiled(.., hs_scale); fan > 1 under a sum reduction.  Per run, on the stream.
+int32_t gigl_hs_chain_update(gigl_ctx* ctx, const float* hs_prev, const float* b_prev, int32_t n_b, int32_t k_prev, float fan,
+                             const float* w, int64_t n_w, float* hs_out);
 bool gigl_fused2_shape_ok(int32_t d0, int32_t hid, int32_t n_out);
 int64_t gigl_fused2_w2h_bytes();
 int32_t gigl_fused2_row_floats();

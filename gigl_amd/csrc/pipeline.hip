@@ -79,6 +79,9 @@ struct gigl_sage_plan {
   // layer over an fp32 table): layer 0's projection applies the last layer's [W_l | W_r] to its hidden rows before they
   // leave the workgroup — hbuf[0] then holds the two K-split planes of p = [W_l h | W_r h] ([2][act_rows][96]) instead of
   // hidden rows, and the last layer is one reduction over p rows written straight into the caller's `out`
+  // layers >= 1 on the half split too (round 5): their operands are previous-layer outputs, bounded from the previous
+  // layer's own scales (gigl_hs_chain_update) — hs_layer[l] = {s_h, s_w, 1 / (s_h s_w)} of layer l, chained from hs_dev
+  float* hs_layer[GIGL_MAX_HOPS] = {nullptr};
   bool f2_ok = false;
   float* f2_dev = nullptr;  // {s_h, s_w2, 1 / (s_h s_w2)}: the second product's scales (gigl_fused2_prepare, per run)
   void* w2h = nullptr;      // W2's fp16 planes
@@ -186,6 +189,15 @@ __global__ __launch_bounds__(256) void plan_stats_kernel(StatsArgs a, unsigned l
 
 // stages of one batch: 0 sample, 1 union, 2+2l gather l, 3+2l linear l, 2+2L take_rows
 int n_stages(const gigl_sage_plan* p) { return 3 + 2 * p->hops; }
+
+// (A/B knob: GIGL_PLAN_HS_LAYERS=0 keeps layers >= 1 on the three bf16 planes)
+bool hs_layers_on() {
+  static const bool on = [] {
+    const char* e = getenv("GIGL_PLAN_HS_LAYERS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
 
 // the fused two-layer projection applies to this plan as it is configured now (every input of the decision drops the
 // captured graphs when it changes: weights, reduction, projected input, half split)
@@ -306,6 +318,18 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
     const int32_t rc = gigl_hs_scale_update(ctx, p->w[0], (int64_t)p->dims[1] * 2 * d, p->hs_sa, p->hs_dev);
     if (rc != GIGL_OK) return rc;
     hs_scale = p->hs_dev;
+  }
+  if (l >= 1 && two_src && p->hs0 && !p->proj && p->hs_layer[l] && hs_layers_on()) {
+    // half split for a layer >= 1: three fp16 products instead of six bf16 ones
+    const float* prev = l == 1 ? p->hs_dev : p->hs_layer[l - 1];
+    float fan = 1.f;
+    if (p->aggr == GIGL_AGGR_SUM)
+      for (int k = 0; k < p->hops; ++k) fan = (float)p->fanouts[k] > fan ? (float)p->fanouts[k] : fan;
+    int32_t rc = gigl_hs_chain_update(ctx, prev, p->bias[l - 1], p->dims[l], 2 * p->dims[l - 1], fan, p->w[l],
+                                      (int64_t)p->dims[l + 1] * 2 * d, p->hs_layer[l]);
+    if (rc != GIGL_OK) return rc;
+    return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
+                             p->hbuf[l & 1], p->hbuf[(l - 1) & 1], nullptr, d, d, p->hs_layer[l]);
   }
   if (l == 0 && fused2_on(p)) {
     int32_t rc = gigl_fused2_prepare(ctx, p->hs_dev, p->bias[0], p->w[1], p->dims[2], 2 * d, p->f2_dev, p->w2h);
@@ -620,11 +644,15 @@ static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, in
   if (p->zero_dev && hipMemset(p->zero_dev, 0, 64) != hipSuccess) ok = false;
   p->hs_dev = p->zero_dev ? reinterpret_cast<float*>(p->zero_dev + 4) : nullptr;
   p->act_rows = act_rows;
+  for (int k = 1; k < hops && with_abuf; ++k) {
+    p->hs_layer[k] = (float*)alloc(64);
+    ok = ok && p->hs_layer[k] && hipMemset(p->hs_layer[k], 0, 64) == hipSuccess;
+  }
   if (with_abuf && hops == 2 && gigl_fused2_shape_ok(dims[0], dims[1], dims[2]) && getenv("GIGL_PLAN_NO_FUSE2") == nullptr &&
       (int64_t)max_out >= 2 * gigl_fused2_row_floats()) {
     p->f2_dev = (float*)alloc(64);
     p->w2h = alloc((size_t)gigl_fused2_w2h_bytes());
-    p->f2_ok = p->f2_dev && p->w2h;
+    p->f2_ok = p->f2_dev && p->w2h && hipMemset(p->f2_dev, 0, 64) == hipSuccess;
     ok = ok && p->f2_ok;
   }
   ok = ok && p->zero_dev && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col && p->un.root_local &&

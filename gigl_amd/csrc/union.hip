@@ -49,11 +49,21 @@ static hipError_t lds_opt_in(int device, int site, const void* fn, int bytes, co
   return e;
 }
 
+// (A/B knob: GIGL_LG_BIG_CAP=16384 keeps the plans' long-row pass on the 128-KB shape)
+static bool lg_big_cap_wide() {
+  static const bool wide = [] {
+    const char* e = getenv("GIGL_LG_BIG_CAP");
+    return e && atoi(e) >= 16384;
+  }();
+  return wide;
+}
+
 namespace {
 
 constexpr int MAXL = GIGL_MAX_HOPS + 1;
 constexpr int TILE = 1024;          // stream positions per count/assign workgroup
 constexpr int BIG_ROW_CAP = 16384;  // LDS bitonic capacity (64 KiB of int32)
+constexpr int LG_BIG_CAP = 4096;    // ... of the plans' long-row pass (lg2_row_sort_big_kernel: 32 KB of dynamic LDS)
 
 // one open-addressing slot: everything the passes need about a node sits in ONE 16-byte entry, so a probe
 // costs one random memory access instead of one per attribute array
@@ -658,8 +668,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 // "flip" form, every compare-exchange ascending, so positions past the row's end act as +inf and any length works —
 // then made distinct chunk by chunk through LDS (a chunk is read completely before its survivors are written at or
 // before its start).  ~0.3 ms for a row of 65,536: rare by construction.  Returns the number of distinct values.
-__device__ int32_t huge_row_sort_distinct(int32_t* __restrict__ row, int32_t m, int32_t* lds /* >= 2 * BIG_ROW_CAP */,
-                                          int32_t* s_tmp /* >= 20 ints of LDS */) {
+__device__ int32_t huge_row_sort_distinct(int32_t* __restrict__ row, int32_t m, int32_t* lds /* >= lds_ints */,
+                                          int32_t* s_tmp /* >= 20 ints of LDS */, int32_t lds_ints = 2 * BIG_ROW_CAP) {
   const int tid = threadIdx.x;
   int64_t pow2 = 1;
   while (pow2 < m) pow2 <<= 1;
@@ -692,8 +702,8 @@ __device__ int32_t huge_row_sort_distinct(int32_t* __restrict__ row, int32_t m, 
   }
   __threadfence_block();
   __syncthreads();
-  // distinct, in order: chunks of 2 * BIG_ROW_CAP values through LDS
-  const int32_t CH = 2 * BIG_ROW_CAP;
+  // distinct, in order: chunks of lds_ints values through LDS
+  const int32_t CH = lds_ints;
   int32_t out = 0;
   for (int32_t c0 = 0; c0 < m; c0 += CH) {
     const int32_t n = min(CH, m - c0);
@@ -1448,6 +1458,10 @@ __global__ __launch_bounds__(256) void lg2_row_sort_kernel(const int32_t* sort_r
 // queued rows: duplicates removed through an LDS hash set (any number of entries, <= BIG_ROW_CAP distinct), the
 // distinct values written back to the head of the row, then the bucket sort of row_sort_big_kernel.  The last
 // workgroup to finish publishes meta[N_EDGES].
+// CAP: distinct values the LDS set / sort hold (2 * CAP ints of dynamic LDS).  The plans launch CAP = 4096 (32 KB: finds a CU
+// next to other streams' kernels; a row of more distinct values — a hub met under > 400 parents of one batch — takes the
+// global-memory path), round 5: the 128-KB shape waited ~200 us per call for a CU with that much LDS free.
+template <int CAP>
 __global__ __launch_bounds__(1024) void lg2_row_sort_big_kernel(const int32_t* rowptr, int32_t* rowend, int32_t* col,
                                                                 const int32_t* big_rows, const int32_t* big_count,
                                                                 int32_t* overflow, int32_t* edge_counters,
@@ -1457,7 +1471,7 @@ __global__ __launch_bounds__(1024) void lg2_row_sort_big_kernel(const int32_t* r
   // tile_edges: per-tile edge counts written by plain stores, added to the total here)
   extern __shared__ int32_t lds[];  // hash set of 2*CAP keys, then A = lds[0..CAP), B = lds[CAP..2CAP)
   int32_t* A = lds;
-  int32_t* B = lds + BIG_ROW_CAP;
+  int32_t* B = lds + CAP;
   __shared__ int32_t s_cnt[NBUCKET];
   __shared__ int32_t s_off[NBUCKET + 1];
   __shared__ int32_t s_w[16];
@@ -1465,19 +1479,19 @@ __global__ __launch_bounds__(1024) void lg2_row_sort_big_kernel(const int32_t* r
   __shared__ int32_t s_min, s_max, s_uniq, s_last;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int32_t nb = *big_count;
-  constexpr uint32_t HMASK = 2 * BIG_ROW_CAP - 1;
+  constexpr uint32_t HMASK = 2 * CAP - 1;
   int32_t edges = 0;
   for (int32_t r = blockIdx.x; r < nb; r += gridDim.x) {
     const int32_t i = big_rows[r];
     const int32_t s = rowptr[i], m_raw = rowend[i] - s;
     // ---- distinct values
-    for (int q = tid; q < 2 * BIG_ROW_CAP; q += 1024) lds[q] = -1;
+    for (int q = tid; q < 2 * CAP; q += 1024) lds[q] = -1;
     if (tid == 0) s_uniq = 0;
     __syncthreads();
     for (int q = tid; q < m_raw; q += 1024) {
       // (more distinct values than the sort holds: the row takes the global-memory path below — stop filling the set,
       // whose probe chains grow without bound as it fills)
-      if (*(volatile int32_t*)&s_uniq > BIG_ROW_CAP) break;
+      if (*(volatile int32_t*)&s_uniq > CAP) break;
       const int32_t v = col[s + q];
       uint32_t h = hash_u32((uint32_t)v) & HMASK;
       for (uint32_t probes = 0; probes <= HMASK; ++probes) {
@@ -1493,8 +1507,8 @@ __global__ __launch_bounds__(1024) void lg2_row_sort_big_kernel(const int32_t* r
     __syncthreads();
     const int32_t m = s_uniq;
     __syncthreads();  // (everybody has read the count before it is reused as the compaction cursor)
-    if (m > BIG_ROW_CAP) {  // more distinct values than the LDS set / sort hold: sorted + made distinct in global memory
-      const int32_t md = huge_row_sort_distinct(col + s, m_raw, lds, s_w);
+    if (m > CAP) {  // more distinct values than the LDS set / sort hold: sorted + made distinct in global memory
+      const int32_t md = huge_row_sort_distinct(col + s, m_raw, lds, s_w, 2 * CAP);
       if (tid == 0) {
         rowend[i] = s + md;
         edges += md;
@@ -1505,7 +1519,7 @@ __global__ __launch_bounds__(1024) void lg2_row_sort_big_kernel(const int32_t* r
     // compact the set into the head of the row (order irrelevant: sorted next)
     if (tid == 0) s_uniq = 0;
     __syncthreads();
-    for (int q = tid; q < 2 * BIG_ROW_CAP; q += 1024) {
+    for (int q = tid; q < 2 * CAP; q += 1024) {
       const int32_t v = lds[q];
       if (v != -1) col[s + atomicAdd(&s_uniq, 1)] = v;
     }
@@ -1747,9 +1761,14 @@ int32_t union_build_lg2(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
     if (blocks < 64) blocks = 64;
     hipLaunchKernelGGL(lg2_row_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, sort_rows, sort_count,
                        out->rowptr, out->rowend, out->col, big_rows, big_count, edge_counters);
-    GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 0, (const void*)lg2_row_sort_big_kernel, 2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
-    // (a handful of workgroups: each needs most of a CU's LDS, and rows of more than MED_ROW entries are rare)
-    hipLaunchKernelGGL(lg2_row_sort_big_kernel, dim3(8), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st,
+    // (a handful of workgroups; rows of more than MED_ROW entries are rare)
+    if (lg_big_cap_wide()) {
+      GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 0, (const void*)lg2_row_sort_big_kernel<BIG_ROW_CAP>, 2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
+      hipLaunchKernelGGL(lg2_row_sort_big_kernel<BIG_ROW_CAP>, dim3(8), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st,
+                       out->rowptr, out->rowend, out->col, big_rows, big_count, out->meta + GIGL_META_OVERFLOW,
+                       edge_counters, ticket_big, out->meta);
+    } else
+    hipLaunchKernelGGL(lg2_row_sort_big_kernel<LG_BIG_CAP>, dim3(8), dim3(1024), 2 * LG_BIG_CAP * sizeof(int32_t), st,
                        out->rowptr, out->rowend, out->col, big_rows, big_count, out->meta + GIGL_META_OVERFLOW,
                        edge_counters, ticket_big, out->meta);
   }
@@ -2579,8 +2598,7 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
   int32_t* tile_counts = zeros + 64 + 32 * EC_STRIDE;
   const int TB = 256;
   auto grid = [&](int64_t n) { return dim3((unsigned)((n + TB - 1) / TB)); };
-  GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 1, (const void*)lg3_dedup_kernel<1024>, 150 * 1024, (const void*)lg2_row_sort_big_kernel,
-                                 2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
+  GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 1, (const void*)lg3_dedup_kernel<1024>, 150 * 1024));
   GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 3, (const void*)lg3_dedup_kernel<512>, 150 * 1024));
   {
     gigl_prof_scope ps(ctx, GIGL_K_UNION_INSERT);
@@ -2617,7 +2635,13 @@ int32_t union_build_lg3(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* t
     if (blocks < 64) blocks = 64;
     hipLaunchKernelGGL(lg2_row_sort_kernel, dim3((unsigned)blocks), dim3(256), 0, st, sort_rows, sort_count, out->rowptr,
                        out->rowend, out->col, big_rows, big_count, edge_counters, EC_STRIDE);
-    hipLaunchKernelGGL(lg2_row_sort_big_kernel, dim3(8), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st, out->rowptr,
+    if (lg_big_cap_wide()) {
+      GIGL_HIP_CHECK(ctx, lds_opt_in(ctx->device, 4, (const void*)lg2_row_sort_big_kernel<BIG_ROW_CAP>, 2 * BIG_ROW_CAP * (int)sizeof(int32_t)));
+      hipLaunchKernelGGL(lg2_row_sort_big_kernel<BIG_ROW_CAP>, dim3(8), dim3(1024), 2 * BIG_ROW_CAP * sizeof(int32_t), st, out->rowptr,
+                       out->rowend, out->col, big_rows, big_count, out->meta + GIGL_META_OVERFLOW, edge_counters,
+                       ticket_big, out->meta, EC_STRIDE, (const int32_t*)tile_edges, n_tiles);
+    } else
+    hipLaunchKernelGGL(lg2_row_sort_big_kernel<LG_BIG_CAP>, dim3(8), dim3(1024), 2 * LG_BIG_CAP * sizeof(int32_t), st, out->rowptr,
                        out->rowend, out->col, big_rows, big_count, out->meta + GIGL_META_OVERFLOW, edge_counters,
                        ticket_big, out->meta, EC_STRIDE, (const int32_t*)tile_edges, n_tiles);
   }
