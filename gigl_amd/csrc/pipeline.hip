@@ -1356,4 +1356,688 @@ int32_t gigl_sage_train_plan_step2(gigl_sage_train_plan* t, const uint32_t* root
 
 const float* gigl_sage_train_plan_loss(gigl_sage_train_plan* t) { return t ? t->loss : nullptr; }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gigl_nablp_train_plan: one LINK-PREDICTION training step per call, all of it in the library (round 5) —
+//   NodeAnchorBasedLinkPredictionModelingTaskSpec.train's loop body
+//   (python/gigl/src/common/modeling_task_specs/node_anchor_based_link_prediction_modeling_task_spec.py:334-451):
+//   infer_task_inputs (utils/infer.py: two encoder forwards — main batch, random-negative batch — query / positive /
+//   random-negative embeddings by root index, inner-product scores of the repeated queries against cat(pos, rand_neg):
+//   decoder.py:64-70), Retrieval.forward -> RetrievalLoss (loss.py:209-331: temperature, same-query and accidental-hit
+//   masks, cross-entropy against the diagonal, summed, / rows), backward, Adam.
+// with the reference's default encoder (GraphSAGE, mean, optional L2-normalised output).  Main batch = b anchors x
+// (1 + P) rooted trees, anchor-major (anchor, its P positive slots; a missing positive repeats the anchor and is masked
+// out by pos_cnt); random negatives = n_rn roots.  Everything is capacity-shaped (Q = b P query rows, C = Q + n_rn
+// candidates, validity masks on the device): no host read, no torch kernel, one captured hipGraph per step.
+struct gigl_nablp_train_plan {
+  gigl_ctx* ctx = nullptr;
+  gigl_ctx* lctx = nullptr;  // private ctx (own arena) bound to the caller's stream: every launch of the step
+  struct Enc {
+    gigl_sage_plan* base = nullptr;  // tree / union workspace of this encode's roots
+    int32_t b = 0;
+    int64_t rows_cap[GIGL_MAX_HOPS] = {0};
+    float* a[GIGL_MAX_HOPS] = {nullptr};
+    float* h[GIGL_MAX_HOPS] = {nullptr};
+    float* dh[GIGL_MAX_HOPS] = {nullptr};
+    float* gw[GIGL_MAX_HOPS] = {nullptr};
+    float* gb[GIGL_MAX_HOPS] = {nullptr};
+    float* emb = nullptr;   // [b][d_out]: the roots' embeddings (normalised when the model says so)
+    float* inv = nullptr;   // [b]: 1 / max(|h_r|, 1e-12) (1 without normalisation; 0: no such root)
+    float* demb = nullptr;  // [b][d_out]
+  } enc[2];                 // 0: main batch, 1: random negatives
+  int32_t L = 0, b = 0, P = 0, n_rn = 0, normalize = 0, remove_hits = 1, act_last = 0;
+  float temperature = 0.07f;
+  int32_t dims[GIGL_MAX_HOPS + 1] = {0};
+  float* w[GIGL_MAX_HOPS] = {nullptr};  // fused [dims[l+1]][2 dims[l]]: borrowed, UPDATED IN PLACE
+  float* bias[GIGL_MAX_HOPS] = {nullptr};
+  float* mom[4 * GIGL_MAX_HOPS] = {nullptr};
+  float* da = nullptr;
+  float* wt = nullptr;
+  void* zero_base = nullptr;  // both encodes' gw | gb | dh: cleared at the start of every step
+  size_t zero_bytes = 0;
+  // the head: repeated queries, candidates, ids, validity, scores and their gradients
+  float *rq = nullptr, *cand = nullptr, *cand_t = nullptr, *scores = nullptr, *dscores = nullptr, *d_rq = nullptr, *d_cand = nullptr;
+  int64_t *qid = nullptr, *cid = nullptr;
+  int32_t* valid = nullptr;    // [C]: candidate column j takes part (rows i < Q use valid[i])
+  int32_t* pos_cnt = nullptr;  // [b] static copy of the step's input
+  int32_t* consts = nullptr;   // device {Q, C, Adam step, ...}
+  float *row_lse = nullptr, *row_loss = nullptr, *loss = nullptr;  // loss[0] = the step's loss, loss[1] = valid query rows
+  float lr = 5e-3f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, wd = 0.f;
+  std::vector<void*> owned;
+  hipGraphExec_t exec = nullptr;
+  bool warm = false;
+  int32_t cap_seed = 0, cap_mode = -1;
+};
+
+namespace {
+
+// e[r] = h[root_local[r]] (x 1 / max(|.|, 1e-12) when normalising: torch.nn.functional.normalize), one wave per root
+__global__ __launch_bounds__(256) void lp_take_norm_kernel(const float* __restrict__ h, const int32_t* __restrict__ root_local,
+                                                           int b, int d, int normalize, const int32_t* __restrict__ meta,
+                                                           float* __restrict__ emb, float* __restrict__ inv) {
+  const int lane = threadIdx.x & 63;
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= b) return;
+  const bool failed = meta[GIGL_META_OVERFLOW] != 0;
+  const int32_t l = failed ? -1 : root_local[r];
+  float* o = emb + (int64_t)r * d;
+  if (l < 0) {
+    const float v = failed ? __builtin_nanf("") : 0.f;
+    for (int c = lane; c < d; c += 64) o[c] = v;
+    if (lane == 0) inv[r] = 0.f;
+    return;
+  }
+  const float* row = h + (int64_t)l * d;
+  float ss = 0.f;
+  for (int c = lane; c < d; c += 64) ss += row[c] * row[c];
+  for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+  const float iv = normalize ? 1.f / fmaxf(sqrtf(ss), 1e-12f) : 1.f;
+  for (int c = lane; c < d; c += 64) o[c] = row[c] * iv;
+  if (lane == 0) inv[r] = iv;
+}
+
+// the head's operands from the two encodes: row q = (anchor i, positive slot j) of rq = the anchor's embedding, row q of
+// cand = that positive's; rows Q.. of cand = the random negatives'; ids for the loss masks; validity of every candidate
+__global__ __launch_bounds__(256) void lp_pack_kernel(const float* __restrict__ e_main, const float* __restrict__ e_rn,
+                                                      const uint32_t* __restrict__ roots_main,
+                                                      const uint32_t* __restrict__ roots_rn,
+                                                      const int32_t* __restrict__ pos_cnt, const float* __restrict__ inv_main,
+                                                      const float* __restrict__ inv_rn, int b, int P, int n_rn, int d,
+                                                      float* __restrict__ rq, float* __restrict__ cand,
+                                                      int64_t* __restrict__ qid, int64_t* __restrict__ cid,
+                                                      int32_t* __restrict__ valid) {
+  const int lane = threadIdx.x & 63;
+  const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int Q = b * P, T = 1 + P;
+  if (row >= Q + n_rn) return;
+  if (row < Q) {
+    const int i = row / P, j = row - i * P;
+    const int ra = i * T, rp = ra + 1 + j;
+    const uint32_t aid = roots_main[ra], pid = roots_main[rp];
+    const bool ok = aid != GIGL_INVALID && pid != GIGL_INVALID && j < pos_cnt[i] && inv_main[ra] != 0.f && inv_main[rp] != 0.f;
+    const float* qa = e_main + (int64_t)ra * d;
+    const float* pa = e_main + (int64_t)rp * d;
+    for (int c = lane; c < d; c += 64) {
+      rq[(int64_t)row * d + c] = ok ? qa[c] : 0.f;
+      cand[(int64_t)row * d + c] = ok ? pa[c] : 0.f;
+    }
+    if (lane == 0) {
+      qid[row] = (int64_t)aid;
+      cid[row] = (int64_t)pid;
+      valid[row] = ok ? 1 : 0;
+    }
+  } else {
+    const int r = row - Q;
+    const uint32_t id = roots_rn[r];
+    const bool ok = id != GIGL_INVALID && inv_rn[r] != 0.f;
+    const float* ea = e_rn + (int64_t)r * d;
+    for (int c = lane; c < d; c += 64) cand[(int64_t)row * d + c] = ok ? ea[c] : 0.f;
+    if (lane == 0) {
+      cid[row] = (int64_t)id;
+      valid[row] = ok ? 1 : 0;
+    }
+  }
+}
+
+__device__ __forceinline__ bool lp_excluded(const int64_t* qid, const int64_t* cid, const int32_t* valid, int remove_hits,
+                                            int Q, int i, int j, int64_t qid_i, int64_t cid_i) {
+  if (!valid[j]) return true;
+  if (j == i) return false;
+  if (j < Q && qid[j] == qid_i) return true;          // another positive of the same query (loss.py:279-305)
+  return remove_hits && cid[j] == cid_i;              // the positive itself among the other candidates (:307-331)
+}
+
+// retrieval loss rows (loss.hip's retrieval_rows_kernel with a validity mask): one workgroup per query row
+__global__ __launch_bounds__(256) void lp_loss_rows_kernel(const float* __restrict__ scores, int Q, int Cn, float temperature,
+                                                           const int64_t* __restrict__ qid, const int64_t* __restrict__ cid,
+                                                           const int32_t* __restrict__ valid, int remove_hits,
+                                                           float* __restrict__ row_lse, float* __restrict__ row_loss) {
+  __shared__ float s_m[4], s_s[4];
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (!valid[i]) {
+    if (tid == 0) {
+      row_lse[i] = 0.f;
+      row_loss[i] = 0.f;
+    }
+    return;
+  }
+  const float* row = scores + (int64_t)i * Cn;
+  const int64_t qid_i = qid[i], cid_i = cid[i];
+  const float it = temperature > 0.f ? 1.f / temperature : 1.f;
+  float m = -INFINITY, s = 0.f;
+  for (int j = tid; j < Cn; j += 256) {
+    if (lp_excluded(qid, cid, valid, remove_hits, Q, i, j, qid_i, cid_i)) continue;
+    const float v = temperature > 0.f ? row[j] / temperature : row[j];
+    if (v > m) {
+      s = s * expf(m - v) + 1.f;
+      m = v;
+    } else {
+      s += expf(v - m);
+    }
+  }
+  (void)it;
+  for (int off = 32; off > 0; off >>= 1) {
+    const float m2 = __shfl_xor(m, off, 64), s2 = __shfl_xor(s, off, 64);
+    const float mm = fmaxf(m, m2);
+    if (mm != -INFINITY) {
+      s = s * expf(m - mm) + s2 * expf(m2 - mm);
+      m = mm;
+    }
+  }
+  if (lane == 0) {
+    s_m[w] = m;
+    s_s[w] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float mm = s_m[0], ss = s_s[0];
+    for (int k = 1; k < 4; ++k) {
+      const float m2 = s_m[k], s2 = s_s[k], mx = fmaxf(mm, m2);
+      if (mx != -INFINITY) {
+        ss = ss * expf(mm - mx) + s2 * expf(m2 - mx);
+        mm = mx;
+      }
+    }
+    const float lse = mm + logf(ss);
+    row_lse[i] = lse;
+    row_loss[i] = lse - (temperature > 0.f ? row[i] / temperature : row[i]);
+  }
+}
+
+// loss[0] = sum of the valid rows' losses / their number (fixed order, in double), loss[1] = that number; Adam's step
+// counter moves when the step will be applied
+__global__ __launch_bounds__(1024) void lp_loss_sum_kernel(const float* __restrict__ row_loss, const int32_t* __restrict__ valid,
+                                                           int Q, float* __restrict__ loss, int32_t* __restrict__ step,
+                                                           const int32_t* __restrict__ meta_a, const int32_t* __restrict__ meta_b) {
+  __shared__ double s_w[16];
+  __shared__ int s_n[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  double acc = 0.0;
+  int n = 0;
+  for (int i = tid; i < Q; i += 1024) {
+    acc += (double)row_loss[i];
+    n += valid[i] ? 1 : 0;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    acc += __shfl_xor(acc, off, 64);
+    n += __shfl_xor(n, off, 64);
+  }
+  if (lane == 0) {
+    s_w[w] = acc;
+    s_n[w] = n;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    int nn = 0;
+    for (int k = 0; k < 16; ++k) {
+      t += s_w[k];
+      nn += s_n[k];
+    }
+    const bool failed = meta_a[GIGL_META_OVERFLOW] != 0 || meta_b[GIGL_META_OVERFLOW] != 0;
+    loss[0] = failed ? __builtin_nanf("") : (float)(t / (double)(nn > 0 ? nn : 1));
+    loss[1] = (float)nn;
+    if (!failed) *step += 1;
+  }
+}
+
+// dscores = d loss / d scores: (softmax - onehot) / temperature / rows for the columns that take part, 0 elsewhere
+__global__ __launch_bounds__(256) void lp_loss_backward_kernel(const float* __restrict__ scores, int Q, int Cn, float temperature,
+                                                               const int64_t* __restrict__ qid, const int64_t* __restrict__ cid,
+                                                               const int32_t* __restrict__ valid, int remove_hits,
+                                                               const float* __restrict__ row_lse, const float* __restrict__ loss,
+                                                               float* __restrict__ dscores) {
+  const int i = blockIdx.x;
+  float* out = dscores + (int64_t)i * Cn;
+  if (!valid[i]) {
+    for (int j = threadIdx.x; j < Cn; j += 256) out[j] = 0.f;
+    return;
+  }
+  const float* row = scores + (int64_t)i * Cn;
+  const int64_t qid_i = qid[i], cid_i = cid[i];
+  const float lse = row_lse[i];
+  const float nrows = loss[1] > 0.f ? loss[1] : 1.f;
+  const float scale = (temperature > 0.f ? 1.f / temperature : 1.f) / nrows;
+  for (int j = threadIdx.x; j < Cn; j += 256) {
+    float d = 0.f;
+    if (!lp_excluded(qid, cid, valid, remove_hits, Q, i, j, qid_i, cid_i)) {
+      const float v = temperature > 0.f ? row[j] / temperature : row[j];
+      d = (expf(v - lse) - (j == i ? 1.f : 0.f)) * scale;
+    }
+    out[j] = d;
+  }
+}
+
+// d emb of the two encodes from d rq / d cand: an anchor's row sums its P query rows, a positive's row is its candidate
+// row, a random negative's its own; then through the normalisation (dx = (g - y <y, g>) / max(|x|, eps)) and added to the
+// last layer's output gradient at the root's local row (roots that are the same node share it: atomics).  One wave per root.
+__global__ __launch_bounds__(256) void lp_unpack_scatter_kernel(const float* __restrict__ d_rq, const float* __restrict__ d_cand,
+                                                                const int32_t* __restrict__ valid, const float* __restrict__ emb,
+                                                                const float* __restrict__ inv,
+                                                                const int32_t* __restrict__ root_local, int which, int b, int P,
+                                                                int n_rn, int d, int normalize, float* __restrict__ dh_last) {
+  const int lane = threadIdx.x & 63;
+  const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int T = 1 + P, Q = b * P;
+  const int n_roots = which == 0 ? b * T : n_rn;
+  if (r >= n_roots) return;
+  const float iv = inv[r];
+  if (iv == 0.f) return;
+  const int32_t l = root_local[r];
+  if (l < 0) return;
+  const float* y = emb + (int64_t)r * d;
+  float dot = 0.f;
+  // (d <= 64 * 8: a lane keeps up to 8 columns)
+  float g[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = lane + 64 * u;
+    float v = 0.f;
+    if (c < d) {
+      if (which == 1) {
+        v = valid[Q + r] ? d_cand[(int64_t)(Q + r) * d + c] : 0.f;
+      } else {
+        const int i = r / T, t = r - i * T;
+        if (t == 0) {
+          for (int j = 0; j < P; ++j)
+            if (valid[i * P + j]) v += d_rq[(int64_t)(i * P + j) * d + c];
+        } else if (valid[i * P + t - 1]) {
+          v = d_cand[(int64_t)(i * P + t - 1) * d + c];
+        }
+      }
+      dot += v * y[c];
+    }
+    g[u] = v;
+  }
+  for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off, 64);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int c = lane + 64 * u;
+    if (c < d) {
+      const float dx = normalize ? (g[u] - y[c] * dot) * iv : g[u];
+      if (dx != 0.f) atomicAdd(&dh_last[(int64_t)l * d + c], dx);
+    }
+  }
+}
+
+// Adam over the SUM of the two encodes' gradients (both forwards share the weights)
+struct AdamPack2 {
+  float* p[2 * GIGL_MAX_HOPS];
+  const float* g1[2 * GIGL_MAX_HOPS];
+  const float* g2[2 * GIGL_MAX_HOPS];
+  float* m[2 * GIGL_MAX_HOPS];
+  float* v[2 * GIGL_MAX_HOPS];
+  int64_t n[2 * GIGL_MAX_HOPS];
+  int32_t count;
+  float lr, beta1, beta2, eps, wd;
+};
+
+__global__ __launch_bounds__(256) void lp_adam_kernel(AdamPack2 a, const int32_t* __restrict__ step_dev,
+                                                      const int32_t* __restrict__ meta_a, const int32_t* __restrict__ meta_b) {
+  if (meta_a[GIGL_META_OVERFLOW] != 0 || meta_b[GIGL_META_OVERFLOW] != 0) return;  // a failed batch trains nothing
+  const double t = (double)*step_dev;
+  const float bc1 = (float)(1.0 - pow((double)a.beta1, t)), bc2s = (float)sqrt(1.0 - pow((double)a.beta2, t));
+  const float step_size = a.lr / bc1;
+  for (int k = 0; k < a.count; ++k) {
+    float* p = a.p[k];
+    float* m = a.m[k];
+    float* v = a.v[k];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += (int64_t)gridDim.x * blockDim.x) {
+      const float w = p[i];
+      const float gr = (a.g1[k][i] + a.g2[k][i]) + a.wd * w;
+      const float mm = m[i] + (gr - m[i]) * (1.f - a.beta1);
+      const float vv = v[i] * a.beta2 + (1.f - a.beta2) * gr * gr;
+      m[i] = mm;
+      v[i] = vv;
+      p[i] = w - step_size * (mm / (sqrtf(vv) / bc2s + a.eps));
+    }
+  }
+}
+
+int32_t lp_forward(gigl_nablp_train_plan* t, int which) {
+  gigl_nablp_train_plan::Enc& e = t->enc[which];
+  gigl_sage_plan* p = e.base;
+  gigl_ctx* ctx = t->lctx;
+  const int L = t->L;
+  int32_t rc = GIGL_OK;
+  const int32_t* n_local = p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr;
+  for (int l = 0; l < L; ++l) {
+    const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
+    const int d = t->dims[l];
+    if (l == 0)
+      rc = gigl_gather_reduce_mixed(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, p->un.rowptr, p->un.rowend, p->un.col,
+                                    n_rows, e.rows_cap[0], GIGL_AGGR_MEAN, n_local, e.a[0]);
+    else
+      rc = gigl_gather_reduce(ctx, e.h[l - 1], GIGL_DTYPE_F32, d, nullptr, p->un.rowptr, p->un.rowend, p->un.col, n_rows,
+                              e.rows_cap[l], GIGL_AGGR_MEAN, e.a[l]);
+    if (rc != GIGL_OK) return rc;
+    rc = gigl_linear(ctx, e.a[l], t->w[l], t->bias[l], n_rows, e.rows_cap[l], 2 * d, t->dims[l + 1],
+                     (l < L - 1 || t->act_last) ? 1 : 0, e.h[l]);
+    if (rc != GIGL_OK) return rc;
+  }
+  const int dout = t->dims[L];
+  hipLaunchKernelGGL(lp_take_norm_kernel, dim3((unsigned)((e.b + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)e.h[L - 1],
+                     (const int32_t*)p->un.root_local, e.b, dout, t->normalize, (const int32_t*)p->un.meta, e.emb, e.inv);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t lp_backward(gigl_nablp_train_plan* t, int which) {
+  gigl_nablp_train_plan::Enc& e = t->enc[which];
+  gigl_sage_plan* p = e.base;
+  gigl_ctx* ctx = t->lctx;
+  hipStream_t st = ctx->stream;
+  const int L = t->L;
+  int32_t rc = GIGL_OK;
+  for (int l = L - 1; l >= 0; --l) {
+    const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
+    const int d = t->dims[l], n_out = t->dims[l + 1];
+    const bool act = l < L - 1 || t->act_last;
+    rc = gigl_linear_weight_grad(ctx, e.dh[l], e.a[l], act ? e.h[l] : nullptr, n_rows, e.rows_cap[l], n_out, 2 * d, e.gw[l],
+                                 t->bias[l] ? e.gb[l] : nullptr);
+    if (rc != GIGL_OK) return rc;
+    if (l == 0) break;
+    if (act) {
+      int64_t blocks = (e.rows_cap[l] * n_out + 255) / 256;
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, e.dh[l], (const float*)e.h[l], n_rows, n_out);
+    }
+    {
+      int64_t blocks = ((int64_t)n_out * 2 * d + 255) / 256;
+      hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)t->w[l], n_out, 2 * d, t->wt);
+    }
+    rc = gigl_linear(ctx, e.dh[l], t->wt, nullptr, n_rows, e.rows_cap[l], n_out, 2 * d, 0, t->da);
+    if (rc != GIGL_OK) return rc;
+    rc = gigl_gather_mean_backward(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, e.rows_cap[l], e.dh[l - 1]);
+    if (rc != GIGL_OK) return rc;
+  }
+  return GIGL_OK;
+}
+
+// every launch of a step, on lctx's stream (the caller's)
+int32_t lp_enqueue(gigl_nablp_train_plan* t, int32_t sampling_seed, int32_t mode) {
+  gigl_ctx* ctx = t->lctx;
+  hipStream_t st = ctx->stream;
+  const int L = t->L, d = t->dims[L], Q = t->b * t->P, Cn = Q + t->n_rn;
+  int32_t rc = GIGL_OK;
+  gigl_fill_u32(st, t->zero_base, 0u, (int64_t)(t->zero_bytes / 4));
+  for (int k = 0; k < 2; ++k) {  // sample + union of both root sets
+    gigl_sage_plan* p = t->enc[k].base;
+    rc = enqueue_range(p, 0, 2, p->roots_buf, sampling_seed, mode, nullptr);
+    if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(p->ctx));
+  }
+  for (int k = 0; k < 2; ++k) {
+    rc = lp_forward(t, k);
+    if (rc != GIGL_OK) return rc;
+  }
+  const gigl_sage_plan *pm = t->enc[0].base, *pr = t->enc[1].base;
+  hipLaunchKernelGGL(lp_pack_kernel, dim3((unsigned)((Cn + 3) / 4)), dim3(256), 0, st, (const float*)t->enc[0].emb,
+                     (const float*)t->enc[1].emb, (const uint32_t*)pm->roots_buf, (const uint32_t*)pr->roots_buf,
+                     (const int32_t*)t->pos_cnt, (const float*)t->enc[0].inv, (const float*)t->enc[1].inv, t->b, t->P, t->n_rn,
+                     d, t->rq, t->cand, t->qid, t->cid, t->valid);
+  // scores[q][c] = <rq[q], cand[c]>  (decoder.py:64-70: torch.mm(q, c.T))
+  rc = gigl_linear(ctx, t->rq, t->cand, nullptr, t->consts + 0, Q, d, Cn, 0, t->scores);
+  if (rc != GIGL_OK) return rc;
+  hipLaunchKernelGGL(lp_loss_rows_kernel, dim3((unsigned)Q), dim3(256), 0, st, (const float*)t->scores, Q, Cn, t->temperature,
+                     (const int64_t*)t->qid, (const int64_t*)t->cid, (const int32_t*)t->valid, t->remove_hits, t->row_lse,
+                     t->row_loss);
+  hipLaunchKernelGGL(lp_loss_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)t->row_loss, (const int32_t*)t->valid, Q,
+                     t->loss, t->consts + 2, (const int32_t*)pm->un.meta, (const int32_t*)pr->un.meta);
+  hipLaunchKernelGGL(lp_loss_backward_kernel, dim3((unsigned)Q), dim3(256), 0, st, (const float*)t->scores, Q, Cn,
+                     t->temperature, (const int64_t*)t->qid, (const int64_t*)t->cid, (const int32_t*)t->valid, t->remove_hits,
+                     (const float*)t->row_lse, (const float*)t->loss, t->dscores);
+  // d rq = dscores . cand ;  d cand = dscores^T . rq
+  {
+    int64_t blocks = ((int64_t)Cn * d + 255) / 256;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)t->cand, Cn, d, t->cand_t);
+  }
+  rc = gigl_linear(ctx, t->dscores, t->cand_t, nullptr, t->consts + 0, Q, Cn, d, 0, t->d_rq);
+  if (rc != GIGL_OK) return rc;
+  gigl_fill_u32(st, t->d_cand, 0u, (int64_t)Cn * d);  // (gigl_linear_weight_grad ADDS its chunks' sums to dw)
+  rc = gigl_linear_weight_grad(ctx, t->dscores, t->rq, nullptr, t->consts + 0, Q, Cn, d, t->d_cand, nullptr);
+  if (rc != GIGL_OK) return rc;
+  for (int k = 0; k < 2; ++k) {
+    const gigl_nablp_train_plan::Enc& e = t->enc[k];
+    hipLaunchKernelGGL(lp_unpack_scatter_kernel, dim3((unsigned)((e.b + 3) / 4)), dim3(256), 0, st, (const float*)t->d_rq,
+                       (const float*)t->d_cand, (const int32_t*)t->valid, (const float*)e.emb, (const float*)e.inv,
+                       (const int32_t*)e.base->un.root_local, k, t->b, t->P, t->n_rn, d, t->normalize, e.dh[L - 1]);
+  }
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  for (int k = 0; k < 2; ++k) {
+    rc = lp_backward(t, k);
+    if (rc != GIGL_OK) return rc;
+  }
+  AdamPack2 ap{};
+  for (int l = 0; l < L; ++l) {
+    ap.p[ap.count] = t->w[l];
+    ap.g1[ap.count] = t->enc[0].gw[l];
+    ap.g2[ap.count] = t->enc[1].gw[l];
+    ap.m[ap.count] = t->mom[4 * l];
+    ap.v[ap.count] = t->mom[4 * l + 1];
+    ap.n[ap.count++] = (int64_t)t->dims[l + 1] * 2 * t->dims[l];
+    if (t->bias[l]) {
+      ap.p[ap.count] = t->bias[l];
+      ap.g1[ap.count] = t->enc[0].gb[l];
+      ap.g2[ap.count] = t->enc[1].gb[l];
+      ap.m[ap.count] = t->mom[4 * l + 2];
+      ap.v[ap.count] = t->mom[4 * l + 3];
+      ap.n[ap.count++] = t->dims[l + 1];
+    }
+  }
+  ap.lr = t->lr;
+  ap.beta1 = t->beta1;
+  ap.beta2 = t->beta2;
+  ap.eps = t->eps;
+  ap.wd = t->wd;
+  hipLaunchKernelGGL(lp_adam_kernel, dim3(256), dim3(256), 0, st, ap, (const int32_t*)(t->consts + 2),
+                     (const int32_t*)pm->un.meta, (const int32_t*)pr->un.meta);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+}  // namespace
+
+int32_t gigl_nablp_train_plan_destroy(gigl_nablp_train_plan* t) {
+  if (!t) return GIGL_OK;
+  if (t->ctx) {
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
+  }
+  if (t->exec) hipGraphExecDestroy(t->exec);
+  for (int k = 0; k < 2; ++k)
+    if (t->enc[k].base) gigl_sage_plan_destroy(t->enc[k].base);
+  for (void* q : t->owned) hipFree(q);
+  if (t->lctx) {
+    gigl_ctx_set_stream(t->lctx, nullptr);  // (the stream is the caller's)
+    gigl_ctx_destroy(t->lctx);
+  }
+  delete t;
+  return GIGL_OK;
+}
+
+int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b_anchors,
+                                     int32_t num_positives, int32_t n_random_negatives, const int32_t* fanouts, int32_t hops,
+                                     const int32_t* dims, float* const* w, float* const* bias, int32_t act_last,
+                                     int32_t l2_normalize, float temperature, int32_t remove_accidental_hits, float lr,
+                                     float beta1, float beta2, float eps, float weight_decay, gigl_nablp_train_plan** out) {
+  if (!ctx || !out) return GIGL_E_INVALID_ARG;
+  *out = nullptr;
+  GIGL_REQUIRE(ctx, graph && feat && fanouts && dims && w, "null argument");
+  GIGL_REQUIRE(ctx, hops >= 1 && hops <= GIGL_MAX_HOPS && b_anchors >= 1 && num_positives >= 1 && n_random_negatives >= 0,
+               "bad plan shape");
+  GIGL_REQUIRE(ctx, dims[hops] <= 512, "embedding width %d: the head keeps a row in 8 registers per lane (<= 512)", dims[hops]);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  gigl_nablp_train_plan* t = new (std::nothrow) gigl_nablp_train_plan();
+  if (!t) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
+  t->ctx = ctx;
+  t->L = hops;
+  t->b = b_anchors;
+  t->P = num_positives;
+  t->n_rn = n_random_negatives;
+  t->normalize = l2_normalize ? 1 : 0;
+  t->remove_hits = remove_accidental_hits ? 1 : 0;
+  t->temperature = temperature;
+  t->act_last = act_last;
+  t->lr = lr;
+  t->beta1 = beta1;
+  t->beta2 = beta2;
+  t->eps = eps;
+  t->wd = weight_decay;
+  int32_t rc = gigl_ctx_create(ctx->device, &t->lctx);
+  const int32_t nb[2] = {b_anchors * (1 + num_positives), n_random_negatives > 0 ? n_random_negatives : 1};
+  for (int k = 0; k < 2 && rc == GIGL_OK; ++k) {
+    t->enc[k].b = nb[k];
+    rc = plan_create(t->lctx, graph, feat, nb[k], fanouts, hops, dims, (const float* const*)w, (const float* const*)bias,
+                     act_last, false, &t->enc[k].base);
+    if (rc != GIGL_OK) gigl_fail(ctx, rc, "%s", gigl_last_error(t->lctx));
+  }
+  if (rc != GIGL_OK) {
+    gigl_nablp_train_plan_destroy(t);
+    return rc;
+  }
+  auto alloc = [&](size_t bytes) -> void* {
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    t->owned.push_back(q);
+    return q;
+  };
+  bool ok = true;
+  size_t zero_floats = 0, da_floats = 16, wt_floats = 16;
+  for (int l = 0; l <= hops; ++l) t->dims[l] = dims[l];
+  for (int l = 0; l < hops; ++l) {
+    t->w[l] = w[l];
+    t->bias[l] = bias ? bias[l] : nullptr;
+    const size_t nw = (size_t)dims[l + 1] * 2 * dims[l];
+    wt_floats = std::max(wt_floats, nw);
+    for (int k = 0; k < 4; ++k) {
+      const size_t n = k < 2 ? nw : (size_t)dims[l + 1];
+      t->mom[4 * l + k] = (float*)alloc(n * 4);
+      if (t->mom[4 * l + k] && hipMemset(t->mom[4 * l + k], 0, n * 4) != hipSuccess) ok = false;
+      ok = ok && t->mom[4 * l + k];
+    }
+    for (int k = 0; k < 2; ++k) {
+      gigl_nablp_train_plan::Enc& e = t->enc[k];
+      int64_t rows = 0, width = e.b;
+      for (int i = 0; i <= hops - 1 - l; ++i) {
+        rows += width;
+        width *= fanouts[i];
+      }
+      e.rows_cap[l] = rows;
+      zero_floats += nw + dims[l + 1] + (size_t)rows * dims[l + 1];
+      if (l >= 1) da_floats = std::max(da_floats, (size_t)rows * 2 * dims[l]);
+      e.a[l] = (float*)alloc((size_t)rows * 2 * dims[l] * 4);
+      e.h[l] = (float*)alloc((size_t)rows * dims[l + 1] * 4);
+      ok = ok && e.a[l] && e.h[l];
+    }
+  }
+  float* z = (float*)alloc(zero_floats * 4);
+  t->zero_base = z;
+  t->zero_bytes = zero_floats * 4;
+  for (int k = 0; k < 2 && z; ++k)
+    for (int l = 0; l < hops; ++l) {
+      gigl_nablp_train_plan::Enc& e = t->enc[k];
+      e.gw[l] = z;
+      z += (size_t)dims[l + 1] * 2 * dims[l];
+      e.gb[l] = z;
+      z += dims[l + 1];
+      e.dh[l] = z;
+      z += (size_t)e.rows_cap[l] * dims[l + 1];
+    }
+  const size_t d = (size_t)dims[hops], Q = (size_t)b_anchors * num_positives, Cn = Q + (size_t)t->n_rn;
+  for (int k = 0; k < 2; ++k) {
+    gigl_nablp_train_plan::Enc& e = t->enc[k];
+    e.emb = (float*)alloc((size_t)e.b * d * 4);
+    e.inv = (float*)alloc((size_t)e.b * 4);
+    ok = ok && e.emb && e.inv;
+  }
+  t->da = (float*)alloc(da_floats * 4);
+  t->wt = (float*)alloc(wt_floats * 4);
+  t->rq = (float*)alloc(Q * d * 4);
+  t->cand = (float*)alloc(Cn * d * 4);
+  t->cand_t = (float*)alloc(Cn * d * 4);
+  t->scores = (float*)alloc(Q * Cn * 4);
+  t->dscores = (float*)alloc(Q * Cn * 4);
+  t->d_rq = (float*)alloc(Q * d * 4);
+  t->d_cand = (float*)alloc(Cn * d * 4);
+  t->qid = (int64_t*)alloc(Q * 8);
+  t->cid = (int64_t*)alloc(Cn * 8);
+  t->valid = (int32_t*)alloc(Cn * 4);
+  t->pos_cnt = (int32_t*)alloc((size_t)b_anchors * 4);
+  t->consts = (int32_t*)alloc(64);
+  t->row_lse = (float*)alloc(Q * 4);
+  t->row_loss = (float*)alloc(Q * 4);
+  t->loss = (float*)alloc(64);
+  ok = ok && t->zero_base && t->da && t->wt && t->rq && t->cand && t->cand_t && t->scores && t->dscores && t->d_rq &&
+       t->d_cand && t->qid && t->cid && t->valid && t->pos_cnt && t->consts && t->row_lse && t->row_loss && t->loss;
+  if (ok) {
+    const int32_t c[16] = {(int32_t)Q, (int32_t)Cn, 0 /* Adam's step counter */, 0};
+    if (hipMemcpy(t->consts, c, sizeof(c), hipMemcpyHostToDevice) != hipSuccess || hipMemset(t->loss, 0, 64) != hipSuccess)
+      ok = false;
+  }
+  if (!ok) {
+    gigl_nablp_train_plan_destroy(t);
+    return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the link-prediction training workspace failed");
+  }
+  *out = t;
+  return GIGL_OK;
+}
+
+int32_t gigl_nablp_train_plan_step(gigl_nablp_train_plan* t, const uint32_t* main_roots, const int32_t* pos_cnt,
+                                   const uint32_t* rn_roots, int32_t sampling_seed, int32_t mode, float* loss_out) {
+  if (!t) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = t->ctx;
+  GIGL_REQUIRE(ctx, main_roots && pos_cnt && (rn_roots || t->n_rn == 0), "null argument");
+  if (mode == GIGL_MODE_REPLACE)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the training plan needs duplicate-free trees (no with-replacement mode)");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  if (t->lctx->stream != st || t->lctx->own_stream) {
+    const int32_t rs = gigl_ctx_set_stream(t->lctx, st);
+    if (rs != GIGL_OK) return gigl_fail(ctx, rs, "%s", gigl_last_error(t->lctx));
+  }
+  if (t->cap_seed != sampling_seed || t->cap_mode != mode) {  // seed and mode are baked into the captured launches
+    if (t->exec) {
+      GIGL_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      hipGraphExecDestroy(t->exec);
+      t->exec = nullptr;
+    }
+    t->cap_seed = sampling_seed;
+    t->cap_mode = mode;
+  }
+  // the step's inputs go into the static buffers the (captured) launches read
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->enc[0].base->roots_buf, main_roots, (size_t)t->enc[0].b * 4, hipMemcpyDeviceToDevice, st));
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->pos_cnt, pos_cnt, (size_t)t->b * 4, hipMemcpyDeviceToDevice, st));
+  if (t->n_rn > 0)
+    GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->enc[1].base->roots_buf, rn_roots, (size_t)t->n_rn * 4, hipMemcpyDeviceToDevice, st));
+  else
+    gigl_fill_u32(st, t->enc[1].base->roots_buf, GIGL_INVALID, 1);
+  const int32_t rc = train_run_part(t->lctx, &t->exec, &t->warm, [&]() { return lp_enqueue(t, sampling_seed, mode); }, 1);
+  if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->lctx));
+  if (loss_out) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(loss_out, t->loss, 8, hipMemcpyDeviceToDevice, st));
+  return GIGL_OK;
+}
+
+const float* gigl_nablp_train_plan_loss(gigl_nablp_train_plan* t) { return t ? t->loss : nullptr; }
+
+namespace {
+__global__ __launch_bounds__(256) void lp_add2_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                      float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+}  // namespace
+
+int32_t gigl_nablp_train_plan_grads(gigl_nablp_train_plan* t, int32_t layer, float* gw, float* gb) {
+  if (!t) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = t->ctx;
+  GIGL_REQUIRE(ctx, layer >= 0 && layer < t->L && gw, "bad layer / null output");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int64_t nw = (int64_t)t->dims[layer + 1] * 2 * t->dims[layer];
+  hipLaunchKernelGGL(lp_add2_kernel, dim3(256), dim3(256), 0, ctx->stream, (const float*)t->enc[0].gw[layer],
+                     (const float*)t->enc[1].gw[layer], nw, gw);
+  if (gb && t->bias[layer])
+    hipLaunchKernelGGL(lp_add2_kernel, dim3(4), dim3(256), 0, ctx->stream, (const float*)t->enc[0].gb[layer],
+                       (const float*)t->enc[1].gb[layer], (int64_t)t->dims[layer + 1], gb);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
 }  // extern "C"

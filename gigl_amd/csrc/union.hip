@@ -49,11 +49,14 @@ static hipError_t lds_opt_in(int device, int site, const void* fn, int bytes, co
   return e;
 }
 
-// (A/B knob: GIGL_LG_BIG_CAP=16384 keeps the plans' long-row pass on the 128-KB shape)
+// The plans' long-row pass keeps the 128-KB shape (16 K distinct values per row in LDS).  GIGL_LG_BIG_CAP=4096 selects a
+// 32-KB shape that finds a CU at once — measured (round 5, same box, 2 runs each): 9.47 / 9.50 G edges/s against 9.79 with
+// the wide shape: the pass that waits for an emptied CU throttles its own stream and the projection next to it runs at
+// 14.8 instead of 21.9 us/step overlapped.  Kept as a knob, not the default.
 static bool lg_big_cap_wide() {
   static const bool wide = [] {
     const char* e = getenv("GIGL_LG_BIG_CAP");
-    return e && atoi(e) >= 16384;
+    return !(e && atoi(e) > 0 && atoi(e) <= 4096);
   }();
   return wide;
 }
@@ -63,7 +66,7 @@ namespace {
 constexpr int MAXL = GIGL_MAX_HOPS + 1;
 constexpr int TILE = 1024;          // stream positions per count/assign workgroup
 constexpr int BIG_ROW_CAP = 16384;  // LDS bitonic capacity (64 KiB of int32)
-constexpr int LG_BIG_CAP = 4096;    // ... of the plans' long-row pass (lg2_row_sort_big_kernel: 32 KB of dynamic LDS)
+constexpr int LG_BIG_CAP = 4096;    // ... of the long-row pass under GIGL_LG_BIG_CAP=4096 (32 KB of dynamic LDS; A/B knob)
 
 // one open-addressing slot: everything the passes need about a node sits in ONE 16-byte entry, so a probe
 // costs one random memory access instead of one per attribute array

@@ -1372,6 +1372,79 @@ class SageTrainPlan:
             self._plan = None
 
 
+class NablpTrainPlan:
+    """one LINK-PREDICTION training step per call in the library (include/gigl_hip.h `gigl_nablp_train_plan_*`): sample +
+    union of the main batch (anchors with their positives) and of the random-negative batch -> two GraphSAGE forwards over
+    the shared weights -> inner-product scores -> retrieval loss -> backward of both encodes -> Adam, replayed as one
+    hipGraph per step.  Like SageTrainPlan it trains FUSED weights [W_l | W_r] held here as torch tensors (`load` / `store`
+    move them from / to a models.GraphSAGE)."""
+
+    def __init__(self, eng: HipEngine, model, b_anchors: int, num_positives: int, n_random_negatives: int, fanouts,
+                 temperature: float = 0.07, remove_accidental_hits: bool = True, lr: float = 5e-3,
+                 weight_decay: float = 1e-6, betas=(0.9, 0.999), eps: float = 1e-8):
+        assert eng._graph is not None and eng._feat is not None, "load the graph and the features first"
+        L = len(fanouts)
+        assert model.num_layers == L, "one hop per layer"
+        if not (model._plain and model.aggr == "mean" and model.feats_interaction is None
+                and model.feature_embedding_layer is None and all(c.lin_r is not None for c in model.conv_layers)):
+            raise NotImplementedError("the link-prediction training plan runs plain mean-GraphSAGE layers (conv -> relu)")
+        self.eng, self.b, self.P, self.n_rn = eng, int(b_anchors), int(num_positives), int(n_random_negatives)
+        self.fanouts = [int(f) for f in fanouts]
+        self._lib = eng._lib
+        self.w, self.bias = [], []
+        SageTrainPlan.load(self, model)
+        self.dims = [int(self.w[0].shape[1]) // 2] + [int(w.shape[0]) for w in self.w]
+        self._plan = C.c_void_p()
+        w_arr = (C.c_void_p * L)(*[w.data_ptr() for w in self.w])
+        b_arr = (C.c_void_p * L)(*[(x.data_ptr() if x is not None else None) for x in self.bias])
+        fo = (C.c_int32 * L)(*self.fanouts)
+        dims = (C.c_int32 * (L + 1))(*self.dims)
+        check(self._lib.gigl_nablp_train_plan_create(
+            eng._ctx, eng._graph, eng._feat, self.b, self.P, self.n_rn, fo, L, dims, w_arr, b_arr,
+            1 if model.activation_after_last_conv else 0, 1 if model.should_l2_normalize_embedding_layer_output else 0,
+            float(temperature), 1 if remove_accidental_hits else 0, float(lr), float(betas[0]), float(betas[1]), float(eps),
+            float(weight_decay), C.byref(self._plan)), eng._ctx)
+        self.loss = torch.zeros(2, dtype=torch.float32, device=eng.device)  # {loss, query rows} of the last step
+
+    load = SageTrainPlan.load
+    store = SageTrainPlan.store
+
+    def step(self, main_roots: torch.Tensor, pos_cnt: torch.Tensor, rn_roots: torch.Tensor, sampling_seed: int = 42,
+             mode: int = MODE_SPARK_HASH) -> torch.Tensor:
+        """main_roots int32 device [n_anchors * (1 + P)] anchor-major (anchor, its positive slots), pos_cnt int32 device
+        [n_anchors], rn_roots int32 device [<= n_random_negatives]; short batches are padded here (absent anchors /
+        negatives = 0xFFFFFFFF).  Returns {loss, query rows} (device, owned by the plan)."""
+        T = 1 + self.P
+        assert main_roots.is_cuda and main_roots.dtype == torch.int32 and main_roots.numel() % T == 0
+        na = main_roots.numel() // T
+        assert 0 < na <= self.b and pos_cnt.numel() == na and rn_roots.numel() <= self.n_rn
+        if na < self.b:
+            main_roots = torch.cat([main_roots, torch.full(((self.b - na) * T,), -1, dtype=torch.int32, device=main_roots.device)])
+            pos_cnt = torch.cat([pos_cnt, torch.zeros(self.b - na, dtype=torch.int32, device=pos_cnt.device)])
+        if rn_roots.numel() < self.n_rn:
+            rn_roots = torch.cat([rn_roots, torch.full((self.n_rn - rn_roots.numel(),), -1, dtype=torch.int32,
+                                                       device=main_roots.device)])
+        main_roots, pos_cnt, rn_roots = main_roots.contiguous(), pos_cnt.to(torch.int32).contiguous(), rn_roots.contiguous()
+        self._keep = (main_roots, pos_cnt, rn_roots)
+        p_ = lambda t: C.c_void_p(t.data_ptr())
+        check(self._lib.gigl_nablp_train_plan_step(self._plan, p_(main_roots), p_(pos_cnt), p_(rn_roots) if self.n_rn else None,
+                                                   int(sampling_seed), int(mode), p_(self.loss)), self.eng._ctx)
+        return self.loss
+
+    def grads(self, layer: int):
+        """(d loss / d [W_l | W_r], d loss / d bias) of `layer` from the LAST step (gigl_nablp_train_plan_grads)"""
+        gw = torch.empty_like(self.w[layer])
+        gb = torch.empty_like(self.bias[layer]) if self.bias[layer] is not None else None
+        check(self._lib.gigl_nablp_train_plan_grads(self._plan, int(layer), C.c_void_p(gw.data_ptr()),
+                                                    C.c_void_p(gb.data_ptr()) if gb is not None else None), self.eng._ctx)
+        return gw, gb
+
+    def close(self) -> None:
+        if getattr(self, "_plan", None):
+            self._lib.gigl_nablp_train_plan_destroy(self._plan)
+            self._plan = None
+
+
 class GatPlan(SagePlan):
     """sample -> union -> GAT forward -> one row per root, enqueued by ONE library call (gigl_gat_plan_create; the
     handle is a gigl_sage_plan: run / use_graph / stats / last_batch_to_host are SagePlan's)"""

@@ -604,6 +604,29 @@ class ResidentGraph:
                                 pos_rows=torch.from_numpy(rows.astype(np.int64)).to(self.device),
                                 root_ids=roots.to(torch.int64) & 0xFFFFFFFF, root_index=ri)
 
+    def nablp_root_batches(self, ids: np.ndarray, n_pos: np.ndarray, batch_size: int, num_positives: int):
+        """the ROOT side of nablp_batches only — (main roots anchor-major, positives per anchor, anchor ids) per batch, no
+        batch graph built: what the library's link-prediction training plan takes (engine.NablpTrainPlan samples and
+        collates inside its step); same anchors, positives and order as nablp_batches"""
+        P = int(num_positives)
+        spans = [(lo, min(lo + batch_size, ids.size)) for lo in range(0, ids.size, batch_size)]
+        ar = torch.arange(P, device=self.device).view(1, P)
+        for lo, hi in spans:
+            chunk = ids[lo:hi]
+            anchors = torch.from_numpy(chunk.astype(np.uint32).view(np.int32)).to(self.device)
+            pos, cnt = self.engine.sample_positives(anchors, P, sampling_seed=self.seed)
+            a2 = anchors.view(-1, 1)
+            grouped = torch.where(ar < cnt.view(-1, 1), pos.view(-1, P), a2.expand(-1, P))
+            yield torch.cat([a2, grouped], dim=1).reshape(-1).contiguous(), cnt.to(torch.int32).contiguous(), chunk
+
+    def random_negative_root_batches(self, batch_size: int):
+        """the roots of random_negative_batches, batch by batch, forever (no batch graph built)"""
+        order = self.inference_root_order()
+        while order.size:
+            for lo in range(0, order.size, batch_size):
+                chunk = order[lo:lo + batch_size]
+                yield torch.from_numpy(chunk.astype(np.uint32).view(np.int32)).to(self.device)
+
     def random_negative_batches(self, batch_size: int) -> Iterator[HbmTrainBatch]:
         """the random-negative stream of a link-prediction job sampled in HBM: every node's RootedNodeNeighborhood in
         the order the TFRecord route reads the sampler's files, `batch_size` roots per batch (the last batch of a pass

@@ -1129,6 +1129,38 @@ int32_t gigl_sage_train_plan_step2(gigl_sage_train_plan* plan, const uint32_t* r
 const float* gigl_sage_train_plan_loss(gigl_sage_train_plan* plan);
 int32_t gigl_sage_train_plan_destroy(gigl_sage_train_plan* plan);
 
+/* ---- one LINK-PREDICTION training step per call, all of it in the library (round 5).  Replaces the loop body of
+ * NodeAnchorBasedLinkPredictionModelingTaskSpec.train (python/gigl/src/common/modeling_task_specs/
+ * node_anchor_based_link_prediction_modeling_task_spec.py:334-451) for the reference's default encoder (GraphSAGE, mean
+ * aggregation, optional L2-normalised output) and its default task (Retrieval: inner-product scores of every (anchor,
+ * positive) query row against cat(positives, random negatives), RetrievalLoss with temperature, same-query and
+ * accidental-hit masks, summed cross-entropy / query rows: utils/infer.py, decoder.py:64-70, loss.py:209-331), Adam with L2
+ * weight decay: sample + union of the main batch and of the random-negative batch, two encoder forwards over the SHARED
+ * weights, the head, the backward of both encodes (their weight gradients are added), the update — no torch kernel, no
+ * host read, replayed as ONE hipGraph per step.
+ * create: b_anchors anchors x (1 + num_positives) rooted trees per main batch, n_random_negatives roots per negative
+ *   batch; w[l] = fused [dims[l+1]][2 dims[l]] (= [W_l | W_r]), bias[l] (may be NULL): DEVICE, borrowed and UPDATED IN
+ *   PLACE by every step; dims[hops] <= 512.
+ * step: main_roots DEVICE uint32 [b_anchors * (1 + P)], anchor-major (anchor, its P positive slots; a slot without a
+ *   positive repeats the anchor's id — or any id — and lies at or beyond pos_cnt[anchor]; an absent anchor of a short batch
+ *   is 0xFFFFFFFF with pos_cnt 0), pos_cnt DEVICE int32 [b_anchors], rn_roots DEVICE uint32 [n_random_negatives]
+ *   (0xFFFFFFFF = none).  loss_out (DEVICE float[2], may be NULL) = {loss, query rows that took part};
+ *   gigl_nablp_train_plan_loss returns the plan's own words.  A batch that does not fit its workspace trains nothing and
+ *   reports a NaN loss.  All work is enqueued on the ctx's stream. */
+typedef struct gigl_nablp_train_plan gigl_nablp_train_plan;
+int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b_anchors,
+                                     int32_t num_positives, int32_t n_random_negatives, const int32_t* fanouts, int32_t hops,
+                                     const int32_t* dims, float* const* w, float* const* bias, int32_t act_last,
+                                     int32_t l2_normalize, float temperature, int32_t remove_accidental_hits, float lr,
+                                     float beta1, float beta2, float eps, float weight_decay, gigl_nablp_train_plan** out);
+int32_t gigl_nablp_train_plan_step(gigl_nablp_train_plan* plan, const uint32_t* main_roots, const int32_t* pos_cnt,
+                                   const uint32_t* rn_roots, int32_t sampling_seed, int32_t mode, float* loss_out);
+const float* gigl_nablp_train_plan_loss(gigl_nablp_train_plan* plan);
+/* the LAST step's parameter gradients of layer `layer` (the two encodes' added): gw DEVICE [dims[l+1]][2 dims[l]] (= d loss
+ * / d [W_l | W_r]), gb DEVICE [dims[l+1]] (may be NULL) — what the step's Adam update consumed; for gradient parity tests */
+int32_t gigl_nablp_train_plan_grads(gigl_nablp_train_plan* plan, int32_t layer, float* gw, float* gb);
+int32_t gigl_nablp_train_plan_destroy(gigl_nablp_train_plan* plan);
+
 /* Count-min sketch of candidate ids for the Retrieval task's candidate-sampling correction
  * (python/gigl/src/common/models/layers/count_min_sketch.py:11-95, used by task.py:140-205): table = DEVICE int32
  * [depth][width], zeroed by the caller; cell of (id, row) = hash((id, row)) % width with CPython's tuple hash of two

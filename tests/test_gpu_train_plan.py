@@ -129,3 +129,157 @@ def test_library_training_step_against_the_cpu_restatement(setup):
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
     for k, v in model.state_dict().items():
         np.testing.assert_allclose(v.cpu().numpy(), params[k].detach().numpy(), rtol=1e-3, atol=1e-4, err_msg=k)
+
+
+def _lp_batches(eng, n, b, P, n_rn, steps, seed):
+    """main roots (anchor-major: anchor + its P positive slots, a missing positive repeats the anchor), positives per
+    anchor and random-negative roots of `steps` batches — drawn as the link-prediction trainer's in-HBM route draws them
+    (engine.sample_positives over the out-graph)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(steps):
+        anchors = torch.from_numpy(rng.permutation(n)[:b].astype(np.uint32).view(np.int32)).to(eng.device)
+        pos, cnt = eng.sample_positives(anchors, P, sampling_seed=42)
+        ar = torch.arange(P, device=eng.device).view(1, P)
+        a2 = anchors.view(-1, 1)
+        grouped = torch.where(ar < cnt.view(-1, 1), pos.view(-1, P), a2.expand(-1, P))
+        roots = torch.cat([a2, grouped], dim=1).reshape(-1).contiguous()
+        rn = torch.from_numpy(rng.permutation(n)[:n_rn].astype(np.uint32).view(np.int32)).to(eng.device)
+        out.append((roots, cnt.to(torch.int32).contiguous(), rn))
+    return out
+
+
+def _lp_loss_torch(emb_main, emb_rn, roots, cnt, rn, b, P, temperature):
+    """infer_task_inputs + Retrieval on embeddings, in torch (utils/infer.py; loss.py:209-331 restated row by row in
+    oracle/gnn_ref.retrieval_loss_rows): repeated queries x cat(positives, random negatives), both masks, CE / rows"""
+    T = 1 + P
+    ids = (roots.to(torch.int64) & 0xFFFFFFFF).view(b, T)
+    k = cnt.to(torch.int64)
+    slot = torch.arange(P, device=roots.device).view(1, P)
+    ok = (slot < k.view(-1, 1)).reshape(-1)
+    q_rows = (torch.arange(b, device=roots.device) * T).repeat_interleave(P)[ok]
+    p_rows = (torch.arange(b, device=roots.device).view(-1, 1) * T + 1 + slot).reshape(-1)[ok]
+    rq, pos = emb_main[q_rows], emb_main[p_rows]
+    cand = torch.cat([pos, emb_rn])
+    scores = rq @ cand.T / temperature
+    qid = ids[:, 0].repeat_interleave(P)[ok]
+    cid = torch.cat([ids.reshape(-1)[p_rows], rn.to(torch.int64) & 0xFFFFFFFF])
+    Q, Cn = scores.shape
+    eye = torch.zeros((Q, Cn), dtype=torch.bool, device=scores.device)
+    eye[torch.arange(Q), torch.arange(Q)] = True
+    same_q = torch.zeros_like(eye)
+    same_q[:, :Q] = qid.view(-1, 1) == qid.view(1, -1)
+    hit = cid.view(1, -1) == cid[:Q].view(-1, 1)
+    masked = scores.masked_fill((same_q | hit) & ~eye, torch.finfo(torch.float32).min)
+    return torch.nn.functional.cross_entropy(masked, torch.arange(Q, device=scores.device), reduction="sum") / max(Q, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,fan,b,P,n_rn,norm", [((100, 32, 16), [10, 5], 128, 1, 64, True),
+                                                    ((100, 64, 32), [10, 5], 96, 2, 50, True),
+                                                    ((100, 256, 128), [25, 10], 64, 1, 40, False)])
+def test_library_link_prediction_step_equals_the_autograd_step(setup, dims, fan, b, P, n_rn, norm):
+    """gigl_nablp_train_plan_* (one library call per link-prediction training step: two encodes, inner-product scores,
+    retrieval loss, backward of both encodes, Adam) against the autograd step over the same in-HBM batches — the loop body
+    of node_anchor_based_link_prediction_modeling_task_spec.py:334-451 with the reference's defaults (GraphSAGE encoder,
+    L2-normalised embeddings, temperature 0.07, accidental-hit removal, Adam lr 5e-3 wd 1e-6): same loss history, same
+    trained weights; anchors with fewer than P positives and hipGraph replay included"""
+    from gigl_amd.engine import NablpTrainPlan
+    from gigl_amd.models import GraphSAGE, HipBatch
+    eng, rowptr, col, x, n = setup
+    if getattr(eng, "_graph_out", None) is None:
+        dst = np.repeat(np.arange(n, dtype=np.uint32), np.diff(rowptr).astype(np.int64))
+        eng.build_from_coo(n, dst, col.astype(np.uint32), is_directed=True, out_graph=True)  # (out-edges = reversed in-edges)
+    steps, temp = 8, 0.07
+    batches = _lp_batches(eng, n, b, P, n_rn, steps, seed=5)
+    if P > 1:
+        assert any(int((c < P).sum()) > 0 for _, c, _ in batches)  # (some anchors have fewer than P positives)
+    torch.manual_seed(4)
+    kw = dict(num_layers=2, should_l2_normalize_embedding_layer_output=norm)
+    ref = GraphSAGE(dims[0], dims[1], dims[2], **kw).to(eng.device)
+    lib = GraphSAGE(dims[0], dims[1], dims[2], **kw).to(eng.device)
+    lib.load_state_dict(ref.state_dict())
+    ref.train()
+    opt = torch.optim.Adam(ref.parameters(), lr=5e-3, weight_decay=1e-6)
+    want = []
+    for roots, cnt, rn in batches:
+        embs = []
+        for r in (roots, rn):
+            tree = eng.sample_khop(r, fan)
+            u = eng.union_build(tree)
+            embs.append(ref(HipBatch(eng, tree, u, train=True))[u.root_local[: r.numel()].long()])
+        loss = _lp_loss_torch(embs[0], embs[1], roots, cnt, rn, b, P, temp)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        want.append(float(loss))
+    st = torch.cuda.Stream(device=eng.device)
+    torch.cuda.synchronize()
+    eng.bind_stream(st)
+    plan = NablpTrainPlan(eng, lib, b, P, n_rn, fan, temperature=temp, remove_accidental_hits=True, lr=5e-3, weight_decay=1e-6)
+    got = []
+    with torch.cuda.stream(st):
+        for roots, cnt, rn in batches:  # (eager once, captured on the second step, replayed from then on)
+            got.append(plan.step(roots, cnt, rn).clone())
+    eng.synchronize()
+    rows = [float(v[1]) for v in got]
+    got = [float(v[0]) for v in got]
+    plan.store(lib)
+    plan.close()
+    eng.bind_stream(torch.cuda.current_stream(eng.device))
+    assert rows == [float(int(c.clamp(max=P).sum())) for _, c, _ in batches]
+    # (without the normalisation the logits are unbounded and the loss climbs at this learning rate: a step's rounding is
+    # amplified by the next ones)
+    np.testing.assert_allclose(got, want, rtol=2e-5 if norm else 3e-4, atol=2e-6)
+    for (k, a), (_, bb) in zip(lib.state_dict().items(), ref.state_dict().items()):
+        np.testing.assert_allclose(a.cpu().numpy(), bb.cpu().numpy(), rtol=2e-3, atol=3e-4 if norm else 6e-3, err_msg=k)  # (Adam: an element whose gradient is rounding noise moves by up to lr per step either way)
+
+
+@pytest.mark.gpu
+def test_library_link_prediction_step_against_the_cpu_restatement(setup):
+    """the same step on the CPU: oracle sample -> collate -> fp32 forward of both batches (gnn_ref, every layer over the
+    whole union graph) -> normalise -> scores -> row-wise retrieval loss -> torch autograd -> Adam; a short batch (fewer
+    anchors and negatives than the plan's capacity) is padded and masked"""
+    from gigl_amd.engine import NablpTrainPlan
+    from gigl_amd.models import GraphSAGE
+    eng, rowptr, col, x, n = setup
+    if getattr(eng, "_graph_out", None) is None:
+        dst = np.repeat(np.arange(n, dtype=np.uint32), np.diff(rowptr).astype(np.int64))
+        eng.build_from_coo(n, dst, col.astype(np.uint32), is_directed=True, out_graph=True)
+    b, P, n_rn, fan, steps, temp = 48, 1, 32, [10, 5], 4, 0.07
+    batches = _lp_batches(eng, n, b, P, n_rn, steps, seed=11)
+    batches[-1] = (batches[-1][0][: 2 * 30].contiguous(), batches[-1][1][:30].contiguous(), batches[-1][2][:20].contiguous())
+    torch.manual_seed(6)
+    model = GraphSAGE(100, 32, 16, num_layers=2, should_l2_normalize_embedding_layer_output=True)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    opt = torch.optim.Adam(list(params.values()), lr=5e-3, weight_decay=1e-6)
+    want = []
+    for roots, cnt, rn in batches:
+        embs = []
+        for r in (roots, rn):
+            r_h = r.cpu().numpy().view(np.uint32)
+            nbr, _ = oracle.sample_khop(rowptr, col, r_h, fan, canonical=True)
+            u = oracle.union_build(r_h, fan, nbr)
+            ei = gnn_ref.union_edge_index(u["rowptr"], u["col"])
+            out = gnn_ref.graphsage_forward(torch.from_numpy(x[u["nodes"].astype(np.int64)]), ei, params, 2)
+            out = torch.nn.functional.normalize(out, p=2, dim=1)
+            embs.append(out[torch.from_numpy(u["root_local"].astype(np.int64))])
+        na = cnt.numel()
+        loss = _lp_loss_torch(embs[0], embs[1], roots.cpu(), cnt.cpu(), rn.cpu(), na, P, temp)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        want.append(float(loss))
+    lib = GraphSAGE(100, 32, 16, num_layers=2, should_l2_normalize_embedding_layer_output=True).to(eng.device)
+    lib.load_state_dict(model.state_dict())
+    st = torch.cuda.Stream(device=eng.device)
+    torch.cuda.synchronize()
+    eng.bind_stream(st)
+    plan = NablpTrainPlan(eng, lib, b, P, n_rn, fan, temperature=temp, lr=5e-3, weight_decay=1e-6)
+    with torch.cuda.stream(st):
+        got = [plan.step(*bt).clone() for bt in batches]
+    eng.synchronize()
+    got = [float(v[0]) for v in got]
+    plan.close()
+    eng.bind_stream(torch.cuda.current_stream(eng.device))
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
