@@ -2005,6 +2005,47 @@ def run_lp_train(args, rank, world, local_rank):
     elapsed, steps_total = float(rep_np.sum()), K * len(reps)
     sampled, agg = counts[0] / K, counts[1] / K
     first, lastv = float(losses[0][0]), float(last[0])
+    # ---- the same step driven by torch autograd over in-HBM batches (what the trainer ran before the plan: HipBatch forward
+    # with autograd, torch ops for the head, the fused retrieval loss, torch.optim.Adam), a few steps, for the ratio
+    autograd_ms = None
+    try:
+        import copy
+        from gigl_amd.link_prediction import RetrievalLoss
+        from gigl_amd.models import HipBatch
+        ref = copy.deepcopy(model).train()
+        opt = torch.optim.Adam(ref.parameters(), lr=5e-3, weight_decay=1e-6)
+        lossf = RetrievalLoss(temperature=0.07, remove_accidental_hits=True)
+        T = 1 + P
+
+        def autograd_step(i):
+            roots, cnt, rn = batches[i]
+            embs = []
+            for r in (roots, rn):
+                tree = eng.sample_khop(r, fanouts)
+                u = eng.union_build(tree)
+                embs.append(ref(HipBatch(eng, tree, u, train=True))[u.root_local[: r.numel()].long()])
+            ok = (torch.arange(P, device=dev).view(1, P) < cnt.view(-1, 1)).reshape(-1)
+            q_rows = (torch.arange(B, device=dev) * T).repeat_interleave(P)[ok]
+            p_rows = (torch.arange(B, device=dev).view(-1, 1) * T + 1 + torch.arange(P, device=dev).view(1, P)).reshape(-1)[ok]
+            ids = roots.to(torch.int64) & 0xFFFFFFFF
+            cand = torch.cat([embs[0][p_rows], embs[1]])
+            scores = embs[0][q_rows] @ cand.T
+            loss = lossf.calculate_batch_retrieval_loss(scores, None, ids[q_rows], torch.cat([ids[p_rows], rn.to(torch.int64) & 0xFFFFFFFF]),
+                                                        device=dev) / max(int(q_rows.numel()), 1)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+        with torch.cuda.stream(st):
+            for i in range(2):
+                autograd_step(i)
+            st.synchronize()
+            t1 = time.perf_counter()
+            for i in range(W, W + 8):
+                autograd_step(i)
+            st.synchronize()
+            autograd_ms = (time.perf_counter() - t1) / 8 * 1e3
+    except Exception as exc:  # noqa: BLE001 — a comparison figure only
+        print(f"lp train: autograd comparison unavailable ({type(exc).__name__}: {str(exc)[:200]})", file=sys.stderr)
     line = {
         "metric": "sampled+aggregated edges/s (link-prediction training step)", "value": (sampled + agg) * steps_total / elapsed,
         "unit": "edges/s", "n_gpus": 1, "steps": steps_total, "warmup": W, "ms_per_step": elapsed / steps_total * 1e3,
@@ -2019,7 +2060,8 @@ def run_lp_train(args, rank, world, local_rank):
                    "driver": "gigl_nablp_train_plan_step: ONE library call per step, replayed as one hipGraph; no torch "
                              "kernel inside a step",
                    "sampled_edges_per_step": sampled, "aggregated_edges_per_step": agg,
-                   "loss_first_step": first, "loss_last_step": lastv, "setup_s": round(setup_s, 1)},
+                   "loss_first_step": first, "loss_last_step": lastv,
+                   "autograd_driven_ms_per_step": autograd_ms, "setup_s": round(setup_s, 1)},
         "roofline": None, "cpu_baseline": None,
         "note": "secondary line; the per-kernel picture of a step is the rocprofv3 summary under profiles/ (the plan's launches "
                 "run on a private ctx: no per-group HIP-event timers)",

@@ -1299,7 +1299,7 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   };
   if (p->group_roots < 1 || b % p->group_roots) return fail(GIGL_E_INVALID_ARG, "group_roots must divide b");
   for (int k = 0; k < hops; ++k) {
-    if (fanouts[k] < 1 || fanouts[k] > GIGL_FAST_FANOUT) return fail(GIGL_E_UNSUPPORTED, "fanout outside [1,64]");
+    if (fanouts[k] < 1 || fanouts[k] > GIGL_MAX_FANOUT) return fail(GIGL_E_UNSUPPORTED, "fanout outside [1,1024]");
     if (!w[k]) return fail(GIGL_E_INVALID_ARG, "null weight");
     p->fan[k] = fanouts[k];
     p->w[k] = w[k];

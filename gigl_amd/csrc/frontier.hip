@@ -162,7 +162,7 @@ int32_t gigl_frontier_scatter(gigl_ctx* ctx, const uint32_t* resp, const int32_t
   if (!ctx) return GIGL_E_INVALID_ARG;
   GIGL_REQUIRE(ctx, resp && slot_idx && counts && out_nbr && out_cnt, "null argument");
   GIGL_REQUIRE(ctx, !child_ksums || parent_ksums, "child path sums need the parents' path sums");
-  GIGL_REQUIRE(ctx, world >= 1 && m >= 0 && cap >= 1 && f >= 1 && f <= GIGL_FAST_FANOUT, "bad sizes");
+  GIGL_REQUIRE(ctx, world >= 1 && m >= 0 && cap >= 1 && f >= 1 && f <= GIGL_MAX_FANOUT, "bad sizes");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (m == 0) return GIGL_OK;
   // slots that were not sent (empty parents) have no children

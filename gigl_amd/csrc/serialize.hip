@@ -241,7 +241,7 @@ __device__ __forceinline__ void carve(const RecArgs& a, unsigned char* base, Pla
 
 // x / f for x < 2^20 and 1 <= f <= 64 without the (emulated) integer division: x * ceil(2^26 / f) >> 26 is exact there
 __device__ __forceinline__ uint32_t div_fanout(uint32_t x, uint32_t f) {
-  if (f == 1 || x >= (1u << 20)) return x / f;
+  if (f == 1 || f > 64u || x >= (1u << 20)) return x / f;  // (fanouts past 64: the plain division)
   return __umulhi(x, (((1u << 26) + f - 1u) / f) << 6);
 }
 // edge at edge-stream position q, from the plan's copy of the stream: src NONE = no edge
@@ -1446,8 +1446,8 @@ int32_t fill_args(gigl_ctx* ctx, const int32_t* fanouts, int32_t hops, const gig
   GIGL_REQUIRE(ctx, (o->suffix == nullptr) == (o->suffix_off == nullptr), "suffix and suffix_off go together");
   int64_t s = 1, sum = 0;
   for (int k = 0; k < hops; ++k) {
-    GIGL_REQUIRE(ctx, fanouts[k] >= 1 && fanouts[k] <= GIGL_FAST_FANOUT, "fanout[%d]=%d outside [1,%d]", k,
-                 fanouts[k], GIGL_FAST_FANOUT);
+    GIGL_REQUIRE(ctx, fanouts[k] >= 1 && fanouts[k] <= GIGL_MAX_FANOUT, "fanout[%d]=%d outside [1,%d]", k,
+                 fanouts[k], GIGL_MAX_FANOUT);
     s *= fanouts[k];
     sum += s;
     if (sum > MAX_STREAM) break;

@@ -348,7 +348,7 @@ int32_t gigl_typed_plan_create(gigl_ctx* ctx, const gigl_dag_op* ops, int32_t n_
   } while (0)
   for (int o = 0; o < n_ops; ++o) {
     const gigl_dag_op& op = p->ops[o];
-    if (!op.graph || op.fanout < 1 || op.fanout > GIGL_FAST_FANOUT) PLAN_FAIL("op %d: no graph or fanout outside [1,%d]", o, GIGL_FAST_FANOUT);
+    if (!op.graph || op.fanout < 1 || op.fanout > GIGL_MAX_FANOUT) PLAN_FAIL("op %d: no graph or fanout outside [1,%d]", o, GIGL_MAX_FANOUT);
     if (op.n_parents < 0 || op.n_parents > GIGL_DAG_MAX_PARENTS) PLAN_FAIL("op %d: more than %d parents", o, GIGL_DAG_MAX_PARENTS);
     if (op.frontier_node_type < 0 || op.frontier_node_type >= n_node_types || op.result_node_type < 0 ||
         op.result_node_type >= n_node_types || op.edge_slot < 0 || op.edge_slot >= n_edge_slots)

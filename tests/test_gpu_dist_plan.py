@@ -127,6 +127,15 @@ def test_all_ranks_in_one_process_end_to_end(world, project, dtype):
         e.close()
 
 
+@pytest.mark.parametrize("world,project,fan", [(2, False, [80, 3]), (3, "pre", [70, 2]), (8, True, [3, 100])])
+def test_fanouts_beyond_the_wave_resident_selection(world, project, fan, monkeypatch):
+    """fan-outs past 64 (the reference takes any int: SGSPureSparkV1Task.scala:313-388): the owners answer with the
+    workgroup-per-row selection; trees bit-identical to the oracle, rows to 1e-5"""
+    import sys
+    monkeypatch.setattr(sys.modules[__name__], "FAN", fan)
+    test_all_ranks_in_one_process_end_to_end(world, project, torch.float32)
+
+
 @pytest.mark.parametrize("world,project,dtype", [(2, False, torch.float32), (3, "pre", torch.float16), (8, "pre", torch.float16)])
 def test_in_step_overlap_of_the_own_block_gives_the_same_batches(world, project, dtype, monkeypatch):
     """GIGL_DIST_OVERLAP=1: a rank expands its OWN block of a hop's requests on a side stream while the peers' blocks are

@@ -333,6 +333,32 @@ def test_one_call_typed_plan_equals_the_staged_batch_graph(world):
         assert sum(int(v.shape[1]) for v in g1.edge_index_dict.values()) > 100
 
 
+def test_ops_with_fanouts_beyond_64(world):
+    """num_nodes_to_sample is any int in the reference (GraphDBSampler.scala:45-113): ops past the wave-resident
+    selection's 64 — per-root sets equal to the restatement, the one-call plan equal to the staged path"""
+    s, n, edges, feats, nbrs = world
+    ops = [SamplingOp("op0", A2P, 100, [], OUTGOING), SamplingOp("op1", P2A, 2, ["op0"], OUTGOING),
+           SamplingOp("op2", A2P, 70, ["op1"], OUTGOING)]
+    deg = np.bincount(edges[A2P][0], minlength=n["author"])
+    assert (deg > 100).sum() >= 4  # rows the selection really has to cut
+    roots = np.concatenate([np.argsort(-deg)[:6], np.random.default_rng(3).integers(0, n["author"], 26)])
+    roots = np.unique(roots)
+    _check(world, ops, "author", roots)
+    dag = SamplingOpDAG.from_ops(ops)
+    g0, ri0, u0 = s.batch_graph(roots, "author", dag)
+    g1, ri1, u1 = s.batch_graph_plan(roots, "author", dag, b_max=64)
+    torch.cuda.synchronize()
+    for t in u0:
+        assert torch.equal(u0[t], u1[t]) and torch.equal(g0.x_dict[t], g1.x_dict[t])
+    for k in g0.edge_index_dict:
+        assert torch.equal(g0.edge_index_dict[k], g1.edge_index_dict[k])
+    assert torch.equal(ri0, ri1)
+    # and the device encoder's records of the same DAG
+    bare = s.encode_records(roots, "author", dag, tfrecord_frame=False)
+    msgs = s.getKHopSubgraphForRootNodes(roots, "author", dag)
+    assert len(bare) == len(msgs) and all(b == m.SerializeToString() for b, m in zip(bare, msgs))
+
+
 def test_one_call_typed_plan_at_scale():
     """the typed plan against the staged path on a 600k-node DBLP-shaped graph with skewed authors (hub rows in the
     heavy-row path of the sampler), 2,048 roots per batch: identical node lists, edge lists and root positions; repeated

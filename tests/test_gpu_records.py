@@ -300,7 +300,9 @@ def _random_engine(n, d, seed=5):
     return _engine(n, src, dst, feats), feats, rng
 
 
-@pytest.mark.parametrize("fanouts,where", [([64, 64], "lds"), ([40, 30, 4], "scratch")])
+@pytest.mark.parametrize("fanouts,where", [([64, 64], "lds"), ([40, 30, 4], "scratch"), ([80, 5], "lds, fan-out > 64"),
+                                           ([300], "lds, fan-out > 64"), ([3, 130], "lds, fan-out > 64"),
+                                           ([100, 70], "scratch, fan-out > 64")])
 def test_long_streams_beyond_the_old_2048_position_cap(fanouts, where):
     """4,161 stream positions still plan in LDS; 6,041 take the per-workgroup scratch plan (same code over global
     memory).  Both byte-identical to the restatement."""
