@@ -1327,12 +1327,14 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   p->last_slots = last_slots;
   p->n_global = shard->n * W;
   // (the GAT layers number every union node and read the pulled rows through pos[]: generic union)
+  // (... and the leaf-global union numbers a level-1 row's leaves one per lane: second fan-outs past 64 take the generic one,
+  // as in the one-call plan, pipeline.hip)
   p->dense = kind == 0 && hops == 2 && !p->project && p->n_global < ((int64_t)1 << 32) && (shard_feat->d & 3) == 0 &&
-             getenv("GIGL_DIST_GENERIC_UNION") == nullptr && !(opts && opts->staged);
+             fanouts[1] <= GIGL_FAST_FANOUT && getenv("GIGL_DIST_GENERIC_UNION") == nullptr && !(opts && opts->staged);
   p->own_in_place = p->dense && shard->n < ((int64_t)1 << 30) && getenv("GIGL_DIST_COPY_OWN_ROWS") == nullptr;
   if (p->preproj && (!p->dense || (dims[1] & 3) != 0 || dims[1] > 2048))
-    return fail(GIGL_E_UNSUPPORTED, "pre-projected rows need the dense pull bookkeeping (two hops, no owner-side "
-                                    "projection) and a first-layer width % 4 == 0, <= 2048");
+    return fail(GIGL_E_UNSUPPORTED, "pre-projected rows need the dense pull bookkeeping (two hops, second fan-out <= 64, no "
+                                    "owner-side projection) and a first-layer width % 4 == 0, <= 2048");
   // (dense: the last hop's ids live right behind the union's col array so that rows can alias tree segments)
   p->un.col = (int32_t*)alloc((size_t)(cap_edges + (p->dense ? last_slots : 0)) * 4);
   ok = p->un.col != nullptr;

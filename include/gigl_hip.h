@@ -41,7 +41,8 @@ extern "C" {
 #define GIGL_MAX_HOPS 4
 /* fanouts up to GIGL_FAST_FANOUT take the wave-resident selection (one candidate per lane: the tuned path of every
  * benchmark configuration); larger ones, up to GIGL_MAX_FANOUT, a workgroup-per-row selection with the same results
- * contract (parity mode; gigl_sample_khop, gigl_expand_frontier and the plans built on them) */
+ * contract (parity mode; gigl_sample_khop, gigl_expand_frontier, the one-call / sharded / typed plans built on them and
+ * the record encoders: the reference's numNeighborsToSample is any int, SGSPureSparkV1Task.scala:313-388) */
 #define GIGL_FAST_FANOUT 64
 #define GIGL_MAX_FANOUT 1024
 

@@ -127,13 +127,32 @@ def test_all_ranks_in_one_process_end_to_end(world, project, dtype):
         e.close()
 
 
-@pytest.mark.parametrize("world,project,fan", [(2, False, [80, 3]), (3, "pre", [70, 2]), (8, True, [3, 100])])
+@pytest.mark.parametrize("world,project,fan", [(2, False, [80, 3]), (3, "pre", [70, 2]), (8, True, [100, 3]), (3, True, [3, 100]),
+                                               (2, False, [3, 100])])
 def test_fanouts_beyond_the_wave_resident_selection(world, project, fan, monkeypatch):
     """fan-outs past 64 (the reference takes any int: SGSPureSparkV1Task.scala:313-388): the owners answer with the
-    workgroup-per-row selection; trees bit-identical to the oracle, rows to 1e-5"""
+    workgroup-per-row selection; trees bit-identical to the oracle, rows to 1e-5.  (A second fan-out past 64 takes the
+    generic union instead of the leaf-global one, and pre-projected rows are refused there.)"""
     import sys
     monkeypatch.setattr(sys.modules[__name__], "FAN", fan)
     test_all_ranks_in_one_process_end_to_end(world, project, torch.float32)
+
+
+def test_pre_projected_rows_refuse_a_wide_second_fanout():
+    from gigl_amd._lib import GiglError
+    from gigl_amd.dist import Comm, DistSagePlan
+    rowptr, col, x = make_graph()
+    w, bs = make_model().fused_params()
+    st = torch.cuda.Stream()
+    engs = [shard_engine(rowptr, col, x, r, 2, torch.float32, st) for r in range(2)]
+    comms = Comm.local(engs)
+    table = engs[0].project_features(w[0].to(engs[0].device))
+    with pytest.raises(GiglError, match="second fan-out"):
+        DistSagePlan(comms[0], w, bs, 32, [3, 100], max_window_end=bound_for(rowptr), projected=table)
+    for c in comms:
+        c.close()
+    for e in engs:
+        e.close()
 
 
 @pytest.mark.parametrize("world,project,dtype", [(2, False, torch.float32), (3, "pre", torch.float16), (8, "pre", torch.float16)])
