@@ -39,6 +39,10 @@ struct gigl_ctx {
   void* sampler_table = nullptr;
   // record encoder: x^(8*b*256^j) mod P tables of the CRC-32C combine step (serialize.hip), built lazily
   uint32_t* crc_shift_tbl = nullptr;
+  // ... the write pass's LDS tables (slicing-by-4 CRC | x^(8*4d) byte-sliced | the shift tables again), for row width
+  // enc_tables_d
+  uint32_t* enc_tables = nullptr;
+  int32_t enc_tables_d = -1;
 };
 
 void gigl_sampler_table_free(gigl_ctx* ctx);

@@ -128,6 +128,7 @@ int32_t gigl_ctx_destroy(gigl_ctx* ctx) {
   if (ctx->arena) hipFree(ctx->arena);
   gigl_sampler_table_free(ctx);
   if (ctx->crc_shift_tbl) hipFree(ctx->crc_shift_tbl);
+  if (ctx->enc_tables) hipFree(ctx->enc_tables);
   for (hipEvent_t e : ctx->prof_ev) hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;

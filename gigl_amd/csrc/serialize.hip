@@ -718,6 +718,7 @@ struct EncArgs {
   const uint32_t* row_crc;   // [feat_n] (row_crc_kernel); NULL when d == 0 or the records are not framed
   uint32_t x_row;            // x^(8 * 4d) mod P
   int64_t* rec_size;         // [n_records]
+  const uint32_t* tables;    // crc_t[1024] | row_t[1024] | shift_t[768], tabulated once per ctx and row width
 };
 
 // the state after 4d more bytes of zeros: c * x^(8*4d), from the byte-sliced tables of that constant
@@ -945,22 +946,10 @@ __global__ __launch_bounds__(256) void record_write_kernel(RecArgs a, EncArgs e,
     write_rows(a, seg, out + rec_off[r], ((blockIdx.x - n_grp) % ROWS_WGS) * 4 + w);
     return;
   }
-  __shared__ uint32_t crc_t[1024];
-  __shared__ uint32_t row_t[1024];
-  __shared__ uint32_t shift_t[768];
-  for (uint32_t i = tid; i < 256; i += 256) {
-    uint32_t c = i;
-    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
-    crc_t[i] = c;
-  }
-  for (uint32_t i = tid; i < 768; i += 256) shift_t[i] = a.shift_tbl[i];
-  __syncthreads();
-  for (int j = 1; j < 4; ++j) {
-    const uint32_t prev = crc_t[(j - 1) * 256 + tid];
-    crc_t[j * 256 + tid] = (prev >> 8) ^ crc_t[prev & 0xFF];
-    __syncthreads();
-  }
-  for (uint32_t i = tid; i < 1024; i += 256) row_t[i] = multmodp(e.x_row, (i & 255u) << (8 * (i >> 8)));
+  __shared__ uint32_t crc_t[1024 + 1024 + 768];
+  uint32_t* const row_t = crc_t + 1024;
+  uint32_t* const shift_t = crc_t + 2048;
+  for (uint32_t i = tid; i < 2816; i += 256) crc_t[i] = e.tables[i];
   __syncthreads();
   // from here on the waves go their own ways
   if (w >= wf) return;
@@ -1506,6 +1495,29 @@ int32_t ensure_shift_table(gigl_ctx* ctx) {
   return GIGL_OK;
 }
 
+// crc_t | row_t | shift_t as the write pass holds them in LDS (ctx-owned device table, rebuilt when the row width changes)
+int32_t ensure_enc_tables(gigl_ctx* ctx, int32_t d, uint32_t x_row) {
+  if (ctx->enc_tables && ctx->enc_tables_d == d) return GIGL_OK;
+  std::vector<uint32_t> t(2816);
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+    t[i] = c;
+  }
+  for (int j = 1; j < 4; ++j)
+    for (uint32_t i = 0; i < 256; ++i) {
+      const uint32_t prev = t[(j - 1) * 256 + i];
+      t[j * 256 + i] = (prev >> 8) ^ t[prev & 0xFF];
+    }
+  for (uint32_t i = 0; i < 1024; ++i) t[1024 + i] = host_multmodp(x_row, (i & 255u) << (8 * (i >> 8)));
+  GIGL_HIP_CHECK(ctx, hipMemcpy(t.data() + 2048, ctx->crc_shift_tbl, 768 * 4, hipMemcpyDeviceToHost));
+  if (!ctx->enc_tables) GIGL_HIP_CHECK(ctx, hipMalloc((void**)&ctx->enc_tables, 2816 * 4));
+  else GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (a write pass in flight still reads the old ones)
+  GIGL_HIP_CHECK(ctx, hipMemcpy(ctx->enc_tables, t.data(), 2816 * 4, hipMemcpyHostToDevice));
+  ctx->enc_tables_d = d;
+  return GIGL_OK;
+}
+
 int hvlen(uint64_t v) {
   int n = 1;
   while (v >= 128) {
@@ -1627,6 +1639,9 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
     if (rc != GIGL_OK) return rc;
     e.row_crc = rc_tbl;
   }
+  rc = ensure_enc_tables(ctx, a.d, e.x_row);
+  if (rc != GIGL_OK) return rc;
+  e.tables = ctx->enc_tables;
   // waves per workgroup: as many plans as fit LDS (4, 2 or 1); plans beyond LDS are built in scratch
   const size_t plan = plan_bytes(a), kept = kept_bytes(a);
   const bool big = plan > PLAN_LDS_BYTES;

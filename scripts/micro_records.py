@@ -20,6 +20,7 @@ ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--small", action="store_true")
 ap.add_argument("--device-only", action="store_true", help="only the back-to-back device timing (for rocprofv3 runs)")
+ap.add_argument("--no-verify", action="store_true", help="ablation runs (GIGL_REC_SKIP): the bytes are not the records'")
 a = ap.parse_args()
 eng = HipEngine(0)
 n, d = bench.build_workload(eng, a)
@@ -31,7 +32,7 @@ buf, off = eng.encode_records(tree)
 nbytes = buf.numel()
 recs = wire_ok = None
 from gigl_amd import wire  # noqa: E402
-if True:
+if not a.no_verify:
     recs = list(wire.iter_tfrecords(buf[: int(off[8])].cpu().numpy().tobytes()))  # CRCs verified by the reader
 slots = sum(fan[0] * (fan[1] if k else 1) for k in range(2)) + 1
 torch.cuda.synchronize()
@@ -63,7 +64,7 @@ def device_time(calls=20):
                                                 C.c_void_p(rec_off.data_ptr()), C.c_void_p(status.data_ptr())), eng._ctx)
     call()
     eng._stream.synchronize()
-    assert int(status.item()) == 0 and torch.equal(out[:nbytes], buf)
+    assert a.no_verify or (int(status.item()) == 0 and torch.equal(out[:nbytes], buf))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(eng._stream)
     for _ in range(calls):
