@@ -981,6 +981,15 @@ int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sam
 // depends on no weight — moved into the graph part, out of the layers' serial chain: 0.257 against 0.245 ms/step; the
 // two parts already share the GPU, the step follows the SUM of the launches more than the longer chain.)
 constexpr int TRAIN_WS = 2;
+// the input gradient of layers >= 1 by gigl_gather_mean_backward_transposed (every row written once, no cleared block, no
+// float atomics) when the hidden widths allow float4 rows; GIGL_TRAIN_BWD_ATOMIC=1 keeps the scatter (A/B)
+static bool train_bwd_gather(const int32_t* dims, int32_t hops) {
+  if (getenv("GIGL_TRAIN_BWD_ATOMIC")) return false;
+  for (int l = 1; l < hops; ++l)
+    if (dims[l] & 3) return false;
+  return true;
+}
+
 struct gigl_sage_train_plan {
   gigl_ctx* ctx = nullptr;         // the caller's (its stream carries the layers part; errors are reported on it)
   // two ctxs of the plan's own, for their ARENAS: scratch addresses are baked into the captured launches, and another
@@ -1004,6 +1013,7 @@ struct gigl_sage_train_plan {
   float* a[GIGL_MAX_HOPS] = {nullptr};    // [rows_cap[l]][2 dims[l]]: the layer's [mean | self] operand
   float* h[GIGL_MAX_HOPS] = {nullptr};    // [rows_cap[l]][dims[l+1]]: its output (activated below the last layer)
   float* dh[GIGL_MAX_HOPS] = {nullptr};   // gradient of h[l]
+  bool bwd_gather = false;                // layers >= 1 hand their input gradient down by the transposed gather
   float* da = nullptr;                    // [max rows_cap[l >= 1]][2 max dims]: gradient of a layer's operand
   float* wt = nullptr;                    // a layer's transposed weight
   float* gw[GIGL_MAX_HOPS] = {nullptr};
@@ -1082,7 +1092,12 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
     }
     rc = gigl_linear(ctx, t->dh[l], t->wt, nullptr, n_rows, t->rows_cap[l], n_out, 2 * d, 0, t->da);
     if (rc != GIGL_OK) return rc;
-    rc = gigl_gather_mean_backward(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, t->rows_cap[l], t->dh[l - 1]);
+    if (t->bwd_gather)
+      rc = gigl_gather_mean_backward_transposed(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, t->rows_cap[l],
+                                                p->un.meta + GIGL_META_LEVEL0 + (L - l), t->rows_cap[l - 1], p->un.cap_edges,
+                                                GIGL_AGGR_MEAN, t->dh[l - 1]);
+    else
+      rc = gigl_gather_mean_backward(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, t->rows_cap[l], t->dh[l - 1]);
     if (rc != GIGL_OK) return rc;
   }
   // ---- Adam
@@ -1247,6 +1262,7 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
   bool ok = true;
   size_t zero_floats = 0, da_floats = 16, wt_floats = 16;
   for (int l = 0; l <= hops; ++l) t->dims[l] = dims[l];
+  t->bwd_gather = train_bwd_gather(dims, hops);
   for (int l = 0; l < hops; ++l) {
     t->w[l] = w[l];
     t->bias[l] = bias ? bias[l] : nullptr;
@@ -1257,7 +1273,7 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
     }
     t->rows_cap[l] = rows;
     const size_t nw = (size_t)dims[l + 1] * 2 * dims[l];
-    zero_floats += nw + dims[l + 1] + (size_t)rows * dims[l + 1];
+    zero_floats += nw + dims[l + 1] + (t->bwd_gather && l < hops - 1 ? 0 : (size_t)rows * dims[l + 1]);
     if (l >= 1) {
       da_floats = std::max(da_floats, (size_t)rows * 2 * dims[l]);
       wt_floats = std::max(wt_floats, nw);
@@ -1280,6 +1296,11 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
     z += (size_t)dims[l + 1] * 2 * dims[l];
     t->gb[l] = z;
     z += dims[l + 1];
+    if (t->bwd_gather && l < hops - 1) {  // (written whole by the transposed gather: not part of the cleared block)
+      t->dh[l] = (float*)alloc((size_t)t->rows_cap[l] * dims[l + 1] * 4);
+      ok = ok && t->dh[l];
+      continue;
+    }
     t->dh[l] = z;
     z += (size_t)t->rows_cap[l] * dims[l + 1];
   }
@@ -1392,6 +1413,7 @@ struct gigl_nablp_train_plan {
   float* mom[4 * GIGL_MAX_HOPS] = {nullptr};
   float* da = nullptr;
   float* wt = nullptr;
+  bool bwd_gather = false;    // (as in gigl_sage_train_plan)
   void* zero_base = nullptr;  // both encodes' gw | gb | dh: cleared at the start of every step
   size_t zero_bytes = 0;
   // the head: repeated queries, candidates, ids, validity, scores and their gradients
@@ -1747,7 +1769,12 @@ int32_t lp_backward(gigl_nablp_train_plan* t, int which) {
     }
     rc = gigl_linear(ctx, e.dh[l], t->wt, nullptr, n_rows, e.rows_cap[l], n_out, 2 * d, 0, t->da);
     if (rc != GIGL_OK) return rc;
-    rc = gigl_gather_mean_backward(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, e.rows_cap[l], e.dh[l - 1]);
+    if (t->bwd_gather)
+      rc = gigl_gather_mean_backward_transposed(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, e.rows_cap[l],
+                                                p->un.meta + GIGL_META_LEVEL0 + (L - l), e.rows_cap[l - 1], p->un.cap_edges,
+                                                GIGL_AGGR_MEAN, e.dh[l - 1]);
+    else
+      rc = gigl_gather_mean_backward(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, e.rows_cap[l], e.dh[l - 1]);
     if (rc != GIGL_OK) return rc;
   }
   return GIGL_OK;
@@ -1903,6 +1930,7 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
   bool ok = true;
   size_t zero_floats = 0, da_floats = 16, wt_floats = 16;
   for (int l = 0; l <= hops; ++l) t->dims[l] = dims[l];
+  t->bwd_gather = train_bwd_gather(dims, hops);
   for (int l = 0; l < hops; ++l) {
     t->w[l] = w[l];
     t->bias[l] = bias ? bias[l] : nullptr;
@@ -1922,7 +1950,7 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
         width *= fanouts[i];
       }
       e.rows_cap[l] = rows;
-      zero_floats += nw + dims[l + 1] + (size_t)rows * dims[l + 1];
+      zero_floats += nw + dims[l + 1] + (t->bwd_gather && l < hops - 1 ? 0 : (size_t)rows * dims[l + 1]);
       if (l >= 1) da_floats = std::max(da_floats, (size_t)rows * 2 * dims[l]);
       e.a[l] = (float*)alloc((size_t)rows * 2 * dims[l] * 4);
       e.h[l] = (float*)alloc((size_t)rows * dims[l + 1] * 4);
@@ -1939,6 +1967,11 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
       z += (size_t)dims[l + 1] * 2 * dims[l];
       e.gb[l] = z;
       z += dims[l + 1];
+      if (t->bwd_gather && l < hops - 1) {
+        e.dh[l] = (float*)alloc((size_t)e.rows_cap[l] * dims[l + 1] * 4);
+        ok = ok && e.dh[l];
+        continue;
+      }
       e.dh[l] = z;
       z += (size_t)e.rows_cap[l] * dims[l + 1];
     }

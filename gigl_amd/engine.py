@@ -976,6 +976,19 @@ class HipEngine:
                                                     rows_cap, _lib.AGGR[aggr], sp, C.c_void_p(dsrc.data_ptr())),
               self._ctx)
 
+    def gather_mean_backward_transposed(self, dout: torch.Tensor, d: int, rowptr: torch.Tensor, rowend: Optional[torch.Tensor],
+                                        col: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int, n_src_dev: torch.Tensor,
+                                        dsrc: torch.Tensor, edges_cap: Optional[int] = None, aggr: str = "mean") -> None:
+        """dsrc[j] for j < *n_src_dev = the same gradient, every row WRITTEN once by a gather over the transposed rows
+        (gigl_gather_mean_backward_transposed: no zero-fill, no float atomics); "mean" or "sum"; d % 4 == 0"""
+        if rowend is None:
+            rowend = rowptr[1:]
+        assert dout.is_cuda and dout.is_contiguous() and dsrc.is_contiguous() and dout.dtype == torch.float32
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(self._lib.gigl_gather_mean_backward_transposed(
+            self._ctx, p(dout), d, p(rowptr), p(rowend), p(col), p(n_rows_dev), rows_cap, p(n_src_dev), int(dsrc.shape[0]),
+            int(col.numel()) if edges_cap is None else edges_cap, _lib.AGGR[aggr], p(dsrc)), self._ctx)
+
     def linear(self, a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], m_dev: torch.Tensor,
                m_cap: int, act: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert a.is_cuda and w.is_cuda and a.dtype == torch.float32 and w.dtype == torch.float32

@@ -925,6 +925,17 @@ int32_t gigl_gather_mean_backward(gigl_ctx* ctx, const float* dout, int32_t d, c
                                   const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
                                   int64_t rows_cap, float* dsrc);
 
+/* The same backward as a gather over the transposed rows: every row of dsrc below *n_src_dev is WRITTEN once (no zero-fill,
+ * no float atomics): dsrc[j] = dout[j][d:2d] (j < *n_rows_dev) + sum over the rows i < *n_rows_dev that list j of
+ * dout[i][0:d] / deg_i (aggr = GIGL_AGGR_MEAN; GIGL_AGGR_SUM: without the division).  The transposed lists are built per
+ * call from the rows' CSR (scratch from the ctx arena).  d % 4 == 0; every col[] entry of those rows must be < *n_src_dev
+ * <= src_cap; edges_cap >= the number of edges of those rows.  The sum over a source's readers runs in arrival order
+ * (as the atomics of gigl_gather_mean_backward did). */
+int32_t gigl_gather_mean_backward_transposed(gigl_ctx* ctx, const float* dout, int32_t d, const int32_t* rowptr,
+                                             const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
+                                             int64_t rows_cap, const int32_t* n_src_dev, int64_t src_cap,
+                                             int64_t edges_cap, int32_t aggr, float* dsrc);
+
 /* weight gradient of gigl_linear (training: the backward of PyG's Linear inside SAGEConv, which torch autograd computes
  * as dy^T @ a): dw[n][k] += sum_{i < *m_dev} dy[i][n] a[i][k] and, when db != NULL, db[n] += sum_i dy[i][n] — the rows
  * are the inner dimension and only the first *m_dev of the m_cap allocated rows are read (the rest may hold anything).

@@ -283,3 +283,45 @@ def test_library_link_prediction_step_against_the_cpu_restatement(setup):
     plan.close()
     eng.bind_stream(torch.cuda.current_stream(eng.device))
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,aggr", [(256, "mean"), (128, "mean"), (64, "sum"), (20, "mean"), (300, "sum")])
+def test_transposed_backward_gather_equals_the_scatter_and_a_dense_restatement(d, aggr):
+    """gigl_gather_mean_backward_transposed (every source row written once by a gather over the transposed rows) against
+    the atomics scatter it replaces in the training plans and against a dense fp64 restatement: random ragged rows, sources
+    shared by many rows, sources nobody reads, empty rows; rows past *n_src stay untouched"""
+    from gigl_amd.engine import HipEngine
+    eng = HipEngine(0)
+    st = torch.cuda.Stream()
+    eng.bind_stream(st)
+    rng = np.random.default_rng(d)
+    n_rows, n_src, cap_src = 700, 9000, 9500
+    deg = rng.integers(0, 40, n_rows)
+    deg[:5] = 0
+    rowptr = np.zeros(n_rows + 1, np.int32)
+    rowptr[1:] = np.cumsum(deg)
+    col = rng.integers(0, n_src, int(rowptr[-1])).astype(np.int32)
+    col[: 200] = rng.integers(0, 7, 200)  # a few sources read by very many rows
+    dout = rng.standard_normal((n_rows, 2 * d)).astype(np.float32)
+    want = np.zeros((n_src, d), np.float64)
+    want[:n_rows] += dout[:, d:]
+    for i in range(n_rows):
+        if deg[i]:
+            np.add.at(want, col[rowptr[i]:rowptr[i + 1]], dout[i, :d].astype(np.float64) / (deg[i] if aggr == "mean" else 1.0))
+    dev = eng.device
+    t = lambda a: torch.from_numpy(a).to(dev)
+    with torch.cuda.stream(st):
+        rp, cl, do = t(rowptr), t(col), t(dout)
+        nr = torch.tensor([n_rows], dtype=torch.int32, device=dev)
+        ns = torch.tensor([n_src], dtype=torch.int32, device=dev)
+        got = torch.full((cap_src, d), 7.0, dtype=torch.float32, device=dev)
+        eng.gather_mean_backward_transposed(do, d, rp, None, cl, nr, n_rows, ns, got, aggr=aggr)
+        ref = torch.zeros((cap_src, d), dtype=torch.float32, device=dev)
+        eng.gather_mean_backward(do, d, rp, None, cl, nr, n_rows, ref, aggr=aggr)
+    st.synchronize()
+    g = got.cpu().numpy()
+    np.testing.assert_allclose(g[:n_src], want, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(g[:n_src], ref.cpu().numpy()[:n_src], rtol=2e-5, atol=2e-5)
+    assert (g[n_src:] == 7.0).all()
+    eng.close()
