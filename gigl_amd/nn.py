@@ -135,9 +135,16 @@ class _SageConvFn(torch.autograd.Function):
                 dy = dy * (y > 0).to(dy.dtype)
             # da[n, 2d] = dy[n, N] @ wcat[N, 2d]  ->  linear(a = dy, w = wcat^T)
             da = eng.linear(dy, wcat.t().contiguous(), None, g.n_dev, n, 0)
-            dh = torch.zeros((ctx.src_rows, d), dtype=torch.float32, device=dev)
-            eng.gather_mean_backward(da, d, g.rowptr, getattr(g, "rowend", None), g.col, g.n_dev, n, dh, aggr=ctx.aggr,
-                                     src=ctx.saved_tensors[3] if ctx.aggr == "max" else None)
+            if ctx.aggr in ("mean", "sum") and d % 4 == 0 and ctx.src_rows >= n:
+                # every source row written once by a gather over the transposed rows: no zero-fill, no float atomics
+                dh = torch.empty((ctx.src_rows, d), dtype=torch.float32, device=dev)
+                n_src = torch.full((1,), ctx.src_rows, dtype=torch.int32, device=dev)
+                eng.gather_mean_backward_transposed(da, d, g.rowptr, getattr(g, "rowend", None), g.col, g.n_dev, n, n_src, dh,
+                                                    aggr=ctx.aggr)
+            else:
+                dh = torch.zeros((ctx.src_rows, d), dtype=torch.float32, device=dev)
+                eng.gather_mean_backward(da, d, g.rowptr, getattr(g, "rowend", None), g.col, g.n_dev, n, dh, aggr=ctx.aggr,
+                                         src=ctx.saved_tensors[3] if ctx.aggr == "max" else None)
         return dh, dw[:, :d].contiguous(), db, dw[:, d:].contiguous(), None, None, None, None
 
 
