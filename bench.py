@@ -396,6 +396,9 @@ def main():
                          "GraphSAGE forward with autograd over the union graph, cross-entropy on the roots, backward "
                          "(gigl_gather_reduce_backward + the projections' backward GEMMs) and the Adam update — the loop of "
                          "NodeClassificationModelingTaskSpec._train; a secondary line with its own roofline / cpu_baseline")
+    ap.add_argument("--no-train-prefetch", action="store_true",
+                    help="--train --train-task lp: every step samples its own batch (A/B of the next batch's graph part beside "
+                         "this step's layers)")
     ap.add_argument("--train-task", type=str, default="snc", choices=["snc", "lp"],
                     help="--train: snc = node classification (gigl_sage_train_plan_*); lp = the link-prediction step of the "
                          "reference's default trainer (GraphSAGE encoder, Retrieval task) as ONE library call "
@@ -1976,8 +1979,12 @@ def run_lp_train(args, rank, world, local_rank):
                           weight_decay=1e-6)
     losses = []
     with torch.cuda.stream(st):
-        for i in range(W):  # (eager once, captured on the second step, replayed from then on)
-            losses.append(plan.step(*batches[i]).clone())
+        # (eager once, captured on the second step, replayed from then on; --no-train-prefetch: every step samples its own
+        # batch first instead of finding it prefetched beside the previous step's layers)
+        prefetch = not getattr(args, "no_train_prefetch", False)
+        nxt = lambda i, hi: (batches[i + 1][0], batches[i + 1][2]) if prefetch and i + 1 < hi else None
+        for i in range(W):
+            losses.append(plan.step(*batches[i], next_roots=nxt(i, W)).clone())
     st.synchronize()
     # ---- untimed: exact edge counts of the timed batches (both encodes), through the separate entry points
     counts = np.zeros(2, dtype=np.float64)
@@ -1998,7 +2005,7 @@ def run_lp_train(args, rank, world, local_rank):
         t1 = time.perf_counter()
         with torch.cuda.stream(st):
             for i in range(W, W + K):
-                last = plan.step(*batches[i])
+                last = plan.step(*batches[i], next_roots=nxt(i, W + K))
         st.synchronize()
         reps.append(time.perf_counter() - t1)
     rep_np = np.array(reps)
@@ -2057,8 +2064,10 @@ def run_lp_train(args, rank, world, local_rank):
                                         f"{d}->{hid}->{emb} L2-normalised, inner-product scores [{B * P} x {B * P + NRN}], "
                                         "retrieval loss (temperature 0.07, same-query + accidental-hit masks), backward of "
                                         "both encodes, Adam(lr 5e-3, wd 1e-6)",
-                   "driver": "gigl_nablp_train_plan_step: ONE library call per step, replayed as one hipGraph; no torch "
-                             "kernel inside a step",
+                   "driver": "gigl_nablp_train_plan_step2: ONE library call per step (the next batch's sample + union on a side "
+                             "stream beside this step's layers when prefetch is on), replayed as hipGraphs; no torch kernel "
+                             "inside a step",
+                   "prefetch": prefetch,
                    "sampled_edges_per_step": sampled, "aggregated_edges_per_step": agg,
                    "loss_first_step": first, "loss_last_step": lastv,
                    "autograd_driven_ms_per_step": autograd_ms, "setup_s": round(setup_s, 1)},

@@ -1425,8 +1425,21 @@ struct gigl_nablp_train_plan {
   float *row_lse = nullptr, *row_loss = nullptr, *loss = nullptr;  // loss[0] = the step's loss, loss[1] = valid query rows
   float lr = 5e-3f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, wd = 0.f;
   std::vector<void*> owned;
-  hipGraphExec_t exec = nullptr;
-  bool warm = false;
+  // Two workspaces of trees + union graphs (as gigl_sage_train_plan): the graph part of the NEXT step's roots (sample +
+  // union of both root sets: latency-bound launches) runs on a side stream beside this step's layers
+  static constexpr int WS = 2;
+  struct Work {
+    gigl_ctx* side = nullptr;                    // private ctx with a stream of its own: the graph part's launches
+    gigl_sage_plan* base[2] = {nullptr, nullptr};  // 0: main batch, 1: random negatives
+    hipGraphExec_t exec_graph = nullptr, exec_layers = nullptr;
+    bool warm_graph = false, warm_layers = false;
+    hipEvent_t ev_graph = nullptr;   // end of the graph part last enqueued for this workspace
+    hipEvent_t ev_layers = nullptr;  // end of the layers part that last read it
+    const uint32_t *fetched_main = nullptr, *fetched_rn = nullptr;  // the caller's buffers its graph part ran for
+    bool fetched = false;
+  } work[WS];
+  hipEvent_t ev_now = nullptr;  // "the caller's stream, now": the roots a graph part copies were written before it
+  int cur = 0;
   int32_t cap_seed = 0, cap_mode = -1;
 };
 
@@ -1781,17 +1794,24 @@ int32_t lp_backward(gigl_nablp_train_plan* t, int which) {
 }
 
 // every launch of a step, on lctx's stream (the caller's)
-int32_t lp_enqueue(gigl_nablp_train_plan* t, int32_t sampling_seed, int32_t mode) {
+// sample + union of both root sets of workspace w, on its side stream
+int32_t lp_enqueue_graph(gigl_nablp_train_plan* t, int w, int32_t sampling_seed, int32_t mode) {
+  for (int k = 0; k < 2; ++k) {
+    gigl_sage_plan* p = t->work[w].base[k];
+    const int32_t rc = enqueue_range(p, 0, 2, p->roots_buf, sampling_seed, mode, nullptr);
+    if (rc != GIGL_OK) return rc;
+  }
+  return GIGL_OK;
+}
+
+// everything after the graph part, over workspace w's trees and union graphs, on lctx's stream (the caller's)
+int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
   gigl_ctx* ctx = t->lctx;
   hipStream_t st = ctx->stream;
   const int L = t->L, d = t->dims[L], Q = t->b * t->P, Cn = Q + t->n_rn;
   int32_t rc = GIGL_OK;
+  for (int k = 0; k < 2; ++k) t->enc[k].base = t->work[w].base[k];
   gigl_fill_u32(st, t->zero_base, 0u, (int64_t)(t->zero_bytes / 4));
-  for (int k = 0; k < 2; ++k) {  // sample + union of both root sets
-    gigl_sage_plan* p = t->enc[k].base;
-    rc = enqueue_range(p, 0, 2, p->roots_buf, sampling_seed, mode, nullptr);
-    if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(p->ctx));
-  }
   for (int k = 0; k < 2; ++k) {
     rc = lp_forward(t, k);
     if (rc != GIGL_OK) return rc;
@@ -1869,10 +1889,20 @@ int32_t gigl_nablp_train_plan_destroy(gigl_nablp_train_plan* t) {
     hipSetDevice(t->ctx->device);
     hipStreamSynchronize(t->ctx->stream);
   }
-  if (t->exec) hipGraphExecDestroy(t->exec);
-  for (int k = 0; k < 2; ++k)
-    if (t->enc[k].base) gigl_sage_plan_destroy(t->enc[k].base);
+  for (auto& wk : t->work)
+    if (wk.side) hipStreamSynchronize(wk.side->stream);
+  for (auto& wk : t->work) {
+    if (wk.exec_graph) hipGraphExecDestroy(wk.exec_graph);
+    if (wk.exec_layers) hipGraphExecDestroy(wk.exec_layers);
+    if (wk.ev_graph) hipEventDestroy(wk.ev_graph);
+    if (wk.ev_layers) hipEventDestroy(wk.ev_layers);
+    for (int k = 0; k < 2; ++k)
+      if (wk.base[k]) gigl_sage_plan_destroy(wk.base[k]);
+  }
+  if (t->ev_now) hipEventDestroy(t->ev_now);
   for (void* q : t->owned) hipFree(q);
+  for (auto& wk : t->work)
+    if (wk.side) gigl_ctx_destroy(wk.side);
   if (t->lctx) {
     gigl_ctx_set_stream(t->lctx, nullptr);  // (the stream is the caller's)
     gigl_ctx_destroy(t->lctx);
@@ -1911,12 +1941,22 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
   t->wd = weight_decay;
   int32_t rc = gigl_ctx_create(ctx->device, &t->lctx);
   const int32_t nb[2] = {b_anchors * (1 + num_positives), n_random_negatives > 0 ? n_random_negatives : 1};
-  for (int k = 0; k < 2 && rc == GIGL_OK; ++k) {
-    t->enc[k].b = nb[k];
-    rc = plan_create(t->lctx, graph, feat, nb[k], fanouts, hops, dims, (const float* const*)w, (const float* const*)bias,
-                     act_last, false, &t->enc[k].base);
-    if (rc != GIGL_OK) gigl_fail(ctx, rc, "%s", gigl_last_error(t->lctx));
+  for (int wi = 0; wi < gigl_nablp_train_plan::WS && rc == GIGL_OK; ++wi) {
+    gigl_nablp_train_plan::Work& wk = t->work[wi];
+    rc = gigl_ctx_create(ctx->device, &wk.side);
+    for (int k = 0; k < 2 && rc == GIGL_OK; ++k) {
+      t->enc[k].b = nb[k];
+      rc = plan_create(wk.side, graph, feat, nb[k], fanouts, hops, dims, (const float* const*)w, (const float* const*)bias,
+                       act_last, false, &wk.base[k]);
+      if (rc != GIGL_OK) gigl_fail(ctx, rc, "%s", gigl_last_error(wk.side));
+    }
+    if (rc == GIGL_OK && (hipEventCreateWithFlags(&wk.ev_graph, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&wk.ev_layers, hipEventDisableTiming) != hipSuccess))
+      rc = GIGL_E_HIP;
   }
+  if (rc == GIGL_OK && hipEventCreateWithFlags(&t->ev_now, hipEventDisableTiming) != hipSuccess) rc = GIGL_E_HIP;
+  if (rc == GIGL_OK)
+    for (int k = 0; k < 2; ++k) t->enc[k].base = t->work[0].base[k];
   if (rc != GIGL_OK) {
     gigl_nablp_train_plan_destroy(t);
     return rc;
@@ -2014,11 +2054,39 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
   return GIGL_OK;
 }
 
-int32_t gigl_nablp_train_plan_step(gigl_nablp_train_plan* t, const uint32_t* main_roots, const int32_t* pos_cnt,
-                                   const uint32_t* rn_roots, int32_t sampling_seed, int32_t mode, float* loss_out) {
+namespace {
+// the graph part of workspace w for these roots, on its side stream; work[w].ev_graph marks its end
+int32_t lp_graph_part(gigl_nablp_train_plan* t, int w, const uint32_t* main_roots, const uint32_t* rn_roots,
+                      int32_t sampling_seed, int32_t mode) {
+  gigl_nablp_train_plan::Work& wk = t->work[w];
+  gigl_ctx* sc = wk.side;
+  // the workspace is free once the layers part that last read it is done; the roots were written on the caller's stream
+  GIGL_HIP_CHECK(sc, hipStreamWaitEvent(sc->stream, wk.ev_layers, 0));
+  GIGL_HIP_CHECK(sc, hipEventRecord(t->ev_now, t->ctx->stream));
+  GIGL_HIP_CHECK(sc, hipStreamWaitEvent(sc->stream, t->ev_now, 0));
+  GIGL_HIP_CHECK(sc, hipMemcpyAsync(wk.base[0]->roots_buf, main_roots, (size_t)t->enc[0].b * 4, hipMemcpyDeviceToDevice, sc->stream));
+  if (t->n_rn > 0)
+    GIGL_HIP_CHECK(sc, hipMemcpyAsync(wk.base[1]->roots_buf, rn_roots, (size_t)t->n_rn * 4, hipMemcpyDeviceToDevice, sc->stream));
+  else
+    gigl_fill_u32(sc->stream, wk.base[1]->roots_buf, GIGL_INVALID, 1);
+  const int32_t rc = train_run_part(sc, &wk.exec_graph, &wk.warm_graph,
+                                    [&]() { return lp_enqueue_graph(t, w, sampling_seed, mode); }, 0);
+  if (rc != GIGL_OK) return rc;
+  GIGL_HIP_CHECK(sc, hipEventRecord(wk.ev_graph, sc->stream));
+  wk.fetched_main = main_roots;
+  wk.fetched_rn = rn_roots;
+  wk.fetched = true;
+  return GIGL_OK;
+}
+}  // namespace
+
+int32_t gigl_nablp_train_plan_step2(gigl_nablp_train_plan* t, const uint32_t* main_roots, const int32_t* pos_cnt,
+                                    const uint32_t* rn_roots, const uint32_t* next_main_roots, const uint32_t* next_rn_roots,
+                                    int32_t sampling_seed, int32_t mode, float* loss_out) {
   if (!t) return GIGL_E_INVALID_ARG;
   gigl_ctx* ctx = t->ctx;
   GIGL_REQUIRE(ctx, main_roots && pos_cnt && (rn_roots || t->n_rn == 0), "null argument");
+  GIGL_REQUIRE(ctx, !next_main_roots || next_rn_roots || t->n_rn == 0, "the next step's random negatives are missing");
   if (mode == GIGL_MODE_REPLACE)
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the training plan needs duplicate-free trees (no with-replacement mode)");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -2027,26 +2095,43 @@ int32_t gigl_nablp_train_plan_step(gigl_nablp_train_plan* t, const uint32_t* mai
     const int32_t rs = gigl_ctx_set_stream(t->lctx, st);
     if (rs != GIGL_OK) return gigl_fail(ctx, rs, "%s", gigl_last_error(t->lctx));
   }
-  if (t->cap_seed != sampling_seed || t->cap_mode != mode) {  // seed and mode are baked into the captured launches
-    if (t->exec) {
-      GIGL_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      hipGraphExecDestroy(t->exec);
-      t->exec = nullptr;
+  if (t->cap_seed != sampling_seed || t->cap_mode != mode) {  // seed and mode are baked into the captured graph parts
+    for (auto& wk : t->work) {
+      GIGL_HIP_CHECK(ctx, hipStreamSynchronize(wk.side->stream));
+      if (wk.exec_graph) hipGraphExecDestroy(wk.exec_graph);
+      wk.exec_graph = nullptr;
+      wk.fetched = false;  // (what was prefetched was sampled under the old seed)
     }
     t->cap_seed = sampling_seed;
     t->cap_mode = mode;
   }
-  // the step's inputs go into the static buffers the (captured) launches read
-  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->enc[0].base->roots_buf, main_roots, (size_t)t->enc[0].b * 4, hipMemcpyDeviceToDevice, st));
+  int32_t rc = GIGL_OK;
+  const int w = t->cur;
+  gigl_nablp_train_plan::Work& wk = t->work[w];
+  // this step's trees: prefetched by the previous call for exactly these buffers, or sampled now
+  if (!(wk.fetched && wk.fetched_main == main_roots && wk.fetched_rn == rn_roots)) {
+    rc = lp_graph_part(t, w, main_roots, rn_roots, sampling_seed, mode);
+    if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(wk.side));
+  }
+  wk.fetched = false;  // (consumed)
+  const int wn = (w + 1) % gigl_nablp_train_plan::WS;
+  if (next_main_roots) {  // the next step's graph part goes to the other workspace, beside this step's layers
+    rc = lp_graph_part(t, wn, next_main_roots, next_rn_roots, sampling_seed, mode);
+    if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->work[wn].side));
+  }
   GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->pos_cnt, pos_cnt, (size_t)t->b * 4, hipMemcpyDeviceToDevice, st));
-  if (t->n_rn > 0)
-    GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->enc[1].base->roots_buf, rn_roots, (size_t)t->n_rn * 4, hipMemcpyDeviceToDevice, st));
-  else
-    gigl_fill_u32(st, t->enc[1].base->roots_buf, GIGL_INVALID, 1);
-  const int32_t rc = train_run_part(t->lctx, &t->exec, &t->warm, [&]() { return lp_enqueue(t, sampling_seed, mode); }, 1);
+  GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, wk.ev_graph, 0));
+  rc = train_run_part(t->lctx, &wk.exec_layers, &wk.warm_layers, [&]() { return lp_enqueue_layers(t, w); }, 1);
   if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->lctx));
+  GIGL_HIP_CHECK(ctx, hipEventRecord(wk.ev_layers, st));
   if (loss_out) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(loss_out, t->loss, 8, hipMemcpyDeviceToDevice, st));
+  if (next_main_roots) t->cur = wn;
   return GIGL_OK;
+}
+
+int32_t gigl_nablp_train_plan_step(gigl_nablp_train_plan* t, const uint32_t* main_roots, const int32_t* pos_cnt,
+                                   const uint32_t* rn_roots, int32_t sampling_seed, int32_t mode, float* loss_out) {
+  return gigl_nablp_train_plan_step2(t, main_roots, pos_cnt, rn_roots, nullptr, nullptr, sampling_seed, mode, loss_out);
 }
 
 const float* gigl_nablp_train_plan_loss(gigl_nablp_train_plan* t) { return t ? t->loss : nullptr; }

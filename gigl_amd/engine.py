@@ -1422,26 +1422,44 @@ class NablpTrainPlan:
     load = SageTrainPlan.load
     store = SageTrainPlan.store
 
-    def step(self, main_roots: torch.Tensor, pos_cnt: torch.Tensor, rn_roots: torch.Tensor, sampling_seed: int = 42,
-             mode: int = MODE_SPARK_HASH) -> torch.Tensor:
-        """main_roots int32 device [n_anchors * (1 + P)] anchor-major (anchor, its positive slots), pos_cnt int32 device
-        [n_anchors], rn_roots int32 device [<= n_random_negatives]; short batches are padded here (absent anchors /
-        negatives = 0xFFFFFFFF).  Returns {loss, query rows} (device, owned by the plan)."""
+    def _padded(self, main_roots: torch.Tensor, pos_cnt: Optional[torch.Tensor], rn_roots: torch.Tensor):
         T = 1 + self.P
         assert main_roots.is_cuda and main_roots.dtype == torch.int32 and main_roots.numel() % T == 0
         na = main_roots.numel() // T
-        assert 0 < na <= self.b and pos_cnt.numel() == na and rn_roots.numel() <= self.n_rn
+        assert 0 < na <= self.b and (pos_cnt is None or pos_cnt.numel() == na) and rn_roots.numel() <= self.n_rn
         if na < self.b:
             main_roots = torch.cat([main_roots, torch.full(((self.b - na) * T,), -1, dtype=torch.int32, device=main_roots.device)])
-            pos_cnt = torch.cat([pos_cnt, torch.zeros(self.b - na, dtype=torch.int32, device=pos_cnt.device)])
+            if pos_cnt is not None:
+                pos_cnt = torch.cat([pos_cnt, torch.zeros(self.b - na, dtype=torch.int32, device=pos_cnt.device)])
         if rn_roots.numel() < self.n_rn:
             rn_roots = torch.cat([rn_roots, torch.full((self.n_rn - rn_roots.numel(),), -1, dtype=torch.int32,
                                                        device=main_roots.device)])
-        main_roots, pos_cnt, rn_roots = main_roots.contiguous(), pos_cnt.to(torch.int32).contiguous(), rn_roots.contiguous()
-        self._keep = (main_roots, pos_cnt, rn_roots)
+        return (main_roots.contiguous(), None if pos_cnt is None else pos_cnt.to(torch.int32).contiguous(), rn_roots.contiguous())
+
+    def step(self, main_roots: torch.Tensor, pos_cnt: torch.Tensor, rn_roots: torch.Tensor, sampling_seed: int = 42,
+             mode: int = MODE_SPARK_HASH, next_roots=None) -> torch.Tensor:
+        """main_roots int32 device [n_anchors * (1 + P)] anchor-major (anchor, its positive slots), pos_cnt int32 device
+        [n_anchors], rn_roots int32 device [<= n_random_negatives]; short batches are padded here (absent anchors /
+        negatives = 0xFFFFFFFF).  next_roots = (main_roots, rn_roots) of the NEXT step: its sampling and union build then
+        run on a side stream beside this step's layers (gigl_nablp_train_plan_step2); the next call recognises them by
+        value.  Returns {loss, query rows} (device, owned by the plan)."""
+        pre, self._next = getattr(self, "_next", None), None
+        key = (main_roots.data_ptr(), rn_roots.data_ptr(), main_roots.numel(), rn_roots.numel())
+        main_roots, pos_cnt, rn_roots = self._padded(main_roots, pos_cnt, rn_roots)
+        if pre is not None and pre["key"] == key:  # the (padded) buffers the previous call announced to the plan
+            main_roots, rn_roots = pre["main"], pre["rn"]
+        nxt_m = nxt_r = None
+        if next_roots is not None:
+            nxt_m, _, nxt_r = self._padded(next_roots[0], None, next_roots[1])
+            # (the caller's tensors are kept alive: their addresses identify the batch at the next call)
+            self._next = dict(main=nxt_m, rn=nxt_r, keep=tuple(next_roots),
+                              key=(next_roots[0].data_ptr(), next_roots[1].data_ptr(), next_roots[0].numel(), next_roots[1].numel()))
+        self._keep = (main_roots, pos_cnt, rn_roots, nxt_m, nxt_r)
         p_ = lambda t: C.c_void_p(t.data_ptr())
-        check(self._lib.gigl_nablp_train_plan_step(self._plan, p_(main_roots), p_(pos_cnt), p_(rn_roots) if self.n_rn else None,
-                                                   int(sampling_seed), int(mode), p_(self.loss)), self.eng._ctx)
+        check(self._lib.gigl_nablp_train_plan_step2(
+            self._plan, p_(main_roots), p_(pos_cnt), p_(rn_roots) if self.n_rn else None,
+            p_(nxt_m) if nxt_m is not None else None, p_(nxt_r) if (nxt_r is not None and self.n_rn) else None,
+            int(sampling_seed), int(mode), p_(self.loss)), self.eng._ctx)
         return self.loss
 
     def grads(self, layer: int):

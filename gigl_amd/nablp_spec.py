@@ -881,8 +881,17 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         self.model.train()
         self.train_plan_steps = 0
         every = max(self.validate_every_n_batches, 1)
-        for batch_index, ((roots, cnt, _), rn_roots) in enumerate(zip(main, rn), start=1):
-            loss = plan.step(roots, cnt, rn_roots, sampling_seed=res.seed, mode=MODE_SPARK_HASH)
+        def with_next(it):  # (batch, the batch after it | None)
+            it = iter(it)
+            cur = next(it, None)
+            while cur is not None:
+                nxt = next(it, None)
+                yield cur, nxt
+                cur = nxt
+        for batch_index, (((roots, cnt, _), rn_roots), nxt) in enumerate(with_next(zip(main, rn)), start=1):
+            # the next batch's roots are announced with this step: their sampling + union run beside this step's layers
+            loss = plan.step(roots, cnt, rn_roots, sampling_seed=res.seed, mode=MODE_SPARK_HASH,
+                             next_roots=None if nxt is None else (nxt[0][0], nxt[1]))
             self.train_plan_steps += 1
             self.history.append({"batch": batch_index, "loss": float(loss[0])})
             if batch_index % every == 0:

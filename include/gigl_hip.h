@@ -1149,7 +1149,7 @@ int32_t gigl_sage_train_plan_destroy(gigl_sage_train_plan* plan);
  * accidental-hit masks, summed cross-entropy / query rows: utils/infer.py, decoder.py:64-70, loss.py:209-331), Adam with L2
  * weight decay: sample + union of the main batch and of the random-negative batch, two encoder forwards over the SHARED
  * weights, the head, the backward of both encodes (their weight gradients are added), the update — no torch kernel, no
- * host read, replayed as ONE hipGraph per step.
+ * host read, replayed as two hipGraphs per step (graph part, layers part).
  * create: b_anchors anchors x (1 + num_positives) rooted trees per main batch, n_random_negatives roots per negative
  *   batch; w[l] = fused [dims[l+1]][2 dims[l]] (= [W_l | W_r]), bias[l] (may be NULL): DEVICE, borrowed and UPDATED IN
  *   PLACE by every step; dims[hops] <= 512.
@@ -1167,6 +1167,13 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
                                      float beta1, float beta2, float eps, float weight_decay, gigl_nablp_train_plan** out);
 int32_t gigl_nablp_train_plan_step(gigl_nablp_train_plan* plan, const uint32_t* main_roots, const int32_t* pos_cnt,
                                    const uint32_t* rn_roots, int32_t sampling_seed, int32_t mode, float* loss_out);
+/* step2 = step + the NEXT step's root buffers (may be NULL: then it is step): their graph part — sample + union of both root
+ * sets, latency-bound launches — is enqueued on a side stream into the plan's second workspace and runs beside this
+ * step's layers; the next call finds it done if it is handed the same two buffers (otherwise it samples again).  The
+ * buffers must stay untouched until that call. */
+int32_t gigl_nablp_train_plan_step2(gigl_nablp_train_plan* plan, const uint32_t* main_roots, const int32_t* pos_cnt,
+                                    const uint32_t* rn_roots, const uint32_t* next_main_roots,
+                                    const uint32_t* next_rn_roots, int32_t sampling_seed, int32_t mode, float* loss_out);
 const float* gigl_nablp_train_plan_loss(gigl_nablp_train_plan* plan);
 /* the LAST step's parameter gradients of layer `layer` (the two encodes' added): gw DEVICE [dims[l+1]][2 dims[l]] (= d loss
  * / d [W_l | W_r]), gb DEVICE [dims[l+1]] (may be NULL) — what the step's Adam update consumed; for gradient parity tests */

@@ -175,15 +175,18 @@ def _lp_loss_torch(emb_main, emb_rn, roots, cnt, rn, b, P, temperature):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dims,fan,b,P,n_rn,norm", [((100, 32, 16), [10, 5], 128, 1, 64, True),
-                                                    ((100, 64, 32), [10, 5], 96, 2, 50, True),
-                                                    ((100, 256, 128), [25, 10], 64, 1, 40, False)])
-def test_library_link_prediction_step_equals_the_autograd_step(setup, dims, fan, b, P, n_rn, norm):
+@pytest.mark.parametrize("dims,fan,b,P,n_rn,norm,prefetch", [((100, 32, 16), [10, 5], 128, 1, 64, True, False),
+                                                             ((100, 64, 32), [10, 5], 96, 2, 50, True, True),
+                                                             ((100, 32, 16), [10, 5], 128, 1, 64, True, True),
+                                                             ((100, 256, 128), [25, 10], 64, 1, 40, False, False)])
+def test_library_link_prediction_step_equals_the_autograd_step(setup, dims, fan, b, P, n_rn, norm, prefetch):
     """gigl_nablp_train_plan_* (one library call per link-prediction training step: two encodes, inner-product scores,
     retrieval loss, backward of both encodes, Adam) against the autograd step over the same in-HBM batches — the loop body
     of node_anchor_based_link_prediction_modeling_task_spec.py:334-451 with the reference's defaults (GraphSAGE encoder,
     L2-normalised embeddings, temperature 0.07, accidental-hit removal, Adam lr 5e-3 wd 1e-6): same loss history, same
-    trained weights; anchors with fewer than P positives and hipGraph replay included"""
+    trained weights; anchors with fewer than P positives and hipGraph replay included.  prefetch: most steps announce the
+    next batch's roots (its sampling + union then run on the plan's side stream beside the step's layers), some do not,
+    and one announces a batch that is then NOT the one trained on (the plan must sample again)"""
     from gigl_amd.engine import NablpTrainPlan
     from gigl_amd.models import GraphSAGE, HipBatch
     eng, rowptr, col, x, n = setup
@@ -219,8 +222,12 @@ def test_library_link_prediction_step_equals_the_autograd_step(setup, dims, fan,
     plan = NablpTrainPlan(eng, lib, b, P, n_rn, fan, temperature=temp, remove_accidental_hits=True, lr=5e-3, weight_decay=1e-6)
     got = []
     with torch.cuda.stream(st):
-        for roots, cnt, rn in batches:  # (eager once, captured on the second step, replayed from then on)
-            got.append(plan.step(roots, cnt, rn).clone())
+        for i, (roots, cnt, rn) in enumerate(batches):  # (eager once, captured on the second step, replayed from then on)
+            nxt = None
+            if prefetch and i + 1 < steps and i % 4 != 2:
+                j = i + 1 if i != 4 else 0  # (step 4 announces the wrong batch)
+                nxt = (batches[j][0], batches[j][2])
+            got.append(plan.step(roots, cnt, rn, next_roots=nxt).clone())
     eng.synchronize()
     rows = [float(v[1]) for v in got]
     got = [float(v[0]) for v in got]
