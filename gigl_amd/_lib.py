@@ -62,7 +62,7 @@ SYMBOLS = [
     "gigl_hgt_infer_set_model", "gigl_hgt_infer_use_graph", "gigl_hgt_infer_destroy",
     "gigl_sage_plan_run_part", "gigl_sage_plan_overflow_add",
     "gigl_sage_train_plan_create", "gigl_sage_train_plan_step", "gigl_sage_train_plan_step2", "gigl_sage_train_plan_loss", "gigl_sage_train_plan_destroy",
-    "gigl_nablp_train_plan_create", "gigl_nablp_train_plan_step", "gigl_nablp_train_plan_step2", "gigl_nablp_train_plan_loss", "gigl_nablp_train_plan_destroy", "gigl_nablp_train_plan_grads",
+    "gigl_nablp_train_plan_create", "gigl_nablp_train_plan_step", "gigl_nablp_train_plan_step2", "gigl_gat_nablp_train_plan_create", "gigl_gat_nablp_train_plan_grads", "gigl_nablp_train_plan_loss", "gigl_nablp_train_plan_destroy", "gigl_nablp_train_plan_grads",
 ]
 
 KERNEL_IDS = {
@@ -396,6 +396,9 @@ def load() -> C.CDLL:
         "gigl_sage_train_plan_destroy": [vp],
         "gigl_nablp_train_plan_create": [vp, vp, vp, i32, i32, i32, P(i32), i32, P(i32), vp, vp, i32, i32, C.c_float, i32,
                                          C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp],
+        "gigl_gat_nablp_train_plan_create": [vp, vp, vp, i32, i32, i32, P(i32), i32, P(i32), P(i32), vp, vp, vp, vp, C.c_float,
+                                             i32, C.c_float, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp],
+        "gigl_gat_nablp_train_plan_grads": [vp, i32, vp, vp, vp, vp],
         "gigl_nablp_train_plan_step": [vp, vp, vp, vp, i32, i32, vp],
         "gigl_nablp_train_plan_step2": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
         "gigl_nablp_train_plan_destroy": [vp],

@@ -1424,6 +1424,22 @@ struct gigl_nablp_train_plan {
   int32_t* consts = nullptr;   // device {Q, C, Adam step, ...}
   float *row_lse = nullptr, *row_loss = nullptr, *loss = nullptr;  // loss[0] = the step's loss, loss[1] = valid query rows
   float lr = 5e-3f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, wd = 0.f;
+  // ---- GAT encoder (kind == 1, gigl_gat_nablp_train_plan_create): two layers, the first from the INPUT side
+  int kind = 0;
+  struct Gat {
+    int32_t heads = 1, c0 = 0, c1 = 0, d_in = 0;
+    float slope = 0.2f;
+    float *w[2] = {nullptr, nullptr}, *att_src[2] = {nullptr, nullptr}, *att_dst[2] = {nullptr, nullptr},
+          *bias[2] = {nullptr, nullptr};  // borrowed, UPDATED IN PLACE
+    float* g[8] = {nullptr};    // gradients: w0, att_src0, att_dst0, bias0, w1, att_src1, att_dst1, bias1 (both encodes ADD)
+    float* mom[16] = {nullptr};  // Adam's m, v per parameter tensor
+    int64_t n[8] = {0};
+    float *u = nullptr, *du = nullptr;  // folded attention vectors [2H][d] and their gradient
+    // forward state per encode: z [H][rows1][d], xw [rows1][c1], out_pre [b][c1]; backward scratch shared by both
+    float *z[2] = {nullptr, nullptr}, *xw[2] = {nullptr, nullptr}, *out_pre[2] = {nullptr, nullptr};
+    float *dxw = nullptr, *ds = nullptr, *dd = nullptr, *alpha = nullptr, *dh0 = nullptr, *dh0s = nullptr, *dz = nullptr,
+          *edge_scratch = nullptr;
+  } gat;
   std::vector<void*> owned;
   // Two workspaces of trees + union graphs (as gigl_sage_train_plan): the graph part of the NEXT step's roots (sample +
   // union of both root sets: latency-bound launches) runs on a side stream beside this step's layers
@@ -1718,7 +1734,7 @@ __global__ __launch_bounds__(256) void lp_adam_kernel(AdamPack2 a, const int32_t
     float* v = a.v[k];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += (int64_t)gridDim.x * blockDim.x) {
       const float w = p[i];
-      const float gr = (a.g1[k][i] + a.g2[k][i]) + a.wd * w;
+      const float gr = (a.g1[k][i] + (a.g2[k] ? a.g2[k][i] : 0.f)) + a.wd * w;
       const float mm = m[i] + (gr - m[i]) * (1.f - a.beta1);
       const float vv = v[i] * a.beta2 + (1.f - a.beta2) * gr * gr;
       m[i] = mm;
@@ -1794,6 +1810,11 @@ int32_t lp_backward(gigl_nablp_train_plan* t, int which) {
 }
 
 // every launch of a step, on lctx's stream (the caller's)
+int32_t gat_lp_begin(gigl_nablp_train_plan* t);
+int32_t gat_lp_forward(gigl_nablp_train_plan* t, int which);
+int32_t gat_lp_backward(gigl_nablp_train_plan* t, int which);
+int32_t gat_lp_finish(gigl_nablp_train_plan* t);
+
 // sample + union of both root sets of workspace w, on its side stream
 int32_t lp_enqueue_graph(gigl_nablp_train_plan* t, int w, int32_t sampling_seed, int32_t mode) {
   for (int k = 0; k < 2; ++k) {
@@ -1812,8 +1833,12 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
   int32_t rc = GIGL_OK;
   for (int k = 0; k < 2; ++k) t->enc[k].base = t->work[w].base[k];
   gigl_fill_u32(st, t->zero_base, 0u, (int64_t)(t->zero_bytes / 4));
+  if (t->kind == 1) {
+    rc = gat_lp_begin(t);
+    if (rc != GIGL_OK) return rc;
+  }
   for (int k = 0; k < 2; ++k) {
-    rc = lp_forward(t, k);
+    rc = t->kind == 1 ? gat_lp_forward(t, k) : lp_forward(t, k);
     if (rc != GIGL_OK) return rc;
   }
   const gigl_sage_plan *pm = t->enc[0].base, *pr = t->enc[1].base;
@@ -1850,9 +1875,10 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
   }
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   for (int k = 0; k < 2; ++k) {
-    rc = lp_backward(t, k);
+    rc = t->kind == 1 ? gat_lp_backward(t, k) : lp_backward(t, k);
     if (rc != GIGL_OK) return rc;
   }
+  if (t->kind == 1) return gat_lp_finish(t);
   AdamPack2 ap{};
   for (int l = 0; l < L; ++l) {
     ap.p[ap.count] = t->w[l];
@@ -2146,7 +2172,7 @@ __global__ __launch_bounds__(256) void lp_add2_kernel(const float* __restrict__ 
 int32_t gigl_nablp_train_plan_grads(gigl_nablp_train_plan* t, int32_t layer, float* gw, float* gb) {
   if (!t) return GIGL_E_INVALID_ARG;
   gigl_ctx* ctx = t->ctx;
-  GIGL_REQUIRE(ctx, layer >= 0 && layer < t->L && gw, "bad layer / null output");
+  GIGL_REQUIRE(ctx, t->kind == 0 && layer >= 0 && layer < t->L && gw, "bad plan / layer / null output");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int64_t nw = (int64_t)t->dims[layer + 1] * 2 * t->dims[layer];
   hipLaunchKernelGGL(lp_add2_kernel, dim3(256), dim3(256), 0, ctx->stream, (const float*)t->enc[0].gw[layer],
@@ -2155,6 +2181,419 @@ int32_t gigl_nablp_train_plan_grads(gigl_nablp_train_plan* t, int32_t layer, flo
     hipLaunchKernelGGL(lp_add2_kernel, dim3(4), dim3(256), 0, ctx->stream, (const float*)t->enc[0].gb[layer],
                        (const float*)t->enc[1].gb[layer], (int64_t)t->dims[layer + 1], gb);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// The same step with the GAT encoder of configs[4] (GAT.init_conv_layers, python/gigl/src/common/models/pyg/
+// homogeneous.py:300-343, under node_anchor_based_link_prediction_modeling_task_spec.py:334-451): two GATConv layers,
+// `heads` concatenated heads in the first, one in the second, no edge features.  The first layer runs from the INPUT
+// side (as models_attn.GAT does when the stored rows are wider than heads * channels): attention-weighted sums of the
+// stored rows under the folded vectors u_h = W_h^T att_h (gigl_gat_input_aggregate), then one projection per head — for
+// the nodes of level <= 1 only; the second layer for the roots only.  Backward: gigl_gat_aggregate_backward + epilogue,
+// the projections' weight / input gradients, gigl_gat_input_aggregate_backward (d u), the fold's own backward.  Both
+// encodes ADD into one set of gradients; head, loss, Adam, workspaces and prefetch are gigl_nablp_train_plan's.
+namespace {
+
+// u[h][k] = sum_c att_src[hC + c] W[hC + c][k];  u[H + h][k] = the same with att_dst
+__global__ __launch_bounds__(256) void gat_fold_kernel(const float* __restrict__ w, const float* __restrict__ att_src,
+                                                       const float* __restrict__ att_dst, int H, int C, int d,
+                                                       float* __restrict__ u) {
+  // grid (2H, ceil(d / 64)); a workgroup = 64 columns x 4 slices of the C rows
+  __shared__ float s_part[4][64];
+  const int hh = blockIdx.x;  // 0 .. 2H
+  const int h = hh % H;
+  const float* att = (hh < H ? att_src : att_dst) + h * C;
+  const int k = blockIdx.y * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (k < d)
+    for (int c = q; c < C; c += 4) acc += att[c] * w[(int64_t)(h * C + c) * d + k];
+  s_part[q][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (q == 0 && k < d) u[(int64_t)hh * d + k] = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+}
+// the fold's backward, one workgroup per weight row r = hC + c:
+//   gw[r][k] += att_src[r] du[h][k] + att_dst[r] du[H + h][k];  g_att_src[r] += <W[r], du[h]>;  g_att_dst[r] += <W[r], du[H + h]>
+__global__ __launch_bounds__(256) void gat_fold_backward_kernel(const float* __restrict__ w, const float* __restrict__ att_src,
+                                                                const float* __restrict__ att_dst, const float* __restrict__ du,
+                                                                int H, int C, int d, float* __restrict__ gw,
+                                                                float* __restrict__ g_att_src, float* __restrict__ g_att_dst) {
+  __shared__ float s_a[4], s_b[4];
+  const int r = blockIdx.x, h = r / C;
+  const float as = att_src[r], ad = att_dst[r];
+  const float* ds = du + (int64_t)h * d;
+  const float* dd = du + (int64_t)(H + h) * d;
+  float pa = 0.f, pb = 0.f;
+  for (int k = threadIdx.x; k < d; k += blockDim.x) {
+    const float wv = w[(int64_t)r * d + k], a = ds[k], b = dd[k];
+    gw[(int64_t)r * d + k] += as * a + ad * b;
+    pa += wv * a;
+    pb += wv * b;
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    pa += __shfl_xor(pa, o, 64);
+    pb += __shfl_xor(pb, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_a[threadIdx.x >> 6] = pa;
+    s_b[threadIdx.x >> 6] = pb;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    g_att_src[r] += s_a[0] + s_a[1] + s_a[2] + s_a[3];
+    g_att_dst[r] += s_b[0] + s_b[1] + s_b[2] + s_b[3];
+  }
+}
+// out[h][i][c] = y[i][hC + c] > 0 ? dy[i][hC + c] : 0 for i < *n_rows: the heads' slices of the relu'd layer's gradient, each
+// contiguous (planes rows_cap * C floats apart)
+__global__ __launch_bounds__(256) void gat_split_mask_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                             const int32_t* __restrict__ n_rows_dev, int64_t rows_cap, int H,
+                                                             int C, float* __restrict__ out) {
+  const int64_t n = (int64_t)*n_rows_dev * H * C;
+  const int HC = H * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / HC;
+    const int col = (int)(i - row * HC), h = col / C, c = col - h * C;
+    out[((int64_t)h * rows_cap + row) * C + c] = y[i] > 0.f ? dy[i] : 0.f;
+  }
+}
+// y[i][c] = x[i][c] + bias[c] for i < *n_rows (x without the bias stays: the attention backward wants it)
+__global__ __launch_bounds__(256) void gat_add_bias_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                           const int32_t* __restrict__ n_rows_dev, int C, float* __restrict__ y) {
+  const int64_t n = (int64_t)*n_rows_dev * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = x[i] + (bias ? bias[i % C] : 0.f);
+}
+// gb[c] += sum over the rows i < *n_rows of dy[i][c]: 64 rows per workgroup, one atomic per (workgroup, column)
+__global__ __launch_bounds__(256) void gat_bias_grad_kernel(const float* __restrict__ dy, const int32_t* __restrict__ n_rows_dev,
+                                                            int C, float* __restrict__ gb) {
+  const int n = *n_rows_dev;
+  const int r0 = blockIdx.x * 64, r1 = r0 + 64 < n ? r0 + 64 : n;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += dy[(int64_t)r * C + c];
+    if (acc != 0.f) atomicAdd(&gb[c], acc);
+  }
+}
+
+int64_t gat_rows1(const gigl_nablp_train_plan* t, int which) { return t->enc[which].rows_cap[0]; }
+
+// once per step: the folded attention vectors of the first layer (both encodes read them)
+int32_t gat_lp_begin(gigl_nablp_train_plan* t) {
+  const auto& g = t->gat;
+  hipLaunchKernelGGL(gat_fold_kernel, dim3((unsigned)(2 * g.heads), (unsigned)((g.d_in + 63) / 64)), dim3(256), 0,
+                     t->lctx->stream, (const float*)g.w[0],
+                     (const float*)g.att_src[0], (const float*)g.att_dst[0], g.heads, g.c0, g.d_in, g.u);
+  GIGL_HIP_CHECK(t->lctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gat_lp_forward(gigl_nablp_train_plan* t, int which) {
+  gigl_nablp_train_plan::Enc& e = t->enc[which];
+  gigl_sage_plan* p = e.base;
+  gigl_ctx* ctx = t->lctx;
+  hipStream_t st = ctx->stream;
+  auto& g = t->gat;
+  const int H = g.heads, C0 = g.c0, C1 = g.c1, d = g.d_in;
+  const int64_t rows1 = gat_rows1(t, which);
+  const int32_t* n0 = p->un.meta + GIGL_META_LEVEL0;
+  const int32_t* n1 = p->un.meta + GIGL_META_LEVEL0 + 1;
+  int32_t rc = gigl_gat_input_aggregate(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, g.u, H, g.slope, p->un.rowptr,
+                                        p->un.rowend, p->un.col, n1, rows1, g.z[which]);
+  if (rc != GIGL_OK) return rc;
+  // h0[:, hC:(h+1)C] = relu(z_h W_h^T + b_h): one launch for all heads
+  rc = gigl_linear_batched(ctx, g.z[which], g.w[0], g.bias[0], n1, rows1, d, C0, 1, H, rows1 * d, (int64_t)C0 * d, H * C0, e.h[0]);
+  if (rc != GIGL_OK) return rc;
+  rc = gigl_linear(ctx, e.h[0], g.w[1], nullptr, n1, rows1, H * C0, C1, 0, g.xw[which]);
+  if (rc != GIGL_OK) return rc;
+  rc = gigl_gat_aggregate(ctx, g.xw[which], g.att_src[1], g.att_dst[1], 1, C1, g.slope, 1, p->un.rowptr, p->un.rowend,
+                          p->un.col, n1, rows1, n0, e.rows_cap[1], nullptr, 0, g.alpha, g.out_pre[which]);
+  if (rc != GIGL_OK) return rc;
+  {
+    int64_t blocks = (e.rows_cap[1] * C1 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gat_add_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)g.out_pre[which],
+                       (const float*)g.bias[1], n0, C1, e.h[1]);
+  }
+  hipLaunchKernelGGL(lp_take_norm_kernel, dim3((unsigned)((e.b + 3) / 4)), dim3(256), 0, st, (const float*)e.h[1],
+                     (const int32_t*)p->un.root_local, e.b, C1, t->normalize, (const int32_t*)p->un.meta, e.emb, e.inv);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gat_lp_backward(gigl_nablp_train_plan* t, int which) {
+  gigl_nablp_train_plan::Enc& e = t->enc[which];
+  gigl_sage_plan* p = e.base;
+  gigl_ctx* ctx = t->lctx;
+  hipStream_t st = ctx->stream;
+  auto& g = t->gat;
+  const int H = g.heads, C0 = g.c0, C1 = g.c1, d = g.d_in, HC = H * C0;
+  const int64_t rows1 = gat_rows1(t, which);
+  const int32_t* n0 = p->un.meta + GIGL_META_LEVEL0;
+  const int32_t* n1 = p->un.meta + GIGL_META_LEVEL0 + 1;
+  float *gw0 = g.g[0], *gas0 = g.g[1], *gad0 = g.g[2], *gb0 = g.g[3], *gw1 = g.g[4], *gas1 = g.g[5], *gad1 = g.g[6], *gb1 = g.g[7];
+  (void)gas0;
+  (void)gad0;
+  // ---- second layer (the roots' rows): e.dh[1] = d loss / d (out before the bias)
+  if (g.bias[1])
+    hipLaunchKernelGGL(gat_bias_grad_kernel, dim3((unsigned)((e.rows_cap[1] + 63) / 64)), dim3(256), 0, st, (const float*)e.dh[1],
+                       n0, C1, gb1);
+  gigl_fill_u32(st, g.dxw, 0u, rows1 * C1);
+  gigl_fill_u32(st, g.ds, 0u, g.dd - g.ds + rows1);  // (ds | dd: dd starts where the larger encode's ds ends)
+  int32_t rc = gigl_gat_aggregate_backward(ctx, g.xw[which], g.att_src[1], g.att_dst[1], 1, C1, g.slope, p->un.rowptr,
+                                           p->un.rowend, p->un.col, n1, rows1, n0, e.rows_cap[1], g.out_pre[which], e.dh[1],
+                                           nullptr, 0, p->un.cap_edges, nullptr, g.alpha, g.dxw, g.ds, g.dd, nullptr, nullptr,
+                                           nullptr);
+  if (rc != GIGL_OK) return rc;
+  rc = gigl_gat_backward_epilogue(ctx, g.dxw, g.ds, g.dd, g.xw[which], g.att_src[1], g.att_dst[1], n1, rows1, 1, C1, gas1, gad1);
+  if (rc != GIGL_OK) return rc;
+  rc = gigl_linear_weight_grad(ctx, g.dxw, e.h[0], nullptr, n1, rows1, C1, HC, gw1, nullptr);
+  if (rc != GIGL_OK) return rc;
+  {
+    int64_t blocks = ((int64_t)C1 * HC + 255) / 256;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)g.w[1], C1, HC, t->wt);
+  }
+  rc = gigl_linear(ctx, g.dxw, t->wt, nullptr, n1, rows1, C1, HC, 0, g.dh0);
+  if (rc != GIGL_OK) return rc;
+  // ---- first layer: relu mask, the heads' slices, their projections' backward, the attention-weighted sums' backward
+  {
+    int64_t blocks = (rows1 * HC + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gat_split_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)g.dh0, (const float*)e.h[0],
+                       n1, rows1, H, C0, g.dh0s);
+  }
+  for (int h = 0; h < H; ++h) {
+    const float* dyh = g.dh0s + (int64_t)h * rows1 * C0;
+    rc = gigl_linear_weight_grad(ctx, dyh, g.z[which] + (int64_t)h * rows1 * d, nullptr, n1, rows1, C0, d, gw0 + (int64_t)h * C0 * d,
+                                 g.bias[0] ? gb0 + h * C0 : nullptr);
+    if (rc != GIGL_OK) return rc;
+    {
+      int64_t blocks = ((int64_t)C0 * d + 255) / 256;
+      hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)(g.w[0] + (int64_t)h * C0 * d),
+                         C0, d, t->wt);
+    }
+    rc = gigl_linear(ctx, dyh, t->wt, nullptr, n1, rows1, C0, d, 0, g.dz + (int64_t)h * rows1 * d);
+    if (rc != GIGL_OK) return rc;
+  }
+  rc = gigl_gat_input_aggregate_backward(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, g.u, H, g.slope, p->un.rowptr,
+                                         p->un.rowend, p->un.col, n1, rows1, g.dz, g.edge_scratch, g.du);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return rc;
+}
+
+// after both encodes: d u -> the first layer's weights and attention vectors, then Adam over the eight tensors
+int32_t gat_lp_finish(gigl_nablp_train_plan* t) {
+  gigl_ctx* ctx = t->lctx;
+  hipStream_t st = ctx->stream;
+  auto& g = t->gat;
+  hipLaunchKernelGGL(gat_fold_backward_kernel, dim3((unsigned)(g.heads * g.c0)), dim3(256), 0, st, (const float*)g.w[0],
+                     (const float*)g.att_src[0], (const float*)g.att_dst[0], (const float*)g.du, g.heads, g.c0, g.d_in, g.g[0],
+                     g.g[1], g.g[2]);
+  AdamPack2 ap{};
+  float* params[8] = {g.w[0], g.att_src[0], g.att_dst[0], g.bias[0], g.w[1], g.att_src[1], g.att_dst[1], g.bias[1]};
+  for (int i = 0; i < 8; ++i) {
+    if (!params[i]) continue;
+    ap.p[ap.count] = params[i];
+    ap.g1[ap.count] = g.g[i];
+    ap.g2[ap.count] = nullptr;
+    ap.m[ap.count] = g.mom[2 * i];
+    ap.v[ap.count] = g.mom[2 * i + 1];
+    ap.n[ap.count++] = g.n[i];
+  }
+  ap.lr = t->lr;
+  ap.beta1 = t->beta1;
+  ap.beta2 = t->beta2;
+  ap.eps = t->eps;
+  ap.wd = t->wd;
+  hipLaunchKernelGGL(lp_adam_kernel, dim3(256), dim3(256), 0, st, ap, (const int32_t*)(t->consts + 2),
+                     (const int32_t*)t->enc[0].base->un.meta, (const int32_t*)t->enc[1].base->un.meta);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+}  // namespace
+
+int32_t gigl_gat_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b_anchors,
+                                         int32_t num_positives, int32_t n_random_negatives, const int32_t* fanouts, int32_t hops,
+                                         const int32_t* heads, const int32_t* channels, float* const* w,
+                                         float* const* att_src, float* const* att_dst, float* const* bias,
+                                         float negative_slope, int32_t l2_normalize, float temperature,
+                                         int32_t remove_accidental_hits, float lr, float beta1, float beta2, float eps,
+                                         float weight_decay, gigl_nablp_train_plan** out) {
+  if (!ctx || !out) return GIGL_E_INVALID_ARG;
+  *out = nullptr;
+  GIGL_REQUIRE(ctx, graph && feat && fanouts && heads && channels && w && att_src && att_dst, "null argument");
+  GIGL_REQUIRE(ctx, b_anchors >= 1 && num_positives >= 1 && n_random_negatives >= 0, "bad batch shape");
+  if (hops != 2 || heads[1] != 1)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the GAT link-prediction plan runs two layers, one head in the second");
+  const int H = heads[0], C0 = channels[0], C1 = channels[1], d = feat->d;
+  if ((d & 3) || d > 1024 || (H != 1 && H != 2 && H != 4) || (feat->dtype != GIGL_DTYPE_F32 && feat->dtype != GIGL_DTYPE_F16) ||
+      H * C0 > 1024 || (C0 & 3) || (C1 & 3) || C1 > 512)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "GAT link-prediction plan: feature dim %d / %d heads x %d / %d channels outside "
+                     "the built shapes", d, H, C0, C1);
+  for (int l = 0; l < 2; ++l) GIGL_REQUIRE(ctx, w[l] && att_src[l] && att_dst[l], "layer %d: null parameter", l);
+  if (fanouts[1] > GIGL_FAST_FANOUT) return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "second fan-out beyond %d", GIGL_FAST_FANOUT);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  gigl_nablp_train_plan* t = new (std::nothrow) gigl_nablp_train_plan();
+  if (!t) return gigl_fail(ctx, GIGL_E_OOM, "host OOM");
+  t->ctx = ctx;
+  t->kind = 1;
+  t->L = 2;
+  t->b = b_anchors;
+  t->P = num_positives;
+  t->n_rn = n_random_negatives;
+  t->normalize = l2_normalize ? 1 : 0;
+  t->remove_hits = remove_accidental_hits ? 1 : 0;
+  t->temperature = temperature;
+  t->act_last = 0;
+  t->lr = lr;
+  t->beta1 = beta1;
+  t->beta2 = beta2;
+  t->eps = eps;
+  t->wd = weight_decay;
+  auto& g = t->gat;
+  g.heads = H;
+  g.c0 = C0;
+  g.c1 = C1;
+  g.d_in = d;
+  g.slope = negative_slope;
+  for (int l = 0; l < 2; ++l) {
+    g.w[l] = w[l];
+    g.att_src[l] = att_src[l];
+    g.att_dst[l] = att_dst[l];
+    g.bias[l] = bias ? bias[l] : nullptr;
+  }
+  const int32_t dims[3] = {d, H * C0, C1};
+  for (int l = 0; l <= 2; ++l) t->dims[l] = dims[l];
+  int32_t rc = gigl_ctx_create(ctx->device, &t->lctx);
+  const int32_t nb[2] = {b_anchors * (1 + num_positives), n_random_negatives > 0 ? n_random_negatives : 1};
+  for (int wi = 0; wi < gigl_nablp_train_plan::WS && rc == GIGL_OK; ++wi) {
+    gigl_nablp_train_plan::Work& wk = t->work[wi];
+    rc = gigl_ctx_create(ctx->device, &wk.side);
+    for (int k = 0; k < 2 && rc == GIGL_OK; ++k) {
+      t->enc[k].b = nb[k];
+      // (the base plans are tree + union workspaces here: their own layer buffers stay unused)
+      rc = plan_create(wk.side, graph, feat, nb[k], fanouts, hops, dims, (const float* const*)w, (const float* const*)bias, 0,
+                       false, &wk.base[k]);
+      if (rc != GIGL_OK) gigl_fail(ctx, rc, "%s", gigl_last_error(wk.side));
+      // every node of the batch graph is numbered: gigl_gat_input_aggregate reads its sources through un.nodes
+      if (rc == GIGL_OK) wk.base[k]->leaf_global = false;
+    }
+    if (rc == GIGL_OK && (hipEventCreateWithFlags(&wk.ev_graph, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&wk.ev_layers, hipEventDisableTiming) != hipSuccess))
+      rc = GIGL_E_HIP;
+  }
+  if (rc == GIGL_OK && hipEventCreateWithFlags(&t->ev_now, hipEventDisableTiming) != hipSuccess) rc = GIGL_E_HIP;
+  if (rc != GIGL_OK) {
+    gigl_nablp_train_plan_destroy(t);
+    return rc;
+  }
+  for (int k = 0; k < 2; ++k) t->enc[k].base = t->work[0].base[k];
+  auto alloc = [&](size_t bytes) -> void* {
+    void* q = nullptr;
+    if (hipMalloc(&q, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    t->owned.push_back(q);
+    return q;
+  };
+  bool ok = true;
+  const int64_t n_par[8] = {(int64_t)H * C0 * d, H * C0, H * C0, g.bias[0] ? H * C0 : 0, (int64_t)C1 * H * C0, C1, C1, g.bias[1] ? C1 : 0};
+  size_t zero_floats = (size_t)2 * H * d;  // du
+  for (int i = 0; i < 8; ++i) {
+    g.n[i] = n_par[i];
+    zero_floats += (size_t)n_par[i];
+  }
+  int64_t rows1_max = 0;
+  for (int k = 0; k < 2; ++k) {
+    gigl_nablp_train_plan::Enc& e = t->enc[k];
+    e.rows_cap[0] = (int64_t)e.b * (1 + fanouts[0]);  // nodes of level <= 1
+    e.rows_cap[1] = e.b;
+    if (e.rows_cap[0] > rows1_max) rows1_max = e.rows_cap[0];
+    zero_floats += (size_t)e.b * C1;  // dh[1]
+    e.h[0] = (float*)alloc((size_t)e.rows_cap[0] * H * C0 * 4);
+    e.h[1] = (float*)alloc((size_t)e.b * C1 * 4);
+    g.z[k] = (float*)alloc((size_t)H * e.rows_cap[0] * d * 4);
+    g.xw[k] = (float*)alloc((size_t)e.rows_cap[0] * C1 * 4);
+    g.out_pre[k] = (float*)alloc((size_t)e.b * C1 * 4);
+    e.emb = (float*)alloc((size_t)e.b * C1 * 4);
+    e.inv = (float*)alloc((size_t)e.b * 4);
+    ok = ok && e.h[0] && e.h[1] && g.z[k] && g.xw[k] && g.out_pre[k] && e.emb && e.inv;
+  }
+  float* z = (float*)alloc(zero_floats * 4);
+  t->zero_base = z;
+  t->zero_bytes = zero_floats * 4;
+  if (z) {
+    for (int i = 0; i < 8; ++i) {
+      g.g[i] = z;
+      z += n_par[i];
+    }
+    g.du = z;
+    z += (size_t)2 * H * d;
+    for (int k = 0; k < 2; ++k) {
+      t->enc[k].dh[1] = z;
+      z += (size_t)t->enc[k].b * C1;
+    }
+  }
+  for (int i = 0; i < 8 && ok; ++i)
+    for (int j = 0; j < 2; ++j) {
+      g.mom[2 * i + j] = (float*)alloc((size_t)(n_par[i] ? n_par[i] : 1) * 4);
+      if (!g.mom[2 * i + j] || hipMemset(g.mom[2 * i + j], 0, (size_t)(n_par[i] ? n_par[i] : 1) * 4) != hipSuccess) ok = false;
+    }
+  const int64_t cap_edges = t->work[0].base[0]->un.cap_edges;
+  g.u = (float*)alloc((size_t)2 * H * d * 4);
+  g.dxw = (float*)alloc((size_t)rows1_max * C1 * 4);
+  g.ds = (float*)alloc((size_t)2 * rows1_max * 4);
+  g.dd = g.ds ? g.ds + rows1_max : nullptr;
+  g.alpha = (float*)alloc((size_t)(2 * rows1_max + cap_edges) * 4);
+  g.dh0 = (float*)alloc((size_t)rows1_max * H * C0 * 4);
+  g.dh0s = (float*)alloc((size_t)rows1_max * H * C0 * 4);
+  g.dz = (float*)alloc((size_t)H * rows1_max * d * 4);
+  g.edge_scratch = (float*)alloc((size_t)2 * H * cap_edges * 4);
+  const size_t wt_floats = std::max((size_t)C1 * H * C0, (size_t)C0 * d);
+  t->wt = (float*)alloc(wt_floats * 4);
+  ok = ok && t->zero_base && g.u && g.dxw && g.ds && g.alpha && g.dh0 && g.dh0s && g.dz && g.edge_scratch && t->wt;
+  const size_t de = (size_t)C1, Q = (size_t)b_anchors * num_positives, Cn = Q + (size_t)t->n_rn;
+  t->rq = (float*)alloc(Q * de * 4);
+  t->cand = (float*)alloc(Cn * de * 4);
+  t->cand_t = (float*)alloc(Cn * de * 4);
+  t->scores = (float*)alloc(Q * Cn * 4);
+  t->dscores = (float*)alloc(Q * Cn * 4);
+  t->d_rq = (float*)alloc(Q * de * 4);
+  t->d_cand = (float*)alloc(Cn * de * 4);
+  t->qid = (int64_t*)alloc(Q * 8);
+  t->cid = (int64_t*)alloc(Cn * 8);
+  t->valid = (int32_t*)alloc(Cn * 4);
+  t->pos_cnt = (int32_t*)alloc((size_t)b_anchors * 4);
+  t->consts = (int32_t*)alloc(64);
+  t->row_lse = (float*)alloc(Q * 4);
+  t->row_loss = (float*)alloc(Q * 4);
+  t->loss = (float*)alloc(64);
+  ok = ok && t->rq && t->cand && t->cand_t && t->scores && t->dscores && t->d_rq && t->d_cand && t->qid && t->cid && t->valid &&
+       t->pos_cnt && t->consts && t->row_lse && t->row_loss && t->loss;
+  if (ok) {
+    const int32_t c[16] = {(int32_t)Q, (int32_t)Cn, 0 /* Adam's step counter */, 0};
+    if (hipMemcpy(t->consts, c, sizeof(c), hipMemcpyHostToDevice) != hipSuccess || hipMemset(t->loss, 0, 64) != hipSuccess)
+      ok = false;
+  }
+  if (!ok) {
+    gigl_nablp_train_plan_destroy(t);
+    return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the GAT link-prediction training workspace failed");
+  }
+  *out = t;
+  return GIGL_OK;
+}
+
+int32_t gigl_gat_nablp_train_plan_grads(gigl_nablp_train_plan* t, int32_t layer, float* gw, float* g_att_src,
+                                        float* g_att_dst, float* gb) {
+  if (!t) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = t->ctx;
+  GIGL_REQUIRE(ctx, t->kind == 1 && layer >= 0 && layer < 2 && gw && g_att_src && g_att_dst, "bad plan / layer / null output");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  float* dst[4] = {gw, g_att_src, g_att_dst, gb};
+  for (int i = 0; i < 4; ++i) {
+    const int j = 4 * layer + i;
+    if (!dst[i] || !t->gat.n[j]) continue;
+    GIGL_HIP_CHECK(ctx, hipMemcpyAsync(dst[i], t->gat.g[j], (size_t)t->gat.n[j] * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  }
   return GIGL_OK;
 }
 

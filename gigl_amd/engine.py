@@ -1476,6 +1476,77 @@ class NablpTrainPlan:
             self._plan = None
 
 
+class GatNablpTrainPlan(NablpTrainPlan):
+    """the link-prediction training step with the two-layer GAT encoder (gigl_gat_nablp_train_plan_create; step / loss /
+    prefetch are NablpTrainPlan's).  Trains copies of the encoder's parameters held here as torch tensors (`load` / `store`
+    move them from / to a models_attn.GAT)."""
+
+    def __init__(self, eng: HipEngine, model, b_anchors: int, num_positives: int, n_random_negatives: int, fanouts,
+                 temperature: float = 0.07, remove_accidental_hits: bool = True, lr: float = 5e-3,
+                 weight_decay: float = 1e-6, betas=(0.9, 0.999), eps: float = 1e-8):
+        assert eng._graph is not None and eng._feat is not None, "load the graph and the features first"
+        if not self.applies(model, eng.feat_dim) or len(fanouts) != 2:
+            raise NotImplementedError("the GAT link-prediction plan runs two plain GATConv layers (concatenated heads, one "
+                                      "head in the second, no edge features) whose input rows are wider than the first "
+                                      "layer's output")
+        self.eng, self.b, self.P, self.n_rn = eng, int(b_anchors), int(num_positives), int(n_random_negatives)
+        self.fanouts = [int(f) for f in fanouts]
+        self._lib = eng._lib
+        self.load(model)
+        c0, c1 = model.conv_layers
+        self.heads, self.channels = [int(c0.heads), 1], [int(c0.out_channels), int(c1.out_channels)]
+        self._plan = C.c_void_p()
+        arr = lambda ts: (C.c_void_p * 2)(*[(t.data_ptr() if t is not None else None) for t in ts])
+        check(self._lib.gigl_gat_nablp_train_plan_create(
+            eng._ctx, eng._graph, eng._feat, self.b, self.P, self.n_rn, (C.c_int32 * 2)(*self.fanouts), 2,
+            (C.c_int32 * 2)(*self.heads), (C.c_int32 * 2)(*self.channels), arr(self.w), arr(self.att_src), arr(self.att_dst),
+            arr(self.bias), float(c0.negative_slope), 1 if model.should_l2_normalize_embedding_layer_output else 0,
+            float(temperature), 1 if remove_accidental_hits else 0, float(lr), float(betas[0]), float(betas[1]), float(eps),
+            float(weight_decay), C.byref(self._plan)), eng._ctx)
+        self.loss = torch.zeros(2, dtype=torch.float32, device=eng.device)
+
+    @staticmethod
+    def applies(model, feat_dim: int) -> bool:
+        from .models_attn import GAT, GATConv
+        if type(model) is not GAT or model.num_layers != 2 or model.edge_dim is not None or model.activation_after_last_conv:
+            return False
+        c0, c1 = model.conv_layers
+        if type(c0) is not GATConv or type(c1) is not GATConv or not c0.concat or c1.heads != 1:
+            return False
+        d = int(c0.in_channels)
+        return (d == int(feat_dim) and d % 4 == 0 and d <= 1024 and c0.heads in (1, 2, 4) and d > c0.heads * c0.out_channels
+                and c0.heads * c0.out_channels <= 1024 and c0.out_channels % 4 == 0 and c1.out_channels % 4 == 0
+                and c1.out_channels <= 512 and c0.negative_slope == c1.negative_slope)
+
+    def load(self, model) -> None:
+        dev = self.eng.device
+        f = lambda t: None if t is None else t.detach().to(dev, torch.float32).reshape(-1).contiguous().clone()
+        self.w = [c.lin.weight.detach().to(dev, torch.float32).contiguous().clone() for c in model.conv_layers]
+        self.att_src = [f(c.att_src) for c in model.conv_layers]
+        self.att_dst = [f(c.att_dst) for c in model.conv_layers]
+        self.bias = [f(c.bias) for c in model.conv_layers]
+        if getattr(self, "_plan", None):
+            raise RuntimeError("load() before the plan exists (its parameter pointers are baked into the plan)")
+
+    def store(self, model) -> None:
+        with torch.no_grad():
+            for l, c in enumerate(model.conv_layers):
+                c.lin.weight.copy_(self.w[l])
+                c.att_src.copy_(self.att_src[l].view_as(c.att_src))
+                c.att_dst.copy_(self.att_dst[l].view_as(c.att_dst))
+                if c.bias is not None:
+                    c.bias.copy_(self.bias[l])
+
+    def grads(self, layer: int):
+        """(d W, d att_src, d att_dst, d bias) of `layer` from the LAST step"""
+        outs = [torch.empty_like(self.w[layer]), torch.empty_like(self.att_src[layer]), torch.empty_like(self.att_dst[layer]),
+                torch.empty_like(self.bias[layer]) if self.bias[layer] is not None else None]
+        check(self._lib.gigl_gat_nablp_train_plan_grads(self._plan, int(layer),
+                                                        *[(C.c_void_p(t.data_ptr()) if t is not None else None) for t in outs]),
+              self.eng._ctx)
+        return tuple(outs)
+
+
 class GatPlan(SagePlan):
     """sample -> union -> GAT forward -> one row per root, enqueued by ONE library call (gigl_gat_plan_create; the
     handle is a gigl_sage_plan: run / use_graph / stats / last_batch_to_host are SagePlan's)"""

@@ -836,7 +836,8 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         """-> engine.NablpTrainPlan when this job's training step can run as ONE library call per batch
         (gigl_nablp_train_plan_*: both encodes, the head, the backward and Adam inside the library, a hipGraph per step),
         else None (the autograd loop below).  That is: the in-HBM route with a whole replica in one process, the plain
-        mean-GraphSAGE encoder, the inner-product decoder, the Retrieval task alone with its own cross-entropy and no
+        mean-GraphSAGE encoder — or configs[4]'s two-layer GAT (engine.GatNablpTrainPlan.applies) —, the inner-product
+        decoder, the Retrieval task alone with its own cross-entropy and no
         candidate-sampling correction, torch.optim.Adam with its default betas / eps, a constant learning rate, no gradient
         clipping; trainerArgs train_plan = "off" keeps the autograd loop."""
         if str(self._kwargs.get("train_plan", "auto")).lower() == "off" or self._hbm_split(cfg) is None:
@@ -846,9 +847,11 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
         enc, dec = inner.encoder, inner.decoder
         tasks = list(self.tasks._task_to_fn_map.values())
         from ._lib import MODE_SPARK_HASH
-        if _rank_world()[1] > 1 or res.sharded or res.train_as_graph_data or res.mode != MODE_SPARK_HASH or \
-                type(enc).__module__ != "gigl_amd.models" or \
-                type(enc).__name__ != "GraphSAGE" or len(tasks) != 1 or type(tasks[0]) is not Retrieval or \
+        from .engine import GatNablpTrainPlan
+        sage = type(enc).__module__ == "gigl_amd.models" and type(enc).__name__ == "GraphSAGE" and not res.train_as_graph_data
+        gat = GatNablpTrainPlan.applies(enc, res.feat_dim) and len(res.fanouts) == 2  # (configs[4]'s encoder)
+        if _rank_world()[1] > 1 or res.sharded or res.mode != MODE_SPARK_HASH or not (sage or gat) or \
+                len(tasks) != 1 or type(tasks[0]) is not Retrieval or \
                 tasks[0].should_enable_candidate_sampling_correction or tasks[0].loss._loss is not None or \
                 self.tasks._task_to_weights_map.get(tasks[0].task_name) != 1.0 or \
                 str(getattr(dec, "decoder_type", "inner_product")).split(".")[-1] != "inner_product" or \
@@ -856,14 +859,15 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
                 self._lr_scheduler_cls is not torch.optim.lr_scheduler.ConstantLR or \
                 float(self._lr_scheduler_kwargs.get("factor", 1.0)) != 1.0 or int(enc.conv_layers[-1].out_channels) > 512:
             return None
+        from ._lib import GiglError
         from .engine import NablpTrainPlan
         try:
-            return NablpTrainPlan(res.engine, enc, self.main_sample_batch_size, cfg.num_positive_samples,
-                                  self.random_negative_sample_batch_size, res.fanouts,
-                                  temperature=float(tasks[0].loss._temperature or 0.0),
-                                  remove_accidental_hits=bool(tasks[0].loss._remove_accidental_hits),
-                                  lr=self._optim_kwargs["lr"], weight_decay=self._optim_kwargs["weight_decay"])
-        except NotImplementedError:
+            return (NablpTrainPlan if sage else GatNablpTrainPlan)(
+                res.engine, enc, self.main_sample_batch_size, cfg.num_positive_samples,
+                self.random_negative_sample_batch_size, res.fanouts, temperature=float(tasks[0].loss._temperature or 0.0),
+                remove_accidental_hits=bool(tasks[0].loss._remove_accidental_hits), lr=self._optim_kwargs["lr"],
+                weight_decay=self._optim_kwargs["weight_decay"])
+        except (NotImplementedError, GiglError):
             return None
 
     def _train_with_plan(self, plan, cfg: GbmlConfigPbWrapper, device: torch.device, profiler=None) -> None:

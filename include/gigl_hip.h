@@ -1179,6 +1179,24 @@ const float* gigl_nablp_train_plan_loss(gigl_nablp_train_plan* plan);
  * / d [W_l | W_r]), gb DEVICE [dims[l+1]] (may be NULL) — what the step's Adam update consumed; for gradient parity tests */
 int32_t gigl_nablp_train_plan_grads(gigl_nablp_train_plan* plan, int32_t layer, float* gw, float* gb);
 int32_t gigl_nablp_train_plan_destroy(gigl_nablp_train_plan* plan);
+/* The same plan with the GAT encoder configs[4] names (GAT.init_conv_layers, python/gigl/src/common/models/pyg/
+ * homogeneous.py:300-343): hops == 2, heads[0] in {1, 2, 4} concatenated heads of channels[0] in the first layer, one head of
+ * channels[1] (= the embedding width, <= 512) in the second, no edge features, no activation after the last layer; feature
+ * rows of d % 4 == 0, d <= 1024 floats (fp32 or fp16 table).  The first layer runs from the INPUT side (attention-weighted
+ * sums of the stored rows under the folded attention vectors, then one projection per head) for the nodes of level <= 1, the
+ * second for the roots; the batch graphs number every node (generic union).  Parameters per layer: w [heads*channels][in],
+ * att_src / att_dst [heads*channels], bias [heads*channels] (may be NULL) — DEVICE fp32, borrowed and UPDATED IN PLACE.
+ * step / step2 / loss / destroy are gigl_nablp_train_plan's; _grads hands out the LAST step's gradients of one layer
+ * (g_att_src / g_att_dst [heads*channels]; gb may be NULL). */
+int32_t gigl_gat_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b_anchors,
+                                         int32_t num_positives, int32_t n_random_negatives, const int32_t* fanouts,
+                                         int32_t hops, const int32_t* heads, const int32_t* channels, float* const* w,
+                                         float* const* att_src, float* const* att_dst, float* const* bias,
+                                         float negative_slope, int32_t l2_normalize, float temperature,
+                                         int32_t remove_accidental_hits, float lr, float beta1, float beta2, float eps,
+                                         float weight_decay, gigl_nablp_train_plan** out);
+int32_t gigl_gat_nablp_train_plan_grads(gigl_nablp_train_plan* plan, int32_t layer, float* gw, float* g_att_src,
+                                        float* g_att_dst, float* gb);
 
 /* Count-min sketch of candidate ids for the Retrieval task's candidate-sampling correction
  * (python/gigl/src/common/models/layers/count_min_sketch.py:11-95, used by task.py:140-205): table = DEVICE int32

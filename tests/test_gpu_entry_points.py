@@ -604,18 +604,26 @@ def test_bench_emulated_world_line(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_gat_lp_train_line(tmp_path):
+@pytest.mark.parametrize("driver", ["plan", "autograd"])
+def test_bench_gat_lp_train_line(tmp_path, driver):
     """bench.py --workload gat-lp --train at a toy scale: the link-prediction TRAINING step of the GAT encoder on the
-    in-HBM route (backward + Adam included) emits its line, the loss stays finite and falls from its first value"""
+    in-HBM route (backward + Adam included) emits its line, the loss stays finite and falls from its first value — as the
+    library plan (gigl_gat_nablp_train_plan_*, the default) and as the autograd-driven loop (--gat-train-autograd)"""
     import json
     import subprocess
     import sys
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
     cp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "gat-lp", "--train", "--shard-scale",
-                         "0.001", "--batch", "64", "--steps", "16", "--min-seconds", "0.2"], capture_output=True,
+                         "0.001", "--batch", "64", "--steps", "16", "--min-seconds", "0.2"]
+                        + (["--gat-train-autograd"] if driver == "autograd" else []), capture_output=True,
                         text=True, timeout=600, env=dict(os.environ, GIGL_BENCH_CHILD="1"))
     assert cp.returncode == 0, cp.stderr[-2000:]
     line = json.loads([ln for ln in cp.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["metric"] == "sampled+aggregated edges/s" and line["value"] > 0 and "TRAINING" in line["config"]["workload"]
+    if driver == "plan":
+        assert "gigl_gat_nablp_train_plan" in line["config"]["driver"]
+        assert line["config"]["loss_last_step"] < line["config"]["loss_first_step"]
+        assert line["config"]["autograd_driven_ms_per_step"] > 0  # (the comparison ran)
+        return
     assert line["config"]["loss_last_mean"] < line["config"]["loss_first"]
     assert "gather_mean" in line["roofline"]["by_kernel"] and "linear" in line["roofline"]["by_kernel"]

@@ -332,3 +332,76 @@ def test_transposed_backward_gather_equals_the_scatter_and_a_dense_restatement(d
     np.testing.assert_allclose(g[:n_src], ref.cpu().numpy()[:n_src], rtol=2e-5, atol=2e-5)
     assert (g[n_src:] == 7.0).all()
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads,hid,out,norm,dtype", [(2, 16, 32, True, torch.float32), (1, 32, 16, True, torch.float16),
+                                                       (4, 8, 16, False, torch.float32)])
+def test_library_gat_link_prediction_step_equals_the_autograd_step(setup, heads, hid, out, norm, dtype):
+    """gigl_gat_nablp_train_plan_* — the link-prediction training step with configs[4]'s encoder (two GATConv layers, the
+    first from the input side) as one library call per step — against the autograd step over the same batches handed to
+    models_attn.GAT as device-built batch graphs (hbm.ResidentGraph.train_graph -> GAT._forward_graph_input_side): the
+    first step's parameter gradients (all eight tensors), then the loss history and the trained parameters over several
+    steps with prefetch, hipGraph replay included"""
+    from gigl_amd.engine import GatNablpTrainPlan, HipEngine
+    from gigl_amd.hbm import ResidentGraph
+    from gigl_amd.models_attn import GAT
+    _, rowptr, col, x, n = setup
+    eng = HipEngine(0)
+    eng.load_csc(rowptr, col)
+    eng.load_features(torch.from_numpy(x).to(dtype))
+    dst = np.repeat(np.arange(n, dtype=np.uint32), np.diff(rowptr).astype(np.int64))
+    eng.build_from_coo(n, dst, col.astype(np.uint32), is_directed=True, out_graph=True)
+    fan, b, P, n_rn, steps, temp = [10, 5], 96, 1, 40, 6, 0.07
+    batches = _lp_batches(eng, n, b, P, n_rn, steps, seed=9)
+    torch.manual_seed(6)
+    kw = dict(num_layers=2, heads=heads, should_l2_normalize_embedding_layer_output=norm)
+    ref = GAT(100, hid, out, **kw).to(eng.device)
+    lib = GAT(100, hid, out, **kw).to(eng.device)
+    lib.load_state_dict(ref.state_dict())
+    ref.train()
+    ref.engine = eng
+    res = ResidentGraph.from_engine(eng, np.arange(n, dtype=np.int64), fan)
+    res.train_as_graph_data, res.defer_x = True, True
+    opt = torch.optim.Adam(ref.parameters(), lr=5e-3, weight_decay=1e-6)
+    want, first_grads = [], None
+    for roots, cnt, rn in batches:
+        embs = []
+        for r in (roots, rn):
+            g, ri = res.train_graph(r)
+            embs.append(ref(g)[ri])
+        loss = _lp_loss_torch(embs[0], embs[1], roots, cnt, rn, b, P, temp)
+        opt.zero_grad()
+        loss.backward()
+        if first_grads is None:
+            first_grads = [[c.lin.weight.grad.clone(), c.att_src.grad.reshape(-1).clone(), c.att_dst.grad.reshape(-1).clone(),
+                            c.bias.grad.clone()] for c in ref.conv_layers]
+        opt.step()
+        want.append(float(loss))
+    st = torch.cuda.Stream(device=eng.device)
+    torch.cuda.synchronize()
+    eng.bind_stream(st)
+    plan = GatNablpTrainPlan(eng, lib, b, P, n_rn, fan, temperature=temp, remove_accidental_hits=True, lr=5e-3, weight_decay=1e-6)
+    got = []
+    with torch.cuda.stream(st):
+        for i, (roots, cnt, rn) in enumerate(batches):
+            nxt = (batches[i + 1][0], batches[i + 1][2]) if i + 1 < steps and i != 2 else None
+            got.append(plan.step(roots, cnt, rn, next_roots=nxt).clone())
+            if i == 0:
+                grads = [plan.grads(l) for l in range(2)]
+    eng.synchronize()
+    errs = {}
+    for l in range(2):
+        for name, a, w_ in zip(("w", "att_src", "att_dst", "bias"), grads[l], first_grads[l]):
+            errs[f"layer {l} d {name}"] = float((a - w_).abs().max()) / (float(w_.abs().max()) + 1e-12)
+    got = [float(v[0]) for v in got]
+    print("GAT plan: first-step gradient errors (max |err| / max |grad|):", {k: f"{v:.2e}" for k, v in errs.items()},
+          "| loss", got[0], "vs", want[0])
+    assert max(errs.values()) < 2e-4 and abs(got[0] - want[0]) < 1e-4 * abs(want[0]), (errs, got[0], want[0])
+    plan.store(lib)
+    plan.close()
+    eng.bind_stream(torch.cuda.current_stream(eng.device))
+    np.testing.assert_allclose(got, want, rtol=1e-4 if norm else 1e-3, atol=1e-5)
+    for (k, a), (_, bb) in zip(lib.state_dict().items(), ref.state_dict().items()):
+        np.testing.assert_allclose(a.cpu().numpy(), bb.cpu().numpy(), rtol=5e-3, atol=6e-3, err_msg=k)
+    eng.close()
