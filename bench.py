@@ -958,6 +958,10 @@ def main():
                str(args.shard_plans), "--shard-scale", str(args.shard_scale), "--project-input", args.project_input,
                "--mode", args.mode] + (["--project-on-owner"] if args.project_on_owner else [])
         env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 17))
+        # (under torchrun the parents' rendezvous store belongs to the elastic agent — TORCHELASTIC_USE_AGENT_STORE — and
+        # nobody would host one on the children's port: without these variables the children's rank 0 hosts its own)
+        for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+            env.pop(k)
         sub_err = None
         try:
             cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit)

@@ -75,3 +75,23 @@ def test_a_failing_sharded_sub_record_never_costs_the_headline():
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["roofline"] is not None
     assert "did not finish" in line["sharded"]["error"]
     assert line["headline_is"].startswith("FALLBACK") and "replica per GPU" in line["config"]["graph"]
+
+
+@pytest.mark.gpu
+def test_under_torchrun_the_sharded_headline_rendezvous_works():
+    """the driver launches N > 1 as `python -m torch.distributed.run ... bench.py --gpus N`: the sharded workload's child
+    processes must host their own rendezvous store (torchrun's TORCHELASTIC_USE_AGENT_STORE would make them wait for an
+    agent store on their port until the time limit, and the line would fall back to the replica run)"""
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29671", BENCH, "--gpus", "2", "--small", "--no-cpu-baseline",
+                        "--min-seconds", "0.3", "--min-reps", "2", "--min-rounds", "2", "--group", "8", "--shard-group", "4",
+                        "--shard-scale", "0.0005", "--steps", "16", "--warmup", "8"],
+                       env=_env(GIGL_BENCH_SHARE_GPU="1", GIGL_BENCH_SUB_TIMEOUT="300"), capture_output=True, text=True,
+                       timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and "sharded" not in line, line.get("sharded")
+    assert "MAG240M-shaped" in line["config"]["workload"] and line["comm"]["ranks"] == 2
+    assert line["headline_is"].startswith("mag240m-sharded") and line["replicas"]["value"] > 0
