@@ -405,3 +405,65 @@ def test_library_gat_link_prediction_step_equals_the_autograd_step(setup, heads,
     for (k, a), (_, bb) in zip(lib.state_dict().items(), ref.state_dict().items()):
         np.testing.assert_allclose(a.cpu().numpy(), bb.cpu().numpy(), rtol=5e-3, atol=6e-3, err_msg=k)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_library_gat_link_prediction_step_against_the_cpu_restatement(setup):
+    """the GAT link-prediction step on the CPU: oracle sample -> collate -> fp32 GAT forward of both batches
+    (oracle/gnn_ref.gat_conv, every layer over the WHOLE union graph, projection first — the reference's execution order)
+    -> normalise -> scores -> retrieval loss -> torch autograd -> Adam; a short last batch is padded and masked.  The
+    library runs the first layer from the input side for the nodes of level <= 1 only: same function of the parameters."""
+    from gigl_amd.engine import GatNablpTrainPlan, HipEngine
+    from gigl_amd.models_attn import GAT
+    _, rowptr, col, x, n = setup
+    eng = HipEngine(0)
+    eng.load_csc(rowptr, col)
+    eng.load_features(x)
+    dst = np.repeat(np.arange(n, dtype=np.uint32), np.diff(rowptr).astype(np.int64))
+    eng.build_from_coo(n, dst, col.astype(np.uint32), is_directed=True, out_graph=True)
+    b, P, n_rn, fan, steps, temp, heads = 48, 1, 32, [10, 5], 4, 0.07, 2
+    batches = _lp_batches(eng, n, b, P, n_rn, steps, seed=13)
+    batches[-1] = (batches[-1][0][: 2 * 30].contiguous(), batches[-1][1][:30].contiguous(), batches[-1][2][:20].contiguous())
+    torch.manual_seed(8)
+    model = GAT(100, 16, 32, num_layers=2, heads=heads, should_l2_normalize_embedding_layer_output=True)
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    opt = torch.optim.Adam(list(params.values()), lr=5e-3, weight_decay=1e-6)
+    want = []
+    for roots, cnt, rn in batches:
+        embs = []
+        for r in (roots, rn):
+            r_h = r.cpu().numpy().view(np.uint32)
+            nbr, _ = oracle.sample_khop(rowptr, col, r_h, fan, canonical=True)
+            u = oracle.union_build(r_h, fan, nbr)
+            ei = gnn_ref.union_edge_index(u["rowptr"], u["col"])
+            h = torch.from_numpy(x[u["nodes"].astype(np.int64)])
+            for l, hd in enumerate((heads, 1)):
+                p = f"conv_layers.{l}."
+                h = gnn_ref.gat_conv(h, ei, params[p + "lin.weight"], params[p + "att_src"], params[p + "att_dst"],
+                                     params[p + "bias"], hd)
+                if l == 0:
+                    h = torch.relu(h)
+            h = torch.nn.functional.normalize(h, p=2, dim=1)
+            embs.append(h[torch.from_numpy(u["root_local"].astype(np.int64))])
+        loss = _lp_loss_torch(embs[0], embs[1], roots.cpu(), cnt.cpu(), rn.cpu(), cnt.numel(), P, temp)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        want.append(float(loss))
+    lib = GAT(100, 16, 32, num_layers=2, heads=heads, should_l2_normalize_embedding_layer_output=True).to(eng.device)
+    lib.load_state_dict(model.state_dict())
+    st = torch.cuda.Stream(device=eng.device)
+    torch.cuda.synchronize()
+    eng.bind_stream(st)
+    plan = GatNablpTrainPlan(eng, lib, b, P, n_rn, fan, temperature=temp, lr=5e-3, weight_decay=1e-6)
+    with torch.cuda.stream(st):
+        got = [plan.step(*bt).clone() for bt in batches]
+    eng.synchronize()
+    got = [float(v[0]) for v in got]
+    plan.store(lib)
+    plan.close()
+    print("GAT link-prediction plan vs the CPU restatement: losses", got, "vs", want)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+    for k, v in lib.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), params[k].detach().numpy(), rtol=5e-3, atol=6e-3, err_msg=k)
+    eng.close()
