@@ -3873,28 +3873,23 @@ int32_t gigl_gather_mean_backward(gigl_ctx* ctx, const float* dout, int32_t d, c
   return GIGL_OK;
 }
 
-int32_t gigl_gather_mean_backward_transposed(gigl_ctx* ctx, const float* dout, int32_t d, const int32_t* rowptr,
-                                             const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
-                                             int64_t rows_cap, const int32_t* n_src_dev, int64_t src_cap, int64_t edges_cap,
-                                             int32_t aggr, float* dsrc) {
+int64_t gigl_transposed_rows_words(int64_t src_cap, int64_t edges_cap) { return 3 * src_cap + edges_cap + 64; }
+
+int32_t gigl_transposed_rows_build(gigl_ctx* ctx, const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                   const int32_t* n_rows_dev, int64_t rows_cap, const int32_t* n_src_dev, int64_t src_cap,
+                                   int64_t edges_cap, int32_t* lists) {
   if (!ctx) return GIGL_E_INVALID_ARG;
-  GIGL_REQUIRE(ctx, dout && rowptr && rowend && col && n_rows_dev && n_src_dev && dsrc, "null argument");
-  GIGL_REQUIRE(ctx, d > 0 && (d & 3) == 0 && rows_cap >= 0 && src_cap >= rows_cap && edges_cap >= 0 &&
-                        src_cap < ((int64_t)1 << 31) && edges_cap < ((int64_t)1 << 31),
-               "bad sizes (d must be a multiple of 4)");
-  GIGL_REQUIRE(ctx, aggr == GIGL_AGGR_MEAN || aggr == GIGL_AGGR_SUM, "mean or sum");
+  GIGL_REQUIRE(ctx, rowptr && rowend && col && n_rows_dev && n_src_dev && lists, "null argument");
+  GIGL_REQUIRE(ctx, rows_cap >= 0 && src_cap >= rows_cap && edges_cap >= 0 && src_cap < ((int64_t)1 << 31) &&
+                        edges_cap < ((int64_t)1 << 31), "bad sizes");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (src_cap == 0) return GIGL_OK;
-  // scratch: cnt[src_cap] | fill[src_cap] | cursor (cleared together), ptr[src_cap], list[edges_cap]
-  const int64_t words = 3 * src_cap + edges_cap + 64;
-  int32_t rc = gigl_arena_reset(ctx, words * 4 + 1024);
-  if (rc != GIGL_OK) return rc;
-  int32_t* cnt = (int32_t*)gigl_arena_alloc(ctx, (2 * src_cap + 16) * 4);
-  int32_t* ptr = (int32_t*)gigl_arena_alloc(ctx, src_cap * 4);
-  int32_t* list = (int32_t*)gigl_arena_alloc(ctx, (edges_cap + 1) * 4);
-  if (!cnt || !ptr || !list) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  // lists: cnt[src_cap] | fill[src_cap] | cursor + pad (cleared together) | ptr[src_cap] | list[edges_cap]
+  int32_t* cnt = lists;
   int32_t* fill = cnt + src_cap;
   int32_t* cursor = cnt + 2 * src_cap;
+  int32_t* ptr = cnt + 2 * src_cap + 16;
+  int32_t* list = ptr + src_cap;
   hipStream_t st = ctx->stream;
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_BWD);
   gigl_fill_u32(st, (uint32_t*)cnt, 0u, 2 * src_cap + 1);
@@ -3908,6 +3903,24 @@ int32_t gigl_gather_mean_backward_transposed(gigl_ctx* ctx, const float* dout, i
     hipLaunchKernelGGL(gmt_fill_kernel, dim3((unsigned)wg), dim3(256), 0, st, rowptr, rowend, col, n_rows_dev,
                        (const int32_t*)ptr, fill, list);
   }
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_gather_mean_backward_lists(gigl_ctx* ctx, const float* dout, int32_t d, const int32_t* rowptr,
+                                        const int32_t* rowend, const int32_t* n_rows_dev, const int32_t* n_src_dev,
+                                        int64_t src_cap, const int32_t* lists, int32_t aggr, float* dsrc) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, dout && rowptr && rowend && n_rows_dev && n_src_dev && lists && dsrc, "null argument");
+  GIGL_REQUIRE(ctx, d > 0 && (d & 3) == 0 && src_cap >= 0 && src_cap < ((int64_t)1 << 31), "bad sizes (d must be a multiple of 4)");
+  GIGL_REQUIRE(ctx, aggr == GIGL_AGGR_MEAN || aggr == GIGL_AGGR_SUM, "mean or sum");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (src_cap == 0) return GIGL_OK;
+  const int32_t* cnt = lists;
+  const int32_t* ptr = lists + 2 * src_cap + 16;
+  const int32_t* list = ptr + src_cap;
+  hipStream_t st = ctx->stream;
+  gigl_prof_scope ps(ctx, GIGL_K_GATHER_BWD);
   const int mean = aggr == GIGL_AGGR_MEAN ? 1 : 0;
   const int lpr = d >= 256 ? 64 : (d >= 128 ? 32 : (d >= 64 ? 16 : 8));
   int64_t gg = (src_cap * lpr / 64 + 3) / 4;
@@ -3915,7 +3928,7 @@ int32_t gigl_gather_mean_backward_transposed(gigl_ctx* ctx, const float* dout, i
   if (gg < 1) gg = 1;
 #define GMT(L)                                                                                                          \
   hipLaunchKernelGGL(gmt_gather_kernel<L>, dim3((unsigned)gg), dim3(256), 0, st, dout, d, rowptr, rowend, n_rows_dev,   \
-                     n_src_dev, (const int32_t*)cnt, (const int32_t*)ptr, (const int32_t*)list, dsrc, mean)
+                     n_src_dev, cnt, ptr, list, dsrc, mean)
   if (lpr == 64) GMT(64);
   else if (lpr == 32) GMT(32);
   else if (lpr == 16) GMT(16);
@@ -3923,6 +3936,23 @@ int32_t gigl_gather_mean_backward_transposed(gigl_ctx* ctx, const float* dout, i
 #undef GMT
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
+}
+
+int32_t gigl_gather_mean_backward_transposed(gigl_ctx* ctx, const float* dout, int32_t d, const int32_t* rowptr,
+                                             const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
+                                             int64_t rows_cap, const int32_t* n_src_dev, int64_t src_cap, int64_t edges_cap,
+                                             int32_t aggr, float* dsrc) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, src_cap >= 0 && edges_cap >= 0, "bad sizes");
+  if (src_cap == 0) return GIGL_OK;
+  const int64_t words = gigl_transposed_rows_words(src_cap, edges_cap);
+  int32_t rc = gigl_arena_reset(ctx, words * 4 + 1024);
+  if (rc != GIGL_OK) return rc;
+  int32_t* lists = (int32_t*)gigl_arena_alloc(ctx, words * 4);
+  if (!lists) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  rc = gigl_transposed_rows_build(ctx, rowptr, rowend, col, n_rows_dev, rows_cap, n_src_dev, src_cap, edges_cap, lists);
+  if (rc != GIGL_OK) return rc;
+  return gigl_gather_mean_backward_lists(ctx, dout, d, rowptr, rowend, n_rows_dev, n_src_dev, src_cap, lists, aggr, dsrc);
 }
 
 int32_t gigl_gather_reduce_backward(gigl_ctx* ctx, const float* dout, int32_t d, const int32_t* rowptr,

@@ -1014,6 +1014,7 @@ struct gigl_sage_train_plan {
   float* h[GIGL_MAX_HOPS] = {nullptr};    // [rows_cap[l]][dims[l+1]]: its output (activated below the last layer)
   float* dh[GIGL_MAX_HOPS] = {nullptr};   // gradient of h[l]
   bool bwd_gather = false;                // layers >= 1 hand their input gradient down by the transposed gather
+  int32_t* tlists[TRAIN_WS][GIGL_MAX_HOPS] = {{nullptr}};  // its transposed lists per workspace and layer >= 1, built by the graph part
   float* da = nullptr;                    // [max rows_cap[l >= 1]][2 max dims]: gradient of a layer's operand
   float* wt = nullptr;                    // a layer's transposed weight
   float* gw[GIGL_MAX_HOPS] = {nullptr};
@@ -1037,7 +1038,13 @@ namespace {
 
 int32_t train_enqueue_graph(gigl_sage_train_plan* t, int k, int32_t sampling_seed, int32_t mode) {
   gigl_sage_plan* p = t->base[k];
-  return enqueue_range(p, 0, 2, p->roots_buf, sampling_seed, mode, nullptr);  // sample + union (+ the level guard)
+  int32_t rc = enqueue_range(p, 0, 2, p->roots_buf, sampling_seed, mode, nullptr);  // sample + union (+ the level guard)
+  // ... and who reads which source row in the backward of layers >= 1 (a function of the batch graph alone)
+  for (int l = 1; l < t->L && rc == GIGL_OK && t->bwd_gather; ++l)
+    rc = gigl_transposed_rows_build(p->ctx, p->un.rowptr, p->un.rowend, p->un.col, p->un.meta + GIGL_META_LEVEL0 + (t->L - 1 - l),
+                                    t->rows_cap[l], p->un.meta + GIGL_META_LEVEL0 + (t->L - l), t->rows_cap[l - 1],
+                                    p->un.cap_edges, t->tlists[k][l]);
+  return rc;
 }
 
 int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
@@ -1093,9 +1100,9 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
     rc = gigl_linear(ctx, t->dh[l], t->wt, nullptr, n_rows, t->rows_cap[l], n_out, 2 * d, 0, t->da);
     if (rc != GIGL_OK) return rc;
     if (t->bwd_gather)
-      rc = gigl_gather_mean_backward_transposed(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, t->rows_cap[l],
-                                                p->un.meta + GIGL_META_LEVEL0 + (L - l), t->rows_cap[l - 1], p->un.cap_edges,
-                                                GIGL_AGGR_MEAN, t->dh[l - 1]);
+      rc = gigl_gather_mean_backward_lists(ctx, t->da, d, p->un.rowptr, p->un.rowend, n_rows,
+                                           p->un.meta + GIGL_META_LEVEL0 + (L - l), t->rows_cap[l - 1], t->tlists[k][l],
+                                           GIGL_AGGR_MEAN, t->dh[l - 1]);
     else
       rc = gigl_gather_mean_backward(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, t->rows_cap[l], t->dh[l - 1]);
     if (rc != GIGL_OK) return rc;
@@ -1306,6 +1313,11 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
   }
   t->da = (float*)alloc(da_floats * 4);
   t->wt = (float*)alloc(wt_floats * 4);
+  for (int k = 0; k < TRAIN_WS && t->bwd_gather; ++k)
+    for (int l = 1; l < hops; ++l) {
+      t->tlists[k][l] = (int32_t*)alloc((size_t)gigl_transposed_rows_words(t->rows_cap[l - 1], t->base[k]->un.cap_edges) * 4);
+      ok = ok && t->tlists[k][l];
+    }
   t->labels_buf = (int64_t*)alloc((size_t)b * 8);
   t->n_valid_buf = (int32_t*)alloc(16);
   t->loss_rows = (float*)alloc((size_t)b * 4);
@@ -1451,11 +1463,13 @@ struct gigl_nablp_train_plan {
     bool warm_graph = false, warm_layers = false;
     hipEvent_t ev_graph = nullptr;   // end of the graph part last enqueued for this workspace
     hipEvent_t ev_layers = nullptr;  // end of the layers part that last read it
+    int32_t* tlists[2][GIGL_MAX_HOPS] = {{nullptr}};  // transposed lists of layers >= 1 per encode (SAGE; built by the graph part)
     const uint32_t *fetched_main = nullptr, *fetched_rn = nullptr;  // the caller's buffers its graph part ran for
     bool fetched = false;
   } work[WS];
   hipEvent_t ev_now = nullptr;  // "the caller's stream, now": the roots a graph part copies were written before it
   int cur = 0;
+  int cur_layers_ws = 0;  // the workspace the layers part being enqueued reads
   int32_t cap_seed = 0, cap_mode = -1;
 };
 
@@ -1799,9 +1813,9 @@ int32_t lp_backward(gigl_nablp_train_plan* t, int which) {
     rc = gigl_linear(ctx, e.dh[l], t->wt, nullptr, n_rows, e.rows_cap[l], n_out, 2 * d, 0, t->da);
     if (rc != GIGL_OK) return rc;
     if (t->bwd_gather)
-      rc = gigl_gather_mean_backward_transposed(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, e.rows_cap[l],
-                                                p->un.meta + GIGL_META_LEVEL0 + (L - l), e.rows_cap[l - 1], p->un.cap_edges,
-                                                GIGL_AGGR_MEAN, e.dh[l - 1]);
+      rc = gigl_gather_mean_backward_lists(ctx, t->da, d, p->un.rowptr, p->un.rowend, n_rows,
+                                           p->un.meta + GIGL_META_LEVEL0 + (L - l), e.rows_cap[l - 1],
+                                           t->work[t->cur_layers_ws].tlists[which][l], GIGL_AGGR_MEAN, e.dh[l - 1]);
     else
       rc = gigl_gather_mean_backward(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, e.rows_cap[l], e.dh[l - 1]);
     if (rc != GIGL_OK) return rc;
@@ -1819,7 +1833,12 @@ int32_t gat_lp_finish(gigl_nablp_train_plan* t);
 int32_t lp_enqueue_graph(gigl_nablp_train_plan* t, int w, int32_t sampling_seed, int32_t mode) {
   for (int k = 0; k < 2; ++k) {
     gigl_sage_plan* p = t->work[w].base[k];
-    const int32_t rc = enqueue_range(p, 0, 2, p->roots_buf, sampling_seed, mode, nullptr);
+    int32_t rc = enqueue_range(p, 0, 2, p->roots_buf, sampling_seed, mode, nullptr);
+    // (SAGE: who reads which source row in the backward of layers >= 1 — a function of the batch graph alone)
+    for (int l = 1; l < t->L && rc == GIGL_OK && t->kind == 0 && t->bwd_gather; ++l)
+      rc = gigl_transposed_rows_build(p->ctx, p->un.rowptr, p->un.rowend, p->un.col, p->un.meta + GIGL_META_LEVEL0 + (t->L - 1 - l),
+                                      t->enc[k].rows_cap[l], p->un.meta + GIGL_META_LEVEL0 + (t->L - l),
+                                      t->enc[k].rows_cap[l - 1], p->un.cap_edges, t->work[w].tlists[k][l]);
     if (rc != GIGL_OK) return rc;
   }
   return GIGL_OK;
@@ -1832,6 +1851,7 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
   const int L = t->L, d = t->dims[L], Q = t->b * t->P, Cn = Q + t->n_rn;
   int32_t rc = GIGL_OK;
   for (int k = 0; k < 2; ++k) t->enc[k].base = t->work[w].base[k];
+  t->cur_layers_ws = w;
   gigl_fill_u32(st, t->zero_base, 0u, (int64_t)(t->zero_bytes / 4));
   if (t->kind == 1) {
     rc = gat_lp_begin(t);
@@ -2041,6 +2061,13 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
       e.dh[l] = z;
       z += (size_t)e.rows_cap[l] * dims[l + 1];
     }
+  for (int wi = 0; wi < gigl_nablp_train_plan::WS && t->bwd_gather; ++wi)
+    for (int k = 0; k < 2; ++k)
+      for (int l = 1; l < hops; ++l) {
+        t->work[wi].tlists[k][l] = (int32_t*)alloc(
+            (size_t)gigl_transposed_rows_words(t->enc[k].rows_cap[l - 1], t->work[wi].base[k]->un.cap_edges) * 4);
+        ok = ok && t->work[wi].tlists[k][l];
+      }
   const size_t d = (size_t)dims[hops], Q = (size_t)b_anchors * num_positives, Cn = Q + (size_t)t->n_rn;
   for (int k = 0; k < 2; ++k) {
     gigl_nablp_train_plan::Enc& e = t->enc[k];

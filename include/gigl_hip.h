@@ -935,6 +935,16 @@ int32_t gigl_gather_mean_backward_transposed(gigl_ctx* ctx, const float* dout, i
                                              const int32_t* rowend, const int32_t* col, const int32_t* n_rows_dev,
                                              int64_t rows_cap, const int32_t* n_src_dev, int64_t src_cap,
                                              int64_t edges_cap, int32_t aggr, float* dsrc);
+/* ... in two halves: the transposed lists depend on the batch graph alone, so a training plan builds them beside the
+ * previous step's layers (with the sampling and the union build) and the backward only gathers.  `lists`: DEVICE int32
+ * [gigl_transposed_rows_words(src_cap, edges_cap)], written by _build, read by _lists. */
+int64_t gigl_transposed_rows_words(int64_t src_cap, int64_t edges_cap);
+int32_t gigl_transposed_rows_build(gigl_ctx* ctx, const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
+                                   const int32_t* n_rows_dev, int64_t rows_cap, const int32_t* n_src_dev, int64_t src_cap,
+                                   int64_t edges_cap, int32_t* lists);
+int32_t gigl_gather_mean_backward_lists(gigl_ctx* ctx, const float* dout, int32_t d, const int32_t* rowptr,
+                                        const int32_t* rowend, const int32_t* n_rows_dev, const int32_t* n_src_dev,
+                                        int64_t src_cap, const int32_t* lists, int32_t aggr, float* dsrc);
 
 /* weight gradient of gigl_linear (training: the backward of PyG's Linear inside SAGEConv, which torch autograd computes
  * as dy^T @ a): dw[n][k] += sum_{i < *m_dev} dy[i][n] a[i][k] and, when db != NULL, db[n] += sum_i dy[i][n] — the rows
