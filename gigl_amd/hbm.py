@@ -132,6 +132,11 @@ class HbmNablpBatch:
         return [Node(type="node", id=int(v)) for v in self.anchor_ids.tolist()]
 
 
+# graphs at most this large check every one-call plan's overflow flag synchronously and redo a failed call through the staged
+# launches (a host read per call is nothing next to a pass over so few nodes)
+SMALL_GRAPH_NODES = 1 << 18
+
+
 class ResidentGraph:
     """the job's graph + node features in HBM, with the plans that run batches over it.  One per process (rank)."""
 
@@ -408,12 +413,22 @@ class ResidentGraph:
                         out = torch.nn.functional.normalize(out, p=2, dim=1)  # (the encoder's last step: row-wise)
                 else:
                     out = plan.run(batch.roots, sampling_seed=self.seed, mode=self.mode)
-                    # a call whose union did not fit its workspace hands out NaN rows: every call's flag is added
-                    # into one device counter (no synchronisation here), read by raise_on_overflow()
-                    if self._overflow_acc is None:
-                        self._overflow_acc = torch.zeros(1, dtype=torch.int32, device=self.device)
-                    plan.overflow_add(self._overflow_acc)
-                return out if batch.valid is None else out.index_select(0, batch.valid)
+                    # a call whose union did not fit its workspace hands out NaN rows.  On a SMALL graph (roots are each
+                    # other's sampled neighbours all the time: whole leaf rows become inner rows) the flag is read here
+                    # and such a call is redone batch by batch through the staged launches below, whose buffers are
+                    # sized from the batch's counts; on a large graph every call's flag is added into one device
+                    # counter (no synchronisation here), read by raise_on_overflow()
+                    redo = False
+                    if self.n <= SMALL_GRAPH_NODES:
+                        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+                        plan.overflow_add(flag)
+                        redo = bool(int(flag.item()))
+                    else:
+                        if self._overflow_acc is None:
+                            self._overflow_acc = torch.zeros(1, dtype=torch.int32, device=self.device)
+                        plan.overflow_add(self._overflow_acc)
+                if self.sharded or not redo:
+                    return out if batch.valid is None else out.index_select(0, batch.valid)
             outs = []
             as_graph_data = self.sharded or not encoder_takes_hip_batches(model)
             if as_graph_data and getattr(model, "engine", None) is None:
