@@ -2983,14 +2983,18 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
     const int32_t* __restrict__ col, const int32_t* __restrict__ n_rows_dev, int heads, int C, int group,
     int rows_per_head, float slope, const float* __restrict__ out_pre, const float* __restrict__ dout,
     float* __restrict__ dh, float* __restrict__ d_src, float* __restrict__ d_dst, float* __restrict__ d_edge,
-    const float* __restrict__ edge_attr, int De, const float* __restrict__ umsg, float* __restrict__ zout) {
+    const float* __restrict__ edge_attr, int De, const float* __restrict__ umsg, float* __restrict__ zout, int wpr) {
+  // wpr waves share a destination row (a power of two; 1 with the message term): every wave of the row recomputes its
+  // scalars (pass 1 reads one float per edge), wave q takes the in-edges q, q + wpr, ... of pass 2 and wave 0 the self
+  // loop — a training batch's last layer has ~10^3 rows of ~25 edges, a wave per row leaves most of the GPU idle
   // message term (EdgeAttrGATConv, umsg != NULL): out_i also holds W_msg z_i with z_i = sum_e alpha_e e_e, so
   // d alpha_e gains <u_i, e_e> with u_i = W_msg^T g_i (umsg [rows][heads][De], dense, from the caller) and the kernel
   // returns z_i (zout, same shape) for d W_msg = sum_i g_i (x) z_i.  Component k of a head lives in lane k % group of
   // the head's lanes, register k / group (as in the forward).
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int waves_total = (gridDim.x * blockDim.x) >> 6;
+  const int gwave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int part = gwave & (wpr - 1), wave = gwave / wpr;
+  const int waves_total = ((gridDim.x * blockDim.x) >> 6) / wpr;
   const int n_rows = *n_rows_dev, HC = heads * C, chunks = HC >> 2;
   const int kl = lane & (group - 1);
   int hd[V];
@@ -3112,6 +3116,7 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       dpre_self[v] = al_self[v] * (dal[v] - S[v]) * (pre_self[v] > 0.f ? 1.f : slope);
+      if (part != 0) continue;  // (the self loop's contributions: the row's first wave)
       dd[v] += dpre_self[v];
       if (on[v]) {
         float* o = dh + (int64_t)i * HC + 4 * (v * 64 + lane);
@@ -3122,8 +3127,8 @@ __global__ __launch_bounds__(256) void gat_backward_kernel(
       }
       if (writer[v]) atomicAdd(d_src + (int64_t)i * heads + hd[v], dpre_self[v]);
     }
-    // pass 2: the in-edges
-    for (int e = 0; e < m; ++e) {
+    // pass 2: the in-edges (this wave's share)
+    for (int e = part; e < m; e += wpr) {
       const int j = col[e0 + e];
       if (j == i) continue;
       float4 x[V];
@@ -3833,16 +3838,20 @@ int32_t gigl_gat_aggregate_backward(gigl_ctx* ctx, const float* h, const float* 
   if (edge_attr && cap_edges > 0)
     hipLaunchKernelGGL(gat_edge_alpha_kernel, dim3((unsigned)((cap_edges * heads + 255) / 256)), dim3(256), 0,
                        ctx->stream, edge_attr, edge_dim, att_edge_folded, heads, cap_edges, a_edge);
-  int64_t ablocks = (nodes_cap + 3) / 4, gblocks = (rows_cap + 3) / 4;
+  // (few rows — the roots' layer of a training step — are shared by several waves each; not with the message term, whose
+  // z_out rows are written whole by one wave)
+  const int wpr = u_msg ? 1 : (rows_cap >= 32768 ? 1 : (rows_cap >= 8192 ? 2 : (rows_cap >= 2048 ? 4 : 8)));
+  int64_t ablocks = (nodes_cap + 3) / 4, gblocks = (rows_cap * wpr + 3) / 4;
   if (ablocks > 256 * 32) ablocks = 256 * 32;
   if (gblocks > 256 * 32) gblocks = 256 * 32;
+  gblocks = (gblocks + 1) & ~(int64_t)1;  // (whole rows per launch: 4 waves per workgroup, wpr <= 8)
 #define GAT_BWD(VV)                                                                                                  \
   hipLaunchKernelGGL((gat_alpha_fast_kernel<VV>), dim3((unsigned)ablocks), dim3(256), 0, ctx->stream, h, att_src,   \
                      att_dst, n_nodes_dev, heads, channels, g.group, g.rows_per_head, a_src, a_dst);                \
   hipLaunchKernelGGL((gat_backward_kernel<VV>), dim3((unsigned)gblocks), dim3(256), 0, ctx->stream, h, a_src, a_dst, \
                      a_edge, rowptr, rowend, col, n_rows_dev, heads, channels, g.group, g.rows_per_head,            \
                      negative_slope, out_pre, dout, dh, d_alpha_src, d_alpha_dst, d_alpha_edge, edge_attr, edge_dim,  \
-                     u_msg, z_out)
+                     u_msg, z_out, wpr)
   if (g.V == 1) {
     GAT_BWD(1);
   } else if (g.V == 2) {
