@@ -1042,13 +1042,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ONE || (HS
                                                            const float* __restrict__ self_src = nullptr,
                                                            const uint32_t* __restrict__ self_ids = nullptr,
                                                            int d_mean = 0, int self_ld = 0,
-                                                           const float* __restrict__ hs_scale = nullptr) {
-  // (grid.y = batch of independent products sharing M/K/N: operand b of a / w is a_bstride / w_bstride floats on, its
-  // bias and its N output columns follow the previous batch's)
-  a += blockIdx.y * a_bstride;
-  w += blockIdx.y * w_bstride;
-  if (bias) bias += blockIdx.y * N;
-  y += blockIdx.y * N;
+                                                           const float* __restrict__ hs_scale = nullptr,
+                                                           const gigl_linear_group* __restrict__ groups = nullptr) {
+  // (grid.y = batch of independent products sharing K/N: operand b of a / w is a_bstride / w_bstride floats on, its
+  // bias and its N output columns follow the previous batch's — or, `groups`: every product names its own operands, row
+  // count and output rows: gigl_linear_grouped)
+  if (groups) {
+    const gigl_linear_group g = groups[blockIdx.y];
+    a = g.a;
+    w = g.w;
+    bias = g.bias;
+    m_dev = g.m_dev;
+    y = g.y;
+  } else {
+    a += blockIdx.y * a_bstride;
+    w += blockIdx.y * w_bstride;
+    if (bias) bias += blockIdx.y * N;
+    y += blockIdx.y * N;
+  }
   constexpr int BK = 32, LDK = 32;          // bf16 elements per LDS row (swizzled slots, no padding: split_lds_off)
   constexpr int BM = 128, BN = 64 * NJ;
   constexpr int NPA = HS ? (AHALF ? 1 : 2) : 3, NPW = HS ? 2 : 3;  // planes per operand
@@ -3840,7 +3851,8 @@ int32_t gigl_gat_aggregate_backward(gigl_ctx* ctx, const float* h, const float* 
                        ctx->stream, edge_attr, edge_dim, att_edge_folded, heads, cap_edges, a_edge);
   // (few rows — the roots' layer of a training step — are shared by several waves each; not with the message term, whose
   // z_out rows are written whole by one wave)
-  const int wpr = u_msg ? 1 : (rows_cap >= 32768 ? 1 : (rows_cap >= 8192 ? 2 : (rows_cap >= 2048 ? 4 : 8)));
+  static const bool one_wave = getenv("GIGL_GAT_BWD_ONE_WAVE") != nullptr;  // (A/B knob: a wave per row, as before round 5)
+  const int wpr = (u_msg || one_wave) ? 1 : (rows_cap >= 32768 ? 1 : (rows_cap >= 8192 ? 2 : (rows_cap >= 2048 ? 4 : 8)));
   int64_t ablocks = (nodes_cap + 3) / 4, gblocks = (rows_cap * wpr + 3) / 4;
   if (ablocks > 256 * 32) ablocks = 256 * 32;
   if (gblocks > 256 * 32) gblocks = 256 * 32;
@@ -4386,6 +4398,33 @@ int32_t gigl_linear_batched(gigl_ctx* ctx, const float* a, const float* w, const
   else
     hipLaunchKernelGGL((linear_split_kernel<1, true>), dim3((unsigned)(bm * ((n + 63) / 64)), (unsigned)batch),
                        dim3(256), 0, ctx->stream, a, w, bias, m_dev, k, n, act, y, 0, ldy, a_bstride, w_bstride);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_linear_grouped(gigl_ctx* ctx, const gigl_linear_group* groups_dev, int32_t n_groups, int64_t m_cap_max,
+                            int32_t k, int32_t n, int32_t act) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, groups_dev || n_groups == 0, "null argument");
+  GIGL_REQUIRE(ctx, k > 0 && (k & 3) == 0 && n > 0 && m_cap_max >= 0 && n_groups >= 0 && n_groups <= 65535,
+               "bad sizes (k=%d n=%d groups=%d)", k, n, n_groups);
+  GIGL_REQUIRE(ctx, act == 0 || act == 1, "bad act %d", act);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (m_cap_max == 0 || n_groups == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
+  const int64_t bm = (m_cap_max + 127) / 128;
+  const float* none = nullptr;
+  const int32_t* none_i = nullptr;
+  float* none_y = nullptr;
+  const uint32_t* none_u = nullptr;
+  if (n > 64)
+    hipLaunchKernelGGL((linear_split_kernel<2, true>), dim3((unsigned)(bm * ((n + 127) / 128)), (unsigned)n_groups),
+                       dim3(256), 0, ctx->stream, none, none, none, none_i, k, n, act, none_y, 0, n, (int64_t)0, (int64_t)0, none,
+                       none_u, 0, 0, none, groups_dev);
+  else
+    hipLaunchKernelGGL((linear_split_kernel<1, true>), dim3((unsigned)(bm * ((n + 63) / 64)), (unsigned)n_groups),
+                       dim3(256), 0, ctx->stream, none, none, none, none_i, k, n, act, none_y, 0, n, (int64_t)0, (int64_t)0, none,
+                       none_u, 0, 0, none, groups_dev);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

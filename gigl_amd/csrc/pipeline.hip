@@ -2291,11 +2291,11 @@ __global__ __launch_bounds__(256) void gat_add_bias_kernel(const float* __restri
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = x[i] + (bias ? bias[i % C] : 0.f);
 }
-// gb[c] += sum over the rows i < *n_rows of dy[i][c]: 64 rows per workgroup, one atomic per (workgroup, column)
+// gb[c] += sum over the rows i < *n_rows of dy[i][c]: 8 rows per workgroup, one atomic per (workgroup, column)
 __global__ __launch_bounds__(256) void gat_bias_grad_kernel(const float* __restrict__ dy, const int32_t* __restrict__ n_rows_dev,
                                                             int C, float* __restrict__ gb) {
   const int n = *n_rows_dev;
-  const int r0 = blockIdx.x * 64, r1 = r0 + 64 < n ? r0 + 64 : n;
+  const int r0 = blockIdx.x * 8, r1 = r0 + 8 < n ? r0 + 8 : n;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float acc = 0.f;
     for (int r = r0; r < r1; ++r) acc += dy[(int64_t)r * C + c];
@@ -2363,7 +2363,7 @@ int32_t gat_lp_backward(gigl_nablp_train_plan* t, int which) {
   (void)gad0;
   // ---- second layer (the roots' rows): e.dh[1] = d loss / d (out before the bias)
   if (g.bias[1])
-    hipLaunchKernelGGL(gat_bias_grad_kernel, dim3((unsigned)((e.rows_cap[1] + 63) / 64)), dim3(256), 0, st, (const float*)e.dh[1],
+    hipLaunchKernelGGL(gat_bias_grad_kernel, dim3((unsigned)((e.rows_cap[1] + 7) / 8)), dim3(256), 0, st, (const float*)e.dh[1],
                        n0, C1, gb1);
   gigl_fill_u32(st, g.dxw, 0u, rows1 * C1);
   gigl_fill_u32(st, g.ds, 0u, g.dd - g.ds + rows1);  // (ds | dd: dd starts where the larger encode's ds ends)

@@ -968,6 +968,20 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
 int32_t gigl_linear_batched(gigl_ctx* ctx, const float* a, const float* w, const float* bias, const int32_t* m_dev,
                             int64_t m_cap, int32_t k, int32_t n, int32_t act, int32_t batch, int64_t a_bstride,
                             int64_t w_bstride, int32_t ldy, float* y);
+/* `n_groups` independent products of equal K / N in one launch, every one with its OWN operands, row count and output
+ * rows (row-major, n floats apart): the per-node-type / per-edge-type projections of a typed layer (HGTConv's k_lin /
+ * q_lin / v_lin / a_lin ModuleDicts, python/gigl/src/common/models/pyg/heterogeneous.py:18-120 — one torch Linear call per
+ * type in the reference, one launch per type here before).  groups_dev: DEVICE array; m_cap_max >= every group's row
+ * capacity.  Same kernel and summation order as gigl_linear on each product (k % 4 == 0). */
+typedef struct gigl_linear_group {
+  const float* a;       /* [m][k] */
+  const float* w;       /* [n][k] */
+  const float* bias;    /* [n] or NULL */
+  const int32_t* m_dev; /* DEVICE row count */
+  float* y;             /* [m][n] */
+} gigl_linear_group;
+int32_t gigl_linear_grouped(gigl_ctx* ctx, const gigl_linear_group* groups_dev, int32_t n_groups, int64_t m_cap_max,
+                            int32_t k, int32_t n, int32_t act);
 
 /* ---- retrieval loss of the link-prediction head, fused (temperature -> sampling-probability correction -> duplicate
  *      / accidental-hit masking -> log-softmax -> cross-entropy against the diagonal, one pass over the scores).
