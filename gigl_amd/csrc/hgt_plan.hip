@@ -59,6 +59,14 @@ struct gigl_hgt_infer {
   bool use_graph = true;
   int32_t cap_b = -1;
   uint64_t cap_arena_gen = 0, cap_side_gen = 0;
+  // the layers' per-type / per-slot projections as grouped launches (gigl_linear_grouped): device descriptor table, and per
+  // workspace and layer where its K|V, Q and output groups sit in it (GIGL_HGT_NO_GROUPED=1: one launch per product, A/B)
+  gigl_linear_group* groups_dev = nullptr;
+  struct GroupRange {
+    int kv_off = 0, kv_n = 0, q_off = 0, q_n = 0, o_off = 0, o_n = 0;
+    int64_t kv_cap = 0, q_cap = 0;
+  } gr[2][GIGL_HGT_MAX_LAYERS];
+  bool grouped = false;
   std::vector<void*> owned;
 };
 
@@ -144,6 +152,51 @@ int32_t dev_alloc(gigl_hgt_infer* p, T** out, int64_t count) {
   return GIGL_OK;
 }
 
+// the descriptor table of the layers' grouped projections (after create and after every set_model: weight pointers)
+int32_t hgt_build_groups(gigl_hgt_infer* p) {
+  const gigl_hgt_model& m = p->m;
+  const int64_t Fo = m.hid;
+  const int L = m.n_layers;
+  std::vector<gigl_linear_group> g;
+  for (int k = 0; k < 2; ++k) {
+    const gigl_typed_plan_out& po = p->po[k];
+    for (int l = 0; l < L; ++l) {
+      const gigl_hgt_layer_weights& lw = m.layer[l];
+      const bool last = l == L - 1;
+      const float* h = p->h[l & 1];
+      float* hn = p->h[(l + 1) & 1];
+      gigl_hgt_infer::GroupRange& r = p->gr[k][l];
+      r = gigl_hgt_infer::GroupRange();
+      r.kv_off = (int)g.size();
+      for (int s = 0; s < m.n_slots; ++s) {
+        if (last && p->slot_dst_j[s] != p->root_j) continue;
+        const int sj = p->slot_src_j[s];
+        const int32_t* n_dev = po.n_nodes + m.type_order[sj];
+        const float* x = h + p->dst_off[sj] * Fo;
+        g.push_back(gigl_linear_group{x, lw.wk[s], lw.bk[s], n_dev, p->ks + p->src_off[s] * Fo});
+        g.push_back(gigl_linear_group{x, lw.wv[s], lw.bv[s], n_dev, p->vs + p->src_off[s] * Fo});
+        if (p->cap[sj] > r.kv_cap) r.kv_cap = p->cap[sj];
+      }
+      r.kv_n = (int)g.size() - r.kv_off;
+      if (last) continue;
+      r.q_off = (int)g.size();
+      for (int j = 0; j < m.n_types; ++j) {
+        g.push_back(gigl_linear_group{h + p->dst_off[j] * Fo, lw.wq[j], lw.bq[j], po.n_nodes + m.type_order[j],
+                                      p->qq + p->dst_off[j] * Fo});
+        if (p->cap[j] > r.q_cap) r.q_cap = p->cap[j];
+      }
+      r.q_n = (int)g.size() - r.q_off;
+      r.o_off = (int)g.size();
+      for (int j = 0; j < m.n_types; ++j)
+        g.push_back(gigl_linear_group{p->agg + p->dst_off[j] * Fo, lw.wout[j], lw.bout[j], po.n_nodes + m.type_order[j],
+                                      hn + p->dst_off[j] * Fo});
+      r.o_n = (int)g.size() - r.o_off;
+    }
+  }
+  GIGL_HIP_CHECK(p->ctx, hipMemcpy(p->groups_dev, g.data(), g.size() * sizeof(gigl_linear_group), hipMemcpyHostToDevice));
+  return GIGL_OK;
+}
+
 // GRAPH part of workspace k (side stream): the ops, the numbering, the merged CSR at capacity prefixes
 int32_t hgt_graph_part(gigl_hgt_infer* p, int k, int32_t b) {
   const gigl_hgt_model& m = p->m;
@@ -188,8 +241,13 @@ int32_t hgt_layers_part(gigl_hgt_infer* p, int k, int32_t b) {
   for (int l = 0; l < L; ++l) {
     const gigl_hgt_layer_weights& lw = m.layer[l];
     const bool last = l == L - 1;
+    const gigl_hgt_infer::GroupRange& gr = p->gr[k][l];
     // K / V blocks of the slots this layer reads (the last layer computes the roots' rows: only edges INTO their type)
-    for (int s = 0; s < m.n_slots; ++s) {
+    if (p->grouped) {
+      rc = gigl_linear_grouped(ctx, p->groups_dev + gr.kv_off, gr.kv_n, gr.kv_cap, Fo, Fo, 0);
+      if (rc != GIGL_OK) return rc;
+    }
+    for (int s = 0; s < m.n_slots && !p->grouped; ++s) {
       if (last && p->slot_dst_j[s] != p->root_j) continue;
       const int sj = p->slot_src_j[s];
       const int32_t* n_dev = po.n_nodes + m.type_order[sj];
@@ -199,7 +257,11 @@ int32_t hgt_layers_part(gigl_hgt_infer* p, int k, int32_t b) {
       if (rc != GIGL_OK) return rc;
     }
     if (!last) {
-      for (int j = 0; j < m.n_types; ++j) {
+      if (p->grouped) {
+        rc = gigl_linear_grouped(ctx, p->groups_dev + gr.q_off, gr.q_n, gr.q_cap, Fo, Fo, 0);
+        if (rc != GIGL_OK) return rc;
+      }
+      for (int j = 0; j < m.n_types && !p->grouped; ++j) {
         rc = gigl_linear(ctx, h + p->dst_off[j] * Fo, lw.wq[j], lw.bq[j], po.n_nodes + m.type_order[j], p->cap[j], Fo, Fo, 0,
                          p->qq + p->dst_off[j] * Fo);
         if (rc != GIGL_OK) return rc;
@@ -207,11 +269,17 @@ int32_t hgt_layers_part(gigl_hgt_infer* p, int k, int32_t b) {
       rc = gigl_hgt_aggregate_act(ctx, p->qq, p->ks, p->vs, H, D, csr.rowptr, csr.col, csr.etype, lw.p_rel, p->rows_cap, 1,
                                   p->agg);
       if (rc != GIGL_OK) return rc;
+      if (p->grouped) {
+        rc = gigl_linear_grouped(ctx, p->groups_dev + gr.o_off, gr.o_n, gr.q_cap, Fo, Fo, 0);
+        if (rc != GIGL_OK) return rc;
+      }
       for (int j = 0; j < m.n_types; ++j) {
         const int32_t* n_dev = po.n_nodes + m.type_order[j];
         float* o = hn + p->dst_off[j] * Fo;
-        rc = gigl_linear(ctx, p->agg + p->dst_off[j] * Fo, lw.wout[j], lw.bout[j], n_dev, p->cap[j], Fo, Fo, 0, o);
-        if (rc != GIGL_OK) return rc;
+        if (!p->grouped) {
+          rc = gigl_linear(ctx, p->agg + p->dst_off[j] * Fo, lw.wout[j], lw.bout[j], n_dev, p->cap[j], Fo, Fo, 0, o);
+          if (rc != GIGL_OK) return rc;
+        }
         if (lw.keep[j])
           hipLaunchKernelGGL(hgt_skip_kernel, grid_of(p->cap[j] * (Fo / 4)), dim3(TB), 0, st, o, h + p->dst_off[j] * Fo,
                              lw.keep[j], n_dev, p->cap[j], Fo);
@@ -340,6 +408,7 @@ int32_t gigl_hgt_infer_set_model(gigl_hgt_infer* p, const gigl_hgt_model* model)
     GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     hgt_drop_graphs(p, false, true);  // (the GRAPH parts read no weight)
     p->m = *model;
+    if (p->grouped) return hgt_build_groups(p);
   }
   return GIGL_OK;
 }
@@ -440,7 +509,16 @@ int32_t gigl_hgt_infer_create(gigl_ctx* ctx, gigl_typed_plan* plan, int32_t b_ma
   HGT_ALLOC(p->roots[1], b_max);
   HGT_ALLOC(p->out, (int64_t)b_max * m.out_dim);
   HGT_ALLOC(p->b_dev, 8);
+  HGT_ALLOC(p->groups_dev, (int64_t)2 * m.n_layers * (2 * m.n_slots + 2 * m.n_types));
 #undef HGT_ALLOC
+  p->grouped = (Fo & 3) == 0 && getenv("GIGL_HGT_NO_GROUPED") == nullptr;
+  if (p->grouped) {
+    rc = hgt_build_groups(p);
+    if (rc != GIGL_OK) {
+      gigl_hgt_infer_destroy(p);
+      return rc;
+    }
+  }
   // (both workspaces start free)
   for (int k = 0; k < 2; ++k) GIGL_HIP_CHECK(ctx, hipEventRecord(p->ev_layers[k], ctx->stream));
   *out = p;
