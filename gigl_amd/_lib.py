@@ -33,7 +33,7 @@ SYMBOLS = [
     "gigl_profile_enable", "gigl_profile_read", "gigl_profile_reset",
     "gigl_sage_plan_create", "gigl_sage_plan_set_weights", "gigl_sage_plan_buffers", "gigl_sage_plan_run",
     "gigl_sage_plan_destroy", "gigl_gather_mean_backward", "gigl_gather_mean_backward_transposed", "gigl_transposed_rows_words", "gigl_transposed_rows_build",
-    "gigl_gather_mean_backward_lists", "gigl_expand_frontier", "gigl_gcn_aggregate",
+    "gigl_gather_mean_backward_lists", "gigl_linear_grouped", "gigl_expand_frontier", "gigl_gcn_aggregate",
     "gigl_gat_aggregate", "gigl_gather_rows", "gigl_sage_plan_use_graph", "gigl_sage_plan_flush_profile",
     "gigl_union_build_groups", "gigl_sage_plan_set_groups", "gigl_records_capacity", "gigl_records_encode",
     "gigl_tfrecord_index", "gigl_tfexample_decode", "gigl_collate_records", "gigl_collated_info", "gigl_collated_copy",
@@ -331,6 +331,7 @@ def load() -> C.CDLL:
         "gigl_gather_mean_backward_transposed": [vp, vp, i32, vp, vp, vp, vp, i64, vp, i64, i64, i32, vp],
         "gigl_transposed_rows_build": [vp, vp, vp, vp, vp, i64, vp, i64, i64, vp],
         "gigl_gather_mean_backward_lists": [vp, vp, i32, vp, vp, vp, vp, i64, vp, i32, vp],
+        "gigl_linear_grouped": [vp, vp, i32, i64, i32, i32, i32],
         "gigl_expand_frontier": [vp, vp, vp, vp, i64, i32, i32, i32, i64, vp, vp],
         "gigl_gather_rows": [vp, vp, i32, i32, vp, vp, i64, vp],
         "gigl_frontier_bucket": [vp, vp, vp, i64, i32, i64, vp, vp, vp],
