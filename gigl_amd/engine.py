@@ -976,6 +976,21 @@ class HipEngine:
                                                     rows_cap, _lib.AGGR[aggr], sp, C.c_void_p(dsrc.data_ptr())),
               self._ctx)
 
+    def linear_grouped(self, groups, k: int, n: int, act: int = 0) -> None:
+        """groups: [(a [m_cap, k], w [n, k], bias [n] | None, m_dev int32 [1], y [m_cap, n])] of device fp32 tensors — every
+        product y = act(a w^T + bias) over its first *m_dev rows, all in ONE launch (gigl_linear_grouped)"""
+        import struct
+        blob, cap = b"", 0
+        for a, w, bias, m_dev, y in groups:
+            assert a.is_contiguous() and w.is_contiguous() and y.is_contiguous() and a.shape[1] == k and tuple(w.shape) == (n, k)
+            blob += struct.pack("<5Q", a.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else 0, m_dev.data_ptr(),
+                                y.data_ptr())
+            cap = max(cap, int(a.shape[0]))
+        table = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
+        check(self._lib.gigl_linear_grouped(self._ctx, C.c_void_p(table.data_ptr()), len(groups), cap, int(k), int(n), int(act)),
+              self._ctx)
+        self._keep_groups = table  # (read by the launch: kept until the next call)
+
     def gather_mean_backward_transposed(self, dout: torch.Tensor, d: int, rowptr: torch.Tensor, rowend: Optional[torch.Tensor],
                                         col: torch.Tensor, n_rows_dev: torch.Tensor, rows_cap: int, n_src_dev: torch.Tensor,
                                         dsrc: torch.Tensor, edges_cap: Optional[int] = None, aggr: str = "mean") -> None:

@@ -466,3 +466,34 @@ def test_one_call_typed_inference_step_equals_the_staged_forward(layers, l2):
     np.testing.assert_allclose(one_call(pools[3]), staged(pools[3]), rtol=2e-5, atol=2e-5)
     plan.close()
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n", [(64, 64), (128, 128), (64, 200)])
+def test_grouped_projection_launch_equals_the_single_launches(k, n):
+    """gigl_linear_grouped (the typed layers' per-type / per-slot projections behind one grid) against gigl_linear on every
+    product: bit-identical rows (same kernel, same summation order), rows past a group's device count untouched, groups of
+    very different row counts, one without a bias, one empty"""
+    from gigl_amd.engine import HipEngine
+    eng = HipEngine(0)
+    st = torch.cuda.Stream()
+    eng.bind_stream(st)
+    dev = eng.device
+    g = torch.Generator(device="cpu").manual_seed(k + n)
+    caps, ms = [700, 130, 5000, 64, 256], [651, 130, 4097, 0, 1]
+    groups, want = [], []
+    with torch.cuda.stream(st):
+        for i, (cap, m) in enumerate(zip(caps, ms)):
+            a = torch.randn((cap, k), generator=g).to(dev)
+            w = (torch.randn((n, k), generator=g) / 8).to(dev)
+            bias = None if i == 1 else torch.randn(n, generator=g).to(dev)
+            m_dev = torch.tensor([m], dtype=torch.int32, device=dev)
+            y = torch.full((cap, n), 7.0, device=dev)
+            groups.append((a, w, bias, m_dev, y))
+            want.append(eng.linear(a, w, bias, m_dev, cap, act=1, out=torch.full((cap, n), 7.0, device=dev)))
+        eng.linear_grouped(groups, k, n, act=1)
+    st.synchronize()
+    for (a, w, bias, m_dev, y), ref, m in zip(groups, want, ms):
+        assert torch.equal(y[:m], ref[:m])
+        assert bool((y[m:] == 7.0).all())
+    eng.close()
