@@ -288,11 +288,45 @@ __device__ __forceinline__ uint32_t edge_first(const RecArgs& a, const Plan& pl,
   }
 }
 
-// builds the plan of record r (the 64 lanes of one wave)
+// barrier + scan of the NT threads that build one record's plan: NT = 64 the lanes of one wave (nothing but wave-local
+// ordering), NT = 256 a whole workgroup (s_w: 8 x uint64 of LDS for the waves' totals)
+template <int NT>
+__device__ __forceinline__ void grp_sync() {
+  if constexpr (NT == 64) grp_sync<NT>();
+  else __syncthreads();
+}
+template <int NT>
+__device__ __forceinline__ unsigned long long grp_exscan64(unsigned long long v, unsigned long long& total,
+                                                           unsigned long long* s_w) {
+  unsigned long long wt;
+  const unsigned long long ex = wave_exscan64(v, wt);
+  if constexpr (NT == 64) {
+    total = wt;
+    return ex;
+  } else {
+    const int w = threadIdx.x >> 6;
+    __syncthreads();  // (s_w may still be read from the previous scan)
+    if ((threadIdx.x & 63) == 0) s_w[w] = wt;
+    __syncthreads();
+    unsigned long long base = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < NT / 64; ++q) {
+      const unsigned long long x = s_w[q];
+      if (q < w) base += x;
+      all += x;
+    }
+    total = all;
+    return base + ex;
+  }
+}
+
+// builds the plan of record r: the 64 lanes of one wave (NT = 64), or a workgroup of 256 threads (NT = 256: the same phases
+// with a position or two per thread instead of five per lane — a record's chain of dependent steps gets that much shorter)
+template <int NT>
 __device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int64_t r, Plan& pl,
-                                                          const uint32_t* row_crc) {
+                                                          const uint32_t* row_crc, unsigned long long* s_w = nullptr) {
   const uint32_t n_s = (uint32_t)(a.trees * a.tree_len), n_e = (uint32_t)(a.trees * a.edge_len);
-  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t lane = NT == 64 ? (threadIdx.x & 63) : threadIdx.x;
   // the stream, tree by tree: one (uniform) root load, then every slot load is independent of the others
   for (int tt = 0; tt < a.trees; ++tt) {
     const int64_t t = r * a.trees + tt;
@@ -302,16 +336,16 @@ __device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int6
     for (int k = 0; k < a.hops; ++k) {
       const uint32_t sl = (uint32_t)a.slots[k];
       const uint32_t* src = a.nbr[k] + t * sl;
-      for (uint32_t i = lane; i < sl; i += 64) t_ids[base + i] = root == NONE ? NONE : src[i];
+      for (uint32_t i = lane; i < sl; i += NT) t_ids[base + i] = root == NONE ? NONE : src[i];
       base += sl;
     }
     if (lane == 0) t_ids[base] = root;
   }
-  for (uint32_t i = lane; i < a.hash_cap; i += 64) pl.hslot[i] = NONE;
-  for (uint32_t i = lane; i < a.ehash_cap; i += 64) pl.eslot[i] = NONE;
-  wave_sync();
+  for (uint32_t i = lane; i < a.hash_cap; i += NT) pl.hslot[i] = NONE;
+  for (uint32_t i = lane; i < a.ehash_cap; i += NT) pl.eslot[i] = NONE;
+  grp_sync<NT>();
   // first occurrence of every id in stream order
-  for (uint32_t q = lane; q < n_s; q += 64) {
+  for (uint32_t q = lane; q < n_s; q += NT) {
     const uint32_t id = pl.ids[q];
     if (id == NONE) continue;
     uint32_t h = hash32(id) & (a.hash_cap - 1);
@@ -326,7 +360,7 @@ __device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int6
     }
   }
   if (a.ehash_cap) {
-    for (uint32_t q = lane; q < n_e; q += 64) {
+    for (uint32_t q = lane; q < n_e; q += NT) {
       uint32_t s, d;
       plan_edge(a, pl.ids, q, s, d);
       if (s == NONE) continue;
@@ -344,18 +378,18 @@ __device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int6
       }
     }
   }
-  wave_sync();
+  grp_sync<NT>();
   // nodes: field sizes of first occurrences, scanned in stream order (a lane owns a contiguous run); bytes in the
   // low word, count in the high word of one 64-bit scan
   {
-    const uint32_t per = (n_s + 63) / 64, lo = min(lane * per, n_s), hi = min(lo + per, n_s);
+    const uint32_t per = (n_s + NT - 1) / NT, lo = min(lane * per, n_s), hi = min(lo + per, n_s);
     unsigned long long mine = 0;
     for (uint32_t q = lo; q < hi; ++q) {
       const uint32_t id = pl.ids[q];
       if (id != NONE && node_first(a, pl, id) == q) mine += (1ull << 32) | field_len(node_body_len(a, id));
     }
     unsigned long long tot;
-    const unsigned long long off = wave_exscan64(mine, tot);
+    const unsigned long long off = grp_exscan64<NT>(mine, tot, s_w);
     uint32_t off_b = (uint32_t)off, off_c = 1u + (uint32_t)(off >> 32);
     for (uint32_t q = lo; q < hi; ++q) {
       const uint32_t id = pl.ids[q];
@@ -376,7 +410,7 @@ __device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int6
   }
   // edges
   {
-    const uint32_t per = (n_e + 63) / 64, lo = min(lane * per, n_e), hi = min(lo + per, n_e);
+    const uint32_t per = (n_e + NT - 1) / NT, lo = min(lane * per, n_e), hi = min(lo + per, n_e);
     unsigned long long bytes = 0;
     for (uint32_t q = lo; q < hi; ++q) {
       uint32_t s, d;
@@ -388,7 +422,7 @@ __device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int6
       if (first) bytes += sz;
     }
     unsigned long long tot;
-    uint32_t off_b = (uint32_t)wave_exscan64(bytes, tot);
+    uint32_t off_b = (uint32_t)grp_exscan64<NT>(bytes, tot, s_w);
     for (uint32_t q = lo; q < hi; ++q) {
       const uint32_t sz = pl.edge_off[q];
       if (sz != NONE) {
@@ -398,14 +432,14 @@ __device__ __attribute__((always_inline)) void build_plan(const RecArgs& a, int6
     }
     pl.edges_bytes = (uint32_t)tot;
   }
-  wave_sync();
+  grp_sync<NT>();
   // the rows' tabulated CRC states: independent loads, one round trip for the whole record
   if (row_crc)
-    for (uint32_t i = lane; i <= pl.n_uniq; i += 64) {
+    for (uint32_t i = lane; i <= pl.n_uniq; i += NT) {
       const uint32_t id = pl.uid[i];
       pl.rc[i] = (int64_t)id < a.feat_n ? row_crc[id] : 0u;
     }
-  wave_sync();
+  grp_sync<NT>();
 }
 
 // sizes of the fixed parts of record r (uniform over the workgroup)
@@ -435,15 +469,15 @@ extern __shared__ __align__(16) unsigned char s_dyn[];
 
 // exclusive scan of the record sizes (one workgroup, 8 consecutive sizes per thread and round); status = 1 when the
 // output does not fit
-__global__ __launch_bounds__(1024) void record_scan_kernel(const int64_t* rec_size, int64_t n, int64_t cap,
-                                                           int64_t* rec_off, int32_t* status) {
-  __shared__ int64_t s_w[16];
-  __shared__ int64_t s_run;
+// record sizes -> offsets by the NT threads of one workgroup (s_w: NT / 64 words, s_run: one word of LDS)
+template <int NT>
+__device__ __forceinline__ void scan_sizes(const int64_t* rec_size, int64_t n, int64_t cap, int64_t* rec_off, int32_t* status,
+                                           int64_t* s_w, int64_t& s_run) {
   constexpr int PER = 8;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_run = 0;
   __syncthreads();
-  for (int64_t base = 0; base < n; base += 1024 * PER) {
+  for (int64_t base = 0; base < n; base += NT * PER) {
     const int64_t i0 = base + (int64_t)threadIdx.x * PER;
     int64_t v[PER], mine = 0;
 #pragma unroll
@@ -468,13 +502,20 @@ __global__ __launch_bounds__(1024) void record_scan_kernel(const int64_t* rec_si
       run += v[k];
     }
     __syncthreads();
-    if (threadIdx.x == 1023) s_run = pre + inc;
+    if (threadIdx.x == NT - 1) s_run = pre + inc;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     rec_off[n] = s_run;
     *status = s_run > cap ? 1 : 0;
   }
+}
+
+__global__ __launch_bounds__(1024) void record_scan_kernel(const int64_t* rec_size, int64_t n, int64_t cap,
+                                                           int64_t* rec_off, int32_t* status) {
+  __shared__ int64_t s_w[16];
+  __shared__ int64_t s_run;
+  scan_sizes<1024>(rec_size, n, cap, rec_off, status, s_w, s_run);
 }
 
 // feature row element k of node `id` as the fp32 bit pattern the proto carries
@@ -746,7 +787,7 @@ __global__ __launch_bounds__(256) void record_plan_kernel(RecArgs a, EncArgs e) 
   Plan pl;
   if constexpr (BIG) carve(a, (unsigned char*)seg, pl);
   else carve(a, s_dyn + (size_t)w * e.lds_stride, pl);
-  build_plan(a, r, pl, e.row_crc);
+  build_plan<64>(a, r, pl, e.row_crc);
   const Layout L = layout_of(a, r, pl);
   if (lane == 0) {
     e.rec_size[r] = (int64_t)L.payload + (a.frame ? 16 : 0);
@@ -760,6 +801,37 @@ __global__ __launch_bounds__(256) void record_plan_kernel(RecArgs a, EncArgs e) 
     const uint32_t kw = kept_words(a);
     for (uint32_t i = lane; i < kw; i += 64) seg[i] = pl.hdr[i];
   }
+}
+
+// the same plan by a WORKGROUP per record (plans that fit LDS): calls of a few thousand records are bound by the length of one
+// record's chain of dependent steps, not by throughput — 256 threads walk it with a position or two each
+__global__ __launch_bounds__(256) void record_plan_wg_kernel(RecArgs a, EncArgs e) {
+  // (the sizes are scanned by record_scan_kernel: a ticket per workgroup + the last one scanning was measured at 291 us per
+  // 4,096 records against 169 — every workgroup's release fence writes the L2 back)
+  __shared__ unsigned long long s_w[8];
+  const int64_t r = blockIdx.x;
+  uint32_t* const seg = (uint32_t*)(e.plans + (size_t)r * e.plan_stride);
+  if (a.emit && !a.emit[r]) {
+    if (threadIdx.x == 0) {
+      e.rec_size[r] = 0;
+      seg[0] = NONE;  // no record
+    }
+    return;
+  }
+  Plan pl;
+  carve(a, s_dyn, pl);
+  build_plan<256>(a, r, pl, e.row_crc, s_w);
+  const Layout L = layout_of(a, r, pl);
+  if (threadIdx.x == 0) {
+    e.rec_size[r] = (int64_t)L.payload + (a.frame ? 16 : 0);
+    pl.hdr[0] = pl.n_uniq;
+    pl.hdr[1] = pl.nodes_bytes;
+    pl.hdr[2] = pl.edges_bytes;
+    pl.hdr[3] = L.neg_bytes;
+  }
+  __syncthreads();
+  const uint32_t kw = kept_words(a);
+  for (uint32_t i = threadIdx.x; i < kw; i += 256) seg[i] = pl.hdr[i];
 }
 
 __device__ __attribute__((always_inline)) void write_fields(const RecArgs& a, const EncArgs& e, const Plan& pl,
@@ -1669,7 +1741,14 @@ int32_t gigl_records_encode(gigl_ctx* ctx, const uint32_t* tree_roots, const gig
   if (n_records > 0) {
     const unsigned gp = (unsigned)((n_records + wp - 1) / wp);
     e.lds_stride = plan;
+    // (a workgroup per record while the call is latency-bound; GIGL_REC_PLAN_WG = 0 | 1 forces either shape: A/B)
+    static const int wg_knob = getenv("GIGL_REC_PLAN_WG") ? atoi(getenv("GIGL_REC_PLAN_WG")) : -1;
+    const bool plan_wg = !big && plan <= 64 * 1024 && (wg_knob >= 0 ? wg_knob != 0 : n_records <= 6144);
+    if (plan_wg && plan > 48 * 1024)
+      GIGL_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)record_plan_wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)plan));
     if (big) hipLaunchKernelGGL(record_plan_kernel<true>, dim3(gp), dim3(64 * wp), 0, ctx->stream, a, e);
+    else if (plan_wg) hipLaunchKernelGGL(record_plan_wg_kernel, dim3((unsigned)n_records), dim3(256), plan, ctx->stream, a, e);
     else hipLaunchKernelGGL(record_plan_kernel<false>, dim3(gp), dim3(64 * wp), lds_p, ctx->stream, a, e);
   }
   hipLaunchKernelGGL(record_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const int64_t*)e.rec_size, n_records,
