@@ -475,3 +475,54 @@ def test_trainer_with_margin_and_softmax_tasks(workdir, task):
     hist = [h["loss"] for h in spec.history]
     assert len(hist) >= 2 and all(np.isfinite(hist)) and min(hist[1:]) < 1.25 * hist[0]  # (smoke: moves, does not diverge)
 
+
+
+def test_trainer_runs_the_gat_encoder_through_the_library_plan(workdir, tmp_path):
+    """the reference fixture's graph with 8-wide node features (its own are 2 wide: too narrow for the input-side first
+    layer) and a one-head GAT: HipNodeAnchorLinkPredictionSpec.train hands the job to engine.GatNablpTrainPlan on the in-HBM
+    route (trainer.train_plan_steps counts its steps) and reaches the autograd loop's loss history (`train_plan: off`)"""
+    import yaml
+    from gigl_amd import wire
+    from gigl_amd.trainer import Trainer
+    base = str(tmp_path / "job")
+    shutil.copytree(workdir, base)
+    shutil.rmtree(os.path.join(base, "out", "nablp", "split"), ignore_errors=True)
+    meta_uri = os.path.join(base, "configs", "nablp_preprocessed_metadata.yaml")
+    meta = yaml.safe_load(open(meta_uri))
+    node = meta["condensedNodeTypeToPreprocessedMetadata"]["0"]
+    src_dir = os.path.join(base, node["tfrecordUriPrefix"])
+    ids = sorted(int(wire.decode_tf_example(r)["node_id"][0])
+                 for f in sorted(os.listdir(src_dir)) for r in wire.iter_tfrecords(open(os.path.join(src_dir, f), "rb").read()))
+    rng = np.random.default_rng(0)
+    wide = os.path.join(base, "tables", "nodes_wide")
+    os.makedirs(wide)
+    wire.write_tfrecords(os.path.join(wide, "data.tfrecord"), [
+        wire.encode_tf_example({"node_id": np.array([i], np.int64), "feat": rng.standard_normal(8).astype(np.float32)})
+        for i in ids])
+    node.update(featureDim=8, featureKeys=["feat"], tfrecordUriPrefix="tables/nodes_wide")
+    yaml.safe_dump(meta, open(meta_uri, "w"))
+    doc = yaml.safe_load(open(os.path.join(base, CFG)))
+    args = doc["trainerConfig"]["trainerArgs"]
+    args.update(gnn_model_class_path="gigl_amd.models_attn.GAT", hidden_dim="4", out_channels="8", num_heads="1")
+    doc["inferencerConfig"]["inferencerArgs"].update(args)
+    runs = {}
+    old = os.environ.get("GIGL_AMD_ROUTE")
+    os.environ["GIGL_AMD_ROUTE"] = "hbm"
+    try:
+        for mode in ("auto", "off"):
+            args["train_plan"] = mode
+            yaml.safe_dump(doc, open(os.path.join(base, CFG), "w"))
+            seed_trainer()
+            tr = Trainer()
+            tr.run("job", CFG, None, uri_base=base)
+            assert tr.training_process.route == "hbm"
+            spec = tr.training_process.trainer
+            runs[mode] = ([h["loss"] for h in spec.history], int(getattr(spec, "train_plan_steps", 0)))
+    finally:
+        if old is None:
+            os.environ.pop("GIGL_AMD_ROUTE", None)
+        else:
+            os.environ["GIGL_AMD_ROUTE"] = old
+    (h_plan, n_plan), (h_auto, n_auto) = runs["auto"], runs["off"]
+    assert n_plan == len(h_plan) >= 4 and n_auto == 0
+    np.testing.assert_allclose(h_plan, h_auto, rtol=2e-3)
