@@ -292,7 +292,7 @@ __device__ __forceinline__ uint32_t edge_first(const RecArgs& a, const Plan& pl,
 // ordering), NT = 256 a whole workgroup (s_w: 8 x uint64 of LDS for the waves' totals)
 template <int NT>
 __device__ __forceinline__ void grp_sync() {
-  if constexpr (NT == 64) grp_sync<NT>();
+  if constexpr (NT == 64) wave_sync();
   else __syncthreads();
 }
 template <int NT>

@@ -345,6 +345,25 @@ def test_many_records_and_both_table_types():
         eng.close()
 
 
+def test_wave_per_record_plans_against_the_restatement_frame_by_frame():
+    """calls of more than 6,144 records plan with ONE WAVE per record (build_plan<64>: its phases are ordered by
+    wavefront fences, not workgroup barriers) — every frame of a 7,000-record call, and of a 7,000-record call whose
+    records are too long for LDS (the scratch plan of the same code), against the restatement"""
+    n = 50_000
+    for fanouts, nrec in (([5, 3], 7_000), ([40, 30, 4], 300)):
+        eng, feats, rng = _random_engine(n, 5)
+        roots = rng.integers(0, n, nrec).astype(np.uint32)
+        tree = eng.sample_khop(roots, fanouts)
+        buf, off = eng.encode_records(tree)
+        nbr = [t.cpu().numpy().view(np.uint32) for t in tree.nbr]
+        want = _host_rnn_frames(roots, fanouts, nbr, feats)
+        got = _split(buf, off)
+        assert len(got) == len(want) == nrec
+        bad = [i for i, (g, w) in enumerate(zip(got, want)) if g != w]
+        assert not bad, f"{len(bad)} of {nrec} records differ (first {bad[:5]}), fanouts {fanouts}"
+        eng.close()
+
+
 def test_row_crc_table_matches_the_restatement():
     import ctypes as C
     n, d = 1000, 37
