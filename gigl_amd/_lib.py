@@ -48,7 +48,7 @@ SYMBOLS = [
     "gigl_comm_all_to_all", "gigl_comm_flush_local", "gigl_comm_traffic", "gigl_comm_destroy", "gigl_dist_plan_batch_features", "gigl_dist_plan_batch_graph", "gigl_dist_plan_create",
     "gigl_dist_plan_set_weights", "gigl_dist_plan_phases", "gigl_dist_plan_phase", "gigl_dist_plan_run",
     "gigl_dist_plan_run_local", "gigl_dist_plan_run_interleaved", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
-    "gigl_dist_plan_set_hot_rows",
+    "gigl_dist_plan_set_hot_rows", "gigl_dist_plan_set_peer_tables", "gigl_ipc_export", "gigl_ipc_open", "gigl_ipc_close",
     "gigl_split_hash_slots", "gigl_hgt_aggregate", "gigl_simplehgn_alpha", "gigl_weighted_aggregate",
     "gigl_collate_typed_records", "gigl_collated_typed_info", "gigl_collated_typed_nodes", "gigl_collated_typed_edges",
     "gigl_collated_typed_samples", "gigl_collated_typed_destroy", "gigl_typed_records_capacity",
@@ -176,6 +176,7 @@ STATS = {"sampled": 0, "aggregated": 1, "union_edges": 2, "union_nodes": 3, "exp
          "rows_layer0": 9, "overflow": 13, "pulled_rows": 14, "pull_bucket_max": 15}
 COMM_RCCL, COMM_LOCAL, COMM_CALLBACK = 0, 1, 2
 COMM_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64)
 
 
@@ -189,6 +190,7 @@ class GiglDistPlanOpts(C.Structure):
         ("projected", C.c_void_p),
         ("pull_cap_b", C.c_int64),
         ("staged", C.c_int32),
+        ("peer_direct", C.c_int32),
     ]
 STATS_LEN = 16
 STATS_SAMPLED, STATS_AGGREGATED = 0, 1  # GIGL_STATS_* slots of gigl_sage_plan_stats
@@ -324,6 +326,10 @@ def load() -> C.CDLL:
         "gigl_dist_plan_buffers": [vp, P(GiglTree), P(GiglUnion)],
         "gigl_dist_plan_stats": [vp, vp],
         "gigl_dist_plan_set_hot_rows": [vp, vp, i64, vp],
+        "gigl_dist_plan_set_peer_tables": [vp, P(vp)],
+        "gigl_ipc_export": [vp, vp, vp, P(i64)],
+        "gigl_ipc_open": [vp, vp, i64, P(vp), P(vp)],
+        "gigl_ipc_close": [vp, vp],
         "gigl_dist_plan_destroy": [vp],
         "gigl_retrieval_loss": [vp, vp, i64, i32, i32, C.c_float, vp, vp, vp, vp, vp, vp, vp],
         "gigl_retrieval_loss_backward": [vp, vp, i64, i32, i32, C.c_float, vp, vp, vp, vp, vp, vp],

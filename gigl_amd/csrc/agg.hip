@@ -84,7 +84,12 @@ __device__ __forceinline__ float4_t aggr_combine(float4_t a, float4_t b) {
 // PROJ (the plan's projected-input first layer, pipeline.hip): `src` holds rows ALREADY multiplied by W_l (fp32, d =
 // the layer's output width); the epilogue adds the destination's own W_r row (self_src[self]) and the bias, applies
 // the activation and writes the finished layer output out[i][0:d] — no [mean | self] operand, no projection.
-template <typename T, int LPR, int VPL, int OP = GIGL_AGGR_MEAN, bool PROJ = false>
+// PEER (the sharded plan's peer-mapped route, dist.hip): a non-negative source index is a GLOBAL node id v — its row is row
+// v / world of rank (v % world)'s table, peers[v % world] (this rank's own table included; the other ranks' tables are
+// mapped into this process: hipIpc handles between processes, plain device pointers inside one) — read where it lives,
+// over xGMI for a peer's.  Nothing is claimed, requested, served or received; the sums run over the same rows in the same
+// order as the bucketed route's, so the results are bit-identical.  Replicated hot rows stay -1-h (global_map).
+template <typename T, int LPR, int VPL, int OP = GIGL_AGGR_MEAN, bool PROJ = false, bool PEER = false>
 __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ src, int d,
                                                           const uint32_t* __restrict__ gather_ids,
                                                           const int32_t* __restrict__ rowptr,
@@ -99,14 +104,27 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
                                                           const float* __restrict__ bias = nullptr, int act = 0,
                                                           int ld = 0, int no_self = 0,
                                                           const int32_t* __restrict__ self_ids = nullptr, int ld3 = 0,
-                                                          int own_world = 0, int own_rank = 0) {
+                                                          int own_world = 0, int own_rank = 0,
+                                                          const T* const* __restrict__ peers = nullptr) {
   constexpr int G = 64 / LPR;  // source rows per wave-instruction
   const int64_t rs = PROJ ? (int64_t)ld : (int64_t)d;  // elements between source rows
-  const int64_t rs3 = PROJ && ld3 ? (int64_t)ld3 : (int64_t)d;  // ... of src3 (the rank's own table)
+  const int64_t rs3 = PROJ && ld3 ? (int64_t)ld3 : (int64_t)d;  // ... of src3 (the rank's own table) / of the peers' tables
+  __shared__ const T* s_peers[PEER ? 64 : 1];
+  if constexpr (PEER) {
+    if ((int)threadIdx.x < own_world) s_peers[threadIdx.x] = peers[threadIdx.x];
+    __syncthreads();
+  }
   // a NEGATIVE row index -1-h names a row outside `src` (the sharded plan): h < 2^30 = row h of src2 (replicated hot
   // rows), else row h - 2^30 of src3 (this rank's own feature table)
   auto row_of = [&](int j) -> const T* {
-    if (j >= 0) return src + (int64_t)j * rs;
+    if (j >= 0) {
+      if constexpr (PEER) {
+        const uint32_t q = (uint32_t)j / (uint32_t)own_world;
+        return s_peers[(uint32_t)j - q * (uint32_t)own_world] + (int64_t)q * rs3;
+      } else {
+        return src + (int64_t)j * rs;
+      }
+    }
     const int h = -1 - j;
     return h < (1 << 30) ? src2 + (int64_t)h * d : src3 + (int64_t)(h - (1 << 30)) * rs3;
   };
@@ -124,6 +142,14 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
 
   // source index of column entry `c` of destination row i
   auto translate = [&](int c, int i) -> int {
+    if constexpr (PEER) {  // every source is named by its global id; global_map holds the replicated rows' marks only
+      const int v = (gather_ids && i < n_local) ? (int)gather_ids[c] : c;
+      if (global_map) {
+        const int mk = global_map[(uint32_t)v];
+        if (mk < 0) return mk;
+      }
+      return v;
+    }
     if (gather_ids && i < n_local) return (int)gather_ids[c];
     if (global_map && i >= n_local) {  // global id -> its row in `src`
       // (own_world: the ids this rank owns — id % world == rank — are row id / world of src3, by arithmetic: they are
@@ -145,7 +171,7 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
   // write the finished row i: `acc` holds the reduction in the lanes sl of group `sub` (grp: every group owns its own
   // row; else the whole wave owns row i and group 0 holds the total)
   auto emit = [&](int i, int m, float4_t (&acc)[VPL], bool grp) {
-    const int self = gather_ids ? (int)gather_ids[i] : i;
+    const int self = gather_ids ? (int)gather_ids[i] : i;  // (PEER: the destination's global id)
     const bool writer = grp || sub == 0;
     // mean = sum / deg (a true division, like torch's scatter-mean), 0 for an empty row
     const float dv = (OP == GIGL_AGGR_MEAN && m > 0) ? (float)m : 1.f;
@@ -157,8 +183,9 @@ __global__ __launch_bounds__(256) void gather_mean_kernel(const T* __restrict__ 
         // (a NEGATIVE self_ids[i] = -1 - (2^30 + r): the destination is a node of this rank — its W_r row is the right half
         // of row r of src3, the rank's own [W_l x | W_r x] table, read in place)
         const int sj = self_ids ? self_ids[i] : self;
-        const float* pr = sj >= 0 ? self_src + (int64_t)(uint32_t)sj * rs
-                                  : src3 + (int64_t)((-1 - sj) - (1 << 30)) * rs3 + d;
+        const float* pr;
+        if constexpr (PEER) pr = reinterpret_cast<const float*>(row_of(self)) + d;  // right half of the owner's [W_l x | W_r x] row
+        else pr = sj >= 0 ? self_src + (int64_t)(uint32_t)sj * rs : src3 + (int64_t)((-1 - sj) - (1 << 30)) * rs3 + d;
         float* o = out + (int64_t)i * d;
 #pragma unroll
         for (int v = 0; v < VPL; ++v) {
@@ -3423,26 +3450,36 @@ int32_t launch_gather(gigl_ctx* ctx, const T* src, int d, const uint32_t* gather
                       const int32_t* n_rows_dev, int64_t rows_cap, float* out, int op = GIGL_AGGR_MEAN,
                       const int32_t* n_local_dev = nullptr, int tiled_nkc = 0, const int32_t* global_map = nullptr,
                       const T* src2 = nullptr, const T* src3 = nullptr, int no_self = 0, int own_world = 0,
-                      int own_rank = 0) {
+                      int own_rank = 0, const T* const* peers = nullptr) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
   dim3 g((unsigned)blocks), b(256);
   hipStream_t st = ctx->stream;
   const int vecs = d / 4;
-#define GLO(LPR, VPL, OP)                                                                            \
-  hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, 0, st, src, d, gather_ids, rowptr, \
-                     rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc, global_map, src2, src3,   \
-                     (const float*)nullptr, (const float*)nullptr, 0, 0, no_self, (const int32_t*)nullptr, 0,     \
-                     own_world, own_rank)
+#define GLO(LPR, VPL, OP)                                                                                              \
+  do {                                                                                                                 \
+    if (peers)                                                                                                         \
+      hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP, false, true>), g, b, 0, st, src, d, gather_ids, rowptr,  \
+                         rowend, col, n_rows_dev, out, n_local_dev, tiled_nkc, global_map, src2, src3,                 \
+                         (const float*)nullptr, (const float*)nullptr, 0, 0, no_self, (const int32_t*)nullptr, 0,      \
+                         own_world, own_rank, peers);                                                                  \
+    else                                                                                                               \
+      hipLaunchKernelGGL((gather_mean_kernel<T, LPR, VPL, OP>), g, b, 0, st, src, d, gather_ids, rowptr, rowend, col,  \
+                         n_rows_dev, out, n_local_dev, tiled_nkc, global_map, src2, src3, (const float*)nullptr,       \
+                         (const float*)nullptr, 0, 0, no_self, (const int32_t*)nullptr, 0, own_world, own_rank,        \
+                         (const T* const*)nullptr);                                                                    \
+  } while (0)
 #define GL(LPR, VPL)                                        \
   do {                                                      \
     if (op == GIGL_AGGR_MEAN) GLO(LPR, VPL, GIGL_AGGR_MEAN); \
     else if (op == GIGL_AGGR_SUM) GLO(LPR, VPL, GIGL_AGGR_SUM); \
     else GLO(LPR, VPL, GIGL_AGGR_MAX);                      \
   } while (0)
+  if (peers && (own_world < 1 || own_world > 64))
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "peer-mapped tables: world %d outside [1, 64]", own_world);
   if ((d & 3) != 0 || vecs > 512) {
-    if (tiled_nkc || global_map)
+    if (tiled_nkc || global_map || peers)
       return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the tiled operand layout / global row map need d %% 4 == 0 and d <= 2048");
     hipLaunchKernelGGL((gather_mean_generic_kernel<T>), g, b, 0, st, src, d, gather_ids, rowptr, rowend,
                        col, n_rows_dev, out, op, n_local_dev);
@@ -3464,23 +3501,34 @@ int32_t launch_gather_projected(gigl_ctx* ctx, const float* src_l, const float* 
                                 const int32_t* rowptr, const int32_t* rowend, const int32_t* col,
                                 const int32_t* n_rows_dev, int64_t rows_cap, const int32_t* n_local_dev, int op,
                                 const float* bias, int act, float* out, const int32_t* global_map, const float* src2,
-                                const float* src3, int ld3, const int32_t* self_ids, int own_world, int own_rank) {
+                                const float* src3, int ld3, const int32_t* self_ids, int own_world, int own_rank,
+                                const float* const* peers = nullptr) {
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 16) blocks = 256 * 16;
   if (blocks < 1) blocks = 1;
   dim3 g((unsigned)blocks), b(256);
   const int vecs = d / 4;
+#define GLPP(LPR, VPL, OP)                                                                                            \
+  hipLaunchKernelGGL((gather_mean_kernel<float, LPR, VPL, OP, true, true>), g, b, 0, ctx->stream, src_l, d, gather_ids, \
+                     rowptr, rowend, col, n_rows_dev, out, n_local_dev, 0, global_map, src2, src3, src_r, bias, act, ld, \
+                     0, self_ids, ld3, own_world, own_rank, peers)
 #define GLP(LPR, VPL)                                                                                                 \
   do {                                                                                                                \
-    if (op == GIGL_AGGR_MEAN)                                                                                         \
+    if (peers && op == GIGL_AGGR_MEAN)                                                                                \
+      GLPP(LPR, VPL, GIGL_AGGR_MEAN);                                                                                 \
+    else if (peers)                                                                                                   \
+      GLPP(LPR, VPL, GIGL_AGGR_SUM);                                                                                  \
+    else if (op == GIGL_AGGR_MEAN)                                                                                    \
       hipLaunchKernelGGL((gather_mean_kernel<float, LPR, VPL, GIGL_AGGR_MEAN, true>), g, b, 0, ctx->stream, src_l, d, \
                          gather_ids, rowptr, rowend, col, n_rows_dev, out, n_local_dev, 0, global_map, src2, src3,    \
-                         src_r, bias, act, ld, 0, self_ids, ld3, own_world, own_rank);                                \
+                         src_r, bias, act, ld, 0, self_ids, ld3, own_world, own_rank, (const float* const*)nullptr);  \
     else                                                                                                              \
       hipLaunchKernelGGL((gather_mean_kernel<float, LPR, VPL, GIGL_AGGR_SUM, true>), g, b, 0, ctx->stream, src_l, d,  \
                          gather_ids, rowptr, rowend, col, n_rows_dev, out, n_local_dev, 0, global_map, src2, src3,    \
-                         src_r, bias, act, ld, 0, self_ids, ld3, own_world, own_rank);                                \
+                         src_r, bias, act, ld, 0, self_ids, ld3, own_world, own_rank, (const float* const*)nullptr);  \
   } while (0)
+  if (peers && (own_world < 1 || own_world > 64))
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "peer-mapped tables: world %d outside [1, 64]", own_world);
   if ((d & 3) != 0 || vecs > 512) return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "projected input: width %d (need d %% 4 == 0, d <= 2048)", d);
   if (vecs <= 8) GLP(8, 1);
   else if (vecs <= 16) GLP(16, 1);
@@ -3490,6 +3538,7 @@ int32_t launch_gather_projected(gigl_ctx* ctx, const float* src_l, const float* 
   else if (vecs <= 256) GLP(64, 4);
   else GLP(64, 8);
 #undef GLP
+#undef GLPP
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
@@ -3513,7 +3562,8 @@ int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float
                                   const int32_t* col, const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
                                   const int32_t* n_local_rows_dev, const float* bias, int32_t act, float* out,
                                   const int32_t* global_map, const float* src2, const float* src3, int32_t ld3,
-                                  const int32_t* self_ids, int32_t own_world, int32_t own_rank) {
+                                  const int32_t* self_ids, int32_t own_world, int32_t own_rank,
+                                  const float* const* peers) {
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   if (aggr != GIGL_AGGR_MEAN && aggr != GIGL_AGGR_SUM)
@@ -3521,7 +3571,7 @@ int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   return launch_gather_projected(ctx, src_l, src_r, ld, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap,
                                  n_local_rows_dev, aggr, bias, act, out, global_map, src2, src3, ld3, self_ids, own_world,
-                                 own_rank);
+                                 own_rank, peers);
 }
 
 extern "C" {
@@ -3667,17 +3717,17 @@ int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dty
                                  const int32_t* n_rows_dev, int64_t rows_cap, int32_t aggr,
                                  const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc,
                                  const int32_t* global_map, const void* src2, const void* src3, int32_t no_self,
-                                 int32_t own_world, int32_t own_rank) {
+                                 int32_t own_world, int32_t own_rank, const void* const* peers) {
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (rows_cap == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   if (src_dtype == GIGL_DTYPE_F32)
     return launch_gather<float>(ctx, (const float*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
                                 aggr, n_local_rows_dev, tiled_nkc, global_map, (const float*)src2, (const float*)src3,
-                                no_self, own_world, own_rank);
+                                no_self, own_world, own_rank, (const float* const*)peers);
   return launch_gather<__half>(ctx, (const __half*)src, d, gather_ids, rowptr, rowend, col, n_rows_dev, rows_cap, out,
                                aggr, n_local_rows_dev, tiled_nkc, global_map, (const __half*)src2, (const __half*)src3,
-                               no_self, own_world, own_rank);
+                               no_self, own_world, own_rank, (const __half* const*)peers);
 }
 
 extern "C" {

@@ -117,7 +117,10 @@ int32_t gigl_gather_reduce_mixed(gigl_ctx* ctx, const void* src, int32_t src_dty
                                  const int32_t* n_local_rows_dev, float* out, int32_t tiled_nkc = 0,
                                  const int32_t* global_map = nullptr, const void* src2 = nullptr,
                                  const void* src3 = nullptr, int32_t no_self = 0, int32_t own_world = 0,
-                                 int32_t own_rank = 0);
+                                 int32_t own_rank = 0, const void* const* peers = nullptr);
+// peers (DEVICE array of own_world table pointers; the sharded plan's peer-mapped route): every non-negative source index
+// is a GLOBAL id v, read as row v / own_world of peers[v % own_world] (rows as far apart as src3's); global_map then holds
+// only the replicated rows' marks (-1-h) and may be NULL; `src` is not read
 // own_world > 0 (with global_map): a global id with id % own_world == own_rank is row id / own_world of src3 by arithmetic
 // (the rank's own nodes are never claimed into global_map)
 // no_self (tiled layout): only the reduced half is written, tiled_nkc = ceil(d / 32) chunks per row tile; the
@@ -133,7 +136,9 @@ int32_t gigl_gather_project_mixed(gigl_ctx* ctx, const float* src_l, const float
                                   const int32_t* n_local_rows_dev, const float* bias, int32_t act, float* out,
                                   const int32_t* global_map = nullptr, const float* src2 = nullptr,
                                   const float* src3 = nullptr, int32_t ld3 = 0, const int32_t* self_ids = nullptr,
-                                  int32_t own_world = 0, int32_t own_rank = 0);
+                                  int32_t own_world = 0, int32_t own_rank = 0, const float* const* peers = nullptr);
+// (peers: as in gigl_gather_reduce_mixed — the tables are the ranks' [W_l x | W_r x] rows, ld3 floats apart; destination
+// i's W_r x is the right half of the row of ITS global id gather_ids[i]; src_l / src_r / self_ids are not read)
 // (self_ids[i] < 0, = -1 - (2^30 + r): destination i is a node of this rank — its W_r x is the right half of row r of src3)
 // (sharded plan: global_map / src2 / src3 as in gigl_gather_reduce_mixed — src3's rows ld3 floats apart — and
 // self_ids[i] = the row of src_r that holds destination i's W_r x)

@@ -693,6 +693,13 @@ struct DistStatsArgs {
   const int32_t* rowend;
   const int32_t* pull_counts;  // [world]
   int32_t world;
+  // peer-mapped plans: PULLED_ROWS = the rows the first layer reads from OTHER ranks' tables (per occurrence: nothing is
+  // deduplicated on this route) — the sources of its rows that are neither this rank's nor replicated, plus, over
+  // pre-projected tables, the W_r x half rows of the inner nodes other ranks own
+  int32_t peer, rank, self_rows;
+  const uint32_t* nodes;
+  const int32_t* col;
+  const int32_t* hot_map;
 };
 
 __global__ __launch_bounds__(256) void dist_stats_kernel(DistStatsArgs a, unsigned long long* acc) {
@@ -723,6 +730,18 @@ __global__ __launch_bounds__(256) void dist_stats_kernel(DistStatsArgs a, unsign
   add(GIGL_STATS_AGGREGATED, agg_all);
 #pragma unroll
   for (int l = 0; l < GIGL_MAX_HOPS; ++l) add(GIGL_STATS_AGG_LAYER0 + l, agg[l]);
+  if (a.peer) {
+    long long remote = 0;
+    const int32_t n_local = L >= 2 ? a.meta[GIGL_META_LEVEL0 + L - 2] : 0;
+    for (int64_t i = t0; i < n_rows; i += stride) {
+      for (int32_t e = a.rowptr[i]; e < a.rowend[i]; ++e) {
+        const uint32_t v = i < n_local ? a.nodes[a.col[e]] : (uint32_t)a.col[e];
+        if (v % (uint32_t)a.world != (uint32_t)a.rank && !(a.hot_map && a.hot_map[v] < 0)) ++remote;
+      }
+      if (a.self_rows && a.nodes[i] % (uint32_t)a.world != (uint32_t)a.rank) ++remote;
+    }
+    add(GIGL_STATS_PULLED_ROWS, remote);
+  }
   if (t0 == 0) {
     atomicAdd(&acc[GIGL_STATS_UNION_EDGES], (unsigned long long)a.meta[GIGL_META_N_EDGES]);
     atomicAdd(&acc[GIGL_STATS_UNION_NODES], (unsigned long long)a.meta[GIGL_META_N_NODES]);
@@ -816,6 +835,13 @@ struct gigl_dist_plan {
   int32_t* slot_map = nullptr; // [n_global] receive-buffer row of the id in that call
   uint32_t tag = 0;
   int64_t n_global = 0, last_slots = 0;
+  // peer-mapped route (opts->peer_direct; dense plans): the first layer reads every source row WHERE IT LIVES — row v / world
+  // of rank (v % world)'s table, peers_dev[v % world] (hipIpc-mapped between processes, plain pointers inside one) — so the
+  // feature pull has no claim, no id exchange, no owner-side gather and no receive buffer: phases 2L and 2L + 1 end after
+  // the union graph.  Replicated hot rows keep their marks in slot_map (the only thing it holds then).
+  bool peer = false;
+  const void** peers_dev = nullptr;  // device [world]
+  bool peers_ready = false;
   // activations
   bool tiled_layers = false;  // layers >= 1: tiled gather operand + two-source projection (every dims[l], l >= 1, % 4 == 0)
   float* abuf = nullptr;
@@ -868,7 +894,7 @@ int32_t clear_call(gigl_dist_plan* p) {
   }
   if (!(W == 1 && pull_self_in_place(p))) add(p->ids_s, W * p->pull_cap, 0xFFFFFFFFu);  // (... and requests no row)
   add(p->pull_counts, W + 1, 0u);
-  if (p->project || p->preproj) {
+  if (p->pullb_counts) {
     if (!(W == 1 && pull_self_in_place(p))) add(p->idsb_s, W * p->pull_cap_b, 0xFFFFFFFFu);
     add(p->pullb_counts, W + 1, 0u);
   }
@@ -994,6 +1020,7 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
         hipLaunchKernelGGL(hot_unmark_kernel, dim3((unsigned)grid256(p->n_global)), dim3(256), 0, st, p->stamp, p->n_global, 0);
         p->tag = 1;
       }
+      if (p->peer) return GIGL_OK;  // (rows are read in place, from whichever rank holds them: nothing to request)
       const int32_t* n_inner = p->un.meta + GIGL_META_LEVEL0 + (L - 1);
       const int32_t own = p->own_in_place ? p->rank : -1;
       const bool self_ip = pull_self_in_place(p);
@@ -1043,6 +1070,7 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
   if (phase == 2 * L + 1) {
     // ---- owner: the requested rows, gathered straight into the send buffer (or projected into it)
     const int64_t na = (int64_t)world * p->pull_cap, nb = (int64_t)world * p->pull_cap_b;
+    if (p->peer) return GIGL_OK;
     if (!p->project) {
       const bool in_place = comm_self_in_place(p->comm);
       if (world == 1 && pull_self_in_place(p)) return GIGL_OK;  // (a lone rank requested nothing)
@@ -1078,6 +1106,8 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
     return rc;
   }
   // ---- requester: forward over the union graph, one row per root
+  if (p->peer && !p->peers_ready)
+    return gigl_fail(ctx, GIGL_E_INVALID_ARG, "peer-mapped plan: the ranks' tables were not set (gigl_dist_plan_set_peer_tables)");
   hipLaunchKernelGGL(fold_overflow_kernel, dim3(1), dim3(64), 0, st, p->un.meta, (const int32_t* const*)p->flag_ptrs,
                      p->n_flags, L, (int32_t)(p->act_rows < 0x7FFFFFFF ? p->act_rows : 0x7FFFFFFF));
   GIGL_HIP_CHECK(ctx, hipGetLastError());
@@ -1116,6 +1146,27 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
       hipLaunchKernelGGL(projected_layer_kernel, dim3((unsigned)grid256(rows_cap * dout)), dim3(256), 0, st, p->abuf,
                          (const float*)p->rowsb_r, p->posb, p->bias[0], dout, act, n_rows, rows_cap, p->hbuf[0]);
       GIGL_HIP_CHECK(ctx, hipGetLastError());
+      continue;
+    }
+    if (l == 0 && p->peer) {
+      // every source by its global id (inner rows through un.nodes, leaf rows as they are), read from its owner's table
+      const int32_t* hot_map = p->has_hot ? p->slot_map : nullptr;
+      const int32_t* n_local = p->un.meta + GIGL_META_LEVEL0 + (L - 2);
+      if (p->preproj) {
+        const int dout = p->dims[1];
+        rc = gigl_gather_project_mixed(ctx, nullptr, nullptr, dout, dout, p->un.nodes, p->un.rowptr, p->un.rowend, p->un.col,
+                                       n_rows, rows_cap, p->aggr, n_local, p->bias[0], act, p->hbuf[0], hot_map,
+                                       (const float*)p->hot_rows, nullptr, 2 * dout, nullptr, p->world, p->rank,
+                                       (const float* const*)p->peers_dev);
+        if (rc != GIGL_OK) return rc;
+        continue;
+      }
+      rc = gigl_gather_reduce_mixed(ctx, nullptr, p->feat->dtype, p->dims[0], p->un.nodes, p->un.rowptr, p->un.rowend,
+                                    p->un.col, n_rows, rows_cap, p->aggr, n_local, p->abuf, 0, hot_map, p->hot_rows, nullptr,
+                                    0, p->world, p->rank, p->peers_dev);
+      if (rc != GIGL_OK) return rc;
+      rc = gigl_linear(ctx, p->abuf, p->w[0], p->bias[0], n_rows, rows_cap, 2 * p->dims[0], p->dims[1], act, p->hbuf[0]);
+      if (rc != GIGL_OK) return rc;
       continue;
     }
     if (l == 0 && p->preproj) {  // one reduction over W_l x rows (receive buffer / own table / hot rows) + W_r x + bias
@@ -1332,6 +1383,10 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   p->dense = kind == 0 && hops == 2 && !p->project && p->n_global < ((int64_t)1 << 32) && (shard_feat->d & 3) == 0 &&
              fanouts[1] <= GIGL_FAST_FANOUT && getenv("GIGL_DIST_GENERIC_UNION") == nullptr && !(opts && opts->staged);
   p->own_in_place = p->dense && shard->n < ((int64_t)1 << 30) && getenv("GIGL_DIST_COPY_OWN_ROWS") == nullptr;
+  p->peer = opts && opts->peer_direct != 0;
+  if (p->peer && (!p->dense || p->n_global >= ((int64_t)1 << 31) || W > 64))
+    return fail(GIGL_E_UNSUPPORTED, "the peer-mapped route needs the dense plan shape (SAGE layers, two hops, second fan-out "
+                                    "<= 64, no owner-side projection, not staged), fewer than 2^31 nodes and a world <= 64");
   if (p->preproj && (!p->dense || (dims[1] & 3) != 0 || dims[1] > 2048))
     return fail(GIGL_E_UNSUPPORTED, "pre-projected rows need the dense pull bookkeeping (two hops, second fan-out <= 64, no "
                                     "owner-side projection) and a first-layer width % 4 == 0, <= 2048");
@@ -1393,7 +1448,7 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   p->un.rowptr = (int32_t*)alloc((size_t)(cap_nodes + 2) * 4);
   p->un.rowend = (int32_t*)alloc((size_t)(cap_nodes + 2) * 4);
   p->un.root_local = (int32_t*)alloc((size_t)b * 4);
-  if (p->dense) {
+  if (p->dense && !p->peer) {  // (a peer-mapped plan claims nothing; its hot marks are allocated with the hot set)
     p->stamp = (uint32_t*)alloc((size_t)p->n_global * 4);
     p->slot_map = (int32_t*)alloc((size_t)p->n_global * 4);
     ok = ok && p->stamp && p->slot_map;
@@ -1413,12 +1468,13 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   // (calibrated on warm-up steps, see GIGL_STATS_PULL_BUCKET_MAX), else the worst case / world + 10 %
   int64_t pc = opts && opts->pull_cap > 0 ? opts->pull_cap : (int64_t)std::ceil((double)cap_nodes / (double)W * 1.1) + 512;
   if (pc > cap_nodes) pc = cap_nodes;
+  if (p->peer) pc = 0;  // (no row ever sits in a bucket)
   p->pull_cap = pc;
   p->row_bytes = (p->project || p->preproj) ? (int64_t)dims[1] * 4
                                             : (int64_t)dims[0] * (shard_feat->dtype == GIGL_DTYPE_F32 ? 4 : 2);
   p->ids_s = (uint32_t*)alloc((size_t)W * pc * 4);
   p->ids_r = (uint32_t*)alloc((size_t)W * pc * 4);
-  p->pos = (int32_t*)alloc((size_t)cap_nodes * 4);
+  p->pos = (int32_t*)alloc(p->peer ? 16 : (size_t)cap_nodes * 4);
   p->pull_counts = (int32_t*)alloc((size_t)(W + 1) * 4);
   p->req_counts = (int32_t*)alloc((size_t)(W + 1) * 4);
   p->rows_s = alloc((size_t)W * pc * p->row_bytes);
@@ -1426,7 +1482,16 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   ok = ok && p->own_cnt && p->un.meta && p->un.nodes && p->un.rowptr && p->un.rowend && p->un.col &&
        p->un.root_local && p->ids_s && p->ids_r && p->pos && p->pull_counts && p->req_counts && p->rows_s && p->rows_r;
   p->n_entries_dev = (int32_t*)alloc(16);
-  if (p->preproj && ok) {  // the second pull's buckets (W_r x of the inner nodes)
+  if (p->peer && ok) {
+    p->peers_dev = (const void**)alloc((size_t)W * sizeof(void*));
+    ok = p->peers_dev != nullptr;
+    if (ok && W == 1) {  // a lone rank's only table is its own
+      const void* own = p->preproj ? (const void*)p->preproj : (const void*)shard_feat->rows;
+      ok = hipMemcpy(p->peers_dev, &own, sizeof(void*), hipMemcpyHostToDevice) == hipSuccess;
+      p->peers_ready = ok;
+    }
+  }
+  if (p->preproj && ok && !p->peer) {  // the second pull's buckets (W_r x of the inner nodes)
     int64_t pcb = opts && opts->pull_cap_b > 0 ? opts->pull_cap_b
                                                : (int64_t)std::ceil((double)act_rows / (double)W * (W > 1 ? 1.25 : 1.0)) + 512;
     if (pcb > act_rows) pcb = act_rows;
@@ -1475,7 +1540,7 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   std::vector<const int32_t*> flags;
   for (int k = 0; k < hops; ++k) flags.push_back(p->counts[k] + W);
   flags.push_back(p->pull_counts + W);
-  if (p->project || p->preproj) flags.push_back(p->pullb_counts + W);
+  if (p->pullb_counts) flags.push_back(p->pullb_counts + W);
   p->n_flags = (int)flags.size();
   p->flag_ptrs = (const int32_t**)alloc(flags.size() * sizeof(void*));
   ok = ok && p->abuf && p->hbuf[0] && p->hbuf[1] && p->n_entries_dev && p->flag_ptrs;
@@ -1508,7 +1573,7 @@ __global__ __launch_bounds__(256) void hot_scatter_kernel(const uint32_t* __rest
                                                           uint32_t* __restrict__ stamp, int32_t* __restrict__ slot_map) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_hot && (int64_t)ids[i] < n_global) {
-    stamp[ids[i]] = DIST_HOT_STAMP;
+    if (stamp) stamp[ids[i]] = DIST_HOT_STAMP;  // (a peer-mapped plan has no stamps: slot_map holds the marks alone)
     slot_map[ids[i]] = -1 - (int32_t)i;
   }
 }
@@ -1520,7 +1585,16 @@ int32_t gigl_dist_plan_set_hot_rows(gigl_dist_plan* p, const uint32_t* hot_ids, 
   GIGL_REQUIRE(ctx, p->dense, "replicated hot rows need the dense pull bookkeeping (two hops, raw rows)");
   GIGL_REQUIRE(ctx, n_hot >= 0 && n_hot < ((int64_t)1 << 31) && (n_hot == 0 || (hot_ids && hot_rows)), "bad hot set");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (p->has_hot)  // (the previous set's marks)
+  if (p->peer) {
+    if (!p->slot_map && n_hot > 0) {
+      void* q = nullptr;
+      if (hipMalloc(&q, (size_t)p->n_global * 4) != hipSuccess) return gigl_fail(ctx, GIGL_E_OOM, "hot-row marks: hipMalloc failed");
+      p->owned.push_back(q);
+      p->slot_map = (int32_t*)q;
+      p->has_hot = true;  // (cleared below)
+    }
+    if (p->has_hot) GIGL_HIP_CHECK(ctx, hipMemsetAsync(p->slot_map, 0, (size_t)p->n_global * 4, ctx->stream));
+  } else if (p->has_hot)  // (the previous set's marks)
     hipLaunchKernelGGL(hot_unmark_kernel, dim3((unsigned)grid256(p->n_global)), dim3(256), 0, ctx->stream, p->stamp, p->n_global, 1);
   if (n_hot > 0)
     hipLaunchKernelGGL(hot_scatter_kernel, dim3((unsigned)grid256(n_hot)), dim3(256), 0, ctx->stream, hot_ids, n_hot,
@@ -1529,6 +1603,58 @@ int32_t gigl_dist_plan_set_hot_rows(gigl_dist_plan* p, const uint32_t* hot_ids, 
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (hot_ids may be freed by the caller after this returns)
   p->hot_rows = n_hot > 0 ? hot_rows : nullptr;  // (n_hot == 0: back to "nothing replicated")
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_plan_set_peer_tables(gigl_dist_plan* p, const void* const* tables) {
+  if (!p || !tables) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, p->peer, "not a peer-mapped plan (gigl_dist_plan_opts.peer_direct)");
+  for (int r = 0; r < p->world; ++r) GIGL_REQUIRE(ctx, tables[r], "rank %d's table is null", r);
+  const void* own = p->preproj ? (const void*)p->preproj : (const void*)p->feat->rows;
+  GIGL_REQUIRE(ctx, tables[p->rank] == own, "tables[rank] must be this rank's own table (the plan's %s)",
+               p->preproj ? "pre-projected rows" : "feature rows");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(p->peers_dev, tables, (size_t)p->world * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (`tables` is the caller's host array)
+  p->peers_ready = true;
+  return GIGL_OK;
+}
+
+int32_t gigl_ipc_export(gigl_ctx* ctx, const void* dev_ptr, void* handle, int64_t* offset) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, dev_ptr && handle && offset, "null argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == GIGL_IPC_HANDLE_BYTES, "ipc handle size");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // the handle names the ALLOCATION (a caching allocator hands out interior pointers): the offset travels with it
+  void* base = nullptr;
+  size_t size = 0;
+  GIGL_HIP_CHECK(ctx, hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)dev_ptr));
+  hipIpcMemHandle_t h;
+  GIGL_HIP_CHECK(ctx, hipIpcGetMemHandle(&h, base));
+  memcpy(handle, &h, sizeof(h));
+  *offset = (int64_t)((const char*)dev_ptr - (const char*)base);
+  return GIGL_OK;
+}
+
+int32_t gigl_ipc_open(gigl_ctx* ctx, const void* handle, int64_t offset, void** base, void** ptr) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, handle && base && ptr && offset >= 0, "bad arguments");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  void* b = nullptr;
+  GIGL_HIP_CHECK(ctx, hipIpcOpenMemHandle(&b, h, hipIpcMemLazyEnablePeerAccess));
+  *base = b;
+  *ptr = (char*)b + offset;
+  return GIGL_OK;
+}
+
+int32_t gigl_ipc_close(gigl_ctx* ctx, void* base) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  if (!base) return GIGL_OK;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GIGL_HIP_CHECK(ctx, hipIpcCloseMemHandle(base));
   return GIGL_OK;
 }
 
@@ -1716,6 +1842,12 @@ int32_t gigl_dist_plan_stats(gigl_dist_plan* p, int64_t* acc) {
   a.rowend = p->un.rowend;
   a.pull_counts = p->pull_counts;
   a.world = p->world;
+  a.peer = p->peer ? 1 : 0;
+  a.rank = p->rank;
+  a.self_rows = p->preproj ? 1 : 0;
+  a.nodes = p->un.nodes;
+  a.col = p->un.col;
+  a.hot_map = p->has_hot ? p->slot_map : nullptr;
   int64_t blocks = grid256(most);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(dist_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a, (unsigned long long*)acc);

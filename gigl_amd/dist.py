@@ -392,11 +392,13 @@ class DistSagePlan:
     def __init__(self, comm: Comm, weights, biases, b: int, fanouts: Sequence[int], act_last: bool = False,
                  group_roots: Optional[int] = None, project_on_owner: bool = False, pull_cap: int = 0,
                  hop_slack: float = 0.0, max_window_end: int = -1, projected: Optional[torch.Tensor] = None,
-                 pull_cap_b: int = 0, aggr: str = "mean", staged: bool = False):
+                 pull_cap_b: int = 0, aggr: str = "mean", staged: bool = False, peer_direct: bool = False):
         """aggr: the SAGE layers' reduction ("mean" | "sum" | "max"; "max" pulls raw rows: not with project_on_owner /
         projected).  projected: this rank's pre-projected rows (HipEngine.project_features of the SHARD's table with weights[0]:
         [shard rows, 2*out] fp32) — the pull moves W_l x rows, the first layer is one reduction (gigl_dist_plan_opts.
         projected); recompute and rebuild the plan after a weight update.
+        peer_direct: the peer-mapped route (gigl_dist_plan_opts.peer_direct): rows are read where they live, from the
+        owners' tables mapped into this process — hand them over with set_peer_tables / map_peer_tables before the first step.
         staged: the plan serves TRAINING batches (gigl_dist_plan_opts.staged): sample_and_pull + batch_tensors hand out the
         batch union graph and its dense feature matrix; raw rows, every union node numbered"""
         from . import _lib
@@ -413,6 +415,9 @@ class DistSagePlan:
         o.project_on_owner = 1 if project_on_owner else 0
         o.pull_cap, o.hop_slack, o.max_window_end = int(pull_cap), float(hop_slack), int(max_window_end)
         o.staged = 1 if staged else 0
+        o.peer_direct = 1 if peer_direct else 0
+        self.peer_direct = bool(peer_direct)
+        self._peer_keep = None
         self.staged = bool(staged)
         assert not (staged and (projected is not None or project_on_owner)), "staged batches pull raw rows"
         self.projected = projected
@@ -466,6 +471,53 @@ class DistSagePlan:
         _check(self._lib.gigl_dist_plan_set_hot_rows(self._plan, C.c_void_p(ids.data_ptr()), n,
                                                      C.c_void_p(rows.data_ptr())), self.eng._ctx)
         self._hot = (ids, rows)  # the plan borrows the rows
+
+    # ---- peer-mapped route
+    def own_table(self) -> int:
+        """device address of the table of this rank the other ranks read: its pre-projected rows, or its feature rows"""
+        return int(self.projected.data_ptr()) if self.projected is not None else int(self.eng._feat_ptr.value)
+
+    def set_peer_tables(self, tables: Sequence) -> None:
+        """tables[r]: rank r's table as a device tensor or a raw device address valid in THIS process (the ranks of an
+        in-process group: each other's tensors; separate processes: the addresses map_peer_tables opens)"""
+        assert self.peer_direct and len(tables) == self.comm.world
+        ptrs = [int(t.data_ptr()) if isinstance(t, torch.Tensor) else int(t) for t in tables]
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        _check(self._lib.gigl_dist_plan_set_peer_tables(self._plan, arr), self.eng._ctx)
+        self._peer_keep = list(tables)  # (tensors stay alive with the plan)
+
+    @staticmethod
+    def share_tables(eng, table, group=None) -> Tuple[list, list]:
+        """every rank's `table` mapped into this process: export (hipIpc handle of the allocation + offset), all_gather
+        over `group` (any backend: the handles are host bytes), open the peers'.  `table`: a device tensor or a device address
+        (DistSagePlan.own_table).  Returns (addresses by rank, the opened bases for close_shared).  One call per table and process; the addresses
+        serve every plan of the process."""
+        from . import _lib
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        h = (C.c_uint8 * _lib.IPC_HANDLE_BYTES)()
+        off = C.c_int64()
+        addr = int(table.data_ptr()) if isinstance(table, torch.Tensor) else int(table)
+        _check(eng._lib.gigl_ipc_export(eng._ctx, C.c_void_p(addr), h, C.byref(off)), eng._ctx)
+        mine = bytes(h) + int(off.value).to_bytes(8, "little")
+        got = [None] * world
+        dist.all_gather_object(got, mine, group=group)
+        addrs, bases = [], []
+        for r in range(world):
+            if r == rank:
+                addrs.append(addr)
+                continue
+            hb = (C.c_uint8 * _lib.IPC_HANDLE_BYTES).from_buffer_copy(got[r][:_lib.IPC_HANDLE_BYTES])
+            o = int.from_bytes(got[r][_lib.IPC_HANDLE_BYTES:], "little")
+            base, ptr = C.c_void_p(), C.c_void_p()
+            _check(eng._lib.gigl_ipc_open(eng._ctx, hb, o, C.byref(base), C.byref(ptr)), eng._ctx)
+            addrs.append(int(ptr.value))
+            bases.append(int(base.value))
+        return addrs, bases
+
+    @staticmethod
+    def close_shared(eng, bases: Sequence[int]) -> None:
+        for b in bases:
+            _check(eng._lib.gigl_ipc_close(eng._ctx, C.c_void_p(b)), eng._ctx)
 
     def run(self, roots: torch.Tensor, out: Optional[torch.Tensor] = None, sampling_seed: int = 42) -> torch.Tensor:
         assert roots.is_cuda and roots.dtype == torch.int32 and roots.numel() == self.b and roots.is_contiguous()

@@ -1355,6 +1355,18 @@ typedef struct gigl_dist_plan_opts {
                                 union, feature pull), then read the batch union graph (gigl_dist_plan_buffers) and its
                                 dense feature matrix (gigl_dist_plan_batch_features): what the trainer's collate hands
                                 the encoder (pyg_graph_builder.py:20-69), for a graph sharded over the ranks */
+  int32_t peer_direct;       /* 1: the PEER-MAPPED route of the feature pull — the first layer reads every source row where it
+                                lives: row v / world of rank (v % world)'s table, mapped into this process (hipIpc handles
+                                between processes: gigl_ipc_export / gigl_ipc_open; plain device pointers inside one) and
+                                handed over with gigl_dist_plan_set_peer_tables before the first step.  No claim, no id
+                                exchange, no owner-side gather, no receive buffer: the rows cross xGMI inside the
+                                aggregation kernel's loads, once per OCCURRENCE (per-call dedup goes with the buckets;
+                                replicated hot rows still stay local).  Same rows summed in the same order as the bucketed
+                                route: bit-identical results.  Needs the dense plan shape (SAGE layers, two hops, second
+                                fan-out <= 64, raw or pre-projected rows), < 2^31 nodes, world <= 64, and ranks whose memory
+                                is peer-accessible (one node).  Replaces the same chunked scatter / RPC feature lookup as
+                                the bucketed pull: dist_link_prediction_data_partitioner.py:560-664,
+                                distributed_neighborloader.py:162-192 */
 } gigl_dist_plan_opts;
 int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
                               const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,
@@ -1398,6 +1410,18 @@ int32_t gigl_dist_plan_run_local(gigl_dist_plan* const* plans, int32_t world, co
  * job replicates it at setup, e.g. the nodes that occur most often as in-neighbours).  Results are unchanged; needs
  * the plan's dense pull bookkeeping (two hops, raw rows; GIGL_E_INVALID_ARG otherwise).  n_hot = 0 clears the set. */
 int32_t gigl_dist_plan_set_hot_rows(gigl_dist_plan* plan, const uint32_t* hot_ids, int64_t n_hot, const void* hot_rows);
+/* peer-mapped plans (opts->peer_direct): tables[r] = rank r's table as a DEVICE pointer valid in THIS process — its feature
+ * rows, or its pre-projected [W_l x | W_r x] rows when the plan was created over `projected` — for r = 0 .. world-1 (HOST
+ * array; tables[rank] = the plan's own table).  Once, before the first step (a one-rank world needs no call). */
+int32_t gigl_dist_plan_set_peer_tables(gigl_dist_plan* plan, const void* const* tables);
+/* Sharing a device allocation with the other ranks' processes of the node (what gigl_dist_plan_set_peer_tables is fed
+ * with): export = (handle of the allocation dev_ptr lies in, dev_ptr's offset inside it) — ship both to the peers over any
+ * host channel (torch.distributed all_gather); open = map a peer's allocation into this process, *ptr = the peer's dev_ptr
+ * here, *base = what gigl_ipc_close takes when the plans that read it are gone.  HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf). */
+#define GIGL_IPC_HANDLE_BYTES 64
+int32_t gigl_ipc_export(gigl_ctx* ctx, const void* dev_ptr, void* handle /* HOST [GIGL_IPC_HANDLE_BYTES] */, int64_t* offset);
+int32_t gigl_ipc_open(gigl_ctx* ctx, const void* handle, int64_t offset, void** base, void** ptr);
+int32_t gigl_ipc_close(gigl_ctx* ctx, void* base);
 int32_t gigl_dist_plan_buffers(gigl_dist_plan* plan, gigl_tree* tree, gigl_union* un);
 /* staged plans, after the feature-pull phases of a step: x[i][0:d] (DEVICE fp32 [cap_nodes][d], d = the shard's feature
  * width) = the feature row of union node i for i < meta[GIGL_META_N_NODES] — own rows and rows pulled from their owners
