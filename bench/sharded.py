@@ -1,0 +1,856 @@
+"""bench/sharded.py — BASELINE configs[2]: the hash-partitioned MAG240M-shaped workload (gigl_dist_plan_*), over RCCL
+ranks (run_sharded) and as W emulated ranks in one process on one GPU (run_emulated_world)."""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import torch
+
+from .common import *  # noqa: F401,F403
+from .common import _LIVE_PMC  # noqa: F401
+from .cpu_baseline import run_cpu_baseline
+
+
+def run_sharded(args, rank, world, local_rank, sub=False):
+    """BASELINE.json configs[2]: MAG240M-shaped graph (N=244,160,499, E=1,728,364,232 directed RMAT, D=768 fp16,
+    SURVEY.md 8(d) C3) hash-partitioned over the ranks: rank r holds the CSC rows and feature rows of the nodes
+    with id % world == r.  A step = one batch of B roots per rank through the library's sharded plan
+    (gigl_dist_plan_*, csrc/dist.hip): per hop one all-to-all of (node, K) requests to the owners,
+    gigl_expand_frontier there, one all-to-all back; union graph locally; the UNIQUE node ids pulled from their owners
+    (rows gathered — or projected by the first layer, --project-on-owner — straight into the send buffer); 2-layer
+    GraphSAGE 768->256->256.  Every exchange is issued by the library over RCCL on the plan's stream and nothing in
+    a step reads the device from the host.  Several plans (ctx + stream + communicator each) are in flight: one host
+    thread issues their phases interleaved, in the same order on every rank, so one plan's exchange overlaps the
+    other's expansion / forward.  sub=True: called at the end of the N > 1 headline run for its `sharded` sub-record —
+    returns the record (rank 0) instead of printing it and leaves the process group alone."""
+    import torch.distributed as dist
+    from gigl_amd._lib import STATS, STATS_LEN
+    from gigl_amd.dist import Comm, DistSagePlan
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE
+
+    torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():  # single rank: RCCL with itself (same code path, the exchange is a device copy)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    eng = HipEngine(local_rank)
+    dev = eng.device
+    fanouts = [int(v) for v in args.fanouts.split(",")]
+    L = len(fanouts)
+    B, K, W = args.batch, max(1, args.steps), max(0, args.warmup)
+    if args.shard_scale <= 0.0:  # weak scaling: a rank's shard is 1/8 of MAG240M whatever the world size
+        args.shard_scale = min(1.0, world / 8.0)
+    n = max(int(244_160_499 * args.shard_scale), world * 1024)
+    e_total = max(int(1_728_364_232 * args.shard_scale), 1)
+    d, hid, out_dim = 768, 256, 256
+    t0 = time.time()
+    # ---- this rank's shard: every rank draws the same seeded edge chunks and keeps the edges it owns
+    scale_bits = max(int(np.ceil(np.log2(n))), 10)
+    chunk, keys = 1 << 26, []
+    for ci, c0 in enumerate(range(0, e_total, chunk)):
+        m = min(chunk, e_total - c0)
+        src, dst = rmat_edges_gpu(scale_bits, m, seed=3 + 7919 * ci, device=dev)
+        src = (src * 0x9E3779B1) % n
+        dst = (dst * 0x9E3779B1) % n
+        keep = (dst % world) == rank
+        keys.append(((dst[keep] // world) << 32) | src[keep])
+        del src, dst, keep
+    key = torch.unique(torch.cat(keys))  # sorted by (local row, src), duplicates dropped
+    del keys
+    n_local = (n - rank + world - 1) // world
+    rowptr = torch.zeros(n_local + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(key >> 32, minlength=n_local), 0)
+    col = (key & 0xFFFFFFFF).to(torch.int32)
+    maxdeg = torch.tensor([int((rowptr[1:] - rowptr[:-1]).max())], dtype=torch.int64, device=dev)
+    e_local = torch.tensor([int(col.numel())], dtype=torch.int64, device=dev)
+    all_reduce(maxdeg, dist.ReduceOp.MAX)
+    all_reduce(e_local, dist.ReduceOp.SUM)
+    eng.load_csc(rowptr, col)
+    # replicated hot rows (--shard-hot-frac): the nodes that occur most often as in-neighbours, the same set on every rank
+    hot_ids = None
+    hot_frac = float(args.shard_hot_frac)
+    if hot_frac < 0.0:
+        # auto (the default): hub-row replication ON whenever rows travel (world > 1) — the fraction of the nodes whose
+        # replicated rows fit in 4 % of the HBM still free after the shard is loaded, at most 5 %
+        if world == 1:
+            hot_frac = 0.0
+        else:
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            free_b -= ((n + world - 1) // world) * d * 2  # (the rank's feature rows are loaded below)
+            hot_frac = max(0.0, min(0.05, 0.04 * free_b / max(n * d * 2, 1)))
+        fr = torch.tensor([hot_frac], dtype=torch.float64, device=dev)
+        all_reduce(fr, dist.ReduceOp.MIN)  # the same set on every rank
+        hot_frac = float(fr.item())
+    n_hot = int(n * max(0.0, hot_frac))
+    if n_hot > 0:
+        occ = torch.bincount(col.to(torch.int64) & 0xFFFFFFFF, minlength=n).to(torch.int32)
+        all_reduce(occ, dist.ReduceOp.SUM)
+        hot_ids = torch.topk(occ.to(torch.int64) * (1 << 32) + (n - 1 - torch.arange(n, device=dev)), n_hot).indices
+        hot_ids = hot_ids.to(torch.int32).contiguous()  # (ties broken by id: identical on every rank)
+        del occ
+    del key, rowptr, col
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    x_local = torch.empty((n_local, d), device=dev, dtype=torch.float16)
+    step_rows = max(1, (1 << 28) // d)
+    for i in range(0, n_local, step_rows):
+        x_local[i:i + step_rows] = torch.randn((min(step_rows, n_local - i), d), generator=g, device=dev).to(torch.float16)
+    eng.load_features(x_local)
+    hot_rows = None
+    if hot_ids is not None:  # every rank contributes the rows it owns; the sum over ranks is the replicated table
+        hi = hot_ids.to(torch.int64) & 0xFFFFFFFF
+        mine_hot = (hi % world) == rank
+        hot_rows = torch.zeros((n_hot, d), device=dev, dtype=torch.float16)
+        hot_rows[mine_hot] = x_local[hi[mine_hot] // world]
+        all_reduce(hot_rows, dist.ReduceOp.SUM)
+    del x_local
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    gat = getattr(args, "shard_encoder", "sage") == "gat"
+    if gat:
+        from gigl_amd.models_attn import GAT
+        hid, out_dim = 128, 128
+        model = GAT(d, hid, out_dim, num_layers=L, heads=2).to(dev)
+        hot_ids = None  # (replicated hot rows belong to the SAGE plan's dense bookkeeping)
+        n_hot = 0
+    else:
+        model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
+        w, bs = model.fused_params()
+    # pre-projected rows: every rank projects ITS shard once ([W_l x | W_r x]); the pull then moves 1 KB W_l x rows
+    # instead of 1.5 KB raw rows and no step projects anything.  Timed, and charged to every step as 1 / (this rank's
+    # steps of a full pass over all nodes = N / (B * world)) of its duration
+    pre_s, proj_table = 0.0, None
+    if not gat and not args.project_on_owner and args.project_input != "off" and L == 2 and \
+            (args.project_input == "on" or model.projected_input_pays(eng)):
+        proj_table = torch.empty((n_local, 2 * hid), dtype=torch.float32, device=dev)
+        proj_table.zero_()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        eng.project_features(w[0], out=proj_table)
+        torch.cuda.synchronize()
+        pre_s = time.perf_counter() - tp
+        if hot_ids is not None:  # the replicas become W_l x rows: every rank contributes the rows it owns
+            hi = hot_ids.to(torch.int64) & 0xFFFFFFFF
+            mine_hot = (hi % world) == rank
+            hot_rows = torch.zeros((n_hot, hid), device=dev, dtype=torch.float32)
+            hot_rows[mine_hot] = proj_table[hi[mine_hot] // world, :hid]
+            all_reduce(hot_rows, dist.ReduceOp.SUM)
+    steps_per_pass = max(1, -(-n // (B * world)))
+    pre_per_step_s = pre_s / steps_per_pass
+    # every hash window ends below (hops+1)*n + seed*hops + maxdeg: lets the owners use the range table throughout
+    bound = (L + 1) * n + 42 * L + int(maxdeg.item())
+    mwe = bound if bound < (1 << 30) else -1
+    # G consecutive batches travel together: one set of exchanges and launches per G steps; the union graph keeps the
+    # batches apart (dedup within a batch only), so a step's edges are those of its batch
+    G, S = max(1, args.shard_group), max(1, args.shard_plans)
+    rnd = S * G
+    K_rep = K if (K >= rnd and K % rnd == 0) else max(-(-K // rnd), args.min_rounds) * rnd  # (bench/products.py: --steps)
+    Wp = -(-max(W, 1) // rnd) * rnd
+    N_SEG = 2
+    pool = Wp + N_SEG * K_rep
+    gp = torch.Generator(device="cpu")
+    gp.manual_seed(42)
+    perm = torch.randint(0, n, (pool * world * B,), generator=gp)
+    my = perm.view(pool * world, B)[rank::world].to(torch.int32).to(dev).contiguous().view(-1, G * B)  # [calls, G*B]
+
+    # the peer-mapped route: every rank's table (its pre-projected rows, else its feature rows) mapped into this process once
+    # (hipIpc handles through the process group); the plans read the rows in place
+    route_arg = getattr(args, "shard_route", "auto")
+    peer_ok = not gat and not args.project_on_owner and L == 2 and fanouts[1] <= 64 and n < (1 << 31) and world <= 64
+    peer_route = route_arg == "peer" or (route_arg in ("auto", "both") and peer_ok)
+    if route_arg == "peer" and not peer_ok:
+        raise SystemExit("bench.py: --shard-route peer needs the SAGE plan's dense shape (two hops, second fan-out <= 64, no "
+                         "owner-side projection) and fewer than 2^31 nodes")
+    peer_addrs, peer_bases, route_note = None, [], None
+    if peer_route and world > 1:
+        own = int(proj_table.data_ptr()) if proj_table is not None else int(eng._feat_ptr.value)
+        ok_t = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            peer_addrs, peer_bases = DistSagePlan.share_tables(eng, own)
+        except Exception as ex:  # noqa: BLE001 — (no peer access between these devices / processes)
+            ok_t.zero_()
+            route_note = f"{type(ex).__name__}: {str(ex)[:200]}"
+        all_reduce(ok_t, dist.ReduceOp.MIN)  # every rank takes the same route
+        if int(ok_t.item()) == 0:
+            if route_arg == "peer":
+                raise RuntimeError(f"--shard-route peer: mapping the peers' tables failed on some rank ({route_note})")
+            if peer_bases:
+                DistSagePlan.close_shared(eng, peer_bases)
+            peer_route, peer_addrs, peer_bases = False, None, []
+            route_note = "peer-mapped route not available here (" + (route_note or "another rank failed to map") + \
+                "): the bucketed route ran"
+
+    class Slot:  # one plan in flight: ctx + stream + communicator + plan
+        pass
+
+    def make_slots(pull_cap, pull_cap_b=0):
+        slots = []
+        for si in range(S):
+            sl = Slot()
+            sl.stream = torch.cuda.Stream(device=dev)
+            sl.eng = eng if si == 0 else HipEngine(local_rank)
+            if si:
+                sl.eng.share_resident(eng)
+            sl.eng.bind_stream(sl.stream)
+            sl.comm = Comm.from_torch(sl.eng)  # RCCL (nccl backend); the host-callback transport under gloo
+            if gat:
+                sl.plan = model.make_dist_plan(sl.comm, G * B, fanouts, group_roots=B, max_window_end=mwe, pull_cap=pull_cap)
+            else:
+                sl.plan = DistSagePlan(sl.comm, w, bs, G * B, fanouts, group_roots=B,
+                                       project_on_owner=args.project_on_owner, pull_cap=pull_cap, max_window_end=mwe,
+                                       projected=proj_table, pull_cap_b=pull_cap_b, peer_direct=peer_route)
+                if peer_route and world > 1:
+                    sl.plan.set_peer_tables(peer_addrs)
+            sl.out = sl.plan.new_out()
+            if hot_ids is not None:
+                sl.plan.set_hot_rows(hot_ids, hot_rows)
+            slots.append(sl)
+        return slots
+
+    def close_slots(slots):
+        for sl in slots:
+            sl.plan.close()
+            sl.comm.close()
+        for sl in reversed(slots[1:]):
+            sl.eng.close()
+
+    def run_calls(slots, lo, hi, acc=None):
+        """library calls lo..hi-1 (G batches each), S at a time: the phases of the S plans are issued interleaved by
+        this one thread — the same order on every rank"""
+        lib = slots[0].plan._lib
+        for c0 in range(lo, hi, S):
+            live = [(slots[j], my[c0 + j]) for j in range(min(S, hi - c0))]
+            nl = len(live)
+            # (gigl_dist_plan_run_interleaved: phase 0 of every plan in flight, then phase 1 of every plan, ... from C++)
+            pa = (C.c_void_p * nl)(*[sl.plan._plan for sl, _ in live])
+            ra = (C.c_void_p * nl)(*[r_.data_ptr() for _, r_ in live])
+            oa = (C.c_void_p * nl)(*[sl.out.data_ptr() for sl, _ in live])
+            rc = lib.gigl_dist_plan_run_interleaved(pa, nl, ra, 42, oa)
+            if rc != 0:
+                from gigl_amd._lib import check
+                check(rc, slots[0].eng._ctx)
+            if acc is not None:
+                for sl, _ in live:
+                    sl.plan.stats(acc)
+                    sl.plan.bucket_fill(fill_acc)
+
+    def sync_all(slots):
+        for sl in slots:
+            sl.stream.synchronize()
+
+    # ---- warm-up with default row buckets, then size them from what the warm-up saw (+10 %): rows are the bytes that
+    # matter on the links, so the send buffers should not be padded more than that
+    fill_acc = torch.zeros(4, dtype=torch.int64, device=dev)
+    slots = make_slots(0)
+    acc0 = torch.zeros(STATS_LEN, dtype=torch.int64, device=dev)
+    run_calls(slots, 0, Wp // G, acc0)
+    sync_all(slots)
+    most = acc0[STATS["pull_bucket_max"]:STATS["pull_bucket_max"] + 1].clone()
+    all_reduce(most, dist.ReduceOp.MAX)
+    if int(acc0[STATS["overflow"]].item()):
+        raise RuntimeError("bucket overflow during warm-up")
+    pull_cap = int(int(most.item()) * 1.1) + 64
+    most_b = fill_acc[2:3].clone()
+    all_reduce(most_b, dist.ReduceOp.MAX)
+    pull_cap_b = int(int(most_b.item()) * 1.1) + 64 if proj_table is not None else 0
+    close_slots(slots)
+    slots = make_slots(pull_cap, pull_cap_b)
+    run_calls(slots, 0, Wp // G)
+    sync_all(slots)
+    setup_s = time.time() - t0
+
+    def seg_calls(r):
+        lo = (Wp + (r % N_SEG) * K_rep) // G
+        return lo, lo + K_rep // G
+
+    # ---- untimed: exact counts of the pool segments (sampling is deterministic)
+    seg_acc = torch.zeros((N_SEG, STATS_LEN), dtype=torch.int64, device=dev)
+    for sg in range(N_SEG):
+        run_calls(slots, *seg_calls(sg), acc=seg_acc[sg])
+    sync_all(slots)
+    seg_stats = seg_acc.cpu().numpy().astype(np.float64)
+    if seg_stats[:, STATS["overflow"]].any():
+        raise RuntimeError("bucket overflow in a benchmark batch: rerun with a larger --shard-group slack")
+    # ---- calibration repetition, then the timed region
+    torch.cuda.synchronize()
+    tc = time.perf_counter()
+    run_calls(slots, *seg_calls(0))
+    sync_all(slots)
+    t_cal = time.perf_counter() - tc
+    rr = torch.tensor([int(min(max(np.ceil(args.min_seconds / max(t_cal, 1e-6)), args.min_reps), 2000))],
+                      dtype=torch.int64, device=dev)
+    all_reduce(rr, dist.ReduceOp.MAX)
+    reps = int(rr.item())
+    rep_s = []
+    moved0 = [sl.comm.traffic() for sl in slots]  # (bytes this rank's communicators put on the links so far)
+    for r in range(reps):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_calls(slots, *seg_calls(r))
+        sync_all(slots)
+        torch.cuda.synchronize()
+        rep_s.append(time.perf_counter() - t1)
+    dist.barrier()
+    moved1 = [sl.comm.traffic() for sl in slots]
+    moved_t = torch.tensor([sum(b_[0] - a_[0] for a_, b_ in zip(moved0, moved1)),
+                            sum(b_[1] - a_[1] for a_, b_ in zip(moved0, moved1))], dtype=torch.float64, device=dev)
+    moved_max = moved_t.clone()
+    all_reduce(moved_t, dist.ReduceOp.SUM)
+    all_reduce(moved_max, dist.ReduceOp.MAX)
+    comm_ranks, comm_kind = slots[0].comm.world, slots[0].comm.kind  # (from the communicator: gigl_comm_info)
+    # ---- per-kernel HIP-event times of one more (untimed) repetition: the library's timers on every plan's ctx; the
+    # plans stay interleaved as in the timed region, so an interval includes what the other plans' kernels took from it
+    prof_names = ["expand", "union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr", "gather_mean",
+                  "linear", "dist_prep", "dist_serve"]
+    for sl in slots:
+        sl.eng.profile_enable(prof_names, capacity=8192)
+        sl.eng.profile_reset()
+    run_calls(slots, *seg_calls(0))
+    sync_all(slots)
+    prof_sh = {k: [sum(x) for x in zip(*[sl.eng.profile_read(k) for sl in slots])] for k in prof_names}
+    for sl in slots:
+        sl.eng.profile_enable([], 0)
+    dist.barrier()
+    rep_t = torch.tensor(rep_s, dtype=torch.float64, device=dev)
+    all_reduce(rep_t, dist.ReduceOp.MAX)
+    seg_use = np.array([sum(1 for r in range(reps) if r % N_SEG == sg) for sg in range(N_SEG)], dtype=np.float64)
+    tot = torch.tensor((seg_stats * seg_use[:, None]).sum(0), dtype=torch.float64, device=dev)
+    if peer_route:
+        # the rows of the peer-mapped route never pass through the transport: they cross the links inside the first layer's
+        # loads, one row per occurrence that is neither this rank's nor replicated (counted on the device: PULLED_ROWS)
+        rb_ = hid * 4 if proj_table is not None else d * 2
+        mine = float(tot[STATS["pulled_rows"]].item()) * rb_
+        add_t = torch.tensor([mine, mine], dtype=torch.float64, device=dev)
+        add_m = add_t.clone()
+        all_reduce(add_t, dist.ReduceOp.SUM)
+        all_reduce(add_m, dist.ReduceOp.MAX)
+        moved_t += add_t
+        moved_max += add_m
+    all_reduce(tot, dist.ReduceOp.SUM)
+    tot = tot.cpu().numpy()
+    rep_np = rep_t.cpu().numpy() + K_rep * pre_per_step_s  # (+ every step's share of the shard projection, if any)
+    elapsed = float(rep_np.sum())
+    steps_total = reps * K_rep
+    sampled_all, aggregated_all = float(tot[STATS["sampled"]]), float(tot[STATS["aggregated"]])
+    pulled_all = float(tot[STATS["pulled_rows"]])
+    row_bytes = hid * 4 if (args.project_on_owner or proj_table is not None) else d * 2
+    ms_rep = rep_np / K_rep * 1e3
+    if rank == 0:
+        q = lambda a, p: float(np.percentile(a, p))
+        sent_per_step = world * pull_cap * row_bytes * (2 if args.project_on_owner else 1) / G  # (approx. for B rows)
+        line = {
+            "metric": "sampled+aggregated edges/s", "value": (sampled_all + aggregated_all) / elapsed,
+            "unit": "edges/s", "n_gpus": world, "steps": K_rep, "warmup": Wp,
+            "ms_per_step": elapsed / steps_total * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "steps_requested": K, "warmup_requested": W,
+            "steps_honoured": K_rep == K, "warmup_honoured": Wp == W, "steps_total": steps_total,
+            # the communicator's own view (gigl_comm_info / gigl_comm_traffic), not WORLD_SIZE: how many ranks the
+            # exchanges of the timed region ran between, through which transport, and the bytes they put on the links
+            "rccl_ranks": int(comm_ranks) if comm_kind == 0 else 0,
+            "comm": {"ranks": int(comm_ranks),
+                     "transport": {0: "rccl", 1: "in-process", 2: "host-callback"}.get(int(comm_kind), str(comm_kind)),
+                     "xgmi_bytes_per_step_per_gpu_mean": float(moved_t[0].item()) / max(steps_total * world, 1),
+                     "xgmi_bytes_per_step_busiest_gpu": float(moved_max[0].item()) / max(steps_total, 1),
+                     "xgmi_bytes_per_step_had_blocks_been_full": float(moved_t[1].item()) / max(steps_total * world, 1),
+                     "measured": "gigl_comm_traffic over the timed region: bytes sent to OTHER ranks by this rank's "
+                                 "communicators (all plans in flight); 0 at one rank"
+                                 + ("; + the rows the peer-mapped first layer read from other ranks' tables (counted on the "
+                                    "device, one per occurrence) x their size" if peer_route else "")},
+            "timing": {"repetitions": reps, "steps_per_repetition": K_rep, "timed_region_s": round(elapsed, 3),
+                       "ms_per_step_median": q(ms_rep, 50), "ms_per_step_p10": q(ms_rep, 10),
+                       "ms_per_step_p90": q(ms_rep, 90)},
+            "config": {"workload": f"MAG240M-shaped RMAT x{args.shard_scale:g}: N={n} E={int(e_local.item())} directed, "
+                                   f"D={d} fp16 features, hash-partitioned over {world} rank(s) (owner = id % world), "
+                                   f"fanout={fanouts} B={B}/GPU "
+                                   f"{'GAT heads 2 ' if gat else 'GraphSAGE '}{d}->{hid}->{out_dim}, sampler mode=parity, "
+                                   f"{G} batches per exchange, {S} plans in flight, "
+                                   f"{'%.3g %% of the nodes replicated as hot rows, ' % (100 * hot_frac) if n_hot else ''}"
+                                   + ("rows projected on the owner (256 fp32)" if args.project_on_owner else
+                                      "rows pre-projected once per rank (256 fp32 W_l x rows pulled)" if proj_table is not None
+                                      else "raw rows (768 fp16)")
+                                   + (", peer-mapped feature route (rows read in place from the owners' tables)" if peer_route else ""),
+                       "feature_route": "peer" if peer_route else "bucketed", "feature_route_note": route_note,
+                       "projected_input": (None if proj_table is None else {
+                           "precompute_s": round(pre_s, 4), "steps_per_pass_per_rank": steps_per_pass,
+                           "charged_ms_per_step": pre_per_step_s * 1e3}),
+                       "graph": "CSC rows + feature rows of the owned nodes per rank; per-hop all-to-all frontier "
+                                "exchange and feature pull of the unique union-graph nodes, issued by the library "
+                                "(gigl_dist_plan, RCCL)",
+                       "sampled_edges_per_step": sampled_all / (steps_total * world),
+                       "aggregated_edges_per_step": aggregated_all / (steps_total * world),
+                       "pulled_feature_rows_per_step": pulled_all / (steps_total * world),
+                       "pulled_feature_bytes_per_s": pulled_all * row_bytes / elapsed,
+                       "row_bucket_rows_per_peer": pull_cap,
+                       "row_bytes_sent_per_step_per_rank": sent_per_step,
+                       "row_bucket_fill": None if peer_route else pulled_all / (steps_total * world) / max(world * pull_cap / G, 1),
+                       "setup_s": round(setup_s, 1)},
+            "roofline": None, "cpu_baseline": None,
+        }
+        # ---- roofline of the dominant kernel group (this rank's segment-0 repetition, counted on the device): the byte
+        # model of the single-GPU line; layer 0 reads pre-projected fp32 rows of `hid` columns when the
+        # table was projected, stored fp16 rows of D otherwise
+        if not gat:
+            st0 = seg_stats[0]
+            agg0, agg1 = st0[STATS["agg_layer0"]], st0[STATS["agg_layer0"] + 1]
+            rows0, rows1 = st0[STATS["rows_layer0"]], st0[STATS["rows_layer0"] + 1]
+            if proj_table is not None or args.project_on_owner:
+                b_gather = agg0 * (4 + hid * 4) + rows0 * (8 + 2 * hid * 4)
+            else:
+                b_gather = agg0 * (4 + d * 2) + rows0 * (8 + d * 2 + 2 * d * 4)
+            b_gather += agg1 * (4 + hid * 4) + rows1 * (8 + hid * 4)
+            byk = {k: {"ms_per_step": round(v[0] / K_rep, 5), "launches": int(v[1])} for k, v in prof_sh.items() if v[0] > 0}
+            if byk:
+                dom = max(byk, key=lambda k: byk[k]["ms_per_step"])
+                if "gather_mean" in byk:
+                    gm = byk["gather_mean"]
+                    gm.update(bound="hbm", achieved=round(b_gather / K_rep / (gm["ms_per_step"] * 1e-3) / 1e9, 1),
+                              peak=HBM_PEAK_GBS, unit="GB/s")
+                    gm["frac"] = round(gm["achieved"] / HBM_PEAK_GBS, 4)
+                hk = byk.get("gather_mean", byk[dom])
+                line["roofline"] = {
+                    "bound": "hbm", "kernel": "gather_mean", "achieved": hk.get("achieved"), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": hk.get("frac"), "traffic": None, "dominant": dom,
+                    "alg_bytes_per_launch": round(b_gather / max(hk["launches"], 1)),
+                    "avg_launch_us": round(hk["ms_per_step"] * K_rep / max(hk["launches"], 1) * 1e3, 2),
+                    "launches": hk["launches"],
+                    "timing": f"HIP events on the plans' streams over one untimed repetition of the timed calls ({S} plans "
+                              "in flight: intervals include overlap with the other plans' kernels)",
+                    "by_kernel": byk}
+        # ---- second roofline: xGMI.  Bytes a rank puts on its links per step = what it sends to the
+        # other world-1 ranks: per hop the request buckets (8 B per entry) and, as an owner, the answer buckets
+        # (4*f B per entry); then the id buckets of the feature pull (4 B) and the row buckets.  Buckets travel whole
+        # (fixed capacity, equal split), so `sent` counts padding; `payload` counts the requested entries only.
+        step_s = elapsed / steps_total
+        peers = world - 1
+        m_k, hop_sent = G * B, 0.0
+        for f in fanouts:
+            cap_k = m_k if world <= 2 else min(m_k, int(1.5 * m_k / world) + 512)
+            hop_sent += peers * cap_k * (8 + 4 * f)
+            m_k *= f
+        rows_sent = peers * pull_cap * (row_bytes + 4) * (2 if args.project_on_owner else 1) + \
+            peers * pull_cap_b * (row_bytes + 4)
+        sent_step = (hop_sent + rows_sent) / G
+        payload_step = pulled_all / (steps_total * world) * (row_bytes + 4) + \
+            sampled_all / (steps_total * world) * 4 * peers / max(world, 1)
+        peak_gbs = 7 * 153.0
+        line["roofline_xgmi"] = {
+            "bound": "xgmi", "peak": peak_gbs, "unit": "GB/s per GPU (7 links x 153 GB/s)",
+            "sent_bytes_per_step_per_gpu": sent_step, "payload_bytes_per_step_per_gpu": payload_step,
+            "achieved": sent_step / step_s / 1e9, "frac": sent_step / step_s / 1e9 / peak_gbs,
+            "payload_achieved": payload_step / step_s / 1e9, "links_in_use": min(peers, 7),
+            "transport": ("RCCL ncclSend / ncclRecv groups issued by the library" if dist.get_backend() == "nccl"
+                          else "host callback over " + dist.get_backend() + " (functional check, not xGMI)"),
+            "ranks": world}
+        if world == 1 and not gat and not args.no_cpu_baseline and not sub:
+            # (one rank: the shard is the whole graph, so the single-GPU line's CPU port applies as it is — the oracle
+            # sampler + collate and the fp32 CPU forward over full batches of this graph; at N > 1 no host holds the graph)
+            one, allc = run_cpu_baseline(eng, model, my.view(-1, B), fanouts, Wp, n, d)
+            line["cpu_baseline"], line["cpu_baseline_all_cores"] = one, allc
+        if not sub:
+            emit(line)
+    else:
+        line = None
+    dist.barrier()
+    close_slots(slots)
+    if peer_bases:
+        dist.barrier()  # (nobody unmaps a table a peer still reads)
+        DistSagePlan.close_shared(eng, peer_bases)
+    if not sub:
+        dist.destroy_process_group()
+    eng.close()
+    return line
+
+
+def run_emulated_world(args, local_rank=0, sub=False):
+    """BASELINE configs[2] without an 8-GPU node: all W ranks of the hash-partitioned job as ctxs of ONE process on one
+    GPU (gigl_dist_init_local: the in-process transport the parity tests use — every exchange is a device copy), at the
+    largest MAG240M-shaped scale the GPU holds.  The step's CODE is the multi-GPU step's (gigl_dist_plan_run_local issues
+    every rank's phases in the order the ranks would), so what each rank would put on its links is MEASURED: pulled rows /
+    bytes per rank and step, bucket fill (padding), what hub-row replication takes off the links, and the per-rank
+    compute time (the W ranks' kernels share this GPU: time of a step of all ranks / W).  What is NOT measured is xGMI:
+    `projection` combines the measured bytes with 7 links x 153 GB/s per GPU and says so."""
+    from gigl_amd._lib import STATS, STATS_LEN
+    from gigl_amd.dist import Comm, DistSagePlan
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE
+
+    W = int(args.emulate_world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    fanouts = [int(v) for v in args.fanouts.split(",")]
+    L = len(fanouts)
+    B, G = args.batch, max(1, args.shard_group)
+    d, hid, out_dim = 768, 256, 256
+    t0 = time.time()
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    # stored row + pre-projected row + the sampler's threshold table over (hops + 1) * N + graph + the plans' id-indexed pull
+    # bookkeeping (8 B per node and plan); half of the free memory: workspaces and the generator's temporaries need the rest
+    per_node = d * 2 + 2 * hid * 4 + 13 * (L + 1) + 64 + 8 * W * (1 + max(0, int(getattr(args, "emulate_streams", 0))))
+    scale = args.shard_scale if args.shard_scale > 0 else min(1.0, 0.5 * free_b / per_node / 244_160_499)
+    n = max(int(244_160_499 * scale), W * 1024)
+    e_total = max(int(1_728_364_232 * scale), 1)
+    scale_bits = max(int(np.ceil(np.log2(n))), 10)
+    # ---- every rank's shard (the generator of run_sharded: same seeded chunks, each edge to the owner of its destination)
+    keys = [[] for _ in range(W)]
+    chunk = 1 << 26
+    for ci, c0 in enumerate(range(0, e_total, chunk)):
+        m = min(chunk, e_total - c0)
+        src, dst = rmat_edges_gpu(scale_bits, m, seed=3 + 7919 * ci, device=dev)
+        src = (src * 0x9E3779B1) % n
+        dst = (dst * 0x9E3779B1) % n
+        for r in range(W):
+            keep = (dst % W) == r
+            keys[r].append(((dst[keep] // W) << 32) | src[keep])
+        del src, dst
+    engs, n_local, maxdeg, e_sum = [], [], 0, 0
+    occ = torch.zeros(n, dtype=torch.int32, device=dev)
+    for r in range(W):
+        key = torch.unique(torch.cat(keys[r]))
+        keys[r] = None
+        nl = (n - r + W - 1) // W
+        rowptr = torch.zeros(nl + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(key >> 32, minlength=nl), 0)
+        col = (key & 0xFFFFFFFF).to(torch.int32)
+        maxdeg = max(maxdeg, int((rowptr[1:] - rowptr[:-1]).max()))
+        e_sum += int(col.numel())
+        occ += torch.bincount(col.to(torch.int64) & 0xFFFFFFFF, minlength=n).to(torch.int32)
+        eng = HipEngine(local_rank)
+        eng.load_csc(rowptr, col)
+        engs.append(eng)
+        n_local.append(nl)
+        del key, rowptr, col
+    torch.manual_seed(0)
+    model = GraphSAGE(d, hid, out_dim, num_layers=L).to(dev)
+    w, bs = model.fused_params()
+    hot_frac = 0.01 if args.shard_hot_frac < 0 else float(args.shard_hot_frac)
+    n_hot = int(n * hot_frac)
+    hot_ids = None
+    if n_hot > 0:
+        hot_ids = torch.topk(occ.to(torch.int64) * (1 << 32) + (n - 1 - torch.arange(n, device=dev)), n_hot).indices
+        hot_ids = hot_ids.to(torch.int32).contiguous()
+    del occ
+    use_proj = args.project_input != "off" and L == 2
+    proj, pre_s = [], 0.0
+    hot_rows = torch.zeros((n_hot, hid if use_proj else d), device=dev, dtype=torch.float32 if use_proj else torch.float16) \
+        if n_hot else None
+    step_rows = max(1, (1 << 28) // d)
+    for r in range(W):
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + r)
+        x_local = torch.empty((n_local[r], d), device=dev, dtype=torch.float16)
+        for i in range(0, n_local[r], step_rows):
+            x_local[i:i + step_rows] = torch.randn((min(step_rows, n_local[r] - i), d), generator=g, device=dev).to(torch.float16)
+        engs[r].load_features(x_local)
+        pt = None
+        if use_proj:
+            pt = torch.empty((n_local[r], 2 * hid), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            engs[r].project_features(w[0], out=pt)
+            torch.cuda.synchronize()
+            pre_s = max(pre_s, time.perf_counter() - tp)
+        proj.append(pt)
+        if n_hot:
+            hi = hot_ids.to(torch.int64) & 0xFFFFFFFF
+            mine = (hi % W) == r
+            hot_rows[mine] = (pt[hi[mine] // W, :hid] if use_proj else x_local[hi[mine] // W])
+        del x_local
+    torch.cuda.empty_cache()
+    bound = (L + 1) * n + 42 * L + maxdeg
+    mwe = bound if bound < (1 << 30) else -1
+    comms = Comm.local(engs)
+    K = max(4, min(args.steps // G, 24))  # calls (G batches per rank each) per measurement
+    gp = torch.Generator(device="cpu")
+    gp.manual_seed(42)
+    roots = torch.randint(0, n, ((K + 2) * W, G * B), generator=gp).to(torch.int32).to(dev)
+
+    def make_plans(pull_cap, pull_cap_b, hot, route="bucketed", cms=None):
+        cms = cms if cms is not None else comms
+        peer = route == "peer"
+        plans = [DistSagePlan(cms[r], w, bs, G * B, fanouts, group_roots=B, pull_cap=pull_cap, max_window_end=mwe,
+                              projected=proj[r], pull_cap_b=pull_cap_b, peer_direct=peer) for r in range(W)]
+        if peer:  # every rank's table is a pointer of this process
+            tables = [pl.own_table() for pl in plans]
+            for pl in plans:
+                pl.set_peer_tables(tables)
+        if hot and n_hot:
+            for pl in plans:
+                pl.set_hot_rows(hot_ids, hot_rows)
+        return plans
+
+    def run_calls(plans, lo, hi, accs=None, fills=None):
+        outs = [pl.new_out() for pl in plans]
+        for c in range(lo, hi):
+            DistSagePlan.run_local(plans, [roots[c * W + r] for r in range(W)], outs)
+            if accs is not None:
+                for r, pl in enumerate(plans):
+                    pl.stats(accs[r])
+                    pl.bucket_fill(fills[r])
+        torch.cuda.synchronize()
+
+    traffic = []  # per rank: [moved, full-block] bytes per step of the last measurement
+    ktime = {}    # kernel group -> [ms, launches] summed over the W ranks, last measurement
+    EMU_PROF = ["expand", "expand_heavy", "union_insert", "union_relax", "union_nodes", "union_edge_sort", "union_csr",
+                "gather_mean", "linear", "dist_prep", "dist_serve"]
+
+    def measure_overlapped(hot, route, pull_cap, pull_cap_b):
+        """the per-rank step with a rank's kernels OVERLAPPING as they would on its own GPU: S emulated worlds in flight,
+        each on its own stream, a call (G batches of every one of its W ranks, exchanges included) captured once and
+        replayed as one hipGraph — the launch queue never runs dry, so wall time / (calls x G x W) is the time a GPU
+        spends per rank-step.  The in-process transport's device copies are inside (they read and write the bytes RCCL's
+        send / receive would on a rank's own HBM — whole blocks: count-sized ones need a host read, gigl_comm_set_fixed_blocks);
+        link time is not."""
+        S = max(1, int(args.emulate_streams))
+        worlds = []
+        for s_ in range(S):
+            st_ = torch.cuda.Stream(device=dev)
+            es = []
+            for r in range(W):
+                e_ = HipEngine(local_rank)
+                e_.share_resident(engs[r])
+                e_.bind_stream(st_)
+                es.append(e_)
+            cms = Comm.local(es)
+            for c_ in cms:
+                c_.set_fixed_blocks(True)
+            pls = make_plans(pull_cap, pull_cap_b, hot, route, cms)
+            rts = [torch.empty(G * B, dtype=torch.int32, device=dev) for _ in range(W)]
+            outs = [pl.new_out() for pl in pls]
+            with torch.cuda.stream(st_):
+                for c in range(2):  # eager warm-up: every ctx's arena reaches its size before the capture
+                    for r in range(W):
+                        rts[r].copy_(roots[c * W + r])
+                    DistSagePlan.run_local(pls, rts, outs)
+            st_.synchronize()
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, stream=st_, capture_error_mode="thread_local"):
+                DistSagePlan.run_local(pls, rts, outs)
+            worlds.append((st_, es, cms, pls, rts, outs, g_))
+
+        def go(lo, hi):
+            for c in range(lo, hi):
+                st_, _, _, _, rts, _, g_ = worlds[c % S]
+                with torch.cuda.stream(st_):
+                    for r in range(W):
+                        rts[r].copy_(roots[(c % (K + 2)) * W + r], non_blocking=True)
+                    g_.replay()
+        go(0, 2 * S)
+        torch.cuda.synchronize()
+        n_calls = max(3 * S, ((K * 2) // S) * S)
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            go(0, n_calls)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        over = any(pl.overflowed() for _, _, _, pls, _, _, _ in worlds for pl in pls)
+        for st_, es, cms, pls, rts, outs, g_ in worlds:
+            del g_
+            for pl in pls:
+                pl.close()
+            for c_ in cms:
+                c_.close()
+            for e_ in reversed(es):
+                e_.close()
+        if over:
+            raise RuntimeError("bucket overflow in the overlapped emulated world")
+        return {"streams": S, "calls": n_calls, "ms_per_rank_step": float(np.median(ts)) / (n_calls * G * W) * 1e3,
+                "ms_per_rank_step_all": [round(t / (n_calls * G * W) * 1e3, 6) for t in ts]}
+
+    def measure(hot, route="bucketed"):
+        # bucket capacities from two warm-up calls (+10 %), as the multi-process bench does
+        pull_cap = pull_cap_b = 0
+        if route != "peer":
+            acc0 = [torch.zeros(STATS_LEN, dtype=torch.int64, device=dev) for _ in range(W)]
+            fill0 = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(W)]
+            plans = make_plans(0, 0, hot)
+            run_calls(plans, 0, 2, acc0, fill0)
+            if any(int(a[STATS["overflow"]]) for a in acc0):
+                raise RuntimeError("bucket overflow during the emulated world's warm-up")
+            pull_cap = int(max(int(a[STATS["pull_bucket_max"]]) for a in acc0) * 1.1) + 64
+            pull_cap_b = (int(max(int(f[2]) for f in fill0) * 1.1) + 64) if use_proj else 0
+            for pl in plans:
+                pl.close()
+        plans = make_plans(pull_cap, pull_cap_b, hot, route)
+        run_calls(plans, 0, 2)
+        accs = [torch.zeros(STATS_LEN, dtype=torch.int64, device=dev) for _ in range(W)]
+        fills = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(W)]
+        run_calls(plans, 2, 2 + K, accs, fills)  # counted (untimed)
+        torch.cuda.synchronize()
+        tr0 = np.array([c.traffic() for c in comms], dtype=np.float64)
+        t1 = time.perf_counter()
+        run_calls(plans, 2, 2 + K)               # timed: all W ranks' steps on this one GPU
+        dt = time.perf_counter() - t1
+        # bytes each rank handed to the transport for OTHER ranks over the timed calls (gigl_comm_traffic): as moved —
+        # the feature-row blocks at the size of their request counts — and as full-capacity blocks would have been
+        traffic.clear()
+        traffic.extend(((np.array([c.traffic() for c in comms], dtype=np.float64) - tr0) / (K * G)).tolist())
+        # ---- the ranks' own KERNEL time (untimed repetition, every HIP-event timer of the library on): the W ranks share
+        # one stream here, so an interval is its kernels' duration (+ the host's gap between the two event records when
+        # the launch queue runs dry, which it does: an upper bound).  The in-process transport's device copies stand in
+        # for RCCL and are not kernels of a rank: not counted.
+        for e_ in engs:
+            e_.profile_enable(EMU_PROF, capacity=(K + 2) * 64)
+            e_.profile_reset()
+        run_calls(plans, 2, 2 + K)
+        kt = {k: [sum(x) for x in zip(*[e_.profile_read(k) for e_ in engs])] for k in EMU_PROF}
+        for e_ in engs:
+            e_.profile_enable([], 0)
+        ktime.clear()
+        ktime.update({k: v for k, v in kt.items() if v[0] > 0})
+        st = np.stack([a.cpu().numpy().astype(np.float64) for a in accs])
+        fl = np.stack([f.cpu().numpy().astype(np.float64) for f in fills])
+        if st[:, STATS["overflow"]].any():
+            raise RuntimeError("bucket overflow in the emulated world")
+        for pl in plans:
+            pl.close()
+        return st, fl, dt, pull_cap, pull_cap_b
+
+    row_bytes = hid * 4 if use_proj else d * 2
+    steps = K * G  # steps per rank in a measurement
+    res = {}
+    route_arg = getattr(args, "shard_route", "auto")
+    routes = ["bucketed", "peer"] if route_arg in ("auto", "both") else [route_arg]
+    cases = []
+    for route in routes:
+        pre = "" if route == "bucketed" else "peer_"
+        if n_hot:
+            cases.append((pre + "hot_rows", True, route))
+        if not n_hot or route == "bucketed":
+            cases.append((pre + "no_replication", False, route))
+    for tag, hot, route in cases:
+        st, fl, dt, pull_cap, pull_cap_b = measure(hot, route)
+        overlapped = None
+        if int(getattr(args, "emulate_streams", 0)) > 0 and (hot or not n_hot):
+            overlapped = measure_overlapped(hot, route, pull_cap, pull_cap_b)
+        # bucketed: rows REQUESTED (one per unique id and call); peer: rows READ from other ranks' tables (per occurrence)
+        pulled = st[:, STATS["pulled_rows"]] / steps  # rows per step, per rank
+        # what a rank sends as an OWNER (= what it receives as a requester, by symmetry of the measured totals): the row
+        # buckets travel whole (fixed capacity, equal split): W - 1 peers x capacity x (row + id) per call
+        sent_rows_bytes = (W - 1) * (pull_cap + pull_cap_b) * (row_bytes + 4) / G
+        m_k, hop_bytes = G * B, 0.0
+        for f in fanouts:
+            cap_k = min(m_k, int(1.5 * m_k / W) + 512)
+            hop_bytes += (W - 1) * cap_k * (8 + 4 * f)
+            m_k *= f
+        hop_bytes /= G
+        payload = pulled * (row_bytes + 4)
+        compute_ms = dt / (K * G * W) * 1e3
+        # kernel time per rank-step by group (HIP events), and the byte model of the dominant one (as run_sharded's)
+        kg = {k: round(v[0] / (K * G * W), 6) for k, v in ktime.items()}
+        kernel_ms = float(sum(kg.values()))
+        agg0 = st[:, STATS["agg_layer0"]].sum() / (steps * W)
+        agg1 = st[:, STATS["agg_layer0"] + 1].sum() / (steps * W)
+        rows0 = st[:, STATS["rows_layer0"]].sum() / (steps * W)
+        rows1 = st[:, STATS["rows_layer0"] + 1].sum() / (steps * W)
+        b_gather = (agg0 * (4 + hid * 4) + rows0 * (8 + 2 * hid * 4) if use_proj else
+                    agg0 * (4 + d * 2) + rows0 * (8 + d * 2 + 2 * d * 4)) + agg1 * (4 + hid * 4) + rows1 * (8 + hid * 4)
+        gm_ms = kg.get("gather_mean", 0.0)
+        tr = np.array(traffic, dtype=np.float64)  # [W, 2]
+        if route == "peer":  # the rows never pass through the transport: they cross the links inside the first layer's loads
+            tr = tr + (pulled * row_bytes)[:, None]
+        moved_step, full_step = float(tr[:, 0].max()), float(tr[:, 1].max())  # the busiest rank's
+        per_link = moved_step / (W - 1)  # bytes per peer pair and step: one xGMI link each (W <= 8)
+        link_ms = per_link / 153e9 * 1e3
+        edges_step = (st[:, STATS["sampled"]] + st[:, STATS["aggregated"]]).sum() / (steps * W)
+        ov_ms = overlapped["ms_per_rank_step"] if overlapped else None
+        res[tag] = {
+            "route": route,
+            "route_is": ("peer-mapped: the first layer reads rows in place from the owners' tables (no claim / id exchange / "
+                         "owner-side gather / row exchange); `pulled_rows` = rows read from OTHER ranks' tables, per occurrence"
+                         if route == "peer" else
+                         "bucketed: claim once per call -> id exchange -> owners gather -> count-sized row exchange -> receive "
+                         "buffer; `pulled_rows` = rows requested, one per unique id and call"),
+            "overlapped": overlapped,
+            "pulled_rows_per_step_per_rank": [round(float(v), 1) for v in pulled],
+            "pulled_rows_per_step_mean": float(pulled.mean()),
+            "row_payload_bytes_per_step_per_rank": float(payload.mean()),
+            "bytes_sent_per_step_per_rank": [round(float(v)) for v in tr[:, 0]],
+            "bytes_sent_per_step_busiest_rank": moved_step,
+            "bytes_sent_with_full_blocks_busiest_rank": full_step,
+            "exchange_sizes": "measured by the transport (gigl_comm_traffic) over the timed calls: the feature-row blocks "
+                              "travel at the size of their request counts (the counts ride with the id request), the id / "
+                              "neighbour blocks of the hops and the id buckets at their fixed capacity",
+            "row_bytes_at_full_capacity_per_step_per_rank": float(sent_rows_bytes),
+            "hop_exchange_bytes_sent_per_step_per_rank": float(hop_bytes),
+            "row_bucket_capacity_per_peer": [pull_cap, pull_cap_b],
+            # occupied entries of the row buckets / their capacity, summed over the W - 1 peers (gigl_dist_plan_bucket_fill:
+            # first pull, and the W_r x pull of a pre-projected plan): 1 - fill is padding that would travel over xGMI
+            "row_bucket_fill": float((fl[:, 1].sum() + fl[:, 3].sum()) /
+                                     max(K * W * (W - 1) * (pull_cap + pull_cap_b), 1)),
+            "row_bucket_fill_fullest": float(max(fl[:, 0].max() / max(pull_cap, 1),
+                                                 fl[:, 2].max() / max(pull_cap_b, 1) if pull_cap_b else 0.0)),
+            "rows_in_buckets_per_step_per_rank": float((fl[:, 1].sum() + fl[:, 3].sum()) / (K * G * W)),
+            "sampled_plus_aggregated_edges_per_step_per_rank": float(edges_step),
+            "wall_ms_per_step_per_rank": compute_ms,
+            "kernel_ms_per_step_per_rank": kernel_ms,
+            "kernel_ms_by_group": kg,
+            "sharded_only_kernel_share": round((kg.get("dist_prep", 0.0) + kg.get("dist_serve", 0.0)) / max(kernel_ms, 1e-12), 4),
+            "roofline": {"bound": "hbm", "kernel": "gather_mean", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "achieved": round(b_gather / max(gm_ms * 1e-3, 1e-12) / 1e9, 1),
+                         "frac": round(b_gather / max(gm_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS, 4),
+                         "alg_bytes_per_rank_step": round(b_gather), "ms_per_rank_step": gm_ms,
+                         "timing": "HIP events around the rank's launches; one stream for all W ranks: kernels run alone"},
+            "measured": "all of the above: counted on the device / timed on this GPU with the W ranks sharing it.  wall_ms = "
+                        "host wall clock of eager launches, one plan per rank, phases of the W ranks issued in turn by one "
+                        "host thread (host-bound: the GPU idles most of it); kernel_ms = the HIP-event time of the ranks' own "
+                        "kernels (an upper bound of the kernel time: profiles/r05*_emulated_world8_kernel_time.txt has the "
+                        "rocprofv3 figure of the same run); the in-process transport's copies stand in for RCCL and are in "
+                        "neither",
+            "projection": {
+                "label": "PROJECTION, not a measurement: measured bytes over 7 x 153 GB/s xGMI links per GPU (one link per "
+                         "peer at W = 8) against the measured per-rank KERNEL time with NO overlap between a rank's kernels "
+                         "assumed (the single-rank bench overlaps three plans); exchanges assumed to overlap compute across "
+                         "the plans in flight",
+                "link_ms_per_step": link_ms, "bound": "xgmi" if link_ms > kernel_ms else "compute",
+                "step_ms": max(link_ms, kernel_ms),
+                "whole_node_edges_per_s": W * edges_step / (max(link_ms, kernel_ms) * 1e-3),
+                # the same from the OVERLAPPED per-rank step (S worlds in flight, steps replayed as hipGraphs: `overlapped`),
+                # with the link time hidden behind it and with the link time added on top (nothing hidden)
+                "overlapped_step_ms": ov_ms,
+                "whole_node_edges_per_s_overlapped_links_hidden":
+                    (W * edges_step / (max(link_ms, ov_ms) * 1e-3)) if ov_ms else None,
+                "whole_node_edges_per_s_overlapped_links_not_hidden":
+                    (W * edges_step / ((link_ms + ov_ms) * 1e-3)) if ov_ms else None}}
+    if n_hot and "hot_rows" in res:
+        a, b_ = res["no_replication"]["pulled_rows_per_step_mean"], res["hot_rows"]["pulled_rows_per_step_mean"]
+        res["hot_row_hit_rate"] = {"replicated_fraction_of_nodes": hot_frac, "replica_bytes_per_rank": int(n_hot * row_bytes),
+                                   "pulled_rows_without": a, "pulled_rows_with": b_, "rows_taken_off_the_links": 1.0 - b_ / max(a, 1.0)}
+    # the line's value: the route with the shorter per-rank step (overlapped when measured, else kernel time), links hidden
+    def step_of(e):
+        pj = e["projection"]
+        return max(pj["link_ms_per_step"], pj["overlapped_step_ms"] or pj["step_ms"])
+    cands = [res[t] for t, h, _ in cases if (h or not n_hot)]
+    best = min(cands, key=step_of)
+    best_step = step_of(best)
+    line = {
+        "metric": "sampled+aggregated edges/s",
+        "value": W * best["sampled_plus_aggregated_edges_per_step_per_rank"] / (best_step * 1e-3), "unit": "edges/s",
+        "n_gpus": 1, "emulated_world": W, "steps": steps, "ms_per_step": best_step, "route": best["route"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value_is": "a PROJECTION for W GPUs from quantities measured on ONE GPU (see emulated.*.projection.label); the "
+                    "measured quantities are in `emulated`",
+        "config": {"workload": f"MAG240M-shaped RMAT x{scale:.3g}: N={n} E={e_sum} directed, D={d} fp16, hash-partitioned "
+                               f"over {W} emulated ranks in one process (owner = id % {W}), fanout={fanouts} B={B}/rank, "
+                               f"GraphSAGE {d}->{hid}->{out_dim}, {G} batches per exchange, "
+                               + ("rows pre-projected once per rank (256 fp32 W_l x rows pulled)" if use_proj else "raw rows"),
+                   "transport": "gigl_dist_init_local (in-process: every exchange is a device copy on this GPU)",
+                   "projection_precompute_s_per_rank": round(pre_s, 4), "setup_s": round(time.time() - t0, 1)},
+        "emulated": res, "roofline": best["roofline"], "cpu_baseline": None}
+    for c in comms:
+        c.close()
+    for e in reversed(engs):
+        e.close()
+    torch.cuda.empty_cache()
+    if not sub:
+        emit(line)
+    return line

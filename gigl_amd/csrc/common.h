@@ -43,7 +43,24 @@ struct gigl_ctx {
   // enc_tables_d
   uint32_t* enc_tables = nullptr;
   int32_t enc_tables_d = -1;
+  // gigl_ctx_set_wide_workspaces: plans created on this ctx provision for the WORST batch — every node of the tree an inner
+  // node (roots that are each other's sampled neighbours) — instead of b*(1 + f0 + ...) inner rows: the workspace of the
+  // redo of a batch that overflowed a regular plan
+  bool wide = false;
 };
+
+// rows a plan provisions for the nodes of level <= level_max of a batch of b roots: b*(1 + f0 + ... ) over level_max
+// fan-outs when no root is another root's sampled neighbour; wide: every child of a root-valued slot moves up a level,
+// up to the whole tree (level 0 = the distinct roots: never more than b)
+inline int64_t gigl_level_rows(bool wide, int64_t b, const int32_t* fanouts, int hops, int level_max) {
+  int64_t rows = 0, width = b;
+  const int top = wide && level_max >= 1 ? hops : level_max;
+  for (int i = 0; i <= top; ++i) {
+    rows += width;
+    if (i < hops) width *= fanouts[i];
+  }
+  return rows;
+}
 
 void gigl_sampler_table_free(gigl_ctx* ctx);
 

@@ -102,6 +102,7 @@ struct gigl_comm {
   void* user = nullptr;
   int32_t* h_units = nullptr;       // pinned host [2 * world]: the unit counts of a count-sized exchange
   int64_t moved_bytes = 0, block_bytes = 0;  // sent to OTHER ranks since creation: as moved / had every block been full
+  bool fixed_blocks = false;  // gigl_comm_set_fixed_blocks: count-sized exchanges move whole blocks (no host read: capturable)
 };
 
 namespace {
@@ -159,7 +160,7 @@ int32_t comm_exchange_rows(gigl_comm* c, const void* send, void* recv, int64_t b
   static const bool fixed = getenv("GIGL_DIST_FIXED_BLOCKS") != nullptr;
   gigl_ctx* ctx = c->ctx;
   if (bytes == 0) return GIGL_OK;
-  if (fixed || c->kind == GIGL_COMM_CALLBACK || c->world == 1 || !send_units || !recv_units || unit <= 0)
+  if (fixed || c->fixed_blocks || c->kind == GIGL_COMM_CALLBACK || c->world == 1 || !send_units || !recv_units || unit <= 0)
     return comm_exchange(c, send, recv, bytes, self_in_place);  // (a single rank: nothing leaves the device)
   const int64_t cap_units = bytes / unit;
   if (c->kind == GIGL_COMM_LOCAL) {
@@ -288,6 +289,12 @@ int32_t gigl_comm_all_to_all(gigl_comm* c, const void* send, void* recv, int64_t
   GIGL_REQUIRE(c->ctx, bytes_per_peer >= 0 && (bytes_per_peer == 0 || (send && recv)), "bad all-to-all arguments");
   GIGL_HIP_CHECK(c->ctx, hipSetDevice(c->ctx->device));
   return comm_exchange(c, send, recv, bytes_per_peer);
+}
+
+int32_t gigl_comm_set_fixed_blocks(gigl_comm* c, int32_t on) {
+  if (!c) return GIGL_E_INVALID_ARG;
+  c->fixed_blocks = on != 0;
+  return GIGL_OK;
 }
 
 int32_t gigl_comm_traffic(gigl_comm* c, int64_t* moved_bytes, int64_t* full_block_bytes) {
@@ -645,7 +652,7 @@ __global__ __launch_bounds__(256) void scatter_slots_kernel(const uint32_t* __re
   const int32_t e = pos[i];
   const uint32_t v = e >= 0 ? resp[(int64_t)e * f + j] : GIGL_INVALID;
   out_nbr[t] = v;
-  child_ksums[t] = v == GIGL_INVALID ? 0u : parent_ksums[i] + v;
+  if (child_ksums) child_ksums[t] = v == GIGL_INVALID ? 0u : parent_ksums[i] + v;  // (NULL: the last hop has no children)
   if (j == 0) {
     int n = 0;
     if (e >= 0)
@@ -932,7 +939,7 @@ int32_t scatter_hop(gigl_dist_plan* p, int k, const uint32_t* roots) {
   gigl_prof_scope ps(p->ctx, GIGL_K_DIST_PREP);
   hipLaunchKernelGGL(scatter_slots_kernel, dim3((unsigned)grid256(total)), dim3(256), 0, p->ctx->stream, p->resp_r[k],
                      p->hop_pos[k], k == 0 ? roots : p->child_ksum[k - 1], p->m[k], p->fan[k], p->tree.nbr[k],
-                     p->tree.cnt[k], p->child_ksum[k]);
+                     p->tree.cnt[k], k + 1 < p->hops ? p->child_ksum[k] : (uint32_t*)nullptr);
   GIGL_HIP_CHECK(p->ctx, hipGetLastError());
   return GIGL_OK;
 }
@@ -943,6 +950,16 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
   const int L = p->hops;
   const uint32_t world = (uint32_t)p->world;
   int32_t rc = GIGL_OK;
+  // a LONE rank (world 1 on a transport that needs no self copy) owns every row: its hops are the single-GPU sampler's,
+  // straight into the tree — no bucket, no request / answer blocks, no scatter (the same selection rule and table: the
+  // owners' expansion IS that sampler, run on explicit frontiers)
+  const bool lone_hops = world == 1 && comm_self_in_place(p->comm) && !p->overlap;
+  if (lone_hops && phase < 2 * L) {
+    if (phase != 0) return GIGL_OK;
+    rc = clear_call(p);
+    if (rc != GIGL_OK) return rc;
+    return gigl_sample_khop(ctx, p->shard, roots, p->b, p->fan, L, seed, GIGL_MODE_SPARK_HASH, &p->tree);
+  }
   if (phase < 2 * L && (phase & 1) == 0) {
     // ---- requester: (scatter the previous hop's answers,) bucket this hop's frontier by owner
     const int k = phase >> 1;
@@ -1011,8 +1028,10 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
   }
   if (phase == 2 * L) {
     // ---- requester: last scatter, union graph, feature requests
-    rc = scatter_hop(p, L - 1, roots);
-    if (rc != GIGL_OK) return rc;
+    if (!lone_hops) {
+      rc = scatter_hop(p, L - 1, roots);
+      if (rc != GIGL_OK) return rc;
+    }
     if (p->dense) {
       rc = gigl_union_build_impl(ctx, roots, &p->tree, p->group_roots, &p->un, 1 | (p->shard->multi ? 2 : 0));
       if (rc != GIGL_OK) return rc;

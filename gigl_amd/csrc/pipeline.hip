@@ -63,6 +63,7 @@ struct gigl_sage_plan {
   // leaf-global union (union.hip): pure leaves get no local id and stay global ids in their parents' rows — the
   // plan never computes anything for them, it only gathers their feature rows
   bool leaf_global = false;
+  bool wide = false;  // ctx->wide at creation: rows for the worst batch, every node numbered (generic union)
   bool alias_rows = false;  // tree.nbr[hops-1] == un.col + un.cap_edges (rows may alias tree segments)
   int64_t last_slots = 0;
   int64_t act_rows = 0;         // rows of abuf / hbuf
@@ -247,11 +248,10 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
   const int d = p->dims[l];
   // layer l computes the nodes of level <= L-1-l: at most b*(1 + f0 + f0*f1 + ...) of them — the launch is
   // sized for that bound, not for the whole union (the exact count is read on the device)
-  int64_t rows_cap = 0, width = p->b;
-  for (int i = 0; i <= L - 1 - l; ++i) {
-    rows_cap += width;
-    width *= p->fanouts[i];
-  }
+  const int64_t rows_cap = gigl_level_rows(p->wide, p->b, p->fanouts, L, L - 1 - l);
+  int64_t width = p->b;  // slots of hop L-1-l: with rows_cap, the rows of level <= L-l (the sources of layer l)
+  for (int i = 0; i <= L - 1 - l; ++i) width *= p->fanouts[i];
+  if (p->wide) width = 0;  // (rows_cap is the whole tree already)
   if (p->kind == 1) {
     const int act = (l < L - 1 || p->act_last) ? 1 : 0;
     const bool first = ((s - 2) & 1) == 0;
@@ -598,7 +598,8 @@ static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, in
   bool ok = true;
   // (the two-hop leaf-global builds keep a hop-0 slot's children in a 64-bit mask: last-hop fanouts beyond 64 — the
   // workgroup-per-row sampler path — take the generic union build)
-  p->leaf_global = hops <= 2 && graph->n < ((int64_t)1 << 31) && !(hops == 2 && fanouts[1] > GIGL_FAST_FANOUT);
+  p->wide = ctx->wide;
+  p->leaf_global = !p->wide && hops <= 2 && graph->n < ((int64_t)1 << 31) && !(hops == 2 && fanouts[1] > GIGL_FAST_FANOUT);
   // two hops, leaf-global union: the last hop's sampled ids live right behind the union's col array, so that the
   // rows of level-1 nodes that occur once can BE their tree segments (union.hip, row aliasing)
   int64_t last_slots = b;
@@ -623,11 +624,7 @@ static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, in
   p->un.cap_nodes = cap_nodes;
   p->un.cap_edges = cap_edges;
   // activations exist only for nodes of level < hops (leaves are read straight from the feature table)
-  int64_t act_rows = 0, width = b;
-  for (int k = 0; k < hops; ++k) {
-    act_rows += width;
-    width *= fanouts[k];
-  }
+  const int64_t act_rows = gigl_level_rows(p->wide, b, fanouts, hops, hops - 1);
   p->tiled = getenv("GIGL_PLAN_ROW_MAJOR") == nullptr;  // (A/B knob)
   p->two_source = getenv("GIGL_PLAN_SELF_COPY") == nullptr;  // (A/B knob: set = gather writes [mean | self])
   for (int k = 0; k < hops; ++k)
@@ -1273,11 +1270,7 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
   for (int l = 0; l < hops; ++l) {
     t->w[l] = w[l];
     t->bias[l] = bias ? bias[l] : nullptr;
-    int64_t rows = 0, width = b;  // layer l computes the nodes of level <= L-1-l
-    for (int i = 0; i <= hops - 1 - l; ++i) {
-      rows += width;
-      width *= fanouts[i];
-    }
+    const int64_t rows = gigl_level_rows(ctx->wide, b, fanouts, hops, hops - 1 - l);  // layer l computes the nodes of level <= L-1-l
     t->rows_cap[l] = rows;
     const size_t nw = (size_t)dims[l + 1] * 2 * dims[l];
     zero_floats += nw + dims[l + 1] + (t->bwd_gather && l < hops - 1 ? 0 : (size_t)rows * dims[l + 1]);
@@ -2030,11 +2023,7 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
     }
     for (int k = 0; k < 2; ++k) {
       gigl_nablp_train_plan::Enc& e = t->enc[k];
-      int64_t rows = 0, width = e.b;
-      for (int i = 0; i <= hops - 1 - l; ++i) {
-        rows += width;
-        width *= fanouts[i];
-      }
+      const int64_t rows = gigl_level_rows(ctx->wide, e.b, fanouts, hops, hops - 1 - l);
       e.rows_cap[l] = rows;
       zero_floats += nw + dims[l + 1] + (t->bwd_gather && l < hops - 1 ? 0 : (size_t)rows * dims[l + 1]);
       if (l >= 1) da_floats = std::max(da_floats, (size_t)rows * 2 * dims[l]);
@@ -2532,7 +2521,7 @@ int32_t gigl_gat_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_
   int64_t rows1_max = 0;
   for (int k = 0; k < 2; ++k) {
     gigl_nablp_train_plan::Enc& e = t->enc[k];
-    e.rows_cap[0] = (int64_t)e.b * (1 + fanouts[0]);  // nodes of level <= 1
+    e.rows_cap[0] = gigl_level_rows(ctx->wide, e.b, fanouts, hops, 1);  // nodes of level <= 1
     e.rows_cap[1] = e.b;
     if (e.rows_cap[0] > rows1_max) rows1_max = e.rows_cap[0];
     zero_floats += (size_t)e.b * C1;  // dh[1]

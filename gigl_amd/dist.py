@@ -337,6 +337,10 @@ class Comm:
     def flush_local(self) -> None:
         _check(self.eng._lib.gigl_comm_flush_local(self._h), self.eng._ctx)
 
+    def set_fixed_blocks(self, on: bool) -> None:
+        """whole row blocks instead of count-sized ones (gigl_comm_set_fixed_blocks): no host read in a step"""
+        _check(self.eng._lib.gigl_comm_set_fixed_blocks(self._h, 1 if on else 0), self.eng._ctx)
+
     def traffic(self) -> Tuple[int, int]:
         """(bytes moved, bytes full blocks would have moved) to OTHER ranks since creation (gigl_comm_traffic): the
         sharded plans send only the requested rows of each feature-row block"""

@@ -1309,6 +1309,11 @@ int32_t gigl_dist_init_callback(gigl_ctx* ctx, int32_t rank, int32_t world, gigl
 int32_t gigl_comm_info(gigl_comm* comm, int32_t* rank, int32_t* world, int32_t* kind);
 int32_t gigl_comm_all_to_all(gigl_comm* comm, const void* send, void* recv, int64_t bytes_per_peer);
 int32_t gigl_comm_flush_local(gigl_comm* any_member);
+/* The feature-row exchange moves only the REQUESTED rows of each block, which costs one host read of 2 * world counts per
+ * call (RCCL needs the sizes on the host).  on = 1: whole blocks travel instead — more bytes on the links, no host read
+ * anywhere in a step, so that a step can be captured into a hipGraph (the emulated world of bench/sharded.py replays its
+ * ranks' steps that way).  Set it on every rank of the communicator alike. */
+int32_t gigl_comm_set_fixed_blocks(gigl_comm* comm, int32_t on);
 /* bytes this rank has sent to OTHER ranks since the communicator was created: as moved, and as they would have been
  * with every block sent at its full capacity.  The sharded plans' feature-row exchange moves only the requested rows
  * of each block (the counts travel with the id request; RCCL and in-process groups — the host-callback transport has a

@@ -53,7 +53,12 @@ def test_self_launch_two_ranks_on_one_gpu():
     assert line["comm"]["xgmi_bytes_per_step_per_gpu_mean"] > 0
     assert line["roofline_xgmi"]["ranks"] == 2
     assert line["config"]["pulled_feature_rows_per_step"] > 0  # rows really travelled between the ranks
-    assert 0 < line["config"]["row_bucket_fill"] <= 1.0
+    # same node, one process per rank: the peer-mapped route (the ranks read each other's tables through hipIpc mappings)
+    # — no row ever sits in a bucket; the bucketed route reports how full its row buckets were
+    if line["config"]["feature_route"] == "peer":
+        assert line["config"]["row_bucket_fill"] is None and line["config"]["feature_route_note"] is None
+    else:
+        assert 0 < line["config"]["row_bucket_fill"] <= 1.0
     assert "replicated as hot rows" in line["config"]["workload"]  # hub replication is on by default at world > 1
     rep = line["replicas"]  # the replica-per-GPU run of the same launch: a sub-record now
     assert rep["n_gpus"] == 2 and rep["value"] > 0 and "replica per GPU" in rep["config"]["graph"]

@@ -601,6 +601,16 @@ def test_bench_emulated_world_line(tmp_path):
         assert 0.0 < e["row_bucket_fill"] <= 1.0 and e["projection"]["label"].startswith("PROJECTION")
     assert line["roofline"]["bound"] == "hbm"
     assert emu["hot_row_hit_rate"]["pulled_rows_with"] < emu["hot_row_hit_rate"]["pulled_rows_without"]
+    # the peer-mapped route beside it: no owner-side gather, rows counted per occurrence, and for both routes the OVERLAPPED
+    # per-rank step (worlds in flight replayed as hipGraphs) with the link time beside it, hidden and not hidden
+    pe = emu["peer_hot_rows"]
+    assert pe["route"] == "peer" and "dist_serve" not in pe["kernel_ms_by_group"] and pe["kernel_ms_by_group"]["dist_prep"] > 0
+    assert pe["pulled_rows_per_step_mean"] >= emu["hot_rows"]["pulled_rows_per_step_mean"] > 0
+    for e in (pe, emu["hot_rows"]):
+        pj = e["projection"]
+        assert e["overlapped"]["ms_per_rank_step"] > 0 and pj["overlapped_step_ms"] == e["overlapped"]["ms_per_rank_step"]
+        assert 0 < pj["whole_node_edges_per_s_overlapped_links_not_hidden"] < pj["whole_node_edges_per_s_overlapped_links_hidden"]
+    assert line["route"] in ("peer", "bucketed")
 
 
 @pytest.mark.gpu
