@@ -45,7 +45,7 @@ SYMBOLS = [
     "gigl_gatv2_aggregate_edge_backward", "gigl_transformer_aggregate_edge", "gigl_transformer_aggregate_edge_backward",
     "gigl_sage_plan_stats", "gigl_retrieval_loss", "gigl_retrieval_loss_backward",
     "gigl_comm_unique_id", "gigl_dist_init", "gigl_dist_init_local", "gigl_dist_init_callback", "gigl_comm_info",
-    "gigl_comm_all_to_all", "gigl_comm_flush_local", "gigl_comm_traffic", "gigl_comm_set_fixed_blocks", "gigl_comm_destroy", "gigl_dist_plan_batch_features", "gigl_dist_plan_batch_graph", "gigl_dist_plan_create",
+    "gigl_comm_all_to_all", "gigl_comm_flush_local", "gigl_comm_traffic", "gigl_comm_set_fixed_blocks", "gigl_ctx_set_wide_workspaces", "gigl_sage_train_plan_adopt", "gigl_sage_train_plan_resume", "gigl_nablp_train_plan_adopt", "gigl_comm_destroy", "gigl_dist_plan_batch_features", "gigl_dist_plan_batch_graph", "gigl_dist_plan_create",
     "gigl_dist_plan_set_weights", "gigl_dist_plan_phases", "gigl_dist_plan_phase", "gigl_dist_plan_run",
     "gigl_dist_plan_run_local", "gigl_dist_plan_run_interleaved", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
     "gigl_dist_plan_set_hot_rows", "gigl_dist_plan_set_peer_tables", "gigl_ipc_export", "gigl_ipc_open", "gigl_ipc_close",
@@ -309,6 +309,10 @@ def load() -> C.CDLL:
         "gigl_comm_flush_local": [vp],
         "gigl_comm_traffic": [vp, vp, vp],
         "gigl_comm_set_fixed_blocks": [vp, i32],
+        "gigl_ctx_set_wide_workspaces": [vp, i32],
+        "gigl_sage_train_plan_adopt": [vp, vp],
+        "gigl_sage_train_plan_resume": [vp],
+        "gigl_nablp_train_plan_adopt": [vp, vp],
         "gigl_dist_plan_batch_features": [vp, vp],
         "gigl_dist_plan_batch_graph": [vp, vp, vp, vp, vp, vp, vp],
         "gigl_comm_destroy": [vp],

@@ -137,6 +137,12 @@ int32_t gigl_ctx_destroy(gigl_ctx* ctx) {
 
 const char* gigl_last_error(gigl_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
+int32_t gigl_ctx_set_wide_workspaces(gigl_ctx* ctx, int32_t on) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  ctx->wide = on != 0;
+  return GIGL_OK;
+}
+
 int32_t gigl_ctx_set_stream(gigl_ctx* ctx, void* hip_stream) {
   if (!ctx) return GIGL_E_INVALID_ARG;
   if ((hipStream_t)hip_stream == ctx->stream && !ctx->own_stream) return GIGL_OK;  // already bound: nothing to drain

@@ -396,7 +396,9 @@ __global__ __launch_bounds__(256) void dist_clear_kernel(ClearSegs s) {
     const int64_t w0 = (u - (k ? s.end[k - 1] : 0)) * 4;
     uint32_t* q = s.p[k] + w0;
     const uint32_t v = s.val[k];
-    if (w0 + 4 <= s.words[k]) {
+    // (a segment that starts inside a buffer — a rank's own block of a receive buffer at rank * cap words — is only 4-byte
+    // aligned when cap is not a multiple of 4: scalar stores there)
+    if (w0 + 4 <= s.words[k] && (reinterpret_cast<uintptr_t>(q) & 15) == 0) {
       *reinterpret_cast<uint4*>(q) = make_uint4(v, v, v, v);
     } else {
       for (int64_t t = w0; t < s.words[k]; ++t) s.p[k][t] = v;

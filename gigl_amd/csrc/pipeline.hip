@@ -452,7 +452,8 @@ __global__ __launch_bounds__(256) void ce_roots_kernel(const float* __restrict__
 // loss = sum_i loss_rows[i] / n_valid in a fixed order (one workgroup); the optimiser's step counter moves on
 __global__ __launch_bounds__(1024) void loss_sum_kernel(const float* __restrict__ loss_rows, int b,
                                                         const int32_t* __restrict__ n_valid_dev, float* __restrict__ loss,
-                                                        int32_t* __restrict__ step, const int32_t* __restrict__ meta) {
+                                                        int32_t* __restrict__ step, const int32_t* __restrict__ meta,
+                                                        int32_t* __restrict__ halt) {
   __shared__ float s_p[16];
   float v = 0.f;
   for (int i = threadIdx.x; i < b; i += 1024) v += loss_rows[i];
@@ -464,7 +465,12 @@ __global__ __launch_bounds__(1024) void loss_sum_kernel(const float* __restrict_
     for (int k = 0; k < 16; ++k) t += s_p[k];
     *loss = t / (float)(*n_valid_dev > 0 ? *n_valid_dev : 1);
     // (a failed batch applies no update — adam_kernel returns — so Adam's bias-correction exponent must not move either)
-    if (meta[GIGL_META_OVERFLOW] == 0) *step += 1;
+    // `halt` is STICKY: once a batch has failed, every later step of the queue trains nothing either (NaN loss) until the
+    // host has seen it (gigl_sage_train_plan_resume) — steps are issued without a host read in between, and the batches
+    // behind a failed one must not be applied ahead of its redo
+    if (*halt != 0) *loss = __builtin_nanf("");
+    else if (meta[GIGL_META_OVERFLOW] == 0) *step += 1;
+    else *halt = 1;
   }
 }
 
@@ -496,8 +502,8 @@ struct AdamPack {
 };
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamPack a, const int32_t* __restrict__ step_dev,
-                                                   const int32_t* __restrict__ meta) {
-  if (meta[GIGL_META_OVERFLOW] != 0) return;  // a failed batch trains nothing (its loss is NaN)
+                                                   const int32_t* __restrict__ meta, const int32_t* __restrict__ halt) {
+  if (meta[GIGL_META_OVERFLOW] != 0 || *halt != 0) return;  // a failed batch trains nothing (its loss is NaN)
   const double t = (double)*step_dev;
   const float bc1 = (float)(1.0 - pow((double)a.beta1, t)), bc2s = (float)sqrt(1.0 - pow((double)a.beta2, t));
   const float step_size = a.lr / bc1;
@@ -1020,7 +1026,7 @@ struct gigl_sage_train_plan {
   void* zero_base = nullptr;              // gw | gb | dh: cleared at the start of every step
   size_t zero_bytes = 0;
   int64_t* labels_buf = nullptr;
-  int32_t* n_valid_buf = nullptr;  // [0] real roots of the batch, [1] Adam's step counter
+  int32_t* n_valid_buf = nullptr;  // [0] real roots of the batch, [1] Adam's step counter, [2] sticky "a batch failed" (halt)
   float* loss_rows = nullptr;
   float* loss = nullptr;
   float lr = 0.01f, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f, wd = 0.f;
@@ -1074,7 +1080,8 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
                        (const int32_t*)p->un.root_local, (const int64_t*)t->labels_buf, (const int32_t*)t->n_valid_buf, t->b,
                        (const int32_t*)p->un.meta, t->dh[L - 1], t->loss_rows);
     hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)t->loss_rows, t->b,
-                       (const int32_t*)t->n_valid_buf, t->loss, t->n_valid_buf + 1, (const int32_t*)p->un.meta);
+                       (const int32_t*)t->n_valid_buf, t->loss, t->n_valid_buf + 1, (const int32_t*)p->un.meta,
+                       t->n_valid_buf + 2);
   }
   // ---- backward
   for (int l = L - 1; l >= 0; --l) {
@@ -1126,7 +1133,7 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
   ap.eps = t->eps;
   ap.wd = t->wd;
   hipLaunchKernelGGL(adam_kernel, dim3(256), dim3(256), 0, st, ap, (const int32_t*)(t->n_valid_buf + 1),
-                     (const int32_t*)p->un.meta);
+                     (const int32_t*)p->un.meta, (const int32_t*)(t->n_valid_buf + 2));
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
@@ -1238,6 +1245,7 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
   for (int k = 0; k < TRAIN_WS && rc == GIGL_OK; ++k) {
     rc = gigl_ctx_create(ctx->device, &t->side[k]);
     if (rc != GIGL_OK) break;
+    t->side[k]->wide = ctx->wide;
     rc = plan_create(t->side[k], graph, feat, b, fanouts, hops, dims, (const float* const*)w, (const float* const*)bias,
                      act_last, false, &t->base[k]);
     if (rc != GIGL_OK) gigl_fail(ctx, rc, "%s", gigl_last_error(t->side[k]));
@@ -1381,6 +1389,13 @@ int32_t gigl_sage_train_plan_step2(gigl_sage_train_plan* t, const uint32_t* root
 }
 
 const float* gigl_sage_train_plan_loss(gigl_sage_train_plan* t) { return t ? t->loss : nullptr; }
+
+int32_t gigl_sage_train_plan_resume(gigl_sage_train_plan* t) {
+  if (!t) return GIGL_E_INVALID_ARG;
+  GIGL_HIP_CHECK(t->ctx, hipSetDevice(t->ctx->device));
+  GIGL_HIP_CHECK(t->ctx, hipMemsetAsync(t->n_valid_buf + 2, 0, 4, t->ctx->stream));
+  return GIGL_OK;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // gigl_nablp_train_plan: one LINK-PREDICTION training step per call, all of it in the library (round 5) —
@@ -1983,6 +1998,7 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
   for (int wi = 0; wi < gigl_nablp_train_plan::WS && rc == GIGL_OK; ++wi) {
     gigl_nablp_train_plan::Work& wk = t->work[wi];
     rc = gigl_ctx_create(ctx->device, &wk.side);
+    if (rc == GIGL_OK) wk.side->wide = ctx->wide;
     for (int k = 0; k < 2 && rc == GIGL_OK; ++k) {
       t->enc[k].b = nb[k];
       rc = plan_create(wk.side, graph, feat, nb[k], fanouts, hops, dims, (const float* const*)w, (const float* const*)bias,
@@ -2184,6 +2200,51 @@ __global__ __launch_bounds__(256) void lp_add2_kernel(const float* __restrict__ 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
 }
 }  // namespace
+
+int32_t gigl_sage_train_plan_adopt(gigl_sage_train_plan* dst, gigl_sage_train_plan* src) {
+  if (!dst || !src) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = dst->ctx;
+  GIGL_REQUIRE(ctx, dst->L == src->L, "plans of different depth");
+  for (int l = 0; l <= dst->L; ++l) GIGL_REQUIRE(ctx, dst->dims[l] == src->dims[l], "plans of different widths");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(src->ctx->stream));
+  for (int l = 0; l < dst->L; ++l) {
+    const size_t nw = (size_t)dst->dims[l + 1] * 2 * dst->dims[l];
+    for (int k = 0; k < 4; ++k)
+      GIGL_HIP_CHECK(ctx, hipMemcpyAsync(dst->mom[4 * l + k], src->mom[4 * l + k], (k < 2 ? nw : (size_t)dst->dims[l + 1]) * 4,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(dst->n_valid_buf + 1, src->n_valid_buf + 1, 4, hipMemcpyDeviceToDevice, ctx->stream));
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return GIGL_OK;
+}
+
+int32_t gigl_nablp_train_plan_adopt(gigl_nablp_train_plan* dst, gigl_nablp_train_plan* src) {
+  if (!dst || !src) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = dst->ctx;
+  GIGL_REQUIRE(ctx, dst->L == src->L && dst->kind == src->kind, "plans of different kinds");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(src->ctx->stream));
+  if (dst->kind == 1) {
+    for (int i = 0; i < 8; ++i) {
+      GIGL_REQUIRE(ctx, dst->gat.n[i] == src->gat.n[i], "plans of different widths");
+      for (int j = 0; j < 2; ++j)
+        GIGL_HIP_CHECK(ctx, hipMemcpyAsync(dst->gat.mom[2 * i + j], src->gat.mom[2 * i + j],
+                                           (size_t)(dst->gat.n[i] ? dst->gat.n[i] : 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  } else {
+    for (int l = 0; l <= dst->L; ++l) GIGL_REQUIRE(ctx, dst->dims[l] == src->dims[l], "plans of different widths");
+    for (int l = 0; l < dst->L; ++l) {
+      const size_t nw = (size_t)dst->dims[l + 1] * 2 * dst->dims[l];
+      for (int k = 0; k < 4; ++k)
+        GIGL_HIP_CHECK(ctx, hipMemcpyAsync(dst->mom[4 * l + k], src->mom[4 * l + k], (k < 2 ? nw : (size_t)dst->dims[l + 1]) * 4,
+                                           hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(dst->consts + 2, src->consts + 2, 4, hipMemcpyDeviceToDevice, ctx->stream));
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return GIGL_OK;
+}
 
 int32_t gigl_nablp_train_plan_grads(gigl_nablp_train_plan* t, int32_t layer, float* gw, float* gb) {
   if (!t) return GIGL_E_INVALID_ARG;
@@ -2486,6 +2547,7 @@ int32_t gigl_gat_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_
   for (int wi = 0; wi < gigl_nablp_train_plan::WS && rc == GIGL_OK; ++wi) {
     gigl_nablp_train_plan::Work& wk = t->work[wi];
     rc = gigl_ctx_create(ctx->device, &wk.side);
+    if (rc == GIGL_OK) wk.side->wide = ctx->wide;
     for (int k = 0; k < 2 && rc == GIGL_OK; ++k) {
       t->enc[k].b = nb[k];
       // (the base plans are tree + union workspaces here: their own layer buffers stay unused)

@@ -1332,15 +1332,21 @@ class SageTrainPlan:
         self.w, self.bias = [], []
         self.load(model)
         self.dims = [int(self.w[0].shape[1]) // 2] + [int(w.shape[0]) for w in self.w]
-        self._plan = C.c_void_p()
         w_arr = (C.c_void_p * L)(*[w.data_ptr() for w in self.w])
         b_arr = (C.c_void_p * L)(*[(x.data_ptr() if x is not None else None) for x in self.bias])
         fo = (C.c_int32 * L)(*self.fanouts)
         dims = (C.c_int32 * (L + 1))(*self.dims)
-        check(self._lib.gigl_sage_train_plan_create(eng._ctx, eng._graph, eng._feat, self.b, fo, L, dims, w_arr, b_arr,
-                                                    1 if model.activation_after_last_conv else 0, float(lr),
-                                                    float(betas[0]), float(betas[1]), float(eps), float(weight_decay),
-                                                    C.byref(self._plan)), eng._ctx)
+        act_last = 1 if model.activation_after_last_conv else 0
+
+        def create():
+            h = C.c_void_p()
+            check(self._lib.gigl_sage_train_plan_create(eng._ctx, eng._graph, eng._feat, self.b, fo, L, dims, w_arr, b_arr,
+                                                        act_last, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                                                        float(weight_decay), C.byref(h)), eng._ctx)
+            return h
+        self._create, self._adopt, self._destroy = create, self._lib.gigl_sage_train_plan_adopt, self._lib.gigl_sage_train_plan_destroy
+        self.wide = False
+        self._plan = create()
         self.loss = torch.zeros(1, dtype=torch.float32, device=eng.device)  # the last step's loss (device scalar)
 
     def load(self, model) -> None:
@@ -1367,6 +1373,35 @@ class SageTrainPlan:
                 if b is not None:
                     c.lin_l.bias.copy_(b)
 
+    def grow(self) -> None:
+        """re-create the plan with workspaces for the WORST batch (gigl_ctx_set_wide_workspaces: rows for every node of the
+        tree, the generic union build) and hand it the optimiser state of the plan it replaces — the weights are this
+        object's tensors, shared by construction.  What step_checked does the first time a batch overflows the regular
+        workspace (roots that are each other's sampled neighbours: common on graphs of a few thousand nodes)."""
+        if self.wide:
+            return
+        check(self._lib.gigl_ctx_set_wide_workspaces(self.eng._ctx, 1), self.eng._ctx)
+        try:
+            new = self._create()
+        finally:
+            self._lib.gigl_ctx_set_wide_workspaces(self.eng._ctx, 0)
+        check(self._adopt(new, self._plan), self.eng._ctx)
+        self._destroy(self._plan)
+        self._plan, self.wide = new, True
+        self._next = None  # (a batch announced to the old plan's workspaces is sampled again)
+
+    def step_checked(self, *args, **kwargs) -> float:
+        """step(), its loss read back (synchronises): a batch that did not fit the plan's workspace — NaN loss, nothing
+        trained, Adam's counter unmoved — is REDONE after the plan has grown (grow), so the training run sees every batch
+        the reference's collate would have built (rooted_node_neighborhood_data_loader.py:78-158 has no such bound).  A
+        NaN from a plan that is wide already is the loss's own."""
+        loss = float(self.step(*args, **kwargs)[0])
+        if loss != loss and not self.wide:
+            self.grow()
+            self.overflow_redone = getattr(self, "overflow_redone", 0) + 1
+            loss = float(self.step(*args, **kwargs)[0])
+        return loss
+
     def _padded(self, roots: torch.Tensor) -> torch.Tensor:
         k = int(roots.numel())
         assert roots.is_cuda and roots.dtype == torch.int32 and 0 < k <= self.b
@@ -1374,8 +1409,36 @@ class SageTrainPlan:
             roots = torch.cat([roots, roots[:1].expand(self.b - k)])
         return roots.contiguous()
 
+    def resume(self) -> None:
+        """clear the device-side halt a failed batch left (gigl_sage_train_plan_resume): later steps train again"""
+        check(self._lib.gigl_sage_train_plan_resume(self._plan), self.eng._ctx)
+
+    def run_steps(self, n_steps: int, step_args) -> torch.Tensor:
+        """steps 0 .. n_steps-1 issued back to back WITHOUT a host read (step_args(i) -> the kwargs of step i), their losses
+        collected on the device -> float32 [n_steps].  A batch that does not fit the plan's workspace halts the plan on the
+        device (nothing behind it is applied); the loop then grows the plan (grow) and redoes the steps from that batch on.
+        A batch that fails in a wide plan (a label outside the output width) is skipped, as before."""
+        losses = torch.zeros(max(n_steps, 1), dtype=torch.float32, device=self.eng.device)
+        start = 0
+        while start < n_steps:
+            for i in range(start, n_steps):
+                self.step(**step_args(i), loss_out=losses[i:i + 1])
+            bad = torch.isnan(losses[start:n_steps]).nonzero()  # (synchronises: once per pass, not per step)
+            if bad.numel() == 0:
+                break
+            j = start + int(bad[0])
+            if not self.wide:
+                self.grow()
+                self.overflow_redone = getattr(self, "overflow_redone", 0) + 1
+                start = j
+            else:
+                self.resume()
+                start = j + 1
+        return losses[:n_steps]
+
     def step(self, roots: torch.Tensor, labels: torch.Tensor, sampling_seed: int = 42, mode: int = MODE_SPARK_HASH,
-             next_roots: Optional[torch.Tensor] = None, next_roots2: Optional[torch.Tensor] = None) -> torch.Tensor:
+             next_roots: Optional[torch.Tensor] = None, next_roots2: Optional[torch.Tensor] = None,
+             loss_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """one optimiser step on the batch: roots int32 device [k <= b] (uint32 ids), labels int64 device [k]; a short
         batch is padded with its first root (a repeated root adds nothing to the union graph) and masked out of the loss.
         next_roots: the roots of the batch the NEXT call will be given — its sampling and union graph then run on the
@@ -1390,14 +1453,16 @@ class SageTrainPlan:
         # (read asynchronously by the plan's own streams: kept alive over the next three steps)
         self._keep = (tuple(getattr(self, "_keep", ()))[-2:]) + ((roots, nxt, nxt2),)
         p_ = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        out = self.loss if loss_out is None else loss_out  # (loss_out: a float32 device slot of the caller's)
         check(self._lib.gigl_sage_train_plan_step2(self._plan, p_(roots), p_(labels), k, p_(nxt), p_(nxt2),
-                                                   int(sampling_seed), int(mode), p_(self.loss)), self.eng._ctx)
-        return self.loss
+                                                   int(sampling_seed), int(mode), p_(out)), self.eng._ctx)
+        return out
 
     def close(self) -> None:
         if getattr(self, "_plan", None):
             self._lib.gigl_sage_train_plan_destroy(self._plan)
             self._plan = None
+        self._create = None  # (drops the argument arrays it holds)
 
 
 class NablpTrainPlan:
@@ -1422,20 +1487,28 @@ class NablpTrainPlan:
         self.w, self.bias = [], []
         SageTrainPlan.load(self, model)
         self.dims = [int(self.w[0].shape[1]) // 2] + [int(w.shape[0]) for w in self.w]
-        self._plan = C.c_void_p()
         w_arr = (C.c_void_p * L)(*[w.data_ptr() for w in self.w])
         b_arr = (C.c_void_p * L)(*[(x.data_ptr() if x is not None else None) for x in self.bias])
         fo = (C.c_int32 * L)(*self.fanouts)
         dims = (C.c_int32 * (L + 1))(*self.dims)
-        check(self._lib.gigl_nablp_train_plan_create(
-            eng._ctx, eng._graph, eng._feat, self.b, self.P, self.n_rn, fo, L, dims, w_arr, b_arr,
-            1 if model.activation_after_last_conv else 0, 1 if model.should_l2_normalize_embedding_layer_output else 0,
-            float(temperature), 1 if remove_accidental_hits else 0, float(lr), float(betas[0]), float(betas[1]), float(eps),
-            float(weight_decay), C.byref(self._plan)), eng._ctx)
+        flags = (1 if model.activation_after_last_conv else 0, 1 if model.should_l2_normalize_embedding_layer_output else 0)
+
+        def create():
+            h = C.c_void_p()
+            check(self._lib.gigl_nablp_train_plan_create(
+                eng._ctx, eng._graph, eng._feat, self.b, self.P, self.n_rn, fo, L, dims, w_arr, b_arr, flags[0], flags[1],
+                float(temperature), 1 if remove_accidental_hits else 0, float(lr), float(betas[0]), float(betas[1]), float(eps),
+                float(weight_decay), C.byref(h)), eng._ctx)
+            return h
+        self._create, self._adopt, self._destroy = create, self._lib.gigl_nablp_train_plan_adopt, self._lib.gigl_nablp_train_plan_destroy
+        self.wide = False
+        self._plan = create()
         self.loss = torch.zeros(2, dtype=torch.float32, device=eng.device)  # {loss, query rows} of the last step
 
     load = SageTrainPlan.load
     store = SageTrainPlan.store
+    grow = SageTrainPlan.grow
+    step_checked = SageTrainPlan.step_checked
 
     def _padded(self, main_roots: torch.Tensor, pos_cnt: Optional[torch.Tensor], rn_roots: torch.Tensor):
         T = 1 + self.P
@@ -1489,6 +1562,7 @@ class NablpTrainPlan:
         if getattr(self, "_plan", None):
             self._lib.gigl_nablp_train_plan_destroy(self._plan)
             self._plan = None
+        self._create = None
 
 
 class GatNablpTrainPlan(NablpTrainPlan):
@@ -1510,14 +1584,20 @@ class GatNablpTrainPlan(NablpTrainPlan):
         self.load(model)
         c0, c1 = model.conv_layers
         self.heads, self.channels = [int(c0.heads), 1], [int(c0.out_channels), int(c1.out_channels)]
-        self._plan = C.c_void_p()
         arr = lambda ts: (C.c_void_p * 2)(*[(t.data_ptr() if t is not None else None) for t in ts])
-        check(self._lib.gigl_gat_nablp_train_plan_create(
-            eng._ctx, eng._graph, eng._feat, self.b, self.P, self.n_rn, (C.c_int32 * 2)(*self.fanouts), 2,
-            (C.c_int32 * 2)(*self.heads), (C.c_int32 * 2)(*self.channels), arr(self.w), arr(self.att_src), arr(self.att_dst),
-            arr(self.bias), float(c0.negative_slope), 1 if model.should_l2_normalize_embedding_layer_output else 0,
-            float(temperature), 1 if remove_accidental_hits else 0, float(lr), float(betas[0]), float(betas[1]), float(eps),
-            float(weight_decay), C.byref(self._plan)), eng._ctx)
+        slope, norm = float(c0.negative_slope), 1 if model.should_l2_normalize_embedding_layer_output else 0
+
+        def create():
+            h = C.c_void_p()
+            check(self._lib.gigl_gat_nablp_train_plan_create(
+                eng._ctx, eng._graph, eng._feat, self.b, self.P, self.n_rn, (C.c_int32 * 2)(*self.fanouts), 2,
+                (C.c_int32 * 2)(*self.heads), (C.c_int32 * 2)(*self.channels), arr(self.w), arr(self.att_src), arr(self.att_dst),
+                arr(self.bias), slope, norm, float(temperature), 1 if remove_accidental_hits else 0, float(lr), float(betas[0]),
+                float(betas[1]), float(eps), float(weight_decay), C.byref(h)), eng._ctx)
+            return h
+        self._create, self._adopt, self._destroy = create, self._lib.gigl_nablp_train_plan_adopt, self._lib.gigl_nablp_train_plan_destroy
+        self.wide = False
+        self._plan = create()
         self.loss = torch.zeros(2, dtype=torch.float32, device=eng.device)
 
     @staticmethod

@@ -132,11 +132,6 @@ class HbmNablpBatch:
         return [Node(type="node", id=int(v)) for v in self.anchor_ids.tolist()]
 
 
-# graphs at most this large check every one-call plan's overflow flag synchronously and redo a failed call through the staged
-# launches (a host read per call is nothing next to a pass over so few nodes)
-SMALL_GRAPH_NODES = 1 << 18
-
-
 class ResidentGraph:
     """the job's graph + node features in HBM, with the plans that run batches over it.  One per process (rank)."""
 
@@ -179,7 +174,8 @@ class ResidentGraph:
         self.engine = eng = HipEngine(self.device.index or 0)
         self.comm = None
         self._plans: Dict[tuple, object] = {}
-        self._overflow_acc: Optional[torch.Tensor] = None  # device int32 [1]: plan calls whose rows came out NaN
+        self._unsettled: list = []   # overflow-flag slots of pipelined calls nobody has settled yet (call_overflowed)
+        self.overflow_redone = 0     # plan calls redone through the staged launches (their batch outgrew the workspace)
         self.sharded = bool(self.world > 1 if sharded is None else (sharded and self.world > 1))
         if self.sharded and self.mode == MODE_REPLACE:
             # (the sharded plan samples duplicate-free trees; refused HERE, before anything is built, so that a caller
@@ -226,7 +222,7 @@ class ResidentGraph:
         self.n, self.node_ids, self.labels = int(engine.n_nodes), np.asarray(node_ids, dtype=np.int64), {}
         self.has_in_edge = None
         self.engine, self.comm, self._plans, self.sharded = engine, None, {}, False
-        self._overflow_acc = None
+        self._unsettled, self.overflow_redone = [], 0
         self.feat_dim, self.node_type, self._order_prefixes = int(engine.feat_dim), node_type, [order_prefix]
         self._borrowed_engine = True
         return self
@@ -403,32 +399,38 @@ class ResidentGraph:
         eng.bind_stream(torch.cuda.current_stream(self.device))
         b, g = batch.group_roots, batch.groups
         with torch.no_grad():
-            plan = self._plan_for(model, b, g, lane)
+            plan = None if getattr(batch, "force_staged", False) else self._plan_for(model, b, g, lane)
             if plan is not None:
+                # A call whose batch did not fit the one-call plan's workspace (roots that are each other's sampled
+                # neighbours turn whole leaf rows into inner rows: common on graphs of a few thousand nodes, never seen on
+                # large ones) hands out NaN rows and sets a device flag.  Such a call is REDONE batch by batch through the
+                # staged launches below, whose buffers are sized from the batch's own counts — the reference's collate has
+                # no workspace to overflow (rooted_node_neighborhood_data_loader.py:78-158).  The flag is read here, unless
+                # the caller pipelines its calls (batch.defer_overflow_check: Inferencer.infer_resident keeps a few calls
+                # in flight and settles each one — call_overflowed — before its rows are handed on).
                 if self.sharded:
                     out = plan.run(batch.roots, sampling_seed=self.seed)
-                    plan.raise_on_overflow()
-                    if getattr(model, "should_l2_normalize_embedding_layer_output", False) and \
+                    # every rank takes part in a redo (the staged route's exchanges are collectives): the flags are reduced
+                    redo = self._any_rank(plan.overflowed())
+                    if not redo and getattr(model, "should_l2_normalize_embedding_layer_output", False) and \
                             type(plan).__name__ == "DistSagePlan":
                         out = torch.nn.functional.normalize(out, p=2, dim=1)  # (the encoder's last step: row-wise)
                 else:
                     out = plan.run(batch.roots, sampling_seed=self.seed, mode=self.mode)
-                    # a call whose union did not fit its workspace hands out NaN rows.  On a SMALL graph (roots are each
-                    # other's sampled neighbours all the time: whole leaf rows become inner rows) the flag is read here
-                    # and such a call is redone batch by batch through the staged launches below, whose buffers are
-                    # sized from the batch's counts; on a large graph every call's flag is added into one device
-                    # counter (no synchronisation here), read by raise_on_overflow()
-                    redo = False
-                    if self.n <= SMALL_GRAPH_NODES:
-                        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-                        plan.overflow_add(flag)
-                        redo = bool(int(flag.item()))
+                    slot = self._overflow_slot()
+                    plan.overflow_add(slot["dev"])
+                    if getattr(batch, "defer_overflow_check", False):
+                        slot["host"].copy_(slot["dev"], non_blocking=True)
+                        slot["event"].record(torch.cuda.current_stream(self.device))
+                        batch._overflow_slot = slot
+                        self._unsettled.append(slot)
+                        redo = False
                     else:
-                        if self._overflow_acc is None:
-                            self._overflow_acc = torch.zeros(1, dtype=torch.int32, device=self.device)
-                        plan.overflow_add(self._overflow_acc)
-                if self.sharded or not redo:
+                        redo = bool(int(slot["dev"].item()))
+                        slot["busy"] = False
+                if not redo:
                     return out if batch.valid is None else out.index_select(0, batch.valid)
+                self.overflow_redone += 1
             outs = []
             as_graph_data = self.sharded or not encoder_takes_hip_batches(model)
             if as_graph_data and getattr(model, "engine", None) is None:
@@ -436,7 +438,9 @@ class ResidentGraph:
             for k in range(g):  # staged: sample -> union -> model(HipBatch), one batch at a time
                 if as_graph_data:  # (a sharded graph: the batch assembled from the ranks' shards; encoders without a
                     # forward over HipBatches: the same batch as a PyG-shaped GraphData built on the device)
-                    gd, ri = self.graph_data(batch.roots[k * b: (k + 1) * b].contiguous(), pad_to=b)
+                    # (wide: hop / row buckets at their worst-case sizes — this loop is where a call that overflowed the
+                    # one-call sharded plan is redone, on every rank alike)
+                    gd, ri = self.graph_data(batch.roots[k * b: (k + 1) * b].contiguous(), pad_to=b, wide=self.sharded)
                     outs.append(model(gd)[ri])
                     continue
                 hb = self.hip_batch(batch.roots[k * b: (k + 1) * b])
@@ -444,16 +448,58 @@ class ResidentGraph:
             out = torch.cat(outs)
             return out if batch.valid is None else out.index_select(0, batch.valid)
 
+    def _any_rank(self, flag: bool) -> bool:
+        if self.world <= 1:
+            return bool(flag)
+        import torch.distributed as dist
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
+
+    def _overflow_slot(self) -> dict:
+        """a (device int32, pinned host int32, event) triple for one call's overflow flag, from a small ring"""
+        ring = self.__dict__.setdefault("_overflow_ring", [])
+        for sl in ring:
+            if not sl["busy"]:
+                break
+        else:
+            sl = dict(dev=torch.zeros(1, dtype=torch.int32, device=self.device),
+                      host=torch.zeros(1, dtype=torch.int32).pin_memory(), event=torch.cuda.Event(), busy=False)
+            ring.append(sl)
+        sl["busy"] = True
+        sl["dev"].zero_()
+        return sl
+
+    def call_overflowed(self, batch) -> bool:
+        """settle a call issued with batch.defer_overflow_check: waits for that call (long finished when the caller keeps a
+        few calls in flight) and says whether its rows are NaN — the caller then encodes the batch again with
+        batch.force_staged = True (the staged launches) before it hands the rows on"""
+        sl = getattr(batch, "_overflow_slot", None)
+        if sl is None:
+            return False
+        batch._overflow_slot = None
+        sl["event"].synchronize()
+        over = bool(int(sl["host"][0]))
+        sl["busy"] = False
+        if sl in self._unsettled:
+            self._unsettled.remove(sl)
+        return over
+
     def raise_on_overflow(self) -> None:
-        """RuntimeError when a one-call plan since the last check failed (a batch's union graph did not fit the plan's
-        workspace — roots that are each other's sampled neighbours beyond the node table's slack: its rows are NaN).  Synchronises; callers check once per pass, before the rows are declared written."""
-        if self._overflow_acc is None:
-            return
-        n = int(self._overflow_acc.item())
-        self._overflow_acc.zero_()
+        """RuntimeError when a deferred call (batch.defer_overflow_check) overflowed and was never settled through
+        call_overflowed: its NaN rows were handed on.  Synchronises; callers check once per pass, before the rows are
+        declared written.  (Calls that are not deferred are checked — and redone — inside encode.)"""
+        n = 0
+        for sl in list(self._unsettled):
+            sl["event"].synchronize()
+            n += int(sl["host"][0])
+            sl["busy"] = False
+        self._unsettled.clear()
         if n:
-            raise RuntimeError(f"{n} plan call(s) overflowed their batch workspace (rows are NaN): rerun with "
-                               "route='tfrecord' or a smaller inference batch size")
+            raise RuntimeError(f"{n} pipelined plan call(s) overflowed their batch workspace and were not settled "
+                               "(ResidentGraph.call_overflowed): their rows are NaN")
 
     def hip_batch(self, roots: torch.Tensor, train: bool = False):
         """sampled trees + the batch union graph of `roots` (int32 device ids) as a models.HipBatch"""
@@ -471,7 +517,7 @@ class ResidentGraph:
     train_as_graph_data: bool = False
     defer_x: bool = False  # graph_data leaves the dense feature matrix out (GraphData.x_fn builds it on demand)
 
-    def graph_data(self, roots: torch.Tensor, pad_to: Optional[int] = None):
+    def graph_data(self, roots: torch.Tensor, pad_to: Optional[int] = None, wide: bool = False):
         """the batch of `roots` (int32 device ids) as a nn.GraphData on the device — x = the union nodes' feature rows,
         edge_index = the batch union graph's distinct edges (src -> dst, local ids), edge_attr when the job has edge
         features — what the trainer-side collate builds from the samples' records (pyg_graph_builder.py:20-69), for the
@@ -489,13 +535,16 @@ class ResidentGraph:
             b = int(pad_to or n_real)
             if n_real < b:
                 roots = torch.cat([roots, roots[:1].expand(b - n_real)]).contiguous()
-            plan = self._staged_plan(b)
+            plan = self._staged_plan(b, wide)
             plan.sample_and_pull(roots, sampling_seed=self.seed)
             t = plan.batch_tensors()
             m = t["meta"].cpu().tolist()
+            if self._any_rank(bool(m[8])) and not wide:
+                # a hop / feature-row bucket of the default sizes overflowed on some rank: every rank redoes the batch with
+                # the buckets at their worst-case sizes (hop buckets = the whole frontier, row buckets = every union node)
+                return self.graph_data(roots[:n_real], pad_to=pad_to, wide=True)
             if m[8]:
-                raise RuntimeError("sharded training batch failed: a hop / feature-row bucket overflowed "
-                                   "(meta[GIGL_META_OVERFLOW]); raise hop_slack / pull_cap")
+                raise RuntimeError("sharded batch failed with worst-case buckets (meta[GIGL_META_OVERFLOW]): not a capacity")
             n, e = int(m[0]), int(m[1])
             rowptr, rowend, col, root_local, x = t["rowptr"], t["rowend"], t["col"], t["root_local"], t["x"][:n]
             node_ids = levels = None  # (the rows were pulled from their owners: no resident table to read in place)
@@ -534,16 +583,19 @@ class ResidentGraph:
             g.node_ids, g.table, g.levels = node_ids, eng, levels
         return g, root_local[:n_real].to(torch.int64)
 
-    def _staged_plan(self, b: int):
+    def _staged_plan(self, b: int, wide: bool = False):
         """the sharded plan that serves training batches of b roots (dist.DistSagePlan(staged=True): its forward is never
-        run, the weights are placeholders)"""
+        run, the weights are placeholders).  wide: every bucket at its worst-case size — a batch cannot overflow it (the
+        plan a batch is redone through when it overflowed the default buckets)"""
         plans = self.__dict__.setdefault("_staged_plans", {})
-        if b not in plans:
+        if (b, wide) not in plans:
             from .dist import DistSagePlan
             L = len(self.fanouts)
             w = [torch.zeros((4, 2 * (self.feat_dim if l == 0 else 4)), device=self.device) for l in range(L)]
-            plans[b] = DistSagePlan(self.comm, w, [None] * L, b, self.fanouts, max_window_end=self.max_window_end, staged=True)
-        return plans[b]
+            kw = dict(hop_slack=float(max(self.world, 1)), pull_cap=1 << 40) if wide else {}
+            plans[(b, wide)] = DistSagePlan(self.comm, w, [None] * L, b, self.fanouts, max_window_end=self.max_window_end,
+                                            staged=True, **kw)
+        return plans[(b, wide)]
 
     def train_graph(self, roots: torch.Tensor, pad_to: Optional[int] = None):
         """-> (what the model's forward takes, the roots' rows of its output) for a training / validation batch;

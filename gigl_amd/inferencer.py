@@ -220,14 +220,31 @@ class Inferencer:
         if getattr(resident, "sharded", False) or not hasattr(resident, "lane_engine"):
             n_lanes = 1
         main = torch.cuda.current_stream(dev)
-        if getattr(resident, "_overflow_acc", 1) is None:
-            resident._overflow_acc = torch.zeros(1, dtype=torch.int32, device=dev)
         lanes = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)] if n_lanes > 1 else []
         wstream = torch.cuda.Stream(device=dev) if n_lanes > 1 else None  # the writer's: rows arrive in batch order
         use_lanes = False
+        # Calls on the lanes are PIPELINED: call c's rows are handed to the writer when call c + n_lanes has been issued.  By
+        # then call c is long finished, so settling it (did its batch outgrow the plan's workspace? then its rows are NaN and
+        # the batch is encoded again through the staged launches, on its lane) costs no stall — and no call's rows reach the
+        # writer unchecked, whatever the graph's size.
+        pending = []
+
+        def hand_over(entry):
+            hb_, res_, st_ = entry
+            if getattr(resident, "call_overflowed", lambda _b: False)(hb_):
+                hb_.force_staged, hb_.defer_overflow_check = True, False
+                with torch.cuda.stream(st_):
+                    res_ = inferencer.infer_batch(batch=hb_, device=dev)
+            wstream.wait_stream(st_)
+            with torch.cuda.stream(wstream):
+                for t in (res_.embeddings, res_.predictions):
+                    if t is not None:
+                        t.record_stream(wstream)
+                if hb_.root_ids.size:
+                    writer.add(hb_.root_ids, res_.embeddings, res_.predictions, ids_dev=hb_.root_ids_dev)
         for c, hb in enumerate(resident.root_batches(ids, b, groups)):
             if not use_lanes:
-                res = inferencer.infer_batch(batch=hb, device=dev)
+                res = inferencer.infer_batch(batch=hb, device=dev)  # (checked and, if need be, redone inside encode)
                 if hb.root_ids.size:
                     writer.add(hb.root_ids, res.embeddings, res.predictions, ids_dev=hb.root_ids_dev)
                 if c == 0 and n_lanes > 1 and any(p is not None for p in getattr(resident, "_plans", {}).values()):
@@ -240,21 +257,21 @@ class Inferencer:
                 continue
             lane = 1 + (c % n_lanes)  # (lane 0 is the main stream's ctx: left to the first batch)
             hb.lane = lane
+            hb.defer_overflow_check = True
             with torch.cuda.stream(lanes[lane - 1]):
                 res = inferencer.infer_batch(batch=hb, device=dev)
-            wstream.wait_stream(lanes[lane - 1])
-            with torch.cuda.stream(wstream):
-                for t in (res.embeddings, res.predictions):
-                    if t is not None:
-                        t.record_stream(wstream)
-                if hb.root_ids.size:
-                    writer.add(hb.root_ids, res.embeddings, res.predictions, ids_dev=hb.root_ids_dev)
+            pending.append((hb, res, lanes[lane - 1]))
+            if len(pending) >= n_lanes:
+                hand_over(pending.pop(0))
+        while pending:
+            hand_over(pending.pop(0))
         if use_lanes:
             main.wait_stream(wstream)
             for st in lanes:
                 main.wait_stream(st)
         if hasattr(resident, "raise_on_overflow"):
-            resident.raise_on_overflow()  # (a failed call's rows are NaN: the pass must not end quietly)
+            resident.raise_on_overflow()  # (every pipelined call was settled above: nothing to report)
+        self.hbm_overflow_redone = int(getattr(resident, "overflow_redone", 0))  # calls redone through the staged launches
 
 
 def _typed_run(self, cfg: GbmlConfigPbWrapper, inferencer, dev) -> Dict[str, str]:

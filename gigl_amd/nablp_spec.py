@@ -859,6 +859,15 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
                 self._lr_scheduler_cls is not torch.optim.lr_scheduler.ConstantLR or \
                 float(self._lr_scheduler_kwargs.get("factor", 1.0)) != 1.0 or int(enc.conv_layers[-1].out_channels) > 512:
             return None
+        # the plan's Adam is torch's with default betas / eps and no amsgrad: any other optimiser setting keeps the autograd loop
+        if set(self._optim_kwargs) - {"lr", "weight_decay"}:
+            return None
+        # ... and it trains exactly the tensors its load / store move: the conv layers' weights (+ biases / attention vectors).
+        # A model with any other trainable parameter (a decoder MLP, a final linear, batch norm, embeddings) would have it
+        # silently left untrained
+        covered = {id(p) for c in enc.conv_layers for p in c.parameters()}
+        if any(p.requires_grad and id(p) not in covered for p in inner.parameters()):
+            return None
         from ._lib import GiglError
         from .engine import NablpTrainPlan
         try:
@@ -894,10 +903,15 @@ class HipNodeAnchorLinkPredictionSpec(BaseTrainer, BaseInferencer):
                 cur = nxt
         for batch_index, (((roots, cnt, _), rn_roots), nxt) in enumerate(with_next(zip(main, rn)), start=1):
             # the next batch's roots are announced with this step: their sampling + union run beside this step's layers
-            loss = plan.step(roots, cnt, rn_roots, sampling_seed=res.seed, mode=MODE_SPARK_HASH,
-                             next_roots=None if nxt is None else (nxt[0][0], nxt[1]))
+            # (a batch beyond the plan's workspace — NaN loss, nothing trained — is redone once the plan has grown:
+            # NablpTrainPlan.step_checked; a NaN that survives is the loss's own and ends the run like the autograd loop's would)
+            loss = plan.step_checked(roots, cnt, rn_roots, sampling_seed=res.seed, mode=MODE_SPARK_HASH,
+                                     next_roots=None if nxt is None else (nxt[0][0], nxt[1]))
             self.train_plan_steps += 1
-            self.history.append({"batch": batch_index, "loss": float(loss[0])})
+            self.history.append({"batch": batch_index, "loss": loss})
+            if loss != loss:
+                raise FloatingPointError(f"link-prediction training: the loss of batch {batch_index} is NaN (the plan's workspace "
+                                         f"{'was grown' if plan.wide else 'did not overflow'}: the batch itself produced it)")
             if batch_index % every == 0:
                 plan.store(inner.encoder)
                 metrics = self.validate(val_main, val_rn, cfg, device, self.num_val_batches)

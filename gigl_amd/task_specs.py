@@ -315,14 +315,19 @@ class HipGraphSageNodeClassificationSpec(BaseTrainer, BaseInferencer):
         roots_all = torch.from_numpy(ids.astype(np.uint32).view(np.int32)).to(device)
         labels_all = torch.from_numpy(labels).to(device)
         torch.cuda.synchronize(device)
-        loss = None
+        n_steps = -(-ids.size // b)
+
+        def step_args(i):  # (the next batch's sampling + union overlap this batch's layers)
+            lo = i * b
+            return dict(roots=roots_all[lo:lo + b], labels=labels_all[lo:lo + b], sampling_seed=res.seed, mode=res.mode,
+                        next_roots=roots_all[lo + b:lo + 2 * b], next_roots2=roots_all[lo + 2 * b:lo + 3 * b])
         with torch.cuda.stream(self._train_stream):
-            for lo in range(0, ids.size, b):  # (the next batch's sampling + union overlap this batch's layers)
-                loss = plan.step(roots_all[lo:lo + b], labels_all[lo:lo + b], sampling_seed=res.seed, mode=res.mode,
-                                 next_roots=roots_all[lo + b:lo + 2 * b], next_roots2=roots_all[lo + 2 * b:lo + 3 * b])
+            # no host read between the steps; a batch beyond the plan's workspace halts the queue on the device and is redone
+            # — with everything behind it — once the plan has grown (SageTrainPlan.run_steps)
+            losses = plan.run_steps(n_steps, step_args)
         res.engine.synchronize()
         plan.store(model)
-        return loss.detach().clone().reshape(())
+        return losses[-1].detach().clone().reshape(())
 
     @no_grad_eval
     def infer_batch(self, batch: SupervisedNodeClassificationBatch, device: torch.device = torch.device("cpu")

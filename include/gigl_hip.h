@@ -79,6 +79,15 @@ const char* gigl_last_error(gigl_ctx* ctx);
 /* bind the ctx to a caller-owned hipStream_t; NULL is the legacy default stream.  Until this is
  * called the ctx runs on a private non-blocking stream created by gigl_ctx_create. */
 int32_t gigl_ctx_set_stream(gigl_ctx* ctx, void* hip_stream);
+/* Plans created on this ctx AFTER the call (gigl_sage_plan_create, gigl_gat_plan_create, the three training plans)
+ * provision their batch workspace for the WORST batch instead of the typical one.  A regular plan holds
+ * b*(1 + f0 + ...) inner rows — every batch in which no root is another root's sampled neighbour; a batch beyond that
+ * (children of root-valued slots move up a level: up to the whole tree, common on graphs of a few thousand nodes) is
+ * reported through meta[GIGL_META_OVERFLOW] (NaN rows / NaN loss, nothing trained).  on = 1: rows for every node of the
+ * tree and the generic union build (every node numbered, tables sized by the tree): no batch overflows.  The entry
+ * points create such a plan the first time a batch overflows the regular one and redo the batch through it — the
+ * reference's collate has no such bound (rooted_node_neighborhood_data_loader.py:78-158). */
+int32_t gigl_ctx_set_wide_workspaces(gigl_ctx* ctx, int32_t on);
 int32_t gigl_ctx_synchronize(gigl_ctx* ctx);
 /* pre-size the ctx scratch arena (bytes); grows on demand otherwise (grow = hipMalloc, so
  * warm up once before capturing a hipGraph) */
@@ -1158,12 +1167,27 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
 int32_t gigl_sage_train_plan_step(gigl_sage_train_plan* plan, const uint32_t* roots, const int64_t* labels, int32_t n_valid,
                                   const uint32_t* roots_next, int32_t sampling_seed, int32_t mode, float* loss_out);
 /* the same with the batch AFTER the next announced too (roots_next2: what the call after the next will pass; NULL: none):
- * two graph parts — small latency-bound launches — are then in flight on streams of their own next to this batch's layers */
+ * two graph parts — small latency-bound launches — are then in flight on streams of their own next to this batch's layers.
+ * CONTRACT of an announced batch (roots_next / roots_next2, and main_roots_next / rn_roots_next of
+ * gigl_nablp_train_plan_step2): the plan samples from the announced DEVICE buffer on its own stream right away and
+ * recognises the batch at the next call by the buffer's ADDRESS — the buffer must keep its contents, and must not be
+ * handed over again for a different batch, until the step that consumes it has been issued.  A caller that refills one
+ * static buffer per step must not announce it (pass NULL: the step then samples when it is called). */
 int32_t gigl_sage_train_plan_step2(gigl_sage_train_plan* plan, const uint32_t* roots, const int64_t* labels, int32_t n_valid,
                                    const uint32_t* roots_next, const uint32_t* roots_next2, int32_t sampling_seed,
                                    int32_t mode, float* loss_out);
 const float* gigl_sage_train_plan_loss(gigl_sage_train_plan* plan);
 int32_t gigl_sage_train_plan_destroy(gigl_sage_train_plan* plan);
+/* Steps are issued without a host read in between, so a batch that fails (NaN loss: its union graph did not fit the
+ * workspace, or a label outside the output width) HALTS the plan on the device: every later step of the queue trains
+ * nothing and reports NaN too — the batches behind a failed one are never applied ahead of it.  The host finds the first
+ * NaN in the losses it collected, deals with that batch (a wider plan: gigl_ctx_set_wide_workspaces +
+ * gigl_sage_train_plan_adopt, or skipping it), and resumes: the halt flag is cleared on the plan's stream. */
+int32_t gigl_sage_train_plan_resume(gigl_sage_train_plan* plan);
+/* dst takes over src's optimiser state (Adam's moments and step counter; the weights are the caller's buffers, shared by
+ * construction): a plan re-created with wider workspaces (gigl_ctx_set_wide_workspaces) continues the training run of
+ * the one it replaces.  Same shape and widths; synchronises both plans' streams. */
+int32_t gigl_sage_train_plan_adopt(gigl_sage_train_plan* dst, gigl_sage_train_plan* src);
 
 /* ---- one LINK-PREDICTION training step per call, all of it in the library (round 5).  Replaces the loop body of
  * NodeAnchorBasedLinkPredictionModelingTaskSpec.train (python/gigl/src/common/modeling_task_specs/
@@ -1202,6 +1226,8 @@ const float* gigl_nablp_train_plan_loss(gigl_nablp_train_plan* plan);
 /* the LAST step's parameter gradients of layer `layer` (the two encodes' added): gw DEVICE [dims[l+1]][2 dims[l]] (= d loss
  * / d [W_l | W_r]), gb DEVICE [dims[l+1]] (may be NULL) — what the step's Adam update consumed; for gradient parity tests */
 int32_t gigl_nablp_train_plan_grads(gigl_nablp_train_plan* plan, int32_t layer, float* gw, float* gb);
+/* as gigl_sage_train_plan_adopt, for the link-prediction plans (GraphSAGE and GAT encoders alike) */
+int32_t gigl_nablp_train_plan_adopt(gigl_nablp_train_plan* dst, gigl_nablp_train_plan* src);
 int32_t gigl_nablp_train_plan_destroy(gigl_nablp_train_plan* plan);
 /* The same plan with the GAT encoder configs[4] names (GAT.init_conv_layers, python/gigl/src/common/models/pyg/
  * homogeneous.py:300-343): hops == 2, heads[0] in {1, 2, 4} concatenated heads of channels[0] in the first layer, one head of

@@ -417,64 +417,7 @@ def test_sample_with_replacement_takes_the_staged_forward_on_the_hbm_route(golde
                                rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("small", [False, True])
-def test_overflowed_plan_calls_are_reported_or_redone_by_the_hbm_route(small, monkeypatch):
-    """a root that is its own sampled neighbour makes the children of that occurrence inner-level nodes: with b = 1,
-    fanout [64, 64] the batch does not fit the plan's activation workspace (tests/test_gpu_plan.py).  On a large graph
-    the call's rows are NaN and ResidentGraph.raise_on_overflow reports it (the Inferencer checks at the end of a pass);
-    on a small one (hbm.SMALL_GRAPH_NODES: such batches are common there) the flag is read per call and the call is redone
-    through the staged launches: rows equal to the oracle's forward, nothing to report"""
-    import oracle
-    from oracle import gnn_ref
-    import gigl_amd.hbm as hbm_mod
-    from gigl_amd.engine import HipEngine
-    from gigl_amd.hbm import ResidentGraph
-    from gigl_amd.models import GraphSAGE
-    if not small:
-        monkeypatch.setattr(hbm_mod, "SMALL_GRAPH_NODES", 0)
-    n, d = 400, 8
-    found = None
-    for r in range(1, 200):
-        nbrs = np.unique(np.concatenate([[r], np.arange(200, 320)])).astype(np.uint32)
-        rowptr = np.zeros(n + 1, dtype=np.int64)
-        rowptr[r + 1:] = nbrs.size
-        nbr_o, _ = oracle.sample_khop(rowptr, nbrs, np.array([r], np.uint32), [64, 64], canonical=True)
-        if r in nbr_o[0] and int(oracle.union_build(np.array([r], np.uint32), [64, 64], nbr_o)["meta"][3]) > 65:
-            found = (r, rowptr, nbrs)
-            break
-    assert found is not None
-    r, rowptr, col = found
-    eng = HipEngine(0)
-    try:
-        eng.load_csc(rowptr, col)
-        eng.load_features(np.random.default_rng(0).standard_normal((n, d)).astype(np.float32))
-        res = ResidentGraph.from_engine(eng, np.arange(n), [64, 64])
-        torch.manual_seed(0)
-        model = GraphSAGE(d, 8, 4, num_layers=2).to(eng.device)
-        (hb,) = list(res.root_batches(np.array([r]), 1, 1))
-        out = res.encode(model, hb)
-        if small:
-            nbr_o, _ = oracle.sample_khop(rowptr, col, np.array([r], np.uint32), [64, 64], canonical=True)
-            u = oracle.union_build(np.array([r], np.uint32), [64, 64], nbr_o)
-            feats = np.random.default_rng(0).standard_normal((n, d)).astype(np.float32)
-            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-            want = gnn_ref.graphsage_forward(torch.from_numpy(feats[u["nodes"].astype(np.int64)]),
-                                             gnn_ref.union_edge_index(u["rowptr"], u["col"]), sd, 2)
-            want = want[torch.from_numpy(u["root_local"].astype(np.int64))]
-            np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
-            res.raise_on_overflow()  # (nothing to report)
-        else:
-            assert torch.isnan(out).all()
-            with pytest.raises(RuntimeError, match="overflowed"):
-                res.raise_on_overflow()
-            res.raise_on_overflow()  # (the counter was reset)
-        (ok,) = list(res.root_batches(np.array([r + 200 if r + 200 < n else 201]), 1, 1))
-        assert torch.isfinite(res.encode(model, ok)).all()
-        res.raise_on_overflow()
-        res.close()
-    finally:
-        eng.close()
+# (batches that outgrow the one-call plan's workspace: tests/test_gpu_overflow.py)
 
 
 @pytest.mark.gpu
