@@ -45,7 +45,7 @@ SYMBOLS = [
     "gigl_gatv2_aggregate_edge_backward", "gigl_transformer_aggregate_edge", "gigl_transformer_aggregate_edge_backward",
     "gigl_sage_plan_stats", "gigl_retrieval_loss", "gigl_retrieval_loss_backward",
     "gigl_comm_unique_id", "gigl_dist_init", "gigl_dist_init_local", "gigl_dist_init_callback", "gigl_comm_info",
-    "gigl_comm_all_to_all", "gigl_comm_flush_local", "gigl_comm_traffic", "gigl_comm_set_fixed_blocks", "gigl_ctx_set_wide_workspaces", "gigl_sage_train_plan_adopt", "gigl_sage_train_plan_resume", "gigl_nablp_train_plan_adopt", "gigl_comm_destroy", "gigl_dist_plan_batch_features", "gigl_dist_plan_batch_graph", "gigl_dist_plan_create",
+    "gigl_comm_all_to_all", "gigl_comm_flush_local", "gigl_comm_traffic", "gigl_comm_set_fixed_blocks", "gigl_ctx_set_wide_workspaces", "gigl_sage_train_plan_adopt", "gigl_sage_train_plan_moments", "gigl_nablp_train_plan_moments", "gigl_sage_train_plan_resume", "gigl_nablp_train_plan_adopt", "gigl_comm_destroy", "gigl_dist_plan_batch_features", "gigl_dist_plan_batch_graph", "gigl_dist_plan_create",
     "gigl_dist_plan_set_weights", "gigl_dist_plan_phases", "gigl_dist_plan_phase", "gigl_dist_plan_run",
     "gigl_dist_plan_run_local", "gigl_dist_plan_run_interleaved", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
     "gigl_dist_plan_set_hot_rows", "gigl_dist_plan_set_peer_tables", "gigl_ipc_export", "gigl_ipc_open", "gigl_ipc_close",
@@ -61,7 +61,7 @@ SYMBOLS = [
     "gigl_typed_plan_merged_csr", "gigl_sage_plan_half_split", "gigl_sage_plan_fused_layers", "gigl_sort_distinct_u64", "gigl_sort_distinct_u32",
     "gigl_typed_plan_merged_csr_ex", "gigl_hgt_aggregate_act", "gigl_dist_plan_set_aggr", "gigl_typed_plan_run_nodes", "gigl_typed_plan_run_edges", "gigl_typed_plan_clone", "gigl_hgt_infer_create", "gigl_hgt_infer_run",
     "gigl_hgt_infer_set_model", "gigl_hgt_infer_use_graph", "gigl_hgt_infer_destroy",
-    "gigl_sage_plan_run_part", "gigl_sage_plan_overflow_add",
+    "gigl_sage_plan_run_part", "gigl_sage_plan_set_graph_stream", "gigl_sage_plan_overflow_add",
     "gigl_sage_train_plan_create", "gigl_sage_train_plan_step", "gigl_sage_train_plan_step2", "gigl_sage_train_plan_loss", "gigl_sage_train_plan_destroy",
     "gigl_nablp_train_plan_create", "gigl_nablp_train_plan_step", "gigl_nablp_train_plan_step2", "gigl_gat_nablp_train_plan_create", "gigl_gat_nablp_train_plan_grads", "gigl_nablp_train_plan_loss", "gigl_nablp_train_plan_destroy", "gigl_nablp_train_plan_grads",
 ]
@@ -311,6 +311,8 @@ def load() -> C.CDLL:
         "gigl_comm_set_fixed_blocks": [vp, i32],
         "gigl_ctx_set_wide_workspaces": [vp, i32],
         "gigl_sage_train_plan_adopt": [vp, vp],
+        "gigl_sage_train_plan_moments": [vp, i32, vp, vp, vp, vp],
+        "gigl_nablp_train_plan_moments": [vp, i32, vp, vp],
         "gigl_sage_train_plan_resume": [vp],
         "gigl_nablp_train_plan_adopt": [vp, vp],
         "gigl_dist_plan_batch_features": [vp, vp],
@@ -404,6 +406,7 @@ def load() -> C.CDLL:
         "gigl_sage_plan_half_split": [vp],
         "gigl_sage_plan_fused_layers": [vp],
         "gigl_sage_plan_overflow_add": [vp, vp],
+        "gigl_sage_plan_set_graph_stream": [vp, vp, i32],
         "gigl_sage_train_plan_create": [vp, vp, vp, i32, P(i32), i32, P(i32), vp, vp, i32, C.c_float, C.c_float, C.c_float,
                                         C.c_float, C.c_float, vp],
         "gigl_sage_train_plan_step": [vp, vp, vp, i32, vp, i32, i32, vp],

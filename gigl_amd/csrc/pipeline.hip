@@ -26,6 +26,9 @@ struct Segment {
   hipGraphExec_t exec = nullptr;
 };
 
+// stages [0, GRAPH_STAGES) = sample + union (the GRAPH part: integer work, latency-bound, independent of the weights)
+constexpr int GRAPH_STAGES = 2;
+
 }  // namespace
 
 struct gigl_sage_plan {
@@ -96,6 +99,13 @@ struct gigl_sage_plan {
   uint32_t cap_prof_mask = 0;
   uint64_t cap_arena_gen = 0;  // the ctx arena the captured launches point into
   bool captured = false;
+  // gigl_sage_plan_set_graph_stream: the GRAPH part of every call is issued on this stream (the caller's, typically of a
+  // HIGHER priority than the ctx stream) and the layers wait for it on an event — with several plans in flight the
+  // latency-bound sampler / union launches of one call are then dispatched ahead of the other calls' bandwidth-bound
+  // layers instead of queueing for CUs behind them
+  hipStream_t gstream = nullptr;
+  bool split = false;
+  hipEvent_t ev_in = nullptr, ev_graph = nullptr;
 };
 
 namespace {
@@ -378,10 +388,13 @@ int32_t capture_segments(gigl_sage_plan* p, int32_t sampling_seed, int32_t mode)
     // pointer of the call, instead of a captured write to a static buffer and a device copy of it per call)
     const bool timed = (stage_kernel_mask(p, s) & mask) != 0 || s == n - 1;
     int e = s + 1;
-    while (e < n - 1 && ((stage_kernel_mask(p, e) & mask) != 0) == timed && s != n - 1) ++e;
+    while (e < n - 1 && ((stage_kernel_mask(p, e) & mask) != 0) == timed && s != n - 1 && !(p->split && e == GRAPH_STAGES)) ++e;
     sg.s1 = e;
     if (!timed) {
       hipGraph_t graph = nullptr;
+      // (a graph-part segment of a split plan is captured from — and later launched on — the plan's graph stream)
+      hipStream_t keep = ctx->stream;
+      if (p->split && sg.s1 <= GRAPH_STAGES) ctx->stream = p->gstream;
       hipError_t err = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
       int32_t rc = GIGL_OK;
       if (err == hipSuccess) {
@@ -389,6 +402,7 @@ int32_t capture_segments(gigl_sage_plan* p, int32_t sampling_seed, int32_t mode)
         hipError_t e2 = hipStreamEndCapture(ctx->stream, &graph);
         if (rc == GIGL_OK && e2 != hipSuccess) err = e2;
       }
+      ctx->stream = keep;
       if (rc == GIGL_OK && err == hipSuccess) err = hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0);
       if (graph) hipGraphDestroy(graph);
       if (rc != GIGL_OK) return rc;
@@ -534,7 +548,10 @@ int32_t gigl_sage_plan_destroy(gigl_sage_plan* p) {
     hipSetDevice(p->ctx->device);
     hipStreamSynchronize(p->ctx->stream);
   }
+  if (p->gstream) hipStreamSynchronize(p->gstream);
   drop_graphs(p);
+  if (p->ev_in) hipEventDestroy(p->ev_in);
+  if (p->ev_graph) hipEventDestroy(p->ev_graph);
   for (void* q : p->owned) hipFree(q);
   delete p;
   return GIGL_OK;
@@ -954,6 +971,33 @@ int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sam
     p->cap_arena_gen = ctx->arena_gen;
     return GIGL_OK;
   }
+  if (p->split) {
+    // graph part on the plan's graph stream: behind whatever produced `roots` on the ctx stream, and behind the layers of
+    // the previous call (they read the union graph this call's graph part rewrites)
+    GIGL_HIP_CHECK(ctx, hipEventRecord(p->ev_in, ctx->stream));
+    GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(p->gstream, p->ev_in, 0));
+    GIGL_HIP_CHECK(ctx, hipMemcpyAsync(p->roots_buf, roots, (size_t)p->b * 4, hipMemcpyDeviceToDevice, p->gstream));
+    hipStream_t keep = ctx->stream;
+    bool joined = false;
+    for (const Segment& sg : p->segs) {
+      const bool gpart = sg.s1 <= GRAPH_STAGES;
+      if (!gpart && !joined) {  // the layers wait for the graph part
+        GIGL_HIP_CHECK(ctx, hipEventRecord(p->ev_graph, p->gstream));
+        GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(keep, p->ev_graph, 0));
+        joined = true;
+      }
+      ctx->stream = gpart ? p->gstream : keep;
+      int32_t rc = GIGL_OK;
+      if (sg.exec) {
+        if (hipGraphLaunch(sg.exec, ctx->stream) != hipSuccess) rc = GIGL_E_HIP;
+      } else {
+        rc = enqueue_range(p, sg.s0, sg.s1, p->roots_buf, sampling_seed, mode, out);
+      }
+      ctx->stream = keep;
+      if (rc != GIGL_OK) return rc == GIGL_E_HIP ? gigl_fail(ctx, rc, "hipGraphLaunch failed") : rc;
+    }
+    return GIGL_OK;
+  }
   GIGL_HIP_CHECK(ctx, hipMemcpyAsync(p->roots_buf, roots, (size_t)p->b * 4, hipMemcpyDeviceToDevice, ctx->stream));
   for (const Segment& sg : p->segs) {
     if (sg.exec) {
@@ -963,6 +1007,24 @@ int32_t gigl_sage_plan_run(gigl_sage_plan* p, const uint32_t* roots, int32_t sam
       if (rc != GIGL_OK) return rc;
     }
   }
+  return GIGL_OK;
+}
+
+int32_t gigl_sage_plan_set_graph_stream(gigl_sage_plan* p, void* hip_stream, int32_t on) {
+  if (!p) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, !on || hip_stream, "the graph part needs a created stream of its own");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (p->gstream) GIGL_HIP_CHECK(ctx, hipStreamSynchronize(p->gstream));
+  drop_graphs(p);
+  if (on && !p->ev_in) {
+    if (hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_graph, hipEventDisableTiming) != hipSuccess)
+      return gigl_fail(ctx, GIGL_E_HIP, "hipEventCreate failed");
+  }
+  p->gstream = on ? (hipStream_t)hip_stream : nullptr;
+  p->split = on != 0;
   return GIGL_OK;
 }
 
@@ -2200,6 +2262,42 @@ __global__ __launch_bounds__(256) void lp_add2_kernel(const float* __restrict__ 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
 }
 }  // namespace
+
+int32_t gigl_sage_train_plan_moments(gigl_sage_train_plan* t, int32_t layer, float* m_w, float* v_w, float* m_b, float* v_b) {
+  if (!t) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = t->ctx;
+  GIGL_REQUIRE(ctx, layer >= 0 && layer < t->L, "layer %d", layer);
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t nw = (size_t)t->dims[layer + 1] * 2 * t->dims[layer], nb = (size_t)t->dims[layer + 1];
+  float* dst[4] = {m_w, v_w, m_b, v_b};
+  for (int k = 0; k < 4; ++k)
+    if (dst[k])
+      GIGL_HIP_CHECK(ctx, hipMemcpyAsync(dst[k], t->mom[4 * layer + k], (k < 2 ? nw : nb) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  return GIGL_OK;
+}
+
+int32_t gigl_nablp_train_plan_moments(gigl_nablp_train_plan* t, int32_t index, float* m, float* v) {
+  if (!t) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = t->ctx;
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const float *sm = nullptr, *sv = nullptr;
+  size_t n = 0;
+  if (t->kind == 1) {
+    GIGL_REQUIRE(ctx, index >= 0 && index < 8, "tensor %d", index);
+    sm = t->gat.mom[2 * index];
+    sv = t->gat.mom[2 * index + 1];
+    n = (size_t)t->gat.n[index];
+  } else {
+    GIGL_REQUIRE(ctx, index >= 0 && index < 2 * t->L, "tensor %d", index);
+    const int l = index >> 1, bias = index & 1;
+    sm = t->mom[4 * l + 2 * bias];
+    sv = t->mom[4 * l + 2 * bias + 1];
+    n = bias ? (size_t)t->dims[l + 1] : (size_t)t->dims[l + 1] * 2 * t->dims[l];
+  }
+  if (m && n) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(m, sm, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  if (v && n) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(v, sv, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  return GIGL_OK;
+}
 
 int32_t gigl_sage_train_plan_adopt(gigl_sage_train_plan* dst, gigl_sage_train_plan* src) {
   if (!dst || !src) return GIGL_E_INVALID_ARG;

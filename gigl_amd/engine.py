@@ -1251,6 +1251,14 @@ class SagePlan:
         (gigl_sage_plan_fused_layers)"""
         return bool(self._lib.gigl_sage_plan_fused_layers(self._plan))
 
+    def set_graph_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
+        """issue the graph part (sample + union) of every later call on `stream` — typically
+        torch.cuda.Stream(priority=-1), a higher priority than the engine's stream — with the layers waiting on an event
+        (gigl_sage_plan_set_graph_stream); None: back to one stream"""
+        self._graph_stream = stream  # (kept alive with the plan)
+        check(self._lib.gigl_sage_plan_set_graph_stream(self._plan, C.c_void_p(stream.cuda_stream) if stream is not None else None,
+                                                        1 if stream is not None else 0), self.eng._ctx)
+
     def overflow_add(self, acc: torch.Tensor) -> None:
         """acc (int32 [1], device) += 1 when the batch set run last failed (its rows are NaN): gigl_sage_plan_overflow_add,
         no synchronisation"""
@@ -1409,6 +1417,24 @@ class SageTrainPlan:
             roots = torch.cat([roots, roots[:1].expand(self.b - k)])
         return roots.contiguous()
 
+    def moments(self) -> dict:
+        """Adam's moments as torch.optim.Adam names them, keyed like the model's state dict: {"conv_layers.l.lin_l.weight":
+        (exp_avg, exp_avg_sq), ...lin_r.weight, ...lin_l.bias} (gigl_sage_train_plan_moments; the fused matrix split back)"""
+        out = {}
+        for l, (w, b) in enumerate(zip(self.w, self.bias)):
+            mw, vw = torch.empty_like(w), torch.empty_like(w)
+            mb = vb = None
+            if b is not None:
+                mb, vb = torch.empty_like(b), torch.empty_like(b)
+            p_ = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+            check(self._lib.gigl_sage_train_plan_moments(self._plan, l, p_(mw), p_(vw), p_(mb), p_(vb)), self.eng._ctx)
+            d = int(w.shape[1]) // 2
+            out[f"conv_layers.{l}.lin_l.weight"] = (mw[:, :d], vw[:, :d])
+            out[f"conv_layers.{l}.lin_r.weight"] = (mw[:, d:], vw[:, d:])
+            if b is not None:
+                out[f"conv_layers.{l}.lin_l.bias"] = (mb, vb)
+        return out
+
     def resume(self) -> None:
         """clear the device-side halt a failed batch left (gigl_sage_train_plan_resume): later steps train again"""
         check(self._lib.gigl_sage_train_plan_resume(self._plan), self.eng._ctx)
@@ -1558,6 +1584,23 @@ class NablpTrainPlan:
                                                     C.c_void_p(gb.data_ptr()) if gb is not None else None), self.eng._ctx)
         return gw, gb
 
+    def moments(self) -> dict:
+        """as SageTrainPlan.moments (gigl_nablp_train_plan_moments)"""
+        out = {}
+        for l, (w, b) in enumerate(zip(self.w, self.bias)):
+            mw, vw = torch.empty_like(w), torch.empty_like(w)
+            check(self._lib.gigl_nablp_train_plan_moments(self._plan, 2 * l, C.c_void_p(mw.data_ptr()), C.c_void_p(vw.data_ptr())),
+                  self.eng._ctx)
+            d = int(w.shape[1]) // 2
+            out[f"conv_layers.{l}.lin_l.weight"] = (mw[:, :d], vw[:, :d])
+            out[f"conv_layers.{l}.lin_r.weight"] = (mw[:, d:], vw[:, d:])
+            if b is not None:
+                mb, vb = torch.empty_like(b), torch.empty_like(b)
+                check(self._lib.gigl_nablp_train_plan_moments(self._plan, 2 * l + 1, C.c_void_p(mb.data_ptr()),
+                                                              C.c_void_p(vb.data_ptr())), self.eng._ctx)
+                out[f"conv_layers.{l}.lin_l.bias"] = (mb, vb)
+        return out
+
     def close(self) -> None:
         if getattr(self, "_plan", None):
             self._lib.gigl_nablp_train_plan_destroy(self._plan)
@@ -1640,6 +1683,21 @@ class GatNablpTrainPlan(NablpTrainPlan):
                                                         *[(C.c_void_p(t.data_ptr()) if t is not None else None) for t in outs]),
               self.eng._ctx)
         return tuple(outs)
+
+
+    def moments(self) -> dict:
+        """{"conv_layers.l.lin.weight" | att_src | att_dst | bias: (exp_avg, exp_avg_sq)} (gigl_nablp_train_plan_moments)"""
+        out = {}
+        for l in range(2):
+            for k, (name, ts) in enumerate((("lin.weight", self.w), ("att_src", self.att_src), ("att_dst", self.att_dst),
+                                            ("bias", self.bias))):
+                if ts[l] is None:
+                    continue
+                m, v = torch.empty_like(ts[l]), torch.empty_like(ts[l])
+                check(self._lib.gigl_nablp_train_plan_moments(self._plan, 4 * l + k, C.c_void_p(m.data_ptr()),
+                                                              C.c_void_p(v.data_ptr())), self.eng._ctx)
+                out[f"conv_layers.{l}.{name}"] = (m, v)
+        return out
 
 
 class GatPlan(SagePlan):

@@ -223,19 +223,22 @@ class Inferencer:
         lanes = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)] if n_lanes > 1 else []
         wstream = torch.cuda.Stream(device=dev) if n_lanes > 1 else None  # the writer's: rows arrive in batch order
         use_lanes = False
-        # Calls on the lanes are PIPELINED: call c's rows are handed to the writer when call c + n_lanes has been issued.  By
+        # Calls on the lanes are PIPELINED: call c's rows are handed to the writer when call c + 2 n_lanes has been issued.  By
         # then call c is long finished, so settling it (did its batch outgrow the plan's workspace? then its rows are NaN and
         # the batch is encoded again through the staged launches, on its lane) costs no stall — and no call's rows reach the
         # writer unchecked, whatever the graph's size.
         pending = []
+        depth = 2 * n_lanes  # (the oldest unsettled call finished long ago: settling it never drains the launch queue)
 
         def hand_over(entry):
-            hb_, res_, st_ = entry
+            hb_, res_, st_, done = entry
             if getattr(resident, "call_overflowed", lambda _b: False)(hb_):
                 hb_.force_staged, hb_.defer_overflow_check = True, False
                 with torch.cuda.stream(st_):
                     res_ = inferencer.infer_batch(batch=hb_, device=dev)
-            wstream.wait_stream(st_)
+                    done = torch.cuda.Event()
+                    done.record(st_)
+            wstream.wait_event(done)  # (the call's own end: its lane has later calls queued behind it by now)
             with torch.cuda.stream(wstream):
                 for t in (res_.embeddings, res_.predictions):
                     if t is not None:
@@ -260,8 +263,10 @@ class Inferencer:
             hb.defer_overflow_check = True
             with torch.cuda.stream(lanes[lane - 1]):
                 res = inferencer.infer_batch(batch=hb, device=dev)
-            pending.append((hb, res, lanes[lane - 1]))
-            if len(pending) >= n_lanes:
+                done = torch.cuda.Event()
+                done.record(lanes[lane - 1])
+            pending.append((hb, res, lanes[lane - 1], done))
+            if len(pending) >= depth:
                 hand_over(pending.pop(0))
         while pending:
             hand_over(pending.pop(0))

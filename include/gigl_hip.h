@@ -1137,6 +1137,15 @@ int32_t gigl_sage_plan_fused_layers(gigl_sage_plan* plan);
  * flag into one counter and read it once (gigl_amd/hbm.py) */
 int32_t gigl_sage_plan_overflow_add(gigl_sage_plan* plan, int32_t* acc);
 int32_t gigl_sage_plan_use_graph(gigl_sage_plan* plan, int32_t on);
+/* The GRAPH part of every later call (sample + union: latency-bound integer launches that move a few percent of the
+ * step's bytes) is issued on `hip_stream` — a stream of the caller's, typically created with a HIGHER priority than the
+ * ctx stream — and the layers wait for it on an event; the call still returns without synchronising and is complete when
+ * the ctx stream is.  With several plans in flight (one per ctx / stream, as bench.py and the inferencer run them) the
+ * graph part of one call is then dispatched ahead of the other calls' bandwidth-bound layers instead of queueing for
+ * compute units behind them.  Rows are unchanged (same launches, same order within the call).  hipGraph replay
+ * (gigl_sage_plan_use_graph) captures the two parts separately; eager calls ignore the setting.  on = 0: back to one
+ * stream.  Synchronises both streams. */
+int32_t gigl_sage_plan_set_graph_stream(gigl_sage_plan* plan, void* hip_stream, int32_t on);
 int32_t gigl_sage_plan_flush_profile(gigl_sage_plan* plan);
 int32_t gigl_sage_plan_destroy(gigl_sage_plan* plan);
 
@@ -1188,6 +1197,11 @@ int32_t gigl_sage_train_plan_resume(gigl_sage_train_plan* plan);
  * construction): a plan re-created with wider workspaces (gigl_ctx_set_wide_workspaces) continues the training run of
  * the one it replaces.  Same shape and widths; synchronises both plans' streams. */
 int32_t gigl_sage_train_plan_adopt(gigl_sage_train_plan* dst, gigl_sage_train_plan* src);
+/* Adam's first / second moments of `layer`'s fused weight [dims[l+1]][2 dims[l]] and bias [dims[l+1]] copied into the
+ * caller's DEVICE buffers on the ctx stream (any may be NULL): what torch.optim.Adam keeps as exp_avg / exp_avg_sq —
+ * checkpointing, and the parity tests (moments are linear / quadratic in the gradients: comparable where the raw
+ * parameters of elements with rounding-noise gradients are not) */
+int32_t gigl_sage_train_plan_moments(gigl_sage_train_plan* plan, int32_t layer, float* m_w, float* v_w, float* m_b, float* v_b);
 
 /* ---- one LINK-PREDICTION training step per call, all of it in the library (round 5).  Replaces the loop body of
  * NodeAnchorBasedLinkPredictionModelingTaskSpec.train (python/gigl/src/common/modeling_task_specs/
@@ -1228,6 +1242,9 @@ const float* gigl_nablp_train_plan_loss(gigl_nablp_train_plan* plan);
 int32_t gigl_nablp_train_plan_grads(gigl_nablp_train_plan* plan, int32_t layer, float* gw, float* gb);
 /* as gigl_sage_train_plan_adopt, for the link-prediction plans (GraphSAGE and GAT encoders alike) */
 int32_t gigl_nablp_train_plan_adopt(gigl_nablp_train_plan* dst, gigl_nablp_train_plan* src);
+/* moments of one parameter tensor of a link-prediction plan: GraphSAGE encoder: index = 2 * layer (fused weight) | 2 * layer
+ * + 1 (bias); GAT encoder: index 0..7 = w0, att_src0, att_dst0, bias0, w1, att_src1, att_dst1, bias1 */
+int32_t gigl_nablp_train_plan_moments(gigl_nablp_train_plan* plan, int32_t index, float* m, float* v);
 int32_t gigl_nablp_train_plan_destroy(gigl_nablp_train_plan* plan);
 /* The same plan with the GAT encoder configs[4] names (GAT.init_conv_layers, python/gigl/src/common/models/pyg/
  * homogeneous.py:300-343): hops == 2, heads[0] in {1, 2, 4} concatenated heads of channels[0] in the first layer, one head of

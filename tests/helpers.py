@@ -74,3 +74,41 @@ def check_rnn_validity(root, edges, nodes, rowptr, col, fanout, hops=2, exact_co
             if len(nbrs(a)) <= fanout:
                 want |= set((b, a) for b in nbrs(a))
         assert want <= set(edges)
+
+
+def adam_state_errors(got_params, got_moments, ref_params, ref_moments, determined=1e-3):
+    """How far a trained state is from the reference's, in the quantities that CAN be compared after several Adam steps.
+    Adam moves a parameter by lr * m_hat / (sqrt(v_hat) + eps): where a gradient element is rounding noise (|g| ~ 1e-9 of
+    the tensor's largest) the quotient is +-1 whatever the magnitude, and two correct implementations drift apart by up
+    to lr per step — raw parameters of such elements say nothing.  Compared instead, per tensor:
+      * exp_avg / exp_avg_sq (linear / quadratic in the gradients), as max |diff| / max |reference| — every element;
+      * the parameters on the DETERMINED set: elements whose gradient RMS sqrt(exp_avg_sq) is >= `determined` of the
+        tensor's largest (the reference's moments decide the set), as max |diff|.
+    *_params: name -> tensor; *_moments: name -> (exp_avg, exp_avg_sq).  -> {name: (err_m, err_v, err_param, share of the
+    tensor that is determined)}"""
+    import torch
+    out = {}
+    for k, (mr, vr) in ref_moments.items():
+        m, v = got_moments[k]
+        mr, vr, m, v = (t.detach().double().cpu().reshape(-1) for t in (mr, vr, m, v))
+        p, pr = got_params[k].detach().double().cpu().reshape(-1), ref_params[k].detach().double().cpu().reshape(-1)
+        rms = vr.sqrt()
+        det = rms >= determined * rms.max()
+        out[k] = (float((m - mr).abs().max() / (mr.abs().max() + 1e-300)), float((v - vr).abs().max() / (vr.max() + 1e-300)),
+                  float((p - pr).abs()[det].max()) if bool(det.any()) else 0.0, float(det.double().mean()))
+    return out
+
+
+def torch_adam_moments(opt, named_params):
+    """name -> (exp_avg, exp_avg_sq) of a torch.optim.Adam over `named_params` (name -> parameter)"""
+    return {k: (opt.state[p]["exp_avg"], opt.state[p]["exp_avg_sq"]) for k, p in named_params.items() if p in opt.state}
+
+
+def assert_adam_state(tag, got_params, got_moments, ref_params, ref_moments, tol_m, tol_v, tol_p):
+    errs = adam_state_errors(got_params, got_moments, ref_params, ref_moments)
+    worst = (max(e[0] for e in errs.values()), max(e[1] for e in errs.values()), max(e[2] for e in errs.values()),
+             min(e[3] for e in errs.values()))
+    print(f"{tag}: Adam state vs the reference: exp_avg {worst[0]:.2e} exp_avg_sq {worst[1]:.2e} of the tensors' largest, "
+          f"parameters on the determined set {worst[2]:.2e} (smallest determined share {worst[3]:.2f})")
+    for k, (em, ev, ep, share) in errs.items():
+        assert em <= tol_m and ev <= tol_v and ep <= tol_p, (tag, k, em, ev, ep, share)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import oracle
-from helpers import rmat_edges
+from helpers import assert_adam_state, rmat_edges, torch_adam_moments
 from oracle import gnn_ref
 
 
@@ -31,7 +31,7 @@ def _autograd_losses(eng, model, roots_all, labels_all, b, fan, steps, lr, wd):
     """the step GraphedTrainStep captures, eagerly: sample + union in HBM, forward with autograd, CE, backward, Adam"""
     import torch.nn.functional as F
     from gigl_amd.models import HipBatch
-    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd, foreach=False)  # (amsgrad-free, one tensor at a time)
     losses = []
     for i in range(steps):
         roots = roots_all[i * b:(i + 1) * b]
@@ -43,7 +43,7 @@ def _autograd_losses(eng, model, roots_all, labels_all, b, fan, steps, lr, wd):
         loss.backward()
         opt.step()
         losses.append(float(loss))
-    return losses
+    return losses, torch_adam_moments(opt, dict(model.named_parameters()))
 
 
 @pytest.mark.gpu
@@ -62,7 +62,7 @@ def test_library_training_step_equals_the_autograd_step(setup, dims, fan, b, pre
     lib = GraphSAGE(dims[0], dims[1], dims[2], num_layers=2).to(eng.device)
     lib.load_state_dict(ref.state_dict())
     ref.train()
-    want = _autograd_losses(eng, ref, roots_all, labels_all, b, fan, steps, 0.01, 5e-4)
+    want, ref_moments = _autograd_losses(eng, ref, roots_all, labels_all, b, fan, steps, 0.01, 5e-4)
     st = torch.cuda.Stream(device=eng.device)
     torch.cuda.synchronize()
     eng.bind_stream(st)
@@ -76,12 +76,13 @@ def test_library_training_step_equals_the_autograd_step(setup, dims, fan, b, pre
     eng.synchronize()
     got = [float(v) for v in got]
     plan.store(lib)
+    moments = plan.moments()
     plan.close()
     eng.bind_stream(torch.cuda.current_stream(eng.device))
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
-    for (k, a), (_, bb) in zip(lib.state_dict().items(), ref.state_dict().items()):
-        # (Adam divides by sqrt(v): an element whose gradients are rounding noise moves by up to lr per step either way)
-        np.testing.assert_allclose(a.cpu().numpy(), bb.cpu().numpy(), rtol=2e-3, atol=2e-4, err_msg=k)
+    # trained state: Adam's moments everywhere, the parameters where the gradients (not their rounding) decide the direction
+    assert_adam_state("node-classification plan vs autograd", lib.state_dict(), moments, ref.state_dict(), ref_moments,
+                      tol_m=2e-5, tol_v=2e-5, tol_p=1e-5)
 
 
 @pytest.mark.gpu
@@ -97,7 +98,7 @@ def test_library_training_step_against_the_cpu_restatement(setup):
     torch.manual_seed(2)
     model = GraphSAGE(100, 32, 7, num_layers=2)
     params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    opt = torch.optim.Adam(list(params.values()), lr=0.01, weight_decay=5e-4)
+    opt = torch.optim.Adam(list(params.values()), lr=0.01, weight_decay=5e-4, foreach=False)
     want = []
     for lo in range(0, roots_np.size, b):
         roots = roots_np[lo:lo + b]
@@ -124,11 +125,12 @@ def test_library_training_step_against_the_cpu_restatement(setup):
     eng.synchronize()
     got = [float(v) for v in got]
     plan.store(model)
+    moments = plan.moments()
     plan.close()
     eng.bind_stream(torch.cuda.current_stream(eng.device))
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
-    for k, v in model.state_dict().items():
-        np.testing.assert_allclose(v.cpu().numpy(), params[k].detach().numpy(), rtol=1e-3, atol=1e-4, err_msg=k)
+    assert_adam_state("node-classification plan vs the CPU restatement", model.state_dict(), moments, params,
+                      torch_adam_moments(opt, params), tol_m=1e-4, tol_v=1e-4, tol_p=1e-4)
 
 
 def _lp_batches(eng, n, b, P, n_rn, steps, seed):
@@ -203,7 +205,7 @@ def test_library_link_prediction_step_equals_the_autograd_step(setup, dims, fan,
     lib = GraphSAGE(dims[0], dims[1], dims[2], **kw).to(eng.device)
     lib.load_state_dict(ref.state_dict())
     ref.train()
-    opt = torch.optim.Adam(ref.parameters(), lr=5e-3, weight_decay=1e-6)
+    opt = torch.optim.Adam(ref.parameters(), lr=5e-3, weight_decay=1e-6, foreach=False)
     want = []
     for roots, cnt, rn in batches:
         embs = []
@@ -232,14 +234,17 @@ def test_library_link_prediction_step_equals_the_autograd_step(setup, dims, fan,
     rows = [float(v[1]) for v in got]
     got = [float(v[0]) for v in got]
     plan.store(lib)
+    moments = plan.moments()
     plan.close()
     eng.bind_stream(torch.cuda.current_stream(eng.device))
     assert rows == [float(int(c.clamp(max=P).sum())) for _, c, _ in batches]
     # (without the normalisation the logits are unbounded and the loss climbs at this learning rate: a step's rounding is
     # amplified by the next ones)
     np.testing.assert_allclose(got, want, rtol=2e-5 if norm else 3e-4, atol=2e-6)
-    for (k, a), (_, bb) in zip(lib.state_dict().items(), ref.state_dict().items()):
-        np.testing.assert_allclose(a.cpu().numpy(), bb.cpu().numpy(), rtol=2e-3, atol=3e-4 if norm else 6e-3, err_msg=k)  # (Adam: an element whose gradient is rounding noise moves by up to lr per step either way)
+    assert_adam_state("link-prediction plan vs autograd", lib.state_dict(), moments, ref.state_dict(),
+                      torch_adam_moments(opt, dict(ref.named_parameters())), tol_m=1e-4 if norm else 3e-2,
+                      tol_v=1e-4 if norm else 1e-2, tol_p=1e-4 if norm else 5e-3)  # (not normalised: the climbing loss
+    # amplifies every step's rounding — the loss history itself is only held to 3e-4 there)
 
 
 @pytest.mark.gpu
@@ -259,7 +264,7 @@ def test_library_link_prediction_step_against_the_cpu_restatement(setup):
     torch.manual_seed(6)
     model = GraphSAGE(100, 32, 16, num_layers=2, should_l2_normalize_embedding_layer_output=True)
     params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    opt = torch.optim.Adam(list(params.values()), lr=5e-3, weight_decay=1e-6)
+    opt = torch.optim.Adam(list(params.values()), lr=5e-3, weight_decay=1e-6, foreach=False)
     want = []
     for roots, cnt, rn in batches:
         embs = []
@@ -287,9 +292,13 @@ def test_library_link_prediction_step_against_the_cpu_restatement(setup):
         got = [plan.step(*bt).clone() for bt in batches]
     eng.synchronize()
     got = [float(v[0]) for v in got]
+    plan.store(lib)
+    moments = plan.moments()
     plan.close()
     eng.bind_stream(torch.cuda.current_stream(eng.device))
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
+    assert_adam_state("link-prediction plan vs the CPU restatement", lib.state_dict(), moments, params,
+                      torch_adam_moments(opt, params), tol_m=1e-3, tol_v=1e-3, tol_p=1e-4)
 
 
 @pytest.mark.gpu
@@ -363,7 +372,7 @@ def test_library_gat_link_prediction_step_equals_the_autograd_step(setup, heads,
     ref.engine = eng
     res = ResidentGraph.from_engine(eng, np.arange(n, dtype=np.int64), fan)
     res.train_as_graph_data, res.defer_x = True, True
-    opt = torch.optim.Adam(ref.parameters(), lr=5e-3, weight_decay=1e-6)
+    opt = torch.optim.Adam(ref.parameters(), lr=5e-3, weight_decay=1e-6, foreach=False)
     want, first_grads = [], None
     for roots, cnt, rn in batches:
         embs = []
@@ -399,11 +408,15 @@ def test_library_gat_link_prediction_step_equals_the_autograd_step(setup, heads,
           "| loss", got[0], "vs", want[0])
     assert max(errs.values()) < 2e-4 and abs(got[0] - want[0]) < 1e-4 * abs(want[0]), (errs, got[0], want[0])
     plan.store(lib)
+    moments = plan.moments()
     plan.close()
     eng.bind_stream(torch.cuda.current_stream(eng.device))
     np.testing.assert_allclose(got, want, rtol=1e-4 if norm else 1e-3, atol=1e-5)
-    for (k, a), (_, bb) in zip(lib.state_dict().items(), ref.state_dict().items()):
-        np.testing.assert_allclose(a.cpu().numpy(), bb.cpu().numpy(), rtol=5e-3, atol=6e-3, err_msg=k)
+    flat = lambda sd: {k: v.reshape(-1) for k, v in sd.items()}
+    assert_adam_state("GAT link-prediction plan vs autograd", flat(lib.state_dict()), moments, flat(ref.state_dict()),
+                      {k: (m.reshape(-1), v.reshape(-1)) for k, (m, v) in
+                       torch_adam_moments(opt, dict(ref.named_parameters())).items()},
+                      tol_m=1e-3, tol_v=1e-3, tol_p=1e-4)
     eng.close()
 
 
@@ -427,7 +440,7 @@ def test_library_gat_link_prediction_step_against_the_cpu_restatement(setup):
     torch.manual_seed(8)
     model = GAT(100, 16, 32, num_layers=2, heads=heads, should_l2_normalize_embedding_layer_output=True)
     params = {k: v.detach().clone().requires_grad_(True) for k, v in model.state_dict().items()}
-    opt = torch.optim.Adam(list(params.values()), lr=5e-3, weight_decay=1e-6)
+    opt = torch.optim.Adam(list(params.values()), lr=5e-3, weight_decay=1e-6, foreach=False)
     want = []
     for roots, cnt, rn in batches:
         embs = []
@@ -461,9 +474,12 @@ def test_library_gat_link_prediction_step_against_the_cpu_restatement(setup):
     eng.synchronize()
     got = [float(v[0]) for v in got]
     plan.store(lib)
+    moments = plan.moments()
     plan.close()
     print("GAT link-prediction plan vs the CPU restatement: losses", got, "vs", want)
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5)
-    for k, v in lib.state_dict().items():
-        np.testing.assert_allclose(v.cpu().numpy(), params[k].detach().numpy(), rtol=5e-3, atol=6e-3, err_msg=k)
+    flat = lambda sd: {k: v.reshape(-1) for k, v in sd.items()}
+    assert_adam_state("GAT link-prediction plan vs the CPU restatement", flat(lib.state_dict()), moments, flat(params),
+                      {k: (m.reshape(-1), v.reshape(-1)) for k, (m, v) in torch_adam_moments(opt, params).items()},
+                      tol_m=1e-3, tol_v=1e-3, tol_p=1e-4)
     eng.close()
