@@ -135,7 +135,12 @@ def main():
         args.shard_group = 16 if getattr(args, "emulate_world", 0) and args.emulate_world > 1 else 32
     wl_fan, wl_b = WORKLOAD_DEFAULTS.get(args.workload, ("25,10", 1024))
     args.fanouts = args.fanouts or wl_fan
-    args.batch = args.batch or (4096 if args.entry == "sampler" else wl_b)
+    if not args.batch and args.entry == "sampler":
+        # the sampler job's own call size (gigl_amd.subgraph_sampler.sampler_call_size: up to 32,768 roots per call)
+        from gigl_amd.subgraph_sampler import sampler_call_size
+        wl = WORKLOADS.get(args.workload)
+        args.batch = sampler_call_size(1 << 30, [int(v) for v in args.fanouts.split(",")], int(wl[3]) if wl else 100)
+    args.batch = args.batch or wl_b
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # no launcher: this process becomes one
         sys.exit(self_launch(args))

@@ -2710,6 +2710,214 @@ __global__ __launch_bounds__(256) void gat_input_backward_kernel(
     }
 }
 
+// ---- the same backward in ONE sweep over the source rows (round 6).  The two-sweep kernel reads every source row twice
+// because dpre_e = alpha_e (d alpha_e - S) leaky'(pre_e) needs S = sum_e alpha_e d alpha_e — known only after the row's last
+// edge.  But  sum_e dpre_e x_e = ( sum_e w_e l_e d alpha_e x_e  -  S sum_e w_e l_e x_e ) / den   with w_e = exp(zl_e - max),
+// l_e = leaky'(pre_e), den = sum_e w_e, S = (sum_e w_e d alpha_e) / den: two vector accumulators A, B (and three scalars) per
+// head, kept relative to the RUNNING maximum and rescaled when it grows — the online softmax of the forward applied to its
+// own backward.  Each row is read once; no per-edge scalars are parked (edge_scr is not used).  The self loop is the first
+// "edge" (x_e = x_i, w = 1).  Same lane layout, same cross-row accumulation and final atomics as the two-sweep kernel.
+template <typename T, int V, int H>
+__global__ __launch_bounds__(256) void gat_input_backward_onepass_kernel(
+    const T* __restrict__ src, int d, const uint32_t* __restrict__ gather_ids, const float* __restrict__ u,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ rowend, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ n_rows_dev, float slope, const float* __restrict__ dz, int64_t head_stride,
+    float* __restrict__ du) {
+  constexpr int U = 4;                                  // feature rows in flight per wave
+  constexpr int NV = U * 2 * H, NC = (NV + 15) / 16;    // (logit, d alpha) per head and edge of a group
+  typedef RawRow4<T> RR;
+  typedef typename RR::type raw_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int waves = (int)(((int64_t)gridDim.x * blockDim.x) >> 6);
+  const int n_rows = *n_rows_dev;
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto leaky = [&](float v) { return v > 0.f ? v : slope * v; };
+  auto dot4 = [](const float4_t& a, const float4_t& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; };
+  auto lane_value = [](float v, int from) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), from));
+  };
+  int el[V];
+  bool on[V];
+  float4_t us[H][V], acc_s[H][V], acc_d[H][V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    el[v] = (v * 64 + lane) * 4;
+    on[v] = el[v] < d;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      us[h][v] = on[v] ? *reinterpret_cast<const float4_t*>(u + (int64_t)h * d + el[v]) : zero4;
+      acc_s[h][v] = zero4;
+      acc_d[h][v] = zero4;
+    }
+  }
+  for (int i = wave; i < n_rows; i += waves) {
+    const int e0 = rowptr[i], m = rowend[i] - e0;
+    const uint32_t self_gid = gather_ids[i];
+    float4_t xs[V], dzv[H][V], A[H][V], B[H][V];
+    float sd[H], mx[H], den[H], Sw[H], a_s[H], b_s[H];
+    {
+      float pv[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) pv[k] = 0.f;
+      const T* row = src + (int64_t)self_gid * d;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        xs[v] = on[v] ? RR::f4(RR::load(row, el[v])) : zero4;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          dzv[h][v] = on[v] ? *reinterpret_cast<const float4_t*>(dz + h * head_stride + (int64_t)i * d + el[v]) : zero4;
+          const float4_t udv = on[v] ? *reinterpret_cast<const float4_t*>(u + (int64_t)(H + h) * d + el[v]) : zero4;
+          pv[h] += dot4(xs[v], us[h][v]);
+          pv[H + h] += dot4(xs[v], udv);
+          pv[2 * H + h] += dot4(xs[v], dzv[h][v]);
+        }
+      }
+      const float tot = gigl_wave_reduce16(pv);  // (3H <= 12 values)
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float fs = lane_value(tot, h << 2);
+        sd[h] = lane_value(tot, (H + h) << 2);
+        const float das = lane_value(tot, (2 * H + h) << 2);
+        const float pre_self = fs + sd[h];
+        const float lk = pre_self > 0.f ? 1.f : slope;
+        mx[h] = leaky(pre_self);
+        den[h] = 1.f;     // the self loop: w = exp(zl_self - max) = 1
+        Sw[h] = das;
+        a_s[h] = lk * das;
+        b_s[h] = lk;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          A[h][v] = (lk * das) * xs[v];
+          B[h][v] = lk * xs[v];
+        }
+      }
+    }
+    // a row whose dz is all zero adds nothing (padding rows, rows no root depends on): skipped, wave-uniformly
+    {
+      bool nz = false;
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int v = 0; v < V; ++v) nz |= dzv[h][v].x != 0.f || dzv[h][v].y != 0.f || dzv[h][v].z != 0.f || dzv[h][v].w != 0.f;
+      if (__ballot(nz) == 0ull) continue;
+    }
+    for (int c0 = 0; c0 < m; c0 += 64) {
+      const int mm = min(64, m - c0);
+      uint32_t gid = self_gid;
+      bool take = false;
+      if (lane < mm) {
+        const int j = col[e0 + c0 + lane];
+        take = j != i;
+        gid = gather_ids[j];
+      }
+      const unsigned long long keep = __ballot(take);
+      for (int e = 0; e < mm; e += U) {
+        raw_t x[U][V];
+        bool live[U];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          live[t] = e + t < mm && ((keep >> (e + t)) & 1ull);
+          const T* row = src + (int64_t)__shfl(gid, (e + t) & 63, 64) * d;
+#pragma unroll
+          for (int v = 0; v < V; ++v) x[t][v] = (live[t] && on[v]) ? RR::load(row, el[v]) : RR::zero();
+        }
+        float vals[NC * 16];
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+          float pv[16];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int idx = cc * 16 + k;  // = (t * H + h) * 2 + which
+            float a = 0.f;
+            if (idx < NV) {
+              const int t = idx / (2 * H), h = (idx / 2) % H, which = idx & 1;
+#pragma unroll
+              for (int v = 0; v < V; ++v) a += dot4(RR::f4(x[t][v]), which ? dzv[h][v] : us[h][v]);
+            }
+            pv[k] = a;
+          }
+          const float tot = gigl_wave_reduce16(pv);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) vals[cc * 16 + k] = lane_value(tot, k << 2);
+        }
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+          if (!live[t]) continue;
+#pragma unroll
+          for (int h = 0; h < H; ++h) {
+            const float pre = vals[(t * H + h) * 2] + sd[h], da = vals[(t * H + h) * 2 + 1];
+            const float zl = leaky(pre), lk = pre > 0.f ? 1.f : slope;
+            if (zl > mx[h]) {  // (wave-uniform: the values are broadcasts) the running maximum grows: everything rescales
+              const float sc = __expf(mx[h] - zl);
+              den[h] *= sc;
+              Sw[h] *= sc;
+              a_s[h] *= sc;
+              b_s[h] *= sc;
+#pragma unroll
+              for (int v = 0; v < V; ++v) {
+                A[h][v] = sc * A[h][v];
+                B[h][v] = sc * B[h][v];
+              }
+              mx[h] = zl;
+            }
+            const float w = __expf(zl - mx[h]), c = w * lk, cd = c * da;
+            den[h] += w;
+            Sw[h] += w * da;
+            a_s[h] += cd;
+            b_s[h] += c;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              const float4_t xv = RR::f4(x[t][v]);
+              A[h][v] += cd * xv;
+              B[h][v] += c * xv;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float inv = 1.0f / (den[h] + 1e-16f);
+      const float S = Sw[h] * inv;
+      const float sum_dpre = (a_s[h] - S * b_s[h]) * inv;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        acc_s[h][v] += inv * (A[h][v] - S * B[h][v]);
+        acc_d[h][v] += sum_dpre * xs[v];
+      }
+    }
+  }
+  __shared__ float4_t s_red[2 * H * V * 64];
+  const int wv = threadIdx.x >> 6;
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
+#pragma unroll
+      for (int h = 0; h < H; ++h)
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          float4_t& rs = s_red[(h * V + v) * 64 + lane];
+          float4_t& rd = s_red[((H + h) * V + v) * 64 + lane];
+          rs = w == 0 ? acc_s[h][v] : rs + acc_s[h][v];
+          rd = w == 0 ? acc_d[h][v] : rd + acc_d[h][v];
+        }
+    }
+    __syncthreads();
+  }
+  if (wv != 0) return;
+#pragma unroll
+  for (int h = 0; h < 2 * H; ++h)
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      if (!on[v]) continue;
+      const float4_t t = s_red[(h * V + v) * 64 + lane];
+      float* pu = du + (int64_t)h * d + el[v];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (t[q] != 0.f) atomicAdd(pu + q, t[q]);
+    }
+}
+
 // ---- fast GAT path: one wave per row, every lane owns V float4 chunks of the H*C-wide row (chunk q = v*64 + lane
 // covers channels [4q, 4q+4), all inside one head because C % 4 == 0), so all heads advance together and each source
 // row is read exactly once, coalesced.  Shapes: C/4 a power of two <= 64 (a head = C/4 adjacent lanes of one chunk
@@ -4635,9 +4843,18 @@ int32_t gigl_gat_input_aggregate_backward(gigl_ctx* ctx, const void* src, int32_
   const float slope = negative_slope;
   int64_t blocks = (rows_cap + 3) / 4;
   if (blocks > 256 * 2) blocks = 256 * 2;  // (two workgroups per CU fill its registers; fewer workgroups = fewer final atomics)
+  // (A/B knob: GIGL_GAT_BWD_TWO_SWEEPS=1 keeps the two-sweep kernel — every source row read twice, the edges' logits parked)
+  static const bool two_sweeps = getenv("GIGL_GAT_BWD_TWO_SWEEPS") != nullptr;
 #define GIGL_GAT_BW(TT, PP, HH)                                                                                        \
-  hipLaunchKernelGGL((gat_input_backward_kernel<TT, PP, HH>), dim3((unsigned)blocks), dim3(256), 0, st, (const TT*)src, d, \
-                     gather_ids, u, rowptr, rowend, col, n_rows_dev, slope, dz, head_stride, edge_scratch, du)
+  do {                                                                                                                  \
+    if (two_sweeps)                                                                                                     \
+      hipLaunchKernelGGL((gat_input_backward_kernel<TT, PP, HH>), dim3((unsigned)blocks), dim3(256), 0, st,            \
+                         (const TT*)src, d, gather_ids, u, rowptr, rowend, col, n_rows_dev, slope, dz, head_stride,     \
+                         edge_scratch, du);                                                                            \
+    else                                                                                                                \
+      hipLaunchKernelGGL((gat_input_backward_onepass_kernel<TT, PP, HH>), dim3((unsigned)blocks), dim3(256), 0, st,    \
+                         (const TT*)src, d, gather_ids, u, rowptr, rowend, col, n_rows_dev, slope, dz, head_stride, du); \
+  } while (0)
 #define GIGL_GAT_BW_P(TT, HH)                                                                                          \
   do {                                                                                                                  \
     if (P == 1) GIGL_GAT_BW(TT, 1, HH);                                                                                \

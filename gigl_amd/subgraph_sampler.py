@@ -189,12 +189,29 @@ def _encode_labels(label_keys: Sequence[str], labels: Dict[str, Dict[int, int]],
     return np.frombuffer(b"".join(parts), dtype=np.uint8).copy(), off
 
 
+def sampler_call_size(n_roots: int, fanouts: Sequence[int], feat_dim: int, budget_bytes: int = 4 << 30) -> int:
+    """roots per library call of the sampler job (sample -> encode -> frames out).  The device record encoder has a fixed
+    ~36 us latency floor per pass: 0.24 of the HBM roofline at 4,096 records per call, 0.35 at 32,768
+    (profiles/r05l_encoder_variants.md) — so a call takes as many roots as keep its frames under `budget_bytes`
+    (the reference writes 1,000-record part files from whole partitions: SGSPureSparkV1Task.scala:1019-1040; the call size
+    here only sets how many records are encoded per launch set), at most 32,768, at least 1,024, never more than there are"""
+    nodes, width = 1, 1
+    for f in fanouts:
+        width *= int(f)
+        nodes += width
+    per_record = nodes * (int(feat_dim) * 4 + 24) + (nodes - 1) * 12 + 64  # (feature rows dominate; an upper bound)
+    call = max(1024, min(32768, (budget_bytes // max(per_record, 1)) // 1024 * 1024))
+    return int(max(1, min(call, int(n_roots))))
+
+
 class SubgraphSampler:
     def run(self, applied_task_identifier: str, task_config_uri: str, resource_config_uri: Optional[str] = None,
             cluster_name: Optional[str] = None, debug_cluster_owner_alias: Optional[str] = None,
             custom_worker_image_uri: Optional[str] = None, skip_cluster_delete: bool = False,
             additional_spark35_jar_file_uris: Sequence[str] = (), *, uri_base: Optional[str] = None,
-            device: int = 0, batch_size: int = 4096) -> Dict[str, List[str]]:
+            device: int = 0, batch_size: Optional[int] = None) -> Dict[str, List[str]]:
+        """batch_size: roots per library call (None: sampler_call_size — up to 32,768, where the encoder runs at 0.35 of the
+        HBM roofline instead of 0.24 at 4,096)"""
         cfg = GbmlConfigPbWrapper.from_uri(task_config_uri, uri_base=uri_base)
         # experimental_flags.sample_with_replacement: numNeighborsToSample independent uniform draws per parent
         # (sampleWithReplacementUDF, SGSPureSparkV1Task.scala:42-50,355-364; an unseeded java.util.Random there, a
@@ -211,9 +228,12 @@ class SubgraphSampler:
             seed = 1 + int.from_bytes(os.urandom(3), "little") % ((1 << 20) - 1)
         self.sampling_seed = seed
         if cfg.is_heterogeneous:
-            return self._run_graphdb_nablp(cfg, device, seed, batch_size)
+            return self._run_graphdb_nablp(cfg, device, seed, int(batch_size or 4096))
         n, src, dst, x, labels, node_ids = load_preprocessed_graph(cfg)
         ids = np.asarray(node_ids, dtype=np.uint32)
+        if batch_size is None:
+            batch_size = sampler_call_size(ids.size, cfg.fanouts, int(x.shape[1]) if x is not None and x.ndim == 2 else 0)
+        self.call_size = int(batch_size)
         with HipKHopSamplerService(n, src, dst, x, cfg.is_graph_directed, device=device, sampling_seed=seed,
                                    keep_multi_edges=getattr(cfg, "edge_features", None) is None) as svc:
             svc.sampling_mode = self.sampling_mode

@@ -144,22 +144,24 @@ def test_a_lone_rank_needs_no_tables():
 
 
 # ---- two processes on one GPU: the other process's table through a hipIpc handle
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, transport="gloo"):
     try:
         import torch.distributed as dist
         from gigl_amd.dist import Comm, DistSagePlan, partition_csc, partition_rows, torch_exchange
         from gigl_amd.engine import HipEngine
-        torch.cuda.set_device(0)
+        dev_idx = rank if transport == "rccl" else 0  # (rccl: one GPU per rank, the tables cross xGMI / PCIe for real)
+        torch.cuda.set_device(dev_idx)
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         rowptr, col, x = make_graph()
         model = make_model()
         w, bs = model.fused_params()
-        eng = HipEngine(0)
+        eng = HipEngine(dev_idx)
         st = torch.cuda.Stream(device=eng.device)
         eng.bind_stream(st)
         eng.load_csc(*partition_csc(rowptr, col, rank, world))
         eng.load_features(torch.from_numpy(partition_rows(x, rank, world)))
-        comm = Comm.callback(eng, rank, world, torch_exchange(eng))  # the hops' exchanges travel over gloo
+        # the hops' exchanges: RCCL issued by the library, or gloo through the host callback
+        comm = Comm.rccl_from_torch(eng) if transport == "rccl" else Comm.callback(eng, rank, world, torch_exchange(eng))
         roots = rank_roots(rank, 64)
         rd = torch.from_numpy(roots.view(np.int32)).to(eng.device)
         worst, opened = 0.0, []
@@ -200,13 +202,13 @@ def _worker(rank, world, port, q):
         q.put((rank, "error", traceback.format_exc() + repr(e)))
 
 
-def test_two_processes_one_gpu_read_each_others_tables_through_ipc_handles():
+def _spawn(transport):
     import torch.multiprocessing as mp
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + os.getpid() % 150
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, transport)) for r in range(world)]
     for p in procs:
         p.start()
     res = []
@@ -219,3 +221,14 @@ def test_two_processes_one_gpu_read_each_others_tables_through_ipc_handles():
     for rank, status, info in res:
         assert status == "ok", f"rank {rank}: {info}"
         assert info < 1e-5, (rank, info)
+
+
+def test_two_processes_one_gpu_read_each_others_tables_through_ipc_handles():
+    _spawn("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the build boxes have one)")
+def test_two_rccl_ranks_read_each_others_tables_across_gpus():
+    """the same with one GPU per rank: hop exchanges over RCCL, the peers' tables opened with hipIpcMemLazyEnablePeerAccess and
+    read over the links by the first layer — bit-identical to the bucketed route, 1e-5 of the oracle"""
+    _spawn("rccl")
