@@ -566,7 +566,7 @@ def run_products(args, rank, world, local_rank):
         limit = float(os.environ.get("GIGL_BENCH_SUB_TIMEOUT", "240"))
         cmd = [sys.executable, BENCH_PY, "--workload", "mag240m-sharded", "--emulate-world", "8",
                "--shard-scale", os.environ.get("GIGL_BENCH_EMULATE_SCALE", "0.08"), "--fanouts", "25,10", "--batch", "1024",
-               "--shard-group", "16", "--steps", "256", "--no-cpu-baseline", "--no-live-pmc"]
+               "--shard-group", "32", "--steps", "256", "--no-cpu-baseline", "--no-live-pmc"]
         try:
             cp = subprocess.run(cmd, env=dict(os.environ, GIGL_BENCH_CHILD="1"), capture_output=True, text=True, timeout=limit)
             lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
