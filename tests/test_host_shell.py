@@ -184,3 +184,30 @@ def test_entry_points_fail_loudly_without_gpu(golden_dir):
         Trainer().run("job", cfg, None, uri_base=golden_dir)
     with pytest.raises(RuntimeError):
         Inferencer().run("job", cfg, None, uri_base=golden_dir)
+
+
+def test_sampler_call_size_follows_the_record_size():
+    """roots per library call of the sampler job: up to 32,768 (where the device encoder reaches 0.35 of the HBM roofline), fewer
+    when a call's frames would pass the byte budget, never more than there are roots"""
+    from gigl_amd.subgraph_sampler import sampler_call_size
+    assert sampler_call_size(1 << 30, [25, 10], 100) == 32768           # products-shaped: 276 nodes x ~0.4 KB
+    assert sampler_call_size(1 << 30, [25, 10], 768) == 4096            # MAG240M-wide rows: 4 GiB / ~0.9 MB per record
+    assert sampler_call_size(1 << 30, [25, 10], 768, budget_bytes=32 << 30) == 32768
+    assert sampler_call_size(2708, [10, 5], 1433) == 2708               # Cora: one call
+    assert sampler_call_size(1 << 30, [1000, 1000], 1024) == 1024       # (never below 1,024 while there are that many roots)
+    assert sampler_call_size(0, [10, 5], 8) == 1
+
+
+def test_adam_state_errors_separate_noise_from_determined_elements():
+    """tests/helpers.adam_state_errors: an element whose gradient is rounding noise may sit anywhere within lr * steps of the
+    reference and must not fail the comparison; a determined element that is off must"""
+    import torch
+    from helpers import adam_state_errors
+    g = torch.tensor([1.0, 0.5, 1e-9, -2e-9])           # two real gradients, two noise ones
+    ref_p, ref_m, ref_v = torch.tensor([0.1, 0.2, 0.3, 0.4]), 0.1 * g, 0.001 * g * g
+    got_p = ref_p + torch.tensor([1e-7, -1e-7, 5e-3, -5e-3])   # the noise elements drifted by lr each
+    errs = adam_state_errors({"w": got_p}, {"w": (ref_m.clone(), ref_v.clone())}, {"w": ref_p}, {"w": (ref_m, ref_v)})
+    em, ev, ep, share = errs["w"]
+    assert em == 0 and ev == 0 and ep <= 2e-7 and abs(share - 0.5) < 1e-9
+    bad = adam_state_errors({"w": ref_p + torch.tensor([1e-3, 0, 0, 0])}, {"w": (ref_m, ref_v)}, {"w": ref_p}, {"w": (ref_m, ref_v)})
+    assert bad["w"][2] > 5e-4
