@@ -572,8 +572,8 @@ def run_products(args, rank, world, local_rank):
             lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
             if cp.returncode == 0 and lines:
                 sub = json.loads(lines[-1])
-                line["sharded_emulated"] = {k: sub.get(k) for k in ("emulated_world", "value", "value_is", "ms_per_step",
-                                                                    "config", "emulated")}
+                line["sharded_emulated"] = {k: sub.get(k) for k in ("emulated_world", "value", "value_is", "ms_per_step", "route",
+                                                                    "config", "emulated", "world1_reference")}
             else:
                 line["sharded_emulated"] = {"error": f"exit code {cp.returncode}: {cp.stderr.strip()[-300:]}"}
         except subprocess.TimeoutExpired:

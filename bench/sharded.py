@@ -470,6 +470,98 @@ def run_sharded(args, rank, world, local_rank, sub=False):
     return line
 
 
+def _world1_reference_step(args, dev, local_rank, n1, e1, fanouts, B, G, d, hid, w, bs, S):
+    """the per-rank workload of the emulated world at WORLD 1: one rank holding a graph of n1 = N / W nodes (the W-rank world's
+    per-rank shard size: weak scaling), the same batches per exchange, plans in flight and hipGraph replay — the step the
+    emulated world's OVERLAPPED per-rank step is set against.  -> (ms per step, sampled+aggregated edges per step)"""
+    from gigl_amd._lib import STATS, STATS_LEN
+    from gigl_amd.dist import Comm, DistSagePlan
+    from gigl_amd.engine import HipEngine
+    L = len(fanouts)
+    scale_bits = max(int(np.ceil(np.log2(n1))), 10)
+    keys, chunk = [], 1 << 26
+    for ci, c0 in enumerate(range(0, e1, chunk)):
+        m = min(chunk, e1 - c0)
+        src, dst = rmat_edges_gpu(scale_bits, m, seed=3 + 7919 * ci, device=dev)
+        keys.append((((dst * 0x9E3779B1) % n1) << 32) | ((src * 0x9E3779B1) % n1))
+        del src, dst
+    key = torch.unique(torch.cat(keys))
+    del keys
+    rowptr = torch.zeros(n1 + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(key >> 32, minlength=n1), 0)
+    col = (key & 0xFFFFFFFF).to(torch.int32)
+    maxdeg = int((rowptr[1:] - rowptr[:-1]).max())
+    eng = HipEngine(local_rank)
+    eng.load_csc(rowptr, col)
+    del key, rowptr, col
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    x = torch.empty((n1, d), device=dev, dtype=torch.float16)
+    step_rows = max(1, (1 << 28) // d)
+    for i in range(0, n1, step_rows):
+        x[i:i + step_rows] = torch.randn((min(step_rows, n1 - i), d), generator=g, device=dev).to(torch.float16)
+    eng.load_features(x)
+    del x
+    pt = torch.empty((n1, 2 * hid), dtype=torch.float32, device=dev)
+    eng.project_features(w[0], out=pt)
+    bound = (L + 1) * n1 + 42 * L + maxdeg
+    mwe = bound if bound < (1 << 30) else -1
+    gp = torch.Generator(device="cpu")
+    gp.manual_seed(43)
+    calls = 8
+    roots = torch.randint(0, n1, (calls, G * B), generator=gp).to(torch.int32).to(dev)
+    worlds = []
+    for s_ in range(S):
+        st_ = torch.cuda.Stream(device=dev)
+        e_ = HipEngine(local_rank)
+        e_.share_resident(eng)
+        e_.bind_stream(st_)
+        cm = Comm.local([e_])
+        pl = DistSagePlan(cm[0], w, bs, G * B, fanouts, group_roots=B, max_window_end=mwe, projected=pt, peer_direct=True)
+        rt, out = torch.empty(G * B, dtype=torch.int32, device=dev), pl.new_out()
+        with torch.cuda.stream(st_):
+            for c in range(2):
+                rt.copy_(roots[c])
+                DistSagePlan.run_local([pl], [rt], [out])
+        st_.synchronize()
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_, stream=st_, capture_error_mode="thread_local"):
+            DistSagePlan.run_local([pl], [rt], [out])
+        worlds.append((st_, e_, cm, pl, rt, out, g_))
+    acc = torch.zeros(STATS_LEN, dtype=torch.int64, device=dev)
+    with torch.cuda.stream(worlds[0][0]):
+        for c in range(calls):
+            worlds[0][4].copy_(roots[c])
+            DistSagePlan.run_local([worlds[0][3]], [worlds[0][4]], [worlds[0][5]])
+            worlds[0][3].stats(acc)
+    torch.cuda.synchronize()
+    edges = float(acc[STATS["sampled"]] + acc[STATS["aggregated"]]) / (calls * G)
+
+    def go(n_calls):
+        for c in range(n_calls):
+            st_, _, _, _, rt, _, g_ = worlds[c % S]
+            with torch.cuda.stream(st_):
+                rt.copy_(roots[c % calls], non_blocking=True)
+                g_.replay()
+    go(2 * S)
+    torch.cuda.synchronize()
+    n_calls, ts = 24 * S, []
+    for _ in range(3):
+        t1 = time.perf_counter()
+        go(n_calls)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t1)
+    for st_, e_, cm, pl, rt, out, g_ in worlds:
+        del g_
+        pl.close()
+        cm[0].close()
+        e_.close()
+    eng.close()
+    del pt
+    torch.cuda.empty_cache()
+    return float(np.median(ts)) / (n_calls * G) * 1e3, edges
+
+
 def run_emulated_world(args, local_rank=0, sub=False):
     """BASELINE configs[2] without an 8-GPU node: all W ranks of the hash-partitioned job as ctxs of ONE process on one
     GPU (gigl_dist_init_local: the in-process transport the parity tests use — every exchange is a device copy), at the
@@ -825,6 +917,27 @@ def run_emulated_world(args, local_rank=0, sub=False):
         a, b_ = res["no_replication"]["pulled_rows_per_step_mean"], res["hot_rows"]["pulled_rows_per_step_mean"]
         res["hot_row_hit_rate"] = {"replicated_fraction_of_nodes": hot_frac, "replica_bytes_per_rank": int(n_hot * row_bytes),
                                    "pulled_rows_without": a, "pulled_rows_with": b_, "rows_taken_off_the_links": 1.0 - b_ / max(a, 1.0)}
+    # ---- the same per-rank workload at WORLD 1 (a graph of N / W nodes on one rank), measured the same way: what the W-rank
+    # step is a multiple of.  scaling = W x edges_W / step_W  /  (edges_1 / step_1), with the links hidden and not
+    world1 = None
+    S_ov = int(getattr(args, "emulate_streams", 0))
+    if S_ov > 0:
+        try:
+            ms1, edges1 = _world1_reference_step(args, dev, local_rank, max(n // W, 1024), max(e_total // W, 1), fanouts, B, G, d,
+                                                 hid, w, bs, S_ov)
+            world1 = {"nodes": max(n // W, 1024), "ms_per_step_overlapped": ms1, "sampled_plus_aggregated_edges_per_step": edges1,
+                      "edges_per_s": edges1 / (ms1 * 1e-3),
+                      "measured": f"one rank holding a graph of N / {W} nodes (the emulated world's per-rank shard size), the lone-rank "
+                                  f"sharded step, {G} batches per exchange, {S_ov} plans in flight replayed as hipGraphs"}
+            for tag_, _, _ in cases:
+                e_ = res[tag_]
+                pj = e_["projection"]
+                if pj.get("overlapped_step_ms"):
+                    per1 = world1["edges_per_s"]
+                    pj["scaling_1_to_%d_links_hidden" % W] = pj["whole_node_edges_per_s_overlapped_links_hidden"] / per1
+                    pj["scaling_1_to_%d_links_not_hidden" % W] = pj["whole_node_edges_per_s_overlapped_links_not_hidden"] / per1
+        except Exception as ex:  # noqa: BLE001 — (a reference figure: never costs the record)
+            world1 = {"error": f"{type(ex).__name__}: {str(ex)[:300]}"}
     # the line's value: the route with the shorter per-rank step (overlapped when measured, else kernel time), links hidden
     def step_of(e):
         pj = e["projection"]
@@ -845,7 +958,7 @@ def run_emulated_world(args, local_rank=0, sub=False):
                                + ("rows pre-projected once per rank (256 fp32 W_l x rows pulled)" if use_proj else "raw rows"),
                    "transport": "gigl_dist_init_local (in-process: every exchange is a device copy on this GPU)",
                    "projection_precompute_s_per_rank": round(pre_s, 4), "setup_s": round(time.time() - t0, 1)},
-        "emulated": res, "roofline": best["roofline"], "cpu_baseline": None}
+        "emulated": res, "world1_reference": world1, "roofline": best["roofline"], "cpu_baseline": None}
     for c in comms:
         c.close()
     for e in reversed(engs):

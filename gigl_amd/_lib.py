@@ -48,7 +48,7 @@ SYMBOLS = [
     "gigl_comm_all_to_all", "gigl_comm_flush_local", "gigl_comm_traffic", "gigl_comm_set_fixed_blocks", "gigl_ctx_set_wide_workspaces", "gigl_sage_train_plan_adopt", "gigl_sage_train_plan_moments", "gigl_nablp_train_plan_moments", "gigl_sage_train_plan_resume", "gigl_nablp_train_plan_adopt", "gigl_comm_destroy", "gigl_dist_plan_batch_features", "gigl_dist_plan_batch_graph", "gigl_dist_plan_create",
     "gigl_dist_plan_set_weights", "gigl_dist_plan_phases", "gigl_dist_plan_phase", "gigl_dist_plan_run",
     "gigl_dist_plan_run_local", "gigl_dist_plan_run_interleaved", "gigl_dist_plan_buffers", "gigl_dist_plan_stats", "gigl_dist_plan_destroy",
-    "gigl_dist_plan_set_hot_rows", "gigl_dist_plan_set_peer_tables", "gigl_ipc_export", "gigl_ipc_open", "gigl_ipc_close",
+    "gigl_dist_plan_set_hot_rows", "gigl_dist_plan_set_peer_tables", "gigl_dist_plan_set_peer_graphs", "gigl_sample_khop_peer", "gigl_ipc_export", "gigl_ipc_open", "gigl_ipc_close",
     "gigl_split_hash_slots", "gigl_hgt_aggregate", "gigl_simplehgn_alpha", "gigl_weighted_aggregate",
     "gigl_collate_typed_records", "gigl_collated_typed_info", "gigl_collated_typed_nodes", "gigl_collated_typed_edges",
     "gigl_collated_typed_samples", "gigl_collated_typed_destroy", "gigl_typed_records_capacity",
@@ -191,6 +191,7 @@ class GiglDistPlanOpts(C.Structure):
         ("pull_cap_b", C.c_int64),
         ("staged", C.c_int32),
         ("peer_direct", C.c_int32),
+        ("peer_sample", C.c_int32),
     ]
 STATS_LEN = 16
 STATS_SAMPLED, STATS_AGGREGATED = 0, 1  # GIGL_STATS_* slots of gigl_sage_plan_stats
@@ -334,6 +335,8 @@ def load() -> C.CDLL:
         "gigl_dist_plan_stats": [vp, vp],
         "gigl_dist_plan_set_hot_rows": [vp, vp, i64, vp],
         "gigl_dist_plan_set_peer_tables": [vp, P(vp)],
+        "gigl_dist_plan_set_peer_graphs": [vp, P(vp), P(vp)],
+        "gigl_sample_khop_peer": [vp, vp, vp, i32, i64, i64, vp, i32, P(i32), i32, i32, P(GiglTree)],
         "gigl_ipc_export": [vp, vp, vp, P(i64)],
         "gigl_ipc_open": [vp, vp, i64, P(vp), P(vp)],
         "gigl_ipc_close": [vp, vp],

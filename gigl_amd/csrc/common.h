@@ -120,7 +120,6 @@ void* gigl_arena_alloc(gigl_ctx* ctx, int64_t bytes);
 
 // fills g->maxdeg from the resident rowptr (synchronises the ctx stream)
 int32_t gigl_graph_compute_maxdeg(gigl_ctx* ctx, gigl_graph* g);
-
 // union build with the plan-internal leaf-global option (union.hip)
 int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree, int32_t group_roots,
                               gigl_union* out, int32_t leaf_global);

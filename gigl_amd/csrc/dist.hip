@@ -851,6 +851,12 @@ struct gigl_dist_plan {
   bool peer = false;
   const void** peers_dev = nullptr;  // device [world]
   bool peers_ready = false;
+  // ... and the peer-SAMPLED route (opts->peer_sample, with peer_direct): the ranks' CSC shards are mapped too, and a rank
+  // expands its OWN frontier, reading the owners' adjacency rows where they live (gigl_sample_khop_peer) — no request / answer
+  // buckets, no hop exchange, no scatter: the step has no collective at all
+  bool peer_sample = false, peer_graphs_ready = false;
+  const int64_t** peer_rowptr_dev = nullptr;  // device [world]
+  const uint32_t** peer_col_dev = nullptr;    // device [world]
   // activations
   bool tiled_layers = false;  // layers >= 1: tiled gather operand + two-source projection (every dims[l], l >= 1, % 4 == 0)
   float* abuf = nullptr;
@@ -955,11 +961,18 @@ int32_t phase_impl(gigl_dist_plan* p, int phase, const uint32_t* roots, int32_t 
   // a LONE rank (world 1 on a transport that needs no self copy) owns every row: its hops are the single-GPU sampler's,
   // straight into the tree — no bucket, no request / answer blocks, no scatter (the same selection rule and table: the
   // owners' expansion IS that sampler, run on explicit frontiers)
-  const bool lone_hops = world == 1 && comm_self_in_place(p->comm) && !p->overlap;
+  const bool peer_hops = p->peer_sample && world > 1;
+  const bool lone_hops = (world == 1 && comm_self_in_place(p->comm) && !p->overlap) || peer_hops;
   if (lone_hops && phase < 2 * L) {
     if (phase != 0) return GIGL_OK;
     rc = clear_call(p);
     if (rc != GIGL_OK) return rc;
+    if (peer_hops) {
+      if (!p->peer_graphs_ready)
+        return gigl_fail(ctx, GIGL_E_INVALID_ARG, "peer-sampled plan: the ranks' graph shards were not set (gigl_dist_plan_set_peer_graphs)");
+      return gigl_sample_khop_peer(ctx, p->peer_rowptr_dev, p->peer_col_dev, p->world, p->n_global, p->mwe, roots, p->b, p->fan, L,
+                                   seed, &p->tree);
+    }
     return gigl_sample_khop(ctx, p->shard, roots, p->b, p->fan, L, seed, GIGL_MODE_SPARK_HASH, &p->tree);
   }
   if (phase < 2 * L && (phase & 1) == 0) {
@@ -1408,6 +1421,14 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
   if (p->peer && (!p->dense || p->n_global >= ((int64_t)1 << 31) || W > 64))
     return fail(GIGL_E_UNSUPPORTED, "the peer-mapped route needs the dense plan shape (SAGE layers, two hops, second fan-out "
                                     "<= 64, no owner-side projection, not staged), fewer than 2^31 nodes and a world <= 64");
+  p->peer_sample = opts && opts->peer_sample != 0;
+  if (p->peer_sample) {
+    bool ok_f = p->peer && !shard->multi && p->mwe >= 0;
+    for (int k = 0; k < hops; ++k) ok_f = ok_f && fanouts[k] <= GIGL_FAST_FANOUT;
+    if (!ok_f)
+      return fail(GIGL_E_UNSUPPORTED, "the peer-sampled route needs the peer-mapped feature route (peer_direct), fan-outs <= 64, no "
+                                      "directed multi-edges and a window bound (max_window_end)");
+  }
   if (p->preproj && (!p->dense || (dims[1] & 3) != 0 || dims[1] > 2048))
     return fail(GIGL_E_UNSUPPORTED, "pre-projected rows need the dense pull bookkeeping (two hops, second fan-out <= 64, no "
                                     "owner-side projection) and a first-layer width % 4 == 0, <= 2048");
@@ -1511,6 +1532,11 @@ static int32_t dist_plan_create_impl(gigl_comm* comm, gigl_graph* shard, gigl_fe
       ok = hipMemcpy(p->peers_dev, &own, sizeof(void*), hipMemcpyHostToDevice) == hipSuccess;
       p->peers_ready = ok;
     }
+  }
+  if (p->peer_sample && ok) {
+    p->peer_rowptr_dev = (const int64_t**)alloc((size_t)W * sizeof(void*));
+    p->peer_col_dev = (const uint32_t**)alloc((size_t)W * sizeof(void*));
+    ok = p->peer_rowptr_dev && p->peer_col_dev;
   }
   if (p->preproj && ok && !p->peer) {  // the second pull's buckets (W_r x of the inner nodes)
     int64_t pcb = opts && opts->pull_cap_b > 0 ? opts->pull_cap_b
@@ -1639,6 +1665,21 @@ int32_t gigl_dist_plan_set_peer_tables(gigl_dist_plan* p, const void* const* tab
   GIGL_HIP_CHECK(ctx, hipMemcpyAsync(p->peers_dev, tables, (size_t)p->world * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
   GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // (`tables` is the caller's host array)
   p->peers_ready = true;
+  return GIGL_OK;
+}
+
+int32_t gigl_dist_plan_set_peer_graphs(gigl_dist_plan* p, const int64_t* const* rowptrs, const uint32_t* const* cols) {
+  if (!p || !rowptrs || !cols) return GIGL_E_INVALID_ARG;
+  gigl_ctx* ctx = p->ctx;
+  GIGL_REQUIRE(ctx, p->peer_sample, "not a peer-sampled plan (gigl_dist_plan_opts.peer_sample)");
+  for (int r = 0; r < p->world; ++r) GIGL_REQUIRE(ctx, rowptrs[r] && cols[r], "rank %d's shard is null", r);
+  GIGL_REQUIRE(ctx, rowptrs[p->rank] == p->shard->rowptr && cols[p->rank] == p->shard->col,
+               "rowptrs[rank] / cols[rank] must be this rank's own shard (gigl_graph_device_ptrs)");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(p->peer_rowptr_dev, rowptrs, (size_t)p->world * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(p->peer_col_dev, cols, (size_t)p->world * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+  GIGL_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  p->peer_graphs_ready = true;
   return GIGL_OK;
 }
 

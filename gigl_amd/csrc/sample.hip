@@ -175,7 +175,20 @@ struct ExpandArgs {
   int32_t flat_max;    // rows up to this length read their hash window from the table's flat array
   int32_t multi;       // rows may repeat an id (directed multi-edges): sampled positions are drawn over the multiset,
                        // the ids they hold are written once each (the reference's output is a set of edges)
+  // PEER-MAPPED graph shards (gigl_sample_khop_peer; the sharded plan's peer-sampled route): node v's row is row v /
+  // peer_world of rank (v % peer_world)'s CSC shard, whose rowptr / col arrays are mapped into this process — the
+  // requester expands its own frontier and reads the owners' adjacency where it lives; a descriptor's `s` then carries the
+  // rank in its top 16 bits.  peer_world == 0: off (rowptr / col above)
+  const int64_t* const* peer_rowptr;
+  const uint32_t* const* peer_col;
+  uint32_t peer_world;
 };
+
+// the adjacency row a descriptor's `s` names
+__device__ __forceinline__ const uint32_t* row_of_desc(const ExpandArgs& a, int64_t s) {
+  if (a.peer_world) return a.peer_col[(uint64_t)s >> 48] + (s & (((int64_t)1 << 48) - 1));
+  return a.col + s;
+}
 
 // CSC row of the parent in slot p and K (wrapping int32 sum of the path ids) — wave-uniform.  Slot numbers are
 // < 2^31 (checked by the callers): 32-bit divisions (a 64-bit one costs ~150 scalar instructions, and the CU's
@@ -574,12 +587,21 @@ __global__ __launch_bounds__(256) void plan_rows_kernel(ExpandArgs a, RangeTable
         for (int j = 0; j < a.f; ++j) out[j] = GIGL_INVALID;
         a.out_cnt[p] = 0;
       } else {
-        d.s = a.rowptr[v];
-        const int64_t deg = a.rowptr[v + 1] - d.s;
+        int64_t deg;
+        if (a.peer_world) {
+          const uint32_t q = v / a.peer_world, rk = v - q * a.peer_world;
+          const int64_t* rp = a.peer_rowptr[rk];
+          const int64_t s0 = rp[q];
+          deg = rp[q + 1] - s0;
+          d.s = ((int64_t)rk << 48) | s0;
+        } else {
+          d.s = a.rowptr[v];
+          deg = a.rowptr[v + 1] - d.s;
+        }
         d.n = (uint32_t)deg;
         d.base = ksum + (uint32_t)a.hash_add;  // int32 wrap == uint32 wrap
         if (deg <= a.f && !a.multi) {  // finished here: copy-through, the row is already the canonical ascending set
-          const uint32_t* row = a.col + d.s;
+          const uint32_t* row = row_of_desc(a, d.s);
           for (int j = 0; j < a.f; ++j) out[j] = j < (int)deg ? row[j] : GIGL_INVALID;
           a.out_cnt[p] = (int32_t)deg;
         } else if (deg <= a.f) {
@@ -729,7 +751,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       const unsigned long long m = s0.selmask;
       sel0 = (m >> lane) & 1ull;
       slot0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (sel0) val0 = (a.col + d0.s)[s0.idx - 1];
+      if (sel0) val0 = row_of_desc(a, d0.s)[s0.idx - 1];
     }
     const bool done1 = c1.ahead && !a.multi && select_ahead(s1, d1, c1, lk, li) && !s1.tie;
     uint32_t slot1 = 0, val1 = 0;
@@ -738,7 +760,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
       const unsigned long long m = s1.selmask;
       sel1 = (m >> lane) & 1ull;
       slot1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (sel1) val1 = (a.col + d1.s)[s1.idx - 1];
+      if (sel1) val1 = row_of_desc(a, d1.s)[s1.idx - 1];
     }
     if (done0) {
       if (sel0) a.out_nbr[(int64_t)p0 * f + slot0] = val0;
@@ -764,7 +786,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (lane == 0) a.out_cnt[p] = 0;
         continue;
       }
-      const uint32_t* row = a.col + d.s;
+      const uint32_t* row = row_of_desc(a, d.s);
       const uint32_t n = d.n, base = d.base, T = d.T;
       if (kind == ROW_COPY) {  // copy-through: the row is already the canonical ascending set
         if (a.multi) {
@@ -1515,6 +1537,65 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
       rc = run_expand(ctx, a, tb, covered, heavy_list, heavy_count, desc);
       if (rc != GIGL_OK) return rc;
     }
+    a.anc[k] = out->nbr[k];
+    parents *= fanouts[k];
+  }
+  return GIGL_OK;
+}
+
+int32_t gigl_sample_khop_peer(gigl_ctx* ctx, const int64_t* const* peer_rowptr, const uint32_t* const* peer_col,
+                              int32_t world, int64_t n_global, int64_t max_window_end, const uint32_t* roots, int32_t b,
+                              const int32_t* fanouts, int32_t hops, int32_t sampling_seed, gigl_tree* out) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, peer_rowptr && peer_col && (roots || b == 0) && fanouts && out, "null argument");
+  GIGL_REQUIRE(ctx, hops >= 1 && hops <= GIGL_MAX_HOPS && b >= 0 && world >= 1 && world < (1 << 15), "bad shape");
+  int64_t parents = b, max_parents = b;
+  for (int k = 0; k < hops; ++k) {
+    if (fanouts[k] < 1 || fanouts[k] > GIGL_FAST_FANOUT)
+      return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "peer-mapped sampling takes fan-outs up to %d (fanout[%d]=%d)", GIGL_FAST_FANOUT, k,
+                       fanouts[k]);
+    GIGL_REQUIRE(ctx, out->nbr[k] && out->cnt[k], "tree buffers for hop %d are null", k);
+    if (parents > max_parents) max_parents = parents;
+    parents *= fanouts[k];
+    GIGL_REQUIRE(ctx, parents < (int64_t)1 << 31, "tree too large");
+  }
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  out->hops = hops;
+  out->b = b;
+  for (int k = 0; k < hops; ++k) out->fanouts[k] = fanouts[k];
+  if (b == 0) return GIGL_OK;
+  // every hash window of the job must lie inside the threshold table (the caller's bound): the rows beyond it would take the
+  // workgroup-per-row paths, which read the adjacency of ONE resident graph
+  const uint64_t cap = table_cap_j();
+  if (max_window_end < 0 || (uint64_t)max_window_end + 1 > cap)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "peer-mapped sampling needs a window bound inside the threshold table (max_window_end)");
+  int32_t rc = ensure_table(ctx, (uint64_t)max_window_end + 1);
+  if (rc != GIGL_OK) return rc;
+  const RangeTable tb = ((TableOwner*)ctx->sampler_table)->t;
+  if ((uint64_t)max_window_end >= tb.dom)
+    return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "peer-mapped sampling: the window bound exceeds the threshold table");
+  rc = gigl_arena_reset(ctx, expand_desc_bytes(max_parents) + 1024);
+  if (rc != GIGL_OK) return rc;
+  RowDesc* desc = (RowDesc*)gigl_arena_alloc(ctx, expand_desc_bytes(max_parents));
+  if (!desc) return gigl_fail(ctx, GIGL_E_OOM, "arena exhausted");
+  ExpandArgs a{};
+  a.peer_rowptr = peer_rowptr;
+  a.peer_col = peer_col;
+  a.peer_world = (uint32_t)world;
+  a.n_nodes = n_global;
+  a.multi = 0;
+  a.roots = roots;
+  parents = b;
+  for (int k = 0; k < hops; ++k) {
+    a.hop = k;
+    a.n_parents = parents;
+    a.f = fanouts[k];
+    a.fan[k] = fanouts[k];
+    a.hash_add = (int32_t)((uint32_t)sampling_seed * (uint32_t)(k + 1));
+    a.out_nbr = out->nbr[k];
+    a.out_cnt = out->cnt[k];
+    rc = run_expand(ctx, a, tb, true, nullptr, nullptr, desc);
+    if (rc != GIGL_OK) return rc;
     a.anc[k] = out->nbr[k];
     parents *= fanouts[k];
   }

@@ -396,13 +396,16 @@ class DistSagePlan:
     def __init__(self, comm: Comm, weights, biases, b: int, fanouts: Sequence[int], act_last: bool = False,
                  group_roots: Optional[int] = None, project_on_owner: bool = False, pull_cap: int = 0,
                  hop_slack: float = 0.0, max_window_end: int = -1, projected: Optional[torch.Tensor] = None,
-                 pull_cap_b: int = 0, aggr: str = "mean", staged: bool = False, peer_direct: bool = False):
+                 pull_cap_b: int = 0, aggr: str = "mean", staged: bool = False, peer_direct: bool = False,
+                 peer_sample: bool = False):
         """aggr: the SAGE layers' reduction ("mean" | "sum" | "max"; "max" pulls raw rows: not with project_on_owner /
         projected).  projected: this rank's pre-projected rows (HipEngine.project_features of the SHARD's table with weights[0]:
         [shard rows, 2*out] fp32) — the pull moves W_l x rows, the first layer is one reduction (gigl_dist_plan_opts.
         projected); recompute and rebuild the plan after a weight update.
         peer_direct: the peer-mapped route (gigl_dist_plan_opts.peer_direct): rows are read where they live, from the
         owners' tables mapped into this process — hand them over with set_peer_tables / map_peer_tables before the first step.
+        peer_sample (with peer_direct): the peer-sampled route (gigl_dist_plan_opts.peer_sample): the ranks' graph shards are
+        mapped too (set_peer_graphs) and every rank expands its own frontier over them — a step without any exchange.
         staged: the plan serves TRAINING batches (gigl_dist_plan_opts.staged): sample_and_pull + batch_tensors hand out the
         batch union graph and its dense feature matrix; raw rows, every union node numbered"""
         from . import _lib
@@ -420,7 +423,8 @@ class DistSagePlan:
         o.pull_cap, o.hop_slack, o.max_window_end = int(pull_cap), float(hop_slack), int(max_window_end)
         o.staged = 1 if staged else 0
         o.peer_direct = 1 if peer_direct else 0
-        self.peer_direct = bool(peer_direct)
+        o.peer_sample = 1 if peer_sample else 0
+        self.peer_direct, self.peer_sample = bool(peer_direct), bool(peer_sample)
         self._peer_keep = None
         self.staged = bool(staged)
         assert not (staged and (projected is not None or project_on_owner)), "staged batches pull raw rows"
@@ -489,6 +493,20 @@ class DistSagePlan:
         arr = (C.c_void_p * len(ptrs))(*ptrs)
         _check(self._lib.gigl_dist_plan_set_peer_tables(self._plan, arr), self.eng._ctx)
         self._peer_keep = list(tables)  # (tensors stay alive with the plan)
+
+    def own_graph(self) -> Tuple[int, int]:
+        """device addresses (rowptr, col) of this rank's CSC shard (gigl_graph_device_ptrs)"""
+        rp, cl = C.c_void_p(), C.c_void_p()
+        _check(self._lib.gigl_graph_device_ptrs(self.eng._graph, C.byref(rp), C.byref(cl)), self.eng._ctx)
+        return int(rp.value), int(cl.value)
+
+    def set_peer_graphs(self, rowptrs: Sequence[int], cols: Sequence[int]) -> None:
+        """rowptrs[r] / cols[r]: rank r's CSC shard as device addresses valid in THIS process (own_graph of the ranks of an
+        in-process group; share_tables of each array between processes)"""
+        assert self.peer_sample and len(rowptrs) == len(cols) == self.comm.world
+        ra = (C.c_void_p * len(rowptrs))(*[int(v) for v in rowptrs])
+        ca = (C.c_void_p * len(cols))(*[int(v) for v in cols])
+        _check(self._lib.gigl_dist_plan_set_peer_graphs(self._plan, ra, ca), self.eng._ctx)
 
     @staticmethod
     def share_tables(eng, table, group=None) -> Tuple[list, list]:

@@ -287,6 +287,17 @@ int32_t gigl_sample_khop(gigl_ctx* ctx, gigl_graph* g, const uint32_t* roots, in
                          const int32_t* fanouts, int32_t hops, int32_t sampling_seed,
                          int32_t mode, gigl_tree* out);
 
+/* k-hop sampling (parity mode) over PEER-MAPPED graph shards of a hash-partitioned graph: node v's in-edge row is row
+ * v / world of rank (v % world)'s CSC shard — peer_rowptr[r] / peer_col[r]: DEVICE arrays of `world` pointers, each valid in
+ * this process (a rank's own: gigl_graph_device_ptrs; the others': mapped with gigl_ipc_export / gigl_ipc_open).  The
+ * requester expands its own frontier and reads the owners' adjacency where it lives: what the sharded plan's peer-sampled
+ * route runs instead of the per-hop request / answer exchange (distributed_neighborloader.py:162-192).  Same selection rule
+ * (SamplingStrategy.scala:16-82), threshold table and tree layout as gigl_sample_khop: the trees are bit-identical to a
+ * single process sampling the whole graph.  Fan-outs <= 64, rows without repeated ids, every hash window of the job below
+ * max_window_end (inside the threshold table): GIGL_E_UNSUPPORTED otherwise. */
+int32_t gigl_sample_khop_peer(gigl_ctx* ctx, const int64_t* const* peer_rowptr, const uint32_t* const* peer_col,
+                              int32_t world, int64_t n_global, int64_t max_window_end, const uint32_t* roots, int32_t b,
+                              const int32_t* fanouts, int32_t hops, int32_t sampling_seed, gigl_tree* out);
 /* one hop over an EXPLICIT frontier on a hash-partitioned graph (owner(v) = v % world,
  * python/gigl/distributed/dist_link_prediction_data_partitioner.py:692-695): `shard` holds only the CSC rows of
  * the nodes this rank owns (row v / world, ids inside rows stay global); nodes[i] (all owned by this rank, or
@@ -1415,6 +1426,13 @@ typedef struct gigl_dist_plan_opts {
                                 is peer-accessible (one node).  Replaces the same chunked scatter / RPC feature lookup as
                                 the bucketed pull: dist_link_prediction_data_partitioner.py:560-664,
                                 distributed_neighborloader.py:162-192 */
+  int32_t peer_sample;       /* 1 (with peer_direct): the PEER-SAMPLED route — the ranks' CSC shards are mapped too
+                                (gigl_dist_plan_set_peer_graphs) and every rank expands its OWN frontier, reading the owners'
+                                adjacency rows where they live: no request / answer buckets, no hop exchange, no scatter — the
+                                step has no collective left.  The same selection rule over the same rows: trees and rows
+                                bit-identical to the exchange route.  Needs fan-outs <= 64, no directed multi-edges, a window
+                                bound (max_window_end).  Replaces the per-hop sampling RPC of
+                                distributed_neighborloader.py:162-192 like the exchange route does */
 } gigl_dist_plan_opts;
 int32_t gigl_dist_plan_create(gigl_comm* comm, gigl_graph* shard, gigl_feat* shard_feat, int32_t b,
                               const int32_t* fanouts, int32_t hops, const int32_t* dims, const float* const* w,
@@ -1462,6 +1480,10 @@ int32_t gigl_dist_plan_set_hot_rows(gigl_dist_plan* plan, const uint32_t* hot_id
  * rows, or its pre-projected [W_l x | W_r x] rows when the plan was created over `projected` — for r = 0 .. world-1 (HOST
  * array; tables[rank] = the plan's own table).  Once, before the first step (a one-rank world needs no call). */
 int32_t gigl_dist_plan_set_peer_tables(gigl_dist_plan* plan, const void* const* tables);
+/* peer-sampled plans (opts->peer_sample): rowptrs[r] / cols[r] = rank r's CSC shard (gigl_graph_device_ptrs on rank r, mapped
+ * here through gigl_ipc_export / gigl_ipc_open — two allocations per rank) as DEVICE pointers valid in THIS process (HOST
+ * arrays; entries [rank] = the plan's own shard).  Once, before the first step. */
+int32_t gigl_dist_plan_set_peer_graphs(gigl_dist_plan* plan, const int64_t* const* rowptrs, const uint32_t* const* cols);
 /* Sharing a device allocation with the other ranks' processes of the node (what gigl_dist_plan_set_peer_tables is fed
  * with): export = (handle of the allocation dev_ptr lies in, dev_ptr's offset inside it) — ship both to the peers over any
  * host channel (torch.distributed all_gather); open = map a peer's allocation into this process, *ptr = the peer's dev_ptr

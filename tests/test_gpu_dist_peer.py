@@ -95,6 +95,75 @@ def test_peer_mapped_rows_equal_the_bucketed_route_bit_for_bit(world, pre, dtype
         e.close()
 
 
+@pytest.mark.parametrize("world,pre,dtype,hot", [(2, False, torch.float32, False), (8, True, torch.float16, True),
+                                                 (3, True, torch.float32, False)])
+def test_peer_sampled_step_has_no_exchange_and_equals_the_exchange_route(world, pre, dtype, hot):
+    """gigl_dist_plan_opts.peer_sample: the graph shards are mapped too and every rank expands its own frontier over them
+    (gigl_sample_khop_peer) — trees bit-identical to the oracle's and to the exchange route's, rows bit-identical to the bucketed
+    route's, and NOTHING passes through the transport"""
+    from gigl_amd.dist import Comm, DistSagePlan
+    rowptr, col, x = make_graph()
+    xq = x.astype(np.float16).astype(np.float32) if dtype == torch.float16 else x
+    model = make_model()
+    w, bs = model.fused_params()
+    b, gr = 96, 32
+    st = torch.cuda.Stream()
+    engs = [shard_engine(rowptr, col, x, r, world, dtype, st) for r in range(world)]
+    dev = engs[0].device
+    comms = Comm.local(engs)
+    tables = [e.project_features(w[0].to(dev)) for e in engs] if pre else [None] * world
+    kw = dict(group_roots=gr, max_window_end=bound_for(rowptr))
+    bucketed = [DistSagePlan(comms[r], w, bs, b, FAN, projected=tables[r], **kw) for r in range(world)]
+    full = [DistSagePlan(comms[r], w, bs, b, FAN, projected=tables[r], peer_direct=True, peer_sample=True, **kw)
+            for r in range(world)]
+    addrs = [p.own_table() for p in full]
+    graphs = [p.own_graph() for p in full]
+    for p in full:
+        p.set_peer_tables(addrs)
+        p.set_peer_graphs([g[0] for g in graphs], [g[1] for g in graphs])
+    if hot:
+        occ = np.bincount(col.astype(np.int64), minlength=N)
+        hid = np.argsort(-occ, kind="stable")[: N // 20].astype(np.uint32)
+        hot_ids = torch.from_numpy(hid.view(np.int32))
+        hot_rows = (torch.stack([tables[int(v) % world][int(v) // world, :HID] for v in hid.astype(np.int64)]).contiguous()
+                    if pre else torch.from_numpy(x[hid.astype(np.int64)]).to(dtype))
+        for p in bucketed + full:
+            p.set_hot_rows(hot_ids, hot_rows)
+    roots = [rank_roots(r, b) for r in range(world)]
+    roots_d = [torch.from_numpy(r.view(np.int32)).to(dev) for r in roots]
+    outs_b = DistSagePlan.run_local(bucketed, roots_d)
+    st.synchronize()
+    before = [c.traffic() for c in comms]
+    for _ in range(2):
+        outs_f = DistSagePlan.run_local(full, roots_d)
+    st.synchronize()
+    assert [c.traffic() for c in comms] == before, "the peer-sampled step handed bytes to the transport"
+    for r in range(world):
+        hb, hx = full[r].buffers_to_host(), bucketed[r].buffers_to_host()
+        assert hb["meta"][8] == 0
+        nbr_o, cnt_o = oracle.sample_khop(rowptr, col, roots[r], FAN, canonical=True)
+        for k in range(len(FAN)):
+            assert np.array_equal(hb["nbr"][k], nbr_o[k]) and np.array_equal(hb["cnt"][k], cnt_o[k]), (r, k)
+            assert np.array_equal(hb["nbr"][k], hx["nbr"][k])
+        assert torch.equal(outs_f[r], outs_b[r]), f"rank {r}: rows differ from the bucketed route's"
+        np.testing.assert_allclose(outs_f[r].cpu().numpy(), reference_rows(rowptr, col, xq, model, roots[r], gr),
+                                   rtol=1e-5, atol=1e-5)
+    # what it refuses: a fan-out past the wave-resident selection, no window bound, graphs not set
+    from gigl_amd import _lib
+    with pytest.raises(_lib.GiglError):
+        DistSagePlan(comms[0], w, bs, b, [80, 4], projected=None if not pre else tables[0], peer_direct=True, peer_sample=True, **kw)
+    with pytest.raises(_lib.GiglError):
+        DistSagePlan(comms[0], w, bs, b, FAN, projected=tables[0], peer_direct=True, peer_sample=True, group_roots=gr)
+    with pytest.raises(_lib.GiglError):
+        DistSagePlan(comms[0], w, bs, b, FAN, projected=tables[0], peer_sample=True, **kw)  # (needs peer_direct)
+    for p in bucketed + full:
+        p.close()
+    for c in comms:
+        c.close()
+    for e in engs:
+        e.close()
+
+
 def test_peer_mapped_plan_refuses_what_it_cannot_serve():
     from gigl_amd import _lib
     from gigl_amd.dist import Comm, DistSagePlan
@@ -174,9 +243,21 @@ def _worker(rank, world, port, q, transport="gloo"):
             opened += bases
             assert addrs[rank] == peer.own_table() and all(a for a in addrs)
             peer.set_peer_tables(addrs)
+            # ... and the peer-SAMPLED plan: the other process's CSC shard (two allocations) through ipc handles as well
+            full = DistSagePlan(comm, w, bs, 64, FAN, peer_direct=True, peer_sample=True, **kw)
+            rp, cl = full.own_graph()
+            rps, b1 = DistSagePlan.share_tables(eng, rp)
+            cls, b2 = DistSagePlan.share_tables(eng, cl)
+            opened += b1 + b2
+            full.set_peer_tables(addrs)
+            full.set_peer_graphs(rps, cls)
             ob = bucketed.run(rd)
             op = peer.run(rd)
             st.synchronize()
+            moved0 = comm.traffic()
+            of = full.run(rd)
+            st.synchronize()
+            assert comm.traffic() == moved0 and torch.equal(of, ob), f"pre={pre}: the peer-sampled step differs / used the transport"
             hb = peer.buffers_to_host()
             nbr_o, _ = oracle.sample_khop(rowptr, col, roots, FAN, canonical=True)
             assert hb["meta"][8] == 0 and all(np.array_equal(hb["nbr"][k], nbr_o[k]) for k in range(len(FAN)))
@@ -191,6 +272,7 @@ def _worker(rank, world, port, q, transport="gloo"):
             dist.barrier()  # (nobody unmaps or frees a table somebody still reads)
             bucketed.close()
             peer.close()
+            full.close()
         DistSagePlan.close_shared(eng, opened)
         dist.barrier()
         comm.close()

@@ -611,6 +611,10 @@ def test_bench_emulated_world_line(tmp_path):
         assert e["overlapped"]["ms_per_rank_step"] > 0 and pj["overlapped_step_ms"] == e["overlapped"]["ms_per_rank_step"]
         assert 0 < pj["whole_node_edges_per_s_overlapped_links_not_hidden"] < pj["whole_node_edges_per_s_overlapped_links_hidden"]
     assert line["route"] in ("peer", "bucketed")
+    # ... and the same per-rank workload at world 1, measured the same way: the projection as a multiple of it
+    w1 = line["world1_reference"]
+    assert w1["ms_per_step_overlapped"] > 0 and w1["sampled_plus_aggregated_edges_per_step"] > 0
+    assert pe["projection"]["scaling_1_to_4_links_hidden"] > pe["projection"]["scaling_1_to_4_links_not_hidden"] > 0
 
 
 @pytest.mark.gpu
