@@ -70,11 +70,13 @@ def main():
                     help="products-family workloads: issue every call's graph part (sample + union) on a stream of its own — "
                          "high: of a higher priority than the layers' stream (gigl_sage_plan_set_graph_stream), same: equal "
                          "priority (A/B of the split alone)")
-    ap.add_argument("--shard-route", type=str, default="auto", choices=["auto", "bucketed", "peer", "both"],
+    ap.add_argument("--shard-route", type=str, default="auto", choices=["auto", "bucketed", "peer", "peer-all", "both"],
                     help="mag240m-sharded: how feature rows reach the first layer — bucketed (claim -> id exchange -> owners "
                          "gather -> row exchange over the transport), peer (rows read in place from the owners' tables mapped "
-                         "into the reader: gigl_dist_plan_opts.peer_direct), both (--emulate-world: measure the two side by "
-                         "side), auto (both under --emulate-world, peer when every rank can map its peers' memory)")
+                         "into the reader: gigl_dist_plan_opts.peer_direct), peer-all (… and the owners' graph shards too: every "
+                         "rank expands its own frontier over them, gigl_dist_plan_opts.peer_sample — a step without any "
+                         "exchange), both (--emulate-world: measure all of them side by side), auto (both under "
+                         "--emulate-world, peer-all when every rank can map its peers' memory)")
     ap.add_argument("--emulate-streams", type=int, default=3,
                     help="--emulate-world: emulated worlds in flight (each W ranks on one stream, a step of all its ranks "
                          "replayed as one hipGraph) for the OVERLAPPED per-rank step; 0 skips that measurement")

@@ -165,27 +165,37 @@ def run_sharded(args, rank, world, local_rank, sub=False):
     # (hipIpc handles through the process group); the plans read the rows in place
     route_arg = getattr(args, "shard_route", "auto")
     peer_ok = not gat and not args.project_on_owner and L == 2 and fanouts[1] <= 64 and n < (1 << 31) and world <= 64
-    peer_route = route_arg == "peer" or (route_arg in ("auto", "both") and peer_ok)
-    if route_arg == "peer" and not peer_ok:
+    peer_route = route_arg in ("peer", "peer-all") or (route_arg in ("auto", "both") and peer_ok)
+    peer_all = peer_route and route_arg != "peer" and mwe >= 0 and all(f <= 64 for f in fanouts)
+    if route_arg in ("peer", "peer-all") and not peer_ok:
         raise SystemExit("bench.py: --shard-route peer needs the SAGE plan's dense shape (two hops, second fan-out <= 64, no "
                          "owner-side projection) and fewer than 2^31 nodes")
-    peer_addrs, peer_bases, route_note = None, [], None
+    peer_addrs, peer_bases, route_note, peer_graphs = None, [], None, None
     if peer_route and world > 1:
         own = int(proj_table.data_ptr()) if proj_table is not None else int(eng._feat_ptr.value)
         ok_t = torch.ones(1, dtype=torch.int32, device=dev)
         try:
             peer_addrs, peer_bases = DistSagePlan.share_tables(eng, own)
+            if peer_all:  # the CSC shard's two arrays as well
+                import ctypes as C_
+                rp_, cl_ = C_.c_void_p(), C_.c_void_p()
+                from gigl_amd._lib import check as check_
+                check_(eng._lib.gigl_graph_device_ptrs(eng._graph, C_.byref(rp_), C_.byref(cl_)), eng._ctx)
+                rps, b1 = DistSagePlan.share_tables(eng, int(rp_.value))
+                cls, b2 = DistSagePlan.share_tables(eng, int(cl_.value))
+                peer_bases += b1 + b2
+                peer_graphs = (rps, cls)
         except Exception as ex:  # noqa: BLE001 — (no peer access between these devices / processes)
             ok_t.zero_()
             route_note = f"{type(ex).__name__}: {str(ex)[:200]}"
         all_reduce(ok_t, dist.ReduceOp.MIN)  # every rank takes the same route
         if int(ok_t.item()) == 0:
-            if route_arg == "peer":
-                raise RuntimeError(f"--shard-route peer: mapping the peers' tables failed on some rank ({route_note})")
+            if route_arg in ("peer", "peer-all"):
+                raise RuntimeError(f"--shard-route {route_arg}: mapping the peers' memory failed on some rank ({route_note})")
             if peer_bases:
                 DistSagePlan.close_shared(eng, peer_bases)
-            peer_route, peer_addrs, peer_bases = False, None, []
-            route_note = "peer-mapped route not available here (" + (route_note or "another rank failed to map") + \
+            peer_route, peer_all, peer_addrs, peer_bases, peer_graphs = False, False, None, [], None
+            route_note = "peer-mapped routes not available here (" + (route_note or "another rank failed to map") + \
                 "): the bucketed route ran"
 
     class Slot:  # one plan in flight: ctx + stream + communicator + plan
@@ -206,9 +216,12 @@ def run_sharded(args, rank, world, local_rank, sub=False):
             else:
                 sl.plan = DistSagePlan(sl.comm, w, bs, G * B, fanouts, group_roots=B,
                                        project_on_owner=args.project_on_owner, pull_cap=pull_cap, max_window_end=mwe,
-                                       projected=proj_table, pull_cap_b=pull_cap_b, peer_direct=peer_route)
+                                       projected=proj_table, pull_cap_b=pull_cap_b, peer_direct=peer_route,
+                                       peer_sample=peer_all and world > 1)
                 if peer_route and world > 1:
                     sl.plan.set_peer_tables(peer_addrs)
+                    if peer_all:
+                        sl.plan.set_peer_graphs(*peer_graphs)
             sl.out = sl.plan.new_out()
             if hot_ids is not None:
                 sl.plan.set_hot_rows(hot_ids, hot_rows)
@@ -329,6 +342,9 @@ def run_sharded(args, rank, world, local_rank, sub=False):
         # loads, one row per occurrence that is neither this rank's nor replicated (counted on the device: PULLED_ROWS)
         rb_ = hid * 4 if proj_table is not None else d * 2
         mine = float(tot[STATS["pulled_rows"]].item()) * rb_
+        if peer_all and world > 1:  # + the remote frontier nodes' row bounds (16 B) and sampled ids (4 B each)
+            steps_timed = float(reps * K_rep)
+            mine += (world - 1) / world * (float(tot[STATS["sampled"]].item()) * 4 + steps_timed * B * (1 + fanouts[0]) * 16)
         add_t = torch.tensor([mine, mine], dtype=torch.float64, device=dev)
         add_m = add_t.clone()
         all_reduce(add_t, dist.ReduceOp.SUM)
@@ -377,8 +393,11 @@ def run_sharded(args, rank, world, local_rank, sub=False):
                                    + ("rows projected on the owner (256 fp32)" if args.project_on_owner else
                                       "rows pre-projected once per rank (256 fp32 W_l x rows pulled)" if proj_table is not None
                                       else "raw rows (768 fp16)")
-                                   + (", peer-mapped feature route (rows read in place from the owners' tables)" if peer_route else ""),
+                                   + (", peer-mapped feature route (rows read in place from the owners' tables)" if peer_route else "")
+                                   + (", peer-sampled hops (every rank expands its own frontier over the owners' mapped graph "
+                                      "shards: no exchange in the step)" if peer_all and world > 1 else ""),
                        "feature_route": "peer" if peer_route else "bucketed", "feature_route_note": route_note,
+                       "hop_route": "peer-sampled" if (peer_all and world > 1) else ("lone rank" if world == 1 else "exchange"),
                        "projected_input": (None if proj_table is None else {
                            "precompute_s": round(pre_s, 4), "steps_per_pass_per_rank": steps_per_pass,
                            "charged_ms_per_step": pre_per_step_s * 1e3}),
@@ -667,13 +686,17 @@ def run_emulated_world(args, local_rank=0, sub=False):
 
     def make_plans(pull_cap, pull_cap_b, hot, route="bucketed", cms=None):
         cms = cms if cms is not None else comms
-        peer = route == "peer"
+        peer, peer_all = route in ("peer", "peer-all"), route == "peer-all"
         plans = [DistSagePlan(cms[r], w, bs, G * B, fanouts, group_roots=B, pull_cap=pull_cap, max_window_end=mwe,
-                              projected=proj[r], pull_cap_b=pull_cap_b, peer_direct=peer) for r in range(W)]
+                              projected=proj[r], pull_cap_b=pull_cap_b, peer_direct=peer, peer_sample=peer_all) for r in range(W)]
         if peer:  # every rank's table is a pointer of this process
             tables = [pl.own_table() for pl in plans]
             for pl in plans:
                 pl.set_peer_tables(tables)
+        if peer_all:  # ... and so is every rank's CSC shard
+            graphs = [pl.own_graph() for pl in plans]
+            for pl in plans:
+                pl.set_peer_graphs([g_[0] for g_ in graphs], [g_[1] for g_ in graphs])
         if hot and n_hot:
             for pl in plans:
                 pl.set_hot_rows(hot_ids, hot_rows)
@@ -761,7 +784,7 @@ def run_emulated_world(args, local_rank=0, sub=False):
     def measure(hot, route="bucketed"):
         # bucket capacities from two warm-up calls (+10 %), as the multi-process bench does
         pull_cap = pull_cap_b = 0
-        if route != "peer":
+        if route not in ("peer", "peer-all"):
             acc0 = [torch.zeros(STATS_LEN, dtype=torch.int64, device=dev) for _ in range(W)]
             fill0 = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(W)]
             plans = make_plans(0, 0, hot)
@@ -811,10 +834,11 @@ def run_emulated_world(args, local_rank=0, sub=False):
     steps = K * G  # steps per rank in a measurement
     res = {}
     route_arg = getattr(args, "shard_route", "auto")
-    routes = ["bucketed", "peer"] if route_arg in ("auto", "both") else [route_arg]
+    peer_all_ok = mwe >= 0 and all(f <= 64 for f in fanouts)
+    routes = (["bucketed", "peer"] + (["peer-all"] if peer_all_ok else [])) if route_arg in ("auto", "both") else [route_arg]
     cases = []
     for route in routes:
-        pre = "" if route == "bucketed" else "peer_"
+        pre = {"bucketed": "", "peer": "peer_", "peer-all": "peer_all_"}[route]
         if n_hot:
             cases.append((pre + "hot_rows", True, route))
         if not n_hot or route == "bucketed":
@@ -848,8 +872,14 @@ def run_emulated_world(args, local_rank=0, sub=False):
                     agg0 * (4 + d * 2) + rows0 * (8 + d * 2 + 2 * d * 4)) + agg1 * (4 + hid * 4) + rows1 * (8 + hid * 4)
         gm_ms = kg.get("gather_mean", 0.0)
         tr = np.array(traffic, dtype=np.float64)  # [W, 2]
-        if route == "peer":  # the rows never pass through the transport: they cross the links inside the first layer's loads
+        if route in ("peer", "peer-all"):  # the rows never pass through the transport: they cross the links inside the first layer's loads
             tr = tr + (pulled * row_bytes)[:, None]
+        if route == "peer-all":
+            # ... and neither do the hops: a remote frontier node costs its row bounds (16 B) and the f sampled ids (4 B each) over
+            # the links — counted from the exact sampled-edge counts: (W - 1) / W of the frontier lives on other ranks
+            samp = st[:, STATS["sampled"]] / steps
+            fr_nodes = B * (1 + fanouts[0]) if L >= 2 else B
+            tr = tr + ((W - 1) / W * (samp * 4 + fr_nodes * 16))[:, None]
         moved_step, full_step = float(tr[:, 0].max()), float(tr[:, 1].max())  # the busiest rank's
         per_link = moved_step / (W - 1)  # bytes per peer pair and step: one xGMI link each (W <= 8)
         link_ms = per_link / 153e9 * 1e3
@@ -857,7 +887,11 @@ def run_emulated_world(args, local_rank=0, sub=False):
         ov_ms = overlapped["ms_per_rank_step"] if overlapped else None
         res[tag] = {
             "route": route,
-            "route_is": ("peer-mapped: the first layer reads rows in place from the owners' tables (no claim / id exchange / "
+            "route_is": ("peer-sampled + peer-mapped: every rank expands its own frontier over the owners' mapped graph shards "
+                         "and reads feature rows in place — no exchange at all in the step; link bytes = the remote frontier "
+                         "nodes' row bounds and sampled ids (modelled from the exact counts) + the remote feature rows"
+                         if route == "peer-all" else
+                         "peer-mapped: the first layer reads rows in place from the owners' tables (no claim / id exchange / "
                          "owner-side gather / row exchange); `pulled_rows` = rows read from OTHER ranks' tables, per occurrence"
                          if route == "peer" else
                          "bucketed: claim once per call -> id exchange -> owners gather -> count-sized row exchange -> receive "

@@ -57,6 +57,7 @@ def test_self_launch_two_ranks_on_one_gpu():
     # — no row ever sits in a bucket; the bucketed route reports how full its row buckets were
     if line["config"]["feature_route"] == "peer":
         assert line["config"]["row_bucket_fill"] is None and line["config"]["feature_route_note"] is None
+        assert line["config"]["hop_route"] == "peer-sampled"  # (the ranks' graph shards are mapped as well: no exchange at all)
     else:
         assert 0 < line["config"]["row_bucket_fill"] <= 1.0
     assert "replicated as hot rows" in line["config"]["workload"]  # hub replication is on by default at world > 1

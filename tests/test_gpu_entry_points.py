@@ -606,11 +606,13 @@ def test_bench_emulated_world_line(tmp_path):
     pe = emu["peer_hot_rows"]
     assert pe["route"] == "peer" and "dist_serve" not in pe["kernel_ms_by_group"] and pe["kernel_ms_by_group"]["dist_prep"] > 0
     assert pe["pulled_rows_per_step_mean"] >= emu["hot_rows"]["pulled_rows_per_step_mean"] > 0
-    for e in (pe, emu["hot_rows"]):
+    pa = emu["peer_all_hot_rows"]  # ... and the route without any exchange: the hops peer-sampled too
+    assert pa["route"] == "peer-all" and pa["kernel_ms_by_group"].get("dist_prep", 0.0) < pe["kernel_ms_by_group"]["dist_prep"]
+    for e in (pe, pa, emu["hot_rows"]):
         pj = e["projection"]
         assert e["overlapped"]["ms_per_rank_step"] > 0 and pj["overlapped_step_ms"] == e["overlapped"]["ms_per_rank_step"]
         assert 0 < pj["whole_node_edges_per_s_overlapped_links_not_hidden"] < pj["whole_node_edges_per_s_overlapped_links_hidden"]
-    assert line["route"] in ("peer", "bucketed")
+    assert line["route"] in ("peer", "peer-all", "bucketed")
     # ... and the same per-rank workload at world 1, measured the same way: the projection as a multiple of it
     w1 = line["world1_reference"]
     assert w1["ms_per_step_overlapped"] > 0 and w1["sampled_plus_aggregated_edges_per_step"] > 0
