@@ -174,7 +174,7 @@ class ResidentGraph:
         self.engine = eng = HipEngine(self.device.index or 0)
         self.comm = None
         self._plans: Dict[tuple, object] = {}
-        self._unsettled: list = []   # overflow-flag slots of pipelined calls nobody has settled yet (call_overflowed)
+        self._unsettled: dict = {}   # overflow-flag slots of pipelined calls nobody has settled yet (call_overflowed), by id
         self.overflow_redone = 0     # plan calls redone through the staged launches (their batch outgrew the workspace)
         self.sharded = bool(self.world > 1 if sharded is None else (sharded and self.world > 1))
         if self.sharded and self.mode == MODE_REPLACE:
@@ -222,7 +222,7 @@ class ResidentGraph:
         self.n, self.node_ids, self.labels = int(engine.n_nodes), np.asarray(node_ids, dtype=np.int64), {}
         self.has_in_edge = None
         self.engine, self.comm, self._plans, self.sharded = engine, None, {}, False
-        self._unsettled, self.overflow_redone = [], 0
+        self._unsettled, self.overflow_redone = {}, 0
         self.feat_dim, self.node_type, self._order_prefixes = int(engine.feat_dim), node_type, [order_prefix]
         self._borrowed_engine = True
         return self
@@ -423,7 +423,7 @@ class ResidentGraph:
                         slot["host"].copy_(slot["dev"], non_blocking=True)
                         slot["event"].record(torch.cuda.current_stream(self.device))
                         batch._overflow_slot = slot
-                        self._unsettled.append(slot)
+                        self._unsettled[id(slot)] = slot
                         redo = False
                     else:
                         redo = bool(int(slot["dev"].item()))
@@ -483,8 +483,7 @@ class ResidentGraph:
         sl["event"].synchronize()
         over = bool(int(sl["host"][0]))
         sl["busy"] = False
-        if sl in self._unsettled:
-            self._unsettled.remove(sl)
+        self._unsettled.pop(id(sl), None)
         return over
 
     def raise_on_overflow(self) -> None:
@@ -492,7 +491,7 @@ class ResidentGraph:
         call_overflowed: its NaN rows were handed on.  Synchronises; callers check once per pass, before the rows are
         declared written.  (Calls that are not deferred are checked — and redone — inside encode.)"""
         n = 0
-        for sl in list(self._unsettled):
+        for sl in list(self._unsettled.values()):
             sl["event"].synchronize()
             n += int(sl["host"][0])
             sl["busy"] = False
