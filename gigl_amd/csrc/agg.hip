@@ -4314,14 +4314,8 @@ int32_t gigl_linear(gigl_ctx* ctx, const float* a, const float* w, const float* 
 // the projection over an A operand in the tiled layout gigl_gather_reduce_mixed(..., tiled_nkc) writes
 // ([row tile of 128][K chunk of 32][128 rows][32 floats], tiled_nkc = ceil(k / 32)); k % 4 == 0
 // y rows may be a column slice of wider rows (ldy floats apart): the per-head projections of gigl_gat_input_layer
-int32_t gigl_linear_weight_grad(gigl_ctx* ctx, const float* dy, const float* a, const float* relu_y, const int32_t* m_dev,
-                                int64_t m_cap, int32_t n, int32_t k, float* dw, float* db) {
-  if (!ctx) return GIGL_E_INVALID_ARG;
-  GIGL_REQUIRE(ctx, dy && a && m_dev && dw, "null argument");
-  GIGL_REQUIRE(ctx, n > 0 && k > 0 && m_cap >= 0, "bad sizes");
-  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  if (m_cap == 0) return GIGL_OK;
-  gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
+// rows per chunk of the weight gradient's split over the rows (gigl_linear_weight_grad / _parts)
+static int wgrad_rows_per_chunk(int64_t m_cap, int32_t n, int32_t k) {
   // rows per chunk: 256 for the tens of thousands of rows of a first layer; fewer rows (the roots' layer: ~10^3) are cut
   // finer so that the reduction still spreads over a few hundred workgroups
   int rcw = WG_RC;
@@ -4330,6 +4324,39 @@ int32_t gigl_linear_weight_grad(gigl_ctx* ctx, const float* dy, const float* a, 
   // that the partial sums stay a few tens of MB instead of a copy of dW per 256 rows
   const int64_t tiles = (int64_t)((n + 63) / 64) * ((k + 63) / 64);
   while (rcw < 8192 && ((m_cap + rcw - 1) / rcw) * tiles > 8192) rcw <<= 1;
+  return rcw;
+}
+
+// The per-chunk PARTIAL sums only (no reduction launch): part [chunks][n][k], partb [chunks][n] (may be NULL) in the
+// caller's buffers, *rows_per_chunk = the split.  chunks = ceil(m_cap / rows_per_chunk); only the chunks below
+// ceil(*m_dev / rows_per_chunk) are written.  The training plans sum them inside their Adam kernel (one launch less per layer).
+int64_t gigl_linear_weight_grad_chunks(int64_t m_cap, int32_t n, int32_t k, int32_t* rows_per_chunk) {
+  const int rcw = wgrad_rows_per_chunk(m_cap, n, k);
+  if (rows_per_chunk) *rows_per_chunk = rcw;
+  return (m_cap + rcw - 1) / rcw;
+}
+int32_t gigl_linear_weight_grad_parts(gigl_ctx* ctx, const float* dy, const float* a, const float* relu_y, const int32_t* m_dev,
+                                      int64_t m_cap, int32_t n, int32_t k, float* part, float* partb) {
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (m_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
+  const int rcw = wgrad_rows_per_chunk(m_cap, n, k);
+  const int64_t chunks = (m_cap + rcw - 1) / rcw;
+  const dim3 grid((unsigned)chunks, (unsigned)((n + 63) / 64), (unsigned)((k + 63) / 64));
+  hipLaunchKernelGGL(linear_weight_grad_mfma_kernel, grid, dim3(256), 0, ctx->stream, dy, a, relu_y, m_dev, n, k, part, partb, rcw);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
+int32_t gigl_linear_weight_grad(gigl_ctx* ctx, const float* dy, const float* a, const float* relu_y, const int32_t* m_dev,
+                                int64_t m_cap, int32_t n, int32_t k, float* dw, float* db) {
+  if (!ctx) return GIGL_E_INVALID_ARG;
+  GIGL_REQUIRE(ctx, dy && a && m_dev && dw, "null argument");
+  GIGL_REQUIRE(ctx, n > 0 && k > 0 && m_cap >= 0, "bad sizes");
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (m_cap == 0) return GIGL_OK;
+  gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
+  const int rcw = wgrad_rows_per_chunk(m_cap, n, k);
   const int64_t chunks = (m_cap + rcw - 1) / rcw, nk = (int64_t)n * k;
   int32_t rc = gigl_arena_reset(ctx, chunks * (nk + n) * 4 + 1024);
   if (rc != GIGL_OK) return rc;

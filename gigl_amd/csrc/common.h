@@ -120,6 +120,10 @@ void* gigl_arena_alloc(gigl_ctx* ctx, int64_t bytes);
 
 // fills g->maxdeg from the resident rowptr (synchronises the ctx stream)
 int32_t gigl_graph_compute_maxdeg(gigl_ctx* ctx, gigl_graph* g);
+// the weight gradient's per-chunk partial sums without the reduction launch (agg.hip): see gigl_linear_weight_grad_parts
+int64_t gigl_linear_weight_grad_chunks(int64_t m_cap, int32_t n, int32_t k, int32_t* rows_per_chunk);
+int32_t gigl_linear_weight_grad_parts(gigl_ctx* ctx, const float* dy, const float* a, const float* relu_y, const int32_t* m_dev,
+                                      int64_t m_cap, int32_t n, int32_t k, float* part, float* partb);
 // union build with the plan-internal leaf-global option (union.hip)
 int32_t gigl_union_build_impl(gigl_ctx* ctx, const uint32_t* roots, const gigl_tree* tree, int32_t group_roots,
                               gigl_union* out, int32_t leaf_global);

@@ -424,10 +424,10 @@ int32_t capture_segments(gigl_sage_plan* p, int32_t sampling_seed, int32_t mode)
 // cross-entropy on the roots' rows: one wave per root.  loss_rows[i] = lse(out[rl]) - out[rl][label] for the n_valid real
 // roots (0 for padding); the gradient (softmax - onehot) / n_valid is ADDED to dout[rl] (zeroed before; two roots of a
 // batch that are the same node share a row, hence the atomics — a row with one root gets plain values)
-__global__ __launch_bounds__(256) void ce_roots_kernel(const float* __restrict__ out, int width, const int32_t* __restrict__ root_local,
-                                                       const int64_t* __restrict__ labels, const int32_t* __restrict__ n_valid_dev,
-                                                       int b, const int32_t* __restrict__ meta, float* __restrict__ dout,
-                                                       float* __restrict__ loss_rows) {
+__device__ __forceinline__ void ce_root_row(const float* __restrict__ out, int width, const int32_t* __restrict__ root_local,
+                                            const int64_t* __restrict__ labels, const int32_t* __restrict__ n_valid_dev, int b,
+                                            const int32_t* __restrict__ meta, float* __restrict__ dout,
+                                            float* __restrict__ loss_rows) {
   const int lane = threadIdx.x & 63;
   const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (i >= b) return;
@@ -463,11 +463,56 @@ __global__ __launch_bounds__(256) void ce_roots_kernel(const float* __restrict__
   if (lane == 0) loss_rows[i] = lse - row[lab];
 }
 
+__global__ __launch_bounds__(256) void ce_roots_kernel(const float* __restrict__ out, int width, const int32_t* __restrict__ root_local,
+                                                       const int64_t* __restrict__ labels, const int32_t* __restrict__ n_valid_dev,
+                                                       int b, const int32_t* __restrict__ meta, float* __restrict__ dout,
+                                                       float* __restrict__ loss_rows) {
+  ce_root_row(out, width, root_local, labels, n_valid_dev, b, meta, dout, loss_rows);
+}
+
+// ---- round 6: the node-classification step's small launches folded together (each costs ~5 us of a 0.22-ms step) ----
+// prep: the cleared block (gw | gb | dh), the transposed weights of layers >= 1 (the backward's da = dh . W needs W^T as the
+// projection's weight operand; the weights only change in the previous step's Adam) and the loss ticket, in ONE launch
+struct TrainPrep {
+  uint32_t* zero;
+  int64_t zero_words;
+  const float* w[GIGL_MAX_HOPS];
+  float* wt[GIGL_MAX_HOPS];
+  int32_t rows[GIGL_MAX_HOPS], cols[GIGL_MAX_HOPS];
+  int32_t n_t;
+  int32_t* ticket;
+};
+__global__ __launch_bounds__(256) void train_prep_kernel(TrainPrep a) {
+  const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = t0; i < a.zero_words; i += stride) a.zero[i] = 0u;
+  for (int q = 0; q < a.n_t; ++q) {
+    const int64_t n = (int64_t)a.rows[q] * a.cols[q];
+    for (int64_t i = t0; i < n; i += stride) {
+      const int r = (int)(i / a.cols[q]), c = (int)(i - (int64_t)r * a.cols[q]);
+      a.wt[q][(int64_t)c * a.rows[q] + r] = a.w[q][i];
+    }
+  }
+  if (t0 == 0) *a.ticket = 0;
+}
+
+// the step's inputs into the static buffers the captured launches read — labels, the number of real roots, where the
+// caller wants the loss — in one launch (was: a device copy, a 32-bit fill and, after the step, another device copy)
+__global__ __launch_bounds__(256) void train_stage_kernel(const int64_t* __restrict__ labels, int n_valid, int64_t* __restrict__ labels_buf,
+                                                          int32_t* __restrict__ n_valid_buf, float** __restrict__ loss_slot,
+                                                          float* loss_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_valid) labels_buf[i] = labels[i];
+  if (i == 0) {
+    n_valid_buf[0] = n_valid;
+    *loss_slot = loss_out;
+  }
+}
+
 // loss = sum_i loss_rows[i] / n_valid in a fixed order (one workgroup); the optimiser's step counter moves on
 __global__ __launch_bounds__(1024) void loss_sum_kernel(const float* __restrict__ loss_rows, int b,
                                                         const int32_t* __restrict__ n_valid_dev, float* __restrict__ loss,
                                                         int32_t* __restrict__ step, const int32_t* __restrict__ meta,
-                                                        int32_t* __restrict__ halt) {
+                                                        int32_t* __restrict__ halt, float* const* loss_slot = nullptr) {
   __shared__ float s_p[16];
   float v = 0.f;
   for (int i = threadIdx.x; i < b; i += 1024) v += loss_rows[i];
@@ -485,6 +530,9 @@ __global__ __launch_bounds__(1024) void loss_sum_kernel(const float* __restrict_
     if (*halt != 0) *loss = __builtin_nanf("");
     else if (meta[GIGL_META_OVERFLOW] == 0) *step += 1;
     else *halt = 1;
+    // (round 6: the caller's loss slot, set by train_stage_kernel — no device copy after the step)
+    float* extra = loss_slot ? *loss_slot : nullptr;
+    if (extra) *extra = *loss;
   }
 }
 
@@ -511,6 +559,11 @@ struct AdamPack {
   float* m[2 * GIGL_MAX_HOPS];
   float* v[2 * GIGL_MAX_HOPS];
   int64_t n[2 * GIGL_MAX_HOPS];
+  // round 6: a tensor's gradient may arrive as the weight-gradient kernel's per-chunk PARTIAL sums (part != NULL:
+  // [chunks][n] floats, the chunks below ceil(*rows / rc) hold real rows) — summed here in chunk order, one launch less per layer
+  const float* part[2 * GIGL_MAX_HOPS];
+  const int32_t* rows[2 * GIGL_MAX_HOPS];
+  int32_t rc[2 * GIGL_MAX_HOPS];
   int32_t count;
   float lr, beta1, beta2, eps, wd;
 };
@@ -521,14 +574,33 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamPack a, const int32_t* __
   const double t = (double)*step_dev;
   const float bc1 = (float)(1.0 - pow((double)a.beta1, t)), bc2s = (float)sqrt(1.0 - pow((double)a.beta2, t));
   const float step_size = a.lr / bc1;
-  for (int k = 0; k < a.count; ++k) {
+  // gridDim.y > 1: one slice of the grid per tensor (the partial sums are chains of dependent-latency loads: the tensors'
+  // chains run side by side instead of one after the other)
+  const int k_lo = gridDim.y > 1 ? (int)blockIdx.y : 0, k_hi = gridDim.y > 1 ? (int)blockIdx.y + 1 : a.count;
+  for (int k = k_lo; k < k_hi && k < a.count; ++k) {
     float* p = a.p[k];
     const float* g = a.g[k];
     float* m = a.m[k];
     float* v = a.v[k];
+    const float* part = a.part[k];
+    const int chunks = part ? (*a.rows[k] + a.rc[k] - 1) / a.rc[k] : 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += (int64_t)gridDim.x * blockDim.x) {
       const float w = p[i];
-      const float gr = g[i] + a.wd * w;
+      float gsum = 0.f;
+      if (part) {  // (sixteen chunks' loads in flight, added in chunk order)
+        int c = 0;
+        for (; c + 15 < chunks; c += 16) {
+          float pv[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) pv[q] = part[(int64_t)(c + q) * a.n[k] + i];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) gsum += pv[q];
+        }
+        for (; c < chunks; ++c) gsum += part[(int64_t)c * a.n[k] + i];
+      } else {
+        gsum = g[i];
+      }
+      const float gr = gsum + a.wd * w;
       const float mm = m[i] + (gr - m[i]) * (1.f - a.beta1);
       const float vv = v[i] * a.beta2 + (1.f - a.beta2) * gr * gr;
       m[i] = mm;
@@ -1082,6 +1154,15 @@ struct gigl_sage_train_plan {
   int32_t* tlists[TRAIN_WS][GIGL_MAX_HOPS] = {{nullptr}};  // its transposed lists per workspace and layer >= 1, built by the graph part
   float* da = nullptr;                    // [max rows_cap[l >= 1]][2 max dims]: gradient of a layer's operand
   float* wt = nullptr;                    // a layer's transposed weight
+  // round 6 (GIGL_TRAIN_PLAN_UNFUSED=1 keeps the separate launches: A/B): per-layer transposed weights written by the prep
+  // kernel, the weight gradients' partial sums (summed inside Adam), the fused loss's ticket and the loss pointer slot
+  bool fused_small = false;
+  float* wt_l[GIGL_MAX_HOPS] = {nullptr};
+  float* part_w[GIGL_MAX_HOPS] = {nullptr};
+  float* part_b[GIGL_MAX_HOPS] = {nullptr};
+  int32_t part_rc[GIGL_MAX_HOPS] = {0};
+  int32_t* ticket = nullptr;
+  float** loss_slot = nullptr;
   float* gw[GIGL_MAX_HOPS] = {nullptr};
   float* gb[GIGL_MAX_HOPS] = {nullptr};
   float* mom[4 * GIGL_MAX_HOPS] = {nullptr};  // m_w, v_w, m_b, v_b per layer
@@ -1118,7 +1199,26 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
   const int L = t->L;
   hipStream_t st = ctx->stream;
   int32_t rc = GIGL_OK;
-  gigl_fill_u32(st, t->zero_base, 0u, (int64_t)(t->zero_bytes / 4));
+  const bool fz = t->fused_small;
+  if (fz) {
+    TrainPrep pa{};
+    pa.zero = (uint32_t*)t->zero_base;
+    pa.zero_words = (int64_t)(t->zero_bytes / 4);
+    for (int l = 1; l < L; ++l) {
+      pa.w[pa.n_t] = t->w[l];
+      pa.wt[pa.n_t] = t->wt_l[l];
+      pa.rows[pa.n_t] = t->dims[l + 1];
+      pa.cols[pa.n_t] = 2 * t->dims[l];
+      ++pa.n_t;
+    }
+    pa.ticket = t->ticket;
+    int64_t blocks = (pa.zero_words + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 64) blocks = 64;
+    hipLaunchKernelGGL(train_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pa);
+  } else {
+    gigl_fill_u32(st, t->zero_base, 0u, (int64_t)(t->zero_bytes / 4));
+  }
   const int32_t* n_local = p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr;
   // ---- forward
   for (int l = 0; l < L; ++l) {
@@ -1138,20 +1238,27 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
   // ---- loss on the roots, its gradient into dh[L - 1]
   {
     const int width = t->dims[L];
+    // (the loss rows and their sum stay two launches: folding the sum into the last workgroup of the first — a ticket behind
+    // device-scope fences — took 22.7 us instead of 5.0 + 5.1, and the L2 write-backs of its 256 fences slowed the next batch's
+    // graph part on the side stream: measured, round 6)
     hipLaunchKernelGGL(ce_roots_kernel, dim3((unsigned)((t->b + 3) / 4)), dim3(256), 0, st, (const float*)t->h[L - 1], width,
                        (const int32_t*)p->un.root_local, (const int64_t*)t->labels_buf, (const int32_t*)t->n_valid_buf, t->b,
                        (const int32_t*)p->un.meta, t->dh[L - 1], t->loss_rows);
     hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)t->loss_rows, t->b,
                        (const int32_t*)t->n_valid_buf, t->loss, t->n_valid_buf + 1, (const int32_t*)p->un.meta,
-                       t->n_valid_buf + 2);
+                       t->n_valid_buf + 2, fz ? (float* const*)t->loss_slot : (float* const*)nullptr);
   }
   // ---- backward
   for (int l = L - 1; l >= 0; --l) {
     const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
     const int d = t->dims[l], n_out = t->dims[l + 1];
     const bool act = l < L - 1 || t->act_last;
-    rc = gigl_linear_weight_grad(ctx, t->dh[l], t->a[l], act ? t->h[l] : nullptr, n_rows, t->rows_cap[l], n_out, 2 * d,
-                                 t->gw[l], t->bias[l] ? t->gb[l] : nullptr);
+    if (fz)  // (the partial sums only: Adam adds them up)
+      rc = gigl_linear_weight_grad_parts(ctx, t->dh[l], t->a[l], act ? t->h[l] : nullptr, n_rows, t->rows_cap[l], n_out, 2 * d,
+                                         t->part_w[l], t->bias[l] ? t->part_b[l] : nullptr);
+    else
+      rc = gigl_linear_weight_grad(ctx, t->dh[l], t->a[l], act ? t->h[l] : nullptr, n_rows, t->rows_cap[l], n_out, 2 * d,
+                                   t->gw[l], t->bias[l] ? t->gb[l] : nullptr);
     if (rc != GIGL_OK) return rc;
     if (l == 0) break;  // (the first layer's input is the feature table: no gradient)
     if (act) {
@@ -1159,11 +1266,14 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
       if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, t->dh[l], (const float*)t->h[l], n_rows, n_out);
     }
-    {
+    const float* wt = t->wt;
+    if (fz) {
+      wt = t->wt_l[l];  // (written by the prep kernel)
+    } else {
       int64_t blocks = ((int64_t)n_out * 2 * d + 255) / 256;
       hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)t->w[l], n_out, 2 * d, t->wt);
     }
-    rc = gigl_linear(ctx, t->dh[l], t->wt, nullptr, n_rows, t->rows_cap[l], n_out, 2 * d, 0, t->da);
+    rc = gigl_linear(ctx, t->dh[l], wt, nullptr, n_rows, t->rows_cap[l], n_out, 2 * d, 0, t->da);
     if (rc != GIGL_OK) return rc;
     if (t->bwd_gather)
       rc = gigl_gather_mean_backward_lists(ctx, t->da, d, p->un.rowptr, p->un.rowend, n_rows,
@@ -1176,14 +1286,21 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
   // ---- Adam
   AdamPack ap{};
   for (int l = 0; l < L; ++l) {
+    const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
     ap.p[ap.count] = t->w[l];
     ap.g[ap.count] = t->gw[l];
+    ap.part[ap.count] = fz ? t->part_w[l] : nullptr;
+    ap.rows[ap.count] = n_rows;
+    ap.rc[ap.count] = t->part_rc[l];
     ap.m[ap.count] = t->mom[4 * l];
     ap.v[ap.count] = t->mom[4 * l + 1];
     ap.n[ap.count++] = (int64_t)t->dims[l + 1] * 2 * t->dims[l];
     if (t->bias[l]) {
       ap.p[ap.count] = t->bias[l];
       ap.g[ap.count] = t->gb[l];
+      ap.part[ap.count] = fz ? t->part_b[l] : nullptr;
+      ap.rows[ap.count] = n_rows;
+      ap.rc[ap.count] = t->part_rc[l];
       ap.m[ap.count] = t->mom[4 * l + 2];
       ap.v[ap.count] = t->mom[4 * l + 3];
       ap.n[ap.count++] = t->dims[l + 1];
@@ -1194,8 +1311,8 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
   ap.beta2 = t->beta2;
   ap.eps = t->eps;
   ap.wd = t->wd;
-  hipLaunchKernelGGL(adam_kernel, dim3(256), dim3(256), 0, st, ap, (const int32_t*)(t->n_valid_buf + 1),
-                     (const int32_t*)p->un.meta, (const int32_t*)(t->n_valid_buf + 2));
+  hipLaunchKernelGGL(adam_kernel, fz ? dim3(208, (unsigned)ap.count) : dim3(256), dim3(256), 0, st, ap,
+                     (const int32_t*)(t->n_valid_buf + 1), (const int32_t*)p->un.meta, (const int32_t*)(t->n_valid_buf + 2));
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
@@ -1387,6 +1504,20 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
   t->loss = (float*)alloc(16);
   ok = ok && t->zero_base && t->da && t->wt && t->labels_buf && t->n_valid_buf && t->loss_rows && t->loss;
   if (ok && hipMemset(t->n_valid_buf, 0, 16) != hipSuccess) ok = false;
+  t->fused_small = getenv("GIGL_TRAIN_PLAN_UNFUSED") == nullptr;
+  if (t->fused_small && ok) {
+    t->ticket = (int32_t*)alloc(16);
+    t->loss_slot = (float**)alloc(16);
+    ok = t->ticket && t->loss_slot && hipMemset(t->ticket, 0, 16) == hipSuccess && hipMemset(t->loss_slot, 0, 16) == hipSuccess;
+    for (int l = 0; l < hops && ok; ++l) {
+      const int n_out = dims[l + 1], k2 = 2 * dims[l];
+      const int64_t chunks = gigl_linear_weight_grad_chunks(t->rows_cap[l], n_out, k2, &t->part_rc[l]);
+      t->part_w[l] = (float*)alloc((size_t)chunks * n_out * k2 * 4);
+      t->part_b[l] = (float*)alloc((size_t)chunks * n_out * 4);
+      if (l >= 1) t->wt_l[l] = (float*)alloc((size_t)n_out * k2 * 4);
+      ok = t->part_w[l] && t->part_b[l] && (l == 0 || t->wt_l[l]);
+    }
+  }
   if (!ok) {
     gigl_sage_train_plan_destroy(t);
     return gigl_fail(ctx, GIGL_E_OOM, "hipMalloc of the training workspace failed");
@@ -1435,8 +1566,14 @@ int32_t gigl_sage_train_plan_step2(gigl_sage_train_plan* t, const uint32_t* root
   }
   // the step's inputs go into the static buffers the (captured) launches read: labels, the number of real roots (a
   // 32-bit fill: no host memory involved, ordered on the stream)
-  GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->labels_buf, labels, (size_t)n_valid * 8, hipMemcpyDeviceToDevice, st));
-  GIGL_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)t->n_valid_buf, n_valid, 1, st));
+  if (t->fused_small) {
+    hipLaunchKernelGGL(train_stage_kernel, dim3((unsigned)((n_valid + 255) / 256)), dim3(256), 0, st, labels, n_valid, t->labels_buf,
+                       t->n_valid_buf, t->loss_slot, loss_out);
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+  } else {
+    GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->labels_buf, labels, (size_t)n_valid * 8, hipMemcpyDeviceToDevice, st));
+    GIGL_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)t->n_valid_buf, n_valid, 1, st));
+  }
   GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, t->ev_graph[k], 0));
   if (t->lctx->stream != st || t->lctx->own_stream) {
     const int32_t rs = gigl_ctx_set_stream(t->lctx, st);
@@ -1446,7 +1583,8 @@ int32_t gigl_sage_train_plan_step2(gigl_sage_train_plan* t, const uint32_t* root
   if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->lctx));
   GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_layers[k], st));
   t->cur = (k + 1) % TRAIN_WS;
-  if (loss_out) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(loss_out, t->loss, 4, hipMemcpyDeviceToDevice, st));
+  // (fused: the loss kernel wrote loss_out itself, through the pointer slot the stage kernel set)
+  if (loss_out && !t->fused_small) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(loss_out, t->loss, 4, hipMemcpyDeviceToDevice, st));
   return GIGL_OK;
 }
 
