@@ -482,8 +482,18 @@ struct TrainPrep {
   int32_t n_t;
   int32_t* ticket;
 };
-__global__ __launch_bounds__(256) void train_prep_kernel(TrainPrep a) {
+// the step's inputs into the static buffers the captured launches read — labels, the number of real roots, where the
+// caller wants the loss — in one launch (was: a device copy, a 32-bit fill and, after the step, another device copy)
+__global__ __launch_bounds__(256) void train_stage_kernel(const int64_t* __restrict__ labels, int n_valid, int64_t* __restrict__ labels_buf,
+                                                          int32_t* __restrict__ n_valid_buf, float** __restrict__ loss_slot,
+                                                          float* loss_out, TrainPrep a) {
   const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = t0; i < n_valid; i += stride) labels_buf[i] = labels[i];
+  if (t0 == 0) {
+    n_valid_buf[0] = n_valid;
+    *loss_slot = loss_out;
+  }
+  // ... and the prep work (this launch is eager, ahead of the captured layers: one node less in the replayed graph)
   for (int64_t i = t0; i < a.zero_words; i += stride) a.zero[i] = 0u;
   for (int q = 0; q < a.n_t; ++q) {
     const int64_t n = (int64_t)a.rows[q] * a.cols[q];
@@ -491,20 +501,6 @@ __global__ __launch_bounds__(256) void train_prep_kernel(TrainPrep a) {
       const int r = (int)(i / a.cols[q]), c = (int)(i - (int64_t)r * a.cols[q]);
       a.wt[q][(int64_t)c * a.rows[q] + r] = a.w[q][i];
     }
-  }
-  if (t0 == 0) *a.ticket = 0;
-}
-
-// the step's inputs into the static buffers the captured launches read — labels, the number of real roots, where the
-// caller wants the loss — in one launch (was: a device copy, a 32-bit fill and, after the step, another device copy)
-__global__ __launch_bounds__(256) void train_stage_kernel(const int64_t* __restrict__ labels, int n_valid, int64_t* __restrict__ labels_buf,
-                                                          int32_t* __restrict__ n_valid_buf, float** __restrict__ loss_slot,
-                                                          float* loss_out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_valid) labels_buf[i] = labels[i];
-  if (i == 0) {
-    n_valid_buf[0] = n_valid;
-    *loss_slot = loss_out;
   }
 }
 
@@ -1117,7 +1113,7 @@ int32_t gigl_sage_plan_set_graph_stream(gigl_sage_plan* p, void* hip_stream, int
 // layers than it hides.  roots_next2 of _step2 is then not used.  Also measured: the first layer's aggregation — it
 // depends on no weight — moved into the graph part, out of the layers' serial chain: 0.257 against 0.245 ms/step; the
 // two parts already share the GPU, the step follows the SUM of the launches more than the longer chain.)
-constexpr int TRAIN_WS = 2;
+constexpr int TRAIN_WS = 3;
 // the input gradient of layers >= 1 by gigl_gather_mean_backward_transposed (every row written once, no cleared block, no
 // float atomics) when the hidden widths allow float4 rows; GIGL_TRAIN_BWD_ATOMIC=1 keeps the scatter (A/B)
 static bool train_bwd_gather(const int32_t* dims, int32_t hops) {
@@ -1163,6 +1159,10 @@ struct gigl_sage_train_plan {
   int32_t part_rc[GIGL_MAX_HOPS] = {0};
   int32_t* ticket = nullptr;
   float** loss_slot = nullptr;
+  // the loss rows' sum (+ the step counter / halt flag) on a BRANCH of the captured layers: beside the last layer's weight
+  // gradient instead of in front of it, joined before Adam reads the counter
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   float* gw[GIGL_MAX_HOPS] = {nullptr};
   float* gb[GIGL_MAX_HOPS] = {nullptr};
   float* mom[4 * GIGL_MAX_HOPS] = {nullptr};  // m_w, v_w, m_b, v_b per layer
@@ -1200,25 +1200,7 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
   hipStream_t st = ctx->stream;
   int32_t rc = GIGL_OK;
   const bool fz = t->fused_small;
-  if (fz) {
-    TrainPrep pa{};
-    pa.zero = (uint32_t*)t->zero_base;
-    pa.zero_words = (int64_t)(t->zero_bytes / 4);
-    for (int l = 1; l < L; ++l) {
-      pa.w[pa.n_t] = t->w[l];
-      pa.wt[pa.n_t] = t->wt_l[l];
-      pa.rows[pa.n_t] = t->dims[l + 1];
-      pa.cols[pa.n_t] = 2 * t->dims[l];
-      ++pa.n_t;
-    }
-    pa.ticket = t->ticket;
-    int64_t blocks = (pa.zero_words + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 64) blocks = 64;
-    hipLaunchKernelGGL(train_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pa);
-  } else {
-    gigl_fill_u32(st, t->zero_base, 0u, (int64_t)(t->zero_bytes / 4));
-  }
+  if (!fz) gigl_fill_u32(st, t->zero_base, 0u, (int64_t)(t->zero_bytes / 4));  // (fused: train_stage_kernel cleared it)
   const int32_t* n_local = p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr;
   // ---- forward
   for (int l = 0; l < L; ++l) {
@@ -1244,9 +1226,16 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
     hipLaunchKernelGGL(ce_roots_kernel, dim3((unsigned)((t->b + 3) / 4)), dim3(256), 0, st, (const float*)t->h[L - 1], width,
                        (const int32_t*)p->un.root_local, (const int64_t*)t->labels_buf, (const int32_t*)t->n_valid_buf, t->b,
                        (const int32_t*)p->un.meta, t->dh[L - 1], t->loss_rows);
-    hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, st, (const float*)t->loss_rows, t->b,
+    hipStream_t ls = st;
+    if (fz && t->aux) {  // fork
+      GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_fork, st));
+      GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(t->aux, t->ev_fork, 0));
+      ls = t->aux;
+    }
+    hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(1024), 0, ls, (const float*)t->loss_rows, t->b,
                        (const int32_t*)t->n_valid_buf, t->loss, t->n_valid_buf + 1, (const int32_t*)p->un.meta,
                        t->n_valid_buf + 2, fz ? (float* const*)t->loss_slot : (float* const*)nullptr);
+    if (ls != st) GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_join, ls));
   }
   // ---- backward
   for (int l = L - 1; l >= 0; --l) {
@@ -1311,6 +1300,7 @@ int32_t train_enqueue_layers(gigl_sage_train_plan* t, int k) {
   ap.beta2 = t->beta2;
   ap.eps = t->eps;
   ap.wd = t->wd;
+  if (fz && t->aux) GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, t->ev_join, 0));  // join: Adam reads the step counter / halt flag
   hipLaunchKernelGGL(adam_kernel, fz ? dim3(208, (unsigned)ap.count) : dim3(256), dim3(256), 0, st, ap,
                      (const int32_t*)(t->n_valid_buf + 1), (const int32_t*)p->un.meta, (const int32_t*)(t->n_valid_buf + 2));
   GIGL_HIP_CHECK(ctx, hipGetLastError());
@@ -1397,6 +1387,12 @@ int32_t gigl_sage_train_plan_destroy(gigl_sage_train_plan* t) {
   }
   for (int k = 0; k < TRAIN_WS + 1; ++k)
     if (t->ev_layers[k]) hipEventDestroy(t->ev_layers[k]);
+  if (t->aux) {
+    hipStreamSynchronize(t->aux);
+    hipStreamDestroy(t->aux);
+  }
+  if (t->ev_fork) hipEventDestroy(t->ev_fork);
+  if (t->ev_join) hipEventDestroy(t->ev_join);
   for (void* q : t->owned) hipFree(q);
   for (int k = 0; k < TRAIN_WS; ++k)
     if (t->side[k]) gigl_ctx_destroy(t->side[k]);
@@ -1506,6 +1502,14 @@ int32_t gigl_sage_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat*
   if (ok && hipMemset(t->n_valid_buf, 0, 16) != hipSuccess) ok = false;
   t->fused_small = getenv("GIGL_TRAIN_PLAN_UNFUSED") == nullptr;
   if (t->fused_small && ok) {
+    // (measured, round 6: the sum on a BRANCH of the captured layers — forked after the loss rows, joined before Adam — took
+    // the step from 0.201 to 0.263 ms: a graph with a second branch is replayed through two queues with a barrier packet per
+    // edge.  GIGL_TRAIN_LOSS_BRANCH=1 turns it on for the A/B; off by default)
+    if (getenv("GIGL_TRAIN_LOSS_BRANCH") != nullptr &&
+        (hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking) != hipSuccess ||
+         hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming) != hipSuccess))
+      t->aux = nullptr;
     t->ticket = (int32_t*)alloc(16);
     t->loss_slot = (float**)alloc(16);
     ok = t->ticket && t->loss_slot && hipMemset(t->ticket, 0, 16) == hipSuccess && hipMemset(t->loss_slot, 0, 16) == hipSuccess;
@@ -1567,8 +1571,23 @@ int32_t gigl_sage_train_plan_step2(gigl_sage_train_plan* t, const uint32_t* root
   // the step's inputs go into the static buffers the (captured) launches read: labels, the number of real roots (a
   // 32-bit fill: no host memory involved, ordered on the stream)
   if (t->fused_small) {
-    hipLaunchKernelGGL(train_stage_kernel, dim3((unsigned)((n_valid + 255) / 256)), dim3(256), 0, st, labels, n_valid, t->labels_buf,
-                       t->n_valid_buf, t->loss_slot, loss_out);
+    TrainPrep pa{};
+    pa.zero = (uint32_t*)t->zero_base;
+    pa.zero_words = (int64_t)(t->zero_bytes / 4);
+    for (int l = 1; l < t->L; ++l) {
+      pa.w[pa.n_t] = t->w[l];
+      pa.wt[pa.n_t] = t->wt_l[l];
+      pa.rows[pa.n_t] = t->dims[l + 1];
+      pa.cols[pa.n_t] = 2 * t->dims[l];
+      ++pa.n_t;
+    }
+    pa.ticket = t->ticket;
+    int64_t blocks = (pa.zero_words + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 64) blocks = 64;
+    // (the layers of the previous step read labels_buf / the cleared block: this launch is behind them on the stream)
+    hipLaunchKernelGGL(train_stage_kernel, dim3((unsigned)blocks), dim3(256), 0, st, labels, n_valid, t->labels_buf, t->n_valid_buf,
+                       t->loss_slot, loss_out, pa);
     GIGL_HIP_CHECK(ctx, hipGetLastError());
   } else {
     GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->labels_buf, labels, (size_t)n_valid * 8, hipMemcpyDeviceToDevice, st));
