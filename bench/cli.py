@@ -66,7 +66,7 @@ def main():
                          "run in a child process)")
     ap.add_argument("--no-sharded-sub", action="store_true",
                     help="N > 1 headline: skip the `sharded` sub-record (the mag240m-sharded workload at this N)")
-    ap.add_argument("--graph-priority", type=str, default="off", choices=["off", "high", "same"],
+    ap.add_argument("--graph-priority", type=str, default="off", choices=["off", "high", "same", "shared", "shared-high"],
                     help="products-family workloads: issue every call's graph part (sample + union) on a stream of its own — "
                          "high: of a higher priority than the layers' stream (gigl_sage_plan_set_graph_stream), same: equal "
                          "priority (A/B of the split alone)")

@@ -76,9 +76,16 @@ def run_products(args, rank, world, local_rank):
         plans.append(model.make_plan(engines[s], B, fanouts, groups=G))
         if not args.no_graph:
             plans[s].use_graph(True)  # the call's launches replayed as one hipGraph launch
-            if getattr(args, "graph_priority", "off") != "off":
+            gp_ = getattr(args, "graph_priority", "off")
+            if gp_ in ("high", "same"):
                 # the latency-bound graph part of a call ahead of the other calls' bandwidth-bound layers
-                plans[s].set_graph_stream(torch.cuda.Stream(device=dev, priority=-1 if args.graph_priority == "high" else 0))
+                plans[s].set_graph_stream(torch.cuda.Stream(device=dev, priority=-1 if gp_ == "high" else 0))
+            elif gp_ in ("shared", "shared-high"):
+                # ONE stream for every plan's graph part: a pipeline — the integer halves one after the other on it, the float
+                # halves on the plans' own streams (always one latency-bound kernel beside S bandwidth-bound ones)
+                if s == 0:
+                    shared_graph_stream = torch.cuda.Stream(device=dev, priority=-1 if gp_ == "shared-high" else 0)
+                plans[s].set_graph_stream(shared_graph_stream)
         outs.append(torch.empty((G * B, out_dim), dtype=torch.float32, device=dev))
     # projected input: the first layer's projection of the WHOLE table, once (timed: charged to the steps below)
     projected = args.project_input == "on" or (args.project_input == "auto" and model.projected_input_pays(eng0))
