@@ -4348,6 +4348,18 @@ int32_t gigl_linear_weight_grad_parts(gigl_ctx* ctx, const float* dy, const floa
   return GIGL_OK;
 }
 
+// dw += the chunks' partial sums (in chunk order), likewise db: the reduction launch of gigl_linear_weight_grad on its own —
+// what a plan that keeps partial sums runs when somebody asks for the gradient itself (gigl_nablp_train_plan_grads)
+int32_t gigl_linear_weight_grad_sum(gigl_ctx* ctx, const float* part, const float* partb, const int32_t* m_dev, int32_t n, int32_t k,
+                                    int32_t rows_per_chunk, float* dw, float* db) {
+  GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int64_t nk = (int64_t)n * k;
+  hipLaunchKernelGGL(linear_weight_grad_reduce_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, part, partb,
+                     m_dev, nk, n, dw, db, rows_per_chunk);
+  GIGL_HIP_CHECK(ctx, hipGetLastError());
+  return GIGL_OK;
+}
+
 int32_t gigl_linear_weight_grad(gigl_ctx* ctx, const float* dy, const float* a, const float* relu_y, const int32_t* m_dev,
                                 int64_t m_cap, int32_t n, int32_t k, float* dw, float* db) {
   if (!ctx) return GIGL_E_INVALID_ARG;

@@ -122,6 +122,8 @@ void* gigl_arena_alloc(gigl_ctx* ctx, int64_t bytes);
 int32_t gigl_graph_compute_maxdeg(gigl_ctx* ctx, gigl_graph* g);
 // the weight gradient's per-chunk partial sums without the reduction launch (agg.hip): see gigl_linear_weight_grad_parts
 int64_t gigl_linear_weight_grad_chunks(int64_t m_cap, int32_t n, int32_t k, int32_t* rows_per_chunk);
+int32_t gigl_linear_weight_grad_sum(gigl_ctx* ctx, const float* part, const float* partb, const int32_t* m_dev, int32_t n, int32_t k,
+                                    int32_t rows_per_chunk, float* dw, float* db);
 int32_t gigl_linear_weight_grad_parts(gigl_ctx* ctx, const float* dy, const float* a, const float* relu_y, const int32_t* m_dev,
                                       int64_t m_cap, int32_t n, int32_t k, float* part, float* partb);
 // union build with the plan-internal leaf-global option (union.hip)

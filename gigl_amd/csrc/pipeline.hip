@@ -1640,6 +1640,10 @@ struct gigl_nablp_train_plan {
     float* dh[GIGL_MAX_HOPS] = {nullptr};
     float* gw[GIGL_MAX_HOPS] = {nullptr};
     float* gb[GIGL_MAX_HOPS] = {nullptr};
+    // (round 6) the weight gradients' per-chunk partial sums: added up inside the Adam kernel, no reduce launch per layer
+    float* part_w[GIGL_MAX_HOPS] = {nullptr};
+    float* part_b[GIGL_MAX_HOPS] = {nullptr};
+    int32_t part_rc[GIGL_MAX_HOPS] = {0};
     float* emb = nullptr;   // [b][d_out]: the roots' embeddings (normalised when the model says so)
     float* inv = nullptr;   // [b]: 1 / max(|h_r|, 1e-12) (1 without normalisation; 0: no such root)
     float* demb = nullptr;  // [b][d_out]
@@ -1652,6 +1656,8 @@ struct gigl_nablp_train_plan {
   float* mom[4 * GIGL_MAX_HOPS] = {nullptr};
   float* da = nullptr;
   float* wt = nullptr;
+  bool fused_small = false;   // (SAGE encoder, GIGL_TRAIN_PLAN_UNFUSED unset) partial sums inside Adam, W^T once per step
+  float* wt_l[GIGL_MAX_HOPS] = {nullptr};
   bool bwd_gather = false;    // (as in gigl_sage_train_plan)
   void* zero_base = nullptr;  // both encodes' gw | gb | dh: cleared at the start of every step
   size_t zero_bytes = 0;
@@ -1959,9 +1965,30 @@ struct AdamPack2 {
   float* m[2 * GIGL_MAX_HOPS];
   float* v[2 * GIGL_MAX_HOPS];
   int64_t n[2 * GIGL_MAX_HOPS];
+  // (round 6) part1 / part2 != NULL: the two encodes' gradients as per-chunk partial sums ([chunks][n], the chunks below
+  // ceil(*rows / rc) real), each added up in chunk order, then the two totals — the order of reduce + reduce + add
+  const float* part1[2 * GIGL_MAX_HOPS];
+  const float* part2[2 * GIGL_MAX_HOPS];
+  const int32_t* rows1[2 * GIGL_MAX_HOPS];
+  const int32_t* rows2[2 * GIGL_MAX_HOPS];
+  int32_t rc1[2 * GIGL_MAX_HOPS], rc2[2 * GIGL_MAX_HOPS];
   int32_t count;
   float lr, beta1, beta2, eps, wd;
 };
+
+__device__ __forceinline__ float chunk_sum(const float* __restrict__ part, int chunks, int64_t n, int64_t i) {
+  float s = 0.f;
+  int c = 0;
+  for (; c + 15 < chunks; c += 16) {
+    float pv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) pv[q] = part[(int64_t)(c + q) * n + i];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += pv[q];
+  }
+  for (; c < chunks; ++c) s += part[(int64_t)c * n + i];
+  return s;
+}
 
 __global__ __launch_bounds__(256) void lp_adam_kernel(AdamPack2 a, const int32_t* __restrict__ step_dev,
                                                       const int32_t* __restrict__ meta_a, const int32_t* __restrict__ meta_b) {
@@ -1969,13 +1996,18 @@ __global__ __launch_bounds__(256) void lp_adam_kernel(AdamPack2 a, const int32_t
   const double t = (double)*step_dev;
   const float bc1 = (float)(1.0 - pow((double)a.beta1, t)), bc2s = (float)sqrt(1.0 - pow((double)a.beta2, t));
   const float step_size = a.lr / bc1;
-  for (int k = 0; k < a.count; ++k) {
+  const int k_lo = gridDim.y > 1 ? (int)blockIdx.y : 0, k_hi = gridDim.y > 1 ? (int)blockIdx.y + 1 : a.count;  // (a grid slice per tensor)
+  for (int k = k_lo; k < k_hi && k < a.count; ++k) {
     float* p = a.p[k];
     float* m = a.m[k];
     float* v = a.v[k];
+    const int ch1 = a.part1[k] ? (*a.rows1[k] + a.rc1[k] - 1) / a.rc1[k] : 0;
+    const int ch2 = a.part2[k] ? (*a.rows2[k] + a.rc2[k] - 1) / a.rc2[k] : 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += (int64_t)gridDim.x * blockDim.x) {
       const float w = p[i];
-      const float gr = (a.g1[k][i] + (a.g2[k] ? a.g2[k][i] : 0.f)) + a.wd * w;
+      const float ga = a.part1[k] ? chunk_sum(a.part1[k], ch1, a.n[k], i) : a.g1[k][i];
+      const float gb_ = a.part2[k] ? chunk_sum(a.part2[k], ch2, a.n[k], i) : (a.g2[k] ? a.g2[k][i] : 0.f);
+      const float gr = (ga + gb_) + a.wd * w;
       const float mm = m[i] + (gr - m[i]) * (1.f - a.beta1);
       const float vv = v[i] * a.beta2 + (1.f - a.beta2) * gr * gr;
       m[i] = mm;
@@ -2024,8 +2056,12 @@ int32_t lp_backward(gigl_nablp_train_plan* t, int which) {
     const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
     const int d = t->dims[l], n_out = t->dims[l + 1];
     const bool act = l < L - 1 || t->act_last;
-    rc = gigl_linear_weight_grad(ctx, e.dh[l], e.a[l], act ? e.h[l] : nullptr, n_rows, e.rows_cap[l], n_out, 2 * d, e.gw[l],
-                                 t->bias[l] ? e.gb[l] : nullptr);
+    if (t->fused_small)
+      rc = gigl_linear_weight_grad_parts(ctx, e.dh[l], e.a[l], act ? e.h[l] : nullptr, n_rows, e.rows_cap[l], n_out, 2 * d,
+                                         e.part_w[l], t->bias[l] ? e.part_b[l] : nullptr);
+    else
+      rc = gigl_linear_weight_grad(ctx, e.dh[l], e.a[l], act ? e.h[l] : nullptr, n_rows, e.rows_cap[l], n_out, 2 * d, e.gw[l],
+                                   t->bias[l] ? e.gb[l] : nullptr);
     if (rc != GIGL_OK) return rc;
     if (l == 0) break;
     if (act) {
@@ -2033,11 +2069,14 @@ int32_t lp_backward(gigl_nablp_train_plan* t, int which) {
       if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, e.dh[l], (const float*)e.h[l], n_rows, n_out);
     }
-    {
+    const float* wt = t->wt;
+    if (t->fused_small) {
+      wt = t->wt_l[l];  // (transposed ONCE per step, at the start of the layers: both encodes read it)
+    } else {
       int64_t blocks = ((int64_t)n_out * 2 * d + 255) / 256;
       hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)t->w[l], n_out, 2 * d, t->wt);
     }
-    rc = gigl_linear(ctx, e.dh[l], t->wt, nullptr, n_rows, e.rows_cap[l], n_out, 2 * d, 0, t->da);
+    rc = gigl_linear(ctx, e.dh[l], wt, nullptr, n_rows, e.rows_cap[l], n_out, 2 * d, 0, t->da);
     if (rc != GIGL_OK) return rc;
     if (t->bwd_gather)
       rc = gigl_gather_mean_backward_lists(ctx, t->da, d, p->un.rowptr, p->un.rowend, n_rows,
@@ -2084,6 +2123,11 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
     rc = gat_lp_begin(t);
     if (rc != GIGL_OK) return rc;
   }
+  for (int l = 1; l < L && t->fused_small; ++l) {  // W_l^T for the input gradients of both encodes
+    const int64_t nw = (int64_t)t->dims[l + 1] * 2 * t->dims[l];
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)t->w[l],
+                       t->dims[l + 1], 2 * t->dims[l], t->wt_l[l]);
+  }
   for (int k = 0; k < 2; ++k) {
     rc = t->kind == 1 ? gat_lp_forward(t, k) : lp_forward(t, k);
     if (rc != GIGL_OK) return rc;
@@ -2128,9 +2172,18 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
   if (t->kind == 1) return gat_lp_finish(t);
   AdamPack2 ap{};
   for (int l = 0; l < L; ++l) {
+    const bool fz = t->fused_small;
+    const int32_t* r1 = pm->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
+    const int32_t* r2 = pr->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
     ap.p[ap.count] = t->w[l];
     ap.g1[ap.count] = t->enc[0].gw[l];
     ap.g2[ap.count] = t->enc[1].gw[l];
+    ap.part1[ap.count] = fz ? t->enc[0].part_w[l] : nullptr;
+    ap.part2[ap.count] = fz ? t->enc[1].part_w[l] : nullptr;
+    ap.rows1[ap.count] = r1;
+    ap.rows2[ap.count] = r2;
+    ap.rc1[ap.count] = t->enc[0].part_rc[l];
+    ap.rc2[ap.count] = t->enc[1].part_rc[l];
     ap.m[ap.count] = t->mom[4 * l];
     ap.v[ap.count] = t->mom[4 * l + 1];
     ap.n[ap.count++] = (int64_t)t->dims[l + 1] * 2 * t->dims[l];
@@ -2138,6 +2191,12 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
       ap.p[ap.count] = t->bias[l];
       ap.g1[ap.count] = t->enc[0].gb[l];
       ap.g2[ap.count] = t->enc[1].gb[l];
+      ap.part1[ap.count] = fz ? t->enc[0].part_b[l] : nullptr;
+      ap.part2[ap.count] = fz ? t->enc[1].part_b[l] : nullptr;
+      ap.rows1[ap.count] = r1;
+      ap.rows2[ap.count] = r2;
+      ap.rc1[ap.count] = t->enc[0].part_rc[l];
+      ap.rc2[ap.count] = t->enc[1].part_rc[l];
       ap.m[ap.count] = t->mom[4 * l + 2];
       ap.v[ap.count] = t->mom[4 * l + 3];
       ap.n[ap.count++] = t->dims[l + 1];
@@ -2148,7 +2207,8 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
   ap.beta2 = t->beta2;
   ap.eps = t->eps;
   ap.wd = t->wd;
-  hipLaunchKernelGGL(lp_adam_kernel, dim3(256), dim3(256), 0, st, ap, (const int32_t*)(t->consts + 2),
+  hipLaunchKernelGGL(lp_adam_kernel, t->fused_small ? dim3(208, (unsigned)ap.count) : dim3(256), dim3(256), 0, st, ap,
+                     (const int32_t*)(t->consts + 2),
                      (const int32_t*)pm->un.meta, (const int32_t*)pr->un.meta);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
@@ -2318,6 +2378,19 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
   t->loss = (float*)alloc(64);
   ok = ok && t->zero_base && t->da && t->wt && t->rq && t->cand && t->cand_t && t->scores && t->dscores && t->d_rq &&
        t->d_cand && t->qid && t->cid && t->valid && t->pos_cnt && t->consts && t->row_lse && t->row_loss && t->loss;
+  t->fused_small = getenv("GIGL_TRAIN_PLAN_UNFUSED") == nullptr;
+  for (int l = 0; l < hops && ok && t->fused_small; ++l) {
+    const int n_out = dims[l + 1], k2 = 2 * dims[l];
+    for (int k = 0; k < 2 && ok; ++k) {
+      gigl_nablp_train_plan::Enc& e = t->enc[k];
+      const int64_t chunks = gigl_linear_weight_grad_chunks(e.rows_cap[l], n_out, k2, &e.part_rc[l]);
+      e.part_w[l] = (float*)alloc((size_t)chunks * n_out * k2 * 4);
+      e.part_b[l] = (float*)alloc((size_t)chunks * n_out * 4);
+      ok = e.part_w[l] && e.part_b[l];
+    }
+    if (l >= 1) t->wt_l[l] = (float*)alloc((size_t)n_out * k2 * 4);
+    ok = ok && (l == 0 || t->wt_l[l]);
+  }
   if (ok) {
     const int32_t c[16] = {(int32_t)Q, (int32_t)Cn, 0 /* Adam's step counter */, 0};
     if (hipMemcpy(t->consts, c, sizeof(c), hipMemcpyHostToDevice) != hipSuccess || hipMemset(t->loss, 0, 64) != hipSuccess)
@@ -2507,6 +2580,18 @@ int32_t gigl_nablp_train_plan_grads(gigl_nablp_train_plan* t, int32_t layer, flo
   GIGL_REQUIRE(ctx, t->kind == 0 && layer >= 0 && layer < t->L && gw, "bad plan / layer / null output");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int64_t nw = (int64_t)t->dims[layer + 1] * 2 * t->dims[layer];
+  if (t->fused_small) {  // the step kept partial sums only: add them up now, into the (cleared) gradient buffers
+    for (int k = 0; k < 2; ++k) {
+      gigl_nablp_train_plan::Enc& e = t->enc[k];
+      gigl_fill_u32(ctx->stream, e.gw[layer], 0u, nw);
+      if (t->bias[layer]) gigl_fill_u32(ctx->stream, e.gb[layer], 0u, (int64_t)t->dims[layer + 1]);
+      const int32_t rc = gigl_linear_weight_grad_sum(ctx, e.part_w[layer], t->bias[layer] ? e.part_b[layer] : nullptr,
+                                                     e.base->un.meta + GIGL_META_LEVEL0 + (t->L - 1 - layer), t->dims[layer + 1],
+                                                     2 * t->dims[layer], e.part_rc[layer], e.gw[layer],
+                                                     t->bias[layer] ? e.gb[layer] : nullptr);
+      if (rc != GIGL_OK) return rc;
+    }
+  }
   hipLaunchKernelGGL(lp_add2_kernel, dim3(256), dim3(256), 0, ctx->stream, (const float*)t->enc[0].gw[layer],
                      (const float*)t->enc[1].gw[layer], nw, gw);
   if (gb && t->bias[layer])
