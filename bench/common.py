@@ -42,9 +42,10 @@ MFMA_16BIT_PEAK_TF = 2500.0
 # library timer id -> name prefixes of the device functions it brackets (as rocprofv3 prints them, scripts/pmc_summary.py)
 PMC_KERNELS = {
     "expand": ["plan_rows_kernel", "expand_rows_kernel"],
-    # (round 5, fused layers: the last layer is sage_fused_out_kernel, both projections linear_fused2_kernel)
+    # (fused layers: the last layer is sage_fused_out_kernel, both projections linear_fused2x_kernel — round 5: linear_fused2_kernel)
     "gather_mean": ["gather_mean_kernel", "sage_fused_out_kernel"],
-    "linear": ["linear_split_kernel", "linear_lds_kernel", "linear_mfma_kernel", "linear_fused2_kernel"],
+    "linear": ["linear_split_kernel", "linear_lds_kernel", "linear_mfma_kernel", "linear_fused2_kernel", "linear_fused2w_kernel",
+               "linear_fused2x_kernel"],
     # (the one-call plan's two-hop union build, union.hip "LG2"; the generic build's kernels have other names)
     # (round 4: the LDS-staged build "LG3" — lg3_* — replaced lg2_insert / extras / count / assign / fill)
     "union_insert": ["lg2_init_kernel", "lg2_insert_kernel", "lg2_extras_kernel", "lg3_init_kernel", "lg3_dedup_kernel"],

@@ -203,7 +203,7 @@ def run_products(args, rank, world, local_rank):
     # the dominant group = the one that costs the most WHERE THE NUMBER IS TAKEN: the largest HIP-event time under the timed
     # regime (S streams in flight; the single-stream ranking is kept as `dominant_alone`).  A group is every kernel of one
     # stage of the step: `gather_mean` = the first layer's segmented reduce + the fused last-layer reduction
-    # (gather_mean_kernel + sage_fused_out_kernel), `linear` = the projection(s) (linear_fused2_kernel: the single kernel with
+    # (gather_mean_kernel + sage_fused_out_kernel), `linear` = the projection(s) (linear_fused2x_kernel: the single kernel with
     # the most time in the rocprofv3 summary; its own fractions are groups.linear)
     dominant_alone = dominant
     dominant = max(prof_ovl, key=lambda k: prof_ovl[k][0])
@@ -278,6 +278,8 @@ def run_products(args, rank, world, local_rank):
     # both projections in one kernel (gigl_sage_plan_fused_layers): 2 x 96 floats of [W_l h | W_r h] (two K-split planes)
     # leave the first projection per row instead of the hidden row, the last layer is one reduction over them
     fused_layers = (not projected) and hasattr(plans[0], "fused_layers") and plans[0].fused_layers()
+    # (round 6, linear_fused2x_kernel: ONE plane of whole p rows — fused_planes() == 1)
+    p_planes = plans[0].fused_planes() if fused_layers and hasattr(plans[0], "fused_planes") else 2
 
     def alg_of(st):
         """st: a STATS vector -> (bytes per kernel group, projection flops)"""
@@ -294,13 +296,13 @@ def run_products(args, rank, world, local_rank):
             if fused_layers and l == 1:
                 # the last layer over p rows: per edge the W_l half (48 floats) of both planes, per root the W_r half of
                 # both planes + the output row; no projection
-                ab["gather_mean"] += agg_l * (4 + 2 * 48 * 4) + rows_l * (8 + 2 * 48 * 4 + out_dim * 4)
+                ab["gather_mean"] += agg_l * (4 + p_planes * 48 * 4) + rows_l * (8 + p_planes * 48 * 4 + out_dim * 4)
                 continue
             if fused_layers and l == 0:
                 two_src = True
                 ab["gather_mean"] += agg_l * (4 + dims[l] * s_in) + rows_l * (8 + dims[l] * 4)
                 # operand rows in, two planes of 96 floats out; + the second product's flops (256 -> 96, three products)
-                ab["linear"] += rows_l * (2 * dims[l] + 2 * 96) * 4 + dout * 2 * dims[l] * 4 + 96 * dout * 4
+                ab["linear"] += rows_l * (2 * dims[l] + p_planes * 96) * 4 + dout * 2 * dims[l] * 4 + 96 * dout * 4
                 fl += 2.0 * rows_l * (2 * dims[l] * dout + dout * 96)
                 alg_of.issued += 2.0 * rows_l * (2 * dims[l] * dout + dout * 96) * 3
                 continue
@@ -455,7 +457,7 @@ def run_products(args, rank, world, local_rank):
                 "dominant_from": "largest HIP-event time per kernel group under the TIMED regime (untimed probe with all "
                                  "timers on, the S streams in flight); dominant_alone = the single-stream ranking; a group = "
                                  "all kernels of one stage (gather_mean: gather_mean_kernel + sage_fused_out_kernel; linear: "
-                                 "linear_fused2_kernel, the largest SINGLE kernel of the rocprofv3 summary — its fractions "
+                                 "linear_fused2x_kernel, the largest SINGLE kernel of the rocprofv3 summary — its fractions "
                                  "are groups.linear); `groups` lists every group alone and overlapped",
                 "avg_launch_us": round(avg_launch_ms * 1e3, 2),
                 "alg_bytes_per_launch": round(bytes_per_launch), "launches": int(dom_launches), "note": note,

@@ -1331,7 +1331,11 @@ constexpr int F2_N2 = 96;     // padded width of a p row: [W_l h (out, padded to
 constexpr int F2_HID = 256;   // hidden width the kernel is built for
 constexpr int F2_W2LD = 72;   // halves per staged W2 row (64 + 8 of padding)
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void linear_fused2_kernel(
+// PD = chunks of operands in flight (registers): a chunk's MFMAs last ~0.3 us, a load from HBM under three streams
+// 1-2 us — with ONE chunk in flight (round 5) a workgroup's 7 chunks were 7 round trips one after the other.  WPE = waves
+// per SIMD the register budget is cut for (3: 170 registers, 2: 256).
+template <int PD, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void linear_fused2_kernel(
     const float* __restrict__ a, const float* __restrict__ w, const float* __restrict__ bias,
     const int32_t* __restrict__ m_dev, int K, float* __restrict__ y2, int64_t plane_stride, int a_tiled,
     const float* __restrict__ self_src, const uint32_t* __restrict__ self_ids, int d_mean, int self_ld,
@@ -1369,14 +1373,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
   const int lr = tid >> 3, lc = tid & 7;
-  float4_t ga[4], gw[2 * NJ];
+  float4_t gas[PD][4], gws[PD][2 * NJ];
   const float* self_row[4] = {nullptr, nullptr, nullptr, nullptr};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = m0b + lr + 32 * i;
     if (row < M) self_row[i] = self_src + (int64_t)(self_ids ? self_ids[row] : (uint32_t)row) * self_ld;
   }
-  auto gload = [&](int k0) {
+  auto gload = [&](int k0, float4_t (&ga)[4], float4_t (&gw)[2 * NJ]) {
     const int kk = k0 + lc * 4;
     const float* at = a + ((int64_t)tm * a_tiled + (k0 >> 5)) * 4096 + lc * 4;
 #pragma unroll
@@ -1392,8 +1396,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
       gw[i] = (row < N && kk < K) ? *reinterpret_cast<const float4_t*>(w + (int64_t)row * K + kk) : zero4;
     }
   };
-  gload(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+  for (int s = 0; s < PD; ++s)
+    if (s * BK < K) gload(s * BK, gas[s], gws[s]);
+  auto chunk = [&](int k0, float4_t (&ga)[4], float4_t (&gw)[2 * NJ]) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1406,7 +1412,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
       hsplit_store(gw[i], &s_w[0][o], &s_w[1][o], hs_w);
     }
     __syncthreads();
-    if (k0 + BK < K) gload(k0 + BK);
+    if (k0 + PD * BK < K) gload(k0 + PD * BK, ga, gw);  // (the stage just emptied: PD chunks ahead)
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 16) {
       if (k0 + ks >= K) break;
@@ -1428,6 +1434,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
         for (int j = 0; j < 4; ++j)
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j][HW[t]], fa[HA[t]], acc[j], 0, 0, 0);
     }
+  };
+  for (int k0 = 0; k0 < K; k0 += PD * BK) {
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+      if (k0 + s * BK < K) chunk(k0 + s * BK, gas[s], gws[s]);
   }
   // ---- second product: p[row][0:96] (partial over this tile's 128 hidden columns) = relu(h) . W2p[:, 128 tn ..]^T
   const float s_h = f2_scale[0], o2 = f2_scale[2];
@@ -1488,6 +1499,473 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void l
       const int row = m0b + wv * 32 + 8 * (v >> 2) + 4 * g + (v & 3);
       if (row < M) yp[(int64_t)row * F2_N2 + n * 32 + r] = acc2[n][v] * o2;
     }
+}
+
+// ---- round 6: the same two products with the A operand straight from global memory
+// What the round-5 kernel waited on (SQ counters, profiles/r06h_sq_products.json: matrix pipe 30 %, LDS 21-36 %, vector ALU
+// ~40 % busy, 2.7 waves per SIMD resident, each waiting ~80 % of its cycles; deeper register prefetch at two waves per SIMD
+// was slower, profiles/r06v_*): the chain per 32-k chunk — operands land, EVERY thread splits 16 A + 16 W floats into LDS,
+// barrier, fragments back out of LDS, MFMAs, barrier — with three workgroups per CU to overlap it.  But the four waves split
+// the ROWS, so a wave's A rows are read by that wave only: they need no LDS.  Here
+//   * lane (r, g) of wave wv loads its own row's 16 floats of the chunk (four 16-byte loads: floats 8 q + 4 g .. + 4, so one
+//     instruction reads 32 contiguous bytes per row) and splits them in registers into the two MFMA steps' fragments;
+//   * W1's fp16 planes are laid out ONCE per run (fused2_images_kernel) as the chunk's 16-KB LDS image — swizzle included, k
+//     inside a chunk permuted to the order the lanes hold it: position 16 s + 8 g + e <- k = 16 s + 8 (e / 4) + 4 g + e % 4,
+//     the permutation the accumulator layout imposes on the second product anyway — so a chunk of W is four 16-byte copies
+//     per thread, no vector ALU work, into one of TWO image buffers: ONE barrier per chunk;
+//   * W2's planes likewise, 32 hidden columns (= one accumulator block) per round, ping-ponging between the two buffers.
+// Per chunk and workgroup: 16 KB of LDS writes + 64 KB of reads (was 32 + 80), half the conversions, half the barriers.
+constexpr int F2_IMG1 = 2 * 128 * 32;  // halves per W1 chunk image: [plane][128 hidden columns][32 k, swizzled]
+constexpr int F2_IMG2 = 2 * F2_N2 * 32;  // halves per W2 round image: [plane][96 p columns][32 hidden, swizzled]
+__device__ __forceinline__ int f2_perm(int kpos) {  // k (inside a 32-block) held at fragment position kpos
+  return 16 * (kpos >> 4) + 8 * ((kpos >> 2) & 1) + 4 * ((kpos >> 3) & 1) + (kpos & 3);
+}
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// DBG: `ablate` switches parts of the kernel off (wrong rows; timing experiments only — GIGL_F2_ABLATE, bits: 1 no A loads,
+// 2 no W image copies, 4 one MFMA of three in the first product, 8 no second product, 16 no output stores, 32 no barriers)
+template <int AD, int WPE, bool DBG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void linear_fused2w_kernel(
+    const float* __restrict__ a, const float* __restrict__ bias, const int32_t* __restrict__ m_dev, int K,
+    float* __restrict__ y2, int64_t plane_stride, int a_tiled, const float* __restrict__ self_src,
+    const uint32_t* __restrict__ self_ids, int d_mean, int self_ld, const float* __restrict__ hs_scale,
+    const float* __restrict__ f2_scale, const _Float16* __restrict__ w1img, const _Float16* __restrict__ w2img, int ablate) {
+  const int ab = DBG ? ablate : 0;
+  auto barrier = [&]() {
+    if (!(ab & 32)) __syncthreads();
+  };
+  __shared__ __attribute__((aligned(16))) short s_buf[2][F2_IMG1];
+  const int M = *m_dev;
+  constexpr int tiles_n = 2;
+  const float hs_a = hs_scale[0], hs_o = hs_scale[2];
+  int tm, tn;
+  {  // (as linear_fused2_kernel: the two column tiles of a row tile back to back on one XCD)
+    const unsigned bid = blockIdx.x, span = 8u * (unsigned)tiles_n;
+    const unsigned full = (gridDim.x / span) * span;
+    if (bid < full) {
+      const unsigned grp = bid / span, in = bid % span;
+      tm = (int)(grp * 8u + (in & 7u));
+      tn = (int)(in >> 3);
+    } else {
+      tm = (int)(bid / (unsigned)tiles_n);
+      tn = (int)(bid % (unsigned)tiles_n);
+    }
+  }
+  const int m0b = tm * 128, n0b = tn * 128;
+  if (m0b >= M) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, g = lane >> 5;
+  const int nc = (K + 31) >> 5;
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  float16_t acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+  const int row = m0b + wv * 32 + r;
+  const bool valid = row < M;
+  const float* self_row = valid ? self_src + (int64_t)(self_ids ? self_ids[row] : (uint32_t)row) * self_ld : self_src;
+  const float* at = a + (int64_t)tm * a_tiled * 4096 + (wv * 32 + r) * 32 + 4 * g;
+  auto aload = [&](int c, float4_t (&ra)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = c * 32 + 8 * q + 4 * g;
+      const float* src = kk >= d_mean ? self_row + (kk - d_mean) : at + (int64_t)c * 4096 + 8 * q;
+      ra[q] = (valid && kk < K && !(ab & 1)) ? *reinterpret_cast<const float4_t*>(src) : zero4;
+    }
+  };
+  const u32x4_t* w1src = reinterpret_cast<const u32x4_t*>(w1img) + (int64_t)tn * nc * (F2_IMG1 / 8) + tid;
+  u32x4_t wr0, wr1, wr2, wr3;  // (named: as an array the compiler kept two of them in scratch memory)
+  auto wload = [&](int c) {
+    if (ab & 2) return;
+    const u32x4_t* src = w1src + (int64_t)c * (F2_IMG1 / 8);
+    wr0 = src[0];
+    wr1 = src[256];
+    wr2 = src[512];
+    wr3 = src[768];
+  };
+  auto wstore = [&](int b) {
+    if (ab & 2) return;
+    u32x4_t* dst = reinterpret_cast<u32x4_t*>(s_buf[b]) + tid;
+    dst[0] = wr0;
+    dst[256] = wr1;
+    dst[512] = wr2;
+    dst[768] = wr3;
+  };
+  float4_t ras[AD][4];
+  wload(0);
+#pragma unroll
+  for (int d = 0; d < AD; ++d)
+    if (d < nc) aload(d, ras[d]);
+  wstore(0);
+  if (nc > 1) wload(1);
+  const u32x4_t* w2src = reinterpret_cast<const u32x4_t*>(w2img) + (int64_t)tn * 4 * (F2_IMG2 / 8) + tid;
+  auto w2load = [&](int rd) {
+    const u32x4_t* src = w2src + (int64_t)rd * (F2_IMG2 / 8);
+    wr0 = src[0];
+    wr1 = src[256];
+    wr2 = src[512];
+  };
+  auto w2store = [&](int b) {
+    u32x4_t* dst = reinterpret_cast<u32x4_t*>(s_buf[b]) + tid;
+    dst[0] = wr0;
+    dst[256] = wr1;
+    dst[512] = wr2;
+  };
+  if (nc == 1) w2load(0);
+  barrier();
+  auto chunk = [&](int c, float4_t (&ra)[4]) {
+    half8v_t fa[2][2];  // [MFMA step][plane]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = ra[2 * s + (e >> 2)][e & 3] * hs_a;
+        const _Float16 a1 = (_Float16)x;
+        fa[s][0][e] = a1;
+        fa[s][1][e] = (_Float16)(x - (float)a1);
+      }
+    if (c + AD < nc) aload(c + AD, ra);
+    const short* sw = s_buf[c & 1];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (c * 32 + 16 * s >= K) break;
+      half8v_t fw[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          fw[j][p] = *reinterpret_cast<const half8v_t*>(&sw[p * (F2_IMG1 / 2) + split_lds_off(j * 32 + r, 16 * s + 8 * g)]);
+      constexpr int HA[3] = {1, 0, 0}, HW[3] = {0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if ((ab & 4) && t < 2) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j][HW[t]], fa[s][HA[t]], acc[j], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nc) {
+      wstore((c + 1) & 1);
+      if (c + 2 < nc) wload(c + 2);
+      else w2load(0);  // (the image registers are free from here on: the second product's first round)
+    }
+    barrier();
+  };
+  for (int c = 0; c < nc; c += AD) {
+#pragma unroll
+    for (int d = 0; d < AD; ++d)
+      if (c + d < nc) chunk(c + d, ras[d]);
+  }
+  // ---- second product, one accumulator block (32 hidden columns) per round
+  const float s_h = f2_scale[0], o2 = f2_scale[2];
+  float16_t acc2[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc2[n][v] = 0.f;
+  w2store(0);
+  w2load(1);
+  barrier();
+#pragma unroll
+  for (int rd = 0; rd < 4; ++rd) {
+    if (ab & 8) break;
+    const _Float16* sw2 = reinterpret_cast<const _Float16*>(s_buf[rd & 1]);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      half8v_t h1, h2;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4_t bq = bias ? *reinterpret_cast<const float4_t*>(bias + n0b + 32 * rd + 8 * (2 * hf + q) + 4 * g) : zero4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float x = acc[rd][8 * hf + 4 * q + t] * hs_o + bq[t];
+          x = (x > 0.f ? x : 0.f) * s_h;
+          const _Float16 a1 = (_Float16)x;
+          h1[4 * q + t] = a1;
+          h2[4 * q + t] = (_Float16)(x - (float)a1);
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const half8v_t w1 = *reinterpret_cast<const half8v_t*>(sw2 + split_lds_off(n * 32 + r, 16 * hf + 8 * g));
+        const half8v_t w2 = *reinterpret_cast<const half8v_t*>(sw2 + F2_IMG2 / 2 + split_lds_off(n * 32 + r, 16 * hf + 8 * g));
+        acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, w1, acc2[n], 0, 0, 0);
+        acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, w2, acc2[n], 0, 0, 0);
+        acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, w1, acc2[n], 0, 0, 0);
+      }
+    }
+    if (rd + 1 < 4) {
+      w2store((rd + 1) & 1);
+      if (rd + 2 < 4) w2load(rd + 2);
+      barrier();
+    }
+  }
+  float* yp = y2 + (int64_t)tn * plane_stride;
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int orow = m0b + wv * 32 + 8 * (v >> 2) + 4 * g + (v & 3);
+      if (orow < M && !(ab & 16)) yp[(int64_t)orow * F2_N2 + n * 32 + r] = acc2[n][v] * o2;
+    }
+}
+
+// ---- the whole hidden width in one workgroup (round 6, after the ablation runs of linear_fused2w_kernel,
+// profiles/r06x_fused2w_ablations.txt: the parts of the kernel ADD UP — A loads 1.5 us/step, output stores 0.7, second product
+// 0.9, W copies 0.5, first product's MFMAs 0.7, conversions + bookkeeping 1.3 — nothing hides behind anything else, and two
+// waves per SIMD run as fast as three).  So do less of each: a workgroup takes 128 rows x ALL 256 hidden columns (a wave: 32
+// rows x 256, 128 accumulator registers, two waves per SIMD): a row's A chunk is loaded and split ONCE (was once per column
+// tile: twice), the second product is not K-split any more — one p row of 384 B leaves instead of two partial ones, and
+// sage_fused_out_kernel reads one 192-byte piece per edge instead of two.  LDS: two buffers of two W1 chunk images (64 KB).
+// GLDS: the images go global -> LDS without passing registers (global_load_lds_dwordx4: a wave instruction lands 1 KB at a
+// wave-uniform LDS address + 16 lane — the images are copied in that order anyway): no staging registers, no ds_write pass.
+template <bool DBG, bool GLDS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void linear_fused2x_kernel(
+    const float* __restrict__ a, const float* __restrict__ bias, const int32_t* __restrict__ m_dev, int K,
+    float* __restrict__ y2, int a_tiled, const float* __restrict__ self_src, const uint32_t* __restrict__ self_ids,
+    int d_mean, int self_ld, const float* __restrict__ hs_scale, const float* __restrict__ f2_scale,
+    const _Float16* __restrict__ w1img, const _Float16* __restrict__ w2img, int ablate) {
+  __shared__ __attribute__((aligned(16))) short s_buf[2][2 * F2_IMG1];
+  const int ab = DBG ? ablate : 0;
+  const int M = *m_dev;
+  const float hs_a = hs_scale[0], hs_o = hs_scale[2];
+  const int tm = blockIdx.x, m0b = tm * 128;
+  if (m0b >= M) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int r = lane & 31, g = lane >> 5;
+  const int nc = (K + 31) >> 5;
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  float16_t acc[8];  // [hidden block of 32][.]
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+  const int row = m0b + wv * 32 + r;
+  const bool valid = row < M;
+  const float* self_row = valid ? self_src + (int64_t)(self_ids ? self_ids[row] : (uint32_t)row) * self_ld : self_src;
+  const float* at = a + (int64_t)tm * a_tiled * 4096 + (wv * 32 + r) * 32 + 4 * g;
+  float4_t ra[4];
+  auto aload = [&](int c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kk = c * 32 + 8 * q + 4 * g;
+      const float* src = kk >= d_mean ? self_row + (kk - d_mean) : at + (int64_t)c * 4096 + 8 * q;
+      ra[q] = (valid && kk < K && !(ab & 1)) ? *reinterpret_cast<const float4_t*>(src) : zero4;
+    }
+  };
+  constexpr int IMGU = F2_IMG1 / 8;  // 16-byte units per W1 chunk image
+  const u32x4_t* w1src = reinterpret_cast<const u32x4_t*>(w1img) + tid;
+  u32x4_t wr0, wr1, wr2, wr3, wr4, wr5, wr6, wr7;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto wload = [&](int c, int b) {  // (GLDS: straight into buffer b)
+    if (ab & 2) return;
+    const u32x4_t* s0 = w1src + (int64_t)c * IMGU;
+    const u32x4_t* s1 = w1src + (int64_t)(nc + c) * IMGU;
+    if constexpr (GLDS) {
+      short* dst = s_buf[b] + wv * 512;  // (this wave's 1-KB piece of each quarter image)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((gptr_t)(s0 + 256 * i), (lptr_t)(dst + 2048 * i), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(s1 + 256 * i), (lptr_t)(dst + F2_IMG1 + 2048 * i), 16, 0, 0);
+      }
+    } else {
+      wr0 = s0[0];
+      wr1 = s0[256];
+      wr2 = s0[512];
+      wr3 = s0[768];
+      wr4 = s1[0];
+      wr5 = s1[256];
+      wr6 = s1[512];
+      wr7 = s1[768];
+    }
+  };
+  auto wstore = [&](int b) {
+    if (GLDS || (ab & 2)) return;
+    u32x4_t* dst = reinterpret_cast<u32x4_t*>(s_buf[b]) + tid;
+    dst[0] = wr0;
+    dst[256] = wr1;
+    dst[512] = wr2;
+    dst[768] = wr3;
+    dst[IMGU] = wr4;
+    dst[IMGU + 256] = wr5;
+    dst[IMGU + 512] = wr6;
+    dst[IMGU + 768] = wr7;
+  };
+  const u32x4_t* w2src = reinterpret_cast<const u32x4_t*>(w2img) + tid;
+  auto w2load = [&](int rd, int b) {
+    const u32x4_t* src = w2src + (int64_t)rd * (F2_IMG2 / 8);
+    if constexpr (GLDS) {
+      short* dst = s_buf[b] + wv * 512;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(src + 256 * i), (lptr_t)(dst + 2048 * i), 16, 0, 0);
+    } else {
+      wr0 = src[0];
+      wr1 = src[256];
+      wr2 = src[512];
+    }
+  };
+  auto w2store = [&](int b) {
+    if (GLDS) return;
+    u32x4_t* dst = reinterpret_cast<u32x4_t*>(s_buf[b]) + tid;
+    dst[0] = wr0;
+    dst[256] = wr1;
+    dst[512] = wr2;
+  };
+  auto barrier = [&]() {
+    if (!(ab & 32)) __syncthreads();
+  };
+  // stage k (W1 chunks 0 .. nc - 1, then W2's rounds) lives in buffer k & 1; its image is fetched while stage k - 1 is worked on
+  wload(0, 0);
+  aload(0);
+  wstore(0);
+  if constexpr (!GLDS) {
+    if (nc > 1) wload(1, 1);
+    else w2load(0, 1);
+  }
+  barrier();
+  for (int c = 0; c < nc; ++c) {
+    half8v_t fa[2][2];  // [MFMA step][plane]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float x = ra[2 * s + (e >> 2)][e & 3] * hs_a;
+        const _Float16 a1 = (_Float16)x;
+        fa[s][0][e] = a1;
+        fa[s][1][e] = (_Float16)(x - (float)a1);
+      }
+    if (c + 1 < nc) aload(c + 1);
+    if constexpr (GLDS) {
+      if (c + 1 < nc) wload(c + 1, (c + 1) & 1);
+      else w2load(0, (c + 1) & 1);
+    }
+    const short* sw = s_buf[c & 1];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (c * 32 + 16 * s >= K) break;
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        half8v_t fw[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            fw[j][p] = *reinterpret_cast<const half8v_t*>(
+                &sw[tn * F2_IMG1 + p * (F2_IMG1 / 2) + split_lds_off(j * 32 + r, 16 * s + 8 * g)]);
+        constexpr int HA[3] = {1, 0, 0}, HW[3] = {0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          if ((ab & 4) && t < 2) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[4 * tn + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j][HW[t]], fa[s][HA[t]], acc[4 * tn + j], 0, 0, 0);
+        }
+      }
+    }
+    if constexpr (!GLDS) {
+      if (c + 1 < nc) {
+        wstore((c + 1) & 1);
+        if (c + 2 < nc) wload(c + 2, 0);
+        else w2load(0, 0);  // (the image registers are free from here on: the second product's first round)
+      }
+    }
+    barrier();
+  }
+  // ---- second product, one accumulator block (32 hidden columns) per round, the rounds' W2 images ping-ponging
+  const float s_h = f2_scale[0], o2 = f2_scale[2];
+  float16_t acc2[3];
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc2[n][v] = 0.f;
+  if constexpr (!GLDS) {
+    w2store(nc & 1);
+    w2load(1, 0);
+    barrier();
+  }
+#pragma unroll
+  for (int rd = 0; rd < 8; ++rd) {
+    if (ab & 8) break;
+    const _Float16* sw2 = reinterpret_cast<const _Float16*>(s_buf[(nc + rd) & 1]);
+    if constexpr (GLDS) {
+      if (rd + 1 < 8) w2load(rd + 1, (nc + rd + 1) & 1);
+    }
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      half8v_t h1, h2;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4_t bq = bias ? *reinterpret_cast<const float4_t*>(bias + 32 * rd + 8 * (2 * hf + q) + 4 * g) : zero4;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          float x = acc[rd][8 * hf + 4 * q + t] * hs_o + bq[t];
+          x = (x > 0.f ? x : 0.f) * s_h;
+          const _Float16 a1 = (_Float16)x;
+          h1[4 * q + t] = a1;
+          h2[4 * q + t] = (_Float16)(x - (float)a1);
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const half8v_t w1 = *reinterpret_cast<const half8v_t*>(sw2 + split_lds_off(n * 32 + r, 16 * hf + 8 * g));
+        const half8v_t w2 = *reinterpret_cast<const half8v_t*>(sw2 + F2_IMG2 / 2 + split_lds_off(n * 32 + r, 16 * hf + 8 * g));
+        acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, w1, acc2[n], 0, 0, 0);
+        acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, w2, acc2[n], 0, 0, 0);
+        acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, w1, acc2[n], 0, 0, 0);
+      }
+    }
+    if (rd + 1 < 8) {
+      if constexpr (!GLDS) {
+        w2store((nc + rd + 1) & 1);
+        if (rd + 2 < 8) w2load(rd + 2, 0);
+      }
+      barrier();
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      const int orow = m0b + wv * 32 + 8 * (v >> 2) + 4 * g + (v & 3);
+      if (orow < M && !(ab & 16)) y2[(int64_t)orow * F2_N2 + n * 32 + r] = acc2[n][v] * o2;
+    }
+}
+
+// the LDS images linear_fused2w_kernel copies: per run, after the scales (hs[1] = s_w of the first product, f2[1] = s_w2).
+//   w1img[tn][chunk][plane][split_lds_off(c, kpos)] = plane of s_w W1[128 tn + c][32 chunk + f2_perm(kpos)]  (0 beyond K)
+//   w2img[tn][round][plane][split_lds_off(n, kpos)] = plane of s_w2 W2p[n][128 tn + 32 round + f2_perm(kpos)]
+// (W2p = [W_l ; W_r] of the last layer padded to 96 rows, as fused2_split_kernel).  One thread per element.
+__global__ __launch_bounds__(256) void fused2_images_kernel(const float* __restrict__ hs, const float* __restrict__ f2,
+                                                            const float* __restrict__ w1, int K, const float* __restrict__ w2,
+                                                            int n_out, _Float16* __restrict__ w1img,
+                                                            _Float16* __restrict__ w2img) {
+  const int nc = (K + 31) >> 5;
+  const int n1 = 2 * nc * 128 * 32, n2 = 2 * 4 * F2_N2 * 32;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n1) {
+    const int kpos = i & 31, c = (i >> 5) & 127, blk = i >> 12;  // blk = tn * nc + chunk
+    const int tn = blk / nc, ch = blk - tn * nc;
+    const int k = 32 * ch + f2_perm(kpos);
+    const float x = k < K ? w1[(int64_t)(128 * tn + c) * K + k] * hs[1] : 0.f;
+    const _Float16 a1 = (_Float16)x;
+    _Float16* img = w1img + (int64_t)blk * F2_IMG1 + split_lds_off(c, kpos);
+    img[0] = a1;
+    img[F2_IMG1 / 2] = (_Float16)(x - (float)a1);
+  } else if (i < n1 + n2) {
+    const int e = i - n1;
+    const int kpos = e & 31, rest = e >> 5, n = rest % F2_N2, blk = rest / F2_N2;  // blk = tn * 4 + round
+    const int k = 32 * blk + f2_perm(kpos);  // (128 tn + 32 round + ...)
+    float x = 0.f;
+    if (n < n_out) x = w2[(int64_t)n * 2 * F2_HID + k];
+    else if (n >= F2_N2 / 2 && n - F2_N2 / 2 < n_out) x = w2[(int64_t)(n - F2_N2 / 2) * 2 * F2_HID + F2_HID + k];
+    x *= f2[1];
+    const _Float16 a1 = (_Float16)x;
+    _Float16* img = w2img + (int64_t)blk * F2_IMG2 + split_lds_off(n, kpos);
+    img[0] = a1;
+    img[F2_IMG2 / 2] = (_Float16)(x - (float)a1);
+  }
 }
 
 // f2[0..2] = {s_h, s_w2, 1 / (s_h s_w2)}, per run (the weights are read as they are now): max|b1| and max|W2| over a few
@@ -1635,7 +2113,7 @@ __global__ __launch_bounds__(256) void hs_chain_kernel(const float* __restrict__
 // (reduce = mean / sum; p0 / p1 = the two K-split partial planes, added plane 0 first).  One wave per root slot: four
 // groups of 16 lanes take every fourth edge, 12 lanes of a group a float4 of the 48-float half row each.  Writes the
 // roots' rows straight into the caller's buffer (a failed batch set: NaN rows, as gigl_take_rows).
-template <int OP>
+template <int OP, int PLANES>
 __global__ __launch_bounds__(256) void sage_fused_out_kernel(const float* __restrict__ p, int64_t plane_stride,
                                                              const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ rowend,
@@ -1663,11 +2141,12 @@ __global__ __launch_bounds__(256) void sage_fused_out_kernel(const float* __rest
       const int ja = col[e0 + e], eb = e + 4;
       const int jb = eb < m ? col[e0 + eb] : ja;
       const float4_t a0 = *reinterpret_cast<const float4_t*>(p0 + (int64_t)ja * F2_N2 + 4 * sl);
-      const float4_t a1 = *reinterpret_cast<const float4_t*>(p1 + (int64_t)ja * F2_N2 + 4 * sl);
+      float4_t a1 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (PLANES == 2) a1 = *reinterpret_cast<const float4_t*>(p1 + (int64_t)ja * F2_N2 + 4 * sl);
       float4_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
       if (eb < m) {
         b0 = *reinterpret_cast<const float4_t*>(p0 + (int64_t)jb * F2_N2 + 4 * sl);
-        b1 = *reinterpret_cast<const float4_t*>(p1 + (int64_t)jb * F2_N2 + 4 * sl);
+        if constexpr (PLANES == 2) b1 = *reinterpret_cast<const float4_t*>(p1 + (int64_t)jb * F2_N2 + 4 * sl);
       }
       acc += (a0 + a1) + (b0 + b1);
     }
@@ -1681,7 +2160,8 @@ __global__ __launch_bounds__(256) void sage_fused_out_kernel(const float* __rest
   if (sub == 0 && sl < 12) {
     const float dv = (OP == GIGL_AGGR_MEAN && m > 0) ? (float)m : 1.f;
     const float4_t s0 = *reinterpret_cast<const float4_t*>(p0 + (int64_t)i * F2_N2 + F2_N2 / 2 + 4 * sl);
-    const float4_t s1 = *reinterpret_cast<const float4_t*>(p1 + (int64_t)i * F2_N2 + F2_N2 / 2 + 4 * sl);
+    float4_t s1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (PLANES == 2) s1 = *reinterpret_cast<const float4_t*>(p1 + (int64_t)i * F2_N2 + F2_N2 / 2 + 4 * sl);
     float4_t rr = acc / dv + (s0 + s1);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -4614,13 +5094,31 @@ static int32_t linear_tiled_strided(gigl_ctx* ctx, const float* a_tiled, const f
 bool gigl_fused2_shape_ok(int32_t d0, int32_t hid, int32_t n_out) {
   return hid == F2_HID && n_out >= 1 && n_out <= F2_N2 / 2 && (d0 & 3) == 0 && d0 >= 4;
 }
-int64_t gigl_fused2_w2h_bytes() { return (int64_t)2 * F2_N2 * F2_HID * 2; }
+// [W2's planes as the round-5 kernel reads them | W1 chunk images | W2 round images]  (k1 = the first product's K)
+static int64_t fused2_w2h_legacy_bytes() { return (int64_t)2 * F2_N2 * F2_HID * 2; }
+static int64_t fused2_img1_bytes(int32_t k1) { return (int64_t)2 * ((k1 + 31) / 32) * F2_IMG1 * 2; }
+int64_t gigl_fused2_w2h_bytes(int32_t k1) { return fused2_w2h_legacy_bytes() + fused2_img1_bytes(k1) + (int64_t)2 * 4 * F2_IMG2 * 2; }
+static int fused2_variant() {
+  static const int variant = [] {
+    const char* e = getenv("GIGL_F2_VARIANT");
+    return e ? atoi(e) : 7;  // 0: linear_fused2_kernel (round 5), 4: linear_fused2w_kernel, 7: linear_fused2x_kernel, 8: 7 + LDS-direct
+  }();
+  return variant;
+}
 int32_t gigl_fused2_row_floats() { return F2_N2; }
+int32_t gigl_fused2_planes() { return fused2_variant() >= 7 ? 1 : 2; }
 
-int32_t gigl_fused2_prepare(gigl_ctx* ctx, const float* hs_dev, const float* b1, const float* w2, int32_t n_out, int32_t k1,
-                            float* f2, void* w2h) {
+int32_t gigl_fused2_prepare(gigl_ctx* ctx, const float* hs_dev, const float* b1, const float* w1, const float* w2, int32_t n_out,
+                            int32_t k1, float* f2, void* w2h) {
   // (f2: 16 floats, zero-initialised by the caller once: [4..6] are the scale kernel's accumulators + ticket)
   hipLaunchKernelGGL(fused2_scale_kernel, dim3(24), dim3(256), 0, ctx->stream, hs_dev, b1, w2, n_out * 2 * F2_HID, k1, f2);
+  if (fused2_variant() >= 4) {
+    _Float16* img1 = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(w2h) + fused2_w2h_legacy_bytes());
+    _Float16* img2 = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(img1) + fused2_img1_bytes(k1));
+    const int n = 2 * ((k1 + 31) / 32) * 128 * 32 + 2 * 4 * F2_N2 * 32;
+    hipLaunchKernelGGL(fused2_images_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, hs_dev,
+                       (const float*)f2, w1, k1, w2, n_out, img1, img2);
+  } else
   hipLaunchKernelGGL(fused2_split_kernel, dim3((F2_N2 * F2_HID + 255) / 256), dim3(256), 0, ctx->stream, f2, w2, n_out,
                      (_Float16*)w2h);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
@@ -4648,9 +5146,39 @@ int32_t gigl_linear_fused2(gigl_ctx* ctx, const float* a_tiled, const float* w, 
   if (m_cap == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_LINEAR);
   const int64_t bm = (m_cap + 127) / 128;
-  hipLaunchKernelGGL(linear_fused2_kernel, dim3((unsigned)(bm * 2)), dim3(256), 0, ctx->stream, a_tiled, w, bias, m_dev, k,
-                     y2, plane_stride, (d_mean + 31) / 32, self_src, self_ids, d_mean, self_ld, hs_scale, f2,
-                     (const _Float16*)w2h);
+  const int variant = fused2_variant();
+  if (variant >= 4) {
+    const _Float16* img1 = reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(w2h) + fused2_w2h_legacy_bytes());
+    const _Float16* img2 = reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(img1) + fused2_img1_bytes(k));
+    static const int ablate = [] {
+      const char* e = getenv("GIGL_F2_ABLATE");
+      return e ? atoi(e) : 0;
+    }();
+#define GIGL_F2W_LAUNCH(AD, WPE, DBG)                                                                                         \
+  hipLaunchKernelGGL((linear_fused2w_kernel<AD, WPE, DBG>), dim3((unsigned)(bm * 2)), dim3(256), 0, ctx->stream, a_tiled, bias, \
+                     m_dev, k, y2, plane_stride, (d_mean + 31) / 32, self_src, self_ids, d_mean, self_ld, hs_scale, f2, img1,  \
+                     img2, ablate)
+    if (variant >= 7) {
+#define GIGL_F2X_LAUNCH(DBG, GLDS)                                                                                          \
+  hipLaunchKernelGGL((linear_fused2x_kernel<DBG, GLDS>), dim3((unsigned)bm), dim3(256), 0, ctx->stream, a_tiled, bias, m_dev, k, \
+                     y2, (d_mean + 31) / 32, self_src, self_ids, d_mean, self_ld, hs_scale, f2, img1, img2, ablate)
+      if (ablate) GIGL_F2X_LAUNCH(true, false);
+      else if (variant == 8) GIGL_F2X_LAUNCH(false, true);
+      else GIGL_F2X_LAUNCH(false, false);
+#undef GIGL_F2X_LAUNCH
+    } else if (ablate) GIGL_F2W_LAUNCH(1, 3, true);
+    else GIGL_F2W_LAUNCH(1, 3, false);  // (two A chunks in flight at two waves per SIMD: 6.8 us per step against 5.9)
+#undef GIGL_F2W_LAUNCH
+    GIGL_HIP_CHECK(ctx, hipGetLastError());
+    return GIGL_OK;
+  }
+#define GIGL_F2_LAUNCH(PD, WPE)                                                                                              \
+  hipLaunchKernelGGL((linear_fused2_kernel<PD, WPE>), dim3((unsigned)(bm * 2)), dim3(256), 0, ctx->stream, a_tiled, w, bias, \
+                     m_dev, k, y2, plane_stride, (d_mean + 31) / 32, self_src, self_ids, d_mean, self_ld, hs_scale, f2,      \
+                     (const _Float16*)w2h)
+  // (measured and dropped, profiles/r06v_*: 2 / 3 chunks in flight at two waves per SIMD: 7.6 / 7.8 us per step against 6.3)
+  GIGL_F2_LAUNCH(1, 3);
+#undef GIGL_F2_LAUNCH
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
@@ -4662,12 +5190,18 @@ int32_t gigl_sage_fused_out(gigl_ctx* ctx, const float* p, int64_t plane_stride,
   if (b == 0) return GIGL_OK;
   gigl_prof_scope ps(ctx, GIGL_K_GATHER_MEAN);
   const dim3 g((unsigned)(((int64_t)b + 3) / 4)), blk(256);
-  if (aggr == GIGL_AGGR_MEAN)
-    hipLaunchKernelGGL((sage_fused_out_kernel<GIGL_AGGR_MEAN>), g, blk, 0, ctx->stream, p, plane_stride, rowptr, rowend, col,
-                       root_local, b, n_out, bias, act, meta, out);
-  else
-    hipLaunchKernelGGL((sage_fused_out_kernel<GIGL_AGGR_SUM>), g, blk, 0, ctx->stream, p, plane_stride, rowptr, rowend, col,
-                       root_local, b, n_out, bias, act, meta, out);
+  const bool one = fused2_variant() >= 7;  // (linear_fused2x_kernel: whole p rows, one plane)
+#define GIGL_FOUT(OP, PL)                                                                                                  \
+  hipLaunchKernelGGL((sage_fused_out_kernel<OP, PL>), g, blk, 0, ctx->stream, p, plane_stride, rowptr, rowend, col, root_local, \
+                     b, n_out, bias, act, meta, out)
+  if (aggr == GIGL_AGGR_MEAN) {
+    if (one) GIGL_FOUT(GIGL_AGGR_MEAN, 1);
+    else GIGL_FOUT(GIGL_AGGR_MEAN, 2);
+  } else {
+    if (one) GIGL_FOUT(GIGL_AGGR_SUM, 1);
+    else GIGL_FOUT(GIGL_AGGR_SUM, 2);
+  }
+#undef GIGL_FOUT
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }

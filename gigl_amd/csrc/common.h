@@ -199,10 +199,11 @@ int32_t gigl_gat_input_layer_fused_hs(gigl_ctx* ctx, const void* src, int32_t sr
 int32_t gigl_hs_chain_update(gigl_ctx* ctx, const float* hs_prev, const float* b_prev, int32_t n_b, int32_t k_prev, float fan,
                              const float* w, int64_t n_w, float* hs_out);
 bool gigl_fused2_shape_ok(int32_t d0, int32_t hid, int32_t n_out);
-int64_t gigl_fused2_w2h_bytes();
+int64_t gigl_fused2_w2h_bytes(int32_t k1);
 int32_t gigl_fused2_row_floats();
-int32_t gigl_fused2_prepare(gigl_ctx* ctx, const float* hs_dev, const float* b1, const float* w2, int32_t n_out, int32_t k1,
-                            float* f2, void* w2h);
+int32_t gigl_fused2_planes();  // partial p planes per node: 1 (linear_fused2x_kernel, whole rows) or 2 (K-split over the hidden tiles)
+int32_t gigl_fused2_prepare(gigl_ctx* ctx, const float* hs_dev, const float* b1, const float* w1, const float* w2, int32_t n_out,
+                            int32_t k1, float* f2, void* w2h);
 int32_t gigl_linear_fused2(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
                            int64_t m_cap, int32_t k, float* y2, int64_t plane_stride, const float* self_src,
                            const uint32_t* self_ids, int32_t d_mean, int32_t self_ld, const float* hs_scale,

@@ -342,7 +342,7 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
                              p->hbuf[l & 1], p->hbuf[(l - 1) & 1], nullptr, d, d, p->hs_layer[l]);
   }
   if (l == 0 && fused2_on(p)) {
-    int32_t rc = gigl_fused2_prepare(ctx, p->hs_dev, p->bias[0], p->w[1], p->dims[2], 2 * d, p->f2_dev, p->w2h);
+    int32_t rc = gigl_fused2_prepare(ctx, p->hs_dev, p->bias[0], p->w[0], p->w[1], p->dims[2], 2 * d, p->f2_dev, p->w2h);
     if (rc != GIGL_OK) return rc;
     return gigl_linear_fused2(ctx, p->abuf, p->w[0], p->bias[0], n_rows, rows_cap, 2 * d, p->hbuf[0],
                               (int64_t)p->act_rows * gigl_fused2_row_floats(), (const float*)p->feat->rows, p->un.nodes, d, d,
@@ -739,7 +739,7 @@ static int32_t plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, in
   if (with_abuf && hops == 2 && gigl_fused2_shape_ok(dims[0], dims[1], dims[2]) && getenv("GIGL_PLAN_NO_FUSE2") == nullptr &&
       (int64_t)max_out >= 2 * gigl_fused2_row_floats()) {
     p->f2_dev = (float*)alloc(64);
-    p->w2h = alloc((size_t)gigl_fused2_w2h_bytes());
+    p->w2h = alloc((size_t)gigl_fused2_w2h_bytes(2 * dims[0]));
     p->f2_ok = p->f2_dev && p->w2h && hipMemset(p->f2_dev, 0, 64) == hipSuccess;
     ok = ok && p->f2_ok;
   }
@@ -878,7 +878,7 @@ int32_t gigl_sage_plan_set_weights(gigl_sage_plan* p, const float* const* w, con
 
 int32_t gigl_sage_plan_half_split(gigl_sage_plan* p) { return p && p->hs0 ? 1 : 0; }
 
-int32_t gigl_sage_plan_fused_layers(gigl_sage_plan* p) { return p && fused2_on(p) ? 1 : 0; }
+int32_t gigl_sage_plan_fused_layers(gigl_sage_plan* p) { return p && fused2_on(p) ? gigl_fused2_planes() : 0; }
 
 int32_t gigl_sage_plan_set_aggr(gigl_sage_plan* p, int32_t aggr) {
   if (!p) return GIGL_E_INVALID_ARG;

@@ -1251,6 +1251,10 @@ class SagePlan:
         (gigl_sage_plan_fused_layers)"""
         return bool(self._lib.gigl_sage_plan_fused_layers(self._plan))
 
+    def fused_planes(self) -> int:
+        """partial planes of p rows the fused projection writes per node (0: layers apart; 1: whole rows; 2: K-split)"""
+        return int(self._lib.gigl_sage_plan_fused_layers(self._plan))
+
     def set_graph_stream(self, stream: Optional[torch.cuda.Stream]) -> None:
         """issue the graph part (sample + union) of every later call on `stream` — typically
         torch.cuda.Stream(priority=-1), a higher priority than the engine's stream — with the layers waiting on an event

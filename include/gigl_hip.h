@@ -1136,7 +1136,9 @@ int32_t gigl_sage_plan_set_projected_input(gigl_sage_plan* plan, const float* pr
  * GIGL_GEMM_SPLIT=bf16 in the environment.  GAT plans (gigl_gat_plan_create / _set_weights) take the same decision for
  * their first layer's projection. */
 int32_t gigl_sage_plan_half_split(gigl_sage_plan* plan);
-/* 1 when the plan runs its two SAGE layers' projections in ONE kernel: layer 0's hidden rows are multiplied by the last
+/* Non-zero when the plan runs its two SAGE layers' projections in ONE kernel (the value = the partial planes of p rows that
+ * kernel writes per node: 1 = whole rows, linear_fused2x_kernel, the default; 2 = K-split over the hidden width's two column
+ * tiles, the round-5 kernel, GIGL_F2_VARIANT=0 / 4): layer 0's hidden rows are multiplied by the last
  * layer's [W_l | W_r] before they leave the workgroup (W_l mean_j h_j = mean_j W_l h_j), 2 x out floats per node leave
  * instead of the hidden row, and the last layer (homogeneous.py:122-126 -> SAGEConv: W_l mean + b + W_r self) is one
  * reduction over those rows.  Two layers, hidden width 256, 2 x out <= 96, half-split first layer over an fp32 table, a
