@@ -1327,7 +1327,12 @@ int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a_in, const RangeTable& tb, 
                        desc, covered ? nullptr : heavy_list, heavy_count, wl);
     // persistent: 8 waves per SIMD on every CU at most, a multiple of WORK_LISTS waves
     int64_t wgs = ((a.n_parents + 7) / 8 + 15) / 16 * 16;
-    if (wgs > 2048) wgs = 2048;
+    static const int64_t wgs_max = [] {  // (tuning knob: the persistent grid's size, a multiple of 16)
+      const char* e = getenv("GIGL_EXPAND_WGS");
+      const int64_t v = e ? atoll(e) : 2048;
+      return v < 16 ? (int64_t)16 : v / 16 * 16;
+    }();
+    if (wgs > wgs_max) wgs = wgs_max;
     hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a, tb, (const RowDesc*)desc, wl);
   }
   if (!covered) {

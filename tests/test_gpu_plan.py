@@ -404,3 +404,40 @@ def test_first_layer_half_split_is_bounded_by_the_operands(setup):
         plan.close()
     finally:
         eng3.close()
+
+
+@pytest.mark.parametrize("d_in,n_out", [(4, 1), (12, 47), (36, 48), (128, 16), (260, 5)])
+def test_fused_projection_shapes_against_the_separate_layers(setup, d_in, n_out):
+    """linear_fused2x_kernel over input widths that leave a ragged last 32-k chunk (12, 36, 260), a single chunk (4: K = 8),
+    a [mean | self] boundary inside a chunk and on one (128), and output widths 1 .. 48: the fused plan's rows against the
+    layers run apart (GIGL_PLAN_NO_FUSE2: linear_split_kernel twice + the plain gathers) at 4e-6 of the largest row entry,
+    row counts that leave a partial last 128-row tile (homogeneous.py:107-153)"""
+    import os
+    from gigl_amd.engine import HipEngine
+    from gigl_amd.models import GraphSAGE
+    eng0, rowptr, col, x0, n = setup
+    rng = np.random.default_rng(100 + d_in)
+    x = rng.standard_normal((n, d_in)).astype(np.float32)
+    eng = HipEngine(0)
+    eng.load_csc(rowptr, col)
+    eng.load_features(x)
+    torch.manual_seed(d_in)
+    model = GraphSAGE(d_in, 256, n_out, num_layers=2).to(eng.device)
+    b, fan, G = 77, [7, 5], 2
+    plan = model.make_plan(eng, b, fan, groups=G)
+    assert plan.fused_layers() and plan.fused_planes() in (1, 2)
+    os.environ["GIGL_PLAN_NO_FUSE2"] = "1"
+    try:
+        apart = model.make_plan(eng, b, fan, groups=G)
+    finally:
+        del os.environ["GIGL_PLAN_NO_FUSE2"]
+    assert not apart.fused_layers()
+    roots = rng.integers(0, n, size=G * b).astype(np.uint32)
+    r_dev = torch.from_numpy(roots.view(np.int32)).to(eng.device)
+    out = plan.run(r_dev).cpu().numpy()
+    ref = apart.run(r_dev).cpu().numpy()
+    assert np.isfinite(out).all() and out.shape == (G * b, n_out)
+    assert np.abs(out - ref).max() <= 4e-6 * np.abs(ref).max()
+    plan.close()
+    apart.close()
+    eng.close()
