@@ -1720,7 +1720,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
 // sage_fused_out_kernel reads one 192-byte piece per edge instead of two.  LDS: two buffers of two W1 chunk images (64 KB).
 // GLDS: the images go global -> LDS without passing registers (global_load_lds_dwordx4: a wave instruction lands 1 KB at a
 // wave-uniform LDS address + 16 lane — the images are copied in that order anyway): no staging registers, no ds_write pass.
-template <bool DBG, bool GLDS>
+template <bool DBG, bool GLDS, bool GLDS2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void linear_fused2x_kernel(
     const float* __restrict__ a, const float* __restrict__ bias, const int32_t* __restrict__ m_dev, int K,
     float* __restrict__ y2, int a_tiled, const float* __restrict__ self_src, const uint32_t* __restrict__ self_ids,
@@ -1796,7 +1796,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   const u32x4_t* w2src = reinterpret_cast<const u32x4_t*>(w2img) + tid;
   auto w2load = [&](int rd, int b) {
     const u32x4_t* src = w2src + (int64_t)rd * (F2_IMG2 / 8);
-    if constexpr (GLDS) {
+    if constexpr (GLDS2) {
       short* dst = s_buf[b] + wv * 512;
 #pragma unroll
       for (int i = 0; i < 3; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(src + 256 * i), (lptr_t)(dst + 2048 * i), 16, 0, 0);
@@ -1807,7 +1807,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     }
   };
   auto w2store = [&](int b) {
-    if (GLDS) return;
+    if (GLDS2) return;
     u32x4_t* dst = reinterpret_cast<u32x4_t*>(s_buf[b]) + tid;
     dst[0] = wr0;
     dst[256] = wr1;
@@ -1822,7 +1822,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   wstore(0);
   if constexpr (!GLDS) {
     if (nc > 1) wload(1, 1);
-    else w2load(0, 1);
+    else if constexpr (!GLDS2) w2load(0, 1);
   }
   barrier();
   for (int c = 0; c < nc; ++c) {
@@ -1839,7 +1839,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     if (c + 1 < nc) aload(c + 1);
     if constexpr (GLDS) {
       if (c + 1 < nc) wload(c + 1, (c + 1) & 1);
-      else w2load(0, (c + 1) & 1);
+    }
+    if constexpr (GLDS2) {
+      if (c + 1 == nc) w2load(0, nc & 1);  // (that buffer's last reader was chunk nc - 2)
+    }
+    // the first layer's bias for the second product: fetched during the LAST chunk's MFMAs into the tail of the buffer that
+    // chunk does not read (a W2 round image takes 12 of its 32 KB) — read per lane from global memory inside the rounds, each
+    // of the sixteen (round, half) blocks opened with a wait for its bias load (an L2 round trip behind nine MFMAs)
+    // (LDS-direct: no register lives across the MFMAs for it — four more spilled 37)
+    if (c + 1 == nc && wv == 0) {
+      short* dst = s_buf[nc & 1] + F2_IMG2;
+      if (bias) __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const float4_t*>(bias) + lane), (lptr_t)dst, 16, 0, 0);
+      else reinterpret_cast<float4_t*>(dst)[lane] = zero4;
     }
     const short* sw = s_buf[c & 1];
 #pragma unroll
@@ -1868,11 +1879,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
       if (c + 1 < nc) {
         wstore((c + 1) & 1);
         if (c + 2 < nc) wload(c + 2, 0);
-        else w2load(0, 0);  // (the image registers are free from here on: the second product's first round)
+        else if constexpr (!GLDS2) w2load(0, 0);  // (the image registers are free from here on: the second product's first round)
       }
     }
     barrier();
   }
+  const float4_t* s_bias = reinterpret_cast<const float4_t*>(s_buf[nc & 1] + F2_IMG2);  // [64]: hidden columns 4 i .. 4 i + 3
   // ---- second product, one accumulator block (32 hidden columns) per round, the rounds' W2 images ping-ponging
   const float s_h = f2_scale[0], o2 = f2_scale[2];
   float16_t acc2[3];
@@ -1880,7 +1892,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   for (int n = 0; n < 3; ++n)
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc2[n][v] = 0.f;
-  if constexpr (!GLDS) {
+  if constexpr (!GLDS2) {
     w2store(nc & 1);
     w2load(1, 0);
     barrier();
@@ -1889,7 +1901,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
   for (int rd = 0; rd < 8; ++rd) {
     if (ab & 8) break;
     const _Float16* sw2 = reinterpret_cast<const _Float16*>(s_buf[(nc + rd) & 1]);
-    if constexpr (GLDS) {
+    if constexpr (GLDS2) {
       if (rd + 1 < 8) w2load(rd + 1, (nc + rd + 1) & 1);
     }
 #pragma unroll
@@ -1897,7 +1909,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
       half8v_t h1, h2;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const float4_t bq = bias ? *reinterpret_cast<const float4_t*>(bias + 32 * rd + 8 * (2 * hf + q) + 4 * g) : zero4;
+        const float4_t bq = s_bias[8 * rd + 2 * (2 * hf + q) + g];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           float x = acc[rd][8 * hf + 4 * q + t] * hs_o + bq[t];
@@ -1917,7 +1929,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
       }
     }
     if (rd + 1 < 8) {
-      if constexpr (!GLDS) {
+      if constexpr (!GLDS2) {
         w2store((nc + rd + 1) & 1);
         if (rd + 2 < 8) w2load(rd + 2, 0);
       }
@@ -5159,12 +5171,13 @@ int32_t gigl_linear_fused2(gigl_ctx* ctx, const float* a_tiled, const float* w, 
                      m_dev, k, y2, plane_stride, (d_mean + 31) / 32, self_src, self_ids, d_mean, self_ld, hs_scale, f2, img1,  \
                      img2, ablate)
     if (variant >= 7) {
-#define GIGL_F2X_LAUNCH(DBG, GLDS)                                                                                          \
-  hipLaunchKernelGGL((linear_fused2x_kernel<DBG, GLDS>), dim3((unsigned)bm), dim3(256), 0, ctx->stream, a_tiled, bias, m_dev, k, \
-                     y2, (d_mean + 31) / 32, self_src, self_ids, d_mean, self_ld, hs_scale, f2, img1, img2, ablate)
-      if (ablate) GIGL_F2X_LAUNCH(true, false);
-      else if (variant == 8) GIGL_F2X_LAUNCH(false, true);
-      else GIGL_F2X_LAUNCH(false, false);
+#define GIGL_F2X_LAUNCH(DBG, GLDS, GLDS2)                                                                                   \
+  hipLaunchKernelGGL((linear_fused2x_kernel<DBG, GLDS, GLDS2>), dim3((unsigned)bm), dim3(256), 0, ctx->stream, a_tiled, bias, \
+                     m_dev, k, y2, (d_mean + 31) / 32, self_src, self_ids, d_mean, self_ld, hs_scale, f2, img1, img2, ablate)
+      if (ablate) GIGL_F2X_LAUNCH(true, false, true);
+      else if (variant == 8) GIGL_F2X_LAUNCH(false, true, true);
+      else if (variant == 9) GIGL_F2X_LAUNCH(false, false, false);
+      else GIGL_F2X_LAUNCH(false, false, true);
 #undef GIGL_F2X_LAUNCH
     } else if (ablate) GIGL_F2W_LAUNCH(1, 3, true);
     else GIGL_F2W_LAUNCH(1, 3, false);  // (two A chunks in flight at two waves per SIMD: 6.8 us per step against 5.9)
