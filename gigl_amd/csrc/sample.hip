@@ -554,6 +554,8 @@ struct WorkLists {
   uint32_t* items;  // [WORK_LISTS][cap]
   int32_t* count;   // [WORK_LISTS * WORK_CNT_STRIDE]
   int64_t cap;
+  int32_t iters;  // 0: persistent waves; > 0: steps per copy of a wave (expand_rows_kernel)
+  int32_t wgs;    // workgroups of ONE copy of the grid
 };
 
 __host__ __device__ static inline int64_t work_list_cap(int64_t n_parents) {
@@ -730,11 +732,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
   uint32_t* lk = s_lk[wave_in_block];
   uint32_t* li = s_li[wave_in_block];
   // persistent grid (a multiple of WORK_LISTS waves): wave g walks list g % WORK_LISTS, two rows per step
-  const uint32_t gw = blockIdx.x * 4u + (uint32_t)wave_in_block, n_waves = gridDim.x * 4u;
+  // (wl.iters > 0: the grid is `rounds` copies of the persistent one — copy r of a wave walks steps [r iters, (r + 1) iters) of
+  // that wave's sequence and retires, so that other streams' workgroups get wave slots while a hop is expanded)
+  const uint32_t wgs_p = wl.iters > 0 ? (uint32_t)wl.wgs : gridDim.x;
+  const uint32_t round = blockIdx.x / wgs_p;
+  const uint32_t gw = (blockIdx.x % wgs_p) * 4u + (uint32_t)wave_in_block, n_waves = wgs_p * 4u;
   const uint32_t list = gw % WORK_LISTS, stride = n_waves / WORK_LISTS;
   const int32_t n_items = __builtin_amdgcn_readfirstlane(wl.count[list * WORK_CNT_STRIDE]);
   const uint32_t* items = wl.items + (int64_t)list * wl.cap;
-  for (uint32_t k = gw / WORK_LISTS; (int32_t)(2u * k) < n_items; k += stride) {
+  const uint32_t k_first = gw / WORK_LISTS + stride * round * (uint32_t)wl.iters;
+  const uint32_t k_end = wl.iters > 0 ? k_first + stride * (uint32_t)wl.iters : 0xFFFFFFFFu;
+  for (uint32_t k = k_first; (int32_t)(2u * k) < n_items && k < k_end; k += stride) {
     const uint32_t p0 = __builtin_amdgcn_readfirstlane(items[2u * k]);
     const uint32_t p1 = (int32_t)(2u * k + 1u) < n_items ? __builtin_amdgcn_readfirstlane(items[2u * k + 1u])
                                                          : (uint32_t)a.n_parents;  // (that slot holds a ROW_SKIP descriptor)
@@ -1333,6 +1341,22 @@ int32_t run_expand(gigl_ctx* ctx, const ExpandArgs& a_in, const RangeTable& tb, 
       return v < 16 ? (int64_t)16 : v / 16 * 16;
     }();
     if (wgs > wgs_max) wgs = wgs_max;
+    // (round 6) waves that retire after 16 steps instead of persistent ones: a hop of 1.6 M rows is 13 copies of the 2,048-
+    // workgroup grid, and the other streams' workgroups get wave slots as the copies retire — products 19.5 -> 19.3 us per
+    // step on one box, 18.9 -> 18.7 on another, `expand` 4.8 -> 4.7 us alone (profiles/r06am_expand_iters.txt);
+    // GIGL_EXPAND_ITERS=0 keeps the persistent grid (A/B).  Hops of fewer steps than that are one copy: unchanged.
+    static const int32_t iters = [] {
+      const char* e = getenv("GIGL_EXPAND_ITERS");
+      const int v = e ? atoi(e) : 16;
+      return v < 0 ? 0 : v;
+    }();
+    wl.iters = iters;
+    wl.wgs = (int32_t)wgs;
+    if (iters > 0) {
+      const int64_t stride = wgs * 4 / WORK_LISTS;                       // steps of a list taken per pass of the grid
+      const int64_t steps = (wl.cap / 2 + stride - 1) / stride;          // a wave's longest possible sequence
+      wgs *= (steps + iters - 1) / iters;
+    }
     hipLaunchKernelGGL(expand_rows_kernel, dim3((unsigned)wgs), dim3(256), 0, ctx->stream, a, tb, (const RowDesc*)desc, wl);
   }
   if (!covered) {
