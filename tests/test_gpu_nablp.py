@@ -197,8 +197,9 @@ def test_trainer_in_hbm_route_matches_the_tfrecord_route(workdir, tmp_path, enco
         print(encoder, "in-HBM route vs TFRecord route:", {k: tuple(f"{v:.1e}" for v in e) for k, e in errs.items()})
         for k, (em, ev, ep, share) in errs.items():
             # (measured: <= 2e-3 for the weights; the GAT's att_dst — whose gradient is the LeakyReLU's second-order effect, the
-            # first order cancels in the softmax — 1.2e-2: the backward kernels of both runs sum it with float atomics)
-            assert em <= 0.3 and ev <= 0.3 and ep <= 2e-2, (k, em, ev, ep, share)
+            # first order cancels in the softmax — 1.2e-2 ... 2.2e-2 from run to run: the backward kernels of BOTH runs sum it
+            # with float atomics, so the two sides of this comparison differ by the order of those sums and nothing else)
+            assert em <= 0.3 and ev <= 0.3 and ep <= (5e-2 if ".att_" in k else 2e-2), (k, em, ev, ep, share)
     for k in sd_t:
         np.testing.assert_allclose(sd_h[k].numpy(), sd_t[k].numpy(), rtol=1e-3 if encoder is None else 5e-2,
                                    atol=1e-5 if encoder is None else 0.05)
