@@ -302,7 +302,11 @@ def run_products(args, rank, world, local_rank):
                 two_src = True
                 ab["gather_mean"] += agg_l * (4 + dims[l] * s_in) + rows_l * (8 + dims[l] * 4)
                 # operand rows in, two planes of 96 floats out; + the second product's flops (256 -> 96, three products)
-                ab["linear"] += rows_l * (2 * dims[l] + p_planes * 96) * 4 + dout * 2 * dims[l] * 4 + 96 * dout * 4
+                # (one plane: a tile past the roots writes the W_l columns only — 64 of the 96 floats; the roots are the rows of
+                # the LAST layer)
+                rows_root = st[STATS["rows_layer0"] + 1] if (p_planes == 1 and not os.environ.get("GIGL_F2_ALL_WR")) else rows_l
+                ab["linear"] += rows_l * 2 * dims[l] * 4 + (rows_root * 96 + (rows_l - rows_root) * 64) * 4 * p_planes + \
+                    dout * 2 * dims[l] * 4 + 96 * dout * 4
                 fl += 2.0 * rows_l * (2 * dims[l] * dout + dout * 96)
                 alg_of.issued += 2.0 * rows_l * (2 * dims[l] * dout + dout * 96) * 3
                 continue

@@ -1725,13 +1725,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     const float* __restrict__ a, const float* __restrict__ bias, const int32_t* __restrict__ m_dev, int K,
     float* __restrict__ y2, int a_tiled, const float* __restrict__ self_src, const uint32_t* __restrict__ self_ids,
     int d_mean, int self_ld, const float* __restrict__ hs_scale, const float* __restrict__ f2_scale,
-    const _Float16* __restrict__ w1img, const _Float16* __restrict__ w2img, int ablate) {
+    const _Float16* __restrict__ w1img, const _Float16* __restrict__ w2img, int ablate,
+    const int32_t* __restrict__ n_self_rows) {
   __shared__ __attribute__((aligned(16))) short s_buf[2][2 * F2_IMG1];
   const int ab = DBG ? ablate : 0;
   const int M = *m_dev;
   const float hs_a = hs_scale[0], hs_o = hs_scale[2];
   const int tm = blockIdx.x, m0b = tm * 128;
   if (m0b >= M) return;
+  // the W_r half of a p row (columns 48 .. 94) is read for ROOTS only (sage_fused_out_kernel: the root's own term), and the
+  // rows are numbered level by level — roots first: a tile past them leaves the last 32 columns (all W_r) alone: a third of
+  // the second product's MFMAs and W2 fragment reads, 128 of a row's 384 bytes not written
+  const bool wr_block = !n_self_rows || m0b < *n_self_rows;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int r = lane & 31, g = lane >> 5;
   const int nc = (K + 31) >> 5;
@@ -1921,6 +1926,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
       }
 #pragma unroll
       for (int n = 0; n < 3; ++n) {
+        if (n == 2 && !wr_block) continue;
         const half8v_t w1 = *reinterpret_cast<const half8v_t*>(sw2 + split_lds_off(n * 32 + r, 16 * hf + 8 * g));
         const half8v_t w2 = *reinterpret_cast<const half8v_t*>(sw2 + F2_IMG2 / 2 + split_lds_off(n * 32 + r, 16 * hf + 8 * g));
         acc2[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, w1, acc2[n], 0, 0, 0);
@@ -1937,12 +1943,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void l
     }
   }
 #pragma unroll
-  for (int n = 0; n < 3; ++n)
+  for (int n = 0; n < 3; ++n) {
+    if (n == 2 && !wr_block) continue;
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
       const int orow = m0b + wv * 32 + 8 * (v >> 2) + 4 * g + (v & 3);
       if (orow < M && !(ab & 16)) y2[(int64_t)orow * F2_N2 + n * 32 + r] = acc2[n][v] * o2;
     }
+  }
 }
 
 // the LDS images linear_fused2w_kernel copies: per run, after the scales (hs[1] = s_w of the first product, f2[1] = s_w2).
@@ -5150,7 +5158,7 @@ int32_t gigl_hs_chain_update(gigl_ctx* ctx, const float* hs_prev, const float* b
 int32_t gigl_linear_fused2(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
                            int64_t m_cap, int32_t k, float* y2, int64_t plane_stride, const float* self_src,
                            const uint32_t* self_ids, int32_t d_mean, int32_t self_ld, const float* hs_scale,
-                           const float* f2, const void* w2h) {
+                           const float* f2, const void* w2h, const int32_t* n_root_rows) {
   GIGL_REQUIRE(ctx, a_tiled && w && m_dev && y2 && self_src && hs_scale && f2 && w2h && (k & 3) == 0 && d_mean > 0 &&
                         (d_mean & 3) == 0 && d_mean < k && self_ld >= k - d_mean && (((uintptr_t)bias) & 15) == 0,
                "bad arguments");
@@ -5173,7 +5181,8 @@ int32_t gigl_linear_fused2(gigl_ctx* ctx, const float* a_tiled, const float* w, 
     if (variant >= 7) {
 #define GIGL_F2X_LAUNCH(DBG, GLDS, GLDS2)                                                                                   \
   hipLaunchKernelGGL((linear_fused2x_kernel<DBG, GLDS, GLDS2>), dim3((unsigned)bm), dim3(256), 0, ctx->stream, a_tiled, bias, \
-                     m_dev, k, y2, (d_mean + 31) / 32, self_src, self_ids, d_mean, self_ld, hs_scale, f2, img1, img2, ablate)
+                     m_dev, k, y2, (d_mean + 31) / 32, self_src, self_ids, d_mean, self_ld, hs_scale, f2, img1, img2, ablate, \
+                     n_root_rows)
       if (ablate) GIGL_F2X_LAUNCH(true, false, true);
       else if (variant == 8) GIGL_F2X_LAUNCH(false, true, true);
       else if (variant == 9) GIGL_F2X_LAUNCH(false, false, false);

@@ -207,7 +207,8 @@ int32_t gigl_fused2_prepare(gigl_ctx* ctx, const float* hs_dev, const float* b1,
 int32_t gigl_linear_fused2(gigl_ctx* ctx, const float* a_tiled, const float* w, const float* bias, const int32_t* m_dev,
                            int64_t m_cap, int32_t k, float* y2, int64_t plane_stride, const float* self_src,
                            const uint32_t* self_ids, int32_t d_mean, int32_t self_ld, const float* hs_scale,
-                           const float* f2, const void* w2h);
+                           const float* f2, const void* w2h, const int32_t* n_root_rows = nullptr);
+// (n_root_rows: DEVICE count of the leading rows that are roots — only their W_r half is ever read; NULL: every row's)
 int32_t gigl_sage_fused_out(gigl_ctx* ctx, const float* p, int64_t plane_stride, const int32_t* rowptr,
                             const int32_t* rowend, const int32_t* col, const int32_t* root_local, int32_t b,
                             int32_t n_out, const float* bias, int32_t act, int32_t aggr, const int32_t* meta, float* out);

@@ -346,7 +346,8 @@ int32_t enqueue_stage(gigl_sage_plan* p, int s, const uint32_t* roots, int32_t s
     if (rc != GIGL_OK) return rc;
     return gigl_linear_fused2(ctx, p->abuf, p->w[0], p->bias[0], n_rows, rows_cap, 2 * d, p->hbuf[0],
                               (int64_t)p->act_rows * gigl_fused2_row_floats(), (const float*)p->feat->rows, p->un.nodes, d, d,
-                              hs_scale, p->f2_dev, p->w2h);
+                              hs_scale, p->f2_dev, p->w2h,
+                              getenv("GIGL_F2_ALL_WR") ? nullptr : p->un.meta + GIGL_META_LEVEL0);
   }
   if (two_src)
     return gigl_linear_tiled(ctx, p->abuf, p->w[l], p->bias[l], n_rows, rows_cap, 2 * d, p->dims[l + 1], act,
