@@ -1685,6 +1685,18 @@ struct gigl_nablp_train_plan {
     float *z[2] = {nullptr, nullptr}, *xw[2] = {nullptr, nullptr}, *out_pre[2] = {nullptr, nullptr};
     float *dxw = nullptr, *ds = nullptr, *dd = nullptr, *alpha = nullptr, *dh0 = nullptr, *dh0s = nullptr, *dz = nullptr,
           *edge_scratch = nullptr;
+    // (round 6, as the SAGE plans: GIGL_TRAIN_PLAN_UNFUSED=1 for the A/B) the projections' weight gradients stay per-chunk partial
+    // sums — per encode: W1's, and W0's / b0's per head — added up inside the Adam kernel; W1^T and the heads' W0^T are laid
+    // out once per step
+    bool fused = false;
+    float* part_w1[2] = {nullptr, nullptr};
+    int32_t rc_w1[2] = {0, 0};
+    float* part_w0[2][4] = {{nullptr}};
+    float* part_b0[2][4] = {{nullptr}};
+    int32_t rc_w0[2] = {0, 0};
+    float* wt1 = nullptr;
+    float* wt0[4] = {nullptr};
+    bool parts_pending = false;  // the gradient buffers do not hold the partial sums yet (gigl_gat_nablp_train_plan_grads adds them)
   } gat;
   std::vector<void*> owned;
   // Two workspaces of trees + union graphs (as gigl_sage_train_plan): the graph part of the NEXT step's roots (sample +
@@ -1959,20 +1971,22 @@ __global__ __launch_bounds__(256) void lp_unpack_scatter_kernel(const float* __r
 }
 
 // Adam over the SUM of the two encodes' gradients (both forwards share the weights)
+constexpr int ADAM2_MAX = 16;  // tensors (or slices of tensors: the GAT plan's heads) per launch
 struct AdamPack2 {
-  float* p[2 * GIGL_MAX_HOPS];
-  const float* g1[2 * GIGL_MAX_HOPS];
-  const float* g2[2 * GIGL_MAX_HOPS];
-  float* m[2 * GIGL_MAX_HOPS];
-  float* v[2 * GIGL_MAX_HOPS];
-  int64_t n[2 * GIGL_MAX_HOPS];
+  float* p[ADAM2_MAX];
+  const float* g1[ADAM2_MAX];
+  const float* g2[ADAM2_MAX];
+  float* m[ADAM2_MAX];
+  float* v[ADAM2_MAX];
+  int64_t n[ADAM2_MAX];
   // (round 6) part1 / part2 != NULL: the two encodes' gradients as per-chunk partial sums ([chunks][n], the chunks below
-  // ceil(*rows / rc) real), each added up in chunk order, then the two totals — the order of reduce + reduce + add
-  const float* part1[2 * GIGL_MAX_HOPS];
-  const float* part2[2 * GIGL_MAX_HOPS];
-  const int32_t* rows1[2 * GIGL_MAX_HOPS];
-  const int32_t* rows2[2 * GIGL_MAX_HOPS];
-  int32_t rc1[2 * GIGL_MAX_HOPS], rc2[2 * GIGL_MAX_HOPS];
+  // ceil(*rows / rc) real), each added up in chunk order, then the two totals — the order of reduce + reduce + add; g1 may
+  // hold a further term beside them (the GAT plan: the folded attention vectors' share of W0's gradient)
+  const float* part1[ADAM2_MAX];
+  const float* part2[ADAM2_MAX];
+  const int32_t* rows1[ADAM2_MAX];
+  const int32_t* rows2[ADAM2_MAX];
+  int32_t rc1[ADAM2_MAX], rc2[ADAM2_MAX];
   int32_t count;
   float lr, beta1, beta2, eps, wd;
 };
@@ -2006,8 +2020,9 @@ __global__ __launch_bounds__(256) void lp_adam_kernel(AdamPack2 a, const int32_t
     const int ch2 = a.part2[k] ? (*a.rows2[k] + a.rc2[k] - 1) / a.rc2[k] : 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n[k]; i += (int64_t)gridDim.x * blockDim.x) {
       const float w = p[i];
-      const float ga = a.part1[k] ? chunk_sum(a.part1[k], ch1, a.n[k], i) : a.g1[k][i];
+      float ga = a.part1[k] ? chunk_sum(a.part1[k], ch1, a.n[k], i) : a.g1[k][i];
       const float gb_ = a.part2[k] ? chunk_sum(a.part2[k], ch2, a.n[k], i) : (a.g2[k] ? a.g2[k][i] : 0.f);
+      if (a.part1[k] && a.g1[k]) ga += a.g1[k][i];
       const float gr = (ga + gb_) + a.wd * w;
       const float mm = m[i] + (gr - m[i]) * (1.f - a.beta1);
       const float vv = v[i] * a.beta2 + (1.f - a.beta2) * gr * gr;
@@ -2177,8 +2192,8 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
     const int32_t* r1 = pm->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
     const int32_t* r2 = pr->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
     ap.p[ap.count] = t->w[l];
-    ap.g1[ap.count] = t->enc[0].gw[l];
-    ap.g2[ap.count] = t->enc[1].gw[l];
+    ap.g1[ap.count] = fz ? nullptr : t->enc[0].gw[l];
+    ap.g2[ap.count] = fz ? nullptr : t->enc[1].gw[l];
     ap.part1[ap.count] = fz ? t->enc[0].part_w[l] : nullptr;
     ap.part2[ap.count] = fz ? t->enc[1].part_w[l] : nullptr;
     ap.rows1[ap.count] = r1;
@@ -2190,8 +2205,8 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
     ap.n[ap.count++] = (int64_t)t->dims[l + 1] * 2 * t->dims[l];
     if (t->bias[l]) {
       ap.p[ap.count] = t->bias[l];
-      ap.g1[ap.count] = t->enc[0].gb[l];
-      ap.g2[ap.count] = t->enc[1].gb[l];
+      ap.g1[ap.count] = fz ? nullptr : t->enc[0].gb[l];
+      ap.g2[ap.count] = fz ? nullptr : t->enc[1].gb[l];
       ap.part1[ap.count] = fz ? t->enc[0].part_b[l] : nullptr;
       ap.part2[ap.count] = fz ? t->enc[1].part_b[l] : nullptr;
       ap.rows1[ap.count] = r1;
@@ -2441,6 +2456,7 @@ int32_t gigl_nablp_train_plan_step2(gigl_nablp_train_plan* t, const uint32_t* ma
   if (mode == GIGL_MODE_REPLACE)
     return gigl_fail(ctx, GIGL_E_UNSUPPORTED, "the training plan needs duplicate-free trees (no with-replacement mode)");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  t->gat.parts_pending = t->kind == 1 && t->gat.fused;  // (this step's gradient buffers will lack the partial sums)
   hipStream_t st = ctx->stream;
   if (t->lctx->stream != st || t->lctx->own_stream) {
     const int32_t rs = gigl_ctx_set_stream(t->lctx, st);
@@ -2702,6 +2718,15 @@ int32_t gat_lp_begin(gigl_nablp_train_plan* t) {
   hipLaunchKernelGGL(gat_fold_kernel, dim3((unsigned)(2 * g.heads), (unsigned)((g.d_in + 63) / 64)), dim3(256), 0,
                      t->lctx->stream, (const float*)g.w[0],
                      (const float*)g.att_src[0], (const float*)g.att_dst[0], g.heads, g.c0, g.d_in, g.u);
+  if (g.fused) {  // W1^T and the heads' W0^T for the input gradients of both encodes
+    hipStream_t st = t->lctx->stream;
+    const int HC = g.heads * g.c0;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(((int64_t)g.c1 * HC + 255) / 256)), dim3(256), 0, st, (const float*)g.w[1],
+                       g.c1, HC, g.wt1);
+    for (int h = 0; h < g.heads; ++h)
+      hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)(((int64_t)g.c0 * g.d_in + 255) / 256)), dim3(256), 0, st,
+                         (const float*)(g.w[0] + (int64_t)h * g.c0 * g.d_in), g.c0, g.d_in, g.wt0[h]);
+  }
   GIGL_HIP_CHECK(t->lctx, hipGetLastError());
   return GIGL_OK;
 }
@@ -2765,13 +2790,14 @@ int32_t gat_lp_backward(gigl_nablp_train_plan* t, int which) {
   if (rc != GIGL_OK) return rc;
   rc = gigl_gat_backward_epilogue(ctx, g.dxw, g.ds, g.dd, g.xw[which], g.att_src[1], g.att_dst[1], n1, rows1, 1, C1, gas1, gad1);
   if (rc != GIGL_OK) return rc;
-  rc = gigl_linear_weight_grad(ctx, g.dxw, e.h[0], nullptr, n1, rows1, C1, HC, gw1, nullptr);
+  if (g.fused) rc = gigl_linear_weight_grad_parts(ctx, g.dxw, e.h[0], nullptr, n1, rows1, C1, HC, g.part_w1[which], nullptr);
+  else rc = gigl_linear_weight_grad(ctx, g.dxw, e.h[0], nullptr, n1, rows1, C1, HC, gw1, nullptr);
   if (rc != GIGL_OK) return rc;
-  {
+  if (!g.fused) {
     int64_t blocks = ((int64_t)C1 * HC + 255) / 256;
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)g.w[1], C1, HC, t->wt);
   }
-  rc = gigl_linear(ctx, g.dxw, t->wt, nullptr, n1, rows1, C1, HC, 0, g.dh0);
+  rc = gigl_linear(ctx, g.dxw, g.fused ? g.wt1 : t->wt, nullptr, n1, rows1, C1, HC, 0, g.dh0);
   if (rc != GIGL_OK) return rc;
   // ---- first layer: relu mask, the heads' slices, their projections' backward, the attention-weighted sums' backward
   {
@@ -2782,15 +2808,19 @@ int32_t gat_lp_backward(gigl_nablp_train_plan* t, int which) {
   }
   for (int h = 0; h < H; ++h) {
     const float* dyh = g.dh0s + (int64_t)h * rows1 * C0;
-    rc = gigl_linear_weight_grad(ctx, dyh, g.z[which] + (int64_t)h * rows1 * d, nullptr, n1, rows1, C0, d, gw0 + (int64_t)h * C0 * d,
-                                 g.bias[0] ? gb0 + h * C0 : nullptr);
+    if (g.fused)
+      rc = gigl_linear_weight_grad_parts(ctx, dyh, g.z[which] + (int64_t)h * rows1 * d, nullptr, n1, rows1, C0, d,
+                                         g.part_w0[which][h], g.bias[0] ? g.part_b0[which][h] : nullptr);
+    else
+      rc = gigl_linear_weight_grad(ctx, dyh, g.z[which] + (int64_t)h * rows1 * d, nullptr, n1, rows1, C0, d,
+                                   gw0 + (int64_t)h * C0 * d, g.bias[0] ? gb0 + h * C0 : nullptr);
     if (rc != GIGL_OK) return rc;
-    {
+    if (!g.fused) {
       int64_t blocks = ((int64_t)C0 * d + 255) / 256;
       hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)(g.w[0] + (int64_t)h * C0 * d),
                          C0, d, t->wt);
     }
-    rc = gigl_linear(ctx, dyh, t->wt, nullptr, n1, rows1, C0, d, 0, g.dz + (int64_t)h * rows1 * d);
+    rc = gigl_linear(ctx, dyh, g.fused ? g.wt0[h] : t->wt, nullptr, n1, rows1, C0, d, 0, g.dz + (int64_t)h * rows1 * d);
     if (rc != GIGL_OK) return rc;
   }
   rc = gigl_gat_input_aggregate_backward(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, g.u, H, g.slope, p->un.rowptr,
@@ -2809,22 +2839,45 @@ int32_t gat_lp_finish(gigl_nablp_train_plan* t) {
                      g.g[1], g.g[2]);
   AdamPack2 ap{};
   float* params[8] = {g.w[0], g.att_src[0], g.att_dst[0], g.bias[0], g.w[1], g.att_src[1], g.att_dst[1], g.bias[1]};
+  const int32_t* n1a = t->enc[0].base->un.meta + GIGL_META_LEVEL0 + 1;
+  const int32_t* n1b = t->enc[1].base->un.meta + GIGL_META_LEVEL0 + 1;
+  auto add = [&](float* prm, const float* grad, float* m, float* v, int64_t n, const float* pa, const float* pb, int32_t rca,
+                 int32_t rcb) {
+    ap.p[ap.count] = prm;
+    ap.g1[ap.count] = grad;
+    ap.g2[ap.count] = nullptr;
+    ap.part1[ap.count] = pa;
+    ap.part2[ap.count] = pb;
+    ap.rows1[ap.count] = n1a;
+    ap.rows2[ap.count] = n1b;
+    ap.rc1[ap.count] = rca;
+    ap.rc2[ap.count] = rcb;
+    ap.m[ap.count] = m;
+    ap.v[ap.count] = v;
+    ap.n[ap.count++] = n;
+  };
   for (int i = 0; i < 8; ++i) {
     if (!params[i]) continue;
-    ap.p[ap.count] = params[i];
-    ap.g1[ap.count] = g.g[i];
-    ap.g2[ap.count] = nullptr;
-    ap.m[ap.count] = g.mom[2 * i];
-    ap.v[ap.count] = g.mom[2 * i + 1];
-    ap.n[ap.count++] = g.n[i];
+    if (g.fused && (i == 0 || i == 3)) {  // W0 / b0: a slice per head, each with its own partial sums of both encodes
+      const int64_t ns = i == 0 ? (int64_t)g.c0 * g.d_in : g.c0;
+      for (int h = 0; h < g.heads; ++h)
+        add(params[i] + h * ns, g.g[i] + h * ns, g.mom[2 * i] + h * ns, g.mom[2 * i + 1] + h * ns, ns,
+            i == 0 ? g.part_w0[0][h] : g.part_b0[0][h], i == 0 ? g.part_w0[1][h] : g.part_b0[1][h], g.rc_w0[0], g.rc_w0[1]);
+    } else if (g.fused && i == 4) {
+      add(params[i], g.g[i], g.mom[2 * i], g.mom[2 * i + 1], g.n[i], g.part_w1[0], g.part_w1[1], g.rc_w1[0], g.rc_w1[1]);
+    } else {
+      add(params[i], g.g[i], g.mom[2 * i], g.mom[2 * i + 1], g.n[i], nullptr, nullptr, 0, 0);
+    }
   }
+
   ap.lr = t->lr;
   ap.beta1 = t->beta1;
   ap.beta2 = t->beta2;
   ap.eps = t->eps;
   ap.wd = t->wd;
-  hipLaunchKernelGGL(lp_adam_kernel, dim3(256), dim3(256), 0, st, ap, (const int32_t*)(t->consts + 2),
-                     (const int32_t*)t->enc[0].base->un.meta, (const int32_t*)t->enc[1].base->un.meta);
+  hipLaunchKernelGGL(lp_adam_kernel, g.fused ? dim3(104, (unsigned)ap.count) : dim3(256), dim3(256), 0, st, ap,
+                     (const int32_t*)(t->consts + 2), (const int32_t*)t->enc[0].base->un.meta,
+                     (const int32_t*)t->enc[1].base->un.meta);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return GIGL_OK;
 }
@@ -2970,6 +3023,27 @@ int32_t gigl_gat_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_
   const size_t wt_floats = std::max((size_t)C1 * H * C0, (size_t)C0 * d);
   t->wt = (float*)alloc(wt_floats * 4);
   ok = ok && t->zero_base && g.u && g.dxw && g.ds && g.alpha && g.dh0 && g.dh0s && g.dz && g.edge_scratch && t->wt;
+  g.fused = getenv("GIGL_TRAIN_PLAN_UNFUSED") == nullptr;
+  if (g.fused && ok) {
+    g.wt1 = (float*)alloc((size_t)C1 * H * C0 * 4);
+    ok = g.wt1 != nullptr;
+    for (int h = 0; h < H && ok; ++h) {
+      g.wt0[h] = (float*)alloc((size_t)C0 * d * 4);
+      ok = g.wt0[h] != nullptr;
+    }
+    for (int k = 0; k < 2 && ok; ++k) {
+      const int64_t rows1 = t->enc[k].rows_cap[0];
+      const int64_t ch1 = gigl_linear_weight_grad_chunks(rows1, C1, H * C0, &g.rc_w1[k]);
+      g.part_w1[k] = (float*)alloc((size_t)ch1 * C1 * H * C0 * 4);
+      const int64_t ch0 = gigl_linear_weight_grad_chunks(rows1, C0, d, &g.rc_w0[k]);
+      ok = g.part_w1[k] != nullptr;
+      for (int h = 0; h < H && ok; ++h) {
+        g.part_w0[k][h] = (float*)alloc((size_t)ch0 * C0 * d * 4);
+        g.part_b0[k][h] = (float*)alloc((size_t)ch0 * C0 * 4);
+        ok = g.part_w0[k][h] && g.part_b0[k][h];
+      }
+    }
+  }
   const size_t de = (size_t)C1, Q = (size_t)b_anchors * num_positives, Cn = Q + (size_t)t->n_rn;
   t->rq = (float*)alloc(Q * de * 4);
   t->cand = (float*)alloc(Cn * de * 4);
@@ -3007,6 +3081,18 @@ int32_t gigl_gat_nablp_train_plan_grads(gigl_nablp_train_plan* t, int32_t layer,
   gigl_ctx* ctx = t->ctx;
   GIGL_REQUIRE(ctx, t->kind == 1 && layer >= 0 && layer < 2 && gw && g_att_src && g_att_dst, "bad plan / layer / null output");
   GIGL_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (t->gat.fused && t->gat.parts_pending) {  // the step kept the projections' gradients as partial sums: add them up, once
+    auto& g = t->gat;
+    for (int k = 0; k < 2; ++k) {
+      const int32_t* n1 = t->enc[k].base->un.meta + GIGL_META_LEVEL0 + 1;
+      int32_t rc = gigl_linear_weight_grad_sum(ctx, g.part_w1[k], nullptr, n1, g.c1, g.heads * g.c0, g.rc_w1[k], g.g[4], nullptr);
+      for (int h = 0; h < g.heads && rc == GIGL_OK; ++h)
+        rc = gigl_linear_weight_grad_sum(ctx, g.part_w0[k][h], g.bias[0] ? g.part_b0[k][h] : nullptr, n1, g.c0, g.d_in, g.rc_w0[k],
+                                         g.g[0] + (int64_t)h * g.c0 * g.d_in, g.bias[0] ? g.g[3] + h * g.c0 : nullptr);
+      if (rc != GIGL_OK) return rc;
+    }
+    g.parts_pending = false;
+  }
   float* dst[4] = {gw, g_att_src, g_att_dst, gb};
   for (int i = 0; i < 4; ++i) {
     const int j = 4 * layer + i;

@@ -398,7 +398,13 @@ def test_library_gat_link_prediction_step_equals_the_autograd_step(setup, heads,
             got.append(plan.step(roots, cnt, rn, next_roots=nxt).clone())
             if i == 0:
                 grads = [plan.grads(l) for l in range(2)]
+                again = [plan.grads(l) for l in range(2)]  # (the partial sums are added to the buffers once, not per request)
+            if i == steps - 1:
+                last = [plan.grads(l) for l in range(2)]   # (after replayed steps: the hook still finds this step's sums)
     eng.synchronize()
+    for l in range(2):
+        for a, a2, z in zip(grads[l], again[l], last[l]):
+            assert torch.equal(a, a2) and torch.isfinite(z).all() and float(z.abs().max()) > 0
     errs = {}
     for l in range(2):
         for name, a, w_ in zip(("w", "att_src", "att_dst", "bias"), grads[l], first_grads[l]):
