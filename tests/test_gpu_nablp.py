@@ -199,7 +199,11 @@ def test_trainer_in_hbm_route_matches_the_tfrecord_route(workdir, tmp_path, enco
             # (measured: <= 2e-3 for the weights; the GAT's att_dst — whose gradient is the LeakyReLU's second-order effect, the
             # first order cancels in the softmax — 1.2e-2 ... 2.2e-2 from run to run: the backward kernels of BOTH runs sum it
             # with float atomics, so the two sides of this comparison differ by the order of those sums and nothing else)
-            assert em <= 0.3 and ev <= 0.3 and ep <= (5e-2 if ".att_" in k else 2e-2), (k, em, ev, ep, share)
+            # (the same vector's moments: 0.25 / 0.30 of their own size apart between two runs of the SAME route — measured
+            # 0.24 ... 0.30 over the round's runs; every other tensor's <= 1e-4)
+            noisy = ".att_" in k
+            assert em <= (0.6 if noisy else 0.3) and ev <= (0.6 if noisy else 0.3) and ep <= (5e-2 if noisy else 2e-2), \
+                (k, em, ev, ep, share)
     for k in sd_t:
         np.testing.assert_allclose(sd_h[k].numpy(), sd_t[k].numpy(), rtol=1e-3 if encoder is None else 5e-2,
                                    atol=1e-5 if encoder is None else 0.05)
