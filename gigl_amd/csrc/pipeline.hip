@@ -1714,6 +1714,13 @@ struct gigl_nablp_train_plan {
     bool fetched = false;
   } work[WS];
   hipEvent_t ev_now = nullptr;  // "the caller's stream, now": the roots a graph part copies were written before it
+  // (round 6, SAGE encoder; GIGL_LP_FORK=0 turns it off) the random negatives' encode — ~15 launches of a 512-root batch, all latency — runs
+  // on a stream of its own beside the main batch's, forward and backward: forked after the step's shared preparation, joined
+  // before the scores, forked again after the loss's backward, joined before Adam.  Its only shared scratch is `da`.
+  gigl_ctx* actx = nullptr;
+  float* da2 = nullptr;
+  hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
+  bool fork = false;
   int cur = 0;
   int cur_layers_ws = 0;  // the workspace the layers part being enqueued reads
   int32_t cap_seed = 0, cap_mode = -1;
@@ -2036,7 +2043,7 @@ __global__ __launch_bounds__(256) void lp_adam_kernel(AdamPack2 a, const int32_t
 int32_t lp_forward(gigl_nablp_train_plan* t, int which) {
   gigl_nablp_train_plan::Enc& e = t->enc[which];
   gigl_sage_plan* p = e.base;
-  gigl_ctx* ctx = t->lctx;
+  gigl_ctx* ctx = which == 1 && t->fork ? t->actx : t->lctx;
   const int L = t->L;
   int32_t rc = GIGL_OK;
   const int32_t* n_local = p->leaf_global ? (L >= 2 ? p->un.meta + GIGL_META_LEVEL0 + (L - 2) : p->zero_dev) : nullptr;
@@ -2064,7 +2071,8 @@ int32_t lp_forward(gigl_nablp_train_plan* t, int which) {
 int32_t lp_backward(gigl_nablp_train_plan* t, int which) {
   gigl_nablp_train_plan::Enc& e = t->enc[which];
   gigl_sage_plan* p = e.base;
-  gigl_ctx* ctx = t->lctx;
+  gigl_ctx* ctx = which == 1 && t->fork ? t->actx : t->lctx;
+  float* da = which == 1 && t->fork ? t->da2 : t->da;
   hipStream_t st = ctx->stream;
   const int L = t->L;
   int32_t rc = GIGL_OK;
@@ -2092,14 +2100,14 @@ int32_t lp_backward(gigl_nablp_train_plan* t, int which) {
       int64_t blocks = ((int64_t)n_out * 2 * d + 255) / 256;
       hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)t->w[l], n_out, 2 * d, t->wt);
     }
-    rc = gigl_linear(ctx, e.dh[l], wt, nullptr, n_rows, e.rows_cap[l], n_out, 2 * d, 0, t->da);
+    rc = gigl_linear(ctx, e.dh[l], wt, nullptr, n_rows, e.rows_cap[l], n_out, 2 * d, 0, da);
     if (rc != GIGL_OK) return rc;
     if (t->bwd_gather)
-      rc = gigl_gather_mean_backward_lists(ctx, t->da, d, p->un.rowptr, p->un.rowend, n_rows,
+      rc = gigl_gather_mean_backward_lists(ctx, da, d, p->un.rowptr, p->un.rowend, n_rows,
                                            p->un.meta + GIGL_META_LEVEL0 + (L - l), e.rows_cap[l - 1],
                                            t->work[t->cur_layers_ws].tlists[which][l], GIGL_AGGR_MEAN, e.dh[l - 1]);
     else
-      rc = gigl_gather_mean_backward(ctx, t->da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, e.rows_cap[l], e.dh[l - 1]);
+      rc = gigl_gather_mean_backward(ctx, da, d, p->un.rowptr, p->un.rowend, p->un.col, n_rows, e.rows_cap[l], e.dh[l - 1]);
     if (rc != GIGL_OK) return rc;
   }
   return GIGL_OK;
@@ -2144,9 +2152,17 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)t->w[l],
                        t->dims[l + 1], 2 * t->dims[l], t->wt_l[l]);
   }
+  if (t->fork) {
+    GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_fork[0], st));
+    GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(t->actx->stream, t->ev_fork[0], 0));
+  }
   for (int k = 0; k < 2; ++k) {
     rc = t->kind == 1 ? gat_lp_forward(t, k) : lp_forward(t, k);
     if (rc != GIGL_OK) return rc;
+  }
+  if (t->fork) {
+    GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_join[0], t->actx->stream));
+    GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, t->ev_join[0], 0));
   }
   const gigl_sage_plan *pm = t->enc[0].base, *pr = t->enc[1].base;
   hipLaunchKernelGGL(lp_pack_kernel, dim3((unsigned)((Cn + 3) / 4)), dim3(256), 0, st, (const float*)t->enc[0].emb,
@@ -2181,9 +2197,17 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
                        (const int32_t*)e.base->un.root_local, k, t->b, t->P, t->n_rn, d, t->normalize, e.dh[L - 1]);
   }
   GIGL_HIP_CHECK(ctx, hipGetLastError());
+  if (t->fork) {
+    GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_fork[1], st));
+    GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(t->actx->stream, t->ev_fork[1], 0));
+  }
   for (int k = 0; k < 2; ++k) {
     rc = t->kind == 1 ? gat_lp_backward(t, k) : lp_backward(t, k);
     if (rc != GIGL_OK) return rc;
+  }
+  if (t->fork) {
+    GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_join[1], t->actx->stream));
+    GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, t->ev_join[1], 0));
   }
   if (t->kind == 1) return gat_lp_finish(t);
   AdamPack2 ap{};
@@ -2249,9 +2273,15 @@ int32_t gigl_nablp_train_plan_destroy(gigl_nablp_train_plan* t) {
       if (wk.base[k]) gigl_sage_plan_destroy(wk.base[k]);
   }
   if (t->ev_now) hipEventDestroy(t->ev_now);
+  if (t->actx) hipStreamSynchronize(t->actx->stream);
+  for (int i = 0; i < 2; ++i) {
+    if (t->ev_fork[i]) hipEventDestroy(t->ev_fork[i]);
+    if (t->ev_join[i]) hipEventDestroy(t->ev_join[i]);
+  }
   for (void* q : t->owned) hipFree(q);
   for (auto& wk : t->work)
     if (wk.side) gigl_ctx_destroy(wk.side);
+  if (t->actx) gigl_ctx_destroy(t->actx);
   if (t->lctx) {
     gigl_ctx_set_stream(t->lctx, nullptr);  // (the stream is the caller's)
     gigl_ctx_destroy(t->lctx);
@@ -2406,6 +2436,15 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
     }
     if (l >= 1) t->wt_l[l] = (float*)alloc((size_t)n_out * k2 * 4);
     ok = ok && (l == 0 || t->wt_l[l]);
+  }
+  const char* fork_env = getenv("GIGL_LP_FORK");  // (default on; GIGL_LP_FORK=0 keeps both encodes on the caller's stream: A/B)
+  if (ok && t->fused_small && t->n_rn > 0 && !(fork_env && fork_env[0] == '0')) {
+    t->da2 = (float*)alloc(da_floats * 4);
+    ok = t->da2 != nullptr && gigl_ctx_create(ctx->device, &t->actx) == GIGL_OK;
+    for (int i = 0; i < 2 && ok; ++i)
+      ok = hipEventCreateWithFlags(&t->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&t->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    t->fork = ok;
   }
   if (ok) {
     const int32_t c[16] = {(int32_t)Q, (int32_t)Cn, 0 /* Adam's step counter */, 0};

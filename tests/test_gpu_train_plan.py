@@ -81,8 +81,9 @@ def test_library_training_step_equals_the_autograd_step(setup, dims, fan, b, pre
     eng.bind_stream(torch.cuda.current_stream(eng.device))
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
     # trained state: Adam's moments everywhere, the parameters where the gradients (not their rounding) decide the direction
+    # (tol_p: 1.1e-5 seen once in ~15 runs at 1e-5 — the autograd side sums its gradients with float atomics)
     assert_adam_state("node-classification plan vs autograd", lib.state_dict(), moments, ref.state_dict(), ref_moments,
-                      tol_m=2e-5, tol_v=2e-5, tol_p=1e-5)
+                      tol_m=2e-5, tol_v=2e-5, tol_p=2e-5)
 
 
 @pytest.mark.gpu
