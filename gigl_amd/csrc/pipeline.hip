@@ -1697,6 +1697,13 @@ struct gigl_nablp_train_plan {
     float* wt1 = nullptr;
     float* wt0[4] = {nullptr};
     bool parts_pending = false;  // the gradient buffers do not hold the partial sums yet (gigl_gat_nablp_train_plan_grads adds them)
+    // (fork: the random negatives' encode on a stream of its own) its OWN scratch and accumulators — sized by its rows —
+    // so that nothing is shared with the main batch's encode while both run; folded together after the join
+    struct Alt {
+      float *alpha = nullptr, *dxw = nullptr, *ds = nullptr, *dd = nullptr, *dh0 = nullptr, *dh0s = nullptr, *dz = nullptr,
+            *edge_scratch = nullptr, *du = nullptr;
+      float* g[8] = {nullptr};
+    } x;
   } gat;
   std::vector<void*> owned;
   // Two workspaces of trees + union graphs (as gigl_sage_train_plan): the graph part of the NEXT step's roots (sample +
@@ -2543,6 +2550,9 @@ int32_t gigl_nablp_train_plan_step(gigl_nablp_train_plan* t, const uint32_t* mai
 const float* gigl_nablp_train_plan_loss(gigl_nablp_train_plan* t) { return t ? t->loss : nullptr; }
 
 namespace {
+__global__ __launch_bounds__(256) void lp_acc_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] += src[i];
+}
 __global__ __launch_bounds__(256) void lp_add2_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
                                                       float* __restrict__ out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
@@ -2773,9 +2783,11 @@ int32_t gat_lp_begin(gigl_nablp_train_plan* t) {
 int32_t gat_lp_forward(gigl_nablp_train_plan* t, int which) {
   gigl_nablp_train_plan::Enc& e = t->enc[which];
   gigl_sage_plan* p = e.base;
-  gigl_ctx* ctx = t->lctx;
+  const bool alt = which == 1 && t->fork;
+  gigl_ctx* ctx = alt ? t->actx : t->lctx;
   hipStream_t st = ctx->stream;
   auto& g = t->gat;
+  float* alpha = alt ? g.x.alpha : g.alpha;
   const int H = g.heads, C0 = g.c0, C1 = g.c1, d = g.d_in;
   const int64_t rows1 = gat_rows1(t, which);
   const int32_t* n0 = p->un.meta + GIGL_META_LEVEL0;
@@ -2789,7 +2801,7 @@ int32_t gat_lp_forward(gigl_nablp_train_plan* t, int which) {
   rc = gigl_linear(ctx, e.h[0], g.w[1], nullptr, n1, rows1, H * C0, C1, 0, g.xw[which]);
   if (rc != GIGL_OK) return rc;
   rc = gigl_gat_aggregate(ctx, g.xw[which], g.att_src[1], g.att_dst[1], 1, C1, g.slope, 1, p->un.rowptr, p->un.rowend,
-                          p->un.col, n1, rows1, n0, e.rows_cap[1], nullptr, 0, g.alpha, g.out_pre[which]);
+                          p->un.col, n1, rows1, n0, e.rows_cap[1], nullptr, 0, alpha, g.out_pre[which]);
   if (rc != GIGL_OK) return rc;
   {
     int64_t blocks = (e.rows_cap[1] * C1 + 255) / 256;
@@ -2806,47 +2818,52 @@ int32_t gat_lp_forward(gigl_nablp_train_plan* t, int which) {
 int32_t gat_lp_backward(gigl_nablp_train_plan* t, int which) {
   gigl_nablp_train_plan::Enc& e = t->enc[which];
   gigl_sage_plan* p = e.base;
-  gigl_ctx* ctx = t->lctx;
+  const bool alt = which == 1 && t->fork;
+  gigl_ctx* ctx = alt ? t->actx : t->lctx;
   hipStream_t st = ctx->stream;
   auto& g = t->gat;
+  float *s_alpha = alt ? g.x.alpha : g.alpha, *s_dxw = alt ? g.x.dxw : g.dxw, *s_ds = alt ? g.x.ds : g.ds,
+        *s_dd = alt ? g.x.dd : g.dd, *s_dh0 = alt ? g.x.dh0 : g.dh0, *s_dh0s = alt ? g.x.dh0s : g.dh0s,
+        *s_dz = alt ? g.x.dz : g.dz, *s_edge = alt ? g.x.edge_scratch : g.edge_scratch, *s_du = alt ? g.x.du : g.du;
+  float* const* gg = alt ? g.x.g : g.g;
   const int H = g.heads, C0 = g.c0, C1 = g.c1, d = g.d_in, HC = H * C0;
   const int64_t rows1 = gat_rows1(t, which);
   const int32_t* n0 = p->un.meta + GIGL_META_LEVEL0;
   const int32_t* n1 = p->un.meta + GIGL_META_LEVEL0 + 1;
-  float *gw0 = g.g[0], *gas0 = g.g[1], *gad0 = g.g[2], *gb0 = g.g[3], *gw1 = g.g[4], *gas1 = g.g[5], *gad1 = g.g[6], *gb1 = g.g[7];
+  float *gw0 = gg[0], *gas0 = gg[1], *gad0 = gg[2], *gb0 = gg[3], *gw1 = gg[4], *gas1 = gg[5], *gad1 = gg[6], *gb1 = gg[7];
   (void)gas0;
   (void)gad0;
   // ---- second layer (the roots' rows): e.dh[1] = d loss / d (out before the bias)
   if (g.bias[1])
     hipLaunchKernelGGL(gat_bias_grad_kernel, dim3((unsigned)((e.rows_cap[1] + 7) / 8)), dim3(256), 0, st, (const float*)e.dh[1],
                        n0, C1, gb1);
-  gigl_fill_u32(st, g.dxw, 0u, rows1 * C1);
-  gigl_fill_u32(st, g.ds, 0u, g.dd - g.ds + rows1);  // (ds | dd: dd starts where the larger encode's ds ends)
+  gigl_fill_u32(st, s_dxw, 0u, rows1 * C1);
+  gigl_fill_u32(st, s_ds, 0u, s_dd - s_ds + rows1);  // (ds | dd: dd starts where the larger encode's ds ends)
   int32_t rc = gigl_gat_aggregate_backward(ctx, g.xw[which], g.att_src[1], g.att_dst[1], 1, C1, g.slope, p->un.rowptr,
                                            p->un.rowend, p->un.col, n1, rows1, n0, e.rows_cap[1], g.out_pre[which], e.dh[1],
-                                           nullptr, 0, p->un.cap_edges, nullptr, g.alpha, g.dxw, g.ds, g.dd, nullptr, nullptr,
+                                           nullptr, 0, p->un.cap_edges, nullptr, s_alpha, s_dxw, s_ds, s_dd, nullptr, nullptr,
                                            nullptr);
   if (rc != GIGL_OK) return rc;
-  rc = gigl_gat_backward_epilogue(ctx, g.dxw, g.ds, g.dd, g.xw[which], g.att_src[1], g.att_dst[1], n1, rows1, 1, C1, gas1, gad1);
+  rc = gigl_gat_backward_epilogue(ctx, s_dxw, s_ds, s_dd, g.xw[which], g.att_src[1], g.att_dst[1], n1, rows1, 1, C1, gas1, gad1);
   if (rc != GIGL_OK) return rc;
-  if (g.fused) rc = gigl_linear_weight_grad_parts(ctx, g.dxw, e.h[0], nullptr, n1, rows1, C1, HC, g.part_w1[which], nullptr);
-  else rc = gigl_linear_weight_grad(ctx, g.dxw, e.h[0], nullptr, n1, rows1, C1, HC, gw1, nullptr);
+  if (g.fused) rc = gigl_linear_weight_grad_parts(ctx, s_dxw, e.h[0], nullptr, n1, rows1, C1, HC, g.part_w1[which], nullptr);
+  else rc = gigl_linear_weight_grad(ctx, s_dxw, e.h[0], nullptr, n1, rows1, C1, HC, gw1, nullptr);
   if (rc != GIGL_OK) return rc;
   if (!g.fused) {
     int64_t blocks = ((int64_t)C1 * HC + 255) / 256;
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)g.w[1], C1, HC, t->wt);
   }
-  rc = gigl_linear(ctx, g.dxw, g.fused ? g.wt1 : t->wt, nullptr, n1, rows1, C1, HC, 0, g.dh0);
+  rc = gigl_linear(ctx, s_dxw, g.fused ? g.wt1 : t->wt, nullptr, n1, rows1, C1, HC, 0, s_dh0);
   if (rc != GIGL_OK) return rc;
   // ---- first layer: relu mask, the heads' slices, their projections' backward, the attention-weighted sums' backward
   {
     int64_t blocks = (rows1 * HC + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gat_split_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)g.dh0, (const float*)e.h[0],
-                       n1, rows1, H, C0, g.dh0s);
+    hipLaunchKernelGGL(gat_split_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)s_dh0, (const float*)e.h[0],
+                       n1, rows1, H, C0, s_dh0s);
   }
   for (int h = 0; h < H; ++h) {
-    const float* dyh = g.dh0s + (int64_t)h * rows1 * C0;
+    const float* dyh = s_dh0s + (int64_t)h * rows1 * C0;
     if (g.fused)
       rc = gigl_linear_weight_grad_parts(ctx, dyh, g.z[which] + (int64_t)h * rows1 * d, nullptr, n1, rows1, C0, d,
                                          g.part_w0[which][h], g.bias[0] ? g.part_b0[which][h] : nullptr);
@@ -2859,11 +2876,11 @@ int32_t gat_lp_backward(gigl_nablp_train_plan* t, int which) {
       hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)(g.w[0] + (int64_t)h * C0 * d),
                          C0, d, t->wt);
     }
-    rc = gigl_linear(ctx, dyh, g.fused ? g.wt0[h] : t->wt, nullptr, n1, rows1, C0, d, 0, g.dz + (int64_t)h * rows1 * d);
+    rc = gigl_linear(ctx, dyh, g.fused ? g.wt0[h] : t->wt, nullptr, n1, rows1, C0, d, 0, s_dz + (int64_t)h * rows1 * d);
     if (rc != GIGL_OK) return rc;
   }
   rc = gigl_gat_input_aggregate_backward(ctx, p->feat->rows, p->feat->dtype, d, p->un.nodes, g.u, H, g.slope, p->un.rowptr,
-                                         p->un.rowend, p->un.col, n1, rows1, g.dz, g.edge_scratch, g.du);
+                                         p->un.rowend, p->un.col, n1, rows1, s_dz, s_edge, s_du);
   GIGL_HIP_CHECK(ctx, hipGetLastError());
   return rc;
 }
@@ -2873,6 +2890,8 @@ int32_t gat_lp_finish(gigl_nablp_train_plan* t) {
   gigl_ctx* ctx = t->lctx;
   hipStream_t st = ctx->stream;
   auto& g = t->gat;
+  if (t->fork)  // the random negatives' share of d u, accumulated on its own stream
+    hipLaunchKernelGGL(lp_acc_kernel, dim3(64), dim3(256), 0, st, g.du, (const float*)g.x.du, (int64_t)2 * g.heads * g.d_in);
   hipLaunchKernelGGL(gat_fold_backward_kernel, dim3((unsigned)(g.heads * g.c0)), dim3(256), 0, st, (const float*)g.w[0],
                      (const float*)g.att_src[0], (const float*)g.att_dst[0], (const float*)g.du, g.heads, g.c0, g.d_in, g.g[0],
                      g.g[1], g.g[2]);
@@ -2881,10 +2900,10 @@ int32_t gat_lp_finish(gigl_nablp_train_plan* t) {
   const int32_t* n1a = t->enc[0].base->un.meta + GIGL_META_LEVEL0 + 1;
   const int32_t* n1b = t->enc[1].base->un.meta + GIGL_META_LEVEL0 + 1;
   auto add = [&](float* prm, const float* grad, float* m, float* v, int64_t n, const float* pa, const float* pb, int32_t rca,
-                 int32_t rcb) {
+                 int32_t rcb, const float* grad2 = nullptr) {
     ap.p[ap.count] = prm;
     ap.g1[ap.count] = grad;
-    ap.g2[ap.count] = nullptr;
+    ap.g2[ap.count] = grad2;
     ap.part1[ap.count] = pa;
     ap.part2[ap.count] = pb;
     ap.rows1[ap.count] = n1a;
@@ -2904,8 +2923,9 @@ int32_t gat_lp_finish(gigl_nablp_train_plan* t) {
             i == 0 ? g.part_w0[0][h] : g.part_b0[0][h], i == 0 ? g.part_w0[1][h] : g.part_b0[1][h], g.rc_w0[0], g.rc_w0[1]);
     } else if (g.fused && i == 4) {
       add(params[i], g.g[i], g.mom[2 * i], g.mom[2 * i + 1], g.n[i], g.part_w1[0], g.part_w1[1], g.rc_w1[0], g.rc_w1[1]);
-    } else {
-      add(params[i], g.g[i], g.mom[2 * i], g.mom[2 * i + 1], g.n[i], nullptr, nullptr, 0, 0);
+    } else {  // (fork: the second layer's attention vectors and bias were accumulated per encode)
+      add(params[i], g.g[i], g.mom[2 * i], g.mom[2 * i + 1], g.n[i], nullptr, nullptr, 0, 0,
+          t->fork && i >= 5 ? g.x.g[i] : nullptr);
     }
   }
 
@@ -3013,6 +3033,10 @@ int32_t gigl_gat_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_
     g.n[i] = n_par[i];
     zero_floats += (size_t)n_par[i];
   }
+  // (default on; GIGL_LP_FORK=0 keeps both encodes on the caller's stream: A/B; needs the partial-sum mode)
+  const char* fork_env = getenv("GIGL_LP_FORK");
+  const bool want_fork = n_random_negatives > 0 && getenv("GIGL_TRAIN_PLAN_UNFUSED") == nullptr && !(fork_env && fork_env[0] == '0');
+  if (want_fork) zero_floats += (size_t)2 * H * d + (size_t)(n_par[5] + n_par[6] + n_par[7]);  // the second encode's du, att / bias sums
   int64_t rows1_max = 0;
   for (int k = 0; k < 2; ++k) {
     gigl_nablp_train_plan::Enc& e = t->enc[k];
@@ -3043,6 +3067,14 @@ int32_t gigl_gat_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_
       t->enc[k].dh[1] = z;
       z += (size_t)t->enc[k].b * C1;
     }
+    if (want_fork) {
+      g.x.du = z;
+      z += (size_t)2 * H * d;
+      for (int i = 5; i < 8; ++i) {
+        g.x.g[i] = z;
+        z += n_par[i];
+      }
+    }
   }
   for (int i = 0; i < 8 && ok; ++i)
     for (int j = 0; j < 2; ++j) {
@@ -3063,6 +3095,23 @@ int32_t gigl_gat_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_
   t->wt = (float*)alloc(wt_floats * 4);
   ok = ok && t->zero_base && g.u && g.dxw && g.ds && g.alpha && g.dh0 && g.dh0s && g.dz && g.edge_scratch && t->wt;
   g.fused = getenv("GIGL_TRAIN_PLAN_UNFUSED") == nullptr;
+  if (want_fork && ok) {  // the second encode's own scratch (its rows, its edges), a ctx with a stream of its own, the events
+    const int64_t r1 = t->enc[1].rows_cap[0], ce1 = t->work[0].base[1]->un.cap_edges;
+    g.x.dxw = (float*)alloc((size_t)r1 * C1 * 4);
+    g.x.ds = (float*)alloc((size_t)2 * r1 * 4);
+    g.x.dd = g.x.ds ? g.x.ds + r1 : nullptr;
+    g.x.alpha = (float*)alloc((size_t)(2 * r1 + ce1) * 4);
+    g.x.dh0 = (float*)alloc((size_t)r1 * H * C0 * 4);
+    g.x.dh0s = (float*)alloc((size_t)r1 * H * C0 * 4);
+    g.x.dz = (float*)alloc((size_t)H * r1 * d * 4);
+    g.x.edge_scratch = (float*)alloc((size_t)2 * H * ce1 * 4);
+    ok = g.x.dxw && g.x.ds && g.x.alpha && g.x.dh0 && g.x.dh0s && g.x.dz && g.x.edge_scratch && g.x.du &&
+         gigl_ctx_create(ctx->device, &t->actx) == GIGL_OK;
+    for (int i = 0; i < 2 && ok; ++i)
+      ok = hipEventCreateWithFlags(&t->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&t->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    t->fork = ok;
+  }
   if (g.fused && ok) {
     g.wt1 = (float*)alloc((size_t)C1 * H * C0 * 4);
     ok = g.wt1 != nullptr;
@@ -3137,6 +3186,8 @@ int32_t gigl_gat_nablp_train_plan_grads(gigl_nablp_train_plan* t, int32_t layer,
     const int j = 4 * layer + i;
     if (!dst[i] || !t->gat.n[j]) continue;
     GIGL_HIP_CHECK(ctx, hipMemcpyAsync(dst[i], t->gat.g[j], (size_t)t->gat.n[j] * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (t->fork && j >= 5)  // (the second encode's share, accumulated on its own stream)
+      hipLaunchKernelGGL(lp_acc_kernel, dim3(4), dim3(256), 0, ctx->stream, dst[i], (const float*)t->gat.x.g[j], t->gat.n[j]);
   }
   return GIGL_OK;
 }

@@ -211,7 +211,9 @@ def test_trainer_in_hbm_route_matches_the_tfrecord_route(workdir, tmp_path, enco
     np.testing.assert_allclose(m_h["loss"], m_t["loss"], rtol=tol * 5, atol=1e-6)
     if encoder is None:
         for k in m_t:
-            np.testing.assert_allclose(m_h[k], m_t[k], rtol=1e-4, atol=1e-6)
+            # (the rank metrics move in steps of 1 / (evaluated pairs): one near-tie of the ~300 flipping between the routes —
+            # seen once in ~25 sessions, the trained parameters above agreeing at 1e-3 — is 3.5e-3)
+            np.testing.assert_allclose(m_h[k], m_t[k], rtol=1e-4, atol=1e-6 if k == "loss" else 8e-3)
 
 
 def test_in_hbm_link_prediction_batches_equal_the_collated_records(workdir, tmp_path):
