@@ -4823,7 +4823,12 @@ static int wgrad_rows_per_chunk(int64_t m_cap, int32_t n, int32_t k) {
   // ... and hundreds of thousands of rows (a whole batch graph under a wide table: the GAT layers' backward) coarser, so
   // that the partial sums stay a few tens of MB instead of a copy of dW per 256 rows
   const int64_t tiles = (int64_t)((n + 63) / 64) * ((k + 63) / 64);
-  while (rcw < 8192 && ((m_cap + rcw - 1) / rcw) * tiles > 8192) rcw <<= 1;
+  static const int64_t max_wgs = [] {  // (tuning knob: workgroups — chunks x tiles — the split aims to stay under)
+    const char* e = getenv("GIGL_WGRAD_MAX_WGS");
+    const int64_t v = e ? atoll(e) : 4096;  // (round 6: 8192 before; gat-lp --train 1.75 -> 1.73 ms, the other plans unchanged)
+    return v < 256 ? (int64_t)256 : v;
+  }();
+  while (rcw < 8192 && ((m_cap + rcw - 1) / rcw) * tiles > max_wgs) rcw <<= 1;
   return rcw;
 }
 
