@@ -1721,7 +1721,7 @@ struct gigl_nablp_train_plan {
     bool fetched = false;
   } work[WS];
   hipEvent_t ev_now = nullptr;  // "the caller's stream, now": the roots a graph part copies were written before it
-  // (round 6, SAGE encoder; GIGL_LP_FORK=0 turns it off) the random negatives' encode — ~15 launches of a 512-root batch, all latency — runs
+  // (round 6; opt-in: GIGL_LP_FORK=1) the random negatives' encode — ~15 launches of a 512-root batch, all latency — runs
   // on a stream of its own beside the main batch's, forward and backward: forked after the step's shared preparation, joined
   // before the scores, forked again after the loss's backward, joined before Adam.  Its only shared scratch is `da`.
   gigl_ctx* actx = nullptr;
@@ -2444,8 +2444,11 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
     if (l >= 1) t->wt_l[l] = (float*)alloc((size_t)n_out * k2 * 4);
     ok = ok && (l == 0 || t->wt_l[l]);
   }
-  const char* fork_env = getenv("GIGL_LP_FORK");  // (default on; GIGL_LP_FORK=0 keeps both encodes on the caller's stream: A/B)
-  if (ok && t->fused_small && t->n_rn > 0 && !(fork_env && fork_env[0] == '0')) {
+  // (OPT-IN, GIGL_LP_FORK=1: measured 1.18 -> 1.08 ms per step and bit-identical results, but ONE run of the whole GPU suite
+  // with it on by default died with a segmentation fault inside a step of this plan — 80 runs of the same tests in smaller
+  // sessions did not — so the captured step keeps its single stream unless asked)
+  const char* fork_env = getenv("GIGL_LP_FORK");
+  if (ok && t->fused_small && t->n_rn > 0 && fork_env && fork_env[0] == '1') {
     t->da2 = (float*)alloc(da_floats * 4);
     ok = t->da2 != nullptr && gigl_ctx_create(ctx->device, &t->actx) == GIGL_OK;
     for (int i = 0; i < 2 && ok; ++i)
@@ -3033,9 +3036,9 @@ int32_t gigl_gat_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_
     g.n[i] = n_par[i];
     zero_floats += (size_t)n_par[i];
   }
-  // (default on; GIGL_LP_FORK=0 keeps both encodes on the caller's stream: A/B; needs the partial-sum mode)
+  // (opt-in, GIGL_LP_FORK=1, as the GraphSAGE plan and for the same reason; needs the partial-sum mode)
   const char* fork_env = getenv("GIGL_LP_FORK");
-  const bool want_fork = n_random_negatives > 0 && getenv("GIGL_TRAIN_PLAN_UNFUSED") == nullptr && !(fork_env && fork_env[0] == '0');
+  const bool want_fork = n_random_negatives > 0 && getenv("GIGL_TRAIN_PLAN_UNFUSED") == nullptr && fork_env && fork_env[0] == '1';
   if (want_fork) zero_floats += (size_t)2 * H * d + (size_t)(n_par[5] + n_par[6] + n_par[7]);  // the second encode's du, att / bias sums
   int64_t rows1_max = 0;
   for (int k = 0; k < 2; ++k) {
