@@ -1721,7 +1721,7 @@ struct gigl_nablp_train_plan {
     bool fetched = false;
   } work[WS];
   hipEvent_t ev_now = nullptr;  // "the caller's stream, now": the roots a graph part copies were written before it
-  // (round 6; opt-in: GIGL_LP_FORK=1) the random negatives' encode — ~15 launches of a 512-root batch, all latency — runs
+  // (round 6; GIGL_LP_FORK=0 turns it off) the random negatives' encode — ~15 launches of a 512-root batch, all latency — runs
   // on a stream of its own beside the main batch's, forward and backward: forked after the step's shared preparation, joined
   // before the scores, forked again after the loss's backward, joined before Adam.  Its only shared scratch is `da`.
   gigl_ctx* actx = nullptr;
@@ -2444,11 +2444,11 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
     if (l >= 1) t->wt_l[l] = (float*)alloc((size_t)n_out * k2 * 4);
     ok = ok && (l == 0 || t->wt_l[l]);
   }
-  // (OPT-IN, GIGL_LP_FORK=1: measured 1.18 -> 1.08 ms per step and bit-identical results, but ONE run of the whole GPU suite
-  // with it on by default died with a segmentation fault inside a step of this plan — 80 runs of the same tests in smaller
-  // sessions did not — so the captured step keeps its single stream unless asked)
+  // (default on, GIGL_LP_FORK=0 off: 1.18 -> 1.07 ms per step, bit-identical results.  The forked step's layers part is
+  // launched EAGERLY, not replayed: captured, the two-branch graph brought the whole GPU suite down with a segmentation fault
+  // inside a step — ~400 tests into the session, three runs of three — and never in six runs once it was launched eagerly)
   const char* fork_env = getenv("GIGL_LP_FORK");
-  if (ok && t->fused_small && t->n_rn > 0 && fork_env && fork_env[0] == '1') {
+  if (ok && t->fused_small && t->n_rn > 0 && !(fork_env && fork_env[0] == '0')) {
     t->da2 = (float*)alloc(da_floats * 4);
     ok = t->da2 != nullptr && gigl_ctx_create(ctx->device, &t->actx) == GIGL_OK;
     for (int i = 0; i < 2 && ok; ++i)
@@ -2537,7 +2537,10 @@ int32_t gigl_nablp_train_plan_step2(gigl_nablp_train_plan* t, const uint32_t* ma
   }
   GIGL_HIP_CHECK(ctx, hipMemcpyAsync(t->pos_cnt, pos_cnt, (size_t)t->b * 4, hipMemcpyDeviceToDevice, st));
   GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, wk.ev_graph, 0));
-  rc = train_run_part(t->lctx, &wk.exec_layers, &wk.warm_layers, [&]() { return lp_enqueue_layers(t, w); }, 1);
+  // (a forked step is launched eagerly: as fast as its replay — 1.07 / 1.71 ms both ways — and no graph with a second branch is
+  // ever instantiated; see DESIGN_HISTORY "Round 6" for what those did to a long session)
+  if (t->fork) rc = lp_enqueue_layers(t, w);
+  else rc = train_run_part(t->lctx, &wk.exec_layers, &wk.warm_layers, [&]() { return lp_enqueue_layers(t, w); }, 1);
   if (rc != GIGL_OK) return gigl_fail(ctx, rc, "%s", gigl_last_error(t->lctx));
   GIGL_HIP_CHECK(ctx, hipEventRecord(wk.ev_layers, st));
   if (loss_out) GIGL_HIP_CHECK(ctx, hipMemcpyAsync(loss_out, t->loss, 8, hipMemcpyDeviceToDevice, st));
@@ -3036,9 +3039,9 @@ int32_t gigl_gat_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_
     g.n[i] = n_par[i];
     zero_floats += (size_t)n_par[i];
   }
-  // (opt-in, GIGL_LP_FORK=1, as the GraphSAGE plan and for the same reason; needs the partial-sum mode)
+  // (default on, GIGL_LP_FORK=0 off, as the GraphSAGE plan: the forked step's layers part launched eagerly; needs the partial-sum mode)
   const char* fork_env = getenv("GIGL_LP_FORK");
-  const bool want_fork = n_random_negatives > 0 && getenv("GIGL_TRAIN_PLAN_UNFUSED") == nullptr && fork_env && fork_env[0] == '1';
+  const bool want_fork = n_random_negatives > 0 && getenv("GIGL_TRAIN_PLAN_UNFUSED") == nullptr && !(fork_env && fork_env[0] == '0');
   if (want_fork) zero_floats += (size_t)2 * H * d + (size_t)(n_par[5] + n_par[6] + n_par[7]);  // the second encode's du, att / bias sums
   int64_t rows1_max = 0;
   for (int k = 0; k < 2; ++k) {
