@@ -1728,6 +1728,10 @@ struct gigl_nablp_train_plan {
   float* da2 = nullptr;
   hipEvent_t ev_fork[2] = {nullptr, nullptr}, ev_join[2] = {nullptr, nullptr};
   bool fork = false;
+  // ... and the MAIN batch's weight gradients on a third: nothing in the backward chain waits for them (Adam does), each is a
+  // 40-65 us matrix kernel between the chain's latency-bound ones
+  gigl_ctx* wctx = nullptr;
+  hipEvent_t ev_w = nullptr, ev_wjoin = nullptr;
   int cur = 0;
   int cur_layers_ws = 0;  // the workspace the layers part being enqueued reads
   int32_t cap_seed = 0, cap_mode = -1;
@@ -2087,7 +2091,20 @@ int32_t lp_backward(gigl_nablp_train_plan* t, int which) {
     const int32_t* n_rows = p->un.meta + GIGL_META_LEVEL0 + (L - 1 - l);
     const int d = t->dims[l], n_out = t->dims[l + 1];
     const bool act = l < L - 1 || t->act_last;
-    if (t->fused_small)
+    const bool side_w = which == 0 && t->fork && t->wctx;  // (this gradient on the third stream: see wctx)
+    if (side_w) {
+      // the mask first (the chain needs the masked rows anyway), then the gradient of the MASKED rows beside the chain: the
+      // same products as the masked read of the unmasked rows
+      if (act) {
+        int64_t blocks = (e.rows_cap[l] * n_out + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, e.dh[l], (const float*)e.h[l], n_rows, n_out);
+      }
+      GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_w, st));
+      GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(t->wctx->stream, t->ev_w, 0));
+      rc = gigl_linear_weight_grad_parts(t->wctx, e.dh[l], e.a[l], nullptr, n_rows, e.rows_cap[l], n_out, 2 * d, e.part_w[l],
+                                         t->bias[l] ? e.part_b[l] : nullptr);
+    } else if (t->fused_small)
       rc = gigl_linear_weight_grad_parts(ctx, e.dh[l], e.a[l], act ? e.h[l] : nullptr, n_rows, e.rows_cap[l], n_out, 2 * d,
                                          e.part_w[l], t->bias[l] ? e.part_b[l] : nullptr);
     else
@@ -2095,7 +2112,7 @@ int32_t lp_backward(gigl_nablp_train_plan* t, int which) {
                                    t->bias[l] ? e.gb[l] : nullptr);
     if (rc != GIGL_OK) return rc;
     if (l == 0) break;
-    if (act) {
+    if (act && !side_w) {
       int64_t blocks = (e.rows_cap[l] * n_out + 255) / 256;
       if (blocks > 4096) blocks = 4096;
       hipLaunchKernelGGL(relu_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, e.dh[l], (const float*)e.h[l], n_rows, n_out);
@@ -2215,6 +2232,10 @@ int32_t lp_enqueue_layers(gigl_nablp_train_plan* t, int w) {
   if (t->fork) {
     GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_join[1], t->actx->stream));
     GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, t->ev_join[1], 0));
+    if (t->wctx) {
+      GIGL_HIP_CHECK(ctx, hipEventRecord(t->ev_wjoin, t->wctx->stream));
+      GIGL_HIP_CHECK(ctx, hipStreamWaitEvent(st, t->ev_wjoin, 0));
+    }
   }
   if (t->kind == 1) return gat_lp_finish(t);
   AdamPack2 ap{};
@@ -2281,6 +2302,9 @@ int32_t gigl_nablp_train_plan_destroy(gigl_nablp_train_plan* t) {
   }
   if (t->ev_now) hipEventDestroy(t->ev_now);
   if (t->actx) hipStreamSynchronize(t->actx->stream);
+  if (t->wctx) hipStreamSynchronize(t->wctx->stream);
+  if (t->ev_w) hipEventDestroy(t->ev_w);
+  if (t->ev_wjoin) hipEventDestroy(t->ev_wjoin);
   for (int i = 0; i < 2; ++i) {
     if (t->ev_fork[i]) hipEventDestroy(t->ev_fork[i]);
     if (t->ev_join[i]) hipEventDestroy(t->ev_join[i]);
@@ -2289,6 +2313,7 @@ int32_t gigl_nablp_train_plan_destroy(gigl_nablp_train_plan* t) {
   for (auto& wk : t->work)
     if (wk.side) gigl_ctx_destroy(wk.side);
   if (t->actx) gigl_ctx_destroy(t->actx);
+  if (t->wctx) gigl_ctx_destroy(t->wctx);
   if (t->lctx) {
     gigl_ctx_set_stream(t->lctx, nullptr);  // (the stream is the caller's)
     gigl_ctx_destroy(t->lctx);
@@ -2454,6 +2479,11 @@ int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat
     for (int i = 0; i < 2 && ok; ++i)
       ok = hipEventCreateWithFlags(&t->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&t->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    const char* w_env = getenv("GIGL_LP_WGRAD_STREAM");  // (=0: the main batch's weight gradients stay in its chain)
+    if (ok && t->kind == 0 && !(w_env && w_env[0] == '0'))
+      ok = gigl_ctx_create(ctx->device, &t->wctx) == GIGL_OK &&
+           hipEventCreateWithFlags(&t->ev_w, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&t->ev_wjoin, hipEventDisableTiming) == hipSuccess;
     t->fork = ok;
   }
   if (ok) {
@@ -2852,6 +2882,8 @@ int32_t gat_lp_backward(gigl_nablp_train_plan* t, int which) {
   if (rc != GIGL_OK) return rc;
   rc = gigl_gat_backward_epilogue(ctx, s_dxw, s_ds, s_dd, g.xw[which], g.att_src[1], g.att_dst[1], n1, rows1, 1, C1, gas1, gad1);
   if (rc != GIGL_OK) return rc;
+  // (measured: the main batch's weight gradients on a third stream, as the GraphSAGE plan runs them — 1.75 against 1.71 ms:
+  // these 768-wide ones fill the GPU and slow the chain beside them)
   if (g.fused) rc = gigl_linear_weight_grad_parts(ctx, s_dxw, e.h[0], nullptr, n1, rows1, C1, HC, g.part_w1[which], nullptr);
   else rc = gigl_linear_weight_grad(ctx, s_dxw, e.h[0], nullptr, n1, rows1, C1, HC, gw1, nullptr);
   if (rc != GIGL_OK) return rc;
@@ -3116,6 +3148,11 @@ int32_t gigl_gat_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_
     for (int i = 0; i < 2 && ok; ++i)
       ok = hipEventCreateWithFlags(&t->ev_fork[i], hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&t->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    const char* w_env = getenv("GIGL_LP_WGRAD_STREAM");  // (=0: the main batch's weight gradients stay in its chain)
+    if (ok && t->kind == 0 && !(w_env && w_env[0] == '0'))
+      ok = gigl_ctx_create(ctx->device, &t->wctx) == GIGL_OK &&
+           hipEventCreateWithFlags(&t->ev_w, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&t->ev_wjoin, hipEventDisableTiming) == hipSuccess;
     t->fork = ok;
   }
   if (g.fused && ok) {
