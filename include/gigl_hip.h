@@ -1233,7 +1233,11 @@ int32_t gigl_sage_train_plan_moments(gigl_sage_train_plan* plan, int32_t layer, 
  *   is 0xFFFFFFFF with pos_cnt 0), pos_cnt DEVICE int32 [b_anchors], rn_roots DEVICE uint32 [n_random_negatives]
  *   (0xFFFFFFFF = none).  loss_out (DEVICE float[2], may be NULL) = {loss, query rows that took part};
  *   gigl_nablp_train_plan_loss returns the plan's own words.  A batch that does not fit its workspace trains nothing and
- *   reports a NaN loss.  All work is enqueued on the ctx's stream. */
+ *   reports a NaN loss.  All work is enqueued on the ctx's stream — or, since round 6, on private streams forked from it and
+ *   joined back into it before the step's last launch (the random negatives' encode; the main batch's weight gradients of
+ *   the GraphSAGE encoder): nothing a caller synchronises differently.  Environment, read at plan creation (A/B knobs):
+ *   GIGL_LP_FORK=0 (no private streams), GIGL_LP_WGRAD_STREAM=0 (weight gradients stay in the chain),
+ *   GIGL_TRAIN_PLAN_UNFUSED=1 (a reduce launch per weight gradient instead of partial sums inside the Adam kernel). */
 typedef struct gigl_nablp_train_plan gigl_nablp_train_plan;
 int32_t gigl_nablp_train_plan_create(gigl_ctx* ctx, gigl_graph* graph, gigl_feat* feat, int32_t b_anchors,
                                      int32_t num_positives, int32_t n_random_negatives, const int32_t* fanouts, int32_t hops,
